@@ -1,0 +1,217 @@
+"""Oracle model zoo: sympy statements of the models the parity tests and the benchmark use.
+
+TEST INFRASTRUCTURE ONLY - never imported by the product package.
+
+The reference describes a model symbolically (CasADi SX) and obtains every derivative by AD
+(`hilo_mpc/modules/dynamic_model/dynamic_model.py`); here sympy plays that role, so Jacobians and
+Hessians used by the oracle are *exact symbolic* derivatives, statement-for-statement independent of
+the templated forward-mode AD the HIP kernels use.
+
+Discretisation follows `hilo_mpc/util/modeling.py:1213-1281` (explicit Runge-Kutta: stage
+`k_i = f(x + h*sum_j A[i,j] k_j)`, `x+ = x + h*sum_i b_i k_i`) with the tableaux of
+`modeling.py:1008-1085` and the order->tableau map of `modeling.py:1239-1250`
+(1 forward Euler, 2 midpoint, 3 Kutta, 4 classic).
+"""
+from __future__ import annotations
+
+import numpy as np
+import sympy as sp
+
+# ids shared with include/hilo_hip.h (HILO_MODEL_*)
+MODEL_LINEAR = 0
+MODEL_TOY1D = 1
+MODEL_BIOREACTOR3 = 2
+MODEL_CHEMOSTAT4 = 3
+MODEL_PENDULUM4 = 4
+MODEL_ROBOT6 = 5
+MODEL_CSTR3 = 6
+
+# modeling.py:1008-1085 (only the tableaux reachable through `order`)
+TABLEAUX = {
+    1: dict(A=[[0.]], b=[1.], c=[0.]),
+    2: dict(A=[[0., 0.], [.5, 0.]], b=[0., 1.], c=[0., .5]),
+    3: dict(A=[[0., 0., 0.], [.5, 0., 0.], [-1., 2., 0.]], b=[1 / 6, 2 / 3, 1 / 6], c=[0., .5, 1.]),
+    4: dict(A=[[0., 0., 0., 0.], [.5, 0., 0., 0.], [0., .5, 0., 0.], [0., 0., 1., 0.]],
+            b=[1 / 6, 1 / 3, 1 / 3, 1 / 6], c=[0., .5, .5, 1.]),
+}
+
+
+def _lam(exprs, args):
+    """lambdify a list (or nested list) of scalar expressions into a batched numpy function.
+
+    The returned callable takes arrays shaped [B, n_arg] (or [n_arg]) per argument group and returns
+    an array [B, *shape(exprs)].
+    """
+    exprs = np.array(exprs, dtype=object)
+    shape = exprs.shape
+    flat = [sp.sympify(e) for e in exprs.ravel()]
+    flat_args = [s for grp in args for s in grp]
+    f = sp.lambdify(flat_args, flat, modules='numpy', cse=True)
+
+    def call(*groups):
+        cols = []
+        B = None
+        for g, grp in zip(groups, args):
+            g = np.asarray(g, dtype=float)
+            if g.ndim == 0:
+                g = g.reshape(1)
+            if g.ndim == 1:
+                g = g[None, :]
+            if g.shape[1] != len(grp):
+                raise ValueError(f"argument group has {g.shape[1]} entries, expected {len(grp)}")
+            if g.shape[0] != 1:
+                B = g.shape[0] if B is None else B
+            cols.append(g)
+        B = 1 if B is None else B
+        flat_in = [np.broadcast_to(c[:, i], (B,)) for c in cols for i in range(c.shape[1])]
+        out = f(*flat_in)
+        res = np.empty((B, len(flat)))
+        for i, o in enumerate(out):
+            res[:, i] = np.broadcast_to(np.asarray(o, dtype=float), (B,))
+        return res.reshape((B,) + shape)
+
+    return call
+
+
+class OracleModel:
+    """Symbolic model: x+ = f(x,u,p,dt) (discrete) or dx/dt = f(x,u,p) (continuous); y = h(x,u,p)."""
+
+    def __init__(self, name, model_id, x, u, p, ode, meas=None, discrete=False, dt=None):
+        self.name = name
+        self.model_id = model_id
+        self.x = list(x)
+        self.u = list(u)
+        self.p = list(p)
+        self.dt = dt if dt is not None else sp.Symbol('dt')
+        self.ode = [sp.sympify(e) for e in ode]
+        self.meas = [sp.sympify(e) for e in (meas if meas is not None else [])]
+        self.discrete = discrete
+        self._cache = {}
+
+    nx = property(lambda s: len(s.x))
+    nu = property(lambda s: len(s.u))
+    np_ = property(lambda s: len(s.p))
+    ny = property(lambda s: len(s.meas))
+
+    def discretize(self, order=4):
+        """`Model.discretize('erk'|'rk4', order=...)` (dynamic_model.py:3600-3668 -> modeling.py:1213-1281)."""
+        if self.discrete:
+            return self
+        tab = TABLEAUX[order]
+        A, b = tab['A'], tab['b']
+        h = self.dt
+        X = sp.Matrix(self.x)
+        f = sp.Matrix(self.ode)
+        k = []
+        for i in range(order):
+            ki = sp.zeros(len(self.x), 1)
+            for j in range(i):
+                if A[i][j] != 0:
+                    ki += sp.nsimplify(A[i][j]) * k[j] if False else A[i][j] * k[j]
+            xi = X + h * ki
+            k.append(f.subs(dict(zip(self.x, xi)), simultaneous=True))
+        xn = X
+        for i in range(order):
+            if b[i] != 0:
+                xn = xn + h * b[i] * k[i]
+        return OracleModel(self.name + f'_erk{order}', self.model_id, self.x, self.u, self.p, list(xn),
+                           self.meas, discrete=True, dt=self.dt)
+
+    # ---- numeric callables (batched) -------------------------------------------------------
+    def _get(self, key, builder):
+        if key not in self._cache:
+            self._cache[key] = builder()
+        return self._cache[key]
+
+    def _args(self):
+        return [self.x, self.u, self.p, [self.dt]]
+
+    def f(self, x, u, p, dt):
+        return self._get('f', lambda: _lam(self.ode, self._args()))(x, u, p, dt)
+
+    def fx(self, x, u, p, dt):
+        J = sp.Matrix(self.ode).jacobian(self.x)
+        return self._get('fx', lambda: _lam(J.tolist(), self._args()))(x, u, p, dt)
+
+    def fu(self, x, u, p, dt):
+        J = sp.Matrix(self.ode).jacobian(self.u) if self.nu else sp.zeros(self.nx, 0)
+        if self.nu == 0:
+            return np.zeros((np.atleast_2d(x).shape[0], self.nx, 0))
+        return self._get('fu', lambda: _lam(J.tolist(), self._args()))(x, u, p, dt)
+
+    def h(self, x, u, p, dt):
+        if not self.meas:
+            return np.atleast_2d(np.asarray(x, dtype=float))
+        return self._get('h', lambda: _lam(self.meas, self._args()))(x, u, p, dt)
+
+    def hx(self, x, u, p, dt):
+        if not self.meas:
+            B = np.atleast_2d(x).shape[0]
+            return np.broadcast_to(np.eye(self.nx), (B, self.nx, self.nx)).copy()
+        J = sp.Matrix(self.meas).jacobian(self.x)
+        return self._get('hx', lambda: _lam(J.tolist(), self._args()))(x, u, p, dt)
+
+
+# ---------------------------------------------------------------------------------------------
+# zoo
+# ---------------------------------------------------------------------------------------------
+def linear2_kat():
+    """2-state linear chain of tests/test_KFs.py:247-255 (continuous; the test discretises with ERK-1, dt=1)."""
+    x1, x2, u, k1, k2 = sp.symbols('x_1 x_2 u k_1 k_2')
+    return OracleModel('linear2', MODEL_LINEAR, [x1, x2], [u], [k1, k2],
+                       [-k1 * x1 + u, k1 * x1 - k2 * x2], [x2])
+
+
+def toy1d():
+    """Scalar benchmark of tests/test_KFs.py:548-556: x+ = x/2 + 25 dt x/(1+x^2), y = x^2/20 (discrete)."""
+    x, dt = sp.symbols('x dt')
+    return OracleModel('toy1d', MODEL_TOY1D, [x], [], [], [x / 2 + 25 * dt * x / (1 + x ** 2)], [x ** 2 / 20],
+                       discrete=True, dt=dt)
+
+
+def bioreactor3():
+    """3-state bioreactor of tests/test_KFs.py:691-712; parameters in order of first appearance
+    [alpha, T_amb, mu_0, mu_1, K, Y], input D, measurements (T, cB)."""
+    T, cB, cS, D = sp.symbols('T cB cS D')
+    alpha, T_amb, mu_0, mu_1, K, Y = sp.symbols('alpha T_amb mu_0 mu_1 K Y')
+    r = (mu_0 + mu_1 * T) * cS * cB / (K + cS)
+    return OracleModel('bioreactor3', MODEL_BIOREACTOR3, [T, cB, cS], [D], [alpha, T_amb, mu_0, mu_1, K, Y],
+                       [alpha * (T_amb - T), r - D * cB, -r / Y - D * cS], [T, cB])
+
+
+def chemostat4():
+    """CSTR-sized benchmark model: `ecoli_D1210_conti('simple')`
+    (hilo_mpc/library/models.py:163-198) with the rates mu, Rs, Rfp closed by the formulas of the
+    'complex' variant (models.py:143-148), the inducer factors ISF, IRF held as parameters.
+    States X,S,P,I; inputs DS,DI; parameters Sf,If,ISF,IRF; measurements (X,P)."""
+    X, S, P, I, DS, DI = sp.symbols('X S P I DS DI')
+    Sf, If, ISF, IRF = sp.symbols('Sf If ISF IRF')
+    phi = 0.407 * S / (0.108 + S + S ** 2 / 14814.0)
+    mu = phi * (ISF + 0.22 * IRF / (0.22 + I))
+    Rs = 2 * mu
+    Rfp = phi * (0.0005 + I) / (0.022 + I)
+    D = DS + DI
+    return OracleModel('chemostat4', MODEL_CHEMOSTAT4, [X, S, P, I], [DS, DI], [Sf, If, ISF, IRF],
+                       [mu * X - D * X, -Rs * X - D * S + DS * Sf, Rfp * X - D * P, -D * I + DI * If], [X, P])
+
+
+def pendulum4():
+    """Cart-pendulum of tests/test_NMPC.py:12-43 (states x,v,theta,omega; input F; all states measured)."""
+    x, v, th, om, F = sp.symbols('x v theta omega F')
+    M, m, l, g = 5., 1., 1., 9.81
+    dv = 1. / (M + m - m * sp.cos(th)) * (m * g * sp.sin(th) - m * l * sp.sin(th) * om ** 2 + F)
+    dom = 1. / l * (dv * sp.cos(th) + g * sp.sin(th))
+    return OracleModel('pendulum4', MODEL_PENDULUM4, [x, v, th, om], [F], [], [v, dv, om, dom], [x, v, th, om])
+
+
+ZOO = {
+    'linear2': linear2_kat,
+    'toy1d': toy1d,
+    'bioreactor3': bioreactor3,
+    'chemostat4': chemostat4,
+    'pendulum4': pendulum4,
+}
+
+
+def get(name):
+    return ZOO[name]()
