@@ -1,0 +1,23 @@
+"""hilo_mpc_amd - MI355X-native batched backend for HILO-MPC's solve path.
+
+Host classes mirror the reference API surface for the hot path only:
+`NMPC.setup()/optimize()`, `LMPC`, `MHE.estimate()`, `KF/EKF/UKF.estimate()/predict()/update()`,
+`GaussianProcess.setup()/predict()`, `Kernel`, `Mean` - all with a leading batch axis - on top of the C ABI of
+`libhilo_hip.so` (include/hilo_hip.h).  There is no CPU fallback.
+"""
+from .model import Model
+from .estimator import KalmanFilter, ExtendedKalmanFilter, UnscentedKalmanFilter
+from .gp import GaussianProcess, Kernel, Mean
+
+KF = KalmanFilter
+EKF = ExtendedKalmanFilter
+UKF = UnscentedKalmanFilter
+GP = GaussianProcess
+
+__all__ = ['Model', 'KalmanFilter', 'ExtendedKalmanFilter', 'UnscentedKalmanFilter', 'KF', 'EKF', 'UKF',
+           'GaussianProcess', 'GP', 'Kernel', 'Mean']
+try:                                        # added as the corresponding rows land
+    from .nmpc import NMPC                  # noqa: F401
+    __all__.append('NMPC')
+except ImportError:                         # pragma: no cover
+    pass

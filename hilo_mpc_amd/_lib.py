@@ -1,0 +1,82 @@
+"""ctypes binding of libhilo_hip.so (include/hilo_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or fails to load, importing any compute class raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libhilo_hip.so')
+
+c_double_p = C.c_void_p   # device pointers travel as integers
+c_i64 = C.c_int64
+
+
+class HiloError(RuntimeError):
+    pass
+
+
+class KfDesc(C.Structure):
+    _fields_ = [('model_id', C.c_int32), ('kind', C.c_int32), ('continuous', C.c_int32), ('erk_order', C.c_int32),
+                ('n_sub', C.c_int32), ('lti_nx', C.c_int32), ('lti_nu', C.c_int32), ('lti_ny', C.c_int32),
+                ('dt', C.c_double), ('alpha', C.c_double), ('beta', C.c_double), ('kappa', C.c_double)]
+
+
+_lib = None
+
+
+def _declare(lib):
+    vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    P = C.POINTER
+    sig = {
+        'hilo_abi_version': (C.c_int, []),
+        'hilo_last_error': (C.c_char_p, []),
+        'hilo_device_count': (C.c_int, [P(C.c_int)]),
+        'hilo_model_dims': (C.c_int, [i32, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]),
+        'hilo_malloc': (C.c_int, [P(vp), C.c_uint64, i32]),
+        'hilo_free': (C.c_int, [vp]),
+        'hilo_memcpy_h2d': (C.c_int, [vp, vp, C.c_uint64, vp]),
+        'hilo_memcpy_d2h': (C.c_int, [vp, vp, C.c_uint64, vp]),
+        'hilo_stream_sync': (C.c_int, [vp]),
+        'hilo_kf_create': (C.c_int, [P(KfDesc), i32, P(vp)]),
+        'hilo_kf_destroy': (None, [vp]),
+        'hilo_kf_dims': (C.c_int, [vp, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]),
+        'hilo_kf_predict': (C.c_int, [vp, i64, vp, vp, i64, vp, i64, vp, vp]),
+        'hilo_kf_update': (C.c_int, [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp]),
+        'hilo_kf_step': (C.c_int, [vp, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp]),
+        'hilo_gp_create': (C.c_int, [i32, i32, i32, vp, vp, vp, i32, vp, i32, dbl, P(vp)]),
+        'hilo_gp_destroy': (None, [vp]),
+        'hilo_gp_log_marginal_likelihood': (C.c_int, [vp, P(C.c_double)]),
+        'hilo_gp_predict': (C.c_int, [vp, i64, vp, i32, vp, vp, vp]),
+        'hilo_gp_kernel_matrix': (C.c_int, [i32, i32, vp, i32, i64, vp, i64, vp, vp, vp]),
+        'hilo_gp_mean': (C.c_int, [i32, i32, vp, i32, i64, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        if not hasattr(lib, name):
+            continue                     # symbol coverage is asserted by tests/test_abi.py against the header
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def lib():
+    """The loaded library.  Raises HiloError when it is absent - the product has no other compute path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HiloError(f"{LIB_PATH} not found: build it with `python -m hilo_mpc_amd._build` "
+                            f"(hipcc --offload-arch=gfx950). hilo_mpc_amd has no CPU fallback.")
+        try:
+            _lib = _declare(C.CDLL(LIB_PATH))
+        except OSError as e:
+            raise HiloError(f"cannot load {LIB_PATH}: {e}") from e
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().hilo_last_error().decode(errors='replace')
+        if rc == -1:
+            raise ValueError(msg)
+        raise HiloError(f"libhilo_hip error {rc}: {msg}")

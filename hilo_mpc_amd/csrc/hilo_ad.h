@@ -1,0 +1,141 @@
+// Forward-mode automatic differentiation scalars used by every model-evaluating kernel.
+//
+// The reference obtains all derivatives from CasADi's symbolic AD. On the GPU a model is a
+// C++ functor templated on its scalar type, and derivatives come from instantiating it with
+//   Dual<N>   value + N first-order tangents   (EKF Jacobians F, H; shooting sensitivities A_k, B_k)
+//   Jet2      value + first + second derivative along ONE direction (univariate Taylor, order 2), from which
+//             the Lagrangian-Hessian blocks are recovered by polarisation: H_ij = (q(e_i+e_j) - q(e_i) - q(e_j))/2
+// Everything lives in registers: all loops have compile-time bounds and are fully unrolled.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define HD __host__ __device__ __forceinline__
+
+namespace hilo {
+
+// ------------------------------------------------------------------------------------------------
+// Dual<N>: f, df/ds_1..N
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct Dual {
+  double v;
+  double d[N];
+  HD Dual() {}
+  HD Dual(double c) : v(c) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = 0.0;
+  }
+};
+
+template <int N> HD Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) {
+  Dual<N> r; r.v = a.v + b.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i];
+  return r;
+}
+template <int N> HD Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) {
+  Dual<N> r; r.v = a.v - b.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i];
+  return r;
+}
+template <int N> HD Dual<N> operator-(const Dual<N>& a) {
+  Dual<N> r; r.v = -a.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = -a.d[i];
+  return r;
+}
+template <int N> HD Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) {
+  Dual<N> r; r.v = a.v * b.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+  return r;
+}
+template <int N> HD Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
+  Dual<N> r; const double ib = 1.0 / b.v; r.v = a.v * ib;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+  return r;
+}
+template <int N> HD Dual<N> operator+(const Dual<N>& a, double b) { Dual<N> r = a; r.v += b; return r; }
+template <int N> HD Dual<N> operator+(double b, const Dual<N>& a) { Dual<N> r = a; r.v += b; return r; }
+template <int N> HD Dual<N> operator-(const Dual<N>& a, double b) { Dual<N> r = a; r.v -= b; return r; }
+template <int N> HD Dual<N> operator-(double b, const Dual<N>& a) { Dual<N> r = -a; r.v += b; return r; }
+template <int N> HD Dual<N> operator*(const Dual<N>& a, double b) {
+  Dual<N> r; r.v = a.v * b;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b;
+  return r;
+}
+template <int N> HD Dual<N> operator*(double b, const Dual<N>& a) { return a * b; }
+template <int N> HD Dual<N> operator/(const Dual<N>& a, double b) { return a * (1.0 / b); }
+template <int N> HD Dual<N> operator/(double a, const Dual<N>& b) { return Dual<N>(a) / b; }
+
+template <int N> HD Dual<N> chain(const Dual<N>& a, double f, double df) {
+  Dual<N> r; r.v = f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = df * a.d[i];
+  return r;
+}
+template <int N> HD Dual<N> sin(const Dual<N>& a) { return chain(a, ::sin(a.v), ::cos(a.v)); }
+template <int N> HD Dual<N> cos(const Dual<N>& a) { return chain(a, ::cos(a.v), -::sin(a.v)); }
+template <int N> HD Dual<N> exp(const Dual<N>& a) { const double e = ::exp(a.v); return chain(a, e, e); }
+template <int N> HD Dual<N> log(const Dual<N>& a) { return chain(a, ::log(a.v), 1.0 / a.v); }
+template <int N> HD Dual<N> sqrt(const Dual<N>& a) { const double s = ::sqrt(a.v); return chain(a, s, 0.5 / s); }
+template <int N> HD Dual<N> sq(const Dual<N>& a) { return chain(a, a.v * a.v, 2.0 * a.v); }
+
+// ------------------------------------------------------------------------------------------------
+// Jet2: univariate Taylor coefficients along one direction: f(t) = v + a t + (b/2) t^2 (a = f', b = f'')
+// ------------------------------------------------------------------------------------------------
+struct Jet2 {
+  double v, a, b;
+  HD Jet2() {}
+  HD Jet2(double c) : v(c), a(0.0), b(0.0) {}
+  HD Jet2(double v_, double a_, double b_) : v(v_), a(a_), b(b_) {}
+};
+HD Jet2 operator+(const Jet2& x, const Jet2& y) { return Jet2(x.v + y.v, x.a + y.a, x.b + y.b); }
+HD Jet2 operator-(const Jet2& x, const Jet2& y) { return Jet2(x.v - y.v, x.a - y.a, x.b - y.b); }
+HD Jet2 operator-(const Jet2& x) { return Jet2(-x.v, -x.a, -x.b); }
+HD Jet2 operator*(const Jet2& x, const Jet2& y) {
+  return Jet2(x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + 2.0 * x.a * y.a + x.v * y.b);
+}
+HD Jet2 operator/(const Jet2& x, const Jet2& y) {
+  const double iy = 1.0 / y.v;
+  const double v = x.v * iy;
+  const double a = (x.a - v * y.a) * iy;
+  const double b = (x.b - 2.0 * a * y.a - v * y.b) * iy;
+  return Jet2(v, a, b);
+}
+HD Jet2 operator+(const Jet2& x, double c) { return Jet2(x.v + c, x.a, x.b); }
+HD Jet2 operator+(double c, const Jet2& x) { return Jet2(x.v + c, x.a, x.b); }
+HD Jet2 operator-(const Jet2& x, double c) { return Jet2(x.v - c, x.a, x.b); }
+HD Jet2 operator-(double c, const Jet2& x) { return Jet2(c - x.v, -x.a, -x.b); }
+HD Jet2 operator*(const Jet2& x, double c) { return Jet2(x.v * c, x.a * c, x.b * c); }
+HD Jet2 operator*(double c, const Jet2& x) { return Jet2(x.v * c, x.a * c, x.b * c); }
+HD Jet2 operator/(const Jet2& x, double c) { return x * (1.0 / c); }
+HD Jet2 operator/(double c, const Jet2& y) { return Jet2(c) / y; }
+// g(f): g' f', g'' f'^2 + g' f''
+HD Jet2 chain(const Jet2& x, double g, double g1, double g2) {
+  return Jet2(g, g1 * x.a, g2 * x.a * x.a + g1 * x.b);
+}
+HD Jet2 sin(const Jet2& x) { const double s = ::sin(x.v), c = ::cos(x.v); return chain(x, s, c, -s); }
+HD Jet2 cos(const Jet2& x) { const double s = ::sin(x.v), c = ::cos(x.v); return chain(x, c, -s, -c); }
+HD Jet2 exp(const Jet2& x) { const double e = ::exp(x.v); return chain(x, e, e, e); }
+HD Jet2 log(const Jet2& x) { const double i = 1.0 / x.v; return chain(x, ::log(x.v), i, -i * i); }
+HD Jet2 sqrt(const Jet2& x) { const double s = ::sqrt(x.v); return chain(x, s, 0.5 / s, -0.25 / (s * x.v)); }
+HD Jet2 sq(const Jet2& x) { return chain(x, x.v * x.v, 2.0 * x.v, 2.0); }
+
+// plain doubles take part in the same generic code (explicit overloads: inside this namespace the AD
+// overloads would otherwise hide ::sin etc. and a double would convert silently to Jet2)
+HD double sin(double x) { return ::sin(x); }
+HD double cos(double x) { return ::cos(x); }
+HD double exp(double x) { return ::exp(x); }
+HD double log(double x) { return ::log(x); }
+HD double sqrt(double x) { return ::sqrt(x); }
+HD double sq(double x) { return x * x; }
+HD double value(double x) { return x; }
+template <int N> HD double value(const Dual<N>& x) { return x.v; }
+HD double value(const Jet2& x) { return x.v; }
+
+}  // namespace hilo

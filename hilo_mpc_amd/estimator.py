@@ -1,0 +1,325 @@
+"""Batched Kalman / extended / unscented Kalman filters on the GPU.
+
+API mirror of `hilo_mpc/modules/estimator/kf.py` (+ `_Estimator`, estimator/base.py) with a leading batch axis:
+`setup()`, `Q`/`R` setters (scalar / vector -> diagonal, base.py:105-125), `set_initial_guess(x0, P0)` (P0
+defaults to the identity, base.py:133-134), `set_initial_parameter_values(p)`, `estimate(y=, u=, p=)` (predict
+then update, kf.py:258-265), and the pass-throughs `predict(xP, up, Q)` / `update(pred, y, up, R)` on packed
+`[x|P]` tiles (kf.py:309-325).  All arithmetic runs in libhilo_hip.so (hilo_kf_*); nothing is computed on the host.
+"""
+import ctypes as C
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._device import device, to_dev, ptr, stream_ptr, like_input
+
+KIND = {'Kalman filter': 0, 'extended Kalman filter': 1, 'unscented Kalman filter': 2}
+
+
+class _Solution:
+    """Minimal stand-in for the reference's TimeSeries key language used with filters
+    (`get_by_id('x:f')`, `['x:f']`, base.py:2206-2211,2426-2470): last state, covariance and output."""
+
+    def __init__(self):
+        self._d = {}
+
+    def _set(self, **kw):
+        self._d.update(kw)
+
+    def get_by_id(self, key):
+        name = key.split(':')[0]
+        if name not in self._d:
+            raise KeyError(key)
+        return self._d[name]
+
+    __getitem__ = get_by_id
+
+
+def _cov(v, n, dev):
+    """base.py:105-125."""
+    if isinstance(v, torch.Tensor):
+        t = v.to(device=dev, dtype=torch.float64)
+        if t.ndim >= 2 and t.shape[-1] == n and t.shape[-2] == n:
+            return t.contiguous()
+        v = t.cpu().numpy()
+    a = np.asarray(v, dtype=float)
+    if a.ndim == 0:
+        a = np.eye(n) * float(a)
+    elif a.ndim == 1:
+        a = np.eye(n) * float(a[0]) if (a.size == 1 and n > 1) else np.diag(a)
+    if a.shape[-2:] != (n, n):
+        raise ValueError(f"Dimension mismatch. Supplied dimension is {a.shape[-2]}x{a.shape[-1]}, but required "
+                         f"dimension is {n}x{n}.")
+    return to_dev(a, dev)
+
+
+class _KalmanFilter:
+    _type = None
+
+    def __init__(self, model, id=None, name=None, plot_backend=None, square_root_form=True, device_index=None,
+                 n_sub=None):
+        self._model = model
+        self.name = name
+        self._alpha, self._beta, self._kappa = 1e-3, 2., 0.
+        self._handle = None
+        self._dev_index = device_index
+        self._n_sub = n_sub
+        self._Q = self._R = None
+        self._x = self._P = self._p = None
+        self.solution = _Solution()
+
+    type = property(lambda self: self._type)
+
+    # ---- set-up ------------------------------------------------------------------------------
+    def setup(self, **kwargs):
+        m = self._model
+        if not m._is_setup:
+            m.setup()
+        self._dev = device(self._dev_index)
+        desc = _lib.KfDesc()
+        desc.model_id = m.model_id
+        desc.kind = KIND[self._type]
+        desc.continuous = 0 if m.discrete else 1          # kf.py:95-98
+        desc.erk_order = m.erk_order if m.erk_order else 4
+        desc.n_sub = self._n_sub if self._n_sub else (m.n_sub if m.discrete else 8)
+        if m.name == 'lti':
+            desc.lti_nx, desc.lti_nu, desc.lti_ny = m.n_x, m.n_u, m.n_y
+        desc.dt = m.dt
+        desc.alpha, desc.beta, desc.kappa = self._alpha, self._beta, self._kappa
+        h = C.c_void_p()
+        _lib.check(_lib.lib().hilo_kf_create(C.byref(desc), self._dev.index, C.byref(h)))
+        if self._handle is not None:
+            _lib.lib().hilo_kf_destroy(self._handle)
+        self._handle = h
+        self._n_x, self._n_u, self._n_p, self._n_y = m.n_x, m.n_u, m.n_p, m.n_y
+        self._pred_w = (2 + 3 * m.n_x) if self._type == 'unscented Kalman filter' else m.n_x + 1
+        self._Q = torch.zeros(m.n_x, m.n_x, dtype=torch.float64, device=self._dev)   # kf.py:276-277
+        self._R = torch.zeros(m.n_y, m.n_y, dtype=torch.float64, device=self._dev)
+        if m.name == 'lti':
+            self._p = to_dev(m.lti_parameters(), self._dev, (1, -1))
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.lib().hilo_kf_destroy(self._handle)
+        except Exception:
+            pass
+
+    def _check_setup(self):
+        if self._handle is None:
+            raise RuntimeError(f"{self._type[0].upper() + self._type[1:]} is not set up. Run "
+                               f"{self.__class__.__name__}.setup() before running simulations.")
+
+    # ---- tuning ------------------------------------------------------------------------------
+    @property
+    def Q(self):
+        return self._Q
+
+    @Q.setter
+    def Q(self, v):
+        self._check_setup()
+        self._Q = _cov(v, self._n_x, self._dev)
+
+    @property
+    def R(self):
+        return self._R
+
+    @R.setter
+    def R(self, v):
+        self._check_setup()
+        self._R = _cov(v, self._n_y, self._dev)
+
+    def set_initial_guess(self, x0, P0=None):
+        """base.py:127-142.  x0: [n_x] or [B, n_x]; P0: scalar / vector / matrix (per batch allowed)."""
+        self._check_setup()
+        x = to_dev(x0, self._dev)
+        x = x.reshape(1, -1) if x.ndim <= 1 else x
+        if x.shape[1] != self._n_x:
+            raise ValueError(f"Dimension mismatch. Supplied dimension is {x.shape[1]}, but required dimension is "
+                             f"{self._n_x}.")
+        B = x.shape[0]
+        P = _cov(1. if P0 is None else P0, self._n_x, self._dev)
+        self._x = x.contiguous()
+        self._P = P.expand(B, -1, -1).contiguous() if P.ndim == 2 else P.contiguous()
+
+    def set_initial_parameter_values(self, p):
+        self._check_setup()
+        p = to_dev(p, self._dev)
+        self._p = p.reshape(1, -1) if p.ndim <= 1 else p
+
+    # ---- packed-tile pass-throughs (kf.py:309-325) ------------------------------------------------
+    def _tile(self, t, width):
+        t = to_dev(t, self._dev)
+        if t.ndim == 2:
+            t = t[None]
+        if t.shape[1:] != (self._n_x, width):
+            raise ValueError(f"expected a packed tile of shape [B, {self._n_x}, {width}], got {tuple(t.shape)}")
+        return t.contiguous()
+
+    def _up(self, up, B):
+        n = self._n_u + self._n_p
+        if n == 0:
+            return None, 0
+        t = to_dev(up, self._dev)
+        t = t.reshape(1, -1) if t.ndim <= 1 else t
+        if t.shape[1] != n:
+            raise ValueError(f"Dimension mismatch in [u; p]: got {t.shape[1]}, the model has {self._n_u} inputs and "
+                             f"{self._n_p} parameters")
+        if t.shape[0] not in (1, B):
+            raise ValueError(f"[u; p] has batch {t.shape[0]}, expected 1 or {B}")
+        return t.contiguous(), (0 if t.shape[0] == 1 else n)
+
+    @staticmethod
+    def _cov_stride(M, B):
+        if M.ndim == 2:
+            return 0
+        if M.shape[0] not in (1, B):
+            raise ValueError(f"covariance batch {M.shape[0]} does not match {B}")
+        return 0 if M.shape[0] == 1 else M.shape[1] * M.shape[2]
+
+    def predict(self, xP, up=None, Q=None):
+        """`prediction_step(x0, p, Q)` (kf.py:129-133; UKF :550-554 returns [x|P|X])."""
+        self._check_setup()
+        t = self._tile(xP, self._n_x + 1)
+        B = t.shape[0]
+        upt, us = self._up(up, B)
+        Qt = self._Q if Q is None else _cov(Q, self._n_x, self._dev)
+        out = torch.empty(B, self._n_x, self._pred_w, dtype=torch.float64, device=self._dev)
+        _lib.check(_lib.lib().hilo_kf_predict(self._handle, B, ptr(t), ptr(upt), us, ptr(Qt),
+                                              self._cov_stride(Qt, B), ptr(out), stream_ptr(self._dev)))
+        return like_input(out if np.ndim(xP) == 3 else out[0], xP)
+
+    def update(self, pred, y, up=None, R=None):
+        """`update_step(x0, y, p, R)` (kf.py:182-186; UKF :600-604).  Returns ([x+|P+], y_pred)."""
+        self._check_setup()
+        t = self._tile(pred, self._pred_w)
+        B = t.shape[0]
+        upt, us = self._up(up, B)
+        Rt = self._R if R is None else _cov(R, self._n_y, self._dev)
+        yt = to_dev(y, self._dev).reshape(-1, self._n_y)
+        if yt.shape[0] != B:
+            raise ValueError(f"Dimension mismatch. Supplied {yt.shape[0]} measurement vectors for a batch of {B}.")
+        out = torch.empty(B, self._n_x, self._n_x + 1, dtype=torch.float64, device=self._dev)
+        yp = torch.empty(B, self._n_y, dtype=torch.float64, device=self._dev)
+        _lib.check(_lib.lib().hilo_kf_update(self._handle, B, ptr(t), ptr(yt.contiguous()), ptr(upt), us, ptr(Rt),
+                                             self._cov_stride(Rt, B), ptr(out), ptr(yp), stream_ptr(self._dev)))
+        if np.ndim(pred) == 3:
+            return like_input(out, pred), like_input(yp, pred)
+        return like_input(out[0], pred), like_input(yp[0].reshape(-1, 1), pred)
+
+    # ---- estimate (kf.py:279-307) ----------------------------------------------------------------
+    def estimate(self, y=None, u=None, p=None, **kwargs):
+        self._check_setup()
+        if self._x is None:
+            raise RuntimeError("No initial guess for the states found. Please set initial guess before running "
+                               "the Kalman filter!")
+        if y is None:
+            raise RuntimeError("No measurement data supplied.")
+        B = self._x.shape[0]
+        yt = to_dev(y, self._dev).reshape(-1, self._n_y)
+        if yt.shape[0] != B:
+            if B == 1:                                   # first call decides the batch size
+                B = yt.shape[0]
+                self._x = self._x.expand(B, -1).contiguous()
+                self._P = self._P.expand(B, -1, -1).contiguous()
+            else:
+                raise ValueError(f"Dimension mismatch. Supplied {yt.shape[0]} measurement vectors for {B} filters.")
+        if p is not None:
+            pt = to_dev(p, self._dev)
+            pt = pt.reshape(1, -1) if pt.ndim <= 1 else pt
+        else:
+            pt = self._p
+        if self._n_p and pt is None:
+            raise RuntimeError("No parameter values supplied. Please run set_initial_parameter_values() or pass p=.")
+        if self._n_u:
+            if u is None:
+                raise RuntimeError("No input data supplied.")
+            ut = to_dev(u, self._dev).reshape(-1, self._n_u)
+        parts = []
+        if self._n_u:
+            parts.append(ut.expand(B, -1) if ut.shape[0] == 1 else ut)
+        if self._n_p:
+            parts.append(pt.expand(B, -1) if pt.shape[0] == 1 else pt)
+        upt = torch.cat(parts, dim=1).contiguous() if parts else None
+        us = 0 if upt is None else upt.shape[1]
+        xP = torch.cat([self._x[:, :, None], self._P], dim=2).contiguous()
+        out = torch.empty_like(xP)
+        yp = torch.empty(B, self._n_y, dtype=torch.float64, device=self._dev)
+        _lib.check(_lib.lib().hilo_kf_step(self._handle, B, ptr(xP), ptr(yt.contiguous()), ptr(upt), us,
+                                           ptr(self._Q), self._cov_stride(self._Q, B), ptr(self._R),
+                                           self._cov_stride(self._R, B), ptr(out), ptr(yp),
+                                           stream_ptr(self._dev)))
+        self._x = out[:, :, 0].contiguous()
+        self._P = out[:, :, 1:].contiguous()
+        host = not isinstance(y, torch.Tensor)
+        cv = (lambda t: t.cpu().numpy()) if host else (lambda t: t)
+        xs = cv(self._x)
+        self.solution._set(x=xs.T if (host and B == 1) else xs, P=cv(self._P), y=cv(yp))
+        return self.solution
+
+    # raw device views of the filter state (zero-copy)
+    @property
+    def x(self):
+        return self._x
+
+    @property
+    def P(self):
+        return self._P
+
+
+class KalmanFilter(_KalmanFilter):
+    """kf.py:328-367."""
+    _type = 'Kalman filter'
+
+    def __init__(self, model, **kw):
+        if not model.is_linear():
+            raise ValueError("The supplied model is nonlinear. Please use an estimator targeted at the estimation of "
+                             "nonlinear systems.")
+        super().__init__(model, **kw)
+
+
+class ExtendedKalmanFilter(_KalmanFilter):
+    """kf.py:370-410."""
+    _type = 'extended Kalman filter'
+
+    def __init__(self, model, **kw):
+        if model.is_linear():
+            warnings.warn("The supplied model is linear. For better efficiency use an observer targeted at the "
+                          "estimation of linear systems.")
+        super().__init__(model, **kw)
+
+
+class UnscentedKalmanFilter(_KalmanFilter):
+    """kf.py:413-640."""
+    _type = 'unscented Kalman filter'
+
+    def __init__(self, model, alpha=None, beta=None, kappa=None, **kw):
+        if model.is_linear():
+            warnings.warn("The supplied model is linear. For better efficiency use an observer targeted at the "
+                          "estimation of linear systems.")
+        super().__init__(model, **kw)
+        self.alpha = .001 if alpha is None else alpha
+        self.beta = 2. if beta is None else beta
+        self.kappa = 0. if kappa is None else kappa
+
+    alpha = property(lambda s: float(s._alpha))
+    beta = property(lambda s: float(s._beta))
+    kappa = property(lambda s: float(s._kappa))
+
+    @alpha.setter
+    def alpha(self, v):
+        if v <= 0. or v > 1.:
+            raise ValueError(f"The parameter alpha needs to lie in the interval (0, 1]. Supplied alpha is {float(v)}.")
+        self._alpha = v
+
+    @beta.setter
+    def beta(self, v):
+        self._beta = v
+
+    @kappa.setter
+    def kappa(self, v):
+        if v < 0:
+            raise ValueError(f"The parameter kappa needs to be greater or equal to 0. Supplied kappa is {float(v)}.")
+        self._kappa = v

@@ -1,0 +1,658 @@
+"""Gaussian-process regression (exact inference) on the GPU.
+
+API mirror of `hilo_mpc/modules/machine_learning/gp/` for the inference path:
+`Kernel.<factory>(...)` / `Mean.<factory>(...)` with `+`, `*`, `**` composition (kernel.py:207-435, 1426-1666;
+mean.py:624-766), `Kernel.__call__(X, X_bar)` -> covariance matrix, `GaussianProcess(features, labels, ...)`,
+`set_training_data`, `setup`, `predict(X_query, noise_free)`, `log_marginal_likelihood()`.
+Inputs are feature-major (n_features x n_observations) exactly like the reference (kernel.py:97-140).
+
+A kernel/mean tree is compiled to a flat postfix program (opcodes in include/hilo_hip.h) that the device
+interprets; the numeric work (covariance matrices, Cholesky, alpha, L^-1, predictions) is done by
+libhilo_hip.so only.  Hyper-parameter *fitting* (`fit_model`) is out of scope.
+"""
+import ctypes as C
+from math import factorial, gamma as gamma_fun
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._device import device, to_dev, ptr, stream_ptr
+
+# opcodes (include/hilo_hip.h)
+K_CONST, K_GAMMAEXP, K_MATERN, K_RQ, K_PP, K_POLY, K_NN, K_PERIODIC = range(8)
+K_SUM, K_PRODUCT, K_POWER, K_XX_BEGIN = 16, 17, 18, 19
+M_CONST, M_POLY, M_SUM, M_PRODUCT, M_POWER, M_SCALE = 32, 33, 48, 49, 50, 51
+
+
+def _is_list_like(v):
+    return isinstance(v, (list, tuple, np.ndarray))
+
+
+def _node(op, active, params):
+    return [float(op), float(len(active))] + [float(a) for a in active] + [float(len(params))] + \
+           [float(p) for p in params]
+
+
+def _log(v, is_variance=False):
+    """kernel.py:127-130: hyper-parameters enter as logs; `*variance*` as log(value)/2."""
+    with np.errstate(divide='ignore'):
+        lg = np.log(np.asarray(v, dtype=float))
+    return lg / 2. if is_variance else lg
+
+
+# =================================================================================================
+# Kernels
+# =================================================================================================
+class Kernel:
+    """Base class + factory namespace (kernel.py:49-435)."""
+    acronym = None
+
+    def __init__(self, active_dims=None):
+        self.active_dims = None if active_dims is None else [int(a) for a in np.atleast_1d(active_dims)]
+
+    # ---- composition (kernel.py:276-296) ----
+    def __add__(self, other):
+        return Sum(self, other)
+
+    def __mul__(self, other):
+        return Product(self, other)
+
+    def __pow__(self, power, modulo=None):
+        return Power(self, power)
+
+    def __radd__(self, other):
+        return Sum(other, self)
+
+    def __rmul__(self, other):
+        return Product(other, self)
+
+    # ---- evaluation ----
+    def _active(self, nf):
+        return list(range(nf)) if self.active_dims is None else self.active_dims
+
+    def program(self, nf):
+        raise NotImplementedError
+
+    def __call__(self, X, X_bar=None):
+        """Covariance matrix K[i, j] = k(X[:, i], X_bar[:, j]) (kernel.py:97-140)."""
+        host = not isinstance(X, torch.Tensor)
+        if X_bar is not None and isinstance(X_bar, torch.Tensor) == host:
+            raise ValueError("X and X_bar need to have the same type")
+        dev = device()
+        Xd = to_dev(np.atleast_2d(X) if host else X, dev)
+        Xd = Xd.reshape(1, -1) if Xd.ndim == 1 else Xd
+        Xb = Xd if X_bar is None else to_dev(np.atleast_2d(X_bar) if host else X_bar, dev)
+        Xb = Xb.reshape(1, -1) if Xb.ndim == 1 else Xb
+        assert Xd.shape[0] == Xb.shape[0], "X and X_bar do not have the same input space dimensions"
+        nf = Xd.shape[0]
+        prog = np.asarray(self.program(nf), dtype=np.float64)
+        K = torch.empty(Xd.shape[1], Xb.shape[1], dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().hilo_gp_kernel_matrix(dev.index, nf, prog.ctypes.data, prog.size, Xd.shape[1], ptr(Xd),
+                                                    Xb.shape[1], ptr(Xb), ptr(K), stream_ptr(dev)))
+        return K.cpu().numpy() if host else K
+
+    # ---- factories (kernel.py:228-435) ----
+    @staticmethod
+    def constant(bias=1., bounds=None):
+        return ConstantKernel(bias=bias)
+
+    @staticmethod
+    def squared_exponential(active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
+        return SquaredExponentialKernel(active_dims, signal_variance, length_scales, ard)
+
+    @staticmethod
+    def exponential(active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
+        return ExponentialKernel(active_dims, signal_variance, length_scales, ard)
+
+    @staticmethod
+    def matern_32(active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
+        return Matern32Kernel(active_dims, signal_variance, length_scales, ard)
+
+    @staticmethod
+    def matern_52(active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
+        return Matern52Kernel(active_dims, signal_variance, length_scales, ard)
+
+    @staticmethod
+    def rational_quadratic(active_dims=None, signal_variance=1., length_scales=1., alpha=1., ard=False, bounds=None):
+        return RationalQuadraticKernel(active_dims, signal_variance, length_scales, alpha, ard)
+
+    @staticmethod
+    def piecewise_polynomial(degree, active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
+        return PiecewisePolynomialKernel(degree, active_dims, signal_variance, length_scales, ard)
+
+    @staticmethod
+    def polynomial(degree, active_dims=None, signal_variance=1., offset=1., bounds=None):
+        return PolynomialKernel(degree, active_dims, signal_variance, offset)
+
+    @staticmethod
+    def linear(active_dims=None, signal_variance=1., bounds=None):
+        return LinearKernel(active_dims, signal_variance)
+
+    @staticmethod
+    def neural_network(active_dims=None, signal_variance=1., weight_variance=1., bounds=None):
+        return NeuralNetworkKernel(active_dims, signal_variance, weight_variance)
+
+    @staticmethod
+    def periodic(active_dims=None, signal_variance=1., length_scales=1., period=1., bounds=None):
+        return PeriodicKernel(active_dims, signal_variance, length_scales, period)
+
+
+class ConstantKernel(Kernel):
+    """kernel.py:436-485: exp(2 log bias)."""
+    acronym = "Const"
+
+    def __init__(self, bias=1., bounds=None):
+        super().__init__()
+        self.bias = bias
+
+    def program(self, nf):
+        return _node(K_CONST, [], [np.exp(2 * _log(self.bias))])
+
+
+class StationaryKernel(Kernel):
+    """kernel.py:488-562."""
+    acronym = "Stat"
+
+    def __init__(self, active_dims=None, length_scales=1., ard=False, bounds=None):
+        super().__init__(active_dims=active_dims)
+        if ard and active_dims is None:
+            raise ValueError("The key word 'ard' can only be set to True if the key word 'active_dims' was supplied")
+        if active_dims is not None and _is_list_like(length_scales):
+            if len(active_dims) != len(length_scales):
+                raise ValueError(f"Dimension mismatch between 'active_dims' ({len(active_dims)}) and the number of "
+                                 f"length_scales ({len(length_scales)})")
+        if not _is_list_like(length_scales) and ard:
+            length_scales = len(active_dims) * [length_scales]
+        self.length_scales = length_scales
+
+    def is_isotropic(self):
+        return not _is_list_like(self.length_scales)
+
+    def _M(self, n_active):
+        """kernel.py:538-555: diag(exp(-2 log l))."""
+        ll = _log(self.length_scales)
+        if self.is_isotropic():
+            return [float(np.exp(-2 * ll))] * n_active
+        if ll.size != n_active:
+            raise ValueError("Length scales vector dimension does not equal input space dimension.")
+        return list(np.exp(-2 * ll))
+
+
+class GammaExponentialKernel(StationaryKernel):
+    """kernel.py:565-701: exp(2 log s - alpha d2^(p/2)), p = 2/(1 - exp(-log(gamma/(2-gamma))))."""
+    acronym = "GE"
+
+    def __init__(self, active_dims=None, signal_variance=1., alpha=None, gamma=1., length_scales=1., ard=False,
+                 bounds=None):
+        super().__init__(active_dims, length_scales, ard)
+        self.signal_variance = signal_variance
+        if gamma == 2.:
+            raise ValueError("Value of the hyperparameter 'gamma' is set to 2. Use the squared exponential kernel "
+                             "instead.")
+        self.gamma = gamma / (2 - gamma)
+        self.alpha = 1. if alpha is None else alpha
+
+    def _p_alpha(self):
+        with np.errstate(divide='ignore'):
+            p = 2 / (1 - np.exp(-np.log(self.gamma)))
+        return p, self.alpha
+
+    def program(self, nf):
+        ad = self._active(nf)
+        p, alpha = self._p_alpha()
+        sf2 = np.exp(2 * _log(self.signal_variance, True))
+        return _node(K_GAMMAEXP, ad, [sf2, alpha, p / 2] + self._M(len(ad)))
+
+
+class SquaredExponentialKernel(GammaExponentialKernel):
+    """kernel.py:704-734 (gamma = 2 -> p = 2, alpha = 1/2)."""
+    acronym = "SE"
+
+    def __init__(self, active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
+        StationaryKernel.__init__(self, active_dims, length_scales, ard)
+        self.signal_variance = signal_variance
+        self.gamma = 2.
+        self.alpha = .5
+
+    def _p_alpha(self):
+        return 2., .5
+
+
+class MaternKernel(StationaryKernel):
+    """kernel.py:737-826."""
+    acronym = "Matern"
+
+    def __init__(self, p, active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
+        super().__init__(active_dims, length_scales, ard)
+        self.signal_variance = signal_variance
+        self._p = p
+
+    def _poly(self):
+        p = self._p
+        if p > 1:
+            g1, g2 = gamma_fun(p + 1), gamma_fun(2 * p + 1)
+            poly = [g1 / g2 * factorial(p + k) / (factorial(k) * factorial(p - k)) * 2. ** (p - k)
+                    for k in range(p - 1)]
+        else:
+            poly = []
+        if p == 0:
+            poly.append(0.)
+        elif p >= 1:
+            poly.append(1.)
+        for k in range(len(poly) - 1, 0, -1):
+            poly[k - 1] /= poly[k]
+        return poly
+
+    def program(self, nf):
+        ad = self._active(nf)
+        poly = self._poly()
+        sf2 = np.exp(2 * _log(self.signal_variance, True))
+        return _node(K_MATERN, ad, [sf2, np.sqrt(2 * (self._p + .5)), len(poly)] + poly + self._M(len(ad)))
+
+
+class ExponentialKernel(MaternKernel):
+    acronym = "E"
+
+    def __init__(self, active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
+        super().__init__(0, active_dims, signal_variance, length_scales, ard)
+
+
+class Matern32Kernel(MaternKernel):
+    acronym = "M32"
+
+    def __init__(self, active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
+        super().__init__(1, active_dims, signal_variance, length_scales, ard)
+
+
+class Matern52Kernel(MaternKernel):
+    acronym = "M52"
+
+    def __init__(self, active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
+        super().__init__(2, active_dims, signal_variance, length_scales, ard)
+
+
+class RationalQuadraticKernel(StationaryKernel):
+    """kernel.py:919-1003."""
+    acronym = "RQ"
+
+    def __init__(self, active_dims=None, signal_variance=1., length_scales=1., alpha=1., ard=False, bounds=None):
+        super().__init__(active_dims, length_scales, ard)
+        self.signal_variance = signal_variance
+        self.alpha = alpha
+
+    def program(self, nf):
+        ad = self._active(nf)
+        sf2 = np.exp(2 * _log(self.signal_variance, True))
+        return _node(K_RQ, ad, [sf2, np.exp(_log(self.alpha))] + self._M(len(ad)))
+
+
+class PiecewisePolynomialKernel(StationaryKernel):
+    """kernel.py:1006-1109."""
+    acronym = "PP"
+
+    def __init__(self, degree, active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
+        super().__init__(active_dims, length_scales, ard)
+        self.signal_variance = signal_variance
+        self.degree = degree
+
+    @property
+    def degree(self):
+        return self._q
+
+    @degree.setter
+    def degree(self, value):
+        if value not in [0, 1, 2, 3]:
+            raise ValueError("The property 'degree' has to be one of the following integers: 0, 1, 2, 3")
+        self._q = value
+
+    def program(self, nf):
+        ad = self._active(nf)
+        j = np.floor(len(ad) / 2) + self._q + 1
+        sf2 = np.exp(2 * _log(self.signal_variance, True))
+        return _node(K_PP, ad, [sf2, self._q, j] + self._M(len(ad)))
+
+
+class DotProductKernel(Kernel):
+    acronym = "Dot"
+
+    def __init__(self, active_dims=None, signal_variance=1., offset=1., bounds=None):
+        super().__init__(active_dims=active_dims)
+        self.signal_variance = signal_variance
+        self.offset = offset
+
+
+class PolynomialKernel(DotProductKernel):
+    """kernel.py:1160-1234."""
+    acronym = "Poly"
+
+    def __init__(self, degree, active_dims=None, signal_variance=1., offset=1., bounds=None):
+        super().__init__(active_dims, signal_variance, offset)
+        self.degree = degree
+
+    def program(self, nf):
+        sf2 = np.exp(2 * _log(self.signal_variance, True))
+        return _node(K_POLY, self._active(nf), [sf2, np.exp(_log(self.offset)), self.degree])
+
+
+class LinearKernel(PolynomialKernel):
+    """kernel.py:1237-1259 (degree 1, offset 0)."""
+    acronym = "Lin"
+
+    def __init__(self, active_dims=None, signal_variance=1., bounds=None):
+        super().__init__(1, active_dims, signal_variance)
+        self.offset = 0.
+
+
+class NeuralNetworkKernel(Kernel):
+    """kernel.py:1262-1332."""
+    acronym = "NN"
+
+    def __init__(self, active_dims=None, signal_variance=1., weight_variance=1., bounds=None):
+        super().__init__(active_dims=active_dims)
+        self.signal_variance = signal_variance
+        self.weight_variance = weight_variance
+
+    def program(self, nf):
+        return _node(K_NN, self._active(nf), [np.exp(2 * _log(self.signal_variance, True)),
+                                             np.exp(2 * _log(self.weight_variance, True))])
+
+
+class PeriodicKernel(Kernel):
+    """kernel.py:1335-1423 (scalar expression only for one active dimension)."""
+    acronym = "Periodic"
+
+    def __init__(self, active_dims=None, signal_variance=1., length_scales=1., period=1., bounds=None):
+        super().__init__(active_dims=active_dims)
+        self.signal_variance = signal_variance
+        self.length_scales = length_scales
+        self.period = period
+
+    def program(self, nf):
+        ad = self._active(nf)
+        if len(ad) != 1:
+            raise ValueError("The periodic covariance function is only defined for one active dimension")
+        return _node(K_PERIODIC, ad, [2 * _log(self.signal_variance, True), np.exp(_log(self.length_scales)),
+                                      np.exp(_log(self.period))])
+
+
+class KernelOperator(Kernel):
+    def __init__(self, kernel_1, kernel_2=None):
+        super().__init__()
+        self.kernel_1 = kernel_1
+        self.kernel_2 = kernel_2
+
+
+class Sum(KernelOperator):
+    def program(self, nf):
+        return self.kernel_1.program(nf) + self.kernel_2.program(nf) + _node(K_SUM, [], [])
+
+
+class Product(KernelOperator):
+    def program(self, nf):
+        return self.kernel_1.program(nf) + self.kernel_2.program(nf) + _node(K_PRODUCT, [], [])
+
+
+class Power(KernelOperator):
+    """kernel.py:1630-1666 - evaluates its child at (x, x) (`self.kernel_1(x)`, :1651)."""
+
+    def __init__(self, kernel, power):
+        super().__init__(kernel)
+        self.power = power
+
+    def program(self, nf):
+        return _node(K_XX_BEGIN, [], []) + self.kernel_1.program(nf) + _node(K_POWER, [], [self.power])
+
+
+# =================================================================================================
+# Means (mean.py)
+# =================================================================================================
+class Mean:
+    acronym = None
+
+    def __init__(self, active_dims=None):
+        self.active_dims = None if active_dims is None else [int(a) for a in np.atleast_1d(active_dims)]
+
+    def __add__(self, other):
+        return MeanSum(self, other)
+
+    def __mul__(self, other):
+        if isinstance(other, Mean):
+            return MeanProduct(self, other)
+        return MeanScale(self, other)
+
+    __rmul__ = __mul__
+
+    def __pow__(self, power, modulo=None):
+        return MeanPower(self, power)
+
+    def program(self, nf):
+        raise NotImplementedError
+
+    def __call__(self, X):
+        """mean.py:90-116: returns (1 x n_obs)."""
+        host = not isinstance(X, torch.Tensor)
+        dev = device()
+        Xd = to_dev(np.atleast_2d(X) if host else X, dev)
+        nf, n = Xd.shape
+        prog = np.asarray(self.program(nf), dtype=np.float64)
+        mu = torch.empty(1, n, dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().hilo_gp_mean(dev.index, nf, prog.ctypes.data, prog.size, n, ptr(Xd), ptr(mu),
+                                           stream_ptr(dev)))
+        return mu.cpu().numpy() if host else mu
+
+    @staticmethod
+    def constant(bias=1., hyperprior=None, **kwargs):
+        return ConstantMean(bias)
+
+    @staticmethod
+    def zero():
+        return ZeroMean()
+
+    @staticmethod
+    def one():
+        return OneMean()
+
+    @staticmethod
+    def polynomial(degree, active_dims=None, coefficient=1., offset=1., hyperprior=None, **kwargs):
+        return PolynomialMean(degree, active_dims, coefficient, offset)
+
+    @staticmethod
+    def linear(active_dims=None, coefficient=1., hyperprior=None, **kwargs):
+        return LinearMean(active_dims, coefficient)
+
+
+class ConstantMean(Mean):
+    acronym = "Const"
+
+    def __init__(self, bias=1., hyperprior=None, **kwargs):
+        super().__init__()
+        self.bias = bias
+
+    def program(self, nf):
+        return _node(M_CONST, [], [self.bias])
+
+
+class ZeroMean(ConstantMean):
+    acronym = "Zero"
+
+    def __init__(self):
+        super().__init__(0.)
+
+
+class OneMean(ConstantMean):
+    acronym = "One"
+
+    def __init__(self):
+        super().__init__(1.)
+
+
+class PolynomialMean(Mean):
+    """mean.py:329-470: (M^T x[active] + offset)^p."""
+    acronym = "Poly"
+
+    def __init__(self, degree, active_dims=None, coefficient=1., offset=1., hyperprior=None, **kwargs):
+        super().__init__(active_dims)
+        if active_dims is not None and _is_list_like(coefficient):
+            if len(active_dims) != len(coefficient):
+                raise ValueError(f"Dimension mismatch between 'active_dims' ({len(active_dims)}) and the number of "
+                                 f"coefficients ({len(coefficient)})")
+        self.coefficient = coefficient
+        self.offset = offset
+        self.degree = degree
+
+    def program(self, nf):
+        ad = list(range(nf)) if self.active_dims is None else self.active_dims
+        c = np.asarray(self.coefficient, dtype=float)
+        if c.ndim == 0:
+            c = c * np.ones(len(ad))
+        if c.size != len(ad):
+            raise ValueError("Coefficient vector dimension does not equal input space dimension.")
+        return _node(M_POLY, ad, [self.offset, self.degree] + list(c))
+
+
+class LinearMean(PolynomialMean):
+    acronym = "Lin"
+
+    def __init__(self, active_dims=None, coefficient=1., hyperprior=None, **kwargs):
+        super().__init__(1, active_dims, coefficient)
+        self.offset = 0.
+
+
+class _MeanOp(Mean):
+    def __init__(self, mean_1, mean_2=None):
+        super().__init__()
+        self.mean_1, self.mean_2 = mean_1, mean_2
+
+
+class MeanSum(_MeanOp):
+    def program(self, nf):
+        return self.mean_1.program(nf) + self.mean_2.program(nf) + _node(M_SUM, [], [])
+
+
+class MeanProduct(_MeanOp):
+    def program(self, nf):
+        return self.mean_1.program(nf) + self.mean_2.program(nf) + _node(M_PRODUCT, [], [])
+
+
+class MeanPower(_MeanOp):
+    def __init__(self, mean, power):
+        super().__init__(mean)
+        self.power = power
+
+    def program(self, nf):
+        return self.mean_1.program(nf) + _node(M_POWER, [], [self.power])
+
+
+class MeanScale(_MeanOp):
+    def __init__(self, mean, scale):
+        super().__init__(mean)
+        self.scale = scale
+
+    def program(self, nf):
+        return self.mean_1.program(nf) + _node(M_SCALE, [], [self.scale])
+
+
+# =================================================================================================
+# GaussianProcess (gp.py:112-236, 522-641, 699-718)
+# =================================================================================================
+class GaussianProcess:
+    def __init__(self, features, labels, inference=None, likelihood=None, mean=None, kernel=None, noise_variance=1.,
+                 hyperprior=None, id=None, name=None, solver=None, solver_options=None, **kwargs):
+        if not _is_list_like(features):
+            features = [features]
+        if not _is_list_like(labels):
+            labels = [labels]
+        if len(labels) > 1:
+            raise ValueError("Training a GP on multiple labels is not supported. Please use 'MultiOutputGP' to train "
+                             "GPs on multiple labels.")
+        if inference is not None and (not isinstance(inference, str) or inference.replace(' ', '_').lower() != 'exact'):
+            raise ValueError(f"Inference '{inference}' not recognized")       # only exact inference exists (inference.py)
+        if likelihood is not None and (not isinstance(likelihood, str) or
+                                       likelihood.replace("'", "").replace(' ', '_').lower() != 'gaussian'):
+            raise ValueError("Exact inference is only applicable with Gaussian likelihood. Choose a different "
+                             "inference method in order to use other likelihoods.")
+        self.features, self.labels = list(features), list(labels)
+        self.name = name
+        self.mean = Mean.zero() if mean is None else mean
+        self.kernel = Kernel.squared_exponential() if kernel is None else kernel
+        self.noise_variance = noise_variance
+        self._X_train = self._y_train = None
+        self._handle = None
+        self._dev = None
+
+    n_features = property(lambda s: len(s.features))
+
+    def set_training_data(self, X, y):
+        """gp.py: X (n_features x n), y (1 x n)."""
+        X = np.atleast_2d(np.asarray(X.cpu() if isinstance(X, torch.Tensor) else X, dtype=float))
+        y = np.atleast_2d(np.asarray(y.cpu() if isinstance(y, torch.Tensor) else y, dtype=float))
+        if X.shape[0] != self.n_features:
+            raise ValueError(f"Dimension mismatch. Supplied dimension for the features is {X.shape[0]}, but required "
+                             f"dimension is {self.n_features}.")
+        if y.shape[0] != 1:
+            raise ValueError(f"Dimension mismatch. Supplied dimension for the labels is {y.shape[0]}, but required "
+                             f"dimension is 1.")
+        if X.shape[1] != y.shape[1]:
+            raise ValueError("Number of observations in training matrix and target vector do not match!")
+        self._X_train, self._y_train = X, y
+
+    X_train = property(lambda s: s._X_train)
+    y_train = property(lambda s: s._y_train)
+
+    def setup(self, device_index=None, **kwargs):
+        if self._X_train is None or self._y_train is None:
+            raise RuntimeError("The training data has not been set. Please run the method set_training_data() to "
+                               "proceed.")
+        self._dev = device(device_index)
+        nf, n = self._X_train.shape
+        kp = np.asarray(self.kernel.program(nf), dtype=np.float64)
+        mp = np.asarray(self.mean.program(nf), dtype=np.float64)
+        X = np.ascontiguousarray(self._X_train)
+        y = np.ascontiguousarray(self._y_train.ravel())
+        h = C.c_void_p()
+        _lib.check(_lib.lib().hilo_gp_create(self._dev.index, nf, n, X.ctypes.data, y.ctypes.data, kp.ctypes.data, kp.size,
+                                             mp.ctypes.data, mp.size, float(self.noise_variance), C.byref(h)))
+        self._destroy()
+        self._handle = h
+
+    def _destroy(self):
+        if self._handle is not None:
+            _lib.lib().hilo_gp_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def log_marginal_likelihood(self):
+        if self._handle is None:
+            raise RuntimeError("The GP has not been set up yet. Please run the setup() method before predicting.")
+        v = C.c_double()
+        _lib.check(_lib.lib().hilo_gp_log_marginal_likelihood(self._handle, C.byref(v)))
+        return v.value
+
+    def predict(self, X_query, noise_free=False, return_var=True):
+        """gp.py:699-718: returns (mean (1 x m), var (1 x m)); numpy in -> numpy out, device tensor in -> tensor out."""
+        if self._handle is None:
+            raise RuntimeError("The GP has not been set up yet. Please run the setup() method before predicting.")
+        host = not isinstance(X_query, torch.Tensor)
+        Xq = to_dev(np.atleast_2d(X_query) if host else X_query, self._dev)
+        if Xq.ndim == 1:
+            Xq = Xq.reshape(-1, 1)
+        if Xq.shape[0] != self.n_features:
+            raise ValueError(f"Dimension mismatch. Supplied dimension for the features is {Xq.shape[0]}, but required "
+                             f"dimension is {self.n_features}.")
+        m = Xq.shape[1]
+        mean = torch.empty(1, m, dtype=torch.float64, device=self._dev)
+        var = torch.empty(1, m, dtype=torch.float64, device=self._dev) if return_var else None
+        _lib.check(_lib.lib().hilo_gp_predict(self._handle, m, ptr(Xq), int(bool(noise_free)), ptr(mean), ptr(var),
+                                              stream_ptr(self._dev)))
+        if host:
+            return mean.cpu().numpy(), (var.cpu().numpy() if return_var else None)
+        return mean, var
+
+    def fit_model(self):
+        raise NotImplementedError("Hyper-parameter fitting is outside the accelerated hot path (SURVEY.md 8f rank 2)")

@@ -1,0 +1,100 @@
+"""Model descriptions for the zoo of device functors (hilo_mpc_amd/csrc/hilo_models.h).
+
+The reference's `Model` (hilo_mpc/modules/dynamic_model/dynamic_model.py) is a symbolic CasADi container; the
+hot path only needs its *description*: dimensions, whether it is discrete, the discretisation recipe and the
+sampling interval.  Method names follow the reference (`discretize`, `setup`, `is_linear`).
+"""
+import copy
+
+import numpy as np
+
+
+# name -> (model id, is_linear, state names, input names, parameter names, measurement names)
+ZOO = {
+    'lti': (0, True, None, None, None, None),
+    'toy1d': (1, False, ['x'], [], [], ['y']),
+    'bioreactor3': (2, False, ['T', 'cB', 'cS'], ['D'], ['alpha', 'T_amb', 'mu_0', 'mu_1', 'K', 'Y'],
+                    ['y_0', 'y_1']),
+    'chemostat4': (3, False, ['X', 'S', 'P', 'I'], ['DS', 'DI'], ['Sf', 'If', 'ISF', 'IRF'], ['yX', 'yP']),
+    'pendulum4': (4, False, ['x', 'v', 'theta', 'omega'], ['F'], [], ['yx', 'yv', 'ytheta', 'tomega']),
+    'linear2': (7, True, ['x_1', 'x_2'], ['u'], ['k_1', 'k_2'], ['y']),
+}
+NATIVE_DISCRETE = {'toy1d', 'lti'}
+
+
+class Model:
+    """Zoo model.  `Model('chemostat4').discretize('rk4').setup(dt=1.)`.
+
+    For `Model('lti', A=..., B=..., C=...)` the matrices define a discrete LTI system
+    (`x+ = A x + B u`, `y = C x`, cf. tests/test_LMPC.py:8-19)."""
+
+    def __init__(self, name, A=None, B=None, C=None, discrete=None):
+        if name not in ZOO:
+            raise ValueError(f"unknown model '{name}'; the device zoo holds {sorted(ZOO)}")
+        self.name = name
+        self.model_id, self._linear, xs, us, ps, ys = ZOO[name]
+        self.dt = None
+        self.erk_order = 0          # 0: not discretised
+        self.n_sub = 1
+        self._is_setup = False
+        if name == 'lti':
+            A = np.atleast_2d(np.asarray(A, dtype=float))
+            B = np.atleast_2d(np.asarray(B, dtype=float))
+            if B.shape[0] != A.shape[0]:
+                B = B.T
+            C = np.eye(A.shape[0]) if C is None else np.atleast_2d(np.asarray(C, dtype=float))
+            self.A, self.B, self.C = A, B, C
+            self.n_x, self.n_u, self.n_y = A.shape[0], B.shape[1], C.shape[0]
+            self.n_p = A.size + B.size + C.size
+            self._native_discrete = True
+            xs = [f'x_{i}' for i in range(self.n_x)]
+            us = [f'u_{i}' for i in range(self.n_u)]
+            ps, ys = [], [f'y_{i}' for i in range(self.n_y)]
+        else:
+            # dimensions are those of the device functor; tests/test_abi.py checks this table against
+            # hilo_model_dims() of the built library
+            self.n_x, self.n_u, self.n_p, self.n_y = len(xs), len(us), len(ps), len(ys)
+            self._native_discrete = name in NATIVE_DISCRETE if discrete is None else bool(discrete)
+        self.dynamical_state_names, self.input_names = list(xs), list(us)
+        self.parameter_names, self.measurement_names = list(ps), list(ys)
+
+    # -- reference-like surface ---------------------------------------------------------------
+    @property
+    def discrete(self):
+        return self._native_discrete or self.erk_order > 0
+
+    def is_linear(self):
+        return self._linear
+
+    def lti_parameters(self):
+        return np.concatenate([self.A.ravel(), self.B.ravel(), self.C.ravel()])
+
+    def discretize(self, method='rk4', order=None, inplace=False, n_sub=1):
+        """`Model.discretize` (dynamic_model.py:2113-2456): 'rk4' = classic order 4, 'erk' with order 1..4
+        (modeling.py:1239-1250)."""
+        if method == 'rk4':
+            order = 4
+        elif method == 'erk':
+            order = 1 if order is None else order
+        else:
+            raise ValueError(f"discretisation method '{method}' is not available on the device "
+                             f"(explicit Runge-Kutta 'erk'/'rk4' only)")
+        if order not in (1, 2, 3, 4):
+            raise NotImplementedError(f"Explicit Runge-Kutta discretization for order {order} is not yet "
+                                      f"implemented.")
+        m = self if inplace else copy.copy(self)
+        if not m._native_discrete:
+            m.erk_order = order
+            m.n_sub = n_sub
+        return m
+
+    def setup(self, dt=None):
+        if dt is not None:
+            self.dt = float(dt)
+        if self.dt is None:
+            self.dt = 1.
+        self._is_setup = True
+        return self
+
+    def copy(self):
+        return copy.copy(self)

@@ -1,0 +1,170 @@
+/*
+ * hilo_hip.h - C ABI of libhilo_hip.so: MI355X-native batched MPC / MHE / Kalman / GP solve path.
+ *
+ * This is the drop-in boundary.  HILO-MPC (the reference, pure Python on CasADi) has no C ABI;
+ * its boundary is a Python callable stored in `self._solver` / `self._function` at `setup()` time.  Each entry
+ * point below names the reference interface it replaces (file:line relative to the reference root).
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - every data pointer is a DEVICE pointer (HBM resident) unless its name ends in `_host`;
+ *    hilo_malloc / hilo_memcpy_* are exported so that a binding needs nothing but this library
+ *  - all floating point data is IEEE fp64 (the reference computes in fp64 throughout); indices are int32/int64
+ *  - arrays are row-major with the batch index leading: [batch][...]
+ *  - a `*_stride` argument is the distance in doubles between consecutive instances; 0 = shared by the batch
+ *  - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous w.r.t. the host unless noted
+ *  - every function returns 0 on success or a negative HILO_E* code; hilo_last_error() gives the message
+ *  - handles are not thread-safe; use one handle per host thread / stream
+ */
+#ifndef HILO_HIP_H
+#define HILO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HILO_ABI_VERSION 1
+
+/* error codes */
+#define HILO_OK 0
+#define HILO_EINVAL (-1)   /* bad argument (dimension mismatch, unknown id, NULL pointer) */
+#define HILO_ENOMEM (-2)   /* device allocation failed */
+#define HILO_EHIP (-3)     /* HIP runtime error */
+#define HILO_ENOTSUP (-4)  /* combination not built into this library */
+
+/* model zoo ids (device functors in hilo_mpc_amd/csrc/hilo_models.h) */
+#define HILO_MODEL_LTI 0         /* x+ = A x + B u, y = C x; p = [A|B|C] row-major (mpc.py:2198-2245 LMPC; KF) */
+#define HILO_MODEL_TOY1D 1       /* tests/test_KFs.py:548-556 */
+#define HILO_MODEL_BIOREACTOR3 2 /* tests/test_KFs.py:691-712 */
+#define HILO_MODEL_CHEMOSTAT4 3  /* hilo_mpc/library/models.py:163-198 + rate laws :143-148 */
+#define HILO_MODEL_PENDULUM4 4   /* tests/test_NMPC.py:12-43 */
+#define HILO_MODEL_ROBOT6 5
+#define HILO_MODEL_CSTR3 6
+#define HILO_MODEL_LINEAR2 7     /* tests/test_KFs.py:247-255 */
+
+/* solver status codes: hilo_mpc/modules/optimizer.py:1085-1104 */
+#define HILO_STATUS_SOLVED 1
+#define HILO_STATUS_ACCEPTABLE 2
+#define HILO_STATUS_INFEASIBLE 3
+#define HILO_STATUS_RESTORATION_FAILED 4
+#define HILO_STATUS_MAXITER 5
+#define HILO_STATUS_OTHER (-1)
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* library                                                                                                  */
+/* ------------------------------------------------------------------------------------------------------- */
+int hilo_abi_version(void);
+const char* hilo_last_error(void);           /* thread-local, valid until the next failing call */
+int hilo_device_count(int* count);
+int hilo_model_dims(int model_id, int* nx, int* nu, int* np, int* ny, int* discrete);
+
+int hilo_malloc(void** dptr, uint64_t bytes, int device);
+int hilo_free(void* dptr);
+int hilo_memcpy_h2d(void* dst, const void* src_host, uint64_t bytes, void* stream);
+int hilo_memcpy_d2h(void* dst_host, const void* src, uint64_t bytes, void* stream);
+int hilo_stream_sync(void* stream);
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* Kalman filters: KF / EKF / UKF                                                                           */
+/* replaces the `ca.Function`s built by `_KalmanFilter.setup` (hilo_mpc/modules/estimator/kf.py:207-277):   */
+/*   prediction_step(x0=[x|P], p=[u;p], Q)        kf.py:129-133 (UKF :550-554)                              */
+/*   update_step(x0=[x|P](|X), y, p=[u;p], R)     kf.py:182-186 (UKF :600-604)                              */
+/*   function(x0, y, p, Q, R) = update(predict())  kf.py:258-265, called from `estimate` kf.py:296-306       */
+/* ------------------------------------------------------------------------------------------------------- */
+#define HILO_KF_KF 0
+#define HILO_KF_EKF 1
+#define HILO_KF_UKF 2
+
+typedef struct hilo_kf hilo_kf;
+
+typedef struct hilo_kf_desc {
+  int32_t model_id;   /* HILO_MODEL_* */
+  int32_t kind;       /* HILO_KF_*; KF and EKF share the arithmetic (kf.py:89-96) */
+  int32_t continuous; /* 0: model is (or was discretised to) a map x+ = Phi(x): P- = F P F^T + Q (kf.py:95-96)
+                         1: continuous model: [x; vec P] integrated over dt (kf.py:97-110); the reference uses
+                            CVODES, this library fixed-step RK4 with n_sub sub-steps */
+  int32_t erk_order;  /* `Model.discretize('erk', order)` order 1..4 for continuous==0 on a continuous model */
+  int32_t n_sub;      /* sub-steps per sampling interval (>=1) */
+  int32_t lti_nx, lti_nu, lti_ny; /* only for HILO_MODEL_LTI */
+  double dt;          /* sampling interval */
+  double alpha, beta, kappa; /* UKF tuning (kf.py:446-454 defaults 1e-3, 2, 0) */
+} hilo_kf_desc;
+
+int hilo_kf_create(const hilo_kf_desc* desc, int device, hilo_kf** out);
+void hilo_kf_destroy(hilo_kf* kf);
+/* widths of the packed tiles: xp = nx+1 ([x|P]); pred = nx+1 (KF/EKF) or 1+nx+(2nx+1) (UKF [x|P|X]) */
+int hilo_kf_dims(const hilo_kf* kf, int* nx, int* nu, int* np, int* ny, int* pred_width);
+
+int hilo_kf_predict(hilo_kf* kf, int64_t batch,
+                    const double* xP,                 /* [B][nx][nx+1] */
+                    const double* up, int64_t up_stride, /* [B][nu+np] = vertcat(u, p) (kf.py:130) */
+                    const double* Q, int64_t q_stride,   /* [B][nx][nx] */
+                    double* pred,                     /* [B][nx][pred_width] */
+                    void* stream);
+int hilo_kf_update(hilo_kf* kf, int64_t batch,
+                   const double* pred,                /* [B][nx][pred_width] */
+                   const double* y,                   /* [B][ny] */
+                   const double* up, int64_t up_stride,
+                   const double* R, int64_t r_stride, /* [B][ny][ny] */
+                   double* xP_out,                    /* [B][nx][nx+1] */
+                   double* y_pred,                    /* [B][ny] */
+                   void* stream);
+/* one `estimate()` step: update(predict(.)), fused in one kernel */
+int hilo_kf_step(hilo_kf* kf, int64_t batch, const double* xP, const double* y,
+                 const double* up, int64_t up_stride, const double* Q, int64_t q_stride,
+                 const double* R, int64_t r_stride, double* xP_out, double* y_pred, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* Gaussian process: exact inference + prediction                                                           */
+/* replaces `ca.Function('prediction',[X,w,p],[mean,var])` (hilo_mpc/modules/machine_learning/gp/gp.py:      */
+/* 623-629, called from `predict` gp.py:709) whose body is `ExactInference.get_posterior`                   */
+/* (gp/inference.py:172-221) over `Kernel.__call__` (gp/kernel.py:97-205) and `Mean.__call__` (mean.py:90)  */
+/* ------------------------------------------------------------------------------------------------------- */
+/* kernel / mean programs: postfix list of nodes, each node = [opcode, n_active, active_dims..., n_par, par...]
+   stored as doubles.  opcodes: */
+#define HILO_K_CONST 0       /* par: c = bias^2                                      kernel.py:465-485 */
+#define HILO_K_GAMMAEXP 1    /* par: sf2, alpha, p/2, M[n_active]  (SE: .5, 1)       kernel.py:650-701 */
+#define HILO_K_MATERN 2      /* par: sf2, sqrt(2nu), ncoef, coef..., M[n_active]     kernel.py:783-826 */
+#define HILO_K_RQ 3          /* par: sf2, alpha, M[n_active]                         kernel.py:972-1003 */
+#define HILO_K_PP 4          /* par: sf2, q, j, M[n_active]                          kernel.py:1069-1109 */
+#define HILO_K_POLY 5        /* par: sf2, offset, degree                             kernel.py:1202-1234 */
+#define HILO_K_NN 6          /* par: sf2, w                                          kernel.py:1309-1332 */
+#define HILO_K_PERIODIC 7    /* par: 2*log(sf), l, period  (1 active dim)            kernel.py:1394-1423 */
+#define HILO_K_SUM 16        /* pops 2                                               kernel.py:1562-1593 */
+#define HILO_K_PRODUCT 17    /* pops 2                                               kernel.py:1596-1627 */
+#define HILO_K_POWER 18      /* par: power; child evaluated at (x,x)                 kernel.py:1630-1666 */
+#define HILO_M_CONST 32      /* par: bias                                            mean.py:280-305 */
+#define HILO_M_POLY 33       /* par: offset, degree, coef[n_active]                  mean.py:422-470 */
+#define HILO_M_SUM 48
+#define HILO_M_PRODUCT 49
+#define HILO_M_POWER 50      /* par: power */
+#define HILO_M_SCALE 51      /* par: scale */
+
+typedef struct hilo_gp hilo_gp;
+
+/* Builds K(X,X) + sn2 I, its Cholesky factor, alpha and the log marginal likelihood on the device
+   (inference.py:199-210).  X_train is feature-major [nf][n] exactly like the reference's X (gp.py:605). */
+int hilo_gp_create(int device, int nf, int n,
+                   const double* X_train_host,  /* [nf][n] */
+                   const double* y_train_host,  /* [n] */
+                   const double* kprog_host, int kprog_len,
+                   const double* mprog_host, int mprog_len,
+                   double noise_variance,       /* sn2 = exp(2 * log sqrt(noise_variance)) (inference.py:199) */
+                   hilo_gp** out);
+void hilo_gp_destroy(hilo_gp* gp);
+int hilo_gp_log_marginal_likelihood(hilo_gp* gp, double* lml_host);
+/* gp.py:699-718.  Xq feature-major [nf][m]; mean/var [m]; var may be NULL (mean only). */
+int hilo_gp_predict(hilo_gp* gp, int64_t m, const double* Xq, int noise_free, double* mean, double* var,
+                    void* stream);
+/* covariance matrix only (Kernel.__call__, kernel.py:97-140): K [n1][n2] for feature-major X1 [nf][n1], X2 [nf][n2] */
+int hilo_gp_kernel_matrix(int device, int nf, const double* kprog_host, int kprog_len, int64_t n1,
+                          const double* X1, int64_t n2, const double* X2, double* K, void* stream);
+int hilo_gp_mean(int device, int nf, const double* mprog_host, int mprog_len, int64_t n, const double* X,
+                 double* mu, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HILO_HIP_H */

@@ -178,9 +178,15 @@ def ukf_predict(model, xP, u, p, Q, dt, alpha=1e-3, beta=2., kappa=0.):
         X[:, :, 1 + k] = x + gamma * S[:, :, k]
         X[:, :, 1 + nx + k] = x - gamma * S[:, :, k]
     X = _propagate(model, X, u, p, dt)
-    x_pred = np.einsum('k,bik->bi', W[0], X)
-    d = X - x_pred[:, :, None]
-    P_pred = Q + np.einsum('k,bik,bjk->bij', W[1], d, d)
+    # sequential accumulation in the reference's order (kf.py:542-548): with the default alpha = 1e-3 the
+    # centre weight is ~ -1e6 and the sums cancel by six digits, so the order is part of the result
+    x_pred = np.zeros((B, nx))
+    for k in range(2 * nx + 1):
+        x_pred = x_pred + W[0, k] * X[:, :, k]
+    P_pred = np.broadcast_to(Q, (B, nx, nx)).copy()
+    for k in range(2 * nx + 1):
+        d = X[:, :, k] - x_pred
+        P_pred = P_pred + (W[1, k] * d)[:, :, None] @ d[:, None, :]
     return np.concatenate([x_pred[:, :, None], P_pred, X], axis=2)
 
 
@@ -197,11 +203,16 @@ def ukf_update(model, xPX, y, u, p, R, dt, alpha=1e-3, beta=2., kappa=0.):
     R = _b(as_cov(R, ny) if np.ndim(R) < 3 else R, nd=3)
     _, W = ukf_weights(nx, alpha, beta, kappa)
     Y = np.stack([model.h(X[:, :, k], u, p, dt) for k in range(2 * nx + 1)], axis=2)
-    y_pred = np.einsum('k,bik->bi', W[0], Y)
-    dx = X - x[:, :, None]
-    dy = Y - y_pred[:, :, None]
-    P_xy = np.einsum('k,bik,bjk->bij', W[1], dx, dy)
-    P_yy = R + np.einsum('k,bik,bjk->bij', W[1], dy, dy)
+    y_pred = np.zeros((B, ny))
+    for k in range(2 * nx + 1):                                   # kf.py:583-585
+        y_pred = y_pred + W[0, k] * Y[:, :, k]
+    P_xy = np.zeros((B, nx, ny))
+    P_yy = np.broadcast_to(R, (B, ny, ny)).copy()
+    for k in range(2 * nx + 1):                                   # kf.py:588-592
+        dx = X[:, :, k] - x
+        dy = Y[:, :, k] - y_pred
+        P_xy = P_xy + (W[1, k] * dx)[:, :, None] @ dy[:, None, :]
+        P_yy = P_yy + (W[1, k] * dy)[:, :, None] @ dy[:, None, :]
     x_up, P_up = gain_update(x, P, P_xy, P_yy, y, y_pred)
     return pack(x_up, P_up), y_pred
 

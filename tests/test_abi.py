@@ -1,0 +1,76 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every symbol the header declares, and the
+host-side tables agree with the device zoo.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'hilo_hip.h')
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(hilo_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_loads_and_exports_header_symbols():
+    from hilo_mpc_amd import _lib
+    lib = _lib.lib()
+    assert lib.hilo_abi_version() == 1
+    names = _declared()
+    assert len(names) >= 20
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in include/hilo_hip.h but not exported: {missing}"
+
+
+def test_model_table_matches_device_zoo():
+    from hilo_mpc_amd import _lib, Model
+    from hilo_mpc_amd.model import ZOO
+    lib = _lib.lib()
+    for name in ZOO:
+        if name == 'lti':
+            continue
+        m = Model(name)
+        d = [C.c_int() for _ in range(5)]
+        _lib.check(lib.hilo_model_dims(m.model_id, *[C.byref(v) for v in d]))
+        assert [v.value for v in d] == [m.n_x, m.n_u, m.n_p, m.n_y, int(m._native_discrete)], name
+
+
+def test_oracle_zoo_matches_product_zoo():
+    from hilo_mpc_amd import Model
+    from oracle import models
+    for name in models.ZOO:
+        om = models.get(name)
+        pm = Model(name)
+        assert (om.nx, om.nu, om.np_, om.ny) == (pm.n_x, pm.n_u, pm.n_p, pm.n_y), name
+        assert om.model_id == pm.model_id or name == 'linear2'
+
+
+def test_errors_are_reported_not_swallowed():
+    from hilo_mpc_amd import _lib
+    lib = _lib.lib()
+    rc = lib.hilo_model_dims(999, None, None, None, None, None)
+    assert rc == -1
+    assert b'unknown model id' in lib.hilo_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc)
+
+
+def test_no_cpu_fallback_when_library_missing(monkeypatch):
+    from hilo_mpc_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libhilo_hip.so')
+    with pytest.raises(_lib.HiloError):
+        _lib.lib()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'hilo_mpc_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), f
