@@ -448,9 +448,10 @@ extern "C" int hilo_gp_log_marginal_likelihood(hilo_gp* gp, double* lml_host) {
 
 extern "C" int hilo_gp_predict(hilo_gp* gp, int64_t m, const double* Xq, int noise_free, double* mean, double* var,
                                void* stream) {
-  HILO_REQUIRE(gp && Xq && mean, "hilo_gp_predict: NULL argument");
+  HILO_REQUIRE(gp, "hilo_gp_predict: NULL handle");
   HILO_REQUIRE(m >= 0, "hilo_gp_predict: negative query count");
   if (m == 0) return HILO_OK;
+  HILO_REQUIRE(Xq && mean, "hilo_gp_predict: NULL argument");
   HILO_HIP_CHECK(hipSetDevice(gp->device));
   int Q = 32;
   while (Q > 1 && ((size_t)gp->n * Q + PRED_TPB) * sizeof(double) > 128 * 1024) Q >>= 1;
@@ -468,10 +469,11 @@ extern "C" int hilo_gp_predict(hilo_gp* gp, int64_t m, const double* Xq, int noi
 
 extern "C" int hilo_gp_kernel_matrix(int device, int nf, const double* kprog_host, int klen, int64_t n1, const double* X1,
                                      int64_t n2, const double* X2, double* K, void* stream) {
-  HILO_REQUIRE(kprog_host && X1 && X2 && K, "hilo_gp_kernel_matrix: NULL argument");
+  HILO_REQUIRE(kprog_host, "hilo_gp_kernel_matrix: NULL argument");
   int rc = check_prog(kprog_host, klen, false, nf);
   if (rc) return rc;
   if (n1 == 0 || n2 == 0) return HILO_OK;
+  HILO_REQUIRE(X1 && X2 && K, "hilo_gp_kernel_matrix: NULL argument");
   HILO_HIP_CHECK(hipSetDevice(device));
   double* dprog = nullptr;
   if ((rc = upload(&dprog, kprog_host, klen))) return rc;
@@ -486,10 +488,11 @@ extern "C" int hilo_gp_kernel_matrix(int device, int nf, const double* kprog_hos
 
 extern "C" int hilo_gp_mean(int device, int nf, const double* mprog_host, int mlen, int64_t n, const double* X, double* mu,
                             void* stream) {
-  HILO_REQUIRE(mprog_host && X && mu, "hilo_gp_mean: NULL argument");
+  HILO_REQUIRE(mprog_host, "hilo_gp_mean: NULL argument");
   int rc = check_prog(mprog_host, mlen, true, nf);
   if (rc) return rc;
   if (n == 0) return HILO_OK;
+  HILO_REQUIRE(X && mu, "hilo_gp_mean: NULL argument");
   HILO_HIP_CHECK(hipSetDevice(device));
   double* dprog = nullptr;
   if ((rc = upload(&dprog, mprog_host, mlen))) return rc;

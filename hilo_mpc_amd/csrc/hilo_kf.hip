@@ -519,6 +519,7 @@ static int kf_run(hilo_kf* kf, int mode, int64_t batch, const double* in, const 
                   void* stream) {
   HILO_REQUIRE(kf, "hilo_kf: NULL handle");
   HILO_REQUIRE(batch >= 0, "hilo_kf: negative batch");
+  if (batch == 0) return HILO_OK;
   HILO_REQUIRE(in && out, "hilo_kf: NULL tile pointer");
   HILO_REQUIRE(kf->nu + kf->np == 0 || up, "hilo_kf: the model has %d inputs/parameters but `up` is NULL", kf->nu + kf->np);
   HILO_REQUIRE(us == 0 || us >= kf->nu + kf->np, "hilo_kf: up_stride %lld < nu+np", (long long)us);
