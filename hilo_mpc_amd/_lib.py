@@ -22,6 +22,15 @@ class KfDesc(C.Structure):
                 ('dt', C.c_double), ('alpha', C.c_double), ('beta', C.c_double), ('kappa', C.c_double)]
 
 
+class NmpcDesc(C.Structure):
+    _fields_ = [('model_id', C.c_int32), ('N', C.c_int32), ('Nc', C.c_int32), ('erk_order', C.c_int32),
+                ('n_sub', C.c_int32), ('max_iter', C.c_int32), ('acceptable_iter', C.c_int32), ('reserved', C.c_int32),
+                ('dt', C.c_double), ('tol', C.c_double), ('acceptable_tol', C.c_double), ('mu_init', C.c_double),
+                ('bound_relax_factor', C.c_double)] + \
+               [(n, C.c_void_p) for n in ('Wz', 'zref', 'WN', 'xrefN', 'Wdu', 'x_lb', 'x_ub', 'u_lb', 'u_ub',
+                                          'x_scaling', 'u_scaling', 'x_guess', 'u_guess')]
+
+
 _lib = None
 
 
@@ -44,6 +53,12 @@ def _declare(lib):
         'hilo_kf_predict': (C.c_int, [vp, i64, vp, vp, i64, vp, i64, vp, vp]),
         'hilo_kf_update': (C.c_int, [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp]),
         'hilo_kf_step': (C.c_int, [vp, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp]),
+        'hilo_nmpc_create': (C.c_int, [P(NmpcDesc), i32, P(vp)]),
+        'hilo_nmpc_destroy': (None, [vp]),
+        'hilo_nmpc_dims': (C.c_int, [vp, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]),
+        'hilo_nmpc_reset_warm_start': (C.c_int, [vp]),
+        'hilo_nmpc_solve': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        'hilo_nmpc_plant_step': (C.c_int, [vp, i64, vp, vp, vp, i64, vp, vp]),
         'hilo_gp_create': (C.c_int, [i32, i32, i32, vp, vp, vp, i32, vp, i32, dbl, P(vp)]),
         'hilo_gp_destroy': (None, [vp]),
         'hilo_gp_log_marginal_likelihood': (C.c_int, [vp, P(C.c_double)]),

@@ -1,0 +1,59 @@
+"""Multi-GPU: independent MPC/MHE/KF instances shard embarrassingly over the GPUs of a node (one process per GPU,
+`torch.distributed`, backend 'nccl' = RCCL over xGMI on ROCm).  The reference has no distributed code at all
+(SURVEY.md 2.1); the only exchange this path needs is the per-step gather of `(u0, status, iters)` - a few KB per
+rank, latency bound - so there is exactly one collective per MPC step and no data-path all-reduce."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(batch, rank, world):
+    """Contiguous block partition of `batch` instances: sizes differ by at most one, lower ranks get the extras."""
+    base, rem = divmod(int(batch), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend=None):
+    """Initialise from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK (torchrun contract).  Returns
+    (rank, world, local_rank).  World size 1 does not create a process group."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class StepGather:
+    """One collective per MPC step: every rank contributes its shard's `u0` (fp64) and `(status, iters)` (int32),
+    packed into one fp64 buffer so that a single `all_gather_into_tensor` moves everything (ranks may hold shards
+    of different sizes: buffers are padded to the largest shard)."""
+
+    def __init__(self, batch, nu, rank, world, device):
+        self.batch, self.nu, self.rank, self.world = int(batch), int(nu), rank, world
+        self.sizes = [shard_range(batch, r, world)[1] - shard_range(batch, r, world)[0] for r in range(world)]
+        self.max_n = max(self.sizes) if self.sizes else 0
+        self.width = nu + 2
+        self.send = torch.zeros(self.max_n, self.width, dtype=torch.float64, device=device)
+        self.recv = torch.zeros(world * self.max_n, self.width, dtype=torch.float64, device=device)
+
+    def __call__(self, u0, status, iters):
+        n = self.sizes[self.rank]
+        self.send[:n, :self.nu] = u0
+        self.send[:n, self.nu] = status.to(torch.float64)
+        self.send[:n, self.nu + 1] = iters.to(torch.float64)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.recv, self.send)
+        else:
+            self.recv.copy_(self.send)
+        parts = [self.recv[r * self.max_n: r * self.max_n + self.sizes[r]] for r in range(self.world)]
+        full = torch.cat(parts, dim=0)
+        return full[:, :self.nu], full[:, self.nu].to(torch.int32), full[:, self.nu + 1].to(torch.int32)

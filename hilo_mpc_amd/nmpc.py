@@ -1,0 +1,444 @@
+"""Batched nonlinear MPC on the GPU.
+
+API mirror of `hilo_mpc.NMPC` (hilo_mpc/modules/controller/mpc.py) for the hot path: constructor, `quad_stage_cost`
+/ `quad_terminal_cost` (`add_states`, `add_inputs`, `add_inputs_change`, util/modeling.py:364-450), `horizon`,
+`set_box_constraints` (mpc.py:619-710), `set_initial_guess`, `set_scaling` (optimizer.py:1476-1506),
+`set_nlp_options` (optimizer.py:1388-1474), `setup` (mpc.py:1789-1801), `optimize` (mpc.py:744-857) and
+`return_prediction` (mpc.py:1803-1827) - with a leading batch axis on `x0`, `cp`, `v0`.
+
+Scope of this backend: a model pre-discretised with `model.discretize('rk4'|'erk')` (or natively
+discrete) and `integration_method='discrete'`; quadratic stage / terminal / input-change costs with constant
+references; box constraints; scaling.  Everything numeric is done by `hilo_nmpc_solve` in libhilo_hip.so.
+"""
+import ctypes as C
+import time
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._device import device, to_dev, ptr, stream_ptr
+
+STATUS_TEXT = {1: 'solve_succeeded', 2: 'solved_to_acceptable_level', 3: 'infeasible_problem_detected',
+               4: 'restoration_failed', 5: 'maximum_iterations_exceeded', -1: 'other'}
+
+
+def _wrap_list(v):
+    if v is None:
+        return None
+    if isinstance(v, (int, float)):
+        return [float(v)]
+    return [float(a) for a in np.asarray(v, dtype=float).ravel()]
+
+
+def _weight_matrix(arg, n, name):
+    """QuadraticCost._create_weight_matrix (modeling.py:164-185)."""
+    if isinstance(arg, np.ndarray):
+        if arg.ndim == 2 and arg.shape[0] == arg.shape[1]:
+            W = arg
+        elif arg.ndim == 1:
+            W = np.diag(arg)
+        else:
+            raise TypeError(f"{name} must be a square matrix,a 1-D array or a list of real numbers.")
+    elif isinstance(arg, list):
+        W = np.diag(arg)
+    elif isinstance(arg, (float, int)):
+        W = np.diag([arg])
+    else:
+        raise TypeError(f"The {name} must be a list of floats, numpy array or casadi DM.")
+    W = np.asarray(W, dtype=float)
+    if W.shape[0] != n:
+        raise ValueError(f"states and weights dimensions must be compatible. The states vector you passed me is"
+                         f" {n} long while cost {W.shape}.")
+    return W
+
+
+class QuadraticCost:
+    """`util/modeling.py:89-531` restricted to what the device solver evaluates."""
+
+    def __init__(self, model):
+        self._model = model
+        self._terms = []          # (type, indices, W, ref)
+        self._is_set = False
+
+    def _add(self, kind, names, pool, weights, ref, path_following, trajectory_tracking):
+        if path_following or trajectory_tracking:
+            raise NotImplementedError("path following / trajectory tracking references are not yet offloaded "
+                                      "(SURVEY.md 8f); use constant references")
+        names = [names] if isinstance(names, str) else list(names)
+        ind = []
+        for n in names:
+            if n not in pool:
+                raise ValueError(f"The state {n} does not exist. The available states are {pool}")
+            ind.append(pool.index(n))
+        if weights is None:
+            raise ValueError(f"You passed the following {kind}: {names} to the cost function, but I do not have any "
+                             f"weights for it/them. Please pass me the weights.")
+        W = _weight_matrix(weights, len(names), 'weights')
+        ref = _wrap_list(ref)
+        if ref is not None and len(ref) != len(names):
+            raise ValueError(f"{kind} and reference dimensions must be compatible. The states vector you passed me "
+                             f"is {len(names)} long while cost {len(ref)}.")
+        self._terms.append((kind, ind, W, ref))
+        self._is_set = True
+
+    def add_states(self, names, weights, ref=None, path_following=False, trajectory_tracking=False):
+        self._add('states', names, self._model.dynamical_state_names, weights, ref, path_following, trajectory_tracking)
+
+    def add_inputs(self, names, weights, ref=None, path_following=False, trajectory_tracking=False):
+        self._add('inputs', names, self._model.input_names, weights, ref, path_following, trajectory_tracking)
+
+    def add_inputs_change(self, names, weights):
+        self._add('inputs_change', names, self._model.input_names, weights, None, False, False)
+
+    def add_measurements(self, names, weights, ref=None, path_following=False, trajectory_tracking=False):
+        raise NotImplementedError("measurement costs are not yet offloaded; add the corresponding states instead")
+
+
+class NMPC:
+    _solver_name_list_nlp = ['ipopt', 'hip_ipm']
+
+    def __init__(self, model, id=None, name=None, plot_backend=None, use_sx=True, stats=False, device_index=None):
+        if not model.discrete:
+            warnings.warn("The device backend needs a discrete-time model: call model.discretize('rk4') first "
+                          "(mpc.py's own 'rk4' branch is inconsistent for parametric models, SURVEY.md Q18). "
+                          "I am discretising with 'rk4' for you.")
+            model = model.discretize('rk4')
+        if not model._is_setup:
+            model.setup()
+        self._model = model
+        self.name = name
+        self._stats = stats
+        self._n_x, self._n_u, self._n_p = model.n_x, model.n_u, model.n_p
+        self.quad_stage_cost = QuadraticCost(model)
+        self.quad_terminal_cost = QuadraticCost(model)
+        self._prediction_horizon = self._control_horizon = None
+        self._x_lb = self._x_ub = self._u_lb = self._u_ub = None
+        self._x_guess = self._u_guess = None
+        self._x_scaling = self._u_scaling = None
+        self._nlp_options = None
+        self._solver_options = {}
+        self._handle = None
+        self._dev_index = device_index
+        self._nlp_setup_done = False
+        self._time = 0.
+        self._n_iterations = 0
+        self._nlp_solution = None
+        self._sampling_interval = model.dt
+        self._u_prev = None
+
+    type = 'NMPC'
+
+    # ---- horizons (optimizer.py:1730-1768) ------------------------------------------------------------------
+    @property
+    def horizon(self):
+        return self._prediction_horizon
+
+    @horizon.setter
+    def horizon(self, n):
+        self.prediction_horizon = n
+        self.control_horizon = n
+
+    @property
+    def prediction_horizon(self):
+        return self._prediction_horizon
+
+    @prediction_horizon.setter
+    def prediction_horizon(self, n):
+        if not isinstance(n, (int, np.integer)) or n <= 0:
+            raise ValueError("The prediction horizon must be a positive integer")
+        self._prediction_horizon = int(n)
+
+    @property
+    def control_horizon(self):
+        return self._control_horizon
+
+    @control_horizon.setter
+    def control_horizon(self, n):
+        if not isinstance(n, (int, np.integer)) or n <= 0:
+            raise ValueError("The control horizon must be a positive integer")
+        self._control_horizon = int(n)
+
+    @property
+    def sampling_interval(self):
+        return self._sampling_interval
+
+    n_iterations = property(lambda s: s._n_iterations)
+
+    # ---- problem data ---------------------------------------------------------------------------------------
+    def set_box_constraints(self, x_ub=None, x_lb=None, u_ub=None, u_lb=None, y_ub=None, y_lb=None, z_ub=None, z_lb=None):
+        """mpc.py:619-710."""
+        def chk(v, n, what):
+            if v is None:
+                return None
+            v = _wrap_list(v)
+            if len(v) != n:
+                raise TypeError(f"The model has {n} {what}. You need to pass the same number of bounds.")
+            return v
+        self._x_ub, self._x_lb = chk(x_ub, self._n_x, 'states'), chk(x_lb, self._n_x, 'states')
+        self._u_ub, self._u_lb = chk(u_ub, self._n_u, 'inputs'), chk(u_lb, self._n_u, 'inputs')
+        if y_ub is not None or y_lb is not None or z_ub is not None or z_lb is not None:
+            raise NotImplementedError("measurement / algebraic box constraints are not yet offloaded")
+
+    def set_initial_guess(self, x_guess=None, u_guess=None, z_guess=None):
+        def chk(v, n, what):
+            if v is None:
+                return None
+            v = _wrap_list(v)
+            if len(v) != n:
+                raise ValueError(f"x_guess dimension and model dimension do not match. Model {what} has dimension "
+                                 f"{n} while x_guess has dimension {len(v)}")
+            return v
+        self._x_guess, self._u_guess = chk(x_guess, self._n_x, 'x'), chk(u_guess, self._n_u, 'u')
+
+    def set_scaling(self, x_scaling=None, u_scaling=None, y_scaling=None):
+        """optimizer.py:1476-1506."""
+        def chk(v, n, what):
+            if v is None:
+                return None
+            v = _wrap_list(v)
+            if len(v) != n:
+                raise ValueError(f"{what} scaling dimension does not match the model")
+            return v
+        self._x_scaling, self._u_scaling = chk(x_scaling, self._n_x, 'x'), chk(u_scaling, self._n_u, 'u')
+
+    def set_nlp_options(self, *args, **kwargs):
+        """optimizer.py:1388-1474 (same keys, same allow-lists, same defaults)."""
+        possible = {'integration_method': ['collocation', 'rk4', 'erk', 'discrete', 'idas', 'cvodes'],
+                    'solver': self._solver_name_list_nlp, 'collocation_points': ['radau', 'legendre'],
+                    'objective_function': ['discrete', 'continuous'], 'warm_start': [True, False], 'degree': None,
+                    'print_level': [0, 1], 'ipopt_debugger': [True, False]}
+        opts = {'integration_method': 'collocation', 'collocation_points': 'radau', 'degree': 3, 'print_level': 1,
+                'warm_start': True, 'solver': 'ipopt', 'ipopt_debugger': False, 'objective_function': 'discrete'}
+        given = args[0] if (args and isinstance(args[0], dict)) else kwargs
+        for k, v in (given or {}).items():
+            if k not in opts:
+                raise ValueError(f"The option named {k} does not exist. Possible options are {list(opts)}.")
+            if possible[k] is not None and v not in possible[k]:
+                raise ValueError(f"The option {k} is set to value {v} but the only allowed values are {possible[k]}.")
+            opts[k] = v
+        if opts['integration_method'] != 'discrete':
+            if given and 'integration_method' in given:
+                warnings.warn(f"The integration method is set to {opts['integration_method']} but I notice that the "
+                              f"model is in discrete time. I am overwriting and using discrete mode.")
+            opts['integration_method'] = 'discrete'
+        if opts['ipopt_debugger']:
+            raise NotImplementedError("the IPOPT iteration callback has no device counterpart")
+        self._nlp_options = opts
+
+    def set_solver_opts(self, options=None):
+        """optimizer.py:1342-1370: keys understood here: 'ipopt.tol', 'ipopt.max_iter', 'ipopt.acceptable_tol',
+        'ipopt.acceptable_iter', 'ipopt.mu_init', 'ipopt.bound_relax_factor' (with or without the prefix)."""
+        self._solver_options = {}
+        for k, v in (options or {}).items():
+            self._solver_options[k.split('.')[-1]] = v
+
+    # ---- setup (mpc.py:1133-1801) ---------------------------------------------------------------------------
+    def setup(self, options=None, solver_options=None):
+        if self._prediction_horizon is None:
+            raise ValueError("You must set a prediction horizon length before")
+        if self._control_horizon is None:
+            raise ValueError("You must set a control horizon length before.")
+        if not (self.quad_stage_cost._is_set or self.quad_terminal_cost._is_set):
+            raise ValueError("You need to define a cost function before setting up the mpc.")
+        if self._nlp_options is None or options is not None:
+            self.set_nlp_options(options or {})
+        if solver_options is not None:
+            self.set_solver_opts(solver_options)
+        m = self._model
+        nx, nu = self._n_x, self._n_u
+        nz = nx + nu
+        sx = np.ones(nx) if self._x_scaling is None else np.asarray(self._x_scaling)
+        su = np.ones(nu) if self._u_scaling is None else np.asarray(self._u_scaling)
+        Wz, zref = np.zeros((nz, nz)), np.zeros(nz)
+        Wdu, has_du = np.zeros((nu, nu)), False
+        for kind, ind, W, ref in self.quad_stage_cost._terms:
+            if kind == 'states':
+                Wz[np.ix_(ind, ind)] += W
+                if ref is not None:
+                    zref[ind] = np.asarray(ref) / sx[ind]             # modeling.py:310
+            elif kind == 'inputs':
+                jj = [nx + i for i in ind]
+                Wz[np.ix_(jj, jj)] += W
+                if ref is not None:
+                    zref[jj] = np.asarray(ref) / su[ind]
+            else:
+                Wdu[np.ix_(ind, ind)] += W
+                has_du = True
+        WN, xrefN = np.zeros((nx, nx)), np.zeros(nx)
+        for kind, ind, W, ref in self.quad_terminal_cost._terms:
+            if kind != 'states':
+                raise TypeError("The terminal cost can only contain states")
+            WN[np.ix_(ind, ind)] += W
+            if ref is not None:
+                xrefN[ind] = np.asarray(ref) / sx[ind]
+        self._has_du = has_du
+        keep = []                                                   # keep numpy buffers alive during the call
+
+        def hp(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+            keep.append(a)
+            return a.ctypes.data
+
+        d = _lib.NmpcDesc()
+        d.model_id, d.N, d.Nc = m.model_id, self._prediction_horizon, self._control_horizon
+        d.erk_order = m.erk_order if m.erk_order else 4
+        d.n_sub = m.n_sub
+        so = self._solver_options
+        d.max_iter = int(so.get('max_iter', 0))
+        d.acceptable_iter = int(so.get('acceptable_iter', 0))
+        d.dt = m.dt
+        d.tol = float(so.get('tol', 0.))
+        d.acceptable_tol = float(so.get('acceptable_tol', 0.))
+        d.mu_init = float(so.get('mu_init', 0.))
+        d.bound_relax_factor = float(so.get('bound_relax_factor', -1.))
+        d.Wz, d.zref, d.WN, d.xrefN = hp(Wz), hp(zref), hp(WN), hp(xrefN)
+        d.Wdu = hp(Wdu) if has_du else None
+        d.x_lb, d.x_ub, d.u_lb, d.u_ub = hp(self._x_lb), hp(self._x_ub), hp(self._u_lb), hp(self._u_ub)
+        d.x_scaling, d.u_scaling = hp(self._x_scaling), hp(self._u_scaling)
+        d.x_guess, d.u_guess = hp(self._x_guess), hp(self._u_guess)
+        self._dev = device(self._dev_index)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().hilo_nmpc_create(C.byref(d), self._dev.index, C.byref(h)))
+        self._destroy()
+        self._handle = h
+        dims = [C.c_int() for _ in range(5)]
+        _lib.check(_lib.lib().hilo_nmpc_dims(h, *[C.byref(v) for v in dims]))
+        self._n_v, self._n_g = dims[0].value, dims[1].value
+        N = self._prediction_horizon
+        # integer bookkeeping of mpc.py:1464-1485 (bit-exact index maps)
+        self._x_ind = [list(range(k * nx, (k + 1) * nx)) for k in range(N + 1)]
+        self._u_ind = [list(range((N + 1) * nx + k * nu, (N + 1) * nx + (k + 1) * nu)) for k in range(N)]
+        self._sx, self._su = sx, su
+        self._nlp_setup_done = True
+
+    def _destroy(self):
+        if self._handle is not None:
+            _lib.lib().hilo_nmpc_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    # ---- optimize (mpc.py:744-857) --------------------------------------------------------------------------
+    def optimize(self, x0, cp=None, tvp=None, v0=None, runs=0, fix_x0=True, **kwargs):
+        if not self._nlp_setup_done:
+            raise ValueError("Howdy! You need to setup the MPC before optimizing. Run .setup() on the MPC object.")
+        if runs != 0:
+            raise NotImplementedError("multi-start (runs > 0) uses unseeded random perturbations in the reference "
+                                      "(mpc.py:740) and is not offloaded")
+        if not fix_x0:
+            raise NotImplementedError("fix_x0=False is not yet offloaded")
+        if tvp is not None:
+            raise NotImplementedError("time-varying parameters are not yet offloaded")
+        host = not isinstance(x0, torch.Tensor)
+        x = to_dev(x0, self._dev)
+        single = x.ndim <= 1 or (x.ndim == 2 and x.shape[1] == 1 and x.shape[0] == self._n_x and self._n_x != 1)
+        x = x.reshape(1, -1) if single else x
+        if x.shape[1] != self._n_x:
+            raise ValueError(f"We have an issue mate, the x0 you supplied has dimension {x.shape[1]} but the model has "
+                             f"{self._n_x} states.")
+        B = x.shape[0]
+        if self._n_p != 0:
+            if cp is None:
+                raise ValueError(f"The model has {self._n_p} constant parameter(s): {self._model.parameter_names}. "
+                                 f"You must pass me the value of these before running the optimization to the 'cp' "
+                                 f"parameter.")
+            p = to_dev(cp, self._dev)
+            p = p.reshape(1, -1) if p.ndim <= 1 else p
+            if p.shape[1] != self._n_p or p.shape[0] not in (1, B):
+                raise ValueError(f"The model has {self._n_p} constant parameter(s): {self._model.parameter_names}. "
+                                 f"You must pass me the value of these before running the optimization to the 'cp' "
+                                 f"parameter.")
+            ps = 0 if p.shape[0] == 1 else self._n_p
+        else:
+            if cp is not None:
+                warnings.warn("You are passing a parameter vector in the optimizer, but the model has no defined "
+                              "parameters. I am ignoring the vector.")
+            p, ps = None, 0
+        v0t = None
+        if v0 is not None:
+            v0t = to_dev(v0, self._dev).reshape(-1, self._n_v)
+            if v0t.shape[0] == 1 and B > 1:
+                v0t = v0t.expand(B, -1).contiguous()
+        elif not self._nlp_options['warm_start']:
+            _lib.check(_lib.lib().hilo_nmpc_reset_warm_start(self._handle))
+        u_old = None
+        if self._has_du:
+            # mpc.py:488-493: previous first input, or the guess on the very first call (scaled)
+            if self._u_prev is not None and self._u_prev.shape[0] == B:
+                u_old = self._u_prev
+            else:
+                g = np.zeros(self._n_u) if self._u_guess is None else np.asarray(self._u_guess) / self._su
+                u_old = to_dev(np.tile(g, (B, 1)), self._dev)
+        dev = self._dev
+        v_opt = torch.empty(B, self._n_v, dtype=torch.float64, device=dev)
+        f_opt = torch.empty(B, dtype=torch.float64, device=dev)
+        lam_g = torch.empty(B, self._n_g, dtype=torch.float64, device=dev)
+        u0 = torch.empty(B, self._n_u, dtype=torch.float64, device=dev)
+        status = torch.empty(B, dtype=torch.int32, device=dev)
+        iters = torch.empty(B, dtype=torch.int32, device=dev)
+        kkt = torch.empty(B, dtype=torch.float64, device=dev)
+        t0 = time.time() if self._stats else None
+        _lib.check(_lib.lib().hilo_nmpc_solve(self._handle, B, ptr(x.contiguous()), ptr(p), ps, ptr(v0t), ptr(u_old),
+                                              ptr(v_opt), ptr(f_opt), ptr(lam_g), ptr(u0), ptr(status), ptr(iters),
+                                              ptr(kkt), stream_ptr(dev)))
+        self._nlp_solution = {'x': v_opt, 'f': f_opt, 'lam_g': lam_g, 'status': status, 'iter_count': iters,
+                              'kkt_error': kkt}
+        if self._has_du:
+            self._u_prev = v_opt[:, self._u_ind[0]].contiguous()
+        if self._stats:
+            torch.cuda.synchronize(dev)
+            self._extime = time.time() - t0
+        self._time += self._sampling_interval            # mpc.py:850
+        self._n_iterations += 1                          # mpc.py:853
+        if host:
+            u = u0.cpu().numpy()
+            return u.reshape(-1, 1) if single else u     # single instance: (nu x 1) like the reference's DM
+        return u0[0] if single else u0
+
+    # ---- results --------------------------------------------------------------------------------------------
+    @property
+    def solver_status_code(self):
+        """optimizer.py:1085-1104 codes, one per instance."""
+        return None if self._nlp_solution is None else self._nlp_solution['status'].cpu().numpy()
+
+    def stats(self):
+        s = self._nlp_solution
+        if s is None:
+            return {}
+        st = s['status'].cpu().numpy()
+        return {'return_status': [STATUS_TEXT.get(int(c), 'other') for c in st], 'success': (st == 1) | (st == 2),
+                'iter_count': s['iter_count'].cpu().numpy(), 'kkt_error': s['kkt_error'].cpu().numpy()}
+
+    def return_prediction(self):
+        """mpc.py:1803-1827: (x_pred [B, nx, N+1], u_pred [B, nu, N], None), un-scaled."""
+        if self._nlp_solution is None:
+            warnings.warn("There is still no mpc solution available. Run mpc.optimize() to get one.")
+            return None, None, None
+        v = self._nlp_solution['x'].cpu().numpy()
+        N, nx, nu = self._prediction_horizon, self._n_x, self._n_u
+        X = v[:, :(N + 1) * nx].reshape(-1, N + 1, nx) * self._sx
+        U = v[:, (N + 1) * nx:].reshape(-1, N, nu) * self._su
+        return np.swapaxes(X, 1, 2), np.swapaxes(U, 1, 2), None
+
+    def plant_step(self, x, u, cp=None):
+        """Closed-loop helper: x+ = Phi(x, u, p) with the controller's shooting map, on the device."""
+        x = to_dev(x, self._dev).reshape(-1, self._n_x).contiguous()
+        u = to_dev(u, self._dev).reshape(-1, self._n_u).contiguous()
+        B = x.shape[0]
+        p, ps = None, 0
+        if self._n_p:
+            p = to_dev(cp, self._dev)
+            p = p.reshape(1, -1) if p.ndim <= 1 else p
+            ps = 0 if p.shape[0] == 1 else self._n_p
+        xn = torch.empty_like(x)
+        _lib.check(_lib.lib().hilo_nmpc_plant_step(self._handle, B, ptr(x), ptr(u), ptr(p), ps, ptr(xn),
+                                                   stream_ptr(self._dev)))
+        return xn

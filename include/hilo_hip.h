@@ -164,6 +164,66 @@ int hilo_gp_kernel_matrix(int device, int nf, const double* kprog_host, int kpro
 int hilo_gp_mean(int device, int nf, const double* mprog_host, int mprog_len, int64_t n, const double* X,
                  double* mu, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------- */
+/* NMPC: batched direct multiple shooting + interior point                                                  */
+/* replaces `ca.nlpsol('solver','ipopt',{'f','x','p','g'})` built at hilo_mpc/modules/controller/mpc.py:      */
+/* 1778-1787 and called as `solver(x0=v0, lbx, ubx, lbg, ubg, p)` at mpc.py:722 by `NMPC._optimize`; the       */
+/* transcription it embodies is mpc.py:1455-1787 for a pre-discretised model + `integration_method='discrete'`  */
+/* ------------------------------------------------------------------------------------------------------- */
+typedef struct hilo_nmpc hilo_nmpc;
+
+typedef struct hilo_nmpc_desc {
+  int32_t model_id;     /* HILO_MODEL_* */
+  int32_t N;            /* prediction horizon (mpc.py `horizon`) */
+  int32_t Nc;           /* control horizon; 0 or N (shorter control horizons: not yet supported) */
+  int32_t erk_order;    /* `model.discretize('rk4')` = 4, `('erk', order)` = 1..4 (modeling.py:1239-1250) */
+  int32_t n_sub;        /* sub-steps per interval (1 = the reference's single ERK step) */
+  int32_t max_iter;     /* 0 -> 3000 (IPOPT default) */
+  int32_t acceptable_iter; /* 0 -> 15 */
+  int32_t reserved;
+  double dt;            /* sampling interval (mpc.py:511) */
+  double tol;           /* 0 -> 1e-8 */
+  double acceptable_tol;/* 0 -> 1e-6 */
+  double mu_init;       /* 0 -> 0.1 */
+  double bound_relax_factor; /* < 0 -> 1e-8 (IPOPT default); 0 disables */
+  /* HOST pointers, all optional (NULL = zero weight / no bound / unit scaling / zero guess).
+     Quadratic costs in the form QuadraticCost builds (modeling.py:243-283), on scaled z = (x, u):
+       stage: (z - zref)^T Wz (z - zref);  terminal: (x - xrefN)^T WN (x - xrefN);
+       input change (only interval 0, mpc.py:1631-1635): (u_0 - u_old)^T Wdu (u_0 - u_old) */
+  const double* Wz;     /* [nz][nz], nz = nx+nu */
+  const double* zref;   /* [nz]  already divided by the scaling (modeling.py:310) */
+  const double* WN;     /* [nx][nx] */
+  const double* xrefN;  /* [nx] */
+  const double* Wdu;    /* [nu][nu] */
+  const double* x_lb; const double* x_ub; const double* u_lb; const double* u_ub;  /* original units */
+  const double* x_scaling; const double* u_scaling;                                /* optimizer.py:1476-1506 */
+  const double* x_guess; const double* u_guess;                                    /* original units */
+} hilo_nmpc_desc;
+
+int hilo_nmpc_create(const hilo_nmpc_desc* desc, int device, hilo_nmpc** out);   /* = NMPC.setup(), mpc.py:1789 */
+void hilo_nmpc_destroy(hilo_nmpc* h);
+int hilo_nmpc_dims(const hilo_nmpc* h, int* n_v, int* n_g, int* nx, int* nu, int* np);
+int hilo_nmpc_reset_warm_start(hilo_nmpc* h);
+/* One optimize() for `batch` independent instances (mpc.py:744-857).
+   v layout = the reference's decision vector [x_0..x_N | u_0..u_{N-1}] in scaled variables (mpc.py:1462-1485). */
+int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch,
+                    const double* x0,                 /* [B][nx]  measured state, original units (mpc.py:801) */
+                    const double* p, int64_t p_stride,/* [B][np]  constant parameters `cp` (mpc.py:496-497) */
+                    const double* v0,                 /* [B][n_v] initial guess or NULL -> previous solution
+                                                         (warm start, mpc.py:725-726) / tiled guess (:1468-1482) */
+                    const double* u_old,              /* [B][nu]  previous input for the change penalty or NULL */
+                    double* v_opt,                    /* [B][n_v] */
+                    double* f_opt,                    /* [B] */
+                    double* lam_g,                    /* [B][n_g] multipliers of g (sign: L = f + lam^T g) or NULL */
+                    double* u0,                       /* [B][nu]  first input, un-scaled (mpc.py:856) */
+                    int32_t* status,                  /* [B] HILO_STATUS_* (optimizer.py:1093-1104) */
+                    int32_t* iters,                   /* [B] interior-point iterations */
+                    double* kkt,                      /* [B] scaled optimality error at the returned point or NULL */
+                    void* stream);
+/* x+ = Phi(x, u, p) with the controller's own shooting map: closed-loop harness (control_loop.py:343-396) */
+int hilo_nmpc_plant_step(hilo_nmpc* h, int64_t batch, const double* x, const double* u, const double* p,
+                         int64_t p_stride, double* x_next, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

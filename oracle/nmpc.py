@@ -1,0 +1,520 @@
+"""Oracle: direct multiple-shooting NMPC - transcription + dense primal-dual interior-point solver, numpy.
+
+TEST INFRASTRUCTURE ONLY - never imported by the product package.
+
+PARITY UNPINNED: the reference's NMPC tests hold no numeric assertion (tests/test_NMPC.py are closed-loop smoke
+tests) and its solver, IPOPT, lives in the un-vendored, un-installable dependency `casadi>=3.5` (setup.py:52).
+This file therefore restates
+  (1) the reference's *transcription* for a pre-discretised model with `integration_method='discrete'`
+      (hilo_mpc/modules/controller/mpc.py:1455-1787; recipe of SURVEY Q18): decision vector
+      v = [x_0..x_N | u_0..u_{Nc-1}] in scaled variables (:1462-1485), equality rows x_{k+1} - Phi(x_k,u_k) (:1667),
+      objective sum_k l(x_k,u_k) + V(Phi_{N-1}) (:1676-1682), x_0 pinned through its bounds (:797-802), quadratic
+      costs of `QuadraticCost` (hilo_mpc/util/modeling.py:243-283: (s-r)^T W (s-r), no factor 1/2; references divided
+      by the scaling :310; the input-change term only acts in interval 0, mpc.py:1631-1635), scaling of
+      bounds/guesses (mpc.py:248-263) and of the model (hilo_mpc/modules/base.py:1562-1591), and
+  (2) the published interior-point algorithm IPOPT implements (Waechter & Biegler, Math. Program. 106, 2006):
+      monotone barrier update (their eq. 7), fraction-to-the-boundary rule (8), filter line search (Alg. A,
+      without second-order correction / restoration phase), inertia correction (Alg. IC), scaled optimality
+      error E_mu (5,6), default constants (tol 1e-8, mu_0 0.1, kappa_eps 10, kappa_mu 0.2, theta_mu 1.5,
+      tau_min 0.99, bound_push = bound_frac 1e-2, bound_relax_factor 1e-8, max_iter 3000).
+Its results are cross-checked in tests/ by an independent solver (scipy SLSQP / trust-constr) on the same NLP and
+by the KKT residual at the returned point.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .shooting import ShootingMap
+
+INF = np.inf
+
+# solver status codes, hilo_mpc/modules/optimizer.py:1085-1104
+SOLVED, ACCEPTABLE, INFEASIBLE, RESTORATION_FAILED, MAXITER, OTHER = 1, 2, 3, 4, 5, -1
+
+
+def _wmat(W, n):
+    """QuadraticCost._create_weight_matrix (modeling.py:164-185)."""
+    W = np.asarray(W, dtype=float)
+    if W.ndim == 0:
+        W = np.diag([float(W)] * n) if n > 1 else np.array([[float(W)]])
+    elif W.ndim == 1:
+        W = np.diag(W)
+    assert W.shape == (n, n)
+    return W
+
+
+class NmpcProblem:
+    """Plain description of one NMPC structure (everything `NMPC.setup()` fixes)."""
+
+    def __init__(self, model, dt, N, order=4, n_sub=1, Nc=None,
+                 stage_states=None, stage_inputs=None, input_change=None, terminal_states=None,
+                 x_lb=None, x_ub=None, u_lb=None, u_ub=None, x_scaling=None, u_scaling=None,
+                 x_guess=None, u_guess=None):
+        self.model, self.dt, self.N, self.order = model, float(dt), int(N), order
+        self.Nc = self.N if Nc is None else int(Nc)
+        nx, nu = model.nx, model.nu
+        self.nx, self.nu, self.np_ = nx, nu, model.np_
+        self.nz = nx + nu
+        self.sx = np.ones(nx) if x_scaling is None else np.asarray(x_scaling, dtype=float)
+        self.su = np.ones(nu) if u_scaling is None else np.asarray(u_scaling, dtype=float)
+        # mpc.py:645-701 defaults +-inf; :248-263 bounds and guesses are divided by the scaling
+        self.x_lb = (np.full(nx, -INF) if x_lb is None else np.asarray(x_lb, dtype=float)) / self.sx
+        self.x_ub = (np.full(nx, INF) if x_ub is None else np.asarray(x_ub, dtype=float)) / self.sx
+        self.u_lb = (np.full(nu, -INF) if u_lb is None else np.asarray(u_lb, dtype=float)) / self.su
+        self.u_ub = (np.full(nu, INF) if u_ub is None else np.asarray(u_ub, dtype=float)) / self.su
+        self.x_guess = (np.zeros(nx) if x_guess is None else np.asarray(x_guess, dtype=float)) / self.sx
+        self.u_guess = (np.zeros(nu) if u_guess is None else np.asarray(u_guess, dtype=float)) / self.su
+        self.smap = ShootingMap(model, order, n_sub)
+
+        # ---- quadratic cost as (z - zref)^T Wz (z - zref) on scaled z = (x, u); refs are divided by the scaling
+        self.Wz = np.zeros((self.nz, self.nz))
+        self.zref = np.zeros(self.nz)
+        for ind, W, ref in (stage_states or []):
+            ind = list(ind)
+            self.Wz[np.ix_(ind, ind)] += _wmat(W, len(ind))
+            if ref is not None:
+                self.zref[ind] = np.asarray(ref, dtype=float) / self.sx[ind]       # modeling.py:310
+        for ind, W, ref in (stage_inputs or []):
+            ind = list(ind)
+            jj = [nx + i for i in ind]
+            self.Wz[np.ix_(jj, jj)] += _wmat(W, len(ind))
+            if ref is not None:
+                self.zref[jj] = np.asarray(ref, dtype=float) / self.su[ind]
+        self.Wdu = np.zeros((nu, nu))
+        for ind, W in ([input_change] if input_change else []):
+            ind = list(ind)
+            self.Wdu[np.ix_(ind, ind)] += _wmat(W, len(ind))
+        self.WN = np.zeros((nx, nx))
+        self.xrefN = np.zeros(nx)
+        for ind, W, ref in (terminal_states or []):
+            ind = list(ind)
+            self.WN[np.ix_(ind, ind)] += _wmat(W, len(ind))
+            if ref is not None:
+                self.xrefN[ind] = np.asarray(ref, dtype=float) / self.sx[ind]
+
+        # ---- decision-vector bookkeeping, bit-exact restatement of mpc.py:1462-1485 (integer index maps) ----
+        N, Nc = self.N, self.Nc
+        off = 0
+        self.x_ind = []
+        for _ in range(N + 1):
+            self.x_ind.append(list(range(off, off + nx)))
+            off += nx
+        self.u_ind = []
+        for _ in range(Nc):
+            self.u_ind.append(list(range(off, off + nu)))
+            off += nu
+        self.n_v = off                                           # mpc.py:1440
+        self.n_g = N * nx                                        # mpc.py:1667-1669
+        self.v_lb = np.concatenate([np.tile(self.x_lb, N + 1), np.tile(self.u_lb, Nc)])
+        self.v_ub = np.concatenate([np.tile(self.x_ub, N + 1), np.tile(self.u_ub, Nc)])
+        self.v_guess = np.concatenate([np.tile(self.x_guess, N + 1), np.tile(self.u_guess, Nc)])
+
+    # ---- scaled shooting map (base.py:1562-1591: x := x*s inside the equations, rhs := rhs/s) ----------------
+    def phi(self, xs, us, p, need=0):
+        x = xs * self.sx
+        u = us * self.su
+        if need == 0:
+            return self.smap.value(x, u, p, self.dt) / self.sx
+        f, J, H = self.smap(x, u, p, self.dt)
+        sz = np.concatenate([self.sx, self.su])
+        J = J * sz[None, None, :] / self.sx[None, :, None]
+        H = H * sz[None, None, :, None] * sz[None, None, None, :] / self.sx[None, :, None, None]
+        return f / self.sx, J, H
+
+    def u_of(self, U, k):
+        """mpc.py:1629-1630: beyond the control horizon the last input is held."""
+        return U[:, min(k, self.Nc - 1)]
+
+    # ---- reference-layout NLP functions on v (for the independent scipy cross-check) ------------------------
+    def split(self, v):
+        v = np.atleast_2d(v)
+        X = v[:, :(self.N + 1) * self.nx].reshape(-1, self.N + 1, self.nx)
+        U = v[:, (self.N + 1) * self.nx:].reshape(-1, self.Nc, self.nu)
+        return X, U
+
+    def join(self, X, U):
+        return np.concatenate([X.reshape(X.shape[0], -1), U.reshape(U.shape[0], -1)], axis=1)
+
+    def objective(self, v, p, u_old=None):
+        """mpc.py:1676-1682: J = sum_k l(x_k,u_k) + V(Phi(x_{N-1},u_{N-1}))."""
+        X, U = self.split(v)
+        B = X.shape[0]
+        J = np.zeros(B)
+        for k in range(self.N):
+            z = np.concatenate([X[:, k], self.u_of(U, k)], axis=1) - self.zref
+            J += np.einsum('bi,ij,bj->b', z, self.Wz, z)
+            if k == 0 and u_old is not None:                     # mpc.py:1631-1635
+                d = U[:, 0] - np.atleast_2d(u_old)
+                J += np.einsum('bi,ij,bj->b', d, self.Wdu, d)
+        xN = self.phi(X[:, self.N - 1], self.u_of(U, self.N - 1), p)
+        d = xN - self.xrefN
+        return J + np.einsum('bi,ij,bj->b', d, self.WN, d)
+
+    def constraints(self, v, p):
+        """mpc.py:1667: g = [x_{k+1} - Phi(x_k,u_k)]_k."""
+        X, U = self.split(v)
+        g = [X[:, k + 1] - self.phi(X[:, k], self.u_of(U, k), p) for k in range(self.N)]
+        return np.concatenate(g, axis=1)
+
+
+# ==================================================================================================
+# dense primal-dual interior point (batched over instances)
+# ==================================================================================================
+class IpmOptions:
+    tol = 1e-8
+    acceptable_tol = 1e-6
+    acceptable_iter = 15
+    max_iter = 3000
+    mu_init = 0.1
+    kappa_eps = 10.
+    kappa_mu = 0.2
+    theta_mu = 1.5
+    tau_min = 0.99
+    bound_push = 1e-2
+    bound_frac = 1e-2
+    bound_relax_factor = 1e-8
+    s_max = 100.
+    kappa_sigma = 1e10
+    # filter line search
+    gamma_theta = 1e-5
+    gamma_phi = 1e-8
+    delta = 1.
+    s_theta = 1.1
+    s_phi = 2.3
+    eta_phi = 1e-8
+    theta_min_fact = 1e-4
+    theta_max_fact = 1e4
+    alpha_red = 0.5
+    alpha_min_frac = 0.05
+    max_filter = 16
+    # inertia correction
+    delta_w_min = 1e-20
+    delta_w_0 = 1e-4
+    delta_w_max = 1e40
+    kappa_w_minus = 1. / 3
+    kappa_w_plus = 8.
+    kappa_w_plus_bar = 100.
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise ValueError(f"unknown option {k}")
+            setattr(self, k, v)
+
+
+def _push_interior(w, lb, ub, o):
+    """IPOPT initialisation (Waechter & Biegler sec. 3.6): x <- P[x] with kappa_1 = kappa_2 = bound_push/frac."""
+    w = w.copy()
+    has_l, has_u = np.isfinite(lb), np.isfinite(ub)
+    both = has_l & has_u
+    pl = np.where(both, np.minimum(o.bound_push * np.maximum(1, np.abs(lb)), o.bound_frac * (ub - lb)),
+                  o.bound_push * np.maximum(1, np.abs(lb)))
+    pu = np.where(both, np.minimum(o.bound_push * np.maximum(1, np.abs(ub)), o.bound_frac * (ub - lb)),
+                  o.bound_push * np.maximum(1, np.abs(ub)))
+    with np.errstate(invalid='ignore'):
+        w = np.where(has_l, np.maximum(w, lb + pl), w)
+        w = np.where(has_u, np.minimum(w, ub - pu), w)
+    return w
+
+
+class DenseIpm:
+    """Solves min f(w) s.t. c(w) = 0, l <= w <= u for a batch of NMPC instances.
+
+    Free variables w = [x_1..x_N | u_0..u_{N-1}] (x_0 is fixed by its bounds, mpc.py:797-802, and removed like
+    IPOPT's default `fixed_variable_treatment = make_parameter`).  Requires Nc == N."""
+
+    def __init__(self, prob: NmpcProblem, options: IpmOptions | None = None):
+        assert prob.Nc == prob.N, "oracle IPM: control horizon must equal the prediction horizon"
+        self.pb = prob
+        self.o = options or IpmOptions()
+        N, nx, nu = prob.N, prob.nx, prob.nu
+        self.nw = N * (nx + nu)
+        self.m = N * nx
+        self.ix = [list(range(k * nx, (k + 1) * nx)) for k in range(N)]            # x_{k+1}
+        self.iu = [list(range(N * nx + k * nu, N * nx + (k + 1) * nu)) for k in range(N)]
+        lb = np.concatenate([np.tile(prob.x_lb, N), np.tile(prob.u_lb, N)])
+        ub = np.concatenate([np.tile(prob.x_ub, N), np.tile(prob.u_ub, N)])
+        r = self.o.bound_relax_factor
+        self.lb = np.where(np.isfinite(lb), lb - r * np.maximum(1, np.abs(lb)), lb)
+        self.ub = np.where(np.isfinite(ub), ub + r * np.maximum(1, np.abs(ub)), ub)
+        self.has_l, self.has_u = np.isfinite(self.lb), np.isfinite(self.ub)
+
+    # ---- stage-wise evaluation -------------------------------------------------------------------------------
+    def _XU(self, w, x0):
+        pb = self.pb
+        B = w.shape[0]
+        X = np.concatenate([x0[:, None, :], w[:, :pb.N * pb.nx].reshape(B, pb.N, pb.nx)], axis=1)
+        U = w[:, pb.N * pb.nx:].reshape(B, pb.N, pb.nu)
+        return X, U
+
+    def eval_fc(self, w, x0, p, u_old):
+        """objective (with the terminal term on x_N, which equals Phi_{N-1} on the feasible set) and defects."""
+        pb = self.pb
+        X, U = self._XU(w, x0)
+        B = w.shape[0]
+        f = np.zeros(B)
+        c = np.empty((B, pb.N, pb.nx))
+        for k in range(pb.N):
+            z = np.concatenate([X[:, k], U[:, k]], axis=1) - pb.zref
+            f += np.einsum('bi,ij,bj->b', z, pb.Wz, z)
+            c[:, k] = X[:, k + 1] - pb.phi(X[:, k], U[:, k], p)
+        if u_old is not None:
+            d = U[:, 0] - u_old
+            f += np.einsum('bi,ij,bj->b', d, pb.Wdu, d)
+        d = X[:, pb.N] - pb.xrefN
+        f += np.einsum('bi,ij,bj->b', d, pb.WN, d)
+        return f, c.reshape(B, -1)
+
+    def eval_all(self, w, lam, x0, p, u_old):
+        """f, grad f, c, J (dense), W = hess_ww (f + lam^T c) (dense)."""
+        pb = self.pb
+        N, nx, nu, nz = pb.N, pb.nx, pb.nu, pb.nz
+        X, U = self._XU(w, x0)
+        B = w.shape[0]
+        f = np.zeros(B)
+        g = np.zeros((B, self.nw))
+        c = np.empty((B, N, nx))
+        J = np.zeros((B, self.m, self.nw))
+        W = np.zeros((B, self.nw, self.nw))
+        lam = lam.reshape(B, N, nx)
+        for k in range(N):
+            zi = (self.ix[k - 1] if k > 0 else []) + self.iu[k]           # free columns of stage k's z
+            sel = (list(range(nx)) if k > 0 else []) + list(range(nx, nz))
+            z = np.concatenate([X[:, k], U[:, k]], axis=1) - pb.zref
+            f += np.einsum('bi,ij,bj->b', z, pb.Wz, z)
+            gz = 2 * z @ pb.Wz
+            Hz = np.broadcast_to(2 * pb.Wz, (B, nz, nz)).copy()
+            Phi, Jk, Hk = pb.phi(X[:, k], U[:, k], p, need=2)
+            c[:, k] = X[:, k + 1] - Phi
+            Hz -= np.einsum('bm,bmzy->bzy', lam[:, k], Hk)
+            if k == 0 and u_old is not None:
+                d = U[:, 0] - u_old
+                f += np.einsum('bi,ij,bj->b', d, pb.Wdu, d)
+                gz[:, nx:] += 2 * d @ pb.Wdu
+                Hz[:, nx:, nx:] += 2 * pb.Wdu
+            g[:, zi] += gz[:, sel]
+            W[np.ix_(range(B), zi, zi)] += Hz[np.ix_(range(B), sel, sel)]
+            rows = list(range(k * nx, (k + 1) * nx))
+            J[np.ix_(range(B), rows, zi)] = -Jk[:, :, sel]
+            J[:, rows, self.ix[k]] = 1.0
+        d = X[:, N] - pb.xrefN
+        f += np.einsum('bi,ij,bj->b', d, pb.WN, d)
+        g[:, self.ix[N - 1]] += 2 * d @ pb.WN
+        W[np.ix_(range(B), self.ix[N - 1], self.ix[N - 1])] += 2 * pb.WN
+        return f, g, c.reshape(B, -1), J, W
+
+    # ---- barrier pieces ---------------------------------------------------------------------------------------
+    def _slacks(self, w):
+        sl = np.where(self.has_l, w - self.lb, 1.0)
+        su = np.where(self.has_u, self.ub - w, 1.0)
+        return sl, su
+
+    def barrier(self, f, w, mu):
+        sl, su = self._slacks(w)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            return f - mu * (np.where(self.has_l, np.log(sl), 0).sum(1) + np.where(self.has_u, np.log(su), 0).sum(1))
+
+    def errors(self, g, c, J, lam, zl, zu, w, mu):
+        o = self.o
+        sl, su = self._slacks(w)
+        r_d = g + np.einsum('bmi,bm->bi', J, lam) - zl + zu
+        dual = np.abs(r_d).max(1)
+        prim = np.abs(c).max(1) if c.shape[1] else np.zeros(w.shape[0])
+        cl = np.where(self.has_l, np.abs(sl * zl - mu[:, None]), 0).max(1)
+        cu = np.where(self.has_u, np.abs(su * zu - mu[:, None]), 0).max(1)
+        nb = max(1, int(self.has_l.sum() + self.has_u.sum()))
+        zsum = np.abs(zl).sum(1) + np.abs(zu).sum(1)
+        s_d = np.maximum(o.s_max, (np.abs(lam).sum(1) + zsum) / (self.m + nb)) / o.s_max
+        s_c = np.maximum(o.s_max, zsum / nb) / o.s_max
+        return np.maximum.reduce([dual / s_d, prim, np.maximum(cl, cu) / s_c]), dual, prim, np.maximum(cl, cu)
+
+    # ---- main loop --------------------------------------------------------------------------------------------
+    def solve(self, x0, p, w0=None, u_old=None, verbose=False):
+        """x0 [B,nx] original units; p [B,np] or [np]; w0 optional warm start (free variables, scaled).
+        Returns dict(w, lam, zl, zu, f, status, iters, X, U, kkt)."""
+        o, pb = self.o, self.pb
+        x0 = np.atleast_2d(np.asarray(x0, dtype=float)) / pb.sx
+        B = x0.shape[0]
+        p = np.broadcast_to(np.atleast_2d(np.asarray(p, dtype=float)), (B, pb.np_)) if pb.np_ else np.zeros((B, 0))
+        if u_old is not None:
+            u_old = np.broadcast_to(np.atleast_2d(np.asarray(u_old, dtype=float)), (B, pb.nu))
+        if w0 is None:
+            w0 = np.concatenate([np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N)])
+        w = _push_interior(np.broadcast_to(np.atleast_2d(w0), (B, self.nw)), self.lb, self.ub, o)
+        lam = np.zeros((B, self.m))
+        zl = np.where(self.has_l, 1.0, 0.0) * np.ones((B, 1))
+        zu = np.where(self.has_u, 1.0, 0.0) * np.ones((B, 1))
+        mu = np.full(B, o.mu_init)
+        tau = np.maximum(o.tau_min, 1 - mu)
+        status = np.zeros(B, dtype=np.int32)
+        iters = np.zeros(B, dtype=np.int32)
+        acc_count = np.zeros(B, dtype=np.int32)
+        delta_last = np.zeros(B)
+        filt = [[] for _ in range(B)]
+        f, c = self.eval_fc(w, x0, p, u_old)
+        theta0 = np.abs(c).sum(1)
+        theta_min = o.theta_min_fact * np.maximum(1, theta0)
+        theta_max = o.theta_max_fact * np.maximum(1, theta0)
+        active = np.ones(B, dtype=bool)
+
+        for it in range(o.max_iter + 1):
+            idx = np.nonzero(active)[0]
+            if idx.size == 0:
+                break
+            f_a, g, c, J, Wl = self.eval_all(w[idx], lam[idx], x0[idx], p[idx], None if u_old is None else u_old[idx])
+            E0, dual, prim, compl = self.errors(g, c, J, lam[idx], zl[idx], zu[idx], w[idx], np.zeros(idx.size))
+            done = E0 <= o.tol
+            status[idx[done]] = SOLVED
+            acc = (E0 <= o.acceptable_tol) & ~done
+            acc_count[idx] = np.where(acc, acc_count[idx] + 1, 0)
+            acc_done = acc_count[idx] >= o.acceptable_iter
+            status[idx[acc_done & ~done]] = ACCEPTABLE
+            fin = done | acc_done
+            if it == o.max_iter:
+                status[idx[~fin]] = MAXITER
+                fin = np.ones_like(fin)
+            active[idx[fin]] = False
+            if verbose:
+                print(f"it {it:3d} active {idx.size:4d} E0 max {E0.max():.3e} mu {mu[idx].max():.1e}")
+            keep = ~fin
+            if not keep.any():
+                continue
+            idx, f_a, g, c, J, Wl = idx[keep], f_a[keep], g[keep], c[keep], J[keep], Wl[keep]
+            nb = idx.size
+            # ---- barrier parameter update (monotone; W&B eq. 7) ----
+            for _ in range(20):
+                Emu = self.errors(g, c, J, lam[idx], zl[idx], zu[idx], w[idx], mu[idx])[0]
+                dec = (Emu <= o.kappa_eps * mu[idx]) & (mu[idx] > o.tol / 10 * (1 + 1e-12))
+                if not dec.any():
+                    break
+                j = idx[dec]
+                mu[j] = np.maximum(o.tol / 10, np.minimum(o.kappa_mu * mu[j], mu[j] ** o.theta_mu))
+                tau[j] = np.maximum(o.tau_min, 1 - mu[j])
+                for b in j:
+                    filt[b] = []
+            # ---- search direction with inertia correction ----
+            sl, su = self._slacks(w[idx])
+            Sig = np.where(self.has_l, zl[idx] / sl, 0) + np.where(self.has_u, zu[idx] / su, 0)
+            rhs1 = -(g - np.where(self.has_l, mu[idx, None] / sl, 0) + np.where(self.has_u, mu[idx, None] / su, 0))
+            d = np.zeros((nb, self.nw))
+            lam_new = np.zeros((nb, self.m))
+            delta = np.zeros(nb)
+            todo = np.ones(nb, dtype=bool)
+            first_try = np.ones(nb, dtype=bool)
+            fail = np.zeros(nb, dtype=bool)
+            while todo.any():
+                t = np.nonzero(todo)[0]
+                K = np.zeros((t.size, self.nw + self.m, self.nw + self.m))
+                K[:, :self.nw, :self.nw] = Wl[t] + np.einsum('bi,ij->bij', Sig[t] + delta[t, None], np.eye(self.nw))
+                K[:, :self.nw, self.nw:] = np.swapaxes(J[t], 1, 2)
+                K[:, self.nw:, :self.nw] = J[t]
+                ev = np.linalg.eigvalsh(K)
+                good = ((ev < 0).sum(1) == self.m) & ((ev > 0).sum(1) == self.nw)
+                if good.any():
+                    tg = t[good]
+                    sol = np.linalg.solve(K[good], np.concatenate([rhs1[tg], -c[tg]], axis=1)[:, :, None])[:, :, 0]
+                    d[tg] = sol[:, :self.nw]
+                    lam_new[tg] = sol[:, self.nw:]
+                    todo[tg] = False
+                tb = t[~good]
+                for b in tb:                                       # W&B Alg. IC
+                    if first_try[b]:
+                        dl = delta_last[idx[b]]
+                        delta[b] = o.delta_w_0 if dl == 0 else max(o.delta_w_min, o.kappa_w_minus * dl)
+                        first_try[b] = False
+                    else:
+                        delta[b] *= o.kappa_w_plus_bar if delta_last[idx[b]] == 0 else o.kappa_w_plus
+                    if delta[b] > o.delta_w_max:
+                        fail[b] = True
+                        todo[b] = False
+            used = delta > 0
+            delta_last[idx[used]] = delta[used]
+            dzl = np.where(self.has_l, mu[idx, None] / sl - zl[idx] - zl[idx] / sl * d, 0)
+            dzu = np.where(self.has_u, mu[idx, None] / su - zu[idx] + zu[idx] / su * d, 0)
+            # ---- fraction to the boundary (W&B eq. 8) ----
+            with np.errstate(divide='ignore', invalid='ignore'):
+                a1 = np.where(self.has_l & (d < 0), -tau[idx, None] * sl / d, np.inf).min(1)
+                a2 = np.where(self.has_u & (d > 0), tau[idx, None] * su / d, np.inf).min(1)
+                alpha_max = np.minimum(1.0, np.minimum(a1, a2))
+                b1 = np.where(self.has_l & (dzl < 0), -tau[idx, None] * zl[idx] / dzl, np.inf).min(1)
+                b2 = np.where(self.has_u & (dzu < 0), -tau[idx, None] * zu[idx] / dzu, np.inf).min(1)
+                alpha_z = np.minimum(1.0, np.minimum(b1, b2))
+            # ---- filter line search (W&B Alg. A without SOC / restoration) ----
+            phi0 = self.barrier(f_a, w[idx], mu[idx])
+            th0 = np.abs(c).sum(1)
+            sl_, su_ = sl, su
+            gphi = g - np.where(self.has_l, mu[idx, None] / sl_, 0) + np.where(self.has_u, mu[idx, None] / su_, 0)
+            dphi = np.einsum('bi,bi->b', gphi, d)
+            alpha = alpha_max.copy()
+            accepted = np.zeros(nb, dtype=bool)
+            armijo_type = np.zeros(nb, dtype=bool)
+            accepted[fail] = True                                   # nothing to search
+            w_new = w[idx].copy()
+            for ls in range(60):
+                t = np.nonzero(~accepted)[0]
+                if t.size == 0:
+                    break
+                wt = w[idx[t]] + alpha[t, None] * d[t]
+                ft, ct = self.eval_fc(wt, x0[idx[t]], p[idx[t]], None if u_old is None else u_old[idx[t]])
+                pht = self.barrier(ft, wt, mu[idx[t]])
+                tht = np.abs(ct).sum(1)
+                for q, b in enumerate(t):
+                    gb = idx[b]
+                    ok = np.isfinite(pht[q]) and np.isfinite(tht[q]) and tht[q] <= theta_max[gb]
+                    if ok:
+                        for (tf, pf) in filt[gb]:
+                            if tht[q] >= tf and pht[q] - 10 * np.finfo(float).eps * abs(pf) >= pf:
+                                ok = False
+                                break
+                    sw = False
+                    if ok:
+                        sw = (th0[b] <= theta_min[gb]) and (dphi[b] < 0) and \
+                             (alpha[b] * (-dphi[b]) ** o.s_phi > o.delta * th0[b] ** o.s_theta)
+                        rnd = 10 * np.finfo(float).eps * abs(phi0[b])       # IPOPT's round-off slack in comparisons
+                        if sw:
+                            ok = pht[q] - phi0[b] - rnd <= o.eta_phi * alpha[b] * dphi[b]
+                        else:
+                            ok = (tht[q] <= (1 - o.gamma_theta) * th0[b]) or \
+                                 (pht[q] - phi0[b] - rnd <= -o.gamma_phi * th0[b])
+                    if ok:
+                        accepted[b] = True
+                        armijo_type[b] = sw
+                        w_new[b] = wt[q]
+                    else:
+                        alpha[b] *= o.alpha_red
+                        if alpha[b] < 1e-12:
+                            fail[b] = True
+                            accepted[b] = True
+            bad = fail
+            status[idx[bad]] = RESTORATION_FAILED
+            active[idx[bad]] = False
+            good = ~bad
+            for b in np.nonzero(good & ~armijo_type)[0]:           # augment the filter (W&B eq. 22)
+                gb = idx[b]
+                filt[gb].append(((1 - o.gamma_theta) * th0[b], phi0[b] - o.gamma_phi * th0[b]))
+                if len(filt[gb]) > o.max_filter:
+                    filt[gb].pop(0)
+            gi = idx[good]
+            w[gi] = w_new[good]
+            lam[gi] = lam[gi] + alpha[good, None] * (lam_new[good] - lam[gi])
+            zl[gi] = zl[gi] + alpha_z[good, None] * dzl[good]
+            zu[gi] = zu[gi] + alpha_z[good, None] * dzu[good]
+            # W&B eq. 16: keep z within [mu/(kappa s), kappa mu / s]
+            sl, su = self._slacks(w[gi])
+            zl[gi] = np.where(self.has_l, np.clip(zl[gi], mu[gi, None] / (o.kappa_sigma * sl), o.kappa_sigma * mu[gi, None] / sl), 0)
+            zu[gi] = np.where(self.has_u, np.clip(zu[gi], mu[gi, None] / (o.kappa_sigma * su), o.kappa_sigma * mu[gi, None] / su), 0)
+            iters[gi] += 1
+
+        f, g, c, J, Wl = self.eval_all(w, lam, x0, p, u_old)
+        E0, dual, prim, compl = self.errors(g, c, J, lam, zl, zu, w, np.zeros(B))
+        X, U = self._XU(w, x0)
+        return dict(w=w, lam=lam, zl=zl, zu=zu, f=f, status=status, iters=iters, X=X, U=U, kkt=E0,
+                    dual_inf=dual, prim_inf=prim, compl=compl, u0=U[:, 0] * pb.su)
+
+    # ---- reference layout helpers -----------------------------------------------------------------------------
+    def to_v(self, res):
+        return self.pb.join(res['X'], res['U'])
+
+    def w_from_v(self, v):
+        X, U = self.pb.split(v)
+        return np.concatenate([X[:, 1:].reshape(X.shape[0], -1), U.reshape(U.shape[0], -1)], axis=1)

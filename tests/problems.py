@@ -1,0 +1,50 @@
+"""Shared plain problem specs (SURVEY.md 8d synthetic configurations), buildable as oracle or product objects."""
+import numpy as np
+
+SEED = 20260926
+
+C2 = dict(                       # tracking NMPC on the CSTR-sized chemostat (nx=4, nu=2, N=20)
+    model='chemostat4', dt=1., N=20, order=4,
+    stage_states=[([2], [10.], [2.])],           # P -> 2, weight 10 (nmpc_hybrid_bio.ipynb cell 16 pattern)
+    stage_inputs=[([0, 1], [.1, .1], None)],
+    terminal_states=[([2], [10.], [2.])],
+    x_lb=[0., 0., 0., 0.], u_lb=[0., 0.], u_ub=[1., 1.],
+    x_guess=[.1, 40., 0., 0.], u_guess=[0., 0.],
+    p=[100., 4., 1., 0.],
+)
+
+
+def c2_x0(B, seed=SEED):
+    rng = np.random.default_rng(seed)
+    return np.array([.1, 40., 0., 0.]) * (1 + .1 * rng.uniform(-1, 1, (B, 4)))
+
+
+def oracle_problem(spec):
+    from oracle import models
+    from oracle.nmpc import NmpcProblem
+    kw = {k: v for k, v in spec.items() if k not in ('model', 'p')}
+    return NmpcProblem(models.get(spec['model']), **kw)
+
+
+def product_nmpc(spec, **solver_options):
+    """Build the product NMPC for a plain spec through the reference-style API."""
+    from hilo_mpc_amd import NMPC, Model
+    m = Model(spec['model']).discretize('erk', order=spec.get('order', 4)).setup(dt=spec['dt'])
+    nmpc = NMPC(m)
+    xs, us = m.dynamical_state_names, m.input_names
+    for ind, W, ref in spec.get('stage_states', []):
+        nmpc.quad_stage_cost.add_states(names=[xs[i] for i in ind], weights=list(W), ref=ref)
+    for ind, W, ref in spec.get('stage_inputs', []):
+        nmpc.quad_stage_cost.add_inputs(names=[us[i] for i in ind], weights=list(W), ref=ref)
+    if spec.get('input_change'):
+        ind, W = spec['input_change']
+        nmpc.quad_stage_cost.add_inputs_change(names=[us[i] for i in ind], weights=list(W))
+    for ind, W, ref in spec.get('terminal_states', []):
+        nmpc.quad_terminal_cost.add_states(names=[xs[i] for i in ind], weights=list(W), ref=ref)
+    nmpc.horizon = spec['N']
+    nmpc.set_box_constraints(x_ub=spec.get('x_ub'), x_lb=spec.get('x_lb'), u_ub=spec.get('u_ub'), u_lb=spec.get('u_lb'))
+    nmpc.set_initial_guess(x_guess=spec.get('x_guess'), u_guess=spec.get('u_guess'))
+    if spec.get('x_scaling') or spec.get('u_scaling'):
+        nmpc.set_scaling(x_scaling=spec.get('x_scaling'), u_scaling=spec.get('u_scaling'))
+    nmpc.setup(options={'integration_method': 'discrete'}, solver_options=solver_options or None)
+    return nmpc
