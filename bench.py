@@ -46,6 +46,22 @@ def flops_per_iteration(nx, nu, N, s=4):
     return N * (f_ric + f_dyn)
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per solve launch from the committed rocprofv3 PMC passes (profiles/rNN_summary.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs of this same command).  Calibration (MI355X_MICROARCH.md, HBM section):
+    the kernel reads with 8-byte lanes; against the known per-launch read count (B * (n_v + nx + np) * 8 B) FETCH_SIZE
+    reads 0.9x, so no 2x correction applies to this access pattern; WRITE_SIZE matches the known write count."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_summary.json'))):
+        try:
+            d = json.load(open(f))
+            best = (d['FETCH_SIZE_KB_per_launch']['warm_launches_mean'] + d['WRITE_SIZE_KB_per_launch']['warm_launches_mean']) * 1024
+        except Exception:
+            pass
+    return best
+
+
 def cpu_baseline(spec, x0_sample, n_steps):
     """Oracle port (numpy dense IPM) on a bounded sample: cold solve (untimed warm-up of the closed loop) then
     `n_steps` warm-started closed-loop steps, 1 core."""
@@ -151,13 +167,14 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"instances sharded x{world}",
                        "mean_ipm_iters": mean_iters, "frac_status_1_or_2": ok_frac, "max_kkt_error": kkt_max},
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(),
                          "kernel": "nmpc_solve_kernel<Chemostat4>", "kernel_ms": kern_ms,
                          "note": "fp64 roof: MI355X fp64 vector peak == fp64 MFMA peak = 78.6 TFLOP/s; the kernel is "
                                  "fp64 VALU/latency bound (no MFMA), algorithmic flops = B * mean_iters * N * "
                                  "(F_ric + F_dyn), see DESIGN.md"},
             "roofline_hbm": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                             "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
+                             "algorithmic_bytes_per_launch": bytes_launch,
                              "note": "compulsory bytes only (iterate + parameters in/out); not the binding roof"},
         }
         if not args.no_cpu_baseline:
