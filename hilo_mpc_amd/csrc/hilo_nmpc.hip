@@ -284,25 +284,30 @@ struct Nmpc {
 
   // ---- Riccati factor + solve of the Newton system; returns false when a reduced pivot is not positive ------
   // Hessian block of stage k: W_k + diag(Sigma_k) + delta I ; rhs r = grad - mu/sl + mu/su (slot-wise)
-  __device__ static bool riccati(const NmpcConst& pc, const Lds& l, double mu, double delta) {
+  // `resto` = feasibility-restoration step: H = I, zero gradient (least-norm d with J d = -c)
+  __device__ static bool riccati(const NmpcConst& pc, const Lds& l, double mu, double delta, bool resto = false) {
     const int N = pc.N, t = threadIdx.x, T = blockDim.x;
     // terminal: P_N = 2 WN + Sigma + delta, p_N = r_N
     for (int e = t; e < NX * NX + NX; e += T) {
       if (e < NX * NX) {
         const int i = e / NX, j = e - i * NX;
-        double v = 2.0 * pc.WN[e];
+        double v = resto ? 0.0 : 2.0 * pc.WN[e];
         if (i == j) {
           const int s = N * NZ + i;
-          v += delta;
-          if (pc.lbz[i] > -INFINITY) v += l.zL[s] / (l.Z[s] - pc.lbz[i]);
-          if (pc.ubz[i] < INFINITY) v += l.zU[s] / (pc.ubz[i] - l.Z[s]);
+          v += resto ? 1.0 : delta;
+          if (!resto) {
+            if (pc.lbz[i] > -INFINITY) v += l.zL[s] / (l.Z[s] - pc.lbz[i]);
+            if (pc.ubz[i] < INFINITY) v += l.zU[s] / (pc.ubz[i] - l.Z[s]);
+          }
         }
         l.P[N * NX * NX + e] = v;
       } else {
         const int i = e - NX * NX, s = N * NZ + i;
-        double v = l.grad[s];
-        if (pc.lbz[i] > -INFINITY) v -= mu / (l.Z[s] - pc.lbz[i]);
-        if (pc.ubz[i] < INFINITY) v += mu / (pc.ubz[i] - l.Z[s]);
+        double v = resto ? 0.0 : l.grad[s];
+        if (!resto) {
+          if (pc.lbz[i] > -INFINITY) v -= mu / (l.Z[s] - pc.lbz[i]);
+          if (pc.ubz[i] < INFINITY) v += mu / (pc.ubz[i] - l.Z[s]);
+        }
         l.pv[N * NX + i] = v;
       }
     }
@@ -333,13 +338,13 @@ struct Nmpc {
       for (int e = t; e < NZ * NZ + NZ; e += T) {
         if (e < NZ * NZ) {
           const int i = e / NZ, j = e - i * NZ;
-          double s = l.W[k * NZ * NZ + e];
+          double s = resto ? 0.0 : l.W[k * NZ * NZ + e];
 #pragma unroll
           for (int m = 0; m < NX; ++m) s += AB[m * NZ + i] * l.T1[m * NZ + j];
           if (i == j) {
             const int sl = k * NZ + i;
-            s += delta;
-            if (is_free(N, k, i)) {
+            s += resto ? 1.0 : delta;
+            if (!resto && is_free(N, k, i)) {
               if (pc.lbz[i] > -INFINITY) s += l.zL[sl] / (l.Z[sl] - pc.lbz[i]);
               if (pc.ubz[i] < INFINITY) s += l.zU[sl] / (pc.ubz[i] - l.Z[sl]);
             }
@@ -347,8 +352,8 @@ struct Nmpc {
           l.Mm[e] = s;
         } else {
           const int i = e - NZ * NZ, sl = k * NZ + i;
-          double s = l.grad[sl];
-          if (is_free(N, k, i)) {
+          double s = resto ? 0.0 : l.grad[sl];
+          if (!resto && is_free(N, k, i)) {
             if (pc.lbz[i] > -INFINITY) s -= mu / (l.Z[sl] - pc.lbz[i]);
             if (pc.ubz[i] < INFINITY) s += mu / (pc.ubz[i] - l.Z[sl]);
           }
@@ -454,6 +459,56 @@ struct Nmpc {
     }
     __syncthreads();
     return true;
+  }
+
+  // ---- feasibility restoration, simplified from W&B sec. 3.3 (same statement as oracle/nmpc.py::_restore):
+  // least-norm Newton steps on c(w) = 0 with the fraction-to-the-boundary rule and an Armijo search on
+  // theta = |c|_1 until theta <= 0.9 theta_start and the point is acceptable to the filter.
+  __device__ static bool restore(const NmpcConst& pc, const Lds& l, const double* uo, double mu, double tau,
+                                 int nfilt, double theta_max) {
+    const int N = pc.N, t = threadIdx.x, T = blockDim.x, SL = (N + 1) * NZ;
+    double th = 0.0;
+    for (int e = t; e < N * NX; e += T) th += fabs(l.c[e]);
+    th = block_reduce<OpSum>(th, l.red);
+    const double th_start = th;
+    for (int it = 0; it < 50; ++it) {
+      riccati(pc, l, mu, 0.0, true);
+      double a = 1.0;
+      for (int e = t; e < SL; e += T) {
+        const int k = e / NZ, i = e - k * NZ;
+        if (!is_free(N, k, i)) continue;
+        const double d = l.D[e];
+        if (pc.lbz[i] > -INFINITY && d < 0.0) a = fmin(a, -tau * (l.Z[e] - pc.lbz[i]) / d);
+        if (pc.ubz[i] < INFINITY && d > 0.0) a = fmin(a, tau * (pc.ubz[i] - l.Z[e]) / d);
+      }
+      double alpha = block_reduce<OpMin>(a, l.red);
+      bool ok = false;
+      double tht = 0.0;
+      while (alpha > 1e-10) {
+        for (int e = t; e < SL; e += T) l.Zt[e] = l.Z[e] + alpha * l.D[e];
+        __syncthreads();
+        eval_defects(pc, l, l.Zt, l.ct);
+        __syncthreads();
+        tht = 0.0;
+        for (int e = t; e < N * NX; e += T) tht += fabs(l.ct[e]);
+        tht = block_reduce<OpSum>(tht, l.red);
+        if (isfinite(tht) && tht <= (1.0 - 1e-4 * alpha) * th) { ok = true; break; }
+        alpha *= 0.5;
+      }
+      if (!ok) return false;
+      for (int e = t; e < SL; e += T) l.Z[e] = l.Zt[e];
+      __syncthreads();
+      th = tht;
+      if (th <= 0.9 * th_start && th <= theta_max) {
+        const double ph = eval_objective(pc, l, l.Z, uo) + eval_barrier(pc, l, l.Z, mu);
+        bool acc = true;
+        for (int q = 0; q < nfilt; ++q)
+          if (th >= l.filt[2 * q] && ph >= l.filt[2 * q + 1]) { acc = false; break; }
+        if (acc) return true;
+      }
+      eval_derivs(pc, l, uo);
+    }
+    return false;
   }
 };
 
@@ -617,10 +672,16 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const NmpcConst* __restr
       }
       if (ok) { accepted = true; armijo = sw; break; }
       alpha *= 0.5;
-      if (alpha < 1e-12) break;
+      // W&B eq. 23: below alpha_min the line search gives up and the restoration phase is called
+      double amin = pc.gamma_theta;
+      if (dphi < 0.0) {
+        amin = fmin(amin, pc.gamma_phi * th0 / (-dphi));
+        if (th0 <= theta_min) amin = fmin(amin, pc.delta_ls * pow(th0, pc.s_theta) / pow(-dphi, pc.s_phi));
+      }
+      if (alpha < 0.05 * amin) break;
     }
-    if (!accepted) { st = HILO_STATUS_RESTORATION_FAILED; break; }
-    if (!armijo) {  // augment the filter (W&B eq. 22)
+    const bool do_resto = !accepted;
+    if (!armijo || do_resto) {  // augment the filter (W&B eq. 22); also done before entering restoration
       if (nfilt == NMPC_FILTER) {
         for (int q = t; q < 2 * (NMPC_FILTER - 1); q += T) l.filt[q] = l.filt[q + 2];
         nfilt = NMPC_FILTER - 1;
@@ -631,6 +692,25 @@ __global__ __launch_bounds__(64) void nmpc_solve_kernel(const NmpcConst* __restr
         l.filt[2 * nfilt + 1] = phi0 - pc.gamma_phi * th0;
       }
       ++nfilt;
+      __syncthreads();
+    }
+    if (do_resto) {
+      if (!S::restore(pc, l, uo, mu, tau, nfilt, theta_max)) { st = HILO_STATUS_RESTORATION_FAILED; break; }
+      // IPOPT after restoration: equality multipliers reset (constr_mult_reset_threshold = 0), bound multipliers
+      // reset to 1 when they exceed bound_mult_reset_threshold = 1000
+      double zm = 0.0;
+      for (int e = t; e < SL; e += T) zm = fmax(zm, fmax(l.zL[e], l.zU[e]));
+      zm = block_reduce<OpMax>(zm, l.red);
+      for (int e = t; e < SL; e += T) {
+        const int k = e / NZ, i = e - k * NZ;
+        if (zm > 1e3 && S::is_free(N, k, i)) {
+          l.zL[e] = pc.lbz[i] > -INFINITY ? 1.0 : 0.0;
+          l.zU[e] = pc.ubz[i] < INFINITY ? 1.0 : 0.0;
+        }
+      }
+      for (int e = t; e < N * NX; e += T) l.lam[e] = 0.0;
+      __syncthreads();
+      continue;
     }
     // ---- accept: primal, equality multipliers, bound multipliers (+ W&B eq. 16 safeguard) ----
     for (int e = t; e < SL; e += T) {

@@ -350,6 +350,7 @@ class DenseIpm:
         iters = np.zeros(B, dtype=np.int32)
         acc_count = np.zeros(B, dtype=np.int32)
         delta_last = np.zeros(B)
+        n_resto = np.zeros(B, dtype=np.int32)
         filt = [[] for _ in range(B)]
         f, c = self.eval_fc(w, x0, p, u_old)
         theta0 = np.abs(c).sum(1)
@@ -447,6 +448,7 @@ class DenseIpm:
             dphi = np.einsum('bi,bi->b', gphi, d)
             alpha = alpha_max.copy()
             accepted = np.zeros(nb, dtype=bool)
+            resto = np.zeros(nb, dtype=bool)
             armijo_type = np.zeros(nb, dtype=bool)
             accepted[fail] = True                                   # nothing to search
             w_new = w[idx].copy()
@@ -482,9 +484,34 @@ class DenseIpm:
                         w_new[b] = wt[q]
                     else:
                         alpha[b] *= o.alpha_red
-                        if alpha[b] < 1e-12:
-                            fail[b] = True
+                        # W&B eq. 23: below alpha_min the line search gives up and restoration is called
+                        amin = o.gamma_theta
+                        if dphi[b] < 0:
+                            amin = min(amin, o.gamma_phi * th0[b] / (-dphi[b]))
+                            if th0[b] <= theta_min[gb]:
+                                amin = min(amin, o.delta * th0[b] ** o.s_theta / (-dphi[b]) ** o.s_phi)
+                        if alpha[b] < o.alpha_min_frac * amin:
+                            resto[b] = True
                             accepted[b] = True
+            # ---- feasibility restoration (simplified W&B sec. 3.3) for the instances whose line search gave up ----
+            for b in np.nonzero(resto & ~fail)[0]:
+                gb = idx[b]
+                filt[gb].append(((1 - o.gamma_theta) * th0[b], phi0[b] - o.gamma_phi * th0[b]))
+                wr = self._restore(w[gb], x0[gb], p[gb], None if u_old is None else u_old[gb], mu[gb], tau[gb],
+                                   filt[gb], theta_max[gb])
+                if wr is None:
+                    fail[b] = True
+                else:
+                    w_new[b] = wr
+                    lam[gb] = 0.0                                  # IPOPT: constr_mult_reset_threshold = 0
+                    lam_new[b] = 0.0
+                    dzl[b] = 0.0
+                    dzu[b] = 0.0
+                    if max(zl[gb].max(), zu[gb].max()) > 1e3:      # bound_mult_reset_threshold
+                        zl[gb] = np.where(self.has_l, 1.0, 0.0)
+                        zu[gb] = np.where(self.has_u, 1.0, 0.0)
+                    armijo_type[b] = True                          # the filter was already augmented
+                    n_resto[gb] += 1
             bad = fail
             status[idx[bad]] = RESTORATION_FAILED
             active[idx[bad]] = False
@@ -494,6 +521,9 @@ class DenseIpm:
                 filt[gb].append(((1 - o.gamma_theta) * th0[b], phi0[b] - o.gamma_phi * th0[b]))
                 if len(filt[gb]) > o.max_filter:
                     filt[gb].pop(0)
+            if verbose:
+                print(f"      delta {delta.max():.1e} alpha {alpha.min():.2e} alpha_z {alpha_z.min():.2e} th0 {th0.max():.2e} "
+                      f"dphi {dphi.min():.2e} armijo {armijo_type} resto {resto} |d| {np.abs(d).max():.2e}")
             gi = idx[good]
             w[gi] = w_new[good]
             lam[gi] = lam[gi] + alpha[good, None] * (lam_new[good] - lam[gi])
@@ -508,8 +538,51 @@ class DenseIpm:
         f, g, c, J, Wl = self.eval_all(w, lam, x0, p, u_old)
         E0, dual, prim, compl = self.errors(g, c, J, lam, zl, zu, w, np.zeros(B))
         X, U = self._XU(w, x0)
-        return dict(w=w, lam=lam, zl=zl, zu=zu, f=f, status=status, iters=iters, X=X, U=U, kkt=E0,
+        return dict(w=w, lam=lam, zl=zl, zu=zu, f=f, status=status, iters=iters, X=X, U=U, kkt=E0, n_resto=n_resto,
                     dual_inf=dual, prim_inf=prim, compl=compl, u0=U[:, 0] * pb.su)
+
+    def _restore(self, w, x0, p, u_old, mu, tau, filt, theta_max, max_it=50):
+        """Feasibility restoration, simplified from W&B sec. 3.3: least-norm Newton steps on c(w) = 0
+        (min |d|^2 s.t. J d = -c) with the fraction-to-the-boundary rule and an Armijo search on theta = |c|_1,
+        until theta <= 0.9 theta_start and the point is acceptable to the filter.  Returns the new w or None."""
+        o = self.o
+        w = w[None].copy()
+        x0, p = x0[None], p[None]
+        u_old = None if u_old is None else u_old[None]
+        lam0 = np.zeros((1, self.m))
+        f, g, c, J, _ = self.eval_all(w, lam0, x0, p, u_old)
+        th_start = np.abs(c).sum()
+        th = th_start
+        for _ in range(max_it):
+            K = np.zeros((self.nw + self.m, self.nw + self.m))
+            K[:self.nw, :self.nw] = np.eye(self.nw)
+            K[:self.nw, self.nw:] = J[0].T
+            K[self.nw:, :self.nw] = J[0]
+            K[self.nw:, self.nw:] = -1e-12 * np.eye(self.m)
+            d = np.linalg.solve(K, np.concatenate([np.zeros(self.nw), -c[0]]))[:self.nw][None]
+            sl, su = self._slacks(w)
+            with np.errstate(divide='ignore', invalid='ignore'):
+                a1 = np.where(self.has_l & (d < 0), -tau * sl / d, np.inf).min()
+                a2 = np.where(self.has_u & (d > 0), tau * su / d, np.inf).min()
+            alpha = min(1.0, a1, a2)
+            ok = False
+            while alpha > 1e-10:
+                wt = w + alpha * d
+                ft, ct = self.eval_fc(wt, x0, p, u_old)
+                tht = np.abs(ct).sum()
+                if np.isfinite(tht) and tht <= (1 - 1e-4 * alpha) * th:
+                    ok = True
+                    break
+                alpha *= 0.5
+            if not ok:
+                return None
+            w, th = wt, tht
+            if th <= 0.9 * th_start and th <= theta_max:
+                ph = self.barrier(ft, w, np.array([mu]))[0]
+                if all(not (th >= tf and ph >= pf) for tf, pf in filt):
+                    return w[0]
+            f, g, c, J, _ = self.eval_all(w, lam0, x0, p, u_old)
+        return None
 
     # ---- reference layout helpers -----------------------------------------------------------------------------
     def to_v(self, res):
