@@ -3,8 +3,8 @@
 
 The reference holds no numeric NMPC assertions and cannot run here, so these fixtures are produced by the
 build's own restatement after it passed the scipy cross-check of tests/test_oracle_nmpc.py ("parity unpinned").
-The oracle is run at tol = 1e-10 (100x tighter than IPOPT's default 1e-8) so that the stored v_opt is the KKT point to
-~1e-8: two correct solvers stopped at the default tolerance differ by up to ~1e-5 in weakly curved directions.
+The oracle is run at tol = 1e-9 (10x tighter than IPOPT's default 1e-8) so that the stored v_opt is the KKT point to
+~1e-7: two correct solvers stopped at the default tolerance differ by up to ~1e-5 in weakly curved directions.
 
     python tests/golden/make_nmpc_golden.py
 """
@@ -49,20 +49,20 @@ def closed_loop(pb, ipm, x0, p, n_steps, u_old=None):
 
 def main():
     pb = oracle_problem(C2)
-    ipm = DenseIpm(pb, IpmOptions(tol=1e-10))
+    ipm = DenseIpm(pb, IpmOptions(tol=1e-9))
     x0 = c2_x0(8)
     dump('nmpc_c2.json', 'C2 (tests/problems.py), 8 instances, 3 closed-loop steps, warm-started un-shifted',
          x0, C2['p'], closed_loop(pb, ipm, x0, C2['p'], 3))
     spec = dict(C2, x_scaling=[.1, 40., 2., 1.], u_scaling=[2., 2.])
     pb = oracle_problem(spec)
-    ipm = DenseIpm(pb, IpmOptions(tol=1e-10))
+    ipm = DenseIpm(pb, IpmOptions(tol=1e-9))
     dump('nmpc_c2_scaled.json', 'C2 with x_scaling=[.1,40,2,1], u_scaling=[2,2]', x0[:4], C2['p'],
          closed_loop(pb, ipm, x0[:4], C2['p'], 2))
     pb = NmpcProblem(models.get('pendulum4'), dt=.1, N=25, order=4,
                      stage_states=[([1, 2], [10., 5.], [0., 0.])], stage_inputs=[([0], [.1], None)],
                      input_change=([0], [1.]), x_lb=[-5, -10, -10, -10], x_ub=[5, 10, 10, 10],
                      x_guess=[2.5, 0., .1, 0.], u_guess=[0.])
-    ipm = DenseIpm(pb, IpmOptions(tol=1e-10))
+    ipm = DenseIpm(pb, IpmOptions(tol=1e-9))
     rng = np.random.default_rng(7)
     xp = np.array([2.5, 0., .1, 0.]) + .05 * rng.normal(size=(4, 4))
     dump('nmpc_pendulum.json', 'pendulum of reference tests/test_NMPC.py:12-67 (N=25, weights 10/5/0.1, box on x) plus an '
