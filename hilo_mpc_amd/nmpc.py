@@ -371,8 +371,12 @@ class NMPC:
             _lib.check(_lib.lib().hilo_nmpc_reset_warm_start(self._handle))
         u_old = None
         if self._has_du:
-            # mpc.py:488-493: previous first input, or the guess on the very first call (scaled)
-            if self._u_prev is not None and self._u_prev.shape[0] == B:
+            # mpc.py:488-493: previous first input, or the guess on the very first call (scaled);
+            # `u_old=` (scaled, [B, nu]) overrides the internal memory (batched drivers that re-order instances)
+            if kwargs.get('u_old') is not None:
+                u_old = to_dev(kwargs['u_old'], self._dev).reshape(-1, self._n_u)
+                u_old = (u_old.expand(B, -1) if u_old.shape[0] == 1 else u_old).contiguous()
+            elif self._u_prev is not None and self._u_prev.shape[0] == B:
                 u_old = self._u_prev
             else:
                 g = np.zeros(self._n_u) if self._u_guess is None else np.asarray(self._u_guess) / self._su
