@@ -1,0 +1,17 @@
+import numpy as np, torch, time, sys
+sys.path.insert(0,'.')
+from tests.problems import C2, c2_x0, product_nmpc
+nmpc=product_nmpc(C2)
+B=1024
+x=torch.as_tensor(c2_x0(B),device='cuda'); p=torch.as_tensor(np.array(C2['p']),device='cuda')
+for _ in range(5):
+    u=nmpc.optimize(x,cp=p); x=nmpc.plant_step(x,u,cp=p)
+nmpc.phase_profile(True)
+u=nmpc.optimize(x,cp=p); torch.cuda.synchronize()
+pr=nmpc.phase_profile(True)
+it=int(nmpc._nlp_solution['iter_count'][0])
+print('iters inst0',it, pr, 'total cycles', sum(pr.values()))
+t0=time.perf_counter()
+for _ in range(20):
+    u=nmpc.optimize(x,cp=p); x=nmpc.plant_step(x,u,cp=p)
+torch.cuda.synchronize(); print('ms/step', (time.perf_counter()-t0)/20*1e3, 'mean iters', float(nmpc._nlp_solution['iter_count'].double().mean()))

@@ -16,8 +16,7 @@ GP = GaussianProcess
 
 __all__ = ['Model', 'KalmanFilter', 'ExtendedKalmanFilter', 'UnscentedKalmanFilter', 'KF', 'EKF', 'UKF',
            'GaussianProcess', 'GP', 'Kernel', 'Mean']
-try:                                        # added as the corresponding rows land
-    from .nmpc import NMPC                  # noqa: F401
-    __all__.append('NMPC')
-except ImportError:                         # pragma: no cover
-    pass
+from .nmpc import NMPC
+from .mhe import MovingHorizonEstimator, MHE
+
+__all__ += ['NMPC', 'MovingHorizonEstimator', 'MHE']

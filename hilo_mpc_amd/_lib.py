@@ -31,6 +31,13 @@ class NmpcDesc(C.Structure):
                                           'x_scaling', 'u_scaling', 'x_guess', 'u_guess')]
 
 
+class MheDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('model_id', 'N', 'erk_order', 'n_sub', 'max_iter', 'acceptable_iter')] + \
+               [(n, C.c_double) for n in ('dt', 'tol', 'acceptable_tol', 'mu_init', 'bound_relax_factor')] + \
+               [(n, C.c_void_p) for n in ('Wx', 'Wy', 'Ww', 'x_lb', 'x_ub', 'w_lb', 'w_ub', 'x_scaling', 'w_scaling',
+                                          'u_scaling', 'x_guess', 'w_guess')]
+
+
 _lib = None
 
 
@@ -58,7 +65,13 @@ def _declare(lib):
         'hilo_nmpc_dims': (C.c_int, [vp, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]),
         'hilo_nmpc_reset_warm_start': (C.c_int, [vp]),
         'hilo_nmpc_solve': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        'hilo_nmpc_profile': (C.c_int, [vp, i32, vp]),
         'hilo_nmpc_plant_step': (C.c_int, [vp, i64, vp, vp, vp, i64, vp, vp]),
+        'hilo_mhe_create': (C.c_int, [P(MheDesc), i32, P(vp)]),
+        'hilo_mhe_destroy': (None, [vp]),
+        'hilo_mhe_dims': (C.c_int, [vp] + [P(C.c_int)] * 6),
+        'hilo_mhe_reset_warm_start': (C.c_int, [vp]),
+        'hilo_mhe_estimate': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_gp_create': (C.c_int, [i32, i32, i32, vp, vp, vp, i32, vp, i32, dbl, P(vp)]),
         'hilo_gp_destroy': (None, [vp]),
         'hilo_gp_log_marginal_likelihood': (C.c_int, [vp, P(C.c_double)]),

@@ -1,0 +1,306 @@
+// Batched moving-horizon estimation on the stage-structured interior-point engine (hilo_ocp.h) + C ABI.
+//
+// Replaces `ca.nlpsol("solver",'ipopt',{'f','x','p','g'})` built by `MovingHorizonEstimator.setup`
+// (hilo_mpc/modules/estimator/mhe.py:782-790) and called from `estimate` (mhe.py:375) for a pre-discretised model,
+// `integration_method='discrete'`, state noise, pinned model parameters.  Transcription restated from
+// mhe.py:596-760 (quirks Q7 kept):
+//   v = [p | x_0..x_N | w_0..w_{N-1}]                                         mhe.py:614-655
+//   g_k = x_{k+1} - (Phi_s(x_k, u_meas_k, p) + w_k) = 0                       mhe.py:733-740
+//   J   = arrival(x_0) at k = 0; (h(x_k)-y_k)^T Wy (.) + w_k^T Ww w_k, k >= 1  mhe.py:742-748 (no stage cost at k = 0)
+//   costs act on un-scaled quantities (hilo_mpc/util/modeling.py:665-672)
+// In engine terms: controls := the noise w_k (B_k = I), x_0 free, per-stage data = (u_meas_k, y_meas_k).
+#include <string.h>
+
+#include "hilo_ocp.h"
+
+namespace hilo {
+
+// pc.cost = [Wx | Wy | Ww | su];  par = [model parameters | x_arrival];  sd_k = [u_meas_k | y_meas_k]
+template <class M>
+struct MheNoise {
+  static constexpr int NX = M::NX, NU = M::NX, NY = M::NY, MU = M::NU, NPAR = M::NP + M::NX, NSD = M::NU + M::NY;
+  static constexpr bool FIX_X0 = false;
+  static constexpr int O_WX = 0, O_WY = O_WX + NX * NX, O_WW = O_WY + NY * NY, O_SU = O_WW + NX * NX, O_END = O_SU + MU;
+
+  template <class T>
+  __device__ __forceinline__ static void dyn(const OcpConst& pc, const double* par, const double* sd, int, const T* x,
+                                             const T* w, T* xn) {
+    T xp[NX], xo[NX];
+    double ue[MU > 0 ? MU : 1];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xp[i] = x[i] * pc.sz[i];
+#pragma unroll
+    for (int i = 0; i < MU; ++i) ue[i] = sd[i] * pc.cost[O_SU + i];
+    model_step<M>(pc.order, pc.nsub, xp, ue, par, pc.dt, xo);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]) + w[i];  // mhe.py:739: scaled noise, scaled state
+  }
+
+  template <class T>
+  __device__ __forceinline__ static T stage_cost(const OcpConst& pc, const double* par, const double* sd, int k,
+                                                 const T* x, const T* w) {
+    T xp[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xp[i] = x[i] * pc.sz[i];
+    T acc = T(0.0);
+    if (k == 0) {  // arrival cost (modeling.py:747-777); mhe.py:742-745
+      T d[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) d[i] = xp[i] - par[M::NP + i];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        T s = T(0.0);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s = s + pc.cost[O_WX + i * NX + j] * d[j];
+        acc = acc + d[i] * s;
+      }
+      return acc;
+    }
+    double ue[MU > 0 ? MU : 1];
+#pragma unroll
+    for (int i = 0; i < MU; ++i) ue[i] = sd[i] * pc.cost[O_SU + i];
+    T yv[NY], r[NY];
+    M::meas(xp, ue, par, pc.dt, yv);
+#pragma unroll
+    for (int a = 0; a < NY; ++a) r[a] = yv[a] - sd[MU + a];
+#pragma unroll
+    for (int a = 0; a < NY; ++a) {
+      T s = T(0.0);
+#pragma unroll
+      for (int b = 0; b < NY; ++b) s = s + pc.cost[O_WY + a * NY + b] * r[b];
+      acc = acc + r[a] * s;
+    }
+    T ws[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) ws[i] = w[i] * pc.sz[NX + i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      T s = T(0.0);
+#pragma unroll
+      for (int j = 0; j < NX; ++j) s = s + pc.cost[O_WW + i * NX + j] * ws[j];
+      acc = acc + ws[i] * s;
+    }
+    return acc;
+  }
+
+  template <class T>
+  __device__ __forceinline__ static T term_cost(const OcpConst&, const double*, const double*, const T*) { return T(0.0); }
+};
+
+// par[b] = [p_b | x_arrival_b];  sd[b][k] = [u_meas[b][k] | y_meas[b][k]] for k < N, zeros for k = N
+__global__ void mhe_pack_kernel(int64_t batch, int N, int np, int nx, int nu, int ny, const double* __restrict__ p,
+                                int64_t p_stride, const double* __restrict__ xa, const double* __restrict__ um,
+                                const double* __restrict__ ym, double* __restrict__ par, double* __restrict__ sd) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int wp = np + nx, ws = nu + ny;
+  const int64_t npar = batch * wp, nsd = batch * (N + 1) * ws;
+  if (e < npar) {
+    const int64_t b = e / wp;
+    const int i = (int)(e - b * wp);
+    par[e] = i < np ? p[b * p_stride + i] : xa[b * nx + (i - np)];
+  } else if (e < npar + nsd) {
+    const int64_t q = e - npar;
+    const int64_t b = q / ((N + 1) * ws);
+    const int r = (int)(q - b * (N + 1) * ws), k = r / ws, i = r - k * ws;
+    double v = 0.0;
+    if (k < N) v = i < nu ? um[(b * N + k) * nu + i] : ym[(b * N + k) * ny + (i - nu)];
+    sd[q] = v;
+  }
+}
+
+}  // namespace hilo
+
+using namespace hilo;
+
+struct hilo_mhe {
+  int device, model_id, nx, nu, np, ny, N, n_v, n_g;
+  OcpConst host;
+  OcpConst* dev;
+  double *v_guess, *v_warm, *par_buf, *sd_buf;
+  int64_t warm_batch, buf_batch;
+  int warm_valid;
+  size_t lds_bytes;
+};
+
+#define HILO_MHE_MODELS(X)             \
+  X(HILO_MODEL_CHEMOSTAT4, Chemostat4) \
+  X(HILO_MODEL_BIOREACTOR3, Bioreactor3)
+
+static int mhe_model_dims(int id, int* nx, int* nu, int* np, int* ny, size_t* lds, int N) {
+  switch (id) {
+#define X(ID, T) case ID: *nx = T::NX; *nu = T::NU; *np = T::NP; *ny = T::NY; *lds = Ocp<MheNoise<T>>::lds_doubles(N) * sizeof(double); return HILO_OK;
+    HILO_MHE_MODELS(X)
+#undef X
+  }
+  return fail(HILO_ENOTSUP, "model id %d has no MHE instantiation in this build", id);
+}
+
+extern "C" void hilo_mhe_destroy(hilo_mhe* h) {
+  if (!h) return;
+  double* ptrs[] = {(double*)h->dev, h->v_guess, h->v_warm, h->par_buf, h->sd_buf};
+  for (double* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete h;
+}
+
+extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** out) {
+  HILO_REQUIRE(d && out, "hilo_mhe_create: NULL argument");
+  HILO_REQUIRE(d->N >= 2 && d->N <= 512, "hilo_mhe_create: horizon %d out of range [2, 512]", d->N);
+  HILO_REQUIRE(d->dt > 0.0, "hilo_mhe_create: dt must be positive");
+  int nx, nu, np, ny;
+  size_t lds;
+  int rc = mhe_model_dims(d->model_id, &nx, &nu, &np, &ny, &lds, d->N);
+  if (rc) return rc;
+  if (lds > 160 * 1024) return fail(HILO_ENOTSUP, "horizon %d needs %zu B of LDS per instance (limit 163840)", d->N, lds);
+  hilo_mhe* h = new hilo_mhe();
+  memset(h, 0, sizeof(*h));
+  h->device = device; h->model_id = d->model_id; h->nx = nx; h->nu = nu; h->np = np; h->ny = ny; h->N = d->N;
+  h->n_v = np + (d->N + 1) * nx + d->N * nx;  // mhe.py:596-598
+  h->n_g = d->N * nx;
+  h->lds_bytes = lds;
+  OcpConst& c = h->host;
+  memset(&c, 0, sizeof(c));
+  ocp_default_options(c);
+  c.N = d->N; c.order = d->erk_order >= 1 ? d->erk_order : 4; c.nsub = d->n_sub >= 1 ? d->n_sub : 1; c.dt = d->dt;
+  if (d->max_iter > 0) c.max_iter = d->max_iter;
+  if (d->acceptable_iter > 0) c.acceptable_iter = d->acceptable_iter;
+  if (d->tol > 0) c.tol = d->tol;
+  if (d->acceptable_tol > 0) c.acceptable_tol = d->acceptable_tol;
+  if (d->mu_init > 0) c.mu_init = d->mu_init;
+  for (int i = 0; i < nx; ++i) {
+    c.sz[i] = d->x_scaling ? d->x_scaling[i] : 1.0;
+    c.sz[nx + i] = d->w_scaling ? d->w_scaling[i] : 1.0;
+  }
+  {
+    double* q = c.cost;  // [Wx | Wy | Ww | su]
+    for (int i = 0; i < nx * nx; ++i) *q++ = d->Wx ? d->Wx[i] : 0.0;
+    for (int i = 0; i < ny * ny; ++i) *q++ = d->Wy ? d->Wy[i] : 0.0;
+    for (int i = 0; i < nx * nx; ++i) *q++ = d->Ww ? d->Ww[i] : 0.0;
+    for (int i = 0; i < nu; ++i) *q++ = d->u_scaling ? d->u_scaling[i] : 1.0;
+  }
+  const double relax = d->bound_relax_factor >= 0.0 ? d->bound_relax_factor : 1e-8;
+  for (int i = 0; i < 2 * nx; ++i) {
+    const double* lbs = i < nx ? d->x_lb : d->w_lb;
+    const double* ubs = i < nx ? d->x_ub : d->w_ub;
+    const int j = i < nx ? i : i - nx;
+    double lb = lbs ? lbs[j] / c.sz[i] : -INFINITY, ub = ubs ? ubs[j] / c.sz[i] : INFINITY;
+    if (lb > -INFINITY) lb -= relax * fmax(1.0, fabs(lb));
+    if (ub < INFINITY) ub += relax * fmax(1.0, fabs(ub));
+    HILO_REQUIRE(lb < ub, "hilo_mhe_create: empty box for variable %d", i);
+    c.lbz[i] = lb; c.ubz[i] = ub;
+  }
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->dev, sizeof(OcpConst));
+  if (e == hipSuccess) e = hipMemcpy(h->dev, &c, sizeof(OcpConst), hipMemcpyHostToDevice);
+  const int nvf = h->n_v - np;  // [x-block | w-block]
+  if (e == hipSuccess) e = hipMalloc((void**)&h->v_guess, sizeof(double) * nvf);
+  if (e == hipSuccess) {
+    double* g = new double[nvf];  // mhe.py:633-649: tiled guesses, scaled (mhe.py:229-236)
+    for (int k = 0; k <= d->N; ++k)
+      for (int i = 0; i < nx; ++i) g[k * nx + i] = (d->x_guess ? d->x_guess[i] : 0.0) / c.sz[i];
+    for (int k = 0; k < d->N; ++k)
+      for (int i = 0; i < nx; ++i) g[(d->N + 1) * nx + k * nx + i] = (d->w_guess ? d->w_guess[i] : 0.0) / c.sz[nx + i];
+    e = hipMemcpy(h->v_guess, g, sizeof(double) * nvf, hipMemcpyHostToDevice);
+    delete[] g;
+  }
+  if (e != hipSuccess) {
+    hilo_mhe_destroy(h);
+    return fail(HILO_EHIP, "hilo_mhe_create: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return HILO_OK;
+}
+
+extern "C" int hilo_mhe_dims(const hilo_mhe* h, int* n_v, int* n_g, int* nx, int* nu, int* np, int* ny) {
+  HILO_REQUIRE(h, "hilo_mhe_dims: NULL handle");
+  if (n_v) *n_v = h->n_v;
+  if (n_g) *n_g = h->n_g;
+  if (nx) *nx = h->nx;
+  if (nu) *nu = h->nu;
+  if (np) *np = h->np;
+  if (ny) *ny = h->ny;
+  return HILO_OK;
+}
+
+extern "C" int hilo_mhe_reset_warm_start(hilo_mhe* h) {
+  HILO_REQUIRE(h, "hilo_mhe_reset_warm_start: NULL handle");
+  h->warm_valid = 0;
+  return HILO_OK;
+}
+
+template <class M>
+static int mhe_launch(hilo_mhe* h, int64_t batch, const double* v0, int64_t v0s, int prefix_in_v0, double* v_opt,
+                      double* f_opt, double* lam_g, double* x_opt, int32_t* status, int32_t* iters, double* kkt,
+                      hipStream_t s) {
+  using PB = MheNoise<M>;
+  if (h->lds_bytes > 64 * 1024)
+    HILO_HIP_CHECK(hipFuncSetAttribute((const void*)ocp_solve_kernel<PB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)h->lds_bytes));
+  // v0 rows either carry the parameter prefix (user v0 / previous solution) or not (tiled guess, stride 0)
+  const double* v0p = v0;
+  hipLaunchKernelGGL((ocp_solve_kernel<PB>), dim3((unsigned)batch), dim3(64), h->lds_bytes, s, h->dev, batch,
+                     (const double*)nullptr, h->par_buf, (int64_t)(h->np + h->nx), h->sd_buf,
+                     (int64_t)((h->N + 1) * (h->nu + h->ny)), v0p, v0s, prefix_in_v0 ? h->np : 0, h->np, v_opt, f_opt, lam_g,
+                     x_opt, 1, status, iters, kkt, (long long*)nullptr);
+  HILO_HIP_CHECK(hipGetLastError());
+  return HILO_OK;
+}
+
+extern "C" int hilo_mhe_estimate(hilo_mhe* h, int64_t batch, const double* x_arrival, const double* p, int64_t p_stride,
+                                 const double* u_meas, const double* y_meas, const double* v0, double* v_opt,
+                                 double* f_opt, double* lam_g, double* x_opt, int32_t* status, int32_t* iters, double* kkt,
+                                 void* stream) {
+  HILO_REQUIRE(h, "hilo_mhe_estimate: NULL handle");
+  HILO_REQUIRE(batch >= 0, "hilo_mhe_estimate: negative batch");
+  if (batch == 0) return HILO_OK;
+  HILO_REQUIRE(x_arrival && y_meas && v_opt && f_opt && x_opt && status && iters, "hilo_mhe_estimate: NULL argument");
+  HILO_REQUIRE(h->nu == 0 || u_meas, "hilo_mhe_estimate: the model has %d inputs but u_meas is NULL", h->nu);
+  HILO_REQUIRE(h->np == 0 || p, "hilo_mhe_estimate: the model has %d parameters but p is NULL", h->np);
+  HILO_REQUIRE(p_stride == 0 || p_stride >= h->np, "hilo_mhe_estimate: p_stride %lld < np", (long long)p_stride);
+  HILO_HIP_CHECK(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int wp = h->np + h->nx, ws = h->nu + h->ny;
+  if (h->buf_batch != batch) {
+    if (h->par_buf) HILO_HIP_CHECK(hipFree(h->par_buf));
+    if (h->sd_buf) HILO_HIP_CHECK(hipFree(h->sd_buf));
+    h->par_buf = h->sd_buf = nullptr;
+    hipError_t e = hipMalloc((void**)&h->par_buf, sizeof(double) * (size_t)wp * batch);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->sd_buf, sizeof(double) * (size_t)(h->N + 1) * ws * batch);
+    if (e != hipSuccess) return fail(HILO_ENOMEM, "MHE buffers: %s", hipGetErrorString(e));
+    h->buf_batch = batch;
+  }
+  {
+    const int64_t tot = batch * wp + batch * (int64_t)(h->N + 1) * ws;
+    hipLaunchKernelGGL(mhe_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, batch, h->N, h->np, h->nx,
+                       h->nu, h->ny, p, p_stride, x_arrival, u_meas, y_meas, h->par_buf, h->sd_buf);
+    HILO_HIP_CHECK(hipGetLastError());
+  }
+  const double* vstart = v0;
+  int64_t vstride = h->n_v;
+  int prefix = 1;
+  if (!vstart) {
+    if (h->warm_valid && h->warm_batch == batch) vstart = h->v_warm;  // mhe.py:385
+    else { vstart = h->v_guess; vstride = 0; prefix = 0; }
+  }
+  int rc = HILO_ENOTSUP;
+  switch (h->model_id) {
+#define X(ID, T) case ID: rc = mhe_launch<T>(h, batch, vstart, vstride, prefix, v_opt, f_opt, lam_g, x_opt, status, iters, kkt, s); break;
+    HILO_MHE_MODELS(X)
+#undef X
+  }
+  if (rc) return rc;
+  // the parameter prefix of v_opt: the pinned values (mhe.py:614-623 with p_lb = p_ub)
+  if (h->np > 0)
+    HILO_HIP_CHECK(hipMemcpy2DAsync(v_opt, sizeof(double) * h->n_v, h->par_buf, sizeof(double) * wp,
+                                    sizeof(double) * h->np, batch, hipMemcpyDeviceToDevice, s));
+  if (h->warm_batch != batch) {
+    if (h->v_warm) HILO_HIP_CHECK(hipFree(h->v_warm));
+    h->v_warm = nullptr;
+    hipError_t e = hipMalloc((void**)&h->v_warm, sizeof(double) * h->n_v * batch);
+    if (e != hipSuccess) return fail(HILO_ENOMEM, "warm-start buffer: %s", hipGetErrorString(e));
+    h->warm_batch = batch;
+  }
+  HILO_HIP_CHECK(hipMemcpyAsync(h->v_warm, v_opt, sizeof(double) * h->n_v * batch, hipMemcpyDeviceToDevice, s));
+  h->warm_valid = 1;
+  return HILO_OK;
+}

@@ -1,0 +1,843 @@
+// Generic batched interior-point engine for stage-structured optimal-control NLPs (NMPC, MHE share it).
+//
+//   min  sum_{k<N} l_k(x_k, u_k) + V(x_N)   s.t.  x_{k+1} = F_k(x_k, u_k),  lb <= (x_k, u_k) <= ub,  [x_0 fixed]
+//
+// A problem class is a policy `PB` (dimensions + templated `dyn`, `stage_cost`, `term_cost`); every derivative the
+// solver needs comes from evaluating the policy on second-order univariate Taylor numbers (Jet2) along nz(nz+1)/2
+// directions per stage: value, J.v, grad l.v and v^T (hess l - lam^T hess F) v in one sweep, Hessian blocks by
+// polarisation.  The reference gets the same quantities from CasADi's symbolic AD inside IPOPT.
+//
+// Algorithm (restated from Waechter & Biegler, Math. Program. 106 (2006), the method behind `ca.nlpsol(...,'ipopt')`,
+// hilo_mpc/modules/controller/mpc.py:1780, hilo_mpc/modules/estimator/mhe.py:784): monotone barrier parameter (eq. 7),
+// fraction to the boundary (8), filter line search (Alg. A; alpha_min eq. 23) with a simplified feasibility
+// restoration, inertia correction (Alg. IC) where "inertia" = positivity of the Riccati pivots, scaled optimality
+// error (5,6).  The KKT system is solved by a Riccati recursion over the horizon.
+//
+// Mapping: one workgroup (one wave of 64 lanes) per problem instance, the whole iterate in LDS; see DESIGN.md 5.1.
+#pragma once
+#include <math.h>
+
+#include "hilo_common.h"
+#include "hilo_models.h"
+
+namespace hilo {
+
+constexpr int OCP_MAXNX = 8, OCP_MAXNU = 8, OCP_MAXNZ = OCP_MAXNX + OCP_MAXNU;
+constexpr int OCP_FILTER = 16;
+constexpr int OCP_NCOST = 2 * OCP_MAXNZ * OCP_MAXNZ + 4 * OCP_MAXNZ + 64;
+
+struct OcpConst {
+  int N, order, nsub, max_iter, acceptable_iter, flags;
+  double dt;
+  double lbz[OCP_MAXNZ], ubz[OCP_MAXNZ];  // relaxed bounds of a stage's (x,u) slots (scaled); +-inf if none
+  double sz[OCP_MAXNZ];                   // scaling of (x,u)
+  double cost[OCP_NCOST];                 // policy-defined cost data (weights, references)
+  // interior-point constants (IPOPT defaults)
+  double tol, acceptable_tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac, s_max,
+      kappa_sigma, gamma_theta, gamma_phi, delta_ls, s_theta, s_phi, eta_phi, theta_min_fact, theta_max_fact,
+      delta_w_min, delta_w_0, delta_w_max, kappa_w_minus, kappa_w_plus, kappa_w_plus_bar;
+};
+
+inline void ocp_default_options(OcpConst& c) {
+  c.max_iter = 3000; c.acceptable_iter = 15;
+  c.tol = 1e-8; c.acceptable_tol = 1e-6; c.mu_init = 0.1;
+  c.kappa_eps = 10.0; c.kappa_mu = 0.2; c.theta_mu = 1.5; c.tau_min = 0.99;
+  c.bound_push = 1e-2; c.bound_frac = 1e-2; c.s_max = 100.0; c.kappa_sigma = 1e10;
+  c.gamma_theta = 1e-5; c.gamma_phi = 1e-8; c.delta_ls = 1.0; c.s_theta = 1.1; c.s_phi = 2.3; c.eta_phi = 1e-8;
+  c.theta_min_fact = 1e-4; c.theta_max_fact = 1e4;
+  c.delta_w_min = 1e-20; c.delta_w_0 = 1e-4; c.delta_w_max = 1e40; c.kappa_w_minus = 1.0 / 3; c.kappa_w_plus = 8.0;
+  c.kappa_w_plus_bar = 100.0;
+}
+
+// ---- block-wide reductions (result broadcast to every lane) ------------------------------------------------
+struct OpSum { __device__ static double id() { return 0.0; } __device__ static double f(double a, double b) { return a + b; } };
+struct OpMax { __device__ static double id() { return -INFINITY; } __device__ static double f(double a, double b) { return fmax(a, b); } };
+struct OpMin { __device__ static double id() { return INFINITY; } __device__ static double f(double a, double b) { return fmin(a, b); } };
+
+template <class Op>
+__device__ __forceinline__ double block_reduce(double v, double* scratch) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = Op::f(v, __shfl_xor(v, o, 64));
+  const int nw = blockDim.x >> 6;
+  if (nw == 1) return v;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = Op::id();
+  for (int w = 0; w < nw; ++w) r = Op::f(r, scratch[w]);
+  return r;
+}
+
+enum OcpPhase { PH_DERIV = 0, PH_ERR, PH_RICCATI, PH_STEP, PH_LS, PH_UPDATE, PH_COUNT };
+
+template <class PB>
+struct Ocp {
+  static constexpr int NX = PB::NX, NU = PB::NU, NZ = NX + NU, NDIR = NZ * (NZ + 1) / 2, NXDIR = NX * (NX + 1) / 2;
+  static constexpr int NPAR = PB::NPAR > 0 ? PB::NPAR : 1, NSD = PB::NSD;
+  static constexpr bool FIX_X0 = PB::FIX_X0;
+  static constexpr int NCONST = (sizeof(OcpConst) + 7) / 8;
+
+  struct Lds {
+    const OcpConst* pc;
+    double *Z, *Zt, *D, *zL, *zU, *dzL, *dzU, *grad, *lam, *lamn, *c, *ct, *AB, *W, *Qd, *P, *pv, *Kg, *kff, *T1, *vv,
+        *Mm, *mm, *fk, *filt, *red, *par, *sd;
+  };
+  __host__ __device__ static size_t lds_doubles(int N) {
+    const size_t S = (size_t)(N + 1) * NZ;
+    return NCONST + 8 * S + 4 * (size_t)N * NX + (size_t)N * NX * NZ + (size_t)N * NZ * NZ + (size_t)(N + 1) * NDIR +
+           (size_t)(N + 1) * NX * NX + (size_t)(N + 1) * NX + (size_t)N * NU * NX + (size_t)N * NU + NX * NZ + NX +
+           NZ * NZ + NZ + (N + 1) + 2 * OCP_FILTER + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1;
+  }
+  __device__ static Lds carve(double* base, int N) {
+    Lds l;
+    const size_t S = (size_t)(N + 1) * NZ;
+    double* q = base;
+    auto take = [&](size_t n) { double* r = q; q += n; return r; };
+    l.pc = reinterpret_cast<const OcpConst*>(take(NCONST));
+    l.Z = take(S); l.Zt = take(S); l.D = take(S); l.zL = take(S); l.zU = take(S); l.dzL = take(S); l.dzU = take(S);
+    l.grad = take(S);
+    l.lam = take((size_t)N * NX); l.lamn = take((size_t)N * NX); l.c = take((size_t)N * NX); l.ct = take((size_t)N * NX);
+    l.AB = take((size_t)N * NX * NZ); l.W = take((size_t)N * NZ * NZ); l.Qd = take((size_t)(N + 1) * NDIR);
+    l.P = take((size_t)(N + 1) * NX * NX); l.pv = take((size_t)(N + 1) * NX);
+    l.Kg = take((size_t)N * NU * NX); l.kff = take((size_t)N * NU);
+    l.T1 = take(NX * NZ); l.vv = take(NX); l.Mm = take(NZ * NZ); l.mm = take(NZ);
+    l.fk = take(N + 1); l.filt = take(2 * OCP_FILTER); l.red = take(16); l.par = take(NPAR);
+    l.sd = take((size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1);
+    return l;
+  }
+
+  // a slot (k, i) of the stage-major primal layout is a variable unless it is a pinned x_0 or the unused u_N
+  __device__ static bool is_free(int N, int k, int i) { return !((FIX_X0 && k == 0 && i < NX) || (k == N && i >= NX)); }
+
+  __device__ static void pair_of(int d, int n, int& i, int& j) {  // d >= n -> (i < j) among n slots
+    int r = d - n;
+    i = 0;
+    while (r >= n - 1 - i) { r -= n - 1 - i; ++i; }
+    j = i + 1 + r;
+  }
+  __device__ static int dir_of(int i, int j, int n) { return n + i * (n - 1) - i * (i - 1) / 2 + (j - i - 1); }
+
+  __device__ static const double* sd_of(const Lds& l, int k) { return l.sd + (NSD > 0 ? k * NSD : 0); }
+
+  // ---- values only at a point Zp: defects cp_k = x_{k+1} - F_k(x_k,u_k), returns (f, theta = |c|_1) -------------
+  __device__ static void eval_values(const Lds& l, const double* Zp, double* cp, double& f, double& theta) {
+    const OcpConst& pc = *l.pc;
+    const int N = pc.N;
+    double fpart = 0.0, tpart = 0.0;
+    for (int k = threadIdx.x; k <= N; k += blockDim.x) {
+      double x[NX], u[NU > 0 ? NU : 1];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = Zp[k * NZ + i];
+      if (k < N) {
+        double xn[NX];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = Zp[k * NZ + NX + i];
+        PB::dyn(pc, l.par, sd_of(l, k), k, x, u, xn);
+        fpart += PB::stage_cost(pc, l.par, sd_of(l, k), k, x, u);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const double ci = Zp[(k + 1) * NZ + i] - xn[i];
+          cp[k * NX + i] = ci;
+          tpart += fabs(ci);
+        }
+      } else {
+        fpart += PB::term_cost(pc, l.par, sd_of(l, N), x);
+      }
+    }
+    f = block_reduce<OpSum>(fpart, l.red);
+    theta = block_reduce<OpSum>(tpart, l.red);
+  }
+
+  // -mu * sum log(slacks)
+  __device__ static double eval_barrier(const Lds& l, const double* Zp, double mu) {
+    const OcpConst& pc = *l.pc;
+    const int N = pc.N;
+    double part = 0.0;
+    for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
+      const int k = e / NZ, i = e - k * NZ;
+      if (!is_free(N, k, i)) continue;
+      if (pc.lbz[i] > -INFINITY) part -= log(Zp[e] - pc.lbz[i]);
+      if (pc.ubz[i] < INFINITY) part -= log(pc.ubz[i] - Zp[e]);
+    }
+    return mu * block_reduce<OpSum>(part, l.red);
+  }
+
+  // ---- full derivative evaluation at Z: c, AB, grad, per-stage cost values, Lagrangian Hessian blocks --------
+  __device__ static double eval_derivs(const Lds& l) {
+    const OcpConst& pc = *l.pc;
+    const int N = pc.N;
+    for (int task = threadIdx.x; task < N * NDIR + NXDIR; task += blockDim.x) {
+      if (task < N * NDIR) {
+        const int k = task / NDIR, d = task - k * NDIR;
+        int di = d, dj = -1;
+        if (d >= NZ) pair_of(d, NZ, di, dj);
+        const bool dead = FIX_X0 && k == 0 && di < NX;  // direction touches the pinned x_0
+        if (dead) {
+          l.Qd[task] = 0.0;
+          if (d < NZ) {
+            l.grad[d] = 0.0;
+#pragma unroll
+            for (int m = 0; m < NX; ++m) l.AB[m * NZ + d] = 0.0;
+          }
+          if (d != 0) continue;
+        }
+        Jet2 x[NX], u[NU > 0 ? NU : 1], xn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = Jet2(l.Z[k * NZ + i], (!dead && (i == di || i == dj)) ? 1.0 : 0.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = Jet2(l.Z[k * NZ + NX + i], (NX + i == di || NX + i == dj) ? 1.0 : 0.0, 0.0);
+        PB::dyn(pc, l.par, sd_of(l, k), k, x, u, xn);
+        const Jet2 lc = PB::stage_cost(pc, l.par, sd_of(l, k), k, x, u);
+        double q = lc.b;
+#pragma unroll
+        for (int m = 0; m < NX; ++m) {
+          if (d == 0) l.c[k * NX + m] = l.Z[(k + 1) * NZ + m] - xn[m].v;
+          if (d < NZ && !dead) l.AB[(k * NX + m) * NZ + d] = xn[m].a;
+          q -= l.lam[k * NX + m] * xn[m].b;
+        }
+        if (d == 0) l.fk[k] = lc.v;
+        if (!dead) {
+          l.Qd[task] = q;
+          if (d < NZ) l.grad[k * NZ + d] = lc.a;
+        }
+      } else {  // terminal cost V(x_N): directions over the NX state slots
+        const int d = task - N * NDIR;
+        int di = d, dj = -1;
+        if (d >= NX) pair_of(d, NX, di, dj);
+        Jet2 x[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = Jet2(l.Z[N * NZ + i], (i == di || i == dj) ? 1.0 : 0.0, 0.0);
+        const Jet2 v = PB::term_cost(pc, l.par, sd_of(l, N), x);
+        l.Qd[N * NDIR + d] = v.b;
+        if (d < NX) l.grad[N * NZ + d] = v.a;
+        if (d == 0) l.fk[N] = v.v;
+      }
+    }
+    __syncthreads();
+    // Hessian blocks by polarisation: H_ii = q(e_i), H_ij = (q(e_i+e_j) - q(e_i) - q(e_j)) / 2
+    for (int e = threadIdx.x; e < N * NZ * NZ; e += blockDim.x) {
+      const int k = e / (NZ * NZ), r = e - k * NZ * NZ, i = r / NZ, j = r - i * NZ;
+      const double* Q = l.Qd + k * NDIR;
+      double h;
+      if (i == j) h = Q[i];
+      else {
+        const int a = i < j ? i : j, b = i < j ? j : i;
+        h = 0.5 * (Q[dir_of(a, b, NZ)] - Q[a] - Q[b]);
+      }
+      l.W[e] = h;
+    }
+    double fpart = 0.0;
+    for (int k = threadIdx.x; k <= N; k += blockDim.x) fpart += l.fk[k];
+    for (int a = threadIdx.x; a < NU; a += blockDim.x) l.grad[N * NZ + NX + a] = 0.0;
+    const double f = block_reduce<OpSum>(fpart, l.red);
+    __syncthreads();
+    return f;
+  }
+
+  // dual residual of slot e: grad + J^T lam - zL + zU
+  __device__ static double dual_res(const Lds& l, int N, int e) {
+    const int k = e / NZ, i = e - k * NZ;
+    double r = l.grad[e] - l.zL[e] + l.zU[e];
+    if (i < NX && k >= 1) r += l.lam[(k - 1) * NX + i];
+    if (k < N) {
+#pragma unroll
+      for (int m = 0; m < NX; ++m) r -= l.AB[(k * NX + m) * NZ + i] * l.lam[k * NX + m];
+    }
+    return r;
+  }
+
+  // scaled optimality error pieces (W&B eq. 5)
+  __device__ static void opt_error(const Lds& l, double& dual_s, double& prim, double& s_c) {
+    const OcpConst& pc = *l.pc;
+    const int N = pc.N;
+    double dmax = 0.0, lsum = 0.0, zsum = 0.0, pmax = 0.0, nb = 0.0;
+    for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
+      const int k = e / NZ, i = e - k * NZ;
+      if (!is_free(N, k, i)) continue;
+      dmax = fmax(dmax, fabs(dual_res(l, N, e)));
+      zsum += fabs(l.zL[e]) + fabs(l.zU[e]);
+      nb += (pc.lbz[i] > -INFINITY ? 1.0 : 0.0) + (pc.ubz[i] < INFINITY ? 1.0 : 0.0);
+    }
+    for (int e = threadIdx.x; e < N * NX; e += blockDim.x) {
+      pmax = fmax(pmax, fabs(l.c[e]));
+      lsum += fabs(l.lam[e]);
+    }
+    dmax = block_reduce<OpMax>(dmax, l.red);
+    pmax = block_reduce<OpMax>(pmax, l.red);
+    lsum = block_reduce<OpSum>(lsum, l.red);
+    zsum = block_reduce<OpSum>(zsum, l.red);
+    nb = fmax(1.0, block_reduce<OpSum>(nb, l.red));
+    const double s_d = fmax(pc.s_max, (lsum + zsum) / (N * NX + nb)) / pc.s_max;
+    s_c = fmax(pc.s_max, zsum / nb) / pc.s_max;
+    dual_s = dmax / s_d;
+    prim = pmax;
+  }
+
+  __device__ static double compl_error(const Lds& l, double mu) {
+    const OcpConst& pc = *l.pc;
+    const int N = pc.N;
+    double cm = 0.0;
+    for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
+      const int k = e / NZ, i = e - k * NZ;
+      if (!is_free(N, k, i)) continue;
+      if (pc.lbz[i] > -INFINITY) cm = fmax(cm, fabs((l.Z[e] - pc.lbz[i]) * l.zL[e] - mu));
+      if (pc.ubz[i] < INFINITY) cm = fmax(cm, fabs((pc.ubz[i] - l.Z[e]) * l.zU[e] - mu));
+    }
+    return block_reduce<OpMax>(cm, l.red);
+  }
+
+  // barrier contribution of slot sl (variable index i) to the diagonal and to the right-hand side
+  __device__ __forceinline__ static void barrier_terms(const OcpConst& pc, const Lds& l, int sl, int i, double mu,
+                                                       double& sigma, double& rhs) {
+    if (pc.lbz[i] > -INFINITY) {
+      const double s = l.Z[sl] - pc.lbz[i];
+      sigma += l.zL[sl] / s;
+      rhs -= mu / s;
+    }
+    if (pc.ubz[i] < INFINITY) {
+      const double s = pc.ubz[i] - l.Z[sl];
+      sigma += l.zU[sl] / s;
+      rhs += mu / s;
+    }
+  }
+
+  // ---- Riccati factor + solve of the Newton system; false when a reduced pivot is not positive ---------------
+  // `resto`: feasibility-restoration step (H = I, zero gradient: least-norm d with J d = -c)
+  __device__ static bool riccati(const Lds& l, double mu, double delta, bool resto = false) {
+    const OcpConst& pc = *l.pc;
+    const int N = pc.N, t = threadIdx.x, T = blockDim.x;
+    // terminal: P_N = hess V + Sigma + delta, p_N = grad V - mu/s...
+    for (int e = t; e < NX * NX + NX; e += T) {
+      if (e < NX * NX) {
+        const int i = e / NX, j = e - i * NX;
+        double v = 0.0;
+        if (!resto) {
+          const double* Q = l.Qd + N * NDIR;
+          if (i == j) v = Q[i];
+          else {
+            const int a = i < j ? i : j, b = i < j ? j : i;
+            v = 0.5 * (Q[dir_of(a, b, NX)] - Q[a] - Q[b]);
+          }
+        }
+        if (i == j) {
+          double sg = 0.0, dummy = 0.0;
+          if (!resto) barrier_terms(pc, l, N * NZ + i, i, mu, sg, dummy);
+          v += (resto ? 1.0 : delta) + sg;
+        }
+        l.P[N * NX * NX + e] = v;
+      } else {
+        const int i = e - NX * NX;
+        double sg = 0.0, r = 0.0;
+        if (!resto) {
+          r = l.grad[N * NZ + i];
+          barrier_terms(pc, l, N * NZ + i, i, mu, sg, r);
+        }
+        l.pv[N * NX + i] = r;
+      }
+    }
+    __syncthreads();
+    bool ok = true;
+    for (int k = N - 1; k >= 0; --k) {
+      const double* Pn = l.P + (k + 1) * NX * NX;
+      const double* pn = l.pv + (k + 1) * NX;
+      const double* AB = l.AB + k * NX * NZ;
+      // T1 = P_{k+1} [A B]  (NX x NZ),  vv = P_{k+1} b + p_{k+1},  b = -c_k
+      for (int e = t; e < NX * NZ + NX; e += T) {
+        if (e < NX * NZ) {
+          const int i = e / NZ, j = e - i * NZ;
+          double s = 0.0;
+#pragma unroll
+          for (int m = 0; m < NX; ++m) s += Pn[i * NX + m] * AB[m * NZ + j];
+          l.T1[e] = s;
+        } else {
+          const int i = e - NX * NZ;
+          double s = pn[i];
+#pragma unroll
+          for (int m = 0; m < NX; ++m) s -= Pn[i * NX + m] * l.c[k * NX + m];
+          l.vv[i] = s;
+        }
+      }
+      __syncthreads();
+      // Mm = H_k + [A B]^T T1 ; mm = r_k + [A B]^T vv
+      for (int e = t; e < NZ * NZ + NZ; e += T) {
+        if (e < NZ * NZ) {
+          const int i = e / NZ, j = e - i * NZ;
+          double s = resto ? 0.0 : l.W[k * NZ * NZ + e];
+#pragma unroll
+          for (int m = 0; m < NX; ++m) s += AB[m * NZ + i] * l.T1[m * NZ + j];
+          if (i == j) {
+            double sg = 0.0, dummy = 0.0;
+            if (!resto && is_free(N, k, i)) barrier_terms(pc, l, k * NZ + i, i, mu, sg, dummy);
+            s += (resto ? 1.0 : delta) + sg;
+          }
+          l.Mm[e] = s;
+        } else {
+          const int i = e - NZ * NZ, sl = k * NZ + i;
+          double sg = 0.0, s = 0.0;
+          if (!resto) {
+            s = l.grad[sl];
+            if (is_free(N, k, i)) barrier_terms(pc, l, sl, i, mu, sg, s);
+          }
+#pragma unroll
+          for (int m = 0; m < NX; ++m) s += AB[m * NZ + i] * l.vv[m];
+          l.mm[i] = s;
+        }
+      }
+      __syncthreads();
+      if constexpr (NU > 0) {
+        // Cholesky of M_uu (every lane redundantly; tiny) + positivity test (= inertia test)
+        double Lc[NU * NU];
+        bool pd = true;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          double s = l.Mm[(NX + j) * NZ + NX + j];
+#pragma unroll
+          for (int q = 0; q < j; ++q) s -= Lc[j * NU + q] * Lc[j * NU + q];
+          if (!(s > 0.0)) { pd = false; s = 1.0; }
+          const double dd = sqrt(s);
+          Lc[j * NU + j] = dd;
+#pragma unroll
+          for (int i = j + 1; i < NU; ++i) {
+            double v = l.Mm[(NX + i) * NZ + NX + j];
+#pragma unroll
+            for (int q = 0; q < j; ++q) v -= Lc[i * NU + q] * Lc[j * NU + q];
+            Lc[i * NU + j] = v / dd;
+          }
+        }
+        ok = ok && pd;
+        // K = -M_uu^-1 M_ux (NU x NX), kff = -M_uu^-1 m_u : one lane per column of [M_ux | m_u]
+        for (int col = t; col < NX + 1; col += T) {
+          double y[NU];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) {
+            double s = col < NX ? l.Mm[(NX + a) * NZ + col] : l.mm[NX + a];
+#pragma unroll
+            for (int q = 0; q < a; ++q) s -= Lc[a * NU + q] * y[q];
+            y[a] = s / Lc[a * NU + a];
+          }
+#pragma unroll
+          for (int a = NU - 1; a >= 0; --a) {
+            double s = y[a];
+#pragma unroll
+            for (int q = a + 1; q < NU; ++q) s -= Lc[q * NU + a] * y[q];
+            y[a] = s / Lc[a * NU + a];
+          }
+#pragma unroll
+          for (int a = 0; a < NU; ++a) {
+            if (col < NX) l.Kg[(k * NU + a) * NX + col] = -y[a];
+            else l.kff[k * NU + a] = -y[a];
+          }
+        }
+        __syncthreads();
+      }
+      // P_k = M_xx + M_xu K (symmetrised), p_k = m_x + M_xu kff
+      for (int e = t; e < NX * NX + NX; e += T) {
+        if (e < NX * NX) {
+          const int i = e / NX, j = e - i * NX;
+          double s = 0.5 * (l.Mm[i * NZ + j] + l.Mm[j * NZ + i]);
+#pragma unroll
+          for (int a = 0; a < NU; ++a)
+            s += 0.5 * (l.Mm[i * NZ + NX + a] * l.Kg[(k * NU + a) * NX + j] + l.Mm[j * NZ + NX + a] * l.Kg[(k * NU + a) * NX + i]);
+          l.P[k * NX * NX + e] = s;
+        } else {
+          const int i = e - NX * NX;
+          double s = l.mm[i];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) s += l.Mm[i * NZ + NX + a] * l.kff[k * NU + a];
+          l.pv[k * NX + i] = s;
+        }
+      }
+      __syncthreads();
+    }
+    // initial state: pinned (dx_0 = 0) or free: dx_0 = -P_0^-1 p_0 (P_0 must be positive definite)
+    if constexpr (FIX_X0) {
+      for (int i = t; i < NX; i += T) l.D[i] = 0.0;
+    } else {
+      double Lc[NX * NX], y[NX];
+      bool pd = true;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        double s = l.P[j * NX + j];
+#pragma unroll
+        for (int q = 0; q < j; ++q) s -= Lc[j * NX + q] * Lc[j * NX + q];
+        if (!(s > 0.0)) { pd = false; s = 1.0; }
+        const double dd = sqrt(s);
+        Lc[j * NX + j] = dd;
+#pragma unroll
+        for (int i = j + 1; i < NX; ++i) {
+          double v = l.P[i * NX + j];
+#pragma unroll
+          for (int q = 0; q < j; ++q) v -= Lc[i * NX + q] * Lc[j * NX + q];
+          Lc[i * NX + j] = v / dd;
+        }
+      }
+      ok = ok && pd;
+#pragma unroll
+      for (int a = 0; a < NX; ++a) {
+        double s = l.pv[a];
+#pragma unroll
+        for (int q = 0; q < a; ++q) s -= Lc[a * NX + q] * y[q];
+        y[a] = s / Lc[a * NX + a];
+      }
+#pragma unroll
+      for (int a = NX - 1; a >= 0; --a) {
+        double s = y[a];
+#pragma unroll
+        for (int q = a + 1; q < NX; ++q) s -= Lc[q * NX + a] * y[q];
+        y[a] = s / Lc[a * NX + a];
+      }
+      __syncthreads();
+      if (t == 0) {
+#pragma unroll
+        for (int a = 0; a < NX; ++a) l.D[a] = -y[a];
+      }
+    }
+    if (!ok) return false;
+    __syncthreads();
+    // forward sweep: du_k = K dx_k + kff; dx_{k+1} = A dx_k + B du_k - c_k
+    for (int k = 0; k < N; ++k) {
+      for (int a = t; a < NU; a += T) {
+        double s = l.kff[k * NU + a];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += l.Kg[(k * NU + a) * NX + j] * l.D[k * NZ + j];
+        l.D[k * NZ + NX + a] = s;
+      }
+      __syncthreads();
+      for (int i = t; i < NX; i += T) {
+        double s = -l.c[k * NX + i];
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) s += l.AB[(k * NX + i) * NZ + j] * l.D[k * NZ + j];
+        l.D[(k + 1) * NZ + i] = s;
+      }
+      __syncthreads();
+    }
+    for (int a = t; a < NU; a += T) l.D[N * NZ + NX + a] = 0.0;
+    // new equality multipliers: lam_{k+1} = -(P_{k+1} dx_{k+1} + p_{k+1})
+    for (int e = t; e < N * NX; e += T) {
+      const int k = e / NX, i = e - k * NX;
+      double s = l.pv[(k + 1) * NX + i];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) s += l.P[(k + 1) * NX * NX + i * NX + j] * l.D[(k + 1) * NZ + j];
+      l.lamn[e] = -s;
+    }
+    __syncthreads();
+    return true;
+  }
+
+  // ---- feasibility restoration, simplified from W&B sec. 3.3 (same statement as oracle/nmpc.py::_restore) ------
+  __device__ static bool restore(const Lds& l, double mu, double tau, int nfilt, double theta_max) {
+    const OcpConst& pc = *l.pc;
+    const int N = pc.N, t = threadIdx.x, T = blockDim.x, SL = (N + 1) * NZ;
+    double th = 0.0;
+    for (int e = t; e < N * NX; e += T) th += fabs(l.c[e]);
+    th = block_reduce<OpSum>(th, l.red);
+    const double th_start = th;
+    for (int it = 0; it < 50; ++it) {
+      riccati(l, mu, 0.0, true);
+      double a = 1.0;
+      for (int e = t; e < SL; e += T) {
+        const int k = e / NZ, i = e - k * NZ;
+        if (!is_free(N, k, i)) continue;
+        const double d = l.D[e];
+        if (pc.lbz[i] > -INFINITY && d < 0.0) a = fmin(a, -tau * (l.Z[e] - pc.lbz[i]) / d);
+        if (pc.ubz[i] < INFINITY && d > 0.0) a = fmin(a, tau * (pc.ubz[i] - l.Z[e]) / d);
+      }
+      double alpha = block_reduce<OpMin>(a, l.red);
+      bool ok = false;
+      double tht = 0.0, ft = 0.0;
+      while (alpha > 1e-10) {
+        for (int e = t; e < SL; e += T) l.Zt[e] = l.Z[e] + alpha * l.D[e];
+        __syncthreads();
+        eval_values(l, l.Zt, l.ct, ft, tht);
+        if (isfinite(tht) && tht <= (1.0 - 1e-4 * alpha) * th) { ok = true; break; }
+        alpha *= 0.5;
+      }
+      if (!ok) return false;
+      for (int e = t; e < SL; e += T) l.Z[e] = l.Zt[e];
+      __syncthreads();
+      th = tht;
+      if (th <= 0.9 * th_start && th <= theta_max) {
+        const double ph = ft + eval_barrier(l, l.Z, mu);
+        bool acc = true;
+        for (int q = 0; q < nfilt; ++q)
+          if (th >= l.filt[2 * q] && ph >= l.filt[2 * q + 1]) { acc = false; break; }
+        if (acc) return true;
+      }
+      eval_derivs(l);
+    }
+    return false;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// The solve kernel.  v layout (device, per instance, scaled): [prefix (v_prefix doubles, untouched) | x_0..x_N | u_0..u_{N-1}]
+// ---------------------------------------------------------------------------------------------------------------
+template <class PB>
+__global__ __launch_bounds__(64) void ocp_solve_kernel(const OcpConst* __restrict__ pcg, int64_t batch,
+                                                       const double* __restrict__ x0, const double* __restrict__ par,
+                                                       int64_t par_stride, const double* __restrict__ sdata,
+                                                       int64_t sd_stride, const double* __restrict__ v0,
+                                                       int64_t v0_stride, int v0_prefix, int v_prefix, double* __restrict__ v_opt,
+                                                       double* __restrict__ f_opt, double* __restrict__ lam_g,
+                                                       double* __restrict__ first, int first_kind,
+                                                       int32_t* __restrict__ status, int32_t* __restrict__ iters,
+                                                       double* __restrict__ kkt, long long* __restrict__ prof) {
+  using S = Ocp<PB>;
+  constexpr int NX = S::NX, NU = S::NU, NZ = S::NZ;
+  extern __shared__ double lds_raw[];
+  const int t = threadIdx.x, T = blockDim.x;
+  const int64_t b = blockIdx.x;
+  if (b >= batch) return;
+  const int N = pcg->N;
+  typename S::Lds l = S::carve(lds_raw, N);
+  {  // problem constants into LDS: every later access is an LDS read instead of a global load
+    const double* src = reinterpret_cast<const double*>(pcg);
+    double* dst = lds_raw;
+    for (int i = t; i < S::NCONST; i += T) dst[i] = src[i];
+  }
+  for (int i = t; i < PB::NPAR; i += T) l.par[i] = par[b * par_stride + i];
+  if constexpr (PB::NSD > 0)
+    for (int i = t; i < (N + 1) * PB::NSD; i += T) l.sd[i] = sdata[b * sd_stride + i];
+  __syncthreads();
+  const OcpConst& pc = *l.pc;
+  const int SL = (N + 1) * NZ;
+  long long tprof[PH_COUNT] = {0, 0, 0, 0, 0, 0};
+  long long tlast = prof ? clock64() : 0;
+#define OCP_TICK(ph) if (prof) { const long long tn = clock64(); tprof[ph] += tn - tlast; tlast = tn; }
+
+  // ---- load: warm start in the [x-block | u-block] layout; x_0 pinned to the measurement (mpc.py:801-802) ----
+  const double* vb = v0 + b * v0_stride + v0_prefix;
+  for (int e = t; e < SL; e += T) {
+    const int k = e / NZ, i = e - k * NZ;
+    double v;
+    if (i < NX) v = (S::FIX_X0 && k == 0) ? x0[b * NX + i] / pc.sz[i] : vb[k * NX + i];
+    else v = (k < N) ? vb[(N + 1) * NX + k * NU + (i - NX)] : 0.0;
+    if (S::is_free(N, k, i)) {  // IPOPT start: push into the interior (W&B sec. 3.6)
+      const double lb = pc.lbz[i], ub = pc.ubz[i];
+      const bool hl = lb > -INFINITY, hu = ub < INFINITY;
+      if (hl) {
+        double pl = pc.bound_push * fmax(1.0, fabs(lb));
+        if (hu) pl = fmin(pl, pc.bound_frac * (ub - lb));
+        v = fmax(v, lb + pl);
+      }
+      if (hu) {
+        double pu = pc.bound_push * fmax(1.0, fabs(ub));
+        if (hl) pu = fmin(pu, pc.bound_frac * (ub - lb));
+        v = fmin(v, ub - pu);
+      }
+      l.zL[e] = hl ? 1.0 : 0.0;
+      l.zU[e] = hu ? 1.0 : 0.0;
+    } else {
+      l.zL[e] = 0.0;
+      l.zU[e] = 0.0;
+    }
+    l.Z[e] = v;
+    l.D[e] = 0.0;
+  }
+  for (int e = t; e < N * NX; e += T) l.lam[e] = 0.0;
+  __syncthreads();
+
+  double mu = pc.mu_init, tau = fmax(pc.tau_min, 1.0 - mu);
+  double delta_last = 0.0;
+  int nfilt = 0, acc_count = 0, it = 0, st = 0;
+  double theta_min = 0.0, theta_max = INFINITY;
+  double E0 = INFINITY, fval = 0.0;
+
+  for (it = 0;; ++it) {
+    fval = S::eval_derivs(l);
+    OCP_TICK(PH_DERIV)
+    double th0 = 0.0;
+    for (int e = t; e < N * NX; e += T) th0 += fabs(l.c[e]);
+    th0 = block_reduce<OpSum>(th0, l.red);
+    if (it == 0) {
+      theta_min = pc.theta_min_fact * fmax(1.0, th0);
+      theta_max = pc.theta_max_fact * fmax(1.0, th0);
+    }
+    double dual_s, prim, s_c;
+    S::opt_error(l, dual_s, prim, s_c);
+    const double c0 = S::compl_error(l, 0.0);
+    E0 = fmax(fmax(dual_s, prim), c0 / s_c);
+    if (E0 <= pc.tol) { st = HILO_STATUS_SOLVED; break; }
+    if (E0 <= pc.acceptable_tol) {
+      if (++acc_count >= pc.acceptable_iter) { st = HILO_STATUS_ACCEPTABLE; break; }
+    } else acc_count = 0;
+    if (it >= pc.max_iter) { st = HILO_STATUS_MAXITER; break; }
+    // ---- barrier update (W&B eq. 7) ----
+    for (int r = 0; r < 20; ++r) {
+      const double Emu = fmax(fmax(dual_s, prim), S::compl_error(l, mu) / s_c);
+      if (!(Emu <= pc.kappa_eps * mu && mu > pc.tol / 10 * (1 + 1e-12))) break;
+      mu = fmax(pc.tol / 10, fmin(pc.kappa_mu * mu, pow(mu, pc.theta_mu)));
+      tau = fmax(pc.tau_min, 1.0 - mu);
+      nfilt = 0;
+    }
+    OCP_TICK(PH_ERR)
+    // ---- search direction with inertia correction (W&B Alg. IC) ----
+    double delta = 0.0;
+    bool first_try = true, solved = false;
+    for (;;) {
+      if (S::riccati(l, mu, delta)) { solved = true; break; }
+      if (first_try) {
+        delta = delta_last == 0.0 ? pc.delta_w_0 : fmax(pc.delta_w_min, pc.kappa_w_minus * delta_last);
+        first_try = false;
+      } else {
+        delta *= delta_last == 0.0 ? pc.kappa_w_plus_bar : pc.kappa_w_plus;
+      }
+      if (delta > pc.delta_w_max) break;
+    }
+    if (!solved) { st = HILO_STATUS_RESTORATION_FAILED; break; }
+    if (delta > 0.0) delta_last = delta;
+    OCP_TICK(PH_RICCATI)
+    // ---- bound-multiplier steps, fraction to the boundary (W&B eq. 8), directional derivative ----
+    double a_p = 1.0, a_z = 1.0, dphi = 0.0;
+    for (int e = t; e < SL; e += T) {
+      const int k = e / NZ, i = e - k * NZ;
+      double dl = 0.0, du = 0.0;
+      if (S::is_free(N, k, i)) {
+        const double d = l.D[e];
+        double gphi = l.grad[e];
+        if (pc.lbz[i] > -INFINITY) {
+          const double s = l.Z[e] - pc.lbz[i];
+          dl = mu / s - l.zL[e] - l.zL[e] / s * d;
+          if (d < 0.0) a_p = fmin(a_p, -tau * s / d);
+          if (dl < 0.0) a_z = fmin(a_z, -tau * l.zL[e] / dl);
+          gphi -= mu / s;
+        }
+        if (pc.ubz[i] < INFINITY) {
+          const double s = pc.ubz[i] - l.Z[e];
+          du = mu / s - l.zU[e] + l.zU[e] / s * d;
+          if (d > 0.0) a_p = fmin(a_p, tau * s / d);
+          if (du < 0.0) a_z = fmin(a_z, -tau * l.zU[e] / du);
+          gphi += mu / s;
+        }
+        dphi += gphi * d;
+      }
+      l.dzL[e] = dl;
+      l.dzU[e] = du;
+    }
+    a_p = block_reduce<OpMin>(a_p, l.red);
+    a_z = block_reduce<OpMin>(a_z, l.red);
+    dphi = block_reduce<OpSum>(dphi, l.red);
+    const double phi0 = fval + S::eval_barrier(l, l.Z, mu);
+    OCP_TICK(PH_STEP)
+    // ---- filter line search (W&B Alg. A without second-order correction) ----
+    double alpha = a_p;
+    bool accepted = false, armijo = false;
+    for (int ls = 0; ls < 60; ++ls) {
+      for (int e = t; e < SL; e += T) l.Zt[e] = l.Z[e] + alpha * l.D[e];
+      __syncthreads();
+      double ft, tht;
+      S::eval_values(l, l.Zt, l.ct, ft, tht);
+      const double pht = ft + S::eval_barrier(l, l.Zt, mu);
+      bool ok = isfinite(pht) && isfinite(tht) && tht <= theta_max;
+      if (ok) {
+        for (int q = 0; q < nfilt; ++q) {
+          const double tf = l.filt[2 * q], pf = l.filt[2 * q + 1];
+          if (tht >= tf && pht - 10 * 2.220446049250313e-16 * fabs(pf) >= pf) { ok = false; break; }
+        }
+      }
+      bool sw = false;
+      if (ok) {
+        sw = th0 <= theta_min && dphi < 0.0 && alpha * pow(-dphi, pc.s_phi) > pc.delta_ls * pow(th0, pc.s_theta);
+        const double rnd = 10 * 2.220446049250313e-16 * fabs(phi0);
+        if (sw) ok = pht - phi0 - rnd <= pc.eta_phi * alpha * dphi;
+        else ok = tht <= (1 - pc.gamma_theta) * th0 || pht - phi0 - rnd <= -pc.gamma_phi * th0;
+      }
+      if (ok) { accepted = true; armijo = sw; break; }
+      alpha *= 0.5;
+      // W&B eq. 23: below alpha_min the line search gives up and the restoration phase is called
+      double amin = pc.gamma_theta;
+      if (dphi < 0.0) {
+        amin = fmin(amin, pc.gamma_phi * th0 / (-dphi));
+        if (th0 <= theta_min) amin = fmin(amin, pc.delta_ls * pow(th0, pc.s_theta) / pow(-dphi, pc.s_phi));
+      }
+      if (alpha < 0.05 * amin) break;
+    }
+    OCP_TICK(PH_LS)
+    const bool do_resto = !accepted;
+    if (!armijo || do_resto) {  // augment the filter (W&B eq. 22); also done before entering restoration
+      if (nfilt == OCP_FILTER) {
+        double keep = 0.0;
+        if (t < 2 * (OCP_FILTER - 1)) keep = l.filt[t + 2];
+        __syncthreads();
+        if (t < 2 * (OCP_FILTER - 1)) l.filt[t] = keep;
+        nfilt = OCP_FILTER - 1;
+        __syncthreads();
+      }
+      if (t == 0) {
+        l.filt[2 * nfilt] = (1 - pc.gamma_theta) * th0;
+        l.filt[2 * nfilt + 1] = phi0 - pc.gamma_phi * th0;
+      }
+      ++nfilt;
+      __syncthreads();
+    }
+    if (do_resto) {
+      if (!S::restore(l, mu, tau, nfilt, theta_max)) { st = HILO_STATUS_RESTORATION_FAILED; break; }
+      // IPOPT after restoration: equality multipliers reset (constr_mult_reset_threshold = 0), bound multipliers
+      // reset to 1 when they exceed bound_mult_reset_threshold = 1000
+      double zm = 0.0;
+      for (int e = t; e < SL; e += T) zm = fmax(zm, fmax(l.zL[e], l.zU[e]));
+      zm = block_reduce<OpMax>(zm, l.red);
+      for (int e = t; e < SL; e += T) {
+        const int k = e / NZ, i = e - k * NZ;
+        if (zm > 1e3 && S::is_free(N, k, i)) {
+          l.zL[e] = pc.lbz[i] > -INFINITY ? 1.0 : 0.0;
+          l.zU[e] = pc.ubz[i] < INFINITY ? 1.0 : 0.0;
+        }
+      }
+      for (int e = t; e < N * NX; e += T) l.lam[e] = 0.0;
+      __syncthreads();
+      continue;
+    }
+    // ---- accept: primal, equality multipliers, bound multipliers (+ W&B eq. 16 safeguard) ----
+    for (int e = t; e < SL; e += T) {
+      const int k = e / NZ, i = e - k * NZ;
+      const double znew = l.Zt[e];
+      l.Z[e] = znew;
+      if (S::is_free(N, k, i)) {
+        if (pc.lbz[i] > -INFINITY) {
+          const double s = znew - pc.lbz[i];
+          l.zL[e] = fmin(fmax(l.zL[e] + a_z * l.dzL[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
+        }
+        if (pc.ubz[i] < INFINITY) {
+          const double s = pc.ubz[i] - znew;
+          l.zU[e] = fmin(fmax(l.zU[e] + a_z * l.dzU[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
+        }
+      }
+    }
+    for (int e = t; e < N * NX; e += T) l.lam[e] += alpha * (l.lamn[e] - l.lam[e]);
+    __syncthreads();
+    OCP_TICK(PH_UPDATE)
+  }
+
+  // ---- write back ([x-block | u-block] after the prefix) ----
+  double* vo = v_opt + b * (int64_t)(v_prefix + (N + 1) * NX + N * NU) + v_prefix;
+  for (int e = t; e < SL; e += T) {
+    const int k = e / NZ, i = e - k * NZ;
+    if (i < NX) vo[k * NX + i] = l.Z[e];
+    else if (k < N) vo[(N + 1) * NX + k * NU + (i - NX)] = l.Z[e];
+  }
+  if (lam_g) {
+    for (int e = t; e < N * NX; e += T) {
+      double v = l.lam[e];
+      // terminal cost on F_{N-1} in the reference (mpc.py:1682) vs on x_N here: multipliers of the last defect
+      // differ by grad V(x_N) (flag bit 0)
+      if ((pc.flags & 1) && e >= (N - 1) * NX) v += l.grad[N * NZ + (e - (N - 1) * NX)];
+      lam_g[b * (int64_t)(N * NX) + e] = v;
+    }
+  }
+  if (first) {
+    if (first_kind == 0) { for (int a = t; a < NU; a += T) first[b * NU + a] = l.Z[NX + a] * pc.sz[NX + a]; }
+    else { for (int a = t; a < NX; a += T) first[b * NX + a] = l.Z[N * NZ + a] * pc.sz[a]; }
+  }
+  if (t == 0) {
+    f_opt[b] = fval;
+    status[b] = st;
+    iters[b] = it;
+    if (kkt) kkt[b] = E0;
+    if (prof && b == 0)
+      for (int q = 0; q < PH_COUNT; ++q) prof[q] = tprof[q];
+  }
+#undef OCP_TICK
+}
+
+}  // namespace hilo

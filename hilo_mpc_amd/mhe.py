@@ -1,0 +1,299 @@
+"""Batched moving-horizon estimation on the GPU.
+
+API mirror of `hilo_mpc.MHE` (`MovingHorizonEstimator`, hilo_mpc/modules/estimator/mhe.py) for the hot path:
+`quad_arrival_cost.add_states(weights, guess)`, `quad_stage_cost.add_measurements(weights)`,
+`quad_stage_cost.add_state_noise(weights)` (util/modeling.py:686-777), `horizon`, `set_box_constraints`,
+`set_initial_guess`, `set_scaling`, `setup`, `add_measurements(y_meas, u_meas)` (mhe.py:274-309, ring buffer of the last
+N samples), `estimate(x_arrival=None, p_arrival=None, v0=None)` (mhe.py:311-416; returns `(None, None)` until the
+window is full, then `(x_N, p)` - the one-step-ahead state, mhe.py:381-384) - with a leading batch axis.
+
+Scope: pre-discretised model + `integration_method='discrete'`, state noise, model parameters pinned
+by `p_lb == p_ub` (parameter *estimation* adds horizon-global variables and is not yet offloaded).
+"""
+import ctypes as C
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._device import device, to_dev, ptr, stream_ptr
+from .nmpc import _weight_matrix, _wrap_list, STATUS_TEXT
+
+
+class _ArrivalCost:
+    def __init__(self, model):
+        self._model = model
+        self.Wx = None
+        self.x_guess = None
+        self._is_set = False
+
+    def add_states(self, weights, guess):
+        """modeling.py:747-760."""
+        guess = _wrap_list(guess)
+        if len(guess) != self._model.n_x:
+            raise ValueError(f"The guess must have the same dimension of the model states."
+                             f"There are {self._model.n_x} states but guess has {len(guess)} values.")
+        self.Wx = _weight_matrix(weights, self._model.n_x, 'weights')
+        self.x_guess = guess
+        self._is_set = True
+
+    def add_parameters(self, weights, guess):
+        raise NotImplementedError("parameter estimation is not yet offloaded: pin the parameters with "
+                                  "set_box_constraints(p_lb=p, p_ub=p)")
+
+
+class _StageCost:
+    def __init__(self, model):
+        self._model = model
+        self.Wy = self.Ww = None
+        self._is_set = False
+
+    def add_measurements(self, weights, names=None):
+        """modeling.py:686-712 (all measurements)."""
+        if names is not None and list(names) != list(self._model.measurement_names):
+            raise NotImplementedError("a subset of the measurements is not yet offloaded")
+        self.Wy = _weight_matrix(weights, self._model.n_y, 'weights')
+        self._is_set = True
+
+    def add_state_noise(self, weights):
+        """modeling.py:735-745."""
+        self.Ww = _weight_matrix(weights, self._model.n_x, 'weights')
+        self._is_set = True
+
+    def add_inputs(self, names, weights):
+        raise NotImplementedError("input-noise costs are not yet offloaded")
+
+
+class MovingHorizonEstimator:
+    def __init__(self, model, id=None, name=None, plot_backend=None, time=0., device_index=None):
+        if not model.discrete:
+            warnings.warn("The device backend needs a discrete-time model (MHE's 'rk4' option is not implemented in the "
+                          "reference either, SURVEY.md Q19). I am discretising with 'rk4' for you.")
+            model = model.discretize('rk4')
+        if not model._is_setup:
+            model.setup()
+        self._model = model
+        self.name = name
+        self._n_x, self._n_u, self._n_p, self._n_y = model.n_x, model.n_u, model.n_p, model.n_y
+        self.quad_arrival_cost = _ArrivalCost(model)
+        self.quad_stage_cost = _StageCost(model)
+        self._horizon = None
+        self._x_lb = self._x_ub = self._w_lb = self._w_ub = self._p_lb = self._p_ub = None
+        self._x_guess = self._w_guess = None
+        self._x_scaling = self._w_scaling = self._u_scaling = None
+        self._solver_options = {}
+        self._handle = None
+        self._dev_index = device_index
+        self._nlp_setup_done = False
+        self._time = float(time)
+        self._sampling_interval = model.dt
+        self._meas_counter = 0
+        self._horizon_is_reached = False
+        self._y_hist = self._u_hist = None
+        self._nlp_solution = None
+
+    type = 'MHE'
+
+    @property
+    def horizon(self):
+        return self._horizon
+
+    @horizon.setter
+    def horizon(self, n):
+        if not isinstance(n, (int, np.integer)) or n <= 0:
+            raise ValueError("The horizon must be a positive integer")
+        self._horizon = int(n)
+
+    def set_box_constraints(self, x_ub=None, x_lb=None, w_ub=None, w_lb=None, p_ub=None, p_lb=None, z_ub=None, z_lb=None):
+        def chk(v, n, what):
+            if v is None:
+                return None
+            v = _wrap_list(v)
+            if len(v) != n:
+                raise TypeError(f"The model has {n} {what}. You need to pass the same number of bounds.")
+            return v
+        self._x_ub, self._x_lb = chk(x_ub, self._n_x, 'states'), chk(x_lb, self._n_x, 'states')
+        self._w_ub, self._w_lb = chk(w_ub, self._n_x, 'states'), chk(w_lb, self._n_x, 'states')
+        self._p_ub, self._p_lb = chk(p_ub, self._n_p, 'parameters'), chk(p_lb, self._n_p, 'parameters')
+
+    def set_initial_guess(self, x_guess=None, w_guess=None, p_guess=None, z_guess=None):
+        self._x_guess = None if x_guess is None else _wrap_list(x_guess)
+        self._w_guess = None if w_guess is None else _wrap_list(w_guess)
+
+    def set_scaling(self, x_scaling=None, w_scaling=None, p_scaling=None, u_scaling=None):
+        if p_scaling is not None:
+            raise NotImplementedError("parameter scaling is not offloaded (the parameters are pinned data)")
+        self._x_scaling = None if x_scaling is None else _wrap_list(x_scaling)
+        self._w_scaling = None if w_scaling is None else _wrap_list(w_scaling)
+        self._u_scaling = None if u_scaling is None else _wrap_list(u_scaling)
+
+    def set_solver_opts(self, options=None):
+        self._solver_options = {k.split('.')[-1]: v for k, v in (options or {}).items()}
+
+    def setup(self, options=None, nlp_opts=None, solver='ipopt'):
+        """mhe.py:418-790."""
+        if self._horizon is None:
+            raise ValueError("You must set a horizon length before")
+        if not (self.quad_arrival_cost._is_set or self.quad_stage_cost._is_set):
+            raise ValueError("You need to define a cost function before setting up the MHE.")
+        opts = {'integration_method': 'discrete', 'arrival_guess_update': 'smoothing', 'warm_start': True}
+        for k, v in (options or {}).items():
+            if k == 'integration_method' and v != 'discrete':
+                warnings.warn(f"The integration method is set to {v} but I notice that the model is in discrete time. "
+                              f"I am overwriting and using discrete mode.")
+                continue
+            if k == 'arrival_guess_update' and v == 'filtering':
+                raise NotImplementedError("The filtering update is not yet implemented.")      # mhe.py:257-258
+            opts[k] = v
+        self._nlp_options = opts
+        if nlp_opts is not None:
+            self.set_solver_opts(nlp_opts)
+        if self._n_p:
+            if self._p_lb is None or self._p_ub is None or list(self._p_lb) != list(self._p_ub):
+                raise NotImplementedError("parameter estimation is not yet offloaded: pin the parameters with "
+                                          "set_box_constraints(p_lb=p, p_ub=p)")
+        if self.quad_stage_cost.Ww is None:
+            raise NotImplementedError("MHE without state noise is not yet offloaded (and its 'multiple_shooting' branch "
+                                      "is broken in the reference, SURVEY.md Q8)")
+        m = self._model
+        keep = []
+
+        def hp(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+            keep.append(a)
+            return a.ctypes.data
+
+        d = _lib.MheDesc()
+        d.model_id, d.N = m.model_id, self._horizon
+        d.erk_order = m.erk_order if m.erk_order else 4
+        d.n_sub = m.n_sub
+        so = self._solver_options
+        d.max_iter, d.acceptable_iter = int(so.get('max_iter', 0)), int(so.get('acceptable_iter', 0))
+        d.dt = m.dt
+        d.tol, d.acceptable_tol = float(so.get('tol', 0.)), float(so.get('acceptable_tol', 0.))
+        d.mu_init, d.bound_relax_factor = float(so.get('mu_init', 0.)), float(so.get('bound_relax_factor', -1.))
+        d.Wx, d.Wy, d.Ww = hp(self.quad_arrival_cost.Wx), hp(self.quad_stage_cost.Wy), hp(self.quad_stage_cost.Ww)
+        d.x_lb, d.x_ub, d.w_lb, d.w_ub = hp(self._x_lb), hp(self._x_ub), hp(self._w_lb), hp(self._w_ub)
+        d.x_scaling, d.w_scaling, d.u_scaling = hp(self._x_scaling), hp(self._w_scaling), hp(self._u_scaling)
+        d.x_guess, d.w_guess = hp(self._x_guess), hp(self._w_guess)
+        self._dev = device(self._dev_index)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().hilo_mhe_create(C.byref(d), self._dev.index, C.byref(h)))
+        self._destroy()
+        self._handle = h
+        N, nx, np_ = self._horizon, self._n_x, self._n_p
+        self._n_v, self._n_g = np_ + (N + 1) * nx + N * nx, N * nx
+        # bit-exact index maps of mhe.py:614-655
+        self._p_ind = [list(range(np_))] if np_ else []
+        self._x_ind = [list(range(np_ + k * nx, np_ + (k + 1) * nx)) for k in range(N + 1)]
+        self._w_ind = [list(range(np_ + (N + 1) * nx + k * nx, np_ + (N + 1) * nx + (k + 1) * nx)) for k in range(N)]
+        self._sx = np.ones(nx) if self._x_scaling is None else np.asarray(self._x_scaling)
+        self._p_pinned = None if not np_ else to_dev(np.asarray(self._p_lb, dtype=float), self._dev, (1, -1))
+        self._nlp_setup_done = True
+
+    def _destroy(self):
+        if self._handle is not None:
+            _lib.lib().hilo_mhe_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    # ---- measurement ring buffer (mhe.py:274-309), kept on the device: [B, N, ny] / [B, N, nu] ---------------
+    def add_measurements(self, y_meas, u_meas=None):
+        if not self._nlp_setup_done:
+            raise RuntimeError("You need to setup the MHE by running .setup() before running add_measurements")
+        y = to_dev(y_meas, self._dev).reshape(-1, self._n_y)
+        B = y.shape[0]
+        u = None
+        if self._n_u:
+            if u_meas is None:
+                raise ValueError(f"The model has {self._n_u} input(s); pass their measured values as u_meas")
+            u = to_dev(u_meas, self._dev).reshape(-1, self._n_u)
+            u = u.expand(B, -1) if u.shape[0] == 1 else u
+        N = self._horizon
+        if self._y_hist is None or self._y_hist.shape[0] != B:
+            self._y_hist = torch.zeros(B, N, self._n_y, dtype=torch.float64, device=self._dev)
+            self._u_hist = torch.zeros(B, N, max(self._n_u, 1), dtype=torch.float64, device=self._dev)
+            self._meas_counter = 0
+            self._horizon_is_reached = False
+        if self._meas_counter < N:
+            self._y_hist[:, self._meas_counter] = y
+            if u is not None:
+                self._u_hist[:, self._meas_counter, :self._n_u] = u
+        else:                                                   # shift: the oldest sample is forgotten (mhe.py:304-309)
+            self._y_hist = torch.cat([self._y_hist[:, 1:], y[:, None]], dim=1)
+            if u is not None:
+                self._u_hist = torch.cat([self._u_hist[:, 1:], u[:, None]], dim=1)
+        self._meas_counter += 1
+        if self._meas_counter >= N:
+            self._horizon_is_reached = True
+
+    def estimate(self, x_arrival=None, p_arrival=None, v0=None, runs=0, **kwargs):
+        """mhe.py:311-416."""
+        if not self._nlp_setup_done:
+            raise ValueError("You need to setup the nlp before optimizing. Type *mheObject*.setup()")
+        if runs != 0:
+            raise NotImplementedError("multi-start uses unseeded random perturbations in the reference (mhe.py:399)")
+        self._time += self._sampling_interval                   # mhe.py:333
+        if not self._horizon_is_reached:
+            return None, None                                   # mhe.py:415-416
+        B = self._y_hist.shape[0]
+        dev = self._dev
+        if x_arrival is not None:
+            xa = to_dev(x_arrival, dev).reshape(-1, self._n_x)
+            if xa.shape[1] != self._n_x:
+                raise ValueError(f'The model has {self._n_x} states(s): {self._model.dynamical_state_names}. You must '
+                                 f'pass me a guess of the values before running the optimization')
+            xa = xa.expand(B, -1) if xa.shape[0] == 1 else xa
+        elif self._nlp_solution is not None and self._nlp_solution['x'].shape[0] == B:
+            # 'smoothing' update: x_2 of the previous solution (mhe.py:254-256) - taken as stored, i.e. scaled
+            xa = self._nlp_solution['x'][:, self._x_ind[2]]
+        else:
+            g = self.quad_arrival_cost.x_guess
+            xa = to_dev(np.tile(np.asarray(g if g is not None else np.zeros(self._n_x), dtype=float), (B, 1)), dev)
+        xa = xa.contiguous()
+        v0t = None
+        if v0 is not None:
+            v0t = to_dev(v0, dev).reshape(-1, self._n_v)
+            v0t = (v0t.expand(B, -1) if v0t.shape[0] == 1 else v0t).contiguous()
+        elif not self._nlp_options.get('warm_start', True):
+            _lib.check(_lib.lib().hilo_mhe_reset_warm_start(self._handle))
+        p, ps = (self._p_pinned, 0) if self._n_p else (None, 0)
+        v_opt = torch.empty(B, self._n_v, dtype=torch.float64, device=dev)
+        f_opt = torch.empty(B, dtype=torch.float64, device=dev)
+        lam_g = torch.empty(B, self._n_g, dtype=torch.float64, device=dev)
+        x_opt = torch.empty(B, self._n_x, dtype=torch.float64, device=dev)
+        status = torch.empty(B, dtype=torch.int32, device=dev)
+        iters = torch.empty(B, dtype=torch.int32, device=dev)
+        kkt = torch.empty(B, dtype=torch.float64, device=dev)
+        u_hist = self._u_hist[:, :, :self._n_u].contiguous() if self._n_u else None
+        _lib.check(_lib.lib().hilo_mhe_estimate(self._handle, B, ptr(xa), ptr(p), ps, ptr(u_hist),
+                                                ptr(self._y_hist.contiguous()), ptr(v0t), ptr(v_opt), ptr(f_opt),
+                                                ptr(lam_g), ptr(x_opt), ptr(status), ptr(iters), ptr(kkt),
+                                                stream_ptr(dev)))
+        self._nlp_solution = {'x': v_opt, 'f': f_opt, 'lam_g': lam_g, 'status': status, 'iter_count': iters,
+                              'kkt_error': kkt}
+        p_opt = None if not self._n_p else self._p_pinned.expand(B, -1)
+        return x_opt, p_opt
+
+    @property
+    def solver_status_code(self):
+        return None if self._nlp_solution is None else self._nlp_solution['status'].cpu().numpy()
+
+    def stats(self):
+        s = self._nlp_solution
+        if s is None:
+            return {}
+        st = s['status'].cpu().numpy()
+        return {'return_status': [STATUS_TEXT.get(int(c), 'other') for c in st], 'success': (st == 1) | (st == 2),
+                'iter_count': s['iter_count'].cpu().numpy(), 'kkt_error': s['kkt_error'].cpu().numpy()}
+
+
+MHE = MovingHorizonEstimator

@@ -432,6 +432,16 @@ class NMPC:
         U = v[:, (N + 1) * nx:].reshape(-1, N, nu) * self._su
         return np.swapaxes(X, 1, 2), np.swapaxes(U, 1, 2), None
 
+    def phase_profile(self, enable=True):
+        """Developer aid (hilo_nmpc_profile): shader-clock cycles instance 0 spent per solver phase in the launches
+        since the last call.  Returns a dict or None when collection was just switched on."""
+        names = ['derivatives', 'errors', 'riccati', 'step', 'line_search', 'update']
+        buf = (C.c_longlong * 6)()
+        had = getattr(self, '_prof_on', False)
+        _lib.check(_lib.lib().hilo_nmpc_profile(self._handle, int(bool(enable)), buf if had else None))
+        self._prof_on = bool(enable)
+        return dict(zip(names, list(buf))) if had else None
+
     def plant_step(self, x, u, cp=None):
         """Closed-loop helper: x+ = Phi(x, u, p) with the controller's shooting map, on the device."""
         x = to_dev(x, self._dev).reshape(-1, self._n_x).contiguous()

@@ -220,9 +220,49 @@ int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch,
                     int32_t* iters,                   /* [B] interior-point iterations */
                     double* kkt,                      /* [B] scaled optimality error at the returned point or NULL */
                     void* stream);
+/* developer aid: per-phase shader-clock totals of instance 0 (derivatives, errors, Riccati, step, line search,
+   update); enable != 0 starts collecting, cycles_host[6] (may be NULL) receives the last launch's counters */
+int hilo_nmpc_profile(hilo_nmpc* h, int enable, long long* cycles_host);
 /* x+ = Phi(x, u, p) with the controller's own shooting map: closed-loop harness (control_loop.py:343-396) */
 int hilo_nmpc_plant_step(hilo_nmpc* h, int64_t batch, const double* x, const double* u, const double* p,
                          int64_t p_stride, double* x_next, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* MHE: batched moving-horizon estimation                                                                   */
+/* replaces `ca.nlpsol("solver",'ipopt',...)` built at hilo_mpc/modules/estimator/mhe.py:782-790 and called as */
+/* `solver(x0=v0, lbx, ubx, lbg, ubg, p=param)` at mhe.py:375 by `MovingHorizonEstimator.estimate`; transcription  */
+/* mhe.py:596-760 for a pre-discretised model + `integration_method='discrete'`, state noise, pinned parameters   */
+/* ------------------------------------------------------------------------------------------------------- */
+typedef struct hilo_mhe hilo_mhe;
+
+typedef struct hilo_mhe_desc {
+  int32_t model_id, N, erk_order, n_sub, max_iter, acceptable_iter;
+  double dt, tol, acceptable_tol, mu_init, bound_relax_factor;   /* 0 / <0 -> IPOPT defaults, see hilo_nmpc_desc */
+  /* HOST pointers (NULL = zero weight / no bound / unit scaling / zero guess); costs act on un-scaled quantities
+     (hilo_mpc/util/modeling.py:665-672) */
+  const double* Wx;   /* [nx][nx] arrival weight   (modeling.py:747-777, mhe.py:742-745) */
+  const double* Wy;   /* [ny][ny] measurement weight (modeling.py:686-712) */
+  const double* Ww;   /* [nx][nx] state-noise weight (modeling.py:735-745) */
+  const double* x_lb; const double* x_ub; const double* w_lb; const double* w_ub;   /* original units */
+  const double* x_scaling; const double* w_scaling; const double* u_scaling;
+  const double* x_guess; const double* w_guess;
+} hilo_mhe_desc;
+
+int hilo_mhe_create(const hilo_mhe_desc* desc, int device, hilo_mhe** out);          /* = setup(), mhe.py:418 */
+void hilo_mhe_destroy(hilo_mhe* h);
+int hilo_mhe_dims(const hilo_mhe* h, int* n_v, int* n_g, int* nx, int* nu, int* np, int* ny);
+int hilo_mhe_reset_warm_start(hilo_mhe* h);
+/* One estimate() for `batch` independent estimators over a full window (mhe.py:311-416).
+   v layout = the reference's decision vector [p | x_0..x_N | w_0..w_{N-1}] (scaled, mhe.py:614-655). */
+int hilo_mhe_estimate(hilo_mhe* h, int64_t batch,
+                      const double* x_arrival,            /* [B][nx]   arrival guess, original units (mhe.py:347-351) */
+                      const double* p, int64_t p_stride,  /* [B][np]   pinned model parameters */
+                      const double* u_meas,               /* [B][N][nu] = param['u_meas'] transposed (mhe.py:361-362) */
+                      const double* y_meas,               /* [B][N][ny] = param['y_meas'] transposed (mhe.py:358-359) */
+                      const double* v0,                   /* [B][n_v] or NULL -> previous solution (mhe.py:385) / guess */
+                      double* v_opt, double* f_opt, double* lam_g,
+                      double* x_opt,                      /* [B][nx]  x_N un-scaled: one-step-ahead state (mhe.py:381-384) */
+                      int32_t* status, int32_t* iters, double* kkt, void* stream);
 
 #ifdef __cplusplus
 }

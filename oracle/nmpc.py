@@ -247,9 +247,10 @@ class DenseIpm:
         U = w[:, pb.N * pb.nx:].reshape(B, pb.N, pb.nu)
         return X, U
 
-    def eval_fc(self, w, x0, p, u_old):
+    def eval_fc(self, w, data):
         """objective (with the terminal term on x_N, which equals Phi_{N-1} on the feasible set) and defects."""
         pb = self.pb
+        x0, p, u_old = data['x0'], data['p'], data.get('u_old')
         X, U = self._XU(w, x0)
         B = w.shape[0]
         f = np.zeros(B)
@@ -265,10 +266,11 @@ class DenseIpm:
         f += np.einsum('bi,ij,bj->b', d, pb.WN, d)
         return f, c.reshape(B, -1)
 
-    def eval_all(self, w, lam, x0, p, u_old):
+    def eval_all(self, w, lam, data):
         """f, grad f, c, J (dense), W = hess_ww (f + lam^T c) (dense)."""
         pb = self.pb
         N, nx, nu, nz = pb.N, pb.nx, pb.nu, pb.nz
+        x0, p, u_old = data['x0'], data['p'], data.get('u_old')
         X, U = self._XU(w, x0)
         B = w.shape[0]
         f = np.zeros(B)
@@ -340,6 +342,22 @@ class DenseIpm:
             u_old = np.broadcast_to(np.atleast_2d(np.asarray(u_old, dtype=float)), (B, pb.nu))
         if w0 is None:
             w0 = np.concatenate([np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N)])
+        data = {'x0': x0, 'p': p}
+        if u_old is not None:
+            data['u_old'] = u_old
+        res = self.solve_data(data, w0, verbose)
+        X, U = self._XU(res['w'], x0)
+        res.update(X=X, U=U, u0=U[:, 0] * pb.su)
+        return res
+
+    @staticmethod
+    def _sl(data, idx):
+        return {k: v[idx] for k, v in data.items()}
+
+    def solve_data(self, data, w0, verbose=False):
+        """Generic driver: `data` is a dict of per-instance arrays handed to eval_fc / eval_all."""
+        o = self.o
+        B = next(iter(data.values())).shape[0]
         w = _push_interior(np.broadcast_to(np.atleast_2d(w0), (B, self.nw)), self.lb, self.ub, o)
         lam = np.zeros((B, self.m))
         zl = np.where(self.has_l, 1.0, 0.0) * np.ones((B, 1))
@@ -352,7 +370,7 @@ class DenseIpm:
         delta_last = np.zeros(B)
         n_resto = np.zeros(B, dtype=np.int32)
         filt = [[] for _ in range(B)]
-        f, c = self.eval_fc(w, x0, p, u_old)
+        f, c = self.eval_fc(w, data)
         theta0 = np.abs(c).sum(1)
         theta_min = o.theta_min_fact * np.maximum(1, theta0)
         theta_max = o.theta_max_fact * np.maximum(1, theta0)
@@ -362,7 +380,7 @@ class DenseIpm:
             idx = np.nonzero(active)[0]
             if idx.size == 0:
                 break
-            f_a, g, c, J, Wl = self.eval_all(w[idx], lam[idx], x0[idx], p[idx], None if u_old is None else u_old[idx])
+            f_a, g, c, J, Wl = self.eval_all(w[idx], lam[idx], self._sl(data, idx))
             E0, dual, prim, compl = self.errors(g, c, J, lam[idx], zl[idx], zu[idx], w[idx], np.zeros(idx.size))
             done = E0 <= o.tol
             status[idx[done]] = SOLVED
@@ -457,7 +475,7 @@ class DenseIpm:
                 if t.size == 0:
                     break
                 wt = w[idx[t]] + alpha[t, None] * d[t]
-                ft, ct = self.eval_fc(wt, x0[idx[t]], p[idx[t]], None if u_old is None else u_old[idx[t]])
+                ft, ct = self.eval_fc(wt, self._sl(data, idx[t]))
                 pht = self.barrier(ft, wt, mu[idx[t]])
                 tht = np.abs(ct).sum(1)
                 for q, b in enumerate(t):
@@ -497,8 +515,7 @@ class DenseIpm:
             for b in np.nonzero(resto & ~fail)[0]:
                 gb = idx[b]
                 filt[gb].append(((1 - o.gamma_theta) * th0[b], phi0[b] - o.gamma_phi * th0[b]))
-                wr = self._restore(w[gb], x0[gb], p[gb], None if u_old is None else u_old[gb], mu[gb], tau[gb],
-                                   filt[gb], theta_max[gb])
+                wr = self._restore(w[gb], self._sl(data, np.array([gb])), mu[gb], tau[gb], filt[gb], theta_max[gb])
                 if wr is None:
                     fail[b] = True
                 else:
@@ -535,22 +552,19 @@ class DenseIpm:
             zu[gi] = np.where(self.has_u, np.clip(zu[gi], mu[gi, None] / (o.kappa_sigma * su), o.kappa_sigma * mu[gi, None] / su), 0)
             iters[gi] += 1
 
-        f, g, c, J, Wl = self.eval_all(w, lam, x0, p, u_old)
+        f, g, c, J, Wl = self.eval_all(w, lam, data)
         E0, dual, prim, compl = self.errors(g, c, J, lam, zl, zu, w, np.zeros(B))
-        X, U = self._XU(w, x0)
-        return dict(w=w, lam=lam, zl=zl, zu=zu, f=f, status=status, iters=iters, X=X, U=U, kkt=E0, n_resto=n_resto,
-                    dual_inf=dual, prim_inf=prim, compl=compl, u0=U[:, 0] * pb.su)
+        return dict(w=w, lam=lam, zl=zl, zu=zu, f=f, status=status, iters=iters, kkt=E0, n_resto=n_resto,
+                    dual_inf=dual, prim_inf=prim, compl=compl)
 
-    def _restore(self, w, x0, p, u_old, mu, tau, filt, theta_max, max_it=50):
+    def _restore(self, w, data, mu, tau, filt, theta_max, max_it=50):
         """Feasibility restoration, simplified from W&B sec. 3.3: least-norm Newton steps on c(w) = 0
         (min |d|^2 s.t. J d = -c) with the fraction-to-the-boundary rule and an Armijo search on theta = |c|_1,
         until theta <= 0.9 theta_start and the point is acceptable to the filter.  Returns the new w or None."""
         o = self.o
         w = w[None].copy()
-        x0, p = x0[None], p[None]
-        u_old = None if u_old is None else u_old[None]
         lam0 = np.zeros((1, self.m))
-        f, g, c, J, _ = self.eval_all(w, lam0, x0, p, u_old)
+        f, g, c, J, _ = self.eval_all(w, lam0, data)
         th_start = np.abs(c).sum()
         th = th_start
         for _ in range(max_it):
@@ -568,7 +582,7 @@ class DenseIpm:
             ok = False
             while alpha > 1e-10:
                 wt = w + alpha * d
-                ft, ct = self.eval_fc(wt, x0, p, u_old)
+                ft, ct = self.eval_fc(wt, data)
                 tht = np.abs(ct).sum()
                 if np.isfinite(tht) and tht <= (1 - 1e-4 * alpha) * th:
                     ok = True
@@ -581,7 +595,7 @@ class DenseIpm:
                 ph = self.barrier(ft, w, np.array([mu]))[0]
                 if all(not (th >= tf and ph >= pf) for tf, pf in filt):
                     return w[0]
-            f, g, c, J, _ = self.eval_all(w, lam0, x0, p, u_old)
+            f, g, c, J, _ = self.eval_all(w, lam0, data)
         return None
 
     # ---- reference layout helpers -----------------------------------------------------------------------------

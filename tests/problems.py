@@ -48,3 +48,36 @@ def product_nmpc(spec, **solver_options):
         nmpc.set_scaling(x_scaling=spec.get('x_scaling'), u_scaling=spec.get('u_scaling'))
     nmpc.setup(options={'integration_method': 'discrete'}, solver_options=solver_options or None)
     return nmpc
+
+
+# ---- C3: MHE on the chemostat (nx=4, ny=2, N=30), SURVEY.md 8d ------------------------------------------------
+C3 = dict(model='chemostat4', dt=.25, N=30, order=4, Wx=[4.] * 4, Wy=[16.] * 2, Ww=[1e6] * 4,
+          x_lb=[0., 0., 0., 0.], x_guess=[.1, 40., 0., 0.], p=[100., 4., 1., 0.])
+
+
+def c3_data(B, N=30, seed=SEED):
+    """Truth simulated with the RK4 map from perturbed initial states under slowly varying inputs, measurements
+    y = (X, P) + N(0, 1e-2).  Returns x_arrival [B,4], u_meas [B,N,2], y_meas [B,N,2], x_true [B,N+1,4]."""
+    from oracle import models
+    from oracle.shooting import ShootingMap
+    rng = np.random.default_rng(seed)
+    sm = ShootingMap(models.get('chemostat4'), 4)
+    x = np.array([.1, 40., 0.05, 0.05]) * (1 + .1 * rng.uniform(-1, 1, (B, 4)))
+    xs = [x]
+    u = np.empty((B, N, 2))
+    for k in range(N):
+        u[:, k, 0] = .05 + .03 * np.sin(.3 * k + rng.uniform(0, 6.28, B))
+        u[:, k, 1] = .02 + .01 * np.cos(.2 * k + rng.uniform(0, 6.28, B))
+        x = sm.value(x, u[:, k], C3['p'], C3['dt'])
+        xs.append(x)
+    xt = np.stack(xs, axis=1)
+    y = xt[:, :N][:, :, [0, 2]] + .01 * rng.normal(size=(B, N, 2))
+    xa = xt[:, 0] * (1 + .05 * rng.normal(size=(B, 4)))
+    return xa, u, y, xt
+
+
+def oracle_mhe(spec):
+    from oracle import models
+    from oracle.mhe import MheProblem
+    kw = {k: v for k, v in spec.items() if k not in ('model', 'p')}
+    return MheProblem(models.get(spec['model']), **kw)

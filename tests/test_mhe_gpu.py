@@ -1,0 +1,96 @@
+"""GPU parity: hilo_mhe_estimate (through the reference-style MHE class and the C ABI) vs the oracle (oracle/mhe.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.mhe import MheIpm                                   # noqa: E402
+from tests.problems import C3, c3_data, oracle_mhe              # noqa: E402
+
+
+def product_mhe(spec, **solver_options):
+    from hilo_mpc_amd import MHE, Model
+    m = Model(spec['model']).discretize('erk', order=spec.get('order', 4)).setup(dt=spec['dt'])
+    mhe = MHE(m)
+    mhe.quad_arrival_cost.add_states(weights=list(spec['Wx']), guess=spec['x_guess'])
+    mhe.quad_stage_cost.add_measurements(weights=list(spec['Wy']))
+    mhe.quad_stage_cost.add_state_noise(weights=list(spec['Ww']))
+    mhe.horizon = spec['N']
+    mhe.set_box_constraints(x_lb=spec.get('x_lb'), x_ub=spec.get('x_ub'), p_lb=spec['p'], p_ub=spec['p'])
+    mhe.set_initial_guess(x_guess=spec['x_guess'])
+    mhe.setup(options={'integration_method': 'discrete'}, nlp_opts=solver_options or None)
+    return mhe
+
+
+def test_index_bookkeeping_bit_exact():
+    mhe = product_mhe(C3)
+    pb = oracle_mhe(C3)
+    assert mhe._x_ind == pb.x_ind and mhe._w_ind == pb.w_ind and mhe._p_ind == pb.p_ind     # mhe.py:614-655
+    assert (mhe._n_v, mhe._n_g) == (pb.n_v, pb.n_g) == (4 + 124 + 120, 120)
+
+
+def test_returns_none_until_window_is_full():
+    mhe = product_mhe(C3)
+    xa, u, y, _ = c3_data(2)
+    for k in range(C3['N'] - 1):
+        mhe.add_measurements(y[:, k], u[:, k])
+        assert mhe.estimate() == (None, None)                     # mhe.py:415-416
+    mhe.add_measurements(y[:, -1], u[:, -1])
+    x, p = mhe.estimate(x_arrival=xa)
+    assert x is not None and x.shape == (2, 4) and p.shape == (2, 4)
+    assert mhe._time == C3['dt'] * C3['N']                        # mhe.py:333
+
+
+def test_c3_estimate_vs_oracle_and_ring_buffer():
+    B = 6
+    xa, u, y, xt = c3_data(B)
+    pb = oracle_mhe(C3)
+    ipm = MheIpm(pb)
+    ref = ipm.solve(xa, C3['p'], u, y)
+    assert np.all(ref['status'] == 1)
+    mhe = product_mhe(C3)
+    for k in range(C3['N']):
+        mhe.add_measurements(y[:, k], u[:, k])
+    x, p = mhe.estimate(x_arrival=xa)
+    st = mhe.stats()
+    assert np.array_equal(mhe.solver_status_code, ref['status'])
+    assert np.all(st['kkt_error'] <= 1e-8)
+    f = mhe._nlp_solution['f'].cpu().numpy()
+    np.testing.assert_allclose(f, ref['f'], rtol=1e-7, atol=1e-9)
+    v = mhe._nlp_solution['x'].cpu().numpy()
+    # the measured states (X, P) of every stage are pinned by the data; S and I are only weakly observable through
+    # the saturated growth law (flat directions of the NLP), so they are compared through the objective above
+    Xg = v[:, 4:4 + 31 * 4].reshape(B, 31, 4)
+    np.testing.assert_allclose(Xg[:, 1:, [0, 2]], ref['X'][:, 1:, [0, 2]], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(v[:, :4], np.tile(C3['p'], (B, 1)))            # pinned parameters (mhe.py:614-623)
+    np.testing.assert_allclose(x.cpu().numpy()[:, [0, 2]], ref['x_opt'][:, [0, 2]], rtol=1e-5, atol=1e-6)
+    # next sample: the window shifts (oldest forgotten), arrival guess = previous x_2 ("smoothing", mhe.py:254-256),
+    # warm start = previous solution (mhe.py:385)
+    rng = np.random.default_rng(1)
+    y_new, u_new = y[:, -1] + .01 * rng.normal(size=(B, 2)), u[:, -1]
+    mhe.add_measurements(y_new, u_new)
+    x2, _ = mhe.estimate()
+    y2 = np.concatenate([y[:, 1:], y_new[:, None]], axis=1)
+    u2 = np.concatenate([u[:, 1:], u_new[:, None]], axis=1)
+    ref2 = ipm.solve(v[:, 4:][:, 8:12], C3['p'], u2, y2, w0=v[:, 4:])
+    assert np.array_equal(mhe.solver_status_code, ref2['status'])
+    np.testing.assert_allclose(mhe._nlp_solution['f'].cpu().numpy(), ref2['f'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(x2.cpu().numpy()[:, [0, 2]], ref2['x_opt'][:, [0, 2]], rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_batch_properties():
+    """BASELINE config C3 size (B = 4096): every instance solved, defects vanish, x_0 free, bounds respected."""
+    import torch
+    B = 4096
+    xa, u, y, _ = c3_data(B, seed=11)
+    mhe = product_mhe(C3)
+    for k in range(C3['N']):
+        mhe.add_measurements(torch.as_tensor(y[:, k], device='cuda'), torch.as_tensor(u[:, k], device='cuda'))
+    x, _ = mhe.estimate(x_arrival=torch.as_tensor(xa, device='cuda'))
+    st = mhe.stats()
+    assert np.mean(st['success']) == 1.0
+    assert np.all(st['kkt_error'][mhe.solver_status_code == 1] <= 1e-8)
+    v = mhe._nlp_solution['x']
+    X = v[:, 4:4 + 124].reshape(B, 31, 4)
+    assert float(X.min()) >= -1.0000001e-8
+    assert torch.equal(x, X[:, -1])
