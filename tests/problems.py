@@ -55,6 +55,12 @@ C3 = dict(model='chemostat4', dt=.25, N=30, order=4, Wx=[4.] * 4, Wy=[16.] * 2, 
           x_lb=[0., 0., 0., 0.], x_guess=[.1, 40., 0., 0.], p=[100., 4., 1., 0.])
 
 
+# C3 with the process noise boxed: in the reference's formulation w_0 carries no cost (mhe.py:742-748), so x_1 is free
+# and the weakly observable states S, I make the plain C3 NLP degenerate (several KKT points); the box ties x_1 to
+# Phi(x_0) and makes the minimiser unique - used for the tight parity comparison
+C3B = dict(C3, w_lb=[-1e-3] * 4, w_ub=[1e-3] * 4)
+
+
 def c3_data(B, N=30, seed=SEED):
     """Truth simulated with the RK4 map from perturbed initial states under slowly varying inputs, measurements
     y = (X, P) + N(0, 1e-2).  Returns x_arrival [B,4], u_meas [B,N,2], y_meas [B,N,2], x_true [B,N+1,4]."""

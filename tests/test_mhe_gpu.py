@@ -5,7 +5,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle.mhe import MheIpm                                   # noqa: E402
-from tests.problems import C3, c3_data, oracle_mhe              # noqa: E402
+from tests.problems import C3, C3B, c3_data, oracle_mhe              # noqa: E402
 
 
 def product_mhe(spec, **solver_options):
@@ -16,7 +16,8 @@ def product_mhe(spec, **solver_options):
     mhe.quad_stage_cost.add_measurements(weights=list(spec['Wy']))
     mhe.quad_stage_cost.add_state_noise(weights=list(spec['Ww']))
     mhe.horizon = spec['N']
-    mhe.set_box_constraints(x_lb=spec.get('x_lb'), x_ub=spec.get('x_ub'), p_lb=spec['p'], p_ub=spec['p'])
+    mhe.set_box_constraints(x_lb=spec.get('x_lb'), x_ub=spec.get('x_ub'), w_lb=spec.get('w_lb'), w_ub=spec.get('w_ub'),
+                            p_lb=spec['p'], p_ub=spec['p'])
     mhe.set_initial_guess(x_guess=spec['x_guess'])
     mhe.setup(options={'integration_method': 'discrete'}, nlp_opts=solver_options or None)
     return mhe
@@ -44,26 +45,22 @@ def test_returns_none_until_window_is_full():
 def test_c3_estimate_vs_oracle_and_ring_buffer():
     B = 6
     xa, u, y, xt = c3_data(B)
-    pb = oracle_mhe(C3)
+    pb = oracle_mhe(C3B)
     ipm = MheIpm(pb)
     ref = ipm.solve(xa, C3['p'], u, y)
-    assert np.all(ref['status'] == 1)
-    mhe = product_mhe(C3)
+    mhe = product_mhe(C3B)
     for k in range(C3['N']):
         mhe.add_measurements(y[:, k], u[:, k])
     x, p = mhe.estimate(x_arrival=xa)
     st = mhe.stats()
-    assert np.array_equal(mhe.solver_status_code, ref['status'])
+    assert np.array_equal(mhe.solver_status_code, ref['status']) and np.all(ref['status'] == 1)
     assert np.all(st['kkt_error'] <= 1e-8)
-    f = mhe._nlp_solution['f'].cpu().numpy()
-    np.testing.assert_allclose(f, ref['f'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(mhe._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-8, atol=1e-10)
     v = mhe._nlp_solution['x'].cpu().numpy()
-    # the measured states (X, P) of every stage are pinned by the data; S and I are only weakly observable through
-    # the saturated growth law (flat directions of the NLP), so they are compared through the objective above
-    Xg = v[:, 4:4 + 31 * 4].reshape(B, 31, 4)
-    np.testing.assert_allclose(Xg[:, 1:, [0, 2]], ref['X'][:, 1:, [0, 2]], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(v[:, :4], np.tile(C3['p'], (B, 1)))            # pinned parameters (mhe.py:614-623)
-    np.testing.assert_allclose(x.cpu().numpy()[:, [0, 2]], ref['x_opt'][:, [0, 2]], rtol=1e-5, atol=1e-6)
+    vr = ref['v']
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 1e-5
+    np.testing.assert_allclose(x.cpu().numpy(), ref['x_opt'], rtol=1e-5, atol=1e-6)
     # next sample: the window shifts (oldest forgotten), arrival guess = previous x_2 ("smoothing", mhe.py:254-256),
     # warm start = previous solution (mhe.py:385)
     rng = np.random.default_rng(1)
@@ -75,7 +72,27 @@ def test_c3_estimate_vs_oracle_and_ring_buffer():
     ref2 = ipm.solve(v[:, 4:][:, 8:12], C3['p'], u2, y2, w0=v[:, 4:])
     assert np.array_equal(mhe.solver_status_code, ref2['status'])
     np.testing.assert_allclose(mhe._nlp_solution['f'].cpu().numpy(), ref2['f'], rtol=1e-7, atol=1e-9)
-    np.testing.assert_allclose(x2.cpu().numpy()[:, [0, 2]], ref2['x_opt'][:, [0, 2]], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x2.cpu().numpy(), ref2['x_opt'], rtol=1e-5, atol=1e-6)
+
+
+def test_c3_plain_degenerate_problem_still_solves():
+    """Plain C3 (w_0 free and cost-less, mhe.py:742-748): several KKT points exist, so only solver-independent facts
+    are checked: success, KKT error, feasibility, and that the oracle's objective at the returned point equals the
+    reported one (same NLP)."""
+    B = 4
+    xa, u, y, _ = c3_data(B)
+    pb = oracle_mhe(C3)
+    ipm = MheIpm(pb)
+    mhe = product_mhe(C3)
+    for k in range(C3['N']):
+        mhe.add_measurements(y[:, k], u[:, k])
+    mhe.estimate(x_arrival=xa)
+    assert np.all(np.isin(mhe.solver_status_code, (1, 2)))
+    v = mhe._nlp_solution['x'].cpu().numpy()
+    data = {'p': np.tile(C3['p'], (B, 1)), 'x_arrival': xa, 'u_meas': u, 'y_meas': y}
+    f, c = ipm.eval_fc(v[:, 4:], data)
+    np.testing.assert_allclose(mhe._nlp_solution['f'].cpu().numpy(), f, rtol=1e-12)
+    assert np.abs(c).max() < 1e-8
 
 
 def test_full_size_batch_properties():
