@@ -18,5 +18,6 @@ __all__ = ['Model', 'KalmanFilter', 'ExtendedKalmanFilter', 'UnscentedKalmanFilt
            'GaussianProcess', 'GP', 'Kernel', 'Mean']
 from .nmpc import NMPC
 from .mhe import MovingHorizonEstimator, MHE
+from .lmpc import LMPC
 
-__all__ += ['NMPC', 'MovingHorizonEstimator', 'MHE']
+__all__ += ['NMPC', 'MovingHorizonEstimator', 'MHE', 'LMPC']

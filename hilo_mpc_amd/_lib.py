@@ -72,6 +72,10 @@ def _declare(lib):
         'hilo_mhe_dims': (C.c_int, [vp] + [P(C.c_int)] * 6),
         'hilo_mhe_reset_warm_start': (C.c_int, [vp]),
         'hilo_mhe_estimate': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        'hilo_qp_create': (C.c_int, [i32, i32, i32, P(vp)]),
+        'hilo_qp_destroy': (None, [vp]),
+        'hilo_qp_set_options': (C.c_int, [vp, dbl, i32]),
+        'hilo_qp_solve': (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_gp_create': (C.c_int, [i32, i32, i32, vp, vp, vp, i32, vp, i32, dbl, P(vp)]),
         'hilo_gp_destroy': (None, [vp]),
         'hilo_gp_log_marginal_likelihood': (C.c_int, [vp, P(C.c_double)]),

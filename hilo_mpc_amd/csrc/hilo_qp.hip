@@ -1,0 +1,393 @@
+// Batched dense convex QP solver (one wave per instance, everything LDS-resident) + C ABI: the LMPC path.
+//
+// Replaces the conic solver object of `LMPC.setup` - `ca.conic("solver", 'qpoases', {'h','a'})`
+// (hilo_mpc/modules/controller/mpc.py:2268-2276) - called from `LMPC.optimize` as
+// `solver(h=H, g=g, a=A, lbx, ubx, lba, uba)` (mpc.py:2374):
+//     min 1/2 x^T H x + g^T x   s.t.  lba <= A x <= uba,  lbx <= x <= ubx
+// The reference's Aeq is not stage-banded in general (its input block is `kron(B, I_N)`, mpc.py:2243), so
+// this path is a general dense solver: Mehrotra predictor-corrector interior point; per iteration one Cholesky of
+// H + Sigma (n x n), the Schur complement A (H+Sigma)^-1 A^T (m x m) and its Cholesky, two pairs of triangular
+// solves.  Variables with lbx == ubx (the pinned x_0, mpc.py:2361-2362) are substituted.  Rows must be equalities
+// (lba == uba), which is all the reference generates (polytopic constraints are a TODO there, mpc.py:2249-2250).
+#include <math.h>
+#include <string.h>
+
+#include "hilo_common.h"
+
+namespace hilo {
+
+struct QpDims { int n, m, ldn, ldm, max_iter; double tol, reg; };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// in-place lower Cholesky of the n x n matrix M (leading dimension ld, odd -> conflict-free column access)
+__device__ bool chol_lds(double* M, int n, int ld) {
+  const int t = threadIdx.x;
+  bool ok = true;
+  for (int j = 0; j < n; ++j) {
+    const double ajj = M[j * ld + j];
+    if (!(ajj > 0.0)) ok = false;
+    const double d = sqrt(ajj > 0.0 ? ajj : 1.0), id = 1.0 / d;
+    __syncthreads();
+    for (int i = j + t; i < n; i += 64) M[i * ld + j] = (i == j) ? d : M[i * ld + j] * id;
+    __syncthreads();
+    for (int i = j + 1 + t; i < n; i += 64) {
+      const double lij = M[i * ld + j];
+      for (int k = j + 1; k <= i; ++k) M[i * ld + k] -= lij * M[k * ld + j];
+    }
+    __syncthreads();
+  }
+  return ok;
+}
+
+// X (n x m, ld ldx) <- L^-1 X, one column per lane
+__device__ void trsm_lds(const double* L, int n, int ld, double* X, int m, int ldx) {
+  for (int c = threadIdx.x; c < m; c += 64) {
+    for (int i = 0; i < n; ++i) {
+      double s = X[i * ldx + c];
+      for (int j = 0; j < i; ++j) s -= L[i * ld + j] * X[j * ldx + c];
+      X[i * ldx + c] = s / L[i * ld + i];
+    }
+  }
+  __syncthreads();
+}
+
+// r (length n, in LDS) <- L^-1 r (forward) or L^-T r (backward), column oriented across lanes
+__device__ void trsv_lds(const double* L, int n, int ld, double* r, bool transpose) {
+  const int t = threadIdx.x;
+  if (!transpose) {
+    for (int j = 0; j < n; ++j) {
+      if (t == 0) r[j] /= L[j * ld + j];
+      __syncthreads();
+      const double rj = r[j];
+      for (int i = j + 1 + t; i < n; i += 64) r[i] -= L[i * ld + j] * rj;
+      __syncthreads();
+    }
+  } else {
+    for (int j = n - 1; j >= 0; --j) {
+      if (t == 0) r[j] /= L[j * ld + j];
+      __syncthreads();
+      const double rj = r[j];
+      for (int i = t; i < j; i += 64) r[i] -= L[j * ld + i] * rj;
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void qp_solve_kernel(QpDims qd, int64_t batch, const double* __restrict__ Hg, int64_t hs,
+                                                      const double* __restrict__ gg, int64_t gs,
+                                                      const double* __restrict__ Ag, int64_t as_,
+                                                      const double* __restrict__ lbx, const double* __restrict__ ubx,
+                                                      int64_t bs, const double* __restrict__ lba,
+                                                      const double* __restrict__ uba, int64_t bas,
+                                                      double* __restrict__ x_out, double* __restrict__ f_out,
+                                                      double* __restrict__ lam_a, double* __restrict__ lam_x,
+                                                      int32_t* __restrict__ status, int32_t* __restrict__ iters) {
+  extern __shared__ double lds[];
+  const int n = qd.n, m = qd.m, ldn = qd.ldn, ldm = qd.ldm, t = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  if (b >= batch) return;
+  double* q = lds;
+  auto take = [&](size_t k) { double* r = q; q += k; return r; };
+  double* Hf = take((size_t)n * ldn);   // H with fixed rows/cols removed (identity there)
+  double* Mc = take((size_t)n * ldn);   // H + Sigma -> its Cholesky factor
+  double* Af = take((size_t)m * ldn);   // A with fixed columns zeroed
+  double* X = take((size_t)n * ldm);    // L^-1 Af^T
+  double* S = take((size_t)m * ldm);    // Schur complement -> its Cholesky factor
+  double *x = take(n), *gf = take(n), *l = take(n), *u = take(n), *zl = take(n), *zu = take(n), *r1 = take(n),
+         *dx = take(n), *dzl = take(n), *dzu = take(n), *base = take(n), *xfix = take(n);
+  double *y = take(m), *bf = take(m), *rp = take(m), *dy = take(m);
+  const double* H = Hg + b * hs;
+  const double* A = Ag + b * as_;
+  const double* g = gg + b * gs;
+
+  // ---- load, substitute fixed variables (lbx == ubx) ----
+  int bad_rows = 0;
+  for (int i = t; i < n; i += 64) {
+    const double lo = lbx[b * bs + i], up = ubx[b * bs + i];
+    const bool fx = lo == up;
+    l[i] = fx ? NAN : lo;  // NAN marks a fixed variable
+    u[i] = up;
+    xfix[i] = fx ? lo : 0.0;
+  }
+  for (int r = t; r < m; r += 64)
+    if (lba[b * bas + r] != uba[b * bas + r]) bad_rows = 1;
+  bad_rows = __any(bad_rows);
+  __syncthreads();
+  for (int e = t; e < n * n; e += 64) {
+    const int i = e / n, j = e - i * n;
+    const bool fi = isnan(l[i]), fj = isnan(l[j]);
+    Hf[i * ldn + j] = (fi || fj) ? (i == j ? 1.0 : 0.0) : H[e];
+  }
+  for (int e = t; e < m * n; e += 64) {
+    const int r = e / n, j = e - r * n;
+    Af[r * ldn + j] = isnan(l[j]) ? 0.0 : A[e];
+  }
+  for (int i = t; i < n; i += 64) {
+    double s = g[i];
+    for (int j = 0; j < n; ++j) s += H[i * n + j] * xfix[j];
+    gf[i] = isnan(l[i]) ? 0.0 : s;
+  }
+  for (int r = t; r < m; r += 64) {
+    double s = uba[b * bas + r];
+    for (int j = 0; j < n; ++j) s -= A[r * n + j] * xfix[j];
+    bf[r] = s;
+    y[r] = 0.0;
+  }
+  // starting point: strictly inside the box, unit multipliers
+  double nb_part = 0.0;
+  for (int i = t; i < n; i += 64) {
+    const bool fx = isnan(l[i]);
+    const bool hl = !fx && l[i] > -INFINITY, hu = !fx && u[i] < INFINITY;
+    double xi = 0.0;
+    if (hl && hu) xi = 0.5 * (l[i] + u[i]);
+    else if (hl) xi = fmax(0.0, l[i] + 1.0);
+    else if (hu) xi = fmin(0.0, u[i] - 1.0);
+    x[i] = fx ? 0.0 : xi;
+    zl[i] = hl ? 1.0 : 0.0;
+    zu[i] = hu ? 1.0 : 0.0;
+    nb_part += (hl ? 1.0 : 0.0) + (hu ? 1.0 : 0.0);
+  }
+  const double nb = fmax(1.0, wave_sum(nb_part));
+  double gmax = 0.0;
+  for (int i = t; i < n; i += 64) gmax = fmax(gmax, fabs(gf[i]));
+  gmax = wave_max(gmax);
+  __syncthreads();
+
+  int st = HILO_STATUS_MAXITER, it = 0;
+  if (bad_rows) st = HILO_STATUS_OTHER;
+  for (it = 0; !bad_rows && it < qd.max_iter; ++it) {
+    // residuals: base = -(Hf x + gf + Af^T y), rd = -base - zl + zu, rp = Af x - bf, mu
+    double rdmax = 0.0, mupart = 0.0;
+    for (int i = t; i < n; i += 64) {
+      double s = gf[i];
+      for (int j = 0; j < n; ++j) s += Hf[i * ldn + j] * x[j];
+      for (int r = 0; r < m; ++r) s += Af[r * ldn + i] * y[r];
+      const bool fx = isnan(l[i]);
+      if (fx) s = 0.0;
+      base[i] = -s;
+      rdmax = fmax(rdmax, fabs(s - zl[i] + zu[i]));
+      if (!fx) {
+        if (l[i] > -INFINITY) mupart += (x[i] - l[i]) * zl[i];
+        if (u[i] < INFINITY) mupart += (u[i] - x[i]) * zu[i];
+      }
+    }
+    double rpmax = 0.0;
+    for (int r = t; r < m; r += 64) {
+      double s = -bf[r];
+      for (int j = 0; j < n; ++j) s += Af[r * ldn + j] * x[j];
+      rp[r] = s;
+      rpmax = fmax(rpmax, fabs(s));
+    }
+    rdmax = wave_max(rdmax);
+    rpmax = wave_max(rpmax);
+    const double mu = wave_sum(mupart) / nb;
+    if (fmax(fmax(rdmax / (1.0 + gmax), rpmax), mu) <= qd.tol) { st = HILO_STATUS_SOLVED; break; }
+    if (!isfinite(rdmax) || !isfinite(rpmax) || !isfinite(mu)) { st = HILO_STATUS_INFEASIBLE; break; }
+    // M = Hf + Sigma + reg; factor
+    for (int e = t; e < n * n; e += 64) {
+      const int i = e / n, j = e - i * n;
+      double v = Hf[i * ldn + j];
+      if (i == j && !isnan(l[i])) {
+        v += qd.reg;
+        if (l[i] > -INFINITY) v += zl[i] / (x[i] - l[i]);
+        if (u[i] < INFINITY) v += zu[i] / (u[i] - x[i]);
+      }
+      Mc[i * ldn + j] = v;
+    }
+    __syncthreads();
+    if (!chol_lds(Mc, n, ldn)) { st = HILO_STATUS_OTHER; break; }
+    for (int e = t; e < n * m; e += 64) {
+      const int i = e / m, c = e - i * m;
+      X[i * ldm + c] = Af[c * ldn + i];
+    }
+    __syncthreads();
+    trsm_lds(Mc, n, ldn, X, m, ldm);
+    for (int e = t; e < m * m; e += 64) {
+      const int a = e / m, c = e - a * m;
+      double s = (a == c) ? qd.reg : 0.0;
+      for (int i = 0; i < n; ++i) s += X[i * ldm + a] * X[i * ldm + c];
+      S[a * ldm + c] = s;
+    }
+    __syncthreads();
+    if (m > 0 && !chol_lds(S, m, ldm)) { st = HILO_STATUS_OTHER; break; }
+
+    double sigma_mu = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+      // r1 = base (+ centering/corrector terms in the second pass)
+      for (int i = t; i < n; i += 64) {
+        double s = base[i];
+        if (pass == 1 && !isnan(l[i])) {
+          if (l[i] > -INFINITY) s += (sigma_mu - dx[i] * dzl[i]) / (x[i] - l[i]);
+          if (u[i] < INFINITY) s -= (sigma_mu + dx[i] * dzu[i]) / (u[i] - x[i]);
+        }
+        r1[i] = s;
+      }
+      __syncthreads();
+      trsv_lds(Mc, n, ldn, r1, false);                       // t = L^-1 r1
+      for (int a = t; a < m; a += 64) {
+        double s = rp[a];
+        for (int i = 0; i < n; ++i) s += X[i * ldm + a] * r1[i];
+        dy[a] = s;
+      }
+      __syncthreads();
+      if (m > 0) {
+        trsv_lds(S, m, ldm, dy, false);
+        trsv_lds(S, m, ldm, dy, true);
+      }
+      for (int i = t; i < n; i += 64) {
+        double s = r1[i];
+        for (int a = 0; a < m; ++a) s -= X[i * ldm + a] * dy[a];
+        r1[i] = s;
+      }
+      __syncthreads();
+      trsv_lds(Mc, n, ldn, r1, true);                        // dx = L^-T (t - X dy)
+      // bound-multiplier steps, step lengths
+      double ap = 1.0, ad = 1.0;
+      const double tau = pass == 0 ? 1.0 : fmax(0.995, 1.0 - mu);
+      for (int i = t; i < n; i += 64) {
+        const bool fx = isnan(l[i]);
+        const double d = fx ? 0.0 : r1[i];
+        double dl = 0.0, du = 0.0;
+        if (!fx) {
+          // second pass: the affine products dx_aff*dz_aff are still in dx/dzl/dzu
+          const double cl = pass == 1 ? dx[i] * dzl[i] : 0.0, cu = pass == 1 ? -dx[i] * dzu[i] : 0.0;
+          if (l[i] > -INFINITY) {
+            const double s = x[i] - l[i];
+            dl = (sigma_mu - cl) / s - zl[i] - zl[i] / s * d;
+            if (d < 0.0) ap = fmin(ap, -tau * s / d);
+            if (dl < 0.0) ad = fmin(ad, -tau * zl[i] / dl);
+          }
+          if (u[i] < INFINITY) {
+            const double s = u[i] - x[i];
+            du = (sigma_mu - cu) / s - zu[i] + zu[i] / s * d;
+            if (d > 0.0) ap = fmin(ap, tau * s / d);
+            if (du < 0.0) ad = fmin(ad, -tau * zu[i] / du);
+          }
+        }
+        dx[i] = d; dzl[i] = dl; dzu[i] = du;  // own entries only: no cross-lane hazard
+      }
+      ap = wave_min(ap);
+      ad = wave_min(ad);
+      __syncthreads();
+      if (pass == 0) {
+        double mpart = 0.0;
+        for (int i = t; i < n; i += 64) {
+          if (isnan(l[i])) continue;
+          if (l[i] > -INFINITY) mpart += (x[i] - l[i] + ap * dx[i]) * (zl[i] + ad * dzl[i]);
+          if (u[i] < INFINITY) mpart += (u[i] - x[i] - ap * dx[i]) * (zu[i] + ad * dzu[i]);
+        }
+        const double mu_aff = wave_sum(mpart) / nb;
+        const double sg = mu > 0.0 ? (mu_aff / mu) : 0.0;
+        sigma_mu = sg * sg * sg * mu;
+      } else {
+        for (int i = t; i < n; i += 64) {
+          x[i] += ap * dx[i];
+          zl[i] += ad * dzl[i];
+          zu[i] += ad * dzu[i];
+        }
+        for (int a = t; a < m; a += 64) y[a] += ad * dy[a];
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- outputs (CasADi conic sign convention: H x + g + A^T lam_a + lam_x = 0) ----
+  double fpart = 0.0;
+  for (int i = t; i < n; i += 64) {
+    const bool fx = isnan(l[i]);
+    x[i] = fx ? xfix[i] : x[i];
+  }
+  __syncthreads();
+  for (int i = t; i < n; i += 64) {
+    double hx = 0.0, aty = 0.0;
+    for (int j = 0; j < n; ++j) hx += H[i * n + j] * x[j];
+    for (int r = 0; r < m; ++r) aty += A[r * n + i] * y[r];
+    fpart += x[i] * (0.5 * hx + g[i]);
+    x_out[b * n + i] = x[i];
+    if (lam_x) lam_x[b * n + i] = isnan(l[i]) ? -(hx + g[i] + aty) : zu[i] - zl[i];
+  }
+  if (lam_a)
+    for (int a = t; a < m; a += 64) lam_a[b * m + a] = y[a];
+  fpart = wave_sum(fpart);
+  if (t == 0) {
+    f_out[b] = fpart;
+    status[b] = st;
+    iters[b] = it;
+  }
+}
+
+}  // namespace hilo
+
+using namespace hilo;
+
+struct hilo_qp {
+  int device, n, m;
+  QpDims qd;
+  size_t lds_bytes;
+};
+
+extern "C" int hilo_qp_create(int n, int m, int device, hilo_qp** out) {
+  HILO_REQUIRE(out, "hilo_qp_create: NULL argument");
+  HILO_REQUIRE(n >= 1 && m >= 0, "hilo_qp_create: need n >= 1, m >= 0 (got %d, %d)", n, m);
+  hilo_qp* h = new hilo_qp();
+  h->device = device; h->n = n; h->m = m;
+  QpDims& q = h->qd;
+  q.n = n; q.m = m;
+  q.ldn = n | 1;                 // odd leading dimensions: conflict-free column walks in LDS
+  q.ldm = (m > 0 ? m : 1) | 1;
+  q.max_iter = 100; q.tol = 1e-10; q.reg = 1e-11;
+  h->lds_bytes = sizeof(double) * ((size_t)2 * n * q.ldn + (size_t)m * q.ldn + (size_t)n * q.ldm + (size_t)(m > 0 ? m : 1) * q.ldm +
+                                   12 * (size_t)n + 4 * (size_t)(m > 0 ? m : 1));
+  if (h->lds_bytes > 160 * 1024) {
+    const size_t need = h->lds_bytes;
+    delete h;
+    return fail(HILO_ENOTSUP, "QP of size n=%d, m=%d needs %zu B of LDS per instance (limit 163840)", n, m, need);
+  }
+  *out = h;
+  return HILO_OK;
+}
+
+extern "C" void hilo_qp_destroy(hilo_qp* h) { delete h; }
+
+extern "C" int hilo_qp_set_options(hilo_qp* h, double tol, int max_iter) {
+  HILO_REQUIRE(h, "hilo_qp_set_options: NULL handle");
+  if (tol > 0) h->qd.tol = tol;
+  if (max_iter > 0) h->qd.max_iter = max_iter;
+  return HILO_OK;
+}
+
+extern "C" int hilo_qp_solve(hilo_qp* h, int64_t batch, const double* H, int64_t h_stride, const double* g,
+                             int64_t g_stride, const double* A, int64_t a_stride, const double* lbx, const double* ubx,
+                             int64_t bx_stride, const double* lba, const double* uba, int64_t ba_stride, double* x,
+                             double* f, double* lam_a, double* lam_x, int32_t* status, int32_t* iters, void* stream) {
+  HILO_REQUIRE(h, "hilo_qp_solve: NULL handle");
+  HILO_REQUIRE(batch >= 0, "hilo_qp_solve: negative batch");
+  if (batch == 0) return HILO_OK;
+  HILO_REQUIRE(H && g && lbx && ubx && x && f && status && iters, "hilo_qp_solve: NULL argument");
+  HILO_REQUIRE(h->m == 0 || (A && lba && uba), "hilo_qp_solve: the problem has %d rows but A / lba / uba is NULL", h->m);
+  HILO_REQUIRE(bx_stride >= h->n, "hilo_qp_solve: lbx/ubx are per instance (x_0 is pinned through them, mpc.py:2361-2362)");
+  HILO_HIP_CHECK(hipSetDevice(h->device));
+  if (h->lds_bytes > 64 * 1024)
+    HILO_HIP_CHECK(hipFuncSetAttribute((const void*)qp_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)h->lds_bytes));
+  hipLaunchKernelGGL(qp_solve_kernel, dim3((unsigned)batch), dim3(64), h->lds_bytes, (hipStream_t)stream, h->qd, batch, H,
+                     h_stride, g, g_stride, A, a_stride, lbx, ubx, bx_stride, lba, uba, ba_stride, x, f, lam_a, lam_x, status,
+                     iters);
+  HILO_HIP_CHECK(hipGetLastError());
+  return HILO_OK;
+}

@@ -1,0 +1,213 @@
+"""Batched linear MPC on the GPU.
+
+API mirror of `hilo_mpc.LMPC` (hilo_mpc/modules/controller/mpc.py:1975-2460): `Q`, `R`, `P`, `horizon`,
+`set_box_constraints`, `set_scaling`, `setup(solver=...)`, `optimize(x0)` with a leading batch axis on `x0`.
+The QP is assembled exactly as `LMPC.setup` does (mpc.py:2198-2266) - including the `kron(B, I_N)` input block of the
+parameter-free branch (mpc.py:2243), selectable with `setup(kron_variant='reference'|'corrected')` - and
+solved by `hilo_qp_solve` (dense interior point) in libhilo_hip.so.  Cost convention 1/2 v^T H v (mpc.py:2374, Q6).
+"""
+import ctypes as C
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._device import device, to_dev, ptr, stream_ptr
+from .nmpc import _wrap_list, STATUS_TEXT
+
+
+class LMPC:
+    _solver_name_list_qp = ['qpoases', 'hip_qp']
+
+    def __init__(self, model, id=None, name=None, plot_backend=None, device_index=None):
+        if model.name != 'lti' and not model.is_linear():
+            raise TypeError("The model is nonlinear. Use the NMPC class or linearize the model.")
+        if model.name != 'lti':
+            raise NotImplementedError("LMPC needs an explicit LTI model: Model('lti', A=..., B=...)")
+        if not model._is_setup:
+            model.setup()
+        self._model = model
+        self._n_x, self._n_u = model.n_x, model.n_u
+        self._Q = self._R = self._P = None
+        self._horizon = None
+        self._x_lb = self._x_ub = self._u_lb = self._u_ub = None
+        self._x_scaling = self._u_scaling = None
+        self._handle = None
+        self._dev_index = device_index
+        self._time = 0.
+        self._n_iterations = 0
+        self._nlp_solution = None
+        self._sampling_interval = model.dt
+
+    type = 'LMPC'
+
+    def _mat(self, arg, n):
+        a = np.atleast_2d(np.asarray(arg, dtype=float))
+        if a.shape != (n, n):
+            raise ValueError(f"weight matrix must be {n}x{n}, got {a.shape}")
+        return a
+
+    Q = property(lambda s: s._Q)
+    R = property(lambda s: s._R)
+    P = property(lambda s: s._P)
+
+    @Q.setter
+    def Q(self, arg):
+        self._Q = self._mat(arg, self._n_x)
+
+    @R.setter
+    def R(self, arg):
+        self._R = self._mat(arg, self._n_u)
+
+    @P.setter
+    def P(self, arg):
+        self._P = self._mat(arg, self._n_x)
+
+    @property
+    def horizon(self):
+        return self._horizon
+
+    @horizon.setter
+    def horizon(self, n):
+        if not isinstance(n, (int, np.integer)) or n <= 0:
+            raise ValueError("The horizon must be a positive integer")
+        self._horizon = int(n)
+
+    prediction_horizon = horizon
+    control_horizon = horizon
+
+    def set_box_constraints(self, x_ub=None, x_lb=None, u_ub=None, u_lb=None):
+        def chk(v, n, what):
+            if v is None:
+                return None
+            v = _wrap_list(v)
+            if len(v) != n:
+                raise TypeError(f"The model has {n} {what}. You need to pass the same number of bounds.")
+            return v
+        self._x_ub, self._x_lb = chk(x_ub, self._n_x, 'states'), chk(x_lb, self._n_x, 'states')
+        self._u_ub, self._u_lb = chk(u_ub, self._n_u, 'inputs'), chk(u_lb, self._n_u, 'inputs')
+
+    def set_scaling(self, x_scaling=None, u_scaling=None):
+        self._x_scaling = None if x_scaling is None else _wrap_list(x_scaling)
+        self._u_scaling = None if u_scaling is None else _wrap_list(u_scaling)
+
+    def setup(self, options=None, solver_options=None, solver='qpoases', kron_variant='reference'):
+        """mpc.py:2143-2305.  `kron_variant='reference'` reproduces mpc.py:2243 (`kron(B, I_N)`), 'corrected' uses the
+        block-diagonal input matrix of the time-varying branch (mpc.py:2236-2240)."""
+        if solver not in self._solver_name_list_qp:
+            raise ValueError(f"The solver {solver} does no exist. The possible solver are {self._solver_name_list_qp}.")
+        if self._horizon is None:
+            raise ValueError("You must set a prediction horizon length before")
+        if kron_variant not in ('reference', 'corrected'):
+            raise ValueError("kron_variant must be 'reference' or 'corrected'")
+        N, nx, nu = self._horizon, self._n_x, self._n_u
+        A, B = self._model.A, self._model.B
+        Q = np.zeros((nx, nx)) if self._Q is None else self._Q                                  # mpc.py:2188-2193
+        P = np.zeros((nx, nx)) if self._P is None else self._P
+        R = np.zeros((nu, nu)) if self._R is None else self._R
+        sx = np.ones(nx) if self._x_scaling is None else np.asarray(self._x_scaling)
+        su = np.ones(nu) if self._u_scaling is None else np.asarray(self._u_scaling)
+        Abar1 = np.hstack([np.kron(np.eye(N), A), np.zeros((N * nx, nx))])                      # mpc.py:2209-2213
+        aux2 = np.zeros((N, N + 1))
+        for i in range(N):
+            aux2[i, i + 1] = -1
+        Abar2 = np.kron(aux2, np.eye(nx))                                                         # mpc.py:2233
+        Abar3 = np.kron(B, np.eye(N)) if kron_variant == 'reference' else np.kron(np.eye(N), B)  # mpc.py:2243
+        Aeq = np.hstack([Abar1 + Abar2, Abar3])                                                   # mpc.py:2245
+        n_v = (N + 1) * nx + N * nu
+        H = np.zeros((n_v, n_v))                                                                  # mpc.py:2252-2256
+        H[:N * nx, :N * nx] = np.kron(np.eye(N), Q)
+        H[N * nx:(N + 1) * nx, N * nx:(N + 1) * nx] = P
+        H[(N + 1) * nx:, (N + 1) * nx:] = np.kron(np.eye(N), R)
+        inf = np.inf
+        xl = (np.full(nx, -inf) if self._x_lb is None else np.asarray(self._x_lb, dtype=float)) / sx   # mpc.py:2071-2075
+        xu = (np.full(nx, inf) if self._x_ub is None else np.asarray(self._x_ub, dtype=float)) / sx
+        ul = (np.full(nu, -inf) if self._u_lb is None else np.asarray(self._u_lb, dtype=float)) / su
+        uu = (np.full(nu, inf) if self._u_ub is None else np.asarray(self._u_ub, dtype=float)) / su
+        self._dev = device(self._dev_index)
+        self._H = to_dev(H, self._dev)
+        self._g = torch.zeros(n_v, dtype=torch.float64, device=self._dev)                        # mpc.py:2258
+        self._Ad = to_dev(Aeq, self._dev)
+        self._beq = torch.zeros(N * nx, dtype=torch.float64, device=self._dev)                   # mpc.py:2248
+        self._v_lb = to_dev(np.concatenate([np.tile(xl, N + 1), np.tile(ul, N)]), self._dev)      # mpc.py:2259-2266
+        self._v_ub = to_dev(np.concatenate([np.tile(xu, N + 1), np.tile(uu, N)]), self._dev)
+        self._x_ind = [list(range(k * nx, (k + 1) * nx)) for k in range(N + 1)]                 # mpc.py:2221-2231
+        self._u_ind = [list(range((N + 1) * nx + k * nu, (N + 1) * nx + (k + 1) * nu)) for k in range(N)]
+        self._sx, self._su = to_dev(sx, self._dev), to_dev(su, self._dev)
+        self._n_v, self._n_g = n_v, N * nx
+        h = C.c_void_p()
+        _lib.check(_lib.lib().hilo_qp_create(n_v, N * nx, self._dev.index, C.byref(h)))
+        so = {k.split('.')[-1]: v for k, v in (solver_options or {}).items()}
+        _lib.check(_lib.lib().hilo_qp_set_options(h, float(so.get('tol', 0.)), int(so.get('max_iter', 0))))
+        self._destroy()
+        self._handle = h
+
+    def _destroy(self):
+        if self._handle is not None:
+            _lib.lib().hilo_qp_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def optimize(self, x0, tvp=None, cp=None):
+        """mpc.py:2307-2394."""
+        if self._handle is None:
+            raise ValueError("Howdy! You need to setup the MPC before optimizing. Run .setup() on the MPC object.")
+        if tvp is not None:
+            raise NotImplementedError("time-varying parameters are not yet offloaded")
+        if cp is not None:
+            warnings.warn("You are passing a parameter vector in the optimizer, but the model has no defined "
+                          "parameters. I am ignoring the vector.")
+        host = not isinstance(x0, torch.Tensor)
+        x = to_dev(x0, self._dev)
+        single = x.ndim <= 1 or (x.ndim == 2 and x.shape[1] == 1 and x.shape[0] == self._n_x and self._n_x != 1)
+        x = x.reshape(1, -1) if single else x
+        if x.shape[1] != self._n_x:
+            raise ValueError(f"We have an issue mate, the x0 you supplied has dimension {x.shape[1]} but the model has "
+                             f"{self._n_x} states.")
+        B, dev, n, m = x.shape[0], self._dev, self._n_v, self._n_g
+        lb = self._v_lb.expand(B, -1).contiguous()
+        ub = self._v_ub.expand(B, -1).contiguous()
+        lb[:, :self._n_x] = x / self._sx                                                           # mpc.py:2361-2362
+        ub[:, :self._n_x] = x / self._sx
+        v = torch.empty(B, n, dtype=torch.float64, device=dev)
+        f = torch.empty(B, dtype=torch.float64, device=dev)
+        lam_a = torch.empty(B, m, dtype=torch.float64, device=dev)
+        lam_x = torch.empty(B, n, dtype=torch.float64, device=dev)
+        status = torch.empty(B, dtype=torch.int32, device=dev)
+        iters = torch.empty(B, dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().hilo_qp_solve(self._handle, B, ptr(self._H), 0, ptr(self._g), 0, ptr(self._Ad), 0, ptr(lb),
+                                            ptr(ub), n, ptr(self._beq), ptr(self._beq), 0, ptr(v), ptr(f), ptr(lam_a),
+                                            ptr(lam_x), ptr(status), ptr(iters), stream_ptr(dev)))
+        self._nlp_solution = {'x': v, 'f': f, 'lam_a': lam_a, 'lam_x': lam_x, 'status': status, 'iter_count': iters}
+        self._time += self._sampling_interval                                                     # mpc.py:2386
+        self._n_iterations += 1                                                                   # mpc.py:2392
+        u = v[:, self._u_ind[0]] * self._su                                                       # mpc.py:2377
+        if host:
+            u = u.cpu().numpy()
+            return u.reshape(-1, 1) if single else u
+        return u[0] if single else u
+
+    @property
+    def solver_status_code(self):
+        return None if self._nlp_solution is None else self._nlp_solution['status'].cpu().numpy()
+
+    def stats(self):
+        s = self._nlp_solution
+        if s is None:
+            return {}
+        st = s['status'].cpu().numpy()
+        return {'return_status': [STATUS_TEXT.get(int(c), 'other') for c in st], 'success': st == 1,
+                'iter_count': s['iter_count'].cpu().numpy()}
+
+    def return_prediction(self):
+        v = self._nlp_solution['x'].cpu().numpy()
+        N, nx, nu = self._horizon, self._n_x, self._n_u
+        X = v[:, :(N + 1) * nx].reshape(-1, N + 1, nx) * self._sx.cpu().numpy()
+        U = v[:, (N + 1) * nx:].reshape(-1, N, nu) * self._su.cpu().numpy()
+        return np.swapaxes(X, 1, 2), np.swapaxes(U, 1, 2)

@@ -264,6 +264,29 @@ int hilo_mhe_estimate(hilo_mhe* h, int64_t batch,
                       double* x_opt,                      /* [B][nx]  x_N un-scaled: one-step-ahead state (mhe.py:381-384) */
                       int32_t* status, int32_t* iters, double* kkt, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------- */
+/* LMPC: batched dense convex QP                                                                            */
+/* replaces `ca.conic("solver",'qpoases',{'h': H.sparsity(),'a': Aeq.sparsity()})` built at                    */
+/* hilo_mpc/modules/controller/mpc.py:2268-2276 and called as                                                */
+/* `solver(h=H, g=g, a=Ad, lbx=v_lb, ubx=v_ub, lba=Ad_lb, uba=Ad_ub)` at mpc.py:2374 by `LMPC.optimize`         */
+/*     min 1/2 x^T H x + g^T x   s.t.  lba <= A x <= uba (rows must be equalities),  lbx <= x <= ubx          */
+/* ------------------------------------------------------------------------------------------------------- */
+typedef struct hilo_qp hilo_qp;
+int hilo_qp_create(int n, int m, int device, hilo_qp** out);
+void hilo_qp_destroy(hilo_qp* h);
+int hilo_qp_set_options(hilo_qp* h, double tol /* <=0 keeps 1e-10 */, int max_iter /* <=0 keeps 100 */);
+int hilo_qp_solve(hilo_qp* h, int64_t batch,
+                  const double* H, int64_t h_stride,       /* [B][n][n] row-major (stride 0 = shared) */
+                  const double* g, int64_t g_stride,       /* [B][n] */
+                  const double* A, int64_t a_stride,       /* [B][m][n] */
+                  const double* lbx, const double* ubx, int64_t bx_stride, /* [B][n]; lbx == ubx pins a variable */
+                  const double* lba, const double* uba, int64_t ba_stride, /* [B][m] */
+                  double* x,                               /* [B][n] */
+                  double* f,                               /* [B] */
+                  double* lam_a,                           /* [B][m] or NULL;  H x + g + A^T lam_a + lam_x = 0 */
+                  double* lam_x,                           /* [B][n] or NULL */
+                  int32_t* status, int32_t* iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

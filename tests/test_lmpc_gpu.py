@@ -1,0 +1,83 @@
+"""GPU parity: hilo_qp_solve (through the reference-style LMPC class and the C ABI) vs the oracle (oracle/lmpc.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.lmpc import LmpcProblem, lmpc_optimize             # noqa: E402
+from tests.test_oracle_lmpc import A, B, C1, DT                # noqa: E402
+
+
+def product_lmpc(kron_variant, N=10):
+    from hilo_mpc_amd import LMPC, Model
+    m = Model('lti', A=A, B=B).setup(dt=DT)                     # tests/test_LMPC.py:8-19
+    mpc = LMPC(m)
+    mpc.Q = np.eye(2)
+    mpc.R = 1
+    mpc.horizon = N
+    mpc.set_box_constraints(x_lb=[-5, -5], x_ub=[5, 5], u_lb=[-1], u_ub=[1])
+    mpc.setup(kron_variant=kron_variant)
+    return mpc
+
+
+@pytest.mark.parametrize('variant', ['reference', 'corrected'])
+def test_c1_vs_oracle(variant):
+    """BASELINE configs[0]: LMPC on the discrete double integrator (nx=2, nu=1, N=10), single instance and a batch."""
+    pb = LmpcProblem(**C1, kron_bug=(variant == 'reference'))
+    mpc = product_lmpc(variant)
+    assert mpc._x_ind == pb.x_ind and mpc._u_ind == pb.u_ind and mpc._n_v == 32          # mpc.py:2221-2231
+    np.testing.assert_array_equal(mpc._Ad.cpu().numpy(), pb.Aeq)
+    np.testing.assert_array_equal(mpc._H.cpu().numpy(), pb.H)
+    u = mpc.optimize([1., 1.])                                                          # tests/test_LMPC.py:10
+    ref = lmpc_optimize(pb, [[1., 1.]])
+    assert u.shape == (1, 1) and mpc.solver_status_code[0] == ref['status'][0] == 1
+    np.testing.assert_allclose(u, ref['u'].T, rtol=1e-7, atol=1e-9)
+    rng = np.random.default_rng(3)
+    x0 = np.vstack([[1., 1.], rng.uniform(-2, 2, (63, 2))])
+    ub = mpc.optimize(x0)
+    ref = lmpc_optimize(pb, x0)
+    st = mpc.solver_status_code
+    assert np.array_equal(st == 1, ref['status'] == 1)          # same instances feasible / solved
+    ok = st == 1
+    assert ok.sum() >= 32
+    v = mpc._nlp_solution['x'].cpu().numpy()
+    # the oracle's active-set polish gives the vertex solution to ~1e-13; the interior-point result is within its tol
+    np.testing.assert_allclose(v[ok], ref['v'][ok], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(ub[ok], ref['u'][ok], rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(mpc._nlp_solution['f'].cpu().numpy()[ok], ref['f'][ok], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(mpc._nlp_solution['lam_a'].cpu().numpy()[ok], ref['lam_a'][ok], rtol=1e-5, atol=1e-6)
+    # KKT in CasADi's convention at the returned point
+    lam_x = mpc._nlp_solution['lam_x'].cpu().numpy()[ok]
+    lam_a = mpc._nlp_solution['lam_a'].cpu().numpy()[ok]
+    assert np.abs(v[ok] @ pb.H + lam_a @ pb.Aeq + lam_x).max() < 1e-7
+    assert np.abs(v[ok] @ pb.Aeq.T).max() < 1e-9
+
+
+def test_closed_loop_200_steps_corrected():
+    """tests/test_LMPC.py:30-33: 200 closed-loop steps from x0 = [1, 1]; with the corrected input block the double
+    integrator is driven to the origin."""
+    import torch
+    mpc = product_lmpc('corrected')
+    x = torch.tensor([[1., 1.]], dtype=torch.float64, device='cuda')
+    At, Bt = torch.as_tensor(A, device='cuda'), torch.as_tensor(B, device='cuda')
+    for _ in range(200):
+        u = mpc.optimize(x)
+        x = x @ At.T + u @ Bt.T
+    assert mpc.solver_status_code[0] == 1
+    assert float(x.abs().max()) < 1e-6
+    assert mpc._n_iterations == 200 and abs(mpc._time - 200 * DT) < 1e-9
+
+
+def test_batch_1024_properties_and_errors():
+    import torch
+    mpc = product_lmpc('corrected')
+    rng = np.random.default_rng(5)
+    x0 = torch.as_tensor(rng.uniform(-1.5, 1.5, (1024, 2)), device='cuda')
+    u = mpc.optimize(x0)
+    assert np.all(mpc.solver_status_code == 1)
+    v = mpc._nlp_solution['x']
+    assert torch.equal(v[:, :2], x0) and float(v[:, 22:].abs().max()) <= 1 + 1e-9
+    assert float((v @ mpc._Ad.T).abs().max()) < 1e-9
+    with pytest.raises(ValueError, match="We have an issue mate, the x0 you supplied has dimension 3"):
+        mpc.optimize([1., 2., 3.])
+    assert mpc.optimize(torch.empty(0, 2, dtype=torch.float64, device='cuda')).shape == (0, 1)
