@@ -350,7 +350,7 @@ extern "C" int hilo_qp_create(int n, int m, int device, hilo_qp** out) {
   q.n = n; q.m = m;
   q.ldn = n | 1;                 // odd leading dimensions: conflict-free column walks in LDS
   q.ldm = (m > 0 ? m : 1) | 1;
-  q.max_iter = 100; q.tol = 1e-10; q.reg = 1e-11;
+  q.max_iter = 100; q.tol = 1e-12; q.reg = 1e-12;
   h->lds_bytes = sizeof(double) * ((size_t)2 * n * q.ldn + (size_t)m * q.ldn + (size_t)n * q.ldm + (size_t)(m > 0 ? m : 1) * q.ldm +
                                    12 * (size_t)n + 4 * (size_t)(m > 0 ? m : 1));
   if (h->lds_bytes > 160 * 1024) {

@@ -274,7 +274,7 @@ int hilo_mhe_estimate(hilo_mhe* h, int64_t batch,
 typedef struct hilo_qp hilo_qp;
 int hilo_qp_create(int n, int m, int device, hilo_qp** out);
 void hilo_qp_destroy(hilo_qp* h);
-int hilo_qp_set_options(hilo_qp* h, double tol /* <=0 keeps 1e-10 */, int max_iter /* <=0 keeps 100 */);
+int hilo_qp_set_options(hilo_qp* h, double tol /* <=0 keeps 1e-12 */, int max_iter /* <=0 keeps 100 */);
 int hilo_qp_solve(hilo_qp* h, int64_t batch,
                   const double* H, int64_t h_stride,       /* [B][n][n] row-major (stride 0 = shared) */
                   const double* g, int64_t g_stride,       /* [B][n] */
