@@ -234,11 +234,11 @@ static int mhe_launch(hilo_mhe* h, int64_t batch, const double* v0, int64_t v0s,
                       hipStream_t s) {
   using PB = MheNoise<M>;
   if (h->lds_bytes > 64 * 1024)
-    HILO_HIP_CHECK(hipFuncSetAttribute((const void*)ocp_solve_kernel<PB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HILO_HIP_CHECK(hipFuncSetAttribute((const void*)ocp_solve_kernel<PB, OCP_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)h->lds_bytes));
   // v0 rows either carry the parameter prefix (user v0 / previous solution) or not (tiled guess, stride 0)
   const double* v0p = v0;
-  hipLaunchKernelGGL((ocp_solve_kernel<PB>), dim3((unsigned)batch), dim3(64), h->lds_bytes, s, h->dev, batch,
+  hipLaunchKernelGGL((ocp_solve_kernel<PB, OCP_TPB>), dim3((unsigned)batch), dim3(OCP_TPB), h->lds_bytes, s, h->dev, batch,
                      (const double*)nullptr, h->par_buf, (int64_t)(h->np + h->nx), h->sd_buf,
                      (int64_t)((h->N + 1) * (h->nu + h->ny)), v0p, v0s, prefix_in_v0 ? h->np : 0, h->np, v_opt, f_opt, lam_g,
                      x_opt, 1, status, iters, kkt, (long long*)nullptr);

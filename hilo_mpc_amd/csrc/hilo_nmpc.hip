@@ -261,9 +261,9 @@ static int nmpc_launch(hilo_nmpc* h, int64_t batch, const double* x0, const doub
                        double* kkt, hipStream_t s) {
   using PB = NmpcTrack<M>;
   if (h->lds_bytes > 64 * 1024)
-    HILO_HIP_CHECK(hipFuncSetAttribute((const void*)ocp_solve_kernel<PB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HILO_HIP_CHECK(hipFuncSetAttribute((const void*)ocp_solve_kernel<PB, OCP_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)h->lds_bytes));
-  hipLaunchKernelGGL((ocp_solve_kernel<PB>), dim3((unsigned)batch), dim3(64), h->lds_bytes, s, h->dev, batch, x0, par,
+  hipLaunchKernelGGL((ocp_solve_kernel<PB, OCP_TPB>), dim3((unsigned)batch), dim3(OCP_TPB), h->lds_bytes, s, h->dev, batch, x0, par,
                      (int64_t)(h->np + h->nu), (const double*)nullptr, (int64_t)0, v0, v0s, 0, 0, v_opt, f_opt, lam_g, u0, 0,
                      status, iters, kkt, h->prof);
   HILO_HIP_CHECK(hipGetLastError());
@@ -323,7 +323,8 @@ extern "C" int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch, const double* x0, co
 }
 
 // Developer aid: per-phase shader-clock totals of instance 0 of the next solves
-// (derivatives, errors+barrier update, Riccati, step lengths, line search, update); cycles_host[6]
+// (derivatives, errors+barrier update, Riccati, step lengths, line search, update, #factorisations, #trial points);
+// cycles_host[8]
 extern "C" int hilo_nmpc_profile(hilo_nmpc* h, int enable, long long* cycles_host) {
   HILO_REQUIRE(h, "hilo_nmpc_profile: NULL handle");
   HILO_HIP_CHECK(hipSetDevice(h->device));

@@ -24,6 +24,13 @@ namespace hilo {
 
 constexpr int OCP_MAXNX = 8, OCP_MAXNU = 8, OCP_MAXNZ = OCP_MAXNX + OCP_MAXNU;
 constexpr int OCP_FILTER = 16;
+#ifndef HILO_OCP_TPB
+#define HILO_OCP_TPB 64
+#endif
+#ifndef HILO_OCP_MINW
+#define HILO_OCP_MINW 1
+#endif
+constexpr int OCP_TPB = HILO_OCP_TPB;  // threads per instance (one or more waves)
 constexpr int OCP_NCOST = 2 * OCP_MAXNZ * OCP_MAXNZ + 4 * OCP_MAXNZ + 64;
 
 struct OcpConst {
@@ -68,7 +75,7 @@ __device__ __forceinline__ double block_reduce(double v, double* scratch) {
   return r;
 }
 
-enum OcpPhase { PH_DERIV = 0, PH_ERR, PH_RICCATI, PH_STEP, PH_LS, PH_UPDATE, PH_COUNT };
+enum OcpPhase { PH_DERIV = 0, PH_ERR, PH_RICCATI, PH_STEP, PH_LS, PH_UPDATE, PH_NRIC, PH_NLS, PH_COUNT };
 
 template <class PB>
 struct Ocp {
@@ -79,14 +86,14 @@ struct Ocp {
 
   struct Lds {
     const OcpConst* pc;
-    double *Z, *Zt, *D, *zL, *zU, *dzL, *dzU, *grad, *lam, *lamn, *c, *ct, *AB, *W, *Qd, *P, *pv, *Kg, *kff, *T1, *vv,
-        *Mm, *mm, *fk, *filt, *red, *par, *sd;
+    double *Z, *Zt, *D, *zL, *zU, *dzL, *dzU, *grad, *lam, *lamn, *c, *ct, *AB, *W, *Qd, *P, *pv, *Kg, *kff, *sig, *rb,
+        *Acl, *bcl, *Mm, *mm, *fk, *filt, *red, *par, *sd;
   };
   __host__ __device__ static size_t lds_doubles(int N) {
     const size_t S = (size_t)(N + 1) * NZ;
-    return NCONST + 8 * S + 4 * (size_t)N * NX + (size_t)N * NX * NZ + (size_t)N * NZ * NZ + (size_t)(N + 1) * NDIR +
-           (size_t)(N + 1) * NX * NX + (size_t)(N + 1) * NX + (size_t)N * NU * NX + (size_t)N * NU + NX * NZ + NX +
-           NZ * NZ + NZ + (N + 1) + 2 * OCP_FILTER + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1;
+    return NCONST + 10 * S + 4 * (size_t)N * NX + (size_t)N * NX * NZ + (size_t)N * NZ * NZ + (size_t)(N + 1) * NDIR +
+           (size_t)(N + 1) * NX * NX + (size_t)(N + 1) * NX + (size_t)N * NU * NX + (size_t)N * NU + (size_t)N * NX * NX +
+           (size_t)N * NX + NZ * NZ + NZ + (N + 1) + 2 * OCP_FILTER + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1;
   }
   __device__ static Lds carve(double* base, int N) {
     Lds l;
@@ -100,7 +107,8 @@ struct Ocp {
     l.AB = take((size_t)N * NX * NZ); l.W = take((size_t)N * NZ * NZ); l.Qd = take((size_t)(N + 1) * NDIR);
     l.P = take((size_t)(N + 1) * NX * NX); l.pv = take((size_t)(N + 1) * NX);
     l.Kg = take((size_t)N * NU * NX); l.kff = take((size_t)N * NU);
-    l.T1 = take(NX * NZ); l.vv = take(NX); l.Mm = take(NZ * NZ); l.mm = take(NZ);
+    l.sig = take(S); l.rb = take(S); l.Acl = take((size_t)N * NX * NX); l.bcl = take((size_t)N * NX);
+    l.Mm = take(NZ * NZ); l.mm = take(NZ);
     l.fk = take(N + 1); l.filt = take(2 * OCP_FILTER); l.red = take(16); l.par = take(NPAR);
     l.sd = take((size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1);
     return l;
@@ -286,27 +294,84 @@ struct Ocp {
     return block_reduce<OpMax>(cm, l.red);
   }
 
-  // barrier contribution of slot sl (variable index i) to the diagonal and to the right-hand side
-  __device__ __forceinline__ static void barrier_terms(const OcpConst& pc, const Lds& l, int sl, int i, double mu,
-                                                       double& sigma, double& rhs) {
-    if (pc.lbz[i] > -INFINITY) {
-      const double s = l.Z[sl] - pc.lbz[i];
-      sigma += l.zL[sl] / s;
-      rhs -= mu / s;
+  // ---- barrier terms of every slot, once per iteration (keeps the divisions out of the sequential recursion):
+  //   sig[e] = zL/(z - lb) + zU/(ub - z),   rb[e] = grad[e] - mu/(z - lb) + mu/(ub - z)
+  __device__ static void prep_barrier(const Lds& l, double mu) {
+    const OcpConst& pc = *l.pc;
+    const int N = pc.N;
+    for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
+      const int k = e / NZ, i = e - k * NZ;
+      double sg = 0.0, r = l.grad[e];
+      if (is_free(N, k, i)) {
+        if (pc.lbz[i] > -INFINITY) {
+          const double is = 1.0 / (l.Z[e] - pc.lbz[i]);
+          sg += l.zL[e] * is;
+          r -= mu * is;
+        }
+        if (pc.ubz[i] < INFINITY) {
+          const double is = 1.0 / (pc.ubz[i] - l.Z[e]);
+          sg += l.zU[e] * is;
+          r += mu * is;
+        }
+      }
+      l.sig[e] = sg;
+      l.rb[e] = r;
     }
-    if (pc.ubz[i] < INFINITY) {
-      const double s = pc.ubz[i] - l.Z[sl];
-      sigma += l.zU[sl] / s;
-      rhs += mu / s;
+    __syncthreads();
+  }
+
+  // lower Cholesky factor of the n x n block M (row pitch ld) with reciprocal pivots: L (n x n), invd = 1/diag(L)
+  template <int n>
+  __device__ __forceinline__ static bool small_chol(const double* M, int ld, double* L, double* invd) {
+    bool pd = true;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      double s = M[j * ld + j];
+#pragma unroll
+      for (int q = 0; q < j; ++q) s -= L[j * n + q] * L[j * n + q];
+      if (!(s > 0.0)) { pd = false; s = 1.0; }
+      const double id = rsqrt(s);
+      invd[j] = id;
+      L[j * n + j] = s * id;
+#pragma unroll
+      for (int i = j + 1; i < n; ++i) {
+        double v = M[i * ld + j];
+#pragma unroll
+        for (int q = 0; q < j; ++q) v -= L[i * n + q] * L[j * n + q];
+        L[i * n + j] = v * id;
+      }
+    }
+    return pd;
+  }
+  // y <- (L L^T)^-1 y
+  template <int n>
+  __device__ __forceinline__ static void small_solve(const double* L, const double* invd, double* y) {
+#pragma unroll
+    for (int a = 0; a < n; ++a) {
+      double s = y[a];
+#pragma unroll
+      for (int q = 0; q < a; ++q) s -= L[a * n + q] * y[q];
+      y[a] = s * invd[a];
+    }
+#pragma unroll
+    for (int a = n - 1; a >= 0; --a) {
+      double s = y[a];
+#pragma unroll
+      for (int q = a + 1; q < n; ++q) s -= L[q * n + a] * y[q];
+      y[a] = s * invd[a];
     }
   }
 
   // ---- Riccati factor + solve of the Newton system; false when a reduced pivot is not positive ---------------
+  // Per stage two LDS round trips: (1) M = H_k + [A B]^T P_{k+1} [A B] and its right-hand side, (2) the reduced
+  // pivot block's Cholesky (redundantly per lane), feedback K, feed-forward kff, P_k, p_k.  The forward sweep runs
+  // on closed-loop matrices prepared in parallel and keeps dx in registers (wave shuffles, no LDS round trip).
   // `resto`: feasibility-restoration step (H = I, zero gradient: least-norm d with J d = -c)
   __device__ static bool riccati(const Lds& l, double mu, double delta, bool resto = false) {
     const OcpConst& pc = *l.pc;
     const int N = pc.N, t = threadIdx.x, T = blockDim.x;
-    // terminal: P_N = hess V + Sigma + delta, p_N = grad V - mu/s...
+    (void)mu;
+    // terminal: P_N = hess V + Sigma + delta, p_N = grad V + barrier rhs
     for (int e = t; e < NX * NX + NX; e += T) {
       if (e < NX * NX) {
         const int i = e / NX, j = e - i * NX;
@@ -319,132 +384,97 @@ struct Ocp {
             v = 0.5 * (Q[dir_of(a, b, NX)] - Q[a] - Q[b]);
           }
         }
-        if (i == j) {
-          double sg = 0.0, dummy = 0.0;
-          if (!resto) barrier_terms(pc, l, N * NZ + i, i, mu, sg, dummy);
-          v += (resto ? 1.0 : delta) + sg;
-        }
+        if (i == j) v += resto ? 1.0 : (delta + l.sig[N * NZ + i]);
         l.P[N * NX * NX + e] = v;
       } else {
         const int i = e - NX * NX;
-        double sg = 0.0, r = 0.0;
-        if (!resto) {
-          r = l.grad[N * NZ + i];
-          barrier_terms(pc, l, N * NZ + i, i, mu, sg, r);
-        }
-        l.pv[N * NX + i] = r;
+        l.pv[N * NX + i] = resto ? 0.0 : l.rb[N * NZ + i];
       }
     }
     __syncthreads();
-    bool ok = true;
     for (int k = N - 1; k >= 0; --k) {
       const double* Pn = l.P + (k + 1) * NX * NX;
       const double* pn = l.pv + (k + 1) * NX;
       const double* AB = l.AB + k * NX * NZ;
-      // T1 = P_{k+1} [A B]  (NX x NZ),  vv = P_{k+1} b + p_{k+1},  b = -c_k
-      for (int e = t; e < NX * NZ + NX; e += T) {
-        if (e < NX * NZ) {
-          const int i = e / NZ, j = e - i * NZ;
-          double s = 0.0;
-#pragma unroll
-          for (int m = 0; m < NX; ++m) s += Pn[i * NX + m] * AB[m * NZ + j];
-          l.T1[e] = s;
-        } else {
-          const int i = e - NX * NZ;
-          double s = pn[i];
-#pragma unroll
-          for (int m = 0; m < NX; ++m) s -= Pn[i * NX + m] * l.c[k * NX + m];
-          l.vv[i] = s;
-        }
-      }
-      __syncthreads();
-      // Mm = H_k + [A B]^T T1 ; mm = r_k + [A B]^T vv
+      // (1) Mm = H_k + [A B]^T P_{k+1} [A B];  mm = r_k + [A B]^T (p_{k+1} - P_{k+1} c_k)
       for (int e = t; e < NZ * NZ + NZ; e += T) {
         if (e < NZ * NZ) {
           const int i = e / NZ, j = e - i * NZ;
           double s = resto ? 0.0 : l.W[k * NZ * NZ + e];
 #pragma unroll
-          for (int m = 0; m < NX; ++m) s += AB[m * NZ + i] * l.T1[m * NZ + j];
-          if (i == j) {
-            double sg = 0.0, dummy = 0.0;
-            if (!resto && is_free(N, k, i)) barrier_terms(pc, l, k * NZ + i, i, mu, sg, dummy);
-            s += (resto ? 1.0 : delta) + sg;
+          for (int m = 0; m < NX; ++m) {
+            double tm = 0.0;
+#pragma unroll
+            for (int n = 0; n < NX; ++n) tm += Pn[m * NX + n] * AB[n * NZ + j];
+            s += AB[m * NZ + i] * tm;
           }
+          if (i == j) s += resto ? 1.0 : (delta + l.sig[k * NZ + i]);
           l.Mm[e] = s;
         } else {
-          const int i = e - NZ * NZ, sl = k * NZ + i;
-          double sg = 0.0, s = 0.0;
-          if (!resto) {
-            s = l.grad[sl];
-            if (is_free(N, k, i)) barrier_terms(pc, l, sl, i, mu, sg, s);
-          }
+          const int i = e - NZ * NZ;
+          double s = resto ? 0.0 : l.rb[k * NZ + i];
 #pragma unroll
-          for (int m = 0; m < NX; ++m) s += AB[m * NZ + i] * l.vv[m];
+          for (int m = 0; m < NX; ++m) {
+            double vm = pn[m];
+#pragma unroll
+            for (int n = 0; n < NX; ++n) vm -= Pn[m * NX + n] * l.c[k * NX + n];
+            s += AB[m * NZ + i] * vm;
+          }
           l.mm[i] = s;
         }
       }
       __syncthreads();
+      // (2) pivot block, feedback, cost-to-go
       if constexpr (NU > 0) {
-        // Cholesky of M_uu (every lane redundantly; tiny) + positivity test (= inertia test)
-        double Lc[NU * NU];
-        bool pd = true;
+        double Lc[NU * NU], invd[NU];
+        const bool pd = small_chol<NU>(l.Mm + NX * NZ + NX, NZ, Lc, invd);
+        if (!pd) return false;  // wave-uniform: every lane factors the same block
+        constexpr int NPU = NX * (NX + 1) / 2;  // upper triangle of P_k
+        for (int e = t; e < NPU + NX + NX + 1; e += T) {
+          if (e < NPU) {  // P_k[i][j] = sym(M_xx)[i][j] + M_xu[i] K[:, j],  K[:, j] = -R^-1 M_ux[:, j]
+            int i = 0, r = e;
+            while (r >= NX - i) { r -= NX - i; ++i; }
+            const int j = i + r;
+            double y[NU];
 #pragma unroll
-        for (int j = 0; j < NU; ++j) {
-          double s = l.Mm[(NX + j) * NZ + NX + j];
+            for (int a = 0; a < NU; ++a) y[a] = l.Mm[(NX + a) * NZ + j];
+            small_solve<NU>(Lc, invd, y);
+            double s = 0.5 * (l.Mm[i * NZ + j] + l.Mm[j * NZ + i]);
 #pragma unroll
-          for (int q = 0; q < j; ++q) s -= Lc[j * NU + q] * Lc[j * NU + q];
-          if (!(s > 0.0)) { pd = false; s = 1.0; }
-          const double dd = sqrt(s);
-          Lc[j * NU + j] = dd;
+            for (int a = 0; a < NU; ++a) s -= l.Mm[i * NZ + NX + a] * y[a];
+            l.P[k * NX * NX + i * NX + j] = s;
+            l.P[k * NX * NX + j * NX + i] = s;
+          } else if (e < NPU + NX) {  // p_k[i] = m_x[i] + M_xu[i] kff
+            const int i = e - NPU;
+            double y[NU];
 #pragma unroll
-          for (int i = j + 1; i < NU; ++i) {
-            double v = l.Mm[(NX + i) * NZ + NX + j];
+            for (int a = 0; a < NU; ++a) y[a] = l.mm[NX + a];
+            small_solve<NU>(Lc, invd, y);
+            double s = l.mm[i];
 #pragma unroll
-            for (int q = 0; q < j; ++q) v -= Lc[i * NU + q] * Lc[j * NU + q];
-            Lc[i * NU + j] = v / dd;
+            for (int a = 0; a < NU; ++a) s -= l.Mm[i * NZ + NX + a] * y[a];
+            l.pv[k * NX + i] = s;
+          } else if (e < NPU + 2 * NX) {  // store the feedback column
+            const int j = e - NPU - NX;
+            double y[NU];
+#pragma unroll
+            for (int a = 0; a < NU; ++a) y[a] = l.Mm[(NX + a) * NZ + j];
+            small_solve<NU>(Lc, invd, y);
+#pragma unroll
+            for (int a = 0; a < NU; ++a) l.Kg[(k * NU + a) * NX + j] = -y[a];
+          } else {  // feed-forward
+            double y[NU];
+#pragma unroll
+            for (int a = 0; a < NU; ++a) y[a] = l.mm[NX + a];
+            small_solve<NU>(Lc, invd, y);
+#pragma unroll
+            for (int a = 0; a < NU; ++a) l.kff[k * NU + a] = -y[a];
           }
         }
-        ok = ok && pd;
-        // K = -M_uu^-1 M_ux (NU x NX), kff = -M_uu^-1 m_u : one lane per column of [M_ux | m_u]
-        for (int col = t; col < NX + 1; col += T) {
-          double y[NU];
-#pragma unroll
-          for (int a = 0; a < NU; ++a) {
-            double s = col < NX ? l.Mm[(NX + a) * NZ + col] : l.mm[NX + a];
-#pragma unroll
-            for (int q = 0; q < a; ++q) s -= Lc[a * NU + q] * y[q];
-            y[a] = s / Lc[a * NU + a];
-          }
-#pragma unroll
-          for (int a = NU - 1; a >= 0; --a) {
-            double s = y[a];
-#pragma unroll
-            for (int q = a + 1; q < NU; ++q) s -= Lc[q * NU + a] * y[q];
-            y[a] = s / Lc[a * NU + a];
-          }
-#pragma unroll
-          for (int a = 0; a < NU; ++a) {
-            if (col < NX) l.Kg[(k * NU + a) * NX + col] = -y[a];
-            else l.kff[k * NU + a] = -y[a];
-          }
-        }
-        __syncthreads();
-      }
-      // P_k = M_xx + M_xu K (symmetrised), p_k = m_x + M_xu kff
-      for (int e = t; e < NX * NX + NX; e += T) {
-        if (e < NX * NX) {
-          const int i = e / NX, j = e - i * NX;
-          double s = 0.5 * (l.Mm[i * NZ + j] + l.Mm[j * NZ + i]);
-#pragma unroll
-          for (int a = 0; a < NU; ++a)
-            s += 0.5 * (l.Mm[i * NZ + NX + a] * l.Kg[(k * NU + a) * NX + j] + l.Mm[j * NZ + NX + a] * l.Kg[(k * NU + a) * NX + i]);
-          l.P[k * NX * NX + e] = s;
-        } else {
-          const int i = e - NX * NX;
-          double s = l.mm[i];
-#pragma unroll
-          for (int a = 0; a < NU; ++a) s += l.Mm[i * NZ + NX + a] * l.kff[k * NU + a];
-          l.pv[k * NX + i] = s;
+      } else {
+        for (int e = t; e < NX * NX + NX; e += T) {
+          if (e < NX * NX) l.P[k * NX * NX + e] = 0.5 * (l.Mm[(e / NX) * NZ + e % NX] + l.Mm[(e % NX) * NZ + e / NX]);
+          else l.pv[k * NX + e - NX * NX] = l.mm[e - NX * NX];
         }
       }
       __syncthreads();
@@ -453,73 +483,68 @@ struct Ocp {
     if constexpr (FIX_X0) {
       for (int i = t; i < NX; i += T) l.D[i] = 0.0;
     } else {
-      double Lc[NX * NX], y[NX];
-      bool pd = true;
+      double Lc[NX * NX], invd[NX], y[NX];
+      const bool pd = small_chol<NX>(l.P, NX, Lc, invd);
+      if (!pd) return false;
 #pragma unroll
-      for (int j = 0; j < NX; ++j) {
-        double s = l.P[j * NX + j];
-#pragma unroll
-        for (int q = 0; q < j; ++q) s -= Lc[j * NX + q] * Lc[j * NX + q];
-        if (!(s > 0.0)) { pd = false; s = 1.0; }
-        const double dd = sqrt(s);
-        Lc[j * NX + j] = dd;
-#pragma unroll
-        for (int i = j + 1; i < NX; ++i) {
-          double v = l.P[i * NX + j];
-#pragma unroll
-          for (int q = 0; q < j; ++q) v -= Lc[i * NX + q] * Lc[j * NX + q];
-          Lc[i * NX + j] = v / dd;
-        }
-      }
-      ok = ok && pd;
-#pragma unroll
-      for (int a = 0; a < NX; ++a) {
-        double s = l.pv[a];
-#pragma unroll
-        for (int q = 0; q < a; ++q) s -= Lc[a * NX + q] * y[q];
-        y[a] = s / Lc[a * NX + a];
-      }
-#pragma unroll
-      for (int a = NX - 1; a >= 0; --a) {
-        double s = y[a];
-#pragma unroll
-        for (int q = a + 1; q < NX; ++q) s -= Lc[q * NX + a] * y[q];
-        y[a] = s / Lc[a * NX + a];
-      }
+      for (int a = 0; a < NX; ++a) y[a] = l.pv[a];
+      small_solve<NX>(Lc, invd, y);
       __syncthreads();
       if (t == 0) {
 #pragma unroll
         for (int a = 0; a < NX; ++a) l.D[a] = -y[a];
       }
     }
-    if (!ok) return false;
-    __syncthreads();
-    // forward sweep: du_k = K dx_k + kff; dx_{k+1} = A dx_k + B du_k - c_k
-    for (int k = 0; k < N; ++k) {
-      for (int a = t; a < NU; a += T) {
-        double s = l.kff[k * NU + a];
+    // closed-loop matrices for the forward sweep: Acl = A + B K, bcl = B kff - c  (parallel over stages)
+    for (int e = t; e < N * (NX * NX + NX); e += T) {
+      const int k = e / (NX * NX + NX), r = e - k * (NX * NX + NX);
+      const double* AB = l.AB + k * NX * NZ;
+      if (r < NX * NX) {
+        const int i = r / NX, j = r - i * NX;
+        double s = AB[i * NZ + j];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) s += l.Kg[(k * NU + a) * NX + j] * l.D[k * NZ + j];
-        l.D[k * NZ + NX + a] = s;
-      }
-      __syncthreads();
-      for (int i = t; i < NX; i += T) {
+        for (int a = 0; a < NU; ++a) s += AB[i * NZ + NX + a] * l.Kg[(k * NU + a) * NX + j];
+        l.Acl[k * NX * NX + r] = s;
+      } else {
+        const int i = r - NX * NX;
         double s = -l.c[k * NX + i];
 #pragma unroll
-        for (int j = 0; j < NZ; ++j) s += l.AB[(k * NX + i) * NZ + j] * l.D[k * NZ + j];
-        l.D[(k + 1) * NZ + i] = s;
+        for (int a = 0; a < NU; ++a) s += AB[i * NZ + NX + a] * l.kff[k * NU + a];
+        l.bcl[k * NX + i] = s;
       }
-      __syncthreads();
+    }
+    __syncthreads();
+    // forward sweep on the first wave: lane i < NX carries dx[i] in a register, exchanged by shuffles
+    if (t < 64) {
+      const int i = t < NX ? t : 0;
+      double dxi = l.D[i];
+      for (int k = 0; k < N; ++k) {
+        double s = l.bcl[k * NX + i];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += l.Acl[k * NX * NX + i * NX + j] * __shfl(dxi, j, 64);
+        dxi = s;
+        if (t < NX) l.D[(k + 1) * NZ + i] = dxi;
+      }
+    }
+    __syncthreads();
+    // inputs and new equality multipliers, parallel over stages:
+    //   du_k = K dx_k + kff,   lam_{k+1} = -(P_{k+1} dx_{k+1} + p_{k+1})
+    for (int e = t; e < N * (NU + NX); e += T) {
+      const int k = e / (NU + NX), r = e - k * (NU + NX);
+      if (r < NU) {
+        double s = l.kff[k * NU + r];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += l.Kg[(k * NU + r) * NX + j] * l.D[k * NZ + j];
+        l.D[k * NZ + NX + r] = s;
+      } else {
+        const int i = r - NU;
+        double s = l.pv[(k + 1) * NX + i];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += l.P[(k + 1) * NX * NX + i * NX + j] * l.D[(k + 1) * NZ + j];
+        l.lamn[k * NX + i] = -s;
+      }
     }
     for (int a = t; a < NU; a += T) l.D[N * NZ + NX + a] = 0.0;
-    // new equality multipliers: lam_{k+1} = -(P_{k+1} dx_{k+1} + p_{k+1})
-    for (int e = t; e < N * NX; e += T) {
-      const int k = e / NX, i = e - k * NX;
-      double s = l.pv[(k + 1) * NX + i];
-#pragma unroll
-      for (int j = 0; j < NX; ++j) s += l.P[(k + 1) * NX * NX + i * NX + j] * l.D[(k + 1) * NZ + j];
-      l.lamn[e] = -s;
-    }
     __syncthreads();
     return true;
   }
@@ -572,8 +597,8 @@ struct Ocp {
 // ---------------------------------------------------------------------------------------------------------------
 // The solve kernel.  v layout (device, per instance, scaled): [prefix (v_prefix doubles, untouched) | x_0..x_N | u_0..u_{N-1}]
 // ---------------------------------------------------------------------------------------------------------------
-template <class PB>
-__global__ __launch_bounds__(64) void ocp_solve_kernel(const OcpConst* __restrict__ pcg, int64_t batch,
+template <class PB, int TPB>
+__global__ __launch_bounds__(TPB, HILO_OCP_MINW) void ocp_solve_kernel(const OcpConst* __restrict__ pcg, int64_t batch,
                                                        const double* __restrict__ x0, const double* __restrict__ par,
                                                        int64_t par_stride, const double* __restrict__ sdata,
                                                        int64_t sd_stride, const double* __restrict__ v0,
@@ -601,7 +626,7 @@ __global__ __launch_bounds__(64) void ocp_solve_kernel(const OcpConst* __restric
   __syncthreads();
   const OcpConst& pc = *l.pc;
   const int SL = (N + 1) * NZ;
-  long long tprof[PH_COUNT] = {0, 0, 0, 0, 0, 0};
+  long long tprof[PH_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = prof ? clock64() : 0;
 #define OCP_TICK(ph) if (prof) { const long long tn = clock64(); tprof[ph] += tn - tlast; tlast = tn; }
 
@@ -672,9 +697,11 @@ __global__ __launch_bounds__(64) void ocp_solve_kernel(const OcpConst* __restric
     }
     OCP_TICK(PH_ERR)
     // ---- search direction with inertia correction (W&B Alg. IC) ----
+    S::prep_barrier(l, mu);
     double delta = 0.0;
     bool first_try = true, solved = false;
     for (;;) {
+      tprof[PH_NRIC] += 1;
       if (S::riccati(l, mu, delta)) { solved = true; break; }
       if (first_try) {
         delta = delta_last == 0.0 ? pc.delta_w_0 : fmax(pc.delta_w_min, pc.kappa_w_minus * delta_last);
@@ -726,6 +753,7 @@ __global__ __launch_bounds__(64) void ocp_solve_kernel(const OcpConst* __restric
       for (int e = t; e < SL; e += T) l.Zt[e] = l.Z[e] + alpha * l.D[e];
       __syncthreads();
       double ft, tht;
+      tprof[PH_NLS] += 1;
       S::eval_values(l, l.Zt, l.ct, ft, tht);
       const double pht = ft + S::eval_barrier(l, l.Zt, mu);
       bool ok = isfinite(pht) && isfinite(tht) && tht <= theta_max;

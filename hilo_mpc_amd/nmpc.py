@@ -435,8 +435,8 @@ class NMPC:
     def phase_profile(self, enable=True):
         """Developer aid (hilo_nmpc_profile): shader-clock cycles instance 0 spent per solver phase in the launches
         since the last call.  Returns a dict or None when collection was just switched on."""
-        names = ['derivatives', 'errors', 'riccati', 'step', 'line_search', 'update']
-        buf = (C.c_longlong * 6)()
+        names = ['derivatives', 'errors', 'riccati', 'step', 'line_search', 'update', 'n_factorizations', 'n_trial_points']
+        buf = (C.c_longlong * 8)()
         had = getattr(self, '_prof_on', False)
         _lib.check(_lib.lib().hilo_nmpc_profile(self._handle, int(bool(enable)), buf if had else None))
         self._prof_on = bool(enable)

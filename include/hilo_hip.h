@@ -221,7 +221,8 @@ int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch,
                     double* kkt,                      /* [B] scaled optimality error at the returned point or NULL */
                     void* stream);
 /* developer aid: per-phase shader-clock totals of instance 0 (derivatives, errors, Riccati, step, line search,
-   update); enable != 0 starts collecting, cycles_host[6] (may be NULL) receives the last launch's counters */
+   update, number of factorisations, number of line-search trial points); enable != 0 starts collecting,
+   cycles_host[8] (may be NULL) receives the last launch's counters */
 int hilo_nmpc_profile(hilo_nmpc* h, int enable, long long* cycles_host);
 /* x+ = Phi(x, u, p) with the controller's own shooting map: closed-loop harness (control_loop.py:343-396) */
 int hilo_nmpc_plant_step(hilo_nmpc* h, int64_t batch, const double* x, const double* u, const double* p,
