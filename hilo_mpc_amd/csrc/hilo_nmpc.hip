@@ -19,6 +19,7 @@ template <class M>
 struct NmpcTrack {
   static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU, NPAR = M::NP + M::NU, NSD = 0;
   static constexpr bool FIX_X0 = true;
+  static constexpr bool QUAD_COST = true;  // gradient / Hessian of the stage cost in closed form (cost_grad, cost_hess)
   static constexpr int O_WZ = 0, O_ZREF = O_WZ + NZ * NZ, O_WN = O_ZREF + NZ, O_XREFN = O_WN + NX * NX,
                        O_WDU = O_XREFN + NX, O_HASDU = O_WDU + NU * NU, O_END = O_HASDU + 1;
 
@@ -64,6 +65,25 @@ struct NmpcTrack {
       }
     }
     return acc;
+  }
+
+  // d/dz_i and d2/dz_i dz_j of (z - zref)^T Wz (z - zref) [+ (u - u_old)^T Wdu (u - u_old) in interval 0]
+  __device__ __forceinline__ static double cost_grad(const OcpConst& pc, const double* par, int k, int i, const double* z) {
+    double g = 0.0;
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) g += (pc.cost[O_WZ + i * NZ + j] + pc.cost[O_WZ + j * NZ + i]) * (z[j] - pc.cost[O_ZREF + j]);
+    if (k == 0 && i >= NX && pc.cost[O_HASDU] != 0.0) {
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+        g += (pc.cost[O_WDU + (i - NX) * NU + j] + pc.cost[O_WDU + j * NU + (i - NX)]) * (z[NX + j] - par[M::NP + j]);
+    }
+    return g;
+  }
+  __device__ __forceinline__ static double cost_hess(const OcpConst& pc, int k, int i, int j) {
+    double h = pc.cost[O_WZ + i * NZ + j] + pc.cost[O_WZ + j * NZ + i];
+    if (k == 0 && i >= NX && j >= NX && pc.cost[O_HASDU] != 0.0)
+      h += pc.cost[O_WDU + (i - NX) * NU + (j - NX)] + pc.cost[O_WDU + (j - NX) * NU + (i - NX)];
+    return h;
   }
 
   template <class T>

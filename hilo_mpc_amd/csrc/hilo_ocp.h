@@ -62,7 +62,7 @@ struct OpMax { __device__ static double id() { return -INFINITY; } __device__ st
 struct OpMin { __device__ static double id() { return INFINITY; } __device__ static double f(double a, double b) { return fmin(a, b); } };
 
 template <class Op>
-__device__ __forceinline__ double block_reduce(double v, double* scratch) {
+__device__ __forceinline__ double block_reduce(double v, __attribute__((address_space(3))) double* scratch) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = Op::f(v, __shfl_xor(v, o, 64));
   const int nw = blockDim.x >> 6;
@@ -75,6 +75,10 @@ __device__ __forceinline__ double block_reduce(double v, double* scratch) {
   return r;
 }
 
+// LDS-qualified pointer types: keep the address space through non-inlined calls (ds_read/ds_write, not flat_*)
+typedef __attribute__((address_space(3))) double lds_double;
+typedef const __attribute__((address_space(3))) double lds_cdouble;
+
 enum OcpPhase { PH_DERIV = 0, PH_ERR, PH_RICCATI, PH_STEP, PH_LS, PH_UPDATE, PH_NRIC, PH_NLS, PH_COUNT };
 
 template <class PB>
@@ -85,9 +89,9 @@ struct Ocp {
   static constexpr int NCONST = (sizeof(OcpConst) + 7) / 8;
 
   struct Lds {
-    const OcpConst* pc;
-    double *Z, *Zt, *D, *zL, *zU, *dzL, *dzU, *grad, *lam, *lamn, *c, *ct, *AB, *W, *Qd, *P, *pv, *Kg, *kff, *sig, *rb,
-        *Acl, *bcl, *Mm, *mm, *fk, *filt, *red, *par, *sd;
+    const __attribute__((address_space(3))) OcpConst* pc;
+    lds_double *Z, *Zt, *D, *zL, *zU, *dzL, *dzU, *grad, *lam, *lamn, *c, *ct, *AB, *W, *Qd, *P, *pv, *Kg, *kff, *sig,
+        *rb, *Acl, *bcl, *Mm, *mm, *fk, *filt, *red, *par, *sd;
   };
   __host__ __device__ static size_t lds_doubles(int N) {
     const size_t S = (size_t)(N + 1) * NZ;
@@ -95,12 +99,12 @@ struct Ocp {
            (size_t)(N + 1) * NX * NX + (size_t)(N + 1) * NX + (size_t)N * NU * NX + (size_t)N * NU + (size_t)N * NX * NX +
            (size_t)N * NX + NZ * NZ + NZ + (N + 1) + 2 * OCP_FILTER + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1;
   }
-  __device__ static Lds carve(double* base, int N) {
+  __device__ static Lds carve(lds_double* base, int N) {
     Lds l;
     const size_t S = (size_t)(N + 1) * NZ;
-    double* q = base;
-    auto take = [&](size_t n) { double* r = q; q += n; return r; };
-    l.pc = reinterpret_cast<const OcpConst*>(take(NCONST));
+    lds_double* q = base;
+    auto take = [&](size_t n) { lds_double* r = q; q += n; return r; };
+    l.pc = reinterpret_cast<const __attribute__((address_space(3))) OcpConst*>(take(NCONST));
     l.Z = take(S); l.Zt = take(S); l.D = take(S); l.zL = take(S); l.zU = take(S); l.dzL = take(S); l.dzU = take(S);
     l.grad = take(S);
     l.lam = take((size_t)N * NX); l.lamn = take((size_t)N * NX); l.c = take((size_t)N * NX); l.ct = take((size_t)N * NX);
@@ -125,11 +129,11 @@ struct Ocp {
   }
   __device__ static int dir_of(int i, int j, int n) { return n + i * (n - 1) - i * (i - 1) / 2 + (j - i - 1); }
 
-  __device__ static const double* sd_of(const Lds& l, int k) { return l.sd + (NSD > 0 ? k * NSD : 0); }
+  __device__ static const double* sd_of(const Lds l, int k) { return (const double*)(l.sd + (NSD > 0 ? k * NSD : 0)); }
 
   // ---- values only at a point Zp: defects cp_k = x_{k+1} - F_k(x_k,u_k), returns (f, theta = |c|_1) -------------
-  __device__ static void eval_values(const Lds& l, const double* Zp, double* cp, double& f, double& theta) {
-    const OcpConst& pc = *l.pc;
+  __device__ __attribute__((noinline)) static void eval_values(const Lds l, lds_cdouble* Zp, lds_double* cp, double& f, double& theta) {
+    const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double fpart = 0.0, tpart = 0.0;
     for (int k = threadIdx.x; k <= N; k += blockDim.x) {
@@ -140,8 +144,8 @@ struct Ocp {
         double xn[NX];
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = Zp[k * NZ + NX + i];
-        PB::dyn(pc, l.par, sd_of(l, k), k, x, u, xn);
-        fpart += PB::stage_cost(pc, l.par, sd_of(l, k), k, x, u);
+        PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn);
+        fpart += PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
           const double ci = Zp[(k + 1) * NZ + i] - xn[i];
@@ -149,7 +153,7 @@ struct Ocp {
           tpart += fabs(ci);
         }
       } else {
-        fpart += PB::term_cost(pc, l.par, sd_of(l, N), x);
+        fpart += PB::term_cost(pc, (const double*)l.par, sd_of(l, N), x);
       }
     }
     f = block_reduce<OpSum>(fpart, l.red);
@@ -157,8 +161,8 @@ struct Ocp {
   }
 
   // -mu * sum log(slacks)
-  __device__ static double eval_barrier(const Lds& l, const double* Zp, double mu) {
-    const OcpConst& pc = *l.pc;
+  __device__ static double eval_barrier(const Lds l, lds_cdouble* Zp, double mu) {
+    const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double part = 0.0;
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
@@ -171,8 +175,8 @@ struct Ocp {
   }
 
   // ---- full derivative evaluation at Z: c, AB, grad, per-stage cost values, Lagrangian Hessian blocks --------
-  __device__ static double eval_derivs(const Lds& l) {
-    const OcpConst& pc = *l.pc;
+  __device__ __attribute__((noinline)) static double eval_derivs(const Lds l) {
+    const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     for (int task = threadIdx.x; task < N * NDIR + NXDIR; task += blockDim.x) {
       if (task < N * NDIR) {
@@ -194,8 +198,10 @@ struct Ocp {
         for (int i = 0; i < NX; ++i) x[i] = Jet2(l.Z[k * NZ + i], (!dead && (i == di || i == dj)) ? 1.0 : 0.0, 0.0);
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = Jet2(l.Z[k * NZ + NX + i], (NX + i == di || NX + i == dj) ? 1.0 : 0.0, 0.0);
-        PB::dyn(pc, l.par, sd_of(l, k), k, x, u, xn);
-        const Jet2 lc = PB::stage_cost(pc, l.par, sd_of(l, k), k, x, u);
+        PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn);
+        // a policy with a purely quadratic stage cost supplies value / gradient / (constant) Hessian in closed form
+        Jet2 lc(0.0);
+        if constexpr (!PB::QUAD_COST) lc = PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
         double q = lc.b;
 #pragma unroll
         for (int m = 0; m < NX; ++m) {
@@ -203,10 +209,14 @@ struct Ocp {
           if (d < NZ && !dead) l.AB[(k * NX + m) * NZ + d] = xn[m].a;
           q -= l.lam[k * NX + m] * xn[m].b;
         }
-        if (d == 0) l.fk[k] = lc.v;
+        if constexpr (!PB::QUAD_COST) {
+          if (d == 0) l.fk[k] = lc.v;
+        }
         if (!dead) {
           l.Qd[task] = q;
-          if (d < NZ) l.grad[k * NZ + d] = lc.a;
+          if constexpr (!PB::QUAD_COST) {
+            if (d < NZ) l.grad[k * NZ + d] = lc.a;
+          }
         }
       } else {  // terminal cost V(x_N): directions over the NX state slots
         const int d = task - N * NDIR;
@@ -215,7 +225,7 @@ struct Ocp {
         Jet2 x[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = Jet2(l.Z[N * NZ + i], (i == di || i == dj) ? 1.0 : 0.0, 0.0);
-        const Jet2 v = PB::term_cost(pc, l.par, sd_of(l, N), x);
+        const Jet2 v = PB::term_cost(pc, (const double*)l.par, sd_of(l, N), x);
         l.Qd[N * NDIR + d] = v.b;
         if (d < NX) l.grad[N * NZ + d] = v.a;
         if (d == 0) l.fk[N] = v.v;
@@ -225,14 +235,30 @@ struct Ocp {
     // Hessian blocks by polarisation: H_ii = q(e_i), H_ij = (q(e_i+e_j) - q(e_i) - q(e_j)) / 2
     for (int e = threadIdx.x; e < N * NZ * NZ; e += blockDim.x) {
       const int k = e / (NZ * NZ), r = e - k * NZ * NZ, i = r / NZ, j = r - i * NZ;
-      const double* Q = l.Qd + k * NDIR;
+      lds_cdouble* Q = l.Qd + k * NDIR;
       double h;
       if (i == j) h = Q[i];
       else {
         const int a = i < j ? i : j, b = i < j ? j : i;
         h = 0.5 * (Q[dir_of(a, b, NZ)] - Q[a] - Q[b]);
       }
+      if constexpr (PB::QUAD_COST) h += PB::cost_hess(pc, k, i, j);
       l.W[e] = h;
+    }
+    if constexpr (PB::QUAD_COST) {
+      for (int e = threadIdx.x; e < N * NZ; e += blockDim.x) {
+        const int k = e / NZ, i = e - k * NZ;
+        if (is_free(N, k, i)) l.grad[e] = PB::cost_grad(pc, (const double*)l.par, k, i, (const double*)(l.Z + k * NZ));
+      }
+      for (int k = threadIdx.x; k < N; k += blockDim.x) {
+        double x[NX], u[NU > 0 ? NU : 1];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = l.Z[k * NZ + i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = l.Z[k * NZ + NX + i];
+        l.fk[k] = PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
+      }
+      __syncthreads();
     }
     double fpart = 0.0;
     for (int k = threadIdx.x; k <= N; k += blockDim.x) fpart += l.fk[k];
@@ -243,7 +269,7 @@ struct Ocp {
   }
 
   // dual residual of slot e: grad + J^T lam - zL + zU
-  __device__ static double dual_res(const Lds& l, int N, int e) {
+  __device__ static double dual_res(const Lds l, int N, int e) {
     const int k = e / NZ, i = e - k * NZ;
     double r = l.grad[e] - l.zL[e] + l.zU[e];
     if (i < NX && k >= 1) r += l.lam[(k - 1) * NX + i];
@@ -255,8 +281,8 @@ struct Ocp {
   }
 
   // scaled optimality error pieces (W&B eq. 5)
-  __device__ static void opt_error(const Lds& l, double& dual_s, double& prim, double& s_c) {
-    const OcpConst& pc = *l.pc;
+  __device__ static void opt_error(const Lds l, double& dual_s, double& prim, double& s_c) {
+    const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double dmax = 0.0, lsum = 0.0, zsum = 0.0, pmax = 0.0, nb = 0.0;
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
@@ -281,8 +307,8 @@ struct Ocp {
     prim = pmax;
   }
 
-  __device__ static double compl_error(const Lds& l, double mu) {
-    const OcpConst& pc = *l.pc;
+  __device__ static double compl_error(const Lds l, double mu) {
+    const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double cm = 0.0;
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
@@ -296,8 +322,8 @@ struct Ocp {
 
   // ---- barrier terms of every slot, once per iteration (keeps the divisions out of the sequential recursion):
   //   sig[e] = zL/(z - lb) + zU/(ub - z),   rb[e] = grad[e] - mu/(z - lb) + mu/(ub - z)
-  __device__ static void prep_barrier(const Lds& l, double mu) {
-    const OcpConst& pc = *l.pc;
+  __device__ static void prep_barrier(const Lds l, double mu) {
+    const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
       const int k = e / NZ, i = e - k * NZ;
@@ -322,7 +348,7 @@ struct Ocp {
 
   // lower Cholesky factor of the n x n block M (row pitch ld) with reciprocal pivots: L (n x n), invd = 1/diag(L)
   template <int n>
-  __device__ __forceinline__ static bool small_chol(const double* M, int ld, double* L, double* invd) {
+  __device__ __forceinline__ static bool small_chol(lds_cdouble* M, int ld, double* L, double* invd) {
     bool pd = true;
 #pragma unroll
     for (int j = 0; j < n; ++j) {
@@ -367,8 +393,8 @@ struct Ocp {
   // pivot block's Cholesky (redundantly per lane), feedback K, feed-forward kff, P_k, p_k.  The forward sweep runs
   // on closed-loop matrices prepared in parallel and keeps dx in registers (wave shuffles, no LDS round trip).
   // `resto`: feasibility-restoration step (H = I, zero gradient: least-norm d with J d = -c)
-  __device__ static bool riccati(const Lds& l, double mu, double delta, bool resto = false) {
-    const OcpConst& pc = *l.pc;
+  __device__ __attribute__((noinline)) static bool riccati(const Lds l, double mu, double delta, bool resto = false) {
+    const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N, t = threadIdx.x, T = blockDim.x;
     (void)mu;
     // terminal: P_N = hess V + Sigma + delta, p_N = grad V + barrier rhs
@@ -377,7 +403,7 @@ struct Ocp {
         const int i = e / NX, j = e - i * NX;
         double v = 0.0;
         if (!resto) {
-          const double* Q = l.Qd + N * NDIR;
+          lds_cdouble* Q = l.Qd + N * NDIR;
           if (i == j) v = Q[i];
           else {
             const int a = i < j ? i : j, b = i < j ? j : i;
@@ -393,82 +419,67 @@ struct Ocp {
     }
     __syncthreads();
     for (int k = N - 1; k >= 0; --k) {
-      const double* Pn = l.P + (k + 1) * NX * NX;
-      const double* pn = l.pv + (k + 1) * NX;
-      const double* AB = l.AB + k * NX * NZ;
-      // (1) Mm = H_k + [A B]^T P_{k+1} [A B];  mm = r_k + [A B]^T (p_{k+1} - P_{k+1} c_k)
-      for (int e = t; e < NZ * NZ + NZ; e += T) {
-        if (e < NZ * NZ) {
-          const int i = e / NZ, j = e - i * NZ;
-          double s = resto ? 0.0 : l.W[k * NZ * NZ + e];
+      lds_cdouble* Pn = l.P + (k + 1) * NX * NX;
+      lds_cdouble* pn = l.pv + (k + 1) * NX;
+      lds_cdouble* AB = l.AB + k * NX * NZ;
+      // (1) Mm = H_k + [A B]^T P_{k+1} [A B];  mm = r_k + [A B]^T (p_{k+1} - P_{k+1} c_k).
+      // One uniform code path for the NZ x (NZ+1) entries: column NZ is the right-hand side, i.e. the "column" -c_k
+      // of [A B | -c] with p_{k+1} added.  All operands are fetched before the arithmetic (one LDS wait).
+      for (int e = t; e < NZ * (NZ + 1); e += T) {
+        const int i = e / (NZ + 1), j = e - i * (NZ + 1);
+        const bool rhs = j == NZ;
+        double Pl[NX * NX], ai[NX], aj[NX], pl[NX];
 #pragma unroll
-          for (int m = 0; m < NX; ++m) {
-            double tm = 0.0;
+        for (int q = 0; q < NX * NX; ++q) Pl[q] = Pn[q];
 #pragma unroll
-            for (int n = 0; n < NX; ++n) tm += Pn[m * NX + n] * AB[n * NZ + j];
-            s += AB[m * NZ + i] * tm;
-          }
-          if (i == j) s += resto ? 1.0 : (delta + l.sig[k * NZ + i]);
-          l.Mm[e] = s;
-        } else {
-          const int i = e - NZ * NZ;
-          double s = resto ? 0.0 : l.rb[k * NZ + i];
-#pragma unroll
-          for (int m = 0; m < NX; ++m) {
-            double vm = pn[m];
-#pragma unroll
-            for (int n = 0; n < NX; ++n) vm -= Pn[m * NX + n] * l.c[k * NX + n];
-            s += AB[m * NZ + i] * vm;
-          }
-          l.mm[i] = s;
+        for (int n = 0; n < NX; ++n) {
+          ai[n] = AB[n * NZ + i];
+          aj[n] = rhs ? -l.c[k * NX + n] : AB[n * NZ + j];
+          pl[n] = pn[n];
         }
+        double s = resto ? 0.0 : (rhs ? l.rb[k * NZ + i] : l.W[k * NZ * NZ + i * NZ + j]);
+        const double dg = (i == j) ? (resto ? 1.0 : delta + l.sig[k * NZ + i]) : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NX; ++m) {
+          double tm = rhs ? pl[m] : 0.0;
+#pragma unroll
+          for (int n = 0; n < NX; ++n) tm += Pl[m * NX + n] * aj[n];
+          s += ai[m] * tm;
+        }
+        if (rhs) l.mm[i] = s;
+        else l.Mm[i * NZ + j] = s + dg;
       }
       __syncthreads();
-      // (2) pivot block, feedback, cost-to-go
+      // (2) pivot block (factored redundantly per lane), feedback, cost-to-go: lane (i, j), j = 0..NX:
+      //   y_j = R^-1 M_ux[:, j] (j < NX) or R^-1 m_u (j = NX);  P_k[i][j] = sym(M_xx)[i][j] - M_xu[i] y_j;
+      //   p_k[i] = m_x[i] - M_xu[i] y_NX;  lanes with i = 0 also store K[:, j] = -y_j and kff = -y_NX
       if constexpr (NU > 0) {
         double Lc[NU * NU], invd[NU];
         const bool pd = small_chol<NU>(l.Mm + NX * NZ + NX, NZ, Lc, invd);
         if (!pd) return false;  // wave-uniform: every lane factors the same block
-        constexpr int NPU = NX * (NX + 1) / 2;  // upper triangle of P_k
-        for (int e = t; e < NPU + NX + NX + 1; e += T) {
-          if (e < NPU) {  // P_k[i][j] = sym(M_xx)[i][j] + M_xu[i] K[:, j],  K[:, j] = -R^-1 M_ux[:, j]
-            int i = 0, r = e;
-            while (r >= NX - i) { r -= NX - i; ++i; }
-            const int j = i + r;
-            double y[NU];
+        for (int e = t; e < NX * (NX + 1); e += T) {
+          const int i = e / (NX + 1), j = e - i * (NX + 1);
+          const bool rhs = j == NX;
+          double y[NU], xu[NU];
 #pragma unroll
-            for (int a = 0; a < NU; ++a) y[a] = l.Mm[(NX + a) * NZ + j];
-            small_solve<NU>(Lc, invd, y);
-            double s = 0.5 * (l.Mm[i * NZ + j] + l.Mm[j * NZ + i]);
+          for (int a = 0; a < NU; ++a) {
+            y[a] = rhs ? l.mm[NX + a] : l.Mm[(NX + a) * NZ + j];
+            xu[a] = l.Mm[i * NZ + NX + a];
+          }
+          double s = rhs ? l.mm[i] : 0.5 * (l.Mm[i * NZ + j] + l.Mm[j * NZ + i]);
+          __builtin_amdgcn_sched_barrier(0);
+          small_solve<NU>(Lc, invd, y);
 #pragma unroll
-            for (int a = 0; a < NU; ++a) s -= l.Mm[i * NZ + NX + a] * y[a];
-            l.P[k * NX * NX + i * NX + j] = s;
-            l.P[k * NX * NX + j * NX + i] = s;
-          } else if (e < NPU + NX) {  // p_k[i] = m_x[i] + M_xu[i] kff
-            const int i = e - NPU;
-            double y[NU];
+          for (int a = 0; a < NU; ++a) s -= xu[a] * y[a];
+          if (rhs) l.pv[k * NX + i] = s;
+          else l.P[k * NX * NX + i * NX + j] = s;
+          if (i == 0) {
 #pragma unroll
-            for (int a = 0; a < NU; ++a) y[a] = l.mm[NX + a];
-            small_solve<NU>(Lc, invd, y);
-            double s = l.mm[i];
-#pragma unroll
-            for (int a = 0; a < NU; ++a) s -= l.Mm[i * NZ + NX + a] * y[a];
-            l.pv[k * NX + i] = s;
-          } else if (e < NPU + 2 * NX) {  // store the feedback column
-            const int j = e - NPU - NX;
-            double y[NU];
-#pragma unroll
-            for (int a = 0; a < NU; ++a) y[a] = l.Mm[(NX + a) * NZ + j];
-            small_solve<NU>(Lc, invd, y);
-#pragma unroll
-            for (int a = 0; a < NU; ++a) l.Kg[(k * NU + a) * NX + j] = -y[a];
-          } else {  // feed-forward
-            double y[NU];
-#pragma unroll
-            for (int a = 0; a < NU; ++a) y[a] = l.mm[NX + a];
-            small_solve<NU>(Lc, invd, y);
-#pragma unroll
-            for (int a = 0; a < NU; ++a) l.kff[k * NU + a] = -y[a];
+            for (int a = 0; a < NU; ++a) {
+              if (rhs) l.kff[k * NU + a] = -y[a];
+              else l.Kg[(k * NU + a) * NX + j] = -y[a];
+            }
           }
         }
       } else {
@@ -498,7 +509,7 @@ struct Ocp {
     // closed-loop matrices for the forward sweep: Acl = A + B K, bcl = B kff - c  (parallel over stages)
     for (int e = t; e < N * (NX * NX + NX); e += T) {
       const int k = e / (NX * NX + NX), r = e - k * (NX * NX + NX);
-      const double* AB = l.AB + k * NX * NZ;
+      lds_cdouble* AB = l.AB + k * NX * NZ;
       if (r < NX * NX) {
         const int i = r / NX, j = r - i * NX;
         double s = AB[i * NZ + j];
@@ -514,16 +525,28 @@ struct Ocp {
       }
     }
     __syncthreads();
-    // forward sweep on the first wave: lane i < NX carries dx[i] in a register, exchanged by shuffles
+    // forward sweep on the first wave: lane i < NX carries dx[i] in a register, exchanged by shuffles; the
+    // coefficients of the next stage are fetched while the current one is computed
     if (t < 64) {
       const int i = t < NX ? t : 0;
       double dxi = l.D[i];
-      for (int k = 0; k < N; ++k) {
-        double s = l.bcl[k * NX + i];
+      double ac[NX], bc, an[NX], bn;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) s += l.Acl[k * NX * NX + i * NX + j] * __shfl(dxi, j, 64);
+      for (int j = 0; j < NX; ++j) ac[j] = l.Acl[i * NX + j];
+      bc = l.bcl[i];
+      for (int k = 0; k < N; ++k) {
+        const int kn = k + 1 < N ? k + 1 : k;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) an[j] = l.Acl[kn * NX * NX + i * NX + j];
+        bn = l.bcl[kn * NX + i];
+        double s = bc;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) s += ac[j] * __shfl(dxi, j, 64);
         dxi = s;
         if (t < NX) l.D[(k + 1) * NZ + i] = dxi;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) ac[j] = an[j];
+        bc = bn;
       }
     }
     __syncthreads();
@@ -550,8 +573,8 @@ struct Ocp {
   }
 
   // ---- feasibility restoration, simplified from W&B sec. 3.3 (same statement as oracle/nmpc.py::_restore) ------
-  __device__ static bool restore(const Lds& l, double mu, double tau, int nfilt, double theta_max) {
-    const OcpConst& pc = *l.pc;
+  __device__ __attribute__((noinline)) static bool restore(const Lds l, double mu, double tau, int nfilt, double theta_max) {
+    const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N, t = threadIdx.x, T = blockDim.x, SL = (N + 1) * NZ;
     double th = 0.0;
     for (int e = t; e < N * NX; e += T) th += fabs(l.c[e]);
@@ -598,7 +621,7 @@ struct Ocp {
 // The solve kernel.  v layout (device, per instance, scaled): [prefix (v_prefix doubles, untouched) | x_0..x_N | u_0..u_{N-1}]
 // ---------------------------------------------------------------------------------------------------------------
 template <class PB, int TPB>
-__global__ __launch_bounds__(TPB, HILO_OCP_MINW) void ocp_solve_kernel(const OcpConst* __restrict__ pcg, int64_t batch,
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MINW, HILO_OCP_MINW))) void ocp_solve_kernel(const OcpConst* __restrict__ pcg, int64_t batch,
                                                        const double* __restrict__ x0, const double* __restrict__ par,
                                                        int64_t par_stride, const double* __restrict__ sdata,
                                                        int64_t sd_stride, const double* __restrict__ v0,
@@ -609,7 +632,8 @@ __global__ __launch_bounds__(TPB, HILO_OCP_MINW) void ocp_solve_kernel(const Ocp
                                                        double* __restrict__ kkt, long long* __restrict__ prof) {
   using S = Ocp<PB>;
   constexpr int NX = S::NX, NU = S::NU, NZ = S::NZ;
-  extern __shared__ double lds_raw[];
+  extern __shared__ double lds_raw_generic[];
+  lds_double* lds_raw = (lds_double*)lds_raw_generic;
   const int t = threadIdx.x, T = blockDim.x;
   const int64_t b = blockIdx.x;
   if (b >= batch) return;
@@ -617,14 +641,14 @@ __global__ __launch_bounds__(TPB, HILO_OCP_MINW) void ocp_solve_kernel(const Ocp
   typename S::Lds l = S::carve(lds_raw, N);
   {  // problem constants into LDS: every later access is an LDS read instead of a global load
     const double* src = reinterpret_cast<const double*>(pcg);
-    double* dst = lds_raw;
+    lds_double* dst = lds_raw;
     for (int i = t; i < S::NCONST; i += T) dst[i] = src[i];
   }
   for (int i = t; i < PB::NPAR; i += T) l.par[i] = par[b * par_stride + i];
   if constexpr (PB::NSD > 0)
     for (int i = t; i < (N + 1) * PB::NSD; i += T) l.sd[i] = sdata[b * sd_stride + i];
   __syncthreads();
-  const OcpConst& pc = *l.pc;
+  const OcpConst& pc = *(const OcpConst*)l.pc;
   const int SL = (N + 1) * NZ;
   long long tprof[PH_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = prof ? clock64() : 0;
