@@ -28,7 +28,7 @@ class NmpcDesc(C.Structure):
                 ('dt', C.c_double), ('tol', C.c_double), ('acceptable_tol', C.c_double), ('mu_init', C.c_double),
                 ('bound_relax_factor', C.c_double)] + \
                [(n, C.c_void_p) for n in ('Wz', 'zref', 'WN', 'xrefN', 'Wdu', 'x_lb', 'x_ub', 'u_lb', 'u_ub',
-                                          'x_scaling', 'u_scaling', 'x_guess', 'u_guess')]
+                                          'x_scaling', 'u_scaling', 'x_guess', 'u_guess', 'learned')]
 
 
 class MheDesc(C.Structure):

@@ -22,6 +22,7 @@ namespace hilo {
 // control flow below is scalar.
 // ------------------------------------------------------------------------------------------------
 constexpr int GP_STACK = 8;
+constexpr int GP_PACK_HDR = 5;  // = hilo_models.h GP2_HDR
 constexpr int HILO_K_XX_BEGIN = 19;  // internal marker: evaluate following nodes at (x, x) until the POWER node
 
 __device__ __forceinline__ double d2_active(const double* node, int na, const double* Mdiag, const double* x,
@@ -379,6 +380,7 @@ struct hilo_gp {
   int device, nf, n, klen, mlen;
   double sn2, lml;
   double *X, *y, *kprog, *mprog, *L, *Linv, *alpha, *mu, *out;
+  double *h_kprog, *h_mprog;  // host copies of the programs (gp_pack_se2)
 };
 
 static int upload(double** d, const double* h, size_t count) {
@@ -393,6 +395,8 @@ extern "C" void hilo_gp_destroy(hilo_gp* gp) {
   double* ptrs[] = {gp->X, gp->y, gp->kprog, gp->mprog, gp->L, gp->Linv, gp->alpha, gp->mu, gp->out};
   for (double* p : ptrs)
     if (p) (void)hipFree(p);
+  delete[] gp->h_kprog;
+  delete[] gp->h_mprog;
   delete gp;
 }
 
@@ -412,6 +416,10 @@ extern "C" int hilo_gp_create(int device, int nf, int n, const double* X_host, c
   gp->device = device; gp->nf = nf; gp->n = n; gp->klen = klen; gp->mlen = mlen;
   // inference.py:199: noise_variance = exp(2 * log_sigma_n) with log_sigma_n = log(noise_variance)/2 (kernel.py:127-130)
   gp->sn2 = noise_variance > 0.0 ? exp(2.0 * (log(noise_variance) / 2.0)) : 0.0;
+  gp->h_kprog = new double[klen];
+  gp->h_mprog = new double[mlen];
+  memcpy(gp->h_kprog, kprog_host, sizeof(double) * klen);
+  memcpy(gp->h_mprog, mprog_host, sizeof(double) * mlen);
   const size_t nn = (size_t)n * n;
 #define UP(field, src, cnt) if ((rc = upload(&gp->field, src, cnt))) { hilo_gp_destroy(gp); return rc; }
   UP(X, X_host, (size_t)nf * n) UP(y, y_host, n) UP(kprog, kprog_host, klen) UP(mprog, mprog_host, mlen)
@@ -437,6 +445,39 @@ extern "C" int hilo_gp_create(int device, int nf, int n, const double* X_host, c
   }
   gp->lml = res[0];
   *out = gp;
+  return HILO_OK;
+}
+
+// Posterior mean of a two-feature squared-exponential GP in the layout the model functors read (hilo_models.h GpExt):
+//   [n, sf2, bias, M_0, M_1, (X_0i, X_1i, alpha_i) * n];  mean(x*) = bias + sum_i alpha_i sf2 exp(-d2_i / 2)
+// (inference.py:211-213 with kernel.py:696 at alpha = 1/2, gamma = 2 and mean.py:280-305)
+int hilo::gp_pack_se2(const hilo_gp* gp, double** d_pack) {
+  HILO_REQUIRE(gp && d_pack, "gp_pack_se2: NULL argument");
+  const double* k = gp->h_kprog;
+  const double* m = gp->h_mprog;
+  const bool se = gp->nf == 2 && gp->klen == 10 && (int)k[0] == HILO_K_GAMMAEXP && (int)k[1] == 2 && (int)k[2] == 0 &&
+                  (int)k[3] == 1 && (int)k[4] == 5 && k[6] == 0.5 && k[7] == 1.0;
+  const bool cm = gp->mlen == 4 && (int)m[0] == HILO_M_CONST && (int)m[1] == 0;
+  if (!se || !cm)
+    return fail(HILO_ENOTSUP, "a GP inside a model must have a squared-exponential kernel over its two features and a "
+                              "constant or zero mean in this build");
+  const int n = gp->n;
+  double* X = new double[2 * (size_t)n];
+  double* a = new double[n];
+  double* pack = new double[GP_PACK_HDR + 3 * (size_t)n];
+  hipError_t e = hipSetDevice(gp->device);
+  if (e == hipSuccess) e = hipMemcpy(X, gp->X, sizeof(double) * 2 * n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(a, gp->alpha, sizeof(double) * n, hipMemcpyDeviceToHost);
+  pack[0] = n; pack[1] = k[5]; pack[2] = m[3]; pack[3] = k[8]; pack[4] = k[9];
+  for (int i = 0; i < n; ++i) {
+    pack[GP_PACK_HDR + 3 * i] = X[i];
+    pack[GP_PACK_HDR + 3 * i + 1] = X[n + i];
+    pack[GP_PACK_HDR + 3 * i + 2] = a[i];
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)d_pack, sizeof(double) * (GP_PACK_HDR + 3 * (size_t)n));
+  if (e == hipSuccess) e = hipMemcpy(*d_pack, pack, sizeof(double) * (GP_PACK_HDR + 3 * (size_t)n), hipMemcpyHostToDevice);
+  delete[] X; delete[] a; delete[] pack;
+  if (e != hipSuccess) return fail(HILO_EHIP, "gp_pack_se2: %s", hipGetErrorString(e));
   return HILO_OK;
 }
 

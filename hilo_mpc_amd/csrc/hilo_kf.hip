@@ -452,6 +452,7 @@ extern "C" int hilo_model_dims(int model_id, int* nx, int* nu, int* np, int* ny,
   hilo_kf_desc d = {};
   d.model_id = model_id;
   if (model_id == HILO_MODEL_LTI) return fail(HILO_EINVAL, "LTI dimensions are caller-defined");
+  if (model_id == HILO_MODEL_CHEMOSTAT4_GP) model_id = d.model_id = HILO_MODEL_CHEMOSTAT4;  // same signature
   int a, b, c, e, f;
   int rc = kf_model_dims(&d, &a, &b, &c, &e, &f);
   if (rc) return rc;

@@ -20,19 +20,20 @@ template <class M>
 struct MheNoise {
   static constexpr int NX = M::NX, NU = M::NX, NY = M::NY, MU = M::NU, NPAR = M::NP + M::NX, NSD = M::NU + M::NY;
   static constexpr bool FIX_X0 = false;
+  static constexpr bool COOP = model_has_ext<M>::value;
   static constexpr bool QUAD_COST = false;  // the measurement function may be nonlinear: Taylor evaluation
   static constexpr int O_WX = 0, O_WY = O_WX + NX * NX, O_WW = O_WY + NY * NY, O_SU = O_WW + NX * NX, O_END = O_SU + MU;
 
-  template <class T>
+  template <class T, class E>
   __device__ __forceinline__ static void dyn(const OcpConst& pc, const double* par, const double* sd, int, const T* x,
-                                             const T* w, T* xn) {
+                                             const T* w, T* xn, const E& ext) {
     T xp[NX], xo[NX];
     double ue[MU > 0 ? MU : 1];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xp[i] = x[i] * pc.sz[i];
 #pragma unroll
     for (int i = 0; i < MU; ++i) ue[i] = sd[i] * pc.cost[O_SU + i];
-    model_step<M>(pc.order, pc.nsub, xp, ue, par, pc.dt, xo);
+    model_step<M>(pc.order, pc.nsub, xp, ue, par, pc.dt, xo, ext);
 #pragma unroll
     for (int i = 0; i < NX; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]) + w[i];  // mhe.py:739: scaled noise, scaled state
   }

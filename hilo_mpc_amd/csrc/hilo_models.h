@@ -8,9 +8,15 @@
 //
 // ids match HILO_MODEL_* in include/hilo_hip.h.
 #pragma once
+#include <type_traits>
+
 #include "hilo_ad.h"
 
 namespace hilo {
+
+// LDS-qualified pointer types: keep the address space through non-inlined calls (ds_read/ds_write, not flat_*)
+typedef __attribute__((address_space(3))) double lds_double;
+typedef const __attribute__((address_space(3))) double lds_cdouble;
 
 enum ModelId : int {
   MODEL_LTI = 0,          // x+ = A x + B u, y = C x; A,B,C packed in p (row-major), dims fixed per instantiation
@@ -21,7 +27,88 @@ enum ModelId : int {
   MODEL_ROBOT6 = 5,
   MODEL_CSTR3 = 6,
   MODEL_LINEAR2 = 7,      // reference tests/test_KFs.py:247-255
+  MODEL_CHEMOSTAT4_GP = 8,  // chemostat4 with the growth rate `mu` substituted by a GP mean (dynamic_model.py:3040-3125)
 };
+
+// ------------------------------------------------------------------------------------------------
+// Learned terms.  `Model.substitute_from(gp)` (dynamic_model.py:3040-3125) replaces a model
+// parameter by `gp.predict(features)[0]`, the posterior mean  m(x*) + sum_i alpha_i k(X_i, x*)
+// (inference.py:211-213).  A model whose right-hand side holds such a term receives an `ext` context:
+//   gp    packed posterior (hilo_gp.hip::gp_pack_se2): [n, sf2, bias, M_0, M_1, (X_0i, X_1i, alpha_i) * n] for a
+//         squared-exponential kernel (ARD or isotropic, M_d = 1/l_d^2) and a constant mean, two features
+//   group lanes [gbase, gbase + gs) of the wave evaluate the model at the SAME point (they differ only in their
+//         Taylor directions), so the n kernel evaluations are split among them and summed through LDS.
+// ------------------------------------------------------------------------------------------------
+struct NoExt {};
+constexpr int GP2_HDR = 5;
+struct GpExt {
+  const double* gp;
+  lds_double* scr;  // 12 doubles per lane (partials | group totals); unused when gs == 1
+  int gs, gl, gbase;
+  bool idle;        // lane has no task: contributes nothing, still takes part in the exchange
+};
+
+template <class M, class = void> struct model_has_ext : std::false_type {};
+template <class M> struct model_has_ext<M, std::void_t<decltype(M::EXT)>> : std::bool_constant<M::EXT> {};
+
+// value (ORDER 0) or value / gradient / Hessian (ORDER 2: out = m, g0, g1, h00, h01, h11) of the GP mean at (s, i)
+template <int ORDER>
+__device__ __forceinline__ void gp2_taylor(const GpExt& e, double s, double i, double* out) {
+  constexpr int NC = ORDER == 0 ? 1 : 6;
+  const double* g = e.gp;
+  const int n = (int)g[0];
+  const double sf2 = g[1], bias = g[2], M0 = g[3], M1 = g[4];
+  double acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+  for (int j = e.idle ? n : e.gl; j < n; j += e.gs) {
+    const double* r = g + GP2_HDR + 3 * j;
+    const double d0 = s - r[0], d1 = i - r[1];
+    const double t0 = M0 * d0, t1 = M1 * d1;
+    const double k = r[2] * ::exp(-0.5 * (d0 * t0 + d1 * t1));
+    acc[0] += k;
+    if constexpr (ORDER == 2) {
+      acc[1] -= k * t0;
+      acc[2] -= k * t1;
+      acc[3] += k * (t0 * t0 - M0);
+      acc[4] += k * t0 * t1;
+      acc[5] += k * (t1 * t1 - M1);
+    }
+  }
+  if (e.gs > 1 || e.idle) {  // wave-uniform by construction of the groups (all lanes of a cooperative pass get here)
+    const int lane = threadIdx.x;
+    lds_double* part = e.scr;
+    lds_double* tot = e.scr + 6 * blockDim.x;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) part[lane * 6 + c] = acc[c];
+    __syncthreads();
+    if (!e.idle) {
+      for (int c = e.gl; c < NC; c += e.gs) {
+        double t = 0.0;
+        for (int q = 0; q < e.gs; ++q) t += part[(e.gbase + q) * 6 + c];
+        tot[e.gbase * 6 + c] = t;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = e.idle ? 0.0 : tot[e.gbase * 6 + c];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) out[c] = sf2 * acc[c];
+  out[0] += bias;
+}
+__device__ __forceinline__ double gp2_mean(const GpExt& e, double s, double i) {
+  double o[1];
+  gp2_taylor<0>(e, s, i, o);
+  return o[0];
+}
+__device__ __forceinline__ Jet2 gp2_mean(const GpExt& e, const Jet2& s, const Jet2& i) {
+  double o[6];
+  gp2_taylor<2>(e, s.v, i.v, o);
+  return Jet2(o[0], o[1] * s.a + o[2] * i.a,
+              o[1] * s.b + o[2] * i.b + o[3] * s.a * s.a + 2.0 * o[4] * s.a * i.a + o[5] * i.a * i.a);
+}
 
 // ---- tests/test_KFs.py:247-255: dx1 = -k1 x1 + u, dx2 = k1 x1 - k2 x2, y = x2 -------------------------
 struct Linear2 {
@@ -74,6 +161,30 @@ struct Chemostat4 {
     const T mu = phi * (p[2] + 0.22 * p[3] / (0.22 + I));
     const T Rs = 2.0 * mu;
     const T Rfp = phi * (0.0005 + I) / (0.022 + I);
+    const T D = T(u[0]) + u[1];
+    dx[0] = mu * X - D * X;
+    dx[1] = -1.0 * (Rs * X) - D * S + u[0] * p[0];
+    dx[2] = Rfp * X - D * Pr;
+    dx[3] = -1.0 * (D * I) + u[1] * p[1];
+  }
+  template <class T, class U, class P>
+  HD static void meas(const T* x, const U*, const P*, double, T* y) { y[0] = x[0]; y[1] = x[2]; }
+};
+
+// ---- Chemostat4 with the growth rate of the biomass balance supplied by a GP over the features (S, I) -----
+// (`nmpc_hybrid_bio.ipynb`: `model.substitute_from(gp)` with gp.labels = ['mu']; in the 'simple' model mu only enters
+// dX/dt, hilo_mpc/library/models.py:163-198; Rs and Rfp keep the closed-form rate laws of Chemostat4)
+struct Chemostat4Gp {
+  static constexpr int NX = 4, NU = 2, NP = 4, NY = 2;
+  static constexpr bool DISCRETE = false;
+  static constexpr bool EXT = true;
+  template <class T, class U, class P>
+  __device__ static void ode(const T* x, const U* u, const P* p, double, T* dx, const GpExt& ext) {
+    const T X = x[0], S = x[1], Pr = x[2], I = x[3];
+    const T phi = 0.407 * S / (0.108 + S + S * S / 14814.0);
+    const T Rs = 2.0 * (phi * (p[2] + 0.22 * p[3] / (0.22 + I)));
+    const T Rfp = phi * (0.0005 + I) / (0.022 + I);
+    const T mu = gp2_mean(ext, S, I);
     const T D = T(u[0]) + u[1];
     dx[0] = mu * X - D * X;
     dx[1] = -1.0 * (Rs * X) - D * S + u[0] * p[0];
@@ -152,8 +263,8 @@ template <int I> HD double erk_b(int order) {
   else return order == 4 ? 1.0 / 6 : 0.0;
 }
 
-template <class M, int I, class T, class U, class P>
-HD void erk_stage(int order, const T* x, const U* u, const P* p, double h, T (*k)[M::NX]) {
+template <class M, int I, class T, class U, class P, class E>
+HD void erk_stage(int order, const T* x, const U* u, const P* p, double h, T (*k)[M::NX], const E& ext) {
   constexpr int NX = M::NX;
   if (I < order) {
     T xi[NX];
@@ -165,21 +276,22 @@ HD void erk_stage(int order, const T* x, const U* u, const P* p, double h, T (*k
       if constexpr (I >= 3) acc = acc + (h * erk_a<I, 2>(order)) * k[2][s];
       xi[s] = acc;
     }
-    M::ode(xi, u, p, h, k[I]);
+    if constexpr (model_has_ext<M>::value) M::ode(xi, u, p, h, k[I], ext);
+    else M::ode(xi, u, p, h, k[I]);
   } else {
 #pragma unroll
     for (int s = 0; s < NX; ++s) k[I][s] = T(0.0);
   }
 }
 
-template <class M, class T, class U, class P>
-HD void erk_step(int order, const T* x, const U* u, const P* p, double h, T* xn) {
+template <class M, class T, class U, class P, class E>
+HD void erk_step(int order, const T* x, const U* u, const P* p, double h, T* xn, const E& ext) {
   constexpr int NX = M::NX;
   T k[4][NX];
-  erk_stage<M, 0>(order, x, u, p, h, k);
-  erk_stage<M, 1>(order, x, u, p, h, k);
-  erk_stage<M, 2>(order, x, u, p, h, k);
-  erk_stage<M, 3>(order, x, u, p, h, k);
+  erk_stage<M, 0>(order, x, u, p, h, k, ext);
+  erk_stage<M, 1>(order, x, u, p, h, k, ext);
+  erk_stage<M, 2>(order, x, u, p, h, k, ext);
+  erk_stage<M, 3>(order, x, u, p, h, k, ext);
 #pragma unroll
   for (int s = 0; s < NX; ++s)
     xn[s] = x[s] + (h * erk_b<0>(order)) * k[0][s] + (h * erk_b<1>(order)) * k[1][s] +
@@ -188,10 +300,11 @@ HD void erk_step(int order, const T* x, const U* u, const P* p, double h, T* xn)
 
 // one sampling interval of the shooting map: discrete models are evaluated directly (mpc.py:1381-1389,:1665),
 // continuous ones through ERK of the requested order with `nsub` equal sub-steps
-template <class M, class T, class U, class P>
-HD void model_step(int order, int nsub, const T* x, const U* u, const P* p, double dt, T* xn) {
+template <class M, class T, class U, class P, class E = NoExt>
+HD void model_step(int order, int nsub, const T* x, const U* u, const P* p, double dt, T* xn, const E& ext = E()) {
   if constexpr (M::DISCRETE) {
-    M::ode(x, u, p, dt, xn);
+    if constexpr (model_has_ext<M>::value) M::ode(x, u, p, dt, xn, ext);
+    else M::ode(x, u, p, dt, xn);
   } else {
     constexpr int NX = M::NX;
     const double h = dt / nsub;
@@ -200,7 +313,7 @@ HD void model_step(int order, int nsub, const T* x, const U* u, const P* p, doub
     for (int s = 0; s < NX; ++s) xc[s] = x[s];
     for (int it = 0; it < nsub; ++it) {
       T xt[NX];
-      erk_step<M>(order, xc, u, p, h, xt);
+      erk_step<M>(order, xc, u, p, h, xt, ext);
 #pragma unroll
       for (int s = 0; s < NX; ++s) xc[s] = xt[s];
     }

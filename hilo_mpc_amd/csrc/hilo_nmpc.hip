@@ -19,19 +19,20 @@ template <class M>
 struct NmpcTrack {
   static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU, NPAR = M::NP + M::NU, NSD = 0;
   static constexpr bool FIX_X0 = true;
+  static constexpr bool COOP = model_has_ext<M>::value;  // learned term in the model: lanes share its kernel sum
   static constexpr bool QUAD_COST = true;  // gradient / Hessian of the stage cost in closed form (cost_grad, cost_hess)
   static constexpr int O_WZ = 0, O_ZREF = O_WZ + NZ * NZ, O_WN = O_ZREF + NZ, O_XREFN = O_WN + NX * NX,
                        O_WDU = O_XREFN + NX, O_HASDU = O_WDU + NU * NU, O_END = O_HASDU + 1;
 
-  template <class T>
+  template <class T, class E>
   __device__ __forceinline__ static void dyn(const OcpConst& pc, const double* par, const double*, int, const T* x,
-                                             const T* u, T* xn) {
+                                             const T* u, T* xn, const E& ext) {
     T xp[NX], up[NU > 0 ? NU : 1], xo[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xp[i] = x[i] * pc.sz[i];
 #pragma unroll
     for (int i = 0; i < NU; ++i) up[i] = u[i] * pc.sz[NX + i];
-    model_step<M>(pc.order, pc.nsub, xp, up, par, pc.dt, xo);
+    model_step<M>(pc.order, pc.nsub, xp, up, par, pc.dt, xo, ext);
 #pragma unroll
     for (int i = 0; i < NX; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]);
   }
@@ -118,7 +119,12 @@ __global__ void plant_step_kernel(const OcpConst* __restrict__ pcg, int64_t batc
   for (int i = 0; i < NU; ++i) uv[i] = u[b * NU + i];
 #pragma unroll
   for (int i = 0; i < NP; ++i) pv[i] = par[b * par_stride + i];
-  model_step<M>(pcg->order, pcg->nsub, xv, uv, pv, pcg->dt, xo);
+  if constexpr (model_has_ext<M>::value) {
+    const GpExt ext{pcg->ext, nullptr, 1, 0, 0, false};  // every lane sums its own kernel row
+    model_step<M>(pcg->order, pcg->nsub, xv, uv, pv, pcg->dt, xo, ext);
+  } else {
+    model_step<M>(pcg->order, pcg->nsub, xv, uv, pv, pcg->dt, xo);
+  }
 #pragma unroll
   for (int i = 0; i < NX; ++i) xn[b * NX + i] = xo[i];
 }
@@ -135,6 +141,7 @@ struct hilo_nmpc {
   int64_t par_batch;
   long long* prof;   // optional phase-cycle counters (hilo_nmpc_profile)
   double* v_guess;   // [n_v] device
+  double* ext_pack;  // packed learned term of the model (GpExt) or NULL
   double* v_warm;    // [warm_batch][n_v] device: previous solution (mpc.py:725-726)
   int64_t warm_batch;
   int warm_valid;
@@ -144,7 +151,8 @@ struct hilo_nmpc {
 #define HILO_NMPC_MODELS(X)              \
   X(HILO_MODEL_CHEMOSTAT4, Chemostat4)   \
   X(HILO_MODEL_PENDULUM4, Pendulum4)     \
-  X(HILO_MODEL_BIOREACTOR3, Bioreactor3)
+  X(HILO_MODEL_BIOREACTOR3, Bioreactor3) \
+  X(HILO_MODEL_CHEMOSTAT4_GP, Chemostat4Gp)
 
 static int nmpc_model_dims(int id, int* nx, int* nu, int* np, size_t* lds, int N) {
   switch (id) {
@@ -162,6 +170,7 @@ extern "C" void hilo_nmpc_destroy(hilo_nmpc* h) {
   if (h->v_warm) (void)hipFree(h->v_warm);
   if (h->par_buf) (void)hipFree(h->par_buf);
   if (h->prof) (void)hipFree(h->prof);
+  if (h->ext_pack) (void)hipFree(h->ext_pack);
   delete h;
 }
 
@@ -227,6 +236,19 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   if (d->acceptable_tol > 0) c.acceptable_tol = d->acceptable_tol;
   if (d->mu_init > 0) c.mu_init = d->mu_init;
   hipError_t e = hipSetDevice(device);
+  if (d->model_id == HILO_MODEL_CHEMOSTAT4_GP) {
+    // dynamic_model.py:3040-3125: the label `mu` is replaced by the posterior mean over the features (S, I)
+    if (!d->learned) {
+      hilo_nmpc_destroy(h);
+      return fail(HILO_EINVAL, "hilo_nmpc_create: model 'chemostat4_gp' needs desc.learned (a hilo_gp over the features S, I)");
+    }
+    rc = gp_pack_se2(d->learned, &h->ext_pack);
+    if (rc) { hilo_nmpc_destroy(h); return rc; }
+    c.ext = h->ext_pack;
+  } else if (d->learned) {
+    hilo_nmpc_destroy(h);
+    return fail(HILO_EINVAL, "hilo_nmpc_create: desc.learned given but model %d has no learned term", d->model_id);
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&h->dev, sizeof(OcpConst));
   if (e == hipSuccess) e = hipMemcpy(h->dev, &c, sizeof(OcpConst), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&h->v_guess, sizeof(double) * h->n_v);

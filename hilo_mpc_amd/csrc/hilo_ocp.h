@@ -43,6 +43,7 @@ struct OcpConst {
   double tol, acceptable_tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac, s_max,
       kappa_sigma, gamma_theta, gamma_phi, delta_ls, s_theta, s_phi, eta_phi, theta_min_fact, theta_max_fact,
       delta_w_min, delta_w_0, delta_w_max, kappa_w_minus, kappa_w_plus, kappa_w_plus_bar;
+  const double* ext;  // learned-term data of the model in device memory (hilo_models.h GpExt) or NULL
 };
 
 inline void ocp_default_options(OcpConst& c) {
@@ -75,10 +76,6 @@ __device__ __forceinline__ double block_reduce(double v, __attribute__((address_
   return r;
 }
 
-// LDS-qualified pointer types: keep the address space through non-inlined calls (ds_read/ds_write, not flat_*)
-typedef __attribute__((address_space(3))) double lds_double;
-typedef const __attribute__((address_space(3))) double lds_cdouble;
-
 enum OcpPhase { PH_DERIV = 0, PH_ERR, PH_RICCATI, PH_STEP, PH_LS, PH_UPDATE, PH_NRIC, PH_NLS, PH_COUNT };
 
 template <class PB>
@@ -86,18 +83,22 @@ struct Ocp {
   static constexpr int NX = PB::NX, NU = PB::NU, NZ = NX + NU, NDIR = NZ * (NZ + 1) / 2, NXDIR = NX * (NX + 1) / 2;
   static constexpr int NPAR = PB::NPAR > 0 ? PB::NPAR : 1, NSD = PB::NSD;
   static constexpr bool FIX_X0 = PB::FIX_X0;
+  // model with a learned term: lanes that evaluate the dynamics at the same point share its kernel sum (GpExt)
+  static constexpr bool COOP = PB::COOP;
+  static constexpr int NEXT = COOP ? 12 * OCP_TPB : 0;
+  static_assert(!COOP || (OCP_TPB == 64 && NDIR <= 64), "cooperative models need one wave per instance");
   static constexpr int NCONST = (sizeof(OcpConst) + 7) / 8;
 
   struct Lds {
     const __attribute__((address_space(3))) OcpConst* pc;
     lds_double *Z, *Zt, *D, *zL, *zU, *dzL, *dzU, *grad, *lam, *lamn, *c, *ct, *AB, *W, *Qd, *P, *pv, *Kg, *kff, *sig,
-        *rb, *Acl, *bcl, *Mm, *mm, *fk, *filt, *red, *par, *sd;
+        *rb, *Acl, *bcl, *Mm, *mm, *fk, *filt, *red, *par, *sd, *ext;
   };
   __host__ __device__ static size_t lds_doubles(int N) {
     const size_t S = (size_t)(N + 1) * NZ;
     return NCONST + 10 * S + 4 * (size_t)N * NX + (size_t)N * NX * NZ + (size_t)N * NZ * NZ + (size_t)(N + 1) * NDIR +
            (size_t)(N + 1) * NX * NX + (size_t)(N + 1) * NX + (size_t)N * NU * NX + (size_t)N * NU + (size_t)N * NX * NX +
-           (size_t)N * NX + NZ * NZ + NZ + (N + 1) + 2 * OCP_FILTER + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1;
+           (size_t)N * NX + NZ * NZ + NZ + (N + 1) + 2 * OCP_FILTER + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1 + NEXT;
   }
   __device__ static Lds carve(lds_double* base, int N) {
     Lds l;
@@ -115,6 +116,7 @@ struct Ocp {
     l.Mm = take(NZ * NZ); l.mm = take(NZ);
     l.fk = take(N + 1); l.filt = take(2 * OCP_FILTER); l.red = take(16); l.par = take(NPAR);
     l.sd = take((size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1);
+    l.ext = take(NEXT);
     return l;
   }
 
@@ -136,6 +138,41 @@ struct Ocp {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double fpart = 0.0, tpart = 0.0;
+    if constexpr (COOP) {
+      // groups of gs lanes per interval: the same point in every lane of a group, the kernel sum split among them
+      const int lane = threadIdx.x;
+      int gs = 64 / N;
+      gs = gs < 1 ? 1 : gs;
+      const int ng = 64 / gs, g = lane / gs, gl = lane - g * gs;
+      const double* gp = (const double*)pc.ext;
+      for (int r = 0; r * ng < N; ++r) {
+        const int k = r * ng + g;
+        const bool active = g < ng && k < N;
+        const int kk = active ? k : N - 1;
+        const GpExt ext{gp, l.ext, gs, active ? gl : 0, active ? g * gs : lane, !active};
+        double x[NX], u[NU > 0 ? NU : 1], xn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = Zp[kk * NZ + i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = Zp[kk * NZ + NX + i];
+        PB::dyn(pc, (const double*)l.par, sd_of(l, kk), kk, x, u, xn, ext);
+        if (active && gl == 0) {
+          fpart += PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            const double ci = Zp[(k + 1) * NZ + i] - xn[i];
+            cp[k * NX + i] = ci;
+            tpart += fabs(ci);
+          }
+        }
+      }
+      if (lane == 63) {
+        double x[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = Zp[N * NZ + i];
+        fpart += PB::term_cost(pc, (const double*)l.par, sd_of(l, N), x);
+      }
+    } else
     for (int k = threadIdx.x; k <= N; k += blockDim.x) {
       double x[NX], u[NU > 0 ? NU : 1];
 #pragma unroll
@@ -144,7 +181,7 @@ struct Ocp {
         double xn[NX];
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = Zp[k * NZ + NX + i];
-        PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn);
+        PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
         fpart += PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -178,27 +215,49 @@ struct Ocp {
   __device__ __attribute__((noinline)) static double eval_derivs(const Lds l) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
-    for (int task = threadIdx.x; task < N * NDIR + NXDIR; task += blockDim.x) {
-      if (task < N * NDIR) {
-        const int k = task / NDIR, d = task - k * NDIR;
+    constexpr int GPW = COOP ? 64 / NDIR : 1;  // cooperative: lane groups of NDIR directions, GPW intervals per round
+    const int ntask = COOP ? ((N + GPW - 1) / GPW) * 64 + NXDIR : N * NDIR + NXDIR;
+    const int tbase = ntask - NXDIR;
+    for (int task0 = threadIdx.x; task0 < ntask; task0 += blockDim.x) {
+      if (task0 < tbase) {
+        int k, d, task = task0;
+        bool active = true;
+        if constexpr (COOP) {
+          const int lane = threadIdx.x, g = lane / NDIR;
+          d = lane - g * NDIR;
+          k = (task0 / 64) * GPW + g;
+          active = g < GPW && k < N;
+          if (!active) { k = N - 1; d = 0; }
+          task = k * NDIR + d;
+        } else {
+          k = task / NDIR;
+          d = task - k * NDIR;
+        }
         int di = d, dj = -1;
         if (d >= NZ) pair_of(d, NZ, di, dj);
         const bool dead = FIX_X0 && k == 0 && di < NX;  // direction touches the pinned x_0
-        if (dead) {
+        if (dead && active) {
           l.Qd[task] = 0.0;
           if (d < NZ) {
             l.grad[d] = 0.0;
 #pragma unroll
             for (int m = 0; m < NX; ++m) l.AB[m * NZ + d] = 0.0;
           }
-          if (d != 0) continue;
+          if (d != 0 && !COOP) continue;
         }
         Jet2 x[NX], u[NU > 0 ? NU : 1], xn[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = Jet2(l.Z[k * NZ + i], (!dead && (i == di || i == dj)) ? 1.0 : 0.0, 0.0);
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = Jet2(l.Z[k * NZ + NX + i], (NX + i == di || NX + i == dj) ? 1.0 : 0.0, 0.0);
-        PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn);
+        if constexpr (COOP) {
+          const int lane = threadIdx.x, g = lane / NDIR;
+          const GpExt ext{(const double*)pc.ext, l.ext, NDIR, active ? d : 0, active ? g * NDIR : lane, !active};
+          PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, ext);
+          if (!active) continue;
+        } else {
+          PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
+        }
         // a policy with a purely quadratic stage cost supplies value / gradient / (constant) Hessian in closed form
         Jet2 lc(0.0);
         if constexpr (!PB::QUAD_COST) lc = PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
@@ -218,8 +277,8 @@ struct Ocp {
             if (d < NZ) l.grad[k * NZ + d] = lc.a;
           }
         }
-      } else {  // terminal cost V(x_N): directions over the NX state slots
-        const int d = task - N * NDIR;
+      } else if (task0 < ntask) {  // terminal cost V(x_N): directions over the NX state slots
+        const int d = task0 - tbase;
         int di = d, dj = -1;
         if (d >= NX) pair_of(d, NX, di, dj);
         Jet2 x[NX];

@@ -18,7 +18,10 @@ ZOO = {
     'chemostat4': (3, False, ['X', 'S', 'P', 'I'], ['DS', 'DI'], ['Sf', 'If', 'ISF', 'IRF'], ['yX', 'yP']),
     'pendulum4': (4, False, ['x', 'v', 'theta', 'omega'], ['F'], [], ['yx', 'yv', 'ytheta', 'tomega']),
     'linear2': (7, True, ['x_1', 'x_2'], ['u'], ['k_1', 'k_2'], ['y']),
+    'chemostat4_gp': (8, False, ['X', 'S', 'P', 'I'], ['DS', 'DI'], ['Sf', 'If', 'ISF', 'IRF'], ['yX', 'yP']),
 }
+# zoo models whose right-hand side has a slot for a learned term: base name -> (label, features, hybrid functor)
+LEARNABLE = {'chemostat4': ('mu', ['S', 'I'], 'chemostat4_gp')}
 NATIVE_DISCRETE = {'toy1d', 'lti'}
 
 
@@ -29,6 +32,8 @@ class Model:
     (`x+ = A x + B u`, `y = C x`, cf. tests/test_LMPC.py:8-19)."""
 
     def __init__(self, name, A=None, B=None, C=None, discrete=None):
+        if name == 'chemostat4_gp':
+            raise ValueError("build the hybrid model with Model('chemostat4').substitute_from(gp)")
         if name not in ZOO:
             raise ValueError(f"unknown model '{name}'; the device zoo holds {sorted(ZOO)}")
         self.name = name
@@ -57,6 +62,7 @@ class Model:
             self._native_discrete = name in NATIVE_DISCRETE if discrete is None else bool(discrete)
         self.dynamical_state_names, self.input_names = list(xs), list(us)
         self.parameter_names, self.measurement_names = list(ps), list(ys)
+        self.learned = None         # trained GaussianProcess substituted into the right-hand side
 
     # -- reference-like surface ---------------------------------------------------------------
     @property
@@ -95,6 +101,28 @@ class Model:
             self.dt = 1.
         self._is_setup = True
         return self
+
+    def substitute_from(self, obj):
+        """`Model.substitute_from(gp)` (dynamic_model.py:3040-3125): the quantity named by `gp.labels` is replaced
+        by the GP's posterior mean `gp.predict(features)[0]`, the features being looked up by name among the model's
+        variables (:3056-3061).  The device zoo offers this for the growth rate `mu` of 'chemostat4' over the
+        features (S, I) (`nmpc_hybrid_bio.ipynb`); the GP must be trained (`setup` + `fit_model` or `set_training_data`
+        + `setup`) with a squared-exponential kernel and a constant/zero mean."""
+        if self.name not in LEARNABLE:
+            raise NotImplementedError(f"model '{self.name}' has no learnable term in the device zoo "
+                                      f"(available: {sorted(LEARNABLE)})")
+        label, features, hybrid = LEARNABLE[self.name]
+        if list(getattr(obj, 'labels', [])) != [label] or list(getattr(obj, 'features', [])) != features:
+            raise ValueError(f"model '{self.name}' takes a learned model with labels ['{label}'] and features "
+                             f"{features}; got labels {getattr(obj, 'labels', None)}, features "
+                             f"{getattr(obj, 'features', None)}")
+        if getattr(obj, '_handle', None) is None:
+            raise RuntimeError("The GP has not been set up (trained) yet. Run GaussianProcess.setup() first.")
+        m = self
+        m.name = hybrid
+        m.model_id = ZOO[hybrid][0]
+        m.learned = obj
+        return m
 
     def copy(self):
         return copy.copy(self)

@@ -300,6 +300,8 @@ class NMPC:
         d.x_lb, d.x_ub, d.u_lb, d.u_ub = hp(self._x_lb), hp(self._x_ub), hp(self._u_lb), hp(self._u_ub)
         d.x_scaling, d.u_scaling = hp(self._x_scaling), hp(self._u_scaling)
         d.x_guess, d.u_guess = hp(self._x_guess), hp(self._u_guess)
+        learned = getattr(m, 'learned', None)
+        d.learned = learned._handle if learned is not None else None
         self._dev = device(self._dev_index)
         h = C.c_void_p()
         _lib.check(_lib.lib().hilo_nmpc_create(C.byref(d), self._dev.index, C.byref(h)))

@@ -43,6 +43,8 @@ extern "C" {
 #define HILO_MODEL_ROBOT6 5
 #define HILO_MODEL_CSTR3 6
 #define HILO_MODEL_LINEAR2 7     /* tests/test_KFs.py:247-255 */
+#define HILO_MODEL_CHEMOSTAT4_GP 8 /* CHEMOSTAT4 with the biomass growth rate `mu` replaced by a GP mean over (S, I):
+                                      Model.substitute_from(gp), dynamic_model.py:3040-3125 (NMPC only) */
 
 /* solver status codes: hilo_mpc/modules/optimizer.py:1085-1104 */
 #define HILO_STATUS_SOLVED 1
@@ -198,6 +200,9 @@ typedef struct hilo_nmpc_desc {
   const double* x_lb; const double* x_ub; const double* u_lb; const double* u_ub;  /* original units */
   const double* x_scaling; const double* u_scaling;                                /* optimizer.py:1476-1506 */
   const double* x_guess; const double* u_guess;                                    /* original units */
+  /* learned term of the model (`Model.substitute_from(gp)`, dynamic_model.py:3040-3125): required for
+     HILO_MODEL_CHEMOSTAT4_GP (label `mu`, features S, I; the posterior mean is copied at create), else NULL */
+  const hilo_gp* learned;
 } hilo_nmpc_desc;
 
 int hilo_nmpc_create(const hilo_nmpc_desc* desc, int device, hilo_nmpc** out);   /* = NMPC.setup(), mpc.py:1789 */

@@ -25,6 +25,7 @@ MODEL_CHEMOSTAT4 = 3
 MODEL_PENDULUM4 = 4
 MODEL_ROBOT6 = 5
 MODEL_CSTR3 = 6
+MODEL_CHEMOSTAT4_GP = 8
 
 # modeling.py:1008-1085 (only the tableaux reachable through `order`)
 TABLEAUX = {
@@ -202,6 +203,29 @@ def pendulum4():
     dv = 1. / (M + m - m * sp.cos(th)) * (m * g * sp.sin(th) - m * l * sp.sin(th) * om ** 2 + F)
     dom = 1. / l * (dv * sp.cos(th) + g * sp.sin(th))
     return OracleModel('pendulum4', MODEL_PENDULUM4, [x, v, th, om], [F], [], [v, dv, om, dom], [x, v, th, om])
+
+
+def chemostat4_gp(X_train, alpha, length_scales, signal_variance=1., bias=0.):
+    """`chemostat4` with the growth rate of the biomass balance replaced by a GP posterior mean over (S, I):
+    `model.substitute_from(gp)` (dynamic_model.py:3040-3125; usage `nmpc_hybrid_bio.ipynb`).  The mean is written out
+    term by term - bias + sum_i alpha_i sf2 exp(-1/2 sum_d (x_d - X_di)^2 / l_d^2) (inference.py:211-213,
+    kernel.py:696) - like the unrolled SX expression the reference builds; Rs and Rfp keep their closed forms."""
+    X, S, P, I, DS, DI = sp.symbols('X S P I DS DI')
+    Sf, If, ISF, IRF = sp.symbols('Sf If ISF IRF')
+    Xt = np.atleast_2d(np.asarray(X_train, dtype=float))
+    al = np.asarray(alpha, dtype=float).ravel()
+    ls = np.broadcast_to(np.asarray(length_scales, dtype=float), (2,))
+    M = np.exp(-2 * np.log(ls))                                              # kernel.py:538-555
+    sf2 = float(np.exp(2 * (np.log(signal_variance) / 2)))                   # kernel.py:127-130
+    mu = sp.Float(bias) + sum(float(al[i]) * sf2 * sp.exp(-0.5 * (float(M[0]) * (S - float(Xt[0, i])) ** 2 +
+                                                             float(M[1]) * (I - float(Xt[1, i])) ** 2))
+                              for i in range(Xt.shape[1]))
+    phi = 0.407 * S / (0.108 + S + S ** 2 / 14814.0)
+    Rs = 2 * (phi * (ISF + 0.22 * IRF / (0.22 + I)))
+    Rfp = phi * (0.0005 + I) / (0.022 + I)
+    D = DS + DI
+    return OracleModel('chemostat4_gp', MODEL_CHEMOSTAT4_GP, [X, S, P, I], [DS, DI], [Sf, If, ISF, IRF],
+                       [mu * X - D * X, -Rs * X - D * S + DS * Sf, Rfp * X - D * P, -D * I + DI * If], [X, P])
 
 
 ZOO = {

@@ -29,7 +29,12 @@ def oracle_problem(spec):
 def product_nmpc(spec, **solver_options):
     """Build the product NMPC for a plain spec through the reference-style API."""
     from hilo_mpc_amd import NMPC, Model
-    m = Model(spec['model']).discretize('erk', order=spec.get('order', 4)).setup(dt=spec['dt'])
+    if spec['model'] == 'chemostat4_gp':
+        m = Model('chemostat4')
+        m.substitute_from(product_gp())                 # dynamic_model.py:3040-3125
+    else:
+        m = Model(spec['model'])
+    m = m.discretize('erk', order=spec.get('order', 4)).setup(dt=spec['dt'])
     nmpc = NMPC(m)
     xs, us = m.dynamical_state_names, m.input_names
     for ind, W, ref in spec.get('stage_states', []):
@@ -87,3 +92,43 @@ def oracle_mhe(spec):
     from oracle.mhe import MheProblem
     kw = {k: v for k, v in spec.items() if k not in ('model', 'p')}
     return MheProblem(models.get(spec['model']), **kw)
+
+
+# ---- C4: GP-hybrid NMPC: chemostat4 whose biomass growth rate `mu` comes from a GP over (S, I) ----------
+C4_GP = dict(length_scales=[10., 1.], signal_variance=1., noise_variance=1e-4)
+C4 = dict(C2, model='chemostat4_gp')
+
+
+def c4_training_data(seed=SEED):
+    """200 points on a 20 x 10 grid of S in [0, 40], I in [0, 4]; targets = the closed-form rate (ISF = 1, IRF = 0:
+    the parameter values of C2) + N(0, 1e-4).  Returns X (2 x 200), y (1 x 200)."""
+    S, I = np.meshgrid(np.linspace(0., 40., 20), np.linspace(0., 4., 10), indexing='ij')
+    S, I = S.ravel(), I.ravel()
+    phi = 0.407 * S / (0.108 + S + S ** 2 / 14814.0)
+    mu = phi * (1. + 0.22 * 0. / (0.22 + I))
+    rng = np.random.default_rng(seed + 4)
+    return np.stack([S, I]), (mu + 1e-2 * rng.standard_normal(mu.size))[None, :]
+
+
+def oracle_c4(spec=C4):
+    from oracle import gp as ogp, models
+    from oracle.nmpc import NmpcProblem
+    X, y = c4_training_data()
+    post = ogp.Posterior({'type': 'squared_exponential',
+                          'kwargs': dict(active_dims=[0, 1], length_scales=C4_GP['length_scales'], ard=True,
+                                         signal_variance=C4_GP['signal_variance'])},
+                         {'type': 'zero'}, X, y, C4_GP['noise_variance'])
+    model = models.chemostat4_gp(X, post.alpha, C4_GP['length_scales'], C4_GP['signal_variance'])
+    kw = {k: v for k, v in spec.items() if k not in ('model', 'p')}
+    return NmpcProblem(model, **kw), post
+
+
+def product_gp():
+    from hilo_mpc_amd import GP, Kernel
+    X, y = c4_training_data()
+    gp = GP(['S', 'I'], ['mu'], kernel=Kernel.squared_exponential(active_dims=[0, 1], length_scales=C4_GP['length_scales'],
+                                                                  ard=True, signal_variance=C4_GP['signal_variance']),
+            noise_variance=C4_GP['noise_variance'])
+    gp.set_training_data(X, y)
+    gp.setup()
+    return gp
