@@ -26,12 +26,12 @@ def oracle_problem(spec):
     return NmpcProblem(models.get(spec['model']), **kw)
 
 
-def product_nmpc(spec, **solver_options):
+def product_nmpc(spec, gp=None, **solver_options):
     """Build the product NMPC for a plain spec through the reference-style API."""
     from hilo_mpc_amd import NMPC, Model
     if spec['model'] == 'chemostat4_gp':
         m = Model('chemostat4')
-        m.substitute_from(product_gp())                 # dynamic_model.py:3040-3125
+        m.substitute_from(gp if gp is not None else product_gp())                 # dynamic_model.py:3040-3125
     else:
         m = Model(spec['model'])
     m = m.discretize('erk', order=spec.get('order', 4)).setup(dt=spec['dt'])
@@ -123,9 +123,10 @@ def oracle_c4(spec=C4):
     return NmpcProblem(model, **kw), post
 
 
-def product_gp():
+def product_gp(X=None, y=None):
     from hilo_mpc_amd import GP, Kernel
-    X, y = c4_training_data()
+    if X is None:
+        X, y = c4_training_data()
     gp = GP(['S', 'I'], ['mu'], kernel=Kernel.squared_exponential(active_dims=[0, 1], length_scales=C4_GP['length_scales'],
                                                                   ard=True, signal_variance=C4_GP['signal_variance']),
             noise_variance=C4_GP['noise_variance'])

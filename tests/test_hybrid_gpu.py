@@ -52,6 +52,18 @@ def test_c4_solve_vs_oracle(oracle):
     np.testing.assert_allclose(u[ok], ref['u0'][ok], rtol=1e-4, atol=1e-6)
 
 
+def test_golden_c4_closed_loop():
+    """Committed fixture (tests/golden/make_hybrid_golden.py): GP trained on the fixture's own data, then the closed
+    loop of tests/test_nmpc_gpu.py's fixture check (status exact, v 5e-5 at tol 1e-8, 2e-6 at tol 1e-9)."""
+    import json
+    import os
+    from tests.test_nmpc_gpu import GOLD, _check_against_fixture
+    fx = json.load(open(os.path.join(GOLD, 'nmpc_c4.json')))
+    gp = product_gp(np.array(fx['gp']['X']), np.array(fx['gp']['y']))
+    assert abs(gp.log_marginal_likelihood() - fx['gp']['lml']) < 1e-7 * abs(fx['gp']['lml'])
+    _check_against_fixture(lambda tol: product_nmpc(C4, gp=gp, **({'tol': tol} if tol else {})), fx, fx['p'])
+
+
 def test_hybrid_differs_from_first_principles_and_closes_the_loop():
     """The learned growth rate changes the optimum (the GP is not a no-op), and a warm-started closed loop at the
     C4 batch size per GPU (256) converges everywhere."""
