@@ -17,7 +17,8 @@ GP = GaussianProcess
 __all__ = ['Model', 'KalmanFilter', 'ExtendedKalmanFilter', 'UnscentedKalmanFilter', 'KF', 'EKF', 'UKF',
            'GaussianProcess', 'GP', 'Kernel', 'Mean']
 from .nmpc import NMPC
+from . import expr
 from .mhe import MovingHorizonEstimator, MHE
 from .lmpc import LMPC
 
-__all__ += ['NMPC', 'MovingHorizonEstimator', 'MHE', 'LMPC']
+__all__ += ['NMPC', 'MovingHorizonEstimator', 'MHE', 'LMPC', 'expr']

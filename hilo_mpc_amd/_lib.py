@@ -28,7 +28,14 @@ class NmpcDesc(C.Structure):
                 ('dt', C.c_double), ('tol', C.c_double), ('acceptable_tol', C.c_double), ('mu_init', C.c_double),
                 ('bound_relax_factor', C.c_double)] + \
                [(n, C.c_void_p) for n in ('Wz', 'zref', 'WN', 'xrefN', 'Wdu', 'x_lb', 'x_ub', 'u_lb', 'u_ub',
-                                          'x_scaling', 'u_scaling', 'x_guess', 'u_guess', 'learned')]
+                                          'x_scaling', 'u_scaling', 'x_guess', 'u_guess', 'learned')] + \
+               [('n_path_var', C.c_int32), ('has_u_pf_ref', C.c_int32)] + \
+               [(n, C.c_double) for n in ('theta_guess', 'theta_lb', 'theta_ub', 'u_pf_lb', 'u_pf_ub', 'u_pf_ref',
+                                          'u_pf_weight')] + \
+               [('n_path_stage', C.c_int32), ('n_path_term', C.c_int32)] + \
+               [(n, C.c_void_p) for n in ('path_stage_idx', 'path_stage_W', 'path_term_idx', 'path_term_W', 'path_prog')] + \
+               [(n, C.c_int32) for n in ('path_prog_len', 'n_con', 'con_soft', 'con_prog_len')] + \
+               [(n, C.c_void_p) for n in ('con_prog', 'con_lb', 'con_ub', 'con_weight', 'con_max_violation')]
 
 
 class MheDesc(C.Structure):

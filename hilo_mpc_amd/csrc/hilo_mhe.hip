@@ -20,6 +20,8 @@ template <class M>
 struct MheNoise {
   static constexpr int NX = M::NX, NU = M::NX, NY = M::NY, MU = M::NU, NPAR = M::NP + M::NX, NSD = M::NU + M::NY;
   static constexpr bool FIX_X0 = false;
+  static constexpr bool BIG = false;  // iterate in LDS
+  static constexpr int NC = 0, NXV = NX, NX0 = NX, NU0 = NU;  // no inequality rows; plain [x | u] decision vector
   static constexpr bool COOP = model_has_ext<M>::value;
   static constexpr bool QUAD_COST = false;  // the measurement function may be nonlinear: Taylor evaluation
   static constexpr int O_WX = 0, O_WY = O_WX + NX * NX, O_WW = O_WY + NY * NY, O_SU = O_WW + NX * NX, O_END = O_SU + MU;

@@ -215,6 +215,23 @@ struct Pendulum4 {
   }
 };
 
+// ---- planar mobile robot with heading: px,vx,py,vy,psi,omega; inputs a (along the heading), alpha ----
+struct Robot6 {
+  static constexpr int NX = 6, NU = 2, NP = 0, NY = 2;
+  static constexpr bool DISCRETE = false;
+  template <class T, class U, class P>
+  HD static void ode(const T* x, const U* u, const P*, double, T* dx) {
+    dx[0] = x[1];
+    dx[1] = u[0] * cos(x[4]);
+    dx[2] = x[3];
+    dx[3] = u[0] * sin(x[4]);
+    dx[4] = x[5];
+    dx[5] = T(u[1]);
+  }
+  template <class T, class U, class P>
+  HD static void meas(const T* x, const U*, const P*, double, T* y) { y[0] = x[0]; y[1] = x[2]; }
+};
+
 // ---- LTI with compile-time dims; p = [A (NX*NX) | B (NX*NU) | C (NY*NX)] row-major ------------------------
 template <int NX_, int NU_, int NY_>
 struct Lti {

@@ -9,7 +9,7 @@
 //   term only in interval 0 (mpc.py:1631-1635), the model scaled as in hilo_mpc/modules/base.py:1562-1591.
 #include <string.h>
 
-#include "hilo_ocp.h"
+#include "hilo_nmpc_gen.h"
 
 namespace hilo {
 
@@ -19,6 +19,8 @@ template <class M>
 struct NmpcTrack {
   static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU, NPAR = M::NP + M::NU, NSD = 0;
   static constexpr bool FIX_X0 = true;
+  static constexpr bool BIG = false;  // iterate in LDS
+  static constexpr int NC = 0, NXV = NX, NX0 = NX, NU0 = NU;  // no inequality rows; plain [x | u] decision vector
   static constexpr bool COOP = model_has_ext<M>::value;  // learned term in the model: lanes share its kernel sum
   static constexpr bool QUAD_COST = true;  // gradient / Hessian of the stage cost in closed form (cost_grad, cost_hess)
   static constexpr int O_WZ = 0, O_ZREF = O_WZ + NZ * NZ, O_WN = O_ZREF + NZ, O_XREFN = O_WN + NX * NX,
@@ -142,6 +144,10 @@ struct hilo_nmpc {
   long long* prof;   // optional phase-cycle counters (hilo_nmpc_profile)
   double* v_guess;   // [n_v] device
   double* ext_pack;  // packed learned term of the model (GpExt) or NULL
+  const GenVariant* gen;  // general variant (path following / stage constraints), NULL for the tracking policy
+  int nu_out;        // width of the returned first input (model inputs, without the virtual path input)
+  double* ws;        // iterate workspace of BIG variants [ws_batch][ws_bytes]
+  int64_t ws_batch;
   double* v_warm;    // [warm_batch][n_v] device: previous solution (mpc.py:725-726)
   int64_t warm_batch;
   int warm_valid;
@@ -152,7 +158,8 @@ struct hilo_nmpc {
   X(HILO_MODEL_CHEMOSTAT4, Chemostat4)   \
   X(HILO_MODEL_PENDULUM4, Pendulum4)     \
   X(HILO_MODEL_BIOREACTOR3, Bioreactor3) \
-  X(HILO_MODEL_CHEMOSTAT4_GP, Chemostat4Gp)
+  X(HILO_MODEL_CHEMOSTAT4_GP, Chemostat4Gp) \
+  X(HILO_MODEL_ROBOT6, Robot6)
 
 static int nmpc_model_dims(int id, int* nx, int* nu, int* np, size_t* lds, int N) {
   switch (id) {
@@ -171,6 +178,7 @@ extern "C" void hilo_nmpc_destroy(hilo_nmpc* h) {
   if (h->par_buf) (void)hipFree(h->par_buf);
   if (h->prof) (void)hipFree(h->prof);
   if (h->ext_pack) (void)hipFree(h->ext_pack);
+  if (h->ws) (void)hipFree(h->ws);
   delete h;
 }
 
@@ -189,14 +197,61 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   int rc = nmpc_model_dims(d->model_id, &nx, &nu, &np, &lds, d->N);
   if (rc) return rc;
   HILO_REQUIRE(nx <= OCP_MAXNX && nu <= OCP_MAXNU, "model too large for this build");
+  // ---- general problems: path variable and / or nonlinear stage constraint ----
+  HILO_REQUIRE(d->n_path_var >= 0 && d->n_path_var <= 1, "hilo_nmpc_create: at most one path variable is supported (got %d)",
+               d->n_path_var);
+  HILO_REQUIRE(d->n_con >= 0 && d->n_con <= GEN_NEXPR, "hilo_nmpc_create: at most %d constraint expressions (got %d)", GEN_NEXPR,
+               d->n_con);
+  const bool general = d->n_path_var > 0 || d->n_con > 0;
+  const GenVariant* gv = nullptr;
+  int nth = 0, ne = 0, nrow = 0, n_con_ref = 0;
+  int row_expr[OCP_MAXNC], row_sign[OCP_MAXNC], row_e[OCP_MAXNC], row_ref[OCP_MAXNC];
+  double row_lb[OCP_MAXNC], row_ub[OCP_MAXNC];
+  if (general) {
+    if (d->learned) return fail(HILO_ENOTSUP, "a learned term together with path following / stage constraints is not built");
+    nth = d->n_path_var;
+    if (d->n_con > 0) {
+      HILO_REQUIRE(d->con_prog && d->con_prog_len > 0, "hilo_nmpc_create: n_con > 0 but no constraint program");
+      ne = d->con_soft ? d->n_con : 0;
+      n_con_ref = d->con_soft ? 2 * d->n_con : d->n_con;   // rows per stage in the reference's g (mpc.py:1711-1712)
+      for (int j = 0; j < d->n_con; ++j) {
+        const double lb = d->con_lb ? d->con_lb[j] : -INFINITY, ub = d->con_ub ? d->con_ub[j] : INFINITY;
+        HILO_REQUIRE(lb <= ub, "hilo_nmpc_create: constraint %d has lb > ub", j);
+        if (d->con_soft) {   // c - e <= ub | -c - e <= -lb; a row without a finite bound constrains nothing and is dropped
+          if (ub < INFINITY) {
+            HILO_REQUIRE(nrow < OCP_MAXNC, "too many constraint rows");
+            row_expr[nrow] = j; row_sign[nrow] = 1; row_e[nrow] = j; row_lb[nrow] = -INFINITY; row_ub[nrow] = ub;
+            row_ref[nrow++] = j;
+          }
+          if (lb > -INFINITY) {
+            HILO_REQUIRE(nrow < OCP_MAXNC, "too many constraint rows");
+            row_expr[nrow] = j; row_sign[nrow] = -1; row_e[nrow] = j; row_lb[nrow] = -INFINITY; row_ub[nrow] = -lb;
+            row_ref[nrow++] = d->n_con + j;
+          }
+        } else if (lb > -INFINITY || ub < INFINITY) {
+          HILO_REQUIRE(nrow < OCP_MAXNC, "too many constraint rows");
+          row_expr[nrow] = j; row_sign[nrow] = 1; row_e[nrow] = -1; row_lb[nrow] = lb; row_ub[nrow] = ub;
+          row_ref[nrow++] = j;
+        }
+      }
+    }
+    gv = nmpc_gen_find(d->model_id, nth, ne, nrow, d->N);
+    if (!gv)
+      return fail(HILO_ENOTSUP, "no device instantiation for model %d with %d path variable(s), %d shared slack(s) and %d "
+                                "inequality row(s) per stage at horizon %d in this build", d->model_id, nth, ne, nrow, d->N);
+    lds = gv->lds_bytes(d->N);
+  }
   if (lds > 160 * 1024)
     return fail(HILO_ENOTSUP, "horizon %d needs %zu B of LDS per instance (limit 163840)", d->N, lds);
-  const int nz = nx + nu;
+  // engine dimensions: [model x | theta | e], [model u | u_theta]
+  const int nxe = gv ? gv->nx : nx, nue = gv ? gv->nu : nu, nxv = gv ? gv->nxv : nx;
+  const int nz = nxe + nue;
   hilo_nmpc* h = new hilo_nmpc();
   memset(h, 0, sizeof(*h));
   h->device = device; h->model_id = d->model_id; h->nx = nx; h->nu = nu; h->np = np; h->N = d->N;
-  h->n_v = (d->N + 1) * nx + d->N * nu;  // mpc.py:1440
-  h->n_g = d->N * nx;                    // mpc.py:1667-1669
+  h->gen = gv; h->nu_out = nu;
+  h->n_v = (d->N + 1) * nxv + d->N * nue + ne;   // mpc.py:1440 (+ the soft-constraint slack, :1529-1537)
+  h->n_g = d->N * (nxv + n_con_ref);             // mpc.py:1667-1669, :1707-1725
   h->lds_bytes = lds;
   OcpConst& c = h->host;
   memset(&c, 0, sizeof(c));
@@ -209,8 +264,13 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   double sx[OCP_MAXNX], su[OCP_MAXNU];
   copy_or(sx, d->x_scaling, nx, 1.0);
   copy_or(su, d->u_scaling, nu, 1.0);
-  for (int i = 0; i < nz; ++i) c.sz[i] = i < nx ? sx[i] : su[i - nx];
-  {
+  for (int i = 0; i < nz; ++i) c.sz[i] = 1.0;   // path variable, shared slack, virtual input: unit scaling (mpc.py:1200-1201)
+  for (int i = 0; i < nx; ++i) c.sz[i] = sx[i];
+  for (int i = 0; i < nu; ++i) c.sz[nxe + i] = su[i];
+  const double relax = d->bound_relax_factor >= 0.0 ? d->bound_relax_factor : 1e-8;
+  auto relaxed_lb = [&](double lb) { return lb > -INFINITY ? lb - relax * fmax(1.0, fabs(lb)) : lb; };
+  auto relaxed_ub = [&](double ub) { return ub < INFINITY ? ub + relax * fmax(1.0, fabs(ub)) : ub; };
+  if (!gv) {
     // cost block layout of NmpcTrack<M>: [Wz | zref | WN | xrefN | Wdu | has_du]
     double* q = c.cost;
     for (int i = 0; i < nz * nz; ++i) *q++ = d->Wz ? d->Wz[i] : 0.0;
@@ -219,17 +279,84 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     for (int i = 0; i < nx; ++i) *q++ = d->xrefN ? d->xrefN[i] : 0.0;
     for (int i = 0; i < nu * nu; ++i) *q++ = d->Wdu ? d->Wdu[i] : 0.0;
     *q++ = d->Wdu ? 1.0 : 0.0;
+  } else {
+    // cost block layout of NmpcGen (hilo_nmpc_gen.h); model z index -> engine z index
+    auto ez = [&](int i) { return i < nx ? i : nxe + (i - nx); };
+    const int mz = nx + nu;
+    for (int i = 0; i < mz; ++i) {
+      for (int j = 0; j < mz; ++j) c.cost[gv->o_wz + ez(i) * nz + ez(j)] = d->Wz ? d->Wz[i * mz + j] : 0.0;
+      c.cost[gv->o_zref + ez(i)] = d->zref ? d->zref[i] : 0.0;
+    }
+    for (int i = 0; i < nx; ++i) {
+      for (int j = 0; j < nx; ++j) c.cost[gv->o_wn + i * nxe + j] = d->WN ? d->WN[i * nx + j] : 0.0;
+      c.cost[gv->o_xrefn + i] = d->xrefN ? d->xrefN[i] : 0.0;
+    }
+    for (int i = 0; i < nu * nu; ++i) c.cost[gv->o_wdu + i] = d->Wdu ? d->Wdu[i] : 0.0;
+    c.cost[gv->o_hasdu] = d->Wdu ? 1.0 : 0.0;
+    if (nth && d->has_u_pf_ref) {   // mpc.py:1202-1204
+      const int iu = nxe + nu;
+      c.cost[gv->o_wz + iu * nz + iu] = d->u_pf_weight;
+      c.cost[gv->o_zref + iu] = d->u_pf_ref;
+    }
+    for (int a = 0; a < ne; ++a)    // e^T W e once per stage (mpc.py:1708), W = 1e4 I by default (modeling.py:875)
+      for (int b = 0; b < ne; ++b)
+        c.cost[gv->o_wz + (nx + nth + a) * nz + (nx + nth + b)] = d->con_weight ? d->con_weight[a * ne + b] : (a == b ? 1e4 : 0.0);
+    int rcode = HILO_OK;
+    const char* why = "";
+    int plen = 0;
+    if (nth) {
+      if (d->n_path_stage < 0 || d->n_path_stage > GEN_NPT || d->n_path_term < 0 || d->n_path_term > GEN_NPT)
+        rcode = fail(HILO_EINVAL, "hilo_nmpc_create: at most %d path terms per cost", GEN_NPT);
+      else if ((d->n_path_stage + d->n_path_term > 0) && (!d->path_prog || d->path_prog_len <= 0))
+        rcode = fail(HILO_EINVAL, "hilo_nmpc_create: path terms without reference programs");
+      else if (d->n_path_stage + d->n_path_term > 0 &&
+               expr_check(d->path_prog, d->path_prog_len, d->n_path_stage + d->n_path_term, nxv, 1, np, &why))
+        rcode = fail(HILO_EINVAL, "hilo_nmpc_create: path reference program: %s", why);
+      if (!rcode) {
+        c.cost[gv->o_nps] = d->n_path_stage; c.cost[gv->o_npt] = d->n_path_term;
+        for (int a = 0; a < d->n_path_stage; ++a) {
+          c.cost[gv->o_idxs + a] = d->path_stage_idx[a];
+          if (d->path_stage_idx[a] < 0 || d->path_stage_idx[a] >= nx) rcode = fail(HILO_EINVAL, "path term on state %d", d->path_stage_idx[a]);
+          for (int b = 0; b < d->n_path_stage; ++b) c.cost[gv->o_ws + a * GEN_NPT + b] = d->path_stage_W[a * d->n_path_stage + b];
+        }
+        for (int a = 0; a < d->n_path_term; ++a) {
+          c.cost[gv->o_idxt + a] = d->path_term_idx[a];
+          if (d->path_term_idx[a] < 0 || d->path_term_idx[a] >= nx) rcode = fail(HILO_EINVAL, "path term on state %d", d->path_term_idx[a]);
+          for (int b = 0; b < d->n_path_term; ++b) c.cost[gv->o_wt + a * GEN_NPT + b] = d->path_term_W[a * d->n_path_term + b];
+        }
+        plen = d->n_path_stage + d->n_path_term > 0 ? d->path_prog_len : 0;
+      }
+    }
+    if (!rcode && d->n_con > 0 && expr_check(d->con_prog, d->con_prog_len, d->n_con, nx, nu, np, &why))
+      rcode = fail(HILO_EINVAL, "hilo_nmpc_create: constraint program: %s", why);
+    if (!rcode && gv->o_prog + plen + (d->n_con > 0 ? d->con_prog_len : 0) > OCP_NCOST)
+      rcode = fail(HILO_ENOTSUP, "expression programs too long (%d doubles available)", OCP_NCOST - gv->o_prog);
+    if (rcode) { delete h; return rcode; }
+    for (int i = 0; i < plen; ++i) c.cost[gv->o_prog + i] = d->path_prog[i];
+    if (d->n_con > 0)
+      for (int i = 0; i < d->con_prog_len; ++i) c.cost[gv->o_prog + plen + i] = d->con_prog[i];
+    c.cost[gv->o_nexpr] = d->n_con;
+    c.nc = nrow;
+    c.n_con_ref = n_con_ref;
+    for (int m = 0; m < OCP_MAXNC; ++m) { c.dlb[m] = -INFINITY; c.dub[m] = INFINITY; }
+    for (int m = 0; m < nrow; ++m) {
+      c.cost[gv->o_rowx + m] = row_expr[m]; c.cost[gv->o_rows + m] = row_sign[m]; c.cost[gv->o_rowe + m] = row_e[m];
+      c.dlb[m] = relaxed_lb(row_lb[m]); c.dub[m] = relaxed_ub(row_ub[m]);   // IPOPT relaxes constraint bounds alike
+      c.row_ref[m] = row_ref[m];
+    }
+    for (int i = nx; i < nxe; ++i) c.x0_free_mask |= 1u << i;               // theta_0 and e are variables (mpc.py:785-789)
+    for (int a = 0; a < ne; ++a) c.k0_only_mask |= 1u << (nx + nth + a);    // one box on the shared slack
   }
-  const double relax = d->bound_relax_factor >= 0.0 ? d->bound_relax_factor : 1e-8;
   for (int i = 0; i < nz; ++i) {
     // bounds arrive in original units; scaled like mpc.py:253-259, then relaxed like IPOPT's bound_relax_factor
-    const double* lbs = i < nx ? d->x_lb : d->u_lb;
-    const double* ubs = i < nx ? d->x_ub : d->u_ub;
-    const int j = i < nx ? i : i - nx;
-    double lb = lbs ? lbs[j] / c.sz[i] : -INFINITY, ub = ubs ? ubs[j] / c.sz[i] : INFINITY;
-    if (lb > -INFINITY) lb -= relax * fmax(1.0, fabs(lb));
-    if (ub < INFINITY) ub += relax * fmax(1.0, fabs(ub));
-    HILO_REQUIRE(lb < ub, "hilo_nmpc_create: empty box for variable %d", i);
+    double lb = -INFINITY, ub = INFINITY;
+    if (i < nx) { if (d->x_lb) lb = d->x_lb[i] / c.sz[i]; if (d->x_ub) ub = d->x_ub[i] / c.sz[i]; }
+    else if (i < nx + nth) { lb = d->theta_lb; ub = d->theta_ub; }                                  // mpc.py:1198-1199
+    else if (i < nxe) { lb = 0.0; ub = d->con_max_violation ? d->con_max_violation[i - nx - nth] : INFINITY; }  // :1533-1534
+    else if (i < nxe + nu) { const int j = i - nxe; if (d->u_lb) lb = d->u_lb[j] / c.sz[i]; if (d->u_ub) ub = d->u_ub[j] / c.sz[i]; }
+    else { lb = d->u_pf_lb; ub = d->u_pf_ub; }                                                      // mpc.py:1196-1197
+    lb = relaxed_lb(lb); ub = relaxed_ub(ub);
+    if (!(lb < ub)) { delete h; return fail(HILO_EINVAL, "hilo_nmpc_create: empty box for variable %d", i); }
     c.lbz[i] = lb; c.ubz[i] = ub;
   }
   if (d->tol > 0) c.tol = d->tol;
@@ -255,10 +382,15 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   if (e == hipSuccess) {
     // mpc.py:1468-1482: the guess is tiled over the horizon (scaled, mpc.py:255,259)
     double* g = new double[h->n_v];
-    for (int k = 0; k <= d->N; ++k)
-      for (int i = 0; i < nx; ++i) g[k * nx + i] = (d->x_guess ? d->x_guess[i] : 0.0) / sx[i];
-    for (int k = 0; k < d->N; ++k)
-      for (int i = 0; i < nu; ++i) g[(d->N + 1) * nx + k * nu + i] = (d->u_guess ? d->u_guess[i] : 0.0) / su[i];
+    for (int i = 0; i < h->n_v; ++i) g[i] = 0.0;   // shared slack starts at 0 (mpc.py:1535)
+    for (int k = 0; k <= d->N; ++k) {
+      for (int i = 0; i < nx; ++i) g[k * nxv + i] = (d->x_guess ? d->x_guess[i] : 0.0) / sx[i];
+      if (nth) g[k * nxv + nx] = d->theta_guess;                                              // mpc.py:1194
+    }
+    for (int k = 0; k < d->N; ++k) {
+      for (int i = 0; i < nu; ++i) g[(d->N + 1) * nxv + k * nue + i] = (d->u_guess ? d->u_guess[i] : 0.0) / su[i];
+      if (nth) g[(d->N + 1) * nxv + k * nue + nu] = d->u_pf_lb + 0.0001;                      // mpc.py:1195
+    }
     e = hipMemcpy(h->v_guess, g, sizeof(double) * h->n_v, hipMemcpyHostToDevice);
     delete[] g;
   }
@@ -345,10 +477,24 @@ extern "C" int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch, const double* x0, co
     else { vstart = h->v_guess; vstride = 0; }
   }
   int rc = HILO_ENOTSUP;
-  switch (h->model_id) {
+  if (h->gen) {
+    const size_t wsb = h->gen->ws_bytes(h->N);
+    if (wsb && h->ws_batch != batch) {
+      if (h->ws) HILO_HIP_CHECK(hipFree(h->ws));
+      h->ws = nullptr;
+      hipError_t e = hipMalloc((void**)&h->ws, wsb * (size_t)batch);
+      if (e != hipSuccess) return fail(HILO_ENOMEM, "iterate workspace (%zu B per instance): %s", wsb, hipGetErrorString(e));
+      h->ws_batch = batch;
+    }
+    GenLaunchArgs a{h->dev, batch, x0, h->par_buf, (int64_t)(h->np + h->nu), vstart, vstride, v_opt, f_opt, lam_g, u0,
+                    status, iters, kkt, h->prof, h->lds_bytes, s, h->ws};
+    rc = h->gen->launch(a);
+  } else {
+    switch (h->model_id) {
 #define X(ID, T) case ID: rc = nmpc_launch<T>(h, batch, x0, h->par_buf, vstart, vstride, v_opt, f_opt, lam_g, u0, status, iters, kkt, s); break;
-    HILO_NMPC_MODELS(X)
+      HILO_NMPC_MODELS(X)
 #undef X
+    }
   }
   if (rc) return rc;
   // keep the solution for the next call (un-shifted, like the reference)

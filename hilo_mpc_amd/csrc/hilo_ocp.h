@@ -24,6 +24,7 @@ namespace hilo {
 
 constexpr int OCP_MAXNX = 8, OCP_MAXNU = 8, OCP_MAXNZ = OCP_MAXNX + OCP_MAXNU;
 constexpr int OCP_FILTER = 16;
+constexpr int OCP_MAXNC = 4;  // nonlinear inequality rows per stage
 #ifndef HILO_OCP_TPB
 #define HILO_OCP_TPB 64
 #endif
@@ -44,6 +45,13 @@ struct OcpConst {
       kappa_sigma, gamma_theta, gamma_phi, delta_ls, s_theta, s_phi, eta_phi, theta_min_fact, theta_max_fact,
       delta_w_min, delta_w_0, delta_w_max, kappa_w_minus, kappa_w_plus, kappa_w_plus_bar;
   const double* ext;  // learned-term data of the model in device memory (hilo_models.h GpExt) or NULL
+  // general problems (path following, stage constraints; hilo_nmpc_gen.h)
+  unsigned x0_free_mask;   // bit i: slot i of x_0 is a variable although x_0 is pinned (path variable, shared slack)
+  unsigned k0_only_mask;   // bit i: the box of slot i only applies at stage 0 (shared slack carried as a constant state)
+  int nc, pad_;            // active inequality rows per stage (<= PB::NC)
+  double dlb[OCP_MAXNC], dub[OCP_MAXNC];  // their (relaxed) bounds; +-inf if none
+  int n_con_ref, row_ref[OCP_MAXNC];      // rows per stage in the reference's g and where each active row sits there
+  int pad2_;
 };
 
 inline void ocp_default_options(OcpConst& c) {
@@ -86,42 +94,76 @@ struct Ocp {
   // model with a learned term: lanes that evaluate the dynamics at the same point share its kernel sum (GpExt)
   static constexpr bool COOP = PB::COOP;
   static constexpr int NEXT = COOP ? 12 * OCP_TPB : 0;
+  // nonlinear inequality rows per stage (compile-time capacity; pc.nc of them are active): IPOPT's slack form
+  //   d(x_k,u_k) - s_k = 0,  dlb <= s_k <= dub,  multipliers nu (equality), vL/vU (slack bounds)
+  static constexpr int NC = PB::NC;
+  static_assert(NC <= OCP_MAXNC, "too many constraint rows");
+  // reference decision-vector layout [x (NXV per stage) | u | shared tail (NX - NXV)]; x_0 measurement width; inputs returned
+  static constexpr int NXV = PB::NXV, NX0 = PB::NX0, NU0 = PB::NU0;
   static_assert(!COOP || (OCP_TPB == 64 && NDIR <= 64), "cooperative models need one wave per instance");
   static constexpr int NCONST = (sizeof(OcpConst) + 7) / 8;
 
+  // Storage of the iterate: LDS (default) or, for problems that do not fit (long horizons, wide stages), a per-instance
+  // workspace in global memory (PB::BIG; L2-resident, same code path, longer latencies).  Problem constants, the pivot
+  // block, reduction scratch and the per-instance data always stay in LDS.
+  static constexpr bool BIG = PB::BIG;
+  using dp = std::conditional_t<BIG, double*, lds_double*>;
+  using cdp = std::conditional_t<BIG, const double*, lds_cdouble*>;
   struct Lds {
     const __attribute__((address_space(3))) OcpConst* pc;
-    lds_double *Z, *Zt, *D, *zL, *zU, *dzL, *dzU, *grad, *lam, *lamn, *c, *ct, *AB, *W, *Qd, *P, *pv, *Kg, *kff, *sig,
-        *rb, *Acl, *bcl, *Mm, *mm, *fk, *filt, *red, *par, *sd, *ext;
+    dp Z, Zt, D, zL, zU, dzL, dzU, grad, lam, lamn, c, ct, AB, W, Qd, P, pv, Kg, kff, sig, rb, Acl, bcl;
+    dp cs, cst, cnu, cnun, cvL, cvU, cdvL, cdvU, cds, cd, csig, crb, Jd;  // [N][NC] (Jd: [N][NC][NZ])
+    lds_double *Mm, *mm, *fk, *filt, *red, *par, *sd, *ext;
   };
-  __host__ __device__ static size_t lds_doubles(int N) {
+  __host__ __device__ static size_t iter_doubles(int N) {  // the iterate (LDS or workspace)
     const size_t S = (size_t)(N + 1) * NZ;
-    return NCONST + 10 * S + 4 * (size_t)N * NX + (size_t)N * NX * NZ + (size_t)N * NZ * NZ + (size_t)(N + 1) * NDIR +
+    return 10 * S + 4 * (size_t)N * NX + (size_t)N * NX * NZ + (size_t)N * NZ * NZ + (size_t)(N + 1) * NDIR +
            (size_t)(N + 1) * NX * NX + (size_t)(N + 1) * NX + (size_t)N * NU * NX + (size_t)N * NU + (size_t)N * NX * NX +
-           (size_t)N * NX + NZ * NZ + NZ + (N + 1) + 2 * OCP_FILTER + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1 + NEXT;
+           (size_t)N * NX + (size_t)N * NC * (12 + NZ);
   }
-  __device__ static Lds carve(lds_double* base, int N) {
+  __host__ __device__ static size_t fixed_doubles(int N) {  // always LDS
+    return NCONST + NZ * NZ + NZ + (N + 1) + 2 * OCP_FILTER + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1 + NEXT;
+  }
+  __host__ __device__ static size_t lds_doubles(int N) { return fixed_doubles(N) + (BIG ? 0 : iter_doubles(N)); }
+  __host__ __device__ static size_t ws_doubles(int N) { return BIG ? iter_doubles(N) : 0; }
+  __device__ static Lds carve(lds_double* base, double* ws, int N) {
     Lds l;
     const size_t S = (size_t)(N + 1) * NZ;
     lds_double* q = base;
     auto take = [&](size_t n) { lds_double* r = q; q += n; return r; };
     l.pc = reinterpret_cast<const __attribute__((address_space(3))) OcpConst*>(take(NCONST));
-    l.Z = take(S); l.Zt = take(S); l.D = take(S); l.zL = take(S); l.zU = take(S); l.dzL = take(S); l.dzU = take(S);
-    l.grad = take(S);
-    l.lam = take((size_t)N * NX); l.lamn = take((size_t)N * NX); l.c = take((size_t)N * NX); l.ct = take((size_t)N * NX);
-    l.AB = take((size_t)N * NX * NZ); l.W = take((size_t)N * NZ * NZ); l.Qd = take((size_t)(N + 1) * NDIR);
-    l.P = take((size_t)(N + 1) * NX * NX); l.pv = take((size_t)(N + 1) * NX);
-    l.Kg = take((size_t)N * NU * NX); l.kff = take((size_t)N * NU);
-    l.sig = take(S); l.rb = take(S); l.Acl = take((size_t)N * NX * NX); l.bcl = take((size_t)N * NX);
     l.Mm = take(NZ * NZ); l.mm = take(NZ);
     l.fk = take(N + 1); l.filt = take(2 * OCP_FILTER); l.red = take(16); l.par = take(NPAR);
     l.sd = take((size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1);
     l.ext = take(NEXT);
+    dp w;
+    if constexpr (BIG) w = ws; else w = q;
+    auto big = [&](size_t n) { dp r = w; w += n; return r; };
+    l.Z = big(S); l.Zt = big(S); l.D = big(S); l.zL = big(S); l.zU = big(S); l.dzL = big(S); l.dzU = big(S);
+    l.grad = big(S);
+    l.lam = big((size_t)N * NX); l.lamn = big((size_t)N * NX); l.c = big((size_t)N * NX); l.ct = big((size_t)N * NX);
+    l.AB = big((size_t)N * NX * NZ); l.W = big((size_t)N * NZ * NZ); l.Qd = big((size_t)(N + 1) * NDIR);
+    l.P = big((size_t)(N + 1) * NX * NX); l.pv = big((size_t)(N + 1) * NX);
+    l.Kg = big((size_t)N * NU * NX); l.kff = big((size_t)N * NU);
+    l.sig = big(S); l.rb = big(S); l.Acl = big((size_t)N * NX * NX); l.bcl = big((size_t)N * NX);
+    const size_t R = (size_t)N * NC;
+    l.cs = big(R); l.cst = big(R); l.cnu = big(R); l.cnun = big(R); l.cvL = big(R); l.cvU = big(R);
+    l.cdvL = big(R); l.cdvU = big(R); l.cds = big(R); l.cd = big(R); l.csig = big(R); l.crb = big(R);
+    l.Jd = big(R * NZ);
     return l;
   }
 
   // a slot (k, i) of the stage-major primal layout is a variable unless it is a pinned x_0 or the unused u_N
-  __device__ static bool is_free(int N, int k, int i) { return !((FIX_X0 && k == 0 && i < NX) || (k == N && i >= NX)); }
+  __device__ static bool x0_pinned(const OcpConst& pc, int i) { return FIX_X0 && i < NX && !((pc.x0_free_mask >> i) & 1u); }
+  __device__ static bool is_free(const OcpConst& pc, int k, int i) {
+    return !((k == 0 && x0_pinned(pc, i)) || (k == pc.N && i >= NX));
+  }
+  __device__ static double lb_of(const OcpConst& pc, int k, int i) {
+    return (k > 0 && ((pc.k0_only_mask >> i) & 1u)) ? -INFINITY : pc.lbz[i];
+  }
+  __device__ static double ub_of(const OcpConst& pc, int k, int i) {
+    return (k > 0 && ((pc.k0_only_mask >> i) & 1u)) ? INFINITY : pc.ubz[i];
+  }
 
   __device__ static void pair_of(int d, int n, int& i, int& j) {  // d >= n -> (i < j) among n slots
     int r = d - n;
@@ -134,7 +176,9 @@ struct Ocp {
   __device__ static const double* sd_of(const Lds l, int k) { return (const double*)(l.sd + (NSD > 0 ? k * NSD : 0)); }
 
   // ---- values only at a point Zp: defects cp_k = x_{k+1} - F_k(x_k,u_k), returns (f, theta = |c|_1) -------------
-  __device__ __attribute__((noinline)) static void eval_values(const Lds l, lds_cdouble* Zp, lds_double* cp, double& f, double& theta) {
+  // with inequality rows: theta also counts |d_k - sp_k| for the slacks sp; `dstore` (optional) receives d_k
+  __device__ __attribute__((noinline)) static void eval_values(const Lds l, cdp Zp, dp cp, double& f, double& theta,
+                                                               cdp sp = nullptr, dp dstore = nullptr) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double fpart = 0.0, tpart = 0.0;
@@ -189,6 +233,17 @@ struct Ocp {
           cp[k * NX + i] = ci;
           tpart += fabs(ci);
         }
+        if constexpr (NC > 0) {
+          double dv[NC];
+          PB::con(pc, (const double*)l.par, sd_of(l, k), k, x, u, dv);
+#pragma unroll
+          for (int m = 0; m < NC; ++m) {
+            if (m < pc.nc) {
+              if (dstore) dstore[k * NC + m] = dv[m];
+              if (sp) tpart += fabs(dv[m] - sp[k * NC + m]);
+            }
+          }
+        }
       } else {
         fpart += PB::term_cost(pc, (const double*)l.par, sd_of(l, N), x);
       }
@@ -198,15 +253,23 @@ struct Ocp {
   }
 
   // -mu * sum log(slacks)
-  __device__ static double eval_barrier(const Lds l, lds_cdouble* Zp, double mu) {
+  __device__ static double eval_barrier(const Lds l, cdp Zp, double mu, cdp sp = nullptr) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double part = 0.0;
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
       const int k = e / NZ, i = e - k * NZ;
-      if (!is_free(N, k, i)) continue;
-      if (pc.lbz[i] > -INFINITY) part -= log(Zp[e] - pc.lbz[i]);
-      if (pc.ubz[i] < INFINITY) part -= log(pc.ubz[i] - Zp[e]);
+      if (!is_free(pc, k, i)) continue;
+      if (lb_of(pc, k, i) > -INFINITY) part -= log(Zp[e] - lb_of(pc, k, i));
+      if (ub_of(pc, k, i) < INFINITY) part -= log(ub_of(pc, k, i) - Zp[e]);
+    }
+    if constexpr (NC > 0) {
+      for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
+        const int m = e % NC;
+        if (m >= pc.nc) continue;
+        if (pc.dlb[m] > -INFINITY) part -= log(sp[e] - pc.dlb[m]);
+        if (pc.dub[m] < INFINITY) part -= log(pc.dub[m] - sp[e]);
+      }
     }
     return mu * block_reduce<OpSum>(part, l.red);
   }
@@ -235,13 +298,17 @@ struct Ocp {
         }
         int di = d, dj = -1;
         if (d >= NZ) pair_of(d, NZ, di, dj);
-        const bool dead = FIX_X0 && k == 0 && di < NX;  // direction touches the pinned x_0
+        const bool dead = k == 0 && (x0_pinned(pc, di) || (dj >= 0 && x0_pinned(pc, dj)));  // touches the pinned x_0
         if (dead && active) {
           l.Qd[task] = 0.0;
           if (d < NZ) {
             l.grad[d] = 0.0;
 #pragma unroll
             for (int m = 0; m < NX; ++m) l.AB[m * NZ + d] = 0.0;
+            if constexpr (NC > 0) {
+#pragma unroll
+              for (int m = 0; m < NC; ++m) l.Jd[m * NZ + d] = 0.0;
+            }
           }
           if (d != 0 && !COOP) continue;
         }
@@ -271,6 +338,18 @@ struct Ocp {
         if constexpr (!PB::QUAD_COST) {
           if (d == 0) l.fk[k] = lc.v;
         }
+        if constexpr (NC > 0) {  // inequality rows: value, Jacobian column, nu-weighted second-order term
+          Jet2 dv[NC];
+          PB::con(pc, (const double*)l.par, sd_of(l, k), k, x, u, dv);
+#pragma unroll
+          for (int m = 0; m < NC; ++m) {
+            if (m < pc.nc) {
+              if (d == 0) l.cd[k * NC + m] = dv[m].v;
+              if (d < NZ && !dead) l.Jd[(k * NC + m) * NZ + d] = dv[m].a;
+              q += l.cnu[k * NC + m] * dv[m].b;
+            }
+          }
+        }
         if (!dead) {
           l.Qd[task] = q;
           if constexpr (!PB::QUAD_COST) {
@@ -294,7 +373,7 @@ struct Ocp {
     // Hessian blocks by polarisation: H_ii = q(e_i), H_ij = (q(e_i+e_j) - q(e_i) - q(e_j)) / 2
     for (int e = threadIdx.x; e < N * NZ * NZ; e += blockDim.x) {
       const int k = e / (NZ * NZ), r = e - k * NZ * NZ, i = r / NZ, j = r - i * NZ;
-      lds_cdouble* Q = l.Qd + k * NDIR;
+      cdp Q = l.Qd + k * NDIR;
       double h;
       if (i == j) h = Q[i];
       else {
@@ -302,12 +381,13 @@ struct Ocp {
         h = 0.5 * (Q[dir_of(a, b, NZ)] - Q[a] - Q[b]);
       }
       if constexpr (PB::QUAD_COST) h += PB::cost_hess(pc, k, i, j);
+      if (k == 0 && (x0_pinned(pc, i) || x0_pinned(pc, j))) h = 0.0;
       l.W[e] = h;
     }
     if constexpr (PB::QUAD_COST) {
       for (int e = threadIdx.x; e < N * NZ; e += blockDim.x) {
         const int k = e / NZ, i = e - k * NZ;
-        if (is_free(N, k, i)) l.grad[e] = PB::cost_grad(pc, (const double*)l.par, k, i, (const double*)(l.Z + k * NZ));
+        if (is_free(pc, k, i)) l.grad[e] = PB::cost_grad(pc, (const double*)l.par, k, i, (const double*)(l.Z + k * NZ));
       }
       for (int k = threadIdx.x; k < N; k += blockDim.x) {
         double x[NX], u[NU > 0 ? NU : 1];
@@ -335,6 +415,10 @@ struct Ocp {
     if (k < N) {
 #pragma unroll
       for (int m = 0; m < NX; ++m) r -= l.AB[(k * NX + m) * NZ + i] * l.lam[k * NX + m];
+      if constexpr (NC > 0) {
+#pragma unroll
+        for (int m = 0; m < NC; ++m) r += l.Jd[(k * NC + m) * NZ + i] * l.cnu[k * NC + m];  // inactive rows hold zeros
+      }
     }
     return r;
   }
@@ -346,21 +430,34 @@ struct Ocp {
     double dmax = 0.0, lsum = 0.0, zsum = 0.0, pmax = 0.0, nb = 0.0;
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
       const int k = e / NZ, i = e - k * NZ;
-      if (!is_free(N, k, i)) continue;
+      if (!is_free(pc, k, i)) continue;
       dmax = fmax(dmax, fabs(dual_res(l, N, e)));
       zsum += fabs(l.zL[e]) + fabs(l.zU[e]);
-      nb += (pc.lbz[i] > -INFINITY ? 1.0 : 0.0) + (pc.ubz[i] < INFINITY ? 1.0 : 0.0);
+      nb += (lb_of(pc, k, i) > -INFINITY ? 1.0 : 0.0) + (ub_of(pc, k, i) < INFINITY ? 1.0 : 0.0);
     }
     for (int e = threadIdx.x; e < N * NX; e += blockDim.x) {
       pmax = fmax(pmax, fabs(l.c[e]));
       lsum += fabs(l.lam[e]);
+    }
+    double ncon = 0.0;
+    if constexpr (NC > 0) {  // slack block: dual residual -nu - vL + vU, primal residual d - s
+      for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
+        const int m = e % NC;
+        if (m >= pc.nc) continue;
+        dmax = fmax(dmax, fabs(-l.cnu[e] - l.cvL[e] + l.cvU[e]));
+        pmax = fmax(pmax, fabs(l.cd[e] - l.cs[e]));
+        lsum += fabs(l.cnu[e]);
+        zsum += fabs(l.cvL[e]) + fabs(l.cvU[e]);
+        nb += (pc.dlb[m] > -INFINITY ? 1.0 : 0.0) + (pc.dub[m] < INFINITY ? 1.0 : 0.0);
+      }
+      ncon = (double)N * pc.nc;
     }
     dmax = block_reduce<OpMax>(dmax, l.red);
     pmax = block_reduce<OpMax>(pmax, l.red);
     lsum = block_reduce<OpSum>(lsum, l.red);
     zsum = block_reduce<OpSum>(zsum, l.red);
     nb = fmax(1.0, block_reduce<OpSum>(nb, l.red));
-    const double s_d = fmax(pc.s_max, (lsum + zsum) / (N * NX + nb)) / pc.s_max;
+    const double s_d = fmax(pc.s_max, (lsum + zsum) / (N * NX + ncon + nb)) / pc.s_max;
     s_c = fmax(pc.s_max, zsum / nb) / pc.s_max;
     dual_s = dmax / s_d;
     prim = pmax;
@@ -372,9 +469,17 @@ struct Ocp {
     double cm = 0.0;
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
       const int k = e / NZ, i = e - k * NZ;
-      if (!is_free(N, k, i)) continue;
-      if (pc.lbz[i] > -INFINITY) cm = fmax(cm, fabs((l.Z[e] - pc.lbz[i]) * l.zL[e] - mu));
-      if (pc.ubz[i] < INFINITY) cm = fmax(cm, fabs((pc.ubz[i] - l.Z[e]) * l.zU[e] - mu));
+      if (!is_free(pc, k, i)) continue;
+      if (lb_of(pc, k, i) > -INFINITY) cm = fmax(cm, fabs((l.Z[e] - lb_of(pc, k, i)) * l.zL[e] - mu));
+      if (ub_of(pc, k, i) < INFINITY) cm = fmax(cm, fabs((ub_of(pc, k, i) - l.Z[e]) * l.zU[e] - mu));
+    }
+    if constexpr (NC > 0) {
+      for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
+        const int m = e % NC;
+        if (m >= pc.nc) continue;
+        if (pc.dlb[m] > -INFINITY) cm = fmax(cm, fabs((l.cs[e] - pc.dlb[m]) * l.cvL[e] - mu));
+        if (pc.dub[m] < INFINITY) cm = fmax(cm, fabs((pc.dub[m] - l.cs[e]) * l.cvU[e] - mu));
+      }
     }
     return block_reduce<OpMax>(cm, l.red);
   }
@@ -387,20 +492,40 @@ struct Ocp {
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
       const int k = e / NZ, i = e - k * NZ;
       double sg = 0.0, r = l.grad[e];
-      if (is_free(N, k, i)) {
-        if (pc.lbz[i] > -INFINITY) {
-          const double is = 1.0 / (l.Z[e] - pc.lbz[i]);
+      if (is_free(pc, k, i)) {
+        if (lb_of(pc, k, i) > -INFINITY) {
+          const double is = 1.0 / (l.Z[e] - lb_of(pc, k, i));
           sg += l.zL[e] * is;
           r -= mu * is;
         }
-        if (pc.ubz[i] < INFINITY) {
-          const double is = 1.0 / (pc.ubz[i] - l.Z[e]);
+        if (ub_of(pc, k, i) < INFINITY) {
+          const double is = 1.0 / (ub_of(pc, k, i) - l.Z[e]);
           sg += l.zU[e] * is;
           r += mu * is;
         }
       }
       l.sig[e] = sg;
       l.rb[e] = r;
+    }
+    if constexpr (NC > 0) {  // slack rows: csig = vL/(s - dL) + vU/(dU - s), crb = -mu/(s - dL) + mu/(dU - s)
+      for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
+        const int m = e % NC;
+        double sg = 0.0, r = 0.0;
+        if (m < pc.nc) {
+          if (pc.dlb[m] > -INFINITY) {
+            const double is = 1.0 / (l.cs[e] - pc.dlb[m]);
+            sg += l.cvL[e] * is;
+            r -= mu * is;
+          }
+          if (pc.dub[m] < INFINITY) {
+            const double is = 1.0 / (pc.dub[m] - l.cs[e]);
+            sg += l.cvU[e] * is;
+            r += mu * is;
+          }
+        }
+        l.csig[e] = sg;
+        l.crb[e] = r;
+      }
     }
     __syncthreads();
   }
@@ -462,7 +587,7 @@ struct Ocp {
         const int i = e / NX, j = e - i * NX;
         double v = 0.0;
         if (!resto) {
-          lds_cdouble* Q = l.Qd + N * NDIR;
+          cdp Q = l.Qd + N * NDIR;
           if (i == j) v = Q[i];
           else {
             const int a = i < j ? i : j, b = i < j ? j : i;
@@ -478,9 +603,9 @@ struct Ocp {
     }
     __syncthreads();
     for (int k = N - 1; k >= 0; --k) {
-      lds_cdouble* Pn = l.P + (k + 1) * NX * NX;
-      lds_cdouble* pn = l.pv + (k + 1) * NX;
-      lds_cdouble* AB = l.AB + k * NX * NZ;
+      cdp Pn = l.P + (k + 1) * NX * NX;
+      cdp pn = l.pv + (k + 1) * NX;
+      cdp AB = l.AB + k * NX * NZ;
       // (1) Mm = H_k + [A B]^T P_{k+1} [A B];  mm = r_k + [A B]^T (p_{k+1} - P_{k+1} c_k).
       // One uniform code path for the NZ x (NZ+1) entries: column NZ is the right-hand side, i.e. the "column" -c_k
       // of [A B | -c] with p_{k+1} added.  All operands are fetched before the arithmetic (one LDS wait).
@@ -498,6 +623,16 @@ struct Ocp {
         }
         double s = resto ? 0.0 : (rhs ? l.rb[k * NZ + i] : l.W[k * NZ * NZ + i * NZ + j]);
         const double dg = (i == j) ? (resto ? 1.0 : delta + l.sig[k * NZ + i]) : 0.0;
+        if constexpr (NC > 0) {  // eliminated slack rows: + Jd^T (Sigma_s + delta) Jd, rhs + Jd^T ((Sigma_s + delta)(d - s) + crb)
+          const int jj = rhs ? 0 : j;
+#pragma unroll
+          for (int m = 0; m < NC; ++m) {
+            const int r = k * NC + m;
+            const double wgt = resto ? 1.0 : l.csig[r] + delta;
+            const double right = rhs ? wgt * (l.cd[r] - l.cs[r]) + (resto ? 0.0 : l.crb[r]) : wgt * l.Jd[r * NZ + jj];
+            s += l.Jd[r * NZ + i] * right;
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < NX; ++m) {
@@ -549,15 +684,22 @@ struct Ocp {
       }
       __syncthreads();
     }
-    // initial state: pinned (dx_0 = 0) or free: dx_0 = -P_0^-1 p_0 (P_0 must be positive definite)
-    if constexpr (FIX_X0) {
+    // initial state: pinned (dx_0 = 0) or (partly) free: dx_0 = -P_0^-1 p_0 on the free slots (P_0 must be positive
+    // definite there); pinned rows / columns of P_0 are replaced by the identity
+    if (FIX_X0 && pc.x0_free_mask == 0u) {
       for (int i = t; i < NX; i += T) l.D[i] = 0.0;
     } else {
+      for (int e = t; e < NX * NX; e += T) {
+        const int i = e / NX, j = e - i * NX;
+        const bool pin = x0_pinned(pc, i) || x0_pinned(pc, j);
+        l.Mm[e] = pin ? (i == j ? 1.0 : 0.0) : l.P[e];
+      }
+      __syncthreads();
       double Lc[NX * NX], invd[NX], y[NX];
-      const bool pd = small_chol<NX>(l.P, NX, Lc, invd);
+      const bool pd = small_chol<NX>(l.Mm, NX, Lc, invd);
       if (!pd) return false;
 #pragma unroll
-      for (int a = 0; a < NX; ++a) y[a] = l.pv[a];
+      for (int a = 0; a < NX; ++a) y[a] = x0_pinned(pc, a) ? 0.0 : l.pv[a];
       small_solve<NX>(Lc, invd, y);
       __syncthreads();
       if (t == 0) {
@@ -568,7 +710,7 @@ struct Ocp {
     // closed-loop matrices for the forward sweep: Acl = A + B K, bcl = B kff - c  (parallel over stages)
     for (int e = t; e < N * (NX * NX + NX); e += T) {
       const int k = e / (NX * NX + NX), r = e - k * (NX * NX + NX);
-      lds_cdouble* AB = l.AB + k * NX * NZ;
+      cdp AB = l.AB + k * NX * NZ;
       if (r < NX * NX) {
         const int i = r / NX, j = r - i * NX;
         double s = AB[i * NZ + j];
@@ -628,6 +770,21 @@ struct Ocp {
     }
     for (int a = t; a < NU; a += T) l.D[N * NZ + NX + a] = 0.0;
     __syncthreads();
+    if constexpr (NC > 0) {  // recover the eliminated slack step and the new multipliers of d - s = 0
+      for (int e = t; e < N * NC; e += T) {
+        const int k = e / NC, m = e - k * NC;
+        double ds = 0.0, nun = 0.0;
+        if (m < pc.nc) {
+          ds = l.cd[e] - l.cs[e];
+#pragma unroll
+          for (int i = 0; i < NZ; ++i) ds += l.Jd[e * NZ + i] * l.D[k * NZ + i];
+          nun = resto ? 0.0 : (l.csig[e] + delta) * ds + l.crb[e];
+        }
+        l.cds[e] = ds;
+        l.cnun[e] = nun;
+      }
+      __syncthreads();
+    }
     return true;
   }
 
@@ -637,34 +794,49 @@ struct Ocp {
     const int N = pc.N, t = threadIdx.x, T = blockDim.x, SL = (N + 1) * NZ;
     double th = 0.0;
     for (int e = t; e < N * NX; e += T) th += fabs(l.c[e]);
+    if constexpr (NC > 0)
+      for (int e = t; e < N * NC; e += T) th += (e % NC) < pc.nc ? fabs(l.cd[e] - l.cs[e]) : 0.0;
     th = block_reduce<OpSum>(th, l.red);
     const double th_start = th;
     for (int it = 0; it < 50; ++it) {
       riccati(l, mu, 0.0, true);
       double a = 1.0;
+      if constexpr (NC > 0) {
+        for (int e = t; e < N * NC; e += T) {
+          const int m = e % NC;
+          if (m >= pc.nc) continue;
+          const double d = l.cds[e];
+          if (pc.dlb[m] > -INFINITY && d < 0.0) a = fmin(a, -tau * (l.cs[e] - pc.dlb[m]) / d);
+          if (pc.dub[m] < INFINITY && d > 0.0) a = fmin(a, tau * (pc.dub[m] - l.cs[e]) / d);
+        }
+      }
       for (int e = t; e < SL; e += T) {
         const int k = e / NZ, i = e - k * NZ;
-        if (!is_free(N, k, i)) continue;
+        if (!is_free(pc, k, i)) continue;
         const double d = l.D[e];
-        if (pc.lbz[i] > -INFINITY && d < 0.0) a = fmin(a, -tau * (l.Z[e] - pc.lbz[i]) / d);
-        if (pc.ubz[i] < INFINITY && d > 0.0) a = fmin(a, tau * (pc.ubz[i] - l.Z[e]) / d);
+        if (lb_of(pc, k, i) > -INFINITY && d < 0.0) a = fmin(a, -tau * (l.Z[e] - lb_of(pc, k, i)) / d);
+        if (ub_of(pc, k, i) < INFINITY && d > 0.0) a = fmin(a, tau * (ub_of(pc, k, i) - l.Z[e]) / d);
       }
       double alpha = block_reduce<OpMin>(a, l.red);
       bool ok = false;
       double tht = 0.0, ft = 0.0;
       while (alpha > 1e-10) {
         for (int e = t; e < SL; e += T) l.Zt[e] = l.Z[e] + alpha * l.D[e];
+        if constexpr (NC > 0)
+          for (int e = t; e < N * NC; e += T) l.cst[e] = l.cs[e] + alpha * l.cds[e];
         __syncthreads();
-        eval_values(l, l.Zt, l.ct, ft, tht);
+        eval_values(l, l.Zt, l.ct, ft, tht, l.cst);
         if (isfinite(tht) && tht <= (1.0 - 1e-4 * alpha) * th) { ok = true; break; }
         alpha *= 0.5;
       }
       if (!ok) return false;
       for (int e = t; e < SL; e += T) l.Z[e] = l.Zt[e];
+      if constexpr (NC > 0)
+        for (int e = t; e < N * NC; e += T) l.cs[e] = l.cst[e];
       __syncthreads();
       th = tht;
       if (th <= 0.9 * th_start && th <= theta_max) {
-        const double ph = ft + eval_barrier(l, l.Z, mu);
+        const double ph = ft + eval_barrier(l, l.Z, mu, l.cs);
         bool acc = true;
         for (int q = 0; q < nfilt; ++q)
           if (th >= l.filt[2 * q] && ph >= l.filt[2 * q + 1]) { acc = false; break; }
@@ -688,16 +860,17 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
                                                        double* __restrict__ f_opt, double* __restrict__ lam_g,
                                                        double* __restrict__ first, int first_kind,
                                                        int32_t* __restrict__ status, int32_t* __restrict__ iters,
-                                                       double* __restrict__ kkt, long long* __restrict__ prof) {
+                                                       double* __restrict__ kkt, long long* __restrict__ prof,
+                                                       double* __restrict__ ws = nullptr) {
   using S = Ocp<PB>;
-  constexpr int NX = S::NX, NU = S::NU, NZ = S::NZ;
+  constexpr int NX = S::NX, NU = S::NU, NZ = S::NZ, NC = S::NC, NXV = S::NXV, NTAIL = NX - NXV;
   extern __shared__ double lds_raw_generic[];
   lds_double* lds_raw = (lds_double*)lds_raw_generic;
   const int t = threadIdx.x, T = blockDim.x;
   const int64_t b = blockIdx.x;
   if (b >= batch) return;
   const int N = pcg->N;
-  typename S::Lds l = S::carve(lds_raw, N);
+  typename S::Lds l = S::carve(lds_raw, ws ? ws + b * (int64_t)S::ws_doubles(N) : nullptr, N);
   {  // problem constants into LDS: every later access is an LDS read instead of a global load
     const double* src = reinterpret_cast<const double*>(pcg);
     lds_double* dst = lds_raw;
@@ -718,10 +891,12 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
   for (int e = t; e < SL; e += T) {
     const int k = e / NZ, i = e - k * NZ;
     double v;
-    if (i < NX) v = (S::FIX_X0 && k == 0) ? x0[b * NX + i] / pc.sz[i] : vb[k * NX + i];
-    else v = (k < N) ? vb[(N + 1) * NX + k * NU + (i - NX)] : 0.0;
-    if (S::is_free(N, k, i)) {  // IPOPT start: push into the interior (W&B sec. 3.6)
-      const double lb = pc.lbz[i], ub = pc.ubz[i];
+    // reference layout [x (NXV per stage) | u | shared tail]; the tail is carried as constant states (same value in every stage)
+    if (i < NXV) v = (k == 0 && S::x0_pinned(pc, i)) ? x0[b * S::NX0 + i] / pc.sz[i] : vb[k * NXV + i];
+    else if (i < NX) v = vb[(N + 1) * NXV + N * NU + (i - NXV)];
+    else v = (k < N) ? vb[(N + 1) * NXV + k * NU + (i - NX)] : 0.0;
+    if (S::is_free(pc, k, i)) {  // IPOPT start: push into the interior (W&B sec. 3.6)
+      const double lb = S::lb_of(pc, k, i), ub = S::ub_of(pc, k, i);
       const bool hl = lb > -INFINITY, hu = ub < INFINITY;
       if (hl) {
         double pl = pc.bound_push * fmax(1.0, fabs(lb));
@@ -743,7 +918,40 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     l.D[e] = 0.0;
   }
   for (int e = t; e < N * NX; e += T) l.lam[e] = 0.0;
+  if constexpr (NC > 0) {
+    for (int e = t; e < N * NC; e += T) {
+      l.cs[e] = 0.0; l.cst[e] = 0.0; l.cnu[e] = 0.0; l.cnun[e] = 0.0; l.cvL[e] = 0.0; l.cvU[e] = 0.0; l.cdvL[e] = 0.0;
+      l.cdvU[e] = 0.0; l.cds[e] = 0.0; l.cd[e] = 0.0; l.csig[e] = 0.0; l.crb[e] = 0.0;
+    }
+    for (int e = t; e < N * NC * NZ; e += T) l.Jd[e] = 0.0;
+  }
   __syncthreads();
+  if constexpr (NC > 0) {  // IPOPT: slacks start at d(w_0), pushed into the interior of their bounds
+    double f_, th_;
+    S::eval_values(l, l.Z, l.ct, f_, th_, nullptr, l.cd);
+    __syncthreads();
+    for (int e = t; e < N * NC; e += T) {
+      const int m = e % NC;
+      if (m >= pc.nc) continue;
+      double v = l.cd[e];
+      const double lb = pc.dlb[m], ub = pc.dub[m];
+      const bool hl = lb > -INFINITY, hu = ub < INFINITY;
+      if (hl) {
+        double pl = pc.bound_push * fmax(1.0, fabs(lb));
+        if (hu) pl = fmin(pl, pc.bound_frac * (ub - lb));
+        v = fmax(v, lb + pl);
+      }
+      if (hu) {
+        double pu = pc.bound_push * fmax(1.0, fabs(ub));
+        if (hl) pu = fmin(pu, pc.bound_frac * (ub - lb));
+        v = fmin(v, ub - pu);
+      }
+      l.cs[e] = v;
+      l.cvL[e] = hl ? 1.0 : 0.0;
+      l.cvU[e] = hu ? 1.0 : 0.0;
+    }
+    __syncthreads();
+  }
 
   double mu = pc.mu_init, tau = fmax(pc.tau_min, 1.0 - mu);
   double delta_last = 0.0;
@@ -756,6 +964,8 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     OCP_TICK(PH_DERIV)
     double th0 = 0.0;
     for (int e = t; e < N * NX; e += T) th0 += fabs(l.c[e]);
+    if constexpr (NC > 0)
+      for (int e = t; e < N * NC; e += T) th0 += (e % NC) < pc.nc ? fabs(l.cd[e] - l.cs[e]) : 0.0;
     th0 = block_reduce<OpSum>(th0, l.red);
     if (it == 0) {
       theta_min = pc.theta_min_fact * fmax(1.0, th0);
@@ -802,18 +1012,18 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     for (int e = t; e < SL; e += T) {
       const int k = e / NZ, i = e - k * NZ;
       double dl = 0.0, du = 0.0;
-      if (S::is_free(N, k, i)) {
+      if (S::is_free(pc, k, i)) {
         const double d = l.D[e];
         double gphi = l.grad[e];
-        if (pc.lbz[i] > -INFINITY) {
-          const double s = l.Z[e] - pc.lbz[i];
+        if (S::lb_of(pc, k, i) > -INFINITY) {
+          const double s = l.Z[e] - S::lb_of(pc, k, i);
           dl = mu / s - l.zL[e] - l.zL[e] / s * d;
           if (d < 0.0) a_p = fmin(a_p, -tau * s / d);
           if (dl < 0.0) a_z = fmin(a_z, -tau * l.zL[e] / dl);
           gphi -= mu / s;
         }
-        if (pc.ubz[i] < INFINITY) {
-          const double s = pc.ubz[i] - l.Z[e];
+        if (S::ub_of(pc, k, i) < INFINITY) {
+          const double s = S::ub_of(pc, k, i) - l.Z[e];
           du = mu / s - l.zU[e] + l.zU[e] / s * d;
           if (d > 0.0) a_p = fmin(a_p, tau * s / d);
           if (du < 0.0) a_z = fmin(a_z, -tau * l.zU[e] / du);
@@ -824,21 +1034,47 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       l.dzL[e] = dl;
       l.dzU[e] = du;
     }
+    if constexpr (NC > 0) {
+      for (int e = t; e < N * NC; e += T) {
+        const int m = e % NC;
+        double dl = 0.0, du = 0.0;
+        if (m < pc.nc) {
+          const double d = l.cds[e];
+          if (pc.dlb[m] > -INFINITY) {
+            const double s = l.cs[e] - pc.dlb[m];
+            dl = mu / s - l.cvL[e] - l.cvL[e] / s * d;
+            if (d < 0.0) a_p = fmin(a_p, -tau * s / d);
+            if (dl < 0.0) a_z = fmin(a_z, -tau * l.cvL[e] / dl);
+          }
+          if (pc.dub[m] < INFINITY) {
+            const double s = pc.dub[m] - l.cs[e];
+            du = mu / s - l.cvU[e] + l.cvU[e] / s * d;
+            if (d > 0.0) a_p = fmin(a_p, tau * s / d);
+            if (du < 0.0) a_z = fmin(a_z, -tau * l.cvU[e] / du);
+          }
+          dphi += l.crb[e] * d;
+        }
+        l.cdvL[e] = dl;
+        l.cdvU[e] = du;
+      }
+    }
     a_p = block_reduce<OpMin>(a_p, l.red);
     a_z = block_reduce<OpMin>(a_z, l.red);
     dphi = block_reduce<OpSum>(dphi, l.red);
-    const double phi0 = fval + S::eval_barrier(l, l.Z, mu);
+    const double phi0 = fval + S::eval_barrier(l, l.Z, mu, l.cs);
     OCP_TICK(PH_STEP)
     // ---- filter line search (W&B Alg. A without second-order correction) ----
     double alpha = a_p;
     bool accepted = false, armijo = false;
     for (int ls = 0; ls < 60; ++ls) {
       for (int e = t; e < SL; e += T) l.Zt[e] = l.Z[e] + alpha * l.D[e];
+      if constexpr (NC > 0)
+        for (int e = t; e < N * NC; e += T) l.cst[e] = l.cs[e] + alpha * l.cds[e];
       __syncthreads();
       double ft, tht;
       tprof[PH_NLS] += 1;
-      S::eval_values(l, l.Zt, l.ct, ft, tht);
-      const double pht = ft + S::eval_barrier(l, l.Zt, mu);
+      S::eval_values(l, l.Zt, l.ct, ft, tht, l.cst);
+      const double pht = ft + S::eval_barrier(l, l.Zt, mu, l.cst);
       bool ok = isfinite(pht) && isfinite(tht) && tht <= theta_max;
       if (ok) {
         for (int q = 0; q < nfilt; ++q) {
@@ -887,15 +1123,27 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       // reset to 1 when they exceed bound_mult_reset_threshold = 1000
       double zm = 0.0;
       for (int e = t; e < SL; e += T) zm = fmax(zm, fmax(l.zL[e], l.zU[e]));
+      if constexpr (NC > 0)
+        for (int e = t; e < N * NC; e += T) zm = fmax(zm, fmax(l.cvL[e], l.cvU[e]));
       zm = block_reduce<OpMax>(zm, l.red);
       for (int e = t; e < SL; e += T) {
         const int k = e / NZ, i = e - k * NZ;
-        if (zm > 1e3 && S::is_free(N, k, i)) {
-          l.zL[e] = pc.lbz[i] > -INFINITY ? 1.0 : 0.0;
-          l.zU[e] = pc.ubz[i] < INFINITY ? 1.0 : 0.0;
+        if (zm > 1e3 && S::is_free(pc, k, i)) {
+          l.zL[e] = S::lb_of(pc, k, i) > -INFINITY ? 1.0 : 0.0;
+          l.zU[e] = S::ub_of(pc, k, i) < INFINITY ? 1.0 : 0.0;
         }
       }
       for (int e = t; e < N * NX; e += T) l.lam[e] = 0.0;
+      if constexpr (NC > 0) {
+        for (int e = t; e < N * NC; e += T) {
+          const int m = e % NC;
+          l.cnu[e] = 0.0;
+          if (zm > 1e3 && m < pc.nc) {
+            l.cvL[e] = pc.dlb[m] > -INFINITY ? 1.0 : 0.0;
+            l.cvU[e] = pc.dub[m] < INFINITY ? 1.0 : 0.0;
+          }
+        }
+      }
       __syncthreads();
       continue;
     }
@@ -904,40 +1152,70 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       const int k = e / NZ, i = e - k * NZ;
       const double znew = l.Zt[e];
       l.Z[e] = znew;
-      if (S::is_free(N, k, i)) {
-        if (pc.lbz[i] > -INFINITY) {
-          const double s = znew - pc.lbz[i];
+      if (S::is_free(pc, k, i)) {
+        if (S::lb_of(pc, k, i) > -INFINITY) {
+          const double s = znew - S::lb_of(pc, k, i);
           l.zL[e] = fmin(fmax(l.zL[e] + a_z * l.dzL[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
         }
-        if (pc.ubz[i] < INFINITY) {
-          const double s = pc.ubz[i] - znew;
+        if (S::ub_of(pc, k, i) < INFINITY) {
+          const double s = S::ub_of(pc, k, i) - znew;
           l.zU[e] = fmin(fmax(l.zU[e] + a_z * l.dzU[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
         }
       }
     }
     for (int e = t; e < N * NX; e += T) l.lam[e] += alpha * (l.lamn[e] - l.lam[e]);
+    if constexpr (NC > 0) {
+      for (int e = t; e < N * NC; e += T) {
+        const int m = e % NC;
+        if (m >= pc.nc) continue;
+        const double snew = l.cst[e];
+        l.cs[e] = snew;
+        l.cnu[e] += alpha * (l.cnun[e] - l.cnu[e]);
+        if (pc.dlb[m] > -INFINITY) {
+          const double s = snew - pc.dlb[m];
+          l.cvL[e] = fmin(fmax(l.cvL[e] + a_z * l.cdvL[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
+        }
+        if (pc.dub[m] < INFINITY) {
+          const double s = pc.dub[m] - snew;
+          l.cvU[e] = fmin(fmax(l.cvU[e] + a_z * l.cdvU[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
+        }
+      }
+    }
     __syncthreads();
     OCP_TICK(PH_UPDATE)
   }
 
   // ---- write back ([x-block | u-block] after the prefix) ----
-  double* vo = v_opt + b * (int64_t)(v_prefix + (N + 1) * NX + N * NU) + v_prefix;
+  double* vo = v_opt + b * (int64_t)(v_prefix + (N + 1) * NXV + N * NU + NTAIL) + v_prefix;
   for (int e = t; e < SL; e += T) {
     const int k = e / NZ, i = e - k * NZ;
-    if (i < NX) vo[k * NX + i] = l.Z[e];
-    else if (k < N) vo[(N + 1) * NX + k * NU + (i - NX)] = l.Z[e];
+    if (i < NXV) vo[k * NXV + i] = l.Z[e];
+    else if (i < NX) { if (k == 0) vo[(N + 1) * NXV + N * NU + (i - NXV)] = l.Z[e]; }
+    else if (k < N) vo[(N + 1) * NXV + k * NU + (i - NX)] = l.Z[e];
   }
   if (lam_g) {
-    for (int e = t; e < N * NX; e += T) {
-      double v = l.lam[e];
+    // the reference's g: per stage [shooting defect (NXV rows) | constraint rows (n_con_ref)] (mpc.py:1667, :1707-1725)
+    const int ncr = NC > 0 ? pc.n_con_ref : 0, rows = NXV + ncr;
+    double* lg = lam_g + b * (int64_t)(N * rows);
+    for (int e = t; e < N * NXV; e += T) {
+      const int k = e / NXV, i = e - k * NXV;
+      double v = l.lam[k * NX + i];
       // terminal cost on F_{N-1} in the reference (mpc.py:1682) vs on x_N here: multipliers of the last defect
       // differ by grad V(x_N) (flag bit 0)
-      if ((pc.flags & 1) && e >= (N - 1) * NX) v += l.grad[N * NZ + (e - (N - 1) * NX)];
-      lam_g[b * (int64_t)(N * NX) + e] = v;
+      if ((pc.flags & 1) && k == N - 1) v += l.grad[N * NZ + i];
+      lg[k * rows + i] = v;
+    }
+    if constexpr (NC > 0) {
+      for (int e = t; e < N * ncr; e += T) lg[(e / ncr) * rows + NXV + e % ncr] = 0.0;  // dropped (unbounded) rows
+      __syncthreads();
+      for (int e = t; e < N * NC; e += T) {
+        const int k = e / NC, m = e - k * NC;
+        if (m < pc.nc) lg[k * rows + NXV + pc.row_ref[m]] = l.cnu[e];
+      }
     }
   }
   if (first) {
-    if (first_kind == 0) { for (int a = t; a < NU; a += T) first[b * NU + a] = l.Z[NX + a] * pc.sz[NX + a]; }
+    if (first_kind == 0) { for (int a = t; a < S::NU0; a += T) first[b * S::NU0 + a] = l.Z[NX + a] * pc.sz[NX + a]; }
     else { for (int a = t; a < NX; a += T) first[b * NX + a] = l.Z[N * NZ + a] * pc.sz[a]; }
   }
   if (t == 0) {

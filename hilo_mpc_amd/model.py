@@ -8,6 +8,8 @@ import copy
 
 import numpy as np
 
+from .expr import SymVector
+
 
 # name -> (model id, is_linear, state names, input names, parameter names, measurement names)
 ZOO = {
@@ -17,6 +19,7 @@ ZOO = {
                     ['y_0', 'y_1']),
     'chemostat4': (3, False, ['X', 'S', 'P', 'I'], ['DS', 'DI'], ['Sf', 'If', 'ISF', 'IRF'], ['yX', 'yP']),
     'pendulum4': (4, False, ['x', 'v', 'theta', 'omega'], ['F'], [], ['yx', 'yv', 'ytheta', 'tomega']),
+    'robot6': (5, False, ['px', 'vx', 'py', 'vy', 'psi', 'omega'], ['a', 'alpha'], [], ['ypx', 'ypy']),
     'linear2': (7, True, ['x_1', 'x_2'], ['u'], ['k_1', 'k_2'], ['y']),
     'chemostat4_gp': (8, False, ['X', 'S', 'P', 'I'], ['DS', 'DI'], ['Sf', 'If', 'ISF', 'IRF'], ['yX', 'yP']),
 }
@@ -65,6 +68,11 @@ class Model:
         self.learned = None         # trained GaussianProcess substituted into the right-hand side
 
     # -- reference-like surface ---------------------------------------------------------------
+    # symbols for expressions (the reference's `model.x`, `model.u`, `model.p` SX vectors)
+    x = property(lambda s: SymVector('x', s.dynamical_state_names))
+    u = property(lambda s: SymVector('u', s.input_names))
+    p = property(lambda s: SymVector('p', s.parameter_names))
+
     @property
     def discrete(self):
         return self._native_discrete or self.erk_order > 0

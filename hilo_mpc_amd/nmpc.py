@@ -19,6 +19,7 @@ import torch
 
 from . import _lib
 from ._device import device, to_dev, ptr, stream_ptr
+from .expr import Expr, compile_block
 
 STATUS_TEXT = {1: 'solve_succeeded', 2: 'solved_to_acceptable_level', 3: 'infeasible_problem_detected',
                4: 'restoration_failed', 5: 'maximum_iterations_exceeded', -1: 'other'}
@@ -60,13 +61,29 @@ class QuadraticCost:
     def __init__(self, model):
         self._model = model
         self._terms = []          # (type, indices, W, ref)
+        self._paths = []          # (state indices, W, [expression of theta])
         self._is_set = False
 
     def _add(self, kind, names, pool, weights, ref, path_following, trajectory_tracking):
-        if path_following or trajectory_tracking:
-            raise NotImplementedError("path following / trajectory tracking references are not yet offloaded "
-                                      "(SURVEY.md 8f); use constant references")
+        if trajectory_tracking:
+            raise NotImplementedError("trajectory tracking references are not yet offloaded (SURVEY.md 8f); use "
+                                      "constant or path references")
         names = [names] if isinstance(names, str) else list(names)
+        if path_following:
+            # modeling.py:252-261: the reference is an expression of the path variable, substituted into the cost
+            if kind != 'states':
+                raise NotImplementedError("path references are offloaded for states")
+            ref = [ref] if isinstance(ref, Expr) else list(ref or [])
+            if len(ref) != len(names) or not all(isinstance(r, (Expr, int, float)) for r in ref):
+                raise ValueError("path following needs one expression of the path variable per name")
+            ind = []
+            for n in names:
+                if n not in pool:
+                    raise ValueError(f"The state {n} does not exist. The available states are {pool}")
+                ind.append(pool.index(n))
+            self._paths.append((ind, _weight_matrix(weights, len(names), 'weights'), [Expr.wrap(r) for r in ref]))
+            self._is_set = True
+            return
         ind = []
         for n in names:
             if n not in pool:
@@ -96,6 +113,57 @@ class QuadraticCost:
         raise NotImplementedError("measurement costs are not yet offloaded; add the corresponding states instead")
 
 
+class GenericConstraint:
+    """`util/modeling.py:820-1005`: lb <= constraint(x, u) <= ub per stage; soft: one slack shared by all stages with the
+    penalty e^T weight e per stage (default weight 1e4 I, modeling.py:875)."""
+
+    def __init__(self, model, name='constraint'):
+        self._model, self._name = model, name
+        self._function = None
+        self._lb = self._ub = None
+        self._is_soft = False
+        self._weight = None
+        self._max_violation = None
+        self.e_soft_value = 0
+
+    @property
+    def constraint(self):
+        return self._function
+
+    @constraint.setter
+    def constraint(self, arg):
+        if arg is not None:
+            arg = [arg] if isinstance(arg, Expr) else list(arg)
+            if not all(isinstance(a, Expr) for a in arg):
+                raise TypeError(f"The {self._name} must be an expression of the model symbols (model.x, model.u, "
+                                f"model.p) or None.")
+        self._function = arg
+
+    lb = property(lambda s: s._lb, lambda s, v: setattr(s, '_lb', None if v is None else _wrap_list(v)))
+    ub = property(lambda s: s._ub, lambda s, v: setattr(s, '_ub', None if v is None else _wrap_list(v)))
+    max_violation = property(lambda s: s._max_violation,
+                             lambda s, v: setattr(s, '_max_violation', None if v is None else _wrap_list(v)))
+    weight = property(lambda s: s._weight, lambda s, v: setattr(s, '_weight', v))
+
+    @property
+    def is_soft(self):
+        return self._is_soft
+
+    @is_soft.setter
+    def is_soft(self, arg):
+        if not isinstance(arg, bool):
+            raise TypeError("is_soft must be of type bool")
+        self._is_soft = arg
+
+    @property
+    def size(self):
+        return 0 if self._function is None else len(self._function)
+
+    @property
+    def is_set(self):
+        return self._function is not None
+
+
 class NMPC:
     _solver_name_list_nlp = ['ipopt', 'hip_ipm']
 
@@ -113,6 +181,9 @@ class NMPC:
         self._n_x, self._n_u, self._n_p = model.n_x, model.n_u, model.n_p
         self.quad_stage_cost = QuadraticCost(model)
         self.quad_terminal_cost = QuadraticCost(model)
+        self.stage_constraint = GenericConstraint(model, name='stage constraint')
+        self.terminal_constraint = GenericConstraint(model, name='terminal constraint')
+        self._paths_var_list = []
         self._prediction_horizon = self._control_horizon = None
         self._x_lb = self._x_ub = self._u_lb = self._u_ub = None
         self._x_guess = self._u_guess = None
@@ -165,6 +236,17 @@ class NMPC:
         return self._sampling_interval
 
     n_iterations = property(lambda s: s._n_iterations)
+    n_of_path_vars = property(lambda s: len(s._paths_var_list))
+
+    def create_path_variable(self, name='theta', u_pf_lb=0.0001, u_pf_ub=1, u_pf_ref=None, u_pf_weight=10,
+                             theta_guess=0, theta_lb=0, theta_ub=np.inf):
+        """mpc.py:1025-1053: returns the symbol to build path references with."""
+        if self._paths_var_list:
+            raise NotImplementedError("one path variable per controller is offloaded")
+        self._paths_var_list.append({'name': name, 'u_pf_lb': u_pf_lb, 'u_pf_ub': u_pf_ub, 'u_pf_ref': u_pf_ref,
+                                     'u_pf_weight': u_pf_weight, 'theta_guess': theta_guess, 'theta_lb': theta_lb,
+                                     'theta_ub': theta_ub})
+        return Expr('theta', value=0, name=name)
 
     # ---- problem data ---------------------------------------------------------------------------------------
     def set_box_constraints(self, x_ub=None, x_lb=None, u_ub=None, u_lb=None, y_ub=None, y_lb=None, z_ub=None, z_lb=None):
@@ -302,6 +384,65 @@ class NMPC:
         d.x_guess, d.u_guess = hp(self._x_guess), hp(self._u_guess)
         learned = getattr(m, 'learned', None)
         d.learned = learned._handle if learned is not None else None
+        # ---- path following (mpc.py:1173-1204) ----
+        nth = len(self._paths_var_list)
+        if (self.quad_stage_cost._paths or self.quad_terminal_cost._paths) and not nth:
+            raise ValueError("path references need a path variable: call create_path_variable() first")
+
+        def hi(a):
+            a = np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+            keep.append(a)
+            return a.ctypes.data
+
+        def path_terms(cost):
+            ind, refs = [], []
+            for i, W, r in cost._paths:
+                ind += i
+                refs += r
+            n = len(ind)
+            Wp = np.zeros((n, n))
+            o = 0
+            for i, W, r in cost._paths:
+                Wp[o:o + len(i), o:o + len(i)] = W
+                o += len(i)
+            return ind, Wp, refs
+        if nth:
+            pv = self._paths_var_list[0]
+            d.n_path_var = 1
+            d.theta_guess, d.theta_lb, d.theta_ub = float(pv['theta_guess']), float(pv['theta_lb']), float(pv['theta_ub'])
+            d.u_pf_lb, d.u_pf_ub = float(pv['u_pf_lb']), float(pv['u_pf_ub'])
+            d.has_u_pf_ref = int(pv['u_pf_ref'] is not None)
+            d.u_pf_ref = float(pv['u_pf_ref'] or 0.)
+            d.u_pf_weight = float(pv['u_pf_weight'])
+            si, sW, sr = path_terms(self.quad_stage_cost)
+            ti, tW, tr = path_terms(self.quad_terminal_cost)
+            d.n_path_stage, d.n_path_term = len(si), len(ti)
+            d.path_stage_idx, d.path_stage_W, d.path_term_idx, d.path_term_W = hi(si), hp(sW), hi(ti), hp(tW)
+            prog = compile_block(sr + tr, theta_index=nx)           # theta is state index nx (mpc.py:1181)
+            d.path_prog, d.path_prog_len = hp(prog), len(prog)
+        # ---- nonlinear stage constraint (modeling.py:820-1005) ----
+        if self.terminal_constraint.is_set:
+            raise NotImplementedError("terminal constraints are not yet offloaded")
+        sc = self.stage_constraint
+        ne = 0
+        if sc.is_set:
+            nc = sc.size
+            lb = [-np.inf] * nc if sc.lb is None else sc.lb                  # modeling.py:878-881
+            ub = [np.inf] * nc if sc.ub is None else sc.ub
+            if len(lb) != nc or len(ub) != nc:
+                raise ValueError("The dimensions of the stage constraint function and its bounds are not compatible.")
+            for e in sc.constraint:
+                if e.depends_on('theta'):
+                    raise NotImplementedError("constraints on the path variable are not offloaded")
+            prog = compile_block(sc.constraint)
+            d.n_con, d.con_soft = nc, int(sc.is_soft)
+            d.con_prog, d.con_prog_len = hp(prog), len(prog)
+            d.con_lb, d.con_ub = hp(lb), hp(ub)
+            if sc.is_soft:
+                ne = nc
+                d.con_weight = hp(_weight_matrix(sc.weight, nc, 'weight')) if sc.weight is not None else None
+                d.con_max_violation = hp(sc.max_violation) if sc.max_violation is not None else None
+        self._nth, self._ne = nth, ne
         self._dev = device(self._dev_index)
         h = C.c_void_p()
         _lib.check(_lib.lib().hilo_nmpc_create(C.byref(d), self._dev.index, C.byref(h)))
@@ -311,9 +452,11 @@ class NMPC:
         _lib.check(_lib.lib().hilo_nmpc_dims(h, *[C.byref(v) for v in dims]))
         self._n_v, self._n_g = dims[0].value, dims[1].value
         N = self._prediction_horizon
-        # integer bookkeeping of mpc.py:1464-1485 (bit-exact index maps)
-        self._x_ind = [list(range(k * nx, (k + 1) * nx)) for k in range(N + 1)]
-        self._u_ind = [list(range((N + 1) * nx + k * nu, (N + 1) * nx + (k + 1) * nu)) for k in range(N)]
+        # integer bookkeeping of mpc.py:1464-1537 (bit-exact index maps); a path variable is a state + an input
+        nxa, nua = nx + nth, nu + nth
+        self._x_ind = [list(range(k * nxa, (k + 1) * nxa)) for k in range(N + 1)]
+        self._u_ind = [list(range((N + 1) * nxa + k * nua, (N + 1) * nxa + (k + 1) * nua)) for k in range(N)]
+        self._e_soft_stage_ind = list(range((N + 1) * nxa + N * nua, (N + 1) * nxa + N * nua + ne))
         self._sx, self._su = sx, su
         self._nlp_setup_done = True
 
@@ -398,7 +541,9 @@ class NMPC:
         self._nlp_solution = {'x': v_opt, 'f': f_opt, 'lam_g': lam_g, 'status': status, 'iter_count': iters,
                               'kkt_error': kkt}
         if self._has_du:
-            self._u_prev = v_opt[:, self._u_ind[0]].contiguous()
+            self._u_prev = v_opt[:, self._u_ind[0][:self._n_u]].contiguous()
+        if self._ne:
+            self.stage_constraint.e_soft_value = v_opt[:, self._e_soft_stage_ind]        # mpc.py:833-834
         if self._stats:
             torch.cuda.synchronize(dev)
             self._extime = time.time() - t0
@@ -429,9 +574,10 @@ class NMPC:
             warnings.warn("There is still no mpc solution available. Run mpc.optimize() to get one.")
             return None, None, None
         v = self._nlp_solution['x'].cpu().numpy()
-        N, nx, nu = self._prediction_horizon, self._n_x, self._n_u
-        X = v[:, :(N + 1) * nx].reshape(-1, N + 1, nx) * self._sx
-        U = v[:, (N + 1) * nx:].reshape(-1, N, nu) * self._su
+        N, nx, nu, nth = self._prediction_horizon, self._n_x, self._n_u, self._nth
+        nxa, nua = nx + nth, nu + nth
+        X = v[:, :(N + 1) * nxa].reshape(-1, N + 1, nxa) * np.concatenate([self._sx, np.ones(nth)])
+        U = v[:, (N + 1) * nxa:(N + 1) * nxa + N * nua].reshape(-1, N, nua) * np.concatenate([self._su, np.ones(nth)])
         return np.swapaxes(X, 1, 2), np.swapaxes(U, 1, 2), None
 
     def phase_profile(self, enable=True):

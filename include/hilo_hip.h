@@ -203,7 +203,48 @@ typedef struct hilo_nmpc_desc {
   /* learned term of the model (`Model.substitute_from(gp)`, dynamic_model.py:3040-3125): required for
      HILO_MODEL_CHEMOSTAT4_GP (label `mu`, features S, I; the posterior mean is copied at create), else NULL */
   const hilo_gp* learned;
+  /* ---- path following (mpc.py:1025-1053 `create_path_variable`, :1173-1204): at most one path variable theta.  It
+     becomes state index nx with the virtual input u_theta (input index nu), theta+ = theta + dt u_theta (:1191);
+     theta_0 is a free bounded variable (:785-789 pins only the original states).  Path cost terms
+     (x[idx] - r(theta))^T W (x[idx] - r(theta)) (hilo_mpc/util/modeling.py:252-283), stage and terminal. ---- */
+  int32_t n_path_var;                    /* 0 or 1 */
+  int32_t has_u_pf_ref;                  /* adds (u_theta - u_pf_ref)^2 u_pf_weight to the stage cost (:1202-1204) */
+  double theta_guess, theta_lb, theta_ub, u_pf_lb, u_pf_ub, u_pf_ref, u_pf_weight;
+  int32_t n_path_stage, n_path_term;     /* tracked states per cost, <= 4 each */
+  const int32_t* path_stage_idx; const double* path_stage_W;   /* [n], [n][n] */
+  const int32_t* path_term_idx;  const double* path_term_W;
+  const double* path_prog;               /* n_path_stage + n_path_term expression programs r(theta) (HILO_X_*) */
+  int32_t path_prog_len;
+  /* ---- nonlinear stage constraint lb <= c(x_k,u_k) <= ub, k = 0..N-1 (`GenericConstraint`, modeling.py:820-1005;
+     mpc.py:1271-1283, :1700-1725), on un-scaled variables (modeling.py:843-849).  soft: one slack vector e >= 0 shared by
+     all stages (mpc.py:1529-1537), rows c - e <= ub, -c - e <= -lb, e^T W e added once per stage (:1708); e is appended
+     to the decision vector. ---- */
+  int32_t n_con;                         /* expressions, <= 2 */
+  int32_t con_soft;
+  int32_t con_prog_len;
+  const double* con_prog;                /* n_con programs in the model states (VARX), inputs (VARU), parameters */
+  const double* con_lb; const double* con_ub;      /* [n_con]; -inf / +inf allowed */
+  const double* con_weight;              /* [n_con][n_con] or NULL -> 1e4 I (modeling.py:875) */
+  const double* con_max_violation;       /* [n_con] or NULL -> inf */
 } hilo_nmpc_desc;
+
+/* expression programs: [len, (op, arg) * len/2] back to back; postfix, stack of 8 */
+#define HILO_X_CONST 0   /* arg = value */
+#define HILO_X_VARX 1    /* arg = state index */
+#define HILO_X_VARU 2    /* arg = input index */
+#define HILO_X_VARP 3    /* arg = parameter index */
+#define HILO_X_ADD 10
+#define HILO_X_SUB 11
+#define HILO_X_MUL 12
+#define HILO_X_DIV 13
+#define HILO_X_NEG 14
+#define HILO_X_SQ 15
+#define HILO_X_SIN 16
+#define HILO_X_COS 17
+#define HILO_X_EXP 18
+#define HILO_X_LOG 19
+#define HILO_X_SQRT 20
+#define HILO_X_POWI 21   /* arg = integer exponent in [-16, 16] */
 
 int hilo_nmpc_create(const hilo_nmpc_desc* desc, int device, hilo_nmpc** out);   /* = NMPC.setup(), mpc.py:1789 */
 void hilo_nmpc_destroy(hilo_nmpc* h);

@@ -228,12 +228,22 @@ def chemostat4_gp(X_train, alpha, length_scales, signal_variance=1., bias=0.):
                        [mu * X - D * X, -Rs * X - D * S + DS * Sf, Rfp * X - D * P, -D * I + DI * If], [X, P])
 
 
+def robot6():
+    """Planar mobile robot with heading for the path-following configuration C5 (the reference holds no
+    6-state model - pattern of the point mass in tests/test_NMPC.py:742-775 and path_following_mpc.ipynb cell 3):
+    states px,vx,py,vy,psi,omega; inputs a (acceleration along the heading) and alpha; measurements (px, py)."""
+    px, vx, py, vy, psi, om, a, al = sp.symbols('px vx py vy psi omega a alpha')
+    return OracleModel('robot6', MODEL_ROBOT6, [px, vx, py, vy, psi, om], [a, al], [],
+                       [vx, a * sp.cos(psi), vy, a * sp.sin(psi), om, al], [px, py])
+
+
 ZOO = {
     'linear2': linear2_kat,
     'toy1d': toy1d,
     'bioreactor3': bioreactor3,
     'chemostat4': chemostat4,
     'pendulum4': pendulum4,
+    'robot6': robot6,
 }
 
 

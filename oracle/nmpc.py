@@ -202,6 +202,39 @@ class IpmOptions:
             setattr(self, k, v)
 
 
+def _inertia_ok(K, n_pos, n_neg):
+    """Inertia of the symmetric KKT matrix from a Bunch-Kaufman LDL^T factorisation (what IPOPT reads off its
+    symmetric indefinite solver): 1x1 pivots by sign, 2x2 pivots by their eigenvalue signs.  An eigenvalue
+    decomposition of the whole matrix loses the small eigenvalues next to barrier terms of 1e9 and more."""
+    from scipy.linalg import ldl
+    out = np.zeros(K.shape[0], dtype=bool)
+    for b in range(K.shape[0]):
+        try:
+            _, D, _ = ldl(K[b], lower=True)
+        except Exception:
+            continue
+        n = D.shape[0]
+        pos = neg = 0
+        i = 0
+        while i < n:
+            if i + 1 < n and D[i + 1, i] != 0.0:
+                a, c, d = D[i, i], D[i + 1, i], D[i + 1, i + 1]
+                det, tr = a * d - c * c, a + d
+                if det < 0:
+                    pos += 1
+                    neg += 1
+                elif det > 0:
+                    pos += 2 * (tr > 0)
+                    neg += 2 * (tr < 0)
+                i += 2
+            else:
+                pos += D[i, i] > 0
+                neg += D[i, i] < 0
+                i += 1
+        out[b] = (pos == n_pos) and (neg == n_neg)
+    return out
+
+
 def _push_interior(w, lb, ub, o):
     """IPOPT initialisation (Waechter & Biegler sec. 3.6): x <- P[x] with kappa_1 = kappa_2 = bound_push/frac."""
     w = w.copy()
@@ -427,8 +460,7 @@ class DenseIpm:
                 K[:, :self.nw, :self.nw] = Wl[t] + np.einsum('bi,ij->bij', Sig[t] + delta[t, None], np.eye(self.nw))
                 K[:, :self.nw, self.nw:] = np.swapaxes(J[t], 1, 2)
                 K[:, self.nw:, :self.nw] = J[t]
-                ev = np.linalg.eigvalsh(K)
-                good = ((ev < 0).sum(1) == self.m) & ((ev > 0).sum(1) == self.nw)
+                good = _inertia_ok(K, self.nw, self.m)
                 if good.any():
                     tg = t[good]
                     sol = np.linalg.solve(K[good], np.concatenate([rhs1[tg], -c[tg]], axis=1)[:, :, None])[:, :, 0]

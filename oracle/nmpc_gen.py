@@ -1,0 +1,349 @@
+"""Oracle: the general NMPC transcription - path following and nonlinear stage constraints - on the dense
+interior-point solver of oracle/nmpc.py.
+
+TEST INFRASTRUCTURE ONLY - never imported by the product package.   PARITY UNPINNED (see oracle/nmpc.py): the
+reference's path-following and soft-constraint runs (tests/test_NMPC.py:742-775, path_following_mpc.ipynb) assert no
+numbers, and CasADi/IPOPT cannot be installed here.
+
+Restated from hilo_mpc/modules/controller/mpc.py (pre-discretised model + `integration_method='discrete'`, Q18):
+  * path following (:1025-1053, :1173-1204): every path variable theta becomes a model state with its own virtual input,
+    theta+ = theta + dt u_theta for a discrete model (explicit Euler, :1188-1191); bounds theta in [theta_lb, theta_ub],
+    u_theta in [u_pf_lb, u_pf_ub]; guesses theta_guess and u_pf_lb + 1e-4 (:1194-1195); unit scaling (:1200-1201);
+    optional (u_theta - u_pf_ref)^2 u_pf_weight stage term (:1202-1204).  `optimize` pins only the ORIGINAL states of
+    x_0 (:785-789): theta_0 is a free, bounded variable.  The path cost substitutes the expression of theta for the
+    reference, (s - r(theta))^T W (s - r(theta)) (hilo_mpc/util/modeling.py:252-283), stage and terminal.
+  * stage constraints (`GenericConstraint`, modeling.py:820-1005; mpc.py:1271-1283, :1700-1725): rows
+    lb <= c(x_k, u_k) <= ub for k = 0..N-1 on UN-scaled variables (modeling.py:843-849); soft: ONE slack vector e >= 0
+    shared by all stages (mpc.py:1529-1537), rows c - e <= ub and -c - e <= -lb (:1276-1277), penalty e^T W e added
+    once per stage (:1708), W = 1e4 I by default (modeling.py:875), e <= max_violation.
+    Rows whose bound is infinite on both sides (e.g. -c - e <= +inf when lb = -inf) constrain nothing and are dropped.
+  * decision vector v = [x_0..x_N | u_0..u_{N-1} | e] with the path states/inputs inside x and u (mpc.py:1462-1537);
+    g interleaves per stage the shooting defect and the constraint rows (:1667, :1707-1725).
+Inequality rows are handled the way IPOPT does (Waechter & Biegler 2006, sec. 3.4 of the implementation paper): a slack
+s with d(w) - s = 0 and bounds d_L <= s <= d_U (relaxed by bound_relax_factor), s_0 = d(w_0) pushed into the interior.
+"""
+from __future__ import annotations
+
+import numpy as np
+import sympy as sp
+
+from .models import _lam
+from .nmpc import DenseIpm, IpmOptions, NmpcProblem, _push_interior, _wmat
+
+INF = np.inf
+
+
+def _parse(expr, names):
+    return sp.sympify(expr, locals=names) if isinstance(expr, str) else sp.sympify(expr)
+
+
+class GenNmpcProblem(NmpcProblem):
+    """path = dict(name='theta', theta_guess=0., theta_lb=0., theta_ub=inf, u_pf_lb=1e-4, u_pf_ub=1., u_pf_ref=None,
+                   u_pf_weight=10., stage=[(state indices, weights, [expr in theta, ...])], terminal=[...])
+       constraint = dict(expr=[expr in state/input names, ...], lb=[...], ub=[...], soft=False, weight=None,
+                         max_violation=inf)"""
+
+    def __init__(self, model, dt, N, path=None, constraint=None, **kw):
+        super().__init__(model, dt, N, **kw)
+        nx, nu = self.nx, self.nu
+        self.path = path
+        self.nth = 1 if path else 0
+        self.nxa, self.nua = nx + self.nth, nu + self.nth
+        self.nza = self.nxa + self.nua
+        names = {str(s): s for s in model.x + model.u}
+        zs = [sp.Symbol(f'zs_{i}') for i in range(self.nza)]                 # scaled stage variables
+        xs_sym, us_sym = zs[:self.nxa], zs[self.nxa:]
+        self.sza = np.concatenate([self.sx, np.ones(self.nth), self.su, np.ones(self.nth)])
+        # ---- quadratic part on the augmented z (zero rows for the path variable) ----
+        idx = list(range(nx)) + list(range(self.nxa, self.nxa + nu))
+        self.Wza = np.zeros((self.nza, self.nza))
+        self.Wza[np.ix_(idx, idx)] = self.Wz
+        self.zrefa = np.zeros(self.nza)
+        self.zrefa[idx] = self.zref
+        self.WNa = np.zeros((self.nxa, self.nxa))
+        self.WNa[:nx, :nx] = self.WN
+        self.xrefNa = np.zeros(self.nxa)
+        self.xrefNa[:nx] = self.xrefN
+        # ---- path terms (symbolic in the scaled stage variables) ----
+        lp, Vp = sp.Integer(0), sp.Integer(0)
+        if path:
+            th = sp.Symbol(path.get('name', 'theta'))
+            th_s, uth_s = xs_sym[nx], us_sym[nu]
+            for ind, W, refs in path.get('stage', []):
+                W = _wmat(W, len(ind))
+                d = sp.Matrix([xs_sym[i] - _parse(r, {str(th): th}).subs(th, th_s) for i, r in zip(ind, refs)])
+                lp += (d.T * sp.Matrix(W) * d)[0, 0]
+            for ind, W, refs in path.get('terminal', []):
+                W = _wmat(W, len(ind))
+                d = sp.Matrix([xs_sym[i] - _parse(r, {str(th): th}).subs(th, th_s) for i, r in zip(ind, refs)])
+                Vp += (d.T * sp.Matrix(W) * d)[0, 0]
+            if path.get('u_pf_ref') is not None:
+                lp += (uth_s - path['u_pf_ref']) ** 2 * path.get('u_pf_weight', 10.)
+            self.x_lb = np.concatenate([self.x_lb, [path.get('theta_lb', 0.)]])
+            self.x_ub = np.concatenate([self.x_ub, [path.get('theta_ub', INF)]])
+            self.u_lb = np.concatenate([self.u_lb, [path.get('u_pf_lb', 1e-4)]])
+            self.u_ub = np.concatenate([self.u_ub, [path.get('u_pf_ub', 1.)]])
+            self.x_guess = np.concatenate([self.x_guess, [path.get('theta_guess', 0.)]])
+            self.u_guess = np.concatenate([self.u_guess, [path.get('u_pf_lb', 1e-4) + 1e-4]])
+        self._lp = self._vgh(lp, zs)
+        self._Vp = self._vgh(Vp, xs_sym)
+        # ---- constraint rows d(zs, e) with bounds [dlb, dub] ----
+        self.ne = 0
+        rows, dlb, dub, self.row_ref = [], [], [], []
+        es = []
+        if constraint:
+            sub = {s: zs[i] * self.sza[i] for i, s in enumerate(model.x)}
+            sub.update({s: zs[self.nxa + i] * self.su[i] for i, s in enumerate(model.u)})
+            cs = [_parse(e, names).subs(sub, simultaneous=True) for e in constraint['expr']]
+            nc = len(cs)
+            lb = np.broadcast_to(np.asarray(constraint.get('lb', -INF), dtype=float), (nc,))
+            ub = np.broadcast_to(np.asarray(constraint.get('ub', INF), dtype=float), (nc,))
+            if constraint.get('soft'):
+                self.ne = nc
+                es = [sp.Symbol(f'e_{j}') for j in range(nc)]
+                W = constraint.get('weight')
+                self.We = np.diag(np.ones(nc) * 1e4) if W is None else _wmat(W, nc)       # modeling.py:875
+                self.e_ub = np.broadcast_to(np.asarray(constraint.get('max_violation', INF), dtype=float), (nc,))
+                for j in range(nc):                                                  # mpc.py:1276-1277, :1711-1712
+                    for r, (expr, b) in enumerate(((cs[j] - es[j], ub[j]), (-cs[j] - es[j], -lb[j]))):
+                        if np.isfinite(b):
+                            rows.append(expr), dlb.append(-INF), dub.append(b), self.row_ref.append(r * nc + j)
+            else:
+                for j in range(nc):
+                    if np.isfinite(lb[j]) or np.isfinite(ub[j]):
+                        rows.append(cs[j]), dlb.append(lb[j]), dub.append(ub[j]), self.row_ref.append(j)
+            self.n_con_ref = 2 * nc if constraint.get('soft') else nc            # rows per stage in the reference's g
+        else:
+            self.n_con_ref = 0
+        self.nrow = len(rows)
+        self.dlb, self.dub = np.array(dlb, dtype=float), np.array(dub, dtype=float)
+        ze = zs + es
+        args = [zs, es]
+        self._d = _lam(rows, args) if rows else None
+        self._dj = _lam([[sp.diff(r, a) for a in ze] for r in rows], args) if rows else None
+        self._dh = _lam([[[sp.diff(r, a, b) for b in zs] for a in zs] for r in rows], args) if rows else None
+        # ---- decision-vector bookkeeping of the reference (mpc.py:1462-1537) ----
+        nxa, nua = self.nxa, self.nua
+        off = 0
+        self.x_ind = []
+        for _ in range(N + 1):
+            self.x_ind.append(list(range(off, off + nxa)))
+            off += nxa
+        self.u_ind = []
+        for _ in range(N):
+            self.u_ind.append(list(range(off, off + nua)))
+            off += nua
+        self.e_ind = list(range(off, off + self.ne))
+        self.n_v = off + self.ne
+        self.n_g = N * (nxa + self.n_con_ref)
+
+    @staticmethod
+    def _vgh(expr, syms):
+        expr = sp.sympify(expr)
+        args = [syms]
+        if expr == 0:
+            n = len(syms)
+            return (lambda z: np.zeros(z.shape[0]), lambda z: np.zeros((z.shape[0], n)),
+                    lambda z: np.zeros((z.shape[0], n, n)))
+        v = _lam([expr], args)
+        g = _lam([sp.diff(expr, a) for a in syms], args)
+        h = _lam([[sp.diff(expr, a, b) for b in syms] for a in syms], args)
+        return (lambda z: v(z)[:, 0], g, h)
+
+    # augmented shooting map on scaled variables: [Phi(x,u); theta + dt u_theta]
+    def phia(self, xs, us, p, need=0):
+        nx, nu, nth = self.nx, self.nu, self.nth
+        B = xs.shape[0]
+        if need == 0:
+            f = self.phi(xs[:, :nx], us[:, :nu], p)
+            if nth:
+                f = np.concatenate([f, xs[:, nx:] + self.dt * us[:, nu:]], axis=1)
+            return f
+        f, J, H = self.phi(xs[:, :nx], us[:, :nu], p, need=2)
+        Ja = np.zeros((B, self.nxa, self.nza))
+        Ha = np.zeros((B, self.nxa, self.nza, self.nza))
+        idx = list(range(nx)) + list(range(self.nxa, self.nxa + nu))
+        Ja[np.ix_(range(B), range(nx), idx)] = J
+        Ha[np.ix_(range(B), range(nx), idx, idx)] = H
+        if nth:
+            f = np.concatenate([f, xs[:, nx:] + self.dt * us[:, nu:]], axis=1)
+            Ja[:, nx, nx] = 1.0
+            Ja[:, nx, self.nxa + nu] = self.dt
+        return f, Ja, Ha
+
+
+class GenIpm(DenseIpm):
+    """Free variables w = [theta_0 | xa_1..xa_N | ua_0..ua_{N-1} | e | s_0..s_{N-1}]."""
+
+    def __init__(self, prob: GenNmpcProblem, options: IpmOptions | None = None):
+        self.pb = pb = prob
+        self.o = o = options or IpmOptions()
+        N, nxa, nua, nth, ne, nrow = pb.N, pb.nxa, pb.nua, pb.nth, pb.ne, pb.nrow
+        self.o_x = nth
+        self.o_u = self.o_x + N * nxa
+        self.o_e = self.o_u + N * nua
+        self.o_s = self.o_e + ne
+        self.nw = self.o_s + N * nrow
+        self.m = N * nxa + N * nrow
+        lb = np.concatenate([pb.x_lb[pb.nx:], np.tile(pb.x_lb, N), np.tile(pb.u_lb, N), np.zeros(ne), np.tile(pb.dlb, N)])
+        ub = np.concatenate([pb.x_ub[pb.nx:], np.tile(pb.x_ub, N), np.tile(pb.u_ub, N),
+                             pb.e_ub if ne else np.zeros(0), np.tile(pb.dub, N)])
+        r = o.bound_relax_factor
+        self.lb = np.where(np.isfinite(lb), lb - r * np.maximum(1, np.abs(lb)), lb)
+        self.ub = np.where(np.isfinite(ub), ub + r * np.maximum(1, np.abs(ub)), ub)
+        self.has_l, self.has_u = np.isfinite(self.lb), np.isfinite(self.ub)
+
+    # column of stage k's augmented z entry i in w (-1: pinned x_0 entry)
+    def zcols(self, k):
+        pb = self.pb
+        cols = []
+        for i in range(pb.nxa):
+            if k == 0:
+                cols.append(i - pb.nx if i >= pb.nx else -1)
+            else:
+                cols.append(self.o_x + (k - 1) * pb.nxa + i)
+        cols += [self.o_u + k * pb.nua + j for j in range(pb.nua)]
+        return cols
+
+    def _unpack(self, w, x0):
+        pb = self.pb
+        B = w.shape[0]
+        N, nxa, nua = pb.N, pb.nxa, pb.nua
+        X = np.empty((B, N + 1, nxa))
+        X[:, 0, :pb.nx] = x0
+        X[:, 0, pb.nx:] = w[:, :pb.nth]
+        X[:, 1:] = w[:, self.o_x:self.o_u].reshape(B, N, nxa)
+        U = w[:, self.o_u:self.o_e].reshape(B, N, nua)
+        E = w[:, self.o_e:self.o_s]
+        S = w[:, self.o_s:].reshape(B, N, pb.nrow)
+        return X, U, E, S
+
+    def eval_fc(self, w, data):
+        pb = self.pb
+        x0, p, u_old = data['x0'], data['p'], data.get('u_old')
+        X, U, E, S = self._unpack(w, x0)
+        B, N = w.shape[0], pb.N
+        f = np.zeros(B)
+        c = np.empty((B, N, pb.nxa))
+        cd = np.empty((B, N, pb.nrow))
+        for k in range(N):
+            zk = np.concatenate([X[:, k], U[:, k]], axis=1)
+            z = zk - pb.zrefa
+            f += np.einsum('bi,ij,bj->b', z, pb.Wza, z) + pb._lp[0](zk)
+            if pb.ne:
+                f += np.einsum('bi,ij,bj->b', E, pb.We, E)                     # mpc.py:1708: once per stage
+            c[:, k] = X[:, k + 1] - pb.phia(X[:, k], U[:, k], p)
+            if pb.nrow:
+                cd[:, k] = pb._d(zk, E) - S[:, k]
+        if u_old is not None:
+            d = U[:, 0, :pb.nu] - u_old
+            f += np.einsum('bi,ij,bj->b', d, pb.Wdu, d)
+        d = X[:, N] - pb.xrefNa
+        f += np.einsum('bi,ij,bj->b', d, pb.WNa, d) + pb._Vp[0](X[:, N])
+        return f, np.concatenate([c, cd], axis=2).reshape(B, -1)
+
+    def eval_all(self, w, lam, data):
+        """Constraint order: per stage [defect (nxa) | d - s (nrow)]."""
+        pb = self.pb
+        N, nxa, nua, nza, nrow, ne = pb.N, pb.nxa, pb.nua, pb.nza, pb.nrow, pb.ne
+        x0, p, u_old = data['x0'], data['p'], data.get('u_old')
+        X, U, E, S = self._unpack(w, x0)
+        B = w.shape[0]
+        mk = nxa + nrow
+        f = np.zeros(B)
+        g = np.zeros((B, self.nw))
+        c = np.empty((B, N, mk))
+        J = np.zeros((B, self.m, self.nw))
+        W = np.zeros((B, self.nw, self.nw))
+        lam = lam.reshape(B, N, mk)
+        bi = np.arange(B)
+        ecols = list(range(self.o_e, self.o_s))
+        for k in range(N):
+            cols = self.zcols(k)
+            sel = [i for i, cidx in enumerate(cols) if cidx >= 0]
+            zi = [cols[i] for i in sel]
+            zk = np.concatenate([X[:, k], U[:, k]], axis=1)
+            z = zk - pb.zrefa
+            f += np.einsum('bi,ij,bj->b', z, pb.Wza, z) + pb._lp[0](zk)
+            gz = 2 * z @ pb.Wza + pb._lp[1](zk)
+            Hz = 2 * pb.Wza[None] + pb._lp[2](zk)
+            Phi, Jk, Hk = pb.phia(X[:, k], U[:, k], p, need=2)
+            c[:, k, :nxa] = X[:, k + 1] - Phi
+            Hz = Hz - np.einsum('bm,bmzy->bzy', lam[:, k, :nxa], Hk)
+            rows = list(range(k * mk, k * mk + nxa))
+            J[np.ix_(bi, rows, zi)] = -Jk[:, :, sel]
+            J[:, rows, [self.o_x + k * nxa + i for i in range(nxa)]] = 1.0
+            if nrow:
+                dv = pb._d(zk, E)
+                dj = pb._dj(zk, E)                                              # [B, nrow, nza + ne]
+                dh = pb._dh(zk, E)                                              # [B, nrow, nza, nza]
+                c[:, k, nxa:] = dv - S[:, k]
+                rws = list(range(k * mk + nxa, (k + 1) * mk))
+                J[np.ix_(bi, rws, zi)] = dj[:, :, sel]
+                if ne:
+                    J[np.ix_(bi, rws, ecols)] = dj[:, :, nza:]
+                J[:, rws, [self.o_s + k * nrow + r for r in range(nrow)]] = -1.0
+                Hz = Hz + np.einsum('bm,bmzy->bzy', lam[:, k, nxa:], dh)
+            if ne:
+                f += np.einsum('bi,ij,bj->b', E, pb.We, E)
+                g[:, ecols] += 2 * E @ pb.We
+                W[np.ix_(bi, ecols, ecols)] += 2 * pb.We
+            if k == 0 and u_old is not None:
+                d = U[:, 0, :pb.nu] - u_old
+                f += np.einsum('bi,ij,bj->b', d, pb.Wdu, d)
+                gz[:, nxa:nxa + pb.nu] += 2 * d @ pb.Wdu
+                Hz[:, nxa:nxa + pb.nu, nxa:nxa + pb.nu] += 2 * pb.Wdu
+            g[:, zi] += gz[:, sel]
+            W[np.ix_(bi, zi, zi)] += Hz[np.ix_(bi, sel, sel)]
+        d = X[:, N] - pb.xrefNa
+        xi = [self.o_x + (N - 1) * nxa + i for i in range(nxa)]
+        f += np.einsum('bi,ij,bj->b', d, pb.WNa, d) + pb._Vp[0](X[:, N])
+        g[:, xi] += 2 * d @ pb.WNa + pb._Vp[1](X[:, N])
+        W[np.ix_(bi, xi, xi)] += 2 * pb.WNa[None] + pb._Vp[2](X[:, N])
+        return f, g, c.reshape(B, -1), J, W
+
+    def solve(self, x0, p, w0=None, u_old=None, verbose=False):
+        """w0: warm start for [theta_0 | xa | ua | e] (the slacks always restart at d(w_0), like IPOPT)."""
+        o, pb = self.o, self.pb
+        x0 = np.atleast_2d(np.asarray(x0, dtype=float)) / pb.sx
+        B = x0.shape[0]
+        p = np.broadcast_to(np.atleast_2d(np.asarray(p, dtype=float)), (B, pb.np_)) if pb.np_ else np.zeros((B, 0))
+        data = {'x0': x0, 'p': p}
+        if u_old is not None:
+            data['u_old'] = np.broadcast_to(np.atleast_2d(np.asarray(u_old, dtype=float)), (B, pb.nu))
+        if w0 is None:
+            w0 = np.concatenate([pb.x_guess[pb.nx:], np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N), np.zeros(pb.ne)])
+        w0 = np.broadcast_to(np.atleast_2d(w0)[:, :self.o_s], (B, self.o_s))
+        w0 = _push_interior(w0, self.lb[:self.o_s], self.ub[:self.o_s], o)
+        if pb.nrow:
+            X, U, E, _ = self._unpack(np.concatenate([w0, np.zeros((B, pb.N * pb.nrow))], axis=1), x0)
+            s0 = np.stack([pb._d(np.concatenate([X[:, k], U[:, k]], axis=1), E) for k in range(pb.N)], axis=1)
+            w0 = np.concatenate([w0, s0.reshape(B, -1)], axis=1)
+        res = self.solve_data(data, w0, verbose)
+        X, U, E, S = self._unpack(res['w'], x0)
+        res.update(X=X, U=U, E=E, S=S, u0=U[:, 0, :pb.nu] * pb.su, x0=x0)
+        return res
+
+    # reference layouts -------------------------------------------------------------------------------------------
+    def to_v(self, res):
+        B = res['X'].shape[0]
+        return np.concatenate([res['X'].reshape(B, -1), res['U'].reshape(B, -1), res['E']], axis=1)
+
+    def w_from_v(self, v):
+        """[theta_0 | xa_1.. | ua | e] from the reference's decision vector."""
+        pb = self.pb
+        v = np.atleast_2d(v)
+        nX = (pb.N + 1) * pb.nxa
+        return np.concatenate([v[:, pb.nx:pb.nxa], v[:, pb.nxa:nX], v[:, nX:]], axis=1)
+
+    def lam_g(self, res):
+        """Multipliers in the reference's g order: per stage [defect (nxa) | constraint rows (n_con_ref)]; rows that were
+        dropped (infinite bound) carry a zero multiplier."""
+        pb = self.pb
+        B = res['lam'].shape[0]
+        lam = res['lam'].reshape(B, pb.N, pb.nxa + pb.nrow)
+        out = np.zeros((B, pb.N, pb.nxa + pb.n_con_ref))
+        out[:, :, :pb.nxa] = lam[:, :, :pb.nxa]
+        for r, ref in enumerate(pb.row_ref):
+            out[:, :, pb.nxa + ref] = lam[:, :, pb.nxa + r]
+        return out.reshape(B, -1)

@@ -133,3 +133,76 @@ def product_gp(X=None, y=None):
     gp.set_training_data(X, y)
     gp.setup()
     return gp
+
+
+# ---- general NMPC: nonlinear stage constraints and path following -----------------
+C2H = dict(C2, constraint=dict(expr=['X * S'], lb=[-np.inf], ub=[60.]))                      # hard, one-sided
+C2S = dict(C2, constraint=dict(expr=['X * S'], lb=[-np.inf], ub=[60.], soft=True))           # soft, default W = 1e4
+C5 = dict(                       # path-following NMPC, mobile robot nx=6 (+theta), nu=2 (+u_theta), soft speed limit
+    model='robot6', dt=.1, N=50, order=4,
+    stage_inputs=[([0, 1], [.1, .1], None)],
+    path=dict(theta_guess=0., theta_lb=0., theta_ub=np.inf, u_pf_lb=1e-4, u_pf_ub=1.,
+              stage=[([0, 2], [10., 10.], ['sin(theta)', 'sin(2*theta)'])],
+              terminal=[([0, 2], [10., 10.], ['sin(theta)', 'sin(2*theta)'])]),
+    constraint=dict(expr=['vx**2 + vy**2'], lb=[-np.inf], ub=[4.], soft=True),
+    u_lb=[-5., -5.], u_ub=[5., 5.],
+    x_guess=[0., 1.5, 0., 1.3, .6, 0.], u_guess=[0., 0.],      # guess = nominal initial state (tiled over the horizon)
+    p=[],
+)
+C5S = dict(C5, N=10)             # short horizon for oracle-sized tests
+
+
+def c5_x0(B, seed=SEED):
+    rng = np.random.default_rng(seed + 5)
+    return np.array([0., 1.5, 0., 1.3, .6, 0.]) + .1 * rng.uniform(-1, 1, (B, 6))   # |v|^2 ~ 3.9 +- 0.4 around the limit 4
+
+
+def oracle_gen(spec):
+    from oracle import models
+    from oracle.nmpc_gen import GenNmpcProblem
+    kw = {k: v for k, v in spec.items() if k not in ('model', 'p')}
+    return GenNmpcProblem(models.get(spec['model']), **kw)
+
+
+def product_gen(spec, **solver_options):
+    """Product NMPC for a general spec (path following / stage constraints) through the reference-style API; the
+    expression strings of the spec are evaluated on the model's symbols."""
+    from hilo_mpc_amd import NMPC, Model, expr
+    m = Model(spec['model']).discretize('erk', order=spec.get('order', 4)).setup(dt=spec['dt'])
+    nmpc = NMPC(m)
+    xs, us = m.dynamical_state_names, m.input_names
+    ns = {'sin': expr.sin, 'cos': expr.cos, 'exp': expr.exp, 'log': expr.log, 'sqrt': expr.sqrt}
+    ns.update({n: m.x[n] for n in xs})
+    ns.update({n: m.u[n] for n in us})
+    for ind, W, ref in spec.get('stage_states', []):
+        nmpc.quad_stage_cost.add_states(names=[xs[i] for i in ind], weights=list(W), ref=ref)
+    for ind, W, ref in spec.get('stage_inputs', []):
+        nmpc.quad_stage_cost.add_inputs(names=[us[i] for i in ind], weights=list(W), ref=ref)
+    for ind, W, ref in spec.get('terminal_states', []):
+        nmpc.quad_terminal_cost.add_states(names=[xs[i] for i in ind], weights=list(W), ref=ref)
+    if spec.get('path'):
+        pa = dict(spec['path'])
+        theta = nmpc.create_path_variable(**{k: v for k, v in pa.items() if k not in ('stage', 'terminal')})
+        ns[pa.get('name', 'theta')] = theta
+        for ind, W, refs in pa.get('stage', []):
+            nmpc.quad_stage_cost.add_states(names=[xs[i] for i in ind], weights=list(W), path_following=True,
+                                            ref=[eval(r, dict(ns)) for r in refs])
+        for ind, W, refs in pa.get('terminal', []):
+            nmpc.quad_terminal_cost.add_states(names=[xs[i] for i in ind], weights=list(W), path_following=True,
+                                               ref=[eval(r, dict(ns)) for r in refs])
+    if spec.get('constraint'):
+        co = spec['constraint']
+        nmpc.stage_constraint.constraint = [eval(e, dict(ns)) for e in co['expr']]
+        nmpc.stage_constraint.lb, nmpc.stage_constraint.ub = list(co['lb']), list(co['ub'])
+        nmpc.stage_constraint.is_soft = bool(co.get('soft', False))
+        if co.get('weight') is not None:
+            nmpc.stage_constraint.weight = co['weight']
+        if co.get('max_violation') is not None:
+            nmpc.stage_constraint.max_violation = co['max_violation']
+    nmpc.horizon = spec['N']
+    nmpc.set_box_constraints(x_ub=spec.get('x_ub'), x_lb=spec.get('x_lb'), u_ub=spec.get('u_ub'), u_lb=spec.get('u_lb'))
+    nmpc.set_initial_guess(x_guess=spec.get('x_guess'), u_guess=spec.get('u_guess'))
+    if spec.get('x_scaling') or spec.get('u_scaling'):
+        nmpc.set_scaling(x_scaling=spec.get('x_scaling'), u_scaling=spec.get('u_scaling'))
+    nmpc.setup(options={'integration_method': 'discrete'}, solver_options=solver_options or None)
+    return nmpc

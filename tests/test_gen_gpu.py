@@ -1,0 +1,120 @@
+"""GPU parity of the general NMPC path (SURVEY 8 rows a4 path following, a5 GenericConstraint; configuration C5):
+`hilo_nmpc_solve` through the reference-style API vs the oracle's dense interior-point solver on the reference's
+transcription (oracle/nmpc_gen.py).  Tolerances as in tests/test_nmpc_gpu.py: status codes exact, primal 5e-5 at the
+default tolerance 1e-8, objective 1e-8."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.nmpc_gen import GenIpm                                                              # noqa: E402
+from tests.problems import C2, C2H, C2S, C5, C5S, c2_x0, c5_x0, oracle_gen, product_gen         # noqa: E402
+
+
+def _compare(spec, x0, p, vtol=5e-5, itol=6):
+    pb = oracle_gen(spec)
+    ipm = GenIpm(pb)
+    ref = ipm.solve(x0, p)
+    nmpc = product_gen(spec)
+    assert (nmpc._n_v, nmpc._n_g) == (pb.n_v, pb.n_g)
+    assert nmpc._x_ind == pb.x_ind and nmpc._u_ind == pb.u_ind and nmpc._e_soft_stage_ind == pb.e_ind
+    u = nmpc.optimize(x0, cp=p if len(p) else None)
+    assert np.array_equal(nmpc.solver_status_code, ref['status'])
+    assert np.all(ref['status'] == 1)
+    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), ipm.to_v(ref)
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < vtol
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(u, ref['u0'], rtol=vtol, atol=vtol)
+    assert np.all(nmpc.stats()['kkt_error'] <= 1e-8)
+    # iteration counts are a property of the algorithm, not of parity: same order only (round-off steers the inertia
+    # correction and the filter differently in the dense and the Riccati factorisation)
+    assert np.max(np.abs(nmpc.stats()['iter_count'] - ref['iters'])) <= itol
+    return nmpc, pb, ipm, ref
+
+
+def test_hard_constraint_vs_oracle():
+    nmpc, pb, ipm, ref = _compare(C2H, c2_x0(8), C2['p'])
+    XS = ref['X'][:, :-1, 0] * ref['X'][:, :-1, 1]
+    assert XS.max() > 59.9                                            # the limit X*S <= 60 is active
+    xp, up, _ = nmpc.return_prediction()
+    assert (xp[:, 0, :-1] * xp[:, 1, :-1]).max() <= 60. + 1e-4
+    # multipliers in the reference's g order [defect | constraint row] per stage
+    lam = ipm.lam_g(ref)
+    lam = lam.reshape(lam.shape[0], pb.N, -1)
+    lam[:, -1, :pb.nxa] += 2 * (ref['X'][:, -1] - pb.xrefNa) @ pb.WNa  # terminal cost on Phi_{N-1} (mpc.py:1682)
+    np.testing.assert_allclose(nmpc._nlp_solution['lam_g'].cpu().numpy(), lam.reshape(lam.shape[0], -1), rtol=2e-4, atol=1e-5)
+
+
+def test_soft_constraint_vs_oracle():
+    nmpc, pb, ipm, ref = _compare(C2S, c2_x0(8), C2['p'])
+    e = nmpc.stage_constraint.e_soft_value.cpu().numpy()
+    np.testing.assert_allclose(e, ref['E'], atol=1e-6)
+    assert np.all(e >= -1e-8)
+
+
+def test_soft_constraint_two_sided_rows():
+    """lb and ub finite: both rows c - e <= ub and -c - e <= -lb (mpc.py:1276-1277), 2 multipliers per stage."""
+    spec = dict(C2, constraint=dict(expr=['X * S'], lb=[2.], ub=[60.], soft=True, weight=[[1e3]], max_violation=[5.]))
+    nmpc, pb, ipm, ref = _compare(spec, c2_x0(4), C2['p'])
+    assert nmpc._n_g == pb.N * (pb.nx + 2)
+
+
+def test_path_following_soft_speed_limit_vs_oracle():
+    """C5 at N = 10: theta_0 free, virtual input, path cost nonlinear in theta, soft |v|^2 <= 4 with x_0 at the limit."""
+    x0 = c5_x0(8)
+    nmpc, pb, ipm, ref = _compare(C5S, x0, [])
+    assert ref['E'].max() > 1e-3                                      # some x_0 violate the limit: the slack is used
+    xp, up, _ = nmpc.return_prediction()
+    assert xp.shape == (8, 7, 11) and up.shape == (8, 3, 10)
+    np.testing.assert_allclose(xp[:, :6, 0], x0, rtol=1e-12)
+    assert np.all(np.diff(xp[:, 6], axis=1) > 0)                      # theta advances (u_theta >= 1e-4)
+    # closed loop: warm start from the previous solution, as the reference does
+    x1 = nmpc.plant_step(x0, ref['u0']).cpu().numpy()
+    ref2 = ipm.solve(x1, [], w0=ipm.w_from_v(ipm.to_v(ref)))
+    u2 = nmpc.optimize(x1)
+    assert np.array_equal(nmpc.solver_status_code, ref2['status'])
+    np.testing.assert_allclose(u2, ref2['u0'], rtol=5e-5, atol=5e-5)
+
+
+def test_c5_full_horizon_global_workspace():
+    """C5 as configured (N = 50: 8 engine states, 3 inputs): the iterate does not fit the 160 KB of LDS and lives in the
+    per-instance global workspace; same algorithm, same parity bar.  Then the BASELINE batch per GPU (1024) in closed loop."""
+    x0 = c5_x0(3)
+    nmpc, pb, ipm, ref = _compare(C5, x0, [], itol=15)
+    assert (nmpc._n_v, nmpc._n_g) == (51 * 7 + 50 * 3 + 1, 50 * (7 + 2))      # theta-augmented nx=7, nu=3
+    x = c5_x0(1024)
+    for _ in range(3):
+        u = nmpc.optimize(x)
+        x = nmpc.plant_step(x, u).cpu().numpy()
+    st = nmpc.solver_status_code
+    assert np.mean(st == 1) >= 0.99
+    xp, up, _ = nmpc.return_prediction()
+    assert np.all(xp[:, 1] ** 2 + xp[:, 3] ** 2 <= 4. + nmpc.stage_constraint.e_soft_value.cpu().numpy() + 1e-6)
+
+
+def test_path_following_without_constraint():
+    spec = {k: v for k, v in C5S.items() if k != 'constraint'}
+    _compare(spec, c5_x0(4), [])
+
+
+def test_general_errors():
+    from hilo_mpc_amd import NMPC, Model
+    from hilo_mpc_amd._lib import HiloError
+    m = Model('pendulum4').discretize('rk4').setup(dt=.1)
+    nmpc = NMPC(m)
+    nmpc.quad_stage_cost.add_states(names=['v'], weights=[1.])
+    nmpc.horizon = 5
+    nmpc.stage_constraint.constraint = m.x['v'] ** 2
+    nmpc.stage_constraint.ub = [4.]
+    with pytest.raises(HiloError, match="no device instantiation"):
+        nmpc.setup(options={'integration_method': 'discrete'})
+    with pytest.raises(TypeError, match="is_soft must be of type bool"):
+        nmpc.stage_constraint.is_soft = 1
+    deep = m.x['v']
+    for _ in range(9):
+        deep = 1. / (1. + deep * deep)
+    e = m.x['v']
+    for _ in range(9):
+        e = m.x['x'] + (m.x['v'] * e)                               # right-nested: needs a deeper stack each level
+    with pytest.raises(ValueError, match="too deep"):
+        e.program()

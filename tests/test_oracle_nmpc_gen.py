@@ -1,0 +1,151 @@
+"""CPU: the general NMPC oracle (path following, stage constraints; oracle/nmpc_gen.py) is 'parity unpinned'.  It is
+checked here (a) against the plain oracle when no extra feature is active (identical iterates), (b) by an independent
+scipy SLSQP solve of the reference's transcription with inequality rows and the shared slack, (c) for the integer
+bookkeeping of the decision vector.  Also: the host-side expression compiler against a Python model of the device VM."""
+import math
+
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+from oracle.nmpc import DenseIpm
+from oracle.nmpc_gen import GenIpm
+from tests.problems import C2, C2H, C5, C5S, c2_x0, c5_x0, oracle_gen, oracle_problem
+
+
+def test_general_oracle_reduces_to_the_plain_one():
+    x0 = c2_x0(3)
+    r = GenIpm(oracle_gen(C2)).solve(x0, C2['p'])
+    r0 = DenseIpm(oracle_problem(C2)).solve(x0, C2['p'])
+    assert np.array_equal(r['iters'], r0['iters']) and np.array_equal(r['status'], r0['status'])
+    np.testing.assert_array_equal(r['f'], r0['f'])
+
+
+def test_bookkeeping_c5():
+    pb = oracle_gen(C5)
+    # theta-augmented nx = 7, nu = 3; + one shared slack; 2 constraint rows per stage in g (soft)
+    assert (pb.nxa, pb.nua, pb.ne) == (7, 3, 1)
+    assert pb.n_v == 51 * 7 + 50 * 3 + 1 and pb.n_g == 50 * (7 + 2)
+    assert pb.x_ind[1] == list(range(7, 14)) and pb.u_ind[0] == list(range(357, 360)) and pb.e_ind == [507]
+    assert pb.nrow == 1 and pb.row_ref == [0]            # -c - e <= +inf constrains nothing: dropped
+    assert pb.u_guess[-1] == pytest.approx(2e-4) and pb.u_lb[-1] == 1e-4 and pb.x_lb[-1] == 0.
+
+
+def _slsqp(pb, ipm, res, b, p):
+    """The reference's NLP in its own variables [xa_0 (theta_0 only) .. | ua | e] with x_0 substituted."""
+    N, nxa, nua, nx = pb.N, pb.nxa, pb.nua, pb.nx
+    x0s = res['x0'][b]
+    v_ipm = ipm.to_v(res)[b]
+    free = np.ones(pb.n_v, dtype=bool)
+    free[:nx] = False
+
+    def full(w):
+        v = np.empty(pb.n_v)
+        v[:nx] = x0s
+        v[free] = w
+        return v
+
+    def split(v):
+        X = v[:(N + 1) * nxa].reshape(N + 1, nxa)
+        U = v[(N + 1) * nxa:(N + 1) * nxa + N * nua].reshape(N, nua)
+        return X, U, v[(N + 1) * nxa + N * nua:]
+
+    def obj(w):
+        X, U, E = split(full(w))
+        J = 0.
+        for k in range(N):
+            zk = np.concatenate([X[k], U[k]])[None]
+            z = zk - pb.zrefa
+            J += float(z @ pb.Wza @ z.T) + pb._lp[0](zk)[0] + (float(E @ pb.We @ E) if pb.ne else 0.)
+        d = X[N][None] - pb.xrefNa
+        return J + float(d @ pb.WNa @ d.T) + pb._Vp[0](X[N][None])[0]
+
+    def eq(w):
+        X, U, E = split(full(w))
+        return np.concatenate([X[k + 1] - pb.phia(X[k][None], U[k][None], np.atleast_2d(p))[0] for k in range(N)])
+
+    def ineq(w):                                             # >= 0
+        X, U, E = split(full(w))
+        out = []
+        for k in range(N):
+            d = pb._d(np.concatenate([X[k], U[k]])[None], E[None])[0]
+            out += [np.where(np.isfinite(pb.dub), pb.dub - d, 1.), np.where(np.isfinite(pb.dlb), d - pb.dlb, 1.)]
+        return np.concatenate(out)
+    lb = np.concatenate([np.tile(pb.x_lb, N + 1), np.tile(pb.u_lb, N), np.zeros(pb.ne)])[free]
+    ub = np.concatenate([np.tile(pb.x_ub, N + 1), np.tile(pb.u_ub, N), pb.e_ub if pb.ne else np.zeros(0)])[free]
+    w0 = np.clip(v_ipm[free] + 1e-3 * np.random.default_rng(b).normal(size=free.sum()), lb, ub)
+    cons = [{'type': 'eq', 'fun': eq}] + ([{'type': 'ineq', 'fun': ineq}] if pb.nrow else [])
+    sol = minimize(obj, w0, method='SLSQP', bounds=list(zip(lb, ub)), constraints=cons, options={'ftol': 1e-11, 'maxiter': 800})
+    assert sol.success, sol.message
+    np.testing.assert_allclose(sol.fun, obj(v_ipm[free]), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(sol.x, v_ipm[free], rtol=5e-4, atol=5e-4)
+    assert np.abs(eq(v_ipm[free])).max() < 1e-8 and ineq(v_ipm[free]).min() > -1e-6   # bounds are relaxed by 1e-8 max(1, |b|) like IPOPT
+
+
+def test_hard_constraint_vs_slsqp():
+    spec = dict(C2H, N=6, constraint=dict(expr=['X * S'], lb=[-np.inf], ub=[20.]))
+    pb = oracle_gen(spec)
+    ipm = GenIpm(pb)
+    res = ipm.solve(c2_x0(1), spec['p'])
+    assert res['status'][0] == 1 and res['kkt'][0] <= 1e-8
+    assert (res['X'][0, :-1, 0] * res['X'][0, :-1, 1]).max() > 19.99       # active
+    _slsqp(pb, ipm, res, 0, spec['p'])
+
+
+def test_path_following_with_soft_constraint_vs_slsqp():
+    spec = dict(C5S, N=6, constraint=dict(C5S['constraint'], weight=[[10.]]))    # milder penalty: SLSQP-friendly scaling
+    pb = oracle_gen(spec)
+    ipm = GenIpm(pb)
+    x0 = c5_x0(4)
+    res = ipm.solve(x0, [])
+    assert np.all(res['status'] == 1) and np.all(res['kkt'] <= 1e-8)
+    b = int(np.argmax(res['E'][:, 0]))
+    assert res['E'][b, 0] > 1e-3                                           # the slack is in use
+    _slsqp(pb, ipm, res, b, np.zeros(0))
+    lam = ipm.lam_g(res)
+    assert lam.shape == (4, pb.n_g)
+    assert np.all(lam.reshape(4, pb.N, -1)[:, :, pb.nxa + 1] == 0.)         # the dropped row -c - e <= inf
+
+
+# ---- expression compiler (host) vs a Python model of the device interpreter -------------------------------------------
+def _run(prog, x, u, p):
+    n = int(prog[0])
+    st = []
+    for q in range(1, 1 + n, 2):
+        op, a = int(prog[q]), prog[q + 1]
+        if op == 0: st.append(a)
+        elif op == 1: st.append(x[int(a)])
+        elif op == 2: st.append(u[int(a)])
+        elif op == 3: st.append(p[int(a)])
+        elif op in (10, 11, 12, 13):
+            b, c = st.pop(), st.pop()
+            st.append({10: c + b, 11: c - b, 12: c * b, 13: c / b}[op])
+        else:
+            b = st.pop()
+            st.append({14: -b, 15: b * b, 16: math.sin(b), 17: math.cos(b), 18: math.exp(b),
+                       19: math.log(b) if b > 0 else float('nan'), 20: math.sqrt(abs(b)), 21: b ** int(a)}[op])
+        assert len(st) <= 8
+    assert len(st) == 1
+    return st[0]
+
+
+def test_expression_compiler():
+    from hilo_mpc_amd import Model, expr
+    m = Model('robot6')
+    vx, vy, psi = m.x['vx'], m.x['vy'], m.x[4]
+    a = m.u['a']
+    e = (vx ** 2 + vy ** 2) / (1. + expr.cos(psi) ** 2) - 3 * a + expr.sqrt(vx * vx + 1.) ** -1 + expr.exp(-vy) * expr.log(2. + a * a)
+    x = [.1, 1.2, -.3, .7, .4, 0.]
+    u = [.9, -.2]
+    val = (1.2 ** 2 + .7 ** 2) / (1 + math.cos(.4) ** 2) - 3 * .9 + 1 / math.sqrt(1.2 * 1.2 + 1) + math.exp(-.7) * math.log(2 + .81)
+    assert _run(e.program(), x, u, []) == pytest.approx(val, rel=1e-14)
+    blk = expr.compile_block([vx + 1., 2 * vy])
+    assert blk[0] == 6 and blk[7] == 6 and len(blk) == 14
+    theta = expr.Expr('theta', value=0, name='theta')
+    assert _run(expr.sin(2 * theta).program(theta_index=6), x + [.25], u, []) == pytest.approx(math.sin(.5))
+    with pytest.raises(ValueError, match="only appear in path references"):
+        (theta + vx).program()
+    with pytest.raises(NotImplementedError):
+        vx ** 2.5
+    with pytest.raises(KeyError):
+        m.x['nope']
