@@ -11,7 +11,7 @@ one batched `NMPC.optimize()` (one `hilo_nmpc_solve` launch) + the plant step + 
 (u0, status, iters); `value` = solved MPC instances per second over the whole job, inputs resident in HBM.
 
 The JSON line also carries
-  roofline      the dominant kernel (nmpc_solve_kernel) against the fp64 roof it is bound by (the solve
+  roofline      the dominant kernel (ocp_solve_kernel<NmpcTrack<Chemostat4>,64>) against the fp64 roof it is bound by (the solve
                 is fp64-VALU/latency bound, its compulsory HBM traffic is ~4 KB per solve) - algorithmic flops per
                 launch / HIP-event time of the launches; `roofline_hbm` gives the HBM view for transparency
   cpu_baseline  the oracle's dense interior-point solver (numpy port of the same algorithm; the reference's
@@ -168,7 +168,7 @@ def main():
                        "mean_ipm_iters": mean_iters, "frac_status_1_or_2": ok_frac, "max_kkt_error": kkt_max},
             "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(),
-                         "kernel": "nmpc_solve_kernel<Chemostat4>", "kernel_ms": kern_ms,
+                         "kernel": "ocp_solve_kernel<NmpcTrack<Chemostat4>, 64>", "kernel_ms": kern_ms,
                          "note": "fp64 roof: MI355X fp64 vector peak == fp64 MFMA peak = 78.6 TFLOP/s; the kernel is "
                                  "fp64 VALU/latency bound (no MFMA), algorithmic flops = B * mean_iters * N * "
                                  "(F_ric + F_dyn), see DESIGN.md"},
@@ -178,10 +178,10 @@ def main():
                              "note": "compulsory bytes only (iterate + parameters in/out); not the binding roof"},
         }
         if not args.no_cpu_baseline:
-            ns = 24
-            v, secs = cpu_baseline(spec, c2_x0(ns), 4)
+            ns = 32
+            v, secs = cpu_baseline(spec, c2_x0(ns), 6)
             out["cpu_baseline"] = {"value": v, "unit": "steps/s", "cores": 1, "kind": "port",
-                                   "sample": f"{ns} instances x 4 warm-started closed-loop steps of the same C2 "
+                                   "sample": f"{ns} instances x 6 warm-started closed-loop steps of the same C2 "
                                              f"workload with the oracle's numpy dense interior-point solver "
                                              f"({secs:.1f} s); the reference's CasADi/IPOPT is not installable",
                                    "host_cpus": os.cpu_count()}

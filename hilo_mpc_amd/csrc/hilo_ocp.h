@@ -31,6 +31,13 @@ constexpr int OCP_MAXNC = 4;  // nonlinear inequality rows per stage
 #ifndef HILO_OCP_MINW
 #define HILO_OCP_MINW 1
 #endif
+// the four large phases (derivatives, Riccati, values, restoration) are real function calls: one copy of each in the
+// binary (they have 2-3 call sites), shorter live ranges; -DHILO_OCP_INLINE_PHASES inlines them (tuning experiments)
+#ifdef HILO_OCP_INLINE_PHASES
+#define OCP_PHASE __attribute__((always_inline))
+#else
+#define OCP_PHASE __attribute__((noinline))
+#endif
 constexpr int OCP_TPB = HILO_OCP_TPB;  // threads per instance (one or more waves)
 constexpr int OCP_NCOST = 2 * OCP_MAXNZ * OCP_MAXNZ + 4 * OCP_MAXNZ + 64;
 
@@ -126,6 +133,12 @@ struct Ocp {
   }
   __host__ __device__ static size_t lds_doubles(int N) { return fixed_doubles(N) + (BIG ? 0 : iter_doubles(N)); }
   __host__ __device__ static size_t ws_doubles(int N) { return BIG ? iter_doubles(N) : 0; }
+  // The non-inlined phases take (LDS base, workspace) and re-derive the pointer table: a struct argument would be
+  // passed through scratch memory per lane (measured: 380 MB of scratch writes per 1024-instance launch).
+  __device__ static int horizon_of(lds_double* base) {
+    return reinterpret_cast<const __attribute__((address_space(3))) OcpConst*>(base)->N;
+  }
+  __device__ static Lds carve(lds_double* base, double* ws) { return carve(base, ws, horizon_of(base)); }
   __device__ static Lds carve(lds_double* base, double* ws, int N) {
     Lds l;
     const size_t S = (size_t)(N + 1) * NZ;
@@ -177,8 +190,9 @@ struct Ocp {
 
   // ---- values only at a point Zp: defects cp_k = x_{k+1} - F_k(x_k,u_k), returns (f, theta = |c|_1) -------------
   // with inequality rows: theta also counts |d_k - sp_k| for the slacks sp; `dstore` (optional) receives d_k
-  __device__ __attribute__((noinline)) static void eval_values(const Lds l, cdp Zp, dp cp, double& f, double& theta,
+  __device__ OCP_PHASE static void eval_values(lds_double* lbase, double* ws, cdp Zp, dp cp, double& f, double& theta,
                                                                cdp sp = nullptr, dp dstore = nullptr) {
+    const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double fpart = 0.0, tpart = 0.0;
@@ -275,7 +289,8 @@ struct Ocp {
   }
 
   // ---- full derivative evaluation at Z: c, AB, grad, per-stage cost values, Lagrangian Hessian blocks --------
-  __device__ __attribute__((noinline)) static double eval_derivs(const Lds l) {
+  __device__ OCP_PHASE static double eval_derivs(lds_double* lbase, double* ws) {
+    const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     constexpr int GPW = COOP ? 64 / NDIR : 1;  // cooperative: lane groups of NDIR directions, GPW intervals per round
@@ -577,7 +592,8 @@ struct Ocp {
   // pivot block's Cholesky (redundantly per lane), feedback K, feed-forward kff, P_k, p_k.  The forward sweep runs
   // on closed-loop matrices prepared in parallel and keeps dx in registers (wave shuffles, no LDS round trip).
   // `resto`: feasibility-restoration step (H = I, zero gradient: least-norm d with J d = -c)
-  __device__ __attribute__((noinline)) static bool riccati(const Lds l, double mu, double delta, bool resto = false) {
+  __device__ OCP_PHASE static bool riccati(lds_double* lbase, double* ws, double mu, double delta, bool resto = false) {
+    const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N, t = threadIdx.x, T = blockDim.x;
     (void)mu;
@@ -789,7 +805,8 @@ struct Ocp {
   }
 
   // ---- feasibility restoration, simplified from W&B sec. 3.3 (same statement as oracle/nmpc.py::_restore) ------
-  __device__ __attribute__((noinline)) static bool restore(const Lds l, double mu, double tau, int nfilt, double theta_max) {
+  __device__ OCP_PHASE static bool restore(lds_double* lbase, double* ws, double mu, double tau, int nfilt, double theta_max) {
+    const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N, t = threadIdx.x, T = blockDim.x, SL = (N + 1) * NZ;
     double th = 0.0;
@@ -799,7 +816,7 @@ struct Ocp {
     th = block_reduce<OpSum>(th, l.red);
     const double th_start = th;
     for (int it = 0; it < 50; ++it) {
-      riccati(l, mu, 0.0, true);
+      riccati(lbase, ws, mu, 0.0, true);
       double a = 1.0;
       if constexpr (NC > 0) {
         for (int e = t; e < N * NC; e += T) {
@@ -825,7 +842,7 @@ struct Ocp {
         if constexpr (NC > 0)
           for (int e = t; e < N * NC; e += T) l.cst[e] = l.cs[e] + alpha * l.cds[e];
         __syncthreads();
-        eval_values(l, l.Zt, l.ct, ft, tht, l.cst);
+        eval_values(lbase, ws, l.Zt, l.ct, ft, tht, l.cst);
         if (isfinite(tht) && tht <= (1.0 - 1e-4 * alpha) * th) { ok = true; break; }
         alpha *= 0.5;
       }
@@ -842,7 +859,7 @@ struct Ocp {
           if (th >= l.filt[2 * q] && ph >= l.filt[2 * q + 1]) { acc = false; break; }
         if (acc) return true;
       }
-      eval_derivs(l);
+      eval_derivs(lbase, ws);
     }
     return false;
   }
@@ -870,7 +887,8 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
   const int64_t b = blockIdx.x;
   if (b >= batch) return;
   const int N = pcg->N;
-  typename S::Lds l = S::carve(lds_raw, ws ? ws + b * (int64_t)S::ws_doubles(N) : nullptr, N);
+  double* const wsb = ws ? ws + b * (int64_t)S::ws_doubles(N) : nullptr;
+  typename S::Lds l = S::carve(lds_raw, wsb, N);
   {  // problem constants into LDS: every later access is an LDS read instead of a global load
     const double* src = reinterpret_cast<const double*>(pcg);
     lds_double* dst = lds_raw;
@@ -928,7 +946,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
   __syncthreads();
   if constexpr (NC > 0) {  // IPOPT: slacks start at d(w_0), pushed into the interior of their bounds
     double f_, th_;
-    S::eval_values(l, l.Z, l.ct, f_, th_, nullptr, l.cd);
+    S::eval_values(lds_raw, wsb, l.Z, l.ct, f_, th_, nullptr, l.cd);
     __syncthreads();
     for (int e = t; e < N * NC; e += T) {
       const int m = e % NC;
@@ -960,7 +978,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
   double E0 = INFINITY, fval = 0.0;
 
   for (it = 0;; ++it) {
-    fval = S::eval_derivs(l);
+    fval = S::eval_derivs(lds_raw, wsb);
     OCP_TICK(PH_DERIV)
     double th0 = 0.0;
     for (int e = t; e < N * NX; e += T) th0 += fabs(l.c[e]);
@@ -995,7 +1013,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     bool first_try = true, solved = false;
     for (;;) {
       tprof[PH_NRIC] += 1;
-      if (S::riccati(l, mu, delta)) { solved = true; break; }
+      if (S::riccati(lds_raw, wsb, mu, delta)) { solved = true; break; }
       if (first_try) {
         delta = delta_last == 0.0 ? pc.delta_w_0 : fmax(pc.delta_w_min, pc.kappa_w_minus * delta_last);
         first_try = false;
@@ -1073,7 +1091,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       __syncthreads();
       double ft, tht;
       tprof[PH_NLS] += 1;
-      S::eval_values(l, l.Zt, l.ct, ft, tht, l.cst);
+      S::eval_values(lds_raw, wsb, l.Zt, l.ct, ft, tht, l.cst);
       const double pht = ft + S::eval_barrier(l, l.Zt, mu, l.cst);
       bool ok = isfinite(pht) && isfinite(tht) && tht <= theta_max;
       if (ok) {
@@ -1118,7 +1136,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       __syncthreads();
     }
     if (do_resto) {
-      if (!S::restore(l, mu, tau, nfilt, theta_max)) { st = HILO_STATUS_RESTORATION_FAILED; break; }
+      if (!S::restore(lds_raw, wsb, mu, tau, nfilt, theta_max)) { st = HILO_STATUS_RESTORATION_FAILED; break; }
       // IPOPT after restoration: equality multipliers reset (constr_mult_reset_threshold = 0), bound multipliers
       // reset to 1 when they exceed bound_mult_reset_threshold = 1000
       double zm = 0.0;

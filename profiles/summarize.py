@@ -13,7 +13,7 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 timed = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 here = os.path.dirname(os.path.abspath(__file__))
-KEY = sys.argv[4] if len(sys.argv) > 4 else 'nmpc_solve_kernel'
+KEY = sys.argv[4] if len(sys.argv) > 4 else 'ocp_solve_kernel'
 
 out = {'tag': tag, 'kernel': KEY}
 stats = os.path.join(src, 'trace', f'{tag}_kernel_stats.csv')

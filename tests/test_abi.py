@@ -31,7 +31,7 @@ def test_model_table_matches_device_zoo():
     from hilo_mpc_amd.model import ZOO
     lib = _lib.lib()
     for name in ZOO:
-        if name == 'lti':
+        if name in ('lti', 'chemostat4_gp'):          # caller-defined dims / built by Model.substitute_from
             continue
         m = Model(name)
         d = [C.c_int() for _ in range(5)]
