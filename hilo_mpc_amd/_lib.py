@@ -35,7 +35,8 @@ class NmpcDesc(C.Structure):
                [('n_path_stage', C.c_int32), ('n_path_term', C.c_int32)] + \
                [(n, C.c_void_p) for n in ('path_stage_idx', 'path_stage_W', 'path_term_idx', 'path_term_W', 'path_prog')] + \
                [(n, C.c_int32) for n in ('path_prog_len', 'n_con', 'con_soft', 'con_prog_len')] + \
-               [(n, C.c_void_p) for n in ('con_prog', 'con_lb', 'con_ub', 'con_weight', 'con_max_violation')]
+               [(n, C.c_void_p) for n in ('con_prog', 'con_lb', 'con_ub', 'con_weight', 'con_max_violation')] + \
+               [('collocation_degree', C.c_int32), ('reserved2', C.c_int32), ('coll_A', C.c_void_p), ('coll_D', C.c_void_p)]
 
 
 class MheDesc(C.Structure):

@@ -1,0 +1,224 @@
+// Direct collocation (the reference's default `integration_method`) as an implicit shooting map.
+//
+// Reference transcription (hilo_mpc/util/modeling.py:1091-1211, hilo_mpc/modules/controller/mpc.py:1307-1372, :1497-1518):
+// per interval the d collocation states x_{k,i} are decision variables with
+//     dt f(x_{k,i}, u_k) - sum_{j=0..d} C[j,i] x_{k,j} = 0,  x_{k,0} = x_k,      x_{k+1} - sum_j D_j x_{k,j} = 0.
+// Here the square collocation system of an interval is solved to round-off inside the shooting map (Newton in the
+// Runge-Kutta form  X_i = x + dt sum_j A_ij f(X_j, u),  A = (C_hat^T)^-1, C_hat = C[1:,1:]: same equations, pre-multiplied by
+// a constant matrix so that the Newton matrix I - dt (A (x) I) blockdiag(f_x) needs no pivoting), and the map
+// x+ = sum_j D_j X_j is differentiated exactly: two further Newton sweeps in second-order Taylor arithmetic on the converged
+// point give the first- and second-order coefficients (the k-th sweep fixes the k-th coefficient).  The NLP the
+// interior-point engine sees therefore has the reference's KKT points (the collocation states and their multipliers are
+// reconstructed on output); the iterates differ from a solver that carries the collocation states as variables, and the
+// box of the state is enforced at the shooting nodes, not at the interior collocation points.
+#pragma once
+#include "hilo_models.h"
+
+namespace hilo {
+
+constexpr int COLL_MAXD = 3;
+
+struct CollData {  // host-computed basis (hilo_mpc_amd/nmpc.py restates modeling.py:1091-1127)
+  int d, pad;
+  double A[COLL_MAXD * COLL_MAXD];   // Runge-Kutta matrix of the collocation method
+  double Dc[COLL_MAXD + 1];          // continuity weights D_0..D_d
+};
+
+template <class M, int D>
+struct Colloc {
+  static constexpr int NX = M::NX, NU = M::NU, DN = D * NX;
+
+  // in-place LU without pivoting of the DN x DN matrix a (row-major)
+  __device__ __forceinline__ static void lu(double* a) {
+#pragma unroll
+    for (int k = 0; k < DN; ++k) {
+      const double ip = 1.0 / a[k * DN + k];
+#pragma unroll
+      for (int i = k + 1; i < DN; ++i) {
+        const double f = a[i * DN + k] * ip;
+        a[i * DN + k] = f;
+#pragma unroll
+        for (int j = k + 1; j < DN; ++j) a[i * DN + j] -= f * a[k * DN + j];
+      }
+    }
+  }
+  __device__ __forceinline__ static void lu_solve(const double* a, double* b) {
+#pragma unroll
+    for (int i = 1; i < DN; ++i) {
+      double s = b[i];
+#pragma unroll
+      for (int j = 0; j < i; ++j) s -= a[i * DN + j] * b[j];
+      b[i] = s;
+    }
+#pragma unroll
+    for (int i = DN - 1; i >= 0; --i) {
+      double s = b[i];
+#pragma unroll
+      for (int j = i + 1; j < DN; ++j) s -= a[i * DN + j] * b[j];
+      b[i] = s / a[i * DN + i];
+    }
+  }
+  // solve a^T y = b with the same factors (a = L U  =>  a^T = U^T L^T)
+  __device__ __forceinline__ static void lu_solve_t(const double* a, double* b) {
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      double s = b[i];
+#pragma unroll
+      for (int j = 0; j < i; ++j) s -= a[j * DN + i] * b[j];
+      b[i] = s / a[i * DN + i];
+    }
+#pragma unroll
+    for (int i = DN - 1; i >= 0; --i) {
+      double s = b[i];
+#pragma unroll
+      for (int j = i + 1; j < DN; ++j) s -= a[j * DN + i] * b[j];
+      b[i] = s;
+    }
+  }
+
+  // Newton matrix I - dt (A (x) I) blockdiag(J_j) at the points X, and F_j = f(X_j, u)
+  __device__ __forceinline__ static void newton_matrix(const CollData& cd, const double* X, const double* u, const double* p,
+                                                       double dt, double* mat, double* F) {
+    double J[D][NX * NX];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      Dual<NX> xd[NX], fd[NX];
+#pragma unroll
+      for (int a = 0; a < NX; ++a) {
+        xd[a] = Dual<NX>(X[j * NX + a]);
+        xd[a].d[a] = 1.0;
+      }
+      M::ode(xd, u, p, dt, fd);
+#pragma unroll
+      for (int m = 0; m < NX; ++m) {
+        F[j * NX + m] = fd[m].v;
+#pragma unroll
+        for (int a = 0; a < NX; ++a) J[j][m * NX + a] = fd[m].d[a];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int m = 0; m < NX; ++m)
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+          for (int a = 0; a < NX; ++a)
+            mat[(i * NX + m) * DN + j * NX + a] = ((i == j && m == a) ? 1.0 : 0.0) - dt * cd.A[i * D + j] * J[j][m * NX + a];
+  }
+
+  // collocation states of one interval (values); leaves the LU factors of the Newton matrix at the solution in `mat`
+  __device__ __forceinline__ static void solve(const CollData& cd, const double* x, const double* u, const double* p, double dt,
+                                               double* X, double* mat) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int m = 0; m < NX; ++m) X[i * NX + m] = x[m];
+    for (int it = 0; it < 12; ++it) {
+      double F[DN], R[DN];
+      newton_matrix(cd, X, u, p, dt, mat, F);
+      double scale = 1.0;
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int m = 0; m < NX; ++m) {
+          double r = X[i * NX + m] - x[m];
+#pragma unroll
+          for (int j = 0; j < D; ++j) r -= dt * cd.A[i * D + j] * F[j * NX + m];
+          R[i * NX + m] = -r;
+          scale = fmax(scale, fabs(X[i * NX + m]));
+        }
+      lu(mat);
+      lu_solve(mat, R);
+      double dmax = 0.0;
+#pragma unroll
+      for (int q = 0; q < DN; ++q) {
+        X[q] += R[q];
+        dmax = fmax(dmax, fabs(R[q]));
+      }
+      // iterate to round-off: the factors kept in `mat` then belong to a point within 1e-13 of the solution, which is what
+      // makes the Taylor sweeps below exact.  A NaN (singular pivot) also leaves the loop.
+      if (!(dmax > 1e-13 * scale)) break;
+    }
+  }
+
+  template <class T>
+  __device__ __forceinline__ static void step(const CollData& cd, const T* x, const T* u, const double* p, double dt, T* xn) {
+    double xv[NX], uv[NU > 0 ? NU : 1], X[DN], mat[DN * DN];
+#pragma unroll
+    for (int m = 0; m < NX; ++m) xv[m] = value(x[m]);
+#pragma unroll
+    for (int a = 0; a < NU; ++a) uv[a] = value(u[a]);
+    solve(cd, xv, uv, p, dt, X, mat);
+    if constexpr (std::is_same<T, double>::value) {
+#pragma unroll
+      for (int m = 0; m < NX; ++m) {
+        double s = cd.Dc[0] * xv[m];
+#pragma unroll
+        for (int i = 0; i < D; ++i) s += cd.Dc[i + 1] * X[i * NX + m];
+        xn[m] = s;
+      }
+    } else {
+      Jet2 XJ[DN];
+#pragma unroll
+      for (int q = 0; q < DN; ++q) XJ[q] = Jet2(X[q]);
+#pragma unroll 1
+      for (int rep = 0; rep < 2; ++rep) {
+        Jet2 F[DN];
+#pragma unroll
+        for (int j = 0; j < D; ++j) M::ode(XJ + j * NX, u, p, dt, F + j * NX);
+        double ra[DN], rb[DN];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int m = 0; m < NX; ++m) {
+            Jet2 r = XJ[i * NX + m] - x[m];
+#pragma unroll
+            for (int j = 0; j < D; ++j) r = r - (dt * cd.A[i * D + j]) * F[j * NX + m];
+            ra[i * NX + m] = -r.a;
+            rb[i * NX + m] = -r.b;
+          }
+        lu_solve(mat, ra);
+        lu_solve(mat, rb);
+#pragma unroll
+        for (int q = 0; q < DN; ++q) {
+          XJ[q].a += ra[q];
+          XJ[q].b += rb[q];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < NX; ++m) {
+        Jet2 s = cd.Dc[0] * x[m];
+#pragma unroll
+        for (int i = 0; i < D; ++i) s = s + cd.Dc[i + 1] * XJ[i * NX + m];
+        xn[m] = s;
+      }
+    }
+  }
+
+  // multipliers of the reference's collocation rows G_i = dt f(X_i,u) - sum_j C[j,i] X_j at a KKT point with inactive
+  // collocation-state bounds: G = -(C_hat^T (x) I) R with R the Runge-Kutta residual solved above, so
+  //   G_X^T mu = (D (x) lambda)   <=>   mu = -(A^T (x) I) Mat^-T (D (x) lambda)
+  __device__ static void multipliers(const CollData& cd, const double* X, const double* u, const double* p, double dt,
+                                     const double* lam, double* mu) {
+    double mat[DN * DN], F[DN], y[DN];
+    newton_matrix(cd, X, u, p, dt, mat, F);
+    lu(mat);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int a = 0; a < NX; ++a) y[i * NX + a] = cd.Dc[i + 1] * lam[a];
+    lu_solve_t(mat, y);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int a = 0; a < NX; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) s -= cd.A[j * D + i] * y[j * NX + a];
+        mu[i * NX + a] = s;
+      }
+  }
+};
+
+}  // namespace hilo

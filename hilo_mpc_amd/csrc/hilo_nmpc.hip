@@ -10,101 +10,9 @@
 #include <string.h>
 
 #include "hilo_nmpc_gen.h"
+#include "hilo_nmpc_track.h"
 
 namespace hilo {
-
-// Policy: tracking NMPC with quadratic costs.  pc.cost = [Wz | zref | WN | xrefN | Wdu | has_du],
-// par = [model parameters | u_old (scaled)].
-template <class M>
-struct NmpcTrack {
-  static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU, NPAR = M::NP + M::NU, NSD = 0;
-  static constexpr bool FIX_X0 = true;
-  static constexpr bool BIG = false;  // iterate in LDS
-  static constexpr int NC = 0, NXV = NX, NX0 = NX, NU0 = NU;  // no inequality rows; plain [x | u] decision vector
-  static constexpr bool COOP = model_has_ext<M>::value;  // learned term in the model: lanes share its kernel sum
-  static constexpr bool QUAD_COST = true;  // gradient / Hessian of the stage cost in closed form (cost_grad, cost_hess)
-  static constexpr int O_WZ = 0, O_ZREF = O_WZ + NZ * NZ, O_WN = O_ZREF + NZ, O_XREFN = O_WN + NX * NX,
-                       O_WDU = O_XREFN + NX, O_HASDU = O_WDU + NU * NU, O_END = O_HASDU + 1;
-
-  template <class T, class E>
-  __device__ __forceinline__ static void dyn(const OcpConst& pc, const double* par, const double*, int, const T* x,
-                                             const T* u, T* xn, const E& ext) {
-    T xp[NX], up[NU > 0 ? NU : 1], xo[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xp[i] = x[i] * pc.sz[i];
-#pragma unroll
-    for (int i = 0; i < NU; ++i) up[i] = u[i] * pc.sz[NX + i];
-    model_step<M>(pc.order, pc.nsub, xp, up, par, pc.dt, xo, ext);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]);
-  }
-
-  template <class T>
-  __device__ __forceinline__ static T stage_cost(const OcpConst& pc, const double* par, const double*, int k,
-                                                 const T* x, const T* u) {
-    T z[NZ];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) z[i] = x[i] - pc.cost[O_ZREF + i];
-#pragma unroll
-    for (int i = 0; i < NU; ++i) z[NX + i] = u[i] - pc.cost[O_ZREF + NX + i];
-    T acc = T(0.0);
-#pragma unroll
-    for (int i = 0; i < NZ; ++i) {
-      T s = T(0.0);
-#pragma unroll
-      for (int j = 0; j < NZ; ++j) s = s + pc.cost[O_WZ + i * NZ + j] * z[j];
-      acc = acc + z[i] * s;
-    }
-    if (k == 0 && pc.cost[O_HASDU] != 0.0) {  // mpc.py:1631-1635: the change penalty only sees u_old in interval 0
-      T d[NU > 0 ? NU : 1];
-#pragma unroll
-      for (int i = 0; i < NU; ++i) d[i] = u[i] - par[M::NP + i];
-#pragma unroll
-      for (int i = 0; i < NU; ++i) {
-        T s = T(0.0);
-#pragma unroll
-        for (int j = 0; j < NU; ++j) s = s + pc.cost[O_WDU + i * NU + j] * d[j];
-        acc = acc + d[i] * s;
-      }
-    }
-    return acc;
-  }
-
-  // d/dz_i and d2/dz_i dz_j of (z - zref)^T Wz (z - zref) [+ (u - u_old)^T Wdu (u - u_old) in interval 0]
-  __device__ __forceinline__ static double cost_grad(const OcpConst& pc, const double* par, int k, int i, const double* z) {
-    double g = 0.0;
-#pragma unroll
-    for (int j = 0; j < NZ; ++j) g += (pc.cost[O_WZ + i * NZ + j] + pc.cost[O_WZ + j * NZ + i]) * (z[j] - pc.cost[O_ZREF + j]);
-    if (k == 0 && i >= NX && pc.cost[O_HASDU] != 0.0) {
-#pragma unroll
-      for (int j = 0; j < NU; ++j)
-        g += (pc.cost[O_WDU + (i - NX) * NU + j] + pc.cost[O_WDU + j * NU + (i - NX)]) * (z[NX + j] - par[M::NP + j]);
-    }
-    return g;
-  }
-  __device__ __forceinline__ static double cost_hess(const OcpConst& pc, int k, int i, int j) {
-    double h = pc.cost[O_WZ + i * NZ + j] + pc.cost[O_WZ + j * NZ + i];
-    if (k == 0 && i >= NX && j >= NX && pc.cost[O_HASDU] != 0.0)
-      h += pc.cost[O_WDU + (i - NX) * NU + (j - NX)] + pc.cost[O_WDU + (j - NX) * NU + (i - NX)];
-    return h;
-  }
-
-  template <class T>
-  __device__ __forceinline__ static T term_cost(const OcpConst& pc, const double*, const double*, const T* x) {
-    T z[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) z[i] = x[i] - pc.cost[O_XREFN + i];
-    T acc = T(0.0);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      T s = T(0.0);
-#pragma unroll
-      for (int j = 0; j < NX; ++j) s = s + pc.cost[O_WN + i * NX + j] * z[j];
-      acc = acc + z[i] * s;
-    }
-    return acc;
-  }
-};
 
 // ---- closed-loop helper for benchmarks / tests: x+ = Phi(x, u) with the controller's own shooting map ------------
 template <class M>
@@ -148,6 +56,10 @@ struct hilo_nmpc {
   int nu_out;        // width of the returned first input (model inputs, without the virtual path input)
   double* ws;        // iterate workspace of BIG variants [ws_batch][ws_bytes]
   int64_t ws_batch;
+  const CollVariant* coll;   // collocation variant of the tracking policy or NULL
+  double *vc, *lamc;         // the engine's compact [x | u] solution and defect multipliers (collocation output pass)
+  int64_t vc_batch;
+  int n_vc;                  // (N+1) nx + N nu
   double* v_warm;    // [warm_batch][n_v] device: previous solution (mpc.py:725-726)
   int64_t warm_batch;
   int warm_valid;
@@ -179,6 +91,8 @@ extern "C" void hilo_nmpc_destroy(hilo_nmpc* h) {
   if (h->prof) (void)hipFree(h->prof);
   if (h->ext_pack) (void)hipFree(h->ext_pack);
   if (h->ws) (void)hipFree(h->ws);
+  if (h->vc) (void)hipFree(h->vc);
+  if (h->lamc) (void)hipFree(h->lamc);
   delete h;
 }
 
@@ -241,6 +155,17 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
                                 "inequality row(s) per stage at horizon %d in this build", d->model_id, nth, ne, nrow, d->N);
     lds = gv->lds_bytes(d->N);
   }
+  const CollVariant* cv = nullptr;
+  if (d->collocation_degree > 0) {
+    if (general || d->learned)
+      return fail(HILO_ENOTSUP, "collocation together with path following / stage constraints / learned terms is not built");
+    HILO_REQUIRE(d->coll_A && d->coll_D, "hilo_nmpc_create: collocation needs the basis (coll_A, coll_D)");
+    cv = nmpc_coll_find(d->model_id, d->collocation_degree);
+    if (!cv)
+      return fail(HILO_ENOTSUP, "no collocation instantiation for model %d with degree %d in this build (degree 3 for the "
+                                "continuous zoo models)", d->model_id, d->collocation_degree);
+    lds = cv->lds_bytes(d->N);
+  }
   if (lds > 160 * 1024)
     return fail(HILO_ENOTSUP, "horizon %d needs %zu B of LDS per instance (limit 163840)", d->N, lds);
   // engine dimensions: [model x | theta | e], [model u | u_theta]
@@ -250,8 +175,11 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   memset(h, 0, sizeof(*h));
   h->device = device; h->model_id = d->model_id; h->nx = nx; h->nu = nu; h->np = np; h->N = d->N;
   h->gen = gv; h->nu_out = nu;
-  h->n_v = (d->N + 1) * nxv + d->N * nue + ne;   // mpc.py:1440 (+ the soft-constraint slack, :1529-1537)
-  h->n_g = d->N * (nxv + n_con_ref);             // mpc.py:1667-1669, :1707-1725
+  h->coll = cv;
+  h->n_vc = (d->N + 1) * nx + d->N * nu;
+  const int dn = cv ? cv->degree * nx : 0;
+  h->n_v = (d->N + 1) * nxv + d->N * nue + ne + d->N * dn;   // mpc.py:1440-1443 (+ the soft-constraint slack, :1529-1537)
+  h->n_g = d->N * (nxv + n_con_ref + dn);                    // mpc.py:1657-1669, :1707-1725
   h->lds_bytes = lds;
   OcpConst& c = h->host;
   memset(&c, 0, sizeof(c));
@@ -259,6 +187,11 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   c.N = d->N; c.order = d->erk_order >= 1 ? d->erk_order : 4; c.nsub = d->n_sub >= 1 ? d->n_sub : 1;
   c.dt = d->dt;
   c.flags = 1;  // lam_g in the reference's convention (terminal cost on Phi_{N-1}, mpc.py:1682)
+  if (cv) {
+    c.coll.d = cv->degree;
+    for (int i = 0; i < cv->degree * cv->degree; ++i) c.coll.A[i] = d->coll_A[i];
+    for (int i = 0; i <= cv->degree; ++i) c.coll.Dc[i] = d->coll_D[i];
+  }
   if (d->max_iter > 0) c.max_iter = d->max_iter;
   if (d->acceptable_iter > 0) c.acceptable_iter = d->acceptable_iter;
   double sx[OCP_MAXNX], su[OCP_MAXNU];
@@ -391,6 +324,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
       for (int i = 0; i < nu; ++i) g[(d->N + 1) * nxv + k * nue + i] = (d->u_guess ? d->u_guess[i] : 0.0) / su[i];
       if (nth) g[(d->N + 1) * nxv + k * nue + nu] = d->u_pf_lb + 0.0001;                      // mpc.py:1195
     }
+    for (int q = 0; q < d->N * dn; ++q) g[h->n_vc + q] = (d->x_guess ? d->x_guess[q % nx] : 0.0) / sx[q % nx];   // mpc.py:1321
     e = hipMemcpy(h->v_guess, g, sizeof(double) * h->n_v, hipMemcpyHostToDevice);
     delete[] g;
   }
@@ -477,7 +411,23 @@ extern "C" int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch, const double* x0, co
     else { vstart = h->v_guess; vstride = 0; }
   }
   int rc = HILO_ENOTSUP;
-  if (h->gen) {
+  if (h->coll) {
+    if (h->vc_batch != batch) {
+      if (h->vc) HILO_HIP_CHECK(hipFree(h->vc));
+      if (h->lamc) HILO_HIP_CHECK(hipFree(h->lamc));
+      h->vc = h->lamc = nullptr;
+      hipError_t e = hipMalloc((void**)&h->vc, sizeof(double) * (size_t)h->n_vc * batch);
+      if (e == hipSuccess) e = hipMalloc((void**)&h->lamc, sizeof(double) * (size_t)h->N * h->nx * batch);
+      if (e != hipSuccess) return fail(HILO_ENOMEM, "collocation output buffers: %s", hipGetErrorString(e));
+      h->vc_batch = batch;
+    }
+    // the engine reads the [x | u] head of each (full-layout) start row and writes its compact solution
+    GenLaunchArgs a{h->dev, batch, x0, h->par_buf, (int64_t)(h->np + h->nu), vstart, vstride, h->vc, f_opt, h->lamc, u0,
+                    status, iters, kkt, h->prof, h->lds_bytes, s, nullptr};
+    rc = h->coll->launch(a);
+    if (!rc) rc = h->coll->output(h->dev, batch, h->N, h->vc, lam_g ? h->lamc : nullptr, h->par_buf, (int64_t)(h->np + h->nu),
+                                  v_opt, lam_g, s);
+  } else if (h->gen) {
     const size_t wsb = h->gen->ws_bytes(h->N);
     if (wsb && h->ws_batch != batch) {
       if (h->ws) HILO_HIP_CHECK(hipFree(h->ws));

@@ -214,6 +214,17 @@ struct GenVariant {
 // smallest variant that covers the request and whose LDS footprint at horizon N fits (LDS variants are preferred)
 const GenVariant* nmpc_gen_find(int model_id, int nth, int ne, int nc_needed, int N);
 
+// collocation variants of the tracking policy (hilo_nmpc_coll.hip)
+struct CollVariant {
+  int model_id, degree;
+  size_t (*lds_bytes)(int N);
+  int (*launch)(const GenLaunchArgs& a);
+  // v = [compact v | collocation states], lam_g = per stage [collocation rows | continuity] from the engine's compact output
+  int (*output)(const OcpConst* dev, int64_t batch, int N, const double* vc, const double* lamc, const double* par,
+                int64_t par_stride, double* v, double* lam_g, hipStream_t s);
+};
+const CollVariant* nmpc_coll_find(int model_id, int degree);
+
 template <class PB>
 int gen_launch(const GenLaunchArgs& a) {
   if (a.lds_bytes > 64 * 1024)

@@ -1,0 +1,100 @@
+// Policy of the interior-point engine for tracking NMPC with quadratic costs (QuadraticCost, hilo_mpc/util/modeling.py:243-283).
+#pragma once
+#include "hilo_ocp.h"
+
+namespace hilo {
+
+// Policy: tracking NMPC with quadratic costs.  pc.cost = [Wz | zref | WN | xrefN | Wdu | has_du],
+// par = [model parameters | u_old (scaled)].
+template <class M>
+struct NmpcTrack {
+  static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU, NPAR = M::NP + M::NU, NSD = 0;
+  static constexpr bool FIX_X0 = true;
+  static constexpr bool BIG = false;  // iterate in LDS
+  static constexpr int NC = 0, NXV = NX, NX0 = NX, NU0 = NU;  // no inequality rows; plain [x | u] decision vector
+  static constexpr bool COOP = model_has_ext<M>::value;  // learned term in the model: lanes share its kernel sum
+  static constexpr bool QUAD_COST = true;  // gradient / Hessian of the stage cost in closed form (cost_grad, cost_hess)
+  static constexpr int O_WZ = 0, O_ZREF = O_WZ + NZ * NZ, O_WN = O_ZREF + NZ, O_XREFN = O_WN + NX * NX,
+                       O_WDU = O_XREFN + NX, O_HASDU = O_WDU + NU * NU, O_END = O_HASDU + 1;
+
+  template <class T, class E>
+  __device__ __forceinline__ static void dyn(const OcpConst& pc, const double* par, const double*, int, const T* x,
+                                             const T* u, T* xn, const E& ext) {
+    T xp[NX], up[NU > 0 ? NU : 1], xo[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xp[i] = x[i] * pc.sz[i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) up[i] = u[i] * pc.sz[NX + i];
+    model_step<M>(pc.order, pc.nsub, xp, up, par, pc.dt, xo, ext);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]);
+  }
+
+  template <class T>
+  __device__ __forceinline__ static T stage_cost(const OcpConst& pc, const double* par, const double*, int k,
+                                                 const T* x, const T* u) {
+    T z[NZ];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) z[i] = x[i] - pc.cost[O_ZREF + i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) z[NX + i] = u[i] - pc.cost[O_ZREF + NX + i];
+    T acc = T(0.0);
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+      T s = T(0.0);
+#pragma unroll
+      for (int j = 0; j < NZ; ++j) s = s + pc.cost[O_WZ + i * NZ + j] * z[j];
+      acc = acc + z[i] * s;
+    }
+    if (k == 0 && pc.cost[O_HASDU] != 0.0) {  // mpc.py:1631-1635: the change penalty only sees u_old in interval 0
+      T d[NU > 0 ? NU : 1];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) d[i] = u[i] - par[M::NP + i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        T s = T(0.0);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) s = s + pc.cost[O_WDU + i * NU + j] * d[j];
+        acc = acc + d[i] * s;
+      }
+    }
+    return acc;
+  }
+
+  // d/dz_i and d2/dz_i dz_j of (z - zref)^T Wz (z - zref) [+ (u - u_old)^T Wdu (u - u_old) in interval 0]
+  __device__ __forceinline__ static double cost_grad(const OcpConst& pc, const double* par, int k, int i, const double* z) {
+    double g = 0.0;
+#pragma unroll
+    for (int j = 0; j < NZ; ++j) g += (pc.cost[O_WZ + i * NZ + j] + pc.cost[O_WZ + j * NZ + i]) * (z[j] - pc.cost[O_ZREF + j]);
+    if (k == 0 && i >= NX && pc.cost[O_HASDU] != 0.0) {
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+        g += (pc.cost[O_WDU + (i - NX) * NU + j] + pc.cost[O_WDU + j * NU + (i - NX)]) * (z[NX + j] - par[M::NP + j]);
+    }
+    return g;
+  }
+  __device__ __forceinline__ static double cost_hess(const OcpConst& pc, int k, int i, int j) {
+    double h = pc.cost[O_WZ + i * NZ + j] + pc.cost[O_WZ + j * NZ + i];
+    if (k == 0 && i >= NX && j >= NX && pc.cost[O_HASDU] != 0.0)
+      h += pc.cost[O_WDU + (i - NX) * NU + (j - NX)] + pc.cost[O_WDU + (j - NX) * NU + (i - NX)];
+    return h;
+  }
+
+  template <class T>
+  __device__ __forceinline__ static T term_cost(const OcpConst& pc, const double*, const double*, const T* x) {
+    T z[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) z[i] = x[i] - pc.cost[O_XREFN + i];
+    T acc = T(0.0);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      T s = T(0.0);
+#pragma unroll
+      for (int j = 0; j < NX; ++j) s = s + pc.cost[O_WN + i * NX + j] * z[j];
+      acc = acc + z[i] * s;
+    }
+    return acc;
+  }
+};
+
+}  // namespace hilo

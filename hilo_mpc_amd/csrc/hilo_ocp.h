@@ -17,6 +17,7 @@
 #pragma once
 #include <math.h>
 
+#include "hilo_colloc.h"
 #include "hilo_common.h"
 #include "hilo_models.h"
 
@@ -59,6 +60,7 @@ struct OcpConst {
   double dlb[OCP_MAXNC], dub[OCP_MAXNC];  // their (relaxed) bounds; +-inf if none
   int n_con_ref, row_ref[OCP_MAXNC];      // rows per stage in the reference's g and where each active row sits there
   int pad2_;
+  CollData coll;                          // collocation basis when the shooting map is the implicit one (hilo_colloc.h)
 };
 
 inline void ocp_default_options(OcpConst& c) {

@@ -55,6 +55,30 @@ def _weight_matrix(arg, n, name):
     return W
 
 
+def _collocation_basis(degree, points='radau'):
+    """`RungeKutta._construct_polynomial_basis` (hilo_mpc/util/modeling.py:1091-1127) for tau = [0] +
+    collocation_points(degree, points): D_i = L_i(1), C[i, j] = L_i'(tau_j); plus the Runge-Kutta matrix of the method,
+    A = (C[1:, 1:]^T)^-1, which is the form the device solves the collocation equations in (csrc/hilo_colloc.h)."""
+    from numpy.polynomial import legendre
+    c = np.zeros(degree + 1)
+    if points == 'radau':                      # roots of P_{d-1} - P_d: Gauss-Radau with the right end point
+        c[degree - 1], c[degree] = 1., -1.
+    else:                                      # 'legendre': Gauss points
+        c[degree] = 1.
+    tau = [0.] + list((np.sort(np.real(legendre.legroots(c))) + 1.) / 2.)
+    Cm, D = np.zeros((degree + 1, degree + 1)), np.zeros(degree + 1)
+    for i in range(degree + 1):
+        L = np.poly1d([1.])
+        for j in range(degree + 1):
+            if j != i:
+                L *= np.poly1d([1., -tau[j]]) / (tau[i] - tau[j])
+        D[i] = L(1.)
+        Ld = np.polyder(L)
+        for j in range(degree + 1):
+            Cm[i, j] = Ld(tau[j])
+    return {'d': degree, 'tau': np.array(tau), 'C': Cm, 'D': D, 'A': np.linalg.inv(Cm[1:, 1:].T)}
+
+
 class QuadraticCost:
     """`util/modeling.py:89-531` restricted to what the device solver evaluates."""
 
@@ -168,11 +192,8 @@ class NMPC:
     _solver_name_list_nlp = ['ipopt', 'hip_ipm']
 
     def __init__(self, model, id=None, name=None, plot_backend=None, use_sx=True, stats=False, device_index=None):
-        if not model.discrete:
-            warnings.warn("The device backend needs a discrete-time model: call model.discretize('rk4') first "
-                          "(mpc.py's own 'rk4' branch is inconsistent for parametric models, SURVEY.md Q18). "
-                          "I am discretising with 'rk4' for you.")
-            model = model.discretize('rk4')
+        # a continuous model is transcribed at setup() by `integration_method`: 'collocation' (the reference's default,
+        # optimizer.py:1410-1418) or explicit Runge-Kutta ('rk4' / 'erk'); a discrete(-ised) model uses 'discrete'
         if not model._is_setup:
             model.setup()
         self._model = model
@@ -300,11 +321,20 @@ class NMPC:
             if possible[k] is not None and v not in possible[k]:
                 raise ValueError(f"The option {k} is set to value {v} but the only allowed values are {possible[k]}.")
             opts[k] = v
-        if opts['integration_method'] != 'discrete':
-            if given and 'integration_method' in given:
-                warnings.warn(f"The integration method is set to {opts['integration_method']} but I notice that the "
-                              f"model is in discrete time. I am overwriting and using discrete mode.")
-            opts['integration_method'] = 'discrete'
+        if self._model.discrete:
+            if opts['integration_method'] != 'discrete':
+                if given and 'integration_method' in given:
+                    warnings.warn(f"The integration method is set to {opts['integration_method']} but I notice that the "
+                                  f"model is in discrete time. I am overwriting and using discrete mode.")
+                opts['integration_method'] = 'discrete'                      # optimizer.py:1441-1447
+        else:
+            if opts['integration_method'] == 'discrete':
+                raise ValueError("The integration method is 'discrete' but the model is in continuous time.")
+            if opts['integration_method'] in ('idas', 'cvodes'):
+                raise NotImplementedError("SUNDIALS integrators inside the NLP are not offloaded; use 'collocation', "
+                                          "'rk4' or 'erk'")
+            if opts['integration_method'] == 'collocation' and opts['degree'] != 3:
+                raise NotImplementedError("collocation is built for the reference's default degree 3")
         if opts['ipopt_debugger']:
             raise NotImplementedError("the IPOPT iteration callback has no device counterpart")
         self._nlp_options = opts
@@ -329,6 +359,13 @@ class NMPC:
         if solver_options is not None:
             self.set_solver_opts(solver_options)
         m = self._model
+        coll = None
+        if not m.discrete:
+            if self._nlp_options['integration_method'] == 'collocation':
+                coll = _collocation_basis(self._nlp_options['degree'], self._nlp_options['collocation_points'])
+            else:   # 'rk4' / 'erk': one explicit Runge-Kutta step per interval (modeling.py:1213-1281)
+                m = m.discretize('rk4' if self._nlp_options['integration_method'] == 'rk4' else 'erk',
+                                 order=None if self._nlp_options['integration_method'] == 'rk4' else 1)
         nx, nu = self._n_x, self._n_u
         nz = nx + nu
         sx = np.ones(nx) if self._x_scaling is None else np.asarray(self._x_scaling)
@@ -443,6 +480,10 @@ class NMPC:
                 d.con_weight = hp(_weight_matrix(sc.weight, nc, 'weight')) if sc.weight is not None else None
                 d.con_max_violation = hp(sc.max_violation) if sc.max_violation is not None else None
         self._nth, self._ne = nth, ne
+        if coll is not None:
+            d.collocation_degree = coll['d']
+            d.coll_A, d.coll_D = hp(coll['A']), hp(coll['D'])
+        self._coll = coll
         self._dev = device(self._dev_index)
         h = C.c_void_p()
         _lib.check(_lib.lib().hilo_nmpc_create(C.byref(d), self._dev.index, C.byref(h)))
@@ -457,6 +498,9 @@ class NMPC:
         self._x_ind = [list(range(k * nxa, (k + 1) * nxa)) for k in range(N + 1)]
         self._u_ind = [list(range((N + 1) * nxa + k * nua, (N + 1) * nxa + (k + 1) * nua)) for k in range(N)]
         self._e_soft_stage_ind = list(range((N + 1) * nxa + N * nua, (N + 1) * nxa + N * nua + ne))
+        dn = coll['d'] * nx if coll is not None else 0
+        off = (N + 1) * nxa + N * nua + ne
+        self._ip_ind = [list(range(off + k * dn, off + (k + 1) * dn)) for k in range(N)] if dn else []   # mpc.py:1501-1509
         self._sx, self._su = sx, su
         self._nlp_setup_done = True
 

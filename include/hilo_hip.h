@@ -226,6 +226,15 @@ typedef struct hilo_nmpc_desc {
   const double* con_lb; const double* con_ub;      /* [n_con]; -inf / +inf allowed */
   const double* con_weight;              /* [n_con][n_con] or NULL -> 1e4 I (modeling.py:875) */
   const double* con_max_violation;       /* [n_con] or NULL -> inf */
+  /* ---- integration_method = 'collocation' on the CONTINUOUS model (the reference's default, optimizer.py:1410-1418;
+     hilo_mpc/util/modeling.py:1091-1211, mpc.py:1307-1372): degree d Lagrange basis at Radau / Legendre points.  The caller
+     passes the basis it built (modeling.py:1091-1127): coll_A = (C[1:,1:]^T)^-1 (d x d, the method's Runge-Kutta matrix)
+     and coll_D = D[0..d].  v gains the collocation states ([x | u | ip], mpc.py:1497-1518), g the collocation rows
+     (per stage [collocation rows | continuity], :1657-1669).  0 = explicit Runge-Kutta / discrete model. ---- */
+  int32_t collocation_degree;            /* 0 or 3 in this build */
+  int32_t reserved2;
+  const double* coll_A;                  /* [d][d] */
+  const double* coll_D;                  /* [d+1] */
 } hilo_nmpc_desc;
 
 /* expression programs: [len, (op, arg) * len/2] back to back; postfix, stack of 8 */

@@ -1,0 +1,233 @@
+"""Oracle: NMPC with the reference's DEFAULT transcription - direct collocation (Lagrange basis at Radau points).
+
+TEST INFRASTRUCTURE ONLY - never imported by the product package.   PARITY UNPINNED (see oracle/nmpc.py).
+
+Restated from hilo_mpc/util/modeling.py:1091-1211 (`RungeKutta._construct_polynomial_basis`, `_collocation`) and
+hilo_mpc/modules/controller/mpc.py:1307-1372, :1497-1518, :1657-1666 for a CONTINUOUS model with
+`integration_method='collocation'` (optimizer.py:1410-1418 defaults: 'radau', degree 3) and the default discrete objective:
+  tau = [0] + collocation_points(d, 'radau')          (modeling.py:1108; Radau: roots of P_{d-1} - P_d mapped to (0, 1])
+  Lagrange basis L_i on tau:  D_i = L_i(1), C[i, j] = L_i'(tau_j), B_i = int_0^1 L_i       (modeling.py:1110-1124)
+  per interval, collocation states x_{k,1..d} are decision variables (mpc.py:1501-1509; bounds / guess = the state's, tiled,
+  :1321-1323) with the equations  dt f(x_{k,i}, u_k) - sum_j C[j, i] x_{k,j} = 0,  x_{k,0} = x_k   (modeling.py:1183-1189)
+  and the continuity row  x_{k+1} - sum_j D_j x_{k,j} = 0                                    (modeling.py:1180,1192; mpc.py:1667)
+  v = [x_0..x_N | u_0..u_{N-1} | ip_0..ip_{N-1}],  g per stage = [collocation rows (d nx) | continuity (nx)]  (mpc.py:1657-1669)
+  objective: the discrete sum of the stage cost at the shooting nodes + terminal cost (mpc.py:1676-1682).
+The model is the scaled one (hilo_mpc/modules/base.py:1562-1591).
+"""
+from __future__ import annotations
+
+import numpy as np
+from numpy.polynomial import legendre
+
+from .nmpc import DenseIpm, IpmOptions, NmpcProblem
+
+INF = np.inf
+
+
+def collocation_points(d, method='radau'):
+    """`casadi.collocation_points(d, method)` restated: Gauss-Radau (right end point included) or Gauss-Legendre on (0, 1]."""
+    if method == 'radau':
+        c = np.zeros(d + 1)
+        c[d - 1], c[d] = 1., -1.
+        r = np.sort(np.real(legendre.legroots(c)))
+    elif method == 'legendre':
+        c = np.zeros(d + 1)
+        c[d] = 1.
+        r = np.sort(np.real(legendre.legroots(c)))
+    else:
+        raise ValueError(method)
+    return list((r + 1.) / 2.)
+
+
+def polynomial_basis(d, method='radau'):
+    """B, C, D, tau of modeling.py:1091-1127."""
+    tau = [0.] + collocation_points(d, method)
+    B, C, D = np.zeros(d + 1), np.zeros((d + 1, d + 1)), np.zeros(d + 1)
+    for i in range(d + 1):
+        L = np.poly1d([1.])
+        for j in range(d + 1):
+            if j != i:
+                L *= np.poly1d([1., -tau[j]]) / (tau[i] - tau[j])
+        D[i] = L(1.)
+        Ld = np.polyder(L)
+        for j in range(d + 1):
+            C[i, j] = Ld(tau[j])
+        B[i] = np.polyint(L)(1.)
+    return B, C, D, np.array(tau)
+
+
+class CollNmpcProblem(NmpcProblem):
+    def __init__(self, model, dt, N, degree=3, points='radau', **kw):
+        super().__init__(model, dt, N, **kw)
+        assert not model.discrete, "collocation needs the continuous model"
+        self.d = degree
+        self.B, self.C, self.D, self.tau = polynomial_basis(degree, points)
+        nx, nu, d = self.nx, self.nu, degree
+        off = (N + 1) * nx + N * nu
+        self.ip_ind = [list(range(off + k * d * nx, off + (k + 1) * d * nx)) for k in range(N)]   # mpc.py:1501-1509
+        self.n_v = off + N * d * nx                                                               # mpc.py:1440-1443
+        self.n_g = N * (d * nx + nx)
+        self.v_lb = np.concatenate([self.v_lb, np.tile(self.x_lb, N * d)])
+        self.v_ub = np.concatenate([self.v_ub, np.tile(self.x_ub, N * d)])
+        self.v_guess = np.concatenate([self.v_guess, np.tile(self.x_guess, N * d)])
+
+    # scaled continuous right-hand side with first / second derivatives w.r.t. (xs, us)
+    def rhs(self, xs, us, p, need=0):
+        x, u = xs * self.sx, us * self.su
+        sm = self.smap
+        B = x.shape[0]
+        u = np.broadcast_to(u, (B, self.nu))
+        p = np.broadcast_to(np.atleast_2d(p), (B, self.np_)) if self.np_ else np.zeros((B, 0))
+        if need == 0:
+            return sm._f(x, u, p, self.dt) / self.sx
+        f, fw, fww = sm._rhs(x, u, p, self.dt)
+        sz = np.concatenate([self.sx, self.su])
+        fw = fw * sz[None, None, :] / self.sx[None, :, None]
+        fww = fww * sz[None, None, :, None] * sz[None, None, None, :] / self.sx[None, :, None, None]
+        return f / self.sx, fw, fww
+
+
+class CollIpm(DenseIpm):
+    """Free variables w = [x_1..x_N | u_0..u_{N-1} | X_0..X_{N-1}]  (X_k = the d collocation states of interval k)."""
+
+    def __init__(self, prob: CollNmpcProblem, options: IpmOptions | None = None):
+        self.pb = pb = prob
+        self.o = o = options or IpmOptions()
+        N, nx, nu, d = pb.N, pb.nx, pb.nu, pb.d
+        self.o_u = N * nx
+        self.o_c = self.o_u + N * nu
+        self.nw = self.o_c + N * d * nx
+        self.m = N * (d * nx + nx)
+        lb = np.concatenate([np.tile(pb.x_lb, N), np.tile(pb.u_lb, N), np.tile(pb.x_lb, N * d)])
+        ub = np.concatenate([np.tile(pb.x_ub, N), np.tile(pb.u_ub, N), np.tile(pb.x_ub, N * d)])
+        r = o.bound_relax_factor
+        self.lb = np.where(np.isfinite(lb), lb - r * np.maximum(1, np.abs(lb)), lb)
+        self.ub = np.where(np.isfinite(ub), ub + r * np.maximum(1, np.abs(ub)), ub)
+        self.has_l, self.has_u = np.isfinite(self.lb), np.isfinite(self.ub)
+
+    def xcol(self, k):        # columns of x_k (k >= 1)
+        return [(k - 1) * self.pb.nx + i for i in range(self.pb.nx)]
+
+    def ucol(self, k):
+        return [self.o_u + k * self.pb.nu + i for i in range(self.pb.nu)]
+
+    def ccol(self, k, i):     # columns of collocation state i (1..d) of interval k
+        pb = self.pb
+        return [self.o_c + (k * pb.d + i - 1) * pb.nx + a for a in range(pb.nx)]
+
+    def _unpack(self, w, x0):
+        pb = self.pb
+        B, N, nx, nu, d = w.shape[0], pb.N, pb.nx, pb.nu, pb.d
+        X = np.concatenate([x0[:, None, :], w[:, :N * nx].reshape(B, N, nx)], axis=1)
+        U = w[:, self.o_u:self.o_c].reshape(B, N, nu)
+        Xc = w[:, self.o_c:].reshape(B, N, d, nx)
+        return X, U, Xc
+
+    def _cost(self, X, U, u_old):
+        pb = self.pb
+        f = np.zeros(X.shape[0])
+        for k in range(pb.N):
+            z = np.concatenate([X[:, k], U[:, k]], axis=1) - pb.zref
+            f += np.einsum('bi,ij,bj->b', z, pb.Wz, z)
+        if u_old is not None:
+            dd = U[:, 0] - u_old
+            f += np.einsum('bi,ij,bj->b', dd, pb.Wdu, dd)
+        dd = X[:, pb.N] - pb.xrefN
+        return f + np.einsum('bi,ij,bj->b', dd, pb.WN, dd)
+
+    def eval_fc(self, w, data):
+        pb = self.pb
+        x0, p, u_old = data['x0'], data['p'], data.get('u_old')
+        X, U, Xc = self._unpack(w, x0)
+        B, N, nx, d = w.shape[0], pb.N, pb.nx, pb.d
+        c = np.empty((B, N, d + 1, nx))
+        for k in range(N):
+            xf = pb.D[0] * X[:, k]
+            for i in range(1, d + 1):
+                xp = pb.C[0, i] * X[:, k]
+                for j in range(d):
+                    xp = xp + pb.C[j + 1, i] * Xc[:, k, j]
+                c[:, k, i - 1] = pb.dt * pb.rhs(Xc[:, k, i - 1], U[:, k], p) - xp
+                xf = xf + pb.D[i] * Xc[:, k, i - 1]
+            c[:, k, d] = X[:, k + 1] - xf
+        return self._cost(X, U, u_old), c.reshape(B, -1)
+
+    def eval_all(self, w, lam, data):
+        pb = self.pb
+        N, nx, nu, nz, d = pb.N, pb.nx, pb.nu, pb.nz, pb.d
+        x0, p, u_old = data['x0'], data['p'], data.get('u_old')
+        X, U, Xc = self._unpack(w, x0)
+        B = w.shape[0]
+        bi = np.arange(B)
+        g = np.zeros((B, self.nw))
+        c = np.empty((B, N, d + 1, nx))
+        J = np.zeros((B, self.m, self.nw))
+        W = np.zeros((B, self.nw, self.nw))
+        lam = lam.reshape(B, N, d + 1, nx)
+        mk = (d + 1) * nx
+        eye = np.eye(nx)
+        for k in range(N):
+            # cost at the shooting node
+            z = np.concatenate([X[:, k], U[:, k]], axis=1) - pb.zref
+            gz = 2 * z @ pb.Wz
+            Hz = np.broadcast_to(2 * pb.Wz, (B, nz, nz)).copy()
+            if k == 0 and u_old is not None:
+                dd = U[:, 0] - u_old
+                gz[:, nx:] += 2 * dd @ pb.Wdu
+                Hz[:, nx:, nx:] += 2 * pb.Wdu
+            cols = (self.xcol(k) if k > 0 else []) + self.ucol(k)
+            sel = (list(range(nx)) if k > 0 else []) + list(range(nx, nz))
+            g[:, cols] += gz[:, sel]
+            W[np.ix_(bi, cols, cols)] += Hz[np.ix_(bi, sel, sel)]
+            xf = pb.D[0] * X[:, k]
+            for i in range(1, d + 1):
+                rows = [k * mk + (i - 1) * nx + a for a in range(nx)]
+                f, fw, fww = pb.rhs(Xc[:, k, i - 1], U[:, k], p, need=2)
+                xp = pb.C[0, i] * X[:, k]
+                if k > 0:
+                    J[:, rows, self.xcol(k)] += -pb.C[0, i]
+                for j in range(d):
+                    xp = xp + pb.C[j + 1, i] * Xc[:, k, j]
+                    J[:, rows, self.ccol(k, j + 1)] += -pb.C[j + 1, i]
+                c[:, k, i - 1] = pb.dt * f - xp
+                ci, uc = self.ccol(k, i), self.ucol(k)
+                J[np.ix_(bi, rows, ci)] += pb.dt * fw[:, :, :nx]
+                J[np.ix_(bi, rows, uc)] += pb.dt * fw[:, :, nx:]
+                Hl = pb.dt * np.einsum('bm,bmzy->bzy', lam[:, k, i - 1], fww)
+                both = ci + uc
+                W[np.ix_(bi, both, both)] += Hl
+                xf = xf + pb.D[i] * Xc[:, k, i - 1]
+                rc = [k * mk + d * nx + a for a in range(nx)]
+                J[:, rc, ci] += -pb.D[i]
+            rc = [k * mk + d * nx + a for a in range(nx)]
+            c[:, k, d] = X[:, k + 1] - xf
+            J[:, rc, self.xcol(k + 1)] = 1.0
+            if k > 0:
+                J[:, rc, self.xcol(k)] += -pb.D[0]
+        dd = X[:, N] - pb.xrefN
+        g[:, self.xcol(N)] += 2 * dd @ pb.WN
+        W[np.ix_(bi, self.xcol(N), self.xcol(N))] += 2 * pb.WN
+        return self._cost(X, U, u_old), g, c.reshape(B, -1), J, W
+
+    def solve(self, x0, p, w0=None, u_old=None, verbose=False):
+        pb = self.pb
+        x0 = np.atleast_2d(np.asarray(x0, dtype=float)) / pb.sx
+        B = x0.shape[0]
+        p = np.broadcast_to(np.atleast_2d(np.asarray(p, dtype=float)), (B, pb.np_)) if pb.np_ else np.zeros((B, 0))
+        data = {'x0': x0, 'p': p}
+        if u_old is not None:
+            data['u_old'] = np.broadcast_to(np.atleast_2d(np.asarray(u_old, dtype=float)), (B, pb.nu))
+        if w0 is None:
+            w0 = np.concatenate([np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N), np.tile(pb.x_guess, pb.N * pb.d)])
+        res = self.solve_data(data, w0, verbose)
+        X, U, Xc = self._unpack(res['w'], x0)
+        res.update(X=X, U=U, Xc=Xc, u0=U[:, 0] * pb.su, x0=x0)
+        return res
+
+    def to_v(self, res):
+        B = res['X'].shape[0]
+        return np.concatenate([res['X'].reshape(B, -1), res['U'].reshape(B, -1), res['Xc'].reshape(B, -1)], axis=1)
+
+    def w_from_v(self, v):
+        v = np.atleast_2d(v)
+        return v[:, self.pb.nx:]
