@@ -25,6 +25,7 @@ struct MheNoise {
   static constexpr bool COOP = model_has_ext<M>::value;
   static constexpr bool QUAD_COST = false;  // the measurement function may be nonlinear: Taylor evaluation
   static constexpr int O_WX = 0, O_WY = O_WX + NX * NX, O_WW = O_WY + NY * NY, O_SU = O_WW + NX * NX, O_END = O_SU + MU;
+  static constexpr int NCOST = O_END;
 
   template <class T, class E>
   __device__ __forceinline__ static void dyn(const OcpConst& pc, const double* par, const double* sd, int, const T* x,

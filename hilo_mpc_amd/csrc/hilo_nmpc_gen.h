@@ -37,6 +37,7 @@ struct NmpcGen {
                        O_NEXPR = O_WT + GEN_NPT * GEN_NPT, O_ROWX = O_NEXPR + 1, O_ROWS = O_ROWX + OCP_MAXNC,
                        O_ROWE = O_ROWS + OCP_MAXNC, O_PROG = O_ROWE + OCP_MAXNC;
   static_assert(O_PROG + 64 <= OCP_NCOST, "cost block too small");
+  static constexpr int NCOST = OCP_NCOST;  // expression programs have run-time length: the whole block
 
   template <class T, class E>
   __device__ __forceinline__ static void dyn(const OcpConst& pc, const double* par, const double*, int, const T* x,

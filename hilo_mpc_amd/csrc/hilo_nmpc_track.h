@@ -16,6 +16,7 @@ struct NmpcTrack {
   static constexpr bool QUAD_COST = true;  // gradient / Hessian of the stage cost in closed form (cost_grad, cost_hess)
   static constexpr int O_WZ = 0, O_ZREF = O_WZ + NZ * NZ, O_WN = O_ZREF + NZ, O_XREFN = O_WN + NX * NX,
                        O_WDU = O_XREFN + NX, O_HASDU = O_WDU + NU * NU, O_END = O_HASDU + 1;
+  static constexpr int NCOST = O_END;  // doubles of pc.cost this policy reads (copied to LDS)
 
   template <class T, class E>
   __device__ __forceinline__ static void dyn(const OcpConst& pc, const double* par, const double*, int, const T* x,

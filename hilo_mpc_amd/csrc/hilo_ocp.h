@@ -47,7 +47,6 @@ struct OcpConst {
   double dt;
   double lbz[OCP_MAXNZ], ubz[OCP_MAXNZ];  // relaxed bounds of a stage's (x,u) slots (scaled); +-inf if none
   double sz[OCP_MAXNZ];                   // scaling of (x,u)
-  double cost[OCP_NCOST];                 // policy-defined cost data (weights, references)
   // interior-point constants (IPOPT defaults)
   double tol, acceptable_tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac, s_max,
       kappa_sigma, gamma_theta, gamma_phi, delta_ls, s_theta, s_phi, eta_phi, theta_min_fact, theta_max_fact,
@@ -61,6 +60,9 @@ struct OcpConst {
   int n_con_ref, row_ref[OCP_MAXNC];      // rows per stage in the reference's g and where each active row sits there
   int pad2_;
   CollData coll;                          // collocation basis when the shooting map is the implicit one (hilo_colloc.h)
+  // policy-defined cost data (weights, references, expression programs).  LAST member: an instance copies only the
+  // PB::NCOST doubles its policy uses into LDS (40 KB per instance is the budget for four instances per CU)
+  double cost[OCP_NCOST];
 };
 
 inline void ocp_default_options(OcpConst& c) {
@@ -79,10 +81,30 @@ struct OpSum { __device__ static double id() { return 0.0; } __device__ static d
 struct OpMax { __device__ static double id() { return -INFINITY; } __device__ static double f(double a, double b) { return fmax(a, b); } };
 struct OpMin { __device__ static double id() { return INFINITY; } __device__ static double f(double a, double b) { return fmin(a, b); } };
 
+// wave-wide reduction without LDS traffic: DPP lane permutes inside each row of 16 (xor 1, xor 2, half-mirror, mirror), then
+// the four row totals through v_readlane (scalar registers -> broadcast for free)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double v) {
+  v = Op::f(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = Op::f(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = Op::f(v, dpp_mov<0x141>(v));  // row_half_mirror
+  v = Op::f(v, dpp_mov<0x140>(v));  // row_mirror
+  return Op::f(Op::f(read_lane(v, 0), read_lane(v, 16)), Op::f(read_lane(v, 32), read_lane(v, 48)));
+}
+
 template <class Op>
 __device__ __forceinline__ double block_reduce(double v, __attribute__((address_space(3))) double* scratch) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = Op::f(v, __shfl_xor(v, o, 64));
+  v = wave_reduce<Op>(v);
+  if constexpr (OCP_TPB == 64) return v;
   const int nw = blockDim.x >> 6;
   if (nw == 1) return v;
   __syncthreads();
@@ -110,7 +132,7 @@ struct Ocp {
   // reference decision-vector layout [x (NXV per stage) | u | shared tail (NX - NXV)]; x_0 measurement width; inputs returned
   static constexpr int NXV = PB::NXV, NX0 = PB::NX0, NU0 = PB::NU0;
   static_assert(!COOP || (OCP_TPB == 64 && NDIR <= 64), "cooperative models need one wave per instance");
-  static constexpr int NCONST = (sizeof(OcpConst) + 7) / 8;
+  static constexpr int NCONST = (int)((offsetof(OcpConst, cost) + sizeof(double) * PB::NCOST + 7) / 8);
 
   // Storage of the iterate: LDS (default) or, for problems that do not fit (long horizons, wide stages), a per-instance
   // workspace in global memory (PB::BIG; L2-resident, same code path, longer latencies).  Problem constants, the pivot
@@ -121,12 +143,13 @@ struct Ocp {
   struct Lds {
     const __attribute__((address_space(3))) OcpConst* pc;
     dp Z, Zt, D, zL, zU, dzL, dzU, grad, lam, lamn, c, ct, AB, W, Qd, P, pv, Kg, kff, sig, rb, Acl, bcl;
+    dp lbA, ubA;  // effective box of every slot: -inf / +inf where there is no bound or the slot is not a variable
     dp cs, cst, cnu, cnun, cvL, cvU, cdvL, cdvU, cds, cd, csig, crb, Jd;  // [N][NC] (Jd: [N][NC][NZ])
     lds_double *Mm, *mm, *fk, *filt, *red, *par, *sd, *ext;
   };
   __host__ __device__ static size_t iter_doubles(int N) {  // the iterate (LDS or workspace)
     const size_t S = (size_t)(N + 1) * NZ;
-    return 10 * S + 4 * (size_t)N * NX + (size_t)N * NX * NZ + (size_t)N * NZ * NZ + (size_t)(N + 1) * NDIR +
+    return 12 * S + 4 * (size_t)N * NX + (size_t)N * NX * NZ + (size_t)N * NZ * NZ + (size_t)(N + 1) * NDIR +
            (size_t)(N + 1) * NX * NX + (size_t)(N + 1) * NX + (size_t)N * NU * NX + (size_t)N * NU + (size_t)N * NX * NX +
            (size_t)N * NX + (size_t)N * NC * (12 + NZ);
   }
@@ -161,6 +184,7 @@ struct Ocp {
     l.P = big((size_t)(N + 1) * NX * NX); l.pv = big((size_t)(N + 1) * NX);
     l.Kg = big((size_t)N * NU * NX); l.kff = big((size_t)N * NU);
     l.sig = big(S); l.rb = big(S); l.Acl = big((size_t)N * NX * NX); l.bcl = big((size_t)N * NX);
+    l.lbA = big(S); l.ubA = big(S);
     const size_t R = (size_t)N * NC;
     l.cs = big(R); l.cst = big(R); l.cnu = big(R); l.cnun = big(R); l.cvL = big(R); l.cvU = big(R);
     l.cdvL = big(R); l.cdvU = big(R); l.cds = big(R); l.cd = big(R); l.csig = big(R); l.crb = big(R);
@@ -274,10 +298,9 @@ struct Ocp {
     const int N = pc.N;
     double part = 0.0;
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
-      const int k = e / NZ, i = e - k * NZ;
-      if (!is_free(pc, k, i)) continue;
-      if (lb_of(pc, k, i) > -INFINITY) part -= log(Zp[e] - lb_of(pc, k, i));
-      if (ub_of(pc, k, i) < INFINITY) part -= log(ub_of(pc, k, i) - Zp[e]);
+      const double lb = l.lbA[e], ub = l.ubA[e], z = Zp[e];
+      if (lb > -INFINITY) part -= log(z - lb);
+      if (ub < INFINITY) part -= log(ub - z);
     }
     if constexpr (NC > 0) {
       for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
@@ -450,7 +473,7 @@ struct Ocp {
       if (!is_free(pc, k, i)) continue;
       dmax = fmax(dmax, fabs(dual_res(l, N, e)));
       zsum += fabs(l.zL[e]) + fabs(l.zU[e]);
-      nb += (lb_of(pc, k, i) > -INFINITY ? 1.0 : 0.0) + (ub_of(pc, k, i) < INFINITY ? 1.0 : 0.0);
+      nb += (l.lbA[e] > -INFINITY ? 1.0 : 0.0) + (l.ubA[e] < INFINITY ? 1.0 : 0.0);
     }
     for (int e = threadIdx.x; e < N * NX; e += blockDim.x) {
       pmax = fmax(pmax, fabs(l.c[e]));
@@ -485,10 +508,9 @@ struct Ocp {
     const int N = pc.N;
     double cm = 0.0;
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
-      const int k = e / NZ, i = e - k * NZ;
-      if (!is_free(pc, k, i)) continue;
-      if (lb_of(pc, k, i) > -INFINITY) cm = fmax(cm, fabs((l.Z[e] - lb_of(pc, k, i)) * l.zL[e] - mu));
-      if (ub_of(pc, k, i) < INFINITY) cm = fmax(cm, fabs((ub_of(pc, k, i) - l.Z[e]) * l.zU[e] - mu));
+      const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
+      if (lb > -INFINITY) cm = fmax(cm, fabs((z - lb) * zl - mu));
+      if (ub < INFINITY) cm = fmax(cm, fabs((ub - z) * zu - mu));
     }
     if constexpr (NC > 0) {
       for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
@@ -507,19 +529,17 @@ struct Ocp {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
-      const int k = e / NZ, i = e - k * NZ;
+      const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
       double sg = 0.0, r = l.grad[e];
-      if (is_free(pc, k, i)) {
-        if (lb_of(pc, k, i) > -INFINITY) {
-          const double is = 1.0 / (l.Z[e] - lb_of(pc, k, i));
-          sg += l.zL[e] * is;
-          r -= mu * is;
-        }
-        if (ub_of(pc, k, i) < INFINITY) {
-          const double is = 1.0 / (ub_of(pc, k, i) - l.Z[e]);
-          sg += l.zU[e] * is;
-          r += mu * is;
-        }
+      if (lb > -INFINITY) {
+        const double is = 1.0 / (z - lb);
+        sg += zl * is;
+        r -= mu * is;
+      }
+      if (ub < INFINITY) {
+        const double is = 1.0 / (ub - z);
+        sg += zu * is;
+        r += mu * is;
       }
       l.sig[e] = sg;
       l.rb[e] = r;
@@ -627,27 +647,32 @@ struct Ocp {
       // (1) Mm = H_k + [A B]^T P_{k+1} [A B];  mm = r_k + [A B]^T (p_{k+1} - P_{k+1} c_k).
       // One uniform code path for the NZ x (NZ+1) entries: column NZ is the right-hand side, i.e. the "column" -c_k
       // of [A B | -c] with p_{k+1} added.  All operands are fetched before the arithmetic (one LDS wait).
+      // Branch-free: every operand is fetched unconditionally (clamped index) and chosen by a select, the result goes out
+      // through one store with a selected address - divergent if/else around the loads costs more than the spare loads.
       for (int e = t; e < NZ * (NZ + 1); e += T) {
         const int i = e / (NZ + 1), j = e - i * (NZ + 1);
         const bool rhs = j == NZ;
+        const int jj = rhs ? 0 : j;
         double Pl[NX * NX], ai[NX], aj[NX], pl[NX];
 #pragma unroll
         for (int q = 0; q < NX * NX; ++q) Pl[q] = Pn[q];
 #pragma unroll
         for (int n = 0; n < NX; ++n) {
           ai[n] = AB[n * NZ + i];
-          aj[n] = rhs ? -l.c[k * NX + n] : AB[n * NZ + j];
+          const double ab = AB[n * NZ + jj], cn = l.c[k * NX + n];
+          aj[n] = rhs ? -cn : ab;
           pl[n] = pn[n];
         }
-        double s = resto ? 0.0 : (rhs ? l.rb[k * NZ + i] : l.W[k * NZ * NZ + i * NZ + j]);
-        const double dg = (i == j) ? (resto ? 1.0 : delta + l.sig[k * NZ + i]) : 0.0;
+        const double rbv = l.rb[k * NZ + i], wv = l.W[k * NZ * NZ + i * NZ + jj], sg = l.sig[k * NZ + i];
+        double s = resto ? 0.0 : (rhs ? rbv : wv);
+        const double dg = (i == j) ? (resto ? 1.0 : delta + sg) : 0.0;
         if constexpr (NC > 0) {  // eliminated slack rows: + Jd^T (Sigma_s + delta) Jd, rhs + Jd^T ((Sigma_s + delta)(d - s) + crb)
-          const int jj = rhs ? 0 : j;
 #pragma unroll
           for (int m = 0; m < NC; ++m) {
             const int r = k * NC + m;
             const double wgt = resto ? 1.0 : l.csig[r] + delta;
-            const double right = rhs ? wgt * (l.cd[r] - l.cs[r]) + (resto ? 0.0 : l.crb[r]) : wgt * l.Jd[r * NZ + jj];
+            const double ds = l.cd[r] - l.cs[r], cr = l.crb[r], jr = l.Jd[r * NZ + jj];
+            const double right = rhs ? wgt * ds + (resto ? 0.0 : cr) : wgt * jr;
             s += l.Jd[r * NZ + i] * right;
           }
         }
@@ -659,8 +684,8 @@ struct Ocp {
           for (int n = 0; n < NX; ++n) tm += Pl[m * NX + n] * aj[n];
           s += ai[m] * tm;
         }
-        if (rhs) l.mm[i] = s;
-        else l.Mm[i * NZ + j] = s + dg;
+        lds_double* dst = rhs ? l.mm + i : l.Mm + i * NZ + j;
+        *dst = s + dg;   // dg = 0 in the right-hand-side column (i != NZ)
       }
       __syncthreads();
       // (2) pivot block (factored redundantly per lane), feedback, cost-to-go: lane (i, j), j = 0..NX:
@@ -673,24 +698,27 @@ struct Ocp {
         for (int e = t; e < NX * (NX + 1); e += T) {
           const int i = e / (NX + 1), j = e - i * (NX + 1);
           const bool rhs = j == NX;
+          const int jj = rhs ? 0 : j;
           double y[NU], xu[NU];
 #pragma unroll
           for (int a = 0; a < NU; ++a) {
-            y[a] = rhs ? l.mm[NX + a] : l.Mm[(NX + a) * NZ + j];
+            const double ym = l.mm[NX + a], yM = l.Mm[(NX + a) * NZ + jj];
+            y[a] = rhs ? ym : yM;
             xu[a] = l.Mm[i * NZ + NX + a];
           }
-          double s = rhs ? l.mm[i] : 0.5 * (l.Mm[i * NZ + j] + l.Mm[j * NZ + i]);
+          const double sm = l.mm[i], s1 = l.Mm[i * NZ + jj], s2 = l.Mm[jj * NZ + i];
+          double s = rhs ? sm : 0.5 * (s1 + s2);
           __builtin_amdgcn_sched_barrier(0);
           small_solve<NU>(Lc, invd, y);
 #pragma unroll
           for (int a = 0; a < NU; ++a) s -= xu[a] * y[a];
-          if (rhs) l.pv[k * NX + i] = s;
-          else l.P[k * NX * NX + i * NX + j] = s;
+          dp dst = rhs ? l.pv + k * NX + i : l.P + k * NX * NX + i * NX + j;
+          *dst = s;
           if (i == 0) {
 #pragma unroll
             for (int a = 0; a < NU; ++a) {
-              if (rhs) l.kff[k * NU + a] = -y[a];
-              else l.Kg[(k * NU + a) * NX + j] = -y[a];
+              dp kd = rhs ? l.kff + k * NU + a : l.Kg + (k * NU + a) * NX + j;
+              *kd = -y[a];
             }
           }
         }
@@ -830,11 +858,9 @@ struct Ocp {
         }
       }
       for (int e = t; e < SL; e += T) {
-        const int k = e / NZ, i = e - k * NZ;
-        if (!is_free(pc, k, i)) continue;
-        const double d = l.D[e];
-        if (lb_of(pc, k, i) > -INFINITY && d < 0.0) a = fmin(a, -tau * (l.Z[e] - lb_of(pc, k, i)) / d);
-        if (ub_of(pc, k, i) < INFINITY && d > 0.0) a = fmin(a, tau * (ub_of(pc, k, i) - l.Z[e]) / d);
+        const double d = l.D[e], lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e];
+        if (lb > -INFINITY && d < 0.0) a = fmin(a, -tau * (z - lb) / d);
+        if (ub < INFINITY && d > 0.0) a = fmin(a, tau * (ub - z) / d);
       }
       double alpha = block_reduce<OpMin>(a, l.red);
       bool ok = false;
@@ -915,8 +941,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     if (i < NXV) v = (k == 0 && S::x0_pinned(pc, i)) ? x0[b * S::NX0 + i] / pc.sz[i] : vb[k * NXV + i];
     else if (i < NX) v = vb[(N + 1) * NXV + N * NU + (i - NXV)];
     else v = (k < N) ? vb[(N + 1) * NXV + k * NU + (i - NX)] : 0.0;
-    if (S::is_free(pc, k, i)) {  // IPOPT start: push into the interior (W&B sec. 3.6)
-      const double lb = S::lb_of(pc, k, i), ub = S::ub_of(pc, k, i);
+    const bool fr = S::is_free(pc, k, i);
+    const double lb = fr ? S::lb_of(pc, k, i) : -INFINITY, ub = fr ? S::ub_of(pc, k, i) : INFINITY;
+    l.lbA[e] = lb;
+    l.ubA[e] = ub;
+    if (fr) {  // IPOPT start: push into the interior (W&B sec. 3.6)
       const bool hl = lb > -INFINITY, hu = ub < INFINITY;
       if (hl) {
         double pl = pc.bound_push * fmax(1.0, fabs(lb));
@@ -1030,26 +1059,25 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     // ---- bound-multiplier steps, fraction to the boundary (W&B eq. 8), directional derivative ----
     double a_p = 1.0, a_z = 1.0, dphi = 0.0;
     for (int e = t; e < SL; e += T) {
-      const int k = e / NZ, i = e - k * NZ;
       double dl = 0.0, du = 0.0;
-      if (S::is_free(pc, k, i)) {
-        const double d = l.D[e];
+      {
+        const double d = l.D[e], lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
         double gphi = l.grad[e];
-        if (S::lb_of(pc, k, i) > -INFINITY) {
-          const double s = l.Z[e] - S::lb_of(pc, k, i);
-          dl = mu / s - l.zL[e] - l.zL[e] / s * d;
+        if (lb > -INFINITY) {
+          const double s = z - lb, is = 1.0 / s;
+          dl = mu * is - zl - zl * is * d;
           if (d < 0.0) a_p = fmin(a_p, -tau * s / d);
-          if (dl < 0.0) a_z = fmin(a_z, -tau * l.zL[e] / dl);
-          gphi -= mu / s;
+          if (dl < 0.0) a_z = fmin(a_z, -tau * zl / dl);
+          gphi -= mu * is;
         }
-        if (S::ub_of(pc, k, i) < INFINITY) {
-          const double s = S::ub_of(pc, k, i) - l.Z[e];
-          du = mu / s - l.zU[e] + l.zU[e] / s * d;
+        if (ub < INFINITY) {
+          const double s = ub - z, is = 1.0 / s;
+          du = mu * is - zu + zu * is * d;
           if (d > 0.0) a_p = fmin(a_p, tau * s / d);
-          if (du < 0.0) a_z = fmin(a_z, -tau * l.zU[e] / du);
-          gphi += mu / s;
+          if (du < 0.0) a_z = fmin(a_z, -tau * zu / du);
+          gphi += mu * is;
         }
-        dphi += gphi * d;
+        dphi += gphi * d;   // D = 0 on slots that are not variables
       }
       l.dzL[e] = dl;
       l.dzU[e] = du;
@@ -1147,10 +1175,9 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
         for (int e = t; e < N * NC; e += T) zm = fmax(zm, fmax(l.cvL[e], l.cvU[e]));
       zm = block_reduce<OpMax>(zm, l.red);
       for (int e = t; e < SL; e += T) {
-        const int k = e / NZ, i = e - k * NZ;
-        if (zm > 1e3 && S::is_free(pc, k, i)) {
-          l.zL[e] = S::lb_of(pc, k, i) > -INFINITY ? 1.0 : 0.0;
-          l.zU[e] = S::ub_of(pc, k, i) < INFINITY ? 1.0 : 0.0;
+        if (zm > 1e3) {
+          l.zL[e] = l.lbA[e] > -INFINITY ? 1.0 : 0.0;
+          l.zU[e] = l.ubA[e] < INFINITY ? 1.0 : 0.0;
         }
       }
       for (int e = t; e < N * NX; e += T) l.lam[e] = 0.0;
@@ -1169,18 +1196,15 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     }
     // ---- accept: primal, equality multipliers, bound multipliers (+ W&B eq. 16 safeguard) ----
     for (int e = t; e < SL; e += T) {
-      const int k = e / NZ, i = e - k * NZ;
-      const double znew = l.Zt[e];
+      const double znew = l.Zt[e], lb = l.lbA[e], ub = l.ubA[e];
       l.Z[e] = znew;
-      if (S::is_free(pc, k, i)) {
-        if (S::lb_of(pc, k, i) > -INFINITY) {
-          const double s = znew - S::lb_of(pc, k, i);
-          l.zL[e] = fmin(fmax(l.zL[e] + a_z * l.dzL[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
-        }
-        if (S::ub_of(pc, k, i) < INFINITY) {
-          const double s = S::ub_of(pc, k, i) - znew;
-          l.zU[e] = fmin(fmax(l.zU[e] + a_z * l.dzU[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
-        }
+      if (lb > -INFINITY) {
+        const double s = znew - lb;
+        l.zL[e] = fmin(fmax(l.zL[e] + a_z * l.dzL[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
+      }
+      if (ub < INFINITY) {
+        const double s = ub - znew;
+        l.zU[e] = fmin(fmax(l.zU[e] + a_z * l.dzU[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
       }
     }
     for (int e = t; e < N * NX; e += T) l.lam[e] += alpha * (l.lamn[e] - l.lam[e]);
