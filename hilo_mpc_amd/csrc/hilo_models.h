@@ -324,6 +324,10 @@ HD void model_step(int order, int nsub, const T* x, const U* u, const P* p, doub
     else M::ode(x, u, p, dt, xn);
   } else {
     constexpr int NX = M::NX;
+    if (order == 4 && nsub == 1) {  // the common recipe `model.discretize('rk4')`: tableau folded at compile time
+      erk_step<M>(4, x, u, p, dt, xn, ext);
+      return;
+    }
     const double h = dt / nsub;
     T xc[NX];
 #pragma unroll

@@ -318,6 +318,7 @@ struct Ocp {
     const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
+    const unsigned pinm = FIX_X0 ? (~pc.x0_free_mask) & ((1u << NX) - 1u) : 0u;  // pinned slots of x_0 (bit i)
     constexpr int GPW = COOP ? 64 / NDIR : 1;  // cooperative: lane groups of NDIR directions, GPW intervals per round
     const int ntask = COOP ? ((N + GPW - 1) / GPW) * 64 + NXDIR : N * NDIR + NXDIR;
     const int tbase = ntask - NXDIR;
@@ -338,7 +339,7 @@ struct Ocp {
         }
         int di = d, dj = -1;
         if (d >= NZ) pair_of(d, NZ, di, dj);
-        const bool dead = k == 0 && (x0_pinned(pc, di) || (dj >= 0 && x0_pinned(pc, dj)));  // touches the pinned x_0
+        const bool dead = k == 0 && ((((pinm >> di) | (dj >= 0 ? pinm >> dj : 0u)) & 1u) != 0u);  // touches the pinned x_0
         if (dead && active) {
           l.Qd[task] = 0.0;
           if (d < NZ) {
@@ -369,11 +370,23 @@ struct Ocp {
         Jet2 lc(0.0);
         if constexpr (!PB::QUAD_COST) lc = PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
         double q = lc.b;
+        {  // operands first (one LDS wait), then the two store groups each under ONE condition
+          double zn[NX], lamv[NX];
 #pragma unroll
-        for (int m = 0; m < NX; ++m) {
-          if (d == 0) l.c[k * NX + m] = l.Z[(k + 1) * NZ + m] - xn[m].v;
-          if (d < NZ && !dead) l.AB[(k * NX + m) * NZ + d] = xn[m].a;
-          q -= l.lam[k * NX + m] * xn[m].b;
+          for (int m = 0; m < NX; ++m) {
+            zn[m] = l.Z[(k + 1) * NZ + m];
+            lamv[m] = l.lam[k * NX + m];
+          }
+#pragma unroll
+          for (int m = 0; m < NX; ++m) q -= lamv[m] * xn[m].b;
+          if (d == 0) {
+#pragma unroll
+            for (int m = 0; m < NX; ++m) l.c[k * NX + m] = zn[m] - xn[m].v;
+          }
+          if (d < NZ && !dead) {
+#pragma unroll
+            for (int m = 0; m < NX; ++m) l.AB[(k * NX + m) * NZ + d] = xn[m].a;
+          }
         }
         if constexpr (!PB::QUAD_COST) {
           if (d == 0) l.fk[k] = lc.v;
@@ -421,7 +434,7 @@ struct Ocp {
         h = 0.5 * (Q[dir_of(a, b, NZ)] - Q[a] - Q[b]);
       }
       if constexpr (PB::QUAD_COST) h += PB::cost_hess(pc, k, i, j);
-      if (k == 0 && (x0_pinned(pc, i) || x0_pinned(pc, j))) h = 0.0;
+      if (k == 0 && (((pinm >> i) | (pinm >> j)) & 1u)) h = 0.0;
       l.W[e] = h;
     }
     if constexpr (PB::QUAD_COST) {
