@@ -314,7 +314,9 @@ struct Ocp {
   }
 
   // ---- full derivative evaluation at Z: c, AB, grad, per-stage cost values, Lagrangian Hessian blocks --------
-  __device__ OCP_PHASE static double eval_derivs(lds_double* lbase, double* ws) {
+  // inlined at its call sites: as a real call its ~170 live registers cost 66 callee-saved VGPR saves per call (17 KB of
+  // scratch per wave and call, 120 MB of HBM writes per 1024-instance launch)
+  __device__ __attribute__((always_inline)) static double eval_derivs(lds_double* lbase, double* ws) {
     const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
