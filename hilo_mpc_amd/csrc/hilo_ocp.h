@@ -316,7 +316,7 @@ struct Ocp {
   // ---- full derivative evaluation at Z: c, AB, grad, per-stage cost values, Lagrangian Hessian blocks --------
   // inlined at its call sites: as a real call its ~170 live registers cost 66 callee-saved VGPR saves per call (17 KB of
   // scratch per wave and call, 120 MB of HBM writes per 1024-instance launch)
-  __device__ __attribute__((always_inline)) static double eval_derivs(lds_double* lbase, double* ws) {
+  __device__ __attribute__((always_inline)) static double eval_derivs_body(lds_double* lbase, double* ws) {
     const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
@@ -460,6 +460,14 @@ struct Ocp {
     const double f = block_reduce<OpSum>(fpart, l.red);
     __syncthreads();
     return f;
+  }
+
+  __device__ OCP_PHASE static double eval_derivs_call(lds_double* lbase, double* ws) { return eval_derivs_body(lbase, ws); }
+  // Cooperative models exchange partial sums between lanes through LDS with workgroup barriers in between; as a real
+  // function (barriers kept as instructions) that is what was validated, so they keep the call.
+  __device__ __forceinline__ static double eval_derivs(lds_double* lbase, double* ws) {
+    if constexpr (COOP) return eval_derivs_call(lbase, ws);
+    else return eval_derivs_body(lbase, ws);
   }
 
   // dual residual of slot e: grad + J^T lam - zL + zU
