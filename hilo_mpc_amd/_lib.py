@@ -36,7 +36,8 @@ class NmpcDesc(C.Structure):
                [(n, C.c_void_p) for n in ('path_stage_idx', 'path_stage_W', 'path_term_idx', 'path_term_W', 'path_prog')] + \
                [(n, C.c_int32) for n in ('path_prog_len', 'n_con', 'con_soft', 'con_prog_len')] + \
                [(n, C.c_void_p) for n in ('con_prog', 'con_lb', 'con_ub', 'con_weight', 'con_max_violation')] + \
-               [('collocation_degree', C.c_int32), ('reserved2', C.c_int32), ('coll_A', C.c_void_p), ('coll_D', C.c_void_p)]
+               [('collocation_degree', C.c_int32), ('reserved2', C.c_int32), ('coll_A', C.c_void_p), ('coll_D', C.c_void_p),
+                ('time_varying', C.c_int32), ('reserved3', C.c_int32)]
 
 
 class MheDesc(C.Structure):
@@ -73,6 +74,7 @@ def _declare(lib):
         'hilo_nmpc_dims': (C.c_int, [vp, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]),
         'hilo_nmpc_reset_warm_start': (C.c_int, [vp]),
         'hilo_nmpc_solve': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        'hilo_nmpc_solve_tv': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_nmpc_profile': (C.c_int, [vp, i32, vp]),
         'hilo_nmpc_plant_step': (C.c_int, [vp, i64, vp, vp, vp, i64, vp, vp]),
         'hilo_mhe_create': (C.c_int, [P(MheDesc), i32, P(vp)]),

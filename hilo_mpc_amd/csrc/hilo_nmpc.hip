@@ -56,6 +56,7 @@ struct hilo_nmpc {
   int nu_out;        // width of the returned first input (model inputs, without the virtual path input)
   double* ws;        // iterate workspace of BIG variants [ws_batch][ws_bytes]
   int64_t ws_batch;
+  const TvVariant* tv;       // per-stage-data variant (trajectory references, time-varying parameters) or NULL
   const CollVariant* coll;   // collocation variant of the tracking policy or NULL
   double *vc, *lamc;         // the engine's compact [x | u] solution and defect multipliers (collocation output pass)
   int64_t vc_batch;
@@ -166,6 +167,15 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
                                 "continuous zoo models)", d->model_id, d->collocation_degree);
     lds = cv->lds_bytes(d->N);
   }
+  const TvVariant* tvv = nullptr;
+  if (d->time_varying) {
+    if (general || d->learned || cv)
+      return fail(HILO_ENOTSUP, "per-stage references / parameters together with path following, stage constraints, learned "
+                                "terms or collocation are not built");
+    tvv = nmpc_tv_find(d->model_id);
+    if (!tvv) return fail(HILO_ENOTSUP, "no per-stage-data instantiation for model %d in this build", d->model_id);
+    lds = tvv->lds_bytes(d->N);
+  }
   if (lds > 160 * 1024)
     return fail(HILO_ENOTSUP, "horizon %d needs %zu B of LDS per instance (limit 163840)", d->N, lds);
   // engine dimensions: [model x | theta | e], [model u | u_theta]
@@ -176,6 +186,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   h->device = device; h->model_id = d->model_id; h->nx = nx; h->nu = nu; h->np = np; h->N = d->N;
   h->gen = gv; h->nu_out = nu;
   h->coll = cv;
+  h->tv = tvv;
   h->n_vc = (d->N + 1) * nx + d->N * nu;
   const int dn = cv ? cv->degree * nx : 0;
   h->n_v = (d->N + 1) * nxv + d->N * nue + ne + d->N * dn;   // mpc.py:1440-1443 (+ the soft-constraint slack, :1529-1537)
@@ -360,7 +371,7 @@ __global__ void nmpc_pack_par_kernel(int64_t batch, int np, int nu, const double
   if (e >= batch * w) return;
   const int64_t b = e / w;
   const int i = (int)(e - b * w);
-  out[e] = i < np ? p[b * p_stride + i] : (u_old ? u_old[b * nu + (i - np)] : 0.0);
+  out[e] = i < np ? (p ? p[b * p_stride + i] : 0.0) : (u_old ? u_old[b * nu + (i - np)] : 0.0);
 }
 
 template <class M>
@@ -378,14 +389,16 @@ static int nmpc_launch(hilo_nmpc* h, int64_t batch, const double* x0, const doub
   return HILO_OK;
 }
 
-extern "C" int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch, const double* x0, const double* p, int64_t p_stride,
-                               const double* v0, const double* u_old, double* v_opt, double* f_opt, double* lam_g,
-                               double* u0, int32_t* status, int32_t* iters, double* kkt, void* stream) {
+static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const double* p, int64_t p_stride,
+                           const double* stage_data, int64_t sd_stride, const double* v0, const double* u_old, double* v_opt,
+                           double* f_opt, double* lam_g, double* u0, int32_t* status, int32_t* iters, double* kkt, void* stream) {
   HILO_REQUIRE(h, "hilo_nmpc_solve: NULL handle");
   HILO_REQUIRE(batch >= 0, "hilo_nmpc_solve: negative batch");
   if (batch == 0) return HILO_OK;
   HILO_REQUIRE(x0 && v_opt && f_opt && u0 && status && iters, "hilo_nmpc_solve: NULL argument");
-  HILO_REQUIRE(h->np == 0 || p, "hilo_nmpc_solve: the model has %d parameters but p is NULL (mpc.py:771-780)", h->np);
+  HILO_REQUIRE(h->np == 0 || p || h->tv, "hilo_nmpc_solve: the model has %d parameters but p is NULL (mpc.py:771-780)", h->np);
+  HILO_REQUIRE((h->tv != nullptr) == (stage_data != nullptr),
+               "hilo_nmpc_solve: handles created with desc.time_varying are solved by hilo_nmpc_solve_tv (and only those)");
   HILO_REQUIRE(p_stride == 0 || p_stride >= h->np, "hilo_nmpc_solve: p_stride %lld < np", (long long)p_stride);
   HILO_HIP_CHECK(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
@@ -411,7 +424,11 @@ extern "C" int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch, const double* x0, co
     else { vstart = h->v_guess; vstride = 0; }
   }
   int rc = HILO_ENOTSUP;
-  if (h->coll) {
+  if (h->tv) {
+    GenLaunchArgs a{h->dev, batch, x0, h->par_buf, (int64_t)(h->np + h->nu), vstart, vstride, v_opt, f_opt, lam_g, u0,
+                    status, iters, kkt, h->prof, h->lds_bytes, s, nullptr};
+    rc = h->tv->launch(a, stage_data, sd_stride);
+  } else if (h->coll) {
     if (h->vc_batch != batch) {
       if (h->vc) HILO_HIP_CHECK(hipFree(h->vc));
       if (h->lamc) HILO_HIP_CHECK(hipFree(h->lamc));
@@ -458,6 +475,24 @@ extern "C" int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch, const double* x0, co
   HILO_HIP_CHECK(hipMemcpyAsync(h->v_warm, v_opt, sizeof(double) * h->n_v * batch, hipMemcpyDeviceToDevice, s));
   h->warm_valid = 1;
   return HILO_OK;
+}
+
+extern "C" int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch, const double* x0, const double* p, int64_t p_stride,
+                               const double* v0, const double* u_old, double* v_opt, double* f_opt, double* lam_g,
+                               double* u0, int32_t* status, int32_t* iters, double* kkt, void* stream) {
+  return nmpc_solve_impl(h, batch, x0, p, p_stride, nullptr, 0, v0, u_old, v_opt, f_opt, lam_g, u0, status, iters, kkt, stream);
+}
+
+extern "C" int hilo_nmpc_solve_tv(hilo_nmpc* h, int64_t batch, const double* x0, const double* stage_data, int64_t sd_stride,
+                                  const double* v0, const double* u_old, double* v_opt, double* f_opt, double* lam_g,
+                                  double* u0, int32_t* status, int32_t* iters, double* kkt, void* stream) {
+  HILO_REQUIRE(h && h->tv, "hilo_nmpc_solve_tv: the handle was not created with desc.time_varying");
+  HILO_REQUIRE(batch <= 0 || stage_data, "hilo_nmpc_solve_tv: NULL stage data");
+  const int64_t need = (int64_t)(h->N + 1) * (h->nx + h->nu + h->np);
+  HILO_REQUIRE(sd_stride == 0 || sd_stride >= need, "hilo_nmpc_solve_tv: sd_stride %lld < %lld", (long long)sd_stride,
+               (long long)need);
+  return nmpc_solve_impl(h, batch, x0, nullptr, 0, stage_data, sd_stride, v0, u_old, v_opt, f_opt, lam_g, u0, status, iters, kkt,
+                         stream);
 }
 
 // Developer aid: per-phase shader-clock totals of instance 0 of the next solves

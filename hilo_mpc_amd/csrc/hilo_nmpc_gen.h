@@ -116,7 +116,7 @@ struct NmpcGen {
     return acc;
   }
 
-  __device__ __forceinline__ static double cost_grad(const OcpConst& pc, const double* par, int k, int i, const double* z) {
+  __device__ __forceinline__ static double cost_grad(const OcpConst& pc, const double* par, const double*, int k, int i, const double* z) {
     double g = 0.0;
 #pragma unroll
     for (int j = 0; j < NZ; ++j) g += (pc.cost[O_WZ + i * NZ + j] + pc.cost[O_WZ + j * NZ + i]) * (z[j] - pc.cost[O_ZREF + j]);
@@ -225,6 +225,14 @@ struct CollVariant {
                 int64_t par_stride, double* v, double* lam_g, hipStream_t s);
 };
 const CollVariant* nmpc_coll_find(int model_id, int degree);
+
+// per-stage-data variants of the tracking policy (hilo_nmpc_tv.hip)
+struct TvVariant {
+  int model_id;
+  size_t (*lds_bytes)(int N);
+  int (*launch)(const GenLaunchArgs& a, const double* stage_data, int64_t sd_stride);
+};
+const TvVariant* nmpc_tv_find(int model_id);
 
 template <class PB>
 int gen_launch(const GenLaunchArgs& a) {

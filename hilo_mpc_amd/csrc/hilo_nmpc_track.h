@@ -63,7 +63,7 @@ struct NmpcTrack {
   }
 
   // d/dz_i and d2/dz_i dz_j of (z - zref)^T Wz (z - zref) [+ (u - u_old)^T Wdu (u - u_old) in interval 0]
-  __device__ __forceinline__ static double cost_grad(const OcpConst& pc, const double* par, int k, int i, const double* z) {
+  __device__ __forceinline__ static double cost_grad(const OcpConst& pc, const double* par, const double*, int k, int i, const double* z) {
     double g = 0.0;
 #pragma unroll
     for (int j = 0; j < NZ; ++j) g += (pc.cost[O_WZ + i * NZ + j] + pc.cost[O_WZ + j * NZ + i]) * (z[j] - pc.cost[O_ZREF + j]);

@@ -442,7 +442,7 @@ struct Ocp {
     if constexpr (PB::QUAD_COST) {
       for (int e = threadIdx.x; e < N * NZ; e += blockDim.x) {
         const int k = e / NZ, i = e - k * NZ;
-        if (is_free(pc, k, i)) l.grad[e] = PB::cost_grad(pc, (const double*)l.par, k, i, (const double*)(l.Z + k * NZ));
+        if (is_free(pc, k, i)) l.grad[e] = PB::cost_grad(pc, (const double*)l.par, sd_of(l, k), k, i, (const double*)(l.Z + k * NZ));
       }
       for (int k = threadIdx.x; k < N; k += blockDim.x) {
         double x[NX], u[NU > 0 ? NU : 1];

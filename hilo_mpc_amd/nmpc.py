@@ -86,13 +86,26 @@ class QuadraticCost:
         self._model = model
         self._terms = []          # (type, indices, W, ref)
         self._paths = []          # (state indices, W, [expression of theta])
+        self._trajectories = []   # (kind, names, indices): references supplied per call
         self._is_set = False
 
     def _add(self, kind, names, pool, weights, ref, path_following, trajectory_tracking):
-        if trajectory_tracking:
-            raise NotImplementedError("trajectory tracking references are not yet offloaded (SURVEY.md 8f); use "
-                                      "constant or path references")
         names = [names] if isinstance(names, str) else list(names)
+        if trajectory_tracking:
+            # modeling.py:262-283: the reference is a placeholder filled per call from `optimize(ref_sc=..., ref_tc=...)`
+            # (mpc.py:365-463); a reference given as a function of time is not offloaded
+            if ref is not None:
+                raise NotImplementedError("trajectory references as functions of the time variable are not offloaded; "
+                                          "pass the sampled trajectory to optimize(ref_sc=..., ref_tc=...)")
+            ind = []
+            for n in names:
+                if n not in pool:
+                    raise ValueError(f"The state {n} does not exist. The available states are {pool}")
+                ind.append(pool.index(n))
+            self._terms.append((kind, ind, _weight_matrix(weights, len(names), 'weights'), None))
+            self._trajectories.append((kind, names, ind))
+            self._is_set = True
+            return
         if path_following:
             # modeling.py:252-261: the reference is an expression of the path variable, substituted into the cost
             if kind != 'states':
@@ -132,6 +145,12 @@ class QuadraticCost:
 
     def add_inputs_change(self, names, weights):
         self._add('inputs_change', names, self._model.input_names, weights, None, False, False)
+
+    @property
+    def name_open_varying_trajectories(self):
+        return [n for _, names, _ in self._trajectories for n in names]
+
+    _has_trajectory_following = property(lambda s: bool(s._trajectories))
 
     def add_measurements(self, names, weights, ref=None, path_following=False, trajectory_tracking=False):
         raise NotImplementedError("measurement costs are not yet offloaded; add the corresponding states instead")
@@ -205,6 +224,8 @@ class NMPC:
         self.stage_constraint = GenericConstraint(model, name='stage constraint')
         self.terminal_constraint = GenericConstraint(model, name='terminal constraint')
         self._paths_var_list = []
+        self._time_varying_parameters = []
+        self._time_varying_parameters_values = None
         self._prediction_horizon = self._control_horizon = None
         self._x_lb = self._x_ub = self._u_lb = self._u_ub = None
         self._x_guess = self._u_guess = None
@@ -258,6 +279,29 @@ class NMPC:
 
     n_iterations = property(lambda s: s._n_iterations)
     n_of_path_vars = property(lambda s: len(s._paths_var_list))
+
+    def set_time_varying_parameters(self, names=None, values=None):
+        """optimizer.py:1519-1560: model parameters whose value changes along the horizon; `values` {name: sequence} may be
+        given here (then the horizon window advances with the iteration counter, mpc.py:292-333) or to optimize(tvp=...)."""
+        if names is None:
+            self._time_varying_parameters = []
+        else:
+            if not (isinstance(names, (list, tuple)) and all(isinstance(n, str) for n in names)):
+                raise ValueError('Tvp must be a list of strings with the paramers name that are time varying')
+            for tvp in names:
+                if tvp not in self._model.parameter_names:
+                    raise ValueError(f"I could not find the parameter {tvp} in the model. The models parameters are "
+                                     f"{self._model.parameter_names}.")
+            self._time_varying_parameters = list(names)
+        if values is not None:
+            if not isinstance(values, dict):
+                raise TypeError("The values parameter must be a dictionary.")
+            for key in values:
+                if key not in (names or []):
+                    raise ValueError(f"The key {key} is not in the name vector: {names}. You need to pass a dictionary "
+                                     f"where the keys are the name of the time varying parameters.")
+        self._time_varying_parameters_values = values
+        self._n_tvp = len(self._time_varying_parameters)
 
     def create_path_variable(self, name='theta', u_pf_lb=0.0001, u_pf_ub=1, u_pf_ref=None, u_pf_weight=10,
                              theta_guess=0, theta_lb=0, theta_ub=np.inf):
@@ -480,6 +524,10 @@ class NMPC:
                 d.con_weight = hp(_weight_matrix(sc.weight, nc, 'weight')) if sc.weight is not None else None
                 d.con_max_violation = hp(sc.max_violation) if sc.max_violation is not None else None
         self._nth, self._ne = nth, ne
+        self._tv = bool(self._time_varying_parameters or self.quad_stage_cost._trajectories or
+                        self.quad_terminal_cost._trajectories)
+        d.time_varying = int(self._tv)
+        self._zref_const, self._xrefN_const = zref.copy(), xrefN.copy()
         if coll is not None:
             d.collocation_degree = coll['d']
             d.coll_A, d.coll_D = hp(coll['A']), hp(coll['D'])
@@ -524,8 +572,9 @@ class NMPC:
                                       "(mpc.py:740) and is not offloaded")
         if not fix_x0:
             raise NotImplementedError("fix_x0=False is not yet offloaded")
-        if tvp is not None:
-            raise NotImplementedError("time-varying parameters are not yet offloaded")
+        if tvp is not None and not self._time_varying_parameters:
+            raise ValueError("tvp values were passed but no parameter was declared time varying "
+                             "(set_time_varying_parameters)")
         host = not isinstance(x0, torch.Tensor)
         x = to_dev(x0, self._dev)
         single = x.ndim <= 1 or (x.ndim == 2 and x.shape[1] == 1 and x.shape[0] == self._n_x and self._n_x != 1)
@@ -534,7 +583,11 @@ class NMPC:
             raise ValueError(f"We have an issue mate, the x0 you supplied has dimension {x.shape[1]} but the model has "
                              f"{self._n_x} states.")
         B = x.shape[0]
-        if self._n_p != 0:
+        sd = None
+        if getattr(self, '_tv', False):
+            sd = to_dev(self._stage_table(cp, tvp, kwargs), self._dev).contiguous()
+            p, ps = None, 0
+        elif self._n_p != 0:
             if cp is None:
                 raise ValueError(f"The model has {self._n_p} constant parameter(s): {self._model.parameter_names}. "
                                  f"You must pass me the value of these before running the optimization to the 'cp' "
@@ -579,9 +632,14 @@ class NMPC:
         iters = torch.empty(B, dtype=torch.int32, device=dev)
         kkt = torch.empty(B, dtype=torch.float64, device=dev)
         t0 = time.time() if self._stats else None
-        _lib.check(_lib.lib().hilo_nmpc_solve(self._handle, B, ptr(x.contiguous()), ptr(p), ps, ptr(v0t), ptr(u_old),
-                                              ptr(v_opt), ptr(f_opt), ptr(lam_g), ptr(u0), ptr(status), ptr(iters),
-                                              ptr(kkt), stream_ptr(dev)))
+        if sd is not None:
+            _lib.check(_lib.lib().hilo_nmpc_solve_tv(self._handle, B, ptr(x.contiguous()), ptr(sd), 0, ptr(v0t), ptr(u_old),
+                                                     ptr(v_opt), ptr(f_opt), ptr(lam_g), ptr(u0), ptr(status), ptr(iters),
+                                                     ptr(kkt), stream_ptr(dev)))
+        else:
+            _lib.check(_lib.lib().hilo_nmpc_solve(self._handle, B, ptr(x.contiguous()), ptr(p), ps, ptr(v0t), ptr(u_old),
+                                                  ptr(v_opt), ptr(f_opt), ptr(lam_g), ptr(u0), ptr(status), ptr(iters),
+                                                  ptr(kkt), stream_ptr(dev)))
         self._nlp_solution = {'x': v_opt, 'f': f_opt, 'lam_g': lam_g, 'status': status, 'iter_count': iters,
                               'kkt_error': kkt}
         if self._has_du:
@@ -597,6 +655,103 @@ class NMPC:
             u = u0.cpu().numpy()
             return u.reshape(-1, 1) if single else u     # single instance: (nu x 1) like the reference's DM
         return u0[0] if single else u0
+
+    def _stage_table(self, cp, tvp, kwargs):
+        """[(N+1), nz + np]: per stage [zref_k / scaling | p_k]; row N = terminal reference (first nx entries).
+        References: mpc.py:365-463 (`ref_sc` / `ref_tc`: one value = constant, else the window
+        [n_iterations, n_iterations + N) and the terminal sample n_iterations + N), divided by the scaling like
+        modeling.py:329.  Parameters: mpc.py:335-364 + optimizer.py:905-929 (`cp` holds the NON time-varying parameters in
+        model order; the rows of the tvp window are consumed in model order)."""
+        N, nx, nu, npar = self._prediction_horizon, self._n_x, self._n_u, self._n_p
+        nz = nx + nu
+        tab = np.zeros((N + 1, nz + npar))
+        tab[:N, :nz] = self._zref_const
+        tab[N, :nx] = self._xrefN_const
+        ci = self._n_iterations
+
+        def window(traj, name, terminal):
+            t = _wrap_list(traj)
+            if len(t) == 1:
+                return t[0] if terminal else np.full(N, t[0])
+            if ci + N >= len(t):
+                raise ValueError(f"The length of the varying reference must be one or longer than than the simulation time "
+                                 f"plus the prediction horizon. Please supply data points. The trajectory is long {len(t)} "
+                                 f"but I am predicting at least up to the {ci + N + 1} step.")
+            return t[ci + N] if terminal else np.asarray(t[ci:ci + N])
+        for cost, key, terminal in ((self.quad_stage_cost, 'ref_sc', False), (self.quad_terminal_cost, 'ref_tc', True)):
+            if not cost._trajectories:
+                continue
+            ref = kwargs.get(key)
+            if ref is None:
+                raise ValueError(f"Mate, it looks like the variable(s) {cost.name_open_varying_trajectories} must follow a "
+                                 f"reference, but you did not pass any. Please pass a reference as values in "
+                                 f"optimize({key}=...).")
+            if not isinstance(ref, dict):
+                raise TypeError("The trajectory must be a dict with as key the name of the variables that have a trajectory.")
+            for k_ in ref:
+                if k_ not in cost.name_open_varying_trajectories:
+                    raise ValueError(f"I cannot find the variable {k_} in the variables with varying trajectory. The "
+                                     f"trajectories without reference are {', '.join(cost.name_open_varying_trajectories)}")
+            for kind, names, ind in cost._trajectories:
+                for name, i in zip(names, ind):
+                    col = i if kind == 'states' else nx + i
+                    sc = self._sx[i] if kind == 'states' else self._su[i]
+                    if terminal:
+                        tab[N, col] = window(ref[name], name, True) / sc
+                    else:
+                        tab[:N, col] = window(ref[name], name, False) / sc
+        if npar:
+            names = self._model.parameter_names
+            n_tvp = len(self._time_varying_parameters)
+            cpv = np.zeros(0) if cp is None else np.asarray(cp.cpu() if isinstance(cp, torch.Tensor) else cp, dtype=float).ravel()
+            if cpv.size != npar - n_tvp:
+                raise ValueError(f"The model has {npar - n_tvp} constant parameter(s): "
+                                 f"{[n for n in names if n not in self._time_varying_parameters]}. You must pass me the "
+                                 f"value of these before running the optimization to the 'cp' parameter.")
+            win = np.zeros((n_tvp, N))
+            if n_tvp:
+                if tvp is not None:                                              # mpc.py:341-354
+                    for r, (key, value) in enumerate(tvp.items()):
+                        if len(value) < N:
+                            raise TypeError(f"When passing time-varying parameters, you need to pass a number of values at "
+                                            f"least as long as the prediction horizon. The parameter {key} has {len(value)} "
+                                            f"values but the MPC has a prediction horizon length of {N}.")
+                        win[r] = np.asarray(value[0:N], dtype=float)
+                elif self._time_varying_parameters_values is not None:           # mpc.py:292-333
+                    vals = self._time_varying_parameters_values
+                    if ci == 0 or getattr(self, '_tvp_window', None) is None:
+                        for r, (key, value) in enumerate(vals.items()):
+                            if len(value) < N:
+                                raise TypeError(f"The parameter {key} has {len(value)} values but the MPC has a prediction "
+                                                f"horizon length of {N}.")
+                            win[r] = np.asarray(value[0:N], dtype=float)
+                    else:
+                        win = self._tvp_window.copy()
+                        win[:, :-1] = win[:, 1:]
+                        for r, name in enumerate(self._time_varying_parameters):
+                            value = vals[name]
+                            if ci + N > len(value):
+                                warnings.warn("The prediction horizon is predicting outside the values of the time varying "
+                                              "parameters. I am now taking looping back the values and start from there.")
+                                win[r, -1] = value[ci - N * int(np.floor(ci / N))]
+                            else:
+                                win[r, -1] = value[ci + N - 1]
+                    self._tvp_window = win
+                else:
+                    raise ValueError(f"Mate, I know there are {n_tvp} time varying parameters but you did not pass me any."
+                                     f"Please provide me with the values of the parameters, either to the optimize() "
+                                     f"method or to the set_time_varying_parameters() method.")
+            for k in range(N):                                                   # optimizer.py:905-929
+                it, ic = 0, 0
+                for j, name in enumerate(names):
+                    if name in self._time_varying_parameters:
+                        tab[k, nz + j] = win[it, k]
+                        it += 1
+                    else:
+                        tab[k, nz + j] = cpv[ic]
+                        ic += 1
+            tab[N, nz:] = tab[N - 1, nz:]
+        return tab
 
     # ---- results --------------------------------------------------------------------------------------------
     @property

@@ -235,6 +235,10 @@ typedef struct hilo_nmpc_desc {
   int32_t reserved2;
   const double* coll_A;                  /* [d][d] */
   const double* coll_D;                  /* [d+1] */
+  /* ---- per-stage data: trajectory-tracking references (mpc.py:365-463; modeling.py:262-283) and time-varying parameters
+     (mpc.py:335-364, optimizer.py:905-929).  With time_varying != 0 the handle is solved through hilo_nmpc_solve_tv. ---- */
+  int32_t time_varying;
+  int32_t reserved3;
 } hilo_nmpc_desc;
 
 /* expression programs: [len, (op, arg) * len/2] back to back; postfix, stack of 8 */
@@ -275,6 +279,13 @@ int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch,
                     int32_t* iters,                   /* [B] interior-point iterations */
                     double* kkt,                      /* [B] scaled optimality error at the returned point or NULL */
                     void* stream);
+/* optimize() with per-stage data (handles created with desc.time_varying): stage_data[b][k] = [zref_k (nz, scaled like the
+   references of QuadraticCost, modeling.py:329) | p_k (np)] for k = 0..N; row N holds the terminal reference in its first nx
+   entries.  sd_stride = 0 shares one table among the batch, else >= (N+1)(nz+np).  The constant references of the desc are
+   not used. */
+int hilo_nmpc_solve_tv(hilo_nmpc* h, int64_t batch, const double* x0, const double* stage_data, int64_t sd_stride,
+                       const double* v0, const double* u_old, double* v_opt, double* f_opt, double* lam_g, double* u0,
+                       int32_t* status, int32_t* iters, double* kkt, void* stream);
 /* developer aid: per-phase shader-clock totals of instance 0 (derivatives, errors, Riccati, step, line search,
    update, number of factorisations, number of line-search trial points); enable != 0 starts collecting,
    cycles_host[8] (may be NULL) receives the last launch's counters */

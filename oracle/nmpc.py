@@ -284,18 +284,21 @@ class DenseIpm:
         """objective (with the terminal term on x_N, which equals Phi_{N-1} on the feasible set) and defects."""
         pb = self.pb
         x0, p, u_old = data['x0'], data['p'], data.get('u_old')
+        # trajectory tracking / time-varying parameters (mpc.py:365-463, :335-364): per-stage references zref_k [B,N,nz]
+        # (already divided by the scaling), terminal reference [B,nx], per-stage parameters p_k [B,N,np]
+        zr, xrN, pk = data.get('zref_k'), data.get('xrefN'), data.get('p_k')
         X, U = self._XU(w, x0)
         B = w.shape[0]
         f = np.zeros(B)
         c = np.empty((B, pb.N, pb.nx))
         for k in range(pb.N):
-            z = np.concatenate([X[:, k], U[:, k]], axis=1) - pb.zref
+            z = np.concatenate([X[:, k], U[:, k]], axis=1) - (pb.zref if zr is None else zr[:, k])
             f += np.einsum('bi,ij,bj->b', z, pb.Wz, z)
-            c[:, k] = X[:, k + 1] - pb.phi(X[:, k], U[:, k], p)
+            c[:, k] = X[:, k + 1] - pb.phi(X[:, k], U[:, k], p if pk is None else pk[:, k])
         if u_old is not None:
             d = U[:, 0] - u_old
             f += np.einsum('bi,ij,bj->b', d, pb.Wdu, d)
-        d = X[:, pb.N] - pb.xrefN
+        d = X[:, pb.N] - (pb.xrefN if xrN is None else xrN)
         f += np.einsum('bi,ij,bj->b', d, pb.WN, d)
         return f, c.reshape(B, -1)
 
@@ -304,6 +307,7 @@ class DenseIpm:
         pb = self.pb
         N, nx, nu, nz = pb.N, pb.nx, pb.nu, pb.nz
         x0, p, u_old = data['x0'], data['p'], data.get('u_old')
+        zr, xrN, pk = data.get('zref_k'), data.get('xrefN'), data.get('p_k')
         X, U = self._XU(w, x0)
         B = w.shape[0]
         f = np.zeros(B)
@@ -315,11 +319,11 @@ class DenseIpm:
         for k in range(N):
             zi = (self.ix[k - 1] if k > 0 else []) + self.iu[k]           # free columns of stage k's z
             sel = (list(range(nx)) if k > 0 else []) + list(range(nx, nz))
-            z = np.concatenate([X[:, k], U[:, k]], axis=1) - pb.zref
+            z = np.concatenate([X[:, k], U[:, k]], axis=1) - (pb.zref if zr is None else zr[:, k])
             f += np.einsum('bi,ij,bj->b', z, pb.Wz, z)
             gz = 2 * z @ pb.Wz
             Hz = np.broadcast_to(2 * pb.Wz, (B, nz, nz)).copy()
-            Phi, Jk, Hk = pb.phi(X[:, k], U[:, k], p, need=2)
+            Phi, Jk, Hk = pb.phi(X[:, k], U[:, k], p if pk is None else pk[:, k], need=2)
             c[:, k] = X[:, k + 1] - Phi
             Hz -= np.einsum('bm,bmzy->bzy', lam[:, k], Hk)
             if k == 0 and u_old is not None:
@@ -332,7 +336,7 @@ class DenseIpm:
             rows = list(range(k * nx, (k + 1) * nx))
             J[np.ix_(range(B), rows, zi)] = -Jk[:, :, sel]
             J[:, rows, self.ix[k]] = 1.0
-        d = X[:, N] - pb.xrefN
+        d = X[:, N] - (pb.xrefN if xrN is None else xrN)
         f += np.einsum('bi,ij,bj->b', d, pb.WN, d)
         g[:, self.ix[N - 1]] += 2 * d @ pb.WN
         W[np.ix_(range(B), self.ix[N - 1], self.ix[N - 1])] += 2 * pb.WN
@@ -364,9 +368,10 @@ class DenseIpm:
         return np.maximum.reduce([dual / s_d, prim, np.maximum(cl, cu) / s_c]), dual, prim, np.maximum(cl, cu)
 
     # ---- main loop --------------------------------------------------------------------------------------------
-    def solve(self, x0, p, w0=None, u_old=None, verbose=False):
+    def solve(self, x0, p, w0=None, u_old=None, verbose=False, zref_k=None, xrefN=None, p_k=None):
         """x0 [B,nx] original units; p [B,np] or [np]; w0 optional warm start (free variables, scaled).
-        Returns dict(w, lam, zl, zu, f, status, iters, X, U, kkt)."""
+        zref_k [N,nz] / xrefN [nx]: per-stage / terminal references in ORIGINAL units (divided by the scaling here like
+        modeling.py:329); p_k [N,np]: per-stage model parameters.  Returns dict(w, lam, zl, zu, f, status, iters, X, U, kkt)."""
         o, pb = self.o, self.pb
         x0 = np.atleast_2d(np.asarray(x0, dtype=float)) / pb.sx
         B = x0.shape[0]
@@ -378,6 +383,13 @@ class DenseIpm:
         data = {'x0': x0, 'p': p}
         if u_old is not None:
             data['u_old'] = u_old
+        sz = np.concatenate([pb.sx, pb.su])
+        if zref_k is not None:
+            data['zref_k'] = np.broadcast_to(np.asarray(zref_k, dtype=float) / sz, (B, pb.N, pb.nz))
+        if xrefN is not None:
+            data['xrefN'] = np.broadcast_to(np.asarray(xrefN, dtype=float) / pb.sx, (B, pb.nx))
+        if p_k is not None:
+            data['p_k'] = np.broadcast_to(np.asarray(p_k, dtype=float), (B, pb.N, pb.np_))
         res = self.solve_data(data, w0, verbose)
         X, U = self._XU(res['w'], x0)
         res.update(X=X, U=U, u0=U[:, 0] * pb.su)

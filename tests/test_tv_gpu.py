@@ -1,0 +1,85 @@
+"""GPU parity of trajectory tracking (`add_states(..., trajectory_tracking=True)` + `optimize(ref_sc=, ref_tc=)`) and
+time-varying parameters (`set_time_varying_parameters`, `optimize(tvp=)`): SURVEY 8 rows a4 / a18 (hilo_nmpc_solve_tv)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.nmpc import DenseIpm                             # noqa: E402
+from tests.problems import C2, c2_x0, oracle_problem         # noqa: E402
+
+N = 12
+
+
+def _product(tvp_names=None, values=None):
+    from hilo_mpc_amd import NMPC, Model
+    m = Model('chemostat4').discretize('rk4').setup(dt=1.)
+    nmpc = NMPC(m)
+    nmpc.quad_stage_cost.add_states(names=['P'], weights=[10.], trajectory_tracking=True)
+    nmpc.quad_stage_cost.add_inputs(names=['DS', 'DI'], weights=[.1, .1])
+    nmpc.quad_terminal_cost.add_states(names=['P'], weights=[10.], trajectory_tracking=True)
+    nmpc.horizon = N
+    nmpc.set_box_constraints(x_lb=C2['x_lb'], u_lb=C2['u_lb'], u_ub=C2['u_ub'])
+    nmpc.set_initial_guess(x_guess=C2['x_guess'], u_guess=C2['u_guess'])
+    if tvp_names:
+        nmpc.set_time_varying_parameters(tvp_names, values)
+    nmpc.setup(options={'integration_method': 'discrete'})
+    return nmpc
+
+
+def test_trajectory_and_tvp_closed_loop_vs_oracle():
+    pb = oracle_problem(dict(C2, N=N))
+    ipm = DenseIpm(pb)
+    x = c2_x0(6)
+    traj = list(1. + .05 * np.arange(40))                       # reference of P over time
+    sf = list(100. + 2. * np.sin(.3 * np.arange(40)))            # feed concentration Sf over time
+    nmpc = _product(['Sf'])
+    w = None
+    for it in range(3):
+        zr = np.zeros((N, 6))
+        zr[:, 2] = traj[it:it + N]
+        pk = np.tile(C2['p'], (N, 1))
+        pk[:, 0] = sf[it:it + N]
+        ref = ipm.solve(x, C2['p'], w0=w, zref_k=zr, xrefN=[0., 0., traj[it + N], 0.], p_k=pk)
+        u = nmpc.optimize(x, cp=C2['p'][1:], tvp={'Sf': sf[it:]}, ref_sc={'P': traj}, ref_tc={'P': traj})
+        assert np.array_equal(nmpc.solver_status_code, ref['status']) and np.all(ref['status'] == 1)
+        v, vr = nmpc._nlp_solution['x'].cpu().numpy(), ipm.to_v(ref)
+        assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 5e-5, it
+        np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-8)
+        np.testing.assert_allclose(u, ref['u0'], rtol=5e-5, atol=1e-6)
+        w = ref['w']
+        x = pb.phi(x / pb.sx, ref['U'][:, 0], pk[0]) * pb.sx
+
+
+def test_stored_tvp_window_advances_and_constant_reference():
+    """`set_time_varying_parameters(names, values)`: the window advances with the iteration counter (mpc.py:292-333); a
+    one-element reference is constant over the horizon (mpc.py:391-394)."""
+    sf = list(100. + np.arange(40.))
+    nmpc = _product(['Sf'], {'Sf': sf})
+    x = c2_x0(2)
+    nmpc.optimize(x, cp=C2['p'][1:], ref_sc={'P': [2.]}, ref_tc={'P': [2.]})
+    np.testing.assert_array_equal(nmpc._tvp_window[0], sf[:N])
+    nmpc.optimize(x, cp=C2['p'][1:], ref_sc={'P': [2.]}, ref_tc={'P': [2.]})
+    np.testing.assert_array_equal(nmpc._tvp_window[0], sf[1:N + 1])
+    # constant reference + constant parameter == the plain controller
+    from tests.problems import product_nmpc
+    plain = product_nmpc(dict(C2, N=N))
+    nm2 = _product(['Sf'])
+    u_tv = nm2.optimize(x, cp=C2['p'][1:], tvp={'Sf': [100.] * N}, ref_sc={'P': [2.]}, ref_tc={'P': [2.]})
+    u_pl = plain.optimize(x, cp=C2['p'])
+    np.testing.assert_allclose(u_tv, u_pl, rtol=1e-9, atol=1e-12)
+
+
+def test_tv_errors():
+    nmpc = _product(['Sf'])
+    x = c2_x0(1)
+    with pytest.raises(ValueError, match="must follow a reference"):
+        nmpc.optimize(x, cp=C2['p'][1:], tvp={'Sf': [100.] * N})
+    with pytest.raises(ValueError, match="did not pass me any"):
+        nmpc.optimize(x, cp=C2['p'][1:], ref_sc={'P': [2.]}, ref_tc={'P': [2.]})
+    with pytest.raises(TypeError, match="at least as long as the prediction horizon"):
+        nmpc.optimize(x, cp=C2['p'][1:], tvp={'Sf': [100.] * 3}, ref_sc={'P': [2.]}, ref_tc={'P': [2.]})
+    with pytest.raises(ValueError, match="longer than than the simulation time"):
+        nmpc.optimize(x, cp=C2['p'][1:], tvp={'Sf': [100.] * N}, ref_sc={'P': [2., 2., 2.]}, ref_tc={'P': [2.]})
+    with pytest.raises(ValueError, match="constant parameter"):
+        nmpc.optimize(x, cp=C2['p'], tvp={'Sf': [100.] * N}, ref_sc={'P': [2.]}, ref_tc={'P': [2.]})
