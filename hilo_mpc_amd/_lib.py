@@ -44,7 +44,9 @@ class MheDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('model_id', 'N', 'erk_order', 'n_sub', 'max_iter', 'acceptable_iter')] + \
                [(n, C.c_double) for n in ('dt', 'tol', 'acceptable_tol', 'mu_init', 'bound_relax_factor')] + \
                [(n, C.c_void_p) for n in ('Wx', 'Wy', 'Ww', 'x_lb', 'x_ub', 'w_lb', 'w_ub', 'x_scaling', 'w_scaling',
-                                          'u_scaling', 'x_guess', 'w_guess')]
+                                          'u_scaling', 'x_guess', 'w_guess')] + \
+               [('estimate_parameters', C.c_int32), ('reserved', C.c_int32)] + \
+               [(n, C.c_void_p) for n in ('Wp', 'p_lb', 'p_ub', 'p_scaling', 'p_guess')]
 
 
 _lib = None

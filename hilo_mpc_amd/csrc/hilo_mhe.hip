@@ -11,6 +11,7 @@
 // In engine terms: controls := the noise w_k (B_k = I), x_0 free, per-stage data = (u_meas_k, y_meas_k).
 #include <string.h>
 
+#include "hilo_mhe_est.h"
 #include "hilo_ocp.h"
 
 namespace hilo {
@@ -125,6 +126,9 @@ struct hilo_mhe {
   int64_t warm_batch, buf_batch;
   int warm_valid;
   size_t lds_bytes;
+  const MheEstVariant* est;          // parameter-estimating variant or NULL
+  double *x0e, *v0e, *ve, *lame, *v_guess_e;   // engine-layout buffers of the estimating variant
+  unsigned est_mask;                 // bit j: parameter j is a variable
 };
 
 #define HILO_MHE_MODELS(X)             \
@@ -142,7 +146,8 @@ static int mhe_model_dims(int id, int* nx, int* nu, int* np, int* ny, size_t* ld
 
 extern "C" void hilo_mhe_destroy(hilo_mhe* h) {
   if (!h) return;
-  double* ptrs[] = {(double*)h->dev, h->v_guess, h->v_warm, h->par_buf, h->sd_buf};
+  double* ptrs[] = {(double*)h->dev, h->v_guess, h->v_warm, h->par_buf, h->sd_buf, h->x0e, h->v0e, h->ve, h->lame,
+                    h->v_guess_e};
   for (double* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -156,9 +161,16 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
   size_t lds;
   int rc = mhe_model_dims(d->model_id, &nx, &nu, &np, &ny, &lds, d->N);
   if (rc) return rc;
+  const MheEstVariant* ev = nullptr;
+  if (d->estimate_parameters && np > 0) {
+    ev = mhe_est_find(d->model_id);
+    if (!ev) return fail(HILO_ENOTSUP, "model id %d has no parameter-estimating MHE instantiation in this build", d->model_id);
+    lds = ev->lds_bytes(d->N);
+  }
   if (lds > 160 * 1024) return fail(HILO_ENOTSUP, "horizon %d needs %zu B of LDS per instance (limit 163840)", d->N, lds);
   hilo_mhe* h = new hilo_mhe();
   memset(h, 0, sizeof(*h));
+  h->est = ev;
   h->device = device; h->model_id = d->model_id; h->nx = nx; h->nu = nu; h->np = np; h->ny = ny; h->N = d->N;
   h->n_v = np + (d->N + 1) * nx + d->N * nx;  // mhe.py:596-598
   h->n_g = d->N * nx;
@@ -194,9 +206,60 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
     HILO_REQUIRE(lb < ub, "hilo_mhe_create: empty box for variable %d", i);
     c.lbz[i] = lb; c.ubz[i] = ub;
   }
+  if (ev) {
+    // engine state = [x | p], engine input = w: re-lay the per-slot data of the plain variant
+    const int nxa = nx + np;
+    int o[5];
+    ev->offsets(o);
+    double sz[OCP_MAXNZ], lb[OCP_MAXNZ], ub[OCP_MAXNZ];
+    for (int i = 0; i < 2 * nx; ++i) { sz[i] = c.sz[i]; lb[i] = c.lbz[i]; ub[i] = c.ubz[i]; }
+    HILO_REQUIRE(nxa + nx <= OCP_MAXNZ && nxa <= OCP_MAXNX + OCP_MAXNU, "model too large for parameter estimation in this build");
+    memset(c.cost, 0, sizeof(c.cost));
+    for (int i = 0; i < nx * nx; ++i) c.cost[o[0] + i] = d->Wx ? d->Wx[i] : 0.0;
+    for (int i = 0; i < np * np; ++i) c.cost[o[1] + i] = d->Wp ? d->Wp[i] : 0.0;
+    for (int i = 0; i < ny * ny; ++i) c.cost[o[2] + i] = d->Wy ? d->Wy[i] : 0.0;
+    for (int i = 0; i < nx * nx; ++i) c.cost[o[3] + i] = d->Ww ? d->Ww[i] : 0.0;
+    for (int i = 0; i < nu; ++i) c.cost[o[4] + i] = d->u_scaling ? d->u_scaling[i] : 1.0;
+    for (int i = 0; i < nx; ++i) {
+      c.sz[i] = sz[i]; c.lbz[i] = lb[i]; c.ubz[i] = ub[i];
+      c.sz[nxa + i] = sz[nx + i]; c.lbz[nxa + i] = lb[nx + i]; c.ubz[nxa + i] = ub[nx + i];
+      c.x0_free_mask |= 1u << i;
+    }
+    for (int j = 0; j < np; ++j) {
+      const double sp = d->p_scaling ? d->p_scaling[j] : 1.0;
+      double pl = d->p_lb ? d->p_lb[j] / sp : -INFINITY, pu = d->p_ub ? d->p_ub[j] / sp : INFINITY;
+      if (!(pl <= pu)) { delete h; return fail(HILO_EINVAL, "hilo_mhe_create: p_lb > p_ub for parameter %d", j); }
+      const bool estimated = pl < pu;
+      c.sz[nx + j] = sp;
+      c.k0_only_mask |= 1u << (nx + j);                         // one box (and one barrier term) per parameter
+      if (estimated) {
+        c.x0_free_mask |= 1u << (nx + j);
+        h->est_mask |= 1u << j;
+        if (pl > -INFINITY) pl -= relax * fmax(1.0, fabs(pl));
+        if (pu < INFINITY) pu += relax * fmax(1.0, fabs(pu));
+        c.lbz[nx + j] = pl; c.ubz[nx + j] = pu;
+      } else {
+        c.lbz[nx + j] = -INFINITY; c.ubz[nx + j] = INFINITY;   // pinned through x_0 (IPOPT: fixed variable removed)
+      }
+    }
+  }
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc((void**)&h->dev, sizeof(OcpConst));
   if (e == hipSuccess) e = hipMemcpy(h->dev, &c, sizeof(OcpConst), hipMemcpyHostToDevice);
+  if (ev && e == hipSuccess) {
+    // tiled guess in engine layout: [x_guess | p_guess] per stage, w_guess (mhe.py:620, :633-649)
+    const int nxa = nx + np, nve = (d->N + 1) * nxa + d->N * nx;
+    double* g = new double[nve];
+    for (int k = 0; k <= d->N; ++k) {
+      for (int i = 0; i < nx; ++i) g[k * nxa + i] = (d->x_guess ? d->x_guess[i] : 0.0) / c.sz[i];
+      for (int j = 0; j < np; ++j) g[k * nxa + nx + j] = (d->p_guess ? d->p_guess[j] : 0.0) / c.sz[nx + j];
+    }
+    for (int k = 0; k < d->N; ++k)
+      for (int i = 0; i < nx; ++i) g[(d->N + 1) * nxa + k * nx + i] = (d->w_guess ? d->w_guess[i] : 0.0) / c.sz[nxa + i];
+    e = hipMalloc((void**)&h->v_guess_e, sizeof(double) * nve);
+    if (e == hipSuccess) e = hipMemcpy(h->v_guess_e, g, sizeof(double) * nve, hipMemcpyHostToDevice);
+    delete[] g;
+  }
   const int nvf = h->n_v - np;  // [x-block | w-block]
   if (e == hipSuccess) e = hipMalloc((void**)&h->v_guess, sizeof(double) * nvf);
   if (e == hipSuccess) {
@@ -279,6 +342,43 @@ extern "C" int hilo_mhe_estimate(hilo_mhe* h, int64_t batch, const double* x_arr
     hipLaunchKernelGGL(mhe_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, batch, h->N, h->np, h->nx,
                        h->nu, h->ny, p, p_stride, x_arrival, u_meas, y_meas, h->par_buf, h->sd_buf);
     HILO_HIP_CHECK(hipGetLastError());
+  }
+  if (h->est) {
+    const int nxa = h->nx + h->np, nve = (h->N + 1) * nxa + h->N * h->nx;
+    if (!h->ve || h->warm_batch != batch) {
+      double** bufs[] = {&h->x0e, &h->v0e, &h->ve, &h->lame, &h->v_warm};
+      const size_t sizes[] = {(size_t)nxa, (size_t)nve, (size_t)nve, (size_t)h->N * nxa, (size_t)h->n_v};
+      for (int q = 0; q < 5; ++q) {
+        if (*bufs[q]) HILO_HIP_CHECK(hipFree(*bufs[q]));
+        *bufs[q] = nullptr;
+        hipError_t e = hipMalloc((void**)bufs[q], sizeof(double) * sizes[q] * batch);
+        if (e != hipSuccess) return fail(HILO_ENOMEM, "MHE buffers: %s", hipGetErrorString(e));
+      }
+      h->warm_batch = batch;
+      h->warm_valid = 0;
+    }
+    // x0e = [unused | p]: the pinned parameter slots take their value from here; par = [x_arrival | p (arrival)]
+    {
+      int rc2 = mhe_est_pack(batch, h->nx, h->np, p, p_stride, x_arrival, h->x0e, h->par_buf, s);
+      if (rc2) return rc2;
+    }
+    const double* start = h->v_guess_e;
+    int64_t stride = 0;
+    const double* vref = v0 ? v0 : (h->warm_valid ? h->v_warm : nullptr);
+    if (vref) {
+      int rc2 = mhe_est_convert_in(batch, h->N, h->nx, h->np, vref, h->n_v, h->v0e, s);
+      if (rc2) return rc2;
+      start = h->v0e;
+      stride = nve;
+    }
+    MheEstArgs a{h->dev, batch, h->x0e, h->par_buf, h->sd_buf, (int64_t)((h->N + 1) * ws), start, stride, h->ve, f_opt, h->lame,
+                 status, iters, kkt, h->lds_bytes, s};
+    int rc2 = h->est->launch(a);
+    if (!rc2) rc2 = mhe_est_convert_out(h->dev, batch, h->N, h->nx, h->np, h->ve, h->lame, v_opt, lam_g, x_opt, s);
+    if (rc2) return rc2;
+    HILO_HIP_CHECK(hipMemcpyAsync(h->v_warm, v_opt, sizeof(double) * h->n_v * batch, hipMemcpyDeviceToDevice, s));
+    h->warm_valid = 1;
+    return HILO_OK;
   }
   const double* vstart = v0;
   int64_t vstride = h->n_v;

@@ -7,8 +7,9 @@ API mirror of `hilo_mpc.MHE` (`MovingHorizonEstimator`, hilo_mpc/modules/estimat
 N samples), `estimate(x_arrival=None, p_arrival=None, v0=None)` (mhe.py:311-416; returns `(None, None)` until the
 window is full, then `(x_N, p)` - the one-step-ahead state, mhe.py:381-384) - with a leading batch axis.
 
-Scope: pre-discretised model + `integration_method='discrete'`, state noise, model parameters pinned
-by `p_lb == p_ub` (parameter *estimation* adds horizon-global variables and is not yet offloaded).
+Scope: pre-discretised model + `integration_method='discrete'`, state noise; model parameters either
+pinned by `p_lb == p_ub` or ESTIMATED (`quad_arrival_cost.add_parameters(weights, guess)`, bounds / guess / scaling of p,
+mhe.py:614-623) - `estimate` then returns `(x_opt, p_opt)`.
 """
 import ctypes as C
 import warnings
@@ -26,6 +27,8 @@ class _ArrivalCost:
         self._model = model
         self.Wx = None
         self.x_guess = None
+        self.Wp = None
+        self.p_guess = None
         self._is_set = False
 
     def add_states(self, weights, guess):
@@ -39,8 +42,14 @@ class _ArrivalCost:
         self._is_set = True
 
     def add_parameters(self, weights, guess):
-        raise NotImplementedError("parameter estimation is not yet offloaded: pin the parameters with "
-                                  "set_box_constraints(p_lb=p, p_ub=p)")
+        """modeling.py:762-777: (p - p_arrival)^T W (p - p_arrival) over ALL model parameters."""
+        guess = _wrap_list(guess)
+        if len(guess) != self._model.n_p:
+            raise ValueError(f"The guess must have the same dimension of the model parameters."
+                             f"There are {self._model.n_p} parameters but guess has {len(guess)} values.")
+        self.Wp = _weight_matrix(weights, self._model.n_p, 'weights')
+        self.p_guess = guess
+        self._is_set = True
 
 
 class _StageCost:
@@ -120,10 +129,10 @@ class MovingHorizonEstimator:
     def set_initial_guess(self, x_guess=None, w_guess=None, p_guess=None, z_guess=None):
         self._x_guess = None if x_guess is None else _wrap_list(x_guess)
         self._w_guess = None if w_guess is None else _wrap_list(w_guess)
+        self._p_guess = None if p_guess is None else _wrap_list(p_guess)
 
     def set_scaling(self, x_scaling=None, w_scaling=None, p_scaling=None, u_scaling=None):
-        if p_scaling is not None:
-            raise NotImplementedError("parameter scaling is not offloaded (the parameters are pinned data)")
+        self._p_scaling = None if p_scaling is None else _wrap_list(p_scaling)
         self._x_scaling = None if x_scaling is None else _wrap_list(x_scaling)
         self._w_scaling = None if w_scaling is None else _wrap_list(w_scaling)
         self._u_scaling = None if u_scaling is None else _wrap_list(u_scaling)
@@ -149,10 +158,9 @@ class MovingHorizonEstimator:
         self._nlp_options = opts
         if nlp_opts is not None:
             self.set_solver_opts(nlp_opts)
-        if self._n_p:
-            if self._p_lb is None or self._p_ub is None or list(self._p_lb) != list(self._p_ub):
-                raise NotImplementedError("parameter estimation is not yet offloaded: pin the parameters with "
-                                          "set_box_constraints(p_lb=p, p_ub=p)")
+        pinned = bool(self._n_p) and self._p_lb is not None and self._p_ub is not None and \
+            list(self._p_lb) == list(self._p_ub)
+        self._estimating = bool(self._n_p) and not pinned
         if self.quad_stage_cost.Ww is None:
             raise NotImplementedError("MHE without state noise is not yet offloaded (and its 'multiple_shooting' branch "
                                       "is broken in the reference, SURVEY.md Q8)")
@@ -179,6 +187,11 @@ class MovingHorizonEstimator:
         d.x_lb, d.x_ub, d.w_lb, d.w_ub = hp(self._x_lb), hp(self._x_ub), hp(self._w_lb), hp(self._w_ub)
         d.x_scaling, d.w_scaling, d.u_scaling = hp(self._x_scaling), hp(self._w_scaling), hp(self._u_scaling)
         d.x_guess, d.w_guess = hp(self._x_guess), hp(self._w_guess)
+        if self._estimating:
+            d.estimate_parameters = 1
+            d.Wp = hp(self.quad_arrival_cost.Wp)
+            d.p_lb, d.p_ub = hp(self._p_lb), hp(self._p_ub)
+            d.p_scaling, d.p_guess = hp(getattr(self, '_p_scaling', None)), hp(getattr(self, '_p_guess', None))
         self._dev = device(self._dev_index)
         h = C.c_void_p()
         _lib.check(_lib.lib().hilo_mhe_create(C.byref(d), self._dev.index, C.byref(h)))
@@ -191,7 +204,8 @@ class MovingHorizonEstimator:
         self._x_ind = [list(range(np_ + k * nx, np_ + (k + 1) * nx)) for k in range(N + 1)]
         self._w_ind = [list(range(np_ + (N + 1) * nx + k * nx, np_ + (N + 1) * nx + (k + 1) * nx)) for k in range(N)]
         self._sx = np.ones(nx) if self._x_scaling is None else np.asarray(self._x_scaling)
-        self._p_pinned = None if not np_ else to_dev(np.asarray(self._p_lb, dtype=float), self._dev, (1, -1))
+        self._sp = np.ones(np_) if getattr(self, '_p_scaling', None) is None else np.asarray(self._p_scaling)
+        self._p_pinned = None if (not np_ or self._estimating) else to_dev(np.asarray(self._p_lb, dtype=float), self._dev, (1, -1))
         self._nlp_setup_done = True
 
     def _destroy(self):
@@ -266,6 +280,20 @@ class MovingHorizonEstimator:
         elif not self._nlp_options.get('warm_start', True):
             _lib.check(_lib.lib().hilo_mhe_reset_warm_start(self._handle))
         p, ps = (self._p_pinned, 0) if self._n_p else (None, 0)
+        if self._estimating:
+            # `p` = arrival value of the estimated parameters and value of the pinned ones (mhe.py:352-356): given, else
+            # the previous estimate (scaled, like the state smoothing of mhe.py:254-256), else the arrival-cost guess
+            if p_arrival is not None:
+                pa = to_dev(p_arrival, dev).reshape(-1, self._n_p)
+            elif self._nlp_solution is not None and self._nlp_solution['x'].shape[0] == B:
+                pa = self._nlp_solution['x'][:, self._p_ind[0]]
+            else:
+                g = self.quad_arrival_cost.p_guess
+                if g is None:
+                    g = getattr(self, '_p_guess', None) or np.zeros(self._n_p)
+                pa = to_dev(np.asarray(g, dtype=float), dev).reshape(1, -1)
+            pa = (pa.expand(B, -1) if pa.shape[0] == 1 else pa).contiguous()
+            p, ps = pa, self._n_p
         v_opt = torch.empty(B, self._n_v, dtype=torch.float64, device=dev)
         f_opt = torch.empty(B, dtype=torch.float64, device=dev)
         lam_g = torch.empty(B, self._n_g, dtype=torch.float64, device=dev)
@@ -280,7 +308,12 @@ class MovingHorizonEstimator:
                                                 stream_ptr(dev)))
         self._nlp_solution = {'x': v_opt, 'f': f_opt, 'lam_g': lam_g, 'status': status, 'iter_count': iters,
                               'kkt_error': kkt}
-        p_opt = None if not self._n_p else self._p_pinned.expand(B, -1)
+        if not self._n_p:
+            p_opt = None
+        elif self._estimating:
+            p_opt = v_opt[:, self._p_ind[0]] * torch.as_tensor(self._sp, device=dev)      # mhe.py:377-378
+        else:
+            p_opt = self._p_pinned.expand(B, -1)
         return x_opt, p_opt
 
     @property

@@ -313,6 +313,15 @@ typedef struct hilo_mhe_desc {
   const double* x_lb; const double* x_ub; const double* w_lb; const double* w_ub;   /* original units */
   const double* x_scaling; const double* w_scaling; const double* u_scaling;
   const double* x_guess; const double* w_guess;
+  /* ---- parameter estimation (mhe.py:614-623: the parameters head the decision vector with bounds p_lb / p_ub and guess
+     p_guess; arrival term (p - p_arrival)^T Wp (p - p_arrival), modeling.py:747-777).  estimate_parameters = 0: all
+     parameters are pinned to the `p` handed to hilo_mhe_estimate.  != 0: parameter j is estimated iff p_lb[j] < p_ub[j]
+     (NULL bound = unbounded = estimated), `p` then carries p_arrival for the estimated and the value for the pinned ones;
+     the estimate is the prefix of v_opt (scaled by p_scaling). ---- */
+  int32_t estimate_parameters;
+  int32_t reserved;
+  const double* Wp;          /* [np][np] */
+  const double* p_lb; const double* p_ub; const double* p_scaling; const double* p_guess;   /* [np], original units */
 } hilo_mhe_desc;
 
 int hilo_mhe_create(const hilo_mhe_desc* desc, int device, hilo_mhe** out);          /* = setup(), mhe.py:418 */

@@ -182,3 +182,168 @@ class MheIpm(DenseIpm):
         X, Wn = self._XW(res['w'])
         res.update(X=X, Wn=Wn, x_opt=X[:, -1] * pb.sx, v=np.concatenate([p, res['w']], axis=1))
         return res
+
+
+# ======================================================================================================================
+# parameter estimation: the model parameters are decision variables (mhe.py:614-623), bounded by p_lb / p_ub, with the
+# arrival term (p - p_arrival)^T Wp (p - p_arrival) next to the state one (util/modeling.py:747-777, mhe.py:742-745).
+# ======================================================================================================================
+class MheEstProblem(MheProblem):
+    """`est` = indices of the parameters that are estimated (p_lb < p_ub); the others are pinned through their bounds and
+    enter as data, like IPOPT's treatment of fixed variables.  p_scaling as in mhe.py (the model sees p * sp)."""
+
+    def __init__(self, model, dt, N, est, Wp=None, p_lb=None, p_ub=None, p_scaling=None, p_guess=None, **kw):
+        from .models import OracleModel
+        super().__init__(model, dt, N, **kw)
+        self.est = list(est)
+        ne = len(self.est)
+        self.ne = ne
+        self.sp = np.ones(ne) if p_scaling is None else np.asarray(p_scaling, dtype=float)
+        self.Wp = _wmat(0. if Wp is None else Wp, ne)
+        self.p_lb = (np.full(ne, -INF) if p_lb is None else np.asarray(p_lb, dtype=float)) / self.sp
+        self.p_ub = (np.full(ne, INF) if p_ub is None else np.asarray(p_ub, dtype=float)) / self.sp
+        self.p_guess = (np.zeros(ne) if p_guess is None else np.asarray(p_guess, dtype=float)) / self.sp
+        # derivatives w.r.t. the estimated parameters: augment the model with them as constant states
+        pe = [model.p[i] for i in self.est]
+        aug = OracleModel(model.name + '_pest', model.model_id, model.x + pe, model.u,
+                          [q for i, q in enumerate(model.p) if i not in self.est],
+                          list(model.ode) + [sp.Integer(0)] * ne, model.meas, discrete=model.discrete, dt=model.dt)
+        self.smap_aug = ShootingMap(aug, kw.get('order', 4), kw.get('n_sub', 1))
+        args = [aug.x, aug.u, aug.p, [aug.dt]]
+        H = sp.Matrix(aug.meas)
+        self._ha = _lam(list(H), args)
+        self._hax = _lam(H.jacobian(aug.x).tolist(), args)
+        self._haxx = _lam([[[sp.diff(H[m], a, b) for b in aug.x] for a in aug.x] for m in range(model.ny)], args)
+        self.fixed = [i for i in range(model.np_) if i not in self.est]
+
+    def phi_aug(self, xs, pes, u, pfix, need=0):
+        """scaled states xs, scaled estimated parameters pes -> Phi_s and derivatives w.r.t. (xs, pes)."""
+        nx, ne = self.nx, self.ne
+        xa = np.concatenate([xs * self.sx, pes * self.sp], axis=1)
+        ue = u * self.su
+        if need == 0:
+            return self.smap_aug.value(xa, ue, pfix, self.dt)[:, :nx] / self.sx
+        f, J, H = self.smap_aug(xa, ue, pfix, self.dt)
+        sa = np.concatenate([self.sx, self.sp])
+        na = nx + ne
+        J = J[:, :nx, :na] * sa[None, None, :] / self.sx[None, :, None]
+        H = H[:, :nx, :na, :na] * sa[None, None, :, None] * sa[None, None, None, :] / self.sx[None, :, None, None]
+        return f[:, :nx] / self.sx, J, H
+
+    def meas_aug(self, xs, pes, u, pfix, need=0):
+        xa = np.concatenate([xs * self.sx, pes * self.sp], axis=1)
+        ue = u * self.su
+        h = self._ha(xa, ue, pfix, self.dt)
+        if need == 0:
+            return h
+        sa = np.concatenate([self.sx, self.sp])
+        return h, self._hax(xa, ue, pfix, self.dt) * sa[None, None, :], \
+            self._haxx(xa, ue, pfix, self.dt) * sa[None, None, :, None] * sa[None, None, None, :]
+
+
+class MheEstIpm(DenseIpm):
+    """Free variables w = [p_est | x_0..x_N | w_0..w_{N-1}]."""
+
+    def __init__(self, prob: MheEstProblem, options: IpmOptions | None = None):
+        self.pb = pb = prob
+        self.o = options or IpmOptions()
+        N, nx, ne = pb.N, pb.nx, pb.ne
+        self.o_x = ne
+        self.o_w = ne + (N + 1) * nx
+        self.nw = self.o_w + N * nx
+        self.m = N * nx
+        lb = np.concatenate([pb.p_lb, np.tile(pb.x_lb, N + 1), np.tile(pb.w_lb, N)])
+        ub = np.concatenate([pb.p_ub, np.tile(pb.x_ub, N + 1), np.tile(pb.w_ub, N)])
+        r = self.o.bound_relax_factor
+        self.lb = np.where(np.isfinite(lb), lb - r * np.maximum(1, np.abs(lb)), lb)
+        self.ub = np.where(np.isfinite(ub), ub + r * np.maximum(1, np.abs(ub)), ub)
+        self.has_l, self.has_u = np.isfinite(self.lb), np.isfinite(self.ub)
+
+    def _split(self, w):
+        pb = self.pb
+        B = w.shape[0]
+        return w[:, :pb.ne], w[:, self.o_x:self.o_w].reshape(B, pb.N + 1, pb.nx), w[:, self.o_w:].reshape(B, pb.N, pb.nx)
+
+    def eval_fc(self, w, data):
+        pb = self.pb
+        P, X, Wn = self._split(w)
+        B = w.shape[0]
+        pf, xa, pa, um, ym = data['p_fixed'], data['x_arrival'], data['p_arrival'], data['u_meas'], data['y_meas']
+        d = X[:, 0] * pb.sx - xa
+        dp = P * pb.sp - pa
+        f = np.einsum('bi,ij,bj->b', d, pb.Wx, d) + np.einsum('bi,ij,bj->b', dp, pb.Wp, dp)
+        c = np.empty((B, pb.N, pb.nx))
+        for k in range(pb.N):
+            c[:, k] = X[:, k + 1] - (pb.phi_aug(X[:, k], P, um[:, k], pf) + Wn[:, k])
+            if k >= 1:
+                r = pb.meas_aug(X[:, k], P, um[:, k], pf) - ym[:, k]
+                ws = Wn[:, k] * pb.sw
+                f += np.einsum('bi,ij,bj->b', r, pb.Wy, r) + np.einsum('bi,ij,bj->b', ws, pb.Ww, ws)
+        return f, c.reshape(B, -1)
+
+    def eval_all(self, w, lam, data):
+        pb = self.pb
+        N, nx, ne = pb.N, pb.nx, pb.ne
+        P, X, Wn = self._split(w)
+        B = w.shape[0]
+        pf, xa, pa, um, ym = data['p_fixed'], data['x_arrival'], data['p_arrival'], data['u_meas'], data['y_meas']
+        g = np.zeros((B, self.nw))
+        c = np.empty((B, N, nx))
+        J = np.zeros((B, self.m, self.nw))
+        W = np.zeros((B, self.nw, self.nw))
+        lam = lam.reshape(B, N, nx)
+        bi = np.arange(B)
+        pc = list(range(ne))
+        xc = lambda k: [self.o_x + k * nx + i for i in range(nx)]      # noqa: E731
+        wc = lambda k: [self.o_w + k * nx + i for i in range(nx)]      # noqa: E731
+        d = X[:, 0] * pb.sx - xa
+        dp = P * pb.sp - pa
+        f = np.einsum('bi,ij,bj->b', d, pb.Wx, d) + np.einsum('bi,ij,bj->b', dp, pb.Wp, dp)
+        g[:, xc(0)] += 2 * (d @ pb.Wx) * pb.sx
+        W[np.ix_(bi, xc(0), xc(0))] += 2 * pb.Wx * np.outer(pb.sx, pb.sx)
+        g[:, pc] += 2 * (dp @ pb.Wp) * pb.sp
+        W[np.ix_(bi, pc, pc)] += 2 * pb.Wp * np.outer(pb.sp, pb.sp)
+        for k in range(N):
+            Phi, Jk, Hk = pb.phi_aug(X[:, k], P, um[:, k], pf, need=2)
+            c[:, k] = X[:, k + 1] - (Phi + Wn[:, k])
+            rows = list(range(k * nx, (k + 1) * nx))
+            cols = xc(k) + pc                                         # order of the augmented (x, p_est)
+            J[np.ix_(bi, rows, cols)] += -Jk
+            J[:, rows, xc(k + 1)] += 1.0
+            J[:, rows, wc(k)] += -1.0
+            W[np.ix_(bi, cols, cols)] -= np.einsum('bm,bmzy->bzy', lam[:, k], Hk)
+            if k >= 1:
+                h, hx, hxx = pb.meas_aug(X[:, k], P, um[:, k], pf, need=2)
+                r = h - ym[:, k]
+                rW = r @ pb.Wy
+                f += np.einsum('bi,bi->b', rW, r)
+                g[:, cols] += 2 * np.einsum('bm,bmz->bz', rW, hx)
+                W[np.ix_(bi, cols, cols)] += 2 * np.einsum('bmz,mn,bny->bzy', hx, pb.Wy, hx) + \
+                    2 * np.einsum('bm,bmzy->bzy', rW, hxx)
+                ws = Wn[:, k] * pb.sw
+                f += np.einsum('bi,ij,bj->b', ws, pb.Ww, ws)
+                g[:, wc(k)] += 2 * (ws @ pb.Ww) * pb.sw
+                W[np.ix_(bi, wc(k), wc(k))] += 2 * pb.Ww * np.outer(pb.sw, pb.sw)
+        return f, g, c.reshape(B, -1), J, W
+
+    def solve(self, x_arrival, p_arrival, p_fixed, u_meas, y_meas, w0=None, verbose=False):
+        """p_arrival [B,ne] (original units), p_fixed [B,np-ne]; returns dict(..., P (scaled), p_opt = P * sp, X, Wn,
+        x_opt = x_N * sx, v = reference layout [p (all, scaled) | x | w])."""
+        pb = self.pb
+        xa = np.atleast_2d(np.asarray(x_arrival, dtype=float))
+        B = xa.shape[0]
+        pa = np.broadcast_to(np.atleast_2d(np.asarray(p_arrival, dtype=float)), (B, pb.ne))
+        pf = np.broadcast_to(np.atleast_2d(np.asarray(p_fixed, dtype=float)), (B, len(pb.fixed))) if pb.fixed \
+            else np.zeros((B, 0))
+        um = np.asarray(u_meas, dtype=float).reshape(B, pb.N, pb.nu)
+        ym = np.asarray(y_meas, dtype=float).reshape(B, pb.N, pb.ny)
+        if w0 is None:
+            w0 = np.concatenate([pb.p_guess, np.tile(pb.x_guess, pb.N + 1), np.tile(pb.w_guess, pb.N)])
+        res = self.solve_data({'p_fixed': pf, 'x_arrival': xa, 'p_arrival': pa, 'u_meas': um, 'y_meas': ym}, w0, verbose)
+        P, X, Wn = self._split(res['w'])
+        pall = np.zeros((B, pb.np_))
+        pall[:, pb.est] = P
+        pall[:, pb.fixed] = pf
+        res.update(P=P, p_opt=P * pb.sp, X=X, Wn=Wn, x_opt=X[:, -1] * pb.sx,
+                   v=np.concatenate([pall, X.reshape(B, -1), Wn.reshape(B, -1)], axis=1))
+        return res

@@ -113,3 +113,68 @@ def test_full_size_batch_properties(spec, min_success):
     X = v[:, 4:4 + 124].reshape(B, 31, 4)
     assert float(X.min()) >= -1.0000001e-8
     assert torch.equal(x, X[:, -1])
+
+
+# ---- parameter estimation (mhe.py:614-623, modeling.py:762-777) ------------------------------------------------------------
+def _mhe_est(N, est, p_lb, p_ub, Wp, p_guess, p_scaling=None):
+    from hilo_mpc_amd import MHE, Model
+    m = Model('chemostat4').discretize('erk', order=C3B.get('order', 4)).setup(dt=C3B['dt'])
+    mhe = MHE(m)
+    mhe.quad_arrival_cost.add_states(weights=C3B['Wx'], guess=C3B['x_guess'])
+    mhe.quad_arrival_cost.add_parameters(weights=Wp, guess=p_guess)
+    mhe.quad_stage_cost.add_measurements(weights=C3B['Wy'])
+    mhe.quad_stage_cost.add_state_noise(weights=C3B['Ww'])
+    mhe.horizon = N
+    mhe.set_box_constraints(x_lb=C3B['x_lb'], w_lb=C3B['w_lb'], w_ub=C3B['w_ub'], p_lb=p_lb, p_ub=p_ub)
+    mhe.set_initial_guess(x_guess=C3B['x_guess'], p_guess=p_guess)
+    if p_scaling is not None:
+        mhe.set_scaling(p_scaling=p_scaling)
+    mhe.setup(options={'integration_method': 'discrete'})
+    return mhe
+
+
+@pytest.mark.parametrize('p_scaling', [None, [1., 1., .5, 1.]])
+def test_parameter_estimation_vs_oracle(p_scaling):
+    """ISF (parameter 2, the factor of the growth rate) is estimated from a wrong arrival value 0.7 (truth 1.0); the other
+    three parameters are pinned through p_lb == p_ub."""
+    from oracle import models
+    from oracle.mhe import MheEstIpm, MheEstProblem
+    N, B = 10, 6
+    xa, um, ym, _ = c3_data(B, N=N)
+    kw = {k: v for k, v in C3B.items() if k not in ('model', 'p')}
+    kw['N'] = N
+    sp0 = None if p_scaling is None else [p_scaling[2]]
+    pb = MheEstProblem(models.get('chemostat4'), est=[2], Wp=[1e-2], p_lb=[.2], p_ub=[2.], p_guess=[.7], p_scaling=sp0, **kw)
+    ipm = MheEstIpm(pb)
+    ref = ipm.solve(xa, [.7], [100., 4., 0.], um, ym)
+    assert np.all(ref['status'] == 1)
+    mhe = _mhe_est(N, [2], [100., 4., .2, 0.], [100., 4., 2., 0.], np.diag([0., 0., 1e-2, 0.]), [100., 4., .7, 0.], p_scaling)
+    assert mhe._n_v == 4 + 11 * 4 + 10 * 4 and mhe._p_ind == [[0, 1, 2, 3]]
+    for k in range(N):
+        mhe.add_measurements(ym[:, k], um[:, k])
+    x_opt, p_opt = mhe.estimate(x_arrival=xa, p_arrival=[100., 4., .7, 0.])
+    assert np.array_equal(mhe.solver_status_code, ref['status'])
+    np.testing.assert_allclose(p_opt.cpu().numpy()[:, 2], ref['p_opt'][:, 0], rtol=2e-5)
+    np.testing.assert_allclose(p_opt.cpu().numpy()[:, [0, 1, 3]], np.tile([100., 4., 0.], (B, 1)), rtol=1e-13)
+    v, vr = mhe._nlp_solution['x'].cpu().numpy(), ref['v']
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 5e-5
+    np.testing.assert_allclose(x_opt.cpu().numpy(), ref['x_opt'], rtol=5e-5, atol=1e-6)
+    np.testing.assert_allclose(mhe._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(mhe._nlp_solution['lam_g'].cpu().numpy(), ref['lam'], rtol=2e-4, atol=1e-5)
+    assert np.all(np.abs(ref['p_opt'][:, 0] - 1.) < .15)          # the data pulls the estimate from 0.7 to the truth 1.0
+    # next window: the arrival values default to the previous estimate (state: x_2; parameters: p), warm start
+    mhe.add_measurements(ym[:, -1], um[:, -1])
+    x2, p2 = mhe.estimate()
+    assert np.all(mhe.solver_status_code == 1)
+    assert np.all(np.abs(p2.cpu().numpy()[:, 2] - 1.) < .35)       # (the repeated sample is not consistent data)
+
+
+def test_all_parameters_pinned_equals_plain_mhe():
+    """p_lb == p_ub for every parameter: the estimating API reduces to the pinned variant."""
+    N, B = 8, 4
+    xa, um, ym, _ = c3_data(B, N=N)
+    mhe = product_mhe(dict(C3B, N=N))
+    for k in range(N):
+        mhe.add_measurements(ym[:, k], um[:, k])
+    x1, p1 = mhe.estimate(x_arrival=xa)
+    assert not mhe._estimating and np.allclose(p1.cpu().numpy(), C3B['p'])
