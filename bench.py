@@ -178,10 +178,10 @@ def main():
                              "note": "compulsory bytes only (iterate + parameters in/out); not the binding roof"},
         }
         if not args.no_cpu_baseline:
-            ns = 32
-            v, secs = cpu_baseline(spec, c2_x0(ns), 6)
+            ns = 40
+            v, secs = cpu_baseline(spec, c2_x0(ns), 8)
             out["cpu_baseline"] = {"value": v, "unit": "steps/s", "cores": 1, "kind": "port",
-                                   "sample": f"{ns} instances x 6 warm-started closed-loop steps of the same C2 "
+                                   "sample": f"{ns} instances x 8 warm-started closed-loop steps of the same C2 "
                                              f"workload with the oracle's numpy dense interior-point solver "
                                              f"({secs:.1f} s); the reference's CasADi/IPOPT is not installable",
                                    "host_cpus": os.cpu_count()}
