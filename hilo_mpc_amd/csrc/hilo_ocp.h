@@ -487,16 +487,30 @@ struct Ocp {
   }
 
   // scaled optimality error pieces (W&B eq. 5)
-  __device__ static void opt_error(const Lds l, double& dual_s, double& prim, double& s_c) {
+  // also returns the complementarity errors for barrier parameters 0 and mu (same pass over the slots)
+  __device__ static void opt_error(const Lds l, double mu, double& dual_s, double& prim, double& s_c, double& compl0,
+                                   double& compl_mu) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
-    double dmax = 0.0, lsum = 0.0, zsum = 0.0, pmax = 0.0, nb = 0.0;
+    double dmax = 0.0, lsum = 0.0, zsum = 0.0, pmax = 0.0, nb = 0.0, c0 = 0.0, cm = 0.0;
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
       const int k = e / NZ, i = e - k * NZ;
       if (!is_free(pc, k, i)) continue;
       dmax = fmax(dmax, fabs(dual_res(l, N, e)));
-      zsum += fabs(l.zL[e]) + fabs(l.zU[e]);
-      nb += (l.lbA[e] > -INFINITY ? 1.0 : 0.0) + (l.ubA[e] < INFINITY ? 1.0 : 0.0);
+      const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
+      zsum += fabs(zl) + fabs(zu);
+      if (lb > -INFINITY) {
+        nb += 1.0;
+        const double p = (z - lb) * zl;
+        c0 = fmax(c0, fabs(p));
+        cm = fmax(cm, fabs(p - mu));
+      }
+      if (ub < INFINITY) {
+        nb += 1.0;
+        const double p = (ub - z) * zu;
+        c0 = fmax(c0, fabs(p));
+        cm = fmax(cm, fabs(p - mu));
+      }
     }
     for (int e = threadIdx.x; e < N * NX; e += blockDim.x) {
       pmax = fmax(pmax, fabs(l.c[e]));
@@ -511,10 +525,23 @@ struct Ocp {
         pmax = fmax(pmax, fabs(l.cd[e] - l.cs[e]));
         lsum += fabs(l.cnu[e]);
         zsum += fabs(l.cvL[e]) + fabs(l.cvU[e]);
-        nb += (pc.dlb[m] > -INFINITY ? 1.0 : 0.0) + (pc.dub[m] < INFINITY ? 1.0 : 0.0);
+        if (pc.dlb[m] > -INFINITY) {
+          nb += 1.0;
+          const double p = (l.cs[e] - pc.dlb[m]) * l.cvL[e];
+          c0 = fmax(c0, fabs(p));
+          cm = fmax(cm, fabs(p - mu));
+        }
+        if (pc.dub[m] < INFINITY) {
+          nb += 1.0;
+          const double p = (pc.dub[m] - l.cs[e]) * l.cvU[e];
+          c0 = fmax(c0, fabs(p));
+          cm = fmax(cm, fabs(p - mu));
+        }
       }
       ncon = (double)N * pc.nc;
     }
+    compl0 = block_reduce<OpMax>(c0, l.red);
+    compl_mu = block_reduce<OpMax>(cm, l.red);
     dmax = block_reduce<OpMax>(dmax, l.red);
     pmax = block_reduce<OpMax>(pmax, l.red);
     lsum = block_reduce<OpSum>(lsum, l.red);
@@ -1043,9 +1070,8 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       theta_min = pc.theta_min_fact * fmax(1.0, th0);
       theta_max = pc.theta_max_fact * fmax(1.0, th0);
     }
-    double dual_s, prim, s_c;
-    S::opt_error(l, dual_s, prim, s_c);
-    const double c0 = S::compl_error(l, 0.0);
+    double dual_s, prim, s_c, c0, cmu;
+    S::opt_error(l, mu, dual_s, prim, s_c, c0, cmu);
     E0 = fmax(fmax(dual_s, prim), c0 / s_c);
     if (E0 <= pc.tol) { st = HILO_STATUS_SOLVED; break; }
     if (E0 <= pc.acceptable_tol) {
@@ -1054,7 +1080,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     if (it >= pc.max_iter) { st = HILO_STATUS_MAXITER; break; }
     // ---- barrier update (W&B eq. 7) ----
     for (int r = 0; r < 20; ++r) {
-      const double Emu = fmax(fmax(dual_s, prim), S::compl_error(l, mu) / s_c);
+      const double Emu = fmax(fmax(dual_s, prim), (r == 0 ? cmu : S::compl_error(l, mu)) / s_c);
       if (!(Emu <= pc.kappa_eps * mu && mu > pc.tol / 10 * (1 + 1e-12))) break;
       mu = fmax(pc.tol / 10, fmin(pc.kappa_mu * mu, pow(mu, pc.theta_mu)));
       tau = fmax(pc.tau_min, 1.0 - mu);
