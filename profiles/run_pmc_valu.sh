@@ -1,0 +1,16 @@
+#!/bin/bash
+# Instruction-issue counters of the solve kernel (own rocprofv3 passes, kernel-trace only):
+#   python profiles/summarize_pmc.py gpurun_out/pmc_$TAG
+TAG=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python $ROOT/bench.py --no-cpu-baseline --steps 6 --warmup 14"
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT"; do
+  name=$(echo $set | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$name -o $TAG -- $BENCH > $OUT/$name.log 2>&1 || echo "failed: $set"
+done
+cd $ROOT
+find $OUT -name "*counter_collection.csv" | head
