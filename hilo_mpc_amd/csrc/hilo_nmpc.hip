@@ -56,6 +56,7 @@ struct hilo_nmpc {
   int nu_out;        // width of the returned first input (model inputs, without the virtual path input)
   double* ws;        // iterate workspace of BIG variants [ws_batch][ws_bytes]
   int64_t ws_batch;
+  const TrackBigVariant* big; // long-horizon variant of the tracking policy (iterate in the workspace) or NULL
   const TvVariant* tv;       // per-stage-data variant (trajectory references, time-varying parameters) or NULL
   const CollVariant* coll;   // collocation variant of the tracking policy or NULL
   double *vc, *lamc;         // the engine's compact [x | u] solution and defect multipliers (collocation output pass)
@@ -176,6 +177,11 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     if (!tvv) return fail(HILO_ENOTSUP, "no per-stage-data instantiation for model %d in this build", d->model_id);
     lds = tvv->lds_bytes(d->N);
   }
+  const TrackBigVariant* bigv = nullptr;
+  if (lds > 160 * 1024 && !general && !cv && !tvv && !d->learned) {
+    bigv = nmpc_track_big_find(d->model_id);   // long horizon: iterate in a global-memory workspace
+    if (bigv) lds = bigv->lds_bytes(d->N);
+  }
   if (lds > 160 * 1024)
     return fail(HILO_ENOTSUP, "horizon %d needs %zu B of LDS per instance (limit 163840)", d->N, lds);
   // engine dimensions: [model x | theta | e], [model u | u_theta]
@@ -187,6 +193,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   h->gen = gv; h->nu_out = nu;
   h->coll = cv;
   h->tv = tvv;
+  h->big = bigv;
   h->n_vc = (d->N + 1) * nx + d->N * nu;
   const int dn = cv ? cv->degree * nx : 0;
   h->n_v = (d->N + 1) * nxv + d->N * nue + ne + d->N * dn;   // mpc.py:1440-1443 (+ the soft-constraint slack, :1529-1537)
@@ -444,8 +451,8 @@ static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const 
     rc = h->coll->launch(a);
     if (!rc) rc = h->coll->output(h->dev, batch, h->N, h->vc, lam_g ? h->lamc : nullptr, h->par_buf, (int64_t)(h->np + h->nu),
                                   v_opt, lam_g, s);
-  } else if (h->gen) {
-    const size_t wsb = h->gen->ws_bytes(h->N);
+  } else if (h->gen || h->big) {
+    const size_t wsb = h->gen ? h->gen->ws_bytes(h->N) : h->big->ws_bytes(h->N);
     if (wsb && h->ws_batch != batch) {
       if (h->ws) HILO_HIP_CHECK(hipFree(h->ws));
       h->ws = nullptr;
@@ -455,7 +462,7 @@ static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const 
     }
     GenLaunchArgs a{h->dev, batch, x0, h->par_buf, (int64_t)(h->np + h->nu), vstart, vstride, v_opt, f_opt, lam_g, u0,
                     status, iters, kkt, h->prof, h->lds_bytes, s, h->ws};
-    rc = h->gen->launch(a);
+    rc = h->gen ? h->gen->launch(a) : h->big->launch(a);
   } else {
     switch (h->model_id) {
 #define X(ID, T) case ID: rc = nmpc_launch<T>(h, batch, x0, h->par_buf, vstart, vstride, v_opt, f_opt, lam_g, u0, status, iters, kkt, s); break;

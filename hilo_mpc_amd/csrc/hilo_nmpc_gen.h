@@ -226,6 +226,15 @@ struct CollVariant {
 };
 const CollVariant* nmpc_coll_find(int model_id, int degree);
 
+// long-horizon variants of the tracking policy: iterate in a global-memory workspace (hilo_nmpc_long.hip)
+struct TrackBigVariant {
+  int model_id;
+  size_t (*lds_bytes)(int N);
+  size_t (*ws_bytes)(int N);
+  int (*launch)(const GenLaunchArgs& a);
+};
+const TrackBigVariant* nmpc_track_big_find(int model_id);
+
 // per-stage-data variants of the tracking policy (hilo_nmpc_tv.hip)
 struct TvVariant {
   int model_id;

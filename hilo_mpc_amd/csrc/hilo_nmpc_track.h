@@ -6,11 +6,11 @@ namespace hilo {
 
 // Policy: tracking NMPC with quadratic costs.  pc.cost = [Wz | zref | WN | xrefN | Wdu | has_du],
 // par = [model parameters | u_old (scaled)].
-template <class M>
+template <class M, bool BIG_ = false>
 struct NmpcTrack {
   static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU, NPAR = M::NP + M::NU, NSD = 0;
   static constexpr bool FIX_X0 = true;
-  static constexpr bool BIG = false;  // iterate in LDS
+  static constexpr bool BIG = BIG_;  // false: iterate in LDS; true: per-instance global workspace (long horizons)
   static constexpr int NC = 0, NXV = NX, NX0 = NX, NU0 = NU;  // no inequality rows; plain [x | u] decision vector
   static constexpr bool COOP = model_has_ext<M>::value;  // learned term in the model: lanes share its kernel sum
   static constexpr bool QUAD_COST = true;  // gradient / Hessian of the stage cost in closed form (cost_grad, cost_hess)

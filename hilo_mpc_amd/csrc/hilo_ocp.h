@@ -754,7 +754,7 @@ struct Ocp {
           for (int a = 0; a < NU; ++a) {
             const double ym = l.mm[NX + a], yM = l.Mm[(NX + a) * NZ + jj];
             y[a] = rhs ? ym : yM;
-            xu[a] = l.Mm[i * NZ + NX + a];
+            xu[a] = l.Mm[(NX + a) * NZ + i];   // M_ux^T: the same block on both sides of R^-1
           }
           const double sm = l.mm[i], s1 = l.Mm[i * NZ + jj], s2 = l.Mm[jj * NZ + i];
           double s = rhs ? sm : 0.5 * (s1 + s2);
@@ -762,8 +762,14 @@ struct Ocp {
           small_solve<NU>(Lc, invd, y);
 #pragma unroll
           for (int a = 0; a < NU; ++a) s -= xu[a] * y[a];
-          dp dst = rhs ? l.pv + k * NX + i : l.P + k * NX * NX + i * NX + j;
-          *dst = s;
+          // P_k is kept EXACTLY symmetric: entry (i, j), i <= j, is computed once and stored twice.  Rounding-level
+          // asymmetry is not damped by the recursion - for unstable dynamics it grows like the open loop and destroyed the
+          // pivots after ~38 stages of the chemostat.
+          if (rhs) l.pv[k * NX + i] = s;
+          else if (i <= jj) {
+            l.P[k * NX * NX + i * NX + jj] = s;
+            l.P[k * NX * NX + jj * NX + i] = s;
+          }
           if (i == 0) {
 #pragma unroll
             for (int a = 0; a < NU; ++a) {
