@@ -78,7 +78,10 @@ inline void ocp_default_options(OcpConst& c) {
 
 // ---- block-wide reductions (result broadcast to every lane) ------------------------------------------------
 struct OpSum { __device__ static double id() { return 0.0; } __device__ static double f(double a, double b) { return a + b; } };
-struct OpMax { __device__ static double id() { return -INFINITY; } __device__ static double f(double a, double b) { return fmax(a, b); } };
+// NaN-propagating maximum: fmax() silently drops NaN, which would let an error measure pass its tolerance with a NaN
+// multiplier or residual somewhere in the iterate
+__device__ __forceinline__ double nmax(double a, double b) { return (a != a || a > b) ? a : b; }
+struct OpMax { __device__ static double id() { return -INFINITY; } __device__ static double f(double a, double b) { return nmax(a, b); } };
 struct OpMin { __device__ static double id() { return INFINITY; } __device__ static double f(double a, double b) { return fmin(a, b); } };
 
 // wave-wide reduction without LDS traffic: DPP lane permutes inside each row of 16 (xor 1, xor 2, half-mirror, mirror), then
@@ -496,24 +499,24 @@ struct Ocp {
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
       const int k = e / NZ, i = e - k * NZ;
       if (!is_free(pc, k, i)) continue;
-      dmax = fmax(dmax, fabs(dual_res(l, N, e)));
+      dmax = nmax(dmax, fabs(dual_res(l, N, e)));
       const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
       zsum += fabs(zl) + fabs(zu);
       if (lb > -INFINITY) {
         nb += 1.0;
         const double p = (z - lb) * zl;
-        c0 = fmax(c0, fabs(p));
-        cm = fmax(cm, fabs(p - mu));
+        c0 = nmax(c0, fabs(p));
+        cm = nmax(cm, fabs(p - mu));
       }
       if (ub < INFINITY) {
         nb += 1.0;
         const double p = (ub - z) * zu;
-        c0 = fmax(c0, fabs(p));
-        cm = fmax(cm, fabs(p - mu));
+        c0 = nmax(c0, fabs(p));
+        cm = nmax(cm, fabs(p - mu));
       }
     }
     for (int e = threadIdx.x; e < N * NX; e += blockDim.x) {
-      pmax = fmax(pmax, fabs(l.c[e]));
+      pmax = nmax(pmax, fabs(l.c[e]));
       lsum += fabs(l.lam[e]);
     }
     double ncon = 0.0;
@@ -521,21 +524,21 @@ struct Ocp {
       for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
         const int m = e % NC;
         if (m >= pc.nc) continue;
-        dmax = fmax(dmax, fabs(-l.cnu[e] - l.cvL[e] + l.cvU[e]));
-        pmax = fmax(pmax, fabs(l.cd[e] - l.cs[e]));
+        dmax = nmax(dmax, fabs(-l.cnu[e] - l.cvL[e] + l.cvU[e]));
+        pmax = nmax(pmax, fabs(l.cd[e] - l.cs[e]));
         lsum += fabs(l.cnu[e]);
         zsum += fabs(l.cvL[e]) + fabs(l.cvU[e]);
         if (pc.dlb[m] > -INFINITY) {
           nb += 1.0;
           const double p = (l.cs[e] - pc.dlb[m]) * l.cvL[e];
-          c0 = fmax(c0, fabs(p));
-          cm = fmax(cm, fabs(p - mu));
+          c0 = nmax(c0, fabs(p));
+          cm = nmax(cm, fabs(p - mu));
         }
         if (pc.dub[m] < INFINITY) {
           nb += 1.0;
           const double p = (pc.dub[m] - l.cs[e]) * l.cvU[e];
-          c0 = fmax(c0, fabs(p));
-          cm = fmax(cm, fabs(p - mu));
+          c0 = nmax(c0, fabs(p));
+          cm = nmax(cm, fabs(p - mu));
         }
       }
       ncon = (double)N * pc.nc;
@@ -559,15 +562,15 @@ struct Ocp {
     double cm = 0.0;
     for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
       const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
-      if (lb > -INFINITY) cm = fmax(cm, fabs((z - lb) * zl - mu));
-      if (ub < INFINITY) cm = fmax(cm, fabs((ub - z) * zu - mu));
+      if (lb > -INFINITY) cm = nmax(cm, fabs((z - lb) * zl - mu));
+      if (ub < INFINITY) cm = nmax(cm, fabs((ub - z) * zu - mu));
     }
     if constexpr (NC > 0) {
       for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
         const int m = e % NC;
         if (m >= pc.nc) continue;
-        if (pc.dlb[m] > -INFINITY) cm = fmax(cm, fabs((l.cs[e] - pc.dlb[m]) * l.cvL[e] - mu));
-        if (pc.dub[m] < INFINITY) cm = fmax(cm, fabs((pc.dub[m] - l.cs[e]) * l.cvU[e] - mu));
+        if (pc.dlb[m] > -INFINITY) cm = nmax(cm, fabs((l.cs[e] - pc.dlb[m]) * l.cvL[e] - mu));
+        if (pc.dub[m] < INFINITY) cm = nmax(cm, fabs((pc.dub[m] - l.cs[e]) * l.cvU[e] - mu));
       }
     }
     return block_reduce<OpMax>(cm, l.red);
@@ -1078,7 +1081,8 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     }
     double dual_s, prim, s_c, c0, cmu;
     S::opt_error(l, mu, dual_s, prim, s_c, c0, cmu);
-    E0 = fmax(fmax(dual_s, prim), c0 / s_c);
+    E0 = nmax(nmax(dual_s, prim), c0 / s_c);
+    if (E0 != E0) { st = HILO_STATUS_OTHER; break; }   // NaN in the iterate: IPOPT's 'Invalid_Number_Detected' -> -1
     if (E0 <= pc.tol) { st = HILO_STATUS_SOLVED; break; }
     if (E0 <= pc.acceptable_tol) {
       if (++acc_count >= pc.acceptable_iter) { st = HILO_STATUS_ACCEPTABLE; break; }
@@ -1086,7 +1090,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     if (it >= pc.max_iter) { st = HILO_STATUS_MAXITER; break; }
     // ---- barrier update (W&B eq. 7) ----
     for (int r = 0; r < 20; ++r) {
-      const double Emu = fmax(fmax(dual_s, prim), (r == 0 ? cmu : S::compl_error(l, mu)) / s_c);
+      const double Emu = nmax(nmax(dual_s, prim), (r == 0 ? cmu : S::compl_error(l, mu)) / s_c);
       if (!(Emu <= pc.kappa_eps * mu && mu > pc.tol / 10 * (1 + 1e-12))) break;
       mu = fmax(pc.tol / 10, fmin(pc.kappa_mu * mu, pow(mu, pc.theta_mu)));
       tau = fmax(pc.tau_min, 1.0 - mu);

@@ -96,12 +96,14 @@ __global__ __launch_bounds__(64) void qp_solve_kernel(QpDims qd, int64_t batch, 
                                                       const double* __restrict__ uba, int64_t bas,
                                                       double* __restrict__ x_out, double* __restrict__ f_out,
                                                       double* __restrict__ lam_a, double* __restrict__ lam_x,
-                                                      int32_t* __restrict__ status, int32_t* __restrict__ iters) {
+                                                      int32_t* __restrict__ status, int32_t* __restrict__ iters,
+                                                      double* __restrict__ ws, int64_t ws_stride) {
   extern __shared__ double lds[];
   const int n = qd.n, m = qd.m, ldn = qd.ldn, ldm = qd.ldm, t = threadIdx.x;
   const int64_t b = blockIdx.x;
   if (b >= batch) return;
-  double* q = lds;
+  // working set in LDS, or - for QPs beyond 160 KB - in a per-instance workspace in global memory (same code, flat pointers)
+  double* q = ws ? ws + b * ws_stride : lds;
   auto take = [&](size_t k) { double* r = q; q += k; return r; };
   double* Hf = take((size_t)n * ldn);   // H with fixed rows/cols removed (identity there)
   double* Mc = take((size_t)n * ldn);   // H + Sigma -> its Cholesky factor
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(64) void qp_solve_kernel(QpDims qd, int64_t batch, 
   if (bad_rows) st = HILO_STATUS_OTHER;
   for (it = 0; !bad_rows && it < qd.max_iter; ++it) {
     // residuals: base = -(Hf x + gf + Af^T y), rd = -base - zl + zu, rp = Af x - bf, mu
-    double rdmax = 0.0, mupart = 0.0;
+    double rdmax = 0.0, mupart = 0.0, nonfinite = 0.0;   // fmax() drops NaN: count non-finite residuals explicitly
     for (int i = t; i < n; i += 64) {
       double s = gf[i];
       for (int j = 0; j < n; ++j) s += Hf[i * ldn + j] * x[j];
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(64) void qp_solve_kernel(QpDims qd, int64_t batch, 
       if (fx) s = 0.0;
       base[i] = -s;
       rdmax = fmax(rdmax, fabs(s - zl[i] + zu[i]));
+      nonfinite += isfinite(s - zl[i] + zu[i]) ? 0.0 : 1.0;
       if (!fx) {
         if (l[i] > -INFINITY) mupart += (x[i] - l[i]) * zl[i];
         if (u[i] < INFINITY) mupart += (u[i] - x[i]) * zu[i];
@@ -192,12 +195,14 @@ __global__ __launch_bounds__(64) void qp_solve_kernel(QpDims qd, int64_t batch, 
       for (int j = 0; j < n; ++j) s += Af[r * ldn + j] * x[j];
       rp[r] = s;
       rpmax = fmax(rpmax, fabs(s));
+      nonfinite += isfinite(s) ? 0.0 : 1.0;
     }
     rdmax = wave_max(rdmax);
     rpmax = wave_max(rpmax);
     const double mu = wave_sum(mupart) / nb;
+    nonfinite = wave_sum(nonfinite);
+    if (nonfinite > 0.0 || !isfinite(rdmax) || !isfinite(rpmax) || !isfinite(mu)) { st = HILO_STATUS_INFEASIBLE; break; }
     if (fmax(fmax(rdmax / (1.0 + gmax), rpmax), mu) <= qd.tol) { st = HILO_STATUS_SOLVED; break; }
-    if (!isfinite(rdmax) || !isfinite(rpmax) || !isfinite(mu)) { st = HILO_STATUS_INFEASIBLE; break; }
     // M = Hf + Sigma + reg; factor
     for (int e = t; e < n * n; e += 64) {
       const int i = e / n, j = e - i * n;
@@ -296,7 +301,12 @@ __global__ __launch_bounds__(64) void qp_solve_kernel(QpDims qd, int64_t batch, 
         sigma_mu = sg * sg * sg * mu;
       } else {
         for (int i = t; i < n; i += 64) {
-          x[i] += ap * dx[i];
+          double xi = x[i] + ap * dx[i];
+          // near convergence (mu ~ 1e-13) the fraction-to-the-boundary step can round a slack to exactly zero: keep every
+          // slack at least a few ulps wide so that z / slack stays finite
+          if (l[i] > -INFINITY) xi = fmax(xi, l[i] + 4.0e-16 * fmax(1.0, fabs(l[i])));
+          if (u[i] < INFINITY) xi = fmin(xi, u[i] - 4.0e-16 * fmax(1.0, fabs(u[i])));
+          x[i] = xi;
           zl[i] += ad * dzl[i];
           zu[i] += ad * dzu[i];
         }
@@ -338,7 +348,10 @@ using namespace hilo;
 struct hilo_qp {
   int device, n, m;
   QpDims qd;
-  size_t lds_bytes;
+  size_t lds_bytes;      // working set per instance
+  bool big;              // working set in global memory
+  double* ws;
+  int64_t ws_batch;
 };
 
 extern "C" int hilo_qp_create(int n, int m, int device, hilo_qp** out) {
@@ -353,16 +366,18 @@ extern "C" int hilo_qp_create(int n, int m, int device, hilo_qp** out) {
   q.max_iter = 100; q.tol = 1e-12; q.reg = 1e-12;
   h->lds_bytes = sizeof(double) * ((size_t)2 * n * q.ldn + (size_t)m * q.ldn + (size_t)n * q.ldm + (size_t)(m > 0 ? m : 1) * q.ldm +
                                    12 * (size_t)n + 4 * (size_t)(m > 0 ? m : 1));
-  if (h->lds_bytes > 160 * 1024) {
-    const size_t need = h->lds_bytes;
-    delete h;
-    return fail(HILO_ENOTSUP, "QP of size n=%d, m=%d needs %zu B of LDS per instance (limit 163840)", n, m, need);
-  }
+  h->big = h->lds_bytes > 160 * 1024;   // e.g. LMPC with nx=2, nu=1 beyond N = 22
+  h->ws = nullptr;
+  h->ws_batch = 0;
   *out = h;
   return HILO_OK;
 }
 
-extern "C" void hilo_qp_destroy(hilo_qp* h) { delete h; }
+extern "C" void hilo_qp_destroy(hilo_qp* h) {
+  if (!h) return;
+  if (h->ws) (void)hipFree(h->ws);
+  delete h;
+}
 
 extern "C" int hilo_qp_set_options(hilo_qp* h, double tol, int max_iter) {
   HILO_REQUIRE(h, "hilo_qp_set_options: NULL handle");
@@ -382,12 +397,21 @@ extern "C" int hilo_qp_solve(hilo_qp* h, int64_t batch, const double* H, int64_t
   HILO_REQUIRE(h->m == 0 || (A && lba && uba), "hilo_qp_solve: the problem has %d rows but A / lba / uba is NULL", h->m);
   HILO_REQUIRE(bx_stride >= h->n, "hilo_qp_solve: lbx/ubx are per instance (x_0 is pinned through them, mpc.py:2361-2362)");
   HILO_HIP_CHECK(hipSetDevice(h->device));
-  if (h->lds_bytes > 64 * 1024)
+  if (h->big) {
+    if (h->ws_batch != batch) {
+      if (h->ws) HILO_HIP_CHECK(hipFree(h->ws));
+      h->ws = nullptr;
+      hipError_t e = hipMalloc((void**)&h->ws, h->lds_bytes * (size_t)batch);
+      if (e != hipSuccess) return fail(HILO_ENOMEM, "QP workspace (%zu B per instance): %s", h->lds_bytes, hipGetErrorString(e));
+      h->ws_batch = batch;
+    }
+  } else if (h->lds_bytes > 64 * 1024) {
     HILO_HIP_CHECK(hipFuncSetAttribute((const void*)qp_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)h->lds_bytes));
-  hipLaunchKernelGGL(qp_solve_kernel, dim3((unsigned)batch), dim3(64), h->lds_bytes, (hipStream_t)stream, h->qd, batch, H,
-                     h_stride, g, g_stride, A, a_stride, lbx, ubx, bx_stride, lba, uba, ba_stride, x, f, lam_a, lam_x, status,
-                     iters);
+  }
+  hipLaunchKernelGGL(qp_solve_kernel, dim3((unsigned)batch), dim3(64), h->big ? 0 : h->lds_bytes, (hipStream_t)stream, h->qd,
+                     batch, H, h_stride, g, g_stride, A, a_stride, lbx, ubx, bx_stride, lba, uba, ba_stride, x, f, lam_a, lam_x,
+                     status, iters, h->big ? h->ws : (double*)nullptr, (int64_t)(h->lds_bytes / sizeof(double)));
   HILO_HIP_CHECK(hipGetLastError());
   return HILO_OK;
 }

@@ -81,3 +81,19 @@ def test_batch_1024_properties_and_errors():
     with pytest.raises(ValueError, match="We have an issue mate, the x0 you supplied has dimension 3"):
         mpc.optimize([1., 2., 3.])
     assert mpc.optimize(torch.empty(0, 2, dtype=torch.float64, device='cuda')).shape == (0, 1)
+
+
+@pytest.mark.parametrize('N', [30, 60])
+def test_long_horizon_qp_in_global_workspace(N):
+    """Beyond N = 22 the dense working set of the QP (n = 3N + 2, m = 2N) exceeds the LDS: it then lives in a per-instance
+    global-memory workspace; parity with the oracle's QP solver on the corrected assembly."""
+    rng = np.random.default_rng(3)
+    x0 = rng.uniform(-1.5, 1.5, (8, 2))
+    mpc = product_lmpc('corrected', N=N)
+    u = mpc.optimize(x0)
+    ref = lmpc_optimize(LmpcProblem(**dict(C1, N=N), kron_bug=False), x0)
+    st = mpc.solver_status_code
+    assert np.array_equal(st == 1, ref['status'] == 1) and (st == 1).sum() >= 6
+    ok = st == 1
+    np.testing.assert_allclose(u[ok], ref['u'][ok], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(mpc._nlp_solution['x'].cpu().numpy()[ok], ref['v'][ok], atol=1e-6)
