@@ -118,3 +118,13 @@ def test_general_errors():
         e = m.x['x'] + (m.x['v'] * e)                               # right-nested: needs a deeper stack each level
     with pytest.raises(ValueError, match="too deep"):
         e.program()
+
+
+@pytest.mark.parametrize('name', ['soft+scaling', 'path+soft+scaling'])
+def test_general_problems_with_scaling(name):
+    """Scaling together with constraints / path following: the constraint acts on un-scaled quantities (modeling.py:843-849),
+    the quadratic cost on scaled ones (modeling.py:310)."""
+    if name == 'soft+scaling':
+        _compare(dict(C2S, x_scaling=[.1, 40., 2., 1.], u_scaling=[2., 2.]), c2_x0(4), C2['p'])
+    else:
+        _compare(dict(C5S, x_scaling=[1., 2., 1., 2., 1., 1.], u_scaling=[5., 5.]), c5_x0(4), [])

@@ -19,6 +19,8 @@ def product_mhe(spec, **solver_options):
     mhe.set_box_constraints(x_lb=spec.get('x_lb'), x_ub=spec.get('x_ub'), w_lb=spec.get('w_lb'), w_ub=spec.get('w_ub'),
                             p_lb=spec['p'], p_ub=spec['p'])
     mhe.set_initial_guess(x_guess=spec['x_guess'])
+    if spec.get('x_scaling') or spec.get('w_scaling') or spec.get('u_scaling'):
+        mhe.set_scaling(x_scaling=spec.get('x_scaling'), w_scaling=spec.get('w_scaling'), u_scaling=spec.get('u_scaling'))
     mhe.setup(options={'integration_method': 'discrete'}, nlp_opts=solver_options or None)
     return mhe
 
@@ -178,3 +180,24 @@ def test_all_parameters_pinned_equals_plain_mhe():
         mhe.add_measurements(ym[:, k], um[:, k])
     x1, p1 = mhe.estimate(x_arrival=xa)
     assert not mhe._estimating and np.allclose(p1.cpu().numpy(), C3B['p'])
+
+
+@pytest.mark.parametrize('over', [dict(x_scaling=[.5, 40., 2., 1.]), dict(w_scaling=[1e-3] * 4), dict(u_scaling=[.1, .1]),
+                                  dict(x_scaling=[.5, 40., 2., 1.], w_scaling=[1e-3] * 4, u_scaling=[.1, .1])])
+def test_scalings_vs_oracle(over):
+    """x / w / u scaling (mhe.py:229-242, :352: the measured inputs enter the scaled model un-divided, Q-quirk kept)."""
+    N = 8
+    spec = dict(C3B, N=N, **over)
+    xa, um, ym, _ = c3_data(3, N=N)
+    pb = oracle_mhe(spec)
+    ipm = MheIpm(pb)
+    ref = ipm.solve(xa, spec['p'], um, ym)
+    mhe = product_mhe(spec)
+    for k in range(N):
+        mhe.add_measurements(ym[:, k], um[:, k])
+    x, _ = mhe.estimate(x_arrival=xa)
+    assert np.array_equal(mhe.solver_status_code, ref['status']) and np.all(ref['status'] == 1)
+    v, vr = mhe._nlp_solution['x'].cpu().numpy(), ref['v']
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 5e-5
+    np.testing.assert_allclose(x.cpu().numpy(), ref['x_opt'], rtol=5e-5, atol=1e-6)
+    np.testing.assert_allclose(mhe._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-7, atol=1e-10)
