@@ -118,7 +118,9 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
                d->n_path_var);
   HILO_REQUIRE(d->n_con >= 0 && d->n_con <= GEN_NEXPR, "hilo_nmpc_create: at most %d constraint expressions (got %d)", GEN_NEXPR,
                d->n_con);
-  const bool general = d->n_path_var > 0 || d->n_con > 0;
+  HILO_REQUIRE(d->n_tcon >= 0 && d->n_tcon <= GEN_NEXPR, "hilo_nmpc_create: at most %d terminal constraint expressions (got %d)",
+               GEN_NEXPR, d->n_tcon);
+  const bool general = d->n_path_var > 0 || d->n_con > 0 || d->n_tcon > 0;
   const GenVariant* gv = nullptr;
   int nth = 0, ne = 0, nrow = 0, n_con_ref = 0;
   int row_expr[OCP_MAXNC], row_sign[OCP_MAXNC], row_e[OCP_MAXNC], row_ref[OCP_MAXNC];
@@ -151,10 +153,14 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
         }
       }
     }
-    gv = nmpc_gen_find(d->model_id, nth, ne, nrow, d->N);
+    if (d->n_tcon > 0) {
+      HILO_REQUIRE(d->tcon_prog && d->tcon_prog_len > 0, "hilo_nmpc_create: n_tcon > 0 but no terminal constraint program");
+      HILO_REQUIRE(nrow + d->n_tcon <= OCP_MAXNC, "too many constraint rows");
+    }
+    gv = nmpc_gen_find(d->model_id, nth, ne, nrow + d->n_tcon, d->N);
     if (!gv)
       return fail(HILO_ENOTSUP, "no device instantiation for model %d with %d path variable(s), %d shared slack(s) and %d "
-                                "inequality row(s) per stage at horizon %d in this build", d->model_id, nth, ne, nrow, d->N);
+                                "inequality row(s) per stage at horizon %d in this build", d->model_id, nth, ne, nrow + d->n_tcon, d->N);
     lds = gv->lds_bytes(d->N);
   }
   const CollVariant* cv = nullptr;
@@ -197,7 +203,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   h->n_vc = (d->N + 1) * nx + d->N * nu;
   const int dn = cv ? cv->degree * nx : 0;
   h->n_v = (d->N + 1) * nxv + d->N * nue + ne + d->N * dn;   // mpc.py:1440-1443 (+ the soft-constraint slack, :1529-1537)
-  h->n_g = d->N * (nxv + n_con_ref + dn);                    // mpc.py:1657-1669, :1707-1725
+  h->n_g = d->N * (nxv + n_con_ref + dn) + (general ? d->n_tcon : 0);   // mpc.py:1657-1669, :1693-1725
   h->lds_bytes = lds;
   OcpConst& c = h->host;
   memset(&c, 0, sizeof(c));
@@ -280,20 +286,33 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     }
     if (!rcode && d->n_con > 0 && expr_check(d->con_prog, d->con_prog_len, d->n_con, nx, nu, np, &why))
       rcode = fail(HILO_EINVAL, "hilo_nmpc_create: constraint program: %s", why);
-    if (!rcode && gv->o_prog + plen + (d->n_con > 0 ? d->con_prog_len : 0) > OCP_NCOST)
+    if (!rcode && d->n_tcon > 0 && expr_check(d->tcon_prog, d->tcon_prog_len, d->n_tcon, nx, nu, np, &why))
+      rcode = fail(HILO_EINVAL, "hilo_nmpc_create: terminal constraint program: %s", why);
+    if (!rcode && gv->o_prog + plen + (d->n_con > 0 ? d->con_prog_len : 0) + (d->n_tcon > 0 ? d->tcon_prog_len : 0) > OCP_NCOST)
       rcode = fail(HILO_ENOTSUP, "expression programs too long (%d doubles available)", OCP_NCOST - gv->o_prog);
     if (rcode) { delete h; return rcode; }
     for (int i = 0; i < plen; ++i) c.cost[gv->o_prog + i] = d->path_prog[i];
     if (d->n_con > 0)
       for (int i = 0; i < d->con_prog_len; ++i) c.cost[gv->o_prog + plen + i] = d->con_prog[i];
+    {
+      const int off = gv->o_prog + plen + (d->n_con > 0 ? d->con_prog_len : 0);
+      for (int i = 0; i < (d->n_tcon > 0 ? d->tcon_prog_len : 0); ++i) c.cost[off + i] = d->tcon_prog[i];
+    }
     c.cost[gv->o_nexpr] = d->n_con;
+    c.cost[gv->o_ntexpr] = d->n_tcon;
     c.nc = nrow;
+    c.nc_term = d->n_tcon;
     c.n_con_ref = n_con_ref;
     for (int m = 0; m < OCP_MAXNC; ++m) { c.dlb[m] = -INFINITY; c.dub[m] = INFINITY; }
     for (int m = 0; m < nrow; ++m) {
       c.cost[gv->o_rowx + m] = row_expr[m]; c.cost[gv->o_rows + m] = row_sign[m]; c.cost[gv->o_rowe + m] = row_e[m];
       c.dlb[m] = relaxed_lb(row_lb[m]); c.dub[m] = relaxed_ub(row_ub[m]);   // IPOPT relaxes constraint bounds alike
       c.row_ref[m] = row_ref[m];
+    }
+    for (int j = 0; j < d->n_tcon; ++j) {
+      const double lb = d->tcon_lb ? d->tcon_lb[j] : -INFINITY, ub = d->tcon_ub ? d->tcon_ub[j] : INFINITY;
+      if (!(lb <= ub)) { delete h; return fail(HILO_EINVAL, "hilo_nmpc_create: terminal constraint %d has lb > ub", j); }
+      c.dlb[nrow + j] = relaxed_lb(lb); c.dub[nrow + j] = relaxed_ub(ub);
     }
     for (int i = nx; i < nxe; ++i) c.x0_free_mask |= 1u << i;               // theta_0 and e are variables (mpc.py:785-789)
     for (int a = 0; a < ne; ++a) c.k0_only_mask |= 1u << (nx + nth + a);    // one box on the shared slack

@@ -34,7 +34,7 @@ struct NmpcGen {
                        O_WDU = O_XREFN + NX, O_HASDU = O_WDU + MU * MU,
                        O_NPS = O_HASDU + 1, O_NPT = O_NPS + 1, O_IDXS = O_NPT + 1, O_WS = O_IDXS + GEN_NPT,
                        O_IDXT = O_WS + GEN_NPT * GEN_NPT, O_WT = O_IDXT + GEN_NPT,
-                       O_NEXPR = O_WT + GEN_NPT * GEN_NPT, O_ROWX = O_NEXPR + 1, O_ROWS = O_ROWX + OCP_MAXNC,
+                       O_NEXPR = O_WT + GEN_NPT * GEN_NPT, O_NTEXPR = O_NEXPR + 1, O_ROWX = O_NTEXPR + 1, O_ROWS = O_ROWX + OCP_MAXNC,
                        O_ROWE = O_ROWS + OCP_MAXNC, O_PROG = O_ROWE + OCP_MAXNC;
   static_assert(O_PROG + 64 <= OCP_NCOST, "cost block too small");
   static constexpr int NCOST = OCP_NCOST;  // expression programs have run-time length: the whole block
@@ -154,10 +154,11 @@ struct NmpcGen {
     return acc;
   }
 
-  // inequality rows d_m = sign_m c_{expr_m}(x sx, u su) - e_{slack_m}  (mpc.py:1276-1277; modeling.py:843-849)
+  // inequality rows d_m = sign_m c_{expr_m}(x sx, u su) - e_{slack_m}  (mpc.py:1276-1277; modeling.py:843-849); at the last
+  // stage additionally the hard terminal rows c_T(x_end sx) on the integrated end state xn (mpc.py:1693-1700)
   template <class T>
-  __device__ __forceinline__ static void con(const OcpConst& pc, const double* par, const double*, int, const T* x,
-                                             const T* u, T* d) {
+  __device__ __forceinline__ static void con(const OcpConst& pc, const double* par, const double*, int k, const T* x,
+                                             const T* u, const T* xn, T* d) {
     T xs[MX], us[MU > 0 ? MU : 1], ce[GEN_NEXPR];
 #pragma unroll
     for (int i = 0; i < MX; ++i) xs[i] = x[i] * pc.sz[i];
@@ -184,6 +185,22 @@ struct NmpcGen {
         d[m] = v;
       }
     }
+    const int nte = (int)pc.cost[O_NTEXPR];
+    if (nte > 0 && k == pc.N - 1) {
+      T xe[MX];
+#pragma unroll
+      for (int i = 0; i < MX; ++i) xe[i] = xn[i] * pc.sz[i];
+#pragma unroll
+      for (int j = 0; j < GEN_NEXPR; ++j) {
+        if (j < nte) {
+          const T v = expr_eval<MX, MU>(prog, xe, us, par);
+          prog += 1 + (int)prog[0];
+#pragma unroll
+          for (int m = 0; m < (NC > 0 ? NC : 1); ++m)
+            if (m < NC && m == pc.nc + j) d[m] = v;
+        }
+      }
+    }
   }
 };
 
@@ -207,7 +224,7 @@ struct GenVariant {
   int model_id, nth, ne, nc, big;            // key
   int nx, nu, nxv, mx, mu, np;               // engine / reference dimensions
   int o_wz, o_zref, o_wn, o_xrefn, o_wdu, o_hasdu, o_nps, o_npt, o_idxs, o_ws, o_idxt, o_wt, o_nexpr, o_rowx, o_rows,
-      o_rowe, o_prog;
+      o_rowe, o_prog, o_ntexpr;
   size_t (*lds_bytes)(int N);
   size_t (*ws_bytes)(int N);
   int (*launch)(const GenLaunchArgs& a);
@@ -264,7 +281,7 @@ GenVariant gen_variant(int model_id) {
   using PB = NmpcGen<M, NTH, NE, NC, BIG>;
   return GenVariant{model_id, NTH, NE, NC, BIG ? 1 : 0, PB::NX, PB::NU, PB::NXV, PB::MX, PB::MU, M::NP,
                     PB::O_WZ, PB::O_ZREF, PB::O_WN, PB::O_XREFN, PB::O_WDU, PB::O_HASDU, PB::O_NPS, PB::O_NPT, PB::O_IDXS,
-                    PB::O_WS, PB::O_IDXT, PB::O_WT, PB::O_NEXPR, PB::O_ROWX, PB::O_ROWS, PB::O_ROWE, PB::O_PROG,
+                    PB::O_WS, PB::O_IDXT, PB::O_WT, PB::O_NEXPR, PB::O_ROWX, PB::O_ROWS, PB::O_ROWE, PB::O_PROG, PB::O_NTEXPR,
                     &gen_lds<PB>, &gen_ws<PB>, &gen_launch<PB>};
 }
 

@@ -55,7 +55,8 @@ struct OcpConst {
   // general problems (path following, stage constraints; hilo_nmpc_gen.h)
   unsigned x0_free_mask;   // bit i: slot i of x_0 is a variable although x_0 is pinned (path variable, shared slack)
   unsigned k0_only_mask;   // bit i: the box of slot i only applies at stage 0 (shared slack carried as a constant state)
-  int nc, pad_;            // active inequality rows per stage (<= PB::NC)
+  int nc, nc_term;         // inequality rows of every stage; further rows that only exist at the last stage N-1 (terminal
+                           // constraint on the integrated end state, mpc.py:1693-1700); nc + nc_term <= PB::NC
   double dlb[OCP_MAXNC], dub[OCP_MAXNC];  // their (relaxed) bounds; +-inf if none
   int n_con_ref, row_ref[OCP_MAXNC];      // rows per stage in the reference's g and where each active row sits there
   int pad2_;
@@ -95,13 +96,36 @@ __device__ __forceinline__ double dpp_mov(double v) {
 __device__ __forceinline__ double read_lane(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+// Wave-uniform values (one wave per instance: every solver decision is the same in all 64 lanes).  The compiler cannot
+// see that for values that come back from a called phase or through memory, treats them as divergent and then lowers the
+// solver's control flow with EXEC masks and keeps its scalars in vector registers.  v_readfirstlane pins them to scalar
+// registers: scalar branches, and no vector live ranges across the divergent element loops (a register-allocator copy
+// placed before the EXEC restore of such a loop's exit block lost the filter size of a constrained variant - see DESIGN.md).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+__device__ __forceinline__ double uni(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(3))) T* uni(__attribute__((address_space(3))) T* p) {
+  return (__attribute__((address_space(3))) T*)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)p);
+}
+template <class T>
+__device__ __forceinline__ T* uni(T* p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+struct FTheta { double f, theta; };  // objective and constraint violation of a point
+
 template <class Op>
 __device__ __forceinline__ double wave_reduce(double v) {
   v = Op::f(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
   v = Op::f(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
   v = Op::f(v, dpp_mov<0x141>(v));  // row_half_mirror
   v = Op::f(v, dpp_mov<0x140>(v));  // row_mirror
-  return Op::f(Op::f(read_lane(v, 0), read_lane(v, 16)), Op::f(read_lane(v, 32), read_lane(v, 48)));
+  return uni(Op::f(Op::f(read_lane(v, 0), read_lane(v, 16)), Op::f(read_lane(v, 32), read_lane(v, 48))));
 }
 
 template <class Op>
@@ -200,6 +224,10 @@ struct Ocp {
   __device__ static bool is_free(const OcpConst& pc, int k, int i) {
     return !((k == 0 && x0_pinned(pc, i)) || (k == pc.N && i >= NX));
   }
+  // inequality row m exists at stage k
+  __device__ static bool row_on(const OcpConst& pc, int k, int m) {
+    return m < pc.nc || (k == pc.N - 1 && m < pc.nc + pc.nc_term);
+  }
   __device__ static double lb_of(const OcpConst& pc, int k, int i) {
     return (k > 0 && ((pc.k0_only_mask >> i) & 1u)) ? -INFINITY : pc.lbz[i];
   }
@@ -219,8 +247,8 @@ struct Ocp {
 
   // ---- values only at a point Zp: defects cp_k = x_{k+1} - F_k(x_k,u_k), returns (f, theta = |c|_1) -------------
   // with inequality rows: theta also counts |d_k - sp_k| for the slacks sp; `dstore` (optional) receives d_k
-  __device__ OCP_PHASE static void eval_values(lds_double* lbase, double* ws, cdp Zp, dp cp, double& f, double& theta,
-                                                               cdp sp = nullptr, dp dstore = nullptr) {
+  __device__ OCP_PHASE static FTheta eval_values_call(lds_double* lbase, double* ws, cdp Zp, dp cp, cdp sp, dp dstore) {
+    lbase = uni(lbase); ws = uni(ws); Zp = uni(Zp); cp = uni(cp); sp = uni(sp); dstore = uni(dstore);
     const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
@@ -278,10 +306,10 @@ struct Ocp {
         }
         if constexpr (NC > 0) {
           double dv[NC];
-          PB::con(pc, (const double*)l.par, sd_of(l, k), k, x, u, dv);
+          PB::con(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dv);
 #pragma unroll
           for (int m = 0; m < NC; ++m) {
-            if (m < pc.nc) {
+            if (row_on(pc, k, m)) {
               if (dstore) dstore[k * NC + m] = dv[m];
               if (sp) tpart += fabs(dv[m] - sp[k * NC + m]);
             }
@@ -291,8 +319,14 @@ struct Ocp {
         fpart += PB::term_cost(pc, (const double*)l.par, sd_of(l, N), x);
       }
     }
-    f = block_reduce<OpSum>(fpart, l.red);
-    theta = block_reduce<OpSum>(tpart, l.red);
+    const double fr = block_reduce<OpSum>(fpart, l.red);
+    return FTheta{fr, block_reduce<OpSum>(tpart, l.red)};
+  }
+
+  __device__ __forceinline__ static FTheta eval_values(lds_double* lbase, double* ws, cdp Zp, dp cp, cdp sp = nullptr,
+                                                      dp dstore = nullptr) {
+    const FTheta r = eval_values_call(lbase, ws, Zp, cp, sp, dstore);
+    return FTheta{uni(r.f), uni(r.theta)};
   }
 
   // -mu * sum log(slacks)
@@ -308,12 +342,12 @@ struct Ocp {
     if constexpr (NC > 0) {
       for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
         const int m = e % NC;
-        if (m >= pc.nc) continue;
+        if (!row_on(pc, e / NC, m)) continue;
         if (pc.dlb[m] > -INFINITY) part -= log(sp[e] - pc.dlb[m]);
         if (pc.dub[m] < INFINITY) part -= log(pc.dub[m] - sp[e]);
       }
     }
-    return mu * block_reduce<OpSum>(part, l.red);
+    return uni(mu * block_reduce<OpSum>(part, l.red));
   }
 
   // ---- full derivative evaluation at Z: c, AB, grad, per-stage cost values, Lagrangian Hessian blocks --------
@@ -398,10 +432,10 @@ struct Ocp {
         }
         if constexpr (NC > 0) {  // inequality rows: value, Jacobian column, nu-weighted second-order term
           Jet2 dv[NC];
-          PB::con(pc, (const double*)l.par, sd_of(l, k), k, x, u, dv);
+          PB::con(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dv);
 #pragma unroll
           for (int m = 0; m < NC; ++m) {
-            if (m < pc.nc) {
+            if (row_on(pc, k, m)) {
               if (d == 0) l.cd[k * NC + m] = dv[m].v;
               if (d < NZ && !dead) l.Jd[(k * NC + m) * NZ + d] = dv[m].a;
               q += l.cnu[k * NC + m] * dv[m].b;
@@ -465,11 +499,13 @@ struct Ocp {
     return f;
   }
 
-  __device__ OCP_PHASE static double eval_derivs_call(lds_double* lbase, double* ws) { return eval_derivs_body(lbase, ws); }
+  __device__ OCP_PHASE static double eval_derivs_call(lds_double* lbase, double* ws) {
+    return eval_derivs_body(uni(lbase), uni(ws));
+  }
   // Cooperative models exchange partial sums between lanes through LDS with workgroup barriers in between; as a real
   // function (barriers kept as instructions) that is what was validated, so they keep the call.
   __device__ __forceinline__ static double eval_derivs(lds_double* lbase, double* ws) {
-    if constexpr (COOP) return eval_derivs_call(lbase, ws);
+    if constexpr (COOP) return uni(eval_derivs_call(lbase, ws));
     else return eval_derivs_body(lbase, ws);
   }
 
@@ -491,7 +527,7 @@ struct Ocp {
 
   // scaled optimality error pieces (W&B eq. 5)
   // also returns the complementarity errors for barrier parameters 0 and mu (same pass over the slots)
-  __device__ static void opt_error(const Lds l, double mu, double& dual_s, double& prim, double& s_c, double& compl0,
+  __device__ __forceinline__ static void opt_error(const Lds l, double mu, double& dual_s, double& prim, double& s_c, double& compl0,
                                    double& compl_mu) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
@@ -523,7 +559,7 @@ struct Ocp {
     if constexpr (NC > 0) {  // slack block: dual residual -nu - vL + vU, primal residual d - s
       for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
         const int m = e % NC;
-        if (m >= pc.nc) continue;
+        if (!row_on(pc, e / NC, m)) continue;
         dmax = nmax(dmax, fabs(-l.cnu[e] - l.cvL[e] + l.cvU[e]));
         pmax = nmax(pmax, fabs(l.cd[e] - l.cs[e]));
         lsum += fabs(l.cnu[e]);
@@ -541,7 +577,7 @@ struct Ocp {
           cm = nmax(cm, fabs(p - mu));
         }
       }
-      ncon = (double)N * pc.nc;
+      ncon = (double)N * pc.nc + pc.nc_term;
     }
     compl0 = block_reduce<OpMax>(c0, l.red);
     compl_mu = block_reduce<OpMax>(cm, l.red);
@@ -549,10 +585,10 @@ struct Ocp {
     pmax = block_reduce<OpMax>(pmax, l.red);
     lsum = block_reduce<OpSum>(lsum, l.red);
     zsum = block_reduce<OpSum>(zsum, l.red);
-    nb = fmax(1.0, block_reduce<OpSum>(nb, l.red));
+    nb = uni(fmax(1.0, block_reduce<OpSum>(nb, l.red)));
     const double s_d = fmax(pc.s_max, (lsum + zsum) / (N * NX + ncon + nb)) / pc.s_max;
-    s_c = fmax(pc.s_max, zsum / nb) / pc.s_max;
-    dual_s = dmax / s_d;
+    s_c = uni(fmax(pc.s_max, zsum / nb) / pc.s_max);
+    dual_s = uni(dmax / s_d);
     prim = pmax;
   }
 
@@ -568,7 +604,7 @@ struct Ocp {
     if constexpr (NC > 0) {
       for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
         const int m = e % NC;
-        if (m >= pc.nc) continue;
+        if (!row_on(pc, e / NC, m)) continue;
         if (pc.dlb[m] > -INFINITY) cm = nmax(cm, fabs((l.cs[e] - pc.dlb[m]) * l.cvL[e] - mu));
         if (pc.dub[m] < INFINITY) cm = nmax(cm, fabs((pc.dub[m] - l.cs[e]) * l.cvU[e] - mu));
       }
@@ -601,7 +637,7 @@ struct Ocp {
       for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
         const int m = e % NC;
         double sg = 0.0, r = 0.0;
-        if (m < pc.nc) {
+        if (row_on(pc, e / NC, m)) {
           if (pc.dlb[m] > -INFINITY) {
             const double is = 1.0 / (l.cs[e] - pc.dlb[m]);
             sg += l.cvL[e] * is;
@@ -668,6 +704,7 @@ struct Ocp {
   // on closed-loop matrices prepared in parallel and keeps dx in registers (wave shuffles, no LDS round trip).
   // `resto`: feasibility-restoration step (H = I, zero gradient: least-norm d with J d = -c)
   __device__ OCP_PHASE static bool riccati(lds_double* lbase, double* ws, double mu, double delta, bool resto = false) {
+    lbase = uni(lbase); ws = uni(ws); mu = uni(mu); delta = uni(delta); resto = uni(resto);
     const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N, t = threadIdx.x, T = blockDim.x;
@@ -879,7 +916,7 @@ struct Ocp {
       for (int e = t; e < N * NC; e += T) {
         const int k = e / NC, m = e - k * NC;
         double ds = 0.0, nun = 0.0;
-        if (m < pc.nc) {
+        if (row_on(pc, k, m)) {
           ds = l.cd[e] - l.cs[e];
 #pragma unroll
           for (int i = 0; i < NZ; ++i) ds += l.Jd[e * NZ + i] * l.D[k * NZ + i];
@@ -895,13 +932,14 @@ struct Ocp {
 
   // ---- feasibility restoration, simplified from W&B sec. 3.3 (same statement as oracle/nmpc.py::_restore) ------
   __device__ OCP_PHASE static bool restore(lds_double* lbase, double* ws, double mu, double tau, int nfilt, double theta_max) {
+    lbase = uni(lbase); ws = uni(ws); mu = uni(mu); tau = uni(tau); nfilt = uni(nfilt); theta_max = uni(theta_max);
     const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N, t = threadIdx.x, T = blockDim.x, SL = (N + 1) * NZ;
     double th = 0.0;
     for (int e = t; e < N * NX; e += T) th += fabs(l.c[e]);
     if constexpr (NC > 0)
-      for (int e = t; e < N * NC; e += T) th += (e % NC) < pc.nc ? fabs(l.cd[e] - l.cs[e]) : 0.0;
+      for (int e = t; e < N * NC; e += T) th += row_on(pc, e / NC, e % NC) ? fabs(l.cd[e] - l.cs[e]) : 0.0;
     th = block_reduce<OpSum>(th, l.red);
     const double th_start = th;
     for (int it = 0; it < 50; ++it) {
@@ -910,7 +948,7 @@ struct Ocp {
       if constexpr (NC > 0) {
         for (int e = t; e < N * NC; e += T) {
           const int m = e % NC;
-          if (m >= pc.nc) continue;
+          if (!row_on(pc, e / NC, m)) continue;
           const double d = l.cds[e];
           if (pc.dlb[m] > -INFINITY && d < 0.0) a = fmin(a, -tau * (l.cs[e] - pc.dlb[m]) / d);
           if (pc.dub[m] < INFINITY && d > 0.0) a = fmin(a, tau * (pc.dub[m] - l.cs[e]) / d);
@@ -929,9 +967,10 @@ struct Ocp {
         if constexpr (NC > 0)
           for (int e = t; e < N * NC; e += T) l.cst[e] = l.cs[e] + alpha * l.cds[e];
         __syncthreads();
-        eval_values(lbase, ws, l.Zt, l.ct, ft, tht, l.cst);
+        const FTheta trial = eval_values(lbase, ws, l.Zt, l.ct, l.cst);
+        ft = trial.f; tht = trial.theta;
         if (isfinite(tht) && tht <= (1.0 - 1e-4 * alpha) * th) { ok = true; break; }
-        alpha *= 0.5;
+        alpha = uni(alpha * 0.5);
       }
       if (!ok) return false;
       for (int e = t; e < SL; e += T) l.Z[e] = l.Zt[e];
@@ -1035,12 +1074,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
   }
   __syncthreads();
   if constexpr (NC > 0) {  // IPOPT: slacks start at d(w_0), pushed into the interior of their bounds
-    double f_, th_;
-    S::eval_values(lds_raw, wsb, l.Z, l.ct, f_, th_, nullptr, l.cd);
+    S::eval_values(lds_raw, wsb, l.Z, l.ct, nullptr, l.cd);
     __syncthreads();
     for (int e = t; e < N * NC; e += T) {
       const int m = e % NC;
-      if (m >= pc.nc) continue;
+      if (!S::row_on(pc, e / NC, m)) continue;
       double v = l.cd[e];
       const double lb = pc.dlb[m], ub = pc.dub[m];
       const bool hl = lb > -INFINITY, hu = ub < INFINITY;
@@ -1061,7 +1099,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     __syncthreads();
   }
 
-  double mu = pc.mu_init, tau = fmax(pc.tau_min, 1.0 - mu);
+  double mu = uni(pc.mu_init), tau = uni(fmax(pc.tau_min, 1.0 - mu));
   double delta_last = 0.0;
   int nfilt = 0, acc_count = 0, it = 0, st = 0;
   double theta_min = 0.0, theta_max = INFINITY;
@@ -1073,15 +1111,15 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     double th0 = 0.0;
     for (int e = t; e < N * NX; e += T) th0 += fabs(l.c[e]);
     if constexpr (NC > 0)
-      for (int e = t; e < N * NC; e += T) th0 += (e % NC) < pc.nc ? fabs(l.cd[e] - l.cs[e]) : 0.0;
+      for (int e = t; e < N * NC; e += T) th0 += S::row_on(pc, e / NC, e % NC) ? fabs(l.cd[e] - l.cs[e]) : 0.0;
     th0 = block_reduce<OpSum>(th0, l.red);
     if (it == 0) {
-      theta_min = pc.theta_min_fact * fmax(1.0, th0);
-      theta_max = pc.theta_max_fact * fmax(1.0, th0);
+      theta_min = uni(pc.theta_min_fact * fmax(1.0, th0));
+      theta_max = uni(pc.theta_max_fact * fmax(1.0, th0));
     }
     double dual_s, prim, s_c, c0, cmu;
     S::opt_error(l, mu, dual_s, prim, s_c, c0, cmu);
-    E0 = nmax(nmax(dual_s, prim), c0 / s_c);
+    E0 = uni(nmax(nmax(dual_s, prim), c0 / s_c));
     if (E0 != E0) { st = HILO_STATUS_OTHER; break; }   // NaN in the iterate: IPOPT's 'Invalid_Number_Detected' -> -1
     if (E0 <= pc.tol) { st = HILO_STATUS_SOLVED; break; }
     if (E0 <= pc.acceptable_tol) {
@@ -1090,10 +1128,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     if (it >= pc.max_iter) { st = HILO_STATUS_MAXITER; break; }
     // ---- barrier update (W&B eq. 7) ----
     for (int r = 0; r < 20; ++r) {
-      const double Emu = nmax(nmax(dual_s, prim), (r == 0 ? cmu : S::compl_error(l, mu)) / s_c);
+      const double Emu = uni(nmax(nmax(dual_s, prim), (r == 0 ? cmu : S::compl_error(l, mu)) / s_c));
       if (!(Emu <= pc.kappa_eps * mu && mu > pc.tol / 10 * (1 + 1e-12))) break;
-      mu = fmax(pc.tol / 10, fmin(pc.kappa_mu * mu, pow(mu, pc.theta_mu)));
-      tau = fmax(pc.tau_min, 1.0 - mu);
+      mu = uni(fmax(pc.tol / 10, fmin(pc.kappa_mu * mu, pow(mu, pc.theta_mu))));
+      tau = uni(fmax(pc.tau_min, 1.0 - mu));
       nfilt = 0;
     }
     OCP_TICK(PH_ERR)
@@ -1103,12 +1141,12 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     bool first_try = true, solved = false;
     for (;;) {
       tprof[PH_NRIC] += 1;
-      if (S::riccati(lds_raw, wsb, mu, delta)) { solved = true; break; }
+      if (uni(S::riccati(lds_raw, wsb, mu, delta))) { solved = true; break; }
       if (first_try) {
-        delta = delta_last == 0.0 ? pc.delta_w_0 : fmax(pc.delta_w_min, pc.kappa_w_minus * delta_last);
+        delta = uni(delta_last == 0.0 ? pc.delta_w_0 : fmax(pc.delta_w_min, pc.kappa_w_minus * delta_last));
         first_try = false;
       } else {
-        delta *= delta_last == 0.0 ? pc.kappa_w_plus_bar : pc.kappa_w_plus;
+        delta = uni(delta * (delta_last == 0.0 ? pc.kappa_w_plus_bar : pc.kappa_w_plus));
       }
       if (delta > pc.delta_w_max) break;
     }
@@ -1145,7 +1183,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       for (int e = t; e < N * NC; e += T) {
         const int m = e % NC;
         double dl = 0.0, du = 0.0;
-        if (m < pc.nc) {
+        if (S::row_on(pc, e / NC, m)) {
           const double d = l.cds[e];
           if (pc.dlb[m] > -INFINITY) {
             const double s = l.cs[e] - pc.dlb[m];
@@ -1168,7 +1206,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     a_p = block_reduce<OpMin>(a_p, l.red);
     a_z = block_reduce<OpMin>(a_z, l.red);
     dphi = block_reduce<OpSum>(dphi, l.red);
-    const double phi0 = fval + S::eval_barrier(l, l.Z, mu, l.cs);
+    const double phi0 = uni(fval + S::eval_barrier(l, l.Z, mu, l.cs));
     OCP_TICK(PH_STEP)
     // ---- filter line search (W&B Alg. A without second-order correction) ----
     double alpha = a_p;
@@ -1178,10 +1216,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       if constexpr (NC > 0)
         for (int e = t; e < N * NC; e += T) l.cst[e] = l.cs[e] + alpha * l.cds[e];
       __syncthreads();
-      double ft, tht;
       tprof[PH_NLS] += 1;
-      S::eval_values(lds_raw, wsb, l.Zt, l.ct, ft, tht, l.cst);
-      const double pht = ft + S::eval_barrier(l, l.Zt, mu, l.cst);
+      const FTheta trial = S::eval_values(lds_raw, wsb, l.Zt, l.ct, l.cst);
+      const double ft = trial.f, tht = trial.theta;
+      const double pht = uni(ft + S::eval_barrier(l, l.Zt, mu, l.cst));
       bool ok = isfinite(pht) && isfinite(tht) && tht <= theta_max;
       if (ok) {
         for (int q = 0; q < nfilt; ++q) {
@@ -1197,7 +1235,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
         else ok = tht <= (1 - pc.gamma_theta) * th0 || pht - phi0 - rnd <= -pc.gamma_phi * th0;
       }
       if (ok) { accepted = true; armijo = sw; break; }
-      alpha *= 0.5;
+      alpha = uni(alpha * 0.5);
       // W&B eq. 23: below alpha_min the line search gives up and the restoration phase is called
       double amin = pc.gamma_theta;
       if (dphi < 0.0) {
@@ -1225,7 +1263,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       __syncthreads();
     }
     if (do_resto) {
-      if (!S::restore(lds_raw, wsb, mu, tau, nfilt, theta_max)) { st = HILO_STATUS_RESTORATION_FAILED; break; }
+      if (!uni(S::restore(lds_raw, wsb, mu, tau, nfilt, theta_max))) { st = HILO_STATUS_RESTORATION_FAILED; break; }
       // IPOPT after restoration: equality multipliers reset (constr_mult_reset_threshold = 0), bound multipliers
       // reset to 1 when they exceed bound_mult_reset_threshold = 1000
       double zm = 0.0;
@@ -1244,7 +1282,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
         for (int e = t; e < N * NC; e += T) {
           const int m = e % NC;
           l.cnu[e] = 0.0;
-          if (zm > 1e3 && m < pc.nc) {
+          if (zm > 1e3 && S::row_on(pc, e / NC, m)) {
             l.cvL[e] = pc.dlb[m] > -INFINITY ? 1.0 : 0.0;
             l.cvU[e] = pc.dub[m] < INFINITY ? 1.0 : 0.0;
           }
@@ -1270,7 +1308,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     if constexpr (NC > 0) {
       for (int e = t; e < N * NC; e += T) {
         const int m = e % NC;
-        if (m >= pc.nc) continue;
+        if (!S::row_on(pc, e / NC, m)) continue;
         const double snew = l.cst[e];
         l.cs[e] = snew;
         l.cnu[e] += alpha * (l.cnun[e] - l.cnu[e]);
@@ -1298,8 +1336,9 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
   }
   if (lam_g) {
     // the reference's g: per stage [shooting defect (NXV rows) | constraint rows (n_con_ref)] (mpc.py:1667, :1707-1725)
-    const int ncr = NC > 0 ? pc.n_con_ref : 0, rows = NXV + ncr;
-    double* lg = lam_g + b * (int64_t)(N * rows);
+    // the last stage carries the terminal rows between its defect and its stage rows (mpc.py:1693-1700 before :1707)
+    const int ncr = NC > 0 ? pc.n_con_ref : 0, ntr = NC > 0 ? pc.nc_term : 0, rows = NXV + ncr;
+    double* lg = lam_g + b * (int64_t)(N * rows + ntr);
     for (int e = t; e < N * NXV; e += T) {
       const int k = e / NXV, i = e - k * NXV;
       double v = l.lam[k * NX + i];
@@ -1309,11 +1348,15 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       lg[k * rows + i] = v;
     }
     if constexpr (NC > 0) {
-      for (int e = t; e < N * ncr; e += T) lg[(e / ncr) * rows + NXV + e % ncr] = 0.0;  // dropped (unbounded) rows
+      for (int e = t; e < N * ncr; e += T) {  // dropped (unbounded) rows
+        const int k = e / ncr;
+        lg[k * rows + NXV + (k == N - 1 ? ntr : 0) + e % ncr] = 0.0;
+      }
       __syncthreads();
       for (int e = t; e < N * NC; e += T) {
         const int k = e / NC, m = e - k * NC;
-        if (m < pc.nc) lg[k * rows + NXV + pc.row_ref[m]] = l.cnu[e];
+        if (m < pc.nc) lg[k * rows + NXV + (k == N - 1 ? ntr : 0) + pc.row_ref[m]] = l.cnu[e];
+        else if (k == N - 1 && m < pc.nc + ntr) lg[k * rows + NXV + (m - pc.nc)] = l.cnu[e];
       }
     }
   }

@@ -502,8 +502,23 @@ class NMPC:
             prog = compile_block(sr + tr, theta_index=nx)           # theta is state index nx (mpc.py:1181)
             d.path_prog, d.path_prog_len = hp(prog), len(prog)
         # ---- nonlinear stage constraint (modeling.py:820-1005) ----
-        if self.terminal_constraint.is_set:
-            raise NotImplementedError("terminal constraints are not yet offloaded")
+        tc = self.terminal_constraint
+        if tc.is_set:
+            # hard: lb <= c_T(x_end) <= ub on the integrated end state (mpc.py:1693-1700)
+            if tc.is_soft:
+                raise NotImplementedError("soft terminal constraints are not offloaded (the reference evaluates them at "
+                                          "x_{N-1} with a second slack vector, mpc.py:1684-1692)")
+            for e in tc.constraint:
+                if e.depends_on('theta') or e.depends_on('u'):
+                    raise ValueError("The terminal constraint is a function of the states (and parameters) only")
+            nt = tc.size
+            tlb = [-np.inf] * nt if tc.lb is None else tc.lb
+            tub = [np.inf] * nt if tc.ub is None else tc.ub
+            if len(tlb) != nt or len(tub) != nt:
+                raise ValueError("The dimensions of the terminal constraint function and its bounds are not compatible.")
+            prog = compile_block(tc.constraint)
+            d.n_tcon, d.tcon_prog, d.tcon_prog_len = nt, hp(prog), len(prog)
+            d.tcon_lb, d.tcon_ub = hp(tlb), hp(tub)
         sc = self.stage_constraint
         ne = 0
         if sc.is_set:

@@ -43,7 +43,7 @@ class GenNmpcProblem(NmpcProblem):
        constraint = dict(expr=[expr in state/input names, ...], lb=[...], ub=[...], soft=False, weight=None,
                          max_violation=inf)"""
 
-    def __init__(self, model, dt, N, path=None, constraint=None, **kw):
+    def __init__(self, model, dt, N, path=None, constraint=None, terminal_constraint=None, **kw):
         super().__init__(model, dt, N, **kw)
         nx, nu = self.nx, self.nu
         self.path = path
@@ -122,6 +122,20 @@ class GenNmpcProblem(NmpcProblem):
         self._d = _lam(rows, args) if rows else None
         self._dj = _lam([[sp.diff(r, a) for a in ze] for r in rows], args) if rows else None
         self._dh = _lam([[[sp.diff(r, a, b) for b in zs] for a in zs] for r in rows], args) if rows else None
+        # ---- hard terminal constraint on the integrated end state Phi(x_{N-1}, u_{N-1}) (mpc.py:1693-1700), un-scaled ----
+        self.nt = 0
+        if terminal_constraint:
+            if terminal_constraint.get('soft'):
+                raise NotImplementedError("soft terminal constraints")
+            xsym = [sp.Symbol(f'xe_{i}') for i in range(nx)]
+            ct = [_parse(e, names).subs(dict(zip(model.x, xsym)), simultaneous=True) for e in terminal_constraint['expr']]
+            self.nt = len(ct)
+            self.tlb = np.broadcast_to(np.asarray(terminal_constraint.get('lb', -INF), dtype=float), (self.nt,)).copy()
+            self.tub = np.broadcast_to(np.asarray(terminal_constraint.get('ub', INF), dtype=float), (self.nt,)).copy()
+            ax = [xsym]
+            self._ct = _lam(ct, ax)
+            self._ctj = _lam([[sp.diff(c, a) for a in xsym] for c in ct], ax)
+            self._cth = _lam([[[sp.diff(c, a, b) for b in xsym] for a in xsym] for c in ct], ax)
         # ---- decision-vector bookkeeping of the reference (mpc.py:1462-1537) ----
         nxa, nua = self.nxa, self.nua
         off = 0
@@ -135,7 +149,7 @@ class GenNmpcProblem(NmpcProblem):
             off += nua
         self.e_ind = list(range(off, off + self.ne))
         self.n_v = off + self.ne
-        self.n_g = N * (nxa + self.n_con_ref)
+        self.n_g = N * (nxa + self.n_con_ref) + self.nt
 
     @staticmethod
     def _vgh(expr, syms):
@@ -183,11 +197,13 @@ class GenIpm(DenseIpm):
         self.o_u = self.o_x + N * nxa
         self.o_e = self.o_u + N * nua
         self.o_s = self.o_e + ne
-        self.nw = self.o_s + N * nrow
-        self.m = N * nxa + N * nrow
-        lb = np.concatenate([pb.x_lb[pb.nx:], np.tile(pb.x_lb, N), np.tile(pb.u_lb, N), np.zeros(ne), np.tile(pb.dlb, N)])
+        self.o_t = self.o_s + N * nrow                       # slacks of the terminal rows
+        self.nw = self.o_t + pb.nt
+        self.m = N * nxa + N * nrow + pb.nt
+        lb = np.concatenate([pb.x_lb[pb.nx:], np.tile(pb.x_lb, N), np.tile(pb.u_lb, N), np.zeros(ne), np.tile(pb.dlb, N),
+                             pb.tlb if pb.nt else np.zeros(0)])
         ub = np.concatenate([pb.x_ub[pb.nx:], np.tile(pb.x_ub, N), np.tile(pb.u_ub, N),
-                             pb.e_ub if ne else np.zeros(0), np.tile(pb.dub, N)])
+                             pb.e_ub if ne else np.zeros(0), np.tile(pb.dub, N), pb.tub if pb.nt else np.zeros(0)])
         r = o.bound_relax_factor
         self.lb = np.where(np.isfinite(lb), lb - r * np.maximum(1, np.abs(lb)), lb)
         self.ub = np.where(np.isfinite(ub), ub + r * np.maximum(1, np.abs(ub)), ub)
@@ -215,7 +231,7 @@ class GenIpm(DenseIpm):
         X[:, 1:] = w[:, self.o_x:self.o_u].reshape(B, N, nxa)
         U = w[:, self.o_u:self.o_e].reshape(B, N, nua)
         E = w[:, self.o_e:self.o_s]
-        S = w[:, self.o_s:].reshape(B, N, pb.nrow)
+        S = w[:, self.o_s:self.o_t].reshape(B, N, pb.nrow)
         return X, U, E, S
 
     def eval_fc(self, w, data):
@@ -240,7 +256,11 @@ class GenIpm(DenseIpm):
             f += np.einsum('bi,ij,bj->b', d, pb.Wdu, d)
         d = X[:, N] - pb.xrefNa
         f += np.einsum('bi,ij,bj->b', d, pb.WNa, d) + pb._Vp[0](X[:, N])
-        return f, np.concatenate([c, cd], axis=2).reshape(B, -1)
+        call = np.concatenate([c, cd], axis=2).reshape(B, -1)
+        if pb.nt:
+            xe = pb.phia(X[:, N - 1], U[:, N - 1], p)[:, :pb.nx] * pb.sx
+            call = np.concatenate([call, pb._ct(xe) - w[:, self.o_t:]], axis=1)
+        return f, call
 
     def eval_all(self, w, lam, data):
         """Constraint order: per stage [defect (nxa) | d - s (nrow)]."""
@@ -255,7 +275,8 @@ class GenIpm(DenseIpm):
         c = np.empty((B, N, mk))
         J = np.zeros((B, self.m, self.nw))
         W = np.zeros((B, self.nw, self.nw))
-        lam = lam.reshape(B, N, mk)
+        lam_t = lam[:, N * mk:]
+        lam = lam[:, :N * mk].reshape(B, N, mk)
         bi = np.arange(B)
         ecols = list(range(self.o_e, self.o_s))
         for k in range(N):
@@ -293,6 +314,18 @@ class GenIpm(DenseIpm):
                 f += np.einsum('bi,ij,bj->b', d, pb.Wdu, d)
                 gz[:, nxa:nxa + pb.nu] += 2 * d @ pb.Wdu
                 Hz[:, nxa:nxa + pb.nu, nxa:nxa + pb.nu] += 2 * pb.Wdu
+            if pb.nt and k == N - 1:      # c_T(Phi(z) sx) - s_T: chain rule through the shooting map
+                nx = pb.nx
+                xe = Phi[:, :nx] * pb.sx
+                cv, cj, ch = pb._ct(xe), pb._ctj(xe), pb._cth(xe)
+                Js = Jk[:, :nx] * pb.sx[None, :, None]                                   # d xe / d z
+                ct_rows = list(range(N * mk, N * mk + pb.nt))
+                c_term = cv - w[:, self.o_t:]
+                J[np.ix_(bi, ct_rows, zi)] = np.einsum('bma,baz->bmz', cj, Js)[:, :, sel]
+                J[:, ct_rows, [self.o_t + r for r in range(pb.nt)]] = -1.0
+                Hs = Hk[:, :nx] * pb.sx[None, :, None, None]
+                Hz = Hz + np.einsum('bm,bmac,baz,bcy->bzy', lam_t, ch, Js, Js) + \
+                    np.einsum('bm,bma,bazy->bzy', lam_t, cj, Hs)
             g[:, zi] += gz[:, sel]
             W[np.ix_(bi, zi, zi)] += Hz[np.ix_(bi, sel, sel)]
         d = X[:, N] - pb.xrefNa
@@ -300,7 +333,10 @@ class GenIpm(DenseIpm):
         f += np.einsum('bi,ij,bj->b', d, pb.WNa, d) + pb._Vp[0](X[:, N])
         g[:, xi] += 2 * d @ pb.WNa + pb._Vp[1](X[:, N])
         W[np.ix_(bi, xi, xi)] += 2 * pb.WNa[None] + pb._Vp[2](X[:, N])
-        return f, g, c.reshape(B, -1), J, W
+        call = c.reshape(B, -1)
+        if pb.nt:
+            call = np.concatenate([call, c_term], axis=1)
+        return f, g, call, J, W
 
     def solve(self, x0, p, w0=None, u_old=None, verbose=False):
         """w0: warm start for [theta_0 | xa | ua | e] (the slacks always restart at d(w_0), like IPOPT)."""
@@ -315,10 +351,14 @@ class GenIpm(DenseIpm):
             w0 = np.concatenate([pb.x_guess[pb.nx:], np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N), np.zeros(pb.ne)])
         w0 = np.broadcast_to(np.atleast_2d(w0)[:, :self.o_s], (B, self.o_s))
         w0 = _push_interior(w0, self.lb[:self.o_s], self.ub[:self.o_s], o)
-        if pb.nrow:
-            X, U, E, _ = self._unpack(np.concatenate([w0, np.zeros((B, pb.N * pb.nrow))], axis=1), x0)
-            s0 = np.stack([pb._d(np.concatenate([X[:, k], U[:, k]], axis=1), E) for k in range(pb.N)], axis=1)
-            w0 = np.concatenate([w0, s0.reshape(B, -1)], axis=1)
+        if pb.nrow or pb.nt:
+            X, U, E, _ = self._unpack(np.concatenate([w0, np.zeros((B, pb.N * pb.nrow + pb.nt))], axis=1), x0)
+            if pb.nrow:
+                s0 = np.stack([pb._d(np.concatenate([X[:, k], U[:, k]], axis=1), E) for k in range(pb.N)], axis=1)
+                w0 = np.concatenate([w0, s0.reshape(B, -1)], axis=1)
+            if pb.nt:
+                xe = pb.phia(X[:, pb.N - 1], U[:, pb.N - 1], p)[:, :pb.nx] * pb.sx
+                w0 = np.concatenate([w0, pb._ct(xe)], axis=1)
         res = self.solve_data(data, w0, verbose)
         X, U, E, S = self._unpack(res['w'], x0)
         res.update(X=X, U=U, E=E, S=S, u0=U[:, 0, :pb.nu] * pb.su, x0=x0)
@@ -341,9 +381,15 @@ class GenIpm(DenseIpm):
         dropped (infinite bound) carry a zero multiplier."""
         pb = self.pb
         B = res['lam'].shape[0]
-        lam = res['lam'].reshape(B, pb.N, pb.nxa + pb.nrow)
+        mk = pb.nxa + pb.nrow
+        lam = res['lam'][:, :pb.N * mk].reshape(B, pb.N, mk)
         out = np.zeros((B, pb.N, pb.nxa + pb.n_con_ref))
         out[:, :, :pb.nxa] = lam[:, :, :pb.nxa]
         for r, ref in enumerate(pb.row_ref):
             out[:, :, pb.nxa + ref] = lam[:, :, pb.nxa + r]
-        return out.reshape(B, -1)
+        if not pb.nt:
+            return out.reshape(B, -1)
+        # last stage: [defect | terminal rows | stage rows] (mpc.py:1693-1700 before :1707)
+        head = out[:, :-1].reshape(B, -1)
+        last = out[:, -1]
+        return np.concatenate([head, last[:, :pb.nxa], res['lam'][:, pb.N * mk:], last[:, pb.nxa:]], axis=1)

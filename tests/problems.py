@@ -199,6 +199,10 @@ def product_gen(spec, **solver_options):
             nmpc.stage_constraint.weight = co['weight']
         if co.get('max_violation') is not None:
             nmpc.stage_constraint.max_violation = co['max_violation']
+    if spec.get('terminal_constraint'):
+        tc = spec['terminal_constraint']
+        nmpc.terminal_constraint.constraint = [eval(e, dict(ns)) for e in tc['expr']]
+        nmpc.terminal_constraint.lb, nmpc.terminal_constraint.ub = list(tc['lb']), list(tc['ub'])
     nmpc.horizon = spec['N']
     nmpc.set_box_constraints(x_ub=spec.get('x_ub'), x_lb=spec.get('x_lb'), u_ub=spec.get('u_ub'), u_lb=spec.get('u_lb'))
     nmpc.set_initial_guess(x_guess=spec.get('x_guess'), u_guess=spec.get('u_guess'))

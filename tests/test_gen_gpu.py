@@ -128,3 +128,18 @@ def test_general_problems_with_scaling(name):
         _compare(dict(C2S, x_scaling=[.1, 40., 2., 1.], u_scaling=[2., 2.]), c2_x0(4), C2['p'])
     else:
         _compare(dict(C5S, x_scaling=[1., 2., 1., 2., 1., 1.], u_scaling=[5., 5.]), c5_x0(4), [])
+
+
+def test_hard_terminal_constraint_vs_oracle():
+    """`nmpc.terminal_constraint` (hard): rows on the integrated end state, between the last defect and the last stage rows
+    in g (mpc.py:1693-1700); here together with a hard stage constraint."""
+    tc = dict(expr=['X + P', 'S'], lb=[-np.inf, 30.], ub=[1.0, np.inf])
+    for spec in (dict(C2, N=8, terminal_constraint=tc), dict(C2H, N=8, terminal_constraint=dict(expr=['X + P'], lb=[-np.inf], ub=[1.]))):
+        nmpc, pb, ipm, ref = _compare(spec, c2_x0(4), C2['p'])
+        xp, up, _ = nmpc.return_prediction()
+        assert np.all(xp[:, 0, -1] + xp[:, 2, -1] <= 1. + 1e-5)
+        lam = ipm.lam_g(ref)
+        nxa = pb.nxa
+        last = (pb.N - 1) * (nxa + pb.n_con_ref)
+        lam[:, last:last + nxa] += 2 * (ref['X'][:, -1] - pb.xrefNa) @ pb.WNa          # terminal cost convention (mpc.py:1682)
+        np.testing.assert_allclose(nmpc._nlp_solution['lam_g'].cpu().numpy(), lam, rtol=2e-4, atol=2e-5)

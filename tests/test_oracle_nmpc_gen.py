@@ -67,14 +67,17 @@ def _slsqp(pb, ipm, res, b, p):
     def ineq(w):                                             # >= 0
         X, U, E = split(full(w))
         out = []
-        for k in range(N):
+        for k in range(N if pb.nrow else 0):
             d = pb._d(np.concatenate([X[k], U[k]])[None], E[None])[0]
             out += [np.where(np.isfinite(pb.dub), pb.dub - d, 1.), np.where(np.isfinite(pb.dlb), d - pb.dlb, 1.)]
+        if pb.nt:                                            # terminal rows on the integrated end state (mpc.py:1693-1700)
+            ct = pb._ct(pb.phia(X[N - 1][None], U[N - 1][None], np.atleast_2d(p))[:, :pb.nx] * pb.sx)[0]
+            out += [np.where(np.isfinite(pb.tub), pb.tub - ct, 1.), np.where(np.isfinite(pb.tlb), ct - pb.tlb, 1.)]
         return np.concatenate(out)
     lb = np.concatenate([np.tile(pb.x_lb, N + 1), np.tile(pb.u_lb, N), np.zeros(pb.ne)])[free]
     ub = np.concatenate([np.tile(pb.x_ub, N + 1), np.tile(pb.u_ub, N), pb.e_ub if pb.ne else np.zeros(0)])[free]
     w0 = np.clip(v_ipm[free] + 1e-3 * np.random.default_rng(b).normal(size=free.sum()), lb, ub)
-    cons = [{'type': 'eq', 'fun': eq}] + ([{'type': 'ineq', 'fun': ineq}] if pb.nrow else [])
+    cons = [{'type': 'eq', 'fun': eq}] + ([{'type': 'ineq', 'fun': ineq}] if pb.nrow or pb.nt else [])
     sol = minimize(obj, w0, method='SLSQP', bounds=list(zip(lb, ub)), constraints=cons, options={'ftol': 1e-11, 'maxiter': 800})
     assert sol.success, sol.message
     np.testing.assert_allclose(sol.fun, obj(v_ipm[free]), rtol=1e-6, atol=1e-8)
@@ -89,6 +92,18 @@ def test_hard_constraint_vs_slsqp():
     res = ipm.solve(c2_x0(1), spec['p'])
     assert res['status'][0] == 1 and res['kkt'][0] <= 1e-8
     assert (res['X'][0, :-1, 0] * res['X'][0, :-1, 1]).max() > 19.99       # active
+    _slsqp(pb, ipm, res, 0, spec['p'])
+
+
+def test_hard_terminal_constraint_vs_slsqp():
+    spec = dict(C2, N=6, terminal_constraint=dict(expr=['X + P', 'S'], lb=[-np.inf, 30.], ub=[1.0, np.inf]))
+    pb = oracle_gen(spec)
+    ipm = GenIpm(pb)
+    res = ipm.solve(c2_x0(1), spec['p'])
+    assert res['status'][0] == 1 and res['kkt'][0] <= 1e-8
+    xe = res['X'][0, -1] * pb.sx
+    assert xe[0] + xe[2] > 1. - 1e-6                                       # X + P <= 1 is active at the end state
+    assert pb.n_g == 6 * 4 + 2                                              # two rows after the last defect (mpc.py:1693-1700)
     _slsqp(pb, ipm, res, 0, spec['p'])
 
 
