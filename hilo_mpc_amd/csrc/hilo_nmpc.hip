@@ -47,6 +47,7 @@ struct hilo_nmpc {
   int device, model_id, nx, nu, np, N, n_v, n_g;
   OcpConst host;
   OcpConst* dev;
+  unsigned base_free_mask;   // x_0 components that are variables by construction (theta_0, shared slack)
   double* par_buf;   // [par_batch][np + nu] device: model parameters | u_old
   int64_t par_batch;
   long long* prof;   // optional phase-cycle counters (hilo_nmpc_profile)
@@ -346,6 +347,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     hilo_nmpc_destroy(h);
     return fail(HILO_EINVAL, "hilo_nmpc_create: desc.learned given but model %d has no learned term", d->model_id);
   }
+  h->base_free_mask = c.x0_free_mask;
   if (e == hipSuccess) e = hipMalloc((void**)&h->dev, sizeof(OcpConst));
   if (e == hipSuccess) e = hipMemcpy(h->dev, &c, sizeof(OcpConst), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&h->v_guess, sizeof(double) * h->n_v);
@@ -380,6 +382,19 @@ extern "C" int hilo_nmpc_dims(const hilo_nmpc* h, int* n_v, int* n_g, int* nx, i
   if (nx) *nx = h->nx;
   if (nu) *nu = h->nu;
   if (np) *np = h->np;
+  return HILO_OK;
+}
+
+// optimize(..., fix_x0=False) (mpc.py:797-807): the measured state is not imposed; x_0 is a variable inside the state box.
+// The engine already carries free x_0 components (path variable, shared slack): the model states join that mask.
+extern "C" int hilo_nmpc_set_fix_x0(hilo_nmpc* h, int fix_x0) {
+  HILO_REQUIRE(h, "hilo_nmpc_set_fix_x0: NULL handle");
+  const unsigned want = fix_x0 ? h->base_free_mask : (h->base_free_mask | ((1u << h->nx) - 1u));
+  if (want == h->host.x0_free_mask) return HILO_OK;
+  HILO_HIP_CHECK(hipSetDevice(h->device));
+  HILO_HIP_CHECK(hipDeviceSynchronize());   // launches in flight still read the constants
+  h->host.x0_free_mask = want;
+  HILO_HIP_CHECK(hipMemcpy(&h->dev->x0_free_mask, &want, sizeof(unsigned), hipMemcpyHostToDevice));
   return HILO_OK;
 }
 

@@ -350,6 +350,38 @@ class NMPC:
             return v
         self._x_scaling, self._u_scaling = chk(x_scaling, self._n_x, 'x'), chk(u_scaling, self._n_u, 'u')
 
+    # ---- compact setters of the reference (same names, argument order and meaning) -------------------------------------
+    def set_quadratic_stage_cost(self, states=None, cost_states=None, states_references=None, inputs=None, cost_inputs=None,
+                                 inputs_references=None):
+        """mpc.py:1064-1084: set-point tracking in one call."""
+        if states is not None:
+            self.quad_stage_cost.add_states(names=states, weights=cost_states, ref=states_references)
+        if inputs is not None:
+            self.quad_stage_cost.add_inputs(names=inputs, weights=cost_inputs, ref=inputs_references)
+
+    def set_quadratic_terminal_cost(self, states=None, cost=None, references=None):
+        """mpc.py:1086-1100."""
+        self.quad_terminal_cost.add_states(names=states, weights=cost, ref=references)
+
+    @staticmethod
+    def _set_constraint(c, function, lb, ub, is_soft, max_violation, weight, name):
+        c.constraint = function
+        c.lb, c.ub = lb, ub
+        c.is_soft = is_soft
+        c.max_violation = None if max_violation is None or np.all(np.isinf(np.atleast_1d(max_violation))) else max_violation
+        c.weight = weight
+        c._name = name
+
+    def set_stage_constraints(self, stage_constraint=None, lb=None, ub=None, is_soft=False, max_violation=np.inf, weight=None,
+                              name='stage_constraint'):
+        """optimizer.py:1154-1178: lb <= stage_constraint(x, u) <= ub in every stage."""
+        self._set_constraint(self.stage_constraint, stage_constraint, lb, ub, is_soft, max_violation, weight, name)
+
+    def set_terminal_constraints(self, terminal_constraint, name='terminal_constraint', lb=None, ub=None, is_soft=False,
+                                 max_violation=np.inf, weight=None):
+        """mpc.py:1102-1131 (note the reference's argument order: name before the bounds)."""
+        self._set_constraint(self.terminal_constraint, terminal_constraint, lb, ub, is_soft, max_violation, weight, name)
+
     def set_nlp_options(self, *args, **kwargs):
         """optimizer.py:1388-1474 (same keys, same allow-lists, same defaults)."""
         possible = {'integration_method': ['collocation', 'rk4', 'erk', 'discrete', 'idas', 'cvodes'],
@@ -585,8 +617,10 @@ class NMPC:
         if runs != 0:
             raise NotImplementedError("multi-start (runs > 0) uses unseeded random perturbations in the reference "
                                       "(mpc.py:740) and is not offloaded")
-        if not fix_x0:
-            raise NotImplementedError("fix_x0=False is not yet offloaded")
+        if not fix_x0 and (kwargs.get('x0_lb') is not None or kwargs.get('x0_ub') is not None):
+            raise NotImplementedError("fix_x0=False with a separate box x0_lb / x0_ub (mpc.py:803-804) is not offloaded; "
+                                      "x_0 is free inside [x_lb, x_ub]")
+        _lib.check(_lib.lib().hilo_nmpc_set_fix_x0(self._handle, int(bool(fix_x0))))     # mpc.py:797-807
         if tvp is not None and not self._time_varying_parameters:
             raise ValueError("tvp values were passed but no parameter was declared time varying "
                              "(set_time_varying_parameters)")

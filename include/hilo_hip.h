@@ -269,6 +269,10 @@ int hilo_nmpc_create(const hilo_nmpc_desc* desc, int device, hilo_nmpc** out);  
 void hilo_nmpc_destroy(hilo_nmpc* h);
 int hilo_nmpc_dims(const hilo_nmpc* h, int* n_v, int* n_g, int* nx, int* nu, int* np);
 int hilo_nmpc_reset_warm_start(hilo_nmpc* h);
+/* optimize(fix_x0=...) of mpc.py:797-807: 1 (default) pins x_0 to the measured state; 0 leaves x_0 free inside the state
+   box [x_lb, x_ub] (the `x0` argument of hilo_nmpc_solve is then ignored, the start value comes from the warm start / guess).
+   Synchronises the device when the setting changes. */
+int hilo_nmpc_set_fix_x0(hilo_nmpc* h, int fix_x0);
 /* One optimize() for `batch` independent instances (mpc.py:744-857).
    v layout = the reference's decision vector [x_0..x_N | u_0..u_{N-1}] in scaled variables (mpc.py:1462-1485). */
 int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch,

@@ -187,22 +187,24 @@ class GenNmpcProblem(NmpcProblem):
 
 
 class GenIpm(DenseIpm):
-    """Free variables w = [theta_0 | xa_1..xa_N | ua_0..ua_{N-1} | e | s_0..s_{N-1}]."""
+    """Free variables w = [x_0 (only with free_x0) | theta_0 | xa_1..xa_N | ua_0..ua_{N-1} | e | s_0..s_{N-1}].
+    free_x0: optimize(fix_x0=False) of mpc.py:797-807 - the measured state is not imposed, x_0 lives in the state box."""
 
-    def __init__(self, prob: GenNmpcProblem, options: IpmOptions | None = None):
+    def __init__(self, prob: GenNmpcProblem, options: IpmOptions | None = None, free_x0=False):
         self.pb = pb = prob
         self.o = o = options or IpmOptions()
         N, nxa, nua, nth, ne, nrow = pb.N, pb.nxa, pb.nua, pb.nth, pb.ne, pb.nrow
-        self.o_x = nth
+        self.n0 = pb.nx if free_x0 else 0
+        self.o_x = self.n0 + nth
         self.o_u = self.o_x + N * nxa
         self.o_e = self.o_u + N * nua
         self.o_s = self.o_e + ne
         self.o_t = self.o_s + N * nrow                       # slacks of the terminal rows
         self.nw = self.o_t + pb.nt
         self.m = N * nxa + N * nrow + pb.nt
-        lb = np.concatenate([pb.x_lb[pb.nx:], np.tile(pb.x_lb, N), np.tile(pb.u_lb, N), np.zeros(ne), np.tile(pb.dlb, N),
+        lb = np.concatenate([pb.x_lb[pb.nx - self.n0:], np.tile(pb.x_lb, N), np.tile(pb.u_lb, N), np.zeros(ne), np.tile(pb.dlb, N),
                              pb.tlb if pb.nt else np.zeros(0)])
-        ub = np.concatenate([pb.x_ub[pb.nx:], np.tile(pb.x_ub, N), np.tile(pb.u_ub, N),
+        ub = np.concatenate([pb.x_ub[pb.nx - self.n0:], np.tile(pb.x_ub, N), np.tile(pb.u_ub, N),
                              pb.e_ub if ne else np.zeros(0), np.tile(pb.dub, N), pb.tub if pb.nt else np.zeros(0)])
         r = o.bound_relax_factor
         self.lb = np.where(np.isfinite(lb), lb - r * np.maximum(1, np.abs(lb)), lb)
@@ -215,7 +217,7 @@ class GenIpm(DenseIpm):
         cols = []
         for i in range(pb.nxa):
             if k == 0:
-                cols.append(i - pb.nx if i >= pb.nx else -1)
+                cols.append(self.n0 + i - pb.nx if i >= pb.nx else (i if self.n0 else -1))
             else:
                 cols.append(self.o_x + (k - 1) * pb.nxa + i)
         cols += [self.o_u + k * pb.nua + j for j in range(pb.nua)]
@@ -226,8 +228,8 @@ class GenIpm(DenseIpm):
         B = w.shape[0]
         N, nxa, nua = pb.N, pb.nxa, pb.nua
         X = np.empty((B, N + 1, nxa))
-        X[:, 0, :pb.nx] = x0
-        X[:, 0, pb.nx:] = w[:, :pb.nth]
+        X[:, 0, :pb.nx] = w[:, :self.n0] if self.n0 else x0
+        X[:, 0, pb.nx:] = w[:, self.n0:self.n0 + pb.nth]
         X[:, 1:] = w[:, self.o_x:self.o_u].reshape(B, N, nxa)
         U = w[:, self.o_u:self.o_e].reshape(B, N, nua)
         E = w[:, self.o_e:self.o_s]
@@ -348,7 +350,7 @@ class GenIpm(DenseIpm):
         if u_old is not None:
             data['u_old'] = np.broadcast_to(np.atleast_2d(np.asarray(u_old, dtype=float)), (B, pb.nu))
         if w0 is None:
-            w0 = np.concatenate([pb.x_guess[pb.nx:], np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N), np.zeros(pb.ne)])
+            w0 = np.concatenate([pb.x_guess[pb.nx - self.n0:], np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N), np.zeros(pb.ne)])
         w0 = np.broadcast_to(np.atleast_2d(w0)[:, :self.o_s], (B, self.o_s))
         w0 = _push_interior(w0, self.lb[:self.o_s], self.ub[:self.o_s], o)
         if pb.nrow or pb.nt:
@@ -374,7 +376,7 @@ class GenIpm(DenseIpm):
         pb = self.pb
         v = np.atleast_2d(v)
         nX = (pb.N + 1) * pb.nxa
-        return np.concatenate([v[:, pb.nx:pb.nxa], v[:, pb.nxa:nX], v[:, nX:]], axis=1)
+        return np.concatenate([v[:, pb.nx - self.n0:pb.nxa], v[:, pb.nxa:nX], v[:, nX:]], axis=1)
 
     def lam_g(self, res):
         """Multipliers in the reference's g order: per stage [defect (nxa) | constraint rows (n_con_ref)]; rows that were

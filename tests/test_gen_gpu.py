@@ -143,3 +143,33 @@ def test_hard_terminal_constraint_vs_oracle():
         last = (pb.N - 1) * (nxa + pb.n_con_ref)
         lam[:, last:last + nxa] += 2 * (ref['X'][:, -1] - pb.xrefNa) @ pb.WNa          # terminal cost convention (mpc.py:1682)
         np.testing.assert_allclose(nmpc._nlp_solution['lam_g'].cpu().numpy(), lam, rtol=2e-4, atol=2e-5)
+
+
+def test_free_initial_state_vs_oracle():
+    """`optimize(x0, fix_x0=False)` (mpc.py:797-807): x_0 is a variable inside the state box, the measured state is ignored;
+    switching back to fix_x0=True restores the classic problem on the same handle."""
+    from tests.problems import product_nmpc, oracle_problem
+    from oracle.nmpc import DenseIpm
+    spec = dict(C2, N=8, x_lb=[1., 10., 0., 0.], x_ub=[8., 60., 5., 20.], x_guess=[4., 30., 1., 5.])
+    pb = oracle_gen(spec)
+    ipm = GenIpm(pb, free_x0=True)
+    x0 = c2_x0(4)
+    ref = ipm.solve(x0, C2['p'])
+    assert np.all(ref['status'] == 1)
+    nmpc = product_nmpc(spec)
+    u = nmpc.optimize(x0, cp=C2['p'], fix_x0=False)
+    assert np.array_equal(nmpc.solver_status_code, ref['status'])
+    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), ipm.to_v(ref)
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 5e-5
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(u, ref['u0'], rtol=5e-5, atol=5e-5)
+    assert np.abs(v[:, :4] - x0 / pb.sx).max() > 1e-2                      # x_0 really moved away from the measurement
+    fixed = DenseIpm(oracle_problem(spec)).solve(x0, C2['p'])
+    nmpc2 = product_nmpc(spec)
+    nmpc2.optimize(x0, cp=C2['p'], fix_x0=False)
+    nmpc2._nlp_options['warm_start'] = False
+    u2 = nmpc2.optimize(x0, cp=C2['p'])                                     # fix_x0=True again, cold start
+    assert np.array_equal(nmpc2.solver_status_code, fixed['status'])
+    np.testing.assert_allclose(u2, fixed['u0'], rtol=5e-5, atol=5e-5)
+    with pytest.raises(NotImplementedError):
+        nmpc.optimize(x0, cp=C2['p'], fix_x0=False, x0_lb=[0., 0., 0., 0.])

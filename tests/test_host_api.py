@@ -1,0 +1,81 @@
+"""CPU: host-side contract of the reference-style front end (no device needed before setup()): the compact setters fill
+the same objects as the long form (mpc.py:1064-1131, optimizer.py:1154-1178), argument validation raises what the reference
+raises, options follow the reference's allow-lists (optimizer.py:1388-1474)."""
+import numpy as np
+import pytest
+
+from hilo_mpc_amd import NMPC, Model, expr
+
+
+def _model():
+    return Model('chemostat4').discretize('erk', order=4).setup(dt=0.5)
+
+
+def test_compact_cost_setters_equal_the_long_form():
+    m = _model()
+    a, b = NMPC(m), NMPC(m)
+    a.set_quadratic_stage_cost(states=['X', 'S'], cost_states=[1., 2.], states_references=[5., 10.], inputs=['DS'],
+                               cost_inputs=[.1], inputs_references=[.2])
+    a.set_quadratic_terminal_cost(states=['X'], cost=[3.], references=[5.])
+    b.quad_stage_cost.add_states(names=['X', 'S'], weights=[1., 2.], ref=[5., 10.])
+    b.quad_stage_cost.add_inputs(names=['DS'], weights=[.1], ref=[.2])
+    b.quad_terminal_cost.add_states(names=['X'], weights=[3.], ref=[5.])
+    for ca, cb in ((a.quad_stage_cost, b.quad_stage_cost), (a.quad_terminal_cost, b.quad_terminal_cost)):
+        assert len(ca._terms) == len(cb._terms)
+        for (k1, i1, W1, r1), (k2, i2, W2, r2) in zip(ca._terms, cb._terms):
+            assert (k1, i1, r1) == (k2, i2, r2) and np.array_equal(W1, W2)
+    c = NMPC(m)
+    c.set_quadratic_stage_cost(states=['X'], cost_states=[1.])            # inputs left out: no input term, no error
+    assert [t[0] for t in c.quad_stage_cost._terms] == ['states']
+
+
+def test_compact_constraint_setters():
+    m = _model()
+    n = NMPC(m)
+    n.set_stage_constraints(m.x['X'] * m.x['S'], lb=[0.], ub=[60.], is_soft=True, weight=[[100.]])
+    sc = n.stage_constraint
+    assert sc.is_set and sc.size == 1 and sc.is_soft and sc.lb == [0.] and sc.ub == [60.] and sc.max_violation is None
+    assert np.array_equal(np.asarray(sc.weight), [[100.]])
+    n.set_terminal_constraints([m.x['X'] + m.x['P'], m.x['S']], lb=[-np.inf, 30.], ub=[1., np.inf])
+    tc = n.terminal_constraint
+    assert tc.is_set and tc.size == 2 and not tc.is_soft and tc.ub == [1., np.inf]
+    n.set_stage_constraints(None)
+    assert not n.stage_constraint.is_set
+    with pytest.raises(TypeError):
+        n.set_stage_constraints('X*S')                                      # strings are not expressions
+    with pytest.raises(TypeError):
+        n.stage_constraint.is_soft = 1
+
+
+def test_cost_argument_errors():
+    m = _model()
+    n = NMPC(m)
+    with pytest.raises(ValueError, match="does not exist"):
+        n.quad_stage_cost.add_states(names=['nope'], weights=[1.])
+    with pytest.raises(ValueError, match="weights"):
+        n.quad_stage_cost.add_states(names=['X'], weights=None)
+    with pytest.raises(ValueError, match="dimensions"):
+        n.quad_stage_cost.add_states(names=['X', 'S'], weights=[1., 1.], ref=[1.])
+    with pytest.raises(TypeError, match="same number of bounds"):       # optimizer.py:1318-1386 raises TypeError
+        n.set_box_constraints(x_ub=[1., 2.])
+    with pytest.raises(ValueError):
+        n.set_scaling(u_scaling=[1.])
+
+
+def test_expression_symbols_and_depth():
+    m = _model()
+    with pytest.raises(KeyError):
+        m.x['nope']
+    e = m.x['X']
+    for _ in range(9):
+        e = 1. + (e * e)                                                   # right-nested: needs a deeper stack
+    deep = m.x['S']
+    for _ in range(10):
+        deep = m.x['X'] + (m.x['S'] * deep)
+    with pytest.raises(ValueError, match="too deep"):
+        deep.program()
+    assert (m.x['X'] ** 2).program()[0] == 4.                               # [len | VARX 0 | SQ 0]
+    with pytest.raises(NotImplementedError):
+        m.x['X'] ** 2.5
+    with pytest.raises(ValueError, match="path variable"):
+        expr.Expr('theta', name='theta').program()

@@ -107,6 +107,43 @@ def test_hard_terminal_constraint_vs_slsqp():
     _slsqp(pb, ipm, res, 0, spec['p'])
 
 
+def test_free_initial_state_vs_slsqp():
+    """fix_x0=False (mpc.py:797-807): x_0 is a bounded variable; independent SLSQP solve of the same transcription."""
+    spec = dict(C2, N=5, x_lb=[1., 10., 0., 0.], x_ub=[8., 60., 5., 20.], x_guess=[4., 30., 1., 5.])
+    pb = oracle_gen(spec)
+    ipm = GenIpm(pb, free_x0=True)
+    res = ipm.solve(c2_x0(1), spec['p'])
+    assert res['status'][0] == 1 and res['kkt'][0] <= 1e-8
+    N, nx, nu = pb.N, pb.nx, pb.nu
+    p = np.atleast_2d(spec['p'])
+
+    def split(v):
+        return v[:(N + 1) * nx].reshape(N + 1, nx), v[(N + 1) * nx:].reshape(N, nu)
+
+    def obj(v):
+        X, U = split(v)
+        J = 0.
+        for k in range(N):
+            z = np.concatenate([X[k], U[k]]) - pb.zrefa[0] if pb.zrefa.ndim > 1 else np.concatenate([X[k], U[k]]) - pb.zrefa
+            J += float(z @ pb.Wza @ z)
+        d = X[N] - (pb.xrefNa[0] if pb.xrefNa.ndim > 1 else pb.xrefNa)
+        return J + float(d @ pb.WNa @ d)
+
+    def eq(v):
+        X, U = split(v)
+        return np.concatenate([X[k + 1] - pb.phia(X[k][None], U[k][None], p)[0] for k in range(N)])
+    v_ipm = ipm.to_v(res)[0]
+    lb = np.concatenate([np.tile(pb.x_lb, N + 1), np.tile(pb.u_lb, N)])
+    ub = np.concatenate([np.tile(pb.x_ub, N + 1), np.tile(pb.u_ub, N)])
+    w0 = np.clip(v_ipm + 1e-3 * np.random.default_rng(0).normal(size=v_ipm.size), lb, ub)
+    sol = minimize(obj, w0, method='SLSQP', bounds=list(zip(lb, ub)), constraints=[{'type': 'eq', 'fun': eq}],
+                   options={'ftol': 1e-12, 'maxiter': 800})
+    assert sol.success, sol.message
+    np.testing.assert_allclose(sol.fun, obj(v_ipm), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(sol.x, v_ipm, rtol=5e-4, atol=5e-4)
+    assert abs(v_ipm[0] - c2_x0(1)[0, 0] / pb.sx[0]) > 1e-2                  # not the measured state
+
+
 def test_path_following_with_soft_constraint_vs_slsqp():
     spec = dict(C5S, N=6, constraint=dict(C5S['constraint'], weight=[[10.]]))    # milder penalty: SLSQP-friendly scaling
     pb = oracle_gen(spec)
