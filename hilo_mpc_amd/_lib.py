@@ -37,7 +37,8 @@ class NmpcDesc(C.Structure):
                [(n, C.c_int32) for n in ('path_prog_len', 'n_con', 'con_soft', 'con_prog_len')] + \
                [(n, C.c_void_p) for n in ('con_prog', 'con_lb', 'con_ub', 'con_weight', 'con_max_violation')] + \
                [('n_tcon', C.c_int32), ('tcon_prog_len', C.c_int32), ('tcon_prog', C.c_void_p), ('tcon_lb', C.c_void_p),
-                ('tcon_ub', C.c_void_p)] + \
+                ('tcon_ub', C.c_void_p), ('tcon_soft', C.c_int32), ('reserved4', C.c_int32), ('tcon_weight', C.c_void_p),
+                ('tcon_max_violation', C.c_void_p)] + \
                [('collocation_degree', C.c_int32), ('reserved2', C.c_int32), ('coll_A', C.c_void_p), ('coll_D', C.c_void_p),
                 ('time_varying', C.c_int32), ('reserved3', C.c_int32)]
 

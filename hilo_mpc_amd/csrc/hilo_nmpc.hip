@@ -125,6 +125,9 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   const GenVariant* gv = nullptr;
   int nth = 0, ne = 0, nrow = 0, n_con_ref = 0;
   int row_expr[OCP_MAXNC], row_sign[OCP_MAXNC], row_e[OCP_MAXNC], row_ref[OCP_MAXNC];
+  int ntrow = 0, n_tcon_ref = 0, ne_stage = 0;   // terminal rows of the engine / of the reference's g; slacks of the stage constraint
+  int trow_expr[OCP_MAXNC], trow_sign[OCP_MAXNC], trow_e[OCP_MAXNC], trow_ref[OCP_MAXNC];
+  double trow_lb[OCP_MAXNC], trow_ub[OCP_MAXNC];
   double row_lb[OCP_MAXNC], row_ub[OCP_MAXNC];
   if (general) {
     if (d->learned) return fail(HILO_ENOTSUP, "a learned term together with path following / stage constraints is not built");
@@ -154,14 +157,36 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
         }
       }
     }
+    ne_stage = ne;
     if (d->n_tcon > 0) {
       HILO_REQUIRE(d->tcon_prog && d->tcon_prog_len > 0, "hilo_nmpc_create: n_tcon > 0 but no terminal constraint program");
-      HILO_REQUIRE(nrow + d->n_tcon <= OCP_MAXNC, "too many constraint rows");
+      if (d->tcon_soft) {
+        if (ne_stage > 0 || d->n_tcon != 1)
+          return fail(HILO_ENOTSUP, "one shared slack in this build: a soft terminal constraint needs n_tcon = 1 and a hard (or "
+                                    "no) stage constraint");
+        ne += d->n_tcon;
+      }
+      n_tcon_ref = d->tcon_soft ? 2 * d->n_tcon : d->n_tcon;   // mpc.py:1687-1690 / :1696-1698
+      for (int j = 0; j < d->n_tcon; ++j) {
+        const double lb = d->tcon_lb ? d->tcon_lb[j] : -INFINITY, ub = d->tcon_ub ? d->tcon_ub[j] : INFINITY;
+        HILO_REQUIRE(lb <= ub, "hilo_nmpc_create: terminal constraint %d has lb > ub", j);
+        auto add = [&](int sign, int e, double rlb, double rub, int ref) {
+          trow_expr[ntrow] = j; trow_sign[ntrow] = sign; trow_e[ntrow] = e; trow_lb[ntrow] = rlb; trow_ub[ntrow] = rub;
+          trow_ref[ntrow++] = ref;
+        };
+        HILO_REQUIRE(nrow + ntrow + (d->tcon_soft ? (ub < INFINITY) + (lb > -INFINITY) : 1) <= OCP_MAXNC, "too many constraint rows");
+        if (d->tcon_soft) {   // same row pair as the soft stage constraint; the slack index counts after the stage slacks
+          if (ub < INFINITY) add(1, ne_stage + j, -INFINITY, ub, j);
+          if (lb > -INFINITY) add(-1, ne_stage + j, -INFINITY, -lb, d->n_tcon + j);
+        } else {
+          add(1, -1, lb, ub, j);
+        }
+      }
     }
-    gv = nmpc_gen_find(d->model_id, nth, ne, nrow + d->n_tcon, d->N);
+    gv = nmpc_gen_find(d->model_id, nth, ne, nrow + ntrow, d->N);
     if (!gv)
       return fail(HILO_ENOTSUP, "no device instantiation for model %d with %d path variable(s), %d shared slack(s) and %d "
-                                "inequality row(s) per stage at horizon %d in this build", d->model_id, nth, ne, nrow + d->n_tcon, d->N);
+                                "inequality row(s) per stage at horizon %d in this build", d->model_id, nth, ne, nrow + ntrow, d->N);
     lds = gv->lds_bytes(d->N);
   }
   const CollVariant* cv = nullptr;
@@ -204,7 +229,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   h->n_vc = (d->N + 1) * nx + d->N * nu;
   const int dn = cv ? cv->degree * nx : 0;
   h->n_v = (d->N + 1) * nxv + d->N * nue + ne + d->N * dn;   // mpc.py:1440-1443 (+ the soft-constraint slack, :1529-1537)
-  h->n_g = d->N * (nxv + n_con_ref + dn) + (general ? d->n_tcon : 0);   // mpc.py:1657-1669, :1693-1725
+  h->n_g = d->N * (nxv + n_con_ref + dn) + (general ? n_tcon_ref : 0);   // mpc.py:1657-1669, :1684-1725
   h->lds_bytes = lds;
   OcpConst& c = h->host;
   memset(&c, 0, sizeof(c));
@@ -256,9 +281,13 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
       c.cost[gv->o_wz + iu * nz + iu] = d->u_pf_weight;
       c.cost[gv->o_zref + iu] = d->u_pf_ref;
     }
-    for (int a = 0; a < ne; ++a)    // e^T W e once per stage (mpc.py:1708), W = 1e4 I by default (modeling.py:875)
-      for (int b = 0; b < ne; ++b)
-        c.cost[gv->o_wz + (nx + nth + a) * nz + (nx + nth + b)] = d->con_weight ? d->con_weight[a * ne + b] : (a == b ? 1e4 : 0.0);
+    for (int a = 0; a < ne_stage; ++a)    // e^T W e once per stage (mpc.py:1708), W = 1e4 I by default (modeling.py:875)
+      for (int b = 0; b < ne_stage; ++b)
+        c.cost[gv->o_wz + (nx + nth + a) * nz + (nx + nth + b)] = d->con_weight ? d->con_weight[a * ne_stage + b] : (a == b ? 1e4 : 0.0);
+    for (int a = ne_stage; a < ne; ++a)   // e_T^T W e_T once (mpc.py:1686): a terminal weight on the constant state e_T
+      for (int b = ne_stage; b < ne; ++b)
+        c.cost[gv->o_wn + (nx + nth + a) * nxe + (nx + nth + b)] =
+            d->tcon_weight ? d->tcon_weight[(a - ne_stage) * d->n_tcon + (b - ne_stage)] : (a == b ? 1e4 : 0.0);
     int rcode = HILO_OK;
     const char* why = "";
     int plen = 0;
@@ -302,18 +331,20 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     c.cost[gv->o_nexpr] = d->n_con;
     c.cost[gv->o_ntexpr] = d->n_tcon;
     c.nc = nrow;
-    c.nc_term = d->n_tcon;
+    c.nc_term = ntrow;
     c.n_con_ref = n_con_ref;
+    c.n_tcon_ref = n_tcon_ref;
+    c.cost[gv->o_tsoft] = d->tcon_soft ? 1.0 : 0.0;
     for (int m = 0; m < OCP_MAXNC; ++m) { c.dlb[m] = -INFINITY; c.dub[m] = INFINITY; }
     for (int m = 0; m < nrow; ++m) {
       c.cost[gv->o_rowx + m] = row_expr[m]; c.cost[gv->o_rows + m] = row_sign[m]; c.cost[gv->o_rowe + m] = row_e[m];
       c.dlb[m] = relaxed_lb(row_lb[m]); c.dub[m] = relaxed_ub(row_ub[m]);   // IPOPT relaxes constraint bounds alike
-      c.row_ref[m] = row_ref[m];
+      c.row_ref[m] = (short)row_ref[m];
     }
-    for (int j = 0; j < d->n_tcon; ++j) {
-      const double lb = d->tcon_lb ? d->tcon_lb[j] : -INFINITY, ub = d->tcon_ub ? d->tcon_ub[j] : INFINITY;
-      if (!(lb <= ub)) { delete h; return fail(HILO_EINVAL, "hilo_nmpc_create: terminal constraint %d has lb > ub", j); }
-      c.dlb[nrow + j] = relaxed_lb(lb); c.dub[nrow + j] = relaxed_ub(ub);
+    for (int r = 0; r < ntrow; ++r) {
+      c.cost[gv->o_trowx + r] = trow_expr[r]; c.cost[gv->o_trows + r] = trow_sign[r]; c.cost[gv->o_trowe + r] = trow_e[r];
+      c.dlb[nrow + r] = relaxed_lb(trow_lb[r]); c.dub[nrow + r] = relaxed_ub(trow_ub[r]);
+      c.trow_ref[r] = (short)trow_ref[r];
     }
     for (int i = nx; i < nxe; ++i) c.x0_free_mask |= 1u << i;               // theta_0 and e are variables (mpc.py:785-789)
     for (int a = 0; a < ne; ++a) c.k0_only_mask |= 1u << (nx + nth + a);    // one box on the shared slack
@@ -323,7 +354,12 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     double lb = -INFINITY, ub = INFINITY;
     if (i < nx) { if (d->x_lb) lb = d->x_lb[i] / c.sz[i]; if (d->x_ub) ub = d->x_ub[i] / c.sz[i]; }
     else if (i < nx + nth) { lb = d->theta_lb; ub = d->theta_ub; }                                  // mpc.py:1198-1199
-    else if (i < nxe) { lb = 0.0; ub = d->con_max_violation ? d->con_max_violation[i - nx - nth] : INFINITY; }  // :1533-1534
+    else if (i < nxe) {                                                                             // :1533-1534, :1544-1545
+      const int a = i - nx - nth;
+      lb = 0.0;
+      ub = a < ne_stage ? (d->con_max_violation ? d->con_max_violation[a] : INFINITY)
+                        : (d->tcon_max_violation ? d->tcon_max_violation[a - ne_stage] : INFINITY);
+    }
     else if (i < nxe + nu) { const int j = i - nxe; if (d->u_lb) lb = d->u_lb[j] / c.sz[i]; if (d->u_ub) ub = d->u_ub[j] / c.sz[i]; }
     else { lb = d->u_pf_lb; ub = d->u_pf_ub; }                                                      // mpc.py:1196-1197
     lb = relaxed_lb(lb); ub = relaxed_ub(ub);

@@ -35,7 +35,8 @@ struct NmpcGen {
                        O_NPS = O_HASDU + 1, O_NPT = O_NPS + 1, O_IDXS = O_NPT + 1, O_WS = O_IDXS + GEN_NPT,
                        O_IDXT = O_WS + GEN_NPT * GEN_NPT, O_WT = O_IDXT + GEN_NPT,
                        O_NEXPR = O_WT + GEN_NPT * GEN_NPT, O_NTEXPR = O_NEXPR + 1, O_ROWX = O_NTEXPR + 1, O_ROWS = O_ROWX + OCP_MAXNC,
-                       O_ROWE = O_ROWS + OCP_MAXNC, O_PROG = O_ROWE + OCP_MAXNC;
+                       O_ROWE = O_ROWS + OCP_MAXNC, O_TSOFT = O_ROWE + OCP_MAXNC, O_TROWX = O_TSOFT + 1,
+                       O_TROWS = O_TROWX + OCP_MAXNC, O_TROWE = O_TROWS + OCP_MAXNC, O_PROG = O_TROWE + OCP_MAXNC;
   static_assert(O_PROG + 64 <= OCP_NCOST, "cost block too small");
   static constexpr int NCOST = OCP_NCOST;  // expression programs have run-time length: the whole block
 
@@ -155,7 +156,8 @@ struct NmpcGen {
   }
 
   // inequality rows d_m = sign_m c_{expr_m}(x sx, u su) - e_{slack_m}  (mpc.py:1276-1277; modeling.py:843-849); at the last
-  // stage additionally the hard terminal rows c_T(x_end sx) on the integrated end state xn (mpc.py:1693-1700)
+  // stage additionally the terminal rows: hard, c_T(x_end sx) on the integrated end state xn (mpc.py:1693-1700), or soft,
+  // sign c_T(x_{N-1} sx) - e_T on the state the last interval starts from (mpc.py:1684-1692)
   template <class T>
   __device__ __forceinline__ static void con(const OcpConst& pc, const double* par, const double*, int k, const T* x,
                                              const T* u, const T* xn, T* d) {
@@ -187,17 +189,28 @@ struct NmpcGen {
     }
     const int nte = (int)pc.cost[O_NTEXPR];
     if (nte > 0 && k == pc.N - 1) {
-      T xe[MX];
+      const bool soft = pc.cost[O_TSOFT] != 0.0;
+      T xe[MX], ct[GEN_NEXPR];
 #pragma unroll
-      for (int i = 0; i < MX; ++i) xe[i] = xn[i] * pc.sz[i];
+      for (int i = 0; i < MX; ++i) xe[i] = soft ? xs[i] : xn[i] * pc.sz[i];
 #pragma unroll
       for (int j = 0; j < GEN_NEXPR; ++j) {
+        ct[j] = T(0.0);
         if (j < nte) {
-          const T v = expr_eval<MX, MU>(prog, xe, us, par);
+          ct[j] = expr_eval<MX, MU>(prog, xe, us, par);
           prog += 1 + (int)prog[0];
+        }
+      }
 #pragma unroll
-          for (int m = 0; m < (NC > 0 ? NC : 1); ++m)
-            if (m < NC && m == pc.nc + j) d[m] = v;
+      for (int m = 0; m < (NC > 0 ? NC : 1); ++m) {
+        const int r = m - pc.nc;   // terminal row index
+        if (m < NC && r >= 0 && r < pc.nc_term) {
+          T v = pc.cost[O_TROWS + r] * pick<GEN_NEXPR>(ct, (int)pc.cost[O_TROWX + r]);
+          if constexpr (NE > 0) {
+            const int ei = (int)pc.cost[O_TROWE + r];
+            if (ei >= 0) v = v - pick<NE>(x + MX + NTH, ei);
+          }
+          d[m] = v;
         }
       }
     }
@@ -224,7 +237,7 @@ struct GenVariant {
   int model_id, nth, ne, nc, big;            // key
   int nx, nu, nxv, mx, mu, np;               // engine / reference dimensions
   int o_wz, o_zref, o_wn, o_xrefn, o_wdu, o_hasdu, o_nps, o_npt, o_idxs, o_ws, o_idxt, o_wt, o_nexpr, o_rowx, o_rows,
-      o_rowe, o_prog, o_ntexpr;
+      o_rowe, o_prog, o_ntexpr, o_tsoft, o_trowx, o_trows, o_trowe;
   size_t (*lds_bytes)(int N);
   size_t (*ws_bytes)(int N);
   int (*launch)(const GenLaunchArgs& a);
@@ -282,6 +295,7 @@ GenVariant gen_variant(int model_id) {
   return GenVariant{model_id, NTH, NE, NC, BIG ? 1 : 0, PB::NX, PB::NU, PB::NXV, PB::MX, PB::MU, M::NP,
                     PB::O_WZ, PB::O_ZREF, PB::O_WN, PB::O_XREFN, PB::O_WDU, PB::O_HASDU, PB::O_NPS, PB::O_NPT, PB::O_IDXS,
                     PB::O_WS, PB::O_IDXT, PB::O_WT, PB::O_NEXPR, PB::O_ROWX, PB::O_ROWS, PB::O_ROWE, PB::O_PROG, PB::O_NTEXPR,
+                    PB::O_TSOFT, PB::O_TROWX, PB::O_TROWS, PB::O_TROWE,
                     &gen_lds<PB>, &gen_ws<PB>, &gen_launch<PB>};
 }
 

@@ -58,8 +58,8 @@ struct OcpConst {
   int nc, nc_term;         // inequality rows of every stage; further rows that only exist at the last stage N-1 (terminal
                            // constraint on the integrated end state, mpc.py:1693-1700); nc + nc_term <= PB::NC
   double dlb[OCP_MAXNC], dub[OCP_MAXNC];  // their (relaxed) bounds; +-inf if none
-  int n_con_ref, row_ref[OCP_MAXNC];      // rows per stage in the reference's g and where each active row sits there
-  int pad2_;
+  int n_con_ref, n_tcon_ref;              // rows per stage / terminal rows in the reference's g ...
+  short row_ref[OCP_MAXNC], trow_ref[OCP_MAXNC];   // ... and where each active stage / terminal row sits there
   CollData coll;                          // collocation basis when the shooting map is the implicit one (hilo_colloc.h)
   // policy-defined cost data (weights, references, expression programs).  LAST member: an instance copies only the
   // PB::NCOST doubles its policy uses into LDS (40 KB per instance is the budget for four instances per CU)
@@ -1337,7 +1337,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
   if (lam_g) {
     // the reference's g: per stage [shooting defect (NXV rows) | constraint rows (n_con_ref)] (mpc.py:1667, :1707-1725)
     // the last stage carries the terminal rows between its defect and its stage rows (mpc.py:1693-1700 before :1707)
-    const int ncr = NC > 0 ? pc.n_con_ref : 0, ntr = NC > 0 ? pc.nc_term : 0, rows = NXV + ncr;
+    const int ncr = NC > 0 ? pc.n_con_ref : 0, ntr = NC > 0 ? pc.n_tcon_ref : 0, rows = NXV + ncr;
     double* lg = lam_g + b * (int64_t)(N * rows + ntr);
     for (int e = t; e < N * NXV; e += T) {
       const int k = e / NXV, i = e - k * NXV;
@@ -1352,11 +1352,12 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
         const int k = e / ncr;
         lg[k * rows + NXV + (k == N - 1 ? ntr : 0) + e % ncr] = 0.0;
       }
+      for (int e = t; e < ntr; e += T) lg[(N - 1) * rows + NXV + e] = 0.0;
       __syncthreads();
       for (int e = t; e < N * NC; e += T) {
         const int k = e / NC, m = e - k * NC;
         if (m < pc.nc) lg[k * rows + NXV + (k == N - 1 ? ntr : 0) + pc.row_ref[m]] = l.cnu[e];
-        else if (k == N - 1 && m < pc.nc + ntr) lg[k * rows + NXV + (m - pc.nc)] = l.cnu[e];
+        else if (k == N - 1 && m < pc.nc + pc.nc_term) lg[k * rows + NXV + pc.trow_ref[m - pc.nc]] = l.cnu[e];
       }
     }
   }

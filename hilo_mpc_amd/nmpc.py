@@ -536,10 +536,8 @@ class NMPC:
         # ---- nonlinear stage constraint (modeling.py:820-1005) ----
         tc = self.terminal_constraint
         if tc.is_set:
-            # hard: lb <= c_T(x_end) <= ub on the integrated end state (mpc.py:1693-1700)
-            if tc.is_soft:
-                raise NotImplementedError("soft terminal constraints are not offloaded (the reference evaluates them at "
-                                          "x_{N-1} with a second slack vector, mpc.py:1684-1692)")
+            # hard: lb <= c_T(x_end) <= ub on the integrated end state (mpc.py:1693-1700); soft: on x_{N-1} with the slack
+            # e_soft_term behind the stage slack in v (mpc.py:1540-1548, :1684-1692)
             for e in tc.constraint:
                 if e.depends_on('theta') or e.depends_on('u'):
                     raise ValueError("The terminal constraint is a function of the states (and parameters) only")
@@ -551,6 +549,10 @@ class NMPC:
             prog = compile_block(tc.constraint)
             d.n_tcon, d.tcon_prog, d.tcon_prog_len = nt, hp(prog), len(prog)
             d.tcon_lb, d.tcon_ub = hp(tlb), hp(tub)
+            if tc.is_soft:
+                d.tcon_soft = 1
+                d.tcon_weight = hp(_weight_matrix(tc.weight, nt, 'weight')) if tc.weight is not None else None
+                d.tcon_max_violation = hp(tc.max_violation) if tc.max_violation is not None else None
         sc = self.stage_constraint
         ne = 0
         if sc.is_set:
@@ -570,7 +572,8 @@ class NMPC:
                 ne = nc
                 d.con_weight = hp(_weight_matrix(sc.weight, nc, 'weight')) if sc.weight is not None else None
                 d.con_max_violation = hp(sc.max_violation) if sc.max_violation is not None else None
-        self._nth, self._ne = nth, ne
+        ne_term = tc.size if tc.is_set and tc.is_soft else 0
+        self._nth, self._ne, self._ne_term = nth, ne, ne_term
         self._tv = bool(self._time_varying_parameters or self.quad_stage_cost._trajectories or
                         self.quad_terminal_cost._trajectories)
         d.time_varying = int(self._tv)
@@ -593,8 +596,10 @@ class NMPC:
         self._x_ind = [list(range(k * nxa, (k + 1) * nxa)) for k in range(N + 1)]
         self._u_ind = [list(range((N + 1) * nxa + k * nua, (N + 1) * nxa + (k + 1) * nua)) for k in range(N)]
         self._e_soft_stage_ind = list(range((N + 1) * nxa + N * nua, (N + 1) * nxa + N * nua + ne))
-        dn = coll['d'] * nx if coll is not None else 0
         off = (N + 1) * nxa + N * nua + ne
+        self._e_soft_term_ind = list(range(off, off + ne_term))                                           # mpc.py:1542-1543
+        dn = coll['d'] * nx if coll is not None else 0
+        off += ne_term
         self._ip_ind = [list(range(off + k * dn, off + (k + 1) * dn)) for k in range(N)] if dn else []   # mpc.py:1501-1509
         self._sx, self._su = sx, su
         self._nlp_setup_done = True
@@ -695,6 +700,8 @@ class NMPC:
             self._u_prev = v_opt[:, self._u_ind[0][:self._n_u]].contiguous()
         if self._ne:
             self.stage_constraint.e_soft_value = v_opt[:, self._e_soft_stage_ind]        # mpc.py:833-834
+        if self._ne_term:
+            self.terminal_constraint.e_soft_value = v_opt[:, self._e_soft_term_ind]      # mpc.py:840-841
         if self._stats:
             torch.cuda.synchronize(dev)
             self._extime = time.time() - t0

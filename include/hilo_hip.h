@@ -226,12 +226,18 @@ typedef struct hilo_nmpc_desc {
   const double* con_lb; const double* con_ub;      /* [n_con]; -inf / +inf allowed */
   const double* con_weight;              /* [n_con][n_con] or NULL -> 1e4 I (modeling.py:875) */
   const double* con_max_violation;       /* [n_con] or NULL -> inf */
-  /* hard terminal constraint lb <= c_T(x_end) <= ub on the integrated end state Phi(x_{N-1}, u_{N-1}) (mpc.py:1693-1700;
+  /* terminal constraint; hard: lb <= c_T(x_end) <= ub on the integrated end state Phi(x_{N-1}, u_{N-1}) (mpc.py:1693-1700;
      `nmpc.terminal_constraint`), un-scaled states; its rows sit between the last defect and the last stage rows in g */
   int32_t n_tcon;                        /* expressions, n_con + n_tcon rows <= 4 in this build */
   int32_t tcon_prog_len;
   const double* tcon_prog;
   const double* tcon_lb; const double* tcon_ub;
+  /* soft terminal constraint (mpc.py:1684-1692): c_T(x_{N-1}) - e_T <= ub, -c_T(x_{N-1}) - e_T <= -lb on the state the last
+     interval starts from, one slack e_T in [0, max_violation] after the stage slack in v (mpc.py:1540-1548), e_T^T W e_T once
+     in the objective.  One shared slack in total in this build: n_tcon = 1 and the stage constraint hard or absent. */
+  int32_t tcon_soft; int32_t reserved4;
+  const double* tcon_weight;             /* [n_tcon][n_tcon] or NULL -> 1e4 I */
+  const double* tcon_max_violation;      /* [n_tcon] or NULL -> inf */
   /* ---- integration_method = 'collocation' on the CONTINUOUS model (the reference's default, optimizer.py:1410-1418;
      hilo_mpc/util/modeling.py:1091-1211, mpc.py:1307-1372): degree d Lagrange basis at Radau / Legendre points.  The caller
      passes the basis it built (modeling.py:1091-1127): coll_A = (C[1:,1:]^T)^-1 (d x d, the method's Runge-Kutta matrix)

@@ -123,15 +123,38 @@ class GenNmpcProblem(NmpcProblem):
         self._dj = _lam([[sp.diff(r, a) for a in ze] for r in rows], args) if rows else None
         self._dh = _lam([[[sp.diff(r, a, b) for b in zs] for a in zs] for r in rows], args) if rows else None
         # ---- hard terminal constraint on the integrated end state Phi(x_{N-1}, u_{N-1}) (mpc.py:1693-1700), un-scaled ----
-        self.nt = 0
+        # soft (mpc.py:1684-1692, :1540-1548): rows  c_T(x_{N-1}) - e_T <= ub,  -c_T(x_{N-1}) - e_T <= -lb  on the state the
+        # last interval STARTS from, slack e_T in [0, max_violation] behind the stage slack in v, e_T^T W e_T once in J.
+        # Terminal row r of the solver: tsign[r] * c_T[texpr[r]](xe) - e_T[texpr[r]] (soft)  in [tlb[r], tub[r]].
+        self.nt = self.ne_t = self.n_tcon_ref = 0
+        self.t_soft = False
         if terminal_constraint:
-            if terminal_constraint.get('soft'):
-                raise NotImplementedError("soft terminal constraints")
             xsym = [sp.Symbol(f'xe_{i}') for i in range(nx)]
             ct = [_parse(e, names).subs(dict(zip(model.x, xsym)), simultaneous=True) for e in terminal_constraint['expr']]
-            self.nt = len(ct)
-            self.tlb = np.broadcast_to(np.asarray(terminal_constraint.get('lb', -INF), dtype=float), (self.nt,)).copy()
-            self.tub = np.broadcast_to(np.asarray(terminal_constraint.get('ub', INF), dtype=float), (self.nt,)).copy()
+            nct = len(ct)
+            lbt = np.broadcast_to(np.asarray(terminal_constraint.get('lb', -INF), dtype=float), (nct,))
+            ubt = np.broadcast_to(np.asarray(terminal_constraint.get('ub', INF), dtype=float), (nct,))
+            self.t_soft = bool(terminal_constraint.get('soft'))
+            self.texpr, self.tsign, self.trow_ref, tlb, tub = [], [], [], [], []
+            if self.t_soft:
+                self.ne_t = nct
+                W = terminal_constraint.get('weight')
+                self.WeT = np.diag(np.ones(nct) * 1e4) if W is None else _wmat(W, nct)    # modeling.py:875
+                self.eT_ub = np.broadcast_to(np.asarray(terminal_constraint.get('max_violation', INF), dtype=float), (nct,))
+                for j in range(nct):
+                    for r, (sg, b) in enumerate(((1., ubt[j]), (-1., -lbt[j]))):
+                        if np.isfinite(b):
+                            self.texpr.append(j), self.tsign.append(sg), tlb.append(-INF), tub.append(b)
+                            self.trow_ref.append(r * nct + j)
+                self.n_tcon_ref = 2 * nct
+            else:
+                for j in range(nct):
+                    self.texpr.append(j), self.tsign.append(1.), tlb.append(lbt[j]), tub.append(ubt[j])
+                    self.trow_ref.append(j)
+                self.n_tcon_ref = nct
+            self.nt = len(self.texpr)
+            self.tsign = np.array(self.tsign)
+            self.tlb, self.tub = np.array(tlb, dtype=float), np.array(tub, dtype=float)
             ax = [xsym]
             self._ct = _lam(ct, ax)
             self._ctj = _lam([[sp.diff(c, a) for a in xsym] for c in ct], ax)
@@ -148,8 +171,9 @@ class GenNmpcProblem(NmpcProblem):
             self.u_ind.append(list(range(off, off + nua)))
             off += nua
         self.e_ind = list(range(off, off + self.ne))
-        self.n_v = off + self.ne
-        self.n_g = N * (nxa + self.n_con_ref) + self.nt
+        self.eT_ind = list(range(off + self.ne, off + self.ne + self.ne_t))
+        self.n_v = off + self.ne + self.ne_t
+        self.n_g = N * (nxa + self.n_con_ref) + self.n_tcon_ref
 
     @staticmethod
     def _vgh(expr, syms):
@@ -198,14 +222,16 @@ class GenIpm(DenseIpm):
         self.o_x = self.n0 + nth
         self.o_u = self.o_x + N * nxa
         self.o_e = self.o_u + N * nua
-        self.o_s = self.o_e + ne
+        self.o_eT = self.o_e + ne                            # slack of the soft terminal constraint
+        self.o_s = self.o_eT + pb.ne_t
         self.o_t = self.o_s + N * nrow                       # slacks of the terminal rows
         self.nw = self.o_t + pb.nt
         self.m = N * nxa + N * nrow + pb.nt
-        lb = np.concatenate([pb.x_lb[pb.nx - self.n0:], np.tile(pb.x_lb, N), np.tile(pb.u_lb, N), np.zeros(ne), np.tile(pb.dlb, N),
+        lb = np.concatenate([pb.x_lb[pb.nx - self.n0:], np.tile(pb.x_lb, N), np.tile(pb.u_lb, N), np.zeros(ne + pb.ne_t), np.tile(pb.dlb, N),
                              pb.tlb if pb.nt else np.zeros(0)])
         ub = np.concatenate([pb.x_ub[pb.nx - self.n0:], np.tile(pb.x_ub, N), np.tile(pb.u_ub, N),
-                             pb.e_ub if ne else np.zeros(0), np.tile(pb.dub, N), pb.tub if pb.nt else np.zeros(0)])
+                             pb.e_ub if ne else np.zeros(0), pb.eT_ub if pb.ne_t else np.zeros(0), np.tile(pb.dub, N),
+                             pb.tub if pb.nt else np.zeros(0)])
         r = o.bound_relax_factor
         self.lb = np.where(np.isfinite(lb), lb - r * np.maximum(1, np.abs(lb)), lb)
         self.ub = np.where(np.isfinite(ub), ub + r * np.maximum(1, np.abs(ub)), ub)
@@ -232,7 +258,7 @@ class GenIpm(DenseIpm):
         X[:, 0, pb.nx:] = w[:, self.n0:self.n0 + pb.nth]
         X[:, 1:] = w[:, self.o_x:self.o_u].reshape(B, N, nxa)
         U = w[:, self.o_u:self.o_e].reshape(B, N, nua)
-        E = w[:, self.o_e:self.o_s]
+        E = w[:, self.o_e:self.o_eT]
         S = w[:, self.o_s:self.o_t].reshape(B, N, pb.nrow)
         return X, U, E, S
 
@@ -260,9 +286,20 @@ class GenIpm(DenseIpm):
         f += np.einsum('bi,ij,bj->b', d, pb.WNa, d) + pb._Vp[0](X[:, N])
         call = np.concatenate([c, cd], axis=2).reshape(B, -1)
         if pb.nt:
-            xe = pb.phia(X[:, N - 1], U[:, N - 1], p)[:, :pb.nx] * pb.sx
-            call = np.concatenate([call, pb._ct(xe) - w[:, self.o_t:]], axis=1)
+            call = np.concatenate([call, self._term_rows(w, X, U, p) - w[:, self.o_t:]], axis=1)
+        if pb.ne_t:
+            ET = w[:, self.o_eT:self.o_s]
+            f += np.einsum('bi,ij,bj->b', ET, pb.WeT, ET)                      # mpc.py:1686: once
         return f, call
+
+    def _term_rows(self, w, X, U, p):
+        """Values of the terminal rows (without their slacks s_T)."""
+        pb = self.pb
+        if pb.t_soft:
+            xe = X[:, pb.N - 1, :pb.nx] * pb.sx
+            return pb.tsign * pb._ct(xe)[:, pb.texpr] - w[:, self.o_eT:self.o_s][:, pb.texpr]
+        xe = pb.phia(X[:, pb.N - 1], U[:, pb.N - 1], p)[:, :pb.nx] * pb.sx
+        return pb._ct(xe)[:, pb.texpr]
 
     def eval_all(self, w, lam, data):
         """Constraint order: per stage [defect (nxa) | d - s (nrow)]."""
@@ -280,7 +317,7 @@ class GenIpm(DenseIpm):
         lam_t = lam[:, N * mk:]
         lam = lam[:, :N * mk].reshape(B, N, mk)
         bi = np.arange(B)
-        ecols = list(range(self.o_e, self.o_s))
+        ecols = list(range(self.o_e, self.o_eT))
         for k in range(N):
             cols = self.zcols(k)
             sel = [i for i, cidx in enumerate(cols) if cidx >= 0]
@@ -316,7 +353,25 @@ class GenIpm(DenseIpm):
                 f += np.einsum('bi,ij,bj->b', d, pb.Wdu, d)
                 gz[:, nxa:nxa + pb.nu] += 2 * d @ pb.Wdu
                 Hz[:, nxa:nxa + pb.nu, nxa:nxa + pb.nu] += 2 * pb.Wdu
-            if pb.nt and k == N - 1:      # c_T(Phi(z) sx) - s_T: chain rule through the shooting map
+            if pb.nt and k == N - 1 and pb.t_soft:      # sign c_T(x_{N-1} sx) - e_T - s_T
+                nx = pb.nx
+                xe = X[:, k, :nx] * pb.sx
+                cv, cj, ch = pb._ct(xe), pb._ctj(xe), pb._cth(xe)
+                sg = pb.tsign
+                ET = w[:, self.o_eT:self.o_s]
+                ct_rows = list(range(N * mk, N * mk + pb.nt))
+                c_term = sg * cv[:, pb.texpr] - ET[:, pb.texpr] - w[:, self.o_t:]
+                Jz = np.zeros((B, pb.nt, nza))
+                Jz[:, :, :nx] = sg[None, :, None] * cj[:, pb.texpr] * pb.sx[None, None, :]
+                J[np.ix_(bi, ct_rows, zi)] = Jz[:, :, sel]
+                J[:, ct_rows, [self.o_eT + j for j in pb.texpr]] = -1.0
+                J[:, ct_rows, [self.o_t + r for r in range(pb.nt)]] = -1.0
+                Hz[:, :nx, :nx] += np.einsum('bm,bmac->bac', lam_t * sg, ch[:, pb.texpr]) * np.outer(pb.sx, pb.sx)[None]
+                tcols = list(range(self.o_eT, self.o_s))
+                f += np.einsum('bi,ij,bj->b', ET, pb.WeT, ET)
+                g[:, tcols] += 2 * ET @ pb.WeT
+                W[np.ix_(bi, tcols, tcols)] += 2 * pb.WeT
+            elif pb.nt and k == N - 1:      # c_T(Phi(z) sx) - s_T: chain rule through the shooting map
                 nx = pb.nx
                 xe = Phi[:, :nx] * pb.sx
                 cv, cj, ch = pb._ct(xe), pb._ctj(xe), pb._cth(xe)
@@ -350,7 +405,7 @@ class GenIpm(DenseIpm):
         if u_old is not None:
             data['u_old'] = np.broadcast_to(np.atleast_2d(np.asarray(u_old, dtype=float)), (B, pb.nu))
         if w0 is None:
-            w0 = np.concatenate([pb.x_guess[pb.nx - self.n0:], np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N), np.zeros(pb.ne)])
+            w0 = np.concatenate([pb.x_guess[pb.nx - self.n0:], np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N), np.zeros(pb.ne + pb.ne_t)])
         w0 = np.broadcast_to(np.atleast_2d(w0)[:, :self.o_s], (B, self.o_s))
         w0 = _push_interior(w0, self.lb[:self.o_s], self.ub[:self.o_s], o)
         if pb.nrow or pb.nt:
@@ -359,8 +414,8 @@ class GenIpm(DenseIpm):
                 s0 = np.stack([pb._d(np.concatenate([X[:, k], U[:, k]], axis=1), E) for k in range(pb.N)], axis=1)
                 w0 = np.concatenate([w0, s0.reshape(B, -1)], axis=1)
             if pb.nt:
-                xe = pb.phia(X[:, pb.N - 1], U[:, pb.N - 1], p)[:, :pb.nx] * pb.sx
-                w0 = np.concatenate([w0, pb._ct(xe)], axis=1)
+                wz = np.concatenate([w0, np.zeros((B, self.nw - w0.shape[1]))], axis=1)
+                w0 = np.concatenate([w0, self._term_rows(wz, X, U, p)], axis=1)
         res = self.solve_data(data, w0, verbose)
         X, U, E, S = self._unpack(res['w'], x0)
         res.update(X=X, U=U, E=E, S=S, u0=U[:, 0, :pb.nu] * pb.su, x0=x0)
@@ -369,7 +424,7 @@ class GenIpm(DenseIpm):
     # reference layouts -------------------------------------------------------------------------------------------
     def to_v(self, res):
         B = res['X'].shape[0]
-        return np.concatenate([res['X'].reshape(B, -1), res['U'].reshape(B, -1), res['E']], axis=1)
+        return np.concatenate([res['X'].reshape(B, -1), res['U'].reshape(B, -1), res['E'], res['w'][:, self.o_eT:self.o_s]], axis=1)
 
     def w_from_v(self, v):
         """[theta_0 | xa_1.. | ua | e] from the reference's decision vector."""
@@ -394,4 +449,6 @@ class GenIpm(DenseIpm):
         # last stage: [defect | terminal rows | stage rows] (mpc.py:1693-1700 before :1707)
         head = out[:, :-1].reshape(B, -1)
         last = out[:, -1]
-        return np.concatenate([head, last[:, :pb.nxa], res['lam'][:, pb.N * mk:], last[:, pb.nxa:]], axis=1)
+        lt = np.zeros((B, pb.n_tcon_ref))                                   # dropped (unbounded) rows: zero multiplier
+        lt[:, pb.trow_ref] = res['lam'][:, pb.N * mk:]
+        return np.concatenate([head, last[:, :pb.nxa], lt, last[:, pb.nxa:]], axis=1)

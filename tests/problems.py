@@ -203,6 +203,11 @@ def product_gen(spec, **solver_options):
         tc = spec['terminal_constraint']
         nmpc.terminal_constraint.constraint = [eval(e, dict(ns)) for e in tc['expr']]
         nmpc.terminal_constraint.lb, nmpc.terminal_constraint.ub = list(tc['lb']), list(tc['ub'])
+        nmpc.terminal_constraint.is_soft = bool(tc.get('soft', False))
+        if tc.get('weight') is not None:
+            nmpc.terminal_constraint.weight = tc['weight']
+        if tc.get('max_violation') is not None:
+            nmpc.terminal_constraint.max_violation = tc['max_violation']
     nmpc.horizon = spec['N']
     nmpc.set_box_constraints(x_ub=spec.get('x_ub'), x_lb=spec.get('x_lb'), u_ub=spec.get('u_ub'), u_lb=spec.get('u_lb'))
     nmpc.set_initial_guess(x_guess=spec.get('x_guess'), u_guess=spec.get('u_guess'))

@@ -144,6 +144,59 @@ def test_free_initial_state_vs_slsqp():
     assert abs(v_ipm[0] - c2_x0(1)[0, 0] / pb.sx[0]) > 1e-2                  # not the measured state
 
 
+SOFT_T = dict(expr=['X + P'], lb=[0.5], ub=[1.0], soft=True, weight=[[50.]])
+
+
+@pytest.mark.parametrize('spec', [
+    dict(C2, N=4, terminal_constraint=SOFT_T),                                                        # soft terminal rows
+    dict(C2H, N=4, terminal_constraint=dict(expr=['S'], lb=[45.], ub=[np.inf], soft=True)),           # + hard stage row
+    dict(C2H, N=4, terminal_constraint=dict(expr=['X + P', 'S'], lb=[-np.inf, 30.], ub=[1., np.inf])),  # hard terminal rows
+    dict(C2, N=4, constraint=dict(expr=['X * S'], lb=[5.], ub=[60.], soft=True)),                    # soft stage rows
+], ids=['soft_terminal', 'hard_stage_soft_terminal', 'hard_terminal', 'soft_stage'])
+def test_derivatives_by_finite_differences(spec):
+    """Gradient, constraint Jacobian and Lagrangian Hessian of the oracle against central differences of its own value
+    functions (the value path is the plain restatement of mpc.py:1654-1725)."""
+    pb = oracle_gen(spec)
+    ipm = GenIpm(pb)
+    rng = np.random.default_rng(1)
+    B = 2
+    data = {'x0': c2_x0(B) / pb.sx, 'p': np.broadcast_to(np.atleast_2d(spec['p']), (B, 4))}
+    w = np.abs(rng.normal(size=(B, ipm.nw))) + 0.5
+    lam = rng.normal(size=(B, ipm.m))
+    f, g, c, J, W = ipm.eval_all(w, lam, data)
+    f2, c2 = ipm.eval_fc(w, data)
+    np.testing.assert_allclose(f, f2, rtol=1e-14)
+    np.testing.assert_allclose(c, c2, rtol=1e-14, atol=1e-14)
+
+    def lag_grad(wq):
+        _, gq, _, Jq, _ = ipm.eval_all(wq, lam, data)
+        return gq + np.einsum('bm,bmn->bn', lam, Jq)
+    h = 1e-6
+    for i in range(ipm.nw):
+        wp, wm = w.copy(), w.copy()
+        wp[:, i] += h
+        wm[:, i] -= h
+        (fp, cp), (fm, cm) = ipm.eval_fc(wp, data), ipm.eval_fc(wm, data)
+        np.testing.assert_allclose(g[:, i], (fp - fm) / (2 * h), rtol=2e-6, atol=2e-5 + 1e-9 * np.abs(f).max() / h)   # round-off of f / h
+        np.testing.assert_allclose(J[:, :, i], (cp - cm) / (2 * h), rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(W[:, :, i], (lag_grad(wp) - lag_grad(wm)) / (2 * h), rtol=2e-5, atol=2e-4)
+
+
+def test_soft_terminal_constraint_bookkeeping_and_solution():
+    spec = dict(C2, N=6, terminal_constraint=SOFT_T)
+    pb = oracle_gen(spec)
+    assert pb.n_v == 7 * 4 + 6 * 2 + 1 and pb.eT_ind == [40] and pb.n_g == 6 * 4 + 2     # mpc.py:1540-1548, :1687-1690
+    ipm = GenIpm(pb)
+    res = ipm.solve(c2_x0(2), spec['p'])
+    assert np.all(res['status'] == 1)
+    eT = res['w'][:, ipm.o_eT:ipm.o_s][:, 0]
+    xm = res['X'][:, -2] * pb.sx                                                          # x_{N-1}: mpc.py:1685 uses x_ii
+    np.testing.assert_allclose(xm[:, 0] + xm[:, 2] - eT, 1.0, atol=1e-6)                  # X + P - e_T = ub: active
+    assert np.all(eT > 0.1)
+    lam = ipm.lam_g(res)
+    assert lam.shape[1] == pb.n_g and np.all(np.abs(lam[:, 5 * 4 + 4 + 1]) < 1e-7) and np.all(lam[:, 5 * 4 + 4] > 1.)   # ub row active, lb row not
+
+
 def test_path_following_with_soft_constraint_vs_slsqp():
     spec = dict(C5S, N=6, constraint=dict(C5S['constraint'], weight=[[10.]]))    # milder penalty: SLSQP-friendly scaling
     pb = oracle_gen(spec)
