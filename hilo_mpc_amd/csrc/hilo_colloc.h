@@ -16,7 +16,7 @@
 
 namespace hilo {
 
-constexpr int COLL_MAXD = 3;
+constexpr int COLL_MAXD = 4;
 
 struct CollData {  // host-computed basis (hilo_mpc_amd/nmpc.py restates modeling.py:1091-1127)
   int d, pad;

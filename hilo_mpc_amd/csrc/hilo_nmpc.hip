@@ -197,7 +197,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     cv = nmpc_coll_find(d->model_id, d->collocation_degree);
     if (!cv)
       return fail(HILO_ENOTSUP, "no collocation instantiation for model %d with degree %d in this build (degree 3 for the "
-                                "continuous zoo models)", d->model_id, d->collocation_degree);
+                                "continuous zoo models, 1-4 for chemostat4)", d->model_id, d->collocation_degree);
     lds = cv->lds_bytes(d->N);
   }
   const TvVariant* tvv = nullptr;

@@ -96,6 +96,15 @@ __device__ __forceinline__ double dpp_mov(double v) {
 __device__ __forceinline__ double read_lane(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+// Element loops: lane t handles e = t, t + T, ...  Written with a wave-uniform trip count and a predicated body instead of
+// `for (e = t; e < n; e += T)`: the exit of a lane-strided loop is a join block that starts with the EXEC restore, and the
+// ROCm 7.2 register allocator sometimes places the register saves of a following call in front of that restore, where they
+// execute for no lane (see uni() below and tools/check_exec_prologue.py).  With a scalar loop branch the block after the
+// loop is entered with every lane enabled.
+#define OCP_FOR(e, n) \
+  for (int e##_base = 0; e##_base < (n); e##_base += OCP_TPB) \
+    if (const int e = e##_base + (int)threadIdx.x; e < (n))
+
 // Wave-uniform values (one wave per instance: every solver decision is the same in all 64 lanes).  The compiler cannot
 // see that for values that come back from a called phase or through memory, treats them as divergent and then lowers the
 // solver's control flow with EXEC masks and keeps its scalars in vector registers.  v_readfirstlane pins them to scalar
@@ -288,7 +297,7 @@ struct Ocp {
         fpart += PB::term_cost(pc, (const double*)l.par, sd_of(l, N), x);
       }
     } else
-    for (int k = threadIdx.x; k <= N; k += blockDim.x) {
+    OCP_FOR(k, (N) + 1) {
       double x[NX], u[NU > 0 ? NU : 1];
 #pragma unroll
       for (int i = 0; i < NX; ++i) x[i] = Zp[k * NZ + i];
@@ -334,13 +343,13 @@ struct Ocp {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double part = 0.0;
-    for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
+    OCP_FOR(e, (N + 1) * NZ) {
       const double lb = l.lbA[e], ub = l.ubA[e], z = Zp[e];
       if (lb > -INFINITY) part -= log(z - lb);
       if (ub < INFINITY) part -= log(ub - z);
     }
     if constexpr (NC > 0) {
-      for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
+      OCP_FOR(e, N * NC) {
         const int m = e % NC;
         if (!row_on(pc, e / NC, m)) continue;
         if (pc.dlb[m] > -INFINITY) part -= log(sp[e] - pc.dlb[m]);
@@ -361,7 +370,7 @@ struct Ocp {
     constexpr int GPW = COOP ? 64 / NDIR : 1;  // cooperative: lane groups of NDIR directions, GPW intervals per round
     const int ntask = COOP ? ((N + GPW - 1) / GPW) * 64 + NXDIR : N * NDIR + NXDIR;
     const int tbase = ntask - NXDIR;
-    for (int task0 = threadIdx.x; task0 < ntask; task0 += blockDim.x) {
+    OCP_FOR(task0, ntask) {
       if (task0 < tbase) {
         int k, d, task = task0;
         bool active = true;
@@ -463,7 +472,7 @@ struct Ocp {
     }
     __syncthreads();
     // Hessian blocks by polarisation: H_ii = q(e_i), H_ij = (q(e_i+e_j) - q(e_i) - q(e_j)) / 2
-    for (int e = threadIdx.x; e < N * NZ * NZ; e += blockDim.x) {
+    OCP_FOR(e, N * NZ * NZ) {
       const int k = e / (NZ * NZ), r = e - k * NZ * NZ, i = r / NZ, j = r - i * NZ;
       cdp Q = l.Qd + k * NDIR;
       double h;
@@ -477,11 +486,11 @@ struct Ocp {
       l.W[e] = h;
     }
     if constexpr (PB::QUAD_COST) {
-      for (int e = threadIdx.x; e < N * NZ; e += blockDim.x) {
+      OCP_FOR(e, N * NZ) {
         const int k = e / NZ, i = e - k * NZ;
         if (is_free(pc, k, i)) l.grad[e] = PB::cost_grad(pc, (const double*)l.par, sd_of(l, k), k, i, (const double*)(l.Z + k * NZ));
       }
-      for (int k = threadIdx.x; k < N; k += blockDim.x) {
+      OCP_FOR(k, N) {
         double x[NX], u[NU > 0 ? NU : 1];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = l.Z[k * NZ + i];
@@ -492,8 +501,8 @@ struct Ocp {
       __syncthreads();
     }
     double fpart = 0.0;
-    for (int k = threadIdx.x; k <= N; k += blockDim.x) fpart += l.fk[k];
-    for (int a = threadIdx.x; a < NU; a += blockDim.x) l.grad[N * NZ + NX + a] = 0.0;
+    OCP_FOR(k, (N) + 1) fpart += l.fk[k];
+    OCP_FOR(a, NU) l.grad[N * NZ + NX + a] = 0.0;
     const double f = block_reduce<OpSum>(fpart, l.red);
     __syncthreads();
     return f;
@@ -532,7 +541,7 @@ struct Ocp {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double dmax = 0.0, lsum = 0.0, zsum = 0.0, pmax = 0.0, nb = 0.0, c0 = 0.0, cm = 0.0;
-    for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
+    OCP_FOR(e, (N + 1) * NZ) {
       const int k = e / NZ, i = e - k * NZ;
       if (!is_free(pc, k, i)) continue;
       dmax = nmax(dmax, fabs(dual_res(l, N, e)));
@@ -551,13 +560,13 @@ struct Ocp {
         cm = nmax(cm, fabs(p - mu));
       }
     }
-    for (int e = threadIdx.x; e < N * NX; e += blockDim.x) {
+    OCP_FOR(e, N * NX) {
       pmax = nmax(pmax, fabs(l.c[e]));
       lsum += fabs(l.lam[e]);
     }
     double ncon = 0.0;
     if constexpr (NC > 0) {  // slack block: dual residual -nu - vL + vU, primal residual d - s
-      for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
+      OCP_FOR(e, N * NC) {
         const int m = e % NC;
         if (!row_on(pc, e / NC, m)) continue;
         dmax = nmax(dmax, fabs(-l.cnu[e] - l.cvL[e] + l.cvU[e]));
@@ -596,13 +605,13 @@ struct Ocp {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double cm = 0.0;
-    for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
+    OCP_FOR(e, (N + 1) * NZ) {
       const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
       if (lb > -INFINITY) cm = nmax(cm, fabs((z - lb) * zl - mu));
       if (ub < INFINITY) cm = nmax(cm, fabs((ub - z) * zu - mu));
     }
     if constexpr (NC > 0) {
-      for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
+      OCP_FOR(e, N * NC) {
         const int m = e % NC;
         if (!row_on(pc, e / NC, m)) continue;
         if (pc.dlb[m] > -INFINITY) cm = nmax(cm, fabs((l.cs[e] - pc.dlb[m]) * l.cvL[e] - mu));
@@ -617,7 +626,7 @@ struct Ocp {
   __device__ static void prep_barrier(const Lds l, double mu) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
-    for (int e = threadIdx.x; e < (N + 1) * NZ; e += blockDim.x) {
+    OCP_FOR(e, (N + 1) * NZ) {
       const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
       double sg = 0.0, r = l.grad[e];
       if (lb > -INFINITY) {
@@ -634,7 +643,7 @@ struct Ocp {
       l.rb[e] = r;
     }
     if constexpr (NC > 0) {  // slack rows: csig = vL/(s - dL) + vU/(dU - s), crb = -mu/(s - dL) + mu/(dU - s)
-      for (int e = threadIdx.x; e < N * NC; e += blockDim.x) {
+      OCP_FOR(e, N * NC) {
         const int m = e % NC;
         double sg = 0.0, r = 0.0;
         if (row_on(pc, e / NC, m)) {
@@ -710,7 +719,7 @@ struct Ocp {
     const int N = pc.N, t = threadIdx.x, T = blockDim.x;
     (void)mu;
     // terminal: P_N = hess V + Sigma + delta, p_N = grad V + barrier rhs
-    for (int e = t; e < NX * NX + NX; e += T) {
+    OCP_FOR(e, NX * NX + NX) {
       if (e < NX * NX) {
         const int i = e / NX, j = e - i * NX;
         double v = 0.0;
@@ -739,7 +748,7 @@ struct Ocp {
       // of [A B | -c] with p_{k+1} added.  All operands are fetched before the arithmetic (one LDS wait).
       // Branch-free: every operand is fetched unconditionally (clamped index) and chosen by a select, the result goes out
       // through one store with a selected address - divergent if/else around the loads costs more than the spare loads.
-      for (int e = t; e < NZ * (NZ + 1); e += T) {
+      OCP_FOR(e, NZ * (NZ + 1)) {
         const int i = e / (NZ + 1), j = e - i * (NZ + 1);
         const bool rhs = j == NZ;
         const int jj = rhs ? 0 : j;
@@ -785,7 +794,7 @@ struct Ocp {
         double Lc[NU * NU], invd[NU];
         const bool pd = small_chol<NU>(l.Mm + NX * NZ + NX, NZ, Lc, invd);
         if (!pd) return false;  // wave-uniform: every lane factors the same block
-        for (int e = t; e < NX * (NX + 1); e += T) {
+        OCP_FOR(e, NX * (NX + 1)) {
           const int i = e / (NX + 1), j = e - i * (NX + 1);
           const bool rhs = j == NX;
           const int jj = rhs ? 0 : j;
@@ -819,7 +828,7 @@ struct Ocp {
           }
         }
       } else {
-        for (int e = t; e < NX * NX + NX; e += T) {
+        OCP_FOR(e, NX * NX + NX) {
           if (e < NX * NX) l.P[k * NX * NX + e] = 0.5 * (l.Mm[(e / NX) * NZ + e % NX] + l.Mm[(e % NX) * NZ + e / NX]);
           else l.pv[k * NX + e - NX * NX] = l.mm[e - NX * NX];
         }
@@ -829,9 +838,9 @@ struct Ocp {
     // initial state: pinned (dx_0 = 0) or (partly) free: dx_0 = -P_0^-1 p_0 on the free slots (P_0 must be positive
     // definite there); pinned rows / columns of P_0 are replaced by the identity
     if (FIX_X0 && pc.x0_free_mask == 0u) {
-      for (int i = t; i < NX; i += T) l.D[i] = 0.0;
+      OCP_FOR(i, NX) l.D[i] = 0.0;
     } else {
-      for (int e = t; e < NX * NX; e += T) {
+      OCP_FOR(e, NX * NX) {
         const int i = e / NX, j = e - i * NX;
         const bool pin = x0_pinned(pc, i) || x0_pinned(pc, j);
         l.Mm[e] = pin ? (i == j ? 1.0 : 0.0) : l.P[e];
@@ -850,7 +859,7 @@ struct Ocp {
       }
     }
     // closed-loop matrices for the forward sweep: Acl = A + B K, bcl = B kff - c  (parallel over stages)
-    for (int e = t; e < N * (NX * NX + NX); e += T) {
+    OCP_FOR(e, N * (NX * NX + NX)) {
       const int k = e / (NX * NX + NX), r = e - k * (NX * NX + NX);
       cdp AB = l.AB + k * NX * NZ;
       if (r < NX * NX) {
@@ -895,7 +904,7 @@ struct Ocp {
     __syncthreads();
     // inputs and new equality multipliers, parallel over stages:
     //   du_k = K dx_k + kff,   lam_{k+1} = -(P_{k+1} dx_{k+1} + p_{k+1})
-    for (int e = t; e < N * (NU + NX); e += T) {
+    OCP_FOR(e, N * (NU + NX)) {
       const int k = e / (NU + NX), r = e - k * (NU + NX);
       if (r < NU) {
         double s = l.kff[k * NU + r];
@@ -910,10 +919,10 @@ struct Ocp {
         l.lamn[k * NX + i] = -s;
       }
     }
-    for (int a = t; a < NU; a += T) l.D[N * NZ + NX + a] = 0.0;
+    OCP_FOR(a, NU) l.D[N * NZ + NX + a] = 0.0;
     __syncthreads();
     if constexpr (NC > 0) {  // recover the eliminated slack step and the new multipliers of d - s = 0
-      for (int e = t; e < N * NC; e += T) {
+      OCP_FOR(e, N * NC) {
         const int k = e / NC, m = e - k * NC;
         double ds = 0.0, nun = 0.0;
         if (row_on(pc, k, m)) {
@@ -937,16 +946,16 @@ struct Ocp {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N, t = threadIdx.x, T = blockDim.x, SL = (N + 1) * NZ;
     double th = 0.0;
-    for (int e = t; e < N * NX; e += T) th += fabs(l.c[e]);
+    OCP_FOR(e, N * NX) th += fabs(l.c[e]);
     if constexpr (NC > 0)
-      for (int e = t; e < N * NC; e += T) th += row_on(pc, e / NC, e % NC) ? fabs(l.cd[e] - l.cs[e]) : 0.0;
+      OCP_FOR(e, N * NC) th += row_on(pc, e / NC, e % NC) ? fabs(l.cd[e] - l.cs[e]) : 0.0;
     th = block_reduce<OpSum>(th, l.red);
     const double th_start = th;
     for (int it = 0; it < 50; ++it) {
       riccati(lbase, ws, mu, 0.0, true);
       double a = 1.0;
       if constexpr (NC > 0) {
-        for (int e = t; e < N * NC; e += T) {
+        OCP_FOR(e, N * NC) {
           const int m = e % NC;
           if (!row_on(pc, e / NC, m)) continue;
           const double d = l.cds[e];
@@ -954,7 +963,7 @@ struct Ocp {
           if (pc.dub[m] < INFINITY && d > 0.0) a = fmin(a, tau * (pc.dub[m] - l.cs[e]) / d);
         }
       }
-      for (int e = t; e < SL; e += T) {
+      OCP_FOR(e, SL) {
         const double d = l.D[e], lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e];
         if (lb > -INFINITY && d < 0.0) a = fmin(a, -tau * (z - lb) / d);
         if (ub < INFINITY && d > 0.0) a = fmin(a, tau * (ub - z) / d);
@@ -963,9 +972,9 @@ struct Ocp {
       bool ok = false;
       double tht = 0.0, ft = 0.0;
       while (alpha > 1e-10) {
-        for (int e = t; e < SL; e += T) l.Zt[e] = l.Z[e] + alpha * l.D[e];
+        OCP_FOR(e, SL) l.Zt[e] = l.Z[e] + alpha * l.D[e];
         if constexpr (NC > 0)
-          for (int e = t; e < N * NC; e += T) l.cst[e] = l.cs[e] + alpha * l.cds[e];
+          OCP_FOR(e, N * NC) l.cst[e] = l.cs[e] + alpha * l.cds[e];
         __syncthreads();
         const FTheta trial = eval_values(lbase, ws, l.Zt, l.ct, l.cst);
         ft = trial.f; tht = trial.theta;
@@ -973,9 +982,9 @@ struct Ocp {
         alpha = uni(alpha * 0.5);
       }
       if (!ok) return false;
-      for (int e = t; e < SL; e += T) l.Z[e] = l.Zt[e];
+      OCP_FOR(e, SL) l.Z[e] = l.Zt[e];
       if constexpr (NC > 0)
-        for (int e = t; e < N * NC; e += T) l.cs[e] = l.cst[e];
+        OCP_FOR(e, N * NC) l.cs[e] = l.cst[e];
       __syncthreads();
       th = tht;
       if (th <= 0.9 * th_start && th <= theta_max) {
@@ -1018,11 +1027,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
   {  // problem constants into LDS: every later access is an LDS read instead of a global load
     const double* src = reinterpret_cast<const double*>(pcg);
     lds_double* dst = lds_raw;
-    for (int i = t; i < S::NCONST; i += T) dst[i] = src[i];
+    OCP_FOR(i, S::NCONST) dst[i] = src[i];
   }
-  for (int i = t; i < PB::NPAR; i += T) l.par[i] = par[b * par_stride + i];
+  OCP_FOR(i, PB::NPAR) l.par[i] = par[b * par_stride + i];
   if constexpr (PB::NSD > 0)
-    for (int i = t; i < (N + 1) * PB::NSD; i += T) l.sd[i] = sdata[b * sd_stride + i];
+    OCP_FOR(i, (N + 1) * PB::NSD) l.sd[i] = sdata[b * sd_stride + i];
   __syncthreads();
   const OcpConst& pc = *(const OcpConst*)l.pc;
   const int SL = (N + 1) * NZ;
@@ -1032,7 +1041,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
 
   // ---- load: warm start in the [x-block | u-block] layout; x_0 pinned to the measurement (mpc.py:801-802) ----
   const double* vb = v0 + b * v0_stride + v0_prefix;
-  for (int e = t; e < SL; e += T) {
+  OCP_FOR(e, SL) {
     const int k = e / NZ, i = e - k * NZ;
     double v;
     // reference layout [x (NXV per stage) | u | shared tail]; the tail is carried as constant states (same value in every stage)
@@ -1064,19 +1073,19 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     l.Z[e] = v;
     l.D[e] = 0.0;
   }
-  for (int e = t; e < N * NX; e += T) l.lam[e] = 0.0;
+  OCP_FOR(e, N * NX) l.lam[e] = 0.0;
   if constexpr (NC > 0) {
-    for (int e = t; e < N * NC; e += T) {
+    OCP_FOR(e, N * NC) {
       l.cs[e] = 0.0; l.cst[e] = 0.0; l.cnu[e] = 0.0; l.cnun[e] = 0.0; l.cvL[e] = 0.0; l.cvU[e] = 0.0; l.cdvL[e] = 0.0;
       l.cdvU[e] = 0.0; l.cds[e] = 0.0; l.cd[e] = 0.0; l.csig[e] = 0.0; l.crb[e] = 0.0;
     }
-    for (int e = t; e < N * NC * NZ; e += T) l.Jd[e] = 0.0;
+    OCP_FOR(e, N * NC * NZ) l.Jd[e] = 0.0;
   }
   __syncthreads();
   if constexpr (NC > 0) {  // IPOPT: slacks start at d(w_0), pushed into the interior of their bounds
     S::eval_values(lds_raw, wsb, l.Z, l.ct, nullptr, l.cd);
     __syncthreads();
-    for (int e = t; e < N * NC; e += T) {
+    OCP_FOR(e, N * NC) {
       const int m = e % NC;
       if (!S::row_on(pc, e / NC, m)) continue;
       double v = l.cd[e];
@@ -1109,9 +1118,9 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     fval = S::eval_derivs(lds_raw, wsb);
     OCP_TICK(PH_DERIV)
     double th0 = 0.0;
-    for (int e = t; e < N * NX; e += T) th0 += fabs(l.c[e]);
+    OCP_FOR(e, N * NX) th0 += fabs(l.c[e]);
     if constexpr (NC > 0)
-      for (int e = t; e < N * NC; e += T) th0 += S::row_on(pc, e / NC, e % NC) ? fabs(l.cd[e] - l.cs[e]) : 0.0;
+      OCP_FOR(e, N * NC) th0 += S::row_on(pc, e / NC, e % NC) ? fabs(l.cd[e] - l.cs[e]) : 0.0;
     th0 = block_reduce<OpSum>(th0, l.red);
     if (it == 0) {
       theta_min = uni(pc.theta_min_fact * fmax(1.0, th0));
@@ -1155,7 +1164,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     OCP_TICK(PH_RICCATI)
     // ---- bound-multiplier steps, fraction to the boundary (W&B eq. 8), directional derivative ----
     double a_p = 1.0, a_z = 1.0, dphi = 0.0;
-    for (int e = t; e < SL; e += T) {
+    OCP_FOR(e, SL) {
       double dl = 0.0, du = 0.0;
       {
         const double d = l.D[e], lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
@@ -1180,7 +1189,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       l.dzU[e] = du;
     }
     if constexpr (NC > 0) {
-      for (int e = t; e < N * NC; e += T) {
+      OCP_FOR(e, N * NC) {
         const int m = e % NC;
         double dl = 0.0, du = 0.0;
         if (S::row_on(pc, e / NC, m)) {
@@ -1212,9 +1221,9 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     double alpha = a_p;
     bool accepted = false, armijo = false;
     for (int ls = 0; ls < 60; ++ls) {
-      for (int e = t; e < SL; e += T) l.Zt[e] = l.Z[e] + alpha * l.D[e];
+      OCP_FOR(e, SL) l.Zt[e] = l.Z[e] + alpha * l.D[e];
       if constexpr (NC > 0)
-        for (int e = t; e < N * NC; e += T) l.cst[e] = l.cs[e] + alpha * l.cds[e];
+        OCP_FOR(e, N * NC) l.cst[e] = l.cs[e] + alpha * l.cds[e];
       __syncthreads();
       tprof[PH_NLS] += 1;
       const FTheta trial = S::eval_values(lds_raw, wsb, l.Zt, l.ct, l.cst);
@@ -1267,19 +1276,19 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       // IPOPT after restoration: equality multipliers reset (constr_mult_reset_threshold = 0), bound multipliers
       // reset to 1 when they exceed bound_mult_reset_threshold = 1000
       double zm = 0.0;
-      for (int e = t; e < SL; e += T) zm = fmax(zm, fmax(l.zL[e], l.zU[e]));
+      OCP_FOR(e, SL) zm = fmax(zm, fmax(l.zL[e], l.zU[e]));
       if constexpr (NC > 0)
-        for (int e = t; e < N * NC; e += T) zm = fmax(zm, fmax(l.cvL[e], l.cvU[e]));
+        OCP_FOR(e, N * NC) zm = fmax(zm, fmax(l.cvL[e], l.cvU[e]));
       zm = block_reduce<OpMax>(zm, l.red);
-      for (int e = t; e < SL; e += T) {
+      OCP_FOR(e, SL) {
         if (zm > 1e3) {
           l.zL[e] = l.lbA[e] > -INFINITY ? 1.0 : 0.0;
           l.zU[e] = l.ubA[e] < INFINITY ? 1.0 : 0.0;
         }
       }
-      for (int e = t; e < N * NX; e += T) l.lam[e] = 0.0;
+      OCP_FOR(e, N * NX) l.lam[e] = 0.0;
       if constexpr (NC > 0) {
-        for (int e = t; e < N * NC; e += T) {
+        OCP_FOR(e, N * NC) {
           const int m = e % NC;
           l.cnu[e] = 0.0;
           if (zm > 1e3 && S::row_on(pc, e / NC, m)) {
@@ -1292,7 +1301,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       continue;
     }
     // ---- accept: primal, equality multipliers, bound multipliers (+ W&B eq. 16 safeguard) ----
-    for (int e = t; e < SL; e += T) {
+    OCP_FOR(e, SL) {
       const double znew = l.Zt[e], lb = l.lbA[e], ub = l.ubA[e];
       l.Z[e] = znew;
       if (lb > -INFINITY) {
@@ -1304,9 +1313,9 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
         l.zU[e] = fmin(fmax(l.zU[e] + a_z * l.dzU[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
       }
     }
-    for (int e = t; e < N * NX; e += T) l.lam[e] += alpha * (l.lamn[e] - l.lam[e]);
+    OCP_FOR(e, N * NX) l.lam[e] += alpha * (l.lamn[e] - l.lam[e]);
     if constexpr (NC > 0) {
-      for (int e = t; e < N * NC; e += T) {
+      OCP_FOR(e, N * NC) {
         const int m = e % NC;
         if (!S::row_on(pc, e / NC, m)) continue;
         const double snew = l.cst[e];
@@ -1328,7 +1337,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
 
   // ---- write back ([x-block | u-block] after the prefix) ----
   double* vo = v_opt + b * (int64_t)(v_prefix + (N + 1) * NXV + N * NU + NTAIL) + v_prefix;
-  for (int e = t; e < SL; e += T) {
+  OCP_FOR(e, SL) {
     const int k = e / NZ, i = e - k * NZ;
     if (i < NXV) vo[k * NXV + i] = l.Z[e];
     else if (i < NX) { if (k == 0) vo[(N + 1) * NXV + N * NU + (i - NXV)] = l.Z[e]; }
@@ -1339,7 +1348,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     // the last stage carries the terminal rows between its defect and its stage rows (mpc.py:1693-1700 before :1707)
     const int ncr = NC > 0 ? pc.n_con_ref : 0, ntr = NC > 0 ? pc.n_tcon_ref : 0, rows = NXV + ncr;
     double* lg = lam_g + b * (int64_t)(N * rows + ntr);
-    for (int e = t; e < N * NXV; e += T) {
+    OCP_FOR(e, N * NXV) {
       const int k = e / NXV, i = e - k * NXV;
       double v = l.lam[k * NX + i];
       // terminal cost on F_{N-1} in the reference (mpc.py:1682) vs on x_N here: multipliers of the last defect
@@ -1348,13 +1357,13 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       lg[k * rows + i] = v;
     }
     if constexpr (NC > 0) {
-      for (int e = t; e < N * ncr; e += T) {  // dropped (unbounded) rows
+      OCP_FOR(e, N * ncr) {  // dropped (unbounded) rows
         const int k = e / ncr;
         lg[k * rows + NXV + (k == N - 1 ? ntr : 0) + e % ncr] = 0.0;
       }
-      for (int e = t; e < ntr; e += T) lg[(N - 1) * rows + NXV + e] = 0.0;
+      OCP_FOR(e, ntr) lg[(N - 1) * rows + NXV + e] = 0.0;
       __syncthreads();
-      for (int e = t; e < N * NC; e += T) {
+      OCP_FOR(e, N * NC) {
         const int k = e / NC, m = e - k * NC;
         if (m < pc.nc) lg[k * rows + NXV + (k == N - 1 ? ntr : 0) + pc.row_ref[m]] = l.cnu[e];
         else if (k == N - 1 && m < pc.nc + pc.nc_term) lg[k * rows + NXV + pc.trow_ref[m - pc.nc]] = l.cnu[e];
@@ -1362,8 +1371,8 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     }
   }
   if (first) {
-    if (first_kind == 0) { for (int a = t; a < S::NU0; a += T) first[b * S::NU0 + a] = l.Z[NX + a] * pc.sz[NX + a]; }
-    else { for (int a = t; a < NX; a += T) first[b * NX + a] = l.Z[N * NZ + a] * pc.sz[a]; }
+    if (first_kind == 0) { OCP_FOR(a, S::NU0) first[b * S::NU0 + a] = l.Z[NX + a] * pc.sz[NX + a]; }
+    else { OCP_FOR(a, NX) first[b * NX + a] = l.Z[N * NZ + a] * pc.sz[a]; }
   }
   if (t == 0) {
     f_opt[b] = fval;

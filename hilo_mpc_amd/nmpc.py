@@ -409,8 +409,8 @@ class NMPC:
             if opts['integration_method'] in ('idas', 'cvodes'):
                 raise NotImplementedError("SUNDIALS integrators inside the NLP are not offloaded; use 'collocation', "
                                           "'rk4' or 'erk'")
-            if opts['integration_method'] == 'collocation' and opts['degree'] != 3:
-                raise NotImplementedError("collocation is built for the reference's default degree 3")
+            if opts['integration_method'] == 'collocation' and opts['degree'] not in (1, 2, 3, 4):
+                raise NotImplementedError("collocation is built for degrees 1 to 4 (the reference's default is 3)")
         if opts['ipopt_debugger']:
             raise NotImplementedError("the IPOPT iteration callback has no device counterpart")
         self._nlp_options = opts

@@ -243,7 +243,7 @@ typedef struct hilo_nmpc_desc {
      passes the basis it built (modeling.py:1091-1127): coll_A = (C[1:,1:]^T)^-1 (d x d, the method's Runge-Kutta matrix)
      and coll_D = D[0..d].  v gains the collocation states ([x | u | ip], mpc.py:1497-1518), g the collocation rows
      (per stage [collocation rows | continuity], :1657-1669).  0 = explicit Runge-Kutta / discrete model. ---- */
-  int32_t collocation_degree;            /* 0 or 3 in this build */
+  int32_t collocation_degree;            /* 0, or 3 (1..4 for chemostat4) in this build */
   int32_t reserved2;
   const double* coll_A;                  /* [d][d] */
   const double* coll_D;                  /* [d+1] */

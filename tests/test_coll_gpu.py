@@ -69,6 +69,69 @@ def test_c2_collocation_vs_oracle(over):
     np.testing.assert_allclose(u2, ref2['u0'], rtol=5e-5, atol=1e-6)
 
 
+def test_legendre_points_vs_oracle():
+    """options={'collocation_points': 'legendre'} (optimizer.py:1410-1418): Gauss points - only the basis the host passes
+    changes (modeling.py:1091-1127); the end point is then extrapolated (D_0 != 0)."""
+    spec = dict(C2, N=8)
+    x0 = c2_x0(4)
+    kw = {k: v for k, v in spec.items() if k not in ('model', 'p', 'order')}
+    pb = CollNmpcProblem(models.get(spec['model']), points='legendre', **kw)
+    ipm = CollIpm(pb)
+    ref = ipm.solve(x0, spec['p'])
+    assert np.all(ref['status'] == 1) and abs(pb.D[0]) > 1e-3
+    from hilo_mpc_amd import NMPC, Model
+    m = Model(spec['model']).setup(dt=spec['dt'])
+    nmpc = NMPC(m)
+    xs, us = m.dynamical_state_names, m.input_names
+    nmpc.set_quadratic_stage_cost(states=[xs[i] for i in spec['stage_states'][0][0]], cost_states=list(spec['stage_states'][0][1]),
+                                  states_references=spec['stage_states'][0][2],
+                                  inputs=[us[i] for i in spec['stage_inputs'][0][0]], cost_inputs=list(spec['stage_inputs'][0][1]))
+    nmpc.set_quadratic_terminal_cost(states=[xs[i] for i in spec['terminal_states'][0][0]],
+                                     cost=list(spec['terminal_states'][0][1]), references=spec['terminal_states'][0][2])
+    nmpc.horizon = spec['N']
+    nmpc.set_box_constraints(x_lb=spec.get('x_lb'), u_ub=spec.get('u_ub'), u_lb=spec.get('u_lb'))
+    nmpc.set_initial_guess(x_guess=spec.get('x_guess'), u_guess=spec.get('u_guess'))
+    nmpc.setup(options={'collocation_points': 'legendre'})
+    u = nmpc.optimize(x0, cp=spec['p'])
+    assert np.array_equal(nmpc.solver_status_code, ref['status'])
+    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), ipm.to_v(ref)
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 5e-5
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-8)
+    np.testing.assert_allclose(u, ref['u0'], rtol=5e-5, atol=1e-6)
+    radau = _product(spec)
+    ur = radau.optimize(x0, cp=spec['p'])
+    assert np.abs(ur - u).max() > 1e-7                                  # a different discretisation, not the same numbers
+
+
+@pytest.mark.parametrize('degree,points', [(1, 'radau'), (2, 'radau'), (2, 'legendre'), (4, 'radau')])
+def test_other_degrees_vs_oracle(degree, points):
+    """options={'degree': d}: the same implicit shooting map with d collocation points (modeling.py:1091-1211)."""
+    spec = dict(C2, N=6)
+    x0 = c2_x0(3)
+    kw = {k: v for k, v in spec.items() if k not in ('model', 'p', 'order')}
+    pb = CollNmpcProblem(models.get(spec['model']), degree=degree, points=points, **kw)
+    ipm = CollIpm(pb)
+    ref = ipm.solve(x0, spec['p'])
+    assert np.all(ref['status'] == 1)
+    from hilo_mpc_amd import NMPC, Model
+    m = Model(spec['model']).setup(dt=spec['dt'])
+    nmpc = NMPC(m)
+    nmpc.quad_stage_cost.add_states(names=['P'], weights=[10.], ref=[2.])
+    nmpc.quad_stage_cost.add_inputs(names=m.input_names, weights=[.1, .1])
+    nmpc.quad_terminal_cost.add_states(names=['P'], weights=[10.], ref=[2.])
+    nmpc.horizon = spec['N']
+    nmpc.set_box_constraints(x_lb=spec.get('x_lb'), u_ub=spec.get('u_ub'), u_lb=spec.get('u_lb'))
+    nmpc.set_initial_guess(x_guess=spec.get('x_guess'), u_guess=spec.get('u_guess'))
+    nmpc.setup(options={'degree': degree, 'collocation_points': points})
+    assert (nmpc._n_v, nmpc._n_g) == (pb.n_v, pb.n_g) and nmpc._ip_ind == pb.ip_ind
+    u = nmpc.optimize(x0, cp=spec['p'])
+    assert np.array_equal(nmpc.solver_status_code, ref['status'])
+    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), ipm.to_v(ref)
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 5e-5
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-8)
+    np.testing.assert_allclose(u, ref['u0'], rtol=5e-5, atol=1e-6)
+
+
 def test_collocation_differs_from_rk4_and_satisfies_its_equations():
     """Not RK4 in disguise: the collocation optimum differs from the ERK-4 one, and the returned collocation states satisfy
     dt f(x_ki, u_k) = sum_j C[j,i] x_kj and x_{k+1} = sum_j D_j x_kj to round-off."""
@@ -94,8 +157,8 @@ def test_integration_method_validation():
     nmpc.horizon = 5
     with pytest.raises(ValueError, match="continuous time"):
         nmpc.setup(options={'integration_method': 'discrete'})
-    with pytest.raises(NotImplementedError, match="degree 3"):
-        nmpc.setup(options={'degree': 2})
+    with pytest.raises(NotImplementedError, match="degrees 1 to 4"):
+        nmpc.setup(options={'degree': 5})
     nmpc.setup(options={'integration_method': 'rk4'})                  # explicit RK on the continuous model
     assert nmpc._n_v == 6 * 4 + 5 * 2
 

@@ -66,7 +66,8 @@ def check(elf):
     starts = set()
     for k, (a, op, args, _) in enumerate(ins):
         if op == 's_cbranch_execz':
-            starts.add(index.get(a + 4 + 4 * int(args.split()[0])))
+            off = int(args.split()[0])
+            starts.add(index.get(a + 4 + 4 * (off - 65536 if off >= 32768 else off)))   # simm16 is printed unsigned
         elif op == 's_cbranch_execnz' and k + 1 < len(ins):
             starts.add(k + 1)                             # loop left with every lane masked off
     hits = []
