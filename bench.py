@@ -170,7 +170,7 @@ def main():
                          "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(),
                          "kernel": "ocp_solve_kernel<NmpcTrack<Chemostat4>, 64>", "kernel_ms": kern_ms,
                          "note": "fp64 roof: MI355X fp64 vector peak == fp64 MFMA peak = 78.6 TFLOP/s; the kernel is "
-                                 "fp64 VALU/latency bound (no MFMA), algorithmic flops = B * mean_iters * N * "
+                                 "fp64 VALU/latency bound (f64 MFMA only for the Riccati stage products), algorithmic flops = B * mean_iters * N * "
                                  "(F_ric + F_dyn), see DESIGN.md"},
             "roofline_hbm": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),

@@ -126,6 +126,16 @@ __device__ __forceinline__ T* uni(T* p) {
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
   return (T*)(((unsigned long long)hi << 32) | lo);
 }
+// 1/sqrt(x) for x > 0: v_rsq_f64 seed (about 2^-26) and two Newton steps - the library rsqrt() is a ~100-cycle dependent
+// chain that sits on the critical path of every Riccati stage
+__device__ __forceinline__ double rsq_fast(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+}
+typedef double v4d __attribute__((ext_vector_type(4)));   // accumulator of v_mfma_f64_16x16x4
 struct FTheta { double f, theta; };  // objective and constraint violation of a point
 
 template <class Op>
@@ -168,6 +178,9 @@ struct Ocp {
   // reference decision-vector layout [x (NXV per stage) | u | shared tail (NX - NXV)]; x_0 measurement width; inputs returned
   static constexpr int NXV = PB::NXV, NX0 = PB::NX0, NU0 = PB::NU0;
   static_assert(!COOP || (OCP_TPB == 64 && NDIR <= 64), "cooperative models need one wave per instance");
+  // stage products of the Riccati recursion on the f64 matrix cores (one wave per instance, a stage's z and the
+  // right-hand-side column fit the 16 columns of v_mfma_f64_16x16x4)
+  static constexpr bool MFMA_STAGE = OCP_TPB == 64 && NZ + 1 <= 16 && NX <= 16;
   static constexpr int NCONST = (int)((offsetof(OcpConst, cost) + sizeof(double) * PB::NCOST + 7) / 8);
 
   // Storage of the iterate: LDS (default) or, for problems that do not fit (long horizons, wide stages), a per-instance
@@ -675,12 +688,35 @@ struct Ocp {
 #pragma unroll
       for (int q = 0; q < j; ++q) s -= L[j * n + q] * L[j * n + q];
       if (!(s > 0.0)) { pd = false; s = 1.0; }
-      const double id = rsqrt(s);
+      const double id = rsq_fast(s);
       invd[j] = id;
       L[j * n + j] = s * id;
 #pragma unroll
       for (int i = j + 1; i < n; ++i) {
         double v = M[i * ld + j];
+#pragma unroll
+        for (int q = 0; q < j; ++q) v -= L[i * n + q] * L[j * n + q];
+        L[i * n + j] = v * id;
+      }
+    }
+    return pd;
+  }
+  // the same factorisation of a block held in registers (row-major n x n, lower triangle used)
+  template <int n>
+  __device__ __forceinline__ static bool small_chol_reg(const double* M, double* L, double* invd) {
+    bool pd = true;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      double s = M[j * n + j];
+#pragma unroll
+      for (int q = 0; q < j; ++q) s -= L[j * n + q] * L[j * n + q];
+      if (!(s > 0.0)) { pd = false; s = 1.0; }
+      const double id = rsq_fast(s);
+      invd[j] = id;
+      L[j * n + j] = s * id;
+#pragma unroll
+      for (int i = j + 1; i < n; ++i) {
+        double v = M[i * n + j];
 #pragma unroll
         for (int q = 0; q < j; ++q) v -= L[i * n + q] * L[j * n + q];
         L[i * n + j] = v * id;
@@ -743,7 +779,88 @@ struct Ocp {
       cdp Pn = l.P + (k + 1) * NX * NX;
       cdp pn = l.pv + (k + 1) * NX;
       cdp AB = l.AB + k * NX * NZ;
+      double Lc[NU > 0 ? NU * NU : 1], invd[NU > 0 ? NU : 1];   // Cholesky factor of the reduced pivot block R_k
+      bool pd = true, factored = false;
       // (1) Mm = H_k + [A B]^T P_{k+1} [A B];  mm = r_k + [A B]^T (p_{k+1} - P_{k+1} c_k).
+#ifndef HILO_RICCATI_VALU
+      if constexpr (MFMA_STAGE) {
+        // Two chained v_mfma_f64_16x16x4 per 4 rows of the inner dimension, ONE matrix element per lane (lane = 16 g + q):
+        //   T = P_{k+1} [A B | -c] + [0 | p_{k+1}]      A-operand P[q][4kb+g], B-operand [A B | -c][4kb+g][q]
+        //   M = [A B]^T T + [H_k | r_k]                  A-operand AB[4kb+g][q], B-operand T rows 4kb+g = accumulator kb of T
+        // The accumulator of the f64 form holds rows g + 4r, column q in register r - exactly the B-operand layout of the
+        // second product, so T never leaves the registers.  Six distinct-address LDS reads per lane replace the 48
+        // broadcast reads of the vector-ALU form (one wave pulled 17 KB per stage through the LDS port shared by four waves).
+        const int q = t & 15, g = t >> 4;
+        constexpr int KB = (NX + 3) / 4, RB = (NZ + 3) / 4;
+        const int qx = q < NX ? q : NX - 1, qz = q < NZ ? q : NZ - 1;
+        v4d Tacc = {0.0, 0.0, 0.0, 0.0}, Macc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < KB; ++r) {
+          const int row = g + 4 * r, rc = row < NX ? row : NX - 1;
+          const double pv_ = pn[rc];
+          Tacc[r] = (q == NZ && row < NX) ? pv_ : 0.0;
+        }
+        double a1[KB], b1[KB], a2[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const int kk = 4 * kb + g;
+          const bool kv = kk < NX;
+          const int kc = kv ? kk : NX - 1;
+          const double pe = Pn[qx * NX + kc], ab = AB[kc * NZ + qz], cn = l.c[k * NX + kc];
+          a1[kb] = (kv && q < NX) ? pe : 0.0;
+          b1[kb] = kv ? (q < NZ ? ab : (q == NZ ? -cn : 0.0)) : 0.0;
+          a2[kb] = (kv && q < NZ) ? ab : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int i = g + 4 * r;
+          const bool iv = i < NZ, rhs = q == NZ;
+          const int ic = iv ? i : NZ - 1, jj = q < NZ ? q : 0;
+          const double rbv = l.rb[k * NZ + ic], wv = l.W[k * NZ * NZ + ic * NZ + jj], sg = l.sig[k * NZ + ic];
+          double h = resto ? 0.0 : (rhs ? rbv : wv);
+          if (ic == q) h += resto ? 1.0 : delta + sg;
+          if constexpr (NC > 0) {  // eliminated slack rows: + Jd^T (Sigma_s + delta) Jd, rhs + Jd^T ((Sigma_s + delta)(d - s) + crb)
+#pragma unroll
+            for (int m = 0; m < NC; ++m) {
+              const int rr = k * NC + m;
+              const double wgt = resto ? 1.0 : l.csig[rr] + delta;
+              const double ds = l.cd[rr] - l.cs[rr], cr = l.crb[rr], jr = l.Jd[rr * NZ + jj];
+              const double right = rhs ? wgt * ds + (resto ? 0.0 : cr) : wgt * jr;
+              h += l.Jd[rr * NZ + ic] * right;
+            }
+          }
+          Macc[r] = (iv && q <= NZ) ? h : 0.0;
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) Tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kb], b1[kb], Tacc, 0, 0, 0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) Macc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[kb], Tacc[kb], Macc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int i = g + 4 * r;
+          if (i < NZ && q <= NZ) {
+            lds_double* dst = q == NZ ? l.mm + i : l.Mm + i * NZ + q;
+            *dst = Macc[r];
+          }
+        }
+        if constexpr (NU > 0) {
+          // the pivot block R_k = M_uu straight out of the accumulators (entry (i, j) sits in register i / 4 of lane
+          // 16 (i % 4) + j): v_readlane broadcasts instead of waiting for the LDS round trip of Mm, so the factorisation
+          // overlaps the stores above and the loads of phase (2)
+          double Rl[NU * NU];
+#pragma unroll
+          for (int a = 0; a < NU; ++a)
+#pragma unroll
+            for (int c2 = 0; c2 <= a; ++c2) {
+              const int i = NX + a, j = NX + c2;
+              Rl[a * NU + c2] = read_lane(Macc[i / 4], 16 * (i % 4) + j);
+            }
+          pd = small_chol_reg<NU>(Rl, Lc, invd);
+          factored = true;
+        }
+      } else
+#endif
+      {
       // One uniform code path for the NZ x (NZ+1) entries: column NZ is the right-hand side, i.e. the "column" -c_k
       // of [A B | -c] with p_{k+1} added.  All operands are fetched before the arithmetic (one LDS wait).
       // Branch-free: every operand is fetched unconditionally (clamped index) and chosen by a select, the result goes out
@@ -786,13 +903,13 @@ struct Ocp {
         lds_double* dst = rhs ? l.mm + i : l.Mm + i * NZ + j;
         *dst = s + dg;   // dg = 0 in the right-hand-side column (i != NZ)
       }
+      }
       __syncthreads();
       // (2) pivot block (factored redundantly per lane), feedback, cost-to-go: lane (i, j), j = 0..NX:
       //   y_j = R^-1 M_ux[:, j] (j < NX) or R^-1 m_u (j = NX);  P_k[i][j] = sym(M_xx)[i][j] - M_xu[i] y_j;
       //   p_k[i] = m_x[i] - M_xu[i] y_NX;  lanes with i = 0 also store K[:, j] = -y_j and kff = -y_NX
       if constexpr (NU > 0) {
-        double Lc[NU * NU], invd[NU];
-        const bool pd = small_chol<NU>(l.Mm + NX * NZ + NX, NZ, Lc, invd);
+        if (!factored) pd = small_chol<NU>(l.Mm + NX * NZ + NX, NZ, Lc, invd);
         if (!pd) return false;  // wave-uniform: every lane factors the same block
         OCP_FOR(e, NX * (NX + 1)) {
           const int i = e / (NX + 1), j = e - i * (NX + 1);
@@ -893,7 +1010,7 @@ struct Ocp {
         bn = l.bcl[kn * NX + i];
         double s = bc;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) s += ac[j] * __shfl(dxi, j, 64);
+        for (int j = 0; j < NX; ++j) s += ac[j] * read_lane(dxi, j);   // v_readlane: scalar broadcast, no LDS crossbar trip
         dxi = s;
         if (t < NX) l.D[(k + 1) * NZ + i] = dxi;
 #pragma unroll
