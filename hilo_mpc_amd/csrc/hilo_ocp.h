@@ -924,6 +924,13 @@ struct Ocp {
           }
           const double sm = l.mm[i], s1 = l.Mm[i * NZ + jj], s2 = l.Mm[jj * NZ + i];
           double s = rhs ? sm : 0.5 * (s1 + s2);
+          // closed-loop coefficient of the forward sweep, same lane: Acl[i][j] = A[i][j] + B[i] K[:, j], bcl[i] = B[i] kff - c[i]
+          // (K[:, j] = -y_j, kff = -y_NX are this lane's solve)
+          double bi[NU];
+#pragma unroll
+          for (int a = 0; a < NU; ++a) bi[a] = AB[i * NZ + NX + a];
+          const double aij = AB[i * NZ + jj], ci = l.c[k * NX + i];
+          double cl = rhs ? -ci : aij;
           __builtin_amdgcn_sched_barrier(0);
           small_solve<NU>(Lc, invd, y);
 #pragma unroll
@@ -931,6 +938,10 @@ struct Ocp {
           // P_k is kept EXACTLY symmetric: entry (i, j), i <= j, is computed once and stored twice.  Rounding-level
           // asymmetry is not damped by the recursion - for unstable dynamics it grows like the open loop and destroyed the
           // pivots after ~38 stages of the chemostat.
+#pragma unroll
+          for (int a = 0; a < NU; ++a) cl -= bi[a] * y[a];
+          dp cld = rhs ? l.bcl + k * NX + i : l.Acl + k * NX * NX + i * NX + jj;
+          *cld = cl;
           if (rhs) l.pv[k * NX + i] = s;
           else if (i <= jj) {
             l.P[k * NX * NX + i * NX + jj] = s;
@@ -975,8 +986,9 @@ struct Ocp {
         for (int a = 0; a < NX; ++a) l.D[a] = -y[a];
       }
     }
-    // closed-loop matrices for the forward sweep: Acl = A + B K, bcl = B kff - c  (parallel over stages)
-    OCP_FOR(e, N * (NX * NX + NX)) {
+    // closed-loop matrices for the forward sweep: Acl = A + B K, bcl = B kff - c: written by the stage loop above when there
+    // are inputs; without inputs Acl = A, bcl = -c
+    if constexpr (NU == 0) OCP_FOR(e, N * (NX * NX + NX)) {
       const int k = e / (NX * NX + NX), r = e - k * (NX * NX + NX);
       cdp AB = l.AB + k * NX * NZ;
       if (r < NX * NX) {
