@@ -744,9 +744,10 @@ struct Ocp {
   }
 
   // ---- Riccati factor + solve of the Newton system; false when a reduced pivot is not positive ---------------
-  // Per stage two LDS round trips: (1) M = H_k + [A B]^T P_{k+1} [A B] and its right-hand side, (2) the reduced
-  // pivot block's Cholesky (redundantly per lane), feedback K, feed-forward kff, P_k, p_k.  The forward sweep runs
-  // on closed-loop matrices prepared in parallel and keeps dx in registers (wave shuffles, no LDS round trip).
+  // Per stage: (1) M = H_k + [A B]^T P_{k+1} [A B] and its right-hand side on the f64 matrix cores, the reduced pivot
+  // block broadcast from the accumulators and factored (redundantly per lane) while M goes through LDS; (2) feedback K,
+  // feed-forward kff, P_k, p_k and the closed-loop coefficients.  The forward sweep keeps dx in registers (v_readlane
+  // broadcasts, no LDS round trip).
   // `resto`: feasibility-restoration step (H = I, zero gradient: least-norm d with J d = -c)
   __device__ OCP_PHASE static bool riccati(lds_double* lbase, double* ws, double mu, double delta, bool resto = false) {
     lbase = uni(lbase); ws = uni(ws); mu = uni(mu); delta = uni(delta); resto = uni(resto);

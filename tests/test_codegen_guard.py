@@ -1,6 +1,6 @@
 """Build guard: no vector copy / spill may sit in front of the EXEC restore of a join block (tools/check_exec_prologue.py).
 The ROCm 7.2 backend produced that for two NMPC variants under register pressure; the copy executes for no lane and the
-solver's state is garbage afterwards (DESIGN.md 9).  The check disassembles the shipped library, so it covers every kernel."""
+solver's state is garbage afterwards (DESIGN.md 5.1).  The check disassembles the shipped library, so it covers every kernel."""
 import os
 import sys
 

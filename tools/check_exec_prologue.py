@@ -5,7 +5,7 @@ block.  Under register pressure the register allocator sometimes places a live-r
 (`v_mov_b32 vA, vB`, `v_accvgpr_write_b32`, `scratch_store`) in that block BEFORE the `s_or_b64`.  The block is entered
 through `s_cbranch_execz` (or by falling out of an `s_cbranch_execnz` loop), i.e. with EXEC == 0, so the copy executes for
 no lane and the value read back later is garbage.  It cost this project the filter size of the constrained NMPC variants
-(DESIGN.md 9); the solver pins its wave-uniform state to scalar registers since, and this script checks what is left:
+(DESIGN.md 5.1); the solver pins its wave-uniform state to scalar registers since, and this script checks what is left:
 
     python tools/check_exec_prologue.py [libhilo_hip.so]
 
