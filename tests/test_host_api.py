@@ -79,3 +79,64 @@ def test_expression_symbols_and_depth():
         m.x['X'] ** 2.5
     with pytest.raises(ValueError, match="path variable"):
         expr.Expr('theta', name='theta').program()
+
+
+def test_mhe_host_contract():
+    """MHE front end before setup(): same failure modes as mhe.py (horizon / cost checks), unsupported branches refuse."""
+    from hilo_mpc_amd import MHE
+    m = Model('chemostat4').discretize('erk', order=4).setup(dt=0.5)
+    mhe = MHE(m)
+    with pytest.raises(ValueError, match="horizon"):
+        mhe.horizon = 0
+    with pytest.raises(ValueError, match="horizon length"):
+        mhe.setup()
+    mhe.horizon = 5
+    with pytest.raises(ValueError, match="cost function"):
+        mhe.setup()
+    with pytest.raises(ValueError, match="same dimension"):
+        mhe.quad_arrival_cost.add_states(weights=[1., 1., 1., 1.], guess=[1., 2.])
+    with pytest.raises(NotImplementedError):
+        mhe.quad_stage_cost.add_inputs(names=['DS'], weights=[1.])
+    with pytest.raises(TypeError, match="same number of bounds"):
+        mhe.set_box_constraints(x_lb=[0., 0.])
+    with pytest.raises(RuntimeError, match="setup"):
+        mhe.add_measurements([1., 2.])
+    with pytest.raises(ValueError, match="setup"):
+        mhe.estimate()
+
+
+def test_lmpc_host_contract():
+    from hilo_mpc_amd import LMPC
+    with pytest.raises(TypeError, match="nonlinear"):
+        LMPC(Model('chemostat4').discretize('erk', order=4).setup(dt=0.5))
+    m = Model('lti', A=[[1., 1.], [0., 1.]], B=[[0.5], [1.]]).setup(dt=1.)
+    lmpc = LMPC(m)
+    with pytest.raises(ValueError, match="2x2"):
+        lmpc.Q = np.eye(3)
+    lmpc.Q, lmpc.R, lmpc.P = np.eye(2), [[1.]], np.eye(2)
+    with pytest.raises(ValueError, match="horizon"):
+        lmpc.horizon = -1
+    with pytest.raises(ValueError, match="horizon length"):
+        lmpc.setup()
+    lmpc.horizon = 10
+    with pytest.raises(ValueError, match="does no exist"):
+        lmpc.setup(solver='osqp')
+    with pytest.raises(ValueError, match="kron_variant"):
+        lmpc.setup(kron_variant='other')
+    with pytest.raises(TypeError, match="same number of bounds"):
+        lmpc.set_box_constraints(u_ub=[1., 2.])
+    with pytest.raises(ValueError, match="setup"):
+        lmpc.optimize([0., 0.])
+
+
+def test_nmpc_requires_setup_and_options_follow_the_allow_lists():
+    m = _model()
+    n = NMPC(m)
+    with pytest.raises(ValueError, match="setup"):
+        n.optimize([1., 1., 1., 1.])
+    n.quad_stage_cost.add_states(names=['X'], weights=[1.])
+    n.horizon = 5
+    with pytest.raises(ValueError):
+        n.set_nlp_options({'integration_method': 'euler_backward'})      # not in the allow-list (optimizer.py:1388-1474)
+    with pytest.raises((ValueError, KeyError, TypeError)):
+        n.set_nlp_options({'no_such_option': 1})
