@@ -753,7 +753,7 @@ struct Ocp {
     lbase = uni(lbase); ws = uni(ws); mu = uni(mu); delta = uni(delta); resto = uni(resto);
     const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
-    const int N = pc.N, t = threadIdx.x, T = blockDim.x;
+    const int N = pc.N, t = threadIdx.x;
     (void)mu;
     // terminal: P_N = hess V + Sigma + delta, p_N = grad V + barrier rhs
     OCP_FOR(e, NX * NX + NX) {
@@ -1074,7 +1074,7 @@ struct Ocp {
     lbase = uni(lbase); ws = uni(ws); mu = uni(mu); tau = uni(tau); nfilt = uni(nfilt); theta_max = uni(theta_max);
     const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
-    const int N = pc.N, t = threadIdx.x, T = blockDim.x, SL = (N + 1) * NZ;
+    const int N = pc.N, SL = (N + 1) * NZ;
     double th = 0.0;
     OCP_FOR(e, N * NX) th += fabs(l.c[e]);
     if constexpr (NC > 0)
@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
   constexpr int NX = S::NX, NU = S::NU, NZ = S::NZ, NC = S::NC, NXV = S::NXV, NTAIL = NX - NXV;
   extern __shared__ double lds_raw_generic[];
   lds_double* lds_raw = (lds_double*)lds_raw_generic;
-  const int t = threadIdx.x, T = blockDim.x;
+  const int t = threadIdx.x;
   const int64_t b = blockIdx.x;
   if (b >= batch) return;
   const int N = pcg->N;
