@@ -1,0 +1,53 @@
+"""CPU: the oracle's hyper-parameter fit (oracle/gp_fit.py = `GaussianProcess.fit_model`, gp.py:660-697) against the
+reference's own known answers (tests/test_GPs.py:846-904: optima of the GPML toolbox on the 20-point data set of
+tests/test_GPs.py:835-838).  This pins, at non-trivial hyper-parameters of every kernel family, the covariance functions,
+the log parametrisation (kernel.py:127-130), the log marginal likelihood (inference.py:210) and the order of
+`gp.hyperparameters` = [noise variance | kernel parameters] (gp.py:408-414)."""
+import numpy as np
+import pytest
+
+from oracle import gp
+from oracle.gp_fit import fit
+
+x = gp.park_miller_randn(.8, (20, 1))
+y = np.sin(3 * x) + .1 * gp.park_miller_randn(.9, (20, 1))
+X, Y = x.T, y.T
+
+# (kernel, names in the reference's hyper-parameter order, fixed arguments, labels, expected, rtol)
+CASES = [
+    ('squared_exponential', ['length_scales', 'signal_variance'], {}, Y, [.0085251, .5298217, .8114553], 1e-5),
+    ('constant', ['bias'], {}, Y + 3., [.7009480, 3.0498634], 1e-5),
+    ('matern_32', ['length_scales', 'signal_variance'], {}, Y, [.0088262, .8329355, .9398366], 1e-5),
+    ('matern_52', ['length_scales', 'signal_variance'], {}, Y, [.0086694, .7180206, .9571137], 1e-5),
+    ('matern', ['length_scales', 'signal_variance'], {'p': 3}, Y, [.0086179, .6666981, .9421087], 1e-5),
+    ('piecewise_polynomial', ['length_scales', 'signal_variance'], {'degree': 1}, Y, [.0088391, 1.6079331, .6545336], 1e-5),
+    ('piecewise_polynomial', ['length_scales', 'signal_variance'], {'degree': 2}, Y, [.0088244, 2.0883167, .852502], 1e-5),
+    ('piecewise_polynomial', ['length_scales', 'signal_variance'], {'degree': 3}, Y, [.0086766, 2.247363, .7873581], 1e-5),
+    ('polynomial', ['signal_variance', 'offset'], {'degree': 3}, Y, [.0980796, 1.3112287, .5083423], 1e-5),
+    ('linear', ['signal_variance'], {}, Y, [.6627861, .008198], 1e-4),
+    ('neural_network', ['signal_variance', 'weight_variance'], {}, Y, [.0095177, 5.7756069, .1554265], 1e-5),
+    ('periodic', ['signal_variance', 'length_scales', 'period'], {}, Y, [.4975112, .159969, .5905631, .8941061], 1e-3),
+]
+
+
+@pytest.mark.parametrize('kernel,names,fixed,labels,expected,rtol', CASES,
+                         ids=[c[0] + ''.join(f'_{v}' for v in c[2].values()) for c in CASES])
+def test_fit_reproduces_the_reference_optima(kernel, names, fixed, labels, expected, rtol):
+    values, _ = fit(kernel, names, X, labels, noise_variance=np.exp(-2), fixed=fixed)
+    np.testing.assert_allclose(values, expected, rtol=max(rtol, 2e-6))      # the expected values carry 7 digits
+
+
+def test_exponential_kernel_drives_the_noise_to_zero():
+    """tests/test_GPs.py:856-861: noise variance < 1e-5, the other two to 1e-5."""
+    values, _ = fit('exponential', ['length_scales', 'signal_variance'], X, Y, noise_variance=np.exp(-2))
+    assert values[0] < 1e-5
+    np.testing.assert_allclose(values[1:], [.9769135, .5935212], rtol=1e-5)
+
+
+def test_rational_quadratic_flat_direction():
+    """tests/test_GPs.py:871-877: alpha runs off along a flat direction and is ignored; the others are the SE optimum."""
+    values, fv = fit('rational_quadratic', ['length_scales', 'signal_variance', 'alpha'], X, Y, noise_variance=np.exp(-2))
+    np.testing.assert_allclose(values[:3], [.00852509, .529822, .811455], rtol=2e-4)
+    assert values[3] > 1e3
+    se, fse = fit('squared_exponential', ['length_scales', 'signal_variance'], X, Y, noise_variance=np.exp(-2))
+    assert abs(fv - fse) < 1e-5
