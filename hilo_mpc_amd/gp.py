@@ -8,7 +8,8 @@ Inputs are feature-major (n_features x n_observations) exactly like the referenc
 
 A kernel/mean tree is compiled to a flat postfix program (opcodes in include/hilo_hip.h) that the device
 interprets; the numeric work (covariance matrices, Cholesky, alpha, L^-1, predictions) is done by
-libhilo_hip.so only.  Hyper-parameter *fitting* (`fit_model`) is out of scope.
+libhilo_hip.so only.  Hyper-parameter fitting (`fit_model`) drives the device log marginal likelihood
+from a host quasi-Newton loop; an analytic device gradient is the next step.
 """
 import ctypes as C
 from math import factorial, gamma as gamma_fun
@@ -66,6 +67,24 @@ class Kernel:
 
     def __rmul__(self, other):
         return Product(other, self)
+
+    # ---- hyper-parameters (kernel.py:300-350: `hyperparameters`, in declaration order) ----
+    _hyper = ()     # attribute names, in the reference's order
+
+    def hyperparameter_handles(self):
+        """[(owner, attribute, index or None)]: one entry per scalar hyper-parameter (a vector of ARD length scales expands)."""
+        out = []
+        for a in self._hyper:
+            v = getattr(self, a)
+            if _is_list_like(v):
+                out += [(self, a, i) for i in range(len(v))]
+            else:
+                out.append((self, a, None))
+        return out
+
+    @property
+    def hyperparameter_names(self):
+        return [f"{self.acronym}.{a}" + ('' if i is None else f"_{i}") for _, a, i in self.hyperparameter_handles()]
 
     # ---- evaluation ----
     def _active(self, nf):
@@ -141,6 +160,7 @@ class Kernel:
 class ConstantKernel(Kernel):
     """kernel.py:436-485: exp(2 log bias)."""
     acronym = "Const"
+    _hyper = ('bias',)
 
     def __init__(self, bias=1., bounds=None):
         super().__init__()
@@ -153,6 +173,7 @@ class ConstantKernel(Kernel):
 class StationaryKernel(Kernel):
     """kernel.py:488-562."""
     acronym = "Stat"
+    _hyper = ('length_scales', 'signal_variance')
 
     def __init__(self, active_dims=None, length_scales=1., ard=False, bounds=None):
         super().__init__(active_dims=active_dims)
@@ -275,6 +296,7 @@ class Matern52Kernel(MaternKernel):
 class RationalQuadraticKernel(StationaryKernel):
     """kernel.py:919-1003."""
     acronym = "RQ"
+    _hyper = ('length_scales', 'signal_variance', 'alpha')
 
     def __init__(self, active_dims=None, signal_variance=1., length_scales=1., alpha=1., ard=False, bounds=None):
         super().__init__(active_dims, length_scales, ard)
@@ -325,6 +347,7 @@ class DotProductKernel(Kernel):
 class PolynomialKernel(DotProductKernel):
     """kernel.py:1160-1234."""
     acronym = "Poly"
+    _hyper = ('signal_variance', 'offset')
 
     def __init__(self, degree, active_dims=None, signal_variance=1., offset=1., bounds=None):
         super().__init__(active_dims, signal_variance, offset)
@@ -338,6 +361,7 @@ class PolynomialKernel(DotProductKernel):
 class LinearKernel(PolynomialKernel):
     """kernel.py:1237-1259 (degree 1, offset 0)."""
     acronym = "Lin"
+    _hyper = ('signal_variance',)
 
     def __init__(self, active_dims=None, signal_variance=1., bounds=None):
         super().__init__(1, active_dims, signal_variance)
@@ -347,6 +371,7 @@ class LinearKernel(PolynomialKernel):
 class NeuralNetworkKernel(Kernel):
     """kernel.py:1262-1332."""
     acronym = "NN"
+    _hyper = ('signal_variance', 'weight_variance')
 
     def __init__(self, active_dims=None, signal_variance=1., weight_variance=1., bounds=None):
         super().__init__(active_dims=active_dims)
@@ -361,6 +386,7 @@ class NeuralNetworkKernel(Kernel):
 class PeriodicKernel(Kernel):
     """kernel.py:1335-1423 (scalar expression only for one active dimension)."""
     acronym = "Periodic"
+    _hyper = ('signal_variance', 'length_scales', 'period')
 
     def __init__(self, active_dims=None, signal_variance=1., length_scales=1., period=1., bounds=None):
         super().__init__(active_dims=active_dims)
@@ -381,6 +407,17 @@ class KernelOperator(Kernel):
         super().__init__()
         self.kernel_1 = kernel_1
         self.kernel_2 = kernel_2
+
+    def hyperparameter_handles(self):
+        out = self.kernel_1.hyperparameter_handles() if isinstance(self.kernel_1, Kernel) else []
+        if isinstance(self.kernel_2, Kernel):
+            out += self.kernel_2.hyperparameter_handles()
+        return out
+
+    @property
+    def hyperparameter_names(self):
+        out = self.kernel_1.hyperparameter_names if isinstance(self.kernel_1, Kernel) else []
+        return out + (self.kernel_2.hyperparameter_names if isinstance(self.kernel_2, Kernel) else [])
 
 
 class Sum(KernelOperator):
@@ -513,6 +550,7 @@ class PolynomialMean(Mean):
 
 class LinearMean(PolynomialMean):
     acronym = "Lin"
+    _hyper = ('signal_variance',)
 
     def __init__(self, active_dims=None, coefficient=1., hyperprior=None, **kwargs):
         super().__init__(1, active_dims, coefficient)
@@ -634,6 +672,69 @@ class GaussianProcess:
         _lib.check(_lib.lib().hilo_gp_log_marginal_likelihood(self._handle, C.byref(v)))
         return v.value
 
+    # ---- hyper-parameters and their fit (gp.py:408-430, :660-697) ----
+    def _handles(self):
+        return [(self, 'noise_variance', None)] + self.kernel.hyperparameter_handles()
+
+    @property
+    def hyperparameter_names(self):
+        return ['GP.noise_variance'] + self.kernel.hyperparameter_names
+
+    @property
+    def hyperparameter_values(self):
+        """Values in the order of the reference's `gp.hyperparameters`: [noise variance | kernel hyper-parameters]."""
+        return [float(getattr(o, a) if i is None else getattr(o, a)[i]) for o, a, i in self._handles()]
+
+    def _set_hyperparameters(self, values):
+        for (o, a, i), v in zip(self._handles(), values):
+            if i is None:
+                setattr(o, a, float(v))
+            else:
+                cur = list(getattr(o, a))
+                cur[i] = float(v)
+                setattr(o, a, cur)
+
+    def fit_model(self, gtol=1e-8, maxiter=500):
+        """Optimises the hyper-parameters by minimising the negative log marginal likelihood over their logarithms
+        (gp.py:660-697; kernel.py:127-130).  Every objective value is one device factorisation (`hilo_gp_create`) and
+        `hilo_gp_log_marginal_likelihood`; the gradient is taken by central differences of those values (quasi-Newton BFGS
+        on the host - the reference hands the same objective to its NLP solver).  Hyper-parameters of the mean function stay
+        fixed.  Warns, like the reference, when the optimiser does not reach a stationary point."""
+        if self._handle is None:
+            raise RuntimeError("The GP has not been set up yet. Please run the setup() method before fitting.")
+        import warnings
+        from scipy.optimize import minimize
+        dev_index = self._dev.index
+        th0 = np.log(np.asarray(self.hyperparameter_values, dtype=float))
+        if not np.all(np.isfinite(th0)):
+            raise ValueError("Hyper-parameters must be positive to be fitted in log space")
+
+        def f(th):
+            self._set_hyperparameters(np.exp(th))
+            try:
+                self.setup(device_index=dev_index)
+                v = -self.log_marginal_likelihood()
+            except _lib.HiloError:              # covariance matrix not positive definite at this trial point
+                return np.inf
+            return v if np.isfinite(v) else np.inf
+
+        def g(th, h=1e-6):
+            out = np.zeros_like(th)
+            for i in range(th.size):
+                e = np.zeros_like(th)
+                e[i] = h
+                out[i] = (f(th + e) - f(th - e)) / (2 * h)
+            return out
+        res = minimize(f, th0, jac=g, method='BFGS', options={'gtol': gtol, 'maxiter': maxiter})
+        gn = float(np.max(np.abs(g(res.x))))
+        self._optimization_stats = {'success': bool(res.success or gn < 1e-4), 'message': str(res.message),
+                                    'iter_count': int(res.nit), 'max_gradient': gn, 'fun': float(res.fun)}
+        self._set_hyperparameters(np.exp(res.x))
+        self.setup(device_index=dev_index)
+        if not self._optimization_stats['success']:
+            warnings.warn(f"Fitting of GP didn't terminate successfully\nSolver message: {res.message}\n"
+                          f"Try to use a different solver")
+
     def predict(self, X_query, noise_free=False, return_var=True):
         """gp.py:699-718: returns (mean (1 x m), var (1 x m)); numpy in -> numpy out, device tensor in -> tensor out."""
         if self._handle is None:
@@ -653,6 +754,3 @@ class GaussianProcess:
         if host:
             return mean.cpu().numpy(), (var.cpu().numpy() if return_var else None)
         return mean, var
-
-    def fit_model(self):
-        raise NotImplementedError("Hyper-parameter fitting is outside the accelerated hot path (SURVEY.md 8f rank 2)")

@@ -111,3 +111,38 @@ def test_gp_not_positive_definite_is_an_error():
     gp.set_training_data(np.array([[1., 2., 3.]]), np.array([[1., 2., 3.]]))
     with pytest.raises(ValueError, match="not positive definite"):
         gp.setup()
+
+
+@pytest.mark.parametrize('make,shift,expected,rtol', [
+    (lambda K: None, 0., [.0085251, .5298217, .8114553], 1e-5),                       # default kernel: squared exponential
+    (lambda K: K.constant(), 3., [.7009480, 3.0498634], 1e-5),
+    (lambda K: K.matern_32(), 0., [.0088262, .8329355, .9398366], 1e-5),
+    (lambda K: K.neural_network(), 0., [.0095177, 5.7756069, .1554265], 1e-5),
+], ids=['SE', 'Const', 'M32', 'NN'])
+def test_fit_model_reference_kats(make, shift, expected, rtol):
+    """`GaussianProcess.fit_model()` on the device objective against the reference's fitted-value known answers
+    (tests/test_GPs.py:846-904, data set :835-838); a successful fit does not warn (:912-916)."""
+    import warnings
+    from hilo_mpc_amd import GP, Kernel
+    x = ogp.park_miller_randn(.8, (20, 1))
+    y = np.sin(3 * x) + .1 * ogp.park_miller_randn(.9, (20, 1)) + shift
+    g = GP(['x'], ['y'], kernel=make(Kernel), noise_variance=np.exp(-2))
+    g.set_training_data(x.T, y.T)
+    g.setup()
+    lml0 = g.log_marginal_likelihood()
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        g.fit_model()
+    np.testing.assert_allclose(g.hyperparameter_values, expected, rtol=max(rtol, 2e-6))
+    assert g.log_marginal_likelihood() > lml0 and g._optimization_stats['success']
+    xs = np.linspace(-3, 3, 61).reshape(1, -1)
+    mean, var = g.predict(xs)                                                            # the fitted model is set up
+    post = ogp.Posterior(_spec_of(g.kernel), {'type': 'zero'}, x.T, y.T, g.noise_variance)
+    mo, vo = post.predict(xs)
+    np.testing.assert_allclose(mean, mo, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(var, vo, rtol=1e-5, atol=1e-9)
+
+
+def _spec_of(k):
+    t = {'SE': 'squared_exponential', 'Const': 'constant', 'M32': 'matern_32', 'NN': 'neural_network'}[k.acronym]
+    return {'type': t, 'kwargs': {a: getattr(k, a) for a in k._hyper}}

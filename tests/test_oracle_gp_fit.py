@@ -51,3 +51,50 @@ def test_rational_quadratic_flat_direction():
     assert values[3] > 1e3
     se, fse = fit('squared_exponential', ['length_scales', 'signal_variance'], X, Y, noise_variance=np.exp(-2))
     assert abs(fv - fse) < 1e-5
+
+
+# ---- the product's fit_model() driver (host logic) with the device objective replaced by the oracle's LML ----------------
+_ORACLE_TYPE = {'SE': 'squared_exponential', 'Const': 'constant', 'M32': 'matern_32', 'M52': 'matern_52', 'Lin': 'linear',
+                'NN': 'neural_network', 'Periodic': 'periodic', 'Poly': 'polynomial', 'PP': 'piecewise_polynomial',
+                'RQ': 'rational_quadratic', 'E': 'exponential'}
+
+
+def _host_fit(kernel, labels):
+    """GaussianProcess.fit_model with setup()/log_marginal_likelihood() served by the oracle (no device needed)."""
+    import types
+    from hilo_mpc_amd import GP
+    g = GP(['x'], ['y'], kernel=kernel, noise_variance=np.exp(-2))
+    g.set_training_data(X, labels)
+
+    def setup(self, device_index=None, **kw):
+        k = self.kernel
+        kwargs = {a: getattr(k, a) for a in k._hyper}
+        if hasattr(k, 'degree'):
+            kwargs['degree'] = k.degree
+        self._post = gp.Posterior({'type': _ORACLE_TYPE[k.acronym], 'kwargs': kwargs}, {'type': 'zero'}, self._X_train,
+                                  self._y_train, self.noise_variance)
+        self._handle = object()
+        self._dev = types.SimpleNamespace(index=0)
+    g.setup = types.MethodType(setup, g)
+    g.log_marginal_likelihood = types.MethodType(lambda self: self._post.lml, g)
+    g._destroy = types.MethodType(lambda self: None, g)
+    g.setup()
+    g.fit_model()
+    return g
+
+
+@pytest.mark.parametrize('make,labels,expected,rtol', [
+    (lambda K: K.squared_exponential(), Y, [.0085251, .5298217, .8114553], 1e-5),
+    (lambda K: K.constant(), Y + 3., [.7009480, 3.0498634], 1e-5),
+    (lambda K: K.matern_52(), Y, [.0086694, .7180206, .9571137], 1e-5),
+    (lambda K: K.polynomial(3), Y, [.0980796, 1.3112287, .5083423], 1e-5),
+    (lambda K: K.periodic(), Y, [.4975112, .159969, .5905631, .8941061], 1e-3),
+], ids=['SE', 'Const', 'M52', 'Poly', 'Periodic'])
+def test_product_fit_driver_reproduces_the_reference_optima(make, labels, expected, rtol):
+    import warnings
+    from hilo_mpc_amd import Kernel
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                      # a successful fit must not warn (tests/test_GPs.py:912-916)
+        g = _host_fit(make(Kernel), labels)
+    np.testing.assert_allclose(g.hyperparameter_values, expected, rtol=max(rtol, 2e-6))
+    assert g._optimization_stats['success'] and g.hyperparameter_names[0] == 'GP.noise_variance'
