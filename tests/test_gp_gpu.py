@@ -118,7 +118,14 @@ def test_gp_not_positive_definite_is_an_error():
     (lambda K: K.constant(), 3., [.7009480, 3.0498634], 1e-5),
     (lambda K: K.matern_32(), 0., [.0088262, .8329355, .9398366], 1e-5),
     (lambda K: K.neural_network(), 0., [.0095177, 5.7756069, .1554265], 1e-5),
-], ids=['SE', 'Const', 'M32', 'NN'])
+    (lambda K: K.matern_52(), 0., [.0086694, .7180206, .9571137], 1e-5),
+    (lambda K: K.piecewise_polynomial(1), 0., [.0088391, 1.6079331, .6545336], 1e-5),
+    (lambda K: K.piecewise_polynomial(2), 0., [.0088244, 2.0883167, .852502], 1e-5),
+    (lambda K: K.piecewise_polynomial(3), 0., [.0086766, 2.247363, .7873581], 1e-5),
+    (lambda K: K.polynomial(3), 0., [.0980796, 1.3112287, .5083423], 1e-5),
+    (lambda K: K.linear(), 0., [.6627861, .008198], 1e-4),
+    (lambda K: K.periodic(), 0., [.4975112, .159969, .5905631, .8941061], 1e-3),
+], ids=['SE', 'Const', 'M32', 'NN', 'M52', 'PP1', 'PP2', 'PP3', 'Poly', 'Lin', 'Periodic'])
 def test_fit_model_reference_kats(make, shift, expected, rtol):
     """`GaussianProcess.fit_model()` on the device objective against the reference's fitted-value known answers
     (tests/test_GPs.py:846-904, data set :835-838); a successful fit does not warn (:912-916)."""
@@ -144,5 +151,9 @@ def test_fit_model_reference_kats(make, shift, expected, rtol):
 
 
 def _spec_of(k):
-    t = {'SE': 'squared_exponential', 'Const': 'constant', 'M32': 'matern_32', 'NN': 'neural_network'}[k.acronym]
-    return {'type': t, 'kwargs': {a: getattr(k, a) for a in k._hyper}}
+    t = {'SE': 'squared_exponential', 'Const': 'constant', 'M32': 'matern_32', 'NN': 'neural_network', 'M52': 'matern_52',
+         'PP': 'piecewise_polynomial', 'Poly': 'polynomial', 'Lin': 'linear', 'Periodic': 'periodic'}[k.acronym]
+    kw = {a: getattr(k, a) for a in k._hyper}
+    if hasattr(k, 'degree'):
+        kw['degree'] = k.degree
+    return {'type': t, 'kwargs': kw}
