@@ -177,7 +177,7 @@ def main():
                              "algorithmic_bytes_per_launch": bytes_launch,
                              "note": "compulsory bytes only (iterate + parameters in/out); not the binding roof"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only
             ns = 40
             v, secs = cpu_baseline(spec, c2_x0(ns), 8)
             out["cpu_baseline"] = {"value": v, "unit": "steps/s", "cores": 1, "kind": "port",
