@@ -666,11 +666,56 @@ class GaussianProcess:
             pass
 
     def log_marginal_likelihood(self):
+        """Log marginal likelihood of the training data plus the log densities of the hyper-priors (gp.py:553-559)."""
         if self._handle is None:
             raise RuntimeError("The GP has not been set up yet. Please run the setup() method before predicting.")
         v = C.c_double()
         _lib.check(_lib.lib().hilo_gp_log_marginal_likelihood(self._handle, C.byref(v)))
-        return v.value
+        return v.value + self._log_hyperprior()
+
+    # ---- hyper-priors (util/probability.py:61-118, 171-217; gp.py:553-559) ----
+    def set_hyperprior(self, name, prior, mean=0., variance=1., nu=None):
+        """Prior on the hyper-parameter `name` (one of `hyperparameter_names`; `prior`: 'Gaussian', 'Laplace', 'Students_T' or
+        None to remove it).  The reference attaches it as `parameter.prior = 'Laplace'; parameter.prior.mean = ...`; like
+        there the density is evaluated at the optimisation variable - log(value), or log(value)/2 for a `*variance*`
+        parameter - and its logarithm is added to the log marginal likelihood that `fit_model` maximises."""
+        names = self.hyperparameter_names
+        if name not in names:
+            raise KeyError(f"'{name}' is not among the hyper-parameters {names}")
+        if not hasattr(self, '_priors'):
+            self._priors = {}
+        if prior is None:
+            self._priors.pop(name, None)
+            return
+        kind = str(prior).lower().replace("'", '').replace(' ', '_')
+        if kind not in ('gaussian', 'laplace', 'students_t'):
+            raise ValueError(f"Prior '{prior}' not recognized")
+        if kind == 'students_t' and (nu is None or nu <= 2.):
+            raise ValueError("The Student's t prior needs nu > 2")
+        if not variance > 0.:
+            raise ValueError("The variance of a prior must be positive")
+        self._priors[name] = (kind, float(mean), float(variance), None if nu is None else float(nu))
+
+    def _log_hyperprior(self):
+        priors = getattr(self, '_priors', None)
+        if not priors:
+            return 0.
+        from math import lgamma, log, pi, sqrt
+        total = 0.
+        for name, value in zip(self.hyperparameter_names, self.hyperparameter_values):
+            if name not in priors:
+                continue
+            kind, mu, var, nu = priors[name]
+            w = log(value) / 2. if 'variance' in name else log(value)
+            if kind == 'gaussian':
+                total += -(w - mu) ** 2 / (2. * var) - log(2. * pi * var) / 2.
+            elif kind == 'laplace':
+                b = sqrt(var / 2.)
+                total += -abs(w - mu) / b - log(2. * b)
+            else:
+                total += lgamma((nu + 1.) / 2.) - lgamma(nu / 2.) - log(var * (nu - 2.) * pi) / 2. \
+                    - (nu + 1.) / 2. * log(1. + (w - mu) ** 2 / (var * (nu - 2.)))
+        return total
 
     # ---- hyper-parameters and their fit (gp.py:408-430, :660-697) ----
     def _handles(self):

@@ -16,7 +16,23 @@ from scipy.optimize import minimize
 from oracle.gp import Posterior
 
 
-def negative_lml(kernel_type, names, theta, X, y, fixed=None, mean_spec=None):
+def log_prior(kind, w, mean, variance, nu=None):
+    """Log density of a hyper-prior at the optimisation variable w (util/probability.py:61-118; gp.py:553-559: the prior is
+    evaluated at log(value), or log(value)/2 for a `*variance*` parameter, and ADDED to the log marginal likelihood)."""
+    from math import lgamma
+    kind = kind.lower()
+    if kind == 'gaussian':
+        return -(w - mean) ** 2 / (2. * variance) - np.log(2. * np.pi * variance) / 2.
+    if kind == 'laplace':
+        b = np.sqrt(variance / 2.)
+        return -abs(w - mean) / b - np.log(2. * b)
+    if kind in ('students_t', "student's_t", 'studentst'):
+        log_z = lgamma((nu + 1.) / 2.) - lgamma(nu / 2.) - np.log(variance * (nu - 2.) * np.pi) / 2.
+        return log_z - (nu + 1.) / 2. * np.log(1. + (w - mean) ** 2 / (variance * (nu - 2.)))
+    raise ValueError(f"unknown prior {kind}")
+
+
+def negative_lml(kernel_type, names, theta, X, y, fixed=None, mean_spec=None, priors=None):
     """theta = logs of [noise variance | the kernel hyper-parameters `names`]."""
     kw = dict(fixed or {})
     kw.update({n: float(np.exp(t)) for n, t in zip(names, theta[1:])})
@@ -24,16 +40,23 @@ def negative_lml(kernel_type, names, theta, X, y, fixed=None, mean_spec=None):
         post = Posterior({'type': kernel_type, 'kwargs': kw}, mean_spec or {'type': 'zero'}, X, y, float(np.exp(theta[0])))
     except np.linalg.LinAlgError:
         return np.inf
-    return -post.lml if np.isfinite(post.lml) else np.inf
+    if not np.isfinite(post.lml):
+        return np.inf
+    # theta holds log(value); the reference's variable of a `*variance*` parameter is log(value) / 2
+    all_names = ['noise_variance'] + list(names)
+    lp = sum(log_prior(kind, theta[i] / 2. if 'variance' in all_names[i] else theta[i], *args)
+             for i, (kind, *args) in (priors or {}).items())
+    return -(post.lml + lp)
 
 
-def fit(kernel_type, names, X, y, noise_variance=1., start=None, fixed=None, mean_spec=None, h=1e-6):
-    """Returns (values [noise variance | names...], -LML at the optimum)."""
+def fit(kernel_type, names, X, y, noise_variance=1., start=None, fixed=None, mean_spec=None, h=1e-6, priors=None):
+    """Returns (values [noise variance | names...], -(LML + log priors) at the optimum).  priors: {position in
+    [noise variance | names]: (kind, mean, variance[, nu])}."""
     start = dict(start or {})
     th0 = np.log([noise_variance] + [start.get(n, 1.) for n in names])
 
     def f(th):
-        return negative_lml(kernel_type, names, th, X, y, fixed, mean_spec)
+        return negative_lml(kernel_type, names, th, X, y, fixed, mean_spec, priors)
 
     def g(th):
         out = np.zeros_like(th)

@@ -157,3 +157,30 @@ def _spec_of(k):
     if hasattr(k, 'degree'):
         kw['degree'] = k.degree
     return {'type': t, 'kwargs': kw}
+
+
+def test_hyperprior_kats():
+    """Hyper-priors on the device objective: the reference's LML with a Laplace prior on the length scale
+    (tests/test_GPs.py:366-385) and its fit under a Gaussian prior on the noise variance (:596-621); plain fit (:578-591)."""
+    from hilo_mpc_amd import GP
+    X = np.array([[0., .5, 1. / np.sqrt(2.), np.sqrt(3.) / 2., 1., 0.],
+                  [1., np.sqrt(3.) / 2., 1. / np.sqrt(2.), .5, 0., -1.]])
+    y = np.array([[0., np.pi / 6., np.pi / 4., np.pi / 3., np.pi / 2., np.pi]])
+    g = GP(['x', 'y'], 'z')
+    g.set_training_data(X, y)
+    g.setup()
+    g.set_hyperprior('SE.length_scales', 'Laplace', mean=0., variance=1.)
+    np.testing.assert_approx_equal(g.log_marginal_likelihood(), -10.16887303)
+    g.set_hyperprior('SE.length_scales', None)
+    np.testing.assert_approx_equal(g.log_marginal_likelihood(), -9.82229944)
+    before = g.log_marginal_likelihood()
+    g.fit_model()
+    assert g.log_marginal_likelihood() > before and g.noise_variance < 1e-3
+    h = GP(['x', 'y'], 'z')
+    h.set_hyperprior('GP.noise_variance', 'Gaussian', mean=.2, variance=.01)
+    h.set_training_data(X, y + np.array([[.23757934, .55730318, .02598826, .06349002, .26647032, -.137302]]))
+    h.setup()
+    before = h.log_marginal_likelihood()
+    h.fit_model()
+    assert h.log_marginal_likelihood() > before
+    np.testing.assert_allclose(h.noise_variance, 1.406995, rtol=1e-6)

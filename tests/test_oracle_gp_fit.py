@@ -98,3 +98,62 @@ def test_product_fit_driver_reproduces_the_reference_optima(make, labels, expect
         g = _host_fit(make(Kernel), labels)
     np.testing.assert_allclose(g.hyperparameter_values, expected, rtol=max(rtol, 2e-6))
     assert g._optimization_stats['success'] and g.hyperparameter_names[0] == 'GP.noise_variance'
+
+
+# ---- hyper-priors (tests/test_GPs.py:366-385, :596-621) ----------------------------------------------------------------
+X6 = np.array([[0., .5, 1. / np.sqrt(2.), np.sqrt(3.) / 2., 1., 0.], [1., np.sqrt(3.) / 2., 1. / np.sqrt(2.), .5, 0., -1.]])
+Y6 = np.array([[0., np.pi / 6., np.pi / 4., np.pi / 3., np.pi / 2., np.pi]])
+SE2 = ['length_scales', 'signal_variance']
+
+
+def test_lml_with_laplace_prior_kat():
+    from oracle.gp_fit import negative_lml
+    np.testing.assert_approx_equal(-negative_lml('squared_exponential', SE2, np.zeros(3), X6, Y6), -9.82229944)
+    np.testing.assert_approx_equal(-negative_lml('squared_exponential', SE2, np.zeros(3), X6, Y6,
+                                                 priors={1: ('laplace', 0., 1.)}), -10.16887303)
+
+
+def test_fit_with_gaussian_prior_kat():
+    y2 = Y6 + np.array([[.23757934, .55730318, .02598826, .06349002, .26647032, -.137302]])
+    values, _ = fit('squared_exponential', SE2, X6, y2, noise_variance=1., priors={0: ('gaussian', .2, .01)})
+    np.testing.assert_allclose(values[0], 1.406995, rtol=1e-6)
+    plain, _ = fit('squared_exponential', SE2, X6, Y6, noise_variance=1.)
+    assert plain[0] < 1e-3                                                  # tests/test_GPs.py:578-591
+
+
+def test_product_hyperprior_driver():
+    """The product's prior bookkeeping and fit driver (device objective replaced by the oracle's LML)."""
+    import types
+    from hilo_mpc_amd import GP
+    g = GP(['x', 'y'], 'z')
+    g.set_training_data(X6, Y6)
+
+    def setup(self, device_index=None, **kw):
+        k = self.kernel
+        self._post = gp.Posterior({'type': 'squared_exponential', 'kwargs': {a: getattr(k, a) for a in k._hyper}},
+                                  {'type': 'zero'}, self._X_train, self._y_train, self.noise_variance)
+        self._handle, self._dev = object(), types.SimpleNamespace(index=0)
+    import ctypes
+    g.setup = types.MethodType(setup, g)
+    g._destroy = types.MethodType(lambda self: None, g)
+    g.setup()
+    base = type(g).log_marginal_likelihood
+
+    def lml(self):
+        return self._post.lml + self._log_hyperprior()
+    g.log_marginal_likelihood = types.MethodType(lml, g)
+    np.testing.assert_approx_equal(g.log_marginal_likelihood(), -9.82229944)
+    with pytest.raises(KeyError):
+        g.set_hyperprior('SE.nope', 'Laplace')
+    with pytest.raises(ValueError, match="not recognized"):
+        g.set_hyperprior('SE.length_scales', 'Cauchy')
+    g.set_hyperprior('SE.length_scales', 'Laplace', mean=0., variance=1.)
+    np.testing.assert_approx_equal(g.log_marginal_likelihood(), -10.16887303)
+    g.set_hyperprior('SE.length_scales', None)
+    g.set_hyperprior('GP.noise_variance', 'Gaussian', mean=.2, variance=.01)
+    g.set_training_data(X6, Y6 + np.array([[.23757934, .55730318, .02598826, .06349002, .26647032, -.137302]]))
+    g.setup()
+    before = g.log_marginal_likelihood()
+    g.fit_model()
+    assert g.log_marginal_likelihood() > before
+    np.testing.assert_allclose(g.noise_variance, 1.406995, rtol=1e-6)
