@@ -717,6 +717,24 @@ class GaussianProcess:
                     - (nu + 1.) / 2. * log(1. + (w - mu) ** 2 / (var * (nu - 2.)))
         return total
 
+    def predict_quantiles(self, quantiles=None, X_query=None, mean=None, var=None):
+        """gp.py:720-746: (lower, upper) = mean + Phi^-1(q / 100) sqrt(var + noise variance) for the two percentages in
+        `quantiles` (default 2.5 / 97.5), from a noise-free prediction at `X_query` or from a given mean / variance."""
+        from scipy.special import ndtri
+        if quantiles is None:
+            quantiles = (2.5, 97.5)
+        if X_query is not None:
+            mean, var = self.predict(X_query, noise_free=True)
+        elif mean is None and var is None:
+            return None
+        tensor = isinstance(mean, torch.Tensor)
+        m = mean.cpu().numpy() if tensor else np.asarray(mean, dtype=float)
+        v = var.cpu().numpy() if isinstance(var, torch.Tensor) else np.asarray(var, dtype=float)
+        out = [float(ndtri(q / 100.)) * np.sqrt(v + float(self.noise_variance)) + m for q in quantiles]
+        if tensor:
+            out = [torch.as_tensor(o, device=mean.device) for o in out]
+        return out[0], out[1]
+
     # ---- hyper-parameters and their fit (gp.py:408-430, :660-697) ----
     def _handles(self):
         return [(self, 'noise_variance', None)] + self.kernel.hyperparameter_handles()

@@ -184,3 +184,34 @@ def test_hyperprior_kats():
     h.fit_model()
     assert h.log_marginal_likelihood() > before
     np.testing.assert_allclose(h.noise_variance, 1.406995, rtol=1e-6)
+
+
+def test_fit_then_predict_quantiles_like_the_reference_tests():
+    """tests/test_GPs.py:625-740: fit on six noisy points, noise-free prediction has the same mean and a smaller variance,
+    and the predictive quantiles bracket the mean and both generating functions."""
+    from hilo_mpc_amd import GP
+    X = np.array([[0., .5, 1. / np.sqrt(2.), np.sqrt(3.) / 2., 1., 0.],
+                  [1., np.sqrt(3.) / 2., 1. / np.sqrt(2.), .5, 0., -1.]])
+    y = np.array([[0., np.pi / 6., np.pi / 4., np.pi / 3., np.pi / 2., np.pi]])
+    y = y + np.array([[0.05850223, 0.09876431, -0.05570195, 0.15573265, 0.03278181, -0.06901315]])
+    g = GP(['x', 'y'], 'z')
+    with pytest.raises(RuntimeError, match="has not been set up yet"):
+        g.predict(np.array([0., 1.]))
+    g.set_training_data(X, y)
+    g.setup()
+    g.fit_model()
+    Xq = np.array([[.25, .6, .75, .9, .4], [.9, .75, .6, .25, -.5]])
+    mean, var = g.predict(Xq)
+    mean_nf, var_nf = g.predict(Xq, noise_free=True)
+    np.testing.assert_allclose(mean, mean_nf)
+    np.testing.assert_array_less(var_nf, var)
+    y_sin = np.array([[np.arcsin(.25), np.arcsin(.6), np.arcsin(.75), np.arcsin(.9), np.pi + np.arcsin(-.4)]])
+    y_cos = np.array([[np.arccos(.9), np.arccos(.75), np.arccos(.6), np.arccos(.25), np.arccos(-.5)]])
+    for lb, ub in (g.predict_quantiles(X_query=Xq), g.predict_quantiles(quantiles=(1., 99.), mean=mean_nf, var=var_nf)):
+        for inner in (mean, y_sin, y_cos):
+            np.testing.assert_array_less(lb, inner)
+            np.testing.assert_array_less(inner, ub)
+    assert g.predict_quantiles() is None
+    from scipy.stats import norm
+    lb, ub = g.predict_quantiles(X_query=Xq)
+    np.testing.assert_allclose(ub, mean_nf + norm.ppf(.975) * np.sqrt(var_nf + g.noise_variance), rtol=1e-12)
