@@ -74,3 +74,40 @@ def test_product_never_imports_oracle():
             if f.endswith(('.py', '.hip', '.h')):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), f
+
+
+def test_descriptor_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors in hilo_mpc_amd/_lib.py against include/hilo_hip.h compiled by gcc: same field names, order,
+    offsets and sizes for every descriptor struct (a drifted field would silently shift everything behind it)."""
+    import ctypes as C
+    import re
+    import shutil
+    import subprocess
+    from hilo_mpc_amd import _lib
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    header = open(os.path.join(ROOT, 'include', 'hilo_hip.h')).read()
+    pairs = [('hilo_kf_desc', _lib.KfDesc), ('hilo_nmpc_desc', _lib.NmpcDesc), ('hilo_mhe_desc', _lib.MheDesc)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hilo_hip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), header, re.S).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        fields = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if decl:                                      # `type a, b, *c` declares several fields
+                for part in decl.split(','):
+                    fields.append(re.sub(r'\[.*\]', '', part.replace('*', ' ').split()[-1]))
+        assert fields == [f[0] for f in cls._fields_], (cname, fields, [f[0] for f in cls._fields_])
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        lines += [f'  printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));' for f in fields]
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).strip().split('\n'))
+    for cname, cls in pairs:
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(got[f'{cname}.{f}']) == getattr(cls, f).offset, (cname, f)
