@@ -111,3 +111,17 @@ def test_descriptor_layouts_match_the_header(tmp_path):
         assert int(got[cname]) == C.sizeof(cls), cname
         for f, _ in cls._fields_:
             assert int(got[f'{cname}.{f}']) == getattr(cls, f).offset, (cname, f)
+
+
+def test_opcode_tables_match_the_header():
+    """Every `HILO_X_*` (expression VM), `HILO_K_*` (kernels) and `HILO_M_*` (means) opcode of the header has the same value
+    in the host-side compilers (hilo_mpc_amd/expr.py, hilo_mpc_amd/gp.py)."""
+    import re
+    from hilo_mpc_amd import expr, gp
+    header = open(os.path.join(ROOT, 'include', 'hilo_hip.h')).read()
+    seen = 0
+    for prefix, mod in (('X', expr), ('K', gp), ('M', gp)):
+        for name, value in re.findall(r'#define HILO_%s_(\w+)\s+(\(?-?\d+\)?)' % prefix, header):
+            assert getattr(mod, f'{prefix}_{name}') == int(value.strip('()')), (prefix, name)
+            seen += 1
+    assert seen >= 16 + 11 + 6
