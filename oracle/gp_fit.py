@@ -67,3 +67,35 @@ def fit(kernel_type, names, X, y, noise_variance=1., start=None, fixed=None, mea
         return out
     res = minimize(f, th0, jac=g, method='BFGS', options={'gtol': 1e-8, 'maxiter': 1000})
     return np.exp(res.x), float(res.fun)
+
+
+def lml_gradient(kernel_type, names, theta, X, y, fixed=None, mean_spec=None, h=1e-6):
+    """d LML / d theta by the trace formula (Rasmussen & Williams eq. 5.9): 1/2 tr((alpha alpha^T - K_y^-1) dK_y/dtheta_i),
+    K_y = K + sn2 I, with dK/dtheta_i of the KERNEL MATRIX by central differences (the covariance functions are cheap;
+    the factorisation is reused for every i).  This is the shape the device gradient kernel will have: one factorisation,
+    one kernel-matrix derivative per hyper-parameter, one trace."""
+    from oracle.gp import kernel
+    from scipy.linalg import cho_solve
+
+    def K_of(th):
+        kw = dict(fixed or {})
+        kw.update({n: float(np.exp(t)) for n, t in zip(names, th[1:])})
+        Xa = np.atleast_2d(np.asarray(X, dtype=float))
+        return kernel({'type': kernel_type, 'kwargs': kw}, Xa, Xa) + np.exp(theta_noise(th)) * np.eye(Xa.shape[1])
+
+    def theta_noise(th):
+        return th[0]                                      # theta_0 = log(noise variance)
+    theta = np.asarray(theta, dtype=float)
+    kw = dict(fixed or {})
+    kw.update({n: float(np.exp(t)) for n, t in zip(names, theta[1:])})
+    post = Posterior({'type': kernel_type, 'kwargs': kw}, mean_spec or {'type': 'zero'}, X, y, float(np.exp(theta[0])))
+    n = post.R.shape[0]
+    Kinv = cho_solve((post.R, False), np.eye(n))
+    A = np.outer(post.alpha, post.alpha) - Kinv
+    g = np.zeros_like(theta)
+    for i in range(theta.size):
+        e = np.zeros_like(theta)
+        e[i] = h
+        dK = (K_of(theta + e) - K_of(theta - e)) / (2 * h)
+        g[i] = 0.5 * np.sum(A * dK)                       # tr(A dK), both symmetric
+    return g

@@ -157,3 +157,18 @@ def test_product_hyperprior_driver():
     g.fit_model()
     assert g.log_marginal_likelihood() > before
     np.testing.assert_allclose(g.noise_variance, 1.406995, rtol=1e-6)
+
+
+@pytest.mark.parametrize('kernel,names,fixed', [(c[0], c[1], c[2]) for c in CASES[:1] + CASES[2:4] + CASES[8:11]],
+                         ids=['SE', 'M32', 'M52', 'Poly', 'Lin', 'NN'])
+def test_trace_formula_gradient_matches_finite_differences_of_the_lml(kernel, names, fixed):
+    """1/2 tr((alpha alpha^T - K^-1) dK/dtheta) against central differences of the LML itself; zero at the fitted optimum."""
+    from oracle.gp_fit import lml_gradient, negative_lml
+    th = np.log([np.exp(-2)] + [1.3, .7, 1.1][:len(names)])
+    g = lml_gradient(kernel, names, th, X, Y, fixed=fixed)
+    h = 1e-6
+    fd = np.array([-(negative_lml(kernel, names, th + h * e, X, Y, fixed) - negative_lml(kernel, names, th - h * e, X, Y, fixed))
+                   / (2 * h) for e in np.eye(th.size)])
+    np.testing.assert_allclose(g, fd, rtol=2e-6, atol=2e-7)
+    values, _ = fit(kernel, names, X, Y, noise_variance=np.exp(-2), fixed=fixed)
+    assert np.max(np.abs(lml_gradient(kernel, names, np.log(values), X, Y, fixed=fixed))) < 2e-4
