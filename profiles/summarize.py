@@ -7,7 +7,6 @@ summaries under profiles/: the --stats table, per-launch durations of the domina
 import csv
 import json
 import os
-import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
