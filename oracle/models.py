@@ -237,7 +237,20 @@ def robot6():
                        [vx, a * sp.cos(psi), vy, a * sp.sin(psi), om, al], [px, py])
 
 
+def cstr3():
+    """Reversible exothermic reaction A <-> B in a cooled CSTR, `docs/docsource/examples/CSTR_Example.ipynb` cell 6
+    (`true_plant_model`, constants of cell 4): states C_A, C_B, T; input Q; measurement r (the reaction rate)."""
+    CA, CB, T, Q = sp.symbols('C_A C_B T Q')
+    T_0, tau, k_A, k_B, E_A, E_B, R, dH, rho, Cp, C_A_0, V = 400, 60, 5000, 1e6, 1e4, 1.5e4, 1.987, -5000, 1, 1000, 1, 100
+    r = k_A * sp.exp((-E_A) / (R * T)) * CA - k_B * sp.exp((-E_B) / (R * T)) * CB
+    dCA = sp.Rational(1, 1) / tau * (C_A_0 - CA) - r
+    dCB = -sp.Rational(1, 1) / tau * CB + r
+    dT = -(dH * r) / (rho * Cp) + sp.Rational(1, 1) / tau * (T_0 - T) + Q / (rho * Cp * V)
+    return OracleModel('cstr3', MODEL_CSTR3, [CA, CB, T], [Q], [], [dCA, dCB, dT], [r])
+
+
 ZOO = {
+    'cstr3': cstr3,
     'linear2': linear2_kat,
     'toy1d': toy1d,
     'bioreactor3': bioreactor3,

@@ -195,11 +195,19 @@ class IpmOptions:
     kappa_w_plus = 8.
     kappa_w_plus_bar = 100.
 
+    compl_inf_tol = 1e-4
+
     def __init__(self, **kw):
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise ValueError(f"unknown option {k}")
             setattr(self, k, v)
+
+    def mu_floor(self):
+        """Smallest barrier parameter of the monotone update.  W&B eq. (7) writes eps_tol / 10; IPOPT's implementation
+        (MonotoneMuUpdate::CalcNewMuAndTau) uses min(tol, compl_inf_tol) / (barrier_tol_factor + 1) = tol / 11 with the
+        defaults - the value that reproduces the last printed digit of the CSTR notebook's input (59882.1817)."""
+        return min(self.tol, self.compl_inf_tol) / (self.kappa_eps + 1.)
 
 
 def _inertia_ok(K, n_pos, n_neg):
@@ -448,11 +456,11 @@ class DenseIpm:
             # ---- barrier parameter update (monotone; W&B eq. 7) ----
             for _ in range(20):
                 Emu = self.errors(g, c, J, lam[idx], zl[idx], zu[idx], w[idx], mu[idx])[0]
-                dec = (Emu <= o.kappa_eps * mu[idx]) & (mu[idx] > o.tol / 10 * (1 + 1e-12))
+                dec = (Emu <= o.kappa_eps * mu[idx]) & (mu[idx] > o.mu_floor() * (1 + 1e-12))
                 if not dec.any():
                     break
                 j = idx[dec]
-                mu[j] = np.maximum(o.tol / 10, np.minimum(o.kappa_mu * mu[j], mu[j] ** o.theta_mu))
+                mu[j] = np.maximum(o.mu_floor(), np.minimum(o.kappa_mu * mu[j], mu[j] ** o.theta_mu))
                 tau[j] = np.maximum(o.tau_min, 1 - mu[j])
                 for b in j:
                     filt[b] = []

@@ -57,9 +57,23 @@ def polynomial_basis(d, method='radau'):
 
 
 class CollNmpcProblem(NmpcProblem):
-    def __init__(self, model, dt, N, degree=3, points='radau', **kw):
+    """`objective`: 'discrete' = sum_k l(x_k, u_k) (mpc.py:1676-1680), 'continuous' = the quadrature of the Lagrange term
+    through the collocation polynomial, sum_k dt sum_i B_i l(x_{k,i}, u_k) (modeling.py:1195; the reference's default for a
+    continuous model, optimizer.py:1423-1426).
+    `generic_stage` / `generic_term`: sympy expressions of the model's symbols, the `GenericCost` of
+    `nmpc.stage_cost.cost = ...` / `nmpc.terminal_cost.cost = ...` (modeling.py:38-87, mpc.py:213-218).  QUIRK restated: the
+    expression is attached to the model as its quadrature function AFTER the model was scaled (mpc.py:1210 then :1283), and
+    `Model.scale` only substitutes inside the model's own equations (base.py:1169-1179), so the cost's symbols ARE the scaled
+    NLP variables: l is evaluated at (x / x_scaling, u / u_scaling), unlike the dynamics."""
+
+    def __init__(self, model, dt, N, degree=3, points='radau', objective='discrete', generic_stage=None,
+                 generic_term=None, **kw):
         super().__init__(model, dt, N, **kw)
         assert not model.discrete, "collocation needs the continuous model"
+        assert objective in ('discrete', 'continuous')
+        self.objective = objective
+        self.gen_stage = self._gen(generic_stage, model.x + model.u)
+        self.gen_term = self._gen(generic_term, model.x)
         self.d = degree
         self.B, self.C, self.D, self.tau = polynomial_basis(degree, points)
         nx, nu, d = self.nx, self.nu, degree
@@ -70,6 +84,59 @@ class CollNmpcProblem(NmpcProblem):
         self.v_lb = np.concatenate([self.v_lb, np.tile(self.x_lb, N * d)])
         self.v_ub = np.concatenate([self.v_ub, np.tile(self.x_ub, N * d)])
         self.v_guess = np.concatenate([self.v_guess, np.tile(self.x_guess, N * d)])
+
+    def _gen(self, expr, w):
+        """value / gradient / Hessian callables of a generic cost w.r.t. the symbols `w` (scaled variables, see class doc)."""
+        if expr is None:
+            return None
+        import sympy as sp
+        from .models import _lam
+        m = self.model
+        e = sp.sympify(expr)
+        args = [m.x, m.u, m.p]
+        g = [sp.diff(e, a) for a in w]
+        H = [[sp.diff(e, a, b) for b in w] for a in w]
+        return _lam([e], args), _lam(g, args), _lam(H, args)
+
+    def lagrange(self, xs, us, p, k, u_old, need=0):
+        """Lagrange term l(x, u) of interval k on scaled variables: quadratic part (+ input change in interval 0) + generic
+        part.  Returns value [B] (and gradient [B,nz], Hessian [B,nz,nz] w.r.t. z = (xs, us) when need > 0)."""
+        nx = self.nx
+        z = np.concatenate([xs, us], axis=1) - self.zref
+        B = z.shape[0]
+        f = np.einsum('bi,ij,bj->b', z, self.Wz, z)
+        if need:
+            g = z @ (self.Wz + self.Wz.T)
+            H = np.broadcast_to(self.Wz + self.Wz.T, (B, self.nz, self.nz)).copy()
+        if k == 0 and u_old is not None:
+            dd = us - u_old
+            f = f + np.einsum('bi,ij,bj->b', dd, self.Wdu, dd)
+            if need:
+                g[:, nx:] += dd @ (self.Wdu + self.Wdu.T)
+                H[:, nx:, nx:] += self.Wdu + self.Wdu.T
+        if self.gen_stage is not None:
+            pv = p if self.np_ else np.zeros((B, 0))
+            f = f + self.gen_stage[0](xs, us, pv)[:, 0]
+            if need:
+                g += self.gen_stage[1](xs, us, pv)
+                H += self.gen_stage[2](xs, us, pv)
+        return (f, g, H) if need else f
+
+    def mayer(self, xs, p, need=0):
+        d = xs - self.xrefN
+        B = xs.shape[0]
+        f = np.einsum('bi,ij,bj->b', d, self.WN, d)
+        if need:
+            g = d @ (self.WN + self.WN.T)
+            H = np.broadcast_to(self.WN + self.WN.T, (B, self.nx, self.nx)).copy()
+        if self.gen_term is not None:
+            pv = p if self.np_ else np.zeros((B, 0))
+            u0 = np.zeros((B, self.nu))
+            f = f + self.gen_term[0](xs, u0, pv)[:, 0]
+            if need:
+                g += self.gen_term[1](xs, u0, pv)
+                H += self.gen_term[2](xs, u0, pv)
+        return (f, g, H) if need else f
 
     # scaled continuous right-hand side with first / second derivatives w.r.t. (xs, us)
     def rhs(self, xs, us, p, need=0):
@@ -123,17 +190,16 @@ class CollIpm(DenseIpm):
         Xc = w[:, self.o_c:].reshape(B, N, d, nx)
         return X, U, Xc
 
-    def _cost(self, X, U, u_old):
+    def _cost(self, X, U, u_old, Xc=None, p=None):
         pb = self.pb
         f = np.zeros(X.shape[0])
         for k in range(pb.N):
-            z = np.concatenate([X[:, k], U[:, k]], axis=1) - pb.zref
-            f += np.einsum('bi,ij,bj->b', z, pb.Wz, z)
-        if u_old is not None:
-            dd = U[:, 0] - u_old
-            f += np.einsum('bi,ij,bj->b', dd, pb.Wdu, dd)
-        dd = X[:, pb.N] - pb.xrefN
-        return f + np.einsum('bi,ij,bj->b', dd, pb.WN, dd)
+            if pb.objective == 'continuous':
+                for i in range(1, pb.d + 1):
+                    f += pb.dt * pb.B[i] * pb.lagrange(Xc[:, k, i - 1], U[:, k], p, k, u_old)
+            else:
+                f += pb.lagrange(X[:, k], U[:, k], p, k, u_old)
+        return f + pb.mayer(X[:, pb.N], p)
 
     def eval_fc(self, w, data):
         pb = self.pb
@@ -150,7 +216,7 @@ class CollIpm(DenseIpm):
                 c[:, k, i - 1] = pb.dt * pb.rhs(Xc[:, k, i - 1], U[:, k], p) - xp
                 xf = xf + pb.D[i] * Xc[:, k, i - 1]
             c[:, k, d] = X[:, k + 1] - xf
-        return self._cost(X, U, u_old), c.reshape(B, -1)
+        return self._cost(X, U, u_old, Xc, p), c.reshape(B, -1)
 
     def eval_all(self, w, lam, data):
         pb = self.pb
@@ -167,18 +233,19 @@ class CollIpm(DenseIpm):
         mk = (d + 1) * nx
         eye = np.eye(nx)
         for k in range(N):
-            # cost at the shooting node
-            z = np.concatenate([X[:, k], U[:, k]], axis=1) - pb.zref
-            gz = 2 * z @ pb.Wz
-            Hz = np.broadcast_to(2 * pb.Wz, (B, nz, nz)).copy()
-            if k == 0 and u_old is not None:
-                dd = U[:, 0] - u_old
-                gz[:, nx:] += 2 * dd @ pb.Wdu
-                Hz[:, nx:, nx:] += 2 * pb.Wdu
-            cols = (self.xcol(k) if k > 0 else []) + self.ucol(k)
-            sel = (list(range(nx)) if k > 0 else []) + list(range(nx, nz))
-            g[:, cols] += gz[:, sel]
-            W[np.ix_(bi, cols, cols)] += Hz[np.ix_(bi, sel, sel)]
+            if pb.objective == 'continuous':   # quadrature of the Lagrange term at the collocation states (modeling.py:1195)
+                for i in range(1, d + 1):
+                    _, gz, Hz = pb.lagrange(Xc[:, k, i - 1], U[:, k], p, k, u_old, need=1)
+                    cols = self.ccol(k, i) + self.ucol(k)
+                    wq = pb.dt * pb.B[i]
+                    g[:, cols] += wq * gz
+                    W[np.ix_(bi, cols, cols)] += wq * Hz
+            else:                              # cost at the shooting node
+                _, gz, Hz = pb.lagrange(X[:, k], U[:, k], p, k, u_old, need=1)
+                cols = (self.xcol(k) if k > 0 else []) + self.ucol(k)
+                sel = (list(range(nx)) if k > 0 else []) + list(range(nx, nz))
+                g[:, cols] += gz[:, sel]
+                W[np.ix_(bi, cols, cols)] += Hz[np.ix_(bi, sel, sel)]
             xf = pb.D[0] * X[:, k]
             for i in range(1, d + 1):
                 rows = [k * mk + (i - 1) * nx + a for a in range(nx)]
@@ -204,10 +271,10 @@ class CollIpm(DenseIpm):
             J[:, rc, self.xcol(k + 1)] = 1.0
             if k > 0:
                 J[:, rc, self.xcol(k)] += -pb.D[0]
-        dd = X[:, N] - pb.xrefN
-        g[:, self.xcol(N)] += 2 * dd @ pb.WN
-        W[np.ix_(bi, self.xcol(N), self.xcol(N))] += 2 * pb.WN
-        return self._cost(X, U, u_old), g, c.reshape(B, -1), J, W
+        _, gN, HN = pb.mayer(X[:, N], p, need=1)
+        g[:, self.xcol(N)] += gN
+        W[np.ix_(bi, self.xcol(N), self.xcol(N))] += HN
+        return self._cost(X, U, u_old, Xc, p), g, c.reshape(B, -1), J, W
 
     def solve(self, x0, p, w0=None, u_old=None, verbose=False):
         pb = self.pb
