@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libhilo_hip.so')
 SOURCES = ['hilo_api.hip', 'hilo_kf.hip', 'hilo_gp.hip', 'hilo_nmpc.hip', 'hilo_qp.hip', 'hilo_mhe.hip',
-           'hilo_nmpc_gen_chemostat4.hip', 'hilo_nmpc_gen_robot6.hip', 'hilo_nmpc_coll.hip', 'hilo_nmpc_tv.hip', 'hilo_mhe_est.hip', 'hilo_nmpc_long.hip']
+           'hilo_nmpc_gen_chemostat4.hip', 'hilo_nmpc_gen_robot6.hip', 'hilo_nmpc_coll.hip', 'hilo_nmpc_tv.hip', 'hilo_mhe_est.hip', 'hilo_nmpc_long.hip', 'hilo_jit.hip', 'hilo_nmpc_user.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result'] + \
     os.environ.get('HILO_EXTRA_FLAGS', '').split()      # developer knob (tuning sweeps), empty in normal builds
 
@@ -53,7 +53,7 @@ def build(force=False, verbose=True, jobs=None):
             sys.stderr.write(out.decode(errors='replace'))
             raise RuntimeError(f'hipcc failed on {src}')
     if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-lhiprtc', '-ldl']   # hiprtc: run-time compiled user models (csrc/hilo_jit.hip)
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -13,7 +13,7 @@ c_i64 = C.c_int64
 
 
 class HiloError(RuntimeError):
-    pass
+    code = 0
 
 
 class KfDesc(C.Structure):
@@ -40,7 +40,11 @@ class NmpcDesc(C.Structure):
                 ('tcon_ub', C.c_void_p), ('tcon_soft', C.c_int32), ('reserved4', C.c_int32), ('tcon_weight', C.c_void_p),
                 ('tcon_max_violation', C.c_void_p)] + \
                [('collocation_degree', C.c_int32), ('reserved2', C.c_int32), ('coll_A', C.c_void_p), ('coll_D', C.c_void_p),
-                ('time_varying', C.c_int32), ('reserved3', C.c_int32)]
+                ('time_varying', C.c_int32), ('reserved3', C.c_int32)] + \
+               [('user_source', C.c_char_p)] + \
+               [(n, C.c_int32) for n in ('user_nx', 'user_nu', 'user_np', 'user_ny', 'user_discrete', 'user_has_fun', 'user_policy',
+                                         'objective_continuous')] + \
+               [('coll_B', C.c_void_p)]
 
 
 class MheDesc(C.Structure):
@@ -83,6 +87,7 @@ def _declare(lib):
         'hilo_nmpc_solve_tv': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_nmpc_profile': (C.c_int, [vp, i32, vp]),
         'hilo_nmpc_plant_step': (C.c_int, [vp, i64, vp, vp, vp, i64, vp, vp]),
+        'hilo_jit_precompile': (C.c_int, [C.c_char_p] + [i32] * 11),
         'hilo_mhe_create': (C.c_int, [P(MheDesc), i32, P(vp)]),
         'hilo_mhe_destroy': (None, [vp]),
         'hilo_mhe_dims': (C.c_int, [vp] + [P(C.c_int)] * 6),
@@ -127,4 +132,6 @@ def check(rc):
         msg = lib().hilo_last_error().decode(errors='replace')
         if rc == -1:
             raise ValueError(msg)
-        raise HiloError(f"libhilo_hip error {rc}: {msg}")
+        err = HiloError(f"libhilo_hip error {rc}: {msg}")
+        err.code = rc
+        raise err

@@ -1,0 +1,153 @@
+"""Expression trees -> HIP source of the functors the engine is compiled against at run time.
+
+The reference hands CasADi graphs to `ca.nlpsol`, which generates and compiles derivative code at `setup()`
+(hilo_mpc/modules/controller/mpc.py:1778-1787).  The counterpart here: the expressions a user writes on `model.x`,
+`model.u`, `model.p` (hilo_mpc_amd/expr.py) are emitted as templated C++ in the shape of the device zoo
+(hilo_mpc_amd/csrc/hilo_models.h) - the scalar type carries the derivatives (Dual<N>, Jet2, hilo_ad.h) - and compiled
+with hiprtc by the library (csrc/hilo_jit.hip; `desc.user_source` of include/hilo_hip.h).
+
+Emission rules: one `const auto tK = ...;` per distinct inner node, in the order the nodes were CREATED - the order in which
+the user's Python statements were evaluated, so the emitted function reads like the statements that built it (and a zoo
+functor written in the same order compiles to the same code: tests/test_jit_gpu.py compares them bit for bit); shared
+sub-expressions - the same Python object used twice - are evaluated once, exactly like a named temporary of a hand-written
+functor; leaves are array reads, constants are printed with `repr` (round-trip exact).
+"""
+from .expr import Expr
+
+_BIN = {'add': '+', 'sub': '-', 'mul': '*', 'div': '/'}
+_FUN = {'sq': 'sq', 'sin': 'sin', 'cos': 'cos', 'exp': 'exp', 'log': 'log', 'sqrt': 'sqrt'}
+
+
+def _lit(v):
+    v = float(v)
+    if v != v or v in (float('inf'), float('-inf')):
+        raise ValueError("non-finite constant in an expression")
+    s = repr(v)
+    if 'e' not in s and '.' not in s and 'n' not in s:
+        s += '.0'
+    return s
+
+
+class Emitter:
+    """Collects statements for a set of expressions that share sub-expressions."""
+
+    def __init__(self, theta_index=None, x='x', u='u', p='p'):
+        self.theta_index, self.names = theta_index, {'x': x, 'u': u, 'p': p}
+        self.lines, self.memo = [], {}
+
+    def ref(self, e):
+        """Name of the value of `e`; emits the statements of its not-yet-emitted inner nodes in creation order."""
+        e = Expr.wrap(e)
+        if id(e) in self.memo:
+            return self.memo[id(e)]
+        todo, seen, stack = [], set(), [e]
+        while stack:                                  # inner nodes below e that still need a statement
+            n = stack.pop()
+            if id(n) in seen or id(n) in self.memo:
+                continue
+            seen.add(id(n))
+            if n.args:
+                todo.append(n)
+                stack.extend(n.args)
+        for n in sorted(todo, key=lambda q: q.serial):
+            self._one(n)
+        return self._one(e)
+
+    def _one(self, e):
+        if id(e) in self.memo:
+            return self.memo[id(e)]
+        op = e.op
+        if op == 'const':
+            r = _lit(e.value)
+        elif op in ('x', 'u', 'p'):
+            r = f"{self.names[op]}[{int(e.value)}]"
+        elif op == 'theta':
+            if self.theta_index is None:
+                raise ValueError("a path variable can only appear where the path variable is defined (path references, costs)")
+            r = f"{self.names['x']}[{int(self.theta_index) + int(e.value)}]"
+        else:
+            a = [self._one(c) for c in e.args]
+            if op in _BIN:
+                rhs = f"{a[0]} {_BIN[op]} {a[1]}"
+            elif op == 'neg':
+                rhs = f"-1.0 * ({a[0]})"
+            elif op in _FUN:
+                rhs = f"{_FUN[op]}({a[0]})"
+            elif op == 'powi':
+                n = int(e.value)
+                if n == 0:
+                    rhs = "1.0"
+                else:
+                    prod = ' * '.join([a[0]] * abs(n))
+                    rhs = prod if n > 0 else f"1.0 / ({prod})"
+            else:
+                raise ValueError(f"cannot emit operator '{op}'")
+            r = f"t{len(self.lines)}"
+            self.lines.append(f"    const auto {r} = {rhs};")
+        self.memo[id(e)] = r
+        return r
+
+
+def _fn(ret, name, args, body_lines, result_lines):
+    return (f"  template <class T>\n  __device__ __forceinline__ static {ret} {name}({args}) {{\n" +
+            '\n'.join(body_lines + result_lines) + "\n  }\n")
+
+
+def model_source(n_x, n_u, n_p, ode, meas, discrete):
+    """`struct UserModel` for the right-hand side `ode` (list of n_x expressions) and the measurement map `meas`."""
+    if len(ode) != n_x:
+        raise ValueError(f"the model has {n_x} states but {len(ode)} dynamical equations")
+    em = Emitter()
+    dx = [em.ref(e) for e in ode]
+    body = em.lines + [f"    dx[{i}] = T({r});" for i, r in enumerate(dx)]
+    em2 = Emitter()
+    yy = [em2.ref(e) for e in meas]
+    body2 = em2.lines + [f"    y[{i}] = T({r});" for i, r in enumerate(yy)]
+    n_y = len(meas)
+    return (f"struct UserModel {{\n"
+            f"  static constexpr int NX = {n_x}, NU = {n_u}, NP = {n_p}, NY = {n_y};\n"
+            f"  static constexpr bool DISCRETE = {'true' if discrete else 'false'};\n"
+            f"  template <class T, class U, class P>\n"
+            f"  __device__ __forceinline__ static void ode(const T* x, const U* u, const P* p, double dt, T* dx) {{\n"
+            f"    (void)x; (void)u; (void)p; (void)dt;\n" + '\n'.join(body) + "\n  }\n"
+            f"  template <class T, class U, class P>\n"
+            f"  __device__ __forceinline__ static void meas(const T* x, const U* u, const P* p, double dt, T* y) {{\n"
+            f"    (void)x; (void)u; (void)p; (void)dt; (void)y;\n" + '\n'.join(body2) + "\n  }\n};\n")
+
+
+def zoo_alias(functor):
+    return f"using UserModel = {functor};\n"
+
+
+def fun_source(n_x, stage=None, term=None, con=(), tcon=(), path_stage=(), path_term=()):
+    """`struct UserFun` (csrc/hilo_nmpc_user.h): generic costs (scaled variables), constraint expressions (un-scaled
+    variables), path references (functions of the path variable = state index n_x)."""
+    s = ("struct UserFun {\n"
+         f"  static constexpr bool HAS_STAGE = {'true' if stage is not None else 'false'}, "
+         f"HAS_TERM = {'true' if term is not None else 'false'};\n"
+         f"  static constexpr int NEXPR = {len(con)}, NTEXPR = {len(tcon)}, NPS = {len(path_stage)}, NPT = {len(path_term)};\n")
+    if stage is not None:
+        em = Emitter(theta_index=n_x)
+        r = em.ref(stage)
+        s += _fn('T', 'stage', 'const T* x, const T* u, const double* p', ["    (void)x; (void)u; (void)p;"] + em.lines,
+                 [f"    return T({r});"])
+    if term is not None:
+        if Expr.wrap(term).depends_on('u'):
+            raise ValueError("The terminal cost can only contain states")
+        em = Emitter(theta_index=n_x)
+        r = em.ref(term)
+        s += _fn('T', 'term', 'const T* x, const double* p', ["    (void)x; (void)p;"] + em.lines, [f"    return T({r});"])
+    for name, exprs, args in (('con', con, 'const T* x, const T* u, const double* p, T* c'),
+                              ('tcon', tcon, 'const T* x, const T* u, const double* p, T* c')):
+        if exprs:
+            em = Emitter()
+            rr = [em.ref(e) for e in exprs]
+            s += _fn('void', name, args, ["    (void)x; (void)u; (void)p;"] + em.lines,
+                     [f"    c[{i}] = T({r});" for i, r in enumerate(rr)])
+    for name, exprs in (('path_stage', path_stage), ('path_term', path_term)):
+        if exprs:
+            em = Emitter(theta_index=n_x)
+            rr = [em.ref(e) for e in exprs]
+            s += _fn('void', name, 'const T* x, const double* p, T* r', ["    (void)x; (void)p;"] + em.lines,
+                     [f"    r[{i}] = T({q});" for i, q in enumerate(rr)])
+    return s + "};\n"

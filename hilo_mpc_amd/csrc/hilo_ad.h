@@ -7,8 +7,16 @@
 //             the Lagrangian-Hessian blocks are recovered by polarisation: H_ij = (q(e_i+e_j) - q(e_i) - q(e_j))/2
 // Everything lives in registers: all loops have compile-time bounds and are fully unrolled.
 #pragma once
+// Under hiprtc (run-time compilation of user models, hilo_jit.hip) the HIP device API and the math functions are
+// predeclared and no system header is reachable: every #include of a system header is guarded.
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <math.h>
+#else
+#ifndef INFINITY
+#define INFINITY (__builtin_huge_val())
+#endif
+#endif
 
 #define HD __host__ __device__ __forceinline__
 

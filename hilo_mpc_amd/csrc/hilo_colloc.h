@@ -22,6 +22,7 @@ struct CollData {  // host-computed basis (hilo_mpc_amd/nmpc.py restates modelin
   int d, pad;
   double A[COLL_MAXD * COLL_MAXD];   // Runge-Kutta matrix of the collocation method
   double Dc[COLL_MAXD + 1];          // continuity weights D_0..D_d
+  double Bq[COLL_MAXD + 1];          // quadrature weights B_0..B_d = int_0^1 L_i (continuous objective, modeling.py:1195)
 };
 
 template <class M, int D>
@@ -142,21 +143,28 @@ struct Colloc {
     }
   }
 
+  // `Xout` (optional, DN entries): the collocation states themselves, with their Taylor coefficients - what the continuous
+  // objective integrates the Lagrange term over
   template <class T>
-  __device__ __forceinline__ static void step(const CollData& cd, const T* x, const T* u, const double* p, double dt, T* xn) {
+  __device__ __forceinline__ static void step(const CollData& cd, const T* x, const T* u, const double* p, double dt, T* xn,
+                                              T* Xout = nullptr) {
     double xv[NX], uv[NU > 0 ? NU : 1], X[DN], mat[DN * DN];
 #pragma unroll
     for (int m = 0; m < NX; ++m) xv[m] = value(x[m]);
 #pragma unroll
     for (int a = 0; a < NU; ++a) uv[a] = value(u[a]);
     solve(cd, xv, uv, p, dt, X, mat);
-    if constexpr (std::is_same<T, double>::value) {
+    if constexpr (same_type<T, double>::value) {
 #pragma unroll
       for (int m = 0; m < NX; ++m) {
         double s = cd.Dc[0] * xv[m];
 #pragma unroll
         for (int i = 0; i < D; ++i) s += cd.Dc[i + 1] * X[i * NX + m];
         xn[m] = s;
+      }
+      if (Xout) {
+#pragma unroll
+        for (int q = 0; q < DN; ++q) Xout[q] = X[q];
       }
     } else {
       Jet2 XJ[DN];
@@ -192,6 +200,10 @@ struct Colloc {
 #pragma unroll
         for (int i = 0; i < D; ++i) s = s + cd.Dc[i + 1] * XJ[i * NX + m];
         xn[m] = s;
+      }
+      if (Xout) {
+#pragma unroll
+        for (int q = 0; q < DN; ++q) Xout[q] = XJ[q];
       }
     }
   }

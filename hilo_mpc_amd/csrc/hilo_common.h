@@ -1,13 +1,26 @@
 // Shared host-side plumbing for libhilo_hip.so (error reporting, launch helpers) and device tile staging.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
 
 #include "../../include/hilo_hip.h"
+#else
+// run-time compiled device code (hilo_jit.hip): only the status codes of the public header are needed
+#define HILO_STATUS_SOLVED 1
+#define HILO_STATUS_ACCEPTABLE 2
+#define HILO_STATUS_INFEASIBLE 3
+#define HILO_STATUS_RESTORATION_FAILED 4
+#define HILO_STATUS_MAXITER 5
+#define HILO_STATUS_OTHER (-1)
+typedef long long int64_t;
+typedef int int32_t;
+#endif
 
 namespace hilo {
+#ifndef __HIPCC_RTC__
 
 // hilo_gp.hip: device copy of a trained GP's posterior mean in the layout of hilo_models.h::GpExt; the GP must have a
 // squared-exponential kernel over exactly two features and a constant (or zero) mean, HILO_ENOTSUP otherwise
@@ -29,6 +42,8 @@ int fail(int code, const char* fmt, ...);
   do {                                                           \
     if (!(cond)) return ::hilo::fail(HILO_EINVAL, __VA_ARGS__);  \
   } while (0)
+
+#endif  // !__HIPCC_RTC__
 
 // ------------------------------------------------------------------------------------------------
 // Coalesced AoS <-> per-lane staging through LDS.

@@ -1,0 +1,49 @@
+// Run-time compilation of NMPC problems for models that are not in the compiled zoo: host-side interface.
+//
+// The reference builds its solver from a symbolic model at `setup()` (`ca.nlpsol` on the CasADi graph,
+// hilo_mpc/modules/controller/mpc.py:1778-1787).  The counterpart here: the host hands the model (and the problem's
+// free-form functions) as HIP source of functors shaped like csrc/hilo_models.h; this module wraps it into a translation
+// unit that instantiates one of the engine's policies for it, compiles it with hiprtc for gfx950 against the engine
+// headers that ship next to the library, caches the code object on disk, and loads the kernels.
+#pragma once
+#include <string>
+
+#include "hilo_common.h"
+
+namespace hilo {
+
+struct OcpConst;
+
+enum JitPolicy : int {
+  JIT_TRACK = 0,   // NmpcTrack<UserModel, BIG>          (hilo_nmpc_track.h) - identical code path to the zoo models
+  JIT_GEN = 1,     // NmpcGen<UserModel, NTH, NE, NC, BIG> (hilo_nmpc_gen.h): compiles, not used by the host code
+  JIT_USER = 2,    // NmpcUser<UserModel, UserFun, UserCfg> (hilo_nmpc_user.h) - the general policy
+};
+
+struct JitRequest {
+  std::string user_source;   // defines `UserModel` (struct or alias of a zoo functor) and, if has_fun, `UserFun`
+  int policy = JIT_TRACK;
+  int nth = 0, ne = 0, nc = 0, coll_d = 0, N = 1;
+  bool hold = false, cont = false, tv = false, big = false, has_fun = false;
+};
+
+struct JitKernels {
+  hipFunction_t solve = nullptr, plant = nullptr, coll_out = nullptr;
+  int dims[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // nx, nu, np, ny, discrete, lds bytes of the solve kernel, engine NX, engine NU
+};
+
+// compile (or fetch from the in-memory / on-disk cache) and load on `device`; on failure hilo_last_error() holds the compiler log
+int jit_nmpc_kernels(const JitRequest& r, int device, JitKernels* out);
+
+// launch helpers (hipModuleLaunchKernel)
+int jit_launch_solve(hipFunction_t f, const OcpConst* dev, int64_t batch, const double* x0, const double* par, int64_t par_stride,
+                     const double* sdata, int64_t sd_stride, const double* v0, int64_t v0_stride, double* v_opt, double* f_opt,
+                     double* lam_g, double* first, int32_t* status, int32_t* iters, double* kkt, long long* prof, double* ws,
+                     hipStream_t s);
+int jit_launch_plant(hipFunction_t f, const OcpConst* dev, int64_t batch, const double* x, const double* u, const double* par,
+                     int64_t par_stride, double* xn, hipStream_t s);
+int jit_launch_coll_out(hipFunction_t f, const OcpConst* dev, int64_t batch, int N, const double* vc, const double* lamc,
+                        const double* par, int64_t par_stride, const double* sdata, int64_t sd_stride, double* v, double* lam_g,
+                        hipStream_t s);
+
+}  // namespace hilo

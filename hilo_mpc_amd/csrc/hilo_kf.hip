@@ -453,6 +453,14 @@ extern "C" int hilo_model_dims(int model_id, int* nx, int* nu, int* np, int* ny,
   d.model_id = model_id;
   if (model_id == HILO_MODEL_LTI) return fail(HILO_EINVAL, "LTI dimensions are caller-defined");
   if (model_id == HILO_MODEL_CHEMOSTAT4_GP) model_id = d.model_id = HILO_MODEL_CHEMOSTAT4;  // same signature
+  if (model_id == HILO_MODEL_CSTR3) {  // controller-only model (no filter instantiation)
+    if (nx) *nx = Cstr3::NX;
+    if (nu) *nu = Cstr3::NU;
+    if (np) *np = Cstr3::NP;
+    if (ny) *ny = Cstr3::NY;
+    if (discrete) *discrete = Cstr3::DISCRETE;
+    return HILO_OK;
+  }
   if (model_id == HILO_MODEL_ROBOT6) {  // controller-only model (no filter instantiation)
     if (nx) *nx = Robot6::NX;
     if (nu) *nu = Robot6::NU;

@@ -178,7 +178,7 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
   OcpConst& c = h->host;
   memset(&c, 0, sizeof(c));
   ocp_default_options(c);
-  c.N = d->N; c.order = d->erk_order >= 1 ? d->erk_order : 4; c.nsub = d->n_sub >= 1 ? d->n_sub : 1; c.dt = d->dt;
+  c.N = d->N; c.Nc = d->N; c.order = d->erk_order >= 1 ? d->erk_order : 4; c.nsub = d->n_sub >= 1 ? d->n_sub : 1; c.dt = d->dt;
   if (d->max_iter > 0) c.max_iter = d->max_iter;
   if (d->acceptable_iter > 0) c.acceptable_iter = d->acceptable_iter;
   if (d->tol > 0) c.tol = d->tol;

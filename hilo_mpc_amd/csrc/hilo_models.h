@@ -8,8 +8,6 @@
 //
 // ids match HILO_MODEL_* in include/hilo_hip.h.
 #pragma once
-#include <type_traits>
-
 #include "hilo_ad.h"
 
 namespace hilo {
@@ -48,8 +46,17 @@ struct GpExt {
   bool idle;        // lane has no task: contributes nothing, still takes part in the exchange
 };
 
-template <class M, class = void> struct model_has_ext : std::false_type {};
-template <class M> struct model_has_ext<M, std::void_t<decltype(M::EXT)>> : std::bool_constant<M::EXT> {};
+// the few type traits the device code needs, written out: under hiprtc there is no <type_traits>
+template <bool V> struct bool_const { static constexpr bool value = V; };
+template <class...> using void_tt = void;
+template <bool C, class A, class B> struct cond { using type = A; };
+template <class A, class B> struct cond<false, A, B> { using type = B; };
+template <bool C, class A, class B> using cond_t = typename cond<C, A, B>::type;
+template <class A, class B> struct same_type : bool_const<false> {};
+template <class A> struct same_type<A, A> : bool_const<true> {};
+
+template <class M, class = void> struct model_has_ext : bool_const<false> {};
+template <class M> struct model_has_ext<M, void_tt<decltype(M::EXT)>> : bool_const<M::EXT> {};
 
 // value (ORDER 0) or value / gradient / Hessian (ORDER 2: out = m, g0, g1, h00, h01, h11) of the GP mean at (s, i)
 template <int ORDER>
@@ -230,6 +237,27 @@ struct Robot6 {
   }
   template <class T, class U, class P>
   HD static void meas(const T* x, const U*, const P*, double, T* y) { y[0] = x[0]; y[1] = x[2]; }
+};
+
+// ---- docs/docsource/examples/CSTR_Example.ipynb cell 6 (`true_plant_model`, constants of cell 4): reversible exothermic
+// reaction A <-> B in a cooled CSTR; states C_A, C_B, T; input Q; measurement r (the reaction rate).  The statements
+// follow the notebook's expression structure term by term (the same tree the run-time compiled model is emitted from).
+struct Cstr3 {
+  static constexpr int NX = 3, NU = 1, NP = 0, NY = 1;
+  static constexpr bool DISCRETE = false;
+  template <class T>
+  HD static T rate(const T* x) {
+    return 5000.0 * exp(-10000.0 / (1.987 * x[2])) * x[0] - 1000000.0 * exp(-15000.0 / (1.987 * x[2])) * x[1];
+  }
+  template <class T, class U, class P>
+  HD static void ode(const T* x, const U* u, const P*, double, T* dx) {
+    const T r = rate(x);
+    dx[0] = 0.016666666666666666 * (1.0 - x[0]) - r;
+    dx[1] = -0.016666666666666666 * x[1] + r;
+    dx[2] = (-1.0 * (-5000.0 * r)) / 1000.0 + 0.016666666666666666 * (400.0 - x[2]) + u[0] / 100000.0;
+  }
+  template <class T, class U, class P>
+  HD static void meas(const T* x, const U*, const P*, double, T* y) { y[0] = rate(x); }
 };
 
 // ---- LTI with compile-time dims; p = [A (NX*NX) | B (NX*NU) | C (NY*NX)] row-major ------------------------

@@ -43,40 +43,18 @@ __global__ void plant_step_kernel(const OcpConst* __restrict__ pcg, int64_t batc
 
 using namespace hilo;
 
-struct hilo_nmpc {
-  int device, model_id, nx, nu, np, N, n_v, n_g;
-  OcpConst host;
-  OcpConst* dev;
-  unsigned base_free_mask;   // x_0 components that are variables by construction (theta_0, shared slack)
-  double* par_buf;   // [par_batch][np + nu] device: model parameters | u_old
-  int64_t par_batch;
-  long long* prof;   // optional phase-cycle counters (hilo_nmpc_profile)
-  double* v_guess;   // [n_v] device
-  double* ext_pack;  // packed learned term of the model (GpExt) or NULL
-  const GenVariant* gen;  // general variant (path following / stage constraints), NULL for the tracking policy
-  int nu_out;        // width of the returned first input (model inputs, without the virtual path input)
-  double* ws;        // iterate workspace of BIG variants [ws_batch][ws_bytes]
-  int64_t ws_batch;
-  const TrackBigVariant* big; // long-horizon variant of the tracking policy (iterate in the workspace) or NULL
-  const TvVariant* tv;       // per-stage-data variant (trajectory references, time-varying parameters) or NULL
-  const CollVariant* coll;   // collocation variant of the tracking policy or NULL
-  double *vc, *lamc;         // the engine's compact [x | u] solution and defect multipliers (collocation output pass)
-  int64_t vc_batch;
-  int n_vc;                  // (N+1) nx + N nu
-  double* v_warm;    // [warm_batch][n_v] device: previous solution (mpc.py:725-726)
-  int64_t warm_batch;
-  int warm_valid;
-  size_t lds_bytes;
-};
+#include "hilo_nmpc_handle.h"
 
 #define HILO_NMPC_MODELS(X)              \
   X(HILO_MODEL_CHEMOSTAT4, Chemostat4)   \
   X(HILO_MODEL_PENDULUM4, Pendulum4)     \
   X(HILO_MODEL_BIOREACTOR3, Bioreactor3) \
   X(HILO_MODEL_CHEMOSTAT4_GP, Chemostat4Gp) \
-  X(HILO_MODEL_ROBOT6, Robot6)
+  X(HILO_MODEL_ROBOT6, Robot6)           \
+  X(HILO_MODEL_CSTR3, Cstr3)
 
 static int nmpc_model_dims(int id, int* nx, int* nu, int* np, size_t* lds, int N) {
+  *lds = 0;
   switch (id) {
 #define X(ID, T) case ID: *nx = T::NX; *nu = T::NU; *np = T::NP; *lds = Ocp<NmpcTrack<T>>::lds_doubles(N) * sizeof(double); return HILO_OK;
     HILO_NMPC_MODELS(X)
@@ -106,21 +84,44 @@ static void copy_or(double* dst, const double* src, int n, double dflt) {
 extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   HILO_REQUIRE(d && out, "hilo_nmpc_create: NULL argument");
   HILO_REQUIRE(d->N >= 1 && d->N <= 512, "hilo_nmpc_create: horizon %d out of range [1, 512]", d->N);
-  if (d->Nc != 0 && d->Nc != d->N)
-    return fail(HILO_ENOTSUP, "control horizon (%d) != prediction horizon (%d) is not supported yet", d->Nc, d->N);
   HILO_REQUIRE(d->dt > 0.0, "hilo_nmpc_create: dt must be positive");
+  // ---- run-time compiled problems (hilo_jit.hip) ----
+  const bool jit = d->user_source != nullptr;
+  if (jit && d->user_policy == JIT_USER) return nmpc_user_create(d, device, out);
+  HILO_REQUIRE(!jit || d->user_policy == JIT_TRACK, "hilo_nmpc_create: user_policy must be 0 (tracking) or 2 (general)");
+  HILO_REQUIRE(jit || d->model_id != HILO_MODEL_USER, "hilo_nmpc_create: HILO_MODEL_USER needs desc.user_source");
+  if (d->Nc != 0 && d->Nc != d->N)
+    return fail(HILO_ENOTSUP, "control horizon (%d) != prediction horizon (%d) needs the run-time compiled general policy "
+                              "(desc.user_source with user_policy 2)", d->Nc, d->N);
   int nx, nu, np;
   size_t lds;
-  int rc = nmpc_model_dims(d->model_id, &nx, &nu, &np, &lds, d->N);
-  if (rc) return rc;
+  int rc = HILO_OK;
+  if (d->model_id == HILO_MODEL_USER) {
+    nx = d->user_nx; nu = d->user_nu; np = d->user_np;
+    HILO_REQUIRE(nx >= 1 && nu >= 0 && np >= 0, "hilo_nmpc_create: bad user model dimensions");
+  } else {
+    rc = nmpc_model_dims(d->model_id, &nx, &nu, &np, &lds, d->N);
+    if (rc) return rc;
+  }
   HILO_REQUIRE(nx <= OCP_MAXNX && nu <= OCP_MAXNU, "model too large for this build");
+  bool jit_big = false;
+  if (jit) {   // the tracking policy compiled for the user's functor: footprint from the dimensions
+    if (d->n_path_var > 0 || d->n_con > 0 || d->n_tcon > 0 || d->collocation_degree > 0 || d->time_varying || d->learned)
+      return fail(HILO_ENOTSUP, "a run-time compiled model with path following, constraints, collocation, per-stage data or a "
+                                "learned term needs user_policy 2");
+    const int ncost = (nx + nu) * (nx + nu) + (nx + nu) + nx * nx + nx + nu * nu + 1;   // NmpcTrack<M>::NCOST
+    const int nconst = (int)((__builtin_offsetof(OcpConst, cost) + sizeof(double) * ncost + 7) / 8);
+    const size_t fixed = ocp_fixed_doubles(nx, nu, nconst, np + nu, 0, 0, d->N) * sizeof(double);
+    lds = fixed + ocp_iter_doubles(nx, nu, 0, d->N) * sizeof(double);
+    if (lds > 160 * 1024) { jit_big = true; lds = fixed; }
+  }
   // ---- general problems: path variable and / or nonlinear stage constraint ----
   HILO_REQUIRE(d->n_path_var >= 0 && d->n_path_var <= 1, "hilo_nmpc_create: at most one path variable is supported (got %d)",
                d->n_path_var);
-  HILO_REQUIRE(d->n_con >= 0 && d->n_con <= GEN_NEXPR, "hilo_nmpc_create: at most %d constraint expressions (got %d)", GEN_NEXPR,
-               d->n_con);
-  HILO_REQUIRE(d->n_tcon >= 0 && d->n_tcon <= GEN_NEXPR, "hilo_nmpc_create: at most %d terminal constraint expressions (got %d)",
-               GEN_NEXPR, d->n_tcon);
+  HILO_REQUIRE(d->n_con >= 0 && d->n_tcon >= 0, "hilo_nmpc_create: negative constraint count");
+  if (d->n_con > GEN_NEXPR || d->n_tcon > GEN_NEXPR)   // capacity of the precompiled variants, not of the method
+    return fail(HILO_ENOTSUP, "the precompiled variants hold at most %d stage / terminal constraint expressions (got %d / %d); "
+                              "compile the problem at run time (desc.user_source, user_policy 2)", GEN_NEXPR, d->n_con, d->n_tcon);
   const bool general = d->n_path_var > 0 || d->n_con > 0 || d->n_tcon > 0;
   const GenVariant* gv = nullptr;
   int nth = 0, ne = 0, nrow = 0, n_con_ref = 0;
@@ -210,7 +211,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     lds = tvv->lds_bytes(d->N);
   }
   const TrackBigVariant* bigv = nullptr;
-  if (lds > 160 * 1024 && !general && !cv && !tvv && !d->learned) {
+  if (lds > 160 * 1024 && !general && !cv && !tvv && !d->learned && !jit) {
     bigv = nmpc_track_big_find(d->model_id);   // long horizon: iterate in a global-memory workspace
     if (bigv) lds = bigv->lds_bytes(d->N);
   }
@@ -223,6 +224,8 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   memset(h, 0, sizeof(*h));
   h->device = device; h->model_id = d->model_id; h->nx = nx; h->nu = nu; h->np = np; h->N = d->N;
   h->gen = gv; h->nu_out = nu;
+  h->jit_policy = -1;
+  h->nxe = nxe; h->nue = nue; h->nxv = nxv; h->ntail = ne; h->Nc = d->N;
   h->coll = cv;
   h->tv = tvv;
   h->big = bigv;
@@ -234,7 +237,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   OcpConst& c = h->host;
   memset(&c, 0, sizeof(c));
   ocp_default_options(c);
-  c.N = d->N; c.order = d->erk_order >= 1 ? d->erk_order : 4; c.nsub = d->n_sub >= 1 ? d->n_sub : 1;
+  c.N = d->N; c.Nc = d->N; c.order = d->erk_order >= 1 ? d->erk_order : 4; c.nsub = d->n_sub >= 1 ? d->n_sub : 1;
   c.dt = d->dt;
   c.flags = 1;  // lam_g in the reference's convention (terminal cost on Phi_{N-1}, mpc.py:1682)
   if (cv) {
@@ -384,6 +387,21 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     return fail(HILO_EINVAL, "hilo_nmpc_create: desc.learned given but model %d has no learned term", d->model_id);
   }
   h->base_free_mask = c.x0_free_mask;
+  if (jit) {
+    JitRequest rq;
+    rq.user_source = d->user_source;
+    rq.policy = JIT_TRACK;
+    rq.N = d->N;
+    rq.big = jit_big;
+    rc = jit_nmpc_kernels(rq, device, &h->jit);
+    if (!rc && (h->jit.dims[0] != nx || h->jit.dims[1] != nu || h->jit.dims[2] != np))
+      rc = fail(HILO_EINVAL, "hilo_nmpc_create: the compiled UserModel has (nx, nu, np) = (%d, %d, %d), the description says (%d, %d, %d)",
+                h->jit.dims[0], h->jit.dims[1], h->jit.dims[2], nx, nu, np);
+    if (rc) { hilo_nmpc_destroy(h); return rc; }
+    h->jit_policy = JIT_TRACK;
+    h->lds_bytes = 0;   // static LDS inside the compiled kernel
+    h->jit_ws_bytes = jit_big ? ocp_iter_doubles(nx, nu, 0, d->N) * sizeof(double) : 0;
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&h->dev, sizeof(OcpConst));
   if (e == hipSuccess) e = hipMemcpy(h->dev, &c, sizeof(OcpConst), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&h->v_guess, sizeof(double) * h->n_v);
@@ -473,8 +491,8 @@ static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const 
   HILO_REQUIRE(batch >= 0, "hilo_nmpc_solve: negative batch");
   if (batch == 0) return HILO_OK;
   HILO_REQUIRE(x0 && v_opt && f_opt && u0 && status && iters, "hilo_nmpc_solve: NULL argument");
-  HILO_REQUIRE(h->np == 0 || p || h->tv, "hilo_nmpc_solve: the model has %d parameters but p is NULL (mpc.py:771-780)", h->np);
-  HILO_REQUIRE((h->tv != nullptr) == (stage_data != nullptr),
+  HILO_REQUIRE(h->np == 0 || p || h->tv || h->tv_width, "hilo_nmpc_solve: the model has %d parameters but p is NULL (mpc.py:771-780)", h->np);
+  HILO_REQUIRE((h->tv != nullptr || h->tv_width > 0) == (stage_data != nullptr),
                "hilo_nmpc_solve: handles created with desc.time_varying are solved by hilo_nmpc_solve_tv (and only those)");
   HILO_REQUIRE(p_stride == 0 || p_stride >= h->np, "hilo_nmpc_solve: p_stride %lld < np", (long long)p_stride);
   HILO_HIP_CHECK(hipSetDevice(h->device));
@@ -501,7 +519,34 @@ static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const 
     else { vstart = h->v_guess; vstride = 0; }
   }
   int rc = HILO_ENOTSUP;
-  if (h->tv) {
+  if (h->jit_policy >= 0) {
+    const size_t wsb = h->jit_ws_bytes;
+    if (wsb && h->ws_batch != batch) {
+      if (h->ws) HILO_HIP_CHECK(hipFree(h->ws));
+      h->ws = nullptr;
+      hipError_t e = hipMalloc((void**)&h->ws, wsb * (size_t)batch);
+      if (e != hipSuccess) return fail(HILO_ENOMEM, "iterate workspace (%zu B per instance): %s", wsb, hipGetErrorString(e));
+      h->ws_batch = batch;
+    }
+    double *vout = v_opt, *lout = lam_g;
+    if (h->jit_coll_d > 0) {   // the engine writes its compact solution; the output pass adds the collocation states / rows
+      if (h->vc_batch != batch) {
+        if (h->vc) HILO_HIP_CHECK(hipFree(h->vc));
+        if (h->lamc) HILO_HIP_CHECK(hipFree(h->lamc));
+        h->vc = h->lamc = nullptr;
+        hipError_t e = hipMalloc((void**)&h->vc, sizeof(double) * (size_t)h->n_vc * batch);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->lamc, sizeof(double) * (size_t)h->N * h->nxv * batch);
+        if (e != hipSuccess) return fail(HILO_ENOMEM, "collocation output buffers: %s", hipGetErrorString(e));
+        h->vc_batch = batch;
+      }
+      vout = h->vc; lout = h->lamc;
+    }
+    rc = jit_launch_solve(h->jit.solve, h->dev, batch, x0, h->par_buf, (int64_t)(h->np + h->nu), stage_data, sd_stride, vstart,
+                          vstride, vout, f_opt, lout, u0, status, iters, kkt, h->prof, wsb ? h->ws : nullptr, s);
+    if (!rc && h->jit_coll_d > 0)
+      rc = jit_launch_coll_out(h->jit.coll_out, h->dev, batch, h->N, h->vc, h->lamc, h->par_buf, (int64_t)(h->np + h->nu), stage_data,
+                               sd_stride, v_opt, lam_g, s);
+  } else if (h->tv) {
     GenLaunchArgs a{h->dev, batch, x0, h->par_buf, (int64_t)(h->np + h->nu), vstart, vstride, v_opt, f_opt, lam_g, u0,
                     status, iters, kkt, h->prof, h->lds_bytes, s, nullptr};
     rc = h->tv->launch(a, stage_data, sd_stride);
@@ -563,7 +608,7 @@ extern "C" int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch, const double* x0, co
 extern "C" int hilo_nmpc_solve_tv(hilo_nmpc* h, int64_t batch, const double* x0, const double* stage_data, int64_t sd_stride,
                                   const double* v0, const double* u_old, double* v_opt, double* f_opt, double* lam_g,
                                   double* u0, int32_t* status, int32_t* iters, double* kkt, void* stream) {
-  HILO_REQUIRE(h && h->tv, "hilo_nmpc_solve_tv: the handle was not created with desc.time_varying");
+  HILO_REQUIRE(h && (h->tv || h->tv_width), "hilo_nmpc_solve_tv: the handle was not created with desc.time_varying");
   HILO_REQUIRE(batch <= 0 || stage_data, "hilo_nmpc_solve_tv: NULL stage data");
   const int64_t need = (int64_t)(h->N + 1) * (h->nx + h->nu + h->np);
   HILO_REQUIRE(sd_stride == 0 || sd_stride >= need, "hilo_nmpc_solve_tv: sd_stride %lld < %lld", (long long)sd_stride,
@@ -598,6 +643,7 @@ extern "C" int hilo_nmpc_plant_step(hilo_nmpc* h, int64_t batch, const double* x
   if (batch <= 0) return HILO_OK;
   HILO_REQUIRE(x && u && x_next && (h->np == 0 || p), "hilo_nmpc_plant_step: NULL argument");
   HILO_HIP_CHECK(hipSetDevice(h->device));
+  if (h->jit_policy >= 0) return jit_launch_plant(h->jit.plant, h->dev, batch, x, u, p, p_stride, x_next, (hipStream_t)stream);
   const unsigned grid = (unsigned)((batch + 255) / 256);
   switch (h->model_id) {
 #define X(ID, T) case ID: hipLaunchKernelGGL((plant_step_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, h->dev, batch, x, u, p, p_stride, x_next); break;

@@ -101,6 +101,7 @@ const CollVariant* nmpc_coll_find(int model_id, int degree) {
   static const CollVariant v[] = {
       {HILO_MODEL_CHEMOSTAT4, 3, &coll_lds<Chemostat4, 3>, &coll_launch<Chemostat4, 3>, &coll_output<Chemostat4, 3>},
       {HILO_MODEL_PENDULUM4, 3, &coll_lds<Pendulum4, 3>, &coll_launch<Pendulum4, 3>, &coll_output<Pendulum4, 3>},
+      {HILO_MODEL_CSTR3, 3, &coll_lds<Cstr3, 3>, &coll_launch<Cstr3, 3>, &coll_output<Cstr3, 3>},
       {HILO_MODEL_CHEMOSTAT4, 2, &coll_lds<Chemostat4, 2>, &coll_launch<Chemostat4, 2>, &coll_output<Chemostat4, 2>},
       {HILO_MODEL_CHEMOSTAT4, 4, &coll_lds<Chemostat4, 4>, &coll_launch<Chemostat4, 4>, &coll_output<Chemostat4, 4>},
       {HILO_MODEL_CHEMOSTAT4, 1, &coll_lds<Chemostat4, 1>, &coll_launch<Chemostat4, 1>, &coll_output<Chemostat4, 1>},

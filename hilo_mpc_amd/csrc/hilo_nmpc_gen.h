@@ -217,6 +217,7 @@ struct NmpcGen {
   }
 };
 
+#ifndef __HIPCC_RTC__
 // host-side description of one general instantiation (filled per (model, NTH, NE, NC) in hilo_nmpc_gen_*.hip)
 struct GenLaunchArgs {
   const OcpConst* dev;
@@ -298,5 +299,6 @@ GenVariant gen_variant(int model_id) {
                     PB::O_TSOFT, PB::O_TROWX, PB::O_TROWS, PB::O_TROWE,
                     &gen_lds<PB>, &gen_ws<PB>, &gen_launch<PB>};
 }
+#endif  // !__HIPCC_RTC__
 
 }  // namespace hilo

@@ -1,0 +1,286 @@
+// NMPC.setup() for problems on the general run-time compiled policy (csrc/hilo_nmpc_user.h): fills the problem constants
+// in the layout of that policy, asks hilo_jit.hip for the kernels, builds the handle.
+//
+// What the reference does at this point: `NMPC._setup` (hilo_mpc/modules/controller/mpc.py:1133-1787) builds the NLP graph and
+// `ca.nlpsol` compiles its derivatives.  The layout rules restated here are those of hilo_nmpc.hip (same file:line
+// references) extended by: control horizon Nc < N (v = [x (N+1) | u (Nc) | e | ip], mpc.py:1476-1485, :1629-1630), the
+// path variable inside the collocation scheme, generic costs, the continuous objective.
+#include <string.h>
+
+#include "hilo_nmpc_handle.h"
+#include "hilo_nmpc_user.h"
+
+extern "C" int hilo_model_dims(int model_id, int* nx, int* nu, int* np, int* ny, int* discrete);
+extern "C" void hilo_nmpc_destroy(hilo_nmpc* h);
+
+namespace hilo {
+
+static void copy_or1(double* dst, const double* src, int n, double dflt) {
+  for (int i = 0; i < n; ++i) dst[i] = src ? src[i] : dflt;
+}
+
+int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
+  HILO_REQUIRE(d->N >= 1 && d->N <= 512, "hilo_nmpc_create: horizon %d out of range [1, 512]", d->N);
+  HILO_REQUIRE(d->dt > 0.0, "hilo_nmpc_create: dt must be positive");
+  const int N = d->N, Nc = d->Nc > 0 ? d->Nc : d->N;
+  HILO_REQUIRE(Nc <= N, "hilo_nmpc_create: control horizon %d exceeds the prediction horizon %d", Nc, N);
+  int mx, mu, np, ny = 0, discrete = 0;
+  if (d->model_id == HILO_MODEL_USER) {
+    mx = d->user_nx; mu = d->user_nu; np = d->user_np; discrete = d->user_discrete;
+    HILO_REQUIRE(mx >= 1 && mu >= 0 && np >= 0, "hilo_nmpc_create: bad user model dimensions");
+  } else {
+    int rc = hilo_model_dims(d->model_id, &mx, &mu, &np, &ny, &discrete);
+    if (rc) return rc;
+  }
+  if (d->learned) return fail(HILO_ENOTSUP, "a learned term inside a run-time compiled problem is not built");
+  const int nth = d->n_path_var;
+  HILO_REQUIRE(nth >= 0 && nth <= 1, "hilo_nmpc_create: at most one path variable is supported (got %d)", nth);
+  const int D = d->collocation_degree;
+  HILO_REQUIRE(D >= 0 && D <= COLL_MAXD, "hilo_nmpc_create: collocation degree %d out of range [0, %d]", D, COLL_MAXD);
+  HILO_REQUIRE(!D || (d->coll_A && d->coll_D), "hilo_nmpc_create: collocation needs the basis (coll_A, coll_D)");
+  HILO_REQUIRE(!D || !discrete, "hilo_nmpc_create: collocation needs the continuous model");
+  const bool cont = d->objective_continuous != 0 && !discrete;
+  HILO_REQUIRE(!(cont && D) || d->coll_B, "hilo_nmpc_create: the continuous objective with collocation needs coll_B");
+  if (D && (d->n_con > 0 || d->n_tcon > 0))
+    return fail(HILO_ENOTSUP, "collocation together with nonlinear constraints is not built (the reference also imposes them at "
+                              "the collocation points, mpc.py:1338-1356)");
+  // ---- inequality rows (same construction as hilo_nmpc.hip) ----
+  int ne = 0, nrow = 0, n_con_ref = 0, ntrow = 0, n_tcon_ref = 0, ne_stage = 0;
+  int row_expr[OCP_MAXNC], row_sign[OCP_MAXNC], row_e[OCP_MAXNC], row_ref[OCP_MAXNC];
+  int trow_expr[OCP_MAXNC], trow_sign[OCP_MAXNC], trow_e[OCP_MAXNC], trow_ref[OCP_MAXNC];
+  double row_lb[OCP_MAXNC], row_ub[OCP_MAXNC], trow_lb[OCP_MAXNC], trow_ub[OCP_MAXNC];
+  if (d->n_con > 0) {
+    ne = d->con_soft ? d->n_con : 0;
+    n_con_ref = d->con_soft ? 2 * d->n_con : d->n_con;   // rows per stage in the reference's g (mpc.py:1711-1712)
+    for (int j = 0; j < d->n_con; ++j) {
+      const double lb = d->con_lb ? d->con_lb[j] : -INFINITY, ub = d->con_ub ? d->con_ub[j] : INFINITY;
+      HILO_REQUIRE(lb <= ub, "hilo_nmpc_create: constraint %d has lb > ub", j);
+      if (d->con_soft) {   // c - e <= ub | -c - e <= -lb; a row without a finite bound constrains nothing and is dropped
+        if (ub < INFINITY) {
+          HILO_REQUIRE(nrow < OCP_MAXNC, "too many constraint rows");
+          row_expr[nrow] = j; row_sign[nrow] = 1; row_e[nrow] = j; row_lb[nrow] = -INFINITY; row_ub[nrow] = ub; row_ref[nrow++] = j;
+        }
+        if (lb > -INFINITY) {
+          HILO_REQUIRE(nrow < OCP_MAXNC, "too many constraint rows");
+          row_expr[nrow] = j; row_sign[nrow] = -1; row_e[nrow] = j; row_lb[nrow] = -INFINITY; row_ub[nrow] = -lb;
+          row_ref[nrow++] = d->n_con + j;
+        }
+      } else if (lb > -INFINITY || ub < INFINITY) {
+        HILO_REQUIRE(nrow < OCP_MAXNC, "too many constraint rows");
+        row_expr[nrow] = j; row_sign[nrow] = 1; row_e[nrow] = -1; row_lb[nrow] = lb; row_ub[nrow] = ub; row_ref[nrow++] = j;
+      }
+    }
+  }
+  ne_stage = ne;
+  if (d->n_tcon > 0) {
+    if (d->tcon_soft) ne += d->n_tcon;   // slacks e_T behind the stage slacks in v (mpc.py:1540-1548)
+    n_tcon_ref = d->tcon_soft ? 2 * d->n_tcon : d->n_tcon;
+    for (int j = 0; j < d->n_tcon; ++j) {
+      const double lb = d->tcon_lb ? d->tcon_lb[j] : -INFINITY, ub = d->tcon_ub ? d->tcon_ub[j] : INFINITY;
+      HILO_REQUIRE(lb <= ub, "hilo_nmpc_create: terminal constraint %d has lb > ub", j);
+      auto add = [&](int sign, int e, double rlb, double rub, int ref) {
+        trow_expr[ntrow] = j; trow_sign[ntrow] = sign; trow_e[ntrow] = e; trow_lb[ntrow] = rlb; trow_ub[ntrow] = rub;
+        trow_ref[ntrow++] = ref;
+      };
+      HILO_REQUIRE(nrow + ntrow + (d->tcon_soft ? (ub < INFINITY) + (lb > -INFINITY) : 1) <= OCP_MAXNC, "too many constraint rows");
+      if (d->tcon_soft) {
+        if (ub < INFINITY) add(1, ne_stage + j, -INFINITY, ub, j);
+        if (lb > -INFINITY) add(-1, ne_stage + j, -INFINITY, -lb, d->n_tcon + j);
+      } else {
+        add(1, -1, lb, ub, j);
+      }
+    }
+  }
+  const int nc = nrow + ntrow;
+  const bool hold = Nc < N;
+  const int mxa = mx + nth, mua = mu + nth;
+  const int nh = hold ? mua : 0;
+  const int nxe = mxa + ne + nh, nue = mua, nz = nxe + nue;
+  HILO_REQUIRE(nxe <= OCP_MAXNX && nue <= OCP_MAXNU,
+               "hilo_nmpc_create: %d engine states / %d inputs (model + path variable + slacks + held inputs) exceed %d / %d", nxe,
+               nue, OCP_MAXNX, OCP_MAXNU);
+  const int nps = d->n_path_stage, npt = d->n_path_term;
+  HILO_REQUIRE(nps >= 0 && npt >= 0 && nps <= 8 && npt <= 8, "hilo_nmpc_create: at most 8 path terms per cost");
+  HILO_REQUIRE((nps + npt == 0) || nth, "hilo_nmpc_create: path terms need a path variable");
+  const UserLayout L(mx, mu, nth, ne, nps, npt);
+  HILO_REQUIRE(L.o_end <= OCP_NCOST, "hilo_nmpc_create: cost block too small for this problem");
+  const bool tv = d->time_varying != 0;
+  const int nsd = tv ? mx + mu + np : 0;
+  const int nconst = (int)((__builtin_offsetof(OcpConst, cost) + sizeof(double) * L.o_end + 7) / 8);
+  const size_t fixed_b = ocp_fixed_doubles(nxe, nue, nconst, np + mu, nsd, 0, N) * sizeof(double);
+  const size_t iter_b = ocp_iter_doubles(nxe, nue, nc, N) * sizeof(double);
+  const bool big = fixed_b + iter_b > 160 * 1024;
+  if (fixed_b > 160 * 1024) return fail(HILO_ENOTSUP, "horizon %d needs %zu B of LDS for the problem constants alone", N, fixed_b);
+
+  hilo_nmpc* h = new hilo_nmpc();
+  memset(h, 0, sizeof(*h));
+  h->device = device; h->model_id = d->model_id; h->nx = mx; h->nu = mu; h->np = np; h->N = N;
+  h->nu_out = mu; h->jit_policy = JIT_USER;
+  h->nxe = nxe; h->nue = nue; h->nxv = mxa; h->ntail = ne; h->Nc = Nc;
+  h->tv_width = nsd;
+  h->jit_ws_bytes = big ? iter_b : 0;
+  h->jit_coll_d = D;
+  h->n_vc = (N + 1) * mxa + Nc * mua + ne;
+  h->n_v = h->n_vc + N * D * mxa;                                  // mpc.py:1440-1453
+  h->n_g = N * (mxa + n_con_ref + D * mxa) + n_tcon_ref;          // mpc.py:1657-1669, :1684-1725
+  OcpConst& c = h->host;
+  memset(&c, 0, sizeof(c));
+  ocp_default_options(c);
+  c.N = N; c.Nc = Nc; c.order = d->erk_order >= 1 ? d->erk_order : 4; c.nsub = d->n_sub >= 1 ? d->n_sub : 1;
+  c.dt = d->dt;
+  c.flags = 1;
+  if (D) {
+    c.coll.d = D;
+    for (int i = 0; i < D * D; ++i) c.coll.A[i] = d->coll_A[i];
+    for (int i = 0; i <= D; ++i) { c.coll.Dc[i] = d->coll_D[i]; c.coll.Bq[i] = d->coll_B ? d->coll_B[i] : 0.0; }
+  }
+  if (d->max_iter > 0) c.max_iter = d->max_iter;
+  if (d->acceptable_iter > 0) c.acceptable_iter = d->acceptable_iter;
+  if (d->tol > 0) c.tol = d->tol;
+  if (d->acceptable_tol > 0) c.acceptable_tol = d->acceptable_tol;
+  if (d->mu_init > 0) c.mu_init = d->mu_init;
+  double sx[OCP_MAXNX], su[OCP_MAXNU];
+  copy_or1(sx, d->x_scaling, mx, 1.0);
+  copy_or1(su, d->u_scaling, mu, 1.0);
+  for (int i = 0; i < nz; ++i) c.sz[i] = 1.0;   // path variable, slacks, held inputs, virtual input: unit scaling (mpc.py:1200-1201)
+  for (int i = 0; i < mx; ++i) c.sz[i] = sx[i];
+  for (int i = 0; i < mu; ++i) c.sz[nxe + i] = su[i];
+  const double relax = d->bound_relax_factor >= 0.0 ? d->bound_relax_factor : 1e-8;
+  auto relaxed_lb = [&](double lb) { return lb > -INFINITY ? lb - relax * fmax(1.0, fabs(lb)) : lb; };
+  auto relaxed_ub = [&](double ub) { return ub < INFINITY ? ub + relax * fmax(1.0, fabs(ub)) : ub; };
+  // ---- cost block (UserLayout): model z index -> augmented z index [x, theta | u, u_theta]
+  auto az = [&](int i) { return i < mx ? i : mxa + (i - mx); };
+  const int mz = mx + mu, mza = mxa + mua;
+  for (int i = 0; i < mz; ++i) {
+    for (int j = 0; j < mz; ++j) c.cost[L.o_wz + az(i) * mza + az(j)] = d->Wz ? d->Wz[i * mz + j] : 0.0;
+    c.cost[L.o_zref + az(i)] = d->zref ? d->zref[i] : 0.0;
+  }
+  for (int i = 0; i < mx; ++i) {
+    for (int j = 0; j < mx; ++j) c.cost[L.o_wn + i * mxa + j] = d->WN ? d->WN[i * mx + j] : 0.0;
+    c.cost[L.o_xrefn + i] = d->xrefN ? d->xrefN[i] : 0.0;
+  }
+  for (int i = 0; i < mu * mu; ++i) c.cost[L.o_wdu + i] = d->Wdu ? d->Wdu[i] : 0.0;
+  c.cost[L.o_hasdu] = d->Wdu ? 1.0 : 0.0;
+  if (nth && d->has_u_pf_ref) {   // mpc.py:1202-1204
+    const int iu = mxa + mu;
+    c.cost[L.o_wz + iu * mza + iu] = d->u_pf_weight;
+    c.cost[L.o_zref + iu] = d->u_pf_ref;
+  }
+  for (int a = 0; a < ne_stage; ++a)    // e^T W e once per stage (mpc.py:1708), W = 1e4 I by default (modeling.py:875)
+    for (int b = 0; b < ne_stage; ++b)
+      c.cost[L.o_we + a * ne + b] = d->con_weight ? d->con_weight[a * ne_stage + b] : (a == b ? 1e4 : 0.0);
+  for (int a = ne_stage; a < ne; ++a)   // e_T^T W e_T once (mpc.py:1686)
+    for (int b = ne_stage; b < ne; ++b)
+      c.cost[L.o_wet + a * ne + b] = d->tcon_weight ? d->tcon_weight[(a - ne_stage) * d->n_tcon + (b - ne_stage)] : (a == b ? 1e4 : 0.0);
+  int rcode = HILO_OK;
+  for (int a = 0; a < nps; ++a) {
+    if (!d->path_stage_idx || !d->path_stage_W || d->path_stage_idx[a] < 0 || d->path_stage_idx[a] >= mx)
+      rcode = fail(HILO_EINVAL, "hilo_nmpc_create: bad stage path term %d", a);
+    else {
+      c.cost[L.o_idxs + a] = d->path_stage_idx[a];
+      for (int b = 0; b < nps; ++b) c.cost[L.o_ws + a * nps + b] = d->path_stage_W[a * nps + b];
+    }
+  }
+  for (int a = 0; a < npt; ++a) {
+    if (!d->path_term_idx || !d->path_term_W || d->path_term_idx[a] < 0 || d->path_term_idx[a] >= mx)
+      rcode = fail(HILO_EINVAL, "hilo_nmpc_create: bad terminal path term %d", a);
+    else {
+      c.cost[L.o_idxt + a] = d->path_term_idx[a];
+      for (int b = 0; b < npt; ++b) c.cost[L.o_wt + a * npt + b] = d->path_term_W[a * npt + b];
+    }
+  }
+  if (rcode) { delete h; return rcode; }
+  c.nc = nrow; c.nc_term = ntrow; c.n_con_ref = n_con_ref; c.n_tcon_ref = n_tcon_ref;
+  c.cost[L.o_tsoft] = d->tcon_soft ? 1.0 : 0.0;
+  for (int m = 0; m < OCP_MAXNC; ++m) { c.dlb[m] = -INFINITY; c.dub[m] = INFINITY; }
+  for (int m = 0; m < nrow; ++m) {
+    c.cost[L.o_rowx + m] = row_expr[m]; c.cost[L.o_rows + m] = row_sign[m]; c.cost[L.o_rowe + m] = row_e[m];
+    c.dlb[m] = relaxed_lb(row_lb[m]); c.dub[m] = relaxed_ub(row_ub[m]);
+    c.row_ref[m] = (short)row_ref[m];
+  }
+  for (int r = 0; r < ntrow; ++r) {
+    c.cost[L.o_trowx + r] = trow_expr[r]; c.cost[L.o_trows + r] = trow_sign[r]; c.cost[L.o_trowe + r] = trow_e[r];
+    c.dlb[nrow + r] = relaxed_lb(trow_lb[r]); c.dub[nrow + r] = relaxed_ub(trow_ub[r]);
+    c.trow_ref[r] = (short)trow_ref[r];
+  }
+  for (int i = mx; i < mxa + ne; ++i) c.x0_free_mask |= 1u << i;           // theta_0 and the slacks are variables (mpc.py:785-789)
+  for (int a = 0; a < ne; ++a) c.k0_only_mask |= 1u << (mxa + a);          // one box per shared slack
+  h->base_free_mask = c.x0_free_mask;
+  // ---- boxes of the engine's z = [x | theta | e | uh | u | u_theta], scaled like mpc.py:253-259, relaxed like IPOPT ----
+  for (int i = 0; i < nz; ++i) {
+    double lb = -INFINITY, ub = INFINITY;
+    if (i < mx) { if (d->x_lb) lb = d->x_lb[i] / c.sz[i]; if (d->x_ub) ub = d->x_ub[i] / c.sz[i]; }
+    else if (i < mxa) { lb = d->theta_lb; ub = d->theta_ub; }                                      // mpc.py:1198-1199
+    else if (i < mxa + ne) {                                                                       // :1533-1534, :1544-1545
+      const int a = i - mxa;
+      lb = 0.0;
+      ub = a < ne_stage ? (d->con_max_violation ? d->con_max_violation[a] : INFINITY)
+                        : (d->tcon_max_violation ? d->tcon_max_violation[a - ne_stage] : INFINITY);
+    }
+    else if (i < nxe) {}                                                                            // held inputs: states without a box
+    else if (i < nxe + mu) { const int j = i - nxe; if (d->u_lb) lb = d->u_lb[j] / c.sz[i]; if (d->u_ub) ub = d->u_ub[j] / c.sz[i]; }
+    else { lb = d->u_pf_lb; ub = d->u_pf_ub; }                                                      // mpc.py:1196-1197
+    lb = relaxed_lb(lb); ub = relaxed_ub(ub);
+    if (!(lb < ub)) { delete h; return fail(HILO_EINVAL, "hilo_nmpc_create: empty box for variable %d", i); }
+    c.lbz[i] = lb; c.ubz[i] = ub;
+  }
+  // ---- compile / load ----
+  JitRequest rq;
+  rq.user_source = d->user_source;
+  rq.policy = JIT_USER;
+  rq.nth = nth; rq.ne = ne; rq.nc = nc; rq.coll_d = D; rq.N = N;
+  rq.hold = hold; rq.cont = cont; rq.tv = tv; rq.big = big; rq.has_fun = d->user_has_fun != 0;
+  int rc = jit_nmpc_kernels(rq, device, &h->jit);
+  if (!rc && (h->jit.dims[0] != mx || h->jit.dims[1] != mu || h->jit.dims[2] != np || h->jit.dims[6] != nxe || h->jit.dims[7] != nue))
+    rc = fail(HILO_EINVAL, "hilo_nmpc_create: the compiled problem has model (nx, nu, np) = (%d, %d, %d), engine (%d, %d); the "
+                           "description says (%d, %d, %d), (%d, %d)", h->jit.dims[0], h->jit.dims[1], h->jit.dims[2], h->jit.dims[6],
+              h->jit.dims[7], mx, mu, np, nxe, nue);
+  if (rc) { hilo_nmpc_destroy(h); return rc; }
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->dev, sizeof(OcpConst));
+  if (e == hipSuccess) e = hipMemcpy(h->dev, &c, sizeof(OcpConst), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->v_guess, sizeof(double) * h->n_v);
+  if (e == hipSuccess) {
+    // mpc.py:1468-1482: the guess is tiled over the horizon (scaled, mpc.py:255,259); slacks start at 0 (mpc.py:1535)
+    double* g = new double[h->n_v];
+    for (int i = 0; i < h->n_v; ++i) g[i] = 0.0;
+    for (int k = 0; k <= N; ++k) {
+      for (int i = 0; i < mx; ++i) g[k * mxa + i] = (d->x_guess ? d->x_guess[i] : 0.0) / sx[i];
+      if (nth) g[k * mxa + mx] = d->theta_guess;                                            // mpc.py:1194
+    }
+    for (int k = 0; k < Nc; ++k) {
+      for (int i = 0; i < mu; ++i) g[(N + 1) * mxa + k * mua + i] = (d->u_guess ? d->u_guess[i] : 0.0) / su[i];
+      if (nth) g[(N + 1) * mxa + k * mua + mu] = d->u_pf_lb + 0.0001;                       // mpc.py:1195
+    }
+    for (int q = 0; q < N * D * mxa; ++q) {                                                 // mpc.py:1321
+      const int i = q % mxa;
+      g[h->n_vc + q] = i < mx ? (d->x_guess ? d->x_guess[i] : 0.0) / sx[i] : d->theta_guess;
+    }
+    e = hipMemcpy(h->v_guess, g, sizeof(double) * h->n_v, hipMemcpyHostToDevice);
+    delete[] g;
+  }
+  if (e != hipSuccess) {
+    hilo_nmpc_destroy(h);
+    return fail(HILO_EHIP, "hilo_nmpc_create: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return HILO_OK;
+}
+
+}  // namespace hilo
+
+using namespace hilo;
+
+extern "C" int hilo_jit_precompile(const char* user_source, int policy, int nth, int ne, int nc, int coll_d, int N, int hold, int cont,
+                                   int tv, int big, int has_fun) {
+  HILO_REQUIRE(user_source, "hilo_jit_precompile: NULL source");
+  JitRequest rq;
+  rq.user_source = user_source;
+  rq.policy = policy; rq.nth = nth; rq.ne = ne; rq.nc = nc; rq.coll_d = coll_d; rq.N = N;
+  rq.hold = hold != 0; rq.cont = cont != 0; rq.tv = tv != 0; rq.big = big != 0; rq.has_fun = has_fun != 0;
+  JitKernels k;
+  setenv("HILO_JIT_COMPILE_ONLY", "1", 1);
+  const int rc = jit_nmpc_kernels(rq, 0, &k);
+  unsetenv("HILO_JIT_COMPILE_ONLY");
+  return rc;
+}

@@ -15,15 +15,13 @@
 //
 // Mapping: one workgroup (one wave of 64 lanes) per problem instance, the whole iterate in LDS; see DESIGN.md 5.1.
 #pragma once
-#include <math.h>
-
 #include "hilo_colloc.h"
 #include "hilo_common.h"
 #include "hilo_models.h"
 
 namespace hilo {
 
-constexpr int OCP_MAXNX = 8, OCP_MAXNU = 8, OCP_MAXNZ = OCP_MAXNX + OCP_MAXNU;
+constexpr int OCP_MAXNX = 12, OCP_MAXNU = 8, OCP_MAXNZ = OCP_MAXNX + OCP_MAXNU;
 constexpr int OCP_FILTER = 16;
 constexpr int OCP_MAXNC = 4;  // nonlinear inequality rows per stage
 #ifndef HILO_OCP_TPB
@@ -44,6 +42,7 @@ constexpr int OCP_NCOST = 2 * OCP_MAXNZ * OCP_MAXNZ + 4 * OCP_MAXNZ + 64;
 
 struct OcpConst {
   int N, order, nsub, max_iter, acceptable_iter, flags;
+  int Nc, reserved0;   // control horizon (mpc.py:1629-1630: beyond it the last input is held); read by policies with NH > 0
   double dt;
   double lbz[OCP_MAXNZ], ubz[OCP_MAXNZ];  // relaxed bounds of a stage's (x,u) slots (scaled); +-inf if none
   double sz[OCP_MAXNZ];                   // scaling of (x,u)
@@ -161,6 +160,27 @@ __device__ __forceinline__ double block_reduce(double v, __attribute__((address_
   return r;
 }
 
+// optional members of a policy, with their defaults
+//   NH     number of inputs carried as extra states so that they can be HELD beyond the control horizon (0: Nc == N)
+//   FUSED  the policy evaluates the shooting map and the Lagrange term of an interval together (`dyn_cost`): the
+//          continuous objective integrates the cost through the collocation states / Runge-Kutta stages of the map
+template <class PB, class = void> struct pb_nh { static constexpr int value = 0; };
+template <class PB> struct pb_nh<PB, void_tt<decltype(PB::NH)>> { static constexpr int value = PB::NH; };
+template <class PB, class = void> struct pb_fused { static constexpr bool value = false; };
+template <class PB> struct pb_fused<PB, void_tt<decltype(PB::FUSED)>> { static constexpr bool value = PB::FUSED; };
+
+// LDS / workspace footprint as plain functions of the dimensions (the host sizes run-time compiled problems with them)
+__host__ __device__ constexpr size_t ocp_iter_doubles(int NX, int NU, int NC, int N) {
+  const size_t NZ = NX + NU, NDIR = NZ * (NZ + 1) / 2, S = (size_t)(N + 1) * NZ;
+  return 12 * S + 4 * (size_t)N * NX + (size_t)N * NX * NZ + (size_t)N * NZ * NZ + (size_t)(N + 1) * NDIR +
+         (size_t)(N + 1) * NX * NX + (size_t)(N + 1) * NX + (size_t)N * NU * NX + (size_t)N * NU + (size_t)N * NX * NX +
+         (size_t)N * NX + (size_t)N * NC * (12 + NZ);
+}
+__host__ __device__ constexpr size_t ocp_fixed_doubles(int NX, int NU, int NCONST, int NPAR, int NSD, int NEXT, int N) {
+  const size_t NZ = NX + NU;
+  return NCONST + NZ * NZ + NZ + (N + 1) + 2 * 16 + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1 + NEXT;
+}
+
 enum OcpPhase { PH_DERIV = 0, PH_ERR, PH_RICCATI, PH_STEP, PH_LS, PH_UPDATE, PH_NRIC, PH_NLS, PH_COUNT };
 
 template <class PB>
@@ -168,6 +188,8 @@ struct Ocp {
   static constexpr int NX = PB::NX, NU = PB::NU, NZ = NX + NU, NDIR = NZ * (NZ + 1) / 2, NXDIR = NX * (NX + 1) / 2;
   static constexpr int NPAR = PB::NPAR > 0 ? PB::NPAR : 1, NSD = PB::NSD;
   static constexpr bool FIX_X0 = PB::FIX_X0;
+  static constexpr int NH = pb_nh<PB>::value;          // held inputs (states NX-NH..NX-1), control horizon pc.Nc
+  static constexpr bool FUSED = pb_fused<PB>::value;   // dyn_cost(): shooting map + Lagrange term in one evaluation
   // model with a learned term: lanes that evaluate the dynamics at the same point share its kernel sum (GpExt)
   static constexpr bool COOP = PB::COOP;
   static constexpr int NEXT = COOP ? 12 * OCP_TPB : 0;
@@ -181,14 +203,14 @@ struct Ocp {
   // stage products of the Riccati recursion on the f64 matrix cores (one wave per instance, a stage's z and the
   // right-hand-side column fit the 16 columns of v_mfma_f64_16x16x4)
   static constexpr bool MFMA_STAGE = OCP_TPB == 64 && NZ + 1 <= 16 && NX <= 16;
-  static constexpr int NCONST = (int)((offsetof(OcpConst, cost) + sizeof(double) * PB::NCOST + 7) / 8);
+  static constexpr int NCONST = (int)((__builtin_offsetof(OcpConst, cost) + sizeof(double) * PB::NCOST + 7) / 8);
 
   // Storage of the iterate: LDS (default) or, for problems that do not fit (long horizons, wide stages), a per-instance
   // workspace in global memory (PB::BIG; L2-resident, same code path, longer latencies).  Problem constants, the pivot
   // block, reduction scratch and the per-instance data always stay in LDS.
   static constexpr bool BIG = PB::BIG;
-  using dp = std::conditional_t<BIG, double*, lds_double*>;
-  using cdp = std::conditional_t<BIG, const double*, lds_cdouble*>;
+  using dp = cond_t<BIG, double*, lds_double*>;
+  using cdp = cond_t<BIG, const double*, lds_cdouble*>;
   struct Lds {
     const __attribute__((address_space(3))) OcpConst* pc;
     dp Z, Zt, D, zL, zU, dzL, dzU, grad, lam, lamn, c, ct, AB, W, Qd, P, pv, Kg, kff, sig, rb, Acl, bcl;
@@ -196,17 +218,13 @@ struct Ocp {
     dp cs, cst, cnu, cnun, cvL, cvU, cdvL, cdvU, cds, cd, csig, crb, Jd;  // [N][NC] (Jd: [N][NC][NZ])
     lds_double *Mm, *mm, *fk, *filt, *red, *par, *sd, *ext;
   };
-  __host__ __device__ static size_t iter_doubles(int N) {  // the iterate (LDS or workspace)
-    const size_t S = (size_t)(N + 1) * NZ;
-    return 12 * S + 4 * (size_t)N * NX + (size_t)N * NX * NZ + (size_t)N * NZ * NZ + (size_t)(N + 1) * NDIR +
-           (size_t)(N + 1) * NX * NX + (size_t)(N + 1) * NX + (size_t)N * NU * NX + (size_t)N * NU + (size_t)N * NX * NX +
-           (size_t)N * NX + (size_t)N * NC * (12 + NZ);
+  static_assert(OCP_FILTER == 16, "ocp_fixed_doubles assumes a filter of 16 entries");
+  __host__ __device__ static constexpr size_t iter_doubles(int N) { return ocp_iter_doubles(NX, NU, NC, N); }  // the iterate (LDS or workspace)
+  __host__ __device__ static constexpr size_t fixed_doubles(int N) {  // always LDS
+    return ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, N);
   }
-  __host__ __device__ static size_t fixed_doubles(int N) {  // always LDS
-    return NCONST + NZ * NZ + NZ + (N + 1) + 2 * OCP_FILTER + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1 + NEXT;
-  }
-  __host__ __device__ static size_t lds_doubles(int N) { return fixed_doubles(N) + (BIG ? 0 : iter_doubles(N)); }
-  __host__ __device__ static size_t ws_doubles(int N) { return BIG ? iter_doubles(N) : 0; }
+  __host__ __device__ static constexpr size_t lds_doubles(int N) { return fixed_doubles(N) + (BIG ? 0 : iter_doubles(N)); }
+  __host__ __device__ static constexpr size_t ws_doubles(int N) { return BIG ? iter_doubles(N) : 0; }
   // The non-inlined phases take (LDS base, workspace) and re-derive the pointer table: a struct argument would be
   // passed through scratch memory per lane (measured: 380 MB of scratch writes per 1024-instance launch).
   __device__ static int horizon_of(lds_double* base) {
@@ -244,6 +262,9 @@ struct Ocp {
   // a slot (k, i) of the stage-major primal layout is a variable unless it is a pinned x_0 or the unused u_N
   __device__ static bool x0_pinned(const OcpConst& pc, int i) { return FIX_X0 && i < NX && !((pc.x0_free_mask >> i) & 1u); }
   __device__ static bool is_free(const OcpConst& pc, int k, int i) {
+    if constexpr (NH > 0) {
+      if (i >= NX && k >= pc.Nc) return false;   // beyond the control horizon the input is not a variable
+    }
     return !((k == 0 && x0_pinned(pc, i)) || (k == pc.N && i >= NX));
   }
   // inequality row m exists at stage k
@@ -318,8 +339,12 @@ struct Ocp {
         double xn[NX];
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = Zp[k * NZ + NX + i];
-        PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
-        fpart += PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
+        if constexpr (FUSED) {
+          fpart += PB::dyn_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
+        } else {
+          PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
+          fpart += PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
+        }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
           const double ci = Zp[(k + 1) * NZ + i] - xn[i];
@@ -425,11 +450,14 @@ struct Ocp {
           PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, ext);
           if (!active) continue;
         } else {
-          PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
+          if constexpr (!FUSED) PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
         }
         // a policy with a purely quadratic stage cost supplies value / gradient / (constant) Hessian in closed form
         Jet2 lc(0.0);
-        if constexpr (!PB::QUAD_COST) lc = PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
+        if constexpr (FUSED) {
+          static_assert(!FUSED || (!COOP && !PB::QUAD_COST), "fused cost: Taylor evaluation, no cooperative model");
+          lc = PB::dyn_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
+        } else if constexpr (!PB::QUAD_COST) lc = PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
         double q = lc.b;
         {  // operands first (one LDS wait), then the two store groups each under ONE condition
           double zn[NX], lamv[NX];
@@ -905,6 +933,22 @@ struct Ocp {
         *dst = s + dg;   // dg = 0 in the right-hand-side column (i != NZ)
       }
       }
+      if constexpr (NH > 0) {
+        // beyond the control horizon the inputs of the stage are not variables (mpc.py:1629-1630): their rows / columns of
+        // the stage matrix are replaced by the identity and a zero right-hand side, so K = 0, kff = 0, P_k = M_xx
+        if (k >= pc.Nc) {
+          __syncthreads();
+          OCP_FOR(e, NU * (NZ + 1)) {
+            const int a = e / (NZ + 1), j = e - a * (NZ + 1);
+            if (j == NZ) l.mm[NX + a] = 0.0;
+            else {
+              l.Mm[(NX + a) * NZ + j] = (j == NX + a) ? 1.0 : 0.0;
+              l.Mm[j * NZ + NX + a] = (j == NX + a) ? 1.0 : 0.0;
+            }
+          }
+          factored = false;   // phase (2) factors the identity block from LDS
+        }
+      }
       __syncthreads();
       // (2) pivot block (factored redundantly per lane), feedback, cost-to-go: lane (i, j), j = 0..NX:
       //   y_j = R^-1 M_ux[:, j] (j < NX) or R^-1 m_u (j = NX);  P_k[i][j] = sym(M_xx)[i][j] - M_xu[i] y_j;
@@ -1133,21 +1177,21 @@ struct Ocp {
 // ---------------------------------------------------------------------------------------------------------------
 // The solve kernel.  v layout (device, per instance, scaled): [prefix (v_prefix doubles, untouched) | x_0..x_N | u_0..u_{N-1}]
 // ---------------------------------------------------------------------------------------------------------------
+// The whole solve of one instance: a device function, so that the same body serves the kernels compiled into the library
+// (dynamic LDS) and the kernels compiled at run time for user models (static LDS sized for their horizon, hilo_jit.hip).
 template <class PB, int TPB>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MINW, HILO_OCP_MINW))) void ocp_solve_kernel(const OcpConst* __restrict__ pcg, int64_t batch,
-                                                       const double* __restrict__ x0, const double* __restrict__ par,
-                                                       int64_t par_stride, const double* __restrict__ sdata,
-                                                       int64_t sd_stride, const double* __restrict__ v0,
-                                                       int64_t v0_stride, int v0_prefix, int v_prefix, double* __restrict__ v_opt,
-                                                       double* __restrict__ f_opt, double* __restrict__ lam_g,
-                                                       double* __restrict__ first, int first_kind,
-                                                       int32_t* __restrict__ status, int32_t* __restrict__ iters,
-                                                       double* __restrict__ kkt, long long* __restrict__ prof,
-                                                       double* __restrict__ ws = nullptr) {
+__device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpConst* __restrict__ pcg, int64_t batch,
+                                               const double* __restrict__ x0, const double* __restrict__ par,
+                                               int64_t par_stride, const double* __restrict__ sdata,
+                                               int64_t sd_stride, const double* __restrict__ v0,
+                                               int64_t v0_stride, int v0_prefix, int v_prefix, double* __restrict__ v_opt,
+                                               double* __restrict__ f_opt, double* __restrict__ lam_g,
+                                               double* __restrict__ first, int first_kind,
+                                               int32_t* __restrict__ status, int32_t* __restrict__ iters,
+                                               double* __restrict__ kkt, long long* __restrict__ prof,
+                                               double* __restrict__ ws) {
   using S = Ocp<PB>;
-  constexpr int NX = S::NX, NU = S::NU, NZ = S::NZ, NC = S::NC, NXV = S::NXV, NTAIL = NX - NXV;
-  extern __shared__ double lds_raw_generic[];
-  lds_double* lds_raw = (lds_double*)lds_raw_generic;
+  constexpr int NX = S::NX, NU = S::NU, NZ = S::NZ, NC = S::NC, NXV = S::NXV, NH = S::NH, NTAIL = NX - NXV - NH;
   const int t = threadIdx.x;
   const int64_t b = blockIdx.x;
   if (b >= batch) return;
@@ -1175,9 +1219,13 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     const int k = e / NZ, i = e - k * NZ;
     double v;
     // reference layout [x (NXV per stage) | u | shared tail]; the tail is carried as constant states (same value in every stage)
+    // with a control horizon Nc < N the reference holds Nc input blocks; the held copy of stage k is the input of stage
+    // min(k - 1, Nc - 1) (zero at stage 0, where it is pinned and never read)
+    const int Ncv = NH > 0 ? pc.Nc : N;
     if (i < NXV) v = (k == 0 && S::x0_pinned(pc, i)) ? x0[b * S::NX0 + i] / pc.sz[i] : vb[k * NXV + i];
-    else if (i < NX) v = vb[(N + 1) * NXV + N * NU + (i - NXV)];
-    else v = (k < N) ? vb[(N + 1) * NXV + k * NU + (i - NX)] : 0.0;
+    else if (i < NXV + NTAIL) v = vb[(N + 1) * NXV + Ncv * NU + (i - NXV)];
+    else if (i < NX) v = k == 0 ? 0.0 : vb[(N + 1) * NXV + ((k - 1 < Ncv ? k - 1 : Ncv - 1)) * NU + (i - NXV - NTAIL)];
+    else v = (k < Ncv) ? vb[(N + 1) * NXV + k * NU + (i - NX)] : 0.0;
     const bool fr = S::is_free(pc, k, i);
     const double lb = fr ? S::lb_of(pc, k, i) : -INFINITY, ub = fr ? S::ub_of(pc, k, i) : INFINITY;
     l.lbA[e] = lb;
@@ -1238,6 +1286,9 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     __syncthreads();
   }
 
+  // smallest barrier parameter: W&B eq. (7) writes eps_tol / 10; IPOPT's MonotoneMuUpdate uses
+  // min(tol, compl_inf_tol) / (barrier_tol_factor + 1) - the value behind the last printed digit of the reference's CSTR notebook
+  const double mu_min = uni(fmin(pc.tol, 1e-4) / (pc.kappa_eps + 1.0));
   double mu = uni(pc.mu_init), tau = uni(fmax(pc.tau_min, 1.0 - mu));
   double delta_last = 0.0;
   int nfilt = 0, acc_count = 0, it = 0, st = 0;
@@ -1268,8 +1319,8 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
     // ---- barrier update (W&B eq. 7) ----
     for (int r = 0; r < 20; ++r) {
       const double Emu = uni(nmax(nmax(dual_s, prim), (r == 0 ? cmu : S::compl_error(l, mu)) / s_c));
-      if (!(Emu <= pc.kappa_eps * mu && mu > pc.tol / 10 * (1 + 1e-12))) break;
-      mu = uni(fmax(pc.tol / 10, fmin(pc.kappa_mu * mu, pow(mu, pc.theta_mu))));
+      if (!(Emu <= pc.kappa_eps * mu && mu > mu_min * (1 + 1e-12))) break;
+      mu = uni(fmax(mu_min, fmin(pc.kappa_mu * mu, pow(mu, pc.theta_mu))));
       tau = uni(fmax(pc.tau_min, 1.0 - mu));
       nfilt = 0;
     }
@@ -1466,12 +1517,14 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
   }
 
   // ---- write back ([x-block | u-block] after the prefix) ----
-  double* vo = v_opt + b * (int64_t)(v_prefix + (N + 1) * NXV + N * NU + NTAIL) + v_prefix;
+  const int Ncw = NH > 0 ? pc.Nc : N;
+  double* vo = v_opt + b * (int64_t)(v_prefix + (N + 1) * NXV + Ncw * NU + NTAIL) + v_prefix;
   OCP_FOR(e, SL) {
     const int k = e / NZ, i = e - k * NZ;
     if (i < NXV) vo[k * NXV + i] = l.Z[e];
-    else if (i < NX) { if (k == 0) vo[(N + 1) * NXV + N * NU + (i - NXV)] = l.Z[e]; }
-    else if (k < N) vo[(N + 1) * NXV + k * NU + (i - NX)] = l.Z[e];
+    else if (i < NXV + NTAIL) { if (k == 0) vo[(N + 1) * NXV + Ncw * NU + (i - NXV)] = l.Z[e]; }
+    else if (i < NX) {}   // held inputs: copies of u_{Nc-1}, not part of the reference's decision vector
+    else if (k < Ncw) vo[(N + 1) * NXV + k * NU + (i - NX)] = l.Z[e];
   }
   if (lam_g) {
     // the reference's g: per stage [shooting defect (NXV rows) | constraint rows (n_con_ref)] (mpc.py:1667, :1707-1725)
@@ -1513,6 +1566,22 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
       for (int q = 0; q < PH_COUNT; ++q) prof[q] = tprof[q];
   }
 #undef OCP_TICK
+}
+
+template <class PB, int TPB>
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MINW, HILO_OCP_MINW))) void ocp_solve_kernel(const OcpConst* __restrict__ pcg, int64_t batch,
+                                                       const double* __restrict__ x0, const double* __restrict__ par,
+                                                       int64_t par_stride, const double* __restrict__ sdata,
+                                                       int64_t sd_stride, const double* __restrict__ v0,
+                                                       int64_t v0_stride, int v0_prefix, int v_prefix, double* __restrict__ v_opt,
+                                                       double* __restrict__ f_opt, double* __restrict__ lam_g,
+                                                       double* __restrict__ first, int first_kind,
+                                                       int32_t* __restrict__ status, int32_t* __restrict__ iters,
+                                                       double* __restrict__ kkt, long long* __restrict__ prof,
+                                                       double* __restrict__ ws = nullptr) {
+  extern __shared__ double lds_raw_generic[];
+  ocp_solve_body<PB, TPB>((lds_double*)lds_raw_generic, pcg, batch, x0, par, par_stride, sdata, sd_stride, v0, v0_stride, v0_prefix,
+                          v_prefix, v_opt, f_opt, lam_g, first, first_kind, status, iters, kkt, prof, ws);
 }
 
 }  // namespace hilo

@@ -21,10 +21,13 @@ STACK = 8
 
 class Expr:
     """Node of an expression tree: op in {'const','x','u','p','theta', binary / unary op names}."""
-    __slots__ = ('op', 'args', 'value', 'name')
+    __slots__ = ('op', 'args', 'value', 'name', 'serial')
+    _count = 0
 
     def __init__(self, op, args=(), value=None, name=None):
         self.op, self.args, self.value, self.name = op, tuple(args), value, name
+        Expr._count += 1
+        self.serial = Expr._count        # creation order = the order the user's statements were evaluated (code emission)
 
     # ---- operators -----------------------------------------------------------------------------------------
     @staticmethod

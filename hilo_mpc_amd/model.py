@@ -8,7 +8,8 @@ import copy
 
 import numpy as np
 
-from .expr import SymVector
+from . import expr as _expr
+from .expr import Expr, SymVector
 
 
 # name -> (model id, is_linear, state names, input names, parameter names, measurement names)
@@ -20,25 +21,51 @@ ZOO = {
     'chemostat4': (3, False, ['X', 'S', 'P', 'I'], ['DS', 'DI'], ['Sf', 'If', 'ISF', 'IRF'], ['yX', 'yP']),
     'pendulum4': (4, False, ['x', 'v', 'theta', 'omega'], ['F'], [], ['yx', 'yv', 'ytheta', 'tomega']),
     'robot6': (5, False, ['px', 'vx', 'py', 'vy', 'psi', 'omega'], ['a', 'alpha'], [], ['ypx', 'ypy']),
+    'cstr3': (6, False, ['C_A', 'C_B', 'T'], ['Q'], [], ['r']),           # CSTR_Example.ipynb cell 6
     'linear2': (7, True, ['x_1', 'x_2'], ['u'], ['k_1', 'k_2'], ['y']),
     'chemostat4_gp': (8, False, ['X', 'S', 'P', 'I'], ['DS', 'DI'], ['Sf', 'If', 'ISF', 'IRF'], ['yX', 'yP']),
 }
 # zoo models whose right-hand side has a slot for a learned term: base name -> (label, features, hybrid functor)
 LEARNABLE = {'chemostat4': ('mu', ['S', 'I'], 'chemostat4_gp')}
 NATIVE_DISCRETE = {'toy1d', 'lti'}
+# device functor of each zoo model (csrc/hilo_models.h): what a run-time compiled problem aliases as `UserModel`
+ZOO_FUNCTOR = {'toy1d': 'Toy1D', 'bioreactor3': 'Bioreactor3', 'chemostat4': 'Chemostat4', 'pendulum4': 'Pendulum4',
+               'robot6': 'Robot6', 'linear2': 'Linear2', 'cstr3': 'Cstr3'}
+MODEL_USER = 100    # HILO_MODEL_USER: the model is defined by expressions and compiled at setup (csrc/hilo_jit.hip)
 
 
 class Model:
-    """Zoo model.  `Model('chemostat4').discretize('rk4').setup(dt=1.)`.
+    """Zoo model: `Model('chemostat4').discretize('rk4').setup(dt=1.)`, or a model defined by expressions like the reference's
+    (`Model.set_dynamical_states / set_inputs / set_parameters / set_dynamical_equations / set_measurement_equations`,
+    hilo_mpc/modules/dynamic_model/dynamic_model.py:1293-1553):
+
+        m = Model(name='plant')
+        x = m.set_dynamical_states(['C_A', 'C_B', 'T']); u = m.set_inputs(['Q'])
+        r = 5000 * exp(-1e4 / (1.987 * x[2])) * x[0] - 1e6 * exp(-1.5e4 / (1.987 * x[2])) * x[1]
+        m.set_dynamical_equations([(1 - x[0]) / 60 - r, -x[1] / 60 + r, 5 * r + (400 - x[2]) / 60 + u[0] / 1e5])
+        m.setup(dt=1.)
+
+    Such a model is emitted as a device functor (hilo_mpc_amd/codegen.py) and compiled with hiprtc at `NMPC.setup()`.
 
     For `Model('lti', A=..., B=..., C=...)` the matrices define a discrete LTI system
     (`x+ = A x + B u`, `y = C x`, cf. tests/test_LMPC.py:8-19)."""
 
-    def __init__(self, name, A=None, B=None, C=None, discrete=None):
+    def __init__(self, name=None, A=None, B=None, C=None, discrete=None, id=None, plot_backend=None, **kwargs):
         if name == 'chemostat4_gp':
             raise ValueError("build the hybrid model with Model('chemostat4').substitute_from(gp)")
         if name not in ZOO:
-            raise ValueError(f"unknown model '{name}'; the device zoo holds {sorted(ZOO)}")
+            # a model defined by expressions
+            self.name = name
+            self._symbolic = True
+            self.model_id, self._linear = MODEL_USER, False
+            self.dt, self.erk_order, self.n_sub, self._is_setup = None, 0, 1, False
+            self._native_discrete = bool(discrete)
+            self.dynamical_state_names, self.input_names, self.parameter_names, self.measurement_names = [], [], [], []
+            self.n_x = self.n_u = self.n_p = self.n_y = 0
+            self._ode, self._meas = None, []
+            self.learned = None
+            return
+        self._symbolic = False
         self.name = name
         self.model_id, self._linear, xs, us, ps, ys = ZOO[name]
         self.dt = None
@@ -77,6 +104,80 @@ class Model:
     def discrete(self):
         return self._native_discrete or self.erk_order > 0
 
+    # -- models defined by expressions ----------------------------------------------------------------
+    def _declare(self, attr, names, kind):
+        if not self._symbolic:
+            raise RuntimeError(f"'{self.name}' is a model of the device zoo; its variables are fixed")
+        names = [names] if isinstance(names, str) else list(names)
+        if len(set(names)) != len(names):
+            raise ValueError(f"duplicate names in {names}")
+        setattr(self, attr, names)
+        self.n_x, self.n_u, self.n_p = len(self.dynamical_state_names), len(self.input_names), len(self.parameter_names)
+        return SymVector(kind, names)
+
+    def set_dynamical_states(self, *names):
+        """dynamic_model.py `set_dynamical_states`: returns the symbols of the states."""
+        return self._declare('dynamical_state_names', names[0] if len(names) == 1 and not isinstance(names[0], str) else names, 'x')
+
+    def set_inputs(self, *names):
+        return self._declare('input_names', names[0] if len(names) == 1 and not isinstance(names[0], str) else names, 'u')
+
+    def set_parameters(self, *names):
+        return self._declare('parameter_names', names[0] if len(names) == 1 and not isinstance(names[0], str) else names, 'p')
+
+    def _parse(self, eqs):
+        """Expressions, or strings of the model's variable names with sin / cos / exp / log / sqrt (the right-hand side of
+        an optional `... = ` is taken, like the reference's equation strings, util/parsing.py)."""
+        ns = {n: getattr(_expr, n) for n in ('sin', 'cos', 'exp', 'log', 'sqrt')}
+        for vec in (self.x, self.u, self.p):
+            ns.update({n: vec[n] for n in vec._names})
+        out = []
+        for e in ([eqs] if isinstance(eqs, (Expr, str, int, float)) else list(eqs)):
+            if isinstance(e, str):
+                e = eval(e.split('=')[-1].replace('^', '**'), {'__builtins__': {}}, dict(ns))
+            out.append(Expr.wrap(e))
+        return out
+
+    def set_dynamical_equations(self, equations):
+        """dynamic_model.py:1293-1405: one right-hand side per state (dx/dt for a continuous model, x+ for a discrete one)."""
+        if not self._symbolic:
+            raise RuntimeError(f"'{self.name}' is a model of the device zoo; its equations are fixed")
+        eqs = self._parse(equations)
+        if len(eqs) != self.n_x:
+            raise ValueError(f"the model has {self.n_x} dynamical states but {len(eqs)} equations were supplied")
+        self._ode = eqs
+
+    def set_measurement_equations(self, equations):
+        """dynamic_model.py:1407-1460; the measurements are named y_0, y_1, ... like the reference's defaults."""
+        if not self._symbolic:
+            raise RuntimeError(f"'{self.name}' is a model of the device zoo; its equations are fixed")
+        self._meas = self._parse(equations)
+        self.measurement_names = [f'y_{i}' for i in range(len(self._meas))]
+        self.n_y = len(self._meas)
+
+    def set_equations(self, ode=None, meas=None, **kwargs):
+        if ode is not None:
+            self.set_dynamical_equations(ode)
+        if meas is not None:
+            self.set_measurement_equations(meas)
+
+    def user_source(self):
+        """HIP source that defines `UserModel` for the run-time compiled path: the emitted functor, or the alias of the
+        zoo functor."""
+        from . import codegen
+        if self._symbolic:
+            if self._ode is None:
+                raise RuntimeError("Model is not set up: no dynamical equations (set_dynamical_equations)")
+            for e in self._ode + self._meas:
+                if e.depends_on('theta'):
+                    raise ValueError("a path variable cannot appear in the model equations")
+            return codegen.model_source(self.n_x, self.n_u, self.n_p, self._ode, self._meas, self._native_discrete)
+        if self.name == 'lti':
+            return codegen.zoo_alias(f"Lti<{self.n_x}, {self.n_u}, {self.n_y}>")
+        if self.name not in ZOO_FUNCTOR:
+            raise NotImplementedError(f"model '{self.name}' cannot be used in a run-time compiled problem")
+        return codegen.zoo_alias(ZOO_FUNCTOR[self.name])
+
     def is_linear(self):
         return self._linear
 
@@ -103,6 +204,8 @@ class Model:
         return m
 
     def setup(self, dt=None):
+        if self._symbolic and self._ode is None:
+            raise RuntimeError("Model is not set up: no dynamical equations (set_dynamical_equations)")
         if dt is not None:
             self.dt = float(dt)
         if self.dt is None:
@@ -116,7 +219,7 @@ class Model:
         variables (:3056-3061).  The device zoo offers this for the growth rate `mu` of 'chemostat4' over the
         features (S, I) (`nmpc_hybrid_bio.ipynb`); the GP must be trained (`setup` + `fit_model` or `set_training_data`
         + `setup`) with a squared-exponential kernel and a constant/zero mean."""
-        if self.name not in LEARNABLE:
+        if self._symbolic or self.name not in LEARNABLE:
             raise NotImplementedError(f"model '{self.name}' has no learnable term in the device zoo "
                                       f"(available: {sorted(LEARNABLE)})")
         label, features, hybrid = LEARNABLE[self.name]

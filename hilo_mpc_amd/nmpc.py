@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 from ._device import device, to_dev, ptr, stream_ptr
-from .expr import Expr, compile_block
+from .expr import Expr, compile_block as _compile_block
 
 STATUS_TEXT = {1: 'solve_succeeded', 2: 'solved_to_acceptable_level', 3: 'infeasible_problem_detected',
                4: 'restoration_failed', 5: 'maximum_iterations_exceeded', -1: 'other'}
@@ -66,7 +66,7 @@ def _collocation_basis(degree, points='radau'):
     else:                                      # 'legendre': Gauss points
         c[degree] = 1.
     tau = [0.] + list((np.sort(np.real(legendre.legroots(c))) + 1.) / 2.)
-    Cm, D = np.zeros((degree + 1, degree + 1)), np.zeros(degree + 1)
+    Cm, D, Bq = np.zeros((degree + 1, degree + 1)), np.zeros(degree + 1), np.zeros(degree + 1)
     for i in range(degree + 1):
         L = np.poly1d([1.])
         for j in range(degree + 1):
@@ -76,7 +76,8 @@ def _collocation_basis(degree, points='radau'):
         Ld = np.polyder(L)
         for j in range(degree + 1):
             Cm[i, j] = Ld(tau[j])
-    return {'d': degree, 'tau': np.array(tau), 'C': Cm, 'D': D, 'A': np.linalg.inv(Cm[1:, 1:].T)}
+        Bq[i] = np.polyint(L)(1.)                # quadrature weights of the continuous objective (modeling.py:1124)
+    return {'d': degree, 'tau': np.array(tau), 'C': Cm, 'D': D, 'B': Bq, 'A': np.linalg.inv(Cm[1:, 1:].T)}
 
 
 class QuadraticCost:
@@ -156,6 +157,31 @@ class QuadraticCost:
         raise NotImplementedError("measurement costs are not yet offloaded; add the corresponding states instead")
 
 
+class GenericCost:
+    """`util/modeling.py:38-87`: a free-form cost, `nmpc.stage_cost.cost = expression of model.x / model.u / model.p`
+    (assignments accumulate, like the reference's `self._cost += arg`).
+
+    Restated quirk of the reference: the expression is attached to the model after the model has been scaled
+    (mpc.py:1210 then :1283; `Model.scale` only substitutes inside the model's own equations, base.py:1169-1179), so its
+    symbols are the scaled NLP variables - with `set_scaling(x_scaling=s)` the cost sees x / s."""
+
+    def __init__(self, model):
+        self._model = model
+        self._cost = None
+        self._is_set = False
+
+    @property
+    def cost(self):
+        return 0 if self._cost is None else self._cost
+
+    @cost.setter
+    def cost(self, arg):
+        if not isinstance(arg, Expr):
+            raise TypeError('The cost function must be an expression of the model symbols (model.x, model.u, model.p).')
+        self._cost = arg if self._cost is None else self._cost + arg
+        self._is_set = True
+
+
 class GenericConstraint:
     """`util/modeling.py:820-1005`: lb <= constraint(x, u) <= ub per stage; soft: one slack shared by all stages with the
     penalty e^T weight e per stage (default weight 1e4 I, modeling.py:875)."""
@@ -221,6 +247,8 @@ class NMPC:
         self._n_x, self._n_u, self._n_p = model.n_x, model.n_u, model.n_p
         self.quad_stage_cost = QuadraticCost(model)
         self.quad_terminal_cost = QuadraticCost(model)
+        self.stage_cost = GenericCost(model)
+        self.terminal_cost = GenericCost(model)
         self.stage_constraint = GenericConstraint(model, name='stage constraint')
         self.terminal_constraint = GenericConstraint(model, name='terminal constraint')
         self._paths_var_list = []
@@ -388,8 +416,11 @@ class NMPC:
                     'solver': self._solver_name_list_nlp, 'collocation_points': ['radau', 'legendre'],
                     'objective_function': ['discrete', 'continuous'], 'warm_start': [True, False], 'degree': None,
                     'print_level': [0, 1], 'ipopt_debugger': [True, False]}
+        # optimizer.py:1423-1426: the objective is the integral of the Lagrange term for a continuous model, the sum for a
+        # discrete one
         opts = {'integration_method': 'collocation', 'collocation_points': 'radau', 'degree': 3, 'print_level': 1,
-                'warm_start': True, 'solver': 'ipopt', 'ipopt_debugger': False, 'objective_function': 'discrete'}
+                'warm_start': True, 'solver': 'ipopt', 'ipopt_debugger': False,
+                'objective_function': 'discrete' if self._model.discrete else 'continuous'}
         given = args[0] if (args and isinstance(args[0], dict)) else kwargs
         for k, v in (given or {}).items():
             if k not in opts:
@@ -428,8 +459,11 @@ class NMPC:
             raise ValueError("You must set a prediction horizon length before")
         if self._control_horizon is None:
             raise ValueError("You must set a control horizon length before.")
-        if not (self.quad_stage_cost._is_set or self.quad_terminal_cost._is_set):
+        if not (self.quad_stage_cost._is_set or self.quad_terminal_cost._is_set or self.stage_cost._is_set or
+                self.terminal_cost._is_set):
             raise ValueError("You need to define a cost function before setting up the mpc.")
+        if self._control_horizon > self._prediction_horizon:
+            raise ValueError("The control horizon must be smaller or equal to the prediction horizon")
         if self._nlp_options is None or options is not None:
             self.set_nlp_options(options or {})
         if solver_options is not None:
@@ -477,6 +511,17 @@ class NMPC:
             a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
             keep.append(a)
             return a.ctypes.data
+
+        prog_fail = []
+
+        def compile_block(exprs, theta_index=None):
+            # postfix programs for the precompiled policies' interpreter; an expression it cannot hold (too deep) sends the
+            # problem to the run-time compiled policy, where expressions are compiled
+            try:
+                return _compile_block(exprs, theta_index=theta_index)
+            except (ValueError, NotImplementedError) as err:
+                prog_fail.append(str(err))
+                return [0.]
 
         d = _lib.NmpcDesc()
         d.model_id, d.N, d.Nc = m.model_id, self._prediction_horizon, self._control_horizon
@@ -583,22 +628,67 @@ class NMPC:
             d.coll_A, d.coll_D = hp(coll['A']), hp(coll['D'])
         self._coll = coll
         self._dev = device(self._dev_index)
+        # ---- route: precompiled zoo variant, or compiled at run time (csrc/hilo_jit.hip) ----
+        N, Nc = self._prediction_horizon, self._control_horizon
+        cont = (not self._model.discrete) and self._nlp_options['objective_function'] == 'continuous'
+        generic = self.stage_cost._is_set or self.terminal_cost._is_set
+        general = bool(nth or sc.is_set or tc.is_set)
+        need_user = generic or Nc < N or cont or (coll is not None and (general or self._tv)) or (self._tv and general) or \
+            bool(prog_fail)
+        sym = getattr(m, '_symbolic', False)
+        if coll is not None:
+            d.coll_B = hp(coll['B'])
+        d.objective_continuous = int(cont)
+
+        def jit_desc(policy):
+            from . import codegen
+            src = m.user_source()
+            if policy == 2:
+                src += codegen.fun_source(
+                    nx, stage=self.stage_cost._cost, term=self.terminal_cost._cost,
+                    con=sc.constraint if sc.is_set else (), tcon=tc.constraint if tc.is_set else (),
+                    path_stage=[r for _, _, rr in self.quad_stage_cost._paths for r in rr],
+                    path_term=[r for _, _, rr in self.quad_terminal_cost._paths for r in rr])
+                d.user_has_fun = 1
+                d.path_prog, d.path_prog_len = None, 0          # expressions are compiled in, not interpreted
+                d.con_prog, d.con_prog_len, d.tcon_prog, d.tcon_prog_len = None, 0, None, 0
+            self._user_source = src
+            d.user_source = src.encode()
+            d.user_policy = policy
+            d.user_nx, d.user_nu, d.user_np, d.user_ny = m.n_x, m.n_u, m.n_p, m.n_y
+            d.user_discrete = int(getattr(m, '_native_discrete', False))
+
         h = C.c_void_p()
-        _lib.check(_lib.lib().hilo_nmpc_create(C.byref(d), self._dev.index, C.byref(h)))
+        if sym or need_user:
+            if getattr(m, 'learned', None) is not None:
+                raise NotImplementedError("a learned term inside a run-time compiled problem is not offloaded")
+            jit_desc(2 if (need_user or general or coll is not None or self._tv) else 0)
+            _lib.check(_lib.lib().hilo_nmpc_create(C.byref(d), self._dev.index, C.byref(h)))
+        else:
+            try:
+                _lib.check(_lib.lib().hilo_nmpc_create(C.byref(d), self._dev.index, C.byref(h)))
+            except _lib.HiloError as err:
+                # no precompiled variant for this combination of features: compile the general policy for the zoo functor
+                if err.code != -4 or getattr(m, 'learned', None) is not None:
+                    raise
+                jit_desc(2)
+                _lib.check(_lib.lib().hilo_nmpc_create(C.byref(d), self._dev.index, C.byref(h)))
+        self._jit = bool(d.user_source)
         self._destroy()
         self._handle = h
         dims = [C.c_int() for _ in range(5)]
         _lib.check(_lib.lib().hilo_nmpc_dims(h, *[C.byref(v) for v in dims]))
         self._n_v, self._n_g = dims[0].value, dims[1].value
-        N = self._prediction_horizon
-        # integer bookkeeping of mpc.py:1464-1537 (bit-exact index maps); a path variable is a state + an input
+        N, Nc = self._prediction_horizon, self._control_horizon
+        # integer bookkeeping of mpc.py:1464-1537 (bit-exact index maps); a path variable is a state + an input;
+        # the control horizon holds Nc input blocks (mpc.py:1476-1485)
         nxa, nua = nx + nth, nu + nth
         self._x_ind = [list(range(k * nxa, (k + 1) * nxa)) for k in range(N + 1)]
-        self._u_ind = [list(range((N + 1) * nxa + k * nua, (N + 1) * nxa + (k + 1) * nua)) for k in range(N)]
-        self._e_soft_stage_ind = list(range((N + 1) * nxa + N * nua, (N + 1) * nxa + N * nua + ne))
-        off = (N + 1) * nxa + N * nua + ne
+        self._u_ind = [list(range((N + 1) * nxa + k * nua, (N + 1) * nxa + (k + 1) * nua)) for k in range(Nc)]
+        self._e_soft_stage_ind = list(range((N + 1) * nxa + Nc * nua, (N + 1) * nxa + Nc * nua + ne))
+        off = (N + 1) * nxa + Nc * nua + ne
         self._e_soft_term_ind = list(range(off, off + ne_term))                                           # mpc.py:1542-1543
-        dn = coll['d'] * nx if coll is not None else 0
+        dn = coll['d'] * nxa if coll is not None else 0
         off += ne_term
         self._ip_ind = [list(range(off + k * dn, off + (k + 1) * dn)) for k in range(N)] if dn else []   # mpc.py:1501-1509
         self._sx, self._su = sx, su
@@ -829,10 +919,10 @@ class NMPC:
             warnings.warn("There is still no mpc solution available. Run mpc.optimize() to get one.")
             return None, None, None
         v = self._nlp_solution['x'].cpu().numpy()
-        N, nx, nu, nth = self._prediction_horizon, self._n_x, self._n_u, self._nth
+        N, Nc, nx, nu, nth = self._prediction_horizon, self._control_horizon, self._n_x, self._n_u, self._nth
         nxa, nua = nx + nth, nu + nth
         X = v[:, :(N + 1) * nxa].reshape(-1, N + 1, nxa) * np.concatenate([self._sx, np.ones(nth)])
-        U = v[:, (N + 1) * nxa:(N + 1) * nxa + N * nua].reshape(-1, N, nua) * np.concatenate([self._su, np.ones(nth)])
+        U = v[:, (N + 1) * nxa:(N + 1) * nxa + Nc * nua].reshape(-1, Nc, nua) * np.concatenate([self._su, np.ones(nth)])
         return np.swapaxes(X, 1, 2), np.swapaxes(U, 1, 2), None
 
     def phase_profile(self, enable=True):

@@ -177,7 +177,7 @@ typedef struct hilo_nmpc hilo_nmpc;
 typedef struct hilo_nmpc_desc {
   int32_t model_id;     /* HILO_MODEL_* */
   int32_t N;            /* prediction horizon (mpc.py `horizon`) */
-  int32_t Nc;           /* control horizon; 0 or N (shorter control horizons: not yet supported) */
+  int32_t Nc;           /* control horizon (mpc.py:1629-1630); 0 = N.  Nc < N needs user_policy 2 (run-time compiled) */
   int32_t erk_order;    /* `model.discretize('rk4')` = 4, `('erk', order)` = 1..4 (modeling.py:1239-1250) */
   int32_t n_sub;        /* sub-steps per interval (1 = the reference's single ERK step) */
   int32_t max_iter;     /* 0 -> 3000 (IPOPT default) */
@@ -251,7 +251,35 @@ typedef struct hilo_nmpc_desc {
      (mpc.py:335-364, optimizer.py:905-929).  With time_varying != 0 the handle is solved through hilo_nmpc_solve_tv. ---- */
   int32_t time_varying;
   int32_t reserved3;
+  /* ---- models and problem functions compiled at RUN TIME (what `Model.set_dynamical_equations` /
+     `nmpc.stage_cost.cost = ...` accept as CasADi graphs in the reference, dynamic_model.py:1293-1553, modeling.py:38-87).
+     `user_source` is HIP source text that defines, inside namespace hilo,
+        UserModel   a functor shaped like the zoo of csrc/hilo_models.h (NX, NU, NP, NY, DISCRETE, templated `ode`, `meas`),
+                    or an alias of a zoo functor (`using UserModel = Chemostat4;`)
+        UserFun     (user_has_fun != 0) the problem's free-form functions, csrc/hilo_nmpc_user.h: generic stage / terminal
+                    cost on the SCALED variables (see that header for the reference quirk), constraint expressions on the
+                    un-scaled ones, path references
+     It is compiled with hiprtc for gfx950 against the engine headers that ship next to the library (csrc/), the code object
+     is cached (HILO_JIT_CACHE or <library dir>/jit_cache).  model_id = HILO_MODEL_USER takes the model from the source;
+     a zoo model_id with user_source set compiles the general policy for that zoo functor.
+     user_policy: 0 = the tracking policy (same code path as the zoo models), 1 = the general policy with expression
+     programs (path following / constraints as above), 2 = the policy of csrc/hilo_nmpc_user.h, which adds: generic costs,
+     the continuous objective, collocation together with path following, control horizon Nc < N, per-stage data. ---- */
+  const char* user_source;
+  int32_t user_nx, user_nu, user_np, user_ny, user_discrete;   /* dimensions of UserModel (checked against the compiled code) */
+  int32_t user_has_fun;
+  int32_t user_policy;
+  int32_t objective_continuous;   /* 1: integrate the Lagrange term with the shooting map (optimizer.py:1423-1426) */
+  const double* coll_B;           /* [d+1] quadrature weights B_i of the collocation basis (modeling.py:1124), continuous objective */
+  /* with user_policy 2 the constraint / path expressions are compiled into UserFun: n_con, n_tcon, n_path_stage, n_path_term
+     count them as above, the *_prog pointers stay NULL */
 } hilo_nmpc_desc;
+
+#define HILO_MODEL_USER 100    /* model defined by desc.user_source */
+/* Compile a user problem into the cache without loading it (no GPU needed): what `__graft_entry__.build()` uses to pre-warm
+   the cache, and what the CPU test-suite uses to check that generated sources compile for gfx950. */
+int hilo_jit_precompile(const char* user_source, int policy, int nth, int ne, int nc, int coll_d, int N, int hold, int cont,
+                        int tv, int big, int has_fun);
 
 /* expression programs: [len, (op, arg) * len/2] back to back; postfix, stack of 8 */
 #define HILO_X_CONST 0   /* arg = value */

@@ -26,10 +26,49 @@ def oracle_problem(spec):
     return NmpcProblem(models.get(spec['model']), **kw)
 
 
-def product_nmpc(spec, gp=None, **solver_options):
+def symbolic_model(name):
+    """The zoo models written as expressions - what a reference user does with `Model.set_dynamical_equations`
+    (dynamic_model.py:1293-1553).  Each statement mirrors the compiled functor of csrc/hilo_models.h term by term, so that the
+    emitted code and the hand-written one are the same expression tree."""
+    from hilo_mpc_amd import Model
+    from hilo_mpc_amd.expr import cos, exp, sin
+    m = Model(name=name + '_expr')
+    if name == 'chemostat4':
+        x = m.set_dynamical_states(['X', 'S', 'P', 'I'])
+        u = m.set_inputs(['DS', 'DI'])
+        p = m.set_parameters(['Sf', 'If', 'ISF', 'IRF'])
+        X, S, Pr, I = x
+        phi = 0.407 * S / (0.108 + S + S * S / 14814.0)
+        mu = phi * (p[2] + 0.22 * p[3] / (0.22 + I))
+        Rs = 2.0 * mu
+        Rfp = phi * (0.0005 + I) / (0.022 + I)
+        D = u[0] + u[1]
+        m.set_dynamical_equations([mu * X - D * X, -(Rs * X) - D * S + u[0] * p[0], Rfp * X - D * Pr, -(D * I) + u[1] * p[1]])
+        m.set_measurement_equations([X, Pr])
+    elif name == 'pendulum4':
+        x = m.set_dynamical_states(['x', 'v', 'theta', 'omega'])
+        u = m.set_inputs(['F'])
+        M, mm, l, g = 5.0, 1.0, 1.0, 9.81
+        s, c = sin(x[2]), cos(x[2])
+        dv = 1.0 / (M + mm - mm * c) * (mm * g * s - mm * l * s * x[3] * x[3] + u[0])
+        m.set_dynamical_equations([x[1], dv, x[3], 1.0 / l * (dv * c + g * s)])
+        m.set_measurement_equations([x[0], x[1], x[2], x[3]])
+    elif name == 'cstr3':
+        x = m.set_dynamical_states(['C_A', 'C_B', 'T'])
+        u = m.set_inputs(['Q'])
+        m.set_dynamical_equations(cstr_equations(x, u)[0])
+        m.set_measurement_equations([cstr_equations(x, u)[1]])
+    else:
+        raise ValueError(name)
+    return m
+
+
+def product_nmpc(spec, gp=None, model=None, **solver_options):
     """Build the product NMPC for a plain spec through the reference-style API."""
     from hilo_mpc_amd import NMPC, Model
-    if spec['model'] == 'chemostat4_gp':
+    if model is not None:
+        m = model
+    elif spec['model'] == 'chemostat4_gp':
         m = Model('chemostat4')
         m.substitute_from(gp if gp is not None else product_gp())                 # dynamic_model.py:3040-3125
     else:
@@ -41,18 +80,99 @@ def product_nmpc(spec, gp=None, **solver_options):
         nmpc.quad_stage_cost.add_states(names=[xs[i] for i in ind], weights=list(W), ref=ref)
     for ind, W, ref in spec.get('stage_inputs', []):
         nmpc.quad_stage_cost.add_inputs(names=[us[i] for i in ind], weights=list(W), ref=ref)
+    if spec.get('Nc'):
+        nmpc.prediction_horizon, nmpc.control_horizon = spec['N'], spec['Nc']
     if spec.get('input_change'):
         ind, W = spec['input_change']
         nmpc.quad_stage_cost.add_inputs_change(names=[us[i] for i in ind], weights=list(W))
     for ind, W, ref in spec.get('terminal_states', []):
         nmpc.quad_terminal_cost.add_states(names=[xs[i] for i in ind], weights=list(W), ref=ref)
-    nmpc.horizon = spec['N']
+    if not spec.get('Nc'):
+        nmpc.horizon = spec['N']
     nmpc.set_box_constraints(x_ub=spec.get('x_ub'), x_lb=spec.get('x_lb'), u_ub=spec.get('u_ub'), u_lb=spec.get('u_lb'))
     nmpc.set_initial_guess(x_guess=spec.get('x_guess'), u_guess=spec.get('u_guess'))
     if spec.get('x_scaling') or spec.get('u_scaling'):
         nmpc.set_scaling(x_scaling=spec.get('x_scaling'), u_scaling=spec.get('u_scaling'))
     nmpc.setup(options={'integration_method': 'discrete'}, solver_options=solver_options or None)
     return nmpc
+
+
+# ---- the reference's only published NMPC result: docs/docsource/examples/CSTR_Example.ipynb ---------------------------------
+# cell 4 constants; cell 6 `true_plant_model`; cell 14 controller; cell 16 printed output after 1000 closed-loop steps
+CSTR = dict(T_0=400., tau=60., k_A=5000., k_B=1e6, E_A=1e4, E_B=1.5e4, R=1.987, dH=-5000., rho=1., Cp=1000., C_A_0=1., V=100.,
+            x_lb=[0., 0., 400.], x_ub=[1., 1., 500.], u_lb=[0.], u_ub=[1e5], x_scaling=[1., 1., 1e2], u_scaling=[1e5],
+            x_guess=[0.4912, 0.5088, 438.47], u_guess=[59881.84], heat_price=7e-7, N=10, dt=1., x0=[1., 0., 400.])
+CSTR_PRINTED = ('59882.1817', '0.4912', '0.5088', '438.4732')        # Q, C_A, C_B, T of the line "True: ..."
+
+
+def cstr_equations(x, u, lib=None):
+    """Right-hand side and reaction rate exactly as the notebook writes them (cell 6), on any symbol type."""
+    if lib is None:
+        from hilo_mpc_amd import expr as lib
+    c = CSTR
+    C_A, C_B, T, Q = x[0], x[1], x[2], u[0]
+    r = c['k_A'] * lib.exp((-c['E_A']) / (c['R'] * T)) * C_A - c['k_B'] * lib.exp((-c['E_B']) / (c['R'] * T)) * C_B
+    dC_A = 1 / c['tau'] * (c['C_A_0'] - C_A) - r
+    dC_B = -1 / c['tau'] * C_B + r
+    dT = -(c['dH'] * r) / (c['rho'] * c['Cp']) + 1 / c['tau'] * (c['T_0'] - T) + Q / (c['rho'] * c['Cp'] * c['V'])
+    return [dC_A, dC_B, dT], r
+
+
+def cstr_nmpc(heat_price=None, **solver_options):
+    """Cell 14, statement by statement, on the product API."""
+    from hilo_mpc_amd import NMPC, Model
+    c = CSTR
+    plant = Model(name='plant')
+    x = plant.set_dynamical_states(['C_A', 'C_B', 'T'])
+    u = plant.set_inputs(['Q'])
+    ode, r = cstr_equations(x, u)
+    plant.set_dynamical_equations(ode)
+    plant.set_measurement_equations([r])
+    plant.setup(dt=c['dt'])
+    nmpc = NMPC(plant)
+    nmpc.set_scaling(x_scaling=c['x_scaling'], u_scaling=c['u_scaling'])
+    nmpc.stage_cost.cost = plant.x[0] / c['C_A_0'] + plant.u[0] * (c['heat_price'] if heat_price is None else heat_price)
+    nmpc.horizon = c['N']
+    nmpc.set_box_constraints(x_lb=c['x_lb'], x_ub=c['x_ub'], u_lb=c['u_lb'], u_ub=c['u_ub'])
+    nmpc.set_initial_guess(x_guess=c['x_guess'], u_guess=c['u_guess'])
+    nmpc.setup(options={'print_level': 0}, solver_options=solver_options or None)
+    return nmpc
+
+
+def cstr_oracle(**ipm_options):
+    from oracle import models
+    from oracle.nmpc import IpmOptions
+    from oracle.nmpc_coll import CollIpm, CollNmpcProblem
+    c = CSTR
+    m = models.get('cstr3')
+    pb = CollNmpcProblem(m, dt=c['dt'], N=c['N'], degree=3, objective='continuous',
+                         generic_stage=m.x[0] / c['C_A_0'] + m.u[0] * c['heat_price'],
+                         x_lb=c['x_lb'], x_ub=c['x_ub'], u_lb=c['u_lb'], u_ub=c['u_ub'], x_scaling=c['x_scaling'],
+                         u_scaling=c['u_scaling'], x_guess=c['x_guess'], u_guess=c['u_guess'])
+    return pb, CollIpm(pb, IpmOptions(**ipm_options))
+
+
+def cstr_plant(x, u, n_sub=50):
+    """One sampling interval of the true plant: classic RK4 with `n_sub` sub-steps (numpy; test harness, stands in for the
+    reference's CVODES call `plant.simulate(u=u)`)."""
+    import numpy as _np
+
+    class L:
+        exp = staticmethod(_np.exp)
+    x = _np.array(x, dtype=float)
+    u = _np.asarray(u, dtype=float).reshape(x.shape[0], 1)
+    h = CSTR['dt'] / n_sub
+
+    def f(z):
+        d, _ = cstr_equations([z[:, 0], z[:, 1], z[:, 2]], [u[:, 0]], lib=L)
+        return _np.stack(d, axis=1)
+    for _ in range(n_sub):
+        k1 = f(x)
+        k2 = f(x + .5 * h * k1)
+        k3 = f(x + .5 * h * k2)
+        k4 = f(x + h * k3)
+        x = x + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+    return x
 
 
 # ---- C3: MHE on the chemostat (nx=4, ny=2, N=30), SURVEY.md 8d ------------------------------------------------

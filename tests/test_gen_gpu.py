@@ -106,8 +106,11 @@ def test_general_errors():
     nmpc.horizon = 5
     nmpc.stage_constraint.constraint = m.x['v'] ** 2
     nmpc.stage_constraint.ub = [4.]
-    with pytest.raises(HiloError, match="no device instantiation"):
-        nmpc.setup(options={'integration_method': 'discrete'})
+    # no precompiled variant for (pendulum4, one hard row): compiled at run time for the zoo functor instead of failing
+    nmpc.setup(options={'integration_method': 'discrete'})
+    assert nmpc._jit
+    u = nmpc.optimize(np.array([[.2, 1., .1, 0.]]))
+    assert nmpc.solver_status_code[0] == 1 and np.all(np.isfinite(u))
     with pytest.raises(TypeError, match="is_soft must be of type bool"):
         nmpc.stage_constraint.is_soft = 1
     deep = m.x['v']
@@ -198,7 +201,7 @@ def test_soft_terminal_constraint_vs_oracle():
         last = (pb.N - 1) * (pb.nxa + pb.n_con_ref)
         lam[:, last:last + pb.nxa] += 2 * (ref['X'][:, -1] - pb.xrefNa) @ pb.WNa        # terminal cost convention (mpc.py:1682)
         np.testing.assert_allclose(nmpc._nlp_solution['lam_g'].cpu().numpy(), lam, rtol=2e-4, atol=2e-5)
-    from hilo_mpc_amd._lib import HiloError
+    # soft stage AND soft terminal constraint: two slacks - no precompiled variant, compiled at run time for the zoo functor
     both = dict(C2S, N=8, terminal_constraint=dict(expr=['S'], lb=[45.], ub=[np.inf], soft=True))
-    with pytest.raises(HiloError, match="one shared slack"):
-        product_gen(both)
+    nmpc, pb, ipm, ref = _compare(both, c2_x0(4), C2['p'])
+    assert nmpc._jit and nmpc._e_soft_term_ind == pb.eT_ind and len(pb.e_ind) == 1
