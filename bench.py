@@ -1,25 +1,39 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path named by BASELINE.json: batched NMPC steps/s at fixed (nx, nu, N).
+"""Benchmark of the hot path named by BASELINE.json: batched MPC / MHE / Kalman / GP steps per second.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload = BASELINE.json configs[1] (SURVEY.md 8d "C2"): tracking NMPC on the CSTR-sized chemostat (nx=4, nu=2,
-N=20), B=1024 instances PER GPU (weak scaling), closed loop, warm-started (mpc.py:725-726).  A "step" of the harness is
-one batched `NMPC.optimize()` (one `hilo_nmpc_solve` launch) + the plant step + (N>1) the per-step RCCL gather of
-(u0, status, iters); `value` = solved MPC instances per second over the whole job, inputs resident in HBM.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under
+`torch.distributed.run` with one process per GPU (RCCL over xGMI for the one collective of a step).
 
-The JSON line also carries
-  roofline      the dominant kernel (ocp_solve_kernel<NmpcTrack<Chemostat4>,64>) against the fp64 roof it is bound by (the solve
-                is fp64-VALU/latency bound, its compulsory HBM traffic is ~4 KB per solve) - algorithmic flops per
-                launch / HIP-event time of the launches; `roofline_hbm` gives the HBM view for transparency
-  cpu_baseline  the oracle's dense interior-point solver (numpy port of the same algorithm; the reference's
-                CasADi/IPOPT cannot be installed) timed on this host, 1 core, bounded sample
+Default workload = BASELINE.json configs[1] (SURVEY.md 8d "C2"): tracking NMPC on the CSTR-sized chemostat (nx=4, nu=2,
+N=20), B=1024 instances PER GPU (weak scaling), closed loop, warm-started (mpc.py:725-726).  `--config` selects the other
+configurations of SURVEY 8d, each printing its own JSON line:
+
+  C1          LMPC double integrator (nx=2, nu=1, N=10), batch of 1024 QPs (+ single-instance latency in `config`)
+  C2          tracking NMPC chemostat4, B = 1024 per GPU (weak)
+  C3-mhe      MHE chemostat4 N=30, B = 4096 per GPU (weak): one add_measurements + estimate per step
+  C3-ekf      EKF step chemostat4, B = 4096 per GPU (weak)      } HBM-bound: 8 (2 nx (nx+1) + 2 ny + nu + np) bytes per step
+  C3-ukf      UKF step chemostat4, B = 4096 per GPU (weak)      }
+  C4          GP-hybrid NMPC (GP with 200 training points inside the model), B = 2048 in total (strong sharding)
+  C5          path-following NMPC robot6 N=50 with a soft constraint, B = 8192 in total (strong sharding)
+  gp-predict  GaussianProcess.predict with variance, n = 200 training points, 2^18 query columns per GPU and step
+
+A "step" of the harness is one pass of the configuration's hot call over the whole (sharded) batch + (closed loops) the plant
+step + the per-step gather of (u0, status, iters); `value` = instances (or query columns) processed per second over the whole
+job, inputs resident in HBM.
+
+Every line carries
+  roofline      the dominant kernel against the roof that bounds it: algorithmic flops (solves, GP) or
+                algorithmic bytes (filters) per launch / the HIP-event time of that launch on the stream it runs on
+  cpu_baseline  (N = 1 only) the oracle's CPU restatement of the same computation on a bounded sample of the same workload
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,29 +45,41 @@ if ROOT not in sys.path:
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X fp64 vector = fp64 matrix (MFMA) peak, dense
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md
+CONFIGS = ('C1', 'C2', 'C3-mhe', 'C3-ekf', 'C3-ukf', 'C4', 'C5', 'gp-predict')
 
-# algorithmic flop model (DESIGN.md "Roofline"): per interior-point iteration and shooting interval
+# algorithmic flop model: per interior-point iteration and shooting interval
 #   F_ric = 7/3 nx^3 + 4 nx^2 nu + 2 nx nu^2 + nu^3/3 + 8 nx^2 + 8 nx nu + 2 nu^2          
 #   F_dyn = s (C_f + C_J + C_H) + s 2 nx^2 nz + s 4 nz^3        (RHS + Jacobian + contracted Hessian, chain rules)
-# chemostat4 op counts from sympy CSE of the right-hand side: C_f = 33, C_J = 60, C_H = 121
+# op counts of the right-hand sides (sympy CSE): chemostat4 C_f = 33, C_J = 60, C_H = 121; robot6 6 / 8 / 8;
+# a GP term of n training points over two features adds n * 22 per stage point (kernel value, gradient, Hessian)
 C_F, C_J, C_H = 33, 60, 121
+MODEL_OPS = {'chemostat4': (33, 60, 121), 'robot6': (6, 8, 8), 'chemostat4_gp': (33 + 200 * 22, 60, 121)}
 
 
-def flops_per_iteration(nx, nu, N, s=4):
+def f_ric(nx, nu):
+    return 7 / 3 * nx ** 3 + 4 * nx ** 2 * nu + 2 * nx * nu ** 2 + nu ** 3 / 3 + 8 * nx ** 2 + 8 * nx * nu + 2 * nu ** 2
+
+
+def flops_per_iteration(nx, nu, N, s=4, ops=(C_F, C_J, C_H)):
+    """DESIGN model: includes the lambda-contracted Hessian of the shooting map (the exact-Hessian interior point needs it)."""
     nz = nx + nu
-    f_ric = 7 / 3 * nx ** 3 + 4 * nx ** 2 * nu + 2 * nx * nu ** 2 + nu ** 3 / 3 + 8 * nx ** 2 + 8 * nx * nu + 2 * nu ** 2
-    f_dyn = s * (C_F + C_J + C_H) + s * 2 * nx ** 2 * nz + s * 4 * nz ** 3
-    return N * (f_ric + f_dyn)
+    f_dyn = s * sum(ops) + s * 2 * nx ** 2 * nz + s * 4 * nz ** 3
+    return N * (f_ric(nx, nu) + f_dyn)
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per solve launch from the committed rocprofv3 PMC passes (profiles/rNN_summary.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate --pmc runs of this same command).  Calibration (MI355X_MICROARCH.md, HBM section):
-    the kernel reads with 8-byte lanes; against the known per-launch read count (B * (n_v + nx + np) * 8 B) FETCH_SIZE
-    reads 0.9x, so no 2x correction applies to this access pattern; WRITE_SIZE matches the known write count."""
+def flops_per_iteration_survey(nx, nu, N, s=4, ops=(C_F, C_J, C_H)):
+    """SURVEY 8d formula as written: F_dyn = s (C_f + C_J + 2 nx^2 (nx + nu))."""
+    return N * (f_ric(nx, nu) + s * (ops[0] + ops[1] + 2 * nx ** 2 * (nx + nu)))
+
+
+def pmc_traffic_bytes(tag_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN_<config>_summary.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command), newest round first; None if this
+    configuration has no committed PMC pass.  Calibration: see DESIGN.md 5 (8-byte lanes: no 2x correction)."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_summary.json'))):
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_{tag_key}_summary.json')) +
+                    (sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_summary.json'))) if tag_key == 'C2' else [])):
         try:
             d = json.load(open(f))
             best = (d['FETCH_SIZE_KB_per_launch']['warm_launches_mean'] + d['WRITE_SIZE_KB_per_launch']['warm_launches_mean']) * 1024
@@ -62,21 +88,403 @@ def pmc_traffic_bytes():
     return best
 
 
-def cpu_baseline(spec, x0_sample, n_steps):
-    """Oracle port (numpy dense IPM) on a bounded sample: cold solve (untimed warm-up of the closed loop) then
-    `n_steps` warm-started closed-loop steps, 1 core."""
-    from oracle.nmpc import DenseIpm
-    from tests.problems import oracle_problem
-    pb = oracle_problem(spec)
-    ipm = DenseIpm(pb)
-    res = ipm.solve(x0_sample, spec['p'])
-    x = pb.phi(x0_sample / pb.sx, res['U'][:, 0], spec['p']) * pb.sx
-    t0 = time.perf_counter()
-    for _ in range(n_steps):
-        res = ipm.solve(x, spec['p'], w0=res['w'])
-        x = pb.phi(x / pb.sx, res['U'][:, 0], spec['p']) * pb.sx
-    dt = time.perf_counter() - t0
-    return x0_sample.shape[0] * n_steps / dt, dt
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads: each returns dict(step=callable, events=list filled by step, finish=callable -> (extra config, roofline dict),
+#                              units=instances per step on this rank, cpu=callable -> cpu_baseline dict)
+# ---------------------------------------------------------------------------------------------------------------------
+def _events(torch, n):
+    return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+
+
+def _ipm_stats(torch, log):
+    iters = torch.stack([i for i, _, _ in log]).to(torch.float64)
+    status = torch.stack([s for _, s, _ in log])
+    kkt = torch.stack([k for _, _, k in log])
+    ok = ((status == 1) | (status == 2))
+    return float(iters.mean().item()), float(ok.to(torch.float64).mean().item()), float(kkt[ok].max().item()) if bool(ok.any()) else float('nan')
+
+
+def _solve_roofline(kernel, B, mean_iters, nx, nu, N, ops, kern_ms, tag, n_v, n_g, n_p):
+    fl = B * mean_iters * flops_per_iteration(nx, nu, N, ops=ops)
+    fl_s = B * mean_iters * flops_per_iteration_survey(nx, nu, N, ops=ops)
+    tf = fl / (kern_ms * 1e-3) / 1e12
+    bytes_launch = B * 8 * (2 * n_v + 2 * n_g + nx + n_p + nu)      # SURVEY 8d bytes_nmpc (compulsory)
+    gbs = bytes_launch / (kern_ms * 1e-3) / 1e9
+    return {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+            "traffic": pmc_traffic_bytes(tag), "kernel": kernel, "kernel_ms": kern_ms,
+            "frac_survey_formula": fl_s / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            "note": "fp64 roof: MI355X fp64 vector peak == fp64 MFMA peak = 78.6 TFLOP/s; the solve is fp64 VALU/latency bound "
+                    "(f64 MFMA for the Riccati stage products); algorithmic flops = B * mean_iters * N * (F_ric + F_dyn) "
+                    "(DESIGN.md 5.1; `frac_survey_formula` uses SURVEY 8d's F_dyn without the contracted Hessian)",
+            "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": bytes_launch, "note": "compulsory bytes only; not the binding roof"}}
+
+
+def wl_nmpc(cfg, args, torch, dev, rank, world):
+    from hilo_mpc_amd.dist import StepGather, shard_range
+    from tests import problems as P
+    if cfg == 'C2':
+        spec, B, gB = P.C2, args.batch or 1024, (args.batch or 1024) * world
+        nmpc = P.product_nmpc(spec)
+        x0 = P.c2_x0(B, seed=P.SEED + rank)
+        kernel, model, ex, eu = "ocp_solve_kernel<NmpcTrack<Chemostat4>, 64>", 'chemostat4', 4, 2
+        workload = "C2 tracking NMPC chemostat4 nx=4 nu=2 N=20 rk4+discrete, closed loop warm-started"
+    elif cfg == 'C4':
+        spec, gB = P.C4, args.batch or 2048
+        lo, hi = shard_range(gB, rank, world)
+        B = hi - lo
+        nmpc = P.product_nmpc(spec)
+        x0 = P.c2_x0(gB)[lo:hi]
+        kernel, model, ex, eu = "ocp_solve_kernel<NmpcTrack<Chemostat4Gp>, 64>", 'chemostat4_gp', 4, 2
+        workload = "C4 GP-hybrid NMPC chemostat4 + GP(200 points, SE-ARD) nx=4 nu=2 N=20, closed loop warm-started"
+    else:
+        spec, gB = P.C5, args.batch or 8192
+        lo, hi = shard_range(gB, rank, world)
+        B = hi - lo
+        nmpc = P.product_gen(spec)
+        x0 = P.c5_x0(gB)[lo:hi]
+        kernel, model, ex, eu = "ocp_solve_kernel<NmpcGen<Robot6, 1, 1, 2, true>, 64>", 'robot6', 8, 3
+        workload = ("C5 path-following NMPC robot6 (ODE; engine nx=6+theta+slack, nu=2+u_theta) N=50 soft constraint, Riccati "
+                    "interior point with the iterate in a global-memory workspace, closed loop warm-started")
+    N = nmpc.horizon
+    x = torch.as_tensor(x0, device=dev)
+    p = torch.as_tensor(np.asarray(spec['p'], dtype=np.float64), device=dev) if len(spec['p']) else None
+    gather = StepGather(gB if cfg != 'C2' else B * world, nmpc._n_u, rank, world, dev)
+    ev, log = [], []
+
+    def step(timed):
+        nonlocal x
+        if timed:
+            e = _events(torch, 1)[0]
+            e[0].record()
+        u = nmpc.optimize(x, cp=p)                         # one hilo_nmpc_solve launch for the whole shard
+        if timed:
+            e[1].record()
+            ev.append(e)
+        sol = nmpc._nlp_solution
+        gather(u, sol['status'], sol['iter_count'])        # the one collective of the step (RCCL all-gather)
+        if timed:
+            log.append((sol['iter_count'], sol['status'], sol['kkt_error']))
+        x = nmpc.plant_step(x, u, cp=p)
+
+    def finish():
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        mean_iters, ok_frac, kkt_max = _ipm_stats(torch, log)
+        roof = _solve_roofline(kernel, B, mean_iters, ex, eu, N, MODEL_OPS[model], kern_ms, cfg, nmpc._n_v, nmpc._n_g, len(spec['p']))
+        extra = {"workload": workload, "batch_per_gpu": B, "global_batch": gB if cfg != 'C2' else B * world,
+                 "parallelism": f"instances sharded x{world}", "mean_ipm_iters": mean_iters, "frac_status_1_or_2": ok_frac,
+                 "max_kkt_error": kkt_max}
+        return extra, roof, ("weak" if cfg == 'C2' else "strong")
+
+    def cpu():
+        t0 = time.perf_counter()
+        if cfg == 'C5':
+            from oracle.nmpc_gen import GenIpm
+            pb = P.oracle_gen(spec)
+            ipm, ns, nst = GenIpm(pb), 2, 1
+            xs = P.c5_x0(ns)
+            res = ipm.solve(xs, spec['p'])
+            t0 = time.perf_counter()
+            for _ in range(nst):
+                res = ipm.solve(xs, spec['p'], w0=res['w'])
+            what = "GenIpm (dense KKT, numpy)"
+        else:
+            from oracle.nmpc import DenseIpm
+            pb = P.oracle_problem(spec) if cfg == 'C2' else P.oracle_c4()[0]
+            ipm = DenseIpm(pb)
+            ns, nst = (40, 8) if cfg == 'C2' else (4, 2)
+            xs = P.c2_x0(ns)
+            res = ipm.solve(xs, spec['p'])
+            xs = pb.phi(xs / pb.sx, res['U'][:, 0], spec['p']) * pb.sx
+            t0 = time.perf_counter()
+            for _ in range(nst):
+                res = ipm.solve(xs, spec['p'], w0=res['w'])
+                xs = pb.phi(xs / pb.sx, res['U'][:, 0], spec['p']) * pb.sx
+            what = "DenseIpm (dense KKT, numpy)"
+        secs = time.perf_counter() - t0
+        return {"value": ns * nst / secs, "unit": "steps/s", "cores": 1, "kind": "port",
+                "sample": f"{ns} instances x {nst} warm-started steps of the same {cfg} workload with the oracle's {what} "
+                          f"({secs:.1f} s); the reference's CasADi/IPOPT is not installable", "host_cpus": os.cpu_count()}
+    return dict(step=step, finish=finish, units=B, cpu=cpu, unit="steps/s",
+                metric="MPC steps/sec (batched instances, whole node) at fixed (nx,nu,N)")
+
+
+def wl_mhe(args, torch, dev, rank, world):
+    from tests import problems as P
+    from tests.test_mhe_gpu import product_mhe
+    spec, B = P.C3B, args.batch or 4096
+    xa, u, y, xt = P.c3_data(B, seed=11 + rank)
+    mhe = product_mhe(spec)
+    N = spec['N']
+    yd, ud = torch.as_tensor(y, device=dev), torch.as_tensor(u, device=dev)
+    for k in range(N):
+        mhe.add_measurements(yd[:, k], ud[:, k])
+    mhe.estimate(x_arrival=torch.as_tensor(xa, device=dev))
+    rng = np.random.default_rng(5 + rank)
+    noise = torch.as_tensor(.01 * rng.normal(size=(64, B, 2)), device=dev)
+    ev, log, cnt = [], [], [0]
+
+    def step(timed):
+        k = cnt[0] % 64
+        cnt[0] += 1
+        mhe.add_measurements(yd[:, -1] + noise[k], ud[:, -1])      # window shifts by one sample (device ring buffer)
+        if timed:
+            e = _events(torch, 1)[0]
+            e[0].record()
+        mhe.estimate()
+        if timed:
+            e[1].record()
+            ev.append(e)
+            s = mhe._nlp_solution
+            log.append((s['iter_count'], s['status'], s['kkt_error']))
+
+    def finish():
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        mean_iters, ok_frac, kkt_max = _ipm_stats(torch, log)
+        roof = _solve_roofline("ocp_solve_kernel<MheNoise<Chemostat4>, 64>", B, mean_iters, 4, 4, N, MODEL_OPS['chemostat4'], kern_ms,
+                               'C3-mhe', mhe._n_v, mhe._n_g, 4 + 4 * N)
+        extra = {"workload": "C3 MHE chemostat4 nx=4 ny=2 N=30 with state noise (boxed), one new sample per step, warm-started",
+                 "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"instances sharded x{world}",
+                 "mean_ipm_iters": mean_iters, "frac_status_1_or_2": ok_frac, "max_kkt_error": kkt_max}
+        return extra, roof, "weak"
+
+    def cpu():
+        from oracle.mhe import MheIpm
+        pb = P.oracle_mhe(spec)
+        ipm, ns = MheIpm(pb), 8
+        t0 = time.perf_counter()
+        ipm.solve(xa[:ns], spec['p'], u[:ns], y[:ns])
+        secs = time.perf_counter() - t0
+        return {"value": ns / secs, "unit": "steps/s", "cores": 1, "kind": "port",
+                "sample": f"{ns} cold estimates of the same C3 window with the oracle's MheIpm (dense KKT, numpy; {secs:.1f} s)",
+                "host_cpus": os.cpu_count()}
+    return dict(step=step, finish=finish, units=B, cpu=cpu, unit="steps/s",
+                metric="MHE estimates/sec (batched instances, whole node) at fixed (nx,ny,N)")
+
+
+def wl_kf(kind, args, torch, dev, rank, world):
+    from hilo_mpc_amd import EKF, UKF, Model
+    B = args.batch or 4096
+    rng = np.random.default_rng(20260926 + rank)
+    x = np.array([.1, 40., .5, .2]) * (1 + .1 * rng.uniform(-1, 1, (B, 4)))
+    Pm = np.tile(np.eye(4), (B, 1, 1))
+    f = (EKF if kind == 'ekf' else UKF)(Model('chemostat4').discretize('rk4').setup(dt=1.))
+    f.setup()
+    f.Q, f.R = 1e-4, 1e-2
+    f.set_initial_guess(torch.as_tensor(x, device=dev), P0=torch.as_tensor(Pm, device=dev))
+    u = torch.as_tensor(rng.uniform(0, .3, (B, 2)), device=dev)
+    p = torch.as_tensor(np.tile([100., 4., 1., 0.], (B, 1)), device=dev)
+    ynoise = torch.as_tensor(.1 * rng.normal(size=(16, B, 2)), device=dev)
+    ev, cnt = [], [0]
+
+    def step(timed):
+        y = f.x[:, [0, 2]] + ynoise[cnt[0] % 16]
+        cnt[0] += 1
+        if timed:
+            e = _events(torch, 1)[0]
+            e[0].record()
+        f.estimate(y=y, u=u, p=p)
+        if timed:
+            e[1].record()
+            ev.append(e)
+
+    def finish():
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        nx, ny, nu, npar = 4, 2, 2, 4
+        bytes_step = 8 * (2 * nx * (nx + 1) + 2 * ny + nu + npar)          # SURVEY 8d bytes_kf
+        gbs = B * bytes_step / (kern_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": pmc_traffic_bytes('C3-' + kind), "kernel": f"kf_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}, 2>",
+                "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": B * bytes_step,
+                "note": "bytes_kf = 8 (2 nx (nx+1) + 2 ny + nu + np) per filter step (SURVEY 8d); at B = 4096 one launch moves "
+                        "1.6 MB, i.e. the launch is latency bound, not bandwidth bound: see config.large_batch for the "
+                        "bandwidth-bound regime"}
+        # bandwidth regime: the same kernel on a batch that fills the chip (B = 2^20), 10 launches
+        Bl = 1 << 20
+        fl = (EKF if kind == 'ekf' else UKF)(Model('chemostat4').discretize('rk4').setup(dt=1.))
+        fl.setup()
+        fl.Q, fl.R = 1e-4, 1e-2
+        xl = torch.as_tensor(np.array([.1, 40., .5, .2]), device=dev).repeat(Bl, 1) * (1 + .1 * torch.rand(Bl, 4, device=dev, dtype=torch.float64))
+        fl.set_initial_guess(xl, P0=torch.eye(4, device=dev, dtype=torch.float64).repeat(Bl, 1, 1))
+        ul, pl = u[:1].repeat(Bl, 1), p[:1].repeat(Bl, 1)
+        yl = xl[:, [0, 2]].contiguous()
+        for _ in range(2):
+            fl.estimate(y=yl, u=ul, p=pl)
+        el = _events(torch, 10)
+        for a, b in el:
+            a.record()
+            fl.estimate(y=yl, u=ul, p=pl)
+            b.record()
+        torch.cuda.synchronize(dev)
+        ms = float(np.mean([a.elapsed_time(b) for a, b in el]))
+        extra = {"workload": f"C3 {kind.upper()} step chemostat4 nx=4 ny=2 (predict + update fused), Q = 1e-4 I, R = 1e-2 I",
+                 "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"instances sharded x{world}",
+                 "large_batch": {"batch": Bl, "ms_per_launch": ms, "steps_per_s": Bl / (ms * 1e-3),
+                                 "hbm_GBps": Bl * bytes_step / (ms * 1e-3) / 1e9,
+                                 "hbm_frac": Bl * bytes_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "note": "event time includes the host class's packing copies ([x|P] concat, [u;p] concat)"}}
+        return extra, roof, "weak"
+
+    def cpu():
+        from oracle import kf as okf, models as om
+        mdl = om.get('chemostat4').discretize(4)
+        xP = okf.pack(x, Pm)
+        yy = x[:, [0, 2]]
+        uu, pp = u.cpu().numpy(), p.cpu().numpy()
+        stepf = okf.kf_step if kind == 'ekf' else okf.ukf_step
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 8.:
+            stepf(mdl, xP, yy, uu, pp, 1e-4, 1e-2, 1.)
+            n += 1
+        secs = time.perf_counter() - t0
+        return {"value": n * B / secs, "unit": "steps/s", "cores": 1, "kind": "port",
+                "sample": f"{n} batched steps of B = {B} with the oracle's numpy-vectorised {kind.upper()} ({secs:.1f} s)",
+                "host_cpus": os.cpu_count()}
+    return dict(step=step, finish=finish, units=B, cpu=cpu, unit="steps/s",
+                metric="Kalman filter steps/sec (batched instances, whole node)")
+
+
+def wl_gp(args, torch, dev, rank, world):
+    from tests import problems as P
+    gp = P.product_gp()
+    m = args.batch or (1 << 18)
+    rng = np.random.default_rng(3 + rank)
+    Xq = torch.as_tensor(np.stack([rng.uniform(0, 40, m), rng.uniform(0, 4, m)]), device=dev)
+    n, nf = 200, 2
+    ev = []
+
+    def step(timed):
+        if timed:
+            e = _events(torch, 1)[0]
+            e[0].record()
+        gp.predict(Xq)
+        if timed:
+            e[1].record()
+            ev.append(e)
+
+    def finish():
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        fl_q = n * (3 * nf + 20) + 2 * n + n * n                        # mean + triangular product per query
+        tf = m * fl_q / (kern_ms * 1e-3) / 1e12
+        by = m * 8 * (nf + 2)
+        roof = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                "traffic": pmc_traffic_bytes('gp-predict'), "kernel": "gp_predict_kernel", "kernel_ms": kern_ms,
+                "note": "fp64 compute roof: flops per query = n (3 nf + 20) + 2 n (mean) + n^2 (|L^-1 k*|^2), n = 200; "
+                        "compulsory HBM traffic is 8 (nf + 2) bytes per query (arithmetic intensity ~1400 flop/B)",
+                "hbm": {"achieved": by / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": by / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by}}
+        extra = {"workload": "GaussianProcess.predict (mean + variance), SE-ARD kernel, n = 200 training points, nf = 2",
+                 "queries_per_gpu": m, "global_queries": m * world, "parallelism": f"query columns sharded x{world}"}
+        return extra, roof, "weak"
+
+    def cpu():
+        post = P.oracle_c4()[1]
+        mq = 20000
+        Xh = Xq[:, :mq].cpu().numpy()
+        t0 = time.perf_counter()
+        nrep = 0
+        while time.perf_counter() - t0 < 8.:
+            post.predict(Xh)
+            nrep += 1
+        secs = time.perf_counter() - t0
+        return {"value": nrep * mq / secs, "unit": "predictions/s", "cores": 1, "kind": "port",
+                "sample": f"{nrep} x {mq} query columns with the oracle's numpy Posterior.predict ({secs:.1f} s; BLAS threads as "
+                          f"numpy is configured)", "host_cpus": os.cpu_count()}
+    return dict(step=step, finish=finish, units=m, cpu=cpu, unit="predictions/s",
+                metric="GP predictions/sec (query columns with variance, whole node)")
+
+
+def wl_lmpc(args, torch, dev, rank, world):
+    from tests.test_lmpc_gpu import product_lmpc
+    B = args.batch or 1024
+    mpc = product_lmpc('corrected')
+    rng = np.random.default_rng(20260926 + rank)
+    x = torch.as_tensor(rng.uniform(-4, 4, (B, 2)), device=dev)
+    Ad = torch.as_tensor(np.array([[1., .5], [0., 1.]]), device=dev)
+    Bd = torch.as_tensor(np.array([[.125], [.5]]), device=dev)
+    ev, log = [], []
+
+    def step(timed):
+        nonlocal x
+        if timed:
+            e = _events(torch, 1)[0]
+            e[0].record()
+        u = mpc.optimize(x)
+        if timed:
+            e[1].record()
+            ev.append(e)
+            log.append(mpc._nlp_solution['iter_count'])
+        x = x @ Ad.T + u @ Bd.T
+
+    def finish():
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        iters = float(torch.stack(log).double().mean().item())
+        n, mq = 32, 20
+        fl_it = 2 * mq * mq * n + mq ** 3 / 3 + 4 * mq * mq + 6 * n * mq
+        tf = B * iters * fl_it / (kern_ms * 1e-3) / 1e12
+        one = product_lmpc('corrected')
+        x1 = torch.as_tensor(np.array([[1., 1.]]), device=dev)
+        for _ in range(3):
+            one.optimize(x1)
+        torch.cuda.synchronize(dev)
+        e1 = _events(torch, 20)
+        for a, b in e1:
+            a.record()
+            one.optimize(x1)
+            b.record()
+        torch.cuda.synchronize(dev)
+        roof = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                "traffic": pmc_traffic_bytes('C1'), "kernel": "qp_solve_kernel", "kernel_ms": kern_ms,
+                "note": "dense Mehrotra predictor-corrector, 32 variables / 20 equalities: flops per iteration = 2 m^2 n + m^3/3 "
+                        "+ 4 m^2 + 6 n m; a 32-variable QP per workgroup is latency bound"}
+        extra = {"workload": "C1 LMPC discrete double integrator nx=2 nu=1 N=10 (corrected input block), closed loop",
+                 "batch_per_gpu": B, "global_batch": B * world, "mean_qp_iters": iters,
+                 "single_instance_latency_us": float(np.mean([a.elapsed_time(b) for a, b in e1])) * 1e3}
+        return extra, roof, "weak"
+
+    def cpu():
+        from oracle.lmpc import LmpcProblem, lmpc_optimize
+        from tests.test_oracle_lmpc import C1
+        pb = LmpcProblem(**C1, kron_bug=False)
+        xs = rng.uniform(-4, 4, (64, 2))
+        t0 = time.perf_counter()
+        nrep = 0
+        while time.perf_counter() - t0 < 8.:
+            lmpc_optimize(pb, xs)
+            nrep += 1
+        secs = time.perf_counter() - t0
+        return {"value": nrep * 64 / secs, "unit": "steps/s", "cores": 1, "kind": "port",
+                "sample": f"{nrep} x 64 QPs with the oracle's dense Mehrotra + active-set polish (numpy; {secs:.1f} s)",
+                "host_cpus": os.cpu_count()}
+    return dict(step=step, finish=finish, units=B, cpu=cpu, unit="steps/s",
+                metric="LMPC steps/sec (batched QPs, whole node)")
+
+
+def build_workload(cfg, args, torch, dev, rank, world):
+    if cfg in ('C2', 'C4', 'C5'):
+        return wl_nmpc(cfg, args, torch, dev, rank, world)
+    if cfg == 'C3-mhe':
+        return wl_mhe(args, torch, dev, rank, world)
+    if cfg in ('C3-ekf', 'C3-ukf'):
+        return wl_kf(cfg[3:], args, torch, dev, rank, world)
+    if cfg == 'gp-predict':
+        return wl_gp(args, torch, dev, rank, world)
+    return wl_lmpc(args, torch, dev, rank, world)
+
+
+def respawn(args):
+    """`python bench.py --gpus N` without a torchrun environment: one process per GPU under torch.distributed.run."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -84,35 +492,27 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=1024, help='instances per GPU')
+    ap.add_argument('--config', choices=CONFIGS, default='C2')
+    ap.add_argument('--batch', type=int, default=0, help='instances per GPU (weak configs) / in total (C4, C5); 0 = the config default')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(respawn(args))
+
     import torch
     import torch.distributed as dist
-    from hilo_mpc_amd.dist import init_from_env, StepGather
-    from tests.problems import C2, c2_x0, product_nmpc
+    from hilo_mpc_amd.dist import init_from_env
 
     rank, world, local = init_from_env()
     if world != args.gpus:
         if rank == 0:
-            print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+            print(f"error: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local if world > 1 else 0)
     dev = torch.device('cuda', torch.cuda.current_device())
 
-    spec = C2
-    B = args.batch
-    nmpc = product_nmpc(spec)
-    nx, nu, N = nmpc._n_x, nmpc._n_u, nmpc.horizon
-    x = torch.as_tensor(c2_x0(B, seed=20260926 + rank), device=dev)
-    p = torch.as_tensor(np.asarray(spec['p'], dtype=np.float64), device=dev)
-    gather = StepGather(B * world, nu, rank, world, dev)
-
-    def step(x):
-        u = nmpc.optimize(x, cp=p)                         # one hilo_nmpc_solve launch for the whole shard
-        sol = nmpc._nlp_solution
-        gather(u, sol['status'], sol['iter_count'])        # the one collective of the step (RCCL all-gather)
-        return nmpc.plant_step(x, u, cp=p)
+    wl = build_workload(args.config, args, torch, dev, rank, world)
 
     def sync():
         if world > 1:
@@ -120,71 +520,32 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        x = step(x)
+        wl['step'](False)
     sync()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    it_sum, n_ok, kkt_max = 0.0, 0, 0.0
-    iters_log = []
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        # HIP events bracket exactly the solve launch on the stream it is launched on (torch's current stream)
-        ev[k][0].record()
-        u = nmpc.optimize(x, cp=p)
-        ev[k][1].record()
-        sol = nmpc._nlp_solution
-        gather(u, sol['status'], sol['iter_count'])
-        iters_log.append((sol['iter_count'], sol['status'], sol['kkt_error']))
-        x = nmpc.plant_step(x, u, cp=p)
+    for _ in range(args.steps):
+        wl['step'](True)
     sync()
     elapsed = time.perf_counter() - t0
+    units = float(wl['units'])
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    iters_all = torch.stack([i for i, _, _ in iters_log]).to(torch.float64)
-    status_all = torch.stack([s for _, s, _ in iters_log])
-    kkt_all = torch.stack([k for _, _, k in iters_log])
-    mean_iters = float(iters_all.mean().item())
-    ok_frac = float(((status_all == 1) | (status_all == 2)).to(torch.float64).mean().item())
-    kkt_max = float(kkt_all.max().item())
+        tot = torch.tensor([units], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        units = float(tot.item())
+    extra, roof, scaling = wl['finish']()
 
     if rank == 0:
-        total_steps = B * world * args.steps
-        value = total_steps / elapsed
-        flops_launch = B * mean_iters * flops_per_iteration(nx, nu, N)
-        achieved_tf = flops_launch / (kern_ms * 1e-3) / 1e12
-        n_v, n_g, n_p = (N + 1) * nx + N * nu, N * nx, len(spec['p'])
-        bytes_launch = B * 8 * (2 * n_v + 2 * n_g + nx + n_p + nu)      # SURVEY 8d bytes_nmpc
-        achieved_gbs = bytes_launch / (kern_ms * 1e-3) / 1e9
-        out = {
-            "metric": "MPC steps/sec (batched instances, whole node) at fixed (nx,nu,N)",
-            "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2 tracking NMPC chemostat4 nx=4 nu=2 N=20 rk4+discrete, closed loop warm-started",
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"instances sharded x{world}",
-                       "mean_ipm_iters": mean_iters, "frac_status_1_or_2": ok_frac, "max_kkt_error": kkt_max},
-            "roofline": {"bound": "mfma", "achieved": achieved_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / FP64_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(),
-                         "kernel": "ocp_solve_kernel<NmpcTrack<Chemostat4>, 64>", "kernel_ms": kern_ms,
-                         "note": "fp64 roof: MI355X fp64 vector peak == fp64 MFMA peak = 78.6 TFLOP/s; the kernel is "
-                                 "fp64 VALU/latency bound (f64 MFMA only for the Riccati stage products), algorithmic flops = B * mean_iters * N * "
-                                 "(F_ric + F_dyn), see DESIGN.md"},
-            "roofline_hbm": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
-                             "algorithmic_bytes_per_launch": bytes_launch,
-                             "note": "compulsory bytes only (iterate + parameters in/out); not the binding roof"},
-        }
+        out = {"metric": wl['metric'], "value": units * args.steps / elapsed, "unit": wl['unit'], "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+               "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": dict(extra, name=args.config, rccl_world_size=world), "roofline": roof}
+        if 'hbm' in roof:
+            out["roofline_hbm"] = dict(roof.pop('hbm'), bound="hbm", traffic=roof['traffic'])
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only
-            ns = 40
-            v, secs = cpu_baseline(spec, c2_x0(ns), 8)
-            out["cpu_baseline"] = {"value": v, "unit": "steps/s", "cores": 1, "kind": "port",
-                                   "sample": f"{ns} instances x 8 warm-started closed-loop steps of the same C2 "
-                                             f"workload with the oracle's numpy dense interior-point solver "
-                                             f"({secs:.1f} s); the reference's CasADi/IPOPT is not installable",
-                                   "host_cpus": os.cpu_count()}
+            out["cpu_baseline"] = wl['cpu']()
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

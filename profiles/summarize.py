@@ -1,58 +1,77 @@
 #!/usr/bin/env python3
-"""Condense a rocprofv3 output directory (gpurun_out/prof_rNN/{trace,pmc_fetch,pmc_write}) into the small, tracked
-summaries under profiles/: the --stats table, per-launch durations of the dominant kernel, PMC byte counters.
+"""Condense rocprofv3 output (gpurun_out/prof_rNN/<config>/{trace,pmc_fetch,pmc_write}, written by profiles/run_profile.sh)
+into the small, tracked summaries under profiles/: per configuration the --stats table, the launch durations of the dominant
+kernel, the PMC byte counters and the bench line of the same build.
 
-    python profiles/summarize.py gpurun_out/prof_r01 r01 [timed_launches]
+    python profiles/summarize.py gpurun_out/prof_r02 r02
 """
 import csv
+import glob
 import json
 import os
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
-timed = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 here = os.path.dirname(os.path.abspath(__file__))
-KEY = sys.argv[4] if len(sys.argv) > 4 else 'ocp_solve_kernel'
+# substring that identifies the dominant kernel of each configuration in the trace
+KEYS = {'C1': 'qp_solve_kernel', 'C2': 'ocp_solve_kernel', 'C3-mhe': 'ocp_solve_kernel', 'C3-ekf': 'kf_kernel',
+        'C3-ukf': 'kf_kernel', 'C4': 'ocp_solve_kernel', 'C5': 'ocp_solve_kernel', 'gp-predict': 'gp_predict'}
 
-out = {'tag': tag, 'kernel': KEY}
-stats = os.path.join(src, 'trace', f'{tag}_kernel_stats.csv')
-if os.path.exists(stats):
-    rows = list(csv.DictReader(open(stats)))
-    short = []
-    for r in rows:
-        r = dict(r)
-        r['Name'] = r['Name'][:110]
-        short.append(r)
-    with open(os.path.join(here, f'{tag}_kernel_stats.csv'), 'w', newline='') as f:
-        w = csv.DictWriter(f, fieldnames=list(short[0].keys()))
-        w.writeheader()
-        w.writerows(short)
-    k = [r for r in rows if KEY in r['Name']][0]
-    out['stats_all_launches'] = {'calls': int(k['Calls']), 'avg_ns': float(k['AverageNs']),
-                                 'min_ns': float(k['MinNs']), 'max_ns': float(k['MaxNs']),
-                                 'percentage': float(k['Percentage'])}
-trace = os.path.join(src, 'trace', f'{tag}_kernel_trace.csv')
-if os.path.exists(trace):
-    rows = [r for r in csv.DictReader(open(trace)) if KEY in r['Kernel_Name']]
-    d = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rows]
-    out['launch_ns'] = d
-    t = d[-timed:]
-    out['timed_region'] = {'launches': len(t), 'avg_ns': sum(t) / len(t), 'min_ns': min(t), 'max_ns': max(t)}
-    r0 = rows[-1]
-    out['resources'] = {k: r0.get(k) for k in ('Workgroup_Size', 'Grid_Size', 'LDS_Block_Size', 'Scratch_Size',
-                                               'VGPR_Count', 'Accum_VGPR_Count', 'SGPR_Count') if k in r0}
-for name, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
-    p = os.path.join(src, name, f'{tag}_counter_collection.csv')
-    if os.path.exists(p):
-        v = [float(r['Counter_Value']) for r in csv.DictReader(open(p)) if KEY in r['Kernel_Name'] and r['Counter_Name'] == ctr]
-        if v:
-            out[ctr + '_KB_per_launch'] = {'n': len(v), 'mean': sum(v) / len(v), 'min': min(v), 'max': max(v),
-                                           'warm_launches_mean': sum(v[2:]) / max(1, len(v[2:]))}
-log = os.path.join(src, 'bench_under_rocprof.log')
-if os.path.exists(log):
-    for line in open(log):
-        if line.startswith('{"metric"'):
-            out['bench_line_under_profiler'] = json.loads(line)
-with open(os.path.join(here, f'{tag}_summary.json'), 'w') as f:
-    json.dump(out, f, indent=1)
-print(json.dumps({k: v for k, v in out.items() if k not in ('launch_ns', 'bench_line_under_profiler')}, indent=1))
+
+def find(d, pattern):
+    f = glob.glob(os.path.join(d, '**', pattern), recursive=True)
+    return f[0] if f else None
+
+
+for cdir in sorted(glob.glob(os.path.join(src, '*'))):
+    cfg = os.path.basename(cdir)
+    if cfg not in KEYS:
+        continue
+    key = KEYS[cfg]
+    out = {'tag': tag, 'config': cfg, 'kernel_key': key}
+    line = None
+    bj = os.path.join(cdir, 'bench_n1.json')
+    if os.path.exists(bj):
+        for ln in open(bj):
+            if ln.startswith('{"metric"'):
+                line = json.loads(ln)
+    if line:
+        out['bench_line'] = line
+        timed = line['steps']
+    else:
+        timed = 20
+    stats = find(os.path.join(cdir, 'trace'), '*kernel_stats.csv')
+    if stats:
+        rows = list(csv.DictReader(open(stats)))
+        out['kernel_stats_top'] = [{k: (r[k][:100] if k == 'Name' else r[k]) for k in ('Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage')}
+                                   for r in rows[:8]]
+        k = [r for r in rows if key in r['Name']]
+        if k:
+            k = k[0]
+            out['kernel_name'] = k['Name'][:160]
+            out['stats_all_launches'] = {'calls': int(k['Calls']), 'avg_ns': float(k['AverageNs']), 'min_ns': float(k['MinNs']),
+                                         'max_ns': float(k['MaxNs']), 'percentage': float(k['Percentage'])}
+    trace = find(os.path.join(cdir, 'trace'), '*kernel_trace.csv')
+    if trace:
+        rows = [r for r in csv.DictReader(open(trace)) if key in r['Kernel_Name']]
+        d = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rows]
+        if d:
+            t = d[-timed:]
+            out['timed_region'] = {'launches': len(t), 'avg_ns': sum(t) / len(t), 'min_ns': min(t), 'max_ns': max(t)}
+            r0 = rows[-1]
+            out['resources'] = {k: r0.get(k) for k in ('Workgroup_Size', 'Grid_Size', 'LDS_Block_Size', 'Scratch_Size', 'VGPR_Count',
+                                                       'Accum_VGPR_Count', 'SGPR_Count') if k in r0}
+    for name, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
+        p = find(os.path.join(cdir, name), '*counter_collection.csv')
+        if p:
+            v = [float(r['Counter_Value']) for r in csv.DictReader(open(p)) if key in r['Kernel_Name'] and r['Counter_Name'] == ctr]
+            if v:
+                out[ctr + '_KB_per_launch'] = {'n': len(v), 'mean': sum(v) / len(v), 'min': min(v), 'max': max(v),
+                                               'warm_launches_mean': sum(v[2:]) / max(1, len(v[2:]))}
+    with open(os.path.join(here, f'{tag}_{cfg}_summary.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    brief = {k: v for k, v in out.items() if k in ('config', 'kernel_name', 'timed_region', 'FETCH_SIZE_KB_per_launch', 'WRITE_SIZE_KB_per_launch')}
+    if line:
+        brief['value'] = line['value']
+        brief['roofline'] = {k: line['roofline'].get(k) for k in ('bound', 'achieved', 'frac', 'kernel_ms')}
+    print(json.dumps(brief))
