@@ -296,33 +296,10 @@ def wl_kf(kind, args, torch, dev, rank, world):
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": pmc_traffic_bytes('C3-' + kind), "kernel": f"kf_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}, 2>",
                 "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": B * bytes_step,
-                "note": "bytes_kf = 8 (2 nx (nx+1) + 2 ny + nu + np) per filter step (SURVEY 8d); at B = 4096 one launch moves "
-                        "1.6 MB, i.e. the launch is latency bound, not bandwidth bound: see config.large_batch for the "
-                        "bandwidth-bound regime"}
-        # bandwidth regime: the same kernel on a batch that fills the chip (B = 2^20), 10 launches
-        Bl = 1 << 20
-        fl = (EKF if kind == 'ekf' else UKF)(Model('chemostat4').discretize('rk4').setup(dt=1.))
-        fl.setup()
-        fl.Q, fl.R = 1e-4, 1e-2
-        xl = torch.as_tensor(np.array([.1, 40., .5, .2]), device=dev).repeat(Bl, 1) * (1 + .1 * torch.rand(Bl, 4, device=dev, dtype=torch.float64))
-        fl.set_initial_guess(xl, P0=torch.eye(4, device=dev, dtype=torch.float64).repeat(Bl, 1, 1))
-        ul, pl = u[:1].repeat(Bl, 1), p[:1].repeat(Bl, 1)
-        yl = xl[:, [0, 2]].contiguous()
-        for _ in range(2):
-            fl.estimate(y=yl, u=ul, p=pl)
-        el = _events(torch, 10)
-        for a, b in el:
-            a.record()
-            fl.estimate(y=yl, u=ul, p=pl)
-            b.record()
-        torch.cuda.synchronize(dev)
-        ms = float(np.mean([a.elapsed_time(b) for a, b in el]))
+                "note": "bytes_kf = 8 (2 nx (nx+1) + 2 ny + nu + np) per filter step (SURVEY 8d); at the configuration's B = 4096 "
+                        "one launch moves 1.6 MB and is latency bound; `--batch 1048576` measures the bandwidth-bound regime"}
         extra = {"workload": f"C3 {kind.upper()} step chemostat4 nx=4 ny=2 (predict + update fused), Q = 1e-4 I, R = 1e-2 I",
-                 "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"instances sharded x{world}",
-                 "large_batch": {"batch": Bl, "ms_per_launch": ms, "steps_per_s": Bl / (ms * 1e-3),
-                                 "hbm_GBps": Bl * bytes_step / (ms * 1e-3) / 1e9,
-                                 "hbm_frac": Bl * bytes_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "note": "event time includes the host class's packing copies ([x|P] concat, [u;p] concat)"}}
+                 "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"instances sharded x{world}"}
         return extra, roof, "weak"
 
     def cpu():

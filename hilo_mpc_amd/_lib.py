@@ -16,6 +16,11 @@ class HiloError(RuntimeError):
     code = 0
 
 
+class NotPositiveDefinite(HiloError, ValueError):
+    """HILO_ENOTPD: K + sn2 I has a non-positive pivot (the reference adds no jitter, inference.py:206)."""
+    code = -5
+
+
 class KfDesc(C.Structure):
     _fields_ = [('model_id', C.c_int32), ('kind', C.c_int32), ('continuous', C.c_int32), ('erk_order', C.c_int32),
                 ('n_sub', C.c_int32), ('lti_nx', C.c_int32), ('lti_nu', C.c_int32), ('lti_ny', C.c_int32),
@@ -83,6 +88,7 @@ def _declare(lib):
         'hilo_nmpc_dims': (C.c_int, [vp, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]),
         'hilo_nmpc_reset_warm_start': (C.c_int, [vp]),
         'hilo_nmpc_set_fix_x0': (C.c_int, [vp, i32]),
+        'hilo_nmpc_set_x0_box': (C.c_int, [vp, vp, vp]),
         'hilo_nmpc_solve': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_nmpc_solve_tv': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_nmpc_profile': (C.c_int, [vp, i32, vp]),
@@ -100,6 +106,8 @@ def _declare(lib):
         'hilo_gp_create': (C.c_int, [i32, i32, i32, vp, vp, vp, i32, vp, i32, dbl, P(vp)]),
         'hilo_gp_destroy': (None, [vp]),
         'hilo_gp_log_marginal_likelihood': (C.c_int, [vp, P(C.c_double)]),
+        'hilo_gp_refit': (C.c_int, [vp, vp, i32, dbl]),
+        'hilo_gp_lml_gradient': (C.c_int, [vp, i32, vp, vp, vp, vp]),
         'hilo_gp_predict': (C.c_int, [vp, i64, vp, i32, vp, vp, vp]),
         'hilo_gp_kernel_matrix': (C.c_int, [i32, i32, vp, i32, i64, vp, i64, vp, vp, vp]),
         'hilo_gp_mean': (C.c_int, [i32, i32, vp, i32, i64, vp, vp, vp]),
@@ -132,6 +140,8 @@ def check(rc):
         msg = lib().hilo_last_error().decode(errors='replace')
         if rc == -1:
             raise ValueError(msg)
+        if rc == -5:
+            raise NotPositiveDefinite(msg)
         err = HiloError(f"libhilo_hip error {rc}: {msg}")
         err.code = rc
         raise err

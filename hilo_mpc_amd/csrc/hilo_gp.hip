@@ -198,11 +198,12 @@ __device__ double eval_mean(const double* __restrict__ prog, int len, const doub
 __global__ void kmat_kernel(const double* __restrict__ prog, int len, int nf, int64_t n1, const double* __restrict__ X1,
                             int64_t n2, const double* __restrict__ X2, double diag_add, double* __restrict__ K) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t i = blockIdx.y;
   if (j >= n2) return;
-  double v = eval_kernel(prog, len, X1 + i, n1, X2 + j, n2);
-  if (i == j) v += diag_add;
-  K[i * n2 + j] = v;
+  for (int64_t i = blockIdx.y; i < n1; i += gridDim.y) {   // rows strided over gridDim.y (at most 65535 blocks in y)
+    double v = eval_kernel(prog, len, X1 + i, n1, X2 + j, n2);
+    if (i == j) v += diag_add;
+    K[i * n2 + j] = v;
+  }
 }
 
 __global__ void mean_kernel(const double* __restrict__ prog, int len, int64_t n, const double* __restrict__ X,
@@ -278,19 +279,69 @@ __global__ __launch_bounds__(FACT_TPB) void gp_factor_kernel(int n, double* __re
     out[1] = (double)bad;
   }
   (void)quad;
-  // --- Linv = L^-1 : column c by forward substitution, one column per thread --------------------------
-  for (int c = t; c < n; c += FACT_TPB) {
-    for (int i = 0; i < n; ++i) {
-      double s = (i == c) ? 1.0 : 0.0;
-      if (i >= c) {
-        for (int j = c; j < i; ++j) s -= A[(int64_t)i * n + j] * Linv[(int64_t)j * n + c];
-        s /= A[(int64_t)i * n + i];
-      } else {
-        s = 0.0;
-      }
-      Linv[(int64_t)i * n + c] = s;
-    }
+  (void)Linv;
+}
+
+// Linv = L^-1, needed by the predictive variance only (built on first use after a fit): one wave per column c, forward
+// substitution with the dot products spread over the lanes; row-major full matrix, zeros above the diagonal
+__global__ __launch_bounds__(64) void gp_linv_kernel(int n, const double* __restrict__ L, double* __restrict__ Linv, int lp) {
+  extern __shared__ double col[];   // column c of L^-1 while it is built
+  const int c = blockIdx.x, lane = threadIdx.x;
+  for (int i = c; i < n; ++i) {
+    double s = 0.0;
+    for (int j = c + lane; j < i; j += 64) s += L[(int64_t)i * n + j] * col[j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) col[i] = ((i == c ? 1.0 : 0.0) - s) / L[(int64_t)i * n + i];
+    __syncthreads();
   }
+  for (int i = lane; i < n; i += 64) Linv[(int64_t)i * lp + c] = i < c ? 0.0 : col[i];   // row pitch lp, zero padded
+}
+
+// L^-1 in MFMA-operand order for the register-resident predict kernel: block (row tile it, k-block kb <= last block of the
+// tile) holds its 64 A-operand values in lane order, lane 16 g + q <-> L^-1[16 it + q][4 kb + g]; blocks of one row tile are
+// consecutive, tile it starts at block 2 it (it + 1).  One wave-wide load of an operand is then 512 contiguous bytes (four
+// cache lines) instead of sixteen 32-byte pieces of sixteen rows.
+__global__ void gp_linv_swizzle_kernel(int nt, const double* __restrict__ Linv, int lp, double* __restrict__ Ls) {
+  const int blk = blockIdx.x, lane = threadIdx.x, q = lane & 15, g = lane >> 4;
+  int it = 0;
+  while (2 * (it + 1) * (it + 2) <= blk) ++it;
+  const int kb = blk - 2 * it * (it + 1);
+  if (it < nt) Ls[(int64_t)blk * 64 + lane] = Linv[(int64_t)(16 * it + q) * lp + 4 * kb + g];
+}
+
+// d LML / d theta_j = 1/2 tr((alpha alpha^T - K_y^-1) dK_y / d theta_j) (Rasmussen & Williams eq. 5.9): the factorisation of
+// the handle is reused for every hyper-parameter, dK_y/d theta_j comes from central differences of the (cheap) covariance
+// function itself - the two perturbed kernel programs of each theta_j are evaluated element by element.
+//   Amat[a][b] = alpha_a alpha_b - sum_k Linv[k][a] Linv[k][b]
+__global__ void gp_amat_kernel(int n, const double* __restrict__ alpha, const double* __restrict__ Linv, int lp, double* __restrict__ Amat) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * n) return;
+  const int a = e / n, b = e - a * n;
+  double s = 0.0;
+  for (int k = a > b ? a : b; k < n; ++k) s += Linv[(int64_t)k * lp + a] * Linv[(int64_t)k * lp + b];
+  Amat[e] = alpha[a] * alpha[b] - s;
+}
+__global__ __launch_bounds__(256) void gp_grad_kernel(int n, int nf, int klen, const double* __restrict__ progs /*[nt][2][klen]*/,
+                                                      const double* __restrict__ dsn2 /*[nt]: d sn2 / d theta*/,
+                                                      const double* __restrict__ inv2h /*[nt]*/, const double* __restrict__ X,
+                                                      const double* __restrict__ Amat, double* __restrict__ grad) {
+  const int j = blockIdx.y;
+  const double* pp = progs + (int64_t)j * 2 * klen;
+  __shared__ double red[256];
+  double part = 0.0;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n * n; e += gridDim.x * 256) {
+    const int a = e / n, b = e - a * n;
+    double dk = (eval_kernel(pp, klen, X + a, n, X + b, n) - eval_kernel(pp + klen, klen, X + a, n, X + b, n)) * inv2h[j];
+    if (a == b) dk += dsn2[j];
+    part += Amat[e] * dk;
+  }
+  red[threadIdx.x] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(grad + j, 0.5 * red[0]);
 }
 
 // Prediction for a tile of Q queries per workgroup (gp.py:699-718, inference.py:212-217).
@@ -301,7 +352,7 @@ constexpr int PRED_TPB = 256;
 __global__ __launch_bounds__(PRED_TPB) void gp_predict_kernel(const double* __restrict__ kprog, int klen,
                                                               const double* __restrict__ mprog, int mlen, int nf, int n,
                                                               const double* __restrict__ Xt, const double* __restrict__ alpha,
-                                                              const double* __restrict__ Linv, double sn2_add, int64_t m,
+                                                              const double* __restrict__ Linv, int lp, double sn2_add, int64_t m,
                                                               const double* __restrict__ Xq, int Q, double* __restrict__ mean,
                                                               double* __restrict__ var) {
   extern __shared__ double lds[];  // K* tile [n][Q] then reduction scratch [PRED_TPB]
@@ -331,7 +382,7 @@ __global__ __launch_bounds__(PRED_TPB) void gp_predict_kernel(const double* __re
   if (var) {
     double ss = 0.0;
     for (int i = g; i < n; i += G) {
-      const double* Li = Linv + (int64_t)i * n;
+      const double* Li = Linv + (int64_t)i * lp;
       double v = 0.0;
       for (int j = 0; j <= i; ++j) v += Li[j] * Ks[j * Q + q];
       ss += v * v;
@@ -345,6 +396,230 @@ __global__ __launch_bounds__(PRED_TPB) void gp_predict_kernel(const double* __re
       var[q0 + q] = kss - tot + sn2_add;
     }
   }
+}
+
+
+// Prediction on the f64 matrix cores: the variance needs V = L^-1 K* (n x n lower-triangular times n x Q), a GEMM whose
+// column sums of squares are subtracted from k(x*, x*) (inference.py:215-217).  One workgroup = Q = 16 W queries, W waves;
+// wave w owns the 16 query columns of tile w.
+//   phase 1: K* tile [n_pad][Q] into LDS (rows >= n zero), mean = m(x*) + K*^T alpha
+//   phase 2: per 16-row tile `it` of L^-1: acc (16 x 16) = sum over k-blocks of 4 <= the tile's last row (the factor is lower
+//            triangular, later blocks are zero) of v_mfma_f64_16x16x4: A-operand L^-1[16 it + q][4 kb + g] straight from
+//            global memory (L2-resident, one element per lane), B-operand K*[4 kb + g][16 w + q] from LDS; lane = 16 g + q
+//            holds rows 4 r + g of column q in accumulator register r: ss_q += sum_r acc_r^2, combined over g at the end.
+typedef double gp_v4d __attribute__((ext_vector_type(4)));
+template <int W>
+__global__ __launch_bounds__(64 * W) void gp_predict_mfma_kernel(const double* __restrict__ kprog, int klen,
+                                                                 const double* __restrict__ mprog, int mlen, int nf, int n,
+                                                                 const double* __restrict__ Xt, const double* __restrict__ alpha,
+                                                                 const double* __restrict__ Linv, int lp, double sn2_add, int64_t m,
+                                                                 const double* __restrict__ Xq, double* __restrict__ mean,
+                                                                 double* __restrict__ var) {
+  constexpr int Q = 16 * W, TPB = 64 * W;
+  // row pitch Q + 16 doubles: the four row groups g of a B-operand read then fall on disjoint halves of the 64 LDS banks
+  constexpr int P = Q + 16;
+  extern __shared__ double lds[];   // K* tile [n_pad][P] | partial sums [TPB] | kernel program | X_train [nf][n_pad] | queries [nf][Q]
+  const int n_pad = (n + 15) & ~15;
+  double* Ks = lds;
+  double* red = lds + (int64_t)(n_pad + 16) * P;   // 16 spare zero rows: the k-loop runs in groups of eight blocks
+  double* prog_s = red + TPB;
+  double* Xt_s = prog_s + klen;
+  double* Xq_s = Xt_s + (int64_t)nf * n_pad;
+  const int t = threadIdx.x;
+  const int64_t q0 = (int64_t)blockIdx.x * Q;
+  const int nq = (int)((m - q0) < Q ? (m - q0) : Q);
+  // operands of the covariance function once into LDS: every one of the n_pad x Q evaluations below reads them from there
+  for (int e = t; e < klen; e += TPB) prog_s[e] = kprog[e];
+  for (int e = t; e < nf * n_pad; e += TPB) {
+    const int d = e / n_pad, i = e - d * n_pad;
+    Xt_s[e] = i < n ? Xt[(int64_t)d * n + i] : 0.0;
+  }
+  for (int e = t; e < nf * Q; e += TPB) {
+    const int d = e / Q, q = e - d * Q;
+    Xq_s[e] = q < nq ? Xq[(int64_t)d * m + q0 + q] : 0.0;
+  }
+  __syncthreads();
+  // the common case - one squared-exponential node (kernel.py:696 with p = 2) - is evaluated inline; everything else goes
+  // through the interpreter
+  const int na0 = (int)prog_s[1];
+  const bool se = (int)prog_s[0] == HILO_K_GAMMAEXP && klen == 3 + na0 + (int)prog_s[2 + na0] && prog_s[3 + na0 + 2] == 1.0;
+  if (se) {
+    const double sf2 = prog_s[3 + na0], al = prog_s[3 + na0 + 1];
+    const double* Md = prog_s + 3 + na0 + 3;
+    for (int e = t; e < (n_pad + 16) * Q; e += TPB) {
+      const int i = e / Q, q = e - i * Q;
+      double d2 = 0.0;
+      for (int k = 0; k < na0; ++k) {
+        const int d = (int)prog_s[2 + k];
+        const double df = Xt_s[d * n_pad + (i < n_pad ? i : 0)] - Xq_s[d * Q + q];
+        d2 += df * Md[k] * df;
+      }
+      Ks[i * P + q] = (i < n && q < nq) ? sf2 * exp(-al * d2) : 0.0;
+    }
+  } else {
+    for (int e = t; e < (n_pad + 16) * Q; e += TPB) {
+      const int i = e / Q, q = e - i * Q;
+      Ks[i * P + q] = (i < n && q < nq) ? eval_kernel(prog_s, klen, Xt_s + i, n_pad, Xq_s + q, Q) : 0.0;
+    }
+  }
+  __syncthreads();
+  {  // mean: thread (g, q) sums rows g, g + G, ...
+    const int q = t % Q, g = t / Q;
+    constexpr int G = TPB / Q;
+    double s = 0.0;
+    for (int i = g; i < n; i += G) s += Ks[i * P + q] * alpha[i];
+    red[t] = s;
+    __syncthreads();
+    if (g == 0 && q < nq) {
+      double tot = eval_mean(mprog, mlen, Xq + q0 + q, m);
+#pragma unroll
+      for (int k = 0; k < G; ++k) tot += red[k * Q + q];
+      mean[q0 + q] = tot;
+    }
+  }
+  if (!var) return;
+  const int lane = t & 63, w = t >> 6, q = lane & 15, g = lane >> 4;
+  const int ntile = n_pad / 16;
+  double ss = 0.0;
+  const double* Kw = Ks + 16 * w + q;
+  // L^-1 is stored zero padded (rows up to n_pad, row pitch lp = n_pad + 16) and the K* tile carries 16 spare zero rows, so the
+  // k-loop needs no bounds: eight unconditional operand pairs per trip (A from global / L2, B from LDS), eight MFMAs.
+  for (int it = 0; it < ntile; ++it) {
+    gp_v4d acc = {0.0, 0.0, 0.0, 0.0};
+    const double* Lrow = Linv + (int64_t)(16 * it + q) * lp + g;
+    const double* Kg = Kw + g * P;
+    const int nk = 16 * (it + 1);                  // columns up to the last row of this tile; the rest of the row is zero
+    for (int k0 = 0; k0 < nk; k0 += 32) {
+      double a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[u] = Lrow[k0 + 4 * u];
+        b[u] = Kg[(k0 + 4 * u) * P];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ss += acc[r] * acc[r];
+  }
+  // combine the four row groups g of a column (lanes q, 16 + q, 32 + q, 48 + q)
+  ss += __shfl_xor(ss, 16, 64);
+  ss += __shfl_xor(ss, 32, 64);
+  if (g == 0 && 16 * w + q < nq) {
+    const int64_t qi = q0 + 16 * w + q;
+    const double kss = eval_kernel(prog_s, klen, Xq_s + 16 * w + q, Q, Xq_s + 16 * w + q, Q);
+    var[qi] = kss - ss + sn2_add;
+  }
+}
+
+// Register-resident variant for n <= 256 (the sizes the reference's exact GP is used at): lane (g, q) of a wave evaluates the
+// entries K*[4 kb + g][q] of its 16 query columns itself and KEEPS them - they are exactly the B operands of every k-block -
+// so the K* tile never exists in LDS, a workgroup needs only the staged training inputs there, and several workgroups share
+// a CU (the MFMA chains of one hide the operand fetches of the others).  NT = row tiles of 16 (compile-time: the operand
+// registers are indexed statically, both loops are fully unrolled).
+template <int NT>
+__global__ __launch_bounds__(256) void gp_predict_reg_kernel(const double* __restrict__ kprog, int klen,
+                                                             const double* __restrict__ mprog, int mlen, int nf, int n,
+                                                             const double* __restrict__ Xt, const double* __restrict__ alpha,
+                                                             const double* __restrict__ Ls, double sn2_add, int64_t m,
+                                                             const double* __restrict__ Xq, double* __restrict__ mean,
+                                                             double* __restrict__ var) {
+  constexpr int n_pad = 16 * NT, NKB = 4 * NT;
+  extern __shared__ double lds[];   // kernel program | X_train [nf][n_pad] | alpha [n_pad]
+  double* prog_s = lds;
+  double* Xt_s = prog_s + klen;
+  double* al_s = Xt_s + (int64_t)nf * n_pad;
+  const int t = threadIdx.x;
+  for (int e = t; e < klen; e += 256) prog_s[e] = kprog[e];
+  for (int e = t; e < nf * n_pad; e += 256) {
+    const int d = e / n_pad, i = e - d * n_pad;
+    Xt_s[e] = i < n ? Xt[(int64_t)d * n + i] : 0.0;
+  }
+  for (int e = t; e < n_pad; e += 256) al_s[e] = e < n ? alpha[e] : 0.0;
+  __syncthreads();
+  const int lane = t & 63, w = t >> 6, q = lane & 15, g = lane >> 4;
+  const int64_t qi = ((int64_t)blockIdx.x * 4 + w) * 16 + q;
+  const bool qv = qi < m;
+  const int64_t qc = qv ? qi : m - 1;
+  const int na0 = (int)prog_s[1];
+  const bool se = (int)prog_s[0] == HILO_K_GAMMAEXP && klen == 3 + na0 + (int)prog_s[2 + na0] && prog_s[3 + na0 + 2] == 1.0;
+  double kreg[NKB];
+  double msum = 0.0;
+  if (se) {   // one squared-exponential node (kernel.py:696 with p = 2), inline
+    const double sf2 = prog_s[3 + na0], al = prog_s[3 + na0 + 1];
+    const double* Md = prog_s + 3 + na0 + 3;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) kreg[kb] = 0.0;
+    for (int k = 0; k < na0; ++k) {
+      const int d = (int)prog_s[2 + k];
+      const double xq = Xq[(int64_t)d * m + qc], Mk = Md[k];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const double df = Xt_s[d * n_pad + 4 * kb + g] - xq;
+        kreg[kb] += df * Mk * df;
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const double v = (4 * kb + g < n) ? sf2 * exp(-al * kreg[kb]) : 0.0;
+      kreg[kb] = v;
+      msum += v * al_s[4 * kb + g];
+    }
+  } else {
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const int i = 4 * kb + g;
+      const double v = i < n ? eval_kernel(prog_s, klen, Xt_s + i, n_pad, Xq + qc, m) : 0.0;
+      kreg[kb] = v;
+      msum += v * al_s[i];
+    }
+  }
+  msum += __shfl_xor(msum, 16, 64);
+  msum += __shfl_xor(msum, 32, 64);
+  if (g == 0 && qv) mean[qi] = eval_mean(mprog, mlen, Xq + qi, m) + msum;
+  if (!var) return;
+  double ss = 0.0;
+  // A operands (L^-1 from global / L2) in chunks of eight k-blocks, double buffered by hand: the loads of the next chunk are
+  // issued before the MFMAs of the current one and fenced there (left alone, the scheduler serialises load -> wait -> MFMA
+  // through one register pair).  Both loops unroll completely, every index below is a constant.
+  // Row tiles are processed in PAIRS (two independent accumulator chains that share the B operands: one chain alone leaves
+  // the matrix pipe idle for the accumulator latency - measured 193 cycles per dependent f64 MFMA against ~100 issued from
+  // independent chains, tools/dbg/mfma_peak.hip).
+  double abuf[2][2][8];
+  const double* Lq = Ls + lane;   // operand-order copy of L^-1 (gp_linv_swizzle_kernel): block (it, kb) at 2 it (it + 1) + kb
+#define GP_LOAD(IT, C, BUF)                                                                                        \
+  {                                                                                                                \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                                \
+      BUF[0][u] = (8 * (C) + u < 4 * ((IT) + 1)) ? Lq[(2 * (IT) * ((IT) + 1) + 8 * (C) + u) * 64] : 0.0;           \
+      BUF[1][u] = ((IT) + 1 < NT && 8 * (C) + u < 4 * ((IT) + 2)) ? Lq[(2 * ((IT) + 1) * ((IT) + 2) + 8 * (C) + u) * 64] : 0.0; \
+    }                                                                                                              \
+  }
+  GP_LOAD(0, 0, abuf[0])
+  int cur = 0;
+#pragma unroll
+  for (int it = 0; it < NT; it += 2) {
+    gp_v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const int nkb0 = 4 * (it + 1), nkb1 = (it + 1 < NT) ? 4 * (it + 2) : 0, nkb = nkb1 > nkb0 ? nkb1 : nkb0, nch = (nkb + 7) / 8;
+#pragma unroll
+    for (int c = 0; c < nch; ++c) {
+      if (c + 1 < nch) GP_LOAD(it, c + 1, abuf[cur ^ 1])
+      else if (it + 2 < NT) GP_LOAD(it + 2, 0, abuf[cur ^ 1])
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (8 * c + u < nkb0) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[cur][0][u], kreg[8 * c + u], acc0, 0, 0, 0);
+        if (8 * c + u < nkb1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[cur][1][u], kreg[8 * c + u], acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      cur ^= 1;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ss += acc0[r] * acc0[r] + acc1[r] * acc1[r];
+  }
+#undef GP_LOAD
+  ss += __shfl_xor(ss, 16, 64);
+  ss += __shfl_xor(ss, 32, 64);
+  if (g == 0 && qv) var[qi] = eval_kernel(prog_s, klen, Xq + qi, m, Xq + qi, m) - ss + sn2_add;
 }
 
 // host-side validation of a program: returns 0 when well formed, sets max stack depth
@@ -378,8 +653,10 @@ using namespace hilo;
 
 struct hilo_gp {
   int device, nf, n, klen, mlen;
+  int lp;           // row pitch of Linv: n rounded up to 16, plus 16 (zero padded: the MFMA predict kernel reads whole blocks)
+  int linv_valid;   // L^-1 of the current factorisation has been built (predictive variance, gradient)
   double sn2, lml;
-  double *X, *y, *kprog, *mprog, *L, *Linv, *alpha, *mu, *out;
+  double *X, *y, *kprog, *mprog, *L, *Linv, *LinvS, *alpha, *mu, *out;
   double *h_kprog, *h_mprog;  // host copies of the programs (gp_pack_se2)
 };
 
@@ -392,12 +669,47 @@ static int upload(double** d, const double* h, size_t count) {
 
 extern "C" void hilo_gp_destroy(hilo_gp* gp) {
   if (!gp) return;
-  double* ptrs[] = {gp->X, gp->y, gp->kprog, gp->mprog, gp->L, gp->Linv, gp->alpha, gp->mu, gp->out};
+  double* ptrs[] = {gp->X, gp->y, gp->kprog, gp->mprog, gp->L, gp->Linv, gp->LinvS, gp->alpha, gp->mu, gp->out};
   for (double* p : ptrs)
     if (p) (void)hipFree(p);
   delete[] gp->h_kprog;
   delete[] gp->h_mprog;
   delete gp;
+}
+
+// K + sn2 I -> L, alpha, LML with the handle's current kernel program and noise variance
+static int gp_factorize(hilo_gp* gp) {
+  const int n = gp->n;
+  hipStream_t s = 0;
+  gp->linv_valid = 0;
+  hipLaunchKernelGGL(kmat_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, gp->kprog, gp->klen, gp->nf, (int64_t)n, gp->X,
+                     (int64_t)n, gp->X, gp->sn2, gp->L);
+  hipLaunchKernelGGL(mean_kernel, dim3((n + 255) / 256), dim3(256), 0, s, gp->mprog, gp->mlen, (int64_t)n, gp->X, gp->mu);
+  hipLaunchKernelGGL(gp_factor_kernel, dim3(1), dim3(FACT_TPB), 0, s, n, gp->L, gp->y, gp->mu, gp->alpha, gp->Linv, gp->out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  double res[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpy(res, gp->out, sizeof(res), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(HILO_EHIP, "GP factorisation failed: %s", hipGetErrorString(e));
+  if (res[1] != 0.0)   // its own code: a trial point of a hyper-parameter fit may well be indefinite (hilo_gp_refit)
+    return fail(HILO_ENOTPD, "K + sn2 I is not positive definite (pivot %d); the reference adds no jitter "
+                             "(inference.py:206)", (int)res[1]);
+  gp->lml = res[0];
+  return HILO_OK;
+}
+
+static int gp_ensure_linv(hilo_gp* gp) {
+  if (gp->linv_valid) return HILO_OK;
+  HILO_HIP_CHECK(hipMemsetAsync(gp->Linv, 0, sizeof(double) * (size_t)((gp->n + 15) & ~15) * gp->lp, (hipStream_t)0));
+  hipLaunchKernelGGL(gp_linv_kernel, dim3(gp->n), dim3(64), sizeof(double) * gp->n, (hipStream_t)0, gp->n, gp->L, gp->Linv, gp->lp);
+  {
+    const int nt = (gp->n + 15) / 16;
+    hipLaunchKernelGGL(gp_linv_swizzle_kernel, dim3(2 * nt * (nt + 1)), dim3(64), 0, (hipStream_t)0, nt, gp->Linv, gp->lp, gp->LinvS);
+  }
+  HILO_HIP_CHECK(hipGetLastError());
+  HILO_HIP_CHECK(hipStreamSynchronize(0));
+  gp->linv_valid = 1;
+  return HILO_OK;
 }
 
 extern "C" int hilo_gp_create(int device, int nf, int n, const double* X_host, const double* y_host,
@@ -423,27 +735,12 @@ extern "C" int hilo_gp_create(int device, int nf, int n, const double* X_host, c
   const size_t nn = (size_t)n * n;
 #define UP(field, src, cnt) if ((rc = upload(&gp->field, src, cnt))) { hilo_gp_destroy(gp); return rc; }
   UP(X, X_host, (size_t)nf * n) UP(y, y_host, n) UP(kprog, kprog_host, klen) UP(mprog, mprog_host, mlen)
-  UP(L, nullptr, nn) UP(Linv, nullptr, nn) UP(alpha, nullptr, n) UP(mu, nullptr, n) UP(out, nullptr, 2)
+  gp->lp = ((n + 15) & ~15) + 16;
+  UP(L, nullptr, nn) UP(Linv, nullptr, (size_t)((n + 15) & ~15) * gp->lp) UP(alpha, nullptr, n) UP(mu, nullptr, n) UP(out, nullptr, 2)
+  { const int nt = (n + 15) / 16; UP(LinvS, nullptr, (size_t)2 * nt * (nt + 1) * 64) }
 #undef UP
-  hipStream_t s = 0;
-  hipLaunchKernelGGL(kmat_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, gp->kprog, klen, nf, (int64_t)n, gp->X,
-                     (int64_t)n, gp->X, gp->sn2, gp->L);
-  hipLaunchKernelGGL(mean_kernel, dim3((n + 255) / 256), dim3(256), 0, s, gp->mprog, mlen, (int64_t)n, gp->X, gp->mu);
-  hipLaunchKernelGGL(gp_factor_kernel, dim3(1), dim3(FACT_TPB), 0, s, n, gp->L, gp->y, gp->mu, gp->alpha, gp->Linv, gp->out);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  double res[2] = {0, 0};
-  if (e == hipSuccess) e = hipMemcpy(res, gp->out, sizeof(res), hipMemcpyDeviceToHost);
-  if (e != hipSuccess) {
-    hilo_gp_destroy(gp);
-    return fail(HILO_EHIP, "GP factorisation failed: %s", hipGetErrorString(e));
-  }
-  if (res[1] != 0.0) {
-    hilo_gp_destroy(gp);
-    return fail(HILO_EINVAL, "K + sn2 I is not positive definite (pivot %d); the reference adds no jitter "
-                             "(inference.py:206)", (int)res[1]);
-  }
-  gp->lml = res[0];
+  rc = gp_factorize(gp);
+  if (rc) { hilo_gp_destroy(gp); return rc; }
   *out = gp;
   return HILO_OK;
 }
@@ -487,6 +784,60 @@ extern "C" int hilo_gp_log_marginal_likelihood(hilo_gp* gp, double* lml_host) {
   return HILO_OK;
 }
 
+// New hyper-parameters on the same training data: only the kernel program and the noise variance are uploaded, every buffer
+// of the handle is reused (what `GaussianProcess.fit_model` calls per objective value; gp.py:660-697).  On HILO_ENOTPD the
+// handle keeps the programs of the failed trial point but no valid factorisation: refit again before predicting.
+extern "C" int hilo_gp_refit(hilo_gp* gp, const double* kprog_host, int klen, double noise_variance) {
+  HILO_REQUIRE(gp && kprog_host, "hilo_gp_refit: NULL argument");
+  HILO_REQUIRE(klen == gp->klen, "hilo_gp_refit: the kernel program changed its length (%d -> %d): the kernel structure is fixed, "
+                                 "only its hyper-parameters may change", gp->klen, klen);
+  HILO_REQUIRE(noise_variance >= 0.0, "hilo_gp_refit: negative noise variance");
+  int rc = check_prog(kprog_host, klen, false, gp->nf);
+  if (rc) return rc;
+  HILO_HIP_CHECK(hipSetDevice(gp->device));
+  memcpy(gp->h_kprog, kprog_host, sizeof(double) * klen);
+  HILO_HIP_CHECK(hipMemcpy(gp->kprog, kprog_host, sizeof(double) * klen, hipMemcpyHostToDevice));
+  gp->sn2 = noise_variance > 0.0 ? exp(2.0 * (log(noise_variance) / 2.0)) : 0.0;
+  return gp_factorize(gp);
+}
+
+// Gradient of the log marginal likelihood with respect to n_theta hyper-parameters at the handle's current point, by the
+// trace formula 1/2 tr((alpha alpha^T - K_y^-1) dK_y/dtheta_j) on the device.  For each theta_j the caller passes
+// the kernel programs at theta + h_j e_j and theta - h_j e_j ([n_theta][2][klen], host) and the noise variances there
+// ([n_theta][2], host): dK_y/dtheta_j is their central difference, evaluated element-wise next to the trace.
+extern "C" int hilo_gp_lml_gradient(hilo_gp* gp, int n_theta, const double* kprogs_pm_host, const double* noise_pm_host,
+                                    const double* h_host, double* grad_host) {
+  HILO_REQUIRE(gp && kprogs_pm_host && noise_pm_host && h_host && grad_host, "hilo_gp_lml_gradient: NULL argument");
+  HILO_REQUIRE(n_theta >= 1 && n_theta <= 64, "hilo_gp_lml_gradient: n_theta out of range");
+  HILO_HIP_CHECK(hipSetDevice(gp->device));
+  int rc = gp_ensure_linv(gp);
+  if (rc) return rc;
+  const int n = gp->n, klen = gp->klen;
+  for (int j = 0; j < 2 * n_theta; ++j)
+    if ((rc = check_prog(kprogs_pm_host + (size_t)j * klen, klen, false, gp->nf))) return rc;
+  double *d_progs = nullptr, *d_aux = nullptr, *d_A = nullptr;
+  double aux[3 * 64];
+  for (int j = 0; j < n_theta; ++j) {
+    HILO_REQUIRE(h_host[j] > 0.0, "hilo_gp_lml_gradient: step %d must be positive", j);
+    aux[j] = (noise_pm_host[2 * j] - noise_pm_host[2 * j + 1]) / (2.0 * h_host[j]);   // d sn2 / d theta_j
+    aux[64 + j] = 1.0 / (2.0 * h_host[j]);
+    aux[128 + j] = 0.0;
+  }
+  if ((rc = upload(&d_progs, kprogs_pm_host, (size_t)2 * n_theta * klen))) return rc;
+  if ((rc = upload(&d_aux, aux, 3 * 64))) { (void)hipFree(d_progs); return rc; }
+  if ((rc = upload(&d_A, nullptr, (size_t)n * n))) { (void)hipFree(d_progs); (void)hipFree(d_aux); return rc; }
+  hipLaunchKernelGGL(gp_amat_kernel, dim3((n * n + 255) / 256), dim3(256), 0, (hipStream_t)0, n, gp->alpha, gp->Linv, gp->lp, d_A);
+  int gx = (n * n + 255) / 256;
+  gx = gx > 64 ? 64 : gx;
+  hipLaunchKernelGGL(gp_grad_kernel, dim3(gx, n_theta), dim3(256), 0, (hipStream_t)0, n, gp->nf, klen, d_progs, d_aux, d_aux + 64, gp->X,
+                     d_A, d_aux + 128);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(grad_host, d_aux + 128, sizeof(double) * n_theta, hipMemcpyDeviceToHost);
+  (void)hipFree(d_progs); (void)hipFree(d_aux); (void)hipFree(d_A);
+  if (e != hipSuccess) return fail(HILO_EHIP, "hilo_gp_lml_gradient: %s", hipGetErrorString(e));
+  return HILO_OK;
+}
+
 extern "C" int hilo_gp_predict(hilo_gp* gp, int64_t m, const double* Xq, int noise_free, double* mean, double* var,
                                void* stream) {
   HILO_REQUIRE(gp, "hilo_gp_predict: NULL handle");
@@ -494,6 +845,45 @@ extern "C" int hilo_gp_predict(hilo_gp* gp, int64_t m, const double* Xq, int noi
   if (m == 0) return HILO_OK;
   HILO_REQUIRE(Xq && mean, "hilo_gp_predict: NULL argument");
   HILO_HIP_CHECK(hipSetDevice(gp->device));
+  if (var) {
+    int rcl = gp_ensure_linv(gp);   // L^-1 is built on first use after a (re)fit
+    if (rcl) return rcl;
+  }
+  const double sn2 = noise_free ? 0.0 : gp->sn2;
+  const int n_pad = (gp->n + 15) & ~15;
+  if (n_pad <= 256 && !getenv("HILO_GP_PREDICT_VALU") && !getenv("HILO_GP_PREDICT_LDS")) {
+    const size_t lds_r = (gp->klen + (size_t)(gp->nf + 1) * n_pad) * sizeof(double);
+    const unsigned grid = (unsigned)((m + 63) / 64);
+    switch (n_pad / 16) {
+#define R(NT) case NT: hipLaunchKernelGGL((gp_predict_reg_kernel<NT>), dim3(grid), dim3(256), lds_r, (hipStream_t)stream, gp->kprog, \
+                                         gp->klen, gp->mprog, gp->mlen, gp->nf, gp->n, gp->X, gp->alpha, gp->LinvS, sn2, m, Xq, \
+                                         mean, var); break;
+      R(1) R(2) R(3) R(4) R(5) R(6) R(7) R(8) R(9) R(10) R(11) R(12) R(13) R(14) R(15) R(16)
+#undef R
+    }
+    HILO_HIP_CHECK(hipGetLastError());
+    return HILO_OK;
+  }
+  // f64 MFMA path: the K* tile of Q = 16 W queries must fit the LDS next to the reduction scratch
+  int W = 4;
+  auto lds_of = [&](int w) { return ((size_t)(n_pad + 16) * (16 * w + 16) + 64 * w + gp->klen + (size_t)gp->nf * (n_pad + 16 * w)) * sizeof(double); };
+  while (W > 1 && lds_of(W) > 150 * 1024) W >>= 1;
+  const size_t lds_m = lds_of(W);
+  if (lds_m <= 150 * 1024 && !getenv("HILO_GP_PREDICT_VALU")) {
+    const unsigned grid = (unsigned)((m + 16 * W - 1) / (16 * W));
+#define LAUNCH_MFMA(WW)                                                                                                         \
+    {                                                                                                                           \
+      if (lds_m > 64 * 1024)                                                                                                    \
+        HILO_HIP_CHECK(hipFuncSetAttribute((const void*)gp_predict_mfma_kernel<WW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)lds_m));                                                                        \
+      hipLaunchKernelGGL((gp_predict_mfma_kernel<WW>), dim3(grid), dim3(64 * WW), lds_m, (hipStream_t)stream, gp->kprog,         \
+                         gp->klen, gp->mprog, gp->mlen, gp->nf, gp->n, gp->X, gp->alpha, gp->Linv, gp->lp, sn2, m, Xq, mean, var); \
+    }
+    if (W == 4) LAUNCH_MFMA(4) else if (W == 2) LAUNCH_MFMA(2) else LAUNCH_MFMA(1)
+#undef LAUNCH_MFMA
+    HILO_HIP_CHECK(hipGetLastError());
+    return HILO_OK;
+  }
   int Q = 32;
   while (Q > 1 && ((size_t)gp->n * Q + PRED_TPB) * sizeof(double) > 128 * 1024) Q >>= 1;
   const size_t lds = ((size_t)gp->n * Q + PRED_TPB) * sizeof(double);
@@ -502,7 +892,7 @@ extern "C" int hilo_gp_predict(hilo_gp* gp, int64_t m, const double* Xq, int noi
     HILO_HIP_CHECK(hipFuncSetAttribute((const void*)gp_predict_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = (unsigned)((m + Q - 1) / Q);
   hipLaunchKernelGGL(gp_predict_kernel, dim3(grid), dim3(PRED_TPB), lds, (hipStream_t)stream, gp->kprog, gp->klen,
-                     gp->mprog, gp->mlen, gp->nf, gp->n, gp->X, gp->alpha, gp->Linv, noise_free ? 0.0 : gp->sn2, m, Xq, Q,
+                     gp->mprog, gp->mlen, gp->nf, gp->n, gp->X, gp->alpha, gp->Linv, gp->lp, sn2, m, Xq, Q,
                      mean, var);
   HILO_HIP_CHECK(hipGetLastError());
   return HILO_OK;
@@ -518,7 +908,7 @@ extern "C" int hilo_gp_kernel_matrix(int device, int nf, const double* kprog_hos
   HILO_HIP_CHECK(hipSetDevice(device));
   double* dprog = nullptr;
   if ((rc = upload(&dprog, kprog_host, klen))) return rc;
-  hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((n2 + 255) / 256), (unsigned)n1), dim3(256), 0, (hipStream_t)stream, dprog,
+  hipLaunchKernelGGL(kmat_kernel, dim3((unsigned)((n2 + 255) / 256), (unsigned)(n1 < 32768 ? n1 : 32768)), dim3(256), 0, (hipStream_t)stream, dprog,
                      klen, nf, n1, X1, n2, X2, 0.0, K);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);

@@ -452,6 +452,28 @@ extern "C" int hilo_nmpc_set_fix_x0(hilo_nmpc* h, int fix_x0) {
   return HILO_OK;
 }
 
+// optimize(fix_x0=False, x0_lb=..., x0_ub=...) (mpc.py:803-807): own box of x_0 in original units; NULL pointers restore the
+// state box.  Host pointers [nx]; relaxed like every other bound.
+extern "C" int hilo_nmpc_set_x0_box(hilo_nmpc* h, const double* x0_lb_host, const double* x0_ub_host) {
+  HILO_REQUIRE(h, "hilo_nmpc_set_x0_box: NULL handle");
+  OcpConst& c = h->host;
+  const bool on = x0_lb_host || x0_ub_host;
+  if (!on && !(c.flags & 2)) return HILO_OK;
+  const double relax = 1e-8;
+  for (int i = 0; i < h->nx; ++i) {
+    double lb = x0_lb_host ? x0_lb_host[i] / c.sz[i] : -INFINITY, ub = x0_ub_host ? x0_ub_host[i] / c.sz[i] : INFINITY;
+    if (lb > -INFINITY) lb -= relax * fmax(1.0, fabs(lb));
+    if (ub < INFINITY) ub += relax * fmax(1.0, fabs(ub));
+    HILO_REQUIRE(lb < ub, "hilo_nmpc_set_x0_box: empty box for state %d", i);
+    c.x0lb[i] = lb; c.x0ub[i] = ub;
+  }
+  c.flags = on ? (c.flags | 2) : (c.flags & ~2);
+  HILO_HIP_CHECK(hipSetDevice(h->device));
+  HILO_HIP_CHECK(hipDeviceSynchronize());   // launches in flight still read the constants
+  HILO_HIP_CHECK(hipMemcpy(h->dev, &c, __builtin_offsetof(OcpConst, cost), hipMemcpyHostToDevice));
+  return HILO_OK;
+}
+
 extern "C" int hilo_nmpc_reset_warm_start(hilo_nmpc* h) {
   HILO_REQUIRE(h, "hilo_nmpc_reset_warm_start: NULL handle");
   h->warm_valid = 0;

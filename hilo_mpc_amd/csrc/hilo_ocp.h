@@ -45,6 +45,7 @@ struct OcpConst {
   int Nc, reserved0;   // control horizon (mpc.py:1629-1630: beyond it the last input is held); read by policies with NH > 0
   double dt;
   double lbz[OCP_MAXNZ], ubz[OCP_MAXNZ];  // relaxed bounds of a stage's (x,u) slots (scaled); +-inf if none
+  double x0lb[OCP_MAXNX], x0ub[OCP_MAXNX];  // flags bit 1: own box of x_0 (optimize(fix_x0=False, x0_lb=, x0_ub=), mpc.py:803-807)
   double sz[OCP_MAXNZ];                   // scaling of (x,u)
   // interior-point constants (IPOPT defaults)
   double tol, acceptable_tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, bound_frac, s_max,
@@ -272,9 +273,11 @@ struct Ocp {
     return m < pc.nc || (k == pc.N - 1 && m < pc.nc + pc.nc_term);
   }
   __device__ static double lb_of(const OcpConst& pc, int k, int i) {
+    if (k == 0 && (pc.flags & 2) && i < NX0) return pc.x0lb[i];
     return (k > 0 && ((pc.k0_only_mask >> i) & 1u)) ? -INFINITY : pc.lbz[i];
   }
   __device__ static double ub_of(const OcpConst& pc, int k, int i) {
+    if (k == 0 && (pc.flags & 2) && i < NX0) return pc.x0ub[i];
     return (k > 0 && ((pc.k0_only_mask >> i) & 1u)) ? INFINITY : pc.ubz[i];
   }
 

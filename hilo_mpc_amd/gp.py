@@ -51,6 +51,51 @@ class Kernel:
 
     def __init__(self, active_dims=None):
         self.active_dims = None if active_dims is None else [int(a) for a in np.atleast_1d(active_dims)]
+        if not hasattr(self, '_bounds'):
+            self._bounds = {}
+
+    def __init_subclass__(cls, **kw):
+        # every kernel constructor takes `bounds=`: record it after the constructor ran (the outermost class's wins)
+        super().__init_subclass__(**kw)
+        orig = cls.__dict__.get('__init__')
+        if orig is None:
+            return
+        import functools
+        import inspect
+        sig = inspect.signature(orig)
+        if 'bounds' not in sig.parameters:
+            return
+
+        @functools.wraps(orig)
+        def init(self, *a, **k):
+            orig(self, *a, **k)
+            self._set_bounds(sig.bind(self, *a, **k).arguments.get('bounds'))
+        cls.__init__ = init
+
+    def _set_bounds(self, bounds):
+        """`bounds={'signal_variance': 'fixed', 'length_scales': (1e-2, 1e2)}` (util/machine_learning.py:283-334): 'fixed'
+        keeps the hyper-parameter out of `fit_model`, a number is a lower bound, a pair a box (on the value)."""
+        self._bounds = {}
+        for k, b in dict(bounds or {}).items():
+            if k not in self._hyper:
+                raise KeyError(f"'{k}' is not a hyper-parameter of the {self.acronym} kernel ({list(self._hyper)})")
+            if isinstance(b, str):
+                if b != 'fixed':
+                    raise ValueError(f"Unsupported bounds '{b}'")
+                self._bounds[k] = 'fixed'
+            elif isinstance(b, (int, float)):
+                self._bounds[k] = (float(b), np.inf)
+            else:
+                b = tuple(float(v) for v in b)
+                if len(b) == 1:
+                    b = (b[0], np.inf)
+                if len(b) != 2 or not b[0] < b[1]:
+                    raise ValueError("Lower bound not smaller than upper bound!")
+                self._bounds[k] = b
+
+    def hyperparameter_bounds(self):
+        """One entry per scalar hyper-parameter, parallel to `hyperparameter_handles()`: 'fixed', (lb, ub) or None."""
+        return [self._bounds.get(a) for _, a, _ in Kernel.hyperparameter_handles(self)]
 
     # ---- composition (kernel.py:276-296) ----
     def __add__(self, other):
@@ -114,47 +159,47 @@ class Kernel:
     # ---- factories (kernel.py:228-435) ----
     @staticmethod
     def constant(bias=1., bounds=None):
-        return ConstantKernel(bias=bias)
+        return ConstantKernel(bias=bias, bounds=bounds)
 
     @staticmethod
     def squared_exponential(active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
-        return SquaredExponentialKernel(active_dims, signal_variance, length_scales, ard)
+        return SquaredExponentialKernel(active_dims, signal_variance, length_scales, ard, bounds=bounds)
 
     @staticmethod
     def exponential(active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
-        return ExponentialKernel(active_dims, signal_variance, length_scales, ard)
+        return ExponentialKernel(active_dims, signal_variance, length_scales, ard, bounds=bounds)
 
     @staticmethod
     def matern_32(active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
-        return Matern32Kernel(active_dims, signal_variance, length_scales, ard)
+        return Matern32Kernel(active_dims, signal_variance, length_scales, ard, bounds=bounds)
 
     @staticmethod
     def matern_52(active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
-        return Matern52Kernel(active_dims, signal_variance, length_scales, ard)
+        return Matern52Kernel(active_dims, signal_variance, length_scales, ard, bounds=bounds)
 
     @staticmethod
     def rational_quadratic(active_dims=None, signal_variance=1., length_scales=1., alpha=1., ard=False, bounds=None):
-        return RationalQuadraticKernel(active_dims, signal_variance, length_scales, alpha, ard)
+        return RationalQuadraticKernel(active_dims, signal_variance, length_scales, alpha, ard, bounds=bounds)
 
     @staticmethod
     def piecewise_polynomial(degree, active_dims=None, signal_variance=1., length_scales=1., ard=False, bounds=None):
-        return PiecewisePolynomialKernel(degree, active_dims, signal_variance, length_scales, ard)
+        return PiecewisePolynomialKernel(degree, active_dims, signal_variance, length_scales, ard, bounds=bounds)
 
     @staticmethod
     def polynomial(degree, active_dims=None, signal_variance=1., offset=1., bounds=None):
-        return PolynomialKernel(degree, active_dims, signal_variance, offset)
+        return PolynomialKernel(degree, active_dims, signal_variance, offset, bounds=bounds)
 
     @staticmethod
     def linear(active_dims=None, signal_variance=1., bounds=None):
-        return LinearKernel(active_dims, signal_variance)
+        return LinearKernel(active_dims, signal_variance, bounds=bounds)
 
     @staticmethod
     def neural_network(active_dims=None, signal_variance=1., weight_variance=1., bounds=None):
-        return NeuralNetworkKernel(active_dims, signal_variance, weight_variance)
+        return NeuralNetworkKernel(active_dims, signal_variance, weight_variance, bounds=bounds)
 
     @staticmethod
     def periodic(active_dims=None, signal_variance=1., length_scales=1., period=1., bounds=None):
-        return PeriodicKernel(active_dims, signal_variance, length_scales, period)
+        return PeriodicKernel(active_dims, signal_variance, length_scales, period, bounds=bounds)
 
 
 class ConstantKernel(Kernel):
@@ -413,6 +458,10 @@ class KernelOperator(Kernel):
         if isinstance(self.kernel_2, Kernel):
             out += self.kernel_2.hyperparameter_handles()
         return out
+
+    def hyperparameter_bounds(self):
+        out = self.kernel_1.hyperparameter_bounds() if isinstance(self.kernel_1, Kernel) else []
+        return out + (self.kernel_2.hyperparameter_bounds() if isinstance(self.kernel_2, Kernel) else [])
 
     @property
     def hyperparameter_names(self):
@@ -759,40 +808,117 @@ class GaussianProcess:
 
     def fit_model(self, gtol=1e-8, maxiter=500):
         """Optimises the hyper-parameters by minimising the negative log marginal likelihood over their logarithms
-        (gp.py:660-697; kernel.py:127-130).  Every objective value is one device factorisation (`hilo_gp_create`) and
-        `hilo_gp_log_marginal_likelihood`; the gradient is taken by central differences of those values (quasi-Newton BFGS
-        on the host - the reference hands the same objective to its NLP solver).  Hyper-parameters of the mean function stay
+        (gp.py:660-697; kernel.py:127-130).  Every objective value is one device factorisation into the handle's buffers
+        (`hilo_gp_refit`), the gradient is the device trace formula 1/2 tr((alpha alpha^T - K^-1) dK/dtheta)
+        (`hilo_gp_lml_gradient`, one factorisation for all hyper-parameters); quasi-Newton BFGS on the host - the reference
+        hands the same objective to its NLP solver.  An indefinite trial point is +inf, never an exception; the object always
+        ends on a factorised set of hyper-parameters.  Hyper-parameters of the mean function stay
         fixed.  Warns, like the reference, when the optimiser does not reach a stationary point."""
         if self._handle is None:
             raise RuntimeError("The GP has not been set up yet. Please run the setup() method before fitting.")
         import warnings
         from scipy.optimize import minimize
         dev_index = self._dev.index
-        th0 = np.log(np.asarray(self.hyperparameter_values, dtype=float))
-        if not np.all(np.isfinite(th0)):
+        th_all = np.log(np.asarray(self.hyperparameter_values, dtype=float))
+        if not np.all(np.isfinite(th_all)):
             raise ValueError("Hyper-parameters must be positive to be fitted in log space")
+        # bounds of util/machine_learning.py:283-334: 'fixed' hyper-parameters stay out of the optimisation, numeric bounds box
+        # the (log) variable; the noise variance is always free
+        bnd = [None] + list(self.kernel.hyperparameter_bounds())
+        free = [i for i, b in enumerate(bnd) if b != 'fixed']
+        box = [(None if (bnd[i] is None or not bnd[i][0] > 0) else float(np.log(bnd[i][0])),
+                None if (bnd[i] is None or not np.isfinite(bnd[i][1])) else float(np.log(bnd[i][1]))) for i in free]
+        boxed = any(lo is not None or hi is not None for lo, hi in box)
+        set_all = self._set_hyperparameters
+
+        def set_free(values):
+            full = np.exp(th_all)
+            full[free] = values
+            set_all(full)
+        self._set_hyperparameters = set_free            # the closures below only see the free ones
+        th0 = th_all[free]
+
+        lib = _lib.lib()
+        nf = self._X_train.shape[0]
+        h_step = 1e-5
+
+        def program_at(th):
+            self._set_hyperparameters(np.exp(th))
+            return np.ascontiguousarray(self.kernel.program(nf), dtype=np.float64), float(self.noise_variance)
+
+        state = {'th': None, 'ok': False}
+
+        def refit(th):
+            """One device factorisation into the handle's buffers (hilo_gp_refit); False at an indefinite trial point."""
+            kp, nv = program_at(th)
+            try:
+                _lib.check(lib.hilo_gp_refit(self._handle, kp.ctypes.data, kp.size, nv))
+                state['th'], state['ok'] = np.array(th), True
+            except (_lib.NotPositiveDefinite, ValueError):
+                state['th'], state['ok'] = np.array(th), False
+            return state['ok']
 
         def f(th):
-            self._set_hyperparameters(np.exp(th))
-            try:
-                self.setup(device_index=dev_index)
-                v = -self.log_marginal_likelihood()
-            except _lib.HiloError:              # covariance matrix not positive definite at this trial point
+            if not refit(th):
                 return np.inf
+            v = -self.log_marginal_likelihood()
             return v if np.isfinite(v) else np.inf
 
-        def g(th, h=1e-6):
-            out = np.zeros_like(th)
+        def g(th):
+            """-(d LML / d theta) by the device trace formula (hilo_gp_lml_gradient) + the hyper-priors' part by central
+            differences of their closed-form log densities."""
+            if state['th'] is None or not np.array_equal(state['th'], th):
+                refit(th)
+            if not state['ok']:
+                return np.zeros_like(th)
+            progs, noise = [], []
             for i in range(th.size):
-                e = np.zeros_like(th)
-                e[i] = h
-                out[i] = (f(th + e) - f(th - e)) / (2 * h)
-            return out
-        res = minimize(f, th0, jac=g, method='BFGS', options={'gtol': gtol, 'maxiter': maxiter})
-        gn = float(np.max(np.abs(g(res.x))))
+                for sgn in (1., -1.):
+                    e = np.zeros_like(th)
+                    e[i] = sgn * h_step
+                    kp, nv = program_at(th + e)
+                    progs.append(kp)
+                    noise.append(nv)
+            self._set_hyperparameters(np.exp(th))
+            progs = np.ascontiguousarray(np.stack(progs))
+            noise = np.ascontiguousarray(np.array(noise))
+            hh = np.full(th.size, h_step)
+            out = np.zeros(th.size)
+            _lib.check(lib.hilo_gp_lml_gradient(self._handle, th.size, progs.ctypes.data, noise.ctypes.data, hh.ctypes.data,
+                                                out.ctypes.data))
+            if getattr(self, '_priors', None):
+                for i in range(th.size):
+                    e = np.zeros_like(th)
+                    e[i] = h_step
+                    self._set_hyperparameters(np.exp(th + e))
+                    lp = self._log_hyperprior()
+                    self._set_hyperparameters(np.exp(th - e))
+                    out[i] += (lp - self._log_hyperprior()) / (2 * h_step)
+                self._set_hyperparameters(np.exp(th))
+            return -out
+        good = th0.copy()
+        try:
+            if boxed:
+                res = minimize(f, th0, jac=g, method='L-BFGS-B', bounds=box, options={'gtol': gtol, 'ftol': 1e-15, 'maxiter': maxiter})
+            else:
+                res = minimize(f, th0, jac=g, method='BFGS', options={'gtol': gtol, 'maxiter': maxiter})
+            good = res.x
+        finally:
+            # whatever happened inside the optimiser: the object ends on a consistent, factorised set of hyper-parameters
+            self._set_hyperparameters(np.exp(good))
+            self.setup(device_index=dev_index)
+            del self._set_hyperparameters                # back to the class's setter of all hyper-parameters
+        self._set_hyperparameters = set_free
+        gr = g(res.x)
+        del self._set_hyperparameters
+        if boxed:                                        # projected gradient: a bound that is active does not count
+            for i, (lo, hi) in enumerate(box):
+                if (lo is not None and res.x[i] <= lo + 1e-12 and gr[i] > 0) or (hi is not None and res.x[i] >= hi - 1e-12 and gr[i] < 0):
+                    gr[i] = 0.
+        gn = float(np.max(np.abs(gr))) if gr.size else 0.
         self._optimization_stats = {'success': bool(res.success or gn < 1e-4), 'message': str(res.message),
                                     'iter_count': int(res.nit), 'max_gradient': gn, 'fun': float(res.fun)}
-        self._set_hyperparameters(np.exp(res.x))
+        set_free(np.exp(res.x))
         self.setup(device_index=dev_index)
         if not self._optimization_stats['success']:
             warnings.warn(f"Fitting of GP didn't terminate successfully\nSolver message: {res.message}\n"

@@ -710,11 +710,17 @@ class NMPC:
         if not self._nlp_setup_done:
             raise ValueError("Howdy! You need to setup the MPC before optimizing. Run .setup() on the MPC object.")
         if runs != 0:
-            raise NotImplementedError("multi-start (runs > 0) uses unseeded random perturbations in the reference "
-                                      "(mpc.py:740) and is not offloaded")
+            return self._multi_start(x0, cp, tvp, v0, int(runs), fix_x0, kwargs)
+        box = None
         if not fix_x0 and (kwargs.get('x0_lb') is not None or kwargs.get('x0_ub') is not None):
-            raise NotImplementedError("fix_x0=False with a separate box x0_lb / x0_ub (mpc.py:803-804) is not offloaded; "
-                                      "x_0 is free inside [x_lb, x_ub]")
+            # mpc.py:803-807: x_0 is a variable inside its own box instead of the state box
+            box = [None if kwargs.get(k) is None else np.ascontiguousarray(_wrap_list(kwargs[k]), dtype=np.float64)
+                   for k in ('x0_lb', 'x0_ub')]
+            for b in box:
+                if b is not None and b.size != self._n_x:
+                    raise ValueError(f"x0_lb / x0_ub must have {self._n_x} entries")
+        _lib.check(_lib.lib().hilo_nmpc_set_x0_box(self._handle, *[None if (box is None or b is None) else b.ctypes.data
+                                                                    for b in (box or [None, None])]))
         _lib.check(_lib.lib().hilo_nmpc_set_fix_x0(self._handle, int(bool(fix_x0))))     # mpc.py:797-807
         if tvp is not None and not self._time_varying_parameters:
             raise ValueError("tvp values were passed but no parameter was declared time varying "
@@ -801,6 +807,82 @@ class NMPC:
             u = u0.cpu().numpy()
             return u.reshape(-1, 1) if single else u     # single instance: (nu x 1) like the reference's DM
         return u0[0] if single else u0
+
+    def _multi_start(self, x0, cp, tvp, v0, runs, fix_x0, kwargs):
+        """mpc.py:727-741: `runs` solves, the first from the given start, the following from `v0 (1 + (1 - 2 rand) pert_factor)`
+        clipped to the bounds; per instance the best objective among the solves that ended with status 1 or 2 is kept.  The
+        reference draws from the unseeded numpy generator; here `seed=` (default 0) makes the draws reproducible."""
+        pert = float(kwargs.get('pert_factor', 0.1))
+        gen = torch.Generator(device='cpu').manual_seed(int(kwargs.get('seed', 0)))
+        kw = {k: v for k, v in kwargs.items() if k not in ('pert_factor', 'seed')}
+        n_it, t_it = self._n_iterations, self._time
+        best = None
+        start = v0
+        for r in range(runs):
+            self._n_iterations, self._time = n_it, t_it               # one optimize() as far as the counters go
+            u = self.optimize(x0, cp=cp, tvp=tvp, v0=start, runs=0, fix_x0=fix_x0, **kw)
+            sol = self._nlp_solution
+            ok = (sol['status'] == 1) | (sol['status'] == 2)
+            if best is None:
+                best = {k: v.clone() for k, v in sol.items()}
+                best['u0'] = torch.as_tensor(np.asarray(u).reshape(len(ok), -1), device=self._dev) if not isinstance(u, torch.Tensor) else u.reshape(len(ok), -1).clone()
+                base = (to_dev(v0, self._dev).reshape(-1, self._n_v) if v0 is not None else self._guess_vector(len(ok))).clone()
+                best_ok = ok.clone()
+                take = torch.zeros_like(ok)
+            else:
+                take = ok & (~best_ok | (sol['f'] < best['f']))
+                un = torch.as_tensor(np.asarray(u).reshape(len(ok), -1), device=self._dev) if not isinstance(u, torch.Tensor) else u.reshape(len(ok), -1)
+                for k in sol:
+                    best[k][take] = sol[k][take]
+                best['u0'][take] = un[take]
+                best_ok |= ok
+            lb, ub = self._v_bounds()
+            rnd = torch.rand(base.shape, generator=gen, dtype=torch.float64).to(self._dev)
+            start = torch.minimum(torch.maximum(base + base * (1 - 2 * rnd) * pert, lb), ub)
+        u0 = best.pop('u0')
+        self._nlp_solution = best
+        host = not isinstance(x0, torch.Tensor)
+        single = u0.shape[0] == 1 and np.ndim(x0) <= 1
+        if host:
+            un = u0.cpu().numpy()
+            return un.reshape(-1, 1) if single else un
+        return u0[0] if single else u0
+
+    def _guess_vector(self, B):
+        """The tiled initial guess in the reference's v layout (mpc.py:1468-1482), scaled."""
+        N, Nc, nx, nu, nth = self._prediction_horizon, self._control_horizon, self._n_x, self._n_u, self._nth
+        xg = np.zeros(nx) if self._x_guess is None else np.asarray(self._x_guess) / self._sx
+        ug = np.zeros(nu) if self._u_guess is None else np.asarray(self._u_guess) / self._su
+        pv = self._paths_var_list[0] if nth else None
+        xa = np.concatenate([xg, [pv['theta_guess']] if nth else []])
+        ua = np.concatenate([ug, [pv['u_pf_lb'] + 0.0001] if nth else []])
+        v = np.zeros(self._n_v)
+        v[:(N + 1) * (nx + nth)] = np.tile(xa, N + 1)
+        v[(N + 1) * (nx + nth):(N + 1) * (nx + nth) + Nc * (nu + nth)] = np.tile(ua, Nc)
+        for ind in self._ip_ind:
+            v[ind] = np.tile(xa, len(ind) // (nx + nth))
+        return to_dev(np.tile(v, (B, 1)), self._dev)
+
+    def _v_bounds(self):
+        """lbx / ubx of the reference's solver call (mpc.py:722) as device vectors [n_v] (scaled)."""
+        N, Nc, nx, nu, nth = self._prediction_horizon, self._control_horizon, self._n_x, self._n_u, self._nth
+        inf = np.inf
+        xl = np.full(nx, -inf) if self._x_lb is None else np.asarray(self._x_lb) / self._sx
+        xu = np.full(nx, inf) if self._x_ub is None else np.asarray(self._x_ub) / self._sx
+        ul = np.full(nu, -inf) if self._u_lb is None else np.asarray(self._u_lb) / self._su
+        uu = np.full(nu, inf) if self._u_ub is None else np.asarray(self._u_ub) / self._su
+        pv = self._paths_var_list[0] if nth else None
+        xl, xu = np.concatenate([xl, [pv['theta_lb']] if nth else []]), np.concatenate([xu, [pv['theta_ub']] if nth else []])
+        ul, uu = np.concatenate([ul, [pv['u_pf_lb']] if nth else []]), np.concatenate([uu, [pv['u_pf_ub']] if nth else []])
+        lb, ub = np.full(self._n_v, -inf), np.full(self._n_v, inf)
+        nxa, nua = nx + nth, nu + nth
+        lb[:(N + 1) * nxa], ub[:(N + 1) * nxa] = np.tile(xl, N + 1), np.tile(xu, N + 1)
+        lb[(N + 1) * nxa:(N + 1) * nxa + Nc * nua], ub[(N + 1) * nxa:(N + 1) * nxa + Nc * nua] = np.tile(ul, Nc), np.tile(uu, Nc)
+        for ind in (self._e_soft_stage_ind, self._e_soft_term_ind):
+            lb[ind] = 0.
+        for ind in self._ip_ind:
+            lb[ind], ub[ind] = np.tile(xl, len(ind) // nxa), np.tile(xu, len(ind) // nxa)
+        return to_dev(lb, self._dev), to_dev(ub, self._dev)
 
     def _stage_table(self, cp, tvp, kwargs):
         """[(N+1), nz + np]: per stage [zref_k / scaling | p_k]; row N = terminal reference (first nx entries).

@@ -33,6 +33,7 @@ extern "C" {
 #define HILO_ENOMEM (-2)   /* device allocation failed */
 #define HILO_EHIP (-3)     /* HIP runtime error */
 #define HILO_ENOTSUP (-4)  /* combination not built into this library */
+#define HILO_ENOTPD (-5)   /* covariance matrix K + sn2 I not positive definite (the reference adds no jitter, inference.py:206) */
 
 /* model zoo ids (device functors in hilo_mpc_amd/csrc/hilo_models.h) */
 #define HILO_MODEL_LTI 0         /* x+ = A x + B u, y = C x; p = [A|B|C] row-major (mpc.py:2198-2245 LMPC; KF) */
@@ -157,6 +158,16 @@ int hilo_gp_create(int device, int nf, int n,
                    hilo_gp** out);
 void hilo_gp_destroy(hilo_gp* gp);
 int hilo_gp_log_marginal_likelihood(hilo_gp* gp, double* lml_host);
+/* New hyper-parameters on the same training data (one objective value of `GaussianProcess.fit_model`, gp.py:660-697): uploads
+   the kernel program (same length: the kernel structure is fixed) and the noise variance, re-factorises into the handle's
+   buffers.  Returns HILO_ENOTPD at an indefinite trial point (the handle then needs another refit before it predicts). */
+int hilo_gp_refit(hilo_gp* gp, const double* kprog_host, int kprog_len, double noise_variance);
+/* Gradient of the log marginal likelihood (inference.py:210) at the handle's current hyper-parameters by the trace formula
+   1/2 tr((alpha alpha^T - K_y^-1) dK_y/dtheta_j) on the device, one factorisation for all j.  Per theta_j the
+   caller passes the kernel programs and noise variances at theta +- h_j e_j (HOST: [n_theta][2][kprog_len], [n_theta][2],
+   [n_theta]); dK_y/dtheta_j is their central difference, evaluated element-wise inside the trace kernel. */
+int hilo_gp_lml_gradient(hilo_gp* gp, int n_theta, const double* kprogs_pm_host, const double* noise_pm_host,
+                         const double* h_host, double* grad_host);
 /* gp.py:699-718.  Xq feature-major [nf][m]; mean/var [m]; var may be NULL (mean only). */
 int hilo_gp_predict(hilo_gp* gp, int64_t m, const double* Xq, int noise_free, double* mean, double* var,
                     void* stream);
@@ -307,6 +318,9 @@ int hilo_nmpc_reset_warm_start(hilo_nmpc* h);
    box [x_lb, x_ub] (the `x0` argument of hilo_nmpc_solve is then ignored, the start value comes from the warm start / guess).
    Synchronises the device when the setting changes. */
 int hilo_nmpc_set_fix_x0(hilo_nmpc* h, int fix_x0);
+/* optimize(fix_x0=False, x0_lb=..., x0_ub=...) of mpc.py:803-807: an own box for x_0 (HOST pointers [nx], original units;
+   NULL / NULL restores the state box).  Synchronises the device when the setting changes. */
+int hilo_nmpc_set_x0_box(hilo_nmpc* h, const double* x0_lb_host, const double* x0_ub_host);
 /* One optimize() for `batch` independent instances (mpc.py:744-857).
    v layout = the reference's decision vector [x_0..x_N | u_0..u_{N-1}] in scaled variables (mpc.py:1462-1485). */
 int hilo_nmpc_solve(hilo_nmpc* h, int64_t batch,

@@ -262,19 +262,19 @@ class DenseIpm:
     """Solves min f(w) s.t. c(w) = 0, l <= w <= u for a batch of NMPC instances.
 
     Free variables w = [x_1..x_N | u_0..u_{N-1}] (x_0 is fixed by its bounds, mpc.py:797-802, and removed like
-    IPOPT's default `fixed_variable_treatment = make_parameter`).  Requires Nc == N."""
+    IPOPT's default `fixed_variable_treatment = make_parameter`).  A control horizon Nc < N holds Nc input blocks; stage
+    k >= Nc uses the last one (mpc.py:1629-1630)."""
 
     def __init__(self, prob: NmpcProblem, options: IpmOptions | None = None):
-        assert prob.Nc == prob.N, "oracle IPM: control horizon must equal the prediction horizon"
         self.pb = prob
         self.o = options or IpmOptions()
-        N, nx, nu = prob.N, prob.nx, prob.nu
-        self.nw = N * (nx + nu)
+        N, nx, nu, Nc = prob.N, prob.nx, prob.nu, prob.Nc
+        self.nw = N * nx + Nc * nu
         self.m = N * nx
         self.ix = [list(range(k * nx, (k + 1) * nx)) for k in range(N)]            # x_{k+1}
-        self.iu = [list(range(N * nx + k * nu, N * nx + (k + 1) * nu)) for k in range(N)]
-        lb = np.concatenate([np.tile(prob.x_lb, N), np.tile(prob.u_lb, N)])
-        ub = np.concatenate([np.tile(prob.x_ub, N), np.tile(prob.u_ub, N)])
+        self.iu = [list(range(N * nx + min(k, Nc - 1) * nu, N * nx + (min(k, Nc - 1) + 1) * nu)) for k in range(N)]
+        lb = np.concatenate([np.tile(prob.x_lb, N), np.tile(prob.u_lb, Nc)])
+        ub = np.concatenate([np.tile(prob.x_ub, N), np.tile(prob.u_ub, Nc)])
         r = self.o.bound_relax_factor
         self.lb = np.where(np.isfinite(lb), lb - r * np.maximum(1, np.abs(lb)), lb)
         self.ub = np.where(np.isfinite(ub), ub + r * np.maximum(1, np.abs(ub)), ub)
@@ -285,7 +285,8 @@ class DenseIpm:
         pb = self.pb
         B = w.shape[0]
         X = np.concatenate([x0[:, None, :], w[:, :pb.N * pb.nx].reshape(B, pb.N, pb.nx)], axis=1)
-        U = w[:, pb.N * pb.nx:].reshape(B, pb.N, pb.nu)
+        Uc = w[:, pb.N * pb.nx:].reshape(B, pb.Nc, pb.nu)
+        U = Uc[:, np.minimum(np.arange(pb.N), pb.Nc - 1)]      # per stage: the held input beyond the control horizon
         return X, U
 
     def eval_fc(self, w, data):
@@ -342,7 +343,7 @@ class DenseIpm:
             g[:, zi] += gz[:, sel]
             W[np.ix_(range(B), zi, zi)] += Hz[np.ix_(range(B), sel, sel)]
             rows = list(range(k * nx, (k + 1) * nx))
-            J[np.ix_(range(B), rows, zi)] = -Jk[:, :, sel]
+            J[np.ix_(range(B), rows, zi)] += -Jk[:, :, sel]
             J[:, rows, self.ix[k]] = 1.0
         d = X[:, N] - (pb.xrefN if xrN is None else xrN)
         f += np.einsum('bi,ij,bj->b', d, pb.WN, d)
@@ -387,7 +388,7 @@ class DenseIpm:
         if u_old is not None:
             u_old = np.broadcast_to(np.atleast_2d(np.asarray(u_old, dtype=float)), (B, pb.nu))
         if w0 is None:
-            w0 = np.concatenate([np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N)])
+            w0 = np.concatenate([np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.Nc)])
         data = {'x0': x0, 'p': p}
         if u_old is not None:
             data['u_old'] = u_old
@@ -652,7 +653,7 @@ class DenseIpm:
 
     # ---- reference layout helpers -----------------------------------------------------------------------------
     def to_v(self, res):
-        return self.pb.join(res['X'], res['U'])
+        return self.pb.join(res['X'], res['U'][:, :self.pb.Nc])
 
     def w_from_v(self, v):
         X, U = self.pb.split(v)

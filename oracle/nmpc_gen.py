@@ -214,7 +214,8 @@ class GenIpm(DenseIpm):
     """Free variables w = [x_0 (only with free_x0) | theta_0 | xa_1..xa_N | ua_0..ua_{N-1} | e | s_0..s_{N-1}].
     free_x0: optimize(fix_x0=False) of mpc.py:797-807 - the measured state is not imposed, x_0 lives in the state box."""
 
-    def __init__(self, prob: GenNmpcProblem, options: IpmOptions | None = None, free_x0=False):
+    def __init__(self, prob: GenNmpcProblem, options: IpmOptions | None = None, free_x0=False, x0_box=None):
+        """x0_box = (lb, ub) in original units: the own box of x_0 of optimize(fix_x0=False, x0_lb=, x0_ub=) (mpc.py:803-807)."""
         self.pb = pb = prob
         self.o = o = options or IpmOptions()
         N, nxa, nua, nth, ne, nrow = pb.N, pb.nxa, pb.nua, pb.nth, pb.ne, pb.nrow
@@ -232,6 +233,11 @@ class GenIpm(DenseIpm):
         ub = np.concatenate([pb.x_ub[pb.nx - self.n0:], np.tile(pb.x_ub, N), np.tile(pb.u_ub, N),
                              pb.e_ub if ne else np.zeros(0), pb.eT_ub if pb.ne_t else np.zeros(0), np.tile(pb.dub, N),
                              pb.tub if pb.nt else np.zeros(0)])
+        if x0_box is not None:
+            assert free_x0
+            lb, ub = lb.copy(), ub.copy()
+            lb[:pb.nx] = np.asarray(x0_box[0], dtype=float) / pb.sx
+            ub[:pb.nx] = np.asarray(x0_box[1], dtype=float) / pb.sx
         r = o.bound_relax_factor
         self.lb = np.where(np.isfinite(lb), lb - r * np.maximum(1, np.abs(lb)), lb)
         self.ub = np.where(np.isfinite(ub), ub + r * np.maximum(1, np.abs(ub)), ub)

@@ -174,8 +174,19 @@ def test_free_initial_state_vs_oracle():
     u2 = nmpc2.optimize(x0, cp=C2['p'])                                     # fix_x0=True again, cold start
     assert np.array_equal(nmpc2.solver_status_code, fixed['status'])
     np.testing.assert_allclose(u2, fixed['u0'], rtol=5e-5, atol=5e-5)
-    with pytest.raises(NotImplementedError):
-        nmpc.optimize(x0, cp=C2['p'], fix_x0=False, x0_lb=[0., 0., 0., 0.])
+    # own box for x_0 (optimize(fix_x0=False, x0_lb=, x0_ub=), mpc.py:803-807), then back to the state box on the same handle
+    box = ([2., 20., 0., 1.], [3., 35., 2., 8.])
+    refb = GenIpm(pb, free_x0=True, x0_box=box).solve(x0, C2['p'])
+    assert np.all(refb['status'] == 1)
+    nmpc._nlp_options['warm_start'] = False
+    ub_ = nmpc.optimize(x0, cp=C2['p'], fix_x0=False, x0_lb=box[0], x0_ub=box[1])
+    vb = nmpc._nlp_solution['x'].cpu().numpy()
+    assert np.array_equal(nmpc.solver_status_code, refb['status'])
+    assert np.max(np.abs(vb - ipm.to_v(refb)) / np.maximum(1., np.abs(ipm.to_v(refb)))) < 5e-5
+    np.testing.assert_allclose(ub_, refb['u0'], rtol=5e-5, atol=5e-5)
+    assert np.all(vb[:, :4] >= np.array(box[0]) - 1e-6) and np.all(vb[:, :4] <= np.array(box[1]) + 1e-6)
+    u3 = nmpc.optimize(x0, cp=C2['p'], fix_x0=False)
+    np.testing.assert_allclose(u3, ref['u0'], rtol=5e-5, atol=5e-5)
 
 
 def test_soft_terminal_constraint_vs_oracle():

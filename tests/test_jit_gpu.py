@@ -168,3 +168,39 @@ def test_no_precompiled_variant_falls_back_to_runtime_compilation():
     assert np.array_equal(nmpc.solver_status_code, ref['status'])
     np.testing.assert_allclose(u, ref['u0'], rtol=5e-5, atol=1e-6)
     np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-8)
+
+
+@pytest.mark.parametrize('Nc', [1, 3, 7])
+def test_control_horizon_shorter_than_prediction_horizon(Nc):
+    """mpc.py:1476-1485, :1629-1630: Nc input blocks in v, the last one held over the rest of the horizon.  On the device the
+    held input is a state of the engine that stages k >= Nc read; oracle: the same NLP with Nc input blocks."""
+    from oracle.nmpc import DenseIpm
+    from tests.problems import oracle_problem
+    spec = dict(C2, N=8, Nc=Nc, input_change=([0, 1], [.5, .5]))
+    pb = oracle_problem(spec)
+    ipm = DenseIpm(pb)
+    x0 = c2_x0(6)
+    u_old = np.tile([.1, .05], (6, 1))
+    ref = ipm.solve(x0, spec['p'], u_old=u_old)
+    assert np.all(ref['status'] == 1)
+    nmpc = product_nmpc(spec)
+    assert nmpc._jit and nmpc.control_horizon == Nc and nmpc.prediction_horizon == 8
+    assert (nmpc._n_v, nmpc._n_g) == (pb.n_v, pb.n_g) == (9 * 4 + Nc * 2, 8 * 4)
+    assert nmpc._x_ind == pb.x_ind and nmpc._u_ind == pb.u_ind
+    u = nmpc.optimize(x0, cp=spec['p'], u_old=u_old)
+    assert np.array_equal(nmpc.solver_status_code, ref['status'])
+    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), ipm.to_v(ref)
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 5e-5
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-8)
+    np.testing.assert_allclose(u, ref['u0'], rtol=5e-5, atol=1e-6)
+    lam = ref['lam'].copy()
+    lam[:, -4:] += 2 * (ref['X'][:, -1] - pb.xrefN) @ pb.WN               # terminal cost on Phi_{N-1} (mpc.py:1682)
+    np.testing.assert_allclose(nmpc._nlp_solution['lam_g'].cpu().numpy(), lam, rtol=2e-4, atol=2e-5)
+    xp, up, _ = nmpc.return_prediction()
+    assert xp.shape == (6, 4, 9) and up.shape == (6, 2, Nc)
+    # warm-started second solve from the returned vector (un-shifted, mpc.py:725-726)
+    x1 = nmpc.plant_step(x0, u, cp=spec['p']).cpu().numpy()
+    ref2 = ipm.solve(x1, spec['p'], w0=ref['w'], u_old=ref['U'][:, 0])
+    u2 = nmpc.optimize(x1, cp=spec['p'])
+    assert np.array_equal(nmpc.solver_status_code, ref2['status'])
+    np.testing.assert_allclose(u2, ref2['u0'], rtol=5e-5, atol=1e-6)

@@ -63,3 +63,25 @@ def test_input_change_term_and_pendulum():
     f_with = pb.objective(v, np.zeros((1, 0)), u_old=np.array([[.3]]))[0]
     f_without = pb.objective(v, np.zeros((1, 0)))[0]
     np.testing.assert_allclose(f_with - f_without, (v[pb.u_ind[0][0]] - .3) ** 2, rtol=1e-10)
+
+
+def test_control_horizon_shorter_than_prediction_horizon_vs_slsqp():
+    """mpc.py:1476-1485, :1629-1630 (Nc input blocks, the last held): the interior-point solution of the Nc < N problem
+    against scipy SLSQP on the reference-layout NLP functions."""
+    from scipy.optimize import minimize
+    from tests.problems import C2, c2_x0, oracle_problem
+    spec = dict(C2, N=8, Nc=3)
+    pb = oracle_problem(spec)
+    assert pb.n_v == 9 * 4 + 3 * 2 and len(pb.u_ind) == 3
+    ipm = DenseIpm(pb)
+    x0 = c2_x0(2)
+    r = ipm.solve(x0, spec['p'])
+    assert np.all(r['status'] == 1)
+    v = ipm.to_v(r)
+    p = np.array(spec['p'])
+    lb, ub = pb.v_lb.copy(), pb.v_ub.copy()
+    lb[:4] = ub[:4] = x0[0] / pb.sx
+    res = minimize(lambda q: pb.objective(q[None], p[None])[0], v[0] + 1e-3,
+                   constraints={'type': 'eq', 'fun': lambda q: pb.constraints(q[None], p[None])[0]},
+                   bounds=list(zip(lb, ub)), method='SLSQP', options={'ftol': 1e-14, 'maxiter': 500})
+    assert res.success and abs(res.fun - r['f'][0]) < 1e-6 * abs(r['f'][0]) and np.abs(res.x - v[0]).max() < 1e-4
