@@ -150,6 +150,7 @@ def wl_nmpc(cfg, args, torch, dev, rank, world):
     x = torch.as_tensor(x0, device=dev)
     p = torch.as_tensor(np.asarray(spec['p'], dtype=np.float64), device=dev) if len(spec['p']) else None
     gather = StepGather(gB if cfg != 'C2' else B * world, nmpc._n_u, rank, world, dev)
+    gather.attach(nmpc)            # plain tracking problems: the solve writes the gather rows itself
     ev, log = [], []
 
     def step(timed):

@@ -89,6 +89,7 @@ def _declare(lib):
         'hilo_nmpc_reset_warm_start': (C.c_int, [vp]),
         'hilo_nmpc_set_fix_x0': (C.c_int, [vp, i32]),
         'hilo_nmpc_set_x0_box': (C.c_int, [vp, vp, vp]),
+        'hilo_nmpc_set_gather': (C.c_int, [vp, vp, i32]),
         'hilo_nmpc_solve': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_nmpc_solve_tv': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_nmpc_profile': (C.c_int, [vp, i32, vp]),

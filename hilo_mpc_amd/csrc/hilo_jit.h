@@ -13,6 +13,7 @@
 namespace hilo {
 
 struct OcpConst;
+struct OcpExtra;
 
 enum JitPolicy : int {
   JIT_TRACK = 0,   // NmpcTrack<UserModel, BIG>          (hilo_nmpc_track.h) - identical code path to the zoo models
@@ -39,7 +40,7 @@ int jit_nmpc_kernels(const JitRequest& r, int device, JitKernels* out);
 int jit_launch_solve(hipFunction_t f, const OcpConst* dev, int64_t batch, const double* x0, const double* par, int64_t par_stride,
                      const double* sdata, int64_t sd_stride, const double* v0, int64_t v0_stride, double* v_opt, double* f_opt,
                      double* lam_g, double* first, int32_t* status, int32_t* iters, double* kkt, long long* prof, double* ws,
-                     hipStream_t s);
+                     hipStream_t s, OcpExtra ex);
 int jit_launch_plant(hipFunction_t f, const OcpConst* dev, int64_t batch, const double* x, const double* u, const double* par,
                      int64_t par_stride, double* xn, hipStream_t s);
 int jit_launch_coll_out(hipFunction_t f, const OcpConst* dev, int64_t batch, int N, const double* vc, const double* lamc,

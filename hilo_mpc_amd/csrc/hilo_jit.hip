@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "hilo_jit.h"
+#include "hilo_ocp.h"
 
 namespace hilo {
 
@@ -108,10 +109,10 @@ void hilo_user_solve(const OcpConst* __restrict__ pcg, int64_t batch, const doub
                      int64_t par_stride, const double* __restrict__ sdata, int64_t sd_stride, const double* __restrict__ v0,
                      int64_t v0_stride, double* __restrict__ v_opt, double* __restrict__ f_opt, double* __restrict__ lam_g,
                      double* __restrict__ first, int32_t* __restrict__ status, int32_t* __restrict__ iters, double* __restrict__ kkt,
-                     long long* __restrict__ prof, double* __restrict__ ws) {
+                     long long* __restrict__ prof, double* __restrict__ ws, const OcpExtra ex) {
   __shared__ double lds[USER_LDS];
   ocp_solve_body<PB, 64>((lds_double*)lds, pcg, batch, x0, par, par_stride, sdata, sd_stride, v0, v0_stride, 0, 0, v_opt, f_opt,
-                         lam_g, first, 0, status, iters, kkt, prof, ws);
+                         lam_g, first, 0, status, iters, kkt, prof, ws, ex);
 }
 
 extern "C" __global__ void hilo_user_plant(const OcpConst* __restrict__ pcg, int64_t batch, const double* __restrict__ x,
@@ -237,9 +238,9 @@ int jit_nmpc_kernels(const JitRequest& r, int device, JitKernels* out) {
 int jit_launch_solve(hipFunction_t f, const OcpConst* dev, int64_t batch, const double* x0, const double* par, int64_t par_stride,
                      const double* sdata, int64_t sd_stride, const double* v0, int64_t v0_stride, double* v_opt, double* f_opt,
                      double* lam_g, double* first, int32_t* status, int32_t* iters, double* kkt, long long* prof, double* ws,
-                     hipStream_t s) {
+                     hipStream_t s, OcpExtra ex) {
   void* args[] = {&dev, &batch, &x0, &par, &par_stride, &sdata, &sd_stride, &v0, &v0_stride, &v_opt, &f_opt, &lam_g, &first,
-                  &status, &iters, &kkt, &prof, &ws};
+                  &status, &iters, &kkt, &prof, &ws, &ex};
   HILO_HIP_CHECK(hipModuleLaunchKernel(f, (unsigned)batch, 1, 1, 64, 1, 1, 0, s, args, nullptr));
   return HILO_OK;
 }

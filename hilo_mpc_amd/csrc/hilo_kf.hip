@@ -10,7 +10,7 @@
 
 namespace hilo {
 
-constexpr int KF_TPB = 128;
+constexpr int KF_TPB = 64;   // one wave per workgroup
 
 struct KfParams {
   int kind, continuous, erk_order, n_sub;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(KF_TPB) void kf_kernel(KfParams kp, int64_t batch, 
                                                     int64_t up_stride, const double* __restrict__ Q,
                                                     int64_t q_stride, const double* __restrict__ R,
                                                     int64_t r_stride, double* __restrict__ out_tile,
-                                                    double* __restrict__ y_pred) {
+                                                    double* __restrict__ y_pred, int ipw) {
   constexpr int NX = M::NX, NY = M::NY, NUP = M::NU + M::NP, NS = 2 * NX + 1;
   constexpr int XP = NX * (NX + 1);                          // [x|P]
   constexpr int PRED = UKF ? NX * (1 + NX + NS) : XP;        // predict output / update input
@@ -330,8 +330,10 @@ __global__ __launch_bounds__(KF_TPB) void kf_kernel(KfParams kp, int64_t batch, 
   constexpr int BIG = IN_ROW > OUT_ROW ? IN_ROW : OUT_ROW;
   __shared__ double lds[KF_TPB * TilePitch<BIG>::value];
 
-  const int64_t first = (int64_t)blockIdx.x * KF_TPB;
-  const int count = (int)((batch - first) < KF_TPB ? (batch - first) : KF_TPB);
+  // `ipw` instances per workgroup (<= KF_TPB): a small batch is spread over all compute units (16 instances per wave at the
+  // BASELINE size 4096 -> 256 workgroups), a large one fills every lane
+  const int64_t first = (int64_t)blockIdx.x * ipw;
+  const int count = (int)((batch - first) < ipw ? (batch - first) : ipw);
   const int64_t inst = first + threadIdx.x;
   const bool active = (int)threadIdx.x < count;
 
@@ -392,9 +394,11 @@ int launch(const KfParams& kp, int64_t batch, const double* in, const double* y,
            int64_t up_stride, const double* Q, int64_t q_stride, const double* R, int64_t r_stride, double* out,
            double* y_pred, hipStream_t s) {
   if (batch == 0) return HILO_OK;
-  const unsigned grid = (unsigned)((batch + KF_TPB - 1) / KF_TPB);
+  int64_t ipw = (batch + 1023) / 1024;   // 256 compute units x 4 SIMDs
+  ipw = ipw < 16 ? 16 : (ipw > KF_TPB ? KF_TPB : ipw);
+  const unsigned grid = (unsigned)((batch + ipw - 1) / ipw);
   hipLaunchKernelGGL((kf_kernel<M, UKF, MODE>), dim3(grid), dim3(KF_TPB), 0, s, kp, batch, in, y, up, up_stride, Q,
-                     q_stride, R, r_stride, out, y_pred);
+                     q_stride, R, r_stride, out, y_pred, (int)ipw);
   HILO_HIP_CHECK(hipGetLastError());
   return HILO_OK;
 }

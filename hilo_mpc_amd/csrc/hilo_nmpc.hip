@@ -474,6 +474,24 @@ extern "C" int hilo_nmpc_set_x0_box(hilo_nmpc* h, const double* x0_lb_host, cons
   return HILO_OK;
 }
 
+static bool nmpc_is_direct(const hilo_nmpc* h) {
+  return !h->tv && !h->coll && !h->gen && !h->big && h->jit_coll_d == 0 && h->tv_width == 0 &&
+         (h->jit_policy < 0 || h->jit_ws_bytes == 0);
+}
+
+// Result gather of a sharded batch (hilo_mpc_amd/dist.py): the solve writes row b = [u0 (nu) | status | iterations] (fp64) of
+// `table` ([batch][stride], stride >= nu + 2, device) itself, so that the collective can start from it without a packing
+// kernel.  NULL switches it off.  Plain tracking problems only (the others ignore it).
+extern "C" int hilo_nmpc_set_gather(hilo_nmpc* h, double* table, int stride) {
+  HILO_REQUIRE(h, "hilo_nmpc_set_gather: NULL handle");
+  HILO_REQUIRE(!table || stride >= h->nu + 2, "hilo_nmpc_set_gather: stride %d < nu + 2", stride);
+  if (table && !nmpc_is_direct(h))
+    return fail(HILO_ENOTSUP, "hilo_nmpc_set_gather: this problem kind does not write the gather row itself; pack it on the host");
+  h->gather = table;
+  h->gather_stride = stride;
+  return HILO_OK;
+}
+
 extern "C" int hilo_nmpc_reset_warm_start(hilo_nmpc* h) {
   HILO_REQUIRE(h, "hilo_nmpc_reset_warm_start: NULL handle");
   h->warm_valid = 0;
@@ -494,14 +512,14 @@ __global__ void nmpc_pack_par_kernel(int64_t batch, int np, int nu, const double
 template <class M>
 static int nmpc_launch(hilo_nmpc* h, int64_t batch, const double* x0, const double* par, const double* v0, int64_t v0s,
                        double* v_opt, double* f_opt, double* lam_g, double* u0, int32_t* status, int32_t* iters,
-                       double* kkt, hipStream_t s) {
+                       double* kkt, hipStream_t s, int64_t par_stride, OcpExtra ex) {
   using PB = NmpcTrack<M>;
   if (h->lds_bytes > 64 * 1024)
     HILO_HIP_CHECK(hipFuncSetAttribute((const void*)ocp_solve_kernel<PB, OCP_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)h->lds_bytes));
   hipLaunchKernelGGL((ocp_solve_kernel<PB, OCP_TPB>), dim3((unsigned)batch), dim3(OCP_TPB), h->lds_bytes, s, h->dev, batch, x0, par,
-                     (int64_t)(h->np + h->nu), (const double*)nullptr, (int64_t)0, v0, v0s, 0, 0, v_opt, f_opt, lam_g, u0, 0,
-                     status, iters, kkt, h->prof);
+                     par_stride, (const double*)nullptr, (int64_t)0, v0, v0s, 0, 0, v_opt, f_opt, lam_g, u0, 0,
+                     status, iters, kkt, h->prof, (double*)nullptr, ex);
   HILO_HIP_CHECK(hipGetLastError());
   return HILO_OK;
 }
@@ -520,19 +538,42 @@ static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const 
   HILO_HIP_CHECK(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
   const int w = h->np + h->nu;
-  if (h->par_batch != batch) {
-    if (h->par_buf) HILO_HIP_CHECK(hipFree(h->par_buf));
-    h->par_buf = nullptr;
-    hipError_t e = hipMalloc((void**)&h->par_buf, sizeof(double) * (size_t)w * batch);
-    if (e != hipSuccess) return fail(HILO_ENOMEM, "parameter buffer: %s", hipGetErrorString(e));
-    h->par_batch = batch;
-  }
-  {
+  // Plain tracking problems (precompiled or run-time compiled, no collocation output pass) take the parameter row from the
+  // caller's arrays, write the warm-start copy and the gather row themselves: a step is ONE launch.  The other variants keep
+  // the packed [p | u_old] row and the device copy of the solution.
+  const bool direct = nmpc_is_direct(h);
+  if (direct) {
+    if (h->warm_batch != batch) {
+      if (h->v_warm) HILO_HIP_CHECK(hipFree(h->v_warm));
+      h->v_warm = nullptr;
+      hipError_t e = hipMalloc((void**)&h->v_warm, sizeof(double) * h->n_v * batch);
+      if (e != hipSuccess) return fail(HILO_ENOMEM, "warm-start buffer: %s", hipGetErrorString(e));
+      h->warm_batch = batch;
+      h->warm_valid = 0;
+    }
+  } else {
+    if (h->par_batch != batch) {
+      if (h->par_buf) HILO_HIP_CHECK(hipFree(h->par_buf));
+      h->par_buf = nullptr;
+      hipError_t e = hipMalloc((void**)&h->par_buf, sizeof(double) * (size_t)w * batch);
+      if (e != hipSuccess) return fail(HILO_ENOMEM, "parameter buffer: %s", hipGetErrorString(e));
+      h->par_batch = batch;
+    }
     const int64_t tot = batch * w;
     hipLaunchKernelGGL(nmpc_pack_par_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, batch, h->np, h->nu, p,
                        p_stride, u_old, h->par_buf);
     HILO_HIP_CHECK(hipGetLastError());
   }
+  OcpExtra ex = OcpExtra();
+  if (direct) {
+    ex.par2 = u_old;
+    ex.npar1 = h->np;
+    ex.v_copy = h->v_warm;
+    ex.gather = h->gather;
+    ex.gather_stride = h->gather_stride;
+  }
+  const double* par_arg = direct ? (p ? p : x0) : h->par_buf;   // np == 0: never dereferenced
+  const int64_t par_stride_arg = direct ? p_stride : (int64_t)w;
   // initial guess: explicit v0, else the previous solution (warm start, mpc.py:725-726), else the tiled guess
   const double* vstart = v0;
   int64_t vstride = h->n_v;
@@ -563,8 +604,8 @@ static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const 
       }
       vout = h->vc; lout = h->lamc;
     }
-    rc = jit_launch_solve(h->jit.solve, h->dev, batch, x0, h->par_buf, (int64_t)(h->np + h->nu), stage_data, sd_stride, vstart,
-                          vstride, vout, f_opt, lout, u0, status, iters, kkt, h->prof, wsb ? h->ws : nullptr, s);
+    rc = jit_launch_solve(h->jit.solve, h->dev, batch, x0, par_arg, par_stride_arg, stage_data, sd_stride, vstart,
+                          vstride, vout, f_opt, lout, u0, status, iters, kkt, h->prof, wsb ? h->ws : nullptr, s, ex);
     if (!rc && h->jit_coll_d > 0)
       rc = jit_launch_coll_out(h->jit.coll_out, h->dev, batch, h->N, h->vc, h->lamc, h->par_buf, (int64_t)(h->np + h->nu), stage_data,
                                sd_stride, v_opt, lam_g, s);
@@ -602,12 +643,13 @@ static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const 
     rc = h->gen ? h->gen->launch(a) : h->big->launch(a);
   } else {
     switch (h->model_id) {
-#define X(ID, T) case ID: rc = nmpc_launch<T>(h, batch, x0, h->par_buf, vstart, vstride, v_opt, f_opt, lam_g, u0, status, iters, kkt, s); break;
+#define X(ID, T) case ID: rc = nmpc_launch<T>(h, batch, x0, par_arg, vstart, vstride, v_opt, f_opt, lam_g, u0, status, iters, kkt, s, par_stride_arg, ex); break;
       HILO_NMPC_MODELS(X)
 #undef X
     }
   }
   if (rc) return rc;
+  if (direct) { h->warm_valid = 1; return HILO_OK; }   // the solve wrote the warm-start copy itself
   // keep the solution for the next call (un-shifted, like the reference)
   if (h->warm_batch != batch) {
     if (h->v_warm) HILO_HIP_CHECK(hipFree(h->v_warm));

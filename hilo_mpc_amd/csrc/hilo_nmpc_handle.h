@@ -38,6 +38,8 @@ struct hilo_nmpc {
   int tv_width;              // doubles per stage of the per-stage data table (0: none)
   size_t jit_ws_bytes;       // per-instance iterate workspace of a run-time compiled problem (0: iterate in LDS)
   int jit_coll_d;            // collocation degree of a run-time compiled problem (output pass needed) or 0
+  double* gather;            // caller's gather table (hilo_nmpc_set_gather) or NULL
+  int gather_stride;
 };
 
 

@@ -182,6 +182,21 @@ __host__ __device__ constexpr size_t ocp_fixed_doubles(int NX, int NU, int NCONS
   return NCONST + NZ * NZ + NZ + (N + 1) + 2 * 16 + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1 + NEXT;
 }
 
+// Optional plumbing of a solve launch that saves separate kernels around it (all members may stay zero):
+//   par2 / npar1  the per-instance parameter row comes from TWO arrays: entries [0, npar1) from `par` (row stride par_stride),
+//                 the remaining NPAR - npar1 from `par2` (dense rows; NULL = zeros) - model parameters and the previous input
+//                 of an NMPC step, without a packing kernel in front of the solve
+//   v_copy        second copy of the solution rows (the handle's warm-start buffer, mpc.py:725-726) - no device copy after it
+//   gather        row b of a [batch][gather_stride] fp64 table receives [first output (u_0) | status | iterations]: the send
+//                 buffer of the per-step result gather (hilo_mpc_amd/dist.py)
+struct OcpExtra {
+  const double* par2;
+  int npar1;
+  int gather_stride;
+  double* v_copy;
+  double* gather;
+};
+
 enum OcpPhase { PH_DERIV = 0, PH_ERR, PH_RICCATI, PH_STEP, PH_LS, PH_UPDATE, PH_NRIC, PH_NLS, PH_COUNT };
 
 template <class PB>
@@ -1192,7 +1207,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
                                                double* __restrict__ first, int first_kind,
                                                int32_t* __restrict__ status, int32_t* __restrict__ iters,
                                                double* __restrict__ kkt, long long* __restrict__ prof,
-                                               double* __restrict__ ws) {
+                                               double* __restrict__ ws, const OcpExtra ex = OcpExtra()) {
   using S = Ocp<PB>;
   constexpr int NX = S::NX, NU = S::NU, NZ = S::NZ, NC = S::NC, NXV = S::NXV, NH = S::NH, NTAIL = NX - NXV - NH;
   const int t = threadIdx.x;
@@ -1206,7 +1221,15 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     lds_double* dst = lds_raw;
     OCP_FOR(i, S::NCONST) dst[i] = src[i];
   }
-  OCP_FOR(i, PB::NPAR) l.par[i] = par[b * par_stride + i];
+  {
+    const int n1 = ex.par2 || ex.npar1 > 0 ? ex.npar1 : PB::NPAR;   // default: the whole row from `par`
+    OCP_FOR(i, PB::NPAR) {
+      double v = 0.0;
+      if (i < n1) v = par[b * par_stride + i];
+      else if (ex.par2) v = ex.par2[b * (int64_t)(PB::NPAR - n1) + (i - n1)];
+      l.par[i] = v;
+    }
+  }
   if constexpr (PB::NSD > 0)
     OCP_FOR(i, (N + 1) * PB::NSD) l.sd[i] = sdata[b * sd_stride + i];
   __syncthreads();
@@ -1522,12 +1545,19 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
   // ---- write back ([x-block | u-block] after the prefix) ----
   const int Ncw = NH > 0 ? pc.Nc : N;
   double* vo = v_opt + b * (int64_t)(v_prefix + (N + 1) * NXV + Ncw * NU + NTAIL) + v_prefix;
+  double* const vo2 = ex.v_copy ? ex.v_copy + (vo - v_opt) : nullptr;
   OCP_FOR(e, SL) {
     const int k = e / NZ, i = e - k * NZ;
-    if (i < NXV) vo[k * NXV + i] = l.Z[e];
-    else if (i < NXV + NTAIL) { if (k == 0) vo[(N + 1) * NXV + Ncw * NU + (i - NXV)] = l.Z[e]; }
+    int dst = -1;
+    if (i < NXV) dst = k * NXV + i;
+    else if (i < NXV + NTAIL) { if (k == 0) dst = (N + 1) * NXV + Ncw * NU + (i - NXV); }
     else if (i < NX) {}   // held inputs: copies of u_{Nc-1}, not part of the reference's decision vector
-    else if (k < Ncw) vo[(N + 1) * NXV + k * NU + (i - NX)] = l.Z[e];
+    else if (k < Ncw) dst = (N + 1) * NXV + k * NU + (i - NX);
+    if (dst >= 0) {
+      const double zv = l.Z[e];
+      vo[dst] = zv;
+      if (vo2) vo2[dst] = zv;
+    }
   }
   if (lam_g) {
     // the reference's g: per stage [shooting defect (NXV rows) | constraint rows (n_con_ref)] (mpc.py:1667, :1707-1725)
@@ -1560,6 +1590,11 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     if (first_kind == 0) { OCP_FOR(a, S::NU0) first[b * S::NU0 + a] = l.Z[NX + a] * pc.sz[NX + a]; }
     else { OCP_FOR(a, NX) first[b * NX + a] = l.Z[N * NZ + a] * pc.sz[a]; }
   }
+  if (ex.gather && first_kind == 0) {
+    double* gr = ex.gather + b * (int64_t)ex.gather_stride;
+    OCP_FOR(a, S::NU0) gr[a] = l.Z[NX + a] * pc.sz[NX + a];
+    if (t == 0) { gr[S::NU0] = (double)st; gr[S::NU0 + 1] = (double)it; }
+  }
   if (t == 0) {
     f_opt[b] = fval;
     status[b] = st;
@@ -1581,10 +1616,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
                                                        double* __restrict__ first, int first_kind,
                                                        int32_t* __restrict__ status, int32_t* __restrict__ iters,
                                                        double* __restrict__ kkt, long long* __restrict__ prof,
-                                                       double* __restrict__ ws = nullptr) {
+                                                       double* __restrict__ ws = nullptr, const OcpExtra ex = OcpExtra()) {
   extern __shared__ double lds_raw_generic[];
   ocp_solve_body<PB, TPB>((lds_double*)lds_raw_generic, pcg, batch, x0, par, par_stride, sdata, sd_stride, v0, v0_stride, v0_prefix,
-                          v_prefix, v_opt, f_opt, lam_g, first, first_kind, status, iters, kkt, prof, ws);
+                          v_prefix, v_opt, f_opt, lam_g, first, first_kind, status, iters, kkt, prof, ws, ex);
 }
 
 }  // namespace hilo

@@ -45,15 +45,26 @@ class StepGather:
         self.send = torch.zeros(self.max_n, self.width, dtype=torch.float64, device=device)
         self.recv = torch.zeros(world * self.max_n, self.width, dtype=torch.float64, device=device)
 
-    def __call__(self, u0, status, iters):
+    def attach(self, nmpc):
+        """Let the controller's solve kernel write its rows [u0 | status | iters] straight into the send buffer
+        (hilo_nmpc_set_gather): a step is then one launch + one collective.  Returns True when the controller supports it."""
+        self.attached = bool(nmpc.set_gather_buffer(self.send))
+        return self.attached
+
+    attached = False
+
+    def __call__(self, u0=None, status=None, iters=None):
         n = self.sizes[self.rank]
-        self.send[:n, :self.nu] = u0
-        self.send[:n, self.nu] = status.to(torch.float64)
-        self.send[:n, self.nu + 1] = iters.to(torch.float64)
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.recv, self.send)
+        if not self.attached:
+            self.send[:n, :self.nu] = u0
+            self.send[:n, self.nu] = status.to(torch.float64)
+            self.send[:n, self.nu + 1] = iters.to(torch.float64)
+        if self.world == 1:
+            full = self.send[:n]
         else:
-            self.recv.copy_(self.send)
-        parts = [self.recv[r * self.max_n: r * self.max_n + self.sizes[r]] for r in range(self.world)]
-        full = torch.cat(parts, dim=0)
+            dist.all_gather_into_tensor(self.recv, self.send)
+            if len(set(self.sizes)) == 1:
+                full = self.recv
+            else:
+                full = torch.cat([self.recv[r * self.max_n: r * self.max_n + self.sizes[r]] for r in range(self.world)], dim=0)
         return full[:, :self.nu], full[:, self.nu].to(torch.int32), full[:, self.nu + 1].to(torch.int32)

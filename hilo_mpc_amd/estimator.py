@@ -233,26 +233,46 @@ class _KalmanFilter:
             pt = self._p
         if self._n_p and pt is None:
             raise RuntimeError("No parameter values supplied. Please run set_initial_parameter_values() or pass p=.")
+        ut = None
         if self._n_u:
             if u is None:
                 raise RuntimeError("No input data supplied.")
             ut = to_dev(u, self._dev).reshape(-1, self._n_u)
-        parts = []
-        if self._n_u:
-            parts.append(ut.expand(B, -1) if ut.shape[0] == 1 else ut)
-        if self._n_p:
-            parts.append(pt.expand(B, -1) if pt.shape[0] == 1 else pt)
-        upt = torch.cat(parts, dim=1).contiguous() if parts else None
-        us = 0 if upt is None else upt.shape[1]
-        xP = torch.cat([self._x[:, :, None], self._P], dim=2).contiguous()
-        out = torch.empty_like(xP)
+        # [u; p] of kf.py:130 in a buffer the filter keeps: per step only the rows that changed are written (no allocation,
+        # no concatenation kernel); the packed [x|P] tile ping-pongs between two resident buffers, x and P are views of it
+        nup = self._n_u + self._n_p
+        upt, us = None, 0
+        if nup:
+            buf = getattr(self, '_up_buf', None)
+            if buf is None or buf.shape[0] != B:
+                buf = self._up_buf = torch.empty(B, nup, dtype=torch.float64, device=self._dev)
+                self._up_p_src = None
+            if self._n_u:
+                buf[:, :self._n_u] = ut
+            if self._n_p:
+                key = (pt.data_ptr(), pt._version, tuple(pt.shape))
+                if self._up_p_src != key:
+                    buf[:, self._n_u:] = pt
+                    self._up_p_src = key
+            upt, us = buf, nup
+        tiles = getattr(self, '_xP_bufs', None)
+        if tiles is None or tiles[0].shape[0] != B:
+            tiles = self._xP_bufs = [torch.empty(B, self._n_x, self._n_x + 1, dtype=torch.float64, device=self._dev) for _ in range(2)]
+            self._xP_cur = -1
+        if self._xP_cur < 0 or self._x.data_ptr() != tiles[self._xP_cur].data_ptr():
+            # state set from outside (set_initial_guess, manual assignment): pack it once
+            tiles[0][:, :, 0] = self._x
+            tiles[0][:, :, 1:] = self._P
+            self._xP_cur = 0
+        xP, out = tiles[self._xP_cur], tiles[1 - self._xP_cur]
         yp = torch.empty(B, self._n_y, dtype=torch.float64, device=self._dev)
         _lib.check(_lib.lib().hilo_kf_step(self._handle, B, ptr(xP), ptr(yt.contiguous()), ptr(upt), us,
                                            ptr(self._Q), self._cov_stride(self._Q, B), ptr(self._R),
                                            self._cov_stride(self._R, B), ptr(out), ptr(yp),
                                            stream_ptr(self._dev)))
-        self._x = out[:, :, 0].contiguous()
-        self._P = out[:, :, 1:].contiguous()
+        self._xP_cur = 1 - self._xP_cur
+        self._x = out[:, :, 0]          # strided views of the resident tile (zero copy)
+        self._P = out[:, :, 1:]
         host = not isinstance(y, torch.Tensor)
         cv = (lambda t: t.cpu().numpy()) if host else (lambda t: t)
         xs = cv(self._x)

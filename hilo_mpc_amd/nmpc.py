@@ -1017,6 +1017,23 @@ class NMPC:
         self._prof_on = bool(enable)
         return dict(zip(names, list(buf))) if had else None
 
+    def set_gather_buffer(self, table):
+        """Sharded batches: the solve writes [u0 | status | iterations] rows (fp64) into `table` ([B, >= nu + 2], device) itself
+        (hilo_nmpc_set_gather).  Returns False for problem kinds whose solve does not offer it (the caller then packs)."""
+        if table is None:
+            _lib.check(_lib.lib().hilo_nmpc_set_gather(self._handle, None, 0))
+            return False
+        if not table.is_contiguous():
+            return False
+        try:
+            _lib.check(_lib.lib().hilo_nmpc_set_gather(self._handle, ptr(table), int(table.shape[1])))
+        except _lib.HiloError as err:
+            if err.code != -4:
+                raise
+            return False
+        self._gather_table = table
+        return True
+
     def plant_step(self, x, u, cp=None):
         """Closed-loop helper: x+ = Phi(x, u, p) with the controller's shooting map, on the device."""
         x = to_dev(x, self._dev).reshape(-1, self._n_x).contiguous()

@@ -314,6 +314,10 @@ int hilo_nmpc_create(const hilo_nmpc_desc* desc, int device, hilo_nmpc** out);  
 void hilo_nmpc_destroy(hilo_nmpc* h);
 int hilo_nmpc_dims(const hilo_nmpc* h, int* n_v, int* n_g, int* nx, int* nu, int* np);
 int hilo_nmpc_reset_warm_start(hilo_nmpc* h);
+/* Sharded batches (one process per GPU, hilo_mpc_amd/dist.py): let the solve write row b = [u0 (nu) | status | iterations]
+   (fp64) of the device table [batch][stride] itself - the send buffer of the per-step result gather.  NULL switches it off.
+   Honoured by plain tracking problems; the reference has no counterpart (single instance, no batching). */
+int hilo_nmpc_set_gather(hilo_nmpc* h, double* table, int stride);
 /* optimize(fix_x0=...) of mpc.py:797-807: 1 (default) pins x_0 to the measured state; 0 leaves x_0 free inside the state
    box [x_lb, x_ub] (the `x0` argument of hilo_nmpc_solve is then ignored, the start value comes from the warm start / guess).
    Synchronises the device when the setting changes. */
