@@ -175,7 +175,7 @@ __host__ __device__ constexpr size_t ocp_iter_doubles(int NX, int NU, int NC, in
   const size_t NZ = NX + NU, NDIR = NZ * (NZ + 1) / 2, S = (size_t)(N + 1) * NZ;
   return 12 * S + 4 * (size_t)N * NX + (size_t)N * NX * NZ + (size_t)N * NZ * NZ + (size_t)(N + 1) * NDIR +
          (size_t)(N + 1) * NX * NX + (size_t)(N + 1) * NX + (size_t)N * NU * NX + (size_t)N * NU + (size_t)N * NX * NX +
-         (size_t)N * NX + (size_t)N * NC * (12 + NZ);
+         (size_t)N * NX + (size_t)N * NX + (size_t)N * NC * (14 + NZ);
 }
 __host__ __device__ constexpr size_t ocp_fixed_doubles(int NX, int NU, int NCONST, int NPAR, int NSD, int NEXT, int N) {
   const size_t NZ = NX + NU;
@@ -232,6 +232,7 @@ struct Ocp {
     dp Z, Zt, D, zL, zU, dzL, dzU, grad, lam, lamn, c, ct, AB, W, Qd, P, pv, Kg, kff, sig, rb, Acl, bcl;
     dp lbA, ubA;  // effective box of every slot: -inf / +inf where there is no bound or the slot is not a variable
     dp cs, cst, cnu, cnun, cvL, cvU, cdvL, cdvU, cds, cd, csig, crb, Jd;  // [N][NC] (Jd: [N][NC][NZ])
+    dp c0, cd0, cdt;  // second-order correction: saved defects / row values, row values at the trial point
     lds_double *Mm, *mm, *fk, *filt, *red, *par, *sd, *ext;
   };
   static_assert(OCP_FILTER == 16, "ocp_fixed_doubles assumes a filter of 16 entries");
@@ -272,6 +273,7 @@ struct Ocp {
     l.cs = big(R); l.cst = big(R); l.cnu = big(R); l.cnun = big(R); l.cvL = big(R); l.cvU = big(R);
     l.cdvL = big(R); l.cdvU = big(R); l.cds = big(R); l.cd = big(R); l.csig = big(R); l.crb = big(R);
     l.Jd = big(R * NZ);
+    l.c0 = big((size_t)N * NX); l.cd0 = big(R); l.cdt = big(R);
     return l;
   }
 
@@ -814,11 +816,11 @@ struct Ocp {
             v = 0.5 * (Q[dir_of(a, b, NX)] - Q[a] - Q[b]);
           }
         }
-        if (i == j) v += resto ? 1.0 : (delta + l.sig[N * NZ + i]);
+        if (i == j) v += (resto ? 1.0 : delta) + l.sig[N * NZ + i];
         l.P[N * NX * NX + e] = v;
       } else {
         const int i = e - NX * NX;
-        l.pv[N * NX + i] = resto ? 0.0 : l.rb[N * NZ + i];
+        l.pv[N * NX + i] = l.rb[N * NZ + i];
       }
     }
     __syncthreads();
@@ -864,15 +866,15 @@ struct Ocp {
           const bool iv = i < NZ, rhs = q == NZ;
           const int ic = iv ? i : NZ - 1, jj = q < NZ ? q : 0;
           const double rbv = l.rb[k * NZ + ic], wv = l.W[k * NZ * NZ + ic * NZ + jj], sg = l.sig[k * NZ + ic];
-          double h = resto ? 0.0 : (rhs ? rbv : wv);
-          if (ic == q) h += resto ? 1.0 : delta + sg;
+          double h = rhs ? rbv : (resto ? 0.0 : wv);
+          if (ic == q) h += (resto ? 1.0 : delta) + sg;
           if constexpr (NC > 0) {  // eliminated slack rows: + Jd^T (Sigma_s + delta) Jd, rhs + Jd^T ((Sigma_s + delta)(d - s) + crb)
 #pragma unroll
             for (int m = 0; m < NC; ++m) {
               const int rr = k * NC + m;
-              const double wgt = resto ? 1.0 : l.csig[rr] + delta;
+              const double wgt = (resto ? 1.0 : delta) + l.csig[rr];
               const double ds = l.cd[rr] - l.cs[rr], cr = l.crb[rr], jr = l.Jd[rr * NZ + jj];
-              const double right = rhs ? wgt * ds + (resto ? 0.0 : cr) : wgt * jr;
+              const double right = rhs ? wgt * ds + cr : wgt * jr;
               h += l.Jd[rr * NZ + ic] * right;
             }
           }
@@ -927,15 +929,15 @@ struct Ocp {
           pl[n] = pn[n];
         }
         const double rbv = l.rb[k * NZ + i], wv = l.W[k * NZ * NZ + i * NZ + jj], sg = l.sig[k * NZ + i];
-        double s = resto ? 0.0 : (rhs ? rbv : wv);
-        const double dg = (i == j) ? (resto ? 1.0 : delta + sg) : 0.0;
+        double s = rhs ? rbv : (resto ? 0.0 : wv);
+        const double dg = (i == j) ? ((resto ? 1.0 : delta) + sg) : 0.0;
         if constexpr (NC > 0) {  // eliminated slack rows: + Jd^T (Sigma_s + delta) Jd, rhs + Jd^T ((Sigma_s + delta)(d - s) + crb)
 #pragma unroll
           for (int m = 0; m < NC; ++m) {
             const int r = k * NC + m;
-            const double wgt = resto ? 1.0 : l.csig[r] + delta;
+            const double wgt = (resto ? 1.0 : delta) + l.csig[r];
             const double ds = l.cd[r] - l.cs[r], cr = l.crb[r], jr = l.Jd[r * NZ + jj];
-            const double right = rhs ? wgt * ds + (resto ? 0.0 : cr) : wgt * jr;
+            const double right = rhs ? wgt * ds + cr : wgt * jr;
             s += l.Jd[r * NZ + i] * right;
           }
         }
@@ -1121,7 +1123,7 @@ struct Ocp {
           ds = l.cd[e] - l.cs[e];
 #pragma unroll
           for (int i = 0; i < NZ; ++i) ds += l.Jd[e * NZ + i] * l.D[k * NZ + i];
-          nun = resto ? 0.0 : (l.csig[e] + delta) * ds + l.crb[e];
+          nun = resto ? 0.0 : (l.csig[e] + delta) * ds + l.crb[e];   // restoration resets the multipliers afterwards
         }
         l.cds[e] = ds;
         l.cnun[e] = nun;
@@ -1132,7 +1134,12 @@ struct Ocp {
   }
 
   // ---- feasibility restoration, simplified from W&B sec. 3.3 (same statement as oracle/nmpc.py::_restore) ------
-  __device__ OCP_PHASE static bool restore(lds_double* lbase, double* ws, double mu, double tau, int nfilt, double theta_max) {
+  // Returns 0: restored (Z, cs hold a point acceptable to the filter), 1: failed, 2: converged to a point of locally minimal
+  // infeasibility (IPOPT's 'Infeasible_Problem_Detected').  The step solves
+  //     min 1/2 |d|^2 - mu_R sum ln(slacks)   s.t.   J d = -c,      mu_R = max(mu, |c|_inf)
+  // - IPOPT's restoration NLP keeps its iterates inside the bounds with a barrier of that parameter (W&B sec. 3.3); without the
+  // barrier's Newton terms the least-norm step runs into the bounds and the fraction-to-the-boundary rule stalls it.
+  __device__ OCP_PHASE static int restore(lds_double* lbase, double* ws, double mu, double tau, int nfilt, double theta_max) {
     lbase = uni(lbase); ws = uni(ws); mu = uni(mu); tau = uni(tau); nfilt = uni(nfilt); theta_max = uni(theta_max);
     const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
@@ -1143,9 +1150,42 @@ struct Ocp {
       OCP_FOR(e, N * NC) th += row_on(pc, e / NC, e % NC) ? fabs(l.cd[e] - l.cs[e]) : 0.0;
     th = block_reduce<OpSum>(th, l.red);
     const double th_start = th;
+    double th_ref = th;
     for (int it = 0; it < 50; ++it) {
+      // ten iterations without reducing the violation by 1e-4 in total: the iterates sit at a point of locally minimal
+      // infeasibility (IPOPT's restoration NLP would converge there and report Infeasible_Problem_Detected)
+      if (it % 10 == 9) {
+        if (th > (1.0 - 1e-4) * th_ref && th > 1e-6) return 2;
+        th_ref = th;
+      }
+      double cmax = 0.0;
+      OCP_FOR(e, N * NX) cmax = nmax(cmax, fabs(l.c[e]));
+      if constexpr (NC > 0)
+        OCP_FOR(e, N * NC) cmax = nmax(cmax, row_on(pc, e / NC, e % NC) ? fabs(l.cd[e] - l.cs[e]) : 0.0);
+      const double mu_r = uni(fmax(mu, block_reduce<OpMax>(cmax, l.red)));
+      OCP_FOR(e, SL) {
+        const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e];
+        double sg = 0.0, r = 0.0;
+        if (lb > -INFINITY) { const double is = 1.0 / (z - lb); sg += mu_r * is * is; r -= mu_r * is; }
+        if (ub < INFINITY) { const double is = 1.0 / (ub - z); sg += mu_r * is * is; r += mu_r * is; }
+        l.sig[e] = sg;
+        l.rb[e] = r;
+      }
+      if constexpr (NC > 0) {
+        OCP_FOR(e, N * NC) {
+          const int m = e % NC;
+          double sg = 0.0, r = 0.0;
+          if (row_on(pc, e / NC, m)) {
+            if (pc.dlb[m] > -INFINITY) { const double is = 1.0 / (l.cs[e] - pc.dlb[m]); sg += mu_r * is * is; r -= mu_r * is; }
+            if (pc.dub[m] < INFINITY) { const double is = 1.0 / (pc.dub[m] - l.cs[e]); sg += mu_r * is * is; r += mu_r * is; }
+          }
+          l.csig[e] = sg;
+          l.crb[e] = r;
+        }
+      }
+      __syncthreads();
       riccati(lbase, ws, mu, 0.0, true);
-      double a = 1.0;
+      double a = 1.0, dmax = 0.0;
       if constexpr (NC > 0) {
         OCP_FOR(e, N * NC) {
           const int m = e % NC;
@@ -1157,10 +1197,14 @@ struct Ocp {
       }
       OCP_FOR(e, SL) {
         const double d = l.D[e], lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e];
+        dmax = nmax(dmax, fabs(d));
         if (lb > -INFINITY && d < 0.0) a = fmin(a, -tau * (z - lb) / d);
         if (ub < INFINITY && d > 0.0) a = fmin(a, tau * (ub - z) / d);
       }
       double alpha = block_reduce<OpMin>(a, l.red);
+      dmax = block_reduce<OpMax>(dmax, l.red);
+      // the restoration problem is stationary while the constraints are still violated: locally infeasible
+      if (dmax <= 1e-9 && th > 1e-6) return 2;
       bool ok = false;
       double tht = 0.0, ft = 0.0;
       while (alpha > 1e-10) {
@@ -1173,7 +1217,9 @@ struct Ocp {
         if (isfinite(tht) && tht <= (1.0 - 1e-4 * alpha) * th) { ok = true; break; }
         alpha = uni(alpha * 0.5);
       }
-      if (!ok) return false;
+      // no step length reduces the violation along the (barrier-deflected) Newton direction of the constraints: a point of
+      // locally minimal infeasibility inside the box
+      if (!ok) return th > 1e-6 ? 2 : 1;
       OCP_FOR(e, SL) l.Z[e] = l.Zt[e];
       if constexpr (NC > 0)
         OCP_FOR(e, N * NC) l.cs[e] = l.cst[e];
@@ -1184,11 +1230,11 @@ struct Ocp {
         bool acc = true;
         for (int q = 0; q < nfilt; ++q)
           if (th >= l.filt[2 * q] && ph >= l.filt[2 * q + 1]) { acc = false; break; }
-        if (acc) return true;
+        if (acc) return 0;
       }
       eval_derivs(lbase, ws);
     }
-    return false;
+    return 1;
   }
 };
 
@@ -1424,7 +1470,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     dphi = block_reduce<OpSum>(dphi, l.red);
     const double phi0 = uni(fval + S::eval_barrier(l, l.Z, mu, l.cs));
     OCP_TICK(PH_STEP)
-    // ---- filter line search (W&B Alg. A without second-order correction) ----
+    // ---- filter line search (W&B Alg. A) ----
     double alpha = a_p;
     bool accepted = false, armijo = false;
     for (int ls = 0; ls < 60; ++ls) {
@@ -1433,7 +1479,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
         OCP_FOR(e, N * NC) l.cst[e] = l.cs[e] + alpha * l.cds[e];
       __syncthreads();
       tprof[PH_NLS] += 1;
-      const FTheta trial = S::eval_values(lds_raw, wsb, l.Zt, l.ct, l.cst);
+      const FTheta trial = S::eval_values(lds_raw, wsb, l.Zt, l.ct, l.cst, l.cdt);
       const double ft = trial.f, tht = trial.theta;
       const double pht = uni(ft + S::eval_barrier(l, l.Zt, mu, l.cst));
       bool ok = isfinite(pht) && isfinite(tht) && tht <= theta_max;
@@ -1451,6 +1497,75 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
         else ok = tht <= (1 - pc.gamma_theta) * th0 || pht - phi0 - rnd <= -pc.gamma_phi * th0;
       }
       if (ok) { accepted = true; armijo = sw; break; }
+      // ---- second-order correction (W&B sec. 2.4): the full step was rejected and did not reduce the violation.  The same
+      // system is solved with c_soc = alpha c(x_k) + c(x_k + alpha d); up to four corrections while theta drops by kappa_soc.
+      if (ls == 0 && tht >= th0) {
+        OCP_FOR(e, N * NX) l.c0[e] = l.c[e];
+        if constexpr (NC > 0)
+          OCP_FOR(e, N * NC) l.cd0[e] = l.cd[e];
+        double a_prev = alpha, th_old = tht;
+        bool soc_ok = false, soc_sw = false;
+        for (int ps = 0; ps < 4; ++ps) {
+          OCP_FOR(e, N * NX) l.c[e] = a_prev * l.c[e] + l.ct[e];
+          if constexpr (NC > 0) {
+            OCP_FOR(e, N * NC) {
+              if (S::row_on(pc, e / NC, e % NC)) l.cd[e] = l.cs[e] + a_prev * (l.cd[e] - l.cs[e]) + (l.cdt[e] - l.cst[e]);
+            }
+          }
+          __syncthreads();
+          tprof[PH_NRIC] += 1;
+          if (!uni(S::riccati(lds_raw, wsb, mu, delta))) break;
+          double a = 1.0;
+          OCP_FOR(e, SL) {
+            const double d = l.D[e], lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e];
+            if (lb > -INFINITY && d < 0.0) a = fmin(a, -tau * (z - lb) / d);
+            if (ub < INFINITY && d > 0.0) a = fmin(a, tau * (ub - z) / d);
+          }
+          if constexpr (NC > 0) {
+            OCP_FOR(e, N * NC) {
+              const int m = e % NC;
+              if (!S::row_on(pc, e / NC, m)) continue;
+              const double d = l.cds[e];
+              if (pc.dlb[m] > -INFINITY && d < 0.0) a = fmin(a, -tau * (l.cs[e] - pc.dlb[m]) / d);
+              if (pc.dub[m] < INFINITY && d > 0.0) a = fmin(a, tau * (pc.dub[m] - l.cs[e]) / d);
+            }
+          }
+          const double a_s = block_reduce<OpMin>(a, l.red);
+          OCP_FOR(e, SL) l.Zt[e] = l.Z[e] + a_s * l.D[e];
+          if constexpr (NC > 0)
+            OCP_FOR(e, N * NC) l.cst[e] = l.cs[e] + a_s * l.cds[e];
+          __syncthreads();
+          tprof[PH_NLS] += 1;
+          const FTheta t2 = S::eval_values(lds_raw, wsb, l.Zt, l.ct, l.cst, l.cdt);
+          const double ths = t2.theta;
+          const double phs = uni(t2.f + S::eval_barrier(l, l.Zt, mu, l.cst));
+          bool oks = isfinite(phs) && isfinite(ths) && ths <= theta_max;
+          if (oks) {
+            for (int q = 0; q < nfilt; ++q) {
+              const double tf = l.filt[2 * q], pf = l.filt[2 * q + 1];
+              if (ths >= tf && phs - 10 * 2.220446049250313e-16 * fabs(pf) >= pf) { oks = false; break; }
+            }
+          }
+          if (oks) {
+            const bool sw2 = th0 <= theta_min && dphi < 0.0 && alpha * pow(-dphi, pc.s_phi) > pc.delta_ls * pow(th0, pc.s_theta);
+            const double rnd = 10 * 2.220446049250313e-16 * fabs(phi0);
+            if (sw2) oks = phs - phi0 - rnd <= pc.eta_phi * alpha * dphi;
+            else oks = ths <= (1 - pc.gamma_theta) * th0 || phs - phi0 - rnd <= -pc.gamma_phi * th0;
+            if (oks) { soc_ok = true; soc_sw = sw2; break; }
+          }
+          if (!(ths <= 0.99 * th_old)) break;
+          th_old = ths;
+          a_prev = a_s;
+        }
+        if (soc_ok) { accepted = true; armijo = soc_sw; break; }
+        // no luck: back to the uncorrected direction (defects, row values, step, multipliers) and on with the backtracking
+        OCP_FOR(e, N * NX) l.c[e] = l.c0[e];
+        if constexpr (NC > 0)
+          OCP_FOR(e, N * NC) l.cd[e] = l.cd0[e];
+        __syncthreads();
+        tprof[PH_NRIC] += 1;
+        (void)uni(S::riccati(lds_raw, wsb, mu, delta));
+      }
       alpha = uni(alpha * 0.5);
       // W&B eq. 23: below alpha_min the line search gives up and the restoration phase is called
       double amin = pc.gamma_theta;
@@ -1479,7 +1594,8 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
       __syncthreads();
     }
     if (do_resto) {
-      if (!uni(S::restore(lds_raw, wsb, mu, tau, nfilt, theta_max))) { st = HILO_STATUS_RESTORATION_FAILED; break; }
+      const int rr = uni(S::restore(lds_raw, wsb, mu, tau, nfilt, theta_max));
+      if (rr != 0) { st = rr == 2 ? HILO_STATUS_INFEASIBLE : HILO_STATUS_RESTORATION_FAILED; break; }
       // IPOPT after restoration: equality multipliers reset (constr_mult_reset_threshold = 0), bound multipliers
       // reset to 1 when they exceed bound_mult_reset_threshold = 1000
       double zm = 0.0;

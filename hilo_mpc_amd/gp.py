@@ -806,6 +806,37 @@ class GaussianProcess:
                 cur[i] = float(v)
                 setattr(o, a, cur)
 
+    # ---- device services of fit_model (overridable: the CPU tests of the host driver serve them from the oracle) ----
+    def _device_refit(self):
+        """Factorise at the object's current hyper-parameters into the handle's buffers (hilo_gp_refit)."""
+        kp = np.ascontiguousarray(self.kernel.program(self._X_train.shape[0]), dtype=np.float64)
+        try:
+            _lib.check(_lib.lib().hilo_gp_refit(self._handle, kp.ctypes.data, kp.size, float(self.noise_variance)))
+            return True
+        except (_lib.NotPositiveDefinite, ValueError):
+            return False
+
+    def _device_lml_gradient(self, th, h):
+        """d LML / d theta at the FREE log hyper-parameters `th` (the object is factorised there): hilo_gp_lml_gradient with
+        the kernel programs / noise variances at th +- h e_i."""
+        nf = self._X_train.shape[0]
+        progs, noise = [], []
+        for i in range(th.size):
+            for sgn in (1., -1.):
+                e = np.zeros_like(th)
+                e[i] = sgn * h
+                self._set_hyperparameters(np.exp(th + e))
+                progs.append(np.ascontiguousarray(self.kernel.program(nf), dtype=np.float64))
+                noise.append(float(self.noise_variance))
+        self._set_hyperparameters(np.exp(th))
+        progs = np.ascontiguousarray(np.stack(progs))
+        noise = np.ascontiguousarray(np.array(noise))
+        hh = np.full(th.size, float(h))
+        out = np.zeros(th.size)
+        _lib.check(_lib.lib().hilo_gp_lml_gradient(self._handle, th.size, progs.ctypes.data, noise.ctypes.data, hh.ctypes.data,
+                                                   out.ctypes.data))
+        return out
+
     def fit_model(self, gtol=1e-8, maxiter=500):
         """Optimises the hyper-parameters by minimising the negative log marginal likelihood over their logarithms
         (gp.py:660-697; kernel.py:127-130).  Every objective value is one device factorisation into the handle's buffers
@@ -838,24 +869,13 @@ class GaussianProcess:
         self._set_hyperparameters = set_free            # the closures below only see the free ones
         th0 = th_all[free]
 
-        lib = _lib.lib()
-        nf = self._X_train.shape[0]
         h_step = 1e-5
-
-        def program_at(th):
-            self._set_hyperparameters(np.exp(th))
-            return np.ascontiguousarray(self.kernel.program(nf), dtype=np.float64), float(self.noise_variance)
-
         state = {'th': None, 'ok': False}
 
         def refit(th):
-            """One device factorisation into the handle's buffers (hilo_gp_refit); False at an indefinite trial point."""
-            kp, nv = program_at(th)
-            try:
-                _lib.check(lib.hilo_gp_refit(self._handle, kp.ctypes.data, kp.size, nv))
-                state['th'], state['ok'] = np.array(th), True
-            except (_lib.NotPositiveDefinite, ValueError):
-                state['th'], state['ok'] = np.array(th), False
+            """One device factorisation into the handle's buffers; False at an indefinite trial point."""
+            self._set_hyperparameters(np.exp(th))
+            state['th'], state['ok'] = np.array(th), bool(self._device_refit())
             return state['ok']
 
         def f(th):
@@ -865,27 +885,13 @@ class GaussianProcess:
             return v if np.isfinite(v) else np.inf
 
         def g(th):
-            """-(d LML / d theta) by the device trace formula (hilo_gp_lml_gradient) + the hyper-priors' part by central
-            differences of their closed-form log densities."""
+            """-(d LML / d theta) by the device trace formula + the hyper-priors' part by central differences of their
+            closed-form log densities."""
             if state['th'] is None or not np.array_equal(state['th'], th):
                 refit(th)
             if not state['ok']:
                 return np.zeros_like(th)
-            progs, noise = [], []
-            for i in range(th.size):
-                for sgn in (1., -1.):
-                    e = np.zeros_like(th)
-                    e[i] = sgn * h_step
-                    kp, nv = program_at(th + e)
-                    progs.append(kp)
-                    noise.append(nv)
-            self._set_hyperparameters(np.exp(th))
-            progs = np.ascontiguousarray(np.stack(progs))
-            noise = np.ascontiguousarray(np.array(noise))
-            hh = np.full(th.size, h_step)
-            out = np.zeros(th.size)
-            _lib.check(lib.hilo_gp_lml_gradient(self._handle, th.size, progs.ctypes.data, noise.ctypes.data, hh.ctypes.data,
-                                                out.ctypes.data))
+            out = self._device_lml_gradient(th, h_step)
             if getattr(self, '_priors', None):
                 for i in range(th.size):
                     e = np.zeros_like(th)
@@ -894,7 +900,7 @@ class GaussianProcess:
                     lp = self._log_hyperprior()
                     self._set_hyperparameters(np.exp(th - e))
                     out[i] += (lp - self._log_hyperprior()) / (2 * h_step)
-                self._set_hyperparameters(np.exp(th))
+            self._set_hyperparameters(np.exp(th))
             return -out
         good = th0.copy()
         try:

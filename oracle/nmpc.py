@@ -196,6 +196,12 @@ class IpmOptions:
     kappa_w_plus_bar = 100.
 
     compl_inf_tol = 1e-4
+    constr_mult_init_max = 1e3      # IPOPT: least-squares estimate of the equality multipliers at the start, dropped if larger
+    max_soc = 4                     # second-order correction steps (W&B sec. 2.4), kappa_soc = 0.99
+    kappa_soc = 0.99
+    ls_mult_init = False            # option; the device engine starts from lambda = 0, so does the oracle by default
+    soc = True
+    resto_barrier = True
 
     def __init__(self, **kw):
         for k, v in kw.items():
@@ -423,7 +429,22 @@ class DenseIpm:
         acc_count = np.zeros(B, dtype=np.int32)
         delta_last = np.zeros(B)
         n_resto = np.zeros(B, dtype=np.int32)
+        soc_used = np.zeros(B, dtype=np.int32)
         filt = [[] for _ in range(B)]
+        if o.ls_mult_init and self.m:
+            # W&B sec. 3.6: lambda_0 from  [I J^T; J 0] [w; lambda] = -[grad f - zL + zU; 0]; discarded when it is large
+            _, g0, _, J0, _ = self.eval_all(w, lam, data)
+            K = np.zeros((B, self.nw + self.m, self.nw + self.m))
+            K[:, :self.nw, :self.nw] = np.eye(self.nw)
+            K[:, :self.nw, self.nw:] = np.swapaxes(J0, 1, 2)
+            K[:, self.nw:, :self.nw] = J0
+            rhs = np.concatenate([-(g0 - zl + zu), np.zeros((B, self.m))], axis=1)
+            try:
+                lam0 = np.linalg.solve(K, rhs[:, :, None])[:, self.nw:, 0]
+                ok = np.isfinite(lam0).all(1) & (np.abs(lam0).max(1) <= o.constr_mult_init_max)
+                lam = np.where(ok[:, None], lam0, 0.0)
+            except np.linalg.LinAlgError:
+                pass
         f, c = self.eval_fc(w, data)
         theta0 = np.abs(c).sum(1)
         theta_min = o.theta_min_fact * np.maximum(1, theta0)
@@ -471,6 +492,7 @@ class DenseIpm:
             rhs1 = -(g - np.where(self.has_l, mu[idx, None] / sl, 0) + np.where(self.has_u, mu[idx, None] / su, 0))
             d = np.zeros((nb, self.nw))
             lam_new = np.zeros((nb, self.m))
+            Kkeep = [None] * nb
             delta = np.zeros(nb)
             todo = np.ones(nb, dtype=bool)
             first_try = np.ones(nb, dtype=bool)
@@ -488,6 +510,8 @@ class DenseIpm:
                     d[tg] = sol[:, :self.nw]
                     lam_new[tg] = sol[:, self.nw:]
                     todo[tg] = False
+                    for q_, b_ in enumerate(tg):
+                        Kkeep[b_] = K[good][q_]
                 tb = t[~good]
                 for b in tb:                                       # W&B Alg. IC
                     if first_try[b]:
@@ -519,6 +543,7 @@ class DenseIpm:
             dphi = np.einsum('bi,bi->b', gphi, d)
             alpha = alpha_max.copy()
             accepted = np.zeros(nb, dtype=bool)
+            infeasible = np.zeros(nb, dtype=bool)
             resto = np.zeros(nb, dtype=bool)
             armijo_type = np.zeros(nb, dtype=bool)
             accepted[fail] = True                                   # nothing to search
@@ -549,6 +574,47 @@ class DenseIpm:
                         else:
                             ok = (tht[q] <= (1 - o.gamma_theta) * th0[b]) or \
                                  (pht[q] - phi0[b] - rnd <= -o.gamma_phi * th0[b])
+                    if not ok and ls == 0 and o.soc and tht[q] >= th0[b] and Kkeep[b] is not None:
+                        # second-order correction (W&B sec. 2.4): d_soc solves the same system with the constraint value
+                        # c_soc = alpha c(x_k) + c(x_k + alpha d); up to max_soc corrections while theta drops by kappa_soc
+                        c_soc = alpha[b] * c[b] + ct[q]
+                        th_old = tht[q]
+                        for _ in range(o.max_soc):
+                            sol = np.linalg.solve(Kkeep[b], np.concatenate([rhs1[b], -c_soc]))
+                            ds = sol[:self.nw]
+                            slb, sub = self._slacks(w[gb:gb + 1])
+                            with np.errstate(divide='ignore', invalid='ignore'):
+                                a1 = np.where(self.has_l & (ds < 0), -tau[gb] * slb[0] / ds, np.inf).min()
+                                a2 = np.where(self.has_u & (ds > 0), tau[gb] * sub[0] / ds, np.inf).min()
+                            a_s = min(1.0, a1, a2)
+                            ws = w[gb:gb + 1] + a_s * ds[None]
+                            fs, cs = self.eval_fc(ws, self._sl(data, np.array([gb])))
+                            phs = self.barrier(fs, ws, mu[gb:gb + 1])[0]
+                            ths = np.abs(cs).sum()
+                            oks = np.isfinite(phs) and np.isfinite(ths) and ths <= theta_max[gb]
+                            if oks:
+                                for (tf, pf) in filt[gb]:
+                                    if ths >= tf and phs - 10 * np.finfo(float).eps * abs(pf) >= pf:
+                                        oks = False
+                                        break
+                            if oks:
+                                sw2 = (th0[b] <= theta_min[gb]) and (dphi[b] < 0) and \
+                                      (alpha[b] * (-dphi[b]) ** o.s_phi > o.delta * th0[b] ** o.s_theta)
+                                rnd = 10 * np.finfo(float).eps * abs(phi0[b])
+                                if sw2:
+                                    oks = phs - phi0[b] - rnd <= o.eta_phi * alpha[b] * dphi[b]
+                                else:
+                                    oks = (ths <= (1 - o.gamma_theta) * th0[b]) or (phs - phi0[b] - rnd <= -o.gamma_phi * th0[b])
+                                if oks:
+                                    ok, sw = True, sw2
+                                    wt[q] = ws[0]
+                                    lam_new[b] = sol[self.nw:]
+                                    soc_used[gb] += 1
+                                    break
+                            if not (ths <= o.kappa_soc * th_old):
+                                break
+                            th_old = ths
+                            c_soc = a_s * c_soc + cs[0]
                     if ok:
                         accepted[b] = True
                         armijo_type[b] = sw
@@ -569,7 +635,10 @@ class DenseIpm:
                 gb = idx[b]
                 filt[gb].append(((1 - o.gamma_theta) * th0[b], phi0[b] - o.gamma_phi * th0[b]))
                 wr = self._restore(w[gb], self._sl(data, np.array([gb])), mu[gb], tau[gb], filt[gb], theta_max[gb])
-                if wr is None:
+                if isinstance(wr, str):                            # 'infeasible': IPOPT's Infeasible_Problem_Detected -> 3
+                    infeasible[b] = True
+                    fail[b] = True
+                elif wr is None:
                     fail[b] = True
                 else:
                     w_new[b] = wr
@@ -583,7 +652,7 @@ class DenseIpm:
                     armijo_type[b] = True                          # the filter was already augmented
                     n_resto[gb] += 1
             bad = fail
-            status[idx[bad]] = RESTORATION_FAILED
+            status[idx[bad]] = np.where(infeasible[bad], INFEASIBLE, RESTORATION_FAILED)
             active[idx[bad]] = False
             good = ~bad
             for b in np.nonzero(good & ~armijo_type)[0]:           # augment the filter (W&B eq. 22)
@@ -607,7 +676,7 @@ class DenseIpm:
 
         f, g, c, J, Wl = self.eval_all(w, lam, data)
         E0, dual, prim, compl = self.errors(g, c, J, lam, zl, zu, w, np.zeros(B))
-        return dict(w=w, lam=lam, zl=zl, zu=zu, f=f, status=status, iters=iters, kkt=E0, n_resto=n_resto,
+        return dict(w=w, lam=lam, zl=zl, zu=zu, f=f, status=status, iters=iters, kkt=E0, n_resto=n_resto, n_soc=soc_used,
                     dual_inf=dual, prim_inf=prim, compl=compl)
 
     def _restore(self, w, data, mu, tau, filt, theta_max, max_it=50):
@@ -620,13 +689,31 @@ class DenseIpm:
         f, g, c, J, _ = self.eval_all(w, lam0, data)
         th_start = np.abs(c).sum()
         th = th_start
-        for _ in range(max_it):
+        th_ref = th
+        for it_r in range(max_it):
+            # ten iterations without reducing the violation by 1e-4 in total: the iterates sit at a point of locally minimal
+            # infeasibility (IPOPT's restoration NLP would converge there and report Infeasible_Problem_Detected)
+            if it_r % 10 == 9:
+                if th > (1 - 1e-4) * th_ref and th > 1e-6:
+                    return 'infeasible'
+                th_ref = th
+            # step of the restoration subproblem  min 1/2 |d|^2 - mu_R sum ln(slacks)  s.t.  J d = -c  (IPOPT's restoration
+            # NLP keeps its iterates inside the bounds with the barrier of parameter mu_R = max(mu, |c|_inf), W&B sec. 3.3):
+            # the barrier's Newton terms Sigma_R = mu_R / s^2, r_R = -mu_R / s keep the steps away from the bounds, where the
+            # plain least-norm step gets stuck behind the fraction-to-the-boundary rule
+            sl, su = self._slacks(w)
+            mu_r = max(mu, float(np.abs(c).max())) if o.resto_barrier else 0.0
+            sig = np.where(self.has_l, mu_r / sl ** 2, 0.0) + np.where(self.has_u, mu_r / su ** 2, 0.0)
+            rb = -np.where(self.has_l, mu_r / sl, 0.0) + np.where(self.has_u, mu_r / su, 0.0)
             K = np.zeros((self.nw + self.m, self.nw + self.m))
-            K[:self.nw, :self.nw] = np.eye(self.nw)
+            K[:self.nw, :self.nw] = np.eye(self.nw) + np.diag(sig[0])
             K[:self.nw, self.nw:] = J[0].T
             K[self.nw:, :self.nw] = J[0]
             K[self.nw:, self.nw:] = -1e-12 * np.eye(self.m)
-            d = np.linalg.solve(K, np.concatenate([np.zeros(self.nw), -c[0]]))[:self.nw][None]
+            d = np.linalg.solve(K, np.concatenate([-rb[0], -c[0]]))[:self.nw][None]
+            dmax = float(np.abs(d).max())
+            if dmax <= 1e-9 and th > 1e-6:     # stationary point of the restoration problem with violated constraints
+                return 'infeasible'
             sl, su = self._slacks(w)
             with np.errstate(divide='ignore', invalid='ignore'):
                 a1 = np.where(self.has_l & (d < 0), -tau * sl / d, np.inf).min()
@@ -642,7 +729,9 @@ class DenseIpm:
                     break
                 alpha *= 0.5
             if not ok:
-                return None
+                # no step length reduces the violation along the (barrier-deflected) Newton direction of the constraints: a point
+                # of locally minimal infeasibility inside the box
+                return 'infeasible' if th > 1e-6 else None
             w, th = wt, tht
             if th <= 0.9 * th_start and th <= theta_max:
                 ph = self.barrier(ft, w, np.array([mu]))[0]

@@ -216,3 +216,16 @@ def test_soft_terminal_constraint_vs_oracle():
     both = dict(C2S, N=8, terminal_constraint=dict(expr=['S'], lb=[45.], ub=[np.inf], soft=True))
     nmpc, pb, ipm, ref = _compare(both, c2_x0(4), C2['p'])
     assert nmpc._jit and nmpc._e_soft_term_ind == pb.eT_ind and len(pb.e_ind) == 1
+
+
+def test_c5_from_a_cold_zero_velocity_guess_solves_everywhere():
+    """C5 (N = 50, soft speed limit, iterate in the global workspace) started from an all-zero state guess - far from the path,
+    the line search has to go through the feasibility restoration - and three closed-loop steps: every instance status 1."""
+    import torch
+    spec = dict(C5, x_guess=[0., 0., 0., 0., 0., 0.])
+    nmpc = product_gen(spec)
+    x = torch.as_tensor(c5_x0(256), device='cuda')
+    for _ in range(3):
+        u = nmpc.optimize(x)
+        assert np.all(nmpc.solver_status_code == 1), np.unique(nmpc.solver_status_code, return_counts=True)
+        x = nmpc.plant_step(x, u)

@@ -97,7 +97,7 @@ def test_c3_plain_degenerate_problem_still_solves():
     assert np.abs(c).max() < 1e-8
 
 
-@pytest.mark.parametrize('spec,min_success', [(C3B, 1.0), (C3, 0.99)])
+@pytest.mark.parametrize('spec,min_success', [(C3B, 1.0), (C3, 0.995)])
 def test_full_size_batch_properties(spec, min_success):
     """BASELINE config C3 size (B = 4096): instances solved, bounds respected, x_opt = x_N.  The plain C3 NLP is
     degenerate (see C3B in tests/problems.py); a fraction of a percent of its instances ends in status 4."""

@@ -84,4 +84,6 @@ def test_control_horizon_shorter_than_prediction_horizon_vs_slsqp():
     res = minimize(lambda q: pb.objective(q[None], p[None])[0], v[0] + 1e-3,
                    constraints={'type': 'eq', 'fun': lambda q: pb.constraints(q[None], p[None])[0]},
                    bounds=list(zip(lb, ub)), method='SLSQP', options={'ftol': 1e-14, 'maxiter': 500})
-    assert res.success and abs(res.fun - r['f'][0]) < 1e-6 * abs(r['f'][0]) and np.abs(res.x - v[0]).max() < 1e-4
+    # SLSQP may stop with 'positive directional derivative' at the optimum: judge it by what it found
+    assert abs(res.fun - r['f'][0]) < 1e-6 * abs(r['f'][0]) and np.abs(res.x - v[0]).max() < 1e-4
+    assert np.abs(pb.constraints(res.x[None], p[None])).max() < 1e-8
