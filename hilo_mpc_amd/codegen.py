@@ -73,6 +73,13 @@ class Emitter:
                 rhs = f"-1.0 * ({a[0]})"
             elif op in _FUN:
                 rhs = f"{_FUN[op]}({a[0]})"
+            elif op == 'gp':
+                # posterior mean of learned term #value at the features a[...] (csrc/hilo_models.h::gp_se_mean); the features
+                # are brought to their common scalar type (states and inputs may carry different derivative types)
+                g = f"g{len(self.lines)}"
+                self.lines.append(f"    using {g}_t = decltype({' + '.join(['0.0'] + a)});")
+                self.lines.append(f"    const {g}_t {g}[] = {{{', '.join(f'{g}_t({q})' for q in a)}}};")
+                rhs = f"gp_se_mean(hilo_user_gp[{int(e.value)}], {g})"
             elif op == 'powi':
                 n = int(e.value)
                 if n == 0:

@@ -25,6 +25,8 @@ namespace hilo {
 // hilo_gp.hip: device copy of a trained GP's posterior mean in the layout of hilo_models.h::GpExt; the GP must have a
 // squared-exponential kernel over exactly two features and a constant (or zero) mean, HILO_ENOTSUP otherwise
 int gp_pack_se2(const hilo_gp* gp, double** d_pack);
+// the same for any number of active features, in the layout of hilo_models.h::gp_se_mean (run-time compiled models)
+int gp_pack_se(const hilo_gp* gp, double** d_pack);
 
 // thread-local last-error text (hilo_last_error)
 char* err_buf();

@@ -778,6 +778,42 @@ int hilo::gp_pack_se2(const hilo_gp* gp, double** d_pack) {
   return HILO_OK;
 }
 
+// Posterior mean of a squared-exponential GP with a constant / zero mean over ANY number of features, in the layout the
+// run-time compiled models read (hilo_models.h::gp_se_mean): [n, na, sf2, bias, (active dim) * na, M * na, (X_{ad_k, i} * na,
+// alpha_i) * n].  `Model.substitute_from(gp)` of a model written as expressions (dynamic_model.py:3040-3125).
+int hilo::gp_pack_se(const hilo_gp* gp, double** d_pack) {
+  HILO_REQUIRE(gp && d_pack, "gp_pack_se: NULL argument");
+  const double* k = gp->h_kprog;
+  const double* m = gp->h_mprog;
+  const int na = (int)k[1];
+  const bool se = (int)k[0] == HILO_K_GAMMAEXP && na >= 1 && na <= 8 && gp->klen == 3 + na + 3 + na && (int)k[2 + na] == 3 + na &&
+                  k[3 + na + 1] == 0.5 && k[3 + na + 2] == 1.0;
+  const bool cm = gp->mlen == 4 && (int)m[0] == HILO_M_CONST && (int)m[1] == 0;
+  if (!se || !cm)
+    return fail(HILO_ENOTSUP, "a GP inside a run-time compiled model must have a squared-exponential kernel (up to 8 active "
+                              "features) and a constant or zero mean");
+  const int n = gp->n, nf = gp->nf;
+  const size_t len = 4 + 2 * (size_t)na + (size_t)n * (na + 1);
+  double* X = new double[(size_t)nf * n];
+  double* a = new double[n];
+  double* pack = new double[len];
+  hipError_t e = hipSetDevice(gp->device);
+  if (e == hipSuccess) e = hipMemcpy(X, gp->X, sizeof(double) * nf * n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(a, gp->alpha, sizeof(double) * n, hipMemcpyDeviceToHost);
+  pack[0] = n; pack[1] = na; pack[2] = k[3 + na]; pack[3] = m[3];
+  for (int q = 0; q < na; ++q) { pack[4 + q] = k[2 + q]; pack[4 + na + q] = k[3 + na + 3 + q]; }
+  for (int i = 0; i < n; ++i) {
+    double* r = pack + 4 + 2 * na + (size_t)i * (na + 1);
+    for (int q = 0; q < na; ++q) r[q] = X[(size_t)(int)k[2 + q] * n + i];
+    r[na] = a[i];
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)d_pack, sizeof(double) * len);
+  if (e == hipSuccess) e = hipMemcpy(*d_pack, pack, sizeof(double) * len, hipMemcpyHostToDevice);
+  delete[] X; delete[] a; delete[] pack;
+  if (e != hipSuccess) return fail(HILO_EHIP, "gp_pack_se: %s", hipGetErrorString(e));
+  return HILO_OK;
+}
+
 extern "C" int hilo_gp_log_marginal_likelihood(hilo_gp* gp, double* lml_host) {
   HILO_REQUIRE(gp && lml_host, "hilo_gp_log_marginal_likelihood: NULL argument");
   *lml_host = gp->lml;

@@ -26,15 +26,21 @@ struct JitRequest {
   int policy = JIT_TRACK;
   int nth = 0, ne = 0, nc = 0, coll_d = 0, N = 1;
   bool hold = false, cont = false, tv = false, big = false, has_fun = false;
+  bool private_module = false;   // load a module of its own (its learned-term table belongs to ONE handle); the code object
+                                 // still comes from the cache
 };
 
 struct JitKernels {
   hipFunction_t solve = nullptr, plant = nullptr, coll_out = nullptr;
+  hipModule_t owned = nullptr;         // set for a private module: jit_unload() when the handle goes
+  const double** gp_table = nullptr;   // device address of the module's hilo_user_gp[4] (learned terms of the user model)
   int dims[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // nx, nu, np, ny, discrete, lds bytes of the solve kernel, engine NX, engine NU
 };
 
 // compile (or fetch from the in-memory / on-disk cache) and load on `device`; on failure hilo_last_error() holds the compiler log
 int jit_nmpc_kernels(const JitRequest& r, int device, JitKernels* out);
+
+void jit_unload(JitKernels* k);
 
 // launch helpers (hipModuleLaunchKernel)
 int jit_launch_solve(hipFunction_t f, const OcpConst* dev, int64_t batch, const double* x0, const double* par, int64_t par_stride,

@@ -83,6 +83,9 @@ static std::string translation_unit(const JitRequest& r) {
            r.policy, r.nth, r.ne, r.nc, r.coll_d, r.N, (int)r.hold, (int)r.cont, (int)r.tv, (int)r.big, (int)r.has_fun);
   std::string s(cfg);
   s += "#include \"hilo_nmpc_gen.h\"\n#include \"hilo_nmpc_track.h\"\n#include \"hilo_nmpc_user.h\"\n";
+  // device pointers to the packed learned terms (gp_pack_se) the user source refers to as hilo_user_gp[k]; written by the host
+  // after the module is loaded (a module with learned terms is private to its handle: JitRequest::private_module).
+  s += "extern \"C\" { __device__ const double* hilo_user_gp[4]; }\n";   // unmangled: looked up with hipModuleGetGlobal
   s += "namespace hilo {\n";
   s += r.user_source;
   s += R"(
@@ -188,7 +191,7 @@ int jit_nmpc_kernels(const JitRequest& r, int device, JitKernels* out) {
   const std::string mkey = std::string(key) + "@" + std::to_string(device);
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_loaded.find(mkey);
-  if (it != g_loaded.end()) { *out = it->second.k; return HILO_OK; }
+  if (!r.private_module && it != g_loaded.end()) { *out = it->second.k; return HILO_OK; }
 
   const char* env = getenv("HILO_JIT_CACHE");
   const std::string cdir = env && *env ? std::string(env) : dir + "/jit_cache";
@@ -224,15 +227,27 @@ int jit_nmpc_kernels(const JitRequest& r, int device, JitKernels* out) {
   HILO_HIP_CHECK(hipModuleGetFunction(&m.k.plant, m.mod, "hilo_user_plant"));
   HILO_HIP_CHECK(hipModuleGetFunction(&m.k.coll_out, m.mod, "hilo_user_coll_out"));
   HILO_HIP_CHECK(hipModuleGetFunction(&info, m.mod, "hilo_user_info"));
+  {
+    hipDeviceptr_t gptr = nullptr;
+    size_t gbytes = 0;
+    HILO_HIP_CHECK(hipModuleGetGlobal(&gptr, &gbytes, m.mod, "hilo_user_gp"));
+    m.k.gp_table = (const double**)gptr;
+  }
   int* dinfo = nullptr;
   HILO_HIP_CHECK(hipMalloc((void**)&dinfo, sizeof(int) * 8));
   void* args[] = {&dinfo};
   HILO_HIP_CHECK(hipModuleLaunchKernel(info, 1, 1, 1, 1, 1, 1, 0, nullptr, args, nullptr));
   HILO_HIP_CHECK(hipMemcpy(m.k.dims, dinfo, sizeof(int) * 8, hipMemcpyDeviceToHost));
   HILO_HIP_CHECK(hipFree(dinfo));
-  g_loaded[mkey] = m;
+  if (r.private_module) m.k.owned = m.mod;
+  else g_loaded[mkey] = m;
   *out = m.k;
   return HILO_OK;
+}
+
+void jit_unload(JitKernels* k) {
+  if (k && k->owned) (void)hipModuleUnload(k->owned);
+  if (k) *k = JitKernels();
 }
 
 int jit_launch_solve(hipFunction_t f, const OcpConst* dev, int64_t batch, const double* x0, const double* par, int64_t par_stride,

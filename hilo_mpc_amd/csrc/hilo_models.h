@@ -117,6 +117,29 @@ __device__ __forceinline__ Jet2 gp2_mean(const GpExt& e, const Jet2& s, const Je
               o[1] * s.b + o[2] * i.b + o[3] * s.a * s.a + 2.0 * o[4] * s.a * i.a + o[5] * i.a * i.a);
 }
 
+// Learned term of a run-time compiled model: posterior mean of a squared-exponential GP over any number of features, every
+// lane sums all n kernel terms itself in the scalar type it is evaluated with (values, Dual, Jet2) - general, not fast; the
+// two-feature zoo variant above shares the sum among the lanes of a stage.  `feat` holds the GP's features in ITS order
+// (gp.features); pack = hilo_gp.hip::gp_pack_se.
+template <class T>
+__device__ __forceinline__ T gp_se_mean(const double* g, const T* feat) {
+  const int n = (int)g[0], na = (int)g[1];
+  const double sf2 = g[2], bias = g[3];
+  const double* ad = g + 4;
+  const double* Md = g + 4 + na;
+  const double* r = g + 4 + 2 * na;
+  T acc = T(0.0);
+  for (int i = 0; i < n; ++i, r += na + 1) {
+    T d2 = T(0.0);
+    for (int q = 0; q < na; ++q) {
+      const T df = feat[(int)ad[q]] - r[q];
+      d2 = d2 + Md[q] * (df * df);
+    }
+    acc = acc + r[na] * exp(-0.5 * d2);
+  }
+  return bias + sf2 * acc;
+}
+
 // ---- tests/test_KFs.py:247-255: dx1 = -k1 x1 + u, dx2 = k1 x1 - k2 x2, y = x2 -------------------------
 struct Linear2 {
   static constexpr int NX = 2, NU = 1, NP = 2, NY = 1;

@@ -71,6 +71,9 @@ extern "C" void hilo_nmpc_destroy(hilo_nmpc* h) {
   if (h->par_buf) (void)hipFree(h->par_buf);
   if (h->prof) (void)hipFree(h->prof);
   if (h->ext_pack) (void)hipFree(h->ext_pack);
+  for (double* g : h->user_gp_pack)
+    if (g) (void)hipFree(g);
+  jit_unload(&h->jit);
   if (h->ws) (void)hipFree(h->ws);
   if (h->vc) (void)hipFree(h->vc);
   if (h->lamc) (void)hipFree(h->lamc);
@@ -106,7 +109,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   HILO_REQUIRE(nx <= OCP_MAXNX && nu <= OCP_MAXNU, "model too large for this build");
   bool jit_big = false;
   if (jit) {   // the tracking policy compiled for the user's functor: footprint from the dimensions
-    if (d->n_path_var > 0 || d->n_con > 0 || d->n_tcon > 0 || d->collocation_degree > 0 || d->time_varying || d->learned)
+    if (d->n_path_var > 0 || d->n_con > 0 || d->n_tcon > 0 || d->collocation_degree > 0 || d->time_varying || d->learned)   // (learned terms of a user model: desc.user_gp)
       return fail(HILO_ENOTSUP, "a run-time compiled model with path following, constraints, collocation, per-stage data or a "
                                 "learned term needs user_policy 2");
     const int ncost = (nx + nu) * (nx + nu) + (nx + nu) + nx * nx + nx + nu * nu + 1;   // NmpcTrack<M>::NCOST
@@ -393,10 +396,12 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     rq.policy = JIT_TRACK;
     rq.N = d->N;
     rq.big = jit_big;
+    rq.private_module = d->n_user_gp > 0;
     rc = jit_nmpc_kernels(rq, device, &h->jit);
     if (!rc && (h->jit.dims[0] != nx || h->jit.dims[1] != nu || h->jit.dims[2] != np))
       rc = fail(HILO_EINVAL, "hilo_nmpc_create: the compiled UserModel has (nx, nu, np) = (%d, %d, %d), the description says (%d, %d, %d)",
                 h->jit.dims[0], h->jit.dims[1], h->jit.dims[2], nx, nu, np);
+    if (!rc) rc = nmpc_bind_user_gps(h, d);
     if (rc) { hilo_nmpc_destroy(h); return rc; }
     h->jit_policy = JIT_TRACK;
     h->lds_bytes = 0;   // static LDS inside the compiled kernel

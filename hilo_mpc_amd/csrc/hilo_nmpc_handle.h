@@ -38,6 +38,7 @@ struct hilo_nmpc {
   int tv_width;              // doubles per stage of the per-stage data table (0: none)
   size_t jit_ws_bytes;       // per-instance iterate workspace of a run-time compiled problem (0: iterate in LDS)
   int jit_coll_d;            // collocation degree of a run-time compiled problem (output pass needed) or 0
+  double* user_gp_pack[4];   // packed learned terms of a run-time compiled model (gp_pack_se) or NULL
   double* gather;            // caller's gather table (hilo_nmpc_set_gather) or NULL
   int gather_stride;
 };
@@ -46,4 +47,6 @@ struct hilo_nmpc {
 namespace hilo {
 // creation of a problem on the general run-time compiled policy (csrc/hilo_nmpc_user.h)
 int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out);
+// packs desc.user_gp[] and writes the pointers into the loaded module's table; no-op without learned terms
+int nmpc_bind_user_gps(hilo_nmpc* h, const hilo_nmpc_desc* d);
 }

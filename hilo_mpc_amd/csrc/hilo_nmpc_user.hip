@@ -32,7 +32,7 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
     int rc = hilo_model_dims(d->model_id, &mx, &mu, &np, &ny, &discrete);
     if (rc) return rc;
   }
-  if (d->learned) return fail(HILO_ENOTSUP, "a learned term inside a run-time compiled problem is not built");
+  if (d->learned) return fail(HILO_ENOTSUP, "run-time compiled problems take their learned terms through desc.user_gp");
   const int nth = d->n_path_var;
   HILO_REQUIRE(nth >= 0 && nth <= 1, "hilo_nmpc_create: at most one path variable is supported (got %d)", nth);
   const int D = d->collocation_degree;
@@ -230,11 +230,13 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   rq.policy = JIT_USER;
   rq.nth = nth; rq.ne = ne; rq.nc = nc; rq.coll_d = D; rq.N = N;
   rq.hold = hold; rq.cont = cont; rq.tv = tv; rq.big = big; rq.has_fun = d->user_has_fun != 0;
+  rq.private_module = d->n_user_gp > 0;
   int rc = jit_nmpc_kernels(rq, device, &h->jit);
   if (!rc && (h->jit.dims[0] != mx || h->jit.dims[1] != mu || h->jit.dims[2] != np || h->jit.dims[6] != nxe || h->jit.dims[7] != nue))
     rc = fail(HILO_EINVAL, "hilo_nmpc_create: the compiled problem has model (nx, nu, np) = (%d, %d, %d), engine (%d, %d); the "
                            "description says (%d, %d, %d), (%d, %d)", h->jit.dims[0], h->jit.dims[1], h->jit.dims[2], h->jit.dims[6],
               h->jit.dims[7], mx, mu, np, nxe, nue);
+  if (!rc) rc = nmpc_bind_user_gps(h, d);
   if (rc) { hilo_nmpc_destroy(h); return rc; }
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc((void**)&h->dev, sizeof(OcpConst));
@@ -264,6 +266,21 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
     return fail(HILO_EHIP, "hilo_nmpc_create: %s", hipGetErrorString(e));
   }
   *out = h;
+  return HILO_OK;
+}
+
+int nmpc_bind_user_gps(hilo_nmpc* h, const hilo_nmpc_desc* d) {
+  HILO_REQUIRE(d->n_user_gp >= 0 && d->n_user_gp <= 4, "hilo_nmpc_create: at most 4 learned terms (got %d)", d->n_user_gp);
+  if (d->n_user_gp == 0) return HILO_OK;
+  HILO_REQUIRE(h->jit.gp_table, "hilo_nmpc_create: the compiled module exports no learned-term table");
+  const double* table[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int k = 0; k < d->n_user_gp; ++k) {
+    HILO_REQUIRE(d->user_gp[k], "hilo_nmpc_create: user_gp[%d] is NULL", k);
+    int rc = gp_pack_se(d->user_gp[k], &h->user_gp_pack[k]);
+    if (rc) return rc;
+    table[k] = h->user_gp_pack[k];
+  }
+  HILO_HIP_CHECK(hipMemcpy((void*)h->jit.gp_table, table, sizeof(table), hipMemcpyHostToDevice));
   return HILO_OK;
 }
 

@@ -64,6 +64,35 @@ class Expr:
             return self.name
         return f"{self.op}({', '.join(map(repr, self.args))})"
 
+    # ---- substitution --------------------------------------------------------------------------------------
+    def nodes(self, out=None):
+        """All distinct nodes below (and including) this one, keyed by id."""
+        out = {} if out is None else out
+        stack = [self]
+        while stack:
+            n = stack.pop()
+            if id(n) not in out:
+                out[id(n)] = n
+                stack.extend(n.args)
+        return out
+
+    @staticmethod
+    def substitute(exprs, leaf):
+        """Rebuilds `exprs` with every leaf replaced by `leaf(node)` (None = keep).  Sharing is preserved and the new nodes
+        are created in the creation order of the old ones, so the emitted code keeps the order of the user's statements."""
+        allnodes = {}
+        for e in exprs:
+            e.nodes(allnodes)
+        new = {}
+        for n in sorted(allnodes.values(), key=lambda q: q.serial):
+            if n.args:
+                a = tuple(new[id(c)] for c in n.args)
+                new[id(n)] = n if all(x is y for x, y in zip(a, n.args)) else Expr(n.op, a, n.value, n.name)
+            else:
+                r = leaf(n)
+                new[id(n)] = n if r is None else r
+        return [new[id(e)] for e in exprs]
+
     # ---- compilation ---------------------------------------------------------------------------------------
     def depends_on(self, kind):
         return self.op == kind or any(a.depends_on(kind) for a in self.args)
@@ -86,6 +115,8 @@ class Expr:
             out += [X_VARX, float(theta_index)]
         elif op == 'powi':
             out += [X_POWI, float(self.value)]
+        elif op == 'gp':
+            raise ValueError("a learned term cannot be evaluated by the device interpreter (run-time compiled models only)")
         else:
             out += [{'add': X_ADD, 'sub': X_SUB, 'mul': X_MUL, 'div': X_DIV, 'neg': X_NEG, 'sq': X_SQ, 'sin': X_SIN,
                      'cos': X_COS, 'exp': X_EXP, 'log': X_LOG, 'sqrt': X_SQRT}[op], 0.]

@@ -64,6 +64,7 @@ class Model:
             self.n_x = self.n_u = self.n_p = self.n_y = 0
             self._ode, self._meas = None, []
             self.learned = None
+            self._gps = []              # trained GPs substituted into the equations (substitute_from)
             return
         self._symbolic = False
         self.name = name
@@ -219,7 +220,13 @@ class Model:
         variables (:3056-3061).  The device zoo offers this for the growth rate `mu` of 'chemostat4' over the
         features (S, I) (`nmpc_hybrid_bio.ipynb`); the GP must be trained (`setup` + `fit_model` or `set_training_data`
         + `setup`) with a squared-exponential kernel and a constant/zero mean."""
-        if self._symbolic or self.name not in LEARNABLE:
+        if isinstance(obj, (list, tuple, set)):
+            for o in obj:
+                self.substitute_from(o)
+            return self
+        if self._symbolic:
+            return self._substitute_symbolic(obj)
+        if self.name not in LEARNABLE:
             raise NotImplementedError(f"model '{self.name}' has no learnable term in the device zoo "
                                       f"(available: {sorted(LEARNABLE)})")
         label, features, hybrid = LEARNABLE[self.name]
@@ -234,6 +241,53 @@ class Model:
         m.model_id = ZOO[hybrid][0]
         m.learned = obj
         return m
+
+    def _substitute_symbolic(self, gp):
+        """The general case for a model written as expressions: the label must be a parameter (the reference only handles
+        parameters either, dynamic_model.py:3000-3004 `self._p.remove`), which leaves the parameter vector; the features are
+        states, inputs or remaining parameters, looked up by name (:3056-3061).  In the compiled right-hand side the
+        parameter becomes `gp_se_mean(<packed GP>, features)` (csrc/hilo_models.h), differentiated like any other
+        operation by the scalar type it is evaluated with."""
+        labels, features = list(getattr(gp, 'labels', [])), list(getattr(gp, 'features', []))
+        if len(labels) != 1 or not callable(getattr(gp, 'predict', None)):
+            raise ValueError("substitute_from takes a learned model with exactly one label")
+        if getattr(gp, '_handle', None) is None:
+            raise RuntimeError("The GP has not been set up (trained) yet. Run GaussianProcess.setup() first.")
+        if self._ode is None:
+            raise RuntimeError("set the model equations before substituting a learned term")
+        if labels[0] not in self.parameter_names:
+            raise ValueError(f"label '{labels[0]}' is not a parameter of model '{self.name}' (parameters: "
+                             f"{self.parameter_names})")
+        if len(self._gps) >= 4:
+            raise NotImplementedError("at most 4 learned terms per model")
+        ip = self.parameter_names.index(labels[0])
+        keep = [n for n in self.parameter_names if n != labels[0]]
+        newp = SymVector('p', keep)
+        feats = []
+        for f in features:
+            if f == labels[0]:
+                raise ValueError(f"feature '{f}' is the label itself")
+            for vec in (self.x, self.u, newp):
+                if f in vec._names:
+                    feats.append(vec[f])
+                    break
+            else:
+                raise ValueError(f"feature '{f}' is not a state, input or parameter of model '{self.name}'")
+        node = Expr('gp', feats, value=len(self._gps), name=labels[0])
+
+        def leaf(n):
+            if n.op != 'p':
+                return None
+            i = int(n.value)
+            return node if i == ip else (newp[i - 1] if i > ip else None)
+
+        neq = len(self._ode)
+        out = Expr.substitute(self._ode + self._meas, leaf)
+        self._ode, self._meas = out[:neq], out[neq:]
+        self.parameter_names, self.n_p = keep, len(keep)
+        self._gps.append(gp)
+        self._is_setup = False
+        return self
 
     def copy(self):
         return copy.copy(self)

@@ -657,6 +657,10 @@ class NMPC:
             d.user_policy = policy
             d.user_nx, d.user_nu, d.user_np, d.user_ny = m.n_x, m.n_u, m.n_p, m.n_y
             d.user_discrete = int(getattr(m, '_native_discrete', False))
+            gps = list(getattr(m, '_gps', []))
+            d.n_user_gp = len(gps)
+            for k, g in enumerate(gps):
+                d.user_gp[k] = g._handle.value if hasattr(g._handle, 'value') else g._handle
 
         h = C.c_void_p()
         if sym or need_user:

@@ -282,6 +282,11 @@ typedef struct hilo_nmpc_desc {
   int32_t user_policy;
   int32_t objective_continuous;   /* 1: integrate the Lagrange term with the shooting map (optimizer.py:1423-1426) */
   const double* coll_B;           /* [d+1] quadrature weights B_i of the collocation basis (modeling.py:1124), continuous objective */
+  /* learned terms of a run-time compiled model (`Model.substitute_from(gp)`, dynamic_model.py:3040-3125): up to 4 trained GPs
+     (squared-exponential kernel over up to 8 features, constant / zero mean); the emitted model refers to them as
+     gp_se_mean(hilo_user_gp[k], features) (csrc/hilo_models.h) */
+  int32_t n_user_gp; int32_t reserved5;
+  const hilo_gp* user_gp[4];
   /* with user_policy 2 the constraint / path expressions are compiled into UserFun: n_con, n_tcon, n_path_stage, n_path_term
      count them as above, the *_prog pointers stay NULL */
 } hilo_nmpc_desc;

@@ -45,6 +45,20 @@ def symbolic_model(name):
         D = u[0] + u[1]
         m.set_dynamical_equations([mu * X - D * X, -(Rs * X) - D * S + u[0] * p[0], Rfp * X - D * Pr, -(D * I) + u[1] * p[1]])
         m.set_measurement_equations([X, Pr])
+    elif name == 'chemostat4_mu':
+        # the chemostat whose growth rate of the biomass balance is a parameter `mu` - to be replaced by a learned model
+        # (`model.substitute_from(gp)`, nmpc_hybrid_bio.ipynb); the other rates keep their closed forms
+        x = m.set_dynamical_states(['X', 'S', 'P', 'I'])
+        u = m.set_inputs(['DS', 'DI'])
+        p = m.set_parameters(['Sf', 'If', 'ISF', 'IRF', 'mu'])
+        X, S, Pr, I = x
+        phi = 0.407 * S / (0.108 + S + S * S / 14814.0)
+        Rs = 2.0 * (phi * (p[2] + 0.22 * p[3] / (0.22 + I)))
+        Rfp = phi * (0.0005 + I) / (0.022 + I)
+        D = u[0] + u[1]
+        m.set_dynamical_equations([p['mu'] * X - D * X, -(Rs * X) - D * S + u[0] * p[0], Rfp * X - D * Pr,
+                                   -(D * I) + u[1] * p[1]])
+        m.set_measurement_equations([X, Pr])
     elif name == 'pendulum4':
         x = m.set_dynamical_states(['x', 'v', 'theta', 'omega'])
         u = m.set_inputs(['F'])

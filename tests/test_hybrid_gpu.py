@@ -80,13 +80,91 @@ def test_hybrid_differs_from_first_principles_and_closes_the_loop():
     assert np.all(np.isfinite(x)) and np.all(x >= -1e-6)
 
 
+def test_learned_term_in_a_model_written_as_expressions_equals_the_zoo_hybrid():
+    """`substitute_from` as a mechanism (row a17): the chemostat written as expressions with a PARAMETER `mu`, replaced by
+    the trained GP and compiled at setup, against the precompiled hybrid functor - same shooting map (the kernel sum is
+    taken in a different order: 1e-12), same optimum and status."""
+    from tests.problems import symbolic_model
+    gp = product_gp()
+    m = symbolic_model('chemostat4_mu')
+    assert m.parameter_names == ['Sf', 'If', 'ISF', 'IRF', 'mu']
+    m.substitute_from(gp)
+    assert m.parameter_names == ['Sf', 'If', 'ISF', 'IRF'] and m.n_p == 4          # the label leaves the parameter vector
+    sym, zoo = product_nmpc(C4, model=m), product_nmpc(C4, gp=gp)
+    assert sym._jit and 'gp_se_mean(hilo_user_gp[0]' in sym._user_source
+    rng = np.random.default_rng(7)
+    B = 64
+    x = np.array([.1, 40., 0., 0.]) * (1 + .3 * rng.uniform(-1, 1, (B, 4))) + np.array([0, 0, .5, .5]) * rng.uniform(0, 1, (B, 4))
+    u = rng.uniform(0, 1, (B, 2))
+    np.testing.assert_allclose(sym.plant_step(x, u, cp=C4['p']).cpu().numpy(), zoo.plant_step(x, u, cp=C4['p']).cpu().numpy(),
+                               rtol=1e-12, atol=1e-14)
+    x0 = c2_x0(8)
+    us, uz = sym.optimize(x0, cp=C4['p']), zoo.optimize(x0, cp=C4['p'])
+    assert np.array_equal(sym.solver_status_code, zoo.solver_status_code) and np.all(zoo.solver_status_code == 1)
+    np.testing.assert_allclose(us, uz, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(sym._nlp_solution['f'].cpu().numpy(), zoo._nlp_solution['f'].cpu().numpy(), rtol=1e-10)
+    # a second controller on a DIFFERENT GP shares the code object but not the learned-term table
+    X, y = __import__('tests.problems', fromlist=['c4_training_data']).c4_training_data(seed=99)
+    gp2 = product_gp(X, 1.5 * y)
+    m2 = symbolic_model('chemostat4_mu')
+    m2.substitute_from(gp2)
+    sym2 = product_nmpc(C4, model=m2)
+    u2 = sym2.optimize(x0, cp=C4['p'])
+    assert np.abs(u2 - us).max() > 1e-3
+    # the first one is unaffected (warm-started now: same optimum to solver accuracy, not the same round-off path)
+    np.testing.assert_allclose(sym.optimize(x0, cp=C4['p']), us, rtol=1e-6, atol=1e-8)
+
+
+def test_learned_term_over_state_input_and_parameter_features():
+    """Features are looked up by name among states, inputs and parameters (dynamic_model.py:3056-3061); three features,
+    constant mean.  The compiled shooting map against RK4 in numpy with `gp.predict` for the rate."""
+    from hilo_mpc_amd import GP, Kernel, Mean, NMPC
+    from tests.problems import symbolic_model
+    rng = np.random.default_rng(11)
+    n = 60
+    Xt = np.stack([rng.uniform(0, 40, n), rng.uniform(0, 1, n), rng.uniform(.5, 1.5, n)])
+    yt = (0.4 * Xt[0] / (1. + Xt[0]) * Xt[2] - .05 * Xt[1])[None, :]
+    gp = GP(['S', 'DS', 'ISF'], ['mu'], kernel=Kernel.squared_exponential(active_dims=[0, 1, 2], length_scales=[8., .7, .6],
+                                                                          ard=True, signal_variance=.8),
+            mean=Mean.constant(bias=.1), noise_variance=1e-3)
+    gp.set_training_data(Xt, yt)
+    gp.setup()
+    m = symbolic_model('chemostat4_mu')
+    m.substitute_from(gp)
+    m = m.discretize('erk', order=4).setup(dt=.5)
+    nmpc = NMPC(m)
+    nmpc.quad_stage_cost.add_states(names=['X'], weights=[1.], ref=[1.])
+    nmpc.horizon = 5
+    nmpc.setup(options={'integration_method': 'discrete'})
+    B = 32
+    x = np.array([.1, 30., .1, .2]) * (1 + .3 * rng.uniform(-1, 1, (B, 4)))
+    u = rng.uniform(0, 1, (B, 2))
+    p = np.array([40., 4., 1., .3])
+
+    def rhs(x):
+        X, S, Pr, I = x.T
+        mu = np.asarray(gp.predict(np.stack([S, u[:, 0], np.full(B, p[2])]))[0]).ravel()
+        phi = 0.407 * S / (0.108 + S + S * S / 14814.0)
+        Rs = 2.0 * (phi * (p[2] + 0.22 * p[3] / (0.22 + I)))
+        Rfp = phi * (0.0005 + I) / (0.022 + I)
+        D = u[:, 0] + u[:, 1]
+        return np.stack([mu * X - D * X, -(Rs * X) - D * S + u[:, 0] * p[0], Rfp * X - D * Pr, -(D * I) + u[:, 1] * p[1]], 1)
+
+    h = .5
+    k1 = rhs(x); k2 = rhs(x + h / 2 * k1); k3 = rhs(x + h / 2 * k2); k4 = rhs(x + h * k3)
+    ref = x + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+    np.testing.assert_allclose(nmpc.plant_step(x, u, cp=p).cpu().numpy(), ref, rtol=1e-9, atol=1e-11)
+    nmpc.optimize(x[:4], cp=p)
+    assert np.all(nmpc.solver_status_code == 1)
+
+
 def test_substitute_from_errors():
     from hilo_mpc_amd import GP, Kernel, Model
     gp = GP(['S', 'I'], ['mu'])
     with pytest.raises(RuntimeError, match="has not been set up"):
         Model('chemostat4').substitute_from(gp)
     with pytest.raises(NotImplementedError, match="no learnable term"):
-        Model('pendulum4').substitute_from(gp)
+        Model('pendulum4').substitute_from(product_gp())
     bad = GP(['X', 'S'], ['mu'])
     with pytest.raises(ValueError, match="labels"):
         Model('chemostat4').substitute_from(bad)

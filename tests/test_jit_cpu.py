@@ -1,0 +1,61 @@
+"""Generated sources compile for gfx950 (hiprtc needs no GPU): the expression front-end (hilo_mpc_amd/codegen.py) against the
+engine headers, including a learned term inside a model written as expressions.  Nothing is executed
+here - the GPU suite (tests/test_jit_gpu.py, tests/test_hybrid_gpu.py) runs the same sources."""
+import pytest
+
+from hilo_mpc_amd import _lib, codegen
+from tests.problems import symbolic_model
+
+
+class _TrainedGp:
+    """What `substitute_from` looks at: labels, features, a callable predict, a handle (never dereferenced here)."""
+
+    def __init__(self, features, labels):
+        self.features, self.labels, self._handle = list(features), list(labels), object()
+
+    def predict(self, X):
+        raise AssertionError
+
+
+def _compile(src, policy=0, nth=0, ne=0, nc=0, coll_d=0, N=8, hold=0, cont=0, tv=0, big=0, has_fun=0):
+    _lib.check(_lib.lib().hilo_jit_precompile(src.encode(), policy, nth, ne, nc, coll_d, N, hold, cont, tv, big, has_fun))
+
+
+def test_learned_term_substitution_rewrites_the_parameter_vector():
+    m = symbolic_model('chemostat4_mu')
+    m.substitute_from(_TrainedGp(['S', 'DS', 'ISF'], ['mu']))
+    assert m.parameter_names == ['Sf', 'If', 'ISF', 'IRF'] and m.n_p == 4 and len(m._gps) == 1
+    src = m.user_source()
+    assert 'gp_se_mean(hilo_user_gp[0], g' in src and 'p[4]' not in src
+    # the features in the GP's order: state S = x[1], input DS = u[0], parameter ISF = p[2]
+    line = [ln for ln in src.splitlines() if '_t(' in ln][0]
+    assert [q.split('(')[1].rstrip(')') for q in line.split('{')[1].split('}')[0].split(', ')] == ['x[1]', 'u[0]', 'p[2]']
+
+
+def test_substitute_errors():
+    m = symbolic_model('chemostat4_mu')
+    with pytest.raises(ValueError, match="not a parameter"):
+        m.substitute_from(_TrainedGp(['S'], ['X']))
+    with pytest.raises(ValueError, match="is not a state, input or parameter"):
+        m.substitute_from(_TrainedGp(['nope'], ['mu']))
+    with pytest.raises(ValueError, match="exactly one label"):
+        m.substitute_from(_TrainedGp(['S'], ['mu', 'Sf']))
+    untrained = _TrainedGp(['S'], ['mu'])
+    untrained._handle = None
+    with pytest.raises(RuntimeError, match="has not been set up"):
+        m.substitute_from(untrained)
+
+
+@pytest.mark.parametrize('policy', [0, 2])
+def test_generated_hybrid_model_compiles(policy):
+    m = symbolic_model('chemostat4_mu')
+    m.substitute_from(_TrainedGp(['S', 'I'], ['mu']))
+    src = m.user_source()
+    if policy == 2:
+        src += codegen.fun_source(m.n_x)
+    _compile(src, policy=policy, has_fun=int(policy == 2))
+
+
+def test_compile_error_is_reported_with_the_compiler_log():
+    with pytest.raises(ValueError, match="run-time compilation"):
+        _compile("struct UserModel { this is not C++ };\n")
