@@ -120,6 +120,68 @@ def _solve_roofline(kernel, B, mean_iters, nx, nu, N, ops, kern_ms, tag, n_v, n_
                     "algorithmic_bytes_per_launch": bytes_launch, "note": "compulsory bytes only; not the binding roof"}}
 
 
+def cpu_baseline_c2(spec, nst=50):
+    """the C++17 / OpenMP Riccati interior point of oracle/cpu (validated against the numpy oracle in
+    tests/test_cpu_baseline.py: same statuses, iteration counts and solutions) on the SAME closed-loop workload - 5 warm-up
+    + 50 timed warm-started steps - with all host cores and with one; plus scipy SLSQP on the identical transcribed NLP."""
+    from oracle.cpu import CpuNmpc, max_threads
+    from tests import problems as P
+    pb = P.oracle_problem(spec)
+    cpu = CpuNmpc(pb)
+    C = max_threads()
+
+    def loop(nb, nt, nst=nst, nwarm=5):
+        xs, v, t0, its = P.c2_x0(nb), None, 0.0, []
+        for k in range(nwarm + nst):
+            if k == nwarm:
+                t0 = time.perf_counter()
+            r = cpu.solve(xs, spec['p'], v0=v, n_threads=nt)
+            xs, v = cpu.plant_step(xs, r['u0'], spec['p'], n_threads=nt), r['v']
+            if k >= nwarm:
+                its.append(r['iters'].mean())
+        secs = time.perf_counter() - t0
+        return nb * nst / secs, secs, float(np.mean(its)), float(np.mean((r['status'] == 1) | (r['status'] == 2)))
+    nb_all = 1024
+    v_all, s_all, it_all, ok_all = loop(nb_all, C)
+    v_one, s_one, _, _ = loop(128, 1, nst=min(nst, 20))
+    # secondary reference point: an off-the-shelf dense NLP solver (scipy SLSQP) cold on one instance of the same NLP, with the
+    # oracle's exact gradient and constraint Jacobian (x_0 substituted: the free variables of the oracle are v without x_0)
+    from oracle.nmpc import DenseIpm
+    from scipy.optimize import minimize
+    ipm = DenseIpm(pb)
+    data = {'x0': P.c2_x0(1) / pb.sx, 'p': np.atleast_2d(np.asarray(spec['p'], dtype=float))}
+    lam0, cache = np.zeros((1, ipm.m)), {}
+
+    def ev(w):
+        k = w.tobytes()
+        if k not in cache:
+            cache.clear()
+            f, g, c, J, _ = ipm.eval_all(w[None], lam0, data)
+            cache[k] = (f[0], g[0], c[0], J[0])
+        return cache[k]
+    nx = pb.nx
+    t0 = time.perf_counter()
+    sol = minimize(lambda w: ev(w)[0], np.concatenate([np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N)]),
+                   jac=lambda w: ev(w)[1], method='SLSQP', bounds=list(zip(pb.v_lb[nx:], pb.v_ub[nx:])),
+                   constraints=[{'type': 'eq', 'fun': lambda w: ev(w)[2], 'jac': lambda w: ev(w)[3]}],
+                   options={'ftol': 1e-12, 'maxiter': 500})
+    slsqp_ms = (time.perf_counter() - t0) * 1e3
+    model = ''
+    try:
+        model = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
+    except Exception:
+        pass
+    return {"value": v_all, "unit": "steps/s", "cores": C, "kind": "port", "one_core_value": v_one,
+            "cpu_model": model, "mean_ipm_iters": it_all, "frac_status_1_or_2": ok_all,
+            "slsqp_ms_per_solve": slsqp_ms, "slsqp_iterations": int(sol.nit),
+            "sample": f"oracle/cpu C++17/OpenMP Riccati interior point (same algorithm and constants as the numpy oracle, validated "
+                      f"against it): C2 closed loop, {nb_all} instances x {nst} warm-started steps on {C} threads ({s_all:.1f} s); "
+                      f"one_core_value: 128 instances x {min(nst, 20)} steps on 1 thread ({s_one:.1f} s); slsqp: scipy SLSQP with the oracle's exact "
+                      f"derivatives, cold, one instance of the same NLP (converged: {bool(sol.success)}); the reference's CasADi/IPOPT is not installable",
+            "host_cpus": os.cpu_count()}
+
+
+
 def wl_nmpc(cfg, args, torch, dev, rank, world):
     from hilo_mpc_amd.dist import StepGather, shard_range
     from tests import problems as P
@@ -178,6 +240,8 @@ def wl_nmpc(cfg, args, torch, dev, rank, world):
         return extra, roof, ("weak" if cfg == 'C2' else "strong")
 
     def cpu():
+        if cfg == 'C2':
+            return cpu_baseline_c2(spec)
         t0 = time.perf_counter()
         if cfg == 'C5':
             from oracle.nmpc_gen import GenIpm
@@ -191,9 +255,9 @@ def wl_nmpc(cfg, args, torch, dev, rank, world):
             what = "GenIpm (dense KKT, numpy)"
         else:
             from oracle.nmpc import DenseIpm
-            pb = P.oracle_problem(spec) if cfg == 'C2' else P.oracle_c4()[0]
+            pb = P.oracle_c4()[0]
             ipm = DenseIpm(pb)
-            ns, nst = (40, 8) if cfg == 'C2' else (4, 2)
+            ns, nst = 4, 2
             xs = P.c2_x0(ns)
             res = ipm.solve(xs, spec['p'])
             xs = pb.phi(xs / pb.sx, res['U'][:, 0], spec['p']) * pb.sx

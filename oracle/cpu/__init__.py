@@ -1,0 +1,104 @@
+"""ctypes front of the C++/OpenMP CPU baseline (oracle/cpu/nmpc_cpu.cpp).
+
+TEST INFRASTRUCTURE / BASELINE ONLY - used by tests/test_cpu_baseline.py and by bench.py's `cpu_baseline` leg, never by the
+product package.  The library takes the product's own problem descriptor (`hilo_nmpc_desc`, include/hilo_hip.h); here the
+descriptor is filled from the oracle's `NmpcProblem`, so the C++ solver and the numpy solver see the same numbers.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, 'libhilo_cpu.so')
+_lib = None
+
+
+def build(force=False):
+    src = [os.path.join(HERE, 'nmpc_cpu.cpp'), os.path.join(HERE, '..', '..', 'include', 'hilo_hip.h')]
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
+        subprocess.check_call(['make', '-s', '-C', HERE] + (['-B'] if force else []))
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB)
+        i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
+        _lib.hilo_cpu_last_error.restype = C.c_char_p
+        _lib.hilo_cpu_nmpc_create.argtypes = [vp, C.POINTER(vp)]
+        _lib.hilo_cpu_nmpc_destroy.argtypes = [vp]
+        _lib.hilo_cpu_nmpc_destroy.restype = None
+        _lib.hilo_cpu_nmpc_solve.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+        _lib.hilo_cpu_plant_step.argtypes = [vp, i64, vp, vp, vp, i64, vp, C.c_int]
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().hilo_cpu_last_error().decode())
+
+
+class CpuNmpc:
+    """Tracking NMPC of an oracle `NmpcProblem` on the C++ baseline."""
+
+    def __init__(self, pb, **options):
+        from hilo_mpc_amd._lib import NmpcDesc              # the ctypes mirror of hilo_nmpc_desc (tests/test_abi.py checks it)
+        self.pb = pb
+        d = NmpcDesc()
+        d.model_id, d.N, d.erk_order, d.n_sub, d.dt = pb.model.model_id, pb.N, pb.order, pb.smap.n_sub, pb.dt
+        d.bound_relax_factor = -1.
+        for k, v in options.items():
+            setattr(d, k, v)
+        keep = []
+
+        def hp(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            keep.append(a)
+            return a.ctypes.data
+        d.Wz, d.zref, d.WN, d.xrefN = hp(pb.Wz), hp(pb.zref), hp(pb.WN), hp(pb.xrefN)
+        d.x_lb, d.x_ub, d.u_lb, d.u_ub = hp(pb.x_lb * pb.sx), hp(pb.x_ub * pb.sx), hp(pb.u_lb * pb.su), hp(pb.u_ub * pb.su)
+        d.x_scaling, d.u_scaling = hp(pb.sx), hp(pb.su)
+        d.x_guess, d.u_guess = hp(pb.x_guess * pb.sx), hp(pb.u_guess * pb.su)
+        if np.abs(pb.Wdu).max() > 0 or pb.Nc != pb.N:
+            raise NotImplementedError("the CPU baseline covers tracking NMPC with box bounds only")
+        h = C.c_void_p()
+        _check(lib().hilo_cpu_nmpc_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self.n_v = (pb.N + 1) * pb.nx + pb.N * pb.nu
+
+    def __del__(self):
+        if getattr(self, '_h', None) is not None and _lib is not None:
+            _lib.hilo_cpu_nmpc_destroy(self._h)
+            self._h = None
+
+    def solve(self, x0, p, v0=None, n_threads=0):
+        pb = self.pb
+        x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
+        B = x0.shape[0]
+        par = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(np.asarray(p, dtype=np.float64)), (B, pb.np_))) if pb.np_ else None
+        v0 = None if v0 is None else np.ascontiguousarray(np.broadcast_to(v0, (B, self.n_v)), dtype=np.float64)
+        v, f, u0 = np.empty((B, self.n_v)), np.empty(B), np.empty((B, pb.nu))
+        st, it, kkt = np.empty(B, np.int32), np.empty(B, np.int32), np.empty(B)
+        _check(lib().hilo_cpu_nmpc_solve(self._h, B, x0.ctypes.data, par.ctypes.data if par is not None else None, pb.np_,
+                                         v0.ctypes.data if v0 is not None else None, v.ctypes.data, f.ctypes.data, u0.ctypes.data,
+                                         st.ctypes.data, it.ctypes.data, kkt.ctypes.data, int(n_threads)))
+        return dict(v=v, f=f, u0=u0, status=st, iters=it, kkt=kkt)
+
+    def plant_step(self, x, u, p, n_threads=0):
+        pb = self.pb
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        B = x.shape[0]
+        u = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(u), (B, pb.nu)), dtype=np.float64)
+        par = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(np.asarray(p, dtype=np.float64)), (B, pb.np_))) if pb.np_ else None
+        xn = np.empty_like(x)
+        _check(lib().hilo_cpu_plant_step(self._h, B, x.ctypes.data, u.ctypes.data, par.ctypes.data if par is not None else None,
+                                         pb.np_, xn.ctypes.data, int(n_threads)))
+        return xn
+
+
+def max_threads():
+    return int(lib().hilo_cpu_max_threads())

@@ -93,7 +93,8 @@ def check(elf):
 def main(lib):
     total = 0
     with tempfile.TemporaryDirectory() as tmp:
-        for elf in code_objects(lib, tmp):
+        # a run-time compiled code object (jit_cache/*.hsaco) is a plain gfx950 ELF, the library a fat binary of several
+        for elf in ([lib] if lib.endswith('.hsaco') else code_objects(lib, tmp)):
             for func, bad in check(elf):
                 total += 1
                 print(f'{func}:')
