@@ -111,15 +111,21 @@ def model_source(n_x, n_u, n_p, ode, meas, discrete):
     yy = [em2.ref(e) for e in meas]
     body2 = em2.lines + [f"    y[{i}] = T({r});" for i, r in enumerate(yy)]
     n_y = len(meas)
-    return (f"struct UserModel {{\n"
-            f"  static constexpr int NX = {n_x}, NU = {n_u}, NP = {n_p}, NY = {n_y};\n"
-            f"  static constexpr bool DISCRETE = {'true' if discrete else 'false'};\n"
-            f"  template <class T, class U, class P>\n"
-            f"  __device__ __forceinline__ static void ode(const T* x, const U* u, const P* p, double dt, T* dx) {{\n"
-            f"    (void)x; (void)u; (void)p; (void)dt;\n" + '\n'.join(body) + "\n  }\n"
-            f"  template <class T, class U, class P>\n"
-            f"  __device__ __forceinline__ static void meas(const T* x, const U* u, const P* p, double dt, T* y) {{\n"
-            f"    (void)x; (void)u; (void)p; (void)dt; (void)y;\n" + '\n'.join(body2) + "\n  }\n};\n")
+    src = (f"struct UserModel {{\n"
+           f"  static constexpr int NX = {n_x}, NU = {n_u}, NP = {n_p}, NY = {n_y};\n"
+           f"  static constexpr bool DISCRETE = {'true' if discrete else 'false'};\n"
+           f"  template <class T, class U, class P>\n"
+           f"  __device__ __forceinline__ static void ode(const T* x, const U* u, const P* p, double dt, T* dx) {{\n"
+           f"    (void)x; (void)u; (void)p; (void)dt;\n" + '\n'.join(body) + "\n  }\n"
+           f"  template <class T, class U, class P>\n"
+           f"  __device__ __forceinline__ static void meas(const T* x, const U* u, const P* p, double dt, T* y) {{\n"
+           f"    (void)x; (void)u; (void)p; (void)dt; (void)y;\n" + '\n'.join(body2) + "\n  }\n};\n")
+    # symbolic first / second derivatives for the engine's derivative phase (csrc/hilo_ocp.h::eval_derivs_sym); a model with
+    # a learned term keeps the Taylor sweeps
+    if not any(n.op == 'gp' for e in ode for n in Expr.wrap(e).nodes().values()):
+        from .symdiff import sym_source
+        src += sym_source('UserModel', n_x, n_u, ode)
+    return src
 
 
 def zoo_alias(functor):

@@ -109,6 +109,34 @@ HD double rcp_fast(double x) {
 #endif
 }
 
+// A double whose division is x * rcp_fast(y) (1-2 ulp) instead of the IEEE sequence (a ~150-cycle dependent chain): the scalar
+// type the engine's derivative phase evaluates model right-hand sides with - the same rounding the Taylor numbers below use
+// for their value component.
+struct FastD {
+  double v;
+  HD FastD() {}
+  HD FastD(double c) : v(c) {}
+};
+HD FastD operator+(FastD a, FastD b) { return FastD(a.v + b.v); }
+HD FastD operator-(FastD a, FastD b) { return FastD(a.v - b.v); }
+HD FastD operator-(FastD a) { return FastD(-a.v); }
+HD FastD operator*(FastD a, FastD b) { return FastD(a.v * b.v); }
+HD FastD operator/(FastD a, FastD b) { return FastD(a.v * rcp_fast(b.v)); }
+HD FastD operator+(FastD a, double c) { return FastD(a.v + c); }
+HD FastD operator+(double c, FastD a) { return FastD(c + a.v); }
+HD FastD operator-(FastD a, double c) { return FastD(a.v - c); }
+HD FastD operator-(double c, FastD a) { return FastD(c - a.v); }
+HD FastD operator*(FastD a, double c) { return FastD(a.v * c); }
+HD FastD operator*(double c, FastD a) { return FastD(c * a.v); }
+HD FastD operator/(FastD a, double c) { return FastD(a.v * (1.0 / c)); }
+HD FastD operator/(double c, FastD a) { return FastD(c * rcp_fast(a.v)); }
+HD FastD sin(FastD a) { return FastD(::sin(a.v)); }
+HD FastD cos(FastD a) { return FastD(::cos(a.v)); }
+HD FastD exp(FastD a) { return FastD(::exp(a.v)); }
+HD FastD log(FastD a) { return FastD(::log(a.v)); }
+HD FastD sqrt(FastD a) { return FastD(::sqrt(a.v)); }
+HD FastD sq(FastD a) { return FastD(a.v * a.v); }
+
 struct Jet2 {
   double v, a, b;
   HD Jet2() {}

@@ -79,8 +79,8 @@ static std::string translation_unit(const JitRequest& r) {
            "#define HILO_USER_POLICY %d\n"
            "#define HILO_USER_NTH %d\n#define HILO_USER_NE %d\n#define HILO_USER_NC %d\n#define HILO_USER_COLL_D %d\n"
            "#define HILO_USER_N %d\n#define HILO_USER_HOLD %d\n#define HILO_USER_CONT %d\n#define HILO_USER_TV %d\n"
-           "#define HILO_USER_BIG %d\n#define HILO_USER_HAS_FUN %d\n",
-           r.policy, r.nth, r.ne, r.nc, r.coll_d, r.N, (int)r.hold, (int)r.cont, (int)r.tv, (int)r.big, (int)r.has_fun);
+           "#define HILO_USER_BIG %d\n#define HILO_USER_HAS_FUN %d\n#define HILO_USER_SYM %d\n",
+           r.policy, r.nth, r.ne, r.nc, r.coll_d, r.N, (int)r.hold, (int)r.cont, (int)r.tv, (int)r.big, (int)r.has_fun, (int)r.sym);
   std::string s(cfg);
   s += "#include \"hilo_nmpc_gen.h\"\n#include \"hilo_nmpc_track.h\"\n#include \"hilo_nmpc_user.h\"\n";
   // device pointers to the packed learned terms (gp_pack_se) the user source refers to as hilo_user_gp[k]; written by the host
@@ -97,7 +97,7 @@ struct UserCfg {
 using UserFun = NoUserFun;
 #endif
 #if HILO_USER_POLICY == 0
-using PB = NmpcTrack<UserModel, UserCfg::BIG>;
+using PB = NmpcTrack<UserModel, UserCfg::BIG, HILO_USER_SYM>;
 #elif HILO_USER_POLICY == 1
 using PB = NmpcGen<UserModel, UserCfg::NTH, UserCfg::NE, UserCfg::NC, UserCfg::BIG>;
 #else

@@ -55,6 +55,10 @@ template <bool C, class A, class B> using cond_t = typename cond<C, A, B>::type;
 template <class A, class B> struct same_type : bool_const<false> {};
 template <class A> struct same_type<A, A> : bool_const<true> {};
 
+// symbolic derivatives of a model's right-hand side (generated: hilo_models_sym.h for the zoo, hilo_mpc_amd/codegen.py for
+// models written as expressions); absent -> the engine differentiates with Taylor sweeps
+template <class M> struct ModelSym { static constexpr bool value = false; };
+
 template <class M, class = void> struct model_has_ext : bool_const<false> {};
 template <class M> struct model_has_ext<M, void_tt<decltype(M::EXT)>> : bool_const<M::EXT> {};
 
@@ -395,3 +399,5 @@ HD void model_step(int order, int nsub, const T* x, const U* u, const P* p, doub
 }
 
 }  // namespace hilo
+
+#include "hilo_models_sym.h"

@@ -7,6 +7,7 @@
 //   x_0 pinned (mpc.py:797-802; removed from the variables like IPOPT's make_parameter), box bounds on x, u,
 //   quadratic costs of QuadraticCost (hilo_mpc/util/modeling.py:243-283) on the scaled variables, the input-change
 //   term only in interval 0 (mpc.py:1631-1635), the model scaled as in hilo_mpc/modules/base.py:1562-1591.
+#include <stdlib.h>
 #include <string.h>
 
 #include "hilo_nmpc_gen.h"
@@ -396,6 +397,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     rq.policy = JIT_TRACK;
     rq.N = d->N;
     rq.big = jit_big;
+    rq.sym = (d->n_sub <= 1) && !getenv("HILO_NMPC_TAYLOR");
     rq.private_module = d->n_user_gp > 0;
     rc = jit_nmpc_kernels(rq, device, &h->jit);
     if (!rc && (h->jit.dims[0] != nx || h->jit.dims[1] != nu || h->jit.dims[2] != np))
@@ -514,11 +516,10 @@ __global__ void nmpc_pack_par_kernel(int64_t batch, int np, int nu, const double
   out[e] = i < np ? (p ? p[b * p_stride + i] : 0.0) : (u_old ? u_old[b * nu + (i - np)] : 0.0);
 }
 
-template <class M>
-static int nmpc_launch(hilo_nmpc* h, int64_t batch, const double* x0, const double* par, const double* v0, int64_t v0s,
-                       double* v_opt, double* f_opt, double* lam_g, double* u0, int32_t* status, int32_t* iters,
-                       double* kkt, hipStream_t s, int64_t par_stride, OcpExtra ex) {
-  using PB = NmpcTrack<M>;
+template <class PB>
+static int nmpc_launch_pb(hilo_nmpc* h, int64_t batch, const double* x0, const double* par, const double* v0, int64_t v0s,
+                          double* v_opt, double* f_opt, double* lam_g, double* u0, int32_t* status, int32_t* iters,
+                          double* kkt, hipStream_t s, int64_t par_stride, OcpExtra ex) {
   if (h->lds_bytes > 64 * 1024)
     HILO_HIP_CHECK(hipFuncSetAttribute((const void*)ocp_solve_kernel<PB, OCP_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)h->lds_bytes));
@@ -527,6 +528,20 @@ static int nmpc_launch(hilo_nmpc* h, int64_t batch, const double* x0, const doub
                      status, iters, kkt, h->prof, (double*)nullptr, ex);
   HILO_HIP_CHECK(hipGetLastError());
   return HILO_OK;
+}
+
+template <class M>
+static int nmpc_launch(hilo_nmpc* h, int64_t batch, const double* x0, const double* par, const double* v0, int64_t v0s,
+                       double* v_opt, double* f_opt, double* lam_g, double* u0, int32_t* status, int32_t* iters,
+                       double* kkt, hipStream_t s, int64_t par_stride, OcpExtra ex) {
+  using PB = NmpcTrack<M>;
+  if constexpr (PB::SYM) {
+    // symbolic model derivatives cover one Runge-Kutta step per interval; sub-stepped integration keeps the Taylor sweeps
+    if (h->host.nsub != 1 || getenv("HILO_NMPC_TAYLOR"))
+      return nmpc_launch_pb<NmpcTrack<M, false, false>>(h, batch, x0, par, v0, v0s, v_opt, f_opt, lam_g, u0, status, iters, kkt, s,
+                                                         par_stride, ex);
+  }
+  return nmpc_launch_pb<PB>(h, batch, x0, par, v0, v0s, v_opt, f_opt, lam_g, u0, status, iters, kkt, s, par_stride, ex);
 }
 
 static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const double* p, int64_t p_stride,
@@ -722,3 +737,11 @@ extern "C" int hilo_nmpc_plant_step(hilo_nmpc* h, int64_t batch, const double* x
   HILO_HIP_CHECK(hipGetLastError());
   return HILO_OK;
 }
+
+#ifdef HILO_OCP_DPROF
+extern "C" int hilo_debug_dprof(long long* out, int reset) {
+  if (out) HILO_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(hilo::g_dprof), sizeof(long long) * 16));
+  if (reset) { long long z[16] = {0}; HILO_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(hilo::g_dprof), z, sizeof(z))); }
+  return HILO_OK;
+}
+#endif

@@ -8,8 +8,8 @@
 namespace hilo {
 
 template <class M, int D>
-struct NmpcColl : NmpcTrack<M> {
-  using Base = NmpcTrack<M>;
+struct NmpcColl : NmpcTrack<M, false, false> {   // its own shooting map: Taylor derivatives
+  using Base = NmpcTrack<M, false, false>;
   static constexpr int NX = Base::NX, NU = Base::NU;
   template <class T, class E>
   __device__ __forceinline__ static void dyn(const OcpConst& pc, const double* par, const double*, int, const T* x,

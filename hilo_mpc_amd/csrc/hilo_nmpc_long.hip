@@ -6,7 +6,7 @@
 namespace hilo {
 
 const TrackBigVariant* nmpc_track_big_find(int model_id) {
-#define V(ID, M) {ID, &gen_lds<NmpcTrack<M, true>>, &gen_ws<NmpcTrack<M, true>>, &gen_launch<NmpcTrack<M, true>>}
+#define V(ID, M) {ID, &gen_lds<NmpcTrack<M, true, false>>, &gen_ws<NmpcTrack<M, true, false>>, &gen_launch<NmpcTrack<M, true, false>>}
   static const TrackBigVariant v[] = {
       V(HILO_MODEL_CHEMOSTAT4, Chemostat4), V(HILO_MODEL_PENDULUM4, Pendulum4), V(HILO_MODEL_BIOREACTOR3, Bioreactor3),
       V(HILO_MODEL_ROBOT6, Robot6),

@@ -6,8 +6,12 @@ namespace hilo {
 
 // Policy: tracking NMPC with quadratic costs.  pc.cost = [Wz | zref | WN | xrefN | Wdu | has_du],
 // par = [model parameters | u_old (scaled)].
-template <class M, bool BIG_ = false>
+// SYM_: take the model derivatives from generated symbolic code when the model has it (ModelSym<M>) - the host selects
+// SYM_ = false for sub-stepped integration (n_sub > 1), which only the Taylor path covers.
+template <class M, bool BIG_ = false, bool SYM_ = true>
 struct NmpcTrack {
+  using Model = M;
+  static constexpr bool SYM = SYM_ && ModelSym<M>::value && !model_has_ext<M>::value;
   static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU, NPAR = M::NP + M::NU, NSD = 0;
   static constexpr bool FIX_X0 = true;
   static constexpr bool BIG = BIG_;  // false: iterate in LDS; true: per-instance global workspace (long horizons)
@@ -79,6 +83,17 @@ struct NmpcTrack {
     if (k == 0 && i >= NX && j >= NX && pc.cost[O_HASDU] != 0.0)
       h += pc.cost[O_WDU + (i - NX) * NU + (j - NX)] + pc.cost[O_WDU + (j - NX) * NU + (i - NX)];
     return h;
+  }
+
+  // closed forms of the terminal cost (x - xrefN)^T WN (x - xrefN): gradient entry, (constant) Hessian entry
+  __device__ __forceinline__ static double term_grad(const OcpConst& pc, int i, const double* x) {
+    double g = 0.0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) g += (pc.cost[O_WN + i * NX + j] + pc.cost[O_WN + j * NX + i]) * (x[j] - pc.cost[O_XREFN + j]);
+    return g;
+  }
+  __device__ __forceinline__ static double term_hess(const OcpConst& pc, int i, int j) {
+    return pc.cost[O_WN + i * NX + j] + pc.cost[O_WN + j * NX + i];
   }
 
   template <class T>

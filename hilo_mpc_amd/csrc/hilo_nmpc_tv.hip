@@ -9,8 +9,8 @@
 namespace hilo {
 
 template <class M>
-struct NmpcTv : NmpcTrack<M> {
-  using Base = NmpcTrack<M>;
+struct NmpcTv : NmpcTrack<M, false, false> {   // its own shooting map: Taylor derivatives
+  using Base = NmpcTrack<M, false, false>;
   static constexpr int NX = Base::NX, NU = Base::NU, NZ = Base::NZ, NP = M::NP;
   static constexpr int NSD = NZ + NP;
   using Base::O_HASDU; using Base::O_WDU; using Base::O_WN; using Base::O_WZ;

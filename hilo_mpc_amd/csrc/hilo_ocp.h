@@ -167,6 +167,8 @@ __device__ __forceinline__ double block_reduce(double v, __attribute__((address_
 //          continuous objective integrates the cost through the collocation states / Runge-Kutta stages of the map
 template <class PB, class = void> struct pb_nh { static constexpr int value = 0; };
 template <class PB> struct pb_nh<PB, void_tt<decltype(PB::NH)>> { static constexpr int value = PB::NH; };
+template <class PB, class = void> struct pb_sym { static constexpr bool value = false; };
+template <class PB> struct pb_sym<PB, void_tt<decltype(PB::SYM)>> { static constexpr bool value = PB::SYM; };
 template <class PB, class = void> struct pb_fused { static constexpr bool value = false; };
 template <class PB> struct pb_fused<PB, void_tt<decltype(PB::FUSED)>> { static constexpr bool value = PB::FUSED; };
 
@@ -197,6 +199,15 @@ struct OcpExtra {
   double* gather;
 };
 
+#ifdef HILO_OCP_DPROF
+__device__ long long g_dprof[16];
+#define DTICK(i) { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long tn_ = clock64(); g_dprof[i] += tn_ - dt_; dt_ = tn_; } }
+#define DTICK0 long long dt_ = clock64();
+#else
+#define DTICK(i)
+#define DTICK0
+#endif
+
 enum OcpPhase { PH_DERIV = 0, PH_ERR, PH_RICCATI, PH_STEP, PH_LS, PH_UPDATE, PH_NRIC, PH_NLS, PH_COUNT };
 
 template <class PB>
@@ -206,6 +217,9 @@ struct Ocp {
   static constexpr bool FIX_X0 = PB::FIX_X0;
   static constexpr int NH = pb_nh<PB>::value;          // held inputs (states NX-NH..NX-1), control horizon pc.Nc
   static constexpr bool FUSED = pb_fused<PB>::value;   // dyn_cost(): shooting map + Lagrange term in one evaluation
+  // model derivatives as generated straight-line code (ModelSym<PB::Model>, csrc/hilo_models_sym.h / codegen): second-order
+  // adjoint through the Runge-Kutta stages instead of Taylor sweeps per direction pair (eval_derivs_sym)
+  static constexpr bool SYM = pb_sym<PB>::value;
   // model with a learned term: lanes that evaluate the dynamics at the same point share its kernel sum (GpExt)
   static constexpr bool COOP = PB::COOP;
   static constexpr int NEXT = COOP ? 12 * OCP_TPB : 0;
@@ -362,7 +376,18 @@ struct Ocp {
         if constexpr (FUSED) {
           fpart += PB::dyn_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
         } else {
-          PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
+          if constexpr (SYM) {   // the arithmetic of the derivative phase (division = x * rcp_fast(y)): same defects in both
+            FastD xf[NX], uf[NU > 0 ? NU : 1], xnf[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xf[i] = FastD(x[i]);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) uf[i] = FastD(u[i]);
+            PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, xf, uf, xnf, NoExt{});
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xn[i] = xnf[i].v;
+          } else {
+            PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
+          }
           fpart += PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
         }
 #pragma unroll
@@ -569,6 +594,268 @@ struct Ocp {
     return f;
   }
 
+
+  // ---- derivative evaluation from symbolic model derivatives (SYM policies: quadratic cost, no inequality rows) ----------
+  // What CasADi hands IPOPT in the reference - the Hessian of the Lagrangian of the discretised model from a symbolic graph
+  // with shared sub-expressions (mpc.py:1778-1787) - instead of NZ (NZ + 1) / 2 second-order Taylor sweeps per interval:
+  //   stages     X_i = x + h sum_j a_ij k_j,  k_i = f(X_i, u);         Phi = x + h sum_i b_i k_i
+  //   adjoint    kb_i = h b_i lam' + h sum_{j > i} a_ji f_x(X_j)^T kb_j            (lam' = lam / s_x: scaled variables)
+  //   tangent    dX_i = [I 0] + h sum_j a_ij dk_j,  dk_i = J_i dW_i,  dW_i = [dX_i; 0 I],  J_i = f_w(X_i, u)
+  //   Hessian    lam'^T Phi_ww = sum_i dW_i^T H_i dW_i,  H_i = sum_m kb_i[m] d2 f_m / dw2 (X_i, u)   (second-order adjoint: the
+  //              stage points are affine in the slopes, f is the only nonlinearity)
+  // J_i and H_i come from ModelSym<M>::jh (generated, ~150 operations for the chemostat against ~240 per Taylor sweep and
+  // RK stage, 21 sweeps).  A lane owns CPL columns (directions) of one interval; the lanes of an interval exchange the tangent
+  // columns of the current stage through the interval's block of l.W, which receives the Hessian at the end.
+  // SYM policies: the Hessian of the terminal cost is constant - written once per solve in the direction form the Riccati
+  // start reads (Q[e_i] = H_ii, Q[e_i + e_j] = H_ii + H_jj + 2 H_ij)
+  __device__ static void term_hess_dirs(const Lds l) {
+    const OcpConst& pc = *(const OcpConst*)l.pc;
+    const int N = pc.N;
+    OCP_FOR(d, NXDIR) {
+      int di = d, dj = -1;
+      if (d >= NX) pair_of(d, NX, di, dj);
+      double q = PB::term_hess(pc, di, di);
+      if (dj >= 0) q += PB::term_hess(pc, dj, dj) + 2.0 * PB::term_hess(pc, di, dj);
+      l.Qd[N * NDIR + d] = q;
+    }
+  }
+
+  __device__ __attribute__((always_inline)) static double eval_derivs_sym(lds_double* lbase, double* ws) {
+    using M = typename PB::Model;
+    using MS = ModelSym<M>;
+    static_assert(PB::QUAD_COST && NC == 0 && !COOP && !FUSED && M::NX == NX && M::NU == NU, "SYM: plain tracking policies");
+    constexpr bool DISC = M::DISCRETE;
+    constexpr int CPL = 2, LPI = (NZ + CPL - 1) / CPL;
+    const Lds l = carve(lbase, ws);
+    const OcpConst& pc = *(const OcpConst*)l.pc;
+    const int N = pc.N;
+    const int order = DISC ? 1 : pc.order;
+    const double h = pc.dt;
+    const unsigned pinm = FIX_X0 ? (~pc.x0_free_mask) & ((1u << NX) - 1u) : 0u;
+    // tableau entries that can be non-zero for orders 1..4 (modeling.py:1239-1250): a10, a20, a21, a32
+    const double a10 = order >= 2 ? 0.5 : 0.0, a20 = order == 3 ? -1.0 : 0.0, a21 = order == 3 ? 2.0 : (order == 4 ? 0.5 : 0.0),
+                 a32 = order == 4 ? 1.0 : 0.0;
+    const double hb[4] = {DISC ? 1.0 : h * erk_b<0>(order), DISC ? 0.0 : h * erk_b<1>(order), DISC ? 0.0 : h * erk_b<2>(order),
+                          DISC ? 0.0 : h * erk_b<3>(order)};
+    const double* par = (const double*)l.par;
+    DTICK0
+    double fpart = 0.0;
+    OCP_FOR(a, NU) l.grad[N * NZ + NX + a] = 0.0;
+    DTICK(7)
+    constexpr int IPP = OCP_TPB / LPI;             // intervals per pass: the LPI lanes of an interval work in the same pass
+    static_assert(IPP >= 1, "SYM: more column groups than lanes");
+    for (int kbase = 0; kbase < N; kbase += IPP) {
+      const int li = (int)threadIdx.x / LPI;
+      const bool act = li < IPP && kbase + li < N;
+      const int k = act ? kbase + li : N - 1, g = act ? (int)threadIdx.x - li * LPI : 0, c0 = g * CPL;
+      double zs[NZ], sz[NZ], isz[NX], x[NX], u[NU > 0 ? NU : 1], lamp[NX], X[4][NX], kb[4][NX];
+#pragma unroll
+      for (int i = 0; i < NZ; ++i) {
+        zs[i] = l.Z[k * NZ + i];
+        sz[i] = pc.sz[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        isz[i] = rcp_fast(sz[i]);
+        x[i] = zs[i] * sz[i];
+        lamp[i] = l.lam[k * NX + i] * isz[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NU; ++i) u[i] = zs[NX + i] * sz[NX + i];
+      // stage cost: value (one lane of the interval) and the gradient rows of this lane's columns, closed form; the lanes of the
+      // last interval add the terminal cost V(x_N) (its constant Hessian is written once per solve: term_hess_dirs)
+      double ch[NZ][CPL];
+      {
+        double xN[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xN[i] = l.Z[N * NZ + i];
+        if (act) {
+          if (g == 0) fpart += PB::stage_cost(pc, par, sd_of(l, k), k, zs, zs + NX);
+          if (g == 0 && k == N - 1) fpart += PB::term_cost(pc, par, sd_of(l, N), xN);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const int col = c0 + c;
+            if (col < NZ) l.grad[k * NZ + col] = is_free(pc, k, col) ? PB::cost_grad(pc, par, sd_of(l, k), k, col, zs) : 0.0;
+            if (col < NX && k == N - 1) l.grad[N * NZ + col] = PB::term_grad(pc, col, xN);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+#pragma unroll
+          for (int r = 0; r < NZ; ++r) ch[r][c] = (c0 + c < NZ && r >= c0 + c) ? PB::cost_hess(pc, k, r, c0 + c) : 0.0;
+      }
+      {  // stage points, slopes, Phi, defect
+        FastD kk[4][NX], uf[NU > 0 ? NU : 1];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) uf[i] = FastD(u[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          FastD Xf[NX];
+#pragma unroll
+          for (int s = 0; s < NX; ++s) {
+            double acc = x[s];
+            if (i == 1) acc += (h * a10) * kk[0][s].v;
+            if (i == 2) acc += (h * a20) * kk[0][s].v + (h * a21) * kk[1][s].v;
+            if (i == 3) acc += (h * a32) * kk[2][s].v;
+            X[i][s] = acc;
+            Xf[s] = FastD(acc);
+          }
+          if (i < order) {
+            M::ode(Xf, uf, par, h, kk[i]);
+          } else {
+#pragma unroll
+            for (int s = 0; s < NX; ++s) kk[i][s] = FastD(0.0);
+          }
+        }
+        if (act && g == 0) {
+#pragma unroll
+          for (int s = 0; s < NX; ++s) {
+            const double phi = (DISC ? 0.0 : x[s]) + hb[0] * kk[0][s].v + hb[1] * kk[1][s].v + hb[2] * kk[2][s].v + hb[3] * kk[3][s].v;
+            l.c[k * NX + s] = l.Z[(k + 1) * NZ + s] - phi * isz[s];
+          }
+        }
+      }
+      DTICK(0)
+      // adjoint weights of the slopes (reverse over the stages)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s = 0; s < NX; ++s) kb[i][s] = hb[i] * lamp[s];
+#pragma unroll
+      for (int j = 3; j >= 1; --j) {
+        if (j < order) {
+          double fx[NX * NX], t[NX];
+          MS::jx(X[j], u, par, fx);
+#pragma unroll
+          for (int n = 0; n < NX; ++n) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < NX; ++m) acc += fx[m * NX + n] * kb[j][m];
+            t[n] = acc;
+          }
+#pragma unroll
+          for (int n = 0; n < NX; ++n) {
+            if (j == 3) kb[2][n] += (h * a32) * t[n];
+            if (j == 2) { kb[1][n] += (h * a21) * t[n]; kb[0][n] += (h * a20) * t[n]; }
+            if (j == 1) kb[0][n] += (h * a10) * t[n];
+          }
+        }
+      }
+      DTICK(1)
+      // tangent columns and the second-order adjoint, stage by stage
+      dp scr = l.W + (size_t)k * NZ * NZ;           // [NX][NZ] tangent block dX_i of the interval (exchange between its lanes)
+      double dXc[NX][CPL], dX2[NX][CPL], dPhi[NX][CPL], G[NZ][CPL];
+#pragma unroll
+      for (int s = 0; s < NX; ++s)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          dXc[s][c] = (c0 + c == s) ? 1.0 : 0.0;
+          dX2[s][c] = dXc[s][c];
+          dPhi[s][c] = DISC ? 0.0 : dXc[s][c];
+        }
+#pragma unroll
+      for (int r = 0; r < NZ; ++r)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) G[r][c] = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < order) {
+          if (act) {
+#pragma unroll
+            for (int s = 0; s < NX; ++s)
+#pragma unroll
+              for (int c = 0; c < CPL; ++c)
+                if (c0 + c < NZ) scr[s * NZ + c0 + c] = dXc[s][c];
+          }
+          __syncthreads();
+          double dK[NX][CPL], v[NZ][CPL];
+          {
+            double J[NX * NZ], H[NZ * (NZ + 1) / 2];
+            MS::jh(X[i], u, par, kb[i], J, H);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+              const int col = c0 + c;
+#pragma unroll
+              for (int m = 0; m < NX; ++m) {
+                double acc = 0.0;
+#pragma unroll
+                for (int n = 0; n < NX; ++n) acc += J[m * NZ + n] * dXc[n][c];
+#pragma unroll
+                for (int n = NX; n < NZ; ++n) acc += (col == n) ? J[m * NZ + n] : 0.0;
+                dK[m][c] = acc;
+              }
+#pragma unroll
+              for (int a = 0; a < NZ; ++a) {   // v = H_i dW_i[:, col]
+                double acc = 0.0;
+#pragma unroll
+                for (int n = 0; n < NX; ++n) acc += H[a >= n ? a * (a + 1) / 2 + n : n * (n + 1) / 2 + a] * dXc[n][c];
+#pragma unroll
+                for (int n = NX; n < NZ; ++n) acc += (col == n) ? H[a >= n ? a * (a + 1) / 2 + n : n * (n + 1) / 2 + a] : 0.0;
+                v[a][c] = acc;
+              }
+            }
+          }
+          // G[r][col] += dW_i[:, r]^T v = sum_{a < NX} dX_i[a][r] v[a] + (r >= NX ? v[r] : 0)
+#pragma unroll
+          for (int r = 0; r < NZ; ++r) {
+            double col_r[NX];
+#pragma unroll
+            for (int a = 0; a < NX; ++a) col_r[a] = scr[a * NZ + r];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+              double acc = r >= NX ? v[r][c] : 0.0;
+#pragma unroll
+              for (int a = 0; a < NX; ++a) acc += col_r[a] * v[a][c];
+              G[r][c] += acc;
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < NX; ++s)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+              const double e = (c0 + c == s) ? 1.0 : 0.0;
+              dPhi[s][c] += hb[i] * dK[s][c];
+              if (i == 0) { dXc[s][c] = e + (h * a10) * dK[s][c]; dX2[s][c] = e + (h * a20) * dK[s][c]; }
+              if (i == 1) dXc[s][c] = dX2[s][c] + (h * a21) * dK[s][c];
+              if (i == 2) dXc[s][c] = e + (h * a32) * dK[s][c];
+            }
+          __syncthreads();   // every lane of the interval has read the block before the next stage overwrites it
+        }
+      }
+      DTICK(2)
+      if (act) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const int col = c0 + c;
+          if (col < NZ) {
+            const bool pin_c = k == 0 && ((pinm >> col) & 1u);
+            double sc = sz[0];
+#pragma unroll
+            for (int r = 1; r < NZ; ++r) sc = col == r ? sz[r] : sc;
+#pragma unroll
+            for (int m = 0; m < NX; ++m) l.AB[(k * NX + m) * NZ + col] = pin_c ? 0.0 : dPhi[m][c] * sc * isz[m];
+            // the interval's block of W: entries (r, col) and (col, r) for r >= col from ONE value (exact symmetry)
+#pragma unroll
+            for (int r = 0; r < NZ; ++r) {
+              if (r >= col) {
+                const bool pin = pin_c || (k == 0 && ((pinm >> r) & 1u));
+                const double hv = pin ? 0.0 : ch[r][c] - sz[r] * sc * G[r][c];
+                l.W[(size_t)k * NZ * NZ + r * NZ + col] = hv;
+                l.W[(size_t)k * NZ * NZ + col * NZ + r] = hv;
+              }
+            }
+          }
+        }
+      }
+      DTICK(3)
+    }
+    __syncthreads();
+    const double f = block_reduce<OpSum>(fpart, l.red);
+    __syncthreads();
+    DTICK(6)
+    return f;
+  }
+
   __device__ OCP_PHASE static double eval_derivs_call(lds_double* lbase, double* ws) {
     return eval_derivs_body(uni(lbase), uni(ws));
   }
@@ -576,6 +863,7 @@ struct Ocp {
   // function (barriers kept as instructions) that is what was validated, so they keep the call.
   __device__ __forceinline__ static double eval_derivs(lds_double* lbase, double* ws) {
     if constexpr (COOP) return uni(eval_derivs_call(lbase, ws));
+    else if constexpr (SYM) return eval_derivs_sym(lbase, ws);
     else return eval_derivs_body(lbase, ws);
   }
 
@@ -1367,6 +1655,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
   double theta_min = 0.0, theta_max = INFINITY;
   double E0 = INFINITY, fval = 0.0;
 
+  if constexpr (S::SYM) S::term_hess_dirs(l);
   for (it = 0;; ++it) {
     fval = S::eval_derivs(lds_raw, wsb);
     OCP_TICK(PH_DERIV)

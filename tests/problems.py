@@ -33,19 +33,10 @@ def symbolic_model(name):
     from hilo_mpc_amd import Model
     from hilo_mpc_amd.expr import cos, exp, sin
     m = Model(name=name + '_expr')
-    if name == 'chemostat4':
-        x = m.set_dynamical_states(['X', 'S', 'P', 'I'])
-        u = m.set_inputs(['DS', 'DI'])
-        p = m.set_parameters(['Sf', 'If', 'ISF', 'IRF'])
-        X, S, Pr, I = x
-        phi = 0.407 * S / (0.108 + S + S * S / 14814.0)
-        mu = phi * (p[2] + 0.22 * p[3] / (0.22 + I))
-        Rs = 2.0 * mu
-        Rfp = phi * (0.0005 + I) / (0.022 + I)
-        D = u[0] + u[1]
-        m.set_dynamical_equations([mu * X - D * X, -(Rs * X) - D * S + u[0] * p[0], Rfp * X - D * Pr, -(D * I) + u[1] * p[1]])
-        m.set_measurement_equations([X, Pr])
-    elif name == 'chemostat4_mu':
+    if name in ('chemostat4', 'pendulum4', 'cstr3'):
+        from hilo_mpc_amd import zoo_expr
+        return zoo_expr.define(m, name)
+    if name == 'chemostat4_mu':
         # the chemostat whose growth rate of the biomass balance is a parameter `mu` - to be replaced by a learned model
         # (`model.substitute_from(gp)`, nmpc_hybrid_bio.ipynb); the other rates keep their closed forms
         x = m.set_dynamical_states(['X', 'S', 'P', 'I'])
@@ -59,19 +50,6 @@ def symbolic_model(name):
         m.set_dynamical_equations([p['mu'] * X - D * X, -(Rs * X) - D * S + u[0] * p[0], Rfp * X - D * Pr,
                                    -(D * I) + u[1] * p[1]])
         m.set_measurement_equations([X, Pr])
-    elif name == 'pendulum4':
-        x = m.set_dynamical_states(['x', 'v', 'theta', 'omega'])
-        u = m.set_inputs(['F'])
-        M, mm, l, g = 5.0, 1.0, 1.0, 9.81
-        s, c = sin(x[2]), cos(x[2])
-        dv = 1.0 / (M + mm - mm * c) * (mm * g * s - mm * l * s * x[3] * x[3] + u[0])
-        m.set_dynamical_equations([x[1], dv, x[3], 1.0 / l * (dv * c + g * s)])
-        m.set_measurement_equations([x[0], x[1], x[2], x[3]])
-    elif name == 'cstr3':
-        x = m.set_dynamical_states(['C_A', 'C_B', 'T'])
-        u = m.set_inputs(['Q'])
-        m.set_dynamical_equations(cstr_equations(x, u)[0])
-        m.set_measurement_equations([cstr_equations(x, u)[1]])
     else:
         raise ValueError(name)
     return m
@@ -120,16 +98,8 @@ CSTR_PRINTED = ('59882.1817', '0.4912', '0.5088', '438.4732')        # Q, C_A, C
 
 
 def cstr_equations(x, u, lib=None):
-    """Right-hand side and reaction rate exactly as the notebook writes them (cell 6), on any symbol type."""
-    if lib is None:
-        from hilo_mpc_amd import expr as lib
-    c = CSTR
-    C_A, C_B, T, Q = x[0], x[1], x[2], u[0]
-    r = c['k_A'] * lib.exp((-c['E_A']) / (c['R'] * T)) * C_A - c['k_B'] * lib.exp((-c['E_B']) / (c['R'] * T)) * C_B
-    dC_A = 1 / c['tau'] * (c['C_A_0'] - C_A) - r
-    dC_B = -1 / c['tau'] * C_B + r
-    dT = -(c['dH'] * r) / (c['rho'] * c['Cp']) + 1 / c['tau'] * (c['T_0'] - T) + Q / (c['rho'] * c['Cp'] * c['V'])
-    return [dC_A, dC_B, dT], r
+    from hilo_mpc_amd.zoo_expr import cstr_equations as f
+    return f(x, u, lib)
 
 
 def cstr_nmpc(heat_price=None, **solver_options):

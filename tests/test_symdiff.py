@@ -1,0 +1,52 @@
+"""Symbolic model derivatives of the engine's derivative phase (hilo_mpc_amd/symdiff.py -> csrc/hilo_models_sym.h) against the
+oracle's sympy derivatives of the same right-hand sides (oracle/shooting.py), and the committed header against its generator."""
+import os
+
+import numpy as np
+import pytest
+
+from hilo_mpc_amd import zoo_expr
+from hilo_mpc_amd.model import Model
+from hilo_mpc_amd.symdiff import derivative_dag
+from oracle import models
+from oracle.shooting import ShootingMap
+
+POINTS = {'chemostat4': ([.5, 20., 1., .5], [.3, .2], [40., 4., 1., .3]),
+          'pendulum4': ([.4, -.3, .7, 1.2], [2.], []),
+          'cstr3': ([.5, .5, 430.], [5e4], [])}
+
+
+@pytest.mark.parametrize('name', sorted(POINTS))
+def test_symbolic_jacobian_and_contracted_hessian_vs_sympy(name):
+    m = zoo_expr.define(Model(name=name + '_expr'), name)
+    g, f, J, H, _ = derivative_dag(m.n_x, m.n_u, m._ode)
+    sm = ShootingMap(models.get(name), 1)
+    rng = np.random.default_rng(3)
+    nz = m.n_x + m.n_u
+    for _ in range(5):
+        x0, u0, p0 = POINTS[name]
+        x = np.array(x0) * (1 + .2 * rng.uniform(-1, 1, len(x0)))
+        u = np.array(u0) * (1 + .2 * rng.uniform(-1, 1, len(u0)))
+        p = np.array(p0)
+        kb = rng.normal(size=m.n_x)
+        fr, Jr, Hr = (a[0] for a in sm._rhs(x[None], u[None], p[None] if len(p0) else np.zeros((1, 0)), np.array([[1.]])))
+        out = g.evaluate(f + [J[a][b] for a in range(m.n_x) for b in range(nz)] + H, x, u, p, kb)
+        np.testing.assert_allclose(out[:m.n_x], fr, rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(np.array(out[m.n_x:m.n_x + m.n_x * nz]).reshape(m.n_x, nz), Jr, rtol=1e-12, atol=1e-13)
+        Hc = np.einsum('m,mab->ab', kb, Hr)
+        Hs = np.zeros((nz, nz))
+        q = m.n_x + m.n_x * nz
+        for i in range(nz):
+            for j in range(i + 1):
+                Hs[i, j] = Hs[j, i] = out[q]
+                q += 1
+        np.testing.assert_allclose(Hs, Hc, rtol=1e-11, atol=1e-12 * max(1., np.abs(Hc).max()))
+
+
+def test_committed_header_is_what_the_generator_writes():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import gen_model_sym
+    assert open(os.path.join(root, 'hilo_mpc_amd', 'csrc', 'hilo_models_sym.h')).read() == gen_model_sym.generate(), \
+        "run tools/gen_model_sym.py"
