@@ -77,9 +77,14 @@ def pmc_traffic_bytes(tag_key):
     FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command), newest round first; None if this
     configuration has no committed PMC pass.  Calibration: see DESIGN.md 5 (8-byte lanes: no 2x correction)."""
     import glob
+    import re
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_{tag_key}_summary.json')) +
-                    (sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_summary.json'))) if tag_key == 'C2' else [])):
+    files = [f for f in glob.glob(os.path.join(ROOT, 'profiles', f'r*_{tag_key}_summary.json'))
+             if re.fullmatch(rf'r\d\d_{re.escape(tag_key)}_summary\.json', os.path.basename(f))]     # round tags only (r02, not r02a)
+    if tag_key == 'C2':
+        files += [f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_summary.json'))
+                  if re.fullmatch(r'r\d\d_summary\.json', os.path.basename(f))]                      # round 1's single summary
+    for f in sorted(files, key=lambda q: os.path.basename(q)[:3]):
         try:
             d = json.load(open(f))
             best = (d['FETCH_SIZE_KB_per_launch']['warm_launches_mean'] + d['WRITE_SIZE_KB_per_launch']['warm_launches_mean']) * 1024
@@ -120,7 +125,7 @@ def _solve_roofline(kernel, B, mean_iters, nx, nu, N, ops, kern_ms, tag, n_v, n_
                     "algorithmic_bytes_per_launch": bytes_launch, "note": "compulsory bytes only; not the binding roof"}}
 
 
-def cpu_baseline_c2(spec, nst=50):
+def cpu_baseline_c2(spec, nst=50, slsqp=True):
     """the C++17 / OpenMP Riccati interior point of oracle/cpu (validated against the numpy oracle in
     tests/test_cpu_baseline.py: same statuses, iteration counts and solutions) on the SAME closed-loop workload - 5 warm-up
     + 50 timed warm-started steps - with all host cores and with one; plus scipy SLSQP on the identical transcribed NLP."""
@@ -141,31 +146,33 @@ def cpu_baseline_c2(spec, nst=50):
                 its.append(r['iters'].mean())
         secs = time.perf_counter() - t0
         return nb * nst / secs, secs, float(np.mean(its)), float(np.mean((r['status'] == 1) | (r['status'] == 2)))
-    nb_all = 1024
+    nb_all = max(1024, 64 * C)       # at least 64 instances per thread and call
     v_all, s_all, it_all, ok_all = loop(nb_all, C)
     v_one, s_one, _, _ = loop(128, 1, nst=min(nst, 20))
-    # secondary reference point: an off-the-shelf dense NLP solver (scipy SLSQP) cold on one instance of the same NLP, with the
-    # oracle's exact gradient and constraint Jacobian (x_0 substituted: the free variables of the oracle are v without x_0)
-    from oracle.nmpc import DenseIpm
-    from scipy.optimize import minimize
-    ipm = DenseIpm(pb)
-    data = {'x0': P.c2_x0(1) / pb.sx, 'p': np.atleast_2d(np.asarray(spec['p'], dtype=float))}
-    lam0, cache = np.zeros((1, ipm.m)), {}
+    slsqp_ms, sol = None, None
+    if slsqp:
+        # secondary reference point: an off-the-shelf dense NLP solver (scipy SLSQP) cold on one instance of the same NLP, with the
+        # oracle's exact gradient and constraint Jacobian (x_0 substituted: the free variables of the oracle are v without x_0)
+        from oracle.nmpc import DenseIpm
+        from scipy.optimize import minimize
+        ipm = DenseIpm(pb)
+        data = {'x0': P.c2_x0(1) / pb.sx, 'p': np.atleast_2d(np.asarray(spec['p'], dtype=float))}
+        lam0, cache = np.zeros((1, ipm.m)), {}
 
-    def ev(w):
-        k = w.tobytes()
-        if k not in cache:
-            cache.clear()
-            f, g, c, J, _ = ipm.eval_all(w[None], lam0, data)
-            cache[k] = (f[0], g[0], c[0], J[0])
-        return cache[k]
-    nx = pb.nx
-    t0 = time.perf_counter()
-    sol = minimize(lambda w: ev(w)[0], np.concatenate([np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N)]),
-                   jac=lambda w: ev(w)[1], method='SLSQP', bounds=list(zip(pb.v_lb[nx:], pb.v_ub[nx:])),
-                   constraints=[{'type': 'eq', 'fun': lambda w: ev(w)[2], 'jac': lambda w: ev(w)[3]}],
-                   options={'ftol': 1e-12, 'maxiter': 500})
-    slsqp_ms = (time.perf_counter() - t0) * 1e3
+        def ev(w):
+            k = w.tobytes()
+            if k not in cache:
+                cache.clear()
+                f, g, c, J, _ = ipm.eval_all(w[None], lam0, data)
+                cache[k] = (f[0], g[0], c[0], J[0])
+            return cache[k]
+        nx = pb.nx
+        t0 = time.perf_counter()
+        sol = minimize(lambda w: ev(w)[0], np.concatenate([np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N)]),
+                       jac=lambda w: ev(w)[1], method='SLSQP', bounds=list(zip(pb.v_lb[nx:], pb.v_ub[nx:])),
+                       constraints=[{'type': 'eq', 'fun': lambda w: ev(w)[2], 'jac': lambda w: ev(w)[3]}],
+                       options={'ftol': 1e-12, 'maxiter': 500})
+        slsqp_ms = (time.perf_counter() - t0) * 1e3
     model = ''
     try:
         model = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
@@ -173,11 +180,11 @@ def cpu_baseline_c2(spec, nst=50):
         pass
     return {"value": v_all, "unit": "steps/s", "cores": C, "kind": "port", "one_core_value": v_one,
             "cpu_model": model, "mean_ipm_iters": it_all, "frac_status_1_or_2": ok_all,
-            "slsqp_ms_per_solve": slsqp_ms, "slsqp_iterations": int(sol.nit),
+            "slsqp_ms_per_solve": slsqp_ms, "slsqp_iterations": int(sol.nit) if sol is not None else None,
             "sample": f"oracle/cpu C++17/OpenMP Riccati interior point (same algorithm and constants as the numpy oracle, validated "
                       f"against it): C2 closed loop, {nb_all} instances x {nst} warm-started steps on {C} threads ({s_all:.1f} s); "
                       f"one_core_value: 128 instances x {min(nst, 20)} steps on 1 thread ({s_one:.1f} s); slsqp: scipy SLSQP with the oracle's exact "
-                      f"derivatives, cold, one instance of the same NLP (converged: {bool(sol.success)}); the reference's CasADi/IPOPT is not installable",
+                      f"derivatives, cold, one instance of the same NLP (converged: {bool(sol.success) if sol is not None else None}); the reference's CasADi/IPOPT is not installable",
             "host_cpus": os.cpu_count()}
 
 
@@ -217,12 +224,11 @@ def wl_nmpc(cfg, args, torch, dev, rank, world):
 
     def step(timed):
         nonlocal x
-        if timed:
-            e = _events(torch, 1)[0]
-            e[0].record()
+        e = _events(torch, 1)[0]        # warm-up steps run the identical path (event creation included)
+        e[0].record()
         u = nmpc.optimize(x, cp=p)                         # one hilo_nmpc_solve launch for the whole shard
+        e[1].record()
         if timed:
-            e[1].record()
             ev.append(e)
         sol = nmpc._nlp_solution
         gather(u, sol['status'], sol['iter_count'])        # the one collective of the step (RCCL all-gather)
@@ -293,12 +299,11 @@ def wl_mhe(args, torch, dev, rank, world):
         k = cnt[0] % 64
         cnt[0] += 1
         mhe.add_measurements(yd[:, -1] + noise[k], ud[:, -1])      # window shifts by one sample (device ring buffer)
-        if timed:
-            e = _events(torch, 1)[0]
-            e[0].record()
+        e = _events(torch, 1)[0]        # warm-up steps run the identical path (event creation included)
+        e[0].record()
         mhe.estimate()
+        e[1].record()
         if timed:
-            e[1].record()
             ev.append(e)
             s = mhe._nlp_solution
             log.append((s['iter_count'], s['status'], s['kkt_error']))
@@ -345,12 +350,11 @@ def wl_kf(kind, args, torch, dev, rank, world):
     def step(timed):
         y = f.x[:, [0, 2]] + ynoise[cnt[0] % 16]
         cnt[0] += 1
-        if timed:
-            e = _events(torch, 1)[0]
-            e[0].record()
+        e = _events(torch, 1)[0]        # warm-up steps run the identical path (event creation included)
+        e[0].record()
         f.estimate(y=y, u=u, p=p)
+        e[1].record()
         if timed:
-            e[1].record()
             ev.append(e)
 
     def finish():
@@ -397,12 +401,11 @@ def wl_gp(args, torch, dev, rank, world):
     ev = []
 
     def step(timed):
-        if timed:
-            e = _events(torch, 1)[0]
-            e[0].record()
+        e = _events(torch, 1)[0]        # warm-up steps run the identical path (event creation included)
+        e[0].record()
         gp.predict(Xq)
+        e[1].record()
         if timed:
-            e[1].record()
             ev.append(e)
 
     def finish():
@@ -449,12 +452,11 @@ def wl_lmpc(args, torch, dev, rank, world):
 
     def step(timed):
         nonlocal x
-        if timed:
-            e = _events(torch, 1)[0]
-            e[0].record()
+        e = _events(torch, 1)[0]        # warm-up steps run the identical path (event creation included)
+        e[0].record()
         u = mpc.optimize(x)
+        e[1].record()
         if timed:
-            e[1].record()
             ev.append(e)
             log.append(mpc._nlp_solution['iter_count'])
         x = x @ Ad.T + u @ Bd.T

@@ -54,12 +54,15 @@ for cdir in sorted(glob.glob(os.path.join(src, '*'))):
     trace = find(os.path.join(cdir, 'trace'), '*kernel_trace.csv')
     if trace:
         rows = [r for r in csv.DictReader(open(trace)) if key in r['Kernel_Name']]
+        if rows and 'Grid_Size_X' in rows[0]:   # the step's launches (full batch), not the single-instance latency probe of C1
+            gmax = max(int(r['Grid_Size_X']) for r in rows)
+            rows = [r for r in rows if int(r['Grid_Size_X']) == gmax]
         d = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rows]
         if d:
             t = d[-timed:]
             out['timed_region'] = {'launches': len(t), 'avg_ns': sum(t) / len(t), 'min_ns': min(t), 'max_ns': max(t)}
             r0 = rows[-1]
-            out['resources'] = {k: r0.get(k) for k in ('Workgroup_Size', 'Grid_Size', 'LDS_Block_Size', 'Scratch_Size', 'VGPR_Count',
+            out['resources'] = {k: r0.get(k) for k in ('Workgroup_Size_X', 'Grid_Size_X', 'LDS_Block_Size', 'Scratch_Size', 'VGPR_Count',
                                                        'Accum_VGPR_Count', 'SGPR_Count') if k in r0}
     for name, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
         p = find(os.path.join(cdir, name), '*counter_collection.csv')
@@ -68,6 +71,11 @@ for cdir in sorted(glob.glob(os.path.join(src, '*'))):
             if v:
                 out[ctr + '_KB_per_launch'] = {'n': len(v), 'mean': sum(v) / len(v), 'min': min(v), 'max': max(v),
                                                'warm_launches_mean': sum(v[2:]) / max(1, len(v[2:]))}
+    if line and 'FETCH_SIZE_KB_per_launch' in out and 'WRITE_SIZE_KB_per_launch' in out:
+        # the line was printed before these passes were condensed: its `traffic` field is filled from THIS run's counters
+        line['roofline']['traffic'] = (out['FETCH_SIZE_KB_per_launch']['warm_launches_mean'] +
+                                       out['WRITE_SIZE_KB_per_launch']['warm_launches_mean']) * 1024
+        line['roofline']['traffic_source'] = f'profiles/{tag}_{cfg}_summary.json (FETCH_SIZE + WRITE_SIZE passes of this run)'
     with open(os.path.join(here, f'{tag}_{cfg}_summary.json'), 'w') as f:
         json.dump(out, f, indent=1)
     brief = {k: v for k, v in out.items() if k in ('config', 'kernel_name', 'timed_region', 'FETCH_SIZE_KB_per_launch', 'WRITE_SIZE_KB_per_launch')}

@@ -35,3 +35,36 @@ def test_committed_profile_is_consistent_with_the_bench_line():
     r = line['roofline']
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['bound'] in ('hbm', 'mfma')
     assert set(line['cpu_baseline']) >= {'value', 'unit', 'cores', 'kind', 'sample'}
+
+
+def test_round_2_profiles_are_consistent_with_their_bench_lines():
+    """One summary per configuration (profiles/r02_<config>_summary.json: rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes +
+    the bench line of the same build and run): the HIP-event duration of the line agrees with the trace, `traffic` is the sum of
+    the two PMC passes, the fractions follow from achieved / peak, every line carries the CPU baseline."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r02_*_summary.json')))
+    assert {os.path.basename(f)[4:-13] for f in files} >= {'C1', 'C2', 'C3-mhe', 'C3-ekf', 'C3-ukf', 'C4', 'C5', 'gp-predict'}
+    for f in files:
+        s = json.load(open(f))
+        line, cfg = s['bench_line'], s['config']
+        r = line['roofline']
+        trace_ms = s['timed_region']['avg_ns'] * 1e-6
+        if cfg in ('C3-ekf', 'C3-ukf'):
+            # a 7 - 15 us kernel: the event pair also sees the launch gap, the trace only the kernel
+            assert trace_ms <= r['kernel_ms'] < trace_ms + 0.05, cfg
+        else:
+            assert abs(trace_ms - r['kernel_ms']) / trace_ms < 0.08, (cfg, trace_ms, r['kernel_ms'])
+        traffic = (s['FETCH_SIZE_KB_per_launch']['warm_launches_mean'] + s['WRITE_SIZE_KB_per_launch']['warm_launches_mean']) * 1024
+        assert abs(r['traffic'] - traffic) <= 1e-9 * traffic, cfg
+        assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['bound'] in ('hbm', 'mfma'), cfg
+        assert set(line['cpu_baseline']) >= {'value', 'unit', 'cores', 'kind', 'sample'}, cfg
+        assert line['config']['name'] == cfg and line['n_gpus'] == 1 and line['vs_baseline'] is None
+
+
+def test_cpu_baseline_leg_of_c2_runs_here():
+    """The C++/OpenMP leg of the C2 line on a reduced sample (no GPU needed): fields, and all-core >= one-core."""
+    from tests.problems import C2
+    b = _bench()
+    out = b.cpu_baseline_c2(C2, nst=3, slsqp=False)
+    assert out['kind'] == 'port' and out['cores'] >= 1 and out['value'] > 0 and out['one_core_value'] > 0
+    assert out['frac_status_1_or_2'] == 1.0
