@@ -18,7 +18,10 @@ Each module is a plain numpy/sympy restatement of one slice of the reference hot
 
 Pinning status (see DESIGN.md section "Oracle"):
   KF / EKF / UKF / kernels / means / GP-LML : pinned by the reference's own known-answer tests
-  NMPC / LMPC / MHE                          : PARITY UNPINNED (the reference holds no numeric
+  NMPC interior point + collocation          : pinned by the numbers the reference's CSTR notebook prints
+                                               (tests/golden/nmpc_cstr.json)
+  multiple-shooting NMPC / LMPC / MHE        : PARITY UNPINNED (the reference holds no numeric
                                                assertion for them and CasADi/IPOPT is not installable
                                                here); cross-checked by an independent scipy solver.
+  oracle/cpu                                 : the C++/OpenMP CPU baseline of bench.py, validated against oracle/nmpc.py
 """

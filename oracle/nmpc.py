@@ -2,7 +2,9 @@
 
 TEST INFRASTRUCTURE ONLY - never imported by the product package.
 
-PARITY UNPINNED: the reference's NMPC tests hold no numeric assertion (tests/test_NMPC.py are closed-loop smoke
+PARITY: pinned for the interior-point method and the collocation transcription by the reference's CSTR notebook (see
+oracle/nmpc_coll.py); this module's multiple-shooting transcription itself has no reference number to hold on to - PARITY
+UNPINNED for it: the reference's NMPC tests hold no numeric assertion (tests/test_NMPC.py are closed-loop smoke
 tests) and its solver, IPOPT, lives in the un-vendored, un-installable dependency `casadi>=3.5` (setup.py:52).
 This file therefore restates
   (1) the reference's *transcription* for a pre-discretised model with `integration_method='discrete'`

@@ -1,6 +1,11 @@
 """Oracle: NMPC with the reference's DEFAULT transcription - direct collocation (Lagrange basis at Radau points).
 
-TEST INFRASTRUCTURE ONLY - never imported by the product package.   PARITY UNPINNED (see oracle/nmpc.py).
+TEST INFRASTRUCTURE ONLY - never imported by the product package.
+
+PINNED by the reference's only published NMPC numbers: docs/docsource/examples/CSTR_Example.ipynb (cells 4/6/14/16) prints
+'True: Q: 59882.1817 C_A: 0.4912 C_B: 0.5088 T: 438.4732' after 1000 closed-loop steps of the economic NMPC (GenericCost,
+default collocation Radau-3, continuous objective); this module + the interior-point method of oracle/nmpc.py print the same
+line (tests/golden/make_cstr_golden.py -> tests/golden/nmpc_cstr.json, tests/test_oracle_nmpc_coll.py).
 
 Restated from hilo_mpc/util/modeling.py:1091-1211 (`RungeKutta._construct_polynomial_basis`, `_collocation`) and
 hilo_mpc/modules/controller/mpc.py:1307-1372, :1497-1518, :1657-1666 for a CONTINUOUS model with
