@@ -49,7 +49,7 @@ class NmpcDesc(C.Structure):
                [('user_source', C.c_char_p)] + \
                [(n, C.c_int32) for n in ('user_nx', 'user_nu', 'user_np', 'user_ny', 'user_discrete', 'user_has_fun', 'user_policy',
                                          'objective_continuous')] + \
-               [('coll_B', C.c_void_p), ('n_user_gp', C.c_int32), ('reserved5', C.c_int32), ('user_gp', C.c_void_p * 4)]
+               [('coll_B', C.c_void_p), ('n_user_gp', C.c_int32), ('user_nz', C.c_int32), ('user_gp', C.c_void_p * 4)]
 
 
 class MheDesc(C.Structure):

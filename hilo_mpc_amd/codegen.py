@@ -32,7 +32,7 @@ class Emitter:
     """Collects statements for a set of expressions that share sub-expressions."""
 
     def __init__(self, theta_index=None, x='x', u='u', p='p'):
-        self.theta_index, self.names = theta_index, {'x': x, 'u': u, 'p': p}
+        self.theta_index, self.names = theta_index, {'x': x, 'u': u, 'p': p, 'z': 'z'}
         self.lines, self.memo = [], {}
 
     def ref(self, e):
@@ -59,7 +59,7 @@ class Emitter:
         op = e.op
         if op == 'const':
             r = _lit(e.value)
-        elif op in ('x', 'u', 'p'):
+        elif op in ('x', 'u', 'p', 'z'):
             r = f"{self.names[op]}[{int(e.value)}]"
         elif op == 'theta':
             if self.theta_index is None:
@@ -126,6 +126,56 @@ def model_source(n_x, n_u, n_p, ode, meas, discrete):
         from .symdiff import sym_source
         src += sym_source('UserModel', n_x, n_u, ode)
     return src
+
+
+def dae_model_source(n_x, n_u, n_p, n_z, ode, alg, meas, z_guess):
+    """`struct UserModel` of a semi-explicit index-1 DAE  dx/dt = f(x, z, u, p),  0 = g(x, z, u, p).  The engine sees the ODE
+    dx/dt = f(x, zeta(x, u, p), u, p): `ode` solves the algebraic equations for z by Newton's method IN THE SCALAR TYPE it is
+    called with (values, forward duals, second-order Taylor numbers - each sweep after the values have converged fixes one more
+    derivative order; csrc/hilo_models.h::dae_solve), so the derivatives the interior point needs are those of the implicit
+    function.  `ode_z`, `alg`, `alg_jz` (dg/dz, symbolic) are the raw functions; the output pass of the collocation policy
+    reconstructs z at the collocation points and the multipliers of the algebraic rows from them."""
+    from .symdiff import Dag
+    if len(ode) != n_x or len(alg) != n_z:
+        raise ValueError("dimension mismatch between states and equations")
+    if any(n.op == 'gp' for e in list(ode) + list(alg) for n in Expr.wrap(e).nodes().values()):
+        raise NotImplementedError("a learned term inside a DAE model is not built")
+    em = Emitter()
+    dx = [em.ref(e) for e in ode]
+    body_f = em.lines + [f"    dx[{i}] = T({r});" for i, r in enumerate(dx)]
+    em = Emitter()
+    rr = [em.ref(e) for e in alg]
+    body_g = em.lines + [f"    r[{i}] = T({q});" for i, q in enumerate(rr)]
+    g = Dag()
+    memo = {}
+    gn = [g.from_expr(e, memo) for e in alg]
+    zs = [g.var('z', i) for i in range(n_z)]
+    Jz = [g.diff(gn[a], zs[b]) for a in range(n_z) for b in range(n_z)]
+    lines, ref = g.emit(Jz, generic=True)
+    body_j = lines + [f"    J[{q}] = T({ref[n]});" for q, n in enumerate(Jz)]
+    em = Emitter()
+    yy = [em.ref(e) for e in meas]
+    body_y = em.lines + [f"    y[{i}] = T({r});" for i, r in enumerate(yy)]
+    zg = ', '.join(_lit(v) for v in z_guess)
+    sig = "const T* x, const T* z, const T* u, const P* p"
+    return (f"struct UserModel {{\n"
+            f"  static constexpr int NX = {n_x}, NU = {n_u}, NP = {n_p}, NY = {len(meas)}, NZ = {n_z};\n"
+            f"  static constexpr bool DISCRETE = false;\n"
+            f"  __device__ __forceinline__ static double z_guess(int i) {{ const double g[{n_z}] = {{{zg}}}; return g[i]; }}\n"
+            f"  template <class T, class P>\n  __device__ __forceinline__ static void ode_z({sig}, T* dx) {{\n"
+            f"    (void)x; (void)z; (void)u; (void)p;\n" + '\n'.join(body_f) + "\n  }\n"
+            f"  template <class T, class P>\n  __device__ __forceinline__ static void alg({sig}, T* r) {{\n"
+            f"    (void)x; (void)z; (void)u; (void)p;\n" + '\n'.join(body_g) + "\n  }\n"
+            f"  template <class T, class P>\n  __device__ __forceinline__ static void alg_jz({sig}, T* J) {{\n"
+            f"    (void)x; (void)z; (void)u; (void)p;\n" + '\n'.join(body_j) + "\n  }\n"
+            f"  template <class T, class P>\n  __device__ __forceinline__ static void meas_z({sig}, T* y) {{\n"
+            f"    (void)x; (void)z; (void)u; (void)p; (void)y;\n" + '\n'.join(body_y) + "\n  }\n"
+            f"  template <class T, class U, class P>\n"
+            f"  __device__ __forceinline__ static void ode(const T* x, const U* u, const P* p, double, T* dx) {{\n"
+            f"    dae_ode<UserModel>(x, u, p, dx);\n  }}\n"
+            f"  template <class T, class U, class P>\n"
+            f"  __device__ __forceinline__ static void meas(const T* x, const U* u, const P* p, double, T* y) {{\n"
+            f"    dae_meas<UserModel>(x, u, p, y);\n  }}\n}};\n")
 
 
 def zoo_alias(functor):

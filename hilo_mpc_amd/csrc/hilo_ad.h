@@ -175,6 +175,12 @@ HD Jet2 log(const Jet2& x) { const double i = 1.0 / x.v; return chain(x, ::log(x
 HD Jet2 sqrt(const Jet2& x) { const double s = ::sqrt(x.v); return chain(x, s, 0.5 / s, -0.25 / (s * x.v)); }
 HD Jet2 sq(const Jet2& x) { return chain(x, x.v * x.v, 2.0 * x.v, 2.0); }
 
+// value part of any of the scalar types (decisions inside generic code: pivoting, convergence tests)
+HD double valof(double v) { return v; }
+HD double valof(const FastD& v) { return v.v; }
+HD double valof(const Jet2& v) { return v.v; }
+template <int N> HD double valof(const Dual<N>& v) { return v.v; }
+
 // plain doubles take part in the same generic code (explicit overloads: inside this namespace the AD
 // overloads would otherwise hide ::sin etc. and a double would convert silently to Jet2)
 HD double sin(double x) { return ::sin(x); }

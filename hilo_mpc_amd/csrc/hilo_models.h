@@ -144,6 +144,87 @@ __device__ __forceinline__ T gp_se_mean(const double* g, const T* feat) {
   return bias + sf2 * acc;
 }
 
+// ---- semi-explicit index-1 DAE  dx/dt = f(x, z, u, p),  0 = g(x, z, u, p)  of a run-time compiled model (codegen.py::
+// dae_model_source: M::NZ, M::z_guess, M::ode_z, M::alg, M::alg_jz, M::meas_z) -----------------------------------------------
+// Newton's method on g(x, z, u, p) = 0 for z IN THE SCALAR TYPE Z: started from the model's constant guess, iterated until the
+// value of the residual is at round-off, then two more sweeps - in Taylor / dual arithmetic every sweep after the values have
+// converged makes one more derivative order of the implicit function z = zeta(x, u, p) exact.
+template <class M, class Z, class P>
+__device__ __forceinline__ void dae_solve(const Z* x, const Z* u, const P* p, Z* z) {
+  constexpr int NZ = M::NZ;
+#pragma unroll
+  for (int i = 0; i < NZ; ++i) z[i] = Z(M::z_guess(i));
+  int done = 0;
+  for (int it = 0; it < 40 && done < 2; ++it) {
+    Z r[NZ], J[NZ * NZ];
+    M::alg(x, z, u, p, r);
+    M::alg_jz(x, z, u, p, J);
+    double rmax = 0.0, zmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) {
+      rmax = fmax(rmax, fabs(valof(r[i])));
+      zmax = fmax(zmax, fabs(valof(z[i])));
+    }
+    // J dz = r by Gaussian elimination with partial pivoting on the values (static indices: conditional swaps)
+#pragma unroll
+    for (int c = 0; c < NZ; ++c) {
+#pragma unroll
+      for (int q = c + 1; q < NZ; ++q) {
+        if (fabs(valof(J[q * NZ + c])) > fabs(valof(J[c * NZ + c]))) {
+#pragma unroll
+          for (int j = c; j < NZ; ++j) { const Z t = J[c * NZ + j]; J[c * NZ + j] = J[q * NZ + j]; J[q * NZ + j] = t; }
+          const Z t = r[c]; r[c] = r[q]; r[q] = t;
+        }
+      }
+      const Z ip = 1.0 / J[c * NZ + c];
+#pragma unroll
+      for (int q = c + 1; q < NZ; ++q) {
+        const Z f = J[q * NZ + c] * ip;
+#pragma unroll
+        for (int j = c + 1; j < NZ; ++j) J[q * NZ + j] = J[q * NZ + j] - f * J[c * NZ + j];
+        r[q] = r[q] - f * r[c];
+      }
+    }
+#pragma unroll
+    for (int c = NZ - 1; c >= 0; --c) {
+      Z acc = r[c];
+#pragma unroll
+      for (int j = c + 1; j < NZ; ++j) acc = acc - J[c * NZ + j] * r[j];
+      r[c] = acc / J[c * NZ + c];
+    }
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) z[i] = z[i] - r[i];
+    if (rmax <= 1e-13 * (1.0 + zmax)) ++done;   // the values had converged before this sweep
+  }
+}
+
+// the ODE the engine sees: dx/dt = f(x, zeta(x, u, p), u, p); likewise the measurement map
+template <class M, class T, class U, class P>
+__device__ __forceinline__ void dae_ode(const T* x, const U* u, const P* p, T* dx) {
+  using Z = decltype(*x + *u);
+  static_assert(same_type<Z, T>::value, "dae_ode: the state's scalar type must carry the input's");
+  constexpr int NX = M::NX, NU = M::NU;
+  Z uz[NU > 0 ? NU : 1], z[M::NZ];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) uz[i] = Z(u[i]);
+  dae_solve<M>(x, uz, p, z);
+  M::ode_z(x, z, uz, p, dx);
+  (void)NX;
+}
+template <class M, class T, class U, class P>
+__device__ __forceinline__ void dae_meas(const T* x, const U* u, const P* p, T* y) {
+  using Z = decltype(*x + *u);
+  static_assert(same_type<Z, T>::value, "dae_meas: the state's scalar type must carry the input's");
+  constexpr int NU = M::NU;
+  Z uz[NU > 0 ? NU : 1], z[M::NZ];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) uz[i] = Z(u[i]);
+  dae_solve<M>(x, uz, p, z);
+  M::meas_z(x, z, uz, p, y);
+}
+template <class M, class = void> struct model_nz { static constexpr int value = 0; };
+template <class M> struct model_nz<M, void_tt<decltype(M::NZ)>> { static constexpr int value = M::NZ; };
+
 // ---- tests/test_KFs.py:247-255: dx1 = -k1 x1 + u, dx2 = k1 x1 - k2 x2, y = x2 -------------------------
 struct Linear2 {
   static constexpr int NX = 2, NU = 1, NP = 2, NY = 1;

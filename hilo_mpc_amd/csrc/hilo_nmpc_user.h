@@ -361,13 +361,19 @@ struct NmpcUser {
                                      const double* __restrict__ sdata, int64_t sd_stride, double* __restrict__ v,
                                      double* __restrict__ lam_g) {
     constexpr int DD = D > 0 ? D : 1, DN = DD * MXA;
+    // semi-explicit DAE model (codegen.py::dae_model_source): the reference carries the algebraic states as variables - node
+    // blocks z_0..z_N behind the inputs (they enter no constraint: the guess), zp_k = z at the d collocation points behind the
+    // interval's collocation states - and the algebraic rows behind each collocation point's rows (mpc.py:1488-1518,
+    // modeling.py:1183-1190).  The engine solved the ODE with z eliminated; z and the multipliers of its rows are rebuilt here.
+    constexpr int NZA = model_nz<M>::value, DB = DN + DD * NZA, NZA1 = NZA > 0 ? NZA : 1;
+    static_assert(NZA == 0 || NTH == 0, "a DAE model with a path variable is not built");
     const OcpConst& pc = *pcg;
     const int N = pc.N, Nc = NH > 0 ? pc.Nc : N;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= batch * N) return;
     const int64_t b = e / N;
     const int k = (int)(e - b * N);
-    const int n_vc = (N + 1) * MXA + Nc * MUA + NE, nv = n_vc + N * DN;
+    const int n_vc = (N + 1) * MXA + Nc * MUA + NE, n_zn = (N + 1) * NZA, nv = n_vc + n_zn + N * DB;
     const double* row = vc + b * n_vc;
     const double* pr = par + b * par_stride;
     const double* sd = C::TV ? sdata + b * sd_stride + (int64_t)k * NSD : nullptr;
@@ -388,7 +394,21 @@ struct NmpcUser {
 #pragma unroll
     for (int i = 0; i < DD; ++i)
 #pragma unroll
-      for (int m = 0; m < MXA; ++m) out[n_vc + k * DN + i * MXA + m] = X[i * MXA + m] / pc.sz[m];
+      for (int m = 0; m < MXA; ++m) out[n_vc + n_zn + k * DB + i * MXA + m] = X[i * MXA + m] / pc.sz[m];
+    double zc[DD * NZA1];
+    if constexpr (NZA > 0) {
+#pragma unroll
+      for (int a = 0; a < NZA; ++a) {
+        out[n_vc + k * NZA + a] = M::z_guess(a);
+        if (k == N - 1) out[n_vc + N * NZA + a] = M::z_guess(a);
+      }
+#pragma unroll
+      for (int i = 0; i < DD; ++i) {
+        dae_solve<M>(X + i * MXA, u, p, zc + i * NZA);
+#pragma unroll
+        for (int a = 0; a < NZA; ++a) out[n_vc + n_zn + k * DB + DN + i * NZA + a] = zc[i * NZA + a];
+      }
+    }
     if (!lam_g) return;
     double lam[MXA], y[DN], F_[DN], mu[DN];
 #pragma unroll
@@ -437,13 +457,68 @@ struct NmpcUser {
         for (int j = 0; j < DD; ++j) s -= pc.coll.A[j * DD + i] * y[j * MXA + a];
         mu[i * MXA + a] = s;
       }
-    double* lg = lam_g + b * (int64_t)(N * (DN + MXA)) + k * (DN + MXA);
+    double* lg = lam_g + b * (int64_t)(N * (DB + MXA)) + k * (DB + MXA);
 #pragma unroll
     for (int i = 0; i < DD; ++i)
 #pragma unroll
-      for (int m = 0; m < MXA; ++m) lg[i * MXA + m] = mu[i * MXA + m] * pc.sz[m];
+      for (int m = 0; m < MXA; ++m) lg[i * (MXA + NZA) + m] = mu[i * MXA + m] * pc.sz[m];
+    if constexpr (NZA > 0) {
+      // stationarity in z_i:  dt (df/dz)^T mu_i + (dg/dz)^T nu_i = 0   (mu_i: multiplier of the un-scaled collocation row)
 #pragma unroll
-    for (int m = 0; m < MXA; ++m) lg[DN + m] = lamc[b * (int64_t)(N * MXA) + k * MXA + m];
+      for (int i = 0; i < DD; ++i) {
+        Dual<NZA1> xd[MX], ud[MU > 0 ? MU : 1], zd[NZA1], fd[MX], gd[NZA1];
+#pragma unroll
+        for (int q = 0; q < MX; ++q) xd[q] = Dual<NZA1>(X[i * MXA + q]);
+#pragma unroll
+        for (int q = 0; q < MU; ++q) ud[q] = Dual<NZA1>(u[q]);
+#pragma unroll
+        for (int a = 0; a < NZA; ++a) {
+          zd[a] = Dual<NZA1>(zc[i * NZA + a]);
+          zd[a].d[a] = 1.0;
+        }
+        M::ode_z(xd, zd, ud, p, fd);
+        M::alg(xd, zd, ud, p, gd);
+        double G[NZA1 * NZA1], rhs[NZA1];      // G = (dg/dz)^T, rhs = -dt (df/dz)^T mu_i
+#pragma unroll
+        for (int a = 0; a < NZA; ++a) {
+          double acc = 0.0;
+#pragma unroll
+          for (int m = 0; m < MX; ++m) acc += fd[m].d[a] * mu[i * MXA + m];
+          rhs[a] = -pc.dt * acc;
+#pragma unroll
+          for (int c = 0; c < NZA; ++c) G[a * NZA + c] = gd[c].d[a];
+        }
+#pragma unroll
+        for (int c = 0; c < NZA; ++c) {        // Gaussian elimination with partial pivoting (static indices)
+#pragma unroll
+          for (int q = c + 1; q < NZA; ++q) {
+            if (fabs(G[q * NZA + c]) > fabs(G[c * NZA + c])) {
+#pragma unroll
+              for (int j = c; j < NZA; ++j) { const double t = G[c * NZA + j]; G[c * NZA + j] = G[q * NZA + j]; G[q * NZA + j] = t; }
+              const double t = rhs[c]; rhs[c] = rhs[q]; rhs[q] = t;
+            }
+          }
+#pragma unroll
+          for (int q = c + 1; q < NZA; ++q) {
+            const double f = G[q * NZA + c] / G[c * NZA + c];
+#pragma unroll
+            for (int j = c + 1; j < NZA; ++j) G[q * NZA + j] -= f * G[c * NZA + j];
+            rhs[q] -= f * rhs[c];
+          }
+        }
+#pragma unroll
+        for (int c = NZA - 1; c >= 0; --c) {
+          double acc = rhs[c];
+#pragma unroll
+          for (int j = c + 1; j < NZA; ++j) acc -= G[c * NZA + j] * rhs[j];
+          rhs[c] = acc / G[c * NZA + c];
+        }
+#pragma unroll
+        for (int a = 0; a < NZA; ++a) lg[i * (MXA + NZA) + MXA + a] = rhs[a];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MXA; ++m) lg[DB + m] = lamc[b * (int64_t)(N * MXA) + k * MXA + m];
   }
 };
 

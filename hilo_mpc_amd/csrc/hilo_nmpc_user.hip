@@ -120,9 +120,13 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   h->tv_width = nsd;
   h->jit_ws_bytes = big ? iter_b : 0;
   h->jit_coll_d = D;
+  const int nza = d->model_id == HILO_MODEL_USER ? d->user_nz : 0;
+  HILO_REQUIRE(nza >= 0 && nza <= 4, "hilo_nmpc_create: at most 4 algebraic states (got %d)", nza);
+  if (nza > 0 && (D == 0 || nth > 0 || ne > 0))
+    return fail(HILO_ENOTSUP, "algebraic states (DAE) are built for the collocation transcription without a path variable or slacks");
   h->n_vc = (N + 1) * mxa + Nc * mua + ne;
-  h->n_v = h->n_vc + N * D * mxa;                                  // mpc.py:1440-1453
-  h->n_g = N * (mxa + n_con_ref + D * mxa) + n_tcon_ref;          // mpc.py:1657-1669, :1684-1725
+  h->n_v = h->n_vc + (nza ? (N + 1) * nza : 0) + N * D * (mxa + nza);   // mpc.py:1440-1453, :1488-1518
+  h->n_g = N * (mxa + n_con_ref + D * (mxa + nza)) + n_tcon_ref;       // mpc.py:1657-1669, :1684-1725
   OcpConst& c = h->host;
   memset(&c, 0, sizeof(c));
   ocp_default_options(c);
@@ -254,7 +258,7 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
       for (int i = 0; i < mu; ++i) g[(N + 1) * mxa + k * mua + i] = (d->u_guess ? d->u_guess[i] : 0.0) / su[i];
       if (nth) g[(N + 1) * mxa + k * mua + mu] = d->u_pf_lb + 0.0001;                       // mpc.py:1195
     }
-    for (int q = 0; q < N * D * mxa; ++q) {                                                 // mpc.py:1321
+    for (int q = 0; q < (nza ? 0 : N * D * mxa); ++q) {   // mpc.py:1321 (DAE layout: only the [x | u] head is a start value)
       const int i = q % mxa;
       g[h->n_vc + q] = i < mx ? (d->x_guess ? d->x_guess[i] : 0.0) / sx[i] : d->theta_guess;
     }

@@ -60,7 +60,7 @@ class Expr:
     def __repr__(self):
         if self.op == 'const':
             return repr(self.value)
-        if self.op in ('x', 'u', 'p', 'theta'):
+        if self.op in ('x', 'u', 'p', 'z', 'theta'):
             return self.name
         return f"{self.op}({', '.join(map(repr, self.args))})"
 
@@ -117,6 +117,8 @@ class Expr:
             out += [X_POWI, float(self.value)]
         elif op == 'gp':
             raise ValueError("a learned term cannot be evaluated by the device interpreter (run-time compiled models only)")
+        elif op == 'z':
+            raise ValueError("an algebraic state cannot be evaluated by the device interpreter (run-time compiled models only)")
         else:
             out += [{'add': X_ADD, 'sub': X_SUB, 'mul': X_MUL, 'div': X_DIV, 'neg': X_NEG, 'sq': X_SQ, 'sin': X_SIN,
                      'cos': X_COS, 'exp': X_EXP, 'log': X_LOG, 'sqrt': X_SQRT}[op], 0.]

@@ -65,6 +65,7 @@ class Model:
             self._ode, self._meas = None, []
             self.learned = None
             self._gps = []              # trained GPs substituted into the equations (substitute_from)
+            self.algebraic_state_names, self.n_z, self._alg = [], 0, []    # semi-explicit DAE: 0 = g(x, z, u, p)
             return
         self._symbolic = False
         self.name = name
@@ -100,6 +101,7 @@ class Model:
     x = property(lambda s: SymVector('x', s.dynamical_state_names))
     u = property(lambda s: SymVector('u', s.input_names))
     p = property(lambda s: SymVector('p', s.parameter_names))
+    z = property(lambda s: SymVector('z', getattr(s, 'algebraic_state_names', [])))
 
     @property
     def discrete(self):
@@ -114,6 +116,7 @@ class Model:
             raise ValueError(f"duplicate names in {names}")
         setattr(self, attr, names)
         self.n_x, self.n_u, self.n_p = len(self.dynamical_state_names), len(self.input_names), len(self.parameter_names)
+        self.n_z = len(self.algebraic_state_names)
         return SymVector(kind, names)
 
     def set_dynamical_states(self, *names):
@@ -126,11 +129,24 @@ class Model:
     def set_parameters(self, *names):
         return self._declare('parameter_names', names[0] if len(names) == 1 and not isinstance(names[0], str) else names, 'p')
 
+    def set_algebraic_states(self, *names):
+        """dynamic_model.py `set_algebraic_states`: the z of a semi-explicit DAE  dx/dt = f(x, z, u, p),  0 = g(x, z, u, p)."""
+        return self._declare('algebraic_state_names', names[0] if len(names) == 1 and not isinstance(names[0], str) else names, 'z')
+
+    def set_algebraic_equations(self, equations):
+        """dynamic_model.py `set_algebraic_equations`: one residual per algebraic state (index 1: dg/dz regular)."""
+        if not self._symbolic:
+            raise RuntimeError(f"'{self.name}' is a model of the device zoo; its equations are fixed")
+        eqs = self._parse(equations)
+        if len(eqs) != self.n_z:
+            raise ValueError(f"the model has {self.n_z} algebraic states but {len(eqs)} algebraic equations were supplied")
+        self._alg = eqs
+
     def _parse(self, eqs):
         """Expressions, or strings of the model's variable names with sin / cos / exp / log / sqrt (the right-hand side of
         an optional `... = ` is taken, like the reference's equation strings, util/parsing.py)."""
         ns = {n: getattr(_expr, n) for n in ('sin', 'cos', 'exp', 'log', 'sqrt')}
-        for vec in (self.x, self.u, self.p):
+        for vec in (self.x, self.u, self.p, self.z):
             ns.update({n: vec[n] for n in vec._names})
         out = []
         for e in ([eqs] if isinstance(eqs, (Expr, str, int, float)) else list(eqs)):
@@ -162,16 +178,23 @@ class Model:
         if meas is not None:
             self.set_measurement_equations(meas)
 
-    def user_source(self):
+    def user_source(self, z_guess=None):
         """HIP source that defines `UserModel` for the run-time compiled path: the emitted functor, or the alias of the
-        zoo functor."""
+        zoo functor.  z_guess: start of the Newton iteration on the algebraic equations of a DAE (`set_initial_guess(z_guess=)`)."""
         from . import codegen
         if self._symbolic:
             if self._ode is None:
                 raise RuntimeError("Model is not set up: no dynamical equations (set_dynamical_equations)")
-            for e in self._ode + self._meas:
+            for e in self._ode + self._meas + self._alg:
                 if e.depends_on('theta'):
                     raise ValueError("a path variable cannot appear in the model equations")
+            if self.n_z and len(self._alg) != self.n_z:
+                raise RuntimeError("Model is not set up: algebraic states without algebraic equations (set_algebraic_equations)")
+            if self.n_z:
+                if self._native_discrete:
+                    raise NotImplementedError("algebraic states of a discrete model are not built")
+                return codegen.dae_model_source(self.n_x, self.n_u, self.n_p, self.n_z, self._ode, self._alg, self._meas,
+                                                z_guess if z_guess is not None else [0.] * self.n_z)
             return codegen.model_source(self.n_x, self.n_u, self.n_p, self._ode, self._meas, self._native_discrete)
         if self.name == 'lti':
             return codegen.zoo_alias(f"Lti<{self.n_x}, {self.n_u}, {self.n_y}>")

@@ -353,8 +353,14 @@ class NMPC:
             return v
         self._x_ub, self._x_lb = chk(x_ub, self._n_x, 'states'), chk(x_lb, self._n_x, 'states')
         self._u_ub, self._u_lb = chk(u_ub, self._n_u, 'inputs'), chk(u_lb, self._n_u, 'inputs')
-        if y_ub is not None or y_lb is not None or z_ub is not None or z_lb is not None:
-            raise NotImplementedError("measurement / algebraic box constraints are not yet offloaded")
+        if y_ub is not None or y_lb is not None:
+            raise NotImplementedError("measurement box constraints are not yet offloaded")
+        for b in (z_ub, z_lb):
+            # the algebraic states are eliminated through their equations: a finite box on them would have to
+            # become a nonlinear inequality row
+            if b is not None and np.any(np.isfinite(np.asarray(_wrap_list(b), dtype=float))):
+                raise NotImplementedError("finite bounds on algebraic states are not offloaded (default: -inf / +inf, "
+                                          "mpc.py:645-701)")
 
     def set_initial_guess(self, x_guess=None, u_guess=None, z_guess=None):
         def chk(v, n, what):
@@ -366,6 +372,7 @@ class NMPC:
                                  f"{n} while x_guess has dimension {len(v)}")
             return v
         self._x_guess, self._u_guess = chk(x_guess, self._n_x, 'x'), chk(u_guess, self._n_u, 'u')
+        self._z_guess = chk(z_guess, getattr(self._model, 'n_z', 0), 'z')
 
     def set_scaling(self, x_scaling=None, u_scaling=None, y_scaling=None):
         """optimizer.py:1476-1506."""
@@ -642,7 +649,15 @@ class NMPC:
 
         def jit_desc(policy):
             from . import codegen
-            src = m.user_source()
+            nza = getattr(m, 'n_z', 0)
+            if nza:
+                if coll is None or nth or general and (sc.is_set or tc.is_set):
+                    raise NotImplementedError("algebraic states (DAE models) are offloaded for the collocation transcription "
+                                              "(the reference's default) without path variables or nonlinear constraints")
+                src = m.user_source(z_guess=getattr(self, '_z_guess', None))
+                d.user_nz = nza
+            else:
+                src = m.user_source()
             if policy == 2:
                 src += codegen.fun_source(
                     nx, stage=self.stage_cost._cost, term=self.terminal_cost._cost,
@@ -694,7 +709,13 @@ class NMPC:
         self._e_soft_term_ind = list(range(off, off + ne_term))                                           # mpc.py:1542-1543
         dn = coll['d'] * nxa if coll is not None else 0
         off += ne_term
-        self._ip_ind = [list(range(off + k * dn, off + (k + 1) * dn)) for k in range(N)] if dn else []   # mpc.py:1501-1509
+        nza = getattr(m, 'n_z', 0) if coll is not None else 0
+        # algebraic states: node blocks z_0..z_N behind the slacks' predecessors, then per interval [ip_k | zp_k] (mpc.py:1488-1518)
+        self._z_ind = [list(range(off + k * nza, off + (k + 1) * nza)) for k in range(N + 1)] if nza else []
+        off += (N + 1) * nza
+        dz = coll['d'] * nza if coll is not None else 0
+        self._ip_ind = [list(range(off + k * (dn + dz), off + k * (dn + dz) + dn)) for k in range(N)] if dn else []   # mpc.py:1501-1509
+        self._zp_ind = [list(range(off + k * (dn + dz) + dn, off + (k + 1) * (dn + dz))) for k in range(N)] if dz else []
         self._sx, self._su = sx, su
         self._nlp_setup_done = True
 
@@ -865,6 +886,10 @@ class NMPC:
         v[(N + 1) * (nx + nth):(N + 1) * (nx + nth) + Nc * (nu + nth)] = np.tile(ua, Nc)
         for ind in self._ip_ind:
             v[ind] = np.tile(xa, len(ind) // (nx + nth))
+        zg = getattr(self, '_z_guess', None)
+        if zg is not None:
+            for ind in getattr(self, '_z_ind', []) + getattr(self, '_zp_ind', []):
+                v[ind] = np.tile(np.asarray(zg, dtype=float), len(ind) // len(zg))
         return to_dev(np.tile(v, (B, 1)), self._dev)
 
     def _v_bounds(self):

@@ -151,7 +151,7 @@ class Dag:
             op = n.op
             if op == 'const':
                 r = self.const(n.value)
-            elif op in ('x', 'u', 'p'):
+            elif op in ('x', 'u', 'p', 'z'):
                 r = self.var(op, n.value)
             elif op == 'add':
                 r = self.add(*a)
@@ -184,7 +184,7 @@ class Dag:
         op, a, b, v = self.nodes[i]
         if i == wrt:
             r = self.const(1.0)
-        elif op in ('const', 'x', 'u', 'p', 'kb'):
+        elif op in ('const', 'x', 'u', 'p', 'z', 'kb'):
             r = self.const(0.0)
         elif op == 'add':
             r = self.add(self.diff(a, wrt), self.diff(b, wrt))
@@ -212,9 +212,11 @@ class Dag:
         return r
 
     # ---- emission --------------------------------------------------------------------------------------------------------
-    def emit(self, outputs, names=('x', 'u', 'p')):
-        """Straight-line statements for the nodes `outputs` depend on; returns (lines, {node: C expression})."""
-        nm = dict(zip(('x', 'u', 'p'), names), kb='kb')
+    def emit(self, outputs, names=('x', 'u', 'p'), generic=False):
+        """Straight-line statements for the nodes `outputs` depend on; returns (lines, {node: C expression}).  generic: for a
+        templated scalar type (`const auto`, reciprocal as 1.0 / x) instead of double."""
+        nm = dict(zip(('x', 'u', 'p'), names), kb='kb', z='z')
+        ctype = 'auto' if generic else 'double'
         need, stack = set(), [o for o in outputs]
         while stack:
             i = stack.pop()
@@ -235,7 +237,7 @@ class Dag:
                 if v < 0:
                     ref[i] = f"({ref[i]})"
                 continue
-            if op in ('x', 'u', 'p', 'kb'):
+            if op in ('x', 'u', 'p', 'kb', 'z'):
                 ref[i] = f"{nm[op]}[{v}]"
                 continue
             if op in ('add', 'sub', 'mul'):
@@ -243,18 +245,18 @@ class Dag:
             elif op == 'neg':
                 rhs = f"-{ref[a]}"
             elif op == 'recip':
-                rhs = f"rcp_fast({ref[a]})"                       # csrc/hilo_ad.h: v_rcp_f64 + two Newton steps
+                rhs = f"1.0 / {ref[a]}" if generic else f"rcp_fast({ref[a]})"   # csrc/hilo_ad.h: v_rcp_f64 + two Newton steps
             else:
                 rhs = f"{op}({ref[a]})"
             ref[i] = f"s{len(lines)}"
-            lines.append(f"    const double {ref[i]} = {rhs};")
+            lines.append(f"    const {ctype} {ref[i]} = {rhs};")
         return lines, ref
 
 
     # ---- numeric evaluation (tests: the derivative DAG against the oracle's sympy derivatives) ---------------------------------
-    def evaluate(self, outputs, x, u, p, kb=()):
+    def evaluate(self, outputs, x, u, p, kb=(), z=()):
         val = {}
-        env = {'x': x, 'u': u, 'p': p, 'kb': kb}
+        env = {'x': x, 'u': u, 'p': p, 'kb': kb, 'z': z}
         fn = {'sin': math.sin, 'cos': math.cos, 'exp': math.exp, 'log': math.log, 'sqrt': math.sqrt}
         need, stack = set(), list(outputs)
         while stack:

@@ -285,7 +285,9 @@ typedef struct hilo_nmpc_desc {
   /* learned terms of a run-time compiled model (`Model.substitute_from(gp)`, dynamic_model.py:3040-3125): up to 4 trained GPs
      (squared-exponential kernel over up to 8 features, constant / zero mean); the emitted model refers to them as
      gp_se_mean(hilo_user_gp[k], features) (csrc/hilo_models.h) */
-  int32_t n_user_gp; int32_t reserved5;
+  int32_t n_user_gp;
+  int32_t user_nz;                /* algebraic states of the user model (semi-explicit DAE, `set_algebraic_states`): the source's
+                                     UserModel::NZ; v / g gain the z blocks and rows of mpc.py:1488-1518 (collocation only) */
   const hilo_gp* user_gp[4];
   /* with user_policy 2 the constraint / path expressions are compiled into UserFun: n_con, n_tcon, n_path_stage, n_path_term
      count them as above, the *_prog pointers stay NULL */

@@ -77,7 +77,10 @@ def _lam(exprs, args):
 class OracleModel:
     """Symbolic model: x+ = f(x,u,p,dt) (discrete) or dx/dt = f(x,u,p) (continuous); y = h(x,u,p)."""
 
-    def __init__(self, name, model_id, x, u, p, ode, meas=None, discrete=False, dt=None):
+    def __init__(self, name, model_id, x, u, p, ode, meas=None, discrete=False, dt=None, z=None, alg=None):
+        # z / alg: algebraic states and equations 0 = g(x, z, u, p) of a semi-explicit DAE (dynamic_model.py `set_algebraic_*`)
+        self.z = list(z) if z is not None else []
+        self.alg = [sp.sympify(e) for e in (alg if alg is not None else [])]
         self.name = name
         self.model_id = model_id
         self.x = list(x)
@@ -228,6 +231,36 @@ def chemostat4_gp(X_train, alpha, length_scales, signal_variance=1., bias=0.):
                        [mu * X - D * X, -Rs * X - D * S + DS * Sf, Rfp * X - D * P, -D * I + DI * If], [X, P])
 
 
+def pendulum4_dae():
+    """The DAE of the reference's own NMPC test (tests/test_NMPC.py:1866-1911): the cart-pendulum with the height of the
+    pendulum tip as algebraic state, 0 = h + l cos(theta) - y."""
+    m = pendulum4()
+    y = sp.Symbol('y')
+    return OracleModel('pendulum4_dae', -1, m.x, m.u, [], m.ode, m.meas, z=[y], alg=[0.5 + 1.0 * sp.cos(m.x[2]) - y])
+
+
+def chemostat4_dae():
+    """chemostat4 with the growth rate as an ALGEBRAIC state that feeds back into the biomass and substrate balances:
+    0 = mu - phi(S) (ISF + 0.22 IRF / (0.22 + I)).  Eliminating mu gives chemostat4 itself - the DAE oracle and the product's
+    eliminated form must both land on the ODE problem's solution."""
+    X, S, P, I, DS, DI, mu = sp.symbols('X S P I DS DI mu')
+    Sf, If, ISF, IRF = sp.symbols('Sf If ISF IRF')
+    phi = 0.407 * S / (0.108 + S + S ** 2 / 14814.0)
+    Rfp = phi * (0.0005 + I) / (0.022 + I)
+    D = DS + DI
+    return OracleModel('chemostat4_dae', -1, [X, S, P, I], [DS, DI], [Sf, If, ISF, IRF],
+                       [mu * X - D * X, -2 * mu * X - D * S + DS * Sf, Rfp * X - D * P, -D * I + DI * If], [X, P],
+                       z=[mu], alg=[mu - phi * (ISF + 0.22 * IRF / (0.22 + I))])
+
+
+def robot6_dae():
+    """C5's DAE variant: the robot with the squared speed as algebraic state, 0 = z - (vx^2 + vy^2), which the
+    dynamics do not use (a constraint / output quantity, the pendulum pattern)."""
+    m = robot6()
+    z = sp.Symbol('z')
+    return OracleModel('robot6_dae', -1, m.x, m.u, [], m.ode, m.meas, z=[z], alg=[z - (m.x[1] ** 2 + m.x[3] ** 2)])
+
+
 def robot6():
     """Planar mobile robot with heading for the path-following configuration C5 (the reference holds no
     6-state model - pattern of the point mass in tests/test_NMPC.py:742-775 and path_following_mpc.ipynb cell 3):
@@ -257,6 +290,9 @@ ZOO = {
     'chemostat4': chemostat4,
     'pendulum4': pendulum4,
     'robot6': robot6,
+    'pendulum4_dae': pendulum4_dae,
+    'robot6_dae': robot6_dae,
+    'chemostat4_dae': chemostat4_dae,
 }
 
 

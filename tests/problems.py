@@ -36,7 +36,32 @@ def symbolic_model(name):
     if name in ('chemostat4', 'pendulum4', 'cstr3'):
         from hilo_mpc_amd import zoo_expr
         return zoo_expr.define(m, name)
-    if name == 'chemostat4_mu':
+    if name == 'chemostat4_dae':
+        # oracle/models.py::chemostat4_dae: the growth rate as algebraic state that feeds back into the balances
+        x = m.set_dynamical_states(['X', 'S', 'P', 'I'])
+        u = m.set_inputs(['DS', 'DI'])
+        p = m.set_parameters(['Sf', 'If', 'ISF', 'IRF'])
+        z = m.set_algebraic_states(['mu'])
+        X, S, Pr, I = x
+        phi = 0.407 * S / (0.108 + S + S * S / 14814.0)
+        Rfp = phi * (0.0005 + I) / (0.022 + I)
+        D = u[0] + u[1]
+        m.set_dynamical_equations([z[0] * X - D * X, -(2.0 * z[0] * X) - D * S + u[0] * p[0], Rfp * X - D * Pr,
+                                   -(D * I) + u[1] * p[1]])
+        m.set_algebraic_equations([z[0] - phi * (p[2] + 0.22 * p[3] / (0.22 + I))])
+        m.set_measurement_equations([X, Pr])
+    elif name == 'pendulum4_dae':
+        # the reference's DAE test model (tests/test_NMPC.py:1866-1911): height of the pendulum tip as algebraic state
+        x = m.set_dynamical_states(['x', 'v', 'theta', 'omega'])
+        u = m.set_inputs(['F'])
+        z = m.set_algebraic_states(['y'])
+        M, mm, l, g, h = 5.0, 1.0, 1.0, 9.81, .5
+        s, c = sin(x[2]), cos(x[2])
+        dv = 1.0 / (M + mm - mm * c) * (mm * g * s - mm * l * s * x[3] * x[3] + u[0])
+        m.set_dynamical_equations([x[1], dv, x[3], 1.0 / l * (dv * c + g * s)])
+        m.set_algebraic_equations([h + l * c - z[0]])
+        m.set_measurement_equations([x[0], x[1], x[2], x[3]])
+    elif name == 'chemostat4_mu':
         # the chemostat whose growth rate of the biomass balance is a parameter `mu` - to be replaced by a learned model
         # (`model.substitute_from(gp)`, nmpc_hybrid_bio.ipynb); the other rates keep their closed forms
         x = m.set_dynamical_states(['X', 'S', 'P', 'I'])

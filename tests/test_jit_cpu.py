@@ -59,3 +59,14 @@ def test_generated_hybrid_model_compiles(policy):
 def test_compile_error_is_reported_with_the_compiler_log():
     with pytest.raises(ValueError, match="run-time compilation"):
         _compile("struct UserModel { this is not C++ };\n")
+
+
+@pytest.mark.parametrize('name', ['pendulum4_dae', 'chemostat4_dae'])
+def test_generated_dae_model_compiles_with_the_collocation_policy(name):
+    """Semi-explicit DAE (set_algebraic_states / set_algebraic_equations): the emitted model solves its algebraic equations
+    inside `ode` in whatever scalar type it is called with; general policy, Radau-3 collocation, continuous objective."""
+    m = symbolic_model(name)
+    assert m.n_z == 1
+    src = m.user_source(z_guess=[1.4])
+    assert 'NZ = 1' in src and 'dae_ode<UserModel>' in src and 'alg_jz' in src
+    _compile(src + codegen.fun_source(m.n_x), policy=2, coll_d=3, cont=1, has_fun=1)
