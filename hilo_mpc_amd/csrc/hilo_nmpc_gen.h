@@ -12,6 +12,9 @@
 // copies stay exactly consistent under Newton steps, so the iterates are those of the reference's single-e problem.
 // Engine state = [model x (MX) | theta (NTH) | e (NE)], engine input = [model u (MU) | u_theta (NTH)].
 #pragma once
+#ifndef __HIPCC_RTC__
+#include <stdlib.h>
+#endif
 #include "hilo_expr.h"
 #include "hilo_ocp.h"
 
@@ -274,12 +277,26 @@ struct TvVariant {
 };
 const TvVariant* nmpc_tv_find(int model_id);
 
+// workgroups of a workspace-mode launch: by default one per instance.  HILO_BIG_SLOTS=n makes n workgroups walk over the
+// instances with one cache-resident workspace slot each - measured on C5 (B = 8192): 1024 slots 420 ms, 512: 655 ms, 256: 1164 ms
+// against 392 ms with one workgroup per instance, i.e. the kernel is bound by per-wave latency, not by workspace bandwidth
+inline int64_t big_grid_slots() {
+  static int64_t slots = 0;
+  if (!slots) {
+    const char* e = getenv("HILO_BIG_SLOTS");
+    slots = e && atoll(e) > 0 ? atoll(e) : (int64_t)1 << 40;
+  }
+  return slots;
+}
+
 template <class PB>
 int gen_launch(const GenLaunchArgs& a) {
   if (a.lds_bytes > 64 * 1024)
     HILO_HIP_CHECK(hipFuncSetAttribute((const void*)ocp_solve_kernel<PB, OCP_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)a.lds_bytes));
-  hipLaunchKernelGGL((ocp_solve_kernel<PB, OCP_TPB>), dim3((unsigned)a.batch), dim3(OCP_TPB), a.lds_bytes, a.stream, a.dev,
+  unsigned grid = (unsigned)a.batch;
+  if constexpr (PB::BIG) grid = (unsigned)(a.batch < big_grid_slots() ? a.batch : big_grid_slots());
+  hipLaunchKernelGGL((ocp_solve_kernel<PB, OCP_TPB>), dim3(grid), dim3(OCP_TPB), a.lds_bytes, a.stream, a.dev,
                      a.batch, a.x0, a.par, a.par_stride, (const double*)nullptr, (int64_t)0, a.v0, a.v0_stride, 0, 0, a.v_opt,
                      a.f_opt, a.lam_g, a.u0, 0, a.status, a.iters, a.kkt, a.prof, a.ws);
   HILO_HIP_CHECK(hipGetLastError());

@@ -1541,14 +1541,15 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
                                                double* __restrict__ first, int first_kind,
                                                int32_t* __restrict__ status, int32_t* __restrict__ iters,
                                                double* __restrict__ kkt, long long* __restrict__ prof,
-                                               double* __restrict__ ws, const OcpExtra ex = OcpExtra()) {
+                                               double* __restrict__ ws, const OcpExtra ex = OcpExtra(), int64_t b_in = -1,
+                                               int64_t ws_slot = -1) {
   using S = Ocp<PB>;
   constexpr int NX = S::NX, NU = S::NU, NZ = S::NZ, NC = S::NC, NXV = S::NXV, NH = S::NH, NTAIL = NX - NXV - NH;
   const int t = threadIdx.x;
-  const int64_t b = blockIdx.x;
+  const int64_t b = b_in >= 0 ? b_in : (int64_t)blockIdx.x;     // instance; workspace slot (workspace mode: one per WORKGROUP)
   if (b >= batch) return;
   const int N = pcg->N;
-  double* const wsb = ws ? ws + b * (int64_t)S::ws_doubles(N) : nullptr;
+  double* const wsb = ws ? ws + (ws_slot >= 0 ? ws_slot : b) * (int64_t)S::ws_doubles(N) : nullptr;
   typename S::Lds l = S::carve(lds_raw, wsb, N);
   {  // problem constants into LDS: every later access is an LDS read instead of a global load
     const double* src = reinterpret_cast<const double*>(pcg);
@@ -2023,8 +2024,19 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(HILO_OCP_MI
                                                        double* __restrict__ kkt, long long* __restrict__ prof,
                                                        double* __restrict__ ws = nullptr, const OcpExtra ex = OcpExtra()) {
   extern __shared__ double lds_raw_generic[];
-  ocp_solve_body<PB, TPB>((lds_double*)lds_raw_generic, pcg, batch, x0, par, par_stride, sdata, sd_stride, v0, v0_stride, v0_prefix,
-                          v_prefix, v_opt, f_opt, lam_g, first, first_kind, status, iters, kkt, prof, ws, ex);
+  if constexpr (PB::BIG) {
+    // workspace mode: a workgroup walks over instances blockIdx.x, + gridDim.x, ... and keeps ONE workspace slot (grid = batch
+    // by default: one instance per workgroup; a smaller grid keeps the slots cache-resident, see big_grid_slots())
+    for (int64_t b = blockIdx.x; b < batch; b += gridDim.x) {
+      ocp_solve_body<PB, TPB>((lds_double*)lds_raw_generic, pcg, batch, x0, par, par_stride, sdata, sd_stride, v0, v0_stride,
+                              v0_prefix, v_prefix, v_opt, f_opt, lam_g, first, first_kind, status, iters, kkt, prof, ws, ex, b,
+                              (int64_t)blockIdx.x);
+      __syncthreads();
+    }
+  } else {
+    ocp_solve_body<PB, TPB>((lds_double*)lds_raw_generic, pcg, batch, x0, par, par_stride, sdata, sd_stride, v0, v0_stride,
+                            v0_prefix, v_prefix, v_opt, f_opt, lam_g, first, first_kind, status, iters, kkt, prof, ws, ex);
+  }
 }
 
 }  // namespace hilo
