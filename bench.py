@@ -212,7 +212,7 @@ def wl_nmpc(cfg, args, torch, dev, rank, world):
         B = hi - lo
         nmpc = P.product_gen(spec)
         x0 = P.c5_x0(gB)[lo:hi]
-        kernel, model, ex, eu = "ocp_solve_kernel<NmpcGen<Robot6, 1, 1, 2, true>, 64>", 'robot6', 8, 3
+        kernel, model, ex, eu = "hilo_user_solve (general policy NmpcUser<Robot6, path variable, soft constraint>, compiled at run time)", 'robot6', 8, 3
         workload = ("C5 path-following NMPC robot6 (ODE; engine nx=6+theta+slack, nu=2+u_theta) N=50 soft constraint, Riccati "
                     "interior point with the iterate in a global-memory workspace, closed loop warm-started")
     N = nmpc.horizon

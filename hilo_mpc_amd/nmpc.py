@@ -11,6 +11,7 @@ discrete) and `integration_method='discrete'`; quadratic stage / terminal / inpu
 references; box constraints; scaling.  Everything numeric is done by `hilo_nmpc_solve` in libhilo_hip.so.
 """
 import ctypes as C
+import os
 import time
 import warnings
 
@@ -20,6 +21,7 @@ import torch
 from . import _lib
 from ._device import device, to_dev, ptr, stream_ptr
 from .expr import Expr, compile_block as _compile_block
+from .model import ZOO_FUNCTOR as ZOO_FUNCTOR_NAMES
 
 STATUS_TEXT = {1: 'solve_succeeded', 2: 'solved_to_acceptable_level', 3: 'infeasible_problem_detected',
                4: 'restoration_failed', 5: 'maximum_iterations_exceeded', -1: 'other'}
@@ -678,6 +680,16 @@ class NMPC:
                 d.user_gp[k] = g._handle.value if hasattr(g._handle, 'value') else g._handle
 
         h = C.c_void_p()
+        # Problems with a path variable or nonlinear constraints: the run-time compiled general policy (expressions compiled
+        # in, horizon a compile-time constant) is the default - measured 1.8x faster than the precompiled variants with their
+        # expression interpreter on C5 (218 vs 392 ms per 8192-instance step) at the price of seconds of hiprtc at the first
+        # setup() of a problem structure (cached on disk afterwards).  HILO_NMPC_BACKEND=precompiled keeps the library's variants.
+        backend = os.environ.get('HILO_NMPC_BACKEND', 'auto')
+        if backend not in ('auto', 'precompiled', 'runtime'):
+            raise ValueError(f"HILO_NMPC_BACKEND must be auto, precompiled or runtime (got '{backend}')")
+        if getattr(m, 'learned', None) is None and not sym and m.name in ZOO_FUNCTOR_NAMES and \
+                (backend == 'runtime' or (backend == 'auto' and general and not prog_fail)):
+            need_user = True
         if sym or need_user:
             if getattr(m, 'learned', None) is not None:
                 raise NotImplementedError("a learned term inside a run-time compiled problem is not offloaded")

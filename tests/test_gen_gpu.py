@@ -7,6 +7,14 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=['precompiled', 'runtime'])
+def backend(request, monkeypatch):
+    """Every case on both routes: the library's precompiled variants (expression interpreter) and the general policy compiled at
+    run time, which is the default for problems with a path variable or nonlinear constraints (hilo_mpc_amd/nmpc.py)."""
+    monkeypatch.setenv('HILO_NMPC_BACKEND', request.param)
+    return request.param
+
 from oracle.nmpc_gen import GenIpm                                                              # noqa: E402
 from tests.problems import C2, C2H, C2S, C5, C5S, c2_x0, c5_x0, oracle_gen, product_gen         # noqa: E402
 
