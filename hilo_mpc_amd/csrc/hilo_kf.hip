@@ -315,8 +315,16 @@ __device__ __forceinline__ void ukf_update(const KfParams& kp, double* x, double
 
 // ---- kernels --------------------------------------------------------------------------------------------
 // MODE 0 = predict, 1 = update, 2 = fused step.  UKF template flag selects sigma-point arithmetic.
+#ifndef HILO_KF_WAVES
+#define HILO_KF_WAVES 0   // 0: let the compiler choose the occupancy (measured best)
+#endif
+#if HILO_KF_WAVES > 0
+#define KF_OCC __attribute__((amdgpu_waves_per_eu(HILO_KF_WAVES, HILO_KF_WAVES)))
+#else
+#define KF_OCC
+#endif
 template <class M, bool UKF, int MODE>
-__global__ __launch_bounds__(KF_TPB) void kf_kernel(KfParams kp, int64_t batch, const double* __restrict__ in_tile,
+__global__ __launch_bounds__(KF_TPB) KF_OCC void kf_kernel(KfParams kp, int64_t batch, const double* __restrict__ in_tile,
                                                     const double* __restrict__ y, const double* __restrict__ up,
                                                     int64_t up_stride, const double* __restrict__ Q,
                                                     int64_t q_stride, const double* __restrict__ R,
