@@ -489,6 +489,13 @@ static bool nmpc_is_direct(const hilo_nmpc* h) {
 // Result gather of a sharded batch (hilo_mpc_amd/dist.py): the solve writes row b = [u0 (nu) | status | iterations] (fp64) of
 // `table` ([batch][stride], stride >= nu + 2, device) itself, so that the collective can start from it without a packing
 // kernel.  NULL switches it off.  Plain tracking problems only (the others ignore it).
+extern "C" int hilo_nmpc_set_aux_outputs(hilo_nmpc* h, double* g, double* lam_x) {
+  HILO_REQUIRE(h, "hilo_nmpc_set_aux_outputs: NULL handle");
+  h->aux_g = g;
+  h->aux_lam_x = lam_x;
+  return HILO_OK;
+}
+
 extern "C" int hilo_nmpc_set_gather(hilo_nmpc* h, double* table, int stride) {
   HILO_REQUIRE(h, "hilo_nmpc_set_gather: NULL handle");
   HILO_REQUIRE(!table || stride >= h->nu + 2, "hilo_nmpc_set_gather: stride %d < nu + 2", stride);
@@ -592,6 +599,10 @@ static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const 
     ex.gather = h->gather;
     ex.gather_stride = h->gather_stride;
   }
+  if (h->jit_coll_d == 0 && !h->coll) {   // layouts the engine writes itself (no collocation output pass)
+    ex.lam_x = h->aux_lam_x;
+    ex.g = lam_g ? h->aux_g : nullptr;
+  }
   const double* par_arg = direct ? (p ? p : x0) : h->par_buf;   // np == 0: never dereferenced
   const int64_t par_stride_arg = direct ? p_stride : (int64_t)w;
   // initial guess: explicit v0, else the previous solution (warm start, mpc.py:725-726), else the tiled guess
@@ -660,6 +671,8 @@ static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const 
     }
     GenLaunchArgs a{h->dev, batch, x0, h->par_buf, (int64_t)(h->np + h->nu), vstart, vstride, v_opt, f_opt, lam_g, u0,
                     status, iters, kkt, h->prof, h->lds_bytes, s, h->ws};
+    a.ex.lam_x = ex.lam_x;
+    a.ex.g = ex.g;
     rc = h->gen ? h->gen->launch(a) : h->big->launch(a);
   } else {
     switch (h->model_id) {

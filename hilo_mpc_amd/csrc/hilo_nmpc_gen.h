@@ -236,6 +236,7 @@ struct GenLaunchArgs {
   size_t lds_bytes;
   hipStream_t stream;
   double* ws;   // per-instance workspace (BIG variants) or NULL
+  OcpExtra ex = OcpExtra();
 };
 struct GenVariant {
   int model_id, nth, ne, nc, big;            // key
@@ -298,7 +299,7 @@ int gen_launch(const GenLaunchArgs& a) {
   if constexpr (PB::BIG) grid = (unsigned)(a.batch < big_grid_slots() ? a.batch : big_grid_slots());
   hipLaunchKernelGGL((ocp_solve_kernel<PB, OCP_TPB>), dim3(grid), dim3(OCP_TPB), a.lds_bytes, a.stream, a.dev,
                      a.batch, a.x0, a.par, a.par_stride, (const double*)nullptr, (int64_t)0, a.v0, a.v0_stride, 0, 0, a.v_opt,
-                     a.f_opt, a.lam_g, a.u0, 0, a.status, a.iters, a.kkt, a.prof, a.ws);
+                     a.f_opt, a.lam_g, a.u0, 0, a.status, a.iters, a.kkt, a.prof, a.ws, a.ex);
   HILO_HIP_CHECK(hipGetLastError());
   return HILO_OK;
 }

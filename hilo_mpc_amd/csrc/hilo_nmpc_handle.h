@@ -39,6 +39,8 @@ struct hilo_nmpc {
   size_t jit_ws_bytes;       // per-instance iterate workspace of a run-time compiled problem (0: iterate in LDS)
   int jit_coll_d;            // collocation degree of a run-time compiled problem (output pass needed) or 0
   double* user_gp_pack[4];   // packed learned terms of a run-time compiled model (gp_pack_se) or NULL
+  double* aux_g;             // caller's buffers for the constraint values / bound multipliers of the next solves, or NULL
+  double* aux_lam_x;
   double* gather;            // caller's gather table (hilo_nmpc_set_gather) or NULL
   int gather_stride;
 };

@@ -191,12 +191,16 @@ __host__ __device__ constexpr size_t ocp_fixed_doubles(int NX, int NU, int NCONS
 //   v_copy        second copy of the solution rows (the handle's warm-start buffer, mpc.py:725-726) - no device copy after it
 //   gather        row b of a [batch][gather_stride] fp64 table receives [first output (u_0) | status | iterations]: the send
 //                 buffer of the per-step result gather (hilo_mpc_amd/dist.py)
+//   lam_x / g     the other two vectors of the reference's solver result (mpc.py:722-723 keeps `sol` whole): bound multipliers in
+//                 the layout of v (CasADi's sign: z_U - z_L; 0 for a pinned x_0) and the constraint values in the layout of lam_g
 struct OcpExtra {
   const double* par2;
   int npar1;
   int gather_stride;
   double* v_copy;
   double* gather;
+  double* lam_x;
+  double* g;
 };
 
 #ifdef HILO_OCP_DPROF
@@ -1963,6 +1967,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
       const double zv = l.Z[e];
       vo[dst] = zv;
       if (vo2) vo2[dst] = zv;
+      if (ex.lam_x) (ex.lam_x + (vo - v_opt))[dst] = S::is_free(pc, k, i) ? l.zU[e] - l.zL[e] : 0.0;
     }
   }
   if (lam_g) {
@@ -1970,6 +1975,19 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     // the last stage carries the terminal rows between its defect and its stage rows (mpc.py:1693-1700 before :1707)
     const int ncr = NC > 0 ? pc.n_con_ref : 0, ntr = NC > 0 ? pc.n_tcon_ref : 0, rows = NXV + ncr;
     double* lg = lam_g + b * (int64_t)(N * rows + ntr);
+    double* const gg = ex.g ? ex.g + b * (int64_t)(N * rows + ntr) : nullptr;
+    if (gg) {   // constraint values at the returned point: defects x_{k+1} - F_k, then the rows (dropped rows: 0)
+      OCP_FOR(e, N * rows + ntr) gg[e] = 0.0;
+      __syncthreads();
+      OCP_FOR(e, N * NXV) gg[(e / NXV) * rows + e % NXV] = l.c[(e / NXV) * NX + e % NXV];
+      if constexpr (NC > 0) {
+        OCP_FOR(e, N * NC) {
+          const int k = e / NC, m = e - k * NC;
+          if (m < pc.nc) gg[k * rows + NXV + (k == N - 1 ? ntr : 0) + pc.row_ref[m]] = l.cd[e];
+          else if (k == N - 1 && m < pc.nc + pc.nc_term) gg[k * rows + NXV + pc.trow_ref[m - pc.nc]] = l.cd[e];
+        }
+      }
+    }
     OCP_FOR(e, N * NXV) {
       const int k = e / NXV, i = e - k * NXV;
       double v = l.lam[k * NX + i];

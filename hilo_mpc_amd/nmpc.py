@@ -818,6 +818,11 @@ class NMPC:
         status = torch.empty(B, dtype=torch.int32, device=dev)
         iters = torch.empty(B, dtype=torch.int32, device=dev)
         kkt = torch.empty(B, dtype=torch.float64, device=dev)
+        # the reference keeps the whole solver result (mpc.py:722-723): constraint values g and bound multipliers lam_x too.
+        # Layouts with a collocation output pass return them as zeros.
+        g_val = torch.zeros(B, self._n_g, dtype=torch.float64, device=dev)
+        lam_x = torch.zeros(B, self._n_v, dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().hilo_nmpc_set_aux_outputs(self._handle, ptr(g_val), ptr(lam_x)))
         t0 = time.time() if self._stats else None
         if sd is not None:
             _lib.check(_lib.lib().hilo_nmpc_solve_tv(self._handle, B, ptr(x.contiguous()), ptr(sd), 0, ptr(v0t), ptr(u_old),
@@ -827,8 +832,8 @@ class NMPC:
             _lib.check(_lib.lib().hilo_nmpc_solve(self._handle, B, ptr(x.contiguous()), ptr(p), ps, ptr(v0t), ptr(u_old),
                                                   ptr(v_opt), ptr(f_opt), ptr(lam_g), ptr(u0), ptr(status), ptr(iters),
                                                   ptr(kkt), stream_ptr(dev)))
-        self._nlp_solution = {'x': v_opt, 'f': f_opt, 'lam_g': lam_g, 'status': status, 'iter_count': iters,
-                              'kkt_error': kkt}
+        self._nlp_solution = {'x': v_opt, 'f': f_opt, 'lam_g': lam_g, 'g': g_val, 'lam_x': lam_x, 'status': status,
+                              'iter_count': iters, 'kkt_error': kkt}
         if self._has_du:
             self._u_prev = v_opt[:, self._u_ind[0][:self._n_u]].contiguous()
         if self._ne:

@@ -321,6 +321,11 @@ int hilo_nmpc_create(const hilo_nmpc_desc* desc, int device, hilo_nmpc** out);  
 void hilo_nmpc_destroy(hilo_nmpc* h);
 int hilo_nmpc_dims(const hilo_nmpc* h, int* n_v, int* n_g, int* nx, int* nu, int* np);
 int hilo_nmpc_reset_warm_start(hilo_nmpc* h);
+/* The other two vectors of the reference's solver result (`self._nlp_solution = sol`, mpc.py:722-723): bound multipliers
+   lam_x [batch][n_v] (layout of v; CasADi's sign z_U - z_L; 0 for the pinned x_0) and constraint values g [batch][n_g] (layout
+   of lam_g; written when the solve is given a lam_g buffer).  DEVICE buffers the following solves write, or NULL to stop.
+   Layouts with a collocation output pass do not fill them (HILO leaves the buffers untouched). */
+int hilo_nmpc_set_aux_outputs(hilo_nmpc* h, double* g, double* lam_x);
 /* Sharded batches (one process per GPU, hilo_mpc_amd/dist.py): let the solve write row b = [u0 (nu) | status | iterations]
    (fp64) of the device table [batch][stride] itself - the send buffer of the per-step result gather.  NULL switches it off.
    Honoured by plain tracking problems; the reference has no counterpart (single instance, no batching). */
