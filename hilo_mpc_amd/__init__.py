@@ -20,5 +20,6 @@ from .nmpc import NMPC
 from . import expr
 from .mhe import MovingHorizonEstimator, MHE
 from .lmpc import LMPC
+from .control_loop import SimpleControlLoop
 
-__all__ += ['NMPC', 'MovingHorizonEstimator', 'MHE', 'LMPC', 'expr']
+__all__ += ['NMPC', 'MovingHorizonEstimator', 'MHE', 'LMPC', 'expr', 'SimpleControlLoop']

@@ -90,6 +90,7 @@ class QuadraticCost:
         self._terms = []          # (type, indices, W, ref)
         self._paths = []          # (state indices, W, [expression of theta])
         self._trajectories = []   # (kind, names, indices): references supplied per call
+        self._meas_terms = []     # (measurement indices, W, ref): costs on y = h(x, u) (modeling.py:385-408)
         self._is_set = False
 
     def _add(self, kind, names, pool, weights, ref, path_following, trajectory_tracking):
@@ -156,7 +157,49 @@ class QuadraticCost:
     _has_trajectory_following = property(lambda s: bool(s._trajectories))
 
     def add_measurements(self, names, weights, ref=None, path_following=False, trajectory_tracking=False):
-        raise NotImplementedError("measurement costs are not yet offloaded; add the corresponding states instead")
+        """modeling.py:385-408: (h(x, u) - ref)^T W (h(x, u) - ref) on the model's measurement equations; the reference (a
+        constant here) is divided by the measurement scaling at setup (modeling.py:310)."""
+        if path_following or trajectory_tracking:
+            raise NotImplementedError("measurement costs with path / trajectory references are not offloaded")
+        names = [names] if isinstance(names, str) else list(names)
+        ind = []
+        for n in names:
+            if n not in self._model.measurement_names:
+                raise ValueError(f"The measurement {n} does not exist. The available measurements are "
+                                 f"{self._model.measurement_names}")
+            ind.append(self._model.measurement_names.index(n))
+        W = _weight_matrix(weights, len(ind), 'weights')
+        r = np.zeros(len(ind)) if ref is None else np.asarray(_wrap_list(ref), dtype=float)
+        if r.size != len(ind):
+            raise ValueError("the reference must have one entry per measurement")
+        self._meas_terms.append((ind, W, r))
+        self._is_set = True
+
+    def _measurement_cost(self, y_scaling):
+        """The measurement terms as ONE expression of the model symbols (run-time compiled like a GenericCost; evaluated on the
+        scaled variables like every cost of the reference), or None."""
+        if not self._meas_terms:
+            return None
+        m = self._model
+        if getattr(m, '_symbolic', False):
+            meas = m._meas
+        else:
+            from . import zoo_expr
+            from .model import Model
+            if m.name not in zoo_expr.FUNCTOR:
+                raise NotImplementedError(f"measurement costs need the measurement equations as expressions; model '{m.name}' "
+                                          f"of the device zoo has none (available: {sorted(zoo_expr.FUNCTOR)})")
+            meas = zoo_expr.define(Model(name=m.name + '_expr'), m.name)._meas
+        sy = np.ones(len(meas)) if y_scaling is None else np.asarray(y_scaling, dtype=float)
+        total = None
+        for ind, W, r in self._meas_terms:
+            e = [meas[i] - float(r[q] / sy[i]) for q, i in enumerate(ind)]
+            for a in range(len(ind)):
+                for b in range(len(ind)):
+                    if W[a, b] != 0.0:
+                        t = float(W[a, b]) * (e[a] * e[b])
+                        total = t if total is None else total + t
+        return total
 
 
 class GenericCost:
@@ -386,6 +429,7 @@ class NMPC:
                 raise ValueError(f"{what} scaling dimension does not match the model")
             return v
         self._x_scaling, self._u_scaling = chk(x_scaling, self._n_x, 'x'), chk(u_scaling, self._n_u, 'u')
+        self._y_scaling = chk(y_scaling, getattr(self._model, 'n_y', 0), 'y')
 
     # ---- compact setters of the reference (same names, argument order and meaning) -------------------------------------
     def set_quadratic_stage_cost(self, states=None, cost_states=None, states_references=None, inputs=None, cost_inputs=None,
@@ -640,7 +684,13 @@ class NMPC:
         # ---- route: precompiled zoo variant, or compiled at run time (csrc/hilo_jit.hip) ----
         N, Nc = self._prediction_horizon, self._control_horizon
         cont = (not self._model.discrete) and self._nlp_options['objective_function'] == 'continuous'
-        generic = self.stage_cost._is_set or self.terminal_cost._is_set
+        ys = getattr(self, '_y_scaling', None)
+        meas_stage, meas_term = self.quad_stage_cost._measurement_cost(ys), self.quad_terminal_cost._measurement_cost(ys)
+        gen_stage = self.stage_cost._cost if meas_stage is None else \
+            (meas_stage if self.stage_cost._cost is None else self.stage_cost._cost + meas_stage)
+        gen_term = self.terminal_cost._cost if meas_term is None else \
+            (meas_term if self.terminal_cost._cost is None else self.terminal_cost._cost + meas_term)
+        generic = gen_stage is not None or gen_term is not None
         general = bool(nth or sc.is_set or tc.is_set)
         need_user = generic or Nc < N or cont or (coll is not None and (general or self._tv)) or (self._tv and general) or \
             bool(prog_fail)
@@ -662,7 +712,7 @@ class NMPC:
                 src = m.user_source()
             if policy == 2:
                 src += codegen.fun_source(
-                    nx, stage=self.stage_cost._cost, term=self.terminal_cost._cost,
+                    nx, stage=gen_stage, term=gen_term,
                     con=sc.constraint if sc.is_set else (), tcon=tc.constraint if tc.is_set else (),
                     path_stage=[r for _, _, rr in self.quad_stage_cost._paths for r in rr],
                     path_term=[r for _, _, rr in self.quad_terminal_cost._paths for r in rr])

@@ -204,3 +204,43 @@ def test_control_horizon_shorter_than_prediction_horizon(Nc):
     u2 = nmpc.optimize(x1, cp=spec['p'])
     assert np.array_equal(nmpc.solver_status_code, ref2['status'])
     np.testing.assert_allclose(u2, ref2['u0'], rtol=5e-5, atol=1e-6)
+
+
+def test_measurement_cost_terms_vs_oracle():
+    """`quad_stage_cost.add_measurements` (modeling.py:385-408): a cost on y = h(x, u) - here the CSTR's reaction rate, a
+    nonlinear measurement - against the oracle with the same term written as a generic stage cost on the scaled variables."""
+    import sympy as sp
+    from hilo_mpc_amd import NMPC, Model
+    from oracle import models
+    from oracle.nmpc_coll import CollIpm, CollNmpcProblem
+    from tests.problems import CSTR, cstr_equations
+    c = CSTR
+    plant = Model(name='plant')
+    x = plant.set_dynamical_states(['C_A', 'C_B', 'T'])
+    u = plant.set_inputs(['Q'])
+    ode, r = cstr_equations(x, u)
+    plant.set_dynamical_equations(ode)
+    plant.set_measurement_equations([r])
+    plant.setup(dt=c['dt'])
+    nmpc = NMPC(plant)
+    nmpc.quad_stage_cost.add_measurements(names=['y_0'], weights=[2e3], ref=[.004])
+    nmpc.quad_stage_cost.add_inputs(names=['Q'], weights=[1e-11], ref=[5e4])
+    nmpc.horizon = 6
+    nmpc.set_box_constraints(x_lb=c['x_lb'], x_ub=c['x_ub'], u_lb=c['u_lb'], u_ub=c['u_ub'])
+    nmpc.set_initial_guess(x_guess=c['x_guess'], u_guess=c['u_guess'])
+    nmpc.setup(solver_options={'ipopt.tol': 1e-10})
+    assert nmpc._jit and 'HAS_STAGE = true' in nmpc._user_source
+    m = models.get('cstr3')
+    rate = 5000. * sp.exp(-1e4 / (1.987 * m.x[2])) * m.x[0] - 1e6 * sp.exp(-1.5e4 / (1.987 * m.x[2])) * m.x[1]
+    pb = CollNmpcProblem(m, dt=c['dt'], N=6, degree=3, objective='continuous', generic_stage=2e3 * (rate - .004) ** 2,
+                         stage_inputs=[([0], [1e-11], [5e4])], x_lb=c['x_lb'], x_ub=c['x_ub'], u_lb=c['u_lb'], u_ub=c['u_ub'],
+                         x_guess=c['x_guess'], u_guess=c['u_guess'])
+    from oracle.nmpc import IpmOptions
+    x0 = np.array([[.6, .4, 430.], [.5, .5, 438.]])
+    ref = CollIpm(pb, IpmOptions(tol=1e-10)).solve(x0, [])
+    un = nmpc.optimize(x0)
+    assert np.array_equal(nmpc.solver_status_code, ref['status']) and np.all(ref['status'] == 1)
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-9)
+    np.testing.assert_allclose(un, ref['u0'], rtol=1e-5)
+    with pytest.raises(ValueError, match="does not exist"):
+        nmpc.quad_stage_cost.add_measurements(names=['nope'], weights=[1.])
