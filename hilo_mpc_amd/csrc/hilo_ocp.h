@@ -1083,6 +1083,178 @@ struct Ocp {
     }
   }
 
+  // ---- backward recursion with the cost-to-go in registers (MFMA_STAGE policies with inputs, no held inputs) ----------------
+  // The accumulator layout of v_mfma_f64_16x16x4 puts entry (row g + 4 r, column q) of the stage matrix
+  //     M = [A B]^T P_{k+1} [A B] + [H_k | r_k]          (column NZ = right-hand side)
+  // into register r of lane 16 g + q.  The same lane then computes entry (g + 4 r, q) of P_k (q < NX) or of p_k (q = NZ):
+  //     P_k[i][j] = sym(M_xx)[i][j] - w_i . w_j,   w_j = L^-1 M_ux[:, j],   R_k = M_uu = L L^T     (p_k: column NZ)
+  // - with the columns of M_ux fetched from the lanes that hold them (ds_bpermute: the LDS crossbar without a store / barrier /
+  // load round trip) - and that register IS the A operand P_k[q][4 kb + g] of the next stage's first product (P symmetric, and
+  // kept bitwise symmetric: both lanes of a pair run the same arithmetic on swapped factors).  So the recursion never waits
+  // for LDS: feedback, closed-loop matrices, P_k and p_k are stored for the forward sweep on the side.
+  // operands of stage k that do not depend on the recursion (fetched one stage ahead of their use)
+  struct StageOps {
+    double b1[(NX + 3) / 4], a2[(NX + 3) / 4], ai_q[(NX + 3) / 4], ci[(NX + 3) / 4], bi[(NX + 3) / 4][NU > 0 ? NU : 1];
+    v4d M0;
+  };
+  __device__ __forceinline__ static void stage_ops(const Lds l, int k, double delta, bool resto, int q, int g, StageOps& o) {
+    constexpr int KB = (NX + 3) / 4, RB = (NZ + 3) / 4;
+    const int qz = q < NZ ? q : NZ - 1;
+    cdp AB = l.AB + k * NX * NZ;
+    o.M0 = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int kk = 4 * kb + g;
+      const bool kv = kk < NX;
+      const int kc = kv ? kk : NX - 1;
+      const double ab = AB[kc * NZ + qz], cn = l.c[k * NX + kc];
+      o.b1[kb] = kv ? (q < NZ ? ab : (q == NZ ? -cn : 0.0)) : 0.0;
+      o.a2[kb] = (kv && q < NZ) ? ab : 0.0;
+      o.ai_q[kb] = ab;        // A[i][q] for i = 4 kb + g, q < NX (closed-loop coefficient)
+      o.ci[kb] = cn;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) o.bi[kb][a] = AB[kc * NZ + NX + a];
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int i = g + 4 * r;
+      const bool iv = i < NZ, rhs = q == NZ;
+      const int ic = iv ? i : NZ - 1, jj = q < NZ ? q : 0;
+      const double rbv = l.rb[k * NZ + ic], wv = l.W[k * NZ * NZ + ic * NZ + jj], sg = l.sig[k * NZ + ic];
+      double h = rhs ? rbv : (resto ? 0.0 : wv);
+      if (ic == q) h += (resto ? 1.0 : delta) + sg;
+      if constexpr (NC > 0) {  // eliminated slack rows: + Jd^T (Sigma_s + delta) Jd, rhs + Jd^T ((Sigma_s + delta)(d - s) + crb)
+#pragma unroll
+        for (int m = 0; m < NC; ++m) {
+          const int rr = k * NC + m;
+          const double wgt = (resto ? 1.0 : delta) + l.csig[rr];
+          const double ds = l.cd[rr] - l.cs[rr], cr = l.crb[rr], jr = l.Jd[rr * NZ + jj];
+          const double right = rhs ? wgt * ds + cr : wgt * jr;
+          h += l.Jd[rr * NZ + ic] * right;
+        }
+      }
+      o.M0[r] = (iv && q <= NZ) ? h : 0.0;
+    }
+  }
+
+  // ---- backward recursion with the cost-to-go in registers (MFMA_STAGE policies with inputs, no held inputs) ----------------
+  // The accumulator layout of v_mfma_f64_16x16x4 puts entry (row g + 4 r, column q) of the stage matrix
+  //     M = [A B]^T P_{k+1} [A B] + [H_k | r_k]          (column NZ = right-hand side)
+  // into register r of lane 16 g + q.  The same lane then computes entry (g + 4 r, q) of P_k (q < NX) or of p_k (q = NZ):
+  //     P_k[i][j] = sym(M_xx)[i][j] - w_i . w_j,   w_j = L^-1 M_ux[:, j],   R_k = M_uu = L L^T     (p_k: column NZ)
+  // - with the columns of M_ux fetched from the lanes that hold them (ds_bpermute: the LDS crossbar without a store / barrier /
+  // load round trip) - and that register IS the A operand P_k[q][4 kb + g] of the next stage's first product (P symmetric, and
+  // kept bitwise symmetric: both lanes of a pair run the same arithmetic on swapped factors).  So the recursion never waits
+  // for LDS: feedback, closed-loop matrices, P_k and p_k are stored for the forward sweep on the side, the operands of the
+  // next stage are fetched while the pivot block of this one is factored (one basic block per stage: the positivity of the
+  // pivots is collected and tested after the loop).
+  __device__ __forceinline__ static bool backward_reg(const Lds l, const OcpConst& pc, int N, double delta, bool resto) {
+    const int t = threadIdx.x, q = t & 15, g = t >> 4;
+    constexpr int KB = (NX + 3) / 4;
+    const int qx = q < NX ? q : NX - 1;
+    const bool colP = q < NX, colR = q == NZ;
+    double Pr[KB], pr[KB];
+#pragma unroll
+    for (int r = 0; r < KB; ++r) {
+      const int row = g + 4 * r, rc = row < NX ? row : NX - 1;
+      const double pe = l.P[N * NX * NX + rc * NX + qx], pv_ = l.pv[N * NX + rc];
+      Pr[r] = (row < NX && colP) ? pe : 0.0;
+      pr[r] = (row < NX && colR) ? pv_ : 0.0;
+    }
+    StageOps o;
+    stage_ops(l, N - 1, delta, resto, q, g, o);
+    bool pd = true;
+    for (int k = N - 1; k >= 0; --k) {
+      // T = P_{k+1} [A B | -c] + [0 | p_{k+1}];  M = [A B]^T T + [H_k | r_k]
+      v4d Tacc = {0.0, 0.0, 0.0, 0.0}, Macc = o.M0;
+#pragma unroll
+      for (int r = 0; r < KB; ++r) Tacc[r] = pr[r];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) Tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pr[kb], o.b1[kb], Tacc, 0, 0, 0);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) Macc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a2[kb], Tacc[kb], Macc, 0, 0, 0);
+      const StageOps c = o;                           // this stage's closed-loop operands
+      stage_ops(l, k > 0 ? k - 1 : 0, delta, resto, q, g, o);   // next stage's operands: in flight during the factorisation
+      // cross-lane fetches of the M_ux columns and the mirrored M_xx entries, all issued before they are needed
+      double wq[NU], yq[NU], wi[KB][NU], mji[KB];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) wq[a] = __shfl(Macc[(NX + a) / 4], 16 * ((NX + a) % 4) + q);
+#pragma unroll
+      for (int r = 0; r < KB; ++r) {
+        const int i = g + 4 * r, ic = i < NX ? i : NX - 1;
+#pragma unroll
+        for (int a = 0; a < NU; ++a) wi[r][a] = __shfl(Macc[(NX + a) / 4], 16 * ((NX + a) % 4) + ic);
+        mji[r] = 0.0;   // M[q][i]: register q / 4 of lane 16 (q % 4) + i
+#pragma unroll
+        for (int rr = 0; rr < KB; ++rr) {
+          const double v = __shfl(Macc[rr], 16 * (qx % 4) + ic);
+          mji[r] = (qx / 4 == rr) ? v : mji[r];
+        }
+      }
+      // reduced pivot block R_k = M_uu out of the accumulators, factored redundantly per lane
+      double Rl[NU * NU], Lc[NU * NU], invd[NU];
+#pragma unroll
+      for (int a = 0; a < NU; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 <= a; ++c2) {
+          const int i = NX + a, j = NX + c2;
+          Rl[a * NU + c2] = read_lane(Macc[i / 4], 16 * (i % 4) + j);
+        }
+      pd = small_chol_reg<NU>(Rl, Lc, invd) && pd;
+      // this lane's column: w_q = L^-1 M_ux[:, q] (column NZ: m_u), y_q = L^-T w_q
+#pragma unroll
+      for (int a = 0; a < NU; ++a) {
+        double sv = wq[a];
+#pragma unroll
+        for (int c2 = 0; c2 < a; ++c2) sv -= Lc[a * NU + c2] * wq[c2];
+        wq[a] = sv * invd[a];
+      }
+#pragma unroll
+      for (int a = NU - 1; a >= 0; --a) {
+        double sv = wq[a];
+#pragma unroll
+        for (int c2 = a + 1; c2 < NU; ++c2) sv -= Lc[c2 * NU + a] * yq[c2];
+        yq[a] = sv * invd[a];
+      }
+      if (g == 0 && (colP || colR)) {   // feedback K[:, q] = -y_q, feed-forward kff = -y_NZ
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          dp kd = colR ? l.kff + k * NU + a : l.Kg + (k * NU + a) * NX + qx;
+          *kd = -yq[a];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < KB; ++r) {
+        const int i = g + 4 * r, ic = i < NX ? i : NX - 1;
+        const bool valid = i < NX;
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          double sv = wi[r][a];
+#pragma unroll
+          for (int c2 = 0; c2 < a; ++c2) sv -= Lc[a * NU + c2] * wi[r][c2];
+          wi[r][a] = sv * invd[a];
+        }
+        double sv = colR ? Macc[r] : 0.5 * (Macc[r] + mji[r]);
+#pragma unroll
+        for (int a = 0; a < NU; ++a) sv -= wi[r][a] * wq[a];
+        double cl = colR ? -c.ci[r] : c.ai_q[r];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) cl -= c.bi[r][a] * yq[a];
+        Pr[r] = (valid && colP) ? sv : 0.0;
+        pr[r] = (valid && colR) ? sv : 0.0;
+        if (valid && colP) {
+          l.P[k * NX * NX + ic * NX + qx] = sv;
+          l.Acl[k * NX * NX + ic * NX + qx] = cl;
+        }
+        if (valid && colR) {
+          l.pv[k * NX + ic] = sv;
+          l.bcl[k * NX + ic] = cl;
+        }
+      }
+    }
+    return uni(pd);
+  }
+
   // ---- Riccati factor + solve of the Newton system; false when a reduced pivot is not positive ---------------
   // Per stage: (1) M = H_k + [A B]^T P_{k+1} [A B] and its right-hand side on the f64 matrix cores, the reduced pivot
   // block broadcast from the accumulators and factored (redundantly per lane) while M goes through LDS; (2) feedback K,
@@ -1116,6 +1288,12 @@ struct Ocp {
       }
     }
     __syncthreads();
+#ifndef HILO_RICCATI_LDS
+    if constexpr (MFMA_STAGE && NU > 0 && NH == 0) {
+      if (!backward_reg(l, pc, N, delta, resto)) return false;
+      __syncthreads();
+    } else
+#endif
     for (int k = N - 1; k >= 0; --k) {
       cdp Pn = l.P + (k + 1) * NX * NX;
       cdp pn = l.pv + (k + 1) * NX;
@@ -1407,6 +1585,7 @@ struct Ocp {
     }
     OCP_FOR(a, NU) l.D[N * NZ + NX + a] = 0.0;
     __syncthreads();
+    DTICK(11)
     if constexpr (NC > 0) {  // recover the eliminated slack step and the new multipliers of d - s = 0
       OCP_FOR(e, N * NC) {
         const int k = e / NC, m = e - k * NC;

@@ -134,6 +134,7 @@ def test_learned_term_over_state_input_and_parameter_features():
     m = m.discretize('erk', order=4).setup(dt=.5)
     nmpc = NMPC(m)
     nmpc.quad_stage_cost.add_states(names=['X'], weights=[1.], ref=[1.])
+    nmpc.quad_stage_cost.add_inputs(names=['DS', 'DI'], weights=[.1, .1])      # a regular problem: every input is priced
     nmpc.horizon = 5
     nmpc.setup(options={'integration_method': 'discrete'})
     B = 32

@@ -17,3 +17,4 @@ u = nmpc.optimize(x, cp=p); torch.cuda.synchronize()
 f(out, 0)
 it = int(nmpc._nlp_solution['iter_count'][0]) + 1
 print('derivative evaluations', it, [round(v / it) for v in out[:8]])
+print('riccati per call: backward loop, x0 part, forward sweep, recovery', [round(v / (it - 1)) for v in out[8:12]])
