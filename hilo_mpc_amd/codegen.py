@@ -124,7 +124,7 @@ def model_source(n_x, n_u, n_p, ode, meas, discrete):
     # a learned term keeps the Taylor sweeps
     if not any(n.op == 'gp' for e in ode for n in Expr.wrap(e).nodes().values()):
         from .symdiff import sym_source
-        src += sym_source('UserModel', n_x, n_u, ode)
+        src += sym_source('UserModel', n_x, n_u, ode, meas if not any(n.op == 'gp' for e in meas for n in Expr.wrap(e).nodes().values()) else None)
     return src
 
 

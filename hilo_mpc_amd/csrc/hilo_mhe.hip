@@ -9,6 +9,7 @@
 //   J   = arrival(x_0) at k = 0; (h(x_k)-y_k)^T Wy (.) + w_k^T Ww w_k, k >= 1  mhe.py:742-748 (no stage cost at k = 0)
 //   costs act on un-scaled quantities (hilo_mpc/util/modeling.py:665-672)
 // In engine terms: controls := the noise w_k (B_k = I), x_0 free, per-stage data = (u_meas_k, y_meas_k).
+#include <stdlib.h>
 #include <string.h>
 
 #include "hilo_mhe_est.h"
@@ -17,8 +18,13 @@
 namespace hilo {
 
 // pc.cost = [Wx | Wy | Ww | su];  par = [model parameters | x_arrival];  sd_k = [u_meas_k | y_meas_k]
-template <class M>
+// SYM_: model / measurement derivatives from generated symbolic code when the model has it (the host selects SYM_ = false for
+// sub-stepped integration)
+template <class M, bool SYM_ = true>
 struct MheNoise {
+  using Model = M;
+  static constexpr bool SYM_MHE = SYM_ && ModelSym<M>::value && ModelSym<M>::HAS_MEAS && !model_has_ext<M>::value &&
+                                  !M::DISCRETE && M::NX % 2 == 0;
   static constexpr int NX = M::NX, NU = M::NX, NY = M::NY, MU = M::NU, NPAR = M::NP + M::NX, NSD = M::NU + M::NY;
   static constexpr bool FIX_X0 = false;
   static constexpr bool BIG = false;  // iterate in LDS
@@ -296,11 +302,10 @@ extern "C" int hilo_mhe_reset_warm_start(hilo_mhe* h) {
   return HILO_OK;
 }
 
-template <class M>
-static int mhe_launch(hilo_mhe* h, int64_t batch, const double* v0, int64_t v0s, int prefix_in_v0, double* v_opt,
-                      double* f_opt, double* lam_g, double* x_opt, int32_t* status, int32_t* iters, double* kkt,
-                      hipStream_t s) {
-  using PB = MheNoise<M>;
+template <class PB>
+static int mhe_launch_pb(hilo_mhe* h, int64_t batch, const double* v0, int64_t v0s, int prefix_in_v0, double* v_opt,
+                         double* f_opt, double* lam_g, double* x_opt, int32_t* status, int32_t* iters, double* kkt,
+                         hipStream_t s) {
   if (h->lds_bytes > 64 * 1024)
     HILO_HIP_CHECK(hipFuncSetAttribute((const void*)ocp_solve_kernel<PB, OCP_TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)h->lds_bytes));
@@ -312,6 +317,17 @@ static int mhe_launch(hilo_mhe* h, int64_t batch, const double* v0, int64_t v0s,
                      x_opt, 1, status, iters, kkt, (long long*)nullptr);
   HILO_HIP_CHECK(hipGetLastError());
   return HILO_OK;
+}
+
+template <class M>
+static int mhe_launch(hilo_mhe* h, int64_t batch, const double* v0, int64_t v0s, int prefix_in_v0, double* v_opt,
+                      double* f_opt, double* lam_g, double* x_opt, int32_t* status, int32_t* iters, double* kkt,
+                      hipStream_t s) {
+  if constexpr (MheNoise<M>::SYM_MHE) {
+    if (h->host.nsub != 1 || getenv("HILO_NMPC_TAYLOR"))
+      return mhe_launch_pb<MheNoise<M, false>>(h, batch, v0, v0s, prefix_in_v0, v_opt, f_opt, lam_g, x_opt, status, iters, kkt, s);
+  }
+  return mhe_launch_pb<MheNoise<M>>(h, batch, v0, v0s, prefix_in_v0, v_opt, f_opt, lam_g, x_opt, status, iters, kkt, s);
 }
 
 extern "C" int hilo_mhe_estimate(hilo_mhe* h, int64_t batch, const double* x_arrival, const double* p, int64_t p_stride,

@@ -57,7 +57,7 @@ template <class A> struct same_type<A, A> : bool_const<true> {};
 
 // symbolic derivatives of a model's right-hand side (generated: hilo_models_sym.h for the zoo, hilo_mpc_amd/codegen.py for
 // models written as expressions); absent -> the engine differentiates with Taylor sweeps
-template <class M> struct ModelSym { static constexpr bool value = false; };
+template <class M> struct ModelSym { static constexpr bool value = false, HAS_MEAS = false; };
 
 template <class M, class = void> struct model_has_ext : bool_const<false> {};
 template <class M> struct model_has_ext<M, void_tt<decltype(M::EXT)>> : bool_const<M::EXT> {};

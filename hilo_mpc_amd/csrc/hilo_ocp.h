@@ -169,6 +169,8 @@ template <class PB, class = void> struct pb_nh { static constexpr int value = 0;
 template <class PB> struct pb_nh<PB, void_tt<decltype(PB::NH)>> { static constexpr int value = PB::NH; };
 template <class PB, class = void> struct pb_sym { static constexpr bool value = false; };
 template <class PB> struct pb_sym<PB, void_tt<decltype(PB::SYM)>> { static constexpr bool value = PB::SYM; };
+template <class PB, class = void> struct pb_sym_mhe { static constexpr bool value = false; };
+template <class PB> struct pb_sym_mhe<PB, void_tt<decltype(PB::SYM_MHE)>> { static constexpr bool value = PB::SYM_MHE; };
 template <class PB, class = void> struct pb_fused { static constexpr bool value = false; };
 template <class PB> struct pb_fused<PB, void_tt<decltype(PB::FUSED)>> { static constexpr bool value = PB::FUSED; };
 
@@ -224,6 +226,7 @@ struct Ocp {
   // model derivatives as generated straight-line code (ModelSym<PB::Model>, csrc/hilo_models_sym.h / codegen): second-order
   // adjoint through the Runge-Kutta stages instead of Taylor sweeps per direction pair (eval_derivs_sym)
   static constexpr bool SYM = pb_sym<PB>::value;
+  static constexpr bool SYM_MHE = pb_sym_mhe<PB>::value;   // the same for the moving-horizon estimator's policy (eval_derivs_sym_mhe)
   // model with a learned term: lanes that evaluate the dynamics at the same point share its kernel sum (GpExt)
   static constexpr bool COOP = PB::COOP;
   static constexpr int NEXT = COOP ? 12 * OCP_TPB : 0;
@@ -380,7 +383,7 @@ struct Ocp {
         if constexpr (FUSED) {
           fpart += PB::dyn_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
         } else {
-          if constexpr (SYM) {   // the arithmetic of the derivative phase (division = x * rcp_fast(y)): same defects in both
+          if constexpr (SYM || SYM_MHE) {   // the arithmetic of the derivative phase (division = x * rcp_fast(y)): same defects in both
             FastD xf[NX], uf[NU > 0 ? NU : 1], xnf[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) xf[i] = FastD(x[i]);
@@ -860,6 +863,310 @@ struct Ocp {
     return f;
   }
 
+  // ---- the same derivative evaluation for the moving-horizon estimator (policy MheNoise, csrc/hilo_mhe.hip) ----------------
+  // Engine variables of stage k: z = (x_k, w_k) with x_{k+1} = Phi(x_k; u_meas_k, p) / s_x + w_k.  Only x enters nonlinearly:
+  // tangent columns for the NX state directions (NX / 2 lanes per interval: N = 30 is one pass), B_k = I, and a Hessian with the
+  // blocks  W_xx = l_xx - lam'^T Phi_xx,  W_ww = l_ww,  W_xw = 0.  Cost of the reference (mhe.py:742-748): arrival
+  // (x_0 - x_a)^T Wx (.) at k = 0; for k >= 1  r^T Wy r + w^T Ww w  with r = h(x_k) - y_k on UN-scaled quantities - value,
+  // gradient and Hessian from the symbolic measurement derivatives ModelSym<M>::mjh (Jy, and Hy contracted with 2 Wy r).
+  __device__ __attribute__((always_inline)) static double eval_derivs_sym_mhe(lds_double* lbase, double* ws) {
+    using M = typename PB::Model;
+    using MS = ModelSym<M>;
+    constexpr int MU = PB::MU, NY = PB::NY, MZ = NX + MU, MU1 = MU > 0 ? MU : 1, NP = M::NP;
+    static_assert(NU == NX && NC == 0 && !COOP && !FIX_X0 && NH == 0 && !M::DISCRETE && NX % 2 == 0, "SYM_MHE: the MheNoise policy");
+    constexpr int CPL = 2, LPI = NX / CPL;
+    const Lds l = carve(lbase, ws);
+    const OcpConst& pc = *(const OcpConst*)l.pc;
+    const int N = pc.N, order = pc.order;
+    const double h = pc.dt;
+    const double a10 = order >= 2 ? 0.5 : 0.0, a20 = order == 3 ? -1.0 : 0.0, a21 = order == 3 ? 2.0 : (order == 4 ? 0.5 : 0.0),
+                 a32 = order == 4 ? 1.0 : 0.0;
+    const double hb[4] = {h * erk_b<0>(order), h * erk_b<1>(order), h * erk_b<2>(order), h * erk_b<3>(order)};
+    const double* par = (const double*)l.par;
+    double fpart = 0.0;
+    OCP_FOR(d, NXDIR) l.Qd[N * NDIR + d] = 0.0;          // no terminal cost (mhe.py: the window ends with the last measurement)
+    OCP_FOR(a, NZ) l.grad[N * NZ + a] = 0.0;
+    constexpr int IPP = OCP_TPB / LPI;
+    for (int kbase = 0; kbase < N; kbase += IPP) {
+      const int li = (int)threadIdx.x / LPI;
+      const bool act = li < IPP && kbase + li < N;
+      const int k = act ? kbase + li : N - 1, g = act ? (int)threadIdx.x - li * LPI : 0, c0 = g * CPL;
+      const double* sd = sd_of(l, k);
+      double xsv[NX], wv[NX], sz[NX], sw[NX], isz[NX], x[NX], ue[MU1], lamp[NX], X[4][NX], kb[4][NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        xsv[i] = l.Z[k * NZ + i];
+        wv[i] = l.Z[k * NZ + NX + i];
+        sz[i] = pc.sz[i];
+        sw[i] = pc.sz[NX + i];
+        isz[i] = rcp_fast(sz[i]);
+        x[i] = xsv[i] * sz[i];
+        lamp[i] = l.lam[k * NX + i] * isz[i];
+      }
+#pragma unroll
+      for (int i = 0; i < MU; ++i) ue[i] = sd[i] * pc.cost[PB::O_SU + i];
+      // ---- cost of the stage: value (one lane), gradient entries and Hessian columns of this lane ----
+      double chx[NX][CPL], chw[NX][CPL], gx[CPL], gw[CPL];
+      {
+        double Jy[NY * NX], Hy[NX * (NX + 1) / 2], kby[NY], r[NY], yv[NY], ws_[NX];
+        double val = 0.0;
+        if (k == 0) {   // arrival cost on the un-scaled state
+          double d[NX];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) d[i] = x[i] - par[NP + i];
+#pragma unroll
+          for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int j = 0; j < NX; ++j) val += d[i] * pc.cost[PB::O_WX + i * NX + j] * d[j];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const int col = c0 + c;
+            double gacc = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) gacc += (pc.cost[PB::O_WX + col * NX + j] + pc.cost[PB::O_WX + j * NX + col]) * d[j];
+            double scol = sz[0];
+#pragma unroll
+            for (int q2 = 1; q2 < NX; ++q2) scol = col == q2 ? sz[q2] : scol;
+            gx[c] = gacc * scol;
+            gw[c] = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < NX; ++rr) {
+              chx[rr][c] = (pc.cost[PB::O_WX + rr * NX + col] + pc.cost[PB::O_WX + col * NX + rr]) * sz[rr] * scol;
+              chw[rr][c] = 0.0;
+            }
+          }
+        } else {
+          // r = h(x) - y, kb = (Wy + Wy^T) r, then Jy and the kb-contracted Hessian of h
+#pragma unroll
+          for (int a = 0; a < NY; ++a) kby[a] = 0.0;
+          MS::mjh(x, ue, par, kby, yv, Jy, Hy);   // first call: only y is used
+#pragma unroll
+          for (int a = 0; a < NY; ++a) r[a] = yv[a] - sd[MU + a];
+#pragma unroll
+          for (int a = 0; a < NY; ++a) {
+            double acc = 0.0;
+#pragma unroll
+            for (int b2 = 0; b2 < NY; ++b2) {
+              acc += (pc.cost[PB::O_WY + a * NY + b2] + pc.cost[PB::O_WY + b2 * NY + a]) * r[b2];
+              val += r[a] * pc.cost[PB::O_WY + a * NY + b2] * r[b2];
+            }
+            kby[a] = acc;
+          }
+          MS::mjh(x, ue, par, kby, yv, Jy, Hy);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) ws_[i] = wv[i] * sw[i];
+#pragma unroll
+          for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int j = 0; j < NX; ++j) val += ws_[i] * pc.cost[PB::O_WW + i * NX + j] * ws_[j];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const int col = c0 + c;
+            double scol = sz[0], swcol = sw[0];
+#pragma unroll
+            for (int q2 = 1; q2 < NX; ++q2) { scol = col == q2 ? sz[q2] : scol; swcol = col == q2 ? sw[q2] : swcol; }
+            double gacc = 0.0, gwacc = 0.0;
+#pragma unroll
+            for (int a = 0; a < NY; ++a) {
+              double jac = Jy[a * NX + 0];
+#pragma unroll
+              for (int q2 = 1; q2 < NX; ++q2) jac = col == q2 ? Jy[a * NX + q2] : jac;
+              gacc += kby[a] * jac;
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) gwacc += (pc.cost[PB::O_WW + col * NX + j] + pc.cost[PB::O_WW + j * NX + col]) * ws_[j];
+            gx[c] = gacc * scol;
+            gw[c] = gwacc * swcol;
+#pragma unroll
+            for (int rr = 0; rr < NX; ++rr) {
+              // (Jy^T (Wy + Wy^T) Jy)[rr][col] + Hy(kb)[rr][col]
+              double acc = 0.0;
+#pragma unroll
+              for (int a = 0; a < NY; ++a) {
+                double t2 = 0.0;
+#pragma unroll
+                for (int b2 = 0; b2 < NY; ++b2) {
+                  double jb = Jy[b2 * NX + 0];
+#pragma unroll
+                  for (int q2 = 1; q2 < NX; ++q2) jb = col == q2 ? Jy[b2 * NX + q2] : jb;
+                  t2 += (pc.cost[PB::O_WY + a * NY + b2] + pc.cost[PB::O_WY + b2 * NY + a]) * jb;
+                }
+                acc += Jy[a * NX + rr] * t2;
+              }
+              double hy = 0.0;
+#pragma unroll
+              for (int q2 = 0; q2 < NX; ++q2) {
+                const double hv2 = Hy[rr >= q2 ? rr * (rr + 1) / 2 + q2 : q2 * (q2 + 1) / 2 + rr];
+                hy = col == q2 ? hv2 : hy;
+              }
+              chx[rr][c] = (acc + hy) * sz[rr] * scol;
+              chw[rr][c] = (pc.cost[PB::O_WW + rr * NX + col] + pc.cost[PB::O_WW + col * NX + rr]) * sw[rr] * swcol;
+            }
+          }
+        }
+        if (act && g == 0) fpart += val;
+      }
+      {  // stage points, slopes, Phi, defect
+        FastD kk[4][NX], uf[MU1];
+#pragma unroll
+        for (int i = 0; i < MU; ++i) uf[i] = FastD(ue[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          FastD Xf[NX];
+#pragma unroll
+          for (int s2 = 0; s2 < NX; ++s2) {
+            double acc = x[s2];
+            if (i == 1) acc += (h * a10) * kk[0][s2].v;
+            if (i == 2) acc += (h * a20) * kk[0][s2].v + (h * a21) * kk[1][s2].v;
+            if (i == 3) acc += (h * a32) * kk[2][s2].v;
+            X[i][s2] = acc;
+            Xf[s2] = FastD(acc);
+          }
+          if (i < order) {
+            M::ode(Xf, uf, par, h, kk[i]);
+          } else {
+#pragma unroll
+            for (int s2 = 0; s2 < NX; ++s2) kk[i][s2] = FastD(0.0);
+          }
+        }
+        if (act && g == 0) {
+#pragma unroll
+          for (int s2 = 0; s2 < NX; ++s2) {
+            const double phi = x[s2] + hb[0] * kk[0][s2].v + hb[1] * kk[1][s2].v + hb[2] * kk[2][s2].v + hb[3] * kk[3][s2].v;
+            l.c[k * NX + s2] = l.Z[(k + 1) * NZ + s2] - (phi * isz[s2] + wv[s2]);
+          }
+        }
+      }
+      // adjoint weights of the slopes (reverse over the stages)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s2 = 0; s2 < NX; ++s2) kb[i][s2] = hb[i] * lamp[s2];
+#pragma unroll
+      for (int j = 3; j >= 1; --j) {
+        if (j < order) {
+          double fx[NX * NX], t2[NX];
+          MS::jx(X[j], ue, par, fx);
+#pragma unroll
+          for (int n = 0; n < NX; ++n) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < NX; ++m) acc += fx[m * NX + n] * kb[j][m];
+            t2[n] = acc;
+          }
+#pragma unroll
+          for (int n = 0; n < NX; ++n) {
+            if (j == 3) kb[2][n] += (h * a32) * t2[n];
+            if (j == 2) { kb[1][n] += (h * a21) * t2[n]; kb[0][n] += (h * a20) * t2[n]; }
+            if (j == 1) kb[0][n] += (h * a10) * t2[n];
+          }
+        }
+      }
+      // tangent columns (state directions only) and the second-order adjoint, stage by stage
+      dp scr = l.W + (size_t)k * NZ * NZ;           // [NX][NX] tangent block of the interval
+      double dXc[NX][CPL], dX2[NX][CPL], dPhi[NX][CPL], G[NX][CPL];
+#pragma unroll
+      for (int s2 = 0; s2 < NX; ++s2)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          dXc[s2][c] = (c0 + c == s2) ? 1.0 : 0.0;
+          dX2[s2][c] = dXc[s2][c];
+          dPhi[s2][c] = dXc[s2][c];
+          G[s2][c] = 0.0;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < order) {
+          if (act) {
+#pragma unroll
+            for (int s2 = 0; s2 < NX; ++s2)
+#pragma unroll
+              for (int c = 0; c < CPL; ++c) scr[s2 * NX + c0 + c] = dXc[s2][c];
+          }
+          __syncthreads();
+          double dK[NX][CPL], v[NX][CPL];
+          {
+            double J[NX * MZ], H[MZ * (MZ + 1) / 2];
+            MS::jh(X[i], ue, par, kb[i], J, H);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+#pragma unroll
+              for (int m = 0; m < NX; ++m) {
+                double acc = 0.0;
+#pragma unroll
+                for (int n = 0; n < NX; ++n) acc += J[m * MZ + n] * dXc[n][c];
+                dK[m][c] = acc;
+              }
+#pragma unroll
+              for (int a = 0; a < NX; ++a) {
+                double acc = 0.0;
+#pragma unroll
+                for (int n = 0; n < NX; ++n) acc += H[a >= n ? a * (a + 1) / 2 + n : n * (n + 1) / 2 + a] * dXc[n][c];
+                v[a][c] = acc;
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < NX; ++r) {
+            double col_r[NX];
+#pragma unroll
+            for (int a = 0; a < NX; ++a) col_r[a] = scr[a * NX + r];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+              double acc = 0.0;
+#pragma unroll
+              for (int a = 0; a < NX; ++a) acc += col_r[a] * v[a][c];
+              G[r][c] += acc;
+            }
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < NX; ++s2)
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+              const double e = (c0 + c == s2) ? 1.0 : 0.0;
+              dPhi[s2][c] += hb[i] * dK[s2][c];
+              if (i == 0) { dXc[s2][c] = e + (h * a10) * dK[s2][c]; dX2[s2][c] = e + (h * a20) * dK[s2][c]; }
+              if (i == 1) dXc[s2][c] = dX2[s2][c] + (h * a21) * dK[s2][c];
+              if (i == 2) dXc[s2][c] = e + (h * a32) * dK[s2][c];
+            }
+          __syncthreads();
+        }
+      }
+      if (act) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const int col = c0 + c;
+          double scol = sz[0];
+#pragma unroll
+          for (int q2 = 1; q2 < NX; ++q2) scol = col == q2 ? sz[q2] : scol;
+          l.grad[k * NZ + col] = gx[c];
+          l.grad[k * NZ + NX + col] = gw[c];
+#pragma unroll
+          for (int m = 0; m < NX; ++m) {
+            l.AB[(k * NX + m) * NZ + col] = dPhi[m][c] * scol * isz[m];       // A = d(Phi / s_x) / d x_s
+            l.AB[(k * NX + m) * NZ + NX + col] = m == col ? 1.0 : 0.0;        // B = I (additive noise)
+          }
+#pragma unroll
+          for (int r = 0; r < NX; ++r) {
+            if (r >= col) {   // one value for (r, col) and (col, r): exact symmetry
+              const double hxx = chx[r][c] - sz[r] * scol * G[r][c], hww = chw[r][c];
+              l.W[(size_t)k * NZ * NZ + r * NZ + col] = hxx;
+              l.W[(size_t)k * NZ * NZ + col * NZ + r] = hxx;
+              l.W[(size_t)k * NZ * NZ + (NX + r) * NZ + NX + col] = hww;
+              l.W[(size_t)k * NZ * NZ + (NX + col) * NZ + NX + r] = hww;
+            }
+            l.W[(size_t)k * NZ * NZ + (NX + r) * NZ + col] = 0.0;             // state / noise cross block
+            l.W[(size_t)k * NZ * NZ + col * NZ + NX + r] = 0.0;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const double f = block_reduce<OpSum>(fpart, l.red);
+    __syncthreads();
+    return f;
+  }
+
   __device__ OCP_PHASE static double eval_derivs_call(lds_double* lbase, double* ws) {
     return eval_derivs_body(uni(lbase), uni(ws));
   }
@@ -868,6 +1175,7 @@ struct Ocp {
   __device__ __forceinline__ static double eval_derivs(lds_double* lbase, double* ws) {
     if constexpr (COOP) return uni(eval_derivs_call(lbase, ws));
     else if constexpr (SYM) return eval_derivs_sym(lbase, ws);
+    else if constexpr (SYM_MHE) return eval_derivs_sym_mhe(lbase, ws);
     else return eval_derivs_body(lbase, ws);
   }
 

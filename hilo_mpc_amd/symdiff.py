@@ -304,7 +304,7 @@ def derivative_dag(n_x, n_u, ode):
     return g, f, J, H, kb
 
 
-def sym_source(struct_name, n_x, n_u, ode):
+def sym_source(struct_name, n_x, n_u, ode, meas=None):
     """`template <> struct ModelSym<struct_name>` with jx and jh for the right-hand side `ode` (expressions)."""
     g, f, J, H, kb = derivative_dag(n_x, n_u, ode)
     nz = n_x + n_u
@@ -316,6 +316,35 @@ def sym_source(struct_name, n_x, n_u, ode):
     body2 = (lines2 + [f"    J[{m * nz + j}] = {ref2[J[m][j]]};" for m in range(n_x) for j in range(nz)] +
              [f"    H[{q}] = {ref2[h]};" for q, h in enumerate(H)])
     nops = len(lines2)
+    meas_fn = ""
+    if meas:
+        # measurement map: Jy = dh/dx [NY][NX], Hy = sum_a kb[a] d2 h_a / dx2 (packed lower triangle) - the measurement term of
+        # the moving-horizon estimator's cost (csrc/hilo_ocp.h::eval_derivs_sym_mhe)
+        gm = Dag()
+        mm = {}
+        hn = [gm.from_expr(e, mm) for e in meas]
+        xs = [gm.var('x', i) for i in range(n_x)]
+        Jy = [[gm.diff(hn[a], xs[j]) for j in range(n_x)] for a in range(len(meas))]
+        kbm = [gm._mk('kb', value=a) for a in range(len(meas))]
+        Hy = []
+        for i in range(n_x):
+            for j in range(i + 1):
+                acc = gm.const(0.0)
+                for a in range(len(meas)):
+                    acc = gm.add(acc, gm.mul(kbm[a], gm.diff(Jy[a][i], xs[j])))
+                Hy.append(acc)
+        lines3, ref3 = gm.emit(hn + [Jy[a][j] for a in range(len(meas)) for j in range(n_x)] + Hy)
+        body3 = (lines3 + [f"    y[{a}] = {ref3[hn[a]]};" for a in range(len(meas))] +
+                 [f"    Jy[{a * n_x + j}] = {ref3[Jy[a][j]]};" for a in range(len(meas)) for j in range(n_x)] +
+                 [f"    Hy[{q}] = {ref3[h]};" for q, h in enumerate(Hy)])
+        meas_fn = (f"  static constexpr bool HAS_MEAS = true;\n"
+                   f"  // {len(lines3)} operations: y = h(x, u, p), Jy = dh/dx row-major [NY][NX], Hy = sum_a kb[a] d2h_a/dx2 (packed lower)\n"
+                   f"  template <class P>\n"
+                   f"  __device__ __forceinline__ static void mjh(const double* x, const double* u, const P* p, const double* kb,\n"
+                   f"                                             double* y, double* Jy, double* Hy) {{\n"
+                   f"    (void)x; (void)u; (void)p; (void)kb; (void)y; (void)Jy; (void)Hy;\n" + '\n'.join(body3) + "\n  }\n")
+    else:
+        meas_fn = "  static constexpr bool HAS_MEAS = false;\n"
     return (f"template <> struct ModelSym<{struct_name}> {{\n"
             f"  static constexpr bool value = true;\n"
             f"  // {len(lines1)} operations\n"
@@ -326,4 +355,4 @@ def sym_source(struct_name, n_x, n_u, ode):
             f"  template <class P>\n"
             f"  __device__ __forceinline__ static void jh(const double* x, const double* u, const P* p, const double* kb, double* J,\n"
             f"                                            double* H) {{\n"
-            f"    (void)x; (void)u; (void)p; (void)kb;\n" + '\n'.join(body2) + "\n  }\n};\n")
+            f"    (void)x; (void)u; (void)p; (void)kb;\n" + '\n'.join(body2) + "\n  }\n" + meas_fn + "};\n")
