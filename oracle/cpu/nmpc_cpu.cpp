@@ -214,6 +214,10 @@ struct Solver {
   // Riccati
   std::vector<double> P, pv, K, kff, dX, dU, lamn;
   std::vector<std::pair<double, double>> filt;
+  // work vectors of solve() / restore(): allocated once per solver object (one per thread), not per instance - with many
+  // threads the allocator otherwise serialises the batch
+  std::vector<double> ct, Xt, Ut, qx, qu, sgx, sgu, dgx, dgu, dzlx, dzux, dzlu, dzuu, csoc, dXs, dUs, lams, lam_step, Xs, Us, cs,
+      r_lam0, r_qx, r_qu, r_sgx, r_sgu, r_Xt, r_Ut, r_ct;
 
   Solver(const Problem& pb_, const double* p_) : pb(pb_), N(pb_.N), p(p_) {
     X.resize((N + 1) * NX); U.resize(N * NU); lam.assign(N * NX, 0.0);
@@ -222,6 +226,13 @@ struct Solver {
     Hz.resize(N * NZ * NZ); HN.resize(NX * NX);
     P.resize((N + 1) * NX * NX); pv.resize((N + 1) * NX); K.resize(N * NU * NX); kff.resize(N * NU);
     dX.resize((N + 1) * NX); dU.resize(N * NU); lamn.resize(N * NX);
+    ct.resize(c.size()); Xt.resize(X.size()); Ut.resize(U.size()); qx.resize((N + 1) * NX); qu.resize(N * NU);
+    sgx.assign((N + 1) * NX, 0.0); sgu.resize(N * NU); dgx.resize((N + 1) * NX); dgu.resize(N * NU);
+    dzlx.resize(N * NX); dzux.resize(N * NX); dzlu.resize(N * NU); dzuu.resize(N * NU); csoc.resize(c.size());
+    dXs.resize(dX.size()); dUs.resize(dU.size()); lams.resize(lamn.size()); lam_step.resize(lamn.size());
+    Xs.resize(X.size()); Us.resize(U.size()); cs.resize(c.size());
+    r_lam0.assign(N * NX, 0.0); r_qx.resize((N + 1) * NX); r_qu.resize(N * NU); r_sgx.assign((N + 1) * NX, 0.0); r_sgu.resize(N * NU);
+    r_Xt.resize(X.size()); r_Ut.resize(U.size()); r_ct.resize(c.size());
     const double r = pb.relax;
     nb = 0;
     for (int i = 0; i < NX; ++i) {
@@ -498,7 +509,9 @@ struct Solver {
 
   // feasibility restoration (DenseIpm._restore): 0 = new point in X/U, 1 = failed, 2 = locally infeasible
   int restore(double mu, double tau, double theta_max) {
-    std::vector<double> lam0(N * NX, 0.0), qx((N + 1) * NX), qu(N * NU), sgx((N + 1) * NX, 0.0), sgu(N * NU), Xt(X.size()), Ut(U.size()), ct(c.size());
+    std::vector<double>&lam0 = r_lam0, &qx = r_qx, &qu = r_qu, &sgx = r_sgx, &sgu = r_sgu, &Xt = r_Xt, &Ut = r_Ut, &ct = r_ct;
+    std::fill(lam0.begin(), lam0.end(), 0.0);
+    std::fill(sgx.begin(), sgx.end(), 0.0);
     eval_all(lam0.data());
     const double th_start = l1(c);
     double th = th_start, th_ref = th;
@@ -569,8 +582,7 @@ struct Solver {
     double mu = pb.mu_init, tau = std::max(tau_min, 1 - mu), delta_last = 0.0;
     int status = 0, iters = 0, acc_count = 0;
     filt.clear();
-    std::vector<double> ct(c.size()), Xt(X.size()), Ut(U.size()), qx((N + 1) * NX), qu(N * NU), sgx((N + 1) * NX, 0.0), sgu(N * NU),
-        dgx((N + 1) * NX), dgu(N * NU), dzlx(N * NX), dzux(N * NX), dzlu(N * NU), dzuu(N * NU), csoc(c.size()), dXs, dUs, lams;
+    std::fill(sgx.begin(), sgx.end(), 0.0);
     double f = eval_fc(X.data(), U.data(), ct.data());
     const double theta0 = l1(ct);
     const double theta_min = 1e-4 * std::max(1.0, theta0), theta_max = 1e4 * std::max(1.0, theta0);
@@ -648,7 +660,7 @@ struct Solver {
       for (int i = 0; i < N * NU; ++i) dphi += qu[i] * dU[i];
       double alpha = alpha_max;
       bool accepted = false, armijo = false, resto = false;
-      std::vector<double> lam_step = lamn;
+      lam_step = lamn;
       for (int ls = 0; ls < 60 && !accepted; ++ls) {
         for (size_t i = 0; i < X.size(); ++i) Xt[i] = X[i] + alpha * dX[i];
         for (size_t i = 0; i < U.size(); ++i) Ut[i] = U[i] + alpha * dU[i];
@@ -673,7 +685,6 @@ struct Solver {
           for (size_t i = 0; i < c.size(); ++i) csoc[i] = alpha * c[i] + ct[i];
           double th_old = tht;
           dXs = dX; dUs = dU; lams = lamn;
-          std::vector<double> Xs(X.size()), Us(U.size()), cs(c.size());
           for (int q = 0; q < max_soc; ++q) {
             if (!riccati(Hz.data(), HN.data(), dgx.data(), dgu.data(), qx.data(), qu.data(), csoc.data())) break;
             const double a_s = alpha_primal(dX.data(), dU.data(), tau);
@@ -771,7 +782,7 @@ void solve_batch(const Problem& pb, int64_t batch, const double* x0, const doubl
 #pragma omp parallel num_threads(n_threads)
   {
     Solver<M> s(pb, nullptr);
-#pragma omp for schedule(dynamic, 1)
+#pragma omp for schedule(dynamic, 4)
     for (int64_t b = 0; b < batch; ++b) {
       s.p = par ? par + b * par_stride : nullptr;
       int st = 0, itc = 0;
