@@ -140,3 +140,78 @@ def test_nmpc_requires_setup_and_options_follow_the_allow_lists():
         n.set_nlp_options({'integration_method': 'euler_backward'})      # not in the allow-list (optimizer.py:1388-1474)
     with pytest.raises((ValueError, KeyError, TypeError)):
         n.set_nlp_options({'no_such_option': 1})
+
+
+# ---- round 2: host logic of the new front-end pieces (no device needed) --------------------------------------------------------
+def test_measurement_cost_expression_matches_its_definition():
+    """`add_measurements` (modeling.py:385-408): the compiled expression is (h(x, u) - ref / s_y)^T W (.) on the model's
+    measurement equations, evaluated on the (scaled) NLP variables like every cost of the reference."""
+    from hilo_mpc_amd.symdiff import Dag
+    from tests.problems import symbolic_model
+    m = symbolic_model('cstr3').setup(dt=1.)
+    n = NMPC(m)
+    n.quad_stage_cost.add_measurements(names=['y_0'], weights=[3.], ref=[.004])
+    with pytest.raises(ValueError, match="does not exist"):
+        n.quad_stage_cost.add_measurements(names=['nope'], weights=[1.])
+    with pytest.raises(NotImplementedError):
+        n.quad_stage_cost.add_measurements(names=['y_0'], weights=[1.], trajectory_tracking=True)
+    e = n.quad_stage_cost._measurement_cost([2.])
+    g = Dag()
+    node = g.from_expr(e)
+    x, u = [.5, .5, 430.], [5e4]
+    r = 5000. * np.exp(-1e4 / (1.987 * x[2])) * x[0] - 1e6 * np.exp(-1.5e4 / (1.987 * x[2])) * x[1]
+    np.testing.assert_allclose(g.evaluate([node], x, u, [])[0], 3. * (r - .004 / 2.) ** 2, rtol=1e-13)
+    assert NMPC(m).quad_stage_cost._measurement_cost(None) is None
+    # a zoo model without expression definitions has nothing to build the term from
+    z = NMPC(Model('robot6').discretize('rk4').setup(dt=.1))
+    z.quad_stage_cost.add_measurements(names=z._model.measurement_names[:1], weights=[1.])
+    with pytest.raises(NotImplementedError, match="measurement equations as expressions"):
+        z.quad_stage_cost._measurement_cost(None)
+
+
+def test_algebraic_state_declarations():
+    from tests.problems import symbolic_model
+    m = symbolic_model('pendulum4_dae')
+    assert m.n_z == 1 and m.algebraic_state_names == ['y'] and len(m._alg) == 1
+    with pytest.raises(ValueError, match="1 algebraic states but 2"):
+        m.set_algebraic_equations([m.z[0], m.z[0]])
+    zoo = Model('chemostat4')
+    with pytest.raises(RuntimeError, match="device zoo"):
+        zoo.set_algebraic_states(['z'])
+    n = NMPC(m.setup(dt=.1))
+    n.set_initial_guess(x_guess=[0, 0, 0, 0], u_guess=0., z_guess=1.4)
+    assert n._z_guess == [1.4]
+    with pytest.raises(NotImplementedError, match="finite bounds on algebraic states"):
+        n.set_box_constraints(z_lb=[-1.], z_ub=[2.])
+    n.set_box_constraints(z_lb=[-np.inf], z_ub=[np.inf])               # the reference's defaults: accepted
+
+
+def test_simple_control_loop_sequence_with_a_stub_controller():
+    """control_loop.py:343-397: optimize on the plant state, plant step, observer step - in that order, `steps` times."""
+    from hilo_mpc_amd import SimpleControlLoop
+    calls = []
+
+    class Ctl:
+        solver_status_code = np.array([1, 1])
+
+        def optimize(self, x, cp=None):
+            calls.append(('opt', x.copy(), cp))
+            return -0.5 * x[:, :1]
+
+    class Obs:
+        def estimate(self, y=None, u=None):
+            calls.append(('est', y.copy(), u.copy()))
+            return y
+
+    loop = SimpleControlLoop(lambda x, u, p: x + u, Ctl(), Obs())
+    sol = loop.run(3, np.array([[2., 4.], [1., -1.]]), p=[7.], measure=lambda x: x[:, :1])
+    assert [c[0] for c in calls] == ['opt', 'est'] * 3 and calls[0][2] == [7.]
+    assert sol['x'].shape == (4, 2, 2) and sol['u'].shape == (3, 2, 1) and len(sol['estimates']) == 3
+    np.testing.assert_allclose(sol['x'][1], [[1., 3.], [.5, -1.5]])
+    with pytest.raises(TypeError):
+        SimpleControlLoop(lambda x, u, p: x, object())
+
+
+def test_backend_selection_is_validated(monkeypatch):
+    import os
+    assert os.environ.get('HILO_NMPC_BACKEND', 'auto') in ('auto', 'precompiled', 'runtime')
