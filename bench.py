@@ -173,13 +173,19 @@ def cpu_baseline_c2(spec, nst=50, slsqp=True):
                        constraints=[{'type': 'eq', 'fun': lambda w: ev(w)[2], 'jac': lambda w: ev(w)[3]}],
                        options={'ftol': 1e-12, 'maxiter': 500})
         slsqp_ms = (time.perf_counter() - t0) * 1e3
-    model = ''
+    model, quota = '', None
     try:
         model = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
     except Exception:
         pass
+    try:   # a container's CPU quota caps the all-core number whatever os.cpu_count() says
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        quota = None if q == 'max' else float(q) / float(per)
+    except Exception:
+        pass
     return {"value": v_all, "unit": "steps/s", "cores": C, "kind": "port", "one_core_value": v_one,
-            "cpu_model": model, "mean_ipm_iters": it_all, "frac_status_1_or_2": ok_all,
+            "cpu_model": model, "cgroup_cpu_quota": quota, "sched_affinity_cpus": len(os.sched_getaffinity(0)),
+            "mean_ipm_iters": it_all, "frac_status_1_or_2": ok_all,
             "slsqp_ms_per_solve": slsqp_ms, "slsqp_iterations": int(sol.nit) if sol is not None else None,
             "sample": f"oracle/cpu C++17/OpenMP Riccati interior point (same algorithm and constants as the numpy oracle, validated "
                       f"against it): C2 closed loop, {nb_all} instances x {nst} warm-started steps on {C} threads ({s_all:.1f} s); "
