@@ -515,6 +515,11 @@ class Mean:
     def program(self, nf):
         raise NotImplementedError
 
+    def trainable_hyperparameters(self):
+        """Names of the mean's hyper-parameters the reference would fit (mean.py: every `Hyperparameter` that is not
+        `fixed`).  This backend holds them at their values - `fit_model` says so when the list is not empty."""
+        return []
+
     def __call__(self, X):
         """mean.py:90-116: returns (1 x n_obs)."""
         host = not isinstance(X, torch.Tensor)
@@ -529,7 +534,7 @@ class Mean:
 
     @staticmethod
     def constant(bias=1., hyperprior=None, **kwargs):
-        return ConstantMean(bias)
+        return ConstantMean(bias, hyperprior, **kwargs)
 
     @staticmethod
     def zero():
@@ -541,11 +546,11 @@ class Mean:
 
     @staticmethod
     def polynomial(degree, active_dims=None, coefficient=1., offset=1., hyperprior=None, **kwargs):
-        return PolynomialMean(degree, active_dims, coefficient, offset)
+        return PolynomialMean(degree, active_dims, coefficient, offset, hyperprior, **kwargs)
 
     @staticmethod
     def linear(active_dims=None, coefficient=1., hyperprior=None, **kwargs):
-        return LinearMean(active_dims, coefficient)
+        return LinearMean(active_dims, coefficient, hyperprior, **kwargs)
 
 
 class ConstantMean(Mean):
@@ -554,6 +559,10 @@ class ConstantMean(Mean):
     def __init__(self, bias=1., hyperprior=None, **kwargs):
         super().__init__()
         self.bias = bias
+        self._fixed = {k for k, v in (kwargs.get('bounds') or {}).items() if v == 'fixed'}     # mean.py:270-277
+
+    def trainable_hyperparameters(self):
+        return [] if 'bias' in self._fixed or type(self) is not ConstantMean else [f'{self.acronym}.bias']
 
     def program(self, nf):
         return _node(M_CONST, [], [self.bias])
@@ -586,6 +595,13 @@ class PolynomialMean(Mean):
         self.coefficient = coefficient
         self.offset = offset
         self.degree = degree
+        self._fixed = {k for k, v in (kwargs.get('bounds') or {}).items() if v == 'fixed'}     # mean.py:385-405
+
+    def trainable_hyperparameters(self):
+        out = [] if 'coefficient' in self._fixed else [f'{self.acronym}.coefficient']
+        if type(self) is PolynomialMean and 'offset' not in self._fixed:                       # the linear mean's offset is 0, fixed
+            out.append(f'{self.acronym}.offset')
+        return out
 
     def program(self, nf):
         ad = list(range(nf)) if self.active_dims is None else self.active_dims
@@ -602,7 +618,7 @@ class LinearMean(PolynomialMean):
     _hyper = ('signal_variance',)
 
     def __init__(self, active_dims=None, coefficient=1., hyperprior=None, **kwargs):
-        super().__init__(1, active_dims, coefficient)
+        super().__init__(1, active_dims, coefficient, hyperprior, **kwargs)
         self.offset = 0.
 
 
@@ -610,6 +626,9 @@ class _MeanOp(Mean):
     def __init__(self, mean_1, mean_2=None):
         super().__init__()
         self.mean_1, self.mean_2 = mean_1, mean_2
+
+    def trainable_hyperparameters(self):
+        return [n for m in (self.mean_1, self.mean_2) if isinstance(m, Mean) for n in m.trainable_hyperparameters()]
 
 
 class MeanSum(_MeanOp):
@@ -837,6 +856,15 @@ class GaussianProcess:
                                                    out.ctypes.data))
         return out
 
+    def _warn_held_mean(self):
+        import warnings
+        held = self.mean.trainable_hyperparameters() if isinstance(getattr(self, 'mean', None), Mean) else []
+        if held:
+            warnings.warn(f"The hyper-parameters of the mean function {held} are held at their values by this backend; the "
+                          f"reference fits them together with the kernel's (gp.py:408-414). Pass bounds={{...: 'fixed'}} to "
+                          f"the mean to state that on purpose.")
+        return held
+
     def fit_model(self, gtol=1e-8, maxiter=500):
         """Optimises the hyper-parameters by minimising the negative log marginal likelihood over their logarithms
         (gp.py:660-697; kernel.py:127-130).  Every objective value is one device factorisation into the handle's buffers
@@ -849,6 +877,7 @@ class GaussianProcess:
             raise RuntimeError("The GP has not been set up yet. Please run the setup() method before fitting.")
         import warnings
         from scipy.optimize import minimize
+        self._warn_held_mean()
         dev_index = self._dev.index
         th_all = np.log(np.asarray(self.hyperparameter_values, dtype=float))
         if not np.all(np.isfinite(th_all)):

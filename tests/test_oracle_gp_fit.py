@@ -202,3 +202,23 @@ def test_trace_formula_gradient_matches_finite_differences_of_the_lml(kernel, na
     np.testing.assert_allclose(g, fd, rtol=2e-6, atol=2e-7)
     values, _ = fit(kernel, names, X, Y, noise_variance=np.exp(-2), fixed=fixed)
     assert np.max(np.abs(lml_gradient(kernel, names, np.log(values), X, Y, fixed=fixed))) < 2e-4
+
+
+def test_fit_model_says_when_it_holds_mean_hyperparameters():
+    """The reference fits a non-fixed mean hyper-parameter together with the kernel's (gp.py:408-414); this backend holds it and
+    must say so instead of returning other fitted values silently."""
+    import warnings
+    from hilo_mpc_amd import GP, Kernel, Mean
+    assert Mean.constant(2.).trainable_hyperparameters() == ['Const.bias']
+    assert Mean.constant(2., bounds={'bias': 'fixed'}).trainable_hyperparameters() == []
+    assert Mean.zero().trainable_hyperparameters() == [] and Mean.one().trainable_hyperparameters() == []
+    assert (Mean.constant() + Mean.polynomial(2)).trainable_hyperparameters() == ['Const.bias', 'Poly.coefficient', 'Poly.offset']
+    g = GP(['x'], ['y'], kernel=Kernel.squared_exponential(), mean=Mean.constant(.5), noise_variance=.1)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        assert g._warn_held_mean() == ['Const.bias']
+    assert any('mean function' in str(m.message) and 'Const.bias' in str(m.message) for m in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        assert GP(['x'], ['y'], mean=Mean.constant(.5, bounds={'bias': 'fixed'}))._warn_held_mean() == []
+    assert not w
