@@ -68,3 +68,24 @@ def test_cpu_baseline_leg_of_c2_runs_here():
     out = b.cpu_baseline_c2(C2, nst=3, slsqp=False)
     assert out['kind'] == 'port' and out['cores'] >= 1 and out['value'] > 0 and out['one_core_value'] > 0
     assert out['frac_status_1_or_2'] == 1.0
+
+
+def test_bench_spawns_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a torchrun environment re-executes itself under torch.distributed.run with N processes
+    on 127.0.0.1 (the driver's own launch line) and hands its exit status through."""
+    import argparse
+    import sys
+    b = _bench()
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 7
+    monkeypatch.setattr(b.subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--config', 'C4'])
+    rc = b.respawn(argparse.Namespace(gpus=4))
+    cmd = seen['cmd']
+    assert rc == 7 and cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nnodes=1' in cmd and '--nproc-per-node=4' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+    assert cmd[-6:] == ['--gpus', '4', '--steps', '3', '--config', 'C4'] and cmd[-7].endswith('bench.py')
+    assert seen['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
