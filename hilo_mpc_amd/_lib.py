@@ -96,6 +96,7 @@ def _declare(lib):
         'hilo_nmpc_plant_step': (C.c_int, [vp, i64, vp, vp, vp, i64, vp, vp]),
         'hilo_jit_precompile': (C.c_int, [C.c_char_p] + [i32] * 11),
         'hilo_nmpc_set_aux_outputs': (C.c_int, [vp, vp, vp]),
+        'hilo_gp_set_mean_program': (C.c_int, [vp, vp, i32]),
         'hilo_mhe_create': (C.c_int, [P(MheDesc), i32, P(vp)]),
         'hilo_mhe_destroy': (None, [vp]),
         'hilo_mhe_dims': (C.c_int, [vp] + [P(C.c_int)] * 6),

@@ -1019,6 +1019,19 @@ extern "C" int hilo_gp_refit(hilo_gp* gp, const double* kprog_host, int klen, do
   return gp_factorize(gp);
 }
 
+// New hyper-parameters of the MEAN function (same program length: the structure is fixed); takes effect with the next
+// hilo_gp_refit, which re-evaluates the mean on the training inputs before it factorises.
+extern "C" int hilo_gp_set_mean_program(hilo_gp* gp, const double* mprog_host, int mlen) {
+  HILO_REQUIRE(gp && mprog_host, "hilo_gp_set_mean_program: NULL argument");
+  HILO_REQUIRE(mlen == gp->mlen, "hilo_gp_set_mean_program: the mean program changed its length (%d -> %d)", gp->mlen, mlen);
+  int rc = check_prog(mprog_host, mlen, true, gp->nf);
+  if (rc) return rc;
+  HILO_HIP_CHECK(hipSetDevice(gp->device));
+  memcpy(gp->h_mprog, mprog_host, sizeof(double) * mlen);
+  HILO_HIP_CHECK(hipMemcpy(gp->mprog, mprog_host, sizeof(double) * mlen, hipMemcpyHostToDevice));
+  return HILO_OK;
+}
+
 // Gradient of the log marginal likelihood with respect to n_theta hyper-parameters at the handle's current point, by the
 // trace formula 1/2 tr((alpha alpha^T - K_y^-1) dK_y/dtheta_j) on the device.  For each theta_j the caller passes
 // the kernel programs at theta + h_j e_j and theta - h_j e_j ([n_theta][2][klen], host) and the noise variances there

@@ -516,8 +516,13 @@ class Mean:
         raise NotImplementedError
 
     def trainable_hyperparameters(self):
-        """Names of the mean's hyper-parameters the reference would fit (mean.py: every `Hyperparameter` that is not
-        `fixed`).  This backend holds them at their values - `fit_model` says so when the list is not empty."""
+        """Names of the mean's hyper-parameters that `fit_model` optimises together with the kernel's (mean.py: every
+        `Hyperparameter` that is not `fixed`; gp.py:408-414)."""
+        return [f"{o.acronym}.{a}" + ('' if i is None else f"_{i}") for o, a, i in self.hyperparameter_handles()]
+
+    def hyperparameter_handles(self):
+        """[(object, attribute, index or None)] of the trainable (non-fixed) hyper-parameters; their optimisation variable is
+        the value itself (`positive=False` in the reference, mean.py:278)."""
         return []
 
     def __call__(self, X):
@@ -561,8 +566,8 @@ class ConstantMean(Mean):
         self.bias = bias
         self._fixed = {k for k, v in (kwargs.get('bounds') or {}).items() if v == 'fixed'}     # mean.py:270-277
 
-    def trainable_hyperparameters(self):
-        return [] if 'bias' in self._fixed or type(self) is not ConstantMean else [f'{self.acronym}.bias']
+    def hyperparameter_handles(self):
+        return [] if 'bias' in self._fixed or type(self) is not ConstantMean else [(self, 'bias', None)]
 
     def program(self, nf):
         return _node(M_CONST, [], [self.bias])
@@ -597,10 +602,13 @@ class PolynomialMean(Mean):
         self.degree = degree
         self._fixed = {k for k, v in (kwargs.get('bounds') or {}).items() if v == 'fixed'}     # mean.py:385-405
 
-    def trainable_hyperparameters(self):
-        out = [] if 'coefficient' in self._fixed else [f'{self.acronym}.coefficient']
+    def hyperparameter_handles(self):
+        out = []
+        if 'coefficient' not in self._fixed:
+            out += [(self, 'coefficient', i) for i in range(len(self.coefficient))] if _is_list_like(self.coefficient) else \
+                [(self, 'coefficient', None)]
         if type(self) is PolynomialMean and 'offset' not in self._fixed:                       # the linear mean's offset is 0, fixed
-            out.append(f'{self.acronym}.offset')
+            out.append((self, 'offset', None))
         return out
 
     def program(self, nf):
@@ -627,8 +635,8 @@ class _MeanOp(Mean):
         super().__init__()
         self.mean_1, self.mean_2 = mean_1, mean_2
 
-    def trainable_hyperparameters(self):
-        return [n for m in (self.mean_1, self.mean_2) if isinstance(m, Mean) for n in m.trainable_hyperparameters()]
+    def hyperparameter_handles(self):
+        return [h for m in (self.mean_1, self.mean_2) if isinstance(m, Mean) for h in m.hyperparameter_handles()]
 
 
 class MeanSum(_MeanOp):
@@ -830,6 +838,9 @@ class GaussianProcess:
         """Factorise at the object's current hyper-parameters into the handle's buffers (hilo_gp_refit)."""
         kp = np.ascontiguousarray(self.kernel.program(self._X_train.shape[0]), dtype=np.float64)
         try:
+            if self.mean.hyperparameter_handles():
+                mp = np.ascontiguousarray(self.mean.program(self._X_train.shape[0]), dtype=np.float64)
+                _lib.check(_lib.lib().hilo_gp_set_mean_program(self._handle, mp.ctypes.data, mp.size))
             _lib.check(_lib.lib().hilo_gp_refit(self._handle, kp.ctypes.data, kp.size, float(self.noise_variance)))
             return True
         except (_lib.NotPositiveDefinite, ValueError):
@@ -856,28 +867,20 @@ class GaussianProcess:
                                                    out.ctypes.data))
         return out
 
-    def _warn_held_mean(self):
-        import warnings
-        held = self.mean.trainable_hyperparameters() if isinstance(getattr(self, 'mean', None), Mean) else []
-        if held:
-            warnings.warn(f"The hyper-parameters of the mean function {held} are held at their values by this backend; the "
-                          f"reference fits them together with the kernel's (gp.py:408-414). Pass bounds={{...: 'fixed'}} to "
-                          f"the mean to state that on purpose.")
-        return held
-
     def fit_model(self, gtol=1e-8, maxiter=500):
-        """Optimises the hyper-parameters by minimising the negative log marginal likelihood over their logarithms
-        (gp.py:660-697; kernel.py:127-130).  Every objective value is one device factorisation into the handle's buffers
-        (`hilo_gp_refit`), the gradient is the device trace formula 1/2 tr((alpha alpha^T - K^-1) dK/dtheta)
-        (`hilo_gp_lml_gradient`, one factorisation for all hyper-parameters); quasi-Newton BFGS on the host - the reference
-        hands the same objective to its NLP solver.  An indefinite trial point is +inf, never an exception; the object always
-        ends on a factorised set of hyper-parameters.  Hyper-parameters of the mean function stay
-        fixed.  Warns, like the reference, when the optimiser does not reach a stationary point."""
+        """Optimises the hyper-parameters by minimising the negative log marginal likelihood (gp.py:660-697): noise variance and
+        kernel hyper-parameters over their logarithms (kernel.py:127-130), the non-fixed hyper-parameters of the mean function
+        over their values (`positive=False`, mean.py:278; fitted together with the kernel's, gp.py:408-414).  Every objective
+        value is one device factorisation into the handle's buffers (`hilo_gp_refit`), the gradient with respect to the noise /
+        kernel variables is the device trace formula 1/2 tr((alpha alpha^T - K^-1) dK/dtheta) (`hilo_gp_lml_gradient`, one
+        factorisation for all of them), with respect to the few mean variables a central difference of the objective;
+        quasi-Newton BFGS on the host - the reference hands the same objective to its NLP solver.  An indefinite trial point is
+        +inf, never an exception; the object always ends on a factorised set of hyper-parameters.  Warns, like the reference,
+        when the optimiser does not reach a stationary point."""
         if self._handle is None:
             raise RuntimeError("The GP has not been set up yet. Please run the setup() method before fitting.")
         import warnings
         from scipy.optimize import minimize
-        self._warn_held_mean()
         dev_index = self._dev.index
         th_all = np.log(np.asarray(self.hyperparameter_values, dtype=float))
         if not np.all(np.isfinite(th_all)):
@@ -890,39 +893,56 @@ class GaussianProcess:
                 None if (bnd[i] is None or not np.isfinite(bnd[i][1])) else float(np.log(bnd[i][1]))) for i in free]
         boxed = any(lo is not None or hi is not None for lo, hi in box)
         set_all = self._set_hyperparameters
+        # hyper-parameters of the mean function: optimisation variable = the value
+        mh = self.mean.hyperparameter_handles() if isinstance(self.mean, Mean) else []
+        n_log, n_mean = len(free), len(mh)
+
+        def set_mean(values):
+            for (o, a, i), v in zip(mh, values):
+                if i is None:
+                    setattr(o, a, float(v))
+                else:
+                    cur = list(getattr(o, a))
+                    cur[i] = float(v)
+                    setattr(o, a, cur)
+        mv0 = np.array([float(getattr(o, a) if i is None else getattr(o, a)[i]) for o, a, i in mh])
+        box = box + [(None, None)] * n_mean
 
         def set_free(values):
             full = np.exp(th_all)
             full[free] = values
             set_all(full)
         self._set_hyperparameters = set_free            # the closures below only see the free ones
-        th0 = th_all[free]
+        x0 = np.concatenate([th_all[free], mv0])
 
         h_step = 1e-5
-        state = {'th': None, 'ok': False}
+        state = {'x': None, 'ok': False}
 
-        def refit(th):
+        def refit(x):
             """One device factorisation into the handle's buffers; False at an indefinite trial point."""
-            self._set_hyperparameters(np.exp(th))
-            state['th'], state['ok'] = np.array(th), bool(self._device_refit())
+            self._set_hyperparameters(np.exp(x[:n_log]))
+            set_mean(x[n_log:])
+            state['x'], state['ok'] = np.array(x), bool(self._device_refit())
             return state['ok']
 
-        def f(th):
-            if not refit(th):
+        def f(x):
+            if not refit(x):
                 return np.inf
             v = -self.log_marginal_likelihood()
             return v if np.isfinite(v) else np.inf
 
-        def g(th):
-            """-(d LML / d theta) by the device trace formula + the hyper-priors' part by central differences of their
-            closed-form log densities."""
-            if state['th'] is None or not np.array_equal(state['th'], th):
-                refit(th)
+        def g(x):
+            """-(d LML / d x): device trace formula for the noise / kernel variables + the hyper-priors' part by central
+            differences of their closed-form log densities; central differences of the objective for the mean variables."""
+            if state['x'] is None or not np.array_equal(state['x'], x):
+                refit(x)
             if not state['ok']:
-                return np.zeros_like(th)
-            out = self._device_lml_gradient(th, h_step)
+                return np.zeros_like(x)
+            th = x[:n_log]
+            out = np.zeros_like(x)
+            out[:n_log] = self._device_lml_gradient(th, h_step)
             if getattr(self, '_priors', None):
-                for i in range(th.size):
+                for i in range(n_log):
                     e = np.zeros_like(th)
                     e[i] = h_step
                     self._set_hyperparameters(np.exp(th + e))
@@ -930,17 +950,26 @@ class GaussianProcess:
                     self._set_hyperparameters(np.exp(th - e))
                     out[i] += (lp - self._log_hyperprior()) / (2 * h_step)
             self._set_hyperparameters(np.exp(th))
+            for i in range(n_mean):
+                hm = 1e-6 * max(1., abs(x[n_log + i]))
+                e = np.zeros_like(x)
+                e[n_log + i] = hm
+                up, dn = f(x + e), f(x - e)
+                out[n_log + i] = -(up - dn) / (2 * hm) if np.isfinite(up) and np.isfinite(dn) else 0.
+            if n_mean:
+                refit(x)
             return -out
-        good = th0.copy()
+        good = x0.copy()
         try:
             if boxed:
-                res = minimize(f, th0, jac=g, method='L-BFGS-B', bounds=box, options={'gtol': gtol, 'ftol': 1e-15, 'maxiter': maxiter})
+                res = minimize(f, x0, jac=g, method='L-BFGS-B', bounds=box, options={'gtol': gtol, 'ftol': 1e-15, 'maxiter': maxiter})
             else:
-                res = minimize(f, th0, jac=g, method='BFGS', options={'gtol': gtol, 'maxiter': maxiter})
+                res = minimize(f, x0, jac=g, method='BFGS', options={'gtol': gtol, 'maxiter': maxiter})
             good = res.x
         finally:
             # whatever happened inside the optimiser: the object ends on a consistent, factorised set of hyper-parameters
-            self._set_hyperparameters(np.exp(good))
+            self._set_hyperparameters(np.exp(good[:n_log]))
+            set_mean(good[n_log:])
             self.setup(device_index=dev_index)
             del self._set_hyperparameters                # back to the class's setter of all hyper-parameters
         self._set_hyperparameters = set_free
@@ -953,7 +982,8 @@ class GaussianProcess:
         gn = float(np.max(np.abs(gr))) if gr.size else 0.
         self._optimization_stats = {'success': bool(res.success or gn < 1e-4), 'message': str(res.message),
                                     'iter_count': int(res.nit), 'max_gradient': gn, 'fun': float(res.fun)}
-        set_free(np.exp(res.x))
+        set_free(np.exp(res.x[:n_log]))
+        set_mean(res.x[n_log:])
         self.setup(device_index=dev_index)
         if not self._optimization_stats['success']:
             warnings.warn(f"Fitting of GP didn't terminate successfully\nSolver message: {res.message}\n"

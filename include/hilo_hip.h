@@ -162,6 +162,9 @@ int hilo_gp_log_marginal_likelihood(hilo_gp* gp, double* lml_host);
    the kernel program (same length: the kernel structure is fixed) and the noise variance, re-factorises into the handle's
    buffers.  Returns HILO_ENOTPD at an indefinite trial point (the handle then needs another refit before it predicts). */
 int hilo_gp_refit(hilo_gp* gp, const double* kprog_host, int kprog_len, double noise_variance);
+/* New hyper-parameters of the mean function (`Mean` hyper-parameters are fitted together with the kernel's, gp.py:408-414): same
+   program length; the next hilo_gp_refit evaluates the mean with them. */
+int hilo_gp_set_mean_program(hilo_gp* gp, const double* mprog_host, int mprog_len);
 /* Gradient of the log marginal likelihood (inference.py:210) at the handle's current hyper-parameters by the trace formula
    1/2 tr((alpha alpha^T - K_y^-1) dK_y/dtheta_j) on the device, one factorisation for all j.  Per theta_j the
    caller passes the kernel programs and noise variances at theta +- h_j e_j (HOST: [n_theta][2][kprog_len], [n_theta][2],

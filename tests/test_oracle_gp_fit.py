@@ -204,21 +204,46 @@ def test_trace_formula_gradient_matches_finite_differences_of_the_lml(kernel, na
     assert np.max(np.abs(lml_gradient(kernel, names, np.log(values), X, Y, fixed=fixed))) < 2e-4
 
 
-def test_fit_model_says_when_it_holds_mean_hyperparameters():
-    """The reference fits a non-fixed mean hyper-parameter together with the kernel's (gp.py:408-414); this backend holds it and
-    must say so instead of returning other fitted values silently."""
+def test_mean_hyperparameters_are_fitted_with_the_kernels():
+    """gp.py:408-414: a non-fixed hyper-parameter of the mean function is an optimisation variable like the kernel's.  For a
+    constant mean the optimum has a closed form given the covariance: b* = (1^T Ky^-1 y) / (1^T Ky^-1 1); `bounds={'bias':
+    'fixed'}` keeps it out (mean.py:270-277)."""
+    import types
     import warnings
     from hilo_mpc_amd import GP, Kernel, Mean
     assert Mean.constant(2.).trainable_hyperparameters() == ['Const.bias']
     assert Mean.constant(2., bounds={'bias': 'fixed'}).trainable_hyperparameters() == []
     assert Mean.zero().trainable_hyperparameters() == [] and Mean.one().trainable_hyperparameters() == []
     assert (Mean.constant() + Mean.polynomial(2)).trainable_hyperparameters() == ['Const.bias', 'Poly.coefficient', 'Poly.offset']
-    g = GP(['x'], ['y'], kernel=Kernel.squared_exponential(), mean=Mean.constant(.5), noise_variance=.1)
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter('always')
-        assert g._warn_held_mean() == ['Const.bias']
-    assert any('mean function' in str(m.message) and 'Const.bias' in str(m.message) for m in w)
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter('always')
-        assert GP(['x'], ['y'], mean=Mean.constant(.5, bounds={'bias': 'fixed'}))._warn_held_mean() == []
-    assert not w
+    assert Mean.linear(coefficient=[1., 2.]).trainable_hyperparameters() == ['Lin.coefficient_0', 'Lin.coefficient_1']
+
+    def host_fit(mean):
+        g = GP(['x'], ['y'], kernel=Kernel.squared_exponential(), mean=mean, noise_variance=np.exp(-2))
+        g.set_training_data(X, Y + 3.)
+
+        def setup(self, device_index=None, **kw):
+            k = self.kernel
+            self._post = gp.Posterior({'type': 'squared_exponential', 'kwargs': {a: getattr(k, a) for a in k._hyper}},
+                                      {'type': 'constant', 'kwargs': {'bias': self.mean.bias}}, self._X_train, self._y_train,
+                                      self.noise_variance)
+            self._handle, self._dev = object(), types.SimpleNamespace(index=0)
+        g.setup = types.MethodType(setup, g)
+        g.log_marginal_likelihood = types.MethodType(lambda self: self._post.lml, g)
+        g._destroy = types.MethodType(lambda self: None, g)
+        _serve_device_from_oracle(g)
+        g.setup()
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')
+            g.fit_model()
+        return g
+    g = host_fit(Mean.constant(.5))
+    post = g._post
+    Ky = post.R.T @ post.R
+    one, yv = np.ones(Ky.shape[0]), g._y_train.ravel()
+    b_star = (one @ np.linalg.solve(Ky, yv)) / (one @ np.linalg.solve(Ky, one))
+    np.testing.assert_allclose(g.mean.bias, b_star, rtol=1e-5)
+    assert abs(g.mean.bias - 3.) < 1.5 and g._optimization_stats['success']
+    fixed = host_fit(Mean.constant(.5, bounds={'bias': 'fixed'}))
+    assert fixed.mean.bias == .5 and fixed._post.lml < g._post.lml                      # the fitted bias explains the data better
+
+
