@@ -1,4 +1,7 @@
-"""Model descriptions for the zoo of device functors (hilo_mpc_amd/csrc/hilo_models.h).
+"""Model descriptions: the zoo of device functors (hilo_mpc_amd/csrc/hilo_models.h) and models written as expressions
+(`set_dynamical_states / set_inputs / set_parameters / set_algebraic_states`, `set_dynamical_equations`,
+`set_algebraic_equations`, `set_measurement_equations`, `substitute_from`), which hilo_mpc_amd/codegen.py turns into a functor of
+the same shape for the run-time compiler.
 
 The reference's `Model` (hilo_mpc/modules/dynamic_model/dynamic_model.py) is a symbolic CasADi container; the
 hot path only needs its *description*: dimensions, whether it is discrete, the discretisation recipe and the

@@ -6,9 +6,13 @@ API mirror of `hilo_mpc.NMPC` (hilo_mpc/modules/controller/mpc.py) for the hot p
 `set_nlp_options` (optimizer.py:1388-1474), `setup` (mpc.py:1789-1801), `optimize` (mpc.py:744-857) and
 `return_prediction` (mpc.py:1803-1827) - with a leading batch axis on `x0`, `cp`, `v0`.
 
-Scope of this backend: a model pre-discretised with `model.discretize('rk4'|'erk')` (or natively
-discrete) and `integration_method='discrete'`; quadratic stage / terminal / input-change costs with constant
-references; box constraints; scaling.  Everything numeric is done by `hilo_nmpc_solve` in libhilo_hip.so.
+Scope of this backend: models of the device zoo or written as expressions (`Model.set_dynamical_equations`, compiled at
+`setup()`, csrc/hilo_jit.hip), pre-discretised with `model.discretize('rk4'|'erk')` + `integration_method='discrete'` (SURVEY.md
+Q18), or continuous with the reference's default collocation / explicit Runge-Kutta inside the NLP (continuous objective);
+quadratic costs on states / inputs / input changes / measurements with constant, path-following or trajectory references,
+generic costs (`stage_cost.cost = ...`), nonlinear stage / terminal constraints (hard or soft), control horizon, algebraic
+states (collocation), learned terms (`substitute_from(gp)`), box constraints, scaling, multi-start.  Everything numeric is done
+by `hilo_nmpc_solve` in libhilo_hip.so; what is not offloaded raises NotImplementedError, nothing falls back to the CPU.
 """
 import ctypes as C
 import os
