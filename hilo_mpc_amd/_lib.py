@@ -24,7 +24,8 @@ class NotPositiveDefinite(HiloError, ValueError):
 class KfDesc(C.Structure):
     _fields_ = [('model_id', C.c_int32), ('kind', C.c_int32), ('continuous', C.c_int32), ('erk_order', C.c_int32),
                 ('n_sub', C.c_int32), ('lti_nx', C.c_int32), ('lti_nu', C.c_int32), ('lti_ny', C.c_int32),
-                ('dt', C.c_double), ('alpha', C.c_double), ('beta', C.c_double), ('kappa', C.c_double)]
+                ('dt', C.c_double), ('alpha', C.c_double), ('beta', C.c_double), ('kappa', C.c_double),
+                ('user_source', C.c_char_p)]
 
 
 class NmpcDesc(C.Structure):
@@ -97,6 +98,7 @@ def _declare(lib):
         'hilo_jit_precompile': (C.c_int, [C.c_char_p] + [i32] * 11),
         'hilo_nmpc_set_aux_outputs': (C.c_int, [vp, vp, vp]),
         'hilo_gp_set_mean_program': (C.c_int, [vp, vp, i32]),
+        'hilo_jit_precompile_kf': (C.c_int, [C.c_char_p]),
         'hilo_mhe_create': (C.c_int, [P(MheDesc), i32, P(vp)]),
         'hilo_mhe_destroy': (None, [vp]),
         'hilo_mhe_dims': (C.c_int, [vp] + [P(C.c_int)] * 6),

@@ -43,6 +43,15 @@ int jit_nmpc_kernels(const JitRequest& r, int device, JitKernels* out);
 
 void jit_unload(JitKernels* k);
 
+// Kalman / extended / unscented filter kernels of a model given as source (`UserModel`, same shape as for the controllers):
+// f[UKF][MODE] with MODE 0 = predict, 1 = update, 2 = fused step (csrc/hilo_kf_kernel.h::kf_body); launch arguments are those
+// of kf_kernel.  dims = nx, nu, np, ny, discrete.
+struct JitKfKernels {
+  hipFunction_t f[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  int dims[5] = {0, 0, 0, 0, 0};
+};
+int jit_kf_kernels(const std::string& user_source, int device, JitKfKernels* out, bool compile_only = false);
+
 // launch helpers (hipModuleLaunchKernel)
 int jit_launch_solve(hipFunction_t f, const OcpConst* dev, int64_t batch, const double* x0, const double* par, int64_t par_stride,
                      const double* sdata, int64_t sd_stride, const double* v0, int64_t v0_stride, double* v_opt, double* f_opt,

@@ -175,42 +175,60 @@ static int compile(const std::string& tu, const std::vector<std::string>& opts, 
   return HILO_OK;
 }
 
-int jit_nmpc_kernels(const JitRequest& r, int device, JitKernels* out) {
+// key of a translation unit (hash of the unit, the options, the engine headers, the compiler version)
+static int unit_key(const std::string& tu, std::vector<std::string>* opts, std::string* key) {
   const std::string dir = lib_dir(), csrc = dir + "/csrc";
   uint64_t hfp = 0;
   int rc = headers_fingerprint(csrc, &hfp);
   if (rc) return rc;
-  const std::string tu = translation_unit(r);
-  std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + csrc};
+  *opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + csrc};
   uint64_t h = fnv1a(tu, hfp);
-  for (const auto& o : opts) h = fnv1a(o.substr(0, 2) == "-I" ? std::string("-I") : o, h);
+  for (const auto& o : *opts) h = fnv1a(o.substr(0, 2) == "-I" ? std::string("-I") : o, h);
   int rtc_major = 0, rtc_minor = 0;
   hiprtcVersion(&rtc_major, &rtc_minor);
-  char key[64];
-  snprintf(key, sizeof(key), "%016llx_%d_%d", (unsigned long long)h, rtc_major, rtc_minor);
-  const std::string mkey = std::string(key) + "@" + std::to_string(device);
-  std::lock_guard<std::mutex> lock(g_mu);
-  auto it = g_loaded.find(mkey);
-  if (!r.private_module && it != g_loaded.end()) { *out = it->second.k; return HILO_OK; }
+  char k[64];
+  snprintf(k, sizeof(k), "%016llx_%d_%d", (unsigned long long)h, rtc_major, rtc_minor);
+  *key = k;
+  return HILO_OK;
+}
 
+// code object of a translation unit: from the cache (HILO_JIT_CACHE or <library dir>/jit_cache), else compiled and cached
+static int unit_code(const std::string& tu, const std::vector<std::string>& opts, const std::string& key, std::vector<char>& code,
+                     std::string* cpath_out) {
   const char* env = getenv("HILO_JIT_CACHE");
-  const std::string cdir = env && *env ? std::string(env) : dir + "/jit_cache";
+  const std::string cdir = env && *env ? std::string(env) : lib_dir() + "/jit_cache";
   const std::string cpath = cdir + "/" + key + ".hsaco";
-  std::vector<char> code;
+  *cpath_out = cpath;
   std::string cached;
   if (read_file(cpath, cached) && !cached.empty()) {
     code.assign(cached.begin(), cached.end());
-  } else {
-    rc = compile(tu, opts, code);
-    if (rc) return rc;
-    mkdir(cdir.c_str(), 0755);
-    const std::string tmp = cpath + "." + std::to_string((long)getpid()) + ".tmp";
-    if (FILE* f = fopen(tmp.c_str(), "wb")) {   // best effort: a read-only tree only costs the recompilation
-      const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
-      fclose(f);
-      if (!ok || rename(tmp.c_str(), cpath.c_str()) != 0) unlink(tmp.c_str());
-    }
+    return HILO_OK;
   }
+  int rc = compile(tu, opts, code);
+  if (rc) return rc;
+  mkdir(cdir.c_str(), 0755);
+  const std::string tmp = cpath + "." + std::to_string((long)getpid()) + ".tmp";
+  if (FILE* f = fopen(tmp.c_str(), "wb")) {   // best effort: a read-only tree only costs the recompilation
+    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), cpath.c_str()) != 0) unlink(tmp.c_str());
+  }
+  return HILO_OK;
+}
+
+int jit_nmpc_kernels(const JitRequest& r, int device, JitKernels* out) {
+  const std::string tu = translation_unit(r);
+  std::vector<std::string> opts;
+  std::string key, cpath;
+  int rc = unit_key(tu, &opts, &key);
+  if (rc) return rc;
+  const std::string mkey = key + "@" + std::to_string(device);
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_loaded.find(mkey);
+  if (!r.private_module && it != g_loaded.end()) { *out = it->second.k; return HILO_OK; }
+  std::vector<char> code;
+  rc = unit_code(tu, opts, key, code, &cpath);
+  if (rc) return rc;
   if (getenv("HILO_JIT_COMPILE_ONLY")) {   // pre-warming the cache on a machine without a GPU (__graft_entry__.build)
     *out = JitKernels();
     return HILO_OK;
@@ -242,6 +260,69 @@ int jit_nmpc_kernels(const JitRequest& r, int device, JitKernels* out) {
   if (r.private_module) m.k.owned = m.mod;
   else g_loaded[mkey] = m;
   *out = m.k;
+  return HILO_OK;
+}
+
+// ---- filters of models written as expressions: kf_body<UserModel, UKF, MODE> behind six extern "C" kernels ----------------
+static std::map<std::string, JitKfKernels> g_kf_loaded;
+
+int jit_kf_kernels(const std::string& user_source, int device, JitKfKernels* out, bool compile_only) {
+  std::string tu = "#include \"hilo_kf_kernel.h\"\nextern \"C\" { __device__ const double* hilo_user_gp[4]; }\nnamespace hilo {\n";
+  tu += user_source;
+  tu += R"(
+}  // namespace hilo
+using namespace hilo;
+#define HILO_KF_ENTRY(name, UKF, MODE)                                                                                          \
+  extern "C" __global__ __launch_bounds__(KF_TPB) void name(KfParams kp, int64_t batch, const double* __restrict__ in_tile,     \
+                                                            const double* __restrict__ y, const double* __restrict__ up,        \
+                                                            int64_t up_stride, const double* __restrict__ Q, int64_t q_stride,  \
+                                                            const double* __restrict__ R, int64_t r_stride,                     \
+                                                            double* __restrict__ out_tile, double* __restrict__ y_pred, int ipw) { \
+    kf_body<UserModel, UKF, MODE>(kp, batch, in_tile, y, up, up_stride, Q, q_stride, R, r_stride, out_tile, y_pred, ipw);        \
+  }
+HILO_KF_ENTRY(hilo_user_kf_e0, false, 0)
+HILO_KF_ENTRY(hilo_user_kf_e1, false, 1)
+HILO_KF_ENTRY(hilo_user_kf_e2, false, 2)
+HILO_KF_ENTRY(hilo_user_kf_u0, true, 0)
+HILO_KF_ENTRY(hilo_user_kf_u1, true, 1)
+HILO_KF_ENTRY(hilo_user_kf_u2, true, 2)
+extern "C" __global__ void hilo_user_kf_info(int* o) {
+  o[0] = UserModel::NX; o[1] = UserModel::NU; o[2] = UserModel::NP; o[3] = UserModel::NY; o[4] = UserModel::DISCRETE ? 1 : 0;
+}
+)";
+  std::vector<std::string> opts;
+  std::string key, cpath;
+  int rc = unit_key(tu, &opts, &key);
+  if (rc) return rc;
+  const std::string mkey = key + "@" + std::to_string(device);
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_kf_loaded.find(mkey);
+  if (it != g_kf_loaded.end()) { *out = it->second; return HILO_OK; }
+  std::vector<char> code;
+  rc = unit_code(tu, opts, key, code, &cpath);
+  if (rc) return rc;
+  if (compile_only || getenv("HILO_JIT_COMPILE_ONLY")) { *out = JitKfKernels(); return HILO_OK; }
+  HILO_HIP_CHECK(hipSetDevice(device));
+  hipModule_t mod;
+  hipError_t e = hipModuleLoadData(&mod, code.data());
+  if (e != hipSuccess) {
+    unlink(cpath.c_str());
+    return fail(HILO_EHIP, "hipModuleLoadData of the run-time compiled filter failed: %s", hipGetErrorString(e));
+  }
+  JitKfKernels k;
+  const char* names[2][3] = {{"hilo_user_kf_e0", "hilo_user_kf_e1", "hilo_user_kf_e2"}, {"hilo_user_kf_u0", "hilo_user_kf_u1", "hilo_user_kf_u2"}};
+  for (int u = 0; u < 2; ++u)
+    for (int m = 0; m < 3; ++m) HILO_HIP_CHECK(hipModuleGetFunction(&k.f[u][m], mod, names[u][m]));
+  hipFunction_t info = nullptr;
+  HILO_HIP_CHECK(hipModuleGetFunction(&info, mod, "hilo_user_kf_info"));
+  int* dinfo = nullptr;
+  HILO_HIP_CHECK(hipMalloc((void**)&dinfo, sizeof(int) * 8));
+  void* args[] = {&dinfo};
+  HILO_HIP_CHECK(hipModuleLaunchKernel(info, 1, 1, 1, 1, 1, 1, 0, nullptr, args, nullptr));
+  HILO_HIP_CHECK(hipMemcpy(k.dims, dinfo, sizeof(int) * 5, hipMemcpyDeviceToHost));
+  HILO_HIP_CHECK(hipFree(dinfo));
+  g_kf_loaded[mkey] = k;
+  *out = k;
   return HILO_OK;
 }
 

@@ -88,6 +88,12 @@ class _KalmanFilter:
             desc.lti_nx, desc.lti_nu, desc.lti_ny = m.n_x, m.n_u, m.n_y
         desc.dt = m.dt
         desc.alpha, desc.beta, desc.kappa = self._alpha, self._beta, self._kappa
+        if getattr(m, '_symbolic', False):
+            # a model written as expressions: its functor is compiled at setup (csrc/hilo_jit.hip) like the controllers' problems
+            if not m.n_y:
+                raise RuntimeError("The model has no measurement equations (set_measurement_equations)")
+            self._user_source = m.user_source()
+            desc.user_source = self._user_source.encode()
         h = C.c_void_p()
         _lib.check(_lib.lib().hilo_kf_create(C.byref(desc), self._dev.index, C.byref(h)))
         if self._handle is not None:

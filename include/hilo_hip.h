@@ -93,9 +93,15 @@ typedef struct hilo_kf_desc {
   int32_t lti_nx, lti_nu, lti_ny; /* only for HILO_MODEL_LTI */
   double dt;          /* sampling interval */
   double alpha, beta, kappa; /* UKF tuning (kf.py:446-454 defaults 1e-3, 2, 0) */
+  /* model_id = HILO_MODEL_USER (100): the model is the C++ source of `struct UserModel` (the shape of csrc/hilo_models.h; what
+     hilo_mpc_amd/codegen.py emits for `Model.set_dynamical_equations` / `set_measurement_equations`), compiled with hiprtc at
+     create and cached like the controllers' (hilo_nmpc_desc.user_source).  NULL for the zoo models. */
+  const char* user_source;
 } hilo_kf_desc;
 
 int hilo_kf_create(const hilo_kf_desc* desc, int device, hilo_kf** out);
+/* compile the filter kernels of a model source into the cache without loading them (no GPU needed; CPU test-suite, container builds) */
+int hilo_jit_precompile_kf(const char* user_source);
 void hilo_kf_destroy(hilo_kf* kf);
 /* widths of the packed tiles: xp = nx+1 ([x|P]); pred = nx+1 (KF/EKF) or 1+nx+(2nx+1) (UKF [x|P|X]) */
 int hilo_kf_dims(const hilo_kf* kf, int* nx, int* nu, int* np, int* ny, int* pred_width);

@@ -70,3 +70,10 @@ def test_generated_dae_model_compiles_with_the_collocation_policy(name):
     src = m.user_source(z_guess=[1.4])
     assert 'NZ = 1' in src and 'dae_ode<UserModel>' in src and 'alg_jz' in src
     _compile(src + codegen.fun_source(m.n_x), policy=2, coll_d=3, cont=1, has_fun=1)
+
+
+@pytest.mark.parametrize('name', ['chemostat4', 'pendulum4', 'pendulum4_dae'])
+def test_filter_kernels_of_an_expression_model_compile(name):
+    """KF / EKF / UKF on a model written as expressions: the six kernels kf_body<UserModel, UKF, MODE> (predict / update / step)."""
+    m = symbolic_model(name)
+    _lib.check(_lib.lib().hilo_jit_precompile_kf(m.user_source().encode()))

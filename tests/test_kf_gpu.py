@@ -242,3 +242,32 @@ def test_multi_step_idempotent_layout_and_empty_batch():
     np.testing.assert_allclose(upd[sl].cpu().numpy(), ref, rtol=1e-10, atol=1e-13)
     e = f.predict(torch.empty(0, 4, 5, dtype=torch.float64, device='cuda'), torch.empty(0, 6, dtype=torch.float64, device='cuda'))
     assert e.shape == (0, 4, 5)
+
+
+@pytest.mark.parametrize('kind', ['EKF', 'UKF'])
+def test_filters_on_a_model_written_as_expressions_equal_the_zoo_filter(kind):
+    """A model defined with `set_dynamical_equations` / `set_measurement_equations` (compiled at setup, csrc/hilo_jit.hip) in the
+    Kalman filters: the emitted functor is the zoo functor statement by statement; three filter steps (predict + update each)
+    agree with the precompiled filter to round-off (the two translation units are free to contract multiply-adds differently)."""
+    import hilo_mpc_amd as H
+    from tests.problems import symbolic_model
+    x, P, u, p, y = _chemo_batch(200, seed=3)
+    out = []
+    for m in (H.Model('chemostat4'), symbolic_model('chemostat4')):
+        f = getattr(H, kind)(m.discretize('erk', order=4).setup(dt=1.))
+        f.setup()
+        f.Q, f.R = 1e-4, 1e-2
+        f.set_initial_guess(x, P0=P)
+        for _ in range(3):
+            sol = f.estimate(y=y, u=u, p=p)
+        out.append((f.x.cpu().numpy().copy(), f.P.cpu().numpy().copy(), np.asarray(sol['y']).copy()))
+    for a, b in zip(*out):
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-14)
+    # a model without a zoo twin: the DAE pendulum (algebraic state eliminated inside the functor), one EKF step stays finite
+    md = symbolic_model('pendulum4_dae').discretize('rk4').setup(dt=.05)
+    f = H.EKF(md)
+    f.setup()
+    f.Q, f.R = 1e-4, 1e-2
+    f.set_initial_guess(np.array([[2.5, 0., .1, 0.]]), P0=np.eye(4)[None])
+    sol = f.estimate(y=np.array([[2.5, 0., .1, 0.]]), u=np.array([[.2]]))
+    assert np.all(np.isfinite(f.x.cpu().numpy())) and np.all(np.isfinite(f.P.cpu().numpy()))
