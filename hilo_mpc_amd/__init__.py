@@ -17,6 +17,7 @@ GP = GaussianProcess
 __all__ = ['Model', 'KalmanFilter', 'ExtendedKalmanFilter', 'UnscentedKalmanFilter', 'KF', 'EKF', 'UKF',
            'GaussianProcess', 'GP', 'Kernel', 'Mean']
 from .nmpc import NMPC
+from .smpc import SMPC
 from . import expr
 from .mhe import MovingHorizonEstimator, MHE
 from .lmpc import LMPC

@@ -140,6 +140,9 @@ def lib():
     return _lib
 
 
+COMPILED_ONLY = 1   # HILO_COMPILED_ONLY: create() stopped after compiling into the cache (HILO_JIT_COMPILE_ONLY)
+
+
 def check(rc):
     if rc != 0:
         msg = lib().hilo_last_error().decode(errors='replace')

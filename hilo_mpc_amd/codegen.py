@@ -80,6 +80,15 @@ class Emitter:
                 self.lines.append(f"    using {g}_t = decltype({' + '.join(['0.0'] + a)});")
                 self.lines.append(f"    const {g}_t {g}[] = {{{', '.join(f'{g}_t({q})' for q in a)}}};")
                 rhs = f"gp_se_mean(hilo_user_gp[{int(e.value)}], {g})"
+            elif op in ('gpvar', 'gpd'):
+                # posterior variance of a learned term (with the noise variance, `gp.predict(x)[1]`, gp.py:699-713) and the
+                # derivative of its posterior mean with respect to feature j: the terms of the covariance propagation of the
+                # stochastic NMPC (mpc.py:2527-2575); csrc/hilo_models.h::gp_se_var / gp_se_dmean
+                g = f"g{len(self.lines)}"
+                self.lines.append(f"    using {g}_t = decltype({' + '.join(['0.0'] + a)});")
+                self.lines.append(f"    const {g}_t {g}[] = {{{', '.join(f'{g}_t({q})' for q in a)}}};")
+                rhs = (f"gp_se_var(hilo_user_gp[{int(e.value)}], {g})" if op == 'gpvar' else
+                       f"gp_se_dmean(hilo_user_gp[{int(e.value[0])}], {g}, {int(e.value[1])})")
             elif op == 'powi':
                 n = int(e.value)
                 if n == 0:
@@ -122,9 +131,11 @@ def model_source(n_x, n_u, n_p, ode, meas, discrete):
            f"    (void)x; (void)u; (void)p; (void)dt; (void)y;\n" + '\n'.join(body2) + "\n  }\n};\n")
     # symbolic first / second derivatives for the engine's derivative phase (csrc/hilo_ocp.h::eval_derivs_sym); a model with
     # a learned term keeps the Taylor sweeps
-    if not any(n.op == 'gp' for e in ode for n in Expr.wrap(e).nodes().values()):
+    learned = ('gp', 'gpvar', 'gpd')
+    if not any(n.op in learned for e in ode for n in Expr.wrap(e).nodes().values()):
         from .symdiff import sym_source
-        src += sym_source('UserModel', n_x, n_u, ode, meas if not any(n.op == 'gp' for e in meas for n in Expr.wrap(e).nodes().values()) else None)
+        src += sym_source('UserModel', n_x, n_u, ode,
+                          meas if not any(n.op in learned for e in meas for n in Expr.wrap(e).nodes().values()) else None)
     return src
 
 

@@ -962,7 +962,7 @@ int hilo::gp_pack_se2(const hilo_gp* gp, double** d_pack) {
 
 // Posterior mean of a squared-exponential GP with a constant / zero mean over ANY number of features, in the layout the
 // run-time compiled models read (hilo_models.h::gp_se_mean): [n, na, sf2, bias, (active dim) * na, M * na, (X_{ad_k, i} * na,
-// alpha_i) * n].  `Model.substitute_from(gp)` of a model written as expressions (dynamic_model.py:3040-3125).
+// alpha_i) * n | sn2, L^-1 (n <= 64: gp_se_var)].  `Model.substitute_from(gp)` of a model written as expressions (dynamic_model.py:3040-3125).
 int hilo::gp_pack_se(const hilo_gp* gp, double** d_pack) {
   HILO_REQUIRE(gp && d_pack, "gp_pack_se: NULL argument");
   const double* k = gp->h_kprog;
@@ -975,13 +975,26 @@ int hilo::gp_pack_se(const hilo_gp* gp, double** d_pack) {
     return fail(HILO_ENOTSUP, "a GP inside a run-time compiled model must have a squared-exponential kernel (up to 8 active "
                               "features) and a constant or zero mean");
   const int n = gp->n, nf = gp->nf;
-  const size_t len = 4 + 2 * (size_t)na + (size_t)n * (na + 1);
+  // tail for the posterior variance (hilo_models.h::gp_se_var): [sn2, L^-1 row-major n x n], small training sets only
+  const bool with_var = n <= 64;
+  const size_t head = 4 + 2 * (size_t)na + (size_t)n * (na + 1);
+  const size_t len = head + (with_var ? 1 + (size_t)n * n : 0);
+  if (with_var) {
+    int rc = gp_ensure_linv(const_cast<hilo_gp*>(gp));
+    if (rc) return rc;
+  }
   double* X = new double[(size_t)nf * n];
   double* a = new double[n];
   double* pack = new double[len];
   hipError_t e = hipSetDevice(gp->device);
   if (e == hipSuccess) e = hipMemcpy(X, gp->X, sizeof(double) * nf * n, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(a, gp->alpha, sizeof(double) * n, hipMemcpyDeviceToHost);
+  if (with_var) {
+    pack[head] = gp->sn2;
+    if (e == hipSuccess)
+      e = hipMemcpy2D(pack + head + 1, sizeof(double) * n, gp->Linv, sizeof(double) * gp->lp, sizeof(double) * n, n,
+                      hipMemcpyDeviceToHost);
+  }
   pack[0] = n; pack[1] = na; pack[2] = k[3 + na]; pack[3] = m[3];
   for (int q = 0; q < na; ++q) { pack[4 + q] = k[2 + q]; pack[4 + na + q] = k[3 + na + 3 + q]; }
   for (int i = 0; i < n; ++i) {

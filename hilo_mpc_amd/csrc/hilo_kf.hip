@@ -114,6 +114,7 @@ extern "C" int hilo_kf_create(const hilo_kf_desc* desc, int device, hilo_kf** ou
     HILO_REQUIRE(desc->user_source && desc->user_source[0], "hilo_kf_create: HILO_MODEL_USER needs desc.user_source");
     rc = jit_kf_kernels(desc->user_source, device, &jit);
     if (rc) return rc;
+    if (getenv("HILO_JIT_COMPILE_ONLY")) return HILO_COMPILED_ONLY;   // cache warmed, no handle
     nx = jit.dims[0]; nu = jit.dims[1]; np = jit.dims[2]; ny = jit.dims[3]; disc = jit.dims[4];
     HILO_REQUIRE(ny >= 1, "hilo_kf_create: the model has no measurement equations");
   } else {

@@ -144,6 +144,63 @@ __device__ __forceinline__ T gp_se_mean(const double* g, const T* feat) {
   return bias + sf2 * acc;
 }
 
+// d mean / d feature j of the same posterior (the GP Jacobian of the stochastic NMPC's covariance propagation, mpc.py:2534-2539):
+// sf2 sum_i alpha_i exp(-d2_i / 2) (-M_j (x_j - X_ij)); zero for a feature outside the kernel's active dimensions.
+template <class T>
+__device__ __forceinline__ T gp_se_dmean(const double* g, const T* feat, int j) {
+  const int n = (int)g[0], na = (int)g[1];
+  const double sf2 = g[2];
+  const double* ad = g + 4;
+  const double* Md = g + 4 + na;
+  const double* r = g + 4 + 2 * na;
+  int qj = -1;
+  for (int q = 0; q < na; ++q)
+    if ((int)ad[q] == j) qj = q;
+  T acc = T(0.0);
+  if (qj < 0) return acc;
+  for (int i = 0; i < n; ++i, r += na + 1) {
+    T d2 = T(0.0);
+    for (int q = 0; q < na; ++q) {
+      const T df = feat[(int)ad[q]] - r[q];
+      d2 = d2 + Md[q] * (df * df);
+    }
+    acc = acc + (r[na] * Md[qj]) * ((r[qj] - feat[j]) * exp(-0.5 * d2));
+  }
+  return sf2 * acc;
+}
+
+// Posterior variance INCLUDING the noise variance (`gp.predict(x)[1]` with noise_free=False, gp.py:699-713; inference.py:
+// 214-216: k** - v^T v, v = L^-1 k*): the pack carries sn2 and L^-1 (row-major n x n) behind the mean's data.  Every lane keeps
+// k* (n <= GP_VAR_MAX values of T) in private memory: general, not fast.
+constexpr int GP_VAR_MAX = 64;
+template <class T>
+__device__ __forceinline__ T gp_se_var(const double* g, const T* feat) {
+  const int n = (int)g[0], na = (int)g[1];
+  const double sf2 = g[2];
+  const double* ad = g + 4;
+  const double* Md = g + 4 + na;
+  const double* r = g + 4 + 2 * na;
+  const double* tail = r + (size_t)n * (na + 1);
+  const double sn2 = tail[0];
+  const double* Li = tail + 1;
+  T ks[GP_VAR_MAX];
+  for (int i = 0; i < n && i < GP_VAR_MAX; ++i, r += na + 1) {
+    T d2 = T(0.0);
+    for (int q = 0; q < na; ++q) {
+      const T df = feat[(int)ad[q]] - r[q];
+      d2 = d2 + Md[q] * (df * df);
+    }
+    ks[i] = sf2 * exp(-0.5 * d2);
+  }
+  T acc = T(0.0);
+  for (int i = 0; i < n && i < GP_VAR_MAX; ++i, Li += n) {
+    T v = T(0.0);
+    for (int k = 0; k <= i; ++k) v = v + Li[k] * ks[k];
+    acc = acc + v * v;
+  }
+  return (sf2 + sn2) - acc;
+}
+
 // ---- semi-explicit index-1 DAE  dx/dt = f(x, z, u, p),  0 = g(x, z, u, p)  of a run-time compiled model (codegen.py::
 // dae_model_source: M::NZ, M::z_guess, M::ode_z, M::alg, M::alg_jz, M::meas_z) -----------------------------------------------
 // Newton's method on g(x, z, u, p) = 0 for z IN THE SCALAR TYPE Z: started from the model's constant guess, iterated until the

@@ -400,6 +400,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     rq.sym = (d->n_sub <= 1) && !getenv("HILO_NMPC_TAYLOR");
     rq.private_module = d->n_user_gp > 0;
     rc = jit_nmpc_kernels(rq, device, &h->jit);
+    if (!rc && getenv("HILO_JIT_COMPILE_ONLY")) { hilo_nmpc_destroy(h); return HILO_COMPILED_ONLY; }   // cache warmed, no handle
     if (!rc && (h->jit.dims[0] != nx || h->jit.dims[1] != nu || h->jit.dims[2] != np))
       rc = fail(HILO_EINVAL, "hilo_nmpc_create: the compiled UserModel has (nx, nu, np) = (%d, %d, %d), the description says (%d, %d, %d)",
                 h->jit.dims[0], h->jit.dims[1], h->jit.dims[2], nx, nu, np);

@@ -236,6 +236,7 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   rq.hold = hold; rq.cont = cont; rq.tv = tv; rq.big = big; rq.has_fun = d->user_has_fun != 0;
   rq.private_module = d->n_user_gp > 0;
   int rc = jit_nmpc_kernels(rq, device, &h->jit);
+  if (!rc && getenv("HILO_JIT_COMPILE_ONLY")) { hilo_nmpc_destroy(h); return HILO_COMPILED_ONLY; }   // cache warmed, no handle
   if (!rc && (h->jit.dims[0] != mx || h->jit.dims[1] != mu || h->jit.dims[2] != np || h->jit.dims[6] != nxe || h->jit.dims[7] != nue))
     rc = fail(HILO_EINVAL, "hilo_nmpc_create: the compiled problem has model (nx, nu, np) = (%d, %d, %d), engine (%d, %d); the "
                            "description says (%d, %d, %d), (%d, %d)", h->jit.dims[0], h->jit.dims[1], h->jit.dims[2], h->jit.dims[6],

@@ -23,7 +23,7 @@ namespace hilo {
 
 constexpr int OCP_MAXNX = 12, OCP_MAXNU = 8, OCP_MAXNZ = OCP_MAXNX + OCP_MAXNU;
 constexpr int OCP_FILTER = 16;
-constexpr int OCP_MAXNC = 4;  // nonlinear inequality rows per stage
+constexpr int OCP_MAXNC = 8;  // nonlinear inequality rows per stage (stage rows + terminal rows)
 #ifndef HILO_OCP_TPB
 #define HILO_OCP_TPB 64
 #endif

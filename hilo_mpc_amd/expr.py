@@ -115,7 +115,7 @@ class Expr:
             out += [X_VARX, float(theta_index)]
         elif op == 'powi':
             out += [X_POWI, float(self.value)]
-        elif op == 'gp':
+        elif op in ('gp', 'gpvar', 'gpd'):
             raise ValueError("a learned term cannot be evaluated by the device interpreter (run-time compiled models only)")
         elif op == 'z':
             raise ValueError("an algebraic state cannot be evaluated by the device interpreter (run-time compiled models only)")
@@ -168,6 +168,99 @@ class SymVector:
 
     def __iter__(self):
         return iter(self._syms)
+
+
+def _is_c(e, v=None):
+    return e.op == 'const' and (v is None or e.value == v)
+
+
+def _add(a, b):
+    if _is_c(a, 0.0):
+        return b
+    if _is_c(b, 0.0):
+        return a
+    if _is_c(a) and _is_c(b):
+        return Expr.wrap(a.value + b.value)
+    return a + b
+
+
+def _mul(a, b):
+    if _is_c(a, 0.0) or _is_c(b, 0.0):
+        return Expr.wrap(0.0)
+    if _is_c(a, 1.0):
+        return b
+    if _is_c(b, 1.0):
+        return a
+    if _is_c(a) and _is_c(b):
+        return Expr.wrap(a.value * b.value)
+    return a * b
+
+
+def diff(e, var, memo=None):
+    """d e / d var as an expression tree (`ca.jacobian` of the reference where a derivative becomes part of a MODEL, e.g. the
+    covariance propagation of the stochastic NMPC, mpc.py:2534-2575); `var` is a leaf (a state, input or parameter symbol,
+    matched by kind and index).  Zero and unit factors are removed; shared sub-expressions share their derivative.  The
+    derivatives the SOLVER needs are not built here - the compiled code is evaluated in Taylor / dual arithmetic."""
+    memo = {} if memo is None else memo
+    e = Expr.wrap(e)
+    order = sorted(e.nodes().values(), key=lambda q: q.serial)
+    zero, one = Expr.wrap(0.0), Expr.wrap(1.0)
+    for n in order:
+        if id(n) in memo:
+            continue
+        op, a = n.op, n.args
+        d = [memo[id(c)] for c in a]
+        if op in ('x', 'u', 'p', 'z', 'theta'):
+            r = one if (op == var.op and n.value == var.value) else zero
+        elif op == 'const':
+            r = zero
+        elif op == 'add':
+            r = _add(d[0], d[1])
+        elif op == 'sub':
+            r = d[0] if _is_c(d[1], 0.0) else (Expr('neg', (d[1],)) if _is_c(d[0], 0.0) else d[0] - d[1])
+        elif op == 'neg':
+            r = zero if _is_c(d[0], 0.0) else -d[0]
+        elif op == 'mul':
+            r = _add(_mul(d[0], a[1]), _mul(a[0], d[1]))
+        elif op == 'div':                                  # (a / b)' = a' / b - (a / b) b' / b
+            r = zero if _is_c(d[0], 0.0) else d[0] / a[1]
+            if not _is_c(d[1], 0.0):
+                t = _mul(n, d[1]) / a[1]
+                r = -t if _is_c(r, 0.0) else r - t
+        elif op == 'sq':
+            r = _mul(_mul(Expr.wrap(2.0), a[0]), d[0])
+        elif op == 'powi':
+            k = int(n.value)
+            r = zero if k == 0 else _mul(_mul(Expr.wrap(float(k)), a[0] ** (k - 1) if k != 1 else one), d[0])
+        elif op == 'sin':
+            r = _mul(cos(a[0]), d[0])
+        elif op == 'cos':
+            r = _mul(-sin(a[0]), d[0])
+        elif op == 'exp':
+            r = _mul(n, d[0])
+        elif op == 'log':
+            r = zero if _is_c(d[0], 0.0) else d[0] / a[0]
+        elif op == 'sqrt':
+            r = zero if _is_c(d[0], 0.0) else d[0] / (2.0 * n)
+        elif op == 'gp':                                   # chain rule through the posterior mean: sum_j dmean/dfeature_j * feature_j'
+            r = zero
+            for j, dj in enumerate(d):
+                if not _is_c(dj, 0.0):
+                    r = _add(r, _mul(Expr('gpd', a, value=(int(n.value), j), name=n.name), dj))
+        else:
+            raise NotImplementedError(f"no expression-level derivative for operator '{op}'")
+        memo[id(n)] = r
+    return memo[id(e)]
+
+
+def jacobian(exprs, variables):
+    """[[d e_i / d v_j]] for lists of expressions and leaf symbols."""
+    exprs = [Expr.wrap(e) for e in exprs]
+    cols = []
+    for v in variables:
+        memo = {}                                          # one memo per variable: rows share their common sub-expressions
+        cols.append([diff(e, v, memo) for e in exprs])
+    return [[cols[j][i] for j in range(len(variables))] for i in range(len(exprs))]
 
 
 def compile_block(exprs, theta_index=None):

@@ -684,7 +684,11 @@ class NMPC:
             d.collocation_degree = coll['d']
             d.coll_A, d.coll_D = hp(coll['A']), hp(coll['D'])
         self._coll = coll
-        self._dev = device(self._dev_index)
+        # HILO_JIT_COMPILE_ONLY=1 (image builds on machines without a GPU): setup() compiles the problem's kernels into the cache
+        # (<library dir>/jit_cache or HILO_JIT_CACHE) and stops; the controller cannot optimize
+        compile_only = bool(os.environ.get('HILO_JIT_COMPILE_ONLY'))
+        self._dev = None if compile_only else device(self._dev_index)
+        dev_index = 0 if compile_only else self._dev.index
         # ---- route: precompiled zoo variant, or compiled at run time (csrc/hilo_jit.hip) ----
         N, Nc = self._prediction_horizon, self._control_horizon
         cont = (not self._model.discrete) and self._nlp_options['objective_function'] == 'continuous'
@@ -731,7 +735,9 @@ class NMPC:
             gps = list(getattr(m, '_gps', []))
             d.n_user_gp = len(gps)
             for k, g in enumerate(gps):
-                d.user_gp[k] = g._handle.value if hasattr(g._handle, 'value') else g._handle
+                # (compile-only mode never dereferences the handles: any non-NULL value)
+                d.user_gp[k] = 1 if os.environ.get('HILO_JIT_COMPILE_ONLY') else \
+                    (g._handle.value if hasattr(g._handle, 'value') else g._handle)
 
         h = C.c_void_p()
         # Problems with a path variable or nonlinear constraints: the run-time compiled general policy (expressions compiled
@@ -748,17 +754,22 @@ class NMPC:
             if getattr(m, 'learned', None) is not None:
                 raise NotImplementedError("a learned term inside a run-time compiled problem is not offloaded")
             jit_desc(2 if (need_user or general or coll is not None or self._tv) else 0)
-            _lib.check(_lib.lib().hilo_nmpc_create(C.byref(d), self._dev.index, C.byref(h)))
+            rc = _lib.lib().hilo_nmpc_create(C.byref(d), dev_index, C.byref(h))
         else:
-            try:
-                _lib.check(_lib.lib().hilo_nmpc_create(C.byref(d), self._dev.index, C.byref(h)))
-            except _lib.HiloError as err:
+            rc = _lib.lib().hilo_nmpc_create(C.byref(d), dev_index, C.byref(h))
+            if rc == -4 and getattr(m, 'learned', None) is None:
                 # no precompiled variant for this combination of features: compile the general policy for the zoo functor
-                if err.code != -4 or getattr(m, 'learned', None) is not None:
-                    raise
                 jit_desc(2)
-                _lib.check(_lib.lib().hilo_nmpc_create(C.byref(d), self._dev.index, C.byref(h)))
+                rc = _lib.lib().hilo_nmpc_create(C.byref(d), dev_index, C.byref(h))
         self._jit = bool(d.user_source)
+        if compile_only:
+            if rc not in (0, _lib.COMPILED_ONLY) and self._jit:
+                _lib.check(rc)
+            if rc == 0:                                    # (a machine WITH a GPU and a precompiled variant: nothing to compile)
+                _lib.lib().hilo_nmpc_destroy(h)
+            self._nlp_setup_done = False
+            return
+        _lib.check(rc)
         self._destroy()
         self._handle = h
         dims = [C.c_int() for _ in range(5)]

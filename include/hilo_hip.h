@@ -33,6 +33,8 @@ extern "C" {
 #define HILO_ENOMEM (-2)   /* device allocation failed */
 #define HILO_EHIP (-3)     /* HIP runtime error */
 #define HILO_ENOTSUP (-4)  /* combination not built into this library */
+#define HILO_COMPILED_ONLY 1 /* not an error: with HILO_JIT_COMPILE_ONLY set in the environment, hilo_nmpc_create / hilo_kf_create of a
+                               run-time compiled problem stop after compiling it into the cache (machines without a GPU: image builds) */
 #define HILO_ENOTPD (-5)   /* covariance matrix K + sn2 I not positive definite (the reference adds no jitter, inference.py:206) */
 
 /* model zoo ids (device functors in hilo_mpc_amd/csrc/hilo_models.h) */

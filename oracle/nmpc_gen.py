@@ -41,9 +41,10 @@ class GenNmpcProblem(NmpcProblem):
     """path = dict(name='theta', theta_guess=0., theta_lb=0., theta_ub=inf, u_pf_lb=1e-4, u_pf_ub=1., u_pf_ref=None,
                    u_pf_weight=10., stage=[(state indices, weights, [expr in theta, ...])], terminal=[...])
        constraint = dict(expr=[expr in state/input names, ...], lb=[...], ub=[...], soft=False, weight=None,
-                         max_violation=inf)"""
+                         max_violation=inf)
+       generic_stage = sympy expression of the model's state / input symbols added to every stage's cost"""
 
-    def __init__(self, model, dt, N, path=None, constraint=None, terminal_constraint=None, **kw):
+    def __init__(self, model, dt, N, path=None, constraint=None, terminal_constraint=None, generic_stage=None, **kw):
         super().__init__(model, dt, N, **kw)
         nx, nu = self.nx, self.nu
         self.path = path
@@ -85,6 +86,12 @@ class GenNmpcProblem(NmpcProblem):
             self.u_ub = np.concatenate([self.u_ub, [path.get('u_pf_ub', 1.)]])
             self.x_guess = np.concatenate([self.x_guess, [path.get('theta_guess', 0.)]])
             self.u_guess = np.concatenate([self.u_guess, [path.get('u_pf_lb', 1e-4) + 1e-4]])
+        if generic_stage is not None:
+            # `nmpc.stage_cost.cost = ...` (modeling.py:38-87): QUIRK restated (oracle/nmpc_coll.py) - the expression is attached after
+            # the model was scaled, so its symbols are the SCALED variables
+            sub = {s: zs[i] for i, s in enumerate(model.x)}
+            sub.update({s: zs[self.nxa + i] for i, s in enumerate(model.u)})
+            lp += sp.sympify(generic_stage).subs(sub, simultaneous=True)
         self._lp = self._vgh(lp, zs)
         self._Vp = self._vgh(Vp, xs_sym)
         # ---- constraint rows d(zs, e) with bounds [dlb, dub] ----

@@ -344,3 +344,161 @@ def product_gen(spec, **solver_options):
         nmpc.set_scaling(x_scaling=spec.get('x_scaling'), u_scaling=spec.get('u_scaling'))
     nmpc.setup(options={'integration_method': 'discrete'}, solver_options=solver_options or None)
     return nmpc
+
+
+# ---- stochastic NMPC: the reference's own test systems (tests/test_SMPC.py) and a nonlinear one -------------
+SMPC_GP = dict(length_scales=[.5], signal_variance=1., noise_variance=1e-2)
+
+
+def smpc_training_data():
+    """tests/test_SMPC.py:38-39."""
+    X = np.array([[0., .5, 1. / np.sqrt(2.), np.sqrt(3.) / 2., 1., 0.]])
+    y = np.array([[0., np.pi / 6., np.pi / 4., np.pi / 3., np.pi / 2., np.pi]])
+    return X, y
+
+
+SMPC_CASES = {
+    # tests/test_SMPC.py:8-44: a single integrator, explicit Euler with dt = 1, B = [[1]]; input weight and terminal cost added so
+    # that the problem is regular (the reference's smoke configuration leaves the last input undetermined)
+    'siso': dict(order=1, features=[0], Bw=[[1.]], N=10, x0=[15.], cov0=[[0.]], K=[[0.]],
+                 stage_states=[([0], [10.], [1.])], stage_inputs=[([0], [.1], None)], terminal_states=[([0], [10.], [1.])],
+                 x_lb=[10.], x_lb_p=[.9]),
+    # tests/test_SMPC.py:132-170: two integrators, B = [[1], [1]], bounds on both sides.  Map checks and smoke runs only: the
+    # terminal rows take sqrt(Kx_ii) of the INTEGRATED end state, which is negative at trial points with an indefinite Kx
+    # (its off-diagonal entries are free variables) - every solver's path through those NaN rejections is its own
+    'mimo': dict(solve=False, order=1, features=[0], Bw=[[1.], [1.]], N=8, x0=[15., 10.], cov0=[[.01, 0.], [0., .02]],
+                 K=[[-.2, 0.], [0., -.1]],
+                 stage_states=[([0, 1], [10., 10.], [1., 1.])], stage_inputs=[([0, 1], [.1, .1], None)],
+                 terminal_states=[([0, 1], [10., 10.], [1., 1.])],
+                 x_lb=[-100., 0.], x_lb_p=[.95, .95], x_ub=[100., 30.], x_ub_p=[.95, .95]),
+    # a nonlinear plant (pendulum-like, Heun's method): the Jacobian of the known part depends on the state; the learned
+    # term acts on the velocity and reads the angle
+    'pend': dict(order=2, features=[0], Bw=[[0.], [.1]], N=8, x0=[.9, 0.], cov0=[[1e-3, 0.], [0., 1e-3]], K=[[-.5, -.3]],
+                 stage_states=[([0, 1], [10., 1.], [0., 0.])], stage_inputs=[([0], [.1], None)],
+                 terminal_states=[([0, 1], [10., 1.], [0., 0.])],
+                 x_lb=[-1.2, -2.], x_lb_p=[.95, .95], x_ub=[1.2, 2.], x_ub_p=[.95, .95], u_lb=[-3.], u_ub=[3.]),
+}
+
+
+def smpc_models(name):
+    """(product model written as expressions, oracle model), both discretised like the case says (dt = 1)."""
+    import sympy as sp
+    from hilo_mpc_amd import Model
+    from hilo_mpc_amd.expr import sin
+    from oracle.models import OracleModel
+    c = SMPC_CASES[name]
+    m = Model(name=f'smpc_{name}')
+    dt = sp.Symbol('dt')
+    if name == 'siso':
+        x, u = m.set_dynamical_states(['px']), m.set_inputs(['a'])
+        m.set_dynamical_equations([u[0]])
+        px, a = sp.symbols('px a')
+        om = OracleModel(name, -1, [px], [a], [], [a], dt=dt)
+    elif name == 'mimo':
+        x, u = m.set_dynamical_states(['px', 'py']), m.set_inputs(['ax', 'ay'])
+        m.set_dynamical_equations([u[0], u[1]])
+        px, py, ax, ay = sp.symbols('px py ax ay')
+        om = OracleModel(name, -1, [px, py], [ax, ay], [], [ax, ay], dt=dt)
+    else:
+        x, u = m.set_dynamical_states(['th', 'om']), m.set_inputs(['tau'])
+        m.set_dynamical_equations([.3 * x[1], -.3 * sin(x[0]) - .05 * x[1] + .2 * u[0]])
+        th, w, tau = sp.symbols('th om tau')
+        om = OracleModel(name, -1, [th, w], [tau], [], [.3 * w, -.3 * sp.sin(th) - .05 * w + .2 * tau], dt=dt)
+    m.discretize('erk', order=c['order'], inplace=True)
+    m.setup(dt=1.)
+    return m, om.discretize(c['order'])
+
+
+def smpc_oracle_post():
+    from oracle import gp as ogp
+    X, y = smpc_training_data()
+    return ogp.Posterior({'type': 'squared_exponential', 'kwargs': dict(active_dims=[0], length_scales=SMPC_GP['length_scales'],
+                                                                        signal_variance=SMPC_GP['signal_variance'])},
+                         {'type': 'zero'}, X, y, SMPC_GP['noise_variance'])
+
+
+def smpc_product_gp(feature):
+    """GP(['px'], 'z') of tests/test_SMPC.py:37-43 with FIXED hyper-parameters (the parity tests do not depend on a fit)."""
+    from hilo_mpc_amd import GP, Kernel
+    X, y = smpc_training_data()
+    gp = GP([feature], ['z'], kernel=Kernel.squared_exponential(active_dims=[0], length_scales=SMPC_GP['length_scales'],
+                                                                signal_variance=SMPC_GP['signal_variance']),
+            noise_variance=SMPC_GP['noise_variance'])
+    gp.set_training_data(X, y)
+    gp.setup()
+    return gp
+
+
+def smpc_oracle_problem(name, Kgain_is_parameter=True, **kw):
+    from oracle import smpc as osmpc
+    c = SMPC_CASES[name]
+    _, om = smpc_models(name)
+    keys = ('stage_states', 'stage_inputs', 'terminal_states', 'x_lb', 'x_ub', 'x_lb_p', 'x_ub_p', 'u_lb', 'u_ub')
+    return osmpc.smpc_problem(om, [smpc_oracle_post()], [c['features']], c['Bw'], c['N'], c['K'],
+                              Kgain_is_parameter=Kgain_is_parameter, **{k: c[k] for k in keys if k in c}, **kw)
+
+
+def smpc_product(name, gp, Kgain=None, **solver_options):
+    """The same problem through the reference's interface (tests/test_SMPC.py:104-110)."""
+    from hilo_mpc_amd import SMPC
+    c = SMPC_CASES[name]
+    m, _ = smpc_models(name)
+    smpc = SMPC(m, gp, np.asarray(c['Bw']), Kgain=Kgain)
+    smpc.horizon = c['N']
+    xs, us = m.dynamical_state_names, m.input_names
+    for ind, W, ref in c.get('stage_states', []):
+        smpc.quad_stage_cost.add_states(names=[xs[i] for i in ind], weights=list(W), ref=ref)
+    for ind, W, ref in c.get('stage_inputs', []):
+        smpc.quad_stage_cost.add_inputs(names=[us[i] for i in ind], weights=list(W), ref=ref)
+    for ind, W, ref in c.get('terminal_states', []):
+        smpc.quad_terminal_cost.add_states(names=[xs[i] for i in ind], weights=list(W), ref=ref)
+    kw = {k: c[k] for k in ('x_lb', 'x_ub', 'u_lb', 'u_ub', 'x_lb_p', 'x_ub_p') if k in c}
+    smpc.set_box_chance_constraints(**kw)
+    smpc.setup(options={'chance_constraints': 'prs', 'print_level': 0},
+               solver_options={f'ipopt.{k}': v for k, v in solver_options.items()} or None)
+    return smpc
+
+
+def eval_exprs(exprs, x, u, p, gps=()):
+    """Numeric value of expression trees (hilo_mpc_amd/expr.py) at one point - test helper: the product never evaluates its
+    expressions on the host.  gps[k] = dict(mean=f(feats), var=f(feats), dmean=f(feats, j)) for the learned-term nodes."""
+    import math
+    from hilo_mpc_amd.expr import Expr
+    allnodes = {}
+    for e in exprs:
+        Expr.wrap(e).nodes(allnodes)
+    val = {}
+    fn = {'sin': math.sin, 'cos': math.cos, 'exp': math.exp, 'log': math.log, 'sqrt': math.sqrt}
+    for n in sorted(allnodes.values(), key=lambda q: q.serial):
+        a = [val[id(c)] for c in n.args]
+        op = n.op
+        if op == 'const':
+            r = n.value
+        elif op in ('x', 'u', 'p'):
+            r = float({'x': x, 'u': u, 'p': p}[op][int(n.value)])
+        elif op == 'add':
+            r = a[0] + a[1]
+        elif op == 'sub':
+            r = a[0] - a[1]
+        elif op == 'mul':
+            r = a[0] * a[1]
+        elif op == 'div':
+            r = a[0] / a[1]
+        elif op == 'neg':
+            r = -a[0]
+        elif op == 'sq':
+            r = a[0] * a[0]
+        elif op == 'powi':
+            r = a[0] ** int(n.value)
+        elif op in fn:
+            r = fn[op](a[0])
+        elif op == 'gp':
+            r = gps[int(n.value)]['mean'](a)
+        elif op == 'gpvar':
+            r = gps[int(n.value)]['var'](a)
+        elif op == 'gpd':
+            r = gps[int(n.value[0])]['dmean'](a, int(n.value[1]))
+        else:
+            raise NotImplementedError(op)
+        val[id(n)] = r
+    return np.array([val[id(Expr.wrap(e))] for e in exprs])
