@@ -7,6 +7,7 @@ then update, kf.py:258-265), and the pass-throughs `predict(xP, up, Q)` / `updat
 `[x|P]` tiles (kf.py:309-325).  All arithmetic runs in libhilo_hip.so (hilo_kf_*); nothing is computed on the host.
 """
 import ctypes as C
+import os
 import warnings
 
 import numpy as np
@@ -77,7 +78,10 @@ class _KalmanFilter:
         m = self._model
         if not m._is_setup:
             m.setup()
-        self._dev = device(self._dev_index)
+        # HILO_JIT_COMPILE_ONLY=1 (image builds without a GPU): a filter on a model written as expressions is compiled into the
+        # cache and setup() stops; other filters have nothing to compile
+        compile_only = bool(os.environ.get('HILO_JIT_COMPILE_ONLY'))
+        self._dev = None if compile_only else device(self._dev_index)
         desc = _lib.KfDesc()
         desc.model_id = m.model_id
         desc.kind = KIND[self._type]
@@ -95,6 +99,12 @@ class _KalmanFilter:
             self._user_source = m.user_source()
             desc.user_source = self._user_source.encode()
         h = C.c_void_p()
+        if compile_only:
+            if desc.user_source:
+                rc = _lib.lib().hilo_kf_create(C.byref(desc), 0, C.byref(h))
+                if rc != _lib.COMPILED_ONLY:
+                    _lib.check(rc)
+            return
         _lib.check(_lib.lib().hilo_kf_create(C.byref(desc), self._dev.index, C.byref(h)))
         if self._handle is not None:
             _lib.lib().hilo_kf_destroy(self._handle)

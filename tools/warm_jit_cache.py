@@ -1,0 +1,30 @@
+"""Fill the run-time compiler's cache (hilo_mpc_amd/jit_cache, or HILO_JIT_CACHE) on a machine WITHOUT a GPU.
+
+With HILO_JIT_COMPILE_ONLY=1 every `setup()` of a run-time compiled problem compiles its kernels with hiprtc and stops
+(hilo_nmpc_create / hilo_kf_create return HILO_COMPILED_ONLY).  This script drives the GPU tests' problem constructions in that
+mode - the tests themselves fail at their first device call, which is expected and ignored - so that the code objects travel
+with the tree and the GPU box does not spend its first minutes in the compiler.  Problems that need a trained GP on the device
+before setup() are not reached.
+
+    python tools/warm_jit_cache.py [pytest selection ...]
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(argv):
+    cache = os.environ.get('HILO_JIT_CACHE') or os.path.join(ROOT, 'hilo_mpc_amd', 'jit_cache')
+    before = set(os.listdir(cache)) if os.path.isdir(cache) else set()
+    env = dict(os.environ, HILO_JIT_COMPILE_ONLY='1')
+    sel = argv or ['tests']
+    subprocess.call([sys.executable, '-m', 'pytest', '-m', 'gpu', '-q', '-p', 'no:cacheprovider', '--tb=no', '--no-header',
+                     '-W', 'ignore'] + sel, cwd=ROOT, env=env, stdout=subprocess.DEVNULL)
+    after = set(os.listdir(cache)) if os.path.isdir(cache) else set()
+    print(f"{len(after - before)} new code object(s), {len(after)} in {cache}")
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])
