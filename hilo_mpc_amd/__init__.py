@@ -22,5 +22,8 @@ from . import expr
 from .mhe import MovingHorizonEstimator, MHE
 from .lmpc import LMPC
 from .control_loop import SimpleControlLoop
+from .pf import ParticleFilter
 
-__all__ += ['NMPC', 'MovingHorizonEstimator', 'MHE', 'LMPC', 'expr', 'SimpleControlLoop']
+PF = ParticleFilter
+
+__all__ += ['NMPC', 'SMPC', 'MovingHorizonEstimator', 'MHE', 'LMPC', 'expr', 'SimpleControlLoop', 'ParticleFilter', 'PF']

@@ -84,6 +84,9 @@ def _declare(lib):
         'hilo_kf_predict': (C.c_int, [vp, i64, vp, vp, i64, vp, i64, vp, vp]),
         'hilo_kf_update': (C.c_int, [vp, i64, vp, vp, vp, i64, vp, i64, vp, vp, vp]),
         'hilo_kf_step': (C.c_int, [vp, i64, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp]),
+        'hilo_pf_function': (C.c_int, [vp, i64, i32, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp]),
+        'hilo_pf_stats': (C.c_int, [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        'hilo_pf_resample': (C.c_int, [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_nmpc_create': (C.c_int, [P(NmpcDesc), i32, P(vp)]),
         'hilo_nmpc_destroy': (None, [vp]),
         'hilo_nmpc_dims': (C.c_int, [vp, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]),

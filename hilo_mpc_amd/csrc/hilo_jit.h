@@ -48,6 +48,7 @@ void jit_unload(JitKernels* k);
 // of kf_kernel.  dims = nx, nu, np, ny, discrete.
 struct JitKfKernels {
   hipFunction_t f[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  hipFunction_t pf = nullptr;   // particle-filter function of the same model (hilo_kf_kernel.h::pf_body)
   int dims[5] = {0, 0, 0, 0, 0};
 };
 int jit_kf_kernels(const std::string& user_source, int device, JitKfKernels* out, bool compile_only = false);

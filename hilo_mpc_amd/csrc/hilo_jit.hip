@@ -286,6 +286,17 @@ HILO_KF_ENTRY(hilo_user_kf_e2, false, 2)
 HILO_KF_ENTRY(hilo_user_kf_u0, true, 0)
 HILO_KF_ENTRY(hilo_user_kf_u1, true, 1)
 HILO_KF_ENTRY(hilo_user_kf_u2, true, 2)
+extern "C" __global__ __launch_bounds__(PF_TPB) void hilo_user_pf(KfParams kp, int n, const double* __restrict__ X,
+                                                                  const double* __restrict__ y, const double* __restrict__ up,
+                                                                  int64_t up_stride, const double* __restrict__ w,
+                                                                  const double* __restrict__ v, const double* __restrict__ R,
+                                                                  int64_t r_stride, double* __restrict__ Xp, double* __restrict__ Y,
+                                                                  double* __restrict__ q) {
+  constexpr int NX = UserModel::NX, NYE = UserModel::NY > 0 ? UserModel::NY : UserModel::NX;
+  const int64_t b = blockIdx.x;
+  pf_body<UserModel>(kp, n, X + b * n * NX, y + b * NYE, up + b * up_stride, w + b * n * NX, v + b * n * NYE, R + b * r_stride,
+                     Xp + b * n * NX, Y + b * n * NYE, q + b * n);
+}
 extern "C" __global__ void hilo_user_kf_info(int* o) {
   o[0] = UserModel::NX; o[1] = UserModel::NU; o[2] = UserModel::NP; o[3] = UserModel::NY; o[4] = UserModel::DISCRETE ? 1 : 0;
 }
@@ -313,6 +324,7 @@ extern "C" __global__ void hilo_user_kf_info(int* o) {
   const char* names[2][3] = {{"hilo_user_kf_e0", "hilo_user_kf_e1", "hilo_user_kf_e2"}, {"hilo_user_kf_u0", "hilo_user_kf_u1", "hilo_user_kf_u2"}};
   for (int u = 0; u < 2; ++u)
     for (int m = 0; m < 3; ++m) HILO_HIP_CHECK(hipModuleGetFunction(&k.f[u][m], mod, names[u][m]));
+  HILO_HIP_CHECK(hipModuleGetFunction(&k.pf, mod, "hilo_user_pf"));
   hipFunction_t info = nullptr;
   HILO_HIP_CHECK(hipModuleGetFunction(&info, mod, "hilo_user_kf_info"));
   int* dinfo = nullptr;

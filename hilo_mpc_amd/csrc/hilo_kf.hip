@@ -226,3 +226,81 @@ extern "C" int hilo_kf_step(hilo_kf* kf, int64_t batch, const double* xP, const 
                             double* xP_out, double* y_pred, void* stream) {
   return kf_run(kf, 2, batch, xP, y, up, up_stride, Q, q_stride, R, r_stride, xP_out, y_pred, stream);
 }
+
+// ---- particle filter (pf.py): the propagate / measure / weigh function of the reference's setup(), and the resampling gather ----
+namespace hilo {
+template <class M>
+static int pf_launch(const KfParams& kp, int64_t batch, int n, const double* X, const double* y, const double* up, int64_t us,
+                     const double* w, const double* v, const double* R, int64_t rs, double* Xp, double* Y, double* q, hipStream_t s) {
+  hipLaunchKernelGGL((pf_kernel<M>), dim3((unsigned)batch), dim3(PF_TPB), 0, s, kp, n, X, y, up, us, w, v, R, rs, Xp, Y, q);
+  HILO_HIP_CHECK(hipGetLastError());
+  return HILO_OK;
+}
+}  // namespace hilo
+
+extern "C" int hilo_pf_function(hilo_kf* kf, int64_t batch, int n_samples, const double* X, const double* y, const double* up,
+                                int64_t up_stride, const double* w, const double* v, const double* R, int64_t r_stride,
+                                double* X_prop, double* Y, double* q, void* stream) {
+  HILO_REQUIRE(kf, "hilo_pf_function: NULL handle");
+  HILO_REQUIRE(batch >= 0 && n_samples >= 1, "hilo_pf_function: need batch >= 0 and n_samples >= 1");
+  if (batch == 0) return HILO_OK;
+  HILO_REQUIRE(X && y && w && v && R && X_prop && Y && q, "hilo_pf_function: NULL argument");
+  HILO_REQUIRE(kf->nu + kf->np == 0 || up, "hilo_pf_function: the model has %d inputs/parameters but `up` is NULL", kf->nu + kf->np);
+  HILO_REQUIRE(up_stride == 0 || up_stride >= kf->nu + kf->np, "hilo_pf_function: up_stride %lld < nu+np", (long long)up_stride);
+  const int nye = kf->ny > 0 ? kf->ny : kf->nx;
+  HILO_REQUIRE(r_stride == 0 || r_stride >= nye * nye, "hilo_pf_function: bad r_stride");
+  HILO_HIP_CHECK(hipSetDevice(kf->device));
+  hipStream_t s = (hipStream_t)stream;
+  const KfParams& kp = kf->kp;
+  static const double zero = 0.0;
+  if (!up) up = &zero;   // never read (nu + np == 0); keeps the pointer arithmetic of the kernel defined
+  if (kf->desc.model_id == 100 /* HILO_MODEL_USER */) {
+    HILO_REQUIRE(kf->jit.pf, "hilo_pf_function: the run-time compiled particle kernel is not loaded");
+    KfParams kpv = kp;
+    void* args[] = {&kpv, &n_samples, &X, &y, &up, &up_stride, &w, &v, &R, &r_stride, &X_prop, &Y, &q};
+    HILO_HIP_CHECK(hipModuleLaunchKernel(kf->jit.pf, (unsigned)batch, 1, 1, PF_TPB, 1, 1, 0, s, args, nullptr));
+    return HILO_OK;
+  }
+  switch (kf->desc.model_id) {
+#define X_(ID, T) case ID: return pf_launch<T>(kp, batch, n_samples, X, y, up, up_stride, w, v, R, r_stride, X_prop, Y, q, s);
+    HILO_KF_MODELS(X_)
+#undef X_
+    case HILO_MODEL_LTI:
+      if (kf->nx == 2 && kf->ny == 1) return pf_launch<Lti<2, 1, 1>>(kp, batch, n_samples, X, y, up, up_stride, w, v, R, r_stride, X_prop, Y, q, s);
+      if (kf->nx == 2 && kf->ny == 2) return pf_launch<Lti<2, 1, 2>>(kp, batch, n_samples, X, y, up, up_stride, w, v, R, r_stride, X_prop, Y, q, s);
+      return pf_launch<Lti<4, 2, 2>>(kp, batch, n_samples, X, y, up, up_stride, w, v, R, r_stride, X_prop, Y, q, s);
+  }
+  return fail(HILO_EINVAL, "unknown model id %d", kf->desc.model_id);
+}
+
+extern "C" int hilo_pf_resample(hilo_kf* kf, int64_t batch, int n_samples, const double* X_prop, const double* Y, const double* q,
+                                const double* uniforms, double* X, double* Y_out, int32_t* index, void* stream) {
+  HILO_REQUIRE(kf, "hilo_pf_resample: NULL handle");
+  HILO_REQUIRE(batch >= 0 && n_samples >= 1 && n_samples <= 8192, "hilo_pf_resample: need batch >= 0 and 1 <= n_samples <= 8192");
+  if (batch == 0) return HILO_OK;
+  HILO_REQUIRE(X_prop && Y && q && uniforms && X && Y_out && index, "hilo_pf_resample: NULL argument");
+  HILO_HIP_CHECK(hipSetDevice(kf->device));
+  const int nye = kf->ny > 0 ? kf->ny : kf->nx;
+  const size_t lds = sizeof(double) * ((size_t)n_samples + PF_TPB);
+  if (lds > 64 * 1024)
+    HILO_HIP_CHECK(hipFuncSetAttribute((const void*)pf_resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(pf_resample_kernel, dim3((unsigned)batch), dim3(PF_TPB), lds, (hipStream_t)stream, n_samples, kf->nx, nye, X_prop,
+                     Y, q, uniforms, X, Y_out, (int*)index);
+  HILO_HIP_CHECK(hipGetLastError());
+  return HILO_OK;
+}
+
+extern "C" int hilo_pf_stats(hilo_kf* kf, int64_t batch, int n_samples, double* X, const double* Y, const double* add,
+                             double* x_mean, double* y_mean, double* P, double* x_min, double* x_max, void* stream) {
+  HILO_REQUIRE(kf, "hilo_pf_stats: NULL handle");
+  HILO_REQUIRE(batch >= 0 && n_samples >= 2, "hilo_pf_stats: need batch >= 0 and n_samples >= 2");
+  if (batch == 0) return HILO_OK;
+  HILO_REQUIRE(X && Y && x_mean && y_mean && P && x_min && x_max, "hilo_pf_stats: NULL argument");
+  HILO_REQUIRE(kf->nx <= 16, "hilo_pf_stats: built for up to 16 states");
+  HILO_HIP_CHECK(hipSetDevice(kf->device));
+  const int nye = kf->ny > 0 ? kf->ny : kf->nx;
+  hipLaunchKernelGGL(pf_stats_kernel, dim3((unsigned)batch), dim3(PF_TPB), 0, (hipStream_t)stream, n_samples, kf->nx, nye, X, Y, add,
+                     x_mean, y_mean, P, x_min, x_max);
+  HILO_HIP_CHECK(hipGetLastError());
+  return HILO_OK;
+}

@@ -409,4 +409,173 @@ __global__ __launch_bounds__(KF_TPB) KF_OCC void kf_kernel(KfParams kp, int64_t 
   kf_body<M, UKF, MODE>(kp, batch, in_tile, y, up, up_stride, Q, q_stride, R, r_stride, out_tile, y_pred, ipw);
 }
 
+// ---- particle filter (hilo_mpc/modules/estimator/pf.py) ----------------------------------------------------------------------
+// The function the reference assembles at setup() (`_propagate_particles` :103-146, `_evaluate_likelihood` :148-166, `setup`
+// :300-318) and calls once per estimate (:372):
+//     X_prop = Phi(X, u, p) + w        Y = h(X_prop, u, p) + v        q_j = normpdf(Y_j; y, sqrt(R)) / sum_j normpdf(...)
+// One workgroup per filter, the particles strided over its threads (the sum over the particles is a workgroup reduction).
+// Layout: particle-major [N][nx] - the memory order of CasADi's column-major nx x N matrix.  A model without measurement
+// equations measures all its states (:131-134).  For one measurement q is the reference's; for several (where the reference's
+// flattened n_y x N weight matrix is no probability vector) it is the joint likelihood of independent measurements, R diagonal.
+constexpr int PF_TPB = 256;
+
+template <class M>
+__device__ __forceinline__ void pf_body(const KfParams& kp, int n, const double* __restrict__ X, const double* __restrict__ y,
+                                        const double* __restrict__ up, const double* __restrict__ w,
+                                        const double* __restrict__ v, const double* __restrict__ R, double* __restrict__ Xp,
+                                        double* __restrict__ Y, double* __restrict__ q) {
+  constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NYE = M::NY > 0 ? M::NY : M::NX;
+  __shared__ double red[PF_TPB];
+  const int tid = threadIdx.x;
+  double u[MaxOne<NU>::v], p[MaxOne<NP>::v], sig[NYE], ym[NYE];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) u[i] = up[i];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) p[i] = up[NU + i];
+#pragma unroll
+  for (int a = 0; a < NYE; ++a) { sig[a] = ::sqrt(R[a * NYE + a]); ym[a] = y[a]; }
+  double part = 0.0;
+  for (int j = tid; j < n; j += PF_TPB) {
+    double xs[NX], xo[NX], yy[NYE];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xs[i] = X[(int64_t)j * NX + i];
+    if (kp.continuous && !M::DISCRETE)
+      model_step<M>(4, kp.n_sub, xs, u, p, kp.dt, xo);  // the reference integrates with CVODES
+    else
+      model_step<M>(kp.erk_order, kp.n_sub, xs, u, p, kp.dt, xo);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      xo[i] += w[(int64_t)j * NX + i];
+      Xp[(int64_t)j * NX + i] = xo[i];
+    }
+    if constexpr (M::NY > 0) {
+      M::meas(xo, u, p, kp.dt, yy);
+    } else {
+#pragma unroll
+      for (int a = 0; a < NYE; ++a) yy[a] = xo[a];
+    }
+    double l = 1.0;
+#pragma unroll
+    for (int a = 0; a < NYE; ++a) {
+      yy[a] += v[(int64_t)j * NYE + a];
+      Y[(int64_t)j * NYE + a] = yy[a];
+      const double z = (yy[a] - ym[a]) / sig[a];
+      l *= ::exp(-0.5 * (z * z)) / (2.5066282746310002 * sig[a]);   // pf.py:99, sqrt(2 pi)
+    }
+    q[j] = l;
+    part += l;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int o = PF_TPB / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const double total = red[0];
+  for (int j = tid; j < n; j += PF_TPB) q[j] = q[j] / total;   // `q /= ca.sum2(q)` (:158)
+}
+
+template <class M>
+__global__ __launch_bounds__(PF_TPB) void pf_kernel(KfParams kp, int n, const double* __restrict__ X, const double* __restrict__ y,
+                                                    const double* __restrict__ up, int64_t up_stride,
+                                                    const double* __restrict__ w, const double* __restrict__ v,
+                                                    const double* __restrict__ R, int64_t r_stride, double* __restrict__ Xp,
+                                                    double* __restrict__ Y, double* __restrict__ q) {
+  constexpr int NX = M::NX, NYE = M::NY > 0 ? M::NY : M::NX;
+  const int64_t b = blockIdx.x;
+  pf_body<M>(kp, n, X + b * n * NX, y + b * NYE, up + b * up_stride, w + b * n * NX, v + b * n * NYE, R + b * r_stride,
+             Xp + b * n * NX, Y + b * n * NYE, q + b * n);
+}
+
+// Resampling (`np.random.choice(N, size=N, replace=True, p=q)`, pf.py:404-406) with the uniform draws supplied by the caller:
+// numpy's algorithm - cdf = cumsum(q) / cdf[-1], index = searchsorted(cdf, u, side='right') - then the gather of the propagated
+// particles and their measurements.  One workgroup per filter; the cdf lives in LDS (n <= 8192).
+__global__ __launch_bounds__(PF_TPB) void pf_resample_kernel(int n, int nx, int ny, const double* __restrict__ Xp,
+                                                             const double* __restrict__ Y, const double* __restrict__ q,
+                                                             const double* __restrict__ uni, double* __restrict__ X,
+                                                             double* __restrict__ Yr, int* __restrict__ idx) {
+  extern __shared__ double cdf[];          // [n] then PF_TPB partial sums
+  double* part = cdf + n;
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  Xp += b * n * nx; Y += b * n * ny; q += b * n; uni += b * n; X += b * n * nx; Yr += b * n * ny; idx += b * n;
+  const int chunk = (n + PF_TPB - 1) / PF_TPB, lo = tid * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  double s = 0.0;
+  for (int j = lo; j < hi; ++j) { s += q[j]; cdf[j] = s; }      // running sums inside the thread's chunk
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    double acc = 0.0;
+    for (int t = 0; t < PF_TPB; ++t) { const double c = part[t]; part[t] = acc; acc += c; }
+  }
+  __syncthreads();
+  const double off = part[tid];
+  for (int j = lo; j < hi; ++j) cdf[j] += off;
+  __syncthreads();
+  const double last = cdf[n - 1];
+  for (int j = tid; j < n; j += PF_TPB) {
+    const double uj = uni[j] * last;       // u < cdf[i] / last  <=>  u * last < cdf[i]
+    int a = 0, c = n;                      // first i with cdf[i] > uj
+    while (a < c) {
+      const int m = (a + c) >> 1;
+      if (cdf[m] > uj) c = m; else a = m + 1;
+    }
+    const int i = a < n ? a : n - 1;
+    idx[j] = i;
+    for (int k = 0; k < nx; ++k) X[(int64_t)j * nx + k] = Xp[(int64_t)i * nx + k];
+    for (int k = 0; k < ny; ++k) Yr[(int64_t)j * ny + k] = Y[(int64_t)i * ny + k];
+  }
+}
+
+// Statistics of the particle set (pf.py:418-420): x = mean of the particles, y = mean of their measurements, P = np.cov(X)
+// (unbiased, N - 1), plus the per-state minimum / maximum the roughening needs (:409-411).  `add` (nullable): an increment
+// applied to the particles first - the roughening step `X += dx` (:415).  One workgroup per filter.
+__global__ __launch_bounds__(PF_TPB) void pf_stats_kernel(int n, int nx, int ny, double* __restrict__ X,
+                                                          const double* __restrict__ Y, const double* __restrict__ add,
+                                                          double* __restrict__ xm, double* __restrict__ ym,
+                                                          double* __restrict__ P, double* __restrict__ xmin,
+                                                          double* __restrict__ xmax) {
+  __shared__ double red[PF_TPB];
+  __shared__ double mean[16];
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  X += b * n * nx; Y += b * n * ny; xm += b * nx; ym += b * ny; P += b * nx * nx; xmin += b * nx; xmax += b * nx;
+  if (add) {
+    add += b * n * nx;
+    for (int e = tid; e < n * nx; e += PF_TPB) X[e] += add[e];
+    __syncthreads();
+  }
+  auto reduce = [&](double v, int op) {      // 0 sum, 1 min, 2 max
+    red[tid] = v;
+    __syncthreads();
+    for (int o = PF_TPB / 2; o > 0; o >>= 1) {
+      if (tid < o) red[tid] = op == 0 ? red[tid] + red[tid + o] : (op == 1 ? fmin(red[tid], red[tid + o]) : fmax(red[tid], red[tid + o]));
+      __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+  };
+  for (int i = 0; i < nx; ++i) {
+    double s = 0.0, lo = INFINITY, hi = -INFINITY;
+    for (int j = tid; j < n; j += PF_TPB) { const double x = X[(int64_t)j * nx + i]; s += x; lo = fmin(lo, x); hi = fmax(hi, x); }
+    const double m = reduce(s, 0) / n, mn = reduce(lo, 1), mx = reduce(hi, 2);
+    if (tid == 0) { xm[i] = m; mean[i] = m; xmin[i] = mn; xmax[i] = mx; }
+  }
+  for (int a = 0; a < ny; ++a) {
+    double s = 0.0;
+    for (int j = tid; j < n; j += PF_TPB) s += Y[(int64_t)j * ny + a];
+    const double m = reduce(s, 0) / n;
+    if (tid == 0) ym[a] = m;
+  }
+  __syncthreads();
+  for (int i = 0; i < nx; ++i)
+    for (int k = 0; k <= i; ++k) {
+      double s = 0.0;
+      for (int j = tid; j < n; j += PF_TPB) s += (X[(int64_t)j * nx + i] - mean[i]) * (X[(int64_t)j * nx + k] - mean[k]);
+      const double c = reduce(s, 0) / (n - 1);
+      if (tid == 0) { P[i * nx + k] = c; P[k * nx + i] = c; }
+    }
+}
+
 }  // namespace hilo

@@ -105,6 +105,28 @@ int hilo_kf_create(const hilo_kf_desc* desc, int device, hilo_kf** out);
 /* compile the filter kernels of a model source into the cache without loading them (no GPU needed; CPU test-suite, container builds) */
 int hilo_jit_precompile_kf(const char* user_source);
 void hilo_kf_destroy(hilo_kf* kf);
+
+/* Particle filter (hilo_mpc/modules/estimator/pf.py).  The reference assembles ONE function at setup() (pf.py:300-318) and
+   calls it once per estimate (:372); this is that function for a batch of filters of `n_samples` particles each, on the model
+   / sampling interval / discretisation of a filter handle (the `kind` of the handle is irrelevant):
+       X_prop = Phi(X, u, p) + w      Y = h(X_prop, u, p) + v      q_j = normpdf(Y_j; y, sqrt(R)) / sum_j ...   (pf.py:99, :140-158)
+   All particle arrays are particle-major, [B][n_samples][nx] / [B][n_samples][ny] (the memory order of CasADi's column-major
+   nx x n_samples matrices); y [B][ny]; R [B][ny][ny] (r_stride 0: shared), only its diagonal is used (pf.py:155-156); a model
+   without measurement equations measures all states (pf.py:131-134: ny := nx).  The random draws w, v stay with the caller
+   (pf.py:364-368 draws them with numpy). */
+int hilo_pf_function(hilo_kf* kf, int64_t batch, int n_samples, const double* X, const double* y,
+                     const double* up, int64_t up_stride, const double* w, const double* v,
+                     const double* R, int64_t r_stride, double* X_prop, double* Y, double* q, void* stream);
+/* `ind = np.random.choice(N, size=N, replace=True, p=q); X = X[:, ind]; Y = Y[:, ind]` (pf.py:404-407) with the caller's
+   uniform draws in [0, 1) - numpy's own algorithm: index = searchsorted(cumsum(q) / sum(q), u, side='right').
+   uniforms [B][n_samples]; index (int32) [B][n_samples]; n_samples <= 8192. */
+int hilo_pf_resample(hilo_kf* kf, int64_t batch, int n_samples, const double* X_prop, const double* Y, const double* q,
+                     const double* uniforms, double* X, double* Y_out, int32_t* index, void* stream);
+/* Statistics of the particle set (pf.py:409-420): x_mean [B][nx], y_mean [B][ny], P = np.cov(X) [B][nx][nx] (unbiased),
+   x_min / x_max [B][nx] (the spread the roughening scales its noise with).  `add` (NULL or [B][n_samples][nx]) is added to
+   the particles first: the roughening step `X += dx` (pf.py:415). */
+int hilo_pf_stats(hilo_kf* kf, int64_t batch, int n_samples, double* X, const double* Y, const double* add,
+                  double* x_mean, double* y_mean, double* P, double* x_min, double* x_max, void* stream);
 /* widths of the packed tiles: xp = nx+1 ([x|P]); pred = nx+1 (KF/EKF) or 1+nx+(2nx+1) (UKF [x|P|X]) */
 int hilo_kf_dims(const hilo_kf* kf, int* nx, int* nu, int* np, int* ny, int* pred_width);
 

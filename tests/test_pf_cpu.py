@@ -1,0 +1,188 @@
+"""Particle filter on the CPU: the reference's interface tests (tests/test_PFs.py: sampling-function setter,
+warnings, defaults) restated for the product's class, the sampling function `lhsnorm`, and the oracle's restatement of the filter
+(oracle/pf.py) checked where an answer is known: for a linear-Gaussian system the particle estimate tends to the Kalman filter's."""
+import warnings
+
+import numpy as np
+import pytest
+
+from hilo_mpc_amd import Model, PF
+from hilo_mpc_amd.pf import lhsnorm
+
+
+def _toy():
+    return Model('toy1d').setup(dt=1.)          # x/2 + 25 dt x/(1 + x^2), y = x^2/20: the model of tests/test_PFs.py:39-44
+
+
+def test_particle_filter_linear_model_warning():
+    m = Model('linear2').discretize('erk', order=1).setup(dt=1.)
+    with pytest.warns(UserWarning, match="The supplied model is linear. For better efficiency use an observer targeted at the "
+                                         "estimation of linear systems."):
+        PF(m)
+
+
+def test_particle_filter_initial_tuning_parameters():
+    pf = PF(_toy())
+    assert callable(pf.probability_density_function) and pf.variant is None and pf.sample_size == 15
+    assert pf.probability_density_function is lhsnorm and pf.pdf is lhsnorm
+    pf.variant = 'default'
+    pf.sample_size = 20
+    assert pf.variant == 'default' and pf.sample_size == 20 and pf.n_samples == 20
+    assert PF(_toy(), roughening=True)._roughening_tuning_param == .2                 # pf.py:72-76
+    assert PF(_toy(), prior_editing=True, K=.5)._roughening_tuning_param == .5
+
+
+def test_particle_filter_pdf_setter():
+    """tests/test_PFs.py:71-297."""
+    pf = PF(Model('bioreactor3').discretize('rk4').setup(dt=1.))                     # three states like the reference's fixture
+    with pytest.raises(ValueError, match="Probability density function of the particle filter needs to be callable."):
+        pf.probability_density_function = None
+
+    def annotated(mu: np.ndarray, sigma: np.ndarray, n: int) -> np.ndarray:
+        np.random.seed(0)
+        return np.random.multivariate_normal(mu, sigma, size=n)
+
+    pf.probability_density_function = annotated
+    np.testing.assert_allclose(pf.pdf(np.zeros(3), np.eye(3), 3), annotated(np.zeros(3), np.eye(3), 3))
+    assert pf._transpose_pdf is None                                                 # annotated functions are not probed
+
+    def wrong_mu(mu: float, sigma: np.ndarray, n: int) -> np.ndarray: return None
+    def wrong_sigma(mu: np.ndarray, sigma: float, n: int) -> np.ndarray: return None
+    def wrong_n(mu: np.ndarray, sigma: np.ndarray, n: float) -> np.ndarray: return None
+    def wrong_ret(mu: np.ndarray, sigma: np.ndarray, n: int) -> float: return None
+    for f, msg in ((wrong_mu, "The 1st argument to the probability density function \\(pdf\\) needs to be the 'mean' with type ndarray."),
+                   (wrong_sigma, "The 2nd argument to the probability density function \\(pdf\\) needs to be the 'covariance' with type ndarray."),
+                   (wrong_n, "The 3rd argument to the probability density function \\(pdf\\) needs to be the 'sample size' with type int."),
+                   (wrong_ret, "The return value of the probability density function \\(pdf\\) needs to be a 'random sample' with type ndarray.")):
+        with pytest.raises(TypeError, match=msg):
+            pf.probability_density_function = f
+
+    def plain(mu, sigma, n):
+        return np.random.multivariate_normal(mu, sigma, size=n)                      # n x dim: needs transposing
+
+    pf.probability_density_function = plain
+    assert pf._transpose_pdf is True
+    pf.probability_density_function = lambda mu, sigma, n: plain(mu, sigma, n).T
+    assert pf._transpose_pdf is False
+    with pytest.raises(RuntimeError, match="Please make sure that the supplied probability density function"):
+        pf.probability_density_function = lambda mu: mu
+
+
+def test_not_set_up():
+    pf = PF(_toy())
+    with pytest.raises(RuntimeError, match="Particle filter is not set up. Run ParticleFilter.setup\\(\\) before running simulations."):
+        pf.estimate(y=[1.])
+
+
+def test_lhsnorm_is_a_stratified_normal_sample():
+    """pf.py:425-447: exactly one point per probability stratum of every marginal; marginal mean / variance as asked."""
+    from scipy.stats import norm
+    np.random.seed(4)
+    mu, sigma, n = np.array([1., -2.]), np.array([[4., 1.], [1., .25]]), 400
+    x = lhsnorm(mu, sigma, n)
+    assert x.shape == (n, 2)
+    for k in range(2):
+        strata = np.floor(norm.cdf(x[:, k], loc=mu[k], scale=np.sqrt(sigma[k, k])) * n).astype(int)
+        assert sorted(strata) == list(range(n))
+        assert abs(x[:, k].mean() - mu[k]) < 2e-2 * np.sqrt(sigma[k, k]) and abs(x[:, k].var() / sigma[k, k] - 1) < 2e-2
+
+
+def test_oracle_particle_filter_tends_to_the_kalman_filter():
+    """Linear-Gaussian scalar system: the filtered mean / variance of the oracle's particle filter (plain resampling) against the
+    Kalman recursion - a known answer for the restated estimate flow (weights, resampling, statistics)."""
+    import sympy as sp
+    from oracle import pf as opf
+    from oracle.models import OracleModel
+    x = sp.Symbol('x')
+    a, c, Q, R = .9, 1., .04, .01
+    m = OracleModel('ar1', -1, [x], [], [], [a * x], [c * x], discrete=True)
+    np.random.seed(12)
+    f = opf.ParticleFilter(m, 1., n_samples=4000, pdf=lambda mu, s, n: np.random.multivariate_normal(mu, s, size=n))
+    f.Q, f.R = np.array([[Q]]), np.array([[R]])
+    f.set_initial_guess([0.], [[1.]])
+    xk, Pk, xt = 0., 1., .7
+    for k in range(8):
+        xt = a * xt + np.sqrt(Q) * .3 * (-1) ** k
+        y = c * xt
+        # Kalman recursion of the same model
+        xp, Pp = a * xk, a * a * Pk + Q
+        K = Pp * c / (c * c * Pp + R)
+        xk, Pk = xp + K * (y - c * xp), (1 - K * c) * Pp
+        r = f.estimate([y])
+        # the particle set after resampling represents p(x_k | y_1..k) up to Monte-Carlo error (the measurement noise sample
+        # `v` enters Y, the likelihood is evaluated on the noisy Y like the reference does)
+        assert abs(r['x'][0] - xk) < 0.05, (k, r['x'], xk)
+    assert r['P'].shape == (1, 1) and 0 < r['P'][0, 0] < 0.1
+
+
+def test_oracle_function_weights():
+    """normpdf weights of pf.py:99, :155-158 on a hand-computable case."""
+    import sympy as sp
+    from oracle import pf as opf
+    from oracle.models import OracleModel
+    x = sp.Symbol('x')
+    m = OracleModel('id', -1, [x], [], [], [x], [2 * x], discrete=True)
+    X = np.array([[0.], [1.], [2.]])
+    Xp, Y, q = opf.pf_function(m, 1., X, [2.], [], [], np.zeros((3, 1)), np.zeros((3, 1)), [[4.]])
+    np.testing.assert_allclose(Y[:, 0], [0., 2., 4.])
+    wts = np.exp(-.5 * (np.array([0., 2., 4.]) - 2.) ** 2 / 4.)
+    np.testing.assert_allclose(q, wts / wts.sum(), rtol=1e-14)
+
+
+@pytest.mark.parametrize('roughening,prior', [(False, False), (True, False), (True, True)])
+def test_estimate_flow_consumes_the_random_stream_like_the_reference(roughening, prior, monkeypatch):
+    """Host logic of `ParticleFilter.estimate` with the three device calls replaced by numpy stand-ins (no GPU here): seeded,
+    it draws initial sample, process noise, measurement noise, prior-editing noise, resampling uniforms and roughening noise in
+    the reference's order - same particles and indices as oracle/pf.py's restatement of pf.py:340-422."""
+    import torch
+    from oracle import models as omodels, pf as opf
+    om = omodels.get('toy1d')
+    pf = PF(_toy(), roughening=roughening, prior_editing=prior)
+    N = 40
+    pf._sample_size = N
+    pf._handle, pf._dev = object(), torch.device('cpu')
+    pf._n_x = pf._n_ye = pf._n_y = 1
+    pf._n_u = pf._n_p = 0
+    pf._Q = torch.eye(1, dtype=torch.float64)
+    pf._R = torch.eye(1, dtype=torch.float64) * (1e-3 if prior else 1.)      # a tight R makes prior editing fire
+
+    def function(X, y, up, w, v, R=None):
+        X, y, w, v = (np.asarray(t.cpu().numpy() if isinstance(t, torch.Tensor) else t, dtype=float) for t in (X, y, w, v))
+        out = [opf.pf_function(om, 1., X[b], y[b], [], [], w[b], v[b], pf._R.numpy()) for b in range(X.shape[0])]
+        return tuple(torch.as_tensor(np.stack([o[k] for o in out])) for k in range(3))
+
+    def resample(Xp, Y, q, uni):
+        ind = np.stack([(lambda c: (c / c[-1]).searchsorted(uni[b].numpy(), side='right'))(q[b].numpy().cumsum()) for b in range(q.shape[0])])
+        take = lambda A: torch.as_tensor(np.stack([A[b].numpy()[ind[b]] for b in range(A.shape[0])]))
+        return take(Xp), take(Y), torch.as_tensor(ind.astype(np.int32))
+
+    def stats(X, Y, add=None):
+        if add is not None:
+            X += add
+        Xn, Yn = X.numpy(), Y.numpy()
+        P = np.stack([np.atleast_2d(np.cov(Xn[b].T)) for b in range(Xn.shape[0])])
+        return (torch.as_tensor(Xn.mean(axis=1)), torch.as_tensor(Yn.mean(axis=1)), torch.as_tensor(P),
+                torch.as_tensor(Xn.min(axis=1)), torch.as_tensor(Xn.max(axis=1)))
+
+    monkeypatch.setattr(pf, 'function', function)
+    monkeypatch.setattr(pf, '_resample', resample)
+    monkeypatch.setattr(pf, '_stats', stats)
+    pf._x, pf._P = torch.tensor([[6.]], dtype=torch.float64), torch.tensor([[[2.]]], dtype=torch.float64)
+    ref = opf.ParticleFilter(om, 1., n_samples=N, roughening=roughening, prior_editing=prior)
+    ref.Q, ref.R = np.eye(1), pf._R.numpy()
+    ref.set_initial_guess([6.], [[2.]])
+    ys = [[2.3], [2.6], [2.2], [2.5]]
+    np.random.seed(33)
+    got = []
+    for y in ys:
+        s = pf.estimate(y=y)
+        got.append((np.array(s['x']), np.array(s['P']), np.array(s['X']), pf._last['index'].numpy()[0].copy()))
+    np.random.seed(33)
+    for k, y in enumerate(ys):
+        r = ref.estimate(y)
+        x, P, X, ind = got[k]
+        assert np.array_equal(ind, r['index']), k
+        np.testing.assert_allclose(X[0].T, r['X'], rtol=1e-13)
+        np.testing.assert_allclose(x[:, 0], r['x'], rtol=1e-13)
+        np.testing.assert_allclose(P[0], r['P'], rtol=1e-12)
+    assert x.shape == (1, 1) and s['y'].shape == (1, 1)
