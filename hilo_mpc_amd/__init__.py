@@ -2,7 +2,8 @@
 
 Host classes mirror the reference API surface for the hot path only:
 `NMPC.setup()/optimize()`, `LMPC`, `MHE.estimate()`, `KF/EKF/UKF.estimate()/predict()/update()`,
-`GaussianProcess.setup()/predict()`, `Kernel`, `Mean` - all with a leading batch axis - on top of the C ABI of
+`GaussianProcess.setup()/predict()`, `Kernel`, `Mean` - all with a leading batch axis - and the rows marked "next" there
+(models written as expressions, `fit_model`, `SMPC`, `SimpleControlLoop`, `ParticleFilter`), on top of the C ABI of
 `libhilo_hip.so` (include/hilo_hip.h).  There is no CPU fallback.
 """
 from .model import Model

@@ -15,13 +15,14 @@ Each module is a plain numpy/sympy restatement of one slice of the reference hot
   + dense primal-dual interior point (IPOPT lives in the un-vendored ``casadi`` dependency)
 * ``oracle.lmpc``    - LMPC QP (``mpc.py:2143-2394``)
 * ``oracle.smpc``    - deterministic surrogate of the stochastic NMPC (``mpc.py:2512-2645``)
+* ``oracle.pf``      - particle filter (``hilo_mpc/modules/estimator/pf.py``)
 * ``oracle.mhe``     - MHE transcription (``hilo_mpc/modules/estimator/mhe.py:418-790``)
 
 Pinning status (see DESIGN.md section "Oracle"):
   KF / EKF / UKF / kernels / means / GP-LML : pinned by the reference's own known-answer tests
   NMPC interior point + collocation          : pinned by the numbers the reference's CSTR notebook prints
                                                (tests/golden/nmpc_cstr.json)
-  multiple-shooting NMPC / LMPC / MHE / SMPC : PARITY UNPINNED (the reference holds no numeric
+  multiple-shooting NMPC / LMPC / MHE / SMPC / particle filter : PARITY UNPINNED (the reference holds no numeric
                                                assertion for them and CasADi/IPOPT is not installable
                                                here); cross-checked by an independent scipy solver.
   oracle/cpu                                 : the C++/OpenMP CPU baseline of bench.py, validated against oracle/nmpc.py
