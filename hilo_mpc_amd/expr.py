@@ -20,7 +20,7 @@ STACK = 8
 
 
 class Expr:
-    """Node of an expression tree: op in {'const','x','u','p','theta', binary / unary op names}."""
+    """Node of an expression tree: op in {'const','x','u','p','z','theta','t', binary / unary op names, 'gp','gpd','gpvar'}."""
     __slots__ = ('op', 'args', 'value', 'name', 'serial')
     _count = 0
 
@@ -60,7 +60,7 @@ class Expr:
     def __repr__(self):
         if self.op == 'const':
             return repr(self.value)
-        if self.op in ('x', 'u', 'p', 'z', 'theta'):
+        if self.op in ('x', 'u', 'p', 'z', 'theta', 't'):
             return self.name
         return f"{self.op}({', '.join(map(repr, self.args))})"
 

@@ -31,6 +31,34 @@ STATUS_TEXT = {1: 'solve_succeeded', 2: 'solved_to_acceptable_level', 3: 'infeas
                4: 'restoration_failed', 5: 'maximum_iterations_exceeded', -1: 'other'}
 
 
+def _eval_time(e, t):
+    """Value of an expression of the time variable at time t (reference trajectories given as functions, mpc.py:1847)."""
+    import math
+    fn = {'sin': math.sin, 'cos': math.cos, 'exp': math.exp, 'log': math.log, 'sqrt': math.sqrt}
+    val = {}
+    for n in sorted(Expr.wrap(e).nodes().values(), key=lambda q: q.serial):
+        a = [val[id(c)] for c in n.args]
+        op = n.op
+        if op == 'const':
+            r = n.value
+        elif op == 't':
+            r = float(t)
+        elif op in ('add', 'sub', 'mul', 'div'):
+            r = a[0] + a[1] if op == 'add' else a[0] - a[1] if op == 'sub' else a[0] * a[1] if op == 'mul' else a[0] / a[1]
+        elif op == 'neg':
+            r = -a[0]
+        elif op == 'sq':
+            r = a[0] * a[0]
+        elif op == 'powi':
+            r = a[0] ** int(n.value)
+        elif op in fn:
+            r = fn[op](a[0])
+        else:
+            raise ValueError(f"a trajectory reference can only be a function of the time variable (found '{op}')")
+        val[id(n)] = r
+    return val[id(Expr.wrap(e))]
+
+
 def _wrap_list(v):
     if v is None:
         return None
@@ -93,18 +121,29 @@ class QuadraticCost:
         self._model = model
         self._terms = []          # (type, indices, W, ref)
         self._paths = []          # (state indices, W, [expression of theta])
-        self._trajectories = []   # (kind, names, indices): references supplied per call
+        self._trajectories = []   # (kind, names, indices): references supplied per call or as functions of time
+        self._traj_funs = {}      # name -> expression of the time variable (modeling.py:262-283 with `ref` given)
         self._meas_terms = []     # (measurement indices, W, ref): costs on y = h(x, u) (modeling.py:385-408)
         self._is_set = False
 
     def _add(self, kind, names, pool, weights, ref, path_following, trajectory_tracking):
         names = [names] if isinstance(names, str) else list(names)
         if trajectory_tracking:
-            # modeling.py:262-283: the reference is a placeholder filled per call from `optimize(ref_sc=..., ref_tc=...)`
-            # (mpc.py:365-463); a reference given as a function of time is not offloaded
+            # modeling.py:262-283: the reference is a placeholder - filled per call from `optimize(ref_sc=..., ref_tc=...)`
+            # (mpc.py:365-463), or a FUNCTION OF TIME (`ref=sin(nmpc.get_time_variable())`) substituted into the cost
+            # (mpc.py:232-246) and evaluated at the time of each stage, t_0 + k dt (mpc.py:1649, :1727).  Both arrive at the
+            # device as the per-stage reference table of a solve (`_stage_table`).
+            funs = None
             if ref is not None:
-                raise NotImplementedError("trajectory references as functions of the time variable are not offloaded; "
-                                          "pass the sampled trajectory to optimize(ref_sc=..., ref_tc=...)")
+                funs = [ref] if isinstance(ref, (Expr, int, float)) else list(ref)
+                if len(funs) != len(names):
+                    raise ValueError(f"{kind} and reference dimensions must be compatible. The states vector you passed me "
+                                     f"is {len(names)} long while cost {len(funs)}.")
+                funs = [Expr.wrap(f) for f in funs]
+                for f in funs:
+                    if any(n.op in ('x', 'u', 'p', 'z', 'theta', 'gp', 'gpd', 'gpvar') for n in f.nodes().values()):
+                        raise ValueError("a trajectory reference can only be a function of the time variable "
+                                         "(nmpc.get_time_variable())")
             ind = []
             for n in names:
                 if n not in pool:
@@ -112,6 +151,11 @@ class QuadraticCost:
                 ind.append(pool.index(n))
             self._terms.append((kind, ind, _weight_matrix(weights, len(names), 'weights'), None))
             self._trajectories.append((kind, names, ind))
+            for k_, n in enumerate(names):
+                if n in self._traj_funs or (funs is None and n in [q for _, nn, _ in self._trajectories[:-1] for q in nn]):
+                    raise TypeError("Two different varying trajectory for the same states are not allowed.")
+                if funs is not None:
+                    self._traj_funs[n] = funs[k_]
             self._is_set = True
             return
         if path_following:
@@ -156,7 +200,7 @@ class QuadraticCost:
 
     @property
     def name_open_varying_trajectories(self):
-        return [n for _, names, _ in self._trajectories for n in names]
+        return [n for _, names, _ in self._trajectories for n in names if n not in self._traj_funs]   # modeling.py:485-490
 
     _has_trajectory_following = property(lambda s: bool(s._trajectories))
 
@@ -379,6 +423,11 @@ class NMPC:
                                      f"where the keys are the name of the time varying parameters.")
         self._time_varying_parameters_values = values
         self._n_tvp = len(self._time_varying_parameters)
+
+    def get_time_variable(self):
+        """mpc.py:1055-1062: the time symbol for trajectory references given as functions, `ref=[sin(t), ...]`."""
+        self._time_var = Expr('t', name='t')
+        return self._time_var
 
     def create_path_variable(self, name='theta', u_pf_lb=0.0001, u_pf_ub=1, u_pf_ref=None, u_pf_weight=10,
                              theta_guess=0, theta_lb=0, theta_ub=np.inf):
@@ -692,6 +741,10 @@ class NMPC:
         # ---- route: precompiled zoo variant, or compiled at run time (csrc/hilo_jit.hip) ----
         N, Nc = self._prediction_horizon, self._control_horizon
         cont = (not self._model.discrete) and self._nlp_options['objective_function'] == 'continuous'
+        if cont and (self.quad_stage_cost._traj_funs or self.quad_terminal_cost._traj_funs):
+            # the reference integrates r(t) inside the interval then; here references are per-stage data
+            raise NotImplementedError("trajectory references as functions of time are offloaded for the discrete objective; pass "
+                                      "options={'objective_function': 'discrete'}")
         ys = getattr(self, '_y_scaling', None)
         meas_stage, meas_term = self.quad_stage_cost._measurement_cost(ys), self.quad_terminal_cost._measurement_cost(ys)
         gen_stage = self.stage_cost._cost if meas_stage is None else \
@@ -768,6 +821,7 @@ class NMPC:
             if rc == 0:                                    # (a machine WITH a GPU and a precompiled variant: nothing to compile)
                 _lib.lib().hilo_nmpc_destroy(h)
             self._nlp_setup_done = False
+            self._sx, self._su = sx, su
             return
         _lib.check(rc)
         self._destroy()
@@ -1022,9 +1076,11 @@ class NMPC:
                 continue
             ref = kwargs.get(key)
             if ref is None:
-                raise ValueError(f"Mate, it looks like the variable(s) {cost.name_open_varying_trajectories} must follow a "
-                                 f"reference, but you did not pass any. Please pass a reference as values in "
-                                 f"optimize({key}=...).")
+                if cost.name_open_varying_trajectories:
+                    raise ValueError(f"Mate, it looks like the variable(s) {cost.name_open_varying_trajectories} must follow "
+                                     f"a reference, but you did not pass any. Please pass a reference as a function in the "
+                                     f"cost or as values in optimize({key}=...).")
+                ref = {}
             if not isinstance(ref, dict):
                 raise TypeError("The trajectory must be a dict with as key the name of the variables that have a trajectory.")
             for k_ in ref:
@@ -1035,6 +1091,15 @@ class NMPC:
                 for name, i in zip(names, ind):
                     col = i if kind == 'states' else nx + i
                     sc = self._sx[i] if kind == 'states' else self._su[i]
+                    if name in cost._traj_funs:
+                        # function of time: stage k sees r(t_0 + k dt), the terminal term r(t_0 + N dt) (mpc.py:1649-1727: `time`
+                        # starts at the controller's clock and advances by the sampling interval per stage)
+                        f, dt = cost._traj_funs[name], self._sampling_interval
+                        if terminal:
+                            tab[N, col] = _eval_time(f, self._time + N * dt) / sc
+                        else:
+                            tab[:N, col] = [_eval_time(f, self._time + k_ * dt) / sc for k_ in range(N)]
+                        continue
                     if terminal:
                         tab[N, col] = window(ref[name], name, True) / sc
                     else:

@@ -215,3 +215,51 @@ def test_simple_control_loop_sequence_with_a_stub_controller():
 def test_backend_selection_is_validated(monkeypatch):
     import os
     assert os.environ.get('HILO_NMPC_BACKEND', 'auto') in ('auto', 'precompiled', 'runtime')
+
+
+def test_trajectory_reference_as_function_of_time_equals_the_sampled_trajectory(monkeypatch):
+    """`add_states(..., ref=f(t), trajectory_tracking=True)` with `t = nmpc.get_time_variable()` (mpc.py:232-246, :1055-1062): the
+    per-stage reference table of a solve holds f(t_0 + k dt) - the same numbers as the sampled trajectory passed per call; the
+    controller's clock advances by the sampling interval per optimize (mpc.py:850)."""
+    import numpy as np
+    from hilo_mpc_amd import NMPC, Model
+    from hilo_mpc_amd.expr import sin
+    monkeypatch.setenv('HILO_JIT_COMPILE_ONLY', '1')         # setup() without a GPU (nothing is compiled for this zoo problem)
+    N, dt = 6, .5
+
+    def build(fun):
+        m = Model('chemostat4').discretize('rk4').setup(dt=dt)
+        nmpc = NMPC(m)
+        t = nmpc.get_time_variable()
+        kw = dict(ref=[1. + .05 * t + .1 * sin(2. * t)]) if fun else {}
+        nmpc.quad_stage_cost.add_states(names=['P'], weights=[10.], trajectory_tracking=True, **kw)
+        nmpc.quad_stage_cost.add_inputs(names=['DS', 'DI'], weights=[.1, .1])
+        nmpc.quad_terminal_cost.add_states(names=['P'], weights=[10.], trajectory_tracking=True, **kw)
+        nmpc.horizon = N
+        nmpc.set_scaling(x_scaling=[1., 10., 2., 1.])
+        nmpc.setup(options={'integration_method': 'discrete'})
+        return nmpc
+
+    f, s = build(True), build(False)
+    assert f.quad_stage_cost.name_open_varying_trajectories == [] and s.quad_stage_cost.name_open_varying_trajectories == ['P']
+    traj = [1. + .05 * (k * dt) + .1 * np.sin(2. * k * dt) for k in range(40)]
+    cp = [100., 4., 1., 0.]
+    for it in range(3):
+        for c in (f, s):
+            c._time, c._n_iterations = it * dt, it              # what optimize() does after each solve
+        tf = f._stage_table(cp, None, {})
+        ts = s._stage_table(cp, None, {'ref_sc': {'P': traj}, 'ref_tc': {'P': traj}})
+        np.testing.assert_allclose(tf, ts, rtol=1e-15, atol=0)
+        assert tf[0, 2] == traj[it] / 2. and tf[N, 2] == traj[it + N] / 2.
+    with pytest.raises(ValueError, match="already been provided as a function|I cannot find the variable"):
+        f._stage_table(cp, None, {'ref_sc': {'P': traj}})
+    with pytest.raises(ValueError, match="only be a function of the time variable"):
+        m = Model('chemostat4').discretize('rk4').setup(dt=dt)
+        n2 = NMPC(m)
+        n2.quad_stage_cost.add_states(names=['P'], weights=[1.], ref=[m.x['S'] * 2.], trajectory_tracking=True)
+    m = Model('chemostat4').setup(dt=dt)                        # continuous model, continuous objective: refused
+    n3 = NMPC(m)
+    n3.quad_stage_cost.add_states(names=['P'], weights=[1.], ref=[n3.get_time_variable()], trajectory_tracking=True)
+    n3.horizon = 4
+    with pytest.raises(NotImplementedError, match="discrete objective"):
+        n3.setup()
