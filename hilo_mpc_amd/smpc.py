@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from ._device import to_dev
-from .expr import Expr, SymVector, _add, _mul, jacobian, sqrt
+from .expr import Expr, _add, _mul, jacobian, sqrt
 from .model import Model
 from .nmpc import NMPC, _wrap_list
 
@@ -317,8 +317,6 @@ class SMPC(NMPC):
             for j in range(nu):
                 cost = _add(cost, _mul(_c(R[i, j]), Ku[j][i]))
         self.stage_cost.cost = cost
-        opts = dict(options or {})
-        opts.pop('chance_constraints', None)
         cc = self._nlp_options['chance_constraints']
         super().setup(options=None, solver_options=solver_options)
         self._nlp_options['chance_constraints'] = cc

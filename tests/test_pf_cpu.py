@@ -1,7 +1,6 @@
 """Particle filter on the CPU: the reference's interface tests (tests/test_PFs.py: sampling-function setter,
 warnings, defaults) restated for the product's class, the sampling function `lhsnorm`, and the oracle's restatement of the filter
 (oracle/pf.py) checked where an answer is known: for a linear-Gaussian system the particle estimate tends to the Kalman filter's."""
-import warnings
 
 import numpy as np
 import pytest

@@ -9,7 +9,7 @@ import sympy as sp
 
 from hilo_mpc_amd import SMPC, expr
 from hilo_mpc_amd.smpc import _erfinv
-from tests.problems import (SMPC_CASES, eval_exprs, smpc_models, smpc_oracle_post, smpc_oracle_problem, smpc_training_data,
+from tests.problems import (SMPC_CASES, eval_exprs, smpc_models, smpc_oracle_post, smpc_oracle_problem,
                             symbolic_model)
 
 
@@ -205,3 +205,20 @@ def test_whole_problem_compiles(name, fixed_gain, monkeypatch):
     assert not smpc._nlp_setup_done
     with pytest.raises(ValueError, match="need to setup"):
         smpc.optimize(c['x0'], cov_x0=c['cov0'], Kgain=c['K'])
+
+
+@pytest.mark.parametrize('name', ['siso', 'pend'])
+def test_oracle_smpc_solution_vs_slsqp(name):
+    """Independent solver on the same transcription (scipy SLSQP on the reference's NLP in its own variables, x_0 substituted):
+    same minimiser and cost as the oracle's interior point - the cross-check the other unpinned NMPC oracles get."""
+    from oracle.nmpc_gen import GenIpm
+    from tests.test_oracle_nmpc_gen import _slsqp
+    c = SMPC_CASES[name]
+    pb = smpc_oracle_problem(name)
+    ipm = GenIpm(pb)
+    n = len(c['x0'])
+    xa0 = np.concatenate([np.asarray(c['x0'], dtype=float), np.asarray(c['cov0'], dtype=float).T.reshape(-1)])[None]
+    p = np.asarray(c['K'], dtype=float).T.reshape(1, -1)
+    res = ipm.solve(xa0, p)
+    assert res['status'][0] == 1 and res['kkt'][0] <= 1e-8
+    _slsqp(pb, ipm, res, 0, p[0], strict=False)
