@@ -452,13 +452,34 @@ class NMPC:
         self._x_ub, self._x_lb = chk(x_ub, self._n_x, 'states'), chk(x_lb, self._n_x, 'states')
         self._u_ub, self._u_lb = chk(u_ub, self._n_u, 'inputs'), chk(u_lb, self._n_u, 'inputs')
         if y_ub is not None or y_lb is not None:
-            raise NotImplementedError("measurement box constraints are not yet offloaded")
+            # mpc.py:703-708: measurement box constraints ARE an extra stage and terminal constraint on the measurement
+            # equations (they replace whatever stage / terminal constraint was set before, like there)
+            meas = self._meas_exprs()
+            for b in (y_ub, y_lb):
+                if b is not None and len(_wrap_list(b)) != len(meas):
+                    raise TypeError(f"The model has {len(meas)} measurements. You need to pass the same number of bounds.")
+            self.set_stage_constraints(stage_constraint=meas, ub=y_ub, lb=y_lb, name='measurement_constraint')
+            self.set_terminal_constraints(terminal_constraint=meas, ub=y_ub, lb=y_lb, name='measurement_constraint')
         for b in (z_ub, z_lb):
             # the algebraic states are eliminated through their equations: a finite box on them would have to
             # become a nonlinear inequality row
             if b is not None and np.any(np.isfinite(np.asarray(_wrap_list(b), dtype=float))):
                 raise NotImplementedError("finite bounds on algebraic states are not offloaded (default: -inf / +inf, "
                                           "mpc.py:645-701)")
+
+    def _meas_exprs(self):
+        """The model's measurement equations as expressions (models written as expressions; zoo models held as expressions)."""
+        m = self._model
+        if getattr(m, '_symbolic', False):
+            if not m._meas:
+                raise RuntimeError("The model has no measurement equations (set_measurement_equations)")
+            return list(m._meas)
+        from . import zoo_expr
+        from .model import Model
+        if m.name not in zoo_expr.FUNCTOR:
+            raise NotImplementedError(f"measurement constraints need the measurement equations as expressions; model '{m.name}' "
+                                      f"of the device zoo has none (available: {sorted(zoo_expr.FUNCTOR)})")
+        return list(zoo_expr.define(Model(name=m.name + '_expr'), m.name)._meas)
 
     def set_initial_guess(self, x_guess=None, u_guess=None, z_guess=None):
         def chk(v, n, what):

@@ -263,3 +263,27 @@ def test_trajectory_reference_as_function_of_time_equals_the_sampled_trajectory(
     n3.horizon = 4
     with pytest.raises(NotImplementedError, match="discrete objective"):
         n3.setup()
+
+
+def test_measurement_box_constraints_become_stage_and_terminal_constraints(monkeypatch):
+    """`set_box_constraints(y_ub=, y_lb=)` (mpc.py:703-708): an extra stage and terminal constraint on the measurement
+    equations - for a zoo model held as expressions and for a model written as expressions; compiled without a GPU."""
+    import numpy as np
+    from hilo_mpc_amd import NMPC, Model
+    from tests.problems import symbolic_model
+    monkeypatch.setenv('HILO_JIT_COMPILE_ONLY', '1')
+    for m in (Model('chemostat4').discretize('rk4').setup(dt=1.), symbolic_model('chemostat4').discretize('rk4').setup(dt=1.)):
+        nmpc = NMPC(m)
+        nmpc.quad_stage_cost.add_states(names=['P'], weights=[10.], ref=[1.])
+        nmpc.quad_stage_cost.add_inputs(names=['DS', 'DI'], weights=[.1, .1])
+        nmpc.horizon = 5
+        nmpc.set_box_constraints(y_ub=[.5, 2.], u_lb=[0., 0.])
+        sc, tc = nmpc.stage_constraint, nmpc.terminal_constraint
+        assert sc.is_set and tc.is_set and sc.size == 2 and sc.ub == [.5, 2.] and sc.lb is None and sc._name == 'measurement_constraint'
+        assert repr(sc.constraint[0]) == 'X' and repr(sc.constraint[1]) == 'P'          # yX = X, yP = P
+        nmpc.setup(options={'integration_method': 'discrete'})
+        assert 'NEXPR = 2' in nmpc._user_source and 'NTEXPR = 2' in nmpc._user_source
+    with pytest.raises(TypeError, match="The model has 2 measurements"):
+        nmpc.set_box_constraints(y_ub=[1.])
+    with pytest.raises(NotImplementedError, match="measurement equations as expressions"):
+        NMPC(Model('bioreactor3').discretize('rk4').setup(dt=1.)).set_box_constraints(y_lb=[0., 0.])
