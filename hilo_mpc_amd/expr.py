@@ -55,7 +55,13 @@ class Expr:
             return Expr('sq', (self,)) if n == 2 else Expr('powi', (self,), value=n)
         if isinstance(n, numbers.Real) and float(n) == 0.5:
             return Expr('sqrt', (self,))
-        raise NotImplementedError("only integer powers in [-16, 16] and 0.5 are available on the device")
+        if isinstance(n, (numbers.Real, Expr)):
+            # general power of a POSITIVE base through the operations the device has: a^b = exp(b log a)
+            return Expr('exp', (Expr.wrap(n) * Expr('log', (self,)),))
+        raise NotImplementedError("the exponent must be a number or an expression")
+
+    def __rpow__(self, a):
+        return Expr('exp', (self * Expr('log', (Expr.wrap(a),)),))
 
     def __repr__(self):
         if self.op == 'const':
@@ -147,6 +153,27 @@ def _unary(op):
 
 
 sin, cos, exp, log, sqrt = (_unary(n) for n in ('sin', 'cos', 'exp', 'log', 'sqrt'))
+
+
+# functions composed of the device's operations (no new device code; derivatives follow from the parts)
+def tan(a):
+    a = Expr.wrap(a)
+    return sin(a) / cos(a)
+
+
+def sinh(a):
+    e = exp(Expr.wrap(a))
+    return 0.5 * (e - 1.0 / e)
+
+
+def cosh(a):
+    e = exp(Expr.wrap(a))
+    return 0.5 * (e + 1.0 / e)
+
+
+def tanh(a):
+    e2 = exp(2.0 * Expr.wrap(a))
+    return (e2 - 1.0) / (e2 + 1.0)
 
 
 class SymVector:

@@ -146,9 +146,9 @@ class Model:
         self._alg = eqs
 
     def _parse(self, eqs):
-        """Expressions, or strings of the model's variable names with sin / cos / exp / log / sqrt (the right-hand side of
+        """Expressions, or strings of the model's variable names with sin / cos / tan / exp / log / sqrt / sinh / cosh / tanh (the right-hand side of
         an optional `... = ` is taken, like the reference's equation strings, util/parsing.py)."""
-        ns = {n: getattr(_expr, n) for n in ('sin', 'cos', 'exp', 'log', 'sqrt')}
+        ns = {n: getattr(_expr, n) for n in ('sin', 'cos', 'exp', 'log', 'sqrt', 'tan', 'sinh', 'cosh', 'tanh')}
         for vec in (self.x, self.u, self.p, self.z):
             ns.update({n: vec[n] for n in vec._names})
         out = []

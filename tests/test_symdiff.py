@@ -50,3 +50,34 @@ def test_committed_header_is_what_the_generator_writes():
     import gen_model_sym
     assert open(os.path.join(root, 'hilo_mpc_amd', 'csrc', 'hilo_models_sym.h')).read() == gen_model_sym.generate(), \
         "run tools/gen_model_sym.py"
+
+
+def test_composed_functions_and_general_powers():
+    """tan / sinh / cosh / tanh and a^b are composed of the device's operations (hilo_mpc_amd/expr.py): values, the symbolic
+    derivative DAG and the expression-level derivative against sympy."""
+    import math
+    import numpy as np
+    import sympy as sp
+    from hilo_mpc_amd import Model, expr
+    from hilo_mpc_amd.symdiff import derivative_dag
+    from tests.problems import eval_exprs
+    m = Model(name='fun')
+    x, u = m.set_dynamical_states(['a', 'b']), m.set_inputs(['c'])
+    m.set_dynamical_equations([expr.tan(x[0]) + expr.tanh(x[1] * u[0]) + x[0] ** 2.5,
+                               expr.sinh(x[0]) * expr.cosh(x[1]) + (1. + x[1] * x[1]) ** x[0] + 2. ** u[0]])
+    m2 = Model(name='fun2')
+    m2.set_dynamical_states(['a', 'b']), m2.set_inputs(['c'])
+    m2.set_dynamical_equations(['tan(a) + tanh(b * c) + a ^ 2.5', 'sinh(a) * cosh(b) + (1. + b * b) ** a + 2. ** c'])
+    a, b, c = sp.symbols('a b c')
+    f = sp.Matrix([sp.tan(a) + sp.tanh(b * c) + a ** 2.5, sp.sinh(a) * sp.cosh(b) + (1 + b * b) ** a + 2 ** c])
+    J = sp.lambdify([a, b, c], f.jacobian([a, b, c]))
+    F = sp.lambdify([a, b, c], f)
+    pt = (.7, -.4, 1.3)
+    for mod in (m, m2):
+        np.testing.assert_allclose(eval_exprs(mod._ode, pt[:2], pt[2:], []), np.asarray(F(*pt), dtype=float).ravel(), rtol=1e-14)
+        Je = expr.jacobian(mod._ode, list(mod.x) + list(mod.u))
+        np.testing.assert_allclose(eval_exprs([e for r in Je for e in r], pt[:2], pt[2:], []).reshape(2, 3), J(*pt), rtol=1e-12)
+        g, fn, Jd, _, _ = derivative_dag(2, 1, mod._ode)
+        np.testing.assert_allclose(np.array(g.evaluate([Jd[i][j] for i in range(2) for j in range(3)], pt[:2], pt[2:], [])).reshape(2, 3),
+                                   J(*pt), rtol=1e-12)
+    assert math.isclose(eval_exprs([expr.tan(expr.Expr.wrap(.3))], [], [], [])[0], math.tan(.3), rel_tol=1e-15)
