@@ -424,6 +424,47 @@ class NMPC:
         self._time_varying_parameters_values = values
         self._n_tvp = len(self._time_varying_parameters)
 
+    # ---- small accessors of the reference's controller base (optimizer.py:1508-1768, mpc.py:1926-1931) -----------------------
+    current_time = property(lambda s: s._time)
+    initial_time = property(lambda s: s._time)
+    n_tvp = property(lambda s: len(s._time_varying_parameters))
+    x_lb = property(lambda s: s._x_lb)
+    x_ub = property(lambda s: s._x_ub)
+    u_lb = property(lambda s: s._u_lb)
+    u_ub = property(lambda s: s._u_ub)
+    time_var = property(lambda s: getattr(s, '_time_var', []))
+
+    def is_setup(self):
+        return bool(self._nlp_setup_done)
+
+    def set_sampling_interval(self, dt=None):
+        """optimizer.py `set_sampling_interval`: the interval the controller's clock advances by per optimize()."""
+        if dt is not None:
+            if isinstance(dt, (float, int)):
+                self._sampling_interval = dt
+            else:
+                raise TypeError("Sampling interval must be a float.")
+
+    def set_nlp_solver(self, solver):
+        """optimizer.py:1372-1385; the name is checked by `set_nlp_options` ('ipopt' = the interior point of the device)."""
+        self._solver_name = solver
+        self._nlp_solver_is_set = True
+
+    def reset_solution(self):
+        """Forget the last solve: result, warm start, clock and iteration counter."""
+        self._nlp_solution, self._u_prev = None, None
+        self._time, self._n_iterations = 0., 0
+        if self._handle is not None:
+            _lib.check(_lib.lib().hilo_nmpc_reset_warm_start(self._handle))
+
+    def minimize_final_time(self, weight=1):
+        raise NotImplementedError("minimum-time problems (the sampling intervals as variables, mpc.py:1014-1023) are not offloaded")
+
+    def set_custom_constraints_function(self, fun=None, lb=None, ub=None, soft=False, max_violation=np.inf):
+        raise NotImplementedError("a custom constraint is a function of the WHOLE decision vector (mpc.py:1729-1745): it couples "
+                                  "the stages and does not fit the stage-wise solver; use set_stage_constraints / "
+                                  "set_terminal_constraints")
+
     def get_time_variable(self):
         """mpc.py:1055-1062: the time symbol for trajectory references given as functions, `ref=[sin(t), ...]`."""
         self._time_var = Expr('t', name='t')

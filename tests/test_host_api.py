@@ -287,3 +287,28 @@ def test_measurement_box_constraints_become_stage_and_terminal_constraints(monke
         nmpc.set_box_constraints(y_ub=[1.])
     with pytest.raises(NotImplementedError, match="measurement equations as expressions"):
         NMPC(Model('bioreactor3').discretize('rk4').setup(dt=1.)).set_box_constraints(y_lb=[0., 0.])
+
+
+def test_controller_accessors_of_the_reference():
+    """optimizer.py:1508-1768, mpc.py:1926-1931: clock, bounds, time variable, sampling interval, solver name; problems that do
+    not fit the stage-wise solver are refused with a reason."""
+    from hilo_mpc_amd import NMPC, Model
+    nmpc = NMPC(Model('chemostat4').discretize('rk4').setup(dt=.5))
+    assert nmpc.current_time == 0. and nmpc.initial_time == 0. and nmpc.n_iterations == 0 and nmpc.n_tvp == 0
+    assert nmpc.sampling_interval == .5 and not nmpc.is_setup() and nmpc.time_var == []
+    nmpc.set_box_constraints(x_lb=[0., 0., 0., 0.], u_ub=[1., 1.])
+    assert nmpc.x_lb == [0., 0., 0., 0.] and nmpc.x_ub is None and nmpc.u_ub == [1., 1.] and nmpc.u_lb is None
+    t = nmpc.get_time_variable()
+    assert nmpc.time_var is t
+    nmpc.set_sampling_interval(2)
+    assert nmpc.sampling_interval == 2
+    with pytest.raises(TypeError, match="Sampling interval must be a float."):
+        nmpc.set_sampling_interval('1')
+    nmpc.set_time_varying_parameters(['Sf'])
+    assert nmpc.n_tvp == 1
+    nmpc.set_nlp_solver('ipopt')
+    nmpc.reset_solution()
+    with pytest.raises(NotImplementedError, match="minimum-time"):
+        nmpc.minimize_final_time()
+    with pytest.raises(NotImplementedError, match="WHOLE decision vector"):
+        nmpc.set_custom_constraints_function(fun=lambda v, xi, ui: v[0])
