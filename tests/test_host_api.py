@@ -75,8 +75,10 @@ def test_expression_symbols_and_depth():
     with pytest.raises(ValueError, match="too deep"):
         deep.program()
     assert (m.x['X'] ** 2).program()[0] == 4.                               # [len | VARX 0 | SQ 0]
+    assert repr(m.x['X'] ** 2.5) == 'exp(mul(2.5, log(X)))'                  # general power of a positive base: exp(b log a)
+    assert len((m.x['X'] ** 2.5).program()) == 1 + 2 * 5
     with pytest.raises(NotImplementedError):
-        m.x['X'] ** 2.5
+        m.x['X'] ** 'two'
     with pytest.raises(ValueError, match="path variable"):
         expr.Expr('theta', name='theta').program()
 
