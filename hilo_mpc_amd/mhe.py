@@ -147,6 +147,8 @@ class MovingHorizonEstimator:
         if not (self.quad_arrival_cost._is_set or self.quad_stage_cost._is_set):
             raise ValueError("You need to define a cost function before setting up the MHE.")
         opts = {'integration_method': 'discrete', 'arrival_guess_update': 'smoothing', 'warm_start': True}
+        if options is None:
+            options = getattr(self, '_pending_options', None)          # set_nlp_options(...) before setup()
         for k, v in (options or {}).items():
             if k == 'integration_method' and v != 'discrete':
                 warnings.warn(f"The integration method is set to {v} but I notice that the model is in discrete time. "
@@ -315,6 +317,61 @@ class MovingHorizonEstimator:
         else:
             p_opt = self._p_pinned.expand(B, -1)
         return x_opt, p_opt
+
+    def return_mhe_estimation(self):
+        """mhe.py:1214-1232: (x_pred [B, n_x, N+1], w_pred [B, n_x, N]) of the last estimate, un-scaled."""
+        if self._nlp_solution is None:
+            warnings.warn("There is still no mpc solution available. Run mpc.optimize() to get one.")
+            return None, None
+        v = self._nlp_solution['x'].cpu().numpy()
+        N, nx = self._horizon, self._n_x
+        sw = np.ones(nx) if getattr(self, '_w_scaling', None) is None else np.asarray(self._w_scaling, dtype=float)
+        X = v[:, self._x_ind[0][0]:self._x_ind[N][-1] + 1].reshape(-1, N + 1, nx) * self._sx
+        W = v[:, self._w_ind[0][0]:self._w_ind[N - 1][-1] + 1].reshape(-1, N, nx) * sw
+        return np.swapaxes(X, 1, 2), np.swapaxes(W, 1, 2)
+
+    @property
+    def has_state_noise(self):
+        """mhe.py:1234-1246 (this build offloads the state-noise variant only)."""
+        return self.quad_stage_cost.Ww is not None
+
+    @has_state_noise.setter
+    def has_state_noise(self, arg):
+        if not isinstance(arg, bool):
+            raise TypeError("has_state_noise accepts True or False")
+        if not arg:
+            raise NotImplementedError("MHE without state noise is not yet offloaded (and its 'multiple_shooting' branch is broken "
+                                      "in the reference, SURVEY.md Q8)")
+
+    def set_nlp_options(self, *args, **kwargs):
+        """mhe.py:792-860: the options `setup(options=...)` takes, checked against the reference's allow-lists."""
+        possible = {'integration_method': ['collocation', 'rk4', 'erk', 'discrete', 'multiple_shooting'],
+                    'collocation_points': ['radau', 'legendre'], 'degree': None, 'print_level': [0, 1],
+                    'arrival_guess_update': ['filtering', 'smoothing'], 'warm_start': [True, False]}
+        given = args[0] if (args and isinstance(args[0], dict)) else kwargs
+        for k, v in (given or {}).items():
+            if k not in possible:
+                raise ValueError(f"The option named {k} does not exist. Possible options are {list(possible)}.")
+            if possible[k] is not None and v not in possible[k]:
+                raise ValueError(f"The option {k} is set to value {v} but the only allowed values are {possible[k]}.")
+        self._pending_options = dict(given or {})
+
+    def set_time_varying_parameters(self, time_varying_parameters=None):
+        """mhe.py:911-932."""
+        if time_varying_parameters:
+            for tvp in time_varying_parameters:
+                if tvp not in self._model.parameter_names:
+                    raise ValueError(f"The time-varying parameter {tvp} is not in the model0 parameter. "
+                                     f"The model0 parameters are {self._model.parameter_names}.")
+            raise NotImplementedError("time-varying parameters inside the estimation window are not offloaded")
+
+    def set_aux_nonlinear_constraints(self, aux_nl_const=None, ub=None, lb=None):
+        """mhe.py:1070-1087."""
+        if None not in [aux_nl_const, ub, lb]:
+            raise NotImplementedError("nonlinear constraints inside the estimation window are not offloaded")
+        if not all(a is None for a in (aux_nl_const, ub, lb)):
+            raise ValueError("When passing nonlinear constraints, you must pass"
+                             "the nonlinear constraint function, lower and upper bound")
 
     @property
     def solver_status_code(self):

@@ -105,6 +105,37 @@ def test_mhe_host_contract():
         mhe.add_measurements([1., 2.])
     with pytest.raises(ValueError, match="setup"):
         mhe.estimate()
+    # mhe.py:792-860, :911-932, :1070-1087, :1214-1246
+    with pytest.raises(ValueError, match="The option named nope does not exist"):
+        mhe.set_nlp_options({'nope': 1})
+    with pytest.raises(ValueError, match="only allowed values"):
+        mhe.set_nlp_options(arrival_guess_update='sometimes')
+    mhe.set_nlp_options({'arrival_guess_update': 'smoothing', 'print_level': 0})
+    with pytest.raises(ValueError, match="is not in the model0 parameter"):
+        mhe.set_time_varying_parameters(['nope'])
+    with pytest.raises(NotImplementedError):
+        mhe.set_time_varying_parameters(['Sf'])
+    mhe.set_time_varying_parameters()
+    with pytest.raises(ValueError, match="you must pass"):
+        mhe.set_aux_nonlinear_constraints(aux_nl_const=m.x['X'], ub=[1.])
+    mhe.set_aux_nonlinear_constraints()
+    with pytest.raises(TypeError, match="has_state_noise accepts True or False"):
+        mhe.has_state_noise = 1
+    assert mhe.has_state_noise is False
+    mhe.quad_stage_cost.add_state_noise(weights=[1., 1., 1., 1.])
+    assert mhe.has_state_noise is True
+    with pytest.warns(UserWarning, match="no mpc solution"):
+        assert mhe.return_mhe_estimation() == (None, None)
+    # layout of the window in the decision vector (mhe.py:614-655): [p | x_0..x_N | w_0..w_{N-1}], un-scaled on return
+    import torch
+    mhe._x_ind = [list(range(k * 4, (k + 1) * 4)) for k in range(6)]
+    mhe._w_ind = [list(range(24 + k * 4, 24 + (k + 1) * 4)) for k in range(5)]
+    mhe._sx, mhe._w_scaling = np.array([1., 10., 1., 1.]), [2., 1., 1., 1.]
+    v = np.arange(2 * 44, dtype=float).reshape(2, 44)
+    mhe._nlp_solution = {'x': torch.as_tensor(v)}
+    X, W = mhe.return_mhe_estimation()
+    assert X.shape == (2, 4, 6) and W.shape == (2, 4, 5)
+    assert X[1, 1, 2] == v[1, 2 * 4 + 1] * 10. and W[0, 0, 3] == v[0, 24 + 3 * 4] * 2.
 
 
 def test_lmpc_host_contract():
