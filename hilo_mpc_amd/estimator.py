@@ -295,6 +295,20 @@ class _KalmanFilter:
         self.solution._set(x=xs.T if (host and B == 1) else xs, P=cv(self._P), y=cv(yp))
         return self.solution
 
+    # accessors of the reference's estimator base (estimator/base.py:60-200)
+    n_x = property(lambda s: s._model.n_x)
+    n_u = property(lambda s: s._model.n_u)
+    n_p = property(lambda s: s._model.n_p)
+    n_y = property(lambda s: s._model.n_y)
+    n_z = property(lambda s: getattr(s._model, 'n_z', 0))
+    n_p_est = property(lambda s: 0)                       # the filters estimate states only
+    process_noise_covariance = property(lambda s: s._Q)
+    measurement_noise_covariance = property(lambda s: s._R)
+    error_covariance = property(lambda s: s._P)
+
+    def is_setup(self):
+        return self._handle is not None
+
     # raw device views of the filter state (zero-copy)
     @property
     def x(self):

@@ -712,6 +712,11 @@ class GaussianProcess:
         self._X_train, self._y_train = X, y
 
     X_train = property(lambda s: s._X_train)
+
+    def is_setup(self):
+        """gp.py `is_setup`."""
+        return getattr(self, '_handle', None) is not None
+
     y_train = property(lambda s: s._y_train)
 
     def setup(self, device_index=None, **kwargs):
