@@ -253,7 +253,7 @@ def test_expression_compiler():
     assert _run(expr.sin(2 * theta).program(theta_index=6), x + [.25], u, []) == pytest.approx(math.sin(.5))
     with pytest.raises(ValueError, match="only appear in path references"):
         (theta + vx).program()
-    with pytest.raises(NotImplementedError):
-        vx ** 2.5
+    # a general power of a positive base is composed as exp(b log a)
+    assert _run((vx ** 2.5).program(), x, u, []) == pytest.approx(1.2 ** 2.5, rel=1e-14)
     with pytest.raises(KeyError):
         m.x['nope']
