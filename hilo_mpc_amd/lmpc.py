@@ -77,6 +77,19 @@ class LMPC:
     prediction_horizon = horizon
     control_horizon = horizon
 
+    prediction_horizon = property(lambda s: s._horizon)                 # mpc.py:2429-2435
+    control_horizon = property(lambda s: s._horizon)
+
+    # mpc.py:2396-2406: not available for the linear MPC
+    def set_stage_constraints(self, *args, **kwargs):
+        raise NotImplementedError("The method set_stage_constraints is not available for LMPC.")
+
+    def set_custom_constraints_function(self, *args, **kwargs):
+        raise NotImplementedError("The method set_custom_constraints_function is not available for LMPC.")
+
+    def set_initial_guess(self, *args, **kwargs):
+        raise NotImplementedError("The method set_initial_guess is not available for LMPC.")
+
     def set_box_constraints(self, x_ub=None, x_lb=None, u_ub=None, u_lb=None):
         def chk(v, n, what):
             if v is None:

@@ -144,6 +144,9 @@ def test_lmpc_host_contract():
         LMPC(Model('chemostat4').discretize('erk', order=4).setup(dt=0.5))
     m = Model('lti', A=[[1., 1.], [0., 1.]], B=[[0.5], [1.]]).setup(dt=1.)
     lmpc = LMPC(m)
+    for f in ('set_stage_constraints', 'set_custom_constraints_function', 'set_initial_guess'):      # mpc.py:2396-2406
+        with pytest.raises(NotImplementedError, match=f"The method {f} is not available for LMPC."):
+            getattr(lmpc, f)()
     with pytest.raises(ValueError, match="2x2"):
         lmpc.Q = np.eye(3)
     lmpc.Q, lmpc.R, lmpc.P = np.eye(2), [[1.]], np.eye(2)
