@@ -77,9 +77,6 @@ class LMPC:
     prediction_horizon = horizon
     control_horizon = horizon
 
-    prediction_horizon = property(lambda s: s._horizon)                 # mpc.py:2429-2435
-    control_horizon = property(lambda s: s._horizon)
-
     # mpc.py:2396-2406: not available for the linear MPC
     def set_stage_constraints(self, *args, **kwargs):
         raise NotImplementedError("The method set_stage_constraints is not available for LMPC.")
