@@ -22,20 +22,18 @@ KIND['particle filter'] = 1          # the handle only carries the model, the sa
 
 
 def lhsnorm(mu, sigma, n):
-    """pf.py:425-447: Latin-hypercube sample of a normal distribution with independent components (marginal variances
-    `diag(sigma)`), ranks taken from a correlated normal sample."""
+    """Latin-hypercube sample of a normal distribution, [n, dim] (pf.py:425-447): a correlated normal sample only supplies the
+    RANKS per component; each component then takes one point per probability stratum, (rank - U(0, 1)) / n, mapped through the
+    inverse normal cdf with the marginal mean and variance `diag(sigma)`.  Draws from numpy's global generator in the reference's
+    order: `multivariate_normal(mu, sigma, size=n)`, then `rand(n, dim)`."""
     from scipy.stats import norm
-    n_m = mu.size
+    mu = np.asarray(mu, dtype=float)
+    sigma = np.asarray(sigma, dtype=float)
     z = np.random.multivariate_normal(mu, sigma, size=n)
-    x = np.zeros_like(z, dtype=z.dtype)
-    idz = np.argsort(z, axis=0)
-    for k in range(n_m):
-        x[idz[:, k], k] = np.linspace(1, n, n)
-    x -= np.random.rand(*x.shape)
-    x /= n
-    for k in range(n_m):
-        x[:, k] = norm.ppf(x[:, k], loc=mu[k], scale=np.sqrt(sigma[k, k]))
-    return x
+    ranks = np.empty_like(z)
+    np.put_along_axis(ranks, np.argsort(z, axis=0), np.arange(1., n + 1.)[:, None], axis=0)
+    strata = (ranks - np.random.rand(n, mu.size)) / n
+    return norm.ppf(strata, loc=mu[None, :], scale=np.sqrt(np.diag(sigma))[None, :])
 
 
 class ParticleFilter(_KalmanFilter):

@@ -18,17 +18,17 @@ from scipy.stats import norm
 
 
 def lhsnorm(mu, sigma, n):
-    n_m = mu.size
-    z = np.random.multivariate_normal(mu, sigma, size=n)
-    x = np.zeros_like(z, dtype=z.dtype)
-    idz = np.argsort(z, axis=0)
-    for k in range(n_m):
-        x[idz[:, k], k] = np.linspace(1, n, n)
-    x -= np.random.rand(*x.shape)
-    x /= n
-    for k in range(n_m):
-        x[:, k] = norm.ppf(x[:, k], loc=mu[k], scale=np.sqrt(sigma[k, k]))
-    return x
+    """pf.py:425-447, component by component: ranks of a correlated normal sample pick the stratum, a uniform draw the place
+    inside it, the inverse normal cdf (marginal mean and standard deviation) the value."""
+    dim = np.size(mu)
+    sample = np.random.multivariate_normal(mu, sigma, size=n)        # only its ranks are used
+    jitter = np.random.rand(n, dim)
+    out = np.empty((n, dim))
+    for k in range(dim):
+        rank = np.empty(n)
+        rank[np.argsort(sample[:, k])] = np.arange(1, n + 1)
+        out[:, k] = norm.ppf((rank - jitter[:, k]) / n, loc=mu[k], scale=np.sqrt(sigma[k, k]))
+    return out
 
 
 def pf_function(model, dt, X, y, u, p, w, v, R):

@@ -185,3 +185,19 @@ def test_estimate_flow_consumes_the_random_stream_like_the_reference(roughening,
         np.testing.assert_allclose(x[:, 0], r['x'], rtol=1e-13)
         np.testing.assert_allclose(P[0], r['P'], rtol=1e-12)
     assert x.shape == (1, 1) and s['y'].shape == (1, 1)
+
+
+def test_lhsnorm_consumes_the_stream_like_the_restated_reference():
+    """The product's vectorised `lhsnorm` against the oracle's column-by-column restatement of pf.py:425-447: same numbers from
+    the same seed (both draw `multivariate_normal(size=n)` and then `rand(n, dim)`), and the same generator state afterwards."""
+    from oracle import pf as opf
+    for seed, (mu, sigma, n) in enumerate([(np.array([1., -2.]), np.array([[4., 1.], [1., .25]]), 60),
+                                           (np.zeros(1), np.array([[2.]]), 15), (np.array([.1, 40., .5]), np.diag([1e-4, 4., .01]), 33)]):
+        np.random.seed(seed)
+        a = lhsnorm(mu, sigma, n)
+        sa = np.random.rand()
+        np.random.seed(seed)
+        b = opf.lhsnorm(mu, sigma, n)
+        sb = np.random.rand()
+        np.testing.assert_array_equal(a, b)
+        assert sa == sb
