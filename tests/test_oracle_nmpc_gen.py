@@ -56,9 +56,9 @@ def _slsqp(pb, ipm, res, b, p, strict=True):
         for k in range(N):
             zk = np.concatenate([X[k], U[k]])[None]
             z = zk - pb.zrefa
-            J += float(z @ pb.Wza @ z.T) + pb._lp[0](zk)[0] + (float(E @ pb.We @ E) if pb.ne else 0.)
+            J += (z @ pb.Wza @ z.T).item() + pb._lp[0](zk)[0] + (float(E @ pb.We @ E) if pb.ne else 0.)
         d = X[N][None] - pb.xrefNa
-        return J + float(d @ pb.WNa @ d.T) + pb._Vp[0](X[N][None])[0]
+        return J + (d @ pb.WNa @ d.T).item() + pb._Vp[0](X[N][None])[0]
 
     def eq(w):
         X, U, E = split(full(w))
