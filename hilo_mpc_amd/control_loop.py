@@ -3,9 +3,9 @@
 
 What the reference's `_run` does per iteration (control_loop.py:343-397): `u = controller.optimize(x0[states of the
 controller's model], cp=p)`, `plant.simulate(u=u, p=p)`, `observer.estimate()` - the controller is fed the PLANT state, the
-observer runs alongside.  Here the plant is advanced on the device with the controller's shooting map when it is the
-controller's own model (`NMPC.plant_step`), or by a callable `(x, u, p) -> x+` the caller supplies (the reference integrates
-the plant with CVODES, which has no device counterpart)."""
+observer runs alongside.  Here the plant is advanced on the device: with the controller's shooting map when it is the
+controller's own model (`NMPC.plant_step`), with `Model.step` for a plant model of its own (a continuous plant is integrated with
+eight classic Runge-Kutta steps per interval in place of the reference's CVODES), or by a callable `(x, u, p) -> x+`."""
 import numpy as np
 import torch
 
@@ -19,13 +19,16 @@ class SimpleControlLoop:
             self._plant_fun, self._plant = plant, None
         else:
             cm = getattr(controller, '_model', None)
-            if cm is None or list(plant.dynamical_state_names) != list(cm.dynamical_state_names) or \
-                    list(plant.input_names) != list(cm.input_names):
-                raise NotImplementedError("a plant model other than the controller's is advanced by a callable "
-                                          "(x, u, p) -> x_next; pass that instead of the Model")
-            if not hasattr(controller, 'plant_step'):
-                raise NotImplementedError("this controller has no device plant step; pass a callable plant")
-            self._plant_fun, self._plant = None, plant
+            if plant is cm and hasattr(controller, 'plant_step'):
+                self._plant_fun, self._plant = None, plant          # the controller's own shooting map
+            else:
+                # a plant of its own (other parameters, discretisation or equations than the controller's model): advanced
+                # on the device by `Model.step` (hilo_pf_function with one particle per instance, no noise)
+                if not hasattr(plant, 'step'):
+                    raise TypeError("the plant must be a Model or a callable (x, u, p) -> x_next")
+                if len(plant.input_names) != len(getattr(cm, 'input_names', plant.input_names)):
+                    raise ValueError("plant and controller model have different numbers of inputs")
+                self._plant_fun, self._plant = (lambda x, u, p: plant.step(x, u, p)[0]), plant
         self.solution = None
 
     def _measure(self, x):

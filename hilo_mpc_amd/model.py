@@ -315,5 +315,111 @@ class Model:
         self._is_setup = False
         return self
 
-    def copy(self):
-        return copy.copy(self)
+    def copy(self, setup=True):
+        m = copy.copy(self)
+        m._sim = None              # the copy simulates its own trajectory
+        return m
+
+    # ---- the model as a PLANT: one sampling interval for a batch of states (dynamic_model.py:3360-3400, :3911-4000) -----------------
+    def _plant_handle(self, device_index=None):
+        """A filter handle of the library carries exactly what a plant step needs - the model functor (zoo, or compiled from the
+        expressions), the sampling interval and the discretisation - and `hilo_pf_function` with one particle per instance and
+        zero noise IS that step: x+ = Phi(x, u, p), y = h(x+, u, p) (a continuous model is integrated with eight classic
+        Runge-Kutta steps per interval in place of the reference's CVODES)."""
+        h = getattr(self, '_plant', None)
+        if h is None or h._model_stamp != (self.dt, self.erk_order, self.n_sub, id(self._ode) if self._symbolic else None):
+            from .estimator import ExtendedKalmanFilter
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                h = ExtendedKalmanFilter(self, device_index=device_index)
+            h.setup()
+            h._model_stamp = (self.dt, self.erk_order, self.n_sub, id(self._ode) if self._symbolic else None)
+            self._plant = h
+        return h
+
+    def step(self, x, u=None, p=None, device_index=None):
+        """x [B, n_x] -> (x_next [B, n_x], y [B, n_y]) after one sampling interval, on the device (numpy in -> numpy out)."""
+        import torch
+        from . import _lib
+        from ._device import ptr, stream_ptr, to_dev
+        if not self._is_setup:
+            raise RuntimeError("Model is not set up. Run Model.setup() before running simulations.")
+        h = self._plant_handle(device_index)
+        dev = h._dev
+        host = not isinstance(x, torch.Tensor)
+        xt = to_dev(x, dev).reshape(-1, self.n_x).contiguous()
+        B = xt.shape[0]
+        parts = []
+        for v, n, what in ((u, self.n_u, 'inputs'), (self.lti_parameters() if self.name == 'lti' else p, h._n_p, 'parameters')):
+            if n:
+                if v is None:
+                    raise RuntimeError(f"The model has {n} {what}; pass them to step() / simulate().")
+                t = to_dev(v, dev).reshape(-1, n)
+                if t.shape[0] not in (1, B):
+                    raise ValueError(f"{what}: batch {t.shape[0]} does not match {B} states")
+                parts.append(t.expand(B, -1))
+        up = torch.cat(parts, dim=1).contiguous() if parts else None
+        ny = h._n_y
+        zeros_x = torch.zeros(B, 1, self.n_x, dtype=torch.float64, device=dev)
+        zeros_y = torch.zeros(B, 1, ny, dtype=torch.float64, device=dev)
+        R = torch.eye(ny, dtype=torch.float64, device=dev)
+        xn, y = torch.empty(B, 1, self.n_x, dtype=torch.float64, device=dev), torch.empty(B, 1, ny, dtype=torch.float64, device=dev)
+        q = torch.empty(B, 1, dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().hilo_pf_function(h._handle, B, 1, ptr(xt), ptr(zeros_y), ptr(up), (up.shape[1] if up is not None else 0),
+                                               ptr(zeros_x), ptr(zeros_y), ptr(R), 0, ptr(xn), ptr(y), ptr(q), stream_ptr(dev)))
+        xn, y = xn[:, 0], y[:, 0]
+        return (xn.cpu().numpy(), y.cpu().numpy()) if host else (xn, y)
+
+    def set_initial_conditions(self, x0, t0=0., z0=None):
+        """dynamic_model.py:3360-3400 (a batch of states is allowed: [B, n_x])."""
+        if not self._is_setup:
+            raise RuntimeError("Model is not set up. Run Model.setup() before setting the initial conditions.")
+        x = np.atleast_2d(np.asarray(x0.cpu() if hasattr(x0, 'cpu') else x0, dtype=float))
+        if x.shape[1] != self.n_x:
+            x = x.T
+        if x.shape[1] != self.n_x:
+            raise ValueError(f"Dimension mismatch. Supplied dimension for the initial states is {x.shape[1]}, but required "
+                             f"dimension is {self.n_x}.")
+        self._sim = {'t': [float(t0)], 'x': [x], 'y': [], 'u': []}
+
+    def simulate(self, u=None, p=None, steps=1, **kwargs):
+        """dynamic_model.py:3911-4000: advance the stored state by `steps` sampling intervals with the inputs held; results in
+        `model.solution` (`solution['x:f']` the last state, `solution['x']` the trajectory)."""
+        if not self._is_setup:
+            raise RuntimeError("Model is not set up. Run Model.setup() before running simulations.")
+        if getattr(self, '_sim', None) is None:
+            raise RuntimeError("No initial dynamical states found. Please set initial conditions before simulating the model.")
+        if u is not None:
+            u = np.asarray(u.cpu() if hasattr(u, 'cpu') else u, dtype=float)
+            u = u.reshape(1, -1) if u.size == self.n_u else (u.T if u.ndim == 2 and u.shape[0] == self.n_u and u.shape[1] != self.n_u else u)
+        for _ in range(int(steps)):
+            x, y = self.step(self._sim['x'][-1], u, p)
+            self._sim['x'].append(x), self._sim['y'].append(y), self._sim['u'].append(u)
+            self._sim['t'].append(self._sim['t'][-1] + self.dt)
+
+    @property
+    def solution(self):
+        """`model.solution['x:f']`, `['y:f']`, `['t:f']`, `['x']` ... (the key language of base.py:2426-2470 for the last value /
+        the whole series; single instance: column vectors like the reference's)."""
+        sim = getattr(self, '_sim', None)
+
+        class _View:
+            def __getitem__(_, key):
+                if sim is None:
+                    raise KeyError(key)
+                name, _, sel = key.partition(':')
+                series = sim[name]
+                if not series:
+                    raise KeyError(key)
+                if sel in ('f', '-1'):
+                    v = np.asarray(series[-1])
+                    return v.T if (v.ndim == 2 and v.shape[0] == 1) else v
+                if sel == '0':
+                    v = np.asarray(series[0])
+                    return v.T if (v.ndim == 2 and v.shape[0] == 1) else v
+                a = np.asarray(series)
+                return a[:, 0].T if (a.ndim == 3 and a.shape[1] == 1) else a
+
+            get_by_id = __getitem__
+        return _View()

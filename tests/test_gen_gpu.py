@@ -238,41 +238,3 @@ def test_c5_from_a_cold_zero_velocity_guess_solves_everywhere():
         assert np.all(nmpc.solver_status_code == 1), np.unique(nmpc.solver_status_code, return_counts=True)
         x = nmpc.plant_step(x, u)
 
-
-def test_measurement_box_constraints_equal_explicit_stage_and_terminal_constraints():
-    """`set_box_constraints(y_ub=)` (mpc.py:703-708) IS a stage + terminal constraint on the measurement equations: identical
-    solves, and the bound holds along the prediction where the solver converged."""
-    from hilo_mpc_amd import NMPC, Model
-
-    def build(as_y):
-        m = Model('chemostat4').discretize('rk4').setup(dt=C2['dt'])
-        nmpc = NMPC(m)
-        xs, us = m.dynamical_state_names, m.input_names
-        for ind, W, ref in C2['stage_states']:
-            nmpc.quad_stage_cost.add_states(names=[xs[i] for i in ind], weights=list(W), ref=ref)
-        for ind, W, ref in C2['stage_inputs']:
-            nmpc.quad_stage_cost.add_inputs(names=[us[i] for i in ind], weights=list(W), ref=ref)
-        for ind, W, ref in C2['terminal_states']:
-            nmpc.quad_terminal_cost.add_states(names=[xs[i] for i in ind], weights=list(W), ref=ref)
-        nmpc.horizon = 8
-        box = dict(x_lb=C2.get('x_lb'), u_lb=C2.get('u_lb'), u_ub=C2.get('u_ub'))
-        if as_y:
-            nmpc.set_box_constraints(y_ub=[10., .45], **box)                    # yX = X, yP = P
-        else:
-            nmpc.set_box_constraints(**box)
-            nmpc.set_stage_constraints(stage_constraint=[m.x['X'], m.x['P']], ub=[10., .45])
-            nmpc.set_terminal_constraints(terminal_constraint=[m.x['X'], m.x['P']], ub=[10., .45])
-        nmpc.set_initial_guess(x_guess=C2['x_guess'], u_guess=C2['u_guess'])
-        nmpc.setup(options={'integration_method': 'discrete', 'print_level': 0})
-        return nmpc
-
-    a, b = build(True), build(False)
-    assert (a._n_v, a._n_g) == (b._n_v, b._n_g) and a._user_source == b._user_source
-    x0 = c2_x0(6)
-    ua, ub = a.optimize(x0, cp=C2['p']), b.optimize(x0, cp=C2['p'])
-    assert np.array_equal(a.solver_status_code, b.solver_status_code)
-    np.testing.assert_array_equal(ua, ub)
-    np.testing.assert_array_equal(a._nlp_solution['x'].cpu().numpy(), b._nlp_solution['x'].cpu().numpy())
-    ok = a.solver_status_code == 1
-    xp = a.return_prediction()[0]
-    assert np.all(xp[ok][:, 2, :-1] <= .45 + 1e-6)

@@ -348,3 +348,37 @@ def test_controller_accessors_of_the_reference():
         nmpc.minimize_final_time()
     with pytest.raises(NotImplementedError, match="WHOLE decision vector"):
         nmpc.set_custom_constraints_function(fun=lambda v, xi, ui: v[0])
+
+
+def test_model_as_plant_host_contract(monkeypatch):
+    """`set_initial_conditions` / `simulate` / `solution` (dynamic_model.py:3360-3400, :3911-4000) around the device plant step
+    (stubbed here: no GPU): error behaviour, orientation of the stored states, the key language of the solution."""
+    import numpy as np
+    from hilo_mpc_amd import Model
+    m = Model('chemostat4').discretize('rk4')
+    with pytest.raises(RuntimeError, match="Model is not set up. Run Model.setup\\(\\) before setting the initial conditions."):
+        m.set_initial_conditions([.1, 40., 0., 0.])
+    m.setup(dt=.5)
+    with pytest.raises(RuntimeError, match="No initial dynamical states found"):
+        m.simulate(u=[.1, .2], p=[100., 4., 1., 0.])
+    with pytest.raises(ValueError, match="Dimension mismatch"):
+        m.set_initial_conditions([1., 2., 3.])
+    m.set_initial_conditions([.1, 40., 0., 0.])
+    calls = []
+
+    def step(x, u=None, p=None, device_index=None):
+        calls.append((np.array(x), None if u is None else np.array(u)))
+        return x + 1., x[:, [0, 2]]
+    monkeypatch.setattr(m, 'step', step)
+    m.simulate(u=[.1, .2], p=[100., 4., 1., 0.], steps=3)
+    assert len(calls) == 3 and calls[0][1].shape == (1, 2)
+    sol = m.solution
+    np.testing.assert_array_equal(sol['x:f'], np.array([[3.1], [43.], [3.], [3.]]))          # column vector like the reference's DM
+    np.testing.assert_array_equal(sol['x:0'], np.array([[.1], [40.], [0.], [0.]]))
+    assert sol['x'].shape == (4, 4) and sol['y'].shape == (2, 3) and sol['t:f'] == 1.5
+    c = m.copy(setup=False)
+    assert c._sim is None and m._sim is not None
+    # a batch of plants keeps the batch axis
+    m.set_initial_conditions(np.ones((5, 4)))
+    m.simulate(u=np.zeros((5, 2)), p=[100., 4., 1., 0.])
+    assert m.solution['x:f'].shape == (5, 4) and m.solution['x'].shape == (2, 5, 4)
