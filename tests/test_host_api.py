@@ -382,3 +382,50 @@ def test_model_as_plant_host_contract(monkeypatch):
     m.set_initial_conditions(np.ones((5, 4)))
     m.simulate(u=np.zeros((5, 2)), p=[100., 4., 1., 0.])
     assert m.solution['x:f'].shape == (5, 4) and m.solution['x'].shape == (2, 5, 4)
+
+
+def test_model_step_passes_the_arguments_of_the_c_signature(monkeypatch):
+    """`Model.step` against a stand-in for `hilo_pf_function` that READS its pointer arguments the way include/hilo_hip.h
+    declares them (batch, n_samples, X, y, up, up_stride, w, v, R, r_stride, X_prop, Y, q, stream) and answers with the oracle's
+    model - argument order, strides and shapes of the host call, without a GPU."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from hilo_mpc_amd import Model, _lib
+    from oracle import models as omodels
+    m = Model('chemostat4').discretize('rk4').setup(dt=.5)
+    om = omodels.get('chemostat4').discretize(4)
+
+    class H:
+        _dev, _handle, _n_p, _n_y = torch.device('cpu'), 1234, 4, 2
+    monkeypatch.setattr(m, '_plant_handle', lambda device_index=None: H)
+    monkeypatch.setattr('hilo_mpc_amd._device.stream_ptr', lambda dev: 0)
+
+    def arr(ptr, n):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(n,))
+
+    class Lib:
+        @staticmethod
+        def hilo_pf_function(h, B, N, X, y, up, us, w, v, R, rs, Xp, Y, q, stream):
+            assert (h, N, us, rs) == (1234, 1, 6, 0)
+            x = arr(X, B * 4).reshape(B, 4)
+            upv = arr(up, B * 6).reshape(B, 6)
+            assert not arr(w, B * 4).any() and not arr(v, B * 2).any() and np.array_equal(arr(R, 4), [1., 0., 0., 1.])
+            xn = om.f(x, upv[:, :2], upv[:, 2:], .5)
+            arr(Xp, B * 4)[:] = xn.ravel()
+            arr(Y, B * 2)[:] = om.h(xn, upv[:, :2], upv[:, 2:], .5).ravel()
+            arr(q, B)[:] = 1.
+            return 0
+    monkeypatch.setattr(_lib, 'lib', lambda: Lib)
+    rng = np.random.default_rng(0)
+    X = np.array([.1, 40., .5, .2]) * (1 + .1 * rng.standard_normal((5, 4)))
+    U = rng.uniform(0, .3, (5, 2))
+    p = [100., 4., 1., 0.]
+    xn, y = m.step(X, U, p)
+    ref = om.f(X, U, np.tile(p, (5, 1)), .5)
+    np.testing.assert_allclose(xn, ref, rtol=1e-14)
+    np.testing.assert_allclose(y, ref[:, [0, 2]], rtol=1e-14)
+    with pytest.raises(RuntimeError, match="The model has 2 inputs"):
+        m.step(X, None, p)
+    with pytest.raises(ValueError, match="does not match"):
+        m.step(X, U[:3], p)
