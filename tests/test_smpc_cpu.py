@@ -222,3 +222,25 @@ def test_oracle_smpc_solution_vs_slsqp(name):
     res = ipm.solve(xa0, p)
     assert res['status'][0] == 1 and res['kkt'][0] <= 1e-8
     _slsqp(pb, ipm, res, 0, p[0], strict=False)
+
+
+def test_surrogate_with_two_learned_terms():
+    """Two GPs on different states (`SMPC(model, [gp_1, gp_2], B)` with B of shape n_x x 2): stacked means, block-diagonal
+    variances and stacked Jacobians of the surrogate against the oracle."""
+    from oracle.smpc import smpc_surrogate
+    m, om = smpc_models('pend')
+    post = smpc_oracle_post()
+    Bw = np.array([[.05, 0.], [.02, .1]])
+    K = np.array([[-.5, -.3]])
+    smpc = SMPC(m, [_TrainedGp(['th']), _TrainedGp(['om'])], Bw, Kgain=K)
+    sur, _, _ = smpc_surrogate(om, [post, post], [[0], [1]], Bw, K)
+    gpf = [_oracle_gp_functions(post)] * 2
+    rng = np.random.default_rng(5)
+    for _ in range(4):
+        mean = rng.uniform(-.3, 1.2, 2)
+        A = rng.uniform(-1, 1, (2, 2))
+        cov = .05 * A @ A.T
+        u = rng.uniform(-1, 1, 1)
+        xa = np.concatenate([mean, cov.T.reshape(-1)])
+        np.testing.assert_allclose(eval_exprs(smpc._model._ode, xa, u, [], gpf), sur.f(xa, u, [], 1.)[0], rtol=1e-10, atol=1e-12)
+    assert len(smpc._model._gps) == 2
