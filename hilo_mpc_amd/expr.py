@@ -66,7 +66,7 @@ class Expr:
     def __repr__(self):
         if self.op == 'const':
             return repr(self.value)
-        if self.op in ('x', 'u', 'p', 'z', 'theta', 't'):
+        if self.op in ('x', 'u', 'p', 'z', 'theta', 't', 'dt'):
             return self.name
         return f"{self.op}({', '.join(map(repr, self.args))})"
 
@@ -239,7 +239,7 @@ def diff(e, var, memo=None):
         d = [memo[id(c)] for c in a]
         if op in ('x', 'u', 'p', 'z', 'theta'):
             r = one if (op == var.op and n.value == var.value) else zero
-        elif op == 'const':
+        elif op in ('const', 'dt', 't'):
             r = zero
         elif op == 'add':
             r = _add(d[0], d[1])

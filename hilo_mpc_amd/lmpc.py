@@ -21,6 +21,8 @@ class LMPC:
     _solver_name_list_qp = ['qpoases', 'hip_qp']
 
     def __init__(self, model, id=None, name=None, plot_backend=None, device_index=None):
+        if getattr(model, '_symbolic', False):
+            raise NotImplementedError("LMPC takes the matrices of the system: Model('lti', A=..., B=..., C=...)")
         if model.name != 'lti' and not model.is_linear():
             raise TypeError("The model is nonlinear. Use the NMPC class or linearize the model.")
         if model.name != 'lti':

@@ -149,6 +149,7 @@ class Model:
         """Expressions, or strings of the model's variable names with sin / cos / tan / exp / log / sqrt / sinh / cosh / tanh (the right-hand side of
         an optional `... = ` is taken, like the reference's equation strings, util/parsing.py)."""
         ns = {n: getattr(_expr, n) for n in ('sin', 'cos', 'exp', 'log', 'sqrt', 'tan', 'sinh', 'cosh', 'tanh')}
+        ns['dt'] = Expr('dt', name='dt')            # the sampling interval inside the equations of a discrete model
         for vec in (self.x, self.u, self.p, self.z):
             ns.update({n: vec[n] for n in vec._names})
         out = []
@@ -166,6 +167,7 @@ class Model:
         if len(eqs) != self.n_x:
             raise ValueError(f"the model has {self.n_x} dynamical states but {len(eqs)} equations were supplied")
         self._ode = eqs
+        self._linear = self._check_linearity()
 
     def set_measurement_equations(self, equations):
         """dynamic_model.py:1407-1460; the measurements are named y_0, y_1, ... like the reference's defaults."""
@@ -174,12 +176,55 @@ class Model:
         self._meas = self._parse(equations)
         self.measurement_names = [f'y_{i}' for i in range(len(self._meas))]
         self.n_y = len(self._meas)
+        self._linear = self._check_linearity()
 
-    def set_equations(self, ode=None, meas=None, **kwargs):
+    def set_equations(self, equations=None, ode=None, meas=None, alg=None, **kwargs):
+        """dynamic_model.py:1508-1553: `equations` as text (one string with line breaks, or a list of lines; grammar in
+        hilo_mpc_amd/parsing.py) declares states, measurements, algebraic states, inputs and parameters by the way they appear;
+        or the equation groups separately (`ode=`, `alg=`, `meas=`)."""
+        if equations is not None:
+            if not self._symbolic:
+                raise RuntimeError(f"'{self.name}' is a model of the device zoo; its equations are fixed")
+            if not (isinstance(equations, str) or (isinstance(equations, (list, tuple)) and all(isinstance(q, str) for q in equations))):
+                raise TypeError("equations must be a string or a list of strings")
+            from .parsing import parse_dynamic_equations
+            pm = parse_dynamic_equations(equations, discrete=self._native_discrete, x=self.dynamical_state_names,
+                                         y=self.measurement_names if self._meas else (), z=self.algebraic_state_names,
+                                         u=self.input_names, p=self.parameter_names)
+            if any(e is None for e in pm.ode):
+                missing = [n for n, e in zip(pm.x, pm.ode) if e is None]
+                raise ValueError(f"no dynamical equation for the state(s) {missing}")
+            self.dynamical_state_names, self.input_names, self.parameter_names = pm.x, pm.u, pm.p
+            self.algebraic_state_names = pm.z
+            self.n_x, self.n_u, self.n_p, self.n_z = len(pm.x), len(pm.u), len(pm.p), len(pm.z)
+            if len(pm.alg) != len(pm.z):
+                raise ValueError(f"the model has {len(pm.z)} algebraic states but {len(pm.alg)} algebraic equations were supplied")
+            self._ode, self._alg = pm.ode, pm.alg
+            self._meas, self.measurement_names, self.n_y = pm.meas, list(pm.y), len(pm.meas)
+            self._equation_notes = pm.notes
+            self._is_setup = False
+            self._linear = self._check_linearity()
+            return
         if ode is not None:
             self.set_dynamical_equations(ode)
+        if alg is not None:
+            self.set_algebraic_equations(alg)
         if meas is not None:
             self.set_measurement_equations(meas)
+
+    def _check_linearity(self):
+        """dynamic_model.py `_check_linearity`: the right-hand sides are linear in (x, z, u) when no entry of their Jacobian depends
+        on these variables (parameters may appear in the matrices)."""
+        if not self._symbolic or self._ode is None:
+            return self._linear
+        from .expr import jacobian
+        rows = list(self._ode) + list(self._alg) + list(self._meas)
+        w = list(self.x) + list(self.z) + list(self.u)
+        try:
+            J = jacobian(rows, w)
+        except NotImplementedError:
+            return False
+        return not any(n.op in ('x', 'z', 'u') for r in J for e in r for n in e.nodes().values())
 
     def user_source(self, z_guess=None):
         """HIP source that defines `UserModel` for the run-time compiled path: the emitted functor, or the alias of the
@@ -191,6 +236,17 @@ class Model:
             for e in self._ode + self._meas + self._alg:
                 if e.depends_on('theta'):
                     raise ValueError("a path variable cannot appear in the model equations")
+            if any(e.depends_on('dt') for e in self._ode + self._meas + self._alg):
+                # the sampling interval written into the equations of a discrete model (`25*dt*x/(1 + x^2)`): a number once the
+                # model is set up
+                if self.dt is None:
+                    raise RuntimeError("Model is not set up: the equations use the sampling interval dt (Model.setup(dt=...))")
+                dtc = Expr.wrap(float(self.dt))
+                n1, n2 = len(self._ode), len(self._ode) + len(self._meas)
+                sub = Expr.substitute(self._ode + self._meas + self._alg, lambda n: dtc if n.op == 'dt' else None)
+                m = copy.copy(self)
+                m._ode, m._meas, m._alg = sub[:n1], sub[n1:n2], sub[n2:]
+                return m.user_source(z_guess)
             if self.n_z and len(self._alg) != self.n_z:
                 raise RuntimeError("Model is not set up: algebraic states without algebraic equations (set_algebraic_equations)")
             if self.n_z:
