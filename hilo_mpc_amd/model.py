@@ -132,6 +132,18 @@ class Model:
     def set_parameters(self, *names):
         return self._declare('parameter_names', names[0] if len(names) == 1 and not isinstance(names[0], str) else names, 'p')
 
+    def set_measurements(self, *names):
+        """dynamic_model.py `set_measurements`: names of the measurements (their equations follow with
+        `set_measurement_equations`)."""
+        if not self._symbolic:
+            raise RuntimeError(f"'{self.name}' is a model of the device zoo; its variables are fixed")
+        names = names[0] if len(names) == 1 and not isinstance(names[0], str) else names
+        names = [names] if isinstance(names, str) else list(names)
+        if len(set(names)) != len(names):
+            raise ValueError(f"duplicate names in {names}")
+        self._declared_measurements = names
+        return SymVector('y', names)
+
     def set_algebraic_states(self, *names):
         """dynamic_model.py `set_algebraic_states`: the z of a semi-explicit DAE  dx/dt = f(x, z, u, p),  0 = g(x, z, u, p)."""
         return self._declare('algebraic_state_names', names[0] if len(names) == 1 and not isinstance(names[0], str) else names, 'z')
@@ -170,11 +182,13 @@ class Model:
         self._linear = self._check_linearity()
 
     def set_measurement_equations(self, equations):
-        """dynamic_model.py:1407-1460; the measurements are named y_0, y_1, ... like the reference's defaults."""
+        """dynamic_model.py:1407-1460; the measurements carry the names given to `set_measurements`, y_0, y_1, ... otherwise (the
+        reference's defaults)."""
         if not self._symbolic:
             raise RuntimeError(f"'{self.name}' is a model of the device zoo; its equations are fixed")
         self._meas = self._parse(equations)
-        self.measurement_names = [f'y_{i}' for i in range(len(self._meas))]
+        named = getattr(self, '_declared_measurements', None)
+        self.measurement_names = list(named) if named and len(named) == len(self._meas) else [f'y_{i}' for i in range(len(self._meas))]
         self.n_y = len(self._meas)
         self._linear = self._check_linearity()
 

@@ -129,3 +129,17 @@ def test_text_models_compile_for_the_device():
     d.set_equations(equations=['x(k+1) = x(k)/2 + 25*dt*x(k)/(1 + x(k)^2)', 'y(k) = x(k)^2/20'])
     d.setup(dt=1.)
     _lib.check(_lib.lib().hilo_jit_precompile_kf(d.user_source().encode()))
+
+
+def test_reference_style_declaration_with_named_measurement():
+    """tests/test_PFs.py:39-44 as written there."""
+    m = Model(name='toy_ref', discrete=True)
+    m.set_dynamical_states('x')
+    m.set_measurements('y')
+    m.set_dynamical_equations('x/2 + 25*dt*x/(1 + x^2)')
+    m.set_measurement_equations('x^2/20')
+    m.setup(dt=1.)
+    assert m.measurement_names == ['y'] and m.n_y == 1 and not m.is_linear()
+    from hilo_mpc_amd import PF
+    pf = PF(m)
+    assert pf.sample_size == 15 and pf.variant is None
