@@ -83,3 +83,18 @@ def test_closed_loop_with_a_plant_model_of_its_own():
     b = SimpleControlLoop(nmpc._model, product_nmpc(C2)).run(3, x0, p=C2['p'])
     np.testing.assert_allclose(a['x'], b['x'], rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(a['u'], b['u'], rtol=1e-8, atol=1e-10)
+
+
+def test_model_given_as_text_equals_the_zoo_model():
+    """`Model.set_equations(equations=<text>)` (the benchmark system of tests/test_PFs.py:39-44, with `dt` in the difference
+    equation): its compiled functor steps and measures like the zoo's Toy1D."""
+    from hilo_mpc_amd import Model
+    m = Model(name='toy_text', discrete=True)
+    m.set_equations(equations=['x(k+1) = x(k)/2 + 25*dt*x(k)/(1 + x(k)^2)', 'y(k) = x(k)^2/20'])
+    m.setup(dt=1.)
+    zoo = Model('toy1d').setup(dt=1.)
+    X = np.linspace(-6., 6., 41)[:, None]
+    xa, ya = m.step(X)
+    xb, yb = zoo.step(X)
+    np.testing.assert_allclose(xa, xb, rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(ya, yb, rtol=1e-13, atol=1e-15)
