@@ -9,6 +9,10 @@ Host classes mirror the reference API surface for the hot path only (SURVEY.md s
 from .model import Model
 from .estimator import KalmanFilter, ExtendedKalmanFilter, UnscentedKalmanFilter
 from .gp import GaussianProcess, Kernel, Mean
+# the kernel and mean classes under the names of the reference's flat namespace (hilo_mpc/__init__.py:66-87)
+from .gp import (ConstantKernel, SquaredExponentialKernel, MaternKernel, ExponentialKernel, Matern32Kernel, Matern52Kernel,
+                 RationalQuadraticKernel, PiecewisePolynomialKernel, DotProductKernel, PolynomialKernel, LinearKernel,
+                 NeuralNetworkKernel, PeriodicKernel, ConstantMean, ZeroMean, OneMean, PolynomialMean, LinearMean)
 
 KF = KalmanFilter
 EKF = ExtendedKalmanFilter
@@ -16,7 +20,10 @@ UKF = UnscentedKalmanFilter
 GP = GaussianProcess
 
 __all__ = ['Model', 'KalmanFilter', 'ExtendedKalmanFilter', 'UnscentedKalmanFilter', 'KF', 'EKF', 'UKF',
-           'GaussianProcess', 'GP', 'Kernel', 'Mean']
+           'GaussianProcess', 'GP', 'Kernel', 'Mean', 'ConstantKernel', 'SquaredExponentialKernel', 'MaternKernel',
+           'ExponentialKernel', 'Matern32Kernel', 'Matern52Kernel', 'RationalQuadraticKernel', 'PiecewisePolynomialKernel',
+           'DotProductKernel', 'PolynomialKernel', 'LinearKernel', 'NeuralNetworkKernel', 'PeriodicKernel', 'ConstantMean',
+           'ZeroMean', 'OneMean', 'PolynomialMean', 'LinearMean']
 from .nmpc import NMPC
 from .smpc import SMPC
 from . import expr
