@@ -61,6 +61,9 @@ class _KalmanFilter:
 
     def __init__(self, model, id=None, name=None, plot_backend=None, square_root_form=True, device_index=None,
                  n_sub=None):
+        if not model._is_setup:                                   # estimator/base.py:74-76
+            raise RuntimeError(f"Model is not set up. Run Model.setup() before passing it to the "
+                               f"{'Kalman filter' if 'Kalman' in (self._type or '') else self._type}.")
         self._model = model
         self.name = name
         self._alpha, self._beta, self._kappa = 1e-3, 2., 0.
@@ -234,6 +237,10 @@ class _KalmanFilter:
         if y is None:
             raise RuntimeError("No measurement data supplied.")
         B = self._x.shape[0]
+        for name, val, n in (('y', y, self._n_y), ('u', u, self._n_u), ('p', p, self._n_p)):
+            if val is not None and n and int(np.size(val.cpu() if isinstance(val, torch.Tensor) else val)) % n:
+                raise ValueError(f"Dimension mismatch for variable {name}. Supplied dimension is "
+                                 f"{int(np.size(val.cpu() if isinstance(val, torch.Tensor) else val))}, but required dimension is {n}.")
         yt = to_dev(y, self._dev).reshape(-1, self._n_y)
         if yt.shape[0] != B:
             if B == 1:                                   # first call decides the batch size

@@ -429,3 +429,17 @@ def test_model_step_passes_the_arguments_of_the_c_signature(monkeypatch):
         m.step(X, None, p)
     with pytest.raises(ValueError, match="does not match"):
         m.step(X, U[:3], p)
+
+
+def test_filters_need_a_model_that_is_set_up():
+    """estimator/base.py:74-76; tests/test_KFs.py:24-34 - and the order of the checks: linearity first (kf.py:340-346)."""
+    from hilo_mpc_amd import EKF, KF, PF, UKF
+    for cls in (EKF, UKF):
+        with pytest.raises(RuntimeError, match="Model is not set up. Run Model.setup\\(\\) before passing it to the Kalman filter."):
+            cls(Model('chemostat4').discretize('rk4'))
+    with pytest.raises(RuntimeError, match="before passing it to the particle filter."):
+        PF(Model('chemostat4').discretize('rk4'))
+    with pytest.raises(ValueError, match="The supplied model is nonlinear"):
+        KF(Model('toy1d'))
+    with pytest.raises(RuntimeError, match="Model is not set up"):
+        KF(Model('linear2').discretize('erk', order=1))
