@@ -237,10 +237,12 @@ class _KalmanFilter:
         if y is None:
             raise RuntimeError("No measurement data supplied.")
         B = self._x.shape[0]
-        for name, val, n in (('y', y, self._n_y), ('u', u, self._n_u), ('p', p, self._n_p)):
-            if val is not None and n and int(np.size(val.cpu() if isinstance(val, torch.Tensor) else val)) % n:
-                raise ValueError(f"Dimension mismatch for variable {name}. Supplied dimension is "
-                                 f"{int(np.size(val.cpu() if isinstance(val, torch.Tensor) else val))}, but required dimension is {n}.")
+        for name, val, n in (('y', y, self._n_y), ('u', u, self._n_u), ('p', p, self._n_p)):     # base.py `_process_inputs`
+            if val is not None and n:
+                size = val.numel() if isinstance(val, torch.Tensor) else int(np.size(val))
+                if size % n:
+                    raise ValueError(f"Dimension mismatch for variable {name}. Supplied dimension is {size}, but required "
+                                     f"dimension is {n}.")
         yt = to_dev(y, self._dev).reshape(-1, self._n_y)
         if yt.shape[0] != B:
             if B == 1:                                   # first call decides the batch size
