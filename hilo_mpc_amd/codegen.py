@@ -15,7 +15,8 @@ functor; leaves are array reads, constants are printed with `repr` (round-trip e
 from .expr import Expr
 
 _BIN = {'add': '+', 'sub': '-', 'mul': '*', 'div': '/'}
-_FUN = {'sq': 'sq', 'sin': 'sin', 'cos': 'cos', 'exp': 'exp', 'log': 'log', 'sqrt': 'sqrt'}
+_FUN = {n: n for n in ('sq', 'sin', 'cos', 'exp', 'log', 'sqrt', 'log10', 'fabs', 'sign', 'asin', 'acos', 'atan', 'asinh', 'acosh',
+                       'atanh')}        # csrc/hilo_ad.h: one overload per scalar type
 
 
 def _lit(v):
@@ -73,6 +74,8 @@ class Emitter:
                 rhs = f"-1.0 * ({a[0]})"
             elif op in _FUN:
                 rhs = f"{_FUN[op]}({a[0]})"
+            elif op == 'atan2':
+                rhs = f"atan2({a[0]}, {a[1]})"
             elif op == 'gp':
                 # posterior mean of learned term #value at the features a[...] (csrc/hilo_models.h::gp_se_mean); the features
                 # are brought to their common scalar type (states and inputs may carry different derivative types)

@@ -92,6 +92,27 @@ template <int N> HD Dual<N> exp(const Dual<N>& a) { const double e = ::exp(a.v);
 template <int N> HD Dual<N> log(const Dual<N>& a) { return chain(a, ::log(a.v), 1.0 / a.v); }
 template <int N> HD Dual<N> sqrt(const Dual<N>& a) { const double s = ::sqrt(a.v); return chain(a, s, 0.5 / s); }
 template <int N> HD Dual<N> sq(const Dual<N>& a) { return chain(a, a.v * a.v, 2.0 * a.v); }
+// the rest of the reference's function table (hilo_mpc/util/parsing.py:36-58); non-smooth ones as CasADi differentiates them:
+// d|a| = sign(a) da, d sign(a) = 0
+HD double sgn_of(double v) { return v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : 0.0); }
+template <int N> HD Dual<N> log10(const Dual<N>& a) { return chain(a, ::log10(a.v), 0.4342944819032518 / a.v); }
+template <int N> HD Dual<N> fabs(const Dual<N>& a) { return chain(a, ::fabs(a.v), sgn_of(a.v)); }
+template <int N> HD Dual<N> sign(const Dual<N>& a) { return chain(a, sgn_of(a.v), 0.0); }
+template <int N> HD Dual<N> asin(const Dual<N>& a) { return chain(a, ::asin(a.v), 1.0 / ::sqrt(1.0 - a.v * a.v)); }
+template <int N> HD Dual<N> acos(const Dual<N>& a) { return chain(a, ::acos(a.v), -1.0 / ::sqrt(1.0 - a.v * a.v)); }
+template <int N> HD Dual<N> atan(const Dual<N>& a) { return chain(a, ::atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
+template <int N> HD Dual<N> asinh(const Dual<N>& a) { return chain(a, ::asinh(a.v), 1.0 / ::sqrt(a.v * a.v + 1.0)); }
+template <int N> HD Dual<N> acosh(const Dual<N>& a) { return chain(a, ::acosh(a.v), 1.0 / ::sqrt(a.v * a.v - 1.0)); }
+template <int N> HD Dual<N> atanh(const Dual<N>& a) { return chain(a, ::atanh(a.v), 1.0 / (1.0 - a.v * a.v)); }
+template <int N> HD Dual<N> atan2(const Dual<N>& y, const Dual<N>& x) {
+  Dual<N> r; r.v = ::atan2(y.v, x.v);
+  const double ir = 1.0 / (x.v * x.v + y.v * y.v);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = (x.v * y.d[i] - y.v * x.d[i]) * ir;
+  return r;
+}
+template <int N> HD Dual<N> atan2(const Dual<N>& y, double x) { return atan2(y, Dual<N>(x)); }
+template <int N> HD Dual<N> atan2(double y, const Dual<N>& x) { return atan2(Dual<N>(y), x); }
 
 // ------------------------------------------------------------------------------------------------
 // Jet2: univariate Taylor coefficients along one direction: f(t) = v + a t + (b/2) t^2 (a = f', b = f'')
@@ -136,6 +157,18 @@ HD FastD exp(FastD a) { return FastD(::exp(a.v)); }
 HD FastD log(FastD a) { return FastD(::log(a.v)); }
 HD FastD sqrt(FastD a) { return FastD(::sqrt(a.v)); }
 HD FastD sq(FastD a) { return FastD(a.v * a.v); }
+HD FastD log10(FastD a) { return FastD(::log10(a.v)); }
+HD FastD fabs(FastD a) { return FastD(::fabs(a.v)); }
+HD FastD sign(FastD a) { return FastD(sgn_of(a.v)); }
+HD FastD asin(FastD a) { return FastD(::asin(a.v)); }
+HD FastD acos(FastD a) { return FastD(::acos(a.v)); }
+HD FastD atan(FastD a) { return FastD(::atan(a.v)); }
+HD FastD asinh(FastD a) { return FastD(::asinh(a.v)); }
+HD FastD acosh(FastD a) { return FastD(::acosh(a.v)); }
+HD FastD atanh(FastD a) { return FastD(::atanh(a.v)); }
+HD FastD atan2(FastD y, FastD x) { return FastD(::atan2(y.v, x.v)); }
+HD FastD atan2(FastD y, double x) { return FastD(::atan2(y.v, x)); }
+HD FastD atan2(double y, FastD x) { return FastD(::atan2(y, x.v)); }
 
 struct Jet2 {
   double v, a, b;
@@ -174,6 +207,23 @@ HD Jet2 exp(const Jet2& x) { const double e = ::exp(x.v); return chain(x, e, e, 
 HD Jet2 log(const Jet2& x) { const double i = 1.0 / x.v; return chain(x, ::log(x.v), i, -i * i); }
 HD Jet2 sqrt(const Jet2& x) { const double s = ::sqrt(x.v); return chain(x, s, 0.5 / s, -0.25 / (s * x.v)); }
 HD Jet2 sq(const Jet2& x) { return chain(x, x.v * x.v, 2.0 * x.v, 2.0); }
+HD Jet2 log10(const Jet2& x) { const double i = 1.0 / x.v, c = 0.4342944819032518; return chain(x, ::log10(x.v), c * i, -c * i * i); }
+HD Jet2 fabs(const Jet2& x) { return chain(x, ::fabs(x.v), sgn_of(x.v), 0.0); }
+HD Jet2 sign(const Jet2& x) { return chain(x, sgn_of(x.v), 0.0, 0.0); }
+HD Jet2 asin(const Jet2& x) { const double r = 1.0 / ::sqrt(1.0 - x.v * x.v); return chain(x, ::asin(x.v), r, x.v * r * r * r); }
+HD Jet2 acos(const Jet2& x) { const double r = 1.0 / ::sqrt(1.0 - x.v * x.v); return chain(x, ::acos(x.v), -r, -x.v * r * r * r); }
+HD Jet2 atan(const Jet2& x) { const double r = 1.0 / (1.0 + x.v * x.v); return chain(x, ::atan(x.v), r, -2.0 * x.v * r * r); }
+HD Jet2 asinh(const Jet2& x) { const double r = 1.0 / ::sqrt(x.v * x.v + 1.0); return chain(x, ::asinh(x.v), r, -x.v * r * r * r); }
+HD Jet2 acosh(const Jet2& x) { const double r = 1.0 / ::sqrt(x.v * x.v - 1.0); return chain(x, ::acosh(x.v), r, -x.v * r * r * r); }
+HD Jet2 atanh(const Jet2& x) { const double r = 1.0 / (1.0 - x.v * x.v); return chain(x, ::atanh(x.v), r, 2.0 * x.v * r * r); }
+// f = atan2(y, x):  f' = n / r with n = x y' - y x', r = x^2 + y^2;  f'' = (n' r - n r') / r^2, n' = x y'' - y x'', r' = 2 (x x' + y y')
+HD Jet2 atan2(const Jet2& y, const Jet2& x) {
+  const double r = x.v * x.v + y.v * y.v, ir = 1.0 / r, n = x.v * y.a - y.v * x.a;
+  const double n1 = x.v * y.b - y.v * x.b, r1 = 2.0 * (x.v * x.a + y.v * y.a);
+  return Jet2(::atan2(y.v, x.v), n * ir, (n1 * r - n * r1) * ir * ir);
+}
+HD Jet2 atan2(const Jet2& y, double x) { return atan2(y, Jet2(x)); }
+HD Jet2 atan2(double y, const Jet2& x) { return atan2(Jet2(y), x); }
 
 // value part of any of the scalar types (decisions inside generic code: pivoting, convergence tests)
 HD double valof(double v) { return v; }
@@ -189,6 +239,16 @@ HD double exp(double x) { return ::exp(x); }
 HD double log(double x) { return ::log(x); }
 HD double sqrt(double x) { return ::sqrt(x); }
 HD double sq(double x) { return x * x; }
+HD double log10(double x) { return ::log10(x); }
+HD double fabs(double x) { return ::fabs(x); }
+HD double sign(double x) { return sgn_of(x); }
+HD double asin(double x) { return ::asin(x); }
+HD double acos(double x) { return ::acos(x); }
+HD double atan(double x) { return ::atan(x); }
+HD double asinh(double x) { return ::asinh(x); }
+HD double acosh(double x) { return ::acosh(x); }
+HD double atanh(double x) { return ::atanh(x); }
+HD double atan2(double y, double x) { return ::atan2(y, x); }
 HD double value(double x) { return x; }
 template <int N> HD double value(const Dual<N>& x) { return x.v; }
 HD double value(const Jet2& x) { return x.v; }

@@ -176,10 +176,12 @@ template <class PB> struct pb_fused<PB, void_tt<decltype(PB::FUSED)>> { static c
 
 // LDS / workspace footprint as plain functions of the dimensions (the host sizes run-time compiled problems with them)
 __host__ __device__ constexpr size_t ocp_iter_doubles(int NX, int NU, int NC, int N) {
+  // 11 slot vectors (Z Zt D zL zU dzL dzU grad sig lbA ubA), rbN; 4 defect-sized vectors (lam lamn c ct) + c0; the padded stage
+  // blocks AB [N][NX][NZ+1] (column NZ: -c), W [N][NZ][NZ+1] (column NZ: right-hand side), Qd; the merged recursion outputs
+  // P|p [N+1][NX][NX+1], K|kff [N][NU][NX+1], Acl|bcl [N][NX][NX+1]; inequality rows
   const size_t NZ = NX + NU, NDIR = NZ * (NZ + 1) / 2, S = (size_t)(N + 1) * NZ;
-  return 12 * S + 4 * (size_t)N * NX + (size_t)N * NX * NZ + (size_t)N * NZ * NZ + (size_t)(N + 1) * NDIR +
-         (size_t)(N + 1) * NX * NX + (size_t)(N + 1) * NX + (size_t)N * NU * NX + (size_t)N * NU + (size_t)N * NX * NX +
-         (size_t)N * NX + (size_t)N * NX + (size_t)N * NC * (14 + NZ);
+  return 11 * S + NX + 5 * (size_t)N * NX + (size_t)N * NX * (NZ + 1) + (size_t)N * NZ * (NZ + 1) + (size_t)(N + 1) * NDIR +
+         (size_t)(N + 1) * NX * (NX + 1) + (size_t)N * NU * (NX + 1) + (size_t)N * NX * (NX + 1) + (size_t)N * NC * (14 + NZ);
 }
 __host__ __device__ constexpr size_t ocp_fixed_doubles(int NX, int NU, int NCONST, int NPAR, int NSD, int NEXT, int N) {
   const size_t NZ = NX + NU;
@@ -241,6 +243,7 @@ struct Ocp {
   // right-hand-side column fit the 16 columns of v_mfma_f64_16x16x4)
   static constexpr bool MFMA_STAGE = OCP_TPB == 64 && NZ + 1 <= 16 && NX <= 16;
   static constexpr int NCONST = (int)((__builtin_offsetof(OcpConst, cost) + sizeof(double) * PB::NCOST + 7) / 8);
+  static constexpr int ABP = NZ + 1, WP = NZ + 1, PP = NX + 1;   // row pitches of the padded blocks (see Lds)
 
   // Storage of the iterate: LDS (default) or, for problems that do not fit (long horizons, wide stages), a per-instance
   // workspace in global memory (PB::BIG; L2-resident, same code path, longer latencies).  Problem constants, the pivot
@@ -250,7 +253,9 @@ struct Ocp {
   using cdp = cond_t<BIG, const double*, lds_cdouble*>;
   struct Lds {
     const __attribute__((address_space(3))) OcpConst* pc;
-    dp Z, Zt, D, zL, zU, dzL, dzU, grad, lam, lamn, c, ct, AB, W, Qd, P, pv, Kg, kff, sig, rb, Acl, bcl;
+    // AB: [N][NX][ABP] = [A B | -c];  W: [N][NZ][WP] = [Hessian block (+ Sigma on the diagonal after prep_barrier) | rhs];
+    // P: [N+1][NX][PP] = [P_k | p_k];  Kg: [N][NU][PP] = [K_k | kff_k];  Acl: [N][NX][PP] = [A + B K | B kff - c];  rbN: rhs of x_N
+    dp Z, Zt, D, zL, zU, dzL, dzU, grad, lam, lamn, c, ct, AB, W, Qd, P, Kg, sig, rbN, Acl;
     dp lbA, ubA;  // effective box of every slot: -inf / +inf where there is no bound or the slot is not a variable
     dp cs, cst, cnu, cnun, cvL, cvU, cdvL, cdvU, cds, cd, csig, crb, Jd;  // [N][NC] (Jd: [N][NC][NZ])
     dp c0, cd0, cdt;  // second-order correction: saved defects / row values, row values at the trial point
@@ -285,10 +290,10 @@ struct Ocp {
     l.Z = big(S); l.Zt = big(S); l.D = big(S); l.zL = big(S); l.zU = big(S); l.dzL = big(S); l.dzU = big(S);
     l.grad = big(S);
     l.lam = big((size_t)N * NX); l.lamn = big((size_t)N * NX); l.c = big((size_t)N * NX); l.ct = big((size_t)N * NX);
-    l.AB = big((size_t)N * NX * NZ); l.W = big((size_t)N * NZ * NZ); l.Qd = big((size_t)(N + 1) * NDIR);
-    l.P = big((size_t)(N + 1) * NX * NX); l.pv = big((size_t)(N + 1) * NX);
-    l.Kg = big((size_t)N * NU * NX); l.kff = big((size_t)N * NU);
-    l.sig = big(S); l.rb = big(S); l.Acl = big((size_t)N * NX * NX); l.bcl = big((size_t)N * NX);
+    l.AB = big((size_t)N * NX * ABP); l.W = big((size_t)N * NZ * WP); l.Qd = big((size_t)(N + 1) * NDIR);
+    l.P = big((size_t)(N + 1) * NX * PP);
+    l.Kg = big((size_t)N * NU * PP);
+    l.sig = big(S); l.rbN = big(NX); l.Acl = big((size_t)N * NX * PP);
     l.lbA = big(S); l.ubA = big(S);
     const size_t R = (size_t)N * NC;
     l.cs = big(R); l.cst = big(R); l.cnu = big(R); l.cnun = big(R); l.cvL = big(R); l.cvU = big(R);
@@ -428,8 +433,9 @@ struct Ocp {
     return FTheta{uni(r.f), uni(r.theta)};
   }
 
-  // -mu * sum log(slacks)
-  __device__ static double eval_barrier(const Lds l, cdp Zp, double mu, cdp sp = nullptr) {
+  // -sum log(slacks) of a point (the barrier function is mu times this; the sum itself does not depend on mu, so the value of
+  // an accepted trial point is carried into the next iteration instead of being recomputed)
+  __device__ static double barrier_logs(const Lds l, cdp Zp, cdp sp = nullptr) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double part = 0.0;
@@ -446,7 +452,32 @@ struct Ocp {
         if (pc.dub[m] < INFINITY) part -= log(pc.dub[m] - sp[e]);
       }
     }
-    return uni(mu * block_reduce<OpSum>(part, l.red));
+    return uni(block_reduce<OpSum>(part, l.red));
+  }
+  // trial point Zt = Z + alpha D (and the slack rows), formed in the same pass as its -sum log(slacks)
+  __device__ static double form_trial(const Lds l, double alpha) {
+    const OcpConst& pc = *(const OcpConst*)l.pc;
+    const int N = pc.N;
+    double part = 0.0;
+    OCP_FOR(e, (N + 1) * NZ) {
+      const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e] + alpha * l.D[e];
+      l.Zt[e] = z;
+      if (lb > -INFINITY) part -= log(z - lb);
+      if (ub < INFINITY) part -= log(ub - z);
+    }
+    if constexpr (NC > 0) {
+      OCP_FOR(e, N * NC) {
+        const int m = e % NC;
+        const double sv = l.cs[e] + alpha * l.cds[e];
+        l.cst[e] = sv;
+        if (!row_on(pc, e / NC, m)) continue;
+        if (pc.dlb[m] > -INFINITY) part -= log(sv - pc.dlb[m]);
+        if (pc.dub[m] < INFINITY) part -= log(pc.dub[m] - sv);
+      }
+    }
+    const double r = uni(block_reduce<OpSum>(part, l.red));
+    __syncthreads();
+    return r;
   }
 
   // ---- full derivative evaluation at Z: c, AB, grad, per-stage cost values, Lagrangian Hessian blocks --------
@@ -483,7 +514,7 @@ struct Ocp {
           if (d < NZ) {
             l.grad[d] = 0.0;
 #pragma unroll
-            for (int m = 0; m < NX; ++m) l.AB[m * NZ + d] = 0.0;
+            for (int m = 0; m < NX; ++m) l.AB[m * ABP + d] = 0.0;
             if constexpr (NC > 0) {
 #pragma unroll
               for (int m = 0; m < NC; ++m) l.Jd[m * NZ + d] = 0.0;
@@ -526,7 +557,7 @@ struct Ocp {
           }
           if (d < NZ && !dead) {
 #pragma unroll
-            for (int m = 0; m < NX; ++m) l.AB[(k * NX + m) * NZ + d] = xn[m].a;
+            for (int m = 0; m < NX; ++m) l.AB[(k * NX + m) * ABP + d] = xn[m].a;
           }
         }
         if constexpr (!PB::QUAD_COST) {
@@ -576,7 +607,7 @@ struct Ocp {
       }
       if constexpr (PB::QUAD_COST) h += PB::cost_hess(pc, k, i, j);
       if (k == 0 && (((pinm >> i) | (pinm >> j)) & 1u)) h = 0.0;
-      l.W[e] = h;
+      l.W[(k * NZ + i) * WP + j] = h;
     }
     if constexpr (PB::QUAD_COST) {
       OCP_FOR(e, N * NZ) {
@@ -750,7 +781,7 @@ struct Ocp {
       }
       DTICK(1)
       // tangent columns and the second-order adjoint, stage by stage
-      dp scr = l.W + (size_t)k * NZ * NZ;           // [NX][NZ] tangent block dX_i of the interval (exchange between its lanes)
+      dp scr = l.W + (size_t)k * NZ * WP;            // [NX][NZ] tangent block dX_i of the interval (exchange between its lanes)
       double dXc[NX][CPL], dX2[NX][CPL], dPhi[NX][CPL], G[NZ][CPL];
 #pragma unroll
       for (int s = 0; s < NX; ++s)
@@ -840,15 +871,15 @@ struct Ocp {
 #pragma unroll
             for (int r = 1; r < NZ; ++r) sc = col == r ? sz[r] : sc;
 #pragma unroll
-            for (int m = 0; m < NX; ++m) l.AB[(k * NX + m) * NZ + col] = pin_c ? 0.0 : dPhi[m][c] * sc * isz[m];
+            for (int m = 0; m < NX; ++m) l.AB[(k * NX + m) * ABP + col] = pin_c ? 0.0 : dPhi[m][c] * sc * isz[m];
             // the interval's block of W: entries (r, col) and (col, r) for r >= col from ONE value (exact symmetry)
 #pragma unroll
             for (int r = 0; r < NZ; ++r) {
               if (r >= col) {
                 const bool pin = pin_c || (k == 0 && ((pinm >> r) & 1u));
                 const double hv = pin ? 0.0 : ch[r][c] - sz[r] * sc * G[r][c];
-                l.W[(size_t)k * NZ * NZ + r * NZ + col] = hv;
-                l.W[(size_t)k * NZ * NZ + col * NZ + r] = hv;
+                l.W[((size_t)k * NZ + r) * WP + col] = hv;
+                l.W[((size_t)k * NZ + col) * WP + r] = hv;
               }
             }
           }
@@ -1063,7 +1094,7 @@ struct Ocp {
         }
       }
       // tangent columns (state directions only) and the second-order adjoint, stage by stage
-      dp scr = l.W + (size_t)k * NZ * NZ;           // [NX][NX] tangent block of the interval
+      dp scr = l.W + (size_t)k * NZ * WP;            // [NX][NX] tangent block of the interval
       double dXc[NX][CPL], dX2[NX][CPL], dPhi[NX][CPL], G[NX][CPL];
 #pragma unroll
       for (int s2 = 0; s2 < NX; ++s2)
@@ -1143,20 +1174,20 @@ struct Ocp {
           l.grad[k * NZ + NX + col] = gw[c];
 #pragma unroll
           for (int m = 0; m < NX; ++m) {
-            l.AB[(k * NX + m) * NZ + col] = dPhi[m][c] * scol * isz[m];       // A = d(Phi / s_x) / d x_s
-            l.AB[(k * NX + m) * NZ + NX + col] = m == col ? 1.0 : 0.0;        // B = I (additive noise)
+            l.AB[(k * NX + m) * ABP + col] = dPhi[m][c] * scol * isz[m];       // A = d(Phi / s_x) / d x_s
+            l.AB[(k * NX + m) * ABP + NX + col] = m == col ? 1.0 : 0.0;        // B = I (additive noise)
           }
 #pragma unroll
           for (int r = 0; r < NX; ++r) {
             if (r >= col) {   // one value for (r, col) and (col, r): exact symmetry
               const double hxx = chx[r][c] - sz[r] * scol * G[r][c], hww = chw[r][c];
-              l.W[(size_t)k * NZ * NZ + r * NZ + col] = hxx;
-              l.W[(size_t)k * NZ * NZ + col * NZ + r] = hxx;
-              l.W[(size_t)k * NZ * NZ + (NX + r) * NZ + NX + col] = hww;
-              l.W[(size_t)k * NZ * NZ + (NX + col) * NZ + NX + r] = hww;
+              l.W[((size_t)k * NZ + r) * WP + col] = hxx;
+              l.W[((size_t)k * NZ + col) * WP + r] = hxx;
+              l.W[((size_t)k * NZ + NX + r) * WP + NX + col] = hww;
+              l.W[((size_t)k * NZ + NX + col) * WP + NX + r] = hww;
             }
-            l.W[(size_t)k * NZ * NZ + (NX + r) * NZ + col] = 0.0;             // state / noise cross block
-            l.W[(size_t)k * NZ * NZ + col * NZ + NX + r] = 0.0;
+            l.W[((size_t)k * NZ + NX + r) * WP + col] = 0.0;             // state / noise cross block
+            l.W[((size_t)k * NZ + col) * WP + NX + r] = 0.0;
           }
         }
       }
@@ -1186,7 +1217,7 @@ struct Ocp {
     if (i < NX && k >= 1) r += l.lam[(k - 1) * NX + i];
     if (k < N) {
 #pragma unroll
-      for (int m = 0; m < NX; ++m) r -= l.AB[(k * NX + m) * NZ + i] * l.lam[k * NX + m];
+      for (int m = 0; m < NX; ++m) r -= l.AB[(k * NX + m) * ABP + i] * l.lam[k * NX + m];
       if constexpr (NC > 0) {
 #pragma unroll
         for (int m = 0; m < NC; ++m) r += l.Jd[(k * NC + m) * NZ + i] * l.cnu[k * NC + m];  // inactive rows hold zeros
@@ -1198,10 +1229,10 @@ struct Ocp {
   // scaled optimality error pieces (W&B eq. 5)
   // also returns the complementarity errors for barrier parameters 0 and mu (same pass over the slots)
   __device__ __forceinline__ static void opt_error(const Lds l, double mu, double& dual_s, double& prim, double& s_c, double& compl0,
-                                   double& compl_mu) {
+                                   double& compl_mu, double& theta) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
-    double dmax = 0.0, lsum = 0.0, zsum = 0.0, pmax = 0.0, nb = 0.0, c0 = 0.0, cm = 0.0;
+    double dmax = 0.0, lsum = 0.0, zsum = 0.0, pmax = 0.0, nb = 0.0, c0 = 0.0, cm = 0.0, th = 0.0;
     OCP_FOR(e, (N + 1) * NZ) {
       const int k = e / NZ, i = e - k * NZ;
       if (!is_free(pc, k, i)) continue;
@@ -1222,7 +1253,9 @@ struct Ocp {
       }
     }
     OCP_FOR(e, N * NX) {
-      pmax = nmax(pmax, fabs(l.c[e]));
+      const double ca = fabs(l.c[e]);
+      pmax = nmax(pmax, ca);
+      th += ca;
       lsum += fabs(l.lam[e]);
     }
     double ncon = 0.0;
@@ -1232,6 +1265,7 @@ struct Ocp {
         if (!row_on(pc, e / NC, m)) continue;
         dmax = nmax(dmax, fabs(-l.cnu[e] - l.cvL[e] + l.cvU[e]));
         pmax = nmax(pmax, fabs(l.cd[e] - l.cs[e]));
+        th += fabs(l.cd[e] - l.cs[e]);
         lsum += fabs(l.cnu[e]);
         zsum += fabs(l.cvL[e]) + fabs(l.cvU[e]);
         if (pc.dlb[m] > -INFINITY) {
@@ -1249,6 +1283,7 @@ struct Ocp {
       }
       ncon = (double)N * pc.nc + pc.nc_term;
     }
+    theta = block_reduce<OpSum>(th, l.red);
     compl0 = block_reduce<OpMax>(c0, l.red);
     compl_mu = block_reduce<OpMax>(cm, l.red);
     dmax = block_reduce<OpMax>(dmax, l.red);
@@ -1284,6 +1319,18 @@ struct Ocp {
 
   // ---- barrier terms of every slot, once per iteration (keeps the divisions out of the sequential recursion):
   //   sig[e] = zL/(z - lb) + zU/(ub - z),   rb[e] = grad[e] - mu/(z - lb) + mu/(ub - z)
+  // and the stage matrices the recursion reads are completed in place: sig is ADDED to the diagonal of the stage's Hessian
+  // block, rb goes to its right-hand-side column (slot e = (k, i): W[k][i][i] += sig, W[k][i][NZ] = rb; stage N: sig[], rbN[]).
+  // Called once per evaluation of the derivatives (which rewrite the blocks); repeated factorisations reuse the result.
+  __device__ static void stage_rhs(const Lds l, int N, int e, double sg, double r, bool replace) {
+    const int k = e / NZ, i = e - k * NZ;
+    l.sig[e] = sg;
+    if (k < N) {
+      dp w = l.W + (size_t)(k * NZ + i) * WP;
+      w[i] = replace ? sg : w[i] + sg;
+      w[NZ] = r;
+    } else if (i < NX) l.rbN[i] = r;
+  }
   __device__ static void prep_barrier(const Lds l, double mu) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
@@ -1291,17 +1338,16 @@ struct Ocp {
       const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
       double sg = 0.0, r = l.grad[e];
       if (lb > -INFINITY) {
-        const double is = 1.0 / (z - lb);
+        const double is = rcp_fast(z - lb);
         sg += zl * is;
         r -= mu * is;
       }
       if (ub < INFINITY) {
-        const double is = 1.0 / (ub - z);
+        const double is = rcp_fast(ub - z);
         sg += zu * is;
         r += mu * is;
       }
-      l.sig[e] = sg;
-      l.rb[e] = r;
+      stage_rhs(l, N, e, sg, r, false);
     }
     if constexpr (NC > 0) {  // slack rows: csig = vL/(s - dL) + vU/(dU - s), crb = -mu/(s - dL) + mu/(dU - s)
       OCP_FOR(e, N * NC) {
@@ -1309,12 +1355,12 @@ struct Ocp {
         double sg = 0.0, r = 0.0;
         if (row_on(pc, e / NC, m)) {
           if (pc.dlb[m] > -INFINITY) {
-            const double is = 1.0 / (l.cs[e] - pc.dlb[m]);
+            const double is = rcp_fast(l.cs[e] - pc.dlb[m]);
             sg += l.cvL[e] * is;
             r -= mu * is;
           }
           if (pc.dub[m] < INFINITY) {
-            const double is = 1.0 / (pc.dub[m] - l.cs[e]);
+            const double is = rcp_fast(pc.dub[m] - l.cs[e]);
             sg += l.cvU[e] * is;
             r += mu * is;
           }
@@ -1393,61 +1439,7 @@ struct Ocp {
 
   // ---- backward recursion with the cost-to-go in registers (MFMA_STAGE policies with inputs, no held inputs) ----------------
   // The accumulator layout of v_mfma_f64_16x16x4 puts entry (row g + 4 r, column q) of the stage matrix
-  //     M = [A B]^T P_{k+1} [A B] + [H_k | r_k]          (column NZ = right-hand side)
-  // into register r of lane 16 g + q.  The same lane then computes entry (g + 4 r, q) of P_k (q < NX) or of p_k (q = NZ):
-  //     P_k[i][j] = sym(M_xx)[i][j] - w_i . w_j,   w_j = L^-1 M_ux[:, j],   R_k = M_uu = L L^T     (p_k: column NZ)
-  // - with the columns of M_ux fetched from the lanes that hold them (ds_bpermute: the LDS crossbar without a store / barrier /
-  // load round trip) - and that register IS the A operand P_k[q][4 kb + g] of the next stage's first product (P symmetric, and
-  // kept bitwise symmetric: both lanes of a pair run the same arithmetic on swapped factors).  So the recursion never waits
-  // for LDS: feedback, closed-loop matrices, P_k and p_k are stored for the forward sweep on the side.
-  // operands of stage k that do not depend on the recursion (fetched one stage ahead of their use)
-  struct StageOps {
-    double b1[(NX + 3) / 4], a2[(NX + 3) / 4], ai_q[(NX + 3) / 4], ci[(NX + 3) / 4], bi[(NX + 3) / 4][NU > 0 ? NU : 1];
-    v4d M0;
-  };
-  __device__ __forceinline__ static void stage_ops(const Lds l, int k, double delta, bool resto, int q, int g, StageOps& o) {
-    constexpr int KB = (NX + 3) / 4, RB = (NZ + 3) / 4;
-    const int qz = q < NZ ? q : NZ - 1;
-    cdp AB = l.AB + k * NX * NZ;
-    o.M0 = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const int kk = 4 * kb + g;
-      const bool kv = kk < NX;
-      const int kc = kv ? kk : NX - 1;
-      const double ab = AB[kc * NZ + qz], cn = l.c[k * NX + kc];
-      o.b1[kb] = kv ? (q < NZ ? ab : (q == NZ ? -cn : 0.0)) : 0.0;
-      o.a2[kb] = (kv && q < NZ) ? ab : 0.0;
-      o.ai_q[kb] = ab;        // A[i][q] for i = 4 kb + g, q < NX (closed-loop coefficient)
-      o.ci[kb] = cn;
-#pragma unroll
-      for (int a = 0; a < NU; ++a) o.bi[kb][a] = AB[kc * NZ + NX + a];
-    }
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int i = g + 4 * r;
-      const bool iv = i < NZ, rhs = q == NZ;
-      const int ic = iv ? i : NZ - 1, jj = q < NZ ? q : 0;
-      const double rbv = l.rb[k * NZ + ic], wv = l.W[k * NZ * NZ + ic * NZ + jj], sg = l.sig[k * NZ + ic];
-      double h = rhs ? rbv : (resto ? 0.0 : wv);
-      if (ic == q) h += (resto ? 1.0 : delta) + sg;
-      if constexpr (NC > 0) {  // eliminated slack rows: + Jd^T (Sigma_s + delta) Jd, rhs + Jd^T ((Sigma_s + delta)(d - s) + crb)
-#pragma unroll
-        for (int m = 0; m < NC; ++m) {
-          const int rr = k * NC + m;
-          const double wgt = (resto ? 1.0 : delta) + l.csig[rr];
-          const double ds = l.cd[rr] - l.cs[rr], cr = l.crb[rr], jr = l.Jd[rr * NZ + jj];
-          const double right = rhs ? wgt * ds + cr : wgt * jr;
-          h += l.Jd[rr * NZ + ic] * right;
-        }
-      }
-      o.M0[r] = (iv && q <= NZ) ? h : 0.0;
-    }
-  }
-
-  // ---- backward recursion with the cost-to-go in registers (MFMA_STAGE policies with inputs, no held inputs) ----------------
-  // The accumulator layout of v_mfma_f64_16x16x4 puts entry (row g + 4 r, column q) of the stage matrix
-  //     M = [A B]^T P_{k+1} [A B] + [H_k | r_k]          (column NZ = right-hand side)
+  //     M = [A B | -c]^T (P_{k+1} [A B | -c] + [0 | p_{k+1}]) + [H_k | r_k]          (column NZ = right-hand side)
   // into register r of lane 16 g + q.  The same lane then computes entry (g + 4 r, q) of P_k (q < NX) or of p_k (q = NZ):
   //     P_k[i][j] = sym(M_xx)[i][j] - w_i . w_j,   w_j = L^-1 M_ux[:, j],   R_k = M_uu = L L^T     (p_k: column NZ)
   // - with the columns of M_ux fetched from the lanes that hold them (ds_bpermute: the LDS crossbar without a store / barrier /
@@ -1456,33 +1448,80 @@ struct Ocp {
   // for LDS: feedback, closed-loop matrices, P_k and p_k are stored for the forward sweep on the side, the operands of the
   // next stage are fetched while the pivot block of this one is factored (one basic block per stage: the positivity of the
   // pivots is collected and tested after the loop).
-  __device__ __forceinline__ static bool backward_reg(const Lds l, const OcpConst& pc, int N, double delta, bool resto) {
+  // Round 3: the stage blocks sit in LDS in the PADDED form the products read - [A B | -c] with pitch NZ + 1, [H + Sigma | r]
+  // with pitch NZ + 1 (stage_rhs) - so a lane fetches each operand with ONE unconditional load at a clamped column
+  // (columns beyond NZ and rows beyond NZ of M are duplicates that nothing reads; the same register is the B operand of the
+  // first product, the A operand of the second and the open-loop coefficient of the closed-loop update), and every output of
+  // a stage ([P | p], [K | kff], [Acl | bcl], pitch NX + 1) leaves through one predicated store.
+  static constexpr int KB_ = (NX + 3) / 4, RB_ = (NZ + 3) / 4;
+  struct StageOps {
+    double b1[KB_], bi[KB_][NU > 0 ? NU : 1];
+    v4d M0;
+  };
+  __device__ __forceinline__ static void stage_ops(const Lds l, int k, double delta, int q, int g, StageOps& o) {
+    const int qc = q < NZ ? q : NZ;
+    cdp AB = l.AB + (size_t)k * NX * ABP;
+    cdp Wk = l.W + (size_t)k * NZ * WP;
+#pragma unroll
+    for (int kb = 0; kb < KB_; ++kb) {
+      const int kk = 4 * kb + g;
+      const int kc = (NX % 4 == 0 || kk < NX) ? kk : NX - 1;
+      const double ab = AB[kc * ABP + qc];
+      o.b1[kb] = (NX % 4 == 0 || kk < NX) ? ab : 0.0;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) o.bi[kb][a] = AB[kc * ABP + NX + a];
+    }
+    o.M0 = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < RB_; ++r) {
+      const int i = g + 4 * r;
+      const int ic = (NZ % 4 == 0 || i < NZ) ? i : NZ - 1;
+      double h = Wk[ic * WP + qc];
+      if (ic == q) h += delta;
+      if constexpr (NC > 0) {  // eliminated slack rows: + Jd^T (Sigma_s + delta) Jd, rhs + Jd^T ((Sigma_s + delta)(d - s) + crb)
+        const bool rhs = q >= NZ;
+        const int jj = q < NZ ? q : 0;
+#pragma unroll
+        for (int m = 0; m < NC; ++m) {
+          const int rr = k * NC + m;
+          const double wgt = delta + l.csig[rr];
+          const double ds = l.cd[rr] - l.cs[rr], cr = l.crb[rr], jr = l.Jd[rr * NZ + jj];
+          const double right = rhs ? wgt * ds + cr : wgt * jr;
+          h += l.Jd[rr * NZ + ic] * right;
+        }
+      }
+      o.M0[r] = h;
+    }
+  }
+
+  __device__ __forceinline__ static bool backward_reg(const Lds l, int N, double delta) {
     const int t = threadIdx.x, q = t & 15, g = t >> 4;
-    constexpr int KB = (NX + 3) / 4;
+    constexpr int KB = KB_;
     const int qx = q < NX ? q : NX - 1;
-    const bool colP = q < NX, colR = q == NZ;
+    const bool colP = q < NX, colR = q == NZ, use = colP || colR;
+    const int qk = colR ? NX : qx;                 // this lane's column in the [. | rhs] outputs of pitch PP
     double Pr[KB], pr[KB];
 #pragma unroll
     for (int r = 0; r < KB; ++r) {
       const int row = g + 4 * r, rc = row < NX ? row : NX - 1;
-      const double pe = l.P[N * NX * NX + rc * NX + qx], pv_ = l.pv[N * NX + rc];
-      Pr[r] = (row < NX && colP) ? pe : 0.0;
-      pr[r] = (row < NX && colR) ? pv_ : 0.0;
+      const double v = l.P[((size_t)N * NX + rc) * PP + qk];
+      Pr[r] = (row < NX && colP) ? v : 0.0;
+      pr[r] = (row < NX && colR) ? v : 0.0;
     }
     StageOps o;
-    stage_ops(l, N - 1, delta, resto, q, g, o);
+    stage_ops(l, N - 1, delta, q, g, o);
     bool pd = true;
     for (int k = N - 1; k >= 0; --k) {
-      // T = P_{k+1} [A B | -c] + [0 | p_{k+1}];  M = [A B]^T T + [H_k | r_k]
+      // T = P_{k+1} [A B | -c] + [0 | p_{k+1}];  M = [A B | -c]^T T + [H_k | r_k]
       v4d Tacc = {0.0, 0.0, 0.0, 0.0}, Macc = o.M0;
 #pragma unroll
       for (int r = 0; r < KB; ++r) Tacc[r] = pr[r];
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) Tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pr[kb], o.b1[kb], Tacc, 0, 0, 0);
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) Macc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a2[kb], Tacc[kb], Macc, 0, 0, 0);
+      for (int kb = 0; kb < KB; ++kb) Macc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.b1[kb], Tacc[kb], Macc, 0, 0, 0);
       const StageOps c = o;                           // this stage's closed-loop operands
-      stage_ops(l, k > 0 ? k - 1 : 0, delta, resto, q, g, o);   // next stage's operands: in flight during the factorisation
+      stage_ops(l, k > 0 ? k - 1 : 0, delta, q, g, o);   // next stage's operands: in flight during the factorisation
       // cross-lane fetches of the M_ux columns and the mirrored M_xx entries, all issued before they are needed
       double wq[NU], yq[NU], wi[KB][NU], mji[KB];
 #pragma unroll
@@ -1496,7 +1535,7 @@ struct Ocp {
 #pragma unroll
         for (int rr = 0; rr < KB; ++rr) {
           const double v = __shfl(Macc[rr], 16 * (qx % 4) + ic);
-          mji[r] = (qx / 4 == rr) ? v : mji[r];
+          mji[r] = (KB == 1 || qx / 4 == rr) ? v : mji[r];
         }
       }
       // reduced pivot block R_k = M_uu out of the accumulators, factored redundantly per lane
@@ -1524,17 +1563,14 @@ struct Ocp {
         for (int c2 = a + 1; c2 < NU; ++c2) sv -= Lc[c2 * NU + a] * yq[c2];
         yq[a] = sv * invd[a];
       }
-      if (g == 0 && (colP || colR)) {   // feedback K[:, q] = -y_q, feed-forward kff = -y_NZ
+      if (g == 0 && use) {   // feedback K[:, q] = -y_q, feed-forward kff = -y_NZ
 #pragma unroll
-        for (int a = 0; a < NU; ++a) {
-          dp kd = colR ? l.kff + k * NU + a : l.Kg + (k * NU + a) * NX + qx;
-          *kd = -yq[a];
-        }
+        for (int a = 0; a < NU; ++a) l.Kg[((size_t)k * NU + a) * PP + qk] = -yq[a];
       }
 #pragma unroll
       for (int r = 0; r < KB; ++r) {
         const int i = g + 4 * r, ic = i < NX ? i : NX - 1;
-        const bool valid = i < NX;
+        const bool valid = NX % 4 == 0 || i < NX;
 #pragma unroll
         for (int a = 0; a < NU; ++a) {
           double sv = wi[r][a];
@@ -1545,41 +1581,44 @@ struct Ocp {
         double sv = colR ? Macc[r] : 0.5 * (Macc[r] + mji[r]);
 #pragma unroll
         for (int a = 0; a < NU; ++a) sv -= wi[r][a] * wq[a];
-        double cl = colR ? -c.ci[r] : c.ai_q[r];
+        double cl = c.b1[r];                          // A[i][q] (q < NX) or -c[i] (q = NZ)
 #pragma unroll
         for (int a = 0; a < NU; ++a) cl -= c.bi[r][a] * yq[a];
         Pr[r] = (valid && colP) ? sv : 0.0;
         pr[r] = (valid && colR) ? sv : 0.0;
-        if (valid && colP) {
-          l.P[k * NX * NX + ic * NX + qx] = sv;
-          l.Acl[k * NX * NX + ic * NX + qx] = cl;
-        }
-        if (valid && colR) {
-          l.pv[k * NX + ic] = sv;
-          l.bcl[k * NX + ic] = cl;
+        if (valid && use) {
+          l.P[((size_t)k * NX + ic) * PP + qk] = sv;
+          l.Acl[((size_t)k * NX + ic) * PP + qk] = cl;
         }
       }
     }
     return uni(pd);
   }
 
+  // broadcast of lane j's value inside every quad of lanes (DPP quad_perm [j, j, j, j]): the forward sweep's state exchange
+  template <int J>
+  __device__ __forceinline__ static double quad_bcast(double v) { return dpp_mov<J * 0x55>(v); }
+
   // ---- Riccati factor + solve of the Newton system; false when a reduced pivot is not positive ---------------
   // Per stage: (1) M = H_k + [A B]^T P_{k+1} [A B] and its right-hand side on the f64 matrix cores, the reduced pivot
-  // block broadcast from the accumulators and factored (redundantly per lane) while M goes through LDS; (2) feedback K,
-  // feed-forward kff, P_k, p_k and the closed-loop coefficients.  The forward sweep keeps dx in registers (v_readlane
-  // broadcasts, no LDS round trip).
-  // `resto`: feasibility-restoration step (H = I, zero gradient: least-norm d with J d = -c)
+  // block broadcast from the accumulators and factored (redundantly per lane); (2) feedback K, feed-forward kff, P_k, p_k and
+  // the closed-loop coefficients.  The forward sweep keeps dx in registers (DPP / v_readlane broadcasts, no LDS round trip).
+  // The stage matrices [H_k + Sigma | r_k] were completed by prep_barrier (stage_rhs); `delta` is added to their diagonal here.
+  // `resto`: feasibility-restoration step (the caller has replaced the blocks by the barrier diagonal and passes delta = 1: H = I,
+  // least-norm d with J d = -c); here it only switches off the terminal cost's Hessian and the new row multipliers
   __device__ OCP_PHASE static bool riccati(lds_double* lbase, double* ws, double mu, double delta, bool resto = false) {
     lbase = uni(lbase); ws = uni(ws); mu = uni(mu); delta = uni(delta); resto = uni(resto);
     const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N, t = threadIdx.x;
     (void)mu;
-    // terminal: P_N = hess V + Sigma + delta, p_N = grad V + barrier rhs
-    OCP_FOR(e, NX * NX + NX) {
-      if (e < NX * NX) {
-        const int i = e / NX, j = e - i * NX;
-        double v = 0.0;
+    // terminal: P_N = hess V + Sigma + delta, p_N = grad V + barrier rhs; the column -c of the padded [A B | -c] (the defects
+    // change between factorisations of one iteration: second-order correction)
+    OCP_FOR(e, NX * PP) {
+      const int i = e / PP, j = e - i * PP;
+      double v;
+      if (j < NX) {
+        v = 0.0;
         if (!resto) {
           cdp Q = l.Qd + N * NDIR;
           if (i == j) v = Q[i];
@@ -1588,24 +1627,22 @@ struct Ocp {
             v = 0.5 * (Q[dir_of(a, b, NX)] - Q[a] - Q[b]);
           }
         }
-        if (i == j) v += (resto ? 1.0 : delta) + l.sig[N * NZ + i];
-        l.P[N * NX * NX + e] = v;
-      } else {
-        const int i = e - NX * NX;
-        l.pv[N * NX + i] = l.rb[N * NZ + i];
-      }
+        if (i == j) v += delta + l.sig[N * NZ + i];
+      } else v = l.rbN[i];
+      l.P[((size_t)N * NX) * PP + e] = v;
     }
+    OCP_FOR(e, N * NX) l.AB[(size_t)e * ABP + NZ] = -l.c[e];
     __syncthreads();
 #ifndef HILO_RICCATI_LDS
     if constexpr (MFMA_STAGE && NU > 0 && NH == 0) {
-      if (!backward_reg(l, pc, N, delta, resto)) return false;
+      if (!backward_reg(l, N, delta)) return false;
       __syncthreads();
     } else
 #endif
     for (int k = N - 1; k >= 0; --k) {
-      cdp Pn = l.P + (k + 1) * NX * NX;
-      cdp pn = l.pv + (k + 1) * NX;
-      cdp AB = l.AB + k * NX * NZ;
+      cdp Pn = l.P + (size_t)(k + 1) * NX * PP;       // [P_{k+1} | p_{k+1}]
+      cdp AB = l.AB + (size_t)k * NX * ABP;
+      cdp Wk = l.W + (size_t)k * NZ * WP;
       double Lc[NU > 0 ? NU * NU : 1], invd[NU > 0 ? NU : 1];   // Cholesky factor of the reduced pivot block R_k
       bool pd = true, factored = false;
       // (1) Mm = H_k + [A B]^T P_{k+1} [A B];  mm = r_k + [A B]^T (p_{k+1} - P_{k+1} c_k).
@@ -1613,55 +1650,52 @@ struct Ocp {
       if constexpr (MFMA_STAGE) {
         // Two chained v_mfma_f64_16x16x4 per 4 rows of the inner dimension, ONE matrix element per lane (lane = 16 g + q):
         //   T = P_{k+1} [A B | -c] + [0 | p_{k+1}]      A-operand P[q][4kb+g], B-operand [A B | -c][4kb+g][q]
-        //   M = [A B]^T T + [H_k | r_k]                  A-operand AB[4kb+g][q], B-operand T rows 4kb+g = accumulator kb of T
+        //   M = [A B | -c]^T T + [H_k | r_k]             A-operand = the same register, B-operand T rows 4kb+g = accumulator kb of T
         // The accumulator of the f64 form holds rows g + 4r, column q in register r - exactly the B-operand layout of the
-        // second product, so T never leaves the registers.  Six distinct-address LDS reads per lane replace the 48
-        // broadcast reads of the vector-ALU form (one wave pulled 17 KB per stage through the LDS port shared by four waves).
+        // second product, so T never leaves the registers.
         const int q = t & 15, g = t >> 4;
-        constexpr int KB = (NX + 3) / 4, RB = (NZ + 3) / 4;
-        const int qx = q < NX ? q : NX - 1, qz = q < NZ ? q : NZ - 1;
+        constexpr int KB = KB_, RB = RB_;
+        const int qx = q < NX ? q : NX - 1, qc = q < NZ ? q : NZ;
         v4d Tacc = {0.0, 0.0, 0.0, 0.0}, Macc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int r = 0; r < KB; ++r) {
           const int row = g + 4 * r, rc = row < NX ? row : NX - 1;
-          const double pv_ = pn[rc];
+          const double pv_ = Pn[rc * PP + NX];
           Tacc[r] = (q == NZ && row < NX) ? pv_ : 0.0;
         }
-        double a1[KB], b1[KB], a2[KB];
+        double a1[KB], b1[KB];
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
           const int kk = 4 * kb + g;
           const bool kv = kk < NX;
           const int kc = kv ? kk : NX - 1;
-          const double pe = Pn[qx * NX + kc], ab = AB[kc * NZ + qz], cn = l.c[k * NX + kc];
+          const double pe = Pn[qx * PP + kc], ab = AB[kc * ABP + qc];
           a1[kb] = (kv && q < NX) ? pe : 0.0;
-          b1[kb] = kv ? (q < NZ ? ab : (q == NZ ? -cn : 0.0)) : 0.0;
-          a2[kb] = (kv && q < NZ) ? ab : 0.0;
+          b1[kb] = kv ? ab : 0.0;
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
           const int i = g + 4 * r;
-          const bool iv = i < NZ, rhs = q == NZ;
+          const bool iv = i < NZ, rhs = q >= NZ;
           const int ic = iv ? i : NZ - 1, jj = q < NZ ? q : 0;
-          const double rbv = l.rb[k * NZ + ic], wv = l.W[k * NZ * NZ + ic * NZ + jj], sg = l.sig[k * NZ + ic];
-          double h = rhs ? rbv : (resto ? 0.0 : wv);
-          if (ic == q) h += (resto ? 1.0 : delta) + sg;
+          double h = Wk[ic * WP + qc];
+          if (ic == q) h += delta;
           if constexpr (NC > 0) {  // eliminated slack rows: + Jd^T (Sigma_s + delta) Jd, rhs + Jd^T ((Sigma_s + delta)(d - s) + crb)
 #pragma unroll
             for (int m = 0; m < NC; ++m) {
               const int rr = k * NC + m;
-              const double wgt = (resto ? 1.0 : delta) + l.csig[rr];
+              const double wgt = delta + l.csig[rr];
               const double ds = l.cd[rr] - l.cs[rr], cr = l.crb[rr], jr = l.Jd[rr * NZ + jj];
               const double right = rhs ? wgt * ds + cr : wgt * jr;
               h += l.Jd[rr * NZ + ic] * right;
             }
           }
-          Macc[r] = (iv && q <= NZ) ? h : 0.0;
+          Macc[r] = h;
         }
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) Tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kb], b1[kb], Tacc, 0, 0, 0);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) Macc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[kb], Tacc[kb], Macc, 0, 0, 0);
+        for (int kb = 0; kb < KB; ++kb) Macc = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kb], Tacc[kb], Macc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
           const int i = g + 4 * r;
@@ -1672,8 +1706,7 @@ struct Ocp {
         }
         if constexpr (NU > 0) {
           // the pivot block R_k = M_uu straight out of the accumulators (entry (i, j) sits in register i / 4 of lane
-          // 16 (i % 4) + j): v_readlane broadcasts instead of waiting for the LDS round trip of Mm, so the factorisation
-          // overlaps the stores above and the loads of phase (2)
+          // 16 (i % 4) + j): v_readlane broadcasts instead of waiting for the LDS round trip of Mm
           double Rl[NU * NU];
 #pragma unroll
           for (int a = 0; a < NU; ++a)
@@ -1688,32 +1721,28 @@ struct Ocp {
       } else
 #endif
       {
-      // One uniform code path for the NZ x (NZ+1) entries: column NZ is the right-hand side, i.e. the "column" -c_k
+      // One uniform code path for the NZ x (NZ+1) entries: column NZ is the right-hand side, i.e. the column -c_k
       // of [A B | -c] with p_{k+1} added.  All operands are fetched before the arithmetic (one LDS wait).
-      // Branch-free: every operand is fetched unconditionally (clamped index) and chosen by a select, the result goes out
-      // through one store with a selected address - divergent if/else around the loads costs more than the spare loads.
       OCP_FOR(e, NZ * (NZ + 1)) {
         const int i = e / (NZ + 1), j = e - i * (NZ + 1);
         const bool rhs = j == NZ;
         const int jj = rhs ? 0 : j;
         double Pl[NX * NX], ai[NX], aj[NX], pl[NX];
 #pragma unroll
-        for (int q = 0; q < NX * NX; ++q) Pl[q] = Pn[q];
+        for (int q = 0; q < NX * NX; ++q) Pl[q] = Pn[(q / NX) * PP + q % NX];
 #pragma unroll
         for (int n = 0; n < NX; ++n) {
-          ai[n] = AB[n * NZ + i];
-          const double ab = AB[n * NZ + jj], cn = l.c[k * NX + n];
-          aj[n] = rhs ? -cn : ab;
-          pl[n] = pn[n];
+          ai[n] = AB[n * ABP + i];
+          aj[n] = AB[n * ABP + j];       // column NZ: -c
+          pl[n] = Pn[n * PP + NX];
         }
-        const double rbv = l.rb[k * NZ + i], wv = l.W[k * NZ * NZ + i * NZ + jj], sg = l.sig[k * NZ + i];
-        double s = rhs ? rbv : (resto ? 0.0 : wv);
-        const double dg = (i == j) ? ((resto ? 1.0 : delta) + sg) : 0.0;
+        double s = Wk[i * WP + j];       // column NZ: r_k
+        const double dg = (i == j) ? delta : 0.0;
         if constexpr (NC > 0) {  // eliminated slack rows: + Jd^T (Sigma_s + delta) Jd, rhs + Jd^T ((Sigma_s + delta)(d - s) + crb)
 #pragma unroll
           for (int m = 0; m < NC; ++m) {
             const int r = k * NC + m;
-            const double wgt = (resto ? 1.0 : delta) + l.csig[r];
+            const double wgt = delta + l.csig[r];
             const double ds = l.cd[r] - l.cs[r], cr = l.crb[r], jr = l.Jd[r * NZ + jj];
             const double right = rhs ? wgt * ds + cr : wgt * jr;
             s += l.Jd[r * NZ + i] * right;
@@ -1771,9 +1800,8 @@ struct Ocp {
           // (K[:, j] = -y_j, kff = -y_NX are this lane's solve)
           double bi[NU];
 #pragma unroll
-          for (int a = 0; a < NU; ++a) bi[a] = AB[i * NZ + NX + a];
-          const double aij = AB[i * NZ + jj], ci = l.c[k * NX + i];
-          double cl = rhs ? -ci : aij;
+          for (int a = 0; a < NU; ++a) bi[a] = AB[i * ABP + NX + a];
+          double cl = AB[i * ABP + (rhs ? NZ : jj)];
           __builtin_amdgcn_sched_barrier(0);
           small_solve<NU>(Lc, invd, y);
 #pragma unroll
@@ -1783,25 +1811,21 @@ struct Ocp {
           // pivots after ~38 stages of the chemostat.
 #pragma unroll
           for (int a = 0; a < NU; ++a) cl -= bi[a] * y[a];
-          dp cld = rhs ? l.bcl + k * NX + i : l.Acl + k * NX * NX + i * NX + jj;
-          *cld = cl;
-          if (rhs) l.pv[k * NX + i] = s;
+          l.Acl[((size_t)k * NX + i) * PP + j] = cl;
+          if (rhs) l.P[((size_t)k * NX + i) * PP + NX] = s;
           else if (i <= jj) {
-            l.P[k * NX * NX + i * NX + jj] = s;
-            l.P[k * NX * NX + jj * NX + i] = s;
+            l.P[((size_t)k * NX + i) * PP + jj] = s;
+            l.P[((size_t)k * NX + jj) * PP + i] = s;
           }
           if (i == 0) {
 #pragma unroll
-            for (int a = 0; a < NU; ++a) {
-              dp kd = rhs ? l.kff + k * NU + a : l.Kg + (k * NU + a) * NX + j;
-              *kd = -y[a];
-            }
+            for (int a = 0; a < NU; ++a) l.Kg[((size_t)k * NU + a) * PP + j] = -y[a];
           }
         }
       } else {
-        OCP_FOR(e, NX * NX + NX) {
-          if (e < NX * NX) l.P[k * NX * NX + e] = 0.5 * (l.Mm[(e / NX) * NZ + e % NX] + l.Mm[(e % NX) * NZ + e / NX]);
-          else l.pv[k * NX + e - NX * NX] = l.mm[e - NX * NX];
+        OCP_FOR(e, NX * PP) {
+          const int i = e / PP, j = e - i * PP;
+          l.P[((size_t)k * NX) * PP + e] = j < NX ? 0.5 * (l.Mm[i * NZ + j] + l.Mm[j * NZ + i]) : l.mm[i];
         }
       }
       __syncthreads();
@@ -1814,14 +1838,14 @@ struct Ocp {
       OCP_FOR(e, NX * NX) {
         const int i = e / NX, j = e - i * NX;
         const bool pin = x0_pinned(pc, i) || x0_pinned(pc, j);
-        l.Mm[e] = pin ? (i == j ? 1.0 : 0.0) : l.P[e];
+        l.Mm[e] = pin ? (i == j ? 1.0 : 0.0) : l.P[i * PP + j];
       }
       __syncthreads();
       double Lc[NX * NX], invd[NX], y[NX];
       const bool pd = small_chol<NX>(l.Mm, NX, Lc, invd);
       if (!pd) return false;
 #pragma unroll
-      for (int a = 0; a < NX; ++a) y[a] = x0_pinned(pc, a) ? 0.0 : l.pv[a];
+      for (int a = 0; a < NX; ++a) y[a] = x0_pinned(pc, a) ? 0.0 : l.P[a * PP + NX];
       small_solve<NX>(Lc, invd, y);
       __syncthreads();
       if (t == 0) {
@@ -1831,41 +1855,40 @@ struct Ocp {
     }
     // closed-loop matrices for the forward sweep: Acl = A + B K, bcl = B kff - c: written by the stage loop above when there
     // are inputs; without inputs Acl = A, bcl = -c
-    if constexpr (NU == 0) OCP_FOR(e, N * (NX * NX + NX)) {
-      const int k = e / (NX * NX + NX), r = e - k * (NX * NX + NX);
-      cdp AB = l.AB + k * NX * NZ;
-      if (r < NX * NX) {
-        const int i = r / NX, j = r - i * NX;
-        double s = AB[i * NZ + j];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) s += AB[i * NZ + NX + a] * l.Kg[(k * NU + a) * NX + j];
-        l.Acl[k * NX * NX + r] = s;
-      } else {
-        const int i = r - NX * NX;
-        double s = -l.c[k * NX + i];
-#pragma unroll
-        for (int a = 0; a < NU; ++a) s += AB[i * NZ + NX + a] * l.kff[k * NU + a];
-        l.bcl[k * NX + i] = s;
-      }
+    if constexpr (NU == 0) OCP_FOR(e, N * NX * PP) {
+      const int row = e / PP, j = e - row * PP;
+      l.Acl[e] = l.AB[(size_t)row * ABP + (j < NX ? j : NZ)];
     }
     __syncthreads();
-    // forward sweep on the first wave: lane i < NX carries dx[i] in a register, exchanged by shuffles; the
-    // coefficients of the next stage are fetched while the current one is computed
+    // forward sweep on the first wave: lane i < NX carries dx[i] in a register, exchanged by DPP quad broadcasts (NX <= 4) or
+    // v_readlane; the coefficients of the next stage are fetched while the current one is computed
     if (t < 64) {
       const int i = t < NX ? t : 0;
       double dxi = l.D[i];
       double ac[NX], bc, an[NX], bn;
 #pragma unroll
-      for (int j = 0; j < NX; ++j) ac[j] = l.Acl[i * NX + j];
-      bc = l.bcl[i];
+      for (int j = 0; j < NX; ++j) ac[j] = l.Acl[i * PP + j];
+      bc = l.Acl[i * PP + NX];
       for (int k = 0; k < N; ++k) {
         const int kn = k + 1 < N ? k + 1 : k;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) an[j] = l.Acl[kn * NX * NX + i * NX + j];
-        bn = l.bcl[kn * NX + i];
+        for (int j = 0; j < NX; ++j) an[j] = l.Acl[((size_t)kn * NX + i) * PP + j];
+        bn = l.Acl[((size_t)kn * NX + i) * PP + NX];
         double s = bc;
+        if constexpr (NX <= 4) {
+          double dj[4];
+          dj[0] = quad_bcast<0>(dxi); dj[1] = quad_bcast<1>(dxi); dj[2] = quad_bcast<2>(dxi); dj[3] = quad_bcast<3>(dxi);
+          double s2 = 0.0;   // two accumulation chains of half the length
 #pragma unroll
-        for (int j = 0; j < NX; ++j) s += ac[j] * read_lane(dxi, j);   // v_readlane: scalar broadcast, no LDS crossbar trip
+          for (int j = 0; j < NX; ++j) {
+            if (j & 1) s2 += ac[j] * dj[j];
+            else s += ac[j] * dj[j];
+          }
+          s += s2;
+        } else {
+#pragma unroll
+          for (int j = 0; j < NX; ++j) s += ac[j] * read_lane(dxi, j);   // v_readlane: scalar broadcast, no LDS crossbar trip
+        }
         dxi = s;
         if (t < NX) l.D[(k + 1) * NZ + i] = dxi;
 #pragma unroll
@@ -1879,15 +1902,17 @@ struct Ocp {
     OCP_FOR(e, N * (NU + NX)) {
       const int k = e / (NU + NX), r = e - k * (NU + NX);
       if (r < NU) {
-        double s = l.kff[k * NU + r];
+        cdp Kr = l.Kg + ((size_t)k * NU + r) * PP;
+        double s = Kr[NX];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) s += l.Kg[(k * NU + r) * NX + j] * l.D[k * NZ + j];
+        for (int j = 0; j < NX; ++j) s += Kr[j] * l.D[k * NZ + j];
         l.D[k * NZ + NX + r] = s;
       } else {
         const int i = r - NU;
-        double s = l.pv[(k + 1) * NX + i];
+        cdp Prow = l.P + ((size_t)(k + 1) * NX + i) * PP;
+        double s = Prow[NX];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) s += l.P[(k + 1) * NX * NX + i * NX + j] * l.D[(k + 1) * NZ + j];
+        for (int j = 0; j < NX; ++j) s += Prow[j] * l.D[(k + 1) * NZ + j];
         l.lamn[k * NX + i] = -s;
       }
     }
@@ -1942,13 +1967,17 @@ struct Ocp {
       if constexpr (NC > 0)
         OCP_FOR(e, N * NC) cmax = nmax(cmax, row_on(pc, e / NC, e % NC) ? fabs(l.cd[e] - l.cs[e]) : 0.0);
       const double mu_r = uni(fmax(mu, block_reduce<OpMax>(cmax, l.red)));
+      OCP_FOR(e, N * NZ * NZ) {   // the restoration step's Hessian is the identity (added as delta = 1) + the barrier's diagonal
+        const int row = e / NZ;
+        l.W[(size_t)row * WP + (e - row * NZ)] = 0.0;
+      }
+      __syncthreads();
       OCP_FOR(e, SL) {
         const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e];
         double sg = 0.0, r = 0.0;
         if (lb > -INFINITY) { const double is = 1.0 / (z - lb); sg += mu_r * is * is; r -= mu_r * is; }
         if (ub < INFINITY) { const double is = 1.0 / (ub - z); sg += mu_r * is * is; r += mu_r * is; }
-        l.sig[e] = sg;
-        l.rb[e] = r;
+        stage_rhs(l, N, e, sg, r, true);
       }
       if constexpr (NC > 0) {
         OCP_FOR(e, N * NC) {
@@ -1963,7 +1992,7 @@ struct Ocp {
         }
       }
       __syncthreads();
-      riccati(lbase, ws, mu, 0.0, true);
+      riccati(lbase, ws, mu, 1.0, true);
       double a = 1.0, dmax = 0.0;
       if constexpr (NC > 0) {
         OCP_FOR(e, N * NC) {
@@ -2005,7 +2034,7 @@ struct Ocp {
       __syncthreads();
       th = tht;
       if (th <= 0.9 * th_start && th <= theta_max) {
-        const double ph = ft + eval_barrier(l, l.Z, mu, l.cs);
+        const double ph = ft + mu * barrier_logs(l, l.Z, l.cs);
         bool acc = true;
         for (int q = 0; q < nfilt; ++q)
           if (th >= l.filt[2 * q] && ph >= l.filt[2 * q + 1]) { acc = false; break; }
@@ -2146,22 +2175,20 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
   int nfilt = 0, acc_count = 0, it = 0, st = 0;
   double theta_min = 0.0, theta_max = INFINITY;
   double E0 = INFINITY, fval = 0.0;
+  double blog = 0.0;       // -sum log(slacks) at the current iterate, carried over from the accepted trial point
+  bool blog_ok = false;
 
   if constexpr (S::SYM) S::term_hess_dirs(l);
   for (it = 0;; ++it) {
     fval = S::eval_derivs(lds_raw, wsb);
     OCP_TICK(PH_DERIV)
-    double th0 = 0.0;
-    OCP_FOR(e, N * NX) th0 += fabs(l.c[e]);
-    if constexpr (NC > 0)
-      OCP_FOR(e, N * NC) th0 += S::row_on(pc, e / NC, e % NC) ? fabs(l.cd[e] - l.cs[e]) : 0.0;
-    th0 = block_reduce<OpSum>(th0, l.red);
+    double dual_s, prim, s_c, c0, cmu, th0;
+    S::opt_error(l, mu, dual_s, prim, s_c, c0, cmu, th0);
+    th0 = uni(th0);
     if (it == 0) {
       theta_min = uni(pc.theta_min_fact * fmax(1.0, th0));
       theta_max = uni(pc.theta_max_fact * fmax(1.0, th0));
     }
-    double dual_s, prim, s_c, c0, cmu;
-    S::opt_error(l, mu, dual_s, prim, s_c, c0, cmu);
     E0 = uni(nmax(nmax(dual_s, prim), c0 / s_c));
     if (E0 != E0) { st = HILO_STATUS_OTHER; break; }   // NaN in the iterate: IPOPT's 'Invalid_Number_Detected' -> -1
     if (E0 <= pc.tol) { st = HILO_STATUS_SOLVED; break; }
@@ -2173,7 +2200,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     for (int r = 0; r < 20; ++r) {
       const double Emu = uni(nmax(nmax(dual_s, prim), (r == 0 ? cmu : S::compl_error(l, mu)) / s_c));
       if (!(Emu <= pc.kappa_eps * mu && mu > mu_min * (1 + 1e-12))) break;
-      mu = uni(fmax(mu_min, fmin(pc.kappa_mu * mu, pow(mu, pc.theta_mu))));
+      mu = uni(fmax(mu_min, fmin(pc.kappa_mu * mu, pc.theta_mu == 1.5 ? mu * sqrt(mu) : pow(mu, pc.theta_mu))));
       tau = uni(fmax(pc.tau_min, 1.0 - mu));
       nfilt = 0;
     }
@@ -2197,24 +2224,27 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     if (delta > 0.0) delta_last = delta;
     OCP_TICK(PH_RICCATI)
     // ---- bound-multiplier steps, fraction to the boundary (W&B eq. 8), directional derivative ----
-    double a_p = 1.0, a_z = 1.0, dphi = 0.0;
+    // step lengths as tau / max(ratio): the largest relative decrease  -d / slack  (primal) and  -dz / z  (bound multipliers)
+    // over the slots, with the reciprocals of the slacks the multiplier steps need anyway - one division per step length
+    // instead of one per slot and side
+    double r_p = 0.0, r_z = 0.0, dphi = 0.0;
     OCP_FOR(e, SL) {
       double dl = 0.0, du = 0.0;
       {
         const double d = l.D[e], lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
         double gphi = l.grad[e];
         if (lb > -INFINITY) {
-          const double s = z - lb, is = 1.0 / s;
+          const double is = rcp_fast(z - lb);
           dl = mu * is - zl - zl * is * d;
-          if (d < 0.0) a_p = fmin(a_p, -tau * s / d);
-          if (dl < 0.0) a_z = fmin(a_z, -tau * zl / dl);
+          r_p = fmax(r_p, -d * is);
+          r_z = fmax(r_z, -dl * rcp_fast(zl));
           gphi -= mu * is;
         }
         if (ub < INFINITY) {
-          const double s = ub - z, is = 1.0 / s;
+          const double is = rcp_fast(ub - z);
           du = mu * is - zu + zu * is * d;
-          if (d > 0.0) a_p = fmin(a_p, tau * s / d);
-          if (du < 0.0) a_z = fmin(a_z, -tau * zu / du);
+          r_p = fmax(r_p, d * is);
+          r_z = fmax(r_z, -du * rcp_fast(zu));
           gphi += mu * is;
         }
         dphi += gphi * d;   // D = 0 on slots that are not variables
@@ -2229,16 +2259,16 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
         if (S::row_on(pc, e / NC, m)) {
           const double d = l.cds[e];
           if (pc.dlb[m] > -INFINITY) {
-            const double s = l.cs[e] - pc.dlb[m];
-            dl = mu / s - l.cvL[e] - l.cvL[e] / s * d;
-            if (d < 0.0) a_p = fmin(a_p, -tau * s / d);
-            if (dl < 0.0) a_z = fmin(a_z, -tau * l.cvL[e] / dl);
+            const double is = rcp_fast(l.cs[e] - pc.dlb[m]), vl = l.cvL[e];
+            dl = mu * is - vl - vl * is * d;
+            r_p = fmax(r_p, -d * is);
+            r_z = fmax(r_z, -dl * rcp_fast(vl));
           }
           if (pc.dub[m] < INFINITY) {
-            const double s = pc.dub[m] - l.cs[e];
-            du = mu / s - l.cvU[e] + l.cvU[e] / s * d;
-            if (d > 0.0) a_p = fmin(a_p, tau * s / d);
-            if (du < 0.0) a_z = fmin(a_z, -tau * l.cvU[e] / du);
+            const double is = rcp_fast(pc.dub[m] - l.cs[e]), vu = l.cvU[e];
+            du = mu * is - vu + vu * is * d;
+            r_p = fmax(r_p, d * is);
+            r_z = fmax(r_z, -du * rcp_fast(vu));
           }
           dphi += l.crb[e] * d;
         }
@@ -2246,23 +2276,23 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
         l.cdvU[e] = du;
       }
     }
-    a_p = block_reduce<OpMin>(a_p, l.red);
-    a_z = block_reduce<OpMin>(a_z, l.red);
+    r_p = block_reduce<OpMax>(r_p, l.red);
+    r_z = block_reduce<OpMax>(r_z, l.red);
     dphi = block_reduce<OpSum>(dphi, l.red);
-    const double phi0 = uni(fval + S::eval_barrier(l, l.Z, mu, l.cs));
+    const double a_p = uni(r_p > tau ? tau / r_p : 1.0), a_z = uni(r_z > tau ? tau / r_z : 1.0);
+    if (!blog_ok) blog = S::barrier_logs(l, l.Z, l.cs);
+    const double phi0 = uni(fval + mu * blog);
     OCP_TICK(PH_STEP)
     // ---- filter line search (W&B Alg. A) ----
     double alpha = a_p;
     bool accepted = false, armijo = false;
+    double blog_t = 0.0;
     for (int ls = 0; ls < 60; ++ls) {
-      OCP_FOR(e, SL) l.Zt[e] = l.Z[e] + alpha * l.D[e];
-      if constexpr (NC > 0)
-        OCP_FOR(e, N * NC) l.cst[e] = l.cs[e] + alpha * l.cds[e];
-      __syncthreads();
+      blog_t = S::form_trial(l, alpha);
       tprof[PH_NLS] += 1;
       const FTheta trial = S::eval_values(lds_raw, wsb, l.Zt, l.ct, l.cst, l.cdt);
       const double ft = trial.f, tht = trial.theta;
-      const double pht = uni(ft + S::eval_barrier(l, l.Zt, mu, l.cst));
+      const double pht = uni(ft + mu * blog_t);
       bool ok = isfinite(pht) && isfinite(tht) && tht <= theta_max;
       if (ok) {
         for (int q = 0; q < nfilt; ++q) {
@@ -2312,14 +2342,11 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
             }
           }
           const double a_s = block_reduce<OpMin>(a, l.red);
-          OCP_FOR(e, SL) l.Zt[e] = l.Z[e] + a_s * l.D[e];
-          if constexpr (NC > 0)
-            OCP_FOR(e, N * NC) l.cst[e] = l.cs[e] + a_s * l.cds[e];
-          __syncthreads();
+          blog_t = S::form_trial(l, a_s);
           tprof[PH_NLS] += 1;
           const FTheta t2 = S::eval_values(lds_raw, wsb, l.Zt, l.ct, l.cst, l.cdt);
           const double ths = t2.theta;
-          const double phs = uni(t2.f + S::eval_barrier(l, l.Zt, mu, l.cst));
+          const double phs = uni(t2.f + mu * blog_t);
           bool oks = isfinite(phs) && isfinite(ths) && ths <= theta_max;
           if (oks) {
             for (int q = 0; q < nfilt; ++q) {
@@ -2377,6 +2404,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     if (do_resto) {
       const int rr = uni(S::restore(lds_raw, wsb, mu, tau, nfilt, theta_max));
       if (rr != 0) { st = rr == 2 ? HILO_STATUS_INFEASIBLE : HILO_STATUS_RESTORATION_FAILED; break; }
+      blog_ok = false;
       // IPOPT after restoration: equality multipliers reset (constr_mult_reset_threshold = 0), bound multipliers
       // reset to 1 when they exceed bound_mult_reset_threshold = 1000
       double zm = 0.0;
@@ -2405,16 +2433,19 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
       continue;
     }
     // ---- accept: primal, equality multipliers, bound multipliers (+ W&B eq. 16 safeguard) ----
+    blog = blog_t;
+    blog_ok = true;
+    const double ks_lo = uni(mu / pc.kappa_sigma), ks_hi = uni(pc.kappa_sigma * mu);
     OCP_FOR(e, SL) {
       const double znew = l.Zt[e], lb = l.lbA[e], ub = l.ubA[e];
       l.Z[e] = znew;
       if (lb > -INFINITY) {
-        const double s = znew - lb;
-        l.zL[e] = fmin(fmax(l.zL[e] + a_z * l.dzL[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
+        const double is = rcp_fast(znew - lb);
+        l.zL[e] = fmin(fmax(l.zL[e] + a_z * l.dzL[e], ks_lo * is), ks_hi * is);
       }
       if (ub < INFINITY) {
-        const double s = ub - znew;
-        l.zU[e] = fmin(fmax(l.zU[e] + a_z * l.dzU[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
+        const double is = rcp_fast(ub - znew);
+        l.zU[e] = fmin(fmax(l.zU[e] + a_z * l.dzU[e], ks_lo * is), ks_hi * is);
       }
     }
     OCP_FOR(e, N * NX) l.lam[e] += alpha * (l.lamn[e] - l.lam[e]);
@@ -2426,12 +2457,12 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
         l.cs[e] = snew;
         l.cnu[e] += alpha * (l.cnun[e] - l.cnu[e]);
         if (pc.dlb[m] > -INFINITY) {
-          const double s = snew - pc.dlb[m];
-          l.cvL[e] = fmin(fmax(l.cvL[e] + a_z * l.cdvL[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
+          const double is = rcp_fast(snew - pc.dlb[m]);
+          l.cvL[e] = fmin(fmax(l.cvL[e] + a_z * l.cdvL[e], ks_lo * is), ks_hi * is);
         }
         if (pc.dub[m] < INFINITY) {
-          const double s = pc.dub[m] - snew;
-          l.cvU[e] = fmin(fmax(l.cvU[e] + a_z * l.cdvU[e], mu / (pc.kappa_sigma * s)), pc.kappa_sigma * mu / s);
+          const double is = rcp_fast(pc.dub[m] - snew);
+          l.cvU[e] = fmin(fmax(l.cvU[e] + a_z * l.cdvU[e], ks_lo * is), ks_hi * is);
         }
       }
     }

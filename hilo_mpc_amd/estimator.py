@@ -33,7 +33,10 @@ class _Solution:
         name = key.split(':')[0]
         if name not in self._d:
             raise KeyError(key)
-        return self._d[name]
+        v = self._d[name]
+        # device results are views of the filter's resident ping-pong tiles: what the caller gets is a copy of its own, taken
+        # when it asks (a value collected per step must not change two steps later)
+        return v.clone() if isinstance(v, torch.Tensor) else v
 
     __getitem__ = get_by_id
 
@@ -99,6 +102,10 @@ class _KalmanFilter:
             # a model written as expressions: its functor is compiled at setup (csrc/hilo_jit.hip) like the controllers' problems
             if not m.n_y:
                 raise RuntimeError("The model has no measurement equations (set_measurement_equations)")
+            if getattr(m, '_gps', None):
+                # the filter kernels are compiled without the learned-term table of the controllers (desc.user_gp)
+                raise NotImplementedError("Filters on a model with a learned term (Model.substitute_from) are not supported: "
+                                          "the filter kernels carry no Gaussian-process data")
             self._user_source = m.user_source()
             desc.user_source = self._user_source.encode()
         h = C.c_void_p()
@@ -275,8 +282,10 @@ class _KalmanFilter:
             if self._n_u:
                 buf[:, :self._n_u] = ut
             if self._n_p:
-                key = (pt.data_ptr(), pt._version, tuple(pt.shape))
-                if self._up_p_src != key:
+                # parameters passed per call are always written (a temporary's address says nothing about its content); the
+                # filter's own resident vector only when it was replaced or modified in place since the last copy
+                key = (id(pt), pt._version) if (p is None and pt is self._p) else None
+                if key is None or self._up_p_src != key:
                     buf[:, self._n_u:] = pt
                     self._up_p_src = key
             upt, us = buf, nup
@@ -313,19 +322,19 @@ class _KalmanFilter:
     n_p_est = property(lambda s: 0)                       # the filters estimate states only
     process_noise_covariance = property(lambda s: s._Q)
     measurement_noise_covariance = property(lambda s: s._R)
-    error_covariance = property(lambda s: s._P)
+    error_covariance = property(lambda s: None if s._P is None else s._P.clone())
 
     def is_setup(self):
         return self._handle is not None
 
-    # raw device views of the filter state (zero-copy)
+    # filter state on the device: copies (the resident tiles behind them are overwritten two steps later)
     @property
     def x(self):
-        return self._x
+        return None if self._x is None else self._x.clone()
 
     @property
     def P(self):
-        return self._P
+        return None if self._P is None else self._P.clone()
 
 
 class KalmanFilter(_KalmanFilter):

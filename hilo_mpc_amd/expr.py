@@ -20,7 +20,9 @@ STACK = 8
 
 
 class Expr:
-    """Node of an expression tree: op in {'const','x','u','p','z','theta','t', binary / unary op names, 'gp','gpd','gpvar'}."""
+    """Node of an expression tree: op in {'const','x','u','p','z','theta','t', binary / unary op names, 'gp','gpd','gpvar'}.
+    Unary functions: sq sin cos exp log sqrt (device interpreter and compiled code) and - compiled code only - the rest of the
+    reference's table (util/parsing.py:36-58): log10 fabs sign asin acos atan asinh acosh atanh; binary: atan2."""
     __slots__ = ('op', 'args', 'value', 'name', 'serial')
     _count = 0
 
@@ -125,6 +127,8 @@ class Expr:
             raise ValueError("a learned term cannot be evaluated by the device interpreter (run-time compiled models only)")
         elif op == 'z':
             raise ValueError("an algebraic state cannot be evaluated by the device interpreter (run-time compiled models only)")
+        elif op in NATIVE_UNARY or op == 'atan2':
+            raise ValueError(f"'{op}' is a function of the compiled code only (run-time compiled models), not of the device interpreter")
         else:
             out += [{'add': X_ADD, 'sub': X_SUB, 'mul': X_MUL, 'div': X_DIV, 'neg': X_NEG, 'sq': X_SQ, 'sin': X_SIN,
                      'cos': X_COS, 'exp': X_EXP, 'log': X_LOG, 'sqrt': X_SQRT}[op], 0.]
@@ -153,6 +157,29 @@ def _unary(op):
 
 
 sin, cos, exp, log, sqrt = (_unary(n) for n in ('sin', 'cos', 'exp', 'log', 'sqrt'))
+# the rest of the reference's function table (util/parsing.py:36-58 -> ca.log10, ca.sign, ca.fabs, ca.asin, ...): native device
+# functions of the compiled code (csrc/hilo_ad.h), not of the postfix interpreter
+NATIVE_UNARY = ('log10', 'fabs', 'sign', 'asin', 'acos', 'atan', 'asinh', 'acosh', 'atanh')
+log10, fabs, sign, asin, acos, atan, asinh, acosh, atanh = (_unary(n) for n in NATIVE_UNARY)
+arcsin, arccos, arctan, arsinh, arcosh, artanh = asin, acos, atan, asinh, acosh, atanh
+
+
+def atan2(y, x):
+    return Expr('atan2', (Expr.wrap(y), Expr.wrap(x)))
+
+
+arctan2 = atan2
+
+
+def fmin(a, b):
+    """min(a, b) = (a + b - |a - b|) / 2: value and derivatives (CasADi's: the active branch, the mean at a tie) from the parts."""
+    a, b = Expr.wrap(a), Expr.wrap(b)
+    return 0.5 * (a + b - fabs(a - b))
+
+
+def fmax(a, b):
+    a, b = Expr.wrap(a), Expr.wrap(b)
+    return 0.5 * (a + b + fabs(a - b))
 
 
 # functions composed of the device's operations (no new device code; derivatives follow from the parts)
@@ -223,6 +250,20 @@ def _mul(a, b):
     return a * b
 
 
+# derivative of the native unary functions as expressions of their argument
+_D_UNARY = {
+    'log10': lambda a: 0.4342944819032518 / a,
+    'fabs': lambda a: sign(a),
+    'sign': lambda a: Expr.wrap(0.0),
+    'asin': lambda a: 1.0 / sqrt(1.0 - a * a),
+    'acos': lambda a: -1.0 / sqrt(1.0 - a * a),
+    'atan': lambda a: 1.0 / (1.0 + a * a),
+    'asinh': lambda a: 1.0 / sqrt(a * a + 1.0),
+    'acosh': lambda a: 1.0 / sqrt(a * a - 1.0),
+    'atanh': lambda a: 1.0 / (1.0 - a * a),
+}
+
+
 def diff(e, var, memo=None):
     """d e / d var as an expression tree (`ca.jacobian` of the reference where a derivative becomes part of a MODEL, e.g. the
     covariance propagation of the stochastic NMPC, mpc.py:2534-2575); `var` is a leaf (a state, input or parameter symbol,
@@ -269,6 +310,11 @@ def diff(e, var, memo=None):
             r = zero if _is_c(d[0], 0.0) else d[0] / a[0]
         elif op == 'sqrt':
             r = zero if _is_c(d[0], 0.0) else d[0] / (2.0 * n)
+        elif op in _D_UNARY:
+            r = zero if _is_c(d[0], 0.0) else _mul(_D_UNARY[op](a[0]), d[0])
+        elif op == 'atan2':                                # d atan2(y, x) = (x dy - y dx) / (x^2 + y^2)
+            num = _add(_mul(a[1], d[0]), -_mul(a[0], d[1]) if not _is_c(d[1], 0.0) else zero)
+            r = zero if _is_c(num, 0.0) else num / (a[0] * a[0] + a[1] * a[1])
         elif op == 'gp':                                   # chain rule through the posterior mean: sum_j dmean/dfeature_j * feature_j'
             r = zero
             for j, dj in enumerate(d):

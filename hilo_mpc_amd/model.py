@@ -158,9 +158,10 @@ class Model:
         self._alg = eqs
 
     def _parse(self, eqs):
-        """Expressions, or strings of the model's variable names with sin / cos / tan / exp / log / sqrt / sinh / cosh / tanh (the right-hand side of
+        """Expressions, or strings of the model's variable names with the functions of the reference's table (the right-hand side of
         an optional `... = ` is taken, like the reference's equation strings, util/parsing.py)."""
-        ns = {n: getattr(_expr, n) for n in ('sin', 'cos', 'exp', 'log', 'sqrt', 'tan', 'sinh', 'cosh', 'tanh')}
+        from .parsing import FUNCTIONS
+        ns = dict(FUNCTIONS)                        # the reference's function table (util/parsing.py:36-58)
         ns['dt'] = Expr('dt', name='dt')            # the sampling interval inside the equations of a discrete model
         for vec in (self.x, self.u, self.p, self.z):
             ns.update({n: vec[n] for n in vec._names})
@@ -377,9 +378,13 @@ class Model:
             i = int(n.value)
             return node if i == ip else (newp[i - 1] if i > ip else None)
 
-        neq = len(self._ode)
-        out = Expr.substitute(self._ode + self._meas, leaf)
-        self._ode, self._meas = out[:neq], out[neq:]
+        # every equation list that can hold a parameter leaf is re-indexed together (the algebraic equations too)
+        alg = list(getattr(self, '_alg', None) or [])
+        neq, nalg = len(self._ode), len(alg)
+        out = Expr.substitute(self._ode + alg + self._meas, leaf)
+        self._ode, self._meas = out[:neq], out[neq + nalg:]
+        if nalg:
+            self._alg = out[neq:neq + nalg]
         self.parameter_names, self.n_p = keep, len(keep)
         self._gps.append(gp)
         self._is_setup = False
@@ -388,6 +393,8 @@ class Model:
     def copy(self, setup=True):
         m = copy.copy(self)
         m._sim = None              # the copy simulates its own trajectory
+        if hasattr(self, '_gps'):
+            m._gps = list(self._gps)    # learned terms substituted into the copy later must not appear in the original
         return m
 
     # ---- the model as a PLANT: one sampling interval for a batch of states (dynamic_model.py:3360-3400, :3911-4000) -----------------

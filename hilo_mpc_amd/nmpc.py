@@ -34,7 +34,7 @@ STATUS_TEXT = {1: 'solve_succeeded', 2: 'solved_to_acceptable_level', 3: 'infeas
 def _eval_time(e, t):
     """Value of an expression of the time variable at time t (reference trajectories given as functions, mpc.py:1847)."""
     import math
-    fn = {'sin': math.sin, 'cos': math.cos, 'exp': math.exp, 'log': math.log, 'sqrt': math.sqrt}
+    from .symdiff import _NUMERIC as fn
     val = {}
     for n in sorted(Expr.wrap(e).nodes().values(), key=lambda q: q.serial):
         a = [val[id(c)] for c in n.args]
@@ -53,6 +53,8 @@ def _eval_time(e, t):
             r = a[0] ** int(n.value)
         elif op in fn:
             r = fn[op](a[0])
+        elif op == 'atan2':
+            r = math.atan2(a[0], a[1])
         else:
             raise ValueError(f"a trajectory reference can only be a function of the time variable (found '{op}')")
         val[id(n)] = r
@@ -361,6 +363,7 @@ class NMPC:
         self._nlp_solution = None
         self._sampling_interval = model.dt
         self._u_prev = None
+        self._full_solution = False   # keep_full_solution: also return the solver result's `g` and `lam_x`
 
     type = 'NMPC'
 
@@ -973,6 +976,10 @@ class NMPC:
                               "parameters. I am ignoring the vector.")
             p, ps = None, 0
         v0t = None
+        wo = getattr(self, '_warm_override', None)          # best run of a multi-start call: the next call's start vector
+        self._warm_override = None
+        if v0 is None and wo is not None and wo.shape[0] == B and self._nlp_options['warm_start'] and not kwargs.get('_in_multi_start'):
+            v0 = wo
         if v0 is not None:
             v0t = to_dev(v0, self._dev).reshape(-1, self._n_v)
             if v0t.shape[0] == 1 and B > 1:
@@ -1000,9 +1007,12 @@ class NMPC:
         iters = torch.empty(B, dtype=torch.int32, device=dev)
         kkt = torch.empty(B, dtype=torch.float64, device=dev)
         # the reference keeps the whole solver result (mpc.py:722-723): constraint values g and bound multipliers lam_x too.
+        # Opt-in here (`keep_full_solution = True`): two more result vectors per instance that a control loop never reads.
         # Layouts with a collocation output pass return them as zeros.
-        g_val = torch.zeros(B, self._n_g, dtype=torch.float64, device=dev)
-        lam_x = torch.zeros(B, self._n_v, dtype=torch.float64, device=dev)
+        g_val = lam_x = None
+        if self._full_solution:
+            g_val = torch.zeros(B, self._n_g, dtype=torch.float64, device=dev)
+            lam_x = torch.zeros(B, self._n_v, dtype=torch.float64, device=dev)
         _lib.check(_lib.lib().hilo_nmpc_set_aux_outputs(self._handle, ptr(g_val), ptr(lam_x)))
         t0 = time.time() if self._stats else None
         if sd is not None:
@@ -1013,8 +1023,9 @@ class NMPC:
             _lib.check(_lib.lib().hilo_nmpc_solve(self._handle, B, ptr(x.contiguous()), ptr(p), ps, ptr(v0t), ptr(u_old),
                                                   ptr(v_opt), ptr(f_opt), ptr(lam_g), ptr(u0), ptr(status), ptr(iters),
                                                   ptr(kkt), stream_ptr(dev)))
-        self._nlp_solution = {'x': v_opt, 'f': f_opt, 'lam_g': lam_g, 'g': g_val, 'lam_x': lam_x, 'status': status,
-                              'iter_count': iters, 'kkt_error': kkt}
+        self._nlp_solution = {'x': v_opt, 'f': f_opt, 'lam_g': lam_g, 'status': status, 'iter_count': iters, 'kkt_error': kkt}
+        if self._full_solution:
+            self._nlp_solution.update(g=g_val, lam_x=lam_x)
         if self._has_du:
             self._u_prev = v_opt[:, self._u_ind[0][:self._n_u]].contiguous()
         if self._ne:
@@ -1036,20 +1047,31 @@ class NMPC:
         clipped to the bounds; per instance the best objective among the solves that ended with status 1 or 2 is kept.  The
         reference draws from the unseeded numpy generator; here `seed=` (default 0) makes the draws reproducible."""
         pert = float(kwargs.get('pert_factor', 0.1))
+        prev = self._nlp_solution
+        warm = prev['x'].clone() if (prev is not None and self._nlp_options.get('warm_start', True)) else None
         gen = torch.Generator(device='cpu').manual_seed(int(kwargs.get('seed', 0)))
         kw = {k: v for k, v in kwargs.items() if k not in ('pert_factor', 'seed')}
         n_it, t_it = self._n_iterations, self._time
+        u_prev = self._u_prev           # every run solves the SAME problem: the previous input of the change penalty is fixed
         best = None
         start = v0
         for r in range(runs):
             self._n_iterations, self._time = n_it, t_it               # one optimize() as far as the counters go
-            u = self.optimize(x0, cp=cp, tvp=tvp, v0=start, runs=0, fix_x0=fix_x0, **kw)
+            self._u_prev = u_prev
+            u = self.optimize(x0, cp=cp, tvp=tvp, v0=start, runs=0, fix_x0=fix_x0, _in_multi_start=True, **kw)
             sol = self._nlp_solution
             ok = (sol['status'] == 1) | (sol['status'] == 2)
             if best is None:
                 best = {k: v.clone() for k, v in sol.items()}
                 best['u0'] = torch.as_tensor(np.asarray(u).reshape(len(ok), -1), device=self._dev) if not isinstance(u, torch.Tensor) else u.reshape(len(ok), -1).clone()
-                base = (to_dev(v0, self._dev).reshape(-1, self._n_v) if v0 is not None else self._guess_vector(len(ok))).clone()
+                # perturbation base (mpc.py:735): the start vector of the first run - the caller's v0, else the warm start of
+                # the previous call, else the initial guess
+                if v0 is not None:
+                    base = to_dev(v0, self._dev).reshape(-1, self._n_v).clone()
+                elif warm is not None and warm.shape[0] == len(ok):
+                    base = warm
+                else:
+                    base = self._guess_vector(len(ok))
                 best_ok = ok.clone()
                 take = torch.zeros_like(ok)
             else:
@@ -1064,6 +1086,10 @@ class NMPC:
             start = torch.minimum(torch.maximum(base + base * (1 - 2 * rnd) * pert, lb), ub)
         u0 = best.pop('u0')
         self._nlp_solution = best
+        # the memory of the next call belongs to the BEST run (mpc.py:739-741 sets `_v0` from it): previous input and warm start
+        if self._has_du:
+            self._u_prev = best['x'][:, self._u_ind[0][:self._n_u]].contiguous()
+        self._warm_override = best['x']
         host = not isinstance(x0, torch.Tensor)
         single = u0.shape[0] == 1 and np.ndim(x0) <= 1
         if host:
@@ -1254,6 +1280,16 @@ class NMPC:
         _lib.check(_lib.lib().hilo_nmpc_profile(self._handle, int(bool(enable)), buf if had else None))
         self._prof_on = bool(enable)
         return dict(zip(names, list(buf))) if had else None
+
+    @property
+    def keep_full_solution(self):
+        """True: `_nlp_solution` also carries the constraint values `g` and the bound multipliers `lam_x` of the reference's solver
+        result (mpc.py:722-723).  Off by default: a control loop reads neither, and they double the bytes a solve writes."""
+        return self._full_solution
+
+    @keep_full_solution.setter
+    def keep_full_solution(self, arg):
+        self._full_solution = bool(arg)
 
     def set_gather_buffer(self, table):
         """Sharded batches: the solve writes [u0 | status | iterations] rows (fp64) into `table` ([B, >= nu + 2], device) itself

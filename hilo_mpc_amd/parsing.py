@@ -22,7 +22,10 @@ import re
 from . import expr as _expr
 from .expr import Expr
 
-FUNCTIONS = {n: getattr(_expr, n) for n in ('sin', 'cos', 'tan', 'exp', 'log', 'sqrt', 'sinh', 'cosh', 'tanh')}
+# the reference's table (util/parsing.py:36-58), name for name
+FUNCTIONS = {n: getattr(_expr, n) for n in ('sqrt', 'exp', 'log', 'log10', 'sign', 'sin', 'cos', 'tan', 'arcsin', 'arccos',
+                                             'arctan', 'arctan2', 'sinh', 'cosh', 'tanh', 'arsinh', 'arcosh', 'artanh')}
+FUNCTIONS.update(abs=_expr.fabs, min=_expr.fmin, max=_expr.fmax)
 _TIMED = re.compile(r'([A-Za-z_][A-Za-z0-9_]*)\(([kt0-9+\-]{1,3})\)')
 
 

@@ -65,45 +65,46 @@ class ParticleFilter(_KalmanFilter):
     def probability_density_function(self):
         return self._pdf
 
+    # what the reference expects of a sampler `X = pdf(mean, covariance, n)` when it is annotated (pf.py:197-249): position -> type
+    # and the role named in the message
+    _SAMPLER_SIGNATURE = ((np.ndarray, "The 1st argument to the probability density function (pdf) needs to be the 'mean'"),
+                          (np.ndarray, "The 2nd argument to the probability density function (pdf) needs to be the 'covariance'"),
+                          (int, "The 3rd argument to the probability density function (pdf) needs to be the 'sample size'"),
+                          (np.ndarray, "The return value of the probability density function (pdf) needs to be a 'random sample'"))
+
+    def _sampler_orientation(self, pdf):
+        """Draw once from N(0, I): does the sampler return particles as columns (False) or as rows (True)?"""
+        n, size = self._nx_model, self._sample_size
+        try:
+            shape = tuple(np.shape(pdf(np.zeros(n), np.eye(n), size)))
+            if shape == (n, size):
+                return False
+            if shape == (size, n):
+                return True
+            raise ValueError(f"Dimension mismatch. Expected dimension {n}x{size}, got {shape[0]}x{shape[1]}.")
+        except Exception as err:
+            raise RuntimeError(f"The following exception was raised\n"
+                               f"   {type(err).__name__}: '{err.args[0]}'.\nPlease make sure that the "
+                               f"supplied probability density function (pdf) has the following arguments\n"
+                               f"   mu - mean of the pdf (type: numpy.ndarray),\n"
+                               f"   sigma - covariance of the mean (type: numpy.ndarray),\n"
+                               f"   n - sample size (type: int),\n"
+                               f"and the following return value\n"
+                               f"   X - random sample (type: numpy.ndarray).")
+
     @probability_density_function.setter
     def probability_density_function(self, pdf):
+        """A fully annotated sampler (three arguments and the return value) is checked by its annotations and trusted to return
+        particles as columns; anything else is probed with one draw (same decisions and messages as pf.py:197-249)."""
         if not callable(pdf):
             raise ValueError(f"Probability density function of the {self.type} needs to be callable.")
-        annotations = getattr(pdf, '__annotations__', {})
-        run_function = True
-        n_x = self._nx_model
-        if annotations:
-            if len(annotations) == 4 and 'return' in annotations:
-                types = [np.ndarray, np.ndarray, int, np.ndarray]
-                args = ["mean", "covariance", "sample size"]
-                for k, type_ in enumerate(annotations.values()):
-                    if type_ is not types[k]:
-                        no = "1st" if k == 0 else ("2nd" if k == 1 else "3rd")
-                        if k < 3:
-                            raise TypeError(f"The {no} argument to the probability density function (pdf) needs to be "
-                                            f"the '{args[k]}' with type {types[k].__name__}.")
-                        raise TypeError(f"The return value of the probability density function (pdf) needs to be a"
-                                        f" 'random sample' with type {types[k].__name__}.")
-                run_function = False
-        if run_function:
-            try:
-                X = pdf(np.zeros(n_x), np.eye(n_x), self._sample_size)
-                if X.shape != (n_x, self._sample_size):
-                    if X.shape != (self._sample_size, n_x):
-                        raise ValueError(f"Dimension mismatch. Expected dimension {n_x}x{self._sample_size}, got "
-                                         f"{X.shape[0]}x{X.shape[1]}.")
-                    self._transpose_pdf = True
-                else:
-                    self._transpose_pdf = False
-            except Exception as err:
-                raise RuntimeError(f"The following exception was raised\n"
-                                   f"   {type(err).__name__}: '{err.args[0]}'.\nPlease make sure that the "
-                                   f"supplied probability density function (pdf) has the following arguments\n"
-                                   f"   mu - mean of the pdf (type: numpy.ndarray),\n"
-                                   f"   sigma - covariance of the mean (type: numpy.ndarray),\n"
-                                   f"   n - sample size (type: int),\n"
-                                   f"and the following return value\n"
-                                   f"   X - random sample (type: numpy.ndarray).")
+        notes = dict(getattr(pdf, '__annotations__', None) or {})
+        if len(notes) == len(self._SAMPLER_SIGNATURE) and 'return' in notes:
+            for found, (want, what) in zip(notes.values(), self._SAMPLER_SIGNATURE):
+                if found is not want:
+                    raise TypeError(f"{what} with type {want.__name__}.")
+        else:
+            self._transpose_pdf = self._sampler_orientation(pdf)
         self._pdf = pdf
 
     pdf = probability_density_function

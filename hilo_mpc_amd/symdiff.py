@@ -18,6 +18,12 @@ import math
 from .expr import Expr
 
 
+# numeric counterparts of the unary functions (constant folding, evaluate())
+_NUMERIC = {'sin': math.sin, 'cos': math.cos, 'exp': math.exp, 'log': math.log, 'sqrt': math.sqrt, 'log10': math.log10,
+            'fabs': math.fabs, 'sign': lambda v: (v > 0) - (v < 0) + 0.0, 'asin': math.asin, 'acos': math.acos, 'atan': math.atan,
+            'asinh': math.asinh, 'acosh': math.acosh, 'atanh': math.atanh}
+
+
 class Dag:
     """Hash-consed expression DAG with local simplification.  Nodes are integers; `self.nodes[i] = (op, a, b, value)`."""
 
@@ -123,8 +129,13 @@ class Dag:
 
     def fun(self, op, a):
         if self.is_const(a):
-            return self.const({'sin': math.sin, 'cos': math.cos, 'exp': math.exp, 'log': math.log, 'sqrt': math.sqrt}[op](self.cval(a)))
+            return self.const(_NUMERIC[op](self.cval(a)))
         return self._mk(op, a)
+
+    def atan2(self, y, x):
+        if self.is_const(y) and self.is_const(x):
+            return self.const(math.atan2(self.cval(y), self.cval(x)))
+        return self._mk('atan2', y, x)
 
     def sq(self, a):
         return self.mul(a, a)
@@ -167,8 +178,10 @@ class Dag:
                 r = self.sq(a[0])
             elif op == 'powi':
                 r = self.powi(a[0], int(n.value))
-            elif op in ('sin', 'cos', 'exp', 'log', 'sqrt'):
+            elif op in _NUMERIC:
                 r = self.fun(op, a[0])
+            elif op == 'atan2':
+                r = self.atan2(a[0], a[1])
             else:
                 raise NotImplementedError(f"no symbolic derivative for operator '{op}'")
             memo[id(n)] = r
@@ -206,6 +219,25 @@ class Dag:
             r = self.mul(self.recip(a), self.diff(a, wrt))
         elif op == 'sqrt':                                             # d sqrt(a) = da / (2 sqrt(a))
             r = self.mul(self.mul(self.const(0.5), self.recip(i)), self.diff(a, wrt))
+        elif op == 'log10':
+            r = self.mul(self.mul(self.const(0.4342944819032518), self.recip(a)), self.diff(a, wrt))
+        elif op == 'fabs':                                             # CasADi: d|a| = sign(a) da
+            r = self.mul(self.fun('sign', a), self.diff(a, wrt))
+        elif op == 'sign':
+            r = self.const(0.0)
+        elif op in ('asin', 'acos'):                                   # +- da / sqrt(1 - a^2)
+            g = self.recip(self.fun('sqrt', self.sub(self.const(1.0), self.mul(a, a))))
+            r = self.mul(g if op == 'asin' else self.neg(g), self.diff(a, wrt))
+        elif op == 'atan':
+            r = self.mul(self.recip(self.add(self.const(1.0), self.mul(a, a))), self.diff(a, wrt))
+        elif op in ('asinh', 'acosh'):                                 # da / sqrt(a^2 +- 1)
+            inner = self.add(self.mul(a, a), self.const(1.0)) if op == 'asinh' else self.sub(self.mul(a, a), self.const(1.0))
+            r = self.mul(self.recip(self.fun('sqrt', inner)), self.diff(a, wrt))
+        elif op == 'atanh':
+            r = self.mul(self.recip(self.sub(self.const(1.0), self.mul(a, a))), self.diff(a, wrt))
+        elif op == 'atan2':                                            # (x dy - y dx) / (x^2 + y^2), node = atan2(a = y, b = x)
+            num = self.sub(self.mul(b, self.diff(a, wrt)), self.mul(a, self.diff(b, wrt)))
+            r = self.mul(num, self.recip(self.add(self.mul(a, a), self.mul(b, b))))
         else:
             raise NotImplementedError(op)
         self._d[key] = r
@@ -246,6 +278,8 @@ class Dag:
                 rhs = f"-{ref[a]}"
             elif op == 'recip':
                 rhs = f"1.0 / {ref[a]}" if generic else f"rcp_fast({ref[a]})"   # csrc/hilo_ad.h: v_rcp_f64 + two Newton steps
+            elif op == 'atan2':
+                rhs = f"atan2({ref[a]}, {ref[b]})"
             else:
                 rhs = f"{op}({ref[a]})"
             ref[i] = f"s{len(lines)}"
@@ -257,7 +291,7 @@ class Dag:
     def evaluate(self, outputs, x, u, p, kb=(), z=()):
         val = {}
         env = {'x': x, 'u': u, 'p': p, 'kb': kb, 'z': z}
-        fn = {'sin': math.sin, 'cos': math.cos, 'exp': math.exp, 'log': math.log, 'sqrt': math.sqrt}
+        fn = _NUMERIC
         need, stack = set(), list(outputs)
         while stack:
             i = stack.pop()
@@ -280,6 +314,8 @@ class Dag:
                 val[i] = -val[a]
             elif op == 'recip':
                 val[i] = 1.0 / val[a]
+            elif op == 'atan2':
+                val[i] = math.atan2(val[a], val[b])
             else:
                 val[i] = fn[op](val[a])
         return [val[o] for o in outputs]

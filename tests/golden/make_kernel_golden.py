@@ -120,38 +120,53 @@ def extract(path, table, facade_name):
             if 'assert_allclose' not in seg or 'ca.' in seg:
                 continue
             env = {'np': np, facade_name: Facade, **class_ns}
-            for st in fn.body:
-                if isinstance(st, (ast.Import, ast.ImportFrom)):
-                    continue
-                is_assert = (isinstance(st, ast.Expr) and isinstance(st.value, ast.Call)
-                             and ast.unparse(st.value.func) == 'np.testing.assert_allclose')
-                if is_assert:
-                    try:
-                        got = eval(compile(ast.Expression(st.value.args[0]), '<ref-test>', 'eval'), env)
-                        exp = eval(compile(ast.Expression(st.value.args[1]), '<ref-test>', 'eval'), env)
-                        if isinstance(exp, Call):
+
+            def visit(body):
+                for st in body:
+                    if isinstance(st, (ast.Import, ast.ImportFrom)):
+                        continue
+                    if isinstance(st, ast.For):
+                        # known answers asserted inside a loop (`for k in range(4): ... assert_allclose(kernel(x), table[k])`):
+                        # one case per pass, with the loop variable bound
+                        try:
+                            values = list(eval(compile(ast.Expression(st.iter), '<ref-test>', 'eval'), env))
+                        except Exception:
                             continue
-                        kw = {k.arg: eval(compile(ast.Expression(k.value), '<ref-test>', 'eval'), env)
-                              for k in st.value.keywords}
-                    except Exception as e:                       # noqa
-                        print(f'  skip assert in {cls.name}.{fn.name}: {e}', file=sys.stderr)
+                        for v in values:
+                            env[st.target.id] = v
+                            visit(st.body)
                         continue
-                    if not isinstance(got, Call) or isinstance(exp, Call):
+                    is_assert = (isinstance(st, ast.Expr) and isinstance(st.value, ast.Call)
+                                 and ast.unparse(st.value.func) == 'np.testing.assert_allclose')
+                    if is_assert:
+                        try:
+                            got = eval(compile(ast.Expression(st.value.args[0]), '<ref-test>', 'eval'), env)
+                            exp = eval(compile(ast.Expression(st.value.args[1]), '<ref-test>', 'eval'), env)
+                            if isinstance(exp, Call):
+                                continue
+                            kw = {k.arg: eval(compile(ast.Expression(k.value), '<ref-test>', 'eval'), env)
+                                  for k in st.value.keywords}
+                        except Exception as e:                       # noqa
+                            print(f'  skip assert in {cls.name}.{fn.name}: {e}', file=sys.stderr)
+                            continue
+                        if not isinstance(got, Call) or isinstance(exp, Call):
+                            continue
+                        cases.append({
+                            'ref_test': f'{os.path.basename(path)}::{cls.name}::{fn.name}',
+                            'ref_line': st.lineno,
+                            'spec': got.spec.to_json(),
+                            'args': [_clean(np.asarray(a, dtype=float)) for a in got.args],
+                            'expected': _clean(np.asarray(exp, dtype=float)),
+                            'tol': {k: float(v) for k, v in kw.items()},
+                        })
                         continue
-                    cases.append({
-                        'ref_test': f'{os.path.basename(path)}::{cls.name}::{fn.name}',
-                        'ref_line': st.lineno,
-                        'spec': got.spec.to_json(),
-                        'args': [_clean(np.asarray(a, dtype=float)) for a in got.args],
-                        'expected': _clean(np.asarray(exp, dtype=float)),
-                        'tol': {k: float(v) for k, v in kw.items()},
-                    })
-                    continue
-                if isinstance(st, ast.Assign):
-                    try:
-                        exec(compile(ast.Module([st], []), '<ref-test>', 'exec'), env)
-                    except Exception:
-                        pass
+                    if isinstance(st, ast.Assign):
+                        try:
+                            exec(compile(ast.Module([st], []), '<ref-test>', 'exec'), env)
+                        except Exception:
+                            pass
+
+            visit(fn.body)
     return cases
 
 

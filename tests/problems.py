@@ -468,7 +468,9 @@ def eval_exprs(exprs, x, u, p, gps=()):
     for e in exprs:
         Expr.wrap(e).nodes(allnodes)
     val = {}
-    fn = {'sin': math.sin, 'cos': math.cos, 'exp': math.exp, 'log': math.log, 'sqrt': math.sqrt}
+    fn = {'sin': math.sin, 'cos': math.cos, 'exp': math.exp, 'log': math.log, 'sqrt': math.sqrt, 'log10': math.log10,
+          'fabs': math.fabs, 'sign': lambda v: float((v > 0) - (v < 0)), 'asin': math.asin, 'acos': math.acos, 'atan': math.atan,
+          'asinh': math.asinh, 'acosh': math.acosh, 'atanh': math.atanh}
     for n in sorted(allnodes.values(), key=lambda q: q.serial):
         a = [val[id(c)] for c in n.args]
         op = n.op
@@ -490,6 +492,8 @@ def eval_exprs(exprs, x, u, p, gps=()):
             r = a[0] * a[0]
         elif op == 'powi':
             r = a[0] ** int(n.value)
+        elif op == 'atan2':
+            r = math.atan2(a[0], a[1])
         elif op in fn:
             r = fn[op](a[0])
         elif op == 'gp':

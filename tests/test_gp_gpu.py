@@ -316,3 +316,23 @@ def test_fit_model_fits_the_mean_hyperparameters_too():
     held.setup()
     held.fit_model()
     assert held.mean.bias == .2
+
+
+def test_piecewise_polynomial_self_covariance_is_degree_independent():
+    """The three CasADi-only asserts of the reference's kernel tests (test_kernels.py:2720, :2954, :2977 compare the symbolic
+    k(x, x) across the degrees 0..3): the covariance of a point with itself is the signal variance whatever the degree -
+    checked here on numbers (isotropic, ARD, ARD with inactive dimensions)."""
+    x1 = np.array([[.7]])
+    x3 = np.array([[1.], [6.], [.1]])
+    for spec, x in (({'type': 'piecewise_polynomial', 'kwargs': {'signal_variance': .5}}, x1),
+                    ({'type': 'piecewise_polynomial', 'kwargs': {'signal_variance': .5, 'length_scales': [2., 2., 2.]}}, x3),
+                    ({'type': 'piecewise_polynomial', 'kwargs': {'signal_variance': .5, 'length_scales': [2., 2.],
+                                                                 'active_dims': [0, 2]}}, x3)):
+        vals = []
+        for degree in range(4):
+            s = {'type': spec['type'], 'kwargs': dict(spec['kwargs'], degree=degree)}
+            vals.append(kernel_from_spec(s)(x))
+            np.testing.assert_allclose(vals[-1], ogp.kernel(s, x), rtol=1e-13)
+        for v in vals[1:]:
+            np.testing.assert_allclose(v, vals[0])
+        np.testing.assert_allclose(vals[0], [[.5]])

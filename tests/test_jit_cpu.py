@@ -77,3 +77,36 @@ def test_filter_kernels_of_an_expression_model_compile(name):
     """KF / EKF / UKF on a model written as expressions: the six kernels kf_body<UserModel, UKF, MODE> (predict / update / step)."""
     m = symbolic_model(name)
     _lib.check(_lib.lib().hilo_jit_precompile_kf(m.user_source().encode()))
+
+
+def _table_model():
+    """Every function of the reference's table (util/parsing.py:36-58) in one continuous model, written as text."""
+    from hilo_mpc_amd import Model
+    m = Model(name='table')
+    m.set_equations(equations='''
+    da/dt = -a(t) + log10(2 + a(t)^2) + arcsin(a(t)/30) * arccos(b(t)/40) + arctan(a(t)*b(t)) + abs(a(t) - b(t)) * sign(c(k))
+    db/dt = -b(t) + arctan2(a(t), 1 + c(k)^2) + arsinh(b(t)*c(k)) + arcosh(2 + a(t)^2) + artanh(b(t)/50) ...
+            + min(a(t)*c(k), b(t)) + max(a(t), b(t)^2) + tanh(a(t)) + sqrt(1 + exp(-b(t)))
+    y(k) = a(t) + abs(b(t))
+    ''')
+    return m
+
+
+@pytest.mark.parametrize('policy', [0, 2])
+def test_model_with_the_whole_function_table_compiles(policy):
+    """The emitted functor is evaluated in every scalar type of the engine: plain / fast doubles, second-order Taylor numbers
+    (general policy, and the tracking policy's values) and - through the generated symbolic derivatives - straight-line code
+    (tracking policy): all of them need every function of the table (csrc/hilo_ad.h)."""
+    m = _table_model()
+    assert (m.n_x, m.n_u, m.n_y) == (2, 1, 1)
+    src = m.user_source()
+    for name in ('log10(', 'asin(', 'acos(', 'atan(', 'atan2(', 'asinh(', 'acosh(', 'atanh(', 'fabs(', 'sign('):
+        assert name in src, name
+    if policy == 2:
+        src += codegen.fun_source(m.n_x)
+    _compile(src, policy=policy, has_fun=int(policy == 2))
+
+
+def test_filter_kernels_with_the_whole_function_table_compile():
+    """... and first-order dual numbers (Kalman filters)."""
+    _lib.check(_lib.lib().hilo_jit_precompile_kf(_table_model().user_source().encode()))

@@ -51,3 +51,13 @@ def test_gp_rasmussen_lml_kat():
     m2, v2 = post.predict(xs, noise_free=True)
     np.testing.assert_allclose(m1, m2)
     assert np.all(v2 < v1) and np.all(v2 > -1e-12)
+
+
+def test_piecewise_polynomial_self_covariance_is_degree_independent():
+    """test_kernels.py:2720, :2954, :2977 (CasADi-only asserts: the symbolic k(x, x) is the same for the degrees 0..3)."""
+    x3 = np.array([[1.], [6.], [.1]])
+    for kw, x in (({'signal_variance': .5}, np.array([[.7]])), ({'signal_variance': .5, 'length_scales': [2., 2., 2.]}, x3),
+                  ({'signal_variance': .5, 'length_scales': [2., 2.], 'active_dims': [0, 2]}, x3)):
+        vals = [gp.kernel({'type': 'piecewise_polynomial', 'kwargs': dict(kw, degree=d)}, x) for d in range(4)]
+        for v in vals:
+            np.testing.assert_allclose(v, [[.5]])

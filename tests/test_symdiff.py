@@ -81,3 +81,40 @@ def test_composed_functions_and_general_powers():
         np.testing.assert_allclose(np.array(g.evaluate([Jd[i][j] for i in range(2) for j in range(3)], pt[:2], pt[2:], [])).reshape(2, 3),
                                    J(*pt), rtol=1e-12)
     assert math.isclose(eval_exprs([expr.tan(expr.Expr.wrap(.3))], [], [], [])[0], math.tan(.3), rel_tol=1e-15)
+
+
+def test_the_reference_function_table_values_and_derivatives():
+    """util/parsing.py:36-58: log10 sign abs min max arcsin arccos arctan arctan2 arsinh arcosh artanh (with the functions already
+    there: the whole table) - as text and as expressions; values, the expression-level derivative and the symbolic derivative DAG
+    (first and contracted second derivatives) against sympy / finite differences; the non-smooth ones as CasADi differentiates
+    them (d|a| = sign(a) da, d sign = 0, min / max: the active branch)."""
+    import numpy as np
+    import sympy as sp
+    from hilo_mpc_amd import Model, expr
+    from hilo_mpc_amd.parsing import FUNCTIONS
+    from hilo_mpc_amd.symdiff import derivative_dag
+    from tests.problems import eval_exprs
+    assert sorted(FUNCTIONS) == sorted(['sqrt', 'exp', 'log', 'log10', 'sign', 'abs', 'min', 'max', 'sin', 'cos', 'tan', 'arcsin',
+                                        'arccos', 'arctan', 'arctan2', 'sinh', 'cosh', 'tanh', 'arsinh', 'arcosh', 'artanh'])
+    m = Model(name='table')
+    m.set_dynamical_states(['a', 'b']), m.set_inputs(['c'])
+    m.set_dynamical_equations(['log10(2 + a*a) + arcsin(a/3) * arccos(b/4) + arctan(a*b) + abs(a - b) * sign(c)',
+                               'arctan2(a, 1 + c*c) + arsinh(b*c) + arcosh(2 + a*a) + artanh(b/5) + min(a*c, b) + max(a, b*b)'])
+    a, b, c = sp.symbols('a b c', real=True)
+    f = sp.Matrix([sp.log(2 + a * a, 10) + sp.asin(a / 3) * sp.acos(b / 4) + sp.atan(a * b) + sp.Abs(a - b) * sp.sign(c),
+                   sp.atan2(a, 1 + c * c) + sp.asinh(b * c) + sp.acosh(2 + a * a) + sp.atanh(b / 5) + sp.Min(a * c, b) + sp.Max(a, b * b)])
+    for pt in ((.7, -.4, 1.3), (-1.1, .9, -.6), (.2, .3, .8)):
+        F = np.array(f.subs({a: pt[0], b: pt[1], c: pt[2]}).evalf(20), dtype=float).ravel()
+        J = np.array(f.jacobian([a, b, c]).subs({a: pt[0], b: pt[1], c: pt[2]}).evalf(20), dtype=float)
+        np.testing.assert_allclose(eval_exprs(m._ode, pt[:2], pt[2:], []), F, rtol=1e-14)
+        Je = expr.jacobian(m._ode, list(m.x) + list(m.u))
+        np.testing.assert_allclose(eval_exprs([e for r in Je for e in r], pt[:2], pt[2:], []).reshape(2, 3), J, rtol=1e-12, atol=1e-14)
+        g, fn, Jd, H, kb = derivative_dag(2, 1, m._ode)
+        np.testing.assert_allclose(np.array(g.evaluate([Jd[i][j] for i in range(2) for j in range(3)], pt[:2], pt[2:], [])).reshape(2, 3),
+                                   J, rtol=1e-12, atol=1e-14)
+        # contracted Hessian sum_m kb_m d2 f_m / dw2 (packed lower triangle) against sympy
+        kbv = [.3, -1.7]
+        Hs = kbv[0] * sp.hessian(f[0], [a, b, c]) + kbv[1] * sp.hessian(f[1], [a, b, c])
+        Hn = np.array(Hs.subs({a: pt[0], b: pt[1], c: pt[2]}).evalf(20), dtype=float)
+        got = g.evaluate(H, pt[:2], pt[2:], [], kb=kbv)
+        np.testing.assert_allclose(got, [Hn[i][j] for i in range(3) for j in range(i + 1)], rtol=1e-11, atol=1e-13)
