@@ -129,11 +129,24 @@ def cpu_baseline_c2(spec, nst=50, slsqp=True):
     """the C++17 / OpenMP Riccati interior point of oracle/cpu (validated against the numpy oracle in
     tests/test_cpu_baseline.py: same statuses, iteration counts and solutions) on the SAME closed-loop workload - 5 warm-up
     + 50 timed warm-started steps - with all host cores and with one; plus scipy SLSQP on the identical transcribed NLP."""
+    # threads pinned to cores (set before the OpenMP runtime of the baseline library starts)
+    os.environ.setdefault('OMP_PROC_BIND', 'close')
+    os.environ.setdefault('OMP_PLACES', 'cores')
     from oracle.cpu import CpuNmpc, max_threads
     from tests import problems as P
     pb = P.oracle_problem(spec)
     cpu = CpuNmpc(pb)
-    C = max_threads()
+    # the cores this process can actually use: the scheduler affinity AND the container's CPU quota (cgroup) bound it, whatever
+    # the OpenMP runtime or os.cpu_count() report
+    quota = None
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        quota = None if q == 'max' else float(q) / float(per)
+    except Exception:
+        pass
+    C = min(max_threads(), len(os.sched_getaffinity(0)))
+    if quota is not None:
+        C = max(1, min(C, int(quota + 1e-9)))
 
     def loop(nb, nt, nst=nst, nwarm=5):
         xs, v, t0, its = P.c2_x0(nb), None, 0.0, []
@@ -173,14 +186,9 @@ def cpu_baseline_c2(spec, nst=50, slsqp=True):
                        constraints=[{'type': 'eq', 'fun': lambda w: ev(w)[2], 'jac': lambda w: ev(w)[3]}],
                        options={'ftol': 1e-12, 'maxiter': 500})
         slsqp_ms = (time.perf_counter() - t0) * 1e3
-    model, quota = '', None
+    model = ''
     try:
         model = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
-    except Exception:
-        pass
-    try:   # a container's CPU quota caps the all-core number whatever os.cpu_count() says
-        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
-        quota = None if q == 'max' else float(q) / float(per)
     except Exception:
         pass
     return {"value": v_all, "unit": "steps/s", "cores": C, "kind": "port", "one_core_value": v_one,
@@ -188,7 +196,7 @@ def cpu_baseline_c2(spec, nst=50, slsqp=True):
             "mean_ipm_iters": it_all, "frac_status_1_or_2": ok_all,
             "slsqp_ms_per_solve": slsqp_ms, "slsqp_iterations": int(sol.nit) if sol is not None else None,
             "sample": f"oracle/cpu C++17/OpenMP Riccati interior point (same algorithm and constants as the numpy oracle, validated "
-                      f"against it): C2 closed loop, {nb_all} instances x {nst} warm-started steps on {C} threads ({s_all:.1f} s); "
+                      f"against it): C2 closed loop, {nb_all} instances x {nst} warm-started steps on {C} pinned threads = min(OpenMP, affinity, cgroup quota) ({s_all:.1f} s); "
                       f"one_core_value: 128 instances x {min(nst, 20)} steps on 1 thread ({s_one:.1f} s); slsqp: scipy SLSQP with the oracle's exact "
                       f"derivatives, cold, one instance of the same NLP (converged: {bool(sol.success) if sol is not None else None}); the reference's CasADi/IPOPT is not installable",
             "host_cpus": os.cpu_count()}

@@ -31,19 +31,23 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, jobs=None):
-    """Compile every .hip translation unit to an object (in parallel) and link the shared library."""
+def build(force=False, verbose=True, jobs=None, tag=None, extra_flags=()):
+    """Compile every .hip translation unit to an object (in parallel) and link the shared library.
+    tag / extra_flags: a developer variant (tuning sweeps, debug counters) next to the product build - objects in build_<tag>/,
+    library libhilo_hip_<tag>.so, loaded instead of the product library when HILO_LIB_PATH points at it."""
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     headers.append(os.path.join(os.path.dirname(HERE), 'include', 'hilo_hip.h'))
-    objdir = os.path.join(HERE, 'build')
+    objdir = os.path.join(HERE, 'build' if not tag else f'build_{tag}')
+    lib = LIB if not tag else os.path.join(HERE, f'libhilo_hip_{tag}.so')
+    flags = FLAGS + list(extra_flags)
     os.makedirs(objdir, exist_ok=True)
     procs, objs = [], []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src).replace('.hip', '.o'))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+            cmd = [hipcc] + flags + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -52,12 +56,12 @@ def build(force=False, verbose=True, jobs=None):
         if p.returncode != 0:
             sys.stderr.write(out.decode(errors='replace'))
             raise RuntimeError(f'hipcc failed on {src}')
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-lhiprtc', '-ldl']   # hiprtc: run-time compiled user models (csrc/hilo_jit.hip)
+    if force or procs or _stale(lib, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs + ['-lhiprtc', '-ldl']   # hiprtc: run-time compiled user models (csrc/hilo_jit.hip)
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':

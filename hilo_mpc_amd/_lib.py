@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libhilo_hip.so')
+LIB_PATH = os.environ.get('HILO_LIB_PATH') or os.path.join(HERE, 'libhilo_hip.so')   # HILO_LIB_PATH: a developer variant (_build.build(tag=...))
 
 c_double_p = C.c_void_p   # device pointers travel as integers
 c_i64 = C.c_int64
@@ -50,7 +50,8 @@ class NmpcDesc(C.Structure):
                [('user_source', C.c_char_p)] + \
                [(n, C.c_int32) for n in ('user_nx', 'user_nu', 'user_np', 'user_ny', 'user_discrete', 'user_has_fun', 'user_policy',
                                          'objective_continuous')] + \
-               [('coll_B', C.c_void_p), ('n_user_gp', C.c_int32), ('user_nz', C.c_int32), ('user_gp', C.c_void_p * 4)]
+               [('coll_B', C.c_void_p), ('n_user_gp', C.c_int32), ('user_nz', C.c_int32), ('user_gp', C.c_void_p * 4),
+                ('hess_pattern', C.c_void_p), ('max_hessian_perturbation', C.c_double)]
 
 
 class MheDesc(C.Structure):
@@ -59,7 +60,10 @@ class MheDesc(C.Structure):
                [(n, C.c_void_p) for n in ('Wx', 'Wy', 'Ww', 'x_lb', 'x_ub', 'w_lb', 'w_ub', 'x_scaling', 'w_scaling',
                                           'u_scaling', 'x_guess', 'w_guess')] + \
                [('estimate_parameters', C.c_int32), ('reserved', C.c_int32)] + \
-               [(n, C.c_void_p) for n in ('Wp', 'p_lb', 'p_ub', 'p_scaling', 'p_guess')]
+               [(n, C.c_void_p) for n in ('Wp', 'p_lb', 'p_ub', 'p_scaling', 'p_guess')] + \
+               [('user_source', C.c_char_p)] + \
+               [(n, C.c_int32) for n in ('user_nx', 'user_nu', 'user_np', 'user_ny', 'user_discrete', 'collocation_degree')] + \
+               [('coll_A', C.c_void_p), ('coll_D', C.c_void_p)]
 
 
 _lib = None
@@ -94,6 +98,8 @@ def _declare(lib):
         'hilo_nmpc_set_fix_x0': (C.c_int, [vp, i32]),
         'hilo_nmpc_set_x0_box': (C.c_int, [vp, vp, vp]),
         'hilo_nmpc_set_gather': (C.c_int, [vp, vp, i32]),
+        'hilo_nmpc_set_var_bounds': (C.c_int, [vp, vp, vp]),
+        'hilo_kf_steps': (C.c_int, [vp, i64, i32, vp, vp, vp, i64, i64, vp, i64, vp, i64, vp, i32, vp, vp]),
         'hilo_nmpc_solve': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_nmpc_solve_tv': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_nmpc_profile': (C.c_int, [vp, i32, vp]),

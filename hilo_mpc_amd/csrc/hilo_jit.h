@@ -19,6 +19,7 @@ enum JitPolicy : int {
   JIT_TRACK = 0,   // NmpcTrack<UserModel, BIG>          (hilo_nmpc_track.h) - identical code path to the zoo models
   JIT_GEN = 1,     // NmpcGen<UserModel, NTH, NE, NC, BIG> (hilo_nmpc_gen.h): compiles, not used by the host code
   JIT_USER = 2,    // NmpcUser<UserModel, UserFun, UserCfg> (hilo_nmpc_user.h) - the general policy
+  JIT_MHE = 3,     // MheNoise<UserModel, SYM, COLL_D>     (hilo_mhe_policy.h) - moving-horizon estimator with state noise
 };
 
 struct JitRequest {
@@ -49,6 +50,7 @@ void jit_unload(JitKernels* k);
 struct JitKfKernels {
   hipFunction_t f[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   hipFunction_t pf = nullptr;   // particle-filter function of the same model (hilo_kf_kernel.h::pf_body)
+  hipFunction_t multi[2] = {nullptr, nullptr};   // several fused steps per launch (kf_multi_body): [UKF]
   int dims[5] = {0, 0, 0, 0, 0};
 };
 int jit_kf_kernels(const std::string& user_source, int device, JitKfKernels* out, bool compile_only = false);

@@ -143,6 +143,56 @@ extern "C" __global__ void hilo_user_info(int* out) {
   return s;
 }
 
+// The moving-horizon estimator's policy for a model given as source (csrc/hilo_mhe_policy.h): same kernel names as the
+// controllers' unit, so that loading and launching are shared.  v carries the parameter prefix of the reference's layout
+// (mhe.py:614-623): rows of v0 and v_opt are [p (NP) | x | w]; `first` receives x_N un-scaled (mhe.py:381-384).
+static std::string translation_unit_mhe(const JitRequest& r) {
+  char cfg[512];
+  snprintf(cfg, sizeof(cfg), "#define HILO_OCP_TPB 64\n#define HILO_USER_N %d\n#define HILO_USER_COLL_D %d\n#define HILO_USER_SYM %d\n",
+           r.N, r.coll_d, (int)r.sym);
+  std::string s(cfg);
+  s += "#include \"hilo_mhe_policy.h\"\n";
+  s += "extern \"C\" { __device__ const double* hilo_user_gp[4]; }\n";
+  s += "namespace hilo {\n";
+  s += r.user_source;
+  s += R"(
+using PB = MheNoise<UserModel, HILO_USER_SYM, HILO_USER_COLL_D>;
+using EngineT = Ocp<PB>;
+constexpr size_t USER_LDS = EngineT::lds_doubles(HILO_USER_N);
+static_assert(USER_LDS * 8 <= 160 * 1024, "the iterate of this estimation window does not fit the 160 KB of LDS");
+
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void hilo_user_solve(const OcpConst* __restrict__ pcg, int64_t batch, const double* __restrict__ x0, const double* __restrict__ par,
+                     int64_t par_stride, const double* __restrict__ sdata, int64_t sd_stride, const double* __restrict__ v0,
+                     int64_t v0_stride, double* __restrict__ v_opt, double* __restrict__ f_opt, double* __restrict__ lam_g,
+                     double* __restrict__ first, int32_t* __restrict__ status, int32_t* __restrict__ iters, double* __restrict__ kkt,
+                     long long* __restrict__ prof, double* __restrict__ ws, const OcpExtra ex) {
+  __shared__ double lds[USER_LDS];
+  ocp_solve_body<PB, 64>((lds_double*)lds, pcg, batch, x0, par, par_stride, sdata, sd_stride, v0, v0_stride, UserModel::NP,
+                         UserModel::NP, v_opt, f_opt, lam_g, first, 1, status, iters, kkt, prof, ws, ex);
+}
+
+extern "C" __global__ void hilo_user_plant(const OcpConst* __restrict__, int64_t, const double* __restrict__, const double* __restrict__,
+                                           const double* __restrict__, int64_t, double* __restrict__) {}
+
+extern "C" __global__ void hilo_user_coll_out(const OcpConst* __restrict__ pcg, int64_t batch, const double* __restrict__ vc,
+                                              const double* __restrict__ lamc, const double* __restrict__ par, int64_t par_stride,
+                                              const double* __restrict__ sdata, int64_t sd_stride, double* __restrict__ v,
+                                              double* __restrict__ lam_g) {
+#if HILO_USER_COLL_D > 0
+  mhe_coll_output<UserModel, HILO_USER_COLL_D>(pcg, batch, vc, lamc, par, par_stride, sdata, sd_stride, v, lam_g);
+#endif
+}
+
+extern "C" __global__ void hilo_user_info(int* out) {
+  out[0] = UserModel::NX; out[1] = UserModel::NU; out[2] = UserModel::NP; out[3] = UserModel::NY;
+  out[4] = UserModel::DISCRETE ? 1 : 0; out[5] = (int)(USER_LDS * 8); out[6] = PB::NX; out[7] = PB::NU;
+}
+}  // namespace hilo
+)";
+  return s;
+}
+
 struct LoadedModule {
   hipModule_t mod;
   JitKernels k;
@@ -217,7 +267,7 @@ static int unit_code(const std::string& tu, const std::vector<std::string>& opts
 }
 
 int jit_nmpc_kernels(const JitRequest& r, int device, JitKernels* out) {
-  const std::string tu = translation_unit(r);
+  const std::string tu = r.policy == JIT_MHE ? translation_unit_mhe(r) : translation_unit(r);
   std::vector<std::string> opts;
   std::string key, cpath;
   int rc = unit_key(tu, &opts, &key);
@@ -286,6 +336,19 @@ HILO_KF_ENTRY(hilo_user_kf_e2, false, 2)
 HILO_KF_ENTRY(hilo_user_kf_u0, true, 0)
 HILO_KF_ENTRY(hilo_user_kf_u1, true, 1)
 HILO_KF_ENTRY(hilo_user_kf_u2, true, 2)
+#define HILO_KF_MULTI(name, UKF)                                                                                                 \
+  extern "C" __global__ __launch_bounds__(KF_TPB) void name(KfParams kp, int64_t batch, int steps,                              \
+                                                            const double* __restrict__ in_tile, const double* __restrict__ y,   \
+                                                            const double* __restrict__ up, int64_t up_stride, int64_t up_step,  \
+                                                            const double* __restrict__ Q, int64_t q_stride,                     \
+                                                            const double* __restrict__ R, int64_t r_stride,                     \
+                                                            double* __restrict__ out_tile, int64_t out_step,                    \
+                                                            double* __restrict__ y_pred, int ipw) {                             \
+    kf_multi_body<UserModel, UKF>(kp, batch, steps, in_tile, y, up, up_stride, up_step, Q, q_stride, R, r_stride, out_tile,      \
+                                  out_step, y_pred, ipw);                                                                        \
+  }
+HILO_KF_MULTI(hilo_user_kf_em, false)
+HILO_KF_MULTI(hilo_user_kf_um, true)
 extern "C" __global__ __launch_bounds__(PF_TPB) void hilo_user_pf(KfParams kp, int n, const double* __restrict__ X,
                                                                   const double* __restrict__ y, const double* __restrict__ up,
                                                                   int64_t up_stride, const double* __restrict__ w,
@@ -325,6 +388,8 @@ extern "C" __global__ void hilo_user_kf_info(int* o) {
   for (int u = 0; u < 2; ++u)
     for (int m = 0; m < 3; ++m) HILO_HIP_CHECK(hipModuleGetFunction(&k.f[u][m], mod, names[u][m]));
   HILO_HIP_CHECK(hipModuleGetFunction(&k.pf, mod, "hilo_user_pf"));
+  HILO_HIP_CHECK(hipModuleGetFunction(&k.multi[0], mod, "hilo_user_kf_em"));
+  HILO_HIP_CHECK(hipModuleGetFunction(&k.multi[1], mod, "hilo_user_kf_um"));
   hipFunction_t info = nullptr;
   HILO_HIP_CHECK(hipModuleGetFunction(&info, mod, "hilo_user_kf_info"));
   int* dinfo = nullptr;

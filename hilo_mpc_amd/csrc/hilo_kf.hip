@@ -36,6 +36,23 @@ int dispatch_kind(int mode, const KfParams& kp, int64_t batch, const double* in,
   return launch<M, false, 2>(kp, batch, in, y, up, us, Q, qs, R, rs, out, yp, s);
 }
 
+template <class M>
+int launch_multi(const KfParams& kp, int64_t batch, int steps, const double* in, const double* y, const double* up, int64_t us,
+                 int64_t ustep, const double* Q, int64_t qs, const double* R, int64_t rs, double* out, int64_t ostep, double* yp,
+                 hipStream_t s) {
+  int64_t ipw = (batch + 1023) / 1024;       // same instance split as the single step
+  ipw = ipw < 16 ? 16 : (ipw > KF_TPB ? KF_TPB : ipw);
+  const unsigned grid = (unsigned)((batch + ipw - 1) / ipw);
+  if (kp.kind == HILO_KF_UKF)
+    hipLaunchKernelGGL((kf_multi_kernel<M, true>), dim3(grid), dim3(KF_TPB), 0, s, kp, batch, steps, in, y, up, us, ustep, Q, qs, R,
+                       rs, out, ostep, yp, (int)ipw);
+  else
+    hipLaunchKernelGGL((kf_multi_kernel<M, false>), dim3(grid), dim3(KF_TPB), 0, s, kp, batch, steps, in, y, up, us, ustep, Q, qs, R,
+                       rs, out, ostep, yp, (int)ipw);
+  HILO_HIP_CHECK(hipGetLastError());
+  return HILO_OK;
+}
+
 }  // namespace hilo
 
 using namespace hilo;
@@ -225,6 +242,50 @@ extern "C" int hilo_kf_step(hilo_kf* kf, int64_t batch, const double* xP, const 
                             int64_t up_stride, const double* Q, int64_t q_stride, const double* R, int64_t r_stride,
                             double* xP_out, double* y_pred, void* stream) {
   return kf_run(kf, 2, batch, xP, y, up, up_stride, Q, q_stride, R, r_stride, xP_out, y_pred, stream);
+}
+
+// `steps` fused estimate() steps in one launch: the reference's `self._function.mapaccum(steps)` (kf.py:296-306)
+extern "C" int hilo_kf_steps(hilo_kf* kf, int64_t batch, int steps, const double* xP, const double* y, const double* up,
+                             int64_t up_stride, int64_t up_step_stride, const double* Q, int64_t q_stride, const double* R,
+                             int64_t r_stride, double* xP_out, int keep_all, double* y_pred, void* stream) {
+  HILO_REQUIRE(kf, "hilo_kf_steps: NULL handle");
+  HILO_REQUIRE(batch >= 0 && steps >= 1, "hilo_kf_steps: need batch >= 0 and steps >= 1");
+  if (batch == 0) return HILO_OK;
+  HILO_REQUIRE(xP && xP_out && y && y_pred && Q && R, "hilo_kf_steps: NULL argument");
+  HILO_REQUIRE(kf->nu + kf->np == 0 || up, "hilo_kf_steps: the model has %d inputs/parameters but `up` is NULL", kf->nu + kf->np);
+  HILO_REQUIRE(up_stride == 0 || up_stride >= kf->nu + kf->np, "hilo_kf_steps: up_stride %lld < nu+np", (long long)up_stride);
+  HILO_REQUIRE(q_stride == 0 || q_stride >= kf->nx * kf->nx, "hilo_kf_steps: bad q_stride");
+  HILO_REQUIRE(r_stride == 0 || r_stride >= kf->ny * kf->ny, "hilo_kf_steps: bad r_stride");
+  HILO_HIP_CHECK(hipSetDevice(kf->device));
+  hipStream_t s = (hipStream_t)stream;
+  const KfParams& kp = kf->kp;
+  static const double zero = 0.0;
+  if (!up) up = &zero;
+  const int64_t ostep = keep_all ? batch * (int64_t)kf->nx * (kf->nx + 1) : 0;
+  if (kf->desc.model_id == 100 /* HILO_MODEL_USER */) {
+    hipFunction_t f = kf->jit.multi[kp.kind == HILO_KF_UKF ? 1 : 0];
+    HILO_REQUIRE(f, "hilo_kf_steps: the run-time compiled filter kernels are not loaded");
+    int64_t ipw = (batch + 1023) / 1024;
+    ipw = ipw < 16 ? 16 : (ipw > KF_TPB ? KF_TPB : ipw);
+    int ipw_i = (int)ipw;
+    const unsigned grid = (unsigned)((batch + ipw - 1) / ipw);
+    KfParams kpv = kp;
+    int64_t ostep_v = ostep;
+    void* args[] = {&kpv, &batch, &steps, &xP, &y, &up, &up_stride, &up_step_stride, &Q, &q_stride, &R, &r_stride, &xP_out, &ostep_v,
+                    &y_pred, &ipw_i};
+    HILO_HIP_CHECK(hipModuleLaunchKernel(f, grid, 1, 1, KF_TPB, 1, 1, 0, s, args, nullptr));
+    return HILO_OK;
+  }
+  switch (kf->desc.model_id) {
+#define X(ID, T) case ID: return launch_multi<T>(kp, batch, steps, xP, y, up, up_stride, up_step_stride, Q, q_stride, R, r_stride, xP_out, ostep, y_pred, s);
+    HILO_KF_MODELS(X)
+#undef X
+    case HILO_MODEL_LTI:
+      if (kf->nx == 2 && kf->ny == 1) return launch_multi<Lti<2, 1, 1>>(kp, batch, steps, xP, y, up, up_stride, up_step_stride, Q, q_stride, R, r_stride, xP_out, ostep, y_pred, s);
+      if (kf->nx == 2 && kf->ny == 2) return launch_multi<Lti<2, 1, 2>>(kp, batch, steps, xP, y, up, up_stride, up_step_stride, Q, q_stride, R, r_stride, xP_out, ostep, y_pred, s);
+      return launch_multi<Lti<4, 2, 2>>(kp, batch, steps, xP, y, up, up_stride, up_step_stride, Q, q_stride, R, r_stride, xP_out, ostep, y_pred, s);
+  }
+  return fail(HILO_EINVAL, "unknown model id %d", kf->desc.model_id);
 }
 
 // ---- particle filter (pf.py): the propagate / measure / weigh function of the reference's setup(), and the resampling gather ----

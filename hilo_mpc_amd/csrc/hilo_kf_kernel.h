@@ -409,6 +409,83 @@ __global__ __launch_bounds__(KF_TPB) KF_OCC void kf_kernel(KfParams kp, int64_t 
   kf_body<M, UKF, MODE>(kp, batch, in_tile, y, up, up_stride, Q, q_stride, R, r_stride, out_tile, y_pred, ipw);
 }
 
+// ---- several filter steps in ONE launch: `self._function.mapaccum(steps)` of the reference (kf.py:296-306) -----------------------
+// The packed tile is loaded once, `steps` fused predict + update steps run in registers - measurements y [steps][B][ny], inputs
+// either the same every step or [steps][B][nu+np] (up_step = elements between two steps) - and the tile of every step (the
+// reference's accumulated output) or only the last one goes back; y_pred [steps][B][ny].  A filter step at the BASELINE batch
+// (4096 instances = 1.6 MB) is launch-latency bound; K steps per launch divide that latency by K and, with only the last tile
+// written, move 8 (ny + nu + np + ny) bytes per step instead of the tile both ways.
+template <class M, bool UKF>
+__device__ __forceinline__ void kf_multi_body(const KfParams& kp, int64_t batch, int steps, const double* __restrict__ in_tile,
+                                              const double* __restrict__ y, const double* __restrict__ up, int64_t up_stride,
+                                              int64_t up_step, const double* __restrict__ Q, int64_t q_stride,
+                                              const double* __restrict__ R, int64_t r_stride, double* __restrict__ out_tile,
+                                              int64_t out_step, double* __restrict__ y_pred, int ipw) {
+  constexpr int NX = M::NX, NY = M::NY, NUP = M::NU + M::NP, NS = 2 * NX + 1;
+  constexpr int XP = NX * (NX + 1), W = NX + 1;
+  __shared__ double lds[KF_TPB * TilePitch<XP>::value];
+  const int64_t first = (int64_t)blockIdx.x * ipw;
+  const int count = (int)((batch - first) < ipw ? (batch - first) : ipw);
+  const int64_t inst = first + threadIdx.x;
+  const bool active = (int)threadIdx.x < count;
+  double tin[XP];
+  tile_load<XP, KF_TPB>(in_tile, first, count, lds, tin);
+  double x[NX], P[NX * NX], X[UKF ? NX * NS : 1], upv[MaxOne<NUP>::v], yv[NY], ypv[NY], Qv[NX * NX], Rv[NY * NY];
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      x[i] = tin[i * W];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) P[i * NX + j] = tin[i * W + 1 + j];
+    }
+    vec_load<NX * NX>(Q, inst, q_stride, Qv);
+    vec_load<NY * NY>(R, inst, r_stride, Rv);
+    if constexpr (NUP > 0) vec_load<NUP>(up, inst, up_stride, upv);
+  }
+  for (int s = 0; s < steps; ++s) {
+    if (active) {
+      if constexpr (NUP > 0) {
+        if (s > 0 && up_step != 0) vec_load<NUP>(up + (int64_t)s * up_step, inst, up_stride, upv);
+      }
+      const double* u = upv;
+      const double* p = upv + M::NU;
+      vec_load<NY>(y + (int64_t)s * batch * NY, inst, NY, yv);
+      if constexpr (UKF) {
+        ukf_predict<M>(kp, x, P, X, u, p, Qv);
+        ukf_update<M>(kp, x, P, X, yv, u, p, Rv, ypv);
+      } else {
+        ekf_predict<M>(kp, x, P, u, p, Qv);
+        ekf_update<M>(kp, x, P, yv, u, p, Rv, ypv);
+      }
+#pragma unroll
+      for (int a = 0; a < NY; ++a) y_pred[((int64_t)s * batch + inst) * NY + a] = ypv[a];
+    }
+    if (out_step != 0 || s == steps - 1) {   // wave-uniform: every lane takes part in the staged store
+      double tout[XP];
+      if (active) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          tout[i * W] = x[i];
+#pragma unroll
+          for (int j = 0; j < NX; ++j) tout[i * W + 1 + j] = P[i * NX + j];
+        }
+      }
+      tile_store<XP, KF_TPB>(out_tile + (int64_t)s * out_step, first, count, lds, tout);
+    }
+  }
+}
+
+template <class M, bool UKF>
+__global__ __launch_bounds__(KF_TPB) KF_OCC void kf_multi_kernel(KfParams kp, int64_t batch, int steps,
+                                                                 const double* __restrict__ in_tile, const double* __restrict__ y,
+                                                                 const double* __restrict__ up, int64_t up_stride, int64_t up_step,
+                                                                 const double* __restrict__ Q, int64_t q_stride,
+                                                                 const double* __restrict__ R, int64_t r_stride,
+                                                                 double* __restrict__ out_tile, int64_t out_step,
+                                                                 double* __restrict__ y_pred, int ipw) {
+  kf_multi_body<M, UKF>(kp, batch, steps, in_tile, y, up, up_stride, up_step, Q, q_stride, R, r_stride, out_tile, out_step, y_pred, ipw);
+}
+
 // ---- particle filter (hilo_mpc/modules/estimator/pf.py) ----------------------------------------------------------------------
 // The function the reference assembles at setup() (`_propagate_particles` :103-146, `_evaluate_likelihood` :148-166, `setup`
 // :300-318) and calls once per estimate (:372):

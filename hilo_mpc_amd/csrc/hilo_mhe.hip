@@ -9,95 +9,17 @@
 //   J   = arrival(x_0) at k = 0; (h(x_k)-y_k)^T Wy (.) + w_k^T Ww w_k, k >= 1  mhe.py:742-748 (no stage cost at k = 0)
 //   costs act on un-scaled quantities (hilo_mpc/util/modeling.py:665-672)
 // In engine terms: controls := the noise w_k (B_k = I), x_0 free, per-stage data = (u_meas_k, y_meas_k).
+// Round 3: models written as expressions and the collocation transcription (the reference's default, mhe.py:512-561) go
+// through the run-time compiled policy (hilo_jit.hip, JIT_MHE: desc.user_source) - the zoo models too when collocation is asked
+// for; the policy itself lives in hilo_mhe_policy.h.
 #include <stdlib.h>
 #include <string.h>
 
+#include "hilo_jit.h"
 #include "hilo_mhe_est.h"
-#include "hilo_ocp.h"
+#include "hilo_mhe_policy.h"
 
 namespace hilo {
-
-// pc.cost = [Wx | Wy | Ww | su];  par = [model parameters | x_arrival];  sd_k = [u_meas_k | y_meas_k]
-// SYM_: model / measurement derivatives from generated symbolic code when the model has it (the host selects SYM_ = false for
-// sub-stepped integration)
-template <class M, bool SYM_ = true>
-struct MheNoise {
-  using Model = M;
-  static constexpr bool SYM_MHE = SYM_ && ModelSym<M>::value && ModelSym<M>::HAS_MEAS && !model_has_ext<M>::value &&
-                                  !M::DISCRETE && M::NX % 2 == 0;
-  static constexpr int NX = M::NX, NU = M::NX, NY = M::NY, MU = M::NU, NPAR = M::NP + M::NX, NSD = M::NU + M::NY;
-  static constexpr bool FIX_X0 = false;
-  static constexpr bool BIG = false;  // iterate in LDS
-  static constexpr int NC = 0, NXV = NX, NX0 = NX, NU0 = NU;  // no inequality rows; plain [x | u] decision vector
-  static constexpr bool COOP = model_has_ext<M>::value;
-  static constexpr bool QUAD_COST = false;  // the measurement function may be nonlinear: Taylor evaluation
-  static constexpr int O_WX = 0, O_WY = O_WX + NX * NX, O_WW = O_WY + NY * NY, O_SU = O_WW + NX * NX, O_END = O_SU + MU;
-  static constexpr int NCOST = O_END;
-
-  template <class T, class E>
-  __device__ __forceinline__ static void dyn(const OcpConst& pc, const double* par, const double* sd, int, const T* x,
-                                             const T* w, T* xn, const E& ext) {
-    T xp[NX], xo[NX];
-    double ue[MU > 0 ? MU : 1];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xp[i] = x[i] * pc.sz[i];
-#pragma unroll
-    for (int i = 0; i < MU; ++i) ue[i] = sd[i] * pc.cost[O_SU + i];
-    model_step<M>(pc.order, pc.nsub, xp, ue, par, pc.dt, xo, ext);
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]) + w[i];  // mhe.py:739: scaled noise, scaled state
-  }
-
-  template <class T>
-  __device__ __forceinline__ static T stage_cost(const OcpConst& pc, const double* par, const double* sd, int k,
-                                                 const T* x, const T* w) {
-    T xp[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xp[i] = x[i] * pc.sz[i];
-    T acc = T(0.0);
-    if (k == 0) {  // arrival cost (modeling.py:747-777); mhe.py:742-745
-      T d[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) d[i] = xp[i] - par[M::NP + i];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        T s = T(0.0);
-#pragma unroll
-        for (int j = 0; j < NX; ++j) s = s + pc.cost[O_WX + i * NX + j] * d[j];
-        acc = acc + d[i] * s;
-      }
-      return acc;
-    }
-    double ue[MU > 0 ? MU : 1];
-#pragma unroll
-    for (int i = 0; i < MU; ++i) ue[i] = sd[i] * pc.cost[O_SU + i];
-    T yv[NY], r[NY];
-    M::meas(xp, ue, par, pc.dt, yv);
-#pragma unroll
-    for (int a = 0; a < NY; ++a) r[a] = yv[a] - sd[MU + a];
-#pragma unroll
-    for (int a = 0; a < NY; ++a) {
-      T s = T(0.0);
-#pragma unroll
-      for (int b = 0; b < NY; ++b) s = s + pc.cost[O_WY + a * NY + b] * r[b];
-      acc = acc + r[a] * s;
-    }
-    T ws[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) ws[i] = w[i] * pc.sz[NX + i];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      T s = T(0.0);
-#pragma unroll
-      for (int j = 0; j < NX; ++j) s = s + pc.cost[O_WW + i * NX + j] * ws[j];
-      acc = acc + ws[i] * s;
-    }
-    return acc;
-  }
-
-  template <class T>
-  __device__ __forceinline__ static T term_cost(const OcpConst&, const double*, const double*, const T*) { return T(0.0); }
-};
 
 // par[b] = [p_b | x_arrival_b];  sd[b][k] = [u_meas[b][k] | y_meas[b][k]] for k < N, zeros for k = N
 __global__ void mhe_pack_kernel(int64_t batch, int N, int np, int nx, int nu, int ny, const double* __restrict__ p,
@@ -129,9 +51,12 @@ struct hilo_mhe {
   OcpConst host;
   OcpConst* dev;
   double *v_guess, *v_warm, *par_buf, *sd_buf;
-  int64_t warm_batch, buf_batch;
+  int64_t warm_batch, buf_batch, vc_batch;
   int warm_valid;
   size_t lds_bytes;
+  JitKernels jit;                    // run-time compiled policy (desc.user_source) or empty
+  int use_jit, coll_d, n_vc;         // n_vc: row length of the engine's result [p | x | w] (= n_v without the collocation block)
+  double *vc, *lamc;                 // collocation: the engine's result before the output pass
   const MheEstVariant* est;          // parameter-estimating variant or NULL
   double *x0e, *v0e, *ve, *lame, *v_guess_e;   // engine-layout buffers of the estimating variant
   unsigned est_mask;                 // bit j: parameter j is a variable
@@ -153,7 +78,8 @@ static int mhe_model_dims(int id, int* nx, int* nu, int* np, int* ny, size_t* ld
 extern "C" void hilo_mhe_destroy(hilo_mhe* h) {
   if (!h) return;
   double* ptrs[] = {(double*)h->dev, h->v_guess, h->v_warm, h->par_buf, h->sd_buf, h->x0e, h->v0e, h->ve, h->lame,
-                    h->v_guess_e};
+                    h->v_guess_e, h->vc, h->lamc};
+  jit_unload(&h->jit);
   for (double* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -164,11 +90,34 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
   HILO_REQUIRE(d->N >= 2 && d->N <= 512, "hilo_mhe_create: horizon %d out of range [2, 512]", d->N);
   HILO_REQUIRE(d->dt > 0.0, "hilo_mhe_create: dt must be positive");
   int nx, nu, np, ny;
-  size_t lds;
-  int rc = mhe_model_dims(d->model_id, &nx, &nu, &np, &ny, &lds, d->N);
-  if (rc) return rc;
+  size_t lds = 0;
+  int rc = HILO_OK;
+  const bool jit = d->user_source != nullptr;
+  const int D = d->collocation_degree;
+  HILO_REQUIRE(D >= 0 && D <= COLL_MAXD, "hilo_mhe_create: collocation degree %d out of range [0, %d]", D, COLL_MAXD);
+  HILO_REQUIRE(!D || (d->coll_A && d->coll_D), "hilo_mhe_create: collocation needs the basis (coll_A, coll_D)");
+  if (jit) {
+    // dimensions: the description's (model written as expressions) or the zoo's (desc.user_source = alias of the zoo functor)
+    if (d->model_id == HILO_MODEL_USER) {
+      nx = d->user_nx; nu = d->user_nu; np = d->user_np; ny = d->user_ny;
+      HILO_REQUIRE(nx >= 1 && nu >= 0 && np >= 0 && ny >= 1, "hilo_mhe_create: bad user model dimensions");
+      HILO_REQUIRE(2 * nx <= OCP_MAXNZ && nx <= OCP_MAXNU, "hilo_mhe_create: %d states exceed this build's estimator (%d)", nx, OCP_MAXNU);
+    } else {
+      int disc = 0;
+      rc = hilo_model_dims(d->model_id, &nx, &nu, &np, &ny, &disc);
+      if (rc) return rc;
+    }
+    if (d->estimate_parameters && np > 0)
+      return fail(HILO_ENOTSUP, "parameter estimation on the run-time compiled estimator is not built (zoo models with "
+                                "integration_method 'discrete' have it)");
+  } else {
+    HILO_REQUIRE(d->model_id != HILO_MODEL_USER, "hilo_mhe_create: HILO_MODEL_USER needs desc.user_source");
+    if (D) return fail(HILO_ENOTSUP, "the collocation transcription runs on the run-time compiled policy: pass desc.user_source");
+    rc = mhe_model_dims(d->model_id, &nx, &nu, &np, &ny, &lds, d->N);
+    if (rc) return rc;
+  }
   const MheEstVariant* ev = nullptr;
-  if (d->estimate_parameters && np > 0) {
+  if (!jit && d->estimate_parameters && np > 0) {
     ev = mhe_est_find(d->model_id);
     if (!ev) return fail(HILO_ENOTSUP, "model id %d has no parameter-estimating MHE instantiation in this build", d->model_id);
     lds = ev->lds_bytes(d->N);
@@ -178,13 +127,21 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
   memset(h, 0, sizeof(*h));
   h->est = ev;
   h->device = device; h->model_id = d->model_id; h->nx = nx; h->nu = nu; h->np = np; h->ny = ny; h->N = d->N;
-  h->n_v = np + (d->N + 1) * nx + d->N * nx;  // mhe.py:596-598
-  h->n_g = d->N * nx;
+  h->n_vc = np + (d->N + 1) * nx + d->N * nx;               // mhe.py:596-598
+  h->n_v = h->n_vc + d->N * D * nx;                          // + collocation states (mhe.py:600-601)
+  h->n_g = d->N * (nx + D * nx);                             // per stage [collocation rows | continuity] (mhe.py:728, :740)
   h->lds_bytes = lds;
+  h->use_jit = jit ? 1 : 0;
+  h->coll_d = D;
   OcpConst& c = h->host;
   memset(&c, 0, sizeof(c));
   ocp_default_options(c);
   c.N = d->N; c.Nc = d->N; c.order = d->erk_order >= 1 ? d->erk_order : 4; c.nsub = d->n_sub >= 1 ? d->n_sub : 1; c.dt = d->dt;
+  if (D) {
+    c.coll.d = D;
+    for (int i = 0; i < D * D; ++i) c.coll.A[i] = d->coll_A[i];
+    for (int i = 0; i <= D; ++i) { c.coll.Dc[i] = d->coll_D[i]; c.coll.Bq[i] = 0.0; }
+  }
   if (d->max_iter > 0) c.max_iter = d->max_iter;
   if (d->acceptable_iter > 0) c.acceptable_iter = d->acceptable_iter;
   if (d->tol > 0) c.tol = d->tol;
@@ -202,6 +159,7 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
     for (int i = 0; i < nu; ++i) *q++ = d->u_scaling ? d->u_scaling[i] : 1.0;
   }
   const double relax = d->bound_relax_factor >= 0.0 ? d->bound_relax_factor : 1e-8;
+  c.bound_relax = relax;
   for (int i = 0; i < 2 * nx; ++i) {
     const double* lbs = i < nx ? d->x_lb : d->w_lb;
     const double* ubs = i < nx ? d->x_ub : d->w_ub;
@@ -249,6 +207,20 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
       }
     }
   }
+  if (jit) {
+    JitRequest rq;
+    rq.user_source = d->user_source;
+    rq.policy = JIT_MHE;
+    rq.coll_d = D; rq.N = d->N;
+    rq.sym = c.nsub == 1 && !getenv("HILO_NMPC_TAYLOR");
+    rc = jit_nmpc_kernels(rq, device, &h->jit);
+    if (!rc && getenv("HILO_JIT_COMPILE_ONLY")) { delete h; return HILO_COMPILED_ONLY; }   // cache warmed, no handle
+    if (!rc && (h->jit.dims[0] != nx || h->jit.dims[1] != nu || h->jit.dims[2] != np || h->jit.dims[3] != ny))
+      rc = fail(HILO_EINVAL, "hilo_mhe_create: the compiled model has (nx, nu, np, ny) = (%d, %d, %d, %d); the description says "
+                             "(%d, %d, %d, %d)", h->jit.dims[0], h->jit.dims[1], h->jit.dims[2], h->jit.dims[3], nx, nu, np, ny);
+    if (rc) { delete h; return rc; }
+    h->lds_bytes = (size_t)h->jit.dims[5];
+  }
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc((void**)&h->dev, sizeof(OcpConst));
   if (e == hipSuccess) e = hipMemcpy(h->dev, &c, sizeof(OcpConst), hipMemcpyHostToDevice);
@@ -266,14 +238,18 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
     if (e == hipSuccess) e = hipMemcpy(h->v_guess_e, g, sizeof(double) * nve, hipMemcpyHostToDevice);
     delete[] g;
   }
-  const int nvf = h->n_v - np;  // [x-block | w-block]
+  // tiled guess row; the run-time compiled kernel reads every start row behind a parameter prefix ([p | x | w]), the
+  // zoo kernels take the guess without one
+  const int gpre = jit ? np : 0;
+  const int nvf = gpre + h->n_vc - np;
   if (e == hipSuccess) e = hipMalloc((void**)&h->v_guess, sizeof(double) * nvf);
   if (e == hipSuccess) {
     double* g = new double[nvf];  // mhe.py:633-649: tiled guesses, scaled (mhe.py:229-236)
+    for (int i = 0; i < gpre; ++i) g[i] = 0.0;
     for (int k = 0; k <= d->N; ++k)
-      for (int i = 0; i < nx; ++i) g[k * nx + i] = (d->x_guess ? d->x_guess[i] : 0.0) / c.sz[i];
+      for (int i = 0; i < nx; ++i) g[gpre + k * nx + i] = (d->x_guess ? d->x_guess[i] : 0.0) / c.sz[i];
     for (int k = 0; k < d->N; ++k)
-      for (int i = 0; i < nx; ++i) g[(d->N + 1) * nx + k * nx + i] = (d->w_guess ? d->w_guess[i] : 0.0) / c.sz[nx + i];
+      for (int i = 0; i < nx; ++i) g[gpre + (d->N + 1) * nx + k * nx + i] = (d->w_guess ? d->w_guess[i] : 0.0) / c.sz[nx + i];
     e = hipMemcpy(h->v_guess, g, sizeof(double) * nvf, hipMemcpyHostToDevice);
     delete[] g;
   }
@@ -404,6 +380,28 @@ extern "C" int hilo_mhe_estimate(hilo_mhe* h, int64_t batch, const double* x_arr
     else { vstart = h->v_guess; vstride = 0; prefix = 0; }
   }
   int rc = HILO_ENOTSUP;
+  if (h->use_jit) {
+    double *vdst = v_opt, *ldst = lam_g;
+    if (h->coll_d) {   // the engine's result goes to buffers of the handle; the output pass writes the reference's layout
+      if (!h->vc || h->vc_batch != batch || !h->lamc) {
+        if (h->vc) HILO_HIP_CHECK(hipFree(h->vc));
+        if (h->lamc) HILO_HIP_CHECK(hipFree(h->lamc));
+        h->vc = h->lamc = nullptr;
+        hipError_t e = hipMalloc((void**)&h->vc, sizeof(double) * (size_t)h->n_vc * batch);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->lamc, sizeof(double) * (size_t)h->N * h->nx * batch);
+        if (e != hipSuccess) return fail(HILO_ENOMEM, "MHE buffers: %s", hipGetErrorString(e));
+        h->vc_batch = batch;
+      }
+      vdst = h->vc; ldst = h->lamc;
+    }
+    // every start row carries the parameter prefix (the tiled guess has a dummy one): v0_prefix = v_prefix = np in the kernel
+    rc = jit_launch_solve(h->jit.solve, h->dev, batch, nullptr, h->par_buf, (int64_t)wp, h->sd_buf,
+                          (int64_t)((h->N + 1) * ws), vstart, vstride, vdst, f_opt, ldst, x_opt, status, iters, kkt,
+                          nullptr, nullptr, s, OcpExtra());
+    if (!rc && h->coll_d)
+      rc = jit_launch_coll_out(h->jit.coll_out, h->dev, batch, h->N, h->vc, h->lamc, h->par_buf, (int64_t)wp, h->sd_buf,
+                               (int64_t)((h->N + 1) * ws), v_opt, lam_g, s);
+  } else
   switch (h->model_id) {
 #define X(ID, T) case ID: rc = mhe_launch<T>(h, batch, vstart, vstride, prefix, v_opt, f_opt, lam_g, x_opt, status, iters, kkt, s); break;
     HILO_MHE_MODELS(X)

@@ -258,6 +258,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   for (int i = 0; i < nx; ++i) c.sz[i] = sx[i];
   for (int i = 0; i < nu; ++i) c.sz[nxe + i] = su[i];
   const double relax = d->bound_relax_factor >= 0.0 ? d->bound_relax_factor : 1e-8;
+  c.bound_relax = relax;
   auto relaxed_lb = [&](double lb) { return lb > -INFINITY ? lb - relax * fmax(1.0, fabs(lb)) : lb; };
   auto relaxed_ub = [&](double ub) { return ub < INFINITY ? ub + relax * fmax(1.0, fabs(ub)) : ub; };
   if (!gv) {
@@ -376,6 +377,7 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
   if (d->tol > 0) c.tol = d->tol;
   if (d->acceptable_tol > 0) c.acceptable_tol = d->acceptable_tol;
   if (d->mu_init > 0) c.mu_init = d->mu_init;
+  if (d->max_hessian_perturbation > 0) c.delta_w_max = d->max_hessian_perturbation;
   hipError_t e = hipSetDevice(device);
   if (d->model_id == HILO_MODEL_CHEMOSTAT4_GP) {
     // dynamic_model.py:3040-3125: the label `mu` is replaced by the posterior mean over the features (S, I)
@@ -497,6 +499,17 @@ extern "C" int hilo_nmpc_set_aux_outputs(hilo_nmpc* h, double* g, double* lam_x)
   return HILO_OK;
 }
 
+extern "C" int hilo_nmpc_set_var_bounds(hilo_nmpc* h, const double* lbx, const double* ubx) {
+  HILO_REQUIRE(h, "hilo_nmpc_set_var_bounds: NULL handle");
+  HILO_REQUIRE((lbx == nullptr) == (ubx == nullptr), "hilo_nmpc_set_var_bounds: pass both bound arrays or neither");
+  if (lbx && (h->tv || h->coll))
+    return fail(HILO_ENOTSUP, "hilo_nmpc_set_var_bounds: the precompiled per-stage-data / collocation variants take their bounds "
+                              "from the description; the run-time compiled route (desc.user_source) takes them per call");
+  h->var_lb = lbx;
+  h->var_ub = ubx;
+  return HILO_OK;
+}
+
 extern "C" int hilo_nmpc_set_gather(hilo_nmpc* h, double* table, int stride) {
   HILO_REQUIRE(h, "hilo_nmpc_set_gather: NULL handle");
   HILO_REQUIRE(!table || stride >= h->nu + 2, "hilo_nmpc_set_gather: stride %d < nu + 2", stride);
@@ -604,6 +617,9 @@ static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const 
     ex.lam_x = h->aux_lam_x;
     ex.g = lam_g ? h->aux_g : nullptr;
   }
+  ex.lbx = h->var_lb;
+  ex.ubx = h->var_ub;
+  ex.bx_stride = h->n_v;
   const double* par_arg = direct ? (p ? p : x0) : h->par_buf;   // np == 0: never dereferenced
   const int64_t par_stride_arg = direct ? p_stride : (int64_t)w;
   // initial guess: explicit v0, else the previous solution (warm start, mpc.py:725-726), else the tiled guess
@@ -674,6 +690,7 @@ static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const 
                     status, iters, kkt, h->prof, h->lds_bytes, s, h->ws};
     a.ex.lam_x = ex.lam_x;
     a.ex.g = ex.g;
+    a.ex.lbx = ex.lbx; a.ex.ubx = ex.ubx; a.ex.bx_stride = ex.bx_stride;
     rc = h->gen ? h->gen->launch(a) : h->big->launch(a);
   } else {
     switch (h->model_id) {

@@ -43,6 +43,7 @@ struct hilo_nmpc {
   double* aux_lam_x;
   double* gather;            // caller's gather table (hilo_nmpc_set_gather) or NULL
   int gather_stride;
+  const double *var_lb, *var_ub;   // per-call lbx / ubx rows [B][n_v] of the next solves (hilo_nmpc_set_var_bounds) or NULL
 };
 
 

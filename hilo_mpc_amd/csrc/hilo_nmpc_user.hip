@@ -143,6 +143,7 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   if (d->tol > 0) c.tol = d->tol;
   if (d->acceptable_tol > 0) c.acceptable_tol = d->acceptable_tol;
   if (d->mu_init > 0) c.mu_init = d->mu_init;
+  if (d->max_hessian_perturbation > 0) c.delta_w_max = d->max_hessian_perturbation;
   double sx[OCP_MAXNX], su[OCP_MAXNU];
   copy_or1(sx, d->x_scaling, mx, 1.0);
   copy_or1(su, d->u_scaling, mu, 1.0);
@@ -150,6 +151,7 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   for (int i = 0; i < mx; ++i) c.sz[i] = sx[i];
   for (int i = 0; i < mu; ++i) c.sz[nxe + i] = su[i];
   const double relax = d->bound_relax_factor >= 0.0 ? d->bound_relax_factor : 1e-8;
+  c.bound_relax = relax;
   auto relaxed_lb = [&](double lb) { return lb > -INFINITY ? lb - relax * fmax(1.0, fabs(lb)) : lb; };
   auto relaxed_ub = [&](double ub) { return ub < INFINITY ? ub + relax * fmax(1.0, fabs(ub)) : ub; };
   // ---- cost block (UserLayout): model z index -> augmented z index [x, theta | u, u_theta]
@@ -206,6 +208,27 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
     c.cost[L.o_trowx + r] = trow_expr[r]; c.cost[L.o_trows + r] = trow_sign[r]; c.cost[L.o_trowe + r] = trow_e[r];
     c.dlb[nrow + r] = relaxed_lb(trow_lb[r]); c.dub[nrow + r] = relaxed_ub(trow_ub[r]);
     c.trow_ref[r] = (short)trow_ref[r];
+  }
+  // ---- structural sparsity of the interval Hessian (desc.hess_pattern over the augmented model z): which pair directions the
+  // Taylor sweeps visit.  Engine-only variables: the shared slacks couple only through off-diagonal penalty weights (rows are
+  // linear in them); held inputs stand in for the inputs beyond the control horizon - kept dense.
+  if (d->hess_pattern && !hold) {
+    for (auto& w : c.pair_mask) w = 0ull;
+    auto set_pair = [&](int i, int j) {   // engine indices
+      if (i == j) return;
+      const int a = i < j ? i : j, b = i < j ? j : i;
+      const int p = a * (nz - 1) - a * (a - 1) / 2 + (b - a - 1);   // dir_of(a, b, nz) - nz
+      if (p < 256) c.pair_mask[p >> 6] |= 1ull << (p & 63);
+    };
+    auto eng = [&](int a) { return a < mxa ? a : nxe + (a - mxa); };
+    for (int a = 0; a < mza; ++a)
+      for (int b = a + 1; b < mza; ++b)
+        if (d->hess_pattern[a * mza + b] || d->hess_pattern[b * mza + a]) set_pair(eng(a), eng(b));
+    for (int a = 0; a < ne; ++a)
+      for (int b = a + 1; b < ne; ++b)
+        if (c.cost[L.o_we + a * ne + b] != 0.0 || c.cost[L.o_we + b * ne + a] != 0.0 || c.cost[L.o_wet + a * ne + b] != 0.0 ||
+            c.cost[L.o_wet + b * ne + a] != 0.0)
+          set_pair(mxa + a, mxa + b);
   }
   for (int i = mx; i < mxa + ne; ++i) c.x0_free_mask |= 1u << i;           // theta_0 and the slacks are variables (mpc.py:785-789)
   for (int a = 0; a < ne; ++a) c.k0_only_mask |= 1u << (mxa + a);          // one box per shared slack

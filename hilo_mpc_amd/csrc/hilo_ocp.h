@@ -23,7 +23,7 @@ namespace hilo {
 
 constexpr int OCP_MAXNX = 12, OCP_MAXNU = 8, OCP_MAXNZ = OCP_MAXNX + OCP_MAXNU;
 constexpr int OCP_FILTER = 16;
-constexpr int OCP_MAXNC = 8;  // nonlinear inequality rows per stage (stage rows + terminal rows)
+constexpr int OCP_MAXNC = 16;  // nonlinear inequality rows per stage (stage rows + terminal rows)
 #ifndef HILO_OCP_TPB
 #define HILO_OCP_TPB 64
 #endif
@@ -61,6 +61,10 @@ struct OcpConst {
   int n_con_ref, n_tcon_ref;              // rows per stage / terminal rows in the reference's g ...
   short row_ref[OCP_MAXNC], trow_ref[OCP_MAXNC];   // ... and where each active stage / terminal row sits there
   CollData coll;                          // collocation basis when the shooting map is the implicit one (hilo_colloc.h)
+  // Taylor path: bit p of pair_mask = the pair direction e_i + e_j with p = dir_of(i, j, NZ) - NZ is swept (the Hessian entry
+  // (i, j) of the interval's Lagrangian can be non-zero); cleared bits: entry taken as zero.  All ones by default.
+  unsigned long long pair_mask[4];
+  double bound_relax;                     // IPOPT's bound_relax_factor, for bounds that arrive per call (OcpExtra::lbx / ubx)
   // policy-defined cost data (weights, references, expression programs).  LAST member: an instance copies only the
   // PB::NCOST doubles its policy uses into LDS (40 KB per instance is the budget for four instances per CU)
   double cost[OCP_NCOST];
@@ -75,6 +79,7 @@ inline void ocp_default_options(OcpConst& c) {
   c.theta_min_fact = 1e-4; c.theta_max_fact = 1e4;
   c.delta_w_min = 1e-20; c.delta_w_0 = 1e-4; c.delta_w_max = 1e40; c.kappa_w_minus = 1.0 / 3; c.kappa_w_plus = 8.0;
   c.kappa_w_plus_bar = 100.0;
+  for (auto& w : c.pair_mask) w = ~0ull;
 }
 
 // ---- block-wide reductions (result broadcast to every lane) ------------------------------------------------
@@ -84,6 +89,7 @@ struct OpSum { __device__ static double id() { return 0.0; } __device__ static d
 __device__ __forceinline__ double nmax(double a, double b) { return (a != a || a > b) ? a : b; }
 struct OpMax { __device__ static double id() { return -INFINITY; } __device__ static double f(double a, double b) { return nmax(a, b); } };
 struct OpMin { __device__ static double id() { return INFINITY; } __device__ static double f(double a, double b) { return fmin(a, b); } };
+struct OpMax2 { __device__ static double id() { return -INFINITY; } __device__ static double f(double a, double b) { return fmax(a, b); } };   // plain maximum
 
 // wave-wide reduction without LDS traffic: DPP lane permutes inside each row of 16 (xor 1, xor 2, half-mirror, mirror), then
 // the four row totals through v_readlane (scalar registers -> broadcast for free)
@@ -128,11 +134,14 @@ __device__ __forceinline__ T* uni(T* p) {
 }
 // 1/sqrt(x) for x > 0: v_rsq_f64 seed (about 2^-26) and two Newton steps - the library rsqrt() is a ~100-cycle dependent
 // chain that sits on the critical path of every Riccati stage
+#ifndef HILO_RSQ_NEWTON
+#define HILO_RSQ_NEWTON 2
+#endif
 __device__ __forceinline__ double rsq_fast(double x) {
   double y = __builtin_amdgcn_rsq(x);
   const double hx = 0.5 * x;
   y = y * fma(-hx * y, y, 1.5);
-  y = y * fma(-hx * y, y, 1.5);
+  if (HILO_RSQ_NEWTON >= 2) y = y * fma(-hx * y, y, 1.5);
   return y;
 }
 typedef double v4d __attribute__((ext_vector_type(4)));   // accumulator of v_mfma_f64_16x16x4
@@ -176,16 +185,18 @@ template <class PB> struct pb_fused<PB, void_tt<decltype(PB::FUSED)>> { static c
 
 // LDS / workspace footprint as plain functions of the dimensions (the host sizes run-time compiled problems with them)
 __host__ __device__ constexpr size_t ocp_iter_doubles(int NX, int NU, int NC, int N) {
-  // 11 slot vectors (Z Zt D zL zU dzL dzU grad sig lbA ubA), rbN; 4 defect-sized vectors (lam lamn c ct) + c0; the padded stage
+  // 9 slot vectors (Z Zt D zL zU grad sig lbA ubA), rbN; 4 defect-sized vectors (lam lamn c ct) + c0; the padded stage
   // blocks AB [N][NX][NZ+1] (column NZ: -c), W [N][NZ][NZ+1] (column NZ: right-hand side), Qd; the merged recursion outputs
   // P|p [N+1][NX][NX+1], K|kff [N][NU][NX+1], Acl|bcl [N][NX][NX+1]; inequality rows
   const size_t NZ = NX + NU, NDIR = NZ * (NZ + 1) / 2, S = (size_t)(N + 1) * NZ;
-  return 11 * S + NX + 5 * (size_t)N * NX + (size_t)N * NX * (NZ + 1) + (size_t)N * NZ * (NZ + 1) + (size_t)(N + 1) * NDIR +
-         (size_t)(N + 1) * NX * (NX + 1) + (size_t)N * NU * (NX + 1) + (size_t)N * NX * (NX + 1) + (size_t)N * NC * (14 + NZ);
+  return 9 * S + NX + 5 * (size_t)N * NX + (size_t)N * NX * (NZ + 1) + (size_t)N * NZ * (NZ + 1) + (size_t)(N + 1) * NDIR +
+         (size_t)(N + 1) * NX * (NX + 1) + (size_t)N * NU * (NX + 1) + (size_t)N * NX * (NX + 1) + (size_t)N * NC * (14 + NZ) +
+         (size_t)N * 4 * NX;   // an upper bound over the policies (Ocp<PB>::iter_doubles is the exact figure): direction table AND stage points
 }
 __host__ __device__ constexpr size_t ocp_fixed_doubles(int NX, int NU, int NCONST, int NPAR, int NSD, int NEXT, int N) {
   const size_t NZ = NX + NU;
-  return NCONST + NZ * NZ + NZ + (N + 1) + 2 * 16 + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1 + NEXT;
+  return NCONST + NZ * NZ + NZ + (N + 1) + 2 * 16 + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1 + NEXT +
+         (NZ * (NZ + 1) / 2 + 2) / 2;
 }
 
 // Optional plumbing of a solve launch that saves separate kernels around it (all members may stay zero):
@@ -205,6 +216,12 @@ struct OcpExtra {
   double* gather;
   double* lam_x;
   double* g;
+  // lbx / ubx of the reference's solver call (`self._solver(x0=, lbx=, ubx=, ...)`, mpc.py:722): per instance and per call, rows in
+  // the layout of v (scaled variables, row stride bx_stride); NULL = the bounds of the problem description.  IPOPT's bound
+  // relaxation is applied here (pc.bound_relax).  The pinned x_0 slots keep following x0 (mpc.py:797-802 writes x0 into both).
+  const double* lbx;
+  const double* ubx;
+  long long bx_stride;
 };
 
 #ifdef HILO_OCP_DPROF
@@ -253,16 +270,25 @@ struct Ocp {
   using cdp = cond_t<BIG, const double*, lds_cdouble*>;
   struct Lds {
     const __attribute__((address_space(3))) OcpConst* pc;
-    // AB: [N][NX][ABP] = [A B | -c];  W: [N][NZ][WP] = [Hessian block (+ Sigma on the diagonal after prep_barrier) | rhs];
+    // AB: [N][NX][ABP] = [A B | -c];  W: [N][NZ][WP] = [Hessian block (+ Sigma on the diagonal after kkt_pass) | rhs];
     // P: [N+1][NX][PP] = [P_k | p_k];  Kg: [N][NU][PP] = [K_k | kff_k];  Acl: [N][NX][PP] = [A + B K | B kff - c];  rbN: rhs of x_N
-    dp Z, Zt, D, zL, zU, dzL, dzU, grad, lam, lamn, c, ct, AB, W, Qd, P, Kg, sig, rbN, Acl;
+    dp Z, Zt, D, zL, zU, grad, lam, lamn, c, ct, AB, W, Qd, P, Kg, sig, rbN, Acl;
+    dp Xs;   // SYM policies: Runge-Kutta stage points [N][4][NX] of the last values-only evaluation (reused by the derivative phase)
     dp lbA, ubA;  // effective box of every slot: -inf / +inf where there is no bound or the slot is not a variable
     dp cs, cst, cnu, cnun, cvL, cvU, cdvL, cdvU, cds, cd, csig, crb, Jd;  // [N][NC] (Jd: [N][NC][NZ])
     dp c0, cd0, cdt;  // second-order correction: saved defects / row values, row values at the trial point
     lds_double *Mm, *mm, *fk, *filt, *red, *par, *sd, *ext;
+    __attribute__((address_space(3))) int* dirs;   // [0] = number of swept directions per interval, [1..] = their indices d
   };
   static_assert(OCP_FILTER == 16, "ocp_fixed_doubles assumes a filter of 16 entries");
-  __host__ __device__ static constexpr size_t iter_doubles(int N) { return ocp_iter_doubles(NX, NU, NC, N); }  // the iterate (LDS or workspace)
+  // direction table of the Hessian blocks: policies with symbolic derivatives write the blocks directly and keep only the
+  // terminal cost's directions; stage points kept for reuse: SYM policies only
+  __host__ __device__ static constexpr size_t qd_doubles(int N) { return (SYM || SYM_MHE) ? (size_t)NXDIR : (size_t)(N + 1) * NDIR; }
+  __host__ __device__ static constexpr size_t xs_doubles(int N) { return SYM ? (size_t)N * 4 * NX : 0; }
+  __host__ __device__ static constexpr size_t iter_doubles(int N) {  // the iterate (LDS or workspace); <= ocp_iter_doubles + xs
+    return ocp_iter_doubles(NX, NU, NC, N) - (size_t)(N + 1) * NDIR - (size_t)N * 4 * NX + qd_doubles(N) + xs_doubles(N);
+  }
+  __device__ static dp qd_term(const Lds l, int N) { return (SYM || SYM_MHE) ? l.Qd : l.Qd + (size_t)N * NDIR; }
   __host__ __device__ static constexpr size_t fixed_doubles(int N) {  // always LDS
     return ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, N);
   }
@@ -284,13 +310,14 @@ struct Ocp {
     l.fk = take(N + 1); l.filt = take(2 * OCP_FILTER); l.red = take(16); l.par = take(NPAR);
     l.sd = take((size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1);
     l.ext = take(NEXT);
+    l.dirs = reinterpret_cast<__attribute__((address_space(3))) int*>(take((NDIR + 2) / 2));
     dp w;
     if constexpr (BIG) w = ws; else w = q;
     auto big = [&](size_t n) { dp r = w; w += n; return r; };
-    l.Z = big(S); l.Zt = big(S); l.D = big(S); l.zL = big(S); l.zU = big(S); l.dzL = big(S); l.dzU = big(S);
+    l.Z = big(S); l.Zt = big(S); l.D = big(S); l.zL = big(S); l.zU = big(S);
     l.grad = big(S);
     l.lam = big((size_t)N * NX); l.lamn = big((size_t)N * NX); l.c = big((size_t)N * NX); l.ct = big((size_t)N * NX);
-    l.AB = big((size_t)N * NX * ABP); l.W = big((size_t)N * NZ * WP); l.Qd = big((size_t)(N + 1) * NDIR);
+    l.AB = big((size_t)N * NX * ABP); l.W = big((size_t)N * NZ * WP); l.Qd = big(qd_doubles(N));
     l.P = big((size_t)(N + 1) * NX * PP);
     l.Kg = big((size_t)N * NU * PP);
     l.sig = big(S); l.rbN = big(NX); l.Acl = big((size_t)N * NX * PP);
@@ -300,6 +327,7 @@ struct Ocp {
     l.cdvL = big(R); l.cdvU = big(R); l.cds = big(R); l.cd = big(R); l.csig = big(R); l.crb = big(R);
     l.Jd = big(R * NZ);
     l.c0 = big((size_t)N * NX); l.cd0 = big(R); l.cdt = big(R);
+    l.Xs = big(xs_doubles(N));
     return l;
   }
 
@@ -331,6 +359,21 @@ struct Ocp {
     j = i + 1 + r;
   }
   __device__ static int dir_of(int i, int j, int n) { return n + i * (n - 1) - i * (i - 1) / 2 + (j - i - 1); }
+  __device__ static bool pair_on(const OcpConst& pc, int d) {   // d >= NZ: pair direction
+    const int p = d - NZ;
+    return p >= 256 || ((pc.pair_mask[p >> 6] >> (p & 63)) & 1ull) != 0ull;
+  }
+  // the swept directions of an interval (all NZ unit directions + the active pairs), once per solve
+  __device__ static void build_dirs(const Lds l) {
+    const OcpConst& pc = *(const OcpConst*)l.pc;
+    if (threadIdx.x == 0) {
+      int n = 0;
+      for (int d = 0; d < NDIR; ++d)
+        if (d < NZ || pair_on(pc, d)) l.dirs[1 + n++] = d;
+      l.dirs[0] = n;
+    }
+    __syncthreads();
+  }
 
   __device__ static const double* sd_of(const Lds l, int k) { return (const double*)(l.sd + (NSD > 0 ? k * NSD : 0)); }
 
@@ -387,8 +430,26 @@ struct Ocp {
         for (int i = 0; i < NU; ++i) u[i] = Zp[k * NZ + NX + i];
         if constexpr (FUSED) {
           fpart += PB::dyn_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
+        } else if constexpr (SYM) {
+          // the derivative phase's own stage-point routine; the points are kept (l.Xs) for the derivative phase that follows
+          // when this trial point is accepted
+          using M = typename PB::Model;
+          double xp[NX], up[NU > 0 ? NU : 1], X[4][NX], phi[NX];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xp[i] = x[i] * pc.sz[i];
+#pragma unroll
+          for (int i = 0; i < NU; ++i) up[i] = u[i] * pc.sz[NX + i];
+          sym_points<M>(M::DISCRETE ? 1 : pc.order, pc.dt, xp, up, (const double*)l.par, X, phi);
+          dp xs = l.Xs + (size_t)k * 4 * NX;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < NX; ++q) xs[i * NX + q] = X[i][q];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xn[i] = phi[i] * rcp_fast(pc.sz[i]);
+          fpart += PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
         } else {
-          if constexpr (SYM || SYM_MHE) {   // the arithmetic of the derivative phase (division = x * rcp_fast(y)): same defects in both
+          if constexpr (SYM_MHE) {   // the arithmetic of the derivative phase (division = x * rcp_fast(y)): same defects in both
             FastD xf[NX], uf[NU > 0 ? NU : 1], xnf[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) xf[i] = FastD(x[i]);
@@ -433,17 +494,22 @@ struct Ocp {
     return FTheta{uni(r.f), uni(r.theta)};
   }
 
+  // -log(z - lb) - log(ub - z) of one slot with ONE logarithm (of the product of its slacks: a two-sided slot costs what a
+  // one-sided one does); a non-positive slack gives NaN like the logarithm would (two negative slacks must not cancel)
+  __device__ __forceinline__ static double slot_log(double lb, double ub, double z) {
+    const bool hl = lb > -INFINITY, hu = ub < INFINITY;
+    if (!hl && !hu) return 0.0;
+    const double sl = hl ? z - lb : 1.0, su = hu ? ub - z : 1.0;
+    const double r = -log(sl * su);
+    return (sl > 0.0 && su > 0.0) ? r : __builtin_nan("");
+  }
   // -sum log(slacks) of a point (the barrier function is mu times this; the sum itself does not depend on mu, so the value of
   // an accepted trial point is carried into the next iteration instead of being recomputed)
   __device__ static double barrier_logs(const Lds l, cdp Zp, cdp sp = nullptr) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double part = 0.0;
-    OCP_FOR(e, (N + 1) * NZ) {
-      const double lb = l.lbA[e], ub = l.ubA[e], z = Zp[e];
-      if (lb > -INFINITY) part -= log(z - lb);
-      if (ub < INFINITY) part -= log(ub - z);
-    }
+    OCP_FOR(e, (N + 1) * NZ) part += slot_log(l.lbA[e], l.ubA[e], Zp[e]);
     if constexpr (NC > 0) {
       OCP_FOR(e, N * NC) {
         const int m = e % NC;
@@ -460,10 +526,9 @@ struct Ocp {
     const int N = pc.N;
     double part = 0.0;
     OCP_FOR(e, (N + 1) * NZ) {
-      const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e] + alpha * l.D[e];
+      const double z = l.Z[e] + alpha * l.D[e];
       l.Zt[e] = z;
-      if (lb > -INFINITY) part -= log(z - lb);
-      if (ub < INFINITY) part -= log(ub - z);
+      part += slot_log(l.lbA[e], l.ubA[e], z);
     }
     if constexpr (NC > 0) {
       OCP_FOR(e, N * NC) {
@@ -489,7 +554,8 @@ struct Ocp {
     const int N = pc.N;
     const unsigned pinm = FIX_X0 ? (~pc.x0_free_mask) & ((1u << NX) - 1u) : 0u;  // pinned slots of x_0 (bit i)
     constexpr int GPW = COOP ? 64 / NDIR : 1;  // cooperative: lane groups of NDIR directions, GPW intervals per round
-    const int ntask = COOP ? ((N + GPW - 1) / GPW) * 64 + NXDIR : N * NDIR + NXDIR;
+    const int nact = COOP ? NDIR : uni(l.dirs[0]);   // swept directions per interval (pair_mask)
+    const int ntask = COOP ? ((N + GPW - 1) / GPW) * 64 + NXDIR : N * nact + NXDIR;
     const int tbase = ntask - NXDIR;
     OCP_FOR(task0, ntask) {
       if (task0 < tbase) {
@@ -503,8 +569,9 @@ struct Ocp {
           if (!active) { k = N - 1; d = 0; }
           task = k * NDIR + d;
         } else {
-          k = task / NDIR;
-          d = task - k * NDIR;
+          k = task0 / nact;
+          d = l.dirs[1 + (task0 - k * nact)];
+          task = k * NDIR + d;
         }
         int di = d, dj = -1;
         if (d >= NZ) pair_of(d, NZ, di, dj);
@@ -589,7 +656,7 @@ struct Ocp {
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = Jet2(l.Z[N * NZ + i], (i == di || i == dj) ? 1.0 : 0.0, 0.0);
         const Jet2 v = PB::term_cost(pc, (const double*)l.par, sd_of(l, N), x);
-        l.Qd[N * NDIR + d] = v.b;
+        qd_term(l, N)[d] = v.b;
         if (d < NX) l.grad[N * NZ + d] = v.a;
         if (d == 0) l.fk[N] = v.v;
       }
@@ -602,8 +669,8 @@ struct Ocp {
       double h;
       if (i == j) h = Q[i];
       else {
-        const int a = i < j ? i : j, b = i < j ? j : i;
-        h = 0.5 * (Q[dir_of(a, b, NZ)] - Q[a] - Q[b]);
+        const int a = i < j ? i : j, b = i < j ? j : i, dd = dir_of(a, b, NZ);
+        h = (COOP || pair_on(pc, dd)) ? 0.5 * (Q[dd] - Q[a] - Q[b]) : 0.0;
       }
       if constexpr (PB::QUAD_COST) h += PB::cost_hess(pc, k, i, j);
       if (k == 0 && (((pinm >> i) | (pinm >> j)) & 1u)) h = 0.0;
@@ -646,6 +713,44 @@ struct Ocp {
   // columns of the current stage through the interval's block of l.W, which receives the Hessian at the end.
   // SYM policies: the Hessian of the terminal cost is constant - written once per solve in the direction form the Riccati
   // start reads (Q[e_i] = H_ii, Q[e_i + e_j] = H_ii + H_jj + 2 H_ij)
+  // Runge-Kutta stage points X_i and the integrated state Phi of one interval (SYM policies: the tableau of orders 1..4 written
+  // out, model divisions as x * rcp_fast(y)): ONE routine for the values-only pass of the line search and for the derivative
+  // phase, so that a trial point the line search accepted leaves exactly the stage points the derivative phase needs (l.Xs)
+  template <class M>
+  __device__ __forceinline__ static void sym_points(int order, double h, const double* x, const double* u, const double* par,
+                                                    double (*X)[NX], double* phi) {
+    constexpr bool DISC = M::DISCRETE;
+    const double a10 = order >= 2 ? 0.5 : 0.0, a20 = order == 3 ? -1.0 : 0.0, a21 = order == 3 ? 2.0 : (order == 4 ? 0.5 : 0.0),
+                 a32 = order == 4 ? 1.0 : 0.0;
+    const double hb[4] = {DISC ? 1.0 : h * erk_b<0>(order), DISC ? 0.0 : h * erk_b<1>(order), DISC ? 0.0 : h * erk_b<2>(order),
+                          DISC ? 0.0 : h * erk_b<3>(order)};
+    FastD kk[4][NX], uf[NU > 0 ? NU : 1];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) uf[i] = FastD(u[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      FastD Xf[NX];
+#pragma unroll
+      for (int s = 0; s < NX; ++s) {
+        double acc = x[s];
+        if (i == 1) acc += (h * a10) * kk[0][s].v;
+        if (i == 2) acc += (h * a20) * kk[0][s].v + (h * a21) * kk[1][s].v;
+        if (i == 3) acc += (h * a32) * kk[2][s].v;
+        X[i][s] = acc;
+        Xf[s] = FastD(acc);
+      }
+      if (i < order) {
+        M::ode(Xf, uf, par, h, kk[i]);
+      } else {
+#pragma unroll
+        for (int s = 0; s < NX; ++s) kk[i][s] = FastD(0.0);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NX; ++s)
+      phi[s] = (DISC ? 0.0 : x[s]) + hb[0] * kk[0][s].v + hb[1] * kk[1][s].v + hb[2] * kk[2][s].v + hb[3] * kk[3][s].v;
+  }
+
   __device__ static void term_hess_dirs(const Lds l) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
@@ -654,11 +759,13 @@ struct Ocp {
       if (d >= NX) pair_of(d, NX, di, dj);
       double q = PB::term_hess(pc, di, di);
       if (dj >= 0) q += PB::term_hess(pc, dj, dj) + 2.0 * PB::term_hess(pc, di, dj);
-      l.Qd[N * NDIR + d] = q;
+      qd_term(l, N)[d] = q;
     }
   }
 
-  __device__ __attribute__((always_inline)) static double eval_derivs_sym(lds_double* lbase, double* ws) {
+  // `reuse`: the iterate is the trial point the line search just evaluated (eval_values): its stage points are in l.Xs, its
+  // defects were copied to l.c and its objective is known - the Runge-Kutta slopes and the cost value are not recomputed
+  __device__ __attribute__((always_inline)) static double eval_derivs_sym(lds_double* lbase, double* ws, bool reuse = false) {
     using M = typename PB::Model;
     using MS = ModelSym<M>;
     static_assert(PB::QUAD_COST && NC == 0 && !COOP && !FUSED && M::NX == NX && M::NU == NU, "SYM: plain tracking policies");
@@ -708,8 +815,8 @@ struct Ocp {
 #pragma unroll
         for (int i = 0; i < NX; ++i) xN[i] = l.Z[N * NZ + i];
         if (act) {
-          if (g == 0) fpart += PB::stage_cost(pc, par, sd_of(l, k), k, zs, zs + NX);
-          if (g == 0 && k == N - 1) fpart += PB::term_cost(pc, par, sd_of(l, N), xN);
+          if (g == 0 && !reuse) fpart += PB::stage_cost(pc, par, sd_of(l, k), k, zs, zs + NX);
+          if (g == 0 && k == N - 1 && !reuse) fpart += PB::term_cost(pc, par, sd_of(l, N), xN);
 #pragma unroll
           for (int c = 0; c < CPL; ++c) {
             const int col = c0 + c;
@@ -722,36 +829,19 @@ struct Ocp {
 #pragma unroll
           for (int r = 0; r < NZ; ++r) ch[r][c] = (c0 + c < NZ && r >= c0 + c) ? PB::cost_hess(pc, k, r, c0 + c) : 0.0;
       }
-      {  // stage points, slopes, Phi, defect
-        FastD kk[4][NX], uf[NU > 0 ? NU : 1];
-#pragma unroll
-        for (int i = 0; i < NU; ++i) uf[i] = FastD(u[i]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          FastD Xf[NX];
-#pragma unroll
-          for (int s = 0; s < NX; ++s) {
-            double acc = x[s];
-            if (i == 1) acc += (h * a10) * kk[0][s].v;
-            if (i == 2) acc += (h * a20) * kk[0][s].v + (h * a21) * kk[1][s].v;
-            if (i == 3) acc += (h * a32) * kk[2][s].v;
-            X[i][s] = acc;
-            Xf[s] = FastD(acc);
-          }
-          if (i < order) {
-            M::ode(Xf, uf, par, h, kk[i]);
-          } else {
-#pragma unroll
-            for (int s = 0; s < NX; ++s) kk[i][s] = FastD(0.0);
-          }
-        }
+      if (!reuse) {  // stage points, slopes, Phi, defect
+        double phi[NX];
+        sym_points<M>(order, h, x, u, par, X, phi);
         if (act && g == 0) {
 #pragma unroll
-          for (int s = 0; s < NX; ++s) {
-            const double phi = (DISC ? 0.0 : x[s]) + hb[0] * kk[0][s].v + hb[1] * kk[1][s].v + hb[2] * kk[2][s].v + hb[3] * kk[3][s].v;
-            l.c[k * NX + s] = l.Z[(k + 1) * NZ + s] - phi * isz[s];
-          }
+          for (int s = 0; s < NX; ++s) l.c[k * NX + s] = l.Z[(k + 1) * NZ + s] - phi[s] * isz[s];
         }
+      } else {
+        cdp xs = l.Xs + (size_t)k * 4 * NX;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int s = 0; s < NX; ++s) X[i][s] = xs[i * NX + s];
       }
       DTICK(0)
       // adjoint weights of the slopes (reverse over the stages)
@@ -915,7 +1005,7 @@ struct Ocp {
     const double hb[4] = {h * erk_b<0>(order), h * erk_b<1>(order), h * erk_b<2>(order), h * erk_b<3>(order)};
     const double* par = (const double*)l.par;
     double fpart = 0.0;
-    OCP_FOR(d, NXDIR) l.Qd[N * NDIR + d] = 0.0;          // no terminal cost (mhe.py: the window ends with the last measurement)
+    OCP_FOR(d, NXDIR) qd_term(l, N)[d] = 0.0;          // no terminal cost (mhe.py: the window ends with the last measurement)
     OCP_FOR(a, NZ) l.grad[N * NZ + a] = 0.0;
     constexpr int IPP = OCP_TPB / LPI;
     for (int kbase = 0; kbase < N; kbase += IPP) {
@@ -1226,102 +1316,13 @@ struct Ocp {
     return r;
   }
 
-  // scaled optimality error pieces (W&B eq. 5)
-  // also returns the complementarity errors for barrier parameters 0 and mu (same pass over the slots)
-  __device__ __forceinline__ static void opt_error(const Lds l, double mu, double& dual_s, double& prim, double& s_c, double& compl0,
-                                   double& compl_mu, double& theta) {
-    const OcpConst& pc = *(const OcpConst*)l.pc;
-    const int N = pc.N;
-    double dmax = 0.0, lsum = 0.0, zsum = 0.0, pmax = 0.0, nb = 0.0, c0 = 0.0, cm = 0.0, th = 0.0;
-    OCP_FOR(e, (N + 1) * NZ) {
-      const int k = e / NZ, i = e - k * NZ;
-      if (!is_free(pc, k, i)) continue;
-      dmax = nmax(dmax, fabs(dual_res(l, N, e)));
-      const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
-      zsum += fabs(zl) + fabs(zu);
-      if (lb > -INFINITY) {
-        nb += 1.0;
-        const double p = (z - lb) * zl;
-        c0 = nmax(c0, fabs(p));
-        cm = nmax(cm, fabs(p - mu));
-      }
-      if (ub < INFINITY) {
-        nb += 1.0;
-        const double p = (ub - z) * zu;
-        c0 = nmax(c0, fabs(p));
-        cm = nmax(cm, fabs(p - mu));
-      }
-    }
-    OCP_FOR(e, N * NX) {
-      const double ca = fabs(l.c[e]);
-      pmax = nmax(pmax, ca);
-      th += ca;
-      lsum += fabs(l.lam[e]);
-    }
-    double ncon = 0.0;
-    if constexpr (NC > 0) {  // slack block: dual residual -nu - vL + vU, primal residual d - s
-      OCP_FOR(e, N * NC) {
-        const int m = e % NC;
-        if (!row_on(pc, e / NC, m)) continue;
-        dmax = nmax(dmax, fabs(-l.cnu[e] - l.cvL[e] + l.cvU[e]));
-        pmax = nmax(pmax, fabs(l.cd[e] - l.cs[e]));
-        th += fabs(l.cd[e] - l.cs[e]);
-        lsum += fabs(l.cnu[e]);
-        zsum += fabs(l.cvL[e]) + fabs(l.cvU[e]);
-        if (pc.dlb[m] > -INFINITY) {
-          nb += 1.0;
-          const double p = (l.cs[e] - pc.dlb[m]) * l.cvL[e];
-          c0 = nmax(c0, fabs(p));
-          cm = nmax(cm, fabs(p - mu));
-        }
-        if (pc.dub[m] < INFINITY) {
-          nb += 1.0;
-          const double p = (pc.dub[m] - l.cs[e]) * l.cvU[e];
-          c0 = nmax(c0, fabs(p));
-          cm = nmax(cm, fabs(p - mu));
-        }
-      }
-      ncon = (double)N * pc.nc + pc.nc_term;
-    }
-    theta = block_reduce<OpSum>(th, l.red);
-    compl0 = block_reduce<OpMax>(c0, l.red);
-    compl_mu = block_reduce<OpMax>(cm, l.red);
-    dmax = block_reduce<OpMax>(dmax, l.red);
-    pmax = block_reduce<OpMax>(pmax, l.red);
-    lsum = block_reduce<OpSum>(lsum, l.red);
-    zsum = block_reduce<OpSum>(zsum, l.red);
-    nb = uni(fmax(1.0, block_reduce<OpSum>(nb, l.red)));
-    const double s_d = fmax(pc.s_max, (lsum + zsum) / (N * NX + ncon + nb)) / pc.s_max;
-    s_c = uni(fmax(pc.s_max, zsum / nb) / pc.s_max);
-    dual_s = uni(dmax / s_d);
-    prim = pmax;
-  }
-
-  __device__ static double compl_error(const Lds l, double mu) {
-    const OcpConst& pc = *(const OcpConst*)l.pc;
-    const int N = pc.N;
-    double cm = 0.0;
-    OCP_FOR(e, (N + 1) * NZ) {
-      const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
-      if (lb > -INFINITY) cm = nmax(cm, fabs((z - lb) * zl - mu));
-      if (ub < INFINITY) cm = nmax(cm, fabs((ub - z) * zu - mu));
-    }
-    if constexpr (NC > 0) {
-      OCP_FOR(e, N * NC) {
-        const int m = e % NC;
-        if (!row_on(pc, e / NC, m)) continue;
-        if (pc.dlb[m] > -INFINITY) cm = nmax(cm, fabs((l.cs[e] - pc.dlb[m]) * l.cvL[e] - mu));
-        if (pc.dub[m] < INFINITY) cm = nmax(cm, fabs((pc.dub[m] - l.cs[e]) * l.cvU[e] - mu));
-      }
-    }
-    return block_reduce<OpMax>(cm, l.red);
-  }
-
-  // ---- barrier terms of every slot, once per iteration (keeps the divisions out of the sequential recursion):
-  //   sig[e] = zL/(z - lb) + zU/(ub - z),   rb[e] = grad[e] - mu/(z - lb) + mu/(ub - z)
-  // and the stage matrices the recursion reads are completed in place: sig is ADDED to the diagonal of the stage's Hessian
-  // block, rb goes to its right-hand-side column (slot e = (k, i): W[k][i][i] += sig, W[k][i][NZ] = rb; stage N: sig[], rbN[]).
-  // Called once per evaluation of the derivatives (which rewrite the blocks); repeated factorisations reuse the result.
+  // ---- one pass over the iterate per iteration: scaled optimality error (W&B eq. 5) AND the barrier terms of the Newton system.
+  // Per slot: dual residual, multiplier sums, the complementarity products p = slack * multiplier (their largest and smallest
+  // value give max |p - mu| for EVERY barrier parameter: max(pmax - mu, mu - pmin) - the barrier update needs no further pass),
+  // and with the reciprocal slacks already at hand  sig = zL/(z - lb) + zU/(ub - z)  (added to the diagonal of the stage's
+  // Hessian block, stage_rhs) and  q = 1/(z - lb) - 1/(ub - z)  (parked in the right-hand-side column: rb = grad - mu q is
+  // completed by finish_rhs once the barrier parameter of this iteration is known).  Keeps the divisions out of the recursion.
+  struct KktErr { double dual_s, prim, s_c, pmax, pmin, theta; };
   __device__ static void stage_rhs(const Lds l, int N, int e, double sg, double r, bool replace) {
     const int k = e / NZ, i = e - k * NZ;
     l.sig[e] = sg;
@@ -1331,45 +1332,122 @@ struct Ocp {
       w[NZ] = r;
     } else if (i < NX) l.rbN[i] = r;
   }
-  __device__ static void prep_barrier(const Lds l, double mu) {
+  __device__ __forceinline__ static KktErr kkt_pass(const Lds l, double nb) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
+    double dmax = 0.0, lsum = 0.0, zsum = 0.0, pmax = 0.0, cmax = 0.0, cmin = INFINITY, th = 0.0;
     OCP_FOR(e, (N + 1) * NZ) {
-      const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
-      double sg = 0.0, r = l.grad[e];
-      if (lb > -INFINITY) {
-        const double is = rcp_fast(z - lb);
-        sg += zl * is;
-        r -= mu * is;
+      const int k = e / NZ, i = e - k * NZ;
+      double sg = 0.0, q = 0.0;
+      if (is_free(pc, k, i)) {
+        dmax = nmax(dmax, fabs(dual_res(l, N, e)));
+        const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
+        zsum += fabs(zl) + fabs(zu);
+        if (lb > -INFINITY) {
+          const double sl = z - lb, is = rcp_fast(sl), p = sl * zl;
+          cmax = fmax(cmax, p);
+          cmin = fmin(cmin, p);
+          sg += zl * is;
+          q += is;
+        }
+        if (ub < INFINITY) {
+          const double su = ub - z, is = rcp_fast(su), p = su * zu;
+          cmax = fmax(cmax, p);
+          cmin = fmin(cmin, p);
+          sg += zu * is;
+          q -= is;
+        }
       }
-      if (ub < INFINITY) {
-        const double is = rcp_fast(ub - z);
-        sg += zu * is;
-        r += mu * is;
-      }
-      stage_rhs(l, N, e, sg, r, false);
+      stage_rhs(l, N, e, sg, q, false);
     }
-    if constexpr (NC > 0) {  // slack rows: csig = vL/(s - dL) + vU/(dU - s), crb = -mu/(s - dL) + mu/(dU - s)
+    OCP_FOR(e, N * NX) {
+      const double ca = fabs(l.c[e]);
+      pmax = nmax(pmax, ca);
+      th += ca;
+      lsum += fabs(l.lam[e]);
+    }
+    double ncon = 0.0;
+    if constexpr (NC > 0) {  // slack block: dual residual -nu - vL + vU, primal residual d - s; csig, and q_s parked in crb
       OCP_FOR(e, N * NC) {
         const int m = e % NC;
-        double sg = 0.0, r = 0.0;
+        double sg = 0.0, q = 0.0;
         if (row_on(pc, e / NC, m)) {
+          dmax = nmax(dmax, fabs(-l.cnu[e] - l.cvL[e] + l.cvU[e]));
+          pmax = nmax(pmax, fabs(l.cd[e] - l.cs[e]));
+          th += fabs(l.cd[e] - l.cs[e]);
+          lsum += fabs(l.cnu[e]);
+          zsum += fabs(l.cvL[e]) + fabs(l.cvU[e]);
           if (pc.dlb[m] > -INFINITY) {
-            const double is = rcp_fast(l.cs[e] - pc.dlb[m]);
+            const double sl = l.cs[e] - pc.dlb[m], is = rcp_fast(sl), p = sl * l.cvL[e];
+            cmax = fmax(cmax, p);
+            cmin = fmin(cmin, p);
             sg += l.cvL[e] * is;
-            r -= mu * is;
+            q += is;
           }
           if (pc.dub[m] < INFINITY) {
-            const double is = rcp_fast(pc.dub[m] - l.cs[e]);
+            const double su = pc.dub[m] - l.cs[e], is = rcp_fast(su), p = su * l.cvU[e];
+            cmax = fmax(cmax, p);
+            cmin = fmin(cmin, p);
             sg += l.cvU[e] * is;
-            r += mu * is;
+            q -= is;
           }
         }
         l.csig[e] = sg;
-        l.crb[e] = r;
+        l.crb[e] = q;
       }
+      ncon = (double)N * pc.nc + pc.nc_term;
+    }
+    KktErr r;
+    r.theta = uni(block_reduce<OpSum>(th, l.red));
+    r.pmax = uni(block_reduce<OpMax2>(cmax, l.red));
+    r.pmin = uni(block_reduce<OpMin>(cmin, l.red));
+    dmax = block_reduce<OpMax>(dmax, l.red);
+    pmax = block_reduce<OpMax>(pmax, l.red);
+    lsum = block_reduce<OpSum>(lsum, l.red);
+    zsum = block_reduce<OpSum>(zsum, l.red);
+    const double s_d = fmax(pc.s_max, (lsum + zsum) / (N * NX + ncon + nb)) / pc.s_max;
+    // a NaN multiplier or defect must reach the error measure (fmax would drop it): through the sums
+    const double poison = (lsum + zsum + r.theta) * 0.0;      // 0, or NaN
+    r.s_c = uni(fmax(pc.s_max, zsum / nb) / pc.s_max + poison);
+    r.dual_s = uni(dmax / s_d);
+    r.prim = uni(pmax);
+    return r;
+  }
+  // complementarity error for barrier parameter mu from the extreme products
+  __device__ __forceinline__ static double compl_of(const KktErr& r, double mu) { return fmax(fmax(r.pmax - mu, mu - r.pmin), 0.0); }
+  // right-hand sides of the Newton system once mu is fixed: rb = grad - mu q (q parked by kkt_pass), crb = -mu q_s
+  __device__ static void finish_rhs(const Lds l, double mu) {
+    const OcpConst& pc = *(const OcpConst*)l.pc;
+    const int N = pc.N;
+    OCP_FOR(e, (N + 1) * NZ) {
+      const int k = e / NZ, i = e - k * NZ;
+      if (k < N) {
+        dp w = l.W + (size_t)(k * NZ + i) * WP + NZ;
+        *w = l.grad[e] - mu * *w;
+      } else if (i < NX) l.rbN[i] = l.grad[e] - mu * l.rbN[i];
+    }
+    if constexpr (NC > 0) {
+      OCP_FOR(e, N * NC) l.crb[e] = -mu * l.crb[e];
     }
     __syncthreads();
+  }
+  // number of finite bounds of the free slots and the inequality rows: a constant of the problem instance
+  __device__ static double count_bounds(const Lds l) {
+    const OcpConst& pc = *(const OcpConst*)l.pc;
+    const int N = pc.N;
+    double nb = 0.0;
+    OCP_FOR(e, (N + 1) * NZ) {
+      if (!is_free(pc, e / NZ, e % NZ)) continue;
+      nb += (l.lbA[e] > -INFINITY ? 1.0 : 0.0) + (l.ubA[e] < INFINITY ? 1.0 : 0.0);
+    }
+    if constexpr (NC > 0) {
+      OCP_FOR(e, N * NC) {
+        const int m = e % NC;
+        if (!row_on(pc, e / NC, m)) continue;
+        nb += (pc.dlb[m] > -INFINITY ? 1.0 : 0.0) + (pc.dub[m] < INFINITY ? 1.0 : 0.0);
+      }
+    }
+    return uni(fmax(1.0, block_reduce<OpSum>(nb, l.red)));
   }
 
   // lower Cholesky factor of the n x n block M (row pitch ld) with reciprocal pivots: L (n x n), invd = 1/diag(L)
@@ -1398,6 +1476,21 @@ struct Ocp {
   // the same factorisation of a block held in registers (row-major n x n, lower triangle used)
   template <int n>
   __device__ __forceinline__ static bool small_chol_reg(const double* M, double* L, double* invd) {
+    if constexpr (n == 2) {
+      // L11 = sqrt(r00), L21 = r10 / L11, L22 = sqrt(det / r00): rsqrt(r00) and rsqrt(det) do not depend on each other - one
+      // reciprocal-square-root chain on the critical path of a Riccati stage instead of two (same cancellation as r11 - L21^2)
+      const double r00 = M[0], r10 = M[2], r11 = M[3];
+      const double det = fma(r00, r11, -r10 * r10);
+      const bool ok0 = r00 > 0.0, ok1 = det > 0.0;
+      const double i0 = rsq_fast(ok0 ? r00 : 1.0), idt = rsq_fast(ok1 ? det : 1.0);
+      const double s0 = (ok0 ? r00 : 1.0) * i0;          // sqrt(r00)
+      invd[0] = i0;
+      L[0] = s0;
+      L[2] = r10 * i0;
+      invd[1] = idt * s0;                                 // 1 / sqrt(det / r00)
+      L[3] = (ok1 ? det : 1.0) * idt * i0;                // sqrt(det / r00)
+      return ok0 && ok1;
+    }
     bool pd = true;
 #pragma unroll
     for (int j = 0; j < n; ++j) {
@@ -1603,7 +1696,7 @@ struct Ocp {
   // Per stage: (1) M = H_k + [A B]^T P_{k+1} [A B] and its right-hand side on the f64 matrix cores, the reduced pivot
   // block broadcast from the accumulators and factored (redundantly per lane); (2) feedback K, feed-forward kff, P_k, p_k and
   // the closed-loop coefficients.  The forward sweep keeps dx in registers (DPP / v_readlane broadcasts, no LDS round trip).
-  // The stage matrices [H_k + Sigma | r_k] were completed by prep_barrier (stage_rhs); `delta` is added to their diagonal here.
+  // The stage matrices [H_k + Sigma | r_k] were completed by kkt_pass / finish_rhs; `delta` is added to their diagonal here.
   // `resto`: feasibility-restoration step (the caller has replaced the blocks by the barrier diagonal and passes delta = 1: H = I,
   // least-norm d with J d = -c); here it only switches off the terminal cost's Hessian and the new row multipliers
   __device__ OCP_PHASE static bool riccati(lds_double* lbase, double* ws, double mu, double delta, bool resto = false) {
@@ -1612,6 +1705,7 @@ struct Ocp {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N, t = threadIdx.x;
     (void)mu;
+    DTICK0
     // terminal: P_N = hess V + Sigma + delta, p_N = grad V + barrier rhs; the column -c of the padded [A B | -c] (the defects
     // change between factorisations of one iteration: second-order correction)
     OCP_FOR(e, NX * PP) {
@@ -1620,7 +1714,7 @@ struct Ocp {
       if (j < NX) {
         v = 0.0;
         if (!resto) {
-          cdp Q = l.Qd + N * NDIR;
+          cdp Q = qd_term(l, N);
           if (i == j) v = Q[i];
           else {
             const int a = i < j ? i : j, b = i < j ? j : i;
@@ -1637,6 +1731,7 @@ struct Ocp {
     if constexpr (MFMA_STAGE && NU > 0 && NH == 0) {
       if (!backward_reg(l, N, delta)) return false;
       __syncthreads();
+      DTICK(8)
     } else
 #endif
     for (int k = N - 1; k >= 0; --k) {
@@ -1853,6 +1948,7 @@ struct Ocp {
         for (int a = 0; a < NX; ++a) l.D[a] = -y[a];
       }
     }
+    DTICK(9)
     // closed-loop matrices for the forward sweep: Acl = A + B K, bcl = B kff - c: written by the stage loop above when there
     // are inputs; without inputs Acl = A, bcl = -c
     if constexpr (NU == 0) OCP_FOR(e, N * NX * PP) {
@@ -1863,40 +1959,55 @@ struct Ocp {
     // forward sweep on the first wave: lane i < NX carries dx[i] in a register, exchanged by DPP quad broadcasts (NX <= 4) or
     // v_readlane; the coefficients of the next stage are fetched while the current one is computed
     if (t < 64) {
+      // chunks of FU stages: the coefficients of the NEXT chunk are fetched while the current one is computed (one LDS
+      // latency per chunk instead of one per stage - a stage is a handful of dependent multiply-adds)
+      constexpr int FU = 4;
       const int i = t < NX ? t : 0;
       double dxi = l.D[i];
-      double ac[NX], bc, an[NX], bn;
+      double cur[FU][NX + 1], nxt[FU][NX + 1];
+      auto fetch = [&](double (*dst)[NX + 1], int k0) {
 #pragma unroll
-      for (int j = 0; j < NX; ++j) ac[j] = l.Acl[i * PP + j];
-      bc = l.Acl[i * PP + NX];
-      for (int k = 0; k < N; ++k) {
-        const int kn = k + 1 < N ? k + 1 : k;
+        for (int q = 0; q < FU; ++q) {
+          const int kq = k0 + q < N ? k0 + q : N - 1;
+          cdp row = l.Acl + ((size_t)kq * NX + i) * PP;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) an[j] = l.Acl[((size_t)kn * NX + i) * PP + j];
-        bn = l.Acl[((size_t)kn * NX + i) * PP + NX];
-        double s = bc;
-        if constexpr (NX <= 4) {
-          double dj[4];
-          dj[0] = quad_bcast<0>(dxi); dj[1] = quad_bcast<1>(dxi); dj[2] = quad_bcast<2>(dxi); dj[3] = quad_bcast<3>(dxi);
-          double s2 = 0.0;   // two accumulation chains of half the length
-#pragma unroll
-          for (int j = 0; j < NX; ++j) {
-            if (j & 1) s2 += ac[j] * dj[j];
-            else s += ac[j] * dj[j];
-          }
-          s += s2;
-        } else {
-#pragma unroll
-          for (int j = 0; j < NX; ++j) s += ac[j] * read_lane(dxi, j);   // v_readlane: scalar broadcast, no LDS crossbar trip
+          for (int j = 0; j <= NX; ++j) dst[q][j] = row[j];
         }
-        dxi = s;
-        if (t < NX) l.D[(k + 1) * NZ + i] = dxi;
+      };
+      fetch(cur, 0);
+      for (int k0 = 0; k0 < N; k0 += FU) {
+        fetch(nxt, k0 + FU);
 #pragma unroll
-        for (int j = 0; j < NX; ++j) ac[j] = an[j];
-        bc = bn;
+        for (int q = 0; q < FU; ++q) {
+          const int k = k0 + q;
+          double s = cur[q][NX];
+          if constexpr (NX <= 4) {
+            double dj[4];
+            dj[0] = quad_bcast<0>(dxi); dj[1] = quad_bcast<1>(dxi); dj[2] = quad_bcast<2>(dxi); dj[3] = quad_bcast<3>(dxi);
+            double s2 = 0.0;   // two accumulation chains of half the length
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+              if (j & 1) s2 += cur[q][j] * dj[j];
+              else s += cur[q][j] * dj[j];
+            }
+            s += s2;
+          } else {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) s += cur[q][j] * read_lane(dxi, j);   // v_readlane: scalar broadcast, no LDS crossbar trip
+          }
+          if (k < N) {
+            dxi = s;
+            if (t < NX) l.D[(k + 1) * NZ + i] = dxi;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < FU; ++q)
+#pragma unroll
+          for (int j = 0; j <= NX; ++j) cur[q][j] = nxt[q][j];
       }
     }
     __syncthreads();
+    DTICK(10)
     // inputs and new equality multipliers, parallel over stages:
     //   du_k = K dx_k + kff,   lam_{k+1} = -(P_{k+1} dx_{k+1} + p_{k+1})
     OCP_FOR(e, N * (NU + NX)) {
@@ -2108,7 +2219,18 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     else if (i < NX) v = k == 0 ? 0.0 : vb[(N + 1) * NXV + ((k - 1 < Ncv ? k - 1 : Ncv - 1)) * NU + (i - NXV - NTAIL)];
     else v = (k < Ncv) ? vb[(N + 1) * NXV + k * NU + (i - NX)] : 0.0;
     const bool fr = S::is_free(pc, k, i);
-    const double lb = fr ? S::lb_of(pc, k, i) : -INFINITY, ub = fr ? S::ub_of(pc, k, i) : INFINITY;
+    double lb = fr ? S::lb_of(pc, k, i) : -INFINITY, ub = fr ? S::ub_of(pc, k, i) : INFINITY;
+    if (ex.lbx && fr && !(k == 0 && (pc.flags & 2) && i < S::NX0)) {   // bounds of this call (the box of a free x_0 stays its own): the slot's entry of the reference's lbx / ubx (same index as in v)
+      int src = -1;
+      if (i < NXV) src = k * NXV + i;
+      else if (i < NXV + NTAIL) { if (k == 0) src = (N + 1) * NXV + Ncv * NU + (i - NXV); }
+      else if (i >= NX && k < Ncv) src = (N + 1) * NXV + k * NU + (i - NX);
+      if (src >= 0) {
+        const double lo = ex.lbx[b * ex.bx_stride + v_prefix + src], up = ex.ubx[b * ex.bx_stride + v_prefix + src];
+        lb = lo > -INFINITY ? lo - pc.bound_relax * fmax(1.0, fabs(lo)) : lo;
+        ub = up < INFINITY ? up + pc.bound_relax * fmax(1.0, fabs(up)) : up;
+      }
+    }
     l.lbA[e] = lb;
     l.ubA[e] = ub;
     if (fr) {  // IPOPT start: push into the interior (W&B sec. 3.6)
@@ -2179,12 +2301,22 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
   bool blog_ok = false;
 
   if constexpr (S::SYM) S::term_hess_dirs(l);
+  if constexpr (!S::SYM && !S::SYM_MHE && !S::COOP) S::build_dirs(l);
+  const double nb_const = S::count_bounds(l);
+  bool pts_ok = false;      // SYM policies: the iterate is the trial point the line search evaluated last (stage points, defects, f)
+  double f_trial = 0.0;
   for (it = 0;; ++it) {
-    fval = S::eval_derivs(lds_raw, wsb);
+    if constexpr (S::SYM) {
+      if (pts_ok) {
+        OCP_FOR(e, N * NX) l.c[e] = l.ct[e];
+        (void)S::eval_derivs_sym(lds_raw, wsb, true);
+        fval = f_trial;
+      } else fval = S::eval_derivs(lds_raw, wsb);
+    } else fval = S::eval_derivs(lds_raw, wsb);
     OCP_TICK(PH_DERIV)
-    double dual_s, prim, s_c, c0, cmu, th0;
-    S::opt_error(l, mu, dual_s, prim, s_c, c0, cmu, th0);
-    th0 = uni(th0);
+    const typename S::KktErr ke = S::kkt_pass(l, nb_const);
+    const double dual_s = ke.dual_s, prim = ke.prim, s_c = ke.s_c, th0 = ke.theta;
+    const double c0 = uni(fmax(ke.pmax, -ke.pmin));
     if (it == 0) {
       theta_min = uni(pc.theta_min_fact * fmax(1.0, th0));
       theta_max = uni(pc.theta_max_fact * fmax(1.0, th0));
@@ -2198,7 +2330,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     if (it >= pc.max_iter) { st = HILO_STATUS_MAXITER; break; }
     // ---- barrier update (W&B eq. 7) ----
     for (int r = 0; r < 20; ++r) {
-      const double Emu = uni(nmax(nmax(dual_s, prim), (r == 0 ? cmu : S::compl_error(l, mu)) / s_c));
+      const double Emu = uni(nmax(nmax(dual_s, prim), S::compl_of(ke, mu) / s_c));
       if (!(Emu <= pc.kappa_eps * mu && mu > mu_min * (1 + 1e-12))) break;
       mu = uni(fmax(mu_min, fmin(pc.kappa_mu * mu, pc.theta_mu == 1.5 ? mu * sqrt(mu) : pow(mu, pc.theta_mu))));
       tau = uni(fmax(pc.tau_min, 1.0 - mu));
@@ -2206,7 +2338,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     }
     OCP_TICK(PH_ERR)
     // ---- search direction with inertia correction (W&B Alg. IC) ----
-    S::prep_barrier(l, mu);
+    S::finish_rhs(l, mu);
     double delta = 0.0;
     bool first_try = true, solved = false;
     for (;;) {
@@ -2249,8 +2381,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
         }
         dphi += gphi * d;   // D = 0 on slots that are not variables
       }
-      l.dzL[e] = dl;
-      l.dzU[e] = du;
+      (void)dl; (void)du;   // the multiplier steps themselves are recomputed by the update (two slot vectors less in LDS)
     }
     if constexpr (NC > 0) {
       OCP_FOR(e, N * NC) {
@@ -2286,7 +2417,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     // ---- filter line search (W&B Alg. A) ----
     double alpha = a_p;
     bool accepted = false, armijo = false;
-    double blog_t = 0.0;
+    double blog_t = 0.0, f_acc = 0.0;
     for (int ls = 0; ls < 60; ++ls) {
       blog_t = S::form_trial(l, alpha);
       tprof[PH_NLS] += 1;
@@ -2307,7 +2438,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
         if (sw) ok = pht - phi0 - rnd <= pc.eta_phi * alpha * dphi;
         else ok = tht <= (1 - pc.gamma_theta) * th0 || pht - phi0 - rnd <= -pc.gamma_phi * th0;
       }
-      if (ok) { accepted = true; armijo = sw; break; }
+      if (ok) { accepted = true; armijo = sw; f_acc = ft; break; }
       // ---- second-order correction (W&B sec. 2.4): the full step was rejected and did not reduce the violation.  The same
       // system is solved with c_soc = alpha c(x_k) + c(x_k + alpha d); up to four corrections while theta drops by kappa_soc.
       if (ls == 0 && tht >= th0) {
@@ -2359,13 +2490,37 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
             const double rnd = 10 * 2.220446049250313e-16 * fabs(phi0);
             if (sw2) oks = phs - phi0 - rnd <= pc.eta_phi * alpha * dphi;
             else oks = ths <= (1 - pc.gamma_theta) * th0 || phs - phi0 - rnd <= -pc.gamma_phi * th0;
-            if (oks) { soc_ok = true; soc_sw = sw2; break; }
+            if (oks) { soc_ok = true; soc_sw = sw2; f_acc = t2.f; break; }
           }
           if (!(ths <= 0.99 * th_old)) break;
           th_old = ths;
           a_prev = a_s;
         }
-        if (soc_ok) { accepted = true; armijo = soc_sw; break; }
+        if (soc_ok) {
+          // The corrected step replaces the primal step and the equality multipliers; the bound-multiplier steps (which the
+          // update recomputes from the direction in l.D) stay those of the UNCORRECTED direction, like a_z: rebuild it - the
+          // corrected system's multipliers wait in the saved-defect slots meanwhile.  (One more factorisation in a rare branch.)
+          OCP_FOR(e, N * NX) {
+            const double cs0 = l.c0[e];
+            l.c0[e] = l.lamn[e];
+            l.c[e] = cs0;
+          }
+          if constexpr (NC > 0) {
+            OCP_FOR(e, N * NC) {
+              const double cd0 = l.cd0[e];
+              l.cd0[e] = l.cnun[e];
+              l.cd[e] = cd0;
+            }
+          }
+          __syncthreads();
+          tprof[PH_NRIC] += 1;
+          (void)uni(S::riccati(lds_raw, wsb, mu, delta));
+          OCP_FOR(e, N * NX) l.lamn[e] = l.c0[e];
+          if constexpr (NC > 0)
+            OCP_FOR(e, N * NC) l.cnun[e] = l.cd0[e];
+          __syncthreads();
+          accepted = true; armijo = soc_sw; break;
+        }
         // no luck: back to the uncorrected direction (defects, row values, step, multipliers) and on with the backtracking
         OCP_FOR(e, N * NX) l.c[e] = l.c0[e];
         if constexpr (NC > 0)
@@ -2405,6 +2560,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
       const int rr = uni(S::restore(lds_raw, wsb, mu, tau, nfilt, theta_max));
       if (rr != 0) { st = rr == 2 ? HILO_STATUS_INFEASIBLE : HILO_STATUS_RESTORATION_FAILED; break; }
       blog_ok = false;
+      pts_ok = false;
       // IPOPT after restoration: equality multipliers reset (constr_mult_reset_threshold = 0), bound multipliers
       // reset to 1 when they exceed bound_mult_reset_threshold = 1000
       double zm = 0.0;
@@ -2435,17 +2591,21 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     // ---- accept: primal, equality multipliers, bound multipliers (+ W&B eq. 16 safeguard) ----
     blog = blog_t;
     blog_ok = true;
+    pts_ok = true;
+    f_trial = f_acc;
     const double ks_lo = uni(mu / pc.kappa_sigma), ks_hi = uni(pc.kappa_sigma * mu);
     OCP_FOR(e, SL) {
-      const double znew = l.Zt[e], lb = l.lbA[e], ub = l.ubA[e];
+      const double znew = l.Zt[e], zold = l.Z[e], d = l.D[e], lb = l.lbA[e], ub = l.ubA[e];
       l.Z[e] = znew;
-      if (lb > -INFINITY) {
-        const double is = rcp_fast(znew - lb);
-        l.zL[e] = fmin(fmax(l.zL[e] + a_z * l.dzL[e], ks_lo * is), ks_hi * is);
+      if (lb > -INFINITY) {   // dzL = mu / s - zL - zL d / s at the old point (the step phase's formula)
+        const double io = rcp_fast(zold - lb), is = rcp_fast(znew - lb), zl = l.zL[e];
+        const double dl = mu * io - zl - zl * io * d;
+        l.zL[e] = fmin(fmax(zl + a_z * dl, ks_lo * is), ks_hi * is);
       }
       if (ub < INFINITY) {
-        const double is = rcp_fast(ub - znew);
-        l.zU[e] = fmin(fmax(l.zU[e] + a_z * l.dzU[e], ks_lo * is), ks_hi * is);
+        const double io = rcp_fast(ub - zold), is = rcp_fast(ub - znew), zu = l.zU[e];
+        const double du = mu * io - zu + zu * io * d;
+        l.zU[e] = fmin(fmax(zu + a_z * du, ks_lo * is), ks_hi * is);
       }
     }
     OCP_FOR(e, N * NX) l.lam[e] += alpha * (l.lamn[e] - l.lam[e]);

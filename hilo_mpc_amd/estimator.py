@@ -235,6 +235,61 @@ class _KalmanFilter:
             return like_input(out, pred), like_input(yp, pred)
         return like_input(out[0], pred), like_input(yp[0].reshape(-1, 1), pred)
 
+    # ---- several steps per call: `self._function.mapaccum(steps)` (kf.py:296-306) -------------------
+    def _estimate_steps(self, y, u, p, steps):
+        """y [steps, B, n_y]; u [steps, B, n_u] or [B, n_u] (held over the steps); p like a single step.  One launch for all
+        steps (hilo_kf_steps); the solution holds the sequences x [steps, B, n_x], P [steps, B, n_x, n_x], y [steps, B, n_y]."""
+        dev = self._dev
+        yt = to_dev(y, dev)
+        B = self._x.shape[0]
+        if yt.numel() % (steps * self._n_y):
+            raise ValueError(f"Dimension mismatch for variable y. Supplied dimension is {yt.numel()}, but required dimension "
+                             f"is a multiple of {steps * self._n_y}.")
+        yt = yt.reshape(steps, -1, self._n_y).contiguous()
+        if yt.shape[1] != B:
+            if B != 1:
+                raise ValueError(f"Dimension mismatch. Supplied {yt.shape[1]} measurement vectors per step for {B} filters.")
+            B = yt.shape[1]
+            self._x = self._x.expand(B, -1).contiguous()
+            self._P = self._P.expand(B, -1, -1).contiguous()
+        nup = self._n_u + self._n_p
+        upt, us, ustep = None, 0, 0
+        if nup:
+            if self._n_p:
+                pt = self._p if p is None else to_dev(p, dev)
+                if pt is None:
+                    raise RuntimeError("No parameter values supplied. Please run set_initial_parameter_values() or pass p=.")
+                pt = (pt.reshape(1, -1) if pt.ndim <= 1 else pt).expand(B, -1)
+            if self._n_u:
+                if u is None:
+                    raise RuntimeError("No input data supplied.")
+                ut = to_dev(u, dev)
+                per_step = ut.numel() == steps * B * self._n_u and steps > 1
+                ut = ut.reshape(steps, B, self._n_u) if per_step else ut.reshape(-1, self._n_u).expand(B, -1)[None]
+            else:
+                per_step, ut = False, None
+            rows = steps if per_step else 1
+            upt = torch.empty(rows, B, nup, dtype=torch.float64, device=dev)
+            if self._n_u:
+                upt[:, :, :self._n_u] = ut
+            if self._n_p:
+                upt[:, :, self._n_u:] = pt[None]
+            us, ustep = nup, (B * nup if per_step else 0)
+        xP = torch.empty(B, self._n_x, self._n_x + 1, dtype=torch.float64, device=dev)
+        xP[:, :, 0] = self._x
+        xP[:, :, 1:] = self._P
+        out = torch.empty(steps, B, self._n_x, self._n_x + 1, dtype=torch.float64, device=dev)
+        yp = torch.empty(steps, B, self._n_y, dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().hilo_kf_steps(self._handle, B, int(steps), ptr(xP), ptr(yt), ptr(upt), us, ustep, ptr(self._Q),
+                                            self._cov_stride(self._Q, B), ptr(self._R), self._cov_stride(self._R, B), ptr(out), 1,
+                                            ptr(yp), stream_ptr(dev)))
+        self._x, self._P = out[-1, :, :, 0].contiguous(), out[-1, :, :, 1:].contiguous()
+        self._xP_cur = -1                                 # the resident ping-pong tiles are re-packed by the next single step
+        host = not isinstance(y, torch.Tensor)
+        cv = (lambda t: t.cpu().numpy()) if host else (lambda t: t)
+        self.solution._set(x=cv(out[:, :, :, 0]), P=cv(out[:, :, :, 1:]), y=cv(yp))
+        return self.solution
+
     # ---- estimate (kf.py:279-307) ----------------------------------------------------------------
     def estimate(self, y=None, u=None, p=None, **kwargs):
         self._check_setup()
@@ -243,6 +298,8 @@ class _KalmanFilter:
                                "the Kalman filter!")
         if y is None:
             raise RuntimeError("No measurement data supplied.")
+        if int(kwargs.get('steps', 1) or 1) > 1:
+            return self._estimate_steps(y, u, p, int(kwargs['steps']))
         B = self._x.shape[0]
         for name, val, n in (('y', y, self._n_y), ('u', u, self._n_u), ('p', p, self._n_p)):     # base.py `_process_inputs`
             if val is not None and n:

@@ -342,3 +342,38 @@ def compile_block(exprs, theta_index=None):
     for e in exprs:
         out += Expr.wrap(e).program(theta_index)
     return out
+
+
+def hessian_structure(e):
+    """(dep, pairs) of an expression: the leaves it depends on and the leaf pairs (a, b), a <= b in a fixed order of the keys
+    (kind, index), whose second derivative can be non-zero - the usual conservative propagation (a product couples the
+    dependencies of its factors, a nonlinear function those of its argument with themselves).  Used to drop Taylor directions of
+    the interior-point engine's derivative phase whose Hessian entry is structurally zero (csrc/hilo_ocp.h `pair_mask`)."""
+    e = Expr.wrap(e)
+    dep, prs = {}, {}
+
+    def cross(A, B):
+        return {(a, b) if a <= b else (b, a) for a in A for b in B}
+
+    for n in sorted(e.nodes().values(), key=lambda q: q.serial):
+        op, a = n.op, n.args
+        if op in ('x', 'u', 'p', 'z', 'theta'):
+            d, p = {(op, int(n.value) if n.value is not None else 0)}, set()
+        elif not a:
+            d, p = set(), set()
+        else:
+            ds, ps = [dep[id(c)] for c in a], [prs[id(c)] for c in a]
+            d = set().union(*ds)
+            p = set().union(*ps)
+            if op in ('add', 'sub', 'neg'):
+                pass
+            elif op == 'mul':
+                p |= cross(ds[0], ds[1])
+            elif op == 'div':
+                p |= cross(ds[0], ds[1]) | cross(ds[1], ds[1])
+            elif op == 'powi' and int(n.value) in (0, 1):
+                pass
+            else:                                         # sq, powi, every unary function, atan2, learned terms: all pairs
+                p |= cross(d, d)
+        dep[id(n)], prs[id(n)] = d, p
+    return dep[id(e)], prs[id(e)]

@@ -7,9 +7,13 @@ API mirror of `hilo_mpc.MHE` (`MovingHorizonEstimator`, hilo_mpc/modules/estimat
 N samples), `estimate(x_arrival=None, p_arrival=None, v0=None)` (mhe.py:311-416; returns `(None, None)` until the
 window is full, then `(x_N, p)` - the one-step-ahead state, mhe.py:381-384) - with a leading batch axis.
 
-Scope: pre-discretised model + `integration_method='discrete'`, state noise; model parameters either
-pinned by `p_lb == p_ub` or ESTIMATED (`quad_arrival_cost.add_parameters(weights, guess)`, bounds / guess / scaling of p,
-mhe.py:614-623) - `estimate` then returns `(x_opt, p_opt)`.
+Scope: state noise; the reference's integration branches (mhe.py:512-593) - `'collocation'` (its default for a continuous
+model: Radau / Legendre points of degree 1..4, collocation states in `v`, per-stage rows [collocation | continuity] in `lam_g`)
+and `'discrete'` (pre-discretised model; `'rk4'` / `'erk'` discretise the model first); models of the device zoo
+AND models written as expressions or text (`Model.set_dynamical_equations`, compiled with hiprtc at `setup()` around the
+estimator's policy, csrc/hilo_mhe_policy.h); a subset of the measurements in the cost (`add_measurements(weights, names=)`,
+modeling.py:686-712); model parameters either pinned by `p_lb == p_ub` or ESTIMATED (`quad_arrival_cost.add_parameters`,
+bounds / guess / scaling of p, mhe.py:614-623; zoo models with `'discrete'`) - `estimate` then returns `(x_opt, p_opt)`.
 """
 import ctypes as C
 import warnings
@@ -56,13 +60,27 @@ class _StageCost:
     def __init__(self, model):
         self._model = model
         self.Wy = self.Ww = None
+        self.ind_y = list(range(model.n_y))
         self._is_set = False
 
     def add_measurements(self, weights, names=None):
-        """modeling.py:686-712 (all measurements)."""
-        if names is not None and list(names) != list(self._model.measurement_names):
-            raise NotImplementedError("a subset of the measurements is not yet offloaded")
-        self.Wy = _weight_matrix(weights, self._model.n_y, 'weights')
+        """modeling.py:686-712: the measurements `names` (default: all) enter the cost with their measurement equations.  The
+        device policy evaluates the whole measurement map; a subset is the same cost with zero weight on the others, the
+        measured values of the subset placed at their positions (`ind_y`)."""
+        all_names = list(self._model.measurement_names)
+        if names is None:
+            ind = list(range(self._model.n_y))
+        else:
+            names = [names] if isinstance(names, str) else list(names)
+            ind = []
+            for n in names:
+                if n not in all_names:
+                    raise ValueError(f"The measurement {n} does not exist. The available states are {all_names}")
+                ind.append(all_names.index(n))
+        W = _weight_matrix(weights, len(ind), 'weights')
+        self.Wy = np.zeros((self._model.n_y, self._model.n_y))
+        self.Wy[np.ix_(ind, ind)] = W
+        self.ind_y = ind
         self._is_set = True
 
     def add_state_noise(self, weights):
@@ -76,13 +94,9 @@ class _StageCost:
 
 class MovingHorizonEstimator:
     def __init__(self, model, id=None, name=None, plot_backend=None, time=0., device_index=None):
-        if not model.discrete:
-            warnings.warn("The device backend needs a discrete-time model (MHE's 'rk4' option is not implemented in the "
-                          "reference either, SURVEY.md Q19). I am discretising with 'rk4' for you.")
-            model = model.discretize('rk4')
         if not model._is_setup:
             model.setup()
-        self._model = model
+        self._model = model                          # continuous: collocation by default, like the reference (mhe.py:512)
         self.name = name
         self._n_x, self._n_u, self._n_p, self._n_y = model.n_x, model.n_u, model.n_p, model.n_y
         self.quad_arrival_cost = _ArrivalCost(model)
@@ -146,17 +160,32 @@ class MovingHorizonEstimator:
             raise ValueError("You must set a horizon length before")
         if not (self.quad_arrival_cost._is_set or self.quad_stage_cost._is_set):
             raise ValueError("You need to define a cost function before setting up the MHE.")
-        opts = {'integration_method': 'discrete', 'arrival_guess_update': 'smoothing', 'warm_start': True}
+        m = self._model
+        opts = {'integration_method': 'discrete' if m.discrete else 'collocation', 'collocation_points': 'radau', 'degree': 3,
+                'arrival_guess_update': 'smoothing', 'warm_start': True}       # optimizer.py:1410-1418 defaults
         if options is None:
             options = getattr(self, '_pending_options', None)          # set_nlp_options(...) before setup()
         for k, v in (options or {}).items():
-            if k == 'integration_method' and v != 'discrete':
+            if k == 'integration_method' and m.discrete and v != 'discrete':
                 warnings.warn(f"The integration method is set to {v} but I notice that the model is in discrete time. "
                               f"I am overwriting and using discrete mode.")
                 continue
             if k == 'arrival_guess_update' and v == 'filtering':
                 raise NotImplementedError("The filtering update is not yet implemented.")      # mhe.py:257-258
             opts[k] = v
+        method = opts['integration_method']
+        if not m.discrete:
+            if method in ('rk4', 'erk'):
+                # explicit Runge-Kutta inside the window: the pre-discretised model + 'discrete' 
+                m = self._model = m.discretize(method) if method == 'rk4' else m.discretize('erk', order=opts.get('order', 4))
+                if not m._is_setup:
+                    m.setup()
+                method = opts['integration_method'] = 'discrete'
+            elif method == 'discrete':
+                raise ValueError("integration_method 'discrete' needs a discrete-time model (Model.discretize)")
+            elif method != 'collocation':
+                raise NotImplementedError(f"integration method '{method}' is not offloaded (the reference's 'multiple_shooting' "
+                                          f"branch integrates with CVODES)")
         self._nlp_options = opts
         if nlp_opts is not None:
             self.set_solver_opts(nlp_opts)
@@ -166,7 +195,20 @@ class MovingHorizonEstimator:
         if self.quad_stage_cost.Ww is None:
             raise NotImplementedError("MHE without state noise is not yet offloaded (and its 'multiple_shooting' branch "
                                       "is broken in the reference, SURVEY.md Q8)")
-        m = self._model
+        coll = None
+        if method == 'collocation':
+            from .nmpc import _collocation_basis
+            deg = int(opts.get('degree', 3))
+            if not 1 <= deg <= 4:
+                raise NotImplementedError("collocation degrees 1..4 are built")
+            coll = _collocation_basis(deg, opts.get('collocation_points', 'radau'))
+        self._coll = coll
+        # models written as expressions, and every model under collocation: the policy is compiled around the model at setup
+        jit = bool(getattr(m, '_symbolic', False)) or coll is not None
+        if jit and self._estimating:
+            raise NotImplementedError("parameter estimation is offloaded for the zoo models with integration_method 'discrete'")
+        if jit and not m.n_y:
+            raise RuntimeError("The model has no measurement equations (set_measurement_equations)")
         keep = []
 
         def hp(a):
@@ -178,6 +220,14 @@ class MovingHorizonEstimator:
 
         d = _lib.MheDesc()
         d.model_id, d.N = m.model_id, self._horizon
+        if jit:
+            self._user_source = m.user_source()
+            d.user_source = self._user_source.encode()
+            d.user_nx, d.user_nu, d.user_np, d.user_ny = m.n_x, m.n_u, m.n_p, m.n_y
+            d.user_discrete = 1 if getattr(m, '_native_discrete', False) else 0
+        if coll is not None:
+            d.collocation_degree = coll['d']
+            d.coll_A, d.coll_D = hp(coll['A']), hp(coll['D'])
         d.erk_order = m.erk_order if m.erk_order else 4
         d.n_sub = m.n_sub
         so = self._solver_options
@@ -194,17 +244,28 @@ class MovingHorizonEstimator:
             d.Wp = hp(self.quad_arrival_cost.Wp)
             d.p_lb, d.p_ub = hp(self._p_lb), hp(self._p_ub)
             d.p_scaling, d.p_guess = hp(getattr(self, '_p_scaling', None)), hp(getattr(self, '_p_guess', None))
-        self._dev = device(self._dev_index)
+        import os
         h = C.c_void_p()
+        if os.environ.get('HILO_JIT_COMPILE_ONLY'):
+            # filling the run-time compiler's cache on a machine without a GPU (tools/warm_jit_cache.py): compile and stop
+            if jit:
+                rc = _lib.lib().hilo_mhe_create(C.byref(d), 0, C.byref(h))
+                if rc != _lib.COMPILED_ONLY:
+                    _lib.check(rc)
+            return
+        self._dev = device(self._dev_index)
         _lib.check(_lib.lib().hilo_mhe_create(C.byref(d), self._dev.index, C.byref(h)))
         self._destroy()
         self._handle = h
         N, nx, np_ = self._horizon, self._n_x, self._n_p
-        self._n_v, self._n_g = np_ + (N + 1) * nx + N * nx, N * nx
+        dn = coll['d'] * nx if coll is not None else 0
+        self._n_v, self._n_g = np_ + (N + 1) * nx + N * nx + N * dn, N * (nx + dn)
         # bit-exact index maps of mhe.py:614-655
         self._p_ind = [list(range(np_))] if np_ else []
         self._x_ind = [list(range(np_ + k * nx, np_ + (k + 1) * nx)) for k in range(N + 1)]
         self._w_ind = [list(range(np_ + (N + 1) * nx + k * nx, np_ + (N + 1) * nx + (k + 1) * nx)) for k in range(N)]
+        off = np_ + (N + 1) * nx + N * nx                         # collocation states behind the noise block (mhe.py:657-671)
+        self._ip_ind = [list(range(off + k * dn, off + (k + 1) * dn)) for k in range(N)] if dn else []
         self._sx = np.ones(nx) if self._x_scaling is None else np.asarray(self._x_scaling)
         self._sp = np.ones(np_) if getattr(self, '_p_scaling', None) is None else np.asarray(self._p_scaling)
         self._p_pinned = None if (not np_ or self._estimating) else to_dev(np.asarray(self._p_lb, dtype=float), self._dev, (1, -1))
@@ -225,7 +286,20 @@ class MovingHorizonEstimator:
     def add_measurements(self, y_meas, u_meas=None):
         if not self._nlp_setup_done:
             raise RuntimeError("You need to setup the MHE by running .setup() before running add_measurements")
-        y = to_dev(y_meas, self._dev).reshape(-1, self._n_y)
+        ind = self.quad_stage_cost.ind_y
+        y = to_dev(y_meas, self._dev)
+        ns, ny = len(ind), self._n_y
+        if ns != ny:
+            # the cost uses a subset of the measurements: their measured values alone (mhe.py `_check_measurements`) are placed at
+            # their positions of the measurement vector; a full measurement vector is taken as it is
+            width = y.shape[-1] if y.ndim >= 2 else (ns if y.numel() == ns else (ny if y.numel() % ny == 0 else ns))
+            if width == ns:
+                if y.numel() % ns:
+                    raise ValueError(f"Dimension mismatch: {y.numel()} measured values for {ns} measurement(s) in the cost")
+                ys = y.reshape(-1, ns)
+                y = torch.zeros(ys.shape[0], ny, dtype=torch.float64, device=self._dev)
+                y[:, ind] = ys
+        y = y.reshape(-1, self._n_y)
         B = y.shape[0]
         u = None
         if self._n_u:

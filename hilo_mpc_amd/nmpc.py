@@ -706,6 +706,7 @@ class NMPC:
         d.acceptable_tol = float(so.get('acceptable_tol', 0.))
         d.mu_init = float(so.get('mu_init', 0.))
         d.bound_relax_factor = float(so.get('bound_relax_factor', -1.))
+        d.max_hessian_perturbation = float(so.get('max_hessian_perturbation', 0.))
         d.Wz, d.zref, d.WN, d.xrefN = hp(Wz), hp(zref), hp(WN), hp(xrefN)
         d.Wdu = hp(Wdu) if has_du else None
         d.x_lb, d.x_ub, d.u_lb, d.u_ub = hp(self._x_lb), hp(self._x_ub), hp(self._u_lb), hp(self._u_ub)
@@ -845,6 +846,13 @@ class NMPC:
                 d.user_has_fun = 1
                 d.path_prog, d.path_prog_len = None, 0          # expressions are compiled in, not interpreted
                 d.con_prog, d.con_prog_len, d.tcon_prog, d.tcon_prog_len = None, 0, None, 0
+                pat = self._hessian_pattern(m, nx, nu, nth, Wz, Wdu if has_du else None, gen_stage, sc, tc,
+                                            composed=bool(cont or coll is not None))
+                if pat is not None:
+                    pat = np.ascontiguousarray(pat, dtype=np.uint8)
+                    keep.append(pat)
+                    d.hess_pattern = pat.ctypes.data
+                self._hess_pattern = pat
             self._user_source = src
             d.user_source = src.encode()
             d.user_policy = policy
@@ -1009,6 +1017,19 @@ class NMPC:
         # the reference keeps the whole solver result (mpc.py:722-723): constraint values g and bound multipliers lam_x too.
         # Opt-in here (`keep_full_solution = True`): two more result vectors per instance that a control loop never reads.
         # Layouts with a collocation output pass return them as zeros.
+        # lbx / ubx of THIS call (`v_lb=` / `v_ub=`: [n_v] or [B, n_v], scaled like v) - the reference passes its bound vectors
+        # with every solver call (mpc.py:722) and moves entries between calls (mpc.py:797-807); None keeps the setup's bounds
+        vlb, vub = kwargs.get('v_lb'), kwargs.get('v_ub')
+        if (vlb is None) != (vub is None):
+            raise ValueError("pass both v_lb and v_ub (the solver call's lbx and ubx) or neither")
+        if vlb is not None:
+            vlb = to_dev(vlb, self._dev).reshape(-1, self._n_v)
+            vub = to_dev(vub, self._dev).reshape(-1, self._n_v)
+            vlb = (vlb.expand(B, -1) if vlb.shape[0] == 1 else vlb).contiguous()
+            vub = (vub.expand(B, -1) if vub.shape[0] == 1 else vub).contiguous()
+            if vlb.shape[0] != B or vub.shape[0] != B:
+                raise ValueError(f"v_lb / v_ub need one row or {B} rows of {self._n_v} entries")
+        _lib.check(_lib.lib().hilo_nmpc_set_var_bounds(self._handle, ptr(vlb), ptr(vub)))
         g_val = lam_x = None
         if self._full_solution:
             g_val = torch.zeros(B, self._n_g, dtype=torch.float64, device=dev)
@@ -1041,6 +1062,45 @@ class NMPC:
             u = u0.cpu().numpy()
             return u.reshape(-1, 1) if single else u     # single instance: (nu x 1) like the reference's DM
         return u0[0] if single else u0
+
+    def _hessian_pattern(self, m, nx, nu, nth, Wz, Wdu, gen_stage, sc, tc, composed=False):
+        """Structural sparsity of the interval Hessian over the augmented z = [x, theta | u, u_theta] (hilo_mpc_amd/sparsity.py),
+        or None (dense) when the model has no expression form."""
+        from . import zoo_expr
+        from .model import Model
+        from .sparsity import stage_hessian_pattern
+        if getattr(m, 'n_z', 0) or getattr(m, '_gps', None):
+            return None
+        if getattr(m, '_symbolic', False):
+            ode = m._ode
+        elif m.name in zoo_expr.FUNCTOR or m.name in zoo_expr.STRUCTURE_ONLY:
+            ode = zoo_expr.define(Model(name=m.name + '_structure'), m.name)._ode
+        else:
+            return None
+        mza = nx + nth + nu + nth
+        az = lambda i: i if i < nx else nx + nth + (i - nx)            # noqa: E731  model z -> augmented z
+        Wa = np.zeros((mza, mza))
+        W = np.asarray(Wz, dtype=float).reshape(nx + nu, nx + nu)
+        for i in range(nx + nu):
+            for j in range(nx + nu):
+                Wa[az(i), az(j)] = W[i, j]
+        # stage constraints act at the node (mpc.py:1700-1725; with collocation also at the collocation states: composed);
+        # a hard terminal constraint on the integrated end state (mpc.py:1693-1700), a soft one at the node x_{N-1}
+        exprs = [gen_stage] + (list(sc.constraint) if sc.is_set else []) + (list(tc.constraint) if tc.is_set and tc.is_soft else [])
+        exprs_c = list(tc.constraint) if tc.is_set and not tc.is_soft else []
+        terms, o, Wp = [], 0, None
+        if nth:
+            ind, refs = [], []
+            for i, W_, r in self.quad_stage_cost._paths:
+                ind += list(i)
+                refs += list(r)
+            Wp = np.zeros((len(ind), len(ind)))
+            for i, W_, r in self.quad_stage_cost._paths:
+                Wp[o:o + len(i), o:o + len(i)] = W_
+                o += len(i)
+            terms = list(zip(ind, refs))
+        return stage_hessian_pattern(ode, nx, nu, nth, discrete=bool(getattr(m, '_native_discrete', False)), Wz=Wa, Wdu=Wdu,
+                                     exprs=exprs, path_terms=terms, path_weights=Wp, composed=composed, exprs_composed=exprs_c)
 
     def _multi_start(self, x0, cp, tvp, v0, runs, fix_x0, kwargs):
         """mpc.py:727-741: `runs` solves, the first from the given start, the following from `v0 (1 + (1 - 2 rand) pert_factor)`

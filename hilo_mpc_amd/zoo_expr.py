@@ -5,6 +5,8 @@ derivative code of the interior-point engine for these models), and the tests bu
 from . import expr as _e
 
 FUNCTOR = {'chemostat4': 'Chemostat4', 'pendulum4': 'Pendulum4', 'cstr3': 'Cstr3'}
+# models whose expressions are only used to ANALYSE the structure (Hessian sparsity of the general policy): no generated code
+STRUCTURE_ONLY = ('robot6',)
 
 # CSTR_Example.ipynb cell 4
 CSTR = dict(T_0=400., tau=60., k_A=5000., k_B=1e6, E_A=1e4, E_B=1.5e4, R=1.987, dH=-5000., rho=1., Cp=1000., C_A_0=1., V=100.)
@@ -49,6 +51,11 @@ def define(m, name):
         u = m.set_inputs(['Q'])
         m.set_dynamical_equations(cstr_equations(x, u)[0])
         m.set_measurement_equations([cstr_equations(x, u)[1]])
+    elif name == 'robot6':
+        x = m.set_dynamical_states(['px', 'vx', 'py', 'vy', 'psi', 'omega'])
+        u = m.set_inputs(['a', 'alpha'])
+        m.set_dynamical_equations([x[1], u[0] * _e.cos(x[4]), x[3], u[0] * _e.sin(x[4]), x[5], 1.0 * u[1]])
+        m.set_measurement_equations([x[0], x[2]])
     else:
         raise ValueError(name)
     return m

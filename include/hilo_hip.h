@@ -149,6 +149,14 @@ int hilo_kf_step(hilo_kf* kf, int64_t batch, const double* xP, const double* y,
                  const double* up, int64_t up_stride, const double* Q, int64_t q_stride,
                  const double* R, int64_t r_stride, double* xP_out, double* y_pred, void* stream);
 
+/* `steps` estimate() steps in ONE launch: `self._function.mapaccum(steps)` (kf.py:296-306).  y [steps][B][ny]; inputs / parameters
+   the same for every step (up_step_stride = 0) or [steps][B][nu+np] (up_step_stride = elements between two steps); Q, R as
+   for a single step.  keep_all != 0: xP_out [steps][B][nx][nx+1] holds the tile after every step (what mapaccum returns), else
+   [B][nx][nx+1] the last one; y_pred [steps][B][ny]. */
+int hilo_kf_steps(hilo_kf* kf, int64_t batch, int steps, const double* xP, const double* y,
+                  const double* up, int64_t up_stride, int64_t up_step_stride, const double* Q, int64_t q_stride,
+                  const double* R, int64_t r_stride, double* xP_out, int keep_all, double* y_pred, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------- */
 /* Gaussian process: exact inference + prediction                                                           */
 /* replaces `ca.Function('prediction',[X,w,p],[mean,var])` (hilo_mpc/modules/machine_learning/gp/gp.py:      */
@@ -324,6 +332,12 @@ typedef struct hilo_nmpc_desc {
   const hilo_gp* user_gp[4];
   /* with user_policy 2 the constraint / path expressions are compiled into UserFun: n_con, n_tcon, n_path_stage, n_path_term
      count them as above, the *_prog pointers stay NULL */
+  /* user_policy 2: structural sparsity of the Hessian of an interval's Lagrangian, [mza][mza] bytes over the augmented model
+     z = [x, theta | u, u_theta] (1 = the entry can be non-zero; symmetric; NULL = dense).  CasADi evaluates only the non-zero
+     Hessian entries of the graph it is given (mpc.py:1778-1787); here a zero entry drops the Taylor sweep of its direction. */
+  const unsigned char* hess_pattern;
+  double max_hessian_perturbation;   /* IPOPT option of that name (delta_w^max of W&B Alg. IC, default 1e20 there, 1e40 here =
+                                        the oracle's): beyond it the inertia correction gives up -> status 4; <= 0 keeps the default */
 } hilo_nmpc_desc;
 
 #define HILO_MODEL_USER 100    /* model defined by desc.user_source */
@@ -363,6 +377,12 @@ int hilo_nmpc_set_aux_outputs(hilo_nmpc* h, double* g, double* lam_x);
    (fp64) of the device table [batch][stride] itself - the send buffer of the per-step result gather.  NULL switches it off.
    Honoured by plain tracking problems; the reference has no counterpart (single instance, no batching). */
 int hilo_nmpc_set_gather(hilo_nmpc* h, double* table, int stride);
+/* lbx / ubx of the reference's solver call, `self._solver(x0=v0, lbx=self._v_lb, ubx=self._v_ub, ...)` (mpc.py:722): DEVICE rows
+   [batch][n_v] in the layout of v (scaled variables, original bound values: IPOPT's bound_relax_factor is applied by the solve),
+   read by every following hilo_nmpc_solve; NULL, NULL = back to the bounds of the description.  Per instance and per call, so that
+   a caller can move bounds between steps as the reference does (mpc.py:797-807).  The entries of a pinned x_0 are ignored (the
+   solve pins x_0 to the `x0` argument, which is what mpc.py:801-802 writes into both arrays); lb < ub elsewhere. */
+int hilo_nmpc_set_var_bounds(hilo_nmpc* h, const double* lbx, const double* ubx);
 /* optimize(fix_x0=...) of mpc.py:797-807: 1 (default) pins x_0 to the measured state; 0 leaves x_0 free inside the state
    box [x_lb, x_ub] (the `x0` argument of hilo_nmpc_solve is then ignored, the start value comes from the warm start / guess).
    Synchronises the device when the setting changes. */
@@ -429,6 +449,16 @@ typedef struct hilo_mhe_desc {
   int32_t reserved;
   const double* Wp;          /* [np][np] */
   const double* p_lb; const double* p_ub; const double* p_scaling; const double* p_guess;   /* [np], original units */
+  /* ---- run-time compiled estimator (round 3): the model as HIP source of `UserModel` (hilo_nmpc_desc.user_source: the
+     functor emitted from the model's expressions, or the alias of a zoo functor), compiled with hiprtc around the estimator's
+     policy at create (what `MovingHorizonEstimator.setup` -> `ca.nlpsol` does with the CasADi graph, mhe.py:782-790).
+     model_id = HILO_MODEL_USER takes the dimensions below.  collocation_degree > 0: the reference's DEFAULT transcription
+     (mhe.py:512-561; needs a continuous model and user_source): v gains the collocation block behind the noise block,
+     [p | x | w | ip_0..ip_{N-1}] (mhe.py:657-671), lam_g the per-stage rows [collocation (d nx) | continuity (nx)]. ---- */
+  const char* user_source;
+  int32_t user_nx, user_nu, user_np, user_ny, user_discrete, collocation_degree;
+  const double* coll_A;      /* [d][d]  Runge-Kutta matrix of the collocation method (hilo_nmpc_desc.coll_A) */
+  const double* coll_D;      /* [d + 1] continuity weights */
 } hilo_mhe_desc;
 
 int hilo_mhe_create(const hilo_mhe_desc* desc, int device, hilo_mhe** out);          /* = setup(), mhe.py:418 */
@@ -436,7 +466,7 @@ void hilo_mhe_destroy(hilo_mhe* h);
 int hilo_mhe_dims(const hilo_mhe* h, int* n_v, int* n_g, int* nx, int* nu, int* np, int* ny);
 int hilo_mhe_reset_warm_start(hilo_mhe* h);
 /* One estimate() for `batch` independent estimators over a full window (mhe.py:311-416).
-   v layout = the reference's decision vector [p | x_0..x_N | w_0..w_{N-1}] (scaled, mhe.py:614-655). */
+   v layout = the reference's decision vector [p | x_0..x_N | w_0..w_{N-1} (| collocation states)] (scaled, mhe.py:614-671). */
 int hilo_mhe_estimate(hilo_mhe* h, int64_t batch,
                       const double* x_arrival,            /* [B][nx]   arrival guess, original units (mhe.py:347-351) */
                       const double* p, int64_t p_stride,  /* [B][np]   pinned model parameters */

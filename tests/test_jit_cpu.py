@@ -110,3 +110,17 @@ def test_model_with_the_whole_function_table_compiles(policy):
 def test_filter_kernels_with_the_whole_function_table_compile():
     """... and first-order dual numbers (Kalman filters)."""
     _lib.check(_lib.lib().hilo_jit_precompile_kf(_table_model().user_source().encode()))
+
+
+@pytest.mark.parametrize('coll_d', [0, 3])
+@pytest.mark.parametrize('name', ['chemostat4', 'table'])
+def test_moving_horizon_estimator_policy_compiles_for_expression_models(name, coll_d):
+    """JIT_MHE (csrc/hilo_mhe_policy.h around the emitted functor): explicit Runge-Kutta with symbolic derivatives, and the
+    reference's default transcription, collocation (Taylor path), for a zoo twin and for a model without one."""
+    m = symbolic_model(name) if name != 'table' else _table_model()
+    _compile(m.user_source(), policy=3, coll_d=coll_d, N=6)
+
+
+def test_moving_horizon_estimator_policy_compiles_for_a_zoo_functor_under_collocation():
+    from hilo_mpc_amd import Model
+    _compile(Model('chemostat4').user_source(), policy=3, coll_d=2, N=5)

@@ -271,3 +271,45 @@ def test_filters_on_a_model_written_as_expressions_equal_the_zoo_filter(kind):
     f.set_initial_guess(np.array([[2.5, 0., .1, 0.]]), P0=np.eye(4)[None])
     sol = f.estimate(y=np.array([[2.5, 0., .1, 0.]]), u=np.array([[.2]]))
     assert np.all(np.isfinite(f.x.cpu().numpy())) and np.all(np.isfinite(f.P.cpu().numpy()))
+
+
+@pytest.mark.parametrize('kind', ['EKF', 'UKF'])
+@pytest.mark.parametrize('symbolic', [False, True])
+def test_several_steps_in_one_launch_equal_the_single_steps(kind, symbolic):
+    """`estimate(steps=K)` = `self._function.mapaccum(steps)` of the reference (kf.py:296-306): one launch for K filter steps with
+    per-step measurements and inputs (hilo_kf_steps), the tile of every step returned - against K calls of the single step."""
+    import hilo_mpc_amd as H
+    from tests.problems import symbolic_model
+    K, B = 5, 300
+    x, P, u, p, y = _chemo_batch(B, seed=7)
+    rng = np.random.default_rng(8)
+    ys = y[None] + .01 * rng.normal(size=(K, B, 2))
+    us = u[None] * (1 + .1 * rng.uniform(-1, 1, (K, B, 2)))
+    model = (symbolic_model('chemostat4') if symbolic else H.Model('chemostat4')).discretize('erk', order=4).setup(dt=1.)
+    one, many, held = (getattr(H, kind)(model) for _ in range(3))
+    for f in (one, many, held):
+        f.setup()
+        f.Q, f.R = 1e-4, 1e-2
+        f.set_initial_guess(x, P0=P)
+    xs, Ps, yps = [], [], []
+    for k in range(K):
+        sol = one.estimate(y=ys[k], u=us[k], p=p)
+        xs.append(one.x.cpu().numpy()), Ps.append(one.P.cpu().numpy()), yps.append(np.asarray(sol['y']))
+    sol = many.estimate(y=ys, u=us, p=p, steps=K)
+    assert sol['x'].shape == (K, B, 4) and sol['P'].shape == (K, B, 4, 4) and sol['y'].shape == (K, B, 2)
+    np.testing.assert_allclose(sol['x'], np.stack(xs), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(sol['P'], np.stack(Ps), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(sol['y'], np.stack(yps), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(many.x.cpu().numpy(), xs[-1], rtol=1e-13, atol=1e-15)
+    # inputs held over the steps; and a single step after a multi-step call continues from its last tile
+    solh = held.estimate(y=ys, u=us[0], p=p, steps=K)
+    ref = getattr(H, kind)(model)
+    ref.setup()
+    ref.Q, ref.R = 1e-4, 1e-2
+    ref.set_initial_guess(x, P0=P)
+    for k in range(K):
+        ref.estimate(y=ys[k], u=us[0], p=p)
+    np.testing.assert_allclose(solh['x'][-1], ref.x.cpu().numpy(), rtol=1e-13, atol=1e-15)
+    held.estimate(y=ys[0], u=us[0], p=p)
+    ref.estimate(y=ys[0], u=us[0], p=p)
+    np.testing.assert_allclose(held.x.cpu().numpy(), ref.x.cpu().numpy(), rtol=1e-13, atol=1e-15)

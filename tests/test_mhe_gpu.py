@@ -201,3 +201,158 @@ def test_scalings_vs_oracle(over):
     assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 5e-5
     np.testing.assert_allclose(x.cpu().numpy(), ref['x_opt'], rtol=5e-5, atol=1e-6)
     np.testing.assert_allclose(mhe._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-7, atol=1e-10)
+
+
+# ---- round 3: the estimator through the model front-end (SURVEY 8 rows a11 + f1), collocation, measurement subsets --------------
+def _mhe_from(m, spec, options, names=None, Wy=None, **solver_options):
+    from hilo_mpc_amd import MHE
+    mhe = MHE(m)
+    mhe.quad_arrival_cost.add_states(weights=list(spec['Wx']), guess=spec['x_guess'])
+    mhe.quad_stage_cost.add_measurements(weights=list(spec['Wy'] if Wy is None else Wy), names=names)
+    mhe.quad_stage_cost.add_state_noise(weights=list(spec['Ww']))
+    mhe.horizon = spec['N']
+    mhe.set_box_constraints(x_lb=spec.get('x_lb'), x_ub=spec.get('x_ub'), w_lb=spec.get('w_lb'), w_ub=spec.get('w_ub'),
+                            p_lb=spec['p'] or None, p_ub=spec['p'] or None)
+    mhe.set_initial_guess(x_guess=spec['x_guess'])
+    mhe.setup(options=options, nlp_opts=solver_options or None)
+    return mhe
+
+
+def test_expression_model_estimator_equals_the_zoo_functor_bitwise():
+    """chemostat4 written as expressions: the run-time compiled policy (hiprtc, csrc/hilo_mhe_policy.h around the emitted functor
+    and its generated symbolic derivatives) walks the same iterates as the policy compiled into the library."""
+    from tests.problems import symbolic_model
+    N, B = 12, 8
+    spec = dict(C3B, N=N)
+    xa, um, ym, _ = c3_data(B, N=N)
+    zoo = product_mhe(spec)
+    m = symbolic_model('chemostat4').discretize('erk', order=4).setup(dt=spec['dt'])
+    jit = _mhe_from(m, spec, {'integration_method': 'discrete'})
+    assert jit._user_source and 'struct UserModel' in jit._user_source
+    for mhe in (zoo, jit):
+        for k in range(N):
+            mhe.add_measurements(ym[:, k], um[:, k])
+    xz, _ = zoo.estimate(x_arrival=xa)
+    xj, _ = jit.estimate(x_arrival=xa)
+    assert np.array_equal(zoo.solver_status_code, jit.solver_status_code) and np.all(zoo.solver_status_code == 1)
+    assert np.array_equal(zoo._nlp_solution['iter_count'].cpu().numpy(), jit._nlp_solution['iter_count'].cpu().numpy())
+    np.testing.assert_array_equal(zoo._nlp_solution['x'].cpu().numpy(), jit._nlp_solution['x'].cpu().numpy())
+    np.testing.assert_array_equal(xz.cpu().numpy(), xj.cpu().numpy())
+    # second window: warm start from the previous solution (rows with the parameter prefix), smoothing update
+    for mhe in (zoo, jit):
+        mhe.add_measurements(ym[:, -1], um[:, -1])
+    np.testing.assert_array_equal(zoo.estimate()[0].cpu().numpy(), jit.estimate()[0].cpu().numpy())
+
+
+def test_estimator_on_a_model_without_a_zoo_twin_vs_oracle():
+    """The pendulum on a cart has no estimator instantiation in the library: written as expressions it is compiled at setup and
+    estimated against the oracle (oracle/mhe.py on oracle/models.py::pendulum4)."""
+    from oracle import models
+    from oracle.mhe import MheProblem
+    from oracle.shooting import ShootingMap
+    from tests.problems import symbolic_model
+    N, B, dt = 10, 4, .05
+    om = models.get('pendulum4')
+    rng = np.random.default_rng(3)
+    sm = ShootingMap(om, 4)
+    x = np.array([0., 0., .3, 0.]) * (1 + .1 * rng.uniform(-1, 1, (B, 4))) + .01 * rng.normal(size=(B, 4))
+    xs, um = [x], np.empty((B, N, 1))
+    for k in range(N):
+        um[:, k, 0] = .5 * np.sin(.4 * k + rng.uniform(0, 6.28, B))
+        x = sm.value(x, um[:, k], [], dt)
+        xs.append(x)
+    xt = np.stack(xs, axis=1)
+    ym = xt[:, :N] + .01 * rng.normal(size=(B, N, 4))
+    xa = xt[:, 0] + .02 * rng.normal(size=(B, 4))
+    spec = dict(dt=dt, N=N, order=4, Wx=[4.] * 4, Wy=[16.] * 4, Ww=[1e4] * 4, w_lb=[-1e-2] * 4, w_ub=[1e-2] * 4,
+                x_guess=[0., 0., .3, 0.], p=[])
+    pb = MheProblem(om, **{k: v for k, v in spec.items() if k != 'p'})
+    ref = MheIpm(pb).solve(xa, [], um, ym)
+    assert np.all(ref['status'] == 1)
+    m = symbolic_model('pendulum4').discretize('erk', order=4).setup(dt=dt)
+    mhe = _mhe_from(m, spec, {'integration_method': 'discrete'})
+    for k in range(N):
+        mhe.add_measurements(ym[:, k], um[:, k])
+    x_opt, p_opt = mhe.estimate(x_arrival=xa)
+    assert p_opt is None and np.array_equal(mhe.solver_status_code, ref['status'])
+    v, vr = mhe._nlp_solution['x'].cpu().numpy(), ref['v']
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 1e-5
+    np.testing.assert_allclose(mhe._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(x_opt.cpu().numpy(), ref['x_opt'], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('degree,points,symbolic', [(3, 'radau', False), (2, 'radau', True), (3, 'legendre', True)])
+def test_collocation_inside_the_estimator_vs_oracle(degree, points, symbolic):
+    """The reference's DEFAULT integration method (mhe.py:512-561) on the continuous chemostat - zoo functor and expression model:
+    solution incl. the collocation states behind the noise block of v, and lam_g in the reference's row order (per stage
+    [collocation rows | continuity]) against the oracle's simultaneous form (oracle/mhe_coll.py) at a tight matched tolerance."""
+    from hilo_mpc_amd import Model
+    from oracle import models
+    from oracle.mhe_coll import MheCollIpm, MheCollProblem
+    from oracle.nmpc import IpmOptions
+    from tests.problems import symbolic_model
+    N, B = 8, 4
+    spec = dict(C3B, N=N)
+    xa, um, ym, _ = c3_data(B, N=N)
+    pb = MheCollProblem(models.get('chemostat4'), degree=degree, points=points,
+                        **{k: v for k, v in spec.items() if k not in ('model', 'p', 'order')})
+    ref = MheCollIpm(pb, IpmOptions(tol=1e-11)).solve(xa, spec['p'], um, ym)
+    assert np.all(ref['status'] == 1)
+    m = (symbolic_model('chemostat4') if symbolic else Model('chemostat4')).setup(dt=spec['dt'])
+    assert not m.discrete
+    mhe = _mhe_from(m, spec, {'integration_method': 'collocation', 'degree': degree, 'collocation_points': points}, tol=1e-11)
+    nx = 4
+    assert (mhe._n_v, mhe._n_g) == (pb.n_v, pb.n_g) and mhe._ip_ind == pb.ip_ind and mhe._x_ind == pb.x_ind and mhe._w_ind == pb.w_ind
+    for k in range(N):
+        mhe.add_measurements(ym[:, k], um[:, k])
+    x_opt, _ = mhe.estimate(x_arrival=xa)
+    assert np.all(mhe.solver_status_code == 1)
+    v, vr = mhe._nlp_solution['x'].cpu().numpy(), ref['v']
+    assert v.shape == vr.shape == (B, 4 + (N + 1) * nx + N * nx + N * degree * nx)
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 2e-6
+    np.testing.assert_allclose(mhe._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(x_opt.cpu().numpy(), ref['x_opt'], rtol=2e-6, atol=1e-8)
+    lg, lr = mhe._nlp_solution['lam_g'].cpu().numpy(), ref['lam']
+    assert lg.shape == lr.shape == (B, N * (degree * nx + nx))
+    assert np.max(np.abs(lg - lr)) < 2e-4 * max(1., np.abs(lr).max())
+
+
+def test_default_integration_method_of_a_continuous_model_is_collocation():
+    """mhe.py:512 / optimizer.py:1410-1418: a continuous model without an `integration_method` option gets Radau-3 collocation."""
+    from hilo_mpc_amd import Model
+    spec = dict(C3B, N=5)
+    mhe = _mhe_from(Model('chemostat4').setup(dt=spec['dt']), spec, None)
+    assert mhe._nlp_options['integration_method'] == 'collocation' and mhe._coll['d'] == 3
+    assert mhe._n_v == 4 + 6 * 4 + 5 * 4 + 5 * 12 and mhe._n_g == 5 * 16
+
+
+def test_measurement_subset_in_the_cost_vs_oracle():
+    """`quad_stage_cost.add_measurements(weights, names=['yP'])` (modeling.py:686-712): only the product concentration enters the
+    cost; `add_measurements(y)` takes the measured values of that subset (or the whole measurement vector)."""
+    N, B = 8, 4
+    spec = dict(C3B, N=N)
+    xa, um, ym, _ = c3_data(B, N=N)
+    Wy = np.zeros((2, 2))
+    Wy[1, 1] = 16.
+    pb = oracle_mhe(dict(spec, Wy=Wy))
+    ym_sub = ym.copy()
+    ym_sub[:, :, 0] = 0.                                        # the unused measurement carries no weight: any value
+    ref = MheIpm(pb).solve(xa, spec['p'], um, ym_sub)
+    assert np.all(ref['status'] == 1)
+    from hilo_mpc_amd import Model
+    m = Model('chemostat4').discretize('erk', order=4).setup(dt=spec['dt'])
+    name = m.measurement_names[1]
+    outs = []
+    for full in (False, True):
+        mhe = _mhe_from(m, spec, {'integration_method': 'discrete'}, names=[name], Wy=[16.])
+        assert mhe.quad_stage_cost.ind_y == [1]
+        for k in range(N):
+            mhe.add_measurements(ym[:, k] if full else ym[:, k, 1:2], um[:, k])
+        x_opt, _ = mhe.estimate(x_arrival=xa)
+        assert np.array_equal(mhe.solver_status_code, ref['status'])
+        np.testing.assert_allclose(mhe._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(x_opt.cpu().numpy(), ref['x_opt'], rtol=2e-5, atol=1e-6)
+        outs.append(x_opt.cpu().numpy())
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-9)
+    with pytest.raises(ValueError, match="does not exist"):
+        mhe.quad_stage_cost.add_measurements(weights=[1.], names=['nope'])
