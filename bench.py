@@ -358,15 +358,23 @@ def wl_kf(kind, args, torch, dev, rank, world):
     f.set_initial_guess(torch.as_tensor(x, device=dev), P0=torch.as_tensor(Pm, device=dev))
     u = torch.as_tensor(rng.uniform(0, .3, (B, 2)), device=dev)
     p = torch.as_tensor(np.tile([100., 4., 1., 0.], (B, 1)), device=dev)
-    ynoise = torch.as_tensor(.1 * rng.normal(size=(16, B, 2)), device=dev)
+    # K filter steps per launch: the reference's `mapaccum(steps)` (kf.py:296-306), hilo_kf_steps - measurements of K sampling
+    # instants handed over at once (a filter step at this batch is launch-latency bound)
+    K = max(1, int(getattr(args, 'kf_steps', 16) or 16))
+    ybase = torch.as_tensor(x[:, [0, 2]], device=dev)
+    ynoise = torch.as_tensor(.02 * rng.normal(size=(4, K, B, 2)), device=dev)
+    ys = [ybase[None] * (1 + ynoise[q]) for q in range(4)]
     ev, cnt = [], [0]
 
     def step(timed):
-        y = f.x[:, [0, 2]] + ynoise[cnt[0] % 16]
+        y = ys[cnt[0] % 4]
         cnt[0] += 1
         e = _events(torch, 1)[0]        # warm-up steps run the identical path (event creation included)
         e[0].record()
-        f.estimate(y=y, u=u, p=p)
+        if K > 1:
+            f.estimate(y=y, u=u, p=p, steps=K)
+        else:
+            f.estimate(y=y[0], u=u, p=p)
         e[1].record()
         if timed:
             ev.append(e)
@@ -375,13 +383,16 @@ def wl_kf(kind, args, torch, dev, rank, world):
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         nx, ny, nu, npar = 4, 2, 2, 4
         bytes_step = 8 * (2 * nx * (nx + 1) + 2 * ny + nu + npar)          # SURVEY 8d bytes_kf
-        gbs = B * bytes_step / (kern_ms * 1e-3) / 1e9
+        gbs = B * K * bytes_step / (kern_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes('C3-' + kind), "kernel": f"kf_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}, 2>",
-                "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": B * bytes_step,
+                "traffic": pmc_traffic_bytes('C3-' + kind),
+                "kernel": (f"kf_multi_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}>" if K > 1 else
+                           f"kf_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}, 2>"),
+                "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": B * K * bytes_step, "filter_steps_per_launch": K,
                 "note": "bytes_kf = 8 (2 nx (nx+1) + 2 ny + nu + np) per filter step (SURVEY 8d); at the configuration's B = 4096 "
                         "one launch moves 1.6 MB and is latency bound; `--batch 1048576` measures the bandwidth-bound regime"}
-        extra = {"workload": f"C3 {kind.upper()} step chemostat4 nx=4 ny=2 (predict + update fused), Q = 1e-4 I, R = 1e-2 I",
+        extra = {"workload": f"C3 {kind.upper()} step chemostat4 nx=4 ny=2 (predict + update fused, {K} sampling instants per "
+                             f"launch like the reference's mapaccum(steps)), Q = 1e-4 I, R = 1e-2 I",
                  "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"instances sharded x{world}"}
         return extra, roof, "weak"
 
@@ -401,7 +412,7 @@ def wl_kf(kind, args, torch, dev, rank, world):
         return {"value": n * B / secs, "unit": "steps/s", "cores": 1, "kind": "port",
                 "sample": f"{n} batched steps of B = {B} with the oracle's numpy-vectorised {kind.upper()} ({secs:.1f} s)",
                 "host_cpus": os.cpu_count()}
-    return dict(step=step, finish=finish, units=B, cpu=cpu, unit="steps/s",
+    return dict(step=step, finish=finish, units=B * K, cpu=cpu, unit="steps/s",
                 metric="Kalman filter steps/sec (batched instances, whole node)")
 
 
@@ -462,7 +473,7 @@ def wl_lmpc(args, torch, dev, rank, world):
     x = torch.as_tensor(rng.uniform(-4, 4, (B, 2)), device=dev)
     Ad = torch.as_tensor(np.array([[1., .5], [0., 1.]]), device=dev)
     Bd = torch.as_tensor(np.array([[.125], [.5]]), device=dev)
-    ev, log = [], []
+    ev, log, solved = [], [], []
 
     def step(timed):
         nonlocal x
@@ -473,6 +484,7 @@ def wl_lmpc(args, torch, dev, rank, world):
         if timed:
             ev.append(e)
             log.append(mpc._nlp_solution['iter_count'])
+            solved.append(float((mpc.solver_status_code == 1).mean()))
         x = x @ Ad.T + u @ Bd.T
 
     def finish():
@@ -493,11 +505,11 @@ def wl_lmpc(args, torch, dev, rank, world):
             b.record()
         torch.cuda.synchronize(dev)
         roof = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
-                "traffic": pmc_traffic_bytes('C1'), "kernel": "qp_solve_kernel", "kernel_ms": kern_ms,
+                "traffic": pmc_traffic_bytes('C1'), "kernel": "qp_solve_reg_kernel<32, 24>", "kernel_ms": kern_ms,
                 "note": "dense Mehrotra predictor-corrector, 32 variables / 20 equalities: flops per iteration = 2 m^2 n + m^3/3 "
                         "+ 4 m^2 + 6 n m; a 32-variable QP per workgroup is latency bound"}
         extra = {"workload": "C1 LMPC discrete double integrator nx=2 nu=1 N=10 (corrected input block), closed loop",
-                 "batch_per_gpu": B, "global_batch": B * world, "mean_qp_iters": iters,
+                 "batch_per_gpu": B, "global_batch": B * world, "mean_qp_iters": iters, "frac_status_1": float(np.mean(solved)),
                  "single_instance_latency_us": float(np.mean([a.elapsed_time(b) for a, b in e1])) * 1e3}
         return extra, roof, "weak"
 
@@ -553,6 +565,7 @@ def main():
     ap.add_argument('--config', choices=CONFIGS, default='C2')
     ap.add_argument('--batch', type=int, default=0, help='instances per GPU (weak configs) / in total (C4, C5); 0 = the config default')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--kf-steps', type=int, default=16, help='C3-ekf / C3-ukf: filter steps per launch (1 = one launch per step)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:

@@ -1294,7 +1294,11 @@ struct Ocp {
   // Cooperative models exchange partial sums between lanes through LDS with workgroup barriers in between; as a real
   // function (barriers kept as instructions) that is what was validated, so they keep the call.
   __device__ __forceinline__ static double eval_derivs(lds_double* lbase, double* ws) {
+#ifdef HILO_COOP_CALL
     if constexpr (COOP) return uni(eval_derivs_call(lbase, ws));
+#else
+    if constexpr (COOP) return uni(eval_derivs_body(uni(lbase), uni(ws)));   // inlined: the kernel's register budget (one wave per SIMD) instead of a callee's
+#endif
     else if constexpr (SYM) return eval_derivs_sym(lbase, ws);
     else if constexpr (SYM_MHE) return eval_derivs_sym_mhe(lbase, ws);
     else return eval_derivs_body(lbase, ws);

@@ -10,6 +10,7 @@
 // solves.  Variables with lbx == ubx (the pinned x_0, mpc.py:2361-2362) are substituted.  Rows must be equalities
 // (lba == uba), which is all the reference generates (polytopic constraints are a TODO there, mpc.py:2249-2250).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "hilo_common.h"
@@ -341,6 +342,410 @@ __global__ __launch_bounds__(64) void qp_solve_kernel(QpDims qd, int64_t batch, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 3: the same Mehrotra iteration with the FACTORISATIONS IN REGISTERS (n, m <= NP <= 64).
+// The first kernel factors column by column through LDS (a store / barrier / load round trip per column and per substitution
+// step: ~50 dependent LDS round trips per factorisation, 8 triangular solves per iteration) and loses to a CPU core on the
+// 32-variable QP of BASELINE configuration 1.  Here
+//   * lane i holds ROW i of the matrix (H + Sigma, then the Schur complement) in registers; the right-looking Cholesky
+//     broadcasts the pivot and the multipliers with v_readlane - no memory on the critical path;
+//   * the inverse factors are formed once per iteration: lane c forward-substitutes COLUMN c of L^-1 (lanes n .. n+m-1: the
+//     columns of X = L^-1 A^T) entirely in registers against L in LDS (uniform-address reads), so that every later
+//     triangular solve is a matrix-vector product with L^-1 (one pass, no per-column barriers);
+//   * both Mehrotra passes reuse L^-1, X = L^-1 A^T, S = X^T X and S's inverse factor.
+// Same algorithm, constants, start and termination as qp_solve_kernel (which stays the path for larger or workspace-resident QPs).
+__device__ __forceinline__ double qp_read_lane(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double qp_rsq(double x) {   // 1 / sqrt(x): v_rsq_f64 + two Newton steps
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+}
+
+// Lane i holds row i of a symmetric positive definite NP x NP matrix (a smaller matrix is padded with the identity): in-place
+// lower Cholesky factor, row i of L in lane i; `dinv` = reciprocal of this lane's diagonal entry.  Every loop has a compile-time
+// trip count and every array index is a constant: the rows stay in registers.
+template <int NP>
+__device__ __forceinline__ bool qp_chol_rows(double (&row)[NP], double& dinv) {
+  bool ok = true;
+  const int lane = threadIdx.x;
+  dinv = 1.0;
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const double piv = qp_read_lane(row[j], j);
+    const bool pos = piv > 0.0;
+    ok = ok && pos;
+    const double rs = qp_rsq(pos ? piv : 1.0);
+    const double lj = row[j] * rs;            // L[i][j] for the lanes i >= j (lane j: sqrt(pivot))
+    row[j] = lj;
+    dinv = lane == j ? rs : dinv;
+#pragma unroll
+    for (int k = j + 1; k < NP; ++k) row[k] -= lj * qp_read_lane(lj, k);   // L[i][j] L[k][j]; meaningful for the lanes i >= k
+  }
+  return ok;
+}
+
+// this lane's column of L^-1 B: col[i] = (b[i] - sum_{j < i} L[i][j] col[j]) / L[i][i];  L (NP x NP lower, identity padded) and
+// the reciprocal diagonal in LDS (uniform-address reads), the column and the right-hand side in registers
+template <int NP>
+__device__ __forceinline__ void qp_fsub_col(const double* L, int ld, const double* dinv, const double (&rhs)[NP], double (&col)[NP]) {
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    double s = rhs[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) s -= L[i * ld + j] * col[j];
+    col[i] = s * dinv[i];
+  }
+}
+
+template <int NP, int MP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void qp_solve_reg_kernel(
+    QpDims qd, int64_t batch, const double* __restrict__ Hg, int64_t hs, const double* __restrict__ gg, int64_t gs,
+    const double* __restrict__ Ag, int64_t as_, const double* __restrict__ lbx, const double* __restrict__ ubx, int64_t bs,
+    const double* __restrict__ lba, const double* __restrict__ uba, int64_t bas, double* __restrict__ x_out,
+    double* __restrict__ f_out, double* __restrict__ lam_a, double* __restrict__ lam_x, int32_t* __restrict__ status,
+    int32_t* __restrict__ iters) {
+  static_assert(NP <= 64 && MP <= 64 && MP <= NP, "one row / column per lane");
+  extern __shared__ double lds[];
+  constexpr int ldn = NP + 1, ldm = MP + 1;     // odd pitches: conflict-free row-per-lane and column walks
+  const int n = qd.n, m = qd.m, t = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  if (b >= batch) return;
+  double* q = lds;
+  auto take = [&](size_t k) { double* r = q; q += k; return r; };
+  double* Hf = take((size_t)NP * ldn);  // H with fixed rows / columns replaced by the identity (rows / columns >= n: identity)
+  double* Af = take((size_t)MP * ldn);  // A with fixed columns zeroed (rows >= m, columns >= n: zero)
+  double* Lm = take((size_t)NP * ldn);  // H + Sigma -> L = its factor -> (in place) L^-1
+  double* X = take((size_t)NP * ldm);   // L^-1 A^T
+  double* Ls = take((size_t)MP * ldm);  // Schur complement X^T X -> its factor -> its inverse factor
+  double *x = take(NP), *gf = take(NP), *l = take(NP), *u = take(NP), *zl = take(NP), *zu = take(NP), *r1 = take(NP),
+         *dx = take(NP), *dzl = take(NP), *dzu = take(NP), *base = take(NP), *xfix = take(NP), *tv = take(NP), *dinv = take(NP);
+  double *y = take(MP), *bf = take(MP), *rp = take(MP), *dy = take(MP), *wv = take(MP), *dinvs = take(MP);
+  const double* H = Hg + b * hs;
+  const double* A = Ag + b * as_;
+  const double* g = gg + b * gs;
+
+  // ---- load, substitute fixed variables (lbx == ubx): as qp_solve_kernel; padding = identity / zero ----
+  int bad_rows = 0;
+  if (t < NP) {
+    const bool in = t < n;
+    const double lo = in ? lbx[b * bs + t] : 0.0, up = in ? ubx[b * bs + t] : 0.0;
+    const bool fx = lo == up;          // padding slots count as fixed at 0
+    l[t] = fx ? NAN : lo;
+    u[t] = up;
+    xfix[t] = fx ? lo : 0.0;
+  }
+  for (int r = t; r < m; r += 64)
+    if (lba[b * bas + r] != uba[b * bas + r]) bad_rows = 1;
+  bad_rows = __any(bad_rows);
+  __syncthreads();
+  for (int e = t; e < NP * NP; e += 64) {
+    const int i = e / NP, j = e - i * NP;
+    const bool in = i < n && j < n;
+    const bool fi = isnan(l[i]), fj = isnan(l[j]);
+    Hf[i * ldn + j] = (!in || fi || fj) ? (i == j ? 1.0 : 0.0) : H[i * n + j];
+  }
+  for (int e = t; e < MP * NP; e += 64) {
+    const int r = e / NP, j = e - r * NP;
+    Af[r * ldn + j] = (r < m && j < n && !isnan(l[j])) ? A[r * n + j] : 0.0;
+  }
+  if (t < NP) {
+    double s = 0.0;
+    if (t < n) {
+      s = g[t];
+      for (int j = 0; j < n; ++j) s += H[t * n + j] * xfix[j];
+    }
+    gf[t] = isnan(l[t]) ? 0.0 : s;
+  }
+  if (t < MP) {
+    double s = 0.0;
+    if (t < m) {
+      s = uba[b * bas + t];
+      for (int j = 0; j < n; ++j) s -= A[t * n + j] * xfix[j];
+    }
+    bf[t] = s;
+    y[t] = 0.0;
+  }
+  double nb_part = 0.0;
+  if (t < NP) {
+    const int i = t;
+    const bool fx = isnan(l[i]);
+    const bool hl = !fx && l[i] > -INFINITY, hu = !fx && u[i] < INFINITY;
+    double xi = 0.0;
+    if (hl && hu) xi = 0.5 * (l[i] + u[i]);
+    else if (hl) xi = fmax(0.0, l[i] + 1.0);
+    else if (hu) xi = fmin(0.0, u[i] - 1.0);
+    x[i] = fx ? 0.0 : xi;
+    zl[i] = hl ? 1.0 : 0.0;
+    zu[i] = hu ? 1.0 : 0.0;
+    nb_part += (hl ? 1.0 : 0.0) + (hu ? 1.0 : 0.0);
+  }
+  const double nb = fmax(1.0, wave_sum(nb_part));
+  double gmax = 0.0;
+  if (t < NP) gmax = fabs(gf[t]);
+  gmax = wave_max(gmax);
+  __syncthreads();
+
+  int st = HILO_STATUS_MAXITER, it = 0;
+  if (bad_rows) st = HILO_STATUS_OTHER;
+  for (it = 0; !bad_rows && it < qd.max_iter; ++it) {
+    // residuals: base = -(Hf x + gf + Af^T y), rd = -base - zl + zu, rp = Af x - bf, mu
+    double rdmax = 0.0, mupart = 0.0, nonfinite = 0.0;
+    if (t < n) {
+      const int i = t;
+      double s = gf[i];
+      for (int j = 0; j < n; ++j) s += Hf[i * ldn + j] * x[j];
+      for (int r = 0; r < m; ++r) s += Af[r * ldn + i] * y[r];
+      const bool fx = isnan(l[i]);
+      if (fx) s = 0.0;
+      base[i] = -s;
+      rdmax = fabs(s - zl[i] + zu[i]);
+      nonfinite += isfinite(s - zl[i] + zu[i]) ? 0.0 : 1.0;
+      if (!fx) {
+        if (l[i] > -INFINITY) mupart += (x[i] - l[i]) * zl[i];
+        if (u[i] < INFINITY) mupart += (u[i] - x[i]) * zu[i];
+      }
+    }
+    double rpmax = 0.0;
+    if (t < m) {
+      const int r = t;
+      double s = -bf[r];
+      for (int j = 0; j < n; ++j) s += Af[r * ldn + j] * x[j];
+      rp[r] = s;
+      rpmax = fabs(s);
+      nonfinite += isfinite(s) ? 0.0 : 1.0;
+    }
+    rdmax = wave_max(rdmax);
+    rpmax = wave_max(rpmax);
+    const double mu = wave_sum(mupart) / nb;
+    nonfinite = wave_sum(nonfinite);
+    if (nonfinite > 0.0 || !isfinite(rdmax) || !isfinite(rpmax) || !isfinite(mu)) { st = HILO_STATUS_INFEASIBLE; break; }
+    if (fmax(fmax(rdmax / (1.0 + gmax), rpmax), mu) <= qd.tol) { st = HILO_STATUS_SOLVED; break; }
+
+    // ---- M = Hf + Sigma + reg: row i in lane i (lanes >= NP mirror the last row), factored in registers ----
+    const int tr = t < NP ? t : NP - 1;
+    bool okf;
+    {
+      double row[NP];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) row[j] = Hf[tr * ldn + j];
+      double dg = 0.0;
+      if (!isnan(l[tr])) {
+        dg = qd.reg;
+        const double lo = l[tr], up = u[tr], xv = x[tr];
+        if (lo > -INFINITY) dg += zl[tr] / (xv - lo);
+        if (up < INFINITY) dg += zu[tr] / (up - xv);
+      }
+#pragma unroll
+      for (int j = 0; j < NP; ++j) row[j] += (j == tr) ? dg : 0.0;
+      double di;
+      okf = qp_chol_rows<NP>(row, di);
+      if (t < NP) {
+        dinv[t] = di;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) Lm[t * ldn + j] = row[j];   // (entries above the diagonal: never read)
+      }
+    }
+    if (!okf) { st = HILO_STATUS_OTHER; break; }
+    __syncthreads();
+    // ---- columns of X = L^-1 A^T (MP of them) and of L^-1 (NP), 64 per pass; the pass with the columns of L^-1 runs last and
+    // overwrites L once every lane has finished reading it ----
+    constexpr int NCOL = NP + MP;
+#pragma unroll
+    for (int c0 = ((NCOL - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
+      const int c = c0 + t;
+      const bool isL = c < NP, isX = c >= NP && c < NCOL;
+      const double* arow = Af + (size_t)(isX ? c - NP : 0) * ldn;
+      double rhs[NP], col[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const double av = arow[i];
+        rhs[i] = isL ? (i == c ? 1.0 : 0.0) : (isX ? av : 0.0);
+      }
+      qp_fsub_col<NP>(Lm, ldn, dinv, rhs, col);
+      if (isX) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) X[i * ldm + (c - NP)] = col[i];
+      }
+      if (c0 == 0) {
+        __syncthreads();
+        if (isL) {
+#pragma unroll
+          for (int i = 0; i < NP; ++i) Lm[i * ldn + c] = col[i];   // (zeros above the diagonal)
+        }
+      }
+    }
+    __syncthreads();
+    // ---- Schur complement S = X^T X + reg (lower triangle pairs), row a into lane a, factor, inverse factor ----
+    for (int pq = t; pq < MP * (MP + 1) / 2; pq += 64) {
+      int a = (int)((::sqrt(8.0 * pq + 1.0) - 1.0) * 0.5);
+      a += ((a + 1) * (a + 2) / 2 <= pq) ? 1 : 0;
+      a -= (a * (a + 1) / 2 > pq) ? 1 : 0;
+      const int c = pq - a * (a + 1) / 2;
+      double s2 = (a == c) ? (a < m ? qd.reg : 1.0) : 0.0;       // padding rows: identity
+      for (int i = 0; i < n; ++i) s2 += X[i * ldm + a] * X[i * ldm + c];
+      Ls[a * ldm + c] = s2;
+      Ls[c * ldm + a] = s2;
+    }
+    __syncthreads();
+    const int tm = t < MP ? t : MP - 1;
+    bool oks;
+    {
+      double row[MP];
+#pragma unroll
+      for (int j = 0; j < MP; ++j) row[j] = Ls[tm * ldm + j];
+      double di;
+      oks = qp_chol_rows<MP>(row, di);
+      __syncthreads();
+      if (t < MP) {
+        dinvs[t] = di;
+#pragma unroll
+        for (int j = 0; j < MP; ++j) Ls[t * ldm + j] = row[j];
+      }
+    }
+    if (!oks) { st = HILO_STATUS_OTHER; break; }
+    __syncthreads();
+    {
+      double rhs[MP], col[MP];
+#pragma unroll
+      for (int i = 0; i < MP; ++i) rhs[i] = (i == tm) ? 1.0 : 0.0;
+      qp_fsub_col<MP>(Ls, ldm, dinvs, rhs, col);
+      __syncthreads();
+      if (t < MP) {
+#pragma unroll
+        for (int i = 0; i < MP; ++i) Ls[i * ldm + t] = col[i];
+      }
+    }
+    __syncthreads();
+
+    double sigma_mu = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (t < n) {
+        const int i = t;
+        double s = base[i];
+        if (pass == 1 && !isnan(l[i])) {
+          if (l[i] > -INFINITY) s += (sigma_mu - dx[i] * dzl[i]) / (x[i] - l[i]);
+          if (u[i] < INFINITY) s -= (sigma_mu + dx[i] * dzu[i]) / (u[i] - x[i]);
+        }
+        r1[i] = s;
+      }
+      __syncthreads();
+      if (t < n) {                                   // tv = L^-1 r1
+        double s = 0.0;
+        for (int j = 0; j <= t; ++j) s += Lm[t * ldn + j] * r1[j];
+        tv[t] = s;
+      }
+      __syncthreads();
+      if (t < m) {                                   // dy0 = rp + X^T tv
+        double s = rp[t];
+        for (int i = 0; i < n; ++i) s += X[i * ldm + t] * tv[i];
+        dy[t] = s;
+      }
+      __syncthreads();
+      if (t < m) {                                   // wv = Ls^-1 dy0
+        double s = 0.0;
+        for (int c = 0; c <= t; ++c) s += Ls[t * ldm + c] * dy[c];
+        wv[t] = s;
+      }
+      __syncthreads();
+      if (t < m) {                                   // dy = Ls^-T wv
+        double s = 0.0;
+        for (int a = t; a < m; ++a) s += Ls[a * ldm + t] * wv[a];
+        dy[t] = s;
+      }
+      __syncthreads();
+      if (t < n) {                                   // tv <- tv - X dy
+        double s = tv[t];
+        for (int a = 0; a < m; ++a) s -= X[t * ldm + a] * dy[a];
+        tv[t] = s;
+      }
+      __syncthreads();
+      if (t < n) {                                   // dx = L^-T tv
+        double s = 0.0;
+        for (int i = t; i < n; ++i) s += Lm[i * ldn + t] * tv[i];
+        r1[t] = s;
+      }
+      __syncthreads();
+      // bound-multiplier steps, step lengths (as qp_solve_kernel)
+      double ap = 1.0, ad = 1.0;
+      const double tau = pass == 0 ? 1.0 : fmax(0.995, 1.0 - mu);
+      if (t < n) {
+        const int i = t;
+        const bool fx = isnan(l[i]);
+        const double d = fx ? 0.0 : r1[i];
+        double dl = 0.0, du = 0.0;
+        if (!fx) {
+          const double cl = pass == 1 ? dx[i] * dzl[i] : 0.0, cu = pass == 1 ? -dx[i] * dzu[i] : 0.0;
+          if (l[i] > -INFINITY) {
+            const double s = x[i] - l[i];
+            dl = (sigma_mu - cl) / s - zl[i] - zl[i] / s * d;
+            if (d < 0.0) ap = fmin(ap, -tau * s / d);
+            if (dl < 0.0) ad = fmin(ad, -tau * zl[i] / dl);
+          }
+          if (u[i] < INFINITY) {
+            const double s = u[i] - x[i];
+            du = (sigma_mu - cu) / s - zu[i] + zu[i] / s * d;
+            if (d > 0.0) ap = fmin(ap, tau * s / d);
+            if (du < 0.0) ad = fmin(ad, -tau * zu[i] / du);
+          }
+        }
+        dx[i] = d; dzl[i] = dl; dzu[i] = du;
+      }
+      ap = wave_min(ap);
+      ad = wave_min(ad);
+      __syncthreads();
+      if (pass == 0) {
+        double mpart = 0.0;
+        if (t < n && !isnan(l[t])) {
+          const int i = t;
+          if (l[i] > -INFINITY) mpart += (x[i] - l[i] + ap * dx[i]) * (zl[i] + ad * dzl[i]);
+          if (u[i] < INFINITY) mpart += (u[i] - x[i] - ap * dx[i]) * (zu[i] + ad * dzu[i]);
+        }
+        const double mu_aff = wave_sum(mpart) / nb;
+        const double sg = mu > 0.0 ? (mu_aff / mu) : 0.0;
+        sigma_mu = sg * sg * sg * mu;
+      } else {
+        if (t < n) {
+          const int i = t;
+          double xi = x[i] + ap * dx[i];
+          if (l[i] > -INFINITY) xi = fmax(xi, l[i] + 4.0e-16 * fmax(1.0, fabs(l[i])));
+          if (u[i] < INFINITY) xi = fmin(xi, u[i] - 4.0e-16 * fmax(1.0, fabs(u[i])));
+          x[i] = xi;
+          zl[i] += ad * dzl[i];
+          zu[i] += ad * dzu[i];
+        }
+        if (t < m) y[t] += ad * dy[t];
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- outputs (CasADi conic sign convention: H x + g + A^T lam_a + lam_x = 0) ----
+  double fpart = 0.0;
+  if (t < n) x[t] = isnan(l[t]) ? xfix[t] : x[t];
+  __syncthreads();
+  if (t < n) {
+    const int i = t;
+    double hx = 0.0, aty = 0.0;
+    for (int j = 0; j < n; ++j) hx += H[i * n + j] * x[j];
+    for (int r = 0; r < m; ++r) aty += A[r * n + i] * y[r];
+    fpart += x[i] * (0.5 * hx + g[i]);
+    x_out[b * n + i] = x[i];
+    if (lam_x) lam_x[b * n + i] = isnan(l[i]) ? -(hx + g[i] + aty) : zu[i] - zl[i];
+  }
+  if (lam_a && t < m) lam_a[b * m + t] = y[t];
+  fpart = wave_sum(fpart);
+  if (t == 0) {
+    f_out[b] = fpart;
+    status[b] = st;
+    iters[b] = it;
+  }
+}
+
 }  // namespace hilo
 
 using namespace hilo;
@@ -350,6 +755,8 @@ struct hilo_qp {
   QpDims qd;
   size_t lds_bytes;      // working set per instance
   bool big;              // working set in global memory
+  int fast_np, fast_mp;  // register-resident kernel qp_solve_reg_kernel<NP, MP> (n <= NP, m <= MP), 0 = the LDS-column kernel
+  size_t fast_lds;
   double* ws;
   int64_t ws_batch;
 };
@@ -367,6 +774,15 @@ extern "C" int hilo_qp_create(int n, int m, int device, hilo_qp** out) {
   h->lds_bytes = sizeof(double) * ((size_t)2 * n * q.ldn + (size_t)m * q.ldn + (size_t)n * q.ldm + (size_t)(m > 0 ? m : 1) * q.ldm +
                                    12 * (size_t)n + 4 * (size_t)(m > 0 ? m : 1));
   h->big = h->lds_bytes > 160 * 1024;   // e.g. LMPC with nx=2, nu=1 beyond N = 22
+  // small dense QPs (the LMPC of BASELINE configuration 1: n = 32, m = 20): factorisations in registers, padded dimensions
+  h->fast_np = n <= 32 ? 32 : (n <= 64 ? 64 : 0);
+  h->fast_mp = h->fast_np == 32 ? (m <= 24 ? 24 : (m <= 32 ? 32 : 0)) : (h->fast_np == 64 ? (m <= 48 ? 48 : (m <= 64 ? 64 : 0)) : 0);
+  if (!h->fast_mp) h->fast_np = 0;
+  {
+    const size_t NP = h->fast_np, MP = h->fast_mp;
+    h->fast_lds = sizeof(double) * (2 * NP * (NP + 1) + MP * (NP + 1) + NP * (MP + 1) + MP * (MP + 1) + 14 * NP + 6 * MP);
+  }
+  if (h->fast_lds > 160 * 1024 || getenv("HILO_QP_LDS_COLUMNS")) h->fast_np = 0;
   h->ws = nullptr;
   h->ws_batch = 0;
   *out = h;
@@ -397,6 +813,24 @@ extern "C" int hilo_qp_solve(hilo_qp* h, int64_t batch, const double* H, int64_t
   HILO_REQUIRE(h->m == 0 || (A && lba && uba), "hilo_qp_solve: the problem has %d rows but A / lba / uba is NULL", h->m);
   HILO_REQUIRE(bx_stride >= h->n, "hilo_qp_solve: lbx/ubx are per instance (x_0 is pinned through them, mpc.py:2361-2362)");
   HILO_HIP_CHECK(hipSetDevice(h->device));
+  if (h->fast_np) {
+#define HILO_QP_FAST(NPV, MPV)                                                                                                     \
+  if (h->fast_np == NPV && h->fast_mp == MPV) {                                                                                     \
+    if (h->fast_lds > 64 * 1024)                                                                                                    \
+      HILO_HIP_CHECK(hipFuncSetAttribute((const void*)qp_solve_reg_kernel<NPV, MPV>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                         (int)h->fast_lds));                                                                       \
+    hipLaunchKernelGGL((qp_solve_reg_kernel<NPV, MPV>), dim3((unsigned)batch), dim3(64), h->fast_lds, (hipStream_t)stream, h->qd,   \
+                       batch, H, h_stride, g, g_stride, A, a_stride, lbx, ubx, bx_stride, lba, uba, ba_stride, x, f, lam_a, lam_x, \
+                       status, iters);                                                                                            \
+  }
+    HILO_QP_FAST(32, 24)
+    HILO_QP_FAST(32, 32)
+    HILO_QP_FAST(64, 48)
+    HILO_QP_FAST(64, 64)
+#undef HILO_QP_FAST
+    HILO_HIP_CHECK(hipGetLastError());
+    return HILO_OK;
+  }
   if (h->big) {
     if (h->ws_batch != batch) {
       if (h->ws) HILO_HIP_CHECK(hipFree(h->ws));

@@ -97,3 +97,30 @@ def test_long_horizon_qp_in_global_workspace(N):
     ok = st == 1
     np.testing.assert_allclose(u[ok], ref['u'][ok], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(mpc._nlp_solution['x'].cpu().numpy()[ok], ref['v'][ok], atol=1e-6)
+
+
+@pytest.mark.parametrize('N,variant', [(10, 'reference'), (20, 'corrected'), (20, 'reference'), (14, 'corrected')])
+def test_register_resident_kernel_equals_the_lds_column_kernel(N, variant, monkeypatch):
+    """Round 3: QPs with n, m <= 64 run on qp_solve_reg_kernel<NP, MP> (dimensions padded to 32 / 64 and 24 .. 64, factorisations in registers, inverse factors); the first
+    kernel (columns through LDS, HILO_QP_LDS_COLUMNS=1) solves the same iteration - same statuses and iteration counts, solutions
+    to round-off; and the oracle agrees.  N = 20 (n = 62, m = 40) exercises the two-pass column scheme of the 64-wide variant."""
+    rng = np.random.default_rng(11)
+    x0 = rng.uniform(-1.5, 1.5, (48, 2))
+    fast = product_lmpc(variant, N=N)
+    uf = fast.optimize(x0)
+    monkeypatch.setenv('HILO_QP_LDS_COLUMNS', '1')
+    slow = product_lmpc(variant, N=N)
+    us = slow.optimize(x0)
+    assert np.array_equal(fast.solver_status_code, slow.solver_status_code)
+    ok = fast.solver_status_code == 1
+    assert ok.sum() >= 24
+    it_f, it_s = fast._nlp_solution['iter_count'].cpu().numpy(), slow._nlp_solution['iter_count'].cpu().numpy()
+    assert np.max(np.abs(it_f[ok] - it_s[ok])) <= 1
+    np.testing.assert_allclose(uf[ok], us[ok], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(fast._nlp_solution['x'].cpu().numpy()[ok], slow._nlp_solution['x'].cpu().numpy()[ok], atol=1e-8)
+    np.testing.assert_allclose(fast._nlp_solution['lam_a'].cpu().numpy()[ok], slow._nlp_solution['lam_a'].cpu().numpy()[ok],
+                               rtol=1e-6, atol=1e-7)
+    ref = lmpc_optimize(LmpcProblem(**dict(C1, N=N), kron_bug=(variant == 'reference')), x0)
+    both = ok & (ref['status'] == 1)      # (near the feasibility boundary the two iteration budgets may end differently)
+    assert both.sum() >= 24
+    np.testing.assert_allclose(uf[both], ref['u'][both], rtol=1e-6, atol=1e-7)
