@@ -35,6 +35,28 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// the same reductions on the data-parallel primitives (cross-lane moves inside the vector ALU instead of LDS permutes, a sixth of
+// the latency): butterfly inside the rows of 16 lanes, then row_bcast15 / row_bcast31; the total is read from lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double qp_dpp(double v, double ident) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <class Op>
+__device__ __forceinline__ double qp_wave_reduce(double v, double ident, Op op) {
+  v = op(v, qp_dpp<0xB1, 0xf>(v, ident));     // quad_perm [1, 0, 3, 2]
+  v = op(v, qp_dpp<0x4E, 0xf>(v, ident));     // quad_perm [2, 3, 0, 1]
+  v = op(v, qp_dpp<0x141, 0xf>(v, ident));    // row_half_mirror
+  v = op(v, qp_dpp<0x140, 0xf>(v, ident));    // row_mirror: every lane of a row holds the row's total
+  v = op(v, qp_dpp<0x142, 0xa>(v, ident));    // row_bcast15 into rows 1 and 3
+  v = op(v, qp_dpp<0x143, 0xc>(v, ident));    // row_bcast31 into rows 2 and 3
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ double qp_wave_sum(double v) { return qp_wave_reduce(v, 0.0, [](double a, double b) { return a + b; }); }
+__device__ __forceinline__ double qp_wave_min(double v) { return qp_wave_reduce(v, INFINITY, [](double a, double b) { return fmin(a, b); }); }
+__device__ __forceinline__ double qp_wave_max(double v) { return qp_wave_reduce(v, -INFINITY, [](double a, double b) { return fmax(a, b); }); }
+
 // in-place lower Cholesky of the n x n matrix M (leading dimension ld, odd -> conflict-free column access)
 __device__ bool chol_lds(double* M, int n, int ld) {
   const int t = threadIdx.x;
@@ -172,6 +194,7 @@ __global__ __launch_bounds__(64) void qp_solve_kernel(QpDims qd, int64_t batch, 
   __syncthreads();
 
   int st = HILO_STATUS_MAXITER, it = 0;
+  double phi_min = INFINITY;
   if (bad_rows) st = HILO_STATUS_OTHER;
   for (it = 0; !bad_rows && it < qd.max_iter; ++it) {
     // residuals: base = -(Hf x + gf + Af^T y), rd = -base - zl + zu, rp = Af x - bf, mu
@@ -203,7 +226,12 @@ __global__ __launch_bounds__(64) void qp_solve_kernel(QpDims qd, int64_t batch, 
     const double mu = wave_sum(mupart) / nb;
     nonfinite = wave_sum(nonfinite);
     if (nonfinite > 0.0 || !isfinite(rdmax) || !isfinite(rpmax) || !isfinite(mu)) { st = HILO_STATUS_INFEASIBLE; break; }
-    if (fmax(fmax(rdmax / (1.0 + gmax), rpmax), mu) <= qd.tol) { st = HILO_STATUS_SOLVED; break; }
+    const double phi = fmax(fmax(rdmax / (1.0 + gmax), rpmax), mu);
+    if (phi <= qd.tol) { st = HILO_STATUS_SOLVED; break; }
+    // infeasible QP (the reference's qpOASES reports it; a predictor-corrector iteration diverges instead): the termination rule
+    // of OOQP (Gertz & Wright, ACM TOMS 29, 2003) - the merit has grown to 1e4 times its smallest value so far
+    phi_min = fmin(phi_min, phi);
+    if (phi >= 1.0e4 * phi_min) { st = HILO_STATUS_INFEASIBLE; break; }
     // M = Hf + Sigma + reg; factor
     for (int e = t; e < n * n; e += 64) {
       const int i = e / n, j = e - i * n;
@@ -366,41 +394,193 @@ __device__ __forceinline__ double qp_rsq(double x) {   // 1 / sqrt(x): v_rsq_f64
   return y;
 }
 
+// this lane's column of L^-1 B: col[i] = (b[i] - sum_{j < i} L[i][j] col[j]) / L[i][i];  L (NP x NP lower, identity padded) and
+// the reciprocal diagonal in LDS (uniform-address reads), the column in registers, the right-hand side entry by entry
+// An LDS base address held in ONE vector register and opaque to the optimiser: the accesses of an unrolled block become
+// `ds_read base offset:imm`, and reads of data that does not change between iterations (H, A) are not hoisted out of the iteration
+// loop.  (Left to itself the compiler forms every address as a scalar outside the loop - 600 of them, spilled to vector-register
+// lanes - and parks 120 hoisted doubles in AGPRs; under that register pressure the scheduler serialises every LDS read.)
+using qp_lds_cd = const __attribute__((address_space(3))) double*;
+__device__ __forceinline__ qp_lds_cd qp_vbase(const double* p) {
+  qp_lds_cd q = (qp_lds_cd)p;
+  asm volatile("" : "+v"(q));
+  return q;
+}
+
+// a[K0 .. K1) must be in registers here (the compiler waits for the loads that produce them) - eight at a time
+template <int K0, int K1, int N>
+__device__ __forceinline__ void qp_pin(double (&a)[N]) {
+  if constexpr (K1 - K0 >= 8) {
+    asm volatile("" : "+v"(a[K0]), "+v"(a[K0 + 1]), "+v"(a[K0 + 2]), "+v"(a[K0 + 3]), "+v"(a[K0 + 4]), "+v"(a[K0 + 5]),
+                 "+v"(a[K0 + 6]), "+v"(a[K0 + 7]));
+    qp_pin<K0 + 8, K1>(a);
+  } else if constexpr (K1 - K0 >= 1) {
+    asm volatile("" : "+v"(a[K0]));
+    qp_pin<K0 + 1, K1>(a);
+  }
+}
 // Lane i holds row i of a symmetric positive definite NP x NP matrix (a smaller matrix is padded with the identity): in-place
-// lower Cholesky factor, row i of L in lane i; `dinv` = reciprocal of this lane's diagonal entry.  Every loop has a compile-time
-// trip count and every array index is a constant: the rows stay in registers.
-template <int NP>
-__device__ __forceinline__ bool qp_chol_rows(double (&row)[NP], double& dinv) {
-  bool ok = true;
-  const int lane = threadIdx.x;
-  dinv = 1.0;
-#pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    const double piv = qp_read_lane(row[j], j);
+// lower Cholesky factor, row i of L in lane i; `dinv` = reciprocal of this lane's diagonal entry.  Every array index is a constant:
+// the rows stay in registers.  Column J per step, right-looking:
+//   critical path   pivot = row J of lane J (v_readlane), l = row[J] / sqrt(pivot), and the one update the NEXT column waits for,
+//                   row[J + 1] -= l * L[J + 1][J] (v_readlane);
+//   everything else the column l goes through a 64-entry LDS buffer and comes back as broadcast reads, L[k][J] for k >= J + 2; those
+//                   reads are in flight during the next column's critical path and their multiply-adds run after it
+//                   (LDS operations of a wave complete in issue order: the buffer needs no second copy and no wait between the
+//                   write and the reads).
+using qp_lds_d = __attribute__((address_space(3))) double*;
+template <int J, int NP>
+__device__ __forceinline__ void qp_chol_cols(double (&row)[NP], double& dinv, bool& ok, qp_lds_cd cb, qp_lds_d mine, double lprev,
+                                             double (&prev)[NP]) {
+  if constexpr (J < NP) {
+    const double piv = qp_read_lane(row[J], J);
     const bool pos = piv > 0.0;
     ok = ok && pos;
     const double rs = qp_rsq(pos ? piv : 1.0);
-    const double lj = row[j] * rs;            // L[i][j] for the lanes i >= j (lane j: sqrt(pivot))
-    row[j] = lj;
-    dinv = lane == j ? rs : dinv;
+    const double lj = row[J] * rs;            // L[i][J] for the lanes i >= J (lane J: sqrt(pivot))
+    row[J] = lj;
+    dinv = (int)threadIdx.x == J ? rs : dinv;
+    double nxt[NP];
+    if constexpr (J + 1 < NP) {
+      *mine = lj;
+      row[J + 1] -= lj * qp_read_lane(lj, J + 1);
 #pragma unroll
-    for (int k = j + 1; k < NP; ++k) row[k] -= lj * qp_read_lane(lj, k);   // L[i][j] L[k][j]; meaningful for the lanes i >= k
+      for (int k = J + 2; k < NP; ++k) nxt[k] = cb[k];
+    }
+    asm volatile("");                          // (ends the scheduling region: the reads above are issued before what follows)
+    if constexpr (J >= 1) {
+      qp_pin<J + 1, NP>(prev);
+#pragma unroll
+      for (int k = J + 1; k < NP; ++k) row[k] -= lprev * prev[k];   // L[i][J-1] L[k][J-1]; meaningful for the lanes i >= k
+    }
+    qp_chol_cols<J + 1, NP>(row, dinv, ok, cb, mine, lj, nxt);
   }
+}
+template <int NP>
+__device__ __forceinline__ bool qp_chol_rows(double (&row)[NP], double& dinv, double* colbuf) {
+  bool ok = true;
+  dinv = 1.0;
+  double none[NP];
+  qp_lds_d mine = (qp_lds_d)(colbuf + threadIdx.x);
+  asm volatile("" : "+v"(mine));
+  qp_chol_cols<0, NP>(row, dinv, ok, qp_vbase(colbuf), mine, 0.0, none);
   return ok;
 }
 
-// this lane's column of L^-1 B: col[i] = (b[i] - sum_{j < i} L[i][j] col[j]) / L[i][i];  L (NP x NP lower, identity padded) and
-// the reciprocal diagonal in LDS (uniform-address reads), the column and the right-hand side in registers
-template <int NP>
-__device__ __forceinline__ void qp_fsub_col(const double* L, int ld, const double* dinv, const double (&rhs)[NP], double (&col)[NP]) {
+// row I of the forward substitution; `cur` = L[I][0 .. I) already requested from LDS.  Software pipeline written out by hand: the
+// reads of row I + 1 are issued (a statement with side effects ends the scheduling region, so they stay in front of it) before the
+// multiply-adds of row I run.  (The compiler's own order issues one read, waits for it, uses it.)
+template <int I, int NP, class Rhs>
+__device__ __forceinline__ void qp_fsub_rows(qp_lds_cd L, int ld, qp_lds_cd dinv, Rhs& rhs, double (&col)[NP], double (&cur)[NP]) {
+  if constexpr (I < NP) {
+    qp_pin<0, I>(cur);
+    double nxt[NP];
+    if constexpr (I + 1 < NP) {
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    double s = rhs[i];
+      for (int j = 0; j < I + 1; ++j) nxt[j] = L[(I + 1) * ld + j];
+    }
+    const double di = dinv[I];
+    double s0 = rhs(I), s1 = 0.0;               // two chains: the latency of one multiply-add hides behind the other
+    asm volatile("");
 #pragma unroll
-    for (int j = 0; j < i; ++j) s -= L[i * ld + j] * col[j];
-    col[i] = s * dinv[i];
+    for (int j = 0; j + 1 < I; j += 2) {
+      s0 -= cur[j] * col[j];
+      s1 -= cur[j + 1] * col[j + 1];
+    }
+    if constexpr (I % 2 == 1) s0 -= cur[I - 1] * col[I - 1];
+    col[I] = (s0 + s1) * di;
+    // pin the row here: without it the arithmetic is sunk behind the next barrier into the block that stores the column
+    asm volatile("" : "+v"(col[I]));
+    qp_fsub_rows<I + 1, NP>(L, ld, dinv, rhs, col, nxt);
   }
 }
+template <int NP, class Rhs>
+__device__ __forceinline__ void qp_fsub_col(const double* Lg, int ld, const double* dinvg, Rhs rhs, double (&col)[NP]) {
+  double cur[NP];
+  qp_fsub_rows<0, NP>(qp_vbase(Lg), ld, qp_vbase(dinvg), rhs, col, cur);
+}
+
+// sum_j row[j] v[j] over a compile-time length (padded operands, zeros in the padding): every LDS read is issued before the
+// first multiply-add (the empty statement with side effects ends the scheduling region)
+template <int K>
+__device__ __forceinline__ double qp_dot(const double* rowg, const double* vg) {
+  static_assert(K % 2 == 0, "even padded length");
+  const qp_lds_cd v = qp_vbase(vg), row = qp_vbase(rowg);
+  double a[K], w[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { a[j] = row[j]; w[j] = v[j]; }
+  asm volatile("");
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int j = 0; j < K; j += 2) {
+    s0 += a[j] * w[j];
+    s1 += a[j + 1] * w[j + 1];
+  }
+  return s0 + s1;
+}
+// sum_i M[i][t] v[i]: a column walk (consecutive lanes read consecutive addresses)
+template <int K>
+__device__ __forceinline__ double qp_dot_col(const double* colg, int ld, const double* vg) {
+  static_assert(K % 2 == 0, "even padded length");
+  const qp_lds_cd v = qp_vbase(vg), col = qp_vbase(colg);
+  double a[K], w[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) { a[i] = col[i * ld]; w[i] = v[i]; }
+  asm volatile("");
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int i = 0; i < K; i += 2) {
+    s0 += a[i] * w[i];
+    s1 += a[i + 1] * w[i + 1];
+  }
+  return s0 + s1;
+}
+// row[c] += sum_i X[i][a] X[i][c]  (a = this lane's column; the rows of X broadcast): rows i, i + 1 per trip, the reads of the next
+// row in flight while the current one is used
+template <int NP, int MP>
+__device__ __forceinline__ void qp_gram_row(const double* Xg, int ld, int a, double (&row)[MP]) {
+  static_assert(NP % 2 == 0, "two rows per trip");
+  qp_lds_cd xr = qp_vbase(Xg);
+  double p[MP], q[MP], pa, qa;
+#pragma unroll
+  for (int c = 0; c < MP; ++c) p[c] = xr[c];
+  pa = xr[a];
+  for (int i = 0; i < NP; i += 2) {
+    qp_pin<0, MP>(p);
+    asm volatile("" : "+v"(pa));
+#pragma unroll
+    for (int c = 0; c < MP; ++c) q[c] = xr[ld + c];
+    qa = xr[ld + a];
+    asm volatile("");
+#pragma unroll
+    for (int c = 0; c < MP; ++c) row[c] += pa * p[c];
+    const int nx = (i + 2 < NP) ? 2 * ld : 0;            // (the last trip re-reads a row it does not use)
+    qp_pin<0, MP>(q);
+    asm volatile("" : "+v"(qa));
+#pragma unroll
+    for (int c = 0; c < MP; ++c) p[c] = xr[nx + c];
+    pa = xr[nx + a];
+    asm volatile("");
+#pragma unroll
+    for (int c = 0; c < MP; ++c) row[c] += qa * q[c];
+    xr += 2 * ld;
+  }
+}
+
+// Developer build (-DHILO_QP_PROF, tools/dbg/qp_prof.py): clock ticks per section of the iteration, instance 0
+#ifdef HILO_QP_PROF
+__device__ long long g_qp_prof[16];
+#define QP_TICK(i)                                                  \
+  do {                                                              \
+    const long long tk_ = (long long)__builtin_readcyclecounter();  \
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_qp_prof[i] += tk_ - tq_; \
+    tq_ = (long long)__builtin_readcyclecounter();                  \
+  } while (0)
+#define QP_TICK0() long long tq_ = (long long)__builtin_readcyclecounter()
+#else
+#define QP_TICK(i)
+#define QP_TICK0()
+#endif
 
 template <int NP, int MP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void qp_solve_reg_kernel(
@@ -425,9 +605,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   double *x = take(NP), *gf = take(NP), *l = take(NP), *u = take(NP), *zl = take(NP), *zu = take(NP), *r1 = take(NP),
          *dx = take(NP), *dzl = take(NP), *dzu = take(NP), *base = take(NP), *xfix = take(NP), *tv = take(NP), *dinv = take(NP);
   double *y = take(MP), *bf = take(MP), *rp = take(MP), *dy = take(MP), *wv = take(MP), *dinvs = take(MP);
+  double* cbuf = take(64);              // column broadcast buffer of the factorisations
   const double* H = Hg + b * hs;
   const double* A = Ag + b * as_;
   const double* g = gg + b * gs;
+  for (int e = t; e < 14 * NP + 6 * MP; e += 64) x[e] = 0.0;   // every vector, padding included (the padding stays zero)
+  __syncthreads();
 
   // ---- load, substitute fixed variables (lbx == ubx): as qp_solve_kernel; padding = identity / zero ----
   int bad_rows = 0;
@@ -484,22 +667,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     zu[i] = hu ? 1.0 : 0.0;
     nb_part += (hl ? 1.0 : 0.0) + (hu ? 1.0 : 0.0);
   }
-  const double nb = fmax(1.0, wave_sum(nb_part));
+  const double nb = fmax(1.0, qp_wave_sum(nb_part));
   double gmax = 0.0;
   if (t < NP) gmax = fabs(gf[t]);
-  gmax = wave_max(gmax);
+  gmax = qp_wave_max(gmax);
   __syncthreads();
 
   int st = HILO_STATUS_MAXITER, it = 0;
+  double phi_min = INFINITY;
+  QP_TICK0();
   if (bad_rows) st = HILO_STATUS_OTHER;
   for (it = 0; !bad_rows && it < qd.max_iter; ++it) {
+    QP_TICK(0);
     // residuals: base = -(Hf x + gf + Af^T y), rd = -base - zl + zu, rp = Af x - bf, mu
     double rdmax = 0.0, mupart = 0.0, nonfinite = 0.0;
+    const int tr = t < NP ? t : NP - 1, tm = t < MP ? t : MP - 1;   // lanes beyond the padded sizes mirror the last row
+    const double lag = gf[tr] + qp_dot<NP>(Hf + tr * ldn, x) + qp_dot_col<MP>(Af + tr, ldn, y);
+    const double ax = qp_dot<NP>(Af + tm * ldn, x);
+    if (t < m) rp[t] = ax - bf[t];
     if (t < n) {
       const int i = t;
-      double s = gf[i];
-      for (int j = 0; j < n; ++j) s += Hf[i * ldn + j] * x[j];
-      for (int r = 0; r < m; ++r) s += Af[r * ldn + i] * y[r];
+      double s = lag;
       const bool fx = isnan(l[i]);
       if (fx) s = 0.0;
       base[i] = -s;
@@ -512,27 +700,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     double rpmax = 0.0;
     if (t < m) {
-      const int r = t;
-      double s = -bf[r];
-      for (int j = 0; j < n; ++j) s += Af[r * ldn + j] * x[j];
-      rp[r] = s;
+      const double s = rp[t];
       rpmax = fabs(s);
       nonfinite += isfinite(s) ? 0.0 : 1.0;
     }
-    rdmax = wave_max(rdmax);
-    rpmax = wave_max(rpmax);
-    const double mu = wave_sum(mupart) / nb;
-    nonfinite = wave_sum(nonfinite);
+    rdmax = qp_wave_max(rdmax);
+    rpmax = qp_wave_max(rpmax);
+    const double mu = qp_wave_sum(mupart) / nb;
+    nonfinite = qp_wave_sum(nonfinite);
     if (nonfinite > 0.0 || !isfinite(rdmax) || !isfinite(rpmax) || !isfinite(mu)) { st = HILO_STATUS_INFEASIBLE; break; }
-    if (fmax(fmax(rdmax / (1.0 + gmax), rpmax), mu) <= qd.tol) { st = HILO_STATUS_SOLVED; break; }
+    const double phi = fmax(fmax(rdmax / (1.0 + gmax), rpmax), mu);
+    if (phi <= qd.tol) { st = HILO_STATUS_SOLVED; break; }
+    // infeasible QP (the reference's qpOASES reports it; a predictor-corrector iteration diverges instead): the termination rule
+    // of OOQP (Gertz & Wright, ACM TOMS 29, 2003) - the merit has grown to 1e4 times its smallest value so far
+    phi_min = fmin(phi_min, phi);
+    if (phi >= 1.0e4 * phi_min) { st = HILO_STATUS_INFEASIBLE; break; }
 
+    QP_TICK(1);
     // ---- M = Hf + Sigma + reg: row i in lane i (lanes >= NP mirror the last row), factored in registers ----
-    const int tr = t < NP ? t : NP - 1;
     bool okf;
     {
       double row[NP];
+      const qp_lds_cd hrow = qp_vbase(Hf + tr * ldn);
 #pragma unroll
-      for (int j = 0; j < NP; ++j) row[j] = Hf[tr * ldn + j];
+      for (int j = 0; j < NP; ++j) row[j] = hrow[j];
       double dg = 0.0;
       if (!isnan(l[tr])) {
         dg = qd.reg;
@@ -543,7 +734,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
       for (int j = 0; j < NP; ++j) row[j] += (j == tr) ? dg : 0.0;
       double di;
-      okf = qp_chol_rows<NP>(row, di);
+      okf = qp_chol_rows<NP>(row, di, cbuf);
       if (t < NP) {
         dinv[t] = di;
 #pragma unroll
@@ -552,6 +743,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     if (!okf) { st = HILO_STATUS_OTHER; break; }
     __syncthreads();
+    QP_TICK(2);
     // ---- columns of X = L^-1 A^T (MP of them) and of L^-1 (NP), 64 per pass; the pass with the columns of L^-1 runs last and
     // overwrites L once every lane has finished reading it ----
     constexpr int NCOL = NP + MP;
@@ -559,14 +751,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int c0 = ((NCOL - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
       const int c = c0 + t;
       const bool isL = c < NP, isX = c >= NP && c < NCOL;
-      const double* arow = Af + (size_t)(isX ? c - NP : 0) * ldn;
-      double rhs[NP], col[NP];
-#pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        const double av = arow[i];
-        rhs[i] = isL ? (i == c ? 1.0 : 0.0) : (isX ? av : 0.0);
-      }
-      qp_fsub_col<NP>(Lm, ldn, dinv, rhs, col);
+      const qp_lds_cd arow = qp_vbase(Af + (size_t)(isX ? c - NP : 0) * ldn);
+      double col[NP];
+      const double wx = isX ? 1.0 : 0.0, wl = isL ? 1.0 : 0.0;      // branch-free right-hand side: a row of Af or a unit vector
+      qp_fsub_col<NP>(Lm, ldn, dinv, [&](int i) { return fma(arow[i], wx, i == c ? wl : 0.0); }, col);
       if (isX) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) X[i * ldm + (c - NP)] = col[i];
@@ -580,27 +768,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       }
     }
     __syncthreads();
-    // ---- Schur complement S = X^T X + reg (lower triangle pairs), row a into lane a, factor, inverse factor ----
-    for (int pq = t; pq < MP * (MP + 1) / 2; pq += 64) {
-      int a = (int)((::sqrt(8.0 * pq + 1.0) - 1.0) * 0.5);
-      a += ((a + 1) * (a + 2) / 2 <= pq) ? 1 : 0;
-      a -= (a * (a + 1) / 2 > pq) ? 1 : 0;
-      const int c = pq - a * (a + 1) / 2;
-      double s2 = (a == c) ? (a < m ? qd.reg : 1.0) : 0.0;       // padding rows: identity
-      for (int i = 0; i < n; ++i) s2 += X[i * ldm + a] * X[i * ldm + c];
-      Ls[a * ldm + c] = s2;
-      Ls[c * ldm + a] = s2;
-    }
-    __syncthreads();
-    const int tm = t < MP ? t : MP - 1;
+    QP_TICK(3);
+    // ---- Schur complement S = X^T X + reg: row a accumulated in lane a (the rows of X broadcast), factored in registers ----
     bool oks;
     {
       double row[MP];
 #pragma unroll
-      for (int j = 0; j < MP; ++j) row[j] = Ls[tm * ldm + j];
+      for (int c = 0; c < MP; ++c) row[c] = (c == tm) ? (tm < m ? qd.reg : 1.0) : 0.0;    // padding rows: identity
+      qp_gram_row<NP, MP>(X, ldm, tm, row);
       double di;
-      oks = qp_chol_rows<MP>(row, di);
-      __syncthreads();
+    QP_TICK(4);
+      oks = qp_chol_rows<MP>(row, di, cbuf);
       if (t < MP) {
         dinvs[t] = di;
 #pragma unroll
@@ -610,10 +788,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (!oks) { st = HILO_STATUS_OTHER; break; }
     __syncthreads();
     {
-      double rhs[MP], col[MP];
-#pragma unroll
-      for (int i = 0; i < MP; ++i) rhs[i] = (i == tm) ? 1.0 : 0.0;
-      qp_fsub_col<MP>(Ls, ldm, dinvs, rhs, col);
+    QP_TICK(5);
+      double col[MP];
+      qp_fsub_col<MP>(Ls, ldm, dinvs, [&](int i) { return (i == tm) ? 1.0 : 0.0; }, col);
       __syncthreads();
       if (t < MP) {
 #pragma unroll
@@ -622,6 +799,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     __syncthreads();
 
+    QP_TICK(6);
     double sigma_mu = 0.0;
     for (int pass = 0; pass < 2; ++pass) {
       if (t < n) {
@@ -634,40 +812,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         r1[i] = s;
       }
       __syncthreads();
-      if (t < n) {                                   // tv = L^-1 r1
-        double s = 0.0;
-        for (int j = 0; j <= t; ++j) s += Lm[t * ldn + j] * r1[j];
-        tv[t] = s;
+      {                                              // tv = L^-1 r1  (L^-1: zeros above the diagonal)
+        const double s = qp_dot<NP>(Lm + tr * ldn, r1);
+        if (t < n) tv[t] = s;
       }
       __syncthreads();
-      if (t < m) {                                   // dy0 = rp + X^T tv
-        double s = rp[t];
-        for (int i = 0; i < n; ++i) s += X[i * ldm + t] * tv[i];
-        dy[t] = s;
+      {                                              // dy0 = rp + X^T tv
+        const double s = qp_dot_col<NP>(X + tm, ldm, tv);
+        if (t < m) dy[t] = rp[t] + s;
       }
       __syncthreads();
-      if (t < m) {                                   // wv = Ls^-1 dy0
-        double s = 0.0;
-        for (int c = 0; c <= t; ++c) s += Ls[t * ldm + c] * dy[c];
-        wv[t] = s;
+      {                                              // wv = Ls^-1 dy0
+        const double s = qp_dot<MP>(Ls + tm * ldm, dy);
+        if (t < m) wv[t] = s;
       }
       __syncthreads();
-      if (t < m) {                                   // dy = Ls^-T wv
-        double s = 0.0;
-        for (int a = t; a < m; ++a) s += Ls[a * ldm + t] * wv[a];
-        dy[t] = s;
+      {                                              // dy = Ls^-T wv
+        const double s = qp_dot_col<MP>(Ls + tm, ldm, wv);
+        __syncthreads();
+        if (t < m) dy[t] = s;
       }
       __syncthreads();
-      if (t < n) {                                   // tv <- tv - X dy
-        double s = tv[t];
-        for (int a = 0; a < m; ++a) s -= X[t * ldm + a] * dy[a];
-        tv[t] = s;
+      {                                              // tv <- tv - X dy
+        const double s = qp_dot<MP>(X + tr * ldm, dy);
+        if (t < n) tv[t] -= s;
       }
       __syncthreads();
-      if (t < n) {                                   // dx = L^-T tv
-        double s = 0.0;
-        for (int i = t; i < n; ++i) s += Lm[i * ldn + t] * tv[i];
-        r1[t] = s;
+      {                                              // dx = L^-T tv
+        const double s = qp_dot_col<NP>(Lm + tr, ldn, tv);
+        if (t < n) r1[t] = s;
       }
       __syncthreads();
       // bound-multiplier steps, step lengths (as qp_solve_kernel)
@@ -695,8 +868,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
         dx[i] = d; dzl[i] = dl; dzu[i] = du;
       }
-      ap = wave_min(ap);
-      ad = wave_min(ad);
+      ap = qp_wave_min(ap);
+      ad = qp_wave_min(ad);
       __syncthreads();
       if (pass == 0) {
         double mpart = 0.0;
@@ -705,7 +878,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
           if (l[i] > -INFINITY) mpart += (x[i] - l[i] + ap * dx[i]) * (zl[i] + ad * dzl[i]);
           if (u[i] < INFINITY) mpart += (u[i] - x[i] - ap * dx[i]) * (zu[i] + ad * dzu[i]);
         }
-        const double mu_aff = wave_sum(mpart) / nb;
+        const double mu_aff = qp_wave_sum(mpart) / nb;
         const double sg = mu > 0.0 ? (mu_aff / mu) : 0.0;
         sigma_mu = sg * sg * sg * mu;
       } else {
@@ -722,6 +895,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         __syncthreads();
       }
     }
+    QP_TICK(7);
   }
 
   // ---- outputs (CasADi conic sign convention: H x + g + A^T lam_a + lam_x = 0) ----
@@ -738,7 +912,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (lam_x) lam_x[b * n + i] = isnan(l[i]) ? -(hx + g[i] + aty) : zu[i] - zl[i];
   }
   if (lam_a && t < m) lam_a[b * m + t] = y[t];
-  fpart = wave_sum(fpart);
+  fpart = qp_wave_sum(fpart);
   if (t == 0) {
     f_out[b] = fpart;
     status[b] = st;
@@ -780,7 +954,7 @@ extern "C" int hilo_qp_create(int n, int m, int device, hilo_qp** out) {
   if (!h->fast_mp) h->fast_np = 0;
   {
     const size_t NP = h->fast_np, MP = h->fast_mp;
-    h->fast_lds = sizeof(double) * (2 * NP * (NP + 1) + MP * (NP + 1) + NP * (MP + 1) + MP * (MP + 1) + 14 * NP + 6 * MP);
+    h->fast_lds = sizeof(double) * (2 * NP * (NP + 1) + MP * (NP + 1) + NP * (MP + 1) + MP * (MP + 1) + 14 * NP + 6 * MP + 64);
   }
   if (h->fast_lds > 160 * 1024 || getenv("HILO_QP_LDS_COLUMNS")) h->fast_np = 0;
   h->ws = nullptr;
@@ -849,3 +1023,13 @@ extern "C" int hilo_qp_solve(hilo_qp* h, int64_t batch, const double* H, int64_t
   HILO_HIP_CHECK(hipGetLastError());
   return HILO_OK;
 }
+
+#ifdef HILO_QP_PROF
+extern "C" int hilo_qp_debug_prof(long long* out16) {
+  HILO_HIP_CHECK(hipDeviceSynchronize());
+  HILO_HIP_CHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(hilo::g_qp_prof), sizeof(long long) * 16));
+  long long z[16] = {0};
+  HILO_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(hilo::g_qp_prof), z, sizeof(z)));
+  return HILO_OK;
+}
+#endif

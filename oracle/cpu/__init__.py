@@ -1,4 +1,4 @@
-"""ctypes front of the C++/OpenMP CPU baseline (oracle/cpu/nmpc_cpu.cpp).
+"""ctypes front of the C++/OpenMP CPU baseline (oracle/cpu/nmpc_cpu.cpp, kf_cpu.cpp, qp_cpu.cpp).
 
 TEST INFRASTRUCTURE / BASELINE ONLY - used by tests/test_cpu_baseline.py and by bench.py's `cpu_baseline` leg, never by the
 product package.  The library takes the product's own problem descriptor (`hilo_nmpc_desc`, include/hilo_hip.h); here the
@@ -16,7 +16,8 @@ _lib = None
 
 
 def build(force=False):
-    src = [os.path.join(HERE, 'nmpc_cpu.cpp'), os.path.join(HERE, '..', '..', 'include', 'hilo_hip.h')]
+    src = [os.path.join(HERE, f) for f in ('nmpc_cpu.cpp', 'kf_cpu.cpp', 'qp_cpu.cpp', 'models_cpu.h', 'Makefile')] + \
+        [os.path.join(HERE, '..', '..', 'include', 'hilo_hip.h')]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
         subprocess.check_call(['make', '-s', '-C', HERE] + (['-B'] if force else []))
     return LIB
@@ -34,6 +35,10 @@ def lib():
         _lib.hilo_cpu_nmpc_destroy.restype = None
         _lib.hilo_cpu_nmpc_solve.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_int]
         _lib.hilo_cpu_plant_step.argtypes = [vp, i64, vp, vp, vp, i64, vp, C.c_int]
+        _lib.hilo_cpu_set_gp.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]
+        _lib.hilo_cpu_kf_steps.argtypes = [C.c_int, C.c_int, C.c_double, i64, C.c_int, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int]
+        _lib.hilo_cpu_qp_solve.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, i64, vp, vp, C.c_double, C.c_int, C.c_double, vp, vp, vp,
+                                           C.c_int]
     return _lib
 
 
@@ -102,3 +107,49 @@ class CpuNmpc:
 
 def max_threads():
     return int(lib().hilo_cpu_max_threads())
+
+
+_gp_keep = []
+
+
+def set_gp(X_train, alpha, length_scales, signal_variance=1., bias=0.):
+    """The learned term of the chemostat4_gp model (oracle/models.py::chemostat4_gp): squared-exponential posterior mean over (S, I)."""
+    Xt = np.ascontiguousarray(np.atleast_2d(X_train), dtype=np.float64)
+    al = np.ascontiguousarray(np.ravel(alpha), dtype=np.float64)
+    ls = np.broadcast_to(np.asarray(length_scales, dtype=np.float64), (2,))
+    M = np.exp(-2 * np.log(ls))
+    x0, x1 = np.ascontiguousarray(Xt[0]), np.ascontiguousarray(Xt[1])
+    _gp_keep[:] = [x0, x1, al]
+    lib().hilo_cpu_set_gp(al.size, float(signal_variance), float(bias), float(M[0]), float(M[1]), x0.ctypes.data, x1.ctypes.data,
+                          al.ctypes.data)
+
+
+def kf_steps(kind, xP, y, u, p, q, r, dt=1., order=4, n_threads=0):
+    """`steps` fused filter steps (predict + update) of the rk4-discretised chemostat for a batch: xP [B, 4, 5] packed [x | P],
+    y [steps, B, 2]; returns the new tile."""
+    xP = np.array(xP, dtype=np.float64, order='C')
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    if y.ndim == 2:
+        y = y[None]
+    B = xP.shape[0]
+    u = np.ascontiguousarray(np.broadcast_to(u, (B, 2)), dtype=np.float64)
+    p = np.ascontiguousarray(np.broadcast_to(p, (B, 4)), dtype=np.float64)
+    rc = lib().hilo_cpu_kf_steps(int(kind == 'ukf'), int(order), float(dt), B, y.shape[0], xP.ctypes.data, y.ctypes.data, u.ctypes.data,
+                                 p.ctypes.data, float(q), float(r), int(n_threads))
+    if rc != 0:
+        raise RuntimeError('hilo_cpu_kf_steps: bad argument')
+    return xP
+
+
+def qp_solve(H, g, A, b, lbx, ubx, tol=1e-10, max_iter=100, reg=1e-11, n_threads=0):
+    """The batch of QPs of `LMPC.optimize` (shared H, g, A, b; per-instance bounds): dict(x, status, iters)."""
+    H, g, A, b = (np.ascontiguousarray(a, dtype=np.float64) for a in (H, g, A, b))
+    lbx, ubx = np.ascontiguousarray(np.atleast_2d(lbx), dtype=np.float64), np.ascontiguousarray(np.atleast_2d(ubx), dtype=np.float64)
+    B, n = lbx.shape
+    x, st, it = np.empty((B, n)), np.empty(B, np.int32), np.empty(B, np.int32)
+    rc = lib().hilo_cpu_qp_solve(n, A.shape[0], H.ctypes.data, g.ctypes.data, A.ctypes.data, b.ctypes.data, B, lbx.ctypes.data,
+                                 ubx.ctypes.data, float(tol), int(max_iter), float(reg), x.ctypes.data, st.ctypes.data, it.ctypes.data,
+                                 int(n_threads))
+    if rc != 0:
+        raise RuntimeError('hilo_cpu_qp_solve: bad argument')
+    return dict(x=x, status=st, iters=it)

@@ -18,7 +18,8 @@
 //     F_k = R_k + B_k' P_{k+1} B_k has a Cholesky factor;
 //   * derivatives: second-order forward mode (value, gradient, Hessian with respect to the interval's z = (x_k, u_k)) pushed
 //     through the Runge-Kutta stages - what CasADi's SX graph of the discretised model provides to IPOPT (exact Hessian).
-// Scope: tracking NMPC with box bounds and scaling on the models chemostat4 and pendulum4 (configs C2 and the pendulum tests);
+// Scope: tracking NMPC with box bounds and scaling on the models chemostat4, chemostat4 with a learned growth rate (C4) and
+// pendulum4 (configs C2, C4 and the pendulum tests);
 // anything else in the descriptor is refused.  Validated against oracle/nmpc.py in tests/test_cpu_baseline.py before it is timed.
 #include <omp.h>
 
@@ -30,6 +31,7 @@
 #include <vector>
 
 #include "../../include/hilo_hip.h"
+#include "models_cpu.h"
 
 namespace {
 
@@ -119,50 +121,7 @@ template <int N> H2<N> sin(const H2<N>& a) { const double s = std::sin(a.v), c =
 template <int N> H2<N> cos(const H2<N>& a) { const double s = std::sin(a.v), c = std::cos(a.v); return chain(a, c, -s, -c); }
 template <int N> H2<N> exp(const H2<N>& a) { const double e = std::exp(a.v); return chain(a, e, e, e); }
 using std::cos;
-using std::exp;
-using std::sin;
-
-// ---- models (continuous right-hand sides) ------------------------------------------------------------------------------------
-// `ecoli_D1210_conti('simple')` with the closed-form rate laws (hilo_mpc/library/models.py:163-198, :143-148);
-// states X, S, P, I; inputs DS, DI; parameters Sf, If, ISF, IRF
-struct Chemostat4 {
-  static constexpr int NX = 4, NU = 2, NP = 4;
-  template <class T> static void ode(const T* x, const T* u, const double* p, T* dx) {
-    const T& X = x[0]; const T& S = x[1]; const T& P = x[2]; const T& I = x[3];
-    const T phi = 0.407 * S / (0.108 + S + S * S / 14814.0);
-    const T mu = phi * (p[2] + 0.22 * p[3] / (0.22 + I));
-    const T Rs = 2.0 * mu;
-    const T Rfp = phi * (0.0005 + I) / (0.022 + I);
-    const T D = u[0] + u[1];
-    dx[0] = mu * X - D * X;
-    dx[1] = -(Rs * X) - D * S + u[0] * p[0];
-    dx[2] = Rfp * X - D * P;
-    dx[3] = -(D * I) + u[1] * p[1];
-  }
-};
-// cart-pendulum of tests/test_NMPC.py:12-43: x, v, theta, omega; input F
-struct Pendulum4 {
-  static constexpr int NX = 4, NU = 1, NP = 0;
-  template <class T> static void ode(const T* x, const T* u, const double*, T* dx) {
-    const double M = 5.0, m = 1.0, l = 1.0, g = 9.81;
-    const T s = sin(x[2]), c = cos(x[2]);
-    const T dv = 1.0 / (M + m - m * c) * (m * g * s - m * l * s * x[3] * x[3] + u[0]);
-    dx[0] = x[1];
-    dx[1] = dv;
-    dx[2] = x[3];
-    dx[3] = 1.0 / l * (dv * c + g * s);
-  }
-};
-
-// explicit Runge-Kutta tableaux of modeling.py:1239-1250 (order 1: Euler, 2: midpoint, 3: Kutta, 4: classic)
-struct Tableau { int s; double A[4][4], b[4]; };
-const Tableau TAB[5] = {
-    {},
-    {1, {{0}}, {1.0}},
-    {2, {{0}, {0.5}}, {0.0, 1.0}},
-    {3, {{0}, {0.5}, {-1.0, 2.0}}, {1.0 / 6, 2.0 / 3, 1.0 / 6}},
-    {4, {{0}, {0.5}, {0, 0.5}, {0, 0, 1.0}}, {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6}},
-};
+using namespace hilo_cpu;   // models, tableaux (models_cpu.h)
 
 struct Problem {
   int model_id, N, order, n_sub, max_iter, acceptable_iter, nx, nu, np;
@@ -177,7 +136,7 @@ void phi_scaled(const Problem& pb, const T* xs, const T* us, const double* p, T*
   T x[NX], u[NU], k[4][NX], xi[NX];
   for (int i = 0; i < NX; ++i) x[i] = xs[i] * pb.sx[i];
   for (int i = 0; i < NU; ++i) u[i] = us[i] * pb.su[i];
-  const Tableau& t = TAB[pb.order];
+  const Tableau& t = tableau(pb.order);
   const double h = pb.dt / pb.n_sub;
   for (int sub = 0; sub < pb.n_sub; ++sub) {
     for (int i = 0; i < t.s; ++i) {
@@ -820,16 +779,23 @@ const char* hilo_cpu_last_error(void) { return g_err; }
 
 int hilo_cpu_max_threads(void) { return omp_get_max_threads(); }
 
+// the learned term of HILO_MODEL_CHEMOSTAT4_GP (host arrays, kept by the caller): see models_cpu.h::Chemostat4Gp
+void hilo_cpu_set_gp(int n, double sf2, double bias, double M0, double M1, const double* X0, const double* X1, const double* alpha) {
+  GpSe2& g = gp_of_chemostat4();
+  g.n = n; g.sf2 = sf2; g.bias = bias; g.M[0] = M0; g.M[1] = M1; g.X0 = X0; g.X1 = X1; g.alpha = alpha;
+}
+
 // Same descriptor as hilo_nmpc_create (include/hilo_hip.h); the subset this baseline covers is checked here.
 int hilo_cpu_nmpc_create(const hilo_nmpc_desc* d, hilo_cpu_nmpc** out) {
   if (!d || !out) return fail("NULL argument");
   int nx, nu, np;
-  if (d->model_id == HILO_MODEL_CHEMOSTAT4) { nx = 4; nu = 2; np = 4; }
+  if (d->model_id == HILO_MODEL_CHEMOSTAT4 || d->model_id == HILO_MODEL_CHEMOSTAT4_GP) { nx = 4; nu = 2; np = 4; }
   else if (d->model_id == HILO_MODEL_PENDULUM4) { nx = 4; nu = 1; np = 0; }
-  else return fail("the CPU baseline holds the models chemostat4 and pendulum4 only");
+  else return fail("the CPU baseline holds the models chemostat4 (with or without the learned growth rate) and pendulum4 only");
+  if (d->model_id == HILO_MODEL_CHEMOSTAT4_GP && gp_of_chemostat4().n <= 0) return fail("hilo_cpu_set_gp first");
   if (d->N < 1 || d->dt <= 0) return fail("bad horizon / dt");
-  if ((d->Nc && d->Nc != d->N) || d->n_path_var || d->n_con || d->n_tcon || d->collocation_degree || d->time_varying || d->learned ||
-      d->Wdu || d->user_source)
+  if ((d->Nc && d->Nc != d->N) || d->n_path_var || d->n_con || d->n_tcon || d->collocation_degree || d->time_varying ||
+      d->Wdu || d->user_source)     // (d->learned is a DEVICE handle: the learned term comes through hilo_cpu_set_gp)
     return fail("the CPU baseline covers tracking NMPC with box bounds only");
   hilo_cpu_nmpc* h = new hilo_cpu_nmpc();
   Problem& p = h->pb;
@@ -868,6 +834,8 @@ int hilo_cpu_nmpc_solve(hilo_cpu_nmpc* h, int64_t batch, const double* x0, const
   if (n_threads <= 0) n_threads = omp_get_max_threads();
   if (h->pb.model_id == HILO_MODEL_CHEMOSTAT4)
     solve_batch<Chemostat4>(h->pb, batch, x0, par, par_stride, v0, v_opt, f_opt, first_u, status, iters, kkt, n_threads);
+  else if (h->pb.model_id == HILO_MODEL_CHEMOSTAT4_GP)
+    solve_batch<Chemostat4Gp>(h->pb, batch, x0, par, par_stride, v0, v_opt, f_opt, first_u, status, iters, kkt, n_threads);
   else
     solve_batch<Pendulum4>(h->pb, batch, x0, par, par_stride, v0, v_opt, f_opt, first_u, status, iters, kkt, n_threads);
   return 0;
@@ -879,6 +847,7 @@ int hilo_cpu_plant_step(hilo_cpu_nmpc* h, int64_t batch, const double* x, const 
   if (!h || !x || !u || !xn) return fail("NULL argument");
   if (n_threads <= 0) n_threads = omp_get_max_threads();
   if (h->pb.model_id == HILO_MODEL_CHEMOSTAT4) plant_batch<Chemostat4>(h->pb, batch, x, u, par, par_stride, xn, n_threads);
+  else if (h->pb.model_id == HILO_MODEL_CHEMOSTAT4_GP) plant_batch<Chemostat4Gp>(h->pb, batch, x, u, par, par_stride, xn, n_threads);
   else plant_batch<Pendulum4>(h->pb, batch, x, u, par, par_stride, xn, n_threads);
   return 0;
 }

@@ -88,15 +88,22 @@ def solve_qp(H, g, A, b, lb, ub, tol=1e-10, max_iter=100, reg=1e-11):
     y = np.zeros(m)
     zl, zu = np.where(hl, 1., 0.), np.where(hu, 1., 0.)
     nb = max(1, int(hl.sum() + hu.sum()))
-    status, it = 5, 0
+    status, it, phi_min = 5, 0, INF
     for it in range(max_iter):
       with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
           sl, su = np.where(hl, x - l, 1.), np.where(hu, u - x, 1.)
           rd = Hf @ x + gf + Af.T @ y - zl + zu
           rp = Af @ x - bf
           mu = (np.sum(sl * zl * hl) + np.sum(su * zu * hu)) / nb
-          if max(np.abs(rd).max(initial=0) / (1 + np.abs(gf).max(initial=0)), np.abs(rp).max(initial=0), mu) <= tol:
+          phi = max(np.abs(rd).max(initial=0) / (1 + np.abs(gf).max(initial=0)), np.abs(rp).max(initial=0), mu)
+          if phi <= tol:
               status = 1
+              break
+          # infeasible QP: the termination rule of OOQP (Gertz & Wright, ACM TOMS 29, 2003) - the merit has grown to 1e4 times
+          # its smallest value so far (the reference's qpOASES reports infeasibility; this iteration would diverge instead)
+          phi_min = min(phi_min, phi)
+          if phi >= 1e4 * phi_min:
+              status = 3
               break
           M = Hf + np.diag(np.where(hl, zl / sl, 0) + np.where(hu, zu / su, 0) + reg)
           L = np.linalg.cholesky(M)

@@ -60,5 +60,57 @@ def test_thread_count_does_not_change_results():
 def test_out_of_scope_descriptor_is_refused():
     with pytest.raises(NotImplementedError):
         CpuNmpc(oracle_problem(dict(C2, Nc=3)))
-    with pytest.raises(RuntimeError, match="chemostat4 and pendulum4"):
+    with pytest.raises(RuntimeError, match="and pendulum4 only"):
         CpuNmpc(NmpcProblem(models.get('cstr3'), dt=1., N=4))
+
+
+# ---- the other legs of the baseline: learned growth rate (C4), Kalman filters (C3), the LMPC's QP (C1) --------------------------
+def test_c4_learned_growth_rate_vs_oracle():
+    """chemostat4 with the GP posterior mean as growth rate (oracle/models.py::chemostat4_gp): the C++ model sums the same 200
+    kernel terms in second-order forward mode; same iteration path as the numpy oracle."""
+    from oracle.cpu import set_gp
+    from tests.problems import C4, C4_GP, c4_training_data, oracle_c4
+    pb, post = oracle_c4(dict(C4, N=6))
+    X, _ = c4_training_data()
+    set_gp(X, post.alpha, C4_GP['length_scales'], C4_GP['signal_variance'])
+    _compare(pb, c2_x0(2), C2['p'], steps=2)
+
+
+@pytest.mark.parametrize('kind', ['ekf', 'ukf'])
+def test_filter_steps_vs_oracle(kind):
+    from oracle import kf as okf
+    from oracle.cpu import kf_steps
+    rng = np.random.default_rng(4)
+    B, K = 16, 3
+    x = np.array([.1, 40., .5, .2]) * (1 + .1 * rng.uniform(-1, 1, (B, 4)))
+    P = np.tile(np.eye(4), (B, 1, 1)) * rng.uniform(.5, 1.5, (B, 1, 1))
+    u, p = rng.uniform(0, .3, (B, 2)), np.tile([100., 4., 1., 0.], (B, 1))
+    y = x[None, :, [0, 2]] * (1 + .02 * rng.normal(size=(K, B, 2)))
+    mdl = models.get('chemostat4').discretize(4)
+    ref = okf.pack(x, P)
+    stepf = okf.kf_step if kind == 'ekf' else okf.ukf_step
+    for k in range(K):
+        ref, _ = stepf(mdl, ref, y[k], u, p, 1e-4, 1e-2, 1.)
+    got = kf_steps(kind, okf.pack(x, P), y, u, p, 1e-4, 1e-2, dt=1., n_threads=2)
+    # the unscented transform cancels six digits in its weighted sums (alpha = 1e-3): compare at that level
+    np.testing.assert_allclose(got, ref, rtol=1e-9 if kind == 'ekf' else 1e-5, atol=1e-11 if kind == 'ekf' else 1e-8)
+    one = kf_steps(kind, okf.pack(x, P), y, u, p, 1e-4, 1e-2, dt=1., n_threads=1)
+    assert np.array_equal(one, got)
+
+
+def test_lmpc_qp_vs_oracle():
+    from oracle.cpu import qp_solve
+    from oracle.lmpc import LmpcProblem, solve_qp
+    from tests.test_oracle_lmpc import C1
+    pb = LmpcProblem(**C1, kron_bug=False)
+    rng = np.random.default_rng(6)
+    xs = rng.uniform(-4, 4, (40, 2))
+    bnd = [pb.bounds_for(x0) for x0 in xs]
+    lb, ub = np.array([b[0] for b in bnd]), np.array([b[1] for b in bnd])
+    res = qp_solve(pb.H, pb.g, pb.Aeq, pb.beq, lb, ub, n_threads=2)
+    ref = [solve_qp(pb.H, pb.g, pb.Aeq, pb.beq, l, u) for l, u in zip(lb, ub)]
+    st = np.array([r['status'] for r in ref])
+    assert np.array_equal(res['status'], st) and set(np.unique(st)) == {1, 3}
+    assert np.max(np.abs(res['iters'] - np.array([r['iters'] for r in ref]))) <= 1
+    ok = st == 1
+    np.testing.assert_allclose(res['x'][ok], np.array([r['x'] for r in ref])[ok], atol=1e-7)     # (the oracle polishes the vertex)

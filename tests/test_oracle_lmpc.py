@@ -38,7 +38,7 @@ def test_qp_vs_scipy(bug):
         lp = linprog(np.zeros(pb.n_v), A_eq=pb.Aeq, b_eq=pb.beq, bounds=list(zip(lb, ub)))
         if lp.status == 2:
             # some measured states make the QP infeasible (box on x; more often with the scrambled block of mpc.py:2243)
-            assert res['status'] != 1
+            assert res['status'] == 3 and res['iters'] <= 20           # reported, not iterated to the cap
             continue
         n_feasible += 1
         assert res['status'] == 1
@@ -66,3 +66,22 @@ def test_closed_loop_double_integrator():
         assert r['status'][0] == 1
         x = x @ A.T + r['u'] @ B.T
     assert np.abs(x).max() < 1e-3
+
+
+def test_infeasible_states_are_reported_early():
+    """OOQP's termination rule in the predictor-corrector iteration: a measured state from which the box cannot be kept makes the
+    QP infeasible (scipy's phase 1 agrees); the iteration reports status 3 within a few steps and never does so on a feasible QP."""
+    from scipy.optimize import linprog
+    pb = LmpcProblem(**C1, kron_bug=False)
+    rng = np.random.default_rng(8)
+    xs = rng.uniform(-4, 4, (60, 2))
+    res = lmpc_optimize(pb, xs)
+    n_inf = 0
+    for x0, st, it in zip(xs, res['status'], res['iters']):
+        lb, ub = pb.bounds_for(x0)
+        lp = linprog(np.zeros(pb.n_v), A_eq=pb.Aeq, b_eq=pb.beq, bounds=list(zip(lb, ub)))
+        assert (st == 3) == (lp.status == 2) and (st == 1) == (lp.status == 0)
+        if st == 3:
+            n_inf += 1
+            assert it <= 15
+    assert n_inf >= 5
