@@ -125,19 +125,13 @@ def _solve_roofline(kernel, B, mean_iters, nx, nu, N, ops, kern_ms, tag, n_v, n_
                     "algorithmic_bytes_per_launch": bytes_launch, "note": "compulsory bytes only; not the binding roof"}}
 
 
-def cpu_baseline_c2(spec, nst=50, slsqp=True):
-    """BASELINE.md section 3: the C++17 / OpenMP Riccati interior point of oracle/cpu (validated against the numpy oracle in
-    tests/test_cpu_baseline.py: same statuses, iteration counts and solutions) on the SAME closed-loop workload - 5 warm-up
-    + 50 timed warm-started steps - with all host cores and with one; plus scipy SLSQP on the identical transcribed NLP."""
+def host_cores():
+    """The cores this process can actually use: the OpenMP runtime's count, the scheduler affinity AND the container's CPU quota
+    (cgroup) bound it, whatever os.cpu_count() reports.  Returns (cores, quota)."""
     # threads pinned to cores (set before the OpenMP runtime of the baseline library starts)
     os.environ.setdefault('OMP_PROC_BIND', 'close')
     os.environ.setdefault('OMP_PLACES', 'cores')
-    from oracle.cpu import CpuNmpc, max_threads
-    from tests import problems as P
-    pb = P.oracle_problem(spec)
-    cpu = CpuNmpc(pb)
-    # the cores this process can actually use: the scheduler affinity AND the container's CPU quota (cgroup) bound it, whatever
-    # the OpenMP runtime or os.cpu_count() report
+    from oracle.cpu import max_threads
     quota = None
     try:
         q, per = open('/sys/fs/cgroup/cpu.max').read().split()
@@ -147,6 +141,26 @@ def cpu_baseline_c2(spec, nst=50, slsqp=True):
     C = min(max_threads(), len(os.sched_getaffinity(0)))
     if quota is not None:
         C = max(1, min(C, int(quota + 1e-9)))
+    return C, quota
+
+
+def cpu_model_name():
+    try:
+        return [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
+    except Exception:
+        return ''
+
+
+def cpu_baseline_c2(spec, nst=50, slsqp=True, pb=None, label='C2', per_thread=64):
+    """BASELINE.md section 3: the C++17 / OpenMP Riccati interior point of oracle/cpu (validated against the numpy oracle in
+    tests/test_cpu_baseline.py: same statuses, iteration counts and solutions) on the SAME closed-loop workload - 5 warm-up
+    + `nst` timed warm-started steps - with all host cores and with one; plus scipy SLSQP on the identical transcribed NLP.
+    `pb`: another tracking problem of the same shape (C4: the chemostat with the learned growth rate, oracle.cpu.set_gp first)."""
+    C, quota = host_cores()
+    from oracle.cpu import CpuNmpc
+    from tests import problems as P
+    pb = P.oracle_problem(spec) if pb is None else pb
+    cpu = CpuNmpc(pb)
 
     def loop(nb, nt, nst=nst, nwarm=5):
         xs, v, t0, its = P.c2_x0(nb), None, 0.0, []
@@ -159,9 +173,10 @@ def cpu_baseline_c2(spec, nst=50, slsqp=True):
                 its.append(r['iters'].mean())
         secs = time.perf_counter() - t0
         return nb * nst / secs, secs, float(np.mean(its)), float(np.mean((r['status'] == 1) | (r['status'] == 2)))
-    nb_all = max(1024, 64 * C)       # at least 64 instances per thread and call
+    nb_all = max(16 * per_thread, per_thread * C)       # at least `per_thread` instances per thread and call
     v_all, s_all, it_all, ok_all = loop(nb_all, C)
-    v_one, s_one, _, _ = loop(128, 1, nst=min(nst, 20))
+    n_one = min(nst, 20)
+    v_one, s_one, _, _ = loop(2 * per_thread, 1, nst=n_one)
     slsqp_ms, sol = None, None
     if slsqp:
         # secondary reference point: an off-the-shelf dense NLP solver (scipy SLSQP) cold on one instance of the same NLP, with the
@@ -186,21 +201,77 @@ def cpu_baseline_c2(spec, nst=50, slsqp=True):
                        constraints=[{'type': 'eq', 'fun': lambda w: ev(w)[2], 'jac': lambda w: ev(w)[3]}],
                        options={'ftol': 1e-12, 'maxiter': 500})
         slsqp_ms = (time.perf_counter() - t0) * 1e3
-    model = ''
-    try:
-        model = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
-    except Exception:
-        pass
     return {"value": v_all, "unit": "steps/s", "cores": C, "kind": "port", "one_core_value": v_one,
-            "cpu_model": model, "cgroup_cpu_quota": quota, "sched_affinity_cpus": len(os.sched_getaffinity(0)),
+            "cpu_model": cpu_model_name(), "cgroup_cpu_quota": quota, "sched_affinity_cpus": len(os.sched_getaffinity(0)),
             "mean_ipm_iters": it_all, "frac_status_1_or_2": ok_all,
             "slsqp_ms_per_solve": slsqp_ms, "slsqp_iterations": int(sol.nit) if sol is not None else None,
             "sample": f"oracle/cpu C++17/OpenMP Riccati interior point (same algorithm and constants as the numpy oracle, validated "
-                      f"against it): C2 closed loop, {nb_all} instances x {nst} warm-started steps on {C} pinned threads = min(OpenMP, affinity, cgroup quota) ({s_all:.1f} s); "
-                      f"one_core_value: 128 instances x {min(nst, 20)} steps on 1 thread ({s_one:.1f} s); slsqp: scipy SLSQP with the oracle's exact "
-                      f"derivatives, cold, one instance of the same NLP (converged: {bool(sol.success) if sol is not None else None}); the reference's CasADi/IPOPT is not installable",
+                      f"against it): {label} closed loop, {nb_all} instances x {nst} warm-started steps on {C} pinned threads = min(OpenMP, affinity, cgroup quota) ({s_all:.1f} s); "
+                      f"one_core_value: {2 * per_thread} instances x {n_one} steps on 1 thread ({s_one:.1f} s)"
+                      + (f"; slsqp: scipy SLSQP with the oracle's exact derivatives, cold, one instance of the same NLP (converged: "
+                         f"{bool(sol.success)})" if sol is not None else "") + "; the reference's CasADi/IPOPT is not installable",
             "host_cpus": os.cpu_count()}
 
+
+def cpu_leg_kf(kind, K, budget=6., min_batch=4096):
+    # oracle/cpu/kf_cpu.cpp (C++17 / OpenMP, validated against oracle/kf.py in tests/test_cpu_baseline.py): the same K sampling
+    # instants per call for a larger batch, all host cores and one
+    from oracle.cpu import kf_steps
+    from oracle import kf as okf
+    C, quota = host_cores()
+    nb = max(min_batch, (min_batch // 2) * C)
+    rs = np.random.default_rng(5)
+    xs = np.array([.1, 40., .5, .2]) * (1 + .1 * rs.uniform(-1, 1, (nb, 4)))
+    xP = okf.pack(xs, np.tile(np.eye(4), (nb, 1, 1)))
+    yy = xs[None, :, [0, 2]] * (1 + .02 * rs.normal(size=(K, nb, 2)))
+    uu, pp = rs.uniform(0, .3, (nb, 2)), np.tile([100., 4., 1., 0.], (nb, 1))
+
+    def run(nt, budget):
+        kf_steps(kind, xP, yy, uu, pp, 1e-4, 1e-2, dt=1., n_threads=nt)
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget:
+            kf_steps(kind, xP, yy, uu, pp, 1e-4, 1e-2, dt=1., n_threads=nt)
+            n += 1
+        secs = time.perf_counter() - t0
+        return n * nb * K / secs, secs, n
+    v_all, s_all, n_all = run(C, budget)
+    v_one, s_one, n_one = run(1, budget * 2 / 3)
+    return {"value": v_all, "unit": "steps/s", "cores": C, "kind": "port", "one_core_value": v_one,
+            "cpu_model": cpu_model_name(), "cgroup_cpu_quota": quota,
+            "sample": f"oracle/cpu C++17/OpenMP {kind.upper()} (validated against the numpy oracle): {n_all} calls x {nb} instances x "
+                      f"{K} filter steps on {C} pinned threads ({s_all:.1f} s); one_core_value: {n_one} calls on 1 thread ({s_one:.1f} s)",
+            "host_cpus": os.cpu_count()}
+
+
+def cpu_leg_qp(budget=6., min_batch=4096):
+    # oracle/cpu/qp_cpu.cpp (C++17 / OpenMP; the kernels' predictor-corrector iteration, validated against oracle/lmpc.py in
+    # tests/test_cpu_baseline.py) on measured states drawn like the benchmark's, all host cores and one
+    from oracle.cpu import qp_solve
+    from oracle.lmpc import LmpcProblem
+    from tests.test_oracle_lmpc import C1
+    C, quota = host_cores()
+    pb = LmpcProblem(**C1, kron_bug=False)
+    nb = max(min_batch, (min_batch // 4) * C)
+    xs = np.random.default_rng(7).uniform(-4, 4, (nb, 2))
+    bnd = [pb.bounds_for(x0) for x0 in xs]
+    lb, ub = np.array([b[0] for b in bnd]), np.array([b[1] for b in bnd])
+
+    def run(nt, budget):
+        r = qp_solve(pb.H, pb.g, pb.Aeq, pb.beq, lb, ub, tol=1e-12, reg=1e-12, n_threads=nt)
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget:
+            r = qp_solve(pb.H, pb.g, pb.Aeq, pb.beq, lb, ub, tol=1e-12, reg=1e-12, n_threads=nt)
+            n += 1
+        secs = time.perf_counter() - t0
+        return n * nb / secs, secs, n, r
+    v_all, s_all, n_all, r = run(C, budget)
+    v_one, s_one, n_one, _ = run(1, budget * 2 / 3)
+    return {"value": v_all, "unit": "steps/s", "cores": C, "kind": "port", "one_core_value": v_one,
+            "cpu_model": cpu_model_name(), "cgroup_cpu_quota": quota, "mean_qp_iters": float(r['iters'].mean()),
+            "frac_status_1": float((r['status'] == 1).mean()),
+            "sample": f"oracle/cpu C++17/OpenMP dense predictor-corrector QP (the kernels' iteration and tolerances): {n_all} calls x "
+                      f"{nb} QPs on {C} pinned threads ({s_all:.1f} s); one_core_value: {n_one} calls on 1 thread ({s_one:.1f} s); the "
+                      f"reference's CasADi/qpOASES is not installable", "host_cpus": os.cpu_count()}
 
 
 def wl_nmpc(cfg, args, torch, dev, rank, world):
@@ -274,18 +345,12 @@ def wl_nmpc(cfg, args, torch, dev, rank, world):
                 res = ipm.solve(xs, spec['p'], w0=res['w'])
             what = "GenIpm (dense KKT, numpy)"
         else:
-            from oracle.nmpc import DenseIpm
-            pb = P.oracle_c4()[0]
-            ipm = DenseIpm(pb)
-            ns, nst = 4, 2
-            xs = P.c2_x0(ns)
-            res = ipm.solve(xs, spec['p'])
-            xs = pb.phi(xs / pb.sx, res['U'][:, 0], spec['p']) * pb.sx
-            t0 = time.perf_counter()
-            for _ in range(nst):
-                res = ipm.solve(xs, spec['p'], w0=res['w'])
-                xs = pb.phi(xs / pb.sx, res['U'][:, 0], spec['p']) * pb.sx
-            what = "DenseIpm (dense KKT, numpy)"
+            # the C++ baseline with the learned growth rate (oracle/cpu/models_cpu.h::Chemostat4Gp, validated against the numpy oracle)
+            from oracle.cpu import set_gp
+            pb, post = P.oracle_c4()
+            Xtr, _ = P.c4_training_data()
+            set_gp(Xtr, post.alpha, P.C4_GP['length_scales'], P.C4_GP['signal_variance'])
+            return cpu_baseline_c2(spec, nst=10, slsqp=False, pb=pb, label='C4 (200 kernel terms per right-hand side)', per_thread=8)
         secs = time.perf_counter() - t0
         return {"value": ns * nst / secs, "unit": "steps/s", "cores": 1, "kind": "port",
                 "sample": f"{ns} instances x {nst} warm-started steps of the same {cfg} workload with the oracle's {what} "
@@ -397,21 +462,7 @@ def wl_kf(kind, args, torch, dev, rank, world):
         return extra, roof, "weak"
 
     def cpu():
-        from oracle import kf as okf, models as om
-        mdl = om.get('chemostat4').discretize(4)
-        xP = okf.pack(x, Pm)
-        yy = x[:, [0, 2]]
-        uu, pp = u.cpu().numpy(), p.cpu().numpy()
-        stepf = okf.kf_step if kind == 'ekf' else okf.ukf_step
-        t0 = time.perf_counter()
-        n = 0
-        while time.perf_counter() - t0 < 8.:
-            stepf(mdl, xP, yy, uu, pp, 1e-4, 1e-2, 1.)
-            n += 1
-        secs = time.perf_counter() - t0
-        return {"value": n * B / secs, "unit": "steps/s", "cores": 1, "kind": "port",
-                "sample": f"{n} batched steps of B = {B} with the oracle's numpy-vectorised {kind.upper()} ({secs:.1f} s)",
-                "host_cpus": os.cpu_count()}
+        return cpu_leg_kf(kind, K)
     return dict(step=step, finish=finish, units=B * K, cpu=cpu, unit="steps/s",
                 metric="Kalman filter steps/sec (batched instances, whole node)")
 
@@ -514,19 +565,7 @@ def wl_lmpc(args, torch, dev, rank, world):
         return extra, roof, "weak"
 
     def cpu():
-        from oracle.lmpc import LmpcProblem, lmpc_optimize
-        from tests.test_oracle_lmpc import C1
-        pb = LmpcProblem(**C1, kron_bug=False)
-        xs = rng.uniform(-4, 4, (64, 2))
-        t0 = time.perf_counter()
-        nrep = 0
-        while time.perf_counter() - t0 < 8.:
-            lmpc_optimize(pb, xs)
-            nrep += 1
-        secs = time.perf_counter() - t0
-        return {"value": nrep * 64 / secs, "unit": "steps/s", "cores": 1, "kind": "port",
-                "sample": f"{nrep} x 64 QPs with the oracle's dense Mehrotra + active-set polish (numpy; {secs:.1f} s)",
-                "host_cpus": os.cpu_count()}
+        return cpu_leg_qp()
     return dict(step=step, finish=finish, units=B, cpu=cpu, unit="steps/s",
                 metric="LMPC steps/sec (batched QPs, whole node)")
 

@@ -70,6 +70,16 @@ def test_cpu_baseline_leg_of_c2_runs_here():
     assert out['frac_status_1_or_2'] == 1.0
 
 
+def test_cpu_baseline_legs_of_the_filters_and_the_qp_run_here():
+    """The C++/OpenMP legs of the C3 filter lines and the C1 line on a reduced sample (no GPU needed)."""
+    b = _bench()
+    for kind in ('ekf', 'ukf'):
+        out = b.cpu_leg_kf(kind, 4, budget=.3, min_batch=256)
+        assert out['kind'] == 'port' and out['cores'] >= 1 and out['value'] > 0 and out['one_core_value'] > 0 and out['unit'] == 'steps/s'
+    out = b.cpu_leg_qp(budget=.3, min_batch=128)
+    assert out['value'] > 0 and 0.5 < out['frac_status_1'] < 1.0 and out['mean_qp_iters'] < 12
+
+
 def test_bench_spawns_one_rank_per_gpu(monkeypatch):
     """`python bench.py --gpus N` without a torchrun environment re-executes itself under torch.distributed.run with N processes
     on 127.0.0.1 (the driver's own launch line) and hands its exit status through."""
