@@ -14,6 +14,8 @@ namespace hilo {
 
 // LDS-qualified pointer types: keep the address space through non-inlined calls (ds_read/ds_write, not flat_*)
 typedef __attribute__((address_space(3))) double lds_double;
+typedef __attribute__((address_space(1))) double gbl_double;
+typedef const __attribute__((address_space(1))) double gbl_cdouble;
 typedef const __attribute__((address_space(3))) double lds_cdouble;
 
 enum ModelId : int {
@@ -39,11 +41,19 @@ enum ModelId : int {
 // ------------------------------------------------------------------------------------------------
 struct NoExt {};
 constexpr int GP2_HDR = 5;
+constexpr int GP2_MAXN = 256;   // kernel terms of a learned two-feature mean that the solve kernel keeps in LDS (cooperative variant)
 struct GpExt {
-  const double* gp;
-  lds_double* scr;  // 12 doubles per lane (partials | group totals); unused when gs == 1
+  const double* gp;   // packed posterior mean in device memory: [n, sf2, bias, M0, M1, (X0_i, X1_i, alpha_i) * n]
+  lds_double* scr;    // 12 doubles per lane (partials | group totals); unused when gs == 1
   int gs, gl, gbase;
-  bool idle;        // lane has no task: contributes nothing, still takes part in the exchange
+  bool idle;          // lane has no task: contributes nothing, still takes part in the exchange
+  lds_cdouble* tab = nullptr;   // the same table staged in LDS by the solve kernel (or null: read `gp`)
+  // value / gradient / Hessian of the mean at the Runge-Kutta stage points of ONE interval, [4][6] in LDS (or null): written by a
+  // values-only evaluation (the line search's trial point), read instead of summing the kernel terms again when the derivative
+  // phase runs at that very point (`use_cache`); `ctr` counts the model evaluations of the interval
+  lds_double* cache = nullptr;
+  int* ctr = nullptr;
+  bool use_cache = false;
 };
 
 // the few type traits the device code needs, written out: under hiprtc there is no <type_traits>
@@ -62,29 +72,60 @@ template <class M> struct ModelSym { static constexpr bool value = false, HAS_ME
 template <class M, class = void> struct model_has_ext : bool_const<false> {};
 template <class M> struct model_has_ext<M, void_tt<decltype(M::EXT)>> : bool_const<M::EXT> {};
 
+// one kernel term: k = alpha exp(-1/2 (M0 d0^2 + M1 d1^2)) and its contributions to value / gradient / Hessian
+template <int ORDER>
+__device__ __forceinline__ void gp2_term(double x0, double x1, double al, double M0, double M1, double s, double i, double* acc) {
+  const double d0 = s - x0, d1 = i - x1;
+  const double t0 = M0 * d0, t1 = M1 * d1;
+  const double k = al * ::exp(-0.5 * (d0 * t0 + d1 * t1));
+  acc[0] += k;
+  if constexpr (ORDER == 2) {
+    acc[1] -= k * t0;
+    acc[2] -= k * t1;
+    acc[3] += k * (t0 * t0 - M0);
+    acc[4] += k * t0 * t1;
+    acc[5] += k * (t1 * t1 - M1);
+  }
+}
+// this lane's share of the kernel sum: terms j0, j0 + dj, ... in that order (the order is part of the result); four terms'
+// operands are requested before the first exponential so that their latency (LDS or L2) is paid once per four terms
+template <int ORDER, class P>
+__device__ __forceinline__ void gp2_sum(P rows, int n, double M0, double M1, double s, double i, int j0, int dj, double* acc) {
+  int j = j0;
+  for (; j + 3 * dj < n; j += 4 * dj) {
+    double x0[4], x1[4], al[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      P r = rows + 3 * (j + q * dj);
+      x0[q] = r[0]; x1[q] = r[1]; al[q] = r[2];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gp2_term<ORDER>(x0[q], x1[q], al[q], M0, M1, s, i, acc);
+  }
+  for (; j < n; j += dj) {
+    P r = rows + 3 * j;
+    gp2_term<ORDER>(r[0], r[1], r[2], M0, M1, s, i, acc);
+  }
+}
+
 // value (ORDER 0) or value / gradient / Hessian (ORDER 2: out = m, g0, g1, h00, h01, h11) of the GP mean at (s, i)
 template <int ORDER>
 __device__ __forceinline__ void gp2_taylor(const GpExt& e, double s, double i, double* out) {
   constexpr int NC = ORDER == 0 ? 1 : 6;
-  const double* g = e.gp;
-  const int n = (int)g[0];
-  const double sf2 = g[1], bias = g[2], M0 = g[3], M1 = g[4];
   double acc[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) acc[c] = 0.0;
-  for (int j = e.idle ? n : e.gl; j < n; j += e.gs) {
-    const double* r = g + GP2_HDR + 3 * j;
-    const double d0 = s - r[0], d1 = i - r[1];
-    const double t0 = M0 * d0, t1 = M1 * d1;
-    const double k = r[2] * ::exp(-0.5 * (d0 * t0 + d1 * t1));
-    acc[0] += k;
-    if constexpr (ORDER == 2) {
-      acc[1] -= k * t0;
-      acc[2] -= k * t1;
-      acc[3] += k * (t0 * t0 - M0);
-      acc[4] += k * t0 * t1;
-      acc[5] += k * (t1 * t1 - M1);
-    }
+  double sf2, bias;
+  if (e.tab) {                  // wave-uniform
+    lds_cdouble* g = e.tab;
+    const int n = (int)g[0];
+    sf2 = g[1]; bias = g[2];
+    gp2_sum<ORDER>(g + GP2_HDR, n, g[3], g[4], s, i, e.idle ? n : e.gl, e.gs, acc);
+  } else {
+    const double* g = e.gp;
+    const int n = (int)g[0];
+    sf2 = g[1]; bias = g[2];
+    gp2_sum<ORDER>(g + GP2_HDR, n, g[3], g[4], s, i, e.idle ? n : e.gl, e.gs, acc);
   }
   if (e.gs > 1 || e.idle) {  // wave-uniform by construction of the groups (all lanes of a cooperative pass get here)
     const int lane = threadIdx.x;
@@ -96,7 +137,15 @@ __device__ __forceinline__ void gp2_taylor(const GpExt& e, double s, double i, d
     if (!e.idle) {
       for (int c = e.gl; c < NC; c += e.gs) {
         double t = 0.0;
-        for (int q = 0; q < e.gs; ++q) t += part[(e.gbase + q) * 6 + c];
+        int q = 0;
+        for (; q + 8 <= e.gs; q += 8) {   // eight partials requested before the first addition (same order of the sum)
+          double v[8];
+#pragma unroll
+          for (int w = 0; w < 8; ++w) v[w] = part[(e.gbase + q + w) * 6 + c];
+#pragma unroll
+          for (int w = 0; w < 8; ++w) t += v[w];
+        }
+        for (; q < e.gs; ++q) t += part[(e.gbase + q) * 6 + c];
         tot[e.gbase * 6 + c] = t;
       }
     }
@@ -110,13 +159,29 @@ __device__ __forceinline__ void gp2_taylor(const GpExt& e, double s, double i, d
   out[0] += bias;
 }
 __device__ __forceinline__ double gp2_mean(const GpExt& e, double s, double i) {
+  if (e.cache) {               // wave-uniform: keep the second-order data of this stage point for the derivative phase
+    double o[6];
+    gp2_taylor<2>(e, s, i, o);
+    const int idx = (*e.ctr)++;
+    if (idx < 4 && !e.idle && e.gl == 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) e.cache[idx * 6 + c] = o[c];
+    }
+    return o[0];
+  }
   double o[1];
   gp2_taylor<0>(e, s, i, o);
   return o[0];
 }
 __device__ __forceinline__ Jet2 gp2_mean(const GpExt& e, const Jet2& s, const Jet2& i) {
   double o[6];
-  gp2_taylor<2>(e, s.v, i.v, o);
+  if (e.use_cache) {           // wave-uniform
+    const int idx = (*e.ctr)++;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) o[c] = e.cache[(idx < 4 ? idx : 3) * 6 + c];
+  } else {
+    gp2_taylor<2>(e, s.v, i.v, o);
+  }
   return Jet2(o[0], o[1] * s.a + o[2] * i.a,
               o[1] * s.b + o[2] * i.b + o[3] * s.a * s.a + 2.0 * o[4] * s.a * i.a + o[5] * i.a * i.a);
 }

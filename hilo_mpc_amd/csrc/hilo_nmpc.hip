@@ -387,6 +387,15 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     }
     rc = gp_pack_se2(d->learned, &h->ext_pack);
     if (rc) { hilo_nmpc_destroy(h); return rc; }
+    {
+      double nterms = 0.0;   // the solve kernel stages the table in LDS (hilo_models.h GP2_MAXN)
+      HILO_HIP_CHECK(hipMemcpy(&nterms, h->ext_pack, sizeof(double), hipMemcpyDeviceToHost));
+      if (nterms > GP2_MAXN) {
+        hilo_nmpc_destroy(h);
+        return fail(HILO_ENOTSUP, "hilo_nmpc_create: the learned term of 'chemostat4_gp' has %d training points (limit %d)", (int)nterms,
+                    GP2_MAXN);
+      }
+    }
     c.ext = h->ext_pack;
   } else if (d->learned) {
     hilo_nmpc_destroy(h);

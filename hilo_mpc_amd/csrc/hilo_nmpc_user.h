@@ -31,7 +31,7 @@ namespace hilo {
 // ---- layout of pc.cost for NmpcUser: plain function of the dimensions so that the host (hilo_jit.hip) fills the block ----
 struct UserLayout {
   int mza, o_wz, o_zref, o_wn, o_xrefn, o_wdu, o_hasdu, o_we, o_wet, o_ws, o_idxs, o_wt, o_idxt, o_rowx, o_rows, o_rowe,
-      o_trowx, o_trows, o_trowe, o_tsoft, o_end;
+      o_trowx, o_trows, o_trowe, o_tsoft, o_wzm, o_end;
   __host__ __device__ constexpr UserLayout(int mx, int mu, int nth, int ne, int nps, int npt)
       : mza(mx + nth + mu + nth),
         o_wz(0),                                   // [mza x mza] weights on the (scaled) augmented z = [x, theta | u, u_theta]
@@ -53,7 +53,8 @@ struct UserLayout {
         o_trows(o_trowx + OCP_MAXNC),
         o_trowe(o_trows + OCP_MAXNC),
         o_tsoft(o_trowe + OCP_MAXNC),
-        o_end(o_tsoft + 1) {}
+        o_wzm(o_tsoft + 1),                        // [mza] per row of Wz: bit j set iff Wz[i][j] != 0 (as a double: exact below 2^53)
+        o_end(o_wzm + mza) {}
 };
 
 // the model with the path variable(s) appended as states driven by virtual inputs (mpc.py:1181-1191)
@@ -88,6 +89,7 @@ struct NmpcUser {
   static constexpr int NPAR = M::NP + M::NU;
   static constexpr int NSD = C::TV ? (MX + MU + M::NP) : 0;   // per stage [zref_k (model z, scaled) | p_k]; row N: terminal ref
   static constexpr bool FIX_X0 = true, COOP = false, BIG = C::BIG;
+  static constexpr int VEC_N = C::N;    // the horizon is part of the compiled problem: Ocp::VEC_LDS may keep the vectors in LDS
   static constexpr int D = C::COLL_D;                          // collocation degree, 0 = explicit Runge-Kutta / discrete map
   static constexpr bool CONT = C::CONT;                        // continuous objective
   static constexpr bool FUSED = true;
@@ -115,13 +117,19 @@ struct NmpcUser {
       if constexpr (C::TV) { if (i < MU) r = sd[MX + i]; }
       z[MXA + i] = us[i] - r;
     }
+    // z^T Wz z over the NON-ZERO weights only (row masks prepared by the host; wave-uniform scalar tests): a weight matrix is
+    // mostly zeros - in a Taylor sweep every skipped entry is an LDS read and a three-coefficient multiply-add
     T acc = T(0.0);
 #pragma unroll
     for (int i = 0; i < MZA; ++i) {
-      T s = T(0.0);
+      const unsigned m = (unsigned)uni((int)pc.cost[L.o_wzm + i]);
+      if (m != 0u) {
+        T s = T(0.0);
 #pragma unroll
-      for (int j = 0; j < MZA; ++j) s = s + pc.cost[L.o_wz + i * MZA + j] * z[j];
-      acc = acc + z[i] * s;
+        for (int j = 0; j < MZA; ++j)
+          if ((m >> j) & 1u) s = s + pc.cost[L.o_wz + i * MZA + j] * z[j];
+        acc = acc + z[i] * s;
+      }
     }
     if (k == 0 && pc.cost[L.o_hasdu] != 0.0) {   // mpc.py:1631-1635: the change penalty only sees u_old in interval 0
       T d[MU > 0 ? MU : 1];

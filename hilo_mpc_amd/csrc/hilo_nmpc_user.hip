@@ -267,6 +267,12 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   if (!rc) rc = nmpc_bind_user_gps(h, d);
   if (rc) { hilo_nmpc_destroy(h); return rc; }
   hipError_t e = hipSetDevice(device);
+  for (int i = 0; i < mza; ++i) {   // row masks of the non-zero stage weights (hilo_nmpc_user.h::lagrange)
+    unsigned m = 0u;
+    for (int j = 0; j < mza; ++j)
+      if (c.cost[L.o_wz + i * mza + j] != 0.0) m |= 1u << j;
+    c.cost[L.o_wzm + i] = (double)m;
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&h->dev, sizeof(OcpConst));
   if (e == hipSuccess) e = hipMemcpy(h->dev, &c, sizeof(OcpConst), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&h->v_guess, sizeof(double) * h->n_v);

@@ -180,6 +180,10 @@ template <class PB, class = void> struct pb_sym { static constexpr bool value = 
 template <class PB> struct pb_sym<PB, void_tt<decltype(PB::SYM)>> { static constexpr bool value = PB::SYM; };
 template <class PB, class = void> struct pb_sym_mhe { static constexpr bool value = false; };
 template <class PB> struct pb_sym_mhe<PB, void_tt<decltype(PB::SYM_MHE)>> { static constexpr bool value = PB::SYM_MHE; };
+// VEC_N: the horizon as a compile-time constant (run-time compiled policies) - with it a workspace-mode kernel can decide to keep
+// the horizon-long VECTORS of the iterate in LDS (see Ocp::VEC_LDS); 0 = unknown
+template <class PB, class = void> struct pb_vec_n { static constexpr int value = 0; };
+template <class PB> struct pb_vec_n<PB, void_tt<decltype(PB::VEC_N)>> { static constexpr int value = PB::VEC_N; };
 template <class PB, class = void> struct pb_fused { static constexpr bool value = false; };
 template <class PB> struct pb_fused<PB, void_tt<decltype(PB::FUSED)>> { static constexpr bool value = PB::FUSED; };
 
@@ -248,7 +252,9 @@ struct Ocp {
   static constexpr bool SYM_MHE = pb_sym_mhe<PB>::value;   // the same for the moving-horizon estimator's policy (eval_derivs_sym_mhe)
   // model with a learned term: lanes that evaluate the dynamics at the same point share its kernel sum (GpExt)
   static constexpr bool COOP = PB::COOP;
-  static constexpr int NEXT = COOP ? 12 * OCP_TPB : 0;
+  // cooperative models: exchange scratch of the kernel sum (12 doubles per lane) + the learned term's table (hilo_models.h GpExt)
+  static constexpr int NEXT_SCR = COOP ? 12 * OCP_TPB : 0;
+  static constexpr int NEXT = COOP ? NEXT_SCR + GP2_HDR + 3 * GP2_MAXN : 0;
   // nonlinear inequality rows per stage (compile-time capacity; pc.nc of them are active): IPOPT's slack form
   //   d(x_k,u_k) - s_k = 0,  dlb <= s_k <= dub,  multipliers nu (equality), vL/vU (slack bounds)
   static constexpr int NC = PB::NC;
@@ -265,16 +271,42 @@ struct Ocp {
   // Storage of the iterate: LDS (default) or, for problems that do not fit (long horizons, wide stages), a per-instance
   // workspace in global memory (PB::BIG; L2-resident, same code path, longer latencies).  Problem constants, the pivot
   // block, reduction scratch and the per-instance data always stay in LDS.
+  // (the workspace pointers carry the GLOBAL address space: through generic pointers every access would be a flat instruction,
+  // which counts on both the memory and the LDS counter and so can only be waited for with both at zero - one access in flight)
   static constexpr bool BIG = PB::BIG;
-  using dp = cond_t<BIG, double*, lds_double*>;
-  using cdp = cond_t<BIG, const double*, lds_cdouble*>;
+  using dp = cond_t<BIG, gbl_double*, lds_double*>;
+  using cdp = cond_t<BIG, gbl_cdouble*, lds_cdouble*>;
+  // Mixed layout of the workspace mode: when the horizon is a compile-time constant, the vectors every small phase walks over
+  // stay in LDS as far as FOUR instances per CU still fit (40 KB each, constants included) - in this order: primal point, trial
+  // point, step, bound multipliers and effective box (7 slot vectors); equality multipliers and the two defect vectors; the
+  // gradient.  The matrices of the stages go to the workspace.  (Measured on C5: all eleven vectors in LDS cost a fourth resident
+  // instance per CU and lost more than the shorter phases gained - 59.9 k against 67.5 k steps/s.)
+  static constexpr int VEC_N = pb_vec_n<PB>::value;
+  __host__ __device__ static constexpr size_t vec_doubles_level(int N, int level) {
+    return (level >= 1 ? 7 * (size_t)(N + 1) * NZ : 0) + (level >= 2 ? 3 * (size_t)N * NX : 0) + (level >= 3 ? (size_t)(N + 1) * NZ : 0);
+  }
+  static constexpr size_t VEC_BUDGET = 40 * 1024 - 64;
+  static constexpr bool vec_fits(int level) {
+    return (ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, VEC_N) + vec_doubles_level(VEC_N, level)) * sizeof(double) <= VEC_BUDGET;
+  }
+  static constexpr int VEC_LEVEL = !(BIG && VEC_N > 0) ? 0 : (vec_fits(3) ? 3 : (vec_fits(2) ? 2 : (vec_fits(1) ? 1 : 0)));
+  static constexpr bool VEC_LDS = VEC_LEVEL > 0;
+  __host__ __device__ static constexpr size_t vec_doubles(int N) { return vec_doubles_level(N, VEC_LEVEL); }
+  using vp = cond_t<BIG && VEC_LEVEL < 1, gbl_double*, lds_double*>;      // Z Zt D zL zU lbA ubA
+  using cvp = cond_t<BIG && VEC_LEVEL < 1, gbl_cdouble*, lds_cdouble*>;
+  using ep = cond_t<BIG && VEC_LEVEL < 2, gbl_double*, lds_double*>;      // lam c ct
+  using gp_t = cond_t<BIG && VEC_LEVEL < 3, gbl_double*, lds_double*>;    // grad
   struct Lds {
     const __attribute__((address_space(3))) OcpConst* pc;
     // AB: [N][NX][ABP] = [A B | -c];  W: [N][NZ][WP] = [Hessian block (+ Sigma on the diagonal after kkt_pass) | rhs];
     // P: [N+1][NX][PP] = [P_k | p_k];  Kg: [N][NU][PP] = [K_k | kff_k];  Acl: [N][NX][PP] = [A + B K | B kff - c];  rbN: rhs of x_N
-    dp Z, Zt, D, zL, zU, grad, lam, lamn, c, ct, AB, W, Qd, P, Kg, sig, rbN, Acl;
+    vp Z, Zt, D, zL, zU;
+    vp lbA, ubA;  // effective box of every slot: -inf / +inf where there is no bound or the slot is not a variable
+    ep lam, c, ct;
+    gp_t grad;
+    dp lamn, AB, W, Qd, P, Kg, sig, rbN, Acl;
     dp Xs;   // SYM policies: Runge-Kutta stage points [N][4][NX] of the last values-only evaluation (reused by the derivative phase)
-    dp lbA, ubA;  // effective box of every slot: -inf / +inf where there is no bound or the slot is not a variable
+    lds_double* gpc;   // cooperative models: [N][4][6] value / gradient / Hessian of the learned term at the stage points (GpExt::cache)
     dp cs, cst, cnu, cnun, cvL, cvU, cdvL, cdvU, cds, cd, csig, crb, Jd;  // [N][NC] (Jd: [N][NC][NZ])
     dp c0, cd0, cdt;  // second-order correction: saved defects / row values, row values at the trial point
     lds_double *Mm, *mm, *fk, *filt, *red, *par, *sd, *ext;
@@ -284,7 +316,7 @@ struct Ocp {
   // direction table of the Hessian blocks: policies with symbolic derivatives write the blocks directly and keep only the
   // terminal cost's directions; stage points kept for reuse: SYM policies only
   __host__ __device__ static constexpr size_t qd_doubles(int N) { return (SYM || SYM_MHE) ? (size_t)NXDIR : (size_t)(N + 1) * NDIR; }
-  __host__ __device__ static constexpr size_t xs_doubles(int N) { return SYM ? (size_t)N * 4 * NX : 0; }
+  __host__ __device__ static constexpr size_t xs_doubles(int N) { return SYM ? (size_t)N * 4 * NX : (COOP ? (size_t)N * 24 : 0); }
   __host__ __device__ static constexpr size_t iter_doubles(int N) {  // the iterate (LDS or workspace); <= ocp_iter_doubles + xs
     return ocp_iter_doubles(NX, NU, NC, N) - (size_t)(N + 1) * NDIR - (size_t)N * 4 * NX + qd_doubles(N) + xs_doubles(N);
   }
@@ -292,8 +324,10 @@ struct Ocp {
   __host__ __device__ static constexpr size_t fixed_doubles(int N) {  // always LDS
     return ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, N);
   }
-  __host__ __device__ static constexpr size_t lds_doubles(int N) { return fixed_doubles(N) + (BIG ? 0 : iter_doubles(N)); }
-  __host__ __device__ static constexpr size_t ws_doubles(int N) { return BIG ? iter_doubles(N) : 0; }
+  __host__ __device__ static constexpr size_t lds_doubles(int N) {
+    return fixed_doubles(N) + (BIG ? (VEC_LDS ? vec_doubles(N) : 0) : iter_doubles(N));
+  }
+  __host__ __device__ static constexpr size_t ws_doubles(int N) { return BIG ? iter_doubles(N) - (VEC_LDS ? vec_doubles(N) : 0) : 0; }
   // The non-inlined phases take (LDS base, workspace) and re-derive the pointer table: a struct argument would be
   // passed through scratch memory per lane (measured: 380 MB of scratch writes per 1024-instance launch).
   __device__ static int horizon_of(lds_double* base) {
@@ -312,22 +346,37 @@ struct Ocp {
     l.ext = take(NEXT);
     l.dirs = reinterpret_cast<__attribute__((address_space(3))) int*>(take((NDIR + 2) / 2));
     dp w;
-    if constexpr (BIG) w = ws; else w = q;
+    const size_t V = (size_t)N * NX;
+    if constexpr (VEC_LEVEL >= 1) {   // the vectors first, in LDS; everything else in the workspace
+      l.Z = take(S); l.Zt = take(S); l.D = take(S); l.zL = take(S); l.zU = take(S); l.lbA = take(S); l.ubA = take(S);
+    }
+    if constexpr (VEC_LEVEL >= 2) { l.lam = take(V); l.c = take(V); l.ct = take(V); }
+    if constexpr (VEC_LEVEL >= 3) l.grad = take(S);
+    if constexpr (BIG) w = (gbl_double*)ws; else w = q;
     auto big = [&](size_t n) { dp r = w; w += n; return r; };
-    l.Z = big(S); l.Zt = big(S); l.D = big(S); l.zL = big(S); l.zU = big(S);
-    l.grad = big(S);
-    l.lam = big((size_t)N * NX); l.lamn = big((size_t)N * NX); l.c = big((size_t)N * NX); l.ct = big((size_t)N * NX);
+    if constexpr (VEC_LEVEL < 1) {   // (dp and the vector types coincide where these run)
+      l.Z = big(S); l.Zt = big(S); l.D = big(S); l.zL = big(S); l.zU = big(S); l.lbA = big(S); l.ubA = big(S);
+    }
+    if constexpr (VEC_LEVEL < 2) { l.lam = big(V); l.c = big(V); l.ct = big(V); }
+    if constexpr (VEC_LEVEL < 3) l.grad = big(S);
+    l.lamn = big((size_t)N * NX);
     l.AB = big((size_t)N * NX * ABP); l.W = big((size_t)N * NZ * WP); l.Qd = big(qd_doubles(N));
     l.P = big((size_t)(N + 1) * NX * PP);
     l.Kg = big((size_t)N * NU * PP);
     l.sig = big(S); l.rbN = big(NX); l.Acl = big((size_t)N * NX * PP);
-    l.lbA = big(S); l.ubA = big(S);
     const size_t R = (size_t)N * NC;
     l.cs = big(R); l.cst = big(R); l.cnu = big(R); l.cnun = big(R); l.cvL = big(R); l.cvU = big(R);
     l.cdvL = big(R); l.cdvU = big(R); l.cds = big(R); l.cd = big(R); l.csig = big(R); l.crb = big(R);
     l.Jd = big(R * NZ);
     l.c0 = big((size_t)N * NX); l.cd0 = big(R); l.cdt = big(R);
-    l.Xs = big(xs_doubles(N));
+    if constexpr (COOP) {
+      static_assert(!COOP || !BIG, "cooperative models keep the iterate in LDS");
+      l.Xs = nullptr;
+      l.gpc = (lds_double*)big(xs_doubles(N));
+    } else {
+      l.Xs = big(xs_doubles(N));
+      l.gpc = nullptr;
+    }
     return l;
   }
 
@@ -379,7 +428,7 @@ struct Ocp {
 
   // ---- values only at a point Zp: defects cp_k = x_{k+1} - F_k(x_k,u_k), returns (f, theta = |c|_1) -------------
   // with inequality rows: theta also counts |d_k - sp_k| for the slacks sp; `dstore` (optional) receives d_k
-  __device__ OCP_PHASE static FTheta eval_values_call(lds_double* lbase, double* ws, cdp Zp, dp cp, cdp sp, dp dstore) {
+  __device__ OCP_PHASE static FTheta eval_values_call(lds_double* lbase, double* ws, cvp Zp, ep cp, cdp sp, dp dstore) {
     lbase = uni(lbase); ws = uni(ws); Zp = uni(Zp); cp = uni(cp); sp = uni(sp); dstore = uni(dstore);
     const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
@@ -396,7 +445,9 @@ struct Ocp {
         const int k = r * ng + g;
         const bool active = g < ng && k < N;
         const int kk = active ? k : N - 1;
-        const GpExt ext{gp, l.ext, gs, active ? gl : 0, active ? g * gs : lane, !active};
+        int nev = 0;
+        const GpExt ext{gp, l.ext, gs, active ? gl : 0, active ? g * gs : lane, !active, (lds_cdouble*)(l.ext + NEXT_SCR),
+                        pc.nsub == 1 ? l.gpc + kk * 24 : nullptr, &nev, false};
         double x[NX], u[NU > 0 ? NU : 1], xn[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = Zp[kk * NZ + i];
@@ -488,7 +539,7 @@ struct Ocp {
     return FTheta{fr, block_reduce<OpSum>(tpart, l.red)};
   }
 
-  __device__ __forceinline__ static FTheta eval_values(lds_double* lbase, double* ws, cdp Zp, dp cp, cdp sp = nullptr,
+  __device__ __forceinline__ static FTheta eval_values(lds_double* lbase, double* ws, cvp Zp, ep cp, cdp sp = nullptr,
                                                       dp dstore = nullptr) {
     const FTheta r = eval_values_call(lbase, ws, Zp, cp, sp, dstore);
     return FTheta{uni(r.f), uni(r.theta)};
@@ -505,7 +556,7 @@ struct Ocp {
   }
   // -sum log(slacks) of a point (the barrier function is mu times this; the sum itself does not depend on mu, so the value of
   // an accepted trial point is carried into the next iteration instead of being recomputed)
-  __device__ static double barrier_logs(const Lds l, cdp Zp, cdp sp = nullptr) {
+  __device__ static double barrier_logs(const Lds l, cvp Zp, cdp sp = nullptr) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double part = 0.0;
@@ -548,7 +599,7 @@ struct Ocp {
   // ---- full derivative evaluation at Z: c, AB, grad, per-stage cost values, Lagrangian Hessian blocks --------
   // inlined at its call sites: as a real call its ~170 live registers cost 66 callee-saved VGPR saves per call (17 KB of
   // scratch per wave and call, 120 MB of HBM writes per 1024-instance launch)
-  __device__ __attribute__((always_inline)) static double eval_derivs_body(lds_double* lbase, double* ws) {
+  __device__ __attribute__((always_inline)) static double eval_derivs_body(lds_double* lbase, double* ws, bool reuse = false) {
     const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
@@ -596,7 +647,9 @@ struct Ocp {
         for (int i = 0; i < NU; ++i) u[i] = Jet2(l.Z[k * NZ + NX + i], (NX + i == di || NX + i == dj) ? 1.0 : 0.0, 0.0);
         if constexpr (COOP) {
           const int lane = threadIdx.x, g = lane / NDIR;
-          const GpExt ext{(const double*)pc.ext, l.ext, NDIR, active ? d : 0, active ? g * NDIR : lane, !active};
+          int nev = 0;
+          const GpExt ext{(const double*)pc.ext, l.ext, NDIR, active ? d : 0, active ? g * NDIR : lane, !active,
+                          (lds_cdouble*)(l.ext + NEXT_SCR), l.gpc + k * 24, &nev, reuse && pc.nsub == 1};
           PB::dyn(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, ext);
           if (!active) continue;
         } else {
@@ -1293,11 +1346,13 @@ struct Ocp {
   }
   // Cooperative models exchange partial sums between lanes through LDS with workgroup barriers in between; as a real
   // function (barriers kept as instructions) that is what was validated, so they keep the call.
-  __device__ __forceinline__ static double eval_derivs(lds_double* lbase, double* ws) {
+  __device__ __forceinline__ static double eval_derivs(lds_double* lbase, double* ws, bool reuse = false) {
 #ifdef HILO_COOP_CALL
     if constexpr (COOP) return uni(eval_derivs_call(lbase, ws));
 #else
-    if constexpr (COOP) return uni(eval_derivs_body(uni(lbase), uni(ws)));   // inlined: the kernel's register budget (one wave per SIMD) instead of a callee's
+    // inlined: the kernel's register budget (one wave per SIMD) instead of a callee's; `reuse`: the iterate is the trial point the
+    // line search evaluated last - the learned term's value / gradient / Hessian at its stage points are in l.gpc
+    if constexpr (COOP) return uni(eval_derivs_body(uni(lbase), uni(ws), uni(reuse)));
 #endif
     else if constexpr (SYM) return eval_derivs_sym(lbase, ws);
     else if constexpr (SYM_MHE) return eval_derivs_sym_mhe(lbase, ws);
@@ -2202,6 +2257,11 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
   }
   if constexpr (PB::NSD > 0)
     OCP_FOR(i, (N + 1) * PB::NSD) l.sd[i] = sdata[b * sd_stride + i];
+  if constexpr (S::COOP) {   // the learned term's table into LDS: every kernel-sum term is an LDS read instead of an L2 round trip
+    const double* gsrc = pcg->ext;
+    const int nt = GP2_HDR + 3 * (int)gsrc[0];
+    OCP_FOR(i, nt) l.ext[S::NEXT_SCR + i] = gsrc[i];
+  }
   __syncthreads();
   const OcpConst& pc = *(const OcpConst*)l.pc;
   const int SL = (N + 1) * NZ;
@@ -2316,7 +2376,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
         (void)S::eval_derivs_sym(lds_raw, wsb, true);
         fval = f_trial;
       } else fval = S::eval_derivs(lds_raw, wsb);
-    } else fval = S::eval_derivs(lds_raw, wsb);
+    } else fval = S::eval_derivs(lds_raw, wsb, S::COOP && pts_ok);
     OCP_TICK(PH_DERIV)
     const typename S::KktErr ke = S::kkt_pass(l, nb_const);
     const double dual_s = ke.dual_s, prim = ke.prim, s_c = ke.s_c, th0 = ke.theta;

@@ -91,6 +91,19 @@ def _weight_matrix(arg, n, name):
     return W
 
 
+def _constraint_weight(arg, n, name):
+    """The weight of a soft constraint is used as it is given, `e^T weight e` (modeling.py:870, :878): a matrix.  A scalar weighs
+    every slack alike, a vector is taken as a diagonal."""
+    W = np.asarray(arg, dtype=float)
+    if W.ndim == 0:
+        W = float(W) * np.eye(n)
+    elif W.ndim == 1:
+        W = np.diag(W)
+    if W.ndim != 2 or W.shape != (n, n):
+        raise ValueError(f"The weight of the soft {name} must be a {n} x {n} matrix, it is {W.shape}.")
+    return np.ascontiguousarray(W)
+
+
 def _collocation_basis(degree, points='radau'):
     """`RungeKutta._construct_polynomial_basis` (hilo_mpc/util/modeling.py:1091-1127) for tau = [0] +
     collocation_points(degree, points): D_i = L_i(1), C[i, j] = L_i'(tau_j); plus the Runge-Kutta matrix of the method,
@@ -768,7 +781,7 @@ class NMPC:
             d.tcon_lb, d.tcon_ub = hp(tlb), hp(tub)
             if tc.is_soft:
                 d.tcon_soft = 1
-                d.tcon_weight = hp(_weight_matrix(tc.weight, nt, 'weight')) if tc.weight is not None else None
+                d.tcon_weight = hp(_constraint_weight(tc.weight, nt, 'terminal constraint')) if tc.weight is not None else None
                 d.tcon_max_violation = hp(tc.max_violation) if tc.max_violation is not None else None
         sc = self.stage_constraint
         ne = 0
@@ -787,7 +800,7 @@ class NMPC:
             d.con_lb, d.con_ub = hp(lb), hp(ub)
             if sc.is_soft:
                 ne = nc
-                d.con_weight = hp(_weight_matrix(sc.weight, nc, 'weight')) if sc.weight is not None else None
+                d.con_weight = hp(_constraint_weight(sc.weight, nc, 'stage constraint')) if sc.weight is not None else None
                 d.con_max_violation = hp(sc.max_violation) if sc.max_violation is not None else None
         ne_term = tc.size if tc.is_set and tc.is_soft else 0
         self._nth, self._ne, self._ne_term = nth, ne, ne_term

@@ -224,6 +224,15 @@ def test_soft_terminal_constraint_vs_oracle():
     both = dict(C2S, N=8, terminal_constraint=dict(expr=['S'], lb=[45.], ub=[np.inf], soft=True))
     nmpc, pb, ipm, ref = _compare(both, c2_x0(4), C2['p'])
     assert nmpc._jit and nmpc._e_soft_term_ind == pb.eT_ind and len(pb.e_ind) == 1
+    # slack VECTORS: two soft stage rows and two soft terminal expressions (one of them two-sided), e_soft_stage and e_soft_term
+    # side by side behind the inputs in v (mpc.py:1529-1548), a non-default terminal weight
+    vec = dict(C2, N=8, constraint=dict(expr=['X * S', 'P'], lb=[-np.inf, -np.inf], ub=[60., 1.2], soft=True),
+               terminal_constraint=dict(expr=['S', 'X + P'], lb=[45., 0.5], ub=[np.inf, 1.0], soft=True, weight=[[50., 0.], [0., 80.]]))
+    nmpc, pb, ipm, ref = _compare(vec, c2_x0(4), C2['p'])
+    assert nmpc._e_soft_stage_ind == pb.e_ind == [52, 53] and nmpc._e_soft_term_ind == pb.eT_ind == [54, 55]
+    vr = ipm.to_v(ref)
+    np.testing.assert_allclose(nmpc.terminal_constraint.e_soft_value.cpu().numpy(), vr[:, pb.eT_ind], atol=5e-5)
+    assert np.all(vr[:, pb.eT_ind[1]] > .1)                 # the second terminal slack is active
 
 
 def test_c5_from_a_cold_zero_velocity_guess_solves_everywhere():

@@ -10,3 +10,4 @@ grep -E "passed|failed|FAILED|ERROR|hiprtc seconds|rc=|Error" $OUT/pytest.log | 
 for cfg in "$@"; do
   timeout 600 python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; cut -c1-700 $OUT/bench_$cfg.json; tail -n 3 $OUT/bench_$cfg.err
 done
+timeout 300 python tools/phase_profile_c5.py 1024 > $OUT/phase_c5.txt 2>&1; tail -n 1 $OUT/phase_c5.txt
