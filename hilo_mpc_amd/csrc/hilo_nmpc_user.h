@@ -101,7 +101,11 @@ struct NmpcUser {
   using MA = ThetaAug<M, NTH>;
 
   // ---- Lagrange term at a point of the augmented model, SCALED variables xs [MXA], us [MUA] --------------------------
-  template <class T>
+  // MASKED: the quadratic form runs over the non-zero weights only (row masks prepared by the host).  The output pass of the
+  // collocation transcription asks for the plain loop: there (constant seeds, twelve unrolled copies sharing the masks) the
+  // masked form compiled to a wrong gradient for the weighted states with ROCm 7.2 - multipliers of the collocation rows off
+  // by up to 1 % while the solve kernel's result was bit-identical to the plain loop's (tools/dbg/dae_lam.py) - cause not found.
+  template <class T, bool MASKED = true>
   __device__ __forceinline__ static T lagrange(const OcpConst& pc, const double* par, const double* sd, const double* p, int k,
                                                const T* xs, const T* us) {
     T z[MZA];
@@ -122,12 +126,19 @@ struct NmpcUser {
     T acc = T(0.0);
 #pragma unroll
     for (int i = 0; i < MZA; ++i) {
-      const unsigned m = (unsigned)uni((int)pc.cost[L.o_wzm + i]);
-      if (m != 0u) {
+      if constexpr (MASKED) {
+        const unsigned m = (unsigned)uni((int)pc.cost[L.o_wzm + i]);
+        if (m != 0u) {
+          T s = T(0.0);
+#pragma unroll
+          for (int j = 0; j < MZA; ++j)
+            if ((m >> j) & 1u) s = s + pc.cost[L.o_wz + i * MZA + j] * z[j];
+          acc = acc + z[i] * s;
+        }
+      } else {
         T s = T(0.0);
 #pragma unroll
-        for (int j = 0; j < MZA; ++j)
-          if ((m >> j) & 1u) s = s + pc.cost[L.o_wz + i * MZA + j] * z[j];
+        for (int j = 0; j < MZA; ++j) s = s + pc.cost[L.o_wz + i * MZA + j] * z[j];
         acc = acc + z[i] * s;
       }
     }
@@ -446,7 +457,7 @@ struct NmpcUser {
           for (int q = 0; q < MXA; ++q) xj[q] = Jet2(X[i * MXA + q] / pc.sz[q], q == m ? 1.0 : 0.0, 0.0);
 #pragma unroll
           for (int q = 0; q < MUA; ++q) uj[q] = Jet2(us[q]);
-          gl[m] = pc.dt * pc.coll.Bq[i + 1] * lagrange(pc, pr, sd, p, k, xj, uj).a;
+          gl[m] = pc.dt * pc.coll.Bq[i + 1] * lagrange<Jet2, false>(pc, pr, sd, p, k, xj, uj).a;
         }
       }
       // rows of the scaled model: G_s = G / s (base.py:1562-1591)  =>  everything in un-scaled units, mu_s = mu * s
