@@ -61,6 +61,31 @@ def test_round_2_profiles_are_consistent_with_their_bench_lines():
         assert line['config']['name'] == cfg and line['n_gpus'] == 1 and line['vs_baseline'] is None
 
 
+def test_round_3_profiles_are_consistent_with_their_bench_lines():
+    """profiles/r03_<config>_summary.json, same checks as for round 2.  C1 and the filter lines bracket a whole Python step with
+    their HIP events (the solve plus the small kernels around it): the event duration is an upper bound of the trace's."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03_*_summary.json')))
+    assert {os.path.basename(f)[4:-13] for f in files} >= {'C1', 'C2', 'C3-mhe', 'C3-ekf', 'C3-ukf', 'C4', 'C5', 'gp-predict'}
+    for f in files:
+        s = json.load(open(f))
+        line, cfg = s['bench_line'], s['config']
+        r = line['roofline']
+        trace_ms = s['timed_region']['avg_ns'] * 1e-6
+        if cfg in ('C1', 'C3-ekf', 'C3-ukf'):
+            assert trace_ms <= r['kernel_ms'] < trace_ms + 0.1, cfg
+        else:
+            assert abs(trace_ms - r['kernel_ms']) / trace_ms < 0.08, (cfg, trace_ms, r['kernel_ms'])
+        traffic = (s['FETCH_SIZE_KB_per_launch']['warm_launches_mean'] + s['WRITE_SIZE_KB_per_launch']['warm_launches_mean']) * 1024
+        assert abs(r['traffic'] - traffic) <= 1e-9 * traffic, cfg
+        assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['bound'] in ('hbm', 'mfma'), cfg
+        cb = line['cpu_baseline']
+        assert set(cb) >= {'value', 'unit', 'cores', 'kind', 'sample'}, cfg
+        if cfg in ('C1', 'C2', 'C3-ekf', 'C3-ukf', 'C4'):          # the C++ / OpenMP legs: true core count, one-core figure next to it
+            assert cb['cores'] >= 1 and cb['one_core_value'] > 0 and 'C++17' in cb['sample'], cfg
+        assert line['config']['name'] == cfg and line['n_gpus'] == 1 and line['vs_baseline'] is None
+
+
 def test_cpu_baseline_leg_of_c2_runs_here():
     """The C++/OpenMP leg of the C2 line on a reduced sample (no GPU needed): fields, and all-core >= one-core."""
     from tests.problems import C2
