@@ -43,13 +43,26 @@ struct NmpcTrack {
     for (int i = 0; i < NX; ++i) z[i] = x[i] - pc.cost[O_ZREF + i];
 #pragma unroll
     for (int i = 0; i < NU; ++i) z[NX + i] = u[i] - pc.cost[O_ZREF + NX + i];
+    // the weights of two rows are requested from LDS before the first multiply-add (the empty statement with side effects ends
+    // the scheduling region; left alone the compiler reads - waits - uses entry by entry, 70 cycles each at one wave per SIMD)
     T acc = T(0.0);
 #pragma unroll
-    for (int i = 0; i < NZ; ++i) {
-      T s = T(0.0);
+    for (int i0 = 0; i0 < NZ; i0 += 2) {
+      double w[2][NZ];
 #pragma unroll
-      for (int j = 0; j < NZ; ++j) s = s + pc.cost[O_WZ + i * NZ + j] * z[j];
-      acc = acc + z[i] * s;
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) w[a][j] = pc.cost[O_WZ + (i0 + a < NZ ? i0 + a : i0) * NZ + j];
+      asm volatile("");
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        if (i0 + a < NZ) {
+          T s = T(0.0);
+#pragma unroll
+          for (int j = 0; j < NZ; ++j) s = s + w[a][j] * z[j];
+          acc = acc + z[i0 + a] * s;
+        }
+      }
     }
     if (k == 0 && pc.cost[O_HASDU] != 0.0) {  // mpc.py:1631-1635: the change penalty only sees u_old in interval 0
       T d[NU > 0 ? NU : 1];
@@ -69,8 +82,14 @@ struct NmpcTrack {
   // d/dz_i and d2/dz_i dz_j of (z - zref)^T Wz (z - zref) [+ (u - u_old)^T Wdu (u - u_old) in interval 0]
   __device__ __forceinline__ static double cost_grad(const OcpConst& pc, const double* par, const double*, int k, int i, const double* z) {
     double g = 0.0;
+    {
+      double wr[NZ], wc[NZ], zr[NZ];
 #pragma unroll
-    for (int j = 0; j < NZ; ++j) g += (pc.cost[O_WZ + i * NZ + j] + pc.cost[O_WZ + j * NZ + i]) * (z[j] - pc.cost[O_ZREF + j]);
+      for (int j = 0; j < NZ; ++j) { wr[j] = pc.cost[O_WZ + i * NZ + j]; wc[j] = pc.cost[O_WZ + j * NZ + i]; zr[j] = pc.cost[O_ZREF + j]; }
+      asm volatile("");   // (every operand requested before the first use, see stage_cost)
+#pragma unroll
+      for (int j = 0; j < NZ; ++j) g += (wr[j] + wc[j]) * (z[j] - zr[j]);
+    }
     if (k == 0 && i >= NX && pc.cost[O_HASDU] != 0.0) {
 #pragma unroll
       for (int j = 0; j < NU; ++j)
@@ -103,11 +122,22 @@ struct NmpcTrack {
     for (int i = 0; i < NX; ++i) z[i] = x[i] - pc.cost[O_XREFN + i];
     T acc = T(0.0);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      T s = T(0.0);
+    for (int i0 = 0; i0 < NX; i0 += 2) {   // two rows of weights in flight, see stage_cost
+      double w[2][NX];
 #pragma unroll
-      for (int j = 0; j < NX; ++j) s = s + pc.cost[O_WN + i * NX + j] * z[j];
-      acc = acc + z[i] * s;
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) w[a][j] = pc.cost[O_WN + (i0 + a < NX ? i0 + a : i0) * NX + j];
+      asm volatile("");
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        if (i0 + a < NX) {
+          T s = T(0.0);
+#pragma unroll
+          for (int j = 0; j < NX; ++j) s = s + w[a][j] * z[j];
+          acc = acc + z[i0 + a] * s;
+        }
+      }
     }
     return acc;
   }
