@@ -645,6 +645,18 @@ struct Ocp {
         for (int i = 0; i < NX; ++i) x[i] = Jet2(l.Z[k * NZ + i], (!dead && (i == di || i == dj)) ? 1.0 : 0.0, 0.0);
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = Jet2(l.Z[k * NZ + NX + i], (NX + i == di || NX + i == dj) ? 1.0 : 0.0, 0.0);
+        // what the task needs from the rest of the iterate is requested here, in front of the sweep through the shooting map
+        // (in workspace mode the multipliers come from global memory: the round trip hides behind the sweep)
+        double zn[NX], lamv[NX], cnuv[NC > 0 ? NC : 1];
+#pragma unroll
+        for (int m = 0; m < NX; ++m) {
+          zn[m] = l.Z[(k + 1) * NZ + m];
+          lamv[m] = l.lam[k * NX + m];
+        }
+        if constexpr (NC > 0) {
+#pragma unroll
+          for (int m = 0; m < NC; ++m) cnuv[m] = l.cnu[k * NC + m];
+        }
         if constexpr (COOP) {
           const int lane = threadIdx.x, g = lane / NDIR;
           int nev = 0;
@@ -662,13 +674,7 @@ struct Ocp {
           lc = PB::dyn_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
         } else if constexpr (!PB::QUAD_COST) lc = PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
         double q = lc.b;
-        {  // operands first (one LDS wait), then the two store groups each under ONE condition
-          double zn[NX], lamv[NX];
-#pragma unroll
-          for (int m = 0; m < NX; ++m) {
-            zn[m] = l.Z[(k + 1) * NZ + m];
-            lamv[m] = l.lam[k * NX + m];
-          }
+        {  // the two store groups each under ONE condition
 #pragma unroll
           for (int m = 0; m < NX; ++m) q -= lamv[m] * xn[m].b;
           if (d == 0) {
@@ -691,7 +697,7 @@ struct Ocp {
             if (row_on(pc, k, m)) {
               if (d == 0) l.cd[k * NC + m] = dv[m].v;
               if (d < NZ && !dead) l.Jd[(k * NC + m) * NZ + d] = dv[m].a;
-              q += l.cnu[k * NC + m] * dv[m].b;
+              q += cnuv[m] * dv[m].b;
             }
           }
         }
@@ -716,18 +722,52 @@ struct Ocp {
     }
     __syncthreads();
     // Hessian blocks by polarisation: H_ii = q(e_i), H_ij = (q(e_i+e_j) - q(e_i) - q(e_j)) / 2
-    OCP_FOR(e, N * NZ * NZ) {
-      const int k = e / (NZ * NZ), r = e - k * NZ * NZ, i = r / NZ, j = r - i * NZ;
-      cdp Q = l.Qd + k * NDIR;
-      double h;
-      if (i == j) h = Q[i];
-      else {
-        const int a = i < j ? i : j, b = i < j ? j : i, dd = dir_of(a, b, NZ);
-        h = (COOP || pair_on(pc, dd)) ? 0.5 * (Q[dd] - Q[a] - Q[b]) : 0.0;
+    if constexpr (BIG) {
+      // workspace mode: four entries per lane and trip with their twelve table reads requested together (a trip of the plain
+      // loop is one global-memory round trip: 95 of them for N = 50, n_z = 11); a direction that was not swept is read
+      // (whatever the table holds there) and dropped by the select
+      constexpr int U = 4;
+      const int total = N * NZ * NZ;
+      for (int base = 0; base < total; base += OCP_TPB * U) {
+        double qd[U], qa[U], qb[U];
+        int kk[U], ii[U], jj[U];
+        bool on[U], ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e0 = base + u * OCP_TPB + (int)threadIdx.x;
+          ok[u] = e0 < total;
+          const int e = ok[u] ? e0 : 0;
+          const int k = e / (NZ * NZ), r = e - k * NZ * NZ, i = r / NZ, j = r - i * NZ;
+          const int a = i < j ? i : j, b = i < j ? j : i;
+          const int dd = i == j ? i : dir_of(a, b, NZ);
+          cdp Q = l.Qd + k * NDIR;
+          qd[u] = Q[dd]; qa[u] = Q[a]; qb[u] = Q[b];
+          kk[u] = k; ii[u] = i; jj[u] = j;
+          on[u] = i == j || COOP || pair_on(pc, dd);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = kk[u], i = ii[u], j = jj[u];
+          double h = i == j ? qd[u] : (on[u] ? 0.5 * (qd[u] - qa[u] - qb[u]) : 0.0);
+          if constexpr (PB::QUAD_COST) h += PB::cost_hess(pc, k, i, j);
+          if (k == 0 && (((pinm >> i) | (pinm >> j)) & 1u)) h = 0.0;
+          if (ok[u]) l.W[(k * NZ + i) * WP + j] = h;
+        }
       }
-      if constexpr (PB::QUAD_COST) h += PB::cost_hess(pc, k, i, j);
-      if (k == 0 && (((pinm >> i) | (pinm >> j)) & 1u)) h = 0.0;
-      l.W[(k * NZ + i) * WP + j] = h;
+    } else {
+      OCP_FOR(e, N * NZ * NZ) {
+        const int k = e / (NZ * NZ), r = e - k * NZ * NZ, i = r / NZ, j = r - i * NZ;
+        cdp Q = l.Qd + k * NDIR;
+        double h;
+        if (i == j) h = Q[i];
+        else {
+          const int a = i < j ? i : j, b = i < j ? j : i, dd = dir_of(a, b, NZ);
+          h = (COOP || pair_on(pc, dd)) ? 0.5 * (Q[dd] - Q[a] - Q[b]) : 0.0;
+        }
+        if constexpr (PB::QUAD_COST) h += PB::cost_hess(pc, k, i, j);
+        if (k == 0 && (((pinm >> i) | (pinm >> j)) & 1u)) h = 0.0;
+        l.W[(k * NZ + i) * WP + j] = h;
+      }
     }
     if constexpr (PB::QUAD_COST) {
       OCP_FOR(e, N * NZ) {
@@ -1610,7 +1650,14 @@ struct Ocp {
     double b1[KB_], bi[KB_][NU > 0 ? NU : 1];
     v4d M0;
   };
-  __device__ __forceinline__ static void stage_ops(const Lds l, int k, double delta, int q, int g, StageOps& o) {
+  // what a stage reads from the iterate, before any arithmetic: in workspace mode these loads are issued TWO stages ahead
+  // (a global-memory round trip is about two stage times at one wave per SIMD) and turned into operands one stage ahead
+  struct StageRaw {
+    double b1[KB_], bi[KB_][NU > 0 ? NU : 1], w[RB_];
+    double csig[NC > 0 ? NC : 1], cdv[NC > 0 ? NC : 1], csv[NC > 0 ? NC : 1], crb[NC > 0 ? NC : 1], jq[NC > 0 ? NC : 1];
+    double ji[RB_][NC > 0 ? NC : 1];
+  };
+  __device__ __forceinline__ static void stage_load(const Lds l, int k, int q, int g, StageRaw& w) {
     const int qc = q < NZ ? q : NZ;
     cdp AB = l.AB + (size_t)k * NX * ABP;
     cdp Wk = l.W + (size_t)k * NZ * WP;
@@ -1618,32 +1665,61 @@ struct Ocp {
     for (int kb = 0; kb < KB_; ++kb) {
       const int kk = 4 * kb + g;
       const int kc = (NX % 4 == 0 || kk < NX) ? kk : NX - 1;
-      const double ab = AB[kc * ABP + qc];
-      o.b1[kb] = (NX % 4 == 0 || kk < NX) ? ab : 0.0;
+      w.b1[kb] = AB[kc * ABP + qc];
 #pragma unroll
-      for (int a = 0; a < NU; ++a) o.bi[kb][a] = AB[kc * ABP + NX + a];
+      for (int a = 0; a < NU; ++a) w.bi[kb][a] = AB[kc * ABP + NX + a];
+    }
+#pragma unroll
+    for (int r = 0; r < RB_; ++r) {
+      const int i = g + 4 * r;
+      const int ic = (NZ % 4 == 0 || i < NZ) ? i : NZ - 1;
+      w.w[r] = Wk[ic * WP + qc];
+      if constexpr (NC > 0) {
+#pragma unroll
+        for (int m = 0; m < NC; ++m) w.ji[r][m] = l.Jd[(k * NC + m) * NZ + ic];
+      }
+    }
+    if constexpr (NC > 0) {
+      const int jj = q < NZ ? q : 0;
+#pragma unroll
+      for (int m = 0; m < NC; ++m) {
+        const int rr = k * NC + m;
+        w.csig[m] = l.csig[rr]; w.cdv[m] = l.cd[rr]; w.csv[m] = l.cs[rr]; w.crb[m] = l.crb[rr]; w.jq[m] = l.Jd[rr * NZ + jj];
+      }
+    }
+  }
+  __device__ __forceinline__ static void stage_finish(const StageRaw& w, double delta, int q, int g, StageOps& o) {
+#pragma unroll
+    for (int kb = 0; kb < KB_; ++kb) {
+      const int kk = 4 * kb + g;
+      o.b1[kb] = (NX % 4 == 0 || kk < NX) ? w.b1[kb] : 0.0;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) o.bi[kb][a] = w.bi[kb][a];
     }
     o.M0 = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < RB_; ++r) {
       const int i = g + 4 * r;
       const int ic = (NZ % 4 == 0 || i < NZ) ? i : NZ - 1;
-      double h = Wk[ic * WP + qc];
+      double h = w.w[r];
       if (ic == q) h += delta;
       if constexpr (NC > 0) {  // eliminated slack rows: + Jd^T (Sigma_s + delta) Jd, rhs + Jd^T ((Sigma_s + delta)(d - s) + crb)
         const bool rhs = q >= NZ;
-        const int jj = q < NZ ? q : 0;
 #pragma unroll
         for (int m = 0; m < NC; ++m) {
-          const int rr = k * NC + m;
-          const double wgt = delta + l.csig[rr];
-          const double ds = l.cd[rr] - l.cs[rr], cr = l.crb[rr], jr = l.Jd[rr * NZ + jj];
-          const double right = rhs ? wgt * ds + cr : wgt * jr;
-          h += l.Jd[rr * NZ + ic] * right;
+          const double wgt = delta + w.csig[m];
+          const double ds = w.cdv[m] - w.csv[m];
+          const double right = rhs ? wgt * ds + w.crb[m] : wgt * w.jq[m];
+          h += w.ji[r][m] * right;
         }
       }
       o.M0[r] = h;
     }
+  }
+  __device__ __forceinline__ static void stage_ops(const Lds l, int k, double delta, int q, int g, StageOps& o) {
+    StageRaw w;
+    stage_load(l, k, q, g, w);
+    stage_finish(w, delta, q, g, o);
   }
 
   __device__ __forceinline__ static bool backward_reg(const Lds l, int N, double delta) {
@@ -1663,7 +1739,9 @@ struct Ocp {
     StageOps o;
     stage_ops(l, N - 1, delta, q, g, o);
     bool pd = true;
-    for (int k = N - 1; k >= 0; --k) {
+    // one stage: the two chained products (operands `o`), then - with the operands of the coming stages being fetched in the
+    // meantime by `fetch` - the pivot block, feedback, cost-to-go and closed-loop coefficients
+    auto stage = [&](int k, auto&& fetch) __attribute__((always_inline)) {
       // T = P_{k+1} [A B | -c] + [0 | p_{k+1}];  M = [A B | -c]^T T + [H_k | r_k]
       v4d Tacc = {0.0, 0.0, 0.0, 0.0}, Macc = o.M0;
 #pragma unroll
@@ -1673,7 +1751,7 @@ struct Ocp {
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) Macc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.b1[kb], Tacc[kb], Macc, 0, 0, 0);
       const StageOps c = o;                           // this stage's closed-loop operands
-      stage_ops(l, k > 0 ? k - 1 : 0, delta, q, g, o);   // next stage's operands: in flight during the factorisation
+      fetch();
       // cross-lane fetches of the M_ux columns and the mirrored M_xx entries, all issued before they are needed
       double wq[NU], yq[NU], wi[KB][NU], mji[KB];
 #pragma unroll
@@ -1743,6 +1821,20 @@ struct Ocp {
           l.Acl[((size_t)k * NX + ic) * PP + qk] = cl;
         }
       }
+    };
+    if constexpr (BIG) {
+      // workspace mode: raw operands two stages ahead (ping-pong buffers, no register moves), finished one stage ahead
+      StageRaw ra, rb;
+      stage_load(l, N >= 2 ? N - 2 : 0, q, g, ra);
+      int k = N - 1;
+      for (; k >= 1; k -= 2) {
+        stage(k, [&]() __attribute__((always_inline)) { stage_load(l, k >= 2 ? k - 2 : 0, q, g, rb); stage_finish(ra, delta, q, g, o); });
+        stage(k - 1, [&]() __attribute__((always_inline)) { stage_load(l, k >= 3 ? k - 3 : 0, q, g, ra); stage_finish(rb, delta, q, g, o); });
+      }
+      if (k == 0) stage(0, [&]() __attribute__((always_inline)) {});
+    } else {
+      for (int k = N - 1; k >= 0; --k)
+        stage(k, [&]() __attribute__((always_inline)) { stage_ops(l, k > 0 ? k - 1 : 0, delta, q, g, o); });   // next stage's operands: in flight during the factorisation
     }
     return uni(pd);
   }
