@@ -138,8 +138,11 @@ struct Colloc {
         dmax = fmax(dmax, fabs(R[q]));
       }
       // iterate to round-off: the factors kept in `mat` then belong to a point within 1e-13 of the solution, which is what
-      // makes the Taylor sweeps below exact.  A NaN (singular pivot) also leaves the loop.
-      if (!(dmax > 1e-13 * scale)) break;
+      // makes the Taylor sweeps below exact.  A NaN (singular pivot) also leaves the loop.  The exit is WAVE-UNIFORM (every
+      // lane iterates until the last one has converged; a converged lane's further steps are round-off): the exit of a
+      // lane-dependent loop is a join block, and under this function's register pressure the register allocator of ROCm 7.2
+      // put live-range copies in front of that block's EXEC restore (tools/check_exec_prologue.py)
+      if (!__any((int)(dmax > 1e-13 * scale))) break;
     }
   }
 

@@ -204,8 +204,19 @@ static int compile(const std::string& tu, const std::vector<std::string>& opts, 
   hiprtcProgram prog;
   if (hiprtcCreateProgram(&prog, tu.c_str(), "hilo_user.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
     return fail(HILO_EHIP, "hiprtcCreateProgram failed");
+  std::vector<std::string> all(opts);
+  if (const char* e = getenv("HILO_JIT_EXTRA_OPTS")) {   // developer knob: further compiler options, space separated (not part of the cache key)
+    std::string w;
+    for (const char* c = e;; ++c) {
+      if (*c == ' ' || *c == '\0') {
+        if (!w.empty()) all.push_back(w);
+        w.clear();
+        if (*c == '\0') break;
+      } else w += *c;
+    }
+  }
   std::vector<const char*> o;
-  for (const auto& s : opts) o.push_back(s.c_str());
+  for (const auto& s : all) o.push_back(s.c_str());
   const hiprtcResult r = hiprtcCompileProgram(prog, (int)o.size(), o.data());
   if (r != HIPRTC_SUCCESS) {
     size_t n = 0;

@@ -277,7 +277,8 @@ __device__ __forceinline__ void dae_solve(const Z* x, const Z* u, const P* p, Z*
 #pragma unroll
   for (int i = 0; i < NZ; ++i) z[i] = Z(M::z_guess(i));
   int done = 0;
-  for (int it = 0; it < 40 && done < 2; ++it) {
+  for (int it = 0; it < 40; ++it) {
+    if (!__any((int)(done < 2))) break;   // wave-uniform exit (see hilo_colloc.h::solve): further sweeps of a finished lane are harmless
     Z r[NZ], J[NZ * NZ];
     M::alg(x, z, u, p, r);
     M::alg_jz(x, z, u, p, J);

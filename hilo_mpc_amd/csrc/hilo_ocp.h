@@ -401,11 +401,20 @@ struct Ocp {
     return (k > 0 && ((pc.k0_only_mask >> i) & 1u)) ? INFINITY : pc.ubz[i];
   }
 
-  __device__ static void pair_of(int d, int n, int& i, int& j) {  // d >= n -> (i < j) among n slots
-    int r = d - n;
-    i = 0;
-    while (r >= n - 1 - i) { r -= n - 1 - i; ++i; }
-    j = i + 1 + r;
+  // d >= n -> (i < j) among n slots.  A fixed trip count with a predicated body instead of `while (r >= n - 1 - i)`: the exit of
+  // a lane-dependent loop is a join block, and the register allocator of ROCm 7.2 put live-range copies of i in front of that
+  // block's EXEC restore (tools/check_exec_prologue.py found it in a run-time compiled estimator: lanes that skip the loop kept
+  // a stale index)
+  __device__ __forceinline__ static void pair_of(int d, int n, int& i, int& j) {
+    int r = d - n, ii = 0;
+    for (int t = 0; t + 1 < n; ++t) {
+      const int w = n - 1 - ii;
+      const bool go = r >= w;
+      r -= go ? w : 0;
+      ii += go ? 1 : 0;
+    }
+    i = ii;
+    j = ii + 1 + r;
   }
   __device__ static int dir_of(int i, int j, int n) { return n + i * (n - 1) - i * (i - 1) / 2 + (j - i - 1); }
   __device__ static bool pair_on(const OcpConst& pc, int d) {   // d >= NZ: pair direction

@@ -18,6 +18,17 @@ def test_no_vector_copy_before_exec_restore(capsys):
     assert guard.main(LIB) == 0, capsys.readouterr().out
 
 
+@pytest.mark.skipif(not os.path.exists(guard.OBJDUMP), reason='llvm-objdump missing')
+def test_run_time_compiled_problems_in_the_cache_are_clean(capsys):
+    """The defect shows up in run-time compiled problems too (round 3: behind the exits of lane-dependent loops in the collocation
+    Newton iteration and in the index decomposition of the Taylor directions): every code object that travels with the tree is
+    checked.  (An empty cache - a fresh clone - has nothing to check.)"""
+    cache = os.path.join(ROOT, 'hilo_mpc_amd', 'jit_cache')
+    objs = sorted(f for f in os.listdir(cache) if f.endswith('.hsaco')) if os.path.isdir(cache) else []
+    bad = [f for f in objs if guard.main(os.path.join(cache, f)) != 0]
+    assert not bad, (bad, capsys.readouterr().out[-2000:])
+
+
 def test_guard_recognises_the_pattern(tmp_path):
     """The checker on a synthetic listing: a copy before `s_or_b64 exec` at the target of an `s_cbranch_execz` is reported,
     the same copy after it is not."""

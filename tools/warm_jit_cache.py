@@ -24,7 +24,13 @@ def main(argv):
                      '-W', 'ignore'] + sel, cwd=ROOT, env=env, stdout=subprocess.DEVNULL)
     after = set(os.listdir(cache)) if os.path.isdir(cache) else set()
     print(f"{len(after - before)} new code object(s), {len(after)} in {cache}")
+    # the backend's EXEC-prologue defect shows up in run-time compiled problems as well: check what was compiled
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import check_exec_prologue as guard
+    bad = [f for f in sorted(after) if f.endswith('.hsaco') and os.path.exists(guard.OBJDUMP) and guard.main(os.path.join(cache, f)) != 0]
+    print("EXEC-prologue guard:", "clean" if not bad else f"{len(bad)} object(s) flagged: {bad}")
+    return 1 if bad else 0
 
 
 if __name__ == '__main__':
-    main(sys.argv[1:])
+    sys.exit(main(sys.argv[1:]))
