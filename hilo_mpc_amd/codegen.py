@@ -217,7 +217,7 @@ def fun_source(n_x, stage=None, term=None, con=(), tcon=(), path_stage=(), path_
     for name, exprs, args in (('con', con, 'const T* x, const T* u, const double* p, T* c'),
                               ('tcon', tcon, 'const T* x, const T* u, const double* p, T* c')):
         if exprs:
-            em = Emitter()
+            em = Emitter(theta_index=n_x)      # (x is the augmented state: a constraint may involve the path variable)
             rr = [em.ref(e) for e in exprs]
             s += _fn('void', name, args, ["    (void)x; (void)u; (void)p;"] + em.lines,
                      [f"    c[{i}] = T({r});" for i, r in enumerate(rr)])

@@ -791,10 +791,13 @@ class NMPC:
             ub = [np.inf] * nc if sc.ub is None else sc.ub
             if len(lb) != nc or len(ub) != nc:
                 raise ValueError("The dimensions of the stage constraint function and its bounds are not compatible.")
-            for e in sc.constraint:
-                if e.depends_on('theta'):
-                    raise NotImplementedError("constraints on the path variable are not offloaded")
-            prog = compile_block(sc.constraint)
+            if any(e.depends_on('theta') for e in sc.constraint):
+                # a constraint on the path variable (a state of the augmented model, mpc.py:1181-1191): the expression interpreter of
+                # the precompiled variants has no slot for it - the run-time compiled policy compiles the expression in
+                prog_fail.append("constraint on the path variable")
+                prog = [0.]
+            else:
+                prog = compile_block(sc.constraint)
             d.n_con, d.con_soft = nc, int(sc.is_soft)
             d.con_prog, d.con_prog_len = hp(prog), len(prog)
             d.con_lb, d.con_ub = hp(lb), hp(ub)

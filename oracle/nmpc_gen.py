@@ -67,6 +67,7 @@ class GenNmpcProblem(NmpcProblem):
         self.xrefNa[:nx] = self.xrefN
         # ---- path terms (symbolic in the scaled stage variables) ----
         lp, Vp = sp.Integer(0), sp.Integer(0)
+        th = None
         if path:
             th = sp.Symbol(path.get('name', 'theta'))
             th_s, uth_s = xs_sym[nx], us_sym[nu]
@@ -101,7 +102,11 @@ class GenNmpcProblem(NmpcProblem):
         if constraint:
             sub = {s: zs[i] * self.sza[i] for i, s in enumerate(model.x)}
             sub.update({s: zs[self.nxa + i] * self.su[i] for i, s in enumerate(model.u)})
-            cs = [_parse(e, names).subs(sub, simultaneous=True) for e in constraint['expr']]
+            cnames = names
+            if th is not None:                    # a constraint may involve the path variable: it is a state of the augmented model
+                cnames = dict(names, **{str(th): th})
+                sub[th] = zs[nx] * self.sza[nx]
+            cs = [_parse(e, cnames).subs(sub, simultaneous=True) for e in constraint['expr']]
             nc = len(cs)
             lb = np.broadcast_to(np.asarray(constraint.get('lb', -INF), dtype=float), (nc,))
             ub = np.broadcast_to(np.asarray(constraint.get('ub', INF), dtype=float), (nc,))

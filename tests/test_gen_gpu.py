@@ -84,6 +84,20 @@ def test_path_following_soft_speed_limit_vs_oracle():
     np.testing.assert_allclose(u2, ref2['u0'], rtol=5e-5, atol=5e-5)
 
 
+def test_constraint_on_the_path_variable_vs_oracle():
+    """A stage constraint that involves the path variable - a soft tube |px - sin(theta)| <= 0.15 around the first path coordinate
+    next to the soft speed limit (two slacks): theta is a state of the augmented model (mpc.py:1181-1191), the expression is
+    compiled into the run-time compiled policy (the precompiled variants' interpreter has no slot for it)."""
+    spec = dict(C5S, constraint=dict(expr=['vx**2 + vy**2', 'px - sin(theta)'], lb=[-np.inf, -0.15], ub=[4., 0.15], soft=True))
+    x0 = c5_x0(4)
+    nmpc, pb, ipm, ref = _compare(spec, x0, [], itol=10)
+    assert nmpc._jit and (nmpc._n_v, nmpc._n_g) == (109, 110)
+    xp, _, _ = nmpc.return_prediction()
+    e = nmpc.stage_constraint.e_soft_value.cpu().numpy()
+    assert np.abs(xp[:, 0] - np.sin(xp[:, 6])).max() > 0.149 and e[:, 1].max() > 1e-5      # the tube is active, its slack used
+    assert np.all(np.abs(xp[:, 0, :-1] - np.sin(xp[:, 6, :-1])) <= 0.15 + e[:, 1:2] + 1e-6)
+
+
 def test_c5_full_horizon_global_workspace():
     """C5 as configured (N = 50: 8 engine states, 3 inputs): the iterate does not fit the 160 KB of LDS and lives in the
     per-instance global workspace; same algorithm, same parity bar.  Then the BASELINE batch per GPU (1024) in closed loop."""
