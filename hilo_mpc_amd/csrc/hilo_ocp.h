@@ -1444,6 +1444,95 @@ struct Ocp {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double dmax = 0.0, lsum = 0.0, zsum = 0.0, pmax = 0.0, cmax = 0.0, cmin = INFINITY, th = 0.0;
+    if constexpr (BIG) {
+      // workspace mode: three slots per lane and trip, everything a slot reads from global memory (gradient, multipliers, its
+      // column of [A B], inequality rows, the diagonal entry of W it updates) requested before the first use - a trip of the
+      // plain loop is two dependent global round trips (residual, then the read-modify-write of the diagonal)
+      constexpr int U = 3;
+      const int SLT = (N + 1) * NZ;
+      for (int base = 0; base < SLT; base += OCP_TPB * U) {
+        double gr[U], lp[U], ab[U][NX], lm[U][NX], wd[U], jd[U][NC > 0 ? NC : 1], cn[U][NC > 0 ? NC : 1];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e0 = base + u * OCP_TPB + (int)threadIdx.x;
+          ok[u] = e0 < SLT;
+          const int e = ok[u] ? e0 : 0, k = e / NZ, i = e - k * NZ, kc = k < N ? k : N - 1, kp = k >= 1 ? k - 1 : 0;
+          const int ix = i < NX ? i : 0;
+          gr[u] = l.grad[e];
+          lp[u] = l.lam[kp * NX + ix];
+#pragma unroll
+          for (int m = 0; m < NX; ++m) { ab[u][m] = l.AB[(kc * NX + m) * ABP + i]; lm[u][m] = l.lam[kc * NX + m]; }
+          wd[u] = l.W[(size_t)(kc * NZ + i) * WP + i];
+          if constexpr (NC > 0) {
+#pragma unroll
+            for (int m = 0; m < NC; ++m) { jd[u][m] = l.Jd[(kc * NC + m) * NZ + i]; cn[u][m] = l.cnu[kc * NC + m]; }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = base + u * OCP_TPB + (int)threadIdx.x;
+          if (!ok[u]) continue;
+          const int k = e / NZ, i = e - k * NZ;
+          double sg = 0.0, q = 0.0;
+          if (is_free(pc, k, i)) {
+            double r = gr[u] - l.zL[e] + l.zU[e];                 // dual_res, same order of the sum
+            if (i < NX && k >= 1) r += lp[u];
+            if (k < N) {
+#pragma unroll
+              for (int m = 0; m < NX; ++m) r -= ab[u][m] * lm[u][m];
+              if constexpr (NC > 0) {
+#pragma unroll
+                for (int m = 0; m < NC; ++m) r += jd[u][m] * cn[u][m];
+              }
+            }
+            dmax = nmax(dmax, fabs(r));
+            const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
+            zsum += fabs(zl) + fabs(zu);
+            if (lb > -INFINITY) {
+              const double sl = z - lb, is = rcp_fast(sl), p = sl * zl;
+              cmax = fmax(cmax, p);
+              cmin = fmin(cmin, p);
+              sg += zl * is;
+              q += is;
+            }
+            if (ub < INFINITY) {
+              const double su = ub - z, is = rcp_fast(su), p = su * zu;
+              cmax = fmax(cmax, p);
+              cmin = fmin(cmin, p);
+              sg += zu * is;
+              q -= is;
+            }
+          }
+          l.sig[e] = sg;                                            // stage_rhs(l, N, e, sg, q, false)
+          if (k < N) {
+            dp w = l.W + (size_t)(k * NZ + i) * WP;
+            w[i] = wd[u] + sg;
+            w[NZ] = q;
+          } else if (i < NX) l.rbN[i] = q;
+        }
+      }
+      const int NV = N * NX;
+      for (int base = 0; base < NV; base += OCP_TPB * U) {
+        double cv[U], lv[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e0 = base + u * OCP_TPB + (int)threadIdx.x;
+          ok[u] = e0 < NV;
+          cv[u] = l.c[ok[u] ? e0 : 0];
+          lv[u] = l.lam[ok[u] ? e0 : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!ok[u]) continue;
+          const double ca = fabs(cv[u]);
+          pmax = nmax(pmax, ca);
+          th += ca;
+          lsum += fabs(lv[u]);
+        }
+      }
+    } else {
     OCP_FOR(e, (N + 1) * NZ) {
       const int k = e / NZ, i = e - k * NZ;
       double sg = 0.0, q = 0.0;
@@ -1473,6 +1562,7 @@ struct Ocp {
       pmax = nmax(pmax, ca);
       th += ca;
       lsum += fabs(l.lam[e]);
+    }
     }
     double ncon = 0.0;
     if constexpr (NC > 0) {  // slack block: dual residual -nu - vL + vU, primal residual d - s; csig, and q_s parked in crb
@@ -1527,12 +1617,37 @@ struct Ocp {
   __device__ static void finish_rhs(const Lds l, double mu) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
-    OCP_FOR(e, (N + 1) * NZ) {
-      const int k = e / NZ, i = e - k * NZ;
-      if (k < N) {
-        dp w = l.W + (size_t)(k * NZ + i) * WP + NZ;
-        *w = l.grad[e] - mu * *w;
-      } else if (i < NX) l.rbN[i] = l.grad[e] - mu * l.rbN[i];
+    if constexpr (BIG) {   // three slots per lane and trip, reads first (see kkt_pass)
+      constexpr int U = 3;
+      const int SLT = (N + 1) * NZ;
+      for (int base = 0; base < SLT; base += OCP_TPB * U) {
+        double gr[U], qv[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e0 = base + u * OCP_TPB + (int)threadIdx.x;
+          ok[u] = e0 < SLT;
+          const int e = ok[u] ? e0 : 0, k = e / NZ, i = e - k * NZ;
+          gr[u] = l.grad[e];
+          qv[u] = k < N ? l.W[(size_t)(k * NZ + i) * WP + NZ] : l.rbN[i < NX ? i : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = base + u * OCP_TPB + (int)threadIdx.x;
+          if (!ok[u]) continue;
+          const int k = e / NZ, i = e - k * NZ;
+          if (k < N) l.W[(size_t)(k * NZ + i) * WP + NZ] = gr[u] - mu * qv[u];
+          else if (i < NX) l.rbN[i] = gr[u] - mu * qv[u];
+        }
+      }
+    } else {
+      OCP_FOR(e, (N + 1) * NZ) {
+        const int k = e / NZ, i = e - k * NZ;
+        if (k < N) {
+          dp w = l.W + (size_t)(k * NZ + i) * WP + NZ;
+          *w = l.grad[e] - mu * *w;
+        } else if (i < NX) l.rbN[i] = l.grad[e] - mu * l.rbN[i];
+      }
     }
     if constexpr (NC > 0) {
       OCP_FOR(e, N * NC) l.crb[e] = -mu * l.crb[e];
