@@ -83,6 +83,13 @@ class Emitter:
                 self.lines.append(f"    using {g}_t = decltype({' + '.join(['0.0'] + a)});")
                 self.lines.append(f"    const {g}_t {g}[] = {{{', '.join(f'{g}_t({q})' for q in a)}}};")
                 rhs = f"gp_se_mean(hilo_user_gp[{int(e.value)}], {g})"
+            elif op == 'gpk':
+                # posterior mean of a learned term with a general kernel: the helper emitted by gp_helper_source (same table as
+                # gp_se_mean, all features as columns)
+                g = f"g{len(self.lines)}"
+                self.lines.append(f"    using {g}_t = decltype({' + '.join(['0.0'] + a)});")
+                self.lines.append(f"    const {g}_t {g}[] = {{{', '.join(f'{g}_t({q})' for q in a)}}};")
+                rhs = f"hilo_user_gpk{int(e.value)}(hilo_user_gp[{int(e.value)}], {g})"
             elif op in ('gpvar', 'gpd'):
                 # posterior variance of a learned term (with the noise variance, `gp.predict(x)[1]`, gp.py:699-713) and the
                 # derivative of its posterior mean with respect to feature j: the terms of the covariance propagation of the
@@ -112,8 +119,22 @@ def _fn(ret, name, args, body_lines, result_lines):
             '\n'.join(body_lines + result_lines) + "\n  }\n")
 
 
-def model_source(n_x, n_u, n_p, ode, meas, discrete):
-    """`struct UserModel` for the right-hand side `ode` (list of n_x expressions) and the measurement map `meas`."""
+def gp_helper_source(k, nf, kexpr):
+    """Posterior mean of learned term #k with the kernel `kexpr` (an expression of the features, leaves ('x', q), and of a
+    training point, leaves ('p', q); hilo_mpc_amd/gp.py::kernel_expr) in the scalar type T of the caller: bias + sum_i alpha_i
+    k(f, X_i) over the table [n, nf, -, bias, (nf + nf entries), rows (X_0..X_{nf-1}, alpha)] of csrc/hilo_gp.hip::gp_pack_se."""
+    em = Emitter(x='f', p='r')
+    ref = em.ref(kexpr)
+    body = '\n'.join('  ' + ln for ln in em.lines)
+    return (f"template <class T>\n__device__ __forceinline__ T hilo_user_gpk{k}(const double* g, const T* f) {{\n"
+            f"  const int n = (int)g[0];\n  const double* r = g + {4 + 2 * nf};\n  T acc = T(0.0);\n"
+            f"  for (int i = 0; i < n; ++i, r += {nf + 1}) {{\n{body}\n      acc = acc + r[{nf}] * ({ref});\n  }}\n"
+            f"  return g[3] + acc;\n}}\n")
+
+
+def model_source(n_x, n_u, n_p, ode, meas, discrete, helpers=()):
+    """`struct UserModel` for the right-hand side `ode` (list of n_x expressions) and the measurement map `meas`; `helpers`:
+    source of the functions the expressions call (learned terms with general kernels)."""
     if len(ode) != n_x:
         raise ValueError(f"the model has {n_x} states but {len(ode)} dynamical equations")
     em = Emitter()
@@ -123,7 +144,8 @@ def model_source(n_x, n_u, n_p, ode, meas, discrete):
     yy = [em2.ref(e) for e in meas]
     body2 = em2.lines + [f"    y[{i}] = T({r});" for i, r in enumerate(yy)]
     n_y = len(meas)
-    src = (f"struct UserModel {{\n"
+    src = (''.join(helpers) +
+           f"struct UserModel {{\n"
            f"  static constexpr int NX = {n_x}, NU = {n_u}, NP = {n_p}, NY = {n_y};\n"
            f"  static constexpr bool DISCRETE = {'true' if discrete else 'false'};\n"
            f"  template <class T, class U, class P>\n"
@@ -134,7 +156,7 @@ def model_source(n_x, n_u, n_p, ode, meas, discrete):
            f"    (void)x; (void)u; (void)p; (void)dt; (void)y;\n" + '\n'.join(body2) + "\n  }\n};\n")
     # symbolic first / second derivatives for the engine's derivative phase (csrc/hilo_ocp.h::eval_derivs_sym); a model with
     # a learned term keeps the Taylor sweeps
-    learned = ('gp', 'gpvar', 'gpd')
+    learned = ('gp', 'gpvar', 'gpd', 'gpk')
     if not any(n.op in learned for e in ode for n in Expr.wrap(e).nodes().values()):
         from .symdiff import sym_source
         src += sym_source('UserModel', n_x, n_u, ode,
@@ -152,7 +174,7 @@ def dae_model_source(n_x, n_u, n_p, n_z, ode, alg, meas, z_guess):
     from .symdiff import Dag
     if len(ode) != n_x or len(alg) != n_z:
         raise ValueError("dimension mismatch between states and equations")
-    if any(n.op == 'gp' for e in list(ode) + list(alg) for n in Expr.wrap(e).nodes().values()):
+    if any(n.op in ('gp', 'gpk') for e in list(ode) + list(alg) for n in Expr.wrap(e).nodes().values()):
         raise NotImplementedError("a learned term inside a DAE model is not built")
     em = Emitter()
     dx = [em.ref(e) for e in ode]

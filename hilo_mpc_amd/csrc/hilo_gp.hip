@@ -971,10 +971,34 @@ int hilo::gp_pack_se(const hilo_gp* gp, double** d_pack) {
   const bool se = (int)k[0] == HILO_K_GAMMAEXP && na >= 1 && na <= 8 && gp->klen == 3 + na + 3 + na && (int)k[2 + na] == 3 + na &&
                   k[3 + na + 1] == 0.5 && k[3 + na + 2] == 1.0;
   const bool cm = gp->mlen == 4 && (int)m[0] == HILO_M_CONST && (int)m[1] == 0;
-  if (!se || !cm)
-    return fail(HILO_ENOTSUP, "a GP inside a run-time compiled model must have a squared-exponential kernel (up to 8 active "
-                              "features) and a constant or zero mean");
+  if (!cm)
+    return fail(HILO_ENOTSUP, "a GP inside a run-time compiled model must have a constant or zero mean");
   const int n = gp->n, nf = gp->nf;
+  if (!se) {
+    // any other kernel is compiled into the model source (hilo_mpc_amd/codegen.py::gp_helper_source); what the model reads here is
+    // the same table with ALL features as columns: [n, nf, NaN, bias, 0..nf-1, 1.., rows (X_0..X_{nf-1}, alpha)].  The signal
+    // variance slot holds NaN: gp_se_mean on this table (a squared-exponential function called for another kernel) cannot go unnoticed.
+    if (nf < 1 || nf > 8) return fail(HILO_ENOTSUP, "a GP inside a run-time compiled model takes 1 to 8 features (got %d)", nf);
+    const size_t len = 4 + 2 * (size_t)nf + (size_t)n * (nf + 1);
+    double* X = new double[(size_t)nf * n];
+    double* a = new double[n];
+    double* pack = new double[len];
+    hipError_t e = hipSetDevice(gp->device);
+    if (e == hipSuccess) e = hipMemcpy(X, gp->X, sizeof(double) * nf * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(a, gp->alpha, sizeof(double) * n, hipMemcpyDeviceToHost);
+    pack[0] = n; pack[1] = nf; pack[2] = NAN; pack[3] = m[3];
+    for (int q = 0; q < nf; ++q) { pack[4 + q] = q; pack[4 + nf + q] = 1.0; }
+    for (int i = 0; i < n; ++i) {
+      double* r = pack + 4 + 2 * nf + (size_t)i * (nf + 1);
+      for (int q = 0; q < nf; ++q) r[q] = X[(size_t)q * n + i];
+      r[nf] = a[i];
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)d_pack, sizeof(double) * len);
+    if (e == hipSuccess) e = hipMemcpy(*d_pack, pack, sizeof(double) * len, hipMemcpyHostToDevice);
+    delete[] X; delete[] a; delete[] pack;
+    if (e != hipSuccess) return fail(HILO_EHIP, "gp_pack_se: %s", hipGetErrorString(e));
+    return HILO_OK;
+  }
   // tail for the posterior variance (hilo_models.h::gp_se_var): [sn2, L^-1 row-major n x n], small training sets only
   const bool with_var = n <= 64;
   const size_t head = 4 + 2 * (size_t)na + (size_t)n * (na + 1);

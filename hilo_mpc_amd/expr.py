@@ -20,7 +20,7 @@ STACK = 8
 
 
 class Expr:
-    """Node of an expression tree: op in {'const','x','u','p','z','theta','t', binary / unary op names, 'gp','gpd','gpvar'}.
+    """Node of an expression tree: op in {'const','x','u','p','z','theta','t', binary / unary op names, 'gp','gpd','gpvar','gpk'}.
     Unary functions: sq sin cos exp log sqrt (device interpreter and compiled code) and - compiled code only - the rest of the
     reference's table (util/parsing.py:36-58): log10 fabs sign asin acos atan asinh acosh atanh; binary: atan2."""
     __slots__ = ('op', 'args', 'value', 'name', 'serial')
@@ -123,7 +123,7 @@ class Expr:
             out += [X_VARX, float(theta_index)]
         elif op == 'powi':
             out += [X_POWI, float(self.value)]
-        elif op in ('gp', 'gpvar', 'gpd'):
+        elif op in ('gp', 'gpvar', 'gpd', 'gpk'):
             raise ValueError("a learned term cannot be evaluated by the device interpreter (run-time compiled models only)")
         elif op == 'z':
             raise ValueError("an algebraic state cannot be evaluated by the device interpreter (run-time compiled models only)")

@@ -42,6 +42,68 @@ def _log(v, is_variance=False):
     return lg / 2. if is_variance else lg
 
 
+def kernel_expr(prog, f, t):
+    """k(f, t) of a kernel program as an expression tree (hilo_mpc_amd/expr.py) - the formulas of the device interpreter
+    (csrc/hilo_gp.hip::eval_kernel, kernel.py:465-1003, :1562-1627), with the features `f` and the training point `t` as lists
+    of expressions.  Used for a learned term inside a run-time compiled model whose kernel is not the plain squared
+    exponential (hilo_mpc_amd/model.py::substitute_from): the kernel is compiled into the model source and differentiated by the
+    scalar type it is evaluated with.  Distances enter square roots / fractional powers with 1e-300 added, so that the Taylor
+    coefficients stay finite where a query coincides with a training point (the value is unchanged)."""
+    from . import expr as E
+    prog = [float(v) for v in prog]
+    pos, st = 0, []
+    while pos < len(prog):
+        op, na = int(prog[pos]), int(prog[pos + 1])
+        act = [int(v) for v in prog[pos + 2:pos + 2 + na]]
+        npar = int(prog[pos + 2 + na])
+        par = prog[pos + 3 + na:pos + 3 + na + npar]
+        pos += 3 + na + npar
+
+        def d2(M):
+            s2 = E.Expr.wrap(0.0)
+            for k, a in enumerate(act):
+                df = f[a] - t[a]
+                s2 = s2 + float(M[k]) * (df * df)
+            return s2
+
+        if op == K_CONST:
+            v = E.Expr.wrap(par[0])
+        elif op == K_GAMMAEXP:
+            q = d2(par[3:3 + na])
+            e = q if par[2] == 1.0 else (q + 1e-300) ** float(par[2])
+            v = par[0] * E.exp(-par[1] * e)
+        elif op == K_MATERN:
+            nc = int(par[2])
+            d = E.sqrt((par[1] * par[1]) * d2(par[3 + nc:3 + nc + na]) + 1e-300)
+            poly = 1.0 + d * par[3]
+            for k in range(1, nc):
+                poly = 1.0 + d * par[3 + k] * poly
+            v = par[0] * E.exp(-d) * poly
+        elif op == K_RQ:
+            v = par[0] * (1.0 + (0.5 / par[1]) * d2(par[2:2 + na])) ** float(-par[1])
+        elif op == K_SUM:
+            b, a = st.pop(), st.pop()
+            v = a + b
+        elif op == K_PRODUCT:
+            b, a = st.pop(), st.pop()
+            v = a * b
+        else:
+            raise NotImplementedError("a learned term inside a run-time compiled model takes squared-exponential / gamma-exponential, "
+                                      "Matern, rational-quadratic and constant kernels and their sums and products")
+        st.append(v)
+    if len(st) != 1:
+        raise ValueError("malformed kernel program")
+    return st[0]
+
+
+def is_plain_se(prog):
+    """The kernel program is ONE squared-exponential node (the test of csrc/hilo_gp.hip::gp_pack_se)."""
+    prog = [float(v) for v in prog]
+    na = int(prog[1])
+    return int(prog[0]) == K_GAMMAEXP and 1 <= na <= 8 and len(prog) == 3 + na + 3 + na and int(prog[2 + na]) == 3 + na and \
+        prog[3 + na + 1] == 0.5 and prog[3 + na + 2] == 1.0
+
+
 # =================================================================================================
 # Kernels
 # =================================================================================================

@@ -269,7 +269,8 @@ class Model:
                     raise NotImplementedError("algebraic states of a discrete model are not built")
                 return codegen.dae_model_source(self.n_x, self.n_u, self.n_p, self.n_z, self._ode, self._alg, self._meas,
                                                 z_guess if z_guess is not None else [0.] * self.n_z)
-            return codegen.model_source(self.n_x, self.n_u, self.n_p, self._ode, self._meas, self._native_discrete)
+            helpers = [src for _, src in sorted(getattr(self, '_gp_helpers', {}).items())]
+            return codegen.model_source(self.n_x, self.n_u, self.n_p, self._ode, self._meas, self._native_discrete, helpers=helpers)
         if self.name == 'lti':
             return codegen.zoo_alias(f"Lti<{self.n_x}, {self.n_u}, {self.n_y}>")
         if self.name not in ZOO_FUNCTOR:
@@ -370,7 +371,25 @@ class Model:
                     break
             else:
                 raise ValueError(f"feature '{f}' is not a state, input or parameter of model '{self.name}'")
-        node = Expr('gp', feats, value=len(self._gps), name=labels[0])
+        # the plain squared-exponential kernel has a device function of its own (gp_se_mean, also the variance and the mean's
+        # Jacobian of the stochastic NMPC); any other stationary kernel / sum / product is compiled into the model source
+        from .gp import is_plain_se, kernel_expr
+        from . import codegen
+        kern = getattr(gp, 'kernel', None)       # (an object without one is taken to the device function: the library checks its kernel)
+        kprog = list(kern.program(len(features))) if kern is not None else None
+        k = len(self._gps)
+        if kprog is None or is_plain_se(kprog):
+            node = Expr('gp', feats, value=k, name=labels[0])
+        else:
+            if len(features) > 8:
+                raise NotImplementedError("a learned term inside a model takes at most 8 features")
+            fe = [Expr('x', value=q, name=f"f{q}") for q in range(len(features))]
+            te = [Expr('p', value=q, name=f"t{q}") for q in range(len(features))]
+            if not hasattr(self, '_gp_helpers') or self._gp_helpers is None:
+                self._gp_helpers = {}
+            self._gp_helpers = dict(self._gp_helpers)
+            self._gp_helpers[k] = codegen.gp_helper_source(k, len(features), kernel_expr(kprog, fe, te))
+            node = Expr('gpk', feats, value=k, name=labels[0])
 
         def leaf(n):
             if n.op != 'p':
@@ -395,6 +414,8 @@ class Model:
         m._sim = None              # the copy simulates its own trajectory
         if hasattr(self, '_gps'):
             m._gps = list(self._gps)    # learned terms substituted into the copy later must not appear in the original
+        if getattr(self, '_gp_helpers', None):
+            m._gp_helpers = dict(self._gp_helpers)
         return m
 
     # ---- the model as a PLANT: one sampling interval for a batch of states (dynamic_model.py:3360-3400, :3911-4000) -----------------

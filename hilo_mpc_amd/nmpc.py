@@ -156,7 +156,7 @@ class QuadraticCost:
                                      f"is {len(names)} long while cost {len(funs)}.")
                 funs = [Expr.wrap(f) for f in funs]
                 for f in funs:
-                    if any(n.op in ('x', 'u', 'p', 'z', 'theta', 'gp', 'gpd', 'gpvar') for n in f.nodes().values()):
+                    if any(n.op in ('x', 'u', 'p', 'z', 'theta', 'gp', 'gpd', 'gpvar', 'gpk') for n in f.nodes().values()):
                         raise ValueError("a trajectory reference can only be a function of the time variable "
                                          "(nmpc.get_time_variable())")
             ind = []

@@ -187,6 +187,11 @@ class SMPC(NMPC):
                     raise ValueError(f"'{f}' is not in list")
             if gp.X_train.shape[1] > 64:
                 raise NotImplementedError("the posterior variance inside a compiled model is built for up to 64 training points")
+            from .gp import is_plain_se
+            kern = getattr(gp, 'kernel', None)
+            if kern is not None and not is_plain_se(kern.program(len(feats))):
+                raise NotImplementedError("the stochastic NMPC's surrogate (posterior mean, its Jacobian and the posterior variance "
+                                          "inside the compiled model) is built for squared-exponential kernels")
             fx = [x[det_model.dynamical_state_names.index(f)] for f in feats]
             mean = Expr('gp', fx, value=k, name=(list(getattr(gp, 'labels', [])) or ['gp'])[0])
             mu_d.append(mean)

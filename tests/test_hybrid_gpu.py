@@ -159,6 +159,59 @@ def test_learned_term_over_state_input_and_parameter_features():
     assert np.all(nmpc.solver_status_code == 1)
 
 
+@pytest.mark.parametrize('kind', ['matern_52', 'se_plus_rq'])
+def test_learned_term_with_another_kernel_is_compiled_into_the_model(kind):
+    """Round 3: a learned term whose kernel is not the plain squared exponential - the kernel is compiled into the model source
+    (hilo_mpc_amd/gp.py::kernel_expr, codegen.py::gp_helper_source) and differentiated by the Taylor sweeps like the rest of the
+    right-hand side.  The compiled shooting map against RK4 in numpy with `gp.predict` (parity-tested for every kernel family)
+    for the rate; the solve converges (exact first and second derivatives are what makes it)."""
+    from hilo_mpc_amd import GP, Kernel, Mean, NMPC
+    from tests.problems import symbolic_model
+    rng = np.random.default_rng(12)
+    n = 50
+    Xt = np.stack([rng.uniform(0, 40, n), rng.uniform(0, 2, n)])
+    yt = (0.4 * Xt[0] / (1. + Xt[0]) * (1. + .22 / (.22 + Xt[1])))[None, :]
+    if kind == 'matern_52':
+        kern = Kernel.matern_52(active_dims=[0, 1], length_scales=[12., 1.], ard=True, signal_variance=.6)
+    else:
+        kern = Kernel.squared_exponential(active_dims=[0, 1], length_scales=[12., 1.], ard=True, signal_variance=.5) + \
+            Kernel.rational_quadratic(active_dims=[0], length_scales=20., alpha=1.5, signal_variance=.1)
+    gp = GP(['S', 'I'], ['mu'], kernel=kern, mean=Mean.constant(bias=.2), noise_variance=1e-4)
+    gp.set_training_data(Xt, yt)
+    gp.setup()
+    m = symbolic_model('chemostat4_mu')
+    m.substitute_from(gp)
+    assert 'hilo_user_gpk0' in m.user_source()
+    m = m.discretize('erk', order=4).setup(dt=.5)
+    nmpc = NMPC(m)
+    nmpc.quad_stage_cost.add_states(names=['X'], weights=[1.], ref=[1.])
+    nmpc.quad_stage_cost.add_inputs(names=['DS', 'DI'], weights=[.1, .1])
+    nmpc.horizon = 5
+    nmpc.set_box_constraints(u_lb=[0., 0.], u_ub=[1., 1.])
+    nmpc.setup(options={'integration_method': 'discrete'})
+    B = 32
+    x = np.array([.1, 30., .1, .2]) * (1 + .3 * rng.uniform(-1, 1, (B, 4)))
+    u = rng.uniform(0, 1, (B, 2))
+    p = np.array([40., 4., 1., .3])
+
+    def rhs(x):
+        X, S, Pr, I = x.T
+        mu = np.asarray(gp.predict(np.stack([S, I]))[0]).ravel()
+        phi = 0.407 * S / (0.108 + S + S * S / 14814.0)
+        Rs = 2.0 * (phi * (p[2] + 0.22 * p[3] / (0.22 + I)))
+        Rfp = phi * (0.0005 + I) / (0.022 + I)
+        D = u[:, 0] + u[:, 1]
+        return np.stack([mu * X - D * X, -(Rs * X) - D * S + u[:, 0] * p[0], Rfp * X - D * Pr, -(D * I) + u[:, 1] * p[1]], 1)
+
+    h = .5
+    k1 = rhs(x); k2 = rhs(x + h / 2 * k1); k3 = rhs(x + h / 2 * k2); k4 = rhs(x + h * k3)
+    ref = x + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+    np.testing.assert_allclose(nmpc.plant_step(x, u, cp=p).cpu().numpy(), ref, rtol=1e-9, atol=1e-11)
+    nmpc.optimize(x[:8], cp=p)
+    assert np.all(nmpc.solver_status_code == 1) and np.all(nmpc.stats()['kkt_error'] <= 1e-8)
+    assert np.all(nmpc.stats()['iter_count'] < 60)
+
+
 def test_substitute_from_errors():
     from hilo_mpc_amd import GP, Kernel, Model
     gp = GP(['S', 'I'], ['mu'])
