@@ -215,6 +215,21 @@ def test_path_following_with_soft_constraint_vs_slsqp():
     assert np.all(lam.reshape(4, pb.N, -1)[:, :, pb.nxa + 1] == 0.)         # the dropped row -c - e <= inf
 
 
+def test_constraint_on_the_path_variable_vs_slsqp():
+    """A stage constraint that involves the path variable (a soft tube around the first path coordinate next to the soft speed
+    limit: two slacks) - the independent SLSQP solve of the same transcription agrees."""
+    spec = dict(C5S, N=6, constraint=dict(expr=['vx**2 + vy**2', 'px - sin(theta)'], lb=[-np.inf, -0.1], ub=[4., 0.1], soft=True,
+                                         weight=[[10., 0.], [0., 10.]]))
+    pb = oracle_gen(spec)
+    assert pb.ne == 2 and pb.nrow == 3                                   # ub row of the speed limit, both rows of the tube
+    ipm = GenIpm(pb)
+    res = ipm.solve(c5_x0(4), [])
+    assert np.all(res['status'] == 1) and np.all(res['kkt'] <= 1e-8)
+    b = int(np.argmax(res['E'][:, 1]))
+    assert res['E'][b, 1] > 1e-4                                          # the tube's slack is in use
+    _slsqp(pb, ipm, res, b, np.zeros(0))
+
+
 # ---- expression compiler (host) vs a Python model of the device interpreter -------------------------------------------
 def _run(prog, x, u, p):
     n = int(prog[0])
