@@ -443,3 +443,18 @@ def test_filters_need_a_model_that_is_set_up():
         KF(Model('toy1d'))
     with pytest.raises(RuntimeError, match="Model is not set up"):
         KF(Model('linear2').discretize('erk', order=1))
+
+
+def test_soft_constraint_weights_are_used_as_the_matrix_given():
+    """`e^T weight e` (modeling.py:870, :878): a matrix stays the matrix it is - round 3 found `[[50, 0], [0, 80]]` reduced to the
+    vector of its diagonal on the way to the device (two of the four entries read from beyond the array)."""
+    import numpy as np
+    import pytest
+    from hilo_mpc_amd.nmpc import _constraint_weight
+    W = _constraint_weight([[50., 1.], [2., 80.]], 2, 'stage constraint')
+    assert W.shape == (2, 2) and W.flags['C_CONTIGUOUS'] and W[0, 1] == 1. and W[1, 0] == 2.
+    np.testing.assert_array_equal(_constraint_weight(3., 2, 'c'), 3. * np.eye(2))
+    np.testing.assert_array_equal(_constraint_weight([1., 2.], 2, 'c'), np.diag([1., 2.]))
+    np.testing.assert_array_equal(_constraint_weight([[7.]], 1, 'c'), [[7.]])
+    with pytest.raises(ValueError, match="must be a 2 x 2 matrix"):
+        _constraint_weight([[1., 2., 3.]], 2, 'terminal constraint')
