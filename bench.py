@@ -213,6 +213,47 @@ def cpu_baseline_c2(spec, nst=50, slsqp=True, pb=None, label='C2', per_thread=64
             "host_cpus": os.cpu_count()}
 
 
+def cpu_leg_mhe(spec, nst=40, per_thread=128):
+    """oracle/cpu/mhe_cpu.cpp (C++17 / OpenMP: the estimator's transcription on the Riccati interior point of the NMPC leg, validated
+    against oracle/mhe.py in tests/test_cpu_baseline.py) on the benchmark's own loop: window filled, one cold estimate, then per step
+    one new sample shifts the window, arrival guess = x_2 of the previous solution, warm start = the previous solution."""
+    C, quota = host_cores()
+    from oracle.cpu import CpuMhe
+    from tests import problems as P
+    pb = P.oracle_mhe(spec)
+    cpu = CpuMhe(pb)
+    npar, nx = pb.np_, pb.nx
+
+    def loop(nb, nt, nst=nst, nwarm=3):
+        xa, u, y, _ = P.c3_data(nb, seed=11)
+        noise = .01 * np.random.default_rng(5).normal(size=(64, nb, 2))
+        r = cpu.solve(xa, spec['p'], u, y, n_threads=nt)
+        t0, its = 0.0, []
+        for k in range(nwarm + nst):
+            if k == nwarm:
+                t0 = time.perf_counter()
+            y = np.concatenate([y[:, 1:], (y[:, -1] + noise[k % 64])[:, None]], axis=1)
+            u = np.concatenate([u[:, 1:], u[:, -1:]], axis=1)
+            r = cpu.solve(r['v'][:, npar + 2 * nx:npar + 3 * nx], spec['p'], u, y, v0=r['v'], n_threads=nt)
+            if k >= nwarm:
+                its.append(r['iters'].mean())
+        secs = time.perf_counter() - t0
+        return nb * nst / secs, secs, float(np.mean(its)), float(np.mean((r['status'] == 1) | (r['status'] == 2)))
+    nb_all = max(min(256, 16 * per_thread), per_thread * C)
+    v_all, s_all, it_all, ok_all = loop(nb_all, C)
+    n_one = min(nst, 10)
+    n_inst_one = max(1, min(2 * per_thread, 128))
+    v_one, s_one, _, _ = loop(n_inst_one, 1, nst=n_one)
+    return {"value": v_all, "unit": "steps/s", "cores": C, "kind": "port", "one_core_value": v_one,
+            "cpu_model": cpu_model_name(), "cgroup_cpu_quota": quota, "sched_affinity_cpus": len(os.sched_getaffinity(0)),
+            "mean_ipm_iters": it_all, "frac_status_1_or_2": ok_all,
+            "sample": f"oracle/cpu C++17/OpenMP Riccati interior point on the estimator's transcription (same algorithm and constants as "
+                      f"the numpy oracle, validated against it): C3 window loop, {nb_all} instances x {nst} warm-started estimates on "
+                      f"{C} pinned threads = min(OpenMP, affinity, cgroup quota) ({s_all:.1f} s); one_core_value: {n_inst_one} "
+                      f"instances x {n_one} estimates on 1 thread ({s_one:.1f} s); the reference's CasADi/IPOPT is not installable",
+            "host_cpus": os.cpu_count()}
+
+
 def cpu_leg_kf(kind, K, budget=6., min_batch=4096):
     # oracle/cpu/kf_cpu.cpp (C++17 / OpenMP, validated against oracle/kf.py in tests/test_cpu_baseline.py): the same K sampling
     # instants per call for a larger batch, all host cores and one
@@ -240,6 +281,32 @@ def cpu_leg_kf(kind, K, budget=6., min_batch=4096):
             "cpu_model": cpu_model_name(), "cgroup_cpu_quota": quota,
             "sample": f"oracle/cpu C++17/OpenMP {kind.upper()} (validated against the numpy oracle): {n_all} calls x {nb} instances x "
                       f"{K} filter steps on {C} pinned threads ({s_all:.1f} s); one_core_value: {n_one} calls on 1 thread ({s_one:.1f} s)",
+            "host_cpus": os.cpu_count()}
+
+
+def cpu_leg_gp(Xq, budget=6.):
+    # oracle/cpu/gp_cpu.cpp (C++17 / OpenMP over blocks of query columns; validated against oracle/gp.py::Posterior.predict in
+    # tests/test_cpu_baseline.py) on query columns of the benchmark's own draw, all host cores and one
+    from oracle.cpu import gp_predict
+    from tests import problems as P
+    C, quota = host_cores()
+    post = P.oracle_c4()[1]
+    mq = Xq.shape[1]
+
+    def run(nt, budget):
+        gp_predict(post, Xq, n_threads=nt)
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget:
+            gp_predict(post, Xq, n_threads=nt)
+            n += 1
+        secs = time.perf_counter() - t0
+        return n * mq / secs, secs, n
+    v_all, s_all, n_all = run(C, budget)
+    v_one, s_one, n_one = run(1, budget * 2 / 3)
+    return {"value": v_all, "unit": "predictions/s", "cores": C, "kind": "port", "one_core_value": v_one,
+            "cpu_model": cpu_model_name(), "cgroup_cpu_quota": quota,
+            "sample": f"oracle/cpu C++17/OpenMP prediction (mean + variance; validated against the numpy oracle): {n_all} calls x {mq} query "
+                      f"columns on {C} pinned threads ({s_all:.1f} s); one_core_value: {n_one} calls on 1 thread ({s_one:.1f} s)",
             "host_cpus": os.cpu_count()}
 
 
@@ -398,15 +465,7 @@ def wl_mhe(args, torch, dev, rank, world):
         return extra, roof, "weak"
 
     def cpu():
-        from oracle.mhe import MheIpm
-        pb = P.oracle_mhe(spec)
-        ipm, ns = MheIpm(pb), 8
-        t0 = time.perf_counter()
-        ipm.solve(xa[:ns], spec['p'], u[:ns], y[:ns])
-        secs = time.perf_counter() - t0
-        return {"value": ns / secs, "unit": "steps/s", "cores": 1, "kind": "port",
-                "sample": f"{ns} cold estimates of the same C3 window with the oracle's MheIpm (dense KKT, numpy; {secs:.1f} s)",
-                "host_cpus": os.cpu_count()}
+        return cpu_leg_mhe(spec)
     return dict(step=step, finish=finish, units=B, cpu=cpu, unit="steps/s",
                 metric="MHE estimates/sec (batched instances, whole node) at fixed (nx,ny,N)")
 
@@ -500,18 +559,7 @@ def wl_gp(args, torch, dev, rank, world):
         return extra, roof, "weak"
 
     def cpu():
-        post = P.oracle_c4()[1]
-        mq = 20000
-        Xh = Xq[:, :mq].cpu().numpy()
-        t0 = time.perf_counter()
-        nrep = 0
-        while time.perf_counter() - t0 < 8.:
-            post.predict(Xh)
-            nrep += 1
-        secs = time.perf_counter() - t0
-        return {"value": nrep * mq / secs, "unit": "predictions/s", "cores": 1, "kind": "port",
-                "sample": f"{nrep} x {mq} query columns with the oracle's numpy Posterior.predict ({secs:.1f} s; BLAS threads as "
-                          f"numpy is configured)", "host_cpus": os.cpu_count()}
+        return cpu_leg_gp(Xq[:, :1 << 16].cpu().numpy())
     return dict(step=step, finish=finish, units=m, cpu=cpu, unit="predictions/s",
                 metric="GP predictions/sec (query columns with variance, whole node)")
 

@@ -1,4 +1,4 @@
-"""ctypes front of the C++/OpenMP CPU baseline (oracle/cpu/nmpc_cpu.cpp, kf_cpu.cpp, qp_cpu.cpp).
+"""ctypes front of the C++/OpenMP CPU baseline (oracle/cpu/nmpc_cpu.cpp, mhe_cpu.cpp, kf_cpu.cpp, qp_cpu.cpp, gp_cpu.cpp).
 
 TEST INFRASTRUCTURE / BASELINE ONLY - used by tests/test_cpu_baseline.py and by bench.py's `cpu_baseline` leg, never by the
 product package.  The library takes the product's own problem descriptor (`hilo_nmpc_desc`, include/hilo_hip.h); here the
@@ -16,7 +16,7 @@ _lib = None
 
 
 def build(force=False):
-    src = [os.path.join(HERE, f) for f in ('nmpc_cpu.cpp', 'kf_cpu.cpp', 'qp_cpu.cpp', 'models_cpu.h', 'Makefile')] + \
+    src = [os.path.join(HERE, f) for f in ('nmpc_cpu.cpp', 'mhe_cpu.cpp', 'kf_cpu.cpp', 'qp_cpu.cpp', 'gp_cpu.cpp', 'models_cpu.h', 'ipm_cpu.h', 'Makefile')] + \
         [os.path.join(HERE, '..', '..', 'include', 'hilo_hip.h')]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
         subprocess.check_call(['make', '-s', '-C', HERE] + (['-B'] if force else []))
@@ -35,8 +35,15 @@ def lib():
         _lib.hilo_cpu_nmpc_destroy.restype = None
         _lib.hilo_cpu_nmpc_solve.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.c_int]
         _lib.hilo_cpu_plant_step.argtypes = [vp, i64, vp, vp, vp, i64, vp, C.c_int]
+        _lib.hilo_cpu_mhe_last_error.restype = C.c_char_p
+        _lib.hilo_cpu_mhe_create.argtypes = [vp, C.POINTER(vp)]
+        _lib.hilo_cpu_mhe_destroy.argtypes = [vp]
+        _lib.hilo_cpu_mhe_destroy.restype = None
+        _lib.hilo_cpu_mhe_estimate.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
         _lib.hilo_cpu_set_gp.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]
         _lib.hilo_cpu_kf_steps.argtypes = [C.c_int, C.c_int, C.c_double, i64, C.c_int, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int]
+        _lib.hilo_cpu_gp_predict.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, C.c_double, C.c_double, C.c_int, i64, vp, vp,
+                                             vp, C.c_int]
         _lib.hilo_cpu_qp_solve.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, i64, vp, vp, C.c_double, C.c_int, C.c_double, vp, vp, vp,
                                            C.c_int]
     return _lib
@@ -105,6 +112,57 @@ class CpuNmpc:
         return xn
 
 
+class CpuMhe:
+    """Moving-horizon estimator of an oracle `MheProblem` (state noise, pinned parameters) on the C++ baseline."""
+
+    def __init__(self, pb, **options):
+        from hilo_mpc_amd._lib import MheDesc               # the ctypes mirror of hilo_mhe_desc (tests/test_abi.py checks it)
+        self.pb = pb
+        d = MheDesc()
+        d.model_id, d.N, d.erk_order, d.n_sub, d.dt = pb.model.model_id, pb.N, pb.smap.order, pb.smap.n_sub, pb.dt
+        d.bound_relax_factor = -1.
+        for k, v in options.items():
+            setattr(d, k, v)
+        keep = []
+
+        def hp(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            keep.append(a)
+            return a.ctypes.data
+        d.Wx, d.Wy, d.Ww = hp(pb.Wx), hp(pb.Wy), hp(pb.Ww)
+        d.x_lb, d.x_ub, d.w_lb, d.w_ub = hp(pb.x_lb * pb.sx), hp(pb.x_ub * pb.sx), hp(pb.w_lb * pb.sw), hp(pb.w_ub * pb.sw)
+        d.x_scaling, d.w_scaling, d.u_scaling = hp(pb.sx), hp(pb.sw), hp(pb.su)
+        d.x_guess, d.w_guess = hp(pb.x_guess * pb.sx), hp(pb.w_guess * pb.sw)
+        h = C.c_void_p()
+        if lib().hilo_cpu_mhe_create(C.byref(d), C.byref(h)) != 0:
+            raise RuntimeError(lib().hilo_cpu_mhe_last_error().decode())
+        self._h = h
+        self.n_v = pb.n_v
+
+    def __del__(self):
+        if getattr(self, '_h', None) is not None and _lib is not None:
+            _lib.hilo_cpu_mhe_destroy(self._h)
+            self._h = None
+
+    def solve(self, x_arrival, p, u_meas, y_meas, v0=None, n_threads=0):
+        """Arguments like `MheIpm.solve`; v0 = warm start in the reference layout [p | x | w] (scaled)."""
+        pb = self.pb
+        xa = np.ascontiguousarray(np.atleast_2d(x_arrival), dtype=np.float64)
+        B = xa.shape[0]
+        par = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(np.asarray(p, dtype=np.float64)), (B, pb.np_)))
+        um = np.ascontiguousarray(np.asarray(u_meas, dtype=np.float64).reshape(B, pb.N, pb.nu))
+        ym = np.ascontiguousarray(np.asarray(y_meas, dtype=np.float64).reshape(B, pb.N, pb.ny))
+        v0 = None if v0 is None else np.ascontiguousarray(np.broadcast_to(v0, (B, self.n_v)), dtype=np.float64)
+        v, f, xo = np.empty((B, self.n_v)), np.empty(B), np.empty((B, pb.nx))
+        st, it, kkt = np.empty(B, np.int32), np.empty(B, np.int32), np.empty(B)
+        rc = lib().hilo_cpu_mhe_estimate(self._h, B, xa.ctypes.data, par.ctypes.data, pb.np_, um.ctypes.data, ym.ctypes.data,
+                                         v0.ctypes.data if v0 is not None else None, v.ctypes.data, f.ctypes.data, xo.ctypes.data,
+                                         st.ctypes.data, it.ctypes.data, kkt.ctypes.data, int(n_threads))
+        if rc != 0:
+            raise RuntimeError(lib().hilo_cpu_mhe_last_error().decode())
+        return dict(v=v, f=f, x_opt=xo, status=st, iters=it, kkt=kkt)
+
+
 def max_threads():
     return int(lib().hilo_cpu_max_threads())
 
@@ -153,3 +211,27 @@ def qp_solve(H, g, A, b, lbx, ubx, tol=1e-10, max_iter=100, reg=1e-11, n_threads
     if rc != 0:
         raise RuntimeError('hilo_cpu_qp_solve: bad argument')
     return dict(x=x, status=st, iters=it)
+
+
+def gp_predict(post, Xq, noise_free=False, n_threads=0):
+    """`Posterior.predict` of an oracle posterior with a squared-exponential kernel (one length scale per feature or one for all) and
+    a zero / constant mean: (mean [m], var [m])."""
+    ks, ms = post.kernel_spec, post.mean_spec
+    if ks['type'] != 'squared_exponential' or ms['type'] not in ('zero', 'constant'):
+        raise NotImplementedError("the CPU baseline of the prediction covers the squared-exponential kernel with a zero / constant mean")
+    kw = ks['kwargs']
+    dims = list(kw.get('active_dims') or range(post.X.shape[0]))
+    X = np.ascontiguousarray(post.X[dims], dtype=np.float64)
+    Xq = np.ascontiguousarray(np.atleast_2d(np.asarray(Xq, dtype=np.float64))[dims])
+    nf, n = X.shape
+    Minv = np.ascontiguousarray(np.broadcast_to(1. / np.asarray(kw.get('length_scales', 1.), dtype=np.float64) ** 2, (nf,)))
+    al, R = np.ascontiguousarray(post.alpha, dtype=np.float64), np.ascontiguousarray(post.R, dtype=np.float64)
+    bias = float((ms.get('kwargs') or {}).get('bias', 1.)) if ms['type'] == 'constant' else 0.
+    m = Xq.shape[1]
+    mu, var = np.empty(m), np.empty(m)
+    rc = lib().hilo_cpu_gp_predict(n, nf, X.ctypes.data, al.ctypes.data, R.ctypes.data, float(kw.get('signal_variance', 1.)),
+                                   Minv.ctypes.data, bias, float(post.sn2), int(noise_free), m, Xq.ctypes.data, mu.ctypes.data,
+                                   var.ctypes.data, int(n_threads))
+    if rc != 0:
+        raise RuntimeError('hilo_cpu_gp_predict: bad argument')
+    return mu, var

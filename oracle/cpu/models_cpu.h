@@ -1,4 +1,4 @@
-// CPU baseline: model right-hand sides and Runge-Kutta tableaux shared by the legs (nmpc_cpu.cpp, kf_cpu.cpp).
+// CPU baseline: model right-hand sides and Runge-Kutta tableaux shared by the legs (nmpc_cpu.cpp, mhe_cpu.cpp, kf_cpu.cpp).
 // TEST INFRASTRUCTURE / BASELINE ONLY - see nmpc_cpu.cpp.
 #pragma once
 #include <cmath>
@@ -26,6 +26,8 @@ struct Chemostat4 {
     dx[2] = Rfp * X - D * P;
     dx[3] = -(D * I) + u[1] * p[1];
   }
+  static constexpr int NY = 2;      // measurements X and P (hilo_mpc/library/models.py:163-198: `y = [X, P]`)
+  template <class T> static void meas(const T* x, const T*, const double*, T* y) { y[0] = x[0]; y[1] = x[2]; }
 };
 
 // Chemostat4 with the growth rate of the biomass balance given by a GP posterior mean over (S, I) - BASELINE configuration 4,

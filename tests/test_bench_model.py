@@ -105,6 +105,20 @@ def test_cpu_baseline_legs_of_the_filters_and_the_qp_run_here():
     assert out['value'] > 0 and 0.5 < out['frac_status_1'] < 1.0 and out['mean_qp_iters'] < 12
 
 
+def test_cpu_baseline_leg_of_the_estimator_runs_here():
+    """The C++/OpenMP leg of the C3 MHE line on a reduced sample (no GPU needed)."""
+    from tests.problems import C3B
+    out = _bench().cpu_leg_mhe(C3B, nst=2, per_thread=1)
+    assert out['kind'] == 'port' and out['cores'] >= 1 and out['value'] > 0 and out['one_core_value'] > 0 and out['unit'] == 'steps/s'
+    assert out['frac_status_1_or_2'] == 1.0 and 5 < out['mean_ipm_iters'] < 40
+
+
+def test_cpu_baseline_leg_of_the_prediction_runs_here():
+    import numpy as np
+    out = _bench().cpu_leg_gp(np.stack([np.linspace(0, 40, 512), np.linspace(0, 4, 512)]), budget=.2)
+    assert out['kind'] == 'port' and out['value'] > 0 and out['one_core_value'] > 0 and out['unit'] == 'predictions/s'
+
+
 def test_bench_spawns_one_rank_per_gpu(monkeypatch):
     """`python bench.py --gpus N` without a torchrun environment re-executes itself under torch.distributed.run with N processes
     on 127.0.0.1 (the driver's own launch line) and hands its exit status through."""

@@ -114,3 +114,81 @@ def test_lmpc_qp_vs_oracle():
     assert np.max(np.abs(res['iters'] - np.array([r['iters'] for r in ref]))) <= 1
     ok = st == 1
     np.testing.assert_allclose(res['x'][ok], np.array([r['x'] for r in ref])[ok], atol=1e-7)     # (the oracle polishes the vertex)
+
+
+def test_mhe_window_loop_vs_oracle():
+    """oracle/cpu/mhe_cpu.cpp against oracle/mhe.py::MheIpm on the C3 window (boxed noise: unique minimiser): cold estimate, then
+    the benchmark's loop - a new sample shifts the window, arrival guess = x_2 of the previous solution, warm start = the previous
+    solution.  Same statuses, same iteration counts, same solution."""
+    from oracle.cpu import CpuMhe
+    from oracle.mhe import MheIpm
+    from tests.problems import C3B, c3_data, oracle_mhe
+    spec = dict(C3B, N=12)
+    pb = oracle_mhe(spec)
+    ipm, cpu = MheIpm(pb), CpuMhe(pb)
+    xa, u, y, _ = c3_data(3, N=12, seed=4)
+    rng = np.random.default_rng(8)
+    w, v, npar, nx = None, None, pb.np_, pb.nx
+    for k in range(3):
+        ref = ipm.solve(xa, spec['p'], u, y, w0=w)
+        res = cpu.solve(xa, spec['p'], u, y, v0=v, n_threads=2)
+        assert np.array_equal(res['status'], ref['status']) and np.all(ref['status'] == 1)
+        assert np.all(np.abs(res['iters'] - ref['iters']) <= 1), (res['iters'], ref['iters'])
+        assert np.max(np.abs(res['v'] - ref['v']) / np.maximum(1., np.abs(ref['v']))) < 1e-9
+        np.testing.assert_allclose(res['f'], ref['f'], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(res['x_opt'], ref['x_opt'], rtol=1e-9, atol=1e-11)
+        assert np.all(res['kkt'] <= 1e-8)
+        y = np.concatenate([y[:, 1:], (y[:, -1] + .01 * rng.normal(size=(3, 2)))[:, None]], axis=1)
+        u = np.concatenate([u[:, 1:], u[:, -1:]], axis=1)
+        xa, w, v = ref['v'][:, npar + 2 * nx:npar + 3 * nx] * pb.sx, ref['w'], ref['v']
+
+
+def test_mhe_scaled_variables_and_unboxed_noise_vs_oracle():
+    """Scaling of states, noise and inputs (mhe.py:665-672: costs on un-scaled quantities, u_meas un-divided) and the plain C3
+    weights; the unboxed problem is degenerate in the weakly observable states, so the objective is compared there."""
+    from oracle.cpu import CpuMhe
+    from oracle.mhe import MheIpm
+    from tests.problems import C3, C3B, c3_data, oracle_mhe
+    xa, u, y, _ = c3_data(2, N=10, seed=6)
+    spec = dict(C3B, N=10, x_scaling=[.5, 20., .1, .2], w_scaling=[1e-3, 1e-2, 1e-3, 1e-3], u_scaling=[.1, .05])
+    pb = oracle_mhe(spec)
+    ref, res = MheIpm(pb).solve(xa, spec['p'], u / pb.su, y), CpuMhe(pb).solve(xa, spec['p'], u / pb.su, y)
+    assert np.array_equal(res['status'], ref['status']) and np.all(np.abs(res['iters'] - ref['iters']) <= 1)
+    ok = ref['status'] == 1
+    assert ok.any() and np.max((np.abs(res['v'] - ref['v']) / np.maximum(1., np.abs(ref['v'])))[ok]) < 1e-8
+    pb = oracle_mhe(dict(C3, N=10))
+    ref, res = MheIpm(pb).solve(xa, C3['p'], u, y), CpuMhe(pb).solve(xa, C3['p'], u, y)
+    assert np.array_equal(res['status'], ref['status']) and np.all(np.abs(res['iters'] - ref['iters']) <= 1)
+    np.testing.assert_allclose(res['f'], ref['f'], rtol=1e-8, atol=1e-12)
+
+
+def test_mhe_out_of_scope_descriptor_is_refused():
+    from oracle.cpu import CpuMhe
+    from oracle.mhe import MheProblem
+    with pytest.raises(RuntimeError, match="chemostat4 only"):
+        CpuMhe(MheProblem(models.get('cstr3'), dt=1., N=4))
+
+
+def test_gp_prediction_vs_oracle():
+    """oracle/cpu/gp_cpu.cpp against `Posterior.predict`: mean and variance of the benchmark's posterior (200 points, one length
+    scale per feature) at a column count that is no multiple of the block, and a posterior with one length scale, a constant mean
+    and the noise-free variance."""
+    from oracle import gp as ogp
+    from oracle.cpu import gp_predict
+    from tests.problems import c4_training_data, oracle_c4
+    post = oracle_c4()[1]
+    rng = np.random.default_rng(3)
+    Xq = np.stack([rng.uniform(0, 40, 1003), rng.uniform(0, 4, 1003)])
+    mu, var = post.predict(Xq)
+    mc, vc = gp_predict(post, Xq, n_threads=2)
+    np.testing.assert_allclose(mc, mu[0], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(vc, var[0], rtol=1e-9, atol=1e-12)
+    X, y = c4_training_data()
+    post = ogp.Posterior({'type': 'squared_exponential', 'kwargs': dict(length_scales=3., signal_variance=.7)},
+                         {'type': 'constant', 'kwargs': {'bias': .2}}, X[:, :50], y[:, :50], 1e-3)
+    mu, var = post.predict(Xq[:, :37], noise_free=True)
+    mc, vc = gp_predict(post, Xq[:, :37], noise_free=True, n_threads=1)
+    np.testing.assert_allclose(mc, mu[0], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(vc, var[0], rtol=1e-9, atol=1e-13)
+    with pytest.raises(NotImplementedError):
+        gp_predict(ogp.Posterior({'type': 'matern_32', 'kwargs': {}}, {'type': 'zero'}, X[:, :10], y[:, :10], 1e-3), Xq[:, :3])
