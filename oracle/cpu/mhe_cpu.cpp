@@ -45,12 +45,12 @@ struct MheProblem {
 
 template <class M>
 struct MhePolicy {
-  static constexpr int NX = M::NX, NU = M::NX, NZ = 2 * M::NX, NY = M::NY, NUM = M::NU;
-  static constexpr bool FREE0 = true;
+  static constexpr int NX = M::NX, NU = M::NX, NZ = 2 * M::NX, NY = M::NY, NUM = M::NU, NR = 0;
+  bool free0[NX];                    // x_0 is a variable
   using HD = H2<NX>;
   const MheProblem& pb;
   const double *p = nullptr, *xa = nullptr, *um = nullptr, *ym = nullptr;    // per instance: [np], [nx], [N][nu], [N][ny]
-  explicit MhePolicy(const MheProblem& pb_) : pb(pb_) {}
+  explicit MhePolicy(const MheProblem& pb_) : pb(pb_) { std::fill(free0, free0 + NX, true); }
 
   // Phi_s and the measurement function at the scaled state xs (T = double or HD)
   template <class T>

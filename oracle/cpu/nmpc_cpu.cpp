@@ -75,8 +75,8 @@ void phi_scaled(const Problem& pb, const T* xs, const T* us, const double* p, T*
 // F = the scaled shooting map, x_0 pinned ---------------------------------------------------------------------------------------
 template <class M>
 struct TrackPolicy {
-  static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU;
-  static constexpr bool FREE0 = false;
+  static constexpr int NX = M::NX, NU = M::NU, NZ = NX + NU, NR = 0;
+  bool free0[NX] = {};               // x_0 is the measured state
   using HD = H2<NZ>;
   const Problem& pb;
   const double* p = nullptr;
