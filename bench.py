@@ -213,6 +213,40 @@ def cpu_baseline_c2(spec, nst=50, slsqp=True, pb=None, label='C2', per_thread=64
             "host_cpus": os.cpu_count()}
 
 
+def cpu_leg_c5(spec, nst=20, per_thread=32):
+    """oracle/cpu/pf_cpu.cpp (C++17 / OpenMP: C5's transcription - path variable, soft speed limit - on the Riccati interior point of
+    the other legs in the form the device engine uses, validated against oracle/nmpc_gen.py::GenIpm in tests/test_cpu_baseline.py)
+    on the benchmark's own closed loop: warm-started from the previous solution, state advanced by the plant."""
+    C, quota = host_cores()
+    from oracle.cpu import CpuPathNmpc
+    from tests import problems as P
+    cpu = CpuPathNmpc(spec, P.oracle_gen(spec))
+
+    def loop(nb, nt, nst=nst, nwarm=3):
+        xs, w, t0, its = P.c5_x0(nb), None, 0.0, []
+        for k in range(nwarm + nst):
+            if k == nwarm:
+                t0 = time.perf_counter()
+            r = cpu.solve(xs, w0=w, n_threads=nt)
+            xs, w = cpu.plant_step(xs, r['u0'], n_threads=nt), r['w']
+            if k >= nwarm:
+                its.append(r['iters'].mean())
+        secs = time.perf_counter() - t0
+        return nb * nst / secs, secs, float(np.mean(its)), float(np.mean((r['status'] == 1) | (r['status'] == 2)))
+    nb_all = max(min(64, 16 * per_thread), per_thread * C)
+    v_all, s_all, it_all, ok_all = loop(nb_all, C)
+    n_one, n_inst_one = min(nst, 5), max(1, min(2 * per_thread, 16))
+    v_one, s_one, _, _ = loop(n_inst_one, 1, nst=n_one)
+    return {"value": v_all, "unit": "steps/s", "cores": C, "kind": "port", "one_core_value": v_one,
+            "cpu_model": cpu_model_name(), "cgroup_cpu_quota": quota, "sched_affinity_cpus": len(os.sched_getaffinity(0)),
+            "mean_ipm_iters": it_all, "frac_status_1_or_2": ok_all,
+            "sample": f"oracle/cpu C++17/OpenMP Riccati interior point on C5's transcription (path variable and slack as engine states, "
+                      f"inequality rows with IPOPT's slacks; validated against the dense numpy oracle): closed loop, {nb_all} instances "
+                      f"x {nst} warm-started steps on {C} pinned threads = min(OpenMP, affinity, cgroup quota) ({s_all:.1f} s); "
+                      f"one_core_value: {n_inst_one} instances x {n_one} steps on 1 thread ({s_one:.1f} s); the reference's "
+                      f"CasADi/IPOPT is not installable", "host_cpus": os.cpu_count()}
+
+
 def cpu_leg_mhe(spec, nst=40, per_thread=128):
     """oracle/cpu/mhe_cpu.cpp (C++17 / OpenMP: the estimator's transcription on the Riccati interior point of the NMPC leg, validated
     against oracle/mhe.py in tests/test_cpu_baseline.py) on the benchmark's own loop: window filled, one cold estimate, then per step
@@ -400,17 +434,8 @@ def wl_nmpc(cfg, args, torch, dev, rank, world):
     def cpu():
         if cfg == 'C2':
             return cpu_baseline_c2(spec)
-        t0 = time.perf_counter()
         if cfg == 'C5':
-            from oracle.nmpc_gen import GenIpm
-            pb = P.oracle_gen(spec)
-            ipm, ns, nst = GenIpm(pb), 2, 1
-            xs = P.c5_x0(ns)
-            res = ipm.solve(xs, spec['p'])
-            t0 = time.perf_counter()
-            for _ in range(nst):
-                res = ipm.solve(xs, spec['p'], w0=res['w'])
-            what = "GenIpm (dense KKT, numpy)"
+            return cpu_leg_c5(spec)
         else:
             # the C++ baseline with the learned growth rate (oracle/cpu/models_cpu.h::Chemostat4Gp, validated against the numpy oracle)
             from oracle.cpu import set_gp
@@ -418,10 +443,6 @@ def wl_nmpc(cfg, args, torch, dev, rank, world):
             Xtr, _ = P.c4_training_data()
             set_gp(Xtr, post.alpha, P.C4_GP['length_scales'], P.C4_GP['signal_variance'])
             return cpu_baseline_c2(spec, nst=10, slsqp=False, pb=pb, label='C4 (200 kernel terms per right-hand side)', per_thread=8)
-        secs = time.perf_counter() - t0
-        return {"value": ns * nst / secs, "unit": "steps/s", "cores": 1, "kind": "port",
-                "sample": f"{ns} instances x {nst} warm-started steps of the same {cfg} workload with the oracle's {what} "
-                          f"({secs:.1f} s); the reference's CasADi/IPOPT is not installable", "host_cpus": os.cpu_count()}
     return dict(step=step, finish=finish, units=B, cpu=cpu, unit="steps/s",
                 metric="MPC steps/sec (batched instances, whole node) at fixed (nx,nu,N)")
 

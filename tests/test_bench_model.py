@@ -113,6 +113,14 @@ def test_cpu_baseline_leg_of_the_estimator_runs_here():
     assert out['frac_status_1_or_2'] == 1.0 and 5 < out['mean_ipm_iters'] < 40
 
 
+def test_cpu_baseline_leg_of_c5_runs_here():
+    """The C++/OpenMP leg of the C5 line on a reduced sample (no GPU needed)."""
+    from tests.problems import C5
+    out = _bench().cpu_leg_c5(dict(C5, N=12), nst=2, per_thread=1)
+    assert out['kind'] == 'port' and out['cores'] >= 1 and out['value'] > 0 and out['one_core_value'] > 0 and out['unit'] == 'steps/s'
+    assert out['frac_status_1_or_2'] == 1.0 and 3 < out['mean_ipm_iters'] < 60
+
+
 def test_cpu_baseline_leg_of_the_prediction_runs_here():
     import numpy as np
     out = _bench().cpu_leg_gp(np.stack([np.linspace(0, 40, 512), np.linspace(0, 4, 512)]), budget=.2)

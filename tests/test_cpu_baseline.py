@@ -192,3 +192,41 @@ def test_gp_prediction_vs_oracle():
     np.testing.assert_allclose(vc, var[0], rtol=1e-9, atol=1e-13)
     with pytest.raises(NotImplementedError):
         gp_predict(ogp.Posterior({'type': 'matern_32', 'kwargs': {}}, {'type': 'zero'}, X[:, :10], y[:, :10], 1e-3), Xq[:, :3])
+
+
+def test_path_following_with_soft_constraint_vs_oracle():
+    """oracle/cpu/pf_cpu.cpp against oracle/nmpc_gen.py::GenIpm on C5 with a short horizon: cold, then two warm-started steps of
+    the closed loop.  The C++ solver carries the shared slack as a state (the device engine's form), so the multipliers and the
+    iteration path need not be the dense solver's: statuses, minimiser, objective and first input are compared."""
+    from oracle.cpu import CpuPathNmpc
+    from oracle.nmpc_gen import GenIpm
+    from tests.problems import C5S, c5_x0, oracle_gen
+    pb = oracle_gen(C5S)
+    ipm, cpu = GenIpm(pb), CpuPathNmpc(C5S, pb)
+    x0, w_ref, w = c5_x0(3), None, None
+    x0[0, [1, 3]] = 1.6, 1.3                  # over the speed limit at k = 0: the slack has to open
+    for k in range(3):
+        ref = ipm.solve(x0, C5S['p'], w0=w_ref)
+        res = cpu.solve(x0, w0=w, n_threads=2)
+        vr = ipm.to_v(ref)
+        assert np.array_equal(res['status'], ref['status']) and np.all(ref['status'] == 1)
+        assert np.all(np.abs(res['iters'] - ref['iters']) <= 3), (res['iters'], ref['iters'])
+        assert np.max(np.abs(res['v'] - vr) / np.maximum(1., np.abs(vr))) < 1e-6
+        np.testing.assert_allclose(res['f'], ref['f'], rtol=1e-7, atol=1e-10)       # both at tol = 1e-8, penalty weight 1e4
+        np.testing.assert_allclose(res['u0'], ref['u0'], rtol=1e-6, atol=1e-7)
+        assert np.all(res['kkt'] <= 1e-8)
+        if k == 0:
+            assert res['v'][0, -1] > .2 and abs(res['v'][0, -1] - ref['E'][0, 0]) < 1e-7
+        xn = pb.phi(np.atleast_2d(x0), ref['U'][:, 0, :pb.nu], C5S['p'])
+        np.testing.assert_allclose(cpu.plant_step(x0, ref['u0']), xn, rtol=1e-12, atol=1e-13)
+        x0, w_ref, w = xn, ref['w'][:, :ipm.o_s], res['w']
+
+
+def test_path_following_out_of_scope_is_refused():
+    from oracle.cpu import CpuPathNmpc
+    from tests.problems import C2S, C5S, oracle_gen
+    with pytest.raises(NotImplementedError):
+        CpuPathNmpc(C2S, oracle_gen(C2S))
+    spec = dict(C5S, constraint=dict(C5S['constraint'], expr=['vx**2 - vy']))
+    with pytest.raises(NotImplementedError):
+        CpuPathNmpc(spec, oracle_gen(spec))
