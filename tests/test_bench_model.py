@@ -81,8 +81,8 @@ def test_round_3_profiles_are_consistent_with_their_bench_lines():
         assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['bound'] in ('hbm', 'mfma'), cfg
         cb = line['cpu_baseline']
         assert set(cb) >= {'value', 'unit', 'cores', 'kind', 'sample'}, cfg
-        if cfg in ('C1', 'C2', 'C3-ekf', 'C3-ukf', 'C4'):          # the C++ / OpenMP legs: true core count, one-core figure next to it
-            assert cb['cores'] >= 1 and cb['one_core_value'] > 0 and 'C++17' in cb['sample'], cfg
+        # every line carries a C++ / OpenMP leg: true core count, one-core figure next to it
+        assert cb['cores'] >= 1 and cb['one_core_value'] > 0 and 'C++17' in cb['sample'], cfg
         assert line['config']['name'] == cfg and line['n_gpus'] == 1 and line['vs_baseline'] is None
 
 
