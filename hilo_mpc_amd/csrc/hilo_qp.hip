@@ -673,6 +673,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   gmax = qp_wave_max(gmax);
   __syncthreads();
 
+  // H (after the substitution of the fixed variables) diagonal - the LMPC's block of diagonal weights (mpc.py:2307-2330 with
+  // diagonal Q, R, P): H + Sigma is diagonal as well, its factor and L^-1 A^T are one scaling per row, no factorisation
+  bool hdiag;
+  {
+    double off = 0.0;
+    const qp_lds_cd hrow = qp_vbase(Hf + (t < NP ? t : NP - 1) * ldn);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) off = fmax(off, (j == (t < NP ? t : NP - 1)) ? 0.0 : fabs(hrow[j]));
+    hdiag = __all((int)(off == 0.0));
+  }
+
   int st = HILO_STATUS_MAXITER, it = 0;
   double phi_min = INFINITY;
   QP_TICK0();
@@ -717,6 +728,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (phi >= 1.0e4 * phi_min) { st = HILO_STATUS_INFEASIBLE; break; }
 
     QP_TICK(1);
+    double dil = 0.0;                              // hdiag: this lane's entry of the diagonal L^-1
+    if (hdiag) {
+      double d = Hf[tr * ldn + tr];
+      if (!isnan(l[tr])) {
+        d += qd.reg;
+        const double lo = l[tr], up = u[tr], xv = x[tr];
+        if (lo > -INFINITY) d += zl[tr] / (xv - lo);
+        if (up < INFINITY) d += zu[tr] / (up - xv);
+      }
+      if (!__all((int)(d > 0.0 && isfinite(d)))) { st = HILO_STATUS_OTHER; break; }
+      dil = qp_rsq(d);
+      if (t < NP) {
+        const qp_lds_cd acol = qp_vbase(Af + t);
+#pragma unroll
+        for (int r = 0; r < MP; ++r) X[t * ldm + r] = acol[r * ldn] * dil;
+      }
+      __syncthreads();
+    QP_TICK(2);
+    } else {
     // ---- M = Hf + Sigma + reg: row i in lane i (lanes >= NP mirror the last row), factored in registers ----
     bool okf;
     {
@@ -768,6 +798,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       }
     }
     __syncthreads();
+    }
     QP_TICK(3);
     // ---- Schur complement S = X^T X + reg: row a accumulated in lane a (the rows of X broadcast), factored in registers ----
     bool oks;
@@ -813,7 +844,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       }
       __syncthreads();
       {                                              // tv = L^-1 r1  (L^-1: zeros above the diagonal)
-        const double s = qp_dot<NP>(Lm + tr * ldn, r1);
+        const double s = hdiag ? dil * r1[tr] : qp_dot<NP>(Lm + tr * ldn, r1);
         if (t < n) tv[t] = s;
       }
       __syncthreads();
@@ -839,7 +870,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       }
       __syncthreads();
       {                                              // dx = L^-T tv
-        const double s = qp_dot_col<NP>(Lm + tr, ldn, tv);
+        const double s = hdiag ? dil * tv[tr] : qp_dot_col<NP>(Lm + tr, ldn, tv);
         if (t < n) r1[t] = s;
       }
       __syncthreads();

@@ -8,11 +8,14 @@ from oracle.lmpc import LmpcProblem, lmpc_optimize             # noqa: E402
 from tests.test_oracle_lmpc import A, B, C1, DT                # noqa: E402
 
 
-def product_lmpc(kron_variant, N=10):
+QD = np.array([[2., .5], [.5, 1.]])                            # a state weight with off-diagonal entries: H is not diagonal
+
+
+def product_lmpc(kron_variant, N=10, Q=None):
     from hilo_mpc_amd import LMPC, Model
     m = Model('lti', A=A, B=B).setup(dt=DT)                     # tests/test_LMPC.py:8-19
     mpc = LMPC(m)
-    mpc.Q = np.eye(2)
+    mpc.Q = np.eye(2) if Q is None else Q
     mpc.R = 1
     mpc.horizon = N
     mpc.set_box_constraints(x_lb=[-5, -5], x_ub=[5, 5], u_lb=[-1], u_ub=[1])
@@ -99,17 +102,20 @@ def test_long_horizon_qp_in_global_workspace(N):
     np.testing.assert_allclose(mpc._nlp_solution['x'].cpu().numpy()[ok], ref['v'][ok], atol=1e-6)
 
 
-@pytest.mark.parametrize('N,variant', [(10, 'reference'), (20, 'corrected'), (20, 'reference'), (14, 'corrected')])
-def test_register_resident_kernel_equals_the_lds_column_kernel(N, variant, monkeypatch):
+@pytest.mark.parametrize('N,variant,Q', [(10, 'reference', None), (20, 'corrected', None), (20, 'reference', None),
+                                         (14, 'corrected', None), (10, 'corrected', QD), (20, 'corrected', QD)])
+def test_register_resident_kernel_equals_the_lds_column_kernel(N, variant, Q, monkeypatch):
     """Round 3: QPs with n, m <= 64 run on qp_solve_reg_kernel<NP, MP> (dimensions padded to 32 / 64 and 24 .. 64, factorisations in registers, inverse factors); the first
     kernel (columns through LDS, HILO_QP_LDS_COLUMNS=1) solves the same iteration - same statuses and iteration counts, solutions
-    to round-off; and the oracle agrees.  N = 20 (n = 62, m = 40) exercises the two-pass column scheme of the 64-wide variant."""
+    to round-off; and the oracle agrees.  N = 20 (n = 62, m = 40) exercises the two-pass column scheme of the 64-wide variant.
+    Diagonal weights (Q = I: H + Sigma diagonal, the factorisation is one scaling per row) and a weight with off-diagonal entries
+    (the general path: H + Sigma factored in registers)."""
     rng = np.random.default_rng(11)
     x0 = rng.uniform(-1.5, 1.5, (48, 2))
-    fast = product_lmpc(variant, N=N)
+    fast = product_lmpc(variant, N=N, Q=Q)
     uf = fast.optimize(x0)
     monkeypatch.setenv('HILO_QP_LDS_COLUMNS', '1')
-    slow = product_lmpc(variant, N=N)
+    slow = product_lmpc(variant, N=N, Q=Q)
     us = slow.optimize(x0)
     assert np.array_equal(fast.solver_status_code, slow.solver_status_code)
     ok = fast.solver_status_code == 1
@@ -120,7 +126,7 @@ def test_register_resident_kernel_equals_the_lds_column_kernel(N, variant, monke
     np.testing.assert_allclose(fast._nlp_solution['x'].cpu().numpy()[ok], slow._nlp_solution['x'].cpu().numpy()[ok], atol=1e-8)
     np.testing.assert_allclose(fast._nlp_solution['lam_a'].cpu().numpy()[ok], slow._nlp_solution['lam_a'].cpu().numpy()[ok],
                                rtol=1e-6, atol=1e-7)
-    ref = lmpc_optimize(LmpcProblem(**dict(C1, N=N), kron_bug=(variant == 'reference')), x0)
+    ref = lmpc_optimize(LmpcProblem(**dict(C1, N=N, **({} if Q is None else {'Q': Q})), kron_bug=(variant == 'reference')), x0)
     both = ok & (ref['status'] == 1)
     assert both.sum() >= 24
     np.testing.assert_allclose(uf[both], ref['u'][both], rtol=1e-6, atol=1e-5)   # (longer horizons: degenerate vertices, polish)
