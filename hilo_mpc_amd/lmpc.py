@@ -21,12 +21,14 @@ class LMPC:
     _solver_name_list_qp = ['qpoases', 'hip_qp']
 
     def __init__(self, model, id=None, name=None, plot_backend=None, device_index=None):
-        if getattr(model, '_symbolic', False):
-            raise NotImplementedError("LMPC takes the matrices of the system: Model('lti', A=..., B=..., C=...)")
+        sym = getattr(model, '_symbolic', False)
         if model.name != 'lti' and not model.is_linear():
             raise TypeError("The model is nonlinear. Use the NMPC class or linearize the model.")
-        if model.name != 'lti':
-            raise NotImplementedError("LMPC needs an explicit LTI model: Model('lti', A=..., B=...)")
+        if model.name != 'lti' and not sym:
+            raise NotImplementedError("LMPC needs the matrices of the system: Model('lti', A=..., B=...) or a linear / linearised "
+                                      "model written as expressions")
+        if sym and not model.discrete:
+            raise NotImplementedError("LMPC predicts with x+ = A x + B u: discretize the model first (Model.discretize)")
         if not model._is_setup:
             model.setup()
         self._model = model
@@ -114,7 +116,9 @@ class LMPC:
         if kron_variant not in ('reference', 'corrected'):
             raise ValueError("kron_variant must be 'reference' or 'corrected'")
         N, nx, nu = self._horizon, self._n_x, self._n_u
-        A, B = self._model.A, self._model.B
+        # mpc.py:2183-2184: `state_matrix`, `input_matrix` of the model - of a model written as expressions the Jacobians of its
+        # (discretised) equations at the equilibrium point, with the parameter values of `set_initial_parameter_values`
+        A, B, _ = self._model.system_matrices()
         Q = np.zeros((nx, nx)) if self._Q is None else self._Q                                  # mpc.py:2188-2193
         P = np.zeros((nx, nx)) if self._P is None else self._P
         R = np.zeros((nu, nu)) if self._R is None else self._R
@@ -172,7 +176,17 @@ class LMPC:
             raise ValueError("Howdy! You need to setup the MPC before optimizing. Run .setup() on the MPC object.")
         if tvp is not None:
             raise NotImplementedError("time-varying parameters are not yet offloaded")
-        if cp is not None:
+        n_cp = self._model.n_p if getattr(self._model, '_symbolic', False) else 0
+        if n_cp:
+            # constant parameters (mpc.py:2316-2326): the matrices of the QP are those of the values given to
+            # `Model.set_initial_parameter_values` before setup(); other values per call would be another QP
+            if cp is None or np.asarray(cp, dtype=float).size != n_cp:
+                raise ValueError(f"The model has {n_cp} constant parameter(s): {self._model.parameter_names}. You must pass me "
+                                 f"the value of these before running the optimization to the 'cp' parameter.")
+            if not np.array_equal(np.asarray(cp, dtype=float).ravel(), self._model._p_init):
+                raise NotImplementedError("parameter values other than those of Model.set_initial_parameter_values (the matrices "
+                                          "of the QP are assembled at setup): set them on the model and run setup() again")
+        elif cp is not None:
             warnings.warn("You are passing a parameter vector in the optimizer, but the model has no defined "
                           "parameters. I am ignoring the vector.")
         host = not isinstance(x0, torch.Tensor)

@@ -278,7 +278,114 @@ class Model:
         return codegen.zoo_alias(ZOO_FUNCTOR[self.name])
 
     def is_linear(self):
-        return self._linear
+        """dynamic_model.py `is_linear`: a model of the zoo by its table; a model written as expressions when it was linearised or
+        when the Jacobian of its equations with respect to states and inputs holds neither."""
+        if not self._symbolic:
+            return self._linear
+        if getattr(self, '_linearized', False):
+            return True
+        if self._ode is None or self.n_z:
+            return False
+        from .symdiff import Dag
+        g, memo = Dag(), {}
+        rows = [g.from_expr(e, memo) for e in list(self._ode) + list(self._meas)]
+        w = [g.var('x', i) for i in range(self.n_x)] + [g.var('u', i) for i in range(self.n_u)]
+        jac = [g.diff(r, v) for r in rows for v in w]
+        need, stack = set(), list(jac)
+        while stack:
+            i = stack.pop()
+            if i not in need:
+                need.add(i)
+                stack += [c for c in g.nodes[i][1:3] if c >= 0]
+        return not any(g.nodes[i][0] in ('x', 'u') for i in need)
+
+    # ---- linearisation (dynamic_model.py:2488-2612, :3670-3684) and the matrices the linear MPC reads (mpc.py:2183-2184) -----------
+    def linearize(self, name=None, trajectory=None):
+        """The model linearised about its equilibrium point (`set_equilibrium_point`, default: the origin): a copy that reports
+        `is_linear()` and hands out `state_matrix`, `input_matrix`, `output_matrix` - the Jacobians of the equations (of the
+        explicit Runge-Kutta step when the model was discretised first, like in tests/test_LMPC.py:82-85) with respect to states
+        and inputs, in deviation variables."""
+        if not self._symbolic:
+            if self._linear:
+                print("Model is already linear. Linearization is not necessary. Nothing to be done.")
+                return self
+            raise NotImplementedError("the models of the device zoo carry no expressions to linearise")
+        if trajectory is not None:
+            raise NotImplementedError("linearisation along a trajectory is not built")
+        if self._ode is None:
+            print("Model is empty. Nothing to be done.")
+            return self
+        if getattr(self, '_linearized', False):
+            print("Model is already linearized. Nothing to be done.")
+            return self
+        if self.is_linear():
+            print("Model is already linear. Linearization is not necessary. Nothing to be done.")
+            return self
+        if self.n_z:
+            raise NotImplementedError("linearisation of a model with algebraic states is not built")
+        m = self.copy()
+        if name is not None:
+            m.name = name
+        m._linearized = True
+        m._x_eq = m._u_eq = None
+        return m
+
+    def set_equilibrium_point(self, x_eq=None, u_eq=None, z_eq=None):
+        """dynamic_model.py `set_equilibrium_point`: where the Jacobians of a linearised model are taken."""
+        def chk(v, n, what):
+            if v is None:
+                return None
+            v = np.asarray(v, dtype=float).ravel()
+            if v.size != n:
+                raise ValueError(f"Dimension mismatch: the equilibrium point of the {what} has {v.size} entries, the model {n}")
+            return v
+        self._x_eq, self._u_eq = chk(x_eq, self.n_x, 'states'), chk(u_eq, self.n_u, 'inputs')
+
+    def set_initial_parameter_values(self, p=None):
+        """dynamic_model.py `set_initial_parameter_values` (here: the values the system matrices are evaluated with when none
+        are handed over)."""
+        p = np.asarray([] if p is None else p, dtype=float).ravel()
+        if p.size != self.n_p:
+            raise ValueError(f"Dimension mismatch: {p.size} parameter values for {self.n_p} parameters")
+        self._p_init = p
+
+    def system_matrices(self, p=None):
+        """(A, B, C) of a linear (or linearised) model: numeric Jacobians of x+ = f(x, u, p) (a discrete or discretised model) or
+        dx/dt = f (a continuous one that was not discretised) and of y = h(x, u, p) at the equilibrium point."""
+        if not self._symbolic:
+            if self.name == 'lti':
+                return self.A, self.B, self.C
+            raise NotImplementedError("the models of the device zoo carry no expressions to differentiate")
+        if not self.is_linear():
+            raise RuntimeError("The model is nonlinear: linearize it first (Model.linearize)")
+        if self.discrete and not self._native_discrete and self.dt is None:
+            raise RuntimeError("Model is not set up. Run Model.setup(dt=...) before asking for the matrices of a discretised model.")
+        if self.n_p:
+            p = getattr(self, '_p_init', None) if p is None else np.asarray(p, dtype=float).ravel()
+            if p is None or p.size != self.n_p:
+                raise ValueError(f"The model has {self.n_p} parameter(s): {self.parameter_names}. Their values are needed for "
+                                 f"the system matrices (argument `p` / set_initial_parameter_values).")
+        else:
+            p = np.zeros(0)
+        from .smpc import SMPC
+        from .symdiff import Dag
+        fx = SMPC._discrete_map(self, self.dt) if self.discrete else list(self._ode)
+        g, memo = Dag(), {}
+        rows = [g.from_expr(e, memo) for e in list(fx) + list(self._meas)]
+        w = [g.var('x', i) for i in range(self.n_x)] + [g.var('u', i) for i in range(self.n_u)]
+        jac = [g.diff(r, v) for r in rows for v in w]
+        xe = getattr(self, '_x_eq', None)
+        ue = getattr(self, '_u_eq', None)
+        xe = np.zeros(self.n_x) if xe is None else xe
+        ue = np.zeros(self.n_u) if ue is None else ue
+        J = np.array(g.evaluate(jac, xe, ue, p), dtype=float).reshape(len(rows), self.n_x + self.n_u)
+        nx = self.n_x
+        C = J[nx:, :nx] if len(self._meas) else np.eye(nx)
+        return J[:nx, :nx], J[:nx, nx:], C
+
+    state_matrix = property(lambda s: s.system_matrices()[0])
+    input_matrix = property(lambda s: s.system_matrices()[1])
+    output_matrix = property(lambda s: s.system_matrices()[2])
 
     def lti_parameters(self):
         return np.concatenate([self.A.ravel(), self.B.ravel(), self.C.ravel()])

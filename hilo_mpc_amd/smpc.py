@@ -116,10 +116,11 @@ class SMPC(NMPC):
 
     # ---- the surrogate (mpc.py:2512-2614) ------------------------------------------------------------------------------------
     @staticmethod
-    def _discrete_map(m):
+    def _discrete_map(m, dt=1.0):
         """Expressions of x+ of the model: the equations of a discrete model; the explicit Runge-Kutta step of a discretised
         one written out (modeling.py:1213-1281; the reference discretises symbolically, so `det_model.ode` IS this map).  The
-        step size is the SURROGATE's dt = 1 (mpc.py:2483, :2557), whatever the model was set up with."""
+        step size is the SURROGATE's dt = 1 (mpc.py:2483, :2557), whatever the model was set up with; `Model.linearize` hands
+        over the model's own."""
         if not getattr(m, '_symbolic', False):
             raise NotImplementedError("SMPC needs a model written as expressions (set_dynamical_equations); the models of the "
                                       "device zoo carry no expressions to linearise")
@@ -130,7 +131,7 @@ class SMPC(NMPC):
         if m._native_discrete or m.erk_order == 0:
             return list(m._ode)
         A, b = _ERK[m.erk_order]
-        h = 1.0 / m.n_sub
+        h = float(dt) / m.n_sub
         xs = list(m.x)
         cur = list(xs)
         for _ in range(m.n_sub):

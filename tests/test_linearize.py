@@ -1,0 +1,101 @@
+"""`Model.linearize` / `state_matrix` / `input_matrix` for models written as expressions (dynamic_model.py:2488-2612, :3670-3684) and
+what the linear MPC accepts (mpc.py:2183-2184; the models of tests/test_LMPC.py).  Host logic: no GPU."""
+import numpy as np
+import pytest
+
+from hilo_mpc_amd import LMPC, Model, expr
+
+
+def _double_integrator(dt=.5):
+    m = Model(discrete=True)
+    x = m.set_dynamical_states(['x_0', 'x_1'])
+    u = m.set_inputs(['u'])
+    m.set_dynamical_equations([x[0] + dt * x[1] + dt ** 2 / 2 * u[0], x[1] + dt * u[0]])
+    m.setup(dt=dt)
+    return m
+
+
+def _bicycle(with_parameters=False):
+    """tests/test_LMPC.py:58-88 (:118-152 with the lengths as parameters)."""
+    m = Model()
+    s = m.set_dynamical_states(['px', 'py', 'v', 'phi'])
+    i = m.set_inputs(['a', 'delta'])
+    if with_parameters:
+        q = m.set_parameters(['lr', 'lf'])
+        lr, lf = q[0], q[1]
+    else:
+        lr, lf = 1.4, 1.8
+    beta = expr.atan(lr / (lr + lf) * expr.tan(i[1]))
+    m.set_dynamical_equations([s[2] * expr.cos(s[3] + beta), s[2] * expr.sin(s[3] + beta), i[0], s[2] / lr * expr.sin(beta)])
+    m.discretize('rk4', inplace=True)
+    return m
+
+
+def _bicycle_rk4(x, u, h, lr=1.4, lf=1.8):
+    def f(x):
+        beta = np.arctan(lr / (lr + lf) * np.tan(u[1]))
+        return np.array([x[2] * np.cos(x[3] + beta), x[2] * np.sin(x[3] + beta), u[0], x[2] / lr * np.sin(beta)])
+    k1 = f(x)
+    k2 = f(x + h / 2 * k1)
+    k3 = f(x + h / 2 * k2)
+    k4 = f(x + h * k3)
+    return x + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+
+
+def test_linear_model_written_as_expressions_gives_its_matrices():
+    m = _double_integrator()
+    assert m.is_linear()
+    A, B, C = m.system_matrices()
+    np.testing.assert_array_equal(A, [[1., .5], [0., 1.]])           # tests/test_LMPC.py:12-13
+    np.testing.assert_array_equal(B, [[.125], [.5]])
+    np.testing.assert_array_equal(C, np.eye(2))
+    np.testing.assert_array_equal(m.state_matrix, A)
+    np.testing.assert_array_equal(m.input_matrix, B)
+    assert m.linearize() is m                                         # "Model is already linear"
+
+
+@pytest.mark.parametrize('with_parameters', [False, True])
+def test_linearised_bicycle_equals_the_finite_differences_of_its_runge_kutta_step(with_parameters):
+    m = _bicycle(with_parameters)
+    assert not m.is_linear()
+    ml = m.linearize()
+    assert ml.is_linear() and not m.is_linear() and ml.linearize() is ml
+    ml.setup(dt=.05)
+    if with_parameters:
+        with pytest.raises(ValueError, match="parameter"):
+            ml.system_matrices()
+        ml.set_initial_parameter_values(p=[1.4, 1.8])
+    ml.set_equilibrium_point(x_eq=[0, 0, 0, 0], u_eq=[0, 0])
+    A, B, _ = ml.system_matrices()
+    np.testing.assert_allclose(A, [[1, 0, .05, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], atol=1e-15)
+    np.testing.assert_allclose(B[:, 0], [.00125, 0, .05, 0], atol=1e-15)
+    xe, ue = np.array([.3, -.2, 2., .3]), np.array([.4, .1])
+    ml.set_equilibrium_point(x_eq=xe, u_eq=ue)
+    A, B, _ = ml.system_matrices()
+    h, fd = 1e-6, np.empty((4, 6))
+    for j in range(6):
+        e = np.zeros(6)
+        e[j] = h
+        fd[:, j] = (_bicycle_rk4(xe + e[:4], ue + e[4:], .05) - _bicycle_rk4(xe - e[:4], ue - e[4:], .05)) / (2 * h)
+    np.testing.assert_allclose(np.hstack([A, B]), fd, rtol=1e-7, atol=1e-9)
+    with pytest.raises(ValueError, match="Dimension mismatch"):
+        ml.set_equilibrium_point(x_eq=[0, 0, 0], u_eq=[0, 0])
+
+
+def test_what_the_linear_mpc_accepts():
+    LMPC(_double_integrator())
+    ml = _bicycle().linearize()
+    ml.setup(dt=.05)
+    LMPC(ml)
+    with pytest.raises(TypeError, match="nonlinear"):                 # mpc.py: "The model is nonlinear. Use the NMPC class ..."
+        LMPC(_bicycle())
+    mc = Model()
+    x = mc.set_dynamical_states(['x'])
+    u = mc.set_inputs(['u'])
+    mc.set_dynamical_equations([-2. * x[0] + u[0]])
+    assert mc.is_linear()
+    np.testing.assert_array_equal(mc.system_matrices()[0], [[-2.]])   # a continuous model: the matrices of dx/dt
+    with pytest.raises(NotImplementedError, match="discretize"):
+        LMPC(mc)
+    with pytest.raises(NotImplementedError):
+        Model('chemostat4').linearize()

@@ -148,3 +148,38 @@ def test_infeasible_states_are_reported_early(lds_columns, monkeypatch):
     assert (st == 3).sum() >= 20 and (st == 1).sum() >= 100 and set(np.unique(st)) == {1, 3}
     it = mpc._nlp_solution['iter_count'].cpu().numpy()
     assert it[st == 3].max() <= 15 and np.max(np.abs(it - ref['iters'])) <= 1
+
+
+def test_models_written_as_expressions():
+    """A linear model written as expressions gives the QP of the same system handed over as matrices (tests/test_LMPC.py:8-19),
+    bit for bit; the linearised bicycle of tests/test_LMPC.py:58-116 (discretised, linearised about the origin) and its variant
+    with constant parameters (:118-168) set up and solve."""
+    from hilo_mpc_amd import LMPC, Model
+    from tests.test_linearize import _bicycle, _double_integrator
+    ref = product_lmpc('corrected')
+    mpc = LMPC(_double_integrator(DT))
+    mpc.Q, mpc.R, mpc.horizon = np.eye(2), 1, 10
+    mpc.set_box_constraints(x_lb=[-5, -5], x_ub=[5, 5], u_lb=[-1], u_ub=[1])
+    mpc.setup(kron_variant='corrected')
+    np.testing.assert_array_equal(mpc._Ad.cpu().numpy(), ref._Ad.cpu().numpy())
+    x0 = np.random.default_rng(5).uniform(-1.5, 1.5, (16, 2))
+    np.testing.assert_array_equal(mpc.optimize(x0), ref.optimize(x0))
+    for with_parameters in (False, True):
+        ml = _bicycle(with_parameters).linearize()
+        ml.setup(dt=.05)
+        if with_parameters:
+            ml.set_initial_parameter_values(p=[1.4, 1.8])
+        ml.set_equilibrium_point(x_eq=[0, 0, 0, 0], u_eq=[0, 0])
+        mpc = LMPC(ml)
+        mpc.horizon = 10
+        mpc.Q, mpc.R = np.eye(4), np.eye(2)
+        mpc.setup(kron_variant='corrected')
+        cp = [1.4, 1.8] if with_parameters else None
+        u = mpc.optimize([.5, 0, 0, 0], cp=cp)                      # tests/test_LMPC.py:113, :167
+        assert u.shape == (2, 1) and mpc.solver_status_code[0] == 1
+        X, U = mpc.return_prediction()
+        A, B, _ = ml.system_matrices()
+        np.testing.assert_allclose(X[0][:, 1:], A @ X[0][:, :-1] + B @ U[0], atol=1e-9)     # the prediction obeys x+ = A x + B u
+        if with_parameters:
+            with pytest.raises(ValueError, match="constant parameter"):
+                mpc.optimize([.5, 0, 0, 0])
