@@ -43,6 +43,7 @@ class LMPC:
         self._n_iterations = 0
         self._nlp_solution = None
         self._sampling_interval = model.dt
+        self._time_varying_parameters, self._time_varying_parameters_values, self._tvp_window = [], None, None
 
     type = 'LMPC'
 
@@ -106,6 +107,106 @@ class LMPC:
         self._x_scaling = None if x_scaling is None else _wrap_list(x_scaling)
         self._u_scaling = None if u_scaling is None else _wrap_list(u_scaling)
 
+    def set_time_varying_parameters(self, names=None, values=None):
+        """optimizer.py:1519-1560 (see NMPC.set_time_varying_parameters): parameters of the model whose value changes along the
+        horizon - the prediction then uses A(p_k), B(p_k) per stage (mpc.py:2200-2206, :2236-2240)."""
+        if names is None:
+            names = []
+        if not (isinstance(names, (list, tuple)) and all(isinstance(n, str) for n in names)):
+            raise ValueError('Tvp must be a list of strings with the paramers name that are time varying')
+        for tvp in names:
+            if tvp not in self._model.parameter_names:
+                raise ValueError(f"I could not find the parameter {tvp} in the model. The models parameters are "
+                                 f"{self._model.parameter_names}.")
+        if values is not None:
+            if not isinstance(values, dict):
+                raise TypeError("The values parameter must be a dictionary.")
+            for key in values:
+                if key not in names:
+                    raise ValueError(f"The key {key} is not in the name vector: {names}. You need to pass a dictionary "
+                                     f"where the keys are the name of the time varying parameters.")
+        self._time_varying_parameters, self._time_varying_parameters_values, self._tvp_window = list(names), values, None
+
+    n_tvp = property(lambda s: len(s._time_varying_parameters))
+
+    def _n_par(self):
+        return self._model.n_p if getattr(self._model, '_symbolic', False) else 0
+
+    def _equality_matrix(self, As, Bs, kron_variant):
+        """Aeq of mpc.py:2198-2245 from the stage matrices: one (A, B) for all stages - `kron(I, A)` and the input block of the
+        parameter-free branch, `kron(B, I_N)` (:2243) or its corrected form - or one pair per stage (`diagcat`,
+        :2200-2206, :2236-2240)."""
+        N, nx, nu = self._horizon, self._n_x, self._n_u
+        aux2 = np.zeros((N, N + 1))
+        for i in range(N):
+            aux2[i, i + 1] = -1
+        Abar2 = np.kron(aux2, np.eye(nx))                                                         # mpc.py:2233
+        if len(As) == 1:
+            Abar1 = np.kron(np.eye(N), As[0])                                                     # mpc.py:2209-2210
+            Abar3 = np.kron(Bs[0], np.eye(N)) if kron_variant == 'reference' else np.kron(np.eye(N), Bs[0])   # mpc.py:2243
+        else:
+            Abar1, Abar3 = np.zeros((N * nx, N * nx)), np.zeros((N * nx, N * nu))
+            for k in range(N):
+                Abar1[k * nx:(k + 1) * nx, k * nx:(k + 1) * nx] = As[k]
+                Abar3[k * nx:(k + 1) * nx, k * nu:(k + 1) * nu] = Bs[k]
+        Abar1 = np.hstack([Abar1, np.zeros((N * nx, nx))])                                        # mpc.py:2213
+        return np.hstack([Abar1 + Abar2, Abar3])                                                  # mpc.py:2245
+
+    def _stage_parameters(self, cp, tvp):
+        """[N][n_p] parameter values along the horizon: constant ones from `cp`, time-varying ones from `tvp` or the stored series
+        (window advancing with the iteration counter, mpc.py:292-333, :2013-2045)."""
+        N, names, tv = self._horizon, self._model.parameter_names, self._time_varying_parameters
+        npar, n_tvp = len(names), len(tv)
+        cpv = np.zeros(0) if cp is None else np.asarray(cp.cpu() if isinstance(cp, torch.Tensor) else cp, dtype=float).ravel()
+        if cpv.size != npar - n_tvp:
+            raise ValueError(f"The model has {npar - n_tvp} constant parameter(s): {[n for n in names if n not in tv]}. You must "
+                             f"pass me the value of these before running the optimization to the 'cp' parameter.")
+        win = np.zeros((n_tvp, N))
+        if n_tvp:
+            ci = self._n_iterations
+            if tvp is not None:
+                for r, (key, value) in enumerate(tvp.items()):
+                    if len(value) < N:
+                        raise TypeError(f"When passing time-varying parameters, you need to pass a number of values at least as "
+                                        f"long as the prediction horizon. The parameter {key} has {len(value)} values but the MPC "
+                                        f"has a prediction horizon length of {N}.")
+                    win[r] = np.asarray(value[0:N], dtype=float)
+            elif self._time_varying_parameters_values is not None:
+                vals = self._time_varying_parameters_values
+                if ci == 0 or self._tvp_window is None:
+                    for r, name in enumerate(tv):
+                        if len(vals[name]) < N:
+                            raise TypeError(f"The parameter {name} has {len(vals[name])} values but the MPC has a prediction "
+                                            f"horizon length of {N}.")
+                        win[r] = np.asarray(vals[name][0:N], dtype=float)
+                else:
+                    win = self._tvp_window.copy()
+                    win[:, :-1] = win[:, 1:]
+                    for r, name in enumerate(tv):
+                        value = vals[name]
+                        if ci + N > len(value):
+                            warnings.warn("The prediction horizon is predicting outside the values of the time varying "
+                                          "parameters. I am now taking looping back the values and start from there.")
+                            win[r, -1] = value[ci - N * int(np.floor(ci / N))]
+                        else:
+                            win[r, -1] = value[ci + N - 1]
+                self._tvp_window = win
+            else:
+                raise ValueError(f"Mate, I know there are {n_tvp} time varying parameters but you did not pass me any."
+                                 f"Please provide me with the values of the parameters, either to the optimize() method or to "
+                                 f"the set_time_varying_parameters() method.")
+        P = np.empty((N if n_tvp else 1, npar))
+        for k in range(P.shape[0]):
+            it = ic = 0
+            for j, name in enumerate(names):
+                if name in tv:
+                    P[k, j] = win[it, k]
+                    it += 1
+                else:
+                    P[k, j] = cpv[ic]
+                    ic += 1
+        return P
+
     def setup(self, options=None, solver_options=None, solver='qpoases', kron_variant='reference'):
         """mpc.py:2143-2305.  `kron_variant='reference'` reproduces mpc.py:2243 (`kron(B, I_N)`), 'corrected' uses the
         block-diagonal input matrix of the time-varying branch (mpc.py:2236-2240)."""
@@ -117,20 +218,22 @@ class LMPC:
             raise ValueError("kron_variant must be 'reference' or 'corrected'")
         N, nx, nu = self._horizon, self._n_x, self._n_u
         # mpc.py:2183-2184: `state_matrix`, `input_matrix` of the model - of a model written as expressions the Jacobians of its
-        # (discretised) equations at the equilibrium point, with the parameter values of `set_initial_parameter_values`
-        A, B, _ = self._model.system_matrices()
+        # (discretised) equations at the equilibrium point.  With parameters the matrices are formed per call from `cp` / `tvp`
+        # (mpc.py:2343-2366 substitutes them into Aeq there as well); setup() then only fixes the sizes.
+        self._kron_variant = kron_variant
+        self._aeq_key = None
+        if self._n_par():
+            A, B = np.zeros((nx, nx)), np.zeros((nx, nu))
+        else:
+            if self._time_varying_parameters:
+                raise ValueError("time-varying parameters were declared, but the model has no parameters")
+            A, B, _ = self._model.system_matrices()
         Q = np.zeros((nx, nx)) if self._Q is None else self._Q                                  # mpc.py:2188-2193
         P = np.zeros((nx, nx)) if self._P is None else self._P
         R = np.zeros((nu, nu)) if self._R is None else self._R
         sx = np.ones(nx) if self._x_scaling is None else np.asarray(self._x_scaling)
         su = np.ones(nu) if self._u_scaling is None else np.asarray(self._u_scaling)
-        Abar1 = np.hstack([np.kron(np.eye(N), A), np.zeros((N * nx, nx))])                      # mpc.py:2209-2213
-        aux2 = np.zeros((N, N + 1))
-        for i in range(N):
-            aux2[i, i + 1] = -1
-        Abar2 = np.kron(aux2, np.eye(nx))                                                         # mpc.py:2233
-        Abar3 = np.kron(B, np.eye(N)) if kron_variant == 'reference' else np.kron(np.eye(N), B)  # mpc.py:2243
-        Aeq = np.hstack([Abar1 + Abar2, Abar3])                                                   # mpc.py:2245
+        Aeq = self._equality_matrix([A], [B], kron_variant)
         n_v = (N + 1) * nx + N * nu
         H = np.zeros((n_v, n_v))                                                                  # mpc.py:2252-2256
         H[:N * nx, :N * nx] = np.kron(np.eye(N), Q)
@@ -174,21 +277,19 @@ class LMPC:
         """mpc.py:2307-2394."""
         if self._handle is None:
             raise ValueError("Howdy! You need to setup the MPC before optimizing. Run .setup() on the MPC object.")
-        if tvp is not None:
-            raise NotImplementedError("time-varying parameters are not yet offloaded")
-        n_cp = self._model.n_p if getattr(self._model, '_symbolic', False) else 0
-        if n_cp:
-            # constant parameters (mpc.py:2316-2326): the matrices of the QP are those of the values given to
-            # `Model.set_initial_parameter_values` before setup(); other values per call would be another QP
-            if cp is None or np.asarray(cp, dtype=float).size != n_cp:
-                raise ValueError(f"The model has {n_cp} constant parameter(s): {self._model.parameter_names}. You must pass me "
-                                 f"the value of these before running the optimization to the 'cp' parameter.")
-            if not np.array_equal(np.asarray(cp, dtype=float).ravel(), self._model._p_init):
-                raise NotImplementedError("parameter values other than those of Model.set_initial_parameter_values (the matrices "
-                                          "of the QP are assembled at setup): set them on the model and run setup() again")
-        elif cp is not None:
-            warnings.warn("You are passing a parameter vector in the optimizer, but the model has no defined "
-                          "parameters. I am ignoring the vector.")
+        if self._n_par():
+            P = self._stage_parameters(cp, tvp)
+            key = P.tobytes()
+            if key != self._aeq_key:        # new parameter values: the equality block of this QP (host assembly, one upload)
+                mats = [self._model.system_matrices(p=pk) for pk in P]
+                Aeq = self._equality_matrix([m[0] for m in mats], [m[1] for m in mats], self._kron_variant)
+                self._Ad, self._aeq_key = to_dev(Aeq, self._dev), key
+        else:
+            if tvp is not None:
+                raise ValueError("time-varying parameter values were passed, but the model has no parameters")
+            if cp is not None:
+                warnings.warn("You are passing a parameter vector in the optimizer, but the model has no defined "
+                              "parameters. I am ignoring the vector.")
         host = not isinstance(x0, torch.Tensor)
         x = to_dev(x0, self._dev)
         single = x.ndim <= 1 or (x.ndim == 2 and x.shape[1] == 1 and x.shape[0] == self._n_x and self._n_x != 1)

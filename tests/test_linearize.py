@@ -99,3 +99,45 @@ def test_what_the_linear_mpc_accepts():
         LMPC(mc)
     with pytest.raises(NotImplementedError):
         Model('chemostat4').linearize()
+
+
+def test_equality_block_of_the_qp_and_the_parameter_window():
+    """`LMPC._equality_matrix` against the oracle's assembly (both input-block variants) and per-stage matrices; the values of the
+    time-varying parameters along the horizon follow mpc.py:292-333 / :2013-2045 (host logic, no device)."""
+    from oracle.lmpc import LmpcProblem
+    from tests.test_oracle_lmpc import A, B, C1
+    mpc = LMPC(_double_integrator())
+    mpc.horizon = 10
+    for variant, bug in (('reference', True), ('corrected', False)):
+        np.testing.assert_array_equal(mpc._equality_matrix([A], [B], variant), LmpcProblem(**C1, kron_bug=bug).Aeq)
+    np.testing.assert_array_equal(mpc._equality_matrix([A] * 10, [B] * 10, 'reference'), LmpcProblem(**C1, kron_bug=False).Aeq)
+    # tests/test_LMPC.py:189-199: x+ = [[-1, 2 p], [0, -1]] x + u with the parameter varying along the horizon
+    m = Model(discrete=True)
+    x = m.set_dynamical_states(['x_1', 'x_2'])
+    u = m.set_inputs(['u_1', 'u_2'])
+    q = m.set_parameters(['p', 'c'])
+    m.set_dynamical_equations([-1. * x[0] + 2. * q[0] * x[1] + u[0], -1. * x[1] + q[1] * u[1]])
+    m.setup(dt=1.)
+    assert m.is_linear()
+    np.testing.assert_array_equal(m.system_matrices(p=[3., .5])[0], [[-1., 6.], [0., -1.]])
+    np.testing.assert_array_equal(m.system_matrices(p=[3., .5])[1], [[1., 0.], [0., .5]])
+    mpc = LMPC(m)
+    mpc.horizon = 4
+    with pytest.raises(ValueError, match="could not find"):
+        mpc.set_time_varying_parameters(names=['nope'])
+    mpc.set_time_varying_parameters(names=['p'])
+    np.testing.assert_array_equal(mpc._stage_parameters([.5], {'p': [1, 2, 3, 4, 5]}), [[1, .5], [2, .5], [3, .5], [4, .5]])
+    with pytest.raises(TypeError, match="at least as long"):
+        mpc._stage_parameters([.5], {'p': [1, 2]})
+    with pytest.raises(ValueError, match="constant parameter"):
+        mpc._stage_parameters(None, {'p': [1, 2, 3, 4]})
+    with pytest.raises(ValueError, match="did not pass me any"):
+        mpc._stage_parameters([.5], None)
+    mpc.set_time_varying_parameters(names=['p'], values={'p': [1, 2, 3, 4, 5, 6]})
+    np.testing.assert_array_equal(mpc._stage_parameters([.5], None)[:, 0], [1, 2, 3, 4])
+    mpc._n_iterations = 1                                   # the window advances with the iteration counter
+    np.testing.assert_array_equal(mpc._stage_parameters([.5], None)[:, 0], [2, 3, 4, 5])
+    mpc._n_iterations = 2
+    np.testing.assert_array_equal(mpc._stage_parameters([.5], None)[:, 0], [3, 4, 5, 6])
+    mpc.set_time_varying_parameters()                       # constant parameters only: one row
+    np.testing.assert_array_equal(mpc._stage_parameters([3., .5], None), [[3., .5]])

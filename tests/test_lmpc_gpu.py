@@ -183,3 +183,18 @@ def test_models_written_as_expressions():
         if with_parameters:
             with pytest.raises(ValueError, match="constant parameter"):
                 mpc.optimize([.5, 0, 0, 0])
+            # tests/test_LMPC.py:175-188: one length varies along the horizon; held constant it is the constant-parameter problem
+            # in the block-diagonal ("corrected") form of the input block
+            tv = LMPC(ml)
+            tv.horizon = 10
+            tv.Q, tv.R = np.eye(4), np.eye(2)
+            tv.set_time_varying_parameters(names=['lf'])
+            tv.setup()
+            ut = tv.optimize([.5, 0, 0, 0], cp=[1.4], tvp={'lf': [1.8] * 10})
+            np.testing.assert_array_equal(ut, u)
+            ut = tv.optimize([1, 1, 0, 0], cp=[1.4], tvp={'lf': [1.8] * 5 + [1.4] * 5})
+            assert tv.solver_status_code[0] == 1
+            X, U = tv.return_prediction()
+            for k in range(10):
+                Ak, Bk, _ = ml.system_matrices(p=[1.4, 1.8 if k < 5 else 1.4])
+                np.testing.assert_allclose(X[0][:, k + 1], Ak @ X[0][:, k] + Bk @ U[0][:, k], atol=1e-9)
