@@ -198,3 +198,42 @@ def test_models_written_as_expressions():
             for k in range(10):
                 Ak, Bk, _ = ml.system_matrices(p=[1.4, 1.8 if k < 5 else 1.4])
                 np.testing.assert_allclose(X[0][:, k + 1], Ak @ X[0][:, k] + Bk @ U[0][:, k], atol=1e-9)
+
+
+def test_nmpc_and_lmpc_agree_on_a_linear_model_with_a_time_varying_parameter():
+    """tests/test_LMPC.py:189-240 (`test_compare_NMPC_LMPC`): x+ = [[-1, 2 p], [0, -1]] x + u with p changing along the stored series,
+    the same quadratic cost and input bound in both controllers - two transcriptions and two solvers (interior point on the
+    run-time compiled model, the QP kernel on the per-stage matrices) of one problem give the same input, step after step."""
+    from hilo_mpc_amd import LMPC, NMPC, Model
+    m = Model(discrete=True)
+    x = m.set_dynamical_states(['x_1', 'x_2'])
+    u = m.set_inputs(['u_1', 'u_2'])
+    q = m.set_parameters(['p'])
+    m.set_dynamical_equations([-1. * x[0] + 2. * q[0] * x[1] + u[0], -1. * x[1] + u[1]])
+    m.setup(dt=1.)
+    tvp = 12 * [1.] + 30 * [0.]
+    nmpc = NMPC(m)
+    nmpc.horizon = 10
+    nmpc.quad_stage_cost.add_states(names=['x_1', 'x_2'], weights=[1, 1])
+    nmpc.quad_terminal_cost.add_states(names=['x_1', 'x_2'], weights=[1, 1])
+    nmpc.quad_stage_cost.add_inputs(names=['u_1', 'u_2'], weights=[1, 1])
+    nmpc.set_box_constraints(u_ub=[0.5, 10])
+    nmpc.set_time_varying_parameters(names=['p'], values={'p': tvp})
+    nmpc.set_solver_opts({'ipopt.tol': 1e-10})
+    nmpc.setup()
+    lmpc = LMPC(m)
+    lmpc.horizon = 10
+    lmpc.Q, lmpc.P, lmpc.R = np.eye(2), np.eye(2), np.eye(2)
+    lmpc.set_time_varying_parameters(names=['p'], values={'p': tvp})
+    lmpc.set_box_constraints(u_ub=[0.5, 10])
+    lmpc.setup()
+    xi = np.array([[1., 2.], [-.5, 1.5]])
+    active = False
+    for i in range(16):
+        un, ul = nmpc.optimize(xi), lmpc.optimize(xi)
+        assert np.all(nmpc.solver_status_code == 1) and np.all(lmpc.solver_status_code == 1)
+        np.testing.assert_allclose(un, ul, rtol=1e-6, atol=1e-6)
+        active |= bool(np.any(ul[:, 0] > .5 - 1e-6))
+        Ai, Bi, _ = m.system_matrices(p=[tvp[i]])
+        xi = xi @ Ai.T + ul @ Bi.T
+    assert active                                              # the input bound was active on the way
