@@ -286,18 +286,12 @@ class Model:
             return True
         if self._ode is None or self.n_z:
             return False
-        from .symdiff import Dag
-        g, memo = Dag(), {}
-        rows = [g.from_expr(e, memo) for e in list(self._ode) + list(self._meas)]
-        w = [g.var('x', i) for i in range(self.n_x)] + [g.var('u', i) for i in range(self.n_u)]
-        jac = [g.diff(r, v) for r in rows for v in w]
-        need, stack = set(), list(jac)
-        while stack:
-            i = stack.pop()
-            if i not in need:
-                need.add(i)
-                stack += [c for c in g.nodes[i][1:3] if c >= 0]
-        return not any(g.nodes[i][0] in ('x', 'u') for i in need)
+        from .expr import jacobian
+        try:
+            J = jacobian(list(self._ode) + list(self._meas), list(self.x) + list(self.u))
+        except NotImplementedError:          # a node without a derivative rule (a learned term, ...): not known to be linear
+            return False
+        return not any(e.depends_on('x') or e.depends_on('u') for row in J for e in row)
 
     # ---- linearisation (dynamic_model.py:2488-2612, :3670-3684) and the matrices the linear MPC reads (mpc.py:2183-2184) -----------
     def linearize(self, name=None, trajectory=None):
@@ -370,8 +364,15 @@ class Model:
         from .smpc import SMPC
         from .symdiff import Dag
         fx = SMPC._discrete_map(self, self.dt) if self.discrete else list(self._ode)
+        rows = list(fx) + list(self._meas)
+        if any(e.depends_on('t') for e in rows):
+            raise NotImplementedError("system matrices of a model that depends on time explicitly")
+        if any(e.depends_on('dt') for e in rows):      # the sampling interval written into the equations (tests/test_LMPC.py:12-13)
+            if self.dt is None:
+                raise RuntimeError("Model is not set up. Run Model.setup(dt=...) first: the equations hold the sampling interval.")
+            rows = Expr.substitute(rows, lambda n: Expr.wrap(float(self.dt)) if n.op == 'dt' else None)
         g, memo = Dag(), {}
-        rows = [g.from_expr(e, memo) for e in list(fx) + list(self._meas)]
+        rows = [g.from_expr(e, memo) for e in rows]
         w = [g.var('x', i) for i in range(self.n_x)] + [g.var('u', i) for i in range(self.n_u)]
         jac = [g.diff(r, v) for r in rows for v in w]
         xe = getattr(self, '_x_eq', None)
