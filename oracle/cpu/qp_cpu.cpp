@@ -7,7 +7,8 @@
 //
 // The iteration is oracle/lmpc.py::solve_qp statement by statement, without its active-set polish (which the product's kernels
 // do not have either): Mehrotra's predictor-corrector on the free variables (fixed ones, lb == ub, substituted), the Newton system
-// by the Schur complement of the equality constraints - M = H + Sigma + reg I = L L^T, X = L^-1 A^T, S = X^T X + reg I = Ls Ls^T -
+// by the Schur complement of the equality constraints - M = H + Sigma + reg I = L L^T (one square root per entry when H is diagonal,
+// as in the device kernel), X = L^-1 A^T, S = X^T X + reg I = Ls Ls^T -
 // convergence on max(|rd| / (1 + |g|), |rp|, mu) <= tol, infeasibility by OOQP's rule (merit 1e4 times its smallest value so far).
 #include <omp.h>
 
@@ -23,10 +24,10 @@ constexpr double INF = std::numeric_limits<double>::infinity();
 
 struct Work {
   int n, m;
-  std::vector<double> Hf, Af, gf, bf, l, u, x, y, zl, zu, M, X, S, base, r1, dx, dy, dzl, dzu, t, rp, xfix, cl, cu;
+  std::vector<double> Hf, Af, gf, bf, l, u, x, y, zl, zu, M, X, S, base, r1, dx, dy, dzl, dzu, t, rp, xfix, cl, cu, dq;
   std::vector<char> fixed, hl, hu;
   Work(int n_, int m_) : n(n_), m(m_), Hf(n_ * n_), Af(m_ * n_), gf(n_), bf(m_), l(n_), u(n_), x(n_), y(m_), zl(n_), zu(n_), M(n_ * n_),
-                         X(n_ * m_), S(m_ * m_), base(n_), r1(n_), dx(n_), dy(m_), dzl(n_), dzu(n_), t(n_), rp(m_), xfix(n_), cl(n_), cu(n_),
+                         X(n_ * m_), S(m_ * m_), base(n_), r1(n_), dx(n_), dy(m_), dzl(n_), dzu(n_), t(n_), rp(m_), xfix(n_), cl(n_), cu(n_), dq(n_),
                          fixed(n_), hl(n_), hu(n_) {}
 };
 
@@ -72,6 +73,12 @@ int solve_one(Work& k, const double* H, const double* g, const double* A, const 
     for (int j = 0; j < n; ++j) k.Hf[i * n + j] = (k.fixed[i] || k.fixed[j]) ? (i == j ? 1.0 : 0.0) : H[i * n + j];
   for (int r = 0; r < m; ++r)
     for (int j = 0; j < n; ++j) k.Af[r * n + j] = k.fixed[j] ? 0.0 : A[r * n + j];
+  // H diagonal (the LMPC with diagonal weights): H + Sigma is diagonal too - its factor is a square root per entry, like in the
+  // device kernel (csrc/hilo_qp.hip); dq holds the diagonal of the factor
+  bool hdiag = true;
+  for (int i = 0; i < n && hdiag; ++i)
+    for (int j = 0; j < n; ++j)
+      if (i != j && k.Hf[i * n + j] != 0.0) { hdiag = false; break; }
   double gmax = 0.0;
   for (int i = 0; i < n; ++i) {
     double s = g[i];
@@ -104,8 +111,12 @@ int solve_one(Work& k, const double* H, const double* g, const double* A, const 
   int status = 5, it = 0;
   double phi_min = INF;
   auto newton = [&](const double* r, double* dx, double* dy) {
-    for (int i = 0; i < n; ++i) k.t[i] = r[i];
-    fsub(k.M.data(), n, k.t.data());
+    if (hdiag) {
+      for (int i = 0; i < n; ++i) k.t[i] = r[i] / k.dq[i];
+    } else {
+      for (int i = 0; i < n; ++i) k.t[i] = r[i];
+      fsub(k.M.data(), n, k.t.data());
+    }
     for (int a = 0; a < m; ++a) {
       double s = k.rp[a];
       for (int i = 0; i < n; ++i) s += k.X[i * m + a] * k.t[i];
@@ -116,9 +127,9 @@ int solve_one(Work& k, const double* H, const double* g, const double* A, const 
     for (int i = 0; i < n; ++i) {
       double s = k.t[i];
       for (int a = 0; a < m; ++a) s -= k.X[i * m + a] * dy[a];
-      dx[i] = s;
+      dx[i] = hdiag ? s / k.dq[i] : s;
     }
-    bsub(k.M.data(), n, dx);
+    if (!hdiag) bsub(k.M.data(), n, dx);
   };
   auto steps = [&](double tau, double& ap, double& ad) {
     ap = ad = 1.0;
@@ -159,19 +170,38 @@ int solve_one(Work& k, const double* H, const double* g, const double* A, const 
     if (phi <= tol) { status = 1; break; }
     phi_min = std::min(phi_min, phi);
     if (phi >= 1e4 * phi_min) { status = 3; break; }
-    for (int i = 0; i < n * n; ++i) k.M[i] = k.Hf[i];
-    for (int i = 0; i < n; ++i) {
-      if (k.fixed[i]) continue;
-      double d = reg;
-      if (k.hl[i]) d += k.zl[i] / (k.x[i] - k.l[i]);
-      if (k.hu[i]) d += k.zu[i] / (k.u[i] - k.x[i]);
-      k.M[i * n + i] += d;
-    }
-    if (!cholesky(k.M.data(), n)) { status = -1; break; }
-    for (int a = 0; a < m; ++a) {
-      for (int i = 0; i < n; ++i) k.t[i] = k.Af[a * n + i];
-      fsub(k.M.data(), n, k.t.data());
-      for (int i = 0; i < n; ++i) k.X[i * m + a] = k.t[i];
+    if (hdiag) {
+      bool ok = true;
+      for (int i = 0; i < n; ++i) {
+        double d = k.Hf[i * n + i];
+        if (!k.fixed[i]) {
+          d += reg;
+          if (k.hl[i]) d += k.zl[i] / (k.x[i] - k.l[i]);
+          if (k.hu[i]) d += k.zu[i] / (k.u[i] - k.x[i]);
+        }
+        ok = ok && d > 0.0;
+        k.dq[i] = std::sqrt(d);
+      }
+      if (!ok) { status = -1; break; }
+      for (int i = 0; i < n; ++i) {
+        const double di = 1.0 / k.dq[i];
+        for (int a = 0; a < m; ++a) k.X[i * m + a] = k.Af[a * n + i] * di;
+      }
+    } else {
+      for (int i = 0; i < n * n; ++i) k.M[i] = k.Hf[i];
+      for (int i = 0; i < n; ++i) {
+        if (k.fixed[i]) continue;
+        double d = reg;
+        if (k.hl[i]) d += k.zl[i] / (k.x[i] - k.l[i]);
+        if (k.hu[i]) d += k.zu[i] / (k.u[i] - k.x[i]);
+        k.M[i * n + i] += d;
+      }
+      if (!cholesky(k.M.data(), n)) { status = -1; break; }
+      for (int a = 0; a < m; ++a) {
+        for (int i = 0; i < n; ++i) k.t[i] = k.Af[a * n + i];
+        fsub(k.M.data(), n, k.t.data());
+        for (int i = 0; i < n; ++i) k.X[i * m + a] = k.t[i];
+      }
     }
     for (int a = 0; a < m; ++a)
       for (int c = 0; c <= a; ++c) {

@@ -98,11 +98,14 @@ def test_filter_steps_vs_oracle(kind):
     assert np.array_equal(one, got)
 
 
-def test_lmpc_qp_vs_oracle():
+@pytest.mark.parametrize('Q', [None, [[2., .5], [.5, 1.]]])
+def test_lmpc_qp_vs_oracle(Q):
+    """diagonal weights (H + Sigma diagonal: one square root per entry, like the device kernel) and a weight with off-diagonal
+    entries (the general factorisation)."""
     from oracle.cpu import qp_solve
     from oracle.lmpc import LmpcProblem, solve_qp
     from tests.test_oracle_lmpc import C1
-    pb = LmpcProblem(**C1, kron_bug=False)
+    pb = LmpcProblem(**dict(C1, **({} if Q is None else {'Q': np.array(Q)})), kron_bug=False)
     rng = np.random.default_rng(6)
     xs = rng.uniform(-4, 4, (40, 2))
     bnd = [pb.bounds_for(x0) for x0 in xs]
