@@ -225,6 +225,23 @@ def test_path_following_with_soft_constraint_vs_oracle():
         x0, w_ref, w = xn, ref['w'][:, :ipm.o_s], res['w']
 
 
+def test_path_following_at_the_benchmark_size_vs_oracle():
+    """C5 as the benchmark runs it (N = 50, n_v = 508): one cold solve of the C++ leg against the dense numpy solver - same status,
+    same iteration count, same point (the dense solve takes ~20 s, the C++ one ~10 ms)."""
+    from oracle.cpu import CpuPathNmpc
+    from oracle.nmpc_gen import GenIpm
+    from tests.problems import C5, c5_x0, oracle_gen
+    pb = oracle_gen(C5)
+    ipm, cpu = GenIpm(pb), CpuPathNmpc(C5, pb)
+    x0 = c5_x0(1)
+    ref, res = ipm.solve(x0, C5['p']), cpu.solve(x0, n_threads=1)
+    vr = ipm.to_v(ref)
+    assert res['status'][0] == ref['status'][0] == 1 and abs(int(res['iters'][0]) - int(ref['iters'][0])) <= 3
+    assert vr.shape == res['v'].shape == (1, 508)
+    assert np.max(np.abs(res['v'] - vr) / np.maximum(1., np.abs(vr))) < 1e-6
+    np.testing.assert_allclose(res['f'], ref['f'], rtol=1e-8)
+
+
 def test_path_following_out_of_scope_is_refused():
     from oracle.cpu import CpuPathNmpc
     from tests.problems import C2S, C5S, oracle_gen
