@@ -343,6 +343,24 @@ class Model:
             raise ValueError(f"Dimension mismatch: {p.size} parameter values for {self.n_p} parameters")
         self._p_init = p
 
+    def _jacobian_program(self):
+        """(dag, nodes of d rows / d (x, u), number of rows): rows = x+ (or dx/dt) and the measurement equations."""
+        from .smpc import SMPC
+        from .symdiff import Dag
+        fx = SMPC._discrete_map(self, self.dt) if self.discrete else list(self._ode)
+        rows = list(fx) + list(self._meas)
+        if any(e.depends_on('t') for e in rows):
+            raise NotImplementedError("system matrices of a model that depends on time explicitly")
+        if any(e.depends_on('dt') for e in rows):      # the sampling interval written into the equations (tests/test_LMPC.py:12-13)
+            if self.dt is None:
+                raise RuntimeError("Model is not set up. Run Model.setup(dt=...) first: the equations hold the sampling interval.")
+            rows = Expr.substitute(rows, lambda n: Expr.wrap(float(self.dt)) if n.op == 'dt' else None)
+        g, memo = Dag(), {}
+        rows = [g.from_expr(e, memo) for e in rows]
+        w = [g.var('x', i) for i in range(self.n_x)] + [g.var('u', i) for i in range(self.n_u)]
+        jac = [g.diff(r, v) for r in rows for v in w]
+        return g, jac, len(rows)
+
     def system_matrices(self, p=None):
         """(A, B, C) of a linear (or linearised) model: numeric Jacobians of x+ = f(x, u, p) (a discrete or discretised model) or
         dx/dt = f (a continuous one that was not discretised) and of y = h(x, u, p) at the equilibrium point."""
@@ -361,25 +379,19 @@ class Model:
                                  f"the system matrices (argument `p` / set_initial_parameter_values).")
         else:
             p = np.zeros(0)
-        from .smpc import SMPC
-        from .symdiff import Dag
-        fx = SMPC._discrete_map(self, self.dt) if self.discrete else list(self._ode)
-        rows = list(fx) + list(self._meas)
-        if any(e.depends_on('t') for e in rows):
-            raise NotImplementedError("system matrices of a model that depends on time explicitly")
-        if any(e.depends_on('dt') for e in rows):      # the sampling interval written into the equations (tests/test_LMPC.py:12-13)
-            if self.dt is None:
-                raise RuntimeError("Model is not set up. Run Model.setup(dt=...) first: the equations hold the sampling interval.")
-            rows = Expr.substitute(rows, lambda n: Expr.wrap(float(self.dt)) if n.op == 'dt' else None)
-        g, memo = Dag(), {}
-        rows = [g.from_expr(e, memo) for e in rows]
-        w = [g.var('x', i) for i in range(self.n_x)] + [g.var('u', i) for i in range(self.n_u)]
-        jac = [g.diff(r, v) for r in rows for v in w]
+        # the Jacobian as a straight-line program, built once per (equations, discretisation, sampling interval) and evaluated per
+        # call (the linear MPC asks for one pair of matrices per stage when parameters vary along the horizon)
+        stamp = (id(self._ode), id(self._meas), self.erk_order, self.n_sub, self.dt, self.discrete)
+        cache = getattr(self, '_sysmat_cache', None)
+        if cache is None or cache[0] != stamp:
+            g, jac, n_rows = self._jacobian_program()
+            self._sysmat_cache = cache = (stamp, g, jac, n_rows)
+        _, g, jac, n_rows = cache
         xe = getattr(self, '_x_eq', None)
         ue = getattr(self, '_u_eq', None)
         xe = np.zeros(self.n_x) if xe is None else xe
         ue = np.zeros(self.n_u) if ue is None else ue
-        J = np.array(g.evaluate(jac, xe, ue, p), dtype=float).reshape(len(rows), self.n_x + self.n_u)
+        J = np.array(g.evaluate(jac, xe, ue, p), dtype=float).reshape(n_rows, self.n_x + self.n_u)
         nx = self.n_x
         C = J[nx:, :nx] if len(self._meas) else np.eye(nx)
         return J[:nx, :nx], J[:nx, nx:], C
