@@ -655,7 +655,7 @@ static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const 
         if (h->lamc) HILO_HIP_CHECK(hipFree(h->lamc));
         h->vc = h->lamc = nullptr;
         hipError_t e = hipMalloc((void**)&h->vc, sizeof(double) * (size_t)h->n_vc * batch);
-        if (e == hipSuccess) e = hipMalloc((void**)&h->lamc, sizeof(double) * (size_t)h->N * h->nxv * batch);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->lamc, sizeof(double) * (size_t)(h->n_gc ? h->n_gc : h->N * h->nxv) * batch);
         if (e != hipSuccess) return fail(HILO_ENOMEM, "collocation output buffers: %s", hipGetErrorString(e));
         h->vc_batch = batch;
       }

@@ -26,6 +26,7 @@ struct hilo_nmpc {
   double *vc, *lamc;         // the engine's compact [x | u] solution and defect multipliers (collocation output pass)
   int64_t vc_batch;
   int n_vc;                  // (N+1) nx + N nu
+  int n_gc;                  // length of the engine's compact multiplier row of a run-time compiled collocation problem (0: N nxv)
   double* v_warm;    // [warm_batch][n_v] device: previous solution (mpc.py:725-726)
   int64_t warm_batch;
   int warm_valid;

@@ -31,7 +31,7 @@ namespace hilo {
 // ---- layout of pc.cost for NmpcUser: plain function of the dimensions so that the host (hilo_jit.hip) fills the block ----
 struct UserLayout {
   int mza, o_wz, o_zref, o_wn, o_xrefn, o_wdu, o_hasdu, o_we, o_wet, o_ws, o_idxs, o_wt, o_idxt, o_rowx, o_rows, o_rowe,
-      o_trowx, o_trows, o_trowe, o_tsoft, o_wzm, o_end;
+      o_trowx, o_trows, o_trowe, o_tsoft, o_wzm, o_nrow, o_ncr, o_ntr, o_rref, o_trref, o_end;
   __host__ __device__ constexpr UserLayout(int mx, int mu, int nth, int ne, int nps, int npt)
       : mza(mx + nth + mu + nth),
         o_wz(0),                                   // [mza x mza] weights on the (scaled) augmented z = [x, theta | u, u_theta]
@@ -54,7 +54,13 @@ struct UserLayout {
         o_trowe(o_trows + OCP_MAXNC),
         o_tsoft(o_trowe + OCP_MAXNC),
         o_wzm(o_tsoft + 1),                        // [mza] per row of Wz: bit j set iff Wz[i][j] != 0 (as a double: exact below 2^53)
-        o_end(o_wzm + mza) {}
+        o_nrow(o_wzm + mza),                       // collocation + constraints: rows per POINT (the engine's rows of a stage are the
+                                                   // node's rows followed by those of the d collocation points, mpc.py:1338-1356)
+        o_ncr(o_nrow + 1),                         // ... rows per point / terminal rows in the REFERENCE's g (dropped rows included)
+        o_ntr(o_ncr + 1),
+        o_rref(o_ntr + 1),                         // ... and where row r of a point / terminal row r sits there
+        o_trref(o_rref + OCP_MAXNC),
+        o_end(o_trref + OCP_MAXNC) {}
 };
 
 // the model with the path variable(s) appended as states driven by virtual inputs (mpc.py:1181-1191)
@@ -77,6 +83,7 @@ struct ThetaAug {
 struct NoUserFun {
   static constexpr bool HAS_STAGE = false, HAS_TERM = false;
   static constexpr int NEXPR = 0, NTEXPR = 0, NPS = 0, NPT = 0;
+  static constexpr bool CON_USES_Z = false;
 };
 
 template <class M, class F, class C>
@@ -93,6 +100,10 @@ struct NmpcUser {
   static constexpr int D = C::COLL_D;                          // collocation degree, 0 = explicit Runge-Kutta / discrete map
   static constexpr bool CONT = C::CONT;                        // continuous objective
   static constexpr bool FUSED = true;
+  // collocation with nonlinear stage constraints: the reference imposes them at every collocation point as well as at the node
+  // (mpc.py:1338-1356, :1700-1725) - rows of the interior of the shooting map, evaluated together with it
+  static constexpr bool FUSED_CON = C::COLL_D > 0 && F::NEXPR > 0;
+  static constexpr int NZALG = model_nz<M>::value;             // algebraic states of a semi-explicit DAE model (eliminated, see below)
   static constexpr bool QUAD_COST = false;
   static constexpr UserLayout L = UserLayout(MX, MU, NTH, NE, F::NPS, F::NPT);
   static constexpr int NCOST = L.o_end;
@@ -208,6 +219,39 @@ struct NmpcUser {
   template <class T, class E>
   __device__ __forceinline__ static T dyn_cost(const OcpConst& pc, const double* par, const double* sd, int k, const T* x,
                                                const T* u, T* xn, const E&) {
+    return dyn_cost_impl<false>(pc, par, sd, k, x, u, xn, (T*)nullptr);
+  }
+  template <class T, class E>
+  __device__ __forceinline__ static T dyn_cost_con(const OcpConst& pc, const double* par, const double* sd, int k, const T* x,
+                                                   const T* u, T* xn, T* dv, const E&) {
+    return dyn_cost_impl<true>(pc, par, sd, k, x, u, xn, dv);
+  }
+
+  // rows of ONE point (un-scaled xu, uu, algebraic state z or nullptr): d[m0 + r] = sign_r c_{expr_r} - e_{slack_r}, r < nrow
+  template <class T>
+  __device__ __forceinline__ static void rows_at(const OcpConst& pc, const double* p, const T* xu, const T* uu, const T* z,
+                                                 const T* xeng, int m0, int nrow, T* d) {
+    if constexpr (F::NEXPR > 0) {
+      T ce[F::NEXPR];
+      F::con(xu, uu, z, p, ce);
+#pragma unroll
+      for (int m = 0; m < (NC > 0 ? NC : 1); ++m) {
+        const int r = m - m0;
+        if (m < NC && r >= 0 && r < nrow) {
+          T v = pc.cost[L.o_rows + r] * pick<F::NEXPR>(ce, (int)pc.cost[L.o_rowx + r]);
+          if constexpr (NE > 0) {
+            const int ei = (int)pc.cost[L.o_rowe + r];
+            if (ei >= 0) v = v - pick<NE>(xeng + MXA, ei);
+          }
+          d[m] = v;
+        }
+      }
+    }
+  }
+
+  template <bool WITH_CON, class T>
+  __device__ __forceinline__ static T dyn_cost_impl(const OcpConst& pc, const double* par, const double* sd, int k, const T* x,
+                                                    const T* u, T* xn, T* dv) {
     const double* p = C::TV ? sd + MX + MU : par;
     T xp[MXA], up[MUA > 0 ? MUA : 1], us[MUA > 0 ? MUA : 1], xs[MXA], xo[MXA];
 #pragma unroll
@@ -222,7 +266,25 @@ struct NmpcUser {
     T lc = T(0.0);
     if constexpr (D > 0) {
       T Xc[D * MXA];
-      Colloc<MA, D>::step(pc.coll, xp, up, p, pc.dt, xo, CONT ? Xc : nullptr);
+      Colloc<MA, D>::step(pc.coll, xp, up, p, pc.dt, xo, (CONT || WITH_CON) ? Xc : nullptr);
+      if constexpr (WITH_CON) {
+        // rows of the node [0, nrow), then of the collocation points i = 1..d [i nrow, (i + 1) nrow); an expression that names an
+        // algebraic state gets z(x_{k,i}, u_k) at a collocation point; at the node the reference passes the interval's whole zp
+        // block (mpc.py:1707) - for d = 1 that IS z at the collocation point; for d > 1 CasADi rejects the call, and the row is
+        // evaluated with z consistent with the node
+        const int nrow = (int)pc.cost[L.o_nrow];
+        constexpr int NZ1 = NZALG > 0 ? NZALG : 1;
+        T zc[NZ1];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          if constexpr (NZALG > 0 && F::CON_USES_Z) dae_solve<M>(Xc + i * MXA, up, p, zc);
+          rows_at(pc, p, Xc + i * MXA, up, (NZALG > 0 && F::CON_USES_Z) ? zc : (const T*)nullptr, x, (i + 1) * nrow, nrow, dv);
+        }
+        if constexpr (NZALG > 0 && F::CON_USES_Z) {
+          if constexpr (D > 1) dae_solve<M>(xp, up, p, zc);
+        }
+        rows_at(pc, p, xp, up, (NZALG > 0 && F::CON_USES_Z) ? zc : (const T*)nullptr, x, 0, nrow, dv);
+      }
       if constexpr (CONT) {
 #pragma unroll
         for (int i = 0; i < D; ++i) {
@@ -270,6 +332,7 @@ struct NmpcUser {
         lc = lc + x[MXA + a] * s;
       }
     }
+    if constexpr (WITH_CON) term_rows(pc, p, k, xp, up, x, xn, dv);
     return lc;
   }
 
@@ -332,21 +395,13 @@ struct NmpcUser {
       if constexpr (NH > 0) { if (k >= pc.Nc) ui = x[MXA + NE + i]; }
       us[i] = ui * pc.sz[NX + i];
     }
-    if constexpr (F::NEXPR > 0) {
-      T ce[F::NEXPR];
-      F::con(xs, us, p, ce);
-#pragma unroll
-      for (int m = 0; m < (NC > 0 ? NC : 1); ++m) {
-        if (m < NC && m < pc.nc) {
-          T v = pc.cost[L.o_rows + m] * pick<F::NEXPR>(ce, (int)pc.cost[L.o_rowx + m]);
-          if constexpr (NE > 0) {
-            const int ei = (int)pc.cost[L.o_rowe + m];
-            if (ei >= 0) v = v - pick<NE>(x + MXA, ei);
-          }
-          d[m] = v;
-        }
-      }
-    }
+    rows_at(pc, p, xs, us, (const T*)nullptr, x, 0, pc.nc, d);
+    term_rows(pc, p, k, xs, us, x, xn, d);
+  }
+  // terminal rows of the last stage behind the stage rows: engine row pc.nc + r
+  template <class T>
+  __device__ __forceinline__ static void term_rows(const OcpConst& pc, const double* p, int k, const T* xs, const T* us, const T* x,
+                                                   const T* xn, T* d) {
     if constexpr (F::NTEXPR > 0) {
       if (k == pc.N - 1) {
         const bool soft = pc.cost[L.o_tsoft] != 0.0;
@@ -370,30 +425,40 @@ struct NmpcUser {
     }
   }
   // ---- collocation output pass: one thread per (instance, interval) ---------------------------------------------------
-  // The engine eliminates the collocation states (hilo_colloc.h); this reconstructs them and the multipliers of their
-  // equations so that `v` = [x | u | e | ip] and `lam_g` = per stage [collocation rows | continuity] have the reference's
-  // layout (mpc.py:1497-1518, :1657-1669).  Stationarity of the reference's Lagrangian in a collocation state X_i:
-  //     G_X^T mu = D_i lambda - dt B_i grad l(X_i)        (the second term only with the continuous objective)
-  // solved with the Runge-Kutta form of the equations, mu = -(A^T (x) I) Mat^-T rhs (hilo_colloc.h::multipliers).
+  // The engine eliminates the collocation states (hilo_colloc.h) and, for a semi-explicit DAE model (codegen.py::
+  // dae_model_source), the algebraic states; this pass rebuilds them and the multipliers of their equations, so that `v` and
+  // `lam_g` have the reference's layout (mpc.py:1462-1548, :1338-1372, :1657-1725):
+  //     v     = [x | u | z_0..z_N (enter no row: the guess) | per interval (ip_k, zp_k) | e]     (the slacks BEHIND the blocks, :1529)
+  //     lam_g = per interval [rows at the d collocation points | collocation equations, per point (ode rows, alg rows)
+  //                           | continuity | terminal rows (last interval) | rows at the node]
+  // The engine's compact results: vc = [x | u | e], lamc = per interval [continuity | rows: node, point 1..d] with the terminal
+  // rows of the last interval between its continuity multipliers and its rows (Ocp's write-back with identity row maps).
+  // Stationarity of the reference's Lagrangian in a collocation state X_i (z eliminated: total derivatives through zeta):
+  //     G_X^T mu = D_i lambda - dt B_i grad l(X_i) - sum_r nu_{i,r} sign_r grad c_r(X_i)
+  // solved with the Runge-Kutta form of the equations, mu = -(A^T (x) I) Mat^-T rhs (hilo_colloc.h::multipliers); in z_i:
+  //     dt (df/dz)^T mu_i + (dg/dz)^T nu_alg_i + sum_r nu_{i,r} sign_r dc_r/dz = 0.
   __device__ static void coll_output(const OcpConst* __restrict__ pcg, int64_t batch, const double* __restrict__ vc,
                                      const double* __restrict__ lamc, const double* __restrict__ par, int64_t par_stride,
                                      const double* __restrict__ sdata, int64_t sd_stride, double* __restrict__ v,
                                      double* __restrict__ lam_g) {
     constexpr int DD = D > 0 ? D : 1, DN = DD * MXA;
-    // semi-explicit DAE model (codegen.py::dae_model_source): the reference carries the algebraic states as variables - node
-    // blocks z_0..z_N behind the inputs (they enter no constraint: the guess), zp_k = z at the d collocation points behind the
-    // interval's collocation states - and the algebraic rows behind each collocation point's rows (mpc.py:1488-1518,
-    // modeling.py:1183-1190).  The engine solved the ODE with z eliminated; z and the multipliers of its rows are rebuilt here.
-    constexpr int NZA = model_nz<M>::value, DB = DN + DD * NZA, NZA1 = NZA > 0 ? NZA : 1;
-    static_assert(NZA == 0 || NTH == 0, "a DAE model with a path variable is not built");
+    constexpr int NZA = NZALG, DB = DN + DD * NZA, NZA1 = NZA > 0 ? NZA : 1;
+    constexpr bool ROWS = FUSED_CON;                       // stage constraints: rows at the collocation points and the node
+    constexpr bool ZROWS = ROWS && NZA > 0 && F::CON_USES_Z;
+    constexpr int NEX = F::NEXPR > 0 ? F::NEXPR : 1;
     const OcpConst& pc = *pcg;
     const int N = pc.N, Nc = NH > 0 ? pc.Nc : N;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= batch * N) return;
     const int64_t b = e / N;
     const int k = (int)(e - b * N);
-    const int n_vc = (N + 1) * MXA + Nc * MUA + NE, n_zn = (N + 1) * NZA, nv = n_vc + n_zn + N * DB;
+    const int n_head = (N + 1) * MXA + Nc * MUA, n_vc = n_head + NE, n_zn = (N + 1) * NZA, nv = n_vc + n_zn + N * DB;
+    const int ncc = NC > 0 ? pc.nc : 0, ntc = NC > 0 ? pc.nc_term : 0;       // the engine's rows (compact)
+    const int nrow = ROWS ? (int)pc.cost[L.o_nrow] : 0;                       // rows per point
+    const int R = ROWS ? (int)pc.cost[L.o_ncr] : 0, TR = NC > 0 ? (int)pc.cost[L.o_ntr] : 0;   // ... in the reference's g
+    const int cstride = MXA + ncc;
     const double* row = vc + b * n_vc;
+    const double* lrow = lamc ? lamc + b * (int64_t)(N * cstride + ntc) + (int64_t)k * cstride : nullptr;
     const double* pr = par + b * par_stride;
     const double* sd = C::TV ? sdata + b * sd_stride + (int64_t)k * NSD : nullptr;
     const double* p = C::TV ? sd + MX + MU : pr;
@@ -408,30 +473,34 @@ struct NmpcUser {
     }
     Colloc<MA, DD>::solve(pc.coll, x, u, p, pc.dt, X, mat);
     double* out = v + b * nv;
-    if (k == 0)
-      for (int i = 0; i < n_vc; ++i) out[i] = row[i];
+    if (k == 0) {
+      for (int i = 0; i < n_head; ++i) out[i] = row[i];
+      for (int i = 0; i < NE; ++i) out[n_head + n_zn + N * DB + i] = row[n_head + i];
+    }
 #pragma unroll
     for (int i = 0; i < DD; ++i)
 #pragma unroll
-      for (int m = 0; m < MXA; ++m) out[n_vc + n_zn + k * DB + i * MXA + m] = X[i * MXA + m] / pc.sz[m];
+      for (int m = 0; m < MXA; ++m) out[n_head + n_zn + k * DB + i * MXA + m] = X[i * MXA + m] / pc.sz[m];
     double zc[DD * NZA1];
     if constexpr (NZA > 0) {
 #pragma unroll
       for (int a = 0; a < NZA; ++a) {
-        out[n_vc + k * NZA + a] = M::z_guess(a);
-        if (k == N - 1) out[n_vc + N * NZA + a] = M::z_guess(a);
+        out[n_head + k * NZA + a] = M::z_guess(a);
+        if (k == N - 1) out[n_head + N * NZA + a] = M::z_guess(a);
       }
 #pragma unroll
       for (int i = 0; i < DD; ++i) {
         dae_solve<M>(X + i * MXA, u, p, zc + i * NZA);
 #pragma unroll
-        for (int a = 0; a < NZA; ++a) out[n_vc + n_zn + k * DB + DN + i * NZA + a] = zc[i * NZA + a];
+        for (int a = 0; a < NZA; ++a) out[n_head + n_zn + k * DB + DN + i * NZA + a] = zc[i * NZA + a];
       }
     }
     if (!lam_g) return;
+    const int per = DD * R + DB + MXA + R;                    // rows of an interval in the reference's g
+    double* lg = lam_g + b * (int64_t)(N * per + TR) + (int64_t)k * per;
     double lam[MXA], y[DN], F_[DN], mu[DN];
 #pragma unroll
-    for (int m = 0; m < MXA; ++m) lam[m] = lamc[b * (int64_t)(N * MXA) + k * MXA + m];
+    for (int m = 0; m < MXA; ++m) lam[m] = lrow[m];
     if (k == N - 1 && (pc.flags & 1)) {
       // the engine reports the last defect multiplier in the reference's convention (terminal cost on the integrated end
       // state, mpc.py:1682): lambda_ref = lambda + grad V(x_N); the collocation rows need the engine's own lambda
@@ -440,10 +509,12 @@ struct NmpcUser {
       for (int m = 0; m < MXA; ++m) {
         Jet2 xj[NX];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xj[i] = Jet2(i < MXA ? row[N * MXA + i] : 0.0, i == m ? 1.0 : 0.0, 0.0);
+        for (int i = 0; i < NX; ++i) xj[i] = Jet2(i < MXA ? row[N * MXA + i] : (i < MXA + NE ? row[n_head + (i - MXA)] : 0.0), i == m ? 1.0 : 0.0, 0.0);
         lam[m] -= term_cost(pc, pr, sdN, xj).a;
       }
     }
+    // multipliers of the engine's rows of this interval: node rows [0, nrow), point i rows [(i + 1) nrow, (i + 2) nrow)
+    const double* nu = lrow + MXA + (k == N - 1 ? ntc : 0);
 #pragma unroll
     for (int i = 0; i < DD; ++i) {
       double gl[MXA];
@@ -463,6 +534,38 @@ struct NmpcUser {
       // rows of the scaled model: G_s = G / s (base.py:1562-1591)  =>  everything in un-scaled units, mu_s = mu * s
 #pragma unroll
       for (int a = 0; a < MXA; ++a) y[i * MXA + a] = (pc.coll.Dc[i + 1] * lam[a] - gl[a]) / pc.sz[a];
+      if constexpr (ROWS) {
+        // - sum_r nu_{i,r} sign_r grad c_r(X_i): gradient in un-scaled variables, total derivative through z = zeta(X_i, u).
+        // d = 1: the node rows see z of this point too (mpc.py:1707 hands them zp_k) - their z-part joins
+        Dual<MXA> xd[MXA], ud[MUA > 0 ? MUA : 1], zd[NZA1], ce[NEX];
+#pragma unroll
+        for (int q = 0; q < MXA; ++q) {
+          xd[q] = Dual<MXA>(X[i * MXA + q]);
+          xd[q].d[q] = 1.0;
+        }
+#pragma unroll
+        for (int q = 0; q < MUA; ++q) ud[q] = Dual<MXA>(u[q]);
+        if constexpr (ZROWS) dae_solve<M>(xd, ud, p, zd);
+        F::con(xd, ud, ZROWS ? zd : (const Dual<MXA>*)nullptr, p, ce);
+        for (int r = 0; r < nrow; ++r) {
+          const double w = nu[(i + 1) * nrow + r] * pc.cost[L.o_rows + r];
+          const Dual<MXA> c = pick<NEX>(ce, (int)pc.cost[L.o_rowx + r]);
+#pragma unroll
+          for (int a = 0; a < MXA; ++a) y[i * MXA + a] -= w * c.d[a];
+        }
+        if constexpr (ZROWS && D == 1) {
+          Dual<MXA> xk[MXA], cn[NEX];
+#pragma unroll
+          for (int q = 0; q < MXA; ++q) xk[q] = Dual<MXA>(x[q]);
+          F::con(xk, ud, zd, p, cn);
+          for (int r = 0; r < nrow; ++r) {
+            const double w = nu[r] * pc.cost[L.o_rows + r];
+            const Dual<MXA> c = pick<NEX>(cn, (int)pc.cost[L.o_rowx + r]);
+#pragma unroll
+            for (int a = 0; a < MXA; ++a) y[i * MXA + a] -= w * c.d[a];
+          }
+        }
+      }
     }
     Colloc<MA, DD>::newton_matrix(pc.coll, X, u, p, pc.dt, mat, F_);
     Colloc<MA, DD>::lu(mat);
@@ -476,20 +579,41 @@ struct NmpcUser {
         for (int j = 0; j < DD; ++j) s -= pc.coll.A[j * DD + i] * y[j * MXA + a];
         mu[i * MXA + a] = s;
       }
-    double* lg = lam_g + b * (int64_t)(N * (DB + MXA)) + k * (DB + MXA);
+    // ---- rows at the collocation points, at the node, terminal rows: the engine's multipliers at their places ----
+    if constexpr (ROWS) {
+      for (int q = 0; q < DD * R; ++q) lg[q] = 0.0;                                   // dropped (unbounded) rows
+      double* lnode = lg + DD * R + DB + MXA + (k == N - 1 ? TR : 0);
+      for (int q = 0; q < R; ++q) lnode[q] = 0.0;
+      for (int r = 0; r < nrow; ++r) {
+        const int ref = (int)pc.cost[L.o_rref + r];
+        lnode[ref] = nu[r];
+        for (int i = 0; i < DD; ++i) lg[i * R + ref] = nu[(i + 1) * nrow + r];
+      }
+    }
+    if constexpr (NC > 0) {
+      if (k == N - 1 && TR > 0) {
+        double* lt = lg + DD * R + DB + MXA;
+        for (int q = 0; q < TR; ++q) lt[q] = 0.0;
+        for (int r = 0; r < ntc; ++r) lt[(int)pc.cost[L.o_trref + r]] = lrow[MXA + r];
+        if constexpr (!ROWS) {   // (no stage rows under collocation without FUSED_CON)
+        }
+      }
+    }
+    double* lc = lg + DD * R;                                                         // collocation equations
 #pragma unroll
     for (int i = 0; i < DD; ++i)
 #pragma unroll
-      for (int m = 0; m < MXA; ++m) lg[i * (MXA + NZA) + m] = mu[i * MXA + m] * pc.sz[m];
+      for (int m = 0; m < MXA; ++m) lc[i * (MXA + NZA) + m] = mu[i * MXA + m] * pc.sz[m];
     if constexpr (NZA > 0) {
-      // stationarity in z_i:  dt (df/dz)^T mu_i + (dg/dz)^T nu_i = 0   (mu_i: multiplier of the un-scaled collocation row)
+      // stationarity in z_i:  dt (df/dz)^T mu_i + (dg/dz)^T nu_i + sum_r nu_{i,r} sign_r dc_r/dz = 0   (mu_i: multiplier of
+      // the un-scaled collocation row)
 #pragma unroll
       for (int i = 0; i < DD; ++i) {
-        Dual<NZA1> xd[MX], ud[MU > 0 ? MU : 1], zd[NZA1], fd[MX], gd[NZA1];
+        Dual<NZA1> xd[MXA], ud[MUA > 0 ? MUA : 1], zd[NZA1], fd[MX], gd[NZA1];
 #pragma unroll
-        for (int q = 0; q < MX; ++q) xd[q] = Dual<NZA1>(X[i * MXA + q]);
+        for (int q = 0; q < MXA; ++q) xd[q] = Dual<NZA1>(X[i * MXA + q]);
 #pragma unroll
-        for (int q = 0; q < MU; ++q) ud[q] = Dual<NZA1>(u[q]);
+        for (int q = 0; q < MUA; ++q) ud[q] = Dual<NZA1>(u[q]);
 #pragma unroll
         for (int a = 0; a < NZA; ++a) {
           zd[a] = Dual<NZA1>(zc[i * NZA + a]);
@@ -497,7 +621,7 @@ struct NmpcUser {
         }
         M::ode_z(xd, zd, ud, p, fd);
         M::alg(xd, zd, ud, p, gd);
-        double G[NZA1 * NZA1], rhs[NZA1];      // G = (dg/dz)^T, rhs = -dt (df/dz)^T mu_i
+        double G[NZA1 * NZA1], rhs[NZA1];      // G = (dg/dz)^T, rhs = -dt (df/dz)^T mu_i - sum_r nu_r sign_r dc_r/dz
 #pragma unroll
         for (int a = 0; a < NZA; ++a) {
           double acc = 0.0;
@@ -506,6 +630,28 @@ struct NmpcUser {
           rhs[a] = -pc.dt * acc;
 #pragma unroll
           for (int c = 0; c < NZA; ++c) G[a * NZA + c] = gd[c].d[a];
+        }
+        if constexpr (ZROWS) {
+          Dual<NZA1> cz[NEX];
+          F::con(xd, ud, zd, p, cz);
+          for (int r = 0; r < nrow; ++r) {
+            const double w = nu[(i + 1) * nrow + r] * pc.cost[L.o_rows + r];
+            const Dual<NZA1> c = pick<NEX>(cz, (int)pc.cost[L.o_rowx + r]);
+#pragma unroll
+            for (int a = 0; a < NZA; ++a) rhs[a] -= w * c.d[a];
+          }
+          if constexpr (D == 1) {   // the node rows evaluated with this point's z
+            Dual<NZA1> xk[MXA], cn[NEX];
+#pragma unroll
+            for (int q = 0; q < MXA; ++q) xk[q] = Dual<NZA1>(x[q]);
+            F::con(xk, ud, zd, p, cn);
+            for (int r = 0; r < nrow; ++r) {
+              const double w = nu[r] * pc.cost[L.o_rows + r];
+              const Dual<NZA1> c = pick<NEX>(cn, (int)pc.cost[L.o_rowx + r]);
+#pragma unroll
+              for (int a = 0; a < NZA; ++a) rhs[a] -= w * c.d[a];
+            }
+          }
         }
 #pragma unroll
         for (int c = 0; c < NZA; ++c) {        // Gaussian elimination with partial pivoting (static indices)
@@ -533,11 +679,11 @@ struct NmpcUser {
           rhs[c] = acc / G[c * NZA + c];
         }
 #pragma unroll
-        for (int a = 0; a < NZA; ++a) lg[i * (MXA + NZA) + MXA + a] = rhs[a];
+        for (int a = 0; a < NZA; ++a) lc[i * (MXA + NZA) + MXA + a] = rhs[a];
       }
     }
 #pragma unroll
-    for (int m = 0; m < MXA; ++m) lg[DB + m] = lamc[b * (int64_t)(N * MXA) + k * MXA + m];
+    for (int m = 0; m < MXA; ++m) lg[DD * R + DB + m] = lrow[m];
   }
 };
 

@@ -41,9 +41,8 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   HILO_REQUIRE(!D || !discrete, "hilo_nmpc_create: collocation needs the continuous model");
   const bool cont = d->objective_continuous != 0 && !discrete;
   HILO_REQUIRE(!(cont && D) || d->coll_B, "hilo_nmpc_create: the continuous objective with collocation needs coll_B");
-  if (D && (d->n_con > 0 || d->n_tcon > 0))
-    return fail(HILO_ENOTSUP, "collocation together with nonlinear constraints is not built (the reference also imposes them at "
-                              "the collocation points, mpc.py:1338-1356)");
+  if (D && d->n_tcon > 0)
+    return fail(HILO_ENOTSUP, "collocation together with a nonlinear terminal constraint is not built");
   // ---- inequality rows (same construction as hilo_nmpc.hip) ----
   int ne = 0, nrow = 0, n_con_ref = 0, ntrow = 0, n_tcon_ref = 0, ne_stage = 0;
   int row_expr[OCP_MAXNC], row_sign[OCP_MAXNC], row_e[OCP_MAXNC], row_ref[OCP_MAXNC];
@@ -91,6 +90,16 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
       }
     }
   }
+  // collocation: the reference imposes the stage constraints at every collocation point as well as at the node (mpc.py:1338-1356,
+  // :1700-1725) - the engine's rows of a stage are the node's rows followed by those of the d collocation points
+  const int nrow_pt = nrow;
+  if (D && nrow > 0) {
+    HILO_REQUIRE(nrow * (D + 1) + ntrow <= OCP_MAXNC, "hilo_nmpc_create: %d constraint rows at %d points per interval exceed %d", nrow,
+                 D + 1, OCP_MAXNC);
+    for (int i = 1; i <= D; ++i)
+      for (int r = 0; r < nrow_pt; ++r) { row_lb[i * nrow_pt + r] = row_lb[r]; row_ub[i * nrow_pt + r] = row_ub[r]; }
+    nrow = nrow_pt * (D + 1);
+  }
   const int nc = nrow + ntrow;
   const bool hold = Nc < N;
   const int mxa = mx + nth, mua = mu + nth;
@@ -122,11 +131,13 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   h->jit_coll_d = D;
   const int nza = d->model_id == HILO_MODEL_USER ? d->user_nz : 0;
   HILO_REQUIRE(nza >= 0 && nza <= 4, "hilo_nmpc_create: at most 4 algebraic states (got %d)", nza);
-  if (nza > 0 && (D == 0 || nth > 0 || ne > 0))
-    return fail(HILO_ENOTSUP, "algebraic states (DAE) are built for the collocation transcription without a path variable or slacks");
+  if (nza > 0 && D == 0)
+    return fail(HILO_ENOTSUP, "algebraic states (DAE) are built for the collocation transcription");
   h->n_vc = (N + 1) * mxa + Nc * mua + ne;
-  h->n_v = h->n_vc + (nza ? (N + 1) * nza : 0) + N * D * (mxa + nza);   // mpc.py:1440-1453, :1488-1518
-  h->n_g = N * (mxa + n_con_ref + D * (mxa + nza)) + n_tcon_ref;       // mpc.py:1657-1669, :1684-1725
+  h->n_v = h->n_vc + (nza ? (N + 1) * nza : 0) + N * D * (mxa + nza);   // mpc.py:1440-1453, :1488-1548
+  // mpc.py:1338-1372 (per collocation point: constraint rows, then the collocation equations), :1657-1669, :1684-1725
+  h->n_g = N * (mxa + n_con_ref + D * (mxa + nza) + (D ? D * n_con_ref : 0)) + n_tcon_ref;
+  h->n_gc = D ? N * (mxa + nrow) + ntrow : 0;   // the engine's compact multiplier row handed to the output pass
   OcpConst& c = h->host;
   memset(&c, 0, sizeof(c));
   ocp_default_options(c);
@@ -198,16 +209,27 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   if (rcode) { delete h; return rcode; }
   c.nc = nrow; c.nc_term = ntrow; c.n_con_ref = n_con_ref; c.n_tcon_ref = n_tcon_ref;
   c.cost[L.o_tsoft] = d->tcon_soft ? 1.0 : 0.0;
+  c.cost[L.o_nrow] = nrow_pt; c.cost[L.o_ncr] = n_con_ref; c.cost[L.o_ntr] = n_tcon_ref;
   for (int m = 0; m < OCP_MAXNC; ++m) { c.dlb[m] = -INFINITY; c.dub[m] = INFINITY; }
-  for (int m = 0; m < nrow; ++m) {
+  for (int m = 0; m < nrow_pt; ++m) {
     c.cost[L.o_rowx + m] = row_expr[m]; c.cost[L.o_rows + m] = row_sign[m]; c.cost[L.o_rowe + m] = row_e[m];
+    c.cost[L.o_rref + m] = row_ref[m];
+  }
+  for (int m = 0; m < nrow; ++m) {
     c.dlb[m] = relaxed_lb(row_lb[m]); c.dub[m] = relaxed_ub(row_ub[m]);
-    c.row_ref[m] = (short)row_ref[m];
+    c.row_ref[m] = (short)(D ? m : row_ref[m]);
   }
   for (int r = 0; r < ntrow; ++r) {
     c.cost[L.o_trowx + r] = trow_expr[r]; c.cost[L.o_trows + r] = trow_sign[r]; c.cost[L.o_trowe + r] = trow_e[r];
+    c.cost[L.o_trref + r] = trow_ref[r];
     c.dlb[nrow + r] = relaxed_lb(trow_lb[r]); c.dub[nrow + r] = relaxed_ub(trow_ub[r]);
-    c.trow_ref[r] = (short)trow_ref[r];
+    c.trow_ref[r] = (short)(D ? r : trow_ref[r]);
+  }
+  if (D) {
+    // the solve kernel writes its multipliers compactly (identity row maps), the output pass puts them into the reference's order;
+    // the slacks sit BEHIND the collocation blocks in the rows the engine reads (v0, lbx / ubx; mpc.py:1529 follows :1497-1527)
+    c.n_con_ref = nrow; c.n_tcon_ref = ntrow;
+    if (ne > 0) c.tail_off = h->n_v - ne;
   }
   // ---- structural sparsity of the interval Hessian (desc.hess_pattern over the augmented model z): which pair directions the
   // Taylor sweeps visit.  Engine-only variables: the shared slacks couple only through off-diagonal penalty weights (rows are
@@ -288,10 +310,13 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
       for (int i = 0; i < mu; ++i) g[(N + 1) * mxa + k * mua + i] = (d->u_guess ? d->u_guess[i] : 0.0) / su[i];
       if (nth) g[(N + 1) * mxa + k * mua + mu] = d->u_pf_lb + 0.0001;                       // mpc.py:1195
     }
-    for (int q = 0; q < (nza ? 0 : N * D * mxa); ++q) {   // mpc.py:1321 (DAE layout: only the [x | u] head is a start value)
-      const int i = q % mxa;
-      g[h->n_vc + q] = i < mx ? (d->x_guess ? d->x_guess[i] : 0.0) / sx[i] : d->theta_guess;
-    }
+    // mpc.py:1321: the collocation states start at the state guess (only the [x | u] head and the slacks are read back by the engine)
+    const int head = (N + 1) * mxa + Nc * mua, zn = nza ? (N + 1) * nza : 0;
+    for (int k = 0; k < N && D; ++k)
+      for (int i = 0; i < D * mxa; ++i) {
+        const int a = i % mxa;
+        g[head + zn + k * D * (mxa + nza) + i] = a < mx ? (d->x_guess ? d->x_guess[a] : 0.0) / sx[a] : d->theta_guess;
+      }
     e = hipMemcpy(h->v_guess, g, sizeof(double) * h->n_v, hipMemcpyHostToDevice);
     delete[] g;
   }

@@ -42,7 +42,9 @@ constexpr int OCP_NCOST = 2 * OCP_MAXNZ * OCP_MAXNZ + 4 * OCP_MAXNZ + 64;
 
 struct OcpConst {
   int N, order, nsub, max_iter, acceptable_iter, flags;
-  int Nc, reserved0;   // control horizon (mpc.py:1629-1630: beyond it the last input is held); read by policies with NH > 0
+  int Nc;              // control horizon (mpc.py:1629-1630: beyond it the last input is held); read by policies with NH > 0
+  int tail_off;        // offset of the shared tail (slacks) in the rows the engine READS (v0, lbx, ubx) when it is not right behind
+                       // the inputs: with collocation the reference puts the slacks behind the collocation blocks (mpc.py:1529); 0 = default
   double dt;
   double lbz[OCP_MAXNZ], ubz[OCP_MAXNZ];  // relaxed bounds of a stage's (x,u) slots (scaled); +-inf if none
   double x0lb[OCP_MAXNX], x0ub[OCP_MAXNX];  // flags bit 1: own box of x_0 (optimize(fix_x0=False, x0_lb=, x0_ub=), mpc.py:803-807)
@@ -184,6 +186,10 @@ template <class PB> struct pb_sym_mhe<PB, void_tt<decltype(PB::SYM_MHE)>> { stat
 // the horizon-long VECTORS of the iterate in LDS (see Ocp::VEC_LDS); 0 = unknown
 template <class PB, class = void> struct pb_vec_n { static constexpr int value = 0; };
 template <class PB> struct pb_vec_n<PB, void_tt<decltype(PB::VEC_N)>> { static constexpr int value = PB::VEC_N; };
+//   FUSED_CON  the inequality rows are evaluated together with the shooting map (`dyn_cost_con`): under collocation the reference
+//          imposes the stage constraints at the collocation points too (mpc.py:1338-1356) - rows of the map's interior points
+template <class PB, class = void> struct pb_fused_con { static constexpr bool value = false; };
+template <class PB> struct pb_fused_con<PB, void_tt<decltype(PB::FUSED_CON)>> { static constexpr bool value = PB::FUSED_CON; };
 template <class PB, class = void> struct pb_fused { static constexpr bool value = false; };
 template <class PB> struct pb_fused<PB, void_tt<decltype(PB::FUSED)>> { static constexpr bool value = PB::FUSED; };
 
@@ -246,6 +252,7 @@ struct Ocp {
   static constexpr bool FIX_X0 = PB::FIX_X0;
   static constexpr int NH = pb_nh<PB>::value;          // held inputs (states NX-NH..NX-1), control horizon pc.Nc
   static constexpr bool FUSED = pb_fused<PB>::value;   // dyn_cost(): shooting map + Lagrange term in one evaluation
+  static constexpr bool FUSED_CON = pb_fused_con<PB>::value;   // dyn_cost_con(): ... and the inequality rows
   // model derivatives as generated straight-line code (ModelSym<PB::Model>, csrc/hilo_models_sym.h / codegen): second-order
   // adjoint through the Runge-Kutta stages instead of Taylor sweeps per direction pair (eval_derivs_sym)
   static constexpr bool SYM = pb_sym<PB>::value;
@@ -488,7 +495,11 @@ struct Ocp {
         double xn[NX];
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = Zp[k * NZ + NX + i];
-        if constexpr (FUSED) {
+        double dvf[NC > 0 ? NC : 1];
+        if constexpr (FUSED_CON) {
+          static_assert(!FUSED_CON || FUSED, "fused rows need the fused cost");
+          fpart += PB::dyn_cost_con(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dvf, NoExt{});
+        } else if constexpr (FUSED) {
           fpart += PB::dyn_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
         } else if constexpr (SYM) {
           // the derivative phase's own stage-point routine; the points are kept (l.Xs) for the derivative phase that follows
@@ -531,7 +542,10 @@ struct Ocp {
         }
         if constexpr (NC > 0) {
           double dv[NC];
-          PB::con(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dv);
+          if constexpr (FUSED_CON) {
+#pragma unroll
+            for (int m = 0; m < NC; ++m) dv[m] = dvf[m];
+          } else PB::con(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dv);
 #pragma unroll
           for (int m = 0; m < NC; ++m) {
             if (row_on(pc, k, m)) {
@@ -678,7 +692,10 @@ struct Ocp {
         }
         // a policy with a purely quadratic stage cost supplies value / gradient / (constant) Hessian in closed form
         Jet2 lc(0.0);
-        if constexpr (FUSED) {
+        Jet2 dvf[NC > 0 ? NC : 1];
+        if constexpr (FUSED_CON) {
+          lc = PB::dyn_cost_con(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dvf, NoExt{});
+        } else if constexpr (FUSED) {
           static_assert(!FUSED || (!COOP && !PB::QUAD_COST), "fused cost: Taylor evaluation, no cooperative model");
           lc = PB::dyn_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, NoExt{});
         } else if constexpr (!PB::QUAD_COST) lc = PB::stage_cost(pc, (const double*)l.par, sd_of(l, k), k, x, u);
@@ -700,7 +717,10 @@ struct Ocp {
         }
         if constexpr (NC > 0) {  // inequality rows: value, Jacobian column, nu-weighted second-order term
           Jet2 dv[NC];
-          PB::con(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dv);
+          if constexpr (FUSED_CON) {
+#pragma unroll
+            for (int m = 0; m < NC; ++m) dv[m] = dvf[m];
+          } else PB::con(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dv);
 #pragma unroll
           for (int m = 0; m < NC; ++m) {
             if (row_on(pc, k, m)) {
@@ -2495,7 +2515,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     // min(k - 1, Nc - 1) (zero at stage 0, where it is pinned and never read)
     const int Ncv = NH > 0 ? pc.Nc : N;
     if (i < NXV) v = (k == 0 && S::x0_pinned(pc, i)) ? x0[b * S::NX0 + i] / pc.sz[i] : vb[k * NXV + i];
-    else if (i < NXV + NTAIL) v = vb[(N + 1) * NXV + Ncv * NU + (i - NXV)];
+    else if (i < NXV + NTAIL) v = vb[(pc.tail_off > 0 ? pc.tail_off : (N + 1) * NXV + Ncv * NU) + (i - NXV)];
     else if (i < NX) v = k == 0 ? 0.0 : vb[(N + 1) * NXV + ((k - 1 < Ncv ? k - 1 : Ncv - 1)) * NU + (i - NXV - NTAIL)];
     else v = (k < Ncv) ? vb[(N + 1) * NXV + k * NU + (i - NX)] : 0.0;
     const bool fr = S::is_free(pc, k, i);
@@ -2503,7 +2523,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     if (ex.lbx && fr && !(k == 0 && (pc.flags & 2) && i < S::NX0)) {   // bounds of this call (the box of a free x_0 stays its own): the slot's entry of the reference's lbx / ubx (same index as in v)
       int src = -1;
       if (i < NXV) src = k * NXV + i;
-      else if (i < NXV + NTAIL) { if (k == 0) src = (N + 1) * NXV + Ncv * NU + (i - NXV); }
+      else if (i < NXV + NTAIL) { if (k == 0) src = (pc.tail_off > 0 ? pc.tail_off : (N + 1) * NXV + Ncv * NU) + (i - NXV); }
       else if (i >= NX && k < Ncv) src = (N + 1) * NXV + k * NU + (i - NX);
       if (src >= 0) {
         const double lo = ex.lbx[b * ex.bx_stride + v_prefix + src], up = ex.ubx[b * ex.bx_stride + v_prefix + src];

@@ -165,7 +165,10 @@ class LMPC:
         if n_tvp:
             ci = self._n_iterations
             if tvp is not None:
-                for r, (key, value) in enumerate(tvp.items()):
+                for key, value in tvp.items():
+                    if key not in tv:
+                        raise ValueError(f"The parameter {key} was not declared time varying (set_time_varying_parameters: {tv})")
+                    r = tv.index(key)                       # rows of the window follow the declared names, not the dictionary's order
                     if len(value) < N:
                         raise TypeError(f"When passing time-varying parameters, you need to pass a number of values at least as "
                                         f"long as the prediction horizon. The parameter {key} has {len(value)} values but the MPC "
@@ -197,11 +200,10 @@ class LMPC:
                                  f"the set_time_varying_parameters() method.")
         P = np.empty((N if n_tvp else 1, npar))
         for k in range(P.shape[0]):
-            it = ic = 0
+            ic = 0
             for j, name in enumerate(names):
                 if name in tv:
-                    P[k, j] = win[it, k]
-                    it += 1
+                    P[k, j] = win[tv.index(name), k]        # by NAME: the declared order need not be the model's parameter order
                 else:
                     P[k, j] = cpv[ic]
                     ic += 1
@@ -279,7 +281,11 @@ class LMPC:
             raise ValueError("Howdy! You need to setup the MPC before optimizing. Run .setup() on the MPC object.")
         if self._n_par():
             P = self._stage_parameters(cp, tvp)
-            key = P.tobytes()
+            # Aeq also depends on the equilibrium point the matrices are taken at and on the sampling interval
+            # (mpc.py:2350-2353 substitutes x_eq / u_eq with every call)
+            eq = [np.asarray(getattr(self._model, a, None) if getattr(self._model, a, None) is not None else [], dtype=float).ravel()
+                  for a in ('_x_eq', '_u_eq')]
+            key = P.tobytes() + b'|' + eq[0].tobytes() + b'|' + eq[1].tobytes() + b'|' + repr(self._model.dt).encode()
             if key != self._aeq_key:        # new parameter values: the equality block of this QP (host assembly, one upload)
                 mats = [self._model.system_matrices(p=pk) for pk in P]
                 Aeq = self._equality_matrix([m[0] for m in mats], [m[1] for m in mats], self._kron_variant)

@@ -245,6 +245,12 @@ class Model:
         """HIP source that defines `UserModel` for the run-time compiled path: the emitted functor, or the alias of the
         zoo functor.  z_guess: start of the Newton iteration on the algebraic equations of a DAE (`set_initial_guess(z_guess=)`)."""
         from . import codegen
+        if getattr(self, '_linearized', False):
+            # linearize() keeps the nonlinear equations and only marks the copy (the matrices come from system_matrices()); kernels
+            # compiled from it would run the NONLINEAR dynamics in absolute coordinates (the reference rewrites the equations in
+            # deviation variables, dynamic_model.py:2488-2612)
+            raise NotImplementedError("a linearised model (Model.linearize) is offloaded for the linear MPC and system_matrices() only; "
+                                      "filters, NMPC and simulation need the model itself")
         if self._symbolic:
             if self._ode is None:
                 raise RuntimeError("Model is not set up: no dynamical equations (set_dynamical_equations)")

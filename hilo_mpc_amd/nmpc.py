@@ -846,9 +846,11 @@ class NMPC:
             from . import codegen
             nza = getattr(m, 'n_z', 0)
             if nza:
-                if coll is None or nth or general and (sc.is_set or tc.is_set):
+                if coll is None:
                     raise NotImplementedError("algebraic states (DAE models) are offloaded for the collocation transcription "
-                                              "(the reference's default) without path variables or nonlinear constraints")
+                                              "(the reference's default)")
+                if tc.is_set:
+                    raise NotImplementedError("a nonlinear terminal constraint on a DAE model is not offloaded")
                 src = m.user_source(z_guess=getattr(self, '_z_guess', None))
                 d.user_nz = nza
             else:
@@ -924,12 +926,13 @@ class NMPC:
         nxa, nua = nx + nth, nu + nth
         self._x_ind = [list(range(k * nxa, (k + 1) * nxa)) for k in range(N + 1)]
         self._u_ind = [list(range((N + 1) * nxa + k * nua, (N + 1) * nxa + (k + 1) * nua)) for k in range(Nc)]
-        self._e_soft_stage_ind = list(range((N + 1) * nxa + Nc * nua, (N + 1) * nxa + Nc * nua + ne))
-        off = (N + 1) * nxa + Nc * nua + ne
-        self._e_soft_term_ind = list(range(off, off + ne_term))                                           # mpc.py:1542-1543
         dn = coll['d'] * nxa if coll is not None else 0
-        off += ne_term
         nza = getattr(m, 'n_z', 0) if coll is not None else 0
+        off = (N + 1) * nxa + Nc * nua
+        # the slacks of the soft constraints come LAST in v (mpc.py:1529-1548 follows the algebraic and collocation blocks, :1488-1527)
+        eoff = off + (N + 1) * nza + N * (dn + (coll['d'] * nza if coll is not None else 0))
+        self._e_soft_stage_ind = list(range(eoff, eoff + ne))
+        self._e_soft_term_ind = list(range(eoff + ne, eoff + ne + ne_term))                               # mpc.py:1542-1543
         # algebraic states: node blocks z_0..z_N behind the slacks' predecessors, then per interval [ip_k | zp_k] (mpc.py:1488-1518)
         self._z_ind = [list(range(off + k * nza, off + (k + 1) * nza)) for k in range(N + 1)] if nza else []
         off += (N + 1) * nza

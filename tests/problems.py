@@ -61,6 +61,15 @@ def symbolic_model(name):
         m.set_dynamical_equations([x[1], dv, x[3], 1.0 / l * (dv * c + g * s)])
         m.set_algebraic_equations([h + l * c - z[0]])
         m.set_measurement_equations([x[0], x[1], x[2], x[3]])
+    elif name in ('robot6', 'robot6_dae'):
+        # C5's robot (oracle/models.py::robot6) and its DAE variant: the squared speed as algebraic state, 0 = z - (vx^2 + vy^2)
+        x = m.set_dynamical_states(['px', 'vx', 'py', 'vy', 'psi', 'omega'])
+        u = m.set_inputs(['a', 'alpha'])
+        m.set_dynamical_equations([x[1], u[0] * cos(x[4]), x[3], u[0] * sin(x[4]), x[5], u[1]])
+        if name == 'robot6_dae':
+            z = m.set_algebraic_states(['z'])
+            m.set_algebraic_equations([z[0] - (x[1] * x[1] + x[3] * x[3])])
+        m.set_measurement_equations([x[0], x[2]])
     elif name == 'chemostat4_mu':
         # the chemostat whose growth rate of the biomass balance is a parameter `mu` - to be replaced by a learned model
         # (`model.substitute_from(gp)`, nmpc_hybrid_bio.ipynb); the other rates keep their closed forms
@@ -295,14 +304,21 @@ def oracle_gen(spec):
 
 def product_gen(spec, **solver_options):
     """Product NMPC for a general spec (path following / stage constraints) through the reference-style API; the
-    expression strings of the spec are evaluated on the model's symbols."""
+    expression strings of the spec are evaluated on the model's symbols.  spec['collocation'] = dict(degree=, points=, objective=):
+    the continuous model (written as expressions; DAE models too) under the reference's default integration method."""
     from hilo_mpc_amd import NMPC, Model, expr
-    m = Model(spec['model']).discretize('erk', order=spec.get('order', 4)).setup(dt=spec['dt'])
+    coll = spec.get('collocation')
+    if coll is not None:
+        m = symbolic_model(spec['model']).setup(dt=spec['dt'])
+    else:
+        m = Model(spec['model']).discretize('erk', order=spec.get('order', 4)).setup(dt=spec['dt'])
     nmpc = NMPC(m)
     xs, us = m.dynamical_state_names, m.input_names
     ns = {'sin': expr.sin, 'cos': expr.cos, 'exp': expr.exp, 'log': expr.log, 'sqrt': expr.sqrt}
     ns.update({n: m.x[n] for n in xs})
     ns.update({n: m.u[n] for n in us})
+    if getattr(m, 'n_z', 0):
+        ns.update({n: m.z[n] for n in m.algebraic_state_names})
     for ind, W, ref in spec.get('stage_states', []):
         nmpc.quad_stage_cost.add_states(names=[xs[i] for i in ind], weights=list(W), ref=ref)
     for ind, W, ref in spec.get('stage_inputs', []):
@@ -339,11 +355,32 @@ def product_gen(spec, **solver_options):
             nmpc.terminal_constraint.max_violation = tc['max_violation']
     nmpc.horizon = spec['N']
     nmpc.set_box_constraints(x_ub=spec.get('x_ub'), x_lb=spec.get('x_lb'), u_ub=spec.get('u_ub'), u_lb=spec.get('u_lb'))
-    nmpc.set_initial_guess(x_guess=spec.get('x_guess'), u_guess=spec.get('u_guess'))
+    nmpc.set_initial_guess(x_guess=spec.get('x_guess'), u_guess=spec.get('u_guess'), z_guess=spec.get('z_guess'))
     if spec.get('x_scaling') or spec.get('u_scaling'):
         nmpc.set_scaling(x_scaling=spec.get('x_scaling'), u_scaling=spec.get('u_scaling'))
-    nmpc.setup(options={'integration_method': 'discrete'}, solver_options=solver_options or None)
+    if coll is not None:
+        opts = {'integration_method': 'collocation', 'degree': coll.get('degree', 3), 'collocation_points': coll.get('points', 'radau'),
+                'objective_function': coll.get('objective', 'continuous')}
+    else:
+        opts = {'integration_method': 'discrete'}
+    nmpc.setup(options=opts, solver_options=solver_options or None)
     return nmpc
+
+
+# BASELINE configuration 5 as it is written: path following on the robot's DAE (squared speed as algebraic state) with the soft
+# speed limit on that algebraic state, the reference's default transcription (collocation, Radau 3, continuous objective)
+C5D = dict(C5, model='robot6_dae', constraint=dict(expr=['z'], lb=[-np.inf], ub=[4.], soft=True), z_guess=[3.94],
+           collocation=dict(degree=3))
+C5DS = dict(C5D, N=10)
+
+
+def oracle_coll_gen(spec):
+    from oracle import models
+    from oracle.nmpc_coll_gen import GenCollProblem
+    kw = {k: v for k, v in spec.items() if k not in ('model', 'p', 'order', 'collocation')}
+    co = spec.get('collocation', {})
+    return GenCollProblem(models.get(spec['model']), degree=co.get('degree', 3), points=co.get('points', 'radau'),
+                          objective=co.get('objective', 'continuous'), **kw)
 
 
 # ---- stochastic NMPC: the reference's own test systems (tests/test_SMPC.py) and a nonlinear one -------------

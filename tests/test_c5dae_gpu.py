@@ -1,0 +1,130 @@
+"""GPU parity of BASELINE configuration 5 as it is written: path-following NMPC on a DAE with soft constraints - and of what it is
+made of: the reference's default transcription (collocation) together with a path variable (mpc.py:1173-1204), algebraic states
+(mpc.py:1488-1527) and nonlinear stage constraints, which the reference imposes at every collocation point as well as at the node
+(mpc.py:1338-1356, :1700-1725).  The product eliminates the collocation and the algebraic states inside the shooting map and
+rebuilds them - and the multipliers of their rows - in the reference's layout; the oracle (oracle/nmpc_coll_gen.py) carries them
+as variables like the reference.  Both run at tol = 1e-10 (two solvers that stop at a KKT error of 1e-8 agree to 5e-5
+only); tolerances: v 1e-6 relative, f 1e-9, u0 1e-6, multipliers 1e-5."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.nmpc import IpmOptions                                                                  # noqa: E402
+from oracle.nmpc_coll_gen import GenCollIpm                                                          # noqa: E402
+from tests.problems import C2, C5D, C5DS, c2_x0, c5_x0, oracle_coll_gen, product_gen                 # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'nmpc_c5dae.json')
+TOL = 1e-10
+
+
+def _layout(nmpc, pb):
+    assert (nmpc._n_v, nmpc._n_g) == (pb.n_v, pb.n_g)
+    assert nmpc._x_ind == pb.x_ind and nmpc._u_ind == pb.u_ind and nmpc._e_soft_stage_ind == pb.e_ind
+    assert nmpc._ip_ind == pb.ip_ind and nmpc._z_ind == pb.z_ind and nmpc._zp_ind == pb.zp_ind
+
+
+def _compare(spec, x0, p, vtol=1e-6, ltol=1e-5):
+    pb = oracle_coll_gen(spec)
+    ipm = GenCollIpm(pb, IpmOptions(tol=TOL))
+    ref = ipm.solve(x0, p)
+    nmpc = product_gen(spec, **{'ipopt.tol': TOL})
+    _layout(nmpc, pb)
+    u = nmpc.optimize(x0, cp=p if len(p) else None)
+    assert np.array_equal(nmpc.solver_status_code, ref['status']) and np.all(ref['status'] == 1)
+    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), ipm.to_v(ref)
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < vtol
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(u, ref['u0'], rtol=vtol, atol=vtol)
+    lam, lr = nmpc._nlp_solution['lam_g'].cpu().numpy(), ipm.lam_g(ref)
+    assert np.max(np.abs(lam - lr) / np.maximum(1., np.abs(lr))) < ltol
+    return nmpc, pb, ipm, ref
+
+
+def test_c5_dae_short_horizon_vs_oracle():
+    """N = 10, B = 8: theta inside the collocation scheme, the soft limit z <= 4 on the ALGEBRAIC state at the three collocation
+    points and the node of every interval, one shared slack behind the collocation blocks of v."""
+    x0 = c5_x0(8)
+    nmpc, pb, ipm, ref = _compare(C5DS, x0, [])
+    assert (pb.n_v, pb.n_g) == (11 * 7 + 10 * 3 + 11 + 10 * 24 + 1, 10 * (3 * 2 + 24 + 7 + 2))
+    assert ref['E'].max() > 1e-3                                                        # some x_0 break the limit: the slack is used
+    e = nmpc.stage_constraint.e_soft_value.cpu().numpy()
+    np.testing.assert_allclose(e, ref['E'], rtol=1e-6, atol=1e-8)
+    v = nmpc._nlp_solution['x'].cpu().numpy()
+    lam = nmpc._nlp_solution['lam_g'].cpu().numpy().reshape(8, pb.N, -1)
+    # per interval [3 x (z - e <= 4, dropped lower row) | 3 x (7 ode rows, 1 algebraic row) | 7 continuity | node rows (2)]
+    assert np.abs(lam[:, :, [6 + 7, 6 + 15, 6 + 23]]).max() > 1e-3                     # the algebraic rows carry force
+    assert np.all(lam[:, :, [1, 3, 5, 38]] == 0.)                                      # rows without a finite bound: dropped
+    assert lam[:, :, [0, 2, 4, 37]].max() > 1e-3 and lam[:, :, [0, 2, 4, 37]].min() >= 0.   # active upper rows: multipliers >= 0
+    # the algebraic equation holds at the collocation points of the returned vector
+    for k in range(pb.N):
+        Xc = v[:, pb.ip_ind[k]].reshape(8, 3, 7)
+        Zc = v[:, pb.zp_ind[k]].reshape(8, 3)
+        np.testing.assert_allclose(Zc, Xc[:, :, 1] ** 2 + Xc[:, :, 3] ** 2, rtol=1e-12, atol=1e-12)
+    # closed loop, warm start (the reference re-uses the previous solution, mpc.py:725-726)
+    x1 = nmpc.plant_step(x0, ref['u0']).cpu().numpy()
+    ref2 = ipm.solve(x1, [], w0=ipm.w_from_v(ipm.to_v(ref)))
+    u2 = nmpc.optimize(x1)
+    assert np.array_equal(nmpc.solver_status_code, ref2['status'])
+    np.testing.assert_allclose(u2, ref2['u0'], rtol=1e-6, atol=1e-6)
+
+
+def test_degree_one_node_rows_see_the_collocation_points_algebraic_state():
+    """degree = 1 is the only degree for which the reference's node residual `_stage_constraints_fun(.., zp[ii, 0], ..)`
+    (mpc.py:1707) type-checks with algebraic states: it receives z of the single collocation point (Radau: the END of the
+    interval).  Restated as it is, on both sides."""
+    spec = dict(C5DS, N=6, collocation=dict(degree=1))
+    _compare(spec, c5_x0(4), [])
+
+
+def test_hard_and_two_sided_rows_on_an_ode_under_collocation():
+    """chemostat4 (ODE) under collocation with a hard one-sided and a soft two-sided stage constraint side by side is not a
+    reference configuration (one GenericConstraint is hard or soft as a whole) - so: hard rows, then soft two-sided rows."""
+    kw = dict(C2, N=8, collocation=dict(degree=3))
+    kw.pop('order', None)
+    hard = dict(kw, constraint=dict(expr=['X * S', 'S - X'], lb=[-np.inf, 0.], ub=[60., np.inf]))
+    nmpc, pb, ipm, ref = _compare(hard, c2_x0(4), C2['p'])
+    assert pb.n_g == 8 * (3 * 2 + 12 + 4 + 2)
+    soft = dict(kw, constraint=dict(expr=['X * S'], lb=[2.], ub=[60.], soft=True, weight=[[1e3]], max_violation=[5.]))
+    _compare(soft, c2_x0(4), C2['p'])
+    disc = dict(hard, collocation=dict(degree=2, objective='discrete'))
+    _compare(disc, c2_x0(4), C2['p'])
+
+
+def test_c5_dae_full_horizon_vs_fixture_and_batch_properties():
+    """N = 50 (the configuration's horizon), B = 3 against the oracle's solution stored by tests/golden/make_c5dae_golden.py (the
+    dense oracle needs minutes for it); then B = 1024 in closed loop: every instance solved, the slack covers the limit at every
+    node and collocation point, z is consistent with the states."""
+    with open(GOLD) as f:
+        g = json.load(f)
+    x0 = np.array(g['x0'])
+    nmpc = product_gen(C5D, **{'ipopt.tol': TOL})
+    assert (nmpc._n_v, nmpc._n_g) == (g['n_v'], g['n_g']) == (51 * 7 + 50 * 3 + 51 + 50 * 24 + 1, 50 * 39)
+    u = nmpc.optimize(x0)
+    assert np.array_equal(nmpc.solver_status_code, np.array(g['status']))
+    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), np.array(g['v'])
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 1e-6
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), g['f'], rtol=1e-9)
+    np.testing.assert_allclose(u, g['u0'], rtol=1e-6, atol=1e-6)
+    lam, lr = nmpc._nlp_solution['lam_g'].cpu().numpy(), np.array(g['lam_g'])
+    assert np.max(np.abs(lam - lr) / np.maximum(1., np.abs(lr))) < 1e-5
+    nm = product_gen(C5D)
+    x = c5_x0(1024)
+    for _ in range(3):
+        u = nm.optimize(x)
+        assert np.all(nm.solver_status_code == 1), np.unique(nm.solver_status_code, return_counts=True)
+        v = nm._nlp_solution['x'].cpu().numpy()
+        e = v[:, nm._e_soft_stage_ind]
+        assert np.all(e >= -1e-8)
+        for k in range(50):
+            Xc = v[:, nm._ip_ind[k]].reshape(-1, 3, 7)
+            Zc = v[:, nm._zp_ind[k]].reshape(-1, 3)
+            assert np.abs(Zc - (Xc[:, :, 1] ** 2 + Xc[:, :, 3] ** 2)).max() < 1e-10
+            assert np.all(Zc <= 4. + e + 1e-6)
+            xk = v[:, nm._x_ind[k]]
+            assert np.all(xk[:, 1] ** 2 + xk[:, 3] ** 2 <= 4. + e[:, 0] + 1e-6)
+        x = nm.plant_step(x, u).cpu().numpy()
+    assert np.all(np.isfinite(x))
