@@ -376,7 +376,7 @@ def cpu_leg_qp(budget=6., min_batch=4096):
 
 
 def wl_nmpc(cfg, args, torch, dev, rank, world):
-    from hilo_mpc_amd.dist import StepGather, shard_range
+    from hilo_mpc_amd.dist import ClosedLoop, shard_range
     from tests import problems as P
     if cfg == 'C2':
         spec, B, gB = P.C2, args.batch or 1024, (args.batch or 1024) * world
@@ -404,23 +404,19 @@ def wl_nmpc(cfg, args, torch, dev, rank, world):
     N = nmpc.horizon
     x = torch.as_tensor(x0, device=dev)
     p = torch.as_tensor(np.asarray(spec['p'], dtype=np.float64), device=dev) if len(spec['p']) else None
-    gather = StepGather(gB if cfg != 'C2' else B * world, nmpc._n_u, rank, world, dev)
-    gather.attach(nmpc)            # plain tracking problems: the solve writes the gather rows itself
+    # the closed loop of a shard (hilo_mpc_amd/dist.py::ClosedLoop; the same object tests/test_dist_cpu.py drives with a stub
+    # controller over gloo): one hilo_nmpc_solve launch for the whole shard, the one collective of the step (RCCL all-gather;
+    # plain tracking problems: the solve writes the gather rows itself), the plant step
+    loop = ClosedLoop(nmpc, gB if cfg != 'C2' else B * world, nmpc._n_u, rank, world, dev, x, p)
     ev, log = [], []
 
     def step(timed):
-        nonlocal x
         e = _events(torch, 1)[0]        # warm-up steps run the identical path (event creation included)
-        e[0].record()
-        u = nmpc.optimize(x, cp=p)                         # one hilo_nmpc_solve launch for the whole shard
-        e[1].record()
+        loop.step(before=e[0].record, after=e[1].record)
         if timed:
             ev.append(e)
-        sol = nmpc._nlp_solution
-        gather(u, sol['status'], sol['iter_count'])        # the one collective of the step (RCCL all-gather)
-        if timed:
+            sol = nmpc._nlp_solution
             log.append((sol['iter_count'], sol['status'], sol['kkt_error']))
-        x = nmpc.plant_step(x, u, cp=p)
 
     def finish():
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))

@@ -55,6 +55,8 @@ class StepGather:
 
     def __call__(self, u0=None, status=None, iters=None):
         n = self.sizes[self.rank]
+        if n < self.max_n:
+            self.send[n:] = 0.        # padding rows of a smaller shard: never read back, but the wire carries defined values
         if not self.attached:
             self.send[:n, :self.nu] = u0
             self.send[:n, self.nu] = status.to(torch.float64)
@@ -68,3 +70,32 @@ class StepGather:
             else:
                 full = torch.cat([self.recv[r * self.max_n: r * self.max_n + self.sizes[r]] for r in range(self.world)], dim=0)
         return full[:, :self.nu], full[:, self.nu].to(torch.int32), full[:, self.nu + 1].to(torch.int32)
+
+
+class ClosedLoop:
+    """The closed loop of one shard - what `bench.py` times per step and what a deployment runs: solve the shard's instances
+    (ONE launch), gather `(u0, status, iters)` of all shards (ONE collective), advance the shard's plants.  `controller` needs
+    `optimize(x, cp=)`, `plant_step(x, u, cp=)`, `_nlp_solution` with 'status' / 'iter_count' and, optionally,
+    `set_gather_buffer` (the solve kernel writes the gather rows itself)."""
+
+    def __init__(self, controller, batch, nu, rank, world, device, x0, p=None, attach=True):
+        self.ctl, self.p = controller, p
+        self.lo, self.hi = shard_range(batch, rank, world)
+        self.gather = StepGather(batch, nu, rank, world, device)
+        if attach and hasattr(controller, 'set_gather_buffer'):
+            self.gather.attach(controller)
+        self.x = x0
+        self.last = None
+
+    def step(self, before=None, after=None):
+        """One step; `before` / `after` bracket the solve (bench.py records its HIP events there).  Returns the gathered
+        (u0 [B, nu], status [B], iters [B]) of ALL shards."""
+        if before is not None:
+            before()
+        u = self.ctl.optimize(self.x, cp=self.p)
+        if after is not None:
+            after()
+        sol = self.ctl._nlp_solution
+        self.last = self.gather(u, sol['status'], sol['iter_count'])
+        self.x = self.ctl.plant_step(self.x, u, cp=self.p)
+        return self.last

@@ -52,3 +52,88 @@ def test_step_gather_world2_gloo():
     np.testing.assert_array_equal(u, np.stack([idx * 10, idx * 10 + 1], axis=1))
     np.testing.assert_array_equal(st, (idx % 5).astype(np.int32))
     np.testing.assert_array_equal(it, (idx + 3).astype(np.int32))
+
+
+class _StubController:
+    """Stands in for NMPC in the closed loop of a shard: u = -K x, x+ = 0.9 x + [u, 0]; status / iteration count are functions of
+    the state so that a row that ends up at the wrong place of the gathered table is seen.  `kernel_rows=True`: like the solve
+    kernel after hilo_nmpc_set_gather, optimize() writes its rows [u0 | status | iters] into the attached table itself."""
+
+    def __init__(self, nx, nu, kernel_rows):
+        self.nx, self.nu, self.kernel_rows = nx, nu, kernel_rows
+        self.table = None
+        self._nlp_solution = None
+
+    def set_gather_buffer(self, table):
+        if not self.kernel_rows:
+            return False
+        self.table = table
+        return True
+
+    def optimize(self, x, cp=None):
+        u = -0.5 * x[:, :self.nu] + (0. if cp is None else cp[0])
+        st = (x.abs().sum(1) * 7).to(torch.int32) % 5 + 1
+        it = (x.abs().sum(1) * 3).to(torch.int32) + 2
+        self._nlp_solution = {'status': st, 'iter_count': it}
+        if self.table is not None:
+            n = x.shape[0]
+            self.table[:n, :self.nu] = u
+            self.table[:n, self.nu] = st.to(torch.float64)
+            self.table[:n, self.nu + 1] = it.to(torch.float64)
+        return u
+
+    def plant_step(self, x, u, cp=None):
+        xn = 0.9 * x
+        xn[:, :self.nu] += u
+        return xn
+
+
+def _loop_worker(rank, world, port, B, kernel_rows, steps, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from hilo_mpc_amd.dist import ClosedLoop
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    nx, nu = 3, 2
+    lo, hi = shard_range(B, rank, world)
+    x0 = torch.as_tensor(np.random.default_rng(0).uniform(-2, 2, (B, nx)))[lo:hi].clone()
+    loop = ClosedLoop(_StubController(nx, nu, kernel_rows), B, nu, rank, world, torch.device('cpu'), x0, p=torch.tensor([.25]))
+    assert loop.gather.attached == kernel_rows
+    res = []
+    for _ in range(steps):
+        u, st, it = loop.step()
+        res.append((u.numpy().copy(), st.numpy().copy(), it.numpy().copy()))
+    if rank == 0:
+        out.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_closed_loop_step_world2_gloo_uneven_shards():
+    """The closed loop `bench.py` runs per shard (hilo_mpc_amd/dist.py::ClosedLoop) with a stub controller, two ranks with shards
+    of different sizes (6 + 5), both ways of filling the gather rows: the gathered table of every step equals the single-process
+    run of the whole batch."""
+    from hilo_mpc_amd.dist import ClosedLoop
+    B, steps, nx, nu = 11, 3, 3, 2
+    x0 = torch.as_tensor(np.random.default_rng(0).uniform(-2, 2, (B, nx)))
+    one = ClosedLoop(_StubController(nx, nu, False), B, nu, 0, 1, torch.device('cpu'), x0.clone(), p=torch.tensor([.25]))
+    ref = []
+    for _ in range(steps):
+        u, st, it = one.step()
+        ref.append((u.numpy().copy(), st.numpy().copy(), it.numpy().copy()))
+    for kernel_rows in (False, True):
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, B, kernel_rows, steps, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = q.get(timeout=180)
+        for p in procs:
+            p.join(timeout=180)
+            assert p.exitcode == 0
+        for (u, st, it), (ur, sr, ir) in zip(res, ref):
+            np.testing.assert_allclose(u, ur, rtol=0, atol=0)
+            np.testing.assert_array_equal(st, sr)
+            np.testing.assert_array_equal(it, ir)
