@@ -18,7 +18,9 @@ configurations of SURVEY 8d, each printing its own JSON line:
   C3-ekf      EKF step chemostat4, B = 4096 per GPU (weak)      } HBM-bound: 8 (2 nx (nx+1) + 2 ny + nu + np) bytes per step
   C3-ukf      UKF step chemostat4, B = 4096 per GPU (weak)      }
   C4          GP-hybrid NMPC (GP with 200 training points inside the model), B = 2048 in total (strong sharding)
-  C5          path-following NMPC robot6 N=50 with a soft constraint, B = 8192 in total (strong sharding)
+  C5          path-following NMPC robot6 N=50 with a soft constraint, B = 8192 in total (strong sharding): the ODE, pre-discretised
+  C5-dae      BASELINE configuration 5 as it is written: the robot as a DAE (squared speed as algebraic state), the soft limit on the
+              algebraic state, the reference's default transcription (collocation Radau 3, continuous objective), B = 8192 in total
   gp-predict  GaussianProcess.predict with variance, n = 200 training points, 2^18 query columns per GPU and step
 
 A "step" of the harness is one pass of the configuration's hot call over the whole (sharded) batch + (closed loops) the plant
@@ -45,7 +47,7 @@ if ROOT not in sys.path:
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X fp64 vector = fp64 matrix (MFMA) peak, dense
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md
-CONFIGS = ('C1', 'C2', 'C3-mhe', 'C3-ekf', 'C3-ukf', 'C4', 'C5', 'gp-predict')
+CONFIGS = ('C1', 'C2', 'C3-mhe', 'C3-ekf', 'C3-ukf', 'C4', 'C5', 'C5-dae', 'gp-predict')
 
 # algorithmic flop model: per interior-point iteration and shooting interval
 #   F_ric = 7/3 nx^3 + 4 nx^2 nu + 2 nx nu^2 + nu^3/3 + 8 nx^2 + 8 nx nu + 2 nu^2          
@@ -72,13 +74,14 @@ def flops_per_iteration_survey(nx, nu, N, s=4, ops=(C_F, C_J, C_H)):
     return N * (f_ric(nx, nu) + s * (ops[0] + ops[1] + 2 * nx ** 2 * (nx + nu)))
 
 
-def pmc_traffic_bytes(tag_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN_<config>_summary.json:
+def pmc_traffic_bytes(tag_key, with_source=False):
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (profiles/rNN_<config>_summary.json:
     FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command), newest round first; None if this
-    configuration has no committed PMC pass.  Calibration: see DESIGN.md 5 (8-byte lanes: no 2x correction)."""
+    configuration has no committed PMC pass.  Not measured in this run: `traffic_source` of the line names the file.
+    Calibration: see DESIGN.md 5 (8-byte lanes: no 2x correction)."""
     import glob
     import re
-    best = None
+    best, src = None, None
     files = [f for f in glob.glob(os.path.join(ROOT, 'profiles', f'r*_{tag_key}_summary.json'))
              if re.fullmatch(rf'r\d\d_{re.escape(tag_key)}_summary\.json', os.path.basename(f))]     # round tags only (r02, not r02a)
     if tag_key == 'C2':
@@ -88,9 +91,10 @@ def pmc_traffic_bytes(tag_key):
         try:
             d = json.load(open(f))
             best = (d['FETCH_SIZE_KB_per_launch']['warm_launches_mean'] + d['WRITE_SIZE_KB_per_launch']['warm_launches_mean']) * 1024
+            src = f"committed profile profiles/{os.path.basename(f)} (separate --pmc passes of this command; not measured in this run)"
         except Exception:
             pass
-    return best
+    return (best, src) if with_source else best
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -109,18 +113,24 @@ def _ipm_stats(torch, log):
     return float(iters.mean().item()), float(ok.to(torch.float64).mean().item()), float(kkt[ok].max().item()) if bool(ok.any()) else float('nan')
 
 
-def _solve_roofline(kernel, B, mean_iters, nx, nu, N, ops, kern_ms, tag, n_v, n_g, n_p):
-    fl = B * mean_iters * flops_per_iteration(nx, nu, N, ops=ops)
-    fl_s = B * mean_iters * flops_per_iteration_survey(nx, nu, N, ops=ops)
-    tf = fl / (kern_ms * 1e-3) / 1e12
+def _solve_roofline(kernel, B, mean_iters, nx, nu, N, ops, kern_ms, tag, n_v, n_g, n_p, s=4):
+    """Primary figures follow SURVEY 8d as written: flops = K N [F_ric + F_dyn], F_dyn = s (C_f + C_J + 2 nx^2 (nx + nu)); the count
+    that also prices the lambda-contracted Hessian of the shooting map (what an exact-Hessian interior point evaluates, DESIGN.md
+    5.1) is the secondary `frac_with_hessian`."""
+    fl = B * mean_iters * flops_per_iteration(nx, nu, N, s=s, ops=ops)
+    fl_s = B * mean_iters * flops_per_iteration_survey(nx, nu, N, s=s, ops=ops)
+    tf = fl_s / (kern_ms * 1e-3) / 1e12
     bytes_launch = B * 8 * (2 * n_v + 2 * n_g + nx + n_p + nu)      # SURVEY 8d bytes_nmpc (compulsory)
     gbs = bytes_launch / (kern_ms * 1e-3) / 1e9
+    traffic, src = pmc_traffic_bytes(tag, with_source=True)
     return {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
-            "traffic": pmc_traffic_bytes(tag), "kernel": kernel, "kernel_ms": kern_ms,
-            "frac_survey_formula": fl_s / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            "traffic": traffic, "traffic_source": src, "kernel": kernel, "kernel_ms": kern_ms,
+            "frac_with_hessian": fl / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            "algorithmic_flops_per_launch": fl_s,
             "note": "fp64 roof: MI355X fp64 vector peak == fp64 MFMA peak = 78.6 TFLOP/s; the solve is fp64 VALU/latency bound "
-                    "(f64 MFMA for the Riccati stage products); algorithmic flops = B * mean_iters * N * (F_ric + F_dyn) "
-                    "(DESIGN.md 5.1; `frac_survey_formula` uses SURVEY 8d's F_dyn without the contracted Hessian)",
+                    "(f64 MFMA for the Riccati stage products); algorithmic flops = B * mean_iters * N * (F_ric + F_dyn) with SURVEY "
+                    "8d's F_dyn = s (C_f + C_J + 2 nx^2 (nx + nu)) in the reference's dimensions; `frac_with_hessian` adds the "
+                    "contracted Hessian (s C_H + s 4 nz^3, DESIGN.md 5.1)",
             "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_launch": bytes_launch, "note": "compulsory bytes only; not the binding roof"}}
 
@@ -213,14 +223,20 @@ def cpu_baseline_c2(spec, nst=50, slsqp=True, pb=None, label='C2', per_thread=64
             "host_cpus": os.cpu_count()}
 
 
-def cpu_leg_c5(spec, nst=20, per_thread=32):
+def cpu_leg_c5(spec, nst=20, per_thread=32, dae=False):
     """oracle/cpu/pf_cpu.cpp (C++17 / OpenMP: C5's transcription - path variable, soft speed limit - on the Riccati interior point of
     the other legs in the form the device engine uses, validated against oracle/nmpc_gen.py::GenIpm in tests/test_cpu_baseline.py)
-    on the benchmark's own closed loop: warm-started from the previous solution, state advanced by the plant."""
+    on the benchmark's own closed loop: warm-started from the previous solution, state advanced by the plant.
+    dae=True: oracle/cpu/pfdae_cpu.cpp - configuration 5 as BASELINE writes it (the DAE under collocation with the soft limit on the
+    algebraic state at the collocation points and the node; validated against oracle/nmpc_coll_gen.py)."""
     C, quota = host_cores()
-    from oracle.cpu import CpuPathNmpc
+    from oracle.cpu import CpuPathDaeNmpc, CpuPathNmpc
     from tests import problems as P
-    cpu = CpuPathNmpc(spec, P.oracle_gen(spec))
+    if dae:
+        cpu = CpuPathDaeNmpc(spec, P.oracle_coll_gen(spec))
+        nst, per_thread = 8, 2           # a solve costs ~100 x the ODE leg's (21 x 21 collocation systems in second-order forward mode)
+    else:
+        cpu = CpuPathNmpc(spec, P.oracle_gen(spec))
 
     def loop(nb, nt, nst=nst, nwarm=3):
         xs, w, t0, its = P.c5_x0(nb), None, 0.0, []
@@ -233,14 +249,14 @@ def cpu_leg_c5(spec, nst=20, per_thread=32):
                 its.append(r['iters'].mean())
         secs = time.perf_counter() - t0
         return nb * nst / secs, secs, float(np.mean(its)), float(np.mean((r['status'] == 1) | (r['status'] == 2)))
-    nb_all = max(min(64, 16 * per_thread), per_thread * C)
+    nb_all = max(4, 2 * C) if dae else max(min(64, 16 * per_thread), per_thread * C)
     v_all, s_all, it_all, ok_all = loop(nb_all, C)
-    n_one, n_inst_one = min(nst, 5), max(1, min(2 * per_thread, 16))
+    n_one, n_inst_one = (3, 2) if dae else (min(nst, 5), max(1, min(2 * per_thread, 16)))
     v_one, s_one, _, _ = loop(n_inst_one, 1, nst=n_one)
     return {"value": v_all, "unit": "steps/s", "cores": C, "kind": "port", "one_core_value": v_one,
             "cpu_model": cpu_model_name(), "cgroup_cpu_quota": quota, "sched_affinity_cpus": len(os.sched_getaffinity(0)),
             "mean_ipm_iters": it_all, "frac_status_1_or_2": ok_all,
-            "sample": f"oracle/cpu C++17/OpenMP Riccati interior point on C5's transcription (path variable and slack as engine states, "
+            "sample": f"oracle/cpu C++17/OpenMP Riccati interior point on C5's transcription{' AS BASELINE WRITES IT (DAE, collocation Radau 3, rows at the collocation points)' if dae else ''} (path variable and slack as engine states, "
                       f"inequality rows with IPOPT's slacks; validated against the dense numpy oracle): closed loop, {nb_all} instances "
                       f"x {nst} warm-started steps on {C} pinned threads = min(OpenMP, affinity, cgroup quota) ({s_all:.1f} s); "
                       f"one_core_value: {n_inst_one} instances x {n_one} steps on 1 thread ({s_one:.1f} s); the reference's "
@@ -392,13 +408,26 @@ def wl_nmpc(cfg, args, torch, dev, rank, world):
         x0 = P.c2_x0(gB)[lo:hi]
         kernel, model, ex, eu = "ocp_solve_kernel<NmpcTrack<Chemostat4Gp>, 64>", 'chemostat4_gp', 4, 2
         workload = "C4 GP-hybrid NMPC chemostat4 + GP(200 points, SE-ARD) nx=4 nu=2 N=20, closed loop warm-started"
+    elif cfg == 'C5-dae':
+        spec, gB = P.C5D, args.batch or 8192
+        lo, hi = shard_range(gB, rank, world)
+        B = hi - lo
+        nmpc = P.product_gen(spec)
+        x0 = P.c5_x0(gB)[lo:hi]
+        kernel, model, ex, eu = ("hilo_user_solve (general policy NmpcUser<robot6 DAE, path variable, soft constraint on the algebraic "
+                                 "state, collocation Radau 3>, compiled at run time)"), 'robot6', 7, 3
+        workload = ("C5 as BASELINE writes it: path-following NMPC on the robot's DAE (algebraic state z = vx^2 + vy^2, soft limit z <= 4 at "
+                    "the 3 collocation points and the node of every interval), collocation Radau 3 with the continuous objective, N=50; "
+                    "collocation and algebraic states eliminated inside the shooting map, iterate in a global-memory workspace, closed "
+                    "loop warm-started")
     else:
         spec, gB = P.C5, args.batch or 8192
         lo, hi = shard_range(gB, rank, world)
         B = hi - lo
         nmpc = P.product_gen(spec)
         x0 = P.c5_x0(gB)[lo:hi]
-        kernel, model, ex, eu = "hilo_user_solve (general policy NmpcUser<Robot6, path variable, soft constraint>, compiled at run time)", 'robot6', 8, 3
+        # flops with the REFERENCE's dimensions: nx = 6 + theta = 7, nu = 2 + u_theta = 3 (the slack is one variable of v there, not a state)
+        kernel, model, ex, eu = "hilo_user_solve (general policy NmpcUser<Robot6, path variable, soft constraint>, compiled at run time)", 'robot6', 7, 3
         workload = ("C5 path-following NMPC robot6 (ODE; engine nx=6+theta+slack, nu=2+u_theta) N=50 soft constraint, Riccati "
                     "interior point with the iterate in a global-memory workspace, closed loop warm-started")
     N = nmpc.horizon
@@ -421,7 +450,8 @@ def wl_nmpc(cfg, args, torch, dev, rank, world):
     def finish():
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         mean_iters, ok_frac, kkt_max = _ipm_stats(torch, log)
-        roof = _solve_roofline(kernel, B, mean_iters, ex, eu, N, MODEL_OPS[model], kern_ms, cfg, nmpc._n_v, nmpc._n_g, len(spec['p']))
+        roof = _solve_roofline(kernel, B, mean_iters, ex, eu, N, MODEL_OPS[model], kern_ms, cfg, nmpc._n_v, nmpc._n_g, len(spec['p']),
+                               s=3 if cfg == 'C5-dae' else 4)
         extra = {"workload": workload, "batch_per_gpu": B, "global_batch": gB if cfg != 'C2' else B * world,
                  "parallelism": f"instances sharded x{world}", "mean_ipm_iters": mean_iters, "frac_status_1_or_2": ok_frac,
                  "max_kkt_error": kkt_max}
@@ -432,6 +462,8 @@ def wl_nmpc(cfg, args, torch, dev, rank, world):
             return cpu_baseline_c2(spec)
         if cfg == 'C5':
             return cpu_leg_c5(spec)
+        if cfg == 'C5-dae':
+            return cpu_leg_c5(spec, dae=True)
         else:
             # the C++ baseline with the learned growth rate (oracle/cpu/models_cpu.h::Chemostat4Gp, validated against the numpy oracle)
             from oracle.cpu import set_gp
@@ -526,7 +558,7 @@ def wl_kf(kind, args, torch, dev, rank, world):
         bytes_step = 8 * (2 * nx * (nx + 1) + 2 * ny + nu + npar)          # SURVEY 8d bytes_kf
         gbs = B * K * bytes_step / (kern_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes('C3-' + kind),
+                "traffic": pmc_traffic_bytes('C3-' + kind), "traffic_source": pmc_traffic_bytes('C3-' + kind, with_source=True)[1],
                 "kernel": (f"kf_multi_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}>" if K > 1 else
                            f"kf_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}, 2>"),
                 "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": B * K * bytes_step, "filter_steps_per_launch": K,
@@ -566,7 +598,7 @@ def wl_gp(args, torch, dev, rank, world):
         tf = m * fl_q / (kern_ms * 1e-3) / 1e12
         by = m * 8 * (nf + 2)
         roof = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
-                "traffic": pmc_traffic_bytes('gp-predict'), "kernel": "gp_predict_kernel", "kernel_ms": kern_ms,
+                "traffic": pmc_traffic_bytes('gp-predict'), "traffic_source": pmc_traffic_bytes('gp-predict', with_source=True)[1], "kernel": "gp_predict_kernel", "kernel_ms": kern_ms,
                 "note": "fp64 compute roof: flops per query = n (3 nf + 20) + 2 n (mean) + n^2 (|L^-1 k*|^2), n = 200; "
                         "compulsory HBM traffic is 8 (nf + 2) bytes per query (arithmetic intensity ~1400 flop/B)",
                 "hbm": {"achieved": by / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -621,7 +653,7 @@ def wl_lmpc(args, torch, dev, rank, world):
             b.record()
         torch.cuda.synchronize(dev)
         roof = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
-                "traffic": pmc_traffic_bytes('C1'), "kernel": "qp_solve_reg_kernel<32, 24>", "kernel_ms": kern_ms,
+                "traffic": pmc_traffic_bytes('C1'), "traffic_source": pmc_traffic_bytes('C1', with_source=True)[1], "kernel": "qp_solve_reg_kernel<32, 24>", "kernel_ms": kern_ms,
                 "note": "dense Mehrotra predictor-corrector, 32 variables / 20 equalities: flops per iteration = 2 m^2 n + m^3/3 "
                         "+ 4 m^2 + 6 n m; a 32-variable QP per workgroup is latency bound"}
         extra = {"workload": "C1 LMPC discrete double integrator nx=2 nu=1 N=10 (corrected input block), closed loop",
@@ -636,7 +668,7 @@ def wl_lmpc(args, torch, dev, rank, world):
 
 
 def build_workload(cfg, args, torch, dev, rank, world):
-    if cfg in ('C2', 'C4', 'C5'):
+    if cfg in ('C2', 'C4', 'C5', 'C5-dae'):
         return wl_nmpc(cfg, args, torch, dev, rank, world)
     if cfg == 'C3-mhe':
         return wl_mhe(args, torch, dev, rank, world)

@@ -16,7 +16,7 @@ _lib = None
 
 
 def build(force=False):
-    src = [os.path.join(HERE, f) for f in ('nmpc_cpu.cpp', 'mhe_cpu.cpp', 'pf_cpu.cpp', 'kf_cpu.cpp', 'qp_cpu.cpp', 'gp_cpu.cpp', 'models_cpu.h', 'ipm_cpu.h', 'Makefile')] + \
+    src = [os.path.join(HERE, f) for f in ('nmpc_cpu.cpp', 'mhe_cpu.cpp', 'pf_cpu.cpp', 'pfdae_cpu.cpp', 'kf_cpu.cpp', 'qp_cpu.cpp', 'gp_cpu.cpp', 'models_cpu.h', 'ipm_cpu.h', 'Makefile')] + \
         [os.path.join(HERE, '..', '..', 'include', 'hilo_hip.h')]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
         subprocess.check_call(['make', '-s', '-C', HERE] + (['-B'] if force else []))
@@ -46,6 +46,12 @@ def lib():
         _lib.hilo_cpu_pf_destroy.restype = None
         _lib.hilo_cpu_pf_solve.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
         _lib.hilo_cpu_pf_plant_step.argtypes = [vp, i64, vp, vp, vp, C.c_int]
+        _lib.hilo_cpu_pfdae_last_error.restype = C.c_char_p
+        _lib.hilo_cpu_pfdae_create.argtypes = [vp, C.POINTER(vp)]
+        _lib.hilo_cpu_pfdae_destroy.argtypes = [vp]
+        _lib.hilo_cpu_pfdae_destroy.restype = None
+        _lib.hilo_cpu_pfdae_solve.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+        _lib.hilo_cpu_pfdae_plant_step.argtypes = [vp, i64, vp, vp, vp, C.c_int]
         _lib.hilo_cpu_set_gp.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]
         _lib.hilo_cpu_kf_steps.argtypes = [C.c_int, C.c_int, C.c_double, i64, C.c_int, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int]
         _lib.hilo_cpu_gp_predict.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, C.c_double, C.c_double, C.c_int, i64, vp, vp,
@@ -245,6 +251,90 @@ class CpuPathNmpc:
         u = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(u), (x.shape[0], self.pb.nu)), dtype=np.float64)
         xn = np.empty_like(x)
         lib().hilo_cpu_pf_plant_step(self._h, x.shape[0], x.ctypes.data, u.ctypes.data, xn.ctypes.data, int(n_threads))
+        return xn
+
+
+class PfDaeDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('N', 'degree', 'max_iter', 'acceptable_iter')] + \
+               [(n, C.c_double) for n in ('dt', 'tol', 'acceptable_tol', 'mu_init', 'bound_relax_factor')] + \
+               [(n, C.c_void_p) for n in ('coll_A', 'coll_D', 'coll_B', 'Wu', 'uref', 'x_lb', 'x_ub', 'u_lb', 'u_ub', 'x_guess', 'u_guess')] + \
+               [('w_path_stage', C.c_double * 2), ('w_path_term', C.c_double * 2)] + \
+               [(n, C.c_double) for n in ('theta_lb', 'theta_ub', 'theta_guess', 'u_pf_lb', 'u_pf_ub', 'con_ub', 'con_weight',
+                                          'max_violation')]
+
+
+class CpuPathDaeNmpc:
+    """BASELINE configuration 5 as it is written (tests/problems.py::C5D - a `GenCollProblem` of that shape: the robot's DAE, path
+    references (sin theta, sin 2 theta) for (px, py), soft limit z <= ub on the algebraic state, collocation with the continuous
+    objective) on the C++ baseline (pfdae_cpu.cpp); anything else is refused."""
+
+    def __init__(self, spec, pb, **options):
+        path, con = spec.get('path') or {}, spec.get('constraint') or {}
+        nx, nu = pb.nx, pb.nu
+        Wx = pb.Wz.copy()
+        Wx[nx:, nx:] -= np.diag(np.diag(pb.Wz[nx:, nx:]))
+        ok = spec['model'] == 'robot6_dae' and not spec.get('generic_stage') and pb.objective == 'continuous' and \
+            [tuple(t[0]) + tuple(t[2]) for t in path.get('stage', [])] == [(0, 2, 'sin(theta)', 'sin(2*theta)')] and \
+            [tuple(t[0]) + tuple(t[2]) for t in path.get('terminal', [])] == [(0, 2, 'sin(theta)', 'sin(2*theta)')] and \
+            path.get('u_pf_ref') is None and list(con.get('expr', [])) == ['z'] and con.get('soft') and \
+            not np.isfinite(np.asarray(con.get('lb', -np.inf), dtype=float)).any() and \
+            np.all(pb.sx == 1.) and np.all(pb.su == 1.) and pb.Nc == pb.N and np.abs(pb.Wdu).max() == 0 and \
+            np.abs(Wx).max() == 0 and np.abs(pb.WN).max() == 0 and np.all(np.isinf(pb.x_lb[:nx])) and np.all(np.isinf(pb.x_ub[:nx]))
+        if not ok:
+            raise NotImplementedError("the CPU baseline of the general collocation NMPC holds configuration C5-DAE's problem functions only")
+        self.pb = pb
+        d = PfDaeDesc()
+        d.N, d.degree, d.dt = pb.N, pb.d, pb.dt
+        d.bound_relax_factor = -1.
+        for k, v in options.items():
+            setattr(d, k, v)
+        keep = []
+
+        def hp(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            keep.append(a)
+            return a.ctypes.data
+        d.coll_A, d.coll_D, d.coll_B = hp(np.linalg.inv(pb.C[1:, 1:].T)), hp(pb.D), hp(pb.B)
+        d.Wu, d.uref = hp(np.diag(pb.Wz)[nx:]), hp(pb.zref[nx:])
+        d.x_lb, d.x_ub, d.u_lb, d.u_ub = hp(pb.x_lb[:nx]), hp(pb.x_ub[:nx]), hp(pb.u_lb[:nu]), hp(pb.u_ub[:nu])
+        d.x_guess, d.u_guess = hp(pb.x_guess[:nx]), hp(pb.u_guess[:nu])
+        d.w_path_stage[:] = [float(w) for w in path['stage'][0][1]]
+        d.w_path_term[:] = [float(w) for w in path['terminal'][0][1]]
+        d.theta_lb, d.theta_ub, d.theta_guess = pb.x_lb[nx], pb.x_ub[nx], pb.x_guess[nx]
+        d.u_pf_lb, d.u_pf_ub = pb.u_lb[nu], pb.u_ub[nu]
+        d.con_ub, d.con_weight, d.max_violation = float(pb.rows[0][4]), float(pb.We[0, 0]), float(pb.e_ub[0])
+        h = C.c_void_p()
+        if lib().hilo_cpu_pfdae_create(C.byref(d), C.byref(h)) != 0:
+            raise RuntimeError(lib().hilo_cpu_pfdae_last_error().decode())
+        self._h = h
+        self.n_w = (pb.N + 1) * (nx + 2) + pb.N * (nu + 1)
+        self.n_vx = (pb.N + 1) * (nx + 1) + pb.N * (nu + 1) + 1
+
+    def __del__(self):
+        if getattr(self, '_h', None) is not None and _lib is not None:
+            _lib.hilo_cpu_pfdae_destroy(self._h)
+            self._h = None
+
+    def solve(self, x0, w0=None, n_threads=0):
+        """w0: warm start in the solver's own layout (the `w` of a previous call).  `vx` = [x with theta | u with u_theta | e]."""
+        pb = self.pb
+        x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
+        B = x0.shape[0]
+        w0 = None if w0 is None else np.ascontiguousarray(np.broadcast_to(w0, (B, self.n_w)), dtype=np.float64)
+        w, v, f, u0 = np.empty((B, self.n_w)), np.empty((B, self.n_vx)), np.empty(B), np.empty((B, pb.nu))
+        st, it, kkt = np.empty(B, np.int32), np.empty(B, np.int32), np.empty(B)
+        rc = lib().hilo_cpu_pfdae_solve(self._h, B, x0.ctypes.data, w0.ctypes.data if w0 is not None else None, w.ctypes.data,
+                                        v.ctypes.data, f.ctypes.data, u0.ctypes.data, st.ctypes.data, it.ctypes.data, kkt.ctypes.data,
+                                        int(n_threads))
+        if rc != 0:
+            raise RuntimeError(lib().hilo_cpu_pfdae_last_error().decode())
+        return dict(w=w, vx=v, f=f, u0=u0, status=st, iters=it, kkt=kkt)
+
+    def plant_step(self, x, u, n_threads=0):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        u = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(u), (x.shape[0], self.pb.nu)), dtype=np.float64)
+        xn = np.empty_like(x)
+        lib().hilo_cpu_pfdae_plant_step(self._h, x.shape[0], x.ctypes.data, u.ctypes.data, xn.ctypes.data, int(n_threads))
         return xn
 
 

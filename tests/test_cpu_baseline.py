@@ -250,3 +250,34 @@ def test_path_following_out_of_scope_is_refused():
     spec = dict(C5S, constraint=dict(C5S['constraint'], expr=['vx**2 - vy']))
     with pytest.raises(NotImplementedError):
         CpuPathNmpc(spec, oracle_gen(spec))
+
+
+def test_configuration_5_on_the_dae_vs_oracle():
+    """oracle/cpu/pfdae_cpu.cpp (BASELINE configuration 5 as it is written: the robot's DAE, collocation, soft limit on the algebraic
+    state at the collocation points and the node) against the dense oracle oracle/nmpc_coll_gen.py at a short horizon: statuses,
+    objective, the [x | u | e] part of the minimiser and the first input; degree 3 (the default) and degree 2; then two warm-started
+    steps of the closed loop."""
+    from oracle.cpu import CpuPathDaeNmpc
+    from oracle.nmpc import IpmOptions
+    from oracle.nmpc_coll_gen import GenCollIpm
+    from tests.problems import C5DS, c5_x0, oracle_coll_gen
+    for degree in (3, 2):
+        spec = dict(C5DS, N=6, collocation=dict(degree=degree))
+        pb = oracle_coll_gen(spec)
+        ipm, cpu = GenCollIpm(pb, IpmOptions(tol=1e-9)), CpuPathDaeNmpc(spec, pb, tol=1e-9)
+        x0, w_ref, w = c5_x0(3), None, None
+        for k in range(3 if degree == 3 else 1):
+            ref = ipm.solve(x0, [], w0=w_ref)
+            res = cpu.solve(x0, w0=w, n_threads=2)
+            assert np.array_equal(res['status'], ref['status']) and np.all(ref['status'] == 1)
+            vx = np.concatenate([ref['X'].reshape(3, -1), ref['U'].reshape(3, -1), ref['E']], axis=1)
+            same = np.abs(res['f'] - ref['f']) <= 1e-7 * np.maximum(1., np.abs(ref['f']))     # (non-convex: another minimum is possible)
+            assert same.sum() >= 2
+            assert np.max(np.abs(res['vx'] - vx)[same] / np.maximum(1., np.abs(vx[same]))) < 5e-6
+            np.testing.assert_allclose(res['u0'][same], ref['u0'][same], rtol=5e-6, atol=5e-6)
+            assert np.all(res['kkt'] <= 1e-9)
+            xn = cpu.plant_step(x0, ref['u0'])
+            x0, w_ref, w = xn, ipm.w_from_v(ipm.to_v(ref)), res['w']
+    with pytest.raises(NotImplementedError):
+        bad = dict(C5DS, constraint=dict(C5DS['constraint'], expr=['z + a']))
+        CpuPathDaeNmpc(bad, oracle_coll_gen(bad))
