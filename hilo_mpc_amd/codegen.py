@@ -206,6 +206,8 @@ def dae_model_source(n_x, n_u, n_p, n_z, ode, alg, meas, z_guess):
             f"    (void)x; (void)z; (void)u; (void)p;\n" + '\n'.join(body_j) + "\n  }\n"
             f"  template <class T, class P>\n  __device__ __forceinline__ static void meas_z({sig}, T* y) {{\n"
             f"    (void)x; (void)z; (void)u; (void)p; (void)y;\n" + '\n'.join(body_y) + "\n  }\n"
+            f"  static constexpr bool ODE_USES_Z = {'true' if any(Expr.wrap(e).depends_on('z') for e in ode) else 'false'}, "
+            f"MEAS_USES_Z = {'true' if any(Expr.wrap(e).depends_on('z') for e in meas) else 'false'};\n"
             f"  template <class T, class U, class P>\n"
             f"  __device__ __forceinline__ static void ode(const T* x, const U* u, const P* p, double, T* dx) {{\n"
             f"    dae_ode<UserModel>(x, u, p, dx);\n  }}\n"

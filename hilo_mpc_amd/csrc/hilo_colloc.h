@@ -43,7 +43,8 @@ struct Colloc {
       }
     }
   }
-  __device__ __forceinline__ static void lu_solve(const double* a, double* b) {
+  template <class AP>
+  __device__ __forceinline__ static void lu_solve(AP a, double* b) {
 #pragma unroll
     for (int i = 1; i < DN; ++i) {
       double s = b[i];
@@ -57,6 +58,48 @@ struct Colloc {
 #pragma unroll
       for (int j = i + 1; j < DN; ++j) s -= a[i * DN + j] * b[j];
       b[i] = s / a[i * DN + i];
+    }
+  }
+  // two right-hand sides at once against PREPARED factors (`prepare`: the diagonal of U stored as its reciprocal): a row of the
+  // factors is fetched as one group of independent loads while the previous row's multiply-adds run (the factors sit in LDS or
+  // global memory; left to itself the compiler issued load - wait - multiply-add per element: 38 k cycles per solve at one wave
+  // per SIMD, measured on configuration 5's 21 x 21 systems)
+  template <class AP>
+  __device__ __forceinline__ static void lu_solve2_prepared(AP a, double* b, double* c) {
+    double row[DN], nxt[DN];
+    row[0] = a[1 * DN + 0];
+#pragma unroll
+    for (int i = 1; i < DN; ++i) {                       // forward: unit lower factor, row i holds a[i][0..i-1]
+      if (i + 1 < DN) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) nxt[j] = a[(i + 1) * DN + j];
+      } else {
+#pragma unroll
+        for (int j = DN - 1; j < DN; ++j) nxt[j] = a[(DN - 1) * DN + j];   // first row of the backward pass
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      double s = b[i], t = c[i];
+#pragma unroll
+      for (int j = 0; j < i; ++j) { s -= row[j] * b[j]; t -= row[j] * c[j]; }
+      b[i] = s;
+      c[i] = t;
+#pragma unroll
+      for (int j = 0; j < DN; ++j) row[j] = nxt[j];
+    }
+#pragma unroll
+    for (int i = DN - 1; i >= 0; --i) {                  // backward: row i holds a[i][i..DN-1], a[i][i] = 1 / u_ii
+      if (i > 0) {
+#pragma unroll
+        for (int j = i - 1; j < DN; ++j) nxt[j] = a[(i - 1) * DN + j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      double s = b[i], t = c[i];
+#pragma unroll
+      for (int j = i + 1; j < DN; ++j) { s -= row[j] * b[j]; t -= row[j] * c[j]; }
+      b[i] = s * row[i];
+      c[i] = t * row[i];
+#pragma unroll
+      for (int j = 0; j < DN; ++j) row[j] = nxt[j];
     }
   }
   // solve a^T y = b with the same factors (a = L U  =>  a^T = U^T L^T)
@@ -208,6 +251,65 @@ struct Colloc {
 #pragma unroll
         for (int q = 0; q < DN; ++q) Xout[q] = XJ[q];
       }
+    }
+  }
+
+  // The Taylor part of `step` on PREPARED data: `prep` = [converged collocation states X (DN) | LU factors of the Newton matrix at
+  // them (DN x DN)], written once per interval by `prepare` (the values and the factors are the same for every direction of an
+  // interval; `step` would repeat the Newton solve per direction).  Same arithmetic, same numbers as `step`.
+  template <class PP>
+  __device__ __forceinline__ static void prepare(const CollData& cd, const double* x, const double* u, const double* p, double dt,
+                                                 PP prep) {
+    double X[DN], mat[DN * DN];
+    solve(cd, x, u, p, dt, X, mat);
+#pragma unroll
+    for (int q = 0; q < DN; ++q) prep[q] = X[q];
+#pragma unroll
+    for (int i = 0; i < DN; ++i)
+#pragma unroll
+      for (int j = 0; j < DN; ++j) prep[DN + i * DN + j] = i == j ? 1.0 / mat[i * DN + j] : mat[i * DN + j];   // (lu_solve2_prepared)
+  }
+  template <class PP>
+  __device__ __forceinline__ static void step_prepared(const CollData& cd, const Jet2* x, const Jet2* u, const double* p, double dt,
+                                                       Jet2* xn, Jet2* Xout, PP prep) {
+    Jet2 XJ[DN];
+#pragma unroll
+    for (int q = 0; q < DN; ++q) XJ[q] = Jet2(prep[q]);
+#pragma unroll 1
+    for (int rep = 0; rep < 2; ++rep) {
+      Jet2 F[DN];
+#pragma unroll
+      for (int j = 0; j < D; ++j) M::ode(XJ + j * NX, u, p, dt, F + j * NX);
+      double ra[DN], rb[DN];
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int m = 0; m < NX; ++m) {
+          Jet2 r = XJ[i * NX + m] - x[m];
+#pragma unroll
+          for (int j = 0; j < D; ++j) r = r - (dt * cd.A[i * D + j]) * F[j * NX + m];
+          ra[i * NX + m] = -r.a;
+          rb[i * NX + m] = -r.b;
+        }
+#ifndef HILO_DBG_SKIP_LUSOLVE
+      lu_solve2_prepared(prep + DN, ra, rb);
+#endif
+#pragma unroll
+      for (int q = 0; q < DN; ++q) {
+        XJ[q].a += ra[q];
+        XJ[q].b += rb[q];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < NX; ++m) {
+      Jet2 s = cd.Dc[0] * x[m];
+#pragma unroll
+      for (int i = 0; i < D; ++i) s = s + cd.Dc[i + 1] * XJ[i * NX + m];
+      xn[m] = s;
+    }
+    if (Xout) {
+#pragma unroll
+      for (int q = 0; q < DN; ++q) Xout[q] = XJ[q];
     }
   }
 

@@ -274,6 +274,60 @@ __device__ __forceinline__ T gp_se_var(const double* g, const T* feat) {
 template <class M, class Z, class P>
 __device__ __forceinline__ void dae_solve(const Z* x, const Z* u, const P* p, Z* z) {
   constexpr int NZ = M::NZ;
+  if constexpr (!same_type<Z, double>::value && same_type<P, double>::value) {
+    // derivative-carrying scalar types: the VALUES by the iteration below in plain doubles, then two sweeps z <- z - Jv^-1 g(x, z, u)
+    // in the scalar type with the inverse of the value Jacobian (a double matrix): sweep k makes the order-k coefficients of the
+    // implicit function exact - no division in Taylor / dual arithmetic, no iteration in it
+    constexpr int NX = M::NX, NU = M::NU;
+    double xv[NX], uv[NU > 0 ? NU : 1], zv[NZ], Jv[NZ * NZ], Ji[NZ * NZ];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xv[i] = valof(x[i]);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) uv[i] = valof(u[i]);
+    dae_solve<M, double, P>(xv, uv, p, zv);
+    M::alg_jz(xv, zv, uv, p, Jv);
+#pragma unroll
+    for (int i = 0; i < NZ * NZ; ++i) Ji[i] = (i / NZ == i % NZ) ? 1.0 : 0.0;
+#pragma unroll
+    for (int c = 0; c < NZ; ++c) {        // Gauss-Jordan with partial pivoting (static indices: conditional swaps)
+#pragma unroll
+      for (int q = c + 1; q < NZ; ++q) {
+        if (fabs(Jv[q * NZ + c]) > fabs(Jv[c * NZ + c])) {
+#pragma unroll
+          for (int j = 0; j < NZ; ++j) {
+            double t = Jv[c * NZ + j]; Jv[c * NZ + j] = Jv[q * NZ + j]; Jv[q * NZ + j] = t;
+            t = Ji[c * NZ + j]; Ji[c * NZ + j] = Ji[q * NZ + j]; Ji[q * NZ + j] = t;
+          }
+        }
+      }
+      const double ip = 1.0 / Jv[c * NZ + c];
+#pragma unroll
+      for (int j = 0; j < NZ; ++j) { Jv[c * NZ + j] *= ip; Ji[c * NZ + j] *= ip; }
+#pragma unroll
+      for (int q = 0; q < NZ; ++q) {
+        if (q != c) {
+          const double f = Jv[q * NZ + c];
+#pragma unroll
+          for (int j = 0; j < NZ; ++j) { Jv[q * NZ + j] -= f * Jv[c * NZ + j]; Ji[q * NZ + j] -= f * Ji[c * NZ + j]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NZ; ++i) z[i] = Z(zv[i]);
+#pragma unroll
+    for (int sweep = 0; sweep < 2; ++sweep) {
+      Z r[NZ];
+      M::alg(x, z, u, p, r);
+#pragma unroll
+      for (int i = 0; i < NZ; ++i) {
+        Z acc = z[i];
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) acc = acc - Ji[i * NZ + j] * r[j];
+        z[i] = acc;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NZ; ++i) z[i] = Z(M::z_guess(i));
   int done = 0;
@@ -330,7 +384,11 @@ __device__ __forceinline__ void dae_ode(const T* x, const U* u, const P* p, T* d
   Z uz[NU > 0 ? NU : 1], z[M::NZ];
 #pragma unroll
   for (int i = 0; i < NU; ++i) uz[i] = Z(u[i]);
-  dae_solve<M>(x, uz, p, z);
+  if constexpr (M::ODE_USES_Z) dae_solve<M>(x, uz, p, z);   // (an algebraic state that only constraints / outputs name: not solved for here)
+  else {
+#pragma unroll
+    for (int i = 0; i < M::NZ; ++i) z[i] = Z(0.0);
+  }
   M::ode_z(x, z, uz, p, dx);
   (void)NX;
 }
@@ -342,7 +400,11 @@ __device__ __forceinline__ void dae_meas(const T* x, const U* u, const P* p, T* 
   Z uz[NU > 0 ? NU : 1], z[M::NZ];
 #pragma unroll
   for (int i = 0; i < NU; ++i) uz[i] = Z(u[i]);
-  dae_solve<M>(x, uz, p, z);
+  if constexpr (M::MEAS_USES_Z) dae_solve<M>(x, uz, p, z);
+  else {
+#pragma unroll
+    for (int i = 0; i < M::NZ; ++i) z[i] = Z(0.0);
+  }
   M::meas_z(x, z, uz, p, y);
 }
 template <class M, class = void> struct model_nz { static constexpr int value = 0; };

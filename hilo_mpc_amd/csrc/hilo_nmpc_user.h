@@ -104,6 +104,13 @@ struct NmpcUser {
   // (mpc.py:1338-1356, :1700-1725) - rows of the interior of the shooting map, evaluated together with it
   static constexpr bool FUSED_CON = C::COLL_D > 0 && F::NEXPR > 0;
   static constexpr int NZALG = model_nz<M>::value;             // algebraic states of a semi-explicit DAE model (eliminated, see below)
+  // collocation with the iterate in the workspace: the converged collocation states and the factors of the Newton matrix of an
+  // interval are computed ONCE per derivative evaluation and read by all of its Taylor directions (hilo_colloc.h::prepare)
+#ifdef HILO_USER_NO_PREP   // developer knob (tools/dbg/c5dae_prep.py): every Taylor direction solves the collocation system itself
+  static constexpr int PREP = 0;
+#else
+  static constexpr int PREP = (C::COLL_D > 0 && C::BIG) ? C::COLL_D * (M::NX + C::NTH) * (1 + C::COLL_D * (M::NX + C::NTH)) : 0;
+#endif
   static constexpr bool QUAD_COST = false;
   static constexpr UserLayout L = UserLayout(MX, MU, NTH, NE, F::NPS, F::NPT);
   static constexpr int NCOST = L.o_end;
@@ -227,6 +234,27 @@ struct NmpcUser {
     return dyn_cost_impl<true>(pc, par, sd, k, x, u, xn, dv);
   }
 
+  template <class PP>
+  __device__ __forceinline__ static void prepare(const OcpConst& pc, const double* par, const double* sd, int k, const double* x,
+                                                 const double* u, PP prep) {
+    const double* p = C::TV ? sd + MX + MU : par;
+    double xp[MXA], up[MUA > 0 ? MUA : 1];
+#pragma unroll
+    for (int i = 0; i < MXA; ++i) xp[i] = x[i] * pc.sz[i];
+#pragma unroll
+    for (int i = 0; i < MUA; ++i) {
+      double ui = u[i];
+      if constexpr (NH > 0) { if (k >= pc.Nc) ui = x[MXA + NE + i]; }
+      up[i] = ui * pc.sz[NX + i];
+    }
+    if constexpr (D > 0) Colloc<MA, D>::prepare(pc.coll, xp, up, p, pc.dt, prep);
+  }
+  template <class PP>
+  __device__ __forceinline__ static Jet2 dyn_cost_prep(const OcpConst& pc, const double* par, const double* sd, int k, const Jet2* x,
+                                                       const Jet2* u, Jet2* xn, Jet2* dv, PP prep) {
+    return dyn_cost_impl<FUSED_CON>(pc, par, sd, k, x, u, xn, dv, prep);
+  }
+
   // rows of ONE point (un-scaled xu, uu, algebraic state z or nullptr): d[m0 + r] = sign_r c_{expr_r} - e_{slack_r}, r < nrow
   template <class T>
   __device__ __forceinline__ static void rows_at(const OcpConst& pc, const double* p, const T* xu, const T* uu, const T* z,
@@ -249,9 +277,9 @@ struct NmpcUser {
     }
   }
 
-  template <bool WITH_CON, class T>
+  template <bool WITH_CON, class T, class PP = const double*>
   __device__ __forceinline__ static T dyn_cost_impl(const OcpConst& pc, const double* par, const double* sd, int k, const T* x,
-                                                    const T* u, T* xn, T* dv) {
+                                                    const T* u, T* xn, T* dv, PP prep = nullptr) {
     const double* p = C::TV ? sd + MX + MU : par;
     T xp[MXA], up[MUA > 0 ? MUA : 1], us[MUA > 0 ? MUA : 1], xs[MXA], xo[MXA];
 #pragma unroll
@@ -266,7 +294,12 @@ struct NmpcUser {
     T lc = T(0.0);
     if constexpr (D > 0) {
       T Xc[D * MXA];
+      if constexpr (PREP > 0 && same_type<T, Jet2>::value) {
+        if (prep) Colloc<MA, D>::step_prepared(pc.coll, xp, up, p, pc.dt, xo, (CONT || WITH_CON) ? Xc : nullptr, prep);
+        else Colloc<MA, D>::step(pc.coll, xp, up, p, pc.dt, xo, (CONT || WITH_CON) ? Xc : nullptr);
+      } else
       Colloc<MA, D>::step(pc.coll, xp, up, p, pc.dt, xo, (CONT || WITH_CON) ? Xc : nullptr);
+#ifndef HILO_DBG_SKIP_ROWS
       if constexpr (WITH_CON) {
         // rows of the node [0, nrow), then of the collocation points i = 1..d [i nrow, (i + 1) nrow); an expression that names an
         // algebraic state gets z(x_{k,i}, u_k) at a collocation point; at the node the reference passes the interval's whole zp
@@ -285,6 +318,8 @@ struct NmpcUser {
         }
         rows_at(pc, p, xp, up, (NZALG > 0 && F::CON_USES_Z) ? zc : (const T*)nullptr, x, 0, nrow, dv);
       }
+#endif
+#ifndef HILO_DBG_SKIP_QUAD
       if constexpr (CONT) {
 #pragma unroll
         for (int i = 0; i < D; ++i) {
@@ -294,6 +329,7 @@ struct NmpcUser {
           lc = lc + (pc.dt * pc.coll.Bq[i + 1]) * lagrange(pc, par, sd, p, k, xcs, us);
         }
       }
+#endif
     } else if constexpr (M::DISCRETE) {
       MA::ode(xp, up, p, pc.dt, xo);
     } else if constexpr (CONT) {
@@ -473,10 +509,15 @@ struct NmpcUser {
     }
     Colloc<MA, DD>::solve(pc.coll, x, u, p, pc.dt, X, mat);
     double* out = v + b * nv;
-    if (k == 0) {
-      for (int i = 0; i < n_head; ++i) out[i] = row[i];
-      for (int i = 0; i < NE; ++i) out[n_head + n_zn + N * DB + i] = row[n_head + i];
+    // the [x | u] head and the slacks: copied by the N threads of the instance together (uniform trip count, predicated body -
+    // no lane-dependent branch around a loop: DESIGN.md 5.1, tools/check_exec_prologue.py)
+    for (int i0 = 0; i0 < n_head; i0 += N) {
+      const int i = i0 + k;
+      if (i < n_head) out[i] = row[i];
     }
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+      if (k == 0) out[n_head + n_zn + N * DB + i] = row[n_head + i];
 #pragma unroll
     for (int i = 0; i < DD; ++i)
 #pragma unroll
@@ -501,16 +542,19 @@ struct NmpcUser {
     double lam[MXA], y[DN], F_[DN], mu[DN];
 #pragma unroll
     for (int m = 0; m < MXA; ++m) lam[m] = lrow[m];
-    if (k == N - 1 && (pc.flags & 1)) {
+    {
       // the engine reports the last defect multiplier in the reference's convention (terminal cost on the integrated end
-      // state, mpc.py:1682): lambda_ref = lambda + grad V(x_N); the collocation rows need the engine's own lambda
+      // state, mpc.py:1682): lambda_ref = lambda + grad V(x_N); the collocation rows need the engine's own lambda.  Evaluated by
+      // every thread and applied by the last interval's (a select, no lane-dependent branch)
+      const bool last = k == N - 1 && (pc.flags & 1);
       const double* sdN = C::TV ? sdata + b * sd_stride + (int64_t)N * NSD : nullptr;
 #pragma unroll
       for (int m = 0; m < MXA; ++m) {
         Jet2 xj[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xj[i] = Jet2(i < MXA ? row[N * MXA + i] : (i < MXA + NE ? row[n_head + (i - MXA)] : 0.0), i == m ? 1.0 : 0.0, 0.0);
-        lam[m] -= term_cost(pc, pr, sdN, xj).a;
+        const double gv = term_cost(pc, pr, sdN, xj).a;
+        lam[m] -= last ? gv : 0.0;
       }
     }
     // multipliers of the engine's rows of this interval: node rows [0, nrow), point i rows [(i + 1) nrow, (i + 2) nrow)

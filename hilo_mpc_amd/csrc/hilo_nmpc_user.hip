@@ -116,10 +116,14 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   const bool tv = d->time_varying != 0;
   const int nsd = tv ? mx + mu + np : 0;
   const int nconst = (int)((__builtin_offsetof(OcpConst, cost) + sizeof(double) * L.o_end + 7) / 8);
-  const size_t fixed_b = ocp_fixed_doubles(nxe, nue, nconst, np + mu, nsd, 0, N) * sizeof(double);
+  size_t fixed_b = ocp_fixed_doubles(nxe, nue, nconst, np + mu, nsd, 0, N) * sizeof(double);
   const size_t iter_b = ocp_iter_doubles(nxe, nue, nc, N) * sizeof(double);
   const bool big = fixed_b + iter_b > 160 * 1024;
+  if (big && D) fixed_b += (size_t)(D * (mx + nth)) * (1 + D * (mx + nth)) * sizeof(double);   // the staged block of NmpcUser::PREP
   if (fixed_b > 160 * 1024) return fail(HILO_ENOTSUP, "horizon %d needs %zu B of LDS for the problem constants alone", N, fixed_b);
+  // workspace mode under collocation: per interval the converged collocation states and the factors of their Newton matrix
+  // (NmpcUser::PREP, hilo_colloc.h::prepare)
+  const size_t prep_b = (big && D) ? (size_t)N * (D * mxa) * (1 + D * mxa) * sizeof(double) : 0;
 
   hilo_nmpc* h = new hilo_nmpc();
   memset(h, 0, sizeof(*h));
@@ -127,7 +131,7 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   h->nu_out = mu; h->jit_policy = JIT_USER;
   h->nxe = nxe; h->nue = nue; h->nxv = mxa; h->ntail = ne; h->Nc = Nc;
   h->tv_width = nsd;
-  h->jit_ws_bytes = big ? iter_b : 0;
+  h->jit_ws_bytes = big ? iter_b + prep_b : 0;
   h->jit_coll_d = D;
   const int nza = d->model_id == HILO_MODEL_USER ? d->user_nz : 0;
   HILO_REQUIRE(nza >= 0 && nza <= 4, "hilo_nmpc_create: at most 4 algebraic states (got %d)", nza);

@@ -190,6 +190,11 @@ template <class PB> struct pb_vec_n<PB, void_tt<decltype(PB::VEC_N)>> { static c
 //          imposes the stage constraints at the collocation points too (mpc.py:1338-1356) - rows of the map's interior points
 template <class PB, class = void> struct pb_fused_con { static constexpr bool value = false; };
 template <class PB> struct pb_fused_con<PB, void_tt<decltype(PB::FUSED_CON)>> { static constexpr bool value = PB::FUSED_CON; };
+//   PREP   doubles per interval of data the policy prepares ONCE per derivative evaluation (`prepare`) and every Taylor task of the
+//          interval reads (`dyn_cost_prep`): an implicit shooting map's converged stage values and the factors of its Newton matrix
+//          (collocation: the same for all directions of an interval - without it every direction repeats the Newton solve)
+template <class PB, class = void> struct pb_prep { static constexpr int value = 0; };
+template <class PB> struct pb_prep<PB, void_tt<decltype(PB::PREP)>> { static constexpr int value = PB::PREP; };
 template <class PB, class = void> struct pb_fused { static constexpr bool value = false; };
 template <class PB> struct pb_fused<PB, void_tt<decltype(PB::FUSED)>> { static constexpr bool value = PB::FUSED; };
 
@@ -203,10 +208,10 @@ __host__ __device__ constexpr size_t ocp_iter_doubles(int NX, int NU, int NC, in
          (size_t)(N + 1) * NX * (NX + 1) + (size_t)N * NU * (NX + 1) + (size_t)N * NX * (NX + 1) + (size_t)N * NC * (14 + NZ) +
          (size_t)N * 4 * NX;   // an upper bound over the policies (Ocp<PB>::iter_doubles is the exact figure): direction table AND stage points
 }
-__host__ __device__ constexpr size_t ocp_fixed_doubles(int NX, int NU, int NCONST, int NPAR, int NSD, int NEXT, int N) {
+__host__ __device__ constexpr size_t ocp_fixed_doubles(int NX, int NU, int NCONST, int NPAR, int NSD, int NEXT, int N, int NPREP = 0) {
   const size_t NZ = NX + NU;
   return NCONST + NZ * NZ + NZ + (N + 1) + 2 * 16 + 16 + NPAR + (size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1 + NEXT +
-         (NZ * (NZ + 1) / 2 + 2) / 2;
+         (NZ * (NZ + 1) / 2 + 2) / 2 + NPREP;
 }
 
 // Optional plumbing of a solve launch that saves separate kernels around it (all members may stay zero):
@@ -253,6 +258,7 @@ struct Ocp {
   static constexpr int NH = pb_nh<PB>::value;          // held inputs (states NX-NH..NX-1), control horizon pc.Nc
   static constexpr bool FUSED = pb_fused<PB>::value;   // dyn_cost(): shooting map + Lagrange term in one evaluation
   static constexpr bool FUSED_CON = pb_fused_con<PB>::value;   // dyn_cost_con(): ... and the inequality rows
+  static constexpr int PREP = pb_prep<PB>::value;              // per-interval data prepared once per derivative evaluation
   // model derivatives as generated straight-line code (ModelSym<PB::Model>, csrc/hilo_models_sym.h / codegen): second-order
   // adjoint through the Runge-Kutta stages instead of Taylor sweeps per direction pair (eval_derivs_sym)
   static constexpr bool SYM = pb_sym<PB>::value;
@@ -294,7 +300,7 @@ struct Ocp {
   }
   static constexpr size_t VEC_BUDGET = 40 * 1024 - 64;
   static constexpr bool vec_fits(int level) {
-    return (ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, VEC_N) + vec_doubles_level(VEC_N, level)) * sizeof(double) <= VEC_BUDGET;
+    return (ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, VEC_N, PREP) + vec_doubles_level(VEC_N, level)) * sizeof(double) <= VEC_BUDGET;
   }
   static constexpr int VEC_LEVEL = !(BIG && VEC_N > 0) ? 0 : (vec_fits(3) ? 3 : (vec_fits(2) ? 2 : (vec_fits(1) ? 1 : 0)));
   static constexpr bool VEC_LDS = VEC_LEVEL > 0;
@@ -313,6 +319,8 @@ struct Ocp {
     gp_t grad;
     dp lamn, AB, W, Qd, P, Kg, sig, rbN, Acl;
     dp Xs;   // SYM policies: Runge-Kutta stage points [N][4][NX] of the last values-only evaluation (reused by the derivative phase)
+    dp prep; // [N][PREP]: what PB::prepare leaves for the Taylor tasks of an interval
+    lds_double* prepl;   // [PREP]: the block of the interval whose directions are being swept (staged in LDS: every lane reads all of it)
     lds_double* gpc;   // cooperative models: [N][4][6] value / gradient / Hessian of the learned term at the stage points (GpExt::cache)
     dp cs, cst, cnu, cnun, cvL, cvU, cdvL, cdvU, cds, cd, csig, crb, Jd;  // [N][NC] (Jd: [N][NC][NZ])
     dp c0, cd0, cdt;  // second-order correction: saved defects / row values, row values at the trial point
@@ -325,11 +333,12 @@ struct Ocp {
   __host__ __device__ static constexpr size_t qd_doubles(int N) { return (SYM || SYM_MHE) ? (size_t)NXDIR : (size_t)(N + 1) * NDIR; }
   __host__ __device__ static constexpr size_t xs_doubles(int N) { return SYM ? (size_t)N * 4 * NX : (COOP ? (size_t)N * 24 : 0); }
   __host__ __device__ static constexpr size_t iter_doubles(int N) {  // the iterate (LDS or workspace); <= ocp_iter_doubles + xs
-    return ocp_iter_doubles(NX, NU, NC, N) - (size_t)(N + 1) * NDIR - (size_t)N * 4 * NX + qd_doubles(N) + xs_doubles(N);
+    return ocp_iter_doubles(NX, NU, NC, N) - (size_t)(N + 1) * NDIR - (size_t)N * 4 * NX + qd_doubles(N) + xs_doubles(N) +
+           (size_t)N * PREP;
   }
   __device__ static dp qd_term(const Lds l, int N) { return (SYM || SYM_MHE) ? l.Qd : l.Qd + (size_t)N * NDIR; }
   __host__ __device__ static constexpr size_t fixed_doubles(int N) {  // always LDS
-    return ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, N);
+    return ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, N, PREP);
   }
   __host__ __device__ static constexpr size_t lds_doubles(int N) {
     return fixed_doubles(N) + (BIG ? (VEC_LDS ? vec_doubles(N) : 0) : iter_doubles(N));
@@ -352,6 +361,7 @@ struct Ocp {
     l.sd = take((size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1);
     l.ext = take(NEXT);
     l.dirs = reinterpret_cast<__attribute__((address_space(3))) int*>(take((NDIR + 2) / 2));
+    l.prepl = take(PREP);
     dp w;
     const size_t V = (size_t)N * NX;
     if constexpr (VEC_LEVEL >= 1) {   // the vectors first, in LDS; everything else in the workspace
@@ -384,6 +394,7 @@ struct Ocp {
       l.Xs = big(xs_doubles(N));
       l.gpc = nullptr;
     }
+    l.prep = big((size_t)N * PREP);
     return l;
   }
 
@@ -629,9 +640,31 @@ struct Ocp {
     const unsigned pinm = FIX_X0 ? (~pc.x0_free_mask) & ((1u << NX) - 1u) : 0u;  // pinned slots of x_0 (bit i)
     constexpr int GPW = COOP ? 64 / NDIR : 1;  // cooperative: lane groups of NDIR directions, GPW intervals per round
     const int nact = COOP ? NDIR : uni(l.dirs[0]);   // swept directions per interval (pair_mask)
-    const int ntask = COOP ? ((N + GPW - 1) / GPW) * 64 + NXDIR : N * nact + NXDIR;
+    // PREP policies: ONE interval per pass of the wave (its prepared block staged in LDS), PASSES passes per interval
+    const int PASSES = (nact + OCP_TPB - 1) / OCP_TPB;
+    const int ntask = COOP ? ((N + GPW - 1) / GPW) * 64 + NXDIR : (PREP > 0 ? N * PASSES * OCP_TPB + NXDIR : N * nact + NXDIR);
     const int tbase = ntask - NXDIR;
-    OCP_FOR(task0, ntask) {
+    if constexpr (PREP > 0) {   // once per interval: what all its directions share (PB::prepare)
+      OCP_FOR(k, N) {
+        double x[NX], u[NU > 0 ? NU : 1];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = l.Z[k * NZ + i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = l.Z[k * NZ + NX + i];
+        PB::prepare(pc, (const double*)l.par, sd_of(l, k), k, x, u, l.prep + (size_t)k * PREP);
+      }
+      __syncthreads();
+    }
+    for (int task0_base = 0; task0_base < ntask; task0_base += OCP_TPB) {
+      if constexpr (PREP > 0) {
+        if (task0_base < tbase && (task0_base / OCP_TPB) % PASSES == 0) {   // a new interval: stage its block
+          const int kk = task0_base / (OCP_TPB * PASSES);
+          __syncthreads();
+          for (int q = (int)threadIdx.x; q < PREP; q += OCP_TPB) l.prepl[q] = l.prep[(size_t)kk * PREP + q];
+          __syncthreads();
+        }
+      }
+      if (const int task0 = task0_base + (int)threadIdx.x; task0 < ntask) {
       if (task0 < tbase) {
         int k, d, task = task0;
         bool active = true;
@@ -641,6 +674,12 @@ struct Ocp {
           k = (task0 / 64) * GPW + g;
           active = g < GPW && k < N;
           if (!active) { k = N - 1; d = 0; }
+          task = k * NDIR + d;
+        } else if constexpr (PREP > 0) {
+          k = task0 / (OCP_TPB * PASSES);
+          const int slot = task0 - k * OCP_TPB * PASSES;
+          if (slot >= nact) continue;
+          d = l.dirs[1 + slot];
           task = k * NDIR + d;
         } else {
           k = task0 / nact;
@@ -693,7 +732,9 @@ struct Ocp {
         // a policy with a purely quadratic stage cost supplies value / gradient / (constant) Hessian in closed form
         Jet2 lc(0.0);
         Jet2 dvf[NC > 0 ? NC : 1];
-        if constexpr (FUSED_CON) {
+        if constexpr (PREP > 0) {
+          lc = PB::dyn_cost_prep(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dvf, l.prepl);
+        } else if constexpr (FUSED_CON) {
           lc = PB::dyn_cost_con(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dvf, NoExt{});
         } else if constexpr (FUSED) {
           static_assert(!FUSED || (!COOP && !PB::QUAD_COST), "fused cost: Taylor evaluation, no cooperative model");
@@ -747,6 +788,7 @@ struct Ocp {
         qd_term(l, N)[d] = v.b;
         if (d < NX) l.grad[N * NZ + d] = v.a;
         if (d == 0) l.fk[N] = v.v;
+      }
       }
     }
     __syncthreads();

@@ -1088,10 +1088,27 @@ class NMPC:
         from . import zoo_expr
         from .model import Model
         from .sparsity import stage_hessian_pattern
-        if getattr(m, 'n_z', 0) or getattr(m, '_gps', None):
+        if getattr(m, '_gps', None):
             return None
+        elim = None
         if getattr(m, '_symbolic', False):
             ode = m._ode
+            if getattr(m, 'n_z', 0):
+                # algebraic states are eliminated through their equations, z = zeta(x, u): for the structure every one of them
+                # stands for a generic nonlinear function of the states and inputs ANY algebraic equation names (conservative)
+                from .expr import hessian_structure
+                dep = set()
+                for e in m._alg:
+                    dep |= {k for k in hessian_structure(e)[0] if k[0] in ('x', 'u')}
+                if not dep:
+                    return None
+                tot = None
+                for kind, i in sorted(dep):
+                    leaf = (m.x if kind == 'x' else m.u)[i]
+                    tot = leaf if tot is None else tot + leaf
+                surrogate = tot * tot
+                elim = lambda n: surrogate if n.op == 'z' else None        # noqa: E731
+                ode = Expr.substitute(list(ode), elim)
         elif m.name in zoo_expr.FUNCTOR or m.name in zoo_expr.STRUCTURE_ONLY:
             ode = zoo_expr.define(Model(name=m.name + '_structure'), m.name)._ode
         else:
@@ -1107,6 +1124,9 @@ class NMPC:
         # a hard terminal constraint on the integrated end state (mpc.py:1693-1700), a soft one at the node x_{N-1}
         exprs = [gen_stage] + (list(sc.constraint) if sc.is_set else []) + (list(tc.constraint) if tc.is_set and tc.is_soft else [])
         exprs_c = list(tc.constraint) if tc.is_set and not tc.is_soft else []
+        if elim is not None:
+            exprs = [None if e is None else Expr.substitute([Expr.wrap(e)], elim)[0] for e in exprs]
+            exprs_c = [Expr.substitute([Expr.wrap(e)], elim)[0] for e in exprs_c]
         terms, o, Wp = [], 0, None
         if nth:
             ind, refs = [], []

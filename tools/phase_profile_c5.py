@@ -3,9 +3,9 @@ N = 50, general run-time compiled policy, iterate in the global workspace).   py
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from tests.problems import C5, c5_x0, product_gen
+from tests.problems import C5, C5D, c5_x0, product_gen
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-nmpc = product_gen(C5)
+nmpc = product_gen(C5D if os.environ.get("C5DAE") else C5, **({"ipopt.max_iter": 12} if os.environ.get("HILO_DBG_ONE") else {}))
 x = torch.as_tensor(c5_x0(B), device='cuda')
 for _ in range(2):
     u = nmpc.optimize(x)
