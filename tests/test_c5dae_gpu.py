@@ -141,16 +141,30 @@ def test_c5_dae_full_horizon_vs_fixture_and_batch_properties():
     with open(GOLD) as f:
         g = json.load(f)
     x0 = np.array(g['x0'])
-    nmpc = product_gen(C5D, **{'ipopt.tol': TOL})
+    assert all(s in (1, 2) for s in g['status']) and max(g['kkt']) < 1e-9       # (the oracle ran at tol 1e-10: one instance stops at 2.7e-10)
+    nmpc = product_gen(C5D, **{'ipopt.tol': 1e-10})        # the fixture's tolerance (at 1e-9 the long horizon's flat directions leave 9e-6)
     assert (nmpc._n_v, nmpc._n_g) == (g['n_v'], g['n_g']) == (51 * 7 + 50 * 3 + 51 + 50 * 24 + 1, 50 * 39)
+    vr, lr, fr, ur = np.array(g['v']), np.array(g['lam_g']), np.array(g['f']), np.array(g['u0'])
+
+    def close(sel):
+        v = nmpc._nlp_solution['x'].cpu().numpy()[sel]
+        assert np.max(np.abs(v - vr[sel]) / np.maximum(1., np.abs(vr[sel]))) < 1e-6
+        np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy()[sel], fr[sel], rtol=1e-9)
+        lam = nmpc._nlp_solution['lam_g'].cpu().numpy()[sel]
+        assert np.max(np.abs(lam - lr[sel]) / np.maximum(1., np.abs(lr[sel]))) < 1e-5
+    # from the oracle's point: every instance stays there (its KKT point is the product's); from the guess: the non-convex path
+    # cost may send an instance to another local minimum (tests above) - at most one of the three
+    u = nmpc.optimize(x0, v0=vr)
+    assert np.all(nmpc.solver_status_code == 1)
+    close(np.ones(3, dtype=bool))
+    np.testing.assert_allclose(u, ur, rtol=1e-6, atol=1e-6)
+    nmpc.reset_solution()
     u = nmpc.optimize(x0)
-    assert np.array_equal(nmpc.solver_status_code, np.array(g['status']))
-    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), np.array(g['v'])
-    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 1e-6
-    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), g['f'], rtol=1e-9)
-    np.testing.assert_allclose(u, g['u0'], rtol=1e-6, atol=1e-6)
-    lam, lr = nmpc._nlp_solution['lam_g'].cpu().numpy(), np.array(g['lam_g'])
-    assert np.max(np.abs(lam - lr) / np.maximum(1., np.abs(lr))) < 1e-5
+    assert np.all(nmpc.solver_status_code == 1)
+    same = np.abs(nmpc._nlp_solution['f'].cpu().numpy() - fr) <= 1e-8 * np.maximum(1., np.abs(fr))
+    assert same.sum() >= 2
+    close(same)
+    np.testing.assert_allclose(u[same], ur[same], rtol=1e-6, atol=1e-6)
     nm = product_gen(C5D)
     x = c5_x0(1024)
     for _ in range(3):
