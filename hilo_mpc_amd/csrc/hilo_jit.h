@@ -28,6 +28,8 @@ struct JitRequest {
   int nth = 0, ne = 0, nc = 0, coll_d = 0, N = 1;
   bool hold = false, cont = false, tv = false, big = false, has_fun = false;
   bool sym = true;               // JIT_TRACK: symbolic model derivatives when the source provides them (one RK step per interval)
+  bool mhe_gen = false;          // JIT_MHE: the general estimator policy MheGen (parameters as states, optional state noise)
+  bool mhe_noise = true;         // JIT_MHE with mhe_gen: state noise variables present
   bool private_module = false;   // load a module of its own (its learned-term table belongs to ONE handle); the code object
                                  // still comes from the cache
 };

@@ -148,15 +148,22 @@ extern "C" __global__ void hilo_user_info(int* out) {
 // (mhe.py:614-623): rows of v0 and v_opt are [p (NP) | x | w]; `first` receives x_N un-scaled (mhe.py:381-384).
 static std::string translation_unit_mhe(const JitRequest& r) {
   char cfg[512];
-  snprintf(cfg, sizeof(cfg), "#define HILO_OCP_TPB 64\n#define HILO_USER_N %d\n#define HILO_USER_COLL_D %d\n#define HILO_USER_SYM %d\n",
-           r.N, r.coll_d, (int)r.sym);
+  snprintf(cfg, sizeof(cfg), "#define HILO_OCP_TPB 64\n#define HILO_USER_N %d\n#define HILO_USER_COLL_D %d\n#define HILO_USER_SYM %d\n"
+                             "#define HILO_USER_MHE_GEN %d\n#define HILO_USER_MHE_NOISE %d\n",
+           r.N, r.coll_d, (int)r.sym, (int)r.mhe_gen, (int)r.mhe_noise);
   std::string s(cfg);
   s += "#include \"hilo_mhe_policy.h\"\n";
   s += "extern \"C\" { __device__ const double* hilo_user_gp[4]; }\n";
   s += "namespace hilo {\n";
   s += r.user_source;
   s += R"(
+#if HILO_USER_MHE_GEN
+using PB = MheGen<UserModel, HILO_USER_COLL_D, HILO_USER_MHE_NOISE>;
+constexpr int V_PREFIX = 0;             // engine-layout rows [xa | w] (the host converts, hilo_mhe.hip)
+#else
 using PB = MheNoise<UserModel, HILO_USER_SYM, HILO_USER_COLL_D>;
+constexpr int V_PREFIX = UserModel::NP;
+#endif
 using EngineT = Ocp<PB>;
 constexpr size_t USER_LDS = EngineT::lds_doubles(HILO_USER_N);
 static_assert(USER_LDS * 8 <= 160 * 1024, "the iterate of this estimation window does not fit the 160 KB of LDS");
@@ -168,8 +175,8 @@ void hilo_user_solve(const OcpConst* __restrict__ pcg, int64_t batch, const doub
                      double* __restrict__ first, int32_t* __restrict__ status, int32_t* __restrict__ iters, double* __restrict__ kkt,
                      long long* __restrict__ prof, double* __restrict__ ws, const OcpExtra ex) {
   __shared__ double lds[USER_LDS];
-  ocp_solve_body<PB, 64>((lds_double*)lds, pcg, batch, x0, par, par_stride, sdata, sd_stride, v0, v0_stride, UserModel::NP,
-                         UserModel::NP, v_opt, f_opt, lam_g, first, 1, status, iters, kkt, prof, ws, ex);
+  ocp_solve_body<PB, 64>((lds_double*)lds, pcg, batch, x0, par, par_stride, sdata, sd_stride, v0, v0_stride, V_PREFIX,
+                         V_PREFIX, v_opt, f_opt, lam_g, first, 1, status, iters, kkt, prof, ws, ex);
 }
 
 extern "C" __global__ void hilo_user_plant(const OcpConst* __restrict__, int64_t, const double* __restrict__, const double* __restrict__,
@@ -179,7 +186,10 @@ extern "C" __global__ void hilo_user_coll_out(const OcpConst* __restrict__ pcg, 
                                               const double* __restrict__ lamc, const double* __restrict__ par, int64_t par_stride,
                                               const double* __restrict__ sdata, int64_t sd_stride, double* __restrict__ v,
                                               double* __restrict__ lam_g) {
-#if HILO_USER_COLL_D > 0
+#if HILO_USER_MHE_GEN
+  // general estimator: engine layout in, reference layout out; `par` carries the x_opt output buffer (hilo_mhe.hip)
+  mhe_gen_output<UserModel, HILO_USER_COLL_D, HILO_USER_MHE_NOISE>(pcg, batch, vc, lamc, sdata, sd_stride, v, lam_g, (double*)par);
+#elif HILO_USER_COLL_D > 0
   mhe_coll_output<UserModel, HILO_USER_COLL_D>(pcg, batch, vc, lamc, par, par_stride, sdata, sd_stride, v, lam_g);
 #endif
 }

@@ -58,6 +58,7 @@ struct hilo_mhe {
   int use_jit, coll_d, n_vc;         // n_vc: row length of the engine's result [p | x | w] (= n_v without the collocation block)
   double *vc, *lamc;                 // collocation: the engine's result before the output pass
   const MheEstVariant* est;          // parameter-estimating variant or NULL
+  int gen, noise;                    // run-time compiled GENERAL policy (MheGen: parameters as states, optional state noise) / w present
   double *x0e, *v0e, *ve, *lame, *v_guess_e;   // engine-layout buffers of the estimating variant
   unsigned est_mask;                 // bit j: parameter j is a variable
 };
@@ -107,15 +108,20 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
       rc = hilo_model_dims(d->model_id, &nx, &nu, &np, &ny, &disc);
       if (rc) return rc;
     }
-    if (d->estimate_parameters && np > 0)
-      return fail(HILO_ENOTSUP, "parameter estimation on the run-time compiled estimator is not built (zoo models with "
-                                "integration_method 'discrete' have it)");
   } else {
     HILO_REQUIRE(d->model_id != HILO_MODEL_USER, "hilo_mhe_create: HILO_MODEL_USER needs desc.user_source");
     if (D) return fail(HILO_ENOTSUP, "the collocation transcription runs on the run-time compiled policy: pass desc.user_source");
     rc = mhe_model_dims(d->model_id, &nx, &nu, &np, &ny, &lds, d->N);
     if (rc) return rc;
   }
+  // desc.Ww == NULL: an estimator WITHOUT state noise (mhe.py:599: no w block in v; the collocation / discrete branches run without
+  // it, :726-736) - on the general run-time compiled policy, like parameter estimation for models given as source
+  const bool has_noise = d->Ww != nullptr;
+  const bool gen = jit && ((d->estimate_parameters && np > 0) || !has_noise);
+  if (!jit && !has_noise) return fail(HILO_ENOTSUP, "an estimator without state noise runs on the run-time compiled policy: pass desc.user_source");
+  if (gen)
+    HILO_REQUIRE(nx + np <= OCP_MAXNX && (nx + np) + (has_noise ? nx : 0) <= OCP_MAXNZ,
+                 "hilo_mhe_create: %d states + %d parameters exceed this build's general estimator (%d engine states)", nx, np, OCP_MAXNX);
   const MheEstVariant* ev = nullptr;
   if (!jit && d->estimate_parameters && np > 0) {
     ev = mhe_est_find(d->model_id);
@@ -127,7 +133,9 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
   memset(h, 0, sizeof(*h));
   h->est = ev;
   h->device = device; h->model_id = d->model_id; h->nx = nx; h->nu = nu; h->np = np; h->ny = ny; h->N = d->N;
-  h->n_vc = np + (d->N + 1) * nx + d->N * nx;               // mhe.py:596-598
+  h->gen = gen ? 1 : 0;
+  h->noise = has_noise ? 1 : 0;
+  h->n_vc = np + (d->N + 1) * nx + (has_noise ? d->N * nx : 0);   // mhe.py:596-599
   h->n_v = h->n_vc + d->N * D * nx;                          // + collocation states (mhe.py:600-601)
   h->n_g = d->N * (nx + D * nx);                             // per stage [collocation rows | continuity] (mhe.py:728, :740)
   h->lds_bytes = lds;
@@ -170,14 +178,15 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
     HILO_REQUIRE(lb < ub, "hilo_mhe_create: empty box for variable %d", i);
     c.lbz[i] = lb; c.ubz[i] = ub;
   }
-  if (ev) {
+  if (ev || gen) {
     // engine state = [x | p], engine input = w: re-lay the per-slot data of the plain variant
     const int nxa = nx + np;
     int o[5];
-    ev->offsets(o);
+    if (ev) ev->offsets(o);
+    else { o[0] = 0; o[1] = nx * nx; o[2] = o[1] + np * np; o[3] = o[2] + ny * ny; o[4] = o[3] + nx * nx; }   // MheGen::O_*
     double sz[OCP_MAXNZ], lb[OCP_MAXNZ], ub[OCP_MAXNZ];
     for (int i = 0; i < 2 * nx; ++i) { sz[i] = c.sz[i]; lb[i] = c.lbz[i]; ub[i] = c.ubz[i]; }
-    HILO_REQUIRE(nxa + nx <= OCP_MAXNZ && nxa <= OCP_MAXNX + OCP_MAXNU, "model too large for parameter estimation in this build");
+    HILO_REQUIRE(nxa + (has_noise ? nx : 0) <= OCP_MAXNZ && nxa <= OCP_MAXNX + OCP_MAXNU, "model too large for parameter estimation in this build");
     memset(c.cost, 0, sizeof(c.cost));
     for (int i = 0; i < nx * nx; ++i) c.cost[o[0] + i] = d->Wx ? d->Wx[i] : 0.0;
     for (int i = 0; i < np * np; ++i) c.cost[o[1] + i] = d->Wp ? d->Wp[i] : 0.0;
@@ -186,14 +195,14 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
     for (int i = 0; i < nu; ++i) c.cost[o[4] + i] = d->u_scaling ? d->u_scaling[i] : 1.0;
     for (int i = 0; i < nx; ++i) {
       c.sz[i] = sz[i]; c.lbz[i] = lb[i]; c.ubz[i] = ub[i];
-      c.sz[nxa + i] = sz[nx + i]; c.lbz[nxa + i] = lb[nx + i]; c.ubz[nxa + i] = ub[nx + i];
+      if (has_noise) { c.sz[nxa + i] = sz[nx + i]; c.lbz[nxa + i] = lb[nx + i]; c.ubz[nxa + i] = ub[nx + i]; }
       c.x0_free_mask |= 1u << i;
     }
     for (int j = 0; j < np; ++j) {
       const double sp = d->p_scaling ? d->p_scaling[j] : 1.0;
       double pl = d->p_lb ? d->p_lb[j] / sp : -INFINITY, pu = d->p_ub ? d->p_ub[j] / sp : INFINITY;
       if (!(pl <= pu)) { delete h; return fail(HILO_EINVAL, "hilo_mhe_create: p_lb > p_ub for parameter %d", j); }
-      const bool estimated = pl < pu;
+      const bool estimated = d->estimate_parameters && pl < pu;
       c.sz[nx + j] = sp;
       c.k0_only_mask |= 1u << (nx + j);                         // one box (and one barrier term) per parameter
       if (estimated) {
@@ -213,26 +222,29 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
     rq.policy = JIT_MHE;
     rq.coll_d = D; rq.N = d->N;
     rq.sym = c.nsub == 1 && !getenv("HILO_NMPC_TAYLOR");
+    rq.mhe_gen = gen; rq.mhe_noise = has_noise;
     rc = jit_nmpc_kernels(rq, device, &h->jit);
     if (!rc && getenv("HILO_JIT_COMPILE_ONLY")) { delete h; return HILO_COMPILED_ONLY; }   // cache warmed, no handle
     if (!rc && (h->jit.dims[0] != nx || h->jit.dims[1] != nu || h->jit.dims[2] != np || h->jit.dims[3] != ny))
       rc = fail(HILO_EINVAL, "hilo_mhe_create: the compiled model has (nx, nu, np, ny) = (%d, %d, %d, %d); the description says "
                              "(%d, %d, %d, %d)", h->jit.dims[0], h->jit.dims[1], h->jit.dims[2], h->jit.dims[3], nx, nu, np, ny);
+    if (!rc && gen && h->jit.dims[6] != nx + np)
+      rc = fail(HILO_EINVAL, "hilo_mhe_create: the compiled general estimator has %d engine states, expected %d", h->jit.dims[6], nx + np);
     if (rc) { delete h; return rc; }
     h->lds_bytes = (size_t)h->jit.dims[5];
   }
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc((void**)&h->dev, sizeof(OcpConst));
   if (e == hipSuccess) e = hipMemcpy(h->dev, &c, sizeof(OcpConst), hipMemcpyHostToDevice);
-  if (ev && e == hipSuccess) {
+  if ((ev || gen) && e == hipSuccess) {
     // tiled guess in engine layout: [x_guess | p_guess] per stage, w_guess (mhe.py:620, :633-649)
-    const int nxa = nx + np, nve = (d->N + 1) * nxa + d->N * nx;
+    const int nxa = nx + np, nve = (d->N + 1) * nxa + (has_noise ? d->N * nx : 0);
     double* g = new double[nve];
     for (int k = 0; k <= d->N; ++k) {
       for (int i = 0; i < nx; ++i) g[k * nxa + i] = (d->x_guess ? d->x_guess[i] : 0.0) / c.sz[i];
       for (int j = 0; j < np; ++j) g[k * nxa + nx + j] = (d->p_guess ? d->p_guess[j] : 0.0) / c.sz[nx + j];
     }
-    for (int k = 0; k < d->N; ++k)
+    for (int k = 0; k < d->N && has_noise; ++k)
       for (int i = 0; i < nx; ++i) g[(d->N + 1) * nxa + k * nx + i] = (d->w_guess ? d->w_guess[i] : 0.0) / c.sz[nxa + i];
     e = hipMalloc((void**)&h->v_guess_e, sizeof(double) * nve);
     if (e == hipSuccess) e = hipMemcpy(h->v_guess_e, g, sizeof(double) * nve, hipMemcpyHostToDevice);
@@ -241,7 +253,7 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
   // tiled guess row; the run-time compiled kernel reads every start row behind a parameter prefix ([p | x | w]), the
   // zoo kernels take the guess without one
   const int gpre = jit ? np : 0;
-  const int nvf = gpre + h->n_vc - np;
+  const int nvf = gpre + (d->N + 1) * nx + d->N * nx;      // (read by the plain policies only; they always have the noise block)
   if (e == hipSuccess) e = hipMalloc((void**)&h->v_guess, sizeof(double) * nvf);
   if (e == hipSuccess) {
     double* g = new double[nvf];  // mhe.py:633-649: tiled guesses, scaled (mhe.py:229-236)
@@ -335,8 +347,8 @@ extern "C" int hilo_mhe_estimate(hilo_mhe* h, int64_t batch, const double* x_arr
                        h->nu, h->ny, p, p_stride, x_arrival, u_meas, y_meas, h->par_buf, h->sd_buf);
     HILO_HIP_CHECK(hipGetLastError());
   }
-  if (h->est) {
-    const int nxa = h->nx + h->np, nve = (h->N + 1) * nxa + h->N * h->nx;
+  if (h->est || h->gen) {
+    const int nxa = h->nx + h->np, nve = (h->N + 1) * nxa + (h->noise ? h->N * h->nx : 0);
     if (!h->ve || h->warm_batch != batch) {
       double** bufs[] = {&h->x0e, &h->v0e, &h->ve, &h->lame, &h->v_warm};
       const size_t sizes[] = {(size_t)nxa, (size_t)nve, (size_t)nve, (size_t)h->N * nxa, (size_t)h->n_v};
@@ -358,15 +370,26 @@ extern "C" int hilo_mhe_estimate(hilo_mhe* h, int64_t batch, const double* x_arr
     int64_t stride = 0;
     const double* vref = v0 ? v0 : (h->warm_valid ? h->v_warm : nullptr);
     if (vref) {
-      int rc2 = mhe_est_convert_in(batch, h->N, h->nx, h->np, vref, h->n_v, h->v0e, s);
+      int rc2 = mhe_est_convert_in(batch, h->N, h->nx, h->np, vref, h->n_v, h->v0e, s, h->noise);
       if (rc2) return rc2;
       start = h->v0e;
       stride = nve;
     }
     MheEstArgs a{h->dev, batch, h->x0e, h->par_buf, h->sd_buf, (int64_t)((h->N + 1) * ws), start, stride, h->ve, f_opt, h->lame,
                  status, iters, kkt, h->lds_bytes, s};
-    int rc2 = h->est->launch(a);
-    if (!rc2) rc2 = mhe_est_convert_out(h->dev, batch, h->N, h->nx, h->np, h->ve, h->lame, v_opt, lam_g, x_opt, s);
+    int rc2;
+    if (h->gen) {
+      // the general run-time compiled policy: same engine layout; its output pass (the module's `coll_out` kernel, hilo_mhe_policy.h::
+      // mhe_gen_output) writes the reference's v / lam_g with the collocation block and x_opt (handed over in the `par` argument)
+      rc2 = jit_launch_solve(h->jit.solve, h->dev, batch, h->x0e, h->par_buf, (int64_t)nxa, h->sd_buf, (int64_t)((h->N + 1) * ws), start,
+                             stride, h->ve, f_opt, h->lame, nullptr, status, iters, kkt, nullptr, nullptr, s, OcpExtra());
+      if (!rc2)
+        rc2 = jit_launch_coll_out(h->jit.coll_out, h->dev, batch, h->N, h->ve, h->lame, x_opt, 0, h->sd_buf,
+                                  (int64_t)((h->N + 1) * ws), v_opt, lam_g, s);
+    } else {
+      rc2 = h->est->launch(a);
+      if (!rc2) rc2 = mhe_est_convert_out(h->dev, batch, h->N, h->nx, h->np, h->ve, h->lame, v_opt, lam_g, x_opt, s);
+    }
     if (rc2) return rc2;
     HILO_HIP_CHECK(hipMemcpyAsync(h->v_warm, v_opt, sizeof(double) * h->n_v * batch, hipMemcpyDeviceToDevice, s));
     h->warm_valid = 1;

@@ -29,7 +29,8 @@ const MheEstVariant* mhe_est_find(int model_id);
 // x0e[b] = [0 (mx) | p_b], par[b] = [x_arrival_b | p_b]
 int mhe_est_pack(int64_t batch, int mx, int np, const double* p, int64_t p_stride, const double* xa, double* x0e, double* par,
                  hipStream_t s);
-int mhe_est_convert_in(int64_t batch, int N, int mx, int np, const double* v, int64_t v_stride, double* ve, hipStream_t s);
+// has_w = 0: an estimator without state noise (rows [p | x | ...] / [xa])
+int mhe_est_convert_in(int64_t batch, int N, int mx, int np, const double* v, int64_t v_stride, double* ve, hipStream_t s, int has_w = 1);
 int mhe_est_convert_out(const OcpConst* pc, int64_t batch, int N, int mx, int np, const double* ve, const double* lame,
                         double* v, double* lam_g, double* x_opt, hipStream_t s);
 

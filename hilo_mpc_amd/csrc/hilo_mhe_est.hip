@@ -107,8 +107,8 @@ struct MheEst {
 
 // reference row [p | x (N+1)*mx | w N*mx] -> engine row [xa (N+1)*(mx+np) | w]; p replicated over the stages
 __global__ void mhe_est_to_engine(int64_t batch, int N, int mx, int np, const double* __restrict__ v, int64_t v_stride,
-                                  double* __restrict__ ve) {
-  const int nxa = mx + np, ne = (N + 1) * nxa + N * mx;
+                                  double* __restrict__ ve, int has_w) {
+  const int nxa = mx + np, ne = (N + 1) * nxa + (has_w ? N * mx : 0);
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= batch * ne) return;
   const int64_t b = e / ne;
@@ -198,9 +198,9 @@ int mhe_est_pack(int64_t batch, int mx, int np, const double* p, int64_t p_strid
   return HILO_OK;
 }
 
-int mhe_est_convert_in(int64_t batch, int N, int mx, int np, const double* v, int64_t v_stride, double* ve, hipStream_t s) {
-  const int64_t tot = batch * ((int64_t)(N + 1) * (mx + np) + (int64_t)N * mx);
-  hipLaunchKernelGGL(mhe_est_to_engine, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, batch, N, mx, np, v, v_stride, ve);
+int mhe_est_convert_in(int64_t batch, int N, int mx, int np, const double* v, int64_t v_stride, double* ve, hipStream_t s, int has_w) {
+  const int64_t tot = batch * ((int64_t)(N + 1) * (mx + np) + (has_w ? (int64_t)N * mx : 0));
+  hipLaunchKernelGGL(mhe_est_to_engine, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, batch, N, mx, np, v, v_stride, ve, has_w);
   HILO_HIP_CHECK(hipGetLastError());
   return HILO_OK;
 }

@@ -103,6 +103,201 @@ struct MheNoise {
   __device__ __forceinline__ static T term_cost(const OcpConst&, const double*, const double*, const T*) { return T(0.0); }
 };
 
+// ---- the estimator in general: ESTIMATED parameters and / or NO state noise, models compiled at run time -------------------------
+// What the reference's own tests configure (tests/test_MHE.py:20-110, :150-230: continuous model, default collocation, no state
+// noise, `quad_arrival_cost.add_parameters`): mhe.py:596-790 with
+//   v = [p | x_0..x_N | w_0..w_{N-1} (only with state noise, :599) | ip]          J(k = 0) = arrival(x_0, p)  (modeling.py:747-777)
+// In engine terms: the model parameters ride along as constant extra states (p_{k+1} = p_k; estimated ones free at stage 0 and boxed
+// there, pinned ones fixed through x_0 - the form of hilo_mhe_est.hip, same argument for the equality of the iterates), controls :=
+// the noise (NOISE) or none at all (the trajectory is a function of (x_0, p): NU = 0).  Collocation: the augmented model
+// [x' = f(x, u, p); p' = 0] goes through hilo_colloc.h (the Taylor coefficients with respect to p come with it).
+//   pc.cost = [Wx (MX^2) | Wp (NP^2) | Wy | Ww | su];  par = [x_arrival | p_arrival];  sd_k = [u_meas_k | y_meas_k]
+template <class M>
+struct MheParAug {   // [x | p] with p' = 0 / p+ = p
+  static constexpr int NX = M::NX + M::NP, NU = M::NU, NP = 0, NY = M::NY;
+  static constexpr bool DISCRETE = M::DISCRETE;
+  template <class T, class U, class P>
+  __device__ __forceinline__ static void ode(const T* x, const U* u, const P*, double dt, T* dx) {
+    M::ode(x, u, x + M::NX, dt, dx);
+#pragma unroll
+    for (int j = 0; j < M::NP; ++j) dx[M::NX + j] = M::DISCRETE ? x[M::NX + j] : T(0.0);
+  }
+};
+
+template <class M, int CD, bool NOISE>
+struct MheGen {
+  using Model = M;
+  static constexpr int MX = M::NX, NP = M::NP, NX = MX + NP, NU = NOISE ? MX : 0, NY = M::NY, MU = M::NU, NPAR = MX + NP,
+                       NSD = M::NU + M::NY;
+  static constexpr bool FIX_X0 = true;   // with x0_free_mask: states free, estimated parameters free, the others pinned
+  static constexpr bool BIG = false;
+  static constexpr int NC = 0, NXV = NX, NX0 = NX, NU0 = NU > 0 ? NU : 1;
+  static constexpr bool COOP = false;
+  static constexpr bool QUAD_COST = false;
+  static constexpr int O_WX = 0, O_WP = O_WX + MX * MX, O_WY = O_WP + NP * NP, O_WW = O_WY + NY * NY, O_SU = O_WW + MX * MX,
+                       O_END = O_SU + MU;
+  static constexpr int NCOST = O_END;
+  static_assert(CD == 0 || !M::DISCRETE, "collocation needs the continuous model");
+  using MA = MheParAug<M>;
+
+  template <class T, class E>
+  __device__ __forceinline__ static void dyn(const OcpConst& pc, const double*, const double* sd, int, const T* x, const T* w,
+                                             T* xn, const E& ext) {
+    T xa[NX], xo[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xa[i] = x[i] * pc.sz[i];
+    if constexpr (CD > 0) {
+      T ue[MU > 0 ? MU : 1];
+#pragma unroll
+      for (int i = 0; i < MU; ++i) ue[i] = T(sd[i] * pc.cost[O_SU + i]);
+      Colloc<MA, CD>::step(pc.coll, xa, ue, (const double*)nullptr, pc.dt, xo);
+    } else {
+      double ue[MU > 0 ? MU : 1];
+#pragma unroll
+      for (int i = 0; i < MU; ++i) ue[i] = sd[i] * pc.cost[O_SU + i];
+      model_step<M>(pc.order, pc.nsub, xa, ue, xa + MX, pc.dt, xo, ext);
+    }
+#pragma unroll
+    for (int i = 0; i < MX; ++i) {
+      T v = xo[i] * (1.0 / pc.sz[i]);
+      if constexpr (NOISE) v = v + w[i];                       // mhe.py:731 / :736: scaled noise, scaled state
+      xn[i] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) xn[MX + j] = x[MX + j];
+  }
+
+  template <class T>
+  __device__ __forceinline__ static T stage_cost(const OcpConst& pc, const double* par, const double* sd, int k, const T* x,
+                                                 const T* w) {
+    T xp[MX], pp[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int i = 0; i < MX; ++i) xp[i] = x[i] * pc.sz[i];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) pp[j] = x[MX + j] * pc.sz[MX + j];
+    T acc = T(0.0);
+    if (k == 0) {  // arrival cost on states and parameters (modeling.py:747-777; mhe.py:742-745)
+      T d[NX];
+#pragma unroll
+      for (int i = 0; i < MX; ++i) d[i] = xp[i] - par[i];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) d[MX + j] = pp[j] - par[MX + j];
+#pragma unroll
+      for (int i = 0; i < MX; ++i) {
+        T s = T(0.0);
+#pragma unroll
+        for (int j = 0; j < MX; ++j) s = s + pc.cost[O_WX + i * MX + j] * d[j];
+        acc = acc + d[i] * s;
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        T s = T(0.0);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) s = s + pc.cost[O_WP + i * NP + j] * d[MX + j];
+        acc = acc + d[MX + i] * s;
+      }
+      return acc;
+    }
+    double ue[MU > 0 ? MU : 1];
+#pragma unroll
+    for (int i = 0; i < MU; ++i) ue[i] = sd[i] * pc.cost[O_SU + i];
+    T yv[NY], r[NY];
+    M::meas(xp, ue, pp, pc.dt, yv);
+#pragma unroll
+    for (int a = 0; a < NY; ++a) r[a] = yv[a] - sd[MU + a];
+#pragma unroll
+    for (int a = 0; a < NY; ++a) {
+      T s = T(0.0);
+#pragma unroll
+      for (int b = 0; b < NY; ++b) s = s + pc.cost[O_WY + a * NY + b] * r[b];
+      acc = acc + r[a] * s;
+    }
+    if constexpr (NOISE) {
+      T ws[MX];
+#pragma unroll
+      for (int i = 0; i < MX; ++i) ws[i] = w[i] * pc.sz[NX + i];
+#pragma unroll
+      for (int i = 0; i < MX; ++i) {
+        T s = T(0.0);
+#pragma unroll
+        for (int j = 0; j < MX; ++j) s = s + pc.cost[O_WW + i * MX + j] * ws[j];
+        acc = acc + ws[i] * s;
+      }
+    }
+    return acc;
+  }
+
+  template <class T>
+  __device__ __forceinline__ static T term_cost(const OcpConst&, const double*, const double*, const T*) { return T(0.0); }
+};
+
+// Output pass of the general estimator, one thread per (instance, interval k < N) plus one per instance for the tail: from the
+// engine's result in ENGINE layout - ve = [xa_0..xa_N (MX + NP each) | w], lame = [N][MX + NP] - to the reference's
+//   v     = [p (the stage-0 copy, scaled) | x_0..x_N | w (NOISE) | ip_0..ip_{N-1} (collocation)]            mhe.py:614-671
+//   lam_g = per interval [collocation rows (D MX) | continuity (MX)]                                          mhe.py:728, :740
+// and x_opt = x_N un-scaled (mhe.py:381-384).  The collocation states and the multipliers of their rows are rebuilt with the model's
+// own MX x MX blocks at the ESTIMATED parameter values (the parameter rows of the augmented system decouple, hilo_colloc.h).
+template <class M, int D, bool NOISE>
+__device__ __forceinline__ void mhe_gen_output(const OcpConst* __restrict__ pcg, int64_t batch, const double* __restrict__ ve,
+                                               const double* __restrict__ lame, const double* __restrict__ sdata, int64_t sd_stride,
+                                               double* __restrict__ v, double* __restrict__ lam_g, double* __restrict__ x_opt) {
+  using PB = MheGen<M, D, NOISE>;
+  constexpr int MX = M::NX, MU = M::NU, NP = M::NP, NXA = MX + NP, DD = D > 0 ? D : 1, DN = DD * MX, NSD = PB::NSD;
+  const int N = pcg->N;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= batch * N) return;
+  const int64_t b = e / N;
+  const int k = (int)(e - b * N);
+  const int nve = (N + 1) * NXA + (NOISE ? N * MX : 0), nw = NOISE ? N * MX : 0;
+  const int nv = NP + (N + 1) * MX + nw + (D > 0 ? N * DN : 0);
+  const double* row = ve + b * nve;
+  double* out = v + b * nv;
+  // head: p, x_k (and x_N by the last interval's thread), w_k
+#pragma unroll
+  for (int j = 0; j < NP; ++j)
+    if (k == 0) out[j] = row[MX + j];
+#pragma unroll
+  for (int i = 0; i < MX; ++i) {
+    out[NP + k * MX + i] = row[k * NXA + i];
+    if (k == N - 1) {
+      const double xv = row[N * NXA + i];
+      out[NP + N * MX + i] = xv;
+      if (x_opt) x_opt[b * MX + i] = xv * pcg->sz[i];
+    }
+    if constexpr (NOISE) out[NP + (N + 1) * MX + k * MX + i] = row[(N + 1) * NXA + k * MX + i];
+  }
+  const int rows = (D > 0 ? DN : 0) + MX;
+  double* lg = lam_g ? lam_g + b * (int64_t)(N * rows) + (int64_t)k * rows : nullptr;
+  const double* lr = lame ? lame + b * (int64_t)(N * NXA) + (int64_t)k * NXA : nullptr;
+  if constexpr (D > 0) {
+    double x[MX], u[MU > 0 ? MU : 1], p[NP > 0 ? NP : 1], X[DN], mat[DN * DN], lam[MX], mu[DN];
+#pragma unroll
+    for (int i = 0; i < MX; ++i) x[i] = row[k * NXA + i] * pcg->sz[i];
+#pragma unroll
+    for (int i = 0; i < MU; ++i) u[i] = sdata[b * sd_stride + k * NSD + i] * pcg->cost[PB::O_SU + i];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) p[j] = row[MX + j] * pcg->sz[MX + j];
+    Colloc<M, DD>::solve(pcg->coll, x, u, p, pcg->dt, X, mat);
+#pragma unroll
+    for (int i = 0; i < DD; ++i)
+#pragma unroll
+      for (int m = 0; m < MX; ++m) out[NP + (N + 1) * MX + nw + k * DN + i * MX + m] = X[i * MX + m] / pcg->sz[m];
+    if (lg) {
+#pragma unroll
+      for (int m = 0; m < MX; ++m) lam[m] = lr[m] / pcg->sz[m];
+      Colloc<M, DD>::multipliers(pcg->coll, X, u, p, pcg->dt, lam, mu);
+#pragma unroll
+      for (int i = 0; i < DD; ++i)
+#pragma unroll
+        for (int m = 0; m < MX; ++m) lg[i * MX + m] = mu[i * MX + m] * pcg->sz[m];
+    }
+  }
+  if (lg) {
+#pragma unroll
+    for (int m = 0; m < MX; ++m) lg[(D > 0 ? DN : 0) + m] = lr[m];
+  }
+}
+
 // Output pass of the collocation transcription, one thread per (instance, interval): the collocation states (scaled like the
 // states) behind the noise block of v, and lam_g in the reference's row order - per stage [collocation rows (D nx) | continuity
 // (nx)] (mhe.py:728, :740) - with the multipliers of the collocation rows from the continuity multiplier (hilo_colloc.h).

@@ -7,13 +7,15 @@ API mirror of `hilo_mpc.MHE` (`MovingHorizonEstimator`, hilo_mpc/modules/estimat
 N samples), `estimate(x_arrival=None, p_arrival=None, v0=None)` (mhe.py:311-416; returns `(None, None)` until the
 window is full, then `(x_N, p)` - the one-step-ahead state, mhe.py:381-384) - with a leading batch axis.
 
-Scope: state noise; the reference's integration branches (mhe.py:512-593) - `'collocation'` (its default for a continuous
+Scope: with or without state noise (`quad_stage_cost.add_state_noise`; without it the window's trajectory is a function of x_0 and
+the parameters, mhe.py:599, :726-736); the reference's integration branches (mhe.py:512-593) - `'collocation'` (its default for a continuous
 model: Radau / Legendre points of degree 1..4, collocation states in `v`, per-stage rows [collocation | continuity] in `lam_g`)
 and `'discrete'` (pre-discretised model; `'rk4'` / `'erk'` discretise the model first); models of the device zoo
 AND models written as expressions or text (`Model.set_dynamical_equations`, compiled with hiprtc at `setup()` around the
 estimator's policy, csrc/hilo_mhe_policy.h); a subset of the measurements in the cost (`add_measurements(weights, names=)`,
 modeling.py:686-712); model parameters either pinned by `p_lb == p_ub` or ESTIMATED (`quad_arrival_cost.add_parameters`,
-bounds / guess / scaling of p, mhe.py:614-623; zoo models with `'discrete'`) - `estimate` then returns `(x_opt, p_opt)`.
+bounds / guess / scaling of p, mhe.py:614-623; zoo models, models written as expressions, under collocation too) - `estimate` then
+returns `(x_opt, p_opt)`.
 """
 import ctypes as C
 import warnings
@@ -192,9 +194,8 @@ class MovingHorizonEstimator:
         pinned = bool(self._n_p) and self._p_lb is not None and self._p_ub is not None and \
             list(self._p_lb) == list(self._p_ub)
         self._estimating = bool(self._n_p) and not pinned
-        if self.quad_stage_cost.Ww is None:
-            raise NotImplementedError("MHE without state noise is not yet offloaded (and its 'multiple_shooting' branch "
-                                      "is broken in the reference, SURVEY.md Q8)")
+        noise = self.quad_stage_cost.Ww is not None
+        self._noise = noise
         coll = None
         if method == 'collocation':
             from .nmpc import _collocation_basis
@@ -204,9 +205,9 @@ class MovingHorizonEstimator:
             coll = _collocation_basis(deg, opts.get('collocation_points', 'radau'))
         self._coll = coll
         # models written as expressions, and every model under collocation: the policy is compiled around the model at setup
-        jit = bool(getattr(m, '_symbolic', False)) or coll is not None
-        if jit and self._estimating:
-            raise NotImplementedError("parameter estimation is offloaded for the zoo models with integration_method 'discrete'")
+        # ... and every estimator WITHOUT state noise (mhe.py:599, :726-736: the collocation and discrete branches run without the
+        # noise block; what tests/test_MHE.py:20-110 configure): the general policy csrc/hilo_mhe_policy.h::MheGen
+        jit = bool(getattr(m, '_symbolic', False)) or coll is not None or not noise
         if jit and not m.n_y:
             raise RuntimeError("The model has no measurement equations (set_measurement_equations)")
         keep = []
@@ -241,7 +242,8 @@ class MovingHorizonEstimator:
         d.x_guess, d.w_guess = hp(self._x_guess), hp(self._w_guess)
         if self._estimating:
             d.estimate_parameters = 1
-            d.Wp = hp(self.quad_arrival_cost.Wp)
+            Wp = self.quad_arrival_cost.Wp
+            d.Wp = hp(Wp if Wp is not None else np.zeros((self._n_p, self._n_p)))
             d.p_lb, d.p_ub = hp(self._p_lb), hp(self._p_ub)
             d.p_scaling, d.p_guess = hp(getattr(self, '_p_scaling', None)), hp(getattr(self, '_p_guess', None))
         import os
@@ -259,12 +261,13 @@ class MovingHorizonEstimator:
         self._handle = h
         N, nx, np_ = self._horizon, self._n_x, self._n_p
         dn = coll['d'] * nx if coll is not None else 0
-        self._n_v, self._n_g = np_ + (N + 1) * nx + N * nx + N * dn, N * (nx + dn)
+        nw = N * nx if noise else 0                                # mhe.py:599: the noise block exists only with state noise
+        self._n_v, self._n_g = np_ + (N + 1) * nx + nw + N * dn, N * (nx + dn)
         # bit-exact index maps of mhe.py:614-655
         self._p_ind = [list(range(np_))] if np_ else []
         self._x_ind = [list(range(np_ + k * nx, np_ + (k + 1) * nx)) for k in range(N + 1)]
-        self._w_ind = [list(range(np_ + (N + 1) * nx + k * nx, np_ + (N + 1) * nx + (k + 1) * nx)) for k in range(N)]
-        off = np_ + (N + 1) * nx + N * nx                         # collocation states behind the noise block (mhe.py:657-671)
+        self._w_ind = [list(range(np_ + (N + 1) * nx + k * nx, np_ + (N + 1) * nx + (k + 1) * nx)) for k in range(N)] if noise else []
+        off = np_ + (N + 1) * nx + nw                             # collocation states behind the noise block (mhe.py:657-671)
         self._ip_ind = [list(range(off + k * dn, off + (k + 1) * dn)) for k in range(N)] if dn else []
         self._sx = np.ones(nx) if self._x_scaling is None else np.asarray(self._x_scaling)
         self._sp = np.ones(np_) if getattr(self, '_p_scaling', None) is None else np.asarray(self._p_scaling)
@@ -401,6 +404,8 @@ class MovingHorizonEstimator:
         N, nx = self._horizon, self._n_x
         sw = np.ones(nx) if getattr(self, '_w_scaling', None) is None else np.asarray(self._w_scaling, dtype=float)
         X = v[:, self._x_ind[0][0]:self._x_ind[N][-1] + 1].reshape(-1, N + 1, nx) * self._sx
+        if not self._w_ind:
+            return np.swapaxes(X, 1, 2), None
         W = v[:, self._w_ind[0][0]:self._w_ind[N - 1][-1] + 1].reshape(-1, N, nx) * sw
         return np.swapaxes(X, 1, 2), np.swapaxes(W, 1, 2)
 
@@ -413,9 +418,10 @@ class MovingHorizonEstimator:
     def has_state_noise(self, arg):
         if not isinstance(arg, bool):
             raise TypeError("has_state_noise accepts True or False")
+        if arg and self.quad_stage_cost.Ww is None:
+            raise ValueError("state noise needs its weights: quad_stage_cost.add_state_noise(weights=...)")
         if not arg:
-            raise NotImplementedError("MHE without state noise is not yet offloaded (and its 'multiple_shooting' branch is broken "
-                                      "in the reference, SURVEY.md Q8)")
+            self.quad_stage_cost.Ww = None
 
     def set_nlp_options(self, *args, **kwargs):
         """mhe.py:792-860: the options `setup(options=...)` takes, checked against the reference's allow-lists."""

@@ -436,7 +436,8 @@ typedef struct hilo_mhe_desc {
      (hilo_mpc/util/modeling.py:665-672) */
   const double* Wx;   /* [nx][nx] arrival weight   (modeling.py:747-777, mhe.py:742-745) */
   const double* Wy;   /* [ny][ny] measurement weight (modeling.py:686-712) */
-  const double* Ww;   /* [nx][nx] state-noise weight (modeling.py:735-745) */
+  const double* Ww;   /* [nx][nx] state-noise weight (modeling.py:735-745); NULL: an estimator WITHOUT state noise (no w block in v,
+                         mhe.py:599) - models given as source (user_source) */
   const double* x_lb; const double* x_ub; const double* w_lb; const double* w_ub;   /* original units */
   const double* x_scaling; const double* w_scaling; const double* u_scaling;
   const double* x_guess; const double* w_guess;
