@@ -630,6 +630,7 @@ struct NmpcUser {
       for (int q = 0; q < R; ++q) lnode[q] = 0.0;
       for (int r = 0; r < nrow; ++r) {
         const int ref = (int)pc.cost[L.o_rref + r];
+        if (ref < 0) continue;        // the hidden rows of bounded algebraic states: bounds of variables in the reference, not rows of g
         lnode[ref] = nu[r];
         for (int i = 0; i < DD; ++i) lg[i * R + ref] = nu[(i + 1) * nrow + r];
       }

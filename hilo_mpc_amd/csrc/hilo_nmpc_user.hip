@@ -70,6 +70,16 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
       }
     }
   }
+  // finite bounds on algebraic states: hidden hard rows z_a in [lb, ub], bounded at the collocation points only (below)
+  const int nrow_user = nrow;
+  const int nzb = d->n_zbound;
+  HILO_REQUIRE(nzb >= 0 && (nzb == 0 || (D > 0 && d->zb_lb && d->zb_ub)), "hilo_nmpc_create: bounds on algebraic states need collocation");
+  for (int q = 0; q < nzb; ++q) {
+    HILO_REQUIRE(nrow < OCP_MAXNC, "too many constraint rows");
+    HILO_REQUIRE(d->zb_lb[q] <= d->zb_ub[q], "hilo_nmpc_create: z bound %d has lb > ub", q);
+    row_expr[nrow] = d->n_con + q; row_sign[nrow] = 1; row_e[nrow] = -1; row_lb[nrow] = d->zb_lb[q]; row_ub[nrow] = d->zb_ub[q];
+    row_ref[nrow++] = -1;
+  }
   ne_stage = ne;
   if (d->n_tcon > 0) {
     if (d->tcon_soft) ne += d->n_tcon;   // slacks e_T behind the stage slacks in v (mpc.py:1540-1548)
@@ -98,6 +108,7 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
                  D + 1, OCP_MAXNC);
     for (int i = 1; i <= D; ++i)
       for (int r = 0; r < nrow_pt; ++r) { row_lb[i * nrow_pt + r] = row_lb[r]; row_ub[i * nrow_pt + r] = row_ub[r]; }
+    for (int r = nrow_user; r < nrow_pt; ++r) { row_lb[r] = -INFINITY; row_ub[r] = INFINITY; }   // z bounds: not at the node (no z variable there)
     nrow = nrow_pt * (D + 1);
   }
   const int nc = nrow + ntrow;

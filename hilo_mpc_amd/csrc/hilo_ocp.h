@@ -408,7 +408,9 @@ struct Ocp {
   }
   // inequality row m exists at stage k
   __device__ static bool row_on(const OcpConst& pc, int k, int m) {
-    return m < pc.nc || (k == pc.N - 1 && m < pc.nc + pc.nc_term);
+    // (a row without a finite bound constrains nothing: the copies at the node of rows that only exist at the collocation
+    // points - bounds on algebraic states, hilo_nmpc_user.hip - are switched off this way)
+    return (m < pc.nc || (k == pc.N - 1 && m < pc.nc + pc.nc_term)) && (pc.dlb[m] > -INFINITY || pc.dub[m] < INFINITY);
   }
   __device__ static double lb_of(const OcpConst& pc, int k, int i) {
     if (k == 0 && (pc.flags & 2) && i < NX0) return pc.x0lb[i];

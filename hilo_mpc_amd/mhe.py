@@ -443,7 +443,12 @@ class MovingHorizonEstimator:
                 if tvp not in self._model.parameter_names:
                     raise ValueError(f"The time-varying parameter {tvp} is not in the model0 parameter. "
                                      f"The model0 parameters are {self._model.parameter_names}.")
-            raise NotImplementedError("time-varying parameters inside the estimation window are not offloaded")
+            # the reference declares a `tv_p` slot in the solver's parameter struct (mhe.py:677) and never reads it: `p` stays the one
+            # decision vector of the window (mhe.py:614-623, :726-736), `estimate()` fills no values in.  Same here: the names are
+            # checked and remembered, the NLP is unchanged.
+            self._time_varying_parameters = list(time_varying_parameters)
+            warnings.warn("time-varying parameters are declared, but - like in the reference, whose estimator never reads its tv_p "
+                          "slot (mhe.py:677) - they do not enter the estimation problem: p is one vector for the whole window")
 
     def set_aux_nonlinear_constraints(self, aux_nl_const=None, ub=None, lb=None):
         """mhe.py:1070-1087."""

@@ -517,12 +517,13 @@ class NMPC:
                     raise TypeError(f"The model has {len(meas)} measurements. You need to pass the same number of bounds.")
             self.set_stage_constraints(stage_constraint=meas, ub=y_ub, lb=y_lb, name='measurement_constraint')
             self.set_terminal_constraints(terminal_constraint=meas, ub=y_ub, lb=y_lb, name='measurement_constraint')
-        for b in (z_ub, z_lb):
-            # the algebraic states are eliminated through their equations: a finite box on them would have to
-            # become a nonlinear inequality row
-            if b is not None and np.any(np.isfinite(np.asarray(_wrap_list(b), dtype=float))):
-                raise NotImplementedError("finite bounds on algebraic states are not offloaded (default: -inf / +inf, "
-                                          "mpc.py:645-701)")
+        # the algebraic states are eliminated through their equations: a finite box on them (mpc.py:645-701, the box of
+        # the zp blocks of v, :1512-1518) becomes hard rows on z(x_{k,i}, u_k) at the collocation points
+        nza = getattr(self._model, 'n_z', 0)
+        self._z_lb = None if z_lb is None else chk(np.broadcast_to(np.asarray(_wrap_list(z_lb), dtype=float), (nza,)) if np.size(z_lb) == 1
+                                                   else z_lb, nza, 'algebraic states')
+        self._z_ub = None if z_ub is None else chk(np.broadcast_to(np.asarray(_wrap_list(z_ub), dtype=float), (nza,)) if np.size(z_ub) == 1
+                                                   else z_ub, nza, 'algebraic states')
 
     def _meas_exprs(self):
         """The model's measurement equations as expressions (models written as expressions; zoo models held as expressions)."""
@@ -856,9 +857,17 @@ class NMPC:
             else:
                 src = m.user_source()
             if policy == 2:
+                zb = []                      # bounded algebraic states: expressions behind the constraint's, rows at the collocation points
+                if nza:
+                    zl = [-np.inf] * nza if getattr(self, '_z_lb', None) is None else list(self._z_lb)
+                    zu = [np.inf] * nza if getattr(self, '_z_ub', None) is None else list(self._z_ub)
+                    zb = [a for a in range(nza) if np.isfinite(zl[a]) or np.isfinite(zu[a])]
+                    if zb:
+                        d.n_zbound = len(zb)
+                        d.zb_lb, d.zb_ub = hp([zl[a] for a in zb]), hp([zu[a] for a in zb])
                 src += codegen.fun_source(
                     nx, stage=gen_stage, term=gen_term,
-                    con=sc.constraint if sc.is_set else (), tcon=tc.constraint if tc.is_set else (),
+                    con=(list(sc.constraint) if sc.is_set else []) + [m.z[a] for a in zb], tcon=tc.constraint if tc.is_set else (),
                     path_stage=[r for _, _, rr in self.quad_stage_cost._paths for r in rr],
                     path_term=[r for _, _, rr in self.quad_terminal_cost._paths for r in rr])
                 d.user_has_fun = 1

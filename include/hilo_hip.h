@@ -338,6 +338,12 @@ typedef struct hilo_nmpc_desc {
   const unsigned char* hess_pattern;
   double max_hessian_perturbation;   /* IPOPT option of that name (delta_w^max of W&B Alg. IC, default 1e20 there, 1e40 here =
                                         the oracle's): beyond it the inertia correction gives up -> status 4; <= 0 keeps the default */
+  /* finite bounds on algebraic states (`set_box_constraints(z_lb=, z_ub=)`, mpc.py:645-701 -> the box of the zp blocks of v,
+     :1512-1518): UserFun::con evaluates n_zbound further expressions behind the n_con constraint expressions - the bounded
+     algebraic states - which become rows at the collocation points only (the algebraic states are eliminated);
+     they do not appear in lam_g */
+  int32_t n_zbound; int32_t reserved5;
+  const double* zb_lb; const double* zb_ub;        /* [n_zbound]; -inf / +inf allowed on one side */
 } hilo_nmpc_desc;
 
 #define HILO_MODEL_USER 100    /* model defined by desc.user_source */

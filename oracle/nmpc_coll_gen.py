@@ -60,7 +60,7 @@ class GenCollProblem(NmpcProblem):
     quirk restated in oracle/nmpc_coll.py)."""
 
     def __init__(self, model, dt, N, degree=3, points='radau', objective='continuous', path=None, constraint=None,
-                 generic_stage=None, z_guess=None, **kw):
+                 generic_stage=None, z_guess=None, z_lb=None, z_ub=None, **kw):
         kw.pop('order', None)
         super().__init__(model, dt, N, **kw)
         assert not model.discrete and objective in ('continuous', 'discrete')
@@ -73,6 +73,9 @@ class GenCollProblem(NmpcProblem):
         self.nxa, self.nua, self.nzalg = nx + nth, nu + nth, len(m.z)
         nxa, nua, nzg = self.nxa, self.nua, self.nzalg
         self.z_guess = np.zeros(nzg) if z_guess is None else np.asarray(z_guess, dtype=float).reshape(nzg)
+        # box of the algebraic states: the bounds of the zp blocks of v (mpc.py:645-701, :1512-1518; the node blocks enter nothing)
+        self.z_lb = np.full(nzg, -INF) if z_lb is None else np.broadcast_to(np.asarray(z_lb, dtype=float), (nzg,)).copy()
+        self.z_ub = np.full(nzg, INF) if z_ub is None else np.broadcast_to(np.asarray(z_ub, dtype=float), (nzg,)).copy()
         self.sxa = np.concatenate([self.sx, np.ones(nth)])
         self.sua = np.concatenate([self.su, np.ones(nth)])
         if path:
@@ -259,8 +262,7 @@ class GenCollIpm(DenseIpm):
         self.nw = self.o_s + N * self.ns
         self.mk = pb.mk
         self.m = N * self.mk
-        zl = np.full(nzg, -INF)
-        zu = np.full(nzg, INF)
+        zl, zu = pb.z_lb, pb.z_ub
         blk_lb = np.concatenate([np.tile(pb.x_lb, d), np.tile(zl, d)])
         blk_ub = np.concatenate([np.tile(pb.x_ub, d), np.tile(zu, d)])
         slb = np.array([r[3] for r in pb.rows] * (d + 1))

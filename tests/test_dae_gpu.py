@@ -98,11 +98,43 @@ def test_unsupported_dae_configurations_are_refused():
     nmpc = NMPC(m)
     nmpc.quad_stage_cost.add_states(names=['v'], ref=[0], weights=[1])
     nmpc.horizon = 5
-    with pytest.raises(NotImplementedError, match="finite bounds on algebraic states"):
-        nmpc.set_box_constraints(z_lb=[-100], z_ub=[100])
     md = symbolic_model('pendulum4_dae').discretize('rk4').setup(dt=.1)
     n2 = NMPC(md)
     n2.quad_stage_cost.add_states(names=['v'], ref=[0], weights=[1])
     n2.horizon = 5
     with pytest.raises(NotImplementedError, match="collocation"):
         n2.setup(options={'integration_method': 'discrete'})
+
+
+def test_bounds_on_algebraic_states_vs_oracle():
+    """`set_box_constraints(z_lb=, z_ub=)` (mpc.py:645-701: the box of the zp blocks of v; the reference's own DAE test sets one,
+    tests/test_NMPC.py:1964): the product eliminates the algebraic states, so the box becomes hard rows on z(x_{k,i}, u_k) at the
+    collocation points; the oracle bounds its variables.  The pendulum's tip height y >= 1.494 - without it the pendulum is let
+    fall towards the end of the horizon, with it the bound is active there; n_v / n_g are the unbounded problem's."""
+    from hilo_mpc_amd import NMPC
+    from oracle.nmpc_coll_gen import GenCollIpm, GenCollProblem
+    m = symbolic_model('pendulum4_dae').setup(dt=.1)
+    nmpc = NMPC(m)
+    nmpc.quad_stage_cost.add_states(names=['v', 'theta'], ref=[0, 0], weights=[10, 5])
+    nmpc.quad_stage_cost.add_inputs(names='F', weights=0.1)
+    nmpc.horizon = 12
+    nmpc.set_box_constraints(x_ub=[5, 10, 10, 10], x_lb=[-5, -10, -10, -10], z_lb=1.494)
+    nmpc.set_initial_guess(x_guess=[2.5, 0., .1, 0.], u_guess=0., z_guess=1.4)
+    nmpc.setup(solver_options={'ipopt.tol': 1e-10})
+    kw = dict(dt=.1, N=12, z_guess=[1.4], stage_states=[([1, 2], [10., 5.], [0., 0.])], stage_inputs=[([0], [.1], None)],
+              x_lb=[-5, -10, -10, -10], x_ub=[5, 10, 10, 10], x_guess=[2.5, 0., .1, 0.], u_guess=[0.])
+    pb = GenCollProblem(models.get('pendulum4_dae'), z_lb=[1.494], **kw)
+    ipm = GenCollIpm(pb, IpmOptions(tol=1e-10))
+    free = GenCollIpm(GenCollProblem(models.get('pendulum4_dae'), **kw), IpmOptions(tol=1e-10))
+    x0 = np.array([[2.5, 0., .1, 0.], [2., .2, -.1, .1]])
+    ref = ipm.solve(x0, [])
+    assert np.all(ref['status'] == 1) and ref['Zc'].min() < 1.494 + 1e-6 and free.solve(x0, [])['Zc'].min() < 1.1     # the bound is active
+    assert (nmpc._n_v, nmpc._n_g) == (pb.n_v, pb.n_g)
+    u = nmpc.optimize(x0)
+    assert np.all(nmpc.solver_status_code == 1)
+    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), ipm.to_v(ref)
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 1e-6
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-9)
+    np.testing.assert_allclose(u, ref['u0'], rtol=1e-6, atol=1e-8)
+    zp = v[:, [i for k in range(pb.N) for i in nmpc._zp_ind[k]]]
+    assert zp.min() >= 1.494 - 1e-7 and zp.min() < 1.494 + 1e-6
