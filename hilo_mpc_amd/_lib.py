@@ -64,7 +64,8 @@ class MheDesc(C.Structure):
                [(n, C.c_void_p) for n in ('Wp', 'p_lb', 'p_ub', 'p_scaling', 'p_guess')] + \
                [('user_source', C.c_char_p)] + \
                [(n, C.c_int32) for n in ('user_nx', 'user_nu', 'user_np', 'user_ny', 'user_discrete', 'collocation_degree')] + \
-               [('coll_A', C.c_void_p), ('coll_D', C.c_void_p)]
+               [('coll_A', C.c_void_p), ('coll_D', C.c_void_p), ('n_con', C.c_int32), ('reserved6', C.c_int32), ('con_lb', C.c_void_p),
+                ('con_ub', C.c_void_p)]
 
 
 _lib = None

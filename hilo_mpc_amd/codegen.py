@@ -259,3 +259,19 @@ def fun_source(n_x, stage=None, term=None, con=(), tcon=(), path_stage=(), path_
             s += _fn('void', name, 'const T* x, const double* p, T* r', ["    (void)x; (void)p;"] + em.lines,
                      [f"    r[{i}] = T({q});" for i, q in enumerate(rr)])
     return s + "};\n"
+
+
+def mhe_fun_source(con):
+    """`struct UserFun` of an estimator's stage constraint (csrc/hilo_mhe_policy.h::MheGen): the expressions of the (scaled) states
+    and parameters, mhe.py:498-508."""
+    for e in con:
+        e = Expr.wrap(e)
+        if e.depends_on('u') or e.depends_on('z') or e.depends_on('theta'):
+            raise ValueError("the estimator's stage constraint is a function of the states and parameters (mhe.py:501-508: the inputs "
+                             "are data)")
+    em = Emitter()
+    rr = [em.ref(e) for e in con]
+    return ("struct UserFun {\n"
+            f"  static constexpr int NEXPR = {len(con)};\n" +
+            _fn('void', 'con', 'const T* x, const T* p, T* c', ["    (void)x; (void)p;"] + em.lines,
+                [f"    c[{i}] = T({r});" for i, r in enumerate(rr)]) + "};\n")

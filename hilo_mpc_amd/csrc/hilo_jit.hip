@@ -149,8 +149,8 @@ extern "C" __global__ void hilo_user_info(int* out) {
 static std::string translation_unit_mhe(const JitRequest& r) {
   char cfg[512];
   snprintf(cfg, sizeof(cfg), "#define HILO_OCP_TPB 64\n#define HILO_USER_N %d\n#define HILO_USER_COLL_D %d\n#define HILO_USER_SYM %d\n"
-                             "#define HILO_USER_MHE_GEN %d\n#define HILO_USER_MHE_NOISE %d\n",
-           r.N, r.coll_d, (int)r.sym, (int)r.mhe_gen, (int)r.mhe_noise);
+                             "#define HILO_USER_MHE_GEN %d\n#define HILO_USER_MHE_NOISE %d\n#define HILO_USER_HAS_FUN %d\n#define HILO_USER_NC %d\n",
+           r.N, r.coll_d, (int)r.sym, (int)r.mhe_gen, (int)r.mhe_noise, (int)r.has_fun, r.nc);
   std::string s(cfg);
   s += "#include \"hilo_mhe_policy.h\"\n";
   s += "extern \"C\" { __device__ const double* hilo_user_gp[4]; }\n";
@@ -158,7 +158,10 @@ static std::string translation_unit_mhe(const JitRequest& r) {
   s += r.user_source;
   s += R"(
 #if HILO_USER_MHE_GEN
-using PB = MheGen<UserModel, HILO_USER_COLL_D, HILO_USER_MHE_NOISE>;
+#if !HILO_USER_HAS_FUN
+using UserFun = NoMheFun;
+#endif
+using PB = MheGen<UserModel, HILO_USER_COLL_D, HILO_USER_MHE_NOISE, UserFun, HILO_USER_NC>;
 constexpr int V_PREFIX = 0;             // engine-layout rows [xa | w] (the host converts, hilo_mhe.hip)
 #else
 using PB = MheNoise<UserModel, HILO_USER_SYM, HILO_USER_COLL_D>;
@@ -188,7 +191,8 @@ extern "C" __global__ void hilo_user_coll_out(const OcpConst* __restrict__ pcg, 
                                               double* __restrict__ lam_g) {
 #if HILO_USER_MHE_GEN
   // general estimator: engine layout in, reference layout out; `par` carries the x_opt output buffer (hilo_mhe.hip)
-  mhe_gen_output<UserModel, HILO_USER_COLL_D, HILO_USER_MHE_NOISE>(pcg, batch, vc, lamc, sdata, sd_stride, v, lam_g, (double*)par);
+  mhe_gen_output<UserModel, HILO_USER_COLL_D, HILO_USER_MHE_NOISE, UserFun, HILO_USER_NC>(pcg, batch, vc, lamc, sdata, sd_stride, v, lam_g,
+                                                                                          (double*)par);
 #elif HILO_USER_COLL_D > 0
   mhe_coll_output<UserModel, HILO_USER_COLL_D>(pcg, batch, vc, lamc, par, par_stride, sdata, sd_stride, v, lam_g);
 #endif

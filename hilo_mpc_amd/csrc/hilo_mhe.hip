@@ -58,6 +58,7 @@ struct hilo_mhe {
   int use_jit, coll_d, n_vc;         // n_vc: row length of the engine's result [p | x | w] (= n_v without the collocation block)
   double *vc, *lamc;                 // collocation: the engine's result before the output pass
   const MheEstVariant* est;          // parameter-estimating variant or NULL
+  int nc;                            // inequality rows per interval of the engine (stage constraint)
   int gen, noise;                    // run-time compiled GENERAL policy (MheGen: parameters as states, optional state noise) / w present
   double *x0e, *v0e, *ve, *lame, *v_guess_e;   // engine-layout buffers of the estimating variant
   unsigned est_mask;                 // bit j: parameter j is a variable
@@ -117,7 +118,19 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
   // desc.Ww == NULL: an estimator WITHOUT state noise (mhe.py:599: no w block in v; the collocation / discrete branches run without
   // it, :726-736) - on the general run-time compiled policy, like parameter estimation for models given as source
   const bool has_noise = d->Ww != nullptr;
-  const bool gen = jit && ((d->estimate_parameters && np > 0) || !has_noise);
+  HILO_REQUIRE(d->n_con >= 0 && d->n_con <= OCP_MAXNC && (d->n_con == 0 || (jit && d->con_lb && d->con_ub)),
+               "hilo_mhe_create: a stage constraint needs user_source with UserFun and its bounds");
+  const bool gen = jit && ((d->estimate_parameters && np > 0) || !has_noise || d->n_con > 0);
+  // rows of the stage constraint: one per expression with a finite bound; under collocation the node's rows are followed by those of
+  // the D collocation points (mhe.py:536-553, :749-757)
+  int nrow_pt = 0, row_expr[OCP_MAXNC];
+  double row_lb[OCP_MAXNC], row_ub[OCP_MAXNC];
+  for (int j = 0; j < d->n_con; ++j) {
+    HILO_REQUIRE(d->con_lb[j] <= d->con_ub[j], "hilo_mhe_create: constraint %d has lb > ub", j);
+    if (d->con_lb[j] > -INFINITY || d->con_ub[j] < INFINITY) { row_expr[nrow_pt] = j; row_lb[nrow_pt] = d->con_lb[j]; row_ub[nrow_pt++] = d->con_ub[j]; }
+  }
+  const int nrow_all = nrow_pt * (D > 0 ? D + 1 : 1);
+  HILO_REQUIRE(nrow_all <= OCP_MAXNC, "hilo_mhe_create: %d constraint rows per interval exceed %d", nrow_all, OCP_MAXNC);
   if (!jit && !has_noise) return fail(HILO_ENOTSUP, "an estimator without state noise runs on the run-time compiled policy: pass desc.user_source");
   if (gen)
     HILO_REQUIRE(nx + np <= OCP_MAXNX && (nx + np) + (has_noise ? nx : 0) <= OCP_MAXNZ,
@@ -137,7 +150,9 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
   h->noise = has_noise ? 1 : 0;
   h->n_vc = np + (d->N + 1) * nx + (has_noise ? d->N * nx : 0);   // mhe.py:596-599
   h->n_v = h->n_vc + d->N * D * nx;                          // + collocation states (mhe.py:600-601)
-  h->n_g = d->N * (nx + D * nx);                             // per stage [collocation rows | continuity] (mhe.py:728, :740)
+  h->n_g = d->N * (nx + D * nx + (D + 1) * d->n_con);        // per stage [rows at the collocation points | collocation rows |
+                                                             // continuity | rows at the node] (mhe.py:536-553, :728, :740, :749-757)
+  h->nc = nrow_all;
   h->lds_bytes = lds;
   h->use_jit = jit ? 1 : 0;
   h->coll_d = D;
@@ -184,6 +199,7 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
     int o[5];
     if (ev) ev->offsets(o);
     else { o[0] = 0; o[1] = nx * nx; o[2] = o[1] + np * np; o[3] = o[2] + ny * ny; o[4] = o[3] + nx * nx; }   // MheGen::O_*
+    const int o_rowx = o[4] + nu, o_nrow = o_rowx + OCP_MAXNC, o_ncr = o_nrow + 1, o_rref = o_ncr + 1;
     double sz[OCP_MAXNZ], lb[OCP_MAXNZ], ub[OCP_MAXNZ];
     for (int i = 0; i < 2 * nx; ++i) { sz[i] = c.sz[i]; lb[i] = c.lbz[i]; ub[i] = c.ubz[i]; }
     HILO_REQUIRE(nxa + (has_noise ? nx : 0) <= OCP_MAXNZ && nxa <= OCP_MAXNX + OCP_MAXNU, "model too large for parameter estimation in this build");
@@ -193,6 +209,18 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
     for (int i = 0; i < ny * ny; ++i) c.cost[o[2] + i] = d->Wy ? d->Wy[i] : 0.0;
     for (int i = 0; i < nx * nx; ++i) c.cost[o[3] + i] = d->Ww ? d->Ww[i] : 0.0;
     for (int i = 0; i < nu; ++i) c.cost[o[4] + i] = d->u_scaling ? d->u_scaling[i] : 1.0;
+    if (gen && nrow_all > 0) {
+      c.cost[o_nrow] = nrow_pt; c.cost[o_ncr] = d->n_con;
+      for (int m = 0; m < OCP_MAXNC; ++m) { c.dlb[m] = -INFINITY; c.dub[m] = INFINITY; }
+      for (int r = 0; r < nrow_pt; ++r) { c.cost[o_rowx + r] = row_expr[r]; c.cost[o_rref + r] = row_expr[r]; }
+      for (int m = 0; m < nrow_all; ++m) {
+        const int r = m % nrow_pt;
+        c.dlb[m] = row_lb[r] > -INFINITY ? row_lb[r] - relax * fmax(1.0, fabs(row_lb[r])) : row_lb[r];
+        c.dub[m] = row_ub[r] < INFINITY ? row_ub[r] + relax * fmax(1.0, fabs(row_ub[r])) : row_ub[r];
+        c.row_ref[m] = (short)m;
+      }
+      c.nc = nrow_all; c.nc_term = 0; c.n_con_ref = nrow_all; c.n_tcon_ref = 0;   // compact multipliers; the output pass orders them
+    }
     for (int i = 0; i < nx; ++i) {
       c.sz[i] = sz[i]; c.lbz[i] = lb[i]; c.ubz[i] = ub[i];
       if (has_noise) { c.sz[nxa + i] = sz[nx + i]; c.lbz[nxa + i] = lb[nx + i]; c.ubz[nxa + i] = ub[nx + i]; }
@@ -223,6 +251,7 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
     rq.coll_d = D; rq.N = d->N;
     rq.sym = c.nsub == 1 && !getenv("HILO_NMPC_TAYLOR");
     rq.mhe_gen = gen; rq.mhe_noise = has_noise;
+    rq.has_fun = d->n_con > 0; rq.nc = nrow_all;
     rc = jit_nmpc_kernels(rq, device, &h->jit);
     if (!rc && getenv("HILO_JIT_COMPILE_ONLY")) { delete h; return HILO_COMPILED_ONLY; }   // cache warmed, no handle
     if (!rc && (h->jit.dims[0] != nx || h->jit.dims[1] != nu || h->jit.dims[2] != np || h->jit.dims[3] != ny))
@@ -351,7 +380,7 @@ extern "C" int hilo_mhe_estimate(hilo_mhe* h, int64_t batch, const double* x_arr
     const int nxa = h->nx + h->np, nve = (h->N + 1) * nxa + (h->noise ? h->N * h->nx : 0);
     if (!h->ve || h->warm_batch != batch) {
       double** bufs[] = {&h->x0e, &h->v0e, &h->ve, &h->lame, &h->v_warm};
-      const size_t sizes[] = {(size_t)nxa, (size_t)nve, (size_t)nve, (size_t)h->N * nxa, (size_t)h->n_v};
+      const size_t sizes[] = {(size_t)nxa, (size_t)nve, (size_t)nve, (size_t)h->N * (nxa + h->nc), (size_t)h->n_v};
       for (int q = 0; q < 5; ++q) {
         if (*bufs[q]) HILO_HIP_CHECK(hipFree(*bufs[q]));
         *bufs[q] = nullptr;

@@ -9,6 +9,7 @@
 // (the reference's default, mhe.py:512-561; the collocation states are eliminated inside the map - hilo_colloc.h - and rebuilt
 // on output, mhe_coll_output).  In engine terms: controls := the noise w_k (B_k = I), x_0 free, per-stage data = (u_meas_k, y_meas_k).
 #pragma once
+#include "hilo_expr.h"
 #include "hilo_ocp.h"
 
 namespace hilo {
@@ -124,25 +125,40 @@ struct MheParAug {   // [x | p] with p' = 0 / p+ = p
   }
 };
 
-template <class M, int CD, bool NOISE>
+// F for estimators without a stage constraint
+struct NoMheFun {
+  static constexpr int NEXPR = 0;
+};
+
+// Stage constraint of the estimator (`mhe.stage_constraint.constraint = ...`, mhe.py:498-508): HARD rows lb <= c(x, p) <= ub at
+// every node k < N (mhe.py:749-757) and - under collocation - at every collocation point (mhe.py:536-550), like the controller's
+// (hilo_nmpc_user.h).  QUIRKS restated: the expression is evaluated on the NLP's SCALED variables (the estimator never calls the
+// constraint's `_check_and_setup`, so no scaling is substituted), and the soft branch cannot run in the reference (its penalty
+// function is only created by that call): soft constraints are refused.  F::con(x, p, c): NEXPR expressions; row m uses expression
+// pc.cost[O_ROWX + m] (one row per expression with a finite bound).
+template <class M, int CD, bool NOISE, class F = NoMheFun, int NC_ = 0>
 struct MheGen {
   using Model = M;
   static constexpr int MX = M::NX, NP = M::NP, NX = MX + NP, NU = NOISE ? MX : 0, NY = M::NY, MU = M::NU, NPAR = MX + NP,
                        NSD = M::NU + M::NY;
   static constexpr bool FIX_X0 = true;   // with x0_free_mask: states free, estimated parameters free, the others pinned
   static constexpr bool BIG = false;
-  static constexpr int NC = 0, NXV = NX, NX0 = NX, NU0 = NU > 0 ? NU : 1;
+  static constexpr int NC = NC_, NXV = NX, NX0 = NX, NU0 = NU > 0 ? NU : 1;
   static constexpr bool COOP = false;
   static constexpr bool QUAD_COST = false;
+  // rows at the collocation points need the collocation states: evaluated together with the shooting map and the stage cost
+  static constexpr bool FUSED = NC_ > 0 && CD > 0, FUSED_CON = FUSED;
   static constexpr int O_WX = 0, O_WP = O_WX + MX * MX, O_WY = O_WP + NP * NP, O_WW = O_WY + NY * NY, O_SU = O_WW + MX * MX,
-                       O_END = O_SU + MU;
+                       O_ROWX = O_SU + MU, O_NROW = O_ROWX + OCP_MAXNC, O_NCR = O_NROW + 1, O_RREF = O_NCR + 1,
+                       O_END = O_RREF + OCP_MAXNC;
   static constexpr int NCOST = O_END;
   static_assert(CD == 0 || !M::DISCRETE, "collocation needs the continuous model");
+  static_assert(NCOST <= OCP_NCOST, "cost block too small");
   using MA = MheParAug<M>;
 
+  // x_{k+1} of the interval (scaled), optionally the collocation states (un-scaled, augmented [x | p])
   template <class T, class E>
-  __device__ __forceinline__ static void dyn(const OcpConst& pc, const double*, const double* sd, int, const T* x, const T* w,
-                                             T* xn, const E& ext) {
+  __device__ __forceinline__ static void map(const OcpConst& pc, const double* sd, const T* x, const T* w, T* xn, T* Xc, const E& ext) {
     T xa[NX], xo[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xa[i] = x[i] * pc.sz[i];
@@ -150,7 +166,7 @@ struct MheGen {
       T ue[MU > 0 ? MU : 1];
 #pragma unroll
       for (int i = 0; i < MU; ++i) ue[i] = T(sd[i] * pc.cost[O_SU + i]);
-      Colloc<MA, CD>::step(pc.coll, xa, ue, (const double*)nullptr, pc.dt, xo);
+      Colloc<MA, CD>::step(pc.coll, xa, ue, (const double*)nullptr, pc.dt, xo, Xc);
     } else {
       double ue[MU > 0 ? MU : 1];
 #pragma unroll
@@ -165,6 +181,56 @@ struct MheGen {
     }
 #pragma unroll
     for (int j = 0; j < NP; ++j) xn[MX + j] = x[MX + j];
+  }
+
+  template <class T, class E>
+  __device__ __forceinline__ static void dyn(const OcpConst& pc, const double*, const double* sd, int, const T* x, const T* w,
+                                             T* xn, const E& ext) {
+    map(pc, sd, x, w, xn, (T*)nullptr, ext);
+  }
+
+  // rows of ONE point: xs = SCALED [x | p] of the point, d[m0 + r], r < nrow
+  template <class T>
+  __device__ __forceinline__ static void rows_at(const OcpConst& pc, const T* xs, int m0, int nrow, T* d) {
+    if constexpr (F::NEXPR > 0) {
+      T ce[F::NEXPR];
+      F::con(xs, xs + MX, ce);
+#pragma unroll
+      for (int m = 0; m < (NC > 0 ? NC : 1); ++m) {
+        const int r = m - m0;
+        if (m < NC && r >= 0 && r < nrow) d[m] = pick<F::NEXPR>(ce, (int)pc.cost[O_ROWX + r]);
+      }
+    }
+  }
+  template <class T>
+  __device__ __forceinline__ static void con(const OcpConst& pc, const double*, const double*, int, const T* x, const T*, const T*,
+                                             T* d) {
+    rows_at(pc, x, 0, pc.nc, d);
+  }
+  template <class T, class E>
+  __device__ __forceinline__ static T dyn_cost(const OcpConst& pc, const double* par, const double* sd, int k, const T* x,
+                                               const T* w, T* xn, const E& ext) {
+    map(pc, sd, x, w, xn, (T*)nullptr, ext);
+    return stage_cost(pc, par, sd, k, x, w);
+  }
+  template <class T, class E>
+  __device__ __forceinline__ static T dyn_cost_con(const OcpConst& pc, const double* par, const double* sd, int k, const T* x,
+                                                   const T* w, T* xn, T* dv, const E& ext) {
+    constexpr int DD = CD > 0 ? CD : 1;
+    T Xc[DD * NX];
+    map(pc, sd, x, w, xn, Xc, ext);
+    const int nrow = (int)pc.cost[O_NROW];
+    rows_at(pc, x, 0, nrow, dv);                                   // the node (mhe.py:749-757)
+    if constexpr (CD > 0) {
+#pragma unroll
+      for (int i = 0; i < CD; ++i) {                               // the collocation points (mhe.py:536-550): scaled like the states
+        T xs[NX];
+#pragma unroll
+        for (int a = 0; a < NX; ++a) xs[a] = Xc[i * NX + a] * (1.0 / pc.sz[a]);
+        rows_at(pc, xs, (i + 1) * nrow, nrow, dv);
+      }
+    }
+    return stage_cost(pc, par, sd, k, x, w);
   }
 
   template <class T>
@@ -231,18 +297,22 @@ struct MheGen {
   __device__ __forceinline__ static T term_cost(const OcpConst&, const double*, const double*, const T*) { return T(0.0); }
 };
 
-// Output pass of the general estimator, one thread per (instance, interval k < N) plus one per instance for the tail: from the
-// engine's result in ENGINE layout - ve = [xa_0..xa_N (MX + NP each) | w], lame = [N][MX + NP] - to the reference's
+// Output pass of the general estimator, one thread per (instance, interval k < N): from the engine's result in ENGINE layout -
+// ve = [xa_0..xa_N (MX + NP each) | w], lame = per interval [MX + NP defect multipliers | nc row multipliers (node rows, then the
+// collocation points')] - to the reference's
 //   v     = [p (the stage-0 copy, scaled) | x_0..x_N | w (NOISE) | ip_0..ip_{N-1} (collocation)]            mhe.py:614-671
-//   lam_g = per interval [collocation rows (D MX) | continuity (MX)]                                          mhe.py:728, :740
+//   lam_g = per interval [rows at the collocation points (D R) | collocation rows (D MX) | continuity (MX) | rows at the node (R)]
+//                                                                                                          mhe.py:536-553, :728-757
 // and x_opt = x_N un-scaled (mhe.py:381-384).  The collocation states and the multipliers of their rows are rebuilt with the model's
-// own MX x MX blocks at the ESTIMATED parameter values (the parameter rows of the augmented system decouple, hilo_colloc.h).
-template <class M, int D, bool NOISE>
+// own MX x MX blocks at the ESTIMATED parameter values (the parameter rows of the augmented system decouple, hilo_colloc.h); a row
+// at a collocation point enters the stationarity of that collocation state: G_X^T mu = D_i lambda - sum_r nu_{i,r} grad c_r(X_i).
+template <class M, int D, bool NOISE, class F = NoMheFun, int NC_ = 0>
 __device__ __forceinline__ void mhe_gen_output(const OcpConst* __restrict__ pcg, int64_t batch, const double* __restrict__ ve,
                                                const double* __restrict__ lame, const double* __restrict__ sdata, int64_t sd_stride,
                                                double* __restrict__ v, double* __restrict__ lam_g, double* __restrict__ x_opt) {
-  using PB = MheGen<M, D, NOISE>;
+  using PB = MheGen<M, D, NOISE, F, NC_>;
   constexpr int MX = M::NX, MU = M::NU, NP = M::NP, NXA = MX + NP, DD = D > 0 ? D : 1, DN = DD * MX, NSD = PB::NSD;
+  constexpr int NEX = F::NEXPR > 0 ? F::NEXPR : 1;
   const int N = pcg->N;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= batch * N) return;
@@ -250,6 +320,8 @@ __device__ __forceinline__ void mhe_gen_output(const OcpConst* __restrict__ pcg,
   const int k = (int)(e - b * N);
   const int nve = (N + 1) * NXA + (NOISE ? N * MX : 0), nw = NOISE ? N * MX : 0;
   const int nv = NP + (N + 1) * MX + nw + (D > 0 ? N * DN : 0);
+  const int ncc = NC_ > 0 ? pcg->nc : 0;                                     // the engine's rows per interval
+  const int nrow = NC_ > 0 ? (int)pcg->cost[PB::O_NROW] : 0, R = NC_ > 0 ? (int)pcg->cost[PB::O_NCR] : 0;
   const double* row = ve + b * nve;
   double* out = v + b * nv;
   // head: p, x_k (and x_N by the last interval's thread), w_k
@@ -266,11 +338,13 @@ __device__ __forceinline__ void mhe_gen_output(const OcpConst* __restrict__ pcg,
     }
     if constexpr (NOISE) out[NP + (N + 1) * MX + k * MX + i] = row[(N + 1) * NXA + k * MX + i];
   }
-  const int rows = (D > 0 ? DN : 0) + MX;
+  const int DR = D > 0 ? DD * R : 0, DC = D > 0 ? DN : 0;
+  const int rows = DR + DC + MX + R;
   double* lg = lam_g ? lam_g + b * (int64_t)(N * rows) + (int64_t)k * rows : nullptr;
-  const double* lr = lame ? lame + b * (int64_t)(N * NXA) + (int64_t)k * NXA : nullptr;
+  const double* lr = lame ? lame + b * (int64_t)(N * (NXA + ncc)) + (int64_t)k * (NXA + ncc) : nullptr;
+  const double* nu = lr ? lr + NXA : nullptr;
   if constexpr (D > 0) {
-    double x[MX], u[MU > 0 ? MU : 1], p[NP > 0 ? NP : 1], X[DN], mat[DN * DN], lam[MX], mu[DN];
+    double x[MX], u[MU > 0 ? MU : 1], p[NP > 0 ? NP : 1], X[DN], mat[DN * DN];
 #pragma unroll
     for (int i = 0; i < MX; ++i) x[i] = row[k * NXA + i] * pcg->sz[i];
 #pragma unroll
@@ -283,18 +357,59 @@ __device__ __forceinline__ void mhe_gen_output(const OcpConst* __restrict__ pcg,
 #pragma unroll
       for (int m = 0; m < MX; ++m) out[NP + (N + 1) * MX + nw + k * DN + i * MX + m] = X[i * MX + m] / pcg->sz[m];
     if (lg) {
+      double y[DN], F_[DN];
 #pragma unroll
-      for (int m = 0; m < MX; ++m) lam[m] = lr[m] / pcg->sz[m];
-      Colloc<M, DD>::multipliers(pcg->coll, X, u, p, pcg->dt, lam, mu);
+      for (int i = 0; i < DD; ++i) {
+#pragma unroll
+        for (int m = 0; m < MX; ++m) y[i * MX + m] = pcg->coll.Dc[i + 1] * lr[m] / pcg->sz[m];
+        if constexpr (NC_ > 0) {
+          // - sum_r nu_{i,r} grad c_r at the collocation state: the expression acts on the SCALED variables; with the rows of the
+          // scaled model G_s = G / s the right-hand side in un-scaled units is (D_i lambda - sum nu dc/dx_s) / s
+          Dual<MX> xs[NXA], ce[NEX];
+#pragma unroll
+          for (int a = 0; a < MX; ++a) {
+            xs[a] = Dual<MX>(X[i * MX + a] / pcg->sz[a]);
+            xs[a].d[a] = 1.0;
+          }
+#pragma unroll
+          for (int j = 0; j < NP; ++j) xs[MX + j] = Dual<MX>(row[MX + j]);
+          F::con(xs, xs + MX, ce);
+          for (int r = 0; r < nrow; ++r) {
+            const double w8 = nu[(i + 1) * nrow + r];
+            const Dual<MX> c = pick<NEX>(ce, (int)pcg->cost[PB::O_ROWX + r]);
+#pragma unroll
+            for (int a = 0; a < MX; ++a) y[i * MX + a] -= w8 * c.d[a] / pcg->sz[a];
+          }
+        }
+      }
+      Colloc<M, DD>::newton_matrix(pcg->coll, X, u, p, pcg->dt, mat, F_);
+      Colloc<M, DD>::lu(mat);
+      Colloc<M, DD>::lu_solve_t(mat, y);
 #pragma unroll
       for (int i = 0; i < DD; ++i)
 #pragma unroll
-        for (int m = 0; m < MX; ++m) lg[i * MX + m] = mu[i * MX + m] * pcg->sz[m];
+        for (int a = 0; a < MX; ++a) {
+          double s = 0.0;
+#pragma unroll
+          for (int j = 0; j < DD; ++j) s -= pcg->coll.A[j * DD + i] * y[j * MX + a];
+          lg[DR + i * MX + a] = s * pcg->sz[a];
+        }
     }
   }
   if (lg) {
 #pragma unroll
-    for (int m = 0; m < MX; ++m) lg[(D > 0 ? DN : 0) + m] = lr[m];
+    for (int m = 0; m < MX; ++m) lg[DR + DC + m] = lr[m];
+    if constexpr (NC_ > 0) {
+      for (int q = 0; q < DR; ++q) lg[q] = 0.0;
+      for (int q = 0; q < R; ++q) lg[DR + DC + MX + q] = 0.0;
+      for (int r = 0; r < nrow; ++r) {
+        const int ref = (int)pcg->cost[PB::O_RREF + r];
+        lg[DR + DC + MX + ref] = nu[r];
+        if constexpr (D > 0) {
+          for (int i = 0; i < DD; ++i) lg[i * R + ref] = nu[(i + 1) * nrow + r];
+        }
+      }
+    }
   }
 }
 

@@ -103,6 +103,8 @@ class MovingHorizonEstimator:
         self._n_x, self._n_u, self._n_p, self._n_y = model.n_x, model.n_u, model.n_p, model.n_y
         self.quad_arrival_cost = _ArrivalCost(model)
         self.quad_stage_cost = _StageCost(model)
+        from .nmpc import GenericConstraint
+        self.stage_constraint = GenericConstraint(model, name='stage_constraint')        # mhe.py:142
         self._horizon = None
         self._x_lb = self._x_ub = self._w_lb = self._w_ub = self._p_lb = self._p_ub = None
         self._x_guess = self._w_guess = None
@@ -208,6 +210,17 @@ class MovingHorizonEstimator:
         # ... and every estimator WITHOUT state noise (mhe.py:599, :726-736: the collocation and discrete branches run without the
         # noise block; what tests/test_MHE.py:20-110 configure): the general policy csrc/hilo_mhe_policy.h::MheGen
         jit = bool(getattr(m, '_symbolic', False)) or coll is not None or not noise
+        sc = self.stage_constraint
+        if sc.is_set:
+            # mhe.py:498-508, :536-553, :749-757: rows at every node and collocation point.  QUIRKS: the estimator never calls the
+            # constraint's `_check_and_setup` - the expression sees the NLP's SCALED variables, and the soft branch's penalty function
+            # does not exist (`self.stage_constraint.cost(e)` would call None): soft constraints cannot run in the reference
+            if sc.is_soft:
+                raise NotImplementedError("a soft stage constraint cannot run in the reference's estimator (its penalty function is only "
+                                          "created by the controller's setup, modeling.py:839-878 is never called from mhe.py)")
+            if not getattr(m, '_symbolic', False):
+                raise NotImplementedError("the estimator's stage constraint needs a model written as expressions")
+            jit = True
         if jit and not m.n_y:
             raise RuntimeError("The model has no measurement equations (set_measurement_equations)")
         keep = []
@@ -223,6 +236,15 @@ class MovingHorizonEstimator:
         d.model_id, d.N = m.model_id, self._horizon
         if jit:
             self._user_source = m.user_source()
+            if sc.is_set:
+                from . import codegen
+                nc = sc.size
+                lbv = [-np.inf] * nc if sc.lb is None else list(sc.lb)
+                ubv = [np.inf] * nc if sc.ub is None else list(sc.ub)
+                if len(lbv) != nc or len(ubv) != nc:
+                    raise ValueError("The dimensions of the stage constraint function and its bounds are not compatible.")
+                self._user_source += codegen.mhe_fun_source(sc.constraint)
+                d.n_con, d.con_lb, d.con_ub = nc, hp(lbv), hp(ubv)
             d.user_source = self._user_source.encode()
             d.user_nx, d.user_nu, d.user_np, d.user_ny = m.n_x, m.n_u, m.n_p, m.n_y
             d.user_discrete = 1 if getattr(m, '_native_discrete', False) else 0
@@ -262,7 +284,9 @@ class MovingHorizonEstimator:
         N, nx, np_ = self._horizon, self._n_x, self._n_p
         dn = coll['d'] * nx if coll is not None else 0
         nw = N * nx if noise else 0                                # mhe.py:599: the noise block exists only with state noise
-        self._n_v, self._n_g = np_ + (N + 1) * nx + nw + N * dn, N * (nx + dn)
+        ncon = sc.size if sc.is_set else 0
+        self._n_v = np_ + (N + 1) * nx + nw + N * dn
+        self._n_g = N * (nx + dn + ((coll['d'] if coll is not None else 0) + 1) * ncon)         # mhe.py:536-553, :728, :740, :749-757
         # bit-exact index maps of mhe.py:614-655
         self._p_ind = [list(range(np_))] if np_ else []
         self._x_ind = [list(range(np_ + k * nx, np_ + (k + 1) * nx)) for k in range(N + 1)]

@@ -466,6 +466,12 @@ typedef struct hilo_mhe_desc {
   int32_t user_nx, user_nu, user_np, user_ny, user_discrete, collocation_degree;
   const double* coll_A;      /* [d][d]  Runge-Kutta matrix of the collocation method (hilo_nmpc_desc.coll_A) */
   const double* coll_D;      /* [d + 1] continuity weights */
+  /* ---- stage constraint of the estimator (`mhe.stage_constraint`, mhe.py:498-508, :536-553, :749-757): n_con expressions of the
+     SCALED states and parameters, compiled into `UserFun::con(x, p, c)` behind UserModel in user_source; hard rows
+     con_lb <= c <= con_ub at every node k < N and, under collocation, at every collocation point.  (The reference's soft branch
+     cannot run in its estimator: the penalty function is never created.) ---- */
+  int32_t n_con; int32_t reserved6;
+  const double* con_lb; const double* con_ub;   /* [n_con]; -inf / +inf allowed on one side */
 } hilo_mhe_desc;
 
 int hilo_mhe_create(const hilo_mhe_desc* desc, int device, hilo_mhe** out);          /* = setup(), mhe.py:418 */

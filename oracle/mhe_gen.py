@@ -14,6 +14,10 @@ Restated from hilo_mpc/modules/estimator/mhe.py:596-790 (`_setup`):
       (h(x_k) - y_k)' Wy (.) [+ w_k' Ww w_k] (:746-748) - no stage term at k = 0, none at x_N
   the parameters are ONE vector of variables with bounds p_lb / p_ub (:614-623); p_lb = p_ub pins one (IPOPT removes it)
   costs act on un-scaled quantities, the noise is added to the scaled state (oracle/mhe.py restates both).
+  stage constraint (`mhe.stage_constraint`, :498-508): HARD rows lb <= c(x, p) <= ub at every collocation point (:536-553, in front of
+      the collocation equations) and at every node k < N (:749-757, behind the continuity rows).  QUIRKS restated: the estimator never
+      calls the constraint's `_check_and_setup` - the expression is evaluated on the SCALED variables - and the soft branch cannot run
+      (its penalty function is never created).  Rows the IPOPT way: a slack per row with (relaxed) bounds.
 Without state noise the trajectory is a function of (x_0, p) alone - mhe.py:717-728 raises for 'multiple_shooting' only; the
 collocation and discrete branches run (what tests/test_MHE.py:20-110 configure).
 """
@@ -35,7 +39,7 @@ class MheGenProblem:
 
     def __init__(self, model, dt, N, degree=3, points='radau', order=4, noise=True, est=(), Wx=None, Wp=None, Wy=None, Ww=None,
                  x_lb=None, x_ub=None, w_lb=None, w_ub=None, p_lb=None, p_ub=None, x_scaling=None, w_scaling=None, u_scaling=None,
-                 p_scaling=None, x_guess=None, w_guess=None, p_guess=None):
+                 p_scaling=None, x_guess=None, w_guess=None, p_guess=None, constraint=None):
         self.model, self.dt, self.N, self.d, self.noise = model, float(dt), int(N), int(degree), bool(noise)
         m = model
         nx, nu, ny, npar = m.nx, m.nu, m.ny, m.np_
@@ -84,7 +88,28 @@ class MheGenProblem:
             for j, i in enumerate(self.fixed):
                 sub[m.p[i]] = pf[j]
             return sub
+        # constraint = dict(expr=[sympy expressions / strings of the model's state and parameter symbols], lb=[...], ub=[...])
+        self.rows = []                                               # (expression index, lb, ub)
+        cexpr = []
+        if constraint:
+            names = {str(q): q for q in m.x + m.p}
+            cexpr = [sp.sympify(e, locals=names) if isinstance(e, str) else sp.sympify(e) for e in constraint['expr']]
+            lbc = np.broadcast_to(np.asarray(constraint.get('lb', -INF), dtype=float), (len(cexpr),))
+            ubc = np.broadcast_to(np.asarray(constraint.get('ub', INF), dtype=float), (len(cexpr),))
+            self.rows = [(j, lbc[j], ubc[j]) for j in range(len(cexpr)) if np.isfinite(lbc[j]) or np.isfinite(ubc[j])]
+        self.ncon, self.nrow = len(cexpr), len(self.rows)
+        ss = [sp.Symbol(f's{r}') for r in range((d + 1) * self.nrow)]
+
+        def con_rows(xs, sl):
+            sub = {m.x[a]: xs[a] for a in range(nx)}                                     # SCALED variables (no _check_and_setup)
+            for j, i in enumerate(self.est):
+                sub[m.p[i]] = pe[j]
+            for j, i in enumerate(self.fixed):
+                sub[m.p[i]] = pf[j]
+            return [cexpr[j].subs(sub, simultaneous=True) - sl[r] for r, (j, _, _) in enumerate(self.rows)]
         R = []
+        for i in range(d):
+            R += con_rows(Xc[i], ss[i * self.nrow:(i + 1) * self.nrow])
         if d:
             pts = [xk] + Xc
             for i in range(1, d + 1):
@@ -97,6 +122,7 @@ class MheGenProblem:
             xend = [rhs[a].subs(sub, simultaneous=True) / self.sx[a] for a in range(nx)]
         for a in range(nx):
             R.append(xn[a] - (xend[a] + (wk[a] if self.noise else 0)))
+        R += con_rows(xk, ss[d * self.nrow:])
         self.mk = len(R)
         # cost of the interval: arrival at k = 0, stage term at k >= 1 (both on x_k)
         dx = sp.Matrix([self.sx[a] * xk[a] - xa[a] for a in range(nx)])
@@ -110,7 +136,7 @@ class MheGenProblem:
         if self.noise:
             ws = sp.Matrix([self.sw[a] * wk[a] for a in range(nx)])
             cost += inner * (ws.T * sp.Matrix(self.Ww) * ws)[0, 0]
-        q = pe + xk + wk + [s for row in Xc for s in row] + xn
+        q = pe + xk + wk + [s for row in Xc for s in row] + ss + xn
         self.nq = len(q)
         lam = [sp.Symbol(f'l{i}') for i in range(self.mk)]
         args = [q, um, ym, pf, xa, pa, [first, inner], lam]
@@ -131,7 +157,7 @@ class MheGenProblem:
         off += N * nx if self.noise else 0
         self.ip_ind = [list(range(off + k * d * nx, off + (k + 1) * d * nx)) for k in range(N)] if d else []
         self.n_v = off + N * d * nx
-        self.n_g = N * (d * nx + nx)
+        self.n_g = N * (d * nx + nx + (d + 1) * self.ncon)
 
 
 class MheGenIpm(DenseIpm):
@@ -144,10 +170,13 @@ class MheGenIpm(DenseIpm):
         self.o_x = ne
         self.o_w = self.o_x + (N + 1) * nx
         self.o_c = self.o_w + (N * nx if pb.noise else 0)
-        self.nw = self.o_c + N * d * nx
+        self.o_s = self.o_c + N * d * nx
+        self.ns = (d + 1) * pb.nrow
+        self.nw = self.o_s + N * self.ns
         self.m = N * pb.mk
-        lb = np.concatenate([pb.p_lb, np.tile(pb.x_lb, N + 1), np.tile(pb.w_lb, N if pb.noise else 0), np.tile(pb.x_lb, N * d)])
-        ub = np.concatenate([pb.p_ub, np.tile(pb.x_ub, N + 1), np.tile(pb.w_ub, N if pb.noise else 0), np.tile(pb.x_ub, N * d)])
+        slb, sub = np.array([r[1] for r in pb.rows] * (d + 1)), np.array([r[2] for r in pb.rows] * (d + 1))
+        lb = np.concatenate([pb.p_lb, np.tile(pb.x_lb, N + 1), np.tile(pb.w_lb, N if pb.noise else 0), np.tile(pb.x_lb, N * d), np.tile(slb, N)])
+        ub = np.concatenate([pb.p_ub, np.tile(pb.x_ub, N + 1), np.tile(pb.w_ub, N if pb.noise else 0), np.tile(pb.x_ub, N * d), np.tile(sub, N)])
         r = o.bound_relax_factor
         self.lb = np.where(np.isfinite(lb), lb - r * np.maximum(1, np.abs(lb)), lb)
         self.ub = np.where(np.isfinite(ub), ub + r * np.maximum(1, np.abs(ub)), ub)
@@ -160,6 +189,7 @@ class MheGenIpm(DenseIpm):
         if pb.noise:
             c += [self.o_w + k * nx + i for i in range(nx)]
         c += list(range(self.o_c + k * d * nx, self.o_c + (k + 1) * d * nx))
+        c += list(range(self.o_s + k * self.ns, self.o_s + (k + 1) * self.ns))
         return c + [self.o_x + (k + 1) * nx + i for i in range(nx)]
 
     def _args(self, w, data, k, lam):
@@ -202,17 +232,32 @@ class MheGenIpm(DenseIpm):
             g[:, cols] += pb._gcost(*a)
         return f, g, c.reshape(B, -1), J, W
 
-    def solve(self, x_arrival, p_arrival, p_fixed, u_meas, y_meas, w0=None, verbose=False):
-        """x_arrival [B,nx], p_arrival [B,ne], p_fixed [B,np-ne] (original units), u_meas [B,N,nu], y_meas [B,N,ny]."""
+    def data(self, x_arrival, p_arrival, p_fixed, u_meas, y_meas):
         pb = self.pb
         xa = np.atleast_2d(np.asarray(x_arrival, dtype=float))
         B = xa.shape[0]
         bc = lambda v, n: np.broadcast_to(np.atleast_2d(np.asarray(v, dtype=float)), (B, n)) if n else np.zeros((B, 0))   # noqa: E731
-        data = {'x_arrival': xa, 'p_arrival': bc(p_arrival, pb.ne), 'p_fixed': bc(p_fixed, len(pb.fixed)),
+        return {'x_arrival': xa, 'p_arrival': bc(p_arrival, pb.ne), 'p_fixed': bc(p_fixed, len(pb.fixed)),
                 'u_meas': np.asarray(u_meas, dtype=float).reshape(B, pb.N, pb.nu), 'y_meas': np.asarray(y_meas, dtype=float).reshape(B, pb.N, pb.ny)}
+
+    def solve(self, x_arrival, p_arrival, p_fixed, u_meas, y_meas, w0=None, verbose=False):
+        """x_arrival [B,nx], p_arrival [B,ne], p_fixed [B,np-ne] (original units), u_meas [B,N,nu], y_meas [B,N,ny]."""
+        pb = self.pb
+        data = self.data(x_arrival, p_arrival, p_fixed, u_meas, y_meas)
+        B = data['x_arrival'].shape[0]
         if w0 is None:
             w0 = np.concatenate([pb.p_guess, np.tile(pb.x_guess, pb.N + 1), np.tile(pb.w_guess, pb.N if pb.noise else 0),
                                  np.tile(pb.x_guess, pb.N * pb.d)])
+        w0 = np.broadcast_to(np.atleast_2d(w0)[:, :self.o_s], (B, self.o_s))
+        if self.ns:
+            # IPOPT: the row slacks start at their rows' values (of the start point pushed into the interior), pushed inside their bounds
+            from .nmpc import _push_interior
+            w0 = _push_interior(w0, self.lb[:self.o_s], self.ub[:self.o_s], self.o)
+            _, c0 = self.eval_fc(np.concatenate([w0, np.zeros((B, pb.N * self.ns))], axis=1), data)
+            c0 = c0.reshape(B, pb.N, pb.mk)
+            dn = pb.d * pb.nrow
+            s0 = np.concatenate([c0[:, :, :dn], c0[:, :, pb.mk - pb.nrow:]], axis=2)
+            w0 = np.concatenate([w0, s0.reshape(B, -1)], axis=1)
         res = self.solve_data(data, w0, verbose)
         w = res['w']
         N, nx, d = pb.N, pb.nx, pb.d
@@ -222,11 +267,27 @@ class MheGenIpm(DenseIpm):
         pall = np.zeros((B, pb.np_))
         pall[:, pb.est] = P
         pall[:, pb.fixed] = data['p_fixed']
-        res.update(P=P, p_opt=P * pb.sp, X=X, Wn=Wn, x_opt=X[:, -1] * pb.sx, Xc=w[:, self.o_c:].reshape(B, N, d, nx),
-                   v=np.concatenate([pall, w[:, pb.ne:]], axis=1))
+        res.update(P=P, p_opt=P * pb.sp, X=X, Wn=Wn, x_opt=X[:, -1] * pb.sx, Xc=w[:, self.o_c:self.o_s].reshape(B, N, d, nx),
+                   v=np.concatenate([pall, w[:, pb.ne:self.o_s]], axis=1))
         return res
+
+    def lam_g(self, res):
+        """Multipliers in the reference's row order: per interval [rows at the collocation points (d x n_con) | collocation rows |
+        continuity | rows at the node (n_con)]; rows without a finite bound: 0."""
+        pb = self.pb
+        B = res['lam'].shape[0]
+        d, nrow, nc, nx = pb.d, pb.nrow, pb.ncon, pb.nx
+        lam = res['lam'].reshape(B, pb.N, pb.mk)
+        out = np.zeros((B, pb.N, d * nc + d * nx + nx + nc))
+        for i in range(d):
+            for r, (j, _, _) in enumerate(pb.rows):
+                out[:, :, i * nc + j] = lam[:, :, i * nrow + r]
+        out[:, :, d * nc:d * nc + d * nx + nx] = lam[:, :, d * nrow:d * nrow + d * nx + nx]
+        for r, (j, _, _) in enumerate(pb.rows):
+            out[:, :, d * nc + d * nx + nx + j] = lam[:, :, d * nrow + d * nx + nx + r]
+        return out.reshape(B, -1)
 
     def w_from_v(self, v):
         pb = self.pb
         v = np.atleast_2d(v)
-        return np.concatenate([v[:, pb.est], v[:, pb.np_:]], axis=1)
+        return np.concatenate([v[:, pb.est], v[:, pb.np_:]], axis=1)         # (the row slacks always restart at their rows' values)

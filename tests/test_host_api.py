@@ -217,9 +217,11 @@ def test_algebraic_state_declarations():
     n = NMPC(m.setup(dt=.1))
     n.set_initial_guess(x_guess=[0, 0, 0, 0], u_guess=0., z_guess=1.4)
     assert n._z_guess == [1.4]
-    with pytest.raises(NotImplementedError, match="finite bounds on algebraic states"):
-        n.set_box_constraints(z_lb=[-1.], z_ub=[2.])
-    n.set_box_constraints(z_lb=[-np.inf], z_ub=[np.inf])               # the reference's defaults: accepted
+    n.set_box_constraints(z_lb=[-1.], z_ub=[2.])                       # finite bounds: rows on z at the collocation points (tests/test_dae_gpu.py)
+    assert n._z_lb == [-1.] and n._z_ub == [2.]
+    with pytest.raises(TypeError):
+        n.set_box_constraints(z_lb=[-1., 0.])
+    n.set_box_constraints(z_lb=[-np.inf], z_ub=[np.inf])               # the reference's defaults
 
 
 def test_simple_control_loop_sequence_with_a_stub_controller():

@@ -51,12 +51,12 @@ def _oracle(spec, degree, noise, est_idx=(), **kw):
     return pb, MheGenIpm(pb, IpmOptions(tol=TOL))
 
 
-def _compare(mhe, pb, ref, x_opt, p_opt, B):
+def _compare(mhe, pb, ref, x_opt, p_opt, B, vtol=1e-6):
     assert (mhe._n_v, mhe._n_g) == (pb.n_v, pb.n_g)
     assert mhe._x_ind == pb.x_ind and mhe._w_ind == pb.w_ind and mhe._ip_ind == pb.ip_ind and mhe._p_ind == pb.p_ind
     assert np.array_equal(mhe.solver_status_code, ref['status']) and np.all(ref['status'] == 1)
     v, vr = mhe._nlp_solution['x'].cpu().numpy(), ref['v']
-    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 1e-6
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < vtol
     np.testing.assert_allclose(mhe._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(x_opt.cpu().numpy(), ref['x_opt'], rtol=1e-6, atol=1e-8)
     lam, lr = mhe._nlp_solution['lam_g'].cpu().numpy(), ref['lam']
@@ -157,3 +157,68 @@ def test_reference_test_2_configuration_runs():
     # (not exact although the data are: the 'smoothing' update hands x_2 of the previous window to a window that starts one sample
     # later, mhe.py:254-256, and the arrival cost pulls x_0 - and with it k1 - towards that)
     assert abs(float(p_est[0, 0]) - 1.) < 5e-2 and abs(float(x_est[0, 0]) - X) < 5e-2
+
+
+@pytest.mark.parametrize('method,noise', [('collocation', True), ('collocation', False), ('discrete', True), ('discrete', False)])
+def test_hard_stage_constraint_vs_oracle(method, noise):
+    """`mhe.stage_constraint` (mhe.py:498-508; the reference's own use: tests/test_MHE.py:605-660, a band on a concentration under
+    collocation with state noise): hard rows at every collocation point (:536-553) and at every node k < N (:749-757), on the NLP's
+    SCALED variables.  Two expressions, one of them nonlinear; the upper bound on the biomass is 97 % of the unconstrained
+    estimate's maximum, so rows are active; the multipliers come back in the reference's row order."""
+    N, B = 5, 4
+    spec = dict(C3B, N=N)
+    xa, um, ym, _ = c3_data(B, N=N)
+    degree = 3 if method == 'collocation' else 0
+    _, free = _oracle(spec, degree, noise)
+    x_free = free.solve(xa, [], P_TRUE, um, ym)['X']
+    ub = float(np.round(x_free[:, :N, 0].max(axis=1).min() * .97, 4))                    # active in every instance, at a node k < N
+    cons = dict(expr=['X', 'P + 2*I*X'], lb=[-np.inf, 0.], ub=[ub, np.inf])
+    pb, ipm = _oracle(spec, degree, noise, constraint=cons)
+    ref = ipm.solve(xa, [], P_TRUE, um, ym)
+    ref['lam'] = ipm.lam_g(ref)
+    top = ref['X'][:, :N, 0].max(axis=1) if not degree else np.maximum(ref['X'][:, :N, 0].max(axis=1), ref['Xc'][..., 0].max(axis=(1, 2)))
+    assert np.all(top > ub - 1e-7) and np.all(top < ub + 1e-7) and np.all(ref['f'] > free.solve(xa, [], P_TRUE, um, ym)['f'] * 1.1)
+    from hilo_mpc_amd import MHE
+    m = symbolic_model('chemostat4')
+    if method == 'discrete':
+        m = m.discretize('erk', order=4)
+    m = m.setup(dt=spec['dt'])
+    mhe = MHE(m)
+    mhe.quad_arrival_cost.add_states(weights=list(spec['Wx']), guess=spec['x_guess'])
+    mhe.quad_stage_cost.add_measurements(weights=list(spec['Wy']))
+    if noise:
+        mhe.quad_stage_cost.add_state_noise(weights=list(spec['Ww']))
+    mhe.horizon = N
+    mhe.set_box_constraints(x_lb=spec.get('x_lb'), x_ub=spec.get('x_ub'), w_lb=spec.get('w_lb') if noise else None,
+                            w_ub=spec.get('w_ub') if noise else None, p_lb=P_TRUE, p_ub=P_TRUE)
+    mhe.set_initial_guess(x_guess=spec['x_guess'])
+    x = m.x
+    mhe.stage_constraint.constraint = [x[0], x[2] + 2 * x[3] * x[0]]
+    mhe.stage_constraint.lb = [-np.inf, 0.]
+    mhe.stage_constraint.ub = [ub, np.inf]
+    mhe.setup(options={'integration_method': method}, nlp_opts={'ipopt.tol': TOL})
+    for k in range(N):
+        mhe.add_measurements(ym[:, k], um[:, k])
+    x_opt, p_opt = mhe.estimate(x_arrival=xa)
+    # (collocation with noise: one noise variable sits at its bound 1e-3 with a vanishing multiplier - no strict complementarity,
+    # its distance from the bound goes with sqrt(mu) and differs by 3e-6 between two runs that stop one iteration apart)
+    _compare(mhe, pb, ref, x_opt, p_opt, B, vtol=1e-5 if (degree and noise) else 1e-6)
+    lam = mhe._nlp_solution['lam_g'].cpu().numpy().reshape(B, N, -1)
+    d, nx = degree, 4
+    rows = np.concatenate([lam[:, :, :2 * d], lam[:, :, 2 * d + d * nx + nx:]], axis=2)
+    assert np.abs(rows).max() > 1. and np.abs(rows[:, :, 1::2]).max() < 1e-8             # the active bound carries force; expression 2 never binds
+
+
+def test_soft_stage_constraint_is_refused_like_the_reference_fails():
+    from hilo_mpc_amd import MHE
+    m = symbolic_model('chemostat4').setup(dt=C3B['dt'])
+    mhe = MHE(m)
+    mhe.quad_arrival_cost.add_states(weights=list(C3B['Wx']), guess=C3B['x_guess'])
+    mhe.quad_stage_cost.add_measurements(weights=list(C3B['Wy']))
+    mhe.quad_stage_cost.add_state_noise(weights=list(C3B['Ww']))
+    mhe.horizon = 4
+    mhe.stage_constraint.constraint = [m.x[0]]
+    mhe.stage_constraint.ub = [1.]
+    mhe.stage_constraint.is_soft = True
+    with pytest.raises(NotImplementedError, match='soft'):
+        mhe.setup()
