@@ -537,33 +537,53 @@ def wl_kf(kind, args, torch, dev, rank, world):
     ybase = torch.as_tensor(x[:, [0, 2]], device=dev)
     ynoise = torch.as_tensor(.02 * rng.normal(size=(4, K, B, 2)), device=dev)
     ys = [ybase[None] * (1 + ynoise[q]) for q in range(4)]
-    ev, cnt = [], [0]
+    # A launch here lasts tens of microseconds and creating + recording a pair of HIP events costs the host about as much: one
+    # event pair brackets G consecutive launches (G divides the number of timed steps), the launch duration is elapsed / G -
+    # inter-launch gaps included, so it can only be longer than the kernel's own time (the rocprofv3 summary holds that)
+    G = max(g for g in (1, 2, 3, 4, 5) if args.steps % g == 0)
+    ev, cnt, nt, cur = [], [0], [0], [None]
 
     def step(timed):
         y = ys[cnt[0] % 4]
         cnt[0] += 1
-        e = _events(torch, 1)[0]        # warm-up steps run the identical path (event creation included)
-        e[0].record()
+        first = last = True
+        if timed:
+            first, last = nt[0] % G == 0, nt[0] % G == G - 1
+            nt[0] += 1
+        if first:
+            cur[0] = _events(torch, 1)[0]
+            cur[0][0].record()
         if K > 1:
             f.estimate(y=y, u=u, p=p, steps=K)
         else:
             f.estimate(y=y[0], u=u, p=p)
-        e[1].record()
-        if timed:
-            ev.append(e)
+        if last:
+            cur[0][1].record()
+            if timed:
+                ev.append(cur[0])
 
     def finish():
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        kern_ms = float(np.sum([a.elapsed_time(b) for a, b in ev])) / (len(ev) * G)
         nx, ny, nu, npar = 4, 2, 2, 4
         bytes_step = 8 * (2 * nx * (nx + 1) + 2 * ny + nu + npar)          # SURVEY 8d bytes_kf
         gbs = B * K * bytes_step / (kern_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": pmc_traffic_bytes('C3-' + kind), "traffic_source": pmc_traffic_bytes('C3-' + kind, with_source=True)[1],
-                "kernel": (f"kf_multi_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}>" if K > 1 else
+                # csrc/hilo_kf.hip::use_team: a team of lanes per instance (4 for the EKF's Jacobian columns, 16 for the UKF's 9
+                # sigma points) up to two waves per SIMD of teams, one instance per lane beyond
+                "kernel": (f"kf_team_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}>"
+                           if B * (16 if kind == 'ukf' else 4) <= 2 * 1024 * 64 else
+                           f"kf_multi_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}>" if K > 1 else
                            f"kf_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}, 2>"),
-                "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": B * K * bytes_step, "filter_steps_per_launch": K,
-                "note": "bytes_kf = 8 (2 nx (nx+1) + 2 ny + nu + np) per filter step (SURVEY 8d); at the configuration's B = 4096 "
-                        "one launch moves 1.6 MB and is latency bound; `--batch 1048576` measures the bandwidth-bound regime"}
+                "kernel_ms": kern_ms, "launches_per_event_pair": G, "algorithmic_bytes_per_launch": B * K * bytes_step,
+                "filter_steps_per_launch": K,
+                "compulsory_bytes_per_launch": B * 8 * ((nx * (nx + 1) + 2 * ny) * K + nx * (nx + 1) + nu + npar + nx * nx + ny * ny),
+                "note": "bytes_kf = 8 (2 nx (nx+1) + 2 ny + nu + np) per filter step (SURVEY 8d); with K steps per launch the tile "
+                        "stays on chip between steps, so `achieved` / `frac` are an EQUIVALENT bandwidth (what K separate steps "
+                        "would move), not HBM utilisation - `compulsory_bytes_per_launch` is what one launch must move (tile in "
+                        "once, y in and tile + y_pred out per step, [u; p], Q, R); at the configuration's B = 4096 a launch is "
+                        "bound by the latency of one instance's dependent chain (DESIGN 5.2); `--batch 1048576` measures the "
+                        "bandwidth-bound regime"}
         extra = {"workload": f"C3 {kind.upper()} step chemostat4 nx=4 ny=2 (predict + update fused, {K} sampling instants per "
                              f"launch like the reference's mapaccum(steps)), Q = 1e-4 I, R = 1e-2 I",
                  "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"instances sharded x{world}"}

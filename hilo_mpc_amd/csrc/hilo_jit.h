@@ -53,6 +53,7 @@ struct JitKfKernels {
   hipFunction_t f[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   hipFunction_t pf = nullptr;   // particle-filter function of the same model (hilo_kf_kernel.h::pf_body)
   hipFunction_t multi[2] = {nullptr, nullptr};   // several fused steps per launch (kf_multi_body): [UKF]
+  hipFunction_t team[2] = {nullptr, nullptr};    // the same on a team of lanes per instance (kf_team_body): small batches
   int dims[5] = {0, 0, 0, 0, 0};
 };
 int jit_kf_kernels(const std::string& user_source, int device, JitKfKernels* out, bool compile_only = false);

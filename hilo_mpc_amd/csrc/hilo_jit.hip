@@ -374,6 +374,20 @@ HILO_KF_ENTRY(hilo_user_kf_u2, true, 2)
   }
 HILO_KF_MULTI(hilo_user_kf_em, false)
 HILO_KF_MULTI(hilo_user_kf_um, true)
+#define HILO_KF_TEAM(name, UKF)                                                                                                  \
+  extern "C" __global__ __launch_bounds__(KF_TPB) void name(KfParams kp, int64_t batch, int steps,                              \
+                                                            const double* __restrict__ in_tile, const double* __restrict__ y,   \
+                                                            const double* __restrict__ up, int64_t up_stride, int64_t up_step,  \
+                                                            const double* __restrict__ Q, int64_t q_stride,                     \
+                                                            const double* __restrict__ R, int64_t r_stride,                     \
+                                                            double* __restrict__ out_tile, int64_t out_step,                    \
+                                                            double* __restrict__ y_pred) {                                      \
+    if constexpr (KfTeam<UserModel, UKF>::OK)                                                                                    \
+      kf_team_body<UserModel, UKF>(kp, batch, steps, in_tile, y, up, up_stride, up_step, Q, q_stride, R, r_stride, out_tile,     \
+                                   out_step, y_pred);                                                                            \
+  }
+HILO_KF_TEAM(hilo_user_kf_et, false)
+HILO_KF_TEAM(hilo_user_kf_ut, true)
 extern "C" __global__ __launch_bounds__(PF_TPB) void hilo_user_pf(KfParams kp, int n, const double* __restrict__ X,
                                                                   const double* __restrict__ y, const double* __restrict__ up,
                                                                   int64_t up_stride, const double* __restrict__ w,
@@ -415,6 +429,8 @@ extern "C" __global__ void hilo_user_kf_info(int* o) {
   HILO_HIP_CHECK(hipModuleGetFunction(&k.pf, mod, "hilo_user_pf"));
   HILO_HIP_CHECK(hipModuleGetFunction(&k.multi[0], mod, "hilo_user_kf_em"));
   HILO_HIP_CHECK(hipModuleGetFunction(&k.multi[1], mod, "hilo_user_kf_um"));
+  HILO_HIP_CHECK(hipModuleGetFunction(&k.team[0], mod, "hilo_user_kf_et"));
+  HILO_HIP_CHECK(hipModuleGetFunction(&k.team[1], mod, "hilo_user_kf_ut"));
   hipFunction_t info = nullptr;
   HILO_HIP_CHECK(hipModuleGetFunction(&info, mod, "hilo_user_kf_info"));
   int* dinfo = nullptr;

@@ -36,10 +36,40 @@ int dispatch_kind(int mode, const KfParams& kp, int64_t batch, const double* in,
   return launch<M, false, 2>(kp, batch, in, y, up, us, Q, qs, R, rs, out, yp, s);
 }
 
+// One instance on a team of lanes (csrc/hilo_kf_kernel.h::kf_team_body) while one instance per lane would leave lanes idle: up to
+// two waves per SIMD of teams (256 compute units x 4 SIMDs x 64 lanes x 2).  The EKF of a continuous model integrates the
+// augmented ODE on one lane.  HILO_KF_TEAM=0 (developer / test knob) keeps every batch on the one-lane kernels.
+static int team_lanes(int kind, int nx) {
+  int t = 1;
+  const int need = kind == HILO_KF_UKF ? 2 * nx + 1 : nx;
+  while (t < need) t *= 2;
+  return t;
+}
+static bool use_team(const KfParams& kp, int nx, bool discrete, int64_t batch) {
+  static const int knob = [] { const char* e = getenv("HILO_KF_TEAM"); return e ? atoi(e) : 1; }();
+  const int t = team_lanes(kp.kind, nx);
+  if (!knob || t > KF_TPB) return false;
+  if (kp.kind != HILO_KF_UKF && kp.continuous && !discrete) return false;
+  return batch * t <= 2 * 1024 * (int64_t)KF_TPB;
+}
+
 template <class M>
 int launch_multi(const KfParams& kp, int64_t batch, int steps, const double* in, const double* y, const double* up, int64_t us,
                  int64_t ustep, const double* Q, int64_t qs, const double* R, int64_t rs, double* out, int64_t ostep, double* yp,
                  hipStream_t s) {
+  if (use_team(kp, M::NX, M::DISCRETE, batch)) {
+    if (kp.kind == HILO_KF_UKF) {
+      const unsigned grid = (unsigned)((batch + KfTeam<M, true>::TEAMS - 1) / KfTeam<M, true>::TEAMS);
+      hipLaunchKernelGGL((kf_team_kernel<M, true>), dim3(grid), dim3(KF_TPB), 0, s, kp, batch, steps, in, y, up, us, ustep, Q, qs, R, rs,
+                         out, ostep, yp);
+    } else {
+      const unsigned grid = (unsigned)((batch + KfTeam<M, false>::TEAMS - 1) / KfTeam<M, false>::TEAMS);
+      hipLaunchKernelGGL((kf_team_kernel<M, false>), dim3(grid), dim3(KF_TPB), 0, s, kp, batch, steps, in, y, up, us, ustep, Q, qs, R, rs,
+                         out, ostep, yp);
+    }
+    HILO_HIP_CHECK(hipGetLastError());
+    return HILO_OK;
+  }
   int64_t ipw = (batch + 1023) / 1024;       // same instance split as the single step
   ipw = ipw < 16 ? 16 : (ipw > KF_TPB ? KF_TPB : ipw);
   const unsigned grid = (unsigned)((batch + ipw - 1) / ipw);
@@ -61,6 +91,7 @@ struct hilo_kf {
   hilo_kf_desc desc;
   int device;
   int nx, nu, np, ny;
+  bool discrete;
   KfParams kp;
   hilo::JitKfKernels jit;   // model given as source (HILO_MODEL_USER): kernels compiled at create
 };
@@ -156,6 +187,7 @@ extern "C" int hilo_kf_create(const hilo_kf_desc* desc, int device, hilo_kf** ou
   kf->jit = jit;
   kf->device = device;
   kf->nx = nx; kf->nu = nu; kf->np = np; kf->ny = ny;
+  kf->discrete = disc != 0;
   KfParams& kp = kf->kp;
   kp.kind = desc->kind;
   kp.continuous = desc->continuous;
@@ -174,6 +206,13 @@ extern "C" int hilo_kf_create(const hilo_kf_desc* desc, int device, hilo_kf** ou
 
 extern "C" void hilo_kf_destroy(hilo_kf* kf) { delete kf; }
 
+#ifdef HILO_KF_PROF   // developer builds (tools/dbg/kf_phase.py): the cycle stamps of the team kernels
+extern "C" int hilo_debug_kf_prof(unsigned long long* out) {
+  HILO_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(hilo::hilo_kf_prof), sizeof(unsigned long long) * 16));
+  return HILO_OK;
+}
+#endif
+
 // compile the filter kernels of a model source into the cache without loading them (no GPU needed)
 extern "C" int hilo_jit_precompile_kf(const char* user_source) {
   HILO_REQUIRE(user_source && user_source[0], "hilo_jit_precompile_kf: empty source");
@@ -191,6 +230,10 @@ extern "C" int hilo_kf_dims(const hilo_kf* kf, int* nx, int* nu, int* np, int* n
   return HILO_OK;
 }
 
+extern "C" int hilo_kf_steps(hilo_kf* kf, int64_t batch, int steps, const double* xP, const double* y, const double* up,
+                             int64_t up_stride, int64_t up_step_stride, const double* Q, int64_t q_stride, const double* R,
+                             int64_t r_stride, double* xP_out, int keep_all, double* y_pred, void* stream);
+
 static int kf_run(hilo_kf* kf, int mode, int64_t batch, const double* in, const double* y, const double* up,
                   int64_t us, const double* Q, int64_t qs, const double* R, int64_t rs, double* out, double* yp,
                   void* stream) {
@@ -205,6 +248,8 @@ static int kf_run(hilo_kf* kf, int mode, int64_t batch, const double* in, const 
   HILO_HIP_CHECK(hipSetDevice(kf->device));
   hipStream_t s = (hipStream_t)stream;
   const KfParams& kp = kf->kp;
+  if (mode == 2 && use_team(kp, kf->nx, kf->discrete, batch))   // a fused step of a small batch: one step of the team kernel
+    return hilo_kf_steps(kf, batch, 1, in, y, up, us, 0, Q, qs, R, rs, out, 0, yp, stream);
   if (kf->desc.model_id == 100 /* HILO_MODEL_USER */) {
     hipFunction_t f = kf->jit.f[kp.kind == HILO_KF_UKF ? 1 : 0][mode];
     HILO_REQUIRE(f, "hilo_kf: the run-time compiled filter kernels are not loaded");
@@ -263,6 +308,18 @@ extern "C" int hilo_kf_steps(hilo_kf* kf, int64_t batch, int steps, const double
   if (!up) up = &zero;
   const int64_t ostep = keep_all ? batch * (int64_t)kf->nx * (kf->nx + 1) : 0;
   if (kf->desc.model_id == 100 /* HILO_MODEL_USER */) {
+    if (use_team(kp, kf->nx, kf->discrete, batch)) {
+      hipFunction_t f = kf->jit.team[kp.kind == HILO_KF_UKF ? 1 : 0];
+      HILO_REQUIRE(f, "hilo_kf_steps: the run-time compiled filter kernels are not loaded");
+      const int teams = KF_TPB / team_lanes(kp.kind, kf->nx);
+      const unsigned grid = (unsigned)((batch + teams - 1) / teams);
+      KfParams kpv = kp;
+      int64_t ostep_v = ostep;
+      void* args[] = {&kpv, &batch, &steps, &xP, &y, &up, &up_stride, &up_step_stride, &Q, &q_stride, &R, &r_stride, &xP_out, &ostep_v,
+                      &y_pred};
+      HILO_HIP_CHECK(hipModuleLaunchKernel(f, grid, 1, 1, KF_TPB, 1, 1, 0, s, args, nullptr));
+      return HILO_OK;
+    }
     hipFunction_t f = kf->jit.multi[kp.kind == HILO_KF_UKF ? 1 : 0];
     HILO_REQUIRE(f, "hilo_kf_steps: the run-time compiled filter kernels are not loaded");
     int64_t ipw = (batch + 1023) / 1024;

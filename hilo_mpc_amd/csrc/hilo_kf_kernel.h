@@ -486,6 +486,404 @@ __global__ __launch_bounds__(KF_TPB) KF_OCC void kf_multi_kernel(KfParams kp, in
   kf_multi_body<M, UKF>(kp, batch, steps, in_tile, y, up, up_stride, up_step, Q, q_stride, R, r_stride, out_tile, out_step, y_pred, ipw);
 }
 
+// ---- one filter instance on a TEAM of lanes: small batches (the BASELINE's B = 4096) ------------------------------------------------
+// With one instance per lane a launch lasts as long as ONE lane needs for its ~3 k (EKF) / ~9 k (UKF) dependent fp64 instructions per
+// step, however few instances there are.  Here T lanes share an instance - the EKF's Jacobian columns (one forward-mode direction
+// per lane, T = NX rounded up to a power of two), the UKF's sigma points (one point per lane, T >= 2 NX + 1) - and the matrix algebra
+// is spread entry by entry; [x | P], the Jacobian / the sigma points and the small update matrices are staged in LDS (a team lives
+// inside one wave, a workgroup is one wave: `__syncthreads()` is an LDS wait, not a barrier across waves).  Every lane runs every
+// phase (lanes without work of their own repeat a neighbour's, only the LDS stores are predicated): no lane-dependent branch
+// encloses a loop.  The arithmetic of each entry is that of the one-lane kernels above (same order of accumulation, the UKF's
+// sums without FMA contraction).  The EKF of a CONTINUOUS model (augmented ODE, ekf_deriv) stays on the one-lane kernel.
+#ifndef HILO_KF_DBG
+#define HILO_KF_DBG 0   // developer builds: 1 = skip the model evaluation, 2 = skip the gain, 4 = skip the matrix phases (timing only)
+#endif
+#ifdef HILO_KF_PROF   // developer builds: cycle stamps of the phases of a team step (team 0 of workgroup 0, last stamps win)
+__device__ unsigned long long hilo_kf_prof[16];
+#define KF_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) hilo_kf_prof[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define KF_STAMP(k) do { } while (0)
+#endif
+constexpr int kf_pow2(int n) { int p = 1; while (p < n) p *= 2; return p; }
+
+template <class M, bool UKF>
+struct KfTeam {
+  static constexpr int NX = M::NX, NY = M::NY, NS = 2 * NX + 1;
+  static constexpr int T = kf_pow2(UKF ? NS : NX);
+  static constexpr bool OK = T <= KF_TPB;
+  static constexpr int TEAMS = OK ? KF_TPB / T : 1;
+  static constexpr int NA = UKF ? NX * NS : NX * NX;   // EKF: F = dPhi/dx        UKF: propagated sigma points X
+  static constexpr int NB = UKF ? NY * NS : NX * NX;   // EKF: F P                UKF: measured sigma points Y
+  static constexpr int NH = UKF ? 0 : NY * NX;         // EKF: H = dh/dx
+  static constexpr int O_X = 0, O_P = O_X + NX, O_A = O_P + NX * NX, O_B = O_A + NA, O_H = O_B + NB, O_PXY = O_H + NH,
+                       O_PYY = O_PXY + NX * NY, O_K = O_PYY + NY * NY, O_KS = O_K + NX * NY, O_YP = O_KS + NX * NY,
+                       USED = O_YP + NY, SIZE = USED | 1;   // odd pitch: the teams of a wave start in different banks
+};
+
+// 1/sqrt(x): v_rsq_f64 + two Newton steps (<= 2 ulp) - the Cholesky factor of Pyy below needs the reciprocal of its diagonal only
+__device__ __forceinline__ double rsqrt_fast(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+  r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+  return r;
+}
+
+// row i of K = Pxy Pyy^-1 and of K Pyy, and K[i,:] (y - yp) (kf.py:177-180): gain_update's Cholesky solve for one row, with the
+// reciprocals of the factor's diagonal (two dependent rsq instead of two square roots and six divisions in a row)
+template <int NX, int NY>
+__device__ __forceinline__ void gain_row(const double* Pxy_i, const double* Pyy, const double* y, const double* yp, double* K_i,
+                                         double* KS_i, double* dx) {
+  double L[NY * NY], id[NY], z[NY];
+#pragma unroll
+  for (int j = 0; j < NY; ++j) {
+    double s = Pyy[j * NY + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[j * NY + k] * L[j * NY + k];
+    id[j] = rsqrt_fast(s);
+#pragma unroll
+    for (int i = j + 1; i < NY; ++i) {
+      double t = Pyy[i * NY + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i * NY + k] * L[j * NY + k];
+      L[i * NY + j] = t * id[j];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NY; ++a) {
+    double s = Pxy_i[a];
+#pragma unroll
+    for (int b = 0; b < a; ++b) s -= L[a * NY + b] * z[b];
+    z[a] = s * id[a];
+  }
+#pragma unroll
+  for (int a = NY - 1; a >= 0; --a) {
+    double s = z[a];
+#pragma unroll
+    for (int b = a + 1; b < NY; ++b) s -= L[b * NY + a] * K_i[b];
+    K_i[a] = s * id[a];
+  }
+#pragma unroll
+  for (int a = 0; a < NY; ++a) {
+    double s = 0.0;
+#pragma unroll
+    for (int b = 0; b < NY; ++b) s += K_i[b] * Pyy[b * NY + a];
+    KS_i[a] = s;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int a = 0; a < NY; ++a) s += K_i[a] * (y[a] - yp[a]);
+  *dx = s;
+}
+
+// phases shared by both filters: rows of the gain (lanes i < NX), then P -= (K Pyy) K^T entry by entry
+template <class M, bool UKF>
+__device__ __forceinline__ void team_gain(double* __restrict__ sm, int t, const double* yv) {
+  using D = KfTeam<M, UKF>;
+  constexpr int NX = D::NX, NY = D::NY, T = D::T;
+  {
+    const int i = t < NX ? t : NX - 1;
+    double Pxy_i[NY], Pyy[NY * NY], yp[NY], K_i[NY], KS_i[NY], dx;
+#pragma unroll
+    for (int a = 0; a < NY; ++a) { Pxy_i[a] = sm[D::O_PXY + i * NY + a]; yp[a] = sm[D::O_YP + a]; }
+#pragma unroll
+    for (int a = 0; a < NY * NY; ++a) Pyy[a] = sm[D::O_PYY + a];
+    gain_row<NX, NY>(Pxy_i, Pyy, yv, yp, K_i, KS_i, &dx);
+    const double xi = sm[D::O_X + i] + dx;
+    if (t < NX) {
+      sm[D::O_X + i] = xi;
+#pragma unroll
+      for (int a = 0; a < NY; ++a) { sm[D::O_K + i * NY + a] = K_i[a]; sm[D::O_KS + i * NY + a] = KS_i[a]; }
+    }
+  }
+  __syncthreads();
+  KF_STAMP(4);
+#pragma unroll
+  for (int m = 0; m < (NX * NX + T - 1) / T; ++m) {
+    const int e0 = m * T + t, e = e0 < NX * NX ? e0 : NX * NX - 1, i = e / NX, j = e - i * NX;
+    double s = 0.0;
+#pragma unroll
+    for (int a = 0; a < NY; ++a) s += sm[D::O_KS + i * NY + a] * sm[D::O_K + j * NY + a];
+    const double v = sm[D::O_P + e] - s;
+    if (e0 < NX * NX) sm[D::O_P + e] = v;
+  }
+  __syncthreads();
+}
+
+template <class M>
+__device__ __forceinline__ void team_ekf_step(const KfParams& kp, double* __restrict__ sm, int t, const double* u, const double* p,
+                                              const double* Qe, const double* Re, const double* yv) {
+  using D = KfTeam<M, false>;
+  constexpr int NX = D::NX, NY = D::NY, T = D::T;
+  KF_STAMP(0);
+  {
+    // column `dir` of F = dPhi/dx at the prior state (kf.py:91) and of H = dh/dx at the predicted one (:164)
+    const int dir = t < NX ? t : NX - 1;
+    Dual<1> xd[NX], xn[NX], yd[NY];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      xd[i].v = sm[D::O_X + i];
+      xd[i].d[0] = i == dir ? 1.0 : 0.0;
+    }
+    if constexpr (HILO_KF_DBG & 1) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xn[i] = xd[i];
+    } else {
+      model_step<M>(kp.erk_order, kp.n_sub, xd, u, p, kp.dt, xn);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      xd[i].v = xn[i].v;
+      xd[i].d[0] = i == dir ? 1.0 : 0.0;
+    }
+    M::meas(xd, u, p, kp.dt, yd);
+    if (t < NX) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) sm[D::O_A + i * NX + dir] = xn[i].d[0];
+#pragma unroll
+      for (int a = 0; a < NY; ++a) sm[D::O_H + a * NX + dir] = yd[a].d[0];
+    }
+    if (t == 0) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) sm[D::O_X + i] = xn[i].v;
+#pragma unroll
+      for (int a = 0; a < NY; ++a) sm[D::O_YP + a] = yd[a].v;
+    }
+  }
+  __syncthreads();
+  KF_STAMP(1);
+  if constexpr (HILO_KF_DBG & 4) { if (!(HILO_KF_DBG & 2)) team_gain<M, false>(sm, t, yv); return; }
+  // P- = F P F^T + Q (kf.py:95-96)
+  if constexpr (T % NX == 0) {
+    // every entry of a lane lies in column j = t mod NX: w = P F[j,:]^T once, then P-[i,j] = F[i,:] w - no F P staged in between
+    const int j = t % NX;
+    double w[NX], Pn[(NX * NX + T - 1) / T];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      double a = 0.0;
+#pragma unroll
+      for (int l = 0; l < NX; ++l) a += sm[D::O_P + k * NX + l] * sm[D::O_A + j * NX + l];
+      w[k] = a;
+    }
+#pragma unroll
+    for (int m = 0; m < (NX * NX + T - 1) / T; ++m) {
+      const int e0 = m * T + t, e = e0 < NX * NX ? e0 : NX * NX - 1, i = e / NX;
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) a += sm[D::O_A + i * NX + k] * w[k];
+      Pn[m] = a + Qe[m];
+    }
+#pragma unroll
+    for (int m = 0; m < (NX * NX + T - 1) / T; ++m) {       // (all reads of P are done: same wave, program order)
+      const int e0 = m * T + t;
+      if (e0 < NX * NX) sm[D::O_P + e0] = Pn[m];
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < (NX * NX + T - 1) / T; ++m) {
+      const int e0 = m * T + t, e = e0 < NX * NX ? e0 : NX * NX - 1, i = e / NX, j = e - i * NX;
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) a += sm[D::O_A + i * NX + k] * sm[D::O_P + k * NX + j];
+      if (e0 < NX * NX) sm[D::O_B + e] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < (NX * NX + T - 1) / T; ++m) {
+      const int e0 = m * T + t, e = e0 < NX * NX ? e0 : NX * NX - 1, i = e / NX, j = e - i * NX;
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) a += sm[D::O_B + i * NX + k] * sm[D::O_A + j * NX + k];
+      if (e0 < NX * NX) sm[D::O_P + e] = a + Qe[m];
+    }
+  }
+  __syncthreads();
+  KF_STAMP(2);
+  // Pxy = P- H^T and Pyy = H P- H^T + R (kf.py:171-176) in one phase: an entry of Pyy recomputes its column of P- H^T
+  constexpr int NE2 = NX * NY + NY * NY;
+#pragma unroll
+  for (int m = 0; m < (NE2 + T - 1) / T; ++m) {
+    const int e0 = m * T + t, e = e0 < NE2 ? e0 : NE2 - 1;
+    if (e < NX * NY) {
+      const int i = e / NY, a = e - i * NY;
+      double q = 0.0;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) q += sm[D::O_P + i * NX + k] * sm[D::O_H + a * NX + k];
+      if (e0 < NE2) sm[D::O_PXY + e] = q;
+    } else {
+      const int f = e - NX * NY, a = f / NY, b = f - a * NY;
+      double q = 0.0;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) {
+        double c = 0.0;
+#pragma unroll
+        for (int l = 0; l < NX; ++l) c += sm[D::O_P + k * NX + l] * sm[D::O_H + b * NX + l];
+        q += sm[D::O_H + a * NX + k] * c;
+      }
+      if (e0 < NE2) sm[D::O_PYY + f] = q + Re[m];
+    }
+  }
+  __syncthreads();
+  KF_STAMP(3);
+  if constexpr (!(HILO_KF_DBG & 2)) team_gain<M, false>(sm, t, yv);
+  KF_STAMP(5);
+}
+
+template <class M>
+__device__ __forceinline__ void team_ukf_step(const KfParams& kp, double* __restrict__ sm, int t, const double* u, const double* p,
+                                              const double* Qe, const double* Re, const double* yv) {
+#pragma clang fp contract(off)
+  using D = KfTeam<M, true>;
+  constexpr int NX = D::NX, NY = D::NY, NS = D::NS, T = D::T;
+  KF_STAMP(0);
+  {
+    // sigma point k = lane (kf.py:503, :522-527), propagated (:529-533) and measured (:570-575)
+    const int k = t < NS ? t : NS - 1;
+    double x[NX], P[NX * NX], L[NX * NX], xs[NX], xo[NX], ys[NY];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = sm[D::O_X + i];
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) P[i] = sm[D::O_P + i];
+    chol_lower<NX>(P, L);
+    const int row = k == 0 ? 0 : (k <= NX ? k - 1 : k - 1 - NX);
+    const double sg = k == 0 ? 0.0 : (k <= NX ? kp.gamma : -kp.gamma);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      double li = L[i];
+#pragma unroll
+      for (int r = 1; r < NX; ++r) li = row == r ? L[r * NX + i] : li;
+      // (x + gamma l and x - gamma l: x + (-gamma) l rounds like x - gamma l; the centre point is x itself)
+      xs[i] = k == 0 ? x[i] : x[i] + sg * li;
+    }
+    if (kp.continuous && !M::DISCRETE)
+      model_step<M>(4, kp.n_sub, xs, u, p, kp.dt, xo);
+    else
+      model_step<M>(kp.erk_order, kp.n_sub, xs, u, p, kp.dt, xo);
+    M::meas(xo, u, p, kp.dt, ys);
+    if (t < NS) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) sm[D::O_A + i * NS + k] = xo[i];
+#pragma unroll
+      for (int a = 0; a < NY; ++a) sm[D::O_B + a * NS + k] = ys[a];
+    }
+  }
+  __syncthreads();
+  KF_STAMP(1);
+  // weighted means (kf.py:535-541, :577-583)
+#pragma unroll
+  for (int m = 0; m < (NX + NY + T - 1) / T; ++m) {
+    const int e0 = m * T + t, e = e0 < NX + NY ? e0 : NX + NY - 1;
+    const int base = e < NX ? D::O_A + e * NS : D::O_B + (e - NX) * NS;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s = s + (k == 0 ? kp.wm0 : kp.wi) * sm[base + k];
+    if (e0 < NX + NY) sm[e < NX ? D::O_X + e : D::O_YP + (e - NX)] = s;
+  }
+  __syncthreads();
+  KF_STAMP(2);
+  // P- (:543-548), Pxy and Pyy (:585-596): one list of NX^2 + NX NY + NY^2 entries
+  constexpr int NE = NX * NX + NX * NY + NY * NY;
+#pragma unroll
+  for (int m = 0; m < (NE + T - 1) / T; ++m) {
+    const int e0 = m * T + t, e = e0 < NE ? e0 : NE - 1;
+    int ra, rb, ma, mb, dst;          // rows of the two factors in sm, their means
+    double s;
+    if (e < NX * NX) {
+      const int i = e / NX, j = e - i * NX;
+      ra = D::O_A + i * NS; rb = D::O_A + j * NS; ma = D::O_X + i; mb = D::O_X + j; dst = D::O_P + e; s = Qe[m];
+    } else if (e < NX * NX + NX * NY) {
+      const int f = e - NX * NX, i = f / NY, a = f - i * NY;
+      ra = D::O_A + i * NS; rb = D::O_B + a * NS; ma = D::O_X + i; mb = D::O_YP + a; dst = D::O_PXY + f; s = 0.0;
+    } else {
+      const int f = e - NX * NX - NX * NY, a = f / NY, b = f - a * NY;
+      ra = D::O_B + a * NS; rb = D::O_B + b * NS; ma = D::O_YP + a; mb = D::O_YP + b; dst = D::O_PYY + f; s = Re[m];
+    }
+    const double xa = sm[ma], xb = sm[mb];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s = s + ((k == 0 ? kp.wc0 : kp.wi) * (sm[ra + k] - xa)) * (sm[rb + k] - xb);
+    if (e0 < NE) sm[dst] = s;
+  }
+  __syncthreads();
+  KF_STAMP(3);
+  team_gain<M, true>(sm, t, yv);
+  KF_STAMP(5);
+}
+
+// arguments of kf_multi_kernel without `ipw`: a workgroup (one wave) holds KfTeam::TEAMS instances
+template <class M, bool UKF>
+__device__ __forceinline__ void kf_team_body(const KfParams& kp, int64_t batch, int steps, const double* __restrict__ in_tile,
+                                             const double* __restrict__ y, const double* __restrict__ up, int64_t up_stride,
+                                             int64_t up_step, const double* __restrict__ Q, int64_t q_stride,
+                                             const double* __restrict__ R, int64_t r_stride, double* __restrict__ out_tile,
+                                             int64_t out_step, double* __restrict__ y_pred) {
+  using D = KfTeam<M, UKF>;
+  constexpr int NX = D::NX, NY = D::NY, NUP = M::NU + M::NP, T = D::T, XP = NX * (NX + 1), W = NX + 1;
+  constexpr int NE = UKF ? NX * NX + NX * NY + NY * NY : NX * NX;       // entries with a Q (R) term, per lane: Qe[m] (Re[m])
+  constexpr int NER = UKF ? NE : NX * NY + NY * NY, OFFR = UKF ? NX * NX + NX * NY : NX * NY;   // the list whose tail carries R
+  constexpr int MQ = (NE + T - 1) / T, MR = (NER + T - 1) / T;
+  __shared__ double lds[D::TEAMS * D::SIZE];
+  const int team = threadIdx.x / T, t = threadIdx.x - team * T;
+  const int64_t inst0 = (int64_t)blockIdx.x * D::TEAMS + team;
+  const bool valid = inst0 < batch;
+  const int64_t inst = valid ? inst0 : batch - 1;      // a team past the end repeats the last instance and stores nothing
+  double* sm = lds + team * D::SIZE;
+#pragma unroll
+  for (int m = 0; m < (XP + T - 1) / T; ++m) {
+    const int e0 = m * T + t, e = e0 < XP ? e0 : XP - 1, i = e / W, c = e - i * W;
+    const double v = in_tile[inst * XP + e];
+    if (e0 < XP) sm[c == 0 ? D::O_X + i : D::O_P + i * NX + c - 1] = v;
+  }
+  double upv[MaxOne<NUP>::v], yv[NY], Qe[MQ], Re[MR];
+#pragma unroll
+  for (int m = 0; m < MQ; ++m) {
+    const int e0 = m * T + t, e = e0 < NE ? e0 : NE - 1;
+    Qe[m] = e < NX * NX ? Q[inst * q_stride + e] : 0.0;
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    const int e0 = m * T + t, e = e0 < NER ? e0 : NER - 1, f = e - OFFR;
+    Re[m] = f >= 0 ? R[inst * r_stride + f] : 0.0;
+  }
+  if constexpr (NUP > 0) vec_load<NUP>(up, inst, up_stride, upv);
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    if constexpr (NUP > 0) {
+      if (s > 0 && up_step != 0) vec_load<NUP>(up + (int64_t)s * up_step, inst, up_stride, upv);
+    }
+    const double* u = upv;
+    const double* p = upv + M::NU;
+    vec_load<NY>(y + (int64_t)s * batch * NY, inst, NY, yv);
+    KF_STAMP(8);
+    if constexpr (UKF) team_ukf_step<M>(kp, sm, t, u, p, Qe, Re, yv);
+    else team_ekf_step<M>(kp, sm, t, u, p, Qe, Re, yv);
+    KF_STAMP(9);
+    if (valid && t < NY) y_pred[((int64_t)s * batch + inst) * NY + t] = sm[D::O_YP + t];
+    if constexpr (NY > T) {
+      if (valid && t == 0)
+        for (int a = T; a < NY; ++a) y_pred[((int64_t)s * batch + inst) * NY + a] = sm[D::O_YP + a];
+    }
+    if (out_step != 0 || s == steps - 1) {
+#pragma unroll
+      for (int m = 0; m < (XP + T - 1) / T; ++m) {
+        const int e0 = m * T + t, e = e0 < XP ? e0 : XP - 1, i = e / W, c = e - i * W;
+        const double v = sm[c == 0 ? D::O_X + i : D::O_P + i * NX + c - 1];
+        if (valid && e0 < XP) out_tile[(int64_t)s * out_step + inst * XP + e] = v;
+      }
+    }
+    KF_STAMP(10);
+  }
+}
+
+template <class M, bool UKF>
+__global__ __launch_bounds__(KF_TPB) void kf_team_kernel(KfParams kp, int64_t batch, int steps, const double* __restrict__ in_tile,
+                                                         const double* __restrict__ y, const double* __restrict__ up,
+                                                         int64_t up_stride, int64_t up_step, const double* __restrict__ Q,
+                                                         int64_t q_stride, const double* __restrict__ R, int64_t r_stride,
+                                                         double* __restrict__ out_tile, int64_t out_step,
+                                                         double* __restrict__ y_pred) {
+  if constexpr (KfTeam<M, UKF>::OK)
+    kf_team_body<M, UKF>(kp, batch, steps, in_tile, y, up, up_stride, up_step, Q, q_stride, R, r_stride, out_tile, out_step, y_pred);
+}
+
 // ---- particle filter (hilo_mpc/modules/estimator/pf.py) ----------------------------------------------------------------------
 // The function the reference assembles at setup() (`_propagate_particles` :103-146, `_evaluate_likelihood` :148-166, `setup`
 // :300-318) and calls once per estimate (:372):

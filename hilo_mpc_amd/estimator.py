@@ -255,40 +255,58 @@ class _KalmanFilter:
         nup = self._n_u + self._n_p
         upt, us, ustep = None, 0, 0
         if nup:
+            pt = ut = None
             if self._n_p:
                 pt = self._p if p is None else to_dev(p, dev)
                 if pt is None:
                     raise RuntimeError("No parameter values supplied. Please run set_initial_parameter_values() or pass p=.")
-                pt = (pt.reshape(1, -1) if pt.ndim <= 1 else pt).expand(B, -1)
+                pt = pt.reshape(1, -1) if pt.ndim <= 1 else pt
+            per_step = False
             if self._n_u:
                 if u is None:
                     raise RuntimeError("No input data supplied.")
                 ut = to_dev(u, dev)
                 per_step = ut.numel() == steps * B * self._n_u and steps > 1
-                ut = ut.reshape(steps, B, self._n_u) if per_step else ut.reshape(-1, self._n_u).expand(B, -1)[None]
-            else:
-                per_step, ut = False, None
+            # [u; p] rows (kf.py:130) in a buffer the filter keeps; device tensors handed over again unmodified (same object, same
+            # version counter) are not copied again - the launch is then the only work of the call
             rows = steps if per_step else 1
-            upt = torch.empty(rows, B, nup, dtype=torch.float64, device=dev)
-            if self._n_u:
-                upt[:, :, :self._n_u] = ut
-            if self._n_p:
-                upt[:, :, self._n_u:] = pt[None]
-            us, ustep = nup, (B * nup if per_step else 0)
-        xP = torch.empty(B, self._n_x, self._n_x + 1, dtype=torch.float64, device=dev)
-        xP[:, :, 0] = self._x
-        xP[:, :, 1:] = self._P
+            key = tuple((id(t), t._version, tuple(t.shape)) if isinstance(src, torch.Tensor) and src.device == t.device else None
+                        for src, t in ((u, ut), (p if p is not None else self._p, pt)) if t is not None)
+            buf = getattr(self, '_ups_buf', None)
+            if buf is None or buf.shape[0] != rows or buf.shape[1] != B:
+                buf = self._ups_buf = torch.empty(rows, B, nup, dtype=torch.float64, device=dev)
+                self._ups_key = None
+            if None in key or key != self._ups_key:
+                if self._n_u:
+                    buf[:, :, :self._n_u] = ut.reshape(steps, B, self._n_u) if per_step else ut.reshape(-1, self._n_u).expand(B, -1)[None]
+                if self._n_p:
+                    buf[:, :, self._n_u:] = pt.expand(B, -1)[None]
+                self._ups_key, self._ups_src = key, (ut, pt)          # (the sources stay alive: an id is only unique among live objects)
+            upt, us, ustep = buf, nup, (B * nup if per_step else 0)
+        xP = self._packed_tile(B)
         out = torch.empty(steps, B, self._n_x, self._n_x + 1, dtype=torch.float64, device=dev)
         yp = torch.empty(steps, B, self._n_y, dtype=torch.float64, device=dev)
         _lib.check(_lib.lib().hilo_kf_steps(self._handle, B, int(steps), ptr(xP), ptr(yt), ptr(upt), us, ustep, ptr(self._Q),
                                             self._cov_stride(self._Q, B), ptr(self._R), self._cov_stride(self._R, B), ptr(out), 1,
                                             ptr(yp), stream_ptr(dev)))
-        self._x, self._P = out[-1, :, :, 0].contiguous(), out[-1, :, :, 1:].contiguous()
-        self._xP_cur = -1                                 # the resident ping-pong tiles are re-packed by the next single step
+        self._state_tile = out[-1]                              # the last step's packed tile is the filter state: x and P are views of it
+        self._x, self._P = self._state_tile[:, :, 0], self._state_tile[:, :, 1:]
         host = not isinstance(y, torch.Tensor)
         cv = (lambda t: t.cpu().numpy()) if host else (lambda t: t)
         self.solution._set(x=cv(out[:, :, :, 0]), P=cv(out[:, :, :, 1:]), y=cv(yp))
         return self.solution
+
+    def _packed_tile(self, B):
+        """The filter state as a packed [B, nx, nx+1] tile [x | P]: the tile the last step wrote when x and P still are its views
+        (no copy), otherwise (set_initial_guess, assignment from outside) packed once."""
+        t = getattr(self, '_state_tile', None)
+        if (t is not None and t.shape[0] == B and self._x.data_ptr() == t.data_ptr() and self._P.data_ptr() == t.data_ptr() + 8
+                and self._x.stride() == (t.stride(0), t.stride(1)) and self._P.stride() == t.stride()):
+            return t
+        t = torch.empty(B, self._n_x, self._n_x + 1, dtype=torch.float64, device=self._dev)
+        t[:, :, 0] = self._x
+        t[:, :, 1:] = self._P
+        return t
 
     # ---- estimate (kf.py:279-307) ----------------------------------------------------------------
     def estimate(self, y=None, u=None, p=None, **kwargs):
@@ -335,33 +353,33 @@ class _KalmanFilter:
             buf = getattr(self, '_up_buf', None)
             if buf is None or buf.shape[0] != B:
                 buf = self._up_buf = torch.empty(B, nup, dtype=torch.float64, device=self._dev)
-                self._up_p_src = None
+                self._up_p_src = self._up_u_src = None
             if self._n_u:
-                buf[:, :self._n_u] = ut
+                ukey = (id(u), u._version) if isinstance(u, torch.Tensor) and u.device == buf.device else None
+                if ukey is None or getattr(self, '_up_u_src', None) != ukey:
+                    buf[:, :self._n_u] = ut
+                    self._up_u_src, self._up_u_ref = ukey, u
             if self._n_p:
-                # parameters passed per call are always written (a temporary's address says nothing about its content); the
-                # filter's own resident vector only when it was replaced or modified in place since the last copy
-                key = (id(pt), pt._version) if (p is None and pt is self._p) else None
+                # device tensors handed over again unmodified (same live object, same version counter) are not copied again;
+                # host data always is
+                src = self._p if p is None else p
+                key = (id(src), src._version) if isinstance(src, torch.Tensor) and src.device == buf.device else None
                 if key is None or self._up_p_src != key:
                     buf[:, self._n_u:] = pt
-                    self._up_p_src = key
+                    self._up_p_src, self._up_p_ref = key, src          # (kept alive: an id is only unique among live objects)
             upt, us = buf, nup
+        # the packed [x|P] tile ping-pongs between two resident buffers, x and P are views of the one written last
+        xP = self._packed_tile(B)
         tiles = getattr(self, '_xP_bufs', None)
         if tiles is None or tiles[0].shape[0] != B:
             tiles = self._xP_bufs = [torch.empty(B, self._n_x, self._n_x + 1, dtype=torch.float64, device=self._dev) for _ in range(2)]
-            self._xP_cur = -1
-        if self._xP_cur < 0 or self._x.data_ptr() != tiles[self._xP_cur].data_ptr():
-            # state set from outside (set_initial_guess, manual assignment): pack it once
-            tiles[0][:, :, 0] = self._x
-            tiles[0][:, :, 1:] = self._P
-            self._xP_cur = 0
-        xP, out = tiles[self._xP_cur], tiles[1 - self._xP_cur]
+        out = tiles[1] if xP.data_ptr() == tiles[0].data_ptr() else tiles[0]
         yp = torch.empty(B, self._n_y, dtype=torch.float64, device=self._dev)
         _lib.check(_lib.lib().hilo_kf_step(self._handle, B, ptr(xP), ptr(yt.contiguous()), ptr(upt), us,
                                            ptr(self._Q), self._cov_stride(self._Q, B), ptr(self._R),
                                            self._cov_stride(self._R, B), ptr(out), ptr(yp),
                                            stream_ptr(self._dev)))
-        self._xP_cur = 1 - self._xP_cur
+        self._state_tile = out
         self._x = out[:, :, 0]          # strided views of the resident tile (zero copy)
         self._P = out[:, :, 1:]
         host = not isinstance(y, torch.Tensor)

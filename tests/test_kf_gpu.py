@@ -341,3 +341,67 @@ def test_several_steps_in_one_launch_equal_the_single_steps(kind, symbolic):
     held.estimate(y=ys[0], u=us[0], p=p)
     ref.estimate(y=ys[0], u=us[0], p=p)
     np.testing.assert_allclose(held.x.cpu().numpy(), ref.x.cpu().numpy(), rtol=1e-13, atol=1e-15)
+
+
+# ---- the BASELINE batch: one instance on a team of lanes (csrc/hilo_kf_kernel.h::kf_team_body) ---------------------------------
+@pytest.mark.parametrize('kind', ['EKF', 'UKF'])
+def test_filters_at_the_baseline_batch_vs_oracle(kind):
+    """B = 4096 instances, 16 filter steps in one launch (BASELINE config 3 as bench.py runs it) against 16 steps of the oracle.
+    At this batch the library puts one instance on a team of lanes (Jacobian columns / sigma points per lane, LDS-staged).
+    Tolerance: the single step's (1e-11 / 1e-10) grown over 16 steps (worst of 16384 state entries: 3e-9); UKF with alpha = 1 (see above)."""
+    import hilo_mpc_amd as H
+    B, K = 4096, 16
+    x, P, u, p, y = _chemo_batch(B, seed=11)
+    rng = np.random.default_rng(12)
+    ys = y[None] + .01 * rng.normal(size=(K, B, 2))
+    om = omodels.get('chemostat4').discretize(4)
+    tile, yps = okf.pack(x, P), []
+    for k in range(K):
+        if kind == 'EKF':
+            tile, yp = okf.kf_step(om, tile, ys[k], u, p, 1e-4, 1e-2, 1.)
+        else:
+            tile, yp = okf.ukf_step(om, tile, ys[k], u, p, 1e-4, 1e-2, 1., alpha=1.)
+        yps.append(yp)
+    model = H.Model('chemostat4').discretize('rk4').setup(dt=1.)
+    f = H.EKF(model) if kind == 'EKF' else H.UKF(model, alpha=1.)
+    f.setup()
+    f.Q, f.R = 1e-4, 1e-2
+    f.set_initial_guess(x, P0=P)
+    sol = f.estimate(y=ys, u=u, p=p, steps=K)
+    np.testing.assert_allclose(f.x.cpu().numpy(), tile[:, :, 0], rtol=2e-8, atol=1e-12)
+    np.testing.assert_allclose(f.P.cpu().numpy(), tile[:, :, 1:], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(sol['y'], np.stack(yps), rtol=2e-8, atol=1e-12)
+    # ... and a single fused step at this batch (the same team kernel, one step)
+    g = H.EKF(model) if kind == 'EKF' else H.UKF(model, alpha=1.)
+    g.setup()
+    g.Q, g.R = 1e-4, 1e-2
+    g.set_initial_guess(x, P0=P)
+    for k in range(2):
+        g.estimate(y=ys[k], u=u, p=p)
+    np.testing.assert_allclose(g.x.cpu().numpy(), sol['x'][1], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(g.P.cpu().numpy(), sol['P'][1], rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize('kind,symbolic', [('EKF', False), ('UKF', False), ('EKF', True), ('UKF', True)])
+def test_team_and_one_lane_kernels_agree(kind, symbolic):
+    """The same instances inside a small batch (team of lanes per instance) and inside a batch large enough for one instance per
+    lane (> 2 waves per SIMD of teams): same arithmetic per entry, agreement to rounding (UKF with the default alpha = 1e-3:
+    the accumulation order of the weighted sums is the same in both, kf.py:535-548)."""
+    import hilo_mpc_amd as H
+    from tests.problems import symbolic_model
+    K, small, big = 3, 777, 40000
+    x, P, u, p, y = _chemo_batch(big, seed=21)
+    rng = np.random.default_rng(22)
+    ys = y[None] + .01 * rng.normal(size=(K, big, 2))
+    model = (symbolic_model('chemostat4') if symbolic else H.Model('chemostat4')).discretize('rk4').setup(dt=1.)
+    out = []
+    for n in (small, big):
+        f = getattr(H, kind)(model)
+        f.setup()
+        f.Q, f.R = 1e-4, 1e-2
+        f.set_initial_guess(x[:n], P0=P[:n])
+        sol = f.estimate(y=ys[:, :n], u=u[:n], p=p[:n], steps=K)
+        out.append((sol['x'][:, :small], sol['P'][:, :small], sol['y'][:, :small]))
+    tol = dict(rtol=1e-12, atol=1e-14) if kind == 'EKF' else dict(rtol=1e-9, atol=1e-9)
+    for a, b in zip(*out):
+        np.testing.assert_allclose(a, b, **tol)
