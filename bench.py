@@ -652,14 +652,19 @@ def wl_lmpc(args, torch, dev, rank, world):
         if timed:
             ev.append(e)
             log.append(mpc._nlp_solution['iter_count'])
-            solved.append(float((mpc.solver_status_code == 1).mean()))
+            solved.append(mpc._nlp_solution['status'])          # (device tensors: looked at after the timed region)
         x = x @ Ad.T + u @ Bd.T
 
     def finish():
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         iters = float(torch.stack(log).double().mean().item())
+        # flops = K N F_ric(nx, nu), no model evaluation in a linear MPC; the kernel takes its Newton steps by that
+        # recursion (csrc/hilo_qp_ocp.h) when the QP has the stage shape, else (HILO_QP_DENSE=1) the dense count applies
+        nx_, nu_, N_ = 2, 1, 10
+        staged = bool(getattr(mpc, '_qp_stages', False))
         n, mq = 32, 20
-        fl_it = 2 * mq * mq * n + mq ** 3 / 3 + 4 * mq * mq + 6 * n * mq
+        fl_it = (N_ * (7 / 3 * nx_ ** 3 + 4 * nx_ * nx_ * nu_ + 2 * nx_ * nu_ * nu_ + nu_ ** 3 / 3 + 8 * nx_ * nx_ + 8 * nx_ * nu_ + 2 * nu_ * nu_)
+                 if staged else 2 * mq * mq * n + mq ** 3 / 3 + 4 * mq * mq + 6 * n * mq)
         tf = B * iters * fl_it / (kern_ms * 1e-3) / 1e12
         one = product_lmpc('corrected')
         x1 = torch.as_tensor(np.array([[1., 1.]]), device=dev)
@@ -673,11 +678,16 @@ def wl_lmpc(args, torch, dev, rank, world):
             b.record()
         torch.cuda.synchronize(dev)
         roof = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
-                "traffic": pmc_traffic_bytes('C1'), "traffic_source": pmc_traffic_bytes('C1', with_source=True)[1], "kernel": "qp_solve_reg_kernel<32, 24>", "kernel_ms": kern_ms,
-                "note": "dense Mehrotra predictor-corrector, 32 variables / 20 equalities: flops per iteration = 2 m^2 n + m^3/3 "
-                        "+ 4 m^2 + 6 n m; a 32-variable QP per workgroup is latency bound"}
+                "traffic": pmc_traffic_bytes('C1'), "traffic_source": pmc_traffic_bytes('C1', with_source=True)[1],
+                "kernel": "qp_ocp_kernel<2, 1, 16>" if staged else "qp_solve_reg_kernel<32, 24>", "kernel_ms": kern_ms,
+                "flops_per_iteration": fl_it,
+                "note": ("Mehrotra predictor-corrector with the Newton step by a Riccati recursion over the 10 stages (a stage per "
+                         "lane, 4 QPs per wave): flops per iteration = N F_ric(nx, nu) of SURVEY 8(d) = 890 - a chain of 10 "
+                         "dependent 2x2 steps is latency bound, the figure of merit is `single_instance_latency_us`") if staged else
+                        ("dense Mehrotra predictor-corrector, 32 variables / 20 equalities: flops per iteration = 2 m^2 n + m^3/3 "
+                         "+ 4 m^2 + 6 n m; a 32-variable QP per workgroup is latency bound")}
         extra = {"workload": "C1 LMPC discrete double integrator nx=2 nu=1 N=10 (corrected input block), closed loop",
-                 "batch_per_gpu": B, "global_batch": B * world, "mean_qp_iters": iters, "frac_status_1": float(np.mean(solved)),
+                 "batch_per_gpu": B, "global_batch": B * world, "mean_qp_iters": iters, "frac_status_1": float((torch.stack(solved) == 1).double().mean().item()),
                  "single_instance_latency_us": float(np.mean([a.elapsed_time(b) for a, b in e1])) * 1e3}
         return extra, roof, "weak"
 

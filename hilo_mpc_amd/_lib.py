@@ -118,6 +118,7 @@ def _declare(lib):
         'hilo_qp_create': (C.c_int, [i32, i32, i32, P(vp)]),
         'hilo_qp_destroy': (None, [vp]),
         'hilo_qp_set_options': (C.c_int, [vp, dbl, i32]),
+        'hilo_qp_set_stages': (C.c_int, [vp, i32, i32, i32, P(i32)]),
         'hilo_qp_solve': (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_gp_create': (C.c_int, [i32, i32, i32, vp, vp, vp, i32, vp, i32, dbl, P(vp)]),
         'hilo_gp_destroy': (None, [vp]),

@@ -953,6 +953,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 }  // namespace hilo
 
+#include "hilo_qp_ocp.h"
+
+
 using namespace hilo;
 
 struct hilo_qp {
@@ -964,6 +967,7 @@ struct hilo_qp {
   size_t fast_lds;
   double* ws;
   int64_t ws_batch;
+  int ocp_nx, ocp_nu, ocp_N;   // stage structure declared with hilo_qp_set_stages (0: none): the Riccati kernel of hilo_qp_ocp.h
 };
 
 extern "C" int hilo_qp_create(int n, int m, int device, hilo_qp** out) {
@@ -990,6 +994,7 @@ extern "C" int hilo_qp_create(int n, int m, int device, hilo_qp** out) {
   if (h->fast_lds > 160 * 1024 || getenv("HILO_QP_LDS_COLUMNS")) h->fast_np = 0;
   h->ws = nullptr;
   h->ws_batch = 0;
+  h->ocp_nx = h->ocp_nu = h->ocp_N = 0;
   *out = h;
   return HILO_OK;
 }
@@ -1007,6 +1012,29 @@ extern "C" int hilo_qp_set_options(hilo_qp* h, double tol, int max_iter) {
   return HILO_OK;
 }
 
+// The QP has the LMPC's stage shape (hilo_qp_ocp.h; mpc.py:2198-2266 with a block-diagonal input block): hilo_qp_solve then
+// takes its Newton steps by a Riccati recursion over the stages.  Sizes without an instantiation keep the dense kernels
+// (returns HILO_OK either way; `*used` tells which).  N = 0 withdraws the declaration.
+#define HILO_QP_OCP_SIZES(X) X(1, 1) X(2, 1) X(2, 2) X(3, 1) X(3, 2) X(4, 1) X(4, 2)
+extern "C" int hilo_qp_set_stages(hilo_qp* h, int nx, int nu, int N, int* used) {
+  HILO_REQUIRE(h, "hilo_qp_set_stages: NULL handle");
+  if (used) *used = 0;
+  h->ocp_nx = h->ocp_nu = h->ocp_N = 0;
+  if (N == 0) return HILO_OK;
+  HILO_REQUIRE(nx >= 1 && nu >= 1 && N >= 1, "hilo_qp_set_stages: need nx, nu, N >= 1");
+  HILO_REQUIRE(h->n == (N + 1) * nx + N * nu && h->m == N * nx,
+               "hilo_qp_set_stages: n = %d, m = %d do not match (N+1) nx + N nu = %d, N nx = %d", h->n, h->m,
+               (N + 1) * nx + N * nu, N * nx);
+  bool have = false;
+#define X(NXV, NUV) have = have || (nx == NXV && nu == NUV);
+  HILO_QP_OCP_SIZES(X)
+#undef X
+  if (!have || N + 1 > 64 || getenv("HILO_QP_DENSE")) return HILO_OK;
+  h->ocp_nx = nx; h->ocp_nu = nu; h->ocp_N = N;
+  if (used) *used = 1;
+  return HILO_OK;
+}
+
 extern "C" int hilo_qp_solve(hilo_qp* h, int64_t batch, const double* H, int64_t h_stride, const double* g,
                              int64_t g_stride, const double* A, int64_t a_stride, const double* lbx, const double* ubx,
                              int64_t bx_stride, const double* lba, const double* uba, int64_t ba_stride, double* x,
@@ -1018,6 +1046,24 @@ extern "C" int hilo_qp_solve(hilo_qp* h, int64_t batch, const double* H, int64_t
   HILO_REQUIRE(h->m == 0 || (A && lba && uba), "hilo_qp_solve: the problem has %d rows but A / lba / uba is NULL", h->m);
   HILO_REQUIRE(bx_stride >= h->n, "hilo_qp_solve: lbx/ubx are per instance (x_0 is pinned through them, mpc.py:2361-2362)");
   HILO_HIP_CHECK(hipSetDevice(h->device));
+  if (h->ocp_N) {
+    const int N = h->ocp_N;
+#define X(NXV, NUV)                                                                                                                 \
+  if (h->ocp_nx == NXV && h->ocp_nu == NUV) {                                                                                        \
+    if (N + 1 <= 16)                                                                                                                 \
+      hipLaunchKernelGGL((qp_ocp_kernel<NXV, NUV, 16>), dim3((unsigned)((batch + 3) / 4)), dim3(64), 0, (hipStream_t)stream, h->qd,  \
+                         N, batch, H, h_stride, g, g_stride, A, a_stride, lbx, ubx, bx_stride, lba, uba, ba_stride, x, f, lam_a,     \
+                         lam_x, status, iters);                                                                                     \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((qp_ocp_kernel<NXV, NUV, 64>), dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, h->qd, N, batch,    \
+                         H, h_stride, g, g_stride, A, a_stride, lbx, ubx, bx_stride, lba, uba, ba_stride, x, f, lam_a, lam_x,        \
+                         status, iters);                                                                                            \
+  }
+    HILO_QP_OCP_SIZES(X)
+#undef X
+    HILO_HIP_CHECK(hipGetLastError());
+    return HILO_OK;
+  }
   if (h->fast_np) {
 #define HILO_QP_FAST(NPV, MPV)                                                                                                     \
   if (h->fast_np == NPV && h->fast_mp == MPV) {                                                                                     \

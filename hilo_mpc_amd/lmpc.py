@@ -256,11 +256,23 @@ class LMPC:
         self._x_ind = [list(range(k * nx, (k + 1) * nx)) for k in range(N + 1)]                 # mpc.py:2221-2231
         self._u_ind = [list(range((N + 1) * nx + k * nu, (N + 1) * nx + (k + 1) * nu)) for k in range(N)]
         self._sx, self._su = to_dev(sx, self._dev), to_dev(su, self._dev)
+        self._unit_sx, self._unit_su = bool(np.all(sx == 1.)), bool(np.all(su == 1.))
+        self._bound_rows = None
         self._n_v, self._n_g = n_v, N * nx
         h = C.c_void_p()
         _lib.check(_lib.lib().hilo_qp_create(n_v, N * nx, self._dev.index, C.byref(h)))
         so = {k.split('.')[-1]: v for k, v in (solver_options or {}).items()}
         _lib.check(_lib.lib().hilo_qp_set_options(h, float(so.get('tol', 0.)), int(so.get('max_iter', 0))))
+        # A QP with the stage shape x_{k+1} = A_k x_k + B_k u_k (the time-varying branch mpc.py:2236-2240, the corrected input block,
+        # or sizes where `kron(B, I_N)` (:2243) happens to be it) is solved stage by stage (csrc/hilo_qp_ocp.h); the reference's
+        # `kron(B, I_N)` couples the stages differently and stays on the dense kernels.  Variables pinned by equal bounds other than
+        # x_0 are left to the dense kernels too.
+        staged = bool(self._n_par()) or np.array_equal(Aeq, self._equality_matrix([A], [B], 'corrected'))
+        staged = staged and not (np.any(xl == xu) or np.any(ul == uu))
+        used = C.c_int(0)
+        if staged:
+            _lib.check(_lib.lib().hilo_qp_set_stages(h, nx, nu, N, C.byref(used)))
+        self._qp_stages = bool(used.value)
         self._destroy()
         self._handle = h
 
@@ -304,10 +316,14 @@ class LMPC:
             raise ValueError(f"We have an issue mate, the x0 you supplied has dimension {x.shape[1]} but the model has "
                              f"{self._n_x} states.")
         B, dev, n, m = x.shape[0], self._dev, self._n_v, self._n_g
-        lb = self._v_lb.expand(B, -1).contiguous()
-        ub = self._v_ub.expand(B, -1).contiguous()
-        lb[:, :self._n_x] = x / self._sx                                                           # mpc.py:2361-2362
-        ub[:, :self._n_x] = x / self._sx
+        # the bound rows of the batch are resident; per call only the pinned x_0 is written into them (mpc.py:2361-2362)
+        bb = getattr(self, '_bound_rows', None)
+        if bb is None or bb[0].shape[0] != B or bb[2] is not self._v_lb:
+            bb = self._bound_rows = (self._v_lb.expand(B, -1).contiguous(), self._v_ub.expand(B, -1).contiguous(), self._v_lb)
+        lb, ub = bb[0], bb[1]
+        xs = x if self._unit_sx else x / self._sx
+        lb[:, :self._n_x] = xs
+        ub[:, :self._n_x] = xs
         v = torch.empty(B, n, dtype=torch.float64, device=dev)
         f = torch.empty(B, dtype=torch.float64, device=dev)
         lam_a = torch.empty(B, m, dtype=torch.float64, device=dev)
@@ -320,7 +336,8 @@ class LMPC:
         self._nlp_solution = {'x': v, 'f': f, 'lam_a': lam_a, 'lam_x': lam_x, 'status': status, 'iter_count': iters}
         self._time += self._sampling_interval                                                     # mpc.py:2386
         self._n_iterations += 1                                                                   # mpc.py:2392
-        u = v[:, self._u_ind[0]] * self._su                                                       # mpc.py:2377
+        u = v[:, self._u_ind[0][0]:self._u_ind[0][-1] + 1]                                        # mpc.py:2377
+        u = u.clone() if self._unit_su else u * self._su
         if host:
             u = u.cpu().numpy()
             return u.reshape(-1, 1) if single else u

@@ -501,6 +501,12 @@ typedef struct hilo_qp hilo_qp;
 int hilo_qp_create(int n, int m, int device, hilo_qp** out);
 void hilo_qp_destroy(hilo_qp* h);
 int hilo_qp_set_options(hilo_qp* h, double tol /* <=0 keeps 1e-12 */, int max_iter /* <=0 keeps 100 */);
+/* The QP has the stage shape of `LMPC.setup` (mpc.py:2198-2266): v = [x_0 .. x_N | u_0 .. u_{N-1}], H block diagonal over the  */
+/* stages (:2252-2256), rows k: A_k x_k + B_k u_k - x_{k+1} = b_k (:2209-2240; NOT the `kron(B, I_N)` input block of :2243),      */
+/* x_0 - and only x_0 - pinned by lbx == ubx (:2361-2362).  hilo_qp_solve then takes its Newton steps by a Riccati recursion over */
+/* the stages (csrc/hilo_qp_ocp.h) instead of the dense Schur complement; same arguments, same iteration, same outputs.          */
+/* *used = 1 if a stage kernel exists for (nx, nu, N <= 63), 0 = the dense kernels stay.  N = 0 withdraws the declaration.        */
+int hilo_qp_set_stages(hilo_qp* h, int nx, int nu, int N, int* used);
 int hilo_qp_solve(hilo_qp* h, int64_t batch,
                   const double* H, int64_t h_stride,       /* [B][n][n] row-major (stride 0 = shared) */
                   const double* g, int64_t g_stride,       /* [B][n] */

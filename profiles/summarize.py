@@ -14,7 +14,7 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
 # substring that identifies the dominant kernel of each configuration in the trace
-KEYS = {'C1': 'qp_solve_reg_kernel', 'C2': 'ocp_solve_kernel', 'C3-mhe': 'ocp_solve_kernel', 'C3-ekf': 'kf_team_kernel',
+KEYS = {'C1': 'qp_ocp_kernel', 'C2': 'ocp_solve_kernel', 'C3-mhe': 'ocp_solve_kernel', 'C3-ekf': 'kf_team_kernel',
         'C3-ukf': 'kf_team_kernel', 'C4': 'ocp_solve_kernel', 'C5': 'hilo_user_solve', 'C5-dae': 'hilo_user_solve', 'gp-predict': 'gp_predict'}
 
 

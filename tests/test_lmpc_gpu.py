@@ -112,11 +112,13 @@ def test_register_resident_kernel_equals_the_lds_column_kernel(N, variant, Q, mo
     (the general path: H + Sigma factored in registers)."""
     rng = np.random.default_rng(11)
     x0 = rng.uniform(-1.5, 1.5, (48, 2))
+    monkeypatch.setenv('HILO_QP_DENSE', '1')                    # (the corrected block has the stage shape: keep both on the dense kernels)
     fast = product_lmpc(variant, N=N, Q=Q)
     uf = fast.optimize(x0)
     monkeypatch.setenv('HILO_QP_LDS_COLUMNS', '1')
     slow = product_lmpc(variant, N=N, Q=Q)
     us = slow.optimize(x0)
+    assert not fast._qp_stages and not slow._qp_stages
     assert np.array_equal(fast.solver_status_code, slow.solver_status_code)
     ok = fast.solver_status_code == 1
     assert ok.sum() >= 24
@@ -130,6 +132,65 @@ def test_register_resident_kernel_equals_the_lds_column_kernel(N, variant, Q, mo
     both = ok & (ref['status'] == 1)
     assert both.sum() >= 24
     np.testing.assert_allclose(uf[both], ref['u'][both], rtol=1e-6, atol=1e-5)   # (longer horizons: degenerate vertices, polish)
+
+
+@pytest.mark.parametrize('N,Q', [(10, None), (10, QD), (15, QD), (20, None), (40, QD)])
+def test_stage_kernel_equals_the_dense_kernels(N, Q, monkeypatch):
+    """Round 4: a QP with the stage shape (corrected input block) takes its Newton steps by a Riccati recursion over the stages
+    (csrc/hilo_qp_ocp.h: a stage per lane, 16 lanes per instance up to N = 15, a wave beyond) - the same predictor-corrector
+    iteration as the dense kernels: same statuses (incl. the infeasible starts), iteration counts within one, solution, objective
+    and both multiplier sets to round-off; and the oracle agrees."""
+    rng = np.random.default_rng(12)
+    x0 = np.vstack([rng.uniform(-1.5, 1.5, (45, 2)), rng.uniform(-4, 4, (10, 2))])
+    st = product_lmpc('corrected', N=N, Q=Q)
+    assert st._qp_stages
+    u1 = st.optimize(x0)
+    monkeypatch.setenv('HILO_QP_DENSE', '1')
+    de = product_lmpc('corrected', N=N, Q=Q)
+    assert not de._qp_stages
+    u2 = de.optimize(x0)
+    assert np.array_equal(st.solver_status_code, de.solver_status_code)
+    ok = st.solver_status_code == 1
+    assert ok.sum() >= 30 and (st.solver_status_code == 3).sum() >= 1
+    a, b = st._nlp_solution, de._nlp_solution
+    assert np.max(np.abs(a['iter_count'].cpu().numpy() - b['iter_count'].cpu().numpy())) <= 1
+    np.testing.assert_allclose(u1[ok], u2[ok], rtol=1e-8, atol=1e-9)
+    for key, tol in (('x', 1e-8), ('f', 1e-9), ('lam_a', 1e-7), ('lam_x', 1e-7)):
+        np.testing.assert_allclose(a[key].cpu().numpy()[ok], b[key].cpu().numpy()[ok], rtol=tol, atol=tol)
+    ref = lmpc_optimize(LmpcProblem(**dict(C1, N=N, **({} if Q is None else {'Q': Q})), kron_bug=False), x0)
+    both = ok & (ref['status'] == 1)
+    assert both.sum() >= 30
+    np.testing.assert_allclose(u1[both], ref['u'][both], rtol=1e-6, atol=1e-5)
+
+
+def test_stage_kernel_on_a_four_state_two_input_system(monkeypatch):
+    """nx = 4, nu = 2 (two coupled double integrators), N = 12, bounds on states and inputs, B = 64: stage kernel against the
+    dense register kernel; single instance too (the launch of BASELINE configuration 1's shape: one QP)."""
+    from hilo_mpc_amd import LMPC, Model
+    dt = .2
+    A4 = np.array([[1., dt, 0., 0.], [0., 1., 0., 0.], [.05, 0., 1., dt], [0., 0., -.02, 1.]])
+    B4 = np.array([[.5 * dt * dt, 0.], [dt, 0.], [0., .5 * dt * dt], [.1 * dt, dt]])
+
+    def make():
+        mpc = LMPC(Model('lti', A=A4, B=B4).setup(dt=dt))
+        mpc.Q, mpc.R, mpc.P = np.diag([1., .1, 2., .1]), np.array([[1., .2], [.2, .5]]), 3 * np.eye(4)
+        mpc.horizon = 12
+        mpc.set_box_constraints(x_lb=[-3, -2, -3, -2], x_ub=[3, 2, 3, 2], u_lb=[-1, -1.5], u_ub=[1, 1.5])
+        mpc.setup(kron_variant='corrected')
+        return mpc
+    rng = np.random.default_rng(5)
+    x0 = rng.uniform(-1, 1, (64, 4))
+    st = make()
+    assert st._qp_stages
+    u1 = st.optimize(x0)
+    one = st.optimize(x0[3])
+    monkeypatch.setenv('HILO_QP_DENSE', '1')
+    de = make()
+    u2 = de.optimize(x0)
+    assert np.array_equal(st.solver_status_code[:0], de.solver_status_code[:0]) and np.all(de.solver_status_code == 1)
+    np.testing.assert_allclose(u1, u2, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(np.ravel(one), u2[3], rtol=1e-8, atol=1e-9)
+    assert (np.abs(u1[:, 0]) > 1 - 1e-6).sum() >= 3                       # input bounds active somewhere
 
 
 @pytest.mark.parametrize('lds_columns', [False, True])
