@@ -1101,6 +1101,13 @@ extern "C" int hilo_qp_solve(hilo_qp* h, int64_t batch, const double* H, int64_t
   return HILO_OK;
 }
 
+#ifdef HILO_QPO_PROF
+extern "C" int hilo_debug_qpo_prof(unsigned long long* out) {
+  HILO_HIP_CHECK(hipDeviceSynchronize());
+  HILO_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(hilo::hilo_qpo_prof), sizeof(unsigned long long) * 16));
+  return HILO_OK;
+}
+#endif
 #ifdef HILO_QP_PROF
 extern "C" int hilo_qp_debug_prof(long long* out16) {
   HILO_HIP_CHECK(hipDeviceSynchronize());

@@ -17,6 +17,22 @@
 
 namespace hilo {
 
+#ifdef HILO_QPO_PROF   // developer builds: cycle stamps of one iteration of workgroup 0 (tools/dbg/qp_stage_phase.py)
+__device__ unsigned long long hilo_qpo_prof[16];
+#define QPO_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) hilo_qpo_prof[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define QPO_STAMP(k) do { } while (0)
+#endif
+
+// 1 / x: v_rcp_f64 + two Newton steps (<= 1 ulp) instead of the 12-instruction IEEE division sequence; the slacks' reciprocals
+// are formed once per iteration and shared by Sigma, the corrector's right-hand side and the step rule
+__device__ __forceinline__ double ocp_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 template <int G>
 __device__ __forceinline__ double ocp_from_next(double v) {   // lane k <- lane k + 1
   if constexpr (G == 16) return qp_dpp<0x101, 0xf>(v, v);     // row_shl:1
@@ -42,6 +58,39 @@ __device__ __forceinline__ double ocp_reduce(double v, double ident, Op op) {
 template <int G> __device__ __forceinline__ double ocp_sum(double v) { return ocp_reduce<G>(v, 0.0, [](double a, double b) { return a + b; }); }
 template <int G> __device__ __forceinline__ double ocp_min(double v) { return ocp_reduce<G>(v, INFINITY, [](double a, double b) { return fmin(a, b); }); }
 template <int G> __device__ __forceinline__ double ocp_max(double v) { return ocp_reduce<G>(v, -INFINITY, [](double a, double b) { return fmax(a, b); }); }
+
+// One step of a scan over the affine maps v -> Mat v + d the lanes of a row hold (Hillis-Steele): compose this lane's map with
+// the one CTRL lanes away (row_shl:o - the stages behind, row_shr:o - the stages before; beyond the row: the identity).
+template <int NX, int CTRL>
+__device__ __forceinline__ void ocp_scan_step(double (&Mat)[NX][NX], double (&d)[NX]) {
+  double Mo[NX][NX], dn[NX], Mn[NX][NX], dd[NX];
+#pragma unroll
+  for (int a = 0; a < NX; ++a) {
+    dn[a] = qp_dpp<CTRL, 0xf>(d[a], 0.0);
+#pragma unroll
+    for (int c = 0; c < NX; ++c) Mo[a][c] = qp_dpp<CTRL, 0xf>(Mat[a][c], a == c ? 1.0 : 0.0);
+  }
+#pragma unroll
+  for (int a = 0; a < NX; ++a) {
+    double s = d[a];
+#pragma unroll
+    for (int e = 0; e < NX; ++e) s += Mat[a][e] * dn[e];
+    dd[a] = s;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+      double q = 0.0;
+#pragma unroll
+      for (int e = 0; e < NX; ++e) q += Mat[a][e] * Mo[e][c];
+      Mn[a][c] = q;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NX; ++a) {
+    d[a] = dd[a];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) Mat[a][c] = Mn[a][c];
+  }
+}
 
 // Arguments of qp_solve_kernel (dense H [n][n], A [m][n] per instance or shared) + the horizon.  n = (N+1) NX + N NU, m = N NX.
 template <int NX, int NU, int G>
@@ -166,6 +215,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
   for (int iter = 0; iter < qd.max_iter; ++iter) {
     if (!__any(!done)) break;
+    QPO_STAMP(0);
     // ---- residuals: base = -(H v + g + A^T y), rp = A v - b, mu ----
     double rdm = 0.0, mup = 0.0, nonf = 0.0, rpm = 0.0;
     double yprev[NX], xnext[NX];
@@ -226,25 +276,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
       }
     }
     if (!done) it = iter + 1;
+    QPO_STAMP(1);
     // ---- M = H + Sigma + reg, factorisation sweep: P_N = M_N; k = N-1 .. 0 ----
-    double Mx[NX][NX], Mu[NU][NU];
+    double Mx[NX][NX], Mu[NU][NU], ilx[NX], iux[NX], ilu[NU], iuu[NU];   // reciprocal slacks (0 where there is no bound)
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
 #pragma unroll
       for (int j = 0; j < NX; ++j) Mx[i][j] = Q[i][j];
-      double d = qd.reg;
-      if (lx[i] > -INFINITY) d += zlx[i] / (xs[i] - lx[i]);
-      if (ux[i] < INFINITY) d += zux[i] / (ux[i] - xs[i]);
-      Mx[i][i] += d;
+      ilx[i] = lx[i] > -INFINITY ? ocp_rcp(xs[i] - lx[i]) : 0.0;
+      iux[i] = ux[i] < INFINITY ? ocp_rcp(ux[i] - xs[i]) : 0.0;
+      Mx[i][i] += qd.reg + zlx[i] * ilx[i] + zux[i] * iux[i];
     }
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
 #pragma unroll
       for (int j = 0; j < NU; ++j) Mu[i][j] = R[i][j];
-      double d = qd.reg;
-      if (lu[i] > -INFINITY) d += zlu[i] / (us[i] - lu[i]);
-      if (uu[i] < INFINITY) d += zuu[i] / (uu[i] - us[i]);
-      Mu[i][i] += d;
+      ilu[i] = lu[i] > -INFINITY ? ocp_rcp(us[i] - lu[i]) : 0.0;
+      iuu[i] = uu[i] < INFINITY ? ocp_rcp(uu[i] - us[i]) : 0.0;
+      Mu[i][i] += qd.reg + zlu[i] * ilu[i] + zuu[i] * iuu[i];
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i)
@@ -364,30 +413,110 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int c = 0; c < NU; ++c) Qi[a][c] = mine ? Qinv[a][c] : Qi[a][c];
       }
     }
+    QPO_STAMP(2);
     okf = ocp_min<G>(okf);
     if (!done && okf == 0.0) { st = HILO_STATUS_OTHER; done = true; it = iter; }
+    // closed-loop matrix A + B K of this stage: both linear sweeps below are recursions v_next = Acl^(T) v + const
+    double Acl[NX][NX];
+#pragma unroll
+    for (int a = 0; a < NX; ++a)
+#pragma unroll
+      for (int c = 0; c < NX; ++c) {
+        double q = Ak[a][c];
+#pragma unroll
+        for (int e = 0; e < NU; ++e) q += Bk[a][e] * K[e][c];
+        Acl[a][c] = inner ? q : 0.0;
+      }
 
     double sigma_mu = 0.0;
     for (int pass = 0; pass < 2; ++pass) {
+      QPO_STAMP(3 + 4 * pass);
       double r1x[NX], r1u[NU];
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
         double s = basex[i];
-        if (pass == 1) {
-          if (lx[i] > -INFINITY) s += (sigma_mu - dx[i] * dzlx[i]) / (xs[i] - lx[i]);
-          if (ux[i] < INFINITY) s -= (sigma_mu + dx[i] * dzux[i]) / (ux[i] - xs[i]);
-        }
+        if (pass == 1) s += (sigma_mu - dx[i] * dzlx[i]) * ilx[i] - (sigma_mu + dx[i] * dzux[i]) * iux[i];
         r1x[i] = s;
       }
 #pragma unroll
       for (int i = 0; i < NU; ++i) {
         double s = baseu[i];
-        if (pass == 1) {
-          if (lu[i] > -INFINITY) s += (sigma_mu - du[i] * dzlu[i]) / (us[i] - lu[i]);
-          if (uu[i] < INFINITY) s -= (sigma_mu + du[i] * dzuu[i]) / (uu[i] - us[i]);
-        }
+        if (pass == 1) s += (sigma_mu - du[i] * dzlu[i]) * ilu[i] - (sigma_mu + du[i] * dzuu[i]) * iuu[i];
         r1u[i] = s;
       }
+      double ex[NX], eu[NU];
+      if constexpr (G == 16) {
+        // The two sweeps as SCANS over the 16 lanes of the row (4 steps each instead of N dependent ones):
+        //   p_k = Acl_k^T (P_{k+1} rp_k + p_{k+1}) - r1x_k - K_k^T r1u_k,  p_N = -r1x_N        (suffix scan, row_shl)
+        //   dx_{k+1} = Acl_k dx_k + B_k kff_k + rp_k,  dx_0 = 0                                 (prefix scan, row_shr)
+        double Mat[NX][NX], d[NX], w[NX];
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+          double q = 0.0;
+#pragma unroll
+          for (int e = 0; e < NX; ++e) q += Pn[a][e] * rp[e];
+          w[a] = q;
+        }
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+          double q = -r1x[a];
+#pragma unroll
+          for (int e = 0; e < NX; ++e) q += Acl[e][a] * w[e];
+#pragma unroll
+          for (int e = 0; e < NU; ++e) q -= K[e][a] * r1u[e];
+          d[a] = inner ? q : (stage ? -r1x[a] : 0.0);
+#pragma unroll
+          for (int c = 0; c < NX; ++c) Mat[a][c] = inner ? Acl[c][a] : ((!stage && a == c) ? 1.0 : 0.0);
+        }
+        ocp_scan_step<NX, 0x101>(Mat, d);
+        ocp_scan_step<NX, 0x102>(Mat, d);
+        ocp_scan_step<NX, 0x104>(Mat, d);
+        ocp_scan_step<NX, 0x108>(Mat, d);
+#pragma unroll
+        for (int a = 0; a < NX; ++a) pv[a] = d[a];
+        double h[NX];
+#pragma unroll
+        for (int a = 0; a < NX; ++a) h[a] = w[a] + ocp_from_next<G>(pv[a]);
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          double q = -r1u[a];
+#pragma unroll
+          for (int e = 0; e < NX; ++e) q += Bk[e][a] * h[e];
+          eu[a] = q;                                   // (qu)
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          double q = 0.0;
+#pragma unroll
+          for (int e = 0; e < NU; ++e) q -= Qi[a][e] * eu[e];
+          kff[a] = inner ? q : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+          double q = rp[a];
+#pragma unroll
+          for (int e = 0; e < NU; ++e) q += Bk[a][e] * kff[e];
+          d[a] = inner ? q : 0.0;
+#pragma unroll
+          for (int c = 0; c < NX; ++c) Mat[a][c] = inner ? Acl[a][c] : (a == c ? 1.0 : 0.0);
+        }
+        ocp_scan_step<NX, 0x111>(Mat, d);
+        ocp_scan_step<NX, 0x112>(Mat, d);
+        ocp_scan_step<NX, 0x114>(Mat, d);
+        ocp_scan_step<NX, 0x118>(Mat, d);
+#pragma unroll
+        for (int a = 0; a < NX; ++a) {
+          const double prev = ocp_from_prev<G>(d[a]);
+          ex[a] = first ? 0.0 : prev;
+        }
+#pragma unroll
+        for (int a = 0; a < NU; ++a) {
+          double q = kff[a];
+#pragma unroll
+          for (int e = 0; e < NX; ++e) q += K[a][e] * ex[e];
+          eu[a] = inner ? q : 0.0;
+        }
+      } else {
       // backward: p_N = -r1x_N;  h = P_{k+1} rp_k + p_{k+1};  kff = -Quu^-1 (B^T h - r1u);  p_k = A^T h - r1x + Qux^T kff
 #pragma unroll
       for (int i = 0; i < NX; ++i) pv[i] = -r1x[i];
@@ -433,7 +562,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int a = 0; a < NU; ++a) kff[a] = mine ? kq[a] : kff[a];
       }
       // forward: dx_0 = 0;  du_k = K dx_k + kff;  dx_{k+1} = A dx_k + B du_k + rp_k;  dy_k = P_{k+1} dx_{k+1} + p_{k+1}
-      double ex[NX], eu[NU];
 #pragma unroll
       for (int i = 0; i < NX; ++i) ex[i] = 0.0;
 #pragma unroll
@@ -465,6 +593,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
           ex[i] = nxt ? fromprev : ex[i];
         }
       }
+      }
+      QPO_STAMP(4 + 4 * pass);
       double wy[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
@@ -486,17 +616,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const double d = (first || !stage) ? 0.0 : ex[i];
         double dl = 0.0, dub = 0.0;
         const double cl = pass == 1 ? dx[i] * dzlx[i] : 0.0, cu = pass == 1 ? -dx[i] * dzux[i] : 0.0;
+        const double rd_ = ocp_rcp(d);
         if (lx[i] > -INFINITY) {
-          const double s = xs[i] - lx[i];
-          dl = (sigma_mu - cl) / s - zlx[i] - zlx[i] / s * d;
-          if (d < 0.0) ap = fmin(ap, -tau * s / d);
-          if (dl < 0.0) ad = fmin(ad, -tau * zlx[i] / dl);
+          dl = (sigma_mu - cl) * ilx[i] - zlx[i] - zlx[i] * ilx[i] * d;
+          if (d < 0.0) ap = fmin(ap, -tau * (xs[i] - lx[i]) * rd_);
+          if (dl < 0.0) ad = fmin(ad, -tau * zlx[i] * ocp_rcp(dl));
         }
         if (ux[i] < INFINITY) {
-          const double s = ux[i] - xs[i];
-          dub = (sigma_mu - cu) / s - zux[i] + zux[i] / s * d;
-          if (d > 0.0) ap = fmin(ap, tau * s / d);
-          if (dub < 0.0) ad = fmin(ad, -tau * zux[i] / dub);
+          dub = (sigma_mu - cu) * iux[i] - zux[i] + zux[i] * iux[i] * d;
+          if (d > 0.0) ap = fmin(ap, tau * (ux[i] - xs[i]) * rd_);
+          if (dub < 0.0) ad = fmin(ad, -tau * zux[i] * ocp_rcp(dub));
         }
         dx[i] = d; dzlx[i] = dl; dzux[i] = dub;
       }
@@ -505,22 +634,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const double d = inner ? eu[i] : 0.0;
         double dl = 0.0, dub = 0.0;
         const double cl = pass == 1 ? du[i] * dzlu[i] : 0.0, cu = pass == 1 ? -du[i] * dzuu[i] : 0.0;
+        const double rd_ = ocp_rcp(d);
         if (lu[i] > -INFINITY) {
-          const double s = us[i] - lu[i];
-          dl = (sigma_mu - cl) / s - zlu[i] - zlu[i] / s * d;
-          if (d < 0.0) ap = fmin(ap, -tau * s / d);
-          if (dl < 0.0) ad = fmin(ad, -tau * zlu[i] / dl);
+          dl = (sigma_mu - cl) * ilu[i] - zlu[i] - zlu[i] * ilu[i] * d;
+          if (d < 0.0) ap = fmin(ap, -tau * (us[i] - lu[i]) * rd_);
+          if (dl < 0.0) ad = fmin(ad, -tau * zlu[i] * ocp_rcp(dl));
         }
         if (uu[i] < INFINITY) {
-          const double s = uu[i] - us[i];
-          dub = (sigma_mu - cu) / s - zuu[i] + zuu[i] / s * d;
-          if (d > 0.0) ap = fmin(ap, tau * s / d);
-          if (dub < 0.0) ad = fmin(ad, -tau * zuu[i] / dub);
+          dub = (sigma_mu - cu) * iuu[i] - zuu[i] + zuu[i] * iuu[i] * d;
+          if (d > 0.0) ap = fmin(ap, tau * (uu[i] - us[i]) * rd_);
+          if (dub < 0.0) ad = fmin(ad, -tau * zuu[i] * ocp_rcp(dub));
         }
         du[i] = d; dzlu[i] = dl; dzuu[i] = dub;
       }
+      QPO_STAMP(5 + 4 * pass);
       ap = ocp_min<G>(ap);
       ad = ocp_min<G>(ad);
+      QPO_STAMP(6 + 4 * pass);
       if (pass == 0) {
         double mp = 0.0;
 #pragma unroll
