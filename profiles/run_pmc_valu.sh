@@ -8,9 +8,13 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 BENCH="python $ROOT/bench.py --no-cpu-baseline --steps 6 --warmup 14"
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT"; do
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"; do
   name=$(echo $set | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$name -o $TAG -- $BENCH > $OUT/$name.log 2>&1 || echo "failed: $set"
 done
+# the matrix-core counters of the GP prediction kernel (the other place MFMA is used), own pass
+GP="python $ROOT/bench.py --config gp-predict --no-cpu-baseline --steps 6 --warmup 4"
+mkdir -p $OUT/gp
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $OUT/gp/mfma -o $TAG -- $GP > $OUT/gp/mfma.log 2>&1 || echo "failed: gp mfma"
 cd $ROOT
 find $OUT -name "*counter_collection.csv" | head
