@@ -387,12 +387,13 @@ class Model:
             p = np.zeros(0)
         # the Jacobian as a straight-line program, built once per (equations, discretisation, sampling interval) and evaluated per
         # call (the linear MPC asks for one pair of matrices per stage when parameters vary along the horizon)
+        # (the equation lists themselves are kept in the cache entry: an id is only unique among live objects)
         stamp = (id(self._ode), id(self._meas), self.erk_order, self.n_sub, self.dt, self.discrete)
         cache = getattr(self, '_sysmat_cache', None)
-        if cache is None or cache[0] != stamp:
+        if cache is None or cache[0] != stamp or cache[4] is not self._ode or cache[5] is not self._meas:
             g, jac, n_rows = self._jacobian_program()
-            self._sysmat_cache = cache = (stamp, g, jac, n_rows)
-        _, g, jac, n_rows = cache
+            self._sysmat_cache = cache = (stamp, g, jac, n_rows, self._ode, self._meas)
+        _, g, jac, n_rows = cache[:4]
         xe = getattr(self, '_x_eq', None)
         ue = getattr(self, '_u_eq', None)
         xe = np.zeros(self.n_x) if xe is None else xe
