@@ -556,6 +556,25 @@ struct NmpcUser {
         const double gv = term_cost(pc, pr, sdN, xj).a;
         lam[m] -= last ? gv : 0.0;
       }
+      // hard terminal rows act on the integrated end state as well (mpc.py:1693-1700: x_end = sum_j D_j x_{N-1,j}): the collocation
+      // rows of the last interval see  - D_i sum_r nu_r sign_r grad c_r(x_end)  next to D_i lambda
+      if constexpr (F::NTEXPR > 0) {
+        const bool lastc = k == N - 1;
+#pragma unroll
+        for (int m = 0; m < MXA; ++m) {
+          Jet2 xe[MXA], ue[MUA > 0 ? MUA : 1], ct[F::NTEXPR];
+#pragma unroll
+          for (int i = 0; i < MXA; ++i) xe[i] = Jet2(row[N * MXA + i] * pc.sz[i], i == m ? pc.sz[i] : 0.0, 0.0);
+#pragma unroll
+          for (int q = 0; q < MUA; ++q) ue[q] = Jet2(u[q]);
+          F::tcon(xe, ue, p, ct);
+          double acc = 0.0;
+          for (int r = 0; r < ntc; ++r)
+            acc += lamc[b * (int64_t)(N * cstride + ntc) + (int64_t)(N - 1) * cstride + MXA + r] * pc.cost[L.o_trows + r] *
+                   pick<F::NTEXPR>(ct, (int)pc.cost[L.o_trowx + r]).a;
+          lam[m] -= lastc ? acc : 0.0;
+        }
+      }
     }
     // multipliers of the engine's rows of this interval: node rows [0, nrow), point i rows [(i + 1) nrow, (i + 2) nrow)
     const double* nu = lrow + MXA + (k == N - 1 ? ntc : 0);

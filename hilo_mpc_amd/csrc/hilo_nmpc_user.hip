@@ -41,8 +41,8 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   HILO_REQUIRE(!D || !discrete, "hilo_nmpc_create: collocation needs the continuous model");
   const bool cont = d->objective_continuous != 0 && !discrete;
   HILO_REQUIRE(!(cont && D) || d->coll_B, "hilo_nmpc_create: the continuous objective with collocation needs coll_B");
-  if (D && d->n_tcon > 0)
-    return fail(HILO_ENOTSUP, "collocation together with a nonlinear terminal constraint is not built");
+  if (D && d->n_tcon > 0 && d->tcon_soft)
+    return fail(HILO_ENOTSUP, "collocation together with a SOFT terminal constraint is not built (hard ones are)");
   // ---- inequality rows (same construction as hilo_nmpc.hip) ----
   int ne = 0, nrow = 0, n_con_ref = 0, ntrow = 0, n_tcon_ref = 0, ne_stage = 0;
   int row_expr[OCP_MAXNC], row_sign[OCP_MAXNC], row_e[OCP_MAXNC], row_ref[OCP_MAXNC];

@@ -60,7 +60,7 @@ class GenCollProblem(NmpcProblem):
     quirk restated in oracle/nmpc_coll.py)."""
 
     def __init__(self, model, dt, N, degree=3, points='radau', objective='continuous', path=None, constraint=None,
-                 generic_stage=None, z_guess=None, z_lb=None, z_ub=None, **kw):
+                 generic_stage=None, z_guess=None, z_lb=None, z_ub=None, terminal=None, **kw):
         kw.pop('order', None)
         super().__init__(model, dt, N, **kw)
         assert not model.discrete and objective in ('continuous', 'discrete')
@@ -226,6 +226,26 @@ class GenCollProblem(NmpcProblem):
         self._V = _lam([V], [xN])
         self._gV = _lam([sp.diff(V, a) for a in xN], [xN])
         self._HV = _lam([[sp.diff(V, a, b) for b in xN] for a in xN], [xN])
+        # ---- hard terminal constraint (mpc.py:1693-1700): rows on the integrated end state x_end of the last interval, between its
+        # continuity rows and its node rows in g.  Restated on the variable x_N (x_N = x_end at every feasible point) like the Mayer
+        # term above: the multiplier of the last continuity row is handed out in the reference's convention, lambda + grad V +
+        # (grad c_t)' nu_t (GenCollIpm.lam_g).  terminal = dict(expr=[...], lb, ub) in the model's (un-scaled) states.
+        self.trows = []                                              # (expression index, lb, ub)
+        self.n_tcon_ref = 0
+        if terminal:
+            tex = [_parse(e, names) for e in terminal['expr']]
+            self.n_tcon_ref = len(tex)
+            tlb = np.broadcast_to(np.asarray(terminal.get('lb', -INF), dtype=float), (len(tex),))
+            tub = np.broadcast_to(np.asarray(terminal.get('ub', INF), dtype=float), (len(tex),))
+            self.trows = [(j, tlb[j], tub[j]) for j in range(len(tex)) if np.isfinite(tlb[j]) or np.isfinite(tub[j])]
+            subN = {m.x[a]: self.sx[a] * xN[a] for a in range(nx)}
+            T = [tex[j].subs(subN, simultaneous=True) for j, _, _ in self.trows]
+            lt = [sp.Symbol(f'lt{r}') for r in range(len(T))]
+            self._T = _lam(T, [xN, m.p])
+            self._JT = _lam(sp.Matrix(T).jacobian(xN).tolist(), [xN, m.p])
+            LT = sum(a * b for a, b in zip(lt, T))
+            self._HT = _lam([[sp.diff(LT, a, b) for b in xN] for a in xN], [xN, m.p, lt])
+        self.ntrow = len(self.trows)
         # ---- reference layout (mpc.py:1462-1548) ----
         off = (N + 1) * nxa
         self.x_ind = [list(range(k * nxa, (k + 1) * nxa)) for k in range(N + 1)]
@@ -242,7 +262,7 @@ class GenCollProblem(NmpcProblem):
                 off += d * nzg
         self.e_ind = list(range(off, off + ne))
         self.n_v = off + ne
-        self.n_g = N * (d * self.n_con_ref + d * (nxa + nzg) + nxa + self.n_con_ref)
+        self.n_g = N * (d * self.n_con_ref + d * (nxa + nzg) + nxa + self.n_con_ref) + self.n_tcon_ref
 
 
 class GenCollIpm(DenseIpm):
@@ -259,17 +279,19 @@ class GenCollIpm(DenseIpm):
         self.o_e = self.o_c + N * self.blk
         self.o_s = self.o_e + ne
         self.ns = (d + 1) * nrow
-        self.nw = self.o_s + N * self.ns
+        self.o_t = self.o_s + N * self.ns                            # slacks of the terminal rows
+        self.nw = self.o_t + pb.ntrow
         self.mk = pb.mk
-        self.m = N * self.mk
+        self.m = N * self.mk + pb.ntrow
         zl, zu = pb.z_lb, pb.z_ub
         blk_lb = np.concatenate([np.tile(pb.x_lb, d), np.tile(zl, d)])
         blk_ub = np.concatenate([np.tile(pb.x_ub, d), np.tile(zu, d)])
         slb = np.array([r[3] for r in pb.rows] * (d + 1))
         sub = np.array([r[4] for r in pb.rows] * (d + 1))
-        lb = np.concatenate([pb.x_lb[pb.nx:], np.tile(pb.x_lb, N), np.tile(pb.u_lb, N), np.tile(blk_lb, N), np.zeros(ne), np.tile(slb, N)])
+        lb = np.concatenate([pb.x_lb[pb.nx:], np.tile(pb.x_lb, N), np.tile(pb.u_lb, N), np.tile(blk_lb, N), np.zeros(ne), np.tile(slb, N),
+                             np.array([r[1] for r in pb.trows])])
         ub = np.concatenate([pb.x_ub[pb.nx:], np.tile(pb.x_ub, N), np.tile(pb.u_ub, N), np.tile(blk_ub, N),
-                             pb.e_ub if ne else np.zeros(0), np.tile(sub, N)])
+                             pb.e_ub if ne else np.zeros(0), np.tile(sub, N), np.array([r[2] for r in pb.trows])])
         r = o.bound_relax_factor
         self.lb = np.where(np.isfinite(lb), lb - r * np.maximum(1, np.abs(lb)), lb)
         self.ub = np.where(np.isfinite(ub), ub + r * np.maximum(1, np.abs(ub)), ub)
@@ -299,7 +321,7 @@ class GenCollIpm(DenseIpm):
         U = w[:, self.o_u:self.o_c].reshape(B, N, nua)
         blk = w[:, self.o_c:self.o_e].reshape(B, N, self.blk)
         E = w[:, self.o_e:self.o_s]
-        S = w[:, self.o_s:].reshape(B, N, self.ns)
+        S = w[:, self.o_s:self.o_t].reshape(B, N, self.ns)
         return X, U, blk, E, S
 
     def _q(self, X, U, blk, E, S, k):
@@ -325,7 +347,10 @@ class GenCollIpm(DenseIpm):
             f += pb._cost(*a)[:, 0]
             if pb.ne:
                 f += np.einsum('bi,ij,bj->b', E, pb.We, E)                              # mpc.py:1708: once per interval
-        return f + pb._V(X[:, N])[:, 0], c.reshape(B, -1)
+        c = c.reshape(B, -1)
+        if pb.ntrow:
+            c = np.concatenate([c, pb._T(X[:, N], data['p']) - w[:, self.o_t:]], axis=1)
+        return f + pb._V(X[:, N])[:, 0], c
 
     def eval_all(self, w, lam, data):
         pb = self.pb
@@ -337,7 +362,8 @@ class GenCollIpm(DenseIpm):
         c = np.empty((B, N, self.mk))
         J = np.zeros((B, self.m, self.nw))
         W = np.zeros((B, self.nw, self.nw))
-        lam = lam.reshape(B, N, self.mk)
+        lamT = lam[:, N * self.mk:]
+        lam = lam[:, :N * self.mk].reshape(B, N, self.mk)
         ecols = list(range(self.o_e, self.o_s))
         for k in range(N):
             a = self._args(self._q(X, U, blk, E, S, k), data, k, lam[:, k])
@@ -362,7 +388,15 @@ class GenCollIpm(DenseIpm):
         f += pb._V(X[:, N])[:, 0]
         g[:, xi] += pb._gV(X[:, N])
         W[np.ix_(bi, xi, xi)] += pb._HV(X[:, N])
-        return f, g, c.reshape(B, -1), J, W
+        c = c.reshape(B, -1)
+        if pb.ntrow:
+            trows = list(range(N * self.mk, self.m))
+            c = np.concatenate([c, pb._T(X[:, N], data['p']) - w[:, self.o_t:]], axis=1)
+            J[np.ix_(bi, trows, xi)] += pb._JT(X[:, N], data['p'])
+            for r in range(pb.ntrow):
+                J[:, N * self.mk + r, self.o_t + r] = -1.0
+            W[np.ix_(bi, xi, xi)] += pb._HT(X[:, N], data['p'], lamT)
+        return f, g, c, J, W
 
     def start(self, x0, data):
         """w_0 of the reference's guess (mpc.py:1468-1537): states / inputs / collocation blocks tiled, slacks of the soft
@@ -378,14 +412,15 @@ class GenCollIpm(DenseIpm):
         pb, o = self.pb, self.o
         B = w0.shape[0]
         w0 = _push_interior(w0, self.lb[:self.o_s], self.ub[:self.o_s], o)
-        if not pb.nrow:
+        if not pb.nrow and not pb.ntrow:
             return w0
-        wz = np.concatenate([w0, np.zeros((B, pb.N * self.ns))], axis=1)
+        wz = np.concatenate([w0, np.zeros((B, pb.N * self.ns + pb.ntrow))], axis=1)
         _, c = self.eval_fc(wz, data)
-        c = c.reshape(B, pb.N, self.mk)
+        cT = c[:, pb.N * self.mk:]
+        c = c[:, :pb.N * self.mk].reshape(B, pb.N, self.mk)
         d, nrow = pb.d, pb.nrow
         s0 = np.concatenate([c[:, :, :d * nrow], c[:, :, self.mk - nrow:]], axis=2)         # rows = d(w) - s with s = 0
-        return np.concatenate([w0, s0.reshape(B, -1)], axis=1)
+        return np.concatenate([w0, s0.reshape(B, -1), cT], axis=1)
 
     def solve(self, x0, p, w0=None, u_old=None, verbose=False):
         pb = self.pb
@@ -399,6 +434,7 @@ class GenCollIpm(DenseIpm):
         res = self.solve_data(data, self._with_slacks(w0, data), verbose)
         X, U, blk, E, S = self._unpack(res['w'], x0)
         d, nxa, nzg = pb.d, pb.nxa, pb.nzalg
+        res['p_data'] = p
         res.update(X=X, U=U, E=E, S=S, Xc=blk[:, :, :d * nxa].reshape(B, pb.N, d, nxa),
                    Zc=blk[:, :, d * nxa:].reshape(B, pb.N, d, nzg), u0=U[:, 0, :pb.nu] * pb.su, x0=x0)
         return res
@@ -432,7 +468,8 @@ class GenCollIpm(DenseIpm):
         pb = self.pb
         B = res['lam'].shape[0]
         d, nrow, ncr, nxa, nzg = pb.d, pb.nrow, pb.n_con_ref, pb.nxa, pb.nzalg
-        lam = res['lam'].reshape(B, pb.N, self.mk)
+        lamT = res['lam'][:, pb.N * self.mk:]
+        lam = res['lam'][:, :pb.N * self.mk].reshape(B, pb.N, self.mk)
         per = d * ncr + d * (nxa + nzg) + nxa + ncr
         out = np.zeros((B, pb.N, per))
         for i in range(d):
@@ -443,4 +480,16 @@ class GenCollIpm(DenseIpm):
         for r, row in enumerate(pb.rows):
             out[:, :, d * ncr + nb + row[5]] = lam[:, :, d * nrow + nb + r]
         out[:, -1, d * ncr + d * (nxa + nzg):d * ncr + nb] += pb._gV(res['X'][:, pb.N])
-        return out.reshape(B, -1)
+        if not pb.n_tcon_ref:
+            return out.reshape(B, -1)
+        # terminal rows: between the continuity rows and the node rows of the last interval; their pull on x_end joins the
+        # multiplier of that interval's continuity rows
+        p = res.get('p_data')
+        JT = pb._JT(res['X'][:, pb.N], p)
+        out[:, -1, d * ncr + d * (nxa + nzg):d * ncr + nb] += np.einsum('br,bri->bi', lamT, JT)
+        lt = np.zeros((B, pb.n_tcon_ref))
+        for r, (j, _, _) in enumerate(pb.trows):
+            lt[:, j] = lamT[:, r]
+        flat = out.reshape(B, -1)
+        cut = (pb.N - 1) * per + d * ncr + nb
+        return np.concatenate([flat[:, :cut], lt, flat[:, cut:]], axis=1)

@@ -377,10 +377,10 @@ C5DS = dict(C5D, N=10)
 def oracle_coll_gen(spec):
     from oracle import models
     from oracle.nmpc_coll_gen import GenCollProblem
-    kw = {k: v for k, v in spec.items() if k not in ('model', 'p', 'order', 'collocation')}
+    kw = {k: v for k, v in spec.items() if k not in ('model', 'p', 'order', 'collocation', 'terminal_constraint')}
     co = spec.get('collocation', {})
     return GenCollProblem(models.get(spec['model']), degree=co.get('degree', 3), points=co.get('points', 'radau'),
-                          objective=co.get('objective', 'continuous'), **kw)
+                          objective=co.get('objective', 'continuous'), terminal=spec.get('terminal_constraint'), **kw)
 
 
 # ---- stochastic NMPC: the reference's own test systems (tests/test_SMPC.py) and a nonlinear one -------------

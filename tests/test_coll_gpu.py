@@ -241,3 +241,38 @@ def test_explicit_runge_kutta_inside_the_nmpc_with_the_continuous_objective():
     sol = minimize(lambda q: rollout(q)[0], w, method='SLSQP', bounds=list(zip(lb, ub)),
                    constraints=[{'type': 'eq', 'fun': lambda q: rollout(q)[1]}], options={'ftol': 1e-12, 'maxiter': 100})
     assert sol.fun >= J - 1e-7 * abs(J) and np.abs(sol.x - w).max() < 5e-4
+
+
+def test_hard_terminal_constraint_under_collocation_vs_oracle():
+    """A hard terminal constraint with the reference's default integration method (mpc.py:1693-1700 in the collocation branch: rows
+    on the end state of the last interval, in g between its continuity rows and its node rows) - an EQUALITY (lb = ub) on a product
+    of two states and a lower bound, both binding.  The engine imposes the rows on the integrated end state like the reference; the
+    output pass adds their pull to the collocation rows of the last interval.  v 1e-6, objective 1e-9, multipliers 1e-5."""
+    from oracle.nmpc import IpmOptions
+    from oracle.nmpc_coll_gen import GenCollIpm
+    from tests.problems import oracle_coll_gen, product_gen
+    spec = dict(C2, N=6, collocation=dict(degree=3))
+    x0 = c2_x0(4)
+    free = GenCollIpm(oracle_coll_gen(spec), IpmOptions(tol=1e-10))
+    xN = free.solve(x0, spec['p'])['X'][:, -1] * free.pb.sx
+    prod, smin = float((xN[:, 3] * xN[:, 1]).mean()), float(xN[:, 1].max() * 1.002)
+    spec['terminal_constraint'] = dict(expr=['I*S', 'S'], lb=[prod, smin], ub=[prod, np.inf])
+    pb = oracle_coll_gen(spec)
+    ipm = GenCollIpm(pb, IpmOptions(tol=1e-10))
+    ref = ipm.solve(x0, spec['p'])
+    assert np.all(ref['status'] == 1)
+    nmpc = product_gen(spec, **{'ipopt.tol': 1e-10})
+    assert (nmpc._n_v, nmpc._n_g) == (pb.n_v, pb.n_g)
+    u = nmpc.optimize(x0, cp=spec['p'])
+    assert np.all(nmpc.solver_status_code == 1)
+    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), ipm.to_v(ref)
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 1e-6
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-9)
+    np.testing.assert_allclose(u, ref['u0'], rtol=1e-6, atol=1e-8)
+    lam, lr = nmpc._nlp_solution['lam_g'].cpu().numpy(), ipm.lam_g(ref)
+    assert np.max(np.abs(lam - lr) / np.maximum(1., np.abs(lr))) < 1e-5
+    per = (pb.n_g - 2) // pb.N
+    lt = lam[:, (pb.N - 1) * per + 3 * 4 + 4:(pb.N - 1) * per + 3 * 4 + 4 + 2]
+    assert np.all(np.abs(lt[:, 0]) > 1e-4)                                  # the equality carries force
+    xe = v[:, pb.x_ind[-1]]
+    assert np.all(np.abs(xe[:, 3] * xe[:, 1] - prod) < 1e-6 * prod) and np.all(xe[:, 1] >= smin - 1e-6)

@@ -96,3 +96,46 @@ def test_derivatives_equal_finite_differences_and_slsqp_agrees():
             # (degree 1 with the continuous objective: theta_0 and u_theta,0 only enter through theta_0 + dt u_theta,0 - the
             # minimiser is a segment, an interior-point method lands on its analytic centre, an SQP method anywhere on it)
             np.testing.assert_allclose(res.x[:ipm.o_s], w[0, :ipm.o_s], rtol=1e-4, atol=2e-5)
+
+
+def test_hard_terminal_constraint_rows():
+    """mpc.py:1693-1700 under collocation: hard rows on the end state of the last interval, in g between its continuity rows and
+    its node rows.  (1) with bounds that do not bind the solution is the unconstrained one; (2) with binding bounds the rows hold,
+    the stationarity of the oracle's own NLP holds by central differences of its f and rows (independent of its analytic
+    derivatives), and the multiplier of the last continuity rows carries grad c_t' nu_t in the reference's convention."""
+    spec = dict(C2, N=4)
+    kw = {k: v for k, v in spec.items() if k not in ('model', 'p', 'order')}
+    m = models.get('chemostat4')
+    x0 = c2_x0(2)
+    o = IpmOptions(tol=1e-10)
+    free = GenCollIpm(GenCollProblem(m, degree=2, **kw), o)
+    r0 = free.solve(x0, spec['p'])
+    xN = r0['X'][:, -1] * free.pb.sx
+    loose = GenCollIpm(GenCollProblem(m, degree=2, terminal=dict(expr=['I*S', 'S'], lb=[-1e3, -np.inf], ub=[np.inf, 1e6]), **kw), o)
+    r1 = loose.solve(x0, spec['p'])
+    np.testing.assert_allclose(loose.to_v(r1), free.to_v(r0), rtol=1e-8, atol=1e-10)
+    # binding: an EQUALITY on the product I * S (the mean of the free solutions' values) and the substrate at the end above the free
+    # solutions' - both within reach of the two feeds
+    prod, smin = float((xN[:, 3] * xN[:, 1]).mean()), float(xN[:, 1].max() * 1.002)
+    pb = GenCollProblem(m, degree=2, terminal=dict(expr=['I*S', 'S'], lb=[prod, smin], ub=[prod, np.inf]), **kw)
+    ipm = GenCollIpm(pb, o)
+    r = ipm.solve(x0, spec['p'])
+    assert np.all(r['status'] == 1) and pb.n_g == free.pb.n_g + 2 and ipm.lam_g(r).shape == (2, pb.n_g)
+    xe = r['X'][:, -1] * pb.sx
+    assert np.all(xe[:, 1] >= smin - 1e-6) and np.all(np.abs(xe[:, 3] * xe[:, 1] - prod) < 1e-6 * prod) and np.all(r['f'] > r0['f'])
+    data = {'x0': r['x0'], 'p': r['p_data']}
+    for b in range(2):
+        w = r['w'][b]
+        fc = lambda q: ipm.eval_fc(q[None], {k: v[b:b + 1] for k, v in data.items()})          # noqa: E731
+        g = np.zeros(ipm.nw)
+        for i in range(ipm.nw):
+            e = np.zeros(ipm.nw)
+            e[i] = 1e-6 * max(1., abs(w[i]))
+            (fp, cp), (fm, cm) = fc(w + e), fc(w - e)
+            g[i] = ((fp[0] - fm[0]) + r['lam'][b] @ (cp[0] - cm[0])) / (2 * e[i])
+        at = (w - ipm.lb < 1e-6) | (ipm.ub - w < 1e-6)
+        assert np.abs(g[~at]).max() < 2e-6 and np.abs(fc(w)[1]).max() < 1e-8
+    lg = ipm.lam_g(r).reshape(2, -1)
+    per = (pb.n_g - 2) // pb.N
+    lt = lg[:, (pb.N - 1) * per + 2 * 4 + 4:(pb.N - 1) * per + 2 * 4 + 4 + 2]                    # [coll rows (d nx) | continuity (nx) | terminal]
+    assert np.all(np.abs(lt[:, 0]) > 1e-4)                                                       # the equality carries force
