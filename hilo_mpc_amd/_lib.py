@@ -51,7 +51,7 @@ class NmpcDesc(C.Structure):
                [(n, C.c_int32) for n in ('user_nx', 'user_nu', 'user_np', 'user_ny', 'user_discrete', 'user_has_fun', 'user_policy',
                                          'objective_continuous')] + \
                [('coll_B', C.c_void_p), ('n_user_gp', C.c_int32), ('user_nz', C.c_int32), ('user_gp', C.c_void_p * 4),
-                ('hess_pattern', C.c_void_p), ('max_hessian_perturbation', C.c_double), ('n_zbound', C.c_int32), ('reserved5', C.c_int32),
+                ('hess_pattern', C.c_void_p), ('max_hessian_perturbation', C.c_double), ('n_zbound', C.c_int32), ('x0_free_mask', C.c_int32),
                 ('zb_lb', C.c_void_p), ('zb_ub', C.c_void_p)]
 
 

@@ -268,6 +268,7 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
           set_pair(mxa + a, mxa + b);
   }
   for (int i = mx; i < mxa + ne; ++i) c.x0_free_mask |= 1u << i;           // theta_0 and the slacks are variables (mpc.py:785-789)
+  c.x0_free_mask |= (unsigned)d->x0_free_mask & ((1u << mx) - 1u);         // model states declared free (desc.x0_free_mask)
   for (int a = 0; a < ne; ++a) c.k0_only_mask |= 1u << (mxa + a);          // one box per shared slack
   h->base_free_mask = c.x0_free_mask;
   // ---- boxes of the engine's z = [x | theta | e | uh | u | u_theta], scaled like mpc.py:253-259, relaxed like IPOPT ----

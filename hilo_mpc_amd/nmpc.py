@@ -474,7 +474,133 @@ class NMPC:
             _lib.check(_lib.lib().hilo_nmpc_reset_warm_start(self._handle))
 
     def minimize_final_time(self, weight=1):
-        raise NotImplementedError("minimum-time problems (the sampling intervals as variables, mpc.py:1014-1023) are not offloaded")
+        """mpc.py:859-866: the N sampling intervals become decision variables (the last block of `v`, bounds [0, inf), guess dt;
+        forced equal by N - 1 rows at the end of `g`, mpc.py:1746-1751) and J += weight * sum(dt) (:1754)."""
+        self._minimize_final_time_flag = True
+        self._minimize_final_time_weight = float(weight)
+
+    # ---- minimum-time problems ---------------------------------------------------------------------------------------------
+    # All intervals are forced equal, so the problem has ONE more degree of freedom: the common interval.  It is carried as an extra
+    # STATE r with r' = 0 and dt = r^2, on a normalised time axis - the model becomes x' = r^2 f(x, u, p) with sampling interval 1
+    # (identical collocation / Runge-Kutta equations: dt f = r^2 f), the reference's N - 1 equality rows ARE the continuity rows of
+    # r, the objective weight * dt_k is the quadratic stage cost weight * r^2 (integrated over an interval of length 1), and dt >= 0
+    # holds by construction.  r_0 is a variable (desc.x0_free_mask).  Same minimiser and multipliers as the reference's NLP - the
+    # multipliers of its dt rows follow from the continuity multipliers of r, eta_k = -lambda^r_k / (2 r) - different iterates.
+    def _setup_min_time(self, options, solver_options):
+        from .model import Model
+        m = self._model
+        if not getattr(m, '_symbolic', False) or m.discrete or getattr(m, 'n_z', 0):
+            raise NotImplementedError("minimize_final_time needs a continuous model written as expressions without algebraic states")
+        if self.quad_stage_cost._is_set or self.stage_cost._is_set or self.terminal_cost._is_set or self._paths_var_list:
+            raise NotImplementedError("minimize_final_time together with further stage-cost terms or a path variable is not built "
+                                      "(their integrals would scale with the interval)")
+        if self._control_horizon != self._prediction_horizon or self._time_varying_parameters:
+            raise NotImplementedError("minimize_final_time with a shorter control horizon or time-varying parameters is not built")
+        rname = '_dt_root'
+        aug = Model(name=(m.name or 'model') + '_min_time')
+        xa = aug.set_dynamical_states(list(m.dynamical_state_names) + [rname])
+        aug.set_inputs(list(m.input_names))
+        aug.set_parameters(list(m.parameter_names))
+        r = xa[len(m.dynamical_state_names)]
+        aug.set_dynamical_equations([r * r * e for e in m._ode] + [0.0 * r])
+        if m._meas:
+            aug.set_measurement_equations(list(m._meas))
+        aug.setup(dt=1.0)
+        inner = NMPC(aug, device_index=self._dev_index)
+        inner.horizon = self._prediction_horizon
+        inner.quad_stage_cost.add_states(names=[rname], weights=[self._minimize_final_time_weight], ref=[0.])
+        for kind, ind, W, ref in self.quad_terminal_cost._terms:
+            if kind != 'states':
+                raise NotImplementedError("minimize_final_time: the terminal cost may contain states only")
+            inner.quad_terminal_cost.add_states(names=[m.dynamical_state_names[i] for i in ind], weights=W, ref=ref)
+        for mine, theirs in ((self.stage_constraint, inner.stage_constraint), (self.terminal_constraint, inner.terminal_constraint)):
+            if mine.is_set:
+                theirs.constraint, theirs.lb, theirs.ub = mine.constraint, mine.lb, mine.ub
+                theirs.is_soft, theirs.weight, theirs.max_violation = mine.is_soft, mine.weight, mine.max_violation
+        nx, dt = self._n_x, float(m.dt)
+        box = lambda v, fill, last: (list(np.full(nx, fill)) if v is None else list(v)) + [last]      # noqa: E731
+        inner.set_box_constraints(x_lb=box(self._x_lb, -np.inf, 0.), x_ub=box(self._x_ub, np.inf, np.inf), u_lb=self._u_lb, u_ub=self._u_ub)
+        inner.set_initial_guess(x_guess=box(self._x_guess, 0., np.sqrt(dt)), u_guess=self._u_guess)
+        if self._x_scaling is not None or self._u_scaling is not None:
+            inner.set_scaling(x_scaling=None if self._x_scaling is None else list(self._x_scaling) + [1.], u_scaling=self._u_scaling)
+        inner._x0_free_mask = 1 << nx
+        inner.setup(options=options, solver_options=solver_options)
+        if os.environ.get('HILO_JIT_COMPILE_ONLY'):
+            return
+        self._mt = inner
+        N, nu, na = self._prediction_horizon, self._n_u, nx + 1
+        d = 0 if inner._ip_ind == [] else len(inner._ip_ind[0]) // na
+        ne = len(getattr(inner, '_e_soft_stage_ind', []) or [])
+        # index maps of the reference's layout (mpc.py:1462-1548; the dt block last, :1606-1617)
+        self._x_ind = [list(range(k * nx, (k + 1) * nx)) for k in range(N + 1)]
+        off = (N + 1) * nx
+        self._u_ind = [list(range(off + k * nu, off + (k + 1) * nu)) for k in range(N)]
+        off += N * nu
+        self._ip_ind = [list(range(off + k * d * nx, off + (k + 1) * d * nx)) for k in range(N)] if d else []
+        off += N * d * nx
+        self._e_soft_stage_ind = list(range(off, off + ne))
+        off += ne
+        self._dt_ind = list(range(off, off + N))
+        self._n_v = off + N
+        # columns of the inner v that survive, in the reference's order
+        keep = [i for k in range(N + 1) for i in inner._x_ind[k][:nx]] + [i for k in range(N) for i in inner._u_ind[k]]
+        for k in range(N):
+            blk = inner._ip_ind[k] if d else []
+            keep += [blk[i * na + a] for i in range(d) for a in range(nx)]
+        keep += list(getattr(inner, '_e_soft_stage_ind', []) or [])
+        self._mt_keep = keep
+        self._mt_r = [inner._x_ind[k][nx] for k in range(N)]
+        # rows of the inner lam_g: per interval [d R | d na collocation | na continuity | (terminal, last) | R]
+        R = (inner._n_g - N * (d * na + na) - (self.terminal_constraint.size * (2 if self.terminal_constraint.is_soft else 1)
+                                                 if self.terminal_constraint.is_set else 0)) // (N * (d + 1)) if N else 0
+        TR = (self.terminal_constraint.size * (2 if self.terminal_constraint.is_soft else 1)) if self.terminal_constraint.is_set else 0
+        rows, rrow, pos = [], [], 0
+        for k in range(N):
+            rows += list(range(pos, pos + d * R))
+            pos += d * R
+            for i in range(d):
+                rows += list(range(pos, pos + nx))
+                pos += na
+            rows += list(range(pos, pos + nx))
+            rrow.append(pos + nx)
+            pos += na
+            if k == N - 1:
+                rows += list(range(pos, pos + TR))
+                pos += TR
+            rows += list(range(pos, pos + R))
+            pos += R
+        assert pos == inner._n_g, (pos, inner._n_g)
+        self._mt_rows, self._mt_rrow = rows, rrow
+        self._n_g = len(rows) + max(0, N - 1)
+        self._nlp_setup_done = True
+        self._dev = inner._dev
+        self._sx, self._su = inner._sx[:nx], inner._su
+        self._nth = 0
+
+    def _optimize_min_time(self, x0, cp, kwargs):
+        inner = self._mt
+        host = not isinstance(x0, torch.Tensor)
+        x = to_dev(x0, inner._dev)
+        single = x.ndim <= 1 or (x.ndim == 2 and x.shape[1] == 1 and x.shape[0] == self._n_x and self._n_x != 1)
+        x = x.reshape(1, -1) if single else x
+        if x.shape[1] != self._n_x:
+            raise ValueError(f"We have an issue mate, the x0 you supplied has dimension {x.shape[1]} but the model has "
+                             f"{self._n_x} states.")
+        xa = torch.cat([x, torch.full((x.shape[0], 1), float(np.sqrt(self._model.dt)), dtype=torch.float64, device=x.device)], dim=1)
+        u = inner.optimize(xa, cp=cp)
+        s = inner._nlp_solution
+        v = s['x']
+        r = v[:, self._mt_r]
+        lam = s['lam_g']
+        eta = -lam[:, self._mt_rrow[:-1]] / (2.0 * r[:, :-1])
+        self._nlp_solution = {'x': torch.cat([v[:, self._mt_keep], r * r], dim=1), 'f': s['f'],
+                              'lam_g': torch.cat([lam[:, self._mt_rows], eta], dim=1), 'status': s['status'],
+                              'iter_count': s['iter_count'], 'kkt_error': s.get('kkt_error')}
+        self._time += self._sampling_interval
+        self._n_iterations += 1
+        if host:
+            u = u if isinstance(u, np.ndarray) else u.cpu().numpy()
+        return u
 
     def set_custom_constraints_function(self, fun=None, lb=None, ub=None, soft=False, max_violation=np.inf):
         raise NotImplementedError("a custom constraint is a function of the WHOLE decision vector (mpc.py:1729-1745): it couples "
@@ -644,6 +770,8 @@ class NMPC:
             raise ValueError("You must set a prediction horizon length before")
         if self._control_horizon is None:
             raise ValueError("You must set a control horizon length before.")
+        if getattr(self, '_minimize_final_time_flag', False):
+            return self._setup_min_time(options, solver_options)
         if not (self.quad_stage_cost._is_set or self.quad_terminal_cost._is_set or self.stage_cost._is_set or
                 self.terminal_cost._is_set):
             raise ValueError("You need to define a cost function before setting up the mpc.")
@@ -882,6 +1010,7 @@ class NMPC:
                 self._hess_pattern = pat
             self._user_source = src
             d.user_source = src.encode()
+            d.x0_free_mask = int(getattr(self, '_x0_free_mask', 0))
             d.user_policy = policy
             d.user_nx, d.user_nu, d.user_np, d.user_ny = m.n_x, m.n_u, m.n_p, m.n_y
             d.user_discrete = int(getattr(m, '_native_discrete', False))
@@ -966,6 +1095,10 @@ class NMPC:
     def optimize(self, x0, cp=None, tvp=None, v0=None, runs=0, fix_x0=True, **kwargs):
         if not self._nlp_setup_done:
             raise ValueError("Howdy! You need to setup the MPC before optimizing. Run .setup() on the MPC object.")
+        if getattr(self, '_mt', None) is not None:
+            if v0 is not None or runs != 0 or not fix_x0 or tvp is not None:
+                raise NotImplementedError("minimize_final_time: v0 / runs / fix_x0=False / tvp are not built")
+            return self._optimize_min_time(x0, cp, kwargs)
         if runs != 0:
             return self._multi_start(x0, cp, tvp, v0, int(runs), fix_x0, kwargs)
         box = None
@@ -1373,6 +1506,11 @@ class NMPC:
             warnings.warn("There is still no mpc solution available. Run mpc.optimize() to get one.")
             return None, None, None
         v = self._nlp_solution['x'].cpu().numpy()
+        if getattr(self, '_mt', None) is not None:                    # mpc.py:1818-1820: the sampling intervals as third value
+            N, nx, nu = self._prediction_horizon, self._n_x, self._n_u
+            X = v[:, :(N + 1) * nx].reshape(-1, N + 1, nx) * np.asarray(self._sx)
+            U = v[:, (N + 1) * nx:(N + 1) * nx + N * nu].reshape(-1, N, nu) * np.asarray(self._su)
+            return np.swapaxes(X, 1, 2), np.swapaxes(U, 1, 2), v[:, self._dt_ind]
         N, Nc, nx, nu, nth = self._prediction_horizon, self._control_horizon, self._n_x, self._n_u, self._nth
         nxa, nua = nx + nth, nu + nth
         X = v[:, :(N + 1) * nxa].reshape(-1, N + 1, nxa) * np.concatenate([self._sx, np.ones(nth)])

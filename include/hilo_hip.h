@@ -342,7 +342,10 @@ typedef struct hilo_nmpc_desc {
      :1512-1518): UserFun::con evaluates n_zbound further expressions behind the n_con constraint expressions - the bounded
      algebraic states - which become rows at the collocation points only (the algebraic states are eliminated);
      they do not appear in lam_g */
-  int32_t n_zbound; int32_t reserved5;
+  int32_t n_zbound;
+  int32_t x0_free_mask;    /* run-time compiled problems: bit i set = component i of the model state x_0 is NOT pinned to the measured
+                              state but a variable inside the state box (the sampling-interval state of a minimum-time problem,
+                              hilo_mpc_amd/nmpc.py::_setup_min_time); 0 = all of x_0 is pinned (mpc.py:785-789) */
   const double* zb_lb; const double* zb_ub;        /* [n_zbound]; -inf / +inf allowed on one side */
 } hilo_nmpc_desc;
 

@@ -282,7 +282,15 @@ def cstr3():
     return OracleModel('cstr3', MODEL_CSTR3, [CA, CB, T], [Q], [], [dCA, dCB, dT], [r])
 
 
+def racecar2():
+    """The model of the reference's minimum-time test (tests/test_NMPC.py:2706-2735): position and speed of a car, p' = v,
+    v' = u - v."""
+    pp, v, u = sp.symbols('p v u')
+    return OracleModel('racecar2', -1, [pp, v], [u], [], [v, u - v], [pp, v])
+
+
 ZOO = {
+    'racecar2': racecar2,
     'cstr3': cstr3,
     'linear2': linear2_kat,
     'toy1d': toy1d,

@@ -60,7 +60,7 @@ class GenCollProblem(NmpcProblem):
     quirk restated in oracle/nmpc_coll.py)."""
 
     def __init__(self, model, dt, N, degree=3, points='radau', objective='continuous', path=None, constraint=None,
-                 generic_stage=None, z_guess=None, z_lb=None, z_ub=None, terminal=None, **kw):
+                 generic_stage=None, z_guess=None, z_lb=None, z_ub=None, terminal=None, min_time=None, **kw):
         kw.pop('order', None)
         super().__init__(model, dt, N, **kw)
         assert not model.discrete and objective in ('continuous', 'discrete')
@@ -181,6 +181,12 @@ class GenCollProblem(NmpcProblem):
                 out.append(v)
             return out
 
+        # minimum-time problems (mpc.py:859-866, :1452-1453, :1606-1617, :1746-1754): the N sampling intervals are variables
+        # (the last block of v, bounds [0, inf), guess dt), forced equal by N - 1 rows dt_k - dt_{k+1} = 0 at the end of g;
+        # J += weight * sum(dt).  min_time = weight.
+        self.min_time = None if min_time is None else float(min_time)
+        dts = sp.Symbol('dtk') if self.min_time is not None else self.dt
+        self._dts = dts
         pts = [xk] + Xc
         R = []
         for i in range(1, d + 1):                                    # A: residuals at the collocation points
@@ -191,7 +197,7 @@ class GenCollProblem(NmpcProblem):
             if nth:
                 f.append(uk[nu])                                                                 # theta' = u_theta (mpc.py:1192)
             for a in range(nxa):
-                R.append(self.dt * f[a] - sum(self.C[j, i] * pts[j][a] for j in range(d + 1)))
+                R.append(dts * f[a] - sum(self.C[j, i] * pts[j][a] for j in range(d + 1)))
             R += [e.subs(sub, simultaneous=True) for e in m.alg]
         for a in range(nxa):                                         # C: continuity
             R.append(xk1[a] - sum(self.D[j] * pts[j][a] for j in range(d + 1)))
@@ -199,10 +205,14 @@ class GenCollProblem(NmpcProblem):
         self.mk = len(R)
         lam = [sp.Symbol(f'l{r}') for r in range(self.mk)]
         if objective == 'continuous':
-            cost = sum(self.dt * self.B[i] * lagrange(Xc[i - 1], uk) for i in range(1, d + 1))
+            cost = sum(dts * self.B[i] * lagrange(Xc[i - 1], uk) for i in range(1, d + 1))
         else:
             cost = lagrange(xk, uk)
+        if self.min_time is not None:
+            cost = cost + self.min_time * dts
         qn = xk + uk + [s for row in Xc for s in row] + [s for row in Zc for s in row]          # enter non-linearly
+        if self.min_time is not None:
+            qn = qn + [dts]
         ql = es + ss + xk1                                                                      # enter linearly (rows); e^T W e is added apart
         self.nqn, self.nql = len(qn), len(ql)
         q = qn + ql
@@ -262,7 +272,9 @@ class GenCollProblem(NmpcProblem):
                 off += d * nzg
         self.e_ind = list(range(off, off + ne))
         self.n_v = off + ne
-        self.n_g = N * (d * self.n_con_ref + d * (nxa + nzg) + nxa + self.n_con_ref) + self.n_tcon_ref
+        self.dt_ind = list(range(self.n_v, self.n_v + N)) if self.min_time is not None else []
+        self.n_v += len(self.dt_ind)
+        self.n_g = N * (d * self.n_con_ref + d * (nxa + nzg) + nxa + self.n_con_ref) + self.n_tcon_ref + max(0, len(self.dt_ind) - 1)
 
 
 class GenCollIpm(DenseIpm):
@@ -280,18 +292,20 @@ class GenCollIpm(DenseIpm):
         self.o_s = self.o_e + ne
         self.ns = (d + 1) * nrow
         self.o_t = self.o_s + N * self.ns                            # slacks of the terminal rows
-        self.nw = self.o_t + pb.ntrow
+        self.o_dt = self.o_t + pb.ntrow                              # sampling intervals (minimum-time problems)
+        self.ndt = N if pb.min_time is not None else 0
+        self.nw = self.o_dt + self.ndt
         self.mk = pb.mk
-        self.m = N * self.mk + pb.ntrow
+        self.m = N * self.mk + pb.ntrow + max(0, self.ndt - 1)
         zl, zu = pb.z_lb, pb.z_ub
         blk_lb = np.concatenate([np.tile(pb.x_lb, d), np.tile(zl, d)])
         blk_ub = np.concatenate([np.tile(pb.x_ub, d), np.tile(zu, d)])
         slb = np.array([r[3] for r in pb.rows] * (d + 1))
         sub = np.array([r[4] for r in pb.rows] * (d + 1))
         lb = np.concatenate([pb.x_lb[pb.nx:], np.tile(pb.x_lb, N), np.tile(pb.u_lb, N), np.tile(blk_lb, N), np.zeros(ne), np.tile(slb, N),
-                             np.array([r[1] for r in pb.trows])])
+                             np.array([r[1] for r in pb.trows]), np.zeros(self.ndt)])
         ub = np.concatenate([pb.x_ub[pb.nx:], np.tile(pb.x_ub, N), np.tile(pb.u_ub, N), np.tile(blk_ub, N),
-                             pb.e_ub if ne else np.zeros(0), np.tile(sub, N), np.array([r[2] for r in pb.trows])])
+                             pb.e_ub if ne else np.zeros(0), np.tile(sub, N), np.array([r[2] for r in pb.trows]), np.full(self.ndt, np.inf)])
         r = o.bound_relax_factor
         self.lb = np.where(np.isfinite(lb), lb - r * np.maximum(1, np.abs(lb)), lb)
         self.ub = np.where(np.isfinite(ub), ub + r * np.maximum(1, np.abs(ub)), ub)
@@ -306,6 +320,8 @@ class GenCollIpm(DenseIpm):
             cx = [self.o_x + (k - 1) * pb.nxa + i for i in range(pb.nxa)]
         cu = [self.o_u + k * pb.nua + i for i in range(pb.nua)]
         cb = list(range(self.o_c + k * self.blk, self.o_c + (k + 1) * self.blk))
+        if self.ndt:
+            cb = cb + [self.o_dt + k]
         ce = list(range(self.o_e, self.o_s))
         cs = list(range(self.o_s + k * self.ns, self.o_s + (k + 1) * self.ns))
         cn = [self.o_x + k * pb.nxa + i for i in range(pb.nxa)]
@@ -322,9 +338,12 @@ class GenCollIpm(DenseIpm):
         blk = w[:, self.o_c:self.o_e].reshape(B, N, self.blk)
         E = w[:, self.o_e:self.o_s]
         S = w[:, self.o_s:self.o_t].reshape(B, N, self.ns)
+        self._dtv = w[:, self.o_dt:self.o_dt + self.ndt]
         return X, U, blk, E, S
 
     def _q(self, X, U, blk, E, S, k):
+        if self.ndt:
+            return np.concatenate([X[:, k], U[:, k], blk[:, k], self._dtv[:, k:k + 1], E, S[:, k], X[:, k + 1]], axis=1)
         return np.concatenate([X[:, k], U[:, k], blk[:, k], E, S[:, k], X[:, k + 1]], axis=1)
 
     def _args(self, q, data, k, lam):
@@ -349,7 +368,9 @@ class GenCollIpm(DenseIpm):
                 f += np.einsum('bi,ij,bj->b', E, pb.We, E)                              # mpc.py:1708: once per interval
         c = c.reshape(B, -1)
         if pb.ntrow:
-            c = np.concatenate([c, pb._T(X[:, N], data['p']) - w[:, self.o_t:]], axis=1)
+            c = np.concatenate([c, pb._T(X[:, N], data['p']) - w[:, self.o_t:self.o_dt]], axis=1)
+        if self.ndt > 1:
+            c = np.concatenate([c, self._dtv[:, :-1] - self._dtv[:, 1:]], axis=1)
         return f + pb._V(X[:, N])[:, 0], c
 
     def eval_all(self, w, lam, data):
@@ -362,7 +383,7 @@ class GenCollIpm(DenseIpm):
         c = np.empty((B, N, self.mk))
         J = np.zeros((B, self.m, self.nw))
         W = np.zeros((B, self.nw, self.nw))
-        lamT = lam[:, N * self.mk:]
+        lamT = lam[:, N * self.mk:N * self.mk + pb.ntrow]
         lam = lam[:, :N * self.mk].reshape(B, N, self.mk)
         ecols = list(range(self.o_e, self.o_s))
         for k in range(N):
@@ -390,12 +411,18 @@ class GenCollIpm(DenseIpm):
         W[np.ix_(bi, xi, xi)] += pb._HV(X[:, N])
         c = c.reshape(B, -1)
         if pb.ntrow:
-            trows = list(range(N * self.mk, self.m))
-            c = np.concatenate([c, pb._T(X[:, N], data['p']) - w[:, self.o_t:]], axis=1)
+            trows = list(range(N * self.mk, N * self.mk + pb.ntrow))
+            c = np.concatenate([c, pb._T(X[:, N], data['p']) - w[:, self.o_t:self.o_dt]], axis=1)
             J[np.ix_(bi, trows, xi)] += pb._JT(X[:, N], data['p'])
             for r in range(pb.ntrow):
                 J[:, N * self.mk + r, self.o_t + r] = -1.0
             W[np.ix_(bi, xi, xi)] += pb._HT(X[:, N], data['p'], lamT)
+        if self.ndt > 1:
+            c = np.concatenate([c, self._dtv[:, :-1] - self._dtv[:, 1:]], axis=1)
+            r0 = N * self.mk + pb.ntrow
+            for k in range(N - 1):
+                J[:, r0 + k, self.o_dt + k] = 1.0
+                J[:, r0 + k, self.o_dt + k + 1] = -1.0
         return f, g, c, J, W
 
     def start(self, x0, data):
@@ -408,19 +435,24 @@ class GenCollIpm(DenseIpm):
         w0 = np.broadcast_to(w0, (B, self.o_s))
         return w0
 
+    def _tail(self, B):
+        """the variables behind the row slacks that have a guess of their own: the sampling intervals (v_guess = dt, mpc.py:1614)"""
+        return np.full((B, self.ndt), self.pb.dt)
+
     def _with_slacks(self, w0, data):
         pb, o = self.pb, self.o
         B = w0.shape[0]
         w0 = _push_interior(w0, self.lb[:self.o_s], self.ub[:self.o_s], o)
+        tail = _push_interior(self._tail(B), self.lb[self.o_dt:], self.ub[self.o_dt:], o) if self.ndt else np.zeros((B, 0))
         if not pb.nrow and not pb.ntrow:
-            return w0
-        wz = np.concatenate([w0, np.zeros((B, pb.N * self.ns + pb.ntrow))], axis=1)
+            return np.concatenate([w0, tail], axis=1)
+        wz = np.concatenate([w0, np.zeros((B, pb.N * self.ns + pb.ntrow)), tail], axis=1)
         _, c = self.eval_fc(wz, data)
-        cT = c[:, pb.N * self.mk:]
+        cT = c[:, pb.N * self.mk:pb.N * self.mk + pb.ntrow]
         c = c[:, :pb.N * self.mk].reshape(B, pb.N, self.mk)
         d, nrow = pb.d, pb.nrow
         s0 = np.concatenate([c[:, :, :d * nrow], c[:, :, self.mk - nrow:]], axis=2)         # rows = d(w) - s with s = 0
-        return np.concatenate([w0, s0.reshape(B, -1), cT], axis=1)
+        return np.concatenate([w0, s0.reshape(B, -1), cT, tail], axis=1)
 
     def solve(self, x0, p, w0=None, u_old=None, verbose=False):
         pb = self.pb
@@ -435,6 +467,8 @@ class GenCollIpm(DenseIpm):
         X, U, blk, E, S = self._unpack(res['w'], x0)
         d, nxa, nzg = pb.d, pb.nxa, pb.nzalg
         res['p_data'] = p
+        if self.ndt:
+            res['dt'] = res['w'][:, self.o_dt:]
         res.update(X=X, U=U, E=E, S=S, Xc=blk[:, :, :d * nxa].reshape(B, pb.N, d, nxa),
                    Zc=blk[:, :, d * nxa:].reshape(B, pb.N, d, nzg), u0=U[:, 0, :pb.nu] * pb.su, x0=x0)
         return res
@@ -451,6 +485,8 @@ class GenCollIpm(DenseIpm):
             if pb.nzalg:
                 parts.append(res['Zc'][:, k].reshape(B, -1))
         parts.append(res['E'])
+        if self.ndt:
+            parts.append(res['w'][:, self.o_dt:])
         return np.concatenate(parts, axis=1)
 
     def w_from_v(self, v):
@@ -468,7 +504,8 @@ class GenCollIpm(DenseIpm):
         pb = self.pb
         B = res['lam'].shape[0]
         d, nrow, ncr, nxa, nzg = pb.d, pb.nrow, pb.n_con_ref, pb.nxa, pb.nzalg
-        lamT = res['lam'][:, pb.N * self.mk:]
+        lamT = res['lam'][:, pb.N * self.mk:pb.N * self.mk + pb.ntrow]
+        lamD = res['lam'][:, pb.N * self.mk + pb.ntrow:]
         lam = res['lam'][:, :pb.N * self.mk].reshape(B, pb.N, self.mk)
         per = d * ncr + d * (nxa + nzg) + nxa + ncr
         out = np.zeros((B, pb.N, per))
@@ -481,7 +518,7 @@ class GenCollIpm(DenseIpm):
             out[:, :, d * ncr + nb + row[5]] = lam[:, :, d * nrow + nb + r]
         out[:, -1, d * ncr + d * (nxa + nzg):d * ncr + nb] += pb._gV(res['X'][:, pb.N])
         if not pb.n_tcon_ref:
-            return out.reshape(B, -1)
+            return np.concatenate([out.reshape(B, -1), lamD], axis=1)
         # terminal rows: between the continuity rows and the node rows of the last interval; their pull on x_end joins the
         # multiplier of that interval's continuity rows
         p = res.get('p_data')
@@ -492,4 +529,4 @@ class GenCollIpm(DenseIpm):
             lt[:, j] = lamT[:, r]
         flat = out.reshape(B, -1)
         cut = (pb.N - 1) * per + d * ncr + nb
-        return np.concatenate([flat[:, :cut], lt, flat[:, cut:]], axis=1)
+        return np.concatenate([flat[:, :cut], lt, flat[:, cut:], lamD], axis=1)

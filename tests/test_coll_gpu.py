@@ -276,3 +276,65 @@ def test_hard_terminal_constraint_under_collocation_vs_oracle():
     assert np.all(np.abs(lt[:, 0]) > 1e-4)                                  # the equality carries force
     xe = v[:, pb.x_ind[-1]]
     assert np.all(np.abs(xe[:, 3] * xe[:, 1] - prod) < 1e-6 * prod) and np.all(xe[:, 1] >= smin - 1e-6)
+
+
+def _racecar(N, **solver_options):
+    """The reference's minimum-time test (tests/test_NMPC.py:2706-2760) with a shorter horizon."""
+    from hilo_mpc_amd import NMPC, Model
+    from hilo_mpc_amd.expr import sin
+    m = Model(name='racecar')
+    x = m.set_dynamical_states(['p', 'v'])
+    u = m.set_inputs(['u'])
+    m.set_dynamical_equations([x[1], u[0] - x[1]])
+    m.setup(dt=.1)
+    nmpc = NMPC(m)
+    nmpc.minimize_final_time(weight=1)
+    nmpc.horizon = N
+    nmpc.set_initial_guess(x_guess=[0, 0], u_guess=0.)
+    nmpc.set_terminal_constraints(terminal_constraint=m.x[0], lb=1, ub=1)
+    nmpc.set_stage_constraints(stage_constraint=m.x[1] - (1 - sin(2 * np.pi * m.x[0]) / 2), lb=-np.inf, ub=0)
+    nmpc.set_box_constraints(u_lb=0, u_ub=1)
+    nmpc.setup(solver_options=solver_options or None)
+    return nmpc
+
+
+def test_minimum_time_race_car_vs_oracle():
+    """`minimize_final_time` (mpc.py:859-866, :1606-1617, :1746-1754; the reference's own test tests/test_NMPC.py:2706-2760): the N
+    sampling intervals as variables forced equal, J = sum(dt), a terminal EQUALITY p(N) = 1, the speed limit v <= 1 - sin(2 pi p) / 2
+    at every collocation point and node, default options (collocation).  The product carries the common interval as a state r with
+    dt = r^2 (nmpc.py::_setup_min_time) and hands out the reference's layout: v with the dt block last, lam_g with the N - 1 dt rows
+    last.  Same minimiser as the oracle's NLP with dt variables (oracle/nmpc_coll_gen.py, min_time=): v 1e-6, f 1e-8, multipliers 1e-5;
+    the final time is the known ~1.9 s of this example."""
+    from oracle.nmpc import IpmOptions
+    from oracle.nmpc_coll_gen import GenCollIpm, GenCollProblem
+    N = 20
+    pb = GenCollProblem(models.get('racecar2'), dt=.1, N=N, degree=3, constraint=dict(expr=['v - (1 - sin(2*pi*p)/2)'], lb=[-np.inf], ub=[0.]),
+                        terminal=dict(expr=['p'], lb=[1.], ub=[1.]), min_time=1., u_lb=[0.], u_ub=[1.], x_guess=[0., 0.], u_guess=[0.])
+    ipm = GenCollIpm(pb, IpmOptions(tol=1e-10))
+    x0 = np.array([[0., 0.], [.02, .1]])
+    ref = ipm.solve(x0, [])
+    assert np.all(ref['status'] == 1) and abs(ref['dt'][0].sum() - 1.9065) < 1e-3
+    nmpc = _racecar(N, **{'ipopt.tol': 1e-10})
+    assert (nmpc._n_v, nmpc._n_g) == (pb.n_v, pb.n_g) and nmpc._dt_ind == pb.dt_ind and nmpc._x_ind == pb.x_ind and nmpc._u_ind == pb.u_ind
+    u = nmpc.optimize(x0)
+    assert np.all(nmpc.solver_status_code == 1)
+    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), ipm.to_v(ref)
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 1e-6
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-8)
+    np.testing.assert_allclose(u, ref['u0'], rtol=1e-6, atol=1e-7)
+    lam, lr = nmpc._nlp_solution['lam_g'].cpu().numpy(), ipm.lam_g(ref)
+    assert np.max(np.abs(lam - lr) / np.maximum(1., np.abs(lr))) < 1e-5
+    xp, up, dtp = nmpc.return_prediction()
+    assert dtp.shape == (2, N) and np.allclose(dtp, dtp[:, :1]) and abs(dtp[0].sum() - ref['dt'][0].sum()) < 1e-6
+    assert abs(xp[0, 0, -1] - 1.) < 1e-7                                   # the car is at p = 1 at the final time
+
+
+def test_minimum_time_with_the_reference_test_horizon():
+    """N = 100 as in tests/test_NMPC.py:2745 (no oracle at this size): solved, intervals equal, terminal position reached, the speed
+    limit kept at the nodes, final time within 1 % of the N = 20 problem's."""
+    nmpc = _racecar(100)
+    nmpc.optimize([0., 0.])
+    assert nmpc.solver_status_code[0] == 1
+    xp, up, dtp = nmpc.return_prediction()
+    assert np.allclose(dtp, dtp[:, :1], rtol=1e-9) and abs(dtp.sum() - 1.9065) < .02 and abs(xp[0, 0, -1] - 1.) < 1e-6
+    assert np.all(xp[0, 1] - (1 - np.sin(2 * np.pi * xp[0, 0]) / 2) < 1e-6) and np.all((up >= -1e-8) & (up <= 1 + 1e-8))

@@ -346,8 +346,11 @@ def test_controller_accessors_of_the_reference():
     assert nmpc.n_tvp == 1
     nmpc.set_nlp_solver('ipopt')
     nmpc.reset_solution()
-    with pytest.raises(NotImplementedError, match="minimum-time"):
-        nmpc.minimize_final_time()
+    nmpc.minimize_final_time(weight=2)                                  # mpc.py:859-866 (solved in tests/test_coll_gpu.py)
+    assert nmpc._minimize_final_time_flag and nmpc._minimize_final_time_weight == 2.
+    nmpc.horizon = 5
+    with pytest.raises(NotImplementedError, match="continuous model written as expressions"):
+        nmpc.setup()                                                    # (this controller sits on a model of the device zoo)
     with pytest.raises(NotImplementedError, match="WHOLE decision vector"):
         nmpc.set_custom_constraints_function(fun=lambda v, xi, ui: v[0])
 
