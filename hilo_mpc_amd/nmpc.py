@@ -473,6 +473,8 @@ class NMPC:
         if self._handle is not None:
             _lib.check(_lib.lib().hilo_nmpc_reset_warm_start(self._handle))
 
+    SUNDIALS_SUBSTEPS = 64    # Runge-Kutta sub-steps per interval behind integration_method 'cvodes' / 'idas'
+
     def minimize_final_time(self, weight=1):
         """mpc.py:859-866: the N sampling intervals become decision variables (the last block of `v`, bounds [0, inf), guess dt;
         forced equal by N - 1 rows at the end of `g`, mpc.py:1746-1751) and J += weight * sum(dt) (:1754)."""
@@ -749,8 +751,14 @@ class NMPC:
             if opts['integration_method'] == 'discrete':
                 raise ValueError("The integration method is 'discrete' but the model is in continuous time.")
             if opts['integration_method'] in ('idas', 'cvodes'):
-                raise NotImplementedError("SUNDIALS integrators inside the NLP are not offloaded; use 'collocation', "
-                                          "'rk4' or 'erk'")
+                # mpc.py:1421-1434 embeds SUNDIALS' adaptive integrator (CasADi's defaults: reltol 1e-6, abstol 1e-8) in the shooting
+                # map.  The stand-in here is a FIXED-step map - classic Runge-Kutta with 64 sub-steps per interval (1e-8 relative per
+                # interval on the benchmark's chemostat, whose RK4 error only falls below 1e-6 beyond 16 sub-steps) - with exact first
+                # and second derivatives of THAT map.  No error control: a stiff model needs 'collocation' (DESIGN.md 7).
+                if getattr(self._model, 'n_z', 0):
+                    raise NotImplementedError("'idas' on a model with algebraic states is not offloaded: use 'collocation'")
+                warnings.warn(f"integration_method '{opts['integration_method']}': SUNDIALS' adaptive integrator is replaced by a "
+                              f"fixed-step Runge-Kutta map of order 4 with {self.SUNDIALS_SUBSTEPS} sub-steps per sampling interval")
             if opts['integration_method'] == 'collocation' and opts['degree'] not in (1, 2, 3, 4):
                 raise NotImplementedError("collocation is built for degrees 1 to 4 (the reference's default is 3)")
         if opts['ipopt_debugger']:
@@ -786,6 +794,8 @@ class NMPC:
         if not m.discrete:
             if self._nlp_options['integration_method'] == 'collocation':
                 coll = _collocation_basis(self._nlp_options['degree'], self._nlp_options['collocation_points'])
+            elif self._nlp_options['integration_method'] in ('cvodes', 'idas'):
+                m = m.discretize('rk4', n_sub=self.SUNDIALS_SUBSTEPS)     # the stand-in for the adaptive integrator (set_nlp_options)
             else:   # 'rk4' / 'erk': one explicit Runge-Kutta step per interval (modeling.py:1213-1281)
                 m = m.discretize('rk4' if self._nlp_options['integration_method'] == 'rk4' else 'erk',
                                  order=None if self._nlp_options['integration_method'] == 'rk4' else 1)
