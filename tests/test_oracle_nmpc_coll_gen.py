@@ -139,3 +139,39 @@ def test_hard_terminal_constraint_rows():
     per = (pb.n_g - 2) // pb.N
     lt = lg[:, (pb.N - 1) * per + 2 * 4 + 4:(pb.N - 1) * per + 2 * 4 + 4 + 2]                    # [coll rows (d nx) | continuity (nx) | terminal]
     assert np.all(np.abs(lt[:, 0]) > 1e-4)                                                       # the equality carries force
+
+
+def test_minimum_time_variables_and_rows():
+    """mpc.py:859-866, :1606-1617, :1746-1754 restated natively: N sampling-interval variables (last block of v, >= 0, guess dt),
+    N - 1 rows dt_k - dt_{k+1} = 0 at the end of g, J = weight * sum(dt) - on the race car of tests/test_NMPC.py:2706-2760 with
+    N = 8.  The layout figures, equal intervals, the terminal equality, the speed limit at every collocation point, and the
+    stationarity of the oracle's own f and rows by central differences (incl. the dt columns)."""
+    N = 8
+    pb = GenCollProblem(models.get('racecar2'), dt=.1, N=N, degree=3, constraint=dict(expr=['v - (1 - sin(2*pi*p)/2)'], lb=[-np.inf], ub=[0.]),
+                        terminal=dict(expr=['p'], lb=[1.], ub=[1.]), min_time=1., u_lb=[0.], u_ub=[1.], x_guess=[0., 0.], u_guess=[0.])
+    assert pb.n_v == (N + 1) * 2 + N + N * 3 * 2 + N and pb.dt_ind == list(range(pb.n_v - N, pb.n_v))
+    assert pb.n_g == N * (3 * 1 + 3 * 2 + 2 + 1) + 1 + (N - 1)
+    ipm = GenCollIpm(pb, IpmOptions(tol=1e-10))
+    r = ipm.solve(np.array([[0., 0.]]), [])
+    assert r['status'][0] == 1
+    dt = r['dt'][0]
+    assert np.allclose(dt, dt[0], rtol=0, atol=1e-12) and abs(r['f'][0] - dt.sum()) < 1e-12 and 1.8 < dt.sum() < 2.1
+    assert abs(r['X'][0, -1, 0] - 1.) < 2e-8                                         # the equality row: met inside the relaxed box
+    Xc = r['Xc'][0]
+    assert np.all(Xc[..., 1] - (1 - np.sin(2 * np.pi * Xc[..., 0]) / 2) < 1e-7)
+    v, lg = ipm.to_v(r), ipm.lam_g(r)
+    assert v.shape == (1, pb.n_v) and lg.shape == (1, pb.n_g) and np.allclose(v[0, pb.dt_ind], dt)
+    data = {'x0': r['x0'], 'p': r['p_data']}
+    w = r['w'][0]
+    fc = lambda q: ipm.eval_fc(q[None], data)                                          # noqa: E731
+    g = np.zeros(ipm.nw)
+    for i in range(ipm.nw):
+        e = np.zeros(ipm.nw)
+        e[i] = 1e-6 * max(1., abs(w[i]))
+        (fp, cp), (fm, cm) = fc(w + e), fc(w - e)
+        g[i] = ((fp[0] - fm[0]) + r['lam'][0] @ (cp[0] - cm[0])) / (2 * e[i])
+    at = (w - ipm.lb < 1e-6) | (ipm.ub - w < 1e-6)
+    assert np.abs(g[~at]).max() < 5e-6 and np.abs(fc(w)[1]).max() < 1e-8
+    # the multipliers of the dt rows telescope: eta_k - eta_{k-1} = -(weight + mu_k' f) - nonzero, and the last one closes the sum
+    eta = lg[0, -(N - 1):]
+    assert np.abs(eta).max() > 1e-3
