@@ -97,6 +97,34 @@ def pmc_traffic_bytes(tag_key, with_source=False):
     return (best, src) if with_source else best
 
 
+def pmc_issue(tag_key, kernel_key=None):
+    """Issue / matrix-core counters of the dominant kernel from the COMMITTED passes of profiles/run_pmc_valu.sh (newest round first):
+    (dict of derived fractions, source) or (None, None).  Files: profiles/rNN_pmc_issue_<config>.json, and for C2 / gp-predict the
+    older profiles/rNN_pmc_issue.json.  `mfma_busy_frac` = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel duration in shader
+    clocks) when the summary holds it (round 5 on), else None."""
+    import glob
+    import re
+    cands = [f for f in glob.glob(os.path.join(ROOT, 'profiles', f'r*_pmc_issue_{tag_key}.json'))]
+    if tag_key in ('C2', 'gp-predict'):
+        cands += [f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_issue.json'))]
+    for f in sorted(cands, key=lambda q: os.path.basename(q)[:3], reverse=True):
+        try:
+            d = json.load(open(f))
+            if kernel_key and kernel_key in d and isinstance(d[kernel_key], dict):
+                d = d[kernel_key]
+            out = {k: d[k] for k in ('mfma_busy_frac', 'valu_busy_frac', 'valu_insts_per_wave', 'lds_wait_frac') if k in d}
+            if 'mfma_busy_frac' not in out and 'SQ_VALU_MFMA_BUSY_CYCLES' in d and 'kernel_cycles' in d:
+                out['mfma_busy_frac'] = d['SQ_VALU_MFMA_BUSY_CYCLES']['steady_mean'] / (1024.0 * d['kernel_cycles'])
+            if 'valu_busy_frac' not in out and 'SQ_ACTIVE_INST_VALU' in d and 'SQ_WAVE_CYCLES' in d:
+                out['valu_busy_frac'] = d['SQ_ACTIVE_INST_VALU']['steady_mean'] / d['SQ_WAVE_CYCLES']['steady_mean']
+            if out:
+                return out, (f"committed profile profiles/{os.path.basename(f)} (separate --pmc passes of "
+                             f"`bench.py --config {tag_key}`; not measured in this run)")
+        except Exception:
+            pass
+    return None, None
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # workloads: each returns dict(step=callable, events=list filled by step, finish=callable -> (extra config, roofline dict),
 #                              units=instances per step on this rank, cpu=callable -> cpu_baseline dict)
@@ -123,8 +151,11 @@ def _solve_roofline(kernel, B, mean_iters, nx, nu, N, ops, kern_ms, tag, n_v, n_
     bytes_launch = B * 8 * (2 * n_v + 2 * n_g + nx + n_p + nu)      # SURVEY 8d bytes_nmpc (compulsory)
     gbs = bytes_launch / (kern_ms * 1e-3) / 1e9
     traffic, src = pmc_traffic_bytes(tag, with_source=True)
+    issue, isrc = pmc_issue(tag)
     return {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
             "traffic": traffic, "traffic_source": src, "kernel": kernel, "kernel_ms": kern_ms,
+            "mfma_busy_frac": (issue or {}).get('mfma_busy_frac'), "valu_busy_frac": (issue or {}).get('valu_busy_frac'),
+            "mfma_busy_frac_source": isrc,
             "frac_with_hessian": fl / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
             "algorithmic_flops_per_launch": fl_s,
             "note": "fp64 roof: MI355X fp64 vector peak == fp64 MFMA peak = 78.6 TFLOP/s; the solve is fp64 VALU/latency bound "
@@ -566,8 +597,13 @@ def wl_kf(kind, args, torch, dev, rank, world):
         kern_ms = float(np.sum([a.elapsed_time(b) for a, b in ev])) / (len(ev) * G)
         nx, ny, nu, npar = 4, 2, 2, 4
         bytes_step = 8 * (2 * nx * (nx + 1) + 2 * ny + nu + npar)          # SURVEY 8d bytes_kf
-        gbs = B * K * bytes_step / (kern_ms * 1e-3) / 1e9
+        gbs_eq = B * K * bytes_step / (kern_ms * 1e-3) / 1e9
+        comp = B * 8 * ((nx * (nx + 1) + 2 * ny) * K + nx * (nx + 1) + nu + npar + nx * nx + ny * ny)
+        gbs = comp / (kern_ms * 1e-3) / 1e9
+        # primary figure: the bytes ONE launch must move (compulsory) against the HBM peak; the per-step formula of SURVEY 8d times K
+        # is an equivalent bandwidth (what K separate steps would move) and is carried as the secondary figure
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "equivalent_achieved": gbs_eq, "equivalent_frac": gbs_eq / HBM_PEAK_GBS,
                 "traffic": pmc_traffic_bytes('C3-' + kind), "traffic_source": pmc_traffic_bytes('C3-' + kind, with_source=True)[1],
                 # csrc/hilo_kf.hip::use_team: a team of lanes per instance (4 for the EKF's Jacobian columns, 16 for the UKF's 9
                 # sigma points) up to two waves per SIMD of teams, one instance per lane beyond
@@ -577,11 +613,11 @@ def wl_kf(kind, args, torch, dev, rank, world):
                            f"kf_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}, 2>"),
                 "kernel_ms": kern_ms, "launches_per_event_pair": G, "algorithmic_bytes_per_launch": B * K * bytes_step,
                 "filter_steps_per_launch": K,
-                "compulsory_bytes_per_launch": B * 8 * ((nx * (nx + 1) + 2 * ny) * K + nx * (nx + 1) + nu + npar + nx * nx + ny * ny),
-                "note": "bytes_kf = 8 (2 nx (nx+1) + 2 ny + nu + np) per filter step (SURVEY 8d); with K steps per launch the tile "
-                        "stays on chip between steps, so `achieved` / `frac` are an EQUIVALENT bandwidth (what K separate steps "
-                        "would move), not HBM utilisation - `compulsory_bytes_per_launch` is what one launch must move (tile in "
-                        "once, y in and tile + y_pred out per step, [u; p], Q, R); at the configuration's B = 4096 a launch is "
+                "compulsory_bytes_per_launch": comp,
+                "note": "`achieved` / `frac`: the bytes one launch must move (tile in once, y in and tile + y_pred out per step, "
+                        "[u; p], Q, R = `compulsory_bytes_per_launch`) per launch time against the HBM peak.  bytes_kf = 8 (2 nx "
+                        "(nx+1) + 2 ny + nu + np) per filter step (SURVEY 8d) times K steps is what K separate steps would move: "
+                        "`equivalent_achieved` / `equivalent_frac` (the tile stays on chip between the K steps of a launch); at the configuration's B = 4096 a launch is "
                         "bound by the latency of one instance's dependent chain (DESIGN 5.2); `--batch 1048576` measures the "
                         "bandwidth-bound regime"}
         extra = {"workload": f"C3 {kind.upper()} step chemostat4 nx=4 ny=2 (predict + update fused, {K} sampling instants per "
@@ -619,6 +655,8 @@ def wl_gp(args, torch, dev, rank, world):
         by = m * 8 * (nf + 2)
         roof = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
                 "traffic": pmc_traffic_bytes('gp-predict'), "traffic_source": pmc_traffic_bytes('gp-predict', with_source=True)[1], "kernel": "gp_predict_kernel", "kernel_ms": kern_ms,
+                "mfma_busy_frac": (pmc_issue('gp-predict', 'gp_predict_reg_kernel')[0] or {}).get('mfma_busy_frac'),
+                "mfma_busy_frac_source": pmc_issue('gp-predict', 'gp_predict_reg_kernel')[1],
                 "note": "fp64 compute roof: flops per query = n (3 nf + 20) + 2 n (mean) + n^2 (|L^-1 k*|^2), n = 200; "
                         "compulsory HBM traffic is 8 (nf + 2) bytes per query (arithmetic intensity ~1400 flop/B)",
                 "hbm": {"achieved": by / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -686,7 +724,9 @@ def wl_lmpc(args, torch, dev, rank, world):
                          "dependent 2x2 steps is latency bound, the figure of merit is `single_instance_latency_us`") if staged else
                         ("dense Mehrotra predictor-corrector, 32 variables / 20 equalities: flops per iteration = 2 m^2 n + m^3/3 "
                          "+ 4 m^2 + 6 n m; a 32-variable QP per workgroup is latency bound")}
-        extra = {"workload": "C1 LMPC discrete double integrator nx=2 nu=1 N=10 (corrected input block), closed loop",
+        extra = {"workload": "C1 LMPC discrete double integrator nx=2 nu=1 N=10 (corrected input block), closed loop from x0 drawn "
+                             "uniformly in [-4, 4]^2: about 5 % of these measured states cannot keep the box (infeasible QPs, reported "
+                             "as status 3 after a few iterations - `frac_status_1` is the rest)",
                  "batch_per_gpu": B, "global_batch": B * world, "mean_qp_iters": iters, "frac_status_1": float((torch.stack(solved) == 1).double().mean().item()),
                  "single_instance_latency_us": float(np.mean([a.elapsed_time(b) for a, b in e1])) * 1e3}
         return extra, roof, "weak"
@@ -773,12 +813,30 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         units = float(tot.item())
     extra, roof, scaling = wl['finish']()
+    # the headline configuration's value moves with how far the closed loop has settled (fewer interior-point iterations per step
+    # later on): the SAME loop continued for 50 more steps, timed the same way, is reported next to the driver's command
+    settled = None
+    if args.config == 'C2':
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            wl['step'](False)
+        sync()
+        e2 = time.perf_counter() - t1
+        if world > 1:
+            t2 = torch.tensor([e2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            e2 = float(t2.item())
+        settled = {"value": units * 50 / e2, "ms_per_step": e2 / 50 * 1e3,
+                   "steps": f"{args.warmup + args.steps + 1}..{args.warmup + args.steps + 50} of the same closed loop (after the timed region)"}
 
     if rank == 0:
         out = {"metric": wl['metric'], "value": units * args.steps / elapsed, "unit": wl['unit'], "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": dict(extra, name=args.config, rccl_world_size=world), "roofline": roof}
+        if settled is not None:
+            out["settled_loop"] = settled
         if 'hbm' in roof:
             out["roofline_hbm"] = dict(roof.pop('hbm'), bound="hbm", traffic=roof['traffic'])
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only

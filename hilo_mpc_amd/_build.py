@@ -11,6 +11,11 @@ SOURCES = ['hilo_api.hip', 'hilo_kf.hip', 'hilo_gp.hip', 'hilo_nmpc.hip', 'hilo_
            'hilo_nmpc_gen_chemostat4.hip', 'hilo_nmpc_gen_robot6.hip', 'hilo_nmpc_coll.hip', 'hilo_nmpc_tv.hip', 'hilo_mhe_est.hip', 'hilo_nmpc_long.hip', 'hilo_jit.hip', 'hilo_nmpc_user.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result'] + \
     os.environ.get('HILO_EXTRA_FLAGS', '').split()      # developer knob (tuning sweeps), empty in normal builds
+# Translation units built around the interior-point engine (csrc/hilo_ocp.h): the f64 matrix-core products of its Riccati stage take
+# and leave their tiles in VGPRs (no v_accvgpr_read / _write around every product; hiprtc's compiler does not know the option, hilo_jit.hip)
+OCP_FLAGS = ['-mllvm', '-amdgpu-mfma-vgpr-form=1']
+OCP_UNITS = {'hilo_nmpc.hip', 'hilo_mhe.hip', 'hilo_nmpc_gen_chemostat4.hip', 'hilo_nmpc_gen_robot6.hip', 'hilo_nmpc_coll.hip',
+             'hilo_nmpc_tv.hip', 'hilo_mhe_est.hip', 'hilo_nmpc_long.hip'}
 
 
 def _hipcc():
@@ -47,7 +52,7 @@ def build(force=False, verbose=True, jobs=None, tag=None, extra_flags=()):
         obj = os.path.join(objdir, os.path.basename(src).replace('.hip', '.o'))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc] + flags + ['-c', src, '-o', obj]
+            cmd = [hipcc] + flags + (OCP_FLAGS if os.path.basename(src) in OCP_UNITS else []) + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

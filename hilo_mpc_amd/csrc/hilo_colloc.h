@@ -67,7 +67,7 @@ struct Colloc {
   template <class AP>
   __device__ __forceinline__ static void lu_solve2_prepared(AP a, double* b, double* c) {
     double row[DN], nxt[DN];
-    row[0] = a[1 * DN + 0];
+    row[0] = DN > 1 ? a[1 * DN + 0] : a[0];   // (a 1 x 1 system: no forward pass, the backward pass starts with 1 / u_00)
 #pragma unroll
     for (int i = 1; i < DN; ++i) {                       // forward: unit lower factor, row i holds a[i][0..i-1]
       if (i + 1 < DN) {

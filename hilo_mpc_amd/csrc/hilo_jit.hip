@@ -256,6 +256,8 @@ static int unit_key(const std::string& tu, std::vector<std::string>* opts, std::
   uint64_t hfp = 0;
   int rc = headers_fingerprint(csrc, &hfp);
   if (rc) return rc;
+  // (the library build adds -mllvm -amdgpu-mfma-vgpr-form=1 for the engine's units, _build.py; the compiler inside hiprtc does not
+  // know that option and ends the PROCESS on it - run-time compiled problems keep the accumulator-register form of the products)
   *opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + csrc};
   uint64_t h = fnv1a(tu, hfp);
   for (const auto& o : *opts) h = fnv1a(o.substr(0, 2) == "-I" ? std::string("-I") : o, h);

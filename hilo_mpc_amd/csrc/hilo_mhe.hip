@@ -68,9 +68,12 @@ struct hilo_mhe {
   X(HILO_MODEL_CHEMOSTAT4, Chemostat4) \
   X(HILO_MODEL_BIOREACTOR3, Bioreactor3)
 
-static int mhe_model_dims(int id, int* nx, int* nu, int* np, int* ny, size_t* lds, int N) {
+// `taylor`: the launch will take the policy without symbolic derivatives (sub-stepped integration, mhe_launch) - its iterate holds the
+// direction table of the Taylor sweeps and is larger
+static int mhe_model_dims(int id, int* nx, int* nu, int* np, int* ny, size_t* lds, int N, bool taylor) {
   switch (id) {
-#define X(ID, T) case ID: *nx = T::NX; *nu = T::NU; *np = T::NP; *ny = T::NY; *lds = Ocp<MheNoise<T>>::lds_doubles(N) * sizeof(double); return HILO_OK;
+#define X(ID, T) case ID: *nx = T::NX; *nu = T::NU; *np = T::NP; *ny = T::NY; \
+    *lds = (taylor ? Ocp<MheNoise<T, false>>::lds_doubles(N) : Ocp<MheNoise<T>>::lds_doubles(N)) * sizeof(double); return HILO_OK;
     HILO_MHE_MODELS(X)
 #undef X
   }
@@ -112,7 +115,7 @@ extern "C" int hilo_mhe_create(const hilo_mhe_desc* d, int device, hilo_mhe** ou
   } else {
     HILO_REQUIRE(d->model_id != HILO_MODEL_USER, "hilo_mhe_create: HILO_MODEL_USER needs desc.user_source");
     if (D) return fail(HILO_ENOTSUP, "the collocation transcription runs on the run-time compiled policy: pass desc.user_source");
-    rc = mhe_model_dims(d->model_id, &nx, &nu, &np, &ny, &lds, d->N);
+    rc = mhe_model_dims(d->model_id, &nx, &nu, &np, &ny, &lds, d->N, d->n_sub > 1 || getenv("HILO_NMPC_TAYLOR") != nullptr);
     if (rc) return rc;
   }
   // desc.Ww == NULL: an estimator WITHOUT state noise (mhe.py:599: no w block in v; the collocation / discrete branches run without

@@ -97,8 +97,9 @@ struct OpMax2 { __device__ static double id() { return -INFINITY; } __device__ s
 // the four row totals through v_readlane (scalar registers -> broadcast for free)
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  // (every lane of these permutations has a source lane: no "old" value to preserve, so none is initialised)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double read_lane(double v, int lane) {
@@ -1834,33 +1835,85 @@ struct Ocp {
   // first product, the A operand of the second and the open-loop coefficient of the closed-loop update), and every output of
   // a stage ([P | p], [K | kff], [Acl | bcl], pitch NX + 1) leaves through one predicated store.
   static constexpr int KB_ = (NX + 3) / 4, RB_ = (NZ + 3) / 4;
+  // Round 5: DUPLICATED INPUT ROWS.  The 16 x 16 tile of the second product has rows to spare (NZ + 1 <= 4 RB_ of them are in use):
+  // the lanes q >= 4 RB_ feed the input columns of [A B | -c] once more as A operand - rows 4 (RB_ + a) + g of the tile, g = 0..3, all
+  // equal row NX + a of M - so that accumulator register RB_ + a of EVERY lane (g, q) holds M_ux[a][q]: the lane's own column of the
+  // input rows and (lanes NX + c) the pivot block arrive without a cross-lane fetch.  (The same register is the B operand of the first
+  // product: columns >= 4 RB_ of T become copies of P B - nothing reads them.  NZ % 4 != 0 keeps the right-hand-side column NZ below
+  // 4 RB_.)  With at most two inputs the pivot block R = L D L^T is then factored WITHOUT square roots and with its two reciprocals
+  // in parallel (pivot_inverse): 1 / d_0 = 1 / r00 and 1 / d_1 = r00 / det R, l = r10 / r00,
+  //     P_k[i][j] = sym(M_xx)[i][j] - m_i0 m_j0 / d_0 - (m_i1 - l m_i0)(m_j1 - l m_j0) / d_1,      m_j = M_ux[:, j]
+  // - the arithmetic (and the rounding behaviour) of the Cholesky form P = M_xx - w_i . w_j, w = L^-1 D^-1/2 m, with one reciprocal
+  // chain on the critical path instead of two dependent reciprocal square roots.  (The closed form m_i^T adj(R) m_j / det R was
+  // tried first and is NOT usable: with a state constraint active at stage k + 1 the cost-to-go carries sigma j j^T, sigma ~ 1e10,
+  // R and M_ux both contain a rank-one term of that size and the adjugate form cancels terms of order sigma^3 down to sigma -
+  // no digit left; found by the constrained parity tests.)  Positivity of the pivots = r00 > 0 and det R > 0.
+#ifndef HILO_RIC_DUP
+#define HILO_RIC_DUP 1
+#endif
+#ifndef HILO_RIC_TADD
+#define HILO_RIC_TADD 1
+#endif
+#ifndef HILO_FWD_SGPR
+#define HILO_FWD_SGPR 1
+#endif
+  static constexpr bool DUPU = HILO_RIC_DUP && OCP_TPB == 64 && NZ + 1 <= 16 && NX <= 16 && NU >= 1 && NU <= 2 && NH == 0 && NZ % 4 != 0 &&
+                               RB_ + NU <= 4;
+  static constexpr int RD_ = DUPU ? RB_ + NU : RB_;   // accumulator registers of the stage matrix in use
+  // row of the stage matrix that register r of row group g holds (clamped where the tile has no row)
+  __device__ __forceinline__ static int stage_row(int r, int g) {
+    if (DUPU && r >= RB_) return NX + (r - RB_);
+    const int i = g + 4 * r;
+    return (NZ % 4 == 0 || i < NZ) ? i : NZ - 1;
+  }
   struct StageOps {
     double b1[KB_], bi[KB_][NU > 0 ? NU : 1];
     v4d M0;
   };
+  // R = [r00 r10; r10 r11] = L D L^T:  i0 = 1 / d_0,  i1 = 1 / d_1 = r00 / det R,  l = r10 / r00  (the two reciprocals are independent)
+  struct PivotInv { double i0, i1, l; bool ok; };
+  __device__ __forceinline__ static PivotInv pivot_inverse(double r00, double r10, double r11) {
+    PivotInv p;
+    if constexpr (NU == 2) {
+      const double det = fma(r00, r11, -r10 * r10);
+      p.ok = r00 > 0.0 && det > 0.0;
+      p.i0 = rcp_fast(r00);
+      p.i1 = r00 * rcp_fast(det);
+      p.l = r10 * p.i0;
+    } else {
+      p.ok = r00 > 0.0;
+      p.i0 = rcp_fast(r00);
+      p.i1 = 0.0;
+      p.l = 0.0;
+    }
+    return p;
+  }
   // what a stage reads from the iterate, before any arithmetic: in workspace mode these loads are issued TWO stages ahead
   // (a global-memory round trip is about two stage times at one wave per SIMD) and turned into operands one stage ahead
   struct StageRaw {
-    double b1[KB_], bi[KB_][NU > 0 ? NU : 1], w[RB_];
+    double b1[KB_], bi[KB_][NU > 0 ? NU : 1], w[RD_];
     double csig[NC > 0 ? NC : 1], cdv[NC > 0 ? NC : 1], csv[NC > 0 ? NC : 1], crb[NC > 0 ? NC : 1], jq[NC > 0 ? NC : 1];
-    double ji[RB_][NC > 0 ? NC : 1];
+    double ji[RD_][NC > 0 ? NC : 1];
   };
   __device__ __forceinline__ static void stage_load(const Lds l, int k, int q, int g, StageRaw& w) {
     const int qc = q < NZ ? q : NZ;
+    int qa = qc;   // column of [A B | -c] this lane feeds to the products (DUPU: lanes q >= 4 RB_ feed the input columns again)
+    if constexpr (DUPU) {
+      if (q >= 4 * RB_) qa = ((q - 4 * RB_) >> 2) < NU ? NX + ((q - 4 * RB_) >> 2) : NZ;
+    }
     cdp AB = l.AB + (size_t)k * NX * ABP;
     cdp Wk = l.W + (size_t)k * NZ * WP;
 #pragma unroll
     for (int kb = 0; kb < KB_; ++kb) {
       const int kk = 4 * kb + g;
       const int kc = (NX % 4 == 0 || kk < NX) ? kk : NX - 1;
-      w.b1[kb] = AB[kc * ABP + qc];
+      w.b1[kb] = AB[kc * ABP + qa];
 #pragma unroll
       for (int a = 0; a < NU; ++a) w.bi[kb][a] = AB[kc * ABP + NX + a];
     }
 #pragma unroll
-    for (int r = 0; r < RB_; ++r) {
-      const int i = g + 4 * r;
-      const int ic = (NZ % 4 == 0 || i < NZ) ? i : NZ - 1;
+    for (int r = 0; r < RD_; ++r) {
+      const int ic = stage_row(r, g);
       w.w[r] = Wk[ic * WP + qc];
       if constexpr (NC > 0) {
 #pragma unroll
@@ -1886,9 +1939,8 @@ struct Ocp {
     }
     o.M0 = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int r = 0; r < RB_; ++r) {
-      const int i = g + 4 * r;
-      const int ic = (NZ % 4 == 0 || i < NZ) ? i : NZ - 1;
+    for (int r = 0; r < RD_; ++r) {
+      const int ic = stage_row(r, g);
       double h = w.w[r];
       if (ic == q) h += delta;
       if constexpr (NC > 0) {  // eliminated slack rows: + Jd^T (Sigma_s + delta) Jd, rhs + Jd^T ((Sigma_s + delta)(d - s) + crb)
@@ -1932,14 +1984,76 @@ struct Ocp {
     auto stage = [&](int k, auto&& fetch) __attribute__((always_inline)) {
       // T = P_{k+1} [A B | -c] + [0 | p_{k+1}];  M = [A B | -c]^T T + [H_k | r_k]
       v4d Tacc = {0.0, 0.0, 0.0, 0.0}, Macc = o.M0;
+#if HILO_RIC_TADD
+      // the cost-to-go vector joins the right-hand-side column after the product: the product starts from the constant zero tile
+      // (no accumulator registers to clear per stage)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) Tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pr[kb], o.b1[kb], Tacc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < KB; ++r) Tacc[r] += pr[r];
+#else
 #pragma unroll
       for (int r = 0; r < KB; ++r) Tacc[r] = pr[r];
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) Tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pr[kb], o.b1[kb], Tacc, 0, 0, 0);
+#endif
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) Macc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.b1[kb], Tacc[kb], Macc, 0, 0, 0);
       const StageOps c = o;                           // this stage's closed-loop operands
       fetch();
+      if constexpr (DUPU) {
+        // own column of the input rows (duplicated rows: registers RB_ + a), the transposed partner's for the row of this lane
+        double mq[NU], yq[NU], mg[KB][NU], mji[KB];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) mq[a] = Macc[RB_ + a];
+#pragma unroll
+        for (int r = 0; r < KB; ++r) {
+          const int i = g + 4 * r, ic = i < NX ? i : NX - 1;
+          const int src = 16 * (qx % 4) + ic;          // lane (qx % 4, i): M[qx][i] in register qx / 4, M_ux[:, i] in the duplicates
+#pragma unroll
+          for (int a = 0; a < NU; ++a) mg[r][a] = __shfl(Macc[RB_ + a], src);
+          mji[r] = 0.0;
+#pragma unroll
+          for (int rr = 0; rr < KB; ++rr) {
+            const double v = __shfl(Macc[rr], src);
+            mji[r] = (KB == 1 || qx / 4 == rr) ? v : mji[r];
+          }
+        }
+        // pivot block out of the duplicated rows of lanes NX + c (scalar registers), inverted in closed form
+        const double r00 = read_lane(Macc[RB_], NX);
+        PivotInv pv;
+        if constexpr (NU == 2) pv = pivot_inverse(r00, read_lane(Macc[RB_ + 1], NX), read_lane(Macc[RB_ + 1], NX + 1));
+        else pv = pivot_inverse(r00, 0.0, 1.0);
+        pd = pd && pv.ok;
+        double tq = 0.0;
+        if constexpr (NU == 2) {
+          tq = fma(-pv.l, mq[0], mq[1]);
+          yq[1] = tq * pv.i1;
+          yq[0] = fma(-pv.l, yq[1], mq[0] * pv.i0);
+        } else yq[0] = mq[0] * pv.i0;
+        if (g == 0 && use) {   // feedback K[:, q] = -y_q, feed-forward kff = -y_NZ
+#pragma unroll
+          for (int a = 0; a < NU; ++a) l.Kg[((size_t)k * NU + a) * PP + qk] = -yq[a];
+        }
+#pragma unroll
+        for (int r = 0; r < KB; ++r) {
+          const int i = g + 4 * r, ic = i < NX ? i : NX - 1;
+          const bool valid = NX % 4 == 0 || i < NX;
+          const double sym = colR ? Macc[r] : 0.5 * (Macc[r] + mji[r]);
+          double sv = fma(-(mg[r][0] * mq[0]), pv.i0, sym);      // every product: the same bits in the lanes (i, q) and (q, i)
+          if constexpr (NU == 2) sv = fma(-(fma(-pv.l, mg[r][0], mg[r][1]) * tq), pv.i1, sv);
+          double cl = c.b1[r];                          // A[i][q] (q < NX) or -c[i] (q = NZ)
+#pragma unroll
+          for (int a = 0; a < NU; ++a) cl -= c.bi[r][a] * yq[a];
+          Pr[r] = (valid && colP) ? sv : 0.0;
+          pr[r] = (valid && colR) ? sv : 0.0;
+          if (valid && use) {
+            l.P[((size_t)k * NX + ic) * PP + qk] = sv;
+            l.Acl[((size_t)k * NX + ic) * PP + qk] = cl;
+          }
+        }
+        return;
+      }
       // cross-lane fetches of the M_ux columns and the mirrored M_xx entries, all issued before they are needed
       double wq[NU], yq[NU], wi[KB][NU], mji[KB];
 #pragma unroll
@@ -2027,6 +2141,214 @@ struct Ocp {
     return uni(pd);
   }
 
+  // an LDS pointer the compiler must take as it is (it would otherwise split it into a uniform base and a lane offset and add the
+  // two at every access)
+  template <class P>
+  __device__ __forceinline__ static void opaque_lds(P& ptr) {
+    unsigned a = (unsigned)(size_t)ptr;
+    asm volatile("" : "+v"(a));
+    ptr = (P)(size_t)a;
+  }
+
+  // ---- the same recursion, software-pipelined by hand (DUPU policies, iterate in LDS) ------------------------------------------
+  // One wave per SIMD issues one instruction per four clocks whatever it is, and each of the two f64 products occupies the matrix
+  // core for 16 passes during which only INDEPENDENT instructions can issue.  The stage is therefore laid out in source order, with
+  // scheduling barriers, as:  product 1 | outputs of the PREVIOUS stage (feedback, closed-loop row, cost-to-go stores) and the raw
+  // loads of the NEXT stage | product 2 | operands of the next stage finished | pivot block, reciprocal, this lane's entry of P_k.
+  // What lies on the recursion's critical path is the two products, six v_readlane, one reciprocal and about ten multiply-adds.
+#ifndef HILO_RIC_PIPE
+#define HILO_RIC_PIPE 1
+#endif
+  __device__ __forceinline__ static bool backward_dup(const Lds l, int N, double delta) {
+    static_assert(DUPU && !BIG, "backward_dup: duplicated-row policies with the iterate in LDS");
+    const int t = threadIdx.x, q = t & 15, g = t >> 4;
+    constexpr int KB = KB_;
+    const int qx = q < NX ? q : NX - 1;
+    const bool colP = q < NX, colR = q == NZ;
+    const bool use = ((((1u << NX) - 1u) | (1u << NZ)) >> q) & 1u;   // colP or colR, as ONE lane predicate
+    const int qk = colR ? NX : qx;                 // this lane's column in the [. | rhs] outputs of pitch PP
+    const int qc = q < NZ ? q : NZ;
+    int qa = qc;                                   // column of [A B | -c] this lane feeds to the products (see stage_load)
+    if (q >= 4 * RB_) qa = ((q - 4 * RB_) >> 2) < NU ? NX + ((q - 4 * RB_) >> 2) : NZ;
+    double Pr[KB], pr[KB], dl[RD_];
+    int src[KB], srcm[KB];
+#pragma unroll
+    for (int r = 0; r < KB; ++r) {
+      const int row = g + 4 * r, rc = row < NX ? row : NX - 1;
+      const double v = l.P[((size_t)N * NX + rc) * PP + qk];
+      Pr[r] = (row < NX && colP) ? v : 0.0;
+      pr[r] = (row < NX && colR) ? v : 0.0;
+      src[r] = 16 * (qx % 4) + rc;                 // lane (qx % 4, row): M[qx][row] in register qx / 4, M_ux[:, row] in the duplicates
+      srcm[r] = colP ? src[r] : t;                 // the right-hand-side column has no mirrored entry: its own (0.5 (m + m) = m exactly)
+    }
+#pragma unroll
+    for (int r = 0; r < RD_; ++r) dl[r] = stage_row(r, g) == q ? delta : 0.0;   // the inertia correction on this lane's diagonal entries
+    // running pointers of what a lane reads and writes per stage (one decrement each per stage, immediate offsets otherwise).
+    // The loads run one stage ahead: at k = 0 they touch the doubles in front of the arrays - inside the iterate, never used.
+    cdp pB1[KB], pBi[KB], pW[RD_];
+    dp pP[KB], pAcl[KB], pKg;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int kk = 4 * kb + g, kc = (NX % 4 == 0 || kk < NX) ? kk : NX - 1;
+      pB1[kb] = l.AB + ((size_t)(N - 1) * NX + kc) * ABP + qa;
+      pBi[kb] = l.AB + ((size_t)(N - 1) * NX + kc) * ABP + NX;
+      pP[kb] = l.P + ((size_t)(N - 1) * NX + kc) * PP + qk;
+      pAcl[kb] = l.Acl + ((size_t)(N - 1) * NX + kc) * PP + qk;
+    }
+#pragma unroll
+    for (int r = 0; r < RD_; ++r) pW[r] = l.W + ((size_t)(N - 1) * NZ + stage_row(r, g)) * WP + qc;
+    pKg = l.Kg + (size_t)(N - 1) * NU * PP + qk;
+    // (the compiler would split every pointer into a uniform base and a lane offset and add the two at every access)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) { opaque_lds(pB1[kb]); opaque_lds(pBi[kb]); opaque_lds(pP[kb]); opaque_lds(pAcl[kb]); }
+#pragma unroll
+    for (int r = 0; r < RD_; ++r) opaque_lds(pW[r]);
+    opaque_lds(pKg);
+    StageOps oA, oB;      // operands of the current and of the next stage, roles alternating (loop unrolled by two: no register copies)
+    StageRaw raw;
+    auto load = [&]() __attribute__((always_inline)) {   // raw operands of the stage the pointers stand on, then one stage down
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        raw.b1[kb] = pB1[kb][0];
+#pragma unroll
+        for (int a = 0; a < NU; ++a) raw.bi[kb][a] = pBi[kb][a];
+        pB1[kb] -= NX * ABP;
+        pBi[kb] -= NX * ABP;
+      }
+#pragma unroll
+      for (int r = 0; r < RD_; ++r) {
+        raw.w[r] = pW[r][0];
+        pW[r] -= NZ * WP;
+      }
+    };
+    auto finish = [&](StageOps& o, int kn) __attribute__((always_inline)) {
+      if constexpr (NC > 0) {
+        stage_load(l, kn, q, g, raw);   // (the rows of the inequality block; policies with rows take the general routine)
+        stage_finish(raw, delta, q, g, o);
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const int kk = 4 * kb + g;
+          o.b1[kb] = (NX % 4 == 0 || kk < NX) ? raw.b1[kb] : 0.0;
+#pragma unroll
+          for (int a = 0; a < NU; ++a) o.bi[kb][a] = raw.bi[kb][a];
+        }
+        o.M0 = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < RD_; ++r) o.M0[r] = raw.w[r] + dl[r];
+      }
+    };
+    bool pd = true;
+    // outputs of a finished stage (with the operands `po` it ran on), stored during the next stage's second product
+    double d_ny[NU], d_sv[KB];
+#pragma unroll
+    for (int a = 0; a < NU; ++a) d_ny[a] = 0.0;
+#pragma unroll
+    for (int r = 0; r < KB; ++r) d_sv[r] = 0.0;
+    auto emit = [&](const StageOps& po) __attribute__((always_inline)) {
+      // feedback K[:, q] = -y_q (kff = -y_NZ): every row group writes the same value; closed-loop row and cost-to-go entry
+      if (use) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) pKg[a * PP] = d_ny[a];
+#pragma unroll
+        for (int r = 0; r < KB; ++r) {
+          if (NX % 4 == 0 || g + 4 * r < NX) {
+            double cl = po.b1[r];                        // A[i][q] (q < NX) or -c[i] (q = NZ)
+#pragma unroll
+            for (int a = 0; a < NU; ++a) cl = fma(po.bi[r][a], d_ny[a], cl);
+            pP[r][0] = d_sv[r];
+            pAcl[r][0] = cl;
+          }
+        }
+      }
+      pKg -= NU * PP;
+#pragma unroll
+      for (int r = 0; r < KB; ++r) { pP[r] -= NX * PP; pAcl[r] -= NX * PP; }
+    };
+    // one stage on the operands `o`; `on` holds the previous stage's operands on entry (for its outputs) and the next stage's on exit
+    auto stage = [&](int k, const StageOps& o, StageOps& on, bool have) __attribute__((always_inline)) {
+      // T = P_{k+1} [A B | -c] (+ [0 | p_{k+1}] below);  M = [A B | -c]^T T + [H_k | r_k]
+      v4d Tacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) Tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pr[kb], o.b1[kb], Tacc, 0, 0, 0);
+#if HILO_RIC_PIPE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      load();
+#if HILO_RIC_PIPE
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+v"(Tacc));   // the whole tile stays allocated while the product runs (no register of it is reused in its shadow)
+#endif
+#pragma unroll
+      for (int r = 0; r < KB; ++r) Tacc[r] += pr[r];
+      v4d Macc = o.M0;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) Macc = __builtin_amdgcn_mfma_f64_16x16x4f64(o.b1[kb], Tacc[kb], Macc, 0, 0, 0);
+#if HILO_RIC_PIPE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      if (have) emit(on);
+      finish(on, k > 0 ? k - 1 : 0);
+#if HILO_RIC_PIPE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      // own column of the input rows (registers RB_ + a), the transposed partner's for the row(s) of this lane
+      double mq[NU], mg[KB][NU], mji[KB];
+#pragma unroll
+      for (int a = 0; a < NU; ++a) mq[a] = Macc[RB_ + a];
+#pragma unroll
+      for (int r = 0; r < KB; ++r) {
+#pragma unroll
+        for (int a = 0; a < NU; ++a) mg[r][a] = __shfl(Macc[RB_ + a], src[r]);
+        mji[r] = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < KB; ++rr) {
+          const double v = __shfl(Macc[rr], srcm[r]);
+          mji[r] = (KB == 1 || (colP ? qx / 4 : r) == rr) ? v : mji[r];
+        }
+      }
+      const double r00 = read_lane(Macc[RB_], NX);
+      PivotInv pv;
+      if constexpr (NU == 2) pv = pivot_inverse(r00, read_lane(Macc[RB_ + 1], NX), read_lane(Macc[RB_ + 1], NX + 1));
+      else pv = pivot_inverse(r00, 0.0, 1.0);
+      pd = pd && pv.ok;           // (a pivot block that is not positive definite: the factorisation is abandoned after the loop)
+      double tq = 0.0;
+      if constexpr (NU == 2) {    // -y_q = -R^-1 m_q by the two substitutions
+        tq = fma(-pv.l, mq[0], mq[1]);
+        d_ny[1] = -(tq * pv.i1);
+        d_ny[0] = fma(-pv.l, d_ny[1], -(mq[0] * pv.i0));
+      } else d_ny[0] = -(mq[0] * pv.i0);
+#pragma unroll
+      for (int r = 0; r < KB; ++r) {
+        const int i = g + 4 * r;
+        const bool valid = NX % 4 == 0 || i < NX;
+        const double sym = 0.5 * (Macc[r] + mji[r]);
+        double sv = fma(-(mg[r][0] * mq[0]), pv.i0, sym);        // every product: the same bits in the lanes (i, q) and (q, i)
+        if constexpr (NU == 2) sv = fma(-(fma(-pv.l, mg[r][0], mg[r][1]) * tq), pv.i1, sv);
+        d_sv[r] = sv;
+        // rows of T beyond NX are read by nothing when NX fills its blocks of four: lanes q >= NX may keep their (finite) value
+        Pr[r] = (NX % 4 == 0) ? sv : ((valid && colP) ? sv : 0.0);
+        pr[r] = (valid && colR) ? sv : 0.0;
+      }
+    };
+    load();
+    int k = N - 1;
+    bool have = false;      // a finished stage's outputs are waiting to be stored
+    if (N & 1) {            // odd horizon: one stage in front of the pairs
+      finish(oB, k);
+      stage(k, oB, oA, false);
+      --k;
+      have = true;
+    } else finish(oA, k);
+    for (; k >= 1; k -= 2) {
+      stage(k, oA, oB, have);
+      stage(k - 1, oB, oA, true);
+      have = true;
+    }
+    emit(oB);
+    return uni(pd);
+  }
+
   // broadcast of lane j's value inside every quad of lanes (DPP quad_perm [j, j, j, j]): the forward sweep's state exchange
   template <int J>
   __device__ __forceinline__ static double quad_bcast(double v) { return dpp_mov<J * 0x55>(v); }
@@ -2068,7 +2390,10 @@ struct Ocp {
     __syncthreads();
 #ifndef HILO_RICCATI_LDS
     if constexpr (MFMA_STAGE && NU > 0 && NH == 0) {
-      if (!backward_reg(l, N, delta)) return false;
+      bool okb;
+      if constexpr (DUPU && !BIG) okb = backward_dup(l, N, delta);
+      else okb = backward_reg(l, N, delta);
+      if (!okb) return false;
       __syncthreads();
       DTICK(8)
     } else
@@ -2297,6 +2622,63 @@ struct Ocp {
     __syncthreads();
     // forward sweep on the first wave: lane i < NX carries dx[i] in a register, exchanged by DPP quad broadcasts (NX <= 4) or
     // v_readlane; the coefficients of the next stage are fetched while the current one is computed
+#if HILO_FWD_SGPR
+    if (t < 64) {
+      // Round 5: the state step lives in SCALAR registers.  Lane i < NX holds row i of [Acl | bcl] of a chunk of FU stages and computes
+      // dx_{k+1}[i]; v_readlane hands the NX results to every lane as scalar operands of the next stage's multiply-adds (no DPP
+      // moves, no LDS trip).  Two chunk buffers with alternating roles: the next chunk's rows are in flight while the current one
+      // is applied, and no register copies between chunks.  Lanes >= NX duplicate row 0 (same value to the same address).
+      constexpr int FU = 4;
+      const int i = t < NX ? t : 0;
+      double dxs[NX];
+      {
+        const double d0 = l.D[i];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) dxs[j] = read_lane(d0, j);
+      }
+      double ca[FU][NX + 1], cb[FU][NX + 1];
+      auto fetch = [&](double (&dst)[FU][NX + 1], int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < FU; ++q) {
+          const int kq = k0 + q < N ? k0 + q : N - 1;
+          cdp row = l.Acl + ((size_t)kq * NX + i) * PP;
+#pragma unroll
+          for (int j = 0; j <= NX; ++j) dst[q][j] = row[j];
+        }
+      };
+      // (whole chunks run without a test per stage - `tail` is wave-uniform: only the last chunk of a horizon that is no multiple
+      // of FU looks at the stage index)
+      auto run = [&](const double (&c)[FU][NX + 1], int k0) __attribute__((always_inline)) {
+        auto one = [&](int q, int k) __attribute__((always_inline)) {
+          double s = c[q][NX], s2 = 0.0;   // two accumulation chains of half the length
+#pragma unroll
+          for (int j = 0; j < NX; ++j) {
+            if (j & 1) s2 = fma(c[q][j], dxs[j], s2);
+            else s = fma(c[q][j], dxs[j], s);
+          }
+          s += s2;
+          l.D[(k + 1) * NZ + i] = s;
+#pragma unroll
+          for (int j = 0; j < NX; ++j) dxs[j] = read_lane(s, j);
+        };
+        if (k0 + FU <= N) {
+#pragma unroll
+          for (int q = 0; q < FU; ++q) one(q, k0 + q);
+        } else {
+#pragma unroll
+          for (int q = 0; q < FU; ++q)
+            if (k0 + q < N) one(q, k0 + q);
+        }
+      };
+      fetch(ca, 0);
+      for (int k0 = 0; k0 < N; k0 += 2 * FU) {
+        fetch(cb, k0 + FU);
+        run(ca, k0);
+        fetch(ca, k0 + 2 * FU);
+        run(cb, k0 + FU);
+      }
+    }
+#else
     if (t < 64) {
       // chunks of FU stages: the coefficients of the NEXT chunk are fetched while the current one is computed (one LDS
       // latency per chunk instead of one per stage - a stage is a handful of dependent multiply-adds)
@@ -2345,6 +2727,7 @@ struct Ocp {
           for (int j = 0; j <= NX; ++j) cur[q][j] = nxt[q][j];
       }
     }
+#endif
     __syncthreads();
     DTICK(10)
     // inputs and new equality multipliers, parallel over stages:

@@ -236,7 +236,7 @@ class _KalmanFilter:
         return like_input(out[0], pred), like_input(yp[0].reshape(-1, 1), pred)
 
     # ---- several steps per call: `self._function.mapaccum(steps)` (kf.py:296-306) -------------------
-    def _estimate_steps(self, y, u, p, steps):
+    def _estimate_steps(self, y, u, p, steps, inputs_unchanged=False):
         """y [steps, B, n_y]; u [steps, B, n_u] or [B, n_u] (held over the steps); p like a single step.  One launch for all
         steps (hilo_kf_steps); the solution holds the sequences x [steps, B, n_x], P [steps, B, n_x, n_x], y [steps, B, n_y]."""
         dev = self._dev
@@ -267,8 +267,10 @@ class _KalmanFilter:
                     raise RuntimeError("No input data supplied.")
                 ut = to_dev(u, dev)
                 per_step = ut.numel() == steps * B * self._n_u and steps > 1
-            # [u; p] rows (kf.py:130) in a buffer the filter keeps; device tensors handed over again unmodified (same object, same
-            # version counter) are not copied again - the launch is then the only work of the call
+            # [u; p] rows (kf.py:130) in a buffer the filter keeps.  With `inputs_unchanged=True` the CALLER states that device tensors
+            # handed over again (same object, same version counter) hold the same values, and they are not copied again - the
+            # launch is then the only work of the call.  Opt-in: a write through a raw pointer (a kernel of this library filling
+            # the tensor, DLPack consumers, `.data`) does not bump the version counter and would be served stale.
             rows = steps if per_step else 1
             key = tuple((id(t), t._version, tuple(t.shape)) if isinstance(src, torch.Tensor) and src.device == t.device else None
                         for src, t in ((u, ut), (p if p is not None else self._p, pt)) if t is not None)
@@ -276,7 +278,7 @@ class _KalmanFilter:
             if buf is None or buf.shape[0] != rows or buf.shape[1] != B:
                 buf = self._ups_buf = torch.empty(rows, B, nup, dtype=torch.float64, device=dev)
                 self._ups_key = None
-            if None in key or key != self._ups_key:
+            if not inputs_unchanged or None in key or key != self._ups_key:
                 if self._n_u:
                     buf[:, :, :self._n_u] = ut.reshape(steps, B, self._n_u) if per_step else ut.reshape(-1, self._n_u).expand(B, -1)[None]
                 if self._n_p:
@@ -317,7 +319,7 @@ class _KalmanFilter:
         if y is None:
             raise RuntimeError("No measurement data supplied.")
         if int(kwargs.get('steps', 1) or 1) > 1:
-            return self._estimate_steps(y, u, p, int(kwargs['steps']))
+            return self._estimate_steps(y, u, p, int(kwargs['steps']), bool(kwargs.get('inputs_unchanged', False)))
         B = self._x.shape[0]
         for name, val, n in (('y', y, self._n_y), ('u', u, self._n_u), ('p', p, self._n_p)):     # base.py `_process_inputs`
             if val is not None and n:
@@ -349,6 +351,7 @@ class _KalmanFilter:
         # no concatenation kernel); the packed [x|P] tile ping-pongs between two resident buffers, x and P are views of it
         nup = self._n_u + self._n_p
         upt, us = None, 0
+        unchanged = bool(kwargs.get('inputs_unchanged', False))
         if nup:
             buf = getattr(self, '_up_buf', None)
             if buf is None or buf.shape[0] != B:
@@ -356,15 +359,15 @@ class _KalmanFilter:
                 self._up_p_src = self._up_u_src = None
             if self._n_u:
                 ukey = (id(u), u._version) if isinstance(u, torch.Tensor) and u.device == buf.device else None
-                if ukey is None or getattr(self, '_up_u_src', None) != ukey:
+                if not unchanged or ukey is None or getattr(self, '_up_u_src', None) != ukey:
                     buf[:, :self._n_u] = ut
                     self._up_u_src, self._up_u_ref = ukey, u
             if self._n_p:
-                # device tensors handed over again unmodified (same live object, same version counter) are not copied again;
-                # host data always is
+                # estimate(..., inputs_unchanged=True): device tensors handed over again (same live object, same version counter)
+                # are not copied again - the caller's statement, see _estimate_steps; host data always is
                 src = self._p if p is None else p
                 key = (id(src), src._version) if isinstance(src, torch.Tensor) and src.device == buf.device else None
-                if key is None or self._up_p_src != key:
+                if not unchanged or key is None or self._up_p_src != key:
                     buf[:, self._n_u:] = pt
                     self._up_p_src, self._up_p_ref = key, src          # (kept alive: an id is only unique among live objects)
             upt, us = buf, nup

@@ -263,18 +263,22 @@ class LMPC:
         _lib.check(_lib.lib().hilo_qp_create(n_v, N * nx, self._dev.index, C.byref(h)))
         so = {k.split('.')[-1]: v for k, v in (solver_options or {}).items()}
         _lib.check(_lib.lib().hilo_qp_set_options(h, float(so.get('tol', 0.)), int(so.get('max_iter', 0))))
-        # A QP with the stage shape x_{k+1} = A_k x_k + B_k u_k (the time-varying branch mpc.py:2236-2240, the corrected input block,
-        # or sizes where `kron(B, I_N)` (:2243) happens to be it) is solved stage by stage (csrc/hilo_qp_ocp.h); the reference's
-        # `kron(B, I_N)` couples the stages differently and stays on the dense kernels.  Variables pinned by equal bounds other than
-        # x_0 are left to the dense kernels too.
-        staged = bool(self._n_par()) or np.array_equal(Aeq, self._equality_matrix([A], [B], 'corrected'))
-        staged = staged and not (np.any(xl == xu) or np.any(ul == uu))
-        used = C.c_int(0)
-        if staged:
-            _lib.check(_lib.lib().hilo_qp_set_stages(h, nx, nu, N, C.byref(used)))
-        self._qp_stages = bool(used.value)
+        self._pinned_box = bool(np.any(xl == xu) or np.any(ul == uu))
         self._destroy()
         self._handle = h
+        self._declare_stages(Aeq, [A], [B])
+
+    def _declare_stages(self, Aeq, As, Bs):
+        """A QP with the stage shape x_{k+1} = A_k x_k + B_k u_k - the time-varying branch (mpc.py:2236-2240), the corrected input
+        block, or sizes where `kron(B, I_N)` (:2243) happens to be it - is solved stage by stage (csrc/hilo_qp_ocp.h, which reads
+        ONLY the block-diagonal positions of the input block); the reference's `kron(B, I_N)` couples the stages differently and
+        stays on the dense kernels, and so do variables pinned by equal bounds other than x_0.  Decided from the equality block
+        itself, every time it is assembled (setup, new parameter values)."""
+        staged = len(As) > 1 or np.array_equal(Aeq, self._equality_matrix(As, Bs, 'corrected'))
+        staged = staged and not self._pinned_box
+        used = C.c_int(0)
+        _lib.check(_lib.lib().hilo_qp_set_stages(self._handle, self._n_x, self._n_u, self._horizon if staged else 0, C.byref(used)))
+        self._qp_stages = bool(used.value)
 
     def _destroy(self):
         if self._handle is not None:
@@ -299,9 +303,13 @@ class LMPC:
                   for a in ('_x_eq', '_u_eq')]
             key = P.tobytes() + b'|' + eq[0].tobytes() + b'|' + eq[1].tobytes() + b'|' + repr(self._model.dt).encode()
             if key != self._aeq_key:        # new parameter values: the equality block of this QP (host assembly, one upload)
-                mats = [self._model.system_matrices(p=pk) for pk in P]
-                Aeq = self._equality_matrix([m[0] for m in mats], [m[1] for m in mats], self._kron_variant)
+                # one pair per stage only with time-varying parameters (`diagcat`, mpc.py:2200-2206, :2236-2240); constant
+                # parameters alone leave the reference on its `kron(I, A)` / `kron(B, I_N)` branch (:2208-2210, :2241-2243)
+                mats = [self._model.system_matrices(p=pk) for pk in (P if self._time_varying_parameters else P[:1])]
+                As, Bs = [m[0] for m in mats], [m[1] for m in mats]
+                Aeq = self._equality_matrix(As, Bs, self._kron_variant)
                 self._Ad, self._aeq_key = to_dev(Aeq, self._dev), key
+                self._declare_stages(Aeq, As, Bs)
         else:
             if tvp is not None:
                 raise ValueError("time-varying parameter values were passed, but the model has no parameters")

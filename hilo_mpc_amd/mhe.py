@@ -91,7 +91,17 @@ class _StageCost:
         self._is_set = True
 
     def add_inputs(self, names, weights):
-        raise NotImplementedError("input-noise costs are not yet offloaded")
+        """modeling.py:714-733 adds (u - u_meas)^T W (u - u_meas) to the stage term - but the estimator builds its stage function over
+        `[w, x, t_ref]` only (mhe.py:480-483) and calls it with `(w_ii, x_ii, y_ii)` (:743): the model inputs stay FREE symbols of
+        that function (CasADi refuses to create it) and the input measurements are never passed; the inputs are no decision
+        variables of the window either (:596-690).  The reference cannot be set up with this term - nothing to be in parity with."""
+        names = [names] if isinstance(names, str) else list(names)
+        for n in names:
+            if n not in self._model.input_names:
+                raise ValueError(f"The state {n} does not exist. The available states are {list(self._model.input_names)}")
+        raise NotImplementedError("MHE stage cost on inputs: the reference's stage function leaves the model inputs as free symbols "
+                                  "(mhe.py:480-483) and cannot be set up with this term; inputs are data of the window "
+                                  "(add_measurements(y_meas, u_meas)), not variables")
 
 
 class MovingHorizonEstimator:
@@ -187,9 +197,27 @@ class MovingHorizonEstimator:
                 method = opts['integration_method'] = 'discrete'
             elif method == 'discrete':
                 raise ValueError("integration_method 'discrete' needs a discrete-time model (Model.discretize)")
+            elif method == 'multiple_shooting':
+                # mhe.py:586-593, :713-718: CVODES over the interval, the state noise added to its end state.  WITHOUT state noise the
+                # reference never defines the end state of the interval (`x_ii_1` is assigned inside `if
+                # self._state_noise_flag`) and setup() dies with an UnboundLocalError - nothing to be in parity with.  With it, the
+                # stand-in is the one the controller has for 'cvodes' (nmpc.py): a FIXED-step classic Runge-Kutta map with
+                # SUNDIALS_SUBSTEPS sub-steps per sampling interval and exact derivatives of that map; no error control - a stiff
+                # model needs 'collocation' (DESIGN.md 7).
+                if self.quad_stage_cost.Ww is None:
+                    raise NotImplementedError("integration_method 'multiple_shooting' without state noise cannot be set up in the "
+                                              "reference either (mhe.py:713-718 leaves the interval's end state undefined)")
+                if getattr(m, 'n_z', 0):
+                    raise NotImplementedError("'multiple_shooting' on a model with algebraic states is not offloaded: use 'collocation'")
+                from .nmpc import NMPC
+                warnings.warn(f"integration_method 'multiple_shooting': SUNDIALS' adaptive integrator is replaced by a fixed-step "
+                              f"Runge-Kutta map of order 4 with {NMPC.SUNDIALS_SUBSTEPS} sub-steps per sampling interval")
+                m = self._model = m.discretize('rk4', n_sub=NMPC.SUNDIALS_SUBSTEPS)
+                if not m._is_setup:
+                    m.setup()
+                method = opts['integration_method'] = 'discrete'
             elif method != 'collocation':
-                raise NotImplementedError(f"integration method '{method}' is not offloaded (the reference's 'multiple_shooting' "
-                                          f"branch integrates with CVODES)")
+                raise NotImplementedError(f"integration method '{method}' is not offloaded")
         self._nlp_options = opts
         if nlp_opts is not None:
             self.set_solver_opts(nlp_opts)

@@ -472,6 +472,8 @@ class NMPC:
         self._time, self._n_iterations = 0., 0
         if self._handle is not None:
             _lib.check(_lib.lib().hilo_nmpc_reset_warm_start(self._handle))
+        if getattr(self, '_mt', None) is not None:       # minimum-time problems: the solve lives in the inner controller
+            self._mt.reset_solution()
 
     SUNDIALS_SUBSTEPS = 64    # Runge-Kutta sub-steps per interval behind integration_method 'cvodes' / 'idas'
 
@@ -600,9 +602,11 @@ class NMPC:
                               'iter_count': s['iter_count'], 'kkt_error': s.get('kkt_error')}
         self._time += self._sampling_interval
         self._n_iterations += 1
-        if host:
+        if host:                                         # the regular path's conventions: (nu x 1) for a single host state
             u = u if isinstance(u, np.ndarray) else u.cpu().numpy()
-        return u
+            return u.reshape(-1, 1) if single else u.reshape(-1, self._n_u)
+        u = u.reshape(-1, self._n_u)
+        return u[0] if single else u
 
     def set_custom_constraints_function(self, fun=None, lb=None, ub=None, soft=False, max_violation=np.inf):
         raise NotImplementedError("a custom constraint is a function of the WHOLE decision vector (mpc.py:1729-1745): it couples "
@@ -1012,7 +1016,7 @@ class NMPC:
                 d.path_prog, d.path_prog_len = None, 0          # expressions are compiled in, not interpreted
                 d.con_prog, d.con_prog_len, d.tcon_prog, d.tcon_prog_len = None, 0, None, 0
                 pat = self._hessian_pattern(m, nx, nu, nth, Wz, Wdu if has_du else None, gen_stage, sc, tc,
-                                            composed=bool(cont or coll is not None))
+                                            composed=bool(cont or coll is not None), extra=[m.z[a] for a in zb])
                 if pat is not None:
                     pat = np.ascontiguousarray(pat, dtype=np.uint8)
                     keep.append(pat)
@@ -1234,7 +1238,7 @@ class NMPC:
             return u.reshape(-1, 1) if single else u     # single instance: (nu x 1) like the reference's DM
         return u0[0] if single else u0
 
-    def _hessian_pattern(self, m, nx, nu, nth, Wz, Wdu, gen_stage, sc, tc, composed=False):
+    def _hessian_pattern(self, m, nx, nu, nth, Wz, Wdu, gen_stage, sc, tc, composed=False, extra=()):
         """Structural sparsity of the interval Hessian over the augmented z = [x, theta | u, u_theta] (hilo_mpc_amd/sparsity.py),
         or None (dense) when the model has no expression form."""
         from . import zoo_expr
@@ -1274,7 +1278,10 @@ class NMPC:
                 Wa[az(i), az(j)] = W[i, j]
         # stage constraints act at the node (mpc.py:1700-1725; with collocation also at the collocation states: composed);
         # a hard terminal constraint on the integrated end state (mpc.py:1693-1700), a soft one at the node x_{N-1}
-        exprs = [gen_stage] + (list(sc.constraint) if sc.is_set else []) + (list(tc.constraint) if tc.is_set and tc.is_soft else [])
+        # (`extra`: the rows of bounded algebraic states - z itself, i.e. after the elimination the surrogate of every z: their
+        # multiplier-weighted second derivatives belong to the interval Hessian like those of any other row)
+        exprs = [gen_stage] + (list(sc.constraint) if sc.is_set else []) + (list(tc.constraint) if tc.is_set and tc.is_soft else []) + \
+            list(extra)
         exprs_c = list(tc.constraint) if tc.is_set and not tc.is_soft else []
         if elim is not None:
             exprs = [None if e is None else Expr.substitute([Expr.wrap(e)], elim)[0] for e in exprs]

@@ -183,11 +183,12 @@ def test_stage_kernel_on_a_four_state_two_input_system(monkeypatch):
     st = make()
     assert st._qp_stages
     u1 = st.optimize(x0)
+    st1 = st.solver_status_code.copy()
     one = st.optimize(x0[3])
     monkeypatch.setenv('HILO_QP_DENSE', '1')
     de = make()
     u2 = de.optimize(x0)
-    assert np.array_equal(st.solver_status_code[:0], de.solver_status_code[:0]) and np.all(de.solver_status_code == 1)
+    assert np.array_equal(st1, de.solver_status_code) and np.all(de.solver_status_code == 1)
     np.testing.assert_allclose(u1, u2, rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(np.ravel(one), u2[3], rtol=1e-8, atol=1e-9)
     assert (np.abs(u1[:, 0]) > 1 - 1e-6).sum() >= 3                       # input bounds active somewhere
@@ -244,6 +245,23 @@ def test_models_written_as_expressions():
         if with_parameters:
             with pytest.raises(ValueError, match="constant parameter"):
                 mpc.optimize([.5, 0, 0, 0])
+            # constant parameters alone and the DEFAULT setup: the reference stays on its `kron(B, I_N)` branch (mpc.py:2241-2243),
+            # which is not the stage shape for nx > 1 - the stage kernel must not be declared (it reads only the block-diagonal
+            # positions of the input block), and the QP is the one of the same matrices handed over directly
+            df = LMPC(ml)
+            df.horizon = 10
+            df.Q, df.R = np.eye(4), np.eye(2)
+            df.setup()
+            ud = df.optimize([.5, 0, 0, 0], cp=cp)
+            assert not df._qp_stages and df.solver_status_code[0] == 1
+            mat = LMPC(Model('lti', A=A, B=B).setup(dt=.05))
+            mat.horizon = 10
+            mat.Q, mat.R = np.eye(4), np.eye(2)
+            mat.setup()
+            assert not mat._qp_stages
+            np.testing.assert_array_equal(df._Ad.cpu().numpy(), mat._Ad.cpu().numpy())
+            np.testing.assert_array_equal(ud, mat.optimize([.5, 0, 0, 0]))
+            assert not np.allclose(ud, u, atol=1e-6)     # ... and a different problem than the block-diagonal one
             # tests/test_LMPC.py:175-188: one length varies along the horizon; held constant it is the constant-parameter problem
             # in the block-diagonal ("corrected") form of the input block
             tv = LMPC(ml)

@@ -356,3 +356,38 @@ def test_measurement_subset_in_the_cost_vs_oracle():
     np.testing.assert_allclose(outs[0], outs[1], rtol=1e-9)
     with pytest.raises(ValueError, match="does not exist"):
         mhe.quad_stage_cost.add_measurements(weights=[1.], names=['nope'])
+
+
+@pytest.mark.parametrize('symbolic', [False, True])
+def test_multiple_shooting_with_state_noise_vs_oracle(symbolic):
+    """`integration_method='multiple_shooting'` with state noise (mhe.py:586-593, :713-718: CVODES over the interval + w; configured by
+    the reference's tests/test_MHE.py:480-500): accepted with a warning, the interval map is classic Runge-Kutta with 64 sub-steps
+    (the controller's stand-in for 'cvodes') and its exact derivatives - against the oracle on THAT map (oracle/mhe.py, n_sub = 64),
+    zoo functor and expression model.  Without state noise the reference cannot be set up (Q8): refused."""
+    from hilo_mpc_amd import MHE, Model
+    from oracle import models
+    from oracle.mhe import MheProblem
+    from tests.problems import symbolic_model
+    N, B = 5, 3
+    spec = dict(C3B, N=N)
+    xa, um, ym, _ = c3_data(B, N=N)
+    pb = MheProblem(models.get('chemostat4'), n_sub=64, **{k: v for k, v in spec.items() if k not in ('model', 'p')})
+    ref = MheIpm(pb).solve(xa, spec['p'], um, ym)
+    assert np.all(ref['status'] == 1)
+    m = (symbolic_model('chemostat4') if symbolic else Model('chemostat4')).setup(dt=spec['dt'])
+    with pytest.warns(UserWarning, match="fixed-step Runge-Kutta map of order 4 with 64 sub-steps"):
+        mhe = _mhe_from(m, spec, {'integration_method': 'multiple_shooting'})
+    for k in range(N):
+        mhe.add_measurements(ym[:, k], um[:, k])
+    x_opt, _ = mhe.estimate(x_arrival=xa)
+    assert np.array_equal(mhe.solver_status_code, ref['status'])
+    v, vr = mhe._nlp_solution['x'].cpu().numpy(), ref['v']
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 1e-5
+    np.testing.assert_allclose(mhe._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(x_opt.cpu().numpy(), ref['x_opt'], rtol=1e-5, atol=1e-6)
+    plain = MHE(Model('chemostat4').setup(dt=spec['dt']))
+    plain.quad_arrival_cost.add_states(weights=list(spec['Wx']), guess=spec['x_guess'])
+    plain.quad_stage_cost.add_measurements(weights=list(spec['Wy']))
+    plain.horizon = N
+    with pytest.raises(NotImplementedError, match="without state noise"):
+        plain.setup(options={'integration_method': 'multiple_shooting'})

@@ -20,8 +20,9 @@ def main(argv):
     before = set(os.listdir(cache)) if os.path.isdir(cache) else set()
     env = dict(os.environ, HILO_JIT_COMPILE_ONLY='1')
     sel = argv or ['tests']
+    jobs = os.environ.get('HILO_WARM_JOBS', str(max(1, (os.cpu_count() or 2) - 2)))      # pytest-xdist workers (compilations are independent)
     subprocess.call([sys.executable, '-m', 'pytest', '-m', 'gpu', '-q', '-p', 'no:cacheprovider', '--tb=no', '--no-header',
-                     '-W', 'ignore'] + sel, cwd=ROOT, env=env, stdout=subprocess.DEVNULL)
+                     '-W', 'ignore', '-n', jobs] + sel, cwd=ROOT, env=env, stdout=subprocess.DEVNULL)
     after = set(os.listdir(cache)) if os.path.isdir(cache) else set()
     print(f"{len(after - before)} new code object(s), {len(after)} in {cache}")
     # the backend's EXEC-prologue defect shows up in run-time compiled problems as well: check what was compiled
