@@ -1872,17 +1872,28 @@ struct Ocp {
   };
   // R = [r00 r10; r10 r11] = L D L^T:  i0 = 1 / d_0,  i1 = 1 / d_1 = r00 / det R,  l = r10 / r00  (the two reciprocals are independent)
   struct PivotInv { double i0, i1, l; bool ok; };
+  // reciprocal of a pivot: v_rcp_f64 (about 2^-26 relative) + HILO_RCP_PIVOT_NEWTON Newton steps; the lanes (i, j) and (j, i) run the
+  // same instructions on the same bits, so the cost-to-go stays bitwise symmetric whatever the last bits are
+#ifndef HILO_RCP_PIVOT_NEWTON
+#define HILO_RCP_PIVOT_NEWTON 2
+#endif
+  __device__ __forceinline__ static double rcp_pivot(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+#pragma unroll
+    for (int q = 0; q < HILO_RCP_PIVOT_NEWTON; ++q) r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+  }
   __device__ __forceinline__ static PivotInv pivot_inverse(double r00, double r10, double r11) {
     PivotInv p;
     if constexpr (NU == 2) {
       const double det = fma(r00, r11, -r10 * r10);
       p.ok = r00 > 0.0 && det > 0.0;
-      p.i0 = rcp_fast(r00);
-      p.i1 = r00 * rcp_fast(det);
+      p.i0 = rcp_pivot(r00);
+      p.i1 = r00 * rcp_pivot(det);
       p.l = r10 * p.i0;
     } else {
       p.ok = r00 > 0.0;
-      p.i0 = rcp_fast(r00);
+      p.i0 = rcp_pivot(r00);
       p.i1 = 0.0;
       p.l = 0.0;
     }
@@ -2159,6 +2170,11 @@ struct Ocp {
 #ifndef HILO_RIC_PIPE
 #define HILO_RIC_PIPE 1
 #endif
+  // D0: no inertia correction (delta = 0: every factorisation of a converging solve) - the next stage's tile is then the loaded
+  // [H + Sigma | r] as it is.  Nothing in the shadow of the second product may be an f64 vector instruction: the f64 products run on
+  // the same arithmetic units, and the first such instruction (the closed-loop row's multiply-adds and these diagonal adds in the
+  // first version: 120 clocks per stage, measured) waits for the whole product, and with it everything behind it.
+  template <bool D0>
   __device__ __forceinline__ static bool backward_dup(const Lds l, int N, double delta) {
     static_assert(DUPU && !BIG, "backward_dup: duplicated-row policies with the iterate in LDS");
     const int t = threadIdx.x, q = t & 15, g = t >> 4;
@@ -2235,17 +2251,17 @@ struct Ocp {
         }
         o.M0 = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < RD_; ++r) o.M0[r] = raw.w[r] + dl[r];
+        for (int r = 0; r < RD_; ++r) o.M0[r] = D0 ? raw.w[r] : raw.w[r] + dl[r];
       }
     };
     bool pd = true;
     // outputs of a finished stage (with the operands `po` it ran on), stored during the next stage's second product
-    double d_ny[NU], d_sv[KB];
+    double d_ny[NU], d_sv[KB], d_cl[KB];
 #pragma unroll
     for (int a = 0; a < NU; ++a) d_ny[a] = 0.0;
 #pragma unroll
-    for (int r = 0; r < KB; ++r) d_sv[r] = 0.0;
-    auto emit = [&](const StageOps& po) __attribute__((always_inline)) {
+    for (int r = 0; r < KB; ++r) { d_sv[r] = 0.0; d_cl[r] = 0.0; }
+    auto emit = [&]() __attribute__((always_inline)) {
       // feedback K[:, q] = -y_q (kff = -y_NZ): every row group writes the same value; closed-loop row and cost-to-go entry
       if (use) {
 #pragma unroll
@@ -2253,11 +2269,8 @@ struct Ocp {
 #pragma unroll
         for (int r = 0; r < KB; ++r) {
           if (NX % 4 == 0 || g + 4 * r < NX) {
-            double cl = po.b1[r];                        // A[i][q] (q < NX) or -c[i] (q = NZ)
-#pragma unroll
-            for (int a = 0; a < NU; ++a) cl = fma(po.bi[r][a], d_ny[a], cl);
             pP[r][0] = d_sv[r];
-            pAcl[r][0] = cl;
+            pAcl[r][0] = d_cl[r];
           }
         }
       }
@@ -2287,10 +2300,11 @@ struct Ocp {
 #if HILO_RIC_PIPE
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      if (have) emit(on);
+      if (have) emit();
       finish(on, k > 0 ? k - 1 : 0);
 #if HILO_RIC_PIPE
       __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+v"(Macc));   // (as above: rows of the tile nothing reads would otherwise be handed out as temporaries of the shadow)
 #endif
       // own column of the input rows (registers RB_ + a), the transposed partner's for the row(s) of this lane
       double mq[NU], mg[KB][NU], mji[KB];
@@ -2326,6 +2340,10 @@ struct Ocp {
         double sv = fma(-(mg[r][0] * mq[0]), pv.i0, sym);        // every product: the same bits in the lanes (i, q) and (q, i)
         if constexpr (NU == 2) sv = fma(-(fma(-pv.l, mg[r][0], mg[r][1]) * tq), pv.i1, sv);
         d_sv[r] = sv;
+        double cl = o.b1[r];                            // closed-loop row: A[i][q] (q < NX) or -c[i] (q = NZ), + B[i] (-y_q)
+#pragma unroll
+        for (int a = 0; a < NU; ++a) cl = fma(o.bi[r][a], d_ny[a], cl);
+        d_cl[r] = cl;
         // rows of T beyond NX are read by nothing when NX fills its blocks of four: lanes q >= NX may keep their (finite) value
         Pr[r] = (NX % 4 == 0) ? sv : ((valid && colP) ? sv : 0.0);
         pr[r] = (valid && colR) ? sv : 0.0;
@@ -2345,7 +2363,7 @@ struct Ocp {
       stage(k - 1, oB, oA, true);
       have = true;
     }
-    emit(oB);
+    emit();
     return uni(pd);
   }
 
@@ -2391,7 +2409,7 @@ struct Ocp {
 #ifndef HILO_RICCATI_LDS
     if constexpr (MFMA_STAGE && NU > 0 && NH == 0) {
       bool okb;
-      if constexpr (DUPU && !BIG) okb = backward_dup(l, N, delta);
+      if constexpr (DUPU && !BIG) okb = delta == 0.0 ? backward_dup<true>(l, N, delta) : backward_dup<false>(l, N, delta);
       else okb = backward_reg(l, N, delta);
       if (!okb) return false;
       __syncthreads();
