@@ -220,19 +220,20 @@ def zoo_alias(functor):
     return f"using UserModel = {functor};\n"
 
 
-def fun_source(n_x, stage=None, term=None, con=(), tcon=(), path_stage=(), path_term=()):
+def fun_source(n_x, stage=None, term=None, con=(), tcon=(), path_stage=(), path_term=(), acc=()):
     """`struct UserFun` (csrc/hilo_nmpc_user.h): generic costs (scaled variables), constraint expressions (un-scaled
     variables; `z`: the algebraic states of a DAE model at the point, NULL when no expression names one), path references
     (functions of the path variable = state index n_x)."""
     uses_z = any(Expr.wrap(e).depends_on('z') for e in con)
     for what, ee in (('cost', [e for e in (stage, term) if e is not None]), ('terminal constraint', tcon),
-                     ('path reference', list(path_stage) + list(path_term))):
+                     ('path reference', list(path_stage) + list(path_term)), ('custom constraint', acc)):
         if any(Expr.wrap(e).depends_on('z') for e in ee):
             raise NotImplementedError(f"an algebraic state inside a {what} is not offloaded (stage constraints may name them)")
     s = ("struct UserFun {\n"
          f"  static constexpr bool HAS_STAGE = {'true' if stage is not None else 'false'}, "
          f"HAS_TERM = {'true' if term is not None else 'false'};\n"
-         f"  static constexpr int NEXPR = {len(con)}, NTEXPR = {len(tcon)}, NPS = {len(path_stage)}, NPT = {len(path_term)};\n"
+         f"  static constexpr int NEXPR = {len(con)}, NTEXPR = {len(tcon)}, NPS = {len(path_stage)}, NPT = {len(path_term)}, "
+         f"NACC = {len(acc)};\n"
          f"  static constexpr bool CON_USES_Z = {'true' if uses_z else 'false'};\n")
     if stage is not None:
         em = Emitter(theta_index=n_x)
@@ -252,6 +253,11 @@ def fun_source(n_x, stage=None, term=None, con=(), tcon=(), path_stage=(), path_
             rr = [em.ref(e) for e in exprs]
             s += _fn('void', name, args, ["    (void)x; (void)u; (void)p;" + (" (void)z;" if name == 'con' else "")] + em.lines,
                      [f"    c[{i}] = T({r});" for i, r in enumerate(rr)])
+    if acc:      # stage expressions of a custom constraint function (hilo_mpc_amd/custom.py): SCALED states / inputs, like `stage`
+        em = Emitter(theta_index=n_x)
+        rr = [em.ref(e) for e in acc]
+        s += _fn('void', 'acc', 'const T* x, const T* u, const double* p, T* c', ["    (void)x; (void)u; (void)p;"] + em.lines,
+                 [f"    c[{i}] = T({r});" for i, r in enumerate(rr)])
     for name, exprs in (('path_stage', path_stage), ('path_term', path_term)):
         if exprs:
             em = Emitter(theta_index=n_x)

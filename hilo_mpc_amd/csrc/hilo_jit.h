@@ -26,6 +26,7 @@ struct JitRequest {
   std::string user_source;   // defines `UserModel` (struct or alias of a zoo functor) and, if has_fun, `UserFun`
   int policy = JIT_TRACK;
   int nth = 0, ne = 0, nc = 0, coll_d = 0, N = 1;
+  int nq = 0;                    // JIT_USER: accumulator states of custom constraint rows (hilo_nmpc_user.h)
   bool hold = false, cont = false, tv = false, big = false, has_fun = false;
   bool sym = true;               // JIT_TRACK: symbolic model derivatives when the source provides them (one RK step per interval)
   bool mhe_gen = false;          // JIT_MHE: the general estimator policy MheGen (parameters as states, optional state noise)

@@ -79,8 +79,8 @@ static std::string translation_unit(const JitRequest& r) {
            "#define HILO_USER_POLICY %d\n"
            "#define HILO_USER_NTH %d\n#define HILO_USER_NE %d\n#define HILO_USER_NC %d\n#define HILO_USER_COLL_D %d\n"
            "#define HILO_USER_N %d\n#define HILO_USER_HOLD %d\n#define HILO_USER_CONT %d\n#define HILO_USER_TV %d\n"
-           "#define HILO_USER_BIG %d\n#define HILO_USER_HAS_FUN %d\n#define HILO_USER_SYM %d\n",
-           r.policy, r.nth, r.ne, r.nc, r.coll_d, r.N, (int)r.hold, (int)r.cont, (int)r.tv, (int)r.big, (int)r.has_fun, (int)r.sym);
+           "#define HILO_USER_BIG %d\n#define HILO_USER_HAS_FUN %d\n#define HILO_USER_SYM %d\n#define HILO_USER_NQ %d\n",
+           r.policy, r.nth, r.ne, r.nc, r.coll_d, r.N, (int)r.hold, (int)r.cont, (int)r.tv, (int)r.big, (int)r.has_fun, (int)r.sym, r.nq);
   std::string s(cfg);
   s += "#include \"hilo_nmpc_gen.h\"\n#include \"hilo_nmpc_track.h\"\n#include \"hilo_nmpc_user.h\"\n";
   // device pointers to the packed learned terms (gp_pack_se) the user source refers to as hilo_user_gp[k]; written by the host
@@ -90,7 +90,8 @@ static std::string translation_unit(const JitRequest& r) {
   s += r.user_source;
   s += R"(
 struct UserCfg {
-  static constexpr int NTH = HILO_USER_NTH, NE = HILO_USER_NE, NC = HILO_USER_NC, COLL_D = HILO_USER_COLL_D, N = HILO_USER_N;
+  static constexpr int NTH = HILO_USER_NTH, NE = HILO_USER_NE, NC = HILO_USER_NC, COLL_D = HILO_USER_COLL_D, N = HILO_USER_N,
+                       NQ = HILO_USER_NQ;
   static constexpr bool HOLD = HILO_USER_HOLD, CONT = HILO_USER_CONT, TV = HILO_USER_TV, BIG = HILO_USER_BIG;
 };
 #if !HILO_USER_HAS_FUN

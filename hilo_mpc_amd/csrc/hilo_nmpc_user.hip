@@ -100,6 +100,23 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
       }
     }
   }
+  // rows of a custom constraint function (desc.n_acc; hilo_mpc_amd/custom.py): one accumulator state each, imposed as the LAST
+  // terminal rows (hilo_nmpc_user.h::term_rows); in the engine's lam_g they follow the terminal rows - the host moves them to the end
+  // of g, where the reference has them (mpc.py:1729-1745)
+  const int nq = d->n_acc, npsi = d->n_acc_expr;
+  HILO_REQUIRE(nq >= 0 && nq <= 2 && npsi >= 0 && npsi <= 4, "hilo_nmpc_create: at most 2 custom rows over at most 4 stage expressions");
+  if (nq > 0) {
+    HILO_REQUIRE(npsi > 0 && d->acc_coef && d->acc_lb && d->acc_ub, "hilo_nmpc_create: custom rows need acc_coef, acc_lb, acc_ub");
+    if (d->n_tcon > 0 && d->tcon_soft) return fail(HILO_ENOTSUP, "custom rows together with a SOFT terminal constraint are not built");
+    if (d->Nc > 0 && d->Nc < d->N) return fail(HILO_ENOTSUP, "custom rows together with a control horizon Nc < N are not built");
+    for (int r = 0; r < nq; ++r) {
+      HILO_REQUIRE(d->acc_lb[r] <= d->acc_ub[r], "hilo_nmpc_create: custom row %d has lb > ub", r);
+      HILO_REQUIRE(nrow + ntrow < OCP_MAXNC, "too many constraint rows");
+      trow_expr[ntrow] = 0; trow_sign[ntrow] = 0; trow_e[ntrow] = -1; trow_lb[ntrow] = d->acc_lb[r]; trow_ub[ntrow] = d->acc_ub[r];
+      trow_ref[ntrow++] = n_tcon_ref + r;
+    }
+    n_tcon_ref += nq;
+  }
   // collocation: the reference imposes the stage constraints at every collocation point as well as at the node (mpc.py:1338-1356,
   // :1700-1725) - the engine's rows of a stage are the node's rows followed by those of the d collocation points
   const int nrow_pt = nrow;
@@ -115,14 +132,14 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   const bool hold = Nc < N;
   const int mxa = mx + nth, mua = mu + nth;
   const int nh = hold ? mua : 0;
-  const int nxe = mxa + ne + nh, nue = mua, nz = nxe + nue;
+  const int nxe = mxa + ne + nq + nh, nue = mua, nz = nxe + nue;
   HILO_REQUIRE(nxe <= OCP_MAXNX && nue <= OCP_MAXNU,
                "hilo_nmpc_create: %d engine states / %d inputs (model + path variable + slacks + held inputs) exceed %d / %d", nxe,
                nue, OCP_MAXNX, OCP_MAXNU);
   const int nps = d->n_path_stage, npt = d->n_path_term;
   HILO_REQUIRE(nps >= 0 && npt >= 0 && nps <= 8 && npt <= 8, "hilo_nmpc_create: at most 8 path terms per cost");
   HILO_REQUIRE((nps + npt == 0) || nth, "hilo_nmpc_create: path terms need a path variable");
-  const UserLayout L(mx, mu, nth, ne, nps, npt);
+  const UserLayout L(mx, mu, nth, ne, nps, npt, nq, npsi, N);
   HILO_REQUIRE(L.o_end <= OCP_NCOST, "hilo_nmpc_create: cost block too small for this problem");
   const bool tv = d->time_varying != 0;
   const int nsd = tv ? mx + mu + np : 0;
@@ -140,7 +157,7 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   memset(h, 0, sizeof(*h));
   h->device = device; h->model_id = d->model_id; h->nx = mx; h->nu = mu; h->np = np; h->N = N;
   h->nu_out = mu; h->jit_policy = JIT_USER;
-  h->nxe = nxe; h->nue = nue; h->nxv = mxa; h->ntail = ne; h->Nc = Nc;
+  h->nxe = nxe; h->nue = nue; h->nxv = mxa; h->ntail = ne + nq; h->Nc = Nc;   // (the accumulators ride in the tail of v: hidden by the host)
   h->tv_width = nsd;
   h->jit_ws_bytes = big ? iter_b + prep_b : 0;
   h->jit_coll_d = D;
@@ -148,8 +165,8 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   HILO_REQUIRE(nza >= 0 && nza <= 4, "hilo_nmpc_create: at most 4 algebraic states (got %d)", nza);
   if (nza > 0 && D == 0)
     return fail(HILO_ENOTSUP, "algebraic states (DAE) are built for the collocation transcription");
-  h->n_vc = (N + 1) * mxa + Nc * mua + ne;
-  h->n_v = h->n_vc + (nza ? (N + 1) * nza : 0) + N * D * (mxa + nza);   // mpc.py:1440-1453, :1488-1548
+  h->n_vc = (N + 1) * mxa + Nc * mua + ne + nq;
+  h->n_v = h->n_vc + (nza ? (N + 1) * nza : 0) + N * D * (mxa + nza);   // mpc.py:1440-1453, :1488-1548 (+ nq hidden tail entries)
   // mpc.py:1338-1372 (per collocation point: constraint rows, then the collocation equations), :1657-1669, :1684-1725
   h->n_g = N * (mxa + n_con_ref + D * (mxa + nza) + (D ? D * n_con_ref : 0)) + n_tcon_ref;
   h->n_gc = D ? N * (mxa + nrow) + ntrow : 0;   // the engine's compact multiplier row handed to the output pass
@@ -221,6 +238,9 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
       for (int b = 0; b < npt; ++b) c.cost[L.o_wt + a * npt + b] = d->path_term_W[a * npt + b];
     }
   }
+  for (int r = 0; r < nq; ++r)
+    for (int k = 0; k <= N; ++k)
+      for (int j = 0; j < npsi; ++j) c.cost[L.o_acc + (r * (N + 1) + k) * npsi + j] = d->acc_coef[((size_t)r * (N + 1) + k) * npsi + j];
   if (rcode) { delete h; return rcode; }
   c.nc = nrow; c.nc_term = ntrow; c.n_con_ref = n_con_ref; c.n_tcon_ref = n_tcon_ref;
   c.cost[L.o_tsoft] = d->tcon_soft ? 1.0 : 0.0;
@@ -244,7 +264,7 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
     // the solve kernel writes its multipliers compactly (identity row maps), the output pass puts them into the reference's order;
     // the slacks sit BEHIND the collocation blocks in the rows the engine reads (v0, lbx / ubx; mpc.py:1529 follows :1497-1527)
     c.n_con_ref = nrow; c.n_tcon_ref = ntrow;
-    if (ne > 0) c.tail_off = h->n_v - ne;
+    if (ne + nq > 0) c.tail_off = h->n_v - (ne + nq);
   }
   // ---- structural sparsity of the interval Hessian (desc.hess_pattern over the augmented model z): which pair directions the
   // Taylor sweeps visit.  Engine-only variables: the shared slacks couple only through off-diagonal penalty weights (rows are
@@ -295,6 +315,7 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   rq.policy = JIT_USER;
   rq.nth = nth; rq.ne = ne; rq.nc = nc; rq.coll_d = D; rq.N = N;
   rq.hold = hold; rq.cont = cont; rq.tv = tv; rq.big = big; rq.has_fun = d->user_has_fun != 0;
+  rq.nq = nq;
   rq.private_module = d->n_user_gp > 0;
   int rc = jit_nmpc_kernels(rq, device, &h->jit);
   if (!rc && getenv("HILO_JIT_COMPILE_ONLY")) { hilo_nmpc_destroy(h); return HILO_COMPILED_ONLY; }   // cache warmed, no handle

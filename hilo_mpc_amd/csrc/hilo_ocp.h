@@ -196,6 +196,10 @@ template <class PB> struct pb_fused_con<PB, void_tt<decltype(PB::FUSED_CON)>> { 
 //          (collocation: the same for all directions of an interval - without it every direction repeats the Newton solve)
 template <class PB, class = void> struct pb_prep { static constexpr int value = 0; };
 template <class PB> struct pb_prep<PB, void_tt<decltype(PB::PREP)>> { static constexpr int value = PB::PREP; };
+//   LAM_FIX  the policy adjusts the reported multipliers of the LAST shooting defect (`lam_fix`): rows the reference imposes on the
+//          node variable x_N are rows on the integrated end state here (custom constraint functions, hilo_nmpc_user.h)
+template <class PB, class = void> struct pb_lam_fix { static constexpr bool value = false; };
+template <class PB> struct pb_lam_fix<PB, void_tt<decltype(PB::LAM_FIX)>> { static constexpr bool value = PB::LAM_FIX; };
 template <class PB, class = void> struct pb_fused { static constexpr bool value = false; };
 template <class PB> struct pb_fused<PB, void_tt<decltype(PB::FUSED)>> { static constexpr bool value = PB::FUSED; };
 
@@ -3417,6 +3421,16 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
       // terminal cost on F_{N-1} in the reference (mpc.py:1682) vs on x_N here: multipliers of the last defect
       // differ by grad V(x_N) (flag bit 0)
       if ((pc.flags & 1) && k == N - 1) v += l.grad[N * NZ + i];
+      if constexpr (pb_lam_fix<PB>::value && NC > 0) {
+        if (k == N - 1) {
+          double xN[NX], nuN[NC];
+#pragma unroll
+          for (int j = 0; j < NX; ++j) xN[j] = l.Z[N * NZ + j];
+#pragma unroll
+          for (int m = 0; m < NC; ++m) nuN[m] = l.cnu[(N - 1) * NC + m];
+          v += PB::lam_fix(pc, (const double*)l.par, S::sd_of(l, N), i, xN, nuN);
+        }
+      }
       lg[k * rows + i] = v;
     }
     if constexpr (NC > 0) {

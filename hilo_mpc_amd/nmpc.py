@@ -609,9 +609,24 @@ class NMPC:
         return u[0] if single else u
 
     def set_custom_constraints_function(self, fun=None, lb=None, ub=None, soft=False, max_violation=np.inf):
-        raise NotImplementedError("a custom constraint is a function of the WHOLE decision vector (mpc.py:1729-1745): it couples "
-                                  "the stages and does not fit the stage-wise solver; use set_stage_constraints / "
-                                  "set_terminal_constraints")
+        """optimizer.py:1180-1208: `lb <= fun(v, x_ind, u_ind) <= ub`, appended at the end of g (mpc.py:1729-1745); `v` is the
+        (scaled) decision vector, `x_ind` / `u_ind` the index lists of the nodes.  Offloaded for functions that are SUMS OVER THE
+        STAGES of single-stage terms (integrals, budgets, averages - the reference's own use, tests/test_NMPC.py:519-552): each
+        row rides on an accumulator state of the stage-structured problem (hilo_mpc_amd/custom.py); the function is called once at
+        setup() with a vector of symbols.  The soft variant (slack `e_cus`, mpc.py:1551-1556, :1731-1740) is not built."""
+        if soft:
+            raise NotImplementedError("soft custom constraints (the slack e_cus of mpc.py:1551-1556) are not offloaded; hard ones are")
+        if fun is None or not callable(fun):
+            raise TypeError("The custom constraint must be a function fun(v, x_ind, u_ind).")
+        lb = [-np.inf] if lb is None else _wrap_list(lb)                 # optimizer.py:1195-1200
+        ub = [np.inf] if ub is None else _wrap_list(ub)
+        if len(lb) != len(ub):
+            raise ValueError("The custom constraint needs as many lower as upper bounds.")
+        self._custom_constraint_fun = fun
+        self._custom_constraint_fun_lb, self._custom_constraint_fun_ub = [float(v) for v in lb], [float(v) for v in ub]
+        self._custom_constraint_size = len(lb)
+        self._custom_constraint_flag = True
+        self._nlp_setup_done = False
 
     def get_time_variable(self):
         """mpc.py:1055-1062: the time symbol for trajectory references given as functions, `ref=[sin(t), ...]`."""
@@ -984,6 +999,30 @@ class NMPC:
         if coll is not None:
             d.coll_B = hp(coll['B'])
         d.objective_continuous = int(cont)
+        # ---- custom constraint function over the whole decision vector (hilo_mpc_amd/custom.py): accumulator states + terminal rows
+        acc_psi, self._nq, self._custom_const = (), 0, None
+        if getattr(self, '_custom_constraint_flag', False):
+            from .custom import decompose
+            if getattr(self, '_minimize_final_time_flag', False):
+                raise NotImplementedError("a custom constraint together with minimize_final_time is not offloaded")
+            nxa_, nua_ = nx + nth, nu + nth
+            nza_ = getattr(m, 'n_z', 0) if coll is not None else 0
+            dn_ = coll['d'] * (nxa_ + nza_) if coll is not None else 0
+            xi = [list(range(k * nxa_, (k + 1) * nxa_)) for k in range(N + 1)]
+            ui = [list(range((N + 1) * nxa_ + k * nua_, (N + 1) * nxa_ + (k + 1) * nua_)) for k in range(Nc)]
+            n_v_ref = (N + 1) * nxa_ + Nc * nua_ + (N + 1) * nza_ + N * dn_ + ne + ne_term
+            mc = self._custom_constraint_size
+            acc_psi, coef, const = decompose(self._custom_constraint_fun, xi, ui, n_v_ref, m, mc)
+            if Nc < N:
+                raise NotImplementedError("a custom constraint together with a control horizon Nc < N is not offloaded")
+            if any(e.depends_on('theta') for e in acc_psi):
+                raise NotImplementedError("a custom constraint on the path variable is not offloaded")
+            self._nq, self._custom_const = mc, const
+            d.n_acc, d.n_acc_expr = mc, len(acc_psi)
+            d.acc_coef = hp(np.ascontiguousarray(coef, dtype=np.float64).ravel())
+            d.acc_lb = hp(np.asarray(self._custom_constraint_fun_lb) - const)
+            d.acc_ub = hp(np.asarray(self._custom_constraint_fun_ub) - const)
+            need_user = True
 
         def jit_desc(policy):
             from . import codegen
@@ -1011,12 +1050,12 @@ class NMPC:
                     nx, stage=gen_stage, term=gen_term,
                     con=(list(sc.constraint) if sc.is_set else []) + [m.z[a] for a in zb], tcon=tc.constraint if tc.is_set else (),
                     path_stage=[r for _, _, rr in self.quad_stage_cost._paths for r in rr],
-                    path_term=[r for _, _, rr in self.quad_terminal_cost._paths for r in rr])
+                    path_term=[r for _, _, rr in self.quad_terminal_cost._paths for r in rr], acc=list(acc_psi))
                 d.user_has_fun = 1
                 d.path_prog, d.path_prog_len = None, 0          # expressions are compiled in, not interpreted
                 d.con_prog, d.con_prog_len, d.tcon_prog, d.tcon_prog_len = None, 0, None, 0
                 pat = self._hessian_pattern(m, nx, nu, nth, Wz, Wdu if has_du else None, gen_stage, sc, tc,
-                                            composed=bool(cont or coll is not None), extra=[m.z[a] for a in zb])
+                                            composed=bool(cont or coll is not None), extra=[m.z[a] for a in zb] + list(acc_psi))
                 if pat is not None:
                     pat = np.ascontiguousarray(pat, dtype=np.uint8)
                     keep.append(pat)
@@ -1071,7 +1110,16 @@ class NMPC:
         self._handle = h
         dims = [C.c_int() for _ in range(5)]
         _lib.check(_lib.lib().hilo_nmpc_dims(h, *[C.byref(v) for v in dims]))
-        self._n_v, self._n_g = dims[0].value, dims[1].value
+        # (with a custom constraint the engine's rows of v end with its hidden accumulator values; `_n_v` is the reference's n_v)
+        self._n_v_eng = dims[0].value
+        self._n_v, self._n_g = dims[0].value - self._nq, dims[1].value
+        self._g_order = None
+        if self._nq:
+            # the engine's lam_g / g carry the custom rows as the last terminal rows, in front of the last node's stage rows; the
+            # reference appends them to g (mpc.py:1729-1745)
+            R = (2 * sc.size if sc.is_soft else sc.size) if sc.is_set else 0
+            cus = list(range(self._n_g - R - self._nq, self._n_g - R))
+            self._g_order = [i for i in range(self._n_g) if i not in set(cus)] + cus
         N, Nc = self._prediction_horizon, self._control_horizon
         # integer bookkeeping of mpc.py:1464-1537 (bit-exact index maps); a path variable is a state + an input;
         # the control horizon holds Nc input blocks (mpc.py:1476-1485)
@@ -1167,6 +1215,8 @@ class NMPC:
             v0t = to_dev(v0, self._dev).reshape(-1, self._n_v)
             if v0t.shape[0] == 1 and B > 1:
                 v0t = v0t.expand(B, -1).contiguous()
+            if self._nq:                                   # hidden accumulator entries of the engine's rows: they start at zero
+                v0t = torch.cat([v0t, torch.zeros(v0t.shape[0], self._nq, dtype=torch.float64, device=v0t.device)], dim=1).contiguous()
         elif not self._nlp_options['warm_start']:
             _lib.check(_lib.lib().hilo_nmpc_reset_warm_start(self._handle))
         u_old = None
@@ -1182,7 +1232,7 @@ class NMPC:
                 g = np.zeros(self._n_u) if self._u_guess is None else np.asarray(self._u_guess) / self._su
                 u_old = to_dev(np.tile(g, (B, 1)), self._dev)
         dev = self._dev
-        v_opt = torch.empty(B, self._n_v, dtype=torch.float64, device=dev)
+        v_opt = torch.empty(B, self._n_v_eng, dtype=torch.float64, device=dev)
         f_opt = torch.empty(B, dtype=torch.float64, device=dev)
         lam_g = torch.empty(B, self._n_g, dtype=torch.float64, device=dev)
         u0 = torch.empty(B, self._n_u, dtype=torch.float64, device=dev)
@@ -1204,11 +1254,14 @@ class NMPC:
             vub = (vub.expand(B, -1) if vub.shape[0] == 1 else vub).contiguous()
             if vlb.shape[0] != B or vub.shape[0] != B:
                 raise ValueError(f"v_lb / v_ub need one row or {B} rows of {self._n_v} entries")
+            if self._nq:
+                inf = torch.full((B, self._nq), float('inf'), dtype=torch.float64, device=vlb.device)
+                vlb, vub = torch.cat([vlb, -inf], dim=1).contiguous(), torch.cat([vub, inf], dim=1).contiguous()
         _lib.check(_lib.lib().hilo_nmpc_set_var_bounds(self._handle, ptr(vlb), ptr(vub)))
         g_val = lam_x = None
         if self._full_solution:
             g_val = torch.zeros(B, self._n_g, dtype=torch.float64, device=dev)
-            lam_x = torch.zeros(B, self._n_v, dtype=torch.float64, device=dev)
+            lam_x = torch.zeros(B, self._n_v_eng, dtype=torch.float64, device=dev)
         _lib.check(_lib.lib().hilo_nmpc_set_aux_outputs(self._handle, ptr(g_val), ptr(lam_x)))
         t0 = time.time() if self._stats else None
         if sd is not None:
@@ -1219,6 +1272,11 @@ class NMPC:
             _lib.check(_lib.lib().hilo_nmpc_solve(self._handle, B, ptr(x.contiguous()), ptr(p), ps, ptr(v0t), ptr(u_old),
                                                   ptr(v_opt), ptr(f_opt), ptr(lam_g), ptr(u0), ptr(status), ptr(iters),
                                                   ptr(kkt), stream_ptr(dev)))
+        if self._nq:       # the reference's layouts: no accumulator entries in v, the custom rows at the end of g (+ their constant parts)
+            v_opt, lam_g = v_opt[:, :self._n_v], lam_g[:, self._g_order]
+            if self._full_solution:
+                g_val, lam_x = g_val[:, self._g_order].clone(), lam_x[:, :self._n_v]
+                g_val[:, -self._nq:] += torch.as_tensor(self._custom_const, dtype=torch.float64, device=dev)
         self._nlp_solution = {'x': v_opt, 'f': f_opt, 'lam_g': lam_g, 'status': status, 'iter_count': iters, 'kkt_error': kkt}
         if self._full_solution:
             self._nlp_solution.update(g=g_val, lam_x=lam_x)

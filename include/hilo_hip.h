@@ -347,6 +347,14 @@ typedef struct hilo_nmpc_desc {
                               state but a variable inside the state box (the sampling-interval state of a minimum-time problem,
                               hilo_mpc_amd/nmpc.py::_setup_min_time); 0 = all of x_0 is pinned (mpc.py:785-789) */
   const double* zb_lb; const double* zb_ub;        /* [n_zbound]; -inf / +inf allowed on one side */
+  /* custom constraint function over the whole decision vector (`set_custom_constraints_function`, optimizer.py:1180-1208; rows
+     lb <= fun(v, x_ind, u_ind) <= ub at the END of g, mpc.py:1729-1745), in the stage-additive form the host derives from it
+     (hilo_mpc_amd/custom.py):  c_r(v) = sum_{k=0..N} sum_j acc_coef[r][k][j] psi_j(x_k, u_k)  with the n_acc_expr expressions psi_j
+     compiled into UserFun::acc (user_policy 2).  Each of the n_acc rows is carried by an accumulator state of the engine and becomes
+     a hard row on the end of the horizon (csrc/hilo_nmpc_user.h); its multiplier is the LAST n_acc entries of lam_g. */
+  int32_t n_acc, n_acc_expr;
+  const double* acc_coef;      /* [n_acc][N + 1][n_acc_expr] */
+  const double* acc_lb; const double* acc_ub;      /* [n_acc] bounds of the rows (constant parts of the function already removed) */
 } hilo_nmpc_desc;
 
 #define HILO_MODEL_USER 100    /* model defined by desc.user_source */

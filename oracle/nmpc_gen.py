@@ -44,7 +44,10 @@ class GenNmpcProblem(NmpcProblem):
                          max_violation=inf)
        generic_stage = sympy expression of the model's state / input symbols added to every stage's cost"""
 
-    def __init__(self, model, dt, N, path=None, constraint=None, terminal_constraint=None, generic_stage=None, **kw):
+    def __init__(self, model, dt, N, path=None, constraint=None, terminal_constraint=None, generic_stage=None, custom=None, **kw):
+        """custom = dict(fun=f(v, x_ind, u_ind) -> expression(s) of the entries of the (scaled) decision vector v, lb=[...], ub=[...]):
+        `set_custom_constraints_function` (optimizer.py:1180-1208) - rows lb <= fun(v, x_ind, u_ind) <= ub appended to g
+        (mpc.py:1741-1744), kept here as what they are: DENSE rows over the whole vector (sympy derivatives in v)."""
         super().__init__(model, dt, N, **kw)
         nx, nu = self.nx, self.nu
         self.path = path
@@ -186,6 +189,22 @@ class GenNmpcProblem(NmpcProblem):
         self.eT_ind = list(range(off + self.ne, off + self.ne + self.ne_t))
         self.n_v = off + self.ne + self.ne_t
         self.n_g = N * (nxa + self.n_con_ref) + self.n_tcon_ref
+        # ---- custom rows over the whole decision vector ----
+        self.n_cus = 0
+        if custom:
+            vs = [sp.Symbol(f'v_{i}') for i in range(self.n_v)]
+            out = custom['fun'](vs, self.x_ind, self.u_ind)
+            cs = [sp.sympify(e) for e in (out if isinstance(out, (list, tuple)) else [out])]
+            self.n_cus = len(cs)
+            self.cus_lb = np.broadcast_to(np.asarray(custom.get('lb', -INF), dtype=float), (self.n_cus,)).copy()
+            self.cus_ub = np.broadcast_to(np.asarray(custom.get('ub', INF), dtype=float), (self.n_cus,)).copy()
+            used = sorted({int(str(q)[2:]) for c in cs for q in c.free_symbols})
+            self.cus_used = used                                           # entries of v the rows depend on
+            us_ = [vs[i] for i in used]
+            self._cus = _lam(cs, [us_])
+            self._cusj = _lam([[sp.diff(c, a) for a in us_] for c in cs], [us_])
+            self._cush = _lam([[[sp.diff(c, a, b) for b in us_] for a in us_] for c in cs], [us_])
+            self.n_g += self.n_cus
 
     @staticmethod
     def _vgh(expr, syms):
@@ -238,13 +257,15 @@ class GenIpm(DenseIpm):
         self.o_eT = self.o_e + ne                            # slack of the soft terminal constraint
         self.o_s = self.o_eT + pb.ne_t
         self.o_t = self.o_s + N * nrow                       # slacks of the terminal rows
-        self.nw = self.o_t + pb.nt
-        self.m = N * nxa + N * nrow + pb.nt
+        self.o_c = self.o_t + pb.nt                          # slacks of the custom rows (IPOPT's slack form, like every inequality row)
+        ncu = getattr(pb, 'n_cus', 0)
+        self.nw = self.o_c + ncu
+        self.m = N * nxa + N * nrow + pb.nt + ncu
         lb = np.concatenate([pb.x_lb[pb.nx - self.n0:], np.tile(pb.x_lb, N), np.tile(pb.u_lb, N), np.zeros(ne + pb.ne_t), np.tile(pb.dlb, N),
-                             pb.tlb if pb.nt else np.zeros(0)])
+                             pb.tlb if pb.nt else np.zeros(0), pb.cus_lb if ncu else np.zeros(0)])
         ub = np.concatenate([pb.x_ub[pb.nx - self.n0:], np.tile(pb.x_ub, N), np.tile(pb.u_ub, N),
                              pb.e_ub if ne else np.zeros(0), pb.eT_ub if pb.ne_t else np.zeros(0), np.tile(pb.dub, N),
-                             pb.tub if pb.nt else np.zeros(0)])
+                             pb.tub if pb.nt else np.zeros(0), pb.cus_ub if ncu else np.zeros(0)])
         if x0_box is not None:
             assert free_x0
             lb, ub = lb.copy(), ub.copy()
@@ -266,6 +287,23 @@ class GenIpm(DenseIpm):
                 cols.append(self.o_x + (k - 1) * pb.nxa + i)
         cols += [self.o_u + k * pb.nua + j for j in range(pb.nua)]
         return cols
+
+    def _cus_args(self, w, X, U):
+        """Values of the entries of v the custom rows read, and the column of each in w (-1: a pinned entry of x_0)."""
+        pb = self.pb
+        B = w.shape[0]
+        v = np.concatenate([X.reshape(B, -1), U.reshape(B, -1), w[:, self.o_e:self.o_s]], axis=1)
+        col = np.full(pb.n_v, -1)
+        for k in range(pb.N + 1):
+            zc = self.zcols(k) if k < pb.N else [self.o_x + (pb.N - 1) * pb.nxa + i for i in range(pb.nxa)]
+            for i, j in enumerate(pb.x_ind[k]):
+                col[j] = zc[i]
+        for k in range(pb.N):
+            for i, j in enumerate(pb.u_ind[k]):
+                col[j] = self.o_u + k * pb.nua + i
+        for a, j in enumerate(pb.e_ind + pb.eT_ind):
+            col[j] = self.o_e + a
+        return v[:, pb.cus_used], col[pb.cus_used]
 
     def _unpack(self, w, x0):
         pb = self.pb
@@ -308,6 +346,9 @@ class GenIpm(DenseIpm):
         if pb.ne_t:
             ET = w[:, self.o_eT:self.o_s]
             f += np.einsum('bi,ij,bj->b', ET, pb.WeT, ET)                      # mpc.py:1686: once
+        if getattr(pb, 'n_cus', 0):
+            va, _ = self._cus_args(w, X, U)
+            call = np.concatenate([call, pb._cus(va) - w[:, self.o_c:]], axis=1)
         return f, call
 
     def _term_rows(self, w, X, U, p):
@@ -332,7 +373,8 @@ class GenIpm(DenseIpm):
         c = np.empty((B, N, mk))
         J = np.zeros((B, self.m, self.nw))
         W = np.zeros((B, self.nw, self.nw))
-        lam_t = lam[:, N * mk:]
+        lam_c = lam[:, N * mk + pb.nt:]                      # custom rows (behind the terminal rows)
+        lam_t = lam[:, N * mk:N * mk + pb.nt]
         lam = lam[:, :N * mk].reshape(B, N, mk)
         bi = np.arange(B)
         ecols = list(range(self.o_e, self.o_eT))
@@ -411,6 +453,16 @@ class GenIpm(DenseIpm):
         call = c.reshape(B, -1)
         if pb.nt:
             call = np.concatenate([call, c_term], axis=1)
+        ncu = getattr(pb, 'n_cus', 0)
+        if ncu:
+            va, col = self._cus_args(w, X, U)
+            keep = [q for q, cc in enumerate(col) if cc >= 0]
+            wc = [int(col[q]) for q in keep]
+            rws = list(range(self.m - ncu, self.m))
+            call = np.concatenate([call, pb._cus(va) - w[:, self.o_c:]], axis=1)
+            J[np.ix_(bi, rws, wc)] = pb._cusj(va)[:, :, keep]
+            J[:, rws, [self.o_c + r for r in range(ncu)]] = -1.0
+            W[np.ix_(bi, wc, wc)] += np.einsum('bm,bmac->bac', lam_c, pb._cush(va))[np.ix_(bi, keep, keep)]
         return f, g, call, J, W
 
     def solve(self, x0, p, w0=None, u_old=None, verbose=False):
@@ -434,6 +486,10 @@ class GenIpm(DenseIpm):
             if pb.nt:
                 wz = np.concatenate([w0, np.zeros((B, self.nw - w0.shape[1]))], axis=1)
                 w0 = np.concatenate([w0, self._term_rows(wz, X, U, p)], axis=1)
+        if getattr(pb, 'n_cus', 0):      # slacks of the custom rows start at the rows' values, like every slack
+            wz = np.concatenate([w0, np.zeros((B, self.nw - w0.shape[1]))], axis=1)
+            X, U, _, _ = self._unpack(wz, x0)
+            w0 = np.concatenate([w0, pb._cus(self._cus_args(wz, X, U)[0])], axis=1)
         res = self.solve_data(data, w0, verbose)
         X, U, E, S = self._unpack(res['w'], x0)
         res.update(X=X, U=U, E=E, S=S, u0=U[:, 0, :pb.nu] * pb.su, x0=x0)
@@ -462,11 +518,13 @@ class GenIpm(DenseIpm):
         out[:, :, :pb.nxa] = lam[:, :, :pb.nxa]
         for r, ref in enumerate(pb.row_ref):
             out[:, :, pb.nxa + ref] = lam[:, :, pb.nxa + r]
+        ncu = getattr(pb, 'n_cus', 0)
+        lam_cus = res['lam'][:, pb.N * mk + pb.nt:pb.N * mk + pb.nt + ncu]  # custom rows: the last rows of g (mpc.py:1741-1744)
         if not pb.nt:
-            return out.reshape(B, -1)
+            return np.concatenate([out.reshape(B, -1), lam_cus], axis=1)
         # last stage: [defect | terminal rows | stage rows] (mpc.py:1693-1700 before :1707)
         head = out[:, :-1].reshape(B, -1)
         last = out[:, -1]
         lt = np.zeros((B, pb.n_tcon_ref))                                   # dropped (unbounded) rows: zero multiplier
-        lt[:, pb.trow_ref] = res['lam'][:, pb.N * mk:]
-        return np.concatenate([head, last[:, :pb.nxa], lt, last[:, pb.nxa:]], axis=1)
+        lt[:, pb.trow_ref] = res['lam'][:, pb.N * mk:pb.N * mk + pb.nt]
+        return np.concatenate([head, last[:, :pb.nxa], lt, last[:, pb.nxa:], lam_cus], axis=1)

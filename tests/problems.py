@@ -356,6 +356,9 @@ def product_gen(spec, **solver_options):
     nmpc.horizon = spec['N']
     nmpc.set_box_constraints(x_ub=spec.get('x_ub'), x_lb=spec.get('x_lb'), u_ub=spec.get('u_ub'), u_lb=spec.get('u_lb'))
     nmpc.set_initial_guess(x_guess=spec.get('x_guess'), u_guess=spec.get('u_guess'), z_guess=spec.get('z_guess'))
+    if spec.get('custom'):
+        cu = spec['custom']
+        nmpc.set_custom_constraints_function(cu['fun'], lb=cu.get('lb'), ub=cu.get('ub'))
     if spec.get('x_scaling') or spec.get('u_scaling'):
         nmpc.set_scaling(x_scaling=spec.get('x_scaling'), u_scaling=spec.get('u_scaling'))
     if coll is not None:

@@ -1,0 +1,136 @@
+"""GPU: `NMPC.set_custom_constraints_function` (optimizer.py:1180-1208; rows `lb <= fun(v, x_ind, u_ind) <= ub` at the END of g,
+mpc.py:1729-1745) - a function of the whole decision vector, offloaded for sums over the stages of single-stage terms
+(hilo_mpc_amd/custom.py): each row rides on an accumulator state of the stage-structured problem.  The oracle (oracle/nmpc_gen.py)
+keeps the rows as what they are in the reference: dense rows over v - so the comparison is not self-referential."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.nmpc import IpmOptions                                             # noqa: E402
+from oracle.nmpc_gen import GenIpm                                              # noqa: E402
+from tests.problems import C2, c2_x0, oracle_gen, product_gen                 # noqa: E402
+
+
+def _trapezoid(i, dt):
+    def fun(v, x_ind, u_ind):
+        s = 0
+        for k in range(len(x_ind) - 1):
+            s += (v[x_ind[k][i]] + v[x_ind[k + 1][i]]) / 2 * dt            # tests/test_NMPC.py:524-529
+        return s
+    return fun
+
+
+def test_trapezoid_integral_bound_vs_dense_oracle():
+    """Tracking NMPC on the chemostat, N = 8: the trapezoid integral of the product concentration over the horizon bounded at 90 %
+    of its unconstrained value - status, v, f, u_0 and lam_g incl. the custom row's multiplier (last entry) and the multipliers of
+    the LAST shooting defect, which in the reference carry - nu dc/dx_N (the row acts on the node variable x_N there)."""
+    spec = dict(C2, N=8)
+    x0 = c2_x0(6)
+    free = GenIpm(oracle_gen(spec)).solve(x0, C2['p'])
+    X = free['X']
+    ub = float(((X[:, :-1, 2] + X[:, 1:, 2]) / 2 * spec['dt']).sum(1).min() * .9)
+    spec = dict(spec, custom=dict(fun=_trapezoid(2, spec['dt']), lb=0., ub=ub))
+    pb = oracle_gen(spec)
+    ipm = GenIpm(pb, IpmOptions(tol=1e-10))
+    ref = ipm.solve(x0, C2['p'])
+    assert np.all(ref['status'] == 1)
+    nmpc = product_gen(spec, tol=1e-10)
+    assert nmpc._jit and nmpc._nq == 1 and (nmpc._n_v, nmpc._n_g) == (pb.n_v, pb.n_g)
+    nmpc.keep_full_solution = True
+    u = nmpc.optimize(x0, cp=C2['p'])
+    assert np.array_equal(nmpc.solver_status_code, ref['status'])
+    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), ipm.to_v(ref)
+    assert v.shape == vr.shape and np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 1e-6
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-9)
+    np.testing.assert_allclose(u, ref['u0'], rtol=1e-6, atol=1e-8)
+    Xp = v[:, :(spec['N'] + 1) * 4].reshape(-1, spec['N'] + 1, 4)
+    integral = ((Xp[:, :-1, 2] + Xp[:, 1:, 2]) / 2 * spec['dt']).sum(1)
+    np.testing.assert_allclose(integral, ub, rtol=1e-7)                      # active in every instance
+    lam, lr = nmpc._nlp_solution['lam_g'].cpu().numpy(), ipm.lam_g(ref)
+    lr = lr.copy()
+    last = slice((spec['N'] - 1) * 4, spec['N'] * 4)
+    lr[:, last] += 2 * (ref['X'][:, -1] - pb.xrefNa) @ pb.WNa               # terminal cost convention (mpc.py:1682), as in test_gen_gpu
+    assert lam.shape == lr.shape
+    np.testing.assert_allclose(lam[:, -1], lr[:, -1], rtol=1e-5)              # the custom row
+    assert np.all(lam[:, -1] > 1.)
+    np.testing.assert_allclose(lam, lr, rtol=2e-5, atol=1e-5 * np.abs(lr).max())
+    g = nmpc._nlp_solution['g'].cpu().numpy()
+    np.testing.assert_allclose(g[:, -1], integral, rtol=1e-9)                # value of the row in g's last position
+
+
+def test_two_rows_with_nonlinear_stage_terms_and_a_constant():
+    """Two rows: the trapezoid integral (active) and an input-energy budget with a product of a state and an input and a constant
+    part - three stage expressions shared over the stages; against the dense oracle."""
+    spec = dict(C2, N=6)
+    x0 = c2_x0(4)
+
+    def fun(v, x_ind, u_ind):
+        e = 0.5
+        for k in range(len(u_ind)):
+            e = e + 2. * v[u_ind[k][0]] ** 2 + v[x_ind[k][0]] * v[u_ind[k][1]] / 10
+        return [_trapezoid(2, spec['dt'])(v, x_ind, u_ind), e]
+    free = GenIpm(oracle_gen(spec)).solve(x0, C2['p'])
+    X, U = free['X'], free['U']
+    ub0 = float(((X[:, :-1, 2] + X[:, 1:, 2]) / 2 * spec['dt']).sum(1).min() * .92)
+    e_free = .5 + (2 * U[:, :, 0] ** 2 + X[:, :-1, 0] * U[:, :, 1] / 10).sum(1)
+    spec = dict(spec, custom=dict(fun=fun, lb=[0., -np.inf], ub=[ub0, float(.5 + .6 * (e_free.min() - .5))]))      # both rows active
+    pb = oracle_gen(spec)
+    ipm = GenIpm(pb, IpmOptions(tol=1e-10))
+    ref = ipm.solve(x0, C2['p'])
+    assert np.all(ref['status'] == 1)
+    nmpc = product_gen(spec, tol=1e-10)
+    assert nmpc._nq == 2 and (nmpc._n_v, nmpc._n_g) == (pb.n_v, pb.n_g)
+    u = nmpc.optimize(x0, cp=C2['p'])
+    assert np.array_equal(nmpc.solver_status_code, ref['status'])
+    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), ipm.to_v(ref)
+    assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 1e-6
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-9)
+    np.testing.assert_allclose(u, ref['u0'], rtol=1e-6, atol=1e-8)
+    lam, lr = nmpc._nlp_solution['lam_g'].cpu().numpy(), ipm.lam_g(ref)
+    np.testing.assert_allclose(lam[:, -2:], lr[:, -2:], rtol=1e-5, atol=1e-7)
+
+
+def test_the_reference_test_case_under_the_default_collocation():
+    """tests/test_NMPC.py:519-552 as written: the cart pendulum with the `dummy` integrator state (x_5' = u_dummy), tracking
+    theta -> pi and dummy -> 10 over N = 10 under the default transcription (collocation, Radau 3, continuous objective), the
+    trapezoid integral of `dummy` over the nodes in [0, 4].  The reference asserts `integral - 4 < 1e-3`; here also: solved, the
+    row active (the unconstrained problem drives dummy towards 10: integral 4.6), its multiplier positive."""
+    from hilo_mpc_amd import NMPC, Model
+    from hilo_mpc_amd.expr import cos, sin
+    M, m_, l_, g_ = 5., 1., 1., 9.81
+    model = Model()
+    x = model.set_dynamical_states(['x', 'v', 'theta', 'omega', 'dummy'])
+    F = model.set_inputs(['F', 'u_dummy'])
+    v, theta, omega = x[1], x[2], x[3]
+    dv = 1. / (M + m_ - m_ * cos(theta)) * (m_ * g_ * sin(theta) - m_ * l_ * sin(theta) * omega ** 2 + F[0])
+    model.set_dynamical_equations([v, dv, omega, 1. / l_ * (dv * cos(theta) + g_ * sin(theta)), F[1]])
+    dt = .1
+    model.setup(dt=dt)
+    x0 = [2.5, 0., 1.5, 0., 0.]
+
+    def build(custom):
+        nmpc = NMPC(model)
+        nmpc.quad_stage_cost.add_states(names=['theta', 'dummy'], ref=[np.pi, 10], weights=[np.pi, 10])
+        nmpc.horizon = 10
+        nmpc.set_box_constraints(x_ub=[3, 0.5, 10, 10, 10000], x_lb=[2, -0.5, -10, -10, 0])
+        nmpc.set_initial_guess(x_guess=x0, u_guess=[0., 0.])
+        if custom:
+            nmpc.set_custom_constraints_function(lambda v, xi, ui: _trapezoid(4, dt)(v, xi, ui), ub=4, lb=0)
+        nmpc.setup()
+        return nmpc
+
+    def integral(nmpc):
+        x_opt, _, _ = nmpc.return_prediction()
+        return float(((x_opt[0, 4, :-1] + x_opt[0, 4, 1:]) / 2 * dt).sum())
+    free = build(False)
+    free.optimize(x0)
+    assert free.solver_status_code[0] == 1 and integral(free) > 4.2
+    nmpc = build(True)
+    assert nmpc._nlp_options['integration_method'] == 'collocation' and nmpc._n_g == free._n_g + 1 and nmpc._n_v == free._n_v
+    nmpc.optimize(x0)
+    assert nmpc.solver_status_code[0] == 1
+    assert integral(nmpc) - 4 < 1e-3 and abs(integral(nmpc) - 4) < 1e-6           # the reference's assertion; active
+    lam = nmpc._nlp_solution['lam_g'].cpu().numpy()
+    assert lam[0, -1] > 1e-3
+    assert float(nmpc._nlp_solution['f'][0]) > float(free._nlp_solution['f'][0])

@@ -272,3 +272,89 @@ def test_expression_compiler():
     assert _run((vx ** 2.5).program(), x, u, []) == pytest.approx(1.2 ** 2.5, rel=1e-14)
     with pytest.raises(KeyError):
         m.x['nope']
+
+
+def _trapezoid(v, x_ind, u_ind, i=2, dt=.25):
+    """The reference's own custom function (tests/test_NMPC.py:524-529): trapezoid integral of one state over the nodes."""
+    s = 0
+    for k in range(len(x_ind) - 1):
+        s += (v[x_ind[k][i]] + v[x_ind[k + 1][i]]) / 2 * dt
+    return s
+
+
+def test_custom_constraint_rows_dense_oracle_vs_slsqp():
+    """`set_custom_constraints_function` (optimizer.py:1180-1208; rows at the end of g, mpc.py:1741-1744) in the oracle: DENSE rows
+    over the whole decision vector, in IPOPT's slack form.  The interior point and scipy SLSQP on the same transcription find the
+    same point; the row is active; its multiplier is the last entry of lam_g and positive (upper bound active)."""
+    from scipy.optimize import minimize
+    from tests.problems import C2, c2_x0, oracle_gen
+    spec = dict(C2, N=5)
+    x0 = c2_x0(2)
+    free = GenIpm(oracle_gen(spec)).solve(x0, C2['p'])
+    X = free['X']
+    integ = ((X[:, :-1, 2] + X[:, 1:, 2]) / 2 * .25).sum(1)
+    ub = float(integ.min() * .9)
+    pb = oracle_gen(dict(spec, custom=dict(fun=_trapezoid, lb=0., ub=ub)))
+    assert pb.n_g == spec['N'] * 4 + 1 and pb.n_cus == 1
+    ipm = GenIpm(pb)
+    ref = ipm.solve(x0, C2['p'])
+    assert np.all(ref['status'] == 1)
+    X = ref['X']
+    np.testing.assert_allclose(((X[:, :-1, 2] + X[:, 1:, 2]) / 2 * .25).sum(1), ub, rtol=1e-7)
+    lam = ipm.lam_g(ref)
+    assert lam.shape == (2, pb.n_g) and np.all(lam[:, -1] > 1.) and np.all(ref['f'] > free['f'])
+    # SLSQP on the same NLP (free variables of the oracle without the slacks), instance 0
+    nfree = ipm.o_s
+    data = {'x0': x0[:1] / pb.sx, 'p': np.atleast_2d(np.asarray(C2['p'], dtype=float))}
+
+    def ev(wv):
+        w = np.concatenate([wv, np.zeros(ipm.nw - nfree)])[None]
+        f, c = ipm.eval_fc(w, data)
+        return f[0], c[0]
+    nd = pb.N * pb.nxa
+    cons = [{'type': 'eq', 'fun': lambda wv: ev(wv)[1][:nd]},
+            {'type': 'ineq', 'fun': lambda wv: ub - ev(wv)[1][-1]}]         # (the slack is zero in ev: the row's value itself)
+    sol = minimize(lambda wv: ev(wv)[0], ref['w'][0, :nfree] * (1 + 1e-3), method='SLSQP', bounds=list(zip(ipm.lb[:nfree], ipm.ub[:nfree])),
+                   constraints=cons, options={'ftol': 1e-11, 'maxiter': 800})
+    # (with finite-difference gradients SLSQP may stop at its line search next to the optimum, status 8 - like _slsqp above)
+    assert sol.success or sol.status == 8, sol.message
+    np.testing.assert_allclose(sol.fun, ref['f'][0], rtol=1e-6)
+    assert ref['f'][0] <= sol.fun + 1e-9 * abs(sol.fun)
+    np.testing.assert_allclose(sol.x, ref['w'][0, :nfree], rtol=5e-3, atol=5e-3)
+
+
+def test_custom_constraint_decomposition_into_stage_terms():
+    """hilo_mpc_amd/custom.py: the user's function called with symbols, split into single-stage terms - expressions shared between
+    stages, per-stage coefficients, constant parts; the decomposition reproduces the function's value at random points, and a
+    function that multiplies variables of different stages is refused."""
+    from hilo_mpc_amd.custom import decompose
+    from hilo_mpc_amd.symdiff import Dag
+    from tests.problems import symbolic_model
+    m = symbolic_model('chemostat4')
+    N, nx, nu = 4, 4, 2
+    x_ind = [list(range(k * nx, (k + 1) * nx)) for k in range(N + 1)]
+    u_ind = [list(range((N + 1) * nx + k * nu, (N + 1) * nx + (k + 1) * nu)) for k in range(N)]
+    n_v = (N + 1) * nx + N * nu
+
+    def fun(v, x_ind, u_ind):
+        e = 1.5
+        for k in range(len(u_ind)):
+            e = e + 3 * v[u_ind[k][0]] ** 2 - v[x_ind[k][0]] * v[u_ind[k][1]] / 2
+        return [_trapezoid(v, x_ind, u_ind), e - 2 * v[x_ind[N][1]]]
+    psi, coef, const = decompose(fun, x_ind, u_ind, n_v, m)
+    assert len(psi) == 4 and coef.shape == (2, N + 1, 4) and np.allclose(const, [0., 1.5])
+    np.testing.assert_allclose(coef[0, :, 0], [.125, .25, .25, .25, .125])
+    rng = np.random.default_rng(0)
+    v = rng.uniform(.5, 2., n_v)
+    dag, memo = Dag(), {}
+    ids = [dag.from_expr(e, memo) for e in psi]
+    val = const.copy()
+    for k in range(N + 1):
+        xk = v[x_ind[k]]
+        uk = v[u_ind[k]] if k < N else np.zeros(nu)
+        val += coef[:, k] @ np.array(dag.evaluate(ids, xk, uk, []))
+    np.testing.assert_allclose(val, [float(e) for e in fun(list(v), x_ind, u_ind)], rtol=1e-13)
+    with pytest.raises(NotImplementedError, match="DIFFERENT stages"):
+        decompose(lambda v, xi, ui: v[xi[0][0]] * v[xi[1][0]], x_ind, u_ind, n_v, m)
+    with pytest.raises(NotImplementedError, match="neither a state nor an input"):
+        decompose(lambda v, xi, ui: v[n_v + 1] + v[0], x_ind, u_ind, n_v + 3, m)
