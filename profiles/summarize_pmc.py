@@ -19,7 +19,7 @@ cfg = sys.argv[3] if len(sys.argv) > 3 else 'C2'
 KEY = 'hilo_user_solve' if cfg in ('C5', 'C5-dae') else 'ocp_solve_kernel'
 CLOCK_GHZ = 2.4          # MI355X shader clock (MI355X_MICROARCH.md)
 N_SIMD = 1024
-STEADY = 6
+STEADY = {'C2': 6, 'C4': 4, 'C3-mhe': 4, 'C5': 3, 'C5-dae': 2}.get(cfg, 4)     # timed launches of each pass (run_round.sh)
 
 
 def collect(pattern, key, steady):

@@ -351,8 +351,14 @@ def test_controller_accessors_of_the_reference():
     nmpc.horizon = 5
     with pytest.raises(NotImplementedError, match="continuous model written as expressions"):
         nmpc.setup()                                                    # (this controller sits on a model of the device zoo)
-    with pytest.raises(NotImplementedError, match="WHOLE decision vector"):
-        nmpc.set_custom_constraints_function(fun=lambda v, xi, ui: v[0])
+    # optimizer.py:1180-1208: accepted (offloaded for stage-additive functions, tests/test_custom_gpu.py); the soft variant is not built
+    nmpc.set_custom_constraints_function(fun=lambda v, xi, ui: v[0], ub=3)
+    assert nmpc._custom_constraint_flag and nmpc._custom_constraint_size == 1
+    assert nmpc._custom_constraint_fun_lb == [-np.inf] and nmpc._custom_constraint_fun_ub == [3.]
+    with pytest.raises(NotImplementedError, match="soft custom constraints"):
+        nmpc.set_custom_constraints_function(fun=lambda v, xi, ui: v[0], soft=True)
+    with pytest.raises(TypeError, match="must be a function"):
+        nmpc.set_custom_constraints_function(fun=None)
 
 
 def test_model_as_plant_host_contract(monkeypatch):
