@@ -59,8 +59,14 @@ for cdir in sorted(glob.glob(os.path.join(src, '*'))):
             rows = [r for r in rows if int(r['Grid_Size_X']) == gmax]
         d = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rows]
         if d:
-            t = d[-timed:]
+            # the headline configuration continues its loop for 50 more steps after the timed region (bench.py `settled_loop`): the
+            # timed region is the `timed` launches in front of those
+            tail = 50 if (line and 'settled_loop' in line and len(d) >= timed + 50) else 0
+            t = d[len(d) - tail - timed:len(d) - tail]
             out['timed_region'] = {'launches': len(t), 'avg_ns': sum(t) / len(t), 'min_ns': min(t), 'max_ns': max(t)}
+            if tail:
+                ts = d[-tail:]
+                out['settled_region'] = {'launches': len(ts), 'avg_ns': sum(ts) / len(ts), 'min_ns': min(ts), 'max_ns': max(ts)}
             r0 = rows[-1]
             out['resources'] = {k: r0.get(k) for k in ('Workgroup_Size_X', 'Grid_Size_X', 'LDS_Block_Size', 'Scratch_Size', 'VGPR_Count',
                                                        'Accum_VGPR_Count', 'SGPR_Count') if k in r0}
