@@ -351,7 +351,9 @@ typedef struct hilo_nmpc_desc {
      lb <= fun(v, x_ind, u_ind) <= ub at the END of g, mpc.py:1729-1745), in the stage-additive form the host derives from it
      (hilo_mpc_amd/custom.py):  c_r(v) = sum_{k=0..N} sum_j acc_coef[r][k][j] psi_j(x_k, u_k)  with the n_acc_expr expressions psi_j
      compiled into UserFun::acc (user_policy 2).  Each of the n_acc rows is carried by an accumulator state of the engine and becomes
-     a hard row on the end of the horizon (csrc/hilo_nmpc_user.h); its multiplier is the LAST n_acc entries of lam_g. */
+     a hard row on the end of the horizon (csrc/hilo_nmpc_user.h): hilo_nmpc_dims reports n_v INCLUDING the n_acc hidden accumulator
+     entries at the end of v, and the rows are the last n_acc TERMINAL rows of g / lam_g (in front of the last node's stage rows);
+     the reference appends them to g (mpc.py:1744-1745) - hilo_mpc_amd/nmpc.py::_g_order is that permutation. */
   int32_t n_acc, n_acc_expr;
   const double* acc_coef;      /* [n_acc][N + 1][n_acc_expr] */
   const double* acc_lb; const double* acc_ub;      /* [n_acc] bounds of the rows (constant parts of the function already removed) */
