@@ -113,7 +113,8 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     if (d->n_path_var > 0 || d->n_con > 0 || d->n_tcon > 0 || d->collocation_degree > 0 || d->time_varying || d->learned)   // (learned terms of a user model: desc.user_gp)
       return fail(HILO_ENOTSUP, "a run-time compiled model with path following, constraints, collocation, per-stage data or a "
                                 "learned term needs user_policy 2");
-    const int ncost = (nx + nu) * (nx + nu) + (nx + nu) + nx * nx + nx + nu * nu + 1;   // NmpcTrack<M>::NCOST
+    int ncost = (nx + nu) * (nx + nu) + (nx + nu) + nx * nx + nx + nu * nu + 1;   // NmpcTrack<M>::NCOST ...
+    if (ncost + (nx + nu) * (nx + nu) + nu * nu <= OCP_NCOST) ncost += (nx + nu) * (nx + nu) + nu * nu;   // ... with the symmetrised tables (SYMTAB)
     const int nconst = (int)((__builtin_offsetof(OcpConst, cost) + sizeof(double) * ncost + 7) / 8);
     const size_t fixed = ocp_fixed_doubles(nx, nu, nconst, np + nu, 0, 0, d->N) * sizeof(double);
     lds = fixed + ocp_iter_doubles(nx, nu, 0, d->N) * sizeof(double);
@@ -270,6 +271,12 @@ extern "C" int hilo_nmpc_create(const hilo_nmpc_desc* d, int device, hilo_nmpc**
     for (int i = 0; i < nx; ++i) *q++ = d->xrefN ? d->xrefN[i] : 0.0;
     for (int i = 0; i < nu * nu; ++i) *q++ = d->Wdu ? d->Wdu[i] : 0.0;
     *q++ = d->Wdu ? 1.0 : 0.0;
+    if ((q - c.cost) + nz * nz + nu * nu <= OCP_NCOST) {   // NmpcTrack<M>::SYMTAB: Sz = Wz + Wz^T, Sdu = Wdu + Wdu^T
+      for (int i = 0; i < nz; ++i)
+        for (int j = 0; j < nz; ++j) *q++ = d->Wz ? d->Wz[i * nz + j] + d->Wz[j * nz + i] : 0.0;
+      for (int i = 0; i < nu; ++i)
+        for (int j = 0; j < nu; ++j) *q++ = d->Wdu ? d->Wdu[i * nu + j] + d->Wdu[j * nu + i] : 0.0;
+    }
   } else {
     // cost block layout of NmpcGen (hilo_nmpc_gen.h); model z index -> engine z index
     auto ez = [&](int i) { return i < nx ? i : nxe + (i - nx); };
@@ -780,8 +787,8 @@ extern "C" int hilo_nmpc_plant_step(hilo_nmpc* h, int64_t batch, const double* x
 
 #ifdef HILO_OCP_DPROF
 extern "C" int hilo_debug_dprof(long long* out, int reset) {
-  if (out) HILO_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(hilo::g_dprof), sizeof(long long) * 16));
-  if (reset) { long long z[16] = {0}; HILO_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(hilo::g_dprof), z, sizeof(z))); }
+  if (out) HILO_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(hilo::g_dprof), sizeof(long long) * 32));
+  if (reset) { long long z[32] = {0}; HILO_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(hilo::g_dprof), z, sizeof(z))); }
   return HILO_OK;
 }
 #endif

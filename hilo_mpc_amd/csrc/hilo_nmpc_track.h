@@ -4,8 +4,10 @@
 
 namespace hilo {
 
-// Policy: tracking NMPC with quadratic costs.  pc.cost = [Wz | zref | WN | xrefN | Wdu | has_du],
-// par = [model parameters | u_old (scaled)].
+// Policy: tracking NMPC with quadratic costs.  pc.cost = [Wz | zref | WN | xrefN | Wdu | has_du | Sz | Sdu],
+// par = [model parameters | u_old (scaled)].  Sz = Wz + Wz^T, Sdu = Wdu + Wdu^T: the (constant) Hessians of the two terms, written
+// by the host next to the weights when the block has room (SYMTAB) - the derivative phase reads its two columns of them once and
+// takes gradient AND Hessian entries from those registers (cost_cols).
 // SYM_: take the model derivatives from generated symbolic code when the model has it (ModelSym<M>) - the host selects
 // SYM_ = false for sub-stepped integration (n_sub > 1), which only the Taylor path covers.
 template <class M, bool BIG_ = false, bool SYM_ = true>
@@ -19,7 +21,9 @@ struct NmpcTrack {
   static constexpr bool COOP = model_has_ext<M>::value;  // learned term in the model: lanes share its kernel sum
   static constexpr bool QUAD_COST = true;  // gradient / Hessian of the stage cost in closed form (cost_grad, cost_hess)
   static constexpr int O_WZ = 0, O_ZREF = O_WZ + NZ * NZ, O_WN = O_ZREF + NZ, O_XREFN = O_WN + NX * NX,
-                       O_WDU = O_XREFN + NX, O_HASDU = O_WDU + NU * NU, O_END = O_HASDU + 1;
+                       O_WDU = O_XREFN + NX, O_HASDU = O_WDU + NU * NU, O_SZ = O_HASDU + 1, O_SDU = O_SZ + NZ * NZ;
+  static constexpr bool SYMTAB = O_SDU + NU * NU <= OCP_NCOST;     // (hilo_nmpc.hip fills the tables under the same condition)
+  static constexpr int O_END = SYMTAB ? O_SDU + NU * NU : O_SZ;
   static constexpr int NCOST = O_END;  // doubles of pc.cost this policy reads (copied to LDS)
 
   template <class T, class E>
@@ -102,6 +106,54 @@ struct NmpcTrack {
     if (k == 0 && i >= NX && j >= NX && pc.cost[O_HASDU] != 0.0)
       h += pc.cost[O_WDU + (i - NX) * NU + (j - NX)] + pc.cost[O_WDU + (j - NX) * NU + (i - NX)];
     return h;
+  }
+
+  // Gradient entries g[c] and Hessian entries ch[r][c] (r >= column; 0 above the diagonal) of the stage cost for the CPL columns
+  // c0, c0 + 1, .. of interval k at the point z, from the symmetrised weights: 2 * CPL * NZ / 2 wide LDS reads and the references,
+  // all requested before the first use and without a branch - the entry-by-entry forms above cost 66 reads under conditions per
+  // lane and evaluation (4.3 k of the derivative phase's 21.6 k clocks on the benchmark problem).  Same products, same order of
+  // the sums as cost_grad / cost_hess.
+  template <int CPL>
+  __device__ __forceinline__ static void cost_cols(const OcpConst& pc, const double* par, int k, int c0, const double* z,
+                                                   double* g, double (*ch)[CPL]) {
+    static_assert(SYMTAB, "cost_cols needs the symmetrised tables");
+    double S[NZ][CPL], zr[NZ], Sd[NU > 0 ? NU : 1][CPL], uo[NU > 0 ? NU : 1];
+    int col[CPL], cu[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      col[c] = c0 + c < NZ ? c0 + c : NZ - 1;
+      cu[c] = col[c] >= NX ? col[c] - NX : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < NZ; ++r) {
+      zr[r] = pc.cost[O_ZREF + r];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) S[r][c] = pc.cost[O_SZ + r * NZ + col[c]];
+    }
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+      uo[a] = par[M::NP + a];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) Sd[a][c] = pc.cost[O_SDU + a * NU + cu[c]];
+    }
+    const bool du = k == 0 && pc.cost[O_HASDU] != 0.0;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < NZ; ++r) acc += S[r][c] * (z[r] - zr[r]);
+      const bool duc = du && col[c] >= NX;
+      double acd = acc;
+#pragma unroll
+      for (int a = 0; a < NU; ++a) acd += Sd[a][c] * (z[NX + a] - uo[a]);
+      g[c] = duc ? acd : acc;
+#pragma unroll
+      for (int r = 0; r < NZ; ++r) {
+        double h = S[r][c];
+        if (r >= NX) h = duc ? h + Sd[r >= NX ? r - NX : 0][c] : h;
+        ch[r][c] = (c0 + c < NZ && r >= c0 + c) ? h : 0.0;
+      }
+    }
   }
 
   // closed forms of the terminal cost (x - xrefN)^T WN (x - xrefN): gradient entry, (constant) Hessian entry

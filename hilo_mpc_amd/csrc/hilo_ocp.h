@@ -148,7 +148,7 @@ __device__ __forceinline__ double rsq_fast(double x) {
   return y;
 }
 typedef double v4d __attribute__((ext_vector_type(4)));   // accumulator of v_mfma_f64_16x16x4
-struct FTheta { double f, theta; };  // objective and constraint violation of a point
+struct FTheta { double f, theta, x; };  // objective and constraint violation of a point (x: sum of the caller's `extra` over the lanes)
 
 template <class Op>
 __device__ __forceinline__ double wave_reduce(double v) {
@@ -158,6 +158,49 @@ __device__ __forceinline__ double wave_reduce(double v) {
   v = Op::f(v, dpp_mov<0x140>(v));  // row_mirror
   return uni(Op::f(Op::f(read_lane(v, 0), read_lane(v, 16)), Op::f(read_lane(v, 32), read_lane(v, 48))));
 }
+
+// Several wave-wide reductions at once, level by level: the permutes of all values, then their operations - one reduction
+// alone is a chain of dependent DPP moves and f64 operations (two wait states and the operation's latency per link, nothing else
+// to issue with one wave per SIMD); n chains in lock step fill each other's gaps.  OPS: R_SUM / R_MAX (NaN-propagating) /
+// R_MIN / R_MAX2 (plain) per value; results are wave-uniform (scalar registers).
+enum { R_SUM = 0, R_MAX = 1, R_MIN = 2, R_MAX2 = 3 };
+__device__ __forceinline__ double red_apply(int op, double a, double b) {
+  switch (op) {
+    case R_SUM: return a + b;
+    case R_MAX: return nmax(a, b);
+    case R_MIN: return fmin(a, b);
+    default: return fmax(a, b);
+  }
+}
+template <int... OPS>
+struct WaveReduceN {
+  static constexpr int n = sizeof...(OPS);
+  template <int CTRL>
+  __device__ __forceinline__ static void level(double* v) {
+    constexpr int ops[n] = {OPS...};
+    double t[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) t[j] = dpp_mov<CTRL>(v[j]);
+#pragma unroll
+    for (int j = 0; j < n; ++j) v[j] = red_apply(ops[j], v[j], t[j]);
+  }
+  __device__ __forceinline__ static void run(double* v) {
+    static_assert(OCP_TPB == 64, "one wave per instance");
+    constexpr int ops[n] = {OPS...};
+    level<0xB1>(v);
+    level<0x4E>(v);
+    level<0x141>(v);
+    level<0x140>(v);
+    double a[n], b[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      a[j] = red_apply(ops[j], read_lane(v[j], 0), read_lane(v[j], 16));
+      b[j] = red_apply(ops[j], read_lane(v[j], 32), read_lane(v[j], 48));
+    }
+#pragma unroll
+    for (int j = 0; j < n; ++j) v[j] = uni(red_apply(ops[j], a[j], b[j]));
+  }
+};
 
 template <class Op>
 __device__ __forceinline__ double block_reduce(double v, __attribute__((address_space(3))) double* scratch) {
@@ -177,6 +220,17 @@ __device__ __forceinline__ double block_reduce(double v, __attribute__((address_
 //   NH     number of inputs carried as extra states so that they can be HELD beyond the control horizon (0: Nc == N)
 //   FUSED  the policy evaluates the shooting map and the Lagrange term of an interval together (`dyn_cost`): the
 //          continuous objective integrates the cost through the collocation states / Runge-Kutta stages of the map
+// structural non-zeros of a model's generated derivatives (ModelSym<M>::XMASK / JMASK / HMASK, hilo_mpc_amd/symdiff.py); all ones
+// for a model without them
+template <class MS, class = void> struct sym_masks {
+  static constexpr unsigned long long X = ~0ull, J = ~0ull, H = ~0ull;
+};
+template <class MS> struct sym_masks<MS, void_tt<decltype(MS::HAS_MASKS)>> {
+  static constexpr unsigned long long X = MS::HAS_MASKS ? MS::XMASK : ~0ull, J = MS::HAS_MASKS ? MS::JMASK : ~0ull,
+                                      H = MS::HAS_MASKS ? MS::HMASK : ~0ull;
+};
+template <class PB, class = void> struct pb_symtab { static constexpr bool value = false; };
+template <class PB> struct pb_symtab<PB, void_tt<decltype(PB::SYMTAB)>> { static constexpr bool value = PB::SYMTAB; };
 template <class PB, class = void> struct pb_nh { static constexpr int value = 0; };
 template <class PB> struct pb_nh<PB, void_tt<decltype(PB::NH)>> { static constexpr int value = PB::NH; };
 template <class PB, class = void> struct pb_sym { static constexpr bool value = false; };
@@ -245,12 +299,14 @@ struct OcpExtra {
 };
 
 #ifdef HILO_OCP_DPROF
-__device__ long long g_dprof[16];
+__device__ long long g_dprof[32];
 #define DTICK(i) { if (blockIdx.x == 0 && threadIdx.x == 0) { const long long tn_ = clock64(); g_dprof[i] += tn_ - dt_; dt_ = tn_; } }
 #define DTICK0 long long dt_ = clock64();
+#define DTICKR dt_ = clock64();
 #else
 #define DTICK(i)
 #define DTICK0
+#define DTICKR
 #endif
 
 enum OcpPhase { PH_DERIV = 0, PH_ERR, PH_RICCATI, PH_STEP, PH_LS, PH_UPDATE, PH_NRIC, PH_NLS, PH_COUNT };
@@ -411,6 +467,25 @@ struct Ocp {
     }
     return !((k == 0 && x0_pinned(pc, i)) || (k == pc.N && i >= NX));
   }
+  // the same test with the problem constants it reads already in (scalar) registers: inside a slot loop the reads of `pc` sit
+  // in conditional blocks (k == 0, ...) and would be waited for in the middle of the slot's arithmetic
+  struct FreeTest {
+    unsigned pinm;
+    int N, Nc;
+    __device__ bool operator()(int k, int i) const {
+      if constexpr (NH > 0) {
+        if (i >= NX && k >= Nc) return false;
+      }
+      return !((k == 0 && i < NX && ((pinm >> i) & 1u)) || (k == N && i >= NX));
+    }
+  };
+  __device__ static FreeTest free_test(const OcpConst& pc) {
+    FreeTest f;
+    f.pinm = uni((int)(FIX_X0 ? (~pc.x0_free_mask) & ((1u << NX) - 1u) : 0u));
+    f.N = uni(pc.N);
+    f.Nc = NH > 0 ? uni(pc.Nc) : 0;
+    return f;
+  }
   // inequality row m exists at stage k
   __device__ static bool row_on(const OcpConst& pc, int k, int m) {
     // (a row without a finite bound constrains nothing: the copies at the node of rows that only exist at the collocation
@@ -462,7 +537,9 @@ struct Ocp {
 
   // ---- values only at a point Zp: defects cp_k = x_{k+1} - F_k(x_k,u_k), returns (f, theta = |c|_1) -------------
   // with inequality rows: theta also counts |d_k - sp_k| for the slacks sp; `dstore` (optional) receives d_k
-  __device__ OCP_PHASE static FTheta eval_values_call(lds_double* lbase, double* ws, cvp Zp, ep cp, cdp sp, dp dstore) {
+  // `extra`: a per-lane value of the caller's that is summed over the lanes together with f and theta (the line search's
+  // -sum log(slacks) of the trial point: one three-value reduction instead of a reduction of its own in front of this call)
+  __device__ OCP_PHASE static FTheta eval_values_call(lds_double* lbase, double* ws, cvp Zp, ep cp, cdp sp, dp dstore, double extra) {
     lbase = uni(lbase); ws = uni(ws); Zp = uni(Zp); cp = uni(cp); sp = uni(sp); dstore = uni(dstore);
     const Lds l = carve(lbase, ws);
     const OcpConst& pc = *(const OcpConst*)l.pc;
@@ -576,32 +653,66 @@ struct Ocp {
         fpart += PB::term_cost(pc, (const double*)l.par, sd_of(l, N), x);
       }
     }
-    const double fr = block_reduce<OpSum>(fpart, l.red);
-    return FTheta{fr, block_reduce<OpSum>(tpart, l.red)};
+    if constexpr (OCP_TPB == 64) {
+      double rv[3] = {fpart, tpart, extra};
+      WaveReduceN<R_SUM, R_SUM, R_SUM>::run(rv);
+      return FTheta{rv[0], rv[1], rv[2]};
+    } else {
+      const double fr = block_reduce<OpSum>(fpart, l.red);
+      const double tr = block_reduce<OpSum>(tpart, l.red);
+      return FTheta{fr, tr, block_reduce<OpSum>(extra, l.red)};
+    }
   }
 
   __device__ __forceinline__ static FTheta eval_values(lds_double* lbase, double* ws, cvp Zp, ep cp, cdp sp = nullptr,
-                                                      dp dstore = nullptr) {
-    const FTheta r = eval_values_call(lbase, ws, Zp, cp, sp, dstore);
-    return FTheta{uni(r.f), uni(r.theta)};
+                                                      dp dstore = nullptr, double extra = 0.0) {
+    const FTheta r = eval_values_call(lbase, ws, Zp, cp, sp, dstore, extra);
+    return FTheta{uni(r.f), uni(r.theta), uni(r.x)};
   }
 
-  // -log(z - lb) - log(ub - z) of one slot with ONE logarithm (of the product of its slacks: a two-sided slot costs what a
-  // one-sided one does); a non-positive slack gives NaN like the logarithm would (two negative slacks must not cancel)
-  __device__ __forceinline__ static double slot_log(double lb, double ub, double z) {
-    const bool hl = lb > -INFINITY, hu = ub < INFINITY;
-    if (!hl && !hu) return 0.0;
-    const double sl = hl ? z - lb : 1.0, su = hu ? ub - z : 1.0;
-    const double r = -log(sl * su);
-    return (sl > 0.0 && su > 0.0) ? r : __builtin_nan("");
+  // this lane's part of -sum log(slacks) over the slots of a point - TRIAL: of Zt = Z + alpha D, which is formed and stored on the
+  // way.  Two slots per trip, reads first, and ONE logarithm for the (up to four) slacks of the two slots: the f64 logarithm is
+  // a ~120-instruction dependent chain.  (Four slacks between 1e-75 and 1e75 cannot leave the range of a double.)
+  template <bool TRIAL>
+  __device__ __forceinline__ static double slots_log(const Lds l, cvp Zp, double alpha, int N) {
+    constexpr int U = 2;
+    const int SLT = (N + 1) * NZ;
+    double part = 0.0;
+    for (int base = 0; base < SLT; base += OCP_TPB * U) {
+      double lbv[U], ubv[U], zv[U], dv[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e0 = base + u * OCP_TPB + (int)threadIdx.x;
+        ok[u] = e0 < SLT;
+        const int e = ok[u] ? e0 : 0;
+        lbv[u] = l.lbA[e]; ubv[u] = l.ubA[e]; zv[u] = Zp[e];
+        dv[u] = TRIAL ? l.D[e] : 0.0;
+      }
+      double prod = 1.0;
+      bool pos = true;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double z = TRIAL ? zv[u] + alpha * dv[u] : zv[u];
+        if constexpr (TRIAL) {
+          if (ok[u]) l.Zt[base + u * OCP_TPB + (int)threadIdx.x] = z;
+        }
+        const bool hl = ok[u] && lbv[u] > -INFINITY, hu = ok[u] && ubv[u] < INFINITY;
+        const double sl = hl ? z - lbv[u] : 1.0, su = hu ? ubv[u] - z : 1.0;
+        prod *= sl * su;
+        pos = pos && sl > 0.0 && su > 0.0;       // (two negative slacks must not cancel; a NaN slack fails the test as well)
+      }
+      const double r = -log(prod);
+      part += pos ? r : __builtin_nan("");
+    }
+    return part;
   }
   // -sum log(slacks) of a point (the barrier function is mu times this; the sum itself does not depend on mu, so the value of
   // an accepted trial point is carried into the next iteration instead of being recomputed)
   __device__ static double barrier_logs(const Lds l, cvp Zp, cdp sp = nullptr) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
-    double part = 0.0;
-    OCP_FOR(e, (N + 1) * NZ) part += slot_log(l.lbA[e], l.ubA[e], Zp[e]);
+    double part = slots_log<false>(l, Zp, 0.0, N);
     if constexpr (NC > 0) {
       OCP_FOR(e, N * NC) {
         const int m = e % NC;
@@ -613,15 +724,11 @@ struct Ocp {
     return uni(block_reduce<OpSum>(part, l.red));
   }
   // trial point Zt = Z + alpha D (and the slack rows), formed in the same pass as its -sum log(slacks)
-  __device__ static double form_trial(const Lds l, double alpha) {
+  // (returns this lane's part of the sum: reduced by the evaluation of the point that follows - eval_values' `extra`)
+  __device__ static double form_trial_part(const Lds l, double alpha) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
-    double part = 0.0;
-    OCP_FOR(e, (N + 1) * NZ) {
-      const double z = l.Z[e] + alpha * l.D[e];
-      l.Zt[e] = z;
-      part += slot_log(l.lbA[e], l.ubA[e], z);
-    }
+    double part = slots_log<true>(l, l.Z, alpha, N);
     if constexpr (NC > 0) {
       OCP_FOR(e, N * NC) {
         const int m = e % NC;
@@ -632,9 +739,8 @@ struct Ocp {
         if (pc.dub[m] < INFINITY) part -= log(pc.dub[m] - sv);
       }
     }
-    const double r = uni(block_reduce<OpSum>(part, l.red));
     __syncthreads();
-    return r;
+    return part;
   }
 
   // ---- full derivative evaluation at Z: c, AB, grad, per-stage cost values, Lagrangian Hessian blocks --------
@@ -939,6 +1045,7 @@ struct Ocp {
   __device__ __attribute__((always_inline)) static double eval_derivs_sym(lds_double* lbase, double* ws, bool reuse = false) {
     using M = typename PB::Model;
     using MS = ModelSym<M>;
+    using SM = sym_masks<MS>;
     static_assert(PB::QUAD_COST && NC == 0 && !COOP && !FUSED && M::NX == NX && M::NU == NU, "SYM: plain tracking policies");
     constexpr bool DISC = M::DISCRETE;
     constexpr int CPL = 2, LPI = (NZ + CPL - 1) / CPL;
@@ -978,6 +1085,7 @@ struct Ocp {
       }
 #pragma unroll
       for (int i = 0; i < NU; ++i) u[i] = zs[NX + i] * sz[NX + i];
+      DTICK(4)
       // stage cost: value (one lane of the interval) and the gradient rows of this lane's columns, closed form; the lanes of the
       // last interval add the terminal cost V(x_N) (its constant Hessian is written once per solve: term_hess_dirs)
       double ch[NZ][CPL];
@@ -985,6 +1093,20 @@ struct Ocp {
         double xN[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xN[i] = l.Z[N * NZ + i];
+        if constexpr (pb_symtab<PB>::value) {
+          double gc[CPL];
+          PB::template cost_cols<CPL>(pc, par, k, c0, zs, gc, ch);
+          if (act) {
+            if (g == 0 && !reuse) fpart += PB::stage_cost(pc, par, sd_of(l, k), k, zs, zs + NX);
+            if (g == 0 && k == N - 1 && !reuse) fpart += PB::term_cost(pc, par, sd_of(l, N), xN);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+              const int col = c0 + c;
+              if (col < NZ) l.grad[k * NZ + col] = is_free(pc, k, col) ? gc[c] : 0.0;
+              if (col < NX && k == N - 1) l.grad[N * NZ + col] = PB::term_grad(pc, col, xN);
+            }
+          }
+        } else {
         if (act) {
           if (g == 0 && !reuse) fpart += PB::stage_cost(pc, par, sd_of(l, k), k, zs, zs + NX);
           if (g == 0 && k == N - 1 && !reuse) fpart += PB::term_cost(pc, par, sd_of(l, N), xN);
@@ -999,7 +1121,9 @@ struct Ocp {
         for (int c = 0; c < CPL; ++c)
 #pragma unroll
           for (int r = 0; r < NZ; ++r) ch[r][c] = (c0 + c < NZ && r >= c0 + c) ? PB::cost_hess(pc, k, r, c0 + c) : 0.0;
+        }
       }
+      DTICK(5)
       if (!reuse) {  // stage points, slopes, Phi, defect
         double phi[NX];
         sym_points<M>(order, h, x, u, par, X, phi);
@@ -1029,7 +1153,8 @@ struct Ocp {
           for (int n = 0; n < NX; ++n) {
             double acc = 0.0;
 #pragma unroll
-            for (int m = 0; m < NX; ++m) acc += fx[m * NX + n] * kb[j][m];
+            for (int m = 0; m < NX; ++m)
+              if ((SM::X >> (m * NX + n)) & 1ull) acc += fx[m * NX + n] * kb[j][m];
             t[n] = acc;
           }
 #pragma unroll
@@ -1044,6 +1169,13 @@ struct Ocp {
       // tangent columns and the second-order adjoint, stage by stage
       dp scr = l.W + (size_t)k * NZ * WP;            // [NX][NZ] tangent block dX_i of the interval (exchange between its lanes)
       double dXc[NX][CPL], dX2[NX][CPL], dPhi[NX][CPL], G[NZ][CPL];
+      // the input rows of this lane's tangent columns dW = d(x_i, u)/dz[:, col] are constant: 1 where the column IS that input -
+      // as factors (exact: products with 0 and 1) instead of a compare-and-select per term of the products below
+      double eU[NU > 0 ? NU : 1][CPL];
+#pragma unroll
+      for (int a = 0; a < NU; ++a)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) eU[a][c] = (c0 + c == NX + a) ? 1.0 : 0.0;
 #pragma unroll
       for (int s = 0; s < NX; ++s)
 #pragma unroll
@@ -1073,23 +1205,22 @@ struct Ocp {
             MS::jh(X[i], u, par, kb[i], J, H);
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
-              const int col = c0 + c;
 #pragma unroll
               for (int m = 0; m < NX; ++m) {
                 double acc = 0.0;
 #pragma unroll
-                for (int n = 0; n < NX; ++n) acc += J[m * NZ + n] * dXc[n][c];
-#pragma unroll
-                for (int n = NX; n < NZ; ++n) acc += (col == n) ? J[m * NZ + n] : 0.0;
+                for (int n = 0; n < NZ; ++n)
+                  if ((SM::J >> (m * NZ + n)) & 1ull) acc += J[m * NZ + n] * (n < NX ? dXc[n < NX ? n : 0][c] : eU[n >= NX ? n - NX : 0][c]);
                 dK[m][c] = acc;
               }
 #pragma unroll
               for (int a = 0; a < NZ; ++a) {   // v = H_i dW_i[:, col]
                 double acc = 0.0;
 #pragma unroll
-                for (int n = 0; n < NX; ++n) acc += H[a >= n ? a * (a + 1) / 2 + n : n * (n + 1) / 2 + a] * dXc[n][c];
-#pragma unroll
-                for (int n = NX; n < NZ; ++n) acc += (col == n) ? H[a >= n ? a * (a + 1) / 2 + n : n * (n + 1) / 2 + a] : 0.0;
+                for (int n = 0; n < NZ; ++n) {
+                  const int q = a >= n ? a * (a + 1) / 2 + n : n * (n + 1) / 2 + a;
+                  if ((SM::H >> q) & 1ull) acc += H[q] * (n < NX ? dXc[n < NX ? n : 0][c] : eU[n >= NX ? n - NX : 0][c]);
+                }
                 v[a][c] = acc;
               }
             }
@@ -1499,7 +1630,7 @@ struct Ocp {
   // and with the reciprocal slacks already at hand  sig = zL/(z - lb) + zU/(ub - z)  (added to the diagonal of the stage's
   // Hessian block, stage_rhs) and  q = 1/(z - lb) - 1/(ub - z)  (parked in the right-hand-side column: rb = grad - mu q is
   // completed by finish_rhs once the barrier parameter of this iteration is known).  Keeps the divisions out of the recursion.
-  struct KktErr { double dual_s, prim, s_c, pmax, pmin, theta; };
+  struct KktErr { double dual_s, prim, s_c, i_s_c, pmax, pmin, theta; };
   __device__ static void stage_rhs(const Lds l, int N, int e, double sg, double r, bool replace) {
     const int k = e / NZ, i = e - k * NZ;
     l.sig[e] = sg;
@@ -1513,14 +1644,18 @@ struct Ocp {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
     double dmax = 0.0, lsum = 0.0, zsum = 0.0, pmax = 0.0, cmax = 0.0, cmin = INFINITY, th = 0.0;
-    if constexpr (BIG) {
-      // workspace mode: three slots per lane and trip, everything a slot reads from global memory (gradient, multipliers, its
-      // column of [A B], inequality rows, the diagonal entry of W it updates) requested before the first use - a trip of the
-      // plain loop is two dependent global round trips (residual, then the read-modify-write of the diagonal)
-      constexpr int U = 3;
+    DTICK0
+    {
+      // U slots per lane and trip, everything a slot reads (gradient, multipliers, its column of [A B], inequality rows, bounds,
+      // the diagonal entry of W it updates) requested before the first use and the slot's arithmetic written without branches:
+      // a trip of the plain predicated loop is a chain of ten dependent memory round trips (LDS: ~100 clocks each with one wave
+      // per SIMD; workspace mode: global memory)
+      constexpr int U = BIG ? 3 : 2;
       const int SLT = (N + 1) * NZ;
+      const FreeTest free_at = free_test(pc);
       for (int base = 0; base < SLT; base += OCP_TPB * U) {
         double gr[U], lp[U], ab[U][NX], lm[U][NX], wd[U], jd[U][NC > 0 ? NC : 1], cn[U][NC > 0 ? NC : 1];
+        double lbv[U], ubv[U], zv[U], zlv[U], zuv[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1537,48 +1672,44 @@ struct Ocp {
 #pragma unroll
             for (int m = 0; m < NC; ++m) { jd[u][m] = l.Jd[(kc * NC + m) * NZ + i]; cn[u][m] = l.cnu[kc * NC + m]; }
           }
+          lbv[u] = l.lbA[e]; ubv[u] = l.ubA[e]; zv[u] = l.Z[e]; zlv[u] = l.zL[e]; zuv[u] = l.zU[e];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int e = base + u * OCP_TPB + (int)threadIdx.x;
-          if (!ok[u]) continue;
-          const int k = e / NZ, i = e - k * NZ;
-          double sg = 0.0, q = 0.0;
-          if (is_free(pc, k, i)) {
-            double r = gr[u] - l.zL[e] + l.zU[e];                 // dual_res, same order of the sum
-            if (i < NX && k >= 1) r += lp[u];
-            if (k < N) {
+          const int e0 = base + u * OCP_TPB + (int)threadIdx.x;
+          const int e = ok[u] ? e0 : 0, k = e / NZ, i = e - k * NZ;
+          const bool fr = ok[u] && free_at(k, i);
+          const double zl = zlv[u], zu = zuv[u];
+          double r = gr[u] - zl + zu;                                   // dual_res, same order of the sum
+          r = (i < NX && k >= 1) ? r + lp[u] : r;
+          double r2 = r;
 #pragma unroll
-              for (int m = 0; m < NX; ++m) r -= ab[u][m] * lm[u][m];
-              if constexpr (NC > 0) {
+          for (int m = 0; m < NX; ++m) r2 -= ab[u][m] * lm[u][m];
+          if constexpr (NC > 0) {
 #pragma unroll
-                for (int m = 0; m < NC; ++m) r += jd[u][m] * cn[u][m];
-              }
-            }
-            dmax = nmax(dmax, fabs(r));
-            const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
-            zsum += fabs(zl) + fabs(zu);
-            if (lb > -INFINITY) {
-              const double sl = z - lb, is = rcp_fast(sl), p = sl * zl;
-              cmax = fmax(cmax, p);
-              cmin = fmin(cmin, p);
-              sg += zl * is;
-              q += is;
-            }
-            if (ub < INFINITY) {
-              const double su = ub - z, is = rcp_fast(su), p = su * zu;
-              cmax = fmax(cmax, p);
-              cmin = fmin(cmin, p);
-              sg += zu * is;
-              q -= is;
-            }
+            for (int m = 0; m < NC; ++m) r2 += jd[u][m] * cn[u][m];
           }
-          l.sig[e] = sg;                                            // stage_rhs(l, N, e, sg, q, false)
-          if (k < N) {
-            dp w = l.W + (size_t)(k * NZ + i) * WP;
-            w[i] = wd[u] + sg;
-            w[NZ] = q;
-          } else if (i < NX) l.rbN[i] = q;
+          r = k < N ? r2 : r;
+          dmax = fr ? nmax(dmax, fabs(r)) : dmax;
+          zsum += fr ? fabs(zl) + fabs(zu) : 0.0;
+          const bool hl = fr && lbv[u] > -INFINITY, hu = fr && ubv[u] < INFINITY;
+          const double sl = zv[u] - lbv[u], su = ubv[u] - zv[u];
+          const double isl = rcp_fast(hl ? sl : 1.0), isu = rcp_fast(hu ? su : 1.0), pl = sl * zl, pu = su * zu;
+          cmax = hl ? fmax(cmax, pl) : cmax;
+          cmin = hl ? fmin(cmin, pl) : cmin;
+          cmax = hu ? fmax(cmax, pu) : cmax;
+          cmin = hu ? fmin(cmin, pu) : cmin;
+          double sg = hl ? zl * isl : 0.0, q = hl ? isl : 0.0;
+          sg = hu ? sg + zu * isu : sg;
+          q = hu ? q - isu : q;
+          if (ok[u]) {                                                  // stage_rhs(l, N, e, sg, q, false)
+            l.sig[e] = sg;
+            if (k < N) {
+              dp w = l.W + (size_t)(k * NZ + i) * WP;
+              w[i] = wd[u] + sg;
+              w[NZ] = q;
+            } else if (i < NX) l.rbN[i] = q;
+          }
         }
       }
       const int NV = N * NX;
@@ -1594,44 +1725,12 @@ struct Ocp {
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          if (!ok[u]) continue;
           const double ca = fabs(cv[u]);
-          pmax = nmax(pmax, ca);
-          th += ca;
-          lsum += fabs(lv[u]);
+          pmax = ok[u] ? nmax(pmax, ca) : pmax;
+          th += ok[u] ? ca : 0.0;
+          lsum += ok[u] ? fabs(lv[u]) : 0.0;
         }
       }
-    } else {
-    OCP_FOR(e, (N + 1) * NZ) {
-      const int k = e / NZ, i = e - k * NZ;
-      double sg = 0.0, q = 0.0;
-      if (is_free(pc, k, i)) {
-        dmax = nmax(dmax, fabs(dual_res(l, N, e)));
-        const double lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
-        zsum += fabs(zl) + fabs(zu);
-        if (lb > -INFINITY) {
-          const double sl = z - lb, is = rcp_fast(sl), p = sl * zl;
-          cmax = fmax(cmax, p);
-          cmin = fmin(cmin, p);
-          sg += zl * is;
-          q += is;
-        }
-        if (ub < INFINITY) {
-          const double su = ub - z, is = rcp_fast(su), p = su * zu;
-          cmax = fmax(cmax, p);
-          cmin = fmin(cmin, p);
-          sg += zu * is;
-          q -= is;
-        }
-      }
-      stage_rhs(l, N, e, sg, q, false);
-    }
-    OCP_FOR(e, N * NX) {
-      const double ca = fabs(l.c[e]);
-      pmax = nmax(pmax, ca);
-      th += ca;
-      lsum += fabs(l.lam[e]);
-    }
     }
     double ncon = 0.0;
     if constexpr (NC > 0) {  // slack block: dual residual -nu - vL + vU, primal residual d - s; csig, and q_s parked in crb
@@ -1665,29 +1764,57 @@ struct Ocp {
       ncon = (double)N * pc.nc + pc.nc_term;
     }
     KktErr r;
-    r.theta = uni(block_reduce<OpSum>(th, l.red));
-    r.pmax = uni(block_reduce<OpMax2>(cmax, l.red));
-    r.pmin = uni(block_reduce<OpMin>(cmin, l.red));
-    dmax = block_reduce<OpMax>(dmax, l.red);
-    pmax = block_reduce<OpMax>(pmax, l.red);
-    lsum = block_reduce<OpSum>(lsum, l.red);
-    zsum = block_reduce<OpSum>(zsum, l.red);
-    const double s_d = fmax(pc.s_max, (lsum + zsum) / (N * NX + ncon + nb)) / pc.s_max;
+    DTICK(12)
+    if constexpr (OCP_TPB == 64) {
+      double rv[7] = {th, cmax, cmin, dmax, pmax, lsum, zsum};
+      WaveReduceN<R_SUM, R_MAX2, R_MIN, R_MAX, R_MAX, R_SUM, R_SUM>::run(rv);
+      r.theta = rv[0]; r.pmax = rv[1]; r.pmin = rv[2]; dmax = rv[3]; pmax = rv[4]; lsum = rv[5]; zsum = rv[6];
+    } else {
+      r.theta = uni(block_reduce<OpSum>(th, l.red));
+      r.pmax = uni(block_reduce<OpMax2>(cmax, l.red));
+      r.pmin = uni(block_reduce<OpMin>(cmin, l.red));
+      dmax = block_reduce<OpMax>(dmax, l.red);
+      pmax = block_reduce<OpMax>(pmax, l.red);
+      lsum = block_reduce<OpSum>(lsum, l.red);
+      zsum = block_reduce<OpSum>(zsum, l.red);
+    }
+    // (scalings with reciprocals - v_rcp_f64 and two Newton steps, <= 1 ulp - instead of IEEE divisions: five dependent
+    // 13-instruction sequences on wave-uniform values otherwise)
+    const double i_smax = rcp_fast(pc.s_max);
+    const double s_d = fmax(pc.s_max, (lsum + zsum) * rcp_fast(N * NX + ncon + nb)) * i_smax;
     // a NaN multiplier or defect must reach the error measure (fmax would drop it): through the sums
     const double poison = (lsum + zsum + r.theta) * 0.0;      // 0, or NaN
-    r.s_c = uni(fmax(pc.s_max, zsum / nb) / pc.s_max + poison);
-    r.dual_s = uni(dmax / s_d);
+    r.s_c = uni(fmax(pc.s_max, zsum * rcp_fast(nb)) * i_smax + poison);
+    r.i_s_c = uni(rcp_fast(r.s_c));
+    r.dual_s = uni(dmax * rcp_fast(s_d));
     r.prim = uni(pmax);
+    DTICK(13)
     return r;
   }
   // complementarity error for barrier parameter mu from the extreme products
   __device__ __forceinline__ static double compl_of(const KktErr& r, double mu) { return fmax(fmax(r.pmax - mu, mu - r.pmin), 0.0); }
+  // switching condition of the filter line search (W&B eq. 19):  alpha (-dphi)^s_phi > delta_ls th0^s_theta  with nd = -dphi > 0.
+  // Two f64 pow() are 540 instructions on one dependent chain per trial point; decided here in the logarithm with the hardware's
+  // f32 log2 of the mantissas (error of the difference < 2e-6 in units of log2) whenever the two sides are further apart than
+  // 2^(1e-4) - otherwise (and for zero / non-finite arguments) by the pow() expression itself: the same decision in every case.
+  __device__ __forceinline__ static bool switching(const OcpConst& pc, double alpha, double nd, double th0) {
+    const double dls = pc.delta_ls;
+    const bool plain = alpha > 0.0 && nd > 0.0 && th0 > 0.0 && dls > 0.0 && alpha < INFINITY && nd < INFINITY && th0 < INFINITY;
+    if (plain) {
+      auto lg2 = [](double x) {
+        return (double)__builtin_amdgcn_frexp_exp(x) + (double)__builtin_amdgcn_logf((float)__builtin_amdgcn_frexp_mant(x));
+      };
+      const double d = lg2(alpha) + pc.s_phi * lg2(nd) - lg2(dls) - pc.s_theta * lg2(th0);
+      if (fabs(d) > 1e-4) return d > 0.0;
+    }
+    return alpha * pow(nd, pc.s_phi) > dls * pow(th0, pc.s_theta);
+  }
   // right-hand sides of the Newton system once mu is fixed: rb = grad - mu q (q parked by kkt_pass), crb = -mu q_s
   __device__ static void finish_rhs(const Lds l, double mu) {
     const OcpConst& pc = *(const OcpConst*)l.pc;
     const int N = pc.N;
-    if constexpr (BIG) {   // three slots per lane and trip, reads first (see kkt_pass)
-      constexpr int U = 3;
+    {   // U slots per lane and trip, reads first (see kkt_pass)
+      constexpr int U = BIG ? 3 : 2;
       const int SLT = (N + 1) * NZ;
       for (int base = 0; base < SLT; base += OCP_TPB * U) {
         double gr[U], qv[U];
@@ -1708,14 +1835,6 @@ struct Ocp {
           if (k < N) l.W[(size_t)(k * NZ + i) * WP + NZ] = gr[u] - mu * qv[u];
           else if (i < NX) l.rbN[i] = gr[u] - mu * qv[u];
         }
-      }
-    } else {
-      OCP_FOR(e, (N + 1) * NZ) {
-        const int k = e / NZ, i = e - k * NZ;
-        if (k < N) {
-          dp w = l.W + (size_t)(k * NZ + i) * WP + NZ;
-          *w = l.grad[e] - mu * *w;
-        } else if (i < NX) l.rbN[i] = l.grad[e] - mu * l.rbN[i];
       }
     }
     if constexpr (NC > 0) {
@@ -3064,13 +3183,14 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     } else fval = S::eval_derivs(lds_raw, wsb, S::COOP && pts_ok);
     OCP_TICK(PH_DERIV)
     const typename S::KktErr ke = S::kkt_pass(l, nb_const);
-    const double dual_s = ke.dual_s, prim = ke.prim, s_c = ke.s_c, th0 = ke.theta;
+    DTICK0
+    const double dual_s = ke.dual_s, prim = ke.prim, i_s_c = ke.i_s_c, th0 = ke.theta;
     const double c0 = uni(fmax(ke.pmax, -ke.pmin));
     if (it == 0) {
       theta_min = uni(pc.theta_min_fact * fmax(1.0, th0));
       theta_max = uni(pc.theta_max_fact * fmax(1.0, th0));
     }
-    E0 = uni(nmax(nmax(dual_s, prim), c0 / s_c));
+    E0 = uni(nmax(nmax(dual_s, prim), c0 * i_s_c));
     if (E0 != E0) { st = HILO_STATUS_OTHER; break; }   // NaN in the iterate: IPOPT's 'Invalid_Number_Detected' -> -1
     if (E0 <= pc.tol) { st = HILO_STATUS_SOLVED; break; }
     if (E0 <= pc.acceptable_tol) {
@@ -3079,12 +3199,13 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     if (it >= pc.max_iter) { st = HILO_STATUS_MAXITER; break; }
     // ---- barrier update (W&B eq. 7) ----
     for (int r = 0; r < 20; ++r) {
-      const double Emu = uni(nmax(nmax(dual_s, prim), S::compl_of(ke, mu) / s_c));
+      const double Emu = uni(nmax(nmax(dual_s, prim), S::compl_of(ke, mu) * i_s_c));
       if (!(Emu <= pc.kappa_eps * mu && mu > mu_min * (1 + 1e-12))) break;
       mu = uni(fmax(mu_min, fmin(pc.kappa_mu * mu, pc.theta_mu == 1.5 ? mu * sqrt(mu) : pow(mu, pc.theta_mu))));
       tau = uni(fmax(pc.tau_min, 1.0 - mu));
       nfilt = 0;
     }
+    DTICK(14)
     OCP_TICK(PH_ERR)
     // ---- search direction with inertia correction (W&B Alg. IC) ----
     S::finish_rhs(l, mu);
@@ -3104,33 +3225,42 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     if (!solved) { st = HILO_STATUS_RESTORATION_FAILED; break; }
     if (delta > 0.0) delta_last = delta;
     OCP_TICK(PH_RICCATI)
+    DTICKR
     // ---- bound-multiplier steps, fraction to the boundary (W&B eq. 8), directional derivative ----
     // step lengths as tau / max(ratio): the largest relative decrease  -d / slack  (primal) and  -dz / z  (bound multipliers)
     // over the slots, with the reciprocals of the slacks the multiplier steps need anyway - one division per step length
     // instead of one per slot and side
     double r_p = 0.0, r_z = 0.0, dphi = 0.0;
-    OCP_FOR(e, SL) {
-      double dl = 0.0, du = 0.0;
-      {
-        const double d = l.D[e], lb = l.lbA[e], ub = l.ubA[e], z = l.Z[e], zl = l.zL[e], zu = l.zU[e];
-        double gphi = l.grad[e];
-        if (lb > -INFINITY) {
-          const double is = rcp_fast(z - lb);
-          dl = mu * is - zl - zl * is * d;
-          r_p = fmax(r_p, -d * is);
-          r_z = fmax(r_z, -dl * rcp_fast(zl));
-          gphi -= mu * is;
+    {   // U slots per lane and trip, reads first, no branches (see kkt_pass)
+      constexpr int U = S::BIG ? 3 : 2;
+      for (int base = 0; base < SL; base += OCP_TPB * U) {
+        double dv[U], lbv[U], ubv[U], zv[U], zlv[U], zuv[U], gv[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e0 = base + u * OCP_TPB + (int)threadIdx.x;
+          ok[u] = e0 < SL;
+          const int e = ok[u] ? e0 : 0;
+          dv[u] = l.D[e]; lbv[u] = l.lbA[e]; ubv[u] = l.ubA[e]; zv[u] = l.Z[e]; zlv[u] = l.zL[e]; zuv[u] = l.zU[e]; gv[u] = l.grad[e];
         }
-        if (ub < INFINITY) {
-          const double is = rcp_fast(ub - z);
-          du = mu * is - zu + zu * is * d;
-          r_p = fmax(r_p, d * is);
-          r_z = fmax(r_z, -du * rcp_fast(zu));
-          gphi += mu * is;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const double d = dv[u], zl = zlv[u], zu = zuv[u];
+          const bool hl = ok[u] && lbv[u] > -INFINITY, hu = ok[u] && ubv[u] < INFINITY;
+          const double isl = rcp_fast(hl ? zv[u] - lbv[u] : 1.0), isu = rcp_fast(hu ? ubv[u] - zv[u] : 1.0);
+          const double izl = rcp_fast(hl ? zl : 1.0), izu = rcp_fast(hu ? zu : 1.0);
+          // (the multiplier steps themselves are recomputed by the update: two slot vectors less in LDS)
+          const double dl = mu * isl - zl - zl * isl * d, du = mu * isu - zu + zu * isu * d;
+          r_p = hl ? fmax(r_p, -d * isl) : r_p;
+          r_z = hl ? fmax(r_z, -dl * izl) : r_z;
+          r_p = hu ? fmax(r_p, d * isu) : r_p;
+          r_z = hu ? fmax(r_z, -du * izu) : r_z;
+          double gphi = gv[u];
+          gphi = hl ? gphi - mu * isl : gphi;
+          gphi = hu ? gphi + mu * isu : gphi;
+          dphi += ok[u] ? gphi * d : 0.0;   // D = 0 on slots that are not variables
         }
-        dphi += gphi * d;   // D = 0 on slots that are not variables
       }
-      (void)dl; (void)du;   // the multiplier steps themselves are recomputed by the update (two slot vectors less in LDS)
     }
     if constexpr (NC > 0) {
       OCP_FOR(e, N * NC) {
@@ -3156,21 +3286,33 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
         l.cdvU[e] = du;
       }
     }
-    r_p = block_reduce<OpMax>(r_p, l.red);
-    r_z = block_reduce<OpMax>(r_z, l.red);
-    dphi = block_reduce<OpSum>(dphi, l.red);
+    DTICK(15)
+    if constexpr (OCP_TPB == 64) {
+      double rv[3] = {r_p, r_z, dphi};
+      WaveReduceN<R_MAX, R_MAX, R_SUM>::run(rv);
+      r_p = rv[0]; r_z = rv[1]; dphi = rv[2];
+    } else {
+      r_p = block_reduce<OpMax>(r_p, l.red);
+      r_z = block_reduce<OpMax>(r_z, l.red);
+      dphi = block_reduce<OpSum>(dphi, l.red);
+    }
     const double a_p = uni(r_p > tau ? tau / r_p : 1.0), a_z = uni(r_z > tau ? tau / r_z : 1.0);
     if (!blog_ok) blog = S::barrier_logs(l, l.Z, l.cs);
     const double phi0 = uni(fval + mu * blog);
+    DTICK(16)
     OCP_TICK(PH_STEP)
     // ---- filter line search (W&B Alg. A) ----
     double alpha = a_p;
     bool accepted = false, armijo = false;
     double blog_t = 0.0, f_acc = 0.0;
     for (int ls = 0; ls < 60; ++ls) {
-      blog_t = S::form_trial(l, alpha);
+      DTICKR
+      const double blog_part = S::form_trial_part(l, alpha);
+      DTICK(17)
       tprof[PH_NLS] += 1;
-      const FTheta trial = S::eval_values(lds_raw, wsb, l.Zt, l.ct, l.cst, l.cdt);
+      const FTheta trial = S::eval_values(lds_raw, wsb, l.Zt, l.ct, l.cst, l.cdt, blog_part);
+      blog_t = trial.x;
+      DTICK(18)
       const double ft = trial.f, tht = trial.theta;
       const double pht = uni(ft + mu * blog_t);
       bool ok = isfinite(pht) && isfinite(tht) && tht <= theta_max;
@@ -3182,11 +3324,12 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
       }
       bool sw = false;
       if (ok) {
-        sw = th0 <= theta_min && dphi < 0.0 && alpha * pow(-dphi, pc.s_phi) > pc.delta_ls * pow(th0, pc.s_theta);
+        sw = th0 <= theta_min && dphi < 0.0 && S::switching(pc, alpha, -dphi, th0);
         const double rnd = 10 * 2.220446049250313e-16 * fabs(phi0);
         if (sw) ok = pht - phi0 - rnd <= pc.eta_phi * alpha * dphi;
         else ok = tht <= (1 - pc.gamma_theta) * th0 || pht - phi0 - rnd <= -pc.gamma_phi * th0;
       }
+      DTICK(19)
       if (ok) { accepted = true; armijo = sw; f_acc = ft; break; }
       // ---- second-order correction (W&B sec. 2.4): the full step was rejected and did not reduce the violation.  The same
       // system is solved with c_soc = alpha c(x_k) + c(x_k + alpha d); up to four corrections while theta drops by kappa_soc.
@@ -3222,9 +3365,10 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
             }
           }
           const double a_s = block_reduce<OpMin>(a, l.red);
-          blog_t = S::form_trial(l, a_s);
+          const double blog_part2 = S::form_trial_part(l, a_s);
           tprof[PH_NLS] += 1;
-          const FTheta t2 = S::eval_values(lds_raw, wsb, l.Zt, l.ct, l.cst, l.cdt);
+          const FTheta t2 = S::eval_values(lds_raw, wsb, l.Zt, l.ct, l.cst, l.cdt, blog_part2);
+          blog_t = t2.x;
           const double ths = t2.theta;
           const double phs = uni(t2.f + mu * blog_t);
           bool oks = isfinite(phs) && isfinite(ths) && ths <= theta_max;
@@ -3235,7 +3379,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
             }
           }
           if (oks) {
-            const bool sw2 = th0 <= theta_min && dphi < 0.0 && alpha * pow(-dphi, pc.s_phi) > pc.delta_ls * pow(th0, pc.s_theta);
+            const bool sw2 = th0 <= theta_min && dphi < 0.0 && S::switching(pc, alpha, -dphi, th0);
             const double rnd = 10 * 2.220446049250313e-16 * fabs(phi0);
             if (sw2) oks = phs - phi0 - rnd <= pc.eta_phi * alpha * dphi;
             else oks = ths <= (1 - pc.gamma_theta) * th0 || phs - phi0 - rnd <= -pc.gamma_phi * th0;
@@ -3288,6 +3432,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
       if (alpha < 0.05 * amin) break;
     }
     OCP_TICK(PH_LS)
+    DTICKR
     const bool do_resto = !accepted;
     if (!armijo || do_resto) {  // augment the filter (W&B eq. 22); also done before entering restoration
       if (nfilt == OCP_FILTER) {
@@ -3343,21 +3488,48 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     pts_ok = true;
     f_trial = f_acc;
     const double ks_lo = uni(mu / pc.kappa_sigma), ks_hi = uni(pc.kappa_sigma * mu);
-    OCP_FOR(e, SL) {
-      const double znew = l.Zt[e], zold = l.Z[e], d = l.D[e], lb = l.lbA[e], ub = l.ubA[e];
-      l.Z[e] = znew;
-      if (lb > -INFINITY) {   // dzL = mu / s - zL - zL d / s at the old point (the step phase's formula)
-        const double io = rcp_fast(zold - lb), is = rcp_fast(znew - lb), zl = l.zL[e];
-        const double dl = mu * io - zl - zl * io * d;
-        l.zL[e] = fmin(fmax(zl + a_z * dl, ks_lo * is), ks_hi * is);
+    {   // U slots per lane and trip, reads first, no branches (see kkt_pass)
+      constexpr int U = S::BIG ? 3 : 2;
+      for (int base = 0; base < SL; base += OCP_TPB * U) {
+        double zn[U], zo[U], dv[U], lbv[U], ubv[U], zlv[U], zuv[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e0 = base + u * OCP_TPB + (int)threadIdx.x;
+          ok[u] = e0 < SL;
+          const int e = ok[u] ? e0 : 0;
+          zn[u] = l.Zt[e]; zo[u] = l.Z[e]; dv[u] = l.D[e]; lbv[u] = l.lbA[e]; ubv[u] = l.ubA[e]; zlv[u] = l.zL[e]; zuv[u] = l.zU[e];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = base + u * OCP_TPB + (int)threadIdx.x;
+          const double d = dv[u], zl = zlv[u], zu = zuv[u];
+          const bool hl = ok[u] && lbv[u] > -INFINITY, hu = ok[u] && ubv[u] < INFINITY;
+          // dzL = mu / s - zL - zL d / s at the old point (the step phase's formula)
+          const double iol = rcp_fast(hl ? zo[u] - lbv[u] : 1.0), isl = rcp_fast(hl ? zn[u] - lbv[u] : 1.0);
+          const double iou = rcp_fast(hu ? ubv[u] - zo[u] : 1.0), isu = rcp_fast(hu ? ubv[u] - zn[u] : 1.0);
+          const double dl = mu * iol - zl - zl * iol * d, du = mu * iou - zu + zu * iou * d;
+          const double zln = fmin(fmax(zl + a_z * dl, ks_lo * isl), ks_hi * isl), zun = fmin(fmax(zu + a_z * du, ks_lo * isu), ks_hi * isu);
+          if (ok[u]) l.Z[e] = zn[u];
+          if (hl) l.zL[e] = zln;
+          if (hu) l.zU[e] = zun;
+        }
       }
-      if (ub < INFINITY) {
-        const double io = rcp_fast(ub - zold), is = rcp_fast(ub - znew), zu = l.zU[e];
-        const double du = mu * io - zu + zu * io * d;
-        l.zU[e] = fmin(fmax(zu + a_z * du, ks_lo * is), ks_hi * is);
+      const int NV = N * NX;
+      for (int base = 0; base < NV; base += OCP_TPB * U) {
+        double la[U], ln[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e0 = base + u * OCP_TPB + (int)threadIdx.x;
+          ok[u] = e0 < NV;
+          la[u] = l.lam[ok[u] ? e0 : 0]; ln[u] = l.lamn[ok[u] ? e0 : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (ok[u]) l.lam[base + u * OCP_TPB + (int)threadIdx.x] = la[u] + alpha * (ln[u] - la[u]);
       }
     }
-    OCP_FOR(e, N * NX) l.lam[e] += alpha * (l.lamn[e] - l.lam[e]);
     if constexpr (NC > 0) {
       OCP_FOR(e, N * NC) {
         const int m = e % NC;
@@ -3376,6 +3548,7 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
       }
     }
     __syncthreads();
+    DTICK(20)
     OCP_TICK(PH_UPDATE)
   }
 

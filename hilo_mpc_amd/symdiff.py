@@ -352,6 +352,14 @@ def sym_source(struct_name, n_x, n_u, ode, meas=None):
     body2 = (lines2 + [f"    J[{m * nz + j}] = {ref2[J[m][j]]};" for m in range(n_x) for j in range(nz)] +
              [f"    H[{q}] = {ref2[h]};" for q, h in enumerate(H)])
     nops = len(lines2)
+    # structural non-zeros (bit q of JMASK: J[q], of HMASK: H[q]): the derivative phase skips the products with literal zeros - the
+    # compiler may not (0 * x is not 0 for a non-finite x); 0 = no information (more than 64 entries)
+    zero = ('0.0', '(-0.0)')
+    jmask = sum(1 << (m * nz + j) for m in range(n_x) for j in range(nz) if ref2[J[m][j]] not in zero) if n_x * nz <= 64 else 0
+    hmask = sum(1 << q for q, h in enumerate(H) if ref2[h] not in zero) if len(H) <= 64 else 0
+    xmask = sum(1 << (m * n_x + j) for m in range(n_x) for j in range(n_x) if ref1[J[m][j]] not in zero) if n_x * n_x <= 64 else 0
+    masks = (f"  static constexpr bool HAS_MASKS = {'true' if n_x * nz <= 64 and len(H) <= 64 else 'false'};\n"
+             f"  static constexpr unsigned long long XMASK = 0x{xmask:x}ull, JMASK = 0x{jmask:x}ull, HMASK = 0x{hmask:x}ull;\n")
     meas_fn = ""
     if meas:
         # measurement map: Jy = dh/dx [NY][NX], Hy = sum_a kb[a] d2 h_a / dx2 (packed lower triangle) - the measurement term of
@@ -382,7 +390,7 @@ def sym_source(struct_name, n_x, n_u, ode, meas=None):
     else:
         meas_fn = "  static constexpr bool HAS_MEAS = false;\n"
     return (f"template <> struct ModelSym<{struct_name}> {{\n"
-            f"  static constexpr bool value = true;\n"
+            f"  static constexpr bool value = true;\n" + masks +
             f"  // {len(lines1)} operations\n"
             f"  template <class P>\n"
             f"  __device__ __forceinline__ static void jx(const double* x, const double* u, const P* p, double* fx) {{\n"

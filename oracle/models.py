@@ -231,6 +231,115 @@ def chemostat4_gp(X_train, alpha, length_scales, signal_variance=1., bias=0.):
                        [mu * X - D * X, -Rs * X - D * S + DS * Sf, Rfp * X - D * P, -D * I + DI * If], [X, P])
 
 
+def chemostat4_mu():
+    """`chemostat4` with the growth rate of the biomass balance as the LAST PARAMETER `mu` - the model `substitute_from` starts
+    from (dynamic_model.py:3040-3125: the label is a parameter of the model until a learned term replaces it)."""
+    X, S, P, I, DS, DI, mu = sp.symbols('X S P I DS DI mu')
+    Sf, If, ISF, IRF = sp.symbols('Sf If ISF IRF')
+    phi = 0.407 * S / (0.108 + S + S ** 2 / 14814.0)
+    Rs = 2 * (phi * (ISF + 0.22 * IRF / (0.22 + I)))
+    Rfp = phi * (0.0005 + I) / (0.022 + I)
+    D = DS + DI
+    return OracleModel('chemostat4_mu', -1, [X, S, P, I], [DS, DI], [Sf, If, ISF, IRF, mu],
+                       [mu * X - D * X, -Rs * X - D * S + DS * Sf, Rfp * X - D * P, -D * I + DI * If], [X, P])
+
+
+class NumericHybridModel:
+    """The filters' view of a model (nx, ny, discrete, f, fx, h, hx - oracle/kf.py) for `base` (an OracleModel whose LAST
+    parameter is a learned quantity) with that parameter replaced by a function of the states that is given NUMERICALLY:
+    `term(x) -> (value [B], gradient [B, nx])`, e.g. a GP posterior mean (`se_mean_term`).  The symbolic route
+    (`chemostat4_gp`: 200 exponentials written out, then a Runge-Kutta map and its Jacobian by sympy) takes minutes per
+    lambdify; here the chain rule is applied to numbers:
+        f(x) = fb(x, mu(x)),   f_x = fb_x + fb_mu (x) dmu/dx,
+    and `discretize(order)` is the explicit Runge-Kutta map of modeling.py:1213-1281 with its Jacobian propagated stage by
+    stage (dk_i/dx = f_x(x_i) (I + h sum_j a_ij dk_j/dx))."""
+
+    def __init__(self, base, term, order=None, dt=None):
+        self.base, self.term, self.order = base, term, order
+        self.discrete = order is not None
+        self.nx, self.ny, self.nu = base.nx, base.ny, base.nu
+        self.name = base.name + '_hybrid'
+
+    def discretize(self, order=4):
+        return NumericHybridModel(self.base, self.term, order=order)
+
+    def _rhs(self, x, u, p, dt, jac):
+        x = np.atleast_2d(np.asarray(x, dtype=float))
+        B = x.shape[0]
+        mu, dmu = self.term(x)
+        pf = np.concatenate([np.broadcast_to(np.atleast_2d(p), (B, self.base.np_ - 1)), mu[:, None]], axis=1)
+        f = self.base.f(x, u, pf, dt)
+        if not jac:
+            return f, None
+        fx = self.base.fx(x, u, pf, dt)
+        Jp = sp.Matrix(self.base.ode).jacobian([self.base.p[-1]])
+        fmu = self.base._get('fmu', lambda: _lam(Jp.tolist(), self.base._args()))(x, u, pf, dt)      # [B, nx, 1]
+        return f, fx + fmu * dmu[:, None, :]
+
+    def _map(self, x, u, p, dt, jac):
+        if not self.discrete:
+            return self._rhs(x, u, p, dt, jac)
+        x = np.atleast_2d(np.asarray(x, dtype=float))
+        B, nx = x.shape
+        tab = TABLEAUX[self.order]
+        A, b = tab['A'], tab['b']
+        h = float(dt)
+        k, dk = [], []
+        for i in range(self.order):
+            xi, dxi = x.copy(), np.broadcast_to(np.eye(nx), (B, nx, nx)).copy()
+            for j in range(i):
+                if A[i][j] != 0:
+                    xi = xi + h * A[i][j] * k[j]
+                    if jac:
+                        dxi = dxi + h * A[i][j] * dk[j]
+            fi, Ji = self._rhs(xi, u, p, dt, jac)
+            k.append(fi)
+            if jac:
+                dk.append(Ji @ dxi)
+        xn, dxn = x.copy(), np.broadcast_to(np.eye(nx), (B, nx, nx)).copy()
+        for i in range(self.order):
+            xn = xn + h * b[i] * k[i]
+            if jac:
+                dxn = dxn + h * b[i] * dk[i]
+        return xn, dxn
+
+    def f(self, x, u, p, dt):
+        return self._map(x, u, p, dt, False)[0]
+
+    def fx(self, x, u, p, dt):
+        return self._map(x, u, p, dt, True)[1]
+
+    def h(self, x, u, p, dt):
+        B = np.atleast_2d(x).shape[0]
+        pf = np.concatenate([np.broadcast_to(np.atleast_2d(p), (B, self.base.np_ - 1)), np.zeros((B, 1))], axis=1)
+        return self.base.h(x, u, pf, dt)
+
+    def hx(self, x, u, p, dt):
+        B = np.atleast_2d(x).shape[0]
+        pf = np.concatenate([np.broadcast_to(np.atleast_2d(p), (B, self.base.np_ - 1)), np.zeros((B, 1))], axis=1)
+        return self.base.hx(x, u, pf, dt)
+
+
+def se_mean_term(X_train, alpha, length_scales, signal_variance, state_index, bias=0.):
+    """Posterior mean of a GP with the squared-exponential kernel (ARD) over the states `state_index`, and its gradient with
+    respect to ALL states:  m(x) = bias + sum_i alpha_i sf2 exp(-1/2 sum_d (x_d - X_di)^2 / l_d^2)  (inference.py:211-213,
+    kernel.py:696)."""
+    Xt = np.atleast_2d(np.asarray(X_train, dtype=float))
+    al = np.asarray(alpha, dtype=float).ravel()
+    M = np.exp(-2 * np.log(np.broadcast_to(np.asarray(length_scales, dtype=float), (Xt.shape[0],))))
+    sf2 = float(np.exp(2 * (np.log(signal_variance) / 2)))
+    idx = list(state_index)
+
+    def term(x):
+        x = np.atleast_2d(np.asarray(x, dtype=float))
+        d = x[:, idx, None] - Xt[None, :, :]                                    # [B, D, n]
+        kv = sf2 * np.exp(-0.5 * np.einsum('d,bdn->bn', M, d * d)) * al[None, :]
+        g = np.zeros_like(x)
+        g[:, idx] = -np.einsum('bn,bdn->bd', kv, d) * M[None, :]
+        return bias + kv.sum(1), g
+    return term
+
+
 def pendulum4_dae():
     """The DAE of the reference's own NMPC test (tests/test_NMPC.py:1866-1911): the cart-pendulum with the height of the
     pendulum tip as algebraic state, 0 = h + l cos(theta) - y."""

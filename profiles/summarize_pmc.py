@@ -16,10 +16,10 @@ import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 cfg = sys.argv[3] if len(sys.argv) > 3 else 'C2'
-KEY = 'hilo_user_solve' if cfg in ('C5', 'C5-dae') else 'ocp_solve_kernel'
+KEY = 'hilo_user_solve' if cfg in ('C5', 'C5-dae') else 'ocp_solve_kernel'      # cfg 'icache': the I-cache passes of C2 (run_pmc_icache.sh)
 CLOCK_GHZ = 2.4          # MI355X shader clock (MI355X_MICROARCH.md)
 N_SIMD = 1024
-STEADY = {'C2': 6, 'C4': 4, 'C3-mhe': 4, 'C5': 3, 'C5-dae': 2}.get(cfg, 4)     # timed launches of each pass (run_round.sh)
+STEADY = {'C2': 6, 'icache': 6, 'C4': 4, 'C3-mhe': 4, 'C5': 3, 'C5-dae': 2}.get(cfg, 4)     # timed launches of each pass (run_round.sh)
 
 
 def collect(pattern, key, steady):
@@ -50,6 +50,8 @@ def collect(pattern, key, steady):
         out['valu_busy_frac'] = g('SQ_ACTIVE_INST_VALU') / g('SQ_WAVE_CYCLES')
     if g('SQ_WAIT_INST_LDS') is not None and g('SQ_WAVE_CYCLES'):
         out['lds_wait_frac'] = g('SQ_WAIT_INST_LDS') / g('SQ_WAVE_CYCLES')
+    if g('SQC_ICACHE_REQ') and g('SQC_ICACHE_MISSES') is not None:
+        out['icache_miss_frac'] = g('SQC_ICACHE_MISSES') / g('SQC_ICACHE_REQ')
     return out
 
 

@@ -1,0 +1,125 @@
+"""GPU: Kalman filters on a model with a learned term - `Model.substitute_from(gp)` (dynamic_model.py:3040-3125) followed by
+`EKF(model)` / `UKF(model)` (kf.py:369-410, :412-610): the reference's filters differentiate / propagate whatever the model's
+equations contain, the GP posterior mean included.  Oracle: the filter equations of oracle/kf.py on a NUMERIC statement of the
+hybrid model (oracle/models.py::NumericHybridModel: closed-form kernel sum and gradient, chain rule through the Runge-Kutta
+stages - checked against the symbolic statement on a small training set in tests/test_oracle_hybrid.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp as ogp, kf as okf, models as omodels                   # noqa: E402
+from tests.problems import C4_GP, c4_training_data, product_gp, symbolic_model   # noqa: E402
+from tests.util import spd_batch                                                # noqa: E402
+
+
+def _oracle_model(X, y):
+    post = ogp.Posterior({'type': 'squared_exponential',
+                          'kwargs': dict(active_dims=[0, 1], length_scales=C4_GP['length_scales'], ard=True,
+                                         signal_variance=C4_GP['signal_variance'])},
+                         {'type': 'zero'}, X, y, C4_GP['noise_variance'])
+    term = omodels.se_mean_term(X, post.alpha, C4_GP['length_scales'], C4_GP['signal_variance'], [1, 3])
+    return omodels.NumericHybridModel(omodels.chemostat4_mu(), term)
+
+
+def _batch(B, seed):
+    rng = np.random.default_rng(seed)
+    x = np.array([.1, 30., .5, .4]) * (1 + .2 * rng.uniform(-1, 1, (B, 4)))
+    P = spd_batch(rng, B, 4)
+    u = rng.uniform(0, .3, (B, 2))
+    p = np.tile([100., 4., 1., 0.], (B, 1))
+    y = x[:, [0, 2]] + .01 * rng.normal(size=(B, 2))
+    return x, P, u, p, y
+
+
+def _hybrid_model():
+    gp = product_gp()
+    m = symbolic_model('chemostat4_mu')
+    m.substitute_from(gp)
+    return m, gp
+
+
+@pytest.mark.parametrize('B', [3, 300])
+def test_ekf_with_a_learned_term_vs_numeric_oracle(B):
+    """One estimate() of the EKF on the discretised hybrid model (the learned rate inside every Runge-Kutta stage and inside the
+    Jacobian of the map) - x, P, predicted measurement."""
+    from hilo_mpc_amd import EKF
+    X, yt = c4_training_data()
+    om = _oracle_model(X, yt).discretize(4)
+    x, P, u, p, y = _batch(B, 5)
+    ref, ypr = okf.kf_step(om, okf.pack(x, P), y, u, p, 1e-4, 1e-2, 1.)
+    m, gp = _hybrid_model()
+    f = EKF(m.discretize('erk', order=4).setup(dt=1.))
+    f.setup()
+    f.Q, f.R = 1e-4, 1e-2
+    f.set_initial_guess(x, P0=P)
+    sol = f.estimate(y=y, u=u, p=p)
+    # the kernel sum has 200 terms of both signs: 1e-10 relative between two orders of summation
+    np.testing.assert_allclose(np.asarray(f.x.cpu()), ref[:, :, 0], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(np.asarray(f.P.cpu()), ref[:, :, 1:], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(sol['y'], ypr, rtol=1e-9, atol=1e-11)
+    # the learned term matters: the filter of the closed-form model gives another estimate
+    from hilo_mpc_amd import Model
+    g = EKF(Model('chemostat4').discretize('erk', order=4).setup(dt=1.))
+    g.setup()
+    g.Q, g.R = 1e-4, 1e-2
+    g.set_initial_guess(x, P0=P)
+    g.estimate(y=y, u=u, p=p)
+    assert np.abs(np.asarray(g.x.cpu()) - np.asarray(f.x.cpu())).max() > 1e-6
+
+
+def test_ukf_with_a_learned_term_vs_numeric_oracle():
+    from hilo_mpc_amd import UKF
+    B = 65
+    X, yt = c4_training_data()
+    om = _oracle_model(X, yt).discretize(4)
+    x, P, u, p, y = _batch(B, 6)
+    ref, _ = okf.ukf_step(om, okf.pack(x, P), y, u, p, 1e-4, 1e-2, 1., alpha=1.)
+    m, gp = _hybrid_model()
+    f = UKF(m.discretize('rk4').setup(dt=1.), alpha=1.)
+    f.setup()
+    f.Q, f.R = 1e-4, 1e-2
+    f.set_initial_guess(x, P0=P)
+    f.estimate(y=y, u=u, p=p)
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(np.asarray(f.x.cpu()), ref[:, :, 0], rtol=1e-9, atol=1e-9 * scale)
+    np.testing.assert_allclose(np.asarray(f.P.cpu()), ref[:, :, 1:], rtol=1e-8, atol=1e-9 * scale)
+
+
+def test_two_filters_on_different_learned_terms_and_several_steps_per_launch():
+    """Two filters compiled from the same source keep their own learned-term tables; K steps in one launch equal K single
+    steps (the multi-step kernels read the same table)."""
+    from hilo_mpc_amd import EKF
+    B, K = 40, 3
+    x, P, u, p, y = _batch(B, 7)
+    X, yt = c4_training_data()
+    m1, gp1 = _hybrid_model()
+    gp2 = product_gp(X, 1.5 * yt)
+    m2 = symbolic_model('chemostat4_mu')
+    m2.substitute_from(gp2)
+    fs = []
+    for m in (m1, m2):
+        f = EKF(m.discretize('erk', order=4).setup(dt=1.))
+        f.setup()
+        f.Q, f.R = 1e-4, 1e-2
+        fs.append(f)
+    outs = []
+    for f in fs:
+        f.set_initial_guess(x, P0=P)
+        f.estimate(y=y, u=u, p=p)
+        outs.append(np.asarray(f.x.cpu()).copy())
+    assert np.abs(outs[0] - outs[1]).max() > 1e-6
+    om2 = _oracle_model(X, 1.5 * yt).discretize(4)
+    ref2, _ = okf.kf_step(om2, okf.pack(x, P), y, u, p, 1e-4, 1e-2, 1.)
+    np.testing.assert_allclose(outs[1], ref2[:, :, 0], rtol=1e-9, atol=1e-11)
+    # the first filter is unaffected by the second one's table: K steps in one launch against K launches
+    f = fs[0]
+    ys = np.repeat(y[None], K, axis=0) * (1 + .01 * np.arange(K))[:, None, None]
+    f.set_initial_guess(x, P0=P)
+    for k in range(K):
+        f.estimate(y=ys[k], u=u, p=p)
+    x_single, P_single = np.asarray(f.x.cpu()).copy(), np.asarray(f.P.cpu()).copy()
+    f.set_initial_guess(x, P0=P)
+    f.estimate(y=ys, u=u, p=p, steps=K)
+    np.testing.assert_allclose(np.asarray(f.x.cpu()), x_single, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(np.asarray(f.P.cpu()), P_single, rtol=1e-11, atol=1e-14)
