@@ -25,7 +25,7 @@ class KfDesc(C.Structure):
     _fields_ = [('model_id', C.c_int32), ('kind', C.c_int32), ('continuous', C.c_int32), ('erk_order', C.c_int32),
                 ('n_sub', C.c_int32), ('lti_nx', C.c_int32), ('lti_nu', C.c_int32), ('lti_ny', C.c_int32),
                 ('dt', C.c_double), ('alpha', C.c_double), ('beta', C.c_double), ('kappa', C.c_double),
-                ('user_source', C.c_char_p)]
+                ('user_source', C.c_char_p), ('n_user_gp', C.c_int32), ('user_gp', C.c_void_p * 4)]
 
 
 class NmpcDesc(C.Structure):

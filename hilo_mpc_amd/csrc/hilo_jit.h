@@ -56,8 +56,13 @@ struct JitKfKernels {
   hipFunction_t multi[2] = {nullptr, nullptr};   // several fused steps per launch (kf_multi_body): [UKF]
   hipFunction_t team[2] = {nullptr, nullptr};    // the same on a team of lanes per instance (kf_team_body): small batches
   int dims[5] = {0, 0, 0, 0, 0};
+  const double** gp_table = nullptr;   // device address of the module's hilo_user_gp[4] (learned terms of the user model)
+  hipModule_t owned = nullptr;         // a module instance of the filter's own (private_module): unloaded with the handle
 };
-int jit_kf_kernels(const std::string& user_source, int device, JitKfKernels* out, bool compile_only = false);
+// private_module: load an instance of the module for this caller alone (its learned-term table is written per filter)
+int jit_kf_kernels(const std::string& user_source, int device, JitKfKernels* out, bool compile_only = false,
+                   bool private_module = false);
+void jit_kf_unload(JitKfKernels* k);
 
 // launch helpers (hipModuleLaunchKernel)
 int jit_launch_solve(hipFunction_t f, const OcpConst* dev, int64_t batch, const double* x0, const double* par, int64_t par_stride,

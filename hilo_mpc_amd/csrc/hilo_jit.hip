@@ -344,7 +344,7 @@ int jit_nmpc_kernels(const JitRequest& r, int device, JitKernels* out) {
 // ---- filters of models written as expressions: kf_body<UserModel, UKF, MODE> behind six extern "C" kernels ----------------
 static std::map<std::string, JitKfKernels> g_kf_loaded;
 
-int jit_kf_kernels(const std::string& user_source, int device, JitKfKernels* out, bool compile_only) {
+int jit_kf_kernels(const std::string& user_source, int device, JitKfKernels* out, bool compile_only, bool private_module) {
   std::string tu = "#include \"hilo_kf_kernel.h\"\nextern \"C\" { __device__ const double* hilo_user_gp[4]; }\nnamespace hilo {\n";
   tu += user_source;
   tu += R"(
@@ -413,7 +413,7 @@ extern "C" __global__ void hilo_user_kf_info(int* o) {
   const std::string mkey = key + "@" + std::to_string(device);
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_kf_loaded.find(mkey);
-  if (it != g_kf_loaded.end()) { *out = it->second; return HILO_OK; }
+  if (!private_module && it != g_kf_loaded.end()) { *out = it->second; return HILO_OK; }
   std::vector<char> code;
   rc = unit_code(tu, opts, key, code, &cpath);
   if (rc) return rc;
@@ -442,9 +442,21 @@ extern "C" __global__ void hilo_user_kf_info(int* o) {
   HILO_HIP_CHECK(hipModuleLaunchKernel(info, 1, 1, 1, 1, 1, 1, 0, nullptr, args, nullptr));
   HILO_HIP_CHECK(hipMemcpy(k.dims, dinfo, sizeof(int) * 5, hipMemcpyDeviceToHost));
   HILO_HIP_CHECK(hipFree(dinfo));
-  g_kf_loaded[mkey] = k;
+  {
+    hipDeviceptr_t gptr = nullptr;
+    size_t gbytes = 0;
+    HILO_HIP_CHECK(hipModuleGetGlobal(&gptr, &gbytes, mod, "hilo_user_gp"));
+    k.gp_table = (const double**)gptr;
+  }
+  if (private_module) k.owned = mod;
+  else g_kf_loaded[mkey] = k;
   *out = k;
   return HILO_OK;
+}
+
+void jit_kf_unload(JitKfKernels* k) {
+  if (k && k->owned) (void)hipModuleUnload(k->owned);
+  if (k) *k = JitKfKernels();
 }
 
 void jit_unload(JitKernels* k) {

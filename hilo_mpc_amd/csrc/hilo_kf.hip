@@ -94,6 +94,7 @@ struct hilo_kf {
   bool discrete;
   KfParams kp;
   hilo::JitKfKernels jit;   // model given as source (HILO_MODEL_USER): kernels compiled at create
+  double* user_gp_pack[4] = {nullptr, nullptr, nullptr, nullptr};   // packed learned terms of that model (gp_pack_se)
 };
 
 #define HILO_KF_MODELS(X)                 \
@@ -160,7 +161,8 @@ extern "C" int hilo_kf_create(const hilo_kf_desc* desc, int device, hilo_kf** ou
   JitKfKernels jit;
   if (desc->model_id == 100 /* HILO_MODEL_USER */) {
     HILO_REQUIRE(desc->user_source && desc->user_source[0], "hilo_kf_create: HILO_MODEL_USER needs desc.user_source");
-    rc = jit_kf_kernels(desc->user_source, device, &jit);
+    HILO_REQUIRE(desc->n_user_gp >= 0 && desc->n_user_gp <= 4, "hilo_kf_create: at most 4 learned terms (got %d)", desc->n_user_gp);
+    rc = jit_kf_kernels(desc->user_source, device, &jit, false, desc->n_user_gp > 0);
     if (rc) return rc;
     if (getenv("HILO_JIT_COMPILE_ONLY")) return HILO_COMPILED_ONLY;   // cache warmed, no handle
     nx = jit.dims[0]; nu = jit.dims[1]; np = jit.dims[2]; ny = jit.dims[3]; disc = jit.dims[4];
@@ -184,6 +186,7 @@ extern "C" int hilo_kf_create(const hilo_kf_desc* desc, int device, hilo_kf** ou
   hilo_kf* kf = new hilo_kf();
   kf->desc = *desc;
   kf->desc.user_source = nullptr;   // not kept: the kernels are
+  for (auto& g : kf->desc.user_gp) g = nullptr;   // nor the learned terms' handles: their posteriors are packed below
   kf->jit = jit;
   kf->device = device;
   kf->nx = nx; kf->nu = nu; kf->np = np; kf->ny = ny;
@@ -200,11 +203,29 @@ extern "C" int hilo_kf_create(const hilo_kf_desc* desc, int device, hilo_kf** ou
   kp.wm0 = lam / (nx + lam);
   kp.wc0 = lam / (nx + lam) + 1 - desc->alpha * desc->alpha + desc->beta;
   kp.wi = 1 / (2 * (nx + lam));
+  if (desc->model_id == 100 && desc->n_user_gp > 0) {   // learned terms: packed posteriors into the module's table
+    const double* table[4] = {nullptr, nullptr, nullptr, nullptr};
+    rc = kf->jit.gp_table ? HILO_OK : fail(HILO_EHIP, "hilo_kf_create: the compiled module exports no learned-term table");
+    for (int k = 0; !rc && k < desc->n_user_gp; ++k) {
+      if (!desc->user_gp[k]) rc = fail(HILO_EINVAL, "hilo_kf_create: user_gp[%d] is NULL", k);
+      else rc = gp_pack_se(desc->user_gp[k], &kf->user_gp_pack[k]);
+      table[k] = kf->user_gp_pack[k];
+    }
+    if (!rc && hipMemcpy((void*)kf->jit.gp_table, table, sizeof(table), hipMemcpyHostToDevice) != hipSuccess)
+      rc = fail(HILO_EHIP, "hilo_kf_create: writing the learned-term table failed");
+    if (rc) { hilo_kf_destroy(kf); return rc; }
+  }
   *out = kf;
   return HILO_OK;
 }
 
-extern "C" void hilo_kf_destroy(hilo_kf* kf) { delete kf; }
+extern "C" void hilo_kf_destroy(hilo_kf* kf) {
+  if (!kf) return;
+  for (double* g : kf->user_gp_pack)
+    if (g) (void)hipFree(g);
+  jit_kf_unload(&kf->jit);   // (a shared module stays loaded: `owned` is only set for a private instance)
+  delete kf;
+}
 
 #ifdef HILO_KF_PROF   // developer builds (tools/dbg/kf_phase.py): the cycle stamps of the team kernels
 extern "C" int hilo_debug_kf_prof(unsigned long long* out) {

@@ -102,12 +102,15 @@ class _KalmanFilter:
             # a model written as expressions: its functor is compiled at setup (csrc/hilo_jit.hip) like the controllers' problems
             if not m.n_y:
                 raise RuntimeError("The model has no measurement equations (set_measurement_equations)")
-            if getattr(m, '_gps', None):
-                # the filter kernels are compiled without the learned-term table of the controllers (desc.user_gp)
-                raise NotImplementedError("Filters on a model with a learned term (Model.substitute_from) are not supported: "
-                                          "the filter kernels carry no Gaussian-process data")
             self._user_source = m.user_source()
             desc.user_source = self._user_source.encode()
+            # learned terms (Model.substitute_from): the trained GPs behind hilo_user_gp[k] of the source, like the controllers'
+            gps = list(getattr(m, '_gps', None) or [])
+            desc.n_user_gp = len(gps)
+            for k, g in enumerate(gps):
+                # (compile-only mode never dereferences the handles: any non-NULL value)
+                desc.user_gp[k] = 1 if compile_only else (g._handle.value if hasattr(g._handle, 'value') else g._handle)
+            self._gps = gps           # keeps the GP objects alive until the handle is created
         h = C.c_void_p()
         if compile_only:
             if desc.user_source:

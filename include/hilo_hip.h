@@ -99,6 +99,12 @@ typedef struct hilo_kf_desc {
      hilo_mpc_amd/codegen.py emits for `Model.set_dynamical_equations` / `set_measurement_equations`), compiled with hiprtc at
      create and cached like the controllers' (hilo_nmpc_desc.user_source).  NULL for the zoo models. */
   const char* user_source;
+  /* learned terms of the user model (`Model.substitute_from(gp)` before `EKF(model)` / `UKF(model)` / `ParticleFilter(model)`): the
+     source refers to them as hilo_user_gp[k] exactly like a controller's (hilo_nmpc_desc.user_gp); the filter gets a module
+     instance of its own, so two filters compiled from the same source keep their own tables.  The GPs must outlive nothing:
+     their posterior is packed at create. */
+  int32_t n_user_gp;
+  const struct hilo_gp* user_gp[4];   /* trained handles of hilo_gp_create (section 4) */
 } hilo_kf_desc;
 
 int hilo_kf_create(const hilo_kf_desc* desc, int device, hilo_kf** out);
