@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's committed evidence comes from, in one call on the GPU box:
 #   profiles/run_round.sh r05        then (here)  python profiles/summarize.py gpurun_out/prof_r05 r05 ; python profiles/summarize_pmc.py gpurun_out/pmc_r05 r05
-#                                                 python profiles/summarize_pmc.py gpurun_out/pmc_r05_<config> r05 <config>   (C4, C3-mhe, C5, C5-dae)
+#                                                 python profiles/summarize_pmc.py gpurun_out/pmc_r05_<config> r05 <config>   (C4, C3-mhe, C5, C5-dae, icache)
 TAG=${1:-r05}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -13,6 +13,7 @@ profiles/run_pmc_valu.sh $TAG C4 4 6 >> gpurun_out/pmc_$TAG.log 2>&1
 profiles/run_pmc_valu.sh $TAG C3-mhe 4 6 >> gpurun_out/pmc_$TAG.log 2>&1
 profiles/run_pmc_valu.sh $TAG C5 3 3 >> gpurun_out/pmc_$TAG.log 2>&1
 profiles/run_pmc_valu.sh $TAG C5-dae 2 2 >> gpurun_out/pmc_$TAG.log 2>&1
+profiles/run_pmc_icache.sh $TAG >> gpurun_out/pmc_$TAG.log 2>&1      # instruction-cache hit rate of the headline kernel (87 KB of code)
 # the driver's command (20 steps) and a longer timed region (50 steps) of the headline configuration, and the batch sweep
 mkdir -p gpurun_out/bench_$TAG
 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$TAG/C2_20.json 2>/dev/null

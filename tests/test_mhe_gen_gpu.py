@@ -3,6 +3,8 @@ NO state noise, parameters estimated through `quad_arrival_cost.add_parameters` 
 default collocation or with a discretised model - the general policy csrc/hilo_mhe_policy.h::MheGen against the oracle's
 simultaneous form (oracle/mhe_gen.py, which reproduces oracle/mhe.py and oracle/mhe_coll.py on their cases).
 Tolerances at a matched tight tolerance (tol 1e-10): v 1e-6 relative, objective 1e-9, multipliers 1e-5."""
+import json
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,7 @@ from oracle import models                                              # noqa: E
 from oracle.mhe_gen import MheGenIpm, MheGenProblem                    # noqa: E402
 from oracle.nmpc import IpmOptions                                     # noqa: E402
 from tests.problems import C3B, c3_data, symbolic_model                # noqa: E402
+from tests.util import golden_or_compute                               # noqa: E402
 
 TOL = 1e-10
 P_TRUE = [100., 4., 1., 0.]
@@ -51,9 +54,19 @@ def _oracle(spec, degree, noise, est_idx=(), **kw):
     return pb, MheGenIpm(pb, IpmOptions(tol=TOL))
 
 
+def _pb_data(pb):
+    """what _compare reads of an oracle problem, as plain data (fixtures)"""
+    if isinstance(pb, dict):
+        return pb
+    return dict(n_v=int(pb.n_v), n_g=int(pb.n_g), x_ind=pb.x_ind, w_ind=pb.w_ind, ip_ind=pb.ip_ind, p_ind=pb.p_ind)
+
+
 def _compare(mhe, pb, ref, x_opt, p_opt, B, vtol=1e-6):
-    assert (mhe._n_v, mhe._n_g) == (pb.n_v, pb.n_g)
-    assert mhe._x_ind == pb.x_ind and mhe._w_ind == pb.w_ind and mhe._ip_ind == pb.ip_ind and mhe._p_ind == pb.p_ind
+    pb = _pb_data(pb)
+    plain = lambda v: json.loads(json.dumps(v))                                        # noqa: E731  (tuples / numpy ints -> lists / ints)
+    assert (mhe._n_v, mhe._n_g) == (pb['n_v'], pb['n_g'])
+    assert plain(mhe._x_ind) == plain(pb['x_ind']) and plain(mhe._w_ind) == plain(pb['w_ind'])
+    assert plain(mhe._ip_ind) == plain(pb['ip_ind']) and plain(mhe._p_ind) == plain(pb['p_ind'])
     assert np.array_equal(mhe.solver_status_code, ref['status']) and np.all(ref['status'] == 1)
     v, vr = mhe._nlp_solution['x'].cpu().numpy(), ref['v']
     assert np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < vtol
@@ -61,6 +74,41 @@ def _compare(mhe, pb, ref, x_opt, p_opt, B, vtol=1e-6):
     np.testing.assert_allclose(x_opt.cpu().numpy(), ref['x_opt'], rtol=1e-6, atol=1e-8)
     lam, lr = mhe._nlp_solution['lam_g'].cpu().numpy(), ref['lam']
     assert np.max(np.abs(lam - lr) / np.maximum(1., np.abs(lr))) < 1e-5
+
+
+def param_est_case(method, noise):
+    """Oracle side of test_parameter_estimation_on_an_expression_model (minutes of sympy for the discretised model: kept as a
+    fixture under tests/golden/, made by tests/golden/make_mhe_gen_fixtures.py from THIS function)."""
+    N, B = 8, 4
+    spec = dict(C3B, N=N)
+    xa, um, ym, _ = c3_data(B, N=N)
+    degree = 3 if method == 'collocation' else 0
+    pb, ipm = _oracle(spec, degree, noise, est_idx=[2], Wp=[1e-2], p_lb=[.2], p_ub=[2.], p_guess=[.7])
+    ref = ipm.solve(xa, [.7], [100., 4., 0.], um, ym)
+    y_new = ym[:, -1] * 1.001
+    um2, ym2 = np.concatenate([um[:, 1:], um[:, -1:]], axis=1), np.concatenate([ym[:, 1:], y_new[:, None]], axis=1)
+    ref2 = ipm.solve(ref['X'][:, 2] * pb.sx, ref['P'], [100., 4., 0.], um2, ym2, w0=ref['w'])
+    keep = ('status', 'v', 'f', 'x_opt', 'lam', 'p_opt')
+    return dict(pb=_pb_data(pb), ref={k: np.asarray(ref[k]) for k in keep}, ref2={k: np.asarray(ref2[k]) for k in ('status', 'x_opt', 'p_opt')})
+
+
+def hard_con_case(method, noise):
+    """Oracle side of test_hard_stage_constraint_vs_oracle."""
+    N, B = 5, 4
+    spec = dict(C3B, N=N)
+    xa, um, ym, _ = c3_data(B, N=N)
+    degree = 3 if method == 'collocation' else 0
+    _, free = _oracle(spec, degree, noise)
+    sol_free = free.solve(xa, [], P_TRUE, um, ym)
+    x_free = sol_free['X']
+    ub = float(np.round(x_free[:, :N, 0].max(axis=1).min() * .97, 4))                    # active in every instance, at a node k < N
+    cons = dict(expr=['X', 'P + 2*I*X'], lb=[-np.inf, 0.], ub=[ub, np.inf])
+    pb, ipm = _oracle(spec, degree, noise, constraint=cons)
+    ref = ipm.solve(xa, [], P_TRUE, um, ym)
+    ref['lam'] = ipm.lam_g(ref)
+    top = ref['X'][:, :N, 0].max(axis=1) if not degree else np.maximum(ref['X'][:, :N, 0].max(axis=1), ref['Xc'][..., 0].max(axis=(1, 2)))
+    assert np.all(top > ub - 1e-7) and np.all(top < ub + 1e-7) and np.all(ref['f'] > sol_free['f'] * 1.1)
+    return dict(pb=_pb_data(pb), ub=ub, ref={k: np.asarray(ref[k]) for k in ('status', 'v', 'f', 'x_opt', 'lam')})
 
 
 EST = dict(p_lb=[100., 4., .2, 0.], p_ub=[100., 4., 2., 0.], Wp=np.diag([0., 0., 1e-2, 0.]), p_guess=[100., 4., .7, 0.])
@@ -73,25 +121,22 @@ def test_parameter_estimation_on_an_expression_model(method, noise):
     N, B = 8, 4
     spec = dict(C3B, N=N)
     xa, um, ym, _ = c3_data(B, N=N)
-    degree = 3 if method == 'collocation' else 0
-    pb, ipm = _oracle(spec, degree, noise, est_idx=[2], Wp=[1e-2], p_lb=[.2], p_ub=[2.], p_guess=[.7])
-    ref = ipm.solve(xa, [.7], [100., 4., 0.], um, ym)
+    y_new = ym[:, -1] * 1.001
+    R = golden_or_compute(f'mhe_gen_param_est_{method}_{int(noise)}', lambda: param_est_case(method, noise))
+    ref, ref2 = R['ref'], R['ref2']
     mhe = _product(spec, {'integration_method': method}, est=EST, noise=noise)
     assert mhe._estimating and mhe.has_state_noise == noise
     for k in range(N):
         mhe.add_measurements(ym[:, k], um[:, k])
     x_opt, p_opt = mhe.estimate(x_arrival=xa, p_arrival=[100., 4., .7, 0.])
-    _compare(mhe, pb, ref, x_opt, p_opt, B)
+    _compare(mhe, R['pb'], ref, x_opt, p_opt, B)
     np.testing.assert_allclose(p_opt.cpu().numpy()[:, 2], ref['p_opt'][:, 0], rtol=1e-6)
     np.testing.assert_allclose(p_opt.cpu().numpy()[:, [0, 1, 3]], np.tile([100., 4., 0.], (B, 1)), rtol=0, atol=0)
     assert np.all(np.abs(ref['p_opt'][:, 0] - 1.) < .3)                                # the estimate moved from 0.7 towards the truth
     if not noise:
         assert mhe.return_mhe_estimation()[1] is None
     # next sample: window shifts, arrival values from the previous solution (smoothing, mhe.py:254-256), warm start
-    y_new = ym[:, -1] * 1.001
     mhe.add_measurements(y_new, um[:, -1])
-    um2, ym2 = np.concatenate([um[:, 1:], um[:, -1:]], axis=1), np.concatenate([ym[:, 1:], y_new[:, None]], axis=1)
-    ref2 = ipm.solve(ref['X'][:, 2] * pb.sx, ref['P'], [100., 4., 0.], um2, ym2, w0=ref['w'])
     x2, p2 = mhe.estimate()
     assert np.array_equal(mhe.solver_status_code, ref2['status'])
     np.testing.assert_allclose(x2.cpu().numpy(), ref2['x_opt'], rtol=1e-5, atol=1e-7)
@@ -169,15 +214,8 @@ def test_hard_stage_constraint_vs_oracle(method, noise):
     spec = dict(C3B, N=N)
     xa, um, ym, _ = c3_data(B, N=N)
     degree = 3 if method == 'collocation' else 0
-    _, free = _oracle(spec, degree, noise)
-    x_free = free.solve(xa, [], P_TRUE, um, ym)['X']
-    ub = float(np.round(x_free[:, :N, 0].max(axis=1).min() * .97, 4))                    # active in every instance, at a node k < N
-    cons = dict(expr=['X', 'P + 2*I*X'], lb=[-np.inf, 0.], ub=[ub, np.inf])
-    pb, ipm = _oracle(spec, degree, noise, constraint=cons)
-    ref = ipm.solve(xa, [], P_TRUE, um, ym)
-    ref['lam'] = ipm.lam_g(ref)
-    top = ref['X'][:, :N, 0].max(axis=1) if not degree else np.maximum(ref['X'][:, :N, 0].max(axis=1), ref['Xc'][..., 0].max(axis=(1, 2)))
-    assert np.all(top > ub - 1e-7) and np.all(top < ub + 1e-7) and np.all(ref['f'] > free.solve(xa, [], P_TRUE, um, ym)['f'] * 1.1)
+    R = golden_or_compute(f'mhe_gen_hard_con_{method}_{int(noise)}', lambda: hard_con_case(method, noise))
+    ref, ub = R['ref'], float(R['ub'])
     from hilo_mpc_amd import MHE
     m = symbolic_model('chemostat4')
     if method == 'discrete':
@@ -202,7 +240,7 @@ def test_hard_stage_constraint_vs_oracle(method, noise):
     x_opt, p_opt = mhe.estimate(x_arrival=xa)
     # (collocation with noise: one noise variable sits at its bound 1e-3 with a vanishing multiplier - no strict complementarity,
     # its distance from the bound goes with sqrt(mu) and differs by 3e-6 between two runs that stop one iteration apart)
-    _compare(mhe, pb, ref, x_opt, p_opt, B, vtol=1e-5 if (degree and noise) else 1e-6)
+    _compare(mhe, R['pb'], ref, x_opt, p_opt, B, vtol=1e-5 if (degree and noise) else 1e-6)
     lam = mhe._nlp_solution['lam_g'].cpu().numpy().reshape(B, N, -1)
     d, nx = degree, 4
     rows = np.concatenate([lam[:, :, :2 * d], lam[:, :, 2 * d + d * nx + nx:]], axis=2)
