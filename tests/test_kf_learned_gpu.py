@@ -123,3 +123,35 @@ def test_two_filters_on_different_learned_terms_and_several_steps_per_launch():
     f.estimate(y=ys, u=u, p=p, steps=K)
     np.testing.assert_allclose(np.asarray(f.x.cpu()), x_single, rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(np.asarray(f.P.cpu()), P_single, rtol=1e-11, atol=1e-14)
+
+
+def test_particle_filter_function_and_model_step_with_a_learned_term():
+    """The same handle serves the particle filter's function (pf.py:300-318: propagate, measure, weigh) and `Model.step`
+    (dynamic_model.py:3911-4000): both against the numeric oracle model."""
+    from hilo_mpc_amd import PF
+    from oracle import pf as opf
+    X, yt = c4_training_data()
+    om = _oracle_model(X, yt).discretize(4)
+    m, gp = _hybrid_model()
+    m = m.discretize('erk', order=4).setup(dt=.5)
+    x0, u, p = np.array([.1, 30., .5, .4]), np.array([.1, .2]), np.array([100., 4., 1., 0.])
+    pf = PF(m)
+    pf.setup(n_samples=300)
+    rng = np.random.default_rng(9)
+    B, N = 2, 300
+    Xs = x0 * (1 + .1 * rng.standard_normal((B, N, 4)))
+    w = .01 * np.abs(x0) * rng.standard_normal((B, N, 4))
+    R = np.diag([2e-4, 1e-4])
+    v = rng.standard_normal((B, N, 2)) @ np.sqrt(R)
+    y = om.h(om.f(x0[None], u[None], p[None], .5), u[None], p[None], .5)[0] * (1 + .02 * rng.standard_normal((B, 2)))
+    Xp, Y, q = pf.function(Xs, y, np.concatenate([u, p])[None], w, v, R=R)
+    for b in range(B):
+        Xr, Yr, qr = opf.pf_function(om, .5, Xs[b], y[b], u, p, w[b], v[b], R)
+        np.testing.assert_allclose(Xp[b].cpu().numpy(), Xr, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(Y[b].cpu().numpy(), Yr, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(q[b].cpu().numpy(), qr, rtol=1e-6, atol=1e-300)
+    xb = x0 * (1 + .2 * rng.uniform(-1, 1, (50, 4)))
+    ub = np.tile(u, (50, 1))
+    out = m.step(xb, u=ub, p=np.tile(p, (50, 1)))
+    xn = out[0] if isinstance(out, tuple) else out
+    np.testing.assert_allclose(np.asarray(xn.cpu() if hasattr(xn, 'cpu') else xn), om.f(xb, ub, p[None], .5), rtol=1e-10, atol=1e-12)
