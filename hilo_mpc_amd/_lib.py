@@ -101,6 +101,7 @@ def _declare(lib):
         'hilo_nmpc_set_fix_x0': (C.c_int, [vp, i32]),
         'hilo_nmpc_set_x0_box': (C.c_int, [vp, vp, vp]),
         'hilo_nmpc_set_gather': (C.c_int, [vp, vp, i32]),
+        'hilo_nmpc_set_plant_out': (C.c_int, [vp, vp]),
         'hilo_nmpc_set_var_bounds': (C.c_int, [vp, vp, vp]),
         'hilo_kf_steps': (C.c_int, [vp, i64, i32, vp, vp, vp, i64, i64, vp, i64, vp, i64, vp, i32, vp, vp]),
         'hilo_nmpc_solve': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -536,6 +536,15 @@ extern "C" int hilo_nmpc_set_gather(hilo_nmpc* h, double* table, int stride) {
   return HILO_OK;
 }
 
+extern "C" int hilo_nmpc_set_plant_out(hilo_nmpc* h, double* x_next) {
+  HILO_REQUIRE(h, "hilo_nmpc_set_plant_out: NULL handle");
+  if (x_next && !(nmpc_is_direct(h) && h->model_id != HILO_MODEL_CHEMOSTAT4_GP && (h->jit_policy < 0 || h->jit_policy == JIT_TRACK)))
+    return fail(HILO_ENOTSUP, "hilo_nmpc_set_plant_out: this problem kind does not advance the plant in its solve; call "
+                              "hilo_nmpc_plant_step");
+  h->plant_out = x_next;
+  return HILO_OK;
+}
+
 extern "C" int hilo_nmpc_reset_warm_start(hilo_nmpc* h) {
   HILO_REQUIRE(h, "hilo_nmpc_reset_warm_start: NULL handle");
   h->warm_valid = 0;
@@ -628,6 +637,7 @@ static int nmpc_solve_impl(hilo_nmpc* h, int64_t batch, const double* x0, const 
     ex.v_copy = h->v_warm;
     ex.gather = h->gather;
     ex.gather_stride = h->gather_stride;
+    ex.x_next = h->plant_out;
   }
   if (h->jit_coll_d == 0 && !h->coll) {   // layouts the engine writes itself (no collocation output pass)
     ex.lam_x = h->aux_lam_x;

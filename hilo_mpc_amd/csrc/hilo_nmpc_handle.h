@@ -42,6 +42,7 @@ struct hilo_nmpc {
   double* user_gp_pack[4];   // packed learned terms of a run-time compiled model (gp_pack_se) or NULL
   double* aux_g;             // caller's buffers for the constraint values / bound multipliers of the next solves, or NULL
   double* aux_lam_x;
+  double* plant_out;         // caller's buffer for the fused plant step (hilo_nmpc_set_plant_out) or NULL
   double* gather;            // caller's gather table (hilo_nmpc_set_gather) or NULL
   int gather_stride;
   const double *var_lb, *var_ub;   // per-call lbx / ubx rows [B][n_v] of the next solves (hilo_nmpc_set_var_bounds) or NULL

@@ -39,6 +39,24 @@ struct NmpcTrack {
     for (int i = 0; i < NX; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]);
   }
 
+  // x+ = Phi(x, u, p) on UN-scaled quantities: the closed-loop helper plant_step_kernel (hilo_nmpc.hip) as a function - the solve
+  // kernel advances the plant itself when the caller asks for it (OcpExtra::x_next)
+  static constexpr bool PLANT = !COOP;
+  __device__ __forceinline__ static void plant(const OcpConst& pc, const double* par, const double* x, const double* u, double* xn) {
+    if constexpr (PLANT) {
+      double xv[NX], uv[NU > 0 ? NU : 1], pv[M::NP > 0 ? M::NP : 1], xo[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xv[i] = x[i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) uv[i] = u[i];
+#pragma unroll
+      for (int i = 0; i < M::NP; ++i) pv[i] = par[i];
+      model_step<M>(pc.order, pc.nsub, xv, uv, pv, pc.dt, xo);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xn[i] = xo[i];
+    }
+  }
+
   template <class T>
   __device__ __forceinline__ static T stage_cost(const OcpConst& pc, const double* par, const double*, int k,
                                                  const T* x, const T* u) {

@@ -229,6 +229,8 @@ template <class MS> struct sym_masks<MS, void_tt<decltype(MS::HAS_MASKS)>> {
   static constexpr unsigned long long X = MS::HAS_MASKS ? MS::XMASK : ~0ull, J = MS::HAS_MASKS ? MS::JMASK : ~0ull,
                                       H = MS::HAS_MASKS ? MS::HMASK : ~0ull;
 };
+template <class PB, class = void> struct pb_plant { static constexpr bool value = false; };
+template <class PB> struct pb_plant<PB, void_tt<decltype(PB::PLANT)>> { static constexpr bool value = PB::PLANT; };
 template <class PB, class = void> struct pb_symtab { static constexpr bool value = false; };
 template <class PB> struct pb_symtab<PB, void_tt<decltype(PB::SYMTAB)>> { static constexpr bool value = PB::SYMTAB; };
 template <class PB, class = void> struct pb_nh { static constexpr int value = 0; };
@@ -296,6 +298,9 @@ struct OcpExtra {
   const double* lbx;
   const double* ubx;
   long long bx_stride;
+  // closed loops whose plant IS the controller's model (benchmarks, simulations): row b receives x+ = Phi(x0_b, u_0, p_b), the map
+  // of plant_step_kernel on the input just computed - the plant step fused into the solve (policies with PB::PLANT); may alias x0
+  double* x_next;
 };
 
 #ifdef HILO_OCP_DPROF
@@ -3628,6 +3633,16 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
     double* gr = ex.gather + b * (int64_t)ex.gather_stride;
     OCP_FOR(a, S::NU0) gr[a] = l.Z[NX + a] * pc.sz[NX + a];
     if (t == 0) { gr[S::NU0] = (double)st; gr[S::NU0 + 1] = (double)it; }
+  }
+  if constexpr (pb_plant<PB>::value) {
+    if (ex.x_next && t == 0) {   // (one lane: four right-hand sides, under a microsecond - a launch and its gap cost ten)
+      double xs[S::NX0], us[S::NU0 > 0 ? S::NU0 : 1];
+#pragma unroll
+      for (int i = 0; i < S::NX0; ++i) xs[i] = x0[b * S::NX0 + i];
+#pragma unroll
+      for (int a = 0; a < S::NU0; ++a) us[a] = l.Z[NX + a] * pc.sz[NX + a];
+      PB::plant(pc, (const double*)l.par, xs, us, ex.x_next + b * S::NX0);
+    }
   }
   if (t == 0) {
     f_opt[b] = fval;

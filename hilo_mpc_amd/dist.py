@@ -69,7 +69,38 @@ class StepGather:
                 full = self.recv
             else:
                 full = torch.cat([self.recv[r * self.max_n: r * self.max_n + self.sizes[r]] for r in range(self.world)], dim=0)
-        return full[:, :self.nu], full[:, self.nu].to(torch.int32), full[:, self.nu + 1].to(torch.int32)
+        return Gathered(full, self.nu)
+
+
+class Gathered:
+    """(u0 [B, nu], status [B] int32, iters [B] int32) of all shards - unpacks like the tuple it stands for.  The two integer
+    columns are converted from the wire's fp64 when they are LOOKED AT: a loop that only advances (bench.py, a deployment that
+    logs every n-th step) does not pay two conversion launches per step for values nobody reads.  The views alias the gather
+    buffer: they are valid until the next step."""
+
+    def __init__(self, full, nu):
+        self._full, self._nu = full, nu
+
+    @property
+    def u0(self):
+        return self._full[:, :self._nu]
+
+    @property
+    def status(self):
+        return self._full[:, self._nu].to(torch.int32)
+
+    @property
+    def iters(self):
+        return self._full[:, self._nu + 1].to(torch.int32)
+
+    def __iter__(self):
+        return iter((self.u0, self.status, self.iters))
+
+    def __len__(self):
+        return 3
+
+    def __getitem__(self, i):
+        return (self.u0, self.status, self.iters)[i]
 
 
 class ClosedLoop:
@@ -86,6 +117,12 @@ class ClosedLoop:
             self.gather.attach(controller)
         self.x = x0
         self.last = None
+        # the plant is the controller's own model: where the solve kernel offers it, it advances the plant itself (in place: x0 of
+        # the next step is what this step's launch wrote) - one launch per step
+        self.fused_plant = False
+        if attach and hasattr(controller, 'set_plant_buffer') and isinstance(x0, torch.Tensor) and x0.is_cuda:
+            self.x = x0.detach().clone().contiguous()            # the loop's own state buffer (the caller's x0 stays as it is)
+            self.fused_plant = bool(controller.set_plant_buffer(self.x))
 
     def step(self, before=None, after=None):
         """One step; `before` / `after` bracket the solve (bench.py records its HIP events there).  Returns the gathered
@@ -97,5 +134,15 @@ class ClosedLoop:
             after()
         sol = self.ctl._nlp_solution
         self.last = self.gather(u, sol['status'], sol['iter_count'])
-        self.x = self.ctl.plant_step(self.x, u, cp=self.p)
+        if not self.fused_plant:
+            self.x = self.ctl.plant_step(self.x, u, cp=self.p)
         return self.last
+
+    def detach(self):
+        """Give the controller back (its solve stops writing into this loop's buffers)."""
+        if self.fused_plant:
+            self.ctl.set_plant_buffer(None)
+            self.fused_plant = False
+        if getattr(self.gather, 'attached', False):
+            self.ctl.set_gather_buffer(None)
+            self.gather.attached = False

@@ -1629,6 +1629,26 @@ class NMPC:
         self._gather_table = table
         return True
 
+    def set_plant_buffer(self, x_next):
+        """Closed loops whose plant is the controller's own model: every solve writes x+ = Phi(x0, u_0, p) of its instances into
+        `x_next` ([B, n_x], contiguous, device; may be the x0 tensor of the call itself) - the plant step of `plant_step` fused
+        into the solve's launch (hilo_nmpc_set_plant_out).  None switches it off.  Returns False for problem kinds whose kernel
+        does not offer it (the caller then calls `plant_step`)."""
+        if x_next is None:
+            _lib.check(_lib.lib().hilo_nmpc_set_plant_out(self._handle, None))
+            self._plant_table = None
+            return False
+        if not (x_next.is_contiguous() and x_next.dtype == torch.float64 and x_next.shape[-1] == self._n_x):
+            return False
+        try:
+            _lib.check(_lib.lib().hilo_nmpc_set_plant_out(self._handle, ptr(x_next)))
+        except _lib.HiloError as err:
+            if err.code != -4:
+                raise
+            return False
+        self._plant_table = x_next
+        return True
+
     def plant_step(self, x, u, cp=None):
         """Closed-loop helper: x+ = Phi(x, u, p) with the controller's shooting map, on the device."""
         x = to_dev(x, self._dev).reshape(-1, self._n_x).contiguous()

@@ -402,6 +402,11 @@ int hilo_nmpc_set_aux_outputs(hilo_nmpc* h, double* g, double* lam_x);
    (fp64) of the device table [batch][stride] itself - the send buffer of the per-step result gather.  NULL switches it off.
    Honoured by plain tracking problems; the reference has no counterpart (single instance, no batching). */
 int hilo_nmpc_set_gather(hilo_nmpc* h, double* table, int stride);
+/* Closed loops whose plant is the controller's own model (benchmarks, simulations; hilo_nmpc_plant_step): the solve advances the
+   plant itself - row b of x_next [B][nx] receives Phi(x0_b, u_0, p_b) for the input it has just computed (one launch per step
+   instead of two).  x_next may be the x0 buffer of the call (in-place closed loop); NULL switches it off.  HILO_ENOTSUP for problem
+   kinds whose kernel does not offer it (general / run-time compiled policies, the hybrid model, long horizons). */
+int hilo_nmpc_set_plant_out(hilo_nmpc* h, double* x_next);
 /* lbx / ubx of the reference's solver call, `self._solver(x0=v0, lbx=self._v_lb, ubx=self._v_ub, ...)` (mpc.py:722): DEVICE rows
    [batch][n_v] in the layout of v (scaled variables, original bound values: IPOPT's bound_relax_factor is applied by the solve),
    read by every following hilo_nmpc_solve; NULL, NULL = back to the bounds of the description.  Per instance and per call, so that
