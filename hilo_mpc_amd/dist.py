@@ -120,7 +120,7 @@ class ClosedLoop:
         # the plant is the controller's own model: where the solve kernel offers it, it advances the plant itself (in place: x0 of
         # the next step is what this step's launch wrote) - one launch per step
         self.fused_plant = False
-        if attach and hasattr(controller, 'set_plant_buffer') and isinstance(x0, torch.Tensor) and x0.is_cuda:
+        if attach and hasattr(controller, 'set_plant_buffer') and isinstance(x0, torch.Tensor):
             self.x = x0.detach().clone().contiguous()            # the loop's own state buffer (the caller's x0 stays as it is)
             self.fused_plant = bool(controller.set_plant_buffer(self.x))
 

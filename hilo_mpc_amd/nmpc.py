@@ -1638,7 +1638,8 @@ class NMPC:
             _lib.check(_lib.lib().hilo_nmpc_set_plant_out(self._handle, None))
             self._plant_table = None
             return False
-        if not (x_next.is_contiguous() and x_next.dtype == torch.float64 and x_next.shape[-1] == self._n_x):
+        if not (x_next.is_cuda and x_next.device == self._dev and x_next.is_contiguous() and x_next.dtype == torch.float64 and
+                x_next.shape[-1] == self._n_x):
             return False
         try:
             _lib.check(_lib.lib().hilo_nmpc_set_plant_out(self._handle, ptr(x_next)))

@@ -59,10 +59,19 @@ class _StubController:
     the state so that a row that ends up at the wrong place of the gathered table is seen.  `kernel_rows=True`: like the solve
     kernel after hilo_nmpc_set_gather, optimize() writes its rows [u0 | status | iters] into the attached table itself."""
 
-    def __init__(self, nx, nu, kernel_rows):
-        self.nx, self.nu, self.kernel_rows = nx, nu, kernel_rows
+    def __init__(self, nx, nu, kernel_rows, fused_plant=False):
+        self.nx, self.nu, self.kernel_rows, self.fused_plant = nx, nu, kernel_rows, fused_plant
         self.table = None
+        self.x_next = None
+        self.plant_calls = 0
         self._nlp_solution = None
+
+    def set_plant_buffer(self, x_next):                       # like NMPC.set_plant_buffer: optimize() advances the plant itself
+        if x_next is None or not self.fused_plant:
+            self.x_next = None
+            return False
+        self.x_next = x_next
+        return True
 
     def set_gather_buffer(self, table):
         if not self.kernel_rows:
@@ -80,9 +89,14 @@ class _StubController:
             self.table[:n, :self.nu] = u
             self.table[:n, self.nu] = st.to(torch.float64)
             self.table[:n, self.nu + 1] = it.to(torch.float64)
+        if self.x_next is not None:                           # in place, like the solve kernel (x_next aliases x)
+            xn = 0.9 * x
+            xn[:, :self.nu] += u
+            self.x_next.copy_(xn)
         return u
 
     def plant_step(self, x, u, cp=None):
+        self.plant_calls += 1
         xn = 0.9 * x
         xn[:, :self.nu] += u
         return xn
@@ -137,3 +151,26 @@ def test_closed_loop_step_world2_gloo_uneven_shards():
             np.testing.assert_allclose(u, ur, rtol=0, atol=0)
             np.testing.assert_array_equal(st, sr)
             np.testing.assert_array_equal(it, ir)
+
+
+def test_closed_loop_with_the_plant_advanced_by_the_solve():
+    """A controller that offers `set_plant_buffer` (NMPC on plain tracking problems: hilo_nmpc_set_plant_out) advances the loop's state
+    in its optimize(): no plant_step call, the caller's x0 untouched, same trajectory as the loop with a separate plant step; the
+    gathered status / iteration columns are int32 when they are read."""
+    from hilo_mpc_amd.dist import ClosedLoop, Gathered
+    B, nx, nu = 9, 3, 2
+    x0 = torch.as_tensor(np.random.default_rng(1).uniform(-2, 2, (B, nx)))
+    keep = x0.clone()
+    cf, cp = _StubController(nx, nu, True, fused_plant=True), _StubController(nx, nu, False)
+    fused = ClosedLoop(cf, B, nu, 0, 1, torch.device('cpu'), x0, p=torch.tensor([.25]))
+    plain = ClosedLoop(cp, B, nu, 0, 1, torch.device('cpu'), x0.clone(), p=torch.tensor([.25]))
+    assert fused.fused_plant and not plain.fused_plant
+    for _ in range(4):
+        a, b = fused.step(), plain.step()
+        assert isinstance(a, Gathered) and a.status.dtype == torch.int32 and a.iters.dtype == torch.int32
+        for va, vb in zip(a, b):
+            assert torch.equal(va, vb)
+        assert torch.equal(fused.x, plain.x)
+    assert cf.plant_calls == 0 and cp.plant_calls == 4 and torch.equal(x0, keep)
+    fused.detach()
+    assert cf.x_next is None and cf.table is None and not fused.fused_plant        # the controller is its own again
