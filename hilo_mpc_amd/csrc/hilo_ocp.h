@@ -1801,10 +1801,13 @@ struct Ocp {
   // switching condition of the filter line search (W&B eq. 19):  alpha (-dphi)^s_phi > delta_ls th0^s_theta  with nd = -dphi > 0.
   // Two f64 pow() are 540 instructions on one dependent chain per trial point; decided here in the logarithm with the hardware's
   // f32 log2 of the mantissas (error of the difference < 2e-6 in units of log2) whenever the two sides are further apart than
-  // 2^(1e-4) - otherwise (and for zero / non-finite arguments) by the pow() expression itself: the same decision in every case.
+  // 2^(1e-4) - otherwise (and for zero / non-finite / extreme arguments) by the pow() expression itself: the same decision in every
+  // case (tests/test_switching_rule.py restates the rule in numpy and compares the decisions).
   __device__ __forceinline__ static bool switching(const OcpConst& pc, double alpha, double nd, double th0) {
     const double dls = pc.delta_ls;
-    const bool plain = alpha > 0.0 && nd > 0.0 && th0 > 0.0 && dls > 0.0 && alpha < INFINITY && nd < INFINITY && th0 < INFINITY;
+    // (inside these ranges neither power nor the products can overflow or underflow - outside them the pow() expression has a
+    // semantics of its own, inf > inf or 0 > 0, which only the expression itself reproduces)
+    const bool plain = alpha > 1e-30 && alpha < 1e30 && nd > 1e-100 && nd < 1e100 && th0 > 1e-100 && th0 < 1e100 && dls > 1e-30 && dls < 1e30;
     if (plain) {
       auto lg2 = [](double x) {
         return (double)__builtin_amdgcn_frexp_exp(x) + (double)__builtin_amdgcn_logf((float)__builtin_amdgcn_frexp_mant(x));
