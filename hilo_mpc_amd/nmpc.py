@@ -1652,6 +1652,9 @@ class NMPC:
 
     def plant_step(self, x, u, cp=None):
         """Closed-loop helper: x+ = Phi(x, u, p) with the controller's shooting map, on the device."""
+        if getattr(self, '_mt', None) is not None:
+            # (the inner problem's map advances by ITS sampling interval, a state of that problem: not the plant's clock)
+            raise NotImplementedError("plant_step of a minimum-time controller: simulate the plant with Model.step / Model.simulate")
         x = to_dev(x, self._dev).reshape(-1, self._n_x).contiguous()
         u = to_dev(u, self._dev).reshape(-1, self._n_u).contiguous()
         B = x.shape[0]
