@@ -23,5 +23,8 @@ python bench.py --config C3-ekf --batch 1048576 --no-cpu-baseline > gpurun_out/b
 python bench.py --config C3-ukf --batch 1048576 --no-cpu-baseline > gpurun_out/bench_$TAG/C3-ukf_B1M.json 2>/dev/null
 python tools/phase_profile.py 4 > gpurun_out/bench_$TAG/phase_cycles.txt 2>&1 || true
 python tools/phase_profile.py 3 C4 >> gpurun_out/bench_$TAG/phase_cycles.txt 2>&1 || true
+# sub-phase clocks: needs the developer variant of the library, built here (no GPU needed) with
+#   python -c "from hilo_mpc_amd import _build; _build.build(tag='dprof', extra_flags=['-DHILO_OCP_DPROF'])"
+# and removed again after the evidence run (it is not part of the product)
 [ -f hilo_mpc_amd/libhilo_hip_dprof.so ] && HILO_LIB_PATH=$PWD/hilo_mpc_amd/libhilo_hip_dprof.so python tools/dbg/dprof.py >> gpurun_out/bench_$TAG/phase_cycles.txt 2>&1
 ls gpurun_out/prof_$TAG gpurun_out/bench_$TAG
