@@ -30,6 +30,16 @@ class _VLeaf(Expr):
         super().__init__('v', value=int(i), name=f'v[{i}]')
 
 
+def _key(e):
+    """Structural fingerprint of an expression: operator, the operator's own value (the exponent of an integer power, the index of a
+    learned term, ...) and the operands - `repr` leaves the value out, x**3 and x**4 would print alike."""
+    if e.op == 'const':
+        return repr(float(e.value))
+    if not e.args:
+        return f"{e.op}:{getattr(e, 'name', '')}:{e.value!r}"
+    return f"{e.op}[{e.value!r}](" + ','.join(_key(a) for a in e.args) + ')'
+
+
 def _terms(e):
     """[(coefficient, factor or None)] with e = sum coefficient * factor (None: the constant 1)."""
     e = Expr.wrap(e)
@@ -44,15 +54,17 @@ def _terms(e):
         return [(-c, f) for c, f in _terms(e.args[0])]
     if op in ('mul', 'div'):
         ta, tb = _terms(e.args[0]), _terms(e.args[1])
-        ca = sum(c for c, f in ta) if all(f is None for c, f in ta) else None
-        cb = sum(c for c, f in tb) if all(f is None for c, f in tb) else None
-        if op == 'mul':
-            if ca is not None:
-                return [(ca * c, f) for c, f in tb]
-            if cb is not None:
-                return [(cb * c, f) for c, f in ta]
-        elif cb is not None:
-            return [(c / cb, f) for c, f in ta]
+
+        def times(fa, fb):                      # product of two factors (None: the constant 1)
+            return fb if fa is None else (fa if fb is None else fa * fb)
+        if op == 'mul' and len(ta) * len(tb) <= 64:
+            # distributed: (2 x_k) u_k and x_k u_k are the SAME stage expression with different coefficients
+            return [(ca * cb, times(fa, fb)) for ca, fa in ta for cb, fb in tb]
+        if op == 'div' and len(tb) == 1:
+            cb, fb = tb[0]
+            if fb is None:
+                return [(c / cb, f) for c, f in ta]
+            return [(c / cb, (Expr.wrap(1.0) if f is None else f) / fb) for c, f in ta]
     return [(1.0, e)]
 
 
@@ -110,7 +122,7 @@ def decompose(fun, x_ind, u_ind, n_v, model, n_rows=None):
                 kind, _, i = where[int(n.value)]
                 return model.x[i] if kind == 'x' else model.u[i]
             g = Expr.substitute([f], leaf)[0]
-            key = repr(g)
+            key = _key(g)
             if key not in keys:
                 if len(psi) == MAX_PSI:
                     raise NotImplementedError(f"the custom constraint needs more than {MAX_PSI} distinct stage expressions")

@@ -358,3 +358,32 @@ def test_custom_constraint_decomposition_into_stage_terms():
         decompose(lambda v, xi, ui: v[xi[0][0]] * v[xi[1][0]], x_ind, u_ind, n_v, m)
     with pytest.raises(NotImplementedError, match="neither a state nor an input"):
         decompose(lambda v, xi, ui: v[n_v + 1] + v[0], x_ind, u_ind, n_v + 3, m)
+
+
+def test_custom_constraint_functions_that_do_not_fit_the_stage_structure_are_refused_with_the_reason():
+    """hilo_mpc_amd/custom.py::decompose: what is offloaded is a sum over the stages of single-stage terms - anything else says why."""
+    import pytest
+    from hilo_mpc_amd.custom import MAX_PSI, MAX_ROWS, decompose
+    from tests.problems import symbolic_model
+    m = symbolic_model('chemostat4')
+    N, nx, nu = 4, 4, 2
+    x_ind = [list(range(k * nx, (k + 1) * nx)) for k in range(N + 1)]
+    u_ind = [list(range((N + 1) * nx + k * nu, (N + 1) * nx + (k + 1) * nu)) for k in range(N)]
+    n_v = (N + 1) * nx + N * nu + 1                                       # one trailing entry that is no node variable (a slack)
+    psi, coef, const = decompose(lambda v, xi, ui: sum(v[xi[k][2]] for k in range(N + 1)) + 3., x_ind, u_ind, n_v, m)
+    assert len(psi) == 1 and coef.shape == (1, N + 1, 1) and np.all(coef == 1.) and const[0] == 3.
+    with pytest.raises(NotImplementedError, match='DIFFERENT stages'):
+        decompose(lambda v, xi, ui: v[xi[0][0]] * v[xi[1][0]], x_ind, u_ind, n_v, m)
+    with pytest.raises(NotImplementedError, match='neither a state nor an input'):
+        decompose(lambda v, xi, ui: v[n_v - 1] + v[xi[1][0]], x_ind, u_ind, n_v, m)
+    with pytest.raises(NotImplementedError, match='distinct stage expressions'):
+        decompose(lambda v, xi, ui: sum(v[xi[1][0]] ** (j + 2) for j in range(MAX_PSI + 1)), x_ind, u_ind, n_v, m)
+    with pytest.raises(NotImplementedError, match='custom constraint rows'):
+        decompose(lambda v, xi, ui: [v[xi[1][0]]] * (MAX_ROWS + 1), x_ind, u_ind, n_v, m)
+    with pytest.raises(ValueError, match='bound'):
+        decompose(lambda v, xi, ui: [v[xi[1][0]], v[xi[2][0]]], x_ind, u_ind, n_v, m, n_rows=1)
+    with pytest.raises(NotImplementedError, match='decision vector v only'):
+        decompose(lambda v, xi, ui: v[xi[1][0]] + m.x[0], x_ind, u_ind, n_v, m)
+    # the same stage expression with different factors is ONE psi; products inside a stage are fine
+    psi, coef, _ = decompose(lambda v, xi, ui: sum((k + 1.) * v[xi[k][0]] * v[ui[k][1]] for k in range(N)), x_ind, u_ind, n_v, m)
+    assert len(psi) == 1 and np.allclose(coef[0, :N, 0], np.arange(1., N + 1)) and coef[0, N, 0] == 0.
