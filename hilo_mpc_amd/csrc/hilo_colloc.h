@@ -25,6 +25,89 @@ struct CollData {  // host-computed basis (hilo_mpc_amd/nmpc.py restates modelin
   double Bq[COLL_MAXD + 1];          // quadrature weights B_0..B_d = int_0^1 L_i (continuous objective, modeling.py:1195)
 };
 
+// ---- the Newton matrix of an interval factored by the lanes of a wave TOGETHER -----------------------------------------------
+// One COLUMN of the augmented matrix [Mat | right-hand sides] per lane, all of it in registers (DN doubles): lane c < DN of a
+// group owns column c of Mat, the lanes behind them one right-hand side each.  A pivot step sends the pivot column's multipliers
+// to every lane of the group (two ds_bpermute_b32 per double) and each lane updates its own column - no lane ever holds the
+// matrix, nothing goes through memory.  (A private DN x DN matrix per lane is 3.5 KB for configuration 5's 21 x 21 systems:
+// 8.8 KB of scratch per lane and 2.9 TB of traffic per launch, profiles/r05_C5-dae_summary.json.)  No pivoting: the Runge-Kutta
+// form of the collocation equations (see below) keeps the matrix within O(dt) of the identity.
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+template <int DN>
+struct CoopLU {
+  // c: this lane's column within its group (>= DN: a right-hand side), gbase: first lane of the group.  Afterwards a matrix lane
+  // holds its column of U on and above the diagonal (the diagonal as its RECIPROCAL) and the multipliers of L below it; a
+  // right-hand-side lane holds L^-1 b.
+  // KEEP_L = false (the factors only serve the right-hand sides of this call): nothing below the diagonal is kept, so every lane
+  // applies every update to its column unconditionally - a matrix lane's entries below its diagonal are never read again
+  template <bool KEEP_L = true>
+  __device__ __forceinline__ static void eliminate(double* col, int c, int gbase) {
+#pragma unroll
+    for (int k = 0; k < DN; ++k) {
+      const double ip = rcp_fast(col[k]);
+      double l[DN > 1 ? DN : 1];
+#pragma unroll
+      for (int i = k + 1; i < DN; ++i) l[i] = lane_bcast(col[i] * ip, gbase + k);
+      if constexpr (KEEP_L) {
+        if (c > k) {
+#pragma unroll
+          for (int i = k + 1; i < DN; ++i) col[i] = fma(-l[i], col[k], col[i]);
+        } else if (c == k) {
+          col[k] = ip;
+#pragma unroll
+          for (int i = k + 1; i < DN; ++i) col[i] = l[i];
+        }
+      } else {
+        const double ck = col[k];
+        col[k] = c == k ? ip : ck;
+#pragma unroll
+        for (int i = k + 1; i < DN; ++i) col[i] = fma(-l[i], ck, col[i]);
+      }
+    }
+  }
+  // right-hand-side lanes: U x = y in place
+  __device__ __forceinline__ static void back_substitute(double* col, int c, int gbase) {
+#pragma unroll
+    for (int k = DN - 1; k >= 0; --k) {
+      double uk[DN];
+#pragma unroll
+      for (int i = 0; i <= k; ++i) uk[i] = lane_bcast(col[i], gbase + k);   // column k of U from its owner (uk[k] = 1 / u_kk)
+      if (c >= DN) {
+        const double xk = col[k] * uk[k];
+        col[k] = xk;
+#pragma unroll
+        for (int i = 0; i < k; ++i) col[i] = fma(-uk[i], xk, col[i]);
+      }
+    }
+  }
+  // Mat^T y = b with the same factors (Mat^T = U^T L^T): matrix lane c hands in b_c and receives y_c.  Dot-product form - every
+  // coefficient a lane needs is in its own column; the unknowns travel lane to lane.
+  __device__ __forceinline__ static double solve_transposed(const double* col, double b, int c, int gbase) {
+    double s = 0.0, z = 0.0;
+#pragma unroll
+    for (int i = 0; i < DN; ++i) {
+      const double zc = (b - s) * col[i];          // meaningful in lane i: (b_i - sum_{r < i} u_ri z_r) / u_ii
+      const double zi = lane_bcast(zc, gbase + i);
+      z = c == i ? zc : z;
+      s = c > i ? fma(col[i], zi, s) : s;
+    }
+    double t = 0.0, y = 0.0;
+#pragma unroll
+    for (int i = DN - 1; i >= 0; --i) {
+      const double yc = z - t;                     // meaningful in lane i
+      const double yi = lane_bcast(yc, gbase + i);
+      y = c == i ? yc : y;
+      t = c < i ? fma(col[i], yi, t) : t;
+    }
+    return y;
+  }
+};
+
 template <class M, int D>
 struct Colloc {
   static constexpr int NX = M::NX, NU = M::NU, DN = D * NX;

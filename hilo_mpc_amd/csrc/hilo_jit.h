@@ -31,6 +31,8 @@ struct JitRequest {
   bool sym = true;               // JIT_TRACK: symbolic model derivatives when the source provides them (one RK step per interval)
   bool mhe_gen = false;          // JIT_MHE: the general estimator policy MheGen (parameters as states, optional state noise)
   bool mhe_noise = true;         // JIT_MHE with mhe_gen: state noise variables present
+  unsigned wz_mask[24] = {0};    // JIT_USER with has_wz_mask: row masks of the non-zero stage weights (bit j of row i: Wz[i][j] != 0) -
+  bool has_wz_mask = false;      // compile-time constants of the unit, the quadratic form of the Lagrange term unrolls over them
   bool private_module = false;   // load a module of its own (its learned-term table belongs to ONE handle); the code object
                                  // still comes from the cache
 };

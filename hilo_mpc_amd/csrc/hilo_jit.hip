@@ -82,6 +82,13 @@ static std::string translation_unit(const JitRequest& r) {
            "#define HILO_USER_BIG %d\n#define HILO_USER_HAS_FUN %d\n#define HILO_USER_SYM %d\n#define HILO_USER_NQ %d\n",
            r.policy, r.nth, r.ne, r.nc, r.coll_d, r.N, (int)r.hold, (int)r.cont, (int)r.tv, (int)r.big, (int)r.has_fun, (int)r.sym, r.nq);
   std::string s(cfg);
+  {
+    std::string m = "#define HILO_USER_HAS_WZM ";
+    m += r.has_wz_mask ? "1\n" : "0\n";
+    m += "#define HILO_USER_WZM {";
+    for (int i = 0; i < 24; ++i) m += (i ? ", " : "") + std::to_string(r.has_wz_mask ? r.wz_mask[i] : 0u) + "u";
+    s += m + "}\n";
+  }
   s += "#include \"hilo_nmpc_gen.h\"\n#include \"hilo_nmpc_track.h\"\n#include \"hilo_nmpc_user.h\"\n";
   // device pointers to the packed learned terms (gp_pack_se) the user source refers to as hilo_user_gp[k]; written by the host
   // after the module is loaded (a module with learned terms is private to its handle: JitRequest::private_module).
@@ -93,6 +100,8 @@ struct UserCfg {
   static constexpr int NTH = HILO_USER_NTH, NE = HILO_USER_NE, NC = HILO_USER_NC, COLL_D = HILO_USER_COLL_D, N = HILO_USER_N,
                        NQ = HILO_USER_NQ;
   static constexpr bool HOLD = HILO_USER_HOLD, CONT = HILO_USER_CONT, TV = HILO_USER_TV, BIG = HILO_USER_BIG;
+  static constexpr bool HAS_WZM = HILO_USER_HAS_WZM;
+  static constexpr unsigned WZM[24] = HILO_USER_WZM;
 };
 #if !HILO_USER_HAS_FUN
 using UserFun = NoUserFun;
@@ -108,7 +117,10 @@ using EngineT = Ocp<PB>;
 constexpr size_t USER_LDS = EngineT::lds_doubles(UserCfg::N);
 static_assert(USER_LDS * 8 <= 160 * 1024, "the iterate of this problem does not fit the 160 KB of LDS");
 
-extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+#ifndef HILO_USER_WAVES
+#define HILO_USER_WAVES 1
+#endif
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HILO_USER_WAVES, HILO_USER_WAVES)))
 void hilo_user_solve(const OcpConst* __restrict__ pcg, int64_t batch, const double* __restrict__ x0, const double* __restrict__ par,
                      int64_t par_stride, const double* __restrict__ sdata, int64_t sd_stride, const double* __restrict__ v0,
                      int64_t v0_stride, double* __restrict__ v_opt, double* __restrict__ f_opt, double* __restrict__ lam_g,

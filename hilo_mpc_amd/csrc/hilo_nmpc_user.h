@@ -115,10 +115,26 @@ struct NmpcUser {
   static constexpr int NZALG = model_nz<M>::value;             // algebraic states of a semi-explicit DAE model (eliminated, see below)
   // collocation with the iterate in the workspace: the converged collocation states and the factors of the Newton matrix of an
   // interval are computed ONCE per derivative evaluation and read by all of its Taylor directions (hilo_colloc.h::prepare)
+  // ... and when a group of [collocation unknowns | model directions | 1] lanes fits the wave, the lanes of a group solve the
+  // interval's system TOGETHER (hilo_colloc.h::CoopLU: one column per lane, in registers) and the derivatives come from the
+  // implicit-function theorem instead of Taylor sweeps through the Newton iteration (coll_pass below):
+  //     XC    per interval in the workspace: [X (DNC) | the x, u slots they belong to (NWD)]  - written by the values pass
+  //     PREP  per interval: [X (DNC) | dX/dw, one column per model direction (NWD x DNC) | kappa (DNC) | x the block belongs to]
+  static constexpr int DNC = C::COLL_D * (M::NX + C::NTH), NWD = M::NX + M::NU + 2 * C::NTH, CGS = DNC + NWD + 1;
+#ifdef HILO_USER_NO_COOP_COLL   // developer knob: the per-lane Newton solve and the Taylor sweeps against its factors
+  static constexpr bool COOP_COLL = false;
+#else
+  static constexpr bool COOP_COLL = C::COLL_D > 0 && C::BIG && CGS <= 64;
+#endif
+  static constexpr int CG = COOP_COLL ? 64 / CGS : 1;          // intervals per pass of the wave
+#ifdef HILO_USER_VEC_MAX
+  static constexpr int VEC_MAX = HILO_USER_VEC_MAX;            // developer knob: cap on the LDS-resident vectors (Ocp::VEC_LEVEL)
+#endif
+  static constexpr int XCW = COOP_COLL ? DNC + NWD : 0;
 #ifdef HILO_USER_NO_PREP   // developer knob (tools/dbg/c5dae_prep.py): every Taylor direction solves the collocation system itself
   static constexpr int PREP = 0;
 #else
-  static constexpr int PREP = (C::COLL_D > 0 && C::BIG) ? C::COLL_D * (M::NX + C::NTH) * (1 + C::COLL_D * (M::NX + C::NTH)) : 0;
+  static constexpr int PREP = COOP_COLL ? DNC * (NWD + 2) + (M::NX + C::NTH) : ((C::COLL_D > 0 && C::BIG) ? DNC * (1 + DNC) : 0);
 #endif
   static constexpr bool QUAD_COST = false;
   static constexpr UserLayout L = UserLayout(MX, MU, NTH, NE, F::NPS, F::NPT, NQ, NPSI, C::N);
@@ -153,7 +169,18 @@ struct NmpcUser {
     T acc = T(0.0);
 #pragma unroll
     for (int i = 0; i < MZA; ++i) {
-      if constexpr (MASKED) {
+      if constexpr (MASKED && C::HAS_WZM) {
+        // the pattern of the weights is part of the compiled problem (hilo_nmpc_user.hip hands the row masks to the run-time
+        // compiler): the form unrolls over the non-zero entries.  (Tested at run time, the inner test was turned into selects: 1500
+        // of the 2900 instructions of a collocation point's sweep for configuration 5, whose ten-by-ten weight has three entries.)
+        if (C::WZM[i] != 0u) {
+          T s = T(0.0);
+#pragma unroll
+          for (int j = 0; j < MZA; ++j)
+            if ((C::WZM[i] >> j) & 1u) s = s + pc.cost[L.o_wz + i * MZA + j] * z[j];
+          acc = acc + z[i] * s;
+        }
+      } else if constexpr (MASKED) {
         const unsigned m = (unsigned)uni((int)pc.cost[L.o_wzm + i]);
         if (m != 0u) {
           T s = T(0.0);
@@ -264,6 +291,222 @@ struct NmpcUser {
     return dyn_cost_impl<FUSED_CON>(pc, par, sd, k, x, u, xn, dv, prep);
   }
 
+  // values pass of the cooperative transcription: the collocation states come from the workspace (coll_pass<false>)
+  template <class XP>
+  __device__ __forceinline__ static double dyn_cost_xc(const OcpConst& pc, const double* par, const double* sd, int k, const double* x,
+                                                       const double* u, double* xn, double* dv, XP xcp) {
+    return dyn_cost_impl<FUSED_CON>(pc, par, sd, k, x, u, xn, dv, xcp);
+  }
+
+  // inequality row m of a stage is in force (the engine's row_on for a stage row)
+  __device__ __forceinline__ static bool stage_row_live(const OcpConst& pc, int m) {
+    return m < pc.nc && (pc.dlb[m] > -INFINITY || pc.dub[m] < INFINITY);
+  }
+
+  // ---- the collocation systems of the horizon, CG intervals per pass of the wave ----------------------------------------------
+  // Lanes of a group: c < DNC owns column c = (point j, state a) of the Newton matrix  Mat = I - dt (A (x) I) blockdiag(f_x(X_j)),
+  // DNC <= c < DNC + NWD the right-hand side of the tangent dX/dw_(c - DNC) (w: the model's x, theta | u, u_theta, un-scaled),
+  // c = DNC + NWD the Newton residual.  Every pass of the iteration evaluates the model at the D points in Dual<1> arithmetic
+  // with the lane's own seed (one code path for all roles), eliminates, substitutes; the residual lane updates the states
+  // (staged in LDS: `stage`, CG x DNC).  DERIV = false (line search, start of the solve): iterate to 1e-8 relative - quadratic
+  // convergence puts the update's own error at round-off - and leave [X | slots] in `xc`.  DERIV = true (derivative phase):
+  // start from `xc` when it belongs to this point (it does after an accepted trial point: one pass), iterate to 1e-12, keep the
+  // tangents of the last pass and add the ADJOINT of the system for the second-order terms: with
+  //     Phi(X, w) = sum_i dt B_i l(X_i) - lam^T x+(X) + sum_(i,r) nu_(i,r) c_r(X_i)       (what the engine's q sums up)
+  // and y = Mat^-T Phi_X, the second derivative of w -> Phi(X(w), w) along a direction is the second Taylor coefficient of
+  // Phi + sum_j kappa_j^T f(X_j, u), kappa_j = dt sum_i A_ij y_i, along the STRAIGHT line (X + t X_w dir, w + t dir): the curvature
+  // of X(w) drops out against the stationarity of the Lagrangian in X.  The direction tasks (dyn_cost_impl) therefore sweep model,
+  // cost and rows once, with no linear solve, where they swept the Newton iteration twice with two substitutions each.
+  // `from_prep` (values pass of a trial point): start from the iterate's states moved by the change of the interval's initial state
+  template <bool DERIV, class ZP, class LP, class NUP, class XP, class PP>
+  __device__ __forceinline__ static void coll_pass(const OcpConst& pc, const double* par, const double* sd0, ZP Z, LP lam, NUP cnu,
+                                                   int N, XP xc, PP prep, lds_double* stage, bool from_prep = false) {
+    static_assert(COOP_COLL, "cooperative collocation pass");
+    const int lane = threadIdx.x;
+    const int g0 = lane / CGS;
+    const bool ingroup = g0 < CG;
+    const int g = ingroup ? g0 : 0;
+    const int gbase = g * CGS;
+    const int c = ingroup ? lane - gbase : (1 << 20);                // lanes behind the last group: no role
+    const bool is_mat = c < DNC, is_tan = c >= DNC && c < DNC + NWD, is_res = c == DNC + NWD;
+    const int j = is_mat ? c / MXA : 0, a = is_mat ? c - j * MXA : -1, w = is_tan ? c - DNC : -1;
+    lds_double* Xs = stage + g * DNC;
+    const double tol = DERIV ? 1e-12 : 1e-8;
+    for (int k0 = 0; k0 < N; k0 += CG) {
+      const int k = k0 + g;
+      const bool act = ingroup && k < N;
+      const int kk = k < N ? k : N - 1;                              // (a group past the horizon repeats the last interval, unrecorded)
+      const double* sd = C::TV ? sd0 + (size_t)kk * NSD : nullptr;
+      const double* p = C::TV ? sd + MX + MU : par;
+      double xp[MXA], up[MUA > 0 ? MUA : 1];
+#pragma unroll
+      for (int i = 0; i < MXA; ++i) xp[i] = Z[kk * NZ + i] * pc.sz[i];
+#pragma unroll
+      for (int i = 0; i < MUA; ++i) {
+        double ui = Z[kk * NZ + NX + i];
+        if constexpr (NH > 0) { if (kk >= pc.Nc) ui = Z[kk * NZ + MXA + NE + i]; }
+        up[i] = ui * pc.sz[NX + i];
+      }
+      // the slot of the iterate behind model direction c (lanes c < NWD): tag of the states in `xc`
+      int slot = 0;
+      if (c < MXA) slot = c;
+      else if (c < NWD) {
+        slot = NX + (c - MXA);
+        if constexpr (NH > 0) { if (kk >= pc.Nc) slot = MXA + NE + (c - MXA); }
+      }
+      const double tagv = c < NWD ? Z[kk * NZ + slot] : 0.0;
+      bool warm = false;
+      if constexpr (DERIV) {
+        const bool miss = c < NWD && !(xc[(size_t)kk * XCW + DNC + c] == tagv);
+        const unsigned long long mm = __ballot(miss);
+        const unsigned long long gm = CGS >= 64 ? ~0ull : (((1ull << CGS) - 1ull) << gbase);
+        warm = (mm & gm) == 0ull;
+      }
+      __syncthreads();
+      if (is_mat) {
+        double x0c = 0.0;
+#pragma unroll
+        for (int m = 0; m < MXA; ++m) x0c = a == m ? xp[m] : x0c;
+        if constexpr (DERIV) { if (warm) x0c = xc[(size_t)kk * XCW + c]; }
+        else if (from_prep) x0c = prep[(size_t)kk * PREP + c] + (x0c - prep[(size_t)kk * PREP + DNC * (NWD + 2) + (a < 0 ? 0 : a)]);
+        Xs[c] = x0c;
+      }
+      __syncthreads();
+      double col[DNC];
+      for (int it = 0; it < 12; ++it) {
+        double accd[DNC], accv[DNC];
+#pragma unroll
+        for (int q = 0; q < DNC; ++q) { accd[q] = 0.0; accv[q] = 0.0; }
+#pragma unroll
+        for (int jj = 0; jj < D; ++jj) {
+          Dual<1> xd[MXA], ud[MUA > 0 ? MUA : 1], fd[MXA];
+#pragma unroll
+          for (int m = 0; m < MXA; ++m) {
+            xd[m].v = Xs[jj * MXA + m];
+            xd[m].d[0] = (jj == j && m == a) ? 1.0 : 0.0;
+          }
+#pragma unroll
+          for (int b = 0; b < MUA; ++b) {
+            ud[b].v = up[b];
+            ud[b].d[0] = (MXA + b == w) ? 1.0 : 0.0;
+          }
+          MA::ode(xd, ud, p, pc.dt, fd);
+#pragma unroll
+          for (int i = 0; i < D; ++i) {
+            const double aij = pc.coll.A[i * D + jj];
+#pragma unroll
+            for (int m = 0; m < MXA; ++m) {
+              accd[i * MXA + m] = fma(aij, fd[m].d[0], accd[i * MXA + m]);
+              accv[i * MXA + m] = fma(aij, fd[m].v, accv[i * MXA + m]);
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int m = 0; m < MXA; ++m) {
+            const int q = i * MXA + m;
+            const double vm = (q == c ? 1.0 : 0.0) - pc.dt * accd[q];                     // column (j, a) of Mat
+            const double vt = (m == w ? 1.0 : 0.0) + pc.dt * accd[q];                     // Mat X_w = (1 (x) e_w)  |  dt (A (x) I) f_u
+            const double vr = xp[m] - Xs[q] + pc.dt * accv[q];                            // - residual of the Runge-Kutta form
+            col[q] = is_mat ? vm : (is_tan ? (DERIV ? vt : 0.0) : vr);
+          }
+        if constexpr (!DERIV) {
+          // a point whose residual is at round-off needs no further step (the Newton matrix is within O(dt) of the identity:
+          // the step would be as small as the residual): the pass that only confirms convergence ends in front of its elimination
+          double rmax = 0.0, xmax = 1.0;
+          if (is_res) {
+#pragma unroll
+            for (int q = 0; q < DNC; ++q) {
+              rmax = fmax(rmax, fabs(col[q]));
+              xmax = fmax(xmax, fabs(Xs[q]));
+            }
+          }
+          if (it > 0 && !__any((int)(is_res && act && !(rmax <= 1e-12 * xmax)))) break;
+        }
+        CoopLU<DNC>::template eliminate<DERIV>(col, c, gbase);
+        CoopLU<DNC>::back_substitute(col, c, gbase);
+        double dmax = 0.0, scale = 1.0;
+        __syncthreads();
+        if (is_res) {
+#pragma unroll
+          for (int q = 0; q < DNC; ++q) {
+            const double xq = Xs[q] + col[q];
+            Xs[q] = xq;
+            dmax = fmax(dmax, fabs(col[q]));
+            scale = fmax(scale, fabs(xq));
+          }
+        }
+        __syncthreads();
+        // wave-uniform exit: every group iterates until the last one has converged (further passes of a converged group are
+        // round-off); a NaN (singular pivot) also leaves the loop
+        if (!__any((int)(is_res && act && dmax > tol * scale))) break;
+      }
+      if constexpr (!DERIV) {
+        if (act && is_mat) xc[(size_t)kk * XCW + c] = Xs[c];
+        if (act && c < NWD) xc[(size_t)kk * XCW + DNC + c] = tagv;
+      } else {
+        // Phi_X, entry (j, a): derivative of the Lagrange term, the continuity weights and the rows at point j in X_j[a]
+        double gphi = 0.0;
+        {
+          Jet2 xu[MXA], uu[MUA > 0 ? MUA : 1], xcs[MXA], usj[MUA > 0 ? MUA : 1];
+#pragma unroll
+          for (int m = 0; m < MXA; ++m) {
+            xu[m] = Jet2(Xs[j * MXA + m], m == a ? 1.0 : 0.0, 0.0);
+            xcs[m] = xu[m] * (1.0 / pc.sz[m]);
+          }
+#pragma unroll
+          for (int b = 0; b < MUA; ++b) {
+            uu[b] = Jet2(up[b]);
+            usj[b] = Jet2(up[b] * (1.0 / pc.sz[NX + b]));
+          }
+          if constexpr (CONT) gphi += (pc.dt * pc.coll.Bq[j + 1]) * lagrange(pc, par, sd, p, kk, xcs, usj).a;
+#pragma unroll
+          for (int m = 0; m < MXA; ++m) gphi -= (a == m) ? lam[kk * NX + m] * pc.coll.Dc[j + 1] * (1.0 / pc.sz[m]) : 0.0;
+          if constexpr (FUSED_CON) {
+            const int nrow = (int)pc.cost[L.o_nrow];
+            constexpr int NZ1 = NZALG > 0 ? NZALG : 1;
+            Jet2 zc[NZ1], xe[NX], dvl[NC > 0 ? NC : 1];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xe[i] = Jet2(0.0);          // (the slacks enter the rows linearly: no X-derivative)
+#pragma unroll
+            for (int m = 0; m < (NC > 0 ? NC : 1); ++m) dvl[m] = Jet2(0.0);
+            if constexpr (NZALG > 0 && F::CON_USES_Z) dae_solve<M>(xu, uu, p, zc);
+            rows_at(pc, p, xu, uu, (NZALG > 0 && F::CON_USES_Z) ? zc : (const Jet2*)nullptr, xe, 0, nrow, dvl);
+#pragma unroll
+            for (int r = 0; r < (NC > 0 ? NC : 1); ++r) {
+              if (r < nrow) {
+                const int m = (j + 1) * nrow + r;
+                if (stage_row_live(pc, m)) gphi += cnu[kk * NC + m] * dvl[r].a;
+              }
+            }
+          }
+        }
+        const double y = CoopLU<DNC>::solve_transposed(col, is_mat ? gphi : 0.0, c, gbase);
+        double kap = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) kap += pc.coll.A[i * D + j] * lane_bcast(y, gbase + i * MXA + (a < 0 ? 0 : a));
+        kap *= pc.dt;
+        if (act) {
+          if (is_mat) {
+            prep[(size_t)kk * PREP + c] = Xs[c];
+            prep[(size_t)kk * PREP + DNC * (1 + NWD) + c] = kap;
+            if (j == 0) {
+              double xa = 0.0;
+#pragma unroll
+              for (int m = 0; m < MXA; ++m) xa = a == m ? xp[m] : xa;
+              prep[(size_t)kk * PREP + DNC * (NWD + 2) + a] = xa;
+            }
+          } else if (is_tan) {
+#pragma unroll
+            for (int q = 0; q < DNC; ++q) prep[(size_t)kk * PREP + DNC + w * DNC + q] = col[q];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
   // rows of ONE point (un-scaled xu, uu, algebraic state z or nullptr): d[m0 + r] = sign_r c_{expr_r} - e_{slack_r}, r < nrow
   template <class T>
   __device__ __forceinline__ static void rows_at(const OcpConst& pc, const double* p, const T* xu, const T* uu, const T* z,
@@ -303,13 +546,75 @@ struct NmpcUser {
     T lc = T(0.0);
     if constexpr (D > 0) {
       T Xc[D * MXA];
-      if constexpr (PREP > 0 && same_type<T, Jet2>::value) {
+      if constexpr (COOP_COLL) {
+        // The collocation states come from the block the cooperative pass left for this interval (coll_pass): `prep` = the
+        // workspace row [X | slots] for a values evaluation, the staged block [X | dX/dw | kappa] for a direction of the derivative
+        // phase.  A direction moves the states along their tangent (at most two model directions carry a seed: a unit direction
+        // or a pair), the shooting map is LINEAR in them, and the curvature of the eliminated equations enters through kappa.
+        // ONE point at a time in a loop that stays a loop: unrolled, the compiler hoists the table reads of all points to the top
+        // and the task spills (500 scratch instructions per direction pass, 6 MB of scratch traffic per iteration and instance).
+        constexpr bool JET = same_type<T, Jet2>::value;
+        int w1 = 0, w2 = 0;
+        double s1 = 0.0, s2 = 0.0;
+        if constexpr (JET) {
+#pragma unroll
+          for (int w = 0; w < NWD; ++w) {
+            const double aw = w < MXA ? xp[w < MXA ? w : 0].a : up[w >= MXA ? w - MXA : 0].a;
+            const bool nz = aw != 0.0, first = nz && s1 == 0.0;
+            w2 = (nz && !first) ? w : w2;
+            s2 = (nz && !first) ? aw : s2;
+            w1 = first ? w : w1;
+            s1 = first ? aw : s1;
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < MXA; ++m) xo[m] = pc.coll.Dc[0] * xp[m];
+        const int nrow = WITH_CON ? (int)pc.cost[L.o_nrow] : 0;
+        constexpr int NZ1 = NZALG > 0 ? NZALG : 1;
+        constexpr bool ZR = NZALG > 0 && F::CON_USES_Z;
+        double kb = 0.0;
+        T zc[NZ1];
+#pragma unroll 1
+        for (int jj = 0; jj < D; ++jj) {
+          T Xj[MXA];
+#pragma unroll
+          for (int m = 0; m < MXA; ++m) {
+            const int q = jj * MXA + m;
+            if constexpr (JET) Xj[m] = Jet2(prep[q], s1 * prep[DNC + w1 * DNC + q] + s2 * prep[DNC + w2 * DNC + q], 0.0);
+            else Xj[m] = prep[q];
+          }
+          const double dj = pc.coll.Dc[jj + 1];
+#pragma unroll
+          for (int m = 0; m < MXA; ++m) xo[m] = xo[m] + dj * Xj[m];
+          if constexpr (JET) {
+            T Fj[MXA];
+            MA::ode(Xj, up, p, pc.dt, Fj);
+#pragma unroll
+            for (int m = 0; m < MXA; ++m) kb = fma(prep[DNC * (1 + NWD) + jj * MXA + m], Fj[m].b, kb);
+          }
+          if constexpr (WITH_CON) {
+            if constexpr (ZR) dae_solve<M>(Xj, up, p, zc);
+            rows_at(pc, p, Xj, up, ZR ? zc : (const T*)nullptr, x, (jj + 1) * nrow, nrow, dv);
+          }
+          if constexpr (CONT) {
+            T xcs[MXA];
+#pragma unroll
+            for (int m = 0; m < MXA; ++m) xcs[m] = Xj[m] * (1.0 / pc.sz[m]);
+            lc = lc + (pc.dt * pc.coll.Bq[jj + 1]) * lagrange(pc, par, sd, p, k, xcs, us);
+          }
+        }
+        if constexpr (JET) lc = lc + Jet2(0.0, 0.0, kb);
+        if constexpr (WITH_CON) {   // rows at the node (the algebraic state they see: below; d = 1 keeps the collocation point's)
+          if constexpr (ZR && D > 1) dae_solve<M>(xp, up, p, zc);
+          rows_at(pc, p, xp, up, ZR ? zc : (const T*)nullptr, x, 0, nrow, dv);
+        }
+      } else if constexpr (PREP > 0 && same_type<T, Jet2>::value) {
         if (prep) Colloc<MA, D>::step_prepared(pc.coll, xp, up, p, pc.dt, xo, (CONT || WITH_CON) ? Xc : nullptr, prep);
         else Colloc<MA, D>::step(pc.coll, xp, up, p, pc.dt, xo, (CONT || WITH_CON) ? Xc : nullptr);
       } else
       Colloc<MA, D>::step(pc.coll, xp, up, p, pc.dt, xo, (CONT || WITH_CON) ? Xc : nullptr);
 #ifndef HILO_DBG_SKIP_ROWS
-      if constexpr (WITH_CON) {
+      if constexpr (WITH_CON && !COOP_COLL) {
         // rows of the node [0, nrow), then of the collocation points i = 1..d [i nrow, (i + 1) nrow); an expression that names an
         // algebraic state gets z(x_{k,i}, u_k) at a collocation point; at the node the reference passes the interval's whole zp
         // block (mpc.py:1707) - for d = 1 that IS z at the collocation point; for d > 1 CasADi rejects the call, and the row is
@@ -329,7 +634,7 @@ struct NmpcUser {
       }
 #endif
 #ifndef HILO_DBG_SKIP_QUAD
-      if constexpr (CONT) {
+      if constexpr (CONT && !COOP_COLL) {
 #pragma unroll
         for (int i = 0; i < D; ++i) {
           T xcs[MXA];

@@ -147,11 +147,16 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   size_t fixed_b = ocp_fixed_doubles(nxe, nue, nconst, np + mu, nsd, 0, N) * sizeof(double);
   const size_t iter_b = ocp_iter_doubles(nxe, nue, nc, N) * sizeof(double);
   const bool big = fixed_b + iter_b > 160 * 1024;
-  if (big && D) fixed_b += (size_t)(D * (mx + nth)) * (1 + D * (mx + nth)) * sizeof(double);   // the staged block of NmpcUser::PREP
+  // workspace mode under collocation (NmpcUser::PREP / XCW, same formulas): per interval the collocation states with their tangents
+  // and adjoint weights when the lanes of a wave solve the system together (coll_pass), else the states and the factors of their
+  // Newton matrix (hilo_colloc.h::prepare); one interval's block is staged in LDS
+  const int dnc = D * (mx + nth), nwd = mx + mu + 2 * nth;
+  const bool coop = big && D && dnc + nwd + 1 <= 64;
+  const size_t prep_w = !(big && D) ? 0 : (coop ? (size_t)dnc * (nwd + 2) + (mx + nth) : (size_t)dnc * (1 + dnc));
+  const size_t xc_w = coop ? (size_t)(dnc + nwd) : 0;
+  fixed_b += prep_w * sizeof(double);
   if (fixed_b > 160 * 1024) return fail(HILO_ENOTSUP, "horizon %d needs %zu B of LDS for the problem constants alone", N, fixed_b);
-  // workspace mode under collocation: per interval the converged collocation states and the factors of their Newton matrix
-  // (NmpcUser::PREP, hilo_colloc.h::prepare)
-  const size_t prep_b = (big && D) ? (size_t)N * (D * mxa) * (1 + D * mxa) * sizeof(double) : 0;
+  const size_t prep_b = (size_t)N * (prep_w + xc_w) * sizeof(double);
 
   hilo_nmpc* h = new hilo_nmpc();
   memset(h, 0, sizeof(*h));
@@ -317,6 +322,14 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   rq.hold = hold; rq.cont = cont; rq.tv = tv; rq.big = big; rq.has_fun = d->user_has_fun != 0;
   rq.nq = nq;
   rq.private_module = d->n_user_gp > 0;
+  for (int i = 0; i < mza; ++i) {   // row masks of the non-zero stage weights (hilo_nmpc_user.h::lagrange): part of the compiled problem
+    unsigned m = 0u;
+    for (int j = 0; j < mza; ++j)
+      if (c.cost[L.o_wz + i * mza + j] != 0.0) m |= 1u << j;
+    c.cost[L.o_wzm + i] = (double)m;
+    if (i < 24) rq.wz_mask[i] = m;
+  }
+  rq.has_wz_mask = mza <= 24;
   int rc = jit_nmpc_kernels(rq, device, &h->jit);
   if (!rc && getenv("HILO_JIT_COMPILE_ONLY")) { hilo_nmpc_destroy(h); return HILO_COMPILED_ONLY; }   // cache warmed, no handle
   if (!rc && (h->jit.dims[0] != mx || h->jit.dims[1] != mu || h->jit.dims[2] != np || h->jit.dims[6] != nxe || h->jit.dims[7] != nue))
@@ -326,12 +339,6 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   if (!rc) rc = nmpc_bind_user_gps(h, d);
   if (rc) { hilo_nmpc_destroy(h); return rc; }
   hipError_t e = hipSetDevice(device);
-  for (int i = 0; i < mza; ++i) {   // row masks of the non-zero stage weights (hilo_nmpc_user.h::lagrange)
-    unsigned m = 0u;
-    for (int j = 0; j < mza; ++j)
-      if (c.cost[L.o_wz + i * mza + j] != 0.0) m |= 1u << j;
-    c.cost[L.o_wzm + i] = (double)m;
-  }
   if (e == hipSuccess) e = hipMalloc((void**)&h->dev, sizeof(OcpConst));
   if (e == hipSuccess) e = hipMemcpy(h->dev, &c, sizeof(OcpConst), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&h->v_guess, sizeof(double) * h->n_v);

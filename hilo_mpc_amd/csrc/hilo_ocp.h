@@ -254,6 +254,11 @@ template <class PB, class = void> struct pb_prep { static constexpr int value = 
 template <class PB> struct pb_prep<PB, void_tt<decltype(PB::PREP)>> { static constexpr int value = PB::PREP; };
 //   LAM_FIX  the policy adjusts the reported multipliers of the LAST shooting defect (`lam_fix`): rows the reference imposes on the
 //          node variable x_N are rows on the integrated end state here (custom constraint functions, hilo_nmpc_user.h)
+// ... or the lanes of a wave solve the collocation systems together: PB::coll_pass, states per interval in the workspace (PB::XCW)
+template <class PB, class = void> struct pb_vec_max { static constexpr int value = 3; };
+template <class PB> struct pb_vec_max<PB, void_tt<decltype(PB::VEC_MAX)>> { static constexpr int value = PB::VEC_MAX; };
+template <class PB, class = void> struct pb_xcw { static constexpr int value = 0; };
+template <class PB> struct pb_xcw<PB, void_tt<decltype(PB::XCW)>> { static constexpr int value = PB::XCW; };
 template <class PB, class = void> struct pb_lam_fix { static constexpr bool value = false; };
 template <class PB> struct pb_lam_fix<PB, void_tt<decltype(PB::LAM_FIX)>> { static constexpr bool value = PB::LAM_FIX; };
 template <class PB, class = void> struct pb_fused { static constexpr bool value = false; };
@@ -325,6 +330,7 @@ struct Ocp {
   static constexpr bool FUSED = pb_fused<PB>::value;   // dyn_cost(): shooting map + Lagrange term in one evaluation
   static constexpr bool FUSED_CON = pb_fused_con<PB>::value;   // dyn_cost_con(): ... and the inequality rows
   static constexpr int PREP = pb_prep<PB>::value;              // per-interval data prepared once per derivative evaluation
+  static constexpr int XCW = pb_xcw<PB>::value;                // > 0: cooperative collocation (PB::coll_pass, PB::dyn_cost_xc)
   // model derivatives as generated straight-line code (ModelSym<PB::Model>, csrc/hilo_models_sym.h / codegen): second-order
   // adjoint through the Runge-Kutta stages instead of Taylor sweeps per direction pair (eval_derivs_sym)
   static constexpr bool SYM = pb_sym<PB>::value;
@@ -368,7 +374,10 @@ struct Ocp {
   static constexpr bool vec_fits(int level) {
     return (ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, VEC_N, PREP) + vec_doubles_level(VEC_N, level)) * sizeof(double) <= VEC_BUDGET;
   }
-  static constexpr int VEC_LEVEL = !(BIG && VEC_N > 0) ? 0 : (vec_fits(3) ? 3 : (vec_fits(2) ? 2 : (vec_fits(1) ? 1 : 0)));
+  // (a policy may cap the level - PB::VEC_MAX: a problem whose long phases are latency bound trades the LDS-resident vectors for
+  // a second wave per SIMD)
+  static constexpr int VEC_FIT = !(BIG && VEC_N > 0) ? 0 : (vec_fits(3) ? 3 : (vec_fits(2) ? 2 : (vec_fits(1) ? 1 : 0)));
+  static constexpr int VEC_LEVEL = VEC_FIT < pb_vec_max<PB>::value ? VEC_FIT : pb_vec_max<PB>::value;
   static constexpr bool VEC_LDS = VEC_LEVEL > 0;
   __host__ __device__ static constexpr size_t vec_doubles(int N) { return vec_doubles_level(N, VEC_LEVEL); }
   using vp = cond_t<BIG && VEC_LEVEL < 1, gbl_double*, lds_double*>;      // Z Zt D zL zU lbA ubA
@@ -386,6 +395,7 @@ struct Ocp {
     dp lamn, AB, W, Qd, P, Kg, sig, rbN, Acl;
     dp Xs;   // SYM policies: Runge-Kutta stage points [N][4][NX] of the last values-only evaluation (reused by the derivative phase)
     dp prep; // [N][PREP]: what PB::prepare leaves for the Taylor tasks of an interval
+    dp xc;   // [N][XCW]: collocation states of the last values-only evaluation (cooperative collocation)
     lds_double* prepl;   // [PREP]: the block of the interval whose directions are being swept (staged in LDS: every lane reads all of it)
     lds_double* gpc;   // cooperative models: [N][4][6] value / gradient / Hessian of the learned term at the stage points (GpExt::cache)
     dp cs, cst, cnu, cnun, cvL, cvU, cdvL, cdvU, cds, cd, csig, crb, Jd;  // [N][NC] (Jd: [N][NC][NZ])
@@ -400,7 +410,7 @@ struct Ocp {
   __host__ __device__ static constexpr size_t xs_doubles(int N) { return SYM ? (size_t)N * 4 * NX : (COOP ? (size_t)N * 24 : 0); }
   __host__ __device__ static constexpr size_t iter_doubles(int N) {  // the iterate (LDS or workspace); <= ocp_iter_doubles + xs
     return ocp_iter_doubles(NX, NU, NC, N) - (size_t)(N + 1) * NDIR - (size_t)N * 4 * NX + qd_doubles(N) + xs_doubles(N) +
-           (size_t)N * PREP;
+           (size_t)N * PREP + (size_t)N * XCW;
   }
   __device__ static dp qd_term(const Lds l, int N) { return (SYM || SYM_MHE) ? l.Qd : l.Qd + (size_t)N * NDIR; }
   __host__ __device__ static constexpr size_t fixed_doubles(int N) {  // always LDS
@@ -461,6 +471,7 @@ struct Ocp {
       l.gpc = nullptr;
     }
     l.prep = big((size_t)N * PREP);
+    l.xc = big((size_t)N * XCW);
     return l;
   }
 
@@ -586,7 +597,14 @@ struct Ocp {
         for (int i = 0; i < NX; ++i) x[i] = Zp[N * NZ + i];
         fpart += PB::term_cost(pc, (const double*)l.par, sd_of(l, N), x);
       }
-    } else
+    } else {
+    // (a trial point - anything but the iterate itself - is evaluated after the derivative phase: the iterate's collocation
+    // states are in l.prep and start the Newton iteration)
+    if constexpr (XCW > 0) PB::template coll_pass<false>(pc, (const double*)l.par, (const double*)l.sd, Zp, l.lam, l.cnu, N, l.xc, l.prep, l.prepl,
+                                                         uni((size_t)Zp != (size_t)l.Z));
+#ifdef HILO_DBG_TWICE_VALS   // developer knob (tools/dbg/c5dae_twice.sh): the same work again - the launch's extra time is this part's cost
+    if constexpr (XCW > 0) PB::template coll_pass<false>(pc, (const double*)l.par, (const double*)l.sd, Zp, l.lam, l.cnu, N, l.xc, l.prep, l.prepl);
+#endif
     OCP_FOR(k, (N) + 1) {
       double x[NX], u[NU > 0 ? NU : 1];
 #pragma unroll
@@ -596,7 +614,9 @@ struct Ocp {
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = Zp[k * NZ + NX + i];
         double dvf[NC > 0 ? NC : 1];
-        if constexpr (FUSED_CON) {
+        if constexpr (XCW > 0) {
+          fpart += PB::dyn_cost_xc(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dvf, l.xc + (size_t)k * XCW);
+        } else if constexpr (FUSED_CON) {
           static_assert(!FUSED_CON || FUSED, "fused rows need the fused cost");
           fpart += PB::dyn_cost_con(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dvf, NoExt{});
         } else if constexpr (FUSED) {
@@ -657,6 +677,7 @@ struct Ocp {
       } else {
         fpart += PB::term_cost(pc, (const double*)l.par, sd_of(l, N), x);
       }
+    }
     }
     if constexpr (OCP_TPB == 64) {
       double rv[3] = {fpart, tpart, extra};
@@ -762,7 +783,12 @@ struct Ocp {
     const int PASSES = (nact + OCP_TPB - 1) / OCP_TPB;
     const int ntask = COOP ? ((N + GPW - 1) / GPW) * 64 + NXDIR : (PREP > 0 ? N * PASSES * OCP_TPB + NXDIR : N * nact + NXDIR);
     const int tbase = ntask - NXDIR;
-    if constexpr (PREP > 0) {   // once per interval: what all its directions share (PB::prepare)
+    if constexpr (XCW > 0) {    // cooperative collocation: states, tangents and the adjoint weights of every interval
+      PB::template coll_pass<true>(pc, (const double*)l.par, (const double*)l.sd, l.Z, l.lam, l.cnu, N, l.xc, l.prep, l.prepl);
+#ifdef HILO_DBG_TWICE_COLL
+      PB::template coll_pass<true>(pc, (const double*)l.par, (const double*)l.sd, l.Z, l.lam, l.cnu, N, l.xc, l.prep, l.prepl);
+#endif
+    } else if constexpr (PREP > 0) {   // once per interval: what all its directions share (PB::prepare)
       OCP_FOR(k, N) {
         double x[NX], u[NU > 0 ? NU : 1];
 #pragma unroll
@@ -773,6 +799,9 @@ struct Ocp {
       }
       __syncthreads();
     }
+#ifdef HILO_DBG_TWICE_DIRS
+    for (int dbg_rep = 0; dbg_rep < 2; ++dbg_rep)
+#endif
     for (int task0_base = 0; task0_base < ntask; task0_base += OCP_TPB) {
       if constexpr (PREP > 0) {
         if (task0_base < tbase && (task0_base / OCP_TPB) % PASSES == 0) {   // a new interval: stage its block
@@ -1608,6 +1637,10 @@ struct Ocp {
     // line search evaluated last - the learned term's value / gradient / Hessian at its stage points are in l.gpc
     if constexpr (COOP) return uni(eval_derivs_body(uni(lbase), uni(ws), uni(reuse)));
 #endif
+    // cooperative collocation: as a real call - the phase is long (N / CG elimination rounds, N direction passes), and inlined it
+    // shares the register file with everything the solver loop keeps alive: spills inside its loops, which one wave per SIMD sends
+    // to HBM (1.5 TB of scratch writes per 8192-instance launch of configuration 5's DAE problem)
+    else if constexpr (XCW > 0) return uni(eval_derivs_call(lbase, ws));
     else if constexpr (SYM) return eval_derivs_sym(lbase, ws);
     else if constexpr (SYM_MHE) return eval_derivs_sym_mhe(lbase, ws);
     else return eval_derivs_body(lbase, ws);
@@ -3469,21 +3502,23 @@ __device__ __forceinline__ void ocp_solve_body(lds_double* lds_raw, const OcpCon
       OCP_FOR(e, SL) zm = fmax(zm, fmax(l.zL[e], l.zU[e]));
       if constexpr (NC > 0)
         OCP_FOR(e, N * NC) zm = fmax(zm, fmax(l.cvL[e], l.cvU[e]));
-      zm = block_reduce<OpMax>(zm, l.red);
-      OCP_FOR(e, SL) {
-        if (zm > 1e3) {
+      const bool zreset = uni(block_reduce<OpMax>(zm, l.red) > 1e3);   // (wave-uniform: a scalar branch around the element loops)
+      if (zreset) {
+        OCP_FOR(e, SL) {
           l.zL[e] = l.lbA[e] > -INFINITY ? 1.0 : 0.0;
           l.zU[e] = l.ubA[e] < INFINITY ? 1.0 : 0.0;
         }
       }
       OCP_FOR(e, N * NX) l.lam[e] = 0.0;
       if constexpr (NC > 0) {
-        OCP_FOR(e, N * NC) {
-          const int m = e % NC;
-          l.cnu[e] = 0.0;
-          if (zm > 1e3 && S::row_on(pc, e / NC, m)) {
-            l.cvL[e] = pc.dlb[m] > -INFINITY ? 1.0 : 0.0;
-            l.cvU[e] = pc.dub[m] < INFINITY ? 1.0 : 0.0;
+        OCP_FOR(e, N * NC) l.cnu[e] = 0.0;
+        if (zreset) {
+          OCP_FOR(e, N * NC) {
+            const int m = e % NC;
+            const bool on = S::row_on(pc, e / NC, m);
+            const double vl = l.cvL[e], vu = l.cvU[e];
+            l.cvL[e] = on ? (pc.dlb[m] > -INFINITY ? 1.0 : 0.0) : vl;
+            l.cvU[e] = on ? (pc.dub[m] < INFINITY ? 1.0 : 0.0) : vu;
           }
         }
       }
