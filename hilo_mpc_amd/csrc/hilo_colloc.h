@@ -70,6 +70,50 @@ struct CoopLU {
       }
     }
   }
+  // The same with the right-hand sides as a SECOND column `ecol` per lane (a lane may own a matrix column and a right-hand side,
+  // or only one of them with the other column idle): every lane applies the row operations to its `ecol`.
+  template <bool KEEP_L = true>
+  __device__ __forceinline__ static void eliminate2(double* col, double* ecol, int c, int gbase) {
+#pragma unroll
+    for (int k = 0; k < DN; ++k) {
+      const double ck = col[k], ek = ecol[k];
+      const double ip = rcp_fast(ck);
+      col[k] = c == k ? ip : ck;
+      // the step's multipliers are requested together (the broadcasts pipeline), then consumed by both columns; branch-free: a
+      // lane left of the pivot updates entries it never reads again, the pivot's own lane keeps its multipliers (KEEP_L)
+      double l[DN > 1 ? DN : 1];
+#pragma unroll
+      for (int i = k + 1; i < DN; ++i) l[i] = lane_bcast(col[i] * ip, gbase + k);
+#pragma unroll
+      for (int i = k + 1; i < DN; ++i) {
+        ecol[i] = fma(-l[i], ek, ecol[i]);
+        // (pinned here: when only one lane's right-hand side is read afterwards - inside that lane's branch - the optimiser sinks
+        // the whole update chain into the branch, behind the elimination, and keeps every multiplier alive for it: 210 doubles)
+        asm volatile("" : "+v"(ecol[i]));
+        const double ci = fma(-l[i], ck, col[i]);
+        if constexpr (KEEP_L) col[i] = c == k ? l[i] : ci;
+        else col[i] = ci;
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (the unrolled steps are ONE basic block: left alone the scheduler runs all pivot columns
+                                           // first and the right-hand sides last, with every multiplier kept in between)
+    }
+  }
+  __device__ __forceinline__ static void back_substitute2(const double* col, double* ecol, int gbase) {
+#pragma unroll
+    for (int k = DN - 1; k >= 0; --k) {
+      double uk[DN];
+#pragma unroll
+      for (int i = 0; i <= k; ++i) uk[i] = lane_bcast(col[i], gbase + k);   // column k of U from its owner (uk[k] = 1 / u_kk)
+      const double xk = ecol[k] * uk[k];
+      ecol[k] = xk;
+#pragma unroll
+      for (int i = 0; i < k; ++i) {
+        ecol[i] = fma(-uk[i], xk, ecol[i]);
+        asm volatile("" : "+v"(ecol[i]));   // (pinned: see eliminate2)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   // right-hand-side lanes: U x = y in place
   __device__ __forceinline__ static void back_substitute(double* col, int c, int gbase) {
 #pragma unroll

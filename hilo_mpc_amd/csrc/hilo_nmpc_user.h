@@ -120,11 +120,16 @@ struct NmpcUser {
   // implicit-function theorem instead of Taylor sweeps through the Newton iteration (coll_pass below):
   //     XC    per interval in the workspace: [X (DNC) | the x, u slots they belong to (NWD)]  - written by the values pass
   //     PREP  per interval: [X (DNC) | dX/dw, one column per model direction (NWD x DNC) | kappa (DNC) | x the block belongs to]
-  static constexpr int DNC = C::COLL_D * (M::NX + C::NTH), NWD = M::NX + M::NU + 2 * C::NTH, CGS = DNC + NWD + 1;
+  // Lanes of a group: one per column of the Newton matrix; the right-hand sides (NWD tangents + the Newton residual) ride as a
+  // SECOND column in the first lanes when there are no more of them than matrix columns (CTWO: three intervals of configuration
+  // 5's 21 x 21 systems per pass of the wave), else in lanes of their own behind the matrix lanes.
+  static constexpr int DNC = C::COLL_D * (M::NX + C::NTH), NWD = M::NX + M::NU + 2 * C::NTH;
+  static constexpr bool CTWO = NWD + 1 <= DNC;
+  static constexpr int CGS = CTWO ? DNC : DNC + NWD + 1;
 #ifdef HILO_USER_NO_COOP_COLL   // developer knob: the per-lane Newton solve and the Taylor sweeps against its factors
   static constexpr bool COOP_COLL = false;
 #else
-  static constexpr bool COOP_COLL = C::COLL_D > 0 && C::BIG && CGS <= 64;
+  static constexpr bool COOP_COLL = C::COLL_D > 0 && C::BIG && CGS <= 64 && M::NU + C::NTH <= M::NX + C::NTH;
 #endif
   static constexpr int CG = COOP_COLL ? 64 / CGS : 1;          // intervals per pass of the wave
 #ifdef HILO_USER_VEC_MAX
@@ -304,11 +309,13 @@ struct NmpcUser {
   }
 
   // ---- the collocation systems of the horizon, CG intervals per pass of the wave ----------------------------------------------
-  // Lanes of a group: c < DNC owns column c = (point j, state a) of the Newton matrix  Mat = I - dt (A (x) I) blockdiag(f_x(X_j)),
-  // DNC <= c < DNC + NWD the right-hand side of the tangent dX/dw_(c - DNC) (w: the model's x, theta | u, u_theta, un-scaled),
-  // c = DNC + NWD the Newton residual.  Every pass of the iteration evaluates the model at the D points in Dual<1> arithmetic
-  // with the lane's own seed (one code path for all roles), eliminates, substitutes; the residual lane updates the states
-  // (staged in LDS: `stage`, CG x DNC).  DERIV = false (line search, start of the solve): iterate to 1e-8 relative - quadratic
+  // Lane c < DNC of a group owns column c = (point j, state a) of the Newton matrix  Mat = I - dt (A (x) I) blockdiag(f_x(X_j))
+  // in `col`; right-hand side r (tangent dX/dw_r for r < NWD - w: the model's x, theta | u, u_theta, un-scaled -, the Newton
+  // residual for r = NWD) sits in `ecol` of lane r (CTWO) or of lane DNC + r.  Every pass of the iteration: lane (j, a) evaluates
+  // the model at ITS point in Dual arithmetic seeded with x_a (and u_a) - one evaluation per lane, the D points side by side -,
+  // the right-hand sides collect the values / input derivatives they need from the lanes that hold them, the group eliminates
+  // (hilo_colloc.h::CoopLU), substitutes, and the residual's lane updates the states (staged in LDS: `stage`, CG x DNC).
+  // DERIV = false (line search, start of the solve): iterate to 1e-8 relative - quadratic
   // convergence puts the update's own error at round-off - and leave [X | slots] in `xc`.  DERIV = true (derivative phase):
   // start from `xc` when it belongs to this point (it does after an accepted trial point: one pass), iterate to 1e-12, keep the
   // tangents of the last pass and add the ADJOINT of the system for the second-order terms: with
@@ -328,10 +335,14 @@ struct NmpcUser {
     const int g = ingroup ? g0 : 0;
     const int gbase = g * CGS;
     const int c = ingroup ? lane - gbase : (1 << 20);                // lanes behind the last group: no role
-    const bool is_mat = c < DNC, is_tan = c >= DNC && c < DNC + NWD, is_res = c == DNC + NWD;
-    const int j = is_mat ? c / MXA : 0, a = is_mat ? c - j * MXA : -1, w = is_tan ? c - DNC : -1;
+    const bool is_mat = c < DNC;
+    const int j = is_mat ? c / MXA : 0, a = is_mat ? c - j * MXA : 0;
+    const int r = !ingroup ? -1 : (CTWO ? c : c - DNC);              // right-hand side this lane carries (-1 / > NWD: none)
+    const bool is_tan = r >= 0 && r < NWD, is_res = r == NWD;
+    const int bsel = (r >= MXA && r < NWD) ? r - MXA : 0;            // the input a tangent lane differentiates in
     lds_double* Xs = stage + g * DNC;
     const double tol = DERIV ? 1e-12 : 1e-8;
+    constexpr int ND = DERIV ? 2 : 1;
     for (int k0 = 0; k0 < N; k0 += CG) {
       const int k = k0 + g;
       const bool act = ingroup && k < N;
@@ -362,54 +373,62 @@ struct NmpcUser {
         const unsigned long long gm = CGS >= 64 ? ~0ull : (((1ull << CGS) - 1ull) << gbase);
         warm = (mm & gm) == 0ull;
       }
+      double xa = 0.0;                                               // this lane's own state component x_a (matrix lanes)
+#pragma unroll
+      for (int m = 0; m < MXA; ++m) xa = a == m ? xp[m] : xa;
       __syncthreads();
       if (is_mat) {
-        double x0c = 0.0;
-#pragma unroll
-        for (int m = 0; m < MXA; ++m) x0c = a == m ? xp[m] : x0c;
+        double x0c = xa;
         if constexpr (DERIV) { if (warm) x0c = xc[(size_t)kk * XCW + c]; }
-        else if (from_prep) x0c = prep[(size_t)kk * PREP + c] + (x0c - prep[(size_t)kk * PREP + DNC * (NWD + 2) + (a < 0 ? 0 : a)]);
+        else if (from_prep) x0c = prep[(size_t)kk * PREP + c] + (xa - prep[(size_t)kk * PREP + DNC * (NWD + 2) + a]);
         Xs[c] = x0c;
       }
       __syncthreads();
-      double col[DNC];
+      double col[DNC], ecol[DNC];
       for (int it = 0; it < 12; ++it) {
-        double accd[DNC], accv[DNC];
-#pragma unroll
-        for (int q = 0; q < DNC; ++q) { accd[q] = 0.0; accv[q] = 0.0; }
-#pragma unroll
-        for (int jj = 0; jj < D; ++jj) {
-          Dual<1> xd[MXA], ud[MUA > 0 ? MUA : 1], fd[MXA];
+        Dual<ND> fd[MXA];
+        {
+          Dual<ND> xd[MXA], ud[MUA > 0 ? MUA : 1];
 #pragma unroll
           for (int m = 0; m < MXA; ++m) {
-            xd[m].v = Xs[jj * MXA + m];
-            xd[m].d[0] = (jj == j && m == a) ? 1.0 : 0.0;
+            xd[m] = Dual<ND>(Xs[j * MXA + m]);
+            xd[m].d[0] = m == a ? 1.0 : 0.0;
           }
 #pragma unroll
           for (int b = 0; b < MUA; ++b) {
-            ud[b].v = up[b];
-            ud[b].d[0] = (MXA + b == w) ? 1.0 : 0.0;
+            ud[b] = Dual<ND>(up[b]);
+            if constexpr (DERIV) ud[b].d[1] = b == a ? 1.0 : 0.0;
           }
           MA::ode(xd, ud, p, pc.dt, fd);
-#pragma unroll
-          for (int i = 0; i < D; ++i) {
-            const double aij = pc.coll.A[i * D + jj];
-#pragma unroll
-            for (int m = 0; m < MXA; ++m) {
-              accd[i * MXA + m] = fma(aij, fd[m].d[0], accd[i * MXA + m]);
-              accv[i * MXA + m] = fma(aij, fd[m].v, accv[i * MXA + m]);
-            }
-          }
         }
+        // column (j, a) of Mat; the right-hand sides from the lanes that hold their ingredients: f(X_jj) in lane (jj, 0),
+        // df/du_b(X_jj) in lane (jj, b)
+        // (accumulated straight into the lane's right-hand side: tangent  Mat X_w = (1 (x) e_w) | dt (A (x) I) f_u,  residual
+        // x - X + dt (A (x) I) f(X) = minus the residual of the Runge-Kutta form)
 #pragma unroll
-        for (int i = 0; i < D; ++i)
+        for (int i = 0; i < D; ++i) {
+          const double aij = pc.dt * pc.coll.A[i * D + j];
 #pragma unroll
           for (int m = 0; m < MXA; ++m) {
             const int q = i * MXA + m;
-            const double vm = (q == c ? 1.0 : 0.0) - pc.dt * accd[q];                     // column (j, a) of Mat
-            const double vt = (m == w ? 1.0 : 0.0) + pc.dt * accd[q];                     // Mat X_w = (1 (x) e_w)  |  dt (A (x) I) f_u
-            const double vr = xp[m] - Xs[q] + pc.dt * accv[q];                            // - residual of the Runge-Kutta form
-            col[q] = is_mat ? vm : (is_tan ? (DERIV ? vt : 0.0) : vr);
+            col[q] = (q == c ? 1.0 : 0.0) - aij * fd[m].d[0];
+            ecol[q] = is_res ? xp[m] - Xs[q] : ((DERIV && m == r) ? 1.0 : 0.0);
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < D; ++jj)
+#pragma unroll
+          for (int m = 0; m < MXA; ++m) {
+            double fsel = lane_bcast(fd[m].v, gbase + jj * MXA);
+            if constexpr (DERIV) {
+              const double fu = lane_bcast(fd[m].d[1], gbase + jj * MXA + bsel);
+              fsel = is_res ? fsel : ((is_tan && r >= MXA) ? fu : 0.0);
+            } else {
+              fsel = is_res ? fsel : 0.0;
+            }
+            fsel *= pc.dt;
+#pragma unroll
+            for (int i = 0; i < D; ++i) ecol[i * MXA + m] = fma(pc.coll.A[i * D + jj], fsel, ecol[i * MXA + m]);
           }
         if constexpr (!DERIV) {
           // a point whose residual is at round-off needs no further step (the Newton matrix is within O(dt) of the identity:
@@ -418,22 +437,22 @@ struct NmpcUser {
           if (is_res) {
 #pragma unroll
             for (int q = 0; q < DNC; ++q) {
-              rmax = fmax(rmax, fabs(col[q]));
+              rmax = fmax(rmax, fabs(ecol[q]));
               xmax = fmax(xmax, fabs(Xs[q]));
             }
           }
           if (it > 0 && !__any((int)(is_res && act && !(rmax <= 1e-12 * xmax)))) break;
         }
-        CoopLU<DNC>::template eliminate<DERIV>(col, c, gbase);
-        CoopLU<DNC>::back_substitute(col, c, gbase);
+        CoopLU<DNC>::template eliminate2<DERIV>(col, ecol, c, gbase);
+        CoopLU<DNC>::back_substitute2(col, ecol, gbase);
         double dmax = 0.0, scale = 1.0;
         __syncthreads();
         if (is_res) {
 #pragma unroll
           for (int q = 0; q < DNC; ++q) {
-            const double xq = Xs[q] + col[q];
+            const double xq = Xs[q] + ecol[q];
             Xs[q] = xq;
-            dmax = fmax(dmax, fabs(col[q]));
+            dmax = fmax(dmax, fabs(ecol[q]));
             scale = fmax(scale, fabs(xq));
           }
         }
@@ -474,10 +493,10 @@ struct NmpcUser {
             if constexpr (NZALG > 0 && F::CON_USES_Z) dae_solve<M>(xu, uu, p, zc);
             rows_at(pc, p, xu, uu, (NZALG > 0 && F::CON_USES_Z) ? zc : (const Jet2*)nullptr, xe, 0, nrow, dvl);
 #pragma unroll
-            for (int r = 0; r < (NC > 0 ? NC : 1); ++r) {
-              if (r < nrow) {
-                const int m = (j + 1) * nrow + r;
-                if (stage_row_live(pc, m)) gphi += cnu[kk * NC + m] * dvl[r].a;
+            for (int rr = 0; rr < (NC > 0 ? NC : 1); ++rr) {
+              if (rr < nrow) {
+                const int m = (j + 1) * nrow + rr;
+                if (stage_row_live(pc, m)) gphi += cnu[kk * NC + m] * dvl[rr].a;
               }
             }
           }
@@ -485,21 +504,17 @@ struct NmpcUser {
         const double y = CoopLU<DNC>::solve_transposed(col, is_mat ? gphi : 0.0, c, gbase);
         double kap = 0.0;
 #pragma unroll
-        for (int i = 0; i < D; ++i) kap += pc.coll.A[i * D + j] * lane_bcast(y, gbase + i * MXA + (a < 0 ? 0 : a));
+        for (int i = 0; i < D; ++i) kap += pc.coll.A[i * D + j] * lane_bcast(y, gbase + i * MXA + a);
         kap *= pc.dt;
         if (act) {
           if (is_mat) {
             prep[(size_t)kk * PREP + c] = Xs[c];
             prep[(size_t)kk * PREP + DNC * (1 + NWD) + c] = kap;
-            if (j == 0) {
-              double xa = 0.0;
+            if (j == 0) prep[(size_t)kk * PREP + DNC * (NWD + 2) + a] = xa;
+          }
+          if (is_tan) {
 #pragma unroll
-              for (int m = 0; m < MXA; ++m) xa = a == m ? xp[m] : xa;
-              prep[(size_t)kk * PREP + DNC * (NWD + 2) + a] = xa;
-            }
-          } else if (is_tan) {
-#pragma unroll
-            for (int q = 0; q < DNC; ++q) prep[(size_t)kk * PREP + DNC + w * DNC + q] = col[q];
+            for (int q = 0; q < DNC; ++q) prep[(size_t)kk * PREP + DNC + r * DNC + q] = ecol[q];
           }
         }
       }
@@ -544,6 +559,7 @@ struct NmpcUser {
       up[i] = ui * pc.sz[NX + i];
     }
     T lc = T(0.0);
+    double kbq = 0.0;   // cooperative collocation: second-order term of the eliminated collocation equations (added to the cost below)
     if constexpr (D > 0) {
       T Xc[D * MXA];
       if constexpr (COOP_COLL) {
@@ -603,7 +619,7 @@ struct NmpcUser {
             lc = lc + (pc.dt * pc.coll.Bq[jj + 1]) * lagrange(pc, par, sd, p, k, xcs, us);
           }
         }
-        if constexpr (JET) lc = lc + Jet2(0.0, 0.0, kb);
+        if constexpr (JET) kbq = kb;
         if constexpr (WITH_CON) {   // rows at the node (the algebraic state they see: below; d = 1 keeps the collocation point's)
           if constexpr (ZR && D > 1) dae_solve<M>(xp, up, p, zc);
           rows_at(pc, p, xp, up, ZR ? zc : (const T*)nullptr, x, 0, nrow, dv);
@@ -663,6 +679,7 @@ struct NmpcUser {
       model_step<MA>(pc.order, pc.nsub, xp, up, p, pc.dt, xo);
     }
     if constexpr (!CONT || (D == 0 && M::DISCRETE)) lc = lagrange(pc, par, sd, p, k, xs, us);   // discrete objective: l(x_k, u_k)
+    if constexpr (COOP_COLL && same_type<T, Jet2>::value) lc = lc + Jet2(0.0, 0.0, kbq);
 #pragma unroll
     for (int i = 0; i < MXA; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]);
 #pragma unroll

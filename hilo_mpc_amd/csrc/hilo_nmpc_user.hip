@@ -146,15 +146,16 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   const int nconst = (int)((__builtin_offsetof(OcpConst, cost) + sizeof(double) * L.o_end + 7) / 8);
   size_t fixed_b = ocp_fixed_doubles(nxe, nue, nconst, np + mu, nsd, 0, N) * sizeof(double);
   const size_t iter_b = ocp_iter_doubles(nxe, nue, nc, N) * sizeof(double);
-  const bool big = fixed_b + iter_b > 160 * 1024;
+  // (HILO_FORCE_BIG: developer / test knob - a problem that fits LDS runs in workspace mode, the path of the long horizons)
+  const bool big = fixed_b + iter_b > 160 * 1024 || getenv("HILO_FORCE_BIG") != nullptr;
   // workspace mode under collocation (NmpcUser::PREP / XCW, same formulas): per interval the collocation states with their tangents
   // and adjoint weights when the lanes of a wave solve the system together (coll_pass), else the states and the factors of their
   // Newton matrix (hilo_colloc.h::prepare); one interval's block is staged in LDS
   const int dnc = D * (mx + nth), nwd = mx + mu + 2 * nth;
-  const bool coop = big && D && dnc + nwd + 1 <= 64;
+  const bool coop = big && D && (nwd + 1 <= dnc ? dnc : dnc + nwd + 1) <= 64 && mua <= mxa;
   const size_t prep_w = !(big && D) ? 0 : (coop ? (size_t)dnc * (nwd + 2) + (mx + nth) : (size_t)dnc * (1 + dnc));
   const size_t xc_w = coop ? (size_t)(dnc + nwd) : 0;
-  fixed_b += prep_w * sizeof(double);
+  fixed_b += prep_w * (coop ? 3 : 1) * sizeof(double);   // (Ocp::PREPB blocks staged at a time)
   if (fixed_b > 160 * 1024) return fail(HILO_ENOTSUP, "horizon %d needs %zu B of LDS for the problem constants alone", N, fixed_b);
   const size_t prep_b = (size_t)N * (prep_w + xc_w) * sizeof(double);
 

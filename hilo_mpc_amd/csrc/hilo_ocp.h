@@ -331,6 +331,7 @@ struct Ocp {
   static constexpr bool FUSED_CON = pb_fused_con<PB>::value;   // dyn_cost_con(): ... and the inequality rows
   static constexpr int PREP = pb_prep<PB>::value;              // per-interval data prepared once per derivative evaluation
   static constexpr int XCW = pb_xcw<PB>::value;                // > 0: cooperative collocation (PB::coll_pass, PB::dyn_cost_xc)
+  static constexpr int PREPB = XCW > 0 ? 3 : 1;                // per-interval blocks staged in LDS at a time
   // model derivatives as generated straight-line code (ModelSym<PB::Model>, csrc/hilo_models_sym.h / codegen): second-order
   // adjoint through the Runge-Kutta stages instead of Taylor sweeps per direction pair (eval_derivs_sym)
   static constexpr bool SYM = pb_sym<PB>::value;
@@ -372,7 +373,7 @@ struct Ocp {
   }
   static constexpr size_t VEC_BUDGET = 40 * 1024 - 64;
   static constexpr bool vec_fits(int level) {
-    return (ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, VEC_N, PREP) + vec_doubles_level(VEC_N, level)) * sizeof(double) <= VEC_BUDGET;
+    return (ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, VEC_N, PREP * PREPB) + vec_doubles_level(VEC_N, level)) * sizeof(double) <= VEC_BUDGET;
   }
   // (a policy may cap the level - PB::VEC_MAX: a problem whose long phases are latency bound trades the LDS-resident vectors for
   // a second wave per SIMD)
@@ -414,7 +415,7 @@ struct Ocp {
   }
   __device__ static dp qd_term(const Lds l, int N) { return (SYM || SYM_MHE) ? l.Qd : l.Qd + (size_t)N * NDIR; }
   __host__ __device__ static constexpr size_t fixed_doubles(int N) {  // always LDS
-    return ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, N, PREP);
+    return ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, N, PREP * PREPB);
   }
   __host__ __device__ static constexpr size_t lds_doubles(int N) {
     return fixed_doubles(N) + (BIG ? (VEC_LDS ? vec_doubles(N) : 0) : iter_doubles(N));
@@ -437,7 +438,7 @@ struct Ocp {
     l.sd = take((size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1);
     l.ext = take(NEXT);
     l.dirs = reinterpret_cast<__attribute__((address_space(3))) int*>(take((NDIR + 2) / 2));
-    l.prepl = take(PREP);
+    l.prepl = take(PREP * PREPB);
     dp w;
     const size_t V = (size_t)N * NX;
     if constexpr (VEC_LEVEL >= 1) {   // the vectors first, in LDS; everything else in the workspace
@@ -799,11 +800,32 @@ struct Ocp {
       }
       __syncthreads();
     }
+    // Cooperative collocation: the directions of the horizon are PACKED into the passes of the wave - pass p sweeps the tasks
+    // [xbase, xend) of the list (interval k, swept direction s) -> k nact + s, which may belong to up to PREPB intervals; their
+    // blocks are staged side by side.  (One interval per pass left 28 of 64 lanes idle for configuration 5's 36 directions.)
+    // xbase == N nact: the pass of the terminal cost's directions.
+    const int xtotal = N * nact;
 #ifdef HILO_DBG_TWICE_DIRS
-    for (int dbg_rep = 0; dbg_rep < 2; ++dbg_rep)
+    for (int dbg_rep = 0; dbg_rep < 2; ++dbg_rep) {
 #endif
-    for (int task0_base = 0; task0_base < ntask; task0_base += OCP_TPB) {
-      if constexpr (PREP > 0) {
+    int xbase = 0, xend = 0, xklo = 0;
+    for (int task0_base = 0; XCW > 0 ? xbase <= xtotal : task0_base < ntask; task0_base += OCP_TPB, xbase = XCW > 0 ? (xbase < xtotal ? xend : xtotal + 1) : 0) {
+      int xtask0 = 0, xk = 0, xslot = 0;
+      if constexpr (XCW > 0) {
+        if (xbase < xtotal) {
+          xklo = xbase / nact;
+          const int kend = xklo + PREPB < N ? xklo + PREPB : N;
+          xend = xbase + OCP_TPB < kend * nact ? xbase + OCP_TPB : kend * nact;
+          const int nblk = (xend - 1) / nact - xklo + 1;
+          __syncthreads();
+          for (int q = (int)threadIdx.x; q < nblk * PREP; q += OCP_TPB) l.prepl[q] = l.prep[(size_t)xklo * PREP + q];
+          __syncthreads();
+          const int my = xbase + (int)threadIdx.x;
+          xk = my / nact;
+          xslot = my - xk * nact;
+          xtask0 = my < xend ? 0 : ntask;                 // (any value below tbase: an interval's task; ntask: no task in this pass)
+        } else xtask0 = tbase + (int)threadIdx.x;          // the terminal cost's directions
+      } else if constexpr (PREP > 0) {
         if (task0_base < tbase && (task0_base / OCP_TPB) % PASSES == 0) {   // a new interval: stage its block
           const int kk = task0_base / (OCP_TPB * PASSES);
           __syncthreads();
@@ -811,7 +833,7 @@ struct Ocp {
           __syncthreads();
         }
       }
-      if (const int task0 = task0_base + (int)threadIdx.x; task0 < ntask) {
+      if (const int task0 = XCW > 0 ? xtask0 : task0_base + (int)threadIdx.x; task0 < ntask) {
       if (task0 < tbase) {
         int k, d, task = task0;
         bool active = true;
@@ -821,6 +843,10 @@ struct Ocp {
           k = (task0 / 64) * GPW + g;
           active = g < GPW && k < N;
           if (!active) { k = N - 1; d = 0; }
+          task = k * NDIR + d;
+        } else if constexpr (XCW > 0) {
+          k = xk;
+          d = l.dirs[1 + xslot];
           task = k * NDIR + d;
         } else if constexpr (PREP > 0) {
           k = task0 / (OCP_TPB * PASSES);
@@ -879,7 +905,9 @@ struct Ocp {
         // a policy with a purely quadratic stage cost supplies value / gradient / (constant) Hessian in closed form
         Jet2 lc(0.0);
         Jet2 dvf[NC > 0 ? NC : 1];
-        if constexpr (PREP > 0) {
+        if constexpr (XCW > 0) {
+          lc = PB::dyn_cost_prep(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dvf, l.prepl + (k - xklo) * PREP);
+        } else if constexpr (PREP > 0) {
           lc = PB::dyn_cost_prep(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dvf, l.prepl);
         } else if constexpr (FUSED_CON) {
           lc = PB::dyn_cost_con(pc, (const double*)l.par, sd_of(l, k), k, x, u, xn, dvf, NoExt{});
@@ -938,6 +966,9 @@ struct Ocp {
       }
       }
     }
+#ifdef HILO_DBG_TWICE_DIRS
+    }
+#endif
     __syncthreads();
     // Hessian blocks by polarisation: H_ii = q(e_i), H_ij = (q(e_i+e_j) - q(e_i) - q(e_j)) / 2
     if constexpr (BIG) {

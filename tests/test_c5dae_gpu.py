@@ -134,6 +134,35 @@ def test_hard_and_two_sided_rows_on_an_ode_under_collocation():
     _compare(disc, c2_x0(4), C2['p'])
 
 
+@pytest.mark.parametrize('case', ['c5ds', 'band', 'degree1', 'degree1_band', 'ode_hard', 'ode_soft', 'legendre2_discrete'])
+def test_workspace_mode_lanes_solve_the_collocation_systems_together(case, monkeypatch):
+    """The long horizons keep the iterate in a global-memory workspace, and there the lanes of a wave factor an interval's collocation
+    system together and the derivatives come from the implicit-function theorem (hilo_nmpc_user.h::coll_pass) - a different code
+    path from the one the short problems above take.  HILO_FORCE_BIG sends the same short problems down that path, against the same
+    oracle: every lane layout (right-hand sides as second columns: 21 x 21, 12 x 12, 8 x 8 systems; in lanes of their own: degree 1),
+    algebraic states, rows at the collocation points, hard and soft, continuous and discrete objective."""
+    monkeypatch.setenv('HILO_FORCE_BIG', '1')
+    kw = dict(C2, N=8, collocation=dict(degree=3))
+    kw.pop('order', None)
+    hard = dict(kw, constraint=dict(expr=['X * S + 20 * DS', 'S - X + 5 * DI'], lb=[-np.inf, 0.], ub=[60., np.inf]))
+    if case == 'c5ds':
+        _compare(C5DS, c5_x0(8), [], other_minimum=1)
+    elif case == 'band':
+        _compare(dict(C5DS, constraint=dict(expr=['z + 0.1 * a'], lb=[2.5], ub=[4.], soft=True)), c5_x0(6), [], other_minimum=1)
+    elif case == 'degree1':
+        _compare(dict(C5DS, N=6, collocation=dict(degree=1)), c5_x0(4), [], other_minimum=2)
+    elif case == 'degree1_band':
+        _compare(dict(C5DS, N=6, collocation=dict(degree=1), constraint=dict(expr=['z + 0.1 * a'], lb=[2.5], ub=[4.], soft=True)),
+                 c5_x0(4), [], other_minimum=2)
+    elif case == 'ode_hard':
+        _compare(hard, c2_x0(4), C2['p'])
+    elif case == 'ode_soft':
+        _compare(dict(kw, constraint=dict(expr=['X * S + 20 * DS'], lb=[2.], ub=[60.], soft=True, weight=[[1e3]], max_violation=[5.])),
+                 c2_x0(4), C2['p'])
+    else:
+        _compare(dict(hard, collocation=dict(degree=2, objective='discrete', points='legendre')), c2_x0(4), C2['p'])
+
+
 def test_c5_dae_full_horizon_vs_fixture_and_batch_properties():
     """N = 50 (the configuration's horizon), B = 3 against the oracle's solution stored by tests/golden/make_c5dae_golden.py (the
     dense oracle needs minutes for it); then B = 1024 in closed loop: every instance solved, the slack covers the limit at every
