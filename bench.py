@@ -74,11 +74,27 @@ def flops_per_iteration_survey(nx, nu, N, s=4, ops=(C_F, C_J, C_H)):
     return N * (f_ric(nx, nu) + s * (ops[0] + ops[1] + 2 * nx ** 2 * (nx + nu)))
 
 
-def pmc_traffic_bytes(tag_key, with_source=False):
+STALE_BAND = (0.75, 1.33)    # a committed profile whose kernel ran this much faster / slower than this run's is not this kernel's
+
+
+def _stale(profile_ns, kernel_ms):
+    """The counters on the line come from COMMITTED rocprofv3 passes, not from this run (a counter pass cannot share a process with the
+    timed region).  They belong to the kernel that was profiled: when this run's HIP-event time of the dominant kernel differs from the
+    profile's by more than STALE_BAND (a changed kernel, another batch size), the counters are withheld and the line says why."""
+    if profile_ns is None or kernel_ms is None or not profile_ns > 0:
+        return None
+    r = (kernel_ms * 1e6) / profile_ns
+    if r < STALE_BAND[0] or r > STALE_BAND[1]:
+        return f"withheld: the committed profile's kernel ran {profile_ns * 1e-6:.4g} ms, this run's {kernel_ms:.4g} ms - re-profile (profiles/run_round.sh)"
+    return None
+
+
+def pmc_traffic_bytes(tag_key, with_source=False, kernel_ms=None):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (profiles/rNN_<config>_summary.json:
     FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command), newest round first; None if this
-    configuration has no committed PMC pass.  Not measured in this run: `traffic_source` of the line names the file.
-    Calibration: see DESIGN.md 5 (8-byte lanes: no 2x correction)."""
+    configuration has no committed PMC pass - or if that pass profiled a kernel of another duration than this run's (`_stale`).
+    Not measured in this run: `traffic_source` of the line names the file.  Calibration: see DESIGN.md 5 (8-byte lanes: no 2x
+    correction)."""
     import glob
     import re
     best, src = None, None
@@ -92,12 +108,15 @@ def pmc_traffic_bytes(tag_key, with_source=False):
             d = json.load(open(f))
             best = (d['FETCH_SIZE_KB_per_launch']['warm_launches_mean'] + d['WRITE_SIZE_KB_per_launch']['warm_launches_mean']) * 1024
             src = f"committed profile profiles/{os.path.basename(f)} (separate --pmc passes of this command; not measured in this run)"
+            why = _stale((d.get('timed_region') or {}).get('avg_ns'), kernel_ms)
+            if why:
+                best, src = None, f"profiles/{os.path.basename(f)} {why}"
         except Exception:
             pass
     return (best, src) if with_source else best
 
 
-def pmc_issue(tag_key, kernel_key=None):
+def pmc_issue(tag_key, kernel_key=None, kernel_ms=None):
     """Issue / matrix-core counters of the dominant kernel from the COMMITTED passes of profiles/run_pmc_valu.sh (newest round first):
     (dict of derived fractions, source) or (None, None).  Files: profiles/rNN_pmc_issue_<config>.json, and for C2 / gp-predict the
     older profiles/rNN_pmc_issue.json.  `mfma_busy_frac` = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel duration in shader
@@ -118,6 +137,9 @@ def pmc_issue(tag_key, kernel_key=None):
             if 'valu_busy_frac' not in out and 'SQ_ACTIVE_INST_VALU' in d and 'SQ_WAVE_CYCLES' in d:
                 out['valu_busy_frac'] = d['SQ_ACTIVE_INST_VALU']['steady_mean'] / d['SQ_WAVE_CYCLES']['steady_mean']
             if out:
+                why = _stale(d.get('kernel_ns_under_pmc'), kernel_ms)
+                if why:
+                    return None, f"profiles/{os.path.basename(f)} {why}"
                 return out, (f"committed profile profiles/{os.path.basename(f)} (separate --pmc passes of "
                              f"`bench.py --config {tag_key}`; not measured in this run)")
         except Exception:
@@ -150,8 +172,8 @@ def _solve_roofline(kernel, B, mean_iters, nx, nu, N, ops, kern_ms, tag, n_v, n_
     tf = fl_s / (kern_ms * 1e-3) / 1e12
     bytes_launch = B * 8 * (2 * n_v + 2 * n_g + nx + n_p + nu)      # SURVEY 8d bytes_nmpc (compulsory)
     gbs = bytes_launch / (kern_ms * 1e-3) / 1e9
-    traffic, src = pmc_traffic_bytes(tag, with_source=True)
-    issue, isrc = pmc_issue(tag)
+    traffic, src = pmc_traffic_bytes(tag, with_source=True, kernel_ms=kern_ms)
+    issue, isrc = pmc_issue(tag, kernel_ms=kern_ms)
     return {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
             "traffic": traffic, "traffic_source": src, "kernel": kernel, "kernel_ms": kern_ms,
             "mfma_busy_frac": (issue or {}).get('mfma_busy_frac'), "valu_busy_frac": (issue or {}).get('valu_busy_frac'),
@@ -396,7 +418,7 @@ def cpu_leg_qp(budget=6., min_batch=4096):
     # tests/test_cpu_baseline.py) on measured states drawn like the benchmark's, all host cores and one
     from oracle.cpu import qp_solve
     from oracle.lmpc import LmpcProblem
-    from tests.test_oracle_lmpc import C1
+    from tests.problems import C1
     C, quota = host_cores()
     pb = LmpcProblem(**C1, kron_bug=False)
     nb = max(min_batch, (min_batch // 4) * C)
@@ -508,7 +530,7 @@ def wl_nmpc(cfg, args, torch, dev, rank, world):
 
 def wl_mhe(args, torch, dev, rank, world):
     from tests import problems as P
-    from tests.test_mhe_gpu import product_mhe
+    from tests.problems import product_mhe
     spec, B = P.C3B, args.batch or 4096
     xa, u, y, xt = P.c3_data(B, seed=11 + rank)
     mhe = product_mhe(spec)
@@ -604,7 +626,7 @@ def wl_kf(kind, args, torch, dev, rank, world):
         # is an equivalent bandwidth (what K separate steps would move) and is carried as the secondary figure
         roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "equivalent_achieved": gbs_eq, "equivalent_frac": gbs_eq / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes('C3-' + kind), "traffic_source": pmc_traffic_bytes('C3-' + kind, with_source=True)[1],
+                "traffic": pmc_traffic_bytes('C3-' + kind, kernel_ms=kern_ms), "traffic_source": pmc_traffic_bytes('C3-' + kind, with_source=True, kernel_ms=kern_ms)[1],
                 # csrc/hilo_kf.hip::use_team: a team of lanes per instance (4 for the EKF's Jacobian columns, 16 for the UKF's 9
                 # sigma points) up to two waves per SIMD of teams, one instance per lane beyond
                 "kernel": (f"kf_team_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}>"
@@ -654,9 +676,9 @@ def wl_gp(args, torch, dev, rank, world):
         tf = m * fl_q / (kern_ms * 1e-3) / 1e12
         by = m * 8 * (nf + 2)
         roof = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
-                "traffic": pmc_traffic_bytes('gp-predict'), "traffic_source": pmc_traffic_bytes('gp-predict', with_source=True)[1], "kernel": "gp_predict_kernel", "kernel_ms": kern_ms,
-                "mfma_busy_frac": (pmc_issue('gp-predict', 'gp_predict_reg_kernel')[0] or {}).get('mfma_busy_frac'),
-                "mfma_busy_frac_source": pmc_issue('gp-predict', 'gp_predict_reg_kernel')[1],
+                "traffic": pmc_traffic_bytes('gp-predict', kernel_ms=kern_ms), "traffic_source": pmc_traffic_bytes('gp-predict', with_source=True, kernel_ms=kern_ms)[1], "kernel": "gp_predict_kernel", "kernel_ms": kern_ms,
+                "mfma_busy_frac": (pmc_issue('gp-predict', 'gp_predict_reg_kernel', kernel_ms=kern_ms)[0] or {}).get('mfma_busy_frac'),
+                "mfma_busy_frac_source": pmc_issue('gp-predict', 'gp_predict_reg_kernel', kernel_ms=kern_ms)[1],
                 "note": "fp64 compute roof: flops per query = n (3 nf + 20) + 2 n (mean) + n^2 (|L^-1 k*|^2), n = 200; "
                         "compulsory HBM traffic is 8 (nf + 2) bytes per query (arithmetic intensity ~1400 flop/B)",
                 "hbm": {"achieved": by / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -672,7 +694,7 @@ def wl_gp(args, torch, dev, rank, world):
 
 
 def wl_lmpc(args, torch, dev, rank, world):
-    from tests.test_lmpc_gpu import product_lmpc
+    from tests.problems import product_lmpc
     B = args.batch or 1024
     mpc = product_lmpc('corrected')
     rng = np.random.default_rng(20260926 + rank)
@@ -716,7 +738,7 @@ def wl_lmpc(args, torch, dev, rank, world):
             b.record()
         torch.cuda.synchronize(dev)
         roof = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
-                "traffic": pmc_traffic_bytes('C1'), "traffic_source": pmc_traffic_bytes('C1', with_source=True)[1],
+                "traffic": pmc_traffic_bytes('C1', kernel_ms=kern_ms), "traffic_source": pmc_traffic_bytes('C1', with_source=True, kernel_ms=kern_ms)[1],
                 "kernel": "qp_ocp_kernel<2, 1, 16>" if staged else "qp_solve_reg_kernel<32, 24>", "kernel_ms": kern_ms,
                 "flops_per_iteration": fl_it,
                 "note": ("Mehrotra predictor-corrector with the Newton step by a Riccati recursion over the 10 stages (a stage per "
@@ -747,6 +769,39 @@ def build_workload(cfg, args, torch, dev, rank, world):
     if cfg == 'gp-predict':
         return wl_gp(args, torch, dev, rank, world)
     return wl_lmpc(args, torch, dev, rank, world)
+
+
+def timed_region(wl, warmup, steps, world, dev):
+    """The driver's contract: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier + device synchronisation on both
+    sides; the time is the MAX over the ranks, the units the SUM of what the ranks processed per step.  Returns (elapsed seconds,
+    units per step of the whole job).  (Its own function so that the world-2 gloo test of tests/test_dist_cpu.py drives THIS loop -
+    with a stub controller on CPU tensors - and not a copy of it.)"""
+    import torch
+    import torch.distributed as dist
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        if dev.type == 'cuda':
+            torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        wl['step'](False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl['step'](True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    units = float(wl['units'])
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([units], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        units = float(tot.item())
+    return elapsed, units
 
 
 def respawn(args):
@@ -796,22 +851,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        wl['step'](False)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl['step'](True)
-    sync()
-    elapsed = time.perf_counter() - t0
-    units = float(wl['units'])
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        tot = torch.tensor([units], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        units = float(tot.item())
+    elapsed, units = timed_region(wl, args.warmup, args.steps, world, dev)
     extra, roof, scaling = wl['finish']()
     # the headline configuration's value moves with how far the closed loop has settled (fewer interior-point iterations per step
     # later on): the SAME loop continued for 50 more steps, timed the same way, is reported next to the driver's command

@@ -119,7 +119,7 @@ struct NmpcUser {
   // interval's system TOGETHER (hilo_colloc.h::CoopLU: one column per lane, in registers) and the derivatives come from the
   // implicit-function theorem instead of Taylor sweeps through the Newton iteration (coll_pass below):
   //     XC    per interval in the workspace: [X (DNC) | the x, u slots they belong to (NWD)]  - written by the values pass
-  //     PREP  per interval: [X (DNC) | dX/dw, one column per model direction (NWD x DNC) | kappa (DNC) | x the block belongs to]
+  //     PREP  per interval: [X (DNC) | dX/dw, one column per model direction (NWD x DNC) | kappa (DNC) | x, u the block belongs to (NWD)]
   // Lanes of a group: one per column of the Newton matrix; the right-hand sides (NWD tangents + the Newton residual) ride as a
   // SECOND column in the first lanes when there are no more of them than matrix columns (CTWO: three intervals of configuration
   // 5's 21 x 21 systems per pass of the wave), else in lanes of their own behind the matrix lanes.
@@ -139,7 +139,7 @@ struct NmpcUser {
 #ifdef HILO_USER_NO_PREP   // developer knob (tools/dbg/c5dae_prep.py): every Taylor direction solves the collocation system itself
   static constexpr int PREP = 0;
 #else
-  static constexpr int PREP = COOP_COLL ? DNC * (NWD + 2) + (M::NX + C::NTH) : ((C::COLL_D > 0 && C::BIG) ? DNC * (1 + DNC) : 0);
+  static constexpr int PREP = COOP_COLL ? DNC * (NWD + 2) + NWD : ((C::COLL_D > 0 && C::BIG) ? DNC * (1 + DNC) : 0);
 #endif
   static constexpr bool QUAD_COST = false;
   static constexpr UserLayout L = UserLayout(MX, MU, NTH, NE, F::NPS, F::NPT, NQ, NPSI, C::N);
@@ -324,7 +324,7 @@ struct NmpcUser {
   // Phi + sum_j kappa_j^T f(X_j, u), kappa_j = dt sum_i A_ij y_i, along the STRAIGHT line (X + t X_w dir, w + t dir): the curvature
   // of X(w) drops out against the stationarity of the Lagrangian in X.  The direction tasks (dyn_cost_impl) therefore sweep model,
   // cost and rows once, with no linear solve, where they swept the Newton iteration twice with two substitutions each.
-  // `from_prep` (values pass of a trial point): start from the iterate's states moved by the change of the interval's initial state
+  // `from_prep` (values pass of a trial point): start from the first-order prediction off the iterate's states and tangents
   template <bool DERIV, class ZP, class LP, class NUP, class XP, class PP>
   __device__ __forceinline__ static void coll_pass(const OcpConst& pc, const double* par, const double* sd0, ZP Z, LP lam, NUP cnu,
                                                    int N, XP xc, PP prep, lds_double* stage, bool from_prep = false) {
@@ -380,7 +380,15 @@ struct NmpcUser {
       if (is_mat) {
         double x0c = xa;
         if constexpr (DERIV) { if (warm) x0c = xc[(size_t)kk * XCW + c]; }
-        else if (from_prep) x0c = prep[(size_t)kk * PREP + c] + (xa - prep[(size_t)kk * PREP + DNC * (NWD + 2) + a]);
+        else if (from_prep) {
+          // first-order prediction from the iterate's states and tangents: X(w + dw) = X + X_w dw + O(dw^2)
+          x0c = prep[(size_t)kk * PREP + c];
+#pragma unroll
+          for (int w = 0; w < NWD; ++w) {
+            const double wv = w < MXA ? xp[w < MXA ? w : 0] : up[w >= MXA ? w - MXA : 0];
+            x0c = fma(prep[(size_t)kk * PREP + DNC + w * DNC + c], wv - prep[(size_t)kk * PREP + DNC * (NWD + 2) + w], x0c);
+          }
+        }
         Xs[c] = x0c;
       }
       __syncthreads();
@@ -511,6 +519,12 @@ struct NmpcUser {
             prep[(size_t)kk * PREP + c] = Xs[c];
             prep[(size_t)kk * PREP + DNC * (1 + NWD) + c] = kap;
             if (j == 0) prep[(size_t)kk * PREP + DNC * (NWD + 2) + a] = xa;
+            if (j == 0 && a < MUA) {
+              double ua = 0.0;
+#pragma unroll
+              for (int b = 0; b < MUA; ++b) ua = a == b ? up[b] : ua;
+              prep[(size_t)kk * PREP + DNC * (NWD + 2) + MXA + a] = ua;
+            }
           }
           if (is_tan) {
 #pragma unroll
@@ -815,7 +829,12 @@ struct NmpcUser {
         for (int r = 0; r < NQ; ++r) {
           T sacc = xn[MXA + NE + r];
 #pragma unroll
-          for (int j = 0; j < NPSI; ++j) sacc = sacc + pc.cost[L.o_acc + (r * (pc.N + 1) + pc.N) * NPSI + j] * ps[j];
+          for (int j = 0; j < NPSI; ++j) {
+            // SELECTED, not multiplied: an expression of an input is evaluated here at a value it was never meant for (x / u, log u:
+            // inf or NaN), and 0 * NaN would poison the row
+            const double cf = pc.cost[L.o_acc + (r * (pc.N + 1) + pc.N) * NPSI + j];
+            if (cf != 0.0) sacc = sacc + cf * ps[j];
+          }
           val[r] = sacc;
         }
 #pragma unroll
@@ -847,7 +866,10 @@ struct NmpcUser {
 #pragma unroll
         for (int m = 0; m < (NC > 0 ? NC : 1); ++m) nu = (m < NC && m == pc.nc + pc.nc_term - NQ + r) ? nuN[m] : nu;
 #pragma unroll
-        for (int j = 0; j < NPSI; ++j) s -= nu * pc.cost[L.o_acc + (r * (pc.N + 1) + pc.N) * NPSI + j] * ps[j].a;
+        for (int j = 0; j < NPSI; ++j) {
+          const double cf = pc.cost[L.o_acc + (r * (pc.N + 1) + pc.N) * NPSI + j];
+          if (cf != 0.0) s -= nu * cf * ps[j].a;       // (selected: see term_rows)
+        }
       }
       return s;
     } else {
@@ -883,7 +905,8 @@ struct NmpcUser {
     if (e >= batch * N) return;
     const int64_t b = e / N;
     const int k = (int)(e - b * N);
-    const int n_head = (N + 1) * MXA + Nc * MUA, n_vc = n_head + NE, n_zn = (N + 1) * NZA, nv = n_vc + n_zn + N * DB;
+    // (rows of vc and v carry the accumulators of custom constraint rows as hidden tail entries behind the slacks, hilo_nmpc_user.hip)
+    const int n_head = (N + 1) * MXA + Nc * MUA, n_vc = n_head + NE + NQ, n_zn = (N + 1) * NZA, nv = n_vc + n_zn + N * DB;
     const int ncc = NC > 0 ? pc.nc : 0, ntc = NC > 0 ? pc.nc_term : 0;       // the engine's rows (compact)
     const int nrow = ROWS ? (int)pc.cost[L.o_nrow] : 0;                       // rows per point
     const int R = ROWS ? (int)pc.cost[L.o_ncr] : 0, TR = NC > 0 ? (int)pc.cost[L.o_ntr] : 0;   // ... in the reference's g
@@ -913,6 +936,9 @@ struct NmpcUser {
 #pragma unroll
     for (int i = 0; i < NE; ++i)
       if (k == 0) out[n_head + n_zn + N * DB + i] = row[n_head + i];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)      // q_{r,0} = 0: the next warm start reads the pinned value from here
+      if (k == 0) out[n_head + n_zn + N * DB + NE + i] = 0.0;
 #pragma unroll
     for (int i = 0; i < DD; ++i)
 #pragma unroll

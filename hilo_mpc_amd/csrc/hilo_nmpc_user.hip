@@ -153,7 +153,7 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   // Newton matrix (hilo_colloc.h::prepare); one interval's block is staged in LDS
   const int dnc = D * (mx + nth), nwd = mx + mu + 2 * nth;
   const bool coop = big && D && (nwd + 1 <= dnc ? dnc : dnc + nwd + 1) <= 64 && mua <= mxa;
-  const size_t prep_w = !(big && D) ? 0 : (coop ? (size_t)dnc * (nwd + 2) + (mx + nth) : (size_t)dnc * (1 + dnc));
+  const size_t prep_w = !(big && D) ? 0 : (coop ? (size_t)dnc * (nwd + 2) + nwd : (size_t)dnc * (1 + dnc));
   const size_t xc_w = coop ? (size_t)(dnc + nwd) : 0;
   fixed_b += prep_w * (coop ? 3 : 1) * sizeof(double);   // (Ocp::PREPB blocks staged at a time)
   if (fixed_b > 160 * 1024) return fail(HILO_ENOTSUP, "horizon %d needs %zu B of LDS for the problem constants alone", N, fixed_b);

@@ -331,7 +331,10 @@ struct Ocp {
   static constexpr bool FUSED_CON = pb_fused_con<PB>::value;   // dyn_cost_con(): ... and the inequality rows
   static constexpr int PREP = pb_prep<PB>::value;              // per-interval data prepared once per derivative evaluation
   static constexpr int XCW = pb_xcw<PB>::value;                // > 0: cooperative collocation (PB::coll_pass, PB::dyn_cost_xc)
-  static constexpr int PREPB = XCW > 0 ? 3 : 1;                // per-interval blocks staged in LDS at a time
+#ifndef HILO_OCP_PREPB
+#define HILO_OCP_PREPB 3
+#endif
+  static constexpr int PREPB = XCW > 0 ? HILO_OCP_PREPB : 1;   // per-interval blocks staged in LDS at a time
   // model derivatives as generated straight-line code (ModelSym<PB::Model>, csrc/hilo_models_sym.h / codegen): second-order
   // adjoint through the Runge-Kutta stages instead of Taylor sweeps per direction pair (eval_derivs_sym)
   static constexpr bool SYM = pb_sym<PB>::value;

@@ -37,7 +37,12 @@ def _key(e):
         return repr(float(e.value))
     if not e.args:
         return f"{e.op}:{getattr(e, 'name', '')}:{e.value!r}"
-    return f"{e.op}[{e.value!r}](" + ','.join(_key(a) for a in e.args) + ')'
+    keys = [_key(a) for a in e.args]
+    if e.op in ('add', 'mul'):
+        keys.sort()                        # commutative: x * u and u * x are the same stage expression
+    elif e.op == 'sq':
+        return 'mul[None](' + keys[0] + ',' + keys[0] + ')'      # x ** 2 (expr.py: `sq`) and x * x
+    return f"{e.op}[{e.value!r}](" + ','.join(keys) + ')'
 
 
 def _terms(e):
@@ -131,5 +136,6 @@ def decompose(fun, x_ind, u_ind, n_v, model, n_rows=None):
             coef[r, k, keys[key]] += c
     if any(p.depends_on('u') for p in psi):
         j_u = [j for j, p in enumerate(psi) if p.depends_on('u')]
-        assert not np.any(coef[:, N, j_u]), "an input of stage N cannot appear (there is none in v)"
+        if np.any(coef[:, N, j_u]):
+            raise ValueError("the custom constraint reads an input of stage N: there is none in v")
     return psi, coef[:, :, :max(1, len(psi))] if psi else coef[:, :, :1], const

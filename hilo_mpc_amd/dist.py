@@ -138,6 +138,19 @@ class ClosedLoop:
             self.x = self.ctl.plant_step(self.x, u, cp=self.p)
         return self.last
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.detach()
+        return False
+
+    def __del__(self):                      # a loop that goes away must not leave its buffers attached to the controller
+        try:
+            self.detach()
+        except Exception:                   # noqa: BLE001  (interpreter shutdown: the library may be gone)
+            pass
+
     def detach(self):
         """Give the controller back (its solve stops writing into this loop's buffers)."""
         if self.fused_plant:

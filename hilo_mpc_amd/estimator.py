@@ -106,6 +106,8 @@ class _KalmanFilter:
             desc.user_source = self._user_source.encode()
             # learned terms (Model.substitute_from): the trained GPs behind hilo_user_gp[k] of the source, like the controllers'
             gps = list(getattr(m, '_gps', None) or [])
+            if len(gps) > 4:
+                raise NotImplementedError(f"a filter model with {len(gps)} learned terms: at most 4 are offloaded (hilo_kf_desc.user_gp)")
             desc.n_user_gp = len(gps)
             for k, g in enumerate(gps):
                 # (compile-only mode never dereferences the handles: any non-NULL value)

@@ -1000,7 +1000,7 @@ class NMPC:
             d.coll_B = hp(coll['B'])
         d.objective_continuous = int(cont)
         # ---- custom constraint function over the whole decision vector (hilo_mpc_amd/custom.py): accumulator states + terminal rows
-        acc_psi, self._nq, self._custom_const = (), 0, None
+        acc_psi, acc_term, self._nq, self._custom_const = (), (), 0, None
         if getattr(self, '_custom_constraint_flag', False):
             from .custom import decompose
             if getattr(self, '_minimize_final_time_flag', False):
@@ -1018,6 +1018,9 @@ class NMPC:
             if any(e.depends_on('theta') for e in acc_psi):
                 raise NotImplementedError("a custom constraint on the path variable is not offloaded")
             self._nq, self._custom_const = mc, const
+            # stage expressions with a coefficient at stage N act on the integrated END state x_N = F(x_{N-1}, u_{N-1}): their second
+            # derivatives reach the last interval's Hessian through the dynamics (J_F^T psi'' J_F)
+            acc_term = tuple(acc_psi[j] for j in range(len(acc_psi)) if np.any(np.asarray(coef)[:, N, j] != 0.))
             d.n_acc, d.n_acc_expr = mc, len(acc_psi)
             d.acc_coef = hp(np.ascontiguousarray(coef, dtype=np.float64).ravel())
             d.acc_lb = hp(np.asarray(self._custom_constraint_fun_lb) - const)
@@ -1055,7 +1058,8 @@ class NMPC:
                 d.path_prog, d.path_prog_len = None, 0          # expressions are compiled in, not interpreted
                 d.con_prog, d.con_prog_len, d.tcon_prog, d.tcon_prog_len = None, 0, None, 0
                 pat = self._hessian_pattern(m, nx, nu, nth, Wz, Wdu if has_du else None, gen_stage, sc, tc,
-                                            composed=bool(cont or coll is not None), extra=[m.z[a] for a in zb] + list(acc_psi))
+                                            composed=bool(cont or coll is not None), extra=[m.z[a] for a in zb] + list(acc_psi),
+                                            extra_composed=list(acc_term))
                 if pat is not None:
                     pat = np.ascontiguousarray(pat, dtype=np.uint8)
                     keep.append(pat)
@@ -1206,6 +1210,17 @@ class NMPC:
                 warnings.warn("You are passing a parameter vector in the optimizer, but the model has no defined "
                               "parameters. I am ignoring the vector.")
             p, ps = None, 0
+        pt = getattr(self, '_plant_table', None)
+        if pt is not None:
+            # the solve advances the attached plant state in place (set_plant_buffer): only the loop that attached it may call
+            rows = pt.reshape(-1, self._n_x).shape[0]
+            if rows != B:
+                raise ValueError(f"optimize() for {B} instance(s) while a plant buffer of {rows} row(s) is attached "
+                                 f"(set_plant_buffer): the solve would write x+ of instance b to row b of that buffer. Detach it "
+                                 f"with set_plant_buffer(None) first.")
+            if kwargs.get('_in_multi_start'):
+                raise ValueError("optimize(runs > 0) solves several times and would advance the attached plant state (set_plant_buffer) "
+                                 "once per run. Detach it with set_plant_buffer(None) first.")
         v0t = None
         wo = getattr(self, '_warm_override', None)          # best run of a multi-start call: the next call's start vector
         self._warm_override = None
@@ -1296,7 +1311,7 @@ class NMPC:
             return u.reshape(-1, 1) if single else u     # single instance: (nu x 1) like the reference's DM
         return u0[0] if single else u0
 
-    def _hessian_pattern(self, m, nx, nu, nth, Wz, Wdu, gen_stage, sc, tc, composed=False, extra=()):
+    def _hessian_pattern(self, m, nx, nu, nth, Wz, Wdu, gen_stage, sc, tc, composed=False, extra=(), extra_composed=()):
         """Structural sparsity of the interval Hessian over the augmented z = [x, theta | u, u_theta] (hilo_mpc_amd/sparsity.py),
         or None (dense) when the model has no expression form."""
         from . import zoo_expr
@@ -1340,7 +1355,7 @@ class NMPC:
         # multiplier-weighted second derivatives belong to the interval Hessian like those of any other row)
         exprs = [gen_stage] + (list(sc.constraint) if sc.is_set else []) + (list(tc.constraint) if tc.is_set and tc.is_soft else []) + \
             list(extra)
-        exprs_c = list(tc.constraint) if tc.is_set and not tc.is_soft else []
+        exprs_c = (list(tc.constraint) if tc.is_set and not tc.is_soft else []) + list(extra_composed)
         if elim is not None:
             exprs = [None if e is None else Expr.substitute([Expr.wrap(e)], elim)[0] for e in exprs]
             exprs_c = [Expr.substitute([Expr.wrap(e)], elim)[0] for e in exprs_c]

@@ -204,20 +204,77 @@ C3 = dict(model='chemostat4', dt=.25, N=30, order=4, Wx=[4.] * 4, Wy=[16.] * 2, 
 C3B = dict(C3, w_lb=[-1e-3] * 4, w_ub=[1e-3] * 4)
 
 
+def chemostat4_rk4(x, u, p, dt):
+    """One classic Runge-Kutta step of the benchmark's chemostat (`ecoli_D1210_conti('simple')` with the rates of the
+    'complex' variant, library/models.py:143-198) in plain numpy - the synthetic truth of the estimator workloads.  (Plain numpy so
+    that building a workload needs nothing of `oracle/`; the same right-hand side as oracle/models.py::chemostat4 and the product's
+    zoo functor, which tests/test_oracle_mhe.py checks.)"""
+    Sf, If, ISF, IRF = (np.asarray(p, dtype=float) + np.zeros((x.shape[0], 4))).T
+
+    def f(x):
+        X, S, P, I = x.T
+        DS, DI = u.T
+        phi = 0.407 * S / (0.108 + S + S ** 2 / 14814.0)
+        mu = phi * (ISF + 0.22 * IRF / (0.22 + I))
+        Rfp = phi * (0.0005 + I) / (0.022 + I)
+        D = DS + DI
+        return np.stack([mu * X - D * X, -2 * mu * X - D * S + DS * Sf, Rfp * X - D * P, -D * I + DI * If], axis=1)
+    k1 = f(x)
+    k2 = f(x + .5 * dt * k1)
+    k3 = f(x + .5 * dt * k2)
+    k4 = f(x + dt * k3)
+    return x + dt / 6. * (k1 + 2 * k2 + 2 * k3 + k4)
+
+
+def product_mhe(spec, **solver_options):
+    """The product's moving-horizon estimator for a spec of this module (C3 / C3B) through the reference-style API
+    (the pattern of tests/test_MHE.py:403-409)."""
+    from hilo_mpc_amd import MHE, Model
+    m = Model(spec['model']).discretize('erk', order=spec.get('order', 4)).setup(dt=spec['dt'])
+    mhe = MHE(m)
+    mhe.quad_arrival_cost.add_states(weights=list(spec['Wx']), guess=spec['x_guess'])
+    mhe.quad_stage_cost.add_measurements(weights=list(spec['Wy']))
+    mhe.quad_stage_cost.add_state_noise(weights=list(spec['Ww']))
+    mhe.horizon = spec['N']
+    mhe.set_box_constraints(x_lb=spec.get('x_lb'), x_ub=spec.get('x_ub'), w_lb=spec.get('w_lb'), w_ub=spec.get('w_ub'),
+                            p_lb=spec['p'], p_ub=spec['p'])
+    mhe.set_initial_guess(x_guess=spec['x_guess'])
+    if spec.get('x_scaling') or spec.get('w_scaling') or spec.get('u_scaling'):
+        mhe.set_scaling(x_scaling=spec.get('x_scaling'), w_scaling=spec.get('w_scaling'), u_scaling=spec.get('u_scaling'))
+    mhe.setup(options={'integration_method': 'discrete'}, nlp_opts=solver_options or None)
+    return mhe
+
+
+# ---- C1: LMPC on the discrete double integrator (tests/test_LMPC.py:8-33), SURVEY.md 8d ---------------------------------------
+LMPC_DT = .5
+LMPC_A = np.array([[1., LMPC_DT], [0., 1.]])                 # tests/test_LMPC.py:14-15
+LMPC_B = np.array([[LMPC_DT ** 2 / 2], [LMPC_DT]])
+C1 = dict(A=LMPC_A, B=LMPC_B, N=10, Q=np.eye(2), R=[[1.]], x_lb=[-5, -5], x_ub=[5, 5], u_lb=[-1], u_ub=[1])
+
+
+def product_lmpc(kron_variant, N=10, Q=None):
+    from hilo_mpc_amd import LMPC, Model
+    m = Model('lti', A=LMPC_A, B=LMPC_B).setup(dt=LMPC_DT)     # tests/test_LMPC.py:8-19
+    mpc = LMPC(m)
+    mpc.Q = np.eye(2) if Q is None else Q
+    mpc.R = 1
+    mpc.horizon = N
+    mpc.set_box_constraints(x_lb=[-5, -5], x_ub=[5, 5], u_lb=[-1], u_ub=[1])
+    mpc.setup(kron_variant=kron_variant)
+    return mpc
+
+
 def c3_data(B, N=30, seed=SEED):
     """Truth simulated with the RK4 map from perturbed initial states under slowly varying inputs, measurements
     y = (X, P) + N(0, 1e-2).  Returns x_arrival [B,4], u_meas [B,N,2], y_meas [B,N,2], x_true [B,N+1,4]."""
-    from oracle import models
-    from oracle.shooting import ShootingMap
     rng = np.random.default_rng(seed)
-    sm = ShootingMap(models.get('chemostat4'), 4)
     x = np.array([.1, 40., 0.05, 0.05]) * (1 + .1 * rng.uniform(-1, 1, (B, 4)))
     xs = [x]
     u = np.empty((B, N, 2))
     for k in range(N):
         u[:, k, 0] = .05 + .03 * np.sin(.3 * k + rng.uniform(0, 6.28, B))
         u[:, k, 1] = .02 + .01 * np.cos(.2 * k + rng.uniform(0, 6.28, B))
-        x = sm.value(x, u[:, k], C3['p'], C3['dt'])
+        x = chemostat4_rk4(x, u[:, k], C3['p'], C3['dt'])
         xs.append(x)
     xt = np.stack(xs, axis=1)
     y = xt[:, :N][:, :, [0, 2]] + .01 * rng.normal(size=(B, N, 2))

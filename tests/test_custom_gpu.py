@@ -134,3 +134,54 @@ def test_the_reference_test_case_under_the_default_collocation():
     lam = nmpc._nlp_solution['lam_g'].cpu().numpy()
     assert lam[0, -1] > 1e-3
     assert float(nmpc._nlp_solution['f'][0]) > float(free._nlp_solution['f'][0])
+
+
+def test_collocation_custom_row_in_a_batch_and_across_warm_started_calls():
+    """The same problem for THREE instances and two consecutive calls: the output pass of the collocation transcription addresses
+    the engine's compact rows and the rows of `v` per instance - both carry the accumulator of the custom row as a hidden tail entry
+    - and the second call warm-starts from `v`, whose hidden entry pins the accumulator's start value (round-5 advisor finding: with
+    the tail left out of the row lengths, every instance behind the first read shifted rows, and the second call started the
+    accumulator from uninitialised memory).  Every instance must reproduce its own single-instance solve, in both calls."""
+    from hilo_mpc_amd import NMPC, Model
+    from hilo_mpc_amd.expr import cos, sin
+    M, m_, l_, g_ = 5., 1., 1., 9.81
+    model = Model()
+    x = model.set_dynamical_states(['x', 'v', 'theta', 'omega', 'dummy'])
+    F = model.set_inputs(['F', 'u_dummy'])
+    v, theta, omega = x[1], x[2], x[3]
+    dv = 1. / (M + m_ - m_ * cos(theta)) * (m_ * g_ * sin(theta) - m_ * l_ * sin(theta) * omega ** 2 + F[0])
+    model.set_dynamical_equations([v, dv, omega, 1. / l_ * (dv * cos(theta) + g_ * sin(theta)), F[1]])
+    dt = .1
+    model.setup(dt=dt)
+    X0 = np.array([[2.5, 0., 1.5, 0., 0.], [2.4, .1, 1.4, .1, 0.], [2.6, -.1, 1.6, -.1, 0.]])
+
+    def build():
+        nmpc = NMPC(model)
+        nmpc.quad_stage_cost.add_states(names=['theta', 'dummy'], ref=[np.pi, 10], weights=[np.pi, 10])
+        nmpc.horizon = 10
+        nmpc.set_box_constraints(x_ub=[3, 0.5, 10, 10, 10000], x_lb=[2, -0.5, -10, -10, 0])
+        nmpc.set_initial_guess(x_guess=list(X0[0]), u_guess=[0., 0.])
+        nmpc.set_custom_constraints_function(lambda v, xi, ui: _trapezoid(4, dt)(v, xi, ui), ub=4, lb=0)
+        nmpc.setup()
+        return nmpc
+
+    def integral(nmpc):
+        x_opt, _, _ = nmpc.return_prediction()
+        return ((x_opt[:, 4, :-1] + x_opt[:, 4, 1:]) / 2 * dt).sum(axis=1)
+    single = []
+    for b in range(3):
+        one = build()
+        one.optimize(X0[b])
+        assert one.solver_status_code[0] == 1
+        single.append((one._nlp_solution['x'].cpu().numpy()[0], one._nlp_solution['lam_g'].cpu().numpy()[0]))
+    nmpc = build()
+    for call in range(2):
+        nmpc.optimize(X0)
+        assert np.all(nmpc.solver_status_code == 1)
+        np.testing.assert_allclose(integral(nmpc), 4., atol=1e-6)
+        vb, lb = nmpc._nlp_solution['x'].cpu().numpy(), nmpc._nlp_solution['lam_g'].cpu().numpy()
+        assert np.all(np.isfinite(vb)) and np.all(np.isfinite(lb))
+        for b in range(3):
+            assert np.max(np.abs(vb[b] - single[b][0]) / np.maximum(1., np.abs(single[b][0]))) < 1e-6, (call, b)
+            assert np.max(np.abs(lb[b] - single[b][1]) / np.maximum(1., np.abs(single[b][1]))) < 2e-5, (call, b)
+    assert np.all(nmpc._nlp_solution['iter_count'].cpu().numpy() <= 12)            # the second call started at the solution

@@ -174,3 +174,54 @@ def test_closed_loop_with_the_plant_advanced_by_the_solve():
     assert cf.plant_calls == 0 and cp.plant_calls == 4 and torch.equal(x0, keep)
     fused.detach()
     assert cf.x_next is None and cf.table is None and not fused.fused_plant        # the controller is its own again
+
+
+def _bench_worker(rank, world, port, B, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from hilo_mpc_amd.dist import ClosedLoop
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    nx, nu = 3, 2
+    lo, hi = shard_range(B, rank, world)
+    x0 = torch.as_tensor(np.random.default_rng(0).uniform(-2, 2, (B, nx)))[lo:hi].clone()
+    loop = ClosedLoop(_StubController(nx, nu, True), B, nu, rank, world, torch.device('cpu'), x0, p=torch.tensor([.25]))
+    seen = []
+
+    def step(timed):
+        g = loop.step()
+        seen.append((bool(timed), g.u0.numpy().copy()))
+    wl = dict(step=step, units=hi - lo)
+    elapsed, units = bench.timed_region(wl, 2, 4, world, torch.device('cpu'))
+    if rank == 0:
+        out.put((elapsed, units, [t for t, _ in seen], seen[-1][1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_timed_region_world2_gloo():
+    """`bench.py`'s OWN timed loop (bench.timed_region: W untimed steps, K timed steps between barriers, MAX of the times, SUM of the
+    units) driven by two gloo ranks with uneven shards and the stub controller: exactly W + K steps, the units of the whole job, and
+    the last gathered table equal to the single-process closed loop's."""
+    from hilo_mpc_amd.dist import ClosedLoop
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    B, world, nx, nu = 11, 2, 3, 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    elapsed, units, timed, u_last = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert units == B and elapsed > 0. and timed == [False, False, True, True, True, True]
+    x0 = torch.as_tensor(np.random.default_rng(0).uniform(-2, 2, (B, nx)))
+    one = ClosedLoop(_StubController(nx, nu, False), B, nu, 0, 1, torch.device('cpu'), x0.clone(), p=torch.tensor([.25]))
+    for _ in range(6):
+        u, _, _ = one.step()
+    np.testing.assert_array_equal(u_last, u.numpy())

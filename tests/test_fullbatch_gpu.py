@@ -1,0 +1,85 @@
+"""The BASELINE batches are parity-CHECKED, not only property-checked: the product solves the configuration's full batch (C2: 1024,
+C3-MHE: 4096, C5: 1024 instances per GPU) in one launch, and a random subset of 32 instances of THAT launch is compared with the
+oracle's solution of the same instances (round-5 review: the oracle comparisons ran at B = 3 .. 16 only).  The oracle's numbers for
+the subsets are fixtures (tests/golden/fullbatch_*.json, written by tests/golden/make_fullbatch_golden.py from the functions below:
+the dense oracle needs minutes for 32 instances of C5's 50 intervals); HILO_RECOMPUTE_GOLDEN=1 recomputes them in the test.
+Tolerances: those of the small-batch tests of each configuration (v 1e-6 / 5e-5 relative, objective 1e-8, status codes exact)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.problems import C2, C3, C3B, C5, c2_x0, c3_data, c5_x0, oracle_gen, oracle_mhe, oracle_problem, product_gen, product_nmpc   # noqa: E402
+from tests.util import golden_or_compute                                                                                              # noqa: E402
+
+NSUB = 32
+
+
+def subset(B, seed):
+    return np.sort(np.random.default_rng(seed).choice(B, NSUB, replace=False))
+
+
+def oracle_c2():
+    from oracle.nmpc import DenseIpm
+    sel = subset(1024, 21)
+    ipm = DenseIpm(oracle_problem(C2))
+    ref = ipm.solve(c2_x0(1024)[sel], C2['p'])
+    return dict(sel=sel, v=ipm.to_v(ref), f=ref['f'], u0=ref['u0'], status=ref['status'], iters=ref['iters'])
+
+
+def oracle_c3():
+    from oracle.mhe import MheIpm
+    sel = subset(4096, 22)
+    xa, u, y, _ = c3_data(4096, seed=11)
+    ref = MheIpm(oracle_mhe(C3B)).solve(xa[sel], C3['p'], u[sel], y[sel])
+    return dict(sel=sel, v=ref['v'], f=ref['f'], x_opt=ref['x_opt'], status=ref['status'], iters=ref['iters'])
+
+
+def oracle_c5():
+    from oracle.nmpc_gen import GenIpm
+    sel = subset(1024, 23)
+    ipm = GenIpm(oracle_gen(C5))
+    ref = ipm.solve(c5_x0(1024)[sel], [])
+    return dict(sel=sel, v=ipm.to_v(ref), f=ref['f'], u0=ref['u0'], status=ref['status'], iters=ref['iters'])
+
+
+def test_c2_subset_of_the_1024_batch_vs_oracle():
+    g = golden_or_compute('fullbatch_c2', oracle_c2)
+    sel = np.asarray(g['sel'])
+    nmpc = product_nmpc(C2)
+    u = nmpc.optimize(c2_x0(1024), cp=C2['p'])
+    assert np.all(g['status'] == 1) and np.array_equal(nmpc.solver_status_code[sel], g['status'])
+    v = nmpc._nlp_solution['x'].cpu().numpy()[sel]
+    assert np.max(np.abs(v - g['v']) / np.maximum(1., np.abs(g['v']))) < 1e-6
+    np.testing.assert_allclose(u[sel], g['u0'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy()[sel], g['f'], rtol=1e-8)
+    assert np.all(nmpc.stats()['kkt_error'] <= 1e-8)
+
+
+def test_c3_mhe_subset_of_the_4096_batch_vs_oracle():
+    import torch
+    from tests.problems import product_mhe
+    g = golden_or_compute('fullbatch_c3', oracle_c3)
+    sel = np.asarray(g['sel'])
+    xa, u, y, _ = c3_data(4096, seed=11)
+    mhe = product_mhe(C3B)
+    for k in range(C3['N']):
+        mhe.add_measurements(torch.as_tensor(y[:, k], device='cuda'), torch.as_tensor(u[:, k], device='cuda'))
+    x, _ = mhe.estimate(x_arrival=torch.as_tensor(xa, device='cuda'))
+    assert np.all(g['status'] == 1) and np.array_equal(mhe.solver_status_code[sel], g['status'])
+    v = mhe._nlp_solution['x'].cpu().numpy()[sel]
+    assert np.max(np.abs(v - g['v']) / np.maximum(1., np.abs(g['v']))) < 1e-5
+    np.testing.assert_allclose(mhe._nlp_solution['f'].cpu().numpy()[sel], g['f'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(x.cpu().numpy()[sel], g['x_opt'], rtol=1e-5, atol=1e-6)
+
+
+def test_c5_subset_of_the_1024_batch_vs_oracle():
+    g = golden_or_compute('fullbatch_c5', oracle_c5)
+    sel = np.asarray(g['sel'])
+    nmpc = product_gen(C5)
+    u = nmpc.optimize(c5_x0(1024))
+    assert np.all(g['status'] == 1) and np.array_equal(nmpc.solver_status_code[sel], g['status'])
+    v = nmpc._nlp_solution['x'].cpu().numpy()[sel]
+    assert np.max(np.abs(v - g['v']) / np.maximum(1., np.abs(g['v']))) < 5e-5
+    np.testing.assert_allclose(u[sel], g['u0'], rtol=5e-5, atol=5e-5)
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy()[sel], g['f'], rtol=1e-8, atol=1e-10)

@@ -5,22 +5,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle.lmpc import LmpcProblem, lmpc_optimize             # noqa: E402
-from tests.test_oracle_lmpc import A, B, C1, DT                # noqa: E402
+from tests.problems import C1, LMPC_A as A, LMPC_B as B, LMPC_DT as DT, product_lmpc   # noqa: E402
 
 
 QD = np.array([[2., .5], [.5, 1.]])                            # a state weight with off-diagonal entries: H is not diagonal
-
-
-def product_lmpc(kron_variant, N=10, Q=None):
-    from hilo_mpc_amd import LMPC, Model
-    m = Model('lti', A=A, B=B).setup(dt=DT)                     # tests/test_LMPC.py:8-19
-    mpc = LMPC(m)
-    mpc.Q = np.eye(2) if Q is None else Q
-    mpc.R = 1
-    mpc.horizon = N
-    mpc.set_box_constraints(x_lb=[-5, -5], x_ub=[5, 5], u_lb=[-1], u_ub=[1])
-    mpc.setup(kron_variant=kron_variant)
-    return mpc
 
 
 @pytest.mark.parametrize('variant', ['reference', 'corrected'])

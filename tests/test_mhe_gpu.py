@@ -5,24 +5,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle.mhe import MheIpm                                   # noqa: E402
-from tests.problems import C3, C3B, c3_data, oracle_mhe              # noqa: E402
-
-
-def product_mhe(spec, **solver_options):
-    from hilo_mpc_amd import MHE, Model
-    m = Model(spec['model']).discretize('erk', order=spec.get('order', 4)).setup(dt=spec['dt'])
-    mhe = MHE(m)
-    mhe.quad_arrival_cost.add_states(weights=list(spec['Wx']), guess=spec['x_guess'])
-    mhe.quad_stage_cost.add_measurements(weights=list(spec['Wy']))
-    mhe.quad_stage_cost.add_state_noise(weights=list(spec['Ww']))
-    mhe.horizon = spec['N']
-    mhe.set_box_constraints(x_lb=spec.get('x_lb'), x_ub=spec.get('x_ub'), w_lb=spec.get('w_lb'), w_ub=spec.get('w_ub'),
-                            p_lb=spec['p'], p_ub=spec['p'])
-    mhe.set_initial_guess(x_guess=spec['x_guess'])
-    if spec.get('x_scaling') or spec.get('w_scaling') or spec.get('u_scaling'):
-        mhe.set_scaling(x_scaling=spec.get('x_scaling'), w_scaling=spec.get('w_scaling'), u_scaling=spec.get('u_scaling'))
-    mhe.setup(options={'integration_method': 'discrete'}, nlp_opts=solver_options or None)
-    return mhe
+from tests.problems import C3, C3B, c3_data, oracle_mhe, product_mhe # noqa: E402
 
 
 def test_index_bookkeeping_bit_exact():

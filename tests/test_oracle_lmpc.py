@@ -6,10 +6,7 @@ from scipy.optimize import minimize
 
 from oracle.lmpc import LmpcProblem, lmpc_optimize, solve_qp
 
-DT = .5
-A = np.array([[1., DT], [0., 1.]])                 # tests/test_LMPC.py:14-15
-B = np.array([[DT ** 2 / 2], [DT]])
-C1 = dict(A=A, B=B, N=10, Q=np.eye(2), R=[[1.]], x_lb=[-5, -5], x_ub=[5, 5], u_lb=[-1], u_ub=[1])
+from tests.problems import C1, LMPC_A as A, LMPC_B as B, LMPC_DT as DT      # (the benchmark's configuration 1: tests/test_LMPC.py:8-33)
 
 
 def test_layout_and_kron_quirk():
