@@ -962,7 +962,7 @@ int hilo::gp_pack_se2(const hilo_gp* gp, double** d_pack) {
 
 // Posterior mean of a squared-exponential GP with a constant / zero mean over ANY number of features, in the layout the
 // run-time compiled models read (hilo_models.h::gp_se_mean): [n, na, sf2, bias, (active dim) * na, M * na, (X_{ad_k, i} * na,
-// alpha_i) * n | sn2, L^-1 (n <= 64: gp_se_var)].  `Model.substitute_from(gp)` of a model written as expressions (dynamic_model.py:3040-3125).
+// alpha_i) * n | sn2, L^-1 (n <= GP_VAR_MAX: gp_se_var)].  `Model.substitute_from(gp)` of a model written as expressions (dynamic_model.py:3040-3125).
 int hilo::gp_pack_se(const hilo_gp* gp, double** d_pack) {
   HILO_REQUIRE(gp && d_pack, "gp_pack_se: NULL argument");
   const double* k = gp->h_kprog;
@@ -1000,7 +1000,7 @@ int hilo::gp_pack_se(const hilo_gp* gp, double** d_pack) {
     return HILO_OK;
   }
   // tail for the posterior variance (hilo_models.h::gp_se_var): [sn2, L^-1 row-major n x n], small training sets only
-  const bool with_var = n <= 64;
+  const bool with_var = n <= 256;            // = hilo_models.h::GP_VAR_MAX (the k* array of gp_se_var; covers configuration 4's 200 points)
   const size_t head = 4 + 2 * (size_t)na + (size_t)n * (na + 1);
   const size_t len = head + (with_var ? 1 + (size_t)n * n : 0);
   if (with_var) {

@@ -236,8 +236,9 @@ __device__ __forceinline__ T gp_se_dmean(const double* g, const T* feat, int j) 
 
 // Posterior variance INCLUDING the noise variance (`gp.predict(x)[1]` with noise_free=False, gp.py:699-713; inference.py:
 // 214-216: k** - v^T v, v = L^-1 k*): the pack carries sn2 and L^-1 (row-major n x n) behind the mean's data.  Every lane keeps
-// k* (n <= GP_VAR_MAX values of T) in private memory: general, not fast.
-constexpr int GP_VAR_MAX = 64;
+// k* (n <= GP_VAR_MAX values of T) in private memory: general, not fast (indexed at run time the array lives in scratch: 6 KB per
+// lane for second-order Taylor numbers - sized for the 200 training points of BASELINE configuration 4's learned term).
+constexpr int GP_VAR_MAX = 256;
 template <class T>
 __device__ __forceinline__ T gp_se_var(const double* g, const T* feat) {
   const int n = (int)g[0], na = (int)g[1];

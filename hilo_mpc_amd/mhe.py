@@ -384,11 +384,81 @@ class MovingHorizonEstimator:
         """mhe.py:311-416."""
         if not self._nlp_setup_done:
             raise ValueError("You need to setup the nlp before optimizing. Type *mheObject*.setup()")
-        if runs != 0:
-            raise NotImplementedError("multi-start uses unseeded random perturbations in the reference (mhe.py:399)")
         self._time += self._sampling_interval                   # mhe.py:333
         if not self._horizon_is_reached:
             return None, None                                   # mhe.py:415-416
+        wo = getattr(self, '_warm_override', None)              # best run of a multi-start call: the next call's start vector
+        self._warm_override = None
+        if v0 is None and wo is not None and self._nlp_options.get('warm_start', True):
+            v0 = wo
+        if runs != 0:
+            return self._multi_start(x_arrival, p_arrival, v0, int(runs), kwargs)
+        return self._estimate_once(x_arrival, p_arrival, v0)
+
+    def _guess_vector(self, B):
+        """The initial guess in the reference's v layout [p | x_0..x_N | w_0..w_{N-1} | collocation states] (mhe.py:614-660), scaled."""
+        v = np.zeros(self._n_v)
+        sx = np.asarray(self._sx, dtype=float)
+        xg = (np.zeros(self._n_x) if self._x_guess is None else np.asarray(self._x_guess, dtype=float)) / sx
+        for ind in self._x_ind:
+            v[ind] = xg
+        if self._w_ind:
+            sw = np.ones(self._n_x) if getattr(self, '_w_scaling', None) is None else np.asarray(self._w_scaling, dtype=float)
+            wg = (np.zeros(self._n_x) if self._w_guess is None else np.asarray(self._w_guess, dtype=float)) / sw
+            for ind in self._w_ind:
+                v[ind] = wg
+        for ind in getattr(self, '_ip_ind', None) or []:
+            v[ind] = np.tile(xg, len(ind) // self._n_x)
+        if self._n_p and self._p_ind:
+            pg = getattr(self, '_p_guess', None)
+            sp = np.ones(self._n_p) if getattr(self, '_sp', None) is None else np.asarray(self._sp, dtype=float)
+            v[self._p_ind[0]] = (np.zeros(self._n_p) if pg is None else np.asarray(pg, dtype=float)) / sp
+        return to_dev(np.tile(v, (B, 1)), self._dev)
+
+    def _multi_start(self, x_arrival, p_arrival, v0, runs, kwargs):
+        """mhe.py:386-399: `runs` solves of the SAME window, the first from the given start (the caller's v0, else the previous
+        solution, else the initial guess), the following from `v0 + v0 (1 - 2 rand) pert_factor`; per instance the solve with the
+        smallest objective is kept (the reference compares `f` alone, mhe.py:392) and becomes the next call's warm start (:398).
+        The reference draws from the unseeded numpy generator; here `seed=` (default 0) makes the draws reproducible, like
+        `NMPC.optimize(runs=)`."""
+        pert = float(kwargs.get('pert_factor', 0.1))
+        gen = torch.Generator(device='cpu').manual_seed(int(kwargs.get('seed', 0)))
+        B = self._y_hist.shape[0]
+        prev = self._nlp_solution
+        if v0 is not None:
+            base = to_dev(v0, self._dev).reshape(-1, self._n_v)
+            base = (base.expand(B, -1) if base.shape[0] == 1 else base).clone()
+        elif prev is not None and prev['x'].shape[0] == B and self._nlp_options.get('warm_start', True):
+            base = prev['x'].clone()
+        else:
+            base = self._guess_vector(B)
+        # (every run sees the same arrival values: those of the call, else of the state BEFORE the first run)
+        xa_fix = x_arrival if x_arrival is not None else (prev['x'][:, self._x_ind[2]].clone() if prev is not None and prev['x'].shape[0] == B else None)
+        pa_fix = p_arrival if (p_arrival is not None or not self._estimating) else \
+            (prev['x'][:, self._p_ind[0]].clone() if prev is not None and prev['x'].shape[0] == B else None)
+        best, bx, bp = None, None, None
+        start = v0 if v0 is not None else base
+        for _ in range(runs):
+            self._nlp_solution = prev if xa_fix is None else self._nlp_solution
+            x_opt, p_opt = self._estimate_once(xa_fix, pa_fix, start)
+            sol = self._nlp_solution
+            if best is None:
+                best = {k: v.clone() for k, v in sol.items()}
+                bx, bp = x_opt.clone(), (None if p_opt is None else p_opt.clone())
+            else:
+                take = sol['f'] < best['f']
+                for k in sol:
+                    best[k][take] = sol[k][take]
+                bx[take] = x_opt[take]
+                if bp is not None:
+                    bp[take] = p_opt[take]
+            rnd = torch.rand(base.shape, generator=gen, dtype=torch.float64).to(self._dev)
+            start = base + base * (1 - 2 * rnd) * pert
+        self._nlp_solution = best
+        self._warm_override = best['x']
+        return bx, bp
+
+    def _estimate_once(self, x_arrival, p_arrival, v0):
         B = self._y_hist.shape[0]
         dev = self._dev
         if x_arrival is not None:

@@ -186,8 +186,9 @@ class SMPC(NMPC):
             for f in feats:
                 if f not in det_model.dynamical_state_names:            # :2531 `dynamical_state_names.index(i)`
                     raise ValueError(f"'{f}' is not in list")
-            if gp.X_train.shape[1] > 64:
-                raise NotImplementedError("the posterior variance inside a compiled model is built for up to 64 training points")
+            if gp.X_train.shape[1] > 256:
+                raise NotImplementedError("the posterior variance inside a compiled model is built for up to 256 training points "
+                                          "(csrc/hilo_models.h::GP_VAR_MAX)")
             from .gp import is_plain_se
             kern = getattr(gp, 'kernel', None)
             if kern is not None and not is_plain_se(kern.program(len(feats))):

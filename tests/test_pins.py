@@ -180,7 +180,7 @@ def test_hip_mhe_without_state_noise_is_the_kalman_filter_with_q_zero(N):
         mhe.add_measurements(y[k], u_meas=u[k])
         x_est, _ = mhe.estimate()
     assert np.all(mhe.solver_status_code == 1)
-    np.testing.assert_allclose(np.asarray(x_est).reshape(-1), kalman_window(u, y, N, 0., np.eye(2)), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(x_est.cpu().numpy().reshape(-1), kalman_window(u, y, N, 0., np.eye(2)), rtol=1e-8, atol=1e-10)
 
 
 @pytest.mark.gpu
@@ -211,4 +211,4 @@ def test_hip_mhe_with_state_noise_is_the_filter_without_prior_at_x1():
     for k in range(2, N):
         xP, _ = okf.kf_step(model, xP, y[k][None, :], u[k - 1][None, :], p, [Q, Q], KF_R, KF_DT)
     xN = okf.unpack(okf.kf_predict(model, xP, u[N - 1][None, :], p, [Q, Q], KF_DT))[0][0]
-    np.testing.assert_allclose(np.asarray(x_est).reshape(-1), xN, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x_est.cpu().numpy().reshape(-1), xN, rtol=1e-5, atol=1e-6)

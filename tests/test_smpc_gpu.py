@@ -89,3 +89,27 @@ def test_reference_smoke_configurations():
         if smpc.solver_status_code[0] in (1, 2):
             n = m.n_x                                   # predicted variances grow from the zero start, one GP variance per step
             assert np.all(np.diff(xp[0, n]) > 0) and xp[0, n, 0] == 0.
+
+
+def test_posterior_variance_inside_the_compiled_model_at_200_training_points():
+    """The learned term of BASELINE configuration 4 has 200 training points (mpc.py:2573-2612 propagates its posterior variance): the
+    surrogate's compiled `gp_se_var` / `gp_se_mean` against `GaussianProcess.predict` (the prediction kernel, pinned by the
+    reference's GP known answers) on the single integrator with zero state covariance and zero gain, where the propagated
+    covariance IS the posterior variance at the mean state and the mean map is x + u + mean(x)."""
+    from hilo_mpc_amd import GP, Kernel
+    rng = np.random.default_rng(8)
+    X = np.linspace(0., 3., 200)[None, :]
+    y = np.sin(2. * X) + .05 * rng.standard_normal(X.shape)
+    gp = GP(['px'], ['z'], kernel=Kernel.squared_exponential(active_dims=[0], length_scales=[.5], signal_variance=1.), noise_variance=1e-2)
+    gp.set_training_data(X, y)
+    gp.setup()
+    smpc = smpc_product('siso', gp)
+    assert 'gp_se_var(hilo_user_gp[0]' in smpc._user_source
+    xq = rng.uniform(.2, 2.8, 16)
+    u = rng.uniform(-.3, .3, (16, 1))
+    xa = np.stack([xq, np.zeros(16)], axis=1)                     # [mean | covariance entry]
+    got = smpc.plant_step(xa, u, cp=np.zeros((16, 1))).cpu().numpy()
+    mean, var = gp.predict(xq[None, :])
+    mean, var = np.asarray(mean).reshape(-1), np.asarray(var).reshape(-1)
+    np.testing.assert_allclose(got[:, 0], xq + u[:, 0] + mean, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(got[:, 1], var, rtol=1e-7, atol=1e-10)
