@@ -2,7 +2,7 @@
 # Everything the round's committed evidence comes from, in one call on the GPU box:
 #   profiles/run_round.sh r05        then (here)  python profiles/summarize.py gpurun_out/prof_r05 r05 ; python profiles/summarize_pmc.py gpurun_out/pmc_r05 r05
 #                                                 python profiles/summarize_pmc.py gpurun_out/pmc_r05_<config> r05 <config>   (C4, C3-mhe, C5, C5-dae, icache)
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 profiles/run_profile.sh $TAG "C2 C1 C3-mhe C3-ekf C3-ukf C4 gp-predict" 20
