@@ -413,35 +413,51 @@ def cpu_leg_gp(Xq, budget=6.):
             "host_cpus": os.cpu_count()}
 
 
-def cpu_leg_qp(budget=6., min_batch=4096):
+def cpu_leg_qp(budget=6., min_batch=4096, warmup=5, steps=50):
     # oracle/cpu/qp_cpu.cpp (C++17 / OpenMP; the kernels' predictor-corrector iteration, validated against oracle/lmpc.py in
-    # tests/test_cpu_baseline.py) on measured states drawn like the benchmark's, all host cores and one
+    # tests/test_cpu_baseline.py) on THE SAME closed loop as the GPU line: measured states drawn uniformly in [-4, 4]^2 with the
+    # benchmark's seed, then warm-up + timed steps x+ = A x + B u_0 of the command - status fractions and iteration counts are
+    # those of the loop's TIMED steps, like the GPU line's; all host cores and one
     from oracle.cpu import qp_solve
     from oracle.lmpc import LmpcProblem
-    from tests.problems import C1
+    from tests.problems import C1, LMPC_A, LMPC_B
     C, quota = host_cores()
     pb = LmpcProblem(**C1, kron_bug=False)
     nb = max(min_batch, (min_batch // 4) * C)
-    xs = np.random.default_rng(7).uniform(-4, 4, (nb, 2))
-    bnd = [pb.bounds_for(x0) for x0 in xs]
-    lb, ub = np.array([b[0] for b in bnd]), np.array([b[1] for b in bnd])
+    x_start = np.random.default_rng(20260926).uniform(-4, 4, (nb, 2))
+    iu = pb.u_ind[0]
+    loop_steps = warmup + steps
+
+    def loop(nt):
+        """one closed loop of `loop_steps` steps over the batch; returns (iterations, status) of all its solves"""
+        x, its, sts = x_start, [], []
+        for _ in range(loop_steps):
+            lb = np.tile(pb.v_lb, (nb, 1))
+            ub = np.tile(pb.v_ub, (nb, 1))
+            lb[:, pb.x_ind[0]] = ub[:, pb.x_ind[0]] = x / pb.sx                       # mpc.py:2361-2362
+            r = qp_solve(pb.H, pb.g, pb.Aeq, pb.beq, lb, ub, tol=1e-12, reg=1e-12, n_threads=nt)
+            its.append(r['iters'])
+            sts.append(r['status'])
+            x = x @ LMPC_A.T + (r['x'][:, iu] * pb.su) @ LMPC_B.T
+        return np.concatenate(its[warmup:]), np.concatenate(sts[warmup:])
 
     def run(nt, budget):
-        r = qp_solve(pb.H, pb.g, pb.Aeq, pb.beq, lb, ub, tol=1e-12, reg=1e-12, n_threads=nt)
+        loop(nt)
         t0, n = time.perf_counter(), 0
         while time.perf_counter() - t0 < budget:
-            r = qp_solve(pb.H, pb.g, pb.Aeq, pb.beq, lb, ub, tol=1e-12, reg=1e-12, n_threads=nt)
+            its, sts = loop(nt)
             n += 1
         secs = time.perf_counter() - t0
-        return n * nb / secs, secs, n, r
-    v_all, s_all, n_all, r = run(C, budget)
-    v_one, s_one, n_one, _ = run(1, budget * 2 / 3)
+        return n * loop_steps * nb / secs, secs, n, its, sts
+    v_all, s_all, n_all, its, sts = run(C, budget)
+    v_one, s_one, n_one, _, _ = run(1, budget * 2 / 3)
     return {"value": v_all, "unit": "steps/s", "cores": C, "kind": "port", "one_core_value": v_one,
-            "cpu_model": cpu_model_name(), "cgroup_cpu_quota": quota, "mean_qp_iters": float(r['iters'].mean()),
-            "frac_status_1": float((r['status'] == 1).mean()),
-            "sample": f"oracle/cpu C++17/OpenMP dense predictor-corrector QP (the kernels' iteration and tolerances): {n_all} calls x "
-                      f"{nb} QPs on {C} pinned threads ({s_all:.1f} s); one_core_value: {n_one} calls on 1 thread ({s_one:.1f} s); the "
-                      f"reference's CasADi/qpOASES is not installable", "host_cpus": os.cpu_count()}
+            "cpu_model": cpu_model_name(), "cgroup_cpu_quota": quota, "mean_qp_iters": float(its.mean()),
+            "frac_status_1": float((sts == 1).mean()),
+            "sample": f"oracle/cpu C++17/OpenMP dense predictor-corrector QP (the kernels' iteration and tolerances) on the benchmark's own "
+                      f"closed loop (same draw of measured states, {loop_steps} steps): {n_all} loops x {loop_steps} steps x {nb} QPs on {C} "
+                      f"pinned threads ({s_all:.1f} s, host-side assembly of the bound rows included); one_core_value: {n_one} loops on 1 "
+                      f"thread ({s_one:.1f} s); the reference's CasADi/qpOASES is not installable", "host_cpus": os.cpu_count()}
 
 
 def wl_nmpc(cfg, args, torch, dev, rank, world):
@@ -754,7 +770,7 @@ def wl_lmpc(args, torch, dev, rank, world):
         return extra, roof, "weak"
 
     def cpu():
-        return cpu_leg_qp()
+        return cpu_leg_qp(warmup=args.warmup, steps=args.steps)
     return dict(step=step, finish=finish, units=B, cpu=cpu, unit="steps/s",
                 metric="LMPC steps/sec (batched QPs, whole node)")
 

@@ -72,6 +72,7 @@ struct CoopLU {
   }
   // The same with the right-hand sides as a SECOND column `ecol` per lane (a lane may own a matrix column and a right-hand side,
   // or only one of them with the other column idle): every lane applies the row operations to its `ecol`.
+#ifdef HILO_COLL_NO_LOOKAHEAD
   template <bool KEEP_L = true>
   __device__ __forceinline__ static void eliminate2(double* col, double* ecol, int c, int gbase) {
 #pragma unroll
@@ -79,24 +80,86 @@ struct CoopLU {
       const double ck = col[k], ek = ecol[k];
       const double ip = rcp_fast(ck);
       col[k] = c == k ? ip : ck;
-      // the step's multipliers are requested together (the broadcasts pipeline), then consumed by both columns; branch-free: a
-      // lane left of the pivot updates entries it never reads again, the pivot's own lane keeps its multipliers (KEEP_L)
       double l[DN > 1 ? DN : 1];
 #pragma unroll
       for (int i = k + 1; i < DN; ++i) l[i] = lane_bcast(col[i] * ip, gbase + k);
 #pragma unroll
       for (int i = k + 1; i < DN; ++i) {
         ecol[i] = fma(-l[i], ek, ecol[i]);
-        // (pinned here: when only one lane's right-hand side is read afterwards - inside that lane's branch - the optimiser sinks
-        // the whole update chain into the branch, behind the elimination, and keeps every multiplier alive for it: 210 doubles)
         asm volatile("" : "+v"(ecol[i]));
         const double ci = fma(-l[i], ck, col[i]);
         if constexpr (KEEP_L) col[i] = c == k ? l[i] : ci;
         else col[i] = ci;
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#else
+  template <bool KEEP_L = true>
+  __device__ __forceinline__ static void eliminate2(double* col, double* ecol, int c, int gbase) {
+    // LOOK-AHEAD: the multipliers of step k + 1 are formed and their broadcasts requested as soon as the matrix columns have
+    // taken step k - the right-hand sides' updates of step k then run while those broadcasts are in flight (one wave per SIMD:
+    // nothing else hides a ds_bpermute round trip).  Branch-free: a lane left of the pivot updates entries it never reads
+    // again, the pivot's own lane keeps its multipliers (KEEP_L).
+    double l[DN > 1 ? DN : 1], ln[DN > 1 ? DN : 1];
+    double ip = rcp_fast(col[0]);
+#pragma unroll
+    for (int i = 1; i < DN; ++i) l[i] = lane_bcast(col[i] * ip, gbase);
+#pragma unroll
+    for (int k = 0; k < DN; ++k) {
+      const double ck = col[k], ek = ecol[k];
+      col[k] = c == k ? ip : ck;
+#pragma unroll
+      for (int i = k + 1; i < DN; ++i) {
+        const double ci = fma(-l[i], ck, col[i]);
+        if constexpr (KEEP_L) col[i] = c == k ? l[i] : ci;
+        else col[i] = ci;
+      }
+      if (k + 1 < DN) {
+        ip = rcp_fast(col[k + 1]);
+#pragma unroll
+        for (int i = k + 2; i < DN; ++i) ln[i] = lane_bcast(col[i] * ip, gbase + k + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = k + 1; i < DN; ++i) {
+        ecol[i] = fma(-l[i], ek, ecol[i]);
+        // (pinned here: when only one lane's right-hand side is read afterwards - inside that lane's branch - the optimiser sinks
+        // the whole update chain into the branch, behind the elimination, and keeps every multiplier alive for it: 210 doubles)
+        asm volatile("" : "+v"(ecol[i]));
+      }
       __builtin_amdgcn_sched_barrier(0);   // (the unrolled steps are ONE basic block: left alone the scheduler runs all pivot columns
                                            // first and the right-hand sides last, with every multiplier kept in between)
+#pragma unroll
+      for (int i = k + 2; i < DN; ++i) l[i] = ln[i];
     }
+  }
+#endif
+  // U x = y for the right-hand sides, the factor read from LDS: every matrix lane writes its column (on and above the diagonal;
+  // the diagonal is the reciprocal pivot) to `us` (DN x DN doubles of the group), every lane then substitutes its own right-hand
+  // side with broadcast reads - one LDS read per entry of U where lane-to-lane broadcasts took two ds_bpermute each.
+  __device__ __forceinline__ static void back_substitute2_lds(const double* col, double* ecol, int c,
+                                                              __attribute__((address_space(3))) double* us) {
+    if (c < DN) {
+#pragma unroll
+      for (int i = 0; i < DN; ++i) us[c * DN + i] = col[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = DN - 1; k >= 0; --k) {
+      double uk[DN];
+#pragma unroll
+      for (int i = 0; i <= k; ++i) uk[i] = us[k * DN + i];     // the column's reads requested together
+      const double xk = ecol[k] * uk[k];
+      ecol[k] = xk;
+#pragma unroll
+      for (int i = 0; i < k; ++i) {
+        ecol[i] = fma(-uk[i], xk, ecol[i]);
+        asm volatile("" : "+v"(ecol[i]));   // (pinned: see eliminate2)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
   }
   __device__ __forceinline__ static void back_substitute2(const double* col, double* ecol, int gbase) {
 #pragma unroll

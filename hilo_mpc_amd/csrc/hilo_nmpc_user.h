@@ -136,6 +136,7 @@ struct NmpcUser {
   static constexpr int VEC_MAX = HILO_USER_VEC_MAX;            // developer knob: cap on the LDS-resident vectors (Ocp::VEC_LEVEL)
 #endif
   static constexpr int XCW = COOP_COLL ? DNC + NWD : 0;
+  static constexpr int CSTAGE = COOP_COLL ? CG * DNC * (1 + DNC) : 0;   // LDS staging of coll_pass: the groups' states and factors U
 #ifdef HILO_USER_NO_PREP   // developer knob (tools/dbg/c5dae_prep.py): every Taylor direction solves the collocation system itself
   static constexpr int PREP = 0;
 #else
@@ -449,12 +450,18 @@ struct NmpcUser {
               xmax = fmax(xmax, fabs(Xs[q]));
             }
           }
-          if (it > 0 && !__any((int)(is_res && act && !(rmax <= 1e-12 * xmax)))) break;
+          // (a trial point is started from the first-order prediction off the iterate: late in the solve, where the steps are
+          // small, that prediction already IS the solution to round-off and no elimination runs at all)
+          if ((it > 0 || from_prep) && !__any((int)(is_res && act && !(rmax <= 1e-12 * xmax)))) break;
         }
         CoopLU<DNC>::template eliminate2<DERIV>(col, ecol, c, gbase);
+#ifdef HILO_COLL_BPERM_BACKSUB
         CoopLU<DNC>::back_substitute2(col, ecol, gbase);
-        double dmax = 0.0, scale = 1.0;
         __syncthreads();
+#else
+        CoopLU<DNC>::back_substitute2_lds(col, ecol, c, stage + CG * DNC + g * DNC * DNC);
+#endif
+        double dmax = 0.0, scale = 1.0;
         if (is_res) {
 #pragma unroll
           for (int q = 0; q < DNC; ++q) {

@@ -155,7 +155,11 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   const bool coop = big && D && (nwd + 1 <= dnc ? dnc : dnc + nwd + 1) <= 64 && mua <= mxa;
   const size_t prep_w = !(big && D) ? 0 : (coop ? (size_t)dnc * (nwd + 2) + nwd : (size_t)dnc * (1 + dnc));
   const size_t xc_w = coop ? (size_t)(dnc + nwd) : 0;
-  fixed_b += prep_w * (coop ? 3 : 1) * sizeof(double);   // (Ocp::PREPB blocks staged at a time)
+  {   // the LDS staging area (Ocp::PREPL): PREPB blocks of the direction passes, or the cooperative pass's states and factors
+    const size_t cgs = nwd + 1 <= dnc ? dnc : dnc + nwd + 1, cg = coop ? 64 / cgs : 1;
+    const size_t blocks = prep_w * (coop ? 3 : 1), cstage = coop ? cg * dnc * (1 + (size_t)dnc) : 0;
+    fixed_b += (blocks > cstage ? blocks : cstage) * sizeof(double);
+  }
   if (fixed_b > 160 * 1024) return fail(HILO_ENOTSUP, "horizon %d needs %zu B of LDS for the problem constants alone", N, fixed_b);
   const size_t prep_b = (size_t)N * (prep_w + xc_w) * sizeof(double);
 

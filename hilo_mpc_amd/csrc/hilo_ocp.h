@@ -257,6 +257,8 @@ template <class PB> struct pb_prep<PB, void_tt<decltype(PB::PREP)>> { static con
 // ... or the lanes of a wave solve the collocation systems together: PB::coll_pass, states per interval in the workspace (PB::XCW)
 template <class PB, class = void> struct pb_vec_max { static constexpr int value = 3; };
 template <class PB> struct pb_vec_max<PB, void_tt<decltype(PB::VEC_MAX)>> { static constexpr int value = PB::VEC_MAX; };
+template <class PB, class = void> struct pb_cstage { static constexpr int value = 0; };
+template <class PB> struct pb_cstage<PB, void_tt<decltype(PB::CSTAGE)>> { static constexpr int value = PB::CSTAGE; };
 template <class PB, class = void> struct pb_xcw { static constexpr int value = 0; };
 template <class PB> struct pb_xcw<PB, void_tt<decltype(PB::XCW)>> { static constexpr int value = PB::XCW; };
 template <class PB, class = void> struct pb_lam_fix { static constexpr bool value = false; };
@@ -335,6 +337,8 @@ struct Ocp {
 #define HILO_OCP_PREPB 3
 #endif
   static constexpr int PREPB = XCW > 0 ? HILO_OCP_PREPB : 1;   // per-interval blocks staged in LDS at a time
+  // the staging area `prepl`: the blocks of the direction passes, or (never at the same time) the cooperative pass's states + factors
+  static constexpr int PREPL = PREP * PREPB > pb_cstage<PB>::value ? PREP * PREPB : pb_cstage<PB>::value;
   // model derivatives as generated straight-line code (ModelSym<PB::Model>, csrc/hilo_models_sym.h / codegen): second-order
   // adjoint through the Runge-Kutta stages instead of Taylor sweeps per direction pair (eval_derivs_sym)
   static constexpr bool SYM = pb_sym<PB>::value;
@@ -376,7 +380,7 @@ struct Ocp {
   }
   static constexpr size_t VEC_BUDGET = 40 * 1024 - 64;
   static constexpr bool vec_fits(int level) {
-    return (ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, VEC_N, PREP * PREPB) + vec_doubles_level(VEC_N, level)) * sizeof(double) <= VEC_BUDGET;
+    return (ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, VEC_N, PREPL) + vec_doubles_level(VEC_N, level)) * sizeof(double) <= VEC_BUDGET;
   }
   // (a policy may cap the level - PB::VEC_MAX: a problem whose long phases are latency bound trades the LDS-resident vectors for
   // a second wave per SIMD)
@@ -418,7 +422,7 @@ struct Ocp {
   }
   __device__ static dp qd_term(const Lds l, int N) { return (SYM || SYM_MHE) ? l.Qd : l.Qd + (size_t)N * NDIR; }
   __host__ __device__ static constexpr size_t fixed_doubles(int N) {  // always LDS
-    return ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, N, PREP * PREPB);
+    return ocp_fixed_doubles(NX, NU, NCONST, NPAR, NSD, NEXT, N, PREPL);
   }
   __host__ __device__ static constexpr size_t lds_doubles(int N) {
     return fixed_doubles(N) + (BIG ? (VEC_LDS ? vec_doubles(N) : 0) : iter_doubles(N));
@@ -441,7 +445,7 @@ struct Ocp {
     l.sd = take((size_t)(N + 1) * (NSD > 0 ? NSD : 0) + 1);
     l.ext = take(NEXT);
     l.dirs = reinterpret_cast<__attribute__((address_space(3))) int*>(take((NDIR + 2) / 2));
-    l.prepl = take(PREP * PREPB);
+    l.prepl = take(PREPL);
     dp w;
     const size_t V = (size_t)N * NX;
     if constexpr (VEC_LEVEL >= 1) {   // the vectors first, in LDS; everything else in the workspace

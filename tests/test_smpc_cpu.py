@@ -183,8 +183,8 @@ def test_surrogate_errors():
     g._handle = None
     with pytest.raises(RuntimeError, match="has not been set up"):
         SMPC(m, g, [[1.]])
-    with pytest.raises(NotImplementedError, match="64 training points"):
-        SMPC(m, _TrainedGp(['px'], n=65), [[1.]])
+    with pytest.raises(NotImplementedError, match="256 training points"):      # (csrc/hilo_models.h::GP_VAR_MAX; configuration 4 has 200)
+        SMPC(m, _TrainedGp(['px'], n=257), [[1.]])
     with pytest.raises(ValueError, match="B must have shape"):
         SMPC(m, _TrainedGp(['px']), [[1., 2.]])
 
