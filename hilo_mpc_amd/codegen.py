@@ -164,8 +164,11 @@ def model_source(n_x, n_u, n_p, ode, meas, discrete, helpers=()):
     return src
 
 
-def dae_model_source(n_x, n_u, n_p, n_z, ode, alg, meas, z_guess):
-    """`struct UserModel` of a semi-explicit index-1 DAE  dx/dt = f(x, z, u, p),  0 = g(x, z, u, p).  The engine sees the ODE
+def dae_model_source(n_x, n_u, n_p, n_z, ode, alg, meas, z_guess, alg_at_slope=False):
+    """`struct UserModel` of a semi-explicit index-1 DAE  dx/dt = f(x, z, u, p),  0 = g(x, z, u, p).
+    alg_at_slope: the reference's EXPLICIT Runge-Kutta transcription hands the algebraic equations the stage's SLOPE where the state
+    belongs (`alg(t + h c_i, dk, Z[:, i], u, p)`, hilo_mpc/util/modeling.py:1268): the stage's algebraic variables solve
+    g(f(X_i, Z_i, u), Z_i, u) = 0.  Restated as it is - the emitted `alg` (and its dg/dz) is that composition, everything else the same.  The engine sees the ODE
     dx/dt = f(x, zeta(x, u, p), u, p): `ode` solves the algebraic equations for z by Newton's method IN THE SCALAR TYPE it is
     called with (values, forward duals, second-order Taylor numbers - each sweep after the values have converged fixes one more
     derivative order; csrc/hilo_models.h::dae_solve), so the derivatives the interior point needs are those of the implicit
@@ -176,6 +179,9 @@ def dae_model_source(n_x, n_u, n_p, n_z, ode, alg, meas, z_guess):
         raise ValueError("dimension mismatch between states and equations")
     if any(n.op in ('gp', 'gpk') for e in list(ode) + list(alg) for n in Expr.wrap(e).nodes().values()):
         raise NotImplementedError("a learned term inside a DAE model is not built")
+    if alg_at_slope:
+        odes = [Expr.wrap(e) for e in ode]
+        alg = Expr.substitute([Expr.wrap(e) for e in alg], lambda n: odes[int(n.value)] if n.op == 'x' else None)
     em = Emitter()
     dx = [em.ref(e) for e in ode]
     body_f = em.lines + [f"    dx[{i}] = T({r});" for i, r in enumerate(dx)]

@@ -143,6 +143,8 @@ extern "C" __global__ void hilo_user_coll_out(const OcpConst* __restrict__ pcg, 
                                               double* __restrict__ lam_g) {
 #if HILO_USER_POLICY == 2 && HILO_USER_COLL_D > 0
   PB::coll_output(pcg, batch, vc, lamc, par, par_stride, sdata, sd_stride, v, lam_g);
+#elif HILO_USER_POLICY == 2
+  PB::erk_dae_output(pcg, batch, vc, lamc, par, par_stride, sdata, sd_stride, v, lam_g);   // (algebraic states under explicit Runge-Kutta)
 #endif
 }
 

@@ -38,7 +38,8 @@ struct hilo_nmpc {
   int Nc;
   int tv_width;              // doubles per stage of the per-stage data table (0: none)
   size_t jit_ws_bytes;       // per-instance iterate workspace of a run-time compiled problem (0: iterate in LDS)
-  int jit_coll_d;            // collocation degree of a run-time compiled problem (output pass needed) or 0
+  int jit_coll_d;            // non-zero: an output pass follows the solve - the collocation degree of a run-time compiled problem, or
+                             // 100 + order for algebraic states under an explicit Runge-Kutta transcription (hilo_nmpc_user.h::erk_dae_output)
   double* user_gp_pack[4];   // packed learned terms of a run-time compiled model (gp_pack_se) or NULL
   double* aux_g;             // caller's buffers for the constraint values / bound multipliers of the next solves, or NULL
   double* aux_lam_x;

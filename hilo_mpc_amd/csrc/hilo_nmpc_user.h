@@ -884,6 +884,192 @@ struct NmpcUser {
       return 0.0;
     }
   }
+  // ---- output pass of algebraic states under an EXPLICIT Runge-Kutta transcription: one thread per (instance, interval) -------
+  // The reference carries one block of algebraic variables per stage and interval, Z_{k,i}, with the rows
+  //     alg(k_i, Z_{k,i}, u_k) = 0,  k_i = f(X_i, Z_{k,i}, u_k),  X_i = x_k + h sum_(j<i) a_ij k_j       (modeling.py:1258-1275: the
+  // algebraic equations see the stage's SLOPE where the state belongs - restated as it is; the emitted M::alg IS that composition
+  // G(X, Z, u) = g(f(X, Z, u), Z, u), codegen.py::dae_model_source) in front of the continuity rows (mpc.py:1647-1670), and node
+  // blocks z_0..z_N that enter no row (they keep the guess).  The engine eliminates the Z inside the shooting map; this pass rebuilds
+  //     v     = [x | u | z_0..z_N | per interval (Z_{k,1..s})]
+  //     lam_g = per interval [algebraic rows, stage by stage | continuity]
+  // Multipliers of the algebraic rows from the stationarity of the reference's Lagrangian in Z_{k,j}, backwards over the stages:
+  //     kbar_j = -h b_j lambda / s + sum_(m>j) h a_mj Xbar_m          (adjoint of the slope k_j; lambda: the engine's own multiplier)
+  //     nu_j   = -G_Z^-T f_z^T kbar_j
+  //     Xbar_j = h b_j grad l(X_j) + G_X^T nu_j + f_x^T kbar_j        (continuous objective: the quadrature term of the stage point)
+  __device__ static void erk_dae_output(const OcpConst* __restrict__ pcg, int64_t batch, const double* __restrict__ vc,
+                                        const double* __restrict__ lamc, const double* __restrict__ par, int64_t par_stride,
+                                        const double* __restrict__ sdata, int64_t sd_stride, double* __restrict__ v,
+                                        double* __restrict__ lam_g) {
+    if constexpr (NZALG > 0 && D == 0 && !M::DISCRETE && NTH == 0 && NE == 0 && NQ == 0 && NH == 0 && NC == 0) {
+      constexpr int NZA = NZALG, NV = MX + NZA;
+      const OcpConst& pc = *pcg;
+      const int N = pc.N, s = pc.order;
+      const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      if (e >= batch * N) return;
+      const int64_t b = e / N;
+      const int k = (int)(e - b * N);
+      const int n_head = (N + 1) * MX + N * MU, nv = n_head + (N + 1) * NZA + N * s * NZA;
+      const double* row = vc + b * n_head;
+      const double* lrow = lamc ? lamc + b * (int64_t)(N * MX) + (int64_t)k * MX : nullptr;
+      const double* pr = par + b * par_stride;
+      const double* sd = C::TV ? sdata + b * sd_stride + (int64_t)k * NSD : nullptr;
+      const double* p = C::TV ? sd + MX + MU : pr;
+      double* out = v + b * nv;
+      for (int i0 = 0; i0 < n_head; i0 += N) {
+        const int i = i0 + k;
+        if (i < n_head) out[i] = row[i];
+      }
+#pragma unroll
+      for (int a = 0; a < NZA; ++a) {
+        out[n_head + k * NZA + a] = M::z_guess(a);
+        if (k == N - 1) out[n_head + N * NZA + a] = M::z_guess(a);
+      }
+      double A[4][4], bw[4];
+      A[0][0] = A[0][1] = A[0][2] = A[0][3] = A[1][1] = A[1][2] = A[1][3] = A[2][2] = A[2][3] = A[3][3] = A[3][0] = A[3][1] = A[2][0] = 0.0;
+      A[1][0] = erk_a<1, 0>(s); A[2][0] = erk_a<2, 0>(s); A[2][1] = erk_a<2, 1>(s); A[3][2] = erk_a<3, 2>(s);
+      bw[0] = erk_b<0>(s); bw[1] = erk_b<1>(s); bw[2] = erk_b<2>(s); bw[3] = erk_b<3>(s);
+      const double h = pc.dt;
+      double x[MX], u[MU > 0 ? MU : 1], us[MU > 0 ? MU : 1];
+#pragma unroll
+      for (int i = 0; i < MX; ++i) x[i] = row[k * MX + i] * pc.sz[i];
+#pragma unroll
+      for (int i = 0; i < MU; ++i) {
+        us[i] = row[(N + 1) * MX + k * MU + i];
+        u[i] = us[i] * pc.sz[NX + i];
+      }
+      double X[4][MX], Z[4][NZA], K[4][MX];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < s) {
+#pragma unroll
+          for (int a = 0; a < MX; ++a) {
+            double acc = x[a];
+#pragma unroll
+            for (int j = 0; j < i; ++j) acc += h * A[i][j] * K[j][a];
+            X[i][a] = acc;
+          }
+          dae_solve<M>(X[i], u, p, Z[i]);
+          M::ode_z(X[i], Z[i], u, p, K[i]);
+#pragma unroll
+          for (int a = 0; a < NZA; ++a) out[n_head + (N + 1) * NZA + (k * s + i) * NZA + a] = Z[i][a];
+        } else {
+#pragma unroll
+          for (int a = 0; a < MX; ++a) { X[i][a] = x[a]; K[i][a] = 0.0; }
+#pragma unroll
+          for (int a = 0; a < NZA; ++a) Z[i][a] = M::z_guess(a);
+        }
+      }
+      if (!lam_g) return;
+      const int per = s * NZA + MX;
+      double* lg = lam_g + b * (int64_t)(N * per) + (int64_t)k * per;
+      double lam[MX];
+#pragma unroll
+      for (int m = 0; m < MX; ++m) lam[m] = lrow[m];
+      {   // the engine's own multiplier of the last defect (see coll_output): lambda_ref - grad V(x_N)
+        const bool last = k == N - 1 && (pc.flags & 1);
+        const double* sdN = C::TV ? sdata + b * sd_stride + (int64_t)N * NSD : nullptr;
+#pragma unroll
+        for (int m = 0; m < MX; ++m) {
+          Jet2 xj[NX];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xj[i] = Jet2(row[N * MX + i], i == m ? 1.0 : 0.0, 0.0);
+          const double gv = term_cost(pc, pr, sdN, xj).a;
+          lam[m] -= last ? gv : 0.0;
+        }
+      }
+      double kbar[4][MX], Xbar[4][MX], nu[4][NZA];
+#pragma unroll
+      for (int j = 3; j >= 0; --j) {
+        if (j < s) {
+#pragma unroll
+          for (int a = 0; a < MX; ++a) {
+            double acc = -h * bw[j] * lam[a] / pc.sz[a];
+#pragma unroll
+            for (int m = j + 1; m < 4; ++m) acc += (m < s) ? h * A[m][j] * Xbar[m][a] : 0.0;
+            kbar[j][a] = acc;
+          }
+          Dual<NV> xd[MX], zd[NZA], ud[MU > 0 ? MU : 1], fd[MX], gd[NZA];
+#pragma unroll
+          for (int q = 0; q < MX; ++q) { xd[q] = Dual<NV>(X[j][q]); xd[q].d[q] = 1.0; }
+#pragma unroll
+          for (int q = 0; q < NZA; ++q) { zd[q] = Dual<NV>(Z[j][q]); zd[q].d[MX + q] = 1.0; }
+#pragma unroll
+          for (int q = 0; q < MU; ++q) ud[q] = Dual<NV>(u[q]);
+          M::ode_z(xd, zd, ud, p, fd);
+          M::alg(xd, zd, ud, p, gd);
+          double G[NZA * NZA], rhs[NZA];      // G = G_Z^T, rhs = -f_z^T kbar_j
+#pragma unroll
+          for (int a = 0; a < NZA; ++a) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < MX; ++m) acc += fd[m].d[MX + a] * kbar[j][m];
+            rhs[a] = -acc;
+#pragma unroll
+            for (int c = 0; c < NZA; ++c) G[a * NZA + c] = gd[c].d[MX + a];
+          }
+#pragma unroll
+          for (int c = 0; c < NZA; ++c) {        // Gaussian elimination with partial pivoting (static indices)
+#pragma unroll
+            for (int q = c + 1; q < NZA; ++q) {
+              if (fabs(G[q * NZA + c]) > fabs(G[c * NZA + c])) {
+#pragma unroll
+                for (int jj = c; jj < NZA; ++jj) { const double t = G[c * NZA + jj]; G[c * NZA + jj] = G[q * NZA + jj]; G[q * NZA + jj] = t; }
+                const double t = rhs[c]; rhs[c] = rhs[q]; rhs[q] = t;
+              }
+            }
+#pragma unroll
+            for (int q = c + 1; q < NZA; ++q) {
+              const double f = G[q * NZA + c] / G[c * NZA + c];
+#pragma unroll
+              for (int jj = c + 1; jj < NZA; ++jj) G[q * NZA + jj] -= f * G[c * NZA + jj];
+              rhs[q] -= f * rhs[c];
+            }
+          }
+#pragma unroll
+          for (int c = NZA - 1; c >= 0; --c) {
+            double acc = rhs[c];
+#pragma unroll
+            for (int jj = c + 1; jj < NZA; ++jj) acc -= G[c * NZA + jj] * rhs[jj];
+            rhs[c] = acc / G[c * NZA + c];
+          }
+#pragma unroll
+          for (int a = 0; a < NZA; ++a) nu[j][a] = rhs[a];
+          double gl[MX];
+#pragma unroll
+          for (int a = 0; a < MX; ++a) gl[a] = 0.0;
+          if constexpr (CONT) {     // gradient of the Lagrange term at the stage point, in scaled variables
+            Dual<MX> xs[MX], uq[MU > 0 ? MU : 1];
+#pragma unroll
+            for (int q = 0; q < MX; ++q) { xs[q] = Dual<MX>(X[j][q] / pc.sz[q]); xs[q].d[q] = 1.0; }
+#pragma unroll
+            for (int q = 0; q < MU; ++q) uq[q] = Dual<MX>(us[q]);
+            const Dual<MX> lv = lagrange<Dual<MX>, false>(pc, pr, sd, p, k, xs, uq);
+#pragma unroll
+            for (int a = 0; a < MX; ++a) gl[a] = h * bw[j] * lv.d[a] / pc.sz[a];
+          }
+#pragma unroll
+          for (int a = 0; a < MX; ++a) {
+            double acc = gl[a];
+#pragma unroll
+            for (int c = 0; c < NZA; ++c) acc += gd[c].d[a] * nu[j][c];
+#pragma unroll
+            for (int m = 0; m < MX; ++m) acc += fd[m].d[a] * kbar[j][m];
+            Xbar[j][a] = acc;
+          }
+#pragma unroll
+          for (int a = 0; a < NZA; ++a) lg[j * NZA + a] = nu[j][a];
+        } else {
+#pragma unroll
+          for (int a = 0; a < MX; ++a) { kbar[j][a] = 0.0; Xbar[j][a] = 0.0; }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MX; ++m) lg[s * NZA + m] = lrow[m];
+    } else {
+      (void)pcg; (void)batch; (void)vc; (void)lamc; (void)par; (void)par_stride; (void)sdata; (void)sd_stride; (void)v; (void)lam_g;
+    }
+  }
+
   // ---- collocation output pass: one thread per (instance, interval) ---------------------------------------------------
   // The engine eliminates the collocation states (hilo_colloc.h) and, for a semi-explicit DAE model (codegen.py::
   // dae_model_source), the algebraic states; this pass rebuilds them and the multipliers of their equations, so that `v` and

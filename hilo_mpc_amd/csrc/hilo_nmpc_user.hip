@@ -173,12 +173,25 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   h->jit_coll_d = D;
   const int nza = d->model_id == HILO_MODEL_USER ? d->user_nz : 0;
   HILO_REQUIRE(nza >= 0 && nza <= 4, "hilo_nmpc_create: at most 4 algebraic states (got %d)", nza);
-  if (nza > 0 && D == 0)
-    return fail(HILO_ENOTSUP, "algebraic states (DAE) are built for the collocation transcription");
+  // algebraic states under an EXPLICIT Runge-Kutta transcription (mpc.py:1375-1412, modeling.py:1213-1281): one block of algebraic
+  // variables per stage and interval, eliminated inside the shooting map (the emitted model solves them, codegen.py::dae_model_source
+  // with alg_at_slope) and rebuilt with the multipliers of their rows by the output pass (hilo_nmpc_user.h::erk_dae_output) - for the
+  // plain problem shape of the reference's own case (tests/test_NMPC.py:1950-1975): quadratic costs and boxes
+  const int erk_s = d->erk_order >= 1 ? d->erk_order : 4;
+  const bool erk_dae = nza > 0 && D == 0;
+  if (erk_dae) {
+    if (discrete) { delete h; return fail(HILO_ENOTSUP, "algebraic states of a discrete model are not built"); }
+    h->jit_coll_d = 100 + erk_s;      // (non-zero: the output pass runs)
+    if (nrow + ntrow > 0 || nth > 0 || nq > 0 || Nc < N || (d->n_sub > 1) || ne > 0) {
+      delete h;
+      return fail(HILO_ENOTSUP, "algebraic states under an explicit Runge-Kutta transcription are built for quadratic costs and box "
+                                "constraints (no nonlinear / custom constraints, path variable, control horizon, sub-steps): use 'collocation'");
+    }
+  }
   h->n_vc = (N + 1) * mxa + Nc * mua + ne + nq;
-  h->n_v = h->n_vc + (nza ? (N + 1) * nza : 0) + N * D * (mxa + nza);   // mpc.py:1440-1453, :1488-1548 (+ nq hidden tail entries)
+  h->n_v = h->n_vc + (nza ? (N + 1) * nza : 0) + N * D * (mxa + nza) + (erk_dae ? N * erk_s * nza : 0);   // mpc.py:1440-1453, :1488-1548 (+ nq hidden tail entries)
   // mpc.py:1338-1372 (per collocation point: constraint rows, then the collocation equations), :1657-1669, :1684-1725
-  h->n_g = N * (mxa + n_con_ref + D * (mxa + nza) + (D ? D * n_con_ref : 0)) + n_tcon_ref;
+  h->n_g = N * (mxa + n_con_ref + D * (mxa + nza) + (D ? D * n_con_ref : 0) + (erk_dae ? erk_s * nza : 0)) + n_tcon_ref;
   h->n_gc = D ? N * (mxa + nrow) + ntrow : 0;   // the engine's compact multiplier row handed to the output pass
   OcpConst& c = h->host;
   memset(&c, 0, sizeof(c));

@@ -241,7 +241,7 @@ class Model:
             return False
         return not any(n.op in ('x', 'z', 'u') for r in J for e in r for n in e.nodes().values())
 
-    def user_source(self, z_guess=None):
+    def user_source(self, z_guess=None, alg_at_slope=False):
         """HIP source that defines `UserModel` for the run-time compiled path: the emitted functor, or the alias of the
         zoo functor.  z_guess: start of the Newton iteration on the algebraic equations of a DAE (`set_initial_guess(z_guess=)`)."""
         from . import codegen
@@ -267,14 +267,14 @@ class Model:
                 sub = Expr.substitute(self._ode + self._meas + self._alg, lambda n: dtc if n.op == 'dt' else None)
                 m = copy.copy(self)
                 m._ode, m._meas, m._alg = sub[:n1], sub[n1:n2], sub[n2:]
-                return m.user_source(z_guess)
+                return m.user_source(z_guess, alg_at_slope)
             if self.n_z and len(self._alg) != self.n_z:
                 raise RuntimeError("Model is not set up: algebraic states without algebraic equations (set_algebraic_equations)")
             if self.n_z:
                 if self._native_discrete:
                     raise NotImplementedError("algebraic states of a discrete model are not built")
                 return codegen.dae_model_source(self.n_x, self.n_u, self.n_p, self.n_z, self._ode, self._alg, self._meas,
-                                                z_guess if z_guess is not None else [0.] * self.n_z)
+                                                z_guess if z_guess is not None else [0.] * self.n_z, alg_at_slope=alg_at_slope)
             helpers = [src for _, src in sorted(getattr(self, '_gp_helpers', {}).items())]
             return codegen.model_source(self.n_x, self.n_u, self.n_p, self._ode, self._meas, self._native_discrete, helpers=helpers)
         if self.name == 'lti':

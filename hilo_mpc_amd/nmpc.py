@@ -994,7 +994,7 @@ class NMPC:
         generic = gen_stage is not None or gen_term is not None
         general = bool(nth or sc.is_set or tc.is_set)
         need_user = generic or Nc < N or cont or (coll is not None and (general or self._tv)) or (self._tv and general) or \
-            bool(prog_fail)
+            bool(prog_fail) or bool(getattr(m, 'n_z', 0))         # (algebraic states: the general policy owns their output passes)
         sym = getattr(m, '_symbolic', False)
         if coll is not None:
             d.coll_B = hp(coll['B'])
@@ -1031,18 +1031,30 @@ class NMPC:
             from . import codegen
             nza = getattr(m, 'n_z', 0)
             if nza:
-                if coll is None:
-                    raise NotImplementedError("algebraic states (DAE models) are offloaded for the collocation transcription "
-                                              "(the reference's default)")
                 if tc.is_set:
                     raise NotImplementedError("a nonlinear terminal constraint on a DAE model is not offloaded")
-                src = m.user_source(z_guess=getattr(self, '_z_guess', None))
+                if coll is None and self._model.discrete:
+                    raise NotImplementedError("algebraic states of a pre-discretised model are not offloaded: hand the continuous model "
+                                              "over and use 'collocation' (the reference's default) or 'rk4' / 'erk'")
+                if coll is None:
+                    # explicit Runge-Kutta ('rk4' / 'erk', mpc.py:1375-1412): a block of algebraic variables per STAGE, whose equations
+                    # the reference evaluates at the stage's slope (modeling.py:1268) - restated as it is (codegen.py, alg_at_slope);
+                    # built for the shape of the reference's own case (tests/test_NMPC.py:1950-1975): quadratic costs and boxes
+                    if sc.is_set or nth or getattr(self, '_custom_constraint_flag', False) or self._control_horizon < self._prediction_horizon:
+                        raise NotImplementedError("algebraic states under an explicit Runge-Kutta transcription are offloaded for quadratic "
+                                                  "costs and box constraints; use 'collocation' (the reference's default) for the rest")
+                    zl = getattr(self, '_z_lb', None)
+                    zu = getattr(self, '_z_ub', None)
+                    if (zl is not None and np.any(np.isfinite(zl))) or (zu is not None and np.any(np.isfinite(zu))):
+                        warnings.warn("bounds on algebraic states under an explicit Runge-Kutta transcription are not enforced by the "
+                                      "device solver (the stage variables are eliminated); check the returned zp values")
+                src = m.user_source(z_guess=getattr(self, '_z_guess', None), alg_at_slope=coll is None)
                 d.user_nz = nza
             else:
                 src = m.user_source()
             if policy == 2:
                 zb = []                      # bounded algebraic states: expressions behind the constraint's, rows at the collocation points
-                if nza:
+                if nza and coll is not None:
                     zl = [-np.inf] * nza if getattr(self, '_z_lb', None) is None else list(self._z_lb)
                     zu = [np.inf] * nza if getattr(self, '_z_ub', None) is None else list(self._z_ub)
                     zb = [a for a in range(nza) if np.isfinite(zl[a]) or np.isfinite(zu[a])]
@@ -1131,16 +1143,18 @@ class NMPC:
         self._x_ind = [list(range(k * nxa, (k + 1) * nxa)) for k in range(N + 1)]
         self._u_ind = [list(range((N + 1) * nxa + k * nua, (N + 1) * nxa + (k + 1) * nua)) for k in range(Nc)]
         dn = coll['d'] * nxa if coll is not None else 0
-        nza = getattr(m, 'n_z', 0) if coll is not None else 0
+        nza = getattr(m, 'n_z', 0) if (coll is not None or getattr(m, '_symbolic', False)) else 0
+        # algebraic variables per interval: one block per collocation point, or per stage of the explicit Runge-Kutta scheme (mpc.py:1322, :1394)
+        zblocks = coll['d'] if coll is not None else (m.erk_order if m.erk_order else 4)
         off = (N + 1) * nxa + Nc * nua
         # the slacks of the soft constraints come LAST in v (mpc.py:1529-1548 follows the algebraic and collocation blocks, :1488-1527)
-        eoff = off + (N + 1) * nza + N * (dn + (coll['d'] * nza if coll is not None else 0))
+        eoff = off + (N + 1) * nza + N * (dn + zblocks * nza)
         self._e_soft_stage_ind = list(range(eoff, eoff + ne))
         self._e_soft_term_ind = list(range(eoff + ne, eoff + ne + ne_term))                               # mpc.py:1542-1543
         # algebraic states: node blocks z_0..z_N behind the slacks' predecessors, then per interval [ip_k | zp_k] (mpc.py:1488-1518)
         self._z_ind = [list(range(off + k * nza, off + (k + 1) * nza)) for k in range(N + 1)] if nza else []
         off += (N + 1) * nza
-        dz = coll['d'] * nza if coll is not None else 0
+        dz = zblocks * nza
         self._ip_ind = [list(range(off + k * (dn + dz), off + k * (dn + dz) + dn)) for k in range(N)] if dn else []   # mpc.py:1501-1509
         self._zp_ind = [list(range(off + k * (dn + dz) + dn, off + (k + 1) * (dn + dz))) for k in range(N)] if dz else []
         self._sx, self._su = sx, su
