@@ -35,63 +35,101 @@ def init_from_env(backend=None):
 class StepGather:
     """One collective per MPC step: every rank contributes its shard's `u0` (fp64) and `(status, iters)` (int32),
     packed into one fp64 buffer so that a single `all_gather_into_tensor` moves everything (ranks may hold shards
-    of different sizes: buffers are padded to the largest shard)."""
+    of different sizes: buffers are padded to the largest shard).
+
+    The collective is ASYNCHRONOUS (`async_op=True`): it waits for the solve that filled its send buffer and nothing waits for it -
+    the next step's solve (the instances are independent: it needs nothing of the gathered table) is enqueued right behind and
+    runs while the table travels; whoever LOOKS at the gathered table waits for it (`Gathered`).  Two send / receive buffers
+    alternate, and a buffer is handed to the next solve only after the collective that read it - issued one whole step earlier -
+    has completed (`Work.wait()`: a stream dependency for RCCL, not a host stall)."""
 
     def __init__(self, batch, nu, rank, world, device):
         self.batch, self.nu, self.rank, self.world = int(batch), int(nu), rank, world
         self.sizes = [shard_range(batch, r, world)[1] - shard_range(batch, r, world)[0] for r in range(world)]
         self.max_n = max(self.sizes) if self.sizes else 0
         self.width = nu + 2
-        self.send = torch.zeros(self.max_n, self.width, dtype=torch.float64, device=device)
-        self.recv = torch.zeros(world * self.max_n, self.width, dtype=torch.float64, device=device)
+        nbuf = 2 if world > 1 else 1
+        self.sends = [torch.zeros(self.max_n, self.width, dtype=torch.float64, device=device) for _ in range(nbuf)]
+        self.recvs = [torch.zeros(world * self.max_n, self.width, dtype=torch.float64, device=device) for _ in range(nbuf)]
+        self.works = [None] * nbuf
+        self.cur = 0
+        self.ctl = None
+
+    @property
+    def send(self):
+        """the buffer the NEXT solve fills"""
+        return self.sends[self.cur]
 
     def attach(self, nmpc):
         """Let the controller's solve kernel write its rows [u0 | status | iters] straight into the send buffer
         (hilo_nmpc_set_gather): a step is then one launch + one collective.  Returns True when the controller supports it."""
         self.attached = bool(nmpc.set_gather_buffer(self.send))
+        self.ctl = nmpc if self.attached else None
         return self.attached
 
     attached = False
 
     def __call__(self, u0=None, status=None, iters=None):
         n = self.sizes[self.rank]
+        send, recv = self.sends[self.cur], self.recvs[self.cur]
         if n < self.max_n:
-            self.send[n:] = 0.        # padding rows of a smaller shard: never read back, but the wire carries defined values
+            send[n:] = 0.             # padding rows of a smaller shard: never read back, but the wire carries defined values
         if not self.attached:
-            self.send[:n, :self.nu] = u0
-            self.send[:n, self.nu] = status.to(torch.float64)
-            self.send[:n, self.nu + 1] = iters.to(torch.float64)
+            send[:n, :self.nu] = u0
+            send[:n, self.nu] = status.to(torch.float64)
+            send[:n, self.nu + 1] = iters.to(torch.float64)
         if self.world == 1:
-            full = self.send[:n]
-        else:
-            dist.all_gather_into_tensor(self.recv, self.send)
-            if len(set(self.sizes)) == 1:
-                full = self.recv
-            else:
-                full = torch.cat([self.recv[r * self.max_n: r * self.max_n + self.sizes[r]] for r in range(self.world)], dim=0)
-        return Gathered(full, self.nu)
+            return Gathered(send[:n], self.nu)
+        work = dist.all_gather_into_tensor(recv, send, async_op=True)
+        self.works[self.cur] = work
+        out = Gathered(recv, self.nu, work, self.sizes, self.max_n)
+        # the other pair of buffers serves the next step: its last collective (one step old) must be through before the next solve
+        # writes into its send buffer
+        self.cur ^= 1
+        if self.works[self.cur] is not None:
+            self.works[self.cur].wait()
+            self.works[self.cur] = None
+        if self.ctl is not None:
+            self.ctl.set_gather_buffer(self.sends[self.cur])
+        return out
+
+    def finish(self):
+        """wait for the collectives still in flight (end of a loop)"""
+        for i, w in enumerate(self.works):
+            if w is not None:
+                w.wait()
+                self.works[i] = None
 
 
 class Gathered:
     """(u0 [B, nu], status [B] int32, iters [B] int32) of all shards - unpacks like the tuple it stands for.  The two integer
     columns are converted from the wire's fp64 when they are LOOKED AT: a loop that only advances (bench.py, a deployment that
-    logs every n-th step) does not pay two conversion launches per step for values nobody reads.  The views alias the gather
-    buffer: they are valid until the next step."""
+    logs every n-th step) does not pay two conversion launches per step for values nobody reads.  The views alias one of the two
+    gather buffers: they are valid until the step after the next."""
 
-    def __init__(self, full, nu):
-        self._full, self._nu = full, nu
+    def __init__(self, full, nu, work=None, sizes=None, max_n=0):
+        self._full, self._nu, self._work, self._sizes, self._max_n = full, nu, work, sizes, max_n
+
+    def _table(self):
+        """the gathered rows - waits for the collective when somebody looks (see StepGather)"""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+            if len(set(self._sizes)) != 1:     # uneven shards: drop the padding rows
+                self._full = torch.cat([self._full[r * self._max_n: r * self._max_n + self._sizes[r]] for r in range(len(self._sizes))], dim=0)
+        return self._full
 
     @property
     def u0(self):
-        return self._full[:, :self._nu]
+        return self._table()[:, :self._nu]
 
     @property
     def status(self):
-        return self._full[:, self._nu].to(torch.int32)
+        return self._table()[:, self._nu].to(torch.int32)
 
     @property
     def iters(self):
-        return self._full[:, self._nu + 1].to(torch.int32)
+        return self._table()[:, self._nu + 1].to(torch.int32)
 
     def __iter__(self):
         return iter((self.u0, self.status, self.iters))
@@ -153,6 +191,8 @@ class ClosedLoop:
 
     def detach(self):
         """Give the controller back (its solve stops writing into this loop's buffers)."""
+        if hasattr(self.gather, 'finish'):
+            self.gather.finish()
         if self.fused_plant:
             self.ctl.set_plant_buffer(None)
             self.fused_plant = False

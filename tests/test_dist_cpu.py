@@ -225,3 +225,51 @@ def test_bench_timed_region_world2_gloo():
     for _ in range(6):
         u, _, _ = one.step()
     np.testing.assert_array_equal(u_last, u.numpy())
+
+
+def _sparse_reader_worker(rank, world, port, B, look, steps, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from hilo_mpc_amd.dist import ClosedLoop
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    nx, nu = 3, 2
+    lo, hi = shard_range(B, rank, world)
+    x0 = torch.as_tensor(np.random.default_rng(0).uniform(-2, 2, (B, nx)))[lo:hi].clone()
+    loop = ClosedLoop(_StubController(nx, nu, True), B, nu, rank, world, torch.device('cpu'), x0, p=torch.tensor([.25]))
+    res, held = {}, {}
+    for s in range(steps):
+        g = loop.step()
+        held[s] = g                                  # kept WITHOUT looking: the collective stays in flight
+        if s in look:
+            res[s] = (g.u0.numpy().copy(), g.status.numpy().copy())
+    loop.detach()                                    # waits for what is still in flight
+    if rank == 0:
+        out.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_is_asynchronous_and_double_buffered():
+    """The per-step all-gather does not block the loop: a table nobody looks at stays in flight while the next solves run, the two
+    send / receive buffers alternate, and a table looked at LATER (but before its buffer's second reuse) still holds its own step."""
+    from hilo_mpc_amd.dist import ClosedLoop
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    B, world, nx, nu, steps, look = 11, 2, 3, 2, 7, (2, 5, 6)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sparse_reader_worker, args=(r, world, port, B, look, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    x0 = torch.as_tensor(np.random.default_rng(0).uniform(-2, 2, (B, nx)))
+    one = ClosedLoop(_StubController(nx, nu, False), B, nu, 0, 1, torch.device('cpu'), x0.clone(), p=torch.tensor([.25]))
+    for s in range(steps):
+        u, st, _ = one.step()
+        if s in look:
+            np.testing.assert_array_equal(res[s][0], u.numpy())
+            np.testing.assert_array_equal(res[s][1], st.numpy())
