@@ -148,3 +148,21 @@ def test_bench_spawns_one_rank_per_gpu(monkeypatch):
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
     assert cmd[-6:] == ['--gpus', '4', '--steps', '3', '--config', 'C4'] and cmd[-7].endswith('bench.py')
     assert seen['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
+
+
+def test_committed_counters_are_withheld_when_the_profiled_kernel_is_another_one():
+    """bench.py carries HBM traffic / issue counters from COMMITTED rocprofv3 passes (they cannot be collected inside the timed run).
+    When this run's kernel time differs from the profiled kernel's by more than the band, the counters are withheld and the line says
+    why - a later kernel change does not keep stale counters on the driver's line."""
+    b = _bench()
+    import json
+    import os
+    prof = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r06_C2_summary.json')))
+    ms = prof['timed_region']['avg_ns'] * 1e-6
+    t, src = b.pmc_traffic_bytes('C2', with_source=True, kernel_ms=ms)
+    assert t and t > 0 and 'r06_C2_summary.json' in src and 'withheld' not in src
+    t, src = b.pmc_traffic_bytes('C2', with_source=True, kernel_ms=ms * 2.)
+    assert t is None and 'withheld' in src
+    iss, src = b.pmc_issue('C2', kernel_ms=ms * .4)
+    assert iss is None and 'withheld' in src
+    assert b._stale(None, 1.) is None and b._stale(1e6, 1.) is None and b._stale(1e6, 1.2) is None and 'withheld' in b._stale(1e6, 1.5)
