@@ -131,7 +131,7 @@ def pmc_issue(tag_key, kernel_key=None, kernel_ms=None):
             d = json.load(open(f))
             if kernel_key and kernel_key in d and isinstance(d[kernel_key], dict):
                 d = d[kernel_key]
-            out = {k: d[k] for k in ('mfma_busy_frac', 'valu_busy_frac', 'valu_insts_per_wave', 'lds_wait_frac') if k in d}
+            out = {k: d[k] for k in ('mfma_busy_frac', 'valu_busy_frac', 'valu_insts_per_wave', 'lds_wait_frac', 'valu_issue_floor_frac') if k in d}
             if 'mfma_busy_frac' not in out and 'SQ_VALU_MFMA_BUSY_CYCLES' in d and 'kernel_cycles' in d:
                 out['mfma_busy_frac'] = d['SQ_VALU_MFMA_BUSY_CYCLES']['steady_mean'] / (1024.0 * d['kernel_cycles'])
             if 'valu_busy_frac' not in out and 'SQ_ACTIVE_INST_VALU' in d and 'SQ_WAVE_CYCLES' in d:
@@ -647,10 +647,15 @@ def wl_kf(kind, args, torch, dev, rank, world):
                 # sigma points) up to two waves per SIMD of teams, one instance per lane beyond
                 "kernel": (f"kf_team_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}>"
                            if B * (16 if kind == 'ukf' else 4) <= 2 * 1024 * 64 else
-                           f"kf_multi_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}>" if K > 1 else
+                           # `discretize('rk4')` with shared Q, R: the multi-step kernels' LEAN variants (csrc/hilo_kf.hip::launch_multi)
+                           ("kf_multi_kernel<Chemostat4, true, true>" if kind == 'ukf' else "ekf_multi_lean_kernel<Chemostat4>") if K > 1 else
                            f"kf_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}, 2>"),
                 "kernel_ms": kern_ms, "launches_per_event_pair": G, "algorithmic_bytes_per_launch": B * K * bytes_step,
                 "filter_steps_per_launch": K,
+                # one instance per lane (B >= 2^20): what binds is the fp64 issue rate, not HBM - `valu_issue_floor_frac` = 4 clocks x
+                # VALU instructions / (1024 SIMDs x kernel clocks) from the committed counter passes of the same command
+                **({"issue_counters": pmc_issue(f'C3-{kind}_B1M', kernel_ms=kern_ms)[0],
+                    "issue_counters_source": pmc_issue(f'C3-{kind}_B1M', kernel_ms=kern_ms)[1]} if B >= (1 << 20) and K > 1 else {}),
                 "compulsory_bytes_per_launch": comp,
                 "note": "`achieved` / `frac`: the bytes one launch must move (tile in once, y in and tile + y_pred out per step, "
                         "[u; p], Q, R = `compulsory_bytes_per_launch`) per launch time against the HBM peak.  bytes_kf = 8 (2 nx "

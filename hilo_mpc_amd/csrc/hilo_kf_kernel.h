@@ -97,6 +97,26 @@ __device__ __forceinline__ void gain_update(double* x, double* P, const double* 
   }
 }
 
+// classic Runge-Kutta with ONE slope alive: the weighted sum is accumulated stage by stage (the same terms in the same order as
+// erk_step's final sum; the stage points without the tableau's zero entries, which only add exact zeros)
+template <class M, class T, class U, class P>
+__device__ __forceinline__ void rk4_lean(const T* x, const U* u, const P* p, double h, T* xn) {
+  constexpr int NX = M::NX;
+  T k[NX], xi[NX], acc[NX];
+  M::ode(x, u, p, h, k);
+#pragma unroll
+  for (int s = 0; s < NX; ++s) { acc[s] = x[s] + (h * (1.0 / 6)) * k[s]; xi[s] = x[s] + (h * 0.5) * k[s]; }
+  M::ode(xi, u, p, h, k);
+#pragma unroll
+  for (int s = 0; s < NX; ++s) { acc[s] = acc[s] + (h * (1.0 / 3)) * k[s]; xi[s] = x[s] + (h * 0.5) * k[s]; }
+  M::ode(xi, u, p, h, k);
+#pragma unroll
+  for (int s = 0; s < NX; ++s) { acc[s] = acc[s] + (h * (1.0 / 3)) * k[s]; xi[s] = x[s] + (h * 1.0) * k[s]; }
+  M::ode(xi, u, p, h, k);
+#pragma unroll
+  for (int s = 0; s < NX; ++s) xn[s] = acc[s] + (h * (1.0 / 6)) * k[s];
+}
+
 // ---- KF / EKF -------------------------------------------------------------------------------------------
 template <class M>
 __device__ __forceinline__ void ekf_deriv(const double* x, const double* P, const double* u, const double* p,
@@ -123,11 +143,13 @@ __device__ __forceinline__ void ekf_deriv(const double* x, const double* P, cons
     }
 }
 
-template <class M>
+// LEAN (kf_multi_kernel's variant for `discretize('rk4')` with one sub-step and Q, R shared by the batch): rk4_lean and no
+// continuous-time branch - the step then fits 256 registers and two waves share a SIMD
+template <class M, bool LEAN = false>
 __device__ __forceinline__ void ekf_predict(const KfParams& kp, double* x, double* P, const double* u,
                                             const double* p, const double* Q) {
   constexpr int NX = M::NX;
-  if constexpr (!M::DISCRETE) if (kp.continuous) {
+  if constexpr (!M::DISCRETE && !LEAN) if (kp.continuous) {
     // kf.py:97-110: integrate the augmented ODE; classic RK4, n_sub steps (the reference uses CVODES)
     const double h = kp.dt / kp.n_sub;
     for (int it = 0; it < kp.n_sub; ++it) {
@@ -163,7 +185,8 @@ __device__ __forceinline__ void ekf_predict(const KfParams& kp, double* x, doubl
     xd[i] = Dual<NX>(x[i]);
     xd[i].d[i] = 1.0;
   }
-  model_step<M>(kp.erk_order, kp.n_sub, xd, u, p, kp.dt, xn);
+  if constexpr (LEAN && !M::DISCRETE) rk4_lean<M>(xd, u, p, kp.dt, xn);
+  else model_step<M>(kp.erk_order, kp.n_sub, xd, u, p, kp.dt, xn);
   double FP[NX * NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i)
@@ -225,7 +248,7 @@ __device__ __forceinline__ void ekf_update(const KfParams& kp, double* x, double
 // ---- UKF ------------------------------------------------------------------------------------------------
 // The weighted sums follow the reference's accumulation order without FMA contraction: with alpha = 1e-3 the
 // centre weight is ~ -1e6 and six digits cancel, so rounding order is visible in the result.
-template <class M>
+template <class M, bool LEAN = false>
 __device__ __forceinline__ void ukf_predict(const KfParams& kp, double* x, double* P, double* X /*[NX][2NX+1]*/,
                                             const double* u, const double* p, const double* Q) {
 #pragma clang fp contract(off)
@@ -242,7 +265,9 @@ __device__ __forceinline__ void ukf_predict(const KfParams& kp, double* x, doubl
       if (k > NX) s = x[i] - kp.gamma * L[(k - 1 - NX) * NX + i];
       xs[i] = s;
     }
-    if (kp.continuous && !M::DISCRETE)
+    if constexpr (LEAN && !M::DISCRETE)
+      rk4_lean<M>(xs, u, p, kp.dt, xo);
+    else if (kp.continuous && !M::DISCRETE)
       model_step<M>(4, kp.n_sub, xs, u, p, kp.dt, xo);  // the reference integrates with CVODES
     else
       model_step<M>(kp.erk_order, kp.n_sub, xs, u, p, kp.dt, xo);
@@ -415,7 +440,7 @@ __global__ __launch_bounds__(KF_TPB) KF_OCC void kf_kernel(KfParams kp, int64_t 
 // reference's accumulated output) or only the last one goes back; y_pred [steps][B][ny].  A filter step at the BASELINE batch
 // (4096 instances = 1.6 MB) is launch-latency bound; K steps per launch divide that latency by K and, with only the last tile
 // written, move 8 (ny + nu + np + ny) bytes per step instead of the tile both ways.
-template <class M, bool UKF>
+template <class M, bool UKF, bool LEAN = false>
 __device__ __forceinline__ void kf_multi_body(const KfParams& kp, int64_t batch, int steps, const double* __restrict__ in_tile,
                                               const double* __restrict__ y, const double* __restrict__ up, int64_t up_stride,
                                               int64_t up_step, const double* __restrict__ Q, int64_t q_stride,
@@ -430,7 +455,11 @@ __device__ __forceinline__ void kf_multi_body(const KfParams& kp, int64_t batch,
   const bool active = (int)threadIdx.x < count;
   double tin[XP];
   tile_load<XP, KF_TPB>(in_tile, first, count, lds, tin);
-  double x[NX], P[NX * NX], X[UKF ? NX * NS : 1], upv[MaxOne<NUP>::v], yv[NY], ypv[NY], Qv[NX * NX], Rv[NY * NY];
+  double x[NX], P[NX * NX], X[UKF ? NX * NS : 1], upv[MaxOne<NUP>::v], yv[NY], ypv[NY], Qr[LEAN ? 1 : NX * NX], Rr[LEAN ? 1 : NY * NY];
+  // LEAN: Q and R are shared by the batch (strides 0) and read where a step uses them - wave-uniform addresses, no registers held
+  // over the Runge-Kutta stages
+  const double* Qv = LEAN ? Q : Qr;
+  const double* Rv = LEAN ? R : Rr;
   if (active) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -438,8 +467,10 @@ __device__ __forceinline__ void kf_multi_body(const KfParams& kp, int64_t batch,
 #pragma unroll
       for (int j = 0; j < NX; ++j) P[i * NX + j] = tin[i * W + 1 + j];
     }
-    vec_load<NX * NX>(Q, inst, q_stride, Qv);
-    vec_load<NY * NY>(R, inst, r_stride, Rv);
+    if constexpr (!LEAN) {
+      vec_load<NX * NX>(Q, inst, q_stride, Qr);
+      vec_load<NY * NY>(R, inst, r_stride, Rr);
+    }
     if constexpr (NUP > 0) vec_load<NUP>(up, inst, up_stride, upv);
   }
   for (int s = 0; s < steps; ++s) {
@@ -451,10 +482,10 @@ __device__ __forceinline__ void kf_multi_body(const KfParams& kp, int64_t batch,
       const double* p = upv + M::NU;
       vec_load<NY>(y + (int64_t)s * batch * NY, inst, NY, yv);
       if constexpr (UKF) {
-        ukf_predict<M>(kp, x, P, X, u, p, Qv);
+        ukf_predict<M, LEAN>(kp, x, P, X, u, p, Qv);
         ukf_update<M>(kp, x, P, X, yv, u, p, Rv, ypv);
       } else {
-        ekf_predict<M>(kp, x, P, u, p, Qv);
+        ekf_predict<M, LEAN>(kp, x, P, u, p, Qv);
         ekf_update<M>(kp, x, P, yv, u, p, Rv, ypv);
       }
 #pragma unroll
@@ -475,7 +506,7 @@ __device__ __forceinline__ void kf_multi_body(const KfParams& kp, int64_t batch,
   }
 }
 
-template <class M, bool UKF>
+template <class M, bool UKF, bool LEAN = false>
 __global__ __launch_bounds__(KF_TPB) KF_OCC void kf_multi_kernel(KfParams kp, int64_t batch, int steps,
                                                                  const double* __restrict__ in_tile, const double* __restrict__ y,
                                                                  const double* __restrict__ up, int64_t up_stride, int64_t up_step,
@@ -483,7 +514,17 @@ __global__ __launch_bounds__(KF_TPB) KF_OCC void kf_multi_kernel(KfParams kp, in
                                                                  const double* __restrict__ R, int64_t r_stride,
                                                                  double* __restrict__ out_tile, int64_t out_step,
                                                                  double* __restrict__ y_pred, int ipw) {
-  kf_multi_body<M, UKF>(kp, batch, steps, in_tile, y, up, up_stride, up_step, Q, q_stride, R, r_stride, out_tile, out_step, y_pred, ipw);
+  kf_multi_body<M, UKF, LEAN>(kp, batch, steps, in_tile, y, up, up_stride, up_step, Q, q_stride, R, r_stride, out_tile, out_step, y_pred, ipw);
+}
+
+// the EKF's LEAN variant with at least two waves per SIMD asked of the register allocator (chemostat4 lands on 258 registers without)
+template <class M>
+__global__ __launch_bounds__(KF_TPB) __attribute__((amdgpu_waves_per_eu(2))) void ekf_multi_lean_kernel(
+    KfParams kp, int64_t batch, int steps, const double* __restrict__ in_tile, const double* __restrict__ y,
+    const double* __restrict__ up, int64_t up_stride, int64_t up_step, const double* __restrict__ Q, int64_t q_stride,
+    const double* __restrict__ R, int64_t r_stride, double* __restrict__ out_tile, int64_t out_step, double* __restrict__ y_pred,
+    int ipw) {
+  kf_multi_body<M, false, true>(kp, batch, steps, in_tile, y, up, up_stride, up_step, Q, q_stride, R, r_stride, out_tile, out_step, y_pred, ipw);
 }
 
 // ---- one filter instance on a TEAM of lanes: small batches (the BASELINE's B = 4096) ------------------------------------------------

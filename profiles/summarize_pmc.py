@@ -16,7 +16,7 @@ import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 cfg = sys.argv[3] if len(sys.argv) > 3 else 'C2'
-KEY = 'hilo_user_solve' if cfg in ('C5', 'C5-dae') else 'ocp_solve_kernel'      # cfg 'icache': the I-cache passes of C2 (run_pmc_icache.sh)
+KEY = os.environ.get('PMC_KEY') or ('hilo_user_solve' if cfg in ('C5', 'C5-dae') else 'ocp_solve_kernel')      # cfg 'icache': the I-cache passes of C2 (run_pmc_icache.sh)
 CLOCK_GHZ = 2.4          # MI355X shader clock (MI355X_MICROARCH.md)
 N_SIMD = 1024
 STEADY = {'C2': 6, 'icache': 6, 'C4': 4, 'C3-mhe': 4, 'C5': 3, 'C5-dae': 2}.get(cfg, 4)     # timed launches of each pass (run_round.sh)
@@ -48,6 +48,8 @@ def collect(pattern, key, steady):
         out['mfma_busy_frac'] = g('SQ_VALU_MFMA_BUSY_CYCLES') / (N_SIMD * out['kernel_cycles'])
     if g('SQ_ACTIVE_INST_VALU') and g('SQ_WAVE_CYCLES'):
         out['valu_busy_frac'] = g('SQ_ACTIVE_INST_VALU') / g('SQ_WAVE_CYCLES')
+    if g('SQ_INSTS_VALU') and 'kernel_cycles' in out:     # a wave's fp64 / fp32 instruction occupies its SIMD for 4 clocks
+        out['valu_issue_floor_frac'] = 4.0 * g('SQ_INSTS_VALU') / (N_SIMD * out['kernel_cycles'])
     if g('SQ_WAIT_INST_LDS') is not None and g('SQ_WAVE_CYCLES'):
         out['lds_wait_frac'] = g('SQ_WAIT_INST_LDS') / g('SQ_WAVE_CYCLES')
     if g('SQC_ICACHE_REQ') and g('SQC_ICACHE_MISSES') is not None:

@@ -405,3 +405,34 @@ def test_team_and_one_lane_kernels_agree(kind, symbolic):
     tol = dict(rtol=1e-12, atol=1e-14) if kind == 'EKF' else dict(rtol=1e-9, atol=1e-9)
     for a, b in zip(*out):
         np.testing.assert_allclose(a, b, **tol)
+
+
+@pytest.mark.parametrize('kind', ['EKF', 'UKF'])
+def test_lean_variant_of_the_multi_step_kernel_equals_the_general_one(kind):
+    """`discretize('rk4')` with Q, R shared by the batch runs `kf_multi_kernel<.., LEAN>` / `ekf_multi_lean_kernel` (one Runge-Kutta
+    slope alive, Q and R read where they are used: two waves per SIMD); the same values handed over per instance ([B, n, n]) take
+    the general kernel.  Same terms in the same order: equal to rounding of the fused multiply-adds the compiler forms."""
+    import hilo_mpc_amd as H
+    import torch
+    K, B = 4, 40000
+    x, P, u, p, y = _chemo_batch(B, seed=31)
+    rng = np.random.default_rng(32)
+    ys = y[None] + .01 * rng.normal(size=(K, B, 2))
+    model = H.Model('chemostat4').discretize('rk4').setup(dt=1.)
+    Q, R = np.diag([1e-4, 2e-4, 3e-4, 1e-4]) + 1e-5, np.array([[1e-2, 1e-3], [1e-3, 2e-2]])
+    out = []
+    for per_instance in (False, True):
+        f = getattr(H, kind)(model)
+        f.setup()
+        if per_instance:
+            f.Q = torch.as_tensor(np.tile(Q, (B, 1, 1)), device='cuda')
+            f.R = torch.as_tensor(np.tile(R, (B, 1, 1)), device='cuda')
+        else:
+            f.Q, f.R = Q, R
+        f.set_initial_guess(x, P0=P)
+        sol = f.estimate(y=ys, u=u, p=p, steps=K)
+        out.append((sol['x'], sol['P'], sol['y']))
+    tol = dict(rtol=1e-13, atol=1e-15) if kind == 'EKF' else dict(rtol=1e-9, atol=1e-9)
+    for a, b in zip(*out):
+        np.testing.assert_allclose(a, b, **tol)
+
