@@ -53,7 +53,8 @@ class NmpcDesc(C.Structure):
                [('coll_B', C.c_void_p), ('n_user_gp', C.c_int32), ('user_nz', C.c_int32), ('user_gp', C.c_void_p * 4),
                 ('hess_pattern', C.c_void_p), ('max_hessian_perturbation', C.c_double), ('n_zbound', C.c_int32), ('x0_free_mask', C.c_int32),
                 ('zb_lb', C.c_void_p), ('zb_ub', C.c_void_p), ('n_acc', C.c_int32), ('n_acc_expr', C.c_int32),
-                ('acc_coef', C.c_void_p), ('acc_lb', C.c_void_p), ('acc_ub', C.c_void_p)]
+                ('acc_coef', C.c_void_p), ('acc_lb', C.c_void_p), ('acc_ub', C.c_void_p), ('acc_soft', C.c_int32),
+                ('acc_max_violation', C.c_void_p)]
 
 
 class MheDesc(C.Structure):

@@ -74,7 +74,7 @@ int launch_multi(const KfParams& kp, int64_t batch, int steps, const double* in,
   ipw = ipw < 16 ? 16 : (ipw > KF_TPB ? KF_TPB : ipw);
   const unsigned grid = (unsigned)((batch + ipw - 1) / ipw);
   // the common recipe - `discretize('rk4')`, one sub-step, Q and R shared by the batch - on the variant that fits two waves per SIMD
-  // (csrc/hilo_kf_kernel.h::rk4_lean; the same arithmetic, fewer registers)
+  // (csrc/hilo_models.h::rk4_classic without the run-time order dispatch; the same arithmetic, fewer registers)
   const bool rk4 = kp.n_sub == 1 && (kp.kind == HILO_KF_UKF ? (kp.erk_order == 4 || kp.continuous) : (kp.erk_order == 4 && !kp.continuous));
   static const bool lean_knob = [] { const char* e = getenv("HILO_KF_LEAN"); return e ? atoi(e) != 0 : true; }();
   if constexpr (!M::DISCRETE) if (rk4 && qs == 0 && rs == 0 && lean_knob) {

@@ -97,26 +97,6 @@ __device__ __forceinline__ void gain_update(double* x, double* P, const double* 
   }
 }
 
-// classic Runge-Kutta with ONE slope alive: the weighted sum is accumulated stage by stage (the same terms in the same order as
-// erk_step's final sum; the stage points without the tableau's zero entries, which only add exact zeros)
-template <class M, class T, class U, class P>
-__device__ __forceinline__ void rk4_lean(const T* x, const U* u, const P* p, double h, T* xn) {
-  constexpr int NX = M::NX;
-  T k[NX], xi[NX], acc[NX];
-  M::ode(x, u, p, h, k);
-#pragma unroll
-  for (int s = 0; s < NX; ++s) { acc[s] = x[s] + (h * (1.0 / 6)) * k[s]; xi[s] = x[s] + (h * 0.5) * k[s]; }
-  M::ode(xi, u, p, h, k);
-#pragma unroll
-  for (int s = 0; s < NX; ++s) { acc[s] = acc[s] + (h * (1.0 / 3)) * k[s]; xi[s] = x[s] + (h * 0.5) * k[s]; }
-  M::ode(xi, u, p, h, k);
-#pragma unroll
-  for (int s = 0; s < NX; ++s) { acc[s] = acc[s] + (h * (1.0 / 3)) * k[s]; xi[s] = x[s] + (h * 1.0) * k[s]; }
-  M::ode(xi, u, p, h, k);
-#pragma unroll
-  for (int s = 0; s < NX; ++s) xn[s] = acc[s] + (h * (1.0 / 6)) * k[s];
-}
-
 // ---- KF / EKF -------------------------------------------------------------------------------------------
 template <class M>
 __device__ __forceinline__ void ekf_deriv(const double* x, const double* P, const double* u, const double* p,
@@ -143,7 +123,7 @@ __device__ __forceinline__ void ekf_deriv(const double* x, const double* P, cons
     }
 }
 
-// LEAN (kf_multi_kernel's variant for `discretize('rk4')` with one sub-step and Q, R shared by the batch): rk4_lean and no
+// LEAN (kf_multi_kernel's variant for `discretize('rk4')` with one sub-step and Q, R shared by the batch): rk4_classic without the run-time dispatch and no
 // continuous-time branch - the step then fits 256 registers and two waves share a SIMD
 template <class M, bool LEAN = false>
 __device__ __forceinline__ void ekf_predict(const KfParams& kp, double* x, double* P, const double* u,
@@ -185,7 +165,7 @@ __device__ __forceinline__ void ekf_predict(const KfParams& kp, double* x, doubl
     xd[i] = Dual<NX>(x[i]);
     xd[i].d[i] = 1.0;
   }
-  if constexpr (LEAN && !M::DISCRETE) rk4_lean<M>(xd, u, p, kp.dt, xn);
+  if constexpr (LEAN && !M::DISCRETE) rk4_classic<M>(xd, u, p, kp.dt, xn, NoExt());
   else model_step<M>(kp.erk_order, kp.n_sub, xd, u, p, kp.dt, xn);
   double FP[NX * NX];
 #pragma unroll
@@ -265,9 +245,16 @@ __device__ __forceinline__ void ukf_predict(const KfParams& kp, double* x, doubl
       if (k > NX) s = x[i] - kp.gamma * L[(k - 1 - NX) * NX + i];
       xs[i] = s;
     }
-    if constexpr (LEAN && !M::DISCRETE)
-      rk4_lean<M>(xs, u, p, kp.dt, xo);
-    else if (kp.continuous && !M::DISCRETE)
+    if constexpr (LEAN && !M::DISCRETE) {
+      // the model's divisions as x * rcp_fast(y) (<= 1-2 ulp; hilo_ad.h::FastD, the scalar type the engine's derivative phase uses):
+      // the 36 right-hand sides of a step hold 108 IEEE division sequences of 12 instructions otherwise, a third of the step
+      FastD xf[NX], xof[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xf[i] = FastD(xs[i]);
+      rk4_classic<M>(xf, u, p, kp.dt, xof, NoExt());
+#pragma unroll
+      for (int i = 0; i < NX; ++i) xo[i] = xof[i].v;
+    } else if (kp.continuous && !M::DISCRETE)
       model_step<M>(4, kp.n_sub, xs, u, p, kp.dt, xo);  // the reference integrates with CVODES
     else
       model_step<M>(kp.erk_order, kp.n_sub, xs, u, p, kp.dt, xo);

@@ -637,6 +637,32 @@ HD void erk_step(int order, const T* x, const U* u, const P* p, double h, T* xn,
             (h * erk_b<2>(order)) * k[2][s] + (h * erk_b<3>(order)) * k[3][s];
 }
 
+// The classic tableau with ONE slope alive: the weighted sum is accumulated stage by stage - the same terms in the same order as
+// erk_step's final sum - and the stage points leave out the tableau's zero entries (`x + (h 0) k0 + ...`: exact zeros that strict
+// fp64 arithmetic may not drop and that keep every earlier slope alive).  Same results as erk_step<M>(4, ...), a third of its live
+// values: with forward-mode types (Dual<N>, Jet2) the four slopes are most of a kernel's registers.
+template <class M, class T, class U, class P, class E>
+HD void rk4_classic(const T* x, const U* u, const P* p, double h, T* xn, const E& ext) {
+  constexpr int NX = M::NX;
+  T k[NX], xi[NX], acc[NX];
+  auto f = [&](const T* at) {
+    if constexpr (model_has_ext<M>::value) M::ode(at, u, p, h, k, ext);
+    else M::ode(at, u, p, h, k);
+  };
+  f(x);
+#pragma unroll
+  for (int s = 0; s < NX; ++s) { acc[s] = x[s] + (h * (1.0 / 6)) * k[s]; xi[s] = x[s] + (h * 0.5) * k[s]; }
+  f(xi);
+#pragma unroll
+  for (int s = 0; s < NX; ++s) { acc[s] = acc[s] + (h * (1.0 / 3)) * k[s]; xi[s] = x[s] + (h * 0.5) * k[s]; }
+  f(xi);
+#pragma unroll
+  for (int s = 0; s < NX; ++s) { acc[s] = acc[s] + (h * (1.0 / 3)) * k[s]; xi[s] = x[s] + (h * 1.0) * k[s]; }
+  f(xi);
+#pragma unroll
+  for (int s = 0; s < NX; ++s) xn[s] = acc[s] + (h * (1.0 / 6)) * k[s];
+}
+
 // one sampling interval of the shooting map: discrete models are evaluated directly (mpc.py:1381-1389,:1665),
 // continuous ones through ERK of the requested order with `nsub` equal sub-steps
 template <class M, class T, class U, class P, class E = NoExt>
@@ -646,8 +672,12 @@ HD void model_step(int order, int nsub, const T* x, const U* u, const P* p, doub
     else M::ode(x, u, p, dt, xn);
   } else {
     constexpr int NX = M::NX;
-    if (order == 4 && nsub == 1) {  // the common recipe `model.discretize('rk4')`: tableau folded at compile time
+    if (order == 4 && nsub == 1) {  // the common recipe `model.discretize('rk4')`
+#ifdef HILO_RK4_GENERIC               // developer builds: the generic map with the tableau folded at compile time
       erk_step<M>(4, x, u, p, dt, xn, ext);
+#else
+      rk4_classic<M>(x, u, p, dt, xn, ext);
+#endif
       return;
     }
     const double h = dt / nsub;

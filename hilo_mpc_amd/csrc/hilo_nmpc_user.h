@@ -34,6 +34,8 @@
 
 namespace hilo {
 
+constexpr int USER_QROW = 1000;   // terminal row table (o_trowx): USER_QROW + r = a row of custom constraint function r
+
 // ---- layout of pc.cost for NmpcUser: plain function of the dimensions so that the host (hilo_jit.hip) fills the block ----
 struct UserLayout {
   int mza, o_wz, o_zref, o_wn, o_xrefn, o_wdu, o_hasdu, o_we, o_wet, o_ws, o_idxs, o_wt, o_idxt, o_rowx, o_rows, o_rowe,
@@ -811,7 +813,7 @@ struct NmpcUser {
 #pragma unroll
         for (int m = 0; m < (NC > 0 ? NC : 1); ++m) {
           const int r = m - pc.nc;
-          if (m < NC && r >= 0 && r < pc.nc_term) {
+          if (m < NC && r >= 0 && r < pc.nc_term && (int)pc.cost[L.o_trowx + r] < USER_QROW) {
             T v = pc.cost[L.o_trows + r] * pick<F::NTEXPR>(ct, (int)pc.cost[L.o_trowx + r]);
             if constexpr (NE > 0) {
               const int ei = (int)pc.cost[L.o_trowe + r];
@@ -823,8 +825,9 @@ struct NmpcUser {
       }
     }
     if constexpr (NQ > 0) {
-      // custom constraint rows: the LAST NQ terminal rows, q_{r,N} + sum_j a[r][N][j] psi_j(x_N) on the end state of the horizon
-      // (scaled variables; an expression that names an input has a zero coefficient here - v holds no input of stage N)
+      // custom constraint rows: the terminal rows marked USER_QROW + r, sign (q_{r,N} + sum_j a[r][N][j] psi_j(x_N)) - e_cus on the
+      // end state of the horizon (scaled variables; an expression that names an input has a zero coefficient here - v holds no input
+      // of stage N); soft rows (mpc.py:1733-1739): fun - e_cus <= ub and -(fun + e_cus) <= -lb
       if (k == pc.N - 1) {
         T xe[MXA], ue[MUA > 0 ? MUA : 1], ps[NPSI], val[NQ];
 #pragma unroll
@@ -846,8 +849,18 @@ struct NmpcUser {
         }
 #pragma unroll
         for (int m = 0; m < (NC > 0 ? NC : 1); ++m) {
-          const int r = m - (pc.nc + pc.nc_term - NQ);
-          if (m < NC && r >= 0 && r < NQ) d[m] = pick<NQ>(val, r);
+          const int r = m - pc.nc;
+          if (m < NC && r >= 0 && r < pc.nc_term) {
+            const int q = (int)pc.cost[L.o_trowx + r] - USER_QROW;
+            if (q >= 0) {
+              T v = pc.cost[L.o_trows + r] * pick<NQ>(val, q);
+              if constexpr (NE > 0) {
+                const int ei = (int)pc.cost[L.o_trowe + r];
+                if (ei >= 0) v = v - pick<NE>(x + MXA, ei);
+              }
+              d[m] = v;
+            }
+          }
         }
       }
     }
@@ -871,7 +884,10 @@ struct NmpcUser {
       for (int r = 0; r < NQ; ++r) {
         double nu = 0.0;
 #pragma unroll
-        for (int m = 0; m < (NC > 0 ? NC : 1); ++m) nu = (m < NC && m == pc.nc + pc.nc_term - NQ + r) ? nuN[m] : nu;
+        for (int m = 0; m < (NC > 0 ? NC : 1); ++m) {      // a soft function has two rows: sign times multiplier, summed
+          const int t = m - pc.nc;
+          if (m < NC && t >= 0 && t < pc.nc_term && (int)pc.cost[L.o_trowx + t] == USER_QROW + r) nu += pc.cost[L.o_trows + t] * nuN[m];
+        }
 #pragma unroll
         for (int j = 0; j < NPSI; ++j) {
           const double cf = pc.cost[L.o_acc + (r * (pc.N + 1) + pc.N) * NPSI + j];

@@ -44,7 +44,7 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   if (D && d->n_tcon > 0 && d->tcon_soft)
     return fail(HILO_ENOTSUP, "collocation together with a SOFT terminal constraint is not built (hard ones are)");
   // ---- inequality rows (same construction as hilo_nmpc.hip) ----
-  int ne = 0, nrow = 0, n_con_ref = 0, ntrow = 0, n_tcon_ref = 0, ne_stage = 0;
+  int ne = 0, nrow = 0, n_con_ref = 0, ntrow = 0, n_tcon_ref = 0, ne_stage = 0, ne_cus0 = 0;
   int row_expr[OCP_MAXNC], row_sign[OCP_MAXNC], row_e[OCP_MAXNC], row_ref[OCP_MAXNC];
   int trow_expr[OCP_MAXNC], trow_sign[OCP_MAXNC], trow_e[OCP_MAXNC], trow_ref[OCP_MAXNC];
   double row_lb[OCP_MAXNC], row_ub[OCP_MAXNC], trow_lb[OCP_MAXNC], trow_ub[OCP_MAXNC];
@@ -104,18 +104,27 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   // terminal rows (hilo_nmpc_user.h::term_rows); in the engine's lam_g they follow the terminal rows - the host moves them to the end
   // of g, where the reference has them (mpc.py:1729-1745)
   const int nq = d->n_acc, npsi = d->n_acc_expr;
+  ne_cus0 = ne;
   HILO_REQUIRE(nq >= 0 && nq <= 2 && npsi >= 0 && npsi <= 4, "hilo_nmpc_create: at most 2 custom rows over at most 4 stage expressions");
   if (nq > 0) {
     HILO_REQUIRE(npsi > 0 && d->acc_coef && d->acc_lb && d->acc_ub, "hilo_nmpc_create: custom rows need acc_coef, acc_lb, acc_ub");
     if (d->n_tcon > 0 && d->tcon_soft) return fail(HILO_ENOTSUP, "custom rows together with a SOFT terminal constraint are not built");
     if (d->Nc > 0 && d->Nc < d->N) return fail(HILO_ENOTSUP, "custom rows together with a control horizon Nc < N are not built");
-    for (int r = 0; r < nq; ++r) {
-      HILO_REQUIRE(d->acc_lb[r] <= d->acc_ub[r], "hilo_nmpc_create: custom row %d has lb > ub", r);
-      HILO_REQUIRE(nrow + ntrow < OCP_MAXNC, "too many constraint rows");
-      trow_expr[ntrow] = 0; trow_sign[ntrow] = 0; trow_e[ntrow] = -1; trow_lb[ntrow] = d->acc_lb[r]; trow_ub[ntrow] = d->acc_ub[r];
-      trow_ref[ntrow++] = n_tcon_ref + r;
-    }
-    n_tcon_ref += nq;
+    // terminal row table: expression index USER_QROW + r marks a row of custom function r (sign and slack like every soft row)
+    if (d->acc_soft) ne += nq;           // slacks e_cus behind the other slacks in v (mpc.py:1551-1556)
+    for (int pass = 0; pass < (d->acc_soft ? 2 : 1); ++pass)
+      for (int r = 0; r < nq; ++r) {
+        HILO_REQUIRE(d->acc_lb[r] <= d->acc_ub[r], "hilo_nmpc_create: custom row %d has lb > ub", r);
+        const double lb = d->acc_lb[r], ub = d->acc_ub[r];
+        if (d->acc_soft && !(pass == 0 ? ub < INFINITY : lb > -INFINITY)) continue;     // not imposed: zero multiplier in its place
+        HILO_REQUIRE(nrow + ntrow < OCP_MAXNC, "too many constraint rows");
+        trow_expr[ntrow] = USER_QROW + r;
+        if (!d->acc_soft) { trow_sign[ntrow] = 1; trow_e[ntrow] = -1; trow_lb[ntrow] = lb; trow_ub[ntrow] = ub; }
+        else if (pass == 0) { trow_sign[ntrow] = 1; trow_e[ntrow] = ne_cus0 + r; trow_lb[ntrow] = -INFINITY; trow_ub[ntrow] = ub; }      // fun - e <= ub
+        else { trow_sign[ntrow] = -1; trow_e[ntrow] = ne_cus0 + r; trow_lb[ntrow] = -INFINITY; trow_ub[ntrow] = -lb; }                 // -(fun + e) <= -lb
+        trow_ref[ntrow++] = n_tcon_ref + pass * nq + r;
+      }
+    n_tcon_ref += d->acc_soft ? 2 * nq : nq;
   }
   // collocation: the reference imposes the stage constraints at every collocation point as well as at the node (mpc.py:1338-1356,
   // :1700-1725) - the engine's rows of a stage are the node's rows followed by those of the d collocation points
@@ -241,9 +250,10 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   for (int a = 0; a < ne_stage; ++a)    // e^T W e once per stage (mpc.py:1708), W = 1e4 I by default (modeling.py:875)
     for (int b = 0; b < ne_stage; ++b)
       c.cost[L.o_we + a * ne + b] = d->con_weight ? d->con_weight[a * ne_stage + b] : (a == b ? 1e4 : 0.0);
-  for (int a = ne_stage; a < ne; ++a)   // e_T^T W e_T once (mpc.py:1686)
-    for (int b = ne_stage; b < ne; ++b)
+  for (int a = ne_stage; a < ne_cus0; ++a)   // e_T^T W e_T once (mpc.py:1686)
+    for (int b = ne_stage; b < ne_cus0; ++b)
       c.cost[L.o_wet + a * ne + b] = d->tcon_weight ? d->tcon_weight[(a - ne_stage) * d->n_tcon + (b - ne_stage)] : (a == b ? 1e4 : 0.0);
+  for (int a = ne_cus0; a < ne; ++a) c.cost[L.o_wet + a * ne + a] = 1e4;   // 1e4 e_cus^T e_cus once (mpc.py:1732-1733)
   int rcode = HILO_OK;
   for (int a = 0; a < nps; ++a) {
     if (!d->path_stage_idx || !d->path_stage_W || d->path_stage_idx[a] < 0 || d->path_stage_idx[a] >= mx)
@@ -323,7 +333,8 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
       const int a = i - mxa;
       lb = 0.0;
       ub = a < ne_stage ? (d->con_max_violation ? d->con_max_violation[a] : INFINITY)
-                        : (d->tcon_max_violation ? d->tcon_max_violation[a - ne_stage] : INFINITY);
+           : a < ne_cus0 ? (d->tcon_max_violation ? d->tcon_max_violation[a - ne_stage] : INFINITY)
+                         : (d->acc_max_violation ? d->acc_max_violation[a - ne_cus0] : INFINITY);
     }
     else if (i < nxe) {}                                                                            // held inputs: states without a box
     else if (i < nxe + mu) { const int j = i - nxe; if (d->u_lb) lb = d->u_lb[j] / c.sz[i]; if (d->u_ub) ub = d->u_ub[j] / c.sz[i]; }
@@ -361,9 +372,11 @@ int nmpc_user_create(const hilo_nmpc_desc* d, int device, hilo_nmpc** out) {
   if (e == hipSuccess) e = hipMemcpy(h->dev, &c, sizeof(OcpConst), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&h->v_guess, sizeof(double) * h->n_v);
   if (e == hipSuccess) {
-    // mpc.py:1468-1482: the guess is tiled over the horizon (scaled, mpc.py:255,259); slacks start at 0 (mpc.py:1535)
+    // mpc.py:1468-1482: the guess is tiled over the horizon (scaled, mpc.py:255,259); slacks start at 0 (mpc.py:1535) - those of soft
+    // custom rows at the NUMBER of rows (mpc.py:1555 writes the size where the others write zeros)
     double* g = new double[h->n_v];
     for (int i = 0; i < h->n_v; ++i) g[i] = 0.0;
+    for (int a = ne_cus0; a < ne; ++a) g[h->n_v - (ne + nq) + a] = (double)nq;
     for (int k = 0; k <= N; ++k) {
       for (int i = 0; i < mx; ++i) g[k * mxa + i] = (d->x_guess ? d->x_guess[i] : 0.0) / sx[i];
       if (nth) g[k * mxa + mx] = d->theta_guess;                                            // mpc.py:1194

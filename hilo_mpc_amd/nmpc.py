@@ -613,9 +613,9 @@ class NMPC:
         (scaled) decision vector, `x_ind` / `u_ind` the index lists of the nodes.  Offloaded for functions that are SUMS OVER THE
         STAGES of single-stage terms (integrals, budgets, averages - the reference's own use, tests/test_NMPC.py:519-552): each
         row rides on an accumulator state of the stage-structured problem (hilo_mpc_amd/custom.py); the function is called once at
-        setup() with a vector of symbols.  The soft variant (slack `e_cus`, mpc.py:1551-1556, :1731-1740) is not built."""
-        if soft:
-            raise NotImplementedError("soft custom constraints (the slack e_cus of mpc.py:1551-1556) are not offloaded; hard ones are")
+        setup() with a vector of symbols.  soft=True (mpc.py:1551-1556, :1731-1740): one slack `e_cus` per row behind the other slacks
+        in v, in [0, max_violation], penalised by 1e4 e_cus^T e_cus, and TWO rows per function in g - fun - e_cus <= ub, then
+        fun + e_cus >= lb."""
         if fun is None or not callable(fun):
             raise TypeError("The custom constraint must be a function fun(v, x_ind, u_ind).")
         lb = [-np.inf] if lb is None else _wrap_list(lb)                 # optimizer.py:1195-1200
@@ -625,6 +625,11 @@ class NMPC:
         self._custom_constraint_fun = fun
         self._custom_constraint_fun_lb, self._custom_constraint_fun_ub = [float(v) for v in lb], [float(v) for v in ub]
         self._custom_constraint_size = len(lb)
+        self._custom_constraint_is_soft_flag = bool(soft)
+        mv = np.broadcast_to(np.asarray(max_violation, dtype=float).ravel(), (len(lb),)) if np.size(max_violation) in (1, len(lb)) else None
+        if mv is None:
+            raise ValueError("max_violation must be one value or one per custom constraint row.")
+        self._custom_constraint_maximum_violation = mv.copy()
         self._custom_constraint_flag = True
         self._nlp_setup_done = False
 
@@ -1010,8 +1015,11 @@ class NMPC:
             dn_ = coll['d'] * (nxa_ + nza_) if coll is not None else 0
             xi = [list(range(k * nxa_, (k + 1) * nxa_)) for k in range(N + 1)]
             ui = [list(range((N + 1) * nxa_ + k * nua_, (N + 1) * nxa_ + (k + 1) * nua_)) for k in range(Nc)]
-            n_v_ref = (N + 1) * nxa_ + Nc * nua_ + (N + 1) * nza_ + N * dn_ + ne + ne_term
             mc = self._custom_constraint_size
+            csoft = bool(getattr(self, '_custom_constraint_is_soft_flag', False))
+            if csoft and ne_term:
+                raise NotImplementedError("soft custom constraints together with a soft terminal constraint are not offloaded")
+            n_v_ref = (N + 1) * nxa_ + Nc * nua_ + (N + 1) * nza_ + N * dn_ + ne + ne_term + (mc if csoft else 0)
             acc_psi, coef, const = decompose(self._custom_constraint_fun, xi, ui, n_v_ref, m, mc)
             if Nc < N:
                 raise NotImplementedError("a custom constraint together with a control horizon Nc < N is not offloaded")
@@ -1025,6 +1033,9 @@ class NMPC:
             d.acc_coef = hp(np.ascontiguousarray(coef, dtype=np.float64).ravel())
             d.acc_lb = hp(np.asarray(self._custom_constraint_fun_lb) - const)
             d.acc_ub = hp(np.asarray(self._custom_constraint_fun_ub) - const)
+            if csoft:
+                d.acc_soft = 1
+                d.acc_max_violation = hp(self._custom_constraint_maximum_violation)
             need_user = True
 
         def jit_desc(policy):
@@ -1134,7 +1145,8 @@ class NMPC:
             # the engine's lam_g / g carry the custom rows as the last terminal rows, in front of the last node's stage rows; the
             # reference appends them to g (mpc.py:1729-1745)
             R = (2 * sc.size if sc.is_soft else sc.size) if sc.is_set else 0
-            cus = list(range(self._n_g - R - self._nq, self._n_g - R))
+            nqr = self._nq_rows = (2 if getattr(self, '_custom_constraint_is_soft_flag', False) else 1) * self._nq    # mpc.py:1733-1739
+            cus = list(range(self._n_g - R - nqr, self._n_g - R))
             self._g_order = [i for i in range(self._n_g) if i not in set(cus)] + cus
         N, Nc = self._prediction_horizon, self._control_horizon
         # integer bookkeeping of mpc.py:1464-1537 (bit-exact index maps); a path variable is a state + an input;
@@ -1151,6 +1163,8 @@ class NMPC:
         eoff = off + (N + 1) * nza + N * (dn + zblocks * nza)
         self._e_soft_stage_ind = list(range(eoff, eoff + ne))
         self._e_soft_term_ind = list(range(eoff + ne, eoff + ne + ne_term))                               # mpc.py:1542-1543
+        ne_cus = self._nq if (self._nq and getattr(self, '_custom_constraint_is_soft_flag', False)) else 0
+        self._e_cus_ind = list(range(eoff + ne + ne_term, eoff + ne + ne_term + ne_cus))                    # mpc.py:1551-1556
         # algebraic states: node blocks z_0..z_N behind the slacks' predecessors, then per interval [ip_k | zp_k] (mpc.py:1488-1518)
         self._z_ind = [list(range(off + k * nza, off + (k + 1) * nza)) for k in range(N + 1)] if nza else []
         off += (N + 1) * nza
@@ -1303,9 +1317,15 @@ class NMPC:
                                                   ptr(kkt), stream_ptr(dev)))
         if self._nq:       # the reference's layouts: no accumulator entries in v, the custom rows at the end of g (+ their constant parts)
             v_opt, lam_g = v_opt[:, :self._n_v], lam_g[:, self._g_order]
+            soft_rows = self._nq_rows - self._nq          # the engine's row -(fun + e_cus) <= -lb is the reference's fun + e_cus >= lb
+            if soft_rows:
+                lam_g[:, -soft_rows:] = -lam_g[:, -soft_rows:]
             if self._full_solution:
                 g_val, lam_x = g_val[:, self._g_order].clone(), lam_x[:, :self._n_v]
-                g_val[:, -self._nq:] += torch.as_tensor(self._custom_const, dtype=torch.float64, device=dev)
+                if soft_rows:
+                    g_val[:, -soft_rows:] = -g_val[:, -soft_rows:]
+                g_val[:, -self._nq_rows:] += torch.as_tensor(np.tile(self._custom_const, self._nq_rows // self._nq), dtype=torch.float64,
+                                                             device=dev)
         self._nlp_solution = {'x': v_opt, 'f': f_opt, 'lam_g': lam_g, 'status': status, 'iter_count': iters, 'kkt_error': kkt}
         if self._full_solution:
             self._nlp_solution.update(g=g_val, lam_x=lam_x)
@@ -1459,6 +1479,8 @@ class NMPC:
         if zg is not None:
             for ind in getattr(self, '_z_ind', []) + getattr(self, '_zp_ind', []):
                 v[ind] = np.tile(np.asarray(zg, dtype=float), len(ind) // len(zg))
+        if getattr(self, '_e_cus_ind', []):
+            v[self._e_cus_ind] = len(self._e_cus_ind)                      # mpc.py:1555: the size where the other slacks get zeros
         return to_dev(np.tile(v, (B, 1)), self._dev)
 
     def _v_bounds(self):
@@ -1476,8 +1498,10 @@ class NMPC:
         nxa, nua = nx + nth, nu + nth
         lb[:(N + 1) * nxa], ub[:(N + 1) * nxa] = np.tile(xl, N + 1), np.tile(xu, N + 1)
         lb[(N + 1) * nxa:(N + 1) * nxa + Nc * nua], ub[(N + 1) * nxa:(N + 1) * nxa + Nc * nua] = np.tile(ul, Nc), np.tile(uu, Nc)
-        for ind in (self._e_soft_stage_ind, self._e_soft_term_ind):
+        for ind in (self._e_soft_stage_ind, self._e_soft_term_ind, getattr(self, '_e_cus_ind', [])):
             lb[ind] = 0.
+        if getattr(self, '_e_cus_ind', []):
+            ub[self._e_cus_ind] = self._custom_constraint_maximum_violation
         for ind in self._ip_ind:
             lb[ind], ub[ind] = np.tile(xl, len(ind) // nxa), np.tile(xu, len(ind) // nxa)
         return to_dev(lb, self._dev), to_dev(ub, self._dev)

@@ -363,6 +363,11 @@ typedef struct hilo_nmpc_desc {
   int32_t n_acc, n_acc_expr;
   const double* acc_coef;      /* [n_acc][N + 1][n_acc_expr] */
   const double* acc_lb; const double* acc_ub;      /* [n_acc] bounds of the rows (constant parts of the function already removed) */
+  /* soft = True (mpc.py:1551-1556, :1731-1740): one slack e_cus per row in [0, max_violation] BEHIND the other slacks in v,
+     1e4 e_cus^T e_cus once in the objective, and two rows per function in g: fun - e_cus <= ub, then fun + e_cus >= lb (rows with an
+     infinite bound are not imposed and keep a zero multiplier) */
+  int32_t acc_soft;
+  const double* acc_max_violation;                 /* [n_acc] or NULL -> inf */
 } hilo_nmpc_desc;
 
 #define HILO_MODEL_USER 100    /* model defined by desc.user_source */

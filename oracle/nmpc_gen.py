@@ -47,7 +47,10 @@ class GenNmpcProblem(NmpcProblem):
     def __init__(self, model, dt, N, path=None, constraint=None, terminal_constraint=None, generic_stage=None, custom=None, **kw):
         """custom = dict(fun=f(v, x_ind, u_ind) -> expression(s) of the entries of the (scaled) decision vector v, lb=[...], ub=[...]):
         `set_custom_constraints_function` (optimizer.py:1180-1208) - rows lb <= fun(v, x_ind, u_ind) <= ub appended to g
-        (mpc.py:1741-1744), kept here as what they are: DENSE rows over the whole vector (sympy derivatives in v)."""
+        (mpc.py:1741-1744), kept here as what they are: DENSE rows over the whole vector (sympy derivatives in v).
+        custom['soft'] (mpc.py:1551-1556, :1731-1740): ONE slack e_cus per row behind the other slacks in v, in [0, max_violation],
+        start value = the number of rows (:1555), 1e4 e_cus^T e_cus in J, and TWO rows per function: fun - e_cus in (-inf, ub],
+        fun + e_cus in [lb, inf)."""
         super().__init__(model, dt, N, **kw)
         nx, nu = self.nx, self.nu
         self.path = path
@@ -191,6 +194,7 @@ class GenNmpcProblem(NmpcProblem):
         self.n_g = N * (nxa + self.n_con_ref) + self.n_tcon_ref
         # ---- custom rows over the whole decision vector ----
         self.n_cus = 0
+        self.c_soft = bool(custom and custom.get('soft'))
         if custom:
             vs = [sp.Symbol(f'v_{i}') for i in range(self.n_v)]
             out = custom['fun'](vs, self.x_ind, self.u_ind)
@@ -198,6 +202,21 @@ class GenNmpcProblem(NmpcProblem):
             self.n_cus = len(cs)
             self.cus_lb = np.broadcast_to(np.asarray(custom.get('lb', -INF), dtype=float), (self.n_cus,)).copy()
             self.cus_ub = np.broadcast_to(np.asarray(custom.get('ub', INF), dtype=float), (self.n_cus,)).copy()
+            if self.c_soft:
+                assert not self.ne_t, "soft custom rows next to a soft terminal constraint: not restated"
+                n = self.n_cus
+                # the slacks take the place of the terminal slacks' block (same treatment: box [0, max_violation], penalty once)
+                self.ne_t = n
+                self.eT_ind = list(range(self.n_v, self.n_v + n))
+                self.n_v += n
+                self.WeT = np.diag(np.ones(n) * 1e4)                                            # mpc.py:1732
+                self.eT_ub = np.broadcast_to(np.asarray(custom.get('max_violation', INF), dtype=float), (n,)).copy()
+                ec = [sp.Symbol(f'v_{i}') for i in self.eT_ind]
+                vs = vs + ec
+                cs = [c - e for c, e in zip(cs, ec)] + [c + e for c, e in zip(cs, ec)]          # mpc.py:1733-1739
+                self.cus_lb, self.cus_ub = (np.concatenate([np.full(n, -INF), self.cus_lb]),
+                                            np.concatenate([self.cus_ub, np.full(n, INF)]))
+                self.n_cus = 2 * n
             used = sorted({int(str(q)[2:]) for c in cs for q in c.free_symbols})
             self.cus_used = used                                           # entries of v the rows depend on
             us_ = [vs[i] for i in used]
@@ -445,6 +464,12 @@ class GenIpm(DenseIpm):
                     np.einsum('bm,bma,bazy->bzy', lam_t, cj, Hs)
             g[:, zi] += gz[:, sel]
             W[np.ix_(bi, zi, zi)] += Hz[np.ix_(bi, sel, sel)]
+        if pb.ne_t and not pb.t_soft:       # slacks of soft custom rows: 1e4 e^T e once (mpc.py:1732-1733)
+            ET = w[:, self.o_eT:self.o_s]
+            tcols = list(range(self.o_eT, self.o_s))
+            f += np.einsum('bi,ij,bj->b', ET, pb.WeT, ET)
+            g[:, tcols] += 2 * ET @ pb.WeT
+            W[np.ix_(bi, tcols, tcols)] += 2 * pb.WeT
         d = X[:, N] - pb.xrefNa
         xi = [self.o_x + (N - 1) * nxa + i for i in range(nxa)]
         f += np.einsum('bi,ij,bj->b', d, pb.WNa, d) + pb._Vp[0](X[:, N])
@@ -475,7 +500,8 @@ class GenIpm(DenseIpm):
         if u_old is not None:
             data['u_old'] = np.broadcast_to(np.atleast_2d(np.asarray(u_old, dtype=float)), (B, pb.nu))
         if w0 is None:
-            w0 = np.concatenate([pb.x_guess[pb.nx - self.n0:], np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N), np.zeros(pb.ne + pb.ne_t)])
+            w0 = np.concatenate([pb.x_guess[pb.nx - self.n0:], np.tile(pb.x_guess, pb.N), np.tile(pb.u_guess, pb.N), np.zeros(pb.ne),
+                                 np.full(pb.ne_t, float(pb.ne_t) if getattr(pb, 'c_soft', False) else 0.)])           # mpc.py:1555
         w0 = np.broadcast_to(np.atleast_2d(w0)[:, :self.o_s], (B, self.o_s))
         w0 = _push_interior(w0, self.lb[:self.o_s], self.ub[:self.o_s], o)
         if pb.nrow or pb.nt:

@@ -415,7 +415,8 @@ def product_gen(spec, **solver_options):
     nmpc.set_initial_guess(x_guess=spec.get('x_guess'), u_guess=spec.get('u_guess'), z_guess=spec.get('z_guess'))
     if spec.get('custom'):
         cu = spec['custom']
-        nmpc.set_custom_constraints_function(cu['fun'], lb=cu.get('lb'), ub=cu.get('ub'))
+        nmpc.set_custom_constraints_function(cu['fun'], lb=cu.get('lb'), ub=cu.get('ub'), **(
+            dict(soft=True, max_violation=cu.get('max_violation', np.inf)) if cu.get('soft') else {}))
     if spec.get('x_scaling') or spec.get('u_scaling'):
         nmpc.set_scaling(x_scaling=spec.get('x_scaling'), u_scaling=spec.get('u_scaling'))
     if coll is not None:

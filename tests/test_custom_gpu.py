@@ -91,6 +91,55 @@ def test_two_rows_with_nonlinear_stage_terms_and_a_constant():
     np.testing.assert_allclose(lam[:, -2:], lr[:, -2:], rtol=1e-5, atol=1e-7)
 
 
+def test_soft_custom_rows_vs_dense_oracle():
+    """`soft=True` (mpc.py:1551-1556, :1731-1740): one slack e_cus per row behind the other slacks in v, 1e4 e_cus^T e_cus in the
+    objective, two rows per function at the end of g (fun - e_cus <= ub, then fun + e_cus >= lb).  Two rows: the trapezoid integral
+    with a tight upper bound (its slack opens) and the sum of the second input over the horizon bounded from BELOW only (linear: one
+    minimum; its `- e` row is not imposed and keeps a zero multiplier); against the dense oracle - v incl. both slacks, f, u_0, lam_g."""
+    spec = dict(C2, N=6)
+    x0 = c2_x0(4)
+
+    def fun(v, x_ind, u_ind):
+        e = 0
+        for k in range(len(u_ind)):
+            e = e + v[u_ind[k][1]]
+        return [_trapezoid(2, spec['dt'])(v, x_ind, u_ind), e]
+    free = GenIpm(oracle_gen(spec)).solve(x0, C2['p'])
+    X, U = free['X'], free['U']
+    ub0 = float(((X[:, :-1, 2] + X[:, 1:, 2]) / 2 * spec['dt']).sum(1).min() * .9)
+    lb1 = float(U[:, :, 1].sum(1).max() * 2.45)          # (the first row alone moves the sum from 0.073 to 0.11 - 0.13)
+    spec = dict(spec, custom=dict(fun=fun, lb=[0., lb1], ub=[ub0, np.inf], soft=True, max_violation=[5., 7.]))
+    pb = oracle_gen(spec)
+    ipm = GenIpm(pb, IpmOptions(tol=1e-10))
+    ref = ipm.solve(x0, C2['p'])
+    assert np.all(ref['status'] == 1)
+    nmpc = product_gen(spec, tol=1e-10)
+    assert nmpc._jit and nmpc._nq == 2 and (nmpc._n_v, nmpc._n_g) == (pb.n_v, pb.n_g)
+    assert nmpc._e_cus_ind == list(range(pb.n_v - 2, pb.n_v))
+    nmpc.keep_full_solution = True
+    u = nmpc.optimize(x0, cp=C2['p'])
+    assert np.array_equal(nmpc.solver_status_code, ref['status'])
+    v, vr = nmpc._nlp_solution['x'].cpu().numpy(), ipm.to_v(ref)
+    assert v.shape == vr.shape and np.max(np.abs(v - vr) / np.maximum(1., np.abs(vr))) < 1e-6
+    assert np.all(v[:, -2] > 1e-4) and np.all(v[:, -1] > 1e-5)                # both slacks open
+    np.testing.assert_allclose(v[:, -2:], vr[:, -2:], rtol=1e-5)
+    np.testing.assert_allclose(nmpc._nlp_solution['f'].cpu().numpy(), ref['f'], rtol=1e-9)
+    np.testing.assert_allclose(u, ref['u0'], rtol=1e-6, atol=1e-8)
+    lam, lr = nmpc._nlp_solution['lam_g'].cpu().numpy(), ipm.lam_g(ref)
+    assert lam.shape == lr.shape
+    # the four custom rows: [fun_0 - e_0 <= ub (active), fun_1 - e_1 <= inf (not imposed), fun_0 + e_0 >= 0 (inactive), fun_1 + e_1 >= lb (active)]
+    np.testing.assert_allclose(lam[:, -4:], lr[:, -4:], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(lam[:, -4], 2e4 * v[:, -2], rtol=1e-5)         # stationarity in e_0: 2 W e = multiplier
+    np.testing.assert_allclose(lam[:, -1], -2e4 * v[:, -1], rtol=1e-5)
+    assert np.all(lam[:, -3] == 0.)
+    g = nmpc._nlp_solution['g'].cpu().numpy()
+    Xp = v[:, :(spec['N'] + 1) * 4].reshape(-1, spec['N'] + 1, 4)
+    integral = ((Xp[:, :-1, 2] + Xp[:, 1:, 2]) / 2 * spec['dt']).sum(1)
+    np.testing.assert_allclose(g[:, -4], integral - v[:, -2], rtol=1e-9)      # fun_0 - e_0
+    np.testing.assert_allclose(g[:, -2], integral + v[:, -2], rtol=1e-9)      # fun_0 + e_0
+    np.testing.assert_allclose(integral - v[:, -2], ub0, rtol=1e-7)
+
+
 def test_the_reference_test_case_under_the_default_collocation():
     """tests/test_NMPC.py:519-552 as written: the cart pendulum with the `dummy` integrator state (x_5' = u_dummy), tracking
     theta -> pi and dummy -> 10 over N = 10 under the default transcription (collocation, Radau 3, continuous objective), the

@@ -351,12 +351,14 @@ def test_controller_accessors_of_the_reference():
     nmpc.horizon = 5
     with pytest.raises(NotImplementedError, match="continuous model written as expressions"):
         nmpc.setup()                                                    # (this controller sits on a model of the device zoo)
-    # optimizer.py:1180-1208: accepted (offloaded for stage-additive functions, tests/test_custom_gpu.py); the soft variant is not built
+    # optimizer.py:1180-1208: accepted (offloaded for stage-additive functions, hard and soft, tests/test_custom_gpu.py)
     nmpc.set_custom_constraints_function(fun=lambda v, xi, ui: v[0], ub=3)
-    assert nmpc._custom_constraint_flag and nmpc._custom_constraint_size == 1
+    assert nmpc._custom_constraint_flag and nmpc._custom_constraint_size == 1 and not nmpc._custom_constraint_is_soft_flag
     assert nmpc._custom_constraint_fun_lb == [-np.inf] and nmpc._custom_constraint_fun_ub == [3.]
-    with pytest.raises(NotImplementedError, match="soft custom constraints"):
-        nmpc.set_custom_constraints_function(fun=lambda v, xi, ui: v[0], soft=True)
+    nmpc.set_custom_constraints_function(fun=lambda v, xi, ui: [v[0], v[1]], lb=[0, 0], ub=[3, 4], soft=True, max_violation=2.)
+    assert nmpc._custom_constraint_is_soft_flag and list(nmpc._custom_constraint_maximum_violation) == [2., 2.]
+    with pytest.raises(ValueError, match="max_violation must be one value or one per"):
+        nmpc.set_custom_constraints_function(fun=lambda v, xi, ui: [v[0], v[1]], lb=[0, 0], ub=[3, 4], soft=True, max_violation=[1., 2., 3.])
     with pytest.raises(TypeError, match="must be a function"):
         nmpc.set_custom_constraints_function(fun=None)
 

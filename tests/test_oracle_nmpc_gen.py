@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 from scipy.optimize import minimize
 
-from oracle.nmpc import DenseIpm
+from oracle.nmpc import DenseIpm, IpmOptions
 from oracle.nmpc_gen import GenIpm
 from tests.problems import C2, C2H, C5, C5S, c2_x0, c5_x0, oracle_gen, oracle_problem
 
@@ -321,6 +321,56 @@ def test_custom_constraint_rows_dense_oracle_vs_slsqp():
     np.testing.assert_allclose(sol.fun, ref['f'][0], rtol=1e-6)
     assert ref['f'][0] <= sol.fun + 1e-9 * abs(sol.fun)
     np.testing.assert_allclose(sol.x, ref['w'][0, :nfree], rtol=5e-3, atol=5e-3)
+
+
+def test_soft_custom_rows_dense_oracle_vs_slsqp():
+    """custom['soft'] (mpc.py:1551-1556, :1731-1740): the slack e_cus is the last entry of v, in [0, max_violation], 1e4 e_cus^2 in the
+    objective, rows fun - e_cus <= ub and fun + e_cus >= lb at the end of g.  Against scipy SLSQP on the same statement written
+    directly (objective of the un-constrained transcription + 1e4 e^2, one inequality fun - e <= ub); the slack opens, the
+    multiplier of the upper row is 2e4 e (stationarity in e), the lower row is inactive."""
+    from scipy.optimize import minimize
+    from tests.problems import C2, c2_x0, oracle_gen
+    spec = dict(C2, N=5)
+    x0 = c2_x0(2)
+    plain = oracle_gen(spec)
+    free = GenIpm(plain).solve(x0, C2['p'])
+    X = free['X']
+    ub = float(((X[:, :-1, 2] + X[:, 1:, 2]) / 2 * .25).sum(1).min() * .9)
+    pb = oracle_gen(dict(spec, custom=dict(fun=_trapezoid, lb=0., ub=ub, soft=True, max_violation=3.)))
+    assert pb.n_v == plain.n_v + 1 and pb.n_g == plain.n_g + 2 and pb.n_cus == 2 and pb.eT_ind == [pb.n_v - 1]
+    ipm = GenIpm(pb, IpmOptions(tol=1e-10))
+    assert ipm.ub[ipm.o_eT] == pytest.approx(3., rel=1e-7) and ipm.lb[ipm.o_eT] == pytest.approx(0., abs=1e-7)
+    ref = ipm.solve(x0, C2['p'])
+    assert np.all(ref['status'] == 1)
+    e = ipm.to_v(ref)[:, -1]
+    lam = ipm.lam_g(ref)
+    X = ref['X']
+    integ = ((X[:, :-1, 2] + X[:, 1:, 2]) / 2 * .25).sum(1)
+    assert np.all(e > 1e-4)
+    np.testing.assert_allclose(integ - e, ub, rtol=1e-7)
+    np.testing.assert_allclose(lam[:, -2], 2e4 * e, rtol=1e-6)
+    assert np.all(np.abs(lam[:, -1]) < 1e-8)
+    hard = GenIpm(oracle_gen(dict(spec, custom=dict(fun=_trapezoid, lb=0., ub=ub))), IpmOptions(tol=1e-10)).solve(x0, C2['p'])
+    assert np.all(ref['f'] < hard['f']) and np.all(ref['f'] > free['f'])
+    # SLSQP, instance 0: variables [w of the plain transcription | e]
+    ip = GenIpm(plain)
+    nfree = ip.o_s
+    data = {'x0': x0[:1] / plain.sx, 'p': np.atleast_2d(np.asarray(C2['p'], dtype=float))}
+
+    def ev(wv):
+        w = np.concatenate([wv[:-1], np.zeros(ip.nw - nfree)])[None]
+        f, c = ip.eval_fc(w, data)
+        Xw = np.concatenate([data['x0'], wv[ip.o_x:ip.o_u].reshape(plain.N, plain.nxa)], axis=0)
+        return f[0] + 1e4 * wv[-1] ** 2, c[0], ((Xw[:-1, 2] + Xw[1:, 2]) / 2 * .25).sum()
+    nd = plain.N * plain.nxa
+    cons = [{'type': 'eq', 'fun': lambda wv: ev(wv)[1][:nd]},
+            {'type': 'ineq', 'fun': lambda wv: ub - (ev(wv)[2] - wv[-1])}]
+    w0 = np.concatenate([ref['w'][0, :nfree] * (1 + 1e-3), [e[0] * 1.1]])
+    sol = minimize(lambda wv: ev(wv)[0], w0, method='SLSQP', bounds=list(zip(ip.lb[:nfree], ip.ub[:nfree])) + [(0., 3.)],
+                   constraints=cons, options={'ftol': 1e-12, 'maxiter': 800})
+    assert sol.success or sol.status == 8, sol.message
+    np.testing.assert_allclose(sol.fun, ref['f'][0], rtol=1e-6)
+    np.testing.assert_allclose(sol.x[-1], e[0], rtol=2e-2)
 
 
 def test_custom_constraint_decomposition_into_stage_terms():
