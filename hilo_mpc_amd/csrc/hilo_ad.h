@@ -60,8 +60,10 @@ template <int N> HD Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) {
   for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
   return r;
 }
+HD double rcp_fast(double x);   // (below: v_rcp_f64 + two Newton steps, <= 1 ulp; a dependent chain of 5 instructions where the IEEE
+                                // sequence has 12 - the filters' team kernels wait for twelve divisions in a row per step)
 template <int N> HD Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
-  Dual<N> r; const double ib = 1.0 / b.v; r.v = a.v * ib;
+  Dual<N> r; const double ib = rcp_fast(b.v); r.v = a.v * ib;
 #pragma unroll
   for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
   return r;

@@ -226,6 +226,25 @@ __device__ __forceinline__ void ekf_update(const KfParams& kp, double* x, double
 }
 
 // ---- UKF ------------------------------------------------------------------------------------------------
+// One sigma point through the model, on FastD (hilo_ad.h: division = x * rcp_fast(y), <= 2 ulp - the scalar type the interior-point
+// engine's derivative phase uses): a step's 36 right-hand sides hold 108 IEEE division sequences otherwise, a third of the one-lane
+// kernel's instructions and most of the team kernel's dependent chain.  The same function in every UKF kernel.
+template <class M, bool RK4 = false>
+__device__ __forceinline__ void ukf_propagate(const KfParams& kp, const double* xs, const double* u, const double* p, double* xo) {
+  constexpr int NX = M::NX;
+  FastD xf[NX], xof[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xf[i] = FastD(xs[i]);
+  if constexpr (RK4 && !M::DISCRETE)
+    rk4_classic<M>(xf, u, p, kp.dt, xof, NoExt());
+  else if (kp.continuous && !M::DISCRETE)
+    model_step<M>(4, kp.n_sub, xf, u, p, kp.dt, xof);  // the reference integrates with CVODES
+  else
+    model_step<M>(kp.erk_order, kp.n_sub, xf, u, p, kp.dt, xof);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xo[i] = xof[i].v;
+}
+
 // The weighted sums follow the reference's accumulation order without FMA contraction: with alpha = 1e-3 the
 // centre weight is ~ -1e6 and six digits cancel, so rounding order is visible in the result.
 template <class M, bool LEAN = false>
@@ -245,19 +264,7 @@ __device__ __forceinline__ void ukf_predict(const KfParams& kp, double* x, doubl
       if (k > NX) s = x[i] - kp.gamma * L[(k - 1 - NX) * NX + i];
       xs[i] = s;
     }
-    if constexpr (LEAN && !M::DISCRETE) {
-      // the model's divisions as x * rcp_fast(y) (<= 1-2 ulp; hilo_ad.h::FastD, the scalar type the engine's derivative phase uses):
-      // the 36 right-hand sides of a step hold 108 IEEE division sequences of 12 instructions otherwise, a third of the step
-      FastD xf[NX], xof[NX];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) xf[i] = FastD(xs[i]);
-      rk4_classic<M>(xf, u, p, kp.dt, xof, NoExt());
-#pragma unroll
-      for (int i = 0; i < NX; ++i) xo[i] = xof[i].v;
-    } else if (kp.continuous && !M::DISCRETE)
-      model_step<M>(4, kp.n_sub, xs, u, p, kp.dt, xo);  // the reference integrates with CVODES
-    else
-      model_step<M>(kp.erk_order, kp.n_sub, xs, u, p, kp.dt, xo);
+    ukf_propagate<M, LEAN>(kp, xs, u, p, xo);
 #pragma unroll
     for (int i = 0; i < NX; ++i) X[i * NS + k] = xo[i];
   }
@@ -782,10 +789,7 @@ __device__ __forceinline__ void team_ukf_step(const KfParams& kp, double* __rest
       // (x + gamma l and x - gamma l: x + (-gamma) l rounds like x - gamma l; the centre point is x itself)
       xs[i] = k == 0 ? x[i] : x[i] + sg * li;
     }
-    if (kp.continuous && !M::DISCRETE)
-      model_step<M>(4, kp.n_sub, xs, u, p, kp.dt, xo);
-    else
-      model_step<M>(kp.erk_order, kp.n_sub, xs, u, p, kp.dt, xo);
+    ukf_propagate<M>(kp, xs, u, p, xo);
     M::meas(xo, u, p, kp.dt, ys);
     if (t < NS) {
 #pragma unroll

@@ -175,6 +175,23 @@ def test_the_reference_test_case_under_the_default_collocation():
     free = build(False)
     free.optimize(x0)
     assert free.solver_status_code[0] == 1 and integral(free) > 4.2
+    # the same row SOFT under the default transcription (mpc.py:1551-1556, :1731-1740): the slack is the last entry of v, two rows at
+    # the end of g; the penalty 1e4 e^2 lets the integral exceed 4 by e, and stationarity in e reads 2e4 e = the upper row's multiplier
+    soft = NMPC(model)
+    soft.quad_stage_cost.add_states(names=['theta', 'dummy'], ref=[np.pi, 10], weights=[np.pi, 10])
+    soft.horizon = 10
+    soft.set_box_constraints(x_ub=[3, 0.5, 10, 10, 10000], x_lb=[2, -0.5, -10, -10, 0])
+    soft.set_initial_guess(x_guess=x0, u_guess=[0., 0.])
+    soft.set_custom_constraints_function(lambda v, xi, ui: _trapezoid(4, dt)(v, xi, ui), ub=4, lb=0, soft=True, max_violation=1.)
+    soft.setup(solver_options={'tol': 1e-10})
+    assert (soft._n_v, soft._n_g) == (free._n_v + 1, free._n_g + 2) and soft._e_cus_ind == [soft._n_v - 1]
+    soft.optimize(x0)
+    assert soft.solver_status_code[0] == 1
+    vs, ls = soft._nlp_solution['x'].cpu().numpy()[0], soft._nlp_solution['lam_g'].cpu().numpy()[0]
+    e = vs[-1]
+    assert 1e-6 < e < 1. and abs(integral(soft) - e - 4.) < 1e-6
+    np.testing.assert_allclose(ls[-2], 2e4 * e, rtol=1e-5)
+    assert abs(ls[-1]) < 1e-6
     nmpc = build(True)
     assert nmpc._nlp_options['integration_method'] == 'collocation' and nmpc._n_g == free._n_g + 1 and nmpc._n_v == free._n_v
     nmpc.optimize(x0)
@@ -182,7 +199,7 @@ def test_the_reference_test_case_under_the_default_collocation():
     assert integral(nmpc) - 4 < 1e-3 and abs(integral(nmpc) - 4) < 1e-6           # the reference's assertion; active
     lam = nmpc._nlp_solution['lam_g'].cpu().numpy()
     assert lam[0, -1] > 1e-3
-    assert float(nmpc._nlp_solution['f'][0]) > float(free._nlp_solution['f'][0])
+    assert float(nmpc._nlp_solution['f'][0]) > float(soft._nlp_solution['f'][0]) > float(free._nlp_solution['f'][0])
 
 
 def test_collocation_custom_row_in_a_batch_and_across_warm_started_calls():

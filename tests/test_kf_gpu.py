@@ -402,8 +402,8 @@ def test_team_and_one_lane_kernels_agree(kind, symbolic):
         f.set_initial_guess(x[:n], P0=P[:n])
         sol = f.estimate(y=ys[:, :n], u=u[:n], p=p[:n], steps=K)
         out.append((sol['x'][:, :small], sol['P'][:, :small], sol['y'][:, :small]))
-    # UKF: the one-lane kernel of this recipe evaluates the model's divisions as x * rcp(y) (<= 2 ulp, csrc/hilo_kf_kernel.h::ukf_predict
-    # LEAN), the team kernel with IEEE divisions; alpha = 1e-3 weighs the sigma points with ~1e6 and amplifies that rounding
+    # UKF: every kernel propagates its sigma points through csrc/hilo_kf_kernel.h::ukf_propagate - the same operations, but the
+    # compiler contracts multiply-adds differently in the two kernels, and alpha = 1e-3 weighs the sigma points with ~1e6
     tol = dict(rtol=1e-12, atol=1e-14) if kind == 'EKF' else dict(rtol=1e-7, atol=1e-7)
     for a, b in zip(*out):
         np.testing.assert_allclose(a, b, **tol)
@@ -462,8 +462,7 @@ def test_lean_variant_of_the_multi_step_kernel_equals_the_general_one(kind):
         f.set_initial_guess(x, P0=P)
         sol = f.estimate(y=ys, u=u, p=p, steps=K)
         out.append((sol['x'], sol['P'], sol['y']))
-    # UKF: the LEAN variant's model divisions are x * rcp(y) (<= 2 ulp) and alpha = 1e-3 amplifies rounding by ~1e6
-    tol = dict(rtol=1e-13, atol=1e-15) if kind == 'EKF' else dict(rtol=1e-7, atol=1e-7)
+    tol = dict(rtol=1e-13, atol=1e-15) if kind == 'EKF' else dict(rtol=1e-7, atol=1e-7)       # (UKF: see the team kernels' test)
     for a, b in zip(*out):
         np.testing.assert_allclose(a, b, **tol)
 
