@@ -123,6 +123,8 @@ def _declare(lib):
         'hilo_qp_set_options': (C.c_int, [vp, dbl, i32]),
         'hilo_qp_set_stages': (C.c_int, [vp, i32, i32, i32, P(i32)]),
         'hilo_qp_solve': (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]),
+        'hilo_qp_solve_pinned': (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i32, i64, vp, vp, i64, vp, vp, vp, vp, vp,
+                                           vp, vp]),
         'hilo_gp_create': (C.c_int, [i32, i32, i32, vp, vp, vp, i32, vp, i32, dbl, P(vp)]),
         'hilo_gp_destroy': (None, [vp]),
         'hilo_gp_log_marginal_likelihood': (C.c_int, [vp, P(C.c_double)]),

@@ -103,4 +103,18 @@ __device__ __forceinline__ void vec_load(const double* __restrict__ g, int64_t i
   for (int c = 0; c < LEN; ++c) reg[c] = src[c];
 }
 
+// bounds of variable i of instance b: the per-instance (or, with pinned values, shared: bs = 0) rows lbx / ubx, except that the first
+// `npin` variables of hilo_qp_solve_pinned are fixed at xpin[b][i] (the measured state x_0, mpc.py:2361-2362, without the host
+// writing it into two bound rows first)
+__device__ __forceinline__ void qp_bounds(const double* __restrict__ lbx, const double* __restrict__ ubx, int64_t bs,
+                                          const double* __restrict__ xpin, int npin, int64_t ps, int64_t b, int i, double& lo,
+                                          double& up) {
+  if (xpin != nullptr && i < npin) {
+    lo = up = xpin[b * ps + i];
+  } else {
+    lo = lbx[b * bs + i];
+    up = ubx[b * bs + i];
+  }
+}
+
 }  // namespace hilo

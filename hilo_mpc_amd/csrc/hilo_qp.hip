@@ -120,7 +120,8 @@ __global__ __launch_bounds__(64) void qp_solve_kernel(QpDims qd, int64_t batch, 
                                                       double* __restrict__ x_out, double* __restrict__ f_out,
                                                       double* __restrict__ lam_a, double* __restrict__ lam_x,
                                                       int32_t* __restrict__ status, int32_t* __restrict__ iters,
-                                                      double* __restrict__ ws, int64_t ws_stride) {
+                                                      double* __restrict__ ws, int64_t ws_stride,
+                                                      const double* __restrict__ xpin, int npin, int64_t ps) {
   extern __shared__ double lds[];
   const int n = qd.n, m = qd.m, ldn = qd.ldn, ldm = qd.ldm, t = threadIdx.x;
   const int64_t b = blockIdx.x;
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(64) void qp_solve_kernel(QpDims qd, int64_t batch, 
   // ---- load, substitute fixed variables (lbx == ubx) ----
   int bad_rows = 0;
   for (int i = t; i < n; i += 64) {
-    const double lo = lbx[b * bs + i], up = ubx[b * bs + i];
+    double lo, up;
+    qp_bounds(lbx, ubx, bs, xpin, npin, ps, b, i, lo, up);
     const bool fx = lo == up;
     l[i] = fx ? NAN : lo;  // NAN marks a fixed variable
     u[i] = up;
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const double* __restrict__ Ag, int64_t as_, const double* __restrict__ lbx, const double* __restrict__ ubx, int64_t bs,
     const double* __restrict__ lba, const double* __restrict__ uba, int64_t bas, double* __restrict__ x_out,
     double* __restrict__ f_out, double* __restrict__ lam_a, double* __restrict__ lam_x, int32_t* __restrict__ status,
-    int32_t* __restrict__ iters) {
+    int32_t* __restrict__ iters, const double* __restrict__ xpin, int npin, int64_t ps) {
   static_assert(NP <= 64 && MP <= 64 && MP <= NP, "one row / column per lane");
   extern __shared__ double lds[];
   constexpr int ldn = NP + 1, ldm = MP + 1;     // odd pitches: conflict-free row-per-lane and column walks
@@ -616,7 +618,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
   int bad_rows = 0;
   if (t < NP) {
     const bool in = t < n;
-    const double lo = in ? lbx[b * bs + t] : 0.0, up = in ? ubx[b * bs + t] : 0.0;
+    double lo = 0.0, up = 0.0;
+    if (in) qp_bounds(lbx, ubx, bs, xpin, npin, ps, b, t, lo, up);
     const bool fx = lo == up;          // padding slots count as fixed at 0
     l[t] = fx ? NAN : lo;
     u[t] = up;
@@ -1039,12 +1042,25 @@ extern "C" int hilo_qp_solve(hilo_qp* h, int64_t batch, const double* H, int64_t
                              int64_t g_stride, const double* A, int64_t a_stride, const double* lbx, const double* ubx,
                              int64_t bx_stride, const double* lba, const double* uba, int64_t ba_stride, double* x,
                              double* f, double* lam_a, double* lam_x, int32_t* status, int32_t* iters, void* stream) {
+  return hilo_qp_solve_pinned(h, batch, H, h_stride, g, g_stride, A, a_stride, lbx, ubx, bx_stride, nullptr, 0, 0, lba, uba, ba_stride, x,
+                              f, lam_a, lam_x, status, iters, stream);
+}
+
+extern "C" int hilo_qp_solve_pinned(hilo_qp* h, int64_t batch, const double* H, int64_t h_stride, const double* g,
+                                    int64_t g_stride, const double* A, int64_t a_stride, const double* lbx, const double* ubx,
+                                    int64_t bx_stride, const double* xpin, int npin, int64_t ps, const double* lba,
+                                    const double* uba, int64_t ba_stride, double* x, double* f, double* lam_a, double* lam_x,
+                                    int32_t* status, int32_t* iters, void* stream) {
   HILO_REQUIRE(h, "hilo_qp_solve: NULL handle");
   HILO_REQUIRE(batch >= 0, "hilo_qp_solve: negative batch");
   if (batch == 0) return HILO_OK;
   HILO_REQUIRE(H && g && lbx && ubx && x && f && status && iters, "hilo_qp_solve: NULL argument");
   HILO_REQUIRE(h->m == 0 || (A && lba && uba), "hilo_qp_solve: the problem has %d rows but A / lba / uba is NULL", h->m);
-  HILO_REQUIRE(bx_stride >= h->n, "hilo_qp_solve: lbx/ubx are per instance (x_0 is pinned through them, mpc.py:2361-2362)");
+  HILO_REQUIRE(bx_stride >= h->n || (xpin && bx_stride == 0),
+               "hilo_qp_solve: lbx/ubx are per instance (x_0 is pinned through them, mpc.py:2361-2362) unless pinned values are given");
+  HILO_REQUIRE(!xpin || (npin > 0 && npin <= h->n && ps >= npin), "hilo_qp_solve_pinned: %d pinned variables with stride %lld", npin,
+               (long long)ps);
+  if (!xpin) { npin = 0; ps = 0; }
   HILO_HIP_CHECK(hipSetDevice(h->device));
   if (h->ocp_N) {
     const int N = h->ocp_N;
@@ -1053,11 +1069,11 @@ extern "C" int hilo_qp_solve(hilo_qp* h, int64_t batch, const double* H, int64_t
     if (N + 1 <= 16)                                                                                                                 \
       hipLaunchKernelGGL((qp_ocp_kernel<NXV, NUV, 16>), dim3((unsigned)((batch + 3) / 4)), dim3(64), 0, (hipStream_t)stream, h->qd,  \
                          N, batch, H, h_stride, g, g_stride, A, a_stride, lbx, ubx, bx_stride, lba, uba, ba_stride, x, f, lam_a,     \
-                         lam_x, status, iters);                                                                                     \
+                         lam_x, status, iters, xpin, npin, ps);                                                                     \
     else                                                                                                                             \
       hipLaunchKernelGGL((qp_ocp_kernel<NXV, NUV, 64>), dim3((unsigned)batch), dim3(64), 0, (hipStream_t)stream, h->qd, N, batch,    \
                          H, h_stride, g, g_stride, A, a_stride, lbx, ubx, bx_stride, lba, uba, ba_stride, x, f, lam_a, lam_x,        \
-                         status, iters);                                                                                            \
+                         status, iters, xpin, npin, ps);                                                                            \
   }
     HILO_QP_OCP_SIZES(X)
 #undef X
@@ -1072,7 +1088,7 @@ extern "C" int hilo_qp_solve(hilo_qp* h, int64_t batch, const double* H, int64_t
                                          (int)h->fast_lds));                                                                       \
     hipLaunchKernelGGL((qp_solve_reg_kernel<NPV, MPV>), dim3((unsigned)batch), dim3(64), h->fast_lds, (hipStream_t)stream, h->qd,   \
                        batch, H, h_stride, g, g_stride, A, a_stride, lbx, ubx, bx_stride, lba, uba, ba_stride, x, f, lam_a, lam_x, \
-                       status, iters);                                                                                            \
+                       status, iters, xpin, npin, ps);                                                                            \
   }
     HILO_QP_FAST(32, 24)
     HILO_QP_FAST(32, 32)
@@ -1096,7 +1112,7 @@ extern "C" int hilo_qp_solve(hilo_qp* h, int64_t batch, const double* H, int64_t
   }
   hipLaunchKernelGGL(qp_solve_kernel, dim3((unsigned)batch), dim3(64), h->big ? 0 : h->lds_bytes, (hipStream_t)stream, h->qd,
                      batch, H, h_stride, g, g_stride, A, a_stride, lbx, ubx, bx_stride, lba, uba, ba_stride, x, f, lam_a, lam_x,
-                     status, iters, h->big ? h->ws : (double*)nullptr, (int64_t)(h->lds_bytes / sizeof(double)));
+                     status, iters, h->big ? h->ws : (double*)nullptr, (int64_t)(h->lds_bytes / sizeof(double)), xpin, npin, ps);
   HILO_HIP_CHECK(hipGetLastError());
   return HILO_OK;
 }

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const double* __restrict__ Ag, int64_t as_, const double* __restrict__ lbx, const double* __restrict__ ubx, int64_t bs,
     const double* __restrict__ lba, const double* __restrict__ uba, int64_t bas, double* __restrict__ x_out,
     double* __restrict__ f_out, double* __restrict__ lam_a, double* __restrict__ lam_x, int32_t* __restrict__ status,
-    int32_t* __restrict__ iters) {
+    int32_t* __restrict__ iters, const double* __restrict__ xpin, int npin, int64_t ps) {
   constexpr int IPW = 64 / G;
   const int n = qd.n, m = qd.m;
   const int grp = threadIdx.x / G, k = threadIdx.x - grp * G;          // stage of this lane
@@ -127,8 +127,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int j = 0; j < NU; ++j) Bk[i][j] = inner ? A[(int64_t)(ro + i) * n + uo + j] : 0.0;
     gx[i] = g[xo + i];
-    lx[i] = lbx[b * bs + xo + i];
-    ux[i] = ubx[b * bs + xo + i];
+    qp_bounds(lbx, ubx, bs, xpin, npin, ps, b, xo + i, lx[i], ux[i]);
     const bool fx = lx[i] == ux[i];
     if (stage && (fx != (k == 0))) bad = 1;            // x_0 pinned, nothing else: the shape this kernel is built for
     if (!stage) { lx[i] = -INFINITY; ux[i] = INFINITY; }
@@ -141,8 +140,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int j = 0; j < NU; ++j) R[i][j] = inner ? H[(int64_t)(uo + i) * n + uo + j] : (i == j ? 1.0 : 0.0);
     gu[i] = inner ? g[uo + i] : 0.0;
-    lu[i] = inner ? lbx[b * bs + uo + i] : -INFINITY;
-    uu[i] = inner ? ubx[b * bs + uo + i] : INFINITY;
+    lu[i] = -INFINITY; uu[i] = INFINITY;
+    if (inner) qp_bounds(lbx, ubx, bs, xpin, npin, ps, b, uo + i, lu[i], uu[i]);
     if (inner && lu[i] == uu[i]) bad = 1;
   }
   const bool first = k == 0;

@@ -324,28 +324,24 @@ class LMPC:
             raise ValueError(f"We have an issue mate, the x0 you supplied has dimension {x.shape[1]} but the model has "
                              f"{self._n_x} states.")
         B, dev, n, m = x.shape[0], self._dev, self._n_v, self._n_g
-        # the bound rows of the batch are resident; per call only the pinned x_0 is written into them (mpc.py:2361-2362)
-        bb = getattr(self, '_bound_rows', None)
-        if bb is None or bb[0].shape[0] != B or bb[2] is not self._v_lb:
-            bb = self._bound_rows = (self._v_lb.expand(B, -1).contiguous(), self._v_ub.expand(B, -1).contiguous(), self._v_lb)
-        lb, ub = bb[0], bb[1]
-        xs = x if self._unit_sx else x / self._sx
-        lb[:, :self._n_x] = xs
-        ub[:, :self._n_x] = xs
-        v = torch.empty(B, n, dtype=torch.float64, device=dev)
-        f = torch.empty(B, dtype=torch.float64, device=dev)
-        lam_a = torch.empty(B, m, dtype=torch.float64, device=dev)
-        lam_x = torch.empty(B, n, dtype=torch.float64, device=dev)
-        status = torch.empty(B, dtype=torch.int32, device=dev)
-        iters = torch.empty(B, dtype=torch.int32, device=dev)
-        _lib.check(_lib.lib().hilo_qp_solve(self._handle, B, ptr(self._H), 0, ptr(self._g), 0, ptr(self._Ad), 0, ptr(lb),
-                                            ptr(ub), n, ptr(self._beq), ptr(self._beq), 0, ptr(v), ptr(f), ptr(lam_a),
-                                            ptr(lam_x), ptr(status), ptr(iters), stream_ptr(dev)))
+        # mpc.py:2361-2362 writes the measured state into lbx / ubx before every solver call; here the bound rows are ONE pair shared
+        # by the batch and the solve takes the pinned values themselves (hilo_qp_solve_pinned): one launch per step
+        xs = (x if self._unit_sx else x / self._sx).contiguous()
+        # the result vectors of a call: two allocations, contiguous views (a call at this size is bound by the host's time)
+        buf = torch.empty(B * (2 * n + m + 1), dtype=torch.float64, device=dev)
+        v, lam_x, lam_a, f = buf[:B * n].view(B, n), buf[B * n:2 * B * n].view(B, n), buf[2 * B * n:B * (2 * n + m)].view(B, m), \
+            buf[B * (2 * n + m):]
+        ibuf = torch.empty(2, B, dtype=torch.int32, device=dev)
+        status, iters = ibuf[0], ibuf[1]
+        _lib.check(_lib.lib().hilo_qp_solve_pinned(self._handle, B, ptr(self._H), 0, ptr(self._g), 0, ptr(self._Ad), 0, ptr(self._v_lb),
+                                                   ptr(self._v_ub), 0, ptr(xs), self._n_x, self._n_x, ptr(self._beq), ptr(self._beq), 0,
+                                                   ptr(v), ptr(f), ptr(lam_a), ptr(lam_x), ptr(status), ptr(iters), stream_ptr(dev)))
         self._nlp_solution = {'x': v, 'f': f, 'lam_a': lam_a, 'lam_x': lam_x, 'status': status, 'iter_count': iters}
         self._time += self._sampling_interval                                                     # mpc.py:2386
         self._n_iterations += 1                                                                   # mpc.py:2392
         u = v[:, self._u_ind[0][0]:self._u_ind[0][-1] + 1]                                        # mpc.py:2377
-        u = u.clone() if self._unit_su else u * self._su
+        if not self._unit_su:
+            u = u * self._su                   # (unit scaling: a view of this call's own result vector, no copy kernel)
         if host:
             u = u.cpu().numpy()
             return u.reshape(-1, 1) if single else u

@@ -547,6 +547,14 @@ int hilo_qp_solve(hilo_qp* h, int64_t batch,
                   double* lam_a,                           /* [B][m] or NULL;  H x + g + A^T lam_a + lam_x = 0 */
                   double* lam_x,                           /* [B][n] or NULL */
                   int32_t* status, int32_t* iters, void* stream);
+/* The same solve with the first `npin` variables FIXED at xpin[b][0..npin) - what `LMPC.optimize` does with the measured state:    */
+/* `self._lbx[:nx] = self._ubx[:nx] = x0` before every solver call (mpc.py:2361-2362).  lbx / ubx may then be ONE row shared by the   */
+/* batch (bx_stride = 0); their first npin entries are not read.  One launch per step instead of two bound-row writes + the solve.    */
+int hilo_qp_solve_pinned(hilo_qp* h, int64_t batch, const double* H, int64_t h_stride, const double* g, int64_t g_stride,
+                         const double* A, int64_t a_stride, const double* lbx, const double* ubx, int64_t bx_stride,
+                         const double* xpin, int npin, int64_t xpin_stride /* >= npin */, const double* lba, const double* uba,
+                         int64_t ba_stride, double* x, double* f, double* lam_a, double* lam_x, int32_t* status, int32_t* iters,
+                         void* stream);
 
 #ifdef __cplusplus
 }

@@ -151,6 +151,45 @@ def test_stage_kernel_equals_the_dense_kernels(N, Q, monkeypatch):
     np.testing.assert_allclose(u1[both], ref['u'][both], rtol=1e-6, atol=1e-5)
 
 
+@pytest.mark.parametrize('mode', ['stages', 'dense', 'lds_columns'])
+def test_pinned_entry_point_equals_per_instance_bound_rows(mode, monkeypatch):
+    """`hilo_qp_solve_pinned` (the measured states next to ONE pair of bound rows shared by the batch - what `LMPC.optimize` calls)
+    against `hilo_qp_solve` with the reference's own procedure, x_0 written into per-instance rows lbx = ubx (mpc.py:2361-2362):
+    the same bytes in every result vector, on the stage kernel, the register-resident dense kernel and the LDS-column kernel."""
+    import torch
+    from hilo_mpc_amd import _lib
+    from hilo_mpc_amd._device import ptr, stream_ptr
+    if mode != 'stages':
+        monkeypatch.setenv('HILO_QP_DENSE', '1')
+    if mode == 'lds_columns':
+        monkeypatch.setenv('HILO_QP_LDS_COLUMNS', '1')
+    mpc = product_lmpc('corrected')
+    assert bool(mpc._qp_stages) == (mode == 'stages')
+    rng = np.random.default_rng(5)
+    x0 = np.vstack([rng.uniform(-1.5, 1.5, (60, 2)), rng.uniform(-4, 4, (6, 2))])
+    mpc.optimize(x0)
+    a = {k: v.clone() for k, v in mpc._nlp_solution.items()}
+    B, n, m, dev = x0.shape[0], mpc._n_v, mpc._n_g, mpc._dev
+    x = torch.as_tensor(x0, device=dev)
+    lb, ub = mpc._v_lb.expand(B, -1).contiguous(), mpc._v_ub.expand(B, -1).contiguous()
+    lb[:, :2] = x
+    ub[:, :2] = x
+    out = dict(x=torch.empty(B, n, dtype=torch.float64, device=dev), f=torch.empty(B, dtype=torch.float64, device=dev),
+               lam_a=torch.empty(B, m, dtype=torch.float64, device=dev), lam_x=torch.empty(B, n, dtype=torch.float64, device=dev),
+               status=torch.empty(B, dtype=torch.int32, device=dev), iter_count=torch.empty(B, dtype=torch.int32, device=dev))
+    _lib.check(_lib.lib().hilo_qp_solve(mpc._handle, B, ptr(mpc._H), 0, ptr(mpc._g), 0, ptr(mpc._Ad), 0, ptr(lb), ptr(ub), n,
+                                        ptr(mpc._beq), ptr(mpc._beq), 0, ptr(out['x']), ptr(out['f']), ptr(out['lam_a']),
+                                        ptr(out['lam_x']), ptr(out['status']), ptr(out['iter_count']), stream_ptr(dev)))
+    assert (a['status'] == 1).sum() >= 55 and (a['status'] == 3).sum() >= 1
+    for k in out:
+        assert torch.equal(a[k], out[k]), k
+    # argument checks of the new entry: shared rows only together with pinned values
+    with pytest.raises(Exception, match='per instance'):
+        _lib.check(_lib.lib().hilo_qp_solve(mpc._handle, B, ptr(mpc._H), 0, ptr(mpc._g), 0, ptr(mpc._Ad), 0, ptr(mpc._v_lb), ptr(mpc._v_ub), 0,
+                                            ptr(mpc._beq), ptr(mpc._beq), 0, ptr(out['x']), ptr(out['f']), ptr(out['lam_a']),
+                                            ptr(out['lam_x']), ptr(out['status']), ptr(out['iter_count']), stream_ptr(dev)))
+
+
 def test_stage_kernel_on_a_four_state_two_input_system(monkeypatch):
     """nx = 4, nu = 2 (two coupled double integrators), N = 12, bounds on states and inputs, B = 64: stage kernel against the
     dense register kernel; single instance too (the launch of BASELINE configuration 1's shape: one QP)."""
