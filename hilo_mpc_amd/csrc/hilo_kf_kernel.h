@@ -22,17 +22,27 @@ struct KfParams {
 template <int N> struct MaxOne { static constexpr int v = N > 0 ? N : 1; };
 
 // ---- small dense helpers (row-major, compile-time sizes) ------------------------------------------------
+// 1/sqrt(x): v_rsq_f64 + two Newton steps (<= 2 ulp) - the Cholesky factor of Pyy below needs the reciprocal of its diagonal only
+__device__ __forceinline__ double rsqrt_fast(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+  r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+  return r;
+}
+
+// A = L L^T; invd (optional): the reciprocals of L's diagonal.  The diagonal through 1/sqrt (v_rsq_f64 + two Newton steps, <= 2 ulp):
+// sqrt(s) = s * rsqrt(s) and the column scaling by rsqrt(s) itself - the IEEE square root and division are a dependent chain of
+// ~400 cycles per column, four columns deep in the UKF's factorisation of P, which every lane of a team waits for
 template <int N>
-__device__ __forceinline__ void chol_lower(const double* A, double* L) {
-  // A = L L^T
+__device__ __forceinline__ void chol_lower(const double* A, double* L, double* invd = nullptr) {
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     double s = A[j * N + j];
 #pragma unroll
     for (int k = 0; k < j; ++k) s -= L[j * N + k] * L[j * N + k];
-    const double d = ::sqrt(s);
-    L[j * N + j] = d;
-    const double id = 1.0 / d;
+    const double id = rsqrt_fast(s);
+    L[j * N + j] = s * id;
+    if (invd) invd[j] = id;
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
       double t = A[i * N + j];
@@ -49,8 +59,8 @@ __device__ __forceinline__ void chol_lower(const double* A, double* L) {
 template <int NX, int NY>
 __device__ __forceinline__ void gain_update(double* x, double* P, const double* Pxy, const double* Pyy,
                                             const double* y, const double* yp) {
-  double L[NY * NY];
-  chol_lower<NY>(Pyy, L);
+  double L[NY * NY], il[NY];
+  chol_lower<NY>(Pyy, L, il);
   double K[NX * NY];
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
@@ -61,14 +71,14 @@ __device__ __forceinline__ void gain_update(double* x, double* P, const double* 
       double s = Pxy[i * NY + a];
 #pragma unroll
       for (int b = 0; b < a; ++b) s -= L[a * NY + b] * z[b];
-      z[a] = s / L[a * NY + a];
+      z[a] = s * il[a];
     }
 #pragma unroll
     for (int a = NY - 1; a >= 0; --a) {
       double s = z[a];
 #pragma unroll
       for (int b = a + 1; b < NY; ++b) s -= L[b * NY + a] * K[i * NY + b];
-      K[i * NY + a] = s / L[a * NY + a];
+      K[i * NY + a] = s * il[a];
     }
   }
   double KS[NX * NY];  // K Pyy
@@ -554,14 +564,6 @@ struct KfTeam {
                        O_PYY = O_PXY + NX * NY, O_K = O_PYY + NY * NY, O_KS = O_K + NX * NY, O_YP = O_KS + NX * NY,
                        USED = O_YP + NY, SIZE = USED | 1;   // odd pitch: the teams of a wave start in different banks
 };
-
-// 1/sqrt(x): v_rsq_f64 + two Newton steps (<= 2 ulp) - the Cholesky factor of Pyy below needs the reciprocal of its diagonal only
-__device__ __forceinline__ double rsqrt_fast(double x) {
-  double r = __builtin_amdgcn_rsq(x);
-  r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
-  r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
-  return r;
-}
 
 // row i of K = Pxy Pyy^-1 and of K Pyy, and K[i,:] (y - yp) (kf.py:177-180): gain_update's Cholesky solve for one row, with the
 // reciprocals of the factor's diagonal (two dependent rsq instead of two square roots and six divisions in a row)
