@@ -223,7 +223,7 @@ struct Colloc {
   __device__ __forceinline__ static void lu(double* a) {
 #pragma unroll
     for (int k = 0; k < DN; ++k) {
-      const double ip = 1.0 / a[k * DN + k];
+      const double ip = rcp_fast(a[k * DN + k]);
 #pragma unroll
       for (int i = k + 1; i < DN; ++i) {
         const double f = a[i * DN + k] * ip;

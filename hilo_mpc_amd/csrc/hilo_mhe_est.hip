@@ -38,7 +38,7 @@ struct MheEst {
     for (int i = 0; i < MU; ++i) ue[i] = sd[i] * pc.cost[O_SU + i];
     model_step<M>(pc.order, pc.nsub, xp, ue, pp, pc.dt, xo, ext);
 #pragma unroll
-    for (int i = 0; i < MX; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]) + w[i];   // mhe.py:739
+    for (int i = 0; i < MX; ++i) xn[i] = xo[i] * rcp_fast(pc.sz[i]) + w[i];   // mhe.py:739
 #pragma unroll
     for (int j = 0; j < NP; ++j) xn[MX + j] = x[MX + j];
   }

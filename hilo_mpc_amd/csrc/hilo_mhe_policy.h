@@ -50,7 +50,7 @@ struct MheNoise {
       model_step<M>(pc.order, pc.nsub, xp, ue, par, pc.dt, xo, ext);
     }
 #pragma unroll
-    for (int i = 0; i < NX; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]) + w[i];  // mhe.py:739: scaled noise, scaled state
+    for (int i = 0; i < NX; ++i) xn[i] = xo[i] * rcp_fast(pc.sz[i]) + w[i];  // mhe.py:739: scaled noise, scaled state
   }
 
   template <class T>
@@ -175,7 +175,7 @@ struct MheGen {
     }
 #pragma unroll
     for (int i = 0; i < MX; ++i) {
-      T v = xo[i] * (1.0 / pc.sz[i]);
+      T v = xo[i] * rcp_fast(pc.sz[i]);
       if constexpr (NOISE) v = v + w[i];                       // mhe.py:731 / :736: scaled noise, scaled state
       xn[i] = v;
     }
@@ -226,7 +226,7 @@ struct MheGen {
       for (int i = 0; i < CD; ++i) {                               // the collocation points (mhe.py:536-550): scaled like the states
         T xs[NX];
 #pragma unroll
-        for (int a = 0; a < NX; ++a) xs[a] = Xc[i * NX + a] * (1.0 / pc.sz[a]);
+        for (int a = 0; a < NX; ++a) xs[a] = Xc[i * NX + a] * rcp_fast(pc.sz[a]);
         rows_at(pc, xs, (i + 1) * nrow, nrow, dv);
       }
     }

@@ -301,7 +301,7 @@ __device__ __forceinline__ void dae_solve(const Z* x, const Z* u, const P* p, Z*
           }
         }
       }
-      const double ip = 1.0 / Jv[c * NZ + c];
+      const double ip = rcp_fast(Jv[c * NZ + c]);
 #pragma unroll
       for (int j = 0; j < NZ; ++j) { Jv[c * NZ + j] *= ip; Ji[c * NZ + j] *= ip; }
 #pragma unroll

@@ -21,7 +21,7 @@ struct NmpcColl : NmpcTrack<M, false, false> {   // its own shooting map: Taylor
     for (int i = 0; i < NU; ++i) up[i] = u[i] * pc.sz[NX + i];
     Colloc<M, D>::step(pc.coll, xp, up, par, pc.dt, xo);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]);
+    for (int i = 0; i < NX; ++i) xn[i] = xo[i] * rcp_fast(pc.sz[i]);
   }
 };
 

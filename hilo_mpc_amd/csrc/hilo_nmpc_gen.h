@@ -53,7 +53,7 @@ struct NmpcGen {
     for (int i = 0; i < MU; ++i) up[i] = u[i] * pc.sz[NX + i];
     model_step<M>(pc.order, pc.nsub, xp, up, par, pc.dt, xo, ext);
 #pragma unroll
-    for (int i = 0; i < MX; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]);
+    for (int i = 0; i < MX; ++i) xn[i] = xo[i] * rcp_fast(pc.sz[i]);
     if constexpr (NTH > 0) xn[MX] = x[MX] + pc.dt * u[MU];  // mpc.py:1191
 #pragma unroll
     for (int e = 0; e < NE; ++e) xn[MX + NTH + e] = x[MX + NTH + e];

@@ -36,7 +36,7 @@ struct NmpcTrack {
     for (int i = 0; i < NU; ++i) up[i] = u[i] * pc.sz[NX + i];
     model_step<M>(pc.order, pc.nsub, xp, up, par, pc.dt, xo, ext);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]);
+    for (int i = 0; i < NX; ++i) xn[i] = xo[i] * rcp_fast(pc.sz[i]);
   }
 
   // x+ = Phi(x, u, p) on UN-scaled quantities: the closed-loop helper plant_step_kernel (hilo_nmpc.hip) as a function - the solve

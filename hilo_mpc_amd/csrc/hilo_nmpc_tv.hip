@@ -25,7 +25,7 @@ struct NmpcTv : NmpcTrack<M, false, false> {   // its own shooting map: Taylor d
     for (int i = 0; i < NU; ++i) up[i] = u[i] * pc.sz[NX + i];
     model_step<M>(pc.order, pc.nsub, xp, up, sd + NZ, pc.dt, xo, ext);   // p_k (mpc.py:1641 `_rearrange_parameters`)
 #pragma unroll
-    for (int i = 0; i < NX; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]);
+    for (int i = 0; i < NX; ++i) xn[i] = xo[i] * rcp_fast(pc.sz[i]);
   }
 
   template <class T>

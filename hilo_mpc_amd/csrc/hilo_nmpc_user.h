@@ -250,7 +250,7 @@ struct NmpcUser {
           if (i >= 2) acc = acc + (h * (i == 2 ? erk_a<2, 1>(order) : 0.0)) * kk[1][s];
           if (i >= 3) acc = acc + (h * erk_a<3, 2>(order)) * kk[2][s];
           xi[s] = acc;
-          xis[s] = acc * (1.0 / pc.sz[s]);
+          xis[s] = acc * rcp_fast(pc.sz[s]);
         }
         MA::ode(xi, up, p, h, kk[i]);
         const double bi = i == 0 ? erk_b<0>(order) : (i == 1 ? erk_b<1>(order) : (i == 2 ? erk_b<2>(order) : erk_b<3>(order)));
@@ -489,16 +489,16 @@ struct NmpcUser {
 #pragma unroll
           for (int m = 0; m < MXA; ++m) {
             xu[m] = Jet2(Xs[j * MXA + m], m == a ? 1.0 : 0.0, 0.0);
-            xcs[m] = xu[m] * (1.0 / pc.sz[m]);
+            xcs[m] = xu[m] * rcp_fast(pc.sz[m]);
           }
 #pragma unroll
           for (int b = 0; b < MUA; ++b) {
             uu[b] = Jet2(up[b]);
-            usj[b] = Jet2(up[b] * (1.0 / pc.sz[NX + b]));
+            usj[b] = Jet2(up[b] * rcp_fast(pc.sz[NX + b]));
           }
           if constexpr (CONT) gphi += (pc.dt * pc.coll.Bq[j + 1]) * lagrange(pc, par, sd, p, kk, xcs, usj).a;
 #pragma unroll
-          for (int m = 0; m < MXA; ++m) gphi -= (a == m) ? lam[kk * NX + m] * pc.coll.Dc[j + 1] * (1.0 / pc.sz[m]) : 0.0;
+          for (int m = 0; m < MXA; ++m) gphi -= (a == m) ? lam[kk * NX + m] * pc.coll.Dc[j + 1] * rcp_fast(pc.sz[m]) : 0.0;
           if constexpr (FUSED_CON) {
             const int nrow = (int)pc.cost[L.o_nrow];
             constexpr int NZ1 = NZALG > 0 ? NZALG : 1;
@@ -638,7 +638,7 @@ struct NmpcUser {
           if constexpr (CONT) {
             T xcs[MXA];
 #pragma unroll
-            for (int m = 0; m < MXA; ++m) xcs[m] = Xj[m] * (1.0 / pc.sz[m]);
+            for (int m = 0; m < MXA; ++m) xcs[m] = Xj[m] * rcp_fast(pc.sz[m]);
             lc = lc + (pc.dt * pc.coll.Bq[jj + 1]) * lagrange(pc, par, sd, p, k, xcs, us);
           }
         }
@@ -678,7 +678,7 @@ struct NmpcUser {
         for (int i = 0; i < D; ++i) {
           T xcs[MXA];
 #pragma unroll
-          for (int m = 0; m < MXA; ++m) xcs[m] = Xc[i * MXA + m] * (1.0 / pc.sz[m]);
+          for (int m = 0; m < MXA; ++m) xcs[m] = Xc[i * MXA + m] * rcp_fast(pc.sz[m]);
           lc = lc + (pc.dt * pc.coll.Bq[i + 1]) * lagrange(pc, par, sd, p, k, xcs, us);
         }
       }
@@ -704,7 +704,7 @@ struct NmpcUser {
     if constexpr (!CONT || (D == 0 && M::DISCRETE)) lc = lagrange(pc, par, sd, p, k, xs, us);   // discrete objective: l(x_k, u_k)
     if constexpr (COOP_COLL && same_type<T, Jet2>::value) lc = lc + Jet2(0.0, 0.0, kbq);
 #pragma unroll
-    for (int i = 0; i < MXA; ++i) xn[i] = xo[i] * (1.0 / pc.sz[i]);
+    for (int i = 0; i < MXA; ++i) xn[i] = xo[i] * rcp_fast(pc.sz[i]);
 #pragma unroll
     for (int e = 0; e < NE; ++e) xn[MXA + e] = x[MXA + e];            // shared slacks: constant states
     if constexpr (NQ > 0) {                                            // accumulators: + sum_j a[r][k][j] psi_j(x_k, u_k) at the NODE
@@ -833,7 +833,7 @@ struct NmpcUser {
 #pragma unroll
         for (int i = 0; i < MXA; ++i) xe[i] = xn[i];
 #pragma unroll
-        for (int i = 0; i < MUA; ++i) ue[i] = us[i] * (1.0 / pc.sz[NX + i]);
+        for (int i = 0; i < MUA; ++i) ue[i] = us[i] * rcp_fast(pc.sz[NX + i]);
         F::acc(xe, ue, p, ps);
 #pragma unroll
         for (int r = 0; r < NQ; ++r) {
