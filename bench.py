@@ -648,7 +648,7 @@ def wl_kf(kind, args, torch, dev, rank, world):
                 "kernel": (f"kf_team_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}>"
                            if B * (16 if kind == 'ukf' else 4) <= 2 * 1024 * 64 else
                            # `discretize('rk4')` with shared Q, R: the multi-step kernels' LEAN variants (csrc/hilo_kf.hip::launch_multi)
-                           ("kf_multi_kernel<Chemostat4, true, true>" if kind == 'ukf' else "ekf_multi_lean_kernel<Chemostat4>") if K > 1 else
+                           (("kf_multi_kernel<Chemostat4, true, 2>" if B >= 2 * 1024 * 64 else "kf_multi_kernel<Chemostat4, true, 1>") if kind == 'ukf' else "ekf_multi_lean_kernel<Chemostat4>") if K > 1 else
                            f"kf_kernel<Chemostat4, {'true' if kind == 'ukf' else 'false'}, 2>"),
                 "kernel_ms": kern_ms, "launches_per_event_pair": G, "algorithmic_bytes_per_launch": B * K * bytes_step,
                 "filter_steps_per_launch": K,

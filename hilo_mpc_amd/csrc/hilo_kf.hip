@@ -78,8 +78,11 @@ int launch_multi(const KfParams& kp, int64_t batch, int steps, const double* in,
   const bool rk4 = kp.n_sub == 1 && (kp.kind == HILO_KF_UKF ? (kp.erk_order == 4 || kp.continuous) : (kp.erk_order == 4 && !kp.continuous));
   static const bool lean_knob = [] { const char* e = getenv("HILO_KF_LEAN"); return e ? atoi(e) != 0 : true; }();
   if constexpr (!M::DISCRETE) if (rk4 && qs == 0 && rs == 0 && lean_knob) {
-    if (kp.kind == HILO_KF_UKF)
-      hipLaunchKernelGGL((kf_multi_kernel<M, true, true>), dim3(grid), dim3(KF_TPB), 0, s, kp, batch, steps, in, y, up, us, ustep, Q, qs,
+    if (kp.kind == HILO_KF_UKF && batch >= 2 * 1024 * (int64_t)KF_TPB)      // two waves per SIMD to fill: the 252-register variant
+      hipLaunchKernelGGL((kf_multi_kernel<M, true, 2>), dim3(grid), dim3(KF_TPB), 0, s, kp, batch, steps, in, y, up, us, ustep, Q, qs,
+                         R, rs, out, ostep, yp, (int)ipw);
+    else if (kp.kind == HILO_KF_UKF)
+      hipLaunchKernelGGL((kf_multi_kernel<M, true, 1>), dim3(grid), dim3(KF_TPB), 0, s, kp, batch, steps, in, y, up, us, ustep, Q, qs,
                          R, rs, out, ostep, yp, (int)ipw);
     else
       hipLaunchKernelGGL((ekf_multi_lean_kernel<M>), dim3(grid), dim3(KF_TPB), 0, s, kp, batch, steps, in, y, up, us, ustep, Q, qs,

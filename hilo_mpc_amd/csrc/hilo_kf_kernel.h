@@ -344,6 +344,87 @@ __device__ __forceinline__ void ukf_update(const KfParams& kp, double* x, double
   gain_update<NX, NY>(x, P, Pxy, Pyy, y, yp);
 }
 
+// predict + update of ONE step as one routine (the multi-step kernel's LEAN variant): the same sums in the same order as ukf_predict
+// followed by ukf_update - the measured sigma points are taken when a point comes out of the model (the update measures these very
+// points, kf.py:556-570), and the centred points X - x and Y - y_pred, which both covariance sums of each need, are formed ONCE in
+// place of X and Y.  Peak register need: X and Y while the points are propagated, instead of X, its centred copy and Y.
+// SERIAL: one sigma point at a time (a scheduling barrier after each) - 252 registers instead of 294, two waves per SIMD: faster
+// when the batch fills two waves per SIMD (10.4 against 9.1 G steps/s at B = 2^20), slower when it does not (one wave per SIMD then
+// has one dependent chain to issue from: 5.4 against 7.7 G at B = 65536) - csrc/hilo_kf.hip::launch_multi picks by the batch
+template <class M, bool SERIAL>
+__device__ __forceinline__ void ukf_step_fused(const KfParams& kp, double* x, double* P, const double* y, const double* u,
+                                               const double* p, const double* Q, const double* R, double* yp) {
+#pragma clang fp contract(off)
+  constexpr int NX = M::NX, NY = M::NY, NS = 2 * NX + 1;
+  double L[NX * NX], X[NX * NS], Y[NY * NS];
+  chol_lower<NX>(P, L);
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    double xs[NX], xo[NX], ys[NY];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      double s = x[i];
+      if (k >= 1 && k <= NX) s = x[i] + kp.gamma * L[(k - 1) * NX + i];
+      if (k > NX) s = x[i] - kp.gamma * L[(k - 1 - NX) * NX + i];
+      xs[i] = s;
+    }
+    ukf_propagate<M, true>(kp, xs, u, p, xo);
+    M::meas(xo, u, p, kp.dt, ys);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) X[i * NS + k] = xo[i];
+#pragma unroll
+    for (int a = 0; a < NY; ++a) Y[a * NS + k] = ys[a];
+    if constexpr (SERIAL) __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s = s + (k == 0 ? kp.wm0 : kp.wi) * X[i * NS + k];
+    x[i] = s;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) X[i * NS + k] = X[i * NS + k] - s;
+  }
+#pragma unroll
+  for (int a = 0; a < NY; ++a) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s = s + (k == 0 ? kp.wm0 : kp.wi) * Y[a * NS + k];
+    yp[a] = s;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) Y[a * NS + k] = Y[a * NS + k] - s;
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      double s = Q[i * NX + j];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) s = s + ((k == 0 ? kp.wc0 : kp.wi) * X[i * NS + k]) * X[j * NS + k];
+      P[i * NX + j] = s;
+    }
+  double Pxy[NX * NY], Pyy[NY * NY];
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+#pragma unroll
+    for (int a = 0; a < NY; ++a) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) s = s + ((k == 0 ? kp.wc0 : kp.wi) * X[i * NS + k]) * Y[a * NS + k];
+      Pxy[i * NY + a] = s;
+    }
+#pragma unroll
+  for (int a = 0; a < NY; ++a)
+#pragma unroll
+    for (int b = 0; b < NY; ++b) {
+      double s = R[a * NY + b];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) s = s + ((k == 0 ? kp.wc0 : kp.wi) * Y[a * NS + k]) * Y[b * NS + k];
+      Pyy[a * NY + b] = s;
+    }
+  gain_update<NX, NY>(x, P, Pxy, Pyy, y, yp);
+}
+
 // ---- kernels --------------------------------------------------------------------------------------------
 // MODE 0 = predict, 1 = update, 2 = fused step.  UKF template flag selects sigma-point arithmetic.
 #ifndef HILO_KF_WAVES
@@ -444,7 +525,7 @@ __global__ __launch_bounds__(KF_TPB) KF_OCC void kf_kernel(KfParams kp, int64_t 
 // reference's accumulated output) or only the last one goes back; y_pred [steps][B][ny].  A filter step at the BASELINE batch
 // (4096 instances = 1.6 MB) is launch-latency bound; K steps per launch divide that latency by K and, with only the last tile
 // written, move 8 (ny + nu + np + ny) bytes per step instead of the tile both ways.
-template <class M, bool UKF, bool LEAN = false>
+template <class M, bool UKF, int LEAN = 0>      // LEAN: 1 = the common recipe's variant, 2 = (UKF) with the sigma points one at a time
 __device__ __forceinline__ void kf_multi_body(const KfParams& kp, int64_t batch, int steps, const double* __restrict__ in_tile,
                                               const double* __restrict__ y, const double* __restrict__ up, int64_t up_stride,
                                               int64_t up_step, const double* __restrict__ Q, int64_t q_stride,
@@ -485,11 +566,13 @@ __device__ __forceinline__ void kf_multi_body(const KfParams& kp, int64_t batch,
       const double* u = upv;
       const double* p = upv + M::NU;
       vec_load<NY>(y + (int64_t)s * batch * NY, inst, NY, yv);
-      if constexpr (UKF) {
-        ukf_predict<M, LEAN>(kp, x, P, X, u, p, Qv);
+      if constexpr (UKF && LEAN && !M::DISCRETE) {
+        ukf_step_fused<M, LEAN == 2>(kp, x, P, yv, u, p, Qv, Rv, ypv);
+      } else if constexpr (UKF) {
+        ukf_predict<M, (LEAN != 0)>(kp, x, P, X, u, p, Qv);
         ukf_update<M>(kp, x, P, X, yv, u, p, Rv, ypv);
       } else {
-        ekf_predict<M, LEAN>(kp, x, P, u, p, Qv);
+        ekf_predict<M, (LEAN != 0)>(kp, x, P, u, p, Qv);
         ekf_update<M>(kp, x, P, yv, u, p, Rv, ypv);
       }
 #pragma unroll
@@ -510,7 +593,7 @@ __device__ __forceinline__ void kf_multi_body(const KfParams& kp, int64_t batch,
   }
 }
 
-template <class M, bool UKF, bool LEAN = false>
+template <class M, bool UKF, int LEAN = 0>
 __global__ __launch_bounds__(KF_TPB) KF_OCC void kf_multi_kernel(KfParams kp, int64_t batch, int steps,
                                                                  const double* __restrict__ in_tile, const double* __restrict__ y,
                                                                  const double* __restrict__ up, int64_t up_stride, int64_t up_step,
@@ -528,7 +611,7 @@ __global__ __launch_bounds__(KF_TPB) __attribute__((amdgpu_waves_per_eu(2))) voi
     const double* __restrict__ up, int64_t up_stride, int64_t up_step, const double* __restrict__ Q, int64_t q_stride,
     const double* __restrict__ R, int64_t r_stride, double* __restrict__ out_tile, int64_t out_step, double* __restrict__ y_pred,
     int ipw) {
-  kf_multi_body<M, false, true>(kp, batch, steps, in_tile, y, up, up_stride, up_step, Q, q_stride, R, r_stride, out_tile, out_step, y_pred, ipw);
+  kf_multi_body<M, false, 1>(kp, batch, steps, in_tile, y, up, up_stride, up_step, Q, q_stride, R, r_stride, out_tile, out_step, y_pred, ipw);
 }
 
 // ---- one filter instance on a TEAM of lanes: small batches (the BASELINE's B = 4096) ------------------------------------------------
