@@ -29,11 +29,18 @@ class _Solution:
     def _set(self, **kw):
         self._d.update(kw)
 
+    def _set_tile(self, out, yp):
+        """Several steps per call, device results: the packed tiles [steps, B, n_x, n_x + 1] = [x | P] and the predicted outputs; the
+        views x / P are made when asked for (a call's host time is counted in microseconds)."""
+        self._d = {'x': (out, 0), 'P': (out, 1), 'y': yp}
+
     def get_by_id(self, key):
         name = key.split(':')[0]
         if name not in self._d:
             raise KeyError(key)
         v = self._d[name]
+        if isinstance(v, tuple):
+            v = v[0].select(3, 0) if v[1] == 0 else v[0].narrow(3, 1, v[0].shape[3] - 1)
         # device results are views of the filter's resident ping-pong tiles: what the caller gets is a copy of its own, taken
         # when it asks (a value collected per step must not change two steps later)
         return v.clone() if isinstance(v, torch.Tensor) else v
@@ -302,11 +309,12 @@ class _KalmanFilter:
         _lib.check(_lib.lib().hilo_kf_steps(self._handle, B, int(steps), ptr(xP), ptr(yt), ptr(upt), us, ustep, ptr(self._Q),
                                             self._cov_stride(self._Q, B), ptr(self._R), self._cov_stride(self._R, B), ptr(out), 1,
                                             ptr(yp), stream_ptr(dev)))
-        self._state_tile = out[-1]                              # the last step's packed tile is the filter state: x and P are views of it
-        self._x, self._P = self._state_tile[:, :, 0], self._state_tile[:, :, 1:]
-        host = not isinstance(y, torch.Tensor)
-        cv = (lambda t: t.cpu().numpy()) if host else (lambda t: t)
-        self.solution._set(x=cv(out[:, :, :, 0]), P=cv(out[:, :, :, 1:]), y=cv(yp))
+        st = self._state_tile = out.select(0, steps - 1)        # the last step's packed tile is the filter state: x and P are views of it
+        self._x, self._P = st.select(2, 0), st.narrow(2, 1, self._n_x)
+        if isinstance(y, torch.Tensor):
+            self.solution._set_tile(out, yp)
+        else:
+            self.solution._set(x=out[:, :, :, 0].cpu().numpy(), P=out[:, :, :, 1:].cpu().numpy(), y=yp.cpu().numpy())
         return self.solution
 
     def _packed_tile(self, B):
