@@ -105,6 +105,7 @@ def _declare(lib):
         'hilo_nmpc_set_plant_out': (C.c_int, [vp, vp]),
         'hilo_nmpc_set_var_bounds': (C.c_int, [vp, vp, vp]),
         'hilo_kf_steps': (C.c_int, [vp, i64, i32, vp, vp, vp, i64, i64, vp, i64, vp, i64, vp, i32, vp, vp]),
+        'hilo_kf_steps_split': (C.c_int, [vp, i64, i32, vp, vp, vp, i64, i64, vp, i64, vp, i64, vp, i64, vp, i32, vp, vp]),
         'hilo_nmpc_solve': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_nmpc_solve_tv': (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         'hilo_nmpc_profile': (C.c_int, [vp, i32, vp]),

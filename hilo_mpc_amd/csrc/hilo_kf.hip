@@ -328,20 +328,56 @@ extern "C" int hilo_kf_step(hilo_kf* kf, int64_t batch, const double* xP, const 
 }
 
 // `steps` fused estimate() steps in one launch: the reference's `self._function.mapaccum(steps)` (kf.py:296-306)
+static int kf_steps_impl(hilo_kf* kf, int64_t batch, int steps, const double* xP, const double* y, const double* up,
+                         int64_t up_stride, int64_t up_step_stride, const double* pp, int64_t pp_stride, const double* Q,
+                         int64_t q_stride, const double* R, int64_t r_stride, double* xP_out, int keep_all, double* y_pred,
+                         void* stream);
+
 extern "C" int hilo_kf_steps(hilo_kf* kf, int64_t batch, int steps, const double* xP, const double* y, const double* up,
                              int64_t up_stride, int64_t up_step_stride, const double* Q, int64_t q_stride, const double* R,
                              int64_t r_stride, double* xP_out, int keep_all, double* y_pred, void* stream) {
+  HILO_REQUIRE(kf, "hilo_kf_steps: NULL handle");
+  HILO_REQUIRE(up_stride == 0 || up_stride >= kf->nu + kf->np, "hilo_kf_steps: up_stride %lld < nu+np", (long long)up_stride);
+  return kf_steps_impl(kf, batch, steps, xP, y, up, up_stride, up_step_stride, nullptr, 0, Q, q_stride, R, r_stride, xP_out, keep_all,
+                       y_pred, stream);
+}
+
+// The same with the inputs and the parameters in their OWN arrays - what the reference hands its function: u and p are separate
+// arguments there (kf.py:130), and packing [u; p] rows on the device first is a launch of its own per call.
+extern "C" int hilo_kf_steps_split(hilo_kf* kf, int64_t batch, int steps, const double* xP, const double* y, const double* u,
+                                   int64_t u_stride, int64_t u_step_stride, const double* p, int64_t p_stride, const double* Q,
+                                   int64_t q_stride, const double* R, int64_t r_stride, double* xP_out, int keep_all, double* y_pred,
+                                   void* stream) {
+  HILO_REQUIRE(kf, "hilo_kf_steps_split: NULL handle");
+  HILO_REQUIRE(kf->nu == 0 || u, "hilo_kf_steps_split: the model has %d inputs but `u` is NULL", kf->nu);
+  HILO_REQUIRE(kf->np == 0 || p, "hilo_kf_steps_split: the model has %d parameters but `p` is NULL", kf->np);
+  HILO_REQUIRE(u_stride == 0 || u_stride >= kf->nu, "hilo_kf_steps_split: u_stride %lld < nu", (long long)u_stride);
+  HILO_REQUIRE(p_stride == 0 || p_stride >= kf->np, "hilo_kf_steps_split: p_stride %lld < np", (long long)p_stride);
+  if (kf->np == 0)      // one of the two is empty: the other array IS the packed rows
+    return kf_steps_impl(kf, batch, steps, xP, y, u, u_stride, u_step_stride, nullptr, 0, Q, q_stride, R, r_stride, xP_out, keep_all,
+                         y_pred, stream);
+  if (kf->nu == 0)
+    return kf_steps_impl(kf, batch, steps, xP, y, p, p_stride, 0, nullptr, 0, Q, q_stride, R, r_stride, xP_out, keep_all, y_pred, stream);
+  return kf_steps_impl(kf, batch, steps, xP, y, u, u_stride, u_step_stride, p, p_stride, Q, q_stride, R, r_stride, xP_out, keep_all,
+                       y_pred, stream);
+}
+
+static int kf_steps_impl(hilo_kf* kf, int64_t batch, int steps, const double* xP, const double* y, const double* up,
+                         int64_t up_stride, int64_t up_step_stride, const double* pp, int64_t pp_stride, const double* Q,
+                         int64_t q_stride, const double* R, int64_t r_stride, double* xP_out, int keep_all, double* y_pred,
+                         void* stream) {
   HILO_REQUIRE(kf, "hilo_kf_steps: NULL handle");
   HILO_REQUIRE(batch >= 0 && steps >= 1, "hilo_kf_steps: need batch >= 0 and steps >= 1");
   if (batch == 0) return HILO_OK;
   HILO_REQUIRE(xP && xP_out && y && y_pred && Q && R, "hilo_kf_steps: NULL argument");
   HILO_REQUIRE(kf->nu + kf->np == 0 || up, "hilo_kf_steps: the model has %d inputs/parameters but `up` is NULL", kf->nu + kf->np);
-  HILO_REQUIRE(up_stride == 0 || up_stride >= kf->nu + kf->np, "hilo_kf_steps: up_stride %lld < nu+np", (long long)up_stride);
   HILO_REQUIRE(q_stride == 0 || q_stride >= kf->nx * kf->nx, "hilo_kf_steps: bad q_stride");
   HILO_REQUIRE(r_stride == 0 || r_stride >= kf->ny * kf->ny, "hilo_kf_steps: bad r_stride");
   HILO_HIP_CHECK(hipSetDevice(kf->device));
   hipStream_t s = (hipStream_t)stream;
-  const KfParams& kp = kf->kp;
+  KfParams kp = kf->kp;
+  kp.pp = pp;
+  kp.pp_stride = (long long)pp_stride;
   static const double zero = 0.0;
   if (!up) up = &zero;
   const int64_t ostep = keep_all ? batch * (int64_t)kf->nx * (kf->nx + 1) : 0;

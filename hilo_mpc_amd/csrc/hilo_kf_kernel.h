@@ -17,9 +17,25 @@ constexpr int KF_TPB = 64;   // one wave per workgroup
 struct KfParams {
   int kind, continuous, erk_order, n_sub;
   double dt, gamma, wm0, wc0, wi;  // UKF: W_m[0], W_c[0], W[1:] (kf.py:493-500)
+  // hilo_kf_steps_split: the parameters in their own array (rows of np doubles, stride pp_stride or 0 = shared) - `up` then holds
+  // the inputs alone (rows of nu doubles); nullptr: `up` holds the packed rows [u; p]
+  const double* pp = nullptr;
+  long long pp_stride = 0;
 };
 
 template <int N> struct MaxOne { static constexpr int v = N > 0 ? N : 1; };
+
+// [u; p] of one instance into registers: packed rows, or inputs and parameters from their own arrays (KfParams::pp)
+template <class M>
+__device__ __forceinline__ void kf_load_up(const KfParams& kp, const double* __restrict__ up, int64_t inst, int64_t up_stride,
+                                           double* __restrict__ upv) {
+  if (kp.pp != nullptr) {
+    if constexpr (M::NU > 0) vec_load<M::NU>(up, inst, up_stride, upv);
+    if constexpr (M::NP > 0) vec_load<M::NP>(kp.pp, inst, (int64_t)kp.pp_stride, upv + M::NU);
+  } else {
+    vec_load<M::NU + M::NP>(up, inst, up_stride, upv);
+  }
+}
 
 // ---- small dense helpers (row-major, compile-time sizes) ------------------------------------------------
 // 1/sqrt(x): v_rsq_f64 + two Newton steps (<= 2 ulp) - the Cholesky factor of Pyy below needs the reciprocal of its diagonal only
@@ -556,12 +572,12 @@ __device__ __forceinline__ void kf_multi_body(const KfParams& kp, int64_t batch,
       vec_load<NX * NX>(Q, inst, q_stride, Qr);
       vec_load<NY * NY>(R, inst, r_stride, Rr);
     }
-    if constexpr (NUP > 0) vec_load<NUP>(up, inst, up_stride, upv);
+    if constexpr (NUP > 0) kf_load_up<M>(kp, up, inst, up_stride, upv);
   }
   for (int s = 0; s < steps; ++s) {
     if (active) {
       if constexpr (NUP > 0) {
-        if (s > 0 && up_step != 0) vec_load<NUP>(up + (int64_t)s * up_step, inst, up_stride, upv);
+        if (s > 0 && up_step != 0) kf_load_up<M>(kp, up + (int64_t)s * up_step, inst, up_stride, upv);
       }
       const double* u = upv;
       const double* p = upv + M::NU;
@@ -960,11 +976,11 @@ __device__ __forceinline__ void kf_team_body(const KfParams& kp, int64_t batch, 
     const int e0 = m * T + t, e = e0 < NER ? e0 : NER - 1, f = e - OFFR;
     Re[m] = f >= 0 ? R[inst * r_stride + f] : 0.0;
   }
-  if constexpr (NUP > 0) vec_load<NUP>(up, inst, up_stride, upv);
+  if constexpr (NUP > 0) kf_load_up<M>(kp, up, inst, up_stride, upv);
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
     if constexpr (NUP > 0) {
-      if (s > 0 && up_step != 0) vec_load<NUP>(up + (int64_t)s * up_step, inst, up_stride, upv);
+      if (s > 0 && up_step != 0) kf_load_up<M>(kp, up + (int64_t)s * up_step, inst, up_stride, upv);
     }
     const double* u = upv;
     const double* p = upv + M::NU;

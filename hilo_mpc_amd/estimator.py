@@ -264,51 +264,35 @@ class _KalmanFilter:
             B = yt.shape[1]
             self._x = self._x.expand(B, -1).contiguous()
             self._P = self._P.expand(B, -1, -1).contiguous()
-        nup = self._n_u + self._n_p
-        upt, us, ustep = None, 0, 0
-        if nup:
-            pt = ut = None
-            if self._n_p:
-                pt = self._p if p is None else to_dev(p, dev)
-                if pt is None:
-                    raise RuntimeError("No parameter values supplied. Please run set_initial_parameter_values() or pass p=.")
-                pt = pt.reshape(1, -1) if pt.ndim <= 1 else pt
-            per_step = False
-            if self._n_u:
-                if u is None:
-                    raise RuntimeError("No input data supplied.")
-                ut = to_dev(u, dev)
-                per_step = ut.numel() == steps * B * self._n_u and steps > 1
-            # [u; p] rows (kf.py:130) in a buffer the filter keeps.  With `inputs_unchanged=True` the CALLER states that device tensors
-            # handed over again (same object, same version counter) hold the same values, and they are not copied again - the
-            # launch is then the only work of the call.  Opt-in: a write through a raw pointer (a kernel of this library filling
-            # the tensor, DLPack consumers, `.data`) does not bump the version counter and would be served stale.
-            rows = steps if per_step else 1
-            key = tuple((id(t), t._version, tuple(t.shape)) if isinstance(src, torch.Tensor) and src.device == t.device else None
-                        for src, t in ((u, ut), (p if p is not None else self._p, pt)) if t is not None)
-            buf = getattr(self, '_ups_buf', None)
-            if buf is None or buf.shape[0] != rows or buf.shape[1] != B:
-                buf = self._ups_buf = torch.empty(rows, B, nup, dtype=torch.float64, device=dev)
-                self._ups_key = None
-            if not inputs_unchanged or None in key or key != self._ups_key:
-                # one concatenation kernel writes the [u; p] rows (two sliced assignments cost the host ~15 us of the call's ~45)
-                parts = []
-                if self._n_u:
-                    parts.append(ut.reshape(steps, B, self._n_u) if per_step else ut.reshape(-1, self._n_u).expand(B, -1)[None])
-                if self._n_p:
-                    parts.append(pt.expand(B, -1)[None].expand(rows, -1, -1))
-                if len(parts) == 1:
-                    buf.copy_(parts[0])
-                else:
-                    torch.cat(parts, dim=2, out=buf)
-                self._ups_key, self._ups_src = key, (ut, pt)          # (the sources stay alive: an id is only unique among live objects)
-            upt, us, ustep = buf, nup, (B * nup if per_step else 0)
+        # inputs and parameters go over as they are - separate arrays like the separate arguments of the reference's function
+        # (kf.py:130; hilo_kf_steps_split): rows per instance or ONE row shared by the batch (stride 0), the inputs per step or held
+        ut = pt = None
+        us = ustep = ps = 0
+        if self._n_p:
+            pt = self._p if p is None else to_dev(p, dev)
+            if pt is None:
+                raise RuntimeError("No parameter values supplied. Please run set_initial_parameter_values() or pass p=.")
+            pt = pt.reshape(-1, self._n_p)
+            if pt.shape[0] not in (1, B):
+                raise ValueError(f"Dimension mismatch for variable p: {pt.shape[0]} parameter vectors for {B} filters.")
+            ps = self._n_p if pt.shape[0] == B and B > 1 else 0
+        if self._n_u:
+            if u is None:
+                raise RuntimeError("No input data supplied.")
+            ut = to_dev(u, dev)
+            if ut.numel() == steps * B * self._n_u and steps > 1:
+                us, ustep = self._n_u, B * self._n_u
+            else:
+                ut = ut.reshape(-1, self._n_u)
+                if ut.shape[0] not in (1, B):
+                    raise ValueError(f"Dimension mismatch for variable u: {ut.shape[0]} input vectors for {B} filters.")
+                us = self._n_u if ut.shape[0] == B and B > 1 else 0
         xP = self._packed_tile(B)
         out = torch.empty(steps, B, self._n_x, self._n_x + 1, dtype=torch.float64, device=dev)
         yp = torch.empty(steps, B, self._n_y, dtype=torch.float64, device=dev)
-        _lib.check(_lib.lib().hilo_kf_steps(self._handle, B, int(steps), ptr(xP), ptr(yt), ptr(upt), us, ustep, ptr(self._Q),
-                                            self._cov_stride(self._Q, B), ptr(self._R), self._cov_stride(self._R, B), ptr(out), 1,
-                                            ptr(yp), stream_ptr(dev)))
+        _lib.check(_lib.lib().hilo_kf_steps_split(self._handle, B, int(steps), ptr(xP), ptr(yt), ptr(ut), us, ustep, ptr(pt), ps,
+                                                  ptr(self._Q), self._cov_stride(self._Q, B), ptr(self._R), self._cov_stride(self._R, B),
+                                                  ptr(out), 1, ptr(yp), stream_ptr(dev)))
         st = self._state_tile = out.select(0, steps - 1)        # the last step's packed tile is the filter state: x and P are views of it
         self._x, self._P = st.select(2, 0), st.narrow(2, 1, self._n_x)
         if isinstance(y, torch.Tensor):

@@ -162,6 +162,12 @@ int hilo_kf_step(hilo_kf* kf, int64_t batch, const double* xP, const double* y,
 int hilo_kf_steps(hilo_kf* kf, int64_t batch, int steps, const double* xP, const double* y,
                   const double* up, int64_t up_stride, int64_t up_step_stride, const double* Q, int64_t q_stride,
                   const double* R, int64_t r_stride, double* xP_out, int keep_all, double* y_pred, void* stream);
+/* The same with the inputs u [steps or 1][B][nu] and the parameters p [B][np] in their OWN arrays (strides in doubles; 0 = one row   */
+/* shared by the batch) - they are separate arguments of the reference's function (kf.py:130), and a binding need not pack them.    */
+int hilo_kf_steps_split(hilo_kf* kf, int64_t batch, int steps, const double* xP, const double* y,
+                        const double* u, int64_t u_stride, int64_t u_step_stride, const double* p, int64_t p_stride,
+                        const double* Q, int64_t q_stride, const double* R, int64_t r_stride, double* xP_out, int keep_all,
+                        double* y_pred, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------- */
 /* Gaussian process: exact inference + prediction                                                           */
