@@ -248,7 +248,7 @@ class _KalmanFilter:
         return like_input(out[0], pred), like_input(yp[0].reshape(-1, 1), pred)
 
     # ---- several steps per call: `self._function.mapaccum(steps)` (kf.py:296-306) -------------------
-    def _estimate_steps(self, y, u, p, steps, inputs_unchanged=False):
+    def _estimate_steps(self, y, u, p, steps):
         """y [steps, B, n_y]; u [steps, B, n_u] or [B, n_u] (held over the steps); p like a single step.  One launch for all
         steps (hilo_kf_steps); the solution holds the sequences x [steps, B, n_x], P [steps, B, n_x, n_x], y [steps, B, n_y]."""
         dev = self._dev
@@ -322,7 +322,8 @@ class _KalmanFilter:
         if y is None:
             raise RuntimeError("No measurement data supplied.")
         if int(kwargs.get('steps', 1) or 1) > 1:
-            return self._estimate_steps(y, u, p, int(kwargs['steps']), bool(kwargs.get('inputs_unchanged', False)))
+            # (`inputs_unchanged=` is accepted and has nothing left to do here: inputs and parameters are handed over where they are)
+            return self._estimate_steps(y, u, p, int(kwargs['steps']))
         B = self._x.shape[0]
         for name, val, n in (('y', y, self._n_y), ('u', u, self._n_u), ('p', p, self._n_p)):     # base.py `_process_inputs`
             if val is not None and n:
@@ -367,7 +368,8 @@ class _KalmanFilter:
                     self._up_u_src, self._up_u_ref = ukey, u
             if self._n_p:
                 # estimate(..., inputs_unchanged=True): device tensors handed over again (same live object, same version counter)
-                # are not copied again - the caller's statement, see _estimate_steps; host data always is
+                # are not copied again - the caller states that they hold the same values (a write through a raw pointer does not bump the
+                # version counter); host data always is
                 src = self._p if p is None else p
                 key = (id(src), src._version) if isinstance(src, torch.Tensor) and src.device == buf.device else None
                 if not unchanged or key is None or self._up_p_src != key:
